@@ -1,0 +1,65 @@
+# oracle/ref.mk — builds the UNMODIFIED reference (ggml @ 2025-02-13) from the sources where they
+# lie under $(REF) into oracle/_ref/.  Test infrastructure only: the product never links these.
+# No reference source is copied; this is a hand-written recipe (the reference's CMake is not run).
+#
+#   make -f oracle/ref.mk            (from the repo root)
+#
+# Outputs (git-ignored, but they travel to the GPU box with gpurun):
+#   oracle/_ref/libggml-base.so  libggml-cpu.so  libggml.so
+#   oracle/_ref/test-backend-ops  test-quantize-fns  test-mul-mat
+#
+# ISA flags: x86-64-v3 (AVX2+FMA+F16C) instead of the reference's default -march=native so the same
+# binaries run on this container's Xeon and on the GPU box's host CPU.  That selects the AVX2 bodies
+# of quantize_row_q8_0 / ggml_vec_dot_* (src/ggml-cpu/ggml-cpu-quants.c), the ones the oracle in
+# oracle/ggml_oracle.c restates.
+REF   ?= /root/reference
+OUT   ?= oracle/_ref
+CC    ?= gcc
+CXX   ?= g++
+ARCH  ?= -march=x86-64-v3
+OPT   ?= -O3 -DNDEBUG
+DEFS  := -D_GNU_SOURCE -D_XOPEN_SOURCE=600 -DGGML_SCHED_MAX_COPIES=4 -DGGML_SHARED -DGGML_BACKEND_SHARED
+INC   := -I$(REF)/include -I$(REF)/src -I$(REF)/src/ggml-cpu
+CFLAGS_COMMON   := $(OPT) -fPIC -std=gnu11   $(DEFS) $(INC) -w
+CXXFLAGS_COMMON := $(OPT) -fPIC -std=gnu++17 $(DEFS) $(INC) -w
+
+BASE_C   := ggml.c ggml-alloc.c ggml-quants.c
+BASE_CXX := ggml-backend.cpp ggml-opt.cpp ggml-threading.cpp gguf.cpp
+CPU_C    := ggml-cpu/ggml-cpu.c ggml-cpu/ggml-cpu-quants.c
+CPU_CXX  := ggml-cpu/ggml-cpu.cpp ggml-cpu/ggml-cpu-aarch64.cpp ggml-cpu/ggml-cpu-hbm.cpp \
+            ggml-cpu/ggml-cpu-traits.cpp ggml-cpu/amx/amx.cpp ggml-cpu/amx/mmq.cpp
+
+BASE_OBJ := $(patsubst %,$(OUT)/obj/base/%.o,$(BASE_C) $(BASE_CXX))
+CPU_OBJ  := $(patsubst %,$(OUT)/obj/cpu/%.o,$(CPU_C) $(CPU_CXX))
+
+LIBS  := $(OUT)/libggml-base.so $(OUT)/libggml-cpu.so $(OUT)/libggml.so
+BINS  := $(OUT)/test-backend-ops $(OUT)/test-quantize-fns $(OUT)/test-mul-mat
+
+all: $(LIBS) $(BINS)
+
+$(OUT)/obj/base/%.c.o: $(REF)/src/%.c
+	@mkdir -p $(dir $@)
+	$(CC) $(CFLAGS_COMMON) -DGGML_BUILD -c $< -o $@
+$(OUT)/obj/base/%.cpp.o: $(REF)/src/%.cpp
+	@mkdir -p $(dir $@)
+	$(CXX) $(CXXFLAGS_COMMON) -DGGML_BUILD -c $< -o $@
+$(OUT)/obj/cpu/%.c.o: $(REF)/src/%.c
+	@mkdir -p $(dir $@)
+	$(CC) $(CFLAGS_COMMON) $(ARCH) -fopenmp -DGGML_BACKEND_BUILD -DGGML_USE_OPENMP -DGGML_USE_CPU_AARCH64 -c $< -o $@
+$(OUT)/obj/cpu/%.cpp.o: $(REF)/src/%.cpp
+	@mkdir -p $(dir $@)
+	$(CXX) $(CXXFLAGS_COMMON) $(ARCH) -fopenmp -DGGML_BACKEND_BUILD -DGGML_USE_OPENMP -DGGML_USE_CPU_AARCH64 -c $< -o $@
+
+$(OUT)/libggml-base.so: $(BASE_OBJ)
+	$(CXX) -shared -o $@ $^ -lm -lpthread
+$(OUT)/libggml-cpu.so: $(CPU_OBJ) $(OUT)/libggml-base.so
+	$(CXX) -shared -fopenmp -o $@ $(CPU_OBJ) -L$(OUT) -lggml-base -Wl,-rpath,'$$ORIGIN'
+$(OUT)/libggml.so: $(REF)/src/ggml-backend-reg.cpp $(OUT)/libggml-cpu.so
+	$(CXX) $(CXXFLAGS_COMMON) -DGGML_BUILD -DGGML_USE_CPU -shared -o $@ $< -L$(OUT) -lggml-cpu -lggml-base -ldl -Wl,-rpath,'$$ORIGIN'
+
+$(OUT)/test-%: $(REF)/tests/test-%.cpp $(LIBS)
+	$(CXX) $(CXXFLAGS_COMMON) -o $@ $< -L$(OUT) -lggml -lggml-cpu -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN'
+
+clean:
+	rm -rf $(OUT)
+.PHONY: all clean
