@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's metric on MI355X: effective TFLOPS of the Q4_K MUL_MAT hot path.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): Q4_K [4096x4096]·[4096x512] per GPU — the configuration the metric is quoted on
+(BASELINE.json "Q4_K mul_mat 4096² × batch{1,512}"); the batch-1 decode GEMV of the same matrix is reported
+beside it under "decode".  One step = one pass of the hot path over one batch with W and the fp32 activations
+already resident in HBM: Q8_K activation quantization (exactly the CPU backend's) + the MFMA GEMM.
+Multi-GPU: the weight rows (output features) are sharded over ranks as the reference's split buffer does
+(src/ggml-cuda/ggml-cuda.cu:729-742); weak scaling — every rank owns 4096 rows (the N-GPU job is the
+[4096N x 4096] matrix); the output stays sharded (the consumer of a row-split layer is the next K-split layer),
+so the timed data path has no collective; an RCCL all-gather of the output shards is timed separately and
+reported as "with_allgather".
+The oracle/ reference is used only for the cpu_baseline leg (rank 0, N=1), never inside the timed region.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F16_PEAK_TFLOPS = 2516.6      # 256 CU x 2.4 GHz x 4096 flop/clk/CU, dense (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0              # spec; ~6300 achievable
+
+M_PER_GPU, K, B = 4096, 4096, 512
+Q4_K = 12
+
+
+def synth_q4k(m, k, seed):
+    """random but valid Q4_K superblocks (fp16 d/dmin ~ the scale of uniform(-1,1) weights, random 6-bit
+    scales/mins and nibbles) — timing does not depend on the values; parity is tested in tests/."""
+    rng = np.random.default_rng(seed)
+    nb = m * k // 256
+    raw = rng.integers(0, 256, (nb, 144), dtype=np.uint8)
+    raw[:, 0:2] = rng.uniform(0.001, 0.004, nb).astype(np.float16).view(np.uint8).reshape(nb, 2)
+    raw[:, 2:4] = rng.uniform(0.01, 0.03, nb).astype(np.float16).view(np.uint8).reshape(nb, 2)
+    return raw.reshape(-1)
+
+
+def cpu_baseline(seconds=12.0):
+    """the reference CPU backend (oracle/_ref, unmodified ggml built by oracle/ref.mk) on the same workload,
+    all host cores; falls back to the C port (oracle/libggml_oracle.so) when the binary is not in the snapshot."""
+    cores = os.cpu_count() or 1
+    exe = os.path.join(ROOT, "oracle", "_ref", "cpu_baseline")
+    if os.path.exists(exe):
+        try:
+            out = subprocess.run([exe, "q4_K", str(M_PER_GPU), str(K), str(B), str(seconds), str(cores)], capture_output=True, text=True, timeout=seconds * 4 + 60)
+            j = json.loads(out.stdout.strip().splitlines()[-1])
+            return {"value": round(j["gflops"] / 1e3, 4), "unit": "TFLOP/s", "cores": cores, "kind": "reference",
+                    "sample": "full workload Q4_K [4096x4096]·[4096x512], %d runs of ggml-cpu MUL_MAT (AVX2 build), %.1f ms/run" % (j["runs"], j["us_per_run"] / 1e3)}
+        except Exception as e:  # noqa: BLE001
+            print("cpu_baseline(reference) failed: %r" % (e,), file=sys.stderr)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import refutil as R
+    w = synth_q4k(512, K, 7)
+    x = np.random.default_rng(8).uniform(-1, 1, (B, K)).astype(np.float32)
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < seconds:
+        R.o_mul_mat(Q4_K, w, x, 512, K); n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(2.0 * 512 * K * B / dt / 1e12, 4), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+            "sample": "512 of 4096 weight rows x full [4096x512] activations, oracle C port (OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--splitk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if args.gpus > 1 or world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from ggml_amd import native, ops
+    native.lib()
+    L = native.lib()
+
+    # this rank's row shard of the [4096*world x 4096] Q4_K matrix, and the (replicated) activations
+    a = ops.QTensor.from_host_bytes(Q4_K, K, M_PER_GPU, synth_q4k(M_PER_GPU, K, 1234 + rank), device=dev)
+    x = torch.from_numpy(np.random.default_rng(4321).uniform(-1, 1, (B, K)).astype(np.float32)).to(dev)
+    y = torch.empty((B, M_PER_GPU), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(Q4_K, K, B), dtype=torch.uint8, device=dev)
+
+    def step():
+        native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), a.row_bytes, x.data_ptr(), K, y.data_ptr(), M_PER_GPU,
+                                          M_PER_GPU, K, B, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, args.variant, args.splitk, stream))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    flops_step = 2.0 * M_PER_GPU * K * B * world
+    value = flops_step / (ms_per_step * 1e-3) / 1e12
+
+    # ---- the dominant kernel alone (activations prepared once), HIP events on the launch stream -------------
+    native.check(L.ggml_cdna4_prepare_act(Q4_K, x.data_ptr(), K, K, B, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, stream))
+
+    def gemm_only():
+        native.check(L.ggml_cdna4_mul_mat_prepared(Q4_K, a.data.data_ptr(), a.row_bytes, y.data_ptr(), M_PER_GPU, M_PER_GPU, K, B,
+                                                   ws.data_ptr(), ws.numel(), ops.PATH_GEMM, args.variant, args.splitk, stream))
+    for _ in range(5):
+        gemm_only()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.steps):
+        gemm_only()
+    e1.record(); e1.synchronize()
+    gemm_us = e0.elapsed_time(e1) * 1e3 / args.steps
+    gemm_tflops = 2.0 * M_PER_GPU * K * B / (gemm_us * 1e-6) / 1e12
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "effective TFLOPS (2*M*N*K), Q4_K mul_mat [4096x4096]x[4096x512]", "value": round(value, 3), "unit": "TFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "Q4_K MUL_MAT [4096x4096]·[4096x512] per GPU; step = Q8_K activation quantize + fp16-MFMA GEMM, W and fp32 X resident in HBM",
+                       "M_per_gpu": M_PER_GPU, "K": K, "B": B, "parallelism": "row-split x%d, output left sharded" % world,
+                       "gemm_variant": args.variant, "splitk": args.splitk},
+            "tokens_per_s": round(B * world / (ms_per_step * 1e-3), 1),
+            "roofline": {"bound": "mfma", "kernel": "k_gemm_q<Q4_K>", "achieved": round(gemm_tflops, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(gemm_tflops / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                         "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": 2.0 * M_PER_GPU * K * B},
+        }
+
+    # ---- batch-1 decode GEMV of the same matrix (HBM roofline), rank 0 only ------------------------------------
+    if rank == 0:
+        ncopy = 64                                      # 64 x 9.4 MB = 604 MB > 256 MB Infinity Cache: every launch streams from HBM
+        big = torch.from_numpy(np.tile(a.data.cpu().numpy().reshape(-1), ncopy)).to(dev)
+        row_b, mat_b = a.row_bytes, a.row_bytes * M_PER_GPU
+        x1 = x[:1].contiguous()
+        y1 = torch.empty((1, M_PER_GPU), dtype=torch.float32, device=dev)
+        native.check(L.ggml_cdna4_prepare_act(Q4_K, x1.data_ptr(), K, K, 1, ws.data_ptr(), ws.numel(), ops.PATH_GEMV, stream))
+
+        def gemv(i):
+            native.check(L.ggml_cdna4_mul_mat_prepared(Q4_K, big.data_ptr() + (i % ncopy) * mat_b, row_b, y1.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1,
+                                                       ws.data_ptr(), ws.numel(), ops.PATH_GEMV, 0, 0, stream))
+        res = {}
+        for label, rot in (("cold_hbm", True), ("cache_warm", False)):
+            for i in range(20):
+                gemv(i if rot else 0)
+            n = max(args.steps, 256)
+            e0.record()
+            for i in range(n):
+                gemv(i if rot else 0)
+            e1.record(); e1.synchronize()
+            res[label] = e0.elapsed_time(e1) * 1e3 / n
+        alg_bytes = mat_b + K * 1 + (K // 256) * 4 + (K // 16) * 2 + M_PER_GPU * 4    # W + int8 x + scales + bsums + y
+        # full decode step incl. the activation quantize (what graph_compute does for one MUL_MAT node)
+        for _ in range(10):
+            native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), row_b, x1.data_ptr(), K, y1.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1, ws.data_ptr(), ws.numel(), 0, 0, 0, stream))
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        for _ in range(500):
+            native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), row_b, x1.data_ptr(), K, y1.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1, ws.data_ptr(), ws.numel(), 0, 0, 0, stream))
+        torch.cuda.synchronize(dev); full_us = (time.perf_counter() - t0) / 500 * 1e6
+        out["decode"] = {"workload": "Q4_K [4096x4096]·[4096x1] (BASELINE configs[1])", "us_per_gemv_cold_hbm": round(res["cold_hbm"], 3),
+                         "us_per_gemv_cache_warm": round(res["cache_warm"], 3), "us_per_step_with_quantize": round(full_us, 3),
+                         "tokens_per_s": round(1e6 / full_us, 1), "effective_tflops": round(2.0 * M_PER_GPU * K / (res["cold_hbm"] * 1e-6) / 1e12, 3),
+                         "roofline": {"bound": "hbm", "kernel": "k_gemv_q<Q4_K,1>", "achieved": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                      "algorithmic_bytes_per_launch": alg_bytes}}
+        del big
+
+    # ---- the exchange step of a row-split layer, timed separately: all-gather of the output shards ------------
+    if dist is not None:
+        yfull = torch.empty((world, B, M_PER_GPU), dtype=torch.float32, device=dev)
+        for _ in range(3):
+            step(); dist.all_gather_into_tensor(yfull, y)
+        barrier(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(); dist.all_gather_into_tensor(yfull, y)
+        barrier(); el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            ms = float(t.item()) / args.steps * 1e3
+            out["with_allgather"] = {"ms_per_step": round(ms, 5), "value": round(flops_step / (ms * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
+                                     "collective": "RCCL all_gather_into_tensor of fp32 output shards, %d B/rank" % (B * M_PER_GPU * 4)}
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

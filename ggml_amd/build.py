@@ -1,0 +1,113 @@
+"""Build driver for the native parts (no cmake needed: plain hipcc / g++ invocations).
+
+  libcdna4_kernels.so   hand-written HIP kernels + the C-ABI of include/ggml_cdna4.h        (always)
+  libggml-cdna4.so      ggml backend plug-in (ggml_backend_init), compiled against the ggml headers of the
+                        reference tree where they lie — only when that tree is present; the prebuilt
+                        .so travels to the GPU box with the snapshot.
+Both land in ggml_amd/lib/ (git-ignored, in-tree so the GPU box sees them).
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "lib")
+OBJ = os.path.join(ROOT, "build")
+REF = os.environ.get("GGML_REFERENCE_DIR", "/root/reference")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+ARCH = "gfx950"
+# -ffp-contract=off: the activation quantizers must round iscale*x before the int conversion, like the CPU
+HIPFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+
+KERNEL_SRCS = ["quantize_act.hip", "gemv_q.hip", "gemm_q_mfma.hip", "ops.hip", "capi.hip"]
+BACKEND_SRCS = ["backend/ggml_cdna4_backend.cpp", "backend/ggml_cdna4_ops.cpp"]
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout[-4000:], r.stderr[-8000:]))
+    return r
+
+
+def _newer(src_list, out):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in src_list if os.path.exists(s))
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(ROOT, "include", "ggml_cdna4.h"))
+    bdir = os.path.join(CSRC, "backend")
+    hs += [os.path.join(bdir, f) for f in os.listdir(bdir) if f.endswith(".h")]
+    return hs
+
+
+def build_kernels(force=False, verbose=False):
+    os.makedirs(LIB, exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = [s for s in KERNEL_SRCS if os.path.exists(os.path.join(CSRC, s))]
+    objs, jobs = [], []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.replace("/", "_") + ".o")
+        objs.append(obj)
+        if force or _newer([src] + _headers(), obj):
+            jobs.append([HIPCC] + HIPFLAGS + ["-c", src, "-o", obj])
+    if jobs:
+        if verbose:
+            print("[build] compiling %d HIP sources for %s" % (len(jobs), ARCH), file=sys.stderr)
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    out = os.path.join(LIB, "libcdna4_kernels.so")
+    if jobs or not os.path.exists(out):
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
+def have_reference():
+    return os.path.exists(os.path.join(REF, "src", "ggml-backend-impl.h"))
+
+
+def build_backend(force=False, verbose=False):
+    """the ggml plug-in; needs the ggml headers (reference tree).  Returns the path or None."""
+    out = os.path.join(LIB, "libggml-cdna4.so")
+    srcs = [os.path.join(CSRC, s) for s in BACKEND_SRCS]
+    if not all(os.path.exists(s) for s in srcs):
+        return None
+    if not have_reference():
+        return out if os.path.exists(out) else None
+    kern = os.path.join(LIB, "libcdna4_kernels.so")
+    if force or _newer(srcs + _headers() + [kern], out):
+        if verbose:
+            print("[build] compiling ggml backend plug-in", file=sys.stderr)
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O2", "-std=c++17", "-fPIC", "-shared",
+               "-DGGML_BACKEND_DL", "-DGGML_BACKEND_BUILD", "-DGGML_BACKEND_SHARED", "-DGGML_SHARED",
+               "-I" + os.path.join(REF, "include"), "-I" + os.path.join(REF, "src"), "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "backend"),
+               "-o", out] + srcs + ["-L" + LIB, "-lcdna4_kernels", "-Wl,-rpath,$ORIGIN"]
+        _run(cmd)
+    return out
+
+
+def build_oracle(verbose=False):
+    """test infrastructure: the C restatement, and oracle/_ref when the reference tree is present"""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
+
+
+def build_all(force=False, verbose=False):
+    k = build_kernels(force, verbose)
+    b = build_backend(force, verbose)
+    build_oracle(verbose)
+    return k, b
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

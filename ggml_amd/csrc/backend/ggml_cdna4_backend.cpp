@@ -1,0 +1,388 @@
+// ggml_cdna4_backend.cpp — the ggml backend plug-in for MI355X: implements the five function-pointer tables of
+// ggml's backend ABI (src/ggml-backend-impl.h:17-207) and exports `ggml_backend_init` (:215,222-228), so the
+// UNMODIFIED reference binaries load it with GGML_BACKEND_PATH=<this .so> (src/ggml-backend-reg.cpp:577-581)
+// or ggml_backend_load(path).  It is a thin strides-to-pointers layer: all arithmetic is in libcdna4_kernels.so
+// (C-ABI include/ggml_cdna4.h + the op table include/ggml_cdna4_ops.h).  Written from scratch against the ABI;
+// it shares no code with src/ggml-cuda or the src/ggml-hip shim.
+//
+// Error conventions follow SURVEY.md §8(b): programmer errors abort (GGML_ASSERT), OOM -> NULL buffer,
+// runtime failures -> GGML_STATUS_FAILED.  Unsupported ops are declined in supports_op (the scheduler then
+// places them on the CPU backend); nothing is ever computed on the host here.
+#include "ggml.h"
+#include "ggml-backend.h"
+#include "ggml-backend-impl.h"
+#include "ggml_cdna4.h"
+#include "ggml_cdna4_ops.h"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#define CDNA4_MAX_DEVICES 16
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "ggml-cdna4: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); GGML_ABORT("HIP error"); } } while (0)
+
+struct cdna4_device_ctx { int device; std::string name, description; };
+struct cdna4_buft_ctx   { int device; std::string name; };
+struct cdna4_buffer_ctx { int device; void * base; size_t size; };
+struct cdna4_backend_ctx {
+    int device; hipStream_t stream; std::string name;
+    void * ws = nullptr; size_t ws_size = 0;
+    void * need_ws(size_t n) {
+        if (n <= ws_size) return ws;
+        HIP_OK(hipStreamSynchronize(stream));
+        if (ws) HIP_OK(hipFree(ws));
+        ws_size = (n + (8u << 20)) & ~(size_t)((1u << 20) - 1);
+        if (hipMalloc(&ws, ws_size) != hipSuccess) { (void)hipGetLastError(); ws = nullptr; ws_size = 0; }
+        return ws;
+    }
+};
+
+static ggml_backend_reg_t ggml_backend_cdna4_reg(void);
+static ggml_backend_buffer_type_t cdna4_buffer_type(int device);
+static const char * cdna4_buffer_get_name_tag = "CDNA4";
+
+// ============================================================================================================
+// buffer
+static void cdna4_buffer_free(ggml_backend_buffer_t buffer) {
+    cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipFree(ctx->base));
+    delete ctx;
+}
+static void * cdna4_buffer_get_base(ggml_backend_buffer_t buffer) { return ((cdna4_buffer_ctx *)buffer->context)->base; }
+static bool buffer_is_cdna4(ggml_backend_buffer_t buffer) { return buffer && buffer->iface.get_base == cdna4_buffer_get_base; }
+
+static void cdna4_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
+    cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipMemset((char *)tensor->data + offset, value, size));
+    HIP_OK(hipDeviceSynchronize());
+}
+static void cdna4_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipMemcpy((char *)tensor->data + offset, data, size, hipMemcpyHostToDevice));
+}
+static void cdna4_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(data, (const char *)tensor->data + offset, size, hipMemcpyDeviceToHost));
+}
+static bool cdna4_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * src, ggml_tensor * dst) {
+    if (!buffer_is_cdna4(src->buffer)) return false;
+    cdna4_buffer_ctx * sctx = (cdna4_buffer_ctx *)src->buffer->context;
+    cdna4_buffer_ctx * dctx = (cdna4_buffer_ctx *)buffer->context;
+    HIP_OK(hipSetDevice(sctx->device)); HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipSetDevice(dctx->device));
+    if (sctx->device == dctx->device) HIP_OK(hipMemcpy(dst->data, src->data, ggml_nbytes(src), hipMemcpyDeviceToDevice));
+    else HIP_OK(hipMemcpyPeer(dst->data, dctx->device, src->data, sctx->device, ggml_nbytes(src)));
+    HIP_OK(hipDeviceSynchronize());
+    return true;
+}
+static void cdna4_buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
+    cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipMemset(ctx->base, value, ctx->size));
+    HIP_OK(hipDeviceSynchronize());
+}
+static const ggml_backend_buffer_i cdna4_buffer_iface = {
+    /* .free_buffer   = */ cdna4_buffer_free,
+    /* .get_base      = */ cdna4_buffer_get_base,
+    /* .init_tensor   = */ NULL,
+    /* .memset_tensor = */ cdna4_buffer_memset_tensor,
+    /* .set_tensor    = */ cdna4_buffer_set_tensor,
+    /* .get_tensor    = */ cdna4_buffer_get_tensor,
+    /* .cpy_tensor    = */ cdna4_buffer_cpy_tensor,
+    /* .clear         = */ cdna4_buffer_clear,
+    /* .reset         = */ NULL,
+};
+
+// ============================================================================================================
+// buffer type
+static const char * cdna4_buft_get_name(ggml_backend_buffer_type_t buft) { return ((cdna4_buft_ctx *)buft->context)->name.c_str(); }
+static ggml_backend_buffer_t cdna4_buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    cdna4_buft_ctx * bctx = (cdna4_buft_ctx *)buft->context;
+    if (hipSetDevice(bctx->device) != hipSuccess) { (void)hipGetLastError(); return NULL; }
+    void * base = nullptr;
+    const size_t alloc = size + 256;                       // slack: kernels may read whole 16-byte pieces
+    if (hipMalloc(&base, alloc) != hipSuccess) {           // OOM -> NULL, like ggml-cuda.cu:646-651
+        (void)hipGetLastError();
+        fprintf(stderr, "ggml-cdna4: allocating %.2f MiB on device %d failed\n", size / 1048576.0, bctx->device);
+        return NULL;
+    }
+    cdna4_buffer_ctx * ctx = new cdna4_buffer_ctx{bctx->device, base, alloc};
+    return ggml_backend_buffer_init(buft, cdna4_buffer_iface, ctx, size);
+}
+static size_t cdna4_buft_get_alignment(ggml_backend_buffer_type_t) { return 256; }
+static size_t cdna4_buft_get_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor * tensor) {
+    return (ggml_nbytes(tensor) + 15) & ~(size_t)15;       // 16-byte granules: vector loads never straddle tensors
+}
+static bool cdna4_buft_is_host(ggml_backend_buffer_type_t) { return false; }
+static const ggml_backend_buffer_type_i cdna4_buft_iface = {
+    /* .get_name       = */ cdna4_buft_get_name,
+    /* .alloc_buffer   = */ cdna4_buft_alloc_buffer,
+    /* .get_alignment  = */ cdna4_buft_get_alignment,
+    /* .get_max_size   = */ NULL,
+    /* .get_alloc_size = */ cdna4_buft_get_alloc_size,
+    /* .is_host        = */ cdna4_buft_is_host,
+};
+static bool buft_is_cdna4(ggml_backend_buffer_type_t buft) { return buft && buft->iface.get_name == cdna4_buft_get_name; }
+
+// ============================================================================================================
+// op support + dispatch
+static bool is_qweight(ggml_type t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K; }
+
+static bool supports_mul_mat(const ggml_tensor * op) {
+    const ggml_tensor * a = op->src[0], * b = op->src[1];
+    if (op->type != GGML_TYPE_F32 || !ggml_is_contiguous(op)) return false;
+    if (is_qweight(a->type)) {
+        // src1 must be F32 (the CPU backend itself only takes F32 or vec_dot_type, src/ggml-cpu/ggml-cpu.cpp:404-405)
+        if (b->type != GGML_TYPE_F32) return false;
+        if (a->nb[0] != ggml_type_size(a->type) || b->nb[0] != sizeof(float)) return false;
+        if (b->nb[1] % 16 || b->nb[2] % 16 || b->nb[3] % 16) return false;
+        return true;
+    }
+    return cdna4_ops_supports_matmul(op);
+}
+
+static bool supports_mul_mat_id(const ggml_tensor * op) {
+    const ggml_tensor * as = op->src[0], * b = op->src[1], * ids = op->src[2];
+    if (!is_qweight(as->type) || b->type != GGML_TYPE_F32 || ids->type != GGML_TYPE_I32 || op->type != GGML_TYPE_F32) return false;
+    if (!ggml_is_contiguous(as) || !ggml_is_contiguous(b) || !ggml_is_contiguous(op)) return false;
+    if (ids->nb[0] != sizeof(int32_t) || as->ne[3] != 1 || b->ne[3] != 1) return false;
+    return true;
+}
+
+static enum ggml_status compute_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst) {
+    const ggml_tensor * a = dst->src[0], * b = dst->src[1];
+    if (!is_qweight(a->type)) return cdna4_ops_compute(ctx, dst);
+    const int64_t K = a->ne[0], M = a->ne[1], N = b->ne[1];
+    const int64_t r2 = b->ne[2] / a->ne[2], r3 = b->ne[3] / a->ne[3];
+    // all activation rows form one matrix when src0 has no batch dims and src1's batch dims are laid out row after row
+    const bool collapse = a->ne[2] == 1 && a->ne[3] == 1 && b->nb[2] == (size_t)N * b->nb[1] && b->nb[3] == (size_t)b->ne[2] * b->nb[2];
+    const int64_t nbatch = collapse ? 1 : b->ne[2] * b->ne[3];
+    const int64_t Bc = collapse ? N * b->ne[2] * b->ne[3] : N;
+    const size_t need = ggml_cdna4_mul_mat_workspace_size((int)a->type, K, Bc);
+    void * ws = ctx->need_ws(need);
+    if (!ws) return GGML_STATUS_ALLOC_FAILED;
+    for (int64_t ib = 0; ib < nbatch; ib++) {
+        const int64_t i12 = collapse ? 0 : ib % b->ne[2], i13 = collapse ? 0 : ib / b->ne[2];
+        const char * W = (const char *)a->data + (i12 / r2) * a->nb[2] + (i13 / r3) * a->nb[3];
+        const float * X = (const float *)((const char *)b->data + i12 * b->nb[2] + i13 * b->nb[3]);
+        float * Y = (float *)((char *)dst->data + i12 * dst->nb[2] + i13 * dst->nb[3]);
+        const int rc = ggml_cdna4_mul_mat((int)a->type, W, (int64_t)a->nb[1], X, (int64_t)(b->nb[1] / sizeof(float)), Y, (int64_t)(dst->nb[1] / sizeof(float)),
+                                          M, K, Bc, ws, ctx->ws_size, GGML_CDNA4_PATH_AUTO, 0, 0, ctx->stream);
+        if (rc) { fprintf(stderr, "ggml-cdna4: MUL_MAT failed: %s\n", ggml_cdna4_last_error()); return GGML_STATUS_FAILED; }
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+static enum ggml_status compute_mul_mat_id(cdna4_backend_ctx * ctx, ggml_tensor * dst) {
+    const ggml_tensor * as = dst->src[0], * b = dst->src[1], * ids = dst->src[2];
+    const int64_t K = as->ne[0], M = as->ne[1], n_expert = as->ne[2];
+    const int64_t n_b = b->ne[1], n_tok = b->ne[2], n_used = ids->ne[0];
+    const size_t need = ggml_cdna4_mul_mat_workspace_size((int)as->type, K, n_b * n_tok);
+    void * ws = ctx->need_ws(need);
+    if (!ws) return GGML_STATUS_ALLOC_FAILED;
+    const int rc = ggml_cdna4_mul_mat_id((int)as->type, as->data, (int64_t)as->nb[1], (int64_t)as->nb[2],
+                                         (const float *)b->data, (int64_t)(b->nb[1] / 4), (int64_t)(b->nb[2] / 4),
+                                         (const int32_t *)ids->data, (int64_t)(ids->nb[1] / 4),
+                                         (float *)dst->data, (int64_t)(dst->nb[1] / 4), (int64_t)(dst->nb[2] / 4),
+                                         M, K, n_expert, n_used, n_b, n_tok, ws, ctx->ws_size, ctx->stream);
+    if (rc) { fprintf(stderr, "ggml-cdna4: MUL_MAT_ID failed: %s\n", ggml_cdna4_last_error()); return GGML_STATUS_FAILED; }
+    return GGML_STATUS_SUCCESS;
+}
+
+// ============================================================================================================
+// backend (stream)
+static const char * cdna4_backend_get_name(ggml_backend_t backend) { return ((cdna4_backend_ctx *)backend->context)->name.c_str(); }
+static void cdna4_backend_free(ggml_backend_t backend) {
+    cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    delete backend;
+}
+static void cdna4_backend_synchronize(ggml_backend_t backend) {
+    cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+}
+static enum ggml_status cdna4_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
+    cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
+    HIP_OK(hipSetDevice(ctx->device));
+    const int n_nodes = ggml_graph_n_nodes(cgraph);
+    for (int i = 0; i < n_nodes; i++) {
+        ggml_tensor * node = ggml_graph_node(cgraph, i);
+        if (ggml_is_empty(node)) continue;
+        enum ggml_status st = GGML_STATUS_SUCCESS;
+        switch (node->op) {
+            case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
+            case GGML_OP_MUL_MAT:    st = compute_mul_mat(ctx, node); break;
+            case GGML_OP_MUL_MAT_ID: st = compute_mul_mat_id(ctx, node); break;
+            default:                 st = cdna4_ops_compute(ctx, node); break;
+        }
+        if (st != GGML_STATUS_SUCCESS) {
+            fprintf(stderr, "ggml-cdna4: op %s (%s) failed\n", ggml_op_name(node->op), node->name);
+            return st;
+        }
+    }
+    return GGML_STATUS_SUCCESS;
+}
+static const ggml_backend_i cdna4_backend_iface = {
+    /* .get_name           = */ cdna4_backend_get_name,
+    /* .free               = */ cdna4_backend_free,
+    /* .set_tensor_async   = */ NULL,
+    /* .get_tensor_async   = */ NULL,
+    /* .cpy_tensor_async   = */ NULL,
+    /* .synchronize        = */ cdna4_backend_synchronize,
+    /* .graph_plan_create  = */ NULL,
+    /* .graph_plan_free    = */ NULL,
+    /* .graph_plan_update  = */ NULL,
+    /* .graph_plan_compute = */ NULL,
+    /* .graph_compute      = */ cdna4_backend_graph_compute,
+    /* .event_record       = */ NULL,
+    /* .event_wait         = */ NULL,
+};
+static ggml_guid_t cdna4_guid(void) {
+    static ggml_guid guid = {0x63, 0x64, 0x6e, 0x61, 0x34, 0x2d, 0x6d, 0x69, 0x33, 0x35, 0x35, 0x78, 0x2d, 0x67, 0x67, 0x01};
+    return &guid;
+}
+
+// used by the op table to get the stream / scratch without knowing the context layout
+extern "C" void * cdna4_backend_stream(void * ctx) { return (void *)((cdna4_backend_ctx *)ctx)->stream; }
+extern "C" void * cdna4_backend_scratch(void * ctx, size_t n) { return ((cdna4_backend_ctx *)ctx)->need_ws(n); }
+
+// ============================================================================================================
+// device
+static const char * cdna4_dev_get_name(ggml_backend_dev_t dev) { return ((cdna4_device_ctx *)dev->context)->name.c_str(); }
+static const char * cdna4_dev_get_description(ggml_backend_dev_t dev) { return ((cdna4_device_ctx *)dev->context)->description.c_str(); }
+static void cdna4_dev_get_memory(ggml_backend_dev_t dev, size_t * free, size_t * total) {
+    HIP_OK(hipSetDevice(((cdna4_device_ctx *)dev->context)->device));
+    HIP_OK(hipMemGetInfo(free, total));
+}
+static enum ggml_backend_dev_type cdna4_dev_get_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
+static void cdna4_dev_get_props(ggml_backend_dev_t dev, ggml_backend_dev_props * props) {
+    props->name = cdna4_dev_get_name(dev);
+    props->description = cdna4_dev_get_description(dev);
+    props->type = GGML_BACKEND_DEVICE_TYPE_GPU;
+    cdna4_dev_get_memory(dev, &props->memory_free, &props->memory_total);
+    props->caps = { /* async */ false, /* host_buffer */ false, /* buffer_from_host_ptr */ false, /* events */ false };
+}
+static ggml_backend_t cdna4_dev_init_backend(ggml_backend_dev_t dev, const char *) {
+    cdna4_device_ctx * dctx = (cdna4_device_ctx *)dev->context;
+    if (hipSetDevice(dctx->device) != hipSuccess) { (void)hipGetLastError(); return NULL; }
+    cdna4_backend_ctx * ctx = new cdna4_backend_ctx;
+    ctx->device = dctx->device; ctx->name = dctx->name;
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { (void)hipGetLastError(); delete ctx; return NULL; }
+    return new ggml_backend{ /* .guid = */ cdna4_guid(), /* .iface = */ cdna4_backend_iface, /* .device = */ dev, /* .context = */ ctx };
+}
+static ggml_backend_buffer_type_t cdna4_dev_get_buffer_type(ggml_backend_dev_t dev) { return cdna4_buffer_type(((cdna4_device_ctx *)dev->context)->device); }
+
+static bool cdna4_dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
+    switch (op->op) {
+        case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: return true;
+        case GGML_OP_MUL_MAT: return supports_mul_mat(op);
+        case GGML_OP_MUL_MAT_ID: return supports_mul_mat_id(op);
+        default: return cdna4_ops_supports_tensor(op);
+    }
+}
+static bool cdna4_dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
+    return buft_is_cdna4(buft) && ((cdna4_buft_ctx *)buft->context)->device == ((cdna4_device_ctx *)dev->context)->device;
+}
+static bool cdna4_dev_offload_op(ggml_backend_dev_t, const ggml_tensor * op) {
+    // worth moving host-resident weights over PCIe only for batched work (cf. ggml-cuda.cu:3241-3247)
+    const int64_t batch = op->op == GGML_OP_MUL_MAT_ID ? op->ne[2] : op->ne[1];
+    return (op->op == GGML_OP_MUL_MAT || op->op == GGML_OP_MUL_MAT_ID) && batch >= 32;
+}
+static const ggml_backend_device_i cdna4_device_iface = {
+    /* .get_name             = */ cdna4_dev_get_name,
+    /* .get_description      = */ cdna4_dev_get_description,
+    /* .get_memory           = */ cdna4_dev_get_memory,
+    /* .get_type             = */ cdna4_dev_get_type,
+    /* .get_props            = */ cdna4_dev_get_props,
+    /* .init_backend         = */ cdna4_dev_init_backend,
+    /* .get_buffer_type      = */ cdna4_dev_get_buffer_type,
+    /* .get_host_buffer_type = */ NULL,
+    /* .buffer_from_host_ptr = */ NULL,
+    /* .supports_op          = */ cdna4_dev_supports_op,
+    /* .supports_buft        = */ cdna4_dev_supports_buft,
+    /* .offload_op           = */ cdna4_dev_offload_op,
+    /* .event_new            = */ NULL,
+    /* .event_free           = */ NULL,
+    /* .event_synchronize    = */ NULL,
+};
+
+// ============================================================================================================
+// registry
+struct cdna4_reg_ctx {
+    std::vector<ggml_backend_device> devices;
+    std::vector<cdna4_device_ctx> dctx;
+    ggml_backend_buffer_type bufts[CDNA4_MAX_DEVICES];
+    cdna4_buft_ctx buft_ctx[CDNA4_MAX_DEVICES];
+    int n = 0;
+};
+static cdna4_reg_ctx * g_reg = nullptr;
+
+static ggml_backend_buffer_type_t cdna4_buffer_type(int device) {
+    GGML_ASSERT(g_reg && device >= 0 && device < g_reg->n);
+    return &g_reg->bufts[device];
+}
+static const char * cdna4_reg_get_name(ggml_backend_reg_t) { return "CDNA4"; }
+static size_t cdna4_reg_get_device_count(ggml_backend_reg_t reg) { return (size_t)((cdna4_reg_ctx *)reg->context)->n; }
+static ggml_backend_dev_t cdna4_reg_get_device(ggml_backend_reg_t reg, size_t index) {
+    cdna4_reg_ctx * ctx = (cdna4_reg_ctx *)reg->context;
+    GGML_ASSERT(index < (size_t)ctx->n);
+    return &ctx->devices[index];
+}
+static ggml_backend_feature g_features[] = { {"WAVE64", "1"}, {"MFMA_F16", "1"}, {"INT8_DOT", "1"}, {nullptr, nullptr} };
+static ggml_backend_feature * cdna4_get_features(ggml_backend_reg_t) { return g_features; }
+static void * cdna4_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
+    if (strcmp(name, "ggml_backend_get_features") == 0) return (void *)cdna4_get_features;
+    return NULL;
+}
+static const ggml_backend_reg_i cdna4_reg_iface = {
+    /* .get_name         = */ cdna4_reg_get_name,
+    /* .get_device_count = */ cdna4_reg_get_device_count,
+    /* .get_device       = */ cdna4_reg_get_device,
+    /* .get_proc_address = */ cdna4_reg_get_proc_address,
+};
+
+static ggml_backend_reg_t ggml_backend_cdna4_reg(void) {
+    static ggml_backend_reg reg;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        cdna4_reg_ctx * ctx = new cdna4_reg_ctx;
+        int n = ggml_cdna4_device_count();
+        if (n > CDNA4_MAX_DEVICES) n = CDNA4_MAX_DEVICES;
+        ctx->n = n;
+        ctx->dctx.resize(n); ctx->devices.resize(n);
+        reg = ggml_backend_reg{ /* .api_version = */ GGML_BACKEND_API_VERSION, /* .iface = */ cdna4_reg_iface, /* .context = */ ctx };
+        for (int i = 0; i < n; i++) {
+            hipDeviceProp_t prop;
+            std::string desc = "AMD GPU";
+            if (hipGetDeviceProperties(&prop, i) == hipSuccess) desc = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+            ctx->dctx[i] = cdna4_device_ctx{i, "CDNA4" + std::to_string(i), desc};
+            ctx->devices[i] = ggml_backend_device{ /* .iface = */ cdna4_device_iface, /* .reg = */ &reg, /* .context = */ &ctx->dctx[i] };
+            ctx->buft_ctx[i] = cdna4_buft_ctx{i, "CDNA4" + std::to_string(i)};
+            ctx->bufts[i] = ggml_backend_buffer_type{ /* .iface = */ cdna4_buft_iface, /* .device = */ &ctx->devices[i], /* .context = */ &ctx->buft_ctx[i] };
+        }
+        g_reg = ctx;
+    });
+    return &reg;
+}
+
+extern "C" {
+GGML_BACKEND_API ggml_backend_reg_t ggml_backend_init(void) { return ggml_backend_cdna4_reg(); }
+GGML_BACKEND_API int ggml_backend_score(void) { return ggml_cdna4_device_count() > 0 ? 100 : 0; }
+// static-registration entry point for an in-tree build (`ggml_backend_register(ggml_backend_cdna4_reg_public())`)
+GGML_BACKEND_API ggml_backend_reg_t ggml_backend_cdna4_reg_public(void) { return ggml_backend_cdna4_reg(); }
+}

@@ -1,0 +1,137 @@
+// capi.hip — the C-ABI of libcdna4_kernels.so (declared in include/ggml_cdna4.h).
+#include "../../include/ggml_cdna4.h"
+#include "cdna4_common.h"
+#include "cdna4_kernels.h"
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+int cdna4_set_error(hipError_t e, const char *file, int line) {
+    snprintf(g_err, sizeof g_err, "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
+    return -1;
+}
+int cdna4_set_error_msg(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); return -1; }
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline bool is_kq(int t) { return t == CDNA4_Q4_K || t == CDNA4_Q5_K || t == CDNA4_Q6_K; }
+static inline bool is_q(int t) { return is_kq(t) || t == CDNA4_Q4_0 || t == CDNA4_Q8_0; }
+
+// workspace carve: [qs int8 B*K][d f32 B*K/qka][bsums i16 B*K/16][xh f16 B*K]
+struct ws_view { int8_t *qs; float *d; int16_t *bsums; void *xh; size_t total; };
+static ws_view carve(int type, int64_t K, int64_t B, void *base) {
+    ws_view v; uint8_t *p = (uint8_t *)base; size_t off = 0;
+    const int64_t qka = is_kq(type) ? 256 : 32;
+    v.qs = (int8_t *)(p + off); off += align256((size_t)(B * K));
+    v.d = (float *)(p + off); off += align256((size_t)(B * (K / qka)) * 4);
+    v.bsums = (int16_t *)(p + off); off += align256((size_t)(B * (K / 16)) * 2);
+    v.xh = (void *)(p + off); off += align256((size_t)(B * K) * 2);
+    v.total = off;
+    return v;
+}
+
+extern "C" {
+
+int ggml_cdna4_api_version(void) { return GGML_CDNA4_API_VERSION; }
+const char *ggml_cdna4_last_error(void) { return g_err; }
+int ggml_cdna4_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
+int ggml_cdna4_set_device(int device) { hipError_t e = hipSetDevice(device); return e == hipSuccess ? 0 : cdna4_set_error(e, __FILE__, __LINE__); }
+
+size_t ggml_cdna4_row_size(int type, int64_t k) {
+    switch (type) {
+        case CDNA4_F32: return (size_t)k * 4; case CDNA4_F16: return (size_t)k * 2;
+        case CDNA4_Q4_0: return k % 32 ? 0 : (size_t)(k / 32) * 18; case CDNA4_Q8_0: return k % 32 ? 0 : (size_t)(k / 32) * 34;
+        case CDNA4_Q4_K: return k % 256 ? 0 : (size_t)(k / 256) * 144; case CDNA4_Q5_K: return k % 256 ? 0 : (size_t)(k / 256) * 176;
+        case CDNA4_Q6_K: return k % 256 ? 0 : (size_t)(k / 256) * 210;
+    }
+    return 0;
+}
+
+size_t ggml_cdna4_mul_mat_workspace_size(int type, int64_t K, int64_t n_act_rows) {
+    if (!is_q(type) || K <= 0 || n_act_rows <= 0) return 0;
+    return carve(type, K, n_act_rows, nullptr).total;
+}
+
+int ggml_cdna4_quantize_q8_K(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d, int16_t *bsums, void *xh, void *stream) {
+    if (((uintptr_t)x | (uintptr_t)(x_row_stride * 4)) & 15) return cdna4_set_error_msg("quantize_q8_K: x must be 16-byte aligned");
+    if (qs && (!d || !bsums)) return cdna4_set_error_msg("quantize_q8_K: qs needs d and bsums");
+    return cdna4_launch_quantize_q8_K(x, x_row_stride, K, B, qs, d, bsums, xh, (hipStream_t)stream);
+}
+int ggml_cdna4_quantize_q8_0(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d, void *xh, int ref_rounding, void *stream) {
+    if (((uintptr_t)x | (uintptr_t)(x_row_stride * 4)) & 15) return cdna4_set_error_msg("quantize_q8_0: x must be 16-byte aligned");
+    if (qs && !d) return cdna4_set_error_msg("quantize_q8_0: qs needs d");
+    return cdna4_launch_quantize_q8_0(x, x_row_stride, K, B, qs, d, xh, ref_rounding != 0, (hipStream_t)stream);
+}
+
+static int resolve_path(int type, int path, int64_t M, int64_t K, int64_t B) {
+    if (path == GGML_CDNA4_PATH_AUTO) return (B > 8 && cdna4_gemm_q_supported(type, M, K, B)) ? GGML_CDNA4_PATH_GEMM : GGML_CDNA4_PATH_GEMV;
+    return path;
+}
+
+int ggml_cdna4_prepare_act(int type, const float *X, int64_t x_row_stride, int64_t K, int64_t B, void *workspace, size_t workspace_bytes, int path, void *stream) {
+    if (!is_q(type)) return cdna4_set_error_msg("prepare_act: unsupported weight type");
+    if (B <= 0 || K <= 0) return 0;
+    if (!workspace || ((uintptr_t)workspace & 255)) return cdna4_set_error_msg("prepare_act: workspace must be 256-byte aligned");
+    const ws_view v = carve(type, K, B, workspace);
+    if (workspace_bytes < v.total) return cdna4_set_error_msg("prepare_act: workspace too small");
+    const bool want_i8 = path != GGML_CDNA4_PATH_GEMM, want_h = path != GGML_CDNA4_PATH_GEMV;
+    if (is_kq(type)) return ggml_cdna4_quantize_q8_K(X, x_row_stride, K, B, want_i8 ? v.qs : nullptr, v.d, v.bsums, want_h ? v.xh : nullptr, stream);
+    return ggml_cdna4_quantize_q8_0(X, x_row_stride, K, B, want_i8 ? v.qs : nullptr, v.d, want_h ? v.xh : nullptr, 0, stream);
+}
+
+int ggml_cdna4_mul_mat_prepared(int type, const void *W, int64_t w_row_bytes, float *Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,
+                                const void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, void *stream) {
+    if (!is_q(type)) return cdna4_set_error_msg("mul_mat: unsupported weight type");
+    if (M <= 0 || B <= 0) return 0;
+    if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat: K is not a whole number of blocks");
+    const ws_view v = carve(type, K, B, (void *)workspace);
+    if (workspace_bytes < v.total) return cdna4_set_error_msg("mul_mat: workspace too small");
+    path = resolve_path(type, path, M, K, B);
+    if (path == GGML_CDNA4_PATH_GEMM) {
+        cdna4_gemm_args a{};
+        a.type = type; a.W = (const uint8_t *)W; a.w_row_bytes = w_row_bytes; a.xh = v.xh; a.xh_row_elems = K;
+        a.Y = Y; a.y_row_elems = y_row_stride; a.M = (int)M; a.K = (int)K; a.B = (int)B; a.variant = gemm_variant; a.splitk = splitk;
+        return cdna4_launch_gemm_q(a, (hipStream_t)stream);
+    }
+    cdna4_gemv_args g{};
+    g.type = type; g.W = (const uint8_t *)W; g.w_row_bytes = w_row_bytes; g.qs = v.qs; g.d = v.d; g.bsums = v.bsums;
+    g.Y = Y; g.y_col_stride = y_row_stride; g.M = (int)M; g.K = (int)K; g.ncol = (int)B; g.ids = nullptr;
+    return cdna4_launch_gemv_q(g, (hipStream_t)stream);
+}
+
+int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
+                       int64_t M, int64_t K, int64_t B, void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, void *stream) {
+    if (!is_q(type)) return cdna4_set_error_msg("mul_mat: unsupported weight type");
+    if (M <= 0 || B <= 0) return 0;
+    if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat: K is not a whole number of blocks");
+    path = resolve_path(type, path, M, K, B);
+    if (path == GGML_CDNA4_PATH_GEMM && !cdna4_gemm_q_supported(type, M, K, B)) return cdna4_set_error_msg("mul_mat: GEMM path does not support this shape");
+    int rc = ggml_cdna4_prepare_act(type, X, x_row_stride, K, B, workspace, workspace_bytes, path, stream);
+    if (rc) return rc;
+    return ggml_cdna4_mul_mat_prepared(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, stream);
+}
+
+int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t w_expert_bytes, const float *b, int64_t b_row_stride, int64_t b_tok_stride,
+                          const int32_t *ids, int64_t ids_tok_stride, float *dst, int64_t dst_row_stride, int64_t dst_tok_stride,
+                          int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+    if (!is_q(type)) return cdna4_set_error_msg("mul_mat_id: unsupported weight type");
+    if (M <= 0 || n_tok <= 0 || n_used <= 0) return 0;
+    if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat_id: K is not a whole number of blocks");
+    if (n_b != n_used && n_b != 1) return cdna4_set_error_msg("mul_mat_id: b.ne[1] must be n_used or 1");
+    if (dst_tok_stride != n_used * dst_row_stride) return cdna4_set_error_msg("mul_mat_id: dst must be contiguous over (slot, token)");
+    if (b_tok_stride != n_b * b_row_stride) return cdna4_set_error_msg("mul_mat_id: b must be contiguous over (row, token)");
+    const int64_t nact = n_tok * n_b;
+    if (!workspace || ((uintptr_t)workspace & 255)) return cdna4_set_error_msg("mul_mat_id: workspace must be 256-byte aligned");
+    const ws_view v = carve(type, K, nact, workspace);
+    if (workspace_bytes < v.total) return cdna4_set_error_msg("mul_mat_id: workspace too small");
+    int rc = ggml_cdna4_prepare_act(type, b, b_row_stride, K, nact, workspace, workspace_bytes, GGML_CDNA4_PATH_GEMV, stream);
+    if (rc) return rc;
+    cdna4_gemv_args g{};
+    g.type = type; g.W = (const uint8_t *)as; g.w_row_bytes = w_row_bytes; g.qs = v.qs; g.d = v.d; g.bsums = v.bsums;
+    g.Y = dst; g.y_col_stride = dst_row_stride; g.M = (int)M; g.K = (int)K; g.ncol = (int)(n_tok * n_used);
+    g.ids = ids; g.ids_tok_stride = ids_tok_stride; g.w_expert_bytes = w_expert_bytes; g.n_used = (int)n_used; g.n_b = (int)n_b; g.n_expert = (int)n_expert;
+    return cdna4_launch_gemv_q(g, (hipStream_t)stream);
+}
+
+}  // extern "C"

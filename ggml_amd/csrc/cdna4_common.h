@@ -1,0 +1,73 @@
+// cdna4_common.h — shared device helpers for the MI355X (gfx950, wave64) ggml kernels.
+// Block formats follow the reference's normative layout (src/ggml-common.h:161-328); nothing here is
+// derived from src/ggml-cuda.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CDNA4_WAVE 64
+#define QK_K 256
+
+// ggml type ids (include/ggml.h:351-390)
+enum cdna4_type : int {
+    CDNA4_F32 = 0, CDNA4_F16 = 1, CDNA4_Q4_0 = 2, CDNA4_Q8_0 = 8,
+    CDNA4_Q4_K = 12, CDNA4_Q5_K = 13, CDNA4_Q6_K = 14, CDNA4_Q8_K = 15, CDNA4_I32 = 26,
+};
+
+// bytes per block / weights per block
+template <int T> struct QT;
+template <> struct QT<CDNA4_Q4_0> { static constexpr int BYTES = 18,  QK = 32;  static constexpr bool KQ = false; };
+template <> struct QT<CDNA4_Q8_0> { static constexpr int BYTES = 34,  QK = 32;  static constexpr bool KQ = false; };
+template <> struct QT<CDNA4_Q4_K> { static constexpr int BYTES = 144, QK = 256; static constexpr bool KQ = true; };
+template <> struct QT<CDNA4_Q5_K> { static constexpr int BYTES = 176, QK = 256; static constexpr bool KQ = true; };
+template <> struct QT<CDNA4_Q6_K> { static constexpr int BYTES = 210, QK = 256; static constexpr bool KQ = true; };
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// loads with a stated (possibly small) alignment: the compiler picks the widest legal instruction
+struct __attribute__((packed, aligned(2))) u32_a2 { uint32_t v; };
+struct __attribute__((packed, aligned(2))) u16_a2 { uint16_t v; };
+__device__ __forceinline__ uint32_t ld_u32_a2(const uint8_t *p) { return reinterpret_cast<const u32_a2 *>(p)->v; }
+__device__ __forceinline__ uint16_t ld_u16(const uint8_t *p) { return *reinterpret_cast<const uint16_t *>(p); }
+__device__ __forceinline__ u32x4 ld_u32x4(const void *p) { return *reinterpret_cast<const u32x4 *>(p); }
+
+__device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(half_t, h); }
+__device__ __forceinline__ uint16_t f2h_bits(float f) { return __builtin_bit_cast(uint16_t, (half_t)f); }   // RNE
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// 6-bit scale/min pairs of Q4_K / Q5_K: get_scale_min_k4, src/ggml-quants.c:631-638.
+// sc[0..2] are the 12 scale bytes as three little-endian dwords.
+__device__ __forceinline__ uint32_t k4_byte(const uint32_t sc[3], int j) { return (sc[j >> 2] >> (8 * (j & 3))) & 0xFF; }
+__device__ __forceinline__ void k4_scale_min(const uint32_t sc[3], int j, uint32_t &d, uint32_t &m) {
+    if (j < 4) { d = k4_byte(sc, j) & 63; m = k4_byte(sc, j + 4) & 63; }
+    else { d = (k4_byte(sc, j + 4) & 0xF) | ((k4_byte(sc, j - 4) >> 6) << 4); m = (k4_byte(sc, j + 4) >> 4) | ((k4_byte(sc, j) >> 6) << 4); }
+}
+// same with a run-time j on registers (select chains, no scratch)
+__device__ __forceinline__ uint32_t k4_byte_rt(uint32_t a, uint32_t b, uint32_t c, int j) {
+    const uint32_t w = j < 4 ? a : (j < 8 ? b : c);
+    return (w >> (8 * (j & 3))) & 0xFF;
+}
+__device__ __forceinline__ void k4_scale_min_rt(uint32_t a, uint32_t b, uint32_t c, int j, int &d, int &m) {
+    if (j < 4) { d = k4_byte_rt(a, b, c, j) & 63; m = k4_byte_rt(a, b, c, j + 4) & 63; }
+    else { d = (k4_byte_rt(a, b, c, j + 4) & 0xF) | ((k4_byte_rt(a, b, c, j - 4) >> 6) << 4);
+           m = (k4_byte_rt(a, b, c, j + 4) >> 4) | ((k4_byte_rt(a, b, c, j) >> 6) << 4); }
+}
+
+#define CDNA4_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return cdna4_set_error(e_, __FILE__, __LINE__); } while (0)
+int cdna4_set_error(hipError_t e, const char *file, int line);
+int cdna4_set_error_msg(const char *msg);

@@ -1,0 +1,37 @@
+// cdna4_kernels.h — internal launcher prototypes (C++), one per .hip file.  The public C-ABI is
+// include/ggml_cdna4.h, implemented in capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// quantize_act.hip
+int cdna4_launch_quantize_q8_K(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d,
+                               int16_t *bsums, void *xh, hipStream_t st);
+int cdna4_launch_quantize_q8_0(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d,
+                               void *xh, bool ref_rounding, hipStream_t st);
+
+// gemv_q.hip — int8-dot decode path.  Activations are the SoA workspace of quantize_act.hip.
+struct cdna4_gemv_args {
+    int type;
+    const uint8_t *W; int64_t w_row_bytes;          // M rows of K weights
+    const int8_t *qs; const float *d; const int16_t *bsums;   // [ncol][K], [ncol][K/QKA], [ncol][K/16]
+    float *Y; int64_t y_col_stride;                 // Y[c * y_col_stride + m]
+    int M, K, ncol;
+    // MUL_MAT_ID: if ids != nullptr, column c = (token t, slot u): expert = ids[t*ids_tok_stride + u],
+    // W += expert * w_expert_bytes, activation column = t * n_b + (u % n_b)
+    const int32_t *ids; int64_t ids_tok_stride; int64_t w_expert_bytes; int n_used, n_b, n_expert;
+};
+int cdna4_launch_gemv_q(const cdna4_gemv_args &a, hipStream_t st);
+
+// gemm_q_mfma.hip — fp16 MFMA prefill path.  xh = pair-interleaved fp16 activations [B][K].
+struct cdna4_gemm_args {
+    int type;
+    const uint8_t *W; int64_t w_row_bytes;
+    const void *xh; int64_t xh_row_elems;
+    float *Y; int64_t y_row_elems;                  // Y[b * y_row_elems + m]
+    int M, K, B;
+    int variant;                                    // 0 = auto; see gemm_q_mfma.hip
+    int splitk;                                     // 0 = auto
+};
+int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st);
+bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B);

@@ -1,0 +1,361 @@
+// gemm_q_mfma.hip — batched prefill path: Y[b][m] = sum_k W[m][k] * X[b][k], W block-quantized, on the
+// gfx950 matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate).
+//
+// Numerics ("parity mode"): X has already been quantized exactly like the reference CPU
+// backend quantizes src1 (Q8_K / Q8_0, quantize_act.hip) and dequantized to fp16; weights are dequantized
+// block-wise to fp16 with the reference formulas (dequantize_row_q4_K etc., src/ggml-quants.c:255,349,1280,
+// 1482,1690).  Measured rel-L2 vs ggml-cpu ~3e-4 (gate 1e-3); vs the exact product it is ~4e-3 like the CPU.
+//
+// Structure (MI355X-first, not a port of src/ggml-cuda/mmq.cuh):
+//  * work-group = 4 waves, tile 128(m) x 64|128(b); wave w owns m-rows [32w,32w+32) for ALL b of the tile, so
+//    every weight of the tile is dequantized by exactly one lane, in registers, straight into the MFMA B
+//    operand — weights never exist as fp16 in LDS or HBM.
+//  * packed superblocks travel HBM -> LDS untouched via global_load_lds_dwordx4 (16 B/lane, whole 144/176-B
+//    superblocks, coalesced); the 144-B row stride is bank-conflict-free for ds_read_b128.  Formats whose
+//    blocks are only 2-byte aligned (Q6_K 210 B, Q4_0 18 B, Q8_0 34 B) are read per lane from global memory.
+//  * fp16 activations are LDS-staged by global_load_lds in 64-k slices, 128-B rows, 16-B chunks XOR-swizzled by
+//    ((row>>1)&7) on the SOURCE address so the A-fragment ds_read_b128s are conflict-free.
+//  * k is consumed in a permuted order: MFMA A and B fragments only need to agree on which k each slot holds,
+//    so the nibble unpack needs no byte shuffles (see chunk_of() and the pair-interleaved fp16 image).
+//  * double-buffered LDS, one s_waitcnt vmcnt(0) + barrier per 64-k step, next slice issued before the MFMAs.
+//  * optional split-K (fp32 atomics into a zeroed Y) to fill 256 CUs on small problems; XCD-aware tile order
+//    keeps the tiles that share a weight panel on one XCD's L2.
+#include "cdna4_common.h"
+#include "cdna4_kernels.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+__device__ __forceinline__ void glds16(const void *g, void *l_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t *)g, (lds_void_t *)l_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ half2_t as_h2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
+
+#define MAGIC2 0x64006400u   // two fp16 1024.0: (MAGIC2 | q) == 1024 + q exactly for q < 1024
+
+// the 8-halves chunk (of the 64-k slice) that MFMA k-step kk / lane-half h consumes
+template <int TYPE> __device__ __forceinline__ int chunk_of(int kk, int h) {
+    if (QT<TYPE>::KQ) return (kk >> 1) * 4 + 2 * h + (kk & 1);     // low nibbles = k<32, high = k>=32 of the slice
+    return 4 * h + kk;                                              // lane-half h owns 32-block h of the slice
+}
+
+__device__ __forceinline__ half8_t finish_frag(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, half2_t off, half2_t s, half2_t c) {
+    const half2_t r0 = __builtin_elementwise_fma(as_h2(p0) + off, s, c), r1 = __builtin_elementwise_fma(as_h2(p1) + off, s, c);
+    const half2_t r2 = __builtin_elementwise_fma(as_h2(p2) + off, s, c), r3 = __builtin_elementwise_fma(as_h2(p3) + off, s, c);
+    half8_t f = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};
+    return f;
+}
+__device__ __forceinline__ half2_t splat(float v) { const half_t h = (half_t)v; half2_t r = {h, h}; return r; }
+
+// ------------------------------------------------------------------------------------------------------------
+// per-format raw data for one 64-k slice of one weight row, as seen by lane-half h, and the fragment builders.
+// `P` is a byte pointer to the row (global) or to the staged superblock (LDS); the address space is inferred.
+template <int TYPE> struct Raw;
+
+template <> struct Raw<CDNA4_Q4_K> {
+    u32x4 hdr, q;
+    template <typename P> __device__ __forceinline__ void load(P blk, int g, int h) { hdr = ld_u32x4(blk); q = ld_u32x4(blk + 16 + 32 * g + 16 * h); }
+    __device__ __forceinline__ void frags(int g, int h, half8_t (&f)[4]) const {
+        const uint32_t sc[3] = {hdr.y, hdr.z, hdr.w};
+        uint32_t s0, m0, s1, m1;
+        k4_scale_min(sc, 2 * g, s0, m0); k4_scale_min(sc, 2 * g + 1, s1, m1);
+        const float d = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
+        const half_t sl = (half_t)(d * (float)s0), sh = (half_t)(d * (float)s1);
+        const half2_t SL = {sl, sl}, SH = {sh, sh};
+        const half2_t CL = splat(8.f * (float)sl - dmin * (float)m0), CH = splat(8.f * (float)sh - dmin * (float)m1);
+        const half2_t off = {(half_t)-1032.f, (half_t)-1032.f};
+        const uint32_t M = 0x000F000Fu;
+        f[0] = finish_frag((q.x & M) | MAGIC2, ((q.x >> 8) & M) | MAGIC2, (q.y & M) | MAGIC2, ((q.y >> 8) & M) | MAGIC2, off, SL, CL);
+        f[1] = finish_frag((q.z & M) | MAGIC2, ((q.z >> 8) & M) | MAGIC2, (q.w & M) | MAGIC2, ((q.w >> 8) & M) | MAGIC2, off, SL, CL);
+        f[2] = finish_frag(((q.x >> 4) & M) | MAGIC2, ((q.x >> 12) & M) | MAGIC2, ((q.y >> 4) & M) | MAGIC2, ((q.y >> 12) & M) | MAGIC2, off, SH, CH);
+        f[3] = finish_frag(((q.z >> 4) & M) | MAGIC2, ((q.z >> 12) & M) | MAGIC2, ((q.w >> 4) & M) | MAGIC2, ((q.w >> 12) & M) | MAGIC2, off, SH, CH);
+    }
+};
+
+template <> struct Raw<CDNA4_Q5_K> {
+    u32x4 hdr, qh, q;
+    template <typename P> __device__ __forceinline__ void load(P blk, int g, int h) {
+        hdr = ld_u32x4(blk); qh = ld_u32x4(blk + 16 + 16 * h); q = ld_u32x4(blk + 48 + 32 * g + 16 * h);
+    }
+    // value 1024 + nibble + 16*bit for bytes (0,2) [sh=0] or (1,3) [sh=8] of x; bit taken from hq
+    static __device__ __forceinline__ uint32_t pair(uint32_t x, uint32_t hq, int nib_shift, int bit, int sh) {
+        return ((x >> (nib_shift + sh)) & 0x000F000Fu) | ((((hq >> (bit + sh)) & 0x00010001u) << 4)) | MAGIC2;
+    }
+    __device__ __forceinline__ void frags(int g, int h, half8_t (&f)[4]) const {
+        const uint32_t sc[3] = {hdr.y, hdr.z, hdr.w};
+        uint32_t s0, m0, s1, m1;
+        k4_scale_min(sc, 2 * g, s0, m0); k4_scale_min(sc, 2 * g + 1, s1, m1);
+        const float d = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
+        const half_t sl = (half_t)(d * (float)s0), sh = (half_t)(d * (float)s1);
+        const half2_t SL = {sl, sl}, SH = {sh, sh};
+        const half2_t CL = splat(16.f * (float)sl - dmin * (float)m0), CH = splat(16.f * (float)sh - dmin * (float)m1);
+        const half2_t off = {(half_t)-1040.f, (half_t)-1040.f};
+        const int bl = 2 * g, bh = 2 * g + 1;
+        f[0] = finish_frag(pair(q.x, qh.x, 0, bl, 0), pair(q.x, qh.x, 0, bl, 8), pair(q.y, qh.y, 0, bl, 0), pair(q.y, qh.y, 0, bl, 8), off, SL, CL);
+        f[1] = finish_frag(pair(q.z, qh.z, 0, bl, 0), pair(q.z, qh.z, 0, bl, 8), pair(q.w, qh.w, 0, bl, 0), pair(q.w, qh.w, 0, bl, 8), off, SL, CL);
+        f[2] = finish_frag(pair(q.x, qh.x, 4, bh, 0), pair(q.x, qh.x, 4, bh, 8), pair(q.y, qh.y, 4, bh, 0), pair(q.y, qh.y, 4, bh, 8), off, SH, CH);
+        f[3] = finish_frag(pair(q.z, qh.z, 4, bh, 0), pair(q.z, qh.z, 4, bh, 8), pair(q.w, qh.w, 4, bh, 0), pair(q.w, qh.w, 4, bh, 8), off, SH, CH);
+    }
+};
+
+// Q6_K slice s4 of a superblock: half n = s4>>1, p = s4&1 selects quads (2p, 2p+1) = (q1,q2) or (q3,q4)
+template <> struct Raw<CDNA4_Q6_K> {
+    uint32_t la[4], lv[4], hq[4]; float ds[2];
+    template <typename P> __device__ __forceinline__ void load(P blk, int s4, int h) {
+        const int n = s4 >> 1, p = s4 & 1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            la[i] = reinterpret_cast<const u32_a2 *>(blk + 64 * n + 16 * h + 4 * i)->v;
+            lv[i] = reinterpret_cast<const u32_a2 *>(blk + 64 * n + 32 + 16 * h + 4 * i)->v;
+            hq[i] = reinterpret_cast<const u32_a2 *>(blk + 128 + 32 * n + 16 * h + 4 * i)->v;
+        }
+        const float d = h2f(*reinterpret_cast<const uint16_t *>(blk + 208));
+        ds[0] = d * (float)*reinterpret_cast<const int8_t *>(blk + 192 + 8 * n + h + 2 * (2 * p));
+        ds[1] = d * (float)*reinterpret_cast<const int8_t *>(blk + 192 + 8 * n + h + 2 * (2 * p + 1));
+    }
+    static __device__ __forceinline__ uint32_t pair(uint32_t x, uint32_t h, int nib_shift, int bits_shift, int sh) {
+        return ((x >> (nib_shift + sh)) & 0x000F000Fu) | ((((h >> (bits_shift + sh)) & 0x00030003u) << 4)) | MAGIC2;
+    }
+    __device__ __forceinline__ void frags(int s4, int h, half8_t (&f)[4]) const {
+        const int p = s4 & 1, ns = 4 * p;                       // nibble shift: q1,q2 low / q3,q4 high
+        const half2_t off = {(half_t)-1056.f, (half_t)-1056.f}, zero = {(half_t)0.f, (half_t)0.f};
+        const half2_t S0 = splat(ds[0]), S1 = splat(ds[1]);
+        const int b0 = 2 * (2 * p), b1 = 2 * (2 * p + 1);      // qh bit offset of the two quads
+        f[0] = finish_frag(pair(la[0], hq[0], ns, b0, 0), pair(la[0], hq[0], ns, b0, 8), pair(la[1], hq[1], ns, b0, 0), pair(la[1], hq[1], ns, b0, 8), off, S0, zero);
+        f[1] = finish_frag(pair(la[2], hq[2], ns, b0, 0), pair(la[2], hq[2], ns, b0, 8), pair(la[3], hq[3], ns, b0, 0), pair(la[3], hq[3], ns, b0, 8), off, S0, zero);
+        f[2] = finish_frag(pair(lv[0], hq[0], ns, b1, 0), pair(lv[0], hq[0], ns, b1, 8), pair(lv[1], hq[1], ns, b1, 0), pair(lv[1], hq[1], ns, b1, 8), off, S1, zero);
+        f[3] = finish_frag(pair(lv[2], hq[2], ns, b1, 0), pair(lv[2], hq[2], ns, b1, 8), pair(lv[3], hq[3], ns, b1, 0), pair(lv[3], hq[3], ns, b1, 8), off, S1, zero);
+    }
+};
+
+// Q4_0 / Q8_0: the 64-k slice is two 32-blocks, lane-half h owns block h.  `blk` already points at it.
+template <> struct Raw<CDNA4_Q4_0> {
+    uint32_t q[4]; float d;
+    template <typename P> __device__ __forceinline__ void load(P blk, int, int) {
+        d = h2f(*reinterpret_cast<const uint16_t *>(blk));
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] = reinterpret_cast<const u32_a2 *>(blk + 2 + 4 * i)->v;
+    }
+    __device__ __forceinline__ void frags(int, int, half8_t (&f)[4]) const {
+        const half2_t off = {(half_t)-1032.f, (half_t)-1032.f}, zero = {(half_t)0.f, (half_t)0.f}, S = splat(d);
+        const uint32_t M = 0x000F000Fu;
+        f[0] = finish_frag((q[0] & M) | MAGIC2, ((q[0] >> 8) & M) | MAGIC2, (q[1] & M) | MAGIC2, ((q[1] >> 8) & M) | MAGIC2, off, S, zero);
+        f[1] = finish_frag((q[2] & M) | MAGIC2, ((q[2] >> 8) & M) | MAGIC2, (q[3] & M) | MAGIC2, ((q[3] >> 8) & M) | MAGIC2, off, S, zero);
+        f[2] = finish_frag(((q[0] >> 4) & M) | MAGIC2, ((q[0] >> 12) & M) | MAGIC2, ((q[1] >> 4) & M) | MAGIC2, ((q[1] >> 12) & M) | MAGIC2, off, S, zero);
+        f[3] = finish_frag(((q[2] >> 4) & M) | MAGIC2, ((q[2] >> 12) & M) | MAGIC2, ((q[3] >> 4) & M) | MAGIC2, ((q[3] >> 12) & M) | MAGIC2, off, S, zero);
+    }
+};
+template <> struct Raw<CDNA4_Q8_0> {
+    uint32_t q[8]; float d;
+    template <typename P> __device__ __forceinline__ void load(P blk, int, int) {
+        d = h2f(*reinterpret_cast<const uint16_t *>(blk));
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[i] = reinterpret_cast<const u32_a2 *>(blk + 2 + 4 * i)->v ^ 0x80808080u;   // int8 -> biased u8
+    }
+    __device__ __forceinline__ void frags(int, int, half8_t (&f)[4]) const {
+        const half2_t off = {(half_t)-1152.f, (half_t)-1152.f}, zero = {(half_t)0.f, (half_t)0.f}, S = splat(d);
+        const uint32_t M = 0x00FF00FFu;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            f[kk] = finish_frag((q[2 * kk] & M) | MAGIC2, ((q[2 * kk] >> 8) & M) | MAGIC2, (q[2 * kk + 1] & M) | MAGIC2, ((q[2 * kk + 1] >> 8) & M) | MAGIC2, off, S, zero);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+struct gemm_params {
+    const uint8_t *W; int64_t w_row_bytes;
+    const half_t *xh; int64_t xh_row;
+    float *Y; int64_t y_row;
+    int M, K, B, splitk, tiles_m, tiles_b;
+};
+
+template <int TYPE, int BNF, bool WLDS>
+__global__ __launch_bounds__(256) void k_gemm_q(const gemm_params p) {
+    constexpr int TB = 32 * BNF;                 // activation rows per tile
+    constexpr int XS = TB * 128;                 // bytes of one X stage: TB rows x 64 halves
+    constexpr int BLK = QT<TYPE>::BYTES;
+    constexpr int WS = WLDS ? 128 * BLK : 0;     // bytes of one staged weight superblock panel (128 rows)
+    constexpr int NP = BLK / 16;                 // 16-byte pieces per superblock (LDS path only)
+    static_assert(!WLDS || (BLK % 16 == 0 && QT<TYPE>::KQ), "LDS weight staging needs 16-byte aligned superblocks");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * XS + 2 * WS + 16];
+    uint8_t *const Xs = smem, *const Ws = smem + 2 * XS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    // XCD-aware order: consecutive logical ids share the weight row-panel; blocks are dealt round-robin to the
+    // 8 XCDs, so give each XCD a contiguous run of logical ids.
+    const int nblk = gridDim.x;
+    int L = blockIdx.x;
+    if ((nblk & 7) == 0) L = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int tile_b = L % p.tiles_b; L /= p.tiles_b;
+    const int ks = L % p.splitk, tile_m = L / p.splitk;
+    const int m0 = tile_m * 128, b0 = tile_b * TB;
+    const int ksteps = p.K / 64 / p.splitk;      // 64-k slices handled by this block
+    const int kstep0 = ks * ksteps;
+
+    const int mrow = min(m0 + wave * 32 + j, p.M - 1);
+    const uint8_t *const wrow = p.W + (int64_t)mrow * p.w_row_bytes;
+
+    floatx16 acc[BNF];
+#pragma unroll
+    for (int i = 0; i < BNF; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+    // ---- staging helpers -------------------------------------------------------------------------------
+    auto stage_x = [&](int step, int buf) {
+        const int k0 = (kstep0 + step) * 64;
+#pragma unroll
+        for (int i = 0; i < BNF; i++) {
+            const int pc = i * 256 + tid, row = pc >> 3, c = (pc & 7) ^ ((row >> 1) & 7);
+            const int b = min(b0 + row, p.B - 1);
+            glds16(p.xh + (int64_t)b * p.xh_row + k0 + c * 8, Xs + buf * XS + (i * 256 + wave * 64) * 16);
+        }
+    };
+    auto stage_w = [&](int sb, int buf) {           // LDS path: the 128-row panel of superblock sb
+        if (WLDS) {
+#pragma unroll
+            for (int i = 0; i < (2 * NP + 3) / 4; i++) {
+                const int idx = wave + 4 * i;
+                if (idx < 2 * NP) {
+                    const int pc = idx * 64 + lane, row = pc / NP, c = pc % NP;
+                    const int m = min(m0 + row, p.M - 1);
+                    glds16(p.W + (int64_t)m * p.w_row_bytes + (int64_t)sb * BLK + c * 16, Ws + buf * WS + idx * 1024);
+                }
+            }
+        }
+    };
+
+    const int xrow_off = j * 128, xswz = (j >> 1) & 7;
+    auto compute = [&](const Raw<TYPE> &raw, int gsel, int buf) {
+        half8_t wf[4];
+        raw.frags(gsel, h, wf);
+        const uint8_t *xs = Xs + buf * XS + xrow_off;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int coff = (chunk_of<TYPE>(kk, h) ^ xswz) << 4;
+#pragma unroll
+            for (int bf = 0; bf < BNF; bf++) {
+                const half8_t xa = *reinterpret_cast<const half8_t *>(xs + bf * 32 * 128 + coff);
+                acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, wf[kk], acc[bf], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop -------------------------------------------------------------------------------------
+    if (QT<TYPE>::KQ) {
+        const int sb0 = kstep0 >> 2, nsb = ksteps >> 2;
+        stage_x(0, 0);
+        stage_w(sb0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int s = 0; s < nsb; s++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int step = 4 * s + g;
+                if (step + 1 < ksteps) stage_x(step + 1, (step + 1) & 1);
+                if (g == 0 && s + 1 < nsb) stage_w(sb0 + s + 1, (s + 1) & 1);
+                Raw<TYPE> raw;
+                if (WLDS) raw.load(Ws + (s & 1) * WS + (wave * 32 + j) * BLK, g, h);
+                else raw.load(wrow + (int64_t)(sb0 + s) * BLK, g, h);
+                compute(raw, g, step & 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    } else {
+        stage_x(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int step = 0; step < ksteps; step++) {
+            if (step + 1 < ksteps) stage_x(step + 1, (step + 1) & 1);
+            Raw<TYPE> raw;
+            raw.load(wrow + (int64_t)(2 * (kstep0 + step) + h) * BLK, 0, h);
+            compute(raw, 0, step & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D[i][jcol]: lane holds column jcol = j (weight row m), rows i = (r&3) + 8*(r>>2) + 4*h ----
+    const int m = m0 + wave * 32 + j;
+    if (m < p.M) {
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int b = b0 + bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (b < p.B) {
+                    float *dst = p.Y + (int64_t)b * p.y_row + m;
+                    if (p.splitk > 1) unsafeAtomicAdd(dst, acc[bf][r]); else *dst = acc[bf][r];
+                }
+            }
+    }
+}
+
+__global__ void k_zero_rows(float *Y, int64_t y_row, int M, int B) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (int64_t)M * B) Y[(i / M) * y_row + (i % M)] = 0.f;
+}
+
+bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B) {
+    if (M <= 0 || B <= 0) return false;
+    switch (type) {
+        case CDNA4_Q4_K: case CDNA4_Q5_K: case CDNA4_Q6_K: return K > 0 && K % 256 == 0;
+        case CDNA4_Q4_0: case CDNA4_Q8_0: return K > 0 && K % 64 == 0;
+    }
+    return false;
+}
+
+template <int TYPE, int BNF, bool WLDS>
+static int launch_variant(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
+    gemm_params p;
+    p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
+    p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
+    p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 32 * BNF - 1) / (32 * BNF);
+    if (splitk > 1) {
+        const int64_t n = (int64_t)a.M * a.B;
+        hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.Y, a.y_row_elems, a.M, a.B);
+    }
+    hipLaunchKernelGGL((k_gemm_q<TYPE, BNF, WLDS>), dim3(p.tiles_m * p.tiles_b * splitk), dim3(256), 0, st, p);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int TYPE>
+static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
+    constexpr bool CAN_LDS = QT<TYPE>::KQ && (QT<TYPE>::BYTES % 16 == 0);
+    // variant: bit0 = LDS weight staging (Q4_K/Q5_K only), bit1 = 128-wide activation tile.  0 = auto.
+    int variant = a.variant;
+    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0);
+    const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
+    const bool wide = (variant & 2) != 0;
+    // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
+    const int kunits = QT<TYPE>::KQ ? a.K / 256 : a.K / 64;
+    int splitk = a.splitk;
+    if (splitk <= 0) {
+        const int tiles = ((a.M + 127) / 128) * ((a.B + (wide ? 127 : 63)) / (wide ? 128 : 64));
+        splitk = 1;
+        while (tiles * splitk * 2 <= 256 && splitk * 2 <= kunits && kunits % (splitk * 2) == 0 && kunits / (splitk * 2) >= 2) splitk *= 2;
+    }
+    if (splitk < 1 || kunits % splitk) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
+    if constexpr (CAN_LDS) {
+        if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
+    }
+    return wide ? launch_variant<TYPE, 4, false>(a, splitk, st) : launch_variant<TYPE, 2, false>(a, splitk, st);
+}
+
+int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
+    if (a.M <= 0 || a.B <= 0) return 0;
+    if (!cdna4_gemm_q_supported(a.type, a.M, a.K, a.B)) return cdna4_set_error_msg("gemm_q: unsupported type / shape");
+    if ((uintptr_t)a.xh & 15 || (a.xh_row_elems & 7)) return cdna4_set_error_msg("gemm_q: activation image must be 16-byte aligned");
+    if (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 1) return cdna4_set_error_msg("gemm_q: weight rows must be 2-byte aligned");
+    if ((a.type == CDNA4_Q4_K || a.type == CDNA4_Q5_K) && (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15))
+        return cdna4_set_error_msg("gemm_q: Q4_K/Q5_K rows must be 16-byte aligned");
+    switch (a.type) {
+        case CDNA4_Q4_K: return launch_type<CDNA4_Q4_K>(a, st);
+        case CDNA4_Q5_K: return launch_type<CDNA4_Q5_K>(a, st);
+        case CDNA4_Q6_K: return launch_type<CDNA4_Q6_K>(a, st);
+        case CDNA4_Q4_0: return launch_type<CDNA4_Q4_0>(a, st);
+        case CDNA4_Q8_0: return launch_type<CDNA4_Q8_0>(a, st);
+    }
+    return cdna4_set_error_msg("gemm_q: unsupported weight type");
+}

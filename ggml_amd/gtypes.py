@@ -1,0 +1,37 @@
+"""ggml type ids and block geometry (include/ggml.h:351-390, src/ggml-common.h:161-328)."""
+import enum
+
+
+class GGMLType(enum.IntEnum):
+    F32 = 0
+    F16 = 1
+    Q4_0 = 2
+    Q8_0 = 8
+    Q4_K = 12
+    Q5_K = 13
+    Q6_K = 14
+    Q8_K = 15
+    I32 = 26
+
+
+_TYPE_SIZE = {GGMLType.F32: 4, GGMLType.F16: 2, GGMLType.Q4_0: 18, GGMLType.Q8_0: 34, GGMLType.Q4_K: 144,
+              GGMLType.Q5_K: 176, GGMLType.Q6_K: 210, GGMLType.Q8_K: 292, GGMLType.I32: 4}
+_BLCK = {GGMLType.F32: 1, GGMLType.F16: 1, GGMLType.Q4_0: 32, GGMLType.Q8_0: 32, GGMLType.Q4_K: 256,
+         GGMLType.Q5_K: 256, GGMLType.Q6_K: 256, GGMLType.Q8_K: 256, GGMLType.I32: 1}
+QUANT_WEIGHT_TYPES = (GGMLType.Q4_0, GGMLType.Q8_0, GGMLType.Q4_K, GGMLType.Q5_K, GGMLType.Q6_K)
+
+
+def blck_size(t):
+    return _BLCK[GGMLType(t)]
+
+
+def type_size(t):
+    return _TYPE_SIZE[GGMLType(t)]
+
+
+def row_size(t, k):
+    """ggml_row_size (src/ggml.c:1176-1179)"""
+    t = GGMLType(t)
+    if k % _BLCK[t]:
+        raise ValueError("k=%d is not a multiple of the %s block size %d" % (k, t.name, _BLCK[t]))
+    return k // _BLCK[t] * _TYPE_SIZE[t]

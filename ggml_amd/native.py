@@ -1,0 +1,54 @@
+"""ctypes binding of libcdna4_kernels.so (include/ggml_cdna4.h).  Loading is lazy and LOUD: there is no
+fallback path — if the library is missing or there is no GPU, calls raise."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libcdna4_kernels.so")
+BACKEND_PATH = os.path.join(_PKG, "lib", "libggml-cdna4.so")
+
+# every symbol include/ggml_cdna4.h declares: (name, restype, argtypes)
+_i64, _vp, _sz, _int = C.c_int64, C.c_void_p, C.c_size_t, C.c_int
+SYMBOLS = [
+    ("ggml_cdna4_api_version", _int, []),
+    ("ggml_cdna4_last_error", C.c_char_p, []),
+    ("ggml_cdna4_device_count", _int, []),
+    ("ggml_cdna4_set_device", _int, [_int]),
+    ("ggml_cdna4_row_size", _sz, [_int, _i64]),
+    ("ggml_cdna4_mul_mat_workspace_size", _sz, [_int, _i64, _i64]),
+    ("ggml_cdna4_mul_mat", _int, [_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _int, _int, _int, _vp]),
+    ("ggml_cdna4_prepare_act", _int, [_int, _vp, _i64, _i64, _i64, _vp, _sz, _int, _vp]),
+    ("ggml_cdna4_mul_mat_prepared", _int, [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _int, _int, _int, _vp]),
+    ("ggml_cdna4_mul_mat_id", _int, [_int, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64,
+                                     _i64, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
+    ("ggml_cdna4_quantize_q8_K", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    ("ggml_cdna4_quantize_q8_0", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp]),
+]
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """the loaded kernel library; raises NativeError if it was not built"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError("%s not found — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(l, name)          # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if l.ggml_cdna4_api_version() != 1:
+            raise NativeError("libcdna4_kernels.so API version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError("cdna4 kernel library: %s (status %d)" % (lib().ggml_cdna4_last_error().decode(), rc))

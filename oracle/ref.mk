@@ -6,7 +6,8 @@
 #
 # Outputs (git-ignored, but they travel to the GPU box with gpurun):
 #   oracle/_ref/libggml-base.so  libggml-cpu.so  libggml.so
-#   oracle/_ref/test-backend-ops  test-quantize-fns  test-mul-mat
+#   oracle/_ref/test-backend-ops  test-quantize-fns  test-mul-mat   (reference tests, unmodified)
+#   oracle/_ref/cpu_baseline      (oracle/cpu_baseline.cpp: times the reference CPU backend on one MUL_MAT)
 #
 # ISA flags: x86-64-v3 (AVX2+FMA+F16C) instead of the reference's default -march=native so the same
 # binaries run on this container's Xeon and on the GPU box's host CPU.  That selects the AVX2 bodies
@@ -33,7 +34,7 @@ BASE_OBJ := $(patsubst %,$(OUT)/obj/base/%.o,$(BASE_C) $(BASE_CXX))
 CPU_OBJ  := $(patsubst %,$(OUT)/obj/cpu/%.o,$(CPU_C) $(CPU_CXX))
 
 LIBS  := $(OUT)/libggml-base.so $(OUT)/libggml-cpu.so $(OUT)/libggml.so
-BINS  := $(OUT)/test-backend-ops $(OUT)/test-quantize-fns $(OUT)/test-mul-mat
+BINS  := $(OUT)/test-backend-ops $(OUT)/test-quantize-fns $(OUT)/test-mul-mat $(OUT)/cpu_baseline
 
 all: $(LIBS) $(BINS)
 
@@ -58,6 +59,9 @@ $(OUT)/libggml.so: $(REF)/src/ggml-backend-reg.cpp $(OUT)/libggml-cpu.so
 	$(CXX) $(CXXFLAGS_COMMON) -DGGML_BUILD -DGGML_USE_CPU -shared -o $@ $< -L$(OUT) -lggml-cpu -lggml-base -ldl -Wl,-rpath,'$$ORIGIN'
 
 $(OUT)/test-%: $(REF)/tests/test-%.cpp $(LIBS)
+	$(CXX) $(CXXFLAGS_COMMON) -o $@ $< -L$(OUT) -lggml -lggml-cpu -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN'
+
+$(OUT)/cpu_baseline: oracle/cpu_baseline.cpp $(LIBS)
 	$(CXX) $(CXXFLAGS_COMMON) -o $@ $< -L$(OUT) -lggml -lggml-cpu -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN'
 
 clean:

@@ -1,0 +1,99 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/ggml_cdna4.h declares, the plug-in exports ggml's DL entry points, host-side geometry helpers agree
+with the oracle, and the product fails loudly (no CPU fallback) when asked to compute without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+import refutil as R
+
+ROOT = R.ROOT
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    import ggml_amd.native as n
+    return n
+
+
+def test_header_symbols_all_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "ggml_cdna4.h")).read()
+    declared = set(re.findall(r"\b(ggml_cdna4_[a-z0-9_A-Z]+)\s*\(", hdr))
+    declared.discard("ggml_cdna4_type"); declared.discard("ggml_cdna4_path")
+    bound = {s[0] for s in built.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    out = subprocess.run(["nm", "-D", "--defined-only", built.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (ggml_cdna4_\w+)", out))
+    assert declared <= exported, declared - exported
+    built.lib()        # and it dlopens + binds
+
+
+def test_plugin_exports_ggml_entry_points(built):
+    if not os.path.exists(built.BACKEND_PATH):
+        pytest.skip("plug-in not built (needs the ggml headers)")
+    out = subprocess.run(["nm", "-D", "--defined-only", built.BACKEND_PATH], capture_output=True, text=True).stdout
+    assert " T ggml_backend_init" in out and " T ggml_backend_score" in out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(R.REF_DIR, "test-backend-ops")), reason="oracle/_ref not built")
+def test_unmodified_reference_harness_loads_plugin(built):
+    """the stock test-backend-ops dlopens our .so through GGML_BACKEND_PATH (src/ggml-backend-reg.cpp:577-581)"""
+    if not os.path.exists(built.BACKEND_PATH):
+        pytest.skip("plug-in not built")
+    env = dict(os.environ, GGML_BACKEND_PATH=built.BACKEND_PATH)
+    r = subprocess.run([os.path.join(R.REF_DIR, "test-backend-ops"), "test", "-o", "MUL_MAT", "-b", "CDNA40"], env=env, capture_output=True, text=True, timeout=120)
+    txt = r.stdout + r.stderr
+    assert "failed to find ggml_backend_init" not in txt and "failed to load" not in txt, txt[-2000:]
+    assert r.returncode == 0, txt[-2000:]
+
+
+def test_row_size_matches_oracle(built):
+    L = built.lib()
+    o = R.oracle()
+    o.oracle_row_size.restype = C.c_size_t
+    for t in (R.Q4_0, R.Q8_0, R.Q4_K, R.Q5_K, R.Q6_K):
+        for k in (256, 4096, 11008 - 11008 % 256):
+            assert L.ggml_cdna4_row_size(t, k) == o.oracle_row_size(C.c_int(t), C.c_int64(k)) == R.row_size(t, k)
+    assert L.ggml_cdna4_row_size(R.Q4_K, 100) == 0
+    from ggml_amd.gtypes import row_size
+    assert row_size(12, 4096) == 2304
+    with pytest.raises(ValueError):
+        row_size(12, 100)
+
+
+def test_workspace_size_is_monotonic_and_aligned(built):
+    L = built.lib()
+    prev = 0
+    for b in (1, 8, 9, 64, 512):
+        n = L.ggml_cdna4_mul_mat_workspace_size(R.Q4_K, 4096, b)
+        assert n % 256 == 0 and n >= prev and n >= b * 4096 * 3
+        prev = n
+    assert L.ggml_cdna4_mul_mat_workspace_size(0, 4096, 8) == 0     # F32 is not a quantized weight type
+
+
+def test_no_cpu_fallback(built):
+    """without a GPU the product must raise, not compute on the host"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ggml_amd import ops
+    from ggml_amd.native import NativeError
+    w = torch.zeros(16 * 144, dtype=torch.uint8)
+    with pytest.raises(NativeError):
+        ops.QTensor(12, 256, 16, w)
+    with pytest.raises(NativeError):
+        ops.quantize_row_q8_K(torch.zeros(1, 256))
+
+
+def test_product_never_imports_oracle():
+    """only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may touch oracle/"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ggml_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "libggml_oracle" not in src and "ggml_oracle.c" not in src, os.path.join(dirpath, f)
+                assert not re.search(r"^\s*(import|from)\s+refutil", src, re.M), os.path.join(dirpath, f)

@@ -1,0 +1,236 @@
+"""-m gpu parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+Bars: bit-exact for the activation quantizers; rel-L2 <= 1e-5 for the int8-dot GEMV path (exact integer block
+sums, only fp32 summation order differs — measured ~2e-7); rel-L2 <= 1e-3 for the fp16-MFMA GEMM path (the
+tolerance BASELINE.json's north_star states; measured ~3e-4).  Norm-wise, never element-wise."""
+import os
+import numpy as np
+import pytest
+import torch
+import refutil as R
+
+pytestmark = pytest.mark.gpu
+
+WT = list(R.QUANT_TYPES.items())
+TOL_GEMV, TOL_GEMM = 1e-5, 1e-3
+
+
+@pytest.fixture(scope="module")
+def gu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    import gpu_util
+    from ggml_amd import native
+    native.lib()
+    return gpu_util
+
+
+def _x(seed, b, k, kind="uniform"):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        x = rng.uniform(-1, 1, (b, k)).astype(np.float32)
+    elif kind == "normal":
+        x = (rng.standard_normal((b, k)) * 3).astype(np.float32)
+    elif kind == "ties":
+        x = (rng.integers(-254, 255, (b, k)) / 2.0).astype(np.float32)
+    else:
+        x = (0.1 + 2 * np.cos(np.arange(b * k, dtype=np.float32) + seed)).reshape(b, k).astype(np.float32)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------ quantizers
+@pytest.mark.parametrize("kind", ["uniform", "normal", "ties", "cos"])
+def test_quantize_q8_K_bit_exact(gu, kind):
+    from ggml_amd import ops
+    x = _x(5, 12, 2048, kind)
+    x[3, 256:512] = 0
+    x[4, 17] = -9.5; x[4, 300] = 9.5          # equal |max| with opposite signs: first index wins
+    x[5, 700] = 7.25; x[5, 701] = -7.25
+    qs, d, bs, xh = [t.cpu().numpy() for t in ops.quantize_row_q8_K(gu.to_dev(x), want_f16=True)]
+    ref = R.o_quantize_act(R.Q4_K, x).reshape(12, -1, 292)
+    rd = ref[:, :, 0:4].copy().view(np.float32).reshape(12, -1)
+    rq = ref[:, :, 4:260].copy().view(np.int8).reshape(12, -1)
+    rb = ref[:, :, 260:292].copy().view(np.int16).reshape(12, -1)
+    assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+    assert np.array_equal(qs, rq)
+    assert np.array_equal(bs, rb)
+    want = (np.repeat(rd, 256, axis=1) * rq.astype(np.float32)).astype(np.float16)
+    assert np.array_equal(gu.uninterleave(xh).view(np.uint16), want.view(np.uint16))
+
+
+@pytest.mark.parametrize("ref_rounding", [False, True])
+@pytest.mark.parametrize("kind", ["uniform", "normal", "ties"])
+def test_quantize_q8_0_bit_exact(gu, kind, ref_rounding):
+    from ggml_amd import ops
+    x = _x(6, 9, 1024, kind)
+    x[2, 32:64] = 0
+    qs, d, xh = [t.cpu().numpy() for t in ops.quantize_row_q8_0(gu.to_dev(x), ref_rounding=ref_rounding, want_f16=True)]
+    name = "q8_0_ref" if ref_rounding else "q8_0_cpu"
+    ref = np.stack([R.o_quantize_row(name, x[i]) for i in range(9)]).reshape(9, -1, 34)
+    rd = ref[:, :, 0:2].copy().view(np.float16).astype(np.float32).reshape(9, -1)
+    rq = ref[:, :, 2:34].copy().view(np.int8).reshape(9, -1)
+    assert np.array_equal(qs, rq)
+    assert np.array_equal(d, rd)
+    want = (np.repeat(rd, 32, axis=1) * rq.astype(np.float32)).astype(np.float16)
+    assert np.array_equal(gu.uninterleave(xh).view(np.uint16), want.view(np.uint16))
+
+
+# ------------------------------------------------------------------------------------------------ golden
+@pytest.mark.parametrize("name,t", WT)
+def test_golden_fixture_gemv_and_gemm(gu, name, t):
+    """committed fixtures produced by the unmodified reference (tests/golden/make_golden.py)"""
+    from ggml_amd import ops
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "mul_mat_small.npz"))
+    M, K = int(G["M"]), int(G["K"])
+    a = gu.qtensor(t, G[name + "_w"], M, K)
+    x = G[name + "_x"]
+    y = ops.mul_mat(a, gu.to_dev(x), path=ops.PATH_GEMV).cpu().numpy()
+    e = R.rel_l2(y, G[name + "_y"]); gu.report(test="golden_gemv", type=name, rel_l2=e)
+    assert e < TOL_GEMV
+    x16 = np.concatenate([x] * 4)
+    y = ops.mul_mat(a, gu.to_dev(x16), path=ops.PATH_GEMM).cpu().numpy()
+    e = R.rel_l2(y, np.concatenate([G[name + "_y"]] * 4)); gu.report(test="golden_gemm", type=name, rel_l2=e)
+    assert e < TOL_GEMM
+
+
+def test_golden_mul_mat_id(gu):
+    from ggml_amd import ops
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "mul_mat_id_small.npz"))
+    for name in ("q4_K", "q8_0"):
+        t = R.QUANT_TYPES[name]
+        M, K, ne = int(G["M"]), int(G["K"]), int(G["n_expert"])
+        a = gu.qtensor(t, G[name + "_w"], ne * M, K)
+        y = ops.mul_mat_id(a, gu.to_dev(G[name + "_x"]), gu.to_dev(G["ids"]), n_expert=ne).cpu().numpy()
+        e = R.rel_l2(y, G[name + "_y"]); gu.report(test="golden_mul_mat_id", type=name, rel_l2=e)
+        assert e < TOL_GEMV
+
+
+# ------------------------------------------------------------------------------------------------ GEMV
+@pytest.mark.parametrize("name,t", WT)
+@pytest.mark.parametrize("m,k,b", [(16, 256, 1), (16, 256, 3), (48, 1024, 8), (33, 2048, 5), (256, 4096, 2), (7, 8192, 1)])
+def test_gemv_parity(gu, name, t, m, k, b):
+    from ggml_amd import ops
+    w = R.random_weights(t, m, k, seed=m + k)
+    x = _x(b + k, b, k)
+    y = ops.mul_mat(gu.qtensor(t, w, m, k), gu.to_dev(x), path=ops.PATH_GEMV).cpu().numpy()
+    yo = R.o_mul_mat(t, w, x, m, k)
+    e = R.rel_l2(y, yo); gu.report(test="gemv", type=name, m=m, k=k, b=b, rel_l2=e)
+    assert np.isfinite(y).all() and e < TOL_GEMV
+
+
+@pytest.mark.parametrize("name,t", WT)
+def test_gemv_many_columns_and_32_block_k(gu, name, t):
+    """B > 8 through the GEMV path (column groups), and K = one block for the 32-block formats"""
+    from ggml_amd import ops
+    k = 32 if t in (R.Q4_0, R.Q8_0) else 256
+    m, b = 20, 19
+    w = R.random_weights(t, m, k, seed=3)
+    x = _x(9, b, k)
+    y = ops.mul_mat(gu.qtensor(t, w, m, k), gu.to_dev(x), path=ops.PATH_GEMV).cpu().numpy()
+    assert R.rel_l2(y, R.o_mul_mat(t, w, x, m, k)) < TOL_GEMV
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(16, 256, 9), (128, 512, 64), (200, 1024, 100), (130, 768, 33), (512, 2048, 128), (64, 4096, 16)]
+
+
+@pytest.mark.parametrize("name,t", WT)
+@pytest.mark.parametrize("m,k,b", GEMM_SHAPES)
+def test_gemm_parity_auto(gu, name, t, m, k, b):
+    from ggml_amd import ops
+    w = R.random_weights(t, m, k, seed=m * 3 + k)
+    x = _x(b * 7 + k, b, k)
+    # asymmetric data: a transposed C-write or a wrong k permutation cannot pass
+    y = ops.mul_mat(gu.qtensor(t, w, m, k), gu.to_dev(x), path=ops.PATH_GEMM).cpu().numpy()
+    yo = R.o_mul_mat(t, w, x, m, k)
+    e = R.rel_l2(y, yo); ee = R.rel_l2(y, R.o_mul_mat(t, w, x, m, k, exact=True))
+    gu.report(test="gemm_auto", type=name, m=m, k=k, b=b, rel_l2=e, rel_l2_exact=ee)
+    assert np.isfinite(y).all() and e < TOL_GEMM
+
+
+@pytest.mark.parametrize("name,t", WT)
+@pytest.mark.parametrize("variant", [4, 5, 6, 7])
+@pytest.mark.parametrize("splitk", [1, 2])
+def test_gemm_variants(gu, name, t, variant, splitk):
+    """every tile variant (bit0 LDS-staged weights, bit1 128-wide activation tile) x split-K"""
+    from ggml_amd import ops
+    m, k, b = 260, 1024, 150
+    w = R.random_weights(t, m, k, seed=11)
+    x = _x(12, b, k)
+    y = ops.mul_mat(gu.qtensor(t, w, m, k), gu.to_dev(x), path=ops.PATH_GEMM, gemm_variant=variant, splitk=splitk).cpu().numpy()
+    e = R.rel_l2(y, R.o_mul_mat(t, w, x, m, k))
+    gu.report(test="gemm_variant", type=name, variant=variant, splitk=splitk, rel_l2=e)
+    assert np.isfinite(y).all() and e < TOL_GEMM
+
+
+def test_gemm_matches_gemv_statistically(gu):
+    """same inputs through both kernel families: they implement the same reference semantics"""
+    from ggml_amd import ops
+    t, m, k, b = R.Q4_K, 512, 4096, 8
+    w = R.random_weights(t, m, k, seed=21)
+    x = _x(22, b, k)
+    a = gu.qtensor(t, w, m, k)
+    xd = gu.to_dev(np.concatenate([x, x]))
+    yv = ops.mul_mat(a, xd[:8], path=ops.PATH_GEMV).cpu().numpy()
+    ym = ops.mul_mat(a, xd, path=ops.PATH_GEMM).cpu().numpy()
+    assert R.rel_l2(ym[:8], yv) < TOL_GEMM and np.array_equal(ym[:8], ym[8:])
+
+
+# ------------------------------------------------------------------------------------------------ full size
+@pytest.mark.parametrize("name,t", WT)
+def test_full_size_decode_config(gu, name, t):
+    """BASELINE configs[1]: [4096x4096]·[4096x1] — whole output against the oracle"""
+    from ggml_amd import ops
+    m = k = 4096
+    w = R.random_weights(t, m, k, seed=1234)
+    x = _x(4321, 1, k)
+    y = ops.mul_mat(gu.qtensor(t, w, m, k), gu.to_dev(x)).cpu().numpy()
+    e = R.rel_l2(y, R.o_mul_mat(t, w, x, m, k)); gu.report(test="full_decode", type=name, rel_l2=e)
+    assert e < TOL_GEMV
+
+
+@pytest.mark.parametrize("m,k,b", [(4096, 4096, 512), (4096, 11008 - 11008 % 256, 512)])
+def test_full_size_prefill_config(gu, m, k, b):
+    """BASELINE headline / configs[2] shapes (K=11008 rounded down to whole Q4_K superblocks = 10752):
+    a 96-row sample of weight rows against the oracle + size-independent properties on the full output."""
+    from ggml_amd import ops
+    t = R.Q4_K
+    w = R.random_weights(t, m, k, seed=1234)
+    x = _x(4321, b, k)
+    a = gu.qtensor(t, w, m, k)
+    xd = gu.to_dev(x)
+    y = ops.mul_mat(a, xd).cpu().numpy()
+    assert np.isfinite(y).all()
+    rows = np.random.default_rng(0).choice(m, 96, replace=False)
+    rs = R.row_size(t, k)
+    wsub = np.concatenate([w[r * rs:(r + 1) * rs] for r in rows])
+    e = R.rel_l2(y[:, rows], R.o_mul_mat(t, wsub, x, 96, k)); gu.report(test="full_prefill", m=m, k=k, b=b, rel_l2=e)
+    assert e < TOL_GEMM
+    # property 1: permuting weight rows permutes output columns bit-exactly (row independence)
+    perm = np.random.default_rng(1).permutation(m)
+    wp = w.reshape(m, rs)[perm].reshape(-1)
+    yp = ops.mul_mat(gu.qtensor(t, wp, m, k), xd).cpu().numpy()
+    assert np.array_equal(yp, y[:, perm])
+    # property 2: the result for an activation row does not depend on its batch neighbours
+    y2 = ops.mul_mat(a, xd[64:192].contiguous()).cpu().numpy()
+    assert np.array_equal(y2, y[64:192])
+    # property 3: row-sharded evaluation (the multi-GPU partition) concatenates to the full result
+    ysh = np.concatenate([ops.mul_mat(a.rows(lo, lo + m // 4), xd).cpu().numpy() for lo in range(0, m, m // 4)], axis=1)
+    assert np.array_equal(ysh, y)
+
+
+# ------------------------------------------------------------------------------------------------ MUL_MAT_ID
+@pytest.mark.parametrize("name,t", WT)
+@pytest.mark.parametrize("n_expert,n_used,n_b_is_one,n_tok", [(4, 1, False, 1), (4, 2, False, 32), (8, 4, True, 32), (8, 2, False, 3)])
+def test_mul_mat_id_parity(gu, name, t, n_expert, n_used, n_b_is_one, n_tok):
+    """shapes of tests/test-backend-ops.cpp:4089-4119 (m=512, k=256)"""
+    from ggml_amd import ops
+    m, k = 512, 256
+    rng = np.random.default_rng(n_expert * 10 + n_used)
+    w = R.random_weights(t, n_expert * m, k, seed=5)
+    n_b = 1 if n_b_is_one else n_used
+    xb = rng.uniform(-1, 1, (n_tok, n_b, k)).astype(np.float32)
+    ids = np.stack([rng.permutation(n_expert)[:n_used] for _ in range(n_tok)]).astype(np.int32)
+    y = ops.mul_mat_id(gu.qtensor(t, w, n_expert * m, k), gu.to_dev(xb), gu.to_dev(ids), n_expert=n_expert).cpu().numpy()
+    yo = R.o_mul_mat_id(t, w, xb, ids, m, k, n_expert)
+    e = R.rel_l2(y, yo); gu.report(test="mul_mat_id", type=name, rel_l2=e)
+    assert e < TOL_GEMV
