@@ -53,10 +53,16 @@ def cpu_baseline(seconds=12.0):
     exe = os.path.join(ROOT, "oracle", "_ref", "cpu_baseline")
     if os.path.exists(exe):
         try:
-            out = subprocess.run([exe, "q4_K", str(M_PER_GPU), str(K), str(B), str(seconds), str(cores)], capture_output=True, text=True, timeout=seconds * 4 + 60)
-            j = json.loads(out.stdout.strip().splitlines()[-1])
-            return {"value": round(j["gflops"] / 1e3, 4), "unit": "TFLOP/s", "cores": cores, "kind": "reference",
-                    "sample": "full workload Q4_K [4096x4096]·[4096x512], %d runs of ggml-cpu MUL_MAT (AVX2 build), %.1f ms/run" % (j["runs"], j["us_per_run"] / 1e3)}
+            best = None
+            cands = sorted({c for c in (cores, cores // 2, cores // 4, 32, 16) if 1 <= c <= cores}, reverse=True)
+            for nt in cands:          # the reference's threadpool is not guaranteed to scale to every SMT thread: report its best
+                out = subprocess.run([exe, "q4_K", str(M_PER_GPU), str(K), str(B), str(seconds / len(cands)), str(nt)], capture_output=True, text=True, timeout=seconds * 4 + 60)
+                j = json.loads(out.stdout.strip().splitlines()[-1])
+                if best is None or j["gflops"] > best["gflops"]:
+                    best = j
+            return {"value": round(best["gflops"] / 1e3, 4), "unit": "TFLOP/s", "cores": best["threads"], "host_cores": cores, "kind": "reference",
+                    "sample": "full workload Q4_K [4096x4096]·[4096x512], ggml-cpu MUL_MAT (unmodified reference, AVX2 build), best of threads=%s: %d runs, %.1f ms/run"
+                              % (cands, best["runs"], best["us_per_run"] / 1e3)}
         except Exception as e:  # noqa: BLE001
             print("cpu_baseline(reference) failed: %r" % (e,), file=sys.stderr)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,7 +1,105 @@
-// ggml_cdna4_ops.cpp — supporting-op dispatch of the plug-in (see ggml_cdna4_ops.h).
+// ggml_cdna4_ops.cpp — supporting-op dispatch of the plug-in: ggml_tensor -> plain-pointer descriptors
+// (ggml_cdna4_tensor) -> kernels of libcdna4_kernels.so.  supports_* mirrors exactly what the kernels accept;
+// everything else is declined so the scheduler leaves it on the CPU backend.
 #include "ggml_cdna4_ops.h"
 #include "ggml_cdna4.h"
+#include <cstdio>
+#include <cstring>
 
-bool cdna4_ops_supports_tensor(const ggml_tensor * op) { (void)op; return false; }
-bool cdna4_ops_supports_matmul(const ggml_tensor * op) { (void)op; return false; }
-enum ggml_status cdna4_ops_compute(void * backend_ctx, ggml_tensor * node) { (void)backend_ctx; (void)node; return GGML_STATUS_FAILED; }
+static ggml_cdna4_tensor desc(const ggml_tensor * t) {
+    ggml_cdna4_tensor d;
+    d.data = t->data; d.type = (int32_t)t->type; d.reserved = 0;
+    for (int i = 0; i < 4; i++) { d.ne[i] = t->ne[i]; d.nb[i] = (int64_t)t->nb[i]; }
+    return d;
+}
+static bool f32(const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32; }
+static bool qsrc(ggml_type t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K; }
+static bool ff16(ggml_type t) { return t == GGML_TYPE_F32 || t == GGML_TYPE_F16; }
+
+static int unary_id(const ggml_tensor * op) {
+    switch (ggml_get_unary_op(op)) {
+        case GGML_UNARY_OP_GELU: return GGML_CDNA4_GELU;
+        case GGML_UNARY_OP_GELU_QUICK: return GGML_CDNA4_GELU_QUICK;
+        case GGML_UNARY_OP_SILU: return GGML_CDNA4_SILU;
+        case GGML_UNARY_OP_RELU: return GGML_CDNA4_RELU;
+        case GGML_UNARY_OP_TANH: return GGML_CDNA4_TANH;
+        default: return -1;
+    }
+}
+
+bool cdna4_ops_supports_matmul(const ggml_tensor * op) {
+    const ggml_tensor * a = op->src[0], * b = op->src[1];
+    return ff16(a->type) && f32(b) && f32(op) && a->nb[0] == ggml_type_size(a->type) && b->nb[0] == sizeof(float) && ggml_is_contiguous(op);
+}
+
+bool cdna4_ops_supports_tensor(const ggml_tensor * op) {
+    const ggml_tensor * a = op->src[0], * b = op->src[1];
+    switch (op->op) {
+        case GGML_OP_ADD: case GGML_OP_SUB: case GGML_OP_MUL: case GGML_OP_DIV:
+            return f32(a) && f32(b) && f32(op) && ggml_can_repeat(b, a);
+        case GGML_OP_SCALE:
+            return f32(a) && f32(op) && ggml_is_contiguous(a) && ggml_is_contiguous(op);
+        case GGML_OP_UNARY:
+            return f32(a) && f32(op) && ggml_is_contiguous(a) && ggml_is_contiguous(op) && unary_id(op) >= 0;
+        case GGML_OP_NORM: case GGML_OP_RMS_NORM:
+            return f32(a) && f32(op) && a->nb[0] == sizeof(float) && op->nb[0] == sizeof(float);
+        case GGML_OP_SOFT_MAX:
+            return f32(a) && f32(op) && ggml_is_contiguous(a) && ggml_is_contiguous(op) &&
+                   (!b || ((b->type == GGML_TYPE_F32 || b->type == GGML_TYPE_F16) && ggml_is_contiguous(b)));
+        case GGML_OP_DIAG_MASK_INF:
+            return f32(a) && f32(op) && ggml_is_contiguous(a) && ggml_is_contiguous(op);
+        case GGML_OP_GET_ROWS:
+            return (ff16(a->type) || qsrc(a->type)) && b->type == GGML_TYPE_I32 && f32(op) && a->nb[0] == ggml_type_size(a->type);
+        case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: {
+            const ggml_type ta = a->type, td = op->type;
+            if (ff16(ta) && ff16(td)) return true;
+            if (qsrc(ta) && td == GGML_TYPE_F32) return a->nb[0] == ggml_type_size(ta);
+            if (ta == GGML_TYPE_F32 && (td == GGML_TYPE_Q8_0 || td == GGML_TYPE_Q4_0))
+                return a->nb[0] == sizeof(float) && a->ne[0] % 32 == 0 && ggml_is_contiguous(op);
+            return false;
+        }
+        case GGML_OP_ROPE: {
+            const int mode = ((const int32_t *)op->op_params)[2];
+            return f32(a) && f32(op) && b->type == GGML_TYPE_I32 && (mode & ~2) == 0 && (!op->src[2] || op->src[2]->type == GGML_TYPE_F32);
+        }
+        default:
+            return false;
+    }
+}
+
+enum ggml_status cdna4_ops_compute(void * ctx, ggml_tensor * node) {
+    void * stream = cdna4_backend_stream(ctx);
+    const ggml_tensor * a = node->src[0], * b = node->src[1];
+    ggml_cdna4_tensor da = a ? desc(a) : ggml_cdna4_tensor{}, db = b ? desc(b) : ggml_cdna4_tensor{}, dd = desc(node);
+    int rc = -1;
+    switch (node->op) {
+        case GGML_OP_ADD: rc = ggml_cdna4_op_binary(GGML_CDNA4_ADD, &da, &db, &dd, stream); break;
+        case GGML_OP_SUB: rc = ggml_cdna4_op_binary(GGML_CDNA4_SUB, &da, &db, &dd, stream); break;
+        case GGML_OP_MUL: rc = ggml_cdna4_op_binary(GGML_CDNA4_MUL, &da, &db, &dd, stream); break;
+        case GGML_OP_DIV: rc = ggml_cdna4_op_binary(GGML_CDNA4_DIV, &da, &db, &dd, stream); break;
+        case GGML_OP_SCALE: { float s; memcpy(&s, node->op_params, sizeof(float)); rc = ggml_cdna4_op_scale(&da, &dd, s, stream); break; }
+        case GGML_OP_UNARY: rc = ggml_cdna4_op_unary(unary_id(node), &da, &dd, stream); break;
+        case GGML_OP_NORM: case GGML_OP_RMS_NORM: {
+            float eps; memcpy(&eps, node->op_params, sizeof(float));
+            rc = ggml_cdna4_op_norm(&da, &dd, eps, node->op == GGML_OP_RMS_NORM, stream); break;
+        }
+        case GGML_OP_SOFT_MAX: {
+            float scale, max_bias; memcpy(&scale, (const float *)node->op_params + 0, 4); memcpy(&max_bias, (const float *)node->op_params + 1, 4);
+            rc = ggml_cdna4_op_soft_max(&da, b ? &db : nullptr, &dd, scale, max_bias, stream); break;
+        }
+        case GGML_OP_DIAG_MASK_INF: rc = ggml_cdna4_op_diag_mask_inf(&da, &dd, ((const int32_t *)node->op_params)[0], stream); break;
+        case GGML_OP_GET_ROWS: rc = ggml_cdna4_op_get_rows(&da, &db, &dd, stream); break;
+        case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: rc = ggml_cdna4_op_cpy(&da, &dd, 0, stream); break;
+        case GGML_OP_MUL_MAT: rc = ggml_cdna4_op_mul_mat_f(&da, &db, &dd, stream); break;
+        case GGML_OP_ROPE: {
+            const int32_t * ip = (const int32_t *)node->op_params;
+            float fb, fs, ef, af, bf, bs;
+            memcpy(&fb, ip + 5, 4); memcpy(&fs, ip + 6, 4); memcpy(&ef, ip + 7, 4); memcpy(&af, ip + 8, 4); memcpy(&bf, ip + 9, 4); memcpy(&bs, ip + 10, 4);
+            ggml_cdna4_tensor dc = node->src[2] ? desc(node->src[2]) : ggml_cdna4_tensor{};
+            rc = ggml_cdna4_op_rope(&da, &db, node->src[2] ? &dc : nullptr, &dd, ip[1], ip[2], ip[4], fb, fs, ef, af, bf, bs, stream); break;
+        }
+        default: break;
+    }
+    if (rc != 0) { fprintf(stderr, "ggml-cdna4: %s: %s\n", ggml_op_name(node->op), ggml_cdna4_last_error()); return GGML_STATUS_FAILED; }
+    return GGML_STATUS_SUCCESS;
+}

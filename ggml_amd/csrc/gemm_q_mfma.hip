@@ -291,6 +291,116 @@ __global__ __launch_bounds__(256) void k_gemm_q(const gemm_params p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Pipelined K-quant kernel (Q4_K / Q5_K, 64-row activation tile): one barrier per SUPERBLOCK (256 k) instead of
+// per 64-k slice, and an NST-deep LDS ring filled by global_load_lds two superblocks ahead.  A wave never drains
+// its DMA queue in the main loop: `s_waitcnt vmcnt(NL)` leaves the next stage's NL loads in flight across the raw
+// s_barrier (cdna_hip_programming.md §5 "Pipelining across barriers").  Stage = [X: TB rows x 256 halves, 16-B
+// chunks XOR-swizzled by (row & 15) on the source side][W: 128 packed superblocks, untouched].
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TYPE, int BNF, int NST>
+__global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
+    constexpr int TB = 32 * BNF;
+    constexpr int XS = TB * 512;                 // bytes of X per stage (TB rows x 256 halves)
+    constexpr int BLK = QT<TYPE>::BYTES;
+    constexpr int WS = 128 * BLK;
+    constexpr int NP = BLK / 16;
+    constexpr int ST = XS + WS;                  // one ring slot
+    constexpr int XL = XS / 16 / 256;            // X global_load_lds per thread per stage
+    constexpr int WL = (2 * NP + 3) / 4;         // W global_load_lds per wave per stage (tail pieces are loaded twice)
+    constexpr int NL = XL + WL;                  // DMA instructions per wave per stage
+    constexpr int D = NST - 1;                   // prefetch distance in stages
+    static_assert(NST * ST <= 160 * 1024, "LDS ring does not fit");
+    static_assert(D == 1 || D == 2, "ring depth 2 or 3");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[NST * ST];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int nblk = gridDim.x;
+    int L = blockIdx.x;
+    if ((nblk & 7) == 0) L = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int tile_b = L % p.tiles_b; L /= p.tiles_b;
+    const int ks = L % p.splitk, tile_m = L / p.splitk;
+    const int m0 = tile_m * 128, b0 = tile_b * TB;
+    const int nsb = p.K / 256 / p.splitk, sb0 = ks * nsb;
+
+    floatx16 acc[BNF];
+#pragma unroll
+    for (int i = 0; i < BNF; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+    auto issue = [&](int s, int slot) {
+        uint8_t *xs = smem + slot * ST, *ws = xs + XS;
+        const int64_t k0 = (int64_t)(sb0 + s) * 256;
+#pragma unroll
+        for (int i = 0; i < XL; i++) {
+            const int pc = i * 256 + tid, row = pc >> 5, c = (pc & 31) ^ (row & 15);
+            const int b = min(b0 + row, p.B - 1);
+            glds16(p.xh + (int64_t)b * p.xh_row + k0 + c * 8, xs + (i * 256 + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < WL; i++) {
+            int idx = wave + 4 * i;
+            if (idx >= 2 * NP) idx -= 4;                         // wave-uniform: re-load this wave's previous piece
+            const int pc = idx * 64 + lane, row = pc / NP, c = pc % NP;
+            const int m = min(m0 + row, p.M - 1);
+            glds16(p.W + (int64_t)m * p.w_row_bytes + (int64_t)(sb0 + s) * BLK + c * 16, ws + idx * 1024);
+        }
+    };
+
+    const int xrow_off = j * 512, xswz = j & 15;
+    auto compute = [&](int slot) {
+        const uint8_t *xs = smem + slot * ST + xrow_off;
+        const uint8_t *wrow = smem + slot * ST + XS + (wave * 32 + j) * BLK;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            Raw<TYPE> raw;
+            raw.load(wrow, g, h);
+            half8_t wf[4];
+            raw.frags(g, h, wf);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int coff = ((g * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
+#pragma unroll
+                for (int bf = 0; bf < BNF; bf++) {
+                    const half8_t xa = *reinterpret_cast<const half8_t *>(xs + bf * 32 * 512 + coff);
+                    acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, wf[kk], acc[bf], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    issue(0, 0);
+    if (D == 2 && nsb > 1) issue(1, 1);
+    int slot = 0, slot_issue = D % NST;
+    for (int s = 0; s < nsb; s++) {
+        // stages s+1 .. min(s+D-1, nsb-1) may stay in flight
+        if (D == 2 && s + 1 < nsb) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + D < nsb) issue(s + D, slot_issue);
+        compute(slot);
+        slot = slot + 1 == NST ? 0 : slot + 1;
+        slot_issue = slot_issue + 1 == NST ? 0 : slot_issue + 1;
+    }
+
+    const int m = m0 + wave * 32 + j;
+    if (m < p.M) {
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int b = b0 + bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (b < p.B) {
+                    float *dst = p.Y + (int64_t)b * p.y_row + m;
+                    if (p.splitk > 1) unsafeAtomicAdd(dst, acc[bf][r]); else *dst = acc[bf][r];
+                }
+            }
+    }
+}
+
 __global__ void k_zero_rows(float *Y, int64_t y_row, int M, int B) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < (int64_t)M * B) Y[(i / M) * y_row + (i % M)] = 0.f;
@@ -320,24 +430,37 @@ static int launch_variant(const cdna4_gemm_args &a, int splitk, hipStream_t st) 
     return 0;
 }
 
+template <int TYPE, int NST>
+static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
+    gemm_params p;
+    p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
+    p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
+    p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 63) / 64;
+    if (splitk > 1) {
+        const int64_t n = (int64_t)a.M * a.B;
+        hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.Y, a.y_row_elems, a.M, a.B);
+    }
+    hipLaunchKernelGGL((k_gemm_kq_pipe<TYPE, 2, NST>), dim3(p.tiles_m * p.tiles_b * splitk), dim3(256), 0, st, p);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int TYPE>
 static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     constexpr bool CAN_LDS = QT<TYPE>::KQ && (QT<TYPE>::BYTES % 16 == 0);
-    // variant: bit0 = LDS weight staging (Q4_K/Q5_K only), bit1 = 128-wide activation tile.  0 = auto.
+    // variant: bit0 = LDS weight staging (Q4_K/Q5_K only), bit1 = 128-wide activation tile, bit3 = the older
+    // slice-per-barrier kernel instead of the pipelined superblock-per-barrier one.  0 = auto.
     int variant = a.variant;
-    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0);
+    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0);
     const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
     const bool wide = (variant & 2) != 0;
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
     const int kunits = QT<TYPE>::KQ ? a.K / 256 : a.K / 64;
     int splitk = a.splitk;
-    if (splitk <= 0) {
-        const int tiles = ((a.M + 127) / 128) * ((a.B + (wide ? 127 : 63)) / (wide ? 128 : 64));
-        splitk = 1;
-        while (tiles * splitk * 2 <= 256 && splitk * 2 <= kunits && kunits % (splitk * 2) == 0 && kunits / (splitk * 2) >= 2) splitk *= 2;
-    }
+    if (splitk <= 0) splitk = 1;       // split-K sums with fp32 atomics (order-dependent rounding): opt-in only
     if (splitk < 1 || kunits % splitk) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
     if constexpr (CAN_LDS) {
+        if (wlds && !wide && !(variant & 8)) { if constexpr (TYPE == CDNA4_Q4_K) return launch_pipe<TYPE, 3>(a, splitk, st); else return launch_pipe<TYPE, 2>(a, splitk, st); }
         if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
     }
     return wide ? launch_variant<TYPE, 4, false>(a, splitk, st) : launch_variant<TYPE, 2, false>(a, splitk, st);

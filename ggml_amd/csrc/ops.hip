@@ -1,0 +1,503 @@
+// ops.hip — the supporting ops around MUL_MAT as plain HIP kernels (no LDS tricks, no MFMA: these are
+// HBM/L2-bound elementwise / row-reduction ops, written for wave64 with coalesced 4-byte accesses).
+// Semantics follow the reference CPU backend function by function (citations in include/ggml_cdna4.h and
+// next to each kernel); compiled with -ffp-contract=off so mul-then-add sequences round like the CPU's.
+#include "../../include/ggml_cdna4.h"
+#include "cdna4_common.h"
+#include "cdna4_kernels.h"
+#include <math.h>
+
+typedef ggml_cdna4_tensor T4;
+
+static inline int64_t nelem(const T4 *t) { return t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
+static inline int64_t nrows(const T4 *t) { return t->ne[1] * t->ne[2] * t->ne[3]; }
+static inline size_t tsize(int type) {
+    switch (type) { case CDNA4_F32: case CDNA4_I32: return 4; case CDNA4_F16: return 2; case CDNA4_Q4_0: return 18; case CDNA4_Q8_0: return 34;
+                    case CDNA4_Q4_K: return 144; case CDNA4_Q5_K: return 176; case CDNA4_Q6_K: return 210; }
+    return 0;
+}
+static inline int bsize(int type) {
+    switch (type) { case CDNA4_Q4_0: case CDNA4_Q8_0: return 32; case CDNA4_Q4_K: case CDNA4_Q5_K: case CDNA4_Q6_K: return 256; }
+    return 1;
+}
+static inline bool is_contig(const T4 *t) {      // ggml_is_contiguous
+    const int64_t bs = bsize(t->type);
+    if (t->nb[0] != (int64_t)tsize(t->type)) return false;
+    if (t->nb[1] != t->nb[0] * (t->ne[0] / bs)) return false;
+    return t->nb[2] == t->nb[1] * t->ne[1] && t->nb[3] == t->nb[2] * t->ne[2];
+}
+static inline bool same_shape(const T4 *a, const T4 *b) { return a->ne[0] == b->ne[0] && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == b->ne[3]; }
+static inline dim3 grid1d(int64_t n, int per_block = 256) { int64_t g = (n + per_block - 1) / per_block; if (g < 1) g = 1; return dim3((unsigned)g); }
+
+struct idx4 { int64_t i0, i1, i2, i3; };
+__device__ __forceinline__ idx4 unravel(int64_t i, const int64_t ne[4]) {
+    idx4 r; r.i0 = i % ne[0]; i /= ne[0]; r.i1 = i % ne[1]; i /= ne[1]; r.i2 = i % ne[2]; r.i3 = i / ne[2]; return r;
+}
+__device__ __forceinline__ const char *at(const T4 &t, const idx4 &x) { return (const char *)t.data + x.i0 * t.nb[0] + x.i1 * t.nb[1] + x.i2 * t.nb[2] + x.i3 * t.nb[3]; }
+
+__device__ __forceinline__ float block_sum(float v, float *red) {       // 256 threads
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float v, float *red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ------------------------------------------------------------------------------------------------ binary
+template <int OP>
+__global__ __launch_bounds__(256) void k_binary(const T4 a, const T4 b, const T4 d, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const idx4 x = unravel(i, d.ne);
+    const idx4 y = {x.i0 % b.ne[0], x.i1 % b.ne[1], x.i2 % b.ne[2], x.i3 % b.ne[3]};
+    const float u = *(const float *)at(a, x), v = *(const float *)at(b, y);
+    float r;
+    if (OP == GGML_CDNA4_ADD) r = u + v; else if (OP == GGML_CDNA4_SUB) r = u - v; else if (OP == GGML_CDNA4_MUL) r = u * v; else r = u / v;
+    *(float *)at(d, x) = r;
+}
+
+// ------------------------------------------------------------------------------------------------ scale / unary
+__global__ __launch_bounds__(256) void k_scale(const float *__restrict__ x, float *__restrict__ y, float s, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = x[i] * s;
+}
+__device__ __forceinline__ float gelu_f32(float x) {           // ggml_gelu_f32, ggml-cpu.c:1753-1755
+    return 0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x)));
+}
+template <int OP>
+__global__ __launch_bounds__(256) void k_unary(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float r;
+    if (OP == GGML_CDNA4_GELU) {
+        // the CPU reads a 64K-entry fp16 table indexed by fp16(x) (ggml_vec_gelu_f32, ggml-cpu.c:1759-1774)
+        if (v <= -10.0f) r = 0.0f; else if (v >= 10.0f) r = v;
+        else { const float xh = (float)(half_t)v; r = (float)(half_t)gelu_f32(xh); }
+    } else if (OP == GGML_CDNA4_GELU_QUICK) {
+        if (v <= -10.0f || v >= 10.0f) { r = v * (1.0f / (1.0f + expf(-1.702f * v))); }
+        else { const float xh = (float)(half_t)v; r = (float)(half_t)(xh * (1.0f / (1.0f + expf(-1.702f * xh)))); }
+    } else if (OP == GGML_CDNA4_SILU) r = v / (1.0f + expf(-v));
+    else if (OP == GGML_CDNA4_RELU) r = v > 0.f ? v : 0.f;
+    else r = tanhf(v);
+    y[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------------ norm / rms_norm
+// one 256-thread block per row; the row is re-read from L1/L2 (3 passes) — rows are K floats, a few KB
+template <bool RMS>
+__global__ __launch_bounds__(256) void k_norm(const T4 a, const T4 d, float eps) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const idx4 x = {0, row % a.ne[1], (row / a.ne[1]) % a.ne[2], row / (a.ne[1] * a.ne[2])};
+    const float *src = (const float *)at(a, x);
+    float *dst = (float *)at(d, x);
+    const int n = (int)a.ne[0];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float v = src[i]; s += RMS ? v * v : v; }
+    s = block_sum(s, red);
+    const float mean = s / n;
+    if (RMS) {
+        const float scale = 1.0f / sqrtf(mean + eps);
+        for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i] * scale;
+    } else {
+        float s2 = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) { const float v = src[i] - mean; s2 += v * v; }
+        s2 = block_sum(s2, red);
+        const float scale = 1.0f / sqrtf(s2 / n + eps);
+        for (int i = threadIdx.x; i < n; i += 256) dst[i] = (src[i] - mean) * scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ soft_max
+template <int MASK>   // 0 none, 1 f32, 2 f16
+__global__ __launch_bounds__(256) void k_soft_max(const float *__restrict__ x, const void *__restrict__ mask, float *__restrict__ y,
+                                                  int nc, int ne01, int ne02, float scale, float max_bias, float m0, float m1, uint32_t n_head_log2) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const float *sp = x + row * nc;
+    float *dp = y + row * nc;
+    const uint32_t hh = (uint32_t)((row / ne01) % ne02);
+    const float slope = max_bias > 0.0f ? (hh < n_head_log2 ? powf(m0, (float)(hh + 1)) : powf(m1, (float)(2 * (hh - n_head_log2) + 1))) : 1.0f;
+    const int64_t moff = (row % ne01) * (int64_t)nc;
+    auto val = [&](int i) -> float {
+        float v = sp[i] * scale;
+        if (MASK == 1) v += slope * ((const float *)mask)[moff + i];
+        if (MASK == 2) v += slope * (float)((const half_t *)mask)[moff + i];
+        return v;
+    };
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < nc; i += 256) mx = fmaxf(mx, val(i));
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nc; i += 256) { const float e = expf(val(i) - mx); dp[i] = e; s += e; }
+    s = block_sum(s, red);
+    const float inv = 1.0f / s;
+    for (int i = threadIdx.x; i < nc; i += 256) dp[i] *= inv;
+}
+
+// ------------------------------------------------------------------------------------------------ diag_mask_inf
+__global__ __launch_bounds__(256) void k_diag_mask_inf(const float *__restrict__ x, float *__restrict__ y, int64_t n, int nc, int nr, int n_past) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int col = (int)(i % nc), row = (int)((i / nc) % nr);
+    y[i] = col > n_past + row ? -INFINITY : x[i];
+}
+
+// ------------------------------------------------------------------------------------------------ dequantize element
+// element k of a quantized row, with the exact operation order of dequantize_row_* (src/ggml-quants.c)
+template <int TYPE> __device__ __forceinline__ float deq_elem(const uint8_t *row, int64_t k);
+template <> __device__ __forceinline__ float deq_elem<CDNA4_F32>(const uint8_t *row, int64_t k) { return ((const float *)row)[k]; }
+template <> __device__ __forceinline__ float deq_elem<CDNA4_F16>(const uint8_t *row, int64_t k) { return (float)((const half_t *)row)[k]; }
+template <> __device__ __forceinline__ float deq_elem<CDNA4_Q4_0>(const uint8_t *row, int64_t k) {
+    const uint8_t *b = row + (k >> 5) * 18; const int j = (int)(k & 31);
+    const float d = h2f(ld_u16(b)); const uint8_t q = b[2 + (j & 15)];
+    return (float)((j < 16 ? (q & 0x0F) : (q >> 4)) - 8) * d;
+}
+template <> __device__ __forceinline__ float deq_elem<CDNA4_Q8_0>(const uint8_t *row, int64_t k) {
+    const uint8_t *b = row + (k >> 5) * 34;
+    return (float)((const int8_t *)b)[2 + (k & 31)] * h2f(ld_u16(b));
+}
+__device__ __forceinline__ void k4_sm(const uint8_t *q, int j, uint8_t &d, uint8_t &m) {
+    if (j < 4) { d = q[j] & 63; m = q[j + 4] & 63; } else { d = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
+}
+template <> __device__ __forceinline__ float deq_elem<CDNA4_Q4_K>(const uint8_t *row, int64_t k) {
+    const uint8_t *b = row + (k >> 8) * 144; const int j = (int)(k & 255), g = j >> 6, l = j & 31, hi = (j >> 5) & 1;
+    uint8_t sc, m; k4_sm(b + 4, 2 * g + hi, sc, m);
+    const float d = h2f(ld_u16(b)) * sc, mn = h2f(ld_u16(b + 2)) * m;
+    const uint8_t q = b[16 + 32 * g + l];
+    return d * (float)(hi ? (q >> 4) : (q & 0xF)) - mn;
+}
+template <> __device__ __forceinline__ float deq_elem<CDNA4_Q5_K>(const uint8_t *row, int64_t k) {
+    const uint8_t *b = row + (k >> 8) * 176; const int j = (int)(k & 255), g = j >> 6, l = j & 31, hi = (j >> 5) & 1;
+    uint8_t sc, m; k4_sm(b + 4, 2 * g + hi, sc, m);
+    const float d = h2f(ld_u16(b)) * sc, mn = h2f(ld_u16(b + 2)) * m;
+    const uint8_t q = b[48 + 32 * g + l], h = b[16 + l];
+    const int v = (hi ? (q >> 4) : (q & 0xF)) + ((h >> (2 * g + hi)) & 1 ? 16 : 0);
+    return d * (float)v - mn;
+}
+template <> __device__ __forceinline__ float deq_elem<CDNA4_Q6_K>(const uint8_t *row, int64_t k) {
+    const uint8_t *b = row + (k >> 8) * 210; const int j = (int)(k & 255), n = j >> 7, r = j & 127, qd = r >> 5, l = r & 31;
+    const uint8_t ql = b[64 * n + l + ((qd & 1) ? 32 : 0)], qh = b[128 + 32 * n + l];
+    const int q = (int)(int8_t)(((qd & 2) ? (ql >> 4) : (ql & 0xF)) | (((qh >> (2 * qd)) & 3) << 4)) - 32;
+    const float d = h2f(ld_u16(b + 208));
+    const int8_t sc = ((const int8_t *)b)[192 + 8 * n + (l >> 4) + 2 * qd];
+    return d * sc * q;
+}
+
+// ------------------------------------------------------------------------------------------------ get_rows
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_get_rows(const T4 a, const T4 ids, const T4 d, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const idx4 x = unravel(i, d.ne);                         // (k, i10, i11, i12)
+    const int32_t r = *(const int32_t *)((const char *)ids.data + x.i1 * ids.nb[0] + x.i2 * ids.nb[1] + x.i3 * ids.nb[2]);
+    const uint8_t *row = (const uint8_t *)a.data + (int64_t)r * a.nb[1] + x.i2 * a.nb[2] + x.i3 * a.nb[3];
+    *(float *)at(d, x) = deq_elem<TYPE>(row, x.i0);
+}
+
+// ------------------------------------------------------------------------------------------------ cpy
+// logical element i of src -> logical element i of dst (both enumerate ne[0] fastest), ggml_compute_forward_dup
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void k_cpy(const T4 a, const T4 d, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = (float)*(const TS *)at(a, unravel(i, a.ne));
+    *(TD *)at(d, unravel(i, d.ne)) = (TD)v;
+}
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_cpy_q_to_f32(const T4 a, const T4 d, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const idx4 x = unravel(i, a.ne);
+    const uint8_t *row = (const uint8_t *)a.data + x.i1 * a.nb[1] + x.i2 * a.nb[2] + x.i3 * a.nb[3];
+    *(float *)at(d, unravel(i, d.ne)) = deq_elem<TYPE>(row, x.i0);
+}
+// F32 -> Q4_0 / Q8_0: one thread per 32-block; src rows contiguous in ne[0], dst blocks enumerated in logical order
+template <int TYPE, bool REF>
+__global__ __launch_bounds__(256) void k_cpy_f32_to_q(const T4 a, const T4 d, int64_t nblocks) {
+    const int64_t ib = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (ib >= nblocks) return;
+    const int64_t e0 = ib * 32;
+    const float *src = (const float *)at(a, unravel(e0, a.ne));
+    const int64_t bpr = d.ne[0] / 32;                                    // blocks per dst row
+    const idx4 dr = {0, (ib / bpr) % d.ne[1], (ib / (bpr * d.ne[1])) % d.ne[2], ib / (bpr * d.ne[1] * d.ne[2])};
+    uint8_t *out = (uint8_t *)d.data + dr.i1 * d.nb[1] + dr.i2 * d.nb[2] + dr.i3 * d.nb[3] + (ib % bpr) * (TYPE == CDNA4_Q8_0 ? 34 : 18);
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) v[j] = src[j];
+    if (TYPE == CDNA4_Q8_0) {
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; j++) amax = fmaxf(amax, fabsf(v[j]));
+        const float dd = amax / 127.f;
+        const float id = REF ? (dd != 0.f ? 1.0f / dd : 0.f) : (amax != 0.f ? 127.f / amax : 0.f);
+        *(uint16_t *)out = f2h_bits(dd);
+#pragma unroll
+        for (int j = 0; j < 32; j++) ((int8_t *)out)[2 + j] = (int8_t)(REF ? (int)roundf(v[j] * id) : (int)__builtin_rintf(v[j] * id));
+    } else {                                                            // quantize_row_q4_0_ref, src/ggml-quants.c:31-66
+        float amax = 0.f, mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; j++) if (amax < fabsf(v[j])) { amax = fabsf(v[j]); mx = v[j]; }
+        const float dd = mx / -8; const float id = dd != 0.f ? 1.0f / dd : 0.f;
+        *(uint16_t *)out = f2h_bits(dd);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float x0 = v[j] * id, x1 = v[16 + j] * id;
+            const int a0 = (int)(int8_t)(x0 + 8.5f), a1 = (int)(int8_t)(x1 + 8.5f);
+            const uint8_t q0 = (uint8_t)(a0 < 15 ? a0 : 15), q1 = (uint8_t)(a1 < 15 ? a1 : 15);
+            out[2 + j] = q0 | (q1 << 4);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ mul_mat F32/F16
+// one wave per output element (m, n, batch): lanes stride over k (both operands contiguous in k)
+template <typename TW>
+__global__ __launch_bounds__(256) void k_mul_mat_f(const T4 a, const T4 b, const T4 d, int64_t nout) {
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= nout) return;
+    const int lane = threadIdx.x & 63;
+    const idx4 x = unravel(o, d.ne);                                   // (m, n, i2, i3)
+    const int64_t r2 = b.ne[2] / a.ne[2], r3 = b.ne[3] / a.ne[3];
+    const TW *w = (const TW *)((const char *)a.data + x.i0 * a.nb[1] + (x.i2 / r2) * a.nb[2] + (x.i3 / r3) * a.nb[3]);
+    const float *v = (const float *)((const char *)b.data + x.i1 * b.nb[1] + x.i2 * b.nb[2] + x.i3 * b.nb[3]);
+    float s = 0.f;
+    const int K = (int)a.ne[0];
+    for (int k = lane; k < K; k += 64) {
+        float xv = v[k];
+        if (sizeof(TW) == 2) xv = (float)(half_t)xv;                  // vec_dot_type F16: src1 is rounded to fp16 first
+        s = fmaf((float)w[k], xv, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) *(float *)at(d, x) = s;
+}
+
+// ------------------------------------------------------------------------------------------------ rope
+__device__ __forceinline__ float yarn_ramp(float low, float high, int i0) {
+    const float y = (i0 / 2 - low) / fmaxf(0.001f, high - low);
+    return 1 - fminf(1, fmaxf(0, y));
+}
+__global__ __launch_bounds__(256) void k_rope(const T4 a, const int32_t *__restrict__ pos, const float *__restrict__ ff, const T4 d, int64_t npairs,
+                                              int n_dims, int neox, float theta_scale, float freq_scale, float ext_factor, float attn_factor, float c0, float c1) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const int64_t hp = a.ne[0] / 2;
+    const int64_t ip = i % hp; int64_t r = i / hp;
+    const int64_t i1 = r % a.ne[1]; r /= a.ne[1];
+    const int64_t i2 = r % a.ne[2], i3 = r / a.ne[2];
+    const int64_t i0 = 2 * ip;
+    const char *sb = (const char *)a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3];
+    char *db = (char *)d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3];
+    if (i0 >= n_dims) {                                               // untouched tail channels
+        *(float *)(db + i0 * d.nb[0]) = *(const float *)(sb + i0 * a.nb[0]);
+        *(float *)(db + (i0 + 1) * d.nb[0]) = *(const float *)(sb + (i0 + 1) * a.nb[0]);
+        return;
+    }
+    float theta = (float)pos[i2];
+    for (int64_t t = 0; t < ip; t++) theta *= theta_scale;           // same recurrence as ggml_rope_cache_init
+    const float fq = ff ? ff[ip] : 1.0f;
+    const float theta_extrap = theta / fq;
+    const float theta_interp = freq_scale * theta_extrap;
+    float th = theta_interp, mscale = attn_factor;
+    if (ext_factor != 0.0f) {
+        const float ramp_mix = yarn_ramp(c0, c1, (int)i0) * ext_factor;
+        th = theta_interp * (1 - ramp_mix) + theta_extrap * ramp_mix;
+        mscale *= 1.0f + 0.1f * logf(1.0f / freq_scale);
+    }
+    const float ct = cosf(th) * mscale, st = sinf(th) * mscale;
+    const int64_t ia = neox ? ip : i0, ib = neox ? ip + n_dims / 2 : i0 + 1;
+    const float x0 = *(const float *)(sb + ia * a.nb[0]), x1 = *(const float *)(sb + ib * a.nb[0]);
+    *(float *)(db + ia * d.nb[0]) = x0 * ct - x1 * st;
+    *(float *)(db + ib * d.nb[0]) = x0 * st + x1 * ct;
+}
+
+// ============================================================================================================
+#define NEED(cond, msg) do { if (!(cond)) return cdna4_set_error_msg(msg); } while (0)
+
+extern "C" {
+
+int ggml_cdna4_op_binary(int op, const T4 *a, const T4 *b, const T4 *d, void *stream) {
+    NEED(a->type == CDNA4_F32 && b->type == CDNA4_F32 && d->type == CDNA4_F32, "binary: F32 only");
+    NEED(same_shape(a, d), "binary: src0 and dst shapes differ");
+    for (int i = 0; i < 4; i++) NEED(b->ne[i] > 0 && a->ne[i] % b->ne[i] == 0, "binary: src1 is not broadcastable");
+    const int64_t n = nelem(d);
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (op) {
+        case GGML_CDNA4_ADD: hipLaunchKernelGGL(k_binary<GGML_CDNA4_ADD>, grid1d(n), dim3(256), 0, st, *a, *b, *d, n); break;
+        case GGML_CDNA4_SUB: hipLaunchKernelGGL(k_binary<GGML_CDNA4_SUB>, grid1d(n), dim3(256), 0, st, *a, *b, *d, n); break;
+        case GGML_CDNA4_MUL: hipLaunchKernelGGL(k_binary<GGML_CDNA4_MUL>, grid1d(n), dim3(256), 0, st, *a, *b, *d, n); break;
+        case GGML_CDNA4_DIV: hipLaunchKernelGGL(k_binary<GGML_CDNA4_DIV>, grid1d(n), dim3(256), 0, st, *a, *b, *d, n); break;
+        default: return cdna4_set_error_msg("binary: unknown op");
+    }
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+int ggml_cdna4_op_scale(const T4 *a, const T4 *d, float scale, void *stream) {
+    NEED(a->type == CDNA4_F32 && d->type == CDNA4_F32 && is_contig(a) && is_contig(d) && nelem(a) == nelem(d), "scale: contiguous F32 only");
+    const int64_t n = nelem(d);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_scale, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const float *)a->data, (float *)d->data, scale, n);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+int ggml_cdna4_op_unary(int op, const T4 *a, const T4 *d, void *stream) {
+    NEED(a->type == CDNA4_F32 && d->type == CDNA4_F32 && is_contig(a) && is_contig(d) && nelem(a) == nelem(d), "unary: contiguous F32 only");
+    const int64_t n = nelem(d);
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream; const float *x = (const float *)a->data; float *y = (float *)d->data;
+    switch (op) {
+        case GGML_CDNA4_GELU: hipLaunchKernelGGL(k_unary<GGML_CDNA4_GELU>, grid1d(n), dim3(256), 0, st, x, y, n); break;
+        case GGML_CDNA4_GELU_QUICK: hipLaunchKernelGGL(k_unary<GGML_CDNA4_GELU_QUICK>, grid1d(n), dim3(256), 0, st, x, y, n); break;
+        case GGML_CDNA4_SILU: hipLaunchKernelGGL(k_unary<GGML_CDNA4_SILU>, grid1d(n), dim3(256), 0, st, x, y, n); break;
+        case GGML_CDNA4_RELU: hipLaunchKernelGGL(k_unary<GGML_CDNA4_RELU>, grid1d(n), dim3(256), 0, st, x, y, n); break;
+        case GGML_CDNA4_TANH: hipLaunchKernelGGL(k_unary<GGML_CDNA4_TANH>, grid1d(n), dim3(256), 0, st, x, y, n); break;
+        default: return cdna4_set_error_msg("unary: unknown op");
+    }
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+int ggml_cdna4_op_norm(const T4 *a, const T4 *d, float eps, int rms, void *stream) {
+    NEED(a->type == CDNA4_F32 && d->type == CDNA4_F32 && same_shape(a, d) && a->nb[0] == 4 && d->nb[0] == 4, "norm: F32 rows only");
+    const int64_t nr = nrows(a);
+    if (nr == 0 || a->ne[0] == 0) return 0;
+    if (rms) hipLaunchKernelGGL(k_norm<true>, dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps);
+    else hipLaunchKernelGGL(k_norm<false>, dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+int ggml_cdna4_op_soft_max(const T4 *a, const T4 *mask, const T4 *d, float scale, float max_bias, void *stream) {
+    NEED(a->type == CDNA4_F32 && d->type == CDNA4_F32 && is_contig(a) && is_contig(d) && same_shape(a, d), "soft_max: contiguous F32 only");
+    int mt = 0;
+    if (mask) {
+        NEED((mask->type == CDNA4_F32 || mask->type == CDNA4_F16) && is_contig(mask) && mask->ne[0] == a->ne[0] && mask->ne[1] >= a->ne[1], "soft_max: bad mask");
+        mt = mask->type == CDNA4_F32 ? 1 : 2;
+    }
+    const int64_t nr = nrows(a);
+    if (nr == 0 || a->ne[0] == 0) return 0;
+    const uint32_t n_head = (uint32_t)a->ne[2];
+    const uint32_t n_head_log2 = 1u << (uint32_t)floor(log2((double)n_head));
+    const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    hipStream_t st = (hipStream_t)stream;
+    const float *x = (const float *)a->data; float *y = (float *)d->data; const void *mp = mask ? mask->data : nullptr;
+    const int nc = (int)a->ne[0], ne01 = (int)a->ne[1], ne02 = (int)a->ne[2];
+    if (mt == 0) hipLaunchKernelGGL(k_soft_max<0>, dim3((unsigned)nr), dim3(256), 0, st, x, mp, y, nc, ne01, ne02, scale, max_bias, m0, m1, n_head_log2);
+    else if (mt == 1) hipLaunchKernelGGL(k_soft_max<1>, dim3((unsigned)nr), dim3(256), 0, st, x, mp, y, nc, ne01, ne02, scale, max_bias, m0, m1, n_head_log2);
+    else hipLaunchKernelGGL(k_soft_max<2>, dim3((unsigned)nr), dim3(256), 0, st, x, mp, y, nc, ne01, ne02, scale, max_bias, m0, m1, n_head_log2);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+int ggml_cdna4_op_diag_mask_inf(const T4 *a, const T4 *d, int n_past, void *stream) {
+    NEED(a->type == CDNA4_F32 && d->type == CDNA4_F32 && is_contig(a) && is_contig(d) && same_shape(a, d) && n_past >= 0, "diag_mask_inf: contiguous F32 only");
+    const int64_t n = nelem(d);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_diag_mask_inf, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const float *)a->data, (float *)d->data, n, (int)a->ne[0], (int)a->ne[1], n_past);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+int ggml_cdna4_op_get_rows(const T4 *a, const T4 *ids, const T4 *d, void *stream) {
+    NEED(ids->type == CDNA4_I32 && d->type == CDNA4_F32, "get_rows: ids must be I32 and dst F32");
+    NEED(d->ne[0] == a->ne[0] && d->ne[1] == ids->ne[0] && d->ne[2] == ids->ne[1] && d->ne[3] == ids->ne[2], "get_rows: shape mismatch");
+    NEED(a->ne[2] == ids->ne[1] && a->ne[3] == ids->ne[2] && a->nb[0] == (int64_t)tsize(a->type), "get_rows: batch dims mismatch");
+    const int64_t n = nelem(d);
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+#define GR(T) hipLaunchKernelGGL(k_get_rows<T>, grid1d(n), dim3(256), 0, st, *a, *ids, *d, n); break
+    switch (a->type) {
+        case CDNA4_F32: GR(CDNA4_F32); case CDNA4_F16: GR(CDNA4_F16); case CDNA4_Q4_0: GR(CDNA4_Q4_0); case CDNA4_Q8_0: GR(CDNA4_Q8_0);
+        case CDNA4_Q4_K: GR(CDNA4_Q4_K); case CDNA4_Q5_K: GR(CDNA4_Q5_K); case CDNA4_Q6_K: GR(CDNA4_Q6_K);
+        default: return cdna4_set_error_msg("get_rows: unsupported source type");
+    }
+#undef GR
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+int ggml_cdna4_op_cpy(const T4 *a, const T4 *d, int q8_0_ref_rounding, void *stream) {
+    const int64_t n = nelem(a);
+    NEED(n == nelem(d), "cpy: element counts differ");
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int ta = a->type, td = d->type;
+    if ((ta == CDNA4_F32 || ta == CDNA4_F16) && (td == CDNA4_F32 || td == CDNA4_F16)) {
+        if (ta == td && is_contig(a) && is_contig(d)) {
+            hipError_t e = hipMemcpyAsync(d->data, a->data, (size_t)n * tsize(ta), hipMemcpyDeviceToDevice, st);
+            return e == hipSuccess ? 0 : cdna4_set_error(e, __FILE__, __LINE__);
+        }
+        if (ta == CDNA4_F32 && td == CDNA4_F32) hipLaunchKernelGGL((k_cpy<float, float>), grid1d(n), dim3(256), 0, st, *a, *d, n);
+        else if (ta == CDNA4_F32) hipLaunchKernelGGL((k_cpy<float, half_t>), grid1d(n), dim3(256), 0, st, *a, *d, n);
+        else if (td == CDNA4_F32) hipLaunchKernelGGL((k_cpy<half_t, float>), grid1d(n), dim3(256), 0, st, *a, *d, n);
+        else hipLaunchKernelGGL((k_cpy<half_t, half_t>), grid1d(n), dim3(256), 0, st, *a, *d, n);
+    } else if (td == CDNA4_F32 && bsize(ta) > 1) {
+        NEED(a->nb[0] == (int64_t)tsize(ta), "cpy: quantized source rows must be contiguous");
+#define CQ(T) hipLaunchKernelGGL(k_cpy_q_to_f32<T>, grid1d(n), dim3(256), 0, st, *a, *d, n); break
+        switch (ta) { case CDNA4_Q4_0: CQ(CDNA4_Q4_0); case CDNA4_Q8_0: CQ(CDNA4_Q8_0); case CDNA4_Q4_K: CQ(CDNA4_Q4_K); case CDNA4_Q5_K: CQ(CDNA4_Q5_K); case CDNA4_Q6_K: CQ(CDNA4_Q6_K);
+                      default: return cdna4_set_error_msg("cpy: unsupported quantized source"); }
+#undef CQ
+    } else if (ta == CDNA4_F32 && (td == CDNA4_Q8_0 || td == CDNA4_Q4_0)) {
+        NEED(a->nb[0] == 4 && a->ne[0] % 32 == 0 && d->ne[0] % 32 == 0 && d->nb[0] == (int64_t)tsize(td), "cpy: f32->q needs whole 32-blocks per row");
+        const int64_t nbk = n / 32;
+        if (td == CDNA4_Q4_0) hipLaunchKernelGGL((k_cpy_f32_to_q<CDNA4_Q4_0, true>), grid1d(nbk), dim3(256), 0, st, *a, *d, nbk);
+        else if (q8_0_ref_rounding) hipLaunchKernelGGL((k_cpy_f32_to_q<CDNA4_Q8_0, true>), grid1d(nbk), dim3(256), 0, st, *a, *d, nbk);
+        else hipLaunchKernelGGL((k_cpy_f32_to_q<CDNA4_Q8_0, false>), grid1d(nbk), dim3(256), 0, st, *a, *d, nbk);
+    } else return cdna4_set_error_msg("cpy: unsupported type pair");
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+int ggml_cdna4_op_mul_mat_f(const T4 *a, const T4 *b, const T4 *d, void *stream) {
+    NEED((a->type == CDNA4_F32 || a->type == CDNA4_F16) && b->type == CDNA4_F32 && d->type == CDNA4_F32, "mul_mat_f: F32/F16 x F32 only");
+    NEED(a->ne[0] == b->ne[0] && d->ne[0] == a->ne[1] && d->ne[1] == b->ne[1] && d->ne[2] == b->ne[2] && d->ne[3] == b->ne[3], "mul_mat_f: shape mismatch");
+    NEED(a->ne[2] > 0 && a->ne[3] > 0 && b->ne[2] % a->ne[2] == 0 && b->ne[3] % a->ne[3] == 0, "mul_mat_f: batch dims not broadcastable");
+    NEED(a->nb[0] == (int64_t)tsize(a->type) && b->nb[0] == 4, "mul_mat_f: k must be the contiguous dimension");
+    const int64_t nout = nelem(d);
+    if (nout == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->type == CDNA4_F32) hipLaunchKernelGGL(k_mul_mat_f<float>, grid1d(nout, 4), dim3(256), 0, st, *a, *b, *d, nout);
+    else hipLaunchKernelGGL(k_mul_mat_f<half_t>, grid1d(nout, 4), dim3(256), 0, st, *a, *b, *d, nout);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+int ggml_cdna4_op_rope(const T4 *a, const T4 *pos, const T4 *ffac, const T4 *d, int n_dims, int mode, int n_ctx_orig,
+                       float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow, void *stream) {
+    NEED(a->type == CDNA4_F32 && d->type == CDNA4_F32 && same_shape(a, d) && pos->type == CDNA4_I32, "rope: F32 data, I32 positions");
+    NEED((mode & ~2) == 0, "rope: only NORMAL and NEOX modes");
+    NEED(n_dims % 2 == 0 && n_dims <= a->ne[0] && a->ne[0] % 2 == 0 && pos->ne[0] >= a->ne[2], "rope: bad n_dims / positions");
+    if (ffac) NEED(ffac->type == CDNA4_F32 && ffac->ne[0] >= n_dims / 2, "rope: bad freq_factors");
+    const int64_t npairs = nelem(a) / 2;
+    if (npairs == 0) return 0;
+    const float theta_scale = powf(freq_base, -2.0f / n_dims);
+    // ggml_rope_yarn_corr_dims, src/ggml.c:3699-3707
+    auto corr_dim = [&](float n_rot) { return n_dims * logf(n_ctx_orig / (n_rot * 2 * (float)M_PI)) / (2 * logf(freq_base)); };
+    const float c0 = fmaxf(0.f, floorf(corr_dim(beta_fast))), c1 = fminf((float)(n_dims - 1), ceilf(corr_dim(beta_slow)));
+    hipLaunchKernelGGL(k_rope, grid1d(npairs), dim3(256), 0, (hipStream_t)stream, *a, (const int32_t *)pos->data, ffac ? (const float *)ffac->data : nullptr, *d, npairs,
+                       n_dims, (mode & 2) ? 1 : 0, theta_scale, freq_scale, ext_factor, attn_factor, c0, c1);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+int ggml_cdna4_dequantize_row(int type, const void *x, float *y, int64_t k, void *stream) {
+    NEED(bsize(type) > 1 && k % bsize(type) == 0, "dequantize_row: unsupported type or ragged k");
+    T4 a{}, d{};
+    a.data = (void *)x; a.type = type; a.ne[0] = k; a.ne[1] = a.ne[2] = a.ne[3] = 1;
+    a.nb[0] = (int64_t)tsize(type); a.nb[1] = a.nb[2] = a.nb[3] = (k / bsize(type)) * a.nb[0];
+    d.data = y; d.type = CDNA4_F32; d.ne[0] = k; d.ne[1] = d.ne[2] = d.ne[3] = 1; d.nb[0] = 4; d.nb[1] = d.nb[2] = d.nb[3] = 4 * k;
+    return ggml_cdna4_op_cpy(&a, &d, 0, stream);
+}
+
+}  // extern "C"

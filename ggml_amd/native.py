@@ -23,7 +23,24 @@ SYMBOLS = [
                                      _i64, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
     ("ggml_cdna4_quantize_q8_K", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     ("ggml_cdna4_quantize_q8_0", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp]),
+    # supporting ops: tensors are POINTER(Tensor) descriptors
+    ("ggml_cdna4_op_binary", _int, [_int, _vp, _vp, _vp, _vp]),
+    ("ggml_cdna4_op_scale", _int, [_vp, _vp, C.c_float, _vp]),
+    ("ggml_cdna4_op_norm", _int, [_vp, _vp, C.c_float, _int, _vp]),
+    ("ggml_cdna4_op_soft_max", _int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp]),
+    ("ggml_cdna4_op_diag_mask_inf", _int, [_vp, _vp, _int, _vp]),
+    ("ggml_cdna4_op_unary", _int, [_int, _vp, _vp, _vp]),
+    ("ggml_cdna4_op_get_rows", _int, [_vp, _vp, _vp, _vp]),
+    ("ggml_cdna4_op_cpy", _int, [_vp, _vp, _int, _vp]),
+    ("ggml_cdna4_op_mul_mat_f", _int, [_vp, _vp, _vp, _vp]),
+    ("ggml_cdna4_op_rope", _int, [_vp, _vp, _vp, _vp, _int, _int, _int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
+    ("ggml_cdna4_dequantize_row", _int, [_int, _vp, _vp, _i64, _vp]),
 ]
+
+
+class Tensor(C.Structure):
+    """struct ggml_cdna4_tensor (include/ggml_cdna4.h)"""
+    _fields_ = [("data", C.c_void_p), ("type", C.c_int32), ("reserved", C.c_int32), ("ne", C.c_int64 * 4), ("nb", C.c_int64 * 4)]
 
 _lib = None
 
@@ -39,6 +56,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NativeError("%s not found — run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no CPU fallback)" % LIB_PATH)
+        # torch ships its own libamdhip64 (SONAME libamdhip64.so.7).  Map it FIRST so our library binds to the
+        # same HIP runtime instance torch allocates memory / creates streams with; loading ours first would pull
+        # in /opt/rocm's copy as a second runtime in the process.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(l, name)          # AttributeError if the .so does not export a declared symbol

@@ -98,6 +98,57 @@ int ggml_cdna4_quantize_q8_K(const float * x, int64_t x_row_stride, int64_t K, i
 int ggml_cdna4_quantize_q8_0(const float * x, int64_t x_row_stride, int64_t K, int64_t B,
                              int8_t * qs, float * d, void * xh, int ref_rounding, void * stream);
 
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Supporting ops (plain HIP kernels; the reference's counterparts are the ggml_compute_forward_* functions of
+ * src/ggml-cpu/ggml-cpu.c cited per entry).  Tensors are described without ggml types: data pointer, element
+ * type (enum ggml_cdna4_type / GGML_CDNA4_TYPE_I32 = 26), ne[4] elements and nb[4] BYTE strides, in ggml's
+ * dimension order (ne[0] fastest) — exactly the fields of struct ggml_tensor (include/ggml.h:576-608).
+ * --------------------------------------------------------------------------------------------------------- */
+#define GGML_CDNA4_TYPE_I32 26
+
+typedef struct ggml_cdna4_tensor {
+    void *  data;
+    int32_t type;
+    int32_t reserved;
+    int64_t ne[4];
+    int64_t nb[4];
+} ggml_cdna4_tensor;
+
+enum ggml_cdna4_binary_op { GGML_CDNA4_ADD = 0, GGML_CDNA4_SUB = 1, GGML_CDNA4_MUL = 2, GGML_CDNA4_DIV = 3 };
+enum ggml_cdna4_unary_op  { GGML_CDNA4_GELU = 0, GGML_CDNA4_GELU_QUICK = 1, GGML_CDNA4_SILU = 2, GGML_CDNA4_RELU = 3, GGML_CDNA4_TANH = 4 };
+
+/* dst = src0 (op) broadcast(src1), all F32 — ggml_compute_forward_add/sub/mul/div, ggml-cpu.c:4052-5260 */
+int ggml_cdna4_op_binary(int op, const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * src1, const ggml_cdna4_tensor * dst, void * stream);
+/* dst = src0 * scale — ggml_compute_forward_scale, ggml-cpu.c:8047-8100 */
+int ggml_cdna4_op_scale(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, float scale, void * stream);
+/* LayerNorm without affine / RMSNorm over ne[0] — ggml-cpu.c:6929-6978, 7000-7046 */
+int ggml_cdna4_op_norm(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, float eps, int rms, void * stream);
+/* softmax(src0*scale + slope*mask) over ne[0]; mask (F32 or F16, [ne0, ne1]) may be NULL; ALiBi slopes from
+ * max_bias as ggml-cpu.c:8848-8944 */
+int ggml_cdna4_op_soft_max(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * mask, const ggml_cdna4_tensor * dst, float scale, float max_bias, void * stream);
+/* dst = src0 with dst[.., j, i] = -inf for i > n_past + j — ggml-cpu.c:8760-8830 */
+int ggml_cdna4_op_diag_mask_inf(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, int n_past, void * stream);
+/* element-wise activations; GELU reproduces the CPU's fp16 lookup-table semantics (ggml-cpu.c:1759-1774) */
+int ggml_cdna4_op_unary(int op, const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, void * stream);
+/* dst[.., i10, :] = to_float(src0 row ids[i10, i11, i12]) — ggml_compute_forward_get_rows, ggml-cpu.c:8353-8560;
+ * src0 in {F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K} */
+int ggml_cdna4_op_get_rows(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * ids, const ggml_cdna4_tensor * dst, void * stream);
+/* CPY / DUP / CONT: copy with conversion between tensors of equal element count — ggml_compute_forward_dup,
+ * ggml-cpu.c:2860-4050.  Pairs: {F32,F16}->{F32,F16}; F32->{Q8_0,Q4_0}; {Q4_0,Q8_0,Q4_K,Q5_K,Q6_K}->F32.
+ * q8_0_ref_rounding: 0 = the CPU backend's from_float (AVX2 body), 1 = quantize_row_q8_0_ref. */
+int ggml_cdna4_op_cpy(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, int q8_0_ref_rounding, void * stream);
+/* MUL_MAT with F32 or F16 weights and F32 activations, any strides / batch broadcast —
+ * ggml_compute_forward_mul_mat with vec_dot_f32 / vec_dot_f16 (ggml-cpu.c:7428-7605) */
+int ggml_cdna4_op_mul_mat_f(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * src1, const ggml_cdna4_tensor * dst, void * stream);
+/* rotary embedding, modes NORMAL (0) and NEOX (2), with freq_base/freq_scale/ext_factor(yarn)/attn_factor and
+ * optional freq_factors — ggml_compute_forward_rope_f32, ggml-cpu.c:9255-9625 */
+int ggml_cdna4_op_rope(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * pos, const ggml_cdna4_tensor * freq_factors, const ggml_cdna4_tensor * dst,
+                       int n_dims, int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor, float attn_factor,
+                       float beta_fast, float beta_slow, void * stream);
+/* to_float of a quantized row buffer: y[k] f32 <- x (type) — dequantize_row_*, src/ggml-quants.c */
+int ggml_cdna4_dequantize_row(int type, const void * x, float * y, int64_t k, void * stream);
+
 #ifdef __cplusplus
 }
 #endif

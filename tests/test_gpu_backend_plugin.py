@@ -26,6 +26,20 @@ def _run(op):
     return r.returncode, txt
 
 
+SUPPORTING_OPS = ["ADD", "SUB", "MUL", "DIV", "SCALE", "NORM", "RMS_NORM", "SOFT_MAX", "DIAG_MASK_INF", "GELU", "GELU_QUICK",
+                  "SILU", "RELU", "TANH", "GET_ROWS", "CPY", "CONT", "DUP", "ROPE"]
+
+
+@pytest.mark.parametrize("op", SUPPORTING_OPS)
+def test_stock_harness_supporting_ops(op):
+    """plain-HIP supporting ops vs ggml-cpu through the reference's own per-op gates (1e-7 NMSE default,
+    tests/test-backend-ops.cpp:319-321; CPY 1e-6 :1451-1453; SOFT_MAX 1e-6 :2374-2376)"""
+    rc, txt = _run(op)
+    n_ok = len(re.findall(r": OK$", txt, re.M))
+    assert rc == 0 and "FAIL" not in txt, txt[-4000:]
+    assert n_ok >= 1, "no supported case ran for %s\n%s" % (op, txt[-2000:])
+
+
 @pytest.mark.parametrize("op", ["MUL_MAT", "MUL_MAT_ID"])
 def test_stock_harness(op):
     rc, txt = _run(op)

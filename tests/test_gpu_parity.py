@@ -37,6 +37,13 @@ def _x(seed, b, k, kind="uniform"):
     return x
 
 
+def _same_f16(got, want):
+    """fp16 images must agree value for value (+0 == -0: the sign of a zero product is not meaningful)"""
+    g, w = got.astype(np.float32), want.astype(np.float32)
+    bad = np.argwhere(g != w)
+    assert bad.size == 0, "%d mismatches, first at %s: got %r want %r" % (len(bad), bad[0], g[tuple(bad[0])], w[tuple(bad[0])])
+
+
 # ------------------------------------------------------------------------------------------------ quantizers
 @pytest.mark.parametrize("kind", ["uniform", "normal", "ties", "cos"])
 def test_quantize_q8_K_bit_exact(gu, kind):
@@ -54,7 +61,7 @@ def test_quantize_q8_K_bit_exact(gu, kind):
     assert np.array_equal(qs, rq)
     assert np.array_equal(bs, rb)
     want = (np.repeat(rd, 256, axis=1) * rq.astype(np.float32)).astype(np.float16)
-    assert np.array_equal(gu.uninterleave(xh).view(np.uint16), want.view(np.uint16))
+    _same_f16(gu.uninterleave(xh), want)
 
 
 @pytest.mark.parametrize("ref_rounding", [False, True])
@@ -71,7 +78,7 @@ def test_quantize_q8_0_bit_exact(gu, kind, ref_rounding):
     assert np.array_equal(qs, rq)
     assert np.array_equal(d, rd)
     want = (np.repeat(rd, 32, axis=1) * rq.astype(np.float32)).astype(np.float16)
-    assert np.array_equal(gu.uninterleave(xh).view(np.uint16), want.view(np.uint16))
+    _same_f16(gu.uninterleave(xh), want)
 
 
 # ------------------------------------------------------------------------------------------------ golden
@@ -172,7 +179,8 @@ def test_gemm_matches_gemv_statistically(gu):
     xd = gu.to_dev(np.concatenate([x, x]))
     yv = ops.mul_mat(a, xd[:8], path=ops.PATH_GEMV).cpu().numpy()
     ym = ops.mul_mat(a, xd, path=ops.PATH_GEMM).cpu().numpy()
-    assert R.rel_l2(ym[:8], yv) < TOL_GEMM and np.array_equal(ym[:8], ym[8:])
+    assert R.rel_l2(ym[:8], yv) < TOL_GEMM
+    assert np.array_equal(ym[:8], ym[8:])       # deterministic: default path uses no split-K atomics
 
 
 # ------------------------------------------------------------------------------------------------ full size
