@@ -169,11 +169,11 @@ template <int NB> struct Unit<CDNA4_Q8_0, NB> {
     }
 };
 
-template <int TYPE, int NB, bool IDS>
+template <int TYPE, int NB, bool IDS, int ROWS>
 __global__ __launch_bounds__(256) void k_gemv_q(const cdna4_gemv_args a) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.M) return;                                                  // wave-uniform
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= a.M) return;                                                 // wave-uniform
     const uint8_t *Wb = a.W;
     int col[NB], ycol[NB];
     if (IDS) {
@@ -186,28 +186,41 @@ __global__ __launch_bounds__(256) void k_gemv_q(const cdna4_gemv_args a) {
 #pragma unroll
         for (int c = 0; c < NB; c++) { col[c] = blockIdx.y * NB + c; ycol[c] = col[c]; }
     }
-    const uint8_t *wrow = Wb + (int64_t)row * a.w_row_bytes;
-    float acc[NB];
+    // ROWS weight rows per wave: the activation loads (same addresses for every row) are issued once and the
+    // rows' superblock loads are all in flight together
+    float acc[ROWS][NB];
 #pragma unroll
-    for (int c = 0; c < NB; c++) acc[c] = 0.f;
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+        for (int c = 0; c < NB; c++) acc[r][c] = 0.f;
     const int nunits = a.K / Unit<TYPE, NB>::UK;
-    for (int u = lane; u < nunits; u += 64) Unit<TYPE, NB>::dot(wrow, u, a, col, acc);
+    for (int u = lane; u < nunits; u += 64) {
 #pragma unroll
-    for (int c = 0; c < NB; c++) {
-        const float s = wave_sum(acc[c]);
-        if (lane == 0) a.Y[(int64_t)ycol[c] * a.y_col_stride + row] = s;
+        for (int r = 0; r < ROWS; r++) {
+            const int row = min(row0 + r, a.M - 1);
+            Unit<TYPE, NB>::dot(Wb + (int64_t)row * a.w_row_bytes, u, a, col, acc[r]);
+        }
     }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            const float s = wave_sum(acc[r][c]);
+            if (lane == 0 && row0 + r < a.M) a.Y[(int64_t)ycol[c] * a.y_col_stride + row0 + r] = s;
+        }
 }
 
 template <int TYPE, int NB>
 static void launch_nb(const cdna4_gemv_args &a, hipStream_t st) {
-    hipLaunchKernelGGL((k_gemv_q<TYPE, NB, false>), dim3((a.M + 3) / 4, 1), dim3(256), 0, st, a);
+    // few columns and many rows: 4 rows per wave (fewer, fatter waves); otherwise one row per wave
+    if (NB <= 2 && a.M >= 2048) hipLaunchKernelGGL((k_gemv_q<TYPE, NB, false, 4>), dim3((a.M + 15) / 16, 1), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_gemv_q<TYPE, NB, false, 1>), dim3((a.M + 3) / 4, 1), dim3(256), 0, st, a);
 }
 template <int TYPE>
 static int launch_type(const cdna4_gemv_args &a0, hipStream_t st) {
     cdna4_gemv_args a = a0;
     if (a.ids) {
-        hipLaunchKernelGGL((k_gemv_q<TYPE, 1, true>), dim3((a.M + 3) / 4, a.ncol), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_gemv_q<TYPE, 1, true, 1>), dim3((a.M + 3) / 4, a.ncol), dim3(256), 0, st, a);
         CDNA4_CHECK_LAUNCH();
         return 0;
     }
