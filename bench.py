@@ -208,7 +208,7 @@ def main():
 
     # ---- the exchange step of a row-split layer, timed separately: all-gather of the output shards ------------
     if dist is not None:
-        yfull = torch.empty((world, B, M_PER_GPU), dtype=torch.float32, device=dev)
+        yfull = torch.empty((world * B, M_PER_GPU), dtype=torch.float32, device=dev)
         for _ in range(3):
             step(); dist.all_gather_into_tensor(yfull, y)
         barrier(); t0 = time.perf_counter()

@@ -293,27 +293,42 @@ __global__ __launch_bounds__(256) void k_gemm_q(const gemm_params p) {
 
 
 // ------------------------------------------------------------------------------------------------------------
-// Pipelined K-quant kernel (Q4_K / Q5_K, 64-row activation tile): one barrier per SUPERBLOCK (256 k) instead of
-// per 64-k slice, and an NST-deep LDS ring filled by global_load_lds two superblocks ahead.  A wave never drains
-// its DMA queue in the main loop: `s_waitcnt vmcnt(NL)` leaves the next stage's NL loads in flight across the raw
-// s_barrier (cdna_hip_programming.md §5 "Pipelining across barriers").  Stage = [X: TB rows x 256 halves, 16-B
-// chunks XOR-swizzled by (row & 15) on the source side][W: 128 packed superblocks, untouched].
+// Pipelined K-quant kernel (Q4_K / Q5_K).  PMC on the first version showed the waves ISSUE-bound, not latency-bound
+// (SQ_ACTIVE_INST_ANY 62 % vs MFMA busy 18 % at one wave per SIMD): the ~20 VALU ops that unpack 8 weights must be
+// amortised over more MFMAs.  Hence the 128-wide activation tile: every dequantized B fragment feeds BNF = 4 MFMAs.
+//   * stage = SKG 64-k groups of the superblock (SKG = 2 for the 128-wide tile, 4 for the 64-wide one):
+//       X: TB rows x SKG*128 B, 16-B chunks XOR-swizzled by (row & 15) on the SOURCE address (conflict-free b128)
+//       W: 128 rows x NPH 16-B pieces copied HBM->LDS untouched: header (+qh for Q5_K) + this stage's nibbles;
+//          row strides 80/112/144/176 B are all bank-conflict-free for ds_read_b128
+//   * 3-deep LDS ring, loads issued two stages ahead by global_load_lds; `s_waitcnt vmcnt(NL)` + raw s_barrier keep
+//     the next stage's NL DMA instructions in flight across the barrier (never vmcnt(0) in the main loop).
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TYPE, int BNF, int NST>
+template <int TYPE, int SKG> struct WStage {        // which 16-B pieces of a superblock a stage needs
+    static constexpr int NP = QT<TYPE>::BYTES / 16;
+    static constexpr int HDR = TYPE == CDNA4_Q5_K ? 3 : 1;             // header (+ qh) pieces, needed by every stage
+    static constexpr int NPH = SKG == 4 ? NP : HDR + 2 * SKG;          // pieces per row per stage (2 per 64-k group)
+    __device__ static __forceinline__ int src_piece(int p, int part) { return (SKG == 4 || p < HDR) ? p : HDR + 2 * SKG * part + (p - HDR); }
+};
+
+template <int TYPE, int BNF, int SKG>
 __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
+    typedef WStage<TYPE, SKG> WSt;
+    constexpr int NST = 3;
     constexpr int TB = 32 * BNF;
-    constexpr int XS = TB * 512;                 // bytes of X per stage (TB rows x 256 halves)
+    constexpr int RS = SKG * 128;                // X row stride in a stage (bytes)
+    constexpr int XS = TB * RS;                  // X bytes per stage
     constexpr int BLK = QT<TYPE>::BYTES;
-    constexpr int WS = 128 * BLK;
-    constexpr int NP = BLK / 16;
+    constexpr int WRS = WSt::NPH * 16;           // W row stride in a stage
+    constexpr int WS = 128 * WRS;
     constexpr int ST = XS + WS;                  // one ring slot
-    constexpr int XL = XS / 16 / 256;            // X global_load_lds per thread per stage
-    constexpr int WL = (2 * NP + 3) / 4;         // W global_load_lds per wave per stage (tail pieces are loaded twice)
-    constexpr int NL = XL + WL;                  // DMA instructions per wave per stage
-    constexpr int D = NST - 1;                   // prefetch distance in stages
+    constexpr int XL = XS / 16 / 256;            // X DMA instructions per thread per stage
+    constexpr int NWI = 128 * WSt::NPH / 64;     // W DMA wave-instructions per stage
+    constexpr int WL = (NWI + 3) / 4;            // ... per wave (the tail re-loads earlier pieces)
+    constexpr int NL = XL + WL;
+    constexpr int PARTS = 4 / SKG;               // stages per superblock
     static_assert(NST * ST <= 160 * 1024, "LDS ring does not fit");
-    static_assert(D == 1 || D == 2, "ring depth 2 or 3");
+    static_assert(SKG * 8 >= 16, "swizzle needs >= 16 chunks per row");
     __shared__ __attribute__((aligned(16))) uint8_t smem[NST * ST];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
@@ -324,6 +339,7 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
     const int ks = L % p.splitk, tile_m = L / p.splitk;
     const int m0 = tile_m * 128, b0 = tile_b * TB;
     const int nsb = p.K / 256 / p.splitk, sb0 = ks * nsb;
+    const int nstage = nsb * PARTS;
 
     floatx16 acc[BNF];
 #pragma unroll
@@ -331,59 +347,78 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
 
-    auto issue = [&](int s, int slot) {
-        uint8_t *xs = smem + slot * ST, *ws = xs + XS;
-        const int64_t k0 = (int64_t)(sb0 + s) * 256;
+    // DMA source addresses = wave-uniform 64-bit base (SGPRs, advanced by scalar adds per stage) + a per-lane 32-bit
+    // byte offset that never changes: no vector address arithmetic inside the main loop.
+    uint32_t xvoff[XL], wvoff[PARTS][WL];
 #pragma unroll
-        for (int i = 0; i < XL; i++) {
-            const int pc = i * 256 + tid, row = pc >> 5, c = (pc & 31) ^ (row & 15);
-            const int b = min(b0 + row, p.B - 1);
-            glds16(p.xh + (int64_t)b * p.xh_row + k0 + c * 8, xs + (i * 256 + wave * 64) * 16);
-        }
+    for (int i = 0; i < XL; i++) {
+        const int pc = i * 256 + tid, row = pc / (SKG * 8), c = (pc % (SKG * 8)) ^ (row & 15);
+        xvoff[i] = (uint32_t)(min(b0 + row, p.B - 1) - b0) * (uint32_t)(p.xh_row * 2) + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < WL; i++) {
+        int idx = wave + 4 * i;
+        if (idx >= NWI) idx -= 4;                                        // wave-uniform: re-load this wave's previous piece
+        const int pc = idx * 64 + lane, row = pc / WSt::NPH, c = pc % WSt::NPH;
+        const uint32_t ro = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
+#pragma unroll
+        for (int part = 0; part < PARTS; part++) wvoff[part][i] = ro + WSt::src_piece(c, part) * 16;
+    }
+    const char *const xbase = (const char *)p.xh + (int64_t)b0 * p.xh_row * 2 + (int64_t)sb0 * 512;
+    const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
+
+    auto issue = [&](int sbr, int part, int slot) {                      // sbr = superblock relative to sb0
+        uint8_t *xs = smem + slot * ST, *ws = xs + XS;
+        const char *xsrc = xbase + (int64_t)sbr * 512 + part * (SKG * 128);
+        const char *wsrc = wbase + (int64_t)sbr * BLK;
+#pragma unroll
+        for (int i = 0; i < XL; i++) glds16(xsrc + xvoff[i], xs + (i * 256 + wave * 64) * 16);
 #pragma unroll
         for (int i = 0; i < WL; i++) {
             int idx = wave + 4 * i;
-            if (idx >= 2 * NP) idx -= 4;                         // wave-uniform: re-load this wave's previous piece
-            const int pc = idx * 64 + lane, row = pc / NP, c = pc % NP;
-            const int m = min(m0 + row, p.M - 1);
-            glds16(p.W + (int64_t)m * p.w_row_bytes + (int64_t)(sb0 + s) * BLK + c * 16, ws + idx * 1024);
+            if (idx >= NWI) idx -= 4;
+            glds16(wsrc + wvoff[part][i], ws + idx * 1024);
         }
     };
 
-    const int xrow_off = j * 512, xswz = j & 15;
-    auto compute = [&](int slot) {
+    const int xrow_off = j * RS, xswz = j & 15;
+    auto compute = [&](int slot, int part) {                             // `part` is a compile-time constant at every call site
         const uint8_t *xs = smem + slot * ST + xrow_off;
-        const uint8_t *wrow = smem + slot * ST + XS + (wave * 32 + j) * BLK;
+        const uint8_t *wrow = smem + slot * ST + XS + (wave * 32 + j) * WRS;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
+        for (int gl = 0; gl < SKG; gl++) {
             Raw<TYPE> raw;
-            raw.load(wrow, g, h);
+            raw.load(wrow, gl, h);
             half8_t wf[4];
-            raw.frags(g, h, wf);
+            raw.frags(part * SKG + gl, h, wf);
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
-                const int coff = ((g * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
+                const int coff = ((gl * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
 #pragma unroll
                 for (int bf = 0; bf < BNF; bf++) {
-                    const half8_t xa = *reinterpret_cast<const half8_t *>(xs + bf * 32 * 512 + coff);
+                    const half8_t xa = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
                     acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, wf[kk], acc[bf], 0, 0, 0);
                 }
             }
         }
     };
 
-    issue(0, 0);
-    if (D == 2 && nsb > 1) issue(1, 1);
-    int slot = 0, slot_issue = D % NST;
-    for (int s = 0; s < nsb; s++) {
-        // stages s+1 .. min(s+D-1, nsb-1) may stay in flight
-        if (D == 2 && s + 1 < nsb) wait_vmcnt<NL>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (s + D < nsb) issue(s + D, slot_issue);
-        compute(slot);
-        slot = slot + 1 == NST ? 0 : slot + 1;
-        slot_issue = slot_issue + 1 == NST ? 0 : slot_issue + 1;
+    // stage s = (superblock s / PARTS, part s % PARTS); ring slot = s % 3; loads run two stages ahead
+    issue(0, 0, 0);
+    if (nstage > 1) issue(1 / PARTS, 1 % PARTS, 1);
+    int slot = 0;
+    for (int sb = 0; sb < nsb; sb++) {
+#pragma unroll
+        for (int part = 0; part < PARTS; part++) {
+            const int s = sb * PARTS + part;
+            if (s + 1 < nstage) wait_vmcnt<NL>(); else wait_vmcnt<0>();  // stage s+1 may stay in flight
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int slot2 = slot >= 1 ? slot - 1 : 2;                   // (slot + 2) % 3
+            if (s + 2 < nstage) issue(sb + (part + 2) / PARTS, (part + 2) % PARTS, slot2);
+            compute(slot, part);
+            slot = slot == 2 ? 0 : slot + 1;
+        }
     }
 
     const int m = m0 + wave * 32 + j;
@@ -430,17 +465,17 @@ static int launch_variant(const cdna4_gemm_args &a, int splitk, hipStream_t st) 
     return 0;
 }
 
-template <int TYPE, int NST>
+template <int TYPE, int BNF>
 static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
     gemm_params p;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
-    p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 63) / 64;
+    p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 32 * BNF - 1) / (32 * BNF);
     if (splitk > 1) {
         const int64_t n = (int64_t)a.M * a.B;
         hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.Y, a.y_row_elems, a.M, a.B);
     }
-    hipLaunchKernelGGL((k_gemm_kq_pipe<TYPE, 2, NST>), dim3(p.tiles_m * p.tiles_b * splitk), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((k_gemm_kq_pipe<TYPE, BNF, 2>), dim3(p.tiles_m * p.tiles_b * splitk), dim3(256), 0, st, p);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
@@ -449,18 +484,23 @@ template <int TYPE>
 static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     constexpr bool CAN_LDS = QT<TYPE>::KQ && (QT<TYPE>::BYTES % 16 == 0);
     // variant: bit0 = LDS weight staging (Q4_K/Q5_K only), bit1 = 128-wide activation tile, bit3 = the older
-    // slice-per-barrier kernel instead of the pipelined superblock-per-barrier one.  0 = auto.
+    // slice-per-barrier kernel instead of the pipelined one.  0 = auto: widest tile that the batch fills.
     int variant = a.variant;
-    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0);
+    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0);
     const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
     const bool wide = (variant & 2) != 0;
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
     const int kunits = QT<TYPE>::KQ ? a.K / 256 : a.K / 64;
     int splitk = a.splitk;
-    if (splitk <= 0) splitk = 1;       // split-K sums with fp32 atomics (order-dependent rounding): opt-in only
+    if (splitk <= 0) {
+        // auto: at most 2.  Two fp32 contributions added to a zeroed output are order-independent (a+b == b+a), so the
+        // result stays deterministic; deeper splits (atomic sums of >2 terms) are opt-in only.
+        const int tiles = ((a.M + 127) / 128) * ((a.B + (wide ? 127 : 63)) / (wide ? 128 : 64));
+        splitk = (tiles <= 160 && kunits % 2 == 0 && kunits >= 4) ? 2 : 1;
+    }
     if (splitk < 1 || kunits % splitk) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
     if constexpr (CAN_LDS) {
-        if (wlds && !wide && !(variant & 8)) { if constexpr (TYPE == CDNA4_Q4_K) return launch_pipe<TYPE, 3>(a, splitk, st); else return launch_pipe<TYPE, 2>(a, splitk, st); }
+        if (wlds && !(variant & 8)) return wide ? launch_pipe<TYPE, 4>(a, splitk, st) : launch_pipe<TYPE, 2>(a, splitk, st);
         if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
     }
     return wide ? launch_variant<TYPE, 4, false>(a, splitk, st) : launch_variant<TYPE, 2, false>(a, splitk, st);

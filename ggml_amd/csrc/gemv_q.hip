@@ -10,6 +10,7 @@
 // Also serves MUL_MAT_ID (per-column expert base, ids read on the device — no host sync).
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
 
@@ -212,8 +213,10 @@ __global__ __launch_bounds__(256) void k_gemv_q(const cdna4_gemv_args a) {
 
 template <int TYPE, int NB>
 static void launch_nb(const cdna4_gemv_args &a, hipStream_t st) {
-    // few columns and many rows: 4 rows per wave (fewer, fatter waves); otherwise one row per wave
-    if (NB <= 2 && a.M >= 2048) hipLaunchKernelGGL((k_gemv_q<TYPE, NB, false, 4>), dim3((a.M + 15) / 16, 1), dim3(256), 0, st, a);
+    // one row per wave.  (4 rows per wave — fewer, fatter waves sharing the activation loads — measured SLOWER on
+    // MI355X: 6.7 vs 5.3 us cold at 4096x4096; CDNA4_GEMV_ROWS=2 selects the 2-row variant for experiments.)
+    static const int rows_env = getenv("CDNA4_GEMV_ROWS") ? atoi(getenv("CDNA4_GEMV_ROWS")) : 1;
+    if (rows_env == 2 && NB <= 2) hipLaunchKernelGGL((k_gemv_q<TYPE, NB, false, 2>), dim3((a.M + 7) / 8, 1), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_gemv_q<TYPE, NB, false, 1>), dim3((a.M + 3) / 4, 1), dim3(256), 0, st, a);
 }
 template <int TYPE>

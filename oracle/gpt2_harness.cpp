@@ -11,6 +11,27 @@
 #include "examples/gpt-2/main-backend.cpp"
 #undef main
 
+// per-node comparison of the gpt-2 graph between the chosen backend and the CPU backend (what test-backend-ops does
+// for single ops, ggml_backend_compare_graph_backend, src/ggml-backend.cpp:1814-1851) — prints rel-L2 per node
+static bool cmp_cb(int index, struct ggml_tensor * t1, struct ggml_tensor * t2, void * ud) {
+    (void)ud;
+    if (t1->type != GGML_TYPE_F32) return true;
+    const size_t n = ggml_nelements(t1);
+    if (!ggml_is_contiguous(t1) || !ggml_is_contiguous(t2)) { printf("node %4d %-14s %-24s (non-contiguous, skipped)\n", index, ggml_op_desc(t1), t1->name); return true; }
+    std::vector<float> a(n), b(n);
+    ggml_backend_tensor_get(t1, a.data(), 0, n * 4);
+    ggml_backend_tensor_get(t2, b.data(), 0, n * 4);
+    double num = 0, den = 0; size_t nbad = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (std::isinf(b[i]) && a[i] == b[i]) continue;
+        if (!std::isfinite(a[i]) || !std::isfinite(b[i])) { nbad++; continue; }
+        num += ((double)a[i] - b[i]) * ((double)a[i] - b[i]); den += (double)b[i] * b[i];
+    }
+    printf("node %4d %-14s %-24s [%5lld,%5lld,%3lld] rel_l2=%.3e%s\n", index, ggml_op_desc(t1), t1->name, (long long)t1->ne[0], (long long)t1->ne[1], (long long)t1->ne[2],
+           den > 0 ? sqrt(num / den) : sqrt(num), nbad ? " NONFINITE-MISMATCH" : "");
+    return true;
+}
+
 int main(int argc, char ** argv) {
     if (argc < 8) { fprintf(stderr, "usage: %s model backend plugin out n_prompt n_decode threads\n", argv[0]); return 2; }
     const std::string fname = argv[1], backend = argv[2], plugin = argv[3], out = argv[4];
@@ -39,6 +60,23 @@ int main(int argc, char ** argv) {
     std::vector<gpt_vocab::id> prompt(n_prompt);
     for (auto & t : prompt) t = next_tok();
 
+    if (out == "COMPARE") {     // node-by-node against the CPU backend, first on the prompt batch then on one decode step
+        ggml_backend_t cpu = ggml_backend_cpu_init();
+        ggml_backend_cpu_set_n_threads(cpu, n_threads);
+        int n_past = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            std::vector<gpt_vocab::id> toks = pass == 0 ? prompt : std::vector<gpt_vocab::id>{ next_tok() };
+            const int N = (int)toks.size();
+            struct ggml_cgraph * gf = gpt2_graph(model, n_past, N);
+            ggml_gallocr_alloc_graph(allocr, gf);
+            ggml_backend_tensor_set(ggml_graph_get_tensor(gf, "embd"), toks.data(), 0, N * sizeof(int32_t));
+            for (int i = 0; i < N; ++i) { int32_t v = n_past + i; ggml_backend_tensor_set(ggml_graph_get_tensor(gf, "position"), &v, i * sizeof(int32_t), sizeof(v)); }
+            printf("=== pass %d: n_past=%d N=%d ===\n", pass, n_past, N);
+            ggml_backend_compare_graph_backend(model.backend, cpu, gf, cmp_cb, NULL);
+            n_past += N;
+        }
+        return 0;
+    }
     FILE * f = fopen(out.c_str(), "wb");
     std::vector<float> logits;
     int n_past = 0;
