@@ -25,7 +25,7 @@ static ws_view carve(int type, int64_t K, int64_t B, void *base) {
     v.qs = (int8_t *)(p + off); off += align256((size_t)(B * K));
     v.d = (float *)(p + off); off += align256((size_t)(B * (K / qka)) * 4);
     v.bsums = (int16_t *)(p + off); off += align256((size_t)(B * (K / 16)) * 2);
-    v.xh = (void *)(p + off); off += align256((size_t)(B * K) * 2);
+    v.xh = (void *)(p + off); off += align256((size_t)(B * ((K + 127) / 128 * 128)) * 2);    // whole 128-k panels
     v.total = off;
     return v;
 }
@@ -33,6 +33,7 @@ static ws_view carve(int type, int64_t K, int64_t B, void *base) {
 extern "C" {
 
 int ggml_cdna4_api_version(void) { return GGML_CDNA4_API_VERSION; }
+void ggml_cdna4_debug_trace(void *device_buffer) { cdna4_debug_trace = device_buffer; }
 const char *ggml_cdna4_last_error(void) { return g_err; }
 int ggml_cdna4_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 int ggml_cdna4_set_device(int device) { hipError_t e = hipSetDevice(device); return e == hipSuccess ? 0 : cdna4_set_error(e, __FILE__, __LINE__); }

@@ -35,3 +35,5 @@ struct cdna4_gemm_args {
 };
 int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st);
 bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B);
+
+extern void *cdna4_debug_trace;

@@ -22,6 +22,7 @@
 //    keeps the tiles that share a weight panel on one XCD's L2.
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -31,6 +32,17 @@ __device__ __forceinline__ void glds16(const void *g, void *l_wave_base) {
 __device__ __forceinline__ half2_t as_h2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
 
 #define MAGIC2 0x64006400u   // two fp16 1024.0: (MAGIC2 | q) == 1024 + q exactly for q < 1024
+
+// mask / magic held in VGPRs (made opaque to the optimizer once per kernel): `(x & mask) | magic` then selects a single
+// v_and_or_b32 — with two literals the compiler must split it into v_and + v_or (VOP3 takes one literal).
+struct DqConst {
+    uint32_t m4, m8, magic;
+    __device__ __forceinline__ void init() {
+        m4 = 0x000F000Fu; m8 = 0x00FF00FFu; magic = MAGIC2;
+        asm volatile("" : "+v"(m4), "+v"(m8), "+v"(magic));
+    }
+};
+__device__ __forceinline__ uint32_t nib(uint32_t x, const DqConst &c) { return (x & c.m4) | c.magic; }
 
 // the 8-halves chunk (of the 64-k slice) that MFMA k-step kk / lane-half h consumes
 template <int TYPE> __device__ __forceinline__ int chunk_of(int kk, int h) {
@@ -54,6 +66,20 @@ template <int TYPE> struct Raw;
 template <> struct Raw<CDNA4_Q4_K> {
     u32x4 hdr, q;
     template <typename P> __device__ __forceinline__ void load(P blk, int g, int h) { hdr = ld_u32x4(blk); q = ld_u32x4(blk + 16 + 32 * g + 16 * h); }
+    __device__ __forceinline__ void frags(int g, int h, half8_t (&f)[4], const DqConst &c) const {
+        const uint32_t sc[3] = {hdr.y, hdr.z, hdr.w};
+        uint32_t s0, m0, s1, m1;
+        k4_scale_min(sc, 2 * g, s0, m0); k4_scale_min(sc, 2 * g + 1, s1, m1);
+        const float d = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
+        const half_t sl = (half_t)(d * (float)s0), sh = (half_t)(d * (float)s1);
+        const half2_t SL = {sl, sl}, SH = {sh, sh};
+        const half2_t CL = splat(8.f * (float)sl - dmin * (float)m0), CH = splat(8.f * (float)sh - dmin * (float)m1);
+        const half2_t off = {(half_t)-1032.f, (half_t)-1032.f};
+        f[0] = finish_frag(nib(q.x, c), nib(q.x >> 8, c), nib(q.y, c), nib(q.y >> 8, c), off, SL, CL);
+        f[1] = finish_frag(nib(q.z, c), nib(q.z >> 8, c), nib(q.w, c), nib(q.w >> 8, c), off, SL, CL);
+        f[2] = finish_frag(nib(q.x >> 4, c), nib(q.x >> 12, c), nib(q.y >> 4, c), nib(q.y >> 12, c), off, SH, CH);
+        f[3] = finish_frag(nib(q.z >> 4, c), nib(q.z >> 12, c), nib(q.w >> 4, c), nib(q.w >> 12, c), off, SH, CH);
+    }
     __device__ __forceinline__ void frags(int g, int h, half8_t (&f)[4]) const {
         const uint32_t sc[3] = {hdr.y, hdr.z, hdr.w};
         uint32_t s0, m0, s1, m1;
@@ -76,6 +102,7 @@ template <> struct Raw<CDNA4_Q5_K> {
     template <typename P> __device__ __forceinline__ void load(P blk, int g, int h) {
         hdr = ld_u32x4(blk); qh = ld_u32x4(blk + 16 + 16 * h); q = ld_u32x4(blk + 48 + 32 * g + 16 * h);
     }
+    __device__ __forceinline__ void frags(int g, int h, half8_t (&f)[4], const DqConst &) const { frags(g, h, f); }
     // value 1024 + nibble + 16*bit for bytes (0,2) [sh=0] or (1,3) [sh=8] of x; bit taken from hq
     static __device__ __forceinline__ uint32_t pair(uint32_t x, uint32_t hq, int nib_shift, int bit, int sh) {
         return ((x >> (nib_shift + sh)) & 0x000F000Fu) | ((((hq >> (bit + sh)) & 0x00010001u) << 4)) | MAGIC2;
@@ -161,11 +188,15 @@ template <> struct Raw<CDNA4_Q8_0> {
 };
 
 // ------------------------------------------------------------------------------------------------------------
+void *cdna4_debug_trace = nullptr;   // profiling hook (ggml_cdna4_debug_trace): device buffer for k_gemm_kq_w8<.., true>
+
 struct gemm_params {
     const uint8_t *W; int64_t w_row_bytes;
-    const half_t *xh; int64_t xh_row;
+    const half_t *xh; int64_t xh_row;   // xh: k-panel-major fp16 image (see quantize_act.hip); xh_row unused
     float *Y; int64_t y_row;
     int M, K, B, splitk, tiles_m, tiles_b;
+    float *partial; unsigned *flags;   // split-K = 2 hand-off (k_gemm_kq_w8): partial tiles [tile][128][128] + one flag per tile
+    unsigned long long *trace;   // profiling builds only (k_gemm_kq_w8<TYPE, true>): per-phase s_memtime stamps of block 0
 };
 
 template <int TYPE, int BNF, bool WLDS>
@@ -207,7 +238,7 @@ __global__ __launch_bounds__(256) void k_gemm_q(const gemm_params p) {
         for (int i = 0; i < BNF; i++) {
             const int pc = i * 256 + tid, row = pc >> 3, c = (pc & 7) ^ ((row >> 1) & 7);
             const int b = min(b0 + row, p.B - 1);
-            glds16(p.xh + (int64_t)b * p.xh_row + k0 + c * 8, Xs + buf * XS + (i * 256 + wave * 64) * 16);
+            glds16(p.xh + ((int64_t)(k0 >> 7) * p.B + b) * 128 + (k0 & 127) + c * 8, Xs + buf * XS + (i * 256 + wave * 64) * 16);
         }
     };
     auto stage_w = [&](int sb, int buf) {           // LDS path: the 128-row panel of superblock sb
@@ -328,7 +359,7 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
     constexpr int NL = XL + WL;
     constexpr int PARTS = 4 / SKG;               // stages per superblock
     static_assert(NST * ST <= 160 * 1024, "LDS ring does not fit");
-    static_assert(SKG * 8 >= 16, "swizzle needs >= 16 chunks per row");
+    static_assert(SKG == 2, "stage = one 128-k panel of the activation image");
     __shared__ __attribute__((aligned(16))) uint8_t smem[NST * ST];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
@@ -341,6 +372,7 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
     const int nsb = p.K / 256 / p.splitk, sb0 = ks * nsb;
     const int nstage = nsb * PARTS;
 
+    DqConst dq; dq.init();
     floatx16 acc[BNF];
 #pragma unroll
     for (int i = 0; i < BNF; i++)
@@ -353,7 +385,7 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
 #pragma unroll
     for (int i = 0; i < XL; i++) {
         const int pc = i * 256 + tid, row = pc / (SKG * 8), c = (pc % (SKG * 8)) ^ (row & 15);
-        xvoff[i] = (uint32_t)(min(b0 + row, p.B - 1) - b0) * (uint32_t)(p.xh_row * 2) + c * 16;
+        xvoff[i] = (uint32_t)(min(b0 + row, p.B - 1) - b0) * 256u + c * 16;
     }
 #pragma unroll
     for (int i = 0; i < WL; i++) {
@@ -364,12 +396,12 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
 #pragma unroll
         for (int part = 0; part < PARTS; part++) wvoff[part][i] = ro + WSt::src_piece(c, part) * 16;
     }
-    const char *const xbase = (const char *)p.xh + (int64_t)b0 * p.xh_row * 2 + (int64_t)sb0 * 512;
+    const char *const xbase = (const char *)p.xh + ((int64_t)sb0 * 2 * p.B + b0) * 256;    // panel (2*sb0), row b0
     const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
 
     auto issue = [&](int sbr, int part, int slot) {                      // sbr = superblock relative to sb0
         uint8_t *xs = smem + slot * ST, *ws = xs + XS;
-        const char *xsrc = xbase + (int64_t)sbr * 512 + part * (SKG * 128);
+        const char *xsrc = xbase + (int64_t)(sbr * PARTS + part) * p.B * 256;                // one 128-k panel = B rows x 256 B
         const char *wsrc = wbase + (int64_t)sbr * BLK;
 #pragma unroll
         for (int i = 0; i < XL; i++) glds16(xsrc + xvoff[i], xs + (i * 256 + wave * 64) * 16);
@@ -382,6 +414,10 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
     };
 
     const int xrow_off = j * RS, xswz = j & 15;
+    // One 64-k group = 2-3 packed-weight reads + 4*BNF activation-fragment reads, ALL issued before the first use, then the
+    // VALU unpack (which only needs the weight bytes) runs while the fragment reads are in flight, then 4*BNF MFMAs
+    // back to back.  With just-in-time reads (ds_read; s_waitcnt lgkmcnt(0); mfma) every MFMA pair paid a full LDS
+    // round trip: PMC showed the waves parked in s_waitcnt 56-62 % of the time at one and at two waves per SIMD.
     auto compute = [&](int slot, int part) {                             // `part` is a compile-time constant at every call site
         const uint8_t *xs = smem + slot * ST + xrow_off;
         const uint8_t *wrow = smem + slot * ST + XS + (wave * 32 + j) * WRS;
@@ -389,17 +425,20 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
         for (int gl = 0; gl < SKG; gl++) {
             Raw<TYPE> raw;
             raw.load(wrow, gl, h);
-            half8_t wf[4];
-            raw.frags(part * SKG + gl, h, wf);
+            half8_t xa[4][BNF];
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
                 const int coff = ((gl * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
 #pragma unroll
-                for (int bf = 0; bf < BNF; bf++) {
-                    const half8_t xa = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
-                    acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, wf[kk], acc[bf], 0, 0, 0);
-                }
+                for (int bf = 0; bf < BNF; bf++) xa[kk][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            half8_t wf[4];
+            raw.frags(part * SKG + gl, h, wf, dq);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                for (int bf = 0; bf < BNF; bf++) acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[kk][bf], wf[kk], acc[bf], 0, 0, 0);
         }
     };
 
@@ -436,6 +475,234 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 8-wave variant of the pipelined kernel: TWO waves per SIMD.  The 4-wave kernels are bound by single-wave issue
+// rate (one instruction per ~4.8 cycles; ~10 non-MFMA instructions per 32-cycle MFMA); a second wave on each SIMD
+// doubles the issue slots under the same MFMA pipe.  Tile 128(m) x 128(b), stage = 128 k (two 64-k groups):
+// waves 0-3 (khalf 0) consume group 0 of every stage, waves 4-7 (khalf 1) group 1 — an intra-work-group K split —
+// and the two partial accumulators are summed ONCE at the end through LDS (fixed order: deterministic).
+template <int TYPE, bool TRACE = false>
+__global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
+    typedef WStage<TYPE, 2> WSt;
+    constexpr int BNF = 4, TB = 128, NST = 3;
+    constexpr int RS = 256, XS = TB * RS;
+    constexpr int BLK = QT<TYPE>::BYTES;
+    constexpr int WRS = WSt::NPH * 16, WS = 128 * WRS, ST = XS + WS;
+    constexpr int XL = XS / 16 / 512;            // 4
+    constexpr int NWI = 128 * WSt::NPH / 64;     // 10 (Q4_K) / 14 (Q5_K)
+    constexpr int WL = (NWI + 7) / 8;            // 2
+    constexpr int NL = XL + WL;
+    constexpr int SMEM = NST * ST > 128 * 1024 ? NST * ST : 128 * 1024;      // the epilogue needs 2 x 64 KB
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int mg = wave & 3, kh = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int nblk = gridDim.x;
+    int L = blockIdx.x;
+    if ((nblk & 7) == 0) L = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int tile_b = L % p.tiles_b; L /= p.tiles_b;
+    const int ks = L % p.splitk, tile_m = L / p.splitk;
+    const int m0 = tile_m * 128, b0 = tile_b * TB;
+    const int nsb = p.K / 256 / p.splitk, sb0 = ks * nsb, nstage = nsb * 2;
+
+    DqConst dq; dq.init();
+    floatx16 acc[BNF];
+#pragma unroll
+    for (int i = 0; i < BNF; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+    uint32_t xvoff[XL], wvoff[2][WL];
+#pragma unroll
+    for (int i = 0; i < XL; i++) {
+        const int pc = i * 512 + tid, row = pc >> 4, c = (pc & 15) ^ (row & 15);
+        xvoff[i] = (uint32_t)(min(b0 + row, p.B - 1) - b0) * 256u + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < WL; i++) {
+        int idx = wave + 8 * i;
+        if (idx >= NWI) idx -= 8;
+        const int pc = idx * 64 + lane, row = pc / WSt::NPH, c = pc % WSt::NPH;
+        const uint32_t ro = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
+        wvoff[0][i] = ro + WSt::src_piece(c, 0) * 16; wvoff[1][i] = ro + WSt::src_piece(c, 1) * 16;
+    }
+    const char *const xbase = (const char *)p.xh + ((int64_t)sb0 * 2 * p.B + b0) * 256;    // panel (2*sb0), row b0
+    const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
+
+    auto issue = [&](int sbr, int part, int slot) {
+        uint8_t *xs = smem + slot * ST, *ws = xs + XS;
+        const char *xsrc = xbase + (int64_t)(sbr * 2 + part) * p.B * 256;
+        const char *wsrc = wbase + (int64_t)sbr * BLK;
+#pragma unroll
+        for (int i = 0; i < XL; i++) glds16(xsrc + xvoff[i], xs + (i * 512 + wave * 64) * 16);
+#pragma unroll
+        for (int i = 0; i < WL; i++) {
+            int idx = wave + 8 * i;
+            if (idx >= NWI) idx -= 8;
+            glds16(wsrc + wvoff[part][i], ws + idx * 1024);
+        }
+    };
+
+    const int xrow_off = j * RS, xswz = j & 15;
+    // Per stage a wave (1) reads its packed weights + 16 activation fragments from LDS, (2) unpacks 4 B fragments (VALU),
+    // (3) issues 16 MFMAs.  Measured by ablation: (1)+(2) and (3) each cost ~10 us of a 40 us kernel and do NOT overlap
+    // when both waves of a SIMD run them in lockstep.  So the two waves of every SIMD run ONE GROUP OUT OF PHASE:
+    //   khalf 0 ("leader")  : stage s:  read(s) -> unpack(s) -> MFMA(s)
+    //   khalf 1 ("follower"): stage s:  MFMA(s-1) from registers -> read(s) -> unpack(s)
+    // so within a stage the leader's VALU/LDS work runs beside the follower's MFMAs and vice versa, with the same single
+    // barrier per stage.
+    half8_t xa[4][BNF], wf[4];
+    auto load_unpack = [&](int slot, int part) {               // this wave's 64-k group of the stage: group kh
+        const uint8_t *xs = smem + slot * ST + xrow_off;
+        const uint8_t *wrow = smem + slot * ST + XS + (mg * 32 + j) * WRS;
+        Raw<TYPE> raw;
+        raw.load(wrow, kh, h);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int coff = ((kh * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
+#pragma unroll
+            for (int bf = 0; bf < BNF; bf++) xa[kk][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kh == 0) raw.frags(part * 2, h, wf, dq); else raw.frags(part * 2 + 1, h, wf, dq);
+    };
+    // One LDS-DMA instruction costs the issuing wave ~90-170 cycles when issued in a burst right after the barrier
+    // (s_memtime trace: 560-1010 cycles for 6 pieces, with the SIMD's MFMA pipe idle meanwhile).  So the next-next stage's
+    // pieces are issued one at a time BETWEEN the MFMAs of this wave's MFMA block, in the shadow of the matrix pipe.
+    // (Tried and rejected, measured: staging through registers — plain global_load_dwordx4 + ds_write_b128 inside the
+    //  MFMA block — made the block 3x longer, 64 us vs 40 us per call: the waits hipcc puts in front of each ds_write
+    //  serialise the block.  LDS-DMA stays.)
+    auto src_of = [&](int i, int sbr, int part) -> const char * {
+        if (i < XL) return xbase + (int64_t)(sbr * 2 + part) * p.B * 256 + xvoff[i];
+        return wbase + (int64_t)sbr * BLK + wvoff[part][i - XL];
+    };
+    auto lds_of = [&](int i, int slot) -> uint8_t * {                  // wave-uniform base; the DMA adds lane*16
+        uint8_t *xs = smem + slot * ST;
+        if (i < XL) return xs + (i * 512 + wave * 64) * 16;
+        int idx = wave + 8 * (i - XL);
+        if (idx >= NWI) idx -= 8;
+        return xs + XS + idx * 1024;
+    };
+    auto issue_piece = [&](int i, int sbr, int part, int slot) { glds16(src_of(i, sbr, part), lds_of(i, slot)); };
+    auto mfma_block = [&](bool load, int sbr, int part, int slot_l) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+            for (int bf = 0; bf < BNF; bf++) {
+                acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[kk][bf], wf[kk], acc[bf], 0, 0, 0);
+                const int n = kk * BNF + bf;
+                if ((n & 1) && (n >> 1) < NL && load) issue_piece(n >> 1, sbr, part, slot_l);
+            }
+    };
+
+    auto stamp = [&](int s, int ph) {      // TRACE builds: [wave][stage 0..15][phase 0..7] cycle stamps of block 0
+        if (TRACE && blockIdx.x == 0 && s >= 4 && s < 20 && lane == 0) p.trace[(wave * 16 + (s - 4)) * 8 + ph] = __builtin_amdgcn_s_memtime();
+    };
+    issue(0, 0, 0);
+    if (nstage > 1) issue(0, 1, 1);
+    int slot = 0;
+    for (int sb = 0; sb < nsb; sb++) {
+#pragma unroll
+        for (int part = 0; part < 2; part++) {
+            const int s = sb * 2 + part;
+            stamp(s, 0);
+            if (s + 1 < nstage) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+            stamp(s, 1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stamp(s, 2);
+            const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;
+            const bool load = s + 2 < nstage;                        // stage s+2 = (sb+1, part) -> slot2
+            if (kh == 1) {                                           // follower: previous stage's fragments (+ DMA issue)
+                if (s > 0) mfma_block(load, sb + 1, part, slot2); else if (load) issue(sb + 1, part, slot2);
+            }
+            stamp(s, 4);
+            load_unpack(slot, part);
+            stamp(s, 5);
+            if (kh == 0) mfma_block(load, sb + 1, part, slot2);      // leader: this stage's fragments (+ DMA issue)
+            stamp(s, 6);
+            slot = slot1;
+        }
+    }
+    if (kh == 1) mfma_block(false, 0, 0, 0);
+
+    // ---- epilogue: sum the two K halves and write 512-byte output rows.  Through LDS (the ring is dead now):
+    //      khalf 1 parks its accumulators, khalf 0 adds them and writes the 128(b) x 128(m) fp32 tile in [b][m] order,
+    //      then all 512 threads store float4s: 4x fewer store instructions than lane-per-m dword stores.
+    __syncthreads();
+    float4 *red = reinterpret_cast<float4 *>(smem) + (size_t)mg * 1024;   // [16 quads][64 lanes] float4 per m-group (64 KB total)
+    if (kh == 1) {
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++)
+                red[(bf * 4 + q4) * 64 + lane] = make_float4(acc[bf][4 * q4], acc[bf][4 * q4 + 1], acc[bf][4 * q4 + 2], acc[bf][4 * q4 + 3]);
+    }
+    __syncthreads();
+    float *ctile = reinterpret_cast<float *>(smem + 64 * 1024);           // [128 b][128 m] fp32 = 64 KB, after the parked partials
+    constexpr int CLD = 128;
+    if (kh == 0) {
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+                const float4 v = red[(bf * 4 + q4) * 64 + lane];
+                const float add[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int r = 4 * q4 + e;
+                    const int bl = bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // C/D layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                    ctile[bl * CLD + mg * 32 + j] = acc[bf][r] + add[e];
+                }
+            }
+    }
+    __syncthreads();
+    // split-K = 2 without atomics or a zero-fill pass: the ks=1 work-group publishes its 64 KB partial tile to global
+    // scratch (plain stores -> agent-scope release -> relaxed flag), the ks=0 work-group of the same tile polls the flag
+    // (one lane, relaxed), acquires, adds its own half and writes Y.  Fixed summation order: deterministic.  Both
+    // work-groups are co-resident by construction (the launcher only takes this path when the grid fits the chip).
+    const int tile_id = tile_m * p.tiles_b + tile_b;
+    float *part = p.partial ? p.partial + (size_t)tile_id * (128 * 128) : nullptr;
+    const bool producer = p.partial && ks == 1, consumer = p.partial && ks == 0;
+    if (consumer) {
+        if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(p.flags + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    {
+        const int c4 = tid & 31, r0 = tid >> 5;                             // 32 float4 per row, 16 rows per pass
+#pragma unroll
+        for (int pass = 0; pass < 8; pass++) {
+            const int bl = pass * 16 + r0, b = b0 + bl, m = m0 + c4 * 4;
+            float4 v = *reinterpret_cast<const float4 *>(ctile + bl * CLD + c4 * 4);
+            if (producer) { *reinterpret_cast<float4 *>(part + bl * 128 + c4 * 4) = v; continue; }
+            if (consumer) { const float4 o = *reinterpret_cast<const float4 *>(part + bl * 128 + c4 * 4); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            if (b < p.B && m < p.M) {
+                float *dst = p.Y + (int64_t)b * p.y_row + m;
+                if (p.splitk > 1 && !p.partial) {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+                    for (int t = 0; t < 4 && m + t < p.M; t++) unsafeAtomicAdd(dst + t, e[t]);
+                } else if (m + 3 < p.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<float4 *>(dst) = v;
+                else { const float e[4] = {v.x, v.y, v.z, v.w}; for (int t = 0; t < 4 && m + t < p.M; t++) dst[t] = e[t]; }
+            }
+        }
+    }
+    if (producer) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(p.flags + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+
 __global__ void k_zero_rows(float *Y, int64_t y_row, int M, int B) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < (int64_t)M * B) Y[(i / M) * y_row + (i % M)] = 0.f;
@@ -452,7 +719,7 @@ bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B) {
 
 template <int TYPE, int BNF, bool WLDS>
 static int launch_variant(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    gemm_params p;
+    gemm_params p; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 32 * BNF - 1) / (32 * BNF);
@@ -467,7 +734,7 @@ static int launch_variant(const cdna4_gemm_args &a, int splitk, hipStream_t st) 
 
 template <int TYPE, int BNF>
 static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    gemm_params p;
+    gemm_params p; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 32 * BNF - 1) / (32 * BNF);
@@ -480,13 +747,59 @@ static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
     return 0;
 }
 
+// library-owned scratch for the split-K hand-off (partial tiles + flags), grown on demand like a BLAS workspace
+static void *g_scratch = nullptr; static size_t g_scratch_bytes = 0;
+static void *get_scratch(size_t bytes) {
+    if (bytes <= g_scratch_bytes) return g_scratch;
+    (void)hipDeviceSynchronize();
+    if (g_scratch) (void)hipFree(g_scratch);
+    g_scratch = nullptr; g_scratch_bytes = 0;
+    const size_t want = (bytes + (4u << 20)) & ~(size_t)((1u << 20) - 1);
+    if (hipMalloc(&g_scratch, want) != hipSuccess) { (void)hipGetLastError(); g_scratch = nullptr; return nullptr; }
+    g_scratch_bytes = want;
+    return g_scratch;
+}
+static int cu_count() {
+    static int n = 0;
+    if (!n) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; else n = 1; }
+    return n;
+}
+
+template <int TYPE>
+static int launch_w8(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
+    gemm_params p; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr;
+    p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
+    p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
+    p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 127) / 128;
+    p.partial = nullptr; p.flags = nullptr;
+    const int ntiles = p.tiles_m * p.tiles_b;
+    if (splitk == 2 && ntiles * 2 <= cu_count()) {                    // both halves of every tile are resident at once: hand-off
+        const size_t pbytes = (size_t)ntiles * 128 * 128 * 4;
+        char *sc = (char *)get_scratch(pbytes + (size_t)ntiles * 4 + 256);
+        if (!sc) return cdna4_set_error_msg("gemm_q: cannot allocate split-K scratch");
+        p.partial = (float *)sc; p.flags = (unsigned *)(sc + pbytes);
+        hipError_t e = hipMemsetAsync(p.flags, 0, (size_t)ntiles * 4, st);
+        if (e != hipSuccess) return cdna4_set_error(e, __FILE__, __LINE__);
+    } else if (splitk > 1) {
+        const int64_t n = (int64_t)a.M * a.B;
+        hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.Y, a.y_row_elems, a.M, a.B);
+    }
+    p.trace = (unsigned long long *)cdna4_debug_trace;
+    const dim3 grid(p.tiles_m * p.tiles_b * splitk);
+    if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, true>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, false>), grid, dim3(512), 0, st, p);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int TYPE>
 static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     constexpr bool CAN_LDS = QT<TYPE>::KQ && (QT<TYPE>::BYTES % 16 == 0);
     // variant: bit0 = LDS weight staging (Q4_K/Q5_K only), bit1 = 128-wide activation tile, bit3 = the older
-    // slice-per-barrier kernel instead of the pipelined one.  0 = auto: widest tile that the batch fills.
+    // slice-per-barrier kernel instead of the pipelined one, bit4 = the 8-wave (two waves per SIMD) 128x128 kernel.
+    // 0 = auto: widest tile that the batch fills.
     int variant = a.variant;
-    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0);
+    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? 16 : 0);
     const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
     const bool wide = (variant & 2) != 0;
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
@@ -496,10 +809,12 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         // auto: at most 2.  Two fp32 contributions added to a zeroed output are order-independent (a+b == b+a), so the
         // result stays deterministic; deeper splits (atomic sums of >2 terms) are opt-in only.
         const int tiles = ((a.M + 127) / 128) * ((a.B + (wide ? 127 : 63)) / (wide ? 128 : 64));
-        splitk = (tiles <= 160 && kunits % 2 == 0 && kunits >= 4) ? 2 : 1;
+        if (variant & 16) splitk = (tiles * 2 <= cu_count() && kunits % 2 == 0 && kunits >= 4) ? 2 : 1;   // hand-off split: only if co-resident
+        else splitk = 1;
     }
     if (splitk < 1 || kunits % splitk) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
     if constexpr (CAN_LDS) {
+        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, st);
         if (wlds && !(variant & 8)) return wide ? launch_pipe<TYPE, 4>(a, splitk, st) : launch_pipe<TYPE, 2>(a, splitk, st);
         if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
     }
@@ -509,7 +824,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
 int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
     if (a.M <= 0 || a.B <= 0) return 0;
     if (!cdna4_gemm_q_supported(a.type, a.M, a.K, a.B)) return cdna4_set_error_msg("gemm_q: unsupported type / shape");
-    if ((uintptr_t)a.xh & 15 || (a.xh_row_elems & 7)) return cdna4_set_error_msg("gemm_q: activation image must be 16-byte aligned");
+    if ((uintptr_t)a.xh & 15) return cdna4_set_error_msg("gemm_q: activation image must be 16-byte aligned");
     if (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 1) return cdna4_set_error_msg("gemm_q: weight rows must be 2-byte aligned");
     if ((a.type == CDNA4_Q4_K || a.type == CDNA4_Q5_K) && (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15))
         return cdna4_set_error_msg("gemm_q: Q4_K/Q5_K rows must be 16-byte aligned");

@@ -5,8 +5,13 @@
 //                              `ref` = quantize_row_q8_0_ref, src/ggml-quants.c:194-217, for CPY f32->q8_0)
 // Output is a structure-of-arrays workspace (ours, never exposed): int8 qs[B][K], float d[B][K/QK],
 // int16 bsums[B][K/16] (Q8_K only) for the int8-dot GEMV path, and/or the dequantized value d*q rounded
-// to fp16 for the MFMA GEMM path.  The fp16 image is stored PAIR-INTERLEAVED: within every 4 consecutive k
-// the order is (k0,k2,k1,k3), which is the order the nibble/byte unpackers of gemm_q_mfma.hip produce.
+// to fp16 for the MFMA GEMM path.  The fp16 image has two layout twists, both private to this library:
+//  * PAIR-INTERLEAVED: within every 4 consecutive k the order is (k0,k2,k1,k3) — the order the nibble/byte
+//    unpackers of gemm_q_mfma.hip produce;
+//  * K-PANEL-MAJOR: element (b, k) lives at ((k/128)*B + b)*128 + k%128, i.e. [K/128 panels][B rows][128 halves].
+//    A row-major [B][K] image has an 8 KiB row stride at K=4096: every tile row of a GEMM stage then falls on the
+//    same L2 channel and all 256 CUs walk K in lockstep — measured 19 GB/s per CU of LDS-DMA against 108 GB/s
+//    for contiguous 32 KiB stage blocks (tools/microbench/l2_stream.hip).  Panel-major makes a stage contiguous.
 // Compiled with -ffp-contract=off: iscale*x must round before the integer conversion, as on the CPU.
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
@@ -56,7 +61,8 @@ __global__ __launch_bounds__(256) void k_quantize_q8_K(const float *__restrict__
         half_t h[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) h[i] = (half_t)(d * (float)q[i]);
-        *reinterpret_cast<u32x2 *>(xh + base) = pack4h(h[0], h[2], h[1], h[3]);        // pair-interleaved
+        const int64_t k = (int64_t)sb * QK_K + lane * 4;
+        *reinterpret_cast<u32x2 *>(xh + ((k >> 7) * B + b) * 128 + (k & 127)) = pack4h(h[0], h[2], h[1], h[3]);   // pair-interleaved, panel-major
     }
 }
 
@@ -91,7 +97,8 @@ __global__ __launch_bounds__(256) void k_quantize_q8_0(const float *__restrict__
         half_t h[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) h[i] = (half_t)(dh * (float)q[i]);
-        *reinterpret_cast<u32x2 *>(xh + base) = pack4h(h[0], h[2], h[1], h[3]);
+        const int64_t k = (int64_t)ib * 32 + sub * 4;
+        *reinterpret_cast<u32x2 *>(xh + ((k >> 7) * B + b) * 128 + (k & 127)) = pack4h(h[0], h[2], h[1], h[3]);
     }
 }
 

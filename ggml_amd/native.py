@@ -14,6 +14,7 @@ SYMBOLS = [
     ("ggml_cdna4_last_error", C.c_char_p, []),
     ("ggml_cdna4_device_count", _int, []),
     ("ggml_cdna4_set_device", _int, [_int]),
+    ("ggml_cdna4_debug_trace", None, [_vp]),
     ("ggml_cdna4_row_size", _sz, [_int, _i64]),
     ("ggml_cdna4_mul_mat_workspace_size", _sz, [_int, _i64, _i64]),
     ("ggml_cdna4_mul_mat", _int, [_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _int, _int, _int, _vp]),

@@ -135,7 +135,7 @@ def quantize_row_q8_K(x: torch.Tensor, want_f16=False):
     qs = torch.empty((B, K), dtype=torch.int8, device=x.device)
     d = torch.empty((B, K // 256), dtype=torch.float32, device=x.device)
     bs = torch.empty((B, K // 16), dtype=torch.int16, device=x.device)
-    xh = torch.empty((B, K), dtype=torch.float16, device=x.device) if want_f16 else None
+    xh = torch.empty((B, (K + 127) // 128 * 128), dtype=torch.float16, device=x.device) if want_f16 else None
     native.check(L.ggml_cdna4_quantize_q8_K(x.data_ptr(), x.stride(0), K, B, qs.data_ptr(), d.data_ptr(), bs.data_ptr(),
                                             xh.data_ptr() if want_f16 else None, _stream(x.device)))
     return (qs, d, bs, xh) if want_f16 else (qs, d, bs)
@@ -149,7 +149,7 @@ def quantize_row_q8_0(x: torch.Tensor, ref_rounding=False, want_f16=False):
     B, K = x.shape
     qs = torch.empty((B, K), dtype=torch.int8, device=x.device)
     d = torch.empty((B, K // 32), dtype=torch.float32, device=x.device)
-    xh = torch.empty((B, K), dtype=torch.float16, device=x.device) if want_f16 else None
+    xh = torch.empty((B, (K + 127) // 128 * 128), dtype=torch.float16, device=x.device) if want_f16 else None
     native.check(L.ggml_cdna4_quantize_q8_0(x.data_ptr(), x.stride(0), K, B, qs.data_ptr(), d.data_ptr(),
                                             xh.data_ptr() if want_f16 else None, 1 if ref_rounding else 0, _stream(x.device)))
     return (qs, d, xh) if want_f16 else (qs, d)

@@ -48,6 +48,9 @@ int          ggml_cdna4_api_version(void);
 const char * ggml_cdna4_last_error(void);                 /* thread-local, never NULL */
 int          ggml_cdna4_device_count(void);               /* number of visible HIP devices (0 if none) */
 int          ggml_cdna4_set_device(int device);
+/* profiling hook (tools/microbench/gemm_bench only): a 64 KiB device buffer makes the 8-wave GEMM record per-phase
+ * s_memtime stamps of its first work-group; NULL (default) selects the uninstrumented kernel */
+void         ggml_cdna4_debug_trace(void * device_buffer);
 
 size_t ggml_cdna4_row_size(int type, int64_t k);          /* bytes of one row of k weights; 0 if unsupported */
 
@@ -92,7 +95,8 @@ int ggml_cdna4_mul_mat_id(int type, const void * as, int64_t w_row_bytes, int64_
 
 /* Activation quantizers (bit-exact with the reference); outputs may be NULL to skip them.
  *   qs  int8  [B][K]      d  f32 [B][K/256 | K/32]      bsums int16 [B][K/16] (Q8_K only)
- *   xh  fp16  [B][K]  = fp16(d*q), stored pair-interleaved (k0,k2,k1,k3 within every 4) for the MFMA path */
+ *   xh  fp16  B*K halves = fp16(d*q) in the MFMA path's private layout: element (b,k) at ((k/128)*B + b)*128 + k%128
+ *       (k-panel-major), and within every 4 consecutive k the order (k0,k2,k1,k3) (pair-interleaved) */
 int ggml_cdna4_quantize_q8_K(const float * x, int64_t x_row_stride, int64_t K, int64_t B,
                              int8_t * qs, float * d, int16_t * bsums, void * xh, void * stream);
 int ggml_cdna4_quantize_q8_0(const float * x, int64_t x_row_stride, int64_t K, int64_t B,

@@ -14,7 +14,8 @@
 // per-node comparison of the gpt-2 graph between the chosen backend and the CPU backend (what test-backend-ops does
 // for single ops, ggml_backend_compare_graph_backend, src/ggml-backend.cpp:1814-1851) — prints rel-L2 per node
 static bool cmp_cb(int index, struct ggml_tensor * t1, struct ggml_tensor * t2, void * ud) {
-    (void)ud;
+    const bool resync = ud != NULL;     // RESYNC: after comparing, overwrite our result with the CPU's, so every op is
+                                        // judged on IDENTICAL inputs (per-op parity, no error accumulation)
     if (t1->type != GGML_TYPE_F32) return true;
     const size_t n = ggml_nelements(t1);
     if (!ggml_is_contiguous(t1) || !ggml_is_contiguous(t2)) { printf("node %4d %-14s %-24s (non-contiguous, skipped)\n", index, ggml_op_desc(t1), t1->name); return true; }
@@ -29,6 +30,7 @@ static bool cmp_cb(int index, struct ggml_tensor * t1, struct ggml_tensor * t2, 
     }
     printf("node %4d %-14s %-24s [%5lld,%5lld,%3lld] rel_l2=%.3e%s\n", index, ggml_op_desc(t1), t1->name, (long long)t1->ne[0], (long long)t1->ne[1], (long long)t1->ne[2],
            den > 0 ? sqrt(num / den) : sqrt(num), nbad ? " NONFINITE-MISMATCH" : "");
+    if (resync) ggml_backend_tensor_set(t1, b.data(), 0, n * 4);
     return true;
 }
 
@@ -60,7 +62,20 @@ int main(int argc, char ** argv) {
     std::vector<gpt_vocab::id> prompt(n_prompt);
     for (auto & t : prompt) t = next_tok();
 
-    if (out == "COMPARE") {     // node-by-node against the CPU backend, first on the prompt batch then on one decode step
+    if (out == "PERTURB") {     // conditioning of the REFERENCE itself: CPU backend vs CPU backend with the first LayerNorm gain scaled by (1 + 1e-6)
+        std::vector<float> la, lb;
+        if (!gpt2_eval(model, allocr, n_threads, 0, prompt, la)) return 1;
+        struct ggml_tensor * t = model.layers[0].ln_1_g;
+        std::vector<float> w(ggml_nelements(t));
+        ggml_backend_tensor_get(t, w.data(), 0, ggml_nbytes(t));
+        for (auto & v : w) v *= 1.000001f;
+        ggml_backend_tensor_set(t, w.data(), 0, ggml_nbytes(t));
+        if (!gpt2_eval(model, allocr, n_threads, 0, prompt, lb)) return 1;
+        double num = 0, den = 0; for (size_t i = 0; i < la.size(); i++) { num += ((double)la[i] - lb[i]) * ((double)la[i] - lb[i]); den += (double)la[i] * la[i]; }
+        printf("{\"mode\":\"perturb\",\"backend\":\"%s\",\"relative_perturbation\":1e-6,\"logits_rel_l2\":%.6e}\n", ggml_backend_name(model.backend), sqrt(num / den));
+        return 0;
+    }
+    if (out == "COMPARE" || out == "RESYNC") {     // node-by-node against the CPU backend, first on the prompt batch then on one decode step
         ggml_backend_t cpu = ggml_backend_cpu_init();
         ggml_backend_cpu_set_n_threads(cpu, n_threads);
         int n_past = 0;
@@ -72,7 +87,7 @@ int main(int argc, char ** argv) {
             ggml_backend_tensor_set(ggml_graph_get_tensor(gf, "embd"), toks.data(), 0, N * sizeof(int32_t));
             for (int i = 0; i < N; ++i) { int32_t v = n_past + i; ggml_backend_tensor_set(ggml_graph_get_tensor(gf, "position"), &v, i * sizeof(int32_t), sizeof(v)); }
             printf("=== pass %d: n_past=%d N=%d ===\n", pass, n_past, N);
-            ggml_backend_compare_graph_backend(model.backend, cpu, gf, cmp_cb, NULL);
+            ggml_backend_compare_graph_backend(model.backend, cpu, gf, cmp_cb, out == "RESYNC" ? (void *)1 : NULL);
             n_past += N;
         }
         return 0;

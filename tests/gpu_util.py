@@ -24,6 +24,14 @@ def to_dev(x):
 
 
 def uninterleave(xh):
-    """undo the pair-interleaved fp16 image: stored (k0,k2,k1,k3) -> natural order"""
-    a = xh.reshape(xh.shape[0], -1, 4)
-    return a[:, :, [0, 2, 1, 3]].reshape(xh.shape)
+    """undo the private layout of the fp16 activation image: k-panel-major ([K/128][B][128]) and pair-interleaved
+    (stored (k0,k2,k1,k3) within every 4) -> natural [B][K]"""
+    B, K = xh.shape
+    if K % 128 == 0:
+        nat = xh.reshape(K // 128, B, 128).transpose(1, 0, 2).reshape(B, K)
+    else:                                       # K not a whole number of panels: element (b,k) at ((k>>7)*B+b)*128 + (k&127)
+        flat = xh.reshape(-1)
+        kk = np.arange(K)
+        nat = np.stack([flat[((kk >> 7) * B + b) * 128 + (kk & 127)] for b in range(B)])
+    a = nat.reshape(B, -1, 4)
+    return a[:, :, [0, 2, 1, 3]].reshape(B, K)
