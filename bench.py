@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — BASELINE.json's metric on MI355X: effective TFLOPS of the Q4_K MUL_MAT hot path.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--variant V --splitk S   (kernel tuning knobs, 0 = auto)]
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload (config.workload): Q4_K [4096x4096]·[4096x512] per GPU — the configuration the metric is quoted on
@@ -163,7 +163,7 @@ def main():
                        "M_per_gpu": M_PER_GPU, "K": K, "B": B, "parallelism": "row-split x%d, output left sharded" % world,
                        "gemm_variant": args.variant, "splitk": args.splitk},
             "tokens_per_s": round(B * world / (ms_per_step * 1e-3), 1),
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_q<Q4_K>", "achieved": round(gemm_tflops, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "k_gemm_kq_w8<Q4_K> (8-wave 128x128 tile, split-K=2 hand-off)" if args.variant in (0, 23) else "gemm variant %d" % args.variant, "achieved": round(gemm_tflops, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
                          "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": 2.0 * M_PER_GPU * K * B},
         }

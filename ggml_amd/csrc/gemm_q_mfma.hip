@@ -195,7 +195,7 @@ struct gemm_params {
     const half_t *xh; int64_t xh_row;   // xh: k-panel-major fp16 image (see quantize_act.hip); xh_row unused
     float *Y; int64_t y_row;
     int M, K, B, splitk, tiles_m, tiles_b;
-    float *partial; unsigned *flags;   // split-K = 2 hand-off (k_gemm_kq_w8): partial tiles [tile][128][128] + one flag per tile
+    float *partial; unsigned *flags; unsigned epoch;   // split-K = 2 hand-off (k_gemm_kq_w8): partial tiles [tile][128][128], one flag per tile, this launch's tag
     unsigned long long *trace;   // profiling builds only (k_gemm_kq_w8<TYPE, true>): per-phase s_memtime stamps of block 0
 };
 
@@ -659,16 +659,17 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
     }
     __syncthreads();
     // split-K = 2 without atomics or a zero-fill pass: the ks=1 work-group publishes its 64 KB partial tile to global
-    // scratch (plain stores -> agent-scope release -> relaxed flag), the ks=0 work-group of the same tile polls the flag
+    // scratch (write-through sc1 stores, drained by every wave -> relaxed agent-scope flag), the ks=0 work-group of the same tile polls the flag
     // (one lane, relaxed), acquires, adds its own half and writes Y.  Fixed summation order: deterministic.  Both
     // work-groups are co-resident by construction (the launcher only takes this path when the grid fits the chip).
     const int tile_id = tile_m * p.tiles_b + tile_b;
     float *part = p.partial ? p.partial + (size_t)tile_id * (128 * 128) : nullptr;
     const bool producer = p.partial && ks == 1, consumer = p.partial && ks == 0;
+    __amdgpu_buffer_rsrc_t part_rsrc = __builtin_amdgcn_make_buffer_rsrc(part, 0, 128 * 128 * 4, 0x00020000);
     if (consumer) {
         if (tid == 0) {
             unsigned spins = 0;
-            while (__hip_atomic_load(p.flags + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(2);
+            while (__hip_atomic_load(p.flags + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(2);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
@@ -679,7 +680,11 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
         for (int pass = 0; pass < 8; pass++) {
             const int bl = pass * 16 + r0, b = b0 + bl, m = m0 + c4 * 4;
             float4 v = *reinterpret_cast<const float4 *>(ctile + bl * CLD + c4 * 4);
-            if (producer) { *reinterpret_cast<float4 *>(part + bl * 128 + c4 * 4) = v; continue; }
+            if (producer) {     // write-through (sc1) store: the tile goes straight past this XCD's L2, so publishing needs no
+                                // L2 write-back fence (which would flush every dirty line of the XCD, ~8 us measured)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), part_rsrc, (bl * 128 + c4 * 4) * 4, 0, 16);
+                continue;
+            }
             if (consumer) { const float4 o = *reinterpret_cast<const float4 *>(part + bl * 128 + c4 * 4); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
             if (b < p.B && m < p.M) {
                 float *dst = p.Y + (int64_t)b * p.y_row + m;
@@ -694,11 +699,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
     if (producer) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(p.flags + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) __hip_atomic_store(p.flags + tile_id, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every wave drained its sc1 stores above
     }
 }
 
@@ -719,7 +720,7 @@ bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B) {
 
 template <int TYPE, int BNF, bool WLDS>
 static int launch_variant(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    gemm_params p; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr;
+    gemm_params p; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 32 * BNF - 1) / (32 * BNF);
@@ -734,7 +735,7 @@ static int launch_variant(const cdna4_gemm_args &a, int splitk, hipStream_t st) 
 
 template <int TYPE, int BNF>
 static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    gemm_params p; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr;
+    gemm_params p; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 32 * BNF - 1) / (32 * BNF);
@@ -748,16 +749,23 @@ static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
 }
 
 // library-owned scratch for the split-K hand-off (partial tiles + flags), grown on demand like a BLAS workspace
-static void *g_scratch = nullptr; static size_t g_scratch_bytes = 0;
+// (one region per device; launches that use it are assumed to be stream-ordered on that device, as the plug-in's
+// single-stream backend and the one-process-per-GPU bench are).
+static unsigned g_handoff_epoch = 0;        // ONE counter for every kernel instantiation that shares the flag words
+static void *g_scratch[16] = {nullptr}; static size_t g_scratch_bytes[16] = {0};
 static void *get_scratch(size_t bytes) {
-    if (bytes <= g_scratch_bytes) return g_scratch;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
+    if (bytes <= g_scratch_bytes[dev]) return g_scratch[dev];
     (void)hipDeviceSynchronize();
-    if (g_scratch) (void)hipFree(g_scratch);
-    g_scratch = nullptr; g_scratch_bytes = 0;
+    if (g_scratch[dev]) (void)hipFree(g_scratch[dev]);
+    g_scratch[dev] = nullptr; g_scratch_bytes[dev] = 0;
     const size_t want = (bytes + (4u << 20)) & ~(size_t)((1u << 20) - 1);
-    if (hipMalloc(&g_scratch, want) != hipSuccess) { (void)hipGetLastError(); g_scratch = nullptr; return nullptr; }
-    g_scratch_bytes = want;
-    return g_scratch;
+    void *ptr = nullptr;
+    if (hipMalloc(&ptr, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemset(ptr, 0, want) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); return nullptr; }
+    g_scratch[dev] = ptr; g_scratch_bytes[dev] = want;
+    return ptr;
 }
 static int cu_count() {
     static int n = 0;
@@ -767,7 +775,7 @@ static int cu_count() {
 
 template <int TYPE>
 static int launch_w8(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    gemm_params p; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr;
+    gemm_params p; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 127) / 128;
@@ -778,8 +786,11 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
         char *sc = (char *)get_scratch(pbytes + (size_t)ntiles * 4 + 256);
         if (!sc) return cdna4_set_error_msg("gemm_q: cannot allocate split-K scratch");
         p.partial = (float *)sc; p.flags = (unsigned *)(sc + pbytes);
-        hipError_t e = hipMemsetAsync(p.flags, 0, (size_t)ntiles * 4, st);
-        if (e != hipSuccess) return cdna4_set_error(e, __FILE__, __LINE__);
+        // flags carry a per-launch tag instead of being zeroed by a memset node every call (a 256-byte fill cost ~5 us of
+        // GPU time per step): the scratch is zero-filled when allocated, tags start at 1 and never repeat within 2^32
+        // launches.  (Under HIP-graph replay the tag would be frozen: capture is not used on this path.)
+        if (++g_handoff_epoch == 0) ++g_handoff_epoch;
+        p.epoch = g_handoff_epoch;
     } else if (splitk > 1) {
         const int64_t n = (int64_t)a.M * a.B;
         hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.Y, a.y_row_elems, a.M, a.B);
