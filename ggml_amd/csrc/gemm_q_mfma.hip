@@ -66,6 +66,24 @@ template <int TYPE> struct Raw;
 template <> struct Raw<CDNA4_Q4_K> {
     u32x4 hdr, q;
     template <typename P> __device__ __forceinline__ void load(P blk, int g, int h) { hdr = ld_u32x4(blk); q = ld_u32x4(blk + 16 + 32 * g + 16 * h); }
+    // one fragment at a time (software-pipelined schedule): scales once per group, then frag(kk)
+    struct Sc { half2_t SL, CL, SH, CH; };
+    __device__ __forceinline__ Sc scales(int g) const {
+        const uint32_t sc[3] = {hdr.y, hdr.z, hdr.w};
+        uint32_t s0, m0, s1, m1;
+        k4_scale_min(sc, 2 * g, s0, m0); k4_scale_min(sc, 2 * g + 1, s1, m1);
+        const float d = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
+        const half_t sl = (half_t)(d * (float)s0), sh = (half_t)(d * (float)s1);
+        Sc r; r.SL = half2_t{sl, sl}; r.SH = half2_t{sh, sh};
+        r.CL = splat(8.f * (float)sl - dmin * (float)m0); r.CH = splat(8.f * (float)sh - dmin * (float)m1);
+        return r;
+    }
+    __device__ __forceinline__ half8_t frag(int kk, const Sc &z, const DqConst &c) const {
+        const half2_t off = {(half_t)-1032.f, (half_t)-1032.f};
+        const uint32_t a = (kk & 1) ? q.z : q.x, b = (kk & 1) ? q.w : q.y;
+        if (kk < 2) return finish_frag(nib(a, c), nib(a >> 8, c), nib(b, c), nib(b >> 8, c), off, z.SL, z.CL);
+        return finish_frag(nib(a >> 4, c), nib(a >> 12, c), nib(b >> 4, c), nib(b >> 12, c), off, z.SH, z.CH);
+    }
     __device__ __forceinline__ void frags(int g, int h, half8_t (&f)[4], const DqConst &c) const {
         const uint32_t sc[3] = {hdr.y, hdr.z, hdr.w};
         uint32_t s0, m0, s1, m1;
@@ -103,6 +121,24 @@ template <> struct Raw<CDNA4_Q5_K> {
         hdr = ld_u32x4(blk); qh = ld_u32x4(blk + 16 + 16 * h); q = ld_u32x4(blk + 48 + 32 * g + 16 * h);
     }
     __device__ __forceinline__ void frags(int g, int h, half8_t (&f)[4], const DqConst &) const { frags(g, h, f); }
+    struct Sc { half2_t SL, CL, SH, CH; int bl, bh; };
+    __device__ __forceinline__ Sc scales(int g) const {
+        const uint32_t sc[3] = {hdr.y, hdr.z, hdr.w};
+        uint32_t s0, m0, s1, m1;
+        k4_scale_min(sc, 2 * g, s0, m0); k4_scale_min(sc, 2 * g + 1, s1, m1);
+        const float d = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
+        const half_t sl = (half_t)(d * (float)s0), sh = (half_t)(d * (float)s1);
+        Sc r; r.SL = half2_t{sl, sl}; r.SH = half2_t{sh, sh};
+        r.CL = splat(16.f * (float)sl - dmin * (float)m0); r.CH = splat(16.f * (float)sh - dmin * (float)m1);
+        r.bl = 2 * g; r.bh = 2 * g + 1;
+        return r;
+    }
+    __device__ __forceinline__ half8_t frag(int kk, const Sc &z, const DqConst &) const {
+        const half2_t off = {(half_t)-1040.f, (half_t)-1040.f};
+        const uint32_t a = (kk & 1) ? q.z : q.x, b = (kk & 1) ? q.w : q.y, ha = (kk & 1) ? qh.z : qh.x, hb = (kk & 1) ? qh.w : qh.y;
+        if (kk < 2) return finish_frag(pair(a, ha, 0, z.bl, 0), pair(a, ha, 0, z.bl, 8), pair(b, hb, 0, z.bl, 0), pair(b, hb, 0, z.bl, 8), off, z.SL, z.CL);
+        return finish_frag(pair(a, ha, 4, z.bh, 0), pair(a, ha, 4, z.bh, 8), pair(b, hb, 4, z.bh, 0), pair(b, hb, 4, z.bh, 8), off, z.SH, z.CH);
+    }
     // value 1024 + nibble + 16*bit for bytes (0,2) [sh=0] or (1,3) [sh=8] of x; bit taken from hq
     static __device__ __forceinline__ uint32_t pair(uint32_t x, uint32_t hq, int nib_shift, int bit, int sh) {
         return ((x >> (nib_shift + sh)) & 0x000F000Fu) | ((((hq >> (bit + sh)) & 0x00010001u) << 4)) | MAGIC2;
@@ -506,6 +542,10 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
     const int m0 = tile_m * 128, b0 = tile_b * TB;
     const int nsb = p.K / 256 / p.splitk, sb0 = ks * nsb, nstage = nsb * 2;
 
+    // (Tried and rejected, measured: four extra loader waves (12 waves, one loader per SIMD) that do nothing but issue the
+    //  LDS-DMA pieces, compute waves software-pipelined in-wave to fit 168 VGPRs: 44 us vs 37 us per call.  One wave
+    //  sustains only ~1 KiB per 75-90 cycles of LDS-DMA (tools/microbench/l2_stream: 32 GB/s for one wave, 134 GB/s for
+    //  eight), so four loaders cannot feed a stage in time; spreading the pieces over all eight waves can.)
     DqConst dq; dq.init();
     floatx16 acc[BNF];
 #pragma unroll
@@ -586,6 +626,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
     };
     auto issue_piece = [&](int i, int sbr, int part, int slot) { glds16(src_of(i, sbr, part), lds_of(i, slot)); };
     auto mfma_block = [&](bool load, int sbr, int part, int slot_l) {
+        __builtin_amdgcn_s_setprio(1);          // the wave feeding the matrix pipe wins issue arbitration over its partner's unpack
 #pragma unroll
         for (int kk = 0; kk < 4; kk++)
 #pragma unroll
@@ -594,6 +635,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
                 const int n = kk * BNF + bf;
                 if ((n & 1) && (n >> 1) < NL && load) issue_piece(n >> 1, sbr, part, slot_l);
             }
+        __builtin_amdgcn_s_setprio(0);
     };
 
     auto stamp = [&](int s, int ph) {      // TRACE builds: [wave][stage 0..15][phase 0..7] cycle stamps of block 0
