@@ -46,6 +46,26 @@ def synth_q4k(m, k, seed):
     return raw.reshape(-1)
 
 
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of the same command
+    (profiles/rNN/pmc_summary.txt: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE); None if absent."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.txt")))
+    if not files:
+        return None
+    rd = wr = None
+    for ln in open(files[-1]):
+        if kernel_substr in ln:
+            m = re.search(r"read bytes/launch = .*? = ([0-9.]+) MB", ln)
+            if m:
+                rd = float(m.group(1)) * 1e6
+            m = re.search(r"write bytes/launch = .*? = ([0-9.]+) MB", ln)
+            if m:
+                wr = float(m.group(1)) * 1e6
+    return None if rd is None or wr is None else rd + wr
+
+
 def cpu_baseline(seconds=12.0):
     """the reference CPU backend (oracle/_ref, unmodified ggml built by oracle/ref.mk) on the same workload,
     all host cores; falls back to the C port (oracle/libggml_oracle.so) when the binary is not in the snapshot."""
@@ -164,7 +184,9 @@ def main():
                        "gemm_variant": args.variant, "splitk": args.splitk},
             "tokens_per_s": round(B * world / (ms_per_step * 1e-3), 1),
             "roofline": {"bound": "mfma", "kernel": "k_gemm_kq_w8<Q4_K> (8-wave 128x128 tile, split-K=2 hand-off)" if args.variant in (0, 23) else "gemm variant %d" % args.variant, "achieved": round(gemm_tflops, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(gemm_tflops / MFMA_F16_PEAK_TFLOPS, 4),
+                         "traffic": pmc_traffic("k_gemm_kq_w8") if args.variant in (0, 23) else None,
+                         "traffic_note": "HBM-side bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) from the rocprofv3 PMC passes of this command, profiles/rNN/pmc_summary.txt",
                          "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": 2.0 * M_PER_GPU * K * B},
         }
 
@@ -202,7 +224,7 @@ def main():
                          "us_per_gemv_cache_warm": round(res["cache_warm"], 3), "us_per_step_with_quantize": round(full_us, 3),
                          "tokens_per_s": round(1e6 / full_us, 1), "effective_tflops": round(2.0 * M_PER_GPU * K / (res["cold_hbm"] * 1e-6) / 1e12, 3),
                          "roofline": {"bound": "hbm", "kernel": "k_gemv_q<Q4_K,1>", "achieved": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                      "unit": "GB/s", "frac": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                      "unit": "GB/s", "frac": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k_gemv_q<12, 1"),
                                       "algorithmic_bytes_per_launch": alg_bytes}}
         del big
 
