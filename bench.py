@@ -183,7 +183,7 @@ def main():
                        "M_per_gpu": M_PER_GPU, "K": K, "B": B, "parallelism": "row-split x%d, output left sharded" % world,
                        "gemm_variant": args.variant, "splitk": args.splitk},
             "tokens_per_s": round(B * world / (ms_per_step * 1e-3), 1),
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_kq_w8<Q4_K> (8-wave 128x128 tile, split-K=2 hand-off)" if args.variant in (0, 23) else "gemm variant %d" % args.variant, "achieved": round(gemm_tflops, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "k_gemm_kq_w8<Q4_K> (8-wave 128x128 tile, in-wave unpack/MFMA pipeline, split-K=2 symmetric exchange)" if args.variant in (0, 23) else "gemm variant %d" % args.variant, "achieved": round(gemm_tflops, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / MFMA_F16_PEAK_TFLOPS, 4),
                          "traffic": pmc_traffic("k_gemm_kq_w8") if args.variant in (0, 23) else None,
                          "traffic_note": "HBM-side bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) from the rocprofv3 PMC passes of this command, profiles/rNN/pmc_summary.txt",
@@ -202,14 +202,17 @@ def main():
         def gemv(i):
             native.check(L.ggml_cdna4_mul_mat_prepared(Q4_K, big.data_ptr() + (i % ncopy) * mat_b, row_b, y1.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1,
                                                        ws.data_ptr(), ws.numel(), ops.PATH_GEMV, 0, 0, stream))
+        def fused(i):                                    # B=1 ggml_cdna4_mul_mat: activation quantizer fused into the GEMV launch
+            native.check(L.ggml_cdna4_mul_mat(Q4_K, big.data_ptr() + (i % ncopy) * mat_b, row_b, x1.data_ptr(), K, y1.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1,
+                                              ws.data_ptr(), ws.numel(), 0, 0, 0, stream))
         res = {}
-        for label, rot in (("cold_hbm", True), ("cache_warm", False)):
+        for label, fn, rot in (("cold_hbm", gemv, True), ("cache_warm", gemv, False), ("fused_cold_hbm", fused, True), ("fused_cache_warm", fused, False)):
             for i in range(20):
-                gemv(i if rot else 0)
+                fn(i if rot else 0)
             n = max(args.steps, 256)
             e0.record()
             for i in range(n):
-                gemv(i if rot else 0)
+                fn(i if rot else 0)
             e1.record(); e1.synchronize()
             res[label] = e0.elapsed_time(e1) * 1e3 / n
         alg_bytes = mat_b + K * 1 + (K // 256) * 4 + (K // 16) * 2 + M_PER_GPU * 4    # W + int8 x + scales + bsums + y
@@ -220,12 +223,19 @@ def main():
         for _ in range(500):
             native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), row_b, x1.data_ptr(), K, y1.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1, ws.data_ptr(), ws.numel(), 0, 0, 0, stream))
         torch.cuda.synchronize(dev); full_us = (time.perf_counter() - t0) / 500 * 1e6
-        out["decode"] = {"workload": "Q4_K [4096x4096]·[4096x1] (BASELINE configs[1])", "us_per_gemv_cold_hbm": round(res["cold_hbm"], 3),
-                         "us_per_gemv_cache_warm": round(res["cache_warm"], 3), "us_per_step_with_quantize": round(full_us, 3),
-                         "tokens_per_s": round(1e6 / full_us, 1), "effective_tflops": round(2.0 * M_PER_GPU * K / (res["cold_hbm"] * 1e-6) / 1e12, 3),
-                         "roofline": {"bound": "hbm", "kernel": "k_gemv_q<Q4_K,1>", "achieved": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                      "unit": "GB/s", "frac": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k_gemv_q<12, 1"),
-                                      "algorithmic_bytes_per_launch": alg_bytes}}
+        fused_bytes = mat_b + K * 4 + M_PER_GPU * 4                              # W + fp32 x + y (the quantized row never leaves LDS)
+        out["decode"] = {"workload": "Q4_K [4096x4096]·[4096x1] (BASELINE configs[1])",
+                         "us_per_step": round(res["fused_cold_hbm"], 3), "us_per_step_cache_warm": round(res["fused_cache_warm"], 3),
+                         "us_per_step_host_wall": round(full_us, 3), "tokens_per_s": round(1e6 / full_us, 1),
+                         "effective_tflops": round(2.0 * M_PER_GPU * K / (res["fused_cold_hbm"] * 1e-6) / 1e12, 3),
+                         "note": "step = ggml_cdna4_mul_mat at B=1 = ONE launch (activation quantizer fused into the GEMV); cold = 64 rotating copies of W (604 MB > MALL), HIP-event timed; host_wall includes the Python/ctypes call overhead",
+                         "roofline": {"bound": "hbm", "kernel": "k_gemv_q_fused<Q4_K>", "achieved": round(fused_bytes / (res["fused_cold_hbm"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": round(fused_bytes / (res["fused_cold_hbm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k_gemv_q_fused<12"),
+                                      "algorithmic_bytes_per_launch": fused_bytes},
+                         "two_kernel_path": {"us_per_gemv_cold_hbm": round(res["cold_hbm"], 3), "us_per_gemv_cache_warm": round(res["cache_warm"], 3),
+                                             "roofline": {"bound": "hbm", "kernel": "k_gemv_q<Q4_K,1> (pre-quantized activations, B=2..8 and MUL_MAT_ID)", "achieved": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9, 1),
+                                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                          "traffic": pmc_traffic("k_gemv_q<12, 1"), "algorithmic_bytes_per_launch": alg_bytes}}}
         del big
 
     # ---- the exchange step of a row-split layer, timed separately: all-gather of the output shards ------------

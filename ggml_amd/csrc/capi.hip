@@ -107,6 +107,13 @@ int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float
     if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat: K is not a whole number of blocks");
     path = resolve_path(type, path, M, K, B);
     if (path == GGML_CDNA4_PATH_GEMM && !cdna4_gemm_q_supported(type, M, K, B)) return cdna4_set_error_msg("mul_mat: GEMM path does not support this shape");
+    if (path == GGML_CDNA4_PATH_GEMV && cdna4_gemv_fused_supported(type, K, B) && !((uintptr_t)X & 15)) {
+        // single-token decode: the activation quantizer runs inside the GEMV kernel (workspace untouched)
+        cdna4_gemv_args g{};
+        g.type = type; g.W = (const uint8_t *)W; g.w_row_bytes = w_row_bytes; g.Y = Y; g.y_col_stride = y_row_stride;
+        g.M = (int)M; g.K = (int)K; g.ncol = 1; g.ids = nullptr;
+        return cdna4_launch_gemv_q_fused(g, X, (hipStream_t)stream);
+    }
     int rc = ggml_cdna4_prepare_act(type, X, x_row_stride, K, B, workspace, workspace_bytes, path, stream);
     if (rc) return rc;
     return ggml_cdna4_mul_mat_prepared(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, stream);

@@ -22,6 +22,9 @@ struct cdna4_gemv_args {
     const int32_t *ids; int64_t ids_tok_stride; int64_t w_expert_bytes; int n_used, n_b, n_expert;
 };
 int cdna4_launch_gemv_q(const cdna4_gemv_args &a, hipStream_t st);
+// single-column decode with the activation quantizer fused in (x = fp32 row; a.qs/d/bsums unused)
+bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B);
+int cdna4_launch_gemv_q_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st);
 
 // gemm_q_mfma.hip — fp16 MFMA prefill path.  xh = pair-interleaved fp16 activations [B][K].
 struct cdna4_gemm_args {

@@ -23,6 +23,7 @@
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -84,6 +85,14 @@ template <> struct Raw<CDNA4_Q4_K> {
         if (kk < 2) return finish_frag(nib(a, c), nib(a >> 8, c), nib(b, c), nib(b >> 8, c), off, z.SL, z.CL);
         return finish_frag(nib(a >> 4, c), nib(a >> 12, c), nib(b >> 4, c), nib(b >> 12, c), off, z.SH, z.CH);
     }
+    // half2 #i (two of the eight k) of fragment kk: the unit the in-wave pipeline drops between two MFMAs
+    __device__ __forceinline__ uint32_t pairbits(int kk, int i, const Sc &z, const DqConst &c) const {
+        const half2_t off = {(half_t)-1032.f, (half_t)-1032.f};
+        const uint32_t src = (i < 2) ? ((kk & 1) ? q.z : q.x) : ((kk & 1) ? q.w : q.y);
+        const int sh = (kk >= 2 ? 4 : 0) + ((i & 1) ? 8 : 0);
+        const half2_t r = __builtin_elementwise_fma(as_h2(nib(src >> sh, c)) + off, kk < 2 ? z.SL : z.SH, kk < 2 ? z.CL : z.CH);
+        return __builtin_bit_cast(uint32_t, r);
+    }
     __device__ __forceinline__ void frags(int g, int h, half8_t (&f)[4], const DqConst &c) const {
         const uint32_t sc[3] = {hdr.y, hdr.z, hdr.w};
         uint32_t s0, m0, s1, m1;
@@ -138,6 +147,14 @@ template <> struct Raw<CDNA4_Q5_K> {
         const uint32_t a = (kk & 1) ? q.z : q.x, b = (kk & 1) ? q.w : q.y, ha = (kk & 1) ? qh.z : qh.x, hb = (kk & 1) ? qh.w : qh.y;
         if (kk < 2) return finish_frag(pair(a, ha, 0, z.bl, 0), pair(a, ha, 0, z.bl, 8), pair(b, hb, 0, z.bl, 0), pair(b, hb, 0, z.bl, 8), off, z.SL, z.CL);
         return finish_frag(pair(a, ha, 4, z.bh, 0), pair(a, ha, 4, z.bh, 8), pair(b, hb, 4, z.bh, 0), pair(b, hb, 4, z.bh, 8), off, z.SH, z.CH);
+    }
+    __device__ __forceinline__ uint32_t pairbits(int kk, int i, const Sc &z, const DqConst &) const {
+        const half2_t off = {(half_t)-1040.f, (half_t)-1040.f};
+        const uint32_t src = (i < 2) ? ((kk & 1) ? q.z : q.x) : ((kk & 1) ? q.w : q.y);
+        const uint32_t hs = (i < 2) ? ((kk & 1) ? qh.z : qh.x) : ((kk & 1) ? qh.w : qh.y);
+        const half2_t r = __builtin_elementwise_fma(as_h2(pair(src, hs, kk >= 2 ? 4 : 0, kk >= 2 ? z.bh : z.bl, (i & 1) ? 8 : 0)) + off,
+                                                    kk < 2 ? z.SL : z.SH, kk < 2 ? z.CL : z.CH);
+        return __builtin_bit_cast(uint32_t, r);
     }
     // value 1024 + nibble + 16*bit for bytes (0,2) [sh=0] or (1,3) [sh=8] of x; bit taken from hq
     static __device__ __forceinline__ uint32_t pair(uint32_t x, uint32_t hq, int nib_shift, int bit, int sh) {
@@ -231,7 +248,8 @@ struct gemm_params {
     const half_t *xh; int64_t xh_row;   // xh: k-panel-major fp16 image (see quantize_act.hip); xh_row unused
     float *Y; int64_t y_row;
     int M, K, B, splitk, tiles_m, tiles_b;
-    float *partial; unsigned *flags; unsigned epoch;   // split-K = 2 hand-off (k_gemm_kq_w8): partial tiles [tile][128][128], one flag per tile, this launch's tag
+    int sb_split;                                       // hand-off: superblocks [0, sb_split) -> ks=0, the rest -> ks=1
+    float *partial; unsigned *flags; unsigned epoch;   // split-K = 2 exchange (k_gemm_kq_w8): exported half tiles [tile][ks][64][128], one flag per (tile, ks), this launch's tag
     unsigned long long *trace;   // profiling builds only (k_gemm_kq_w8<TYPE, true>): per-phase s_memtime stamps of block 0
 };
 
@@ -517,7 +535,9 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
 // doubles the issue slots under the same MFMA pipe.  Tile 128(m) x 128(b), stage = 128 k (two 64-k groups):
 // waves 0-3 (khalf 0) consume group 0 of every stage, waves 4-7 (khalf 1) group 1 — an intra-work-group K split —
 // and the two partial accumulators are summed ONCE at the end through LDS (fixed order: deterministic).
-template <int TYPE, bool TRACE = false>
+// OPT bit 0: issue the LDS-DMA pieces of stage s+2 in the VALU gaps of the unpack phase (after each fragment build) instead
+//            of between the MFMAs, leaving the MFMA block bare;  bit 1: no s_setprio around the MFMA block.
+template <int TYPE, bool TRACE = false, int OPT = 0>
 __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
     typedef WStage<TYPE, 2> WSt;
     constexpr int BNF = 4, TB = 128, NST = 3;
@@ -540,7 +560,10 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
     const int tile_b = L % p.tiles_b; L /= p.tiles_b;
     const int ks = L % p.splitk, tile_m = L / p.splitk;
     const int m0 = tile_m * 128, b0 = tile_b * TB;
-    const int nsb = p.K / 256 / p.splitk, sb0 = ks * nsb, nstage = nsb * 2;
+    // K range of this work-group in superblocks.  Hand-off split (p.partial): [0, sb_split) -> ks=0, the rest -> ks=1.
+    const int nsb_all = p.K / 256;
+    const int nsb = p.partial ? (ks == 0 ? p.sb_split : nsb_all - p.sb_split) : nsb_all / p.splitk;
+    const int sb0 = p.partial ? (ks == 0 ? 0 : p.sb_split) : ks * nsb, nstage = nsb * 2;
 
     // (Tried and rejected, measured: four extra loader waves (12 waves, one loader per SIMD) that do nothing but issue the
     //  LDS-DMA pieces, compute waves software-pipelined in-wave to fit 168 VGPRs: 44 us vs 37 us per call.  One wave
@@ -570,18 +593,23 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
     const char *const xbase = (const char *)p.xh + ((int64_t)sb0 * 2 * p.B + b0) * 256;    // panel (2*sb0), row b0
     const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
 
-    auto issue = [&](int sbr, int part, int slot) {
-        uint8_t *xs = smem + slot * ST, *ws = xs + XS;
-        const char *xsrc = xbase + (int64_t)(sbr * 2 + part) * p.B * 256;
-        const char *wsrc = wbase + (int64_t)sbr * BLK;
+    // LDS-DMA in the scalar-base form (SGPR pair + 32-bit lane offset, M0 = wave-uniform LDS address): no per-lane 64-bit
+    // address arithmetic (the flat form cost ~5 VALU per piece, ~20 % of this kernel's VALU instructions).
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto dma16 = [&](const char *sbase, uint32_t voff, uint32_t lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+    };
+    auto issue_piece = [&](int i, int sbr, int part, int slot) __attribute__((always_inline)) {         // piece i of stage (sbr, part) -> ring slot
+        const uint32_t l = lds0 + slot * ST;
+        if (i < XL) { dma16(xbase + (int64_t)(sbr * 2 + part) * p.B * 256, xvoff[i], l + (i * 512 + wave_s * 64) * 16); return; }
+        int idx = wave_s + 8 * (i - XL);
+        if (idx >= NWI) idx -= 8;
+        dma16(wbase + (int64_t)sbr * BLK, wvoff[part][i - XL], l + XS + idx * 1024);
+    };
+    auto issue = [&](int sbr, int part, int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < XL; i++) glds16(xsrc + xvoff[i], xs + (i * 512 + wave * 64) * 16);
-#pragma unroll
-        for (int i = 0; i < WL; i++) {
-            int idx = wave + 8 * i;
-            if (idx >= NWI) idx -= 8;
-            glds16(wsrc + wvoff[part][i], ws + idx * 1024);
-        }
+        for (int i = 0; i < NL; i++) issue_piece(i, sbr, part, slot);
     };
 
     const int xrow_off = j * RS, xswz = j & 15;
@@ -592,8 +620,14 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
     //   khalf 1 ("follower"): stage s:  MFMA(s-1) from registers -> read(s) -> unpack(s)
     // so within a stage the leader's VALU/LDS work runs beside the follower's MFMAs and vice versa, with the same single
     // barrier per stage.
+    // One LDS-DMA instruction costs the issuing wave ~90-170 cycles when issued in a burst right after the barrier
+    // (s_memtime trace: 560-1010 cycles for 6 pieces, with the SIMD's MFMA pipe idle meanwhile).  So the next-next stage's
+    // pieces are issued one at a time BETWEEN the MFMAs of this wave's MFMA block, in the shadow of the matrix pipe.
+    // (Tried and rejected, measured: staging through registers — plain global_load_dwordx4 + ds_write_b128 inside the
+    //  MFMA block — made the block 3x longer, 64 us vs 40 us per call: the waits hipcc puts in front of each ds_write
+    //  serialise the block.  LDS-DMA stays.)
     half8_t xa[4][BNF], wf[4];
-    auto load_unpack = [&](int slot, int part) {               // this wave's 64-k group of the stage: group kh
+    auto load_unpack = [&](int slot, int part, bool load, int sbr, int slot_l) __attribute__((always_inline)) {   // this wave's 64-k group of the stage: group kh
         const uint8_t *xs = smem + slot * ST + xrow_off;
         const uint8_t *wrow = smem + slot * ST + XS + (mg * 32 + j) * WRS;
         Raw<TYPE> raw;
@@ -605,28 +639,29 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
             for (int bf = 0; bf < BNF; bf++) xa[kk][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (kh == 0) raw.frags(part * 2, h, wf, dq); else raw.frags(part * 2 + 1, h, wf, dq);
+        if constexpr (OPT & 1) {
+            auto build = [&](int g) __attribute__((always_inline)) {
+                const typename Raw<TYPE>::Sc z = raw.scales(g);
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    wf[kk] = raw.frag(kk, z, dq);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (load) {
+#pragma unroll
+                        for (int i = 0; i < NL; i++)
+                            if (i * 4 / NL == kk) issue_piece(i, sbr, part, slot_l);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (kh == 0) build(part * 2); else build(part * 2 + 1);
+        } else {
+            if (kh == 0) raw.frags(part * 2, h, wf, dq); else raw.frags(part * 2 + 1, h, wf, dq);
+        }
     };
-    // One LDS-DMA instruction costs the issuing wave ~90-170 cycles when issued in a burst right after the barrier
-    // (s_memtime trace: 560-1010 cycles for 6 pieces, with the SIMD's MFMA pipe idle meanwhile).  So the next-next stage's
-    // pieces are issued one at a time BETWEEN the MFMAs of this wave's MFMA block, in the shadow of the matrix pipe.
-    // (Tried and rejected, measured: staging through registers — plain global_load_dwordx4 + ds_write_b128 inside the
-    //  MFMA block — made the block 3x longer, 64 us vs 40 us per call: the waits hipcc puts in front of each ds_write
-    //  serialise the block.  LDS-DMA stays.)
-    auto src_of = [&](int i, int sbr, int part) -> const char * {
-        if (i < XL) return xbase + (int64_t)(sbr * 2 + part) * p.B * 256 + xvoff[i];
-        return wbase + (int64_t)sbr * BLK + wvoff[part][i - XL];
-    };
-    auto lds_of = [&](int i, int slot) -> uint8_t * {                  // wave-uniform base; the DMA adds lane*16
-        uint8_t *xs = smem + slot * ST;
-        if (i < XL) return xs + (i * 512 + wave * 64) * 16;
-        int idx = wave + 8 * (i - XL);
-        if (idx >= NWI) idx -= 8;
-        return xs + XS + idx * 1024;
-    };
-    auto issue_piece = [&](int i, int sbr, int part, int slot) { glds16(src_of(i, sbr, part), lds_of(i, slot)); };
-    auto mfma_block = [&](bool load, int sbr, int part, int slot_l) {
-        __builtin_amdgcn_s_setprio(1);          // the wave feeding the matrix pipe wins issue arbitration over its partner's unpack
+    auto mfma_block = [&](bool load, int sbr, int part, int slot_l) __attribute__((always_inline)) {
+        if constexpr (OPT & 1) load = false;    // pieces are issued by load_unpack
+        if constexpr (!(OPT & 2)) __builtin_amdgcn_s_setprio(1);          // the wave feeding the matrix pipe wins issue arbitration over its partner's unpack
 #pragma unroll
         for (int kk = 0; kk < 4; kk++)
 #pragma unroll
@@ -635,43 +670,153 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
                 const int n = kk * BNF + bf;
                 if ((n & 1) && (n >> 1) < NL && load) issue_piece(n >> 1, sbr, part, slot_l);
             }
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!(OPT & 2)) __builtin_amdgcn_s_setprio(0);
     };
 
-    auto stamp = [&](int s, int ph) {      // TRACE builds: [wave][stage 0..15][phase 0..7] cycle stamps of block 0
+    auto stamp = [&](int s, int ph) __attribute__((always_inline)) {      // TRACE builds: [wave][stage 0..15][phase 0..7] cycle stamps of block 0
         if (TRACE && blockIdx.x == 0 && s >= 4 && s < 20 && lane == 0) p.trace[(wave * 16 + (s - 4)) * 8 + ph] = __builtin_amdgcn_s_memtime();
     };
+    // TRACE builds: kernel-level milestones of the consumer (blockIdx 0) and its hand-off partner, wave 0:
+    // [8*16*8 + 16*ks + i], i: 0 entry, 1 loop done, 2 K-halves summed, 3 tile in LDS, 4 flag seen, 5 stores issued, 6 drained, 7 flag set
+    const bool trace_wg = TRACE && tile_m == 0 && tile_b == 0;
+    auto estamp = [&](int i) __attribute__((always_inline)) {
+        if (TRACE && trace_wg && tid == 0) p.trace[8 * 16 * 8 + 16 * ks + i] = __builtin_amdgcn_s_memtime();
+    };
+    estamp(0);
+    if (TRACE && tid == 0 && blockIdx.x < 1024) p.trace[8 * 16 * 8 + 32 + blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (3 << 11));   // HW_REG_XCC_ID[3:0]
     issue(0, 0, 0);
     if (nstage > 1) issue(0, 1, 1);
     int slot = 0;
-    for (int sb = 0; sb < nsb; sb++) {
+    // `load` (is there a stage s+2 to fetch?) and `part` are compile-time inside a stage: the steady-state stages carry no
+    // branches around the DMA pieces, so the pieces stay where they are placed between the MFMAs / fragment builds.
+    auto stage = [&](auto LD, auto PART, int sb) __attribute__((always_inline)) {
+        constexpr bool load = decltype(LD)::value;
+        constexpr int part = decltype(PART)::value;
+        const int s = sb * 2 + part;
+        stamp(s, 0);
+        if (load || part == 0) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+        stamp(s, 1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp(s, 2);
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;   // stage s+2 = (sb+1, part) -> slot2
+        if (kh == 1) {                                               // follower: previous stage's fragments (+ DMA issue)
+            if (s > 0) mfma_block(load, sb + 1, part, slot2); else if (load && !(OPT & 1)) issue(sb + 1, part, slot2);
+        }
+        stamp(s, 4);
+        load_unpack(slot, part, load, sb + 1, slot2);
+        stamp(s, 5);
+        if (kh == 0) mfma_block(load, sb + 1, part, slot2);          // leader: this stage's fragments (+ DMA issue)
+        stamp(s, 6);
+        slot = slot1;
+    };
+    // OPT bit 2: IN-WAVE PIPELINE.  A stage of a wave is S (LDS reads, scales, the four half2 of fragment 0) followed by
+    // T (16 MFMAs, each followed by the 3-4 VALU instructions that build one half2 of the NEXT fragment, and now and then one
+    // DMA piece): a wave's own unpack hides under its own MFMAs.  OPT bit 3 adds the phase offset on top: the kh=1 wave of
+    // each SIMD runs T of the PREVIOUS stage right after the barrier and S of this stage after it, so one wave's
+    // latency-bound S runs beside its partner's T.  (Without bit 3 all eight waves run S then T in lockstep.)
+    Raw<TYPE> raw_s;
+    typename Raw<TYPE>::Sc z_s;
+    uint32_t cur[4] = {0, 0, 0, 0};
+    constexpr int NS = (OPT & 16) ? NL / 2 : 0;                    // OPT bit 4: the first NL/2 DMA pieces go out in S (under the LDS latency), the rest in T
+    auto S_phase = [&](int slot, auto PART, auto LD, int sbr, int slot_l) __attribute__((always_inline)) {
+        constexpr int part = decltype(PART)::value;
+        __builtin_amdgcn_sched_barrier(0);                           // do not hoist these reads above a preceding T phase (xa is reused)
+        const uint8_t *xs = smem + slot * ST + xrow_off;
+        const uint8_t *wrow = smem + slot * ST + XS + (mg * 32 + j) * WRS;
+        raw_s.load(wrow, kh, h);
 #pragma unroll
-        for (int part = 0; part < 2; part++) {
-            const int s = sb * 2 + part;
-            stamp(s, 0);
-            if (s + 1 < nstage) wait_vmcnt<NL>(); else wait_vmcnt<0>();
-            stamp(s, 1);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            stamp(s, 2);
-            const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;
-            const bool load = s + 2 < nstage;                        // stage s+2 = (sb+1, part) -> slot2
-            if (kh == 1) {                                           // follower: previous stage's fragments (+ DMA issue)
-                if (s > 0) mfma_block(load, sb + 1, part, slot2); else if (load) issue(sb + 1, part, slot2);
+        for (int kk = 0; kk < 4; kk++) {
+            const int coff = ((kh * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
+#pragma unroll
+            for (int bf = 0; bf < BNF; bf++) xa[kk][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(LD)::value) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) issue_piece(i, sbr, part, slot_l);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kh == 0) z_s = raw_s.scales(part * 2); else z_s = raw_s.scales(part * 2 + 1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[i] = raw_s.pairbits(0, i, z_s, dq);
+    };
+    auto T_phase = [&](auto LD, int sbr, int part, int slot_l) __attribute__((always_inline)) {
+        constexpr bool load = decltype(LD)::value;
+        uint32_t nxt[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const u32x4 cw = {cur[0], cur[1], cur[2], cur[3]};
+            const half8_t wfk = __builtin_bit_cast(half8_t, cw);
+#pragma unroll
+            for (int bf = 0; bf < BNF; bf++) {
+                __builtin_amdgcn_sched_barrier(0);
+                acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[kk][bf], wfk, acc[bf], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < 3) nxt[bf] = raw_s.pairbits(kk + 1, bf, z_s, dq);
+                const int n = kk * BNF + bf;
+                constexpr int NT = NL - NS;
+                if (load && (n * NT) / 16 != ((n + 1) * NT) / 16) issue_piece(NS + (n * NT) / 16, sbr, part, slot_l);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) cur[i] = nxt[i];
+        }
+    };
+    auto stage_sym = [&](auto FOLLOWER, auto LD, auto PART, int sb) __attribute__((always_inline)) {
+        constexpr bool follower = decltype(FOLLOWER)::value;
+        constexpr bool load = decltype(LD)::value;
+        constexpr int part = decltype(PART)::value;
+        const int s = sb * 2 + part;
+        stamp(s, 0);
+        if (load || part == 0) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+        stamp(s, 1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp(s, 2);
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;
+        if constexpr (follower) {                                    // T(s-1) [+ this stage's DMA issue], then S(s)
+            if (s > 0) T_phase(LD, sb + 1, part, slot2);
+            else if (load) {
+#pragma unroll
+                for (int i = NS; i < NL; i++) issue_piece(i, sb + 1, part, slot2);
             }
             stamp(s, 4);
-            load_unpack(slot, part);
-            stamp(s, 5);
-            if (kh == 0) mfma_block(load, sb + 1, part, slot2);      // leader: this stage's fragments (+ DMA issue)
+            S_phase(slot, PART, LD, sb + 1, slot2);
             stamp(s, 6);
-            slot = slot1;
+        } else {
+            S_phase(slot, PART, LD, sb + 1, slot2);
+            stamp(s, 4);
+            T_phase(LD, sb + 1, part, slot2);
+            stamp(s, 6);
         }
+        slot = slot1;
+    };
+    typedef std::integral_constant<bool, true> yes_t; typedef std::integral_constant<bool, false> no_t;
+    typedef std::integral_constant<int, 0> p0_t; typedef std::integral_constant<int, 1> p1_t;
+    if constexpr (OPT & 4) {
+        // the two roles are two separate loops (same number of s_barrier arrivals each): no register state is merged
+        // across the role branch inside the loop
+        auto run = [&](auto ROLE) __attribute__((always_inline)) {
+            for (int sb = 0; sb + 1 < nsb; sb++) { stage_sym(ROLE, yes_t{}, p0_t{}, sb); stage_sym(ROLE, yes_t{}, p1_t{}, sb); }
+            stage_sym(ROLE, no_t{}, p0_t{}, nsb - 1); stage_sym(ROLE, no_t{}, p1_t{}, nsb - 1);
+            if (decltype(ROLE)::value) T_phase(no_t{}, 0, 0, 0);
+        };
+        if ((OPT & 8) && kh == 1) run(yes_t{}); else run(no_t{});
+    } else {
+        for (int sb = 0; sb + 1 < nsb; sb++) { stage(yes_t{}, p0_t{}, sb); stage(yes_t{}, p1_t{}, sb); }
+        stage(no_t{}, p0_t{}, nsb - 1); stage(no_t{}, p1_t{}, nsb - 1);
     }
-    if (kh == 1) mfma_block(false, 0, 0, 0);
+    if (!(OPT & 4) && kh == 1) mfma_block(false, 0, 0, 0);
 
-    // ---- epilogue: sum the two K halves and write 512-byte output rows.  Through LDS (the ring is dead now):
-    //      khalf 1 parks its accumulators, khalf 0 adds them and writes the 128(b) x 128(m) fp32 tile in [b][m] order,
-    //      then all 512 threads store float4s: 4x fewer store instructions than lane-per-m dword stores.
+    estamp(1);
+    // ---- epilogue.  (1) The two K halves of the work-group are summed through LDS (the ring is dead now): khalf 1 parks
+    //      its accumulators, khalf 0 adds them IN REGISTERS.  (2) split-K = 2 hand-off, without atomics or a zero-fill
+    //      pass: the ks=1 work-group publishes those registers as they are (register layout, 16 write-through b128 stores
+    //      per lane, no transposition) and raises a per-launch-tagged flag; the ks=0 work-group of the same tile polls the
+    //      flag (one lane, relaxed), acquires, loads the 16 float4 back-to-back and adds them in registers.  Fixed
+    //      summation order: deterministic.  Both work-groups are co-resident by construction (the launcher only takes this
+    //      path when the grid fits the chip).  (3) The final tile goes through LDS in [b][m] order so that all 512 threads
+    //      store 512-byte output rows as float4s: 4x fewer store instructions than lane-per-m dword stores.
     __syncthreads();
     float4 *red = reinterpret_cast<float4 *>(smem) + (size_t)mg * 1024;   // [16 quads][64 lanes] float4 per m-group (64 KB total)
     if (kh == 1) {
@@ -682,55 +827,93 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
                 red[(bf * 4 + q4) * 64 + lane] = make_float4(acc[bf][4 * q4], acc[bf][4 * q4 + 1], acc[bf][4 * q4 + 2], acc[bf][4 * q4 + 3]);
     }
     __syncthreads();
-    float *ctile = reinterpret_cast<float *>(smem + 64 * 1024);           // [128 b][128 m] fp32 = 64 KB, after the parked partials
-    constexpr int CLD = 128;
     if (kh == 0) {
 #pragma unroll
         for (int bf = 0; bf < BNF; bf++)
 #pragma unroll
             for (int q4 = 0; q4 < 4; q4++) {
                 const float4 v = red[(bf * 4 + q4) * 64 + lane];
-                const float add[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int r = 4 * q4 + e;
-                    const int bl = bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // C/D layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-                    ctile[bl * CLD + mg * 32 + j] = acc[bf][r] + add[e];
-                }
+                acc[bf][4 * q4] += v.x; acc[bf][4 * q4 + 1] += v.y; acc[bf][4 * q4 + 2] += v.z; acc[bf][4 * q4 + 3] += v.w;
             }
     }
-    __syncthreads();
-    // split-K = 2 without atomics or a zero-fill pass: the ks=1 work-group publishes its 64 KB partial tile to global
-    // scratch (write-through sc1 stores, drained by every wave -> relaxed agent-scope flag), the ks=0 work-group of the same tile polls the flag
-    // (one lane, relaxed), acquires, adds its own half and writes Y.  Fixed summation order: deterministic.  Both
-    // work-groups are co-resident by construction (the launcher only takes this path when the grid fits the chip).
+    estamp(2);
+    // (2) symmetric exchange: of the tile's 128 activation rows, work-group ks keeps rows [64 ks, 64 ks + 64) (accumulator
+    //     blocks bf = 2ks, 2ks+1) and exports the other 64 rows of its partial sums to its partner.
     const int tile_id = tile_m * p.tiles_b + tile_b;
-    float *part = p.partial ? p.partial + (size_t)tile_id * (128 * 128) : nullptr;
-    const bool producer = p.partial && ks == 1, consumer = p.partial && ks == 0;
-    __amdgpu_buffer_rsrc_t part_rsrc = __builtin_amdgcn_make_buffer_rsrc(part, 0, 128 * 128 * 4, 0x00020000);
-    if (consumer) {
-        if (tid == 0) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(p.flags + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(2);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
+    const bool handoff = p.partial != nullptr;
+    int row_lo = 0, nrows = 128;                                           // rows of the tile this work-group finishes
+    if (handoff) {
+        float *part_out = p.partial + ((size_t)tile_id * 2 + ks) * (64 * 128);
+        const float *part_in = p.partial + ((size_t)tile_id * 2 + (ks ^ 1)) * (64 * 128);
+        auto exchange = [&](auto KS) __attribute__((always_inline)) {
+            constexpr int own = decltype(KS)::value * 2, exp = 2 - own;   // first bf kept / exported
+            if (kh == 0) {
+                // write-through (sc1) stores: the partial goes straight past this XCD's L2, so publishing needs no L2
+                // write-back fence (which would flush every dirty line of the XCD, ~8 us measured)
+                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, 64 * 128 * 4, 0x00020000);
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const float4 v = make_float4(acc[exp + e][4 * q4], acc[exp + e][4 * q4 + 1], acc[exp + e][4 * q4 + 2], acc[exp + e][4 * q4 + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (((mg * 8 + e * 4 + q4) * 64) + lane) * 16, 0, 16);
+                    }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            estamp(5);
+            __syncthreads();                                                // every storing wave has drained its sc1 stores
+            if (tid == 0) {
+                __hip_atomic_store(p.flags + tile_id * 2 + ks, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                estamp(7);
+                unsigned spins = 0;
+                while (__hip_atomic_load(p.flags + tile_id * 2 + (ks ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            estamp(4);
+            if (kh == 0) {
+                const float4 *pp = reinterpret_cast<const float4 *>(part_in) + (size_t)mg * 512 + lane;
+                float4 o[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[i] = pp[i * 64];
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const float4 v = o[e * 4 + q4];
+                        acc[own + e][4 * q4] += v.x; acc[own + e][4 * q4 + 1] += v.y; acc[own + e][4 * q4 + 2] += v.z; acc[own + e][4 * q4 + 3] += v.w;
+                    }
+            }
+        };
+        if (ks == 0) exchange(std::integral_constant<int, 0>{}); else exchange(std::integral_constant<int, 1>{});
+        row_lo = ks * 64; nrows = 64;
     }
+    // (3) [b][m] tile in LDS (rows row_lo .. row_lo + nrows), then wide stores
+    float *ctile = reinterpret_cast<float *>(smem + 64 * 1024);           // [128 b][128 m] fp32 = 64 KB, after the parked partials
+    constexpr int CLD = 128;
+    if (kh == 0) {
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++) {
+            if (bf * 32 < row_lo || bf * 32 >= row_lo + nrows) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int bl = bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;           // C/D layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                ctile[bl * CLD + mg * 32 + j] = acc[bf][r];
+            }
+        }
+    }
+    __syncthreads();
+    estamp(3);
     {
         const int c4 = tid & 31, r0 = tid >> 5;                             // 32 float4 per row, 16 rows per pass
 #pragma unroll
         for (int pass = 0; pass < 8; pass++) {
-            const int bl = pass * 16 + r0, b = b0 + bl, m = m0 + c4 * 4;
-            float4 v = *reinterpret_cast<const float4 *>(ctile + bl * CLD + c4 * 4);
-            if (producer) {     // write-through (sc1) store: the tile goes straight past this XCD's L2, so publishing needs no
-                                // L2 write-back fence (which would flush every dirty line of the XCD, ~8 us measured)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), part_rsrc, (bl * 128 + c4 * 4) * 4, 0, 16);
-                continue;
-            }
-            if (consumer) { const float4 o = *reinterpret_cast<const float4 *>(part + bl * 128 + c4 * 4); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            if (pass * 16 >= nrows) break;
+            const int bl = row_lo + pass * 16 + r0, b = b0 + bl, m = m0 + c4 * 4;
+            const float4 v = *reinterpret_cast<const float4 *>(ctile + bl * CLD + c4 * 4);
             if (b < p.B && m < p.M) {
                 float *dst = p.Y + (int64_t)b * p.y_row + m;
-                if (p.splitk > 1 && !p.partial) {
+                if (p.splitk > 1 && !handoff) {
                     const float e[4] = {v.x, v.y, v.z, v.w};
                     for (int t = 0; t < 4 && m + t < p.M; t++) unsafeAtomicAdd(dst + t, e[t]);
                 } else if (m + 3 < p.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<float4 *>(dst) = v;
@@ -738,11 +921,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
             }
         }
     }
-    if (producer) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(p.flags + tile_id, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every wave drained its sc1 stores above
-    }
+    estamp(6);
 }
 
 
@@ -762,7 +941,7 @@ bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B) {
 
 template <int TYPE, int BNF, bool WLDS>
 static int launch_variant(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    gemm_params p; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0;
+    gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0; p.sb_split = 0;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 32 * BNF - 1) / (32 * BNF);
@@ -777,7 +956,7 @@ static int launch_variant(const cdna4_gemm_args &a, int splitk, hipStream_t st) 
 
 template <int TYPE, int BNF>
 static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    gemm_params p; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0;
+    gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0; p.sb_split = 0;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 32 * BNF - 1) / (32 * BNF);
@@ -816,8 +995,8 @@ static int cu_count() {
 }
 
 template <int TYPE>
-static int launch_w8(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    gemm_params p; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0;
+static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t st) {
+    gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0; p.sb_split = 0;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 127) / 128;
@@ -825,7 +1004,7 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
     const int ntiles = p.tiles_m * p.tiles_b;
     if (splitk == 2 && ntiles * 2 <= cu_count()) {                    // both halves of every tile are resident at once: hand-off
         const size_t pbytes = (size_t)ntiles * 128 * 128 * 4;
-        char *sc = (char *)get_scratch(pbytes + (size_t)ntiles * 4 + 256);
+        char *sc = (char *)get_scratch(pbytes + (size_t)ntiles * 8 + 256);
         if (!sc) return cdna4_set_error_msg("gemm_q: cannot allocate split-K scratch");
         p.partial = (float *)sc; p.flags = (unsigned *)(sc + pbytes);
         // flags carry a per-launch tag instead of being zeroed by a memset node every call (a 256-byte fill cost ~5 us of
@@ -833,14 +1012,23 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
         // launches.  (Under HIP-graph replay the tag would be frozen: capture is not used on this path.)
         if (++g_handoff_epoch == 0) ++g_handoff_epoch;
         p.epoch = g_handoff_epoch;
+        // ks=0 share of K in 1/16ths.  The exchange is symmetric (each work-group exports half of its partial tile and
+        // finishes the other half), so the even split is the default; CDNA4_SPLIT_NUM overrides it for experiments.
+        static const int num = getenv("CDNA4_SPLIT_NUM") ? atoi(getenv("CDNA4_SPLIT_NUM")) : 8;
+        const int total = a.K / 256;
+        int split = (total * num + 8) / 16;
+        p.sb_split = split < 1 ? 1 : (split > total - 1 ? total - 1 : split);
     } else if (splitk > 1) {
         const int64_t n = (int64_t)a.M * a.B;
         hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.Y, a.y_row_elems, a.M, a.B);
     }
     p.trace = (unsigned long long *)cdna4_debug_trace;
     const dim3 grid(p.tiles_m * p.tiles_b * splitk);
-    if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, true>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, false>), grid, dim3(512), 0, st, p);
+#define W8_LAUNCH(O) do { if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, true, O>), grid, dim3(512), 0, st, p); \
+                          else hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, false, O>), grid, dim3(512), 0, st, p); } while (0)
+    switch (opt & 31) { case 0: W8_LAUNCH(0); break; case 1: W8_LAUNCH(1); break; case 2: W8_LAUNCH(2); break; case 3: W8_LAUNCH(3); break;
+                        case 4: W8_LAUNCH(4); break; case 12: W8_LAUNCH(12); break; case 28: W8_LAUNCH(28); break; case 20: W8_LAUNCH(20); break; default: return cdna4_set_error_msg("gemm_q: unknown 8-wave schedule option"); }
+#undef W8_LAUNCH
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
@@ -849,10 +1037,11 @@ template <int TYPE>
 static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     constexpr bool CAN_LDS = QT<TYPE>::KQ && (QT<TYPE>::BYTES % 16 == 0);
     // variant: bit0 = LDS weight staging (Q4_K/Q5_K only), bit1 = 128-wide activation tile, bit3 = the older
-    // slice-per-barrier kernel instead of the pipelined one, bit4 = the 8-wave (two waves per SIMD) 128x128 kernel.
+    // slice-per-barrier kernel instead of the pipelined one, bit4 = the 8-wave (two waves per SIMD) 128x128 kernel,
+    // bits 5-9 = that kernel's schedule option OPT (see k_gemm_kq_w8; 20 = in-wave pipeline with the DMA pieces split over both phases, the default).
     // 0 = auto: widest tile that the batch fills.
     int variant = a.variant;
-    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? 16 : 0);
+    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? (16 | (20 << 5)) : 0);   // 8-wave kernel, in-wave pipeline, DMA pieces split between the S and T phases
     const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
     const bool wide = (variant & 2) != 0;
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
@@ -867,7 +1056,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     }
     if (splitk < 1 || kunits % splitk) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
     if constexpr (CAN_LDS) {
-        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, st);
+        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant >> 5) & 31, st);
         if (wlds && !(variant & 8)) return wide ? launch_pipe<TYPE, 4>(a, splitk, st) : launch_pipe<TYPE, 2>(a, splitk, st);
         if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
     }

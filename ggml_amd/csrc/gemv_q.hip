@@ -10,25 +10,35 @@
 // Also serves MUL_MAT_ID (per-column expert base, ids read on the device — no host sync).
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
+#include "quantize_dev.h"
 #include <stdlib.h>
 
 __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
 
 template <int TYPE, int NB> struct Unit;
 
+// Every unit is split into load() — all of the unit's weight bytes into registers, no activation dependence — and
+// mac() — the integer dots against the quantized activations.  dot() = mac(load()).  The fused decode kernel calls
+// load() BEFORE it quantizes the activation row, so the weight stream's HBM latency overlaps the quantizer.
+
 // ---- Q4_K: unit = (superblock, 64-group g): 32 bytes of nibbles, low -> k 64g+l, high -> 64g+32+l ---------
 template <int NB> struct Unit<CDNA4_Q4_K, NB> {
     static constexpr int UK = 64;
-    __device__ static void dot(const uint8_t *wrow, int u, const cdna4_gemv_args &a, const int (&col)[NB], float (&acc)[NB]) {
+    struct W { u32x4 hdr, q0, q1; };
+    __device__ static W load(const uint8_t *wrow, int u) {
         const int sb = u >> 2, g = u & 3;
         const uint8_t *blk = wrow + (int64_t)sb * 144;
-        const u32x4 hdr = ld_u32x4(blk);
+        W w; w.hdr = ld_u32x4(blk); w.q0 = ld_u32x4(blk + 16 + 32 * g); w.q1 = ld_u32x4(blk + 32 + 32 * g);
+        return w;
+    }
+    template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
+        const int sb = u >> 2, g = u & 3;
+        const u32x4 hdr = wr.hdr;
         const float d = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
         int sc_lo, m_lo, sc_hi, m_hi;
         k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g, sc_lo, m_lo);
         k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g + 1, sc_hi, m_hi);
-        const u32x4 q0 = ld_u32x4(blk + 16 + 32 * g), q1 = ld_u32x4(blk + 32 + 32 * g);
-        const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const uint32_t w[8] = {wr.q0.x, wr.q0.y, wr.q0.z, wr.q0.w, wr.q1.x, wr.q1.y, wr.q1.z, wr.q1.w};
 #pragma unroll
         for (int c = 0; c < NB; c++) {
             const int8_t *y = a.qs + (int64_t)col[c] * a.K + sb * 256 + 64 * g;
@@ -45,23 +55,29 @@ template <int NB> struct Unit<CDNA4_Q4_K, NB> {
             acc[c] += (d * yd) * (float)(sc_lo * sl + sc_hi * sh) - (dmin * yd) * (float)(m_lo * blo + m_hi * bhi);
         }
     }
+    template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
 };
 
 // ---- Q5_K: Q4_K plus a fifth bit per weight from qh[l] bit 2g (low) / 2g+1 (high) ---------------------------
 template <int NB> struct Unit<CDNA4_Q5_K, NB> {
     static constexpr int UK = 64;
-    __device__ static void dot(const uint8_t *wrow, int u, const cdna4_gemv_args &a, const int (&col)[NB], float (&acc)[NB]) {
+    struct W { u32x4 hdr, h0, h1, q0, q1; };
+    __device__ static W load(const uint8_t *wrow, int u) {
         const int sb = u >> 2, g = u & 3;
         const uint8_t *blk = wrow + (int64_t)sb * 176;
-        const u32x4 hdr = ld_u32x4(blk);
+        W w; w.hdr = ld_u32x4(blk); w.h0 = ld_u32x4(blk + 16); w.h1 = ld_u32x4(blk + 32);
+        w.q0 = ld_u32x4(blk + 48 + 32 * g); w.q1 = ld_u32x4(blk + 64 + 32 * g);
+        return w;
+    }
+    template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
+        const int sb = u >> 2, g = u & 3;
+        const u32x4 hdr = wr.hdr;
         const float d = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
         int sc_lo, m_lo, sc_hi, m_hi;
         k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g, sc_lo, m_lo);
         k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g + 1, sc_hi, m_hi);
-        const u32x4 h0 = ld_u32x4(blk + 16), h1 = ld_u32x4(blk + 32);
-        const u32x4 q0 = ld_u32x4(blk + 48 + 32 * g), q1 = ld_u32x4(blk + 64 + 32 * g);
-        const uint32_t qh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-        const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const uint32_t qh[8] = {wr.h0.x, wr.h0.y, wr.h0.z, wr.h0.w, wr.h1.x, wr.h1.y, wr.h1.z, wr.h1.w};
+        const uint32_t w[8] = {wr.q0.x, wr.q0.y, wr.q0.z, wr.q0.w, wr.q1.x, wr.q1.y, wr.q1.z, wr.q1.w};
         uint32_t wl[8], wh[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -84,28 +100,33 @@ template <int NB> struct Unit<CDNA4_Q5_K, NB> {
             acc[c] += (d * yd) * (float)(sc_lo * sl + sc_hi * sh) - (dmin * yd) * (float)(m_lo * blo + m_hi * bhi);
         }
     }
+    template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
 };
 
 // ---- Q6_K: unit = (superblock, half n, 16-lane slice lb): 16 values of l -> 4 x 16 weights at
 //      k = 128n + 32*quad + 16lb + i, int8 scale per 16 (src/ggml-quants.c:1690-1719) -----------------------
 template <int NB> struct Unit<CDNA4_Q6_K, NB> {
     static constexpr int UK = 64;
-    __device__ static void dot(const uint8_t *wrow, int u, const cdna4_gemv_args &a, const int (&col)[NB], float (&acc)[NB]) {
+    struct W { uint32_t q[4][4]; int sc[4]; float d; };
+    __device__ static W load(const uint8_t *wrow, int u) {
         const int sb = u >> 2, n = (u >> 1) & 1, lb = u & 1;
         const uint8_t *blk = wrow + (int64_t)sb * 210;                       // 2-byte aligned only
         const uint8_t *ql_a = blk + 64 * n + 16 * lb, *ql_b = ql_a + 32, *qhp = blk + 128 + 32 * n + 16 * lb;
         const int8_t *scp = reinterpret_cast<const int8_t *>(blk + 192 + 8 * n + lb);
-        const float d = h2f(ld_u16(blk + 208));
-        uint32_t q[4][4];
+        W w; w.d = h2f(ld_u16(blk + 208));
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t la = ld_u32_a2(ql_a + 4 * i), lv = ld_u32_a2(ql_b + 4 * i), hq = ld_u32_a2(qhp + 4 * i);
-            q[0][i] = (la & 0x0F0F0F0Fu) | ((hq & 0x03030303u) << 4);
-            q[1][i] = (lv & 0x0F0F0F0Fu) | (((hq >> 2) & 0x03030303u) << 4);
-            q[2][i] = ((la >> 4) & 0x0F0F0F0Fu) | (((hq >> 4) & 0x03030303u) << 4);
-            q[3][i] = ((lv >> 4) & 0x0F0F0F0Fu) | (((hq >> 6) & 0x03030303u) << 4);
+            w.q[0][i] = (la & 0x0F0F0F0Fu) | ((hq & 0x03030303u) << 4);
+            w.q[1][i] = (lv & 0x0F0F0F0Fu) | (((hq >> 2) & 0x03030303u) << 4);
+            w.q[2][i] = ((la >> 4) & 0x0F0F0F0Fu) | (((hq >> 4) & 0x03030303u) << 4);
+            w.q[3][i] = ((lv >> 4) & 0x0F0F0F0Fu) | (((hq >> 6) & 0x03030303u) << 4);
         }
-        const int sc[4] = {scp[0], scp[2], scp[4], scp[6]};
+        w.sc[0] = scp[0]; w.sc[1] = scp[2]; w.sc[2] = scp[4]; w.sc[3] = scp[6];
+        return w;
+    }
+    template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
+        const int sb = u >> 2, n = (u >> 1) & 1, lb = u & 1;
 #pragma unroll
         for (int c = 0; c < NB; c++) {
             const int8_t *y = a.qs + (int64_t)col[c] * a.K + sb * 256 + 128 * n + 16 * lb;
@@ -114,24 +135,28 @@ template <int NB> struct Unit<CDNA4_Q6_K, NB> {
 #pragma unroll
             for (int qd = 0; qd < 4; qd++) {
                 const u32x4 yv = ld_u32x4(y + 32 * qd);
-                int s = dot4(q[qd][0], yv.x, 0); s = dot4(q[qd][1], yv.y, s); s = dot4(q[qd][2], yv.z, s); s = dot4(q[qd][3], yv.w, s);
-                isum += sc[qd] * (s - 32 * (int)bs[2 * qd]);                // sum (q-32)*y = sum q*y - 32*bsum
+                int s = dot4(wr.q[qd][0], yv.x, 0); s = dot4(wr.q[qd][1], yv.y, s); s = dot4(wr.q[qd][2], yv.z, s); s = dot4(wr.q[qd][3], yv.w, s);
+                isum += wr.sc[qd] * (s - 32 * (int)bs[2 * qd]);             // sum (q-32)*y = sum q*y - 32*bsum
             }
             const float yd = a.d[(int64_t)col[c] * (a.K / 256) + sb];
-            acc[c] += (d * yd) * (float)isum;
+            acc[c] += (wr.d * yd) * (float)isum;
         }
     }
+    template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
 };
 
 // ---- Q4_0: unit = 18-byte block, nibble j -> k j (low), j+16 (high), value q-8 ------------------------------
 template <int NB> struct Unit<CDNA4_Q4_0, NB> {
     static constexpr int UK = 32;
-    __device__ static void dot(const uint8_t *wrow, int u, const cdna4_gemv_args &a, const int (&col)[NB], float (&acc)[NB]) {
+    struct W { float d; uint32_t w[4]; };
+    __device__ static W load(const uint8_t *wrow, int u) {
         const uint8_t *blk = wrow + (int64_t)u * 18;
-        const float d = h2f(ld_u16(blk));
-        uint32_t w[4];
+        W r; r.d = h2f(ld_u16(blk));
 #pragma unroll
-        for (int i = 0; i < 4; i++) w[i] = ld_u32_a2(blk + 2 + 4 * i);
+        for (int i = 0; i < 4; i++) r.w[i] = ld_u32_a2(blk + 2 + 4 * i);
+        return r;
+    }
+    template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
 #pragma unroll
         for (int c = 0; c < NB; c++) {
             const int8_t *y = a.qs + (int64_t)col[c] * a.K + u * 32;
@@ -140,23 +165,27 @@ template <int NB> struct Unit<CDNA4_Q4_0, NB> {
             int s = 0, ys = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                s = dot4(w[i] & 0x0F0F0F0Fu, yl[i], s); s = dot4((w[i] >> 4) & 0x0F0F0F0Fu, yh[i], s);
+                s = dot4(wr.w[i] & 0x0F0F0F0Fu, yl[i], s); s = dot4((wr.w[i] >> 4) & 0x0F0F0F0Fu, yh[i], s);
                 ys = dot4(0x01010101u, yl[i], ys); ys = dot4(0x01010101u, yh[i], ys);
             }
-            acc[c] += (float)(s - 8 * ys) * d * a.d[(int64_t)col[c] * (a.K / 32) + u];
+            acc[c] += (float)(s - 8 * ys) * wr.d * a.d[(int64_t)col[c] * (a.K / 32) + u];
         }
     }
+    template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
 };
 
 // ---- Q8_0: unit = 34-byte block ----------------------------------------------------------------------------
 template <int NB> struct Unit<CDNA4_Q8_0, NB> {
     static constexpr int UK = 32;
-    __device__ static void dot(const uint8_t *wrow, int u, const cdna4_gemv_args &a, const int (&col)[NB], float (&acc)[NB]) {
+    struct W { float d; uint32_t w[8]; };
+    __device__ static W load(const uint8_t *wrow, int u) {
         const uint8_t *blk = wrow + (int64_t)u * 34;
-        const float d = h2f(ld_u16(blk));
-        uint32_t w[8];
+        W r; r.d = h2f(ld_u16(blk));
 #pragma unroll
-        for (int i = 0; i < 8; i++) w[i] = ld_u32_a2(blk + 2 + 4 * i);
+        for (int i = 0; i < 8; i++) r.w[i] = ld_u32_a2(blk + 2 + 4 * i);
+        return r;
+    }
+    template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
 #pragma unroll
         for (int c = 0; c < NB; c++) {
             const int8_t *y = a.qs + (int64_t)col[c] * a.K + u * 32;
@@ -164,10 +193,11 @@ template <int NB> struct Unit<CDNA4_Q8_0, NB> {
             const uint32_t yv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
             int s = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) s = dot4(w[i], yv[i], s);
-            acc[c] += (float)s * (d * a.d[(int64_t)col[c] * (a.K / 32) + u]);
+            for (int i = 0; i < 8; i++) s = dot4(wr.w[i], yv[i], s);
+            acc[c] += (float)s * (wr.d * a.d[(int64_t)col[c] * (a.K / 32) + u]);
         }
     }
+    template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
 };
 
 template <int TYPE, int NB, bool IDS, int ROWS>
@@ -245,6 +275,104 @@ static int launch_type(const cdna4_gemv_args &a0, hipStream_t st) {
     return 0;
 }
 
+
+// ---- fused activation-quantize + GEMV (single-column decode) ------------------------------------------------
+// One launch instead of two for the B=1 MUL_MAT: every workgroup re-quantizes the whole activation row into
+// LDS (K bytes of int8 + scales + bsums; the row is 16 KiB at K=4096 and L2-resident after the first
+// workgroup touched it), then its four waves run the same Unit::dot bodies against LDS.  The redundant
+// quantization costs ~0.5 us of VALU per workgroup and saves a ~3 us kernel plus the launch gap.
+// (Touching the wave's weight row before the quantization to overlap its HBM latency was measured SLOWER: 7.2 vs 6.1 us.)
+struct lds_act { const int8_t *qs; const float *d; const int16_t *bsums; int K; };
+
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_gemv_q_fused(const cdna4_gemv_args a, const float *__restrict__ x) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr bool KQ = QT<TYPE>::KQ;
+    const int K = a.K, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int8_t *sq = reinterpret_cast<int8_t *>(smem);
+    int16_t *sbs = reinterpret_cast<int16_t *>(smem + K);                   // K/8 bytes (Q8_K only)
+    float *sd = reinterpret_cast<float *>(smem + K + (KQ ? K / 8 : 0));
+    const int row = blockIdx.x * 4 + wave;
+    const uint8_t *wrow = a.W + (int64_t)min(row, a.M - 1) * a.w_row_bytes;
+    const int nunits = K / Unit<TYPE, 1>::UK;
+    // this lane's first unit goes into registers now: its HBM latency runs under the quantizer below
+    const typename Unit<TYPE, 1>::W w0 = Unit<TYPE, 1>::load(wrow, min(lane, nunits - 1));
+    // One lane quantizes 16 consecutive values (= one bsums entry, one ds_write_b128): a superblock is 16 adjacent lanes
+    // (4 butterfly rounds), a Q8_0 block 2 lanes (1 round).  The first cut (one wave per superblock, 4 values per lane,
+    // 6 rounds x 3 shuffles, 4 superblocks in sequence per wave) cost ~5 us per work-group and lost to the two-kernel path.
+    for (int c = threadIdx.x; c < K / 16; c += 256) {
+        float e[16];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + c * 16 + 4 * i);
+            e[4 * i] = v.x; e[4 * i + 1] = v.y; e[4 * i + 2] = v.z; e[4 * i + 3] = v.w;
+        }
+        int q[16];
+        if (KQ) {
+            // first index with the largest |x| keeps its SIGNED value (quantize_row_q8_K_ref, src/ggml-quants.c:2485-2491)
+            float amax = 0.f, mx = 0.f; int idx = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) { const float ax = fabsf(e[i]); if (ax > amax) { amax = ax; mx = e[i]; idx = (c & 15) * 16 + i; } }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const float oa = __shfl_xor(amax, o, 64), om = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(idx, o, 64);
+                if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
+            }
+            float d = 0.f; int bsum = 0;
+            if (amax != 0.f) {
+                const float iscale = -127.f / mx;
+#pragma unroll
+                for (int i = 0; i < 16; i++) { const int t = (int)__builtin_rintf(iscale * e[i]); q[i] = t < 127 ? t : 127; bsum += q[i]; }
+                d = 1.0f / iscale;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) q[i] = 0;
+            }
+            sbs[c] = (int16_t)bsum;
+            if ((c & 15) == 0) sd[c >> 4] = d;
+        } else {
+            // AVX2 body of quantize_row_q8_0 (src/ggml-cpu/ggml-cpu-quants.c:778-815): d = amax/127 -> fp16, id = 127/amax, RNE
+            float amax = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) amax = fmaxf(amax, fabsf(e[i]));
+            amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+            const float d = amax / 127.f, id = amax != 0.f ? 127.f / amax : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) q[i] = (int)__builtin_rintf(e[i] * id);
+            if ((c & 1) == 0) sd[c >> 1] = h2f(f2h_bits(d));
+        }
+        u32x4 pk;
+        { const int q0[4] = {q[0], q[1], q[2], q[3]}, q1[4] = {q[4], q[5], q[6], q[7]}, q2[4] = {q[8], q[9], q[10], q[11]}, q3[4] = {q[12], q[13], q[14], q[15]};
+          pk.x = pack4i8(q0); pk.y = pack4i8(q1); pk.z = pack4i8(q2); pk.w = pack4i8(q3); }
+        *reinterpret_cast<u32x4 *>(sq + c * 16) = pk;
+    }
+    __syncthreads();
+    if (row >= a.M) return;
+    const lds_act act{sq, sd, sbs, K};
+    const int col[1] = {0};
+    float acc[1] = {0.f};
+    if (lane < nunits) Unit<TYPE, 1>::mac(w0, lane, act, col, acc);
+    for (int u = lane + 64; u < nunits; u += 64) Unit<TYPE, 1>::dot(wrow, u, act, col, acc);
+    const float s = wave_sum(acc[0]);
+    if (lane == 0) a.Y[row] = s;
+}
+
+size_t cdna4_gemv_fused_lds_bytes(int type, int64_t K) {
+    const bool kq = type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K;
+    return (size_t)(K + (kq ? K / 8 + (K / 256) * 4 : (K / 32) * 4));
+}
+bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B) {
+    static const bool off = getenv("CDNA4_NO_FUSE") != nullptr;
+    return !off && B == 1 && K > 0 && cdna4_gemv_fused_lds_bytes(type, K) <= 64 * 1024;
+}
+template <int TYPE>
+static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st) {
+    const size_t lds = cdna4_gemv_fused_lds_bytes(TYPE, a.K);
+    hipLaunchKernelGGL((k_gemv_q_fused<TYPE>), dim3((a.M + 3) / 4), dim3(256), lds, st, a, x);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
 int cdna4_launch_gemv_q(const cdna4_gemv_args &a, hipStream_t st) {
     if (a.M <= 0 || a.ncol <= 0) return 0;
     if (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes | (uintptr_t)a.qs) & 1) return cdna4_set_error_msg("gemv_q: misaligned operands");
@@ -259,6 +387,26 @@ int cdna4_launch_gemv_q(const cdna4_gemv_args &a, hipStream_t st) {
             return launch_type<CDNA4_Q6_K>(a, st);
         case CDNA4_Q4_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_type<CDNA4_Q4_0>(a, st);
         case CDNA4_Q8_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_type<CDNA4_Q8_0>(a, st);
+    }
+    return cdna4_set_error_msg("gemv_q: unsupported weight type");
+}
+
+// a.qs / a.d / a.bsums are ignored: the activation row x (fp32, 16-byte aligned, K values) is quantized in LDS
+int cdna4_launch_gemv_q_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st) {
+    if (a.M <= 0) return 0;
+    if (!cdna4_gemv_fused_supported(a.type, a.K, a.ncol)) return cdna4_set_error_msg("gemv_q_fused: unsupported shape");
+    if ((uintptr_t)x & 15) return cdna4_set_error_msg("gemv_q_fused: x must be 16-byte aligned");
+    if (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 1) return cdna4_set_error_msg("gemv_q: misaligned operands");
+    switch (a.type) {
+        case CDNA4_Q4_K: case CDNA4_Q5_K:
+            if (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) return cdna4_set_error_msg("gemv_q: Q4_K/Q5_K rows must be 16-byte aligned");
+            if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256");
+            return a.type == CDNA4_Q4_K ? launch_fused<CDNA4_Q4_K>(a, x, st) : launch_fused<CDNA4_Q5_K>(a, x, st);
+        case CDNA4_Q6_K:
+            if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256");
+            return launch_fused<CDNA4_Q6_K>(a, x, st);
+        case CDNA4_Q4_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_Q4_0>(a, x, st);
+        case CDNA4_Q8_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_Q8_0>(a, x, st);
     }
     return cdna4_set_error_msg("gemv_q: unsupported weight type");
 }

@@ -15,54 +15,68 @@
 // Compiled with -ffp-contract=off: iscale*x must round before the integer conversion, as on the CPU.
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
+#include "quantize_dev.h"
 
 __device__ __forceinline__ u32x2 pack4h(half_t a, half_t b, half_t c, half_t d) {
     const half2_t lo = {a, b}, hi = {c, d};
     u32x2 r; r.x = __builtin_bit_cast(uint32_t, lo); r.y = __builtin_bit_cast(uint32_t, hi); return r;
 }
 
-// one wave per 256-element superblock, 4 consecutive elements per lane
+// 16 lanes per 256-element superblock, 16 consecutive elements per lane (one bsums entry, one 16-byte int8 store, one
+// 32-byte fp16 store per lane); 4 butterfly rounds.  (The first version — one wave per superblock, 4 elements per lane,
+// 6 rounds — took 6.0 us for the 512 x 4096 headline batch; the per-lane work is what the fused decode kernel uses too.)
 __global__ __launch_bounds__(256) void k_quantize_q8_K(const float *__restrict__ x, int64_t x_row_stride, int K, int B,
                                                        int8_t *__restrict__ qs, float *__restrict__ dd,
                                                        int16_t *__restrict__ bsums, half_t *__restrict__ xh) {
-    const int lane = threadIdx.x & 63;
-    const int nsb = K / QK_K;
-    const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // superblock id over [B][nsb]
-    if (blk >= (int64_t)B * nsb) return;
-    const int b = (int)(blk / nsb), sb = (int)(blk % nsb);
-    const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t)b * x_row_stride + (int64_t)sb * QK_K + lane * 4);
-    const float e[4] = {v.x, v.y, v.z, v.w};
+    const int nch = K / 16;                                                  // 16-element chunks per row
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;              // chunk id over [B][nch]
+    if (t >= (int64_t)B * nch) return;                                       // whole 16-lane groups drop out together (nch % 16 == 0)
+    const int b = (int)(t / nch), c = (int)(t % nch);
+    const float *px = x + (int64_t)b * x_row_stride + (int64_t)c * 16;
+    float e[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float4 v = *reinterpret_cast<const float4 *>(px + 4 * i);
+        e[4 * i] = v.x; e[4 * i + 1] = v.y; e[4 * i + 2] = v.z; e[4 * i + 3] = v.w;
+    }
     // first index with the largest |x| keeps its SIGNED value (src/ggml-quants.c:2485-2491)
     float amax = 0.f, mx = 0.f; int idx = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) { const float ax = fabsf(e[i]); if (ax > amax) { amax = ax; mx = e[i]; idx = lane * 4 + i; } }
+    for (int i = 0; i < 16; i++) { const float ax = fabsf(e[i]); if (ax > amax) { amax = ax; mx = e[i]; idx = (c & 15) * 16 + i; } }
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
+    for (int o = 1; o < 16; o <<= 1) {
         const float oa = __shfl_xor(amax, o, 64), om = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(idx, o, 64);
         if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
     }
-    int q[4] = {0, 0, 0, 0}; float d = 0.f;
+    int q[16]; float d = 0.f; int bsum = 0;
     if (amax != 0.f) {
         const float iscale = -127.f / mx;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const int t = (int)__builtin_rintf(iscale * e[i]); q[i] = t < 127 ? t : 127; }   // nearest_int == RNE
+        for (int i = 0; i < 16; i++) { const int v = (int)__builtin_rintf(iscale * e[i]); q[i] = v < 127 ? v : 127; bsum += q[i]; }   // nearest_int == RNE
         d = 1.0f / iscale;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) q[i] = 0;
     }
-    const int64_t base = (int64_t)b * K + (int64_t)sb * QK_K + lane * 4;
     if (qs) {
-        const uint32_t packed = (uint32_t)(q[0] & 0xFF) | ((uint32_t)(q[1] & 0xFF) << 8) | ((uint32_t)(q[2] & 0xFF) << 16) | ((uint32_t)(q[3] & 0xFF) << 24);
-        *reinterpret_cast<uint32_t *>(qs + base) = packed;
-        if (lane == 0) dd[(int64_t)b * nsb + sb] = d;
-        int s = q[0] + q[1] + q[2] + q[3];
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
-        if ((lane & 3) == 0) bsums[(int64_t)b * (K / 16) + sb * 16 + (lane >> 2)] = (int16_t)s;
+        u32x4 pk;
+        { const int q0[4] = {q[0], q[1], q[2], q[3]}, q1[4] = {q[4], q[5], q[6], q[7]}, q2[4] = {q[8], q[9], q[10], q[11]}, q3[4] = {q[12], q[13], q[14], q[15]};
+          pk.x = pack4i8(q0); pk.y = pack4i8(q1); pk.z = pack4i8(q2); pk.w = pack4i8(q3); }
+        *reinterpret_cast<u32x4 *>(qs + (int64_t)b * K + (int64_t)c * 16) = pk;
+        bsums[(int64_t)b * nch + c] = (int16_t)bsum;
+        if ((c & 15) == 0) dd[(int64_t)b * (K / QK_K) + (c >> 4)] = d;
     }
     if (xh) {
-        half_t h[4];
+        half_t hv[16];
 #pragma unroll
-        for (int i = 0; i < 4; i++) h[i] = (half_t)(d * (float)q[i]);
-        const int64_t k = (int64_t)sb * QK_K + lane * 4;
-        *reinterpret_cast<u32x2 *>(xh + ((k >> 7) * B + b) * 128 + (k & 127)) = pack4h(h[0], h[2], h[1], h[3]);   // pair-interleaved, panel-major
+        for (int i = 0; i < 16; i++) hv[i] = (half_t)(d * (float)q[i]);
+        const int64_t k = (int64_t)c * 16;
+        half_t *dst = xh + ((k >> 7) * B + b) * 128 + (k & 127);           // pair-interleaved (k0,k2,k1,k3), panel-major
+        u32x4 lo, hi;
+        { const u32x2 a0 = pack4h(hv[0], hv[2], hv[1], hv[3]), a1 = pack4h(hv[4], hv[6], hv[5], hv[7]);
+          const u32x2 a2 = pack4h(hv[8], hv[10], hv[9], hv[11]), a3 = pack4h(hv[12], hv[14], hv[13], hv[15]);
+          lo.x = a0.x; lo.y = a0.y; lo.z = a1.x; lo.w = a1.y; hi.x = a2.x; hi.y = a2.y; hi.z = a3.x; hi.w = a3.y; }
+        *reinterpret_cast<u32x4 *>(dst) = lo; *reinterpret_cast<u32x4 *>(dst + 8) = hi;
     }
 }
 
@@ -78,19 +92,11 @@ __global__ __launch_bounds__(256) void k_quantize_q8_0(const float *__restrict__
     const int b = (int)(blk / nb), ib = (int)(blk % nb), sub = (int)(t & 7);
     const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t)b * x_row_stride + (int64_t)ib * 32 + sub * 4);
     const float e[4] = {v.x, v.y, v.z, v.w};
-    float amax = fmaxf(fmaxf(fabsf(e[0]), fabsf(e[1])), fmaxf(fabsf(e[2]), fabsf(e[3])));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
-    const float d = amax / 127.f;
-    float id;
-    if (REF) id = d != 0.f ? 1.0f / d : 0.f; else id = amax != 0.f ? 127.f / amax : 0.f;
-    int q[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) q[i] = REF ? (int)roundf(e[i] * id) : (int)__builtin_rintf(e[i] * id);
-    const float dh = h2f(f2h_bits(d));                                      // the CPU stores d as fp16 and reads that back
+    int q[4]; float dh;
+    q8_0_block<REF>(e, q, dh);
     const int64_t base = (int64_t)b * K + (int64_t)ib * 32 + sub * 4;
     if (qs) {
-        const uint32_t packed = (uint32_t)(q[0] & 0xFF) | ((uint32_t)(q[1] & 0xFF) << 8) | ((uint32_t)(q[2] & 0xFF) << 16) | ((uint32_t)(q[3] & 0xFF) << 24);
-        *reinterpret_cast<uint32_t *>(qs + base) = packed;
+        *reinterpret_cast<uint32_t *>(qs + base) = pack4i8(q);
         if (sub == 0) dd[(int64_t)b * nb + ib] = dh;
     }
     if (xh) {
@@ -106,8 +112,8 @@ int cdna4_launch_quantize_q8_K(const float *x, int64_t x_row_stride, int64_t K, 
                                int16_t *bsums, void *xh, hipStream_t st) {
     if (K % QK_K) return cdna4_set_error_msg("quantize_q8_K: K must be a multiple of 256");
     if (B == 0 || K == 0) return 0;
-    const int64_t nblk = B * (K / QK_K);
-    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, bsums, (half_t *)xh);
+    const int64_t nthr = B * (K / 16);
+    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, bsums, (half_t *)xh);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

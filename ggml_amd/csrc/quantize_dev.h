@@ -1,0 +1,45 @@
+// quantize_dev.h — the per-block bodies of the activation quantizers, shared by the standalone kernels
+// (quantize_act.hip) and the fused quantize+GEMV decode kernel (gemv_q.hip).  Bit-identical to the CPU:
+//   q8_K_superblock : quantize_row_q8_K_ref, src/ggml-quants.c:2479-2516 (one wave per 256 values)
+//   q8_0_block      : AVX2 body of quantize_row_q8_0, src/ggml-cpu/ggml-cpu-quants.c:778-815 (REF=false) or
+//                     quantize_row_q8_0_ref, src/ggml-quants.c:194-217 (REF=true); 8 lanes per 32 values
+// Must be compiled with -ffp-contract=off (iscale*x rounds before the integer conversion).
+#pragma once
+#include "cdna4_common.h"
+
+// lane holds e[0..3] = x[4*lane .. 4*lane+3] of one superblock; returns q[4] and the block scale d (wave-uniform)
+__device__ __forceinline__ void q8_K_superblock(const float (&e)[4], int lane, int (&q)[4], float &d) {
+    // first index with the largest |x| keeps its SIGNED value (src/ggml-quants.c:2485-2491)
+    float amax = 0.f, mx = 0.f; int idx = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const float ax = fabsf(e[i]); if (ax > amax) { amax = ax; mx = e[i]; idx = lane * 4 + i; } }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float oa = __shfl_xor(amax, o, 64), om = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
+    }
+    q[0] = q[1] = q[2] = q[3] = 0; d = 0.f;
+    if (amax != 0.f) {
+        const float iscale = -127.f / mx;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int t = (int)__builtin_rintf(iscale * e[i]); q[i] = t < 127 ? t : 127; }   // nearest_int == RNE
+        d = 1.0f / iscale;
+    }
+}
+
+// lane holds 4 consecutive values of a 32-value block spread over 8 adjacent lanes; dh = the fp16-rounded scale
+template <bool REF>
+__device__ __forceinline__ void q8_0_block(const float (&e)[4], int (&q)[4], float &dh) {
+    float amax = fmaxf(fmaxf(fabsf(e[0]), fabsf(e[1])), fmaxf(fabsf(e[2]), fabsf(e[3])));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const float d = amax / 127.f;
+    float id;
+    if (REF) id = d != 0.f ? 1.0f / d : 0.f; else id = amax != 0.f ? 127.f / amax : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = REF ? (int)roundf(e[i] * id) : (int)__builtin_rintf(e[i] * id);
+    dh = h2f(f2h_bits(d));                                                  // the CPU stores d as fp16 and reads that back
+}
+
+__device__ __forceinline__ uint32_t pack4i8(const int (&q)[4]) {
+    return (uint32_t)(q[0] & 0xFF) | ((uint32_t)(q[1] & 0xFF) << 8) | ((uint32_t)(q[2] & 0xFF) << 16) | ((uint32_t)(q[3] & 0xFF) << 24);
+}

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out; rm -f gpurun_out/gemm_bench3.txt
+GB_TRACE_SPLITK=2 GB_VARIANTS="407" timeout 120 tools/microbench/gemm_bench 4096 4096 512 407 >> gpurun_out/gemm_bench3.txt 2>&1
+cat gpurun_out/gemm_bench3.txt
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -p no:cacheprovider -x -k "gemv or fused or decode or golden" > gpurun_out/pytest_exp.log 2>&1
+echo "parity rc=$?"; tail -3 gpurun_out/pytest_exp.log
+for v in "A=1" "CDNA4_NO_FUSE=1"; do echo "== $v"; env $v timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['us_per_launch'], json.dumps(d['decode']))"; done

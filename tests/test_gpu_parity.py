@@ -125,6 +125,22 @@ def test_gemv_parity(gu, name, t, m, k, b):
 
 
 @pytest.mark.parametrize("name,t", WT)
+@pytest.mark.parametrize("m,k", [(5, 256), (130, 4096), (64, 16384), (9, 512)])
+def test_fused_decode_equals_two_kernel_path(gu, name, t, m, k):
+    """B=1 ggml_cdna4_mul_mat quantizes the activation row inside the GEMV launch; it must reproduce the
+    quantize-then-GEMV pair bit for bit (same quantizer body, same dot bodies, same reduction order)"""
+    from ggml_amd import ops
+    w = R.random_weights(t, m, k, seed=3 * m + k)
+    x = _x(k - m, 1, k, "normal")
+    a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
+    y_fused = ops.mul_mat(a, xd).cpu().numpy()
+    y_two = ops.mul_mat_prepared(a, ops.PreparedAct(t, xd, path=ops.PATH_GEMV)).cpu().numpy()
+    assert np.array_equal(y_fused.view(np.uint32), y_two.view(np.uint32))
+    e = R.rel_l2(y_fused, R.o_mul_mat(t, w, x, m, k)); gu.report(test="gemv_fused", type=name, m=m, k=k, rel_l2=e)
+    assert e < TOL_GEMV
+
+
+@pytest.mark.parametrize("name,t", WT)
 def test_gemv_many_columns_and_32_block_k(gu, name, t):
     """B > 8 through the GEMV path (column groups), and K = one block for the 32-block formats"""
     from ggml_amd import ops
@@ -155,7 +171,7 @@ def test_gemm_parity_auto(gu, name, t, m, k, b):
 
 
 @pytest.mark.parametrize("name,t", WT)
-@pytest.mark.parametrize("variant", [4, 5, 6, 7, 13, 15, 23])
+@pytest.mark.parametrize("variant", [4, 5, 6, 7, 13, 15, 23, 55, 87, 119, 151, 407, 663, 919])
 @pytest.mark.parametrize("splitk", [1, 2])
 def test_gemm_variants(gu, name, t, variant, splitk):
     """every tile variant (bit0 LDS-staged weights, bit1 128-wide activation tile) x split-K"""

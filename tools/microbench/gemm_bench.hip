@@ -3,6 +3,7 @@
 //   gemm_bench [M K B]        links ../../ggml_amd/lib/libcdna4_kernels.so
 #include "../../include/ggml_cdna4.h"
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,7 +24,11 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     struct cfg { int variant, splitk, ablate; };
     std::vector<cfg> cfgs;
-    for (int v : {0, 5, 23}) for (int sk : {1, 2}) cfgs.push_back({v, sk, 0});
+    // GB_VARIANTS="23,55,151" overrides the variant list (see launch_type() in gemm_q_mfma.hip for the bits)
+    std::vector<int> vars = {0, 5, 23};
+    if (const char *e = getenv("GB_VARIANTS")) { vars.clear(); for (const char *q = e; *q;) { vars.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; } }
+    for (int v : vars) for (int sk : {1, 2}) cfgs.push_back({v, sk, 0});
+    std::vector<float> yref, ycur((size_t)B * M);
     printf("M=%lld K=%lld B=%lld  flops=%.3f G\n", (long long)M, (long long)K, (long long)B, 2.0 * M * K * B / 1e9);
     for (auto c : cfgs) {
         auto run = [&] { return ggml_cdna4_mul_mat_prepared(GGML_CDNA4_TYPE_Q4_K, dw, ggml_cdna4_row_size(GGML_CDNA4_TYPE_Q4_K, K), (float *)dy, M, M, K, B, ws, wsz, GGML_CDNA4_PATH_GEMM, c.variant, c.splitk, 0); };
@@ -32,21 +37,38 @@ int main(int argc, char **argv) {
         const int n = 100;
         hipEventRecord(e0, 0); for (int i = 0; i < n; i++) run(); hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("variant %2d splitk %d ablate %2d : %8.2f us/call  %8.1f TFLOP/s\n", c.variant, c.splitk, c.ablate, ms * 1e3 / n, 2.0 * M * K * B / (ms * 1e-3 / n) / 1e12);
+        hipMemcpy(ycur.data(), dy, ycur.size() * 4, hipMemcpyDeviceToHost);
+        if (yref.empty()) yref = ycur;
+        double num = 0, den = 0; for (size_t i = 0; i < ycur.size(); i++) { const double d = (double)ycur[i] - yref[i]; num += d * d; den += (double)yref[i] * yref[i]; }
+        printf("variant %3d splitk %d ablate %2d : %8.2f us/call  %8.1f TFLOP/s   rel-L2 vs first config %.2e\n", c.variant, c.splitk, c.ablate, ms * 1e3 / n, 2.0 * M * K * B / (ms * 1e-3 / n) / 1e12, sqrt(num / (den + 1e-30)));
     }
-    // per-phase timeline of the 8-wave kernel's first work-group (stages 4..19), from s_memtime stamps
-    unsigned long long *dtr; hipMalloc(&dtr, 65536); hipMemset(dtr, 0, 65536);
-    ggml_cdna4_debug_trace(dtr);
-    ggml_cdna4_mul_mat_prepared(GGML_CDNA4_TYPE_Q4_K, dw, ggml_cdna4_row_size(GGML_CDNA4_TYPE_Q4_K, K), (float *)dy, M, M, K, B, ws, wsz, GGML_CDNA4_PATH_GEMM, argc > 4 ? atoi(argv[4]) : 23, 1, 0);
-    hipDeviceSynchronize();
-    ggml_cdna4_debug_trace(nullptr);
-    std::vector<unsigned long long> tr(8 * 16 * 8); hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost);
-    printf("trace (cycles since the stage-4 stamp of wave 0; phases: 0 stage start, 1 after vmcnt wait, 2 after barrier, 3 after DMA issue, 4 after follower MFMA, 5 after read+unpack, 6 after leader MFMA)\n");
-    const unsigned long long t0 = tr[0];
-    for (int w : {0, 4}) for (int st = 0; st < 6; st++) {
-        printf("wave %d stage %2d:", w, st + 4);
-        for (int ph = 0; ph < 7; ph++) printf(" %7lld", (long long)(tr[(w * 16 + st) * 8 + ph] - t0));
-        printf("\n");
+    // per-phase timeline of the 8-wave kernel's first work-group (stages 4..19), from s_memtime stamps; argv[4] = "23,55,.."
+    unsigned long long *dtr; hipMalloc(&dtr, 65536);
+    std::vector<int> tv; for (const char *q = argc > 4 ? argv[4] : "23"; *q;) { tv.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; }
+    for (int v : tv) {
+        hipMemset(dtr, 0, 65536);
+        ggml_cdna4_debug_trace(dtr);
+        ggml_cdna4_mul_mat_prepared(GGML_CDNA4_TYPE_Q4_K, dw, ggml_cdna4_row_size(GGML_CDNA4_TYPE_Q4_K, K), (float *)dy, M, M, K, B, ws, wsz, GGML_CDNA4_PATH_GEMM, v, getenv("GB_TRACE_SPLITK") ? atoi(getenv("GB_TRACE_SPLITK")) : 1, 0);
+        hipDeviceSynchronize();
+        ggml_cdna4_debug_trace(nullptr);
+        std::vector<unsigned long long> tr(8 * 16 * 8 + 32 + 1024); hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost);
+        {   // which XCD did each work-group land on?  (the tile remap assumes blockIdx % 8)
+            int nb = 0, mism = 0; for (int b = 0; b < 1024; b++) { const unsigned long long x = tr[8 * 16 * 8 + 32 + b]; if (b < 256 || x) { nb++; if ((int)x != b % 8) mism++; } }
+            printf("  XCC_ID check: %d work-groups recorded, %d with XCC_ID != blockIdx %% 8; first 16:", nb, mism);
+            for (int b = 0; b < 16; b++) printf(" %llu", tr[8 * 16 * 8 + 32 + b]); printf("\n");
+        }
+        {   // kernel-level milestones, relative to the consumer work-group's entry stamp
+            const unsigned long long e0 = tr[8 * 16 * 8];
+            static const char *nm[8] = {"entry", "loop done", "K halves summed", "tile in LDS", "flag seen", "stores issued", "drained", "flag set"};
+            for (int ks = 0; ks < 2; ks++) { printf("  %s:", ks ? "producer (ks=1)" : "consumer (ks=0)"); for (int i = 0; i < 8; i++) if (tr[8 * 16 * 8 + 16 * ks + i]) printf("  %s %lld", nm[i], (long long)(tr[8 * 16 * 8 + 16 * ks + i] - e0)); printf("\n"); }
+        }
+        printf("trace variant %d (cycles since the stage-4 stamp of wave 0; phases: 0 stage start, 1 after vmcnt wait, 2 after barrier, 4 after follower MFMA / sym: frag 0 ready, 5 after read+unpack, 6 after leader MFMA / sym: stage end)\n", v);
+        const unsigned long long t0 = tr[0];
+        for (int w : {0, 4}) for (int st = 0; st < 5; st++) {
+            printf("wave %d stage %2d:", w, st + 4);
+            for (int ph : {0, 1, 2, 4, 5, 6}) printf(" %7lld", (long long)(tr[(w * 16 + st) * 8 + ph] - t0));
+            printf("\n");
+        }
     }
     return 0;
 }
