@@ -97,6 +97,53 @@ def cpu_baseline(seconds=12.0):
             "sample": "512 of 4096 weight rows x full [4096x512] activations, oracle C port (OpenMP)"}
 
 
+# (type id, name, block bytes, weights per block, byte offset of the fp16 scale(s))
+FORMATS = [(12, "Q4_K", 144, 256, (0, 2)), (13, "Q5_K", 176, 256, (0, 2)), (14, "Q6_K", 210, 256, (208,)), (2, "Q4_0", 18, 32, (0,)), (8, "Q8_0", 34, 32, (0,))]
+
+
+def synth_blocks(m, k, seed, bbytes, bweights, scale_offs):
+    """random but valid blocks of any of the five formats: random payload bytes, small positive fp16 scales"""
+    rng = np.random.default_rng(seed)
+    nb = m * k // bweights
+    raw = rng.integers(0, 256, (nb, bbytes), dtype=np.uint8)
+    for o in scale_offs:
+        raw[:, o:o + 2] = rng.uniform(0.001, 0.004, nb).astype(np.float16).view(np.uint8).reshape(nb, 2)
+    return raw.reshape(-1)
+
+
+def format_rows(L, native, ops, dev, stream, x, steps):
+    """secondary rows: every weight format at C3' (B=512, GEMM kernel only, activations prepared) and at
+    C2 (B=1, the one-launch fused decode step, cache-warm), HIP-event timed"""
+    rows = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    y = torch.empty((B, M_PER_GPU), dtype=torch.float32, device=dev)
+    for tid, name, bb, bw, so in FORMATS:
+        a = ops.QTensor.from_host_bytes(tid, K, M_PER_GPU, synth_blocks(M_PER_GPU, K, 99 + tid, bb, bw, so), device=dev)
+        ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(tid, K, B), dtype=torch.uint8, device=dev)
+        native.check(L.ggml_cdna4_prepare_act(tid, x.data_ptr(), K, K, B, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, stream))
+
+        def gemm():
+            native.check(L.ggml_cdna4_mul_mat_prepared(tid, a.data.data_ptr(), a.row_bytes, y.data_ptr(), M_PER_GPU, M_PER_GPU, K, B,
+                                                       ws.data_ptr(), ws.numel(), ops.PATH_GEMM, 0, 0, stream))
+
+        def decode():
+            native.check(L.ggml_cdna4_mul_mat(tid, a.data.data_ptr(), a.row_bytes, x.data_ptr(), K, y.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1,
+                                              ws.data_ptr(), ws.numel(), 0, 0, 0, stream))
+        r = {}
+        for label, fn in (("gemm_b512_us", gemm), ("decode_b1_us_cache_warm", decode)):
+            for _ in range(5):
+                fn()
+            e0.record()
+            for _ in range(steps):
+                fn()
+            e1.record(); e1.synchronize()
+            r[label] = round(e0.elapsed_time(e1) * 1e3 / steps, 3)
+        r["gemm_b512_tflops"] = round(2.0 * M_PER_GPU * K * B / (r["gemm_b512_us"] * 1e-6) / 1e12, 1)
+        r["weight_bytes"] = a.row_bytes * M_PER_GPU
+        rows[name] = r
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,6 +284,7 @@ def main():
                                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                                           "traffic": pmc_traffic("k_gemv_q<12, 1"), "algorithmic_bytes_per_launch": alg_bytes}}}
         del big
+        out["formats"] = format_rows(L, native, ops, dev, stream, x, max(50, min(args.steps, 200)))
 
     # ---- the exchange step of a row-split layer, timed separately: all-gather of the output shards ------------
     if dist is not None:
@@ -253,6 +301,21 @@ def main():
             ms = float(t.item()) / args.steps * 1e3
             out["with_allgather"] = {"ms_per_step": round(ms, 5), "value": round(flops_step / (ms * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
                                      "collective": "RCCL all_gather_into_tensor of fp32 output shards, %d B/rank" % (B * M_PER_GPU * 4)}
+        # the K-split variant of the same layer: every rank holds W[:, K-shard] (whole superblocks per row),
+        # computes a full-size partial Y over its shard — the same [4096x4096]·[4096x512] kernel per rank — and the
+        # partials are summed with one RCCL all-reduce
+        for _ in range(3):
+            step(); dist.all_reduce(y)
+        barrier(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(); dist.all_reduce(y)
+        barrier(); el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            ms = float(t.item()) / args.steps * 1e3
+            out["with_allreduce"] = {"ms_per_step": round(ms, 5), "value": round(flops_step / (ms * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
+                                     "collective": "K-split: RCCL all_reduce(sum) of the fp32 partial outputs, %d B" % (B * M_PER_GPU * 4)}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

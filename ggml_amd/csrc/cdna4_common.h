@@ -21,6 +21,15 @@ template <> struct QT<CDNA4_Q8_0> { static constexpr int BYTES = 34,  QK = 32;  
 template <> struct QT<CDNA4_Q4_K> { static constexpr int BYTES = 144, QK = 256; static constexpr bool KQ = true; };
 template <> struct QT<CDNA4_Q5_K> { static constexpr int BYTES = 176, QK = 256; static constexpr bool KQ = true; };
 template <> struct QT<CDNA4_Q6_K> { static constexpr int BYTES = 210, QK = 256; static constexpr bool KQ = true; };
+// library-private re-layouts of the 2-byte-aligned formats into 16-byte-aligned 256-weight superblocks, produced per call
+// into scratch by gemm_q_mfma.hip's repack kernels so that the LDS-DMA pipeline (16-byte pieces) can stage them:
+//   Q4_0R 144 B: fp16 d[8] | 4 x 32 B nibbles in Q4_K order (byte l of group g: low = k 64g+l, high = k 64g+32+l)
+//   Q8_0R 272 B: fp16 d[8] | 256 int8 in k order
+//   Q6_KR 224 B: fp16 d, 14 B pad | int8 scales[16] | ql[128] | qh[64]
+enum : int { CDNA4_Q4_0R = 102, CDNA4_Q8_0R = 108, CDNA4_Q6_KR = 114 };
+template <> struct QT<CDNA4_Q4_0R> { static constexpr int BYTES = 144, QK = 256; static constexpr bool KQ = true; };
+template <> struct QT<CDNA4_Q8_0R> { static constexpr int BYTES = 272, QK = 256; static constexpr bool KQ = false; };
+template <> struct QT<CDNA4_Q6_KR> { static constexpr int BYTES = 224, QK = 256; static constexpr bool KQ = true; };
 
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));

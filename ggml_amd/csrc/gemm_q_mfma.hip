@@ -240,6 +240,150 @@ template <> struct Raw<CDNA4_Q8_0> {
     }
 };
 
+// ---- repacked (16-byte-aligned) forms of Q4_0 / Q8_0 / Q6_K, staged through LDS by the 8-wave kernel -------------
+// `row` = this row's staged bytes of one 128-k stage in LDS; g_local = which 64-k group of the stage (the wave's khalf);
+// scales(g) takes the group's index inside the 256-weight superblock (compile-time after inlining).
+template <> struct Raw<CDNA4_Q4_0R> {
+    u32x4 hdr, q;                                                    // hdr = fp16 d[8]
+    template <typename P> __device__ __forceinline__ void load(P row, int g_local, int h) { hdr = ld_u32x4(row); q = ld_u32x4(row + 16 + 32 * g_local + 16 * h); }
+    struct Sc { half2_t SL, CL, SH, CH; };
+    __device__ __forceinline__ Sc scales(int g) const {
+        const uint32_t dw = g == 0 ? hdr.x : (g == 1 ? hdr.y : (g == 2 ? hdr.z : hdr.w));
+        const half2_t d2 = as_h2(dw), zero = {(half_t)0.f, (half_t)0.f};
+        Sc r; r.SL = half2_t{d2.x, d2.x}; r.SH = half2_t{d2.y, d2.y}; r.CL = zero; r.CH = zero;
+        return r;
+    }
+    __device__ __forceinline__ uint32_t pairbits(int kk, int i, const Sc &z, const DqConst &c) const {
+        const half2_t off = {(half_t)-1032.f, (half_t)-1032.f};
+        const uint32_t src = (i < 2) ? ((kk & 1) ? q.z : q.x) : ((kk & 1) ? q.w : q.y);
+        const int sh = (kk >= 2 ? 4 : 0) + ((i & 1) ? 8 : 0);
+        const half2_t r = (as_h2(nib(src >> sh, c)) + off) * (kk < 2 ? z.SL : z.SH);     // d * (q - 8), one rounding, as the 32-block kernel
+        return __builtin_bit_cast(uint32_t, r);
+    }
+    __device__ __forceinline__ void frags(int g, int, half8_t (&f)[4], const DqConst &c) const {
+        const Sc z = scales(g);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) { const u32x4 w = {pairbits(kk, 0, z, c), pairbits(kk, 1, z, c), pairbits(kk, 2, z, c), pairbits(kk, 3, z, c)}; f[kk] = __builtin_bit_cast(half8_t, w); }
+    }
+};
+
+template <> struct Raw<CDNA4_Q8_0R> {
+    u32x4 hdr, q0, q1; int hh;                                       // lane-half h owns the 32-block h of the 64-k group
+    template <typename P> __device__ __forceinline__ void load(P row, int g_local, int h) {
+        hdr = ld_u32x4(row); q0 = ld_u32x4(row + 16 + 64 * g_local + 32 * h); q1 = ld_u32x4(row + 32 + 64 * g_local + 32 * h); hh = h;
+        q0.x ^= 0x80808080u; q0.y ^= 0x80808080u; q0.z ^= 0x80808080u; q0.w ^= 0x80808080u;      // int8 -> biased u8
+        q1.x ^= 0x80808080u; q1.y ^= 0x80808080u; q1.z ^= 0x80808080u; q1.w ^= 0x80808080u;
+    }
+    struct Sc { half2_t S; };
+    __device__ __forceinline__ Sc scales(int g) const {
+        const uint32_t dw = g == 0 ? hdr.x : (g == 1 ? hdr.y : (g == 2 ? hdr.z : hdr.w));
+        const half2_t d2 = as_h2(dw);
+        const half_t d = hh ? d2.y : d2.x;
+        Sc r; r.S = half2_t{d, d};
+        return r;
+    }
+    __device__ __forceinline__ uint32_t pairbits(int kk, int i, const Sc &z, const DqConst &c) const {
+        const half2_t off = {(half_t)-1152.f, (half_t)-1152.f};
+        const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const uint32_t src = w[2 * kk + (i >> 1)];
+        const half2_t r = (as_h2(((src >> ((i & 1) ? 8 : 0)) & c.m8) | c.magic) + off) * z.S;
+        return __builtin_bit_cast(uint32_t, r);
+    }
+    __device__ __forceinline__ void frags(int g, int, half8_t (&f)[4], const DqConst &c) const {
+        const Sc z = scales(g);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) { const u32x4 w = {pairbits(kk, 0, z, c), pairbits(kk, 1, z, c), pairbits(kk, 2, z, c), pairbits(kk, 3, z, c)}; f[kk] = __builtin_bit_cast(half8_t, w); }
+    }
+};
+
+// staged row of half n: [d, pad : 16][scales[16] : 16][ql[64n .. 64n+63] : 64][qh[32n .. 32n+31] : 32][pad : 16]
+template <> struct Raw<CDNA4_Q6_KR> {
+    u32x4 la, lv, hq, sc; uint32_t dd; int hh;
+    template <typename P> __device__ __forceinline__ void load(P row, int, int h) {
+        dd = *reinterpret_cast<const uint32_t *>(row); sc = ld_u32x4(row + 16);
+        la = ld_u32x4(row + 32 + 16 * h); lv = ld_u32x4(row + 64 + 16 * h); hq = ld_u32x4(row + 96 + 16 * h); hh = h;
+    }
+    struct Sc { half2_t S0, S1; int ns, b0, b1; };
+    __device__ __forceinline__ Sc scales(int g) const {              // g = 2n + p: half n, quads (2p, 2p+1); scale bytes 8n + 4p + h (+2)
+        const uint32_t dw = g == 0 ? sc.x : (g == 1 ? sc.y : (g == 2 ? sc.z : sc.w));
+        const int s0 = (int)(int8_t)(dw >> (8 * hh)), s1 = (int)(int8_t)(dw >> (8 * hh + 16));
+        const float d = h2f(dd & 0xFFFF);
+        const int p = g & 1;
+        Sc r; r.S0 = splat(d * (float)s0); r.S1 = splat(d * (float)s1); r.ns = 4 * p; r.b0 = 2 * (2 * p); r.b1 = 2 * (2 * p + 1);
+        return r;
+    }
+    __device__ __forceinline__ uint32_t pairbits(int kk, int i, const Sc &z, const DqConst &) const {
+        const half2_t off = {(half_t)-1056.f, (half_t)-1056.f};
+        const int wi = 2 * (kk & 1) + (i >> 1), sh = (i & 1) ? 8 : 0;
+        const u32x4 lsrc = kk < 2 ? la : lv;
+        const uint32_t x = wi == 0 ? lsrc.x : (wi == 1 ? lsrc.y : (wi == 2 ? lsrc.z : lsrc.w));
+        const uint32_t hb = wi == 0 ? hq.x : (wi == 1 ? hq.y : (wi == 2 ? hq.z : hq.w));
+        const int bits = kk < 2 ? z.b0 : z.b1;
+        const uint32_t v = ((x >> (z.ns + sh)) & 0x000F000Fu) | ((((hb >> (bits + sh)) & 0x00030003u) << 4)) | MAGIC2;
+        const half2_t r = (as_h2(v) + off) * (kk < 2 ? z.S0 : z.S1);
+        return __builtin_bit_cast(uint32_t, r);
+    }
+    __device__ __forceinline__ void frags(int g, int, half8_t (&f)[4], const DqConst &c) const {
+        const Sc z = scales(g);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) { const u32x4 w = {pairbits(kk, 0, z, c), pairbits(kk, 1, z, c), pairbits(kk, 2, z, c), pairbits(kk, 3, z, c)}; f[kk] = __builtin_bit_cast(half8_t, w); }
+    }
+};
+
+// repack kernels: one thread per (row, superblock); sources are 2-byte aligned
+__global__ __launch_bounds__(256) void k_repack_q4_0(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nsb, uint8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)M * nsb) return;
+    const int row = (int)(t / nsb), sb = (int)(t % nsb);
+    const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)sb * 8 * 18;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(out + ((int64_t)row * nsb + sb) * 144);
+    uint32_t d[4], nb[8][8];                                           // nb[b][i]: 32 weights of block b, one per byte, k order
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const uint8_t *blk = src + b * 18;
+        const uint32_t dh = ld_u16(blk);
+        if (b & 1) d[b >> 1] |= dh << 16; else d[b >> 1] = dh;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const uint32_t w = ld_u32_a2(blk + 2 + 4 * i); nb[b][i] = w & 0x0F0F0F0Fu; nb[b][4 + i] = (w >> 4) & 0x0F0F0F0Fu; }
+    }
+    dst[0] = u32x4{d[0], d[1], d[2], d[3]};
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        uint32_t o[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = nb[2 * g][i] | (nb[2 * g + 1][i] << 4);
+        dst[1 + 2 * g] = u32x4{o[0], o[1], o[2], o[3]}; dst[2 + 2 * g] = u32x4{o[4], o[5], o[6], o[7]};
+    }
+}
+__global__ __launch_bounds__(256) void k_repack_q8_0(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nsb, uint8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)M * nsb) return;
+    const int row = (int)(t / nsb), sb = (int)(t % nsb);
+    const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)sb * 8 * 34;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(out + ((int64_t)row * nsb + sb) * 272);
+    uint32_t d[4];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const uint8_t *blk = src + b * 34;
+        const uint32_t dh = ld_u16(blk);
+        if (b & 1) d[b >> 1] |= dh << 16; else d[b >> 1] = dh;
+        dst[1 + 2 * b] = u32x4{ld_u32_a2(blk + 2), ld_u32_a2(blk + 6), ld_u32_a2(blk + 10), ld_u32_a2(blk + 14)};
+        dst[2 + 2 * b] = u32x4{ld_u32_a2(blk + 18), ld_u32_a2(blk + 22), ld_u32_a2(blk + 26), ld_u32_a2(blk + 30)};
+    }
+    dst[0] = u32x4{d[0], d[1], d[2], d[3]};
+}
+__global__ __launch_bounds__(256) void k_repack_q6_K(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nsb, uint8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)M * nsb) return;
+    const int row = (int)(t / nsb), sb = (int)(t % nsb);
+    const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)sb * 210;       // ql[128] qh[64] scales[16] d
+    u32x4 *dst = reinterpret_cast<u32x4 *>(out + ((int64_t)row * nsb + sb) * 224);
+    dst[0] = u32x4{(uint32_t)ld_u16(src + 208), 0u, 0u, 0u};
+    dst[1] = u32x4{ld_u32_a2(src + 192), ld_u32_a2(src + 196), ld_u32_a2(src + 200), ld_u32_a2(src + 204)};
+#pragma unroll
+    for (int i = 0; i < 12; i++) dst[2 + i] = u32x4{ld_u32_a2(src + 16 * i), ld_u32_a2(src + 16 * i + 4), ld_u32_a2(src + 16 * i + 8), ld_u32_a2(src + 16 * i + 12)};
+}
+
 // ------------------------------------------------------------------------------------------------------------
 void *cdna4_debug_trace = nullptr;   // profiling hook (ggml_cdna4_debug_trace): device buffer for k_gemm_kq_w8<.., true>
 
@@ -394,6 +538,17 @@ template <int TYPE, int SKG> struct WStage {        // which 16-B pieces of a su
     static constexpr int HDR = TYPE == CDNA4_Q5_K ? 3 : 1;             // header (+ qh) pieces, needed by every stage
     static constexpr int NPH = SKG == 4 ? NP : HDR + 2 * SKG;          // pieces per row per stage (2 per 64-k group)
     __device__ static __forceinline__ int src_piece(int p, int part) { return (SKG == 4 || p < HDR) ? p : HDR + 2 * SKG * part + (p - HDR); }
+};
+// repacked forms (8-wave kernel only, SKG = 2).  Row strides of 9 pieces (144 B = 36 dwords) keep the per-lane b128 reads
+// of 32 consecutive rows conflict-free; Q6_KR pads its 8 useful pieces with a dummy 9th for that reason.
+template <> struct WStage<CDNA4_Q4_0R, 2> : WStage<CDNA4_Q4_K, 2> {};
+template <> struct WStage<CDNA4_Q8_0R, 2> {                            // [d[8]] + 4 pieces per 64-k group
+    static constexpr int NPH = 9;
+    __device__ static __forceinline__ int src_piece(int p, int part) { return p < 1 ? p : 1 + 8 * part + (p - 1); }
+};
+template <> struct WStage<CDNA4_Q6_KR, 2> {                            // [d][scales] + ql(half n) 4 pieces + qh(half n) 2 pieces + dummy
+    static constexpr int NPH = 9;
+    __device__ static __forceinline__ int src_piece(int p, int part) { return p < 2 ? p : (p < 6 ? 2 + 4 * part + (p - 2) : (p < 8 ? 10 + 2 * part + (p - 6) : 0)); }
 };
 
 template <int TYPE, int BNF, int SKG>
@@ -973,10 +1128,11 @@ static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
 // (one region per device; launches that use it are assumed to be stream-ordered on that device, as the plug-in's
 // single-stream backend and the one-process-per-GPU bench are).
 static unsigned g_handoff_epoch = 0;        // ONE counter for every kernel instantiation that shares the flag words
-static void *g_scratch[16] = {nullptr}; static size_t g_scratch_bytes[16] = {0};
-static void *get_scratch(size_t bytes) {
+static void *g_scratch[32] = {nullptr}; static size_t g_scratch_bytes[32] = {0};
+static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: split-K exchange buffers, 1: repacked weights
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
+    dev += 16 * kind;
     if (bytes <= g_scratch_bytes[dev]) return g_scratch[dev];
     (void)hipDeviceSynchronize();
     if (g_scratch[dev]) (void)hipFree(g_scratch[dev]);
@@ -1026,7 +1182,8 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     const dim3 grid(p.tiles_m * p.tiles_b * splitk);
 #define W8_LAUNCH(O) do { if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, true, O>), grid, dim3(512), 0, st, p); \
                           else hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, false, O>), grid, dim3(512), 0, st, p); } while (0)
-    switch (opt & 31) { case 0: W8_LAUNCH(0); break; case 1: W8_LAUNCH(1); break; case 2: W8_LAUNCH(2); break; case 3: W8_LAUNCH(3); break;
+    if constexpr (TYPE >= 100) { W8_LAUNCH(20); CDNA4_CHECK_LAUNCH(); return 0; }   // repacked formats: the default schedule only
+    else switch (opt & 31) { case 0: W8_LAUNCH(0); break; case 1: W8_LAUNCH(1); break; case 2: W8_LAUNCH(2); break; case 3: W8_LAUNCH(3); break;
                         case 4: W8_LAUNCH(4); break; case 12: W8_LAUNCH(12); break; case 28: W8_LAUNCH(28); break; case 20: W8_LAUNCH(20); break; default: return cdna4_set_error_msg("gemm_q: unknown 8-wave schedule option"); }
 #undef W8_LAUNCH
     CDNA4_CHECK_LAUNCH();
@@ -1055,6 +1212,30 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         else splitk = 1;
     }
     if (splitk < 1 || kunits % splitk) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
+    if constexpr (TYPE == CDNA4_Q4_0 || TYPE == CDNA4_Q8_0 || TYPE == CDNA4_Q6_K) {
+        // 2-byte-aligned formats at prefill batch sizes: re-lay the weights into 16-byte-aligned superblocks (scratch, per
+        // call: one extra read+write of W, ~5 us at 4096x4096) and run the LDS-DMA pipeline on that — 2.5-3x faster
+        // than the per-lane-load kernel below, which stays for small batches and K % 256 != 0.
+        constexpr int RT = TYPE == CDNA4_Q4_0 ? CDNA4_Q4_0R : (TYPE == CDNA4_Q8_0 ? CDNA4_Q8_0R : CDNA4_Q6_KR);
+        static const bool no_repack = getenv("CDNA4_NO_REPACK") != nullptr;
+        if (a.variant <= 0 && a.B > 64 && a.K % 256 == 0 && !no_repack) {
+            const int nsb = a.K / 256;
+            const size_t rbytes = (size_t)a.M * nsb * QT<RT>::BYTES;
+            uint8_t *rw = (uint8_t *)get_scratch(rbytes + 256, 1);
+            if (!rw) return cdna4_set_error_msg("gemm_q: cannot allocate the repack scratch");
+            const dim3 grid((unsigned)(((int64_t)a.M * nsb + 255) / 256));
+            if (TYPE == CDNA4_Q4_0) hipLaunchKernelGGL(k_repack_q4_0, grid, dim3(256), 0, st, a.W, a.w_row_bytes, a.M, nsb, rw);
+            else if (TYPE == CDNA4_Q8_0) hipLaunchKernelGGL(k_repack_q8_0, grid, dim3(256), 0, st, a.W, a.w_row_bytes, a.M, nsb, rw);
+            else hipLaunchKernelGGL(k_repack_q6_K, grid, dim3(256), 0, st, a.W, a.w_row_bytes, a.M, nsb, rw);
+            CDNA4_CHECK_LAUNCH();
+            cdna4_gemm_args r = a; r.W = rw; r.w_row_bytes = (int64_t)nsb * QT<RT>::BYTES;
+            const int tiles = ((a.M + 127) / 128) * ((a.B + 127) / 128);
+            int sk = a.splitk;
+            if (sk <= 0) sk = (tiles * 2 <= cu_count() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
+            if (sk < 1 || nsb % sk) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
+            return launch_w8<RT>(r, sk, 20, st);
+        }
+    }
     if constexpr (CAN_LDS) {
         if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant >> 5) & 31, st);
         if (wlds && !(variant & 8)) return wide ? launch_pipe<TYPE, 4>(a, splitk, st) : launch_pipe<TYPE, 2>(a, splitk, st);

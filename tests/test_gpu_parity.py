@@ -185,6 +185,29 @@ def test_gemm_variants(gu, name, t, variant, splitk):
     assert np.isfinite(y).all() and e < TOL_GEMM
 
 
+@pytest.mark.parametrize("name,t", [(n, t) for n, t in WT if n in ("q4_0", "q8_0", "q6_K")])
+@pytest.mark.parametrize("m,k,b", [(260, 1024, 150), (129, 768, 65), (4096, 4096, 512)])
+def test_repacked_formats_match_per_lane_kernel(gu, name, t, m, k, b):
+    """Q4_0 / Q8_0 / Q6_K at prefill batch sizes are re-laid into 16-byte-aligned superblocks and run on the LDS-DMA
+    pipeline; explicit variant 6 forces the older per-lane-load kernel on the original bytes.  Same arithmetic per
+    weight (fp16 d*(q-off)), different fp32 summation order only."""
+    from ggml_amd import ops
+    w = R.random_weights(t, m, k, seed=5 * m + k)
+    x = _x(m + b, b, k, "normal" if m < 1000 else "uniform")
+    a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
+    y_new = ops.mul_mat(a, xd, path=ops.PATH_GEMM).cpu().numpy()
+    y_old = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=6, splitk=1).cpu().numpy()
+    e = R.rel_l2(y_new, y_old); gu.report(test="repack_vs_per_lane", type=name, m=m, k=k, b=b, rel_l2=e)
+    assert np.isfinite(y_new).all() and e < 2e-6
+    if m < 1000:
+        assert R.rel_l2(y_new, R.o_mul_mat(t, w, x, m, k)) < TOL_GEMM
+    # the scratch copy is rebuilt per call: a second matrix of the same shape must not see the first one's weights
+    w2 = R.random_weights(t, m, k, seed=77)
+    y2 = ops.mul_mat(gu.qtensor(t, w2, m, k), xd, path=ops.PATH_GEMM).cpu().numpy()
+    y2_old = ops.mul_mat(gu.qtensor(t, w2, m, k), xd, path=ops.PATH_GEMM, gemm_variant=6, splitk=1).cpu().numpy()
+    assert R.rel_l2(y2, y2_old) < 2e-6
+
+
 def test_gemm_matches_gemv_statistically(gu):
     """same inputs through both kernel families: they implement the same reference semantics"""
     from ggml_amd import ops
