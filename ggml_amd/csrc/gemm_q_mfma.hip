@@ -330,58 +330,47 @@ template <> struct Raw<CDNA4_Q6_KR> {
     }
 };
 
-// repack kernels: one thread per (row, superblock); sources are 2-byte aligned
+// repack kernels: one thread per 16-byte OUTPUT piece (coalesced stores; the 2-byte-aligned source bytes of a superblock
+// are read by the 9 / 17 / 14 adjacent threads that build it)
+__device__ __forceinline__ u32x4 ld16_a2(const uint8_t *p) { return u32x4{ld_u32_a2(p), ld_u32_a2(p + 4), ld_u32_a2(p + 8), ld_u32_a2(p + 12)}; }
+__device__ __forceinline__ u32x4 fp16_d8(const uint8_t *src, int bstride) {           // the 8 block scales of a superblock
+    uint32_t d[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) d[b] = (uint32_t)ld_u16(src + (2 * b) * bstride) | ((uint32_t)ld_u16(src + (2 * b + 1) * bstride) << 16);
+    return u32x4{d[0], d[1], d[2], d[3]};
+}
 __global__ __launch_bounds__(256) void k_repack_q4_0(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nsb, uint8_t *__restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (int64_t)M * nsb) return;
-    const int row = (int)(t / nsb), sb = (int)(t % nsb);
+    if (t >= (int64_t)M * nsb * 9) return;
+    const int pc = (int)(t % 9); const int64_t u = t / 9;
+    const int row = (int)(u / nsb), sb = (int)(u % nsb);
     const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)sb * 8 * 18;
-    u32x4 *dst = reinterpret_cast<u32x4 *>(out + ((int64_t)row * nsb + sb) * 144);
-    uint32_t d[4], nb[8][8];                                           // nb[b][i]: 32 weights of block b, one per byte, k order
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-        const uint8_t *blk = src + b * 18;
-        const uint32_t dh = ld_u16(blk);
-        if (b & 1) d[b >> 1] |= dh << 16; else d[b >> 1] = dh;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { const uint32_t w = ld_u32_a2(blk + 2 + 4 * i); nb[b][i] = w & 0x0F0F0F0Fu; nb[b][4 + i] = (w >> 4) & 0x0F0F0F0Fu; }
+    u32x4 o;
+    if (pc == 0) o = fp16_d8(src, 18);
+    else {                                                             // piece (g, e): byte l = 16e + i of group g: low = blk 2g weight l, high = blk 2g+1 weight l
+        const int g = (pc - 1) >> 1, e = (pc - 1) & 1;
+        const u32x4 a = ld16_a2(src + (2 * g) * 18 + 2), c = ld16_a2(src + (2 * g + 1) * 18 + 2);
+        const int sh = 4 * e;                                           // weights 0..15 = low nibbles, 16..31 = high nibbles of the 16 bytes
+        o.x = ((a.x >> sh) & 0x0F0F0F0Fu) | (((c.x >> sh) & 0x0F0F0F0Fu) << 4); o.y = ((a.y >> sh) & 0x0F0F0F0Fu) | (((c.y >> sh) & 0x0F0F0F0Fu) << 4);
+        o.z = ((a.z >> sh) & 0x0F0F0F0Fu) | (((c.z >> sh) & 0x0F0F0F0Fu) << 4); o.w = ((a.w >> sh) & 0x0F0F0F0Fu) | (((c.w >> sh) & 0x0F0F0F0Fu) << 4);
     }
-    dst[0] = u32x4{d[0], d[1], d[2], d[3]};
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        uint32_t o[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) o[i] = nb[2 * g][i] | (nb[2 * g + 1][i] << 4);
-        dst[1 + 2 * g] = u32x4{o[0], o[1], o[2], o[3]}; dst[2 + 2 * g] = u32x4{o[4], o[5], o[6], o[7]};
-    }
+    reinterpret_cast<u32x4 *>(out)[t] = o;
 }
 __global__ __launch_bounds__(256) void k_repack_q8_0(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nsb, uint8_t *__restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (int64_t)M * nsb) return;
-    const int row = (int)(t / nsb), sb = (int)(t % nsb);
+    if (t >= (int64_t)M * nsb * 17) return;
+    const int pc = (int)(t % 17); const int64_t u = t / 17;
+    const int row = (int)(u / nsb), sb = (int)(u % nsb);
     const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)sb * 8 * 34;
-    u32x4 *dst = reinterpret_cast<u32x4 *>(out + ((int64_t)row * nsb + sb) * 272);
-    uint32_t d[4];
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-        const uint8_t *blk = src + b * 34;
-        const uint32_t dh = ld_u16(blk);
-        if (b & 1) d[b >> 1] |= dh << 16; else d[b >> 1] = dh;
-        dst[1 + 2 * b] = u32x4{ld_u32_a2(blk + 2), ld_u32_a2(blk + 6), ld_u32_a2(blk + 10), ld_u32_a2(blk + 14)};
-        dst[2 + 2 * b] = u32x4{ld_u32_a2(blk + 18), ld_u32_a2(blk + 22), ld_u32_a2(blk + 26), ld_u32_a2(blk + 30)};
-    }
-    dst[0] = u32x4{d[0], d[1], d[2], d[3]};
+    reinterpret_cast<u32x4 *>(out)[t] = pc == 0 ? fp16_d8(src, 34) : ld16_a2(src + ((pc - 1) >> 1) * 34 + 2 + 16 * ((pc - 1) & 1));
 }
 __global__ __launch_bounds__(256) void k_repack_q6_K(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nsb, uint8_t *__restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (int64_t)M * nsb) return;
-    const int row = (int)(t / nsb), sb = (int)(t % nsb);
+    if (t >= (int64_t)M * nsb * 14) return;
+    const int pc = (int)(t % 14); const int64_t u = t / 14;
+    const int row = (int)(u / nsb), sb = (int)(u % nsb);
     const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)sb * 210;       // ql[128] qh[64] scales[16] d
-    u32x4 *dst = reinterpret_cast<u32x4 *>(out + ((int64_t)row * nsb + sb) * 224);
-    dst[0] = u32x4{(uint32_t)ld_u16(src + 208), 0u, 0u, 0u};
-    dst[1] = u32x4{ld_u32_a2(src + 192), ld_u32_a2(src + 196), ld_u32_a2(src + 200), ld_u32_a2(src + 204)};
-#pragma unroll
-    for (int i = 0; i < 12; i++) dst[2 + i] = u32x4{ld_u32_a2(src + 16 * i), ld_u32_a2(src + 16 * i + 4), ld_u32_a2(src + 16 * i + 8), ld_u32_a2(src + 16 * i + 12)};
+    reinterpret_cast<u32x4 *>(out)[t] = pc == 0 ? u32x4{(uint32_t)ld_u16(src + 208), 0u, 0u, 0u} : (pc == 1 ? ld16_a2(src + 192) : ld16_a2(src + 16 * (pc - 2)));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1223,7 +1212,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
             const size_t rbytes = (size_t)a.M * nsb * QT<RT>::BYTES;
             uint8_t *rw = (uint8_t *)get_scratch(rbytes + 256, 1);
             if (!rw) return cdna4_set_error_msg("gemm_q: cannot allocate the repack scratch");
-            const dim3 grid((unsigned)(((int64_t)a.M * nsb + 255) / 256));
+            const dim3 grid((unsigned)(((int64_t)a.M * nsb * (QT<RT>::BYTES / 16) + 255) / 256));
             if (TYPE == CDNA4_Q4_0) hipLaunchKernelGGL(k_repack_q4_0, grid, dim3(256), 0, st, a.W, a.w_row_bytes, a.M, nsb, rw);
             else if (TYPE == CDNA4_Q8_0) hipLaunchKernelGGL(k_repack_q8_0, grid, dim3(256), 0, st, a.W, a.w_row_bytes, a.M, nsb, rw);
             else hipLaunchKernelGGL(k_repack_q6_K, grid, dim3(256), 0, st, a.W, a.w_row_bytes, a.M, nsb, rw);

@@ -284,23 +284,30 @@ static int launch_type(const cdna4_gemv_args &a0, hipStream_t st) {
 // (Touching the wave's weight row before the quantization to overlap its HBM latency was measured SLOWER: 7.2 vs 6.1 us.)
 struct lds_act { const int8_t *qs; const float *d; const int16_t *bsums; int K; };
 
-template <int TYPE>
-__global__ __launch_bounds__(256) void k_gemv_q_fused(const cdna4_gemv_args a, const float *__restrict__ x) {
+// NW waves per work-group, ROWS weight rows per wave.  The quantizer's cost is per WORK-GROUP (every work-group redoes the
+// whole row), so fewer, fatter work-groups pay it less often: <4,1> = 1024 work-groups at M=4096, <8,2> = 256 (one per CU).
+template <int TYPE, int NW, int ROWS>
+__global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(const cdna4_gemv_args a, const float *__restrict__ x) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr bool KQ = QT<TYPE>::KQ;
     const int K = a.K, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int8_t *sq = reinterpret_cast<int8_t *>(smem);
     int16_t *sbs = reinterpret_cast<int16_t *>(smem + K);                   // K/8 bytes (Q8_K only)
     float *sd = reinterpret_cast<float *>(smem + K + (KQ ? K / 8 : 0));
-    const int row = blockIdx.x * 4 + wave;
-    const uint8_t *wrow = a.W + (int64_t)min(row, a.M - 1) * a.w_row_bytes;
+    const int row0 = (blockIdx.x * NW + wave) * ROWS;
     const int nunits = K / Unit<TYPE, 1>::UK;
-    // this lane's first unit goes into registers now: its HBM latency runs under the quantizer below
-    const typename Unit<TYPE, 1>::W w0 = Unit<TYPE, 1>::load(wrow, min(lane, nunits - 1));
+    // this lane's first unit of every row goes into registers now: its HBM latency runs under the quantizer below
+    const uint8_t *wrow[ROWS];
+    typename Unit<TYPE, 1>::W w0[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        wrow[r] = a.W + (int64_t)min(row0 + r, a.M - 1) * a.w_row_bytes;
+        w0[r] = Unit<TYPE, 1>::load(wrow[r], min(lane, nunits - 1));
+    }
     // One lane quantizes 16 consecutive values (= one bsums entry, one ds_write_b128): a superblock is 16 adjacent lanes
     // (4 butterfly rounds), a Q8_0 block 2 lanes (1 round).  The first cut (one wave per superblock, 4 values per lane,
     // 6 rounds x 3 shuffles, 4 superblocks in sequence per wave) cost ~5 us per work-group and lost to the two-kernel path.
-    for (int c = threadIdx.x; c < K / 16; c += 256) {
+    for (int c = threadIdx.x; c < K / 16; c += NW * 64) {
         float e[16];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -347,14 +354,17 @@ __global__ __launch_bounds__(256) void k_gemv_q_fused(const cdna4_gemv_args a, c
         *reinterpret_cast<u32x4 *>(sq + c * 16) = pk;
     }
     __syncthreads();
-    if (row >= a.M) return;
+    if (row0 >= a.M) return;
     const lds_act act{sq, sd, sbs, K};
     const int col[1] = {0};
-    float acc[1] = {0.f};
-    if (lane < nunits) Unit<TYPE, 1>::mac(w0, lane, act, col, acc);
-    for (int u = lane + 64; u < nunits; u += 64) Unit<TYPE, 1>::dot(wrow, u, act, col, acc);
-    const float s = wave_sum(acc[0]);
-    if (lane == 0) a.Y[row] = s;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        float acc[1] = {0.f};
+        if (lane < nunits) Unit<TYPE, 1>::mac(w0[r], lane, act, col, acc);
+        for (int u = lane + 64; u < nunits; u += 64) Unit<TYPE, 1>::dot(wrow[r], u, act, col, acc);
+        const float s = wave_sum(acc[0]);
+        if (lane == 0 && row0 + r < a.M) a.Y[row0 + r] = s;
+    }
 }
 
 size_t cdna4_gemv_fused_lds_bytes(int type, int64_t K) {
@@ -368,7 +378,14 @@ bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B) {
 template <int TYPE>
 static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st) {
     const size_t lds = cdna4_gemv_fused_lds_bytes(TYPE, a.K);
-    hipLaunchKernelGGL((k_gemv_q_fused<TYPE>), dim3((a.M + 3) / 4), dim3(256), lds, st, a, x);
+    // CDNA4_FUSED_CFG: 0 = 4 waves x 1 row, 1 = 8 x 2, 2 = 4 x 2, 3 = 8 x 1.  Measured at 4096x4096 Q4_K, cold HBM / cache-warm us:
+    // 6.32/5.52, 5.93/5.39, 6.35/5.49, 5.57/5.79 -> 8 waves x 1 row when the matrix is tall enough to still fill the chip.
+    static const int cfg_env = getenv("CDNA4_FUSED_CFG") ? atoi(getenv("CDNA4_FUSED_CFG")) : -1;
+    const int cfg = cfg_env >= 0 ? cfg_env : (a.M >= 2048 ? 3 : 0);
+    if (cfg == 1) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x);
+    else if (cfg == 2) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 2>), dim3((a.M + 7) / 8), dim3(256), lds, st, a, x);
+    else if (cfg == 3) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 1>), dim3((a.M + 7) / 8), dim3(512), lds, st, a, x);
+    else hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 1>), dim3((a.M + 3) / 4), dim3(256), lds, st, a, x);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
