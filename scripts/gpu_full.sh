@@ -7,7 +7,10 @@ timeout -k 10 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovid
 echo "pytest -m gpu rc=$?" >> gpurun_out/summary.txt; tail -5 gpurun_out/pytest_gpu.log >> gpurun_out/summary.txt
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/summary.txt
 timeout -k 10 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/summary.txt
-timeout 120 tools/microbench/gemm_bench 4096 4096 512 > gpurun_out/gemm_bench.txt 2>&1
+GB_TRACE_SPLITK=2 GB_SPLITKS="0,1,2" GB_VARIANTS="0,5,23,407,663,1031" timeout 180 tools/microbench/gemm_bench 4096 4096 512 663 > gpurun_out/gemm_bench.txt 2>&1
+for shape in "8192 4096 512" "4096 10752 512" "4096 8192 512" "32768 8192 512"; do
+  GB_SPLITKS="0" GB_VARIANTS="0,663,1031" timeout 180 tools/microbench/gemm_bench $shape 2>&1 | grep -E "^M=|^variant" >> gpurun_out/gemm_bench.txt
+done
 R=$PWD; cd /tmp; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_stats" -o r1 -- python "$R/bench.py" --steps 100 --warmup 10 --no-cpu-baseline > "$R/gpurun_out/rocprof_stats.log" 2>&1
 echo "rocprof stats rc=$?" >> "$R/gpurun_out/summary.txt"
@@ -16,4 +19,4 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d "$R/gpurun_out/pmc_$name" -o p -- python "$R/bench.py" --steps 30 --warmup 3 --no-cpu-baseline > "$R/gpurun_out/rocprof_pmc_$name.log" 2>&1
   echo "pmc [$pmc] rc=$?" >> "$R/gpurun_out/summary.txt"
 done
-cd "$R"; cat gpurun_out/summary.txt; cat gpurun_out/gemm_bench.txt | head -8; tail -1 gpurun_out/bench.log
+cd "$R"; cat gpurun_out/summary.txt; grep -E "^M=|^variant" gpurun_out/gemm_bench.txt | head -40; tail -1 gpurun_out/bench.log

@@ -171,7 +171,7 @@ def test_gemm_parity_auto(gu, name, t, m, k, b):
 
 
 @pytest.mark.parametrize("name,t", WT)
-@pytest.mark.parametrize("variant", [4, 5, 6, 7, 13, 15, 23, 55, 87, 119, 151, 407, 663, 919])
+@pytest.mark.parametrize("variant", [4, 5, 6, 7, 13, 15, 23, 55, 87, 119, 151, 407, 663, 919, 1031])
 @pytest.mark.parametrize("splitk", [1, 2])
 def test_gemm_variants(gu, name, t, variant, splitk):
     """every tile variant (bit0 LDS-staged weights, bit1 128-wide activation tile) x split-K"""
@@ -206,6 +206,42 @@ def test_repacked_formats_match_per_lane_kernel(gu, name, t, m, k, b):
     y2 = ops.mul_mat(gu.qtensor(t, w2, m, k), xd, path=ops.PATH_GEMM).cpu().numpy()
     y2_old = ops.mul_mat(gu.qtensor(t, w2, m, k), xd, path=ops.PATH_GEMM, gemm_variant=6, splitk=1).cpu().numpy()
     assert R.rel_l2(y2, y2_old) < 2e-6
+
+
+@pytest.mark.parametrize("m,k,b,splitk", [(300, 2048, 200, 4), (300, 2560, 200, 4), (256, 1024, 128, 4), (513, 1024, 129, 2), (700, 768, 90, 1), (1024, 4096, 512, 0)])
+def test_gemm_256x128_tile_kernel(gu, m, k, b, splitk):
+    """variant bit 10: the 256(m) x 128(b) tile kernel (two weight fragments per activation fragment) with its 1/2/4-way
+    symmetric split-K exchange; ragged M and B edges"""
+    from ggml_amd import ops
+    t = R.Q4_K
+    w = R.random_weights(t, m, k, seed=m + k + b)
+    x = _x(m * 2 + b, b, k)
+    a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
+    y = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=1031, splitk=splitk).cpu().numpy()
+    e = R.rel_l2(y, R.o_mul_mat(t, w, x, m, k)); gu.report(test="gemm_x2", m=m, k=k, b=b, splitk=splitk, rel_l2=e)
+    assert np.isfinite(y).all() and e < TOL_GEMM
+    y2 = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=1031, splitk=splitk).cpu().numpy()
+    assert np.array_equal(y, y2)                                   # deterministic exchange order
+    yd = ops.mul_mat(a, xd, path=ops.PATH_GEMM).cpu().numpy()
+    assert R.rel_l2(y, yd) < 2e-6                                  # same per-weight arithmetic as the default kernel
+
+
+def test_gemm_auto_picks_256x128_kernel_on_huge_grids(gu):
+    """>= 2 x #CUs tiles of 256x128 (the C5-like regime): the auto path is the 256x128-tile kernel without a K split —
+    bit-identical to asking for it explicitly, and within tolerance of the oracle on a row sample"""
+    from ggml_amd import ops
+    t, m, k, b = R.Q4_K, 16384, 256, 1024
+    w = R.random_weights(t, m, k, seed=3)
+    x = _x(8, b, k)
+    a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
+    y = ops.mul_mat(a, xd).cpu().numpy()
+    yx = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=1031, splitk=1).cpu().numpy()
+    assert np.array_equal(y, yx)
+    rows = np.random.default_rng(0).choice(m, 64, replace=False)
+    rs = R.row_size(t, k)
+    wsub = np.concatenate([w[r * rs:(r + 1) * rs] for r in rows])
+    e = R.rel_l2(y[:, rows], R.o_mul_mat(t, wsub, x, 64, k)); gu.report(test="gemm_x2_auto", m=m, k=k, b=b, rel_l2=e)
+    assert np.isfinite(y).all() and e < TOL_GEMM
 
 
 def test_gemm_matches_gemv_statistically(gu):
@@ -260,7 +296,8 @@ def test_full_size_prefill_config(gu, m, k, b):
     # property 2: the result for an activation row does not depend on its batch neighbours
     y2 = ops.mul_mat(a, xd[64:192].contiguous()).cpu().numpy()
     assert np.array_equal(y2, y[64:192])
-    # property 3: row-sharded evaluation (the multi-GPU partition) concatenates to the full result
+    # property 3: row-sharded evaluation (the multi-GPU partition) concatenates to the full result (same kernel and K
+    # split for the shard and the whole at these shapes: bit-identical)
     ysh = np.concatenate([ops.mul_mat(a.rows(lo, lo + m // 4), xd).cpu().numpy() for lo in range(0, m, m // 4)], axis=1)
     assert np.array_equal(ysh, y)
 

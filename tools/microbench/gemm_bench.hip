@@ -27,7 +27,9 @@ int main(int argc, char **argv) {
     // GB_VARIANTS="23,55,151" overrides the variant list (see launch_type() in gemm_q_mfma.hip for the bits)
     std::vector<int> vars = {0, 5, 23};
     if (const char *e = getenv("GB_VARIANTS")) { vars.clear(); for (const char *q = e; *q;) { vars.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; } }
-    for (int v : vars) for (int sk : {1, 2}) cfgs.push_back({v, sk, 0});
+    std::vector<int> sks = {1, 2};
+    if (const char *e = getenv("GB_SPLITKS")) { sks.clear(); for (const char *q = e; *q;) { sks.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; } }
+    for (int v : vars) for (int sk : sks) cfgs.push_back({v, sk, 0});
     std::vector<float> yref, ycur((size_t)B * M);
     printf("M=%lld K=%lld B=%lld  flops=%.3f G\n", (long long)M, (long long)K, (long long)B, 2.0 * M * K * B / 1e9);
     for (auto c : cfgs) {
