@@ -1084,6 +1084,302 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
 
 
 // ------------------------------------------------------------------------------------------------------------
+// k_gemm_kq_w8 with a CROSS-STAGE software pipeline (same tile, ring, DMA and epilogue; see the comment at the main loop).
+template <int TYPE>
+__global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
+    constexpr bool TRACE = false;
+    typedef WStage<TYPE, 2> WSt;
+    constexpr int BNF = 4, TB = 128, NST = 3;
+    constexpr int RS = 256, XS = TB * RS;
+    constexpr int BLK = QT<TYPE>::BYTES;
+    constexpr int WRS = WSt::NPH * 16, WS = 128 * WRS, ST = XS + WS;
+    constexpr int XL = XS / 16 / 512;            // 4
+    constexpr int NWI = 128 * WSt::NPH / 64;     // 10 (Q4_K) / 14 (Q5_K)
+    constexpr int WL = (NWI + 7) / 8;            // 2
+    constexpr int NL = XL + WL;
+    constexpr int SMEM = NST * ST > 128 * 1024 ? NST * ST : 128 * 1024;      // the epilogue needs 2 x 64 KB
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int mg = wave & 3, kh = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int nblk = gridDim.x;
+    int L = blockIdx.x;
+    if ((nblk & 7) == 0) L = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int tile_b = L % p.tiles_b; L /= p.tiles_b;
+    const int ks = L % p.splitk, tile_m = L / p.splitk;
+    const int m0 = tile_m * 128, b0 = tile_b * TB;
+    // K range of this work-group in superblocks.  Hand-off split (p.partial): [0, sb_split) -> ks=0, the rest -> ks=1.
+    const int nsb_all = p.K / 256;
+    const int nsb = p.partial ? (ks == 0 ? p.sb_split : nsb_all - p.sb_split) : nsb_all / p.splitk;
+    const int sb0 = p.partial ? (ks == 0 ? 0 : p.sb_split) : ks * nsb, nstage = nsb * 2;
+
+    // (Tried and rejected, measured: four extra loader waves (12 waves, one loader per SIMD) that do nothing but issue the
+    //  LDS-DMA pieces, compute waves software-pipelined in-wave to fit 168 VGPRs: 44 us vs 37 us per call.  One wave
+    //  sustains only ~1 KiB per 75-90 cycles of LDS-DMA (tools/microbench/l2_stream: 32 GB/s for one wave, 134 GB/s for
+    //  eight), so four loaders cannot feed a stage in time; spreading the pieces over all eight waves can.)
+    DqConst dq; dq.init();
+    floatx16 acc[BNF];
+#pragma unroll
+    for (int i = 0; i < BNF; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+    uint32_t xvoff[XL], wvoff[2][WL];
+#pragma unroll
+    for (int i = 0; i < XL; i++) {
+        const int pc = i * 512 + tid, row = pc >> 4, c = (pc & 15) ^ (row & 15);
+        xvoff[i] = (uint32_t)(min(b0 + row, p.B - 1) - b0) * 256u + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < WL; i++) {
+        int idx = wave + 8 * i;
+        if (idx >= NWI) idx -= 8;
+        const int pc = idx * 64 + lane, row = pc / WSt::NPH, c = pc % WSt::NPH;
+        const uint32_t ro = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
+        wvoff[0][i] = ro + WSt::src_piece(c, 0) * 16; wvoff[1][i] = ro + WSt::src_piece(c, 1) * 16;
+    }
+    const char *const xbase = (const char *)p.xh + ((int64_t)sb0 * 2 * p.B + b0) * 256;    // panel (2*sb0), row b0
+    const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
+
+    // LDS-DMA in the scalar-base form (SGPR pair + 32-bit lane offset, M0 = wave-uniform LDS address): no per-lane 64-bit
+    // address arithmetic (the flat form cost ~5 VALU per piece, ~20 % of this kernel's VALU instructions).
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto dma16 = [&](const char *sbase, uint32_t voff, uint32_t lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+    };
+    auto issue_piece = [&](int i, int sbr, int part, int slot) __attribute__((always_inline)) {         // piece i of stage (sbr, part) -> ring slot
+        const uint32_t l = lds0 + slot * ST;
+        if (i < XL) { dma16(xbase + (int64_t)(sbr * 2 + part) * p.B * 256, xvoff[i], l + (i * 512 + wave_s * 64) * 16); return; }
+        int idx = wave_s + 8 * (i - XL);
+        if (idx >= NWI) idx -= 8;
+        dma16(wbase + (int64_t)sbr * BLK, wvoff[part][i - XL], l + XS + idx * 1024);
+    };
+    auto issue = [&](int sbr, int part, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) issue_piece(i, sbr, part, slot);
+    };
+
+    const int xrow_off = j * RS, xswz = j & 15;
+    auto estamp = [&](int) __attribute__((always_inline)) {};
+    // ---- cross-stage software pipeline -------------------------------------------------------------------------
+    // The barrier of a stage sits in the MIDDLE of its MFMA stream.  Per wave and stage s (ring slot s % 3):
+    //   T_a(s): MFMAs of k-steps 0,1 (fragments in registers since the previous stage) + VALU building fragments 1,2;
+    //           ds_reads of the activation fragments of k-steps 2,3 (the last LDS reads of slot s)
+    //   wait: stage s+1 landed (vmcnt), own LDS reads done (lgkmcnt)  ->  s_barrier  ->  slot s is free
+    //   T_b(s): MFMAs of k-steps 2,3 + VALU building fragment 3 + ALL of the next stage's S work (packed-weight and
+    //           k-step 0,1 activation reads from slot s+1, scale constants, fragment 0) + the DMA pieces of stage s+3 -> slot s
+    // so the LDS latency and the scale arithmetic of stage s+1 run under the MFMAs of stage s instead of in front of its own.
+    Raw<TYPE> raw_c, raw_n;
+    typename Raw<TYPE>::Sc z_c, z_n;
+    half8_t xa[4][BNF];
+    uint32_t cur[4] = {0, 0, 0, 0};
+    auto read_xa = [&](int slot, int kk) __attribute__((always_inline)) {
+        const uint8_t *xs = smem + slot * ST + xrow_off;
+        const int coff = ((kh * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++) xa[kk][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
+    };
+    auto mfma4 = [&](int kk, const uint32_t (&w)[4], auto &&between) __attribute__((always_inline)) {
+        const u32x4 cw = {w[0], w[1], w[2], w[3]};
+        const half8_t wfk = __builtin_bit_cast(half8_t, cw);
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++) {
+            __builtin_amdgcn_sched_barrier(0);
+            acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[kk][bf], wfk, acc[bf], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            between(bf);
+        }
+    };
+    // S work of a stage whose data sits in `slot`: used once in the prologue (nothing to hide it under yet)
+    auto S_first = [&](int slot) __attribute__((always_inline)) {
+        raw_c.load(smem + slot * ST + XS + (mg * 32 + j) * WRS, kh, h);
+        read_xa(slot, 0); read_xa(slot, 1);
+        if (kh == 0) z_c = raw_c.scales(0); else z_c = raw_c.scales(1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[i] = raw_c.pairbits(0, i, z_c, dq);
+    };
+    int slot = 0;
+    // LD: stage s+3 exists (its pieces are issued here);  W2: stage s+2 exists (its pieces are the only ones allowed to be
+    // outstanding at the barrier);  NX: stage s+1 exists (barrier + its S work);  PART: which half of the superblock stage s is
+    auto stage = [&](auto LD, auto W2, auto NX, auto PART, int sb) __attribute__((always_inline)) {
+        constexpr bool load = decltype(LD)::value, w2 = decltype(W2)::value, nx = decltype(NX)::value;
+        constexpr int part = decltype(PART)::value;
+        const int slot1 = slot == 2 ? 0 : slot + 1;
+        uint32_t f1[4], f2[4], f3[4];
+        // ---- T_a
+        read_xa(slot, 2);
+        mfma4(0, cur, [&](int bf) __attribute__((always_inline)) { f1[bf] = raw_c.pairbits(1, bf, z_c, dq); });
+        read_xa(slot, 3);
+        mfma4(1, f1, [&](int bf) __attribute__((always_inline)) { f2[bf] = raw_c.pairbits(2, bf, z_c, dq); });
+        if constexpr (nx) {
+            if (w2) wait_vmcnt<NL>(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's last reads of `slot` have returned
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        // ---- T_b
+        if constexpr (nx) {
+            __builtin_amdgcn_sched_barrier(0);
+            raw_n.load(smem + slot1 * ST + XS + (mg * 32 + j) * WRS, kh, h);
+            read_xa(slot1, 0); read_xa(slot1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // stage s+3 = (sb + (part + 3) / 2, (part + 3) % 2) -> ring slot of stage s
+        mfma4(2, f2, [&](int bf) __attribute__((always_inline)) {
+            f3[bf] = raw_c.pairbits(3, bf, z_c, dq);
+            if constexpr (load) issue_piece(bf, sb + (part + 3) / 2, (part + 3) % 2, slot);
+        });
+        uint32_t f0n[4] = {0, 0, 0, 0};
+        mfma4(3, f3, [&](int bf) __attribute__((always_inline)) {
+            if constexpr (load) { if (4 + bf < NL) issue_piece(4 + bf, sb + (part + 3) / 2, (part + 3) % 2, slot); }
+            if constexpr (nx) {
+                if (bf == 0) { if (kh == 0) z_n = raw_n.scales(((part + 1) & 1) * 2); else z_n = raw_n.scales(((part + 1) & 1) * 2 + 1); }
+                if (bf == 1) { f0n[0] = raw_n.pairbits(0, 0, z_n, dq); f0n[1] = raw_n.pairbits(0, 1, z_n, dq); }
+                if (bf == 2) { f0n[2] = raw_n.pairbits(0, 2, z_n, dq); f0n[3] = raw_n.pairbits(0, 3, z_n, dq); }
+            }
+        });
+        if constexpr (nx) {
+            raw_c = raw_n; z_c = z_n;
+#pragma unroll
+            for (int i = 0; i < 4; i++) cur[i] = f0n[i];
+        }
+        slot = slot1;
+    };
+    static_assert(NL <= 8, "the T_b phase has 8 DMA slots");
+    typedef std::integral_constant<bool, true> yes_t; typedef std::integral_constant<bool, false> no_t;
+    typedef std::integral_constant<int, 0> p0_t; typedef std::integral_constant<int, 1> p1_t;
+    // prologue: stages 0, 1, 2 into slots 0, 1, 2
+    issue(0, 0, 0);
+    issue(0, 1, 1);
+    if (nstage > 2) { issue(1, 0, 2); wait_vmcnt<2 * NL>(); } else wait_vmcnt<NL>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    S_first(0);
+    // stage s = 2 sb + part needs: LD = s + 3 < nstage, W2 = s + 2 < nstage, NX = s + 1 < nstage
+    int sb = 0;
+    for (; sb + 2 < nsb; sb++) { stage(yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); }
+    if (nsb >= 2) { stage(yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(no_t{}, yes_t{}, yes_t{}, p1_t{}, sb); sb++; }   // sb = nsb - 2
+    stage(no_t{}, no_t{}, yes_t{}, p0_t{}, sb); stage(no_t{}, no_t{}, no_t{}, p1_t{}, sb);                                   // sb = nsb - 1
+
+    // ---- epilogue.  (1) The two K halves of the work-group are summed through LDS (the ring is dead now): khalf 1 parks
+    //      its accumulators, khalf 0 adds them IN REGISTERS.  (2) split-K = 2 hand-off, without atomics or a zero-fill
+    //      pass: the ks=1 work-group publishes those registers as they are (register layout, 16 write-through b128 stores
+    //      per lane, no transposition) and raises a per-launch-tagged flag; the ks=0 work-group of the same tile polls the
+    //      flag (one lane, relaxed), acquires, loads the 16 float4 back-to-back and adds them in registers.  Fixed
+    //      summation order: deterministic.  Both work-groups are co-resident by construction (the launcher only takes this
+    //      path when the grid fits the chip).  (3) The final tile goes through LDS in [b][m] order so that all 512 threads
+    //      store 512-byte output rows as float4s: 4x fewer store instructions than lane-per-m dword stores.
+    __syncthreads();
+    float4 *red = reinterpret_cast<float4 *>(smem) + (size_t)mg * 1024;   // [16 quads][64 lanes] float4 per m-group (64 KB total)
+    if (kh == 1) {
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++)
+                red[(bf * 4 + q4) * 64 + lane] = make_float4(acc[bf][4 * q4], acc[bf][4 * q4 + 1], acc[bf][4 * q4 + 2], acc[bf][4 * q4 + 3]);
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+                const float4 v = red[(bf * 4 + q4) * 64 + lane];
+                acc[bf][4 * q4] += v.x; acc[bf][4 * q4 + 1] += v.y; acc[bf][4 * q4 + 2] += v.z; acc[bf][4 * q4 + 3] += v.w;
+            }
+    }
+    estamp(2);
+    // (2) symmetric exchange: of the tile's 128 activation rows, work-group ks keeps rows [64 ks, 64 ks + 64) (accumulator
+    //     blocks bf = 2ks, 2ks+1) and exports the other 64 rows of its partial sums to its partner.
+    const int tile_id = tile_m * p.tiles_b + tile_b;
+    const bool handoff = p.partial != nullptr;
+    int row_lo = 0, nrows = 128;                                           // rows of the tile this work-group finishes
+    if (handoff) {
+        float *part_out = p.partial + ((size_t)tile_id * 2 + ks) * (64 * 128);
+        const float *part_in = p.partial + ((size_t)tile_id * 2 + (ks ^ 1)) * (64 * 128);
+        auto exchange = [&](auto KS) __attribute__((always_inline)) {
+            constexpr int own = decltype(KS)::value * 2, exp = 2 - own;   // first bf kept / exported
+            if (kh == 0) {
+                // write-through (sc1) stores: the partial goes straight past this XCD's L2, so publishing needs no L2
+                // write-back fence (which would flush every dirty line of the XCD, ~8 us measured)
+                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, 64 * 128 * 4, 0x00020000);
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const float4 v = make_float4(acc[exp + e][4 * q4], acc[exp + e][4 * q4 + 1], acc[exp + e][4 * q4 + 2], acc[exp + e][4 * q4 + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (((mg * 8 + e * 4 + q4) * 64) + lane) * 16, 0, 16);
+                    }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            estamp(5);
+            __syncthreads();                                                // every storing wave has drained its sc1 stores
+            if (tid == 0) {
+                __hip_atomic_store(p.flags + tile_id * 2 + ks, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                estamp(7);
+                unsigned spins = 0;
+                while (__hip_atomic_load(p.flags + tile_id * 2 + (ks ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            estamp(4);
+            if (kh == 0) {
+                const float4 *pp = reinterpret_cast<const float4 *>(part_in) + (size_t)mg * 512 + lane;
+                float4 o[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[i] = pp[i * 64];
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const float4 v = o[e * 4 + q4];
+                        acc[own + e][4 * q4] += v.x; acc[own + e][4 * q4 + 1] += v.y; acc[own + e][4 * q4 + 2] += v.z; acc[own + e][4 * q4 + 3] += v.w;
+                    }
+            }
+        };
+        if (ks == 0) exchange(std::integral_constant<int, 0>{}); else exchange(std::integral_constant<int, 1>{});
+        row_lo = ks * 64; nrows = 64;
+    }
+    // (3) [b][m] tile in LDS (rows row_lo .. row_lo + nrows), then wide stores
+    float *ctile = reinterpret_cast<float *>(smem + 64 * 1024);           // [128 b][128 m] fp32 = 64 KB, after the parked partials
+    constexpr int CLD = 128;
+    if (kh == 0) {
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++) {
+            if (bf * 32 < row_lo || bf * 32 >= row_lo + nrows) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int bl = bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;           // C/D layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                ctile[bl * CLD + mg * 32 + j] = acc[bf][r];
+            }
+        }
+    }
+    __syncthreads();
+    estamp(3);
+    {
+        const int c4 = tid & 31, r0 = tid >> 5;                             // 32 float4 per row, 16 rows per pass
+#pragma unroll
+        for (int pass = 0; pass < 8; pass++) {
+            if (pass * 16 >= nrows) break;
+            const int bl = row_lo + pass * 16 + r0, b = b0 + bl, m = m0 + c4 * 4;
+            const float4 v = *reinterpret_cast<const float4 *>(ctile + bl * CLD + c4 * 4);
+            if (b < p.B && m < p.M) {
+                float *dst = p.Y + (int64_t)b * p.y_row + m;
+                if (p.splitk > 1 && !handoff) {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+                    for (int t = 0; t < 4 && m + t < p.M; t++) unsafeAtomicAdd(dst + t, e[t]);
+                } else if (m + 3 < p.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<float4 *>(dst) = v;
+                else { const float e[4] = {v.x, v.y, v.z, v.w}; for (int t = 0; t < 4 && m + t < p.M; t++) dst[t] = e[t]; }
+            }
+        }
+    }
+    estamp(6);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
 // 256(m) x 128(b) work-group tile: the 8-wave in-wave-pipelined kernel with TWO weight fragments per activation
 // fragment.  Wave (mg, kh) owns rows [64 mg, 64 mg + 64) as two 32-row blocks mb = 0, 1, all 128 b, and the kh-th 64-k
 // group of every 128-k stage.  Per MFMA it needs half the activation LDS-DMA pieces, half the activation ds_reads and half
@@ -1460,6 +1756,7 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     const dim3 grid(p.tiles_m * p.tiles_b * splitk);
 #define W8_LAUNCH(O) do { if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, true, O>), grid, dim3(512), 0, st, p); \
                           else hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, false, O>), grid, dim3(512), 0, st, p); } while (0)
+    if (opt == 64) { hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }   // cross-stage pipeline
     if constexpr (TYPE >= 100) { W8_LAUNCH(20); CDNA4_CHECK_LAUNCH(); return 0; }   // repacked formats: the default schedule only
     else switch (opt & 31) { case 0: W8_LAUNCH(0); break; case 1: W8_LAUNCH(1); break; case 2: W8_LAUNCH(2); break; case 3: W8_LAUNCH(3); break;
                         case 4: W8_LAUNCH(4); break; case 12: W8_LAUNCH(12); break; case 28: W8_LAUNCH(28); break; case 20: W8_LAUNCH(20); break; default: return cdna4_set_error_msg("gemm_q: unknown 8-wave schedule option"); }
@@ -1506,10 +1803,11 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     constexpr bool CAN_LDS = QT<TYPE>::KQ && (QT<TYPE>::BYTES % 16 == 0);
     // variant: bit0 = LDS weight staging (Q4_K/Q5_K only), bit1 = 128-wide activation tile, bit3 = the older
     // slice-per-barrier kernel instead of the pipelined one, bit4 = the 8-wave (two waves per SIMD) 128x128 kernel,
-    // bits 5-9 = that kernel's schedule option OPT (see k_gemm_kq_w8; 20 = in-wave pipeline with the DMA pieces split over both phases, the default).
+    // bits 5-9 = that kernel's schedule option OPT (see k_gemm_kq_w8; 20 = in-wave pipeline with the DMA pieces split over both phases),
+    // bit10 = the 256x128-tile kernel k_gemm_kq_x2, bit11 = the cross-stage pipelined k_gemm_kq_w8p (the default).
     // 0 = auto: widest tile that the batch fills.
     int variant = a.variant;
-    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? (16 | (20 << 5)) : 0);   // 8-wave kernel, in-wave pipeline, DMA pieces split between the S and T phases
+    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? (16 | 2048) : 0);   // 8-wave kernel, cross-stage software pipeline (k_gemm_kq_w8p)
     const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
     const bool wide = (variant & 2) != 0;
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
@@ -1555,11 +1853,11 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
             int sk = a.splitk;
             if (sk <= 0) sk = (tiles * 2 <= cu_count() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
             if (sk < 1 || nsb % sk) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
-            return launch_w8<RT>(r, sk, 20, st);
+            return launch_w8<RT>(r, sk, 64, st);
         }
     }
     if constexpr (CAN_LDS) {
-        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant >> 5) & 31, st);
+        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant & 2048) ? 64 : ((variant >> 5) & 31), st);
         if (wlds && !(variant & 8)) return wide ? launch_pipe<TYPE, 4>(a, splitk, st) : launch_pipe<TYPE, 2>(a, splitk, st);
         if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
     }
