@@ -1203,42 +1203,49 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
     int slot = 0;
     // LD: stage s+3 exists (its pieces are issued here);  W2: stage s+2 exists (its pieces are the only ones allowed to be
     // outstanding at the barrier);  NX: stage s+1 exists (barrier + its S work);  PART: which half of the superblock stage s is
-    auto stage = [&](auto LD, auto W2, auto NX, auto PART, int sb) __attribute__((always_inline)) {
-        constexpr bool load = decltype(LD)::value, w2 = decltype(W2)::value, nx = decltype(NX)::value;
+    // The NL DMA pieces of a stage are issued in two halves so that neither half of the MFMA stream carries them all:
+    // pieces [0, NB) of stage s+3 in T_b(s), pieces [NB, NL) of stage s+2 in T_a(s) (both target a slot freed by the barrier
+    // before them; HA = T_a has pieces to issue: stage s+2 exists and was not part of the prologue's three stages).
+    constexpr int NB = (NL + 1) / 2;
+    auto stage = [&](auto LD, auto W2, auto NX, auto HA, auto PART, int sb) __attribute__((always_inline)) {
+        constexpr bool load = decltype(LD)::value, w2 = decltype(W2)::value, nx = decltype(NX)::value, ha = decltype(HA)::value;
         constexpr int part = decltype(PART)::value;
-        const int slot1 = slot == 2 ? 0 : slot + 1;
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;
         uint32_t f1[4], f2[4], f3[4];
-        // ---- T_a
+        // ---- T_a: k-steps 0,1; builds fragments 1, 2 and half of 3; second half of stage s+2's pieces -> slot of stage s-1
         read_xa(slot, 2);
-        mfma4(0, cur, [&](int bf) __attribute__((always_inline)) { f1[bf] = raw_c.pairbits(1, bf, z_c, dq); });
+        mfma4(0, cur, [&](int bf) __attribute__((always_inline)) {
+            f1[bf] = raw_c.pairbits(1, bf, z_c, dq);
+            if (bf < 2) f3[bf] = raw_c.pairbits(3, bf, z_c, dq);
+            if constexpr (ha) { if (NB + bf < NL) issue_piece(NB + bf, sb + (part + 2) / 2, part, slot2); }
+        });
         read_xa(slot, 3);
-        mfma4(1, f1, [&](int bf) __attribute__((always_inline)) { f2[bf] = raw_c.pairbits(2, bf, z_c, dq); });
+        mfma4(1, f1, [&](int bf) __attribute__((always_inline)) {
+            f2[bf] = raw_c.pairbits(2, bf, z_c, dq);
+            if (bf >= 2) f3[bf] = raw_c.pairbits(3, bf, z_c, dq);
+        });
         if constexpr (nx) {
             if (w2) wait_vmcnt<NL>(); else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's last reads of `slot` have returned
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        // ---- T_b
+        // ---- T_b: k-steps 2,3; the next stage's S work; first half of stage s+3's pieces -> slot of stage s
         if constexpr (nx) {
             __builtin_amdgcn_sched_barrier(0);
             raw_n.load(smem + slot1 * ST + XS + (mg * 32 + j) * WRS, kh, h);
             read_xa(slot1, 0); read_xa(slot1, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // stage s+3 = (sb + (part + 3) / 2, (part + 3) % 2) -> ring slot of stage s
-        mfma4(2, f2, [&](int bf) __attribute__((always_inline)) {
-            f3[bf] = raw_c.pairbits(3, bf, z_c, dq);
-            if constexpr (load) issue_piece(bf, sb + (part + 3) / 2, (part + 3) % 2, slot);
-        });
         uint32_t f0n[4] = {0, 0, 0, 0};
-        mfma4(3, f3, [&](int bf) __attribute__((always_inline)) {
-            if constexpr (load) { if (4 + bf < NL) issue_piece(4 + bf, sb + (part + 3) / 2, (part + 3) % 2, slot); }
+        mfma4(2, f2, [&](int bf) __attribute__((always_inline)) {
+            if constexpr (load) { if (bf < NB) issue_piece(bf, sb + (part + 3) / 2, (part + 3) % 2, slot); }
             if constexpr (nx) {
-                if (bf == 0) { if (kh == 0) z_n = raw_n.scales(((part + 1) & 1) * 2); else z_n = raw_n.scales(((part + 1) & 1) * 2 + 1); }
-                if (bf == 1) { f0n[0] = raw_n.pairbits(0, 0, z_n, dq); f0n[1] = raw_n.pairbits(0, 1, z_n, dq); }
-                if (bf == 2) { f0n[2] = raw_n.pairbits(0, 2, z_n, dq); f0n[3] = raw_n.pairbits(0, 3, z_n, dq); }
+                if (bf == 3) { if (kh == 0) z_n = raw_n.scales(((part + 1) & 1) * 2); else z_n = raw_n.scales(((part + 1) & 1) * 2 + 1); }
             }
+        });
+        mfma4(3, f3, [&](int bf) __attribute__((always_inline)) {
+            if constexpr (nx) f0n[bf] = raw_n.pairbits(0, bf, z_n, dq);
         });
         if constexpr (nx) {
             raw_c = raw_n; z_c = z_n;
@@ -1257,11 +1264,14 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     S_first(0);
-    // stage s = 2 sb + part needs: LD = s + 3 < nstage, W2 = s + 2 < nstage, NX = s + 1 < nstage
-    int sb = 0;
-    for (; sb + 2 < nsb; sb++) { stage(yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); }
-    if (nsb >= 2) { stage(yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(no_t{}, yes_t{}, yes_t{}, p1_t{}, sb); sb++; }   // sb = nsb - 2
-    stage(no_t{}, no_t{}, yes_t{}, p0_t{}, sb); stage(no_t{}, no_t{}, no_t{}, p1_t{}, sb);                                   // sb = nsb - 1
+    // stage s = 2 sb + part needs: LD = s + 3 < nstage, W2 = s + 2 < nstage, NX = s + 1 < nstage, HA = W2 && s >= 1
+    // (stage 2's pieces all went out in the prologue)
+    // (the launcher only sends K ranges of >= 3 superblocks per work-group here; shallower ones run k_gemm_kq_w8)
+    stage(yes_t{}, yes_t{}, yes_t{}, no_t{}, p0_t{}, 0); stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, 0);
+    int sb = 1;
+    for (; sb + 2 < nsb; sb++) { stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); }
+    stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(no_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); sb++;   // sb = nsb - 2
+    stage(no_t{}, no_t{}, yes_t{}, no_t{}, p0_t{}, sb); stage(no_t{}, no_t{}, no_t{}, no_t{}, p1_t{}, sb);                  // sb = nsb - 1
 
     // ---- epilogue.  (1) The two K halves of the work-group are summed through LDS (the ring is dead now): khalf 1 parks
     //      its accumulators, khalf 0 adds them IN REGISTERS.  (2) split-K = 2 hand-off, without atomics or a zero-fill
@@ -1756,6 +1766,11 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     const dim3 grid(p.tiles_m * p.tiles_b * splitk);
 #define W8_LAUNCH(O) do { if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, true, O>), grid, dim3(512), 0, st, p); \
                           else hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, false, O>), grid, dim3(512), 0, st, p); } while (0)
+    {   // the cross-stage pipeline is written for K ranges of >= 3 superblocks per work-group; shallower ones take schedule 20
+        const int total = a.K / 256;
+        const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
+        if (opt == 64 && min_nsb < 3) opt = 20;
+    }
     if (opt == 64) { hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }   // cross-stage pipeline
     if constexpr (TYPE >= 100) { W8_LAUNCH(20); CDNA4_CHECK_LAUNCH(); return 0; }   // repacked formats: the default schedule only
     else switch (opt & 31) { case 0: W8_LAUNCH(0); break; case 1: W8_LAUNCH(1); break; case 2: W8_LAUNCH(2); break; case 3: W8_LAUNCH(3); break;
