@@ -31,15 +31,7 @@ template <int NB> struct Unit<CDNA4_Q4_K, NB> {
         W w; w.hdr = ld_u32x4(blk); w.q0 = ld_u32x4(blk + 16 + 32 * g); w.q1 = ld_u32x4(blk + 32 + 32 * g);
         return w;
     }
-    // streamed-once weights: non-temporal loads (experiment knob CDNA4_GEMV_NT=1)
-    __device__ static W load_nt(const uint8_t *wrow, int u) {
-        const int sb = u >> 2, g = u & 3;
-        const uint8_t *blk = wrow + (int64_t)sb * 144;
-        W w; w.hdr = ld_u32x4(blk);
-        w.q0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(blk + 16 + 32 * g));
-        w.q1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(blk + 32 + 32 * g));
-        return w;
-    }
+    // (non-temporal weight loads were measured slower here: 6.06 vs 5.58 us cold at 4096x4096)
     template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
         const int sb = u >> 2, g = u & 3;
         const u32x4 hdr = wr.hdr;
@@ -295,7 +287,7 @@ struct lds_act { const int8_t *qs; const float *d; const int16_t *bsums; int K; 
 
 // NW waves per work-group, ROWS weight rows per wave.  The quantizer's cost is per WORK-GROUP (every work-group redoes the
 // whole row), so fewer, fatter work-groups pay it less often: <4,1> = 1024 work-groups at M=4096, <8,2> = 256 (one per CU).
-template <int TYPE, int NW, int ROWS, bool NT = false>
+template <int TYPE, int NW, int ROWS>
 __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(const cdna4_gemv_args a, const float *__restrict__ x) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr bool KQ = QT<TYPE>::KQ;
@@ -311,8 +303,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(const cdna4_gemv_args 
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         wrow[r] = a.W + (int64_t)min(row0 + r, a.M - 1) * a.w_row_bytes;
-        if constexpr (NT && TYPE == CDNA4_Q4_K) w0[r] = Unit<TYPE, 1>::load_nt(wrow[r], min(lane, nunits - 1));
-        else w0[r] = Unit<TYPE, 1>::load(wrow[r], min(lane, nunits - 1));
+        w0[r] = Unit<TYPE, 1>::load(wrow[r], min(lane, nunits - 1));
     }
     // One lane quantizes 16 consecutive values (= one bsums entry, one ds_write_b128): a superblock is 16 adjacent lanes
     // (4 butterfly rounds), a Q8_0 block 2 lanes (1 round).  The first cut (one wave per superblock, 4 values per lane,
@@ -392,8 +383,6 @@ static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st
     // 6.32/5.52, 5.93/5.39, 6.35/5.49, 5.57/5.79 -> 8 waves x 1 row when the matrix is tall enough to still fill the chip.
     static const int cfg_env = getenv("CDNA4_FUSED_CFG") ? atoi(getenv("CDNA4_FUSED_CFG")) : -1;
     const int cfg = cfg_env >= 0 ? cfg_env : (a.M >= 2048 ? 3 : 0);
-    static const bool nt = getenv("CDNA4_GEMV_NT") != nullptr;
-    if (nt && TYPE == CDNA4_Q4_K && cfg == 3) { hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 1, true>), dim3((a.M + 7) / 8), dim3(512), lds, st, a, x); CDNA4_CHECK_LAUNCH(); return 0; }
     if (cfg == 1) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x);
     else if (cfg == 2) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 2>), dim3((a.M + 7) / 8), dim3(256), lds, st, a, x);
     else if (cfg == 3) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 1>), dim3((a.M + 7) / 8), dim3(512), lds, st, a, x);

@@ -61,7 +61,15 @@ size_t ggml_cdna4_mul_mat_workspace_size(int type, int64_t K, int64_t n_act_rows
  * Y[b * y_row_stride + m] = sum_k W[m][k] * X[b * x_row_stride + k],  m < M, b < B.
  *   W: M rows of K block-quantized weights (type in {Q4_0,Q8_0,Q4_K,Q5_K,Q6_K}), row stride w_row_bytes.
  *   X: f32, Y: f32; strides in ELEMENTS.  workspace: >= ggml_cdna4_mul_mat_workspace_size(type, K, B) bytes,
- *   256-byte aligned.  path: enum ggml_cdna4_path.  gemm_variant / splitk: 0 = auto (tuning knobs).
+ *   256-byte aligned.  path: enum ggml_cdna4_path.  gemm_variant / splitk: 0 = auto (tuning knobs; the bit
+ *   layout of gemm_variant is documented at launch_type() in ggml_amd/csrc/gemm_q_mfma.hip).
+ *   Asynchronous on `stream`; the workspace must stay alive until the stream has passed the call.
+ *   Which kernels run (auto):  B == 1 -> one launch, the activation quantizer fused into the int8-dot GEMV (the
+ *   workspace is not touched);  2 <= B <= 8 -> quantize + GEMV;  B > 8 -> quantize (fp16 image) + MFMA GEMM.
+ *   The GEMM may use library-owned device scratch (split-K exchange buffers; a per-call 16-byte-aligned re-layout
+ *   of Q4_0 / Q8_0 / Q6_K weights at B > 64): one scratch set per device, so GEMM calls on ONE device must be issued
+ *   from one stream at a time (what a ggml backend does anyway: a ggml_backend_t is a single-stream object).  The
+ *   weights themselves are only read.  Results are deterministic for fixed (shape, gemm_variant, splitk).
  */
 int ggml_cdna4_mul_mat(int type, const void * W, int64_t w_row_bytes,
                        const float * X, int64_t x_row_stride,
