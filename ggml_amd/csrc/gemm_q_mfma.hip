@@ -1092,9 +1092,8 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
 
 // ------------------------------------------------------------------------------------------------------------
 // k_gemm_kq_w8 with a CROSS-STAGE software pipeline (same tile, ring, DMA and epilogue; see the comment at the main loop).
-template <int TYPE>
+template <int TYPE, bool TRACE = false>
 __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
-    constexpr bool TRACE = false;
     typedef WStage<TYPE, 2> WSt;
     constexpr int BNF = 4, TB = 128, NST = 3;
     constexpr int RS = 256, XS = TB * RS;
@@ -1111,7 +1110,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int mg = wave & 3, kh = __builtin_amdgcn_readfirstlane(wave >> 2);
-    // the second-dispatched half of a work-group loses every issue arbitration at equal priority; one static raise evens it out
+    // experiment knob (CDNA4_TUNE bit 0): one static priority raise for the second-dispatched half of the work-group
     if ((p.tune & 1) && kh == 1) __builtin_amdgcn_s_setprio(1);
     const int nblk = gridDim.x;
     int L = blockIdx.x;
@@ -1173,6 +1172,11 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
 
     const int xrow_off = j * RS, xswz = j & 15;
     auto estamp = [&](int) __attribute__((always_inline)) {};
+    // TRACE builds: [wave][stage 4..19][phase] s_memtime stamps of block 0: 0 T_a begin, 1 T_a done, 2 after the vmcnt/lgkm
+    // waits, 3 after the barrier, 4 next stage's LDS reads issued, 6 T_b done
+    auto stamp = [&](int s_, int ph) __attribute__((always_inline)) {
+        if (TRACE && blockIdx.x == 0 && s_ >= 4 && s_ < 20 && lane == 0) p.trace[(wave * 16 + (s_ - 4)) * 8 + ph] = __builtin_amdgcn_s_memtime();
+    };
     // ---- cross-stage software pipeline -------------------------------------------------------------------------
     // The barrier of a stage sits in the MIDDLE of its MFMA stream.  Per wave and stage s (ring slot s % 3):
     //   T_a(s): MFMAs of k-steps 0,1 (fragments in registers since the previous stage) + VALU building fragments 1,2;
@@ -1222,6 +1226,8 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
         constexpr int part = decltype(PART)::value;
         const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;
         uint32_t f1[4], f2[4], f3[4];
+        const int s_ = sb * 2 + part;
+        stamp(s_, 0);
         // ---- T_a: k-steps 0,1; builds fragments 1, 2 and half of 3; second half of stage s+2's pieces -> slot of stage s-1
         read_xa(slot, 2);
         mfma4(0, cur, [&](int bf) __attribute__((always_inline)) {
@@ -1234,11 +1240,14 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
             f2[bf] = raw_c.pairbits(2, bf, z_c, dq);
             if (bf >= 2) f3[bf] = raw_c.pairbits(3, bf, z_c, dq);
         });
+        stamp(s_, 1);
         if constexpr (nx) {
             if (w2) wait_vmcnt<NL>(); else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's last reads of `slot` have returned
+            stamp(s_, 2);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            stamp(s_, 3);
         }
         // ---- T_b: k-steps 2,3; the next stage's S work; first half of stage s+3's pieces -> slot of stage s
         if constexpr (nx) {
@@ -1246,6 +1255,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
             raw_n.load(smem + slot1 * ST + XS + (mg * 32 + j) * WRS, kh, h);
             read_xa(slot1, 0); read_xa(slot1, 1);
             __builtin_amdgcn_sched_barrier(0);
+            stamp(s_, 4);
         }
         uint32_t f0n[4] = {0, 0, 0, 0};
         mfma4(2, f2, [&](int bf) __attribute__((always_inline)) {
@@ -1262,6 +1272,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
 #pragma unroll
             for (int i = 0; i < 4; i++) cur[i] = f0n[i];
         }
+        stamp(s_, 6);
         slot = slot1;
     };
     static_assert(NL <= 8, "the T_b phase has 8 DMA slots");
@@ -1785,8 +1796,9 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.Y, a.y_row_elems, a.M, a.B);
     }
     p.trace = (unsigned long long *)cdna4_debug_trace;
-    // bit0: static s_setprio 1 for the later-dispatched khalf-1 waves of k_gemm_kq_w8p (measured -2.5..-3.5 %, two A/B runs)
-    static const int tune_env = getenv("CDNA4_TUNE") ? atoi(getenv("CDNA4_TUNE")) : 1;
+    // bit0: static s_setprio 1 for the later-dispatched khalf-1 waves of k_gemm_kq_w8p (no measurable effect under the
+    // warm-up + round-robin protocol of tools/microbench/gemm_bench: 26.31 vs 26.33 us; off by default)
+    static const int tune_env = getenv("CDNA4_TUNE") ? atoi(getenv("CDNA4_TUNE")) : 0;
     p.tune = tune_env;
     const dim3 grid(p.tiles_m * p.tiles_b * splitk);
 #define W8_LAUNCH(O) do { if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, true, O>), grid, dim3(512), 0, st, p); \
@@ -1796,7 +1808,11 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
         if (opt == 64 && min_nsb < 3) opt = 20;
     }
-    if (opt == 64) { hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }   // cross-stage pipeline
+    if (opt == 64) {                                                      // cross-stage pipeline
+        if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE, true>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE, false>), grid, dim3(512), 0, st, p);
+        CDNA4_CHECK_LAUNCH(); return 0;
+    }
     if constexpr (TYPE >= 100) { W8_LAUNCH(20); CDNA4_CHECK_LAUNCH(); return 0; }   // repacked formats: the default schedule only
     else switch (opt & 31) { case 0: W8_LAUNCH(0); break; case 1: W8_LAUNCH(1); break; case 2: W8_LAUNCH(2); break; case 3: W8_LAUNCH(3); break;
                         case 4: W8_LAUNCH(4); break; case 12: W8_LAUNCH(12); break; case 28: W8_LAUNCH(28); break; case 20: W8_LAUNCH(20); break; default: return cdna4_set_error_msg("gemm_q: unknown 8-wave schedule option"); }
