@@ -1172,6 +1172,8 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
 
     const int xrow_off = j * RS, xswz = j & 15;
     auto estamp = [&](int) __attribute__((always_inline)) {};
+    // TRACE builds: shader clock (s_memtime) against the fixed 100 MHz reference (s_memrealtime) over the whole kernel of block 0
+    if (TRACE && blockIdx.x == 0 && tid == 0) { p.trace[8 * 16 * 8 + 1100] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1101] = __builtin_amdgcn_s_memrealtime(); }
     // TRACE builds: [wave][stage 4..19][phase] s_memtime stamps of block 0: 0 T_a begin, 1 T_a done, 2 after the vmcnt/lgkm
     // waits, 3 after the barrier, 4 next stage's LDS reads issued, 6 T_b done
     auto stamp = [&](int s_, int ph) __attribute__((always_inline)) {
@@ -1412,6 +1414,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
         }
     }
     estamp(6);
+    if (TRACE && blockIdx.x == 0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[8 * 16 * 8 + 1102] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1103] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 
