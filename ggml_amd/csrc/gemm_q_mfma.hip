@@ -396,6 +396,7 @@ struct gemm_params {
     float *Y; int64_t y_row;
     int M, K, B, splitk, tiles_m, tiles_b;
     int sb_split;                                       // hand-off: superblocks [0, sb_split) -> ks=0, the rest -> ks=1
+    int xchg_l2;                                        // split-K exchange through the XCD's L2 (partners co-located) instead of write-through
     int tune;                                           // experiment bits from CDNA4_TUNE (bit0: static s_setprio 1 for the khalf-1 waves)
     float *partial; unsigned *flags; unsigned epoch;   // split-K = 2 exchange (k_gemm_kq_w8): exported half tiles [tile][ks][64][128], one flag per (tile, ks), this launch's tag
     unsigned long long *trace;   // profiling builds only (k_gemm_kq_w8<TYPE, true>): per-phase s_memtime stamps of block 0
@@ -1005,38 +1006,53 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
     if (handoff) {
         float *part_out = p.partial + ((size_t)tile_id * 2 + ks) * (64 * 128);
         const float *part_in = p.partial + ((size_t)tile_id * 2 + (ks ^ 1)) * (64 * 128);
+        // Two transports for the exported half tile.  p.xchg_l2 (the launcher sets it when the tile order puts both
+        // work-groups of every pair on one XCD): plain stores — they are complete once this XCD's L2 has them, which is where
+        // the partner reads them with L1-bypassing (sc0) loads.  Otherwise write-through (sc1) stores past the L2 and an
+        // agent-scope acquire on the reader's side (publishing through an L2 write-back fence instead would flush every dirty
+        // line of the XCD, ~8 us measured).  The flag word carries the launch tag AND the writer's XCC id: a reader on the L2
+        // transport that finds its partner on another XCD poisons the tile with NaN instead of reading stale data.
+        const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;       // HW_REG_XCC_ID[3:0]
+        const unsigned tag = p.epoch << 4;
         auto exchange = [&](auto KS) __attribute__((always_inline)) {
             constexpr int own = decltype(KS)::value * 2, exp = 2 - own;   // first bf kept / exported
             if (kh == 0) {
-                // write-through (sc1) stores: the partial goes straight past this XCD's L2, so publishing needs no L2
-                // write-back fence (which would flush every dirty line of the XCD, ~8 us measured)
                 __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, 64 * 128 * 4, 0x00020000);
 #pragma unroll
                 for (int e = 0; e < 2; e++)
 #pragma unroll
                     for (int q4 = 0; q4 < 4; q4++) {
                         const float4 v = make_float4(acc[exp + e][4 * q4], acc[exp + e][4 * q4 + 1], acc[exp + e][4 * q4 + 2], acc[exp + e][4 * q4 + 3]);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (((mg * 8 + e * 4 + q4) * 64) + lane) * 16, 0, 16);
+                        const int off = (((mg * 8 + e * 4 + q4) * 64) + lane) * 16;
+                        if (p.xchg_l2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 16);
                     }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             estamp(5);
-            __syncthreads();                                                // every storing wave has drained its sc1 stores
+            __syncthreads();                                                // every storing wave has drained its stores
             if (tid == 0) {
-                __hip_atomic_store(p.flags + tile_id * 2 + ks, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.flags + tile_id * 2 + ks, tag | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 estamp(7);
-                unsigned spins = 0;
-                while (__hip_atomic_load(p.flags + tile_id * 2 + (ks ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                xchg_failed = spins >= (1u << 26);                        // partner never showed up (not co-resident): fail LOUDLY, see below
+                unsigned spins = 0, v;
+                while ((((v = __hip_atomic_load(p.flags + tile_id * 2 + (ks ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ^ tag) >> 4) != 0 && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
+                if (!p.xchg_l2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // partner never showed up (not co-resident), or it sits on another XCD while the L2 transport is on: fail LOUDLY
+                xchg_failed = spins >= (1u << 26) || (p.xchg_l2 && (v & 15u) != my_xcc);
             }
             __syncthreads();
             estamp(4);
             if (kh == 0) {
-                const float4 *pp = reinterpret_cast<const float4 *>(part_in) + (size_t)mg * 512 + lane;
                 float4 o[8];
+                if (p.xchg_l2) {
+                    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(part_in), 0, 64 * 128 * 4, 0x00020000);
 #pragma unroll
-                for (int i = 0; i < 8; i++) o[i] = pp[i * 64];
+                    for (int i = 0; i < 8; i++) o[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, ((mg * 8 + i) * 64 + lane) * 16, 0, 1));
+                } else {
+                    const float4 *pp = reinterpret_cast<const float4 *>(part_in) + (size_t)mg * 512 + lane;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) o[i] = pp[i * 64];
+                }
                 if (xchg_failed) {                                          // NaN tile instead of a silently wrong sum
 #pragma unroll
                     for (int i = 0; i < 8; i++) o[i].x = __builtin_nanf("");
@@ -1332,38 +1348,53 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
     if (handoff) {
         float *part_out = p.partial + ((size_t)tile_id * 2 + ks) * (64 * 128);
         const float *part_in = p.partial + ((size_t)tile_id * 2 + (ks ^ 1)) * (64 * 128);
+        // Two transports for the exported half tile.  p.xchg_l2 (the launcher sets it when the tile order puts both
+        // work-groups of every pair on one XCD): plain stores — they are complete once this XCD's L2 has them, which is where
+        // the partner reads them with L1-bypassing (sc0) loads.  Otherwise write-through (sc1) stores past the L2 and an
+        // agent-scope acquire on the reader's side (publishing through an L2 write-back fence instead would flush every dirty
+        // line of the XCD, ~8 us measured).  The flag word carries the launch tag AND the writer's XCC id: a reader on the L2
+        // transport that finds its partner on another XCD poisons the tile with NaN instead of reading stale data.
+        const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;       // HW_REG_XCC_ID[3:0]
+        const unsigned tag = p.epoch << 4;
         auto exchange = [&](auto KS) __attribute__((always_inline)) {
             constexpr int own = decltype(KS)::value * 2, exp = 2 - own;   // first bf kept / exported
             if (kh == 0) {
-                // write-through (sc1) stores: the partial goes straight past this XCD's L2, so publishing needs no L2
-                // write-back fence (which would flush every dirty line of the XCD, ~8 us measured)
                 __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, 64 * 128 * 4, 0x00020000);
 #pragma unroll
                 for (int e = 0; e < 2; e++)
 #pragma unroll
                     for (int q4 = 0; q4 < 4; q4++) {
                         const float4 v = make_float4(acc[exp + e][4 * q4], acc[exp + e][4 * q4 + 1], acc[exp + e][4 * q4 + 2], acc[exp + e][4 * q4 + 3]);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (((mg * 8 + e * 4 + q4) * 64) + lane) * 16, 0, 16);
+                        const int off = (((mg * 8 + e * 4 + q4) * 64) + lane) * 16;
+                        if (p.xchg_l2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 16);
                     }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             estamp(5);
-            __syncthreads();                                                // every storing wave has drained its sc1 stores
+            __syncthreads();                                                // every storing wave has drained its stores
             if (tid == 0) {
-                __hip_atomic_store(p.flags + tile_id * 2 + ks, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.flags + tile_id * 2 + ks, tag | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 estamp(7);
-                unsigned spins = 0;
-                while (__hip_atomic_load(p.flags + tile_id * 2 + (ks ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                xchg_failed = spins >= (1u << 26);                        // partner never showed up (not co-resident): fail LOUDLY, see below
+                unsigned spins = 0, v;
+                while ((((v = __hip_atomic_load(p.flags + tile_id * 2 + (ks ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ^ tag) >> 4) != 0 && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
+                if (!p.xchg_l2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // partner never showed up (not co-resident), or it sits on another XCD while the L2 transport is on: fail LOUDLY
+                xchg_failed = spins >= (1u << 26) || (p.xchg_l2 && (v & 15u) != my_xcc);
             }
             __syncthreads();
             estamp(4);
             if (kh == 0) {
-                const float4 *pp = reinterpret_cast<const float4 *>(part_in) + (size_t)mg * 512 + lane;
                 float4 o[8];
+                if (p.xchg_l2) {
+                    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(part_in), 0, 64 * 128 * 4, 0x00020000);
 #pragma unroll
-                for (int i = 0; i < 8; i++) o[i] = pp[i * 64];
+                    for (int i = 0; i < 8; i++) o[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, ((mg * 8 + i) * 64 + lane) * 16, 0, 1));
+                } else {
+                    const float4 *pp = reinterpret_cast<const float4 *>(part_in) + (size_t)mg * 512 + lane;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) o[i] = pp[i * 64];
+                }
                 if (xchg_failed) {                                          // NaN tile instead of a silently wrong sum
 #pragma unroll
                     for (int i = 0; i < 8; i++) o[i].x = __builtin_nanf("");
@@ -1625,12 +1656,13 @@ __global__ __launch_bounds__(512) void k_gemm_kq_x2(const gemm_params p) {
             }
             __syncthreads();
             if (tid == 0) {
-                __hip_atomic_store(p.flags + tile_id * S + me, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // same word format as k_gemm_kq_w8's flags (launch tag << 4 | XCC id): the kernels share the flag scratch
+                __hip_atomic_store(p.flags + tile_id * S + me, p.epoch << 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int o = 0; o < S; o++) {
                     if (o == me) continue;
                     unsigned spins = 0;
-                    while (__hip_atomic_load(p.flags + tile_id * S + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
+                    while (((__hip_atomic_load(p.flags + tile_id * S + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ (p.epoch << 4)) >> 4) != 0 && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
                     if (spins >= (1u << 26)) xchg_failed = 1;             // a partner never showed up (not co-resident): fail LOUDLY, see below
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1799,6 +1831,12 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.Y, a.y_row_elems, a.M, a.B);
     }
     p.trace = (unsigned long long *)cdna4_debug_trace;
+    {   // both work-groups of a tile share an XCD iff the XCD-aware remap is active (grid % 8 == 0) and each XCD's slice of the
+        // tile order holds whole (tile_b x ks) groups; work-groups go to XCDs round-robin by blockIdx (the kernel verifies it)
+        static const bool l2_env = getenv("CDNA4_XCHG_L2") ? atoi(getenv("CDNA4_XCHG_L2")) != 0 : true;
+        const int nb = p.tiles_m * p.tiles_b * splitk;
+        p.xchg_l2 = (l2_env && p.partial && (nb & 7) == 0 && ((nb >> 3) % (p.tiles_b * 2)) == 0) ? 1 : 0;
+    }
     // bit0: static s_setprio 1 for the later-dispatched khalf-1 waves of k_gemm_kq_w8p (no measurable effect under the
     // warm-up + round-robin protocol of tools/microbench/gemm_bench: 26.31 vs 26.33 us; off by default)
     static const int tune_env = getenv("CDNA4_TUNE") ? atoi(getenv("CDNA4_TUNE")) : 0;
