@@ -1296,7 +1296,8 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
     static_assert(NL <= 8, "the T_b phase has 8 DMA slots");
     typedef std::integral_constant<bool, true> yes_t; typedef std::integral_constant<bool, false> no_t;
     typedef std::integral_constant<int, 0> p0_t; typedef std::integral_constant<int, 1> p1_t;
-    // prologue: stages 0, 1, 2 into slots 0, 1, 2
+    // prologue: stages 0, 1, 2 into slots 0, 1, 2.  (Requesting stage 2 only after stage 0 has landed, weight pieces first,
+    // made no measurable difference: 26.5 us either way.)
     issue(0, 0, 0);
     issue(0, 1, 1);
     if (nstage > 2) { issue(1, 0, 2); wait_vmcnt<2 * NL>(); } else wait_vmcnt<NL>();
