@@ -230,9 +230,9 @@ def main():
                        "M_per_gpu": M_PER_GPU, "K": K, "B": B, "parallelism": "row-split x%d, output left sharded" % world,
                        "gemm_variant": args.variant, "splitk": args.splitk},
             "tokens_per_s": round(B * world / (ms_per_step * 1e-3), 1),
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_kq_w8p<Q4_K> (8-wave 128x128 tile, cross-stage unpack/MFMA pipeline, split-K=2 symmetric exchange)" if args.variant in (0, 23, 2071) else "gemm variant %d" % args.variant, "achieved": round(gemm_tflops, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "k_gemm_kq_w12<Q4_K> (128x128 tile, 8 compute + 4 loader waves, cross-stage unpack/MFMA pipeline, split-K=2 symmetric exchange)" if args.variant in (0, 23, 2071, 4119) else "gemm variant %d" % args.variant, "achieved": round(gemm_tflops, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / MFMA_F16_PEAK_TFLOPS, 4),
-                         "traffic": pmc_traffic("k_gemm_kq_w8p<12") if args.variant in (0, 23, 2071) else None,
+                         "traffic": pmc_traffic("k_gemm_kq_w12<12") if args.variant in (0, 23, 2071, 4119) else None,
                          "traffic_note": "HBM-side bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) from the rocprofv3 PMC passes of this command, profiles/rNN/pmc_summary.txt",
                          "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": 2.0 * M_PER_GPU * K * B},
         }

@@ -1450,6 +1450,363 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
 }
 
 
+// k_gemm_kq_w8p with FOUR EXTRA LOADER WAVES (12 waves, three per SIMD): waves 8-11 do nothing but issue the LDS-DMA pieces
+// (an LDS-DMA instruction parks its wave ~60 cycles; in the 8-wave kernels that park is taken out of the MFMA stream — the
+// DMA-less ablation of k_gemm_kq_w8p ran 26.9 -> 24.7 us with the same memory traffic), waves 0-7 are the compute waves of
+// k_gemm_kq_w8p without any vector-memory instruction in their main loop.  All twelve meet at the same s_barriers.
+template <int TYPE>
+__global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
+    constexpr bool TRACE = false;
+    typedef WStage<TYPE, 2> WSt;
+    constexpr int BNF = 4, TB = 128, NST = 3;
+    constexpr int RS = 256, XS = TB * RS;
+    constexpr int BLK = QT<TYPE>::BYTES;
+    constexpr int WRS = WSt::NPH * 16, WS = 128 * WRS, ST = XS + WS;
+    constexpr int NWI = 128 * WSt::NPH / 64;     // weight wave-pieces per stage: 10 (Q4_K) / 14 (Q5_K)
+    constexpr int XL = XS / 16 / 64 / 4;         // activation wave-pieces per loader wave per stage: 8
+    constexpr int WL = (NWI + 3) / 4;            // weight wave-pieces per loader wave (the tail re-loads earlier pieces)
+    constexpr int NL = XL + WL;                  // 11 (Q4_K)
+    constexpr int SMEM = NST * ST > 128 * 1024 ? NST * ST : 128 * 1024;      // the epilogue needs 2 x 64 KB
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
+    __shared__ int xchg_failed;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int mg = wave & 3, kh = __builtin_amdgcn_readfirstlane(wave >> 2);        // kh = 2: loader wave (mg = its index)
+    const bool is_loader = kh == 2;
+    const int nblk = gridDim.x;
+    int L = blockIdx.x;
+    if ((nblk & 7) == 0) L = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int tile_b = L % p.tiles_b; L /= p.tiles_b;
+    const int ks = L % p.splitk, tile_m = L / p.splitk;
+    const int m0 = tile_m * 128, b0 = tile_b * TB;
+    // K range of this work-group in superblocks.  Hand-off split (p.partial): [0, sb_split) -> ks=0, the rest -> ks=1.
+    const int nsb_all = p.K / 256;
+    const int nsb = p.partial ? (ks == 0 ? p.sb_split : nsb_all - p.sb_split) : nsb_all / p.splitk;
+    const int sb0 = p.partial ? (ks == 0 ? 0 : p.sb_split) : ks * nsb, nstage = nsb * 2;
+
+    DqConst dq; dq.init();
+    floatx16 acc[BNF];
+#pragma unroll
+    for (int i = 0; i < BNF; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+    uint32_t xvoff[XL], wvoff[2][WL];                                 // loader waves only (dead in the compute waves)
+#pragma unroll
+    for (int i = 0; i < XL; i++) {                                     // loader mg owns activation wave-pieces mg, mg + 4, ...
+        const int pc = (mg + 4 * i) * 64 + lane, row = pc >> 4, c = (pc & 15) ^ (row & 15);
+        xvoff[i] = (uint32_t)(min(b0 + row, p.B - 1) - b0) * 256u + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < WL; i++) {
+        int idx = mg + 4 * i;
+        if (idx >= NWI) idx -= 4;
+        const int pc = idx * 64 + lane, row = pc / WSt::NPH, c = pc % WSt::NPH;
+        const uint32_t ro = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
+        wvoff[0][i] = ro + WSt::src_piece(c, 0) * 16; wvoff[1][i] = ro + WSt::src_piece(c, 1) * 16;
+    }
+    const char *const xbase = (const char *)p.xh + ((int64_t)sb0 * 2 * p.B + b0) * 256;    // panel (2*sb0), row b0
+    const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
+
+    // LDS-DMA in the scalar-base form (SGPR pair + 32-bit lane offset, M0 = wave-uniform LDS address): no per-lane 64-bit
+    // address arithmetic (the flat form cost ~5 VALU per piece, ~20 % of this kernel's VALU instructions).
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto dma16 = [&](const char *sbase, uint32_t voff, uint32_t lds_addr) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+    };
+    auto issue_piece = [&](int i, int sbr, int part, int slot) __attribute__((always_inline)) {         // piece i of stage (sbr, part) -> ring slot
+        const uint32_t l = lds0 + slot * ST;
+        const int mg_s = wave_s & 3;
+        if (i < XL) { dma16(xbase + (int64_t)(sbr * 2 + part) * p.B * 256, xvoff[i], l + (mg_s + 4 * i) * 1024); return; }
+        int idx = mg_s + 4 * (i - XL);
+        if (idx >= NWI) idx -= 4;
+        dma16(wbase + (int64_t)sbr * BLK, wvoff[part][i - XL], l + XS + idx * 1024);
+    };
+    auto issue = [&](int sbr, int part, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) issue_piece(i, sbr, part, slot);
+    };
+
+    const int xrow_off = j * RS, xswz = j & 15;
+    auto estamp = [&](int) __attribute__((always_inline)) {};
+    // TRACE builds: shader clock (s_memtime) against the fixed 100 MHz reference (s_memrealtime) over the whole kernel of block 0
+    if (TRACE && blockIdx.x == 0 && tid == 0) { p.trace[8 * 16 * 8 + 1100] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1101] = __builtin_amdgcn_s_memrealtime(); }
+    // TRACE builds: [wave][stage 4..19][phase] s_memtime stamps of block 0: 0 T_a begin, 1 T_a done, 2 after the vmcnt/lgkm
+    // waits, 3 after the barrier, 4 next stage's LDS reads issued, 6 T_b done
+    auto stamp = [&](int s_, int ph) __attribute__((always_inline)) {
+        if (TRACE && blockIdx.x == 0 && s_ >= 4 && s_ < 20 && lane == 0) p.trace[(wave * 16 + (s_ - 4)) * 8 + ph] = __builtin_amdgcn_s_memtime();
+    };
+    // ---- cross-stage software pipeline -------------------------------------------------------------------------
+    // The barrier of a stage sits in the MIDDLE of its MFMA stream.  Per wave and stage s (ring slot s % 3):
+    //   T_a(s): MFMAs of k-steps 0,1 (fragments in registers since the previous stage) + VALU building fragments 1,2;
+    //           ds_reads of the activation fragments of k-steps 2,3 (the last LDS reads of slot s)
+    //   wait: stage s+1 landed (vmcnt), own LDS reads done (lgkmcnt)  ->  s_barrier  ->  slot s is free
+    //   T_b(s): MFMAs of k-steps 2,3 + VALU building fragment 3 + ALL of the next stage's S work (packed-weight and
+    //           k-step 0,1 activation reads from slot s+1, scale constants, fragment 0) + the DMA pieces of stage s+3 -> slot s
+    // so the LDS latency and the scale arithmetic of stage s+1 run under the MFMAs of stage s instead of in front of its own.
+    Raw<TYPE> raw_c, raw_n;
+    typename Raw<TYPE>::Sc z_c, z_n;
+    half8_t xa[4][BNF];
+    uint32_t cur[4] = {0, 0, 0, 0};
+    auto read_xa = [&](int slot, int kk) __attribute__((always_inline)) {
+        const uint8_t *xs = smem + slot * ST + xrow_off;
+        const int coff = ((kh * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++) xa[kk][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
+    };
+    auto mfma4 = [&](int kk, const uint32_t (&w)[4], auto &&between) __attribute__((always_inline)) {
+        const u32x4 cw = {w[0], w[1], w[2], w[3]};
+        const half8_t wfk = __builtin_bit_cast(half8_t, cw);
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++) {
+            __builtin_amdgcn_sched_barrier(0);
+            acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[kk][bf], wfk, acc[bf], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            between(bf);
+        }
+    };
+    // S work of a stage whose data sits in `slot`: used once in the prologue (nothing to hide it under yet)
+    auto S_first = [&](int slot) __attribute__((always_inline)) {
+        raw_c.load(smem + slot * ST + XS + (mg * 32 + j) * WRS, kh, h);
+        read_xa(slot, 0); read_xa(slot, 1);
+        if (kh == 0) z_c = raw_c.scales(0); else z_c = raw_c.scales(1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[i] = raw_c.pairbits(0, i, z_c, dq);
+    };
+    int slot = 0;
+    // LD: stage s+3 exists (its pieces are issued here);  W2: stage s+2 exists (its pieces are the only ones allowed to be
+    // outstanding at the barrier);  NX: stage s+1 exists (barrier + its S work);  PART: which half of the superblock stage s is
+    // The NL DMA pieces of a stage are issued in two halves so that neither half of the MFMA stream carries them all:
+    // pieces [0, NB) of stage s+3 in T_b(s), pieces [NB, NL) of stage s+2 in T_a(s) (both target a slot freed by the barrier
+    // before them; HA = T_a has pieces to issue: stage s+2 exists and was not part of the prologue's three stages).
+    constexpr int NB = (NL + 1) / 2;
+    auto stage = [&](auto LD, auto W2, auto NX, auto HA, auto PART, int sb) __attribute__((always_inline)) {
+        constexpr bool load = decltype(LD)::value, w2 = decltype(W2)::value, nx = decltype(NX)::value, ha = decltype(HA)::value;
+        constexpr int part = decltype(PART)::value;
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;
+        uint32_t f1[4], f2[4], f3[4];
+        const int s_ = sb * 2 + part;
+        stamp(s_, 0);
+        // ---- T_a: k-steps 0,1; builds fragments 1, 2 and half of 3; second half of stage s+2's pieces -> slot of stage s-1
+        read_xa(slot, 2);
+        mfma4(0, cur, [&](int bf) __attribute__((always_inline)) {
+            f1[bf] = raw_c.pairbits(1, bf, z_c, dq);
+            if (bf < 2) f3[bf] = raw_c.pairbits(3, bf, z_c, dq);
+        });
+        read_xa(slot, 3);
+        mfma4(1, f1, [&](int bf) __attribute__((always_inline)) {
+            f2[bf] = raw_c.pairbits(2, bf, z_c, dq);
+            if (bf >= 2) f3[bf] = raw_c.pairbits(3, bf, z_c, dq);
+        });
+        stamp(s_, 1);
+        if constexpr (nx) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's last reads of `slot` have returned
+            stamp(s_, 2);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stamp(s_, 3);
+        }
+        // ---- T_b: k-steps 2,3; the next stage's S work; first half of stage s+3's pieces -> slot of stage s
+        if constexpr (nx) {
+            __builtin_amdgcn_sched_barrier(0);
+            raw_n.load(smem + slot1 * ST + XS + (mg * 32 + j) * WRS, kh, h);
+            read_xa(slot1, 0); read_xa(slot1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(s_, 4);
+        }
+        uint32_t f0n[4] = {0, 0, 0, 0};
+        mfma4(2, f2, [&](int bf) __attribute__((always_inline)) {
+            if constexpr (nx) {
+                if (bf == 3) { if (kh == 0) z_n = raw_n.scales(((part + 1) & 1) * 2); else z_n = raw_n.scales(((part + 1) & 1) * 2 + 1); }
+            }
+        });
+        mfma4(3, f3, [&](int bf) __attribute__((always_inline)) {
+            if constexpr (nx) f0n[bf] = raw_n.pairbits(0, bf, z_n, dq);
+        });
+        if constexpr (nx) {
+            raw_c = raw_n; z_c = z_n;
+#pragma unroll
+            for (int i = 0; i < 4; i++) cur[i] = f0n[i];
+        }
+        stamp(s_, 6);
+        slot = slot1;
+    };
+    typedef std::integral_constant<bool, true> yes_t; typedef std::integral_constant<bool, false> no_t;
+    typedef std::integral_constant<int, 0> p0_t; typedef std::integral_constant<int, 1> p1_t;
+    // loader program: the same barrier sequence as the compute waves (one before the first S work, one in the middle of
+    // every stage that has a successor); after the barrier of stage s, slot s is free and takes stage s+3
+    auto lstage = [&](auto LD, auto W2, auto NX, auto PART, int sb) __attribute__((always_inline)) {
+        constexpr bool load = decltype(LD)::value, w2 = decltype(W2)::value, nx = decltype(NX)::value;
+        constexpr int part = decltype(PART)::value;
+        if constexpr (nx) {
+            if (w2) wait_vmcnt<NL>(); else wait_vmcnt<0>();             // stage s+1 has landed (only stage s+2's pieces may be in flight)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if constexpr (load) issue(sb + (part + 3) / 2, (part + 3) % 2, slot);
+        slot = slot == 2 ? 0 : slot + 1;
+    };
+    if (is_loader) {
+        issue(0, 0, 0);
+        issue(0, 1, 1);
+        if (nstage > 2) { issue(1, 0, 2); wait_vmcnt<2 * NL>(); } else wait_vmcnt<NL>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        lstage(yes_t{}, yes_t{}, yes_t{}, p0_t{}, 0); lstage(yes_t{}, yes_t{}, yes_t{}, p1_t{}, 0);
+        int sb = 1;
+        for (; sb + 2 < nsb; sb++) { lstage(yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); lstage(yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); }
+        lstage(yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); lstage(no_t{}, yes_t{}, yes_t{}, p1_t{}, sb); sb++;
+        lstage(no_t{}, no_t{}, yes_t{}, p0_t{}, sb); lstage(no_t{}, no_t{}, no_t{}, p1_t{}, sb);
+    } else {
+        __builtin_amdgcn_s_barrier();                                   // stage 0 has landed (the loaders waited for it)
+        asm volatile("" ::: "memory");
+        S_first(0);
+        stage(yes_t{}, yes_t{}, yes_t{}, no_t{}, p0_t{}, 0); stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, 0);
+        int sb = 1;
+        for (; sb + 2 < nsb; sb++) { stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); }
+        stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(no_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); sb++;
+        stage(no_t{}, no_t{}, yes_t{}, no_t{}, p0_t{}, sb); stage(no_t{}, no_t{}, no_t{}, no_t{}, p1_t{}, sb);
+    }
+
+    // ---- epilogue.  (1) The two K halves of the work-group are summed through LDS (the ring is dead now): khalf 1 parks
+    //      its accumulators, khalf 0 adds them IN REGISTERS.  (2) split-K = 2 hand-off, without atomics or a zero-fill
+    //      pass: the ks=1 work-group publishes those registers as they are (register layout, 16 write-through b128 stores
+    //      per lane, no transposition) and raises a per-launch-tagged flag; the ks=0 work-group of the same tile polls the
+    //      flag (one lane, relaxed), acquires, loads the 16 float4 back-to-back and adds them in registers.  Fixed
+    //      summation order: deterministic.  Both work-groups are co-resident by construction (the launcher only takes this
+    //      path when the grid fits the chip).  (3) The final tile goes through LDS in [b][m] order so that all 512 threads
+    //      store 512-byte output rows as float4s: 4x fewer store instructions than lane-per-m dword stores.
+    __syncthreads();
+    float4 *red = reinterpret_cast<float4 *>(smem) + (size_t)mg * 1024;   // [16 quads][64 lanes] float4 per m-group (64 KB total)
+    if (kh == 1) {
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++)
+                red[(bf * 4 + q4) * 64 + lane] = make_float4(acc[bf][4 * q4], acc[bf][4 * q4 + 1], acc[bf][4 * q4 + 2], acc[bf][4 * q4 + 3]);
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+                const float4 v = red[(bf * 4 + q4) * 64 + lane];
+                acc[bf][4 * q4] += v.x; acc[bf][4 * q4 + 1] += v.y; acc[bf][4 * q4 + 2] += v.z; acc[bf][4 * q4 + 3] += v.w;
+            }
+    }
+    estamp(2);
+    // (2) symmetric exchange: of the tile's 128 activation rows, work-group ks keeps rows [64 ks, 64 ks + 64) (accumulator
+    //     blocks bf = 2ks, 2ks+1) and exports the other 64 rows of its partial sums to its partner.
+    const int tile_id = tile_m * p.tiles_b + tile_b;
+    const bool handoff = p.partial != nullptr;
+    int row_lo = 0, nrows = 128;                                           // rows of the tile this work-group finishes
+    if (handoff) {
+        float *part_out = p.partial + ((size_t)tile_id * 2 + ks) * (64 * 128);
+        const float *part_in = p.partial + ((size_t)tile_id * 2 + (ks ^ 1)) * (64 * 128);
+        // Two transports for the exported half tile.  p.xchg_l2 (the launcher sets it when the tile order puts both
+        // work-groups of every pair on one XCD): plain stores — they are complete once this XCD's L2 has them, which is where
+        // the partner reads them with L1-bypassing (sc0) loads.  Otherwise write-through (sc1) stores past the L2 and an
+        // agent-scope acquire on the reader's side (publishing through an L2 write-back fence instead would flush every dirty
+        // line of the XCD, ~8 us measured).  The flag word carries the launch tag AND the writer's XCC id: a reader on the L2
+        // transport that finds its partner on another XCD poisons the tile with NaN instead of reading stale data.
+        const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;       // HW_REG_XCC_ID[3:0]
+        const unsigned tag = p.epoch << 4;
+        auto exchange = [&](auto KS) __attribute__((always_inline)) {
+            constexpr int own = decltype(KS)::value * 2, exp = 2 - own;   // first bf kept / exported
+            if (kh == 0) {
+                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, 64 * 128 * 4, 0x00020000);
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const float4 v = make_float4(acc[exp + e][4 * q4], acc[exp + e][4 * q4 + 1], acc[exp + e][4 * q4 + 2], acc[exp + e][4 * q4 + 3]);
+                        const int off = (((mg * 8 + e * 4 + q4) * 64) + lane) * 16;
+                        if (p.xchg_l2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 16);
+                    }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            estamp(5);
+            __syncthreads();                                                // every storing wave has drained its stores
+            if (tid == 0) {
+                __hip_atomic_store(p.flags + tile_id * 2 + ks, tag | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                estamp(7);
+                unsigned spins = 0, v;
+                while ((((v = __hip_atomic_load(p.flags + tile_id * 2 + (ks ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ^ tag) >> 4) != 0 && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
+                if (!p.xchg_l2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // partner never showed up (not co-resident), or it sits on another XCD while the L2 transport is on: fail LOUDLY
+                xchg_failed = spins >= (1u << 26) || (p.xchg_l2 && (v & 15u) != my_xcc);
+            }
+            __syncthreads();
+            estamp(4);
+            if (kh == 0) {
+                float4 o[8];
+                if (p.xchg_l2) {
+                    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(part_in), 0, 64 * 128 * 4, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) o[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, ((mg * 8 + i) * 64 + lane) * 16, 0, 1));
+                } else {
+                    const float4 *pp = reinterpret_cast<const float4 *>(part_in) + (size_t)mg * 512 + lane;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) o[i] = pp[i * 64];
+                }
+                if (xchg_failed) {                                          // NaN tile instead of a silently wrong sum
+#pragma unroll
+                    for (int i = 0; i < 8; i++) o[i].x = __builtin_nanf("");
+                }
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const float4 v = o[e * 4 + q4];
+                        acc[own + e][4 * q4] += v.x; acc[own + e][4 * q4 + 1] += v.y; acc[own + e][4 * q4 + 2] += v.z; acc[own + e][4 * q4 + 3] += v.w;
+                    }
+            }
+        };
+        if (ks == 0) exchange(std::integral_constant<int, 0>{}); else exchange(std::integral_constant<int, 1>{});
+        row_lo = ks * 64; nrows = 64;
+    }
+    // (3) [b][m] tile in LDS (rows row_lo .. row_lo + nrows), then wide stores
+    float *ctile = reinterpret_cast<float *>(smem + 64 * 1024);           // [128 b][128 m] fp32 = 64 KB, after the parked partials
+    constexpr int CLD = 128;
+    if (kh == 0) {
+#pragma unroll
+        for (int bf = 0; bf < BNF; bf++) {
+            if (bf * 32 < row_lo || bf * 32 >= row_lo + nrows) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int bl = bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;           // C/D layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                ctile[bl * CLD + mg * 32 + j] = acc[bf][r];
+            }
+        }
+    }
+    __syncthreads();
+    estamp(3);
+    if (tid < 512) {
+        const int c4 = tid & 31, r0 = tid >> 5;                             // 32 float4 per row, 16 rows per pass
+#pragma unroll
+        for (int pass = 0; pass < 8; pass++) {
+            if (pass * 16 >= nrows) break;
+            const int bl = row_lo + pass * 16 + r0, b = b0 + bl, m = m0 + c4 * 4;
+            const float4 v = *reinterpret_cast<const float4 *>(ctile + bl * CLD + c4 * 4);
+            if (b < p.B && m < p.M) {
+                float *dst = p.Y + (int64_t)b * p.y_row + m;
+                if (p.splitk > 1 && !handoff) {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+                    for (int t = 0; t < 4 && m + t < p.M; t++) unsafeAtomicAdd(dst + t, e[t]);
+                } else if (m + 3 < p.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<float4 *>(dst) = v;
+                else { const float e[4] = {v.x, v.y, v.z, v.w}; for (int t = 0; t < 4 && m + t < p.M; t++) dst[t] = e[t]; }
+            }
+        }
+    }
+    estamp(6);
+    if (TRACE && blockIdx.x == 0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[8 * 16 * 8 + 1102] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1103] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+
 // ------------------------------------------------------------------------------------------------------------
 // 256(m) x 128(b) work-group tile: the 8-wave in-wave-pipelined kernel with TWO weight fragments per activation
 // fragment.  Wave (mg, kh) owns rows [64 mg, 64 mg + 64) as two 32-row blocks mb = 0, 1, all 128 b, and the kh-th 64-k
@@ -1848,8 +2205,9 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     {   // the cross-stage pipeline is written for K ranges of >= 3 superblocks per work-group; shallower ones take schedule 20
         const int total = a.K / 256;
         const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
-        if (opt == 64 && min_nsb < 3) opt = 20;
+        if ((opt == 64 || opt == 65) && min_nsb < 3) opt = 20;
     }
+    if (opt == 65) { hipLaunchKernelGGL((k_gemm_kq_w12<TYPE>), grid, dim3(768), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }   // + loader waves
     if (opt == 64) {                                                      // cross-stage pipeline
         if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE, true>), grid, dim3(512), 0, st, p);
         else hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE, false>), grid, dim3(512), 0, st, p);
@@ -1902,10 +2260,11 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     // variant: bit0 = LDS weight staging (Q4_K/Q5_K only), bit1 = 128-wide activation tile, bit3 = the older
     // slice-per-barrier kernel instead of the pipelined one, bit4 = the 8-wave (two waves per SIMD) 128x128 kernel,
     // bits 5-9 = that kernel's schedule option OPT (see k_gemm_kq_w8; 20 = in-wave pipeline with the DMA pieces split over both phases),
-    // bit10 = the 256x128-tile kernel k_gemm_kq_x2, bit11 = the cross-stage pipelined k_gemm_kq_w8p (the default).
+    // bit10 = the 256x128-tile kernel k_gemm_kq_x2, bit11 = the cross-stage pipelined k_gemm_kq_w8p (the default),
+    // bit12 = k_gemm_kq_w12 = w8p + four loader waves (the default for Q4_K).
     // 0 = auto: widest tile that the batch fills.
     int variant = a.variant;
-    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? (16 | 2048) : 0);   // 8-wave kernel, cross-stage software pipeline (k_gemm_kq_w8p)
+    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? (16 | (TYPE == CDNA4_Q4_K ? 4096 : 2048)) : 0);   // cross-stage pipeline; Q4_K: + loader waves (k_gemm_kq_w12: 168 VGPRs without spills only for this format)
     const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
     const bool wide = (variant & 2) != 0;
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
@@ -1955,7 +2314,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         }
     }
     if constexpr (CAN_LDS) {
-        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant & 2048) ? 64 : ((variant >> 5) & 31), st);
+        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant & 4096) ? 65 : ((variant & 2048) ? 64 : ((variant >> 5) & 31)), st);
         if (wlds && !(variant & 8)) return wide ? launch_pipe<TYPE, 4>(a, splitk, st) : launch_pipe<TYPE, 2>(a, splitk, st);
         if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
     }
