@@ -42,7 +42,7 @@ def _newer(src_list, out):
 
 
 def _headers():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hs.append(os.path.join(ROOT, "include", "ggml_cdna4.h"))
     bdir = os.path.join(CSRC, "backend")
     hs += [os.path.join(bdir, f) for f in os.listdir(bdir) if f.endswith(".h")]

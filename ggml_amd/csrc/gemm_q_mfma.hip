@@ -970,139 +970,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
     if (!(OPT & 4) && kh == 1) mfma_block(false, 0, 0, 0);
 
     estamp(1);
-    // ---- epilogue.  (1) The two K halves of the work-group are summed through LDS (the ring is dead now): khalf 1 parks
-    //      its accumulators, khalf 0 adds them IN REGISTERS.  (2) split-K = 2 hand-off, without atomics or a zero-fill
-    //      pass: the ks=1 work-group publishes those registers as they are (register layout, 16 write-through b128 stores
-    //      per lane, no transposition) and raises a per-launch-tagged flag; the ks=0 work-group of the same tile polls the
-    //      flag (one lane, relaxed), acquires, loads the 16 float4 back-to-back and adds them in registers.  Fixed
-    //      summation order: deterministic.  Both work-groups are co-resident by construction (the launcher only takes this
-    //      path when the grid fits the chip).  (3) The final tile goes through LDS in [b][m] order so that all 512 threads
-    //      store 512-byte output rows as float4s: 4x fewer store instructions than lane-per-m dword stores.
-    __syncthreads();
-    float4 *red = reinterpret_cast<float4 *>(smem) + (size_t)mg * 1024;   // [16 quads][64 lanes] float4 per m-group (64 KB total)
-    if (kh == 1) {
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++)
-                red[(bf * 4 + q4) * 64 + lane] = make_float4(acc[bf][4 * q4], acc[bf][4 * q4 + 1], acc[bf][4 * q4 + 2], acc[bf][4 * q4 + 3]);
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {
-                const float4 v = red[(bf * 4 + q4) * 64 + lane];
-                acc[bf][4 * q4] += v.x; acc[bf][4 * q4 + 1] += v.y; acc[bf][4 * q4 + 2] += v.z; acc[bf][4 * q4 + 3] += v.w;
-            }
-    }
-    estamp(2);
-    // (2) symmetric exchange: of the tile's 128 activation rows, work-group ks keeps rows [64 ks, 64 ks + 64) (accumulator
-    //     blocks bf = 2ks, 2ks+1) and exports the other 64 rows of its partial sums to its partner.
-    const int tile_id = tile_m * p.tiles_b + tile_b;
-    const bool handoff = p.partial != nullptr;
-    int row_lo = 0, nrows = 128;                                           // rows of the tile this work-group finishes
-    if (handoff) {
-        float *part_out = p.partial + ((size_t)tile_id * 2 + ks) * (64 * 128);
-        const float *part_in = p.partial + ((size_t)tile_id * 2 + (ks ^ 1)) * (64 * 128);
-        // Two transports for the exported half tile.  p.xchg_l2 (the launcher sets it when the tile order puts both
-        // work-groups of every pair on one XCD): plain stores — they are complete once this XCD's L2 has them, which is where
-        // the partner reads them with L1-bypassing (sc0) loads.  Otherwise write-through (sc1) stores past the L2 and an
-        // agent-scope acquire on the reader's side (publishing through an L2 write-back fence instead would flush every dirty
-        // line of the XCD, ~8 us measured).  The flag word carries the launch tag AND the writer's XCC id: a reader on the L2
-        // transport that finds its partner on another XCD poisons the tile with NaN instead of reading stale data.
-        const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;       // HW_REG_XCC_ID[3:0]
-        const unsigned tag = p.epoch << 4;
-        auto exchange = [&](auto KS) __attribute__((always_inline)) {
-            constexpr int own = decltype(KS)::value * 2, exp = 2 - own;   // first bf kept / exported
-            if (kh == 0) {
-                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, 64 * 128 * 4, 0x00020000);
-#pragma unroll
-                for (int e = 0; e < 2; e++)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) {
-                        const float4 v = make_float4(acc[exp + e][4 * q4], acc[exp + e][4 * q4 + 1], acc[exp + e][4 * q4 + 2], acc[exp + e][4 * q4 + 3]);
-                        const int off = (((mg * 8 + e * 4 + q4) * 64) + lane) * 16;
-                        if (p.xchg_l2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 16);
-                    }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            estamp(5);
-            __syncthreads();                                                // every storing wave has drained its stores
-            if (tid == 0) {
-                __hip_atomic_store(p.flags + tile_id * 2 + ks, tag | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                estamp(7);
-                unsigned spins = 0, v;
-                while ((((v = __hip_atomic_load(p.flags + tile_id * 2 + (ks ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ^ tag) >> 4) != 0 && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
-                if (!p.xchg_l2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                // partner never showed up (not co-resident), or it sits on another XCD while the L2 transport is on: fail LOUDLY
-                xchg_failed = spins >= (1u << 26) || (p.xchg_l2 && (v & 15u) != my_xcc);
-            }
-            __syncthreads();
-            estamp(4);
-            if (kh == 0) {
-                float4 o[8];
-                if (p.xchg_l2) {
-                    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(part_in), 0, 64 * 128 * 4, 0x00020000);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) o[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, ((mg * 8 + i) * 64 + lane) * 16, 0, 1));
-                } else {
-                    const float4 *pp = reinterpret_cast<const float4 *>(part_in) + (size_t)mg * 512 + lane;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) o[i] = pp[i * 64];
-                }
-                if (xchg_failed) {                                          // NaN tile instead of a silently wrong sum
-#pragma unroll
-                    for (int i = 0; i < 8; i++) o[i].x = __builtin_nanf("");
-                }
-#pragma unroll
-                for (int e = 0; e < 2; e++)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) {
-                        const float4 v = o[e * 4 + q4];
-                        acc[own + e][4 * q4] += v.x; acc[own + e][4 * q4 + 1] += v.y; acc[own + e][4 * q4 + 2] += v.z; acc[own + e][4 * q4 + 3] += v.w;
-                    }
-            }
-        };
-        if (ks == 0) exchange(std::integral_constant<int, 0>{}); else exchange(std::integral_constant<int, 1>{});
-        row_lo = ks * 64; nrows = 64;
-    }
-    // (3) [b][m] tile in LDS (rows row_lo .. row_lo + nrows), then wide stores
-    float *ctile = reinterpret_cast<float *>(smem + 64 * 1024);           // [128 b][128 m] fp32 = 64 KB, after the parked partials
-    constexpr int CLD = 128;
-    if (kh == 0) {
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++) {
-            if (bf * 32 < row_lo || bf * 32 >= row_lo + nrows) continue;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int bl = bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;           // C/D layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-                ctile[bl * CLD + mg * 32 + j] = acc[bf][r];
-            }
-        }
-    }
-    __syncthreads();
-    estamp(3);
-    {
-        const int c4 = tid & 31, r0 = tid >> 5;                             // 32 float4 per row, 16 rows per pass
-#pragma unroll
-        for (int pass = 0; pass < 8; pass++) {
-            if (pass * 16 >= nrows) break;
-            const int bl = row_lo + pass * 16 + r0, b = b0 + bl, m = m0 + c4 * 4;
-            const float4 v = *reinterpret_cast<const float4 *>(ctile + bl * CLD + c4 * 4);
-            if (b < p.B && m < p.M) {
-                float *dst = p.Y + (int64_t)b * p.y_row + m;
-                if (p.splitk > 1 && !handoff) {
-                    const float e[4] = {v.x, v.y, v.z, v.w};
-                    for (int t = 0; t < 4 && m + t < p.M; t++) unsafeAtomicAdd(dst + t, e[t]);
-                } else if (m + 3 < p.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<float4 *>(dst) = v;
-                else { const float e[4] = {v.x, v.y, v.z, v.w}; for (int t = 0; t < 4 && m + t < p.M; t++) dst[t] = e[t]; }
-            }
-        }
-    }
-    estamp(6);
+#include "gemm_w8_epilogue.inc"
 }
 
 
@@ -1313,139 +1181,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
     stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(no_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); sb++;   // sb = nsb - 2
     stage(no_t{}, no_t{}, yes_t{}, no_t{}, p0_t{}, sb); stage(no_t{}, no_t{}, no_t{}, no_t{}, p1_t{}, sb);                  // sb = nsb - 1
 
-    // ---- epilogue.  (1) The two K halves of the work-group are summed through LDS (the ring is dead now): khalf 1 parks
-    //      its accumulators, khalf 0 adds them IN REGISTERS.  (2) split-K = 2 hand-off, without atomics or a zero-fill
-    //      pass: the ks=1 work-group publishes those registers as they are (register layout, 16 write-through b128 stores
-    //      per lane, no transposition) and raises a per-launch-tagged flag; the ks=0 work-group of the same tile polls the
-    //      flag (one lane, relaxed), acquires, loads the 16 float4 back-to-back and adds them in registers.  Fixed
-    //      summation order: deterministic.  Both work-groups are co-resident by construction (the launcher only takes this
-    //      path when the grid fits the chip).  (3) The final tile goes through LDS in [b][m] order so that all 512 threads
-    //      store 512-byte output rows as float4s: 4x fewer store instructions than lane-per-m dword stores.
-    __syncthreads();
-    float4 *red = reinterpret_cast<float4 *>(smem) + (size_t)mg * 1024;   // [16 quads][64 lanes] float4 per m-group (64 KB total)
-    if (kh == 1) {
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++)
-                red[(bf * 4 + q4) * 64 + lane] = make_float4(acc[bf][4 * q4], acc[bf][4 * q4 + 1], acc[bf][4 * q4 + 2], acc[bf][4 * q4 + 3]);
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {
-                const float4 v = red[(bf * 4 + q4) * 64 + lane];
-                acc[bf][4 * q4] += v.x; acc[bf][4 * q4 + 1] += v.y; acc[bf][4 * q4 + 2] += v.z; acc[bf][4 * q4 + 3] += v.w;
-            }
-    }
-    estamp(2);
-    // (2) symmetric exchange: of the tile's 128 activation rows, work-group ks keeps rows [64 ks, 64 ks + 64) (accumulator
-    //     blocks bf = 2ks, 2ks+1) and exports the other 64 rows of its partial sums to its partner.
-    const int tile_id = tile_m * p.tiles_b + tile_b;
-    const bool handoff = p.partial != nullptr;
-    int row_lo = 0, nrows = 128;                                           // rows of the tile this work-group finishes
-    if (handoff) {
-        float *part_out = p.partial + ((size_t)tile_id * 2 + ks) * (64 * 128);
-        const float *part_in = p.partial + ((size_t)tile_id * 2 + (ks ^ 1)) * (64 * 128);
-        // Two transports for the exported half tile.  p.xchg_l2 (the launcher sets it when the tile order puts both
-        // work-groups of every pair on one XCD): plain stores — they are complete once this XCD's L2 has them, which is where
-        // the partner reads them with L1-bypassing (sc0) loads.  Otherwise write-through (sc1) stores past the L2 and an
-        // agent-scope acquire on the reader's side (publishing through an L2 write-back fence instead would flush every dirty
-        // line of the XCD, ~8 us measured).  The flag word carries the launch tag AND the writer's XCC id: a reader on the L2
-        // transport that finds its partner on another XCD poisons the tile with NaN instead of reading stale data.
-        const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;       // HW_REG_XCC_ID[3:0]
-        const unsigned tag = p.epoch << 4;
-        auto exchange = [&](auto KS) __attribute__((always_inline)) {
-            constexpr int own = decltype(KS)::value * 2, exp = 2 - own;   // first bf kept / exported
-            if (kh == 0) {
-                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, 64 * 128 * 4, 0x00020000);
-#pragma unroll
-                for (int e = 0; e < 2; e++)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) {
-                        const float4 v = make_float4(acc[exp + e][4 * q4], acc[exp + e][4 * q4 + 1], acc[exp + e][4 * q4 + 2], acc[exp + e][4 * q4 + 3]);
-                        const int off = (((mg * 8 + e * 4 + q4) * 64) + lane) * 16;
-                        if (p.xchg_l2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 16);
-                    }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            estamp(5);
-            __syncthreads();                                                // every storing wave has drained its stores
-            if (tid == 0) {
-                __hip_atomic_store(p.flags + tile_id * 2 + ks, tag | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                estamp(7);
-                unsigned spins = 0, v;
-                while ((((v = __hip_atomic_load(p.flags + tile_id * 2 + (ks ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ^ tag) >> 4) != 0 && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
-                if (!p.xchg_l2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                // partner never showed up (not co-resident), or it sits on another XCD while the L2 transport is on: fail LOUDLY
-                xchg_failed = spins >= (1u << 26) || (p.xchg_l2 && (v & 15u) != my_xcc);
-            }
-            __syncthreads();
-            estamp(4);
-            if (kh == 0) {
-                float4 o[8];
-                if (p.xchg_l2) {
-                    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(part_in), 0, 64 * 128 * 4, 0x00020000);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) o[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, ((mg * 8 + i) * 64 + lane) * 16, 0, 1));
-                } else {
-                    const float4 *pp = reinterpret_cast<const float4 *>(part_in) + (size_t)mg * 512 + lane;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) o[i] = pp[i * 64];
-                }
-                if (xchg_failed) {                                          // NaN tile instead of a silently wrong sum
-#pragma unroll
-                    for (int i = 0; i < 8; i++) o[i].x = __builtin_nanf("");
-                }
-#pragma unroll
-                for (int e = 0; e < 2; e++)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) {
-                        const float4 v = o[e * 4 + q4];
-                        acc[own + e][4 * q4] += v.x; acc[own + e][4 * q4 + 1] += v.y; acc[own + e][4 * q4 + 2] += v.z; acc[own + e][4 * q4 + 3] += v.w;
-                    }
-            }
-        };
-        if (ks == 0) exchange(std::integral_constant<int, 0>{}); else exchange(std::integral_constant<int, 1>{});
-        row_lo = ks * 64; nrows = 64;
-    }
-    // (3) [b][m] tile in LDS (rows row_lo .. row_lo + nrows), then wide stores
-    float *ctile = reinterpret_cast<float *>(smem + 64 * 1024);           // [128 b][128 m] fp32 = 64 KB, after the parked partials
-    constexpr int CLD = 128;
-    if (kh == 0) {
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++) {
-            if (bf * 32 < row_lo || bf * 32 >= row_lo + nrows) continue;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int bl = bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;           // C/D layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-                ctile[bl * CLD + mg * 32 + j] = acc[bf][r];
-            }
-        }
-    }
-    __syncthreads();
-    estamp(3);
-    {
-        const int c4 = tid & 31, r0 = tid >> 5;                             // 32 float4 per row, 16 rows per pass
-#pragma unroll
-        for (int pass = 0; pass < 8; pass++) {
-            if (pass * 16 >= nrows) break;
-            const int bl = row_lo + pass * 16 + r0, b = b0 + bl, m = m0 + c4 * 4;
-            const float4 v = *reinterpret_cast<const float4 *>(ctile + bl * CLD + c4 * 4);
-            if (b < p.B && m < p.M) {
-                float *dst = p.Y + (int64_t)b * p.y_row + m;
-                if (p.splitk > 1 && !handoff) {
-                    const float e[4] = {v.x, v.y, v.z, v.w};
-                    for (int t = 0; t < 4 && m + t < p.M; t++) unsafeAtomicAdd(dst + t, e[t]);
-                } else if (m + 3 < p.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<float4 *>(dst) = v;
-                else { const float e[4] = {v.x, v.y, v.z, v.w}; for (int t = 0; t < 4 && m + t < p.M; t++) dst[t] = e[t]; }
-            }
-        }
-    }
-    estamp(6);
+#include "gemm_w8_epilogue.inc"
     if (TRACE && blockIdx.x == 0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[8 * 16 * 8 + 1102] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1103] = __builtin_amdgcn_s_memrealtime(); }
 }
 
@@ -1670,139 +1406,7 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
         stage(no_t{}, no_t{}, yes_t{}, no_t{}, p0_t{}, sb); stage(no_t{}, no_t{}, no_t{}, no_t{}, p1_t{}, sb);
     }
 
-    // ---- epilogue.  (1) The two K halves of the work-group are summed through LDS (the ring is dead now): khalf 1 parks
-    //      its accumulators, khalf 0 adds them IN REGISTERS.  (2) split-K = 2 hand-off, without atomics or a zero-fill
-    //      pass: the ks=1 work-group publishes those registers as they are (register layout, 16 write-through b128 stores
-    //      per lane, no transposition) and raises a per-launch-tagged flag; the ks=0 work-group of the same tile polls the
-    //      flag (one lane, relaxed), acquires, loads the 16 float4 back-to-back and adds them in registers.  Fixed
-    //      summation order: deterministic.  Both work-groups are co-resident by construction (the launcher only takes this
-    //      path when the grid fits the chip).  (3) The final tile goes through LDS in [b][m] order so that all 512 threads
-    //      store 512-byte output rows as float4s: 4x fewer store instructions than lane-per-m dword stores.
-    __syncthreads();
-    float4 *red = reinterpret_cast<float4 *>(smem) + (size_t)mg * 1024;   // [16 quads][64 lanes] float4 per m-group (64 KB total)
-    if (kh == 1) {
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++)
-                red[(bf * 4 + q4) * 64 + lane] = make_float4(acc[bf][4 * q4], acc[bf][4 * q4 + 1], acc[bf][4 * q4 + 2], acc[bf][4 * q4 + 3]);
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {
-                const float4 v = red[(bf * 4 + q4) * 64 + lane];
-                acc[bf][4 * q4] += v.x; acc[bf][4 * q4 + 1] += v.y; acc[bf][4 * q4 + 2] += v.z; acc[bf][4 * q4 + 3] += v.w;
-            }
-    }
-    estamp(2);
-    // (2) symmetric exchange: of the tile's 128 activation rows, work-group ks keeps rows [64 ks, 64 ks + 64) (accumulator
-    //     blocks bf = 2ks, 2ks+1) and exports the other 64 rows of its partial sums to its partner.
-    const int tile_id = tile_m * p.tiles_b + tile_b;
-    const bool handoff = p.partial != nullptr;
-    int row_lo = 0, nrows = 128;                                           // rows of the tile this work-group finishes
-    if (handoff) {
-        float *part_out = p.partial + ((size_t)tile_id * 2 + ks) * (64 * 128);
-        const float *part_in = p.partial + ((size_t)tile_id * 2 + (ks ^ 1)) * (64 * 128);
-        // Two transports for the exported half tile.  p.xchg_l2 (the launcher sets it when the tile order puts both
-        // work-groups of every pair on one XCD): plain stores — they are complete once this XCD's L2 has them, which is where
-        // the partner reads them with L1-bypassing (sc0) loads.  Otherwise write-through (sc1) stores past the L2 and an
-        // agent-scope acquire on the reader's side (publishing through an L2 write-back fence instead would flush every dirty
-        // line of the XCD, ~8 us measured).  The flag word carries the launch tag AND the writer's XCC id: a reader on the L2
-        // transport that finds its partner on another XCD poisons the tile with NaN instead of reading stale data.
-        const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u;       // HW_REG_XCC_ID[3:0]
-        const unsigned tag = p.epoch << 4;
-        auto exchange = [&](auto KS) __attribute__((always_inline)) {
-            constexpr int own = decltype(KS)::value * 2, exp = 2 - own;   // first bf kept / exported
-            if (kh == 0) {
-                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, 64 * 128 * 4, 0x00020000);
-#pragma unroll
-                for (int e = 0; e < 2; e++)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) {
-                        const float4 v = make_float4(acc[exp + e][4 * q4], acc[exp + e][4 * q4 + 1], acc[exp + e][4 * q4 + 2], acc[exp + e][4 * q4 + 3]);
-                        const int off = (((mg * 8 + e * 4 + q4) * 64) + lane) * 16;
-                        if (p.xchg_l2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 16);
-                    }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            estamp(5);
-            __syncthreads();                                                // every storing wave has drained its stores
-            if (tid == 0) {
-                __hip_atomic_store(p.flags + tile_id * 2 + ks, tag | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                estamp(7);
-                unsigned spins = 0, v;
-                while ((((v = __hip_atomic_load(p.flags + tile_id * 2 + (ks ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ^ tag) >> 4) != 0 && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
-                if (!p.xchg_l2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                // partner never showed up (not co-resident), or it sits on another XCD while the L2 transport is on: fail LOUDLY
-                xchg_failed = spins >= (1u << 26) || (p.xchg_l2 && (v & 15u) != my_xcc);
-            }
-            __syncthreads();
-            estamp(4);
-            if (kh == 0) {
-                float4 o[8];
-                if (p.xchg_l2) {
-                    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(part_in), 0, 64 * 128 * 4, 0x00020000);
-#pragma unroll
-                    for (int i = 0; i < 8; i++) o[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, ((mg * 8 + i) * 64 + lane) * 16, 0, 1));
-                } else {
-                    const float4 *pp = reinterpret_cast<const float4 *>(part_in) + (size_t)mg * 512 + lane;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) o[i] = pp[i * 64];
-                }
-                if (xchg_failed) {                                          // NaN tile instead of a silently wrong sum
-#pragma unroll
-                    for (int i = 0; i < 8; i++) o[i].x = __builtin_nanf("");
-                }
-#pragma unroll
-                for (int e = 0; e < 2; e++)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) {
-                        const float4 v = o[e * 4 + q4];
-                        acc[own + e][4 * q4] += v.x; acc[own + e][4 * q4 + 1] += v.y; acc[own + e][4 * q4 + 2] += v.z; acc[own + e][4 * q4 + 3] += v.w;
-                    }
-            }
-        };
-        if (ks == 0) exchange(std::integral_constant<int, 0>{}); else exchange(std::integral_constant<int, 1>{});
-        row_lo = ks * 64; nrows = 64;
-    }
-    // (3) [b][m] tile in LDS (rows row_lo .. row_lo + nrows), then wide stores
-    float *ctile = reinterpret_cast<float *>(smem + 64 * 1024);           // [128 b][128 m] fp32 = 64 KB, after the parked partials
-    constexpr int CLD = 128;
-    if (kh == 0) {
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++) {
-            if (bf * 32 < row_lo || bf * 32 >= row_lo + nrows) continue;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int bl = bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;           // C/D layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-                ctile[bl * CLD + mg * 32 + j] = acc[bf][r];
-            }
-        }
-    }
-    __syncthreads();
-    estamp(3);
-    if (tid < 512) {
-        const int c4 = tid & 31, r0 = tid >> 5;                             // 32 float4 per row, 16 rows per pass
-#pragma unroll
-        for (int pass = 0; pass < 8; pass++) {
-            if (pass * 16 >= nrows) break;
-            const int bl = row_lo + pass * 16 + r0, b = b0 + bl, m = m0 + c4 * 4;
-            const float4 v = *reinterpret_cast<const float4 *>(ctile + bl * CLD + c4 * 4);
-            if (b < p.B && m < p.M) {
-                float *dst = p.Y + (int64_t)b * p.y_row + m;
-                if (p.splitk > 1 && !handoff) {
-                    const float e[4] = {v.x, v.y, v.z, v.w};
-                    for (int t = 0; t < 4 && m + t < p.M; t++) unsafeAtomicAdd(dst + t, e[t]);
-                } else if (m + 3 < p.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<float4 *>(dst) = v;
-                else { const float e[4] = {v.x, v.y, v.z, v.w}; for (int t = 0; t < 4 && m + t < p.M; t++) dst[t] = e[t]; }
-            }
-        }
-    }
-    estamp(6);
+#include "gemm_w8_epilogue.inc"
     if (TRACE && blockIdx.x == 0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[8 * 16 * 8 + 1102] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1103] = __builtin_amdgcn_s_memrealtime(); }
 }
 
