@@ -27,6 +27,14 @@ template <> struct QT<CDNA4_Q6_K> { static constexpr int BYTES = 210, QK = 256; 
 //   Q8_0R 272 B: fp16 d[8] | 256 int8 in k order
 //   Q6_KR 224 B: fp16 d, 14 B pad | int8 scales[16] | ql[128] | qh[64]
 enum : int { CDNA4_Q4_0R = 102, CDNA4_Q8_0R = 108, CDNA4_Q6_KR = 114 };
+// "staged" forms: never in HBM — the loader waves of k_gemm_kq_w12 read the ORIGINAL 2-byte-aligned blocks and write these
+// 128-k stage rows straight into the LDS ring (re-layout while staging; no repack kernel, no scratch copy):
+//   Q4_0S 80 B: fp16 d[4], 8 B pad | 2 x 32 B nibbles in Q4_K order       Q8_0S 144 B: fp16 d[4], pad | 2 x 64 int8
+//   Q6_KS 144 B: fp16 d, pad | int8 scales[8], pad | ql[64] | qh[32] | pad   (one 128-weight half of a superblock)
+enum : int { CDNA4_Q4_0S = 202, CDNA4_Q8_0S = 208, CDNA4_Q6_KS = 214 };
+template <> struct QT<CDNA4_Q4_0S> { static constexpr int BYTES = 8 * 18, QK = 256; static constexpr bool KQ = true; };    // BYTES = source bytes per 256 weights
+template <> struct QT<CDNA4_Q8_0S> { static constexpr int BYTES = 8 * 34, QK = 256; static constexpr bool KQ = false; };
+template <> struct QT<CDNA4_Q6_KS> { static constexpr int BYTES = 210, QK = 256; static constexpr bool KQ = true; };
 template <> struct QT<CDNA4_Q4_0R> { static constexpr int BYTES = 144, QK = 256; static constexpr bool KQ = true; };
 template <> struct QT<CDNA4_Q8_0R> { static constexpr int BYTES = 272, QK = 256; static constexpr bool KQ = false; };
 template <> struct QT<CDNA4_Q6_KR> { static constexpr int BYTES = 224, QK = 256; static constexpr bool KQ = true; };

@@ -344,6 +344,122 @@ template <> struct Raw<CDNA4_Q6_KR> {
     }
 };
 
+// ---- "staged" forms: same fragment builders as the repacked ones, but the stage row in LDS only carries THIS stage's scales
+template <> struct Raw<CDNA4_Q4_0S> : Raw<CDNA4_Q4_0R> {
+    __device__ __forceinline__ Sc scales(int g) const {                // hdr.x / hdr.y = the two fp16 d of 64-k group 0 / 1 of the stage
+        const half2_t d2 = as_h2((g & 1) ? hdr.y : hdr.x), zero = {(half_t)0.f, (half_t)0.f};
+        Sc r; r.SL = half2_t{d2.x, d2.x}; r.SH = half2_t{d2.y, d2.y}; r.CL = zero; r.CH = zero;
+        return r;
+    }
+    __device__ __forceinline__ void frags(int g, int, half8_t (&f)[4], const DqConst &c) const {
+        const Sc z = scales(g);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) { const u32x4 w = {pairbits(kk, 0, z, c), pairbits(kk, 1, z, c), pairbits(kk, 2, z, c), pairbits(kk, 3, z, c)}; f[kk] = __builtin_bit_cast(half8_t, w); }
+    }
+};
+template <> struct Raw<CDNA4_Q8_0S> : Raw<CDNA4_Q8_0R> {
+    __device__ __forceinline__ Sc scales(int g) const {
+        const half2_t d2 = as_h2((g & 1) ? hdr.y : hdr.x);
+        const half_t d = hh ? d2.y : d2.x;
+        Sc r; r.S = half2_t{d, d};
+        return r;
+    }
+    __device__ __forceinline__ void frags(int g, int, half8_t (&f)[4], const DqConst &c) const {
+        const Sc z = scales(g);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) { const u32x4 w = {pairbits(kk, 0, z, c), pairbits(kk, 1, z, c), pairbits(kk, 2, z, c), pairbits(kk, 3, z, c)}; f[kk] = __builtin_bit_cast(half8_t, w); }
+    }
+};
+template <> struct Raw<CDNA4_Q6_KS> : Raw<CDNA4_Q6_KR> {
+    __device__ __forceinline__ Sc scales(int g) const {                // sc.x / sc.y: scale bytes 4p + h (+2) of this half's eight scales
+        const uint32_t dw = (g & 1) ? sc.y : sc.x;
+        const int s0 = (int)(int8_t)(dw >> (8 * hh)), s1 = (int)(int8_t)(dw >> (8 * hh + 16));
+        const float d = h2f(dd & 0xFFFF);
+        const int p = g & 1;
+        Sc r; r.S0 = splat(d * (float)s0); r.S1 = splat(d * (float)s1); r.ns = 4 * p; r.b0 = 2 * (2 * p); r.b1 = 2 * (2 * p + 1);
+        return r;
+    }
+    __device__ __forceinline__ void frags(int g, int, half8_t (&f)[4], const DqConst &c) const {
+        const Sc z = scales(g);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) { const u32x4 w = {pairbits(kk, 0, z, c), pairbits(kk, 1, z, c), pairbits(kk, 2, z, c), pairbits(kk, 3, z, c)}; f[kk] = __builtin_bit_cast(half8_t, w); }
+    }
+};
+
+// What one loader lane of k_gemm_kq_w12 does for a staged format: lane (row, gl) of a stage = the gl-th 64-k group of one
+// weight row.  load(): the group's ORIGINAL bytes into registers (2-byte-aligned dword loads); store(): re-laid into the
+// row's slot of the LDS stage.  `src` points at the row's bytes of this 128-k stage.
+template <int TYPE> struct WDirect { static constexpr bool value = false; struct Regs {}; };
+template <> struct WDirect<CDNA4_Q4_0S> {
+    static constexpr bool value = true;
+    static constexpr int STAGE_SRC = 4 * 18;
+    struct Regs { uint32_t w[9]; };
+    __device__ static __forceinline__ Regs load(const uint8_t *src, int gl) {
+        Regs r; const uint8_t *s = src + gl * 36;
+#pragma unroll
+        for (int i = 0; i < 9; i++) r.w[i] = ld_u32_a2(s + 4 * i);
+        return r;
+    }
+    __device__ static __forceinline__ void store(const Regs &r, uint8_t *row, int gl) {
+        // bytes: [dA:2][qsA:16][dB:2][qsB:16]; qsA dword i straddles w[i], w[i+1]; qsB dword i = w[5+i]
+        uint32_t a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[i] = (r.w[i] >> 16) | (r.w[i + 1] << 16); b[i] = r.w[5 + i]; }
+        const uint32_t dd = (r.w[0] & 0xFFFFu) | (r.w[4] & 0xFFFF0000u);                    // dA | dB << 16
+        *reinterpret_cast<uint32_t *>(row + 4 * gl) = dd;
+        u32x4 lo, hi;                                                                       // weights 0..15 / 16..31 of both blocks: low nibble = block A (k < 32), high = block B
+        lo.x = (a[0] & 0x0F0F0F0Fu) | ((b[0] & 0x0F0F0F0Fu) << 4); lo.y = (a[1] & 0x0F0F0F0Fu) | ((b[1] & 0x0F0F0F0Fu) << 4);
+        lo.z = (a[2] & 0x0F0F0F0Fu) | ((b[2] & 0x0F0F0F0Fu) << 4); lo.w = (a[3] & 0x0F0F0F0Fu) | ((b[3] & 0x0F0F0F0Fu) << 4);
+        hi.x = ((a[0] >> 4) & 0x0F0F0F0Fu) | (b[0] & 0xF0F0F0F0u); hi.y = ((a[1] >> 4) & 0x0F0F0F0Fu) | (b[1] & 0xF0F0F0F0u);
+        hi.z = ((a[2] >> 4) & 0x0F0F0F0Fu) | (b[2] & 0xF0F0F0F0u); hi.w = ((a[3] >> 4) & 0x0F0F0F0Fu) | (b[3] & 0xF0F0F0F0u);
+        *reinterpret_cast<u32x4 *>(row + 16 + 32 * gl) = lo; *reinterpret_cast<u32x4 *>(row + 32 + 32 * gl) = hi;
+    }
+};
+template <> struct WDirect<CDNA4_Q8_0S> {
+    static constexpr bool value = true;
+    static constexpr int STAGE_SRC = 4 * 34;
+    struct Regs { uint32_t w[17]; };
+    __device__ static __forceinline__ Regs load(const uint8_t *src, int gl) {
+        Regs r; const uint8_t *s = src + gl * 68;
+#pragma unroll
+        for (int i = 0; i < 17; i++) r.w[i] = ld_u32_a2(s + 4 * i);
+        return r;
+    }
+    __device__ static __forceinline__ void store(const Regs &r, uint8_t *row, int gl) {
+        // bytes: [dA:2][qA:32][dB:2][qB:32]; qA dword i straddles w[i], w[i+1]; qB dword i = w[9+i]
+        uint32_t a[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = (r.w[i] >> 16) | (r.w[i + 1] << 16);
+        *reinterpret_cast<uint32_t *>(row + 4 * gl) = (r.w[0] & 0xFFFFu) | (r.w[8] & 0xFFFF0000u);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(row + 16 + 64 * gl);
+        dst[0] = u32x4{a[0], a[1], a[2], a[3]}; dst[1] = u32x4{a[4], a[5], a[6], a[7]};
+        dst[2] = u32x4{r.w[9], r.w[10], r.w[11], r.w[12]}; dst[3] = u32x4{r.w[13], r.w[14], r.w[15], r.w[16]};
+    }
+};
+template <> struct WDirect<CDNA4_Q6_KS> {
+    static constexpr bool value = true;
+    static constexpr int STAGE_SRC = 0;                                // a stage is half n of a 210-byte superblock: offsets below
+    struct Regs { uint32_t ql[8], qh[4], x[2]; };
+    // src = the superblock; part = which 128-weight half; lane gl takes bytes [32 gl, 32 gl + 32) of ql, [16 gl, +16) of qh,
+    // and gl = 0: d, gl = 1: the half's eight scales
+    __device__ static __forceinline__ Regs load(const uint8_t *sbk, int part, int gl) {
+        Regs r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.ql[i] = ld_u32_a2(sbk + 64 * part + 32 * gl + 4 * i);
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.qh[i] = ld_u32_a2(sbk + 128 + 32 * part + 16 * gl + 4 * i);
+        if (gl == 0) { r.x[0] = ld_u16(sbk + 208); r.x[1] = 0; }
+        else { r.x[0] = ld_u32_a2(sbk + 192 + 8 * part); r.x[1] = ld_u32_a2(sbk + 196 + 8 * part); }
+        return r;
+    }
+    __device__ static __forceinline__ void store(const Regs &r, uint8_t *row, int gl) {
+        *reinterpret_cast<u32x2 *>(row + 16 * gl) = u32x2{r.x[0], r.x[1]};                    // [d, pad] at 0, [scales[8]] at 16
+        u32x4 *ql = reinterpret_cast<u32x4 *>(row + 32 + 32 * gl);
+        ql[0] = u32x4{r.ql[0], r.ql[1], r.ql[2], r.ql[3]}; ql[1] = u32x4{r.ql[4], r.ql[5], r.ql[6], r.ql[7]};
+        *reinterpret_cast<u32x4 *>(row + 96 + 16 * gl) = u32x4{r.qh[0], r.qh[1], r.qh[2], r.qh[3]};
+    }
+};
+
 // repack kernels: one thread per 16-byte OUTPUT piece (coalesced stores; the 2-byte-aligned source bytes of a superblock
 // are read by the 9 / 17 / 14 adjacent threads that build it)
 __device__ __forceinline__ u32x4 ld16_a2(const uint8_t *p) { return u32x4{ld_u32_a2(p), ld_u32_a2(p + 4), ld_u32_a2(p + 8), ld_u32_a2(p + 12)}; }
@@ -555,6 +671,10 @@ template <> struct WStage<CDNA4_Q6_KR, 2> {                            // [d][sc
     static constexpr int NPH = 9;
     __device__ static __forceinline__ int src_piece(int p, int part) { return p < 2 ? p : (p < 6 ? 2 + 4 * part + (p - 2) : (p < 8 ? 10 + 2 * part + (p - 6) : 0)); }
 };
+// staged forms: the LDS stage row has the repacked forms' size; the loader lanes write it, nothing is DMA'd for the weights
+template <> struct WStage<CDNA4_Q4_0S, 2> { static constexpr int NPH = 5; __device__ static __forceinline__ int src_piece(int, int) { return 0; } };
+template <> struct WStage<CDNA4_Q8_0S, 2> { static constexpr int NPH = 9; __device__ static __forceinline__ int src_piece(int, int) { return 0; } };
+template <> struct WStage<CDNA4_Q6_KS, 2> { static constexpr int NPH = 9; __device__ static __forceinline__ int src_piece(int, int) { return 0; } };
 
 template <int TYPE, int BNF, int SKG>
 __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
@@ -1193,6 +1313,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
 template <int TYPE>
 __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     constexpr bool TRACE = false;
+    constexpr bool DIRECT = WDirect<TYPE>::value;   // weights re-laid by the loader lanes from the original blocks (no LDS-DMA for W)
     typedef WStage<TYPE, 2> WSt;
     constexpr int BNF = 4, TB = 128, NST = 3;
     constexpr int RS = 256, XS = TB * RS;
@@ -1200,7 +1321,7 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     constexpr int WRS = WSt::NPH * 16, WS = 128 * WRS, ST = XS + WS;
     constexpr int NWI = 128 * WSt::NPH / 64;     // weight wave-pieces per stage: 10 (Q4_K) / 14 (Q5_K)
     constexpr int XL = XS / 16 / 64 / 4;         // activation wave-pieces per loader wave per stage: 8
-    constexpr int WL = (NWI + 3) / 4;            // weight wave-pieces per loader wave (the tail re-loads earlier pieces)
+    constexpr int WL = DIRECT ? 0 : (NWI + 3) / 4;   // weight wave-pieces per loader wave (the tail re-loads earlier pieces)
     constexpr int NL = XL + WL;                  // 11 (Q4_K)
     constexpr int SMEM = NST * ST > 128 * 1024 ? NST * ST : 128 * 1024;      // the epilogue needs 2 x 64 KB
     static_assert(SMEM <= 160 * 1024, "LDS budget");
@@ -1228,7 +1349,7 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
 
-    uint32_t xvoff[XL], wvoff[2][WL];                                 // loader waves only (dead in the compute waves)
+    uint32_t xvoff[XL], wvoff[2][WL > 0 ? WL : 1];                    // loader waves only (dead in the compute waves)
 #pragma unroll
     for (int i = 0; i < XL; i++) {                                     // loader mg owns activation wave-pieces mg, mg + 4, ...
         const int pc = (mg + 4 * i) * 64 + lane, row = pc >> 4, c = (pc & 15) ^ (row & 15);
@@ -1384,7 +1505,43 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
         if constexpr (load) issue(sb + (part + 3) / 2, (part + 3) % 2, slot);
         slot = slot == 2 ? 0 : slot + 1;
     };
-    if (is_loader) {
+    if (is_loader && DIRECT) {
+        // Staged formats: lane (row, gl) of the four loader waves owns the gl-th 64-k group of one weight row.  Its original
+        // bytes for stage s+4 are in flight (registers) while those of stage s+3 are re-laid into the slot the barrier just freed.
+        if constexpr (DIRECT) {
+            typedef WDirect<TYPE> WD;
+            const int lid = (mg << 6) | lane, lrow = lid >> 1, gl = lid & 1;
+            const uint8_t *const wrow0 = p.W + (int64_t)min(m0 + lrow, p.M - 1) * p.w_row_bytes + (int64_t)sb0 * BLK;
+            auto wload = [&](int st) __attribute__((always_inline)) {   // stage st = (superblock st / 2, half st % 2)
+                if constexpr (TYPE == CDNA4_Q6_KS) return WD::load(wrow0 + (int64_t)(st >> 1) * BLK, st & 1, gl);
+                else return WD::load(wrow0 + (int64_t)(st >> 1) * BLK + (st & 1) * WD::STAGE_SRC, gl);
+            };
+            auto wstore = [&](const typename WD::Regs &r, int slot_) __attribute__((always_inline)) { WD::store(r, smem + slot_ * ST + XS + lrow * WRS, gl); };
+            typename WD::Regs r0 = wload(0), r1 = wload(1), rn = wload(nstage > 2 ? 2 : 1);
+            issue(0, 0, 0); issue(0, 1, 1);
+            if (nstage > 2) issue(1, 0, 2);
+            wstore(r0, 0); wstore(r1, 1);
+            if (nstage > 2) wstore(rn, 2);
+            if (nstage > 3) rn = wload(3);
+            // (wstore() consumed r0 / r1 / rn: the compiler placed the vmcnt waits for those loads; the X pieces are waited here)
+            // every activation piece is older than rn's (>= 3) load instructions: at most those may still be in flight
+            if (nstage > 3) wait_vmcnt<3>(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            for (int st = 0; st + 1 < nstage; st++) {                   // the barrier in the middle of stage st frees slot st % 3
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (st + 3 < nstage) {
+                    wstore(rn, slot);                                   // stage st+3's weights (waits for their loads: everything older has landed too)
+                    issue((st + 3) >> 1, (st + 3) & 1, slot);
+                    if (st + 4 < nstage) rn = wload(st + 4);
+                } else wait_vmcnt<0>();                                 // the tail: the last activation pieces must land before the next barrier
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+        }
+    } else if (is_loader) {
         issue(0, 0, 0);
         issue(0, 1, 1);
         if (nstage > 2) { issue(1, 0, 2); wait_vmcnt<2 * NL>(); } else wait_vmcnt<NL>();
@@ -1812,12 +1969,13 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         if ((opt == 64 || opt == 65) && min_nsb < 3) opt = 20;
     }
     if (opt == 65) { hipLaunchKernelGGL((k_gemm_kq_w12<TYPE>), grid, dim3(768), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }   // + loader waves
+    if constexpr (TYPE >= 200) return cdna4_set_error_msg("gemm_q: staged formats run on the loader-wave kernel only");
     if (opt == 64) {                                                      // cross-stage pipeline
         if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE, true>), grid, dim3(512), 0, st, p);
         else hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE, false>), grid, dim3(512), 0, st, p);
         CDNA4_CHECK_LAUNCH(); return 0;
     }
-    if constexpr (TYPE >= 100) { W8_LAUNCH(20); CDNA4_CHECK_LAUNCH(); return 0; }   // repacked formats: the default schedule only
+    else if constexpr (TYPE >= 100) { W8_LAUNCH(20); CDNA4_CHECK_LAUNCH(); return 0; }   // repacked formats: the default schedule only
     else switch (opt & 31) { case 0: W8_LAUNCH(0); break; case 1: W8_LAUNCH(1); break; case 2: W8_LAUNCH(2); break; case 3: W8_LAUNCH(3); break;
                         case 4: W8_LAUNCH(4); break; case 12: W8_LAUNCH(12); break; case 28: W8_LAUNCH(28); break; case 20: W8_LAUNCH(20); break; default: return cdna4_set_error_msg("gemm_q: unknown 8-wave schedule option"); }
 #undef W8_LAUNCH
@@ -1899,6 +2057,16 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         // than the per-lane-load kernel below, which stays for small batches and K % 256 != 0.
         constexpr int RT = TYPE == CDNA4_Q4_0 ? CDNA4_Q4_0R : (TYPE == CDNA4_Q8_0 ? CDNA4_Q8_0R : CDNA4_Q6_KR);
         static const bool no_repack = getenv("CDNA4_NO_REPACK") != nullptr;
+        static const bool no_staged = getenv("CDNA4_NO_STAGED") != nullptr;
+        if (a.variant <= 0 && a.B > 64 && a.K % 256 == 0 && !no_repack && !no_staged) {
+            // preferred: no copy at all — the loader waves of k_gemm_kq_w12 read the original blocks and re-lay them while
+            // staging (needs >= 3 superblocks of K per work-group, like the cross-stage pipeline itself)
+            constexpr int ST_ = TYPE == CDNA4_Q4_0 ? CDNA4_Q4_0S : (TYPE == CDNA4_Q8_0 ? CDNA4_Q8_0S : CDNA4_Q6_KS);
+            const int nsb = a.K / 256, tiles = ((a.M + 127) / 128) * ((a.B + 127) / 128);
+            int sk = a.splitk;
+            if (sk <= 0) sk = (tiles * 2 <= cu_count() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
+            if (sk >= 1 && nsb % sk == 0 && nsb / sk >= 3) return launch_w8<ST_>(a, sk, 65, st);
+        }
         if (a.variant <= 0 && a.B > 64 && a.K % 256 == 0 && !no_repack) {
             const int nsb = a.K / 256;
             const size_t rbytes = (size_t)a.M * nsb * QT<RT>::BYTES;

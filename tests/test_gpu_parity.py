@@ -186,11 +186,12 @@ def test_gemm_variants(gu, name, t, variant, splitk):
 
 
 @pytest.mark.parametrize("name,t", [(n, t) for n, t in WT if n in ("q4_0", "q8_0", "q6_K")])
-@pytest.mark.parametrize("m,k,b", [(260, 1024, 150), (129, 768, 65), (4096, 4096, 512)])
+@pytest.mark.parametrize("m,k,b", [(260, 1024, 150), (129, 768, 65), (300, 2048, 200), (4096, 4096, 512)])
 def test_repacked_formats_match_per_lane_kernel(gu, name, t, m, k, b):
-    """Q4_0 / Q8_0 / Q6_K at prefill batch sizes are re-laid into 16-byte-aligned superblocks and run on the LDS-DMA
-    pipeline; explicit variant 6 forces the older per-lane-load kernel on the original bytes.  Same arithmetic per
-    weight (fp16 d*(q-off)), different fp32 summation order only."""
+    """Q4_0 / Q8_0 / Q6_K at prefill batch sizes run on the LDS pipeline: with >= 3 superblocks of K per work-group the
+    loader waves of k_gemm_kq_w12 re-lay the original blocks while staging them (shapes 2-4 here), shallower K goes through
+    the per-call re-layout into scratch (shape 1); explicit variant 6 forces the older per-lane-load kernel on the original
+    bytes.  Same arithmetic per weight (fp16 d*(q-off)), different fp32 summation order only."""
     from ggml_amd import ops
     w = R.random_weights(t, m, k, seed=5 * m + k)
     x = _x(m + b, b, k, "normal" if m < 1000 else "uniform")
