@@ -1191,8 +1191,8 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
     //   T_b(s): MFMAs of k-steps 2,3 + VALU building fragment 3 + ALL of the next stage's S work (packed-weight and
     //           k-step 0,1 activation reads from slot s+1, scale constants, fragment 0) + the DMA pieces of stage s+3 -> slot s
     // so the LDS latency and the scale arithmetic of stage s+1 run under the MFMAs of stage s instead of in front of its own.
-    Raw<TYPE> raw_c, raw_n;
-    typename Raw<TYPE>::Sc z_c, z_n;
+    Raw<TYPE> raw_c;                                                   // (after T_a the stage's packed weights and scales are dead:
+    typename Raw<TYPE>::Sc z_c;                                        //  T_b loads the next stage's straight into the same registers)
     half8_t xa[4][BNF];
     uint32_t cur[4] = {0, 0, 0, 0};
     auto read_xa = [&](int slot, int kk) __attribute__((always_inline)) {
@@ -1258,26 +1258,20 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
         // ---- T_b: k-steps 2,3; the next stage's S work; first half of stage s+3's pieces -> slot of stage s
         if constexpr (nx) {
             __builtin_amdgcn_sched_barrier(0);
-            raw_n.load(smem + slot1 * ST + XS + (mg * 32 + j) * WRS, kh, h);
+            raw_c.load(smem + slot1 * ST + XS + (mg * 32 + j) * WRS, kh, h);
             read_xa(slot1, 0); read_xa(slot1, 1);
             __builtin_amdgcn_sched_barrier(0);
             stamp(s_, 4);
         }
-        uint32_t f0n[4] = {0, 0, 0, 0};
         mfma4(2, f2, [&](int bf) __attribute__((always_inline)) {
             if constexpr (load) { if (bf < NB) issue_piece(bf, sb + (part + 3) / 2, (part + 3) % 2, slot); }
             if constexpr (nx) {
-                if (bf == 3) { if (kh == 0) z_n = raw_n.scales(((part + 1) & 1) * 2); else z_n = raw_n.scales(((part + 1) & 1) * 2 + 1); }
+                if (bf == 3) { if (kh == 0) z_c = raw_c.scales(((part + 1) & 1) * 2); else z_c = raw_c.scales(((part + 1) & 1) * 2 + 1); }
             }
         });
         mfma4(3, f3, [&](int bf) __attribute__((always_inline)) {
-            if constexpr (nx) f0n[bf] = raw_n.pairbits(0, bf, z_n, dq);
+            if constexpr (nx) cur[bf] = raw_c.pairbits(0, bf, z_c, dq);
         });
-        if constexpr (nx) {
-            raw_c = raw_n; z_c = z_n;
-#pragma unroll
-            for (int i = 0; i < 4; i++) cur[i] = f0n[i];
-        }
         stamp(s_, 6);
         slot = slot1;
     };
@@ -1403,8 +1397,8 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     //   T_b(s): MFMAs of k-steps 2,3 + VALU building fragment 3 + ALL of the next stage's S work (packed-weight and
     //           k-step 0,1 activation reads from slot s+1, scale constants, fragment 0) + the DMA pieces of stage s+3 -> slot s
     // so the LDS latency and the scale arithmetic of stage s+1 run under the MFMAs of stage s instead of in front of its own.
-    Raw<TYPE> raw_c, raw_n;
-    typename Raw<TYPE>::Sc z_c, z_n;
+    Raw<TYPE> raw_c;                                                   // (after T_a the stage's packed weights and scales are dead:
+    typename Raw<TYPE>::Sc z_c;                                        //  T_b loads the next stage's straight into the same registers)
     half8_t xa[4][BNF];
     uint32_t cur[4] = {0, 0, 0, 0};
     auto read_xa = [&](int slot, int kk) __attribute__((always_inline)) {
@@ -1468,25 +1462,19 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
         // ---- T_b: k-steps 2,3; the next stage's S work; first half of stage s+3's pieces -> slot of stage s
         if constexpr (nx) {
             __builtin_amdgcn_sched_barrier(0);
-            raw_n.load(smem + slot1 * ST + XS + (mg * 32 + j) * WRS, kh, h);
+            raw_c.load(smem + slot1 * ST + XS + (mg * 32 + j) * WRS, kh, h);
             read_xa(slot1, 0); read_xa(slot1, 1);
             __builtin_amdgcn_sched_barrier(0);
             stamp(s_, 4);
         }
-        uint32_t f0n[4] = {0, 0, 0, 0};
         mfma4(2, f2, [&](int bf) __attribute__((always_inline)) {
             if constexpr (nx) {
-                if (bf == 3) { if (kh == 0) z_n = raw_n.scales(((part + 1) & 1) * 2); else z_n = raw_n.scales(((part + 1) & 1) * 2 + 1); }
+                if (bf == 3) { if (kh == 0) z_c = raw_c.scales(((part + 1) & 1) * 2); else z_c = raw_c.scales(((part + 1) & 1) * 2 + 1); }
             }
         });
         mfma4(3, f3, [&](int bf) __attribute__((always_inline)) {
-            if constexpr (nx) f0n[bf] = raw_n.pairbits(0, bf, z_n, dq);
+            if constexpr (nx) cur[bf] = raw_c.pairbits(0, bf, z_c, dq);
         });
-        if constexpr (nx) {
-            raw_c = raw_n; z_c = z_n;
-#pragma unroll
-            for (int i = 0; i < 4; i++) cur[i] = f0n[i];
-        }
         stamp(s_, 6);
         slot = slot1;
     };
@@ -2026,6 +2014,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     // bit12 = k_gemm_kq_w12 = w8p + four loader waves (the default for Q4_K).
     // 0 = auto: widest tile that the batch fills.
     int variant = a.variant;
+    // (Q5_K on the loader-wave kernel: 31.0 vs 30.65 us — its larger Raw<> spills 32 B at 168 VGPRs — so it stays on k_gemm_kq_w8p)
     if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? (16 | (TYPE == CDNA4_Q4_K ? 4096 : 2048)) : 0);   // cross-stage pipeline; Q4_K: + loader waves (k_gemm_kq_w12: 168 VGPRs without spills only for this format)
     const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
     const bool wide = (variant & 2) != 0;
