@@ -130,6 +130,14 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
     if (dst_tok_stride != n_used * dst_row_stride) return cdna4_set_error_msg("mul_mat_id: dst must be contiguous over (slot, token)");
     if (b_tok_stride != n_b * b_row_stride) return cdna4_set_error_msg("mul_mat_id: b must be contiguous over (row, token)");
     const int64_t nact = n_tok * n_b;
+    if (n_tok == 1 && n_used <= 65535 && cdna4_gemv_fused_supported(type, K, 1) && !(((uintptr_t)b | (uintptr_t)(b_row_stride * 4)) & 15)) {
+        // single-token decode of a mixture-of-experts layer: one launch, the activation quantizer runs inside the GEMV
+        cdna4_gemv_args g{};
+        g.type = type; g.W = (const uint8_t *)as; g.w_row_bytes = w_row_bytes; g.Y = dst; g.y_col_stride = dst_row_stride;
+        g.M = (int)M; g.K = (int)K; g.ncol = (int)n_used;
+        g.ids = ids; g.ids_tok_stride = ids_tok_stride; g.w_expert_bytes = w_expert_bytes; g.n_used = (int)n_used; g.n_b = (int)n_b; g.n_expert = (int)n_expert;
+        return cdna4_launch_gemv_q_fused_ids(g, b, b_row_stride, (hipStream_t)stream);
+    }
     if (!workspace || ((uintptr_t)workspace & 255)) return cdna4_set_error_msg("mul_mat_id: workspace must be 256-byte aligned");
     const ws_view v = carve(type, K, nact, workspace);
     if (workspace_bytes < v.total) return cdna4_set_error_msg("mul_mat_id: workspace too small");

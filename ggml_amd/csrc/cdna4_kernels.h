@@ -25,6 +25,8 @@ int cdna4_launch_gemv_q(const cdna4_gemv_args &a, hipStream_t st);
 // single-column decode with the activation quantizer fused in (x = fp32 row; a.qs/d/bsums unused)
 bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B);
 int cdna4_launch_gemv_q_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st);
+// single-token MUL_MAT_ID in one launch (a.ids set, a.ncol = n_used slots; x rows x_row_stride apart, slot u reads row u % a.n_b)
+int cdna4_launch_gemv_q_fused_ids(const cdna4_gemv_args &a, const float *x, int64_t x_row_stride, hipStream_t st);
 
 // gemm_q_mfma.hip — fp16 MFMA prefill path.  xh = pair-interleaved fp16 activations [B][K].
 struct cdna4_gemm_args {

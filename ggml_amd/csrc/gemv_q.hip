@@ -287,10 +287,17 @@ struct lds_act { const int8_t *qs; const float *d; const int16_t *bsums; int K; 
 
 // NW waves per work-group, ROWS weight rows per wave.  The quantizer's cost is per WORK-GROUP (every work-group redoes the
 // whole row), so fewer, fatter work-groups pay it less often: <4,1> = 1024 work-groups at M=4096, <8,2> = 256 (one per CU).
-template <int TYPE, int NW, int ROWS>
-__global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(const cdna4_gemv_args a, const float *__restrict__ x) {
+// IDS: single-token MUL_MAT_ID (mixture-of-experts decode): blockIdx.y = slot u, expert = ids[u] read on the device, the
+// slot's activation row x + (u % n_b) * x_row_stride, output column u.
+template <int TYPE, int NW, int ROWS, bool IDS = false>
+__global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, const float *__restrict__ x, int64_t x_row_stride) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr bool KQ = QT<TYPE>::KQ;
+    if (IDS) {
+        const int u = blockIdx.y, e = a.ids[u];
+        if (e < 0 || e >= a.n_expert) return;                              // whole work-group
+        a.W += (int64_t)e * a.w_expert_bytes; x += (int64_t)(u % a.n_b) * x_row_stride; a.Y += (int64_t)u * a.y_col_stride;
+    }
     const int K = a.K, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int8_t *sq = reinterpret_cast<int8_t *>(smem);
     int16_t *sbs = reinterpret_cast<int16_t *>(smem + K);                   // K/8 bytes (Q8_K only)
@@ -383,10 +390,10 @@ static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st
     // 6.32/5.52, 5.93/5.39, 6.35/5.49, 5.57/5.79 -> 8 waves x 1 row when the matrix is tall enough to still fill the chip.
     static const int cfg_env = getenv("CDNA4_FUSED_CFG") ? atoi(getenv("CDNA4_FUSED_CFG")) : -1;
     const int cfg = cfg_env >= 0 ? cfg_env : (a.M >= 2048 ? 3 : 0);
-    if (cfg == 1) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x);
-    else if (cfg == 2) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 2>), dim3((a.M + 7) / 8), dim3(256), lds, st, a, x);
-    else if (cfg == 3) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 1>), dim3((a.M + 7) / 8), dim3(512), lds, st, a, x);
-    else hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 1>), dim3((a.M + 3) / 4), dim3(256), lds, st, a, x);
+    if (cfg == 1) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x, (int64_t)0);
+    else if (cfg == 2) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 2>), dim3((a.M + 7) / 8), dim3(256), lds, st, a, x, (int64_t)0);
+    else if (cfg == 3) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 1>), dim3((a.M + 7) / 8), dim3(512), lds, st, a, x, (int64_t)0);
+    else hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 1>), dim3((a.M + 3) / 4), dim3(256), lds, st, a, x, (int64_t)0);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
@@ -425,6 +432,33 @@ int cdna4_launch_gemv_q_fused(const cdna4_gemv_args &a, const float *x, hipStrea
             return launch_fused<CDNA4_Q6_K>(a, x, st);
         case CDNA4_Q4_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_Q4_0>(a, x, st);
         case CDNA4_Q8_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_Q8_0>(a, x, st);
+    }
+    return cdna4_set_error_msg("gemv_q: unsupported weight type");
+}
+
+// single-token MUL_MAT_ID: one launch, a.ncol = n_used slots, a.ids / w_expert_bytes / n_expert / n_b as for cdna4_launch_gemv_q
+template <int TYPE>
+static int launch_fused_ids(const cdna4_gemv_args &a, const float *x, int64_t x_row_stride, hipStream_t st) {
+    const size_t lds = cdna4_gemv_fused_lds_bytes(TYPE, a.K);
+    hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 1, true>), dim3((a.M + 7) / 8, a.ncol), dim3(512), lds, st, a, x, x_row_stride);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+int cdna4_launch_gemv_q_fused_ids(const cdna4_gemv_args &a, const float *x, int64_t x_row_stride, hipStream_t st) {
+    if (a.M <= 0 || a.ncol <= 0) return 0;
+    if (!a.ids || !cdna4_gemv_fused_supported(a.type, a.K, 1) || a.ncol > 65535) return cdna4_set_error_msg("gemv_q_fused_ids: unsupported shape");
+    if (((uintptr_t)x | (uintptr_t)(x_row_stride * 4)) & 15) return cdna4_set_error_msg("gemv_q_fused_ids: x rows must be 16-byte aligned");
+    if (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes | (uintptr_t)a.w_expert_bytes) & 1) return cdna4_set_error_msg("gemv_q: misaligned operands");
+    switch (a.type) {
+        case CDNA4_Q4_K: case CDNA4_Q5_K:
+            if (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes | (uintptr_t)a.w_expert_bytes) & 15) return cdna4_set_error_msg("gemv_q: Q4_K/Q5_K rows must be 16-byte aligned");
+            if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256");
+            return a.type == CDNA4_Q4_K ? launch_fused_ids<CDNA4_Q4_K>(a, x, x_row_stride, st) : launch_fused_ids<CDNA4_Q5_K>(a, x, x_row_stride, st);
+        case CDNA4_Q6_K:
+            if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256");
+            return launch_fused_ids<CDNA4_Q6_K>(a, x, x_row_stride, st);
+        case CDNA4_Q4_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_ids<CDNA4_Q4_0>(a, x, x_row_stride, st);
+        case CDNA4_Q8_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_ids<CDNA4_Q8_0>(a, x, x_row_stride, st);
     }
     return cdna4_set_error_msg("gemv_q: unsupported weight type");
 }

@@ -319,3 +319,23 @@ def test_mul_mat_id_parity(gu, name, t, n_expert, n_used, n_b_is_one, n_tok):
     yo = R.o_mul_mat_id(t, w, xb, ids, m, k, n_expert)
     e = R.rel_l2(y, yo); gu.report(test="mul_mat_id", type=name, rel_l2=e)
     assert e < TOL_GEMV
+
+
+@pytest.mark.parametrize("name,t", WT)
+@pytest.mark.parametrize("n_expert,n_used,n_b_is_one", [(8, 2, False), (8, 4, True), (4, 1, False)])
+def test_mul_mat_id_single_token_is_one_fused_launch(gu, name, t, n_expert, n_used, n_b_is_one):
+    """n_tok = 1 (mixture-of-experts decode) quantizes the activation row inside the GEMV launch; the multi-token call takes
+    quantize + GEMV.  Token 0 of a two-token call must therefore equal the single-token call bit for bit."""
+    from ggml_amd import ops
+    m, k = 520, 1024
+    rng = np.random.default_rng(n_expert + 100 * n_used)
+    w = R.random_weights(t, n_expert * m, k, seed=9)
+    n_b = 1 if n_b_is_one else n_used
+    xb = (rng.standard_normal((2, n_b, k)) * 2).astype(np.float32)
+    ids = np.stack([rng.permutation(n_expert)[:n_used] for _ in range(2)]).astype(np.int32)
+    a = gu.qtensor(t, w, n_expert * m, k)
+    y2 = ops.mul_mat_id(a, gu.to_dev(xb), gu.to_dev(ids), n_expert=n_expert).cpu().numpy()
+    y1 = ops.mul_mat_id(a, gu.to_dev(xb[:1]), gu.to_dev(ids[:1]), n_expert=n_expert).cpu().numpy()
+    assert np.array_equal(y1.view(np.uint32), y2[:1].view(np.uint32))
+    e = R.rel_l2(y1, R.o_mul_mat_id(t, w, xb[:1], ids[:1], m, k, n_expert)); gu.report(test="mul_mat_id_fused", type=name, rel_l2=e)
+    assert e < TOL_GEMV
