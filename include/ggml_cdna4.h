@@ -93,6 +93,8 @@ int ggml_cdna4_mul_mat_prepared(int type, const void * W, int64_t w_row_bytes,
  *   b  : f32 [n_tok][n_b][K]   (n_b == n_used or 1; slot u reads row u % n_b)   strides in elements
  *   ids: i32 [n_tok][n_used]   (device memory; never copied to the host)        stride in elements
  *   dst: f32 [n_tok][n_used][M]
+ * n_tok == 1 (decode) runs as ONE launch with the activation quantizer inside the GEMV (workspace untouched);
+ * more tokens quantize the activations into `workspace` first.  Expert ids out of [0, n_expert) leave their slot unwritten.
  */
 int ggml_cdna4_mul_mat_id(int type, const void * as, int64_t w_row_bytes, int64_t w_expert_bytes,
                           const float * b, int64_t b_row_stride, int64_t b_tok_stride,
