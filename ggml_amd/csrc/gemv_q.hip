@@ -304,9 +304,18 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
     float *sd = reinterpret_cast<float *>(smem + K + (KQ ? K / 8 : 0));
     const int row0 = (blockIdx.x * NW + wave) * ROWS;
     const int nunits = K / Unit<TYPE, 1>::UK;
-    // this lane's first unit of every row goes into registers now: its HBM latency runs under the quantizer below
+    // Order matters: a wave's loads RETURN in issue order.  The activation chunk (L2-resident) is requested first so the
+    // quantizer can start as soon as it arrives; the weight rows (HBM) are requested right behind it and stream in under the
+    // quantizer.  (Weights first made the quantizer wait for the whole HBM round trip: 5.46 vs 4.82 us cold, same-box A/B.)
+    const int c_first = threadIdx.x;
+    float4 v_first[4] = {};
     const uint8_t *wrow[ROWS];
     typename Unit<TYPE, 1>::W w0[ROWS];
+    if (c_first < K / 16) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v_first[i] = *reinterpret_cast<const float4 *>(x + c_first * 16 + 4 * i);
+    }
+    asm volatile("" ::: "memory");                                          // keep the weight loads below behind the activation loads
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         wrow[r] = a.W + (int64_t)min(row0 + r, a.M - 1) * a.w_row_bytes;
@@ -315,13 +324,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
     // One lane quantizes 16 consecutive values (= one bsums entry, one ds_write_b128): a superblock is 16 adjacent lanes
     // (4 butterfly rounds), a Q8_0 block 2 lanes (1 round).  The first cut (one wave per superblock, 4 values per lane,
     // 6 rounds x 3 shuffles, 4 superblocks in sequence per wave) cost ~5 us per work-group and lost to the two-kernel path.
-    for (int c = threadIdx.x; c < K / 16; c += NW * 64) {
-        float e[16];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + c * 16 + 4 * i);
-            e[4 * i] = v.x; e[4 * i + 1] = v.y; e[4 * i + 2] = v.z; e[4 * i + 3] = v.w;
-        }
+    auto quantize_chunk = [&](int c, const float4 (&v)[4]) __attribute__((always_inline)) {
+        const float e[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
         int q[16];
         if (KQ) {
             // first index with the largest |x| keeps its SIGNED value (quantize_row_q8_K_ref, src/ggml-quants.c:2485-2491)
@@ -360,6 +364,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
         { const int q0[4] = {q[0], q[1], q[2], q[3]}, q1[4] = {q[4], q[5], q[6], q[7]}, q2[4] = {q[8], q[9], q[10], q[11]}, q3[4] = {q[12], q[13], q[14], q[15]};
           pk.x = pack4i8(q0); pk.y = pack4i8(q1); pk.z = pack4i8(q2); pk.w = pack4i8(q3); }
         *reinterpret_cast<u32x4 *>(sq + c * 16) = pk;
+    };
+    if (c_first < K / 16) quantize_chunk(c_first, v_first);
+    for (int c = c_first + NW * 64; c < K / 16; c += NW * 64) {           // K > 16 * (work-group size): the remaining chunks
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const float4 *>(x + c * 16 + 4 * i);
+        quantize_chunk(c, v);
     }
     __syncthreads();
     if (row0 >= a.M) return;
