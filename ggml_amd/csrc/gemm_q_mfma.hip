@@ -815,8 +815,10 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
 // doubles the issue slots under the same MFMA pipe.  Tile 128(m) x 128(b), stage = 128 k (two 64-k groups):
 // waves 0-3 (khalf 0) consume group 0 of every stage, waves 4-7 (khalf 1) group 1 — an intra-work-group K split —
 // and the two partial accumulators are summed ONCE at the end through LDS (fixed order: deterministic).
-// OPT bit 0: issue the LDS-DMA pieces of stage s+2 in the VALU gaps of the unpack phase (after each fragment build) instead
-//            of between the MFMAs, leaving the MFMA block bare;  bit 1: no s_setprio around the MFMA block.
+// OPT selects the schedule (variant bits 5-9).  Built: 0 = leader/follower phase offset, whole-fragment unpack, DMA pieces
+// between the MFMAs (the first cut of this kernel); 12 = in-wave pipeline (bit 2) + phase offset (bit 3); 20 = in-wave
+// pipeline with the DMA pieces split over the S and T phases (bit 4) — the fallback of k_gemm_kq_w8p / _w12 for shallow K.
+// (Other combinations measured in DESIGN 4.3 — pieces in the unpack phase, no s_setprio — are no longer instantiated.)
 template <int TYPE, bool TRACE = false, int OPT = 0>
 __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
     typedef WStage<TYPE, 2> WSt;
@@ -920,29 +922,10 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
             for (int bf = 0; bf < BNF; bf++) xa[kk][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (OPT & 1) {
-            auto build = [&](int g) __attribute__((always_inline)) {
-                const typename Raw<TYPE>::Sc z = raw.scales(g);
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    wf[kk] = raw.frag(kk, z, dq);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (load) {
-#pragma unroll
-                        for (int i = 0; i < NL; i++)
-                            if (i * 4 / NL == kk) issue_piece(i, sbr, part, slot_l);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            };
-            if (kh == 0) build(part * 2); else build(part * 2 + 1);
-        } else {
-            if (kh == 0) raw.frags(part * 2, h, wf, dq); else raw.frags(part * 2 + 1, h, wf, dq);
-        }
+        if (kh == 0) raw.frags(part * 2, h, wf, dq); else raw.frags(part * 2 + 1, h, wf, dq);
     };
     auto mfma_block = [&](bool load, int sbr, int part, int slot_l) __attribute__((always_inline)) {
-        if constexpr (OPT & 1) load = false;    // pieces are issued by load_unpack
-        if constexpr (!(OPT & 2)) __builtin_amdgcn_s_setprio(1);          // the wave feeding the matrix pipe wins issue arbitration over its partner's unpack
+        __builtin_amdgcn_s_setprio(1);          // the wave feeding the matrix pipe wins issue arbitration over its partner's unpack
 #pragma unroll
         for (int kk = 0; kk < 4; kk++)
 #pragma unroll
@@ -951,7 +934,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
                 const int n = kk * BNF + bf;
                 if ((n & 1) && (n >> 1) < NL && load) issue_piece(n >> 1, sbr, part, slot_l);
             }
-        if constexpr (!(OPT & 2)) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
     };
 
     auto stamp = [&](int s, int ph) __attribute__((always_inline)) {      // TRACE builds: [wave][stage 0..15][phase 0..7] cycle stamps of block 0
@@ -982,7 +965,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
         stamp(s, 2);
         const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;   // stage s+2 = (sb+1, part) -> slot2
         if (kh == 1) {                                               // follower: previous stage's fragments (+ DMA issue)
-            if (s > 0) mfma_block(load, sb + 1, part, slot2); else if (load && !(OPT & 1)) issue(sb + 1, part, slot2);
+            if (s > 0) mfma_block(load, sb + 1, part, slot2); else if (load) issue(sb + 1, part, slot2);
         }
         stamp(s, 4);
         load_unpack(slot, part, load, sb + 1, slot2);
@@ -1964,8 +1947,8 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         CDNA4_CHECK_LAUNCH(); return 0;
     }
     else if constexpr (TYPE >= 100) { W8_LAUNCH(20); CDNA4_CHECK_LAUNCH(); return 0; }   // repacked formats: the default schedule only
-    else switch (opt & 31) { case 0: W8_LAUNCH(0); break; case 1: W8_LAUNCH(1); break; case 2: W8_LAUNCH(2); break; case 3: W8_LAUNCH(3); break;
-                        case 4: W8_LAUNCH(4); break; case 12: W8_LAUNCH(12); break; case 28: W8_LAUNCH(28); break; case 20: W8_LAUNCH(20); break; default: return cdna4_set_error_msg("gemm_q: unknown 8-wave schedule option"); }
+    else switch (opt & 31) { case 0: W8_LAUNCH(0); break; case 12: W8_LAUNCH(12); break; case 20: W8_LAUNCH(20); break;
+                        default: return cdna4_set_error_msg("gemm_q: unknown 8-wave schedule option (0, 12 and 20 are built)"); }
 #undef W8_LAUNCH
     CDNA4_CHECK_LAUNCH();
     return 0;
