@@ -397,10 +397,11 @@ bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B) {
 template <int TYPE>
 static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st) {
     const size_t lds = cdna4_gemv_fused_lds_bytes(TYPE, a.K);
-    // CDNA4_FUSED_CFG: 0 = 4 waves x 1 row, 1 = 8 x 2, 2 = 4 x 2, 3 = 8 x 1.  Measured at 4096x4096 Q4_K, cold HBM / cache-warm us:
-    // 6.32/5.52, 5.93/5.39, 6.35/5.49, 5.57/5.79 -> 8 waves x 1 row when the matrix is tall enough to still fill the chip.
+    // CDNA4_FUSED_CFG: 0 = 4 waves x 1 row, 1 = 8 x 2, 2 = 4 x 2, 3 = 8 x 1.  Measured at 4096x4096 Q4_K with the activation loads
+    // issued first, cold HBM / host wall us: 5.80/5.22, 4.35/4.29, 5.38/4.76, 4.83/4.45 -> 8 waves x 2 rows (one work-group per
+    // CU at M = 4096: the quantizer is paid once per CU) when that still gives every CU a work-group, else 8 x 1, else 4 x 1.
     static const int cfg_env = getenv("CDNA4_FUSED_CFG") ? atoi(getenv("CDNA4_FUSED_CFG")) : -1;
-    const int cfg = cfg_env >= 0 ? cfg_env : (a.M >= 2048 ? 3 : 0);
+    const int cfg = cfg_env >= 0 ? cfg_env : (a.M >= 4096 ? 1 : (a.M >= 2048 ? 3 : 0));
     if (cfg == 1) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x, (int64_t)0);
     else if (cfg == 2) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 2>), dim3((a.M + 7) / 8), dim3(256), lds, st, a, x, (int64_t)0);
     else if (cfg == 3) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 1>), dim3((a.M + 7) / 8), dim3(512), lds, st, a, x, (int64_t)0);
