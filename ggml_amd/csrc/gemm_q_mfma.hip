@@ -1308,6 +1308,7 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int mg = wave & 3, kh = __builtin_amdgcn_readfirstlane(wave >> 2);        // kh = 2: loader wave (mg = its index)
     const bool is_loader = kh == 2;
+    // (static s_setprio for the loader waves, or for the compute waves: no effect, 25.8 us either way)
     const int nblk = gridDim.x;
     int L = blockIdx.x;
     if ((nblk & 7) == 0) L = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
