@@ -37,7 +37,7 @@ n_expert, n_used, n_tok, Mi, Ki = 4, 2, 5, 16, 256
 rng = np.random.default_rng(77)
 ids = np.stack([rng.permutation(n_expert)[:n_used] for _ in range(n_tok)]).astype(np.int32)
 mm = {}
-for name, t in (("q4_K", R.Q4_K), ("q8_0", R.Q8_0)):
+for name, t in (("q4_K", R.Q4_K), ("q8_0", R.Q8_0), ("q4_0", R.Q4_0), ("q5_K", R.Q5_K), ("q6_K", R.Q6_K)):   # (first two first: their draws predate the other three)
     w = R.r_quantize(t, rng.uniform(-1, 1, (n_expert * Mi, Ki)).astype(np.float32))
     xb = rng.uniform(-1, 1, (n_tok, n_used, Ki)).astype(np.float32)
     y = np.zeros((n_tok, n_used, Mi), np.float32)

@@ -102,13 +102,16 @@ def test_golden_fixture_gemv_and_gemm(gu, name, t):
 def test_golden_mul_mat_id(gu):
     from ggml_amd import ops
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "mul_mat_id_small.npz"))
-    for name in ("q4_K", "q8_0"):
+    for name in R.QUANT_TYPES:
         t = R.QUANT_TYPES[name]
         M, K, ne = int(G["M"]), int(G["K"]), int(G["n_expert"])
         a = gu.qtensor(t, G[name + "_w"], ne * M, K)
         y = ops.mul_mat_id(a, gu.to_dev(G[name + "_x"]), gu.to_dev(G["ids"]), n_expert=ne).cpu().numpy()
         e = R.rel_l2(y, G[name + "_y"]); gu.report(test="golden_mul_mat_id", type=name, rel_l2=e)
         assert e < TOL_GEMV
+        # the single-token (one-launch) path against the same fixture
+        y1 = ops.mul_mat_id(a, gu.to_dev(G[name + "_x"][:1]), gu.to_dev(G["ids"][:1]), n_expert=ne).cpu().numpy()
+        assert R.rel_l2(y1, G[name + "_y"][:1]) < TOL_GEMV
 
 
 # ------------------------------------------------------------------------------------------------ GEMV

@@ -34,7 +34,7 @@ def test_mul_mat_golden(name):
     assert R.rel_l2(y, G[name + "_y"]) < 2e-6
 
 
-@pytest.mark.parametrize("name", ["q4_K", "q8_0"])
+@pytest.mark.parametrize("name", list(R.QUANT_TYPES))
 def test_mul_mat_id_golden(name):
     t = R.QUANT_TYPES[name]
     y = R.o_mul_mat_id(t, GID[name + "_w"], GID[name + "_x"], GID["ids"], int(GID["M"]), int(GID["K"]), int(GID["n_expert"]))
