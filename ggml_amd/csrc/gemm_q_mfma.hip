@@ -6,20 +6,21 @@
 // block-wise to fp16 with the reference formulas (dequantize_row_q4_K etc., src/ggml-quants.c:255,349,1280,
 // 1482,1690).  Measured rel-L2 vs ggml-cpu ~3e-4 (gate 1e-3); vs the exact product it is ~4e-3 like the CPU.
 //
-// Structure (MI355X-first, not a port of src/ggml-cuda/mmq.cuh):
-//  * work-group = 4 waves, tile 128(m) x 64|128(b); wave w owns m-rows [32w,32w+32) for ALL b of the tile, so
-//    every weight of the tile is dequantized by exactly one lane, in registers, straight into the MFMA B
-//    operand — weights never exist as fp16 in LDS or HBM.
-//  * packed superblocks travel HBM -> LDS untouched via global_load_lds_dwordx4 (16 B/lane, whole 144/176-B
-//    superblocks, coalesced); the 144-B row stride is bank-conflict-free for ds_read_b128.  Formats whose
-//    blocks are only 2-byte aligned (Q6_K 210 B, Q4_0 18 B, Q8_0 34 B) are read per lane from global memory.
-//  * fp16 activations are LDS-staged by global_load_lds in 64-k slices, 128-B rows, 16-B chunks XOR-swizzled by
-//    ((row>>1)&7) on the SOURCE address so the A-fragment ds_read_b128s are conflict-free.
-//  * k is consumed in a permuted order: MFMA A and B fragments only need to agree on which k each slot holds,
-//    so the nibble unpack needs no byte shuffles (see chunk_of() and the pair-interleaved fp16 image).
-//  * double-buffered LDS, one s_waitcnt vmcnt(0) + barrier per 64-k step, next slice issued before the MFMAs.
-//  * optional split-K (fp32 atomics into a zeroed Y) to fill 256 CUs on small problems; XCD-aware tile order
-//    keeps the tiles that share a weight panel on one XCD's L2.
+// Structure (MI355X-first, not a port of src/ggml-cuda/mmq.cuh) — common to every kernel in this file:
+//  * a wave owns 32 (or 64) weight rows for ALL activation rows of the tile, so every weight of the tile is dequantized by
+//    exactly one lane, in registers, straight into the MFMA B operand — weights never exist as fp16 in LDS or HBM;
+//  * k is consumed in a permuted order: MFMA A and B fragments only need to agree on which k each slot holds, so the
+//    nibble unpack needs no byte shuffles (see chunk_of() and the pair-interleaved, k-panel-major fp16 image);
+//  * packed weights and fp16 activations are staged through a 3-slot LDS ring (global_load_lds_dwordx4, 16-byte chunks
+//    XOR-swizzled on the SOURCE address so the fragment ds_read_b128s are conflict-free); XCD-aware tile order.
+// Kernels, oldest to newest (launch_type() picks; DESIGN.md 4.3 has the measurements):
+//    k_gemm_q        4 waves, slice-per-barrier, per-lane weight loads — any format, small batches, K % 256 != 0
+//    k_gemm_kq_pipe  4 waves, superblock stages, counted vmcnt                      (Q4_K / Q5_K, 8 < B <= 64)
+//    k_gemm_kq_w8    8 waves (two per SIMD), 128x128 tile, in-wave unpack/MFMA pipeline, split-K = 2 exchange
+//    k_gemm_kq_w8p   + cross-stage software pipeline (barrier in the middle of the MFMA stream)   (Q5_K default)
+//    k_gemm_kq_w12   + four LDS-DMA loader waves; they also re-lay Q4_0 / Q8_0 / Q6_K blocks while staging (Q4_K default)
+//    k_gemm_kq_x2    256x128 tile, two weight fragments per activation fragment, 1/2/4-way exchange   (huge grids)
+//    k_repack_*      16-byte-aligned re-layout of Q4_0 / Q8_0 / Q6_K into scratch (shallow-K fallback of the staged path)
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
 #include <stdlib.h>
