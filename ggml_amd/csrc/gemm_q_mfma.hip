@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
 // (an LDS-DMA instruction parks its wave ~60 cycles; in the 8-wave kernels that park is taken out of the MFMA stream — the
 // DMA-less ablation of k_gemm_kq_w8p ran 26.9 -> 24.7 us with the same memory traffic), waves 0-7 are the compute waves of
 // k_gemm_kq_w8p without any vector-memory instruction in their main loop.  All twelve meet at the same s_barriers.
-template <int TYPE>
+template <int TYPE, bool USE_TAB = true>
 __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     constexpr bool TRACE = false;
     constexpr bool DIRECT = WDirect<TYPE>::value;   // weights re-laid by the loader lanes from the original blocks (no LDS-DMA for W)
@@ -1296,7 +1296,11 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     constexpr int BNF = 4, TB = 128, NST = 3;
     constexpr int RS = 256, XS = TB * RS;
     constexpr int BLK = QT<TYPE>::BYTES;
-    constexpr int WRS = WSt::NPH * 16, WS = 128 * WRS, ST = XS + WS;
+    // TAB (Q4_K): the loader waves also turn every row's 6-bit scales / mins into the fp16 (s, c) constants of the stage and
+    // leave them in a small table next to the stage's data, so the compute waves read 8 bytes instead of spending ~30 VALU
+    // per wave and stage on Raw::scales() inside the MFMA stream
+    constexpr bool TAB = USE_TAB && TYPE == CDNA4_Q4_K;
+    constexpr int WRS = WSt::NPH * 16, WS = 128 * WRS, TS = TAB ? 128 * 2 * 8 : 0, ST = XS + WS + TS;
     constexpr int NWI = 128 * WSt::NPH / 64;     // weight wave-pieces per stage: 10 (Q4_K) / 14 (Q5_K)
     constexpr int XL = XS / 16 / 64 / 4;         // activation wave-pieces per loader wave per stage: 8
     constexpr int WL = DIRECT ? 0 : (NWI + 3) / 4;   // weight wave-pieces per loader wave (the tail re-loads earlier pieces)
@@ -1403,11 +1407,21 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
             between(bf);
         }
     };
+    // the (s, c) constants of this lane's (row, 64-k group) for the stage in `slot`, written there by a loader lane
+    auto tab_read = [&](int slot_) __attribute__((always_inline)) {
+        typename Raw<TYPE>::Sc z;
+        if constexpr (TAB) {
+            const u32x2 te = *reinterpret_cast<const u32x2 *>(smem + slot_ * ST + XS + WS + ((mg * 32 + j) * 2 + kh) * 8);
+            const half2_t lo = as_h2(te.x), hi = as_h2(te.y);
+            z.SL = half2_t{lo.x, lo.x}; z.CL = half2_t{lo.y, lo.y}; z.SH = half2_t{hi.x, hi.x}; z.CH = half2_t{hi.y, hi.y};
+        }
+        return z;
+    };
     // S work of a stage whose data sits in `slot`: used once in the prologue (nothing to hide it under yet)
     auto S_first = [&](int slot) __attribute__((always_inline)) {
         raw_c.load(smem + slot * ST + XS + (mg * 32 + j) * WRS, kh, h);
         read_xa(slot, 0); read_xa(slot, 1);
-        if (kh == 0) z_c = raw_c.scales(0); else z_c = raw_c.scales(1);
+        if constexpr (TAB) z_c = tab_read(slot); else { if (kh == 0) z_c = raw_c.scales(0); else z_c = raw_c.scales(1); }
 #pragma unroll
         for (int i = 0; i < 4; i++) cur[i] = raw_c.pairbits(0, i, z_c, dq);
     };
@@ -1454,7 +1468,10 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
         }
         mfma4(2, f2, [&](int bf) __attribute__((always_inline)) {
             if constexpr (nx) {
-                if (bf == 3) { if (kh == 0) z_c = raw_c.scales(((part + 1) & 1) * 2); else z_c = raw_c.scales(((part + 1) & 1) * 2 + 1); }
+                if (bf == 3) {
+                    if constexpr (TAB) z_c = tab_read(slot1);
+                    else { if (kh == 0) z_c = raw_c.scales(((part + 1) & 1) * 2); else z_c = raw_c.scales(((part + 1) & 1) * 2 + 1); }
+                }
             }
         });
         mfma4(3, f3, [&](int bf) __attribute__((always_inline)) {
@@ -1467,15 +1484,43 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     typedef std::integral_constant<int, 0> p0_t; typedef std::integral_constant<int, 1> p1_t;
     // loader program: the same barrier sequence as the compute waves (one before the first S work, one in the middle of
     // every stage that has a successor); after the barrier of stage s, slot s is free and takes stage s+3
+    // TAB: loader lane (row, gl) keeps the 16-byte superblock header of the row in registers one stage ahead (plain global
+    // load, issued BEFORE the stage's DMA pieces so the counted vmcnt wait in front of the next barrier covers it)
+    const int lrow = ((mg << 6) | lane) >> 1, lgl = lane & 1;
+    const uint8_t *const hrow0 = p.W + (int64_t)min(m0 + lrow, p.M - 1) * p.w_row_bytes + (int64_t)sb0 * BLK;
+    auto hload = [&](int sbr) __attribute__((always_inline)) {
+        u32x4 r; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(hrow0 + (int64_t)sbr * BLK) : "memory"); return r;
+    };
+    auto tab_store = [&](const u32x4 &hdr, int part_, int slot_) __attribute__((always_inline)) {   // same arithmetic as Raw<Q4_K>::scales()
+        const int g = part_ * 2 + lgl;
+        int s0, mn0, s1, mn1;
+        k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g, s0, mn0); k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g + 1, s1, mn1);
+        const float d = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
+        const half_t sl = (half_t)(d * (float)s0), sh = (half_t)(d * (float)s1);
+        const half_t cl = (half_t)(8.f * (float)sl - dmin * (float)mn0), ch = (half_t)(8.f * (float)sh - dmin * (float)mn1);
+        u32x2 e; e.x = __builtin_bit_cast(uint32_t, half2_t{sl, cl}); e.y = __builtin_bit_cast(uint32_t, half2_t{sh, ch});
+        *reinterpret_cast<u32x2 *>(smem + slot_ * ST + XS + WS + (lrow * 2 + lgl) * 8) = e;
+    };
+    u32x4 hcur = {0, 0, 0, 0};                                         // header of the superblock of stage s+3
     auto lstage = [&](auto LD, auto W2, auto NX, auto PART, int sb) __attribute__((always_inline)) {
         constexpr bool load = decltype(LD)::value, w2 = decltype(W2)::value, nx = decltype(NX)::value;
         constexpr int part = decltype(PART)::value;
         if constexpr (nx) {
-            if (w2) wait_vmcnt<NL>(); else wait_vmcnt<0>();             // stage s+1 has landed (only stage s+2's pieces may be in flight)
+            // stage s+1 has landed (only stage s+2's pieces may be in flight; the header load is older than those)
+            if (w2) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hcur) : "n"(NL) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hcur) : : "memory");
+            if constexpr (TAB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table written last stage is in LDS
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        if constexpr (load) issue(sb + (part + 3) / 2, (part + 3) % 2, slot);
+        if constexpr (load) {
+            u32x4 hnext = hcur;
+            if constexpr (TAB) {
+                if (2 * sb + part + 4 < nstage) hnext = hload(sb + 2);  // stage s+4 = (sb + 2, part)
+                tab_store(hcur, (part + 3) % 2, slot);
+            }
+            issue(sb + (part + 3) / 2, (part + 3) % 2, slot);
+            hcur = hnext;
+        }
         slot = slot == 2 ? 0 : slot + 1;
     };
     if (is_loader && DIRECT) {
@@ -1515,9 +1560,17 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
             }
         }
     } else if (is_loader) {
+        u32x4 hA = {0, 0, 0, 0};
+        if constexpr (TAB) { hA = hload(0); hcur = hload(1); }         // (this kernel only runs K ranges of >= 3 superblocks)
         issue(0, 0, 0);
         issue(0, 1, 1);
-        if (nstage > 2) { issue(1, 0, 2); wait_vmcnt<2 * NL>(); } else wait_vmcnt<NL>();
+        issue(1, 0, 2);
+        if constexpr (TAB) {
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(hA), "+v"(hcur) : "n"(3 * NL) : "memory");   // the two headers are older than the 3 x NL pieces
+            tab_store(hA, 0, 0); tab_store(hA, 1, 1); tab_store(hcur, 0, 2);
+        }
+        wait_vmcnt<2 * NL>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         lstage(yes_t{}, yes_t{}, yes_t{}, p0_t{}, 0); lstage(yes_t{}, yes_t{}, yes_t{}, p1_t{}, 0);
@@ -1941,7 +1994,12 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
         if ((opt == 64 || opt == 65) && min_nsb < 3) opt = 20;
     }
-    if (opt == 65) { hipLaunchKernelGGL((k_gemm_kq_w12<TYPE>), grid, dim3(768), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }   // + loader waves
+    if (opt == 65) {                                                      // + loader waves
+        static const bool no_tab = getenv("CDNA4_NO_TAB") != nullptr;       // A/B knob: compute waves unpack the scales themselves
+        if (TYPE == CDNA4_Q4_K && no_tab) hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, false>), grid, dim3(768), 0, st, p);
+        else hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true>), grid, dim3(768), 0, st, p);
+        CDNA4_CHECK_LAUNCH(); return 0;
+    }
     if constexpr (TYPE >= 200) return cdna4_set_error_msg("gemm_q: staged formats run on the loader-wave kernel only");
     if (opt == 64) {                                                      // cross-stage pipeline
         if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE, true>), grid, dim3(512), 0, st, p);
