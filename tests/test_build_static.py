@@ -1,0 +1,64 @@
+"""Static properties of the compiled gfx950 kernels that the performance of the hot path depends on, checked from the
+assembly hipcc emits (no GPU needed): the shipped kernels must not spill to scratch, the 12-wave kernel must fit three waves
+per SIMD, and no work-group may ask for more than the CU's 160 KB of LDS."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def gemm_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("asm") / "gemm.s"
+    src = os.path.join(ROOT, "ggml_amd", "csrc", "gemm_q_mfma.hip")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=900)
+    return out.read_text()
+
+
+def _prop(asm, kernel, name):
+    m = re.search(r"\.set %s\.%s, (\d+)" % (re.escape(kernel), name), asm)
+    assert m, "kernel %s not found in the assembly" % kernel
+    return int(m.group(1))
+
+
+def _lds(asm, kernel):
+    m = re.search(r"\.amdhsa_kernel %s\n(?:.*\n)*?\s+\.amdhsa_group_segment_fixed_size (\d+)" % re.escape(kernel), asm)
+    assert m, kernel
+    return int(m.group(1))
+
+
+# mangled names: k_gemm_kq_w12<Q4_K, true>, k_gemm_kq_w8p<Q5_K, false>, k_gemm_kq_w8<Q4_K, false, 20>, k_gemm_kq_x2<Q4_K, 1>
+SHIPPED = [
+    "_Z13k_gemm_kq_w12ILi12ELb1EEv11gemm_params",
+    "_Z13k_gemm_kq_w8pILi13ELb0EEv11gemm_params",
+    "_Z13k_gemm_kq_w8pILi12ELb0EEv11gemm_params",
+    "_Z12k_gemm_kq_w8ILi12ELb0ELi20EEv11gemm_params",
+    "_Z12k_gemm_kq_x2ILi12ELi1EEv11gemm_params",
+    "_Z12k_gemm_kq_x2ILi12ELi4EEv11gemm_params",
+]
+
+
+@pytest.mark.parametrize("kernel", SHIPPED)
+def test_shipped_gemm_kernels_do_not_spill(gemm_asm, kernel):
+    assert _prop(gemm_asm, kernel, "private_seg_size") == 0
+    assert _lds(gemm_asm, kernel) <= 160 * 1024
+
+
+def test_loader_wave_kernel_fits_three_waves_per_simd(gemm_asm):
+    # 12 waves per work-group = 3 per SIMD: 512 registers / 3, allocation granule 8
+    for k in ("_Z13k_gemm_kq_w12ILi12ELb1EEv11gemm_params", "_Z13k_gemm_kq_w12ILi202ELb1EEv11gemm_params",
+              "_Z13k_gemm_kq_w12ILi208ELb1EEv11gemm_params", "_Z13k_gemm_kq_w12ILi214ELb1EEv11gemm_params"):
+        assert _prop(gemm_asm, k, "num_vgpr") + _prop(gemm_asm, k, "num_agpr") <= 168
+
+
+def test_two_waves_per_simd_kernels_fit_256_registers(gemm_asm):
+    for k in SHIPPED[1:]:
+        assert _prop(gemm_asm, k, "num_vgpr") + _prop(gemm_asm, k, "num_agpr") <= 256
