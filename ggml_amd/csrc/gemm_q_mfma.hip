@@ -1288,9 +1288,17 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
 // (an LDS-DMA instruction parks its wave ~60 cycles; in the 8-wave kernels that park is taken out of the MFMA stream — the
 // DMA-less ablation of k_gemm_kq_w8p ran 26.9 -> 24.7 us with the same memory traffic), waves 0-7 are the compute waves of
 // k_gemm_kq_w8p without any vector-memory instruction in their main loop.  All twelve meet at the same s_barriers.
-template <int TYPE, bool USE_TAB = true>
+// EXP: experiment bits (0 = the shipped kernel).  bit0: the compute waves read the next stage's (s, c) table entry right
+// after the stage barrier instead of late in T_b (its LDS latency was exposed in front of fragment 0's first pairbits).
+// Bits 4-8 are timing-only ABLATIONS (results are garbage; instantiated only under -DCDNA4_ABLATIONS for
+// tools/microbench/gemm_bench): 16 loaders skip the activation pieces in the main loop, 32 loaders issue no DMA at all in
+// the main loop, 64 compute waves skip the activation ds_reads in the main loop, 128 no unpack arithmetic (raw bits go to
+// the MFMA), 256 no s_barrier in the main loop.
+template <int TYPE, bool USE_TAB = true, int EXP = 0>
 __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     constexpr bool TRACE = false;
+    constexpr bool EARLY_TAB = (EXP & 1) != 0, A_NOX = (EXP & 16) != 0, A_NODMA = (EXP & 32) != 0, A_NOXREAD = (EXP & 64) != 0,
+                   A_NOUNPACK = (EXP & 128) != 0 && TYPE == CDNA4_Q4_K, A_NOBAR = (EXP & 256) != 0;
     constexpr bool DIRECT = WDirect<TYPE>::value;   // weights re-laid by the loader lanes from the original blocks (no LDS-DMA for W)
     typedef WStage<TYPE, 2> WSt;
     constexpr int BNF = 4, TB = 128, NST = 3;
@@ -1368,6 +1376,12 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
 #pragma unroll
         for (int i = 0; i < NL; i++) issue_piece(i, sbr, part, slot);
     };
+    auto issue_loop = [&](int sbr, int part, int slot) __attribute__((always_inline)) {   // main-loop form (the ablations apply here only)
+        if constexpr (!A_NODMA) {
+#pragma unroll
+            for (int i = A_NOX ? XL : 0; i < NL; i++) issue_piece(i, sbr, part, slot);
+        }
+    };
 
     const int xrow_off = j * RS, xswz = j & 15;
     auto estamp = [&](int) __attribute__((always_inline)) {};
@@ -1421,10 +1435,16 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     auto S_first = [&](int slot) __attribute__((always_inline)) {
         raw_c.load(smem + slot * ST + XS + (mg * 32 + j) * WRS, kh, h);
         read_xa(slot, 0); read_xa(slot, 1);
+        if constexpr (A_NOXREAD) { read_xa(slot, 2); read_xa(slot, 3); }
         if constexpr (TAB) z_c = tab_read(slot); else { if (kh == 0) z_c = raw_c.scales(0); else z_c = raw_c.scales(1); }
 #pragma unroll
         for (int i = 0; i < 4; i++) cur[i] = raw_c.pairbits(0, i, z_c, dq);
     };
+    auto pbits = [&](int kk, int i) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (A_NOUNPACK) { if constexpr (TYPE == CDNA4_Q4_K) return raw_c.q[i] + (uint32_t)kk; else return 0u; }
+        else return raw_c.pairbits(kk, i, z_c, dq);
+    };
+    u32x2 te_c = {0, 0};
     int slot = 0;
     // LD: stage s+3 exists (its pieces are issued here);  W2: stage s+2 exists (its pieces are the only ones allowed to be
     // outstanding at the barrier);  NX: stage s+1 exists (barrier + its S work);  PART: which half of the superblock stage s is
@@ -1440,21 +1460,21 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
         const int s_ = sb * 2 + part;
         stamp(s_, 0);
         // ---- T_a: k-steps 0,1; builds fragments 1, 2 and half of 3; second half of stage s+2's pieces -> slot of stage s-1
-        read_xa(slot, 2);
+        if constexpr (!A_NOXREAD) read_xa(slot, 2);
         mfma4(0, cur, [&](int bf) __attribute__((always_inline)) {
-            f1[bf] = raw_c.pairbits(1, bf, z_c, dq);
-            if (bf < 2) f3[bf] = raw_c.pairbits(3, bf, z_c, dq);
+            f1[bf] = pbits(1, bf);
+            if (bf < 2) f3[bf] = pbits(3, bf);
         });
-        read_xa(slot, 3);
+        if constexpr (!A_NOXREAD) read_xa(slot, 3);
         mfma4(1, f1, [&](int bf) __attribute__((always_inline)) {
-            f2[bf] = raw_c.pairbits(2, bf, z_c, dq);
-            if (bf >= 2) f3[bf] = raw_c.pairbits(3, bf, z_c, dq);
+            f2[bf] = pbits(2, bf);
+            if (bf >= 2) f3[bf] = pbits(3, bf);
         });
         stamp(s_, 1);
         if constexpr (nx) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's last reads of `slot` have returned
             stamp(s_, 2);
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!A_NOBAR) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             stamp(s_, 3);
         }
@@ -1462,20 +1482,29 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
         if constexpr (nx) {
             __builtin_amdgcn_sched_barrier(0);
             raw_c.load(smem + slot1 * ST + XS + (mg * 32 + j) * WRS, kh, h);
-            read_xa(slot1, 0); read_xa(slot1, 1);
+            if constexpr (!A_NOXREAD) { read_xa(slot1, 0); read_xa(slot1, 1); }
+            // (the stage's own constants are dead once T_a has built fragments 1-3: the table entry of stage s+1, written two
+            //  stages ago and published by the barrier above, can be requested together with the stage's other LDS reads)
+            if constexpr (TAB && EARLY_TAB) te_c = *reinterpret_cast<const u32x2 *>(smem + slot1 * ST + XS + WS + ((mg * 32 + j) * 2 + kh) * 8);
             __builtin_amdgcn_sched_barrier(0);
             stamp(s_, 4);
         }
         mfma4(2, f2, [&](int bf) __attribute__((always_inline)) {
             if constexpr (nx) {
                 if (bf == 3) {
-                    if constexpr (TAB) z_c = tab_read(slot1);
+                    if constexpr (TAB) {
+                        if constexpr (!EARLY_TAB) z_c = tab_read(slot1);
+                        else {   // the two dwords requested at the top of T_b: only the splats are left to do here
+                            const half2_t lo = as_h2(te_c.x), hi = as_h2(te_c.y);
+                            z_c.SL = half2_t{lo.x, lo.x}; z_c.CL = half2_t{lo.y, lo.y}; z_c.SH = half2_t{hi.x, hi.x}; z_c.CH = half2_t{hi.y, hi.y};
+                        }
+                    }
                     else { if (kh == 0) z_c = raw_c.scales(((part + 1) & 1) * 2); else z_c = raw_c.scales(((part + 1) & 1) * 2 + 1); }
                 }
             }
         });
         mfma4(3, f3, [&](int bf) __attribute__((always_inline)) {
-            if constexpr (nx) cur[bf] = raw_c.pairbits(0, bf, z_c, dq);
+            if constexpr (nx) cur[bf] = pbits(0, bf);
         });
         stamp(s_, 6);
         slot = slot1;
@@ -1509,7 +1538,7 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
             // stage s+1 has landed (only stage s+2's pieces may be in flight; the header load is older than those)
             if (w2) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hcur) : "n"(NL) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hcur) : : "memory");
             if constexpr (TAB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table written last stage is in LDS
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!A_NOBAR) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
         if constexpr (load) {
@@ -1518,7 +1547,7 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
                 if (2 * sb + part + 4 < nstage) hnext = hload(sb + 2);  // stage s+4 = (sb + 2, part)
                 tab_store(hcur, (part + 3) % 2, slot);
             }
-            issue(sb + (part + 3) / 2, (part + 3) % 2, slot);
+            issue_loop(sb + (part + 3) / 2, (part + 3) % 2, slot);
             hcur = hnext;
         }
         slot = slot == 2 ? 0 : slot + 1;
@@ -1948,7 +1977,7 @@ static int cu_count() {
 }
 
 template <int TYPE>
-static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t st) {
+static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t st, int exp = 0) {
     gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0; p.sb_split = 0;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
@@ -1996,6 +2025,20 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     }
     if (opt == 65) {                                                      // + loader waves
         static const bool no_tab = getenv("CDNA4_NO_TAB") != nullptr;       // A/B knob: compute waves unpack the scales themselves
+        // experiment bits of k_gemm_kq_w12 (variant bits 16+ or CDNA4_W12_EXP), built in -DCDNA4_ABLATIONS libraries
+        // (tools/microbench) only: 1 = early table read (bit-identical, measured: no gain), 16.. = timing-only ablations
+        static const int exp_env = getenv("CDNA4_W12_EXP") ? atoi(getenv("CDNA4_W12_EXP")) : 0;
+        if (exp == 0) exp = exp_env;
+        if constexpr (TYPE == CDNA4_Q4_K) {
+#define W12_EXP(E) case E: hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, E>), grid, dim3(768), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0;
+            if (exp != 0 && !no_tab) switch (exp) {
+#ifdef CDNA4_ABLATIONS
+                W12_EXP(1) W12_EXP(16) W12_EXP(32) W12_EXP(64) W12_EXP(128) W12_EXP(256) W12_EXP(96) W12_EXP(224) W12_EXP(480) W12_EXP(288)
+#endif
+                default: return cdna4_set_error_msg("gemm_q: this k_gemm_kq_w12 experiment is not built");
+            }
+#undef W12_EXP
+        }
         if (TYPE == CDNA4_Q4_K && no_tab) hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, false>), grid, dim3(768), 0, st, p);
         else hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true>), grid, dim3(768), 0, st, p);
         CDNA4_CHECK_LAUNCH(); return 0;
@@ -2118,7 +2161,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         }
     }
     if constexpr (CAN_LDS) {
-        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant & 4096) ? 65 : ((variant & 2048) ? 64 : ((variant >> 5) & 31)), st);
+        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant & 4096) ? 65 : ((variant & 2048) ? 64 : ((variant >> 5) & 31)), st, variant >> 16);
         if (wlds && !(variant & 8)) return wide ? launch_pipe<TYPE, 4>(a, splitk, st) : launch_pipe<TYPE, 2>(a, splitk, st);
         if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
     }

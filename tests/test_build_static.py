@@ -35,9 +35,9 @@ def _lds(asm, kernel):
     return int(m.group(1))
 
 
-# mangled names: k_gemm_kq_w12<Q4_K, true>, k_gemm_kq_w8p<Q5_K, false>, k_gemm_kq_w8<Q4_K, false, 20>, k_gemm_kq_x2<Q4_K, 1>
+# mangled names: k_gemm_kq_w12<Q4_K, true, 0>, k_gemm_kq_w8p<Q5_K, false>, k_gemm_kq_w8<Q4_K, false, 20>, k_gemm_kq_x2<Q4_K, 1>
 SHIPPED = [
-    "_Z13k_gemm_kq_w12ILi12ELb1EEv11gemm_params",
+    "_Z13k_gemm_kq_w12ILi12ELb1ELi0EEv11gemm_params",
     "_Z13k_gemm_kq_w8pILi13ELb0EEv11gemm_params",
     "_Z13k_gemm_kq_w8pILi12ELb0EEv11gemm_params",
     "_Z12k_gemm_kq_w8ILi12ELb0ELi20EEv11gemm_params",
@@ -54,8 +54,8 @@ def test_shipped_gemm_kernels_do_not_spill(gemm_asm, kernel):
 
 def test_loader_wave_kernel_fits_three_waves_per_simd(gemm_asm):
     # 12 waves per work-group = 3 per SIMD: 512 registers / 3, allocation granule 8
-    for k in ("_Z13k_gemm_kq_w12ILi12ELb1EEv11gemm_params", "_Z13k_gemm_kq_w12ILi202ELb1EEv11gemm_params",
-              "_Z13k_gemm_kq_w12ILi208ELb1EEv11gemm_params", "_Z13k_gemm_kq_w12ILi214ELb1EEv11gemm_params"):
+    for k in ("_Z13k_gemm_kq_w12ILi12ELb1ELi0EEv11gemm_params", "_Z13k_gemm_kq_w12ILi202ELb1ELi0EEv11gemm_params",
+              "_Z13k_gemm_kq_w12ILi208ELb1ELi0EEv11gemm_params", "_Z13k_gemm_kq_w12ILi214ELb1ELi0EEv11gemm_params"):
         assert _prop(gemm_asm, k, "num_vgpr") + _prop(gemm_asm, k, "num_agpr") <= 168
 
 
