@@ -1,0 +1,38 @@
+#!/bin/bash
+# First GPU call of the next round (~1 minute of box time): the three measurements DESIGN.md §7 items 0 / 1(a) ask for.
+# Needs `make -C tools/microbench all abl` done in the container (the binaries travel with the snapshot).
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+cd tools/microbench
+# (1) the matrix-pipe price of the unpack mix, the clock the chip holds, and the sustained MFMA-only rate (random / zero data)
+timeout 120 ./mfma_valu 500 > ../../gpurun_out/mfma_valu.txt 2>&1
+# (2) the GPU fault of the 8192x8192x512 sweep: one process per kernel, no trace kernels (argv[4] empty), line-buffered output
+{
+for v in 4119 2101271 31461399 23 2071 663; do
+    echo "== variant $v"
+    GB_VARIANTS=$v GB_SPLITKS=1 GB_ROUNDS=2 timeout 60 ./gemm_bench_abl 8192 8192 512 "" 2>&1 | tail -3
+    echo "   exit $?"
+done
+echo "== trace build of the first-cut kernel (variant 23) at this shape"
+GB_VARIANTS=4119 GB_SPLITKS=1 GB_ROUNDS=1 timeout 60 ./gemm_bench_abl 8192 8192 512 23 2>&1 | tail -4
+} > ../../gpurun_out/fault_8192.txt 2>&1
+# (3) the default path at that shape against the slice-per-barrier kernel (variant 5) through the C-ABI
+cd ../..
+timeout 300 python - > gpurun_out/parity_8192.txt 2>&1 <<'PY'
+import numpy as np, torch
+from ggml_amd import native, ops
+from bench import synth_q4k, Q4_K
+L = native.lib(); dev = torch.device("cuda", 0)
+M, K, B = 8192, 8192, 512
+a = ops.QTensor.from_host_bytes(Q4_K, K, M, synth_q4k(M, K, 7), device=dev)
+x = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (B, K)).astype(np.float32)).to(dev)
+ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(Q4_K, K, B), dtype=torch.uint8, device=dev)
+st = torch.cuda.current_stream(dev).cuda_stream
+out = {}
+for variant in (0, 5):
+    y = torch.empty((B, M), dtype=torch.float32, device=dev)
+    native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), a.row_bytes, x.data_ptr(), K, y.data_ptr(), M, M, K, B, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, variant, 0, st))
+    torch.cuda.synchronize(); out[variant] = y.double()
+print("rel-L2 default vs variant 5 at 8192x8192x512:", float((out[0] - out[5]).norm() / out[5].norm()))
+PY
+tail -2 gpurun_out/mfma_valu.txt; cat gpurun_out/fault_8192.txt | cut -c1-200; cat gpurun_out/parity_8192.txt | tail -3

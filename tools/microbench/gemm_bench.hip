@@ -11,6 +11,7 @@
 #include <random>
 
 int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);          // a GPU fault aborts the process: keep what was printed so far
     const int64_t M = argc > 1 ? atoll(argv[1]) : 4096, K = argc > 2 ? atoll(argv[2]) : 4096, B = argc > 3 ? atoll(argv[3]) : 512;
     const size_t wbytes = ggml_cdna4_row_size(GGML_CDNA4_TYPE_Q4_K, K) * M;
     std::vector<uint8_t> w(wbytes); std::mt19937 g(1);
