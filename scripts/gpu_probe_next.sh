@@ -16,8 +16,13 @@ done
 echo "== trace build of the first-cut kernel (variant 23) at this shape"
 GB_VARIANTS=4119 GB_SPLITKS=1 GB_ROUNDS=1 timeout 60 ./gemm_bench_abl 8192 8192 512 23 2>&1 | tail -4
 } > ../../gpurun_out/fault_8192.txt 2>&1
-# (3) the default path at that shape against the slice-per-barrier kernel (variant 5) through the C-ABI
 cd ../..
+# (2b) candidates that must stay bit-identical (rel-L2 0 against the first config): early table read (EXP 1), balanced epilogue (EXP 2)
+cd tools/microbench
+{ GB_VARIANTS=4119,69655,135191 GB_SPLITKS=0,1 timeout 60 ./gemm_bench_abl 4096 4096 512 "" 2>&1 | tail -8
+  GB_VARIANTS=4119,135191 GB_SPLITKS=1 timeout 60 ./gemm_bench_abl 8192 4096 512 "" 2>&1 | tail -4; } > ../../gpurun_out/w12_candidates.txt 2>&1
+cd ../..
+# (3) the default path at that shape against the slice-per-barrier kernel (variant 5) through the C-ABI
 timeout 300 python - > gpurun_out/parity_8192.txt 2>&1 <<'PY'
 import numpy as np, torch
 from ggml_amd import native, ops
@@ -35,4 +40,4 @@ for variant in (0, 5):
     torch.cuda.synchronize(); out[variant] = y.double()
 print("rel-L2 default vs variant 5 at 8192x8192x512:", float((out[0] - out[5]).norm() / out[5].norm()))
 PY
-tail -2 gpurun_out/mfma_valu.txt; cat gpurun_out/fault_8192.txt | cut -c1-200; cat gpurun_out/parity_8192.txt | tail -3
+tail -2 gpurun_out/mfma_valu.txt; cut -c1-200 gpurun_out/w12_candidates.txt; cat gpurun_out/fault_8192.txt | cut -c1-200; cat gpurun_out/parity_8192.txt | tail -3
