@@ -1,6 +1,7 @@
 """Build driver for the native parts (no cmake needed: plain hipcc / g++ invocations).
 
-  libcdna4_kernels.so   hand-written HIP kernels + the C-ABI of include/ggml_cdna4.h        (always)
+  libcdna4_kernels.so   hand-written HIP kernels + the C-ABI of include/ggml_cdna4.h, and the GGUF reader of
+                        include/ggml_cdna4_gguf.h (host code)                                 (always)
   libggml-cdna4.so      ggml backend plug-in (ggml_backend_init), compiled against the ggml headers of the
                         reference tree where they lie — only when that tree is present; the prebuilt
                         .so travels to the GPU box with the snapshot.
@@ -23,7 +24,7 @@ ARCH = "gfx950"
 # -ffp-contract=off: the activation quantizers must round iscale*x before the int conversion, like the CPU
 HIPFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
-KERNEL_SRCS = ["quantize_act.hip", "gemv_q.hip", "gemm_q_mfma.hip", "ops.hip", "capi.hip"]
+KERNEL_SRCS = ["quantize_act.hip", "gemv_q.hip", "gemm_q_mfma.hip", "ops.hip", "capi.hip", "gguf_reader.cpp"]
 BACKEND_SRCS = ["backend/ggml_cdna4_backend.cpp", "backend/ggml_cdna4_ops.cpp"]
 
 
@@ -44,6 +45,7 @@ def _newer(src_list, out):
 def _headers():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hs.append(os.path.join(ROOT, "include", "ggml_cdna4.h"))
+    hs.append(os.path.join(ROOT, "include", "ggml_cdna4_gguf.h"))
     bdir = os.path.join(CSRC, "backend")
     hs += [os.path.join(bdir, f) for f in os.listdir(bdir) if f.endswith(".h")]
     return hs
