@@ -1295,13 +1295,14 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
 // Bits 4-8 are timing-only ABLATIONS (results are garbage; instantiated only under -DCDNA4_ABLATIONS for
 // tools/microbench/gemm_bench): 16 loaders skip the activation pieces in the main loop, 32 loaders issue no DMA at all in
 // the main loop, 64 compute waves skip the activation ds_reads in the main loop, 128 no unpack arithmetic (raw bits go to
-// the MFMA), 256 no s_barrier in the main loop.  bit1 (results bit-identical, ablation builds only): balanced epilogue.
+// the MFMA), 256 no s_barrier in the main loop, 512 (not an ablation) block 0 records the shader clock.  bit1 (results bit-identical, ablation builds only): balanced epilogue.
 template <int TYPE, bool USE_TAB = true, int EXP = 0>
 __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     constexpr bool TRACE = false;
     constexpr bool EARLY_TAB = (EXP & 1) != 0, A_NOX = (EXP & 16) != 0, A_NODMA = (EXP & 32) != 0, A_NOXREAD = (EXP & 64) != 0,
                    A_NOUNPACK = (EXP & 128) != 0 && TYPE == CDNA4_Q4_K, A_NOBAR = (EXP & 256) != 0;
     constexpr bool EPI_BALANCED = (EXP & 2) != 0;   // epilogue experiment: see gemm_w8_epilogue.inc
+    constexpr bool CLK = (EXP & 512) != 0;          // ablation builds: block 0 records s_memtime / s_memrealtime at entry and exit
     constexpr bool DIRECT = WDirect<TYPE>::value;   // weights re-laid by the loader lanes from the original blocks (no LDS-DMA for W)
     typedef WStage<TYPE, 2> WSt;
     constexpr int BNF = 4, TB = 128, NST = 3;
@@ -1389,7 +1390,7 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     const int xrow_off = j * RS, xswz = j & 15;
     auto estamp = [&](int) __attribute__((always_inline)) {};
     // TRACE builds: shader clock (s_memtime) against the fixed 100 MHz reference (s_memrealtime) over the whole kernel of block 0
-    if (TRACE && blockIdx.x == 0 && tid == 0) { p.trace[8 * 16 * 8 + 1100] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1101] = __builtin_amdgcn_s_memrealtime(); }
+    if ((TRACE || CLK) && p.trace && blockIdx.x == 0 && tid == 0) { p.trace[8 * 16 * 8 + 1100] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1101] = __builtin_amdgcn_s_memrealtime(); }
     // TRACE builds: [wave][stage 4..19][phase] s_memtime stamps of block 0: 0 T_a begin, 1 T_a done, 2 after the vmcnt/lgkm
     // waits, 3 after the barrier, 4 next stage's LDS reads issued, 6 T_b done
     auto stamp = [&](int s_, int ph) __attribute__((always_inline)) {
@@ -1622,7 +1623,7 @@ __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     }
 
 #include "gemm_w8_epilogue.inc"
-    if (TRACE && blockIdx.x == 0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[8 * 16 * 8 + 1102] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1103] = __builtin_amdgcn_s_memrealtime(); }
+    if ((TRACE || CLK) && p.trace && blockIdx.x == 0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[8 * 16 * 8 + 1102] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1103] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 
@@ -2036,7 +2037,7 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
 #define W12_EXP(E) case E: hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, E>), grid, dim3(768), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0;
             if (exp != 0 && !no_tab) switch (exp) {
 #ifdef CDNA4_ABLATIONS
-                W12_EXP(1) W12_EXP(2) W12_EXP(16) W12_EXP(32) W12_EXP(64) W12_EXP(128) W12_EXP(256) W12_EXP(96) W12_EXP(224) W12_EXP(480) W12_EXP(288)
+                W12_EXP(1) W12_EXP(2) W12_EXP(16) W12_EXP(32) W12_EXP(64) W12_EXP(128) W12_EXP(256) W12_EXP(96) W12_EXP(224) W12_EXP(480) W12_EXP(288) W12_EXP(512) W12_EXP(544) W12_EXP(992)
 #endif
                 default: return cdna4_set_error_msg("gemm_q: this k_gemm_kq_w12 experiment is not built");
             }

@@ -61,14 +61,19 @@ int main(int argc, char **argv) {
     for (int v : tv) {
         hipMemset(dtr, 0, 65536);
         ggml_cdna4_debug_trace(dtr);
+        // GB_TRACE_REPS > 1: the stamps come from the LAST of that many back-to-back launches, i.e. from the clock the chip
+        // settles at under sustained load rather than from one cold launch
+        for (int r = 1; r < (getenv("GB_TRACE_REPS") ? atoi(getenv("GB_TRACE_REPS")) : 1); r++)
+            ggml_cdna4_mul_mat_prepared(GGML_CDNA4_TYPE_Q4_K, dw, ggml_cdna4_row_size(GGML_CDNA4_TYPE_Q4_K, K), (float *)dy, M, M, K, B, ws, wsz, GGML_CDNA4_PATH_GEMM, v, getenv("GB_TRACE_SPLITK") ? atoi(getenv("GB_TRACE_SPLITK")) : 1, 0);
         ggml_cdna4_mul_mat_prepared(GGML_CDNA4_TYPE_Q4_K, dw, ggml_cdna4_row_size(GGML_CDNA4_TYPE_Q4_K, K), (float *)dy, M, M, K, B, ws, wsz, GGML_CDNA4_PATH_GEMM, v, getenv("GB_TRACE_SPLITK") ? atoi(getenv("GB_TRACE_SPLITK")) : 1, 0);
         hipDeviceSynchronize();
         ggml_cdna4_debug_trace(nullptr);
         std::vector<unsigned long long> tr(8 * 16 * 8 + 1104); hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost);
         if (tr[8 * 16 * 8 + 1103] > tr[8 * 16 * 8 + 1101]) {
             const double cyc = (double)(tr[8 * 16 * 8 + 1102] - tr[8 * 16 * 8 + 1100]), ref = (double)(tr[8 * 16 * 8 + 1103] - tr[8 * 16 * 8 + 1101]);
-            printf("  block 0: %.0f s_memtime ticks in %.2f us of s_memrealtime (100 MHz) -> s_memtime runs at %.0f MHz\n", cyc, ref / 100.0, cyc / (ref / 100.0));
+            printf("  variant %d block 0: %.0f s_memtime ticks in %.2f us of s_memrealtime (100 MHz) -> s_memtime runs at %.0f MHz\n", v, cyc, ref / 100.0, cyc / (ref / 100.0));
         }
+        if (v >= 65536) continue;                    // k_gemm_kq_w12 experiments record the clock only
         {   // which XCD did each work-group land on?  (the tile remap assumes blockIdx % 8)
             int nb = 0, mism = 0; for (int b = 0; b < 1024; b++) { const unsigned long long x = tr[8 * 16 * 8 + 32 + b]; if (b < 256 || x) { nb++; if ((int)x != b % 8) mism++; } }
             printf("  XCC_ID check: %d work-groups recorded, %d with XCC_ID != blockIdx %% 8; first 16:", nb, mism);
