@@ -21,6 +21,11 @@ cd ../..
 cd tools/microbench
 { GB_VARIANTS=4119,69655,135191 GB_SPLITKS=0,1 timeout 60 ./gemm_bench_abl 4096 4096 512 "" 2>&1 | tail -8
   GB_VARIANTS=4119,135191 GB_SPLITKS=1 timeout 60 ./gemm_bench_abl 8192 4096 512 "" 2>&1 | tail -4; } > ../../gpurun_out/w12_candidates.txt 2>&1
+# (2d) the experimental 4 + 4-wave 256x128 kernel (variant 8199) next to the default (rel-L2 must be ~1e-7): one shape per process,
+#      a short timeout each — a barrier mismatch in a first run would hang
+{ for shape in "1024 1024 256" "4096 4096 512" "8192 4096 512" "32768 8192 512"; do
+    GB_VARIANTS=4119,8199 GB_SPLITKS=0 GB_ROUNDS=2 timeout 30 ./gemm_bench_abl $shape "" 2>&1 | tail -3; echo "   exit $?"
+  done; } > ../../gpurun_out/x4l.txt 2>&1
 # (2c) the clock the chip settles at while the shipped / no-DMA / stripped loops run back to back (EXP bit 512 records it)
 { for shape in "4096 4096" "8192 4096"; do
     GB_VARIANTS=4119 GB_SPLITKS=0 GB_ROUNDS=1 GB_TRACE_SPLITK=0 GB_TRACE_REPS=400 timeout 60 ./gemm_bench_abl $shape 512 33558551,35655703,65015959 2>&1 | grep "block 0"
@@ -44,4 +49,4 @@ for variant in (0, 5):
     torch.cuda.synchronize(); out[variant] = y.double()
 print("rel-L2 default vs variant 5 at 8192x8192x512:", float((out[0] - out[5]).norm() / out[5].norm()))
 PY
-tail -2 gpurun_out/mfma_valu.txt; cut -c1-200 gpurun_out/w12_candidates.txt; cat gpurun_out/w12_clock.txt; cat gpurun_out/fault_8192.txt | cut -c1-200; cat gpurun_out/parity_8192.txt | tail -3
+tail -2 gpurun_out/mfma_valu.txt; cut -c1-200 gpurun_out/w12_candidates.txt; cat gpurun_out/w12_clock.txt; cut -c1-200 gpurun_out/x4l.txt; cat gpurun_out/fault_8192.txt | cut -c1-200; cat gpurun_out/parity_8192.txt | tail -3

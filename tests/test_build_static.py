@@ -62,3 +62,19 @@ def test_loader_wave_kernel_fits_three_waves_per_simd(gemm_asm):
 def test_two_waves_per_simd_kernels_fit_256_registers(gemm_asm):
     for k in SHIPPED[1:]:
         assert _prop(gemm_asm, k, "num_vgpr") + _prop(gemm_asm, k, "num_agpr") <= 256
+
+
+def test_experimental_4plus4_wave_kernel_resources(tmp_path):
+    """gemm_q_x4l.hip (not selected by default): 8 waves = 2 per SIMD -> 256 registers, no scratch, three 52-KB slots"""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "x4l.s"
+    src = os.path.join(ROOT, "ggml_amd", "csrc", "gemm_q_x4l.hip")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=900)
+    asm = out.read_text()
+    for s in (1, 2, 4):
+        k = "_Z14k_gemm_q4k_x4lILi%dEEv11gemm_params" % s
+        assert _prop(asm, k, "private_seg_size") == 0
+        assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= 256
+        assert _lds(asm, k) <= 160 * 1024
