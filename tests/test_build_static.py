@@ -78,3 +78,15 @@ def test_experimental_4plus4_wave_kernel_resources(tmp_path):
         assert _prop(asm, k, "private_seg_size") == 0
         assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= 256
         assert _lds(asm, k) <= 160 * 1024
+
+
+def test_experimental_kernel_data_movement_emulation():
+    """tools/emul/x4l_layout_check.py: the loader -> LDS -> fragment -> MFMA index formulas of gemm_q_x4l.hip, transcribed and
+    run on the CPU, reproduce a direct product of the same fp16 operands exactly (every (b, m) sees every k once, with the
+    activation and the weight of the SAME k in every MFMA slot)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("x4l_layout_check", os.path.join(ROOT, "tools", "emul", "x4l_layout_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(M=256, B=128, K=512, seed=1) < 1e-12
+    assert mod.main(M=200, B=100, K=768, seed=2) < 1e-12          # ragged edges: clamped rows only add work, never wrong sums
