@@ -36,6 +36,7 @@ SYMBOLS = [
     ("ggml_cdna4_gguf_tensor_offset", _sz, [_vp, _i64]),
     ("ggml_cdna4_gguf_tensor_size", _sz, [_vp, _i64]),
     ("ggml_cdna4_gguf_tensor_data", _vp, [_vp, _i64]),
+    ("ggml_cdna4_gguf_upload", _int, [_vp, _i64, _vp, _sz, _vp]),
     ("ggml_cdna4_gguf_blck_size", _i64, [_int]),
     ("ggml_cdna4_gguf_type_size", _sz, [_int]),
 ]
@@ -147,6 +148,12 @@ class GGUFFile:
         a = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p)) if n else np.zeros(0, np.uint8)
         a.flags.writeable = False
         return a
+
+    def upload(self, name_or_id, dst, stream=None):
+        """payload -> the uint8 device tensor `dst` through the library's pinned double buffer (ggml_cdna4_gguf_upload)"""
+        i = self.tensor_id(name_or_id)
+        if self._L.ggml_cdna4_gguf_upload(self._h, i, dst.data_ptr(), dst.numel() * dst.element_size(), stream) != 0:
+            raise GGUFError(self._L.ggml_cdna4_last_error().decode())
 
     def qtensor(self, name_or_id, device=None):
         """the 2-D quantized weight `name` in HBM as an ops.QTensor ([K, M] in ggml order: ne0 = K contiguous, ne1 = M rows)"""

@@ -75,6 +75,12 @@ size_t       ggml_cdna4_gguf_tensor_size  (const ggml_cdna4_gguf * g, int64_t te
 /* host pointer to the payload inside the read-only mapping (valid until close); NULL if the file ends before it does */
 const void * ggml_cdna4_gguf_tensor_data  (const ggml_cdna4_gguf * g, int64_t tensor_id);
 
+/* payload of one tensor -> device memory, through two pinned staging buffers (the CPU fills one while the other is in flight
+ * on `stream`, a hipStream_t, NULL = default stream); returns when the last chunk has left the staging buffers.  Replaces the
+ * reference's blob read + ggml_backend_tensor_set (src/gguf.cpp:644-660, examples/gpt-2/main-backend.cpp:412-420).
+ * 0, or a negative status with ggml_cdna4_last_error().  (Not yet GPU-verified: DESIGN.md 4.5.) */
+int ggml_cdna4_gguf_upload(const ggml_cdna4_gguf * g, int64_t tensor_id, void * dst_device, size_t dst_bytes, void * stream);
+
 /* block size / bytes per block of a ggml tensor type as stored in GGUF files (ggml_blck_size / ggml_type_size,
  * src/ggml.c:1176-1182); 0 for removed or unknown types */
 int64_t ggml_cdna4_gguf_blck_size(int ggml_type);

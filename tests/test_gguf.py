@@ -243,3 +243,23 @@ def test_gguf_weights_through_the_hip_path(gg):
             y = ops.mul_mat(a, torch.from_numpy(x).cuda(), path=ops.PATH_GEMV).cpu().numpy()
             yo = R.o_mul_mat(t.type, np.array(f.tensor_bytes(name)), x, m, k)
             assert np.isfinite(y).all() and R.rel_l2(y, yo) < 1e-5, name
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("CDNA4_TEST_EXPERIMENTAL") != "1", reason="upload path not yet GPU-verified, opt-in: CDNA4_TEST_EXPERIMENTAL=1")
+def test_gguf_upload_through_pinned_staging(gg, tmp_path):
+    """ggml_cdna4_gguf_upload: payloads larger and smaller than the 16-MiB staging chunk arrive in HBM byte for byte"""
+    import torch
+    rng = np.random.default_rng(9)
+    big = rng.integers(0, 256, 40 * (1 << 20) + 4096, dtype=np.uint8)           # 2.5 chunks of I8
+    small = rng.integers(0, 256, 144 * 8, dtype=np.uint8)                       # one Q4_K row set
+    p = str(tmp_path / "up.gguf")
+    open(p, "wb").write(G.py_serialize([], [("big", 24, (big.size,), big.tobytes()), ("w", 12, (256, 8), small.tobytes())]))
+    with gg.GGUFFile(p) as f:
+        for name, ref in (("big", big), ("w", small)):
+            dst = torch.zeros(ref.size, dtype=torch.uint8, device="cuda")
+            f.upload(name, dst, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(dst.cpu().numpy(), ref), name
+        with pytest.raises(gg.GGUFError, match="too small"):
+            f.upload("big", torch.zeros(16, dtype=torch.uint8, device="cuda"))
