@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
 // (Other combinations measured in DESIGN 4.3 — pieces in the unpack phase, no s_setprio — are no longer instantiated.)
 template <int TYPE, bool TRACE = false, int OPT = 0>
 __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
-    constexpr bool EPI_BALANCED = false;
+    constexpr bool EPI_BALANCED = false, EPI_DIRECT = false;
     typedef WStage<TYPE, 2> WSt;
     constexpr int BNF = 4, TB = 128, NST = 3;
     constexpr int RS = 256, XS = TB * RS;
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
 // k_gemm_kq_w8 with a CROSS-STAGE software pipeline (same tile, ring, DMA and epilogue; see the comment at the main loop).
 template <int TYPE, bool TRACE = false>
 __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
-    constexpr bool EPI_BALANCED = false;
+    constexpr bool EPI_BALANCED = false, EPI_DIRECT = false;
     typedef WStage<TYPE, 2> WSt;
     constexpr int BNF = 4, TB = 128, NST = 3;
     constexpr int RS = 256, XS = TB * RS;
@@ -822,13 +822,13 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
 // Bits 4-8 are timing-only ABLATIONS (results are garbage; instantiated only under -DCDNA4_ABLATIONS for
 // tools/microbench/gemm_bench): 16 loaders skip the activation pieces in the main loop, 32 loaders issue no DMA at all in
 // the main loop, 64 compute waves skip the activation ds_reads in the main loop, 128 no unpack arithmetic (raw bits go to
-// the MFMA), 256 no s_barrier in the main loop, 512 (not an ablation) block 0 records the shader clock.  bit1 (results bit-identical, ablation builds only): balanced epilogue.
+// the MFMA), 256 no s_barrier in the main loop, 512 (not an ablation) block 0 records the shader clock.  bit1 / bit2 (results bit-identical, ablation builds only): balanced epilogue / stores straight from registers.
 template <int TYPE, bool USE_TAB = true, int EXP = 0>
 __global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
     constexpr bool TRACE = false;
     constexpr bool EARLY_TAB = (EXP & 1) != 0, A_NOX = (EXP & 16) != 0, A_NODMA = (EXP & 32) != 0, A_NOXREAD = (EXP & 64) != 0,
                    A_NOUNPACK = (EXP & 128) != 0 && TYPE == CDNA4_Q4_K, A_NOBAR = (EXP & 256) != 0;
-    constexpr bool EPI_BALANCED = (EXP & 2) != 0;   // epilogue experiment: see gemm_w8_epilogue.inc
+    constexpr bool EPI_BALANCED = (EXP & 2) != 0, EPI_DIRECT = (EXP & 4) != 0;   // epilogue experiments: see gemm_w8_epilogue.inc
     constexpr bool CLK = (EXP & 512) != 0;          // ablation builds: block 0 records s_memtime / s_memrealtime at entry and exit
     constexpr bool DIRECT = WDirect<TYPE>::value;   // weights re-laid by the loader lanes from the original blocks (no LDS-DMA for W)
     typedef WStage<TYPE, 2> WSt;
@@ -1568,7 +1568,7 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
 #define W12_EXP(E) case E: hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, E>), grid, dim3(768), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0;
             if (exp != 0 && !no_tab) switch (exp) {
 #ifdef CDNA4_ABLATIONS
-                W12_EXP(1) W12_EXP(2) W12_EXP(16) W12_EXP(32) W12_EXP(64) W12_EXP(128) W12_EXP(256) W12_EXP(96) W12_EXP(224) W12_EXP(480) W12_EXP(288) W12_EXP(512) W12_EXP(544) W12_EXP(992)
+                W12_EXP(1) W12_EXP(2) W12_EXP(4) W12_EXP(6) W12_EXP(16) W12_EXP(32) W12_EXP(64) W12_EXP(128) W12_EXP(256) W12_EXP(96) W12_EXP(224) W12_EXP(480) W12_EXP(288) W12_EXP(512) W12_EXP(544) W12_EXP(992)
 #endif
                 default: return cdna4_set_error_msg("gemm_q: this k_gemm_kq_w12 experiment is not built");
             }

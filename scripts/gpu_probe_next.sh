@@ -17,10 +17,10 @@ echo "== trace build of the first-cut kernel (variant 23) at this shape"
 GB_VARIANTS=4119 GB_SPLITKS=1 GB_ROUNDS=1 timeout 60 ./gemm_bench_abl 8192 8192 512 23 2>&1 | tail -4
 } > ../../gpurun_out/fault_8192.txt 2>&1
 cd ../..
-# (2b) candidates that must stay bit-identical (rel-L2 0 against the first config): early table read (EXP 1), balanced epilogue (EXP 2)
+# (2b) candidates that must stay bit-identical (rel-L2 0 against the first config): early table read (EXP 1), balanced epilogue (EXP 2), stores straight from registers (EXP 4), both (EXP 6)
 cd tools/microbench
-{ GB_VARIANTS=4119,69655,135191 GB_SPLITKS=0,1 timeout 60 ./gemm_bench_abl 4096 4096 512 "" 2>&1 | tail -8
-  GB_VARIANTS=4119,135191 GB_SPLITKS=1 timeout 60 ./gemm_bench_abl 8192 4096 512 "" 2>&1 | tail -4; } > ../../gpurun_out/w12_candidates.txt 2>&1
+{ GB_VARIANTS=4119,69655,135191,266263,397335 GB_SPLITKS=0,1 timeout 60 ./gemm_bench_abl 4096 4096 512 "" 2>&1 | tail -12
+  GB_VARIANTS=4119,135191,266263,397335 GB_SPLITKS=1 timeout 60 ./gemm_bench_abl 8192 4096 512 "" 2>&1 | tail -6; } > ../../gpurun_out/w12_candidates.txt 2>&1
 # (2d) the experimental 4 + 4-wave 256x128 kernel (variant 8199) next to the default (rel-L2 must be ~1e-7): one shape per process,
 #      a short timeout each — a barrier mismatch in a first run would hang
 { for shape in "1024 1024 256" "4096 4096 512" "8192 4096 512" "32768 8192 512"; do
