@@ -6,6 +6,8 @@ mkdir -p gpurun_out
 cd tools/microbench
 # (1) the matrix-pipe price of the unpack mix, the clock the chip holds, and the sustained MFMA-only rate (random / zero data)
 timeout 120 ./mfma_valu 500 > ../../gpurun_out/mfma_valu.txt 2>&1
+# (1b) the floor of a one-launch 9.4 MB stream (the decode GEMV's denominator): empty-kernel launch cost, pure-load kernels
+timeout 120 ./launch_floor > ../../gpurun_out/launch_floor.txt 2>&1
 # (2) the GPU fault of the 8192x8192x512 sweep: one process per kernel, no trace kernels (argv[4] empty), line-buffered output
 {
 for v in 4119 2101271 31461399 23 2071 663; do
@@ -53,4 +55,4 @@ PY
 CDNA4_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gguf.py -q -m gpu -k upload > gpurun_out/experimental_tests.txt 2>&1
 CDNA4_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -k 4plus4 >> gpurun_out/experimental_tests.txt 2>&1
 tail -5 gpurun_out/experimental_tests.txt
-tail -2 gpurun_out/mfma_valu.txt; cut -c1-200 gpurun_out/w12_candidates.txt; cat gpurun_out/w12_clock.txt; cut -c1-200 gpurun_out/x4l.txt; cat gpurun_out/fault_8192.txt | cut -c1-200; cat gpurun_out/parity_8192.txt | tail -3
+tail -2 gpurun_out/mfma_valu.txt; cat gpurun_out/launch_floor.txt; cut -c1-200 gpurun_out/w12_candidates.txt; cat gpurun_out/w12_clock.txt; cut -c1-200 gpurun_out/x4l.txt; cat gpurun_out/fault_8192.txt | cut -c1-200; cat gpurun_out/parity_8192.txt | tail -3
