@@ -11,6 +11,7 @@
  * BIT-EXACT against the compiled reference (oracle/_ref, built by oracle/ref.mk) in
  * tests/test_oracle_vs_ref.py and against tests/golden/ fixtures generated from it.
  *
+ * Formats: the five of the HIP path (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K) and, ahead of their kernels, Q4_1, Q5_0, Q5_1, Q2_K, Q3_K.
  * Parity status: PINNED (bit-exact for quantize/dequantize rows, rel-L2 <= 2e-6 for mul_mat) against
  * the reference compiled here from /root/reference; the reference ships no stored golden vectors for
  * quantized MUL_MAT, so the fixtures under tests/golden/ were produced by running the
@@ -25,7 +26,8 @@
 #define K_SCALE_SIZE 12
 
 /* ggml type ids — include/ggml.h:351-390 */
-enum { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q8_0 = 8, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15 };
+enum { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q8_1 = 9, T_Q2_K = 10, T_Q3_K = 11,
+       T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15 };
 
 /* ---- block formats: src/ggml-common.h:161-328 ------------------------------------------------ */
 #pragma pack(push, 1)
@@ -35,6 +37,13 @@ typedef struct { uint16_t d, dmin; uint8_t scales[K_SCALE_SIZE]; uint8_t qs[QK_K
 typedef struct { uint16_t d, dmin; uint8_t scales[K_SCALE_SIZE]; uint8_t qh[QK_K / 8]; uint8_t qs[QK_K / 2]; } block_q5_K; /* :296-308 */
 typedef struct { uint8_t ql[QK_K / 2]; uint8_t qh[QK_K / 4]; int8_t scales[QK_K / 16]; uint16_t d; } block_q6_K; /* :314-320 */
 typedef struct { float d; int8_t qs[QK_K]; int16_t bsums[QK_K / 16]; } block_q8_K;            /* :323-328 */
+/* the formats of SURVEY.md 8(f) rank 4 (oracle only so far: no HIP kernels take them yet) */
+typedef struct { uint16_t d, m; uint8_t qs[16]; } block_q4_1;                                 /* :168-180 */
+typedef struct { uint16_t d; uint8_t qh[4]; uint8_t qs[16]; } block_q5_0;                     /* :182-188 */
+typedef struct { uint16_t d, m; uint8_t qh[4]; uint8_t qs[16]; } block_q5_1;                  /* :190-202 */
+typedef struct { uint16_t d, s; int8_t qs[32]; } block_q8_1;                                  /* :210-222 */
+typedef struct { uint8_t scales[QK_K / 16]; uint8_t qs[QK_K / 4]; uint16_t d, dmin; } block_q2_K; /* :247-260 */
+typedef struct { uint8_t hmask[QK_K / 8]; uint8_t qs[QK_K / 4]; uint8_t scales[12]; uint16_t d; } block_q3_K; /* :267-273 */
 #pragma pack(pop)
 
 /* ---- fp16 <-> fp32, IEEE round-to-nearest-even (semantics of GGML_FP32_TO_FP16 / _FP16_TO_FP32,
@@ -93,14 +102,16 @@ size_t oracle_type_size(int type) {      /* src/ggml.c type_traits table :568-..
         case T_Q4_0: return sizeof(block_q4_0); case T_Q8_0: return sizeof(block_q8_0);
         case T_Q4_K: return sizeof(block_q4_K); case T_Q5_K: return sizeof(block_q5_K);
         case T_Q6_K: return sizeof(block_q6_K); case T_Q8_K: return sizeof(block_q8_K);
+        case T_Q4_1: return sizeof(block_q4_1); case T_Q5_0: return sizeof(block_q5_0); case T_Q5_1: return sizeof(block_q5_1);
+        case T_Q8_1: return sizeof(block_q8_1); case T_Q2_K: return sizeof(block_q2_K); case T_Q3_K: return sizeof(block_q3_K);
     }
     return 0;
 }
 int oracle_blck_size(int type) {
     switch (type) {
         case T_F32: case T_F16: return 1;
-        case T_Q4_0: case T_Q8_0: return 32;
-        case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_Q8_K: return QK_K;
+        case T_Q4_0: case T_Q8_0: case T_Q4_1: case T_Q5_0: case T_Q5_1: case T_Q8_1: return 32;
+        case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_Q8_K: case T_Q2_K: case T_Q3_K: return QK_K;
     }
     return 0;
 }
@@ -184,11 +195,84 @@ void oracle_dequantize_row_q8_K(const void *vx, float *y, int64_t k) {
     for (int64_t i = 0; i < k / QK_K; i++)
         for (int j = 0; j < QK_K; ++j) *y++ = x[i].d * x[i].qs[j];
 }
+/* src/ggml-quants.c:275-293 */
+void oracle_dequantize_row_q4_1(const void *vx, float *y, int64_t k) {
+    const block_q4_1 *x = vx;
+    for (int64_t i = 0; i < k / 32; i++) {
+        const float d = fp16_to_fp32(x[i].d), m = fp16_to_fp32(x[i].m);
+        for (int j = 0; j < 16; ++j) { y[i * 32 + j] = (x[i].qs[j] & 0x0F) * d + m; y[i * 32 + j + 16] = (x[i].qs[j] >> 4) * d + m; }
+    }
+}
+/* the fifth bits of a 32-block: bit j of qh belongs to weight j (low half: j < 16 -> nibble j; high half: j + 16) */
+static inline uint32_t load_qh(const uint8_t *qh) { uint32_t v; memcpy(&v, qh, 4); return v; }
+/* src/ggml-quants.c:295-319 */
+void oracle_dequantize_row_q5_0(const void *vx, float *y, int64_t k) {
+    const block_q5_0 *x = vx;
+    for (int64_t i = 0; i < k / 32; i++) {
+        const float d = fp16_to_fp32(x[i].d); const uint32_t qh = load_qh(x[i].qh);
+        for (int j = 0; j < 16; ++j) {
+            const int x0 = ((x[i].qs[j] & 0x0F) | (((qh >> j) & 1) << 4)) - 16, x1 = ((x[i].qs[j] >> 4) | (((qh >> (j + 16)) & 1) << 4)) - 16;
+            y[i * 32 + j] = x0 * d; y[i * 32 + j + 16] = x1 * d;
+        }
+    }
+}
+/* src/ggml-quants.c:321-347 */
+void oracle_dequantize_row_q5_1(const void *vx, float *y, int64_t k) {
+    const block_q5_1 *x = vx;
+    for (int64_t i = 0; i < k / 32; i++) {
+        const float d = fp16_to_fp32(x[i].d), m = fp16_to_fp32(x[i].m); const uint32_t qh = load_qh(x[i].qh);
+        for (int j = 0; j < 16; ++j) {
+            const int x0 = (x[i].qs[j] & 0x0F) | (((qh >> j) & 1) << 4), x1 = (x[i].qs[j] >> 4) | (((qh >> (j + 16)) & 1) << 4);
+            y[i * 32 + j] = x0 * d + m; y[i * 32 + j + 16] = x1 * d + m;
+        }
+    }
+}
+/* src/ggml-quants.c:712-744: sixteen 16-weight sub-blocks, scales[] = 4-bit scale | 4-bit min << 4; within each 128-half the
+ * 2-bit fields of 32 bytes are walked shift 0,2,4,6, each shift covering two sub-blocks (bytes 0-15, 16-31) */
+void oracle_dequantize_row_q2_K(const void *vx, float *y, int64_t k) {
+    const block_q2_K *x = vx;
+    for (int64_t i = 0; i < k / QK_K; i++) {
+        const float d = fp16_to_fp32(x[i].d), dmin = fp16_to_fp32(x[i].dmin);
+        for (int n = 0; n < 2; n++)
+            for (int sh = 0; sh < 4; sh++)
+                for (int half = 0; half < 2; half++) {
+                    const uint8_t sc = x[i].scales[n * 8 + sh * 2 + half];
+                    const float dl = d * (sc & 0xF), ml = dmin * (sc >> 4);
+                    const uint8_t *q = x[i].qs + 32 * n + 16 * half;
+                    for (int l = 0; l < 16; ++l) *y++ = dl * ((int8_t)((q[l] >> (2 * sh)) & 3)) - ml;
+                }
+    }
+}
+/* the sixteen 6-bit scales of a Q3_K superblock: low 4 bits in scales[0..7] (two per byte), high 2 bits in scales[8..11]
+ * (the aux/kmask shuffle of src/ggml-quants.c:1072-1077, written out per index) */
+static inline int q3_scale(const uint8_t *sc, int j) {
+    const int lo = j < 8 ? (sc[j] & 0xF) : (sc[j - 8] >> 4);
+    const int hi = (sc[8 + (j & 3)] >> (2 * (j >> 2))) & 3;
+    return (lo | (hi << 4)) - 32;
+}
+/* src/ggml-quants.c:1056-1104 */
+void oracle_dequantize_row_q3_K(const void *vx, float *y, int64_t k) {
+    const block_q3_K *x = vx;
+    for (int64_t i = 0; i < k / QK_K; i++) {
+        const float d_all = fp16_to_fp32(x[i].d);
+        for (int n = 0; n < 2; n++)
+            for (int sh = 0; sh < 4; sh++)
+                for (int half = 0; half < 2; half++) {
+                    const float dl = d_all * q3_scale(x[i].scales, n * 8 + sh * 2 + half);
+                    const uint8_t *q = x[i].qs + 32 * n + 16 * half, *hm = x[i].hmask + 16 * half;
+                    const uint8_t m = (uint8_t)(1u << (4 * n + sh));
+                    for (int l = 0; l < 16; ++l) *y++ = dl * ((int8_t)((q[l] >> (2 * sh)) & 3) - ((hm[l] & m) ? 0 : 4));
+                }
+    }
+}
 void oracle_dequantize_row(int type, const void *x, float *y, int64_t k) {
     switch (type) {
         case T_Q4_0: oracle_dequantize_row_q4_0(x, y, k); break; case T_Q8_0: oracle_dequantize_row_q8_0(x, y, k); break;
         case T_Q4_K: oracle_dequantize_row_q4_K(x, y, k); break; case T_Q5_K: oracle_dequantize_row_q5_K(x, y, k); break;
         case T_Q6_K: oracle_dequantize_row_q6_K(x, y, k); break; case T_Q8_K: oracle_dequantize_row_q8_K(x, y, k); break;
+        case T_Q4_1: oracle_dequantize_row_q4_1(x, y, k); break; case T_Q5_0: oracle_dequantize_row_q5_0(x, y, k); break;
+        case T_Q5_1: oracle_dequantize_row_q5_1(x, y, k); break; case T_Q2_K: oracle_dequantize_row_q2_K(x, y, k); break;
+        case T_Q3_K: oracle_dequantize_row_q3_K(x, y, k); break;
         case T_F32: memcpy(y, x, (size_t)k * 4); break;
         case T_F16: for (int64_t i = 0; i < k; i++) y[i] = fp16_to_fp32(((const uint16_t *)x)[i]); break;
     }
@@ -232,6 +316,21 @@ void oracle_quantize_row_q8_0_cpu(const float *x, void *vy, int64_t k) {
         y[i].d = fp32_to_fp16(d);
         const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
         for (int j = 0; j < 32; ++j) y[i].qs[j] = (int8_t)(int)nearbyintf(x[i * 32 + j] * id);  /* RNE */
+    }
+}
+/* src/ggml-cpu/ggml-cpu-quants.c:1076-1119 — the AVX2 body the CPU backend runs for the activations of Q4_1 / Q5_1 weights:
+ * as q8_0_cpu, plus s = fp16(d * sum of the quants) with d still in fp32 */
+void oracle_quantize_row_q8_1_cpu(const float *x, void *vy, int64_t k) {
+    block_q8_1 *y = vy;
+    for (int64_t i = 0; i < k / 32; i++) {
+        float amax = 0.0f;
+        for (int j = 0; j < 32; j++) amax = MAX(amax, fabsf(x[i * 32 + j]));
+        const float d = amax / 127.f;
+        y[i].d = fp32_to_fp16(d);
+        const float id = (amax != 0.0f) ? 127.f / amax : 0.0f;
+        int sum = 0;
+        for (int j = 0; j < 32; ++j) { const int q = (int)nearbyintf(x[i * 32 + j] * id); y[i].qs[j] = (int8_t)q; sum += q; }
+        y[i].s = fp32_to_fp16(d * (float)sum);
     }
 }
 /* src/ggml-quants.c:2479-2516 (quantize_row_q8_K == _ref, src/ggml-cpu/ggml-cpu-quants.c:1646-1648) */
@@ -362,19 +461,114 @@ float oracle_vec_dot_q6_K_q8_K(int n, const void *vx, const void *vy) {
     return sumf;
 }
 
+/* src/ggml-cpu/ggml-cpu-quants.c:2585-2601 */
+float oracle_vec_dot_q4_1_q8_1(int n, const void *vx, const void *vy) {
+    const block_q4_1 *x = vx; const block_q8_1 *y = vy; float sumf = 0;
+    for (int ib = 0; ib < n / 32; ++ib) {
+        int sumi0 = 0, sumi1 = 0;
+        for (int j = 0; j < 16; ++j) { sumi0 += (x[ib].qs[j] & 0x0F) * y[ib].qs[j]; sumi1 += (x[ib].qs[j] >> 4) * y[ib].qs[j + 16]; }
+        sumf += (fp16_to_fp32(x[ib].d) * fp16_to_fp32(y[ib].d)) * (sumi0 + sumi1) + fp16_to_fp32(x[ib].m) * fp16_to_fp32(y[ib].s);
+    }
+    return sumf;
+}
+/* src/ggml-cpu/ggml-cpu-quants.c:2935-2957 */
+float oracle_vec_dot_q5_0_q8_0(int n, const void *vx, const void *vy) {
+    const block_q5_0 *x = vx; const block_q8_0 *y = vy; float sumf = 0;
+    for (int ib = 0; ib < n / 32; ++ib) {
+        const uint32_t qh = load_qh(x[ib].qh);
+        int sumi0 = 0, sumi1 = 0;
+        for (int j = 0; j < 16; ++j) {
+            const int x0 = ((x[ib].qs[j] & 0x0F) | (((qh >> j) & 1) << 4)) - 16, x1 = ((x[ib].qs[j] >> 4) | (((qh >> (j + 16)) & 1) << 4)) - 16;
+            sumi0 += x0 * y[ib].qs[j]; sumi1 += x1 * y[ib].qs[j + 16];
+        }
+        sumf += (fp16_to_fp32(x[ib].d) * fp16_to_fp32(y[ib].d)) * (sumi0 + sumi1);
+    }
+    return sumf;
+}
+/* src/ggml-cpu/ggml-cpu-quants.c:3309-3331 */
+float oracle_vec_dot_q5_1_q8_1(int n, const void *vx, const void *vy) {
+    const block_q5_1 *x = vx; const block_q8_1 *y = vy; float sumf = 0;
+    for (int ib = 0; ib < n / 32; ++ib) {
+        const uint32_t qh = load_qh(x[ib].qh);
+        int sumi0 = 0, sumi1 = 0;
+        for (int j = 0; j < 16; ++j) {
+            const int x0 = (x[ib].qs[j] & 0x0F) | (((qh >> j) & 1) << 4), x1 = (x[ib].qs[j] >> 4) | (((qh >> (j + 16)) & 1) << 4);
+            sumi0 += x0 * y[ib].qs[j]; sumi1 += x1 * y[ib].qs[j + 16];
+        }
+        sumf += (fp16_to_fp32(x[ib].d) * fp16_to_fp32(y[ib].d)) * (sumi0 + sumi1) + fp16_to_fp32(x[ib].m) * fp16_to_fp32(y[ib].s);
+    }
+    return sumf;
+}
+/* src/ggml-cpu/ggml-cpu-quants.c:4725-4764 */
+float oracle_vec_dot_q2_K_q8_K(int n, const void *vx, const void *vy) {
+    const block_q2_K *x = vx; const block_q8_K *y = vy; float sumf = 0;
+    for (int i = 0; i < n / QK_K; ++i) {
+        const uint8_t *sc = x[i].scales; const int8_t *q8 = y[i].qs;
+        int summs = 0;
+        for (int j = 0; j < 16; ++j) summs += y[i].bsums[j] * (sc[j] >> 4);
+        const float dall = y[i].d * fp16_to_fp32(x[i].d), dmin = y[i].d * fp16_to_fp32(x[i].dmin);
+        int isum = 0;
+        for (int nn = 0; nn < 2; nn++)
+            for (int sh = 0; sh < 4; sh++)
+                for (int half = 0; half < 2; half++) {
+                    const uint8_t *q2 = x[i].qs + 32 * nn + 16 * half;
+                    int isuml = 0;
+                    for (int l = 0; l < 16; ++l) isuml += q8[l] * ((q2[l] >> (2 * sh)) & 3);
+                    isum += (sc[nn * 8 + sh * 2 + half] & 0xF) * isuml;
+                    q8 += 16;
+                }
+        sumf += dall * isum - dmin * summs;
+    }
+    return sumf;
+}
+/* src/ggml-cpu/ggml-cpu-quants.c:5482-5545: integer sums in eight lanes (lane = position & 7), scaled per superblock into eight
+ * float partial sums that are added at the very end */
+float oracle_vec_dot_q3_K_q8_K(int n, const void *vx, const void *vy) {
+    const block_q3_K *x = vx; const block_q8_K *y = vy;
+    float sums[8] = {0};
+    for (int i = 0; i < n / QK_K; ++i) {
+        int32_t aux32[8] = {0};
+        const int8_t *q8 = y[i].qs;
+        for (int nn = 0; nn < 2; nn++)
+            for (int sh = 0; sh < 4; sh++)
+                for (int half = 0; half < 2; half++) {
+                    const int scale = q3_scale(x[i].scales, nn * 8 + sh * 2 + half);
+                    const uint8_t *q3 = x[i].qs + 32 * nn + 16 * half, *hm = x[i].hmask + 16 * half;
+                    const uint8_t m = (uint8_t)(1u << (4 * nn + sh));
+                    for (int l = 0; l < 16; ++l) {
+                        const int a = (int)((q3[l] >> (2 * sh)) & 3) - ((hm[l] & m) ? 0 : 4);
+                        aux32[l & 7] += scale * (int16_t)(q8[l] * a);
+                    }
+                    q8 += 16;
+                }
+        const float d = fp16_to_fp32(x[i].d) * y[i].d;
+        for (int l = 0; l < 8; ++l) sums[l] += d * aux32[l];
+    }
+    float sumf = 0;
+    for (int l = 0; l < 8; ++l) sumf += sums[l];
+    return sumf;
+}
+
 /* type_traits_cpu[]: weight type -> (vec_dot, vec_dot_type) — src/ggml-cpu/ggml-cpu.c:253-418 */
 int oracle_vec_dot_type(int type) {
-    switch (type) { case T_Q4_0: case T_Q8_0: return T_Q8_0; case T_Q4_K: case T_Q5_K: case T_Q6_K: return T_Q8_K; }
+    switch (type) {
+        case T_Q4_0: case T_Q8_0: case T_Q5_0: return T_Q8_0; case T_Q4_1: case T_Q5_1: return T_Q8_1;
+        case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_Q2_K: case T_Q3_K: return T_Q8_K;
+    }
     return -1;
 }
 void oracle_quantize_act(int wtype, const float *x, void *y, int64_t k) {
-    if (oracle_vec_dot_type(wtype) == T_Q8_0) oracle_quantize_row_q8_0_cpu(x, y, k); else oracle_quantize_row_q8_K(x, y, k);
+    const int at = oracle_vec_dot_type(wtype);
+    if (at == T_Q8_0) oracle_quantize_row_q8_0_cpu(x, y, k); else if (at == T_Q8_1) oracle_quantize_row_q8_1_cpu(x, y, k); else oracle_quantize_row_q8_K(x, y, k);
 }
 float oracle_vec_dot(int wtype, int n, const void *vx, const void *vy) {
     switch (wtype) {
         case T_Q4_0: return oracle_vec_dot_q4_0_q8_0(n, vx, vy); case T_Q8_0: return oracle_vec_dot_q8_0_q8_0(n, vx, vy);
         case T_Q4_K: return oracle_vec_dot_q4_K_q8_K(n, vx, vy); case T_Q5_K: return oracle_vec_dot_q5_K_q8_K(n, vx, vy);
         case T_Q6_K: return oracle_vec_dot_q6_K_q8_K(n, vx, vy);
+        case T_Q4_1: return oracle_vec_dot_q4_1_q8_1(n, vx, vy); case T_Q5_0: return oracle_vec_dot_q5_0_q8_0(n, vx, vy);
+        case T_Q5_1: return oracle_vec_dot_q5_1_q8_1(n, vx, vy); case T_Q2_K: return oracle_vec_dot_q2_K_q8_K(n, vx, vy);
+        case T_Q3_K: return oracle_vec_dot_q3_K_q8_K(n, vx, vy);
     }
     return NAN;
 }

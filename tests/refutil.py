@@ -10,9 +10,11 @@ REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 
 # ggml type ids (include/ggml.h:351-390)
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 8, 12, 13, 14, 15
-QUANT_TYPES = {"q4_0": Q4_0, "q8_0": Q8_0, "q4_K": Q4_K, "q5_K": Q5_K, "q6_K": Q6_K}
-TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292}
-BLCK = {F32: 1, F16: 1, Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256}
+Q4_1, Q5_0, Q5_1, Q8_1, Q2_K, Q3_K = 3, 6, 7, 9, 10, 11        # oracle only so far: no HIP kernel takes them
+QUANT_TYPES = {"q4_0": Q4_0, "q8_0": Q8_0, "q4_K": Q4_K, "q5_K": Q5_K, "q6_K": Q6_K}          # the formats of the HIP path
+ORACLE_ONLY_TYPES = {"q4_1": Q4_1, "q5_0": Q5_0, "q5_1": Q5_1, "q2_K": Q2_K, "q3_K": Q3_K}
+TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292, Q4_1: 20, Q5_0: 22, Q5_1: 24, Q8_1: 36, Q2_K: 84, Q3_K: 110}
+BLCK = {F32: 1, F16: 1, Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256, Q4_1: 32, Q5_0: 32, Q5_1: 32, Q8_1: 32, Q2_K: 256, Q3_K: 256}
 
 
 def row_size(t, k):
@@ -49,10 +51,15 @@ def o_dequantize(t, wbytes, k):
     return y
 
 
+def act_type(wtype):
+    """type_traits_cpu[wtype].vec_dot_type (src/ggml-cpu/ggml-cpu.c:253-418)"""
+    return Q8_0 if wtype in (Q4_0, Q8_0, Q5_0) else (Q8_1 if wtype in (Q4_1, Q5_1) else Q8_K)
+
+
 def o_quantize_act(wtype, x):
     """activation quantization exactly as the CPU backend does for a weight of type wtype"""
     x = np.ascontiguousarray(x, np.float32)
-    at = Q8_0 if wtype in (Q4_0, Q8_0) else Q8_K
+    at = act_type(wtype)
     b, k = x.shape
     out = np.zeros((b, row_size(at, k)), np.uint8)
     for r in range(b):
@@ -130,7 +137,8 @@ def r_quantize(t, x):
 
 
 _DEQ = {Q4_0: "dequantize_row_q4_0", Q8_0: "dequantize_row_q8_0", Q4_K: "dequantize_row_q4_K",
-        Q5_K: "dequantize_row_q5_K", Q6_K: "dequantize_row_q6_K", Q8_K: "dequantize_row_q8_K"}
+        Q5_K: "dequantize_row_q5_K", Q6_K: "dequantize_row_q6_K", Q8_K: "dequantize_row_q8_K",
+        Q4_1: "dequantize_row_q4_1", Q5_0: "dequantize_row_q5_0", Q5_1: "dequantize_row_q5_1", Q2_K: "dequantize_row_q2_K", Q3_K: "dequantize_row_q3_K"}
 
 
 def r_dequantize(t, wbytes, k):
@@ -146,10 +154,14 @@ def r_quantize_act(wtype, x):
     base, cpu = ref()
     x = np.ascontiguousarray(x, np.float32)
     b, k = x.shape
-    if wtype in (Q4_0, Q8_0):
+    if act_type(wtype) == Q8_0:
         out = np.zeros((b, row_size(Q8_0, k)), np.uint8)
         for r in range(b):
             cpu.quantize_row_q8_0(_p(x[r]), _p(out[r]), C.c_int64(k))
+    elif act_type(wtype) == Q8_1:
+        out = np.zeros((b, row_size(Q8_1, k)), np.uint8)
+        for r in range(b):
+            cpu.quantize_row_q8_1(_p(x[r]), _p(out[r]), C.c_int64(k))
     else:
         out = np.zeros((b, row_size(Q8_K, k)), np.uint8)
         for r in range(b):
@@ -158,7 +170,8 @@ def r_quantize_act(wtype, x):
 
 
 _VD = {Q4_0: "ggml_vec_dot_q4_0_q8_0", Q8_0: "ggml_vec_dot_q8_0_q8_0", Q4_K: "ggml_vec_dot_q4_K_q8_K",
-       Q5_K: "ggml_vec_dot_q5_K_q8_K", Q6_K: "ggml_vec_dot_q6_K_q8_K"}
+       Q5_K: "ggml_vec_dot_q5_K_q8_K", Q6_K: "ggml_vec_dot_q6_K_q8_K", Q4_1: "ggml_vec_dot_q4_1_q8_1", Q5_0: "ggml_vec_dot_q5_0_q8_0",
+       Q5_1: "ggml_vec_dot_q5_1_q8_1", Q2_K: "ggml_vec_dot_q2_K_q8_K", Q3_K: "ggml_vec_dot_q3_K_q8_K"}
 
 
 def r_mul_mat(t, w, x, m, k):

@@ -7,6 +7,7 @@ import refutil as R
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "mul_mat_small.npz"))
 GID = np.load(os.path.join(os.path.dirname(__file__), "golden", "mul_mat_id_small.npz"))
+GM = np.load(os.path.join(os.path.dirname(__file__), "golden", "mul_mat_more_formats.npz"))       # Q4_1 / Q5_0 / Q5_1 / Q2_K / Q3_K (oracle only so far)
 M, K, B = int(G["M"]), int(G["K"]), int(G["B"])
 
 
@@ -48,3 +49,18 @@ def test_mul_mat_id_broadcast_b():
     y = R.o_mul_mat_id(t, GID["q4_K_w"], x, GID["ids"], int(GID["M"]), int(GID["K"]), int(GID["n_expert"]))
     y2 = R.o_mul_mat_id(t, GID["q4_K_w"], np.repeat(x, int(GID["n_used"]), axis=1), GID["ids"], int(GID["M"]), int(GID["K"]), int(GID["n_expert"]))
     assert np.array_equal(y, y2)
+
+
+@pytest.mark.parametrize("name", list(R.ORACLE_ONLY_TYPES))
+def test_more_formats_golden(name):
+    """the formats no HIP kernel takes yet: dequantize and the activation quantizer bit-exact,
+    MUL_MAT to summation order, against fixtures from the unmodified reference"""
+    t = R.ORACLE_ONLY_TYPES[name]
+    assert np.array_equal(R.o_dequantize(t, GM[name + "_w"], K).view(np.uint32), GM[name + "_deq"].view(np.uint32))
+    a, b = R.o_quantize_act(t, GM[name + "_x"]), GM[name + "_act"]
+    if R.act_type(t) == R.Q8_K:             # all-zero Q8_K blocks: the reference leaves bsums unwritten
+        a = a.reshape(B, -1, 292).copy(); b = b.reshape(B, -1, 292).copy()
+        z = np.all(b[:, :, 0:260] == 0, axis=2)
+        a[z, 260:] = 0; b[z, 260:] = 0
+    assert np.array_equal(a, b)
+    assert R.rel_l2(R.o_mul_mat(t, GM[name + "_w"], GM[name + "_x"], M, K), GM[name + "_y"]) < 2e-6

@@ -8,7 +8,7 @@ import refutil as R
 
 pytestmark = pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
 
-WT = [R.Q4_0, R.Q8_0, R.Q4_K, R.Q5_K, R.Q6_K]
+WT = [R.Q4_0, R.Q8_0, R.Q4_K, R.Q5_K, R.Q6_K] + list(R.ORACLE_ONLY_TYPES.values())     # the HIP formats + the oracle-only ones
 
 
 def _data(seed, shape, kind):
@@ -33,7 +33,7 @@ def test_dequantize_bit_exact(t):
 
 
 @pytest.mark.parametrize("kind", ["uniform", "normal", "cos", "ties"])
-@pytest.mark.parametrize("t", [R.Q4_0, R.Q4_K])
+@pytest.mark.parametrize("t", [R.Q4_0, R.Q4_K, R.Q4_1])        # one weight type per activation format: Q8_0, Q8_K, Q8_1
 def test_activation_quantize_bit_exact(t, kind):
     x = _data(7, (16, 2048), kind)
     x[3, 256:512] = 0.0          # an all-zero block
