@@ -13,6 +13,8 @@ Multi-GPU: the weight rows (output features) are sharded over ranks as the refer
 [4096N x 4096] matrix); the output stays sharded (the consumer of a row-split layer is the next K-split layer),
 so the timed data path has no collective; an RCCL all-gather of the output shards is timed separately and
 reported as "with_allgather".
+The decode step is also timed as 64 nodes of a replayed HIP graph ("decode.hipgraph", computed in a child process so that it
+cannot affect the main line; added without a GPU at hand — an "error" field there means the leg failed, nothing else).
 The oracle/ reference is used only for the cpu_baseline leg (rank 0, N=1), never inside the timed region.
 """
 import argparse
@@ -144,6 +146,50 @@ def format_rows(L, native, ops, dev, stream, x, steps):
     return rows
 
 
+def decode_graph_leg():
+    """`bench.py --decode-graph` (a CHILD process of the main run, so that nothing here can take the main JSON line down):
+    the B = 1 decode step as it runs inside a captured graph — 64 one-launch GEMVs over 64 rotating matrices (604 MB > the
+    Infinity Cache) captured once into a HIP graph and replayed, the way ggml-cuda runs decode
+    (src/ggml-cuda/ggml-cuda.cu:2353-2406).  Prints one JSON object."""
+    from ggml_amd import native, ops
+    L = native.lib()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ncopy = 64
+    a = ops.QTensor.from_host_bytes(Q4_K, K, M_PER_GPU, synth_q4k(M_PER_GPU, K, 1234), device=dev)
+    big = torch.from_numpy(np.tile(a.data.cpu().numpy().reshape(-1), ncopy)).to(dev)
+    row_b, mat_b = a.row_bytes, a.row_bytes * M_PER_GPU
+    x1 = torch.from_numpy(np.random.default_rng(4321).uniform(-1, 1, (1, K)).astype(np.float32)).to(dev)
+    y1 = torch.empty((1, M_PER_GPU), dtype=torch.float32, device=dev)
+    ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(Q4_K, K, 1), dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream(device=dev)
+
+    def fused(i):
+        native.check(L.ggml_cdna4_mul_mat(Q4_K, big.data_ptr() + (i % ncopy) * mat_b, row_b, x1.data_ptr(), K, y1.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1,
+                                          ws.data_ptr(), ws.numel(), 0, 0, 0, torch.cuda.current_stream(dev).cuda_stream))
+    with torch.cuda.stream(st):
+        for i in range(ncopy):
+            fused(i)
+    torch.cuda.synchronize(dev)
+    y_eager = y1.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        for i in range(ncopy):
+            fused(i)
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize(dev)
+    same = bool(torch.equal(y1, y_eager))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 50
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record(); e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * ncopy)
+    print(json.dumps({"us_per_step_hipgraph": round(us, 3), "nodes_per_graph": ncopy, "same_result_as_stream_launches": same}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +198,10 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--splitk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode-graph", action="store_true", help="internal: run only the HIP-graph decode leg and print its JSON")
     args = ap.parse_args()
+    if args.decode_graph:
+        return decode_graph_leg()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -284,6 +333,20 @@ def main():
                                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                                           "traffic": pmc_traffic("k_gemv_q<12, 1"), "algorithmic_bytes_per_launch": alg_bytes}}}
         del big
+        # the same decode step replayed from a captured HIP graph (how a decode loop launches it), in a child process: a failure
+        # there is recorded, never propagated
+        if world == 1:
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--decode-graph"], capture_output=True, text=True, timeout=240)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                hg = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:]}
+            except Exception as e:          # noqa: BLE001 — any failure of the optional leg is data, not an error of the run
+                hg = {"error": repr(e)[:300]}
+            if "us_per_step_hipgraph" in hg:
+                gb = fused_bytes / (hg["us_per_step_hipgraph"] * 1e-6) / 1e9
+                hg["roofline"] = {"bound": "hbm", "kernel": "k_gemv_q_fused<Q4_K>, launched from a HIP graph", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(gb / HBM_PEAK_GBS, 4)}
+            out["decode"]["hipgraph"] = hg
         out["formats"] = format_rows(L, native, ops, dev, stream, x, max(50, min(args.steps, 200)))
 
     # ---- the exchange step of a row-split layer, timed separately: all-gather of the output shards ------------
