@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 int cdna4_set_error_msg(const char *msg);          // capi.hip (thread-local message behind ggml_cdna4_last_error())
@@ -100,6 +101,9 @@ struct ggml_cdna4_gguf {
     size_t alignment = kDefaultAlignment, data_offset = 0, data_size = 0;
     std::vector<KV> kv;
     std::vector<TensorInfo> info;
+    // name -> index: the duplicate checks and the find_* getters are O(1) (the reference scans linearly, which makes a header
+    // with millions of keys quadratic)
+    std::unordered_map<std::string, int64_t> kv_index, tensor_index;
     ~ggml_cdna4_gguf() {
         if (map) munmap(const_cast<uint8_t *>(map), file_size);
         if (fd >= 0) close(fd);
@@ -109,8 +113,8 @@ struct ggml_cdna4_gguf {
 namespace {
 
 int64_t find_key(const ggml_cdna4_gguf *g, const std::string &key) {
-    for (size_t i = 0; i < g->kv.size(); i++) if (g->kv[i].key == key) return (int64_t)i;
-    return -1;
+    const auto it = g->kv_index.find(key);
+    return it == g->kv_index.end() ? -1 : it->second;
 }
 
 // one key/value pair at the cursor (src/gguf.cpp:400-459)
@@ -139,6 +143,7 @@ bool read_kv(Cursor &c, ggml_cdna4_gguf *g, int64_t i) {
         c.take(kv.data.data(), kv.data.size());
         if (type == GGML_CDNA4_GGUF_BOOL) for (auto &b : kv.data) b = b != 0;      // gguf_reader::read(bool &), src/gguf.cpp:232-239
     }
+    g->kv_index.emplace(kv.key, (int64_t)g->kv.size());
     g->kv.push_back(std::move(kv));
     return true;
 }
@@ -150,7 +155,7 @@ bool read_tensor_info(Cursor &c, ggml_cdna4_gguf *g, int64_t i) {
     if (t.name.size() >= kMaxName) return fail("gguf: tensor name %" PRId64 " is too long: %zu >= %zu", i, t.name.size(), kMaxName), false;
     // the reference keeps names in a char[64] and compares them as C strings: an embedded NUL ends the name
     t.name.resize(strlen(t.name.c_str()));
-    for (const auto &o : g->info) if (o.name == t.name) return fail("gguf: duplicate tensor name '%s'", t.name.c_str()), false;
+    if (g->tensor_index.count(t.name)) return fail("gguf: duplicate tensor name '%s'", t.name.c_str()), false;
     uint32_t n_dims;
     if (!c.get(n_dims)) return fail("gguf: file ends inside the shape of tensor '%s'", t.name.c_str()), false;
     if (n_dims > (uint32_t)kMaxDims) return fail("gguf: tensor '%s' has invalid number of dimensions: %u > %d", t.name.c_str(), n_dims, kMaxDims), false;
@@ -176,6 +181,7 @@ bool read_tensor_info(Cursor &c, ggml_cdna4_gguf *g, int64_t i) {
     if (blck == 1) { t.nbytes = tsz; for (int j = 0; j < kMaxDims; j++) t.nbytes += (size_t)(t.ne[j] - 1) * nb[j]; }
     else { t.nbytes = (size_t)t.ne[0] * nb[0] / (size_t)blck; for (int j = 1; j < kMaxDims; j++) t.nbytes += (size_t)(t.ne[j] - 1) * nb[j]; }
     if (!c.get(t.offset)) return fail("gguf: file ends inside the offset of tensor '%s'", t.name.c_str()), false;
+    g->tensor_index.emplace(t.name, (int64_t)g->info.size());
     g->info.push_back(std::move(t));
     return true;
 }
@@ -300,8 +306,8 @@ const char *ggml_cdna4_gguf_arr_str(const ggml_cdna4_gguf *g, int64_t id, size_t
 int64_t ggml_cdna4_gguf_n_tensors(const ggml_cdna4_gguf *g) { return (int64_t)g->info.size(); }
 int64_t ggml_cdna4_gguf_find_tensor(const ggml_cdna4_gguf *g, const char *name) {
     if (!name) return -1;
-    for (size_t i = 0; i < g->info.size(); i++) if (g->info[i].name == name) return (int64_t)i;
-    return -1;
+    const auto it = g->tensor_index.find(name);
+    return it == g->tensor_index.end() ? -1 : it->second;
 }
 const char *ggml_cdna4_gguf_tensor_name(const ggml_cdna4_gguf *g, int64_t id) { const TensorInfo *t = ti_at(g, id); return t ? t->name.c_str() : nullptr; }
 int ggml_cdna4_gguf_tensor_type(const ggml_cdna4_gguf *g, int64_t id) { const TensorInfo *t = ti_at(g, id); return t ? t->type : -1; }

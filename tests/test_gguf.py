@@ -263,3 +263,18 @@ def test_gguf_upload_through_pinned_staging(gg, tmp_path):
             assert np.array_equal(dst.cpu().numpy(), ref), name
         with pytest.raises(gg.GGUFError, match="too small"):
             f.upload("big", torch.zeros(16, dtype=torch.uint8, device="cuda"))
+
+
+def test_header_with_many_keys_opens_in_linear_time(gg, tmp_path):
+    """duplicate detection and find_key are hashed: 200,000 keys open in well under a second (a linear scan per key, as in the
+    reference, would be 2e10 string compares)"""
+    import time
+    p = str(tmp_path / "many.gguf")
+    open(p, "wb").write(G.py_serialize([("k%06d" % i, "u32", i) for i in range(200000)], []))
+    L = gg._lib()
+    t0 = time.time()
+    h = L.ggml_cdna4_gguf_open(p.encode(), 1)
+    dt = time.time() - t0
+    assert h and L.ggml_cdna4_gguf_n_kv(h) == 200000 and L.ggml_cdna4_gguf_find_key(h, b"k199999") == 199999
+    L.ggml_cdna4_gguf_close(h)
+    assert dt < 5.0, dt
