@@ -16,6 +16,7 @@
 //   * ring of 3 stages x 52 KB; split-K S in {1, 2, 4} with the symmetric exchange of k_gemm_kq_x2.
 // Same arithmetic per weight as every other Q4_K kernel here (Raw<Q4_K>::pairbits with the loaders' table), same k order.
 #include "gemm_q_common.h"
+#include "gemm_q_x4l_hw.h"
 
 template <int S>
 __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
     const int nsb = nsb_base + (ks < nsb_rem ? 1 : 0), sb0 = ks * nsb_base + (ks < nsb_rem ? ks : nsb_rem);
     const int nstage = nsb * 2;                           // >= 4 (the launcher guarantees two superblocks per work-group)
 
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+    const uint32_t lds0 = X4L_LDS_BASE(smem);
     const char *const xbase = (const char *)p.xh + ((int64_t)sb0 * 2 * p.B + b0) * 256;
     const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
 
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
         for (int r = 0; r < 2; r++) hoff[r] = (uint32_t)(min(m0 + lrow + 128 * r, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
 
         auto dma16 = [&](const char *sbase, uint32_t voff, uint32_t lds_addr) __attribute__((always_inline)) {
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+            X4L_DMA16(voff, sbase, lds_addr);
         };
         auto issue = [&](int st, int slot) __attribute__((always_inline)) {          // stage st = (superblock st >> 1, half st & 1)
             const uint32_t l = lds0 + slot * ST;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
         auto hload = [&](int sbr) __attribute__((always_inline)) {
             Hdr v; const char *sb = wbase + (int64_t)sbr * BLK;
 #pragma unroll
-            for (int r = 0; r < 2; r++) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v.r[r]) : "v"(hoff[r]), "s"(sb) : "memory");
+            for (int r = 0; r < 2; r++) X4L_GLOAD16(v.r[r], hoff[r], sb);
             return v;
         };
         auto tab_store = [&](const Hdr &hd, int part, int slot) __attribute__((always_inline)) {    // the arithmetic of Raw<Q4_K>::scales()
@@ -111,19 +112,19 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
         // prologue: stages 0, 1, 2 -> slots 0, 1, 2
         Hdr h0 = hload(0), hcur = hload(1);
         issue(0, 0); issue(1, 1); issue(2, 2);
-        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(h0.r[0]), "+v"(h0.r[1]), "+v"(hcur.r[0]), "+v"(hcur.r[1]) : "n"(3 * NLD) : "memory");   // the four header loads are older than the pieces
+        X4L_WAIT_VM_TIED4(3 * NLD, h0.r[0], h0.r[1], hcur.r[0], hcur.r[1]);   // the four header loads are older than the pieces
         tab_store(h0, 0, 0); tab_store(h0, 1, 1); tab_store(hcur, 0, 2);
-        wait_vmcnt<2 * NLD>();                                                   // stage 0 has landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        X4L_WAIT_VM(2 * NLD);                                                   // stage 0 has landed
+        X4L_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // barrier B_s (between k-steps 6 and 7 of stage s, s < nstage - 1): stage s + 1 landed, slot of stage s free -> stage s + 3
         int slot = 0;
         Hdr hnext = hcur;
         for (int s = 0; s + 1 < nstage; s++) {
-            if (s + 2 < nstage) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(hcur.r[0]), "+v"(hcur.r[1]), "+v"(hnext.r[0]), "+v"(hnext.r[1]) : "n"(NLD) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hcur.r[0]), "+v"(hcur.r[1]), "+v"(hnext.r[0]), "+v"(hnext.r[1]) : : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the table written last block is in LDS
+            if (s + 2 < nstage) X4L_WAIT_VM_TIED4(NLD, hcur.r[0], hcur.r[1], hnext.r[0], hnext.r[1]);
+            else X4L_WAIT_VM_TIED4(0, hcur.r[0], hcur.r[1], hnext.r[0], hnext.r[1]);
+            X4L_WAIT_LGKM0();                                                    // the table written last block is in LDS
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int st = s + 3;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
                 });
             }
             if (has_next) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's last reads of `slot` have returned
+                X4L_WAIT_LGKM0();                                                // this wave's last reads of `slot` have returned
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (((((mg * 2 + mb) * NBF + bl) * 4 + q4) * 64) + lane) * 16, 0, 16);
                             }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                X4L_WAIT_VM(0);
             }
             __syncthreads();
             if (tid == 0) {

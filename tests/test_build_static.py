@@ -90,3 +90,18 @@ def test_experimental_kernel_data_movement_emulation():
     spec.loader.exec_module(mod)
     assert mod.main(M=256, B=128, K=512, seed=1) < 1e-12
     assert mod.main(M=200, B=100, K=768, seed=2) < 1e-12          # ragged edges: clamped rows only add work, never wrong sums
+
+
+@pytest.mark.parametrize("m,k,b,splitk", [(256, 512, 128, 1), (300, 768, 200, 1), (513, 1024, 129, 2), (256, 2048, 128, 4), (700, 2560, 90, 4)])
+def test_experimental_kernel_source_runs_correctly_on_the_cpu(m, k, b, splitk):
+    """tools/emul: the C++ of k_gemm_q4k_x4l itself, compiled for the host and executed one OS thread per GPU thread (LDS-DMA
+    and waits made synchronous, v_mfma emulated lane for lane, one process per work-group so that the split-K exchange runs
+    between co-resident work-groups) reproduces a direct product of the same fp16 operands — loop bounds, loader vs compute
+    barrier counts (a mismatch would hang: timeout), indexing, ragged edges, uneven K splits, the 2- and 4-way exchange"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(m, k, b, seed=m + k, timeout=300, splitk=splitk) < 1e-6

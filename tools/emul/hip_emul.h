@@ -1,0 +1,88 @@
+// hip_emul.h — just enough of the HIP device environment to run a kernel's SOURCE on the host, one OS thread per GPU thread
+// (test infrastructure; see x4l_emul.cpp).  Include it FIRST: it pre-empts <hip/hip_runtime.h> (tools/emul/shim/hip/).
+// What is emulated faithfully: threadIdx / blockIdx, work-group barriers, LDS as ordinary memory, the lane layout and
+// arithmetic of v_mfma_f32_32x32x16_f16 (fp32 accumulate), plain loads / stores.  What is NOT: asynchrony (LDS-DMA and loads
+// complete immediately, so a missing wait cannot be detected), timing, wave scheduling, bank conflicts.
+#pragma once
+#include <math.h>
+#include <pthread.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <algorithm>
+using std::max;
+using std::min;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static                 // one work-group runs at a time: a static local is shared by its threads
+#define __restrict__
+typedef void *hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
+static inline hipError_t hipGetLastError() { return 0; }
+
+namespace emu {
+struct WaveState { pthread_barrier_t bar; _Float16 A[64][8], B[64][8]; };
+extern thread_local dim3 t_threadIdx, t_blockIdx;
+extern dim3 g_gridDim, g_blockDim;
+extern pthread_barrier_t g_wg_barrier;
+extern WaveState *g_waves;                // one per wave of the running work-group
+inline WaveState &my_wave() { return g_waves[t_threadIdx.x >> 6]; }
+inline void wg_barrier() { pthread_barrier_wait(&g_wg_barrier); }
+}  // namespace emu
+#define threadIdx emu::t_threadIdx
+#define blockIdx emu::t_blockIdx
+#define gridDim emu::g_gridDim
+#define blockDim emu::g_blockDim
+#define __syncthreads() emu::wg_barrier()
+#define __builtin_amdgcn_s_barrier() emu::wg_barrier()
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)      // only ever applied to wave-uniform values in these kernels
+#define __builtin_amdgcn_s_sleep(x) usleep(200)        // spin loops are bounded by iteration count: keep them slow enough for emulated partners
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
+#define __builtin_amdgcn_s_memtime() 0ull
+#define __builtin_amdgcn_s_memrealtime() 0ull
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
+// cross-lane helpers the shared headers declare but the emulated kernels never call
+template <typename T> static inline T __shfl_xor(T v, int, int = 64) { return v; }
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) ((void)0)
+// buffer resources (split-K exchange): a descriptor is just the base pointer here
+typedef void *__amdgpu_buffer_rsrc_t;
+#define __builtin_amdgcn_make_buffer_rsrc(ptr, stride, num, flags) ((void *)(ptr))
+template <typename V> static inline void emu_buffer_store_b128(V v, void *rsrc, int voff) { memcpy((char *)rsrc + voff, &v, 16); }
+#define __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, soff, aux) emu_buffer_store_b128(v, rsrc, voff)
+
+// v_mfma_f32_32x32x16_f16, wave-collective: lane l supplies A[row l % 32][k 8 (l / 32) .. + 7] and B[k ..][col l % 32] and
+// receives D[row (r & 3) + 8 (r >> 2) + 4 (l / 32)][col l % 32] for r = 0 .. 15
+typedef _Float16 emu_half8 __attribute__((ext_vector_type(8)));
+typedef float emu_floatx16 __attribute__((ext_vector_type(16)));
+static inline emu_floatx16 emu_mfma_32x32x16_f16(emu_half8 a, emu_half8 b, emu_floatx16 c) {
+    emu::WaveState &w = emu::my_wave();
+    const int l = emu::t_threadIdx.x & 63;
+    for (int e = 0; e < 8; e++) { w.A[l][e] = a[e]; w.B[l][e] = b[e]; }
+    pthread_barrier_wait(&w.bar);
+    const int n = l & 31, hh = l >> 5;
+    for (int r = 0; r < 16; r++) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float s = 0.f;
+        for (int kh = 0; kh < 2; kh++)
+            for (int e = 0; e < 8; e++) s += (float)w.A[i + 32 * kh][e] * (float)w.B[n + 32 * kh][e];
+        c[r] += s;
+    }
+    pthread_barrier_wait(&w.bar);
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16_f16(a, b, c)

@@ -1,0 +1,83 @@
+// x4l_emul.cpp — runs the SOURCE of k_gemm_q4k_x4l<1> (ggml_amd/csrc/gemm_q_x4l.hip) on the CPU, one OS thread per GPU thread,
+// work-group after work-group, and writes Y.  Test infrastructure (tests/test_build_static.py builds and runs it):
+//   x4l_emul M K B w.bin xh.bin y.bin [splitk]      w = Q4_K rows, xh = the kernel's fp16 activation image, y = fp32 [B][M] (output)
+// A mismatch in barrier counts between loader and compute waves shows up as a hang (the test has a timeout), wrong
+// indexing as wrong numbers.  Asynchrony is not modelled (see hip_emul.h).
+#include "hip_emul.h"
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+#include <thread>
+#include <vector>
+
+#define X4L_HW_OVERRIDE
+#define X4L_LDS_BASE(smem_) 0u
+#define X4L_DMA16(voff, sbase, lds_addr) memcpy(smem + (lds_addr) + 16 * lane, (sbase) + (voff), 16)
+#define X4L_GLOAD16(dst, voff, sbase) memcpy(&(dst), (sbase) + (voff), 16)
+#define X4L_WAIT_VM_TIED4(n, a, b, c, d) ((void)0)
+#define X4L_WAIT_VM(n) ((void)0)
+#define X4L_WAIT_LGKM0() ((void)0)
+
+namespace emu {
+thread_local dim3 t_threadIdx, t_blockIdx;
+dim3 g_gridDim, g_blockDim;
+pthread_barrier_t g_wg_barrier;
+WaveState *g_waves;
+}
+// host-side symbols the launcher in the kernel file refers to
+int cdna4_set_error_msg(const char *m) { fprintf(stderr, "error: %s\n", m); return -1; }
+int cdna4_set_error(hipError_t, const char *, int) { return -1; }
+// memory every work-group must see (the kernel's global buffers): anonymous shared mappings, zero-filled, inherited by the
+// forked work-group processes
+static void *shared_alloc(size_t n) { void *p = mmap(nullptr, n ? n : 1, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0); if (p == MAP_FAILED) { perror("mmap"); exit(2); } return p; }
+void *cdna4_gemm_scratch(size_t n, int) { return shared_alloc(n); }
+unsigned cdna4_gemm_next_epoch() { return 1; }
+int cdna4_gemm_cu_count() { return 256; }
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) emu_launch([&](void) { kernel(__VA_ARGS__); }, grid, block)
+template <typename F> static void emu_launch(F body, dim3 grid, dim3 block) {
+    emu::g_gridDim = grid; emu::g_blockDim = block;
+    const int nthreads = (int)block.x, nwaves = nthreads / 64;
+    // one PROCESS per work-group, all at once: each has its own copy of the kernel's `static` (= __shared__) variables, they
+    // share the global buffers (MAP_SHARED), and the work-groups of a split-K tile are co-resident as the exchange requires
+    std::vector<pid_t> kids;
+    for (unsigned b = 0; b < grid.x; b++) {
+        const pid_t pid = fork();
+        if (pid < 0) { perror("fork"); exit(2); }
+        if (pid > 0) { kids.push_back(pid); continue; }
+        pthread_barrier_init(&emu::g_wg_barrier, nullptr, nthreads);
+        std::vector<emu::WaveState> waves(nwaves);
+        for (auto &w : waves) pthread_barrier_init(&w.bar, nullptr, 64);
+        emu::g_waves = waves.data();
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++)
+            th.emplace_back([&, t, b] { emu::t_threadIdx = dim3(t); emu::t_blockIdx = dim3(b); body(); });
+        for (auto &t : th) t.join();
+        _exit(0);
+    }
+    for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { fprintf(stderr, "work-group process failed\n"); exit(3); } }
+}
+
+#include "../../ggml_amd/csrc/gemm_q_x4l.hip"
+
+static std::vector<uint8_t> slurp(const char *p) {
+    FILE *f = fopen(p, "rb"); if (!f) { perror(p); exit(2); }
+    fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> v((size_t)n); if (fread(v.data(), 1, (size_t)n, f) != (size_t)n) exit(2); fclose(f); return v;
+}
+int main(int argc, char **argv) {
+    if (argc < 7) { fprintf(stderr, "usage: x4l_emul M K B w.bin xh.bin y.bin\n"); return 2; }
+    const int M = atoi(argv[1]), K = atoi(argv[2]), B = atoi(argv[3]);
+    const int splitk = argc > 7 ? atoi(argv[7]) : 1;
+    std::vector<uint8_t> w0 = slurp(argv[4]), xh0 = slurp(argv[5]);
+    uint8_t *w = (uint8_t *)shared_alloc(w0.size()), *xh = (uint8_t *)shared_alloc(xh0.size());
+    memcpy(w, w0.data(), w0.size()); memcpy(xh, xh0.data(), xh0.size());
+    float *y = (float *)shared_alloc((size_t)B * M * 4);
+    for (size_t i = 0; i < (size_t)B * M; i++) y[i] = -12345.f;
+    cdna4_gemm_args a{};
+    a.type = CDNA4_Q4_K; a.W = w; a.w_row_bytes = (int64_t)(K / 256) * 144; a.xh = xh; a.xh_row_elems = K;
+    a.Y = y; a.y_row_elems = M; a.M = M; a.K = K; a.B = B; a.variant = 8199; a.splitk = splitk;
+    if (((uintptr_t)a.W & 15) != 0) { fprintf(stderr, "unaligned W\n"); return 2; }
+    if (cdna4_launch_gemm_q4k_x4l(a, splitk, nullptr) != 0) return 1;
+    FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)B * M, f); fclose(f);
+    return 0;
+}

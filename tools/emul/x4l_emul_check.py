@@ -1,0 +1,67 @@
+"""Runs the kernel SOURCE of gemm_q_x4l.hip on the CPU (tools/emul/x4l_emul, built from x4l_emul.cpp with the ROCm clang as
+a HOST compiler) and compares its output with a direct product of the same fp16 operands.  Complements
+x4l_layout_check.py (formulas transcribed into Python): here the C++ of the kernel itself executes — loop bounds, barrier
+counts of loader vs compute waves (a mismatch hangs: callers use a timeout), register-array indexing, the epilogue.
+
+    python tools/emul/x4l_emul_check.py [M K B]
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import refutil as R  # noqa: E402
+import x4l_layout_check as LC  # noqa: E402
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def build():
+    exe = os.path.join(HERE, "x4l_emul")
+    srcs = [os.path.join(HERE, "x4l_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(ROOT, "ggml_amd", "csrc", f)
+            for f in ("gemm_q_x4l.hip", "gemm_q_x4l_hw.h", "gemm_q_common.h", "cdna4_common.h", "cdna4_kernels.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
+        subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "ggml_amd", "csrc"),
+                        "-Wno-unused-value", "-o", exe, srcs[0]], check=True, capture_output=True, timeout=600)
+    return exe
+
+
+def run(M, K, B, seed=1, timeout=600, splitk=1):
+    rng = np.random.default_rng(seed)
+    nsb = K // 256
+    w = R.random_weights(R.Q4_K, M, K, seed).reshape(M, nsb, LC.BLK)
+    xh = rng.uniform(-1, 1, (B, K)).astype(np.float16)
+    img = np.zeros((K // 128, B, 128), np.float16)               # the kernel's activation image: [K/128][B][128], (k0,k2,k1,k3) within every 4
+    for p in range(128):
+        img[:, :, p] = xh[:, [pan * 128 + (p & ~3) + LC.PERM[p & 3] for pan in range(K // 128)]].T
+    wd = np.zeros((M, K), np.float64)                            # the same fp16 weights the kernel builds
+    for m in range(M):
+        for sb in range(nsb):
+            for G in range(4):
+                sl, cl, sh, ch = LC.table_entry(w[m, sb], G)
+                qs = w[m, sb, 16 + 32 * G:16 + 32 * G + 32]
+                wd[m, sb * 256 + 64 * G:][:32] = ((qs & 15).astype(np.float64) - 8) * np.float64(sl) + np.float64(cl)
+                wd[m, sb * 256 + 64 * G + 32:][:32] = ((qs >> 4).astype(np.float64) - 8) * np.float64(sh) + np.float64(ch)
+    wd = wd.astype(np.float16).astype(np.float64)
+    want = xh.astype(np.float64) @ wd.T
+    with tempfile.TemporaryDirectory() as d:
+        # the weight file must start 16-byte aligned in memory: the emulator reads it into a std::vector (malloc: 16-byte aligned)
+        w.tofile(os.path.join(d, "w.bin")); img.tofile(os.path.join(d, "xh.bin"))
+        r = subprocess.run([build(), str(M), str(K), str(B), os.path.join(d, "w.bin"), os.path.join(d, "xh.bin"), os.path.join(d, "y.bin"), str(splitk)],
+                           capture_output=True, text=True, timeout=timeout)
+        assert r.returncode == 0, r.stderr[-500:]
+        y = np.fromfile(os.path.join(d, "y.bin"), np.float32).reshape(B, M).astype(np.float64)
+    err = np.linalg.norm(y - want) / np.linalg.norm(want)
+    return err
+
+
+if __name__ == "__main__":
+    M, K, B = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 512, 128)
+    S = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    print("kernel source on the CPU vs direct fp16 product, %dx%dx%d split-K %d: rel-L2 %.3e" % (M, K, B, S, run(M, K, B, splitk=S)))
