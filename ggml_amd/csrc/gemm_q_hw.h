@@ -1,0 +1,17 @@
+// gemm_q_hw.h — the statements of the loader-wave GEMM kernel (gemm_kq_w12.inc) that only exist on the GPU — inline assembly for
+// the LDS-DMA, asynchronous register loads, the counted waits, the LDS base address — as macros.  tools/emul/ defines
+// CDNA4_HW_OVERRIDE and host versions before including the kernel, so that the kernel SOURCE can be executed on the CPU (a
+// functional check of indexing, loop structure, barrier counts and the epilogue variants) with no conditional code in the
+// kernel itself.  `smem` and `lane` are the kernel's.
+#pragma once
+#ifndef CDNA4_HW_OVERRIDE
+#define CDNA4_LDS_BASE(smem_) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)(smem_))
+// one LDS-DMA wave-piece: lane L copies 16 bytes from sbase + voff to LDS address lds_addr + 16 L (scalar-base form, M0 = LDS address)
+#define CDNA4_DMA16(voff, sbase, lds_addr) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0")
+// 16-byte global load into registers from a per-lane pointer; asynchronous: valid after a vmcnt wait tied to the destination
+#define CDNA4_GLOAD16_PTR(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#define CDNA4_WAIT_VM_TIED1(n, a) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(n) : "memory")
+#define CDNA4_WAIT_VM_TIED2(n, a, b) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(n) : "memory")
+#define CDNA4_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define CDNA4_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif

@@ -22,6 +22,7 @@
 //    k_gemm_kq_x2    256x128 tile, two weight fragments per activation fragment, 1/2/4-way exchange   (huge grids)
 //    k_repack_*      16-byte-aligned re-layout of Q4_0 / Q8_0 / Q6_K into scratch (shallow-K fallback of the staged path)
 #include "gemm_q_common.h"
+#include "gemm_q_hw.h"
 
 // repack kernels: one thread per 16-byte OUTPUT piece (coalesced stores; the 2-byte-aligned source bytes of a superblock
 // are read by the 9 / 17 / 14 adjacent threads that build it)
@@ -817,342 +818,7 @@ __global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
 // (an LDS-DMA instruction parks its wave ~60 cycles; in the 8-wave kernels that park is taken out of the MFMA stream — the
 // DMA-less ablation of k_gemm_kq_w8p ran 26.9 -> 24.7 us with the same memory traffic), waves 0-7 are the compute waves of
 // k_gemm_kq_w8p without any vector-memory instruction in their main loop.  All twelve meet at the same s_barriers.
-// EXP: experiment bits (0 = the shipped kernel).  bit0: the compute waves read the next stage's (s, c) table entry right
-// after the stage barrier instead of late in T_b (its LDS latency was exposed in front of fragment 0's first pairbits).
-// Bits 4-8 are timing-only ABLATIONS (results are garbage; instantiated only under -DCDNA4_ABLATIONS for
-// tools/microbench/gemm_bench): 16 loaders skip the activation pieces in the main loop, 32 loaders issue no DMA at all in
-// the main loop, 64 compute waves skip the activation ds_reads in the main loop, 128 no unpack arithmetic (raw bits go to
-// the MFMA), 256 no s_barrier in the main loop, 512 (not an ablation) block 0 records the shader clock.  bit1 / bit2 (results bit-identical, ablation builds only): balanced epilogue / stores straight from registers.
-template <int TYPE, bool USE_TAB = true, int EXP = 0>
-__global__ __launch_bounds__(768) void k_gemm_kq_w12(const gemm_params p) {
-    constexpr bool TRACE = false;
-    constexpr bool EARLY_TAB = (EXP & 1) != 0, A_NOX = (EXP & 16) != 0, A_NODMA = (EXP & 32) != 0, A_NOXREAD = (EXP & 64) != 0,
-                   A_NOUNPACK = (EXP & 128) != 0 && TYPE == CDNA4_Q4_K, A_NOBAR = (EXP & 256) != 0;
-    constexpr bool EPI_BALANCED = (EXP & 2) != 0, EPI_DIRECT = (EXP & 4) != 0;   // epilogue experiments: see gemm_w8_epilogue.inc
-    constexpr bool CLK = (EXP & 512) != 0;          // ablation builds: block 0 records s_memtime / s_memrealtime at entry and exit
-    constexpr bool DIRECT = WDirect<TYPE>::value;   // weights re-laid by the loader lanes from the original blocks (no LDS-DMA for W)
-    typedef WStage<TYPE, 2> WSt;
-    constexpr int BNF = 4, TB = 128, NST = 3;
-    constexpr int RS = 256, XS = TB * RS;
-    constexpr int BLK = QT<TYPE>::BYTES;
-    // TAB (Q4_K): the loader waves also turn every row's 6-bit scales / mins into the fp16 (s, c) constants of the stage and
-    // leave them in a small table next to the stage's data, so the compute waves read 8 bytes instead of spending ~30 VALU
-    // per wave and stage on Raw::scales() inside the MFMA stream
-    constexpr bool TAB = USE_TAB && TYPE == CDNA4_Q4_K;
-    constexpr int WRS = WSt::NPH * 16, WS = 128 * WRS, TS = TAB ? 128 * 2 * 8 : 0, ST = XS + WS + TS;
-    constexpr int NWI = 128 * WSt::NPH / 64;     // weight wave-pieces per stage: 10 (Q4_K) / 14 (Q5_K)
-    constexpr int XL = XS / 16 / 64 / 4;         // activation wave-pieces per loader wave per stage: 8
-    constexpr int WL = DIRECT ? 0 : (NWI + 3) / 4;   // weight wave-pieces per loader wave (the tail re-loads earlier pieces)
-    constexpr int NL = XL + WL;                  // 11 (Q4_K)
-    constexpr int SMEM = NST * ST > 128 * 1024 ? NST * ST : 128 * 1024;      // the epilogue needs 2 x 64 KB
-    static_assert(SMEM <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
-    __shared__ int xchg_failed;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int mg = wave & 3, kh = __builtin_amdgcn_readfirstlane(wave >> 2);        // kh = 2: loader wave (mg = its index)
-    const bool is_loader = kh == 2;
-    // (static s_setprio for the loader waves, or for the compute waves: no effect, 25.8 us either way)
-    const int nblk = gridDim.x;
-    int L = blockIdx.x;
-    if ((nblk & 7) == 0) L = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-    const int tile_b = L % p.tiles_b; L /= p.tiles_b;
-    const int ks = L % p.splitk, tile_m = L / p.splitk;
-    const int m0 = tile_m * 128, b0 = tile_b * TB;
-    // K range of this work-group in superblocks.  Hand-off split (p.partial): [0, sb_split) -> ks=0, the rest -> ks=1.
-    const int nsb_all = p.K / 256;
-    const int nsb = p.partial ? (ks == 0 ? p.sb_split : nsb_all - p.sb_split) : nsb_all / p.splitk;
-    const int sb0 = p.partial ? (ks == 0 ? 0 : p.sb_split) : ks * nsb, nstage = nsb * 2;
-
-    DqConst dq; dq.init();
-    floatx16 acc[BNF];
-#pragma unroll
-    for (int i = 0; i < BNF; i++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-
-    uint32_t xvoff[XL], wvoff[2][WL > 0 ? WL : 1];                    // loader waves only (dead in the compute waves)
-#pragma unroll
-    for (int i = 0; i < XL; i++) {                                     // loader mg owns activation wave-pieces mg, mg + 4, ...
-        const int pc = (mg + 4 * i) * 64 + lane, row = pc >> 4, c = (pc & 15) ^ (row & 15);
-        xvoff[i] = (uint32_t)(min(b0 + row, p.B - 1) - b0) * 256u + c * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < WL; i++) {
-        int idx = mg + 4 * i;
-        if (idx >= NWI) idx -= 4;
-        const int pc = idx * 64 + lane, row = pc / WSt::NPH, c = pc % WSt::NPH;
-        const uint32_t ro = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
-        wvoff[0][i] = ro + WSt::src_piece(c, 0) * 16; wvoff[1][i] = ro + WSt::src_piece(c, 1) * 16;
-    }
-    const char *const xbase = (const char *)p.xh + ((int64_t)sb0 * 2 * p.B + b0) * 256;    // panel (2*sb0), row b0
-    const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
-
-    // LDS-DMA in the scalar-base form (SGPR pair + 32-bit lane offset, M0 = wave-uniform LDS address): no per-lane 64-bit
-    // address arithmetic (the flat form cost ~5 VALU per piece, ~20 % of this kernel's VALU instructions).
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    auto dma16 = [&](const char *sbase, uint32_t voff, uint32_t lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
-    };
-    auto issue_piece = [&](int i, int sbr, int part, int slot) __attribute__((always_inline)) {         // piece i of stage (sbr, part) -> ring slot
-        const uint32_t l = lds0 + slot * ST;
-        const int mg_s = wave_s & 3;
-        if (i < XL) { dma16(xbase + (int64_t)(sbr * 2 + part) * p.B * 256, xvoff[i], l + (mg_s + 4 * i) * 1024); return; }
-        int idx = mg_s + 4 * (i - XL);
-        if (idx >= NWI) idx -= 4;
-        dma16(wbase + (int64_t)sbr * BLK, wvoff[part][i - XL], l + XS + idx * 1024);
-    };
-    auto issue = [&](int sbr, int part, int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NL; i++) issue_piece(i, sbr, part, slot);
-    };
-    auto issue_loop = [&](int sbr, int part, int slot) __attribute__((always_inline)) {   // main-loop form (the ablations apply here only)
-        if constexpr (!A_NODMA) {
-#pragma unroll
-            for (int i = A_NOX ? XL : 0; i < NL; i++) issue_piece(i, sbr, part, slot);
-        }
-    };
-
-    const int xrow_off = j * RS, xswz = j & 15;
-    auto estamp = [&](int) __attribute__((always_inline)) {};
-    // TRACE builds: shader clock (s_memtime) against the fixed 100 MHz reference (s_memrealtime) over the whole kernel of block 0
-    if ((TRACE || CLK) && p.trace && blockIdx.x == 0 && tid == 0) { p.trace[8 * 16 * 8 + 1100] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1101] = __builtin_amdgcn_s_memrealtime(); }
-    // TRACE builds: [wave][stage 4..19][phase] s_memtime stamps of block 0: 0 T_a begin, 1 T_a done, 2 after the vmcnt/lgkm
-    // waits, 3 after the barrier, 4 next stage's LDS reads issued, 6 T_b done
-    auto stamp = [&](int s_, int ph) __attribute__((always_inline)) {
-        if (TRACE && blockIdx.x == 0 && s_ >= 4 && s_ < 20 && lane == 0) p.trace[(wave * 16 + (s_ - 4)) * 8 + ph] = __builtin_amdgcn_s_memtime();
-    };
-    // ---- cross-stage software pipeline -------------------------------------------------------------------------
-    // The barrier of a stage sits in the MIDDLE of its MFMA stream.  Per wave and stage s (ring slot s % 3):
-    //   T_a(s): MFMAs of k-steps 0,1 (fragments in registers since the previous stage) + VALU building fragments 1,2;
-    //           ds_reads of the activation fragments of k-steps 2,3 (the last LDS reads of slot s)
-    //   wait: stage s+1 landed (vmcnt), own LDS reads done (lgkmcnt)  ->  s_barrier  ->  slot s is free
-    //   T_b(s): MFMAs of k-steps 2,3 + VALU building fragment 3 + ALL of the next stage's S work (packed-weight and
-    //           k-step 0,1 activation reads from slot s+1, scale constants, fragment 0) + the DMA pieces of stage s+3 -> slot s
-    // so the LDS latency and the scale arithmetic of stage s+1 run under the MFMAs of stage s instead of in front of its own.
-    Raw<TYPE> raw_c;                                                   // (after T_a the stage's packed weights and scales are dead:
-    typename Raw<TYPE>::Sc z_c;                                        //  T_b loads the next stage's straight into the same registers)
-    half8_t xa[4][BNF];
-    uint32_t cur[4] = {0, 0, 0, 0};
-    auto read_xa = [&](int slot, int kk) __attribute__((always_inline)) {
-        const uint8_t *xs = smem + slot * ST + xrow_off;
-        const int coff = ((kh * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++) xa[kk][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
-    };
-    auto mfma4 = [&](int kk, const uint32_t (&w)[4], auto &&between) __attribute__((always_inline)) {
-        const u32x4 cw = {w[0], w[1], w[2], w[3]};
-        const half8_t wfk = __builtin_bit_cast(half8_t, cw);
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++) {
-            __builtin_amdgcn_sched_barrier(0);
-            acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[kk][bf], wfk, acc[bf], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            between(bf);
-        }
-    };
-    // the (s, c) constants of this lane's (row, 64-k group) for the stage in `slot`, written there by a loader lane
-    auto tab_read = [&](int slot_) __attribute__((always_inline)) {
-        typename Raw<TYPE>::Sc z;
-        if constexpr (TAB) {
-            const u32x2 te = *reinterpret_cast<const u32x2 *>(smem + slot_ * ST + XS + WS + ((mg * 32 + j) * 2 + kh) * 8);
-            const half2_t lo = as_h2(te.x), hi = as_h2(te.y);
-            z.SL = half2_t{lo.x, lo.x}; z.CL = half2_t{lo.y, lo.y}; z.SH = half2_t{hi.x, hi.x}; z.CH = half2_t{hi.y, hi.y};
-        }
-        return z;
-    };
-    // S work of a stage whose data sits in `slot`: used once in the prologue (nothing to hide it under yet)
-    auto S_first = [&](int slot) __attribute__((always_inline)) {
-        raw_c.load(smem + slot * ST + XS + (mg * 32 + j) * WRS, kh, h);
-        read_xa(slot, 0); read_xa(slot, 1);
-        if constexpr (A_NOXREAD) { read_xa(slot, 2); read_xa(slot, 3); }
-        if constexpr (TAB) z_c = tab_read(slot); else { if (kh == 0) z_c = raw_c.scales(0); else z_c = raw_c.scales(1); }
-#pragma unroll
-        for (int i = 0; i < 4; i++) cur[i] = raw_c.pairbits(0, i, z_c, dq);
-    };
-    auto pbits = [&](int kk, int i) __attribute__((always_inline)) -> uint32_t {
-        if constexpr (A_NOUNPACK) { if constexpr (TYPE == CDNA4_Q4_K) return raw_c.q[i] + (uint32_t)kk; else return 0u; }
-        else return raw_c.pairbits(kk, i, z_c, dq);
-    };
-    u32x2 te_c = {0, 0};
-    int slot = 0;
-    // LD: stage s+3 exists (its pieces are issued here);  W2: stage s+2 exists (its pieces are the only ones allowed to be
-    // outstanding at the barrier);  NX: stage s+1 exists (barrier + its S work);  PART: which half of the superblock stage s is
-    // The NL DMA pieces of a stage are issued in two halves so that neither half of the MFMA stream carries them all:
-    // pieces [0, NB) of stage s+3 in T_b(s), pieces [NB, NL) of stage s+2 in T_a(s) (both target a slot freed by the barrier
-    // before them; HA = T_a has pieces to issue: stage s+2 exists and was not part of the prologue's three stages).
-    constexpr int NB = (NL + 1) / 2;
-    auto stage = [&](auto LD, auto W2, auto NX, auto HA, auto PART, int sb) __attribute__((always_inline)) {
-        constexpr bool load = decltype(LD)::value, w2 = decltype(W2)::value, nx = decltype(NX)::value, ha = decltype(HA)::value;
-        constexpr int part = decltype(PART)::value;
-        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;
-        uint32_t f1[4], f2[4], f3[4];
-        const int s_ = sb * 2 + part;
-        stamp(s_, 0);
-        // ---- T_a: k-steps 0,1; builds fragments 1, 2 and half of 3; second half of stage s+2's pieces -> slot of stage s-1
-        if constexpr (!A_NOXREAD) read_xa(slot, 2);
-        mfma4(0, cur, [&](int bf) __attribute__((always_inline)) {
-            f1[bf] = pbits(1, bf);
-            if (bf < 2) f3[bf] = pbits(3, bf);
-        });
-        if constexpr (!A_NOXREAD) read_xa(slot, 3);
-        mfma4(1, f1, [&](int bf) __attribute__((always_inline)) {
-            f2[bf] = pbits(2, bf);
-            if (bf >= 2) f3[bf] = pbits(3, bf);
-        });
-        stamp(s_, 1);
-        if constexpr (nx) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's last reads of `slot` have returned
-            stamp(s_, 2);
-            if constexpr (!A_NOBAR) __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            stamp(s_, 3);
-        }
-        // ---- T_b: k-steps 2,3; the next stage's S work; first half of stage s+3's pieces -> slot of stage s
-        if constexpr (nx) {
-            __builtin_amdgcn_sched_barrier(0);
-            raw_c.load(smem + slot1 * ST + XS + (mg * 32 + j) * WRS, kh, h);
-            if constexpr (!A_NOXREAD) { read_xa(slot1, 0); read_xa(slot1, 1); }
-            // (the stage's own constants are dead once T_a has built fragments 1-3: the table entry of stage s+1, written two
-            //  stages ago and published by the barrier above, can be requested together with the stage's other LDS reads)
-            if constexpr (TAB && EARLY_TAB) te_c = *reinterpret_cast<const u32x2 *>(smem + slot1 * ST + XS + WS + ((mg * 32 + j) * 2 + kh) * 8);
-            __builtin_amdgcn_sched_barrier(0);
-            stamp(s_, 4);
-        }
-        mfma4(2, f2, [&](int bf) __attribute__((always_inline)) {
-            if constexpr (nx) {
-                if (bf == 3) {
-                    if constexpr (TAB) {
-                        if constexpr (!EARLY_TAB) z_c = tab_read(slot1);
-                        else {   // the two dwords requested at the top of T_b: only the splats are left to do here
-                            const half2_t lo = as_h2(te_c.x), hi = as_h2(te_c.y);
-                            z_c.SL = half2_t{lo.x, lo.x}; z_c.CL = half2_t{lo.y, lo.y}; z_c.SH = half2_t{hi.x, hi.x}; z_c.CH = half2_t{hi.y, hi.y};
-                        }
-                    }
-                    else { if (kh == 0) z_c = raw_c.scales(((part + 1) & 1) * 2); else z_c = raw_c.scales(((part + 1) & 1) * 2 + 1); }
-                }
-            }
-        });
-        mfma4(3, f3, [&](int bf) __attribute__((always_inline)) {
-            if constexpr (nx) cur[bf] = pbits(0, bf);
-        });
-        stamp(s_, 6);
-        slot = slot1;
-    };
-    typedef std::integral_constant<bool, true> yes_t; typedef std::integral_constant<bool, false> no_t;
-    typedef std::integral_constant<int, 0> p0_t; typedef std::integral_constant<int, 1> p1_t;
-    // loader program: the same barrier sequence as the compute waves (one before the first S work, one in the middle of
-    // every stage that has a successor); after the barrier of stage s, slot s is free and takes stage s+3
-    // TAB: loader lane (row, gl) keeps the 16-byte superblock header of the row in registers one stage ahead (plain global
-    // load, issued BEFORE the stage's DMA pieces so the counted vmcnt wait in front of the next barrier covers it)
-    const int lrow = ((mg << 6) | lane) >> 1, lgl = lane & 1;
-    const uint8_t *const hrow0 = p.W + (int64_t)min(m0 + lrow, p.M - 1) * p.w_row_bytes + (int64_t)sb0 * BLK;
-    auto hload = [&](int sbr) __attribute__((always_inline)) {
-        u32x4 r; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(hrow0 + (int64_t)sbr * BLK) : "memory"); return r;
-    };
-    auto tab_store = [&](const u32x4 &hdr, int part_, int slot_) __attribute__((always_inline)) {   // same arithmetic as Raw<Q4_K>::scales()
-        const int g = part_ * 2 + lgl;
-        int s0, mn0, s1, mn1;
-        k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g, s0, mn0); k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g + 1, s1, mn1);
-        const float d = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
-        const half_t sl = (half_t)(d * (float)s0), sh = (half_t)(d * (float)s1);
-        const half_t cl = (half_t)(8.f * (float)sl - dmin * (float)mn0), ch = (half_t)(8.f * (float)sh - dmin * (float)mn1);
-        u32x2 e; e.x = __builtin_bit_cast(uint32_t, half2_t{sl, cl}); e.y = __builtin_bit_cast(uint32_t, half2_t{sh, ch});
-        *reinterpret_cast<u32x2 *>(smem + slot_ * ST + XS + WS + (lrow * 2 + lgl) * 8) = e;
-    };
-    u32x4 hcur = {0, 0, 0, 0};                                         // header of the superblock of stage s+3
-    auto lstage = [&](auto LD, auto W2, auto NX, auto PART, int sb) __attribute__((always_inline)) {
-        constexpr bool load = decltype(LD)::value, w2 = decltype(W2)::value, nx = decltype(NX)::value;
-        constexpr int part = decltype(PART)::value;
-        if constexpr (nx) {
-            // stage s+1 has landed (only stage s+2's pieces may be in flight; the header load is older than those)
-            if (w2) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hcur) : "n"(NL) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hcur) : : "memory");
-            if constexpr (TAB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table written last stage is in LDS
-            if constexpr (!A_NOBAR) __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-        if constexpr (load) {
-            u32x4 hnext = hcur;
-            if constexpr (TAB) {
-                if (2 * sb + part + 4 < nstage) hnext = hload(sb + 2);  // stage s+4 = (sb + 2, part)
-                tab_store(hcur, (part + 3) % 2, slot);
-            }
-            issue_loop(sb + (part + 3) / 2, (part + 3) % 2, slot);
-            hcur = hnext;
-        }
-        slot = slot == 2 ? 0 : slot + 1;
-    };
-    if (is_loader && DIRECT) {
-        // Staged formats: lane (row, gl) of the four loader waves owns the gl-th 64-k group of one weight row.  Its original
-        // bytes for stage s+4 are in flight (registers) while those of stage s+3 are re-laid into the slot the barrier just freed.
-        if constexpr (DIRECT) {
-            typedef WDirect<TYPE> WD;
-            const int lid = (mg << 6) | lane, lrow = lid >> 1, gl = lid & 1;
-            const uint8_t *const wrow0 = p.W + (int64_t)min(m0 + lrow, p.M - 1) * p.w_row_bytes + (int64_t)sb0 * BLK;
-            auto wload = [&](int st) __attribute__((always_inline)) {   // stage st = (superblock st / 2, half st % 2)
-                if constexpr (TYPE == CDNA4_Q6_KS) return WD::load(wrow0 + (int64_t)(st >> 1) * BLK, st & 1, gl);
-                else return WD::load(wrow0 + (int64_t)(st >> 1) * BLK + (st & 1) * WD::STAGE_SRC, gl);
-            };
-            auto wstore = [&](const typename WD::Regs &r, int slot_) __attribute__((always_inline)) { WD::store(r, smem + slot_ * ST + XS + lrow * WRS, gl); };
-            typename WD::Regs r0 = wload(0), r1 = wload(1), rn = wload(nstage > 2 ? 2 : 1);
-            issue(0, 0, 0); issue(0, 1, 1);
-            if (nstage > 2) issue(1, 0, 2);
-            wstore(r0, 0); wstore(r1, 1);
-            if (nstage > 2) wstore(rn, 2);
-            if (nstage > 3) rn = wload(3);
-            // (wstore() consumed r0 / r1 / rn: the compiler placed the vmcnt waits for those loads; the X pieces are waited here)
-            // every activation piece is older than rn's (>= 3) load instructions: at most those may still be in flight
-            if (nstage > 3) wait_vmcnt<3>(); else wait_vmcnt<0>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            for (int st = 0; st + 1 < nstage; st++) {                   // the barrier in the middle of stage st frees slot st % 3
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (st + 3 < nstage) {
-                    wstore(rn, slot);                                   // stage st+3's weights (waits for their loads: everything older has landed too)
-                    issue((st + 3) >> 1, (st + 3) & 1, slot);
-                    if (st + 4 < nstage) rn = wload(st + 4);
-                } else wait_vmcnt<0>();                                 // the tail: the last activation pieces must land before the next barrier
-                slot = slot == 2 ? 0 : slot + 1;
-            }
-        }
-    } else if (is_loader) {
-        u32x4 hA = {0, 0, 0, 0};
-        if constexpr (TAB) { hA = hload(0); hcur = hload(1); }         // (this kernel only runs K ranges of >= 3 superblocks)
-        issue(0, 0, 0);
-        issue(0, 1, 1);
-        issue(1, 0, 2);
-        if constexpr (TAB) {
-            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(hA), "+v"(hcur) : "n"(3 * NL) : "memory");   // the two headers are older than the 3 x NL pieces
-            tab_store(hA, 0, 0); tab_store(hA, 1, 1); tab_store(hcur, 0, 2);
-        }
-        wait_vmcnt<2 * NL>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        lstage(yes_t{}, yes_t{}, yes_t{}, p0_t{}, 0); lstage(yes_t{}, yes_t{}, yes_t{}, p1_t{}, 0);
-        int sb = 1;
-        for (; sb + 2 < nsb; sb++) { lstage(yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); lstage(yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); }
-        lstage(yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); lstage(no_t{}, yes_t{}, yes_t{}, p1_t{}, sb); sb++;
-        lstage(no_t{}, no_t{}, yes_t{}, p0_t{}, sb); lstage(no_t{}, no_t{}, no_t{}, p1_t{}, sb);
-    } else {
-        __builtin_amdgcn_s_barrier();                                   // stage 0 has landed (the loaders waited for it)
-        asm volatile("" ::: "memory");
-        S_first(0);
-        stage(yes_t{}, yes_t{}, yes_t{}, no_t{}, p0_t{}, 0); stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, 0);
-        int sb = 1;
-        for (; sb + 2 < nsb; sb++) { stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); }
-        stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(no_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); sb++;
-        stage(no_t{}, no_t{}, yes_t{}, no_t{}, p0_t{}, sb); stage(no_t{}, no_t{}, no_t{}, no_t{}, p1_t{}, sb);
-    }
-
-#include "gemm_w8_epilogue.inc"
-    if ((TRACE || CLK) && p.trace && blockIdx.x == 0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[8 * 16 * 8 + 1102] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1103] = __builtin_amdgcn_s_memrealtime(); }
-}
-
+#include "gemm_kq_w12.inc"
 
 // ------------------------------------------------------------------------------------------------------------
 // 256(m) x 128(b) work-group tile: the 8-wave in-wave-pipelined kernel with TWO weight fragments per activation

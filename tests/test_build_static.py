@@ -105,3 +105,24 @@ def test_experimental_kernel_source_runs_correctly_on_the_cpu(m, k, b, splitk):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(m, k, b, seed=m + k, timeout=300, splitk=splitk) < 1e-6
+
+
+@pytest.mark.parametrize("m,k,b,splitk,exp,l2", [(300, 1536, 200, 1, 0, 1), (256, 2048, 128, 2, 0, 1), (256, 2048, 128, 2, 0, 0), (256, 1024, 128, 1, 100, 1),
+                                              (513, 3072, 129, 2, 1, 1), (513, 3072, 129, 2, 2, 0), (300, 1536, 200, 1, 4, 1), (256, 2048, 128, 2, 6, 1)])
+def test_shipped_12_wave_kernel_source_and_its_candidates_on_the_cpu(m, k, b, splitk, exp, l2):
+    """tools/emul/w12_emul: the source of k_gemm_kq_w12 (+ the shared epilogue) executed on the CPU.  exp 0 is the shipped
+    kernel (GPU-verified: this checks the emulator against it), 100 the variant without the loaders' scale table, 1 / 2 / 4 / 6
+    the candidates kept in ablation builds (early table read, balanced epilogue, stores from registers, both): each must give
+    the shipped kernel's result BIT FOR BIT, through both exchange transports"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    err, y = mod.run(m, k, b, seed=5, timeout=600, splitk=splitk, kernel="w12", exp=exp, xchg_l2=l2, return_y=True)
+    assert err < 1e-6
+    if exp != 0:
+        _, y0 = mod.run(m, k, b, seed=5, timeout=600, splitk=splitk, kernel="w12", exp=0, xchg_l2=1, return_y=True)
+        assert np.array_equal(y, y0)

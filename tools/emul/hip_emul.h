@@ -65,6 +65,16 @@ typedef void *__amdgpu_buffer_rsrc_t;
 template <typename V> static inline void emu_buffer_store_b128(V v, void *rsrc, int voff) { memcpy((char *)rsrc + voff, &v, 16); }
 #define __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, soff, aux) emu_buffer_store_b128(v, rsrc, voff)
 
+typedef uint32_t emu_u32x4 __attribute__((ext_vector_type(4)));
+static inline emu_u32x4 emu_buffer_load_b128(void *rsrc, int voff) { emu_u32x4 v; memcpy(&v, (char *)rsrc + voff, 16); return v; }
+#define __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, aux) emu_buffer_load_b128(rsrc, voff)
+#define __builtin_amdgcn_s_getreg(x) 0u             // HW_REG_XCC_ID: every emulated work-group sits on "XCD 0"
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+static inline void unsafeAtomicAdd(float *p, float v) {
+    uint32_t *u = reinterpret_cast<uint32_t *>(p), old = __atomic_load_n(u, __ATOMIC_RELAXED), nw;
+    do { float f; memcpy(&f, &old, 4); f += v; memcpy(&nw, &f, 4); } while (!__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
+
 // v_mfma_f32_32x32x16_f16, wave-collective: lane l supplies A[row l % 32][k 8 (l / 32) .. + 7] and B[k ..][col l % 32] and
 // receives D[row (r & 3) + 8 (r >> 2) + 4 (l / 32)][col l % 32] for r = 0 .. 15
 typedef _Float16 emu_half8 __attribute__((ext_vector_type(8)));

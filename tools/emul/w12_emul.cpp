@@ -1,0 +1,93 @@
+// w12_emul.cpp — runs the SOURCE of k_gemm_kq_w12<Q4_K, true, EXP> (ggml_amd/csrc/gemm_kq_w12.inc + gemm_w8_epilogue.inc: the
+// shipped 12-wave kernel and its bit-identical experiment variants) on the CPU like x4l_emul.cpp does for the experimental
+// kernel.  Test infrastructure.
+//   w12_emul M K B w.bin xh.bin y.bin splitk exp xchg_l2
+#include "hip_emul.h"
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <thread>
+#include <vector>
+
+#define CDNA4_HW_OVERRIDE
+#define CDNA4_LDS_BASE(smem_) 0u
+#define CDNA4_DMA16(voff, sbase, lds_addr) memcpy(smem + (lds_addr) + 16 * lane, (sbase) + (voff), 16)
+#define CDNA4_GLOAD16_PTR(dst, ptr) memcpy(&(dst), (ptr), 16)
+#define CDNA4_WAIT_VM_TIED1(n, a) ((void)0)
+#define CDNA4_WAIT_VM_TIED2(n, a, b) ((void)0)
+#define CDNA4_WAIT_VM(n) ((void)0)
+#define CDNA4_WAIT_LGKM0() ((void)0)
+
+namespace emu {
+thread_local dim3 t_threadIdx, t_blockIdx;
+dim3 g_gridDim, g_blockDim;
+pthread_barrier_t g_wg_barrier;
+WaveState *g_waves;
+}
+int cdna4_set_error_msg(const char *m) { fprintf(stderr, "error: %s\n", m); return -1; }
+static void *shared_alloc(size_t n) { void *p = mmap(nullptr, n ? n : 1, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0); if (p == MAP_FAILED) { perror("mmap"); exit(2); } return p; }
+
+#include "../../ggml_amd/csrc/gemm_q_common.h"
+#include "../../ggml_amd/csrc/gemm_q_hw.h"
+void *cdna4_debug_trace = nullptr;
+#include "../../ggml_amd/csrc/gemm_kq_w12.inc"
+
+template <typename F> static void emu_launch(F body, unsigned nblk, int nthreads) {
+    emu::g_gridDim = dim3(nblk); emu::g_blockDim = dim3(nthreads);
+    std::vector<pid_t> kids;
+    for (unsigned b = 0; b < nblk; b++) {
+        const pid_t pid = fork();
+        if (pid < 0) { perror("fork"); exit(2); }
+        if (pid > 0) { kids.push_back(pid); continue; }
+        pthread_barrier_init(&emu::g_wg_barrier, nullptr, nthreads);
+        std::vector<emu::WaveState> waves(nthreads / 64);
+        for (auto &w : waves) pthread_barrier_init(&w.bar, nullptr, 64);
+        emu::g_waves = waves.data();
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) th.emplace_back([&, t, b] { emu::t_threadIdx = dim3(t); emu::t_blockIdx = dim3(b); body(); });
+        for (auto &t : th) t.join();
+        _exit(0);
+    }
+    for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { fprintf(stderr, "work-group process failed\n"); exit(3); } }
+}
+
+static std::vector<uint8_t> slurp(const char *p) {
+    FILE *f = fopen(p, "rb"); if (!f) { perror(p); exit(2); }
+    fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> v((size_t)n); if (fread(v.data(), 1, (size_t)n, f) != (size_t)n) exit(2); fclose(f); return v;
+}
+int main(int argc, char **argv) {
+    if (argc < 10) { fprintf(stderr, "usage: w12_emul M K B w.bin xh.bin y.bin splitk exp xchg_l2\n"); return 2; }
+    const int M = atoi(argv[1]), K = atoi(argv[2]), B = atoi(argv[3]), splitk = atoi(argv[7]), exp = atoi(argv[8]), l2 = atoi(argv[9]);
+    std::vector<uint8_t> w0 = slurp(argv[4]), xh0 = slurp(argv[5]);
+    uint8_t *w = (uint8_t *)shared_alloc(w0.size()), *xh = (uint8_t *)shared_alloc(xh0.size());
+    memcpy(w, w0.data(), w0.size()); memcpy(xh, xh0.data(), xh0.size());
+    float *y = (float *)shared_alloc((size_t)B * M * 4);
+    for (size_t i = 0; i < (size_t)B * M; i++) y[i] = -12345.f;
+    // the parameter block exactly as launch_w8() (gemm_q_mfma.hip) fills it for this kernel
+    gemm_params p{};
+    p.W = w; p.w_row_bytes = (int64_t)(K / 256) * 144; p.xh = (const half_t *)xh; p.xh_row = K; p.Y = y; p.y_row = M; p.M = M; p.K = K; p.B = B; p.splitk = splitk;
+    p.tiles_m = (M + 127) / 128; p.tiles_b = (B + 127) / 128;
+    const int ntiles = p.tiles_m * p.tiles_b, total = K / 256;
+    if (splitk == 2) {
+        const size_t pbytes = (size_t)ntiles * 128 * 128 * 4;
+        char *sc = (char *)shared_alloc(pbytes + (size_t)ntiles * 8 + 256);
+        p.partial = (float *)sc; p.flags = (unsigned *)(sc + pbytes); p.epoch = 7;
+        int split = (total * 8 + 8) / 16;
+        p.sb_split = split < 1 ? 1 : (split > total - 1 ? total - 1 : split);
+        p.xchg_l2 = l2;
+    } else if (splitk != 1) { fprintf(stderr, "splitk 1 or 2\n"); return 2; }
+    const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
+    if (min_nsb < 3) { fprintf(stderr, "the kernel needs 3 superblocks of K per work-group\n"); return 2; }
+    const unsigned nblk = (unsigned)(ntiles * splitk);
+    switch (exp) {
+        case 0: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 0>(p); }, nblk, 768); break;
+        case 1: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 1>(p); }, nblk, 768); break;
+        case 2: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 2>(p); }, nblk, 768); break;
+        case 4: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 4>(p); }, nblk, 768); break;
+        case 6: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 6>(p); }, nblk, 768); break;
+        case 100: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, false, 0>(p); }, nblk, 768); break;      // compute waves unpack the scales themselves
+        default: fprintf(stderr, "exp not built into the emulator\n"); return 2;
+    }
+    FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)B * M, f); fclose(f);
+    return 0;
+}

@@ -1,9 +1,9 @@
-"""Runs the kernel SOURCE of gemm_q_x4l.hip on the CPU (tools/emul/x4l_emul, built from x4l_emul.cpp with the ROCm clang as
-a HOST compiler) and compares its output with a direct product of the same fp16 operands.  Complements
+"""Runs the kernel SOURCE of gemm_q_x4l.hip (x4l_emul) or of the shipped 12-wave kernel and its experiment variants (w12_emul)
+on the CPU (built from *_emul.cpp with the ROCm clang as a HOST compiler) and compares its output with a direct product of the same fp16 operands.  Complements
 x4l_layout_check.py (formulas transcribed into Python): here the C++ of the kernel itself executes — loop bounds, barrier
 counts of loader vs compute waves (a mismatch hangs: callers use a timeout), register-array indexing, the epilogue.
 
-    python tools/emul/x4l_emul_check.py [M K B]
+    python tools/emul/x4l_emul_check.py [M K B [splitk [x4l|w12 [exp]]]]
 """
 import os
 import subprocess
@@ -22,17 +22,17 @@ import x4l_layout_check as LC  # noqa: E402
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
-def build():
-    exe = os.path.join(HERE, "x4l_emul")
-    srcs = [os.path.join(HERE, "x4l_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(ROOT, "ggml_amd", "csrc", f)
-            for f in ("gemm_q_x4l.hip", "gemm_q_x4l_hw.h", "gemm_q_common.h", "cdna4_common.h", "cdna4_kernels.h")]
+def build(name="x4l"):
+    exe = os.path.join(HERE, name + "_emul")
+    srcs = [os.path.join(HERE, name + "_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(ROOT, "ggml_amd", "csrc", f)
+            for f in ("gemm_q_x4l.hip", "gemm_q_x4l_hw.h", "gemm_kq_w12.inc", "gemm_w8_epilogue.inc", "gemm_q_hw.h", "gemm_q_common.h", "cdna4_common.h", "cdna4_kernels.h")]
     if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
         subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "ggml_amd", "csrc"),
                         "-Wno-unused-value", "-o", exe, srcs[0]], check=True, capture_output=True, timeout=600)
     return exe
 
 
-def run(M, K, B, seed=1, timeout=600, splitk=1):
+def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, return_y=False):
     rng = np.random.default_rng(seed)
     nsb = K // 256
     w = R.random_weights(R.Q4_K, M, K, seed).reshape(M, nsb, LC.BLK)
@@ -53,15 +53,18 @@ def run(M, K, B, seed=1, timeout=600, splitk=1):
     with tempfile.TemporaryDirectory() as d:
         # the weight file must start 16-byte aligned in memory: the emulator reads it into a std::vector (malloc: 16-byte aligned)
         w.tofile(os.path.join(d, "w.bin")); img.tofile(os.path.join(d, "xh.bin"))
-        r = subprocess.run([build(), str(M), str(K), str(B), os.path.join(d, "w.bin"), os.path.join(d, "xh.bin"), os.path.join(d, "y.bin"), str(splitk)],
+        extra = [str(splitk)] if kernel == "x4l" else [str(splitk), str(exp), str(xchg_l2)]
+        r = subprocess.run([build(kernel), str(M), str(K), str(B), os.path.join(d, "w.bin"), os.path.join(d, "xh.bin"), os.path.join(d, "y.bin")] + extra,
                            capture_output=True, text=True, timeout=timeout)
         assert r.returncode == 0, r.stderr[-500:]
         y = np.fromfile(os.path.join(d, "y.bin"), np.float32).reshape(B, M).astype(np.float64)
     err = np.linalg.norm(y - want) / np.linalg.norm(want)
-    return err
+    return (err, y) if return_y else err
 
 
 if __name__ == "__main__":
     M, K, B = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 512, 128)
     S = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-    print("kernel source on the CPU vs direct fp16 product, %dx%dx%d split-K %d: rel-L2 %.3e" % (M, K, B, S, run(M, K, B, splitk=S)))
+    kern = sys.argv[5] if len(sys.argv) > 5 else "x4l"
+    exp = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    print("%s kernel source (exp %d) on the CPU vs direct fp16 product, %dx%dx%d split-K %d: rel-L2 %.3e" % (kern, exp, M, K, B, S, run(M, K, B, splitk=S, kernel=kern, exp=exp)))
