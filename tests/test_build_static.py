@@ -126,3 +126,19 @@ def test_shipped_12_wave_kernel_source_and_its_candidates_on_the_cpu(m, k, b, sp
     if exp != 0:
         _, y0 = mod.run(m, k, b, seed=5, timeout=600, splitk=splitk, kernel="w12", exp=0, xchg_l2=1, return_y=True)
         assert np.array_equal(y, y0)
+
+
+@pytest.mark.parametrize("kernel,m,k,b,splitk", [("x4l", 300, 1536, 200, 1), ("x4l", 256, 2048, 128, 4), ("w12", 300, 1536, 200, 1), ("w12", 256, 2048, 128, 2)])
+def test_counted_vmcnt_waits_are_sufficient_and_tight(kernel, m, k, b, splitk, monkeypatch):
+    """EMU_DEFER_DMA=1: every LDS-DMA copy lands as LATE as the hardware permits — only when an s_waitcnt vmcnt(n) of the issuing
+    wave retires it, in order — so a missing or too-weak wait leaves stale bytes in LDS.  Both kernels pass as written, and fail
+    as soon as every wait tolerates one more outstanding operation (the self-test of this check)"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(m, k, b, seed=3, timeout=600, splitk=splitk, kernel=kernel, defer_dma=True) < 1e-6
+    monkeypatch.setenv("EMU_WEAKEN_WAITS", "1")
+    assert mod.run(m, k, b, seed=3, timeout=600, splitk=splitk, kernel=kernel, defer_dma=True) > 1e-3

@@ -13,6 +13,7 @@
 #include <string.h>
 #include <unistd.h>
 #include <algorithm>
+#include <vector>
 using std::max;
 using std::min;
 
@@ -74,6 +75,24 @@ static inline void unsafeAtomicAdd(float *p, float v) {
     uint32_t *u = reinterpret_cast<uint32_t *>(p), old = __atomic_load_n(u, __ATOMIC_RELAXED), nw;
     do { float f; memcpy(&f, &old, 4); f += v; memcpy(&nw, &f, 4); } while (!__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
 }
+
+// vector-memory queue of one lane, for the counted waits: with EMU_DEFER_DMA=1 an LDS-DMA copy is performed as LATE as the
+// hardware allows — when an s_waitcnt vmcnt(n) of the issuing wave retires it (in order, all but the newest n) — so a wait
+// that is missing or too weak leaves stale bytes in LDS and the result goes wrong.  The default (immediate copies) is the
+// other extreme, which is the one that exposes a slot being overwritten too EARLY.  Register loads always complete at once
+// but still occupy a queue entry, as they do in the hardware's counter.
+namespace emu {
+struct Pending { void *dst; const void *src; };
+extern thread_local std::vector<Pending> t_vmq;
+extern bool g_defer_dma;
+inline void vm_issue(void *dst, const void *src) { if (g_defer_dma) t_vmq.push_back({dst, src}); else { memcpy(dst, src, 16); t_vmq.push_back({nullptr, nullptr}); } }
+inline void vm_issue_done() { t_vmq.push_back({nullptr, nullptr}); }
+extern size_t g_weaken;                   // EMU_WEAKEN_WAITS=k: every vmcnt wait tolerates k more outstanding operations (self-test of the check)
+inline void vm_wait(size_t n) {
+    n += g_weaken;
+    while (t_vmq.size() > n) { const Pending p = t_vmq.front(); t_vmq.erase(t_vmq.begin()); if (p.dst) memcpy(p.dst, p.src, 16); }
+}
+}  // namespace emu
 
 // v_mfma_f32_32x32x16_f16, wave-collective: lane l supplies A[row l % 32][k 8 (l / 32) .. + 7] and B[k ..][col l % 32] and
 // receives D[row (r & 3) + 8 (r >> 2) + 4 (l / 32)][col l % 32] for r = 0 .. 15

@@ -10,11 +10,11 @@
 
 #define CDNA4_HW_OVERRIDE
 #define CDNA4_LDS_BASE(smem_) 0u
-#define CDNA4_DMA16(voff, sbase, lds_addr) memcpy(smem + (lds_addr) + 16 * lane, (sbase) + (voff), 16)
-#define CDNA4_GLOAD16_PTR(dst, ptr) memcpy(&(dst), (ptr), 16)
-#define CDNA4_WAIT_VM_TIED1(n, a) ((void)0)
-#define CDNA4_WAIT_VM_TIED2(n, a, b) ((void)0)
-#define CDNA4_WAIT_VM(n) ((void)0)
+#define CDNA4_DMA16(voff, sbase, lds_addr) emu::vm_issue(smem + (lds_addr) + 16 * lane, (sbase) + (voff))
+#define CDNA4_GLOAD16_PTR(dst, ptr) (memcpy(&(dst), (ptr), 16), emu::vm_issue_done())
+#define CDNA4_WAIT_VM_TIED1(n, a) emu::vm_wait(n)
+#define CDNA4_WAIT_VM_TIED2(n, a, b) emu::vm_wait(n)
+#define CDNA4_WAIT_VM(n) emu::vm_wait(n)
 #define CDNA4_WAIT_LGKM0() ((void)0)
 
 namespace emu {
@@ -22,6 +22,9 @@ thread_local dim3 t_threadIdx, t_blockIdx;
 dim3 g_gridDim, g_blockDim;
 pthread_barrier_t g_wg_barrier;
 WaveState *g_waves;
+thread_local std::vector<Pending> t_vmq;
+bool g_defer_dma = getenv("EMU_DEFER_DMA") && atoi(getenv("EMU_DEFER_DMA")) != 0;
+size_t g_weaken = getenv("EMU_WEAKEN_WAITS") ? (size_t)atoi(getenv("EMU_WEAKEN_WAITS")) : 0;
 }
 int cdna4_set_error_msg(const char *m) { fprintf(stderr, "error: %s\n", m); return -1; }
 static void *shared_alloc(size_t n) { void *p = mmap(nullptr, n ? n : 1, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0); if (p == MAP_FAILED) { perror("mmap"); exit(2); } return p; }

@@ -12,10 +12,10 @@
 
 #define X4L_HW_OVERRIDE
 #define X4L_LDS_BASE(smem_) 0u
-#define X4L_DMA16(voff, sbase, lds_addr) memcpy(smem + (lds_addr) + 16 * lane, (sbase) + (voff), 16)
-#define X4L_GLOAD16(dst, voff, sbase) memcpy(&(dst), (sbase) + (voff), 16)
-#define X4L_WAIT_VM_TIED4(n, a, b, c, d) ((void)0)
-#define X4L_WAIT_VM(n) ((void)0)
+#define X4L_DMA16(voff, sbase, lds_addr) emu::vm_issue(smem + (lds_addr) + 16 * lane, (sbase) + (voff))
+#define X4L_GLOAD16(dst, voff, sbase) (memcpy(&(dst), (sbase) + (voff), 16), emu::vm_issue_done())
+#define X4L_WAIT_VM_TIED4(n, a, b, c, d) emu::vm_wait(n)
+#define X4L_WAIT_VM(n) emu::vm_wait(n)
 #define X4L_WAIT_LGKM0() ((void)0)
 
 namespace emu {
@@ -23,6 +23,9 @@ thread_local dim3 t_threadIdx, t_blockIdx;
 dim3 g_gridDim, g_blockDim;
 pthread_barrier_t g_wg_barrier;
 WaveState *g_waves;
+thread_local std::vector<Pending> t_vmq;
+bool g_defer_dma = getenv("EMU_DEFER_DMA") && atoi(getenv("EMU_DEFER_DMA")) != 0;
+size_t g_weaken = getenv("EMU_WEAKEN_WAITS") ? (size_t)atoi(getenv("EMU_WEAKEN_WAITS")) : 0;
 }
 // host-side symbols the launcher in the kernel file refers to
 int cdna4_set_error_msg(const char *m) { fprintf(stderr, "error: %s\n", m); return -1; }

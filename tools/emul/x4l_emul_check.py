@@ -32,7 +32,7 @@ def build(name="x4l"):
     return exe
 
 
-def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, return_y=False):
+def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, return_y=False, defer_dma=False):
     rng = np.random.default_rng(seed)
     nsb = K // 256
     w = R.random_weights(R.Q4_K, M, K, seed).reshape(M, nsb, LC.BLK)
@@ -55,7 +55,7 @@ def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, 
         w.tofile(os.path.join(d, "w.bin")); img.tofile(os.path.join(d, "xh.bin"))
         extra = [str(splitk)] if kernel == "x4l" else [str(splitk), str(exp), str(xchg_l2)]
         r = subprocess.run([build(kernel), str(M), str(K), str(B), os.path.join(d, "w.bin"), os.path.join(d, "xh.bin"), os.path.join(d, "y.bin")] + extra,
-                           capture_output=True, text=True, timeout=timeout)
+                           capture_output=True, text=True, timeout=timeout, env=dict(os.environ, EMU_DEFER_DMA="1" if defer_dma else "0"))
         assert r.returncode == 0, r.stderr[-500:]
         y = np.fromfile(os.path.join(d, "y.bin"), np.float32).reshape(B, M).astype(np.float64)
     err = np.linalg.norm(y - want) / np.linalg.norm(want)
