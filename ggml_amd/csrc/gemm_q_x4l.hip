@@ -18,15 +18,18 @@
 #include "gemm_q_common.h"
 #include "gemm_q_x4l_hw.h"
 
-template <int S>
+// NMB = 32-row blocks per compute wave: 2 = the 256 x 128 tile described above; 1 = a 128 x 128 tile with the same structure (one
+// activation fragment per MFMA again, but still no K split inside the work-group, one wave per SIMD and loader waves) for
+// the grids that are too small for 256-row tiles (the headline 4096 x 4096 x 512: 128 tiles x split-K 2).
+template <int S, int NMB>
 __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
     constexpr int TYPE = CDNA4_Q4_K;
-    constexpr int BNF = 4, TB = 128, TM = 256, NST = 3;
+    constexpr int BNF = 4, TB = 128, TM = 128 * NMB, NST = 3;
     constexpr int RS = 256, XS = TB * RS;                 // activations: 128 rows x 256 B
     constexpr int BLK = QT<TYPE>::BYTES;                  // 144
     constexpr int WQS = TM * 64, TS = TM * 16;            // nibbles: 256 rows x 64 B; table: 256 rows x 2 groups x 8 B
-    constexpr int ST = XS + WQS + TS;                     // 53,248
-    constexpr int NXL = 8, NWL = 4, NLD = NXL + NWL;      // DMA wave-pieces per loader wave and stage
+    constexpr int ST = XS + WQS + TS;                     // 53,248 (NMB = 2) / 43,008 (NMB = 1)
+    constexpr int NXL = 8, NWL = 2 * NMB, NLD = NXL + NWL; // DMA wave-pieces per loader wave and stage
     constexpr int SMEM = NST * ST > 128 * 1024 ? NST * ST : 128 * 1024;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
@@ -50,9 +53,9 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
     const char *const xbase = (const char *)p.xh + ((int64_t)sb0 * 2 * p.B + b0) * 256;
     const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
 
-    floatx16 acc[2][BNF];
+    floatx16 acc[NMB][BNF];
 #pragma unroll
-    for (int mb = 0; mb < 2; mb++)
+    for (int mb = 0; mb < NMB; mb++)
 #pragma unroll
         for (int i = 0; i < BNF; i++)
 #pragma unroll
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
 
     if (is_loader) {
         // ================================================================ loader waves
-        uint32_t xvoff[NXL], wvoff[NWL], hoff[2];
+        uint32_t xvoff[NXL], wvoff[NWL], hoff[NMB];
 #pragma unroll
         for (int i = 0; i < NXL; i++) {                    // activation wave-piece q = mg + 4 i: LDS bytes [1024 q, 1024 q + 1024) of the slot
             const int pc = (mg + 4 * i) * 64 + lane, row = pc >> 4, c = (pc & 15) ^ (row & 15);
@@ -73,9 +76,9 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
             const int pc = (mg + 4 * i) * 64 + lane, row = pc >> 2, c = (pc & 3) ^ ((row >> 2) & 3);
             wvoff[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes + 16u + c * 16;
         }
-        const int lidx = (mg << 6) | lane, lrow = lidx >> 1, lgl = lidx & 1;      // table: rows lrow and lrow + 128, group lgl of the stage
+        const int lidx = (mg << 6) | lane, lrow = lidx >> 1, lgl = lidx & 1;      // table: rows lrow (and lrow + 128), group lgl of the stage
 #pragma unroll
-        for (int r = 0; r < 2; r++) hoff[r] = (uint32_t)(min(m0 + lrow + 128 * r, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
+        for (int r = 0; r < NMB; r++) hoff[r] = (uint32_t)(min(m0 + lrow + 128 * r, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
 
         auto dma16 = [&](const char *sbase, uint32_t voff, uint32_t lds_addr) __attribute__((always_inline)) {
             X4L_DMA16(voff, sbase, lds_addr);
@@ -88,17 +91,17 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
 #pragma unroll
             for (int i = 0; i < NWL; i++) dma16(ws, wvoff[i], l + XS + (mg + 4 * i) * 1024);
         };
-        struct Hdr { u32x4 r[2]; };
+        struct Hdr { u32x4 r[NMB]; };
         auto hload = [&](int sbr) __attribute__((always_inline)) {
             Hdr v; const char *sb = wbase + (int64_t)sbr * BLK;
 #pragma unroll
-            for (int r = 0; r < 2; r++) X4L_GLOAD16(v.r[r], hoff[r], sb);
+            for (int r = 0; r < NMB; r++) X4L_GLOAD16(v.r[r], hoff[r], sb);
             return v;
         };
         auto tab_store = [&](const Hdr &hd, int part, int slot) __attribute__((always_inline)) {    // the arithmetic of Raw<Q4_K>::scales()
             const int g = part * 2 + lgl;
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
+            for (int r = 0; r < NMB; r++) {
                 const u32x4 hdr = hd.r[r];
                 int s0, mn0, s1, mn1;
                 k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g, s0, mn0); k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g + 1, s1, mn1);
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
         // prologue: stages 0, 1, 2 -> slots 0, 1, 2
         Hdr h0 = hload(0), hcur = hload(1);
         issue(0, 0); issue(1, 1); issue(2, 2);
-        X4L_WAIT_VM_TIED4(3 * NLD, h0.r[0], h0.r[1], hcur.r[0], hcur.r[1]);   // the four header loads are older than the pieces
+        X4L_WAIT_VM_TIED4(3 * NLD, h0.r[0], h0.r[NMB - 1], hcur.r[0], hcur.r[NMB - 1]);   // the four header loads are older than the pieces
         tab_store(h0, 0, 0); tab_store(h0, 1, 1); tab_store(hcur, 0, 2);
         X4L_WAIT_VM(2 * NLD);                                                   // stage 0 has landed
         X4L_WAIT_LGKM0();
@@ -122,8 +125,8 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
         int slot = 0;
         Hdr hnext = hcur;
         for (int s = 0; s + 1 < nstage; s++) {
-            if (s + 2 < nstage) X4L_WAIT_VM_TIED4(NLD, hcur.r[0], hcur.r[1], hnext.r[0], hnext.r[1]);
-            else X4L_WAIT_VM_TIED4(0, hcur.r[0], hcur.r[1], hnext.r[0], hnext.r[1]);
+            if (s + 2 < nstage) X4L_WAIT_VM_TIED4(NLD, hcur.r[0], hcur.r[NMB - 1], hnext.r[0], hnext.r[NMB - 1]);
+            else X4L_WAIT_VM_TIED4(0, hcur.r[0], hcur.r[NMB - 1], hnext.r[0], hnext.r[NMB - 1]);
             X4L_WAIT_LGKM0();                                                    // the table written last block is in LDS
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -140,10 +143,10 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
         // ================================================================ compute waves
         DqConst dq; dq.init();
         const int xrow_off = j * RS, xswz = j & 15;
-        Raw<TYPE> rq[2][2];                               // [row block mb][64-k group g of the stage]: only .q is used
-        typename Raw<TYPE>::Sc z[2][2];
+        Raw<TYPE> rq[NMB][2];                             // [row block mb][64-k group g of the stage]: only .q is used
+        typename Raw<TYPE>::Sc z[NMB][2];
         half8_t xa[2][BNF];                               // activation fragments of one k-step, double-buffered
-        uint32_t cur[2][4], nxt[2][4];
+        uint32_t cur[NMB][4], nxt[NMB][4];
         auto read_xa = [&](int slot_, int t, int buf) __attribute__((always_inline)) {          // k-step t = (g, kk) of the stage
             const uint8_t *xs = smem + slot_ * ST + xrow_off;
             const int coff = (((t >> 2) * 8 + chunk_of<TYPE>(t & 3, h)) ^ xswz) << 4;
@@ -152,21 +155,21 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
         };
         auto read_w = [&](int slot_, int g) __attribute__((always_inline)) {                    // nibbles + table entry of group g, both row blocks
 #pragma unroll
-            for (int mb = 0; mb < 2; mb++) {
-                const int row = mg * 64 + mb * 32 + j;
+            for (int mb = 0; mb < NMB; mb++) {
+                const int row = mg * 32 * NMB + mb * 32 + j;
                 rq[mb][g].q = *reinterpret_cast<const u32x4 *>(smem + slot_ * ST + XS + row * 64 + (((2 * g + h) ^ ((row >> 2) & 3)) << 4));
                 const u32x2 te = *reinterpret_cast<const u32x2 *>(smem + slot_ * ST + XS + WQS + (row * 2 + g) * 8);
                 const half2_t lo = as_h2(te.x), hi = as_h2(te.y);
                 z[mb][g].SL = half2_t{lo.x, lo.x}; z[mb][g].CL = half2_t{lo.y, lo.y}; z[mb][g].SH = half2_t{hi.x, hi.x}; z[mb][g].CH = half2_t{hi.y, hi.y};
             }
         };
-        // 8 MFMAs of k-step t with `between(n)` after the n-th
+        // the 4 NMB MFMAs of k-step t with `between(n)` after the n-th
         auto mfma8 = [&](int buf, auto &&between) __attribute__((always_inline)) {
-            half8_t wfk[2];
+            half8_t wfk[NMB];
 #pragma unroll
-            for (int mb = 0; mb < 2; mb++) { const u32x4 cw = {cur[mb][0], cur[mb][1], cur[mb][2], cur[mb][3]}; wfk[mb] = __builtin_bit_cast(half8_t, cw); }
+            for (int mb = 0; mb < NMB; mb++) { const u32x4 cw = {cur[mb][0], cur[mb][1], cur[mb][2], cur[mb][3]}; wfk[mb] = __builtin_bit_cast(half8_t, cw); }
 #pragma unroll
-            for (int mb = 0; mb < 2; mb++)
+            for (int mb = 0; mb < NMB; mb++)
 #pragma unroll
                 for (int bf = 0; bf < BNF; bf++) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
                     between(mb * 4 + bf);
                 }
 #pragma unroll
-            for (int mb = 0; mb < 2; mb++)
+            for (int mb = 0; mb < NMB; mb++)
 #pragma unroll
                 for (int i = 0; i < 4; i++) cur[mb][i] = nxt[mb][i];
         };
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
         asm volatile("" ::: "memory");
         read_w(0, 0); read_xa(0, 0, 0);
 #pragma unroll
-        for (int mb = 0; mb < 2; mb++)
+        for (int mb = 0; mb < NMB; mb++)
 #pragma unroll
             for (int i = 0; i < 4; i++) { cur[mb][i] = rq[mb][0].pairbits(0, i, z[mb][0], dq); nxt[mb][i] = 0; }
         int slot = 0;
@@ -208,13 +211,13 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
                 read_w(slot1, 0); read_xa(slot1, 0, 0);                          // stage s + 1, published by the barrier
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // k-step 7: the eight half2 of the next stage's first fragments go behind the LAST four MFMAs (their LDS reads
-            // were issued just above and need ~4 MFMAs to return)
+            // k-step 7: the 4 NMB half2 of the next stage's first fragments go behind the LAST 2 NMB MFMAs, two each (their LDS
+            // reads were issued just above and need a few MFMAs to return)
             // (on the last stage the same arithmetic runs on stale registers and its result is never used: no branch in the stream)
             mfma8(1, [&](int n) __attribute__((always_inline)) {
-                if (n >= 4) {
+                if (n >= 2 * NMB) {
 #pragma unroll
-                    for (int e = 0; e < 2; e++) { const int q = (n - 4) * 2 + e, mb = q >> 2, i = q & 3; nxt[mb][i] = rq[mb][0].pairbits(0, i, z[mb][0], dq); }
+                    for (int e = 0; e < 2; e++) { const int q = (n - 2 * NMB) * 2 + e, mb = q >> 2, i = q & 3; nxt[mb][i] = rq[mb][0].pairbits(0, i, z[mb][0], dq); }
                 }
             });
             slot = slot1;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
     const int tile_id = tile_m * p.tiles_b + tile_b;
     constexpr int NBF = BNF / S;                                        // accumulator b-blocks kept per work-group
     if constexpr (S > 1) {
-        constexpr int PF4 = 4 * 2 * NBF * 4 * 64;                        // float4 per (tile, dst, src) partial: [mg][mb][bfl][q4][lane]
+        constexpr int PF4 = 4 * NMB * NBF * 4 * 64;                      // float4 per (tile, dst, src) partial: [mg][mb][bfl][q4][lane]
         float4 *pbase = reinterpret_cast<float4 *>(p.partial) + (size_t)tile_id * S * S * PF4;
         auto exchange = [&](auto KS) __attribute__((always_inline)) {
             constexpr int me = decltype(KS)::value;
@@ -238,14 +241,14 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
                     float4 *dst = pbase + (size_t)(d * S + me) * PF4;
                     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, PF4 * 16, 0x00020000);
 #pragma unroll
-                    for (int mb = 0; mb < 2; mb++)
+                    for (int mb = 0; mb < NMB; mb++)
 #pragma unroll
                         for (int bl = 0; bl < NBF; bl++)
 #pragma unroll
                             for (int q4 = 0; q4 < 4; q4++) {
                                 const int bf = d * NBF + bl;
                                 const float4 v = make_float4(acc[mb][bf][4 * q4], acc[mb][bf][4 * q4 + 1], acc[mb][bf][4 * q4 + 2], acc[mb][bf][4 * q4 + 3]);
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (((((mg * 2 + mb) * NBF + bl) * 4 + q4) * 64) + lane) * 16, 0, 16);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (((((mg * NMB + mb) * NBF + bl) * 4 + q4) * 64) + lane) * 16, 0, 16);
                             }
                 }
                 X4L_WAIT_VM(0);
@@ -269,15 +272,15 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
                 for (int o = 0; o < S; o++) {                            // fixed order: deterministic
                     if (o == me) continue;
                     const float4 *src = pbase + (size_t)(me * S + o) * PF4;
-                    float4 t[2 * NBF * 4];
+                    float4 t[NMB * NBF * 4];
 #pragma unroll
-                    for (int i = 0; i < 2 * NBF * 4; i++) t[i] = src[((mg * 2 * NBF * 4) + i) * 64 + lane];
+                    for (int i = 0; i < NMB * NBF * 4; i++) t[i] = src[((mg * NMB * NBF * 4) + i) * 64 + lane];
                     if (xchg_failed) {                                      // NaN tile instead of a silently wrong sum
 #pragma unroll
-                        for (int i = 0; i < 2 * NBF * 4; i++) t[i].x = __builtin_nanf("");
+                        for (int i = 0; i < NMB * NBF * 4; i++) t[i].x = __builtin_nanf("");
                     }
 #pragma unroll
-                    for (int mb = 0; mb < 2; mb++)
+                    for (int mb = 0; mb < NMB; mb++)
 #pragma unroll
                         for (int bl = 0; bl < NBF; bl++)
 #pragma unroll
@@ -295,28 +298,29 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
         else if (S > 2) exchange(std::integral_constant<int, (S > 2 ? 3 : 0)>{});
     }
     const int row_lo = (S > 1) ? ks * (128 / S) : 0;
-    constexpr int NROWS = 128 / S, CLD = 256;
+    constexpr int NROWS = 128 / S, CLD = TM;
     float *ctile = reinterpret_cast<float *>(smem);                       // the ring is dead: [NROWS][256] fp32 <= 128 KB
     __syncthreads();
     if (!is_loader) {
 #pragma unroll
-        for (int mb = 0; mb < 2; mb++)
+        for (int mb = 0; mb < NMB; mb++)
 #pragma unroll
             for (int bf = 0; bf < BNF; bf++) {
                 if (bf * 32 < row_lo || bf * 32 >= row_lo + NROWS) continue;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int bl = bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h - row_lo;           // C/D layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-                    ctile[bl * CLD + mg * 64 + mb * 32 + j] = acc[mb][bf][r];
+                    ctile[bl * CLD + mg * 32 * NMB + mb * 32 + j] = acc[mb][bf][r];
                 }
             }
     }
     __syncthreads();
     {
-        const int c4 = tid & 63, r0 = tid >> 6;                             // 64 float4 per row, 8 rows per pass
+        constexpr int F4 = TM / 4, RPP = 512 / F4;                          // float4 per row, rows per pass
+        const int c4 = tid % F4, r0 = tid / F4;
 #pragma unroll
-        for (int pass = 0; pass < NROWS / 8; pass++) {
-            const int bl = pass * 8 + r0, b = b0 + row_lo + bl, m = m0 + c4 * 4;
+        for (int pass = 0; pass < NROWS / RPP; pass++) {
+            const int bl = pass * RPP + r0, b = b0 + row_lo + bl, m = m0 + c4 * 4;
             const float4 v = *reinterpret_cast<const float4 *>(ctile + bl * CLD + c4 * 4);
             if (b < p.B && m < p.M) {
                 float *dst = p.Y + (int64_t)b * p.y_row + m;
@@ -329,13 +333,15 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
 
 // launcher: Q4_K, K % 256 == 0, 16-byte-aligned rows; splitk 0 = the widest split whose work-groups are all co-resident and
 // keep two superblocks each.  Returns -1 (with a message) if the shape does not fit.
-int cdna4_launch_gemm_q4k_x4l(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
+template <int NMB>
+static int launch_x4l(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
+    constexpr int TM = 128 * NMB;
     if (a.type != CDNA4_Q4_K || a.K % 256 || ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) != 0))
         return cdna4_set_error_msg("gemm_q: the 4+4-wave 256x128 kernel takes 16-byte-aligned Q4_K rows with K % 256 == 0");
     gemm_params p{};
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B;
-    p.tiles_m = (a.M + 255) / 256; p.tiles_b = (a.B + 127) / 128;
+    p.tiles_m = (a.M + TM - 1) / TM; p.tiles_b = (a.B + 127) / 128;
     const int ntiles = p.tiles_m * p.tiles_b, nsb = a.K / 256, cus = cdna4_gemm_cu_count();
     int S = splitk;
     if (S <= 0) {
@@ -347,16 +353,20 @@ int cdna4_launch_gemm_q4k_x4l(const cdna4_gemm_args &a, int splitk, hipStream_t 
     if (S > 1 && ntiles * S > cus) return cdna4_set_error_msg("gemm_q: the split-K exchange needs every work-group resident");
     p.splitk = S;
     if (S > 1) {
-        const size_t pbytes = (size_t)ntiles * S * (256 * 128 * 4);
+        const size_t pbytes = (size_t)ntiles * S * (TM * 128 * 4);
         char *sc = (char *)cdna4_gemm_scratch(pbytes + (size_t)ntiles * S * 4 + 256, 0);
         if (!sc) return cdna4_set_error_msg("gemm_q: cannot allocate split-K scratch");
         p.partial = (float *)sc; p.flags = (unsigned *)(sc + pbytes);
         p.epoch = cdna4_gemm_next_epoch();
     }
     const dim3 grid(ntiles * S);
-    if (S == 1) hipLaunchKernelGGL((k_gemm_q4k_x4l<1>), grid, dim3(512), 0, st, p);
-    else if (S == 2) hipLaunchKernelGGL((k_gemm_q4k_x4l<2>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((k_gemm_q4k_x4l<4>), grid, dim3(512), 0, st, p);
+    if (S == 1) hipLaunchKernelGGL((k_gemm_q4k_x4l<1, NMB>), grid, dim3(512), 0, st, p);
+    else if (S == 2) hipLaunchKernelGGL((k_gemm_q4k_x4l<2, NMB>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_q4k_x4l<4, NMB>), grid, dim3(512), 0, st, p);
     CDNA4_CHECK_LAUNCH();
     return 0;
+}
+// rows128 != 0: the 128 x 128 tile form (NMB = 1)
+int cdna4_launch_gemm_q4k_x4l(const cdna4_gemm_args &a, int splitk, int rows128, hipStream_t st) {
+    return rows128 ? launch_x4l<1>(a, splitk, st) : launch_x4l<2>(a, splitk, st);
 }

@@ -73,11 +73,12 @@ def test_experimental_4plus4_wave_kernel_resources(tmp_path):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out), src],
                    check=True, capture_output=True, timeout=900)
     asm = out.read_text()
-    for s in (1, 2, 4):
-        k = "_Z14k_gemm_q4k_x4lILi%dEEv11gemm_params" % s
-        assert _prop(asm, k, "private_seg_size") == 0
-        assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= 256
-        assert _lds(asm, k) <= 160 * 1024
+    for nmb in (1, 2):                       # 128 x 128 and 256 x 128 tile forms
+        for s in (1, 2, 4):
+            k = "_Z14k_gemm_q4k_x4lILi%dELi%dEEv11gemm_params" % (s, nmb)
+            assert _prop(asm, k, "private_seg_size") == 0
+            assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= 256
+            assert _lds(asm, k) <= 160 * 1024
 
 
 def test_experimental_kernel_data_movement_emulation():
@@ -92,8 +93,9 @@ def test_experimental_kernel_data_movement_emulation():
     assert mod.main(M=200, B=100, K=768, seed=2) < 1e-12          # ragged edges: clamped rows only add work, never wrong sums
 
 
+@pytest.mark.parametrize("rows128", [0, 1])
 @pytest.mark.parametrize("m,k,b,splitk", [(256, 512, 128, 1), (300, 768, 200, 1), (513, 1024, 129, 2), (256, 2048, 128, 4), (700, 2560, 90, 4)])
-def test_experimental_kernel_source_runs_correctly_on_the_cpu(m, k, b, splitk):
+def test_experimental_kernel_source_runs_correctly_on_the_cpu(m, k, b, splitk, rows128):
     """tools/emul: the C++ of k_gemm_q4k_x4l itself, compiled for the host and executed one OS thread per GPU thread (LDS-DMA
     and waits made synchronous, v_mfma emulated lane for lane, one process per work-group so that the split-K exchange runs
     between co-resident work-groups) reproduces a direct product of the same fp16 operands — loop bounds, loader vs compute
@@ -104,7 +106,7 @@ def test_experimental_kernel_source_runs_correctly_on_the_cpu(m, k, b, splitk):
     spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.run(m, k, b, seed=m + k, timeout=300, splitk=splitk) < 1e-6
+    assert mod.run(m, k, b, seed=m + k, timeout=300, splitk=splitk, exp=rows128) < 1e-6
 
 
 @pytest.mark.parametrize("m,k,b,splitk,exp,l2", [(300, 1536, 200, 1, 0, 1), (256, 2048, 128, 2, 0, 1), (256, 2048, 128, 2, 0, 0), (256, 1024, 128, 1, 100, 1),
@@ -128,8 +130,8 @@ def test_shipped_12_wave_kernel_source_and_its_candidates_on_the_cpu(m, k, b, sp
         assert np.array_equal(y, y0)
 
 
-@pytest.mark.parametrize("kernel,m,k,b,splitk", [("x4l", 300, 1536, 200, 1), ("x4l", 256, 2048, 128, 4), ("w12", 300, 1536, 200, 1), ("w12", 256, 2048, 128, 2)])
-def test_counted_vmcnt_waits_are_sufficient_and_tight(kernel, m, k, b, splitk, monkeypatch):
+@pytest.mark.parametrize("kernel,m,k,b,splitk,exp", [("x4l", 300, 1536, 200, 1, 0), ("x4l", 256, 2048, 128, 4, 0), ("x4l", 300, 1536, 200, 2, 1), ("w12", 300, 1536, 200, 1, 0), ("w12", 256, 2048, 128, 2, 0)])
+def test_counted_vmcnt_waits_are_sufficient_and_tight(kernel, m, k, b, splitk, exp, monkeypatch):
     """EMU_DEFER_DMA=1: every LDS-DMA copy lands as LATE as the hardware permits — only when an s_waitcnt vmcnt(n) of the issuing
     wave retires it, in order — so a missing or too-weak wait leaves stale bytes in LDS.  Both kernels pass as written, and fail
     as soon as every wait tolerates one more outstanding operation (the self-test of this check)"""
@@ -139,6 +141,6 @@ def test_counted_vmcnt_waits_are_sufficient_and_tight(kernel, m, k, b, splitk, m
     spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.run(m, k, b, seed=3, timeout=600, splitk=splitk, kernel=kernel, defer_dma=True) < 1e-6
+    assert mod.run(m, k, b, seed=3, timeout=600, splitk=splitk, kernel=kernel, exp=exp, defer_dma=True) < 1e-6
     monkeypatch.setenv("EMU_WEAKEN_WAITS", "1")
-    assert mod.run(m, k, b, seed=3, timeout=600, splitk=splitk, kernel=kernel, defer_dma=True) > 1e-3
+    assert mod.run(m, k, b, seed=3, timeout=600, splitk=splitk, kernel=kernel, exp=exp, defer_dma=True) > 1e-3

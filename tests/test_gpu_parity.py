@@ -231,8 +231,9 @@ def test_gemm_256x128_tile_kernel(gu, m, k, b, splitk):
 
 
 @pytest.mark.skipif(os.environ.get("CDNA4_TEST_EXPERIMENTAL") != "1", reason="experimental kernel, opt-in: CDNA4_TEST_EXPERIMENTAL=1")
+@pytest.mark.parametrize("variant", [8199, 24583])                # 256 x 128 tile; bit 14: the 128 x 128 tile form
 @pytest.mark.parametrize("m,k,b,splitk", [(256, 512, 128, 1), (300, 2048, 200, 4), (513, 1024, 129, 2), (700, 1536, 90, 1), (1024, 4096, 512, 0), (4096, 4096, 512, 0)])
-def test_gemm_4plus4_wave_256x128_kernel(gu, m, k, b, splitk):
+def test_gemm_4plus4_wave_256x128_kernel(gu, m, k, b, splitk, variant):
     """variant bit 13 (gemm_q_x4l.hip, not selected by default): four compute + four loader waves on a 256x128 tile — same
     per-weight arithmetic and k order as the default kernel, so the results must agree to summation order"""
     from ggml_amd import ops
@@ -240,11 +241,11 @@ def test_gemm_4plus4_wave_256x128_kernel(gu, m, k, b, splitk):
     w = R.random_weights(t, m, k, seed=m + k + b)
     x = _x(m * 2 + b, b, k)
     a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
-    y = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=8199, splitk=splitk).cpu().numpy()
+    y = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=variant, splitk=splitk).cpu().numpy()
     yd = ops.mul_mat(a, xd, path=ops.PATH_GEMM).cpu().numpy()
-    e = R.rel_l2(y, yd); gu.report(test="gemm_x4l", m=m, k=k, b=b, splitk=splitk, rel_l2=e)
+    e = R.rel_l2(y, yd); gu.report(test="gemm_x4l", variant=variant, m=m, k=k, b=b, splitk=splitk, rel_l2=e)
     assert np.isfinite(y).all() and e < 2e-6
-    y2 = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=8199, splitk=splitk).cpu().numpy()
+    y2 = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=variant, splitk=splitk).cpu().numpy()
     assert np.array_equal(y, y2)
     if m < 1100:
         assert R.rel_l2(y, R.o_mul_mat(t, w, x, m, k)) < TOL_GEMM

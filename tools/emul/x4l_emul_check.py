@@ -53,7 +53,7 @@ def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, 
     with tempfile.TemporaryDirectory() as d:
         # the weight file must start 16-byte aligned in memory: the emulator reads it into a std::vector (malloc: 16-byte aligned)
         w.tofile(os.path.join(d, "w.bin")); img.tofile(os.path.join(d, "xh.bin"))
-        extra = [str(splitk)] if kernel == "x4l" else [str(splitk), str(exp), str(xchg_l2)]
+        extra = [str(splitk), str(exp)] if kernel == "x4l" else [str(splitk), str(exp), str(xchg_l2)]       # x4l: exp 1 = the 128 x 128 tile form
         r = subprocess.run([build(kernel), str(M), str(K), str(B), os.path.join(d, "w.bin"), os.path.join(d, "xh.bin"), os.path.join(d, "y.bin")] + extra,
                            capture_output=True, text=True, timeout=timeout, env=dict(os.environ, EMU_DEFER_DMA="1" if defer_dma else "0"))
         assert r.returncode == 0, r.stderr[-500:]
