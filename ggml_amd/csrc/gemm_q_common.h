@@ -484,4 +484,4 @@ template <> struct WStage<CDNA4_Q6_KS, 2> { static constexpr int NPH = 9; __devi
 void *cdna4_gemm_scratch(size_t bytes, int kind);      // per-device scratch, zero-filled when (re)allocated; kind 0: split-K exchange, 1: repacked weights
 unsigned cdna4_gemm_next_epoch();                      // the per-launch tag of the exchange flags (never 0)
 int cdna4_gemm_cu_count();
-int cdna4_launch_gemm_q4k_x4l(const cdna4_gemm_args &a, int splitk, int rows128, hipStream_t st);   // gemm_q_x4l.hip (experimental)
+int cdna4_launch_gemm_q4k_x4l(const cdna4_gemm_args &a, int splitk, int form, hipStream_t st);   // gemm_q_x4l.hip (experimental)

@@ -1316,7 +1316,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         else splitk = 1;
     }
     if constexpr (TYPE == CDNA4_Q4_K) {
-        if (wlds && a.variant > 0 && (variant & 8192)) return cdna4_launch_gemm_q4k_x4l(a, a.splitk, (variant & 16384) != 0, st);   // experimental 4 + 4-wave kernels (explicit only): 256x128 tile, bit14: 128x128
+        if (wlds && a.variant > 0 && (variant & 8192)) return cdna4_launch_gemm_q4k_x4l(a, a.splitk, (variant & 16384) ? 1 : ((variant & 32768) ? 2 : 0), st);   // experimental loader-wave kernels (explicit only): 256x128 tile with 4 compute waves; bit14: 128x128; bit15: 256x128 with 8 compute waves
         if (wlds && (variant & 1024)) return launch_x2<TYPE>(a, a.splitk, st);
         // auto: the 256x128 tile kernel needs half the activation bytes per MFMA, but its deeper tiles only pay off once the
         // grid is at least two full waves of work-groups without any K split (measured: C5 32768x8192x512 272 vs 318 us =

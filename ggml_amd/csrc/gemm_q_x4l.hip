@@ -21,15 +21,18 @@
 // NMB = 32-row blocks per compute wave: 2 = the 256 x 128 tile described above; 1 = a 128 x 128 tile with the same structure (one
 // activation fragment per MFMA again, but still no K split inside the work-group, one wave per SIMD and loader waves) for
 // the grids that are too small for 256-row tiles (the headline 4096 x 4096 x 512: 128 tiles x split-K 2).
-template <int S, int NMB>
-__global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
+// NCW = compute waves: 4 (one per SIMD) or, with NMB = 1, 8 (two per SIMD, 139 registers each: 12 waves fit the 168-register
+// budget) on a 256 x 128 tile — the partner wave hides a wave's LDS latency as in the shipped kernels, at the price of one
+// activation ds_read per MFMA again; the activation DMA per MFMA stays halved.
+template <int S, int NMB, int NCW>
+__global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_params p) {
     constexpr int TYPE = CDNA4_Q4_K;
-    constexpr int BNF = 4, TB = 128, TM = 128 * NMB, NST = 3;
+    constexpr int BNF = 4, TB = 128, TM = 32 * NMB * NCW, NST = 3, NTR = TM / 128;   // NTR: table rows per loader lane
     constexpr int RS = 256, XS = TB * RS;                 // activations: 128 rows x 256 B
     constexpr int BLK = QT<TYPE>::BYTES;                  // 144
     constexpr int WQS = TM * 64, TS = TM * 16;            // nibbles: 256 rows x 64 B; table: 256 rows x 2 groups x 8 B
     constexpr int ST = XS + WQS + TS;                     // 53,248 (NMB = 2) / 43,008 (NMB = 1)
-    constexpr int NXL = 8, NWL = 2 * NMB, NLD = NXL + NWL; // DMA wave-pieces per loader wave and stage
+    constexpr int NXL = 8, NWL = TM / 64, NLD = NXL + NWL; // DMA wave-pieces per loader wave and stage
     constexpr int SMEM = NST * ST > 128 * 1024 ? NST * ST : 128 * 1024;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
@@ -37,8 +40,8 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
 
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_loader = wave >= 4;
-    const int mg = wave & 3;                              // compute: 64-row group; loader: its index
+    const bool is_loader = wave >= NCW;
+    const int mg = is_loader ? wave - NCW : wave;         // compute: its row group; loader: its index (0..3)
     const int nblk = gridDim.x;
     int L = blockIdx.x;
     if ((nblk & 7) == 0) L = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
 
     if (is_loader) {
         // ================================================================ loader waves
-        uint32_t xvoff[NXL], wvoff[NWL], hoff[NMB];
+        uint32_t xvoff[NXL], wvoff[NWL], hoff[NTR];
 #pragma unroll
         for (int i = 0; i < NXL; i++) {                    // activation wave-piece q = mg + 4 i: LDS bytes [1024 q, 1024 q + 1024) of the slot
             const int pc = (mg + 4 * i) * 64 + lane, row = pc >> 4, c = (pc & 15) ^ (row & 15);
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
         }
         const int lidx = (mg << 6) | lane, lrow = lidx >> 1, lgl = lidx & 1;      // table: rows lrow (and lrow + 128), group lgl of the stage
 #pragma unroll
-        for (int r = 0; r < NMB; r++) hoff[r] = (uint32_t)(min(m0 + lrow + 128 * r, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
+        for (int r = 0; r < NTR; r++) hoff[r] = (uint32_t)(min(m0 + lrow + 128 * r, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
 
         auto dma16 = [&](const char *sbase, uint32_t voff, uint32_t lds_addr) __attribute__((always_inline)) {
             X4L_DMA16(voff, sbase, lds_addr);
@@ -91,17 +94,17 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
 #pragma unroll
             for (int i = 0; i < NWL; i++) dma16(ws, wvoff[i], l + XS + (mg + 4 * i) * 1024);
         };
-        struct Hdr { u32x4 r[NMB]; };
+        struct Hdr { u32x4 r[NTR]; };
         auto hload = [&](int sbr) __attribute__((always_inline)) {
             Hdr v; const char *sb = wbase + (int64_t)sbr * BLK;
 #pragma unroll
-            for (int r = 0; r < NMB; r++) X4L_GLOAD16(v.r[r], hoff[r], sb);
+            for (int r = 0; r < NTR; r++) X4L_GLOAD16(v.r[r], hoff[r], sb);
             return v;
         };
         auto tab_store = [&](const Hdr &hd, int part, int slot) __attribute__((always_inline)) {    // the arithmetic of Raw<Q4_K>::scales()
             const int g = part * 2 + lgl;
 #pragma unroll
-            for (int r = 0; r < NMB; r++) {
+            for (int r = 0; r < NTR; r++) {
                 const u32x4 hdr = hd.r[r];
                 int s0, mn0, s1, mn1;
                 k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g, s0, mn0); k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g + 1, s1, mn1);
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
         // prologue: stages 0, 1, 2 -> slots 0, 1, 2
         Hdr h0 = hload(0), hcur = hload(1);
         issue(0, 0); issue(1, 1); issue(2, 2);
-        X4L_WAIT_VM_TIED4(3 * NLD, h0.r[0], h0.r[NMB - 1], hcur.r[0], hcur.r[NMB - 1]);   // the four header loads are older than the pieces
+        X4L_WAIT_VM_TIED4(3 * NLD, h0.r[0], h0.r[NTR - 1], hcur.r[0], hcur.r[NTR - 1]);   // the four header loads are older than the pieces
         tab_store(h0, 0, 0); tab_store(h0, 1, 1); tab_store(hcur, 0, 2);
         X4L_WAIT_VM(2 * NLD);                                                   // stage 0 has landed
         X4L_WAIT_LGKM0();
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
         int slot = 0;
         Hdr hnext = hcur;
         for (int s = 0; s + 1 < nstage; s++) {
-            if (s + 2 < nstage) X4L_WAIT_VM_TIED4(NLD, hcur.r[0], hcur.r[NMB - 1], hnext.r[0], hnext.r[NMB - 1]);
-            else X4L_WAIT_VM_TIED4(0, hcur.r[0], hcur.r[NMB - 1], hnext.r[0], hnext.r[NMB - 1]);
+            if (s + 2 < nstage) X4L_WAIT_VM_TIED4(NLD, hcur.r[0], hcur.r[NTR - 1], hnext.r[0], hnext.r[NTR - 1]);
+            else X4L_WAIT_VM_TIED4(0, hcur.r[0], hcur.r[NTR - 1], hnext.r[0], hnext.r[NTR - 1]);
             X4L_WAIT_LGKM0();                                                    // the table written last block is in LDS
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
     const int tile_id = tile_m * p.tiles_b + tile_b;
     constexpr int NBF = BNF / S;                                        // accumulator b-blocks kept per work-group
     if constexpr (S > 1) {
-        constexpr int PF4 = 4 * NMB * NBF * 4 * 64;                      // float4 per (tile, dst, src) partial: [mg][mb][bfl][q4][lane]
+        constexpr int PF4 = NCW * NMB * NBF * 4 * 64;                      // float4 per (tile, dst, src) partial: [mg][mb][bfl][q4][lane]
         float4 *pbase = reinterpret_cast<float4 *>(p.partial) + (size_t)tile_id * S * S * PF4;
         auto exchange = [&](auto KS) __attribute__((always_inline)) {
             constexpr int me = decltype(KS)::value;
@@ -316,10 +319,10 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
     }
     __syncthreads();
     {
-        constexpr int F4 = TM / 4, RPP = 512 / F4;                          // float4 per row, rows per pass
+        constexpr int F4 = TM / 4, RPP = 512 / F4;                          // float4 per row, rows per pass (the first 512 threads store)
         const int c4 = tid % F4, r0 = tid / F4;
 #pragma unroll
-        for (int pass = 0; pass < NROWS / RPP; pass++) {
+        for (int pass = 0; pass < (tid < 512 ? NROWS / RPP : 0); pass++) {
             const int bl = pass * RPP + r0, b = b0 + row_lo + bl, m = m0 + c4 * 4;
             const float4 v = *reinterpret_cast<const float4 *>(ctile + bl * CLD + c4 * 4);
             if (b < p.B && m < p.M) {
@@ -333,9 +336,9 @@ __global__ __launch_bounds__(512) void k_gemm_q4k_x4l(const gemm_params p) {
 
 // launcher: Q4_K, K % 256 == 0, 16-byte-aligned rows; splitk 0 = the widest split whose work-groups are all co-resident and
 // keep two superblocks each.  Returns -1 (with a message) if the shape does not fit.
-template <int NMB>
+template <int NMB, int NCW>
 static int launch_x4l(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    constexpr int TM = 128 * NMB;
+    constexpr int TM = 32 * NMB * NCW;
     if (a.type != CDNA4_Q4_K || a.K % 256 || ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) != 0))
         return cdna4_set_error_msg("gemm_q: the 4+4-wave 256x128 kernel takes 16-byte-aligned Q4_K rows with K % 256 == 0");
     gemm_params p{};
@@ -360,13 +363,13 @@ static int launch_x4l(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
         p.epoch = cdna4_gemm_next_epoch();
     }
     const dim3 grid(ntiles * S);
-    if (S == 1) hipLaunchKernelGGL((k_gemm_q4k_x4l<1, NMB>), grid, dim3(512), 0, st, p);
-    else if (S == 2) hipLaunchKernelGGL((k_gemm_q4k_x4l<2, NMB>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((k_gemm_q4k_x4l<4, NMB>), grid, dim3(512), 0, st, p);
+    if (S == 1) hipLaunchKernelGGL((k_gemm_q4k_x4l<1, NMB, NCW>), grid, dim3((NCW + 4) * 64), 0, st, p);
+    else if (S == 2) hipLaunchKernelGGL((k_gemm_q4k_x4l<2, NMB, NCW>), grid, dim3((NCW + 4) * 64), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_q4k_x4l<4, NMB, NCW>), grid, dim3((NCW + 4) * 64), 0, st, p);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
-// rows128 != 0: the 128 x 128 tile form (NMB = 1)
-int cdna4_launch_gemm_q4k_x4l(const cdna4_gemm_args &a, int splitk, int rows128, hipStream_t st) {
-    return rows128 ? launch_x4l<1>(a, splitk, st) : launch_x4l<2>(a, splitk, st);
+// form 0: 256 x 128 tile, 4 compute waves x 64 rows; 1: 128 x 128 tile, 4 x 32 rows; 2: 256 x 128 tile, 8 compute waves x 32 rows
+int cdna4_launch_gemm_q4k_x4l(const cdna4_gemm_args &a, int splitk, int form, hipStream_t st) {
+    return form == 1 ? launch_x4l<1, 4>(a, splitk, st) : (form == 2 ? launch_x4l<1, 8>(a, splitk, st) : launch_x4l<2, 4>(a, splitk, st));
 }

@@ -23,10 +23,10 @@ cd ../..
 cd tools/microbench
 { GB_VARIANTS=4119,69655,135191,266263,397335 GB_SPLITKS=0,1 timeout 60 ./gemm_bench_abl 4096 4096 512 "" 2>&1 | tail -12
   GB_VARIANTS=4119,135191,266263,397335 GB_SPLITKS=1 timeout 60 ./gemm_bench_abl 8192 4096 512 "" 2>&1 | tail -6; } > ../../gpurun_out/w12_candidates.txt 2>&1
-# (2d) the experimental 4 + 4-wave kernels (variant 8199: 256x128 tile, 24583: 128x128 tile) next to the default (rel-L2 must be ~1e-7): one shape per process,
+# (2d) the experimental 4 + 4-wave kernels (variant 8199: 256x128 tile / 4 compute waves, 24583: 128x128 tile, 40967: 256x128 / 8 compute waves) next to the default (rel-L2 must be ~1e-7): one shape per process,
 #      a short timeout each — a barrier mismatch in a first run would hang
 { for shape in "1024 1024 256" "4096 4096 512" "8192 4096 512" "32768 8192 512"; do
-    GB_VARIANTS=4119,8199,24583 GB_SPLITKS=0 GB_ROUNDS=2 timeout 30 ./gemm_bench_abl $shape "" 2>&1 | tail -4; echo "   exit $?"
+    GB_VARIANTS=4119,8199,24583,40967 GB_SPLITKS=0 GB_ROUNDS=2 timeout 30 ./gemm_bench_abl $shape "" 2>&1 | tail -5; echo "   exit $?"
   done; } > ../../gpurun_out/x4l.txt 2>&1
 # (2c) the clock the chip settles at while the shipped / no-DMA / stripped loops run back to back (EXP bit 512 records it)
 { for shape in "4096 4096" "8192 4096"; do

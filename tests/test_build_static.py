@@ -73,11 +73,11 @@ def test_experimental_4plus4_wave_kernel_resources(tmp_path):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out), src],
                    check=True, capture_output=True, timeout=900)
     asm = out.read_text()
-    for nmb in (1, 2):                       # 128 x 128 and 256 x 128 tile forms
+    for nmb, ncw, regs in ((2, 4, 256), (1, 4, 256), (1, 8, 168)):        # 256x128 (4 compute waves), 128x128, 256x128 (8 compute waves: 12 waves -> 168 registers)
         for s in (1, 2, 4):
-            k = "_Z14k_gemm_q4k_x4lILi%dELi%dEEv11gemm_params" % (s, nmb)
+            k = "_Z14k_gemm_q4k_x4lILi%dELi%dELi%dEEv11gemm_params" % (s, nmb, ncw)
             assert _prop(asm, k, "private_seg_size") == 0
-            assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= 256
+            assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= regs
             assert _lds(asm, k) <= 160 * 1024
 
 
@@ -93,7 +93,7 @@ def test_experimental_kernel_data_movement_emulation():
     assert mod.main(M=200, B=100, K=768, seed=2) < 1e-12          # ragged edges: clamped rows only add work, never wrong sums
 
 
-@pytest.mark.parametrize("rows128", [0, 1])
+@pytest.mark.parametrize("rows128", [0, 1, 2])      # the kernel's three forms: 256x128 / 4 compute waves, 128x128 / 4, 256x128 / 8
 @pytest.mark.parametrize("m,k,b,splitk", [(256, 512, 128, 1), (300, 768, 200, 1), (513, 1024, 129, 2), (256, 2048, 128, 4), (700, 2560, 90, 4)])
 def test_experimental_kernel_source_runs_correctly_on_the_cpu(m, k, b, splitk, rows128):
     """tools/emul: the C++ of k_gemm_q4k_x4l itself, compiled for the host and executed one OS thread per GPU thread (LDS-DMA
@@ -130,7 +130,7 @@ def test_shipped_12_wave_kernel_source_and_its_candidates_on_the_cpu(m, k, b, sp
         assert np.array_equal(y, y0)
 
 
-@pytest.mark.parametrize("kernel,m,k,b,splitk,exp", [("x4l", 300, 1536, 200, 1, 0), ("x4l", 256, 2048, 128, 4, 0), ("x4l", 300, 1536, 200, 2, 1), ("w12", 300, 1536, 200, 1, 0), ("w12", 256, 2048, 128, 2, 0)])
+@pytest.mark.parametrize("kernel,m,k,b,splitk,exp", [("x4l", 300, 1536, 200, 1, 0), ("x4l", 256, 2048, 128, 4, 0), ("x4l", 300, 1536, 200, 2, 1), ("x4l", 300, 1536, 200, 2, 2), ("w12", 300, 1536, 200, 1, 0), ("w12", 256, 2048, 128, 2, 0)])
 def test_counted_vmcnt_waits_are_sufficient_and_tight(kernel, m, k, b, splitk, exp, monkeypatch):
     """EMU_DEFER_DMA=1: every LDS-DMA copy lands as LATE as the hardware permits — only when an s_waitcnt vmcnt(n) of the issuing
     wave retires it, in order — so a missing or too-weak wait leaves stale bytes in LDS.  Both kernels pass as written, and fail

@@ -231,7 +231,7 @@ def test_gemm_256x128_tile_kernel(gu, m, k, b, splitk):
 
 
 @pytest.mark.skipif(os.environ.get("CDNA4_TEST_EXPERIMENTAL") != "1", reason="experimental kernel, opt-in: CDNA4_TEST_EXPERIMENTAL=1")
-@pytest.mark.parametrize("variant", [8199, 24583])                # 256 x 128 tile; bit 14: the 128 x 128 tile form
+@pytest.mark.parametrize("variant", [8199, 24583, 40967])         # 256 x 128 tile; bit 14: the 128 x 128 tile form; bit 15: 256 x 128 with 8 compute waves
 @pytest.mark.parametrize("m,k,b,splitk", [(256, 512, 128, 1), (300, 2048, 200, 4), (513, 1024, 129, 2), (700, 1536, 90, 1), (1024, 4096, 512, 0), (4096, 4096, 512, 0)])
 def test_gemm_4plus4_wave_256x128_kernel(gu, m, k, b, splitk, variant):
     """variant bit 13 (gemm_q_x4l.hip, not selected by default): four compute + four loader waves on a 256x128 tile — same
