@@ -144,3 +144,31 @@ def test_counted_vmcnt_waits_are_sufficient_and_tight(kernel, m, k, b, splitk, e
     assert mod.run(m, k, b, seed=3, timeout=600, splitk=splitk, kernel=kernel, exp=exp, defer_dma=True) < 1e-6
     monkeypatch.setenv("EMU_WEAKEN_WAITS", "1")
     assert mod.run(m, k, b, seed=3, timeout=600, splitk=splitk, kernel=kernel, exp=exp, defer_dma=True) > 1e-3
+
+
+def test_no_out_of_bounds_access_at_the_shape_that_faulted_on_the_gpu(tmp_path):
+    """DESIGN.md 4.3, open issue: a gemm_bench process at 8192 x 8192 x 512 died with a GPU fault.  The emulator places every
+    global buffer between inaccessible pages; the first and the last work-group of the shipped kernel at that shape (64 stages
+    each, full-size W / activation image / Y) run without touching them"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    M, K, B = 8192, 8192, 512
+    rng = np.random.default_rng(0)
+    nb = M * K // 256
+    w = rng.integers(0, 256, (nb, 144), dtype=np.uint8)
+    w[:, 0:2] = rng.uniform(0.001, 0.004, nb).astype(np.float16).view(np.uint8).reshape(nb, 2)
+    w[:, 2:4] = rng.uniform(0.01, 0.03, nb).astype(np.float16).view(np.uint8).reshape(nb, 2)
+    w.tofile(str(tmp_path / "w.bin"))
+    rng.uniform(-1, 1, (K // 128, B, 128)).astype(np.float16).tofile(str(tmp_path / "xh.bin"))
+    exe = mod.build("w12")
+    for blocks in ("0:1", "255:256"):
+        r = subprocess.run([exe, str(M), str(K), str(B), str(tmp_path / "w.bin"), str(tmp_path / "xh.bin"), str(tmp_path / "y.bin"), "1", "0", "1"],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, EMU_BLOCKS=blocks))
+        assert r.returncode == 0, (blocks, r.stderr[-300:])
+    y = np.fromfile(str(tmp_path / "y.bin"), np.float32).reshape(B, M)
+    assert np.isfinite(y[-128:, -128:]).all() and not (y[-128:, -128:] == -12345.0).any()      # the last work-group's tile was written

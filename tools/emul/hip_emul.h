@@ -50,7 +50,10 @@ inline void wg_barrier() { pthread_barrier_wait(&g_wg_barrier); }
 #define __builtin_amdgcn_s_barrier() emu::wg_barrier()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)      // only ever applied to wave-uniform values in these kernels
-#define __builtin_amdgcn_s_sleep(x) usleep(200)        // spin loops are bounded by iteration count: keep them slow enough for emulated partners
+// spin loops are bounded by iteration count: keep them slow enough for emulated partners, but give up after ~2 minutes of
+// waiting (a partner that is not being emulated, e.g. with EMU_BLOCKS) instead of spinning for hours
+static inline void emu_sleep() { static thread_local unsigned n = 0; usleep(200); if (++n > 600000u) { fprintf(stderr, "emulated spin loop gave up\n"); _exit(9); } }
+#define __builtin_amdgcn_s_sleep(x) emu_sleep()
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_s_memrealtime() 0ull

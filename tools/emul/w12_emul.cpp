@@ -3,7 +3,9 @@
 // kernel.  Test infrastructure.
 //   w12_emul M K B w.bin xh.bin y.bin splitk exp xchg_l2
 #include "hip_emul.h"
+#include <signal.h>
 #include <sys/mman.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <thread>
 #include <vector>
@@ -27,7 +29,15 @@ bool g_defer_dma = getenv("EMU_DEFER_DMA") && atoi(getenv("EMU_DEFER_DMA")) != 0
 size_t g_weaken = getenv("EMU_WEAKEN_WAITS") ? (size_t)atoi(getenv("EMU_WEAKEN_WAITS")) : 0;
 }
 int cdna4_set_error_msg(const char *m) { fprintf(stderr, "error: %s\n", m); return -1; }
-static void *shared_alloc(size_t n) { void *p = mmap(nullptr, n ? n : 1, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0); if (p == MAP_FAILED) { perror("mmap"); exit(2); } return p; }
+// global buffers: shared between the work-group processes, and each ends right in front of an inaccessible page — an access
+// past the end of W, the activation image, Y or the exchange scratch kills the work-group process (reported as a failure)
+static void *shared_alloc(size_t n) {
+    const size_t pg = 4096, body = (n + pg - 1) / pg * pg;
+    char *p = (char *)mmap(nullptr, body + 2 * pg, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) { perror("mmap"); exit(2); }
+    mprotect(p, pg, PROT_NONE); mprotect(p + pg + body, pg, PROT_NONE);      // one in front as well (tight when n is a page multiple)
+    return p + pg + ((body - n) & ~(size_t)15);       // 16-byte aligned, at most 15 bytes of slack before the rear guard page
+}
 
 #include "../../ggml_amd/csrc/gemm_q_common.h"
 #include "../../ggml_amd/csrc/gemm_q_hw.h"
@@ -36,11 +46,16 @@ void *cdna4_debug_trace = nullptr;
 
 template <typename F> static void emu_launch(F body, unsigned nblk, int nthreads) {
     emu::g_gridDim = dim3(nblk); emu::g_blockDim = dim3(nthreads);
+    // EMU_BLOCKS=lo:hi runs only work-groups lo..hi-1 (full-size problems: a few work-groups of a big grid)
+    unsigned b_lo = 0, b_hi = ~0u;
+    if (const char *e = getenv("EMU_BLOCKS")) sscanf(e, "%u:%u", &b_lo, &b_hi);
     std::vector<pid_t> kids;
     for (unsigned b = 0; b < nblk; b++) {
+        if (b < b_lo || b >= b_hi) continue;
         const pid_t pid = fork();
         if (pid < 0) { perror("fork"); exit(2); }
         if (pid > 0) { kids.push_back(pid); continue; }
+        prctl(PR_SET_PDEATHSIG, SIGKILL);                      // never outlive the harness
         pthread_barrier_init(&emu::g_wg_barrier, nullptr, nthreads);
         std::vector<emu::WaveState> waves(nthreads / 64);
         for (auto &w : waves) pthread_barrier_init(&w.bar, nullptr, 64);

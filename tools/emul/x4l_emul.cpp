@@ -4,7 +4,9 @@
 // A mismatch in barrier counts between loader and compute waves shows up as a hang (the test has a timeout), wrong
 // indexing as wrong numbers.  Asynchrony is not modelled (see hip_emul.h).
 #include "hip_emul.h"
+#include <signal.h>
 #include <sys/mman.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 #include <thread>
@@ -32,7 +34,15 @@ int cdna4_set_error_msg(const char *m) { fprintf(stderr, "error: %s\n", m); retu
 int cdna4_set_error(hipError_t, const char *, int) { return -1; }
 // memory every work-group must see (the kernel's global buffers): anonymous shared mappings, zero-filled, inherited by the
 // forked work-group processes
-static void *shared_alloc(size_t n) { void *p = mmap(nullptr, n ? n : 1, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0); if (p == MAP_FAILED) { perror("mmap"); exit(2); } return p; }
+// global buffers: shared between the work-group processes, and each ends right in front of an inaccessible page — an access
+// past the end of W, the activation image, Y or the exchange scratch kills the work-group process (reported as a failure)
+static void *shared_alloc(size_t n) {
+    const size_t pg = 4096, body = (n + pg - 1) / pg * pg;
+    char *p = (char *)mmap(nullptr, body + 2 * pg, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) { perror("mmap"); exit(2); }
+    mprotect(p, pg, PROT_NONE); mprotect(p + pg + body, pg, PROT_NONE);      // one in front as well (tight when n is a page multiple)
+    return p + pg + ((body - n) & ~(size_t)15);       // 16-byte aligned, at most 15 bytes of slack before the rear guard page
+}
 void *cdna4_gemm_scratch(size_t n, int) { return shared_alloc(n); }
 unsigned cdna4_gemm_next_epoch() { return 1; }
 int cdna4_gemm_cu_count() { return 256; }
@@ -42,11 +52,16 @@ template <typename F> static void emu_launch(F body, dim3 grid, dim3 block) {
     const int nthreads = (int)block.x, nwaves = nthreads / 64;
     // one PROCESS per work-group, all at once: each has its own copy of the kernel's `static` (= __shared__) variables, they
     // share the global buffers (MAP_SHARED), and the work-groups of a split-K tile are co-resident as the exchange requires
+    // EMU_BLOCKS=lo:hi runs only work-groups lo..hi-1 (full-size problems: a few work-groups of a big grid)
+    unsigned b_lo = 0, b_hi = ~0u;
+    if (const char *e = getenv("EMU_BLOCKS")) sscanf(e, "%u:%u", &b_lo, &b_hi);
     std::vector<pid_t> kids;
     for (unsigned b = 0; b < grid.x; b++) {
+        if (b < b_lo || b >= b_hi) continue;
         const pid_t pid = fork();
         if (pid < 0) { perror("fork"); exit(2); }
         if (pid > 0) { kids.push_back(pid); continue; }
+        prctl(PR_SET_PDEATHSIG, SIGKILL);                      // never outlive the harness
         pthread_barrier_init(&emu::g_wg_barrier, nullptr, nthreads);
         std::vector<emu::WaveState> waves(nwaves);
         for (auto &w : waves) pthread_barrier_init(&w.bar, nullptr, 64);
