@@ -95,11 +95,13 @@ __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_para
             for (int i = 0; i < NWL; i++) dma16(ws, wvoff[i], l + XS + (mg + 4 * i) * 1024);
         };
         struct Hdr { u32x4 r[NTR]; };
-        auto hload = [&](int sbr) __attribute__((always_inline)) {
-            Hdr v; const char *sb = wbase + (int64_t)sbr * BLK;
-#pragma unroll
-            for (int r = 0; r < NTR; r++) X4L_GLOAD16(v.r[r], hoff[r], sb);
-            return v;
+        // superblock headers of this lane's table rows, SYNCHRONOUS (see gemm_q_x4l_hw.h).  It is called before a block's DMA
+        // pieces are issued, when at most the previous block's pieces — issued a whole stage earlier — can still be in flight, so
+        // the vmcnt(0) inside costs the header's own latency, in a loader wave, once per superblock.
+        auto hload = [&](Hdr &v, int sbr) __attribute__((always_inline)) {
+            const char *sb = wbase + (int64_t)sbr * BLK;
+            if constexpr (NTR == 2) X4L_GLOAD16x2_SYNC(v.r[0], v.r[1], hoff[0], hoff[1], sb);
+            else X4L_GLOAD16_SYNC(v.r[0], hoff[0], sb);
         };
         auto tab_store = [&](const Hdr &hd, int part, int slot) __attribute__((always_inline)) {    // the arithmetic of Raw<Q4_K>::scales()
             const int g = part * 2 + lgl;
@@ -116,9 +118,9 @@ __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_para
             }
         };
         // prologue: stages 0, 1, 2 -> slots 0, 1, 2
-        Hdr h0 = hload(0), hcur = hload(1);
+        Hdr h0, hcur;
+        hload(h0, 0); hload(hcur, 1);
         issue(0, 0); issue(1, 1); issue(2, 2);
-        X4L_WAIT_VM_TIED4(3 * NLD, h0.r[0], h0.r[NTR - 1], hcur.r[0], hcur.r[NTR - 1]);   // the four header loads are older than the pieces
         tab_store(h0, 0, 0); tab_store(h0, 1, 1); tab_store(hcur, 0, 2);
         X4L_WAIT_VM(2 * NLD);                                                   // stage 0 has landed
         X4L_WAIT_LGKM0();
@@ -128,16 +130,16 @@ __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_para
         int slot = 0;
         Hdr hnext = hcur;
         for (int s = 0; s + 1 < nstage; s++) {
-            if (s + 2 < nstage) X4L_WAIT_VM_TIED4(NLD, hcur.r[0], hcur.r[NTR - 1], hnext.r[0], hnext.r[NTR - 1]);
-            else X4L_WAIT_VM_TIED4(0, hcur.r[0], hcur.r[NTR - 1], hnext.r[0], hnext.r[NTR - 1]);
+            if (s + 2 < nstage) X4L_WAIT_VM(NLD); else X4L_WAIT_VM(0);           // only DMA pieces are ever outstanding here
             X4L_WAIT_LGKM0();                                                    // the table written last block is in LDS
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int st = s + 3;
             if (st < nstage) {
-                if ((st & 1) == 0) hcur = hnext;                                 // stage st opens superblock st / 2: its header was requested one block ago
-                if (((st + 1) & 1) == 0 && st + 1 < nstage) hnext = hload((st + 1) >> 1);   // BEFORE this block's pieces: covered by the next counted wait
+                if ((st & 1) == 0) hcur = hnext;                                 // stage st opens superblock st / 2: its header arrived one block ago
+                const bool need = ((st + 1) & 1) == 0 && st + 1 < nstage;
                 tab_store(hcur, st & 1, slot);
+                if (need) hload(hnext, (st + 1) >> 1);                           // the next superblock's header (used from the next block on)
                 issue(st, slot);
             }
             slot = slot == 2 ? 0 : slot + 1;

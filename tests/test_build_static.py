@@ -172,3 +172,44 @@ def test_no_out_of_bounds_access_at_the_shape_that_faulted_on_the_gpu(tmp_path):
         assert r.returncode == 0, (blocks, r.stderr[-300:])
     y = np.fromfile(str(tmp_path / "y.bin"), np.float32).reshape(B, M)
     assert np.isfinite(y[-128:, -128:]).all() and not (y[-128:, -128:] == -12345.0).any()      # the last work-group's tile was written
+
+
+def _reads_before_wait(asm, kernel):
+    """inline-asm register loads (global_load_dwordx4 into VGPRs) whose destination is read by ANY later instruction before
+    the next s_waitcnt vmcnt — the compiler treats an asm output as available at once, the hardware does not interlock"""
+    m = re.search(r"^%s:.*?^\.Lfunc_end" % re.escape(kernel), asm, re.S | re.M)
+    assert m, kernel
+    lines = [ln.split(";")[0].rstrip() for ln in m.group(0).split("\n") if ln.strip() and not ln.strip().startswith(";")]
+    n, bad = 0, []
+    for i, ln in enumerate(lines):
+        mm = re.match(r"\s*global_load_dwordx4 v\[(\d+):(\d+)\], v", ln)
+        if not mm:
+            continue
+        n += 1
+        regs = set(range(int(mm.group(1)), int(mm.group(2)) + 1))
+        for t in lines[i + 1:i + 400]:
+            if "s_waitcnt" in t and "vmcnt" in t:
+                break
+            parts = t.split(None, 1)
+            if len(parts) < 2:
+                continue
+            ops = [x.strip() for x in parts[1].split(",")]
+            srcs = ops if parts[0].startswith(("global_load_lds", "s_", "ds_write", "global_store", "buffer_store")) else ops[1:]
+            used = set()
+            for x in srcs:
+                for a, b in re.findall(r"v\[(\d+):(\d+)\]", x):
+                    used |= set(range(int(a), int(b) + 1))
+                used |= {int(a) for a in re.findall(r"\bv(\d+)\b", x)}
+            if used & regs:
+                bad.append((ln.strip(), t.strip()))
+                break
+    return n, bad
+
+
+def test_asynchronous_register_loads_are_not_read_before_their_wait(gemm_asm):
+    """k_gemm_kq_w12's loader waves load superblock headers into registers with inline asm and wait for them later with a
+    vmcnt wait tied to those registers.  Nothing stops the compiler from copying the registers in between (it did, in a first
+    cut of the experimental kernel); the shipped binary must be free of such reads"""
+    for k in ("_Z13k_gemm_kq_w12ILi12ELb1ELi0EEv11gemm_params", "_Z13k_gemm_kq_w12ILi12ELb0ELi0EEv11gemm_params"):
+        n, bad = _reads_before_wait(gemm_asm, k)
+        assert n > 0 and not bad, (k, bad[:3])

@@ -15,8 +15,8 @@
 #define X4L_HW_OVERRIDE
 #define X4L_LDS_BASE(smem_) 0u
 #define X4L_DMA16(voff, sbase, lds_addr) emu::vm_issue(smem + (lds_addr) + 16 * lane, (sbase) + (voff))
-#define X4L_GLOAD16(dst, voff, sbase) (memcpy(&(dst), (sbase) + (voff), 16), emu::vm_issue_done())
-#define X4L_WAIT_VM_TIED4(n, a, b, c, d) emu::vm_wait(n)
+#define X4L_GLOAD16_SYNC(dst, voff, sbase) (memcpy(&(dst), (sbase) + (voff), 16), emu::vm_wait(0))
+#define X4L_GLOAD16x2_SYNC(d0, d1, v0, v1, sbase) (memcpy(&(d0), (sbase) + (v0), 16), memcpy(&(d1), (sbase) + (v1), 16), emu::vm_wait(0))
 #define X4L_WAIT_VM(n) emu::vm_wait(n)
 #define X4L_WAIT_LGKM0() ((void)0)
 
