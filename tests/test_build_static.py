@@ -169,6 +169,8 @@ def test_no_out_of_bounds_access_at_the_shape_that_faulted_on_the_gpu(tmp_path):
     for blocks in ("0:1", "255:256"):
         r = subprocess.run([exe, str(M), str(K), str(B), str(tmp_path / "w.bin"), str(tmp_path / "xh.bin"), str(tmp_path / "y.bin"), "1", "0", "1"],
                            capture_output=True, text=True, timeout=600, env=dict(os.environ, EMU_BLOCKS=blocks))
+        if r.returncode == 77:
+            pytest.skip("the environment cannot host the emulation (process / thread limits)")
         assert r.returncode == 0, (blocks, r.stderr[-300:])
     y = np.fromfile(str(tmp_path / "y.bin"), np.float32).reshape(B, M)
     assert np.isfinite(y[-128:, -128:]).all() and not (y[-128:, -128:] == -12345.0).any()      # the last work-group's tile was written

@@ -9,6 +9,7 @@
 #include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -59,7 +60,7 @@ template <typename F> static void emu_launch(F body, dim3 grid, dim3 block) {
     for (unsigned b = 0; b < grid.x; b++) {
         if (b < b_lo || b >= b_hi) continue;
         const pid_t pid = fork();
-        if (pid < 0) { perror("fork"); exit(2); }
+        if (pid < 0) { perror("fork"); exit(77); }                 // 77: the environment cannot host the emulation (callers skip)
         if (pid > 0) { kids.push_back(pid); continue; }
         prctl(PR_SET_PDEATHSIG, SIGKILL);                      // never outlive the harness
         pthread_barrier_init(&emu::g_wg_barrier, nullptr, nthreads);
@@ -67,12 +68,17 @@ template <typename F> static void emu_launch(F body, dim3 grid, dim3 block) {
         for (auto &w : waves) pthread_barrier_init(&w.bar, nullptr, 64);
         emu::g_waves = waves.data();
         std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; t++)
-            th.emplace_back([&, t, b] { emu::t_threadIdx = dim3(t); emu::t_blockIdx = dim3(b); body(); });
+        try {
+            for (int t = 0; t < nthreads; t++)
+                th.emplace_back([&, t, b] { emu::t_threadIdx = dim3(t); emu::t_blockIdx = dim3(b); body(); });
+        } catch (const std::system_error &) { _exit(77); }        // thread limit of the environment
         for (auto &t : th) t.join();
         _exit(0);
     }
-    for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { fprintf(stderr, "work-group process failed\n"); exit(3); } }
+    bool cannot = false, failed = false;
+    for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); if (WIFEXITED(st) && WEXITSTATUS(st) == 77) cannot = true; else if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) failed = true; }
+    if (failed) { fprintf(stderr, "work-group process failed\n"); exit(3); }
+    if (cannot) { fprintf(stderr, "the environment cannot host the emulation (process / thread limits)\n"); exit(77); }
 }
 
 #include "../../ggml_amd/csrc/gemm_q_x4l.hip"

@@ -56,6 +56,9 @@ def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, 
         extra = [str(splitk), str(exp)] if kernel == "x4l" else [str(splitk), str(exp), str(xchg_l2)]       # x4l: exp 1 = the 128 x 128 tile form
         r = subprocess.run([build(kernel), str(M), str(K), str(B), os.path.join(d, "w.bin"), os.path.join(d, "xh.bin"), os.path.join(d, "y.bin")] + extra,
                            capture_output=True, text=True, timeout=timeout, env=dict(os.environ, EMU_DEFER_DMA="1" if defer_dma else "0"))
+        if r.returncode == 77:                          # process / thread limits of this environment: nothing was checked
+            import pytest
+            pytest.skip("the environment cannot host the emulation (process / thread limits)")
         assert r.returncode == 0, r.stderr[-500:]
         y = np.fromfile(os.path.join(d, "y.bin"), np.float32).reshape(B, M).astype(np.float64)
     err = np.linalg.norm(y - want) / np.linalg.norm(want)
