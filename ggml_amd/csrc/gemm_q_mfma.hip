@@ -1315,6 +1315,9 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         if (variant & 16) splitk = (tiles * 2 <= cu_count() && kunits % 2 == 0 && kunits >= 4) ? 2 : 1;   // hand-off split: only if co-resident
         else splitk = 1;
     }
+    if constexpr (TYPE == CDNA4_Q5_K) {
+        if (wlds && a.variant > 0 && (variant & 8192) && (variant & 16384)) return cdna4_launch_gemm_q4k_x4l(a, a.splitk, 1, st);   // experimental, explicit only
+    }
     if constexpr (TYPE == CDNA4_Q4_K) {
         if (wlds && a.variant > 0 && (variant & 8192)) return cdna4_launch_gemm_q4k_x4l(a, a.splitk, (variant & 16384) ? 1 : ((variant & 32768) ? 2 : 0), st);   // experimental loader-wave kernels (explicit only): 256x128 tile with 4 compute waves; bit14: 128x128; bit15: 256x128 with 8 compute waves
         if (wlds && (variant & 1024)) return launch_x2<TYPE>(a, a.splitk, st);

@@ -24,15 +24,20 @@
 // NCW = compute waves: 4 (one per SIMD) or, with NMB = 1, 8 (two per SIMD, 139 registers each: 12 waves fit the 168-register
 // budget) on a 256 x 128 tile — the partner wave hides a wave's LDS latency as in the shipped kernels, at the price of one
 // activation ds_read per MFMA again; the activation DMA per MFMA stays halved.
-template <int S, int NMB, int NCW>
+// TYPE = Q4_K, or Q5_K (128 x 128 form only: its stage row also carries the superblock's 32 bytes of fifth bits, and 3 x 60 KB
+// does not fit): the fifth bits sit in their own area, two 16-byte chunks per row, chunk XOR-swizzled by (row >> 3) & 1.
+template <int S, int NMB, int NCW, int TYPE = CDNA4_Q4_K>
 __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_params p) {
-    constexpr int TYPE = CDNA4_Q4_K;
+    constexpr bool Q5 = TYPE == CDNA4_Q5_K;
+    static_assert(TYPE == CDNA4_Q4_K || (Q5 && NMB * NCW == 4), "Q5_K: 128-row tile only");
     constexpr int BNF = 4, TB = 128, TM = 32 * NMB * NCW, NST = 3, NTR = TM / 128;   // NTR: table rows per loader lane
     constexpr int RS = 256, XS = TB * RS;                 // activations: 128 rows x 256 B
-    constexpr int BLK = QT<TYPE>::BYTES;                  // 144
-    constexpr int WQS = TM * 64, TS = TM * 16;            // nibbles: 256 rows x 64 B; table: 256 rows x 2 groups x 8 B
-    constexpr int ST = XS + WQS + TS;                     // 53,248 (NMB = 2) / 43,008 (NMB = 1)
-    constexpr int NXL = 8, NWL = TM / 64, NLD = NXL + NWL; // DMA wave-pieces per loader wave and stage
+    constexpr int BLK = QT<TYPE>::BYTES;                  // 144 / 176
+    constexpr int QOFF = Q5 ? 48 : 16;                    // byte offset of the nibbles in a superblock (Q5_K: header, 32 B of fifth bits, nibbles)
+    constexpr int WQS = TM * 64, QHS = Q5 ? TM * 32 : 0, TS = TM * 16;   // nibbles: TM rows x 64 B; fifth bits: TM x 32 B; table: TM x 2 groups x 8 B
+    constexpr int ST = XS + WQS + QHS + TS;               // 53,248 (Q4_K 256 rows) / 43,008 (Q4_K 128 rows) / 47,104 (Q5_K 128 rows)
+    constexpr int NHL = Q5 ? TM / 128 : 0;                // fifth-bit wave-pieces per loader wave and stage
+    constexpr int NXL = 8, NWL = TM / 64, NLD = NXL + NWL + NHL; // DMA wave-pieces per loader wave and stage
     constexpr int SMEM = NST * ST > 128 * 1024 ? NST * ST : 128 * 1024;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
@@ -68,7 +73,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_para
 
     if (is_loader) {
         // ================================================================ loader waves
-        uint32_t xvoff[NXL], wvoff[NWL], hoff[NTR];
+        uint32_t xvoff[NXL], wvoff[NWL], qhvoff[NHL > 0 ? NHL : 1], hoff[NTR];
 #pragma unroll
         for (int i = 0; i < NXL; i++) {                    // activation wave-piece q = mg + 4 i: LDS bytes [1024 q, 1024 q + 1024) of the slot
             const int pc = (mg + 4 * i) * 64 + lane, row = pc >> 4, c = (pc & 15) ^ (row & 15);
@@ -77,7 +82,12 @@ __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_para
 #pragma unroll
         for (int i = 0; i < NWL; i++) {                    // nibble wave-piece q = mg + 4 i: rows 16 q .. 16 q + 15, four 16-B chunks each
             const int pc = (mg + 4 * i) * 64 + lane, row = pc >> 2, c = (pc & 3) ^ ((row >> 2) & 3);
-            wvoff[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes + 16u + c * 16;
+            wvoff[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes + (uint32_t)QOFF + c * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < NHL; i++) {                    // fifth-bit wave-piece q = mg + 4 i: rows 32 q .. 32 q + 31, two 16-B chunks each
+            const int pc = (mg + 4 * i) * 64 + lane, row = pc >> 1, c = (pc & 1) ^ ((row >> 3) & 1);
+            qhvoff[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes + 16u + c * 16;
         }
         const int lidx = (mg << 6) | lane, lrow = lidx >> 1, lgl = lidx & 1;      // table: rows lrow (and lrow + 128), group lgl of the stage
 #pragma unroll
@@ -88,11 +98,13 @@ __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_para
         };
         auto issue = [&](int st, int slot) __attribute__((always_inline)) {          // stage st = (superblock st >> 1, half st & 1)
             const uint32_t l = lds0 + slot * ST;
-            const char *xs = xbase + (int64_t)st * p.B * 256, *ws = wbase + (int64_t)(st >> 1) * BLK + (st & 1) * 64;
+            const char *xs = xbase + (int64_t)st * p.B * 256, *wsb = wbase + (int64_t)(st >> 1) * BLK, *ws = wsb + (st & 1) * 64;
 #pragma unroll
             for (int i = 0; i < NXL; i++) dma16(xs, xvoff[i], l + (mg + 4 * i) * 1024);
 #pragma unroll
             for (int i = 0; i < NWL; i++) dma16(ws, wvoff[i], l + XS + (mg + 4 * i) * 1024);
+#pragma unroll
+            for (int i = 0; i < NHL; i++) dma16(wsb, qhvoff[i], l + XS + WQS + (mg + 4 * i) * 1024);      // (the same 32 bytes for both stages of a superblock)
         };
         struct Hdr { u32x4 r[NTR]; };
         // superblock headers of this lane's table rows, SYNCHRONOUS (see gemm_q_x4l_hw.h).  It is called before a block's DMA
@@ -112,9 +124,10 @@ __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_para
                 k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g, s0, mn0); k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g + 1, s1, mn1);
                 const float d = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
                 const half_t sl = (half_t)(d * (float)s0), sh = (half_t)(d * (float)s1);
-                const half_t cl = (half_t)(8.f * (float)sl - dmin * (float)mn0), ch = (half_t)(8.f * (float)sh - dmin * (float)mn1);
+                constexpr float ZERO = Q5 ? 16.f : 8.f;             // Raw<TYPE>::scales(): the constant that folds the -zero offset
+                const half_t cl = (half_t)(ZERO * (float)sl - dmin * (float)mn0), ch = (half_t)(ZERO * (float)sh - dmin * (float)mn1);
                 u32x2 e; e.x = __builtin_bit_cast(uint32_t, half2_t{sl, cl}); e.y = __builtin_bit_cast(uint32_t, half2_t{sh, ch});
-                *reinterpret_cast<u32x2 *>(smem + slot * ST + XS + WQS + ((lrow + 128 * r) * 2 + lgl) * 8) = e;
+                *reinterpret_cast<u32x2 *>(smem + slot * ST + XS + WQS + QHS + ((lrow + 128 * r) * 2 + lgl) * 8) = e;
             }
         };
         // prologue: stages 0, 1, 2 -> slots 0, 1, 2
@@ -158,12 +171,16 @@ __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_para
 #pragma unroll
             for (int bf = 0; bf < BNF; bf++) xa[buf][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
         };
-        auto read_w = [&](int slot_, int g) __attribute__((always_inline)) {                    // nibbles + table entry of group g, both row blocks
+        auto read_w = [&](int slot_, int g, int part) __attribute__((always_inline)) {          // nibbles (+ fifth bits) + table entry of group g of the stage (half `part` of its superblock)
 #pragma unroll
             for (int mb = 0; mb < NMB; mb++) {
                 const int row = mg * 32 * NMB + mb * 32 + j;
                 rq[mb][g].q = *reinterpret_cast<const u32x4 *>(smem + slot_ * ST + XS + row * 64 + (((2 * g + h) ^ ((row >> 2) & 3)) << 4));
-                const u32x2 te = *reinterpret_cast<const u32x2 *>(smem + slot_ * ST + XS + WQS + (row * 2 + g) * 8);
+                if constexpr (Q5) {
+                    rq[mb][g].qh = *reinterpret_cast<const u32x4 *>(smem + slot_ * ST + XS + WQS + row * 32 + ((h ^ ((row >> 3) & 1)) << 4));
+                    z[mb][g].bl = 2 * (part * 2 + g); z[mb][g].bh = z[mb][g].bl + 1;   // bit planes of the superblock-global 64-k group
+                }
+                const u32x2 te = *reinterpret_cast<const u32x2 *>(smem + slot_ * ST + XS + WQS + QHS + (row * 2 + g) * 8);
                 const half2_t lo = as_h2(te.x), hi = as_h2(te.y);
                 z[mb][g].SL = half2_t{lo.x, lo.x}; z[mb][g].CL = half2_t{lo.y, lo.y}; z[mb][g].SH = half2_t{hi.x, hi.x}; z[mb][g].CH = half2_t{hi.y, hi.y};
             }
@@ -190,7 +207,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_para
         // prologue: stage 0 landed
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        read_w(0, 0); read_xa(0, 0, 0);
+        read_w(0, 0, 0); read_xa(0, 0, 0);
 #pragma unroll
         for (int mb = 0; mb < NMB; mb++)
 #pragma unroll
@@ -202,7 +219,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_para
 #pragma unroll
             for (int t = 0; t < 7; t++) {                  // k-steps 0..6: one pairbits of k-step t + 1 after every MFMA
                 read_xa(slot, t + 1, (t + 1) & 1);
-                if (t == 1) read_w(slot, 1);               // the second group's nibbles / table: needed from k-step 3 on
+                if (t == 1) read_w(slot, 1, s & 1);        // the second group's nibbles / table: needed from k-step 3 on
                 mfma8(t & 1, [&](int n) __attribute__((always_inline)) {
                     const int t1 = t + 1, g1 = t1 >> 2, mb = n >> 2, i = n & 3;
                     nxt[mb][i] = rq[mb][g1].pairbits(t1 & 3, i, z[mb][g1], dq);
@@ -213,7 +230,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_para
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                read_w(slot1, 0); read_xa(slot1, 0, 0);                          // stage s + 1, published by the barrier
+                read_w(slot1, 0, (s + 1) & 1); read_xa(slot1, 0, 0);             // stage s + 1, published by the barrier
                 __builtin_amdgcn_sched_barrier(0);
             }
             // k-step 7: the 4 NMB half2 of the next stage's first fragments go behind the LAST 2 NMB MFMAs, two each (their LDS
@@ -338,11 +355,11 @@ __global__ __launch_bounds__((NCW + 4) * 64) void k_gemm_q4k_x4l(const gemm_para
 
 // launcher: Q4_K, K % 256 == 0, 16-byte-aligned rows; splitk 0 = the widest split whose work-groups are all co-resident and
 // keep two superblocks each.  Returns -1 (with a message) if the shape does not fit.
-template <int NMB, int NCW>
+template <int NMB, int NCW, int TYPE = CDNA4_Q4_K>
 static int launch_x4l(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
     constexpr int TM = 32 * NMB * NCW;
-    if (a.type != CDNA4_Q4_K || a.K % 256 || ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) != 0))
-        return cdna4_set_error_msg("gemm_q: the 4+4-wave 256x128 kernel takes 16-byte-aligned Q4_K rows with K % 256 == 0");
+    if (a.type != TYPE || a.K % 256 || ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) != 0))
+        return cdna4_set_error_msg("gemm_q: the loader-wave kernel takes 16-byte-aligned Q4_K / Q5_K rows with K % 256 == 0");
     gemm_params p{};
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B;
@@ -365,13 +382,14 @@ static int launch_x4l(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
         p.epoch = cdna4_gemm_next_epoch();
     }
     const dim3 grid(ntiles * S);
-    if (S == 1) hipLaunchKernelGGL((k_gemm_q4k_x4l<1, NMB, NCW>), grid, dim3((NCW + 4) * 64), 0, st, p);
-    else if (S == 2) hipLaunchKernelGGL((k_gemm_q4k_x4l<2, NMB, NCW>), grid, dim3((NCW + 4) * 64), 0, st, p);
-    else hipLaunchKernelGGL((k_gemm_q4k_x4l<4, NMB, NCW>), grid, dim3((NCW + 4) * 64), 0, st, p);
+    if (S == 1) hipLaunchKernelGGL((k_gemm_q4k_x4l<1, NMB, NCW, TYPE>), grid, dim3((NCW + 4) * 64), 0, st, p);
+    else if (S == 2) hipLaunchKernelGGL((k_gemm_q4k_x4l<2, NMB, NCW, TYPE>), grid, dim3((NCW + 4) * 64), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_q4k_x4l<4, NMB, NCW, TYPE>), grid, dim3((NCW + 4) * 64), 0, st, p);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
 // form 0: 256 x 128 tile, 4 compute waves x 64 rows; 1: 128 x 128 tile, 4 x 32 rows; 2: 256 x 128 tile, 8 compute waves x 32 rows
 int cdna4_launch_gemm_q4k_x4l(const cdna4_gemm_args &a, int splitk, int form, hipStream_t st) {
+    if (a.type == CDNA4_Q5_K) return form == 1 ? launch_x4l<1, 4, CDNA4_Q5_K>(a, splitk, st) : cdna4_set_error_msg("gemm_q: Q5_K runs on the 128x128 form of the loader-wave kernel only");
     return form == 1 ? launch_x4l<1, 4>(a, splitk, st) : (form == 2 ? launch_x4l<1, 8>(a, splitk, st) : launch_x4l<2, 4>(a, splitk, st));
 }

@@ -53,6 +53,6 @@ print("rel-L2 default vs variant 5 at 8192x8192x512:", float((out[0] - out[5]).n
 PY
 # (4) the opt-in tests of code written without a GPU: GGUF upload, the 4 + 4-wave kernel
 CDNA4_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gguf.py -q -m gpu -k upload > gpurun_out/experimental_tests.txt 2>&1
-CDNA4_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -k 4plus4 >> gpurun_out/experimental_tests.txt 2>&1
+CDNA4_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "4plus4 or loader_wave_kernel_q5_k" >> gpurun_out/experimental_tests.txt 2>&1
 tail -5 gpurun_out/experimental_tests.txt
 tail -2 gpurun_out/mfma_valu.txt; cat gpurun_out/launch_floor.txt; cut -c1-200 gpurun_out/w12_candidates.txt; cat gpurun_out/w12_clock.txt; cut -c1-200 gpurun_out/x4l.txt; cat gpurun_out/fault_8192.txt | cut -c1-200; cat gpurun_out/parity_8192.txt | tail -3

@@ -73,9 +73,10 @@ def test_experimental_4plus4_wave_kernel_resources(tmp_path):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out), src],
                    check=True, capture_output=True, timeout=900)
     asm = out.read_text()
-    for nmb, ncw, regs in ((2, 4, 256), (1, 4, 256), (1, 8, 168)):        # 256x128 (4 compute waves), 128x128, 256x128 (8 compute waves: 12 waves -> 168 registers)
+    # 256x128 (4 compute waves), 128x128, 256x128 (8 compute waves: 12 waves -> 168 registers), Q5_K 128x128
+    for nmb, ncw, regs, typ in ((2, 4, 256, 12), (1, 4, 256, 12), (1, 8, 168, 12), (1, 4, 256, 13)):
         for s in (1, 2, 4):
-            k = "_Z14k_gemm_q4k_x4lILi%dELi%dELi%dEEv11gemm_params" % (s, nmb, ncw)
+            k = "_Z14k_gemm_q4k_x4lILi%dELi%dELi%dELi%dEEv11gemm_params" % (s, nmb, ncw, typ)
             assert _prop(asm, k, "private_seg_size") == 0
             assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= regs
             assert _lds(asm, k) <= 160 * 1024
@@ -215,3 +216,16 @@ def test_asynchronous_register_loads_are_not_read_before_their_wait(gemm_asm):
     for k in ("_Z13k_gemm_kq_w12ILi12ELb1ELi0EEv11gemm_params", "_Z13k_gemm_kq_w12ILi12ELb0ELi0EEv11gemm_params"):
         n, bad = _reads_before_wait(gemm_asm, k)
         assert n > 0 and not bad, (k, bad[:3])
+
+
+@pytest.mark.parametrize("m,k,b,splitk", [(128, 512, 128, 1), (300, 1536, 200, 1), (513, 1024, 129, 2), (700, 2560, 90, 4)])
+def test_experimental_kernel_q5_k_form_on_the_cpu(m, k, b, splitk):
+    """the Q5_K instantiation of the experimental kernel (128 x 128 form: fifth-bit planes staged in their own swizzled area)"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for defer in (False, True):
+        assert mod.run(m, k, b, seed=m + k, timeout=300, splitk=splitk, exp=1, wtype=13, defer_dma=defer) < 1e-6

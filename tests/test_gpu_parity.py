@@ -251,6 +251,21 @@ def test_gemm_4plus4_wave_256x128_kernel(gu, m, k, b, splitk, variant):
         assert R.rel_l2(y, R.o_mul_mat(t, w, x, m, k)) < TOL_GEMM
 
 
+@pytest.mark.skipif(os.environ.get("CDNA4_TEST_EXPERIMENTAL") != "1", reason="experimental kernel, opt-in: CDNA4_TEST_EXPERIMENTAL=1")
+@pytest.mark.parametrize("m,k,b,splitk", [(128, 512, 128, 1), (300, 2048, 200, 4), (513, 1024, 129, 2), (4096, 4096, 512, 0)])
+def test_gemm_loader_wave_kernel_q5_k(gu, m, k, b, splitk):
+    """variant bits 13 + 14 on Q5_K weights: the 128 x 128 form of gemm_q_x4l.hip with the fifth-bit planes staged"""
+    from ggml_amd import ops
+    t = R.Q5_K
+    w = R.random_weights(t, m, k, seed=m + k + b)
+    x = _x(m * 2 + b, b, k)
+    a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
+    y = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=24583, splitk=splitk).cpu().numpy()
+    yd = ops.mul_mat(a, xd, path=ops.PATH_GEMM).cpu().numpy()
+    e = R.rel_l2(y, yd); gu.report(test="gemm_x4l_q5k", m=m, k=k, b=b, splitk=splitk, rel_l2=e)
+    assert np.isfinite(y).all() and e < 2e-6
+
+
 def test_gemm_auto_picks_256x128_kernel_on_huge_grids(gu):
     """>= 2 x #CUs tiles of 256x128 (the C5-like regime): the auto path is the 256x128-tile kernel without a K split —
     bit-identical to asking for it explicitly, and within tolerance of the oracle on a row sample"""

@@ -1,6 +1,6 @@
 // x4l_emul.cpp — runs the SOURCE of k_gemm_q4k_x4l<1> (ggml_amd/csrc/gemm_q_x4l.hip) on the CPU, one OS thread per GPU thread,
 // work-group after work-group, and writes Y.  Test infrastructure (tests/test_build_static.py builds and runs it):
-//   x4l_emul M K B w.bin xh.bin y.bin [splitk [rows128]]      w = Q4_K rows, xh = the kernel's fp16 activation image, y = fp32 [B][M] (output)
+//   x4l_emul M K B w.bin xh.bin y.bin [splitk [form [type]]]      w = Q4_K (12) or Q5_K (13) rows, xh = the kernel's fp16 activation image, y = fp32 [B][M] (output)
 // A mismatch in barrier counts between loader and compute waves shows up as a hang (the test has a timeout), wrong
 // indexing as wrong numbers.  Asynchrony is not modelled (see hip_emul.h).
 #include "hip_emul.h"
@@ -98,7 +98,8 @@ int main(int argc, char **argv) {
     float *y = (float *)shared_alloc((size_t)B * M * 4);
     for (size_t i = 0; i < (size_t)B * M; i++) y[i] = -12345.f;
     cdna4_gemm_args a{};
-    a.type = CDNA4_Q4_K; a.W = w; a.w_row_bytes = (int64_t)(K / 256) * 144; a.xh = xh; a.xh_row_elems = K;
+    const int type = argc > 9 ? atoi(argv[9]) : CDNA4_Q4_K;
+    a.type = type; a.W = w; a.w_row_bytes = (int64_t)(K / 256) * (type == CDNA4_Q5_K ? 176 : 144); a.xh = xh; a.xh_row_elems = K;
     a.Y = y; a.y_row_elems = M; a.M = M; a.K = K; a.B = B; a.variant = 8199; a.splitk = splitk;
     if (((uintptr_t)a.W & 15) != 0) { fprintf(stderr, "unaligned W\n"); return 2; }
     if (cdna4_launch_gemm_q4k_x4l(a, splitk, argc > 8 ? atoi(argv[8]) : 0, nullptr) != 0) return 1;

@@ -32,10 +32,13 @@ def build(name="x4l"):
     return exe
 
 
-def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, return_y=False, defer_dma=False):
+def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, return_y=False, defer_dma=False, wtype=None):
     rng = np.random.default_rng(seed)
     nsb = K // 256
-    w = R.random_weights(R.Q4_K, M, K, seed).reshape(M, nsb, LC.BLK)
+    wtype = R.Q4_K if wtype is None else wtype
+    q5 = wtype == R.Q5_K
+    blk = 176 if q5 else 144
+    w = R.random_weights(wtype, M, K, seed).reshape(M, nsb, blk)
     xh = rng.uniform(-1, 1, (B, K)).astype(np.float16)
     img = np.zeros((K // 128, B, 128), np.float16)               # the kernel's activation image: [K/128][B][128], (k0,k2,k1,k3) within every 4
     for p in range(128):
@@ -44,16 +47,21 @@ def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, 
     for m in range(M):
         for sb in range(nsb):
             for G in range(4):
-                sl, cl, sh, ch = LC.table_entry(w[m, sb], G)
-                qs = w[m, sb, 16 + 32 * G:16 + 32 * G + 32]
-                wd[m, sb * 256 + 64 * G:][:32] = ((qs & 15).astype(np.float64) - 8) * np.float64(sl) + np.float64(cl)
-                wd[m, sb * 256 + 64 * G + 32:][:32] = ((qs >> 4).astype(np.float64) - 8) * np.float64(sh) + np.float64(ch)
+                sl, cl, sh, ch = LC.table_entry(w[m, sb], G, 16.0 if q5 else 8.0)       # (header layout is the same: d, dmin, scales[12])
+                qs = w[m, sb, (48 if q5 else 16) + 32 * G:][:32]
+                lo, hi = (qs & 15).astype(np.float64), (qs >> 4).astype(np.float64)
+                if q5:                                                              # fifth bits: qh[l] bit 2G (low nibble) / 2G + 1 (high nibble)
+                    qh = w[m, sb, 16:48]
+                    lo += 16 * ((qh >> (2 * G)) & 1); hi += 16 * ((qh >> (2 * G + 1)) & 1)
+                zero = 16.0 if q5 else 8.0
+                wd[m, sb * 256 + 64 * G:][:32] = (lo - zero) * np.float64(sl) + np.float64(cl)
+                wd[m, sb * 256 + 64 * G + 32:][:32] = (hi - zero) * np.float64(sh) + np.float64(ch)
     wd = wd.astype(np.float16).astype(np.float64)
     want = xh.astype(np.float64) @ wd.T
     with tempfile.TemporaryDirectory() as d:
         # the weight file must start 16-byte aligned in memory: the emulator reads it into a std::vector (malloc: 16-byte aligned)
         w.tofile(os.path.join(d, "w.bin")); img.tofile(os.path.join(d, "xh.bin"))
-        extra = [str(splitk), str(exp)] if kernel == "x4l" else [str(splitk), str(exp), str(xchg_l2)]       # x4l: exp 1 = the 128 x 128 tile form
+        extra = [str(splitk), str(exp), str(wtype)] if kernel == "x4l" else [str(splitk), str(exp), str(xchg_l2)]       # x4l: exp 1 = the 128 x 128 tile form
         r = subprocess.run([build(kernel), str(M), str(K), str(B), os.path.join(d, "w.bin"), os.path.join(d, "xh.bin"), os.path.join(d, "y.bin")] + extra,
                            capture_output=True, text=True, timeout=timeout, env=dict(os.environ, EMU_DEFER_DMA="1" if defer_dma else "0"))
         if r.returncode == 77:                          # process / thread limits of this environment: nothing was checked
