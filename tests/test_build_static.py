@@ -229,3 +229,17 @@ def test_experimental_kernel_q5_k_form_on_the_cpu(m, k, b, splitk):
     spec.loader.exec_module(mod)
     for defer in (False, True):
         assert mod.run(m, k, b, seed=m + k, timeout=300, splitk=splitk, exp=1, wtype=13, defer_dma=defer) < 1e-6
+
+
+@pytest.mark.parametrize("cfg", [0, 1])                       # 4 waves x 1 row, 8 waves x 2 rows (the M >= 4096 default)
+@pytest.mark.parametrize("t", [12, 13, 14, 2, 8])             # Q4_K, Q5_K, Q6_K, Q4_0, Q8_0
+def test_decode_kernel_source_on_the_cpu(t, cfg):
+    """tools/emul/gemv_emul: the source of the one-launch decode step (k_gemv_q_fused: in-kernel Q8_K / Q8_0 activation quantizer,
+    int8 dots, wave reduction) executed on the CPU against the oracle's MUL_MAT — a GPU-free regression check of the B = 1 path"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gemv_emul_check", os.path.join(ROOT, "tools", "emul", "gemv_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(t, 37, 2048, seed=t + cfg, env={"CDNA4_FUSED_CFG": str(cfg)}) < 1e-5

@@ -1,0 +1,50 @@
+"""Runs the SOURCE of the B = 1 decode kernel (k_gemv_q_fused, ggml_amd/csrc/gemv_q.hip) on the CPU (tools/emul/gemv_emul) and
+compares with the CPU oracle's MUL_MAT on the same weights and activations.
+
+    python tools/emul/gemv_emul_check.py [type M K]
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import refutil as R  # noqa: E402
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def build():
+    exe = os.path.join(HERE, "gemv_emul")
+    srcs = [os.path.join(HERE, "gemv_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(ROOT, "ggml_amd", "csrc", f)
+            for f in ("gemv_q.hip", "quantize_dev.h", "cdna4_common.h", "cdna4_kernels.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
+        subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "ggml_amd", "csrc"),
+                        "-Wno-unused-value", "-o", exe, srcs[0]], check=True, capture_output=True, timeout=600)
+    return exe
+
+
+def run(t, M, K, seed=1, timeout=600, env=None):
+    assert K % 1024 == 0, "wave-collective shuffles: the quantizer's lanes must fill whole waves"
+    w = R.random_weights(t, M, K, seed)
+    x = np.random.default_rng(seed + 1).uniform(-1, 1, (1, K)).astype(np.float32)
+    want = R.o_mul_mat(t, w, x, M, K)[0]
+    with tempfile.TemporaryDirectory() as d:
+        w.tofile(os.path.join(d, "w.bin")); x.tofile(os.path.join(d, "x.bin"))
+        r = subprocess.run([build(), str(t), str(M), str(K), os.path.join(d, "w.bin"), os.path.join(d, "x.bin"), os.path.join(d, "y.bin")],
+                           capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
+        if r.returncode == 77:
+            import pytest
+            pytest.skip("the environment cannot host the emulation (process / thread limits)")
+        assert r.returncode == 0, r.stderr[-500:]
+        y = np.fromfile(os.path.join(d, "y.bin"), np.float32)
+    return R.rel_l2(y, want)
+
+
+if __name__ == "__main__":
+    t, M, K = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (R.Q4_K, 37, 2048)
+    print("decode kernel source on the CPU vs the oracle, type %d %dx%d: rel-L2 %.3e" % (t, M, K, run(t, M, K)))

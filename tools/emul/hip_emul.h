@@ -34,7 +34,7 @@ static inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 static inline hipError_t hipGetLastError() { return 0; }
 
 namespace emu {
-struct WaveState { pthread_barrier_t bar; _Float16 A[64][8], B[64][8]; };
+struct WaveState { pthread_barrier_t bar; _Float16 A[64][8], B[64][8]; uint32_t xch[64]; };
 extern thread_local dim3 t_threadIdx, t_blockIdx;
 extern dim3 g_gridDim, g_blockDim;
 extern pthread_barrier_t g_wg_barrier;
@@ -61,7 +61,20 @@ static inline void emu_sleep() { static thread_local unsigned n = 0; usleep(200)
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
 #define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
 // cross-lane helpers the shared headers declare but the emulated kernels never call
-template <typename T> static inline T __shfl_xor(T v, int, int = 64) { return v; }
+// __shfl_xor: wave-collective through a per-wave exchange buffer — ALL 64 lanes of the wave must execute it (the emulated
+// kernels only shuffle in wave-uniform control flow for the shapes the tests use)
+template <typename T> static inline T __shfl_xor(T v, int o, int = 64) {
+    static_assert(sizeof(T) == 4, "32-bit shuffles only");
+    emu::WaveState &w = emu::my_wave();
+    const int l = emu::t_threadIdx.x & 63;
+    memcpy(&w.xch[l], &v, 4);
+    pthread_barrier_wait(&w.bar);
+    T r; memcpy(&r, &w.xch[l ^ o], 4);
+    pthread_barrier_wait(&w.bar);
+    return r;
+}
+static inline int emu_sdot4(int a, int b, int c) { for (int i = 0; i < 4; i++) c += (int)(int8_t)(a >> (8 * i)) * (int)(int8_t)(b >> (8 * i)); return c; }
+#define __builtin_amdgcn_sdot4(a, b, c, clamp) emu_sdot4(a, b, c)
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) ((void)0)
 // buffer resources (split-K exchange): a descriptor is just the base pointer here
 typedef void *__amdgpu_buffer_rsrc_t;
