@@ -110,6 +110,8 @@ int main(int argc, char **argv) {
         case 4: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 4>(p); }, nblk, 768); break;
         case 6: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 6>(p); }, nblk, 768); break;
         case 100: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, false, 0>(p); }, nblk, 768); break;      // compute waves unpack the scales themselves
+        case 32: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 32>(p); }, nblk, 768); break;        // timing ablations (results are garbage): bounds checks only
+        case 480: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 480>(p); }, nblk, 768); break;
         default: fprintf(stderr, "exp not built into the emulator\n"); return 2;
     }
     FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)B * M, f); fclose(f);
