@@ -338,486 +338,8 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// 8-wave variant of the pipelined kernel: TWO waves per SIMD.  The 4-wave kernels are bound by single-wave issue
-// rate (one instruction per ~4.8 cycles; ~10 non-MFMA instructions per 32-cycle MFMA); a second wave on each SIMD
-// doubles the issue slots under the same MFMA pipe.  Tile 128(m) x 128(b), stage = 128 k (two 64-k groups):
-// waves 0-3 (khalf 0) consume group 0 of every stage, waves 4-7 (khalf 1) group 1 — an intra-work-group K split —
-// and the two partial accumulators are summed ONCE at the end through LDS (fixed order: deterministic).
-// OPT selects the schedule (variant bits 5-9).  Built: 0 = leader/follower phase offset, whole-fragment unpack, DMA pieces
-// between the MFMAs (the first cut of this kernel); 12 = in-wave pipeline (bit 2) + phase offset (bit 3); 20 = in-wave
-// pipeline with the DMA pieces split over the S and T phases (bit 4) — the fallback of k_gemm_kq_w8p / _w12 for shallow K.
-// (Other combinations measured in DESIGN 4.3 — pieces in the unpack phase, no s_setprio — are no longer instantiated.)
-template <int TYPE, bool TRACE = false, int OPT = 0>
-__global__ __launch_bounds__(512) void k_gemm_kq_w8(const gemm_params p) {
-    constexpr bool EPI_BALANCED = false, EPI_DIRECT = false;
-    typedef WStage<TYPE, 2> WSt;
-    constexpr int BNF = 4, TB = 128, NST = 3;
-    constexpr int RS = 256, XS = TB * RS;
-    constexpr int BLK = QT<TYPE>::BYTES;
-    constexpr int WRS = WSt::NPH * 16, WS = 128 * WRS, ST = XS + WS;
-    constexpr int XL = XS / 16 / 512;            // 4
-    constexpr int NWI = 128 * WSt::NPH / 64;     // 10 (Q4_K) / 14 (Q5_K)
-    constexpr int WL = (NWI + 7) / 8;            // 2
-    constexpr int NL = XL + WL;
-    constexpr int SMEM = NST * ST > 128 * 1024 ? NST * ST : 128 * 1024;      // the epilogue needs 2 x 64 KB
-    static_assert(SMEM <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
-    __shared__ int xchg_failed;
+#include "gemm_kq_w8.inc"
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int mg = wave & 3, kh = __builtin_amdgcn_readfirstlane(wave >> 2);
-    const int nblk = gridDim.x;
-    int L = blockIdx.x;
-    if ((nblk & 7) == 0) L = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-    const int tile_b = L % p.tiles_b; L /= p.tiles_b;
-    const int ks = L % p.splitk, tile_m = L / p.splitk;
-    const int m0 = tile_m * 128, b0 = tile_b * TB;
-    // K range of this work-group in superblocks.  Hand-off split (p.partial): [0, sb_split) -> ks=0, the rest -> ks=1.
-    const int nsb_all = p.K / 256;
-    const int nsb = p.partial ? (ks == 0 ? p.sb_split : nsb_all - p.sb_split) : nsb_all / p.splitk;
-    const int sb0 = p.partial ? (ks == 0 ? 0 : p.sb_split) : ks * nsb, nstage = nsb * 2;
-
-    // (Tried and rejected, measured: four extra loader waves (12 waves, one loader per SIMD) that do nothing but issue the
-    //  LDS-DMA pieces, compute waves software-pipelined in-wave to fit 168 VGPRs: 44 us vs 37 us per call.  One wave
-    //  sustains only ~1 KiB per 75-90 cycles of LDS-DMA (tools/microbench/l2_stream: 32 GB/s for one wave, 134 GB/s for
-    //  eight), so four loaders cannot feed a stage in time; spreading the pieces over all eight waves can.)
-    DqConst dq; dq.init();
-    floatx16 acc[BNF];
-#pragma unroll
-    for (int i = 0; i < BNF; i++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-
-    uint32_t xvoff[XL], wvoff[2][WL];
-#pragma unroll
-    for (int i = 0; i < XL; i++) {
-        const int pc = i * 512 + tid, row = pc >> 4, c = (pc & 15) ^ (row & 15);
-        xvoff[i] = (uint32_t)(min(b0 + row, p.B - 1) - b0) * 256u + c * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < WL; i++) {
-        int idx = wave + 8 * i;
-        if (idx >= NWI) idx -= 8;
-        const int pc = idx * 64 + lane, row = pc / WSt::NPH, c = pc % WSt::NPH;
-        const uint32_t ro = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
-        wvoff[0][i] = ro + WSt::src_piece(c, 0) * 16; wvoff[1][i] = ro + WSt::src_piece(c, 1) * 16;
-    }
-    const char *const xbase = (const char *)p.xh + ((int64_t)sb0 * 2 * p.B + b0) * 256;    // panel (2*sb0), row b0
-    const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
-
-    // LDS-DMA in the scalar-base form (SGPR pair + 32-bit lane offset, M0 = wave-uniform LDS address): no per-lane 64-bit
-    // address arithmetic (the flat form cost ~5 VALU per piece, ~20 % of this kernel's VALU instructions).
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    auto dma16 = [&](const char *sbase, uint32_t voff, uint32_t lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
-    };
-    auto issue_piece = [&](int i, int sbr, int part, int slot) __attribute__((always_inline)) {         // piece i of stage (sbr, part) -> ring slot
-        const uint32_t l = lds0 + slot * ST;
-        if (i < XL) { dma16(xbase + (int64_t)(sbr * 2 + part) * p.B * 256, xvoff[i], l + (i * 512 + wave_s * 64) * 16); return; }
-        int idx = wave_s + 8 * (i - XL);
-        if (idx >= NWI) idx -= 8;
-        dma16(wbase + (int64_t)sbr * BLK, wvoff[part][i - XL], l + XS + idx * 1024);
-    };
-    auto issue = [&](int sbr, int part, int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NL; i++) issue_piece(i, sbr, part, slot);
-    };
-
-    const int xrow_off = j * RS, xswz = j & 15;
-    // Per stage a wave (1) reads its packed weights + 16 activation fragments from LDS, (2) unpacks 4 B fragments (VALU),
-    // (3) issues 16 MFMAs.  Measured by ablation: (1)+(2) and (3) each cost ~10 us of a 40 us kernel and do NOT overlap
-    // when both waves of a SIMD run them in lockstep.  So the two waves of every SIMD run ONE GROUP OUT OF PHASE:
-    //   khalf 0 ("leader")  : stage s:  read(s) -> unpack(s) -> MFMA(s)
-    //   khalf 1 ("follower"): stage s:  MFMA(s-1) from registers -> read(s) -> unpack(s)
-    // so within a stage the leader's VALU/LDS work runs beside the follower's MFMAs and vice versa, with the same single
-    // barrier per stage.
-    // One LDS-DMA instruction costs the issuing wave ~90-170 cycles when issued in a burst right after the barrier
-    // (s_memtime trace: 560-1010 cycles for 6 pieces, with the SIMD's MFMA pipe idle meanwhile).  So the next-next stage's
-    // pieces are issued one at a time BETWEEN the MFMAs of this wave's MFMA block, in the shadow of the matrix pipe.
-    // (Tried and rejected, measured: staging through registers — plain global_load_dwordx4 + ds_write_b128 inside the
-    //  MFMA block — made the block 3x longer, 64 us vs 40 us per call: the waits hipcc puts in front of each ds_write
-    //  serialise the block.  LDS-DMA stays.)
-    half8_t xa[4][BNF], wf[4];
-    auto load_unpack = [&](int slot, int part, bool load, int sbr, int slot_l) __attribute__((always_inline)) {   // this wave's 64-k group of the stage: group kh
-        const uint8_t *xs = smem + slot * ST + xrow_off;
-        const uint8_t *wrow = smem + slot * ST + XS + (mg * 32 + j) * WRS;
-        Raw<TYPE> raw;
-        raw.load(wrow, kh, h);
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            const int coff = ((kh * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
-#pragma unroll
-            for (int bf = 0; bf < BNF; bf++) xa[kk][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (kh == 0) raw.frags(part * 2, h, wf, dq); else raw.frags(part * 2 + 1, h, wf, dq);
-    };
-    auto mfma_block = [&](bool load, int sbr, int part, int slot_l) __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio(1);          // the wave feeding the matrix pipe wins issue arbitration over its partner's unpack
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++)
-#pragma unroll
-            for (int bf = 0; bf < BNF; bf++) {
-                acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[kk][bf], wf[kk], acc[bf], 0, 0, 0);
-                const int n = kk * BNF + bf;
-                if ((n & 1) && (n >> 1) < NL && load) issue_piece(n >> 1, sbr, part, slot_l);
-            }
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    auto stamp = [&](int s, int ph) __attribute__((always_inline)) {      // TRACE builds: [wave][stage 0..15][phase 0..7] cycle stamps of block 0
-        if (TRACE && blockIdx.x == 0 && s >= 4 && s < 20 && lane == 0) p.trace[(wave * 16 + (s - 4)) * 8 + ph] = __builtin_amdgcn_s_memtime();
-    };
-    // TRACE builds: kernel-level milestones of the consumer (blockIdx 0) and its hand-off partner, wave 0:
-    // [8*16*8 + 16*ks + i], i: 0 entry, 1 loop done, 2 K-halves summed, 3 tile in LDS, 4 flag seen, 5 stores issued, 6 drained, 7 flag set
-    const bool trace_wg = TRACE && tile_m == 0 && tile_b == 0;
-    auto estamp = [&](int i) __attribute__((always_inline)) {
-        if (TRACE && trace_wg && tid == 0) p.trace[8 * 16 * 8 + 16 * ks + i] = __builtin_amdgcn_s_memtime();
-    };
-    estamp(0);
-    if (TRACE && tid == 0 && blockIdx.x < 1024) p.trace[8 * 16 * 8 + 32 + blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (3 << 11));   // HW_REG_XCC_ID[3:0]
-    issue(0, 0, 0);
-    if (nstage > 1) issue(0, 1, 1);
-    int slot = 0;
-    // `load` (is there a stage s+2 to fetch?) and `part` are compile-time inside a stage: the steady-state stages carry no
-    // branches around the DMA pieces, so the pieces stay where they are placed between the MFMAs / fragment builds.
-    auto stage = [&](auto LD, auto PART, int sb) __attribute__((always_inline)) {
-        constexpr bool load = decltype(LD)::value;
-        constexpr int part = decltype(PART)::value;
-        const int s = sb * 2 + part;
-        stamp(s, 0);
-        if (load || part == 0) wait_vmcnt<NL>(); else wait_vmcnt<0>();
-        stamp(s, 1);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        stamp(s, 2);
-        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;   // stage s+2 = (sb+1, part) -> slot2
-        if (kh == 1) {                                               // follower: previous stage's fragments (+ DMA issue)
-            if (s > 0) mfma_block(load, sb + 1, part, slot2); else if (load) issue(sb + 1, part, slot2);
-        }
-        stamp(s, 4);
-        load_unpack(slot, part, load, sb + 1, slot2);
-        stamp(s, 5);
-        if (kh == 0) mfma_block(load, sb + 1, part, slot2);          // leader: this stage's fragments (+ DMA issue)
-        stamp(s, 6);
-        slot = slot1;
-    };
-    // OPT bit 2: IN-WAVE PIPELINE.  A stage of a wave is S (LDS reads, scales, the four half2 of fragment 0) followed by
-    // T (16 MFMAs, each followed by the 3-4 VALU instructions that build one half2 of the NEXT fragment, and now and then one
-    // DMA piece): a wave's own unpack hides under its own MFMAs.  OPT bit 3 adds the phase offset on top: the kh=1 wave of
-    // each SIMD runs T of the PREVIOUS stage right after the barrier and S of this stage after it, so one wave's
-    // latency-bound S runs beside its partner's T.  (Without bit 3 all eight waves run S then T in lockstep.)
-    Raw<TYPE> raw_s;
-    typename Raw<TYPE>::Sc z_s;
-    uint32_t cur[4] = {0, 0, 0, 0};
-    constexpr int NS = (OPT & 16) ? NL / 2 : 0;                    // OPT bit 4: the first NL/2 DMA pieces go out in S (under the LDS latency), the rest in T
-    auto S_phase = [&](int slot, auto PART, auto LD, int sbr, int slot_l) __attribute__((always_inline)) {
-        constexpr int part = decltype(PART)::value;
-        __builtin_amdgcn_sched_barrier(0);                           // do not hoist these reads above a preceding T phase (xa is reused)
-        const uint8_t *xs = smem + slot * ST + xrow_off;
-        const uint8_t *wrow = smem + slot * ST + XS + (mg * 32 + j) * WRS;
-        raw_s.load(wrow, kh, h);
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            const int coff = ((kh * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
-#pragma unroll
-            for (int bf = 0; bf < BNF; bf++) xa[kk][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (decltype(LD)::value) {
-#pragma unroll
-            for (int i = 0; i < NS; i++) issue_piece(i, sbr, part, slot_l);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (kh == 0) z_s = raw_s.scales(part * 2); else z_s = raw_s.scales(part * 2 + 1);
-#pragma unroll
-        for (int i = 0; i < 4; i++) cur[i] = raw_s.pairbits(0, i, z_s, dq);
-    };
-    auto T_phase = [&](auto LD, int sbr, int part, int slot_l) __attribute__((always_inline)) {
-        constexpr bool load = decltype(LD)::value;
-        uint32_t nxt[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            const u32x4 cw = {cur[0], cur[1], cur[2], cur[3]};
-            const half8_t wfk = __builtin_bit_cast(half8_t, cw);
-#pragma unroll
-            for (int bf = 0; bf < BNF; bf++) {
-                __builtin_amdgcn_sched_barrier(0);
-                acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[kk][bf], wfk, acc[bf], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kk < 3) nxt[bf] = raw_s.pairbits(kk + 1, bf, z_s, dq);
-                const int n = kk * BNF + bf;
-                constexpr int NT = NL - NS;
-                if (load && (n * NT) / 16 != ((n + 1) * NT) / 16) issue_piece(NS + (n * NT) / 16, sbr, part, slot_l);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) cur[i] = nxt[i];
-        }
-    };
-    auto stage_sym = [&](auto FOLLOWER, auto LD, auto PART, int sb) __attribute__((always_inline)) {
-        constexpr bool follower = decltype(FOLLOWER)::value;
-        constexpr bool load = decltype(LD)::value;
-        constexpr int part = decltype(PART)::value;
-        const int s = sb * 2 + part;
-        stamp(s, 0);
-        if (load || part == 0) wait_vmcnt<NL>(); else wait_vmcnt<0>();
-        stamp(s, 1);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        stamp(s, 2);
-        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;
-        if constexpr (follower) {                                    // T(s-1) [+ this stage's DMA issue], then S(s)
-            if (s > 0) T_phase(LD, sb + 1, part, slot2);
-            else if (load) {
-#pragma unroll
-                for (int i = NS; i < NL; i++) issue_piece(i, sb + 1, part, slot2);
-            }
-            stamp(s, 4);
-            S_phase(slot, PART, LD, sb + 1, slot2);
-            stamp(s, 6);
-        } else {
-            S_phase(slot, PART, LD, sb + 1, slot2);
-            stamp(s, 4);
-            T_phase(LD, sb + 1, part, slot2);
-            stamp(s, 6);
-        }
-        slot = slot1;
-    };
-    typedef std::integral_constant<bool, true> yes_t; typedef std::integral_constant<bool, false> no_t;
-    typedef std::integral_constant<int, 0> p0_t; typedef std::integral_constant<int, 1> p1_t;
-    if constexpr (OPT & 4) {
-        // the two roles are two separate loops (same number of s_barrier arrivals each): no register state is merged
-        // across the role branch inside the loop
-        auto run = [&](auto ROLE) __attribute__((always_inline)) {
-            for (int sb = 0; sb + 1 < nsb; sb++) { stage_sym(ROLE, yes_t{}, p0_t{}, sb); stage_sym(ROLE, yes_t{}, p1_t{}, sb); }
-            stage_sym(ROLE, no_t{}, p0_t{}, nsb - 1); stage_sym(ROLE, no_t{}, p1_t{}, nsb - 1);
-            if (decltype(ROLE)::value) T_phase(no_t{}, 0, 0, 0);
-        };
-        if ((OPT & 8) && kh == 1) run(yes_t{}); else run(no_t{});
-    } else {
-        for (int sb = 0; sb + 1 < nsb; sb++) { stage(yes_t{}, p0_t{}, sb); stage(yes_t{}, p1_t{}, sb); }
-        stage(no_t{}, p0_t{}, nsb - 1); stage(no_t{}, p1_t{}, nsb - 1);
-    }
-    if (!(OPT & 4) && kh == 1) mfma_block(false, 0, 0, 0);
-
-    estamp(1);
-#include "gemm_w8_epilogue.inc"
-}
-
-
-// ------------------------------------------------------------------------------------------------------------
-// k_gemm_kq_w8 with a CROSS-STAGE software pipeline (same tile, ring, DMA and epilogue; see the comment at the main loop).
-template <int TYPE, bool TRACE = false>
-__global__ __launch_bounds__(512) void k_gemm_kq_w8p(const gemm_params p) {
-    constexpr bool EPI_BALANCED = false, EPI_DIRECT = false;
-    typedef WStage<TYPE, 2> WSt;
-    constexpr int BNF = 4, TB = 128, NST = 3;
-    constexpr int RS = 256, XS = TB * RS;
-    constexpr int BLK = QT<TYPE>::BYTES;
-    constexpr int WRS = WSt::NPH * 16, WS = 128 * WRS, ST = XS + WS;
-    constexpr int XL = XS / 16 / 512;            // 4
-    constexpr int NWI = 128 * WSt::NPH / 64;     // 10 (Q4_K) / 14 (Q5_K)
-    constexpr int WL = (NWI + 7) / 8;            // 2
-    constexpr int NL = XL + WL;
-    constexpr int SMEM = NST * ST > 128 * 1024 ? NST * ST : 128 * 1024;      // the epilogue needs 2 x 64 KB
-    static_assert(SMEM <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
-    __shared__ int xchg_failed;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int mg = wave & 3, kh = __builtin_amdgcn_readfirstlane(wave >> 2);
-    // experiment knob (CDNA4_TUNE bit 0): one static priority raise for the second-dispatched half of the work-group
-    if ((p.tune & 1) && kh == 1) __builtin_amdgcn_s_setprio(1);
-    const int nblk = gridDim.x;
-    int L = blockIdx.x;
-    if ((nblk & 7) == 0) L = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-    const int tile_b = L % p.tiles_b; L /= p.tiles_b;
-    const int ks = L % p.splitk, tile_m = L / p.splitk;
-    const int m0 = tile_m * 128, b0 = tile_b * TB;
-    // K range of this work-group in superblocks.  Hand-off split (p.partial): [0, sb_split) -> ks=0, the rest -> ks=1.
-    const int nsb_all = p.K / 256;
-    const int nsb = p.partial ? (ks == 0 ? p.sb_split : nsb_all - p.sb_split) : nsb_all / p.splitk;
-    const int sb0 = p.partial ? (ks == 0 ? 0 : p.sb_split) : ks * nsb, nstage = nsb * 2;
-
-    // (Tried and rejected, measured: four extra loader waves (12 waves, one loader per SIMD) that do nothing but issue the
-    //  LDS-DMA pieces, compute waves software-pipelined in-wave to fit 168 VGPRs: 44 us vs 37 us per call.  One wave
-    //  sustains only ~1 KiB per 75-90 cycles of LDS-DMA (tools/microbench/l2_stream: 32 GB/s for one wave, 134 GB/s for
-    //  eight), so four loaders cannot feed a stage in time; spreading the pieces over all eight waves can.)
-    DqConst dq; dq.init();
-    floatx16 acc[BNF];
-#pragma unroll
-    for (int i = 0; i < BNF; i++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-
-    uint32_t xvoff[XL], wvoff[2][WL];
-#pragma unroll
-    for (int i = 0; i < XL; i++) {
-        const int pc = i * 512 + tid, row = pc >> 4, c = (pc & 15) ^ (row & 15);
-        xvoff[i] = (uint32_t)(min(b0 + row, p.B - 1) - b0) * 256u + c * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < WL; i++) {
-        int idx = wave + 8 * i;
-        if (idx >= NWI) idx -= 8;
-        const int pc = idx * 64 + lane, row = pc / WSt::NPH, c = pc % WSt::NPH;
-        const uint32_t ro = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
-        wvoff[0][i] = ro + WSt::src_piece(c, 0) * 16; wvoff[1][i] = ro + WSt::src_piece(c, 1) * 16;
-    }
-    const char *const xbase = (const char *)p.xh + ((int64_t)sb0 * 2 * p.B + b0) * 256;    // panel (2*sb0), row b0
-    const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
-
-    // LDS-DMA in the scalar-base form (SGPR pair + 32-bit lane offset, M0 = wave-uniform LDS address): no per-lane 64-bit
-    // address arithmetic (the flat form cost ~5 VALU per piece, ~20 % of this kernel's VALU instructions).
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    auto dma16 = [&](const char *sbase, uint32_t voff, uint32_t lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
-    };
-    auto issue_piece = [&](int i, int sbr, int part, int slot) __attribute__((always_inline)) {         // piece i of stage (sbr, part) -> ring slot
-        const uint32_t l = lds0 + slot * ST;
-        if (i < XL) { dma16(xbase + (int64_t)(sbr * 2 + part) * p.B * 256, xvoff[i], l + (i * 512 + wave_s * 64) * 16); return; }
-        int idx = wave_s + 8 * (i - XL);
-        if (idx >= NWI) idx -= 8;
-        dma16(wbase + (int64_t)sbr * BLK, wvoff[part][i - XL], l + XS + idx * 1024);
-    };
-    auto issue = [&](int sbr, int part, int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NL; i++) issue_piece(i, sbr, part, slot);
-    };
-
-    const int xrow_off = j * RS, xswz = j & 15;
-    auto estamp = [&](int) __attribute__((always_inline)) {};
-    // TRACE builds: shader clock (s_memtime) against the fixed 100 MHz reference (s_memrealtime) over the whole kernel of block 0
-    if (TRACE && blockIdx.x == 0 && tid == 0) { p.trace[8 * 16 * 8 + 1100] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1101] = __builtin_amdgcn_s_memrealtime(); }
-    // TRACE builds: [wave][stage 4..19][phase] s_memtime stamps of block 0: 0 T_a begin, 1 T_a done, 2 after the vmcnt/lgkm
-    // waits, 3 after the barrier, 4 next stage's LDS reads issued, 6 T_b done
-    auto stamp = [&](int s_, int ph) __attribute__((always_inline)) {
-        if (TRACE && blockIdx.x == 0 && s_ >= 4 && s_ < 20 && lane == 0) p.trace[(wave * 16 + (s_ - 4)) * 8 + ph] = __builtin_amdgcn_s_memtime();
-    };
-    // ---- cross-stage software pipeline -------------------------------------------------------------------------
-    // The barrier of a stage sits in the MIDDLE of its MFMA stream.  Per wave and stage s (ring slot s % 3):
-    //   T_a(s): MFMAs of k-steps 0,1 (fragments in registers since the previous stage) + VALU building fragments 1,2;
-    //           ds_reads of the activation fragments of k-steps 2,3 (the last LDS reads of slot s)
-    //   wait: stage s+1 landed (vmcnt), own LDS reads done (lgkmcnt)  ->  s_barrier  ->  slot s is free
-    //   T_b(s): MFMAs of k-steps 2,3 + VALU building fragment 3 + ALL of the next stage's S work (packed-weight and
-    //           k-step 0,1 activation reads from slot s+1, scale constants, fragment 0) + the DMA pieces of stage s+3 -> slot s
-    // so the LDS latency and the scale arithmetic of stage s+1 run under the MFMAs of stage s instead of in front of its own.
-    Raw<TYPE> raw_c;                                                   // (after T_a the stage's packed weights and scales are dead:
-    typename Raw<TYPE>::Sc z_c;                                        //  T_b loads the next stage's straight into the same registers)
-    half8_t xa[4][BNF];
-    uint32_t cur[4] = {0, 0, 0, 0};
-    auto read_xa = [&](int slot, int kk) __attribute__((always_inline)) {
-        const uint8_t *xs = smem + slot * ST + xrow_off;
-        const int coff = ((kh * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++) xa[kk][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
-    };
-    auto mfma4 = [&](int kk, const uint32_t (&w)[4], auto &&between) __attribute__((always_inline)) {
-        const u32x4 cw = {w[0], w[1], w[2], w[3]};
-        const half8_t wfk = __builtin_bit_cast(half8_t, cw);
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++) {
-            __builtin_amdgcn_sched_barrier(0);
-            acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[kk][bf], wfk, acc[bf], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            between(bf);
-        }
-    };
-    // S work of a stage whose data sits in `slot`: used once in the prologue (nothing to hide it under yet)
-    auto S_first = [&](int slot) __attribute__((always_inline)) {
-        raw_c.load(smem + slot * ST + XS + (mg * 32 + j) * WRS, kh, h);
-        read_xa(slot, 0); read_xa(slot, 1);
-        if (kh == 0) z_c = raw_c.scales(0); else z_c = raw_c.scales(1);
-#pragma unroll
-        for (int i = 0; i < 4; i++) cur[i] = raw_c.pairbits(0, i, z_c, dq);
-    };
-    int slot = 0;
-    // LD: stage s+3 exists (its pieces are issued here);  W2: stage s+2 exists (its pieces are the only ones allowed to be
-    // outstanding at the barrier);  NX: stage s+1 exists (barrier + its S work);  PART: which half of the superblock stage s is
-    // The NL DMA pieces of a stage are issued in two halves so that neither half of the MFMA stream carries them all:
-    // pieces [0, NB) of stage s+3 in T_b(s), pieces [NB, NL) of stage s+2 in T_a(s) (both target a slot freed by the barrier
-    // before them; HA = T_a has pieces to issue: stage s+2 exists and was not part of the prologue's three stages).
-    constexpr int NB = (NL + 1) / 2;
-    auto stage = [&](auto LD, auto W2, auto NX, auto HA, auto PART, int sb) __attribute__((always_inline)) {
-        constexpr bool load = decltype(LD)::value, w2 = decltype(W2)::value, nx = decltype(NX)::value, ha = decltype(HA)::value;
-        constexpr int part = decltype(PART)::value;
-        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;
-        uint32_t f1[4], f2[4], f3[4];
-        const int s_ = sb * 2 + part;
-        stamp(s_, 0);
-        // ---- T_a: k-steps 0,1; builds fragments 1, 2 and half of 3; second half of stage s+2's pieces -> slot of stage s-1
-        read_xa(slot, 2);
-        mfma4(0, cur, [&](int bf) __attribute__((always_inline)) {
-            f1[bf] = raw_c.pairbits(1, bf, z_c, dq);
-            if (bf < 2) f3[bf] = raw_c.pairbits(3, bf, z_c, dq);
-            if constexpr (ha) { if (NB + bf < NL) issue_piece(NB + bf, sb + (part + 2) / 2, part, slot2); }
-        });
-        read_xa(slot, 3);
-        mfma4(1, f1, [&](int bf) __attribute__((always_inline)) {
-            f2[bf] = raw_c.pairbits(2, bf, z_c, dq);
-            if (bf >= 2) f3[bf] = raw_c.pairbits(3, bf, z_c, dq);
-        });
-        stamp(s_, 1);
-        if constexpr (nx) {
-            if (w2) wait_vmcnt<NL>(); else wait_vmcnt<0>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's last reads of `slot` have returned
-            stamp(s_, 2);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            stamp(s_, 3);
-        }
-        // ---- T_b: k-steps 2,3; the next stage's S work; first half of stage s+3's pieces -> slot of stage s
-        if constexpr (nx) {
-            __builtin_amdgcn_sched_barrier(0);
-            raw_c.load(smem + slot1 * ST + XS + (mg * 32 + j) * WRS, kh, h);
-            read_xa(slot1, 0); read_xa(slot1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            stamp(s_, 4);
-        }
-        mfma4(2, f2, [&](int bf) __attribute__((always_inline)) {
-            if constexpr (load) { if (bf < NB) issue_piece(bf, sb + (part + 3) / 2, (part + 3) % 2, slot); }
-            if constexpr (nx) {
-                if (bf == 3) { if (kh == 0) z_c = raw_c.scales(((part + 1) & 1) * 2); else z_c = raw_c.scales(((part + 1) & 1) * 2 + 1); }
-            }
-        });
-        mfma4(3, f3, [&](int bf) __attribute__((always_inline)) {
-            if constexpr (nx) cur[bf] = raw_c.pairbits(0, bf, z_c, dq);
-        });
-        stamp(s_, 6);
-        slot = slot1;
-    };
-    static_assert(NL <= 8, "the T_b phase has 8 DMA slots");
-    typedef std::integral_constant<bool, true> yes_t; typedef std::integral_constant<bool, false> no_t;
-    typedef std::integral_constant<int, 0> p0_t; typedef std::integral_constant<int, 1> p1_t;
-    // prologue: stages 0, 1, 2 into slots 0, 1, 2.  (Requesting stage 2 only after stage 0 has landed, weight pieces first,
-    // made no measurable difference: 26.5 us either way.)
-    issue(0, 0, 0);
-    issue(0, 1, 1);
-    if (nstage > 2) { issue(1, 0, 2); wait_vmcnt<2 * NL>(); } else wait_vmcnt<NL>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    S_first(0);
-    // stage s = 2 sb + part needs: LD = s + 3 < nstage, W2 = s + 2 < nstage, NX = s + 1 < nstage, HA = W2 && s >= 1
-    // (stage 2's pieces all went out in the prologue)
-    // (the launcher only sends K ranges of >= 3 superblocks per work-group here; shallower ones run k_gemm_kq_w8)
-    stage(yes_t{}, yes_t{}, yes_t{}, no_t{}, p0_t{}, 0); stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, 0);
-    int sb = 1;
-    for (; sb + 2 < nsb; sb++) { stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); }
-    stage(yes_t{}, yes_t{}, yes_t{}, yes_t{}, p0_t{}, sb); stage(no_t{}, yes_t{}, yes_t{}, yes_t{}, p1_t{}, sb); sb++;   // sb = nsb - 2
-    stage(no_t{}, no_t{}, yes_t{}, no_t{}, p0_t{}, sb); stage(no_t{}, no_t{}, no_t{}, no_t{}, p1_t{}, sb);                  // sb = nsb - 1
-
-#include "gemm_w8_epilogue.inc"
-    if (TRACE && blockIdx.x == 0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.trace[8 * 16 * 8 + 1102] = __builtin_amdgcn_s_memtime(); p.trace[8 * 16 * 8 + 1103] = __builtin_amdgcn_s_memrealtime(); }
-}
-
-
-// k_gemm_kq_w8p with FOUR EXTRA LOADER WAVES (12 waves, three per SIMD): waves 8-11 do nothing but issue the LDS-DMA pieces
-// (an LDS-DMA instruction parks its wave ~60 cycles; in the 8-wave kernels that park is taken out of the MFMA stream — the
-// DMA-less ablation of k_gemm_kq_w8p ran 26.9 -> 24.7 us with the same memory traffic), waves 0-7 are the compute waves of
-// k_gemm_kq_w8p without any vector-memory instruction in their main loop.  All twelve meet at the same s_barriers.
 #include "gemm_kq_w12.inc"
 
 // ------------------------------------------------------------------------------------------------------------

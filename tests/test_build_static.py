@@ -243,3 +243,19 @@ def test_decode_kernel_source_on_the_cpu(t, cfg):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(t, 37, 2048, seed=t + cfg, env={"CDNA4_FUSED_CFG": str(cfg)}) < 1e-5
+
+
+@pytest.mark.parametrize("kern,wtype,m,k,b,splitk", [(20, 12, 300, 1536, 200, 1), (20, 12, 256, 2048, 128, 2), (64, 12, 300, 1536, 200, 1), (64, 13, 256, 2048, 128, 2),
+                                                     (64, 13, 300, 1536, 200, 1), (20, 13, 300, 512, 200, 1), (1064, 12, 256, 2048, 128, 2)])
+def test_8_wave_kernel_sources_on_the_cpu(kern, wtype, m, k, b, splitk):
+    """tools/emul/w8_emul: k_gemm_kq_w8 (schedule 20: the shallow-K fallback and the kernel of the repacked formats) and
+    k_gemm_kq_w8p (64: Q5_K's default; 1064: its TRACE build), Q4_K and Q5_K weights, executed on the CPU — with the LDS-DMA
+    landing immediately and as late as the counted waits allow"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for defer in (False, True):
+        assert mod.run(m, k, b, seed=m + k, timeout=600, splitk=splitk, kernel="w8", exp=kern, wtype=wtype, defer_dma=defer) < 1e-6

@@ -1,7 +1,7 @@
-// w12_emul.cpp — runs the SOURCE of k_gemm_kq_w12<Q4_K, true, EXP> (ggml_amd/csrc/gemm_kq_w12.inc + gemm_w8_epilogue.inc: the
-// shipped 12-wave kernel and its bit-identical experiment variants) on the CPU like x4l_emul.cpp does for the experimental
-// kernel.  Test infrastructure.
-//   w12_emul M K B w.bin xh.bin y.bin splitk exp xchg_l2
+// w8_emul.cpp — runs the SOURCE of k_gemm_kq_w8 / k_gemm_kq_w8p (ggml_amd/csrc/gemm_kq_w8.inc + gemm_w8_epilogue.inc: the 8-wave
+// kernels — Q5_K's default, the shallow-K fallback, the A/B baselines and their TRACE builds) on the CPU like w12_emul.cpp.
+// Test infrastructure.
+//   w8_emul M K B w.bin xh.bin y.bin splitk kernel xchg_l2 [type]     kernel: 20 / 12 / 0 = k_gemm_kq_w8 OPT, 64 = w8p, +1000 = TRACE build
 #include "hip_emul.h"
 #include <signal.h>
 #include <sys/mman.h>
@@ -43,7 +43,7 @@ static void *shared_alloc(size_t n) {
 #include "../../ggml_amd/csrc/gemm_q_common.h"
 #include "../../ggml_amd/csrc/gemm_q_hw.h"
 void *cdna4_debug_trace = nullptr;
-#include "../../ggml_amd/csrc/gemm_kq_w12.inc"
+#include "../../ggml_amd/csrc/gemm_kq_w8.inc"
 
 template <typename F> static void emu_launch(F body, unsigned nblk, int nthreads) {
     emu::g_gridDim = dim3(nblk); emu::g_blockDim = dim3(nthreads);
@@ -80,7 +80,7 @@ static std::vector<uint8_t> slurp(const char *p) {
     std::vector<uint8_t> v((size_t)n); if (fread(v.data(), 1, (size_t)n, f) != (size_t)n) exit(2); fclose(f); return v;
 }
 int main(int argc, char **argv) {
-    if (argc < 10) { fprintf(stderr, "usage: w12_emul M K B w.bin xh.bin y.bin splitk exp xchg_l2\n"); return 2; }
+    if (argc < 10) { fprintf(stderr, "usage: w8_emul M K B w.bin xh.bin y.bin splitk kernel xchg_l2 [type]\n"); return 2; }
     const int M = atoi(argv[1]), K = atoi(argv[2]), B = atoi(argv[3]), splitk = atoi(argv[7]), exp = atoi(argv[8]), l2 = atoi(argv[9]);
     std::vector<uint8_t> w0 = slurp(argv[4]), xh0 = slurp(argv[5]);
     uint8_t *w = (uint8_t *)shared_alloc(w0.size()), *xh = (uint8_t *)shared_alloc(xh0.size());
@@ -89,7 +89,10 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < (size_t)B * M; i++) y[i] = -12345.f;
     // the parameter block exactly as launch_w8() (gemm_q_mfma.hip) fills it for this kernel
     gemm_params p{};
-    p.W = w; p.w_row_bytes = (int64_t)(K / 256) * 144; p.xh = (const half_t *)xh; p.xh_row = K; p.Y = y; p.y_row = M; p.M = M; p.K = K; p.B = B; p.splitk = splitk;
+    const int type = argc > 10 ? atoi(argv[10]) : CDNA4_Q4_K;
+    p.W = w; p.w_row_bytes = (int64_t)(K / 256) * (type == CDNA4_Q5_K ? 176 : 144);
+    p.trace = (unsigned long long *)shared_alloc(65536);             // the 64-KiB buffer ggml_cdna4_debug_trace() is given (TRACE builds)
+    p.xh = (const half_t *)xh; p.xh_row = K; p.Y = y; p.y_row = M; p.M = M; p.K = K; p.B = B; p.splitk = splitk;
     p.tiles_m = (M + 127) / 128; p.tiles_b = (B + 127) / 128;
     const int ntiles = p.tiles_m * p.tiles_b, total = K / 256;
     if (splitk == 2) {
@@ -101,19 +104,24 @@ int main(int argc, char **argv) {
         p.xchg_l2 = l2;
     } else if (splitk != 1) { fprintf(stderr, "splitk 1 or 2\n"); return 2; }
     const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
-    if (min_nsb < 3) { fprintf(stderr, "the kernel needs 3 superblocks of K per work-group\n"); return 2; }
     const unsigned nblk = (unsigned)(ntiles * splitk);
-    switch (exp) {
-        case 0: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 0>(p); }, nblk, 768); break;
-        case 1: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 1>(p); }, nblk, 768); break;
-        case 2: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 2>(p); }, nblk, 768); break;
-        case 4: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 4>(p); }, nblk, 768); break;
-        case 6: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 6>(p); }, nblk, 768); break;
-        case 100: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, false, 0>(p); }, nblk, 768); break;      // compute waves unpack the scales themselves
-        case 32: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 32>(p); }, nblk, 768); break;        // timing ablations (results are garbage): bounds checks only
-        case 480: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 480>(p); }, nblk, 768); break;
-        default: fprintf(stderr, "exp not built into the emulator\n"); return 2;
-    }
+    const int kern = exp;
+    if ((kern % 1000) == 64 && min_nsb < 3) { fprintf(stderr, "k_gemm_kq_w8p needs 3 superblocks of K per work-group\n"); return 2; }
+#define RUN(...) emu_launch([&] { __VA_ARGS__(p); }, nblk, 512)
+    if (type == CDNA4_Q4_K) switch (kern) {
+        case 20: RUN(k_gemm_kq_w8<CDNA4_Q4_K, false, 20>); break;
+        case 12: RUN(k_gemm_kq_w8<CDNA4_Q4_K, false, 12>); break;
+        case 0: RUN(k_gemm_kq_w8<CDNA4_Q4_K, false, 0>); break;
+        case 1000: RUN(k_gemm_kq_w8<CDNA4_Q4_K, true, 0>); break;
+        case 1020: RUN(k_gemm_kq_w8<CDNA4_Q4_K, true, 20>); break;
+        case 64: RUN(k_gemm_kq_w8p<CDNA4_Q4_K, false>); break;
+        case 1064: RUN(k_gemm_kq_w8p<CDNA4_Q4_K, true>); break;
+        default: fprintf(stderr, "kernel not built into the emulator\n"); return 2;
+    } else if (type == CDNA4_Q5_K) switch (kern) {
+        case 20: RUN(k_gemm_kq_w8<CDNA4_Q5_K, false, 20>); break;
+        case 64: RUN(k_gemm_kq_w8p<CDNA4_Q5_K, false>); break;
+        default: fprintf(stderr, "kernel not built into the emulator\n"); return 2;
+    } else { fprintf(stderr, "type not built into the emulator\n"); return 2; }
     FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)B * M, f); fclose(f);
     return 0;
 }

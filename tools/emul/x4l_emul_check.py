@@ -25,7 +25,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 def build(name="x4l"):
     exe = os.path.join(HERE, name + "_emul")
     srcs = [os.path.join(HERE, name + "_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(ROOT, "ggml_amd", "csrc", f)
-            for f in ("gemm_q_x4l.hip", "gemm_q_x4l_hw.h", "gemm_kq_w12.inc", "gemm_w8_epilogue.inc", "gemm_q_hw.h", "gemm_q_common.h", "cdna4_common.h", "cdna4_kernels.h")]
+            for f in ("gemm_q_x4l.hip", "gemm_q_x4l_hw.h", "gemm_kq_w12.inc", "gemm_kq_w8.inc", "gemm_w8_epilogue.inc", "gemm_q_hw.h", "gemm_q_common.h", "cdna4_common.h", "cdna4_kernels.h")]
     if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
         subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "ggml_amd", "csrc"),
                         "-Wno-unused-value", "-o", exe, srcs[0]], check=True, capture_output=True, timeout=600)
@@ -61,7 +61,7 @@ def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, 
     with tempfile.TemporaryDirectory() as d:
         # the weight file must start 16-byte aligned in memory: the emulator reads it into a std::vector (malloc: 16-byte aligned)
         w.tofile(os.path.join(d, "w.bin")); img.tofile(os.path.join(d, "xh.bin"))
-        extra = [str(splitk), str(exp), str(wtype)] if kernel == "x4l" else [str(splitk), str(exp), str(xchg_l2)]       # x4l: exp 1 = the 128 x 128 tile form
+        extra = [str(splitk), str(exp), str(wtype)] if kernel == "x4l" else [str(splitk), str(exp), str(xchg_l2), str(wtype)]       # x4l: exp = tile form; w8: exp = kernel
         r = subprocess.run([build(kernel), str(M), str(K), str(B), os.path.join(d, "w.bin"), os.path.join(d, "xh.bin"), os.path.join(d, "y.bin")] + extra,
                            capture_output=True, text=True, timeout=timeout, env=dict(os.environ, EMU_DEFER_DMA="1" if defer_dma else "0"))
         if r.returncode == 77:                          # process / thread limits of this environment: nothing was checked
