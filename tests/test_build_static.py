@@ -259,3 +259,17 @@ def test_8_wave_kernel_sources_on_the_cpu(kern, wtype, m, k, b, splitk):
     spec.loader.exec_module(mod)
     for defer in (False, True):
         assert mod.run(m, k, b, seed=m + k, timeout=600, splitk=splitk, kernel="w8", exp=kern, wtype=wtype, defer_dma=defer) < 1e-6
+
+
+@pytest.mark.parametrize("kind,k,b,dist", [(0, 4096, 8, "uniform"), (0, 2048, 32, "ties"), (1, 4096, 8, "uniform"), (1, 1024, 32, "ties"), (2, 1024, 32, "ties")])
+def test_activation_quantizer_sources_on_the_cpu_bit_exact(kind, k, b, dist):
+    """tools/emul/quant_emul: k_quantize_q8_K / k_quantize_q8_0 (AVX2 and _ref roundings) executed on the CPU equal the oracle's
+    quantize_row_q8_K / _q8_0 bit for bit — quants, scales, bsums — and their fp16 activation image equals fp16(d*q) in the
+    panel-major, pair-interleaved layout; all-zero blocks, a negative maximum and exact .5 ties included"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("quant_emul_check", os.path.join(ROOT, "tools", "emul", "quant_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(kind, k, b, dist=dist, seed=kind + k)
