@@ -273,3 +273,17 @@ def test_activation_quantizer_sources_on_the_cpu_bit_exact(kind, k, b, dist):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(kind, k, b, dist=dist, seed=kind + k)
+
+
+@pytest.mark.parametrize("t", [12, 13, 14, 2, 8])
+def test_multi_column_gemv_source_on_the_cpu(t):
+    """tools/emul/gemv_emul: k_gemv_q (2 <= B <= 8 columns share one pass over the weights) on activations quantized by the
+    oracle, against the oracle's MUL_MAT"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gemv_emul_check", os.path.join(ROOT, "tools", "emul", "gemv_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run_cols(t, 33, 2048, 3, seed=t) < 1e-5
+    assert mod.run_cols(t, 16, 1024, 8, seed=t + 1) < 1e-5

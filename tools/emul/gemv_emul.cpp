@@ -72,8 +72,23 @@ static std::vector<uint8_t> slurp(const char *p) {
     fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
     std::vector<uint8_t> v((size_t)n); if (fread(v.data(), 1, (size_t)n, f) != (size_t)n) exit(2); fclose(f); return v;
 }
+// gemv_emul type M K w.bin qs.bin y.bin ncol d.bin bsums.bin : the multi-column GEMV (2 <= B <= 8) on pre-quantized activations
+static int main_cols(int argc, char **argv) {
+    const int type = atoi(argv[1]), M = atoi(argv[2]), K = atoi(argv[3]), ncol = atoi(argv[7]);
+    std::vector<uint8_t> w0 = slurp(argv[4]), q0 = slurp(argv[5]), d0 = slurp(argv[8]), b0 = slurp(argv[9]);
+    uint8_t *w = (uint8_t *)shared_alloc(w0.size()); int8_t *qs = (int8_t *)shared_alloc(q0.size()); float *d = (float *)shared_alloc(d0.size());
+    int16_t *bs = (int16_t *)shared_alloc(b0.size() ? b0.size() : 16); float *y = (float *)shared_alloc((size_t)M * ncol * 4);
+    memcpy(w, w0.data(), w0.size()); memcpy(qs, q0.data(), q0.size()); memcpy(d, d0.data(), d0.size()); if (b0.size()) memcpy(bs, b0.data(), b0.size());
+    for (int i = 0; i < M * ncol; i++) y[i] = -12345.f;
+    cdna4_gemv_args a{};
+    a.type = type; a.W = w; a.w_row_bytes = (int64_t)(w0.size() / (size_t)M); a.qs = qs; a.d = d; a.bsums = bs; a.Y = y; a.y_col_stride = M; a.M = M; a.K = K; a.ncol = ncol;
+    if (cdna4_launch_gemv_q(a, nullptr) != 0) return 1;
+    FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)M * ncol, f); fclose(f);
+    return 0;
+}
 int main(int argc, char **argv) {
-    if (argc < 7) { fprintf(stderr, "usage: gemv_emul type M K w.bin x.bin y.bin\n"); return 2; }
+    if (argc >= 10) return main_cols(argc, argv);
+    if (argc < 7) { fprintf(stderr, "usage: gemv_emul type M K w.bin x.bin y.bin   |   gemv_emul type M K w.bin qs.bin y.bin ncol d.bin bsums.bin\n"); return 2; }
     const int type = atoi(argv[1]), M = atoi(argv[2]), K = atoi(argv[3]);
     std::vector<uint8_t> w0 = slurp(argv[4]), x0 = slurp(argv[5]);
     uint8_t *w = (uint8_t *)shared_alloc(w0.size()); float *x = (float *)shared_alloc(x0.size()), *y = (float *)shared_alloc((size_t)M * 4);

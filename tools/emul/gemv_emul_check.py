@@ -45,6 +45,34 @@ def run(t, M, K, seed=1, timeout=600, env=None):
     return R.rel_l2(y, want)
 
 
+def run_cols(t, M, K, ncol, seed=1, timeout=600):
+    """the multi-column GEMV (B = 2 .. 8) on activations quantized by the oracle, against the oracle's MUL_MAT"""
+    w = R.random_weights(t, M, K, seed)
+    x = np.random.default_rng(seed + 1).uniform(-1, 1, (ncol, K)).astype(np.float32)
+    want = R.o_mul_mat(t, w, x, M, K)
+    act = R.o_quantize_act(t, x)
+    if R.act_type(t) == R.Q8_K:
+        blk = act.reshape(ncol, K // 256, 292)
+        d = blk[:, :, 0:4].copy().view(np.float32).reshape(ncol, K // 256)
+        qs = blk[:, :, 4:260].copy().view(np.int8).reshape(ncol, K)
+        bs = blk[:, :, 260:292].copy().view(np.int16).reshape(ncol, K // 16)
+    else:
+        blk = act.reshape(ncol, K // 32, 34)
+        d = blk[:, :, 0:2].copy().view(np.float16).astype(np.float32).reshape(ncol, K // 32)
+        qs = blk[:, :, 2:34].copy().view(np.int8).reshape(ncol, K)
+        bs = np.zeros(0, np.int16)
+    with tempfile.TemporaryDirectory() as dd:
+        f = lambda n: os.path.join(dd, n)
+        w.tofile(f("w.bin")); qs.tofile(f("qs.bin")); d.tofile(f("d.bin")); bs.tofile(f("bs.bin"))
+        r = subprocess.run([build(), str(t), str(M), str(K), f("w.bin"), f("qs.bin"), f("y.bin"), str(ncol), f("d.bin"), f("bs.bin")], capture_output=True, text=True, timeout=timeout)
+        if r.returncode == 77:
+            import pytest
+            pytest.skip("the environment cannot host the emulation (process / thread limits)")
+        assert r.returncode == 0, r.stderr[-500:]
+        y = np.fromfile(f("y.bin"), np.float32).reshape(ncol, M)
+    return R.rel_l2(y, want)
+
+
 if __name__ == "__main__":
     t, M, K = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (R.Q4_K, 37, 2048)
     print("decode kernel source on the CPU vs the oracle, type %d %dx%d: rel-L2 %.3e" % (t, M, K, run(t, M, K)))
