@@ -12,6 +12,8 @@
 enum cdna4_type : int {
     CDNA4_F32 = 0, CDNA4_F16 = 1, CDNA4_Q4_0 = 2, CDNA4_Q8_0 = 8,
     CDNA4_Q4_K = 12, CDNA4_Q5_K = 13, CDNA4_Q6_K = 14, CDNA4_Q8_K = 15, CDNA4_I32 = 26,
+    // GEMV units exist (gemv_q.hip, verified on the CPU emulator only so far); not accepted by the C-ABI yet
+    CDNA4_Q5_0 = 6, CDNA4_Q2_K = 10, CDNA4_Q3_K = 11,
 };
 
 // bytes per block / weights per block
@@ -21,6 +23,9 @@ template <> struct QT<CDNA4_Q8_0> { static constexpr int BYTES = 34,  QK = 32;  
 template <> struct QT<CDNA4_Q4_K> { static constexpr int BYTES = 144, QK = 256; static constexpr bool KQ = true; };
 template <> struct QT<CDNA4_Q5_K> { static constexpr int BYTES = 176, QK = 256; static constexpr bool KQ = true; };
 template <> struct QT<CDNA4_Q6_K> { static constexpr int BYTES = 210, QK = 256; static constexpr bool KQ = true; };
+template <> struct QT<CDNA4_Q5_0> { static constexpr int BYTES = 22,  QK = 32;  static constexpr bool KQ = false; };
+template <> struct QT<CDNA4_Q2_K> { static constexpr int BYTES = 84,  QK = 256; static constexpr bool KQ = true; };
+template <> struct QT<CDNA4_Q3_K> { static constexpr int BYTES = 110, QK = 256; static constexpr bool KQ = true; };
 // library-private re-layouts of the 2-byte-aligned formats into 16-byte-aligned 256-weight superblocks, produced per call
 // into scratch by gemm_q_mfma.hip's repack kernels so that the LDS-DMA pipeline (16-byte pieces) can stage them:
 //   Q4_0R 144 B: fp16 d[8] | 4 x 32 B nibbles in Q4_K order (byte l of group g: low = k 64g+l, high = k 64g+32+l)

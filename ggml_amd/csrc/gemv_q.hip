@@ -146,6 +146,126 @@ template <int NB> struct Unit<CDNA4_Q6_K, NB> {
     template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
 };
 
+// ---- formats beyond the five of the C-ABI: units written against the CPU oracle and run only on the CPU
+// ---- emulator so far (tools/emul/gemv_emul); the C-ABI does not accept these types yet -------------------------------
+// bits 0..3 of x -> bit 0 of bytes 0..3
+__device__ __forceinline__ uint32_t spread4(uint32_t x) { return ((x & 0xFu) * 0x00204081u) & 0x01010101u; }
+
+// ---- Q5_0: 22-byte block {fp16 d, qh[4], qs[16]}: Q4_0 plus a fifth bit (bit j of qh: weight j; bit j+16: weight j+16), value q-16
+template <int NB> struct Unit<CDNA4_Q5_0, NB> {
+    static constexpr int UK = 32;
+    struct W { float d; uint32_t qh; uint32_t w[4]; };
+    __device__ static W load(const uint8_t *wrow, int u) {
+        const uint8_t *blk = wrow + (int64_t)u * 22;
+        W r; r.d = h2f(ld_u16(blk)); r.qh = ld_u32_a2(blk + 2);
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.w[i] = ld_u32_a2(blk + 6 + 4 * i);
+        return r;
+    }
+    template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
+        uint32_t wl[4], wh[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            wl[i] = (wr.w[i] & 0x0F0F0F0Fu) | (spread4(wr.qh >> (4 * i)) << 4);
+            wh[i] = ((wr.w[i] >> 4) & 0x0F0F0F0Fu) | (spread4(wr.qh >> (16 + 4 * i)) << 4);
+        }
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            const int8_t *y = a.qs + (int64_t)col[c] * a.K + u * 32;
+            const u32x4 y0 = ld_u32x4(y), y1 = ld_u32x4(y + 16);
+            const uint32_t yl[4] = {y0.x, y0.y, y0.z, y0.w}, yh[4] = {y1.x, y1.y, y1.z, y1.w};
+            int s = 0, ys = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                s = dot4(wl[i], yl[i], s); s = dot4(wh[i], yh[i], s);
+                ys = dot4(0x01010101u, yl[i], ys); ys = dot4(0x01010101u, yh[i], ys);
+            }
+            acc[c] += (float)(s - 16 * ys) * wr.d * a.d[(int64_t)col[c] * (a.K / 32) + u];
+        }
+    }
+    template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
+};
+
+// ---- Q2_K: 84-byte superblock {scales[16] (4-bit scale | 4-bit min << 4), qs[64], fp16 d, dmin}.  Unit = 64 consecutive k =
+// ---- (128-half n, shift pair j): the 32 bytes qs[32n..] at shifts 4j and 4j+2, sub-block scales scales[8n + 4j .. + 3]
+template <int NB> struct Unit<CDNA4_Q2_K, NB> {
+    static constexpr int UK = 64;
+    struct W { uint32_t q[8]; uint32_t sc; float d, dmin; };
+    __device__ static W load(const uint8_t *wrow, int u) {
+        const int sb = u >> 2, n = (u >> 1) & 1, j = u & 1;
+        const uint8_t *blk = wrow + (int64_t)sb * 84;
+        W r; r.sc = ld_u32_a2(blk + 8 * n + 4 * j); r.d = h2f(ld_u16(blk + 80)); r.dmin = h2f(ld_u16(blk + 82));
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.q[i] = ld_u32_a2(blk + 16 + 32 * n + 4 * i);
+        return r;
+    }
+    template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
+        const int sb = u >> 2, idx = u & 3, j = u & 1;
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            const int8_t *y = a.qs + (int64_t)col[c] * a.K + sb * 256 + 64 * idx;
+            const int16_t *bs = a.bsums + (int64_t)col[c] * (a.K / 16) + sb * 16 + 4 * idx;
+            int isum = 0, summs = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {                                   // sub-block t = (shift 2j + (t >> 1), byte half t & 1): k 16 t .. 16 t + 15 of the unit
+                const int sh = 2 * (2 * j + (t >> 1)), half = t & 1;
+                const u32x4 yv = ld_u32x4(y + 16 * t);
+                const uint32_t yy[4] = {yv.x, yv.y, yv.z, yv.w};
+                int s = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) s = dot4((wr.q[4 * half + i] >> sh) & 0x03030303u, yy[i], s);
+                const int scb = (int)((wr.sc >> (8 * t)) & 0xFF);
+                isum += (scb & 0xF) * s; summs += (scb >> 4) * (int)bs[t];
+            }
+            const float yd = a.d[(int64_t)col[c] * (a.K / 256) + sb];
+            acc[c] += (yd * wr.d) * (float)isum - (yd * wr.dmin) * (float)summs;
+        }
+    }
+    template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
+};
+
+// ---- Q3_K: 110-byte superblock {hmask[32], qs[64], scales[12] (sixteen 6-bit, -32), fp16 d}: value = (2 bits | hmask bit << 2) - 4.
+// ---- Same unit as Q2_K; the unit's four scales are the byte lanes of (low nibbles of scales[4j..4j+3], high for n = 1) |
+// ---- ((scales[8..11] >> 2 (2n + j)) & 3) << 4
+template <int NB> struct Unit<CDNA4_Q3_K, NB> {
+    static constexpr int UK = 64;
+    struct W { uint32_t q[8], hm[8]; uint32_t sc; float d; };
+    __device__ static W load(const uint8_t *wrow, int u) {
+        const int sb = u >> 2, n = (u >> 1) & 1, j = u & 1;
+        const uint8_t *blk = wrow + (int64_t)sb * 110;                       // 2-byte aligned only
+        W r; r.d = h2f(ld_u16(blk + 108));
+        const uint32_t lo = ld_u32_a2(blk + 96 + 4 * j), hi = ld_u32_a2(blk + 104);
+        r.sc = ((n ? (lo >> 4) : lo) & 0x0F0F0F0Fu) | (((hi >> (2 * (2 * n + j))) & 0x03030303u) << 4);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { r.q[i] = ld_u32_a2(blk + 32 + 32 * n + 4 * i); r.hm[i] = ld_u32_a2(blk + 4 * i); }
+        return r;
+    }
+    template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
+        const int sb = u >> 2, idx = u & 3, n = (u >> 1) & 1, j = u & 1;
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            const int8_t *y = a.qs + (int64_t)col[c] * a.K + sb * 256 + 64 * idx;
+            const int16_t *bs = a.bsums + (int64_t)col[c] * (a.K / 16) + sb * 16 + 4 * idx;
+            int isum = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int s2 = 2 * j + (t >> 1), half = t & 1;               // shift index 0..3 within the 128-half; hmask bit 4n + s2
+                const u32x4 yv = ld_u32x4(y + 16 * t);
+                const uint32_t yy[4] = {yv.x, yv.y, yv.z, yv.w};
+                int s = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t v = ((wr.q[4 * half + i] >> (2 * s2)) & 0x03030303u) | (((wr.hm[4 * half + i] >> (4 * n + s2)) & 0x01010101u) << 2);
+                    s = dot4(v, yy[i], s);
+                }
+                isum += ((int)((wr.sc >> (8 * t)) & 0xFF) - 32) * (s - 4 * (int)bs[t]);     // sum (v - 4) y = sum v y - 4 bsum
+            }
+            acc[c] += (wr.d * a.d[(int64_t)col[c] * (a.K / 256) + sb]) * (float)isum;
+        }
+    }
+    template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
+};
+
 // ---- Q4_0: unit = 18-byte block, nibble j -> k j (low), j+16 (high), value q-8 ------------------------------
 template <int NB> struct Unit<CDNA4_Q4_0, NB> {
     static constexpr int UK = 32;
@@ -387,7 +507,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
 }
 
 size_t cdna4_gemv_fused_lds_bytes(int type, int64_t K) {
-    const bool kq = type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K;
+    const bool kq = type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K || type == CDNA4_Q2_K || type == CDNA4_Q3_K;
     return (size_t)(K + (kq ? K / 8 + (K / 256) * 4 : (K / 32) * 4));
 }
 bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B) {
@@ -424,6 +544,9 @@ int cdna4_launch_gemv_q(const cdna4_gemv_args &a, hipStream_t st) {
             return launch_type<CDNA4_Q6_K>(a, st);
         case CDNA4_Q4_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_type<CDNA4_Q4_0>(a, st);
         case CDNA4_Q8_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_type<CDNA4_Q8_0>(a, st);
+        case CDNA4_Q5_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_type<CDNA4_Q5_0>(a, st);
+        case CDNA4_Q2_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_type<CDNA4_Q2_K>(a, st);
+        case CDNA4_Q3_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_type<CDNA4_Q3_K>(a, st);
     }
     return cdna4_set_error_msg("gemv_q: unsupported weight type");
 }
@@ -444,6 +567,9 @@ int cdna4_launch_gemv_q_fused(const cdna4_gemv_args &a, const float *x, hipStrea
             return launch_fused<CDNA4_Q6_K>(a, x, st);
         case CDNA4_Q4_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_Q4_0>(a, x, st);
         case CDNA4_Q8_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_Q8_0>(a, x, st);
+        case CDNA4_Q5_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_Q5_0>(a, x, st);
+        case CDNA4_Q2_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused<CDNA4_Q2_K>(a, x, st);
+        case CDNA4_Q3_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused<CDNA4_Q3_K>(a, x, st);
     }
     return cdna4_set_error_msg("gemv_q: unsupported weight type");
 }

@@ -232,7 +232,7 @@ def test_experimental_kernel_q5_k_form_on_the_cpu(m, k, b, splitk):
 
 
 @pytest.mark.parametrize("cfg", [0, 1])                       # 4 waves x 1 row, 8 waves x 2 rows (the M >= 4096 default)
-@pytest.mark.parametrize("t", [12, 13, 14, 2, 8])             # Q4_K, Q5_K, Q6_K, Q4_0, Q8_0
+@pytest.mark.parametrize("t", [12, 13, 14, 2, 8, 6, 10, 11])  # Q4_K, Q5_K, Q6_K, Q4_0, Q8_0 + the units not yet behind the C-ABI: Q5_0, Q2_K, Q3_K
 def test_decode_kernel_source_on_the_cpu(t, cfg):
     """tools/emul/gemv_emul: the source of the one-launch decode step (k_gemv_q_fused: in-kernel Q8_K / Q8_0 activation quantizer,
     int8 dots, wave reduction) executed on the CPU against the oracle's MUL_MAT — a GPU-free regression check of the B = 1 path"""
@@ -275,7 +275,7 @@ def test_activation_quantizer_sources_on_the_cpu_bit_exact(kind, k, b, dist):
     assert mod.run(kind, k, b, dist=dist, seed=kind + k)
 
 
-@pytest.mark.parametrize("t", [12, 13, 14, 2, 8])
+@pytest.mark.parametrize("t", [12, 13, 14, 2, 8, 6, 10, 11])
 def test_multi_column_gemv_source_on_the_cpu(t):
     """tools/emul/gemv_emul: k_gemv_q (2 <= B <= 8 columns share one pass over the weights) on activations quantized by the
     oracle, against the oracle's MUL_MAT"""
