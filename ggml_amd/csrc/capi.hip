@@ -114,6 +114,18 @@ int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float
         g.M = (int)M; g.K = (int)K; g.ncol = 1; g.ids = nullptr;
         return cdna4_launch_gemv_q_fused(g, X, (hipStream_t)stream);
     }
+    if (path == GGML_CDNA4_PATH_GEMM && gemm_variant > 0 && (gemm_variant >> 16) == 1024) {
+        // explicit experimental variant: ONE launch — k_gemm_kq_w12<Q4_K> quantizes the activations itself (the image still
+        // lives in the caller's workspace); every route that cannot do that fails in the launcher, nothing falls back silently
+        if (!workspace || ((uintptr_t)workspace & 255)) return cdna4_set_error_msg("mul_mat: workspace must be 256-byte aligned");
+        const ws_view v = carve(type, K, B, workspace);
+        if (workspace_bytes < v.total) return cdna4_set_error_msg("mul_mat: workspace too small");
+        cdna4_gemm_args a{};
+        a.type = type; a.W = (const uint8_t *)W; a.w_row_bytes = w_row_bytes; a.xh = v.xh; a.xh_row_elems = K;
+        a.Y = Y; a.y_row_elems = y_row_stride; a.M = (int)M; a.K = (int)K; a.B = (int)B; a.variant = gemm_variant; a.splitk = splitk;
+        a.xf = X; a.xf_row_elems = x_row_stride;
+        return cdna4_launch_gemm_q(a, (hipStream_t)stream);
+    }
     int rc = ggml_cdna4_prepare_act(type, X, x_row_stride, K, B, workspace, workspace_bytes, path, stream);
     if (rc) return rc;
     return ggml_cdna4_mul_mat_prepared(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, stream);

@@ -452,7 +452,11 @@ struct gemm_params {
     int xchg_l2;                                        // split-K exchange through the XCD's L2 (partners co-located) instead of write-through
     int tune;                                           // experiment bits from CDNA4_TUNE (bit0: static s_setprio 1 for the khalf-1 waves)
     float *partial; unsigned *flags; unsigned epoch;   // split-K = 2 exchange (k_gemm_kq_w8): exported half tiles [tile][ks][64][128], one flag per (tile, ks), this launch's tag
-    unsigned long long *trace;   // profiling builds only (k_gemm_kq_w8<TYPE, true>): per-phase s_memtime stamps of block 0
+    unsigned long long *trace;   // profiling builds only (k_gemm_kq_w8<TYPE, true>): per-phase s_memtime stamps of block 0    // k_gemm_kq_w12 with the activation quantizer inside the launch (EXP bit 10; appended last so that no other kernel's
+    // argument offsets move): fp32 activations X[b * xf_row + k]; work-groups blockIdx < nq quantize B * K / 16 chunks into xh,
+    // add 1 to *qcount each, and every work-group waits for *qcount == nq before its first load of xh; work-group 0 zeroes
+    // *qzero (the counter slot a launch 32 tags from now will use)
+    const float *xf; int64_t xf_row; unsigned *qcount; unsigned *qzero; int nq;
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

@@ -23,6 +23,7 @@
 //    k_repack_*      16-byte-aligned re-layout of Q4_0 / Q8_0 / Q6_K into scratch (shallow-K fallback of the staged path)
 #include "gemm_q_common.h"
 #include "gemm_q_hw.h"
+#include "quantize_dev.h"
 
 // repack kernels: one thread per 16-byte OUTPUT piece (coalesced stores; the 2-byte-aligned source bytes of a superblock
 // are read by the 9 / 17 / 14 adjacent threads that build it)
@@ -695,6 +696,21 @@ static int cu_count() {
     return n;
 }
 
+// counter slots of the in-launch activation quantizer (k_gemm_kq_w12, EXP bit 10): 64 words per device, zeroed once; launch
+// `tag` counts in slot tag % 64 and zeroes slot (tag + 32) % 64, whose last user finished 32 stream-ordered launches ago
+static unsigned *g_qslots[16] = {nullptr}; static unsigned g_qtag[16] = {0};
+static unsigned *get_qslots(int &dev) {
+    dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
+    if (!g_qslots[dev]) {
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, 64 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(ptr, 0, 64 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); return nullptr; }
+        g_qslots[dev] = (unsigned *)ptr;
+    }
+    return g_qslots[dev];
+}
+
 void *cdna4_gemm_scratch(size_t bytes, int kind) { return get_scratch(bytes, kind); }
 unsigned cdna4_gemm_next_epoch() { if (++g_handoff_epoch == 0) ++g_handoff_epoch; return g_handoff_epoch; }
 int cdna4_gemm_cu_count() { return cu_count(); }
@@ -746,7 +762,24 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
         if ((opt == 64 || opt == 65) && min_nsb < 3) opt = 20;
     }
+    if (a.xf && !(opt == 65 && exp == 1024 && TYPE == CDNA4_Q4_K))
+        return cdna4_set_error_msg("gemm_q: the in-launch activation quantizer exists for k_gemm_kq_w12<Q4_K> only (>= 3 superblocks of K per work-group)");
     if (opt == 65) {                                                      // + loader waves
+        if constexpr (TYPE == CDNA4_Q4_K) {
+            if (exp == 1024) {                                            // the activation quantizer runs inside the launch
+                if (!a.xf) return cdna4_set_error_msg("gemm_q: variant bit 1024 << 16 needs the fp32 activations");
+                if ((((uintptr_t)a.xf | (uintptr_t)(a.xf_row_elems * 4)) & 15) || (int64_t)a.B * a.K * 2 >= (int64_t)1 << 31)
+                    return cdna4_set_error_msg("gemm_q: in-launch quantizer needs 16-byte aligned activation rows and an image below 2 GiB");
+                int dev = 0;
+                unsigned *slots = get_qslots(dev);
+                if (!slots) return cdna4_set_error_msg("gemm_q: cannot allocate the quantizer's counter slots");
+                const unsigned tag = g_qtag[dev]++;
+                p.xf = a.xf; p.xf_row = a.xf_row_elems; p.qcount = slots + (tag & 63); p.qzero = slots + ((tag + 32) & 63);
+                p.nq = (int)grid.x < cu_count() ? (int)grid.x : cu_count();
+                hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 1024>), grid, dim3(768), 0, st, p);
+                CDNA4_CHECK_LAUNCH(); return 0;
+            }
+        }
         static const bool no_tab = getenv("CDNA4_NO_TAB") != nullptr;       // A/B knob: compute waves unpack the scales themselves
         // experiment bits of k_gemm_kq_w12 (variant bits 16+ or CDNA4_W12_EXP), built in -DCDNA4_ABLATIONS libraries
         // (tools/microbench) only: 1 = early table read (bit-identical, measured: no gain), 16.. = timing-only ablations
@@ -827,6 +860,8 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? (16 | (TYPE == CDNA4_Q4_K ? 4096 : 2048)) : 0);   // cross-stage pipeline; Q4_K: + loader waves (k_gemm_kq_w12: 168 VGPRs without spills only for this format)
     const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
     const bool wide = (variant & 2) != 0;
+    if (a.xf && !(TYPE == CDNA4_Q4_K && a.variant > 0 && wlds && (variant & 16) && (variant & 4096) && !(variant & (1024 | 8192)) && (variant >> 16) == 1024))
+        return cdna4_set_error_msg("gemm_q: fp32 activations (no prepared image) are accepted by the explicit variant 4119 | 1024 << 16 of Q4_K only");
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
     const int kunits = QT<TYPE>::KQ ? a.K / 256 : a.K / 64;
     int splitk = a.splitk;

@@ -43,3 +43,30 @@ __device__ __forceinline__ void q8_0_block(const float (&e)[4], int (&q)[4], flo
 __device__ __forceinline__ uint32_t pack4i8(const int (&q)[4]) {
     return (uint32_t)(q[0] & 0xFF) | ((uint32_t)(q[1] & 0xFF) << 8) | ((uint32_t)(q[2] & 0xFF) << 16) | ((uint32_t)(q[3] & 0xFF) << 24);
 }
+
+// One lane's 16-value chunk of a Q8_K superblock -> its 32 bytes of the GEMM's fp16 activation image (pair-interleaved: within
+// every 4 consecutive k the order is k0,k2,k1,k3).  The 16 lanes of a superblock must be adjacent lanes of one wave and all
+// execute this; c15 = the chunk's index within its superblock.  Exactly the arithmetic of k_quantize_q8_K (quantize_act.hip),
+// used by the GEMM variant that quantizes its own activations (k_gemm_kq_w12, EXP bit 10).
+__device__ __forceinline__ void q8_K_chunk16_image(const float (&e)[16], int c15, u32x4 &lo, u32x4 &hi) {
+    float amax = 0.f, mx = 0.f; int idx = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { const float ax = fabsf(e[i]); if (ax > amax) { amax = ax; mx = e[i]; idx = c15 * 16 + i; } }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const float oa = __shfl_xor(amax, o, 64), om = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
+    }
+    half_t hv[16];
+    if (amax != 0.f) {
+        const float iscale = -127.f / mx, d = 1.0f / iscale;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const int v = (int)__builtin_rintf(iscale * e[i]); hv[i] = (half_t)(d * (float)(v < 127 ? v : 127)); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) hv[i] = (half_t)0.f;
+    }
+    auto pk = [](half_t a, half_t b) __attribute__((always_inline)) { const half2_t t = {a, b}; return __builtin_bit_cast(uint32_t, t); };
+    lo.x = pk(hv[0], hv[2]); lo.y = pk(hv[1], hv[3]); lo.z = pk(hv[4], hv[6]); lo.w = pk(hv[5], hv[7]);
+    hi.x = pk(hv[8], hv[10]); hi.y = pk(hv[9], hv[11]); hi.z = pk(hv[12], hv[14]); hi.w = pk(hv[13], hv[15]);
+}

@@ -54,5 +54,10 @@ PY
 # (4) the opt-in tests of code written without a GPU: GGUF upload, the 4 + 4-wave kernel
 CDNA4_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gguf.py -q -m gpu -k upload > gpurun_out/experimental_tests.txt 2>&1
 CDNA4_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "4plus4 or loader_wave_kernel_q5_k" >> gpurun_out/experimental_tests.txt 2>&1
+# (5) the one-launch step: k_gemm_kq_w12<Q4_K> with the activation quantizer inside the launch (variant 4119 | 1024 << 16; verified on
+#     the CPU emulator) — bit-identity with the default path incl. workspace reuse and > 64 launches, then the step time beside the default
+CDNA4_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "in_launch" >> gpurun_out/experimental_tests.txt 2>&1
+timeout 200 python bench.py --fuseq-leg --steps 200 > gpurun_out/fuseq_leg.txt 2>&1
 tail -5 gpurun_out/experimental_tests.txt
+cat gpurun_out/fuseq_leg.txt | tail -2
 tail -2 gpurun_out/mfma_valu.txt; cat gpurun_out/launch_floor.txt; cut -c1-200 gpurun_out/w12_candidates.txt; cat gpurun_out/w12_clock.txt; cut -c1-200 gpurun_out/x4l.txt; cat gpurun_out/fault_8192.txt | cut -c1-200; cat gpurun_out/parity_8192.txt | tail -3

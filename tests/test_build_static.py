@@ -131,6 +131,30 @@ def test_shipped_12_wave_kernel_source_and_its_candidates_on_the_cpu(m, k, b, sp
         assert np.array_equal(y, y0)
 
 
+@pytest.mark.parametrize("m,k,b,splitk,nq,dist", [(256, 1024, 256, 1, None, "uniform"), (300, 1536, 200, 1, None, "uniform"), (256, 2048, 128, 2, 3, "uniform"),
+                                                  (256, 1024, 256, 1, 1, "ties")])
+def test_gemm_with_in_launch_activation_quantizer_on_the_cpu(m, k, b, splitk, nq, dist):
+    """k_gemm_kq_w12<Q4_K, true, 1024> (EXP bit 10: the first nq work-groups quantize the fp32 activations, a one-way grid barrier
+    on a device-coherent counter, then the shipped main loop) on the CPU emulator, work-groups as processes sharing the global
+    buffers: the fp16 image it writes equals fp16(d q) of the oracle's Q8_K rows and its output equals the shipped kernel's on
+    that image, BIT FOR BIT; the counter slot ends at nq and the slot it must recycle is zero.  The image buffer starts as
+    NaNs.  (Cache coherence between XCDs is the part only the GPU can show: opt-in test in test_gpu_parity.py.)"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools", "emul"))
+    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run_fuseq(m, k, b, splitk=splitk, nq=nq, dist=dist)
+
+
+def test_in_launch_quantizer_kernel_does_not_spill(gemm_asm):
+    k = "_Z13k_gemm_kq_w12ILi12ELb1ELi1024EEv11gemm_params"
+    assert _prop(gemm_asm, k, "private_seg_size") == 0 and _prop(gemm_asm, k, "num_vgpr") <= 168
+
+
 @pytest.mark.parametrize("kernel,m,k,b,splitk,exp", [("x4l", 300, 1536, 200, 1, 0), ("x4l", 256, 2048, 128, 4, 0), ("x4l", 300, 1536, 200, 2, 1), ("x4l", 300, 1536, 200, 2, 2), ("w12", 300, 1536, 200, 1, 0), ("w12", 256, 2048, 128, 2, 0)])
 def test_counted_vmcnt_waits_are_sufficient_and_tight(kernel, m, k, b, splitk, exp, monkeypatch):
     """EMU_DEFER_DMA=1: every LDS-DMA copy lands as LATE as the hardware permits — only when an s_waitcnt vmcnt(n) of the issuing

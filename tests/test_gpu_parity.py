@@ -266,6 +266,40 @@ def test_gemm_loader_wave_kernel_q5_k(gu, m, k, b, splitk):
     assert np.isfinite(y).all() and e < 2e-6
 
 
+FUSEQ = 4119 | (1024 << 16)         # k_gemm_kq_w12<Q4_K> with the activation quantizer inside the launch (explicit only)
+
+
+@pytest.mark.skipif(os.environ.get("CDNA4_TEST_EXPERIMENTAL") != "1", reason="experimental kernel, opt-in: CDNA4_TEST_EXPERIMENTAL=1")
+@pytest.mark.parametrize("m,k,b,splitk", [(256, 1024, 256, 1), (300, 1536, 200, 1), (513, 3072, 129, 2), (4096, 4096, 512, 0), (8192, 4096, 512, 0), (4096, 2048, 4096, 1)])
+def test_gemm_with_in_launch_activation_quantizer(gu, m, k, b, splitk):
+    """variant 4119 | 1024 << 16 (verified on the CPU emulator; not selected by default): ONE launch quantizes the activations
+    and multiplies — the result must be the default two-launch path's BIT FOR BIT, also when the same workspace is reused
+    with other activations (a stale cache line of the earlier image would show) and over more launches than counter slots"""
+    from ggml_amd import ops
+    t = R.Q4_K
+    w = R.random_weights(t, m, k, seed=m + k + b)
+    a = gu.qtensor(t, w, m, k)
+    for it in range(3 if m >= 4096 else 70):
+        x = _x(m * 2 + b + it, b, k)
+        xd = gu.to_dev(x)
+        y = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=FUSEQ, splitk=splitk).cpu().numpy()
+        yd = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=4119, splitk=splitk).cpu().numpy()
+        assert np.isfinite(y).all() and np.array_equal(y, yd), it
+    gu.report(test="gemm_fuseq", m=m, k=k, b=b, splitk=splitk, bit_identical=True)
+
+
+@pytest.mark.skipif(os.environ.get("CDNA4_TEST_EXPERIMENTAL") != "1", reason="experimental kernel, opt-in: CDNA4_TEST_EXPERIMENTAL=1")
+def test_in_launch_quantizer_fails_loudly_where_it_does_not_exist(gu):
+    """no silent fallback: other formats, shallow K and the prepared-activation entry point refuse the variant"""
+    from ggml_amd import ops
+    w = R.random_weights(R.Q5_K, 256, 1024, seed=1)
+    with pytest.raises(Exception):
+        ops.mul_mat(gu.qtensor(R.Q5_K, w, 256, 1024), gu.to_dev(_x(1, 128, 1024)), path=ops.PATH_GEMM, gemm_variant=FUSEQ)
+    w = R.random_weights(R.Q4_K, 256, 512, seed=1)
+    with pytest.raises(Exception):
+        ops.mul_mat(gu.qtensor(R.Q4_K, w, 256, 512), gu.to_dev(_x(1, 128, 512)), path=ops.PATH_GEMM, gemm_variant=FUSEQ)
+
+
 def test_gemm_auto_picks_256x128_kernel_on_huge_grids(gu):
     """>= 2 x #CUs tiles of 256x128 (the C5-like regime): the auto path is the 256x128-tile kernel without a K split —
     bit-identical to asking for it explicitly, and within tolerance of the oracle on a row sample"""

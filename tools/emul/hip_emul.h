@@ -60,6 +60,7 @@ static inline void emu_sleep() { static thread_local unsigned n = 0; usleep(200)
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
 #define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, order)
 // cross-lane helpers the shared headers declare but the emulated kernels never call
 // __shfl_xor: wave-collective through a per-wave exchange buffer — ALL 64 lanes of the wave must execute it (the emulated
 // kernels only shuffle in wave-uniform control flow for the shapes the tests use)

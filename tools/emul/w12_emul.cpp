@@ -1,7 +1,9 @@
 // w12_emul.cpp — runs the SOURCE of k_gemm_kq_w12<Q4_K, true, EXP> (ggml_amd/csrc/gemm_kq_w12.inc + gemm_w8_epilogue.inc: the
 // shipped 12-wave kernel and its bit-identical experiment variants) on the CPU like x4l_emul.cpp does for the experimental
 // kernel.  Test infrastructure.
-//   w12_emul M K B w.bin xh.bin y.bin splitk exp xchg_l2
+//   w12_emul M K B w.bin xh.bin y.bin splitk exp xchg_l2 [wtype x.bin nq xh_out.bin]
+// exp 1024 (the activation quantizer inside the launch): xh.bin is only the initial (garbage) content of the image, x.bin holds the
+// fp32 activations [B][K], nq = number of quantizing work-groups, and the image the kernel wrote is saved to xh_out.bin
 #include "hip_emul.h"
 #include <signal.h>
 #include <sys/mman.h>
@@ -42,6 +44,7 @@ static void *shared_alloc(size_t n) {
 
 #include "../../ggml_amd/csrc/gemm_q_common.h"
 #include "../../ggml_amd/csrc/gemm_q_hw.h"
+#include "../../ggml_amd/csrc/quantize_dev.h"
 void *cdna4_debug_trace = nullptr;
 #include "../../ggml_amd/csrc/gemm_kq_w12.inc"
 
@@ -112,6 +115,19 @@ int main(int argc, char **argv) {
         case 100: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, false, 0>(p); }, nblk, 768); break;      // compute waves unpack the scales themselves
         case 32: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 32>(p); }, nblk, 768); break;        // timing ablations (results are garbage): bounds checks only
         case 480: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 480>(p); }, nblk, 768); break;
+        case 1024: {
+            if (argc < 14) { fprintf(stderr, "exp 1024 needs: wtype x.bin nq xh_out.bin\n"); return 2; }
+            std::vector<uint8_t> x0 = slurp(argv[11]);
+            float *xf = (float *)shared_alloc(x0.size()); memcpy(xf, x0.data(), x0.size());
+            unsigned *slots = (unsigned *)shared_alloc(64 * 4); memset(slots, 0, 64 * 4);
+            slots[37] = 123;                                        // the slot this launch must zero for a later one
+            p.xf = xf; p.xf_row = K; p.qcount = slots + 5; p.qzero = slots + 37; p.nq = atoi(argv[12]);
+            if (p.nq < 1 || p.nq > (int)nblk) { fprintf(stderr, "nq out of range\n"); return 2; }
+            emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 1024>(p); }, nblk, 768);
+            if (slots[5] != (unsigned)p.nq || slots[37] != 0) { fprintf(stderr, "counter slots: %u (want %d), %u (want 0)\n", slots[5], p.nq, slots[37]); return 4; }
+            FILE *fo = fopen(argv[13], "wb"); fwrite(xh, 1, xh0.size(), fo); fclose(fo);
+            break;
+        }
         default: fprintf(stderr, "exp not built into the emulator\n"); return 2;
     }
     FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)B * M, f); fclose(f);
