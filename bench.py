@@ -190,6 +190,28 @@ def decode_graph_leg():
     print(json.dumps({"us_per_step_hipgraph": round(us, 3), "nodes_per_graph": ncopy, "same_result_as_stream_launches": same}), flush=True)
 
 
+def diagnostics():
+    """Stand-alone probes of tools/microbench (built by __graft_entry__.build(); each a child process with its own timeout, run
+    after everything that is reported above): what the DESIGN.md §7 list asks of the next GPU call, recorded with the bench line
+    so that a round whose GPU budget is spent still gets them from the round-end run.  Raw text, trimmed."""
+    mb = os.path.join(ROOT, "tools", "microbench")
+    legs = (("launch_floor", ["./launch_floor"], {}, 60),                       # empty-kernel launch cost; pure-load floor of the 9.4 MB decode matrix
+            ("mfma_valu", ["./mfma_valu", "500"], {}, 90),                      # matrix-pipe price of the unpack mix, the clock held, sustained MFMA-only rate
+            # bit-identical candidates of the shipped GEMM (ablation build): early table read / balanced epilogue / stores from registers / both
+            ("w12_candidates", ["./gemm_bench_abl", "4096", "4096", "512", ""], {"GB_VARIANTS": "4119,69655,135191,266263,397335", "GB_SPLITKS": "0"}, 60))
+    res = {}
+    for name, cmd, env, tmo in legs:
+        if not os.path.exists(os.path.join(mb, cmd[0])):
+            res[name] = "not built"
+            continue
+        try:
+            r = subprocess.run(cmd, cwd=mb, capture_output=True, text=True, timeout=tmo, env=dict(os.environ, **env))
+            res[name] = (r.stdout[-2500:] if r.returncode == 0 else "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))
+        except Exception as e:              # noqa: BLE001
+            res[name] = repr(e)[:200]
+    return res
+
+
 FUSEQ_VARIANT = 4119 | (1024 << 16)     # k_gemm_kq_w12<Q4_K> with the Q8_K activation quantizer inside the launch (explicit, experimental)
 
 
@@ -249,6 +271,7 @@ def main():
     ap.add_argument("--splitk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-graph", action="store_true", help="internal: run only the HIP-graph decode leg and print its JSON")
+    ap.add_argument("--no-diagnostics", action="store_true", help="skip the stand-alone probes of tools/microbench at the end of the run")
     ap.add_argument("--fuseq-leg", action="store_true", help="internal: run only the one-launch (in-kernel activation quantizer) leg and print its JSON")
     args = ap.parse_args()
     if args.decode_graph:
@@ -323,6 +346,27 @@ def main():
     e1.record(); e1.synchronize()
     gemm_us = e0.elapsed_time(e1) * 1e3 / args.steps
     gemm_tflops = 2.0 * M_PER_GPU * K * B / (gemm_us * 1e-6) / 1e12
+    # the same launches on all-zero operands (zero weight bytes, zero activation image): identical instruction stream and memory
+    # traffic, almost no toggling in the matrix pipe — the gap to the random-data time is what the chip's power management takes
+    # (the working hypothesis for the loop's ceiling).  Not a result: a diagnostic beside the roofline fraction.
+    zero_us = None
+    if rank == 0:
+        try:
+            wz = torch.zeros_like(a.data)
+            wsz = torch.zeros_like(ws)
+            def gemm_zero():
+                native.check(L.ggml_cdna4_mul_mat_prepared(Q4_K, wz.data_ptr(), a.row_bytes, y.data_ptr(), M_PER_GPU, M_PER_GPU, K, B,
+                                                           wsz.data_ptr(), wsz.numel(), ops.PATH_GEMM, base_variant, args.splitk, stream))
+            for _ in range(50):
+                gemm_zero()
+            e0.record()
+            for _ in range(args.steps):
+                gemm_zero()
+            e1.record(); e1.synchronize()
+            zero_us = round(e0.elapsed_time(e1) * 1e3 / args.steps, 3)
+            del wz, wsz
+        except Exception:               # noqa: BLE001 — optional diagnostic
+            zero_us = None
 
     out = None
     if rank == 0:
@@ -338,7 +382,8 @@ def main():
                          "frac": round(gemm_tflops / MFMA_F16_PEAK_TFLOPS, 4),
                          "traffic": pmc_traffic("k_gemm_kq_w12<12") if args.variant in (0, 23, 2071, 4119) else None,
                          "traffic_note": "HBM-side bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) from the rocprofv3 PMC passes of this command, profiles/rNN/pmc_summary.txt",
-                         "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": 2.0 * M_PER_GPU * K * B},
+                         "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": 2.0 * M_PER_GPU * K * B,
+                         "us_per_launch_all_zero_operands": zero_us},
         }
 
     # ---- batch-1 decode GEMV of the same matrix (HBM roofline), rank 0 only ------------------------------------
@@ -469,6 +514,8 @@ def main():
                 out["one_launch_step_experimental"] = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:], "returncode": r.returncode}
             except Exception as e:          # noqa: BLE001
                 out["one_launch_step_experimental"] = {"error": repr(e)[:300]}
+            if not args.no_diagnostics:
+                out["diagnostics"] = diagnostics()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

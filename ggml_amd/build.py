@@ -104,10 +104,26 @@ def build_oracle(verbose=False):
         raise RuntimeError("oracle build failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
 
 
+def build_microbench(verbose=False):
+    """measurement tools (tools/microbench: stand-alone probes + the -DCDNA4_ABLATIONS twin of the kernel library that
+    gemm_bench_abl links).  bench.py's optional `diagnostics` legs run them when they exist; they are not part of the
+    product, so a failure here is reported and ignored."""
+    try:
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "tools", "microbench"), "all", "abl"], capture_output=True, text=True, timeout=1500)
+        if r.returncode != 0 and verbose:
+            print("[build] tools/microbench failed (ignored):\n" + r.stderr[-1500:])
+        return r.returncode == 0
+    except Exception as e:  # noqa: BLE001
+        if verbose:
+            print("[build] tools/microbench skipped:", repr(e)[:200])
+        return False
+
+
 def build_all(force=False, verbose=False):
     k = build_kernels(force, verbose)
     b = build_backend(force, verbose)
     build_oracle(verbose)
+    build_microbench(verbose)
     return k, b
 
 
