@@ -212,6 +212,7 @@ def diagnostics():
     return res
 
 
+FUSEQ_PFW_VARIANT = 4119 | (3072 << 16) # + weight pre-touch under the quantizer
 FUSEQ_VARIANT = 4119 | (1024 << 16)     # k_gemm_kq_w12<Q4_K> with the Q8_K activation quantizer inside the launch (explicit, experimental)
 
 
@@ -233,21 +234,23 @@ def fuseq_leg(steps):
     def run(x, variant):
         native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), a.row_bytes, x.data_ptr(), K, y.data_ptr(), M_PER_GPU,
                                           M_PER_GPU, K, B, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, variant, 0, stream))
-    same, finite = True, True
+    fused = (FUSEQ_VARIANT, FUSEQ_PFW_VARIANT)
+    same, finite = {v: True for v in fused}, {v: True for v in fused}
     rng = np.random.default_rng(99)
     for it in range(6):                               # fresh activations every time through the SAME workspace: a stale line would show
         x = torch.from_numpy(rng.uniform(-1, 1, (B, K)).astype(np.float32)).to(dev)
         run(x, 4119); torch.cuda.synchronize(dev); y0 = y.clone()
-        y.fill_(7.0)
-        run(x, FUSEQ_VARIANT); torch.cuda.synchronize(dev)
-        finite = finite and bool(torch.isfinite(y).all())
-        same = same and bool(torch.equal(y, y0))
+        for v in fused:
+            y.fill_(7.0)
+            run(x, v); torch.cuda.synchronize(dev)
+            finite[v] = finite[v] and bool(torch.isfinite(y).all())
+            same[v] = same[v] and bool(torch.equal(y, y0))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    best = {4119: 1e30, FUSEQ_VARIANT: 1e30}
+    best = {4119: 1e30, FUSEQ_VARIANT: 1e30, FUSEQ_PFW_VARIANT: 1e30}
     for _ in range(100):
         run(x, 4119)
-    for _ in range(4):                                # alternating blocks: neither variant owns the warm end of the run
-        for v in (4119, FUSEQ_VARIANT):
+    for _ in range(4):                                # alternating blocks: no variant owns the warm end of the run
+        for v in (4119,) + fused:
             for _ in range(10):
                 run(x, v)
             e0.record()
@@ -257,9 +260,12 @@ def fuseq_leg(steps):
             best[v] = min(best[v], e0.elapsed_time(e1) * 1e3 / steps)
     fl = 2.0 * M_PER_GPU * K * B
     print(json.dumps({"what": "step = fp32 X -> Y of Q4_K [4096x4096]·[4096x512]; two launches (k_quantize_q8_K + k_gemm_kq_w12) vs ONE (k_gemm_kq_w12<Q4_K,true,1024>: in-launch quantizer + grid barrier)",
-                      "bit_identical_to_default": same, "finite": finite,
+                      "bit_identical_to_default": same[FUSEQ_VARIANT], "finite": finite[FUSEQ_VARIANT],
                       "us_per_step_two_launches": round(best[4119], 3), "us_per_step_one_launch": round(best[FUSEQ_VARIANT], 3),
-                      "tflops_two_launches": round(fl / best[4119] / 1e6, 2), "tflops_one_launch": round(fl / best[FUSEQ_VARIANT] / 1e6, 2)}), flush=True)
+                      "tflops_two_launches": round(fl / best[4119] / 1e6, 2), "tflops_one_launch": round(fl / best[FUSEQ_VARIANT] / 1e6, 2),
+                      "with_weight_pretouch": {"what": "EXP bit 11: the loader lanes touch the prologue's weight bytes while the activations are quantized",
+                                               "bit_identical_to_default": same[FUSEQ_PFW_VARIANT], "finite": finite[FUSEQ_PFW_VARIANT],
+                                               "us_per_step_one_launch": round(best[FUSEQ_PFW_VARIANT], 3), "tflops_one_launch": round(fl / best[FUSEQ_PFW_VARIANT] / 1e6, 2)}}), flush=True)
 
 
 def main():

@@ -762,11 +762,11 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
         if ((opt == 64 || opt == 65) && min_nsb < 3) opt = 20;
     }
-    if (a.xf && !(opt == 65 && exp == 1024 && TYPE == CDNA4_Q4_K))
+    if (a.xf && !(opt == 65 && (exp == 1024 || exp == 3072) && TYPE == CDNA4_Q4_K))
         return cdna4_set_error_msg("gemm_q: the in-launch activation quantizer exists for k_gemm_kq_w12<Q4_K> only (>= 3 superblocks of K per work-group)");
     if (opt == 65) {                                                      // + loader waves
         if constexpr (TYPE == CDNA4_Q4_K) {
-            if (exp == 1024) {                                            // the activation quantizer runs inside the launch
+            if (exp == 1024 || exp == 3072) {                             // the activation quantizer runs inside the launch (3072: + weight pre-touch)
                 if (!a.xf) return cdna4_set_error_msg("gemm_q: variant bit 1024 << 16 needs the fp32 activations");
                 if ((((uintptr_t)a.xf | (uintptr_t)(a.xf_row_elems * 4)) & 15) || (int64_t)a.B * a.K * 2 >= (int64_t)1 << 31)
                     return cdna4_set_error_msg("gemm_q: in-launch quantizer needs 16-byte aligned activation rows and an image below 2 GiB");
@@ -776,7 +776,8 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
                 const unsigned tag = g_qtag[dev]++;
                 p.xf = a.xf; p.xf_row = a.xf_row_elems; p.qcount = slots + (tag & 63); p.qzero = slots + ((tag + 32) & 63);
                 p.nq = (int)grid.x < cu_count() ? (int)grid.x : cu_count();
-                hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 1024>), grid, dim3(768), 0, st, p);
+                if (exp == 3072) hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 3072>), grid, dim3(768), 0, st, p);
+                else hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 1024>), grid, dim3(768), 0, st, p);
                 CDNA4_CHECK_LAUNCH(); return 0;
             }
         }
@@ -860,7 +861,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? (16 | (TYPE == CDNA4_Q4_K ? 4096 : 2048)) : 0);   // cross-stage pipeline; Q4_K: + loader waves (k_gemm_kq_w12: 168 VGPRs without spills only for this format)
     const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
     const bool wide = (variant & 2) != 0;
-    if (a.xf && !(TYPE == CDNA4_Q4_K && a.variant > 0 && wlds && (variant & 16) && (variant & 4096) && !(variant & (1024 | 8192)) && (variant >> 16) == 1024))
+    if (a.xf && !(TYPE == CDNA4_Q4_K && a.variant > 0 && wlds && (variant & 16) && (variant & 4096) && !(variant & (1024 | 8192)) && ((variant >> 16) == 1024 || (variant >> 16) == 3072)))
         return cdna4_set_error_msg("gemm_q: fp32 activations (no prepared image) are accepted by the explicit variant 4119 | 1024 << 16 of Q4_K only");
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
     const int kunits = QT<TYPE>::KQ ? a.K / 256 : a.K / 64;

@@ -270,8 +270,9 @@ FUSEQ = 4119 | (1024 << 16)         # k_gemm_kq_w12<Q4_K> with the activation qu
 
 
 @pytest.mark.skipif(os.environ.get("CDNA4_TEST_EXPERIMENTAL") != "1", reason="experimental kernel, opt-in: CDNA4_TEST_EXPERIMENTAL=1")
+@pytest.mark.parametrize("fvariant", [4119 | (1024 << 16), 4119 | (3072 << 16)])        # 3072: + weight pre-touch under the quantizer
 @pytest.mark.parametrize("m,k,b,splitk", [(256, 1024, 256, 1), (300, 1536, 200, 1), (513, 3072, 129, 2), (4096, 4096, 512, 0), (8192, 4096, 512, 0), (4096, 2048, 4096, 1)])
-def test_gemm_with_in_launch_activation_quantizer(gu, m, k, b, splitk):
+def test_gemm_with_in_launch_activation_quantizer(gu, m, k, b, splitk, fvariant):
     """variant 4119 | 1024 << 16 (verified on the CPU emulator; not selected by default): ONE launch quantizes the activations
     and multiplies — the result must be the default two-launch path's BIT FOR BIT, also when the same workspace is reused
     with other activations (a stale cache line of the earlier image would show) and over more launches than counter slots"""
@@ -282,10 +283,10 @@ def test_gemm_with_in_launch_activation_quantizer(gu, m, k, b, splitk):
     for it in range(3 if m >= 4096 else 70):
         x = _x(m * 2 + b + it, b, k)
         xd = gu.to_dev(x)
-        y = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=FUSEQ, splitk=splitk).cpu().numpy()
+        y = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=fvariant, splitk=splitk).cpu().numpy()
         yd = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=4119, splitk=splitk).cpu().numpy()
         assert np.isfinite(y).all() and np.array_equal(y, yd), it
-    gu.report(test="gemm_fuseq", m=m, k=k, b=b, splitk=splitk, bit_identical=True)
+    gu.report(test="gemm_fuseq", variant=fvariant, m=m, k=k, b=b, splitk=splitk, bit_identical=True)
 
 
 @pytest.mark.skipif(os.environ.get("CDNA4_TEST_EXPERIMENTAL") != "1", reason="experimental kernel, opt-in: CDNA4_TEST_EXPERIMENTAL=1")

@@ -74,7 +74,7 @@ def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, 
 
 
 
-def run_fuseq(M, K, B, splitk=1, nq=None, seed=3, timeout=900, dist="uniform"):
+def run_fuseq(M, K, B, splitk=1, nq=None, seed=3, timeout=900, dist="uniform", exp=1024):
     """k_gemm_kq_w12<Q4_K, true, 1024> — the variant that quantizes its own activations — against the shipped kernel fed with the
     image the stand-alone quantizer produces (fp16(d * q) of the oracle's Q8_K rows): the image the kernel wrote and its output
     must both match BIT FOR BIT.  The image buffer starts as NaNs, so a read before the grid barrier shows."""
@@ -97,7 +97,7 @@ def run_fuseq(M, K, B, splitk=1, nq=None, seed=3, timeout=900, dist="uniform"):
         w.tofile(f("w.bin")); img.tofile(f("xh.bin")); x.tofile(f("x.bin"))
         np.full(img.shape, np.nan, np.float16).tofile(f("xh_nan.bin"))
         for name, args in (("shipped", [f("xh.bin"), f("y0.bin"), str(splitk), "0", "1"]),
-                           ("fused", [f("xh_nan.bin"), f("y1.bin"), str(splitk), "1024", "1", str(R.Q4_K), f("x.bin"), str(nq), f("xh_out.bin")])):
+                           ("fused", [f("xh_nan.bin"), f("y1.bin"), str(splitk), str(exp), "1", str(R.Q4_K), f("x.bin"), str(nq), f("xh_out.bin")])):
             r = subprocess.run([build("w12"), str(M), str(K), str(B), f("w.bin")] + args, capture_output=True, text=True, timeout=timeout,
                                env=dict(os.environ, EMU_DEFER_DMA="0"))
             if r.returncode == 77:
