@@ -126,6 +126,22 @@ int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float
         a.xf = X; a.xf_row_elems = x_row_stride;
         return cdna4_launch_gemm_q(a, (hipStream_t)stream);
     }
+    {   // CDNA4_FUSEQ=1|2 (experiment knob, default off): offer the fp32 activations to the auto route first — if that route is the
+        // loader-wave Q4_K kernel it quantizes them in-launch (2: + weight pre-touch); otherwise (status 1) the two launches below
+        static const int fuseq_env = getenv("CDNA4_FUSEQ") ? atoi(getenv("CDNA4_FUSEQ")) : 0;
+        if (fuseq_env > 0 && path == GGML_CDNA4_PATH_GEMM && type == CDNA4_Q4_K && gemm_variant <= 0 && B > 64 && workspace && !((uintptr_t)workspace & 255) &&
+            !(((uintptr_t)X | (uintptr_t)(x_row_stride * 4)) & 15) && B * K * 2 < ((int64_t)1 << 31)) {
+            const ws_view v = carve(type, K, B, workspace);
+            if (workspace_bytes >= v.total) {
+                cdna4_gemm_args a{};
+                a.type = type; a.W = (const uint8_t *)W; a.w_row_bytes = w_row_bytes; a.xh = v.xh; a.xh_row_elems = K;
+                a.Y = Y; a.y_row_elems = y_row_stride; a.M = (int)M; a.K = (int)K; a.B = (int)B; a.variant = 0; a.splitk = splitk;
+                a.xf = X; a.xf_row_elems = x_row_stride;
+                const int rc1 = cdna4_launch_gemm_q(a, (hipStream_t)stream);
+                if (rc1 != 1) return rc1;
+            }
+        }
+    }
     int rc = ggml_cdna4_prepare_act(type, X, x_row_stride, K, B, workspace, workspace_bytes, path, stream);
     if (rc) return rc;
     return ggml_cdna4_mul_mat_prepared(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, stream);

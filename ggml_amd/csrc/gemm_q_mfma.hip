@@ -762,8 +762,10 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
         if ((opt == 64 || opt == 65) && min_nsb < 3) opt = 20;
     }
-    if (a.xf && !(opt == 65 && (exp == 1024 || exp == 3072) && TYPE == CDNA4_Q4_K))
+    if (a.xf && !(opt == 65 && (exp == 1024 || exp == 3072) && TYPE == CDNA4_Q4_K)) {
+        if (a.variant <= 0) return 1;                                     // auto: "not fused, nothing launched that matters" — the caller prepares the image and calls again
         return cdna4_set_error_msg("gemm_q: the in-launch activation quantizer exists for k_gemm_kq_w12<Q4_K> only (>= 3 superblocks of K per work-group)");
+    }
     if (opt == 65) {                                                      // + loader waves
         if constexpr (TYPE == CDNA4_Q4_K) {
             if (exp == 1024 || exp == 3072) {                             // the activation quantizer runs inside the launch (3072: + weight pre-touch)
@@ -861,7 +863,11 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? (16 | (TYPE == CDNA4_Q4_K ? 4096 : 2048)) : 0);   // cross-stage pipeline; Q4_K: + loader waves (k_gemm_kq_w12: 168 VGPRs without spills only for this format)
     const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
     const bool wide = (variant & 2) != 0;
-    if (a.xf && !(TYPE == CDNA4_Q4_K && a.variant > 0 && wlds && (variant & 16) && (variant & 4096) && !(variant & (1024 | 8192)) && ((variant >> 16) == 1024 || (variant >> 16) == 3072)))
+    // a.xf with variant 0 (auto; capi.hip offers it when CDNA4_FUSEQ is set): fuse if the auto route is k_gemm_kq_w12<Q4_K>, else return 1
+    static const int fuseq_env = getenv("CDNA4_FUSEQ") ? atoi(getenv("CDNA4_FUSEQ")) : 0;
+    const int auto_exp = (a.xf && a.variant <= 0) ? (fuseq_env == 2 ? 3072 : 1024) : 0;
+    if (a.xf && a.variant <= 0 && !(TYPE == CDNA4_Q4_K && wlds && (variant & 16) && (variant & 4096))) return 1;
+    if (a.xf && a.variant > 0 && !(TYPE == CDNA4_Q4_K && wlds && (variant & 16) && (variant & 4096) && !(variant & (1024 | 8192)) && ((variant >> 16) == 1024 || (variant >> 16) == 3072)))
         return cdna4_set_error_msg("gemm_q: fp32 activations (no prepared image) are accepted by the explicit variant 4119 | 1024 << 16 of Q4_K only");
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
     const int kunits = QT<TYPE>::KQ ? a.K / 256 : a.K / 64;
@@ -885,10 +891,11 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         static const bool no_x2 = getenv("CDNA4_NO_X2") != nullptr;
         if (wlds && a.variant <= 0 && a.splitk <= 0 && a.B > 64 && !no_x2) {
             const int tx = ((a.M + 255) / 256) * ((a.B + 127) / 128);
-            if (tx >= 2 * cu_count()) return launch_x2<TYPE>(a, 1, st);
+            if (tx >= 2 * cu_count()) { if (a.xf) return 1; return launch_x2<TYPE>(a, 1, st); }
         }
     }
     if (splitk < 1 || kunits % splitk) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
+    if constexpr (TYPE != CDNA4_Q4_K) { if (a.xf) return a.variant <= 0 ? 1 : cdna4_set_error_msg("gemm_q: in-launch quantizer: Q4_K only"); }
     if constexpr (TYPE == CDNA4_Q4_0 || TYPE == CDNA4_Q8_0 || TYPE == CDNA4_Q6_K) {
         // 2-byte-aligned formats at prefill batch sizes: re-lay the weights into 16-byte-aligned superblocks (scratch, per
         // call: one extra read+write of W, ~5 us at 4096x4096) and run the LDS-DMA pipeline on that — 2.5-3x faster
@@ -924,7 +931,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         }
     }
     if constexpr (CAN_LDS) {
-        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant & 4096) ? 65 : ((variant & 2048) ? 64 : ((variant >> 5) & 31)), st, variant >> 16);
+        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant & 4096) ? 65 : ((variant & 2048) ? 64 : ((variant >> 5) & 31)), st, auto_exp ? auto_exp : variant >> 16);
         if (wlds && !(variant & 8)) return wide ? launch_pipe<TYPE, 4>(a, splitk, st) : launch_pipe<TYPE, 2>(a, splitk, st);
         if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
     }
