@@ -209,7 +209,37 @@ def diagnostics():
             res[name] = (r.stdout[-2500:] if r.returncode == 0 else "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))
         except Exception as e:              # noqa: BLE001
             res[name] = repr(e)[:200]
+    # last: the default route at the shape of DESIGN 4.3's open issue (own process: a GPU fault there ends only that process)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shape-check", "8192,8192,512"], capture_output=True, text=True, timeout=150)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        res["default_route_8192x8192x512"] = json.loads(line[-1]) if line else {"returncode": r.returncode, "stderr": (r.stderr or "")[-400:]}
+    except Exception as e:                  # noqa: BLE001
+        res["default_route_8192x8192x512"] = repr(e)[:200]
     return res
+
+
+def shape_check_leg(spec):
+    """`bench.py --shape-check M,K,B` (a CHILD process): the default GEMM route at a shape against the first, slice-per-barrier
+    kernel (variant 5) through the C-ABI.  Used for 8192 x 8192 x 512 — the shape at which an ablation harness process once died
+    with a GPU fault (open issue) and which no test of round 1 ran on the default route."""
+    from ggml_amd import native, ops
+    L = native.lib()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    m, k, b = (int(v) for v in spec.split(","))
+    a = ops.QTensor.from_host_bytes(Q4_K, k, m, synth_q4k(m, k, 7), device=dev)
+    x = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (b, k)).astype(np.float32)).to(dev)
+    ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(Q4_K, k, b), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ys = {}
+    for variant in (0, 5):
+        y = torch.empty((b, m), dtype=torch.float32, device=dev)
+        native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), a.row_bytes, x.data_ptr(), k, y.data_ptr(), m, m, k, b, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, variant, 0, st))
+        torch.cuda.synchronize(dev)
+        ys[variant] = y.double()
+    print(json.dumps({"shape": [m, k, b], "finite": bool(torch.isfinite(ys[0]).all()),
+                      "rel_l2_default_vs_variant5": float((ys[0] - ys[5]).norm() / ys[5].norm())}), flush=True)
 
 
 FUSEQ_PFW_VARIANT = 4119 | (3072 << 16) # + weight pre-touch under the quantizer
@@ -277,6 +307,7 @@ def main():
     ap.add_argument("--splitk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-graph", action="store_true", help="internal: run only the HIP-graph decode leg and print its JSON")
+    ap.add_argument("--shape-check", default="", help="internal: M,K,B — default GEMM route against variant 5 at that shape, one JSON object")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the stand-alone probes of tools/microbench at the end of the run")
     ap.add_argument("--fuseq-leg", action="store_true", help="internal: run only the one-launch (in-kernel activation quantizer) leg and print its JSON")
     args = ap.parse_args()
@@ -284,6 +315,8 @@ def main():
         return decode_graph_leg()
     if args.fuseq_leg:
         return fuseq_leg(max(50, min(args.steps, 200)))
+    if args.shape_check:
+        return shape_check_leg(args.shape_check)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
