@@ -209,13 +209,17 @@ def diagnostics():
             res[name] = (r.stdout[-2500:] if r.returncode == 0 else "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))
         except Exception as e:              # noqa: BLE001
             res[name] = repr(e)[:200]
+    # BASELINE configs[2] at its TRUE K = 11008 = 43 superblocks (round 1 measured 10752): today's auto route (no K split for an odd
+    # count: 128 of 256 CUs busy) and the uneven 22 / 21 hand-off split behind CDNA4_ODD_SPLIT=1 (emulator-verified), one process each;
     # last: the default route at the shape of DESIGN 4.3's open issue (own process: a GPU fault there ends only that process)
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shape-check", "8192,8192,512"], capture_output=True, text=True, timeout=150)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        res["default_route_8192x8192x512"] = json.loads(line[-1]) if line else {"returncode": r.returncode, "stderr": (r.stderr or "")[-400:]}
-    except Exception as e:                  # noqa: BLE001
-        res["default_route_8192x8192x512"] = repr(e)[:200]
+    for name, spec, env in (("c3_4096x11008x512", "4096,11008,512", {"CDNA4_ODD_SPLIT": "0"}), ("c3_4096x11008x512_odd_split", "4096,11008,512", {"CDNA4_ODD_SPLIT": "1"}),
+                            ("default_route_8192x8192x512", "8192,8192,512", {})):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shape-check", spec], capture_output=True, text=True, timeout=150, env=dict(os.environ, **env))
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            res[name] = json.loads(line[-1]) if line else {"returncode": r.returncode, "stderr": (r.stderr or "")[-400:]}
+        except Exception as e:              # noqa: BLE001
+            res[name] = repr(e)[:200]
     return res
 
 
@@ -238,8 +242,25 @@ def shape_check_leg(spec):
         native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), a.row_bytes, x.data_ptr(), k, y.data_ptr(), m, m, k, b, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, variant, 0, st))
         torch.cuda.synchronize(dev)
         ys[variant] = y.double()
+    y = torch.empty((b, m), dtype=torch.float32, device=dev)
+    native.check(L.ggml_cdna4_prepare_act(Q4_K, x.data_ptr(), k, k, b, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, st))
+
+    def gemm():
+        native.check(L.ggml_cdna4_mul_mat_prepared(Q4_K, a.data.data_ptr(), a.row_bytes, y.data_ptr(), m, m, k, b, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, 0, 0, st))
+    for _ in range(200):
+        gemm()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e30
+    for _ in range(3):
+        e0.record()
+        for _ in range(50):
+            gemm()
+        e1.record(); e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / 50)
     print(json.dumps({"shape": [m, k, b], "finite": bool(torch.isfinite(ys[0]).all()),
-                      "rel_l2_default_vs_variant5": float((ys[0] - ys[5]).norm() / ys[5].norm())}), flush=True)
+                      "rel_l2_default_vs_variant5": float((ys[0] - ys[5]).norm() / ys[5].norm()),
+                      "gemm_us_per_launch_default_route": round(best, 3), "tflops": round(2.0 * m * k * b / best / 1e6, 1),
+                      "CDNA4_ODD_SPLIT": os.environ.get("CDNA4_ODD_SPLIT", "")}), flush=True)
 
 
 FUSEQ_PFW_VARIANT = 4119 | (3072 << 16) # + weight pre-touch under the quantizer

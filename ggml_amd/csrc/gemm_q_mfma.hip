@@ -872,12 +872,18 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
     const int kunits = QT<TYPE>::KQ ? a.K / 256 : a.K / 64;
     int splitk = a.splitk;
+    bool uneven = false;                            // auto only: hand-off split of an odd superblock count (see below)
     if (splitk <= 0) {
         // auto: at most 2.  Two fp32 contributions added to a zeroed output are order-independent (a+b == b+a), so the
         // result stays deterministic; deeper splits (atomic sums of >2 terms) are opt-in only.
         const int tiles = ((a.M + 127) / 128) * ((a.B + (wide ? 127 : 63)) / (wide ? 128 : 64));
         if (variant & 16) splitk = (tiles * 2 <= cu_count() && kunits % 2 == 0 && kunits >= 4) ? 2 : 1;   // hand-off split: only if co-resident
         else splitk = 1;
+        // CDNA4_ODD_SPLIT=1 (experiment knob, default off until measured on the GPU): an ODD number of superblocks — K = 11008 = 43 x 256,
+        // BASELINE configs[2] — also takes the hand-off split; its two work-groups get sb_split / total - sb_split superblocks
+        // (22 / 21), which the exchange was written for (launch_w8: p.sb_split) and the CPU emulator runs (tests)
+        static const bool odd_split = getenv("CDNA4_ODD_SPLIT") && atoi(getenv("CDNA4_ODD_SPLIT")) != 0;
+        if (odd_split && (variant & 16) && wlds && QT<TYPE>::KQ && tiles * 2 <= cu_count() && (kunits & 1) && kunits >= 7) { splitk = 2; uneven = true; }
     }
     if constexpr (TYPE == CDNA4_Q5_K) {
         if (wlds && a.variant > 0 && (variant & 8192) && (variant & 16384)) return cdna4_launch_gemm_q4k_x4l(a, a.splitk, 1, st);   // experimental, explicit only
@@ -894,7 +900,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
             if (tx >= 2 * cu_count()) { if (a.xf) return 1; return launch_x2<TYPE>(a, 1, st); }
         }
     }
-    if (splitk < 1 || kunits % splitk) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
+    if (splitk < 1 || (kunits % splitk && !uneven)) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
     if constexpr (TYPE != CDNA4_Q4_K) { if (a.xf) return a.variant <= 0 ? 1 : cdna4_set_error_msg("gemm_q: in-launch quantizer: Q4_K only"); }
     if constexpr (TYPE == CDNA4_Q4_0 || TYPE == CDNA4_Q8_0 || TYPE == CDNA4_Q6_K) {
         // 2-byte-aligned formats at prefill batch sizes: re-lay the weights into 16-byte-aligned superblocks (scratch, per

@@ -111,6 +111,7 @@ def test_experimental_kernel_source_runs_correctly_on_the_cpu(m, k, b, splitk, r
 
 
 @pytest.mark.parametrize("m,k,b,splitk,exp,l2", [(300, 1536, 200, 1, 0, 1), (256, 2048, 128, 2, 0, 1), (256, 2048, 128, 2, 0, 0), (256, 1024, 128, 1, 100, 1),
+                                              (256, 1792, 128, 2, 0, 1), (300, 2304, 200, 2, 0, 0),          # ODD superblock counts: uneven 4 / 3 and 5 / 4 hand-off splits (CDNA4_ODD_SPLIT)
                                               (513, 3072, 129, 2, 1, 1), (513, 3072, 129, 2, 2, 0), (300, 1536, 200, 1, 4, 1), (256, 2048, 128, 2, 6, 1)])
 def test_shipped_12_wave_kernel_source_and_its_candidates_on_the_cpu(m, k, b, splitk, exp, l2):
     """tools/emul/w12_emul: the source of k_gemm_kq_w12 (+ the shared epilogue) executed on the CPU.  exp 0 is the shipped
@@ -271,7 +272,7 @@ def test_decode_kernel_source_on_the_cpu(t, cfg):
 
 
 @pytest.mark.parametrize("kern,wtype,m,k,b,splitk", [(20, 12, 300, 1536, 200, 1), (20, 12, 256, 2048, 128, 2), (64, 12, 300, 1536, 200, 1), (64, 13, 256, 2048, 128, 2),
-                                                     (64, 13, 300, 1536, 200, 1), (20, 13, 300, 512, 200, 1), (1064, 12, 256, 2048, 128, 2)])
+                                                     (64, 13, 300, 1536, 200, 1), (20, 13, 300, 512, 200, 1), (1064, 12, 256, 2048, 128, 2), (64, 13, 256, 1792, 128, 2)])
 def test_8_wave_kernel_sources_on_the_cpu(kern, wtype, m, k, b, splitk):
     """tools/emul/w8_emul: k_gemm_kq_w8 (schedule 20: the shallow-K fallback and the kernel of the repacked formats) and
     k_gemm_kq_w8p (64: Q5_K's default; 1064: its TRACE build), Q4_K and Q5_K weights, executed on the CPU — with the LDS-DMA
