@@ -8,7 +8,7 @@ echo "pytest -m gpu rc=$?" >> gpurun_out/summary.txt; tail -5 gpurun_out/pytest_
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/summary.txt
 timeout -k 10 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/summary.txt
 GB_TRACE_SPLITK=2 GB_SPLITKS="0,1,2" GB_VARIANTS="0,5,23,407,663,1031,2071" timeout 180 tools/microbench/gemm_bench 4096 4096 512 663 > gpurun_out/gemm_bench.txt 2>&1
-for shape in "8192 4096 512" "4096 10752 512" "4096 8192 512" "32768 8192 512"; do
+for shape in "8192 4096 512" "4096 10752 512" "4096 11008 512" "4096 8192 512" "32768 8192 512"; do   # 11008 = the true C3 K (43 superblocks, odd: no split unless CDNA4_ODD_SPLIT=1)
   GB_SPLITKS="0" GB_VARIANTS="0,663,1031" timeout 180 tools/microbench/gemm_bench $shape 2>&1 | grep -E "^M=|^variant" >> gpurun_out/gemm_bench.txt
 done
 R=$PWD; cd /tmp; export TMPDIR=/tmp
