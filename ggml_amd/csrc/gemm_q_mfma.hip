@@ -762,13 +762,13 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
         if ((opt == 64 || opt == 65) && min_nsb < 3) opt = 20;
     }
-    if (a.xf && !(opt == 65 && (exp == 1024 || exp == 3072) && TYPE == CDNA4_Q4_K)) {
+    if (a.xf && !(opt == 65 && (exp == 1024 || exp == 3072 || exp == 5120) && TYPE == CDNA4_Q4_K)) {
         if (a.variant <= 0) return 1;                                     // auto: "not fused, nothing launched that matters" — the caller prepares the image and calls again
         return cdna4_set_error_msg("gemm_q: the in-launch activation quantizer exists for k_gemm_kq_w12<Q4_K> only (>= 3 superblocks of K per work-group)");
     }
     if (opt == 65) {                                                      // + loader waves
         if constexpr (TYPE == CDNA4_Q4_K) {
-            if (exp == 1024 || exp == 3072) {                             // the activation quantizer runs inside the launch (3072: + weight pre-touch)
+            if (exp == 1024 || exp == 3072 || exp == 5120) {              // the activation quantizer runs inside the launch (3072: + weight pre-touch; 5120: published by an L2 write-back fence)
                 if (!a.xf) return cdna4_set_error_msg("gemm_q: variant bit 1024 << 16 needs the fp32 activations");
                 if ((((uintptr_t)a.xf | (uintptr_t)(a.xf_row_elems * 4)) & 15) || (int64_t)a.B * a.K * 2 >= (int64_t)1 << 31)
                     return cdna4_set_error_msg("gemm_q: in-launch quantizer needs 16-byte aligned activation rows and an image below 2 GiB");
@@ -779,6 +779,7 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
                 p.xf = a.xf; p.xf_row = a.xf_row_elems; p.qcount = slots + (tag & 63); p.qzero = slots + ((tag + 32) & 63);
                 p.nq = (int)grid.x < cu_count() ? (int)grid.x : cu_count();
                 if (exp == 3072) hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 3072>), grid, dim3(768), 0, st, p);
+                else if (exp == 5120) hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 5120>), grid, dim3(768), 0, st, p);
                 else hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 1024>), grid, dim3(768), 0, st, p);
                 CDNA4_CHECK_LAUNCH(); return 0;
             }
@@ -867,7 +868,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     static const int fuseq_env = getenv("CDNA4_FUSEQ") ? atoi(getenv("CDNA4_FUSEQ")) : 0;
     const int auto_exp = (a.xf && a.variant <= 0) ? (fuseq_env == 2 ? 3072 : 1024) : 0;
     if (a.xf && a.variant <= 0 && !(TYPE == CDNA4_Q4_K && wlds && (variant & 16) && (variant & 4096))) return 1;
-    if (a.xf && a.variant > 0 && !(TYPE == CDNA4_Q4_K && wlds && (variant & 16) && (variant & 4096) && !(variant & (1024 | 8192)) && ((variant >> 16) == 1024 || (variant >> 16) == 3072)))
+    if (a.xf && a.variant > 0 && !(TYPE == CDNA4_Q4_K && wlds && (variant & 16) && (variant & 4096) && !(variant & (1024 | 8192)) && ((variant >> 16) == 1024 || (variant >> 16) == 3072 || (variant >> 16) == 5120)))
         return cdna4_set_error_msg("gemm_q: fp32 activations (no prepared image) are accepted by the explicit variant 4119 | 1024 << 16 of Q4_K only");
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
     const int kunits = QT<TYPE>::KQ ? a.K / 256 : a.K / 64;
