@@ -220,6 +220,18 @@ def diagnostics():
             res[name] = json.loads(line[-1]) if line else {"returncode": r.returncode, "stderr": (r.stderr or "")[-400:]}
         except Exception as e:              # noqa: BLE001
             res[name] = repr(e)[:200]
+    # very last (nothing follows it but the print of the line): the experimental loader-wave kernels of gemm_q_x4l.hip (256x128 / 4 compute
+    # waves, 128x128, 256x128 / 8 compute waves; emulator-verified, never run on a GPU) beside the default at the headline shape —
+    # time and rel-L2 against the default (must be ~1e-7)
+    if os.path.exists(os.path.join(mb, "gemm_bench_abl")):
+        res["x4l_experimental"] = {}
+        for v in (8199, 24583, 40967):      # one process per form: a fault of one does not hide the others
+            try:
+                r = subprocess.run(["./gemm_bench_abl", "4096", "4096", "512", ""], cwd=mb, capture_output=True, text=True, timeout=30,
+                                   env=dict(os.environ, GB_VARIANTS="4119,%d" % v, GB_SPLITKS="0", GB_ROUNDS="2"))
+                res["x4l_experimental"][str(v)] = (r.stdout[-700:] if r.returncode == 0 else "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
+            except Exception as e:          # noqa: BLE001
+                res["x4l_experimental"][str(v)] = repr(e)[:200]
     return res
 
 
