@@ -206,7 +206,8 @@ def diagnostics():
             continue
         try:
             r = subprocess.run(cmd, cwd=mb, capture_output=True, text=True, timeout=tmo, env=dict(os.environ, **env))
-            res[name] = (r.stdout[-2500:] if r.returncode == 0 else "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))
+            txt = r.stdout if len(r.stdout) <= 3200 else r.stdout[:1200] + "\n[...]\n" + r.stdout[-2000:]      # (mfma_valu prints its sustained-rate lines first)
+            res[name] = (txt if r.returncode == 0 else "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))
         except Exception as e:              # noqa: BLE001
             res[name] = repr(e)[:200]
     # BASELINE configs[2] at its TRUE K = 11008 = 43 superblocks (round 1 measured 10752): today's auto route (no K split for an odd
