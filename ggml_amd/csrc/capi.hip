@@ -3,6 +3,7 @@
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -14,8 +15,11 @@ int cdna4_set_error(hipError_t e, const char *file, int line) {
 int cdna4_set_error_msg(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); return -1; }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-static inline bool is_kq(int t) { return t == CDNA4_Q4_K || t == CDNA4_Q5_K || t == CDNA4_Q6_K; }
-static inline bool is_q(int t) { return is_kq(t) || t == CDNA4_Q4_0 || t == CDNA4_Q8_0; }
+// CDNA4_EXTRA_TYPES=1 (experiment knob, default off): Q5_0 / Q2_K / Q3_K through the int8-dot GEMV units of gemv_q.hip (written
+// against the oracle, verified on the CPU emulator, not yet on a GPU); they have no MFMA GEMM, so every batch size takes the GEMV path
+static bool extra_types() { static const bool on = getenv("CDNA4_EXTRA_TYPES") && atoi(getenv("CDNA4_EXTRA_TYPES")) != 0; return on; }
+static inline bool is_kq(int t) { return t == CDNA4_Q4_K || t == CDNA4_Q5_K || t == CDNA4_Q6_K || ((t == CDNA4_Q2_K || t == CDNA4_Q3_K) && extra_types()); }
+static inline bool is_q(int t) { return is_kq(t) || t == CDNA4_Q4_0 || t == CDNA4_Q8_0 || (t == CDNA4_Q5_0 && extra_types()); }
 
 // workspace carve: [qs int8 B*K][d f32 B*K/qka][bsums i16 B*K/16][xh f16 B*K]
 struct ws_view { int8_t *qs; float *d; int16_t *bsums; void *xh; size_t total; };
@@ -44,6 +48,8 @@ size_t ggml_cdna4_row_size(int type, int64_t k) {
         case CDNA4_Q4_0: return k % 32 ? 0 : (size_t)(k / 32) * 18; case CDNA4_Q8_0: return k % 32 ? 0 : (size_t)(k / 32) * 34;
         case CDNA4_Q4_K: return k % 256 ? 0 : (size_t)(k / 256) * 144; case CDNA4_Q5_K: return k % 256 ? 0 : (size_t)(k / 256) * 176;
         case CDNA4_Q6_K: return k % 256 ? 0 : (size_t)(k / 256) * 210;
+        case CDNA4_Q5_0: return k % 32 ? 0 : (size_t)(k / 32) * 22; case CDNA4_Q2_K: return k % 256 ? 0 : (size_t)(k / 256) * 84;
+        case CDNA4_Q3_K: return k % 256 ? 0 : (size_t)(k / 256) * 110;
     }
     return 0;
 }

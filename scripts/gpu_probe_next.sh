@@ -58,6 +58,8 @@ CDNA4_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gpu_parity.py 
 #     the CPU emulator) — bit-identity with the default path incl. workspace reuse and > 64 launches, then the step time beside the default
 CDNA4_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "in_launch" >> gpurun_out/experimental_tests.txt 2>&1
 timeout 200 python bench.py --fuseq-leg --steps 200 > gpurun_out/fuseq_leg.txt 2>&1
+# (5c) Q5_0 / Q2_K / Q3_K through the GEMV units (CDNA4_EXTRA_TYPES=1 in a child process) against the oracle
+CDNA4_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "extra_weight_types" >> gpurun_out/experimental_tests.txt 2>&1
 # (5b) the same quantizer on the AUTO route (CDNA4_FUSEQ=1: every Q4_K prefill GEMM whose auto kernel is k_gemm_kq_w12 becomes one launch): the whole
 #      GEMM parity suite under it — what has to be green before the knob becomes the default
 CDNA4_FUSEQ=1 timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "gemm or mul_mat or full_size" > gpurun_out/pytest_fuseq_auto.log 2>&1; tail -3 gpurun_out/pytest_fuseq_auto.log

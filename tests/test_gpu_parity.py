@@ -301,6 +301,45 @@ def test_in_launch_quantizer_fails_loudly_where_it_does_not_exist(gu):
         ops.mul_mat(gu.qtensor(R.Q4_K, w, 256, 512), gu.to_dev(_x(1, 128, 512)), path=ops.PATH_GEMM, gemm_variant=FUSEQ)
 
 
+_EXTRA_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import refutil as R
+from ggml_amd import native
+L = native.lib(); dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+t = int(sys.argv[2]); m, k = 300, 2048
+w = R.random_weights(t, m, k, seed=t)
+rb = L.ggml_cdna4_row_size(t, k)
+assert rb * m == w.size, (rb, w.size)
+wd = torch.from_numpy(np.ascontiguousarray(w)).to(dev)
+st = torch.cuda.current_stream(dev).cuda_stream
+worst = 0.0
+for b in (1, 3, 8, 20):
+    x = np.random.default_rng(b).uniform(-1, 1, (b, k)).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev); y = torch.empty((b, m), dtype=torch.float32, device=dev)
+    ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(t, k, b), dtype=torch.uint8, device=dev)
+    native.check(L.ggml_cdna4_mul_mat(t, wd.data_ptr(), rb, xd.data_ptr(), k, y.data_ptr(), m, m, k, b, ws.data_ptr(), ws.numel(), 0, 0, 0, st))
+    torch.cuda.synchronize()
+    worst = max(worst, R.rel_l2(y.cpu().numpy(), R.o_mul_mat(t, w, x, m, k)))
+print("WORST", worst)
+assert worst < 1e-5
+"""
+
+
+@pytest.mark.skipif(os.environ.get("CDNA4_TEST_EXPERIMENTAL") != "1", reason="experimental, opt-in: CDNA4_TEST_EXPERIMENTAL=1")
+@pytest.mark.parametrize("t", [R.Q5_0, R.Q2_K, R.Q3_K])
+def test_extra_weight_types_through_the_gemv_units(gu, t):
+    """CDNA4_EXTRA_TYPES=1 (read once per process, hence the child): Q5_0 / Q2_K / Q3_K MUL_MAT through the int8-dot GEMV units
+    (fused decode at B = 1, multi-column above) against the oracle — same integer sums as the CPU backend, tolerance of the GEMV path"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _EXTRA_CHILD, os.path.join(root, "tests"), str(int(t))], capture_output=True, text=True, timeout=300, cwd=root,
+                       env=dict(os.environ, CDNA4_EXTRA_TYPES="1", PYTHONPATH=root))
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-800:])
+    gu.report(test="extra_types_gemv", type=int(t), out=r.stdout.strip()[-60:])
+
+
 def test_gemm_auto_picks_256x128_kernel_on_huge_grids(gu):
     """>= 2 x #CUs tiles of 256x128 (the C5-like regime): the auto path is the 256x128-tile kernel without a K split —
     bit-identical to asking for it explicitly, and within tolerance of the oracle on a row sample"""
