@@ -132,8 +132,8 @@ def test_shipped_12_wave_kernel_source_and_its_candidates_on_the_cpu(m, k, b, sp
         assert np.array_equal(y, y0)
 
 
-@pytest.mark.parametrize("m,k,b,splitk,nq,dist,exp", [(256, 1024, 256, 1, None, "uniform", 1024), (300, 1536, 200, 1, None, "uniform", 1024), (256, 2048, 128, 2, 3, "uniform", 1024),
-                                                      (256, 1024, 256, 1, 1, "ties", 1024), (300, 1536, 200, 1, None, "uniform", 3072), (513, 3072, 129, 2, 5, "uniform", 3072), (300, 1536, 200, 1, None, "uniform", 5120)])
+@pytest.mark.parametrize("m,k,b,splitk,nq,dist,exp", [(256, 2048, 128, 2, 3, "uniform", 1024), (256, 1024, 256, 1, 1, "ties", 1024), (513, 3072, 129, 2, 5, "uniform", 3072),
+                                                      (300, 1536, 200, 1, None, "uniform", 5120), (256, 1792, 128, 2, None, "uniform", 1024)])   # last: odd superblock count, uneven split
 def test_gemm_with_in_launch_activation_quantizer_on_the_cpu(m, k, b, splitk, nq, dist, exp):
     """k_gemm_kq_w12<Q4_K, true, 1024> (EXP bit 10: the first nq work-groups quantize the fp32 activations, a one-way grid barrier
     on a device-coherent counter, then the shipped main loop) on the CPU emulator, work-groups as processes sharing the global
