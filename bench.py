@@ -221,6 +221,18 @@ def diagnostics():
             res[name] = json.loads(line[-1]) if line else {"returncode": r.returncode, "stderr": (r.stderr or "")[-400:]}
         except Exception as e:              # noqa: BLE001
             res[name] = repr(e)[:200]
+    # the opt-in parity tests of code that was written after the round's GPU budget was spent (tests/ run as tests, in a child pytest
+    # with CDNA4_TEST_EXPERIMENTAL=1; only their pass / fail summary is recorded): in-launch quantizer on small and ragged shapes incl.
+    # > 64 launches and the refusal paths, Q5_0 / Q2_K / Q3_K through the GEMV units against the oracle, the GGUF upload
+    for name, targs in (("experimental_parity_tests", ["tests/test_gpu_parity.py", "-k",
+                                                       "extra_weight_types or fails_loudly or (in_launch_activation and (256-1024 or 300-1536 or 513-3072))"]),
+                        ("experimental_gguf_upload_test", ["tests/test_gguf.py", "-k", "upload"])):
+        try:
+            r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + targs, cwd=ROOT, capture_output=True, text=True, timeout=150,
+                               env=dict(os.environ, CDNA4_TEST_EXPERIMENTAL="1"))
+            res[name] = {"returncode": r.returncode, "tail": r.stdout[-600:]}
+        except Exception as e:              # noqa: BLE001
+            res[name] = repr(e)[:200]
     # very last (nothing follows it but the print of the line): the experimental loader-wave kernels of gemm_q_x4l.hip (256x128 / 4 compute
     # waves, 128x128, 256x128 / 8 compute waves; emulator-verified, never run on a GPU) beside the default at the headline shape —
     # time and rel-L2 against the default (must be ~1e-7)
