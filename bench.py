@@ -190,19 +190,30 @@ def decode_graph_leg():
     print(json.dumps({"us_per_step_hipgraph": round(us, 3), "nodes_per_graph": ncopy, "same_result_as_stream_launches": same}), flush=True)
 
 
+T_START = time.time()
+OPTIONAL_BUDGET_S = float(os.environ.get("BENCH_OPTIONAL_BUDGET_S", "240"))   # no optional leg STARTS later than this many seconds into the run
+
+
+def optional_time_left():
+    return OPTIONAL_BUDGET_S - (time.time() - T_START)
+
+
 def diagnostics():
     """Stand-alone probes of tools/microbench (built by __graft_entry__.build(); each a child process with its own timeout, run
     after everything that is reported above): what the DESIGN.md §7 list asks of the next GPU call, recorded with the bench line
     so that a round whose GPU budget is spent still gets them from the round-end run.  Raw text, trimmed."""
     mb = os.path.join(ROOT, "tools", "microbench")
-    legs = (("launch_floor", ["./launch_floor"], {}, 60),                       # empty-kernel launch cost; pure-load floor of the 9.4 MB decode matrix
-            ("mfma_valu", ["./mfma_valu", "500"], {}, 90),                      # matrix-pipe price of the unpack mix, the clock held, sustained MFMA-only rate
-            # bit-identical candidates of the shipped GEMM (ablation build): early table read / balanced epilogue / stores from registers / both
-            ("w12_candidates", ["./gemm_bench_abl", "4096", "4096", "512", ""], {"GB_VARIANTS": "4119,69655,135191,266263,397335", "GB_SPLITKS": "0"}, 60))
+    legs = (# bit-identical candidates of the shipped GEMM (ablation build): early table read / balanced epilogue / stores from registers / both
+            ("w12_candidates", ["./gemm_bench_abl", "4096", "4096", "512", ""], {"GB_VARIANTS": "4119,69655,135191,266263,397335", "GB_SPLITKS": "0"}, 60),
+            ("launch_floor", ["./launch_floor"], {}, 60),                       # empty-kernel launch cost; pure-load floor of the 9.4 MB decode matrix
+            ("mfma_valu", ["./mfma_valu", "500"], {}, 60))                      # matrix-pipe price of the unpack mix, the clock held, sustained MFMA-only rate
     res = {}
     for name, cmd, env, tmo in legs:
         if not os.path.exists(os.path.join(mb, cmd[0])):
             res[name] = "not built"
+            continue
+        if optional_time_left() <= 0:
+            res[name] = "skipped: time budget of the optional legs"
             continue
         try:
             r = subprocess.run(cmd, cwd=mb, capture_output=True, text=True, timeout=tmo, env=dict(os.environ, **env))
@@ -215,8 +226,11 @@ def diagnostics():
     # last: the default route at the shape of DESIGN 4.3's open issue (own process: a GPU fault there ends only that process)
     for name, spec, env in (("c3_4096x11008x512", "4096,11008,512", {"CDNA4_ODD_SPLIT": "0"}), ("c3_4096x11008x512_odd_split", "4096,11008,512", {"CDNA4_ODD_SPLIT": "1"}),
                             ("default_route_8192x8192x512", "8192,8192,512", {})):
+        if optional_time_left() <= 0:
+            res[name] = "skipped: time budget of the optional legs"
+            continue
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shape-check", spec], capture_output=True, text=True, timeout=150, env=dict(os.environ, **env))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shape-check", spec], capture_output=True, text=True, timeout=90, env=dict(os.environ, **env))
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             res[name] = json.loads(line[-1]) if line else {"returncode": r.returncode, "stderr": (r.stderr or "")[-400:]}
         except Exception as e:              # noqa: BLE001
@@ -227,8 +241,11 @@ def diagnostics():
     for name, targs in (("experimental_parity_tests", ["tests/test_gpu_parity.py", "-k",
                                                        "extra_weight_types or fails_loudly or (in_launch_activation and (256-1024 or 300-1536 or 513-3072))"]),
                         ("experimental_gguf_upload_test", ["tests/test_gguf.py", "-k", "upload"])):
+        if optional_time_left() <= 0:
+            res[name] = "skipped: time budget of the optional legs"
+            continue
         try:
-            r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + targs, cwd=ROOT, capture_output=True, text=True, timeout=150,
+            r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + targs, cwd=ROOT, capture_output=True, text=True, timeout=120,
                                env=dict(os.environ, CDNA4_TEST_EXPERIMENTAL="1"))
             res[name] = {"returncode": r.returncode, "tail": r.stdout[-600:]}
         except Exception as e:              # noqa: BLE001
@@ -239,6 +256,9 @@ def diagnostics():
     if os.path.exists(os.path.join(mb, "gemm_bench_abl")):
         res["x4l_experimental"] = {}
         for v in (8199, 24583, 40967):      # one process per form: a fault of one does not hide the others
+            if optional_time_left() <= -30:  # (these are short: allowed to start a little past the budget)
+                res["x4l_experimental"][str(v)] = "skipped: time budget of the optional legs"
+                continue
             try:
                 r = subprocess.run(["./gemm_bench_abl", "4096", "4096", "512", ""], cwd=mb, capture_output=True, text=True, timeout=30,
                                    env=dict(os.environ, GB_VARIANTS="4119,%d" % v, GB_SPLITKS="0", GB_ROUNDS="2"))
@@ -595,11 +615,13 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        if world == 1:
+        if world == 1 and optional_time_left() <= 0:
+            out["one_launch_step_experimental"] = "skipped: time budget of the optional legs"
+        elif world == 1:
             # experimental one-launch step (not the default path, not part of `value`), in a child process so that nothing it does
             # can take this line down; runs last
             try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fuseq-leg", "--steps", str(args.steps)], capture_output=True, text=True, timeout=240)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fuseq-leg", "--steps", str(args.steps)], capture_output=True, text=True, timeout=150)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 out["one_launch_step_experimental"] = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:], "returncode": r.returncode}
             except Exception as e:          # noqa: BLE001
