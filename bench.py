@@ -191,7 +191,7 @@ def decode_graph_leg():
 
 
 T_START = time.time()
-OPTIONAL_BUDGET_S = float(os.environ.get("BENCH_OPTIONAL_BUDGET_S", "240"))   # no optional leg STARTS later than this many seconds into the run
+OPTIONAL_BUDGET_S = float(os.environ.get("BENCH_OPTIONAL_BUDGET_S", "200"))   # no optional leg STARTS later than this many seconds into the run
 
 
 def optional_time_left():
@@ -199,72 +199,70 @@ def optional_time_left():
 
 
 def diagnostics():
-    """Stand-alone probes of tools/microbench (built by __graft_entry__.build(); each a child process with its own timeout, run
-    after everything that is reported above): what the DESIGN.md §7 list asks of the next GPU call, recorded with the bench line
-    so that a round whose GPU budget is spent still gets them from the round-end run.  Raw text, trimmed."""
+    """Stand-alone probes of tools/microbench (built by __graft_entry__.build()), shape checks and the opt-in tests of code that
+    was written after the round's GPU budget was spent — each a child process with its own timeout, run after everything that is
+    reported above, most informative first, none started once the optional time budget is spent: what DESIGN.md 7 asks of the
+    next GPU call, recorded with the bench line.  Raw text, trimmed."""
     mb = os.path.join(ROOT, "tools", "microbench")
-    legs = (# bit-identical candidates of the shipped GEMM (ablation build): early table read / balanced epilogue / stores from registers / both
-            ("w12_candidates", ["./gemm_bench_abl", "4096", "4096", "512", ""], {"GB_VARIANTS": "4119,69655,135191,266263,397335", "GB_SPLITKS": "0"}, 60),
-            ("launch_floor", ["./launch_floor"], {}, 60),                       # empty-kernel launch cost; pure-load floor of the 9.4 MB decode matrix
-            ("mfma_valu", ["./mfma_valu", "500"], {}, 60))                      # matrix-pipe price of the unpack mix, the clock held, sustained MFMA-only rate
     res = {}
-    for name, cmd, env, tmo in legs:
+
+    def tool(name, cmd, env, tmo, slack=0.0):
         if not os.path.exists(os.path.join(mb, cmd[0])):
             res[name] = "not built"
-            continue
-        if optional_time_left() <= 0:
+            return
+        if optional_time_left() <= -slack:
             res[name] = "skipped: time budget of the optional legs"
-            continue
+            return
         try:
             r = subprocess.run(cmd, cwd=mb, capture_output=True, text=True, timeout=tmo, env=dict(os.environ, **env))
             txt = r.stdout if len(r.stdout) <= 3200 else r.stdout[:1200] + "\n[...]\n" + r.stdout[-2000:]      # (mfma_valu prints its sustained-rate lines first)
             res[name] = (txt if r.returncode == 0 else "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))
         except Exception as e:              # noqa: BLE001
             res[name] = repr(e)[:200]
-    # BASELINE configs[2] at its TRUE K = 11008 = 43 superblocks (round 1 measured 10752): today's auto route (no K split for an odd
-    # count: 128 of 256 CUs busy) and the uneven 22 / 21 hand-off split behind CDNA4_ODD_SPLIT=1 (emulator-verified), one process each;
-    # last: the default route at the shape of DESIGN 4.3's open issue (own process: a GPU fault there ends only that process)
-    for name, spec, env in (("c3_4096x11008x512", "4096,11008,512", {"CDNA4_ODD_SPLIT": "0"}), ("c3_4096x11008x512_odd_split", "4096,11008,512", {"CDNA4_ODD_SPLIT": "1"}),
-                            ("default_route_8192x8192x512", "8192,8192,512", {})):
+
+    def shape(name, spec, env):
         if optional_time_left() <= 0:
             res[name] = "skipped: time budget of the optional legs"
-            continue
+            return
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shape-check", spec], capture_output=True, text=True, timeout=90, env=dict(os.environ, **env))
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             res[name] = json.loads(line[-1]) if line else {"returncode": r.returncode, "stderr": (r.stderr or "")[-400:]}
         except Exception as e:              # noqa: BLE001
             res[name] = repr(e)[:200]
-    # the opt-in parity tests of code that was written after the round's GPU budget was spent (tests/ run as tests, in a child pytest
-    # with CDNA4_TEST_EXPERIMENTAL=1; only their pass / fail summary is recorded): in-launch quantizer on small and ragged shapes incl.
-    # > 64 launches and the refusal paths, Q5_0 / Q2_K / Q3_K through the GEMV units against the oracle, the GGUF upload
-    for name, targs in (("experimental_parity_tests", ["tests/test_gpu_parity.py", "-k",
-                                                       "extra_weight_types or fails_loudly or (in_launch_activation and (256-1024 or 300-1536 or 513-3072))"]),
-                        ("experimental_gguf_upload_test", ["tests/test_gguf.py", "-k", "upload"])):
+
+    def tests(name, targs):
         if optional_time_left() <= 0:
             res[name] = "skipped: time budget of the optional legs"
-            continue
+            return
         try:
             r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + targs, cwd=ROOT, capture_output=True, text=True, timeout=120,
                                env=dict(os.environ, CDNA4_TEST_EXPERIMENTAL="1"))
             res[name] = {"returncode": r.returncode, "tail": r.stdout[-600:]}
         except Exception as e:              # noqa: BLE001
             res[name] = repr(e)[:200]
+
+    # bit-identical candidates of the shipped GEMM (ablation build): early table read / balanced epilogue / stores from registers / both
+    tool("w12_candidates", ["./gemm_bench_abl", "4096", "4096", "512", ""], {"GB_VARIANTS": "4119,69655,135191,266263,397335", "GB_SPLITKS": "0"}, 60)
+    # BASELINE configs[2] at its TRUE K = 11008 = 43 superblocks (round 1 measured 10752): today's auto route (no K split for an odd
+    # count: 128 of 256 CUs busy) and the uneven 22 / 21 hand-off split behind CDNA4_ODD_SPLIT=1 (emulator-verified), one process each
+    shape("c3_4096x11008x512", "4096,11008,512", {"CDNA4_ODD_SPLIT": "0"})
+    shape("c3_4096x11008x512_odd_split", "4096,11008,512", {"CDNA4_ODD_SPLIT": "1"})
+    # the opt-in parity tests (tests/ run as tests, in a child pytest with CDNA4_TEST_EXPERIMENTAL=1; only the pass / fail summary is
+    # kept): in-launch quantizer on small and ragged shapes incl. > 64 launches and the refusal paths; Q5_0 / Q2_K / Q3_K through the
+    # GEMV units against the oracle
+    tests("experimental_parity_tests", ["tests/test_gpu_parity.py", "-k", "extra_weight_types or fails_loudly or (in_launch_activation and (256-1024 or 300-1536 or 513-3072))"])
+    # the default route at the shape of DESIGN 4.3's open issue (own process: a GPU fault there ends only that process)
+    shape("default_route_8192x8192x512", "8192,8192,512", {})
+    tool("launch_floor", ["./launch_floor"], {}, 60)                    # empty-kernel launch cost; pure-load floor of the 9.4 MB decode matrix
+    tool("mfma_valu", ["./mfma_valu", "500"], {}, 60)                   # matrix-pipe price of the unpack mix, the clock held, sustained MFMA-only rate
+    tests("experimental_gguf_upload_test", ["tests/test_gguf.py", "-k", "upload"])
     # very last (nothing follows it but the print of the line): the experimental loader-wave kernels of gemm_q_x4l.hip (256x128 / 4 compute
-    # waves, 128x128, 256x128 / 8 compute waves; emulator-verified, never run on a GPU) beside the default at the headline shape —
-    # time and rel-L2 against the default (must be ~1e-7)
-    if os.path.exists(os.path.join(mb, "gemm_bench_abl")):
-        res["x4l_experimental"] = {}
-        for v in (8199, 24583, 40967):      # one process per form: a fault of one does not hide the others
-            if optional_time_left() <= -30:  # (these are short: allowed to start a little past the budget)
-                res["x4l_experimental"][str(v)] = "skipped: time budget of the optional legs"
-                continue
-            try:
-                r = subprocess.run(["./gemm_bench_abl", "4096", "4096", "512", ""], cwd=mb, capture_output=True, text=True, timeout=30,
-                                   env=dict(os.environ, GB_VARIANTS="4119,%d" % v, GB_SPLITKS="0", GB_ROUNDS="2"))
-                res["x4l_experimental"][str(v)] = (r.stdout[-700:] if r.returncode == 0 else "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
-            except Exception as e:          # noqa: BLE001
-                res["x4l_experimental"][str(v)] = repr(e)[:200]
+    # waves, 128x128, 256x128 / 8 compute waves; emulator-verified, never run on a GPU) beside the default at the headline shape — time and
+    # rel-L2 against the default (must be ~1e-7); one process per form: a fault of one does not hide the others.  (Short: allowed to start
+    # a little past the budget.)
+    for v in (8199, 24583, 40967):
+        tool("x4l_experimental_%d" % v, ["./gemm_bench_abl", "4096", "4096", "512", ""], {"GB_VARIANTS": "4119,%d" % v, "GB_SPLITKS": "0", "GB_ROUNDS": "2"}, 30, slack=30.0)
     return res
 
 
