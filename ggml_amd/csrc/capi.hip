@@ -120,7 +120,7 @@ int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float
         g.M = (int)M; g.K = (int)K; g.ncol = 1; g.ids = nullptr;
         return cdna4_launch_gemv_q_fused(g, X, (hipStream_t)stream);
     }
-    if (path == GGML_CDNA4_PATH_GEMM && gemm_variant > 0 && ((gemm_variant >> 16) == 1024 || (gemm_variant >> 16) == 3072 || (gemm_variant >> 16) == 5120)) {
+    if (path == GGML_CDNA4_PATH_GEMM && gemm_variant > 0 && ((gemm_variant >> 16) == 1024 || (gemm_variant >> 16) == 3072 || (gemm_variant >> 16) == 5120 || (gemm_variant >> 16) == 9216)) {
         // explicit experimental variant: ONE launch — k_gemm_kq_w12<Q4_K> quantizes the activations itself (the image still
         // lives in the caller's workspace); every route that cannot do that fails in the launcher, nothing falls back silently
         if (!workspace || ((uintptr_t)workspace & 255)) return cdna4_set_error_msg("mul_mat: workspace must be 256-byte aligned");

@@ -696,16 +696,17 @@ static int cu_count() {
     return n;
 }
 
-// counter slots of the in-launch activation quantizer (k_gemm_kq_w12, EXP bit 10): 64 words per device, zeroed once; launch
-// `tag` counts in slot tag % 64 and zeroes slot (tag + 32) % 64, whose last user finished 32 stream-ordered launches ago
+// counter slots of the in-launch activation quantizer (k_gemm_kq_w12, EXP bit 10): 64 slots of 16 words per device, zeroed once;
+// launch `tag` counts in slot tag % 64 (word 0, or one word per group with EXP bit 13) and zeroes slot (tag + 32) % 64, whose last
+// user finished 32 stream-ordered launches ago
 static unsigned *g_qslots[16] = {nullptr}; static unsigned g_qtag[16] = {0};
 static unsigned *get_qslots(int &dev) {
     dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
     if (!g_qslots[dev]) {
         void *ptr = nullptr;
-        if (hipMalloc(&ptr, 64 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipMemset(ptr, 0, 64 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); return nullptr; }
+        if (hipMalloc(&ptr, 64 * 16 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(ptr, 0, 64 * 16 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); return nullptr; }
         g_qslots[dev] = (unsigned *)ptr;
     }
     return g_qslots[dev];
@@ -762,13 +763,13 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
         if ((opt == 64 || opt == 65) && min_nsb < 3) opt = 20;
     }
-    if (a.xf && !(opt == 65 && (exp == 1024 || exp == 3072 || exp == 5120) && TYPE == CDNA4_Q4_K)) {
+    if (a.xf && !(opt == 65 && (exp == 1024 || exp == 3072 || exp == 5120 || exp == 9216) && TYPE == CDNA4_Q4_K)) {
         if (a.variant <= 0) return 1;                                     // auto: "not fused, nothing launched that matters" — the caller prepares the image and calls again
         return cdna4_set_error_msg("gemm_q: the in-launch activation quantizer exists for k_gemm_kq_w12<Q4_K> only (>= 3 superblocks of K per work-group)");
     }
     if (opt == 65) {                                                      // + loader waves
         if constexpr (TYPE == CDNA4_Q4_K) {
-            if (exp == 1024 || exp == 3072 || exp == 5120) {              // the activation quantizer runs inside the launch (3072: + weight pre-touch; 5120: published by an L2 write-back fence)
+            if (exp == 1024 || exp == 3072 || exp == 5120 || exp == 9216) {              // the activation quantizer runs inside the launch (3072: + weight pre-touch; 5120: published by an L2 write-back fence)
                 if (!a.xf) return cdna4_set_error_msg("gemm_q: variant bit 1024 << 16 needs the fp32 activations");
                 if ((((uintptr_t)a.xf | (uintptr_t)(a.xf_row_elems * 4)) & 15) || (int64_t)a.B * a.K * 2 >= (int64_t)1 << 31)
                     return cdna4_set_error_msg("gemm_q: in-launch quantizer needs 16-byte aligned activation rows and an image below 2 GiB");
@@ -776,10 +777,14 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
                 unsigned *slots = get_qslots(dev);
                 if (!slots) return cdna4_set_error_msg("gemm_q: cannot allocate the quantizer's counter slots");
                 const unsigned tag = g_qtag[dev]++;
-                p.xf = a.xf; p.xf_row = a.xf_row_elems; p.qcount = slots + (tag & 63); p.qzero = slots + ((tag + 32) & 63);
+                p.xf = a.xf; p.xf_row = a.xf_row_elems; p.qcount = slots + (tag & 63) * 16; p.qzero = slots + ((tag + 32) & 63) * 16;
                 p.nq = (int)grid.x < cu_count() ? (int)grid.x : cu_count();
                 if (exp == 3072) hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 3072>), grid, dim3(768), 0, st, p);
                 else if (exp == 5120) hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 5120>), grid, dim3(768), 0, st, p);
+                else if (exp == 9216) {                                   // one counter per (activation tile, K range) group: needs the whole grid resident
+                    if ((int)grid.x > cu_count() || p.tiles_b * splitk > 16) return cdna4_set_error_msg("gemm_q: the grouped in-launch quantizer needs a grid of at most #CUs work-groups and at most 16 groups");
+                    hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 9216>), grid, dim3(768), 0, st, p);
+                }
                 else hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 1024>), grid, dim3(768), 0, st, p);
                 CDNA4_CHECK_LAUNCH(); return 0;
             }
@@ -868,7 +873,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     static const int fuseq_env = getenv("CDNA4_FUSEQ") ? atoi(getenv("CDNA4_FUSEQ")) : 0;
     const int auto_exp = (a.xf && a.variant <= 0) ? (fuseq_env == 2 ? 3072 : 1024) : 0;
     if (a.xf && a.variant <= 0 && !(TYPE == CDNA4_Q4_K && wlds && (variant & 16) && (variant & 4096))) return 1;
-    if (a.xf && a.variant > 0 && !(TYPE == CDNA4_Q4_K && wlds && (variant & 16) && (variant & 4096) && !(variant & (1024 | 8192)) && ((variant >> 16) == 1024 || (variant >> 16) == 3072 || (variant >> 16) == 5120)))
+    if (a.xf && a.variant > 0 && !(TYPE == CDNA4_Q4_K && wlds && (variant & 16) && (variant & 4096) && !(variant & (1024 | 8192)) && ((variant >> 16) == 1024 || (variant >> 16) == 3072 || (variant >> 16) == 5120 || (variant >> 16) == 9216)))
         return cdna4_set_error_msg("gemm_q: fp32 activations (no prepared image) are accepted by the explicit variant 4119 | 1024 << 16 of Q4_K only");
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
     const int kunits = QT<TYPE>::KQ ? a.K / 256 : a.K / 64;

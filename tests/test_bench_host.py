@@ -27,6 +27,6 @@ def test_optional_legs_respect_the_time_budget(monkeypatch):
 
 def test_experimental_variants_are_distinct_and_explicit(monkeypatch):
     b = _bench(monkeypatch, 240)
-    vs = {b.FUSEQ_VARIANT, b.FUSEQ_PFW_VARIANT, b.FUSEQ_WBL2_VARIANT}
-    assert len(vs) == 3 and all(v > 0 and (v & 0xFFFF) == 4119 and (v >> 16) in (1024, 3072, 5120) for v in vs)
+    vs = {b.FUSEQ_VARIANT, b.FUSEQ_PFW_VARIANT, b.FUSEQ_WBL2_VARIANT, b.FUSEQ_GRP_VARIANT}
+    assert len(vs) == 4 and all(0 < v < 2 ** 31 and (v & 0xFFFF) == 4119 and (v >> 16) in (1024, 3072, 5120, 9216) for v in vs)
     assert 0 < b.optional_time_left() <= 240   # (the default is 200 s; the env var of this test sets 240)

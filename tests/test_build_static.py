@@ -133,7 +133,8 @@ def test_shipped_12_wave_kernel_source_and_its_candidates_on_the_cpu(m, k, b, sp
 
 
 @pytest.mark.parametrize("m,k,b,splitk,nq,dist,exp", [(256, 2048, 128, 2, 3, "uniform", 1024), (256, 1024, 256, 1, 1, "ties", 1024), (513, 3072, 129, 2, 5, "uniform", 3072),
-                                                      (300, 1536, 200, 1, None, "uniform", 5120), (256, 1792, 128, 2, None, "uniform", 1024)])   # last: odd superblock count, uneven split
+                                                      (300, 1536, 200, 1, None, "uniform", 5120), (256, 1792, 128, 2, None, "uniform", 1024),   # odd superblock count, uneven split
+                                                      (300, 1536, 200, 1, None, "uniform", 9216), (256, 1792, 256, 2, None, "uniform", 9216)])   # grouped counters (ragged tile; uneven split)
 def test_gemm_with_in_launch_activation_quantizer_on_the_cpu(m, k, b, splitk, nq, dist, exp):
     """k_gemm_kq_w12<Q4_K, true, 1024> (EXP bit 10: the first nq work-groups quantize the fp32 activations, a one-way grid barrier
     on a device-coherent counter, then the shipped main loop) on the CPU emulator, work-groups as processes sharing the global
@@ -151,7 +152,7 @@ def test_gemm_with_in_launch_activation_quantizer_on_the_cpu(m, k, b, splitk, nq
     assert mod.run_fuseq(m, k, b, splitk=splitk, nq=nq, dist=dist, exp=exp)     # 3072 = + weight pre-touch under the quantizer (EXP bit 11)
 
 
-@pytest.mark.parametrize("exp", [1024, 3072, 5120])
+@pytest.mark.parametrize("exp", [1024, 3072, 5120, 9216])
 def test_in_launch_quantizer_kernel_does_not_spill(gemm_asm, exp):
     k = "_Z13k_gemm_kq_w12ILi12ELb1ELi%dEEv11gemm_params" % exp
     assert _prop(gemm_asm, k, "private_seg_size") == 0 and _prop(gemm_asm, k, "num_vgpr") <= 168

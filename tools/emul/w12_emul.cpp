@@ -115,18 +115,23 @@ int main(int argc, char **argv) {
         case 100: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, false, 0>(p); }, nblk, 768); break;      // compute waves unpack the scales themselves
         case 32: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 32>(p); }, nblk, 768); break;        // timing ablations (results are garbage): bounds checks only
         case 480: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 480>(p); }, nblk, 768); break;
-        case 1024: case 3072: case 5120: {
+        case 1024: case 3072: case 5120: case 9216: {
             if (argc < 14) { fprintf(stderr, "exp 1024 / 3072 needs: wtype x.bin nq xh_out.bin\n"); return 2; }
             std::vector<uint8_t> x0 = slurp(argv[11]);
             float *xf = (float *)shared_alloc(x0.size()); memcpy(xf, x0.data(), x0.size());
-            unsigned *slots = (unsigned *)shared_alloc(64 * 4); memset(slots, 0, 64 * 4);
-            slots[37] = 123;                                        // the slot this launch must zero for a later one
-            p.xf = xf; p.xf_row = K; p.qcount = slots + 5; p.qzero = slots + 37; p.nq = atoi(argv[12]);
+            unsigned *slots = (unsigned *)shared_alloc(64 * 16 * 4); memset(slots, 0, 64 * 16 * 4);
+            const int ngrp = exp == 9216 ? p.tiles_b * splitk : 1;  // EXP bit 13: one counter per (activation tile, K range) group
+            for (int g = 0; g < ngrp; g++) slots[37 * 16 + g] = 123;  // the words this launch must zero for a later one
+            p.xf = xf; p.xf_row = K; p.qcount = slots + 5 * 16; p.qzero = slots + 37 * 16; p.nq = atoi(argv[12]);
             if (p.nq < 1 || p.nq > (int)nblk) { fprintf(stderr, "nq out of range\n"); return 2; }
             if (exp == 3072) emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 3072>(p); }, nblk, 768);
             else if (exp == 5120) emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 5120>(p); }, nblk, 768);
+            else if (exp == 9216) emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 9216>(p); }, nblk, 768);
             else emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 1024>(p); }, nblk, 768);
-            if (slots[5] != (unsigned)p.nq || slots[37] != 0) { fprintf(stderr, "counter slots: %u (want %d), %u (want 0)\n", slots[5], p.nq, slots[37]); return 4; }
+            for (int g = 0; g < ngrp; g++) {
+                const unsigned want = exp == 9216 ? (unsigned)p.tiles_m : (unsigned)p.nq;
+                if (slots[5 * 16 + g] != want || slots[37 * 16 + g] != 0) { fprintf(stderr, "counter words of group %d: %u (want %u), %u (want 0)\n", g, slots[5 * 16 + g], want, slots[37 * 16 + g]); return 4; }
+            }
             FILE *fo = fopen(argv[13], "wb"); fwrite(xh, 1, xh0.size(), fo); fclose(fo);
             break;
         }
