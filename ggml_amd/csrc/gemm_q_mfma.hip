@@ -771,6 +771,7 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         if constexpr (TYPE == CDNA4_Q4_K) {
             if (exp == 1024 || exp == 3072 || exp == 5120 || exp == 9216) {              // the activation quantizer runs inside the launch (3072: + weight pre-touch; 5120: published by an L2 write-back fence)
                 if (!a.xf) return cdna4_set_error_msg("gemm_q: variant bit 1024 << 16 needs the fp32 activations");
+                if (exp == 9216 && a.variant <= 0 && ((int)grid.x > cu_count() || p.tiles_b * splitk > 16)) exp = 1024;   // auto route: the global counter serves any grid
                 if ((((uintptr_t)a.xf | (uintptr_t)(a.xf_row_elems * 4)) & 15) || (int64_t)a.B * a.K * 2 >= (int64_t)1 << 31)
                     return cdna4_set_error_msg("gemm_q: in-launch quantizer needs 16-byte aligned activation rows and an image below 2 GiB");
                 int dev = 0;
@@ -871,7 +872,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     const bool wide = (variant & 2) != 0;
     // a.xf with variant 0 (auto; capi.hip offers it when CDNA4_FUSEQ is set): fuse if the auto route is k_gemm_kq_w12<Q4_K>, else return 1
     static const int fuseq_env = getenv("CDNA4_FUSEQ") ? atoi(getenv("CDNA4_FUSEQ")) : 0;
-    const int auto_exp = (a.xf && a.variant <= 0) ? (fuseq_env == 2 ? 3072 : 1024) : 0;
+    const int auto_exp = (a.xf && a.variant <= 0) ? (fuseq_env == 2 ? 3072 : (fuseq_env == 3 ? 9216 : 1024)) : 0;   // 3: grouped counters where the grid is resident, else the global counter
     if (a.xf && a.variant <= 0 && !(TYPE == CDNA4_Q4_K && wlds && (variant & 16) && (variant & 4096))) return 1;
     if (a.xf && a.variant > 0 && !(TYPE == CDNA4_Q4_K && wlds && (variant & 16) && (variant & 4096) && !(variant & (1024 | 8192)) && ((variant >> 16) == 1024 || (variant >> 16) == 3072 || (variant >> 16) == 5120 || (variant >> 16) == 9216)))
         return cdna4_set_error_msg("gemm_q: fp32 activations (no prepared image) are accepted by the explicit variant 4119 | 1024 << 16 of Q4_K only");
