@@ -136,7 +136,9 @@ static bool buft_is_cdna4(ggml_backend_buffer_type_t buft) { return buft && buft
 
 // ============================================================================================================
 // op support + dispatch
-static bool is_qweight(ggml_type t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K; }
+// Q5_0 / Q2_K / Q3_K: int8-dot GEMV units only (ggml_cdna4.h); the other five also have the MFMA prefill GEMM
+static bool is_qweight(ggml_type t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K ||
+                                             t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K; }
 
 static bool supports_mul_mat(const ggml_tensor * op) {
     const ggml_tensor * a = op->src[0], * b = op->src[1];
@@ -156,6 +158,9 @@ static bool supports_mul_mat_id(const ggml_tensor * op) {
     if (!is_qweight(as->type) || b->type != GGML_TYPE_F32 || ids->type != GGML_TYPE_I32 || op->type != GGML_TYPE_F32) return false;
     if (!ggml_is_contiguous(as) || !ggml_is_contiguous(b) || !ggml_is_contiguous(op)) return false;
     if (ids->nb[0] != sizeof(int32_t) || as->ne[3] != 1 || b->ne[3] != 1) return false;
+    // what ggml_cdna4_mul_mat_id accepts: any b->ne[1] dividing n_used (slot u reads row u % ne11, as ggml-cpu.c:7752), 16-byte
+    // activation rows (the quantizers load float4)
+    if (b->ne[1] <= 0 || ids->ne[0] % b->ne[1] || b->nb[1] % 16) return false;
     return true;
 }
 

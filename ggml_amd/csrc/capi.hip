@@ -15,11 +15,9 @@ int cdna4_set_error(hipError_t e, const char *file, int line) {
 int cdna4_set_error_msg(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); return -1; }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-// CDNA4_EXTRA_TYPES=1 (experiment knob, default off): Q5_0 / Q2_K / Q3_K through the int8-dot GEMV units of gemv_q.hip (written
-// against the oracle, verified on the CPU emulator, not yet on a GPU); they have no MFMA GEMM, so every batch size takes the GEMV path
-static bool extra_types() { static const bool on = getenv("CDNA4_EXTRA_TYPES") && atoi(getenv("CDNA4_EXTRA_TYPES")) != 0; return on; }
-static inline bool is_kq(int t) { return t == CDNA4_Q4_K || t == CDNA4_Q5_K || t == CDNA4_Q6_K || ((t == CDNA4_Q2_K || t == CDNA4_Q3_K) && extra_types()); }
-static inline bool is_q(int t) { return is_kq(t) || t == CDNA4_Q4_0 || t == CDNA4_Q8_0 || (t == CDNA4_Q5_0 && extra_types()); }
+// Q5_0 / Q2_K / Q3_K run through the int8-dot GEMV units of gemv_q.hip at every batch size (no MFMA GEMM for them yet)
+static inline bool is_kq(int t) { return t == CDNA4_Q4_K || t == CDNA4_Q5_K || t == CDNA4_Q6_K || t == CDNA4_Q2_K || t == CDNA4_Q3_K; }
+static inline bool is_q(int t) { return is_kq(t) || t == CDNA4_Q4_0 || t == CDNA4_Q8_0 || t == CDNA4_Q5_0; }
 
 // workspace carve: [qs int8 B*K][d f32 B*K/qka][bsums i16 B*K/16][xh f16 B*K]
 struct ws_view { int8_t *qs; float *d; int16_t *bsums; void *xh; size_t total; };
@@ -120,34 +118,6 @@ int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float
         g.M = (int)M; g.K = (int)K; g.ncol = 1; g.ids = nullptr;
         return cdna4_launch_gemv_q_fused(g, X, (hipStream_t)stream);
     }
-    if (path == GGML_CDNA4_PATH_GEMM && gemm_variant > 0 && ((gemm_variant >> 16) == 1024 || (gemm_variant >> 16) == 3072 || (gemm_variant >> 16) == 5120 || (gemm_variant >> 16) == 9216)) {
-        // explicit experimental variant: ONE launch — k_gemm_kq_w12<Q4_K> quantizes the activations itself (the image still
-        // lives in the caller's workspace); every route that cannot do that fails in the launcher, nothing falls back silently
-        if (!workspace || ((uintptr_t)workspace & 255)) return cdna4_set_error_msg("mul_mat: workspace must be 256-byte aligned");
-        const ws_view v = carve(type, K, B, workspace);
-        if (workspace_bytes < v.total) return cdna4_set_error_msg("mul_mat: workspace too small");
-        cdna4_gemm_args a{};
-        a.type = type; a.W = (const uint8_t *)W; a.w_row_bytes = w_row_bytes; a.xh = v.xh; a.xh_row_elems = K;
-        a.Y = Y; a.y_row_elems = y_row_stride; a.M = (int)M; a.K = (int)K; a.B = (int)B; a.variant = gemm_variant; a.splitk = splitk;
-        a.xf = X; a.xf_row_elems = x_row_stride;
-        return cdna4_launch_gemm_q(a, (hipStream_t)stream);
-    }
-    {   // CDNA4_FUSEQ=1|2 (experiment knob, default off): offer the fp32 activations to the auto route first — if that route is the
-        // loader-wave Q4_K kernel it quantizes them in-launch (2: + weight pre-touch); otherwise (status 1) the two launches below
-        static const int fuseq_env = getenv("CDNA4_FUSEQ") ? atoi(getenv("CDNA4_FUSEQ")) : 0;
-        if (fuseq_env > 0 && path == GGML_CDNA4_PATH_GEMM && type == CDNA4_Q4_K && gemm_variant <= 0 && B > 64 && workspace && !((uintptr_t)workspace & 255) &&
-            !(((uintptr_t)X | (uintptr_t)(x_row_stride * 4)) & 15) && B * K * 2 < ((int64_t)1 << 31)) {
-            const ws_view v = carve(type, K, B, workspace);
-            if (workspace_bytes >= v.total) {
-                cdna4_gemm_args a{};
-                a.type = type; a.W = (const uint8_t *)W; a.w_row_bytes = w_row_bytes; a.xh = v.xh; a.xh_row_elems = K;
-                a.Y = Y; a.y_row_elems = y_row_stride; a.M = (int)M; a.K = (int)K; a.B = (int)B; a.variant = 0; a.splitk = splitk;
-                a.xf = X; a.xf_row_elems = x_row_stride;
-                const int rc1 = cdna4_launch_gemm_q(a, (hipStream_t)stream);
-                if (rc1 != 1) return rc1;
-            }
-        }
-    }
     int rc = ggml_cdna4_prepare_act(type, X, x_row_stride, K, B, workspace, workspace_bytes, path, stream);
     if (rc) return rc;
     return ggml_cdna4_mul_mat_prepared(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, stream);
@@ -160,7 +130,7 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
     if (!is_q(type)) return cdna4_set_error_msg("mul_mat_id: unsupported weight type");
     if (M <= 0 || n_tok <= 0 || n_used <= 0) return 0;
     if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat_id: K is not a whole number of blocks");
-    if (n_b != n_used && n_b != 1) return cdna4_set_error_msg("mul_mat_id: b.ne[1] must be n_used or 1");
+    if (n_b <= 0 || n_used % n_b) return cdna4_set_error_msg("mul_mat_id: n_used must be a multiple of b.ne[1]");   // ggml_mul_mat_id: ids->ne[0] % b->ne[1] == 0 (src/ggml.c:2747); slot u reads row u % n_b
     if (dst_tok_stride != n_used * dst_row_stride) return cdna4_set_error_msg("mul_mat_id: dst must be contiguous over (slot, token)");
     if (b_tok_stride != n_b * b_row_stride) return cdna4_set_error_msg("mul_mat_id: b must be contiguous over (row, token)");
     const int64_t nact = n_tok * n_b;

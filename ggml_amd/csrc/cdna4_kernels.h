@@ -37,9 +37,6 @@ struct cdna4_gemm_args {
     int M, K, B;
     int variant;                                    // 0 = auto; see gemm_q_mfma.hip
     int splitk;                                     // 0 = auto
-    // non-null: xh is NOT prepared — the GEMM kernel quantizes these fp32 activations (X[b * xf_row_elems + k]) into xh itself
-    // (explicit Q4_K variant 4119 | 1024 << 16 only; any other route fails loudly)
-    const float *xf; int64_t xf_row_elems;
 };
 int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st);
 bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B);

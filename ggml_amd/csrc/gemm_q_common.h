@@ -1,4 +1,4 @@
-// gemm_q_common.h — device-side building blocks shared by the MFMA GEMM kernels (gemm_q_mfma.hip, gemm_q_x4l.hip):
+// gemm_q_common.h — device-side building blocks shared by the MFMA GEMM kernels (gemm_q_mfma.hip, gemm_q_t64.hip):
 // the nibble -> fp16 unpack helpers, the per-format Raw<TYPE> fragment builders, the loader-side re-layout WDirect<TYPE>,
 // the stage geometry WStage<TYPE, SKG> and the kernel parameter block.  Everything here is a template or __forceinline__.
 #pragma once
@@ -452,11 +452,7 @@ struct gemm_params {
     int xchg_l2;                                        // split-K exchange through the XCD's L2 (partners co-located) instead of write-through
     int tune;                                           // experiment bits from CDNA4_TUNE (bit0: static s_setprio 1 for the khalf-1 waves)
     float *partial; unsigned *flags; unsigned epoch;   // split-K = 2 exchange (k_gemm_kq_w8): exported half tiles [tile][ks][64][128], one flag per (tile, ks), this launch's tag
-    unsigned long long *trace;   // profiling builds only (k_gemm_kq_w8<TYPE, true>): per-phase s_memtime stamps of block 0    // k_gemm_kq_w12 with the activation quantizer inside the launch (EXP bit 10; appended last so that no other kernel's
-    // argument offsets move): fp32 activations X[b * xf_row + k]; work-groups blockIdx < nq quantize B * K / 16 chunks into xh,
-    // add 1 to *qcount each, and every work-group waits for *qcount == nq before its first load of xh; work-group 0 zeroes
-    // *qzero (the counter slot a launch 32 tags from now will use)
-    const float *xf; int64_t xf_row; unsigned *qcount; unsigned *qzero; int nq;
+    unsigned long long *trace;   // profiling builds only (k_gemm_kq_w8<TYPE, true>): per-phase s_memtime stamps of block 0
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -488,4 +484,3 @@ template <> struct WStage<CDNA4_Q6_KS, 2> { static constexpr int NPH = 9; __devi
 void *cdna4_gemm_scratch(size_t bytes, int kind);      // per-device scratch, zero-filled when (re)allocated; kind 0: split-K exchange, 1: repacked weights
 unsigned cdna4_gemm_next_epoch();                      // the per-launch tag of the exchange flags (never 0)
 int cdna4_gemm_cu_count();
-int cdna4_launch_gemm_q4k_x4l(const cdna4_gemm_args &a, int splitk, int form, hipStream_t st);   // gemm_q_x4l.hip (experimental)

@@ -690,26 +690,12 @@ static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: sp
     g_scratch[dev] = ptr; g_scratch_bytes[dev] = want;
     return ptr;
 }
-static int cu_count() {
-    static int n = 0;
-    if (!n) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; else n = 1; }
-    return n;
-}
-
-// counter slots of the in-launch activation quantizer (k_gemm_kq_w12, EXP bit 10): 64 slots of 16 words per device, zeroed once;
-// launch `tag` counts in slot tag % 64 (word 0, or one word per group with EXP bit 13) and zeroes slot (tag + 32) % 64, whose last
-// user finished 32 stream-ordered launches ago
-static unsigned *g_qslots[16] = {nullptr}; static unsigned g_qtag[16] = {0};
-static unsigned *get_qslots(int &dev) {
-    dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
-    if (!g_qslots[dev]) {
-        void *ptr = nullptr;
-        if (hipMalloc(&ptr, 64 * 16 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipMemset(ptr, 0, 64 * 16 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); return nullptr; }
-        g_qslots[dev] = (unsigned *)ptr;
-    }
-    return g_qslots[dev];
+static int cu_count() {                                            // of the CURRENT device (cached per device)
+    static int n[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 1; }
+    if (!n[dev]) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n[dev] = pr.multiProcessorCount; else { (void)hipGetLastError(); n[dev] = 1; } }
+    return n[dev];
 }
 
 void *cdna4_gemm_scratch(size_t bytes, int kind) { return get_scratch(bytes, kind); }
@@ -763,33 +749,7 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
         if ((opt == 64 || opt == 65) && min_nsb < 3) opt = 20;
     }
-    if (a.xf && !(opt == 65 && (exp == 1024 || exp == 3072 || exp == 5120 || exp == 9216) && TYPE == CDNA4_Q4_K)) {
-        if (a.variant <= 0) return 1;                                     // auto: "not fused, nothing launched that matters" — the caller prepares the image and calls again
-        return cdna4_set_error_msg("gemm_q: the in-launch activation quantizer exists for k_gemm_kq_w12<Q4_K> only (>= 3 superblocks of K per work-group)");
-    }
     if (opt == 65) {                                                      // + loader waves
-        if constexpr (TYPE == CDNA4_Q4_K) {
-            if (exp == 1024 || exp == 3072 || exp == 5120 || exp == 9216) {              // the activation quantizer runs inside the launch (3072: + weight pre-touch; 5120: published by an L2 write-back fence)
-                if (!a.xf) return cdna4_set_error_msg("gemm_q: variant bit 1024 << 16 needs the fp32 activations");
-                if (exp == 9216 && a.variant <= 0 && ((int)grid.x > cu_count() || p.tiles_b * splitk > 16)) exp = 1024;   // auto route: the global counter serves any grid
-                if ((((uintptr_t)a.xf | (uintptr_t)(a.xf_row_elems * 4)) & 15) || (int64_t)a.B * a.K * 2 >= (int64_t)1 << 31)
-                    return cdna4_set_error_msg("gemm_q: in-launch quantizer needs 16-byte aligned activation rows and an image below 2 GiB");
-                int dev = 0;
-                unsigned *slots = get_qslots(dev);
-                if (!slots) return cdna4_set_error_msg("gemm_q: cannot allocate the quantizer's counter slots");
-                const unsigned tag = g_qtag[dev]++;
-                p.xf = a.xf; p.xf_row = a.xf_row_elems; p.qcount = slots + (tag & 63) * 16; p.qzero = slots + ((tag + 32) & 63) * 16;
-                p.nq = (int)grid.x < cu_count() ? (int)grid.x : cu_count();
-                if (exp == 3072) hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 3072>), grid, dim3(768), 0, st, p);
-                else if (exp == 5120) hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 5120>), grid, dim3(768), 0, st, p);
-                else if (exp == 9216) {                                   // one counter per (activation tile, K range) group: needs the whole grid resident
-                    if ((int)grid.x > cu_count() || p.tiles_b * splitk > 16) return cdna4_set_error_msg("gemm_q: the grouped in-launch quantizer needs a grid of at most #CUs work-groups and at most 16 groups");
-                    hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 9216>), grid, dim3(768), 0, st, p);
-                }
-                else hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, 1024>), grid, dim3(768), 0, st, p);
-                CDNA4_CHECK_LAUNCH(); return 0;
-            }
-        }
         static const bool no_tab = getenv("CDNA4_NO_TAB") != nullptr;       // A/B knob: compute waves unpack the scales themselves
         // experiment bits of k_gemm_kq_w12 (variant bits 16+ or CDNA4_W12_EXP), built in -DCDNA4_ABLATIONS libraries
         // (tools/microbench) only: 1 = early table read (bit-identical, measured: no gain), 16.. = timing-only ablations
@@ -863,19 +823,13 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     // slice-per-barrier kernel instead of the pipelined one, bit4 = the 8-wave (two waves per SIMD) 128x128 kernel,
     // bits 5-9 = that kernel's schedule option OPT (see k_gemm_kq_w8; 20 = in-wave pipeline with the DMA pieces split over both phases),
     // bit10 = the 256x128-tile kernel k_gemm_kq_x2, bit11 = the cross-stage pipelined k_gemm_kq_w8p (the default),
-    // bit12 = k_gemm_kq_w12 = w8p + four loader waves (the default for Q4_K), bit13 = the experimental k_gemm_q4k_x4l (gemm_q_x4l.hip).
+    // bit12 = k_gemm_kq_w12 = w8p + four loader waves (the default for Q4_K).
     // 0 = auto: widest tile that the batch fills.
     int variant = a.variant;
     // (Q5_K on the loader-wave kernel: 31.0 vs 30.65 us — its larger Raw<> spills 32 B at 168 VGPRs — so it stays on k_gemm_kq_w8p)
     if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? (16 | (TYPE == CDNA4_Q4_K ? 4096 : 2048)) : 0);   // cross-stage pipeline; Q4_K: + loader waves (k_gemm_kq_w12: 168 VGPRs without spills only for this format)
     const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
     const bool wide = (variant & 2) != 0;
-    // a.xf with variant 0 (auto; capi.hip offers it when CDNA4_FUSEQ is set): fuse if the auto route is k_gemm_kq_w12<Q4_K>, else return 1
-    static const int fuseq_env = getenv("CDNA4_FUSEQ") ? atoi(getenv("CDNA4_FUSEQ")) : 0;
-    const int auto_exp = (a.xf && a.variant <= 0) ? (fuseq_env == 2 ? 3072 : (fuseq_env == 3 ? 9216 : 1024)) : 0;   // 3: grouped counters where the grid is resident, else the global counter
-    if (a.xf && a.variant <= 0 && !(TYPE == CDNA4_Q4_K && wlds && (variant & 16) && (variant & 4096))) return 1;
-    if (a.xf && a.variant > 0 && !(TYPE == CDNA4_Q4_K && wlds && (variant & 16) && (variant & 4096) && !(variant & (1024 | 8192)) && ((variant >> 16) == 1024 || (variant >> 16) == 3072 || (variant >> 16) == 5120 || (variant >> 16) == 9216)))
-        return cdna4_set_error_msg("gemm_q: fp32 activations (no prepared image) are accepted by the explicit variant 4119 | 1024 << 16 of Q4_K only");
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
     const int kunits = QT<TYPE>::KQ ? a.K / 256 : a.K / 64;
     int splitk = a.splitk;
@@ -886,17 +840,12 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         const int tiles = ((a.M + 127) / 128) * ((a.B + (wide ? 127 : 63)) / (wide ? 128 : 64));
         if (variant & 16) splitk = (tiles * 2 <= cu_count() && kunits % 2 == 0 && kunits >= 4) ? 2 : 1;   // hand-off split: only if co-resident
         else splitk = 1;
-        // CDNA4_ODD_SPLIT=1 (experiment knob, default off until measured on the GPU): an ODD number of superblocks — K = 11008 = 43 x 256,
-        // BASELINE configs[2] — also takes the hand-off split; its two work-groups get sb_split / total - sb_split superblocks
-        // (22 / 21), which the exchange was written for (launch_w8: p.sb_split) and the CPU emulator runs (tests)
-        static const bool odd_split = getenv("CDNA4_ODD_SPLIT") && atoi(getenv("CDNA4_ODD_SPLIT")) != 0;
-        if (odd_split && (variant & 16) && wlds && QT<TYPE>::KQ && tiles * 2 <= cu_count() && (kunits & 1) && kunits >= 7) { splitk = 2; uneven = true; }
-    }
-    if constexpr (TYPE == CDNA4_Q5_K) {
-        if (wlds && a.variant > 0 && (variant & 8192) && (variant & 16384)) return cdna4_launch_gemm_q4k_x4l(a, a.splitk, 1, st);   // experimental, explicit only
+        // An ODD number of superblocks — K = 11008 = 43 x 256, BASELINE configs[2] — also takes the hand-off split: its two
+        // work-groups get sb_split / total - sb_split superblocks (22 / 21), which the exchange was written for (launch_w8:
+        // p.sb_split).  Measured on MI355X (round-1 driver run): rel-L2 7.2e-7 vs the unsplit kernel, 59.7 vs 69.6 us.
+        if ((variant & 16) && wlds && QT<TYPE>::KQ && tiles * 2 <= cu_count() && (kunits & 1) && kunits >= 7) { splitk = 2; uneven = true; }
     }
     if constexpr (TYPE == CDNA4_Q4_K) {
-        if (wlds && a.variant > 0 && (variant & 8192)) return cdna4_launch_gemm_q4k_x4l(a, a.splitk, (variant & 16384) ? 1 : ((variant & 32768) ? 2 : 0), st);   // experimental loader-wave kernels (explicit only): 256x128 tile with 4 compute waves; bit14: 128x128; bit15: 256x128 with 8 compute waves
         if (wlds && (variant & 1024)) return launch_x2<TYPE>(a, a.splitk, st);
         // auto: the 256x128 tile kernel needs half the activation bytes per MFMA, but its deeper tiles only pay off once the
         // grid is at least two full waves of work-groups without any K split (measured: C5 32768x8192x512 272 vs 318 us =
@@ -904,11 +853,10 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         static const bool no_x2 = getenv("CDNA4_NO_X2") != nullptr;
         if (wlds && a.variant <= 0 && a.splitk <= 0 && a.B > 64 && !no_x2) {
             const int tx = ((a.M + 255) / 256) * ((a.B + 127) / 128);
-            if (tx >= 2 * cu_count()) { if (a.xf) return 1; return launch_x2<TYPE>(a, 1, st); }
+            if (tx >= 2 * cu_count()) return launch_x2<TYPE>(a, 1, st);
         }
     }
     if (splitk < 1 || (kunits % splitk && !uneven)) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
-    if constexpr (TYPE != CDNA4_Q4_K) { if (a.xf) return a.variant <= 0 ? 1 : cdna4_set_error_msg("gemm_q: in-launch quantizer: Q4_K only"); }
     if constexpr (TYPE == CDNA4_Q4_0 || TYPE == CDNA4_Q8_0 || TYPE == CDNA4_Q6_K) {
         // 2-byte-aligned formats at prefill batch sizes: re-lay the weights into 16-byte-aligned superblocks (scratch, per
         // call: one extra read+write of W, ~5 us at 4096x4096) and run the LDS-DMA pipeline on that — 2.5-3x faster
@@ -944,7 +892,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         }
     }
     if constexpr (CAN_LDS) {
-        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant & 4096) ? 65 : ((variant & 2048) ? 64 : ((variant >> 5) & 31)), st, auto_exp ? auto_exp : variant >> 16);
+        if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant & 4096) ? 65 : ((variant & 2048) ? 64 : ((variant >> 5) & 31)), st, variant >> 16);
         if (wlds && !(variant & 8)) return wide ? launch_pipe<TYPE, 4>(a, splitk, st) : launch_pipe<TYPE, 2>(a, splitk, st);
         if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
     }

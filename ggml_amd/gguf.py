@@ -155,7 +155,7 @@ class GGUFFile:
         if self._L.ggml_cdna4_gguf_upload(self._h, i, dst.data_ptr(), dst.numel() * dst.element_size(), stream) != 0:
             raise GGUFError(self._L.ggml_cdna4_last_error().decode())
 
-    def qtensor(self, name_or_id, device=None):
+    def qtensor(self, name_or_id, device="cuda"):
         """the 2-D quantized weight `name` in HBM as an ops.QTensor ([K, M] in ggml order: ne0 = K contiguous, ne1 = M rows)"""
         from . import ops
         t = self.tensors[self.tensor_id(name_or_id)]

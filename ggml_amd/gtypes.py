@@ -6,7 +6,10 @@ class GGMLType(enum.IntEnum):
     F32 = 0
     F16 = 1
     Q4_0 = 2
+    Q5_0 = 6
     Q8_0 = 8
+    Q2_K = 10
+    Q3_K = 11
     Q4_K = 12
     Q5_K = 13
     Q6_K = 14
@@ -15,10 +18,13 @@ class GGMLType(enum.IntEnum):
 
 
 _TYPE_SIZE = {GGMLType.F32: 4, GGMLType.F16: 2, GGMLType.Q4_0: 18, GGMLType.Q8_0: 34, GGMLType.Q4_K: 144,
-              GGMLType.Q5_K: 176, GGMLType.Q6_K: 210, GGMLType.Q8_K: 292, GGMLType.I32: 4}
+              GGMLType.Q5_K: 176, GGMLType.Q6_K: 210, GGMLType.Q8_K: 292, GGMLType.I32: 4,
+              GGMLType.Q5_0: 22, GGMLType.Q2_K: 84, GGMLType.Q3_K: 110}
 _BLCK = {GGMLType.F32: 1, GGMLType.F16: 1, GGMLType.Q4_0: 32, GGMLType.Q8_0: 32, GGMLType.Q4_K: 256,
-         GGMLType.Q5_K: 256, GGMLType.Q6_K: 256, GGMLType.Q8_K: 256, GGMLType.I32: 1}
-QUANT_WEIGHT_TYPES = (GGMLType.Q4_0, GGMLType.Q8_0, GGMLType.Q4_K, GGMLType.Q5_K, GGMLType.Q6_K)
+         GGMLType.Q5_K: 256, GGMLType.Q6_K: 256, GGMLType.Q8_K: 256, GGMLType.I32: 1,
+         GGMLType.Q5_0: 32, GGMLType.Q2_K: 256, GGMLType.Q3_K: 256}
+# Q5_0 / Q2_K / Q3_K: int8-dot GEMV units only (every batch size takes the GEMV path)
+QUANT_WEIGHT_TYPES = (GGMLType.Q4_0, GGMLType.Q8_0, GGMLType.Q4_K, GGMLType.Q5_K, GGMLType.Q6_K, GGMLType.Q5_0, GGMLType.Q2_K, GGMLType.Q3_K)
 
 
 def blck_size(t):

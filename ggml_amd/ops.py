@@ -60,6 +60,19 @@ def _need_gpu(t, what):
         raise native.NativeError("%s must be a GPU tensor (there is no CPU path)" % what)
 
 
+def _same_device(dev, **tensors):
+    """the library keys its per-device state (split-K scratch, CU count) on the CURRENT device: every operand must live on
+    the device the call is issued for, and the call is issued with that device current"""
+    for name, t in tensors.items():
+        if t is not None and t.device != dev:
+            raise ValueError("%s lives on %s, expected %s" % (name, t.device, dev))
+
+
+def _check_out(out, B, M, dev):
+    if out.dtype != torch.float32 or out.dim() != 2 or tuple(out.shape) != (B, M) or out.stride(1) != 1 or out.device != dev:
+        raise ValueError("out must be float32 (%d, %d) with contiguous rows on %s" % (B, M, dev))
+
+
 def mul_mat(a: QTensor, b: torch.Tensor, out=None, path=PATH_AUTO, gemm_variant=0, splitk=0):
     """ggml_mul_mat(a, b) for quantized a, f32 b of shape (B, K).  Returns f32 (B, M)."""
     L = native.lib()
@@ -68,13 +81,17 @@ def mul_mat(a: QTensor, b: torch.Tensor, out=None, path=PATH_AUTO, gemm_variant=
         raise ValueError("b must be float32 (B, K=%d) with contiguous rows" % a.K)   # ggml_can_mul_mat, src/ggml.c:2686
     B = b.shape[0]
     dev = b.device
+    _same_device(dev, a=a.data)
     if out is None:
         out = torch.empty((B, a.M), dtype=torch.float32, device=dev)
+    else:
+        _check_out(out, B, a.M, dev)
     nws = L.ggml_cdna4_mul_mat_workspace_size(int(a.type), a.K, max(B, 1))
     ws = _workspace(dev, nws)
-    native.check(L.ggml_cdna4_mul_mat(int(a.type), a.data.data_ptr(), a.row_bytes, b.data_ptr(), b.stride(0),
-                                      out.data_ptr(), out.stride(0), a.M, a.K, B, ws.data_ptr(), ws.numel(),
-                                      path, gemm_variant, splitk, _stream(dev)))
+    with torch.cuda.device(dev):
+        native.check(L.ggml_cdna4_mul_mat(int(a.type), a.data.data_ptr(), a.row_bytes, b.data_ptr(), b.stride(0),
+                                          out.data_ptr(), out.stride(0), a.M, a.K, B, ws.data_ptr(), ws.numel(),
+                                          path, gemm_variant, splitk, _stream(dev)))
     return out
 
 
@@ -88,8 +105,9 @@ class PreparedAct:
         self.type, self.B, self.K, self.path = GGMLType(wtype), b.shape[0], b.shape[1], path
         n = L.ggml_cdna4_mul_mat_workspace_size(int(self.type), self.K, max(self.B, 1))
         self.ws = torch.empty(n, dtype=torch.uint8, device=b.device)
-        native.check(L.ggml_cdna4_prepare_act(int(self.type), b.data_ptr(), b.stride(0), self.K, self.B,
-                                              self.ws.data_ptr(), self.ws.numel(), path, _stream(b.device)))
+        with torch.cuda.device(b.device):
+            native.check(L.ggml_cdna4_prepare_act(int(self.type), b.data_ptr(), b.stride(0), self.K, self.B,
+                                                  self.ws.data_ptr(), self.ws.numel(), path, _stream(b.device)))
 
 
 def mul_mat_prepared(a: QTensor, act: PreparedAct, out=None, path=None, gemm_variant=0, splitk=0):
@@ -97,11 +115,15 @@ def mul_mat_prepared(a: QTensor, act: PreparedAct, out=None, path=None, gemm_var
     if act.K != a.K:
         raise ValueError("K mismatch")
     dev = act.ws.device
+    _same_device(dev, a=a.data)
     if out is None:
         out = torch.empty((act.B, a.M), dtype=torch.float32, device=dev)
-    native.check(L.ggml_cdna4_mul_mat_prepared(int(a.type), a.data.data_ptr(), a.row_bytes, out.data_ptr(), out.stride(0),
-                                               a.M, a.K, act.B, act.ws.data_ptr(), act.ws.numel(),
-                                               act.path if path is None else path, gemm_variant, splitk, _stream(dev)))
+    else:
+        _check_out(out, act.B, a.M, dev)
+    with torch.cuda.device(dev):
+        native.check(L.ggml_cdna4_mul_mat_prepared(int(a.type), a.data.data_ptr(), a.row_bytes, out.data_ptr(), out.stride(0),
+                                                   a.M, a.K, act.B, act.ws.data_ptr(), act.ws.numel(),
+                                                   act.path if path is None else path, gemm_variant, splitk, _stream(dev)))
     return out
 
 
@@ -119,7 +141,9 @@ def mul_mat_id(as_: "list[QTensor] | QTensor", b: torch.Tensor, ids: torch.Tenso
     ws = _workspace(b.device, nws)
     b = b.contiguous()
     ids = ids.to(torch.int32).contiguous()
-    native.check(L.ggml_cdna4_mul_mat_id(int(a.type), a.data.data_ptr(), a.row_bytes, M * a.row_bytes,
+    _same_device(b.device, a=a.data, ids=ids)
+    with torch.cuda.device(b.device):
+      native.check(L.ggml_cdna4_mul_mat_id(int(a.type), a.data.data_ptr(), a.row_bytes, M * a.row_bytes,
                                          b.data_ptr(), b.stride(1), b.stride(0), ids.data_ptr(), ids.stride(0),
                                          out.data_ptr(), out.stride(1), out.stride(0), M, K, n_expert, n_used, n_b, n_tok,
                                          ws.data_ptr(), ws.numel(), _stream(b.device)))

@@ -35,6 +35,8 @@ extern "C" {
 enum ggml_cdna4_type {
     GGML_CDNA4_TYPE_F32 = 0, GGML_CDNA4_TYPE_F16 = 1, GGML_CDNA4_TYPE_Q4_0 = 2, GGML_CDNA4_TYPE_Q8_0 = 8,
     GGML_CDNA4_TYPE_Q4_K = 12, GGML_CDNA4_TYPE_Q5_K = 13, GGML_CDNA4_TYPE_Q6_K = 14,
+    /* MUL_MAT / MUL_MAT_ID only, through the int8-dot GEMV units at every batch size (no MFMA GEMM, no dequantize_row yet) */
+    GGML_CDNA4_TYPE_Q5_0 = 6, GGML_CDNA4_TYPE_Q2_K = 10, GGML_CDNA4_TYPE_Q3_K = 11,
 };
 
 /* which kernel family ggml_cdna4_mul_mat uses */
@@ -59,7 +61,7 @@ size_t ggml_cdna4_mul_mat_workspace_size(int type, int64_t K, int64_t n_act_rows
 
 /*
  * Y[b * y_row_stride + m] = sum_k W[m][k] * X[b * x_row_stride + k],  m < M, b < B.
- *   W: M rows of K block-quantized weights (type in {Q4_0,Q8_0,Q4_K,Q5_K,Q6_K}), row stride w_row_bytes.
+ *   W: M rows of K block-quantized weights (type in {Q4_0,Q8_0,Q4_K,Q5_K,Q6_K} + GEMV-only {Q5_0,Q2_K,Q3_K}), row stride w_row_bytes.
  *   X: f32, Y: f32; strides in ELEMENTS.  workspace: >= ggml_cdna4_mul_mat_workspace_size(type, K, B) bytes,
  *   256-byte aligned.  path: enum ggml_cdna4_path.  gemm_variant / splitk: 0 = auto (tuning knobs; the bit
  *   layout of gemm_variant is documented at launch_type() in ggml_amd/csrc/gemm_q_mfma.hip).
@@ -90,7 +92,7 @@ int ggml_cdna4_mul_mat_prepared(int type, const void * W, int64_t w_row_bytes,
 /*
  * MUL_MAT_ID (mixture-of-experts routing), include/ggml.h ggml_mul_mat_id:
  *   as : n_expert matrices of M rows x K weights, expert stride w_expert_bytes
- *   b  : f32 [n_tok][n_b][K]   (n_b == n_used or 1; slot u reads row u % n_b)   strides in elements
+ *   b  : f32 [n_tok][n_b][K]   (n_used % n_b == 0; slot u reads row u % n_b)     strides in elements
  *   ids: i32 [n_tok][n_used]   (device memory; never copied to the host)        stride in elements
  *   dst: f32 [n_tok][n_used][M]
  * n_tok == 1 (decode) runs as ONE launch with the activation quantizer inside the GEMV (workspace untouched);

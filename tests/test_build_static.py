@@ -64,54 +64,8 @@ def test_two_waves_per_simd_kernels_fit_256_registers(gemm_asm):
         assert _prop(gemm_asm, k, "num_vgpr") + _prop(gemm_asm, k, "num_agpr") <= 256
 
 
-def test_experimental_4plus4_wave_kernel_resources(tmp_path):
-    """gemm_q_x4l.hip (not selected by default): 8 waves = 2 per SIMD -> 256 registers, no scratch, three 52-KB slots"""
-    if not os.path.exists(HIPCC):
-        pytest.skip("hipcc not available")
-    out = tmp_path / "x4l.s"
-    src = os.path.join(ROOT, "ggml_amd", "csrc", "gemm_q_x4l.hip")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out), src],
-                   check=True, capture_output=True, timeout=900)
-    asm = out.read_text()
-    # 256x128 (4 compute waves), 128x128, 256x128 (8 compute waves: 12 waves -> 168 registers), Q5_K 128x128
-    for nmb, ncw, regs, typ in ((2, 4, 256, 12), (1, 4, 256, 12), (1, 8, 168, 12), (1, 4, 256, 13)):
-        for s in (1, 2, 4):
-            k = "_Z14k_gemm_q4k_x4lILi%dELi%dELi%dELi%dEEv11gemm_params" % (s, nmb, ncw, typ)
-            assert _prop(asm, k, "private_seg_size") == 0
-            assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= regs
-            assert _lds(asm, k) <= 160 * 1024
-
-
-def test_experimental_kernel_data_movement_emulation():
-    """tools/emul/x4l_layout_check.py: the loader -> LDS -> fragment -> MFMA index formulas of gemm_q_x4l.hip, transcribed and
-    run on the CPU, reproduce a direct product of the same fp16 operands exactly (every (b, m) sees every k once, with the
-    activation and the weight of the SAME k in every MFMA slot)"""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("x4l_layout_check", os.path.join(ROOT, "tools", "emul", "x4l_layout_check.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    assert mod.main(M=256, B=128, K=512, seed=1) < 1e-12
-    assert mod.main(M=200, B=100, K=768, seed=2) < 1e-12          # ragged edges: clamped rows only add work, never wrong sums
-
-
-@pytest.mark.parametrize("rows128", [0, 1, 2])      # the kernel's three forms: 256x128 / 4 compute waves, 128x128 / 4, 256x128 / 8
-@pytest.mark.parametrize("m,k,b,splitk", [(256, 512, 128, 1), (300, 768, 200, 1), (513, 1024, 129, 2), (256, 2048, 128, 4), (700, 2560, 90, 4)])
-def test_experimental_kernel_source_runs_correctly_on_the_cpu(m, k, b, splitk, rows128):
-    """tools/emul: the C++ of k_gemm_q4k_x4l itself, compiled for the host and executed one OS thread per GPU thread (LDS-DMA
-    and waits made synchronous, v_mfma emulated lane for lane, one process per work-group so that the split-K exchange runs
-    between co-resident work-groups) reproduces a direct product of the same fp16 operands — loop bounds, loader vs compute
-    barrier counts (a mismatch would hang: timeout), indexing, ragged edges, uneven K splits, the 2- and 4-way exchange"""
-    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
-        pytest.skip("ROCm clang not available")
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    assert mod.run(m, k, b, seed=m + k, timeout=300, splitk=splitk, exp=rows128) < 1e-6
-
-
 @pytest.mark.parametrize("m,k,b,splitk,exp,l2", [(300, 1536, 200, 1, 0, 1), (256, 2048, 128, 2, 0, 1), (256, 2048, 128, 2, 0, 0), (256, 1024, 128, 1, 100, 1),
-                                              (256, 1792, 128, 2, 0, 1), (300, 2304, 200, 2, 0, 0),          # ODD superblock counts: uneven 4 / 3 and 5 / 4 hand-off splits (CDNA4_ODD_SPLIT)
+                                              (256, 1792, 128, 2, 0, 1), (300, 2304, 200, 2, 0, 0),          # ODD superblock counts: uneven 4 / 3 and 5 / 4 hand-off splits (the default route for odd counts)
                                               (513, 3072, 129, 2, 1, 1), (513, 3072, 129, 2, 2, 0), (300, 1536, 200, 1, 4, 1), (256, 2048, 128, 2, 6, 1)])
 def test_shipped_12_wave_kernel_source_and_its_candidates_on_the_cpu(m, k, b, splitk, exp, l2):
     """tools/emul/w12_emul: the source of k_gemm_kq_w12 (+ the shared epilogue) executed on the CPU.  exp 0 is the shipped
@@ -122,7 +76,7 @@ def test_shipped_12_wave_kernel_source_and_its_candidates_on_the_cpu(m, k, b, sp
         pytest.skip("ROCm clang not available")
     import importlib.util
     import numpy as np
-    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
+    spec = importlib.util.spec_from_file_location("emul_check", os.path.join(ROOT, "tools", "emul", "emul_check.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     err, y = mod.run(m, k, b, seed=5, timeout=600, splitk=splitk, kernel="w12", exp=exp, xchg_l2=l2, return_y=True)
@@ -132,33 +86,7 @@ def test_shipped_12_wave_kernel_source_and_its_candidates_on_the_cpu(m, k, b, sp
         assert np.array_equal(y, y0)
 
 
-@pytest.mark.parametrize("m,k,b,splitk,nq,dist,exp", [(256, 2048, 128, 2, 3, "uniform", 1024), (256, 1024, 256, 1, 1, "ties", 1024), (513, 3072, 129, 2, 5, "uniform", 3072),
-                                                      (300, 1536, 200, 1, None, "uniform", 5120), (256, 1792, 128, 2, None, "uniform", 1024),   # odd superblock count, uneven split
-                                                      (300, 1536, 200, 1, None, "uniform", 9216), (256, 1792, 256, 2, None, "uniform", 9216)])   # grouped counters (ragged tile; uneven split)
-def test_gemm_with_in_launch_activation_quantizer_on_the_cpu(m, k, b, splitk, nq, dist, exp):
-    """k_gemm_kq_w12<Q4_K, true, 1024> (EXP bit 10: the first nq work-groups quantize the fp32 activations, a one-way grid barrier
-    on a device-coherent counter, then the shipped main loop) on the CPU emulator, work-groups as processes sharing the global
-    buffers: the fp16 image it writes equals fp16(d q) of the oracle's Q8_K rows and its output equals the shipped kernel's on
-    that image, BIT FOR BIT; the counter slot ends at nq and the slot it must recycle is zero.  The image buffer starts as
-    NaNs.  (Cache coherence between XCDs is the part only the GPU can show: opt-in test in test_gpu_parity.py.)"""
-    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
-        pytest.skip("ROCm clang not available")
-    import importlib.util
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "tools", "emul"))
-    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    assert mod.run_fuseq(m, k, b, splitk=splitk, nq=nq, dist=dist, exp=exp)     # 3072 = + weight pre-touch under the quantizer (EXP bit 11)
-
-
-@pytest.mark.parametrize("exp", [1024, 3072, 5120, 9216])
-def test_in_launch_quantizer_kernel_does_not_spill(gemm_asm, exp):
-    k = "_Z13k_gemm_kq_w12ILi12ELb1ELi%dEEv11gemm_params" % exp
-    assert _prop(gemm_asm, k, "private_seg_size") == 0 and _prop(gemm_asm, k, "num_vgpr") <= 168
-
-
-@pytest.mark.parametrize("kernel,m,k,b,splitk,exp", [("x4l", 300, 1536, 200, 1, 0), ("x4l", 256, 2048, 128, 4, 0), ("x4l", 300, 1536, 200, 2, 1), ("x4l", 300, 1536, 200, 2, 2), ("w12", 300, 1536, 200, 1, 0), ("w12", 256, 2048, 128, 2, 0)])
+@pytest.mark.parametrize("kernel,m,k,b,splitk,exp", [("w12", 300, 1536, 200, 1, 0), ("w12", 256, 2048, 128, 2, 0)])
 def test_counted_vmcnt_waits_are_sufficient_and_tight(kernel, m, k, b, splitk, exp, monkeypatch):
     """EMU_DEFER_DMA=1: every LDS-DMA copy lands as LATE as the hardware permits — only when an s_waitcnt vmcnt(n) of the issuing
     wave retires it, in order — so a missing or too-weak wait leaves stale bytes in LDS.  Both kernels pass as written, and fail
@@ -166,7 +94,7 @@ def test_counted_vmcnt_waits_are_sufficient_and_tight(kernel, m, k, b, splitk, e
     if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
         pytest.skip("ROCm clang not available")
     import importlib.util
-    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
+    spec = importlib.util.spec_from_file_location("emul_check", os.path.join(ROOT, "tools", "emul", "emul_check.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(m, k, b, seed=3, timeout=600, splitk=splitk, kernel=kernel, exp=exp, defer_dma=True) < 1e-6
@@ -182,7 +110,7 @@ def test_no_out_of_bounds_access_at_the_shape_that_faulted_on_the_gpu(tmp_path):
         pytest.skip("ROCm clang not available")
     import importlib.util
     import numpy as np
-    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
+    spec = importlib.util.spec_from_file_location("emul_check", os.path.join(ROOT, "tools", "emul", "emul_check.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     M, K, B = 8192, 8192, 512
@@ -245,19 +173,6 @@ def test_asynchronous_register_loads_are_not_read_before_their_wait(gemm_asm):
         assert n > 0 and not bad, (k, bad[:3])
 
 
-@pytest.mark.parametrize("m,k,b,splitk", [(128, 512, 128, 1), (300, 1536, 200, 1), (513, 1024, 129, 2), (700, 2560, 90, 4)])
-def test_experimental_kernel_q5_k_form_on_the_cpu(m, k, b, splitk):
-    """the Q5_K instantiation of the experimental kernel (128 x 128 form: fifth-bit planes staged in their own swizzled area)"""
-    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
-        pytest.skip("ROCm clang not available")
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    for defer in (False, True):
-        assert mod.run(m, k, b, seed=m + k, timeout=300, splitk=splitk, exp=1, wtype=13, defer_dma=defer) < 1e-6
-
-
 @pytest.mark.parametrize("cfg", [0, 1])                       # 4 waves x 1 row, 8 waves x 2 rows (the M >= 4096 default)
 @pytest.mark.parametrize("t", [12, 13, 14, 2, 8, 6, 10, 11])  # Q4_K, Q5_K, Q6_K, Q4_0, Q8_0 + the units not yet behind the C-ABI: Q5_0, Q2_K, Q3_K
 def test_decode_kernel_source_on_the_cpu(t, cfg):
@@ -281,7 +196,7 @@ def test_8_wave_kernel_sources_on_the_cpu(kern, wtype, m, k, b, splitk):
     if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
         pytest.skip("ROCm clang not available")
     import importlib.util
-    spec = importlib.util.spec_from_file_location("x4l_emul_check", os.path.join(ROOT, "tools", "emul", "x4l_emul_check.py"))
+    spec = importlib.util.spec_from_file_location("emul_check", os.path.join(ROOT, "tools", "emul", "emul_check.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     for defer in (False, True):

@@ -1,9 +1,9 @@
-"""Runs the kernel SOURCE of gemm_q_x4l.hip (x4l_emul) or of the shipped 12-wave kernel and its experiment variants (w12_emul)
-on the CPU (built from *_emul.cpp with the ROCm clang as a HOST compiler) and compares its output with a direct product of the same fp16 operands.  Complements
-x4l_layout_check.py (formulas transcribed into Python): here the C++ of the kernel itself executes — loop bounds, barrier
+"""Runs kernel SOURCES on the CPU: tools/emul/<name>_emul.cpp includes a kernel of ggml_amd/csrc and is built with the ROCm
+clang as a HOST compiler (hip_emul.h: one OS thread per GPU thread, MFMA / LDS-DMA / counted waits emulated); the output is
+compared with a direct product of the same fp16 operands.  What executes is the C++ of the kernel itself — loop bounds, barrier
 counts of loader vs compute waves (a mismatch hangs: callers use a timeout), register-array indexing, the epilogue.
 
-    python tools/emul/x4l_emul_check.py [M K B [splitk [x4l|w12 [exp]]]]
+    python tools/emul/emul_check.py [M K B [splitk [w12|w8|t64 [exp]]]]
 """
 import os
 import subprocess
@@ -17,22 +17,22 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import refutil as R  # noqa: E402
-import x4l_layout_check as LC  # noqa: E402
+import layout_ref as LC  # noqa: E402
 
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
-def build(name="x4l"):
+def build(name="w12"):
     exe = os.path.join(HERE, name + "_emul")
     srcs = [os.path.join(HERE, name + "_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(ROOT, "ggml_amd", "csrc", f)
-            for f in ("gemm_q_x4l.hip", "gemm_q_x4l_hw.h", "gemm_kq_w12.inc", "gemm_kq_w8.inc", "gemm_w8_epilogue.inc", "gemm_q_hw.h", "gemm_q_common.h", "cdna4_common.h", "cdna4_kernels.h", "quantize_dev.h")]
+            for f in ("gemm_kq_w12.inc", "gemm_kq_w8.inc", "gemm_w8_epilogue.inc", "gemm_q_hw.h", "gemm_q_common.h", "cdna4_common.h", "cdna4_kernels.h", "quantize_dev.h")]
     if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
         subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "ggml_amd", "csrc"),
                         "-Wno-unused-value", "-o", exe, srcs[0]], check=True, capture_output=True, timeout=600)
     return exe
 
 
-def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, return_y=False, defer_dma=False, wtype=None):
+def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="w12", exp=0, xchg_l2=1, return_y=False, defer_dma=False, wtype=None):
     rng = np.random.default_rng(seed)
     nsb = K // 256
     wtype = R.Q4_K if wtype is None else wtype
@@ -61,7 +61,7 @@ def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, 
     with tempfile.TemporaryDirectory() as d:
         # the weight file must start 16-byte aligned in memory: the emulator reads it into a std::vector (malloc: 16-byte aligned)
         w.tofile(os.path.join(d, "w.bin")); img.tofile(os.path.join(d, "xh.bin"))
-        extra = [str(splitk), str(exp), str(wtype)] if kernel == "x4l" else [str(splitk), str(exp), str(xchg_l2), str(wtype)]       # x4l: exp = tile form; w8: exp = kernel
+        extra = [str(splitk), str(exp), str(xchg_l2), str(wtype)]       # w8: exp = kernel
         r = subprocess.run([build(kernel), str(M), str(K), str(B), os.path.join(d, "w.bin"), os.path.join(d, "xh.bin"), os.path.join(d, "y.bin")] + extra,
                            capture_output=True, text=True, timeout=timeout, env=dict(os.environ, EMU_DEFER_DMA="1" if defer_dma else "0"))
         if r.returncode == 77:                          # process / thread limits of this environment: nothing was checked
@@ -74,46 +74,9 @@ def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="x4l", exp=0, xchg_l2=1, 
 
 
 
-def run_fuseq(M, K, B, splitk=1, nq=None, seed=3, timeout=900, dist="uniform", exp=1024):
-    """k_gemm_kq_w12<Q4_K, true, 1024> — the variant that quantizes its own activations — against the shipped kernel fed with the
-    image the stand-alone quantizer produces (fp16(d * q) of the oracle's Q8_K rows): the image the kernel wrote and its output
-    must both match BIT FOR BIT.  The image buffer starts as NaNs, so a read before the grid barrier shows."""
-    import quant_emul_check as QC
-    nsb = K // 256
-    w = R.random_weights(R.Q4_K, M, K, seed).reshape(M, nsb, 144)
-    x = QC.data(dist, (B, K), seed)
-    ref = R.o_quantize_act(R.Q4_K, x).reshape(B, K // 256, 292)
-    dd = ref[:, :, 0:4].copy().view(np.float32).reshape(B, K // 256)
-    qs = ref[:, :, 4:260].copy().view(np.int8).reshape(B, K)
-    want = (np.repeat(dd, 256, axis=1) * qs.astype(np.float32)).astype(np.float16)
-    img = np.zeros((K // 128, B, 128), np.float16)
-    for p in range(128):
-        img[:, :, p] = want[:, [pan * 128 + (p & ~3) + LC.PERM[p & 3] for pan in range(K // 128)]].T
-    ntiles = ((M + 127) // 128) * ((B + 127) // 128)
-    nq = ntiles * splitk if nq is None else nq
-    out = {}
-    with tempfile.TemporaryDirectory() as d:
-        f = lambda n: os.path.join(d, n)  # noqa: E731
-        w.tofile(f("w.bin")); img.tofile(f("xh.bin")); x.tofile(f("x.bin"))
-        np.full(img.shape, np.nan, np.float16).tofile(f("xh_nan.bin"))
-        for name, args in (("shipped", [f("xh.bin"), f("y0.bin"), str(splitk), "0", "1"]),
-                           ("fused", [f("xh_nan.bin"), f("y1.bin"), str(splitk), str(exp), "1", str(R.Q4_K), f("x.bin"), str(nq), f("xh_out.bin")])):
-            r = subprocess.run([build("w12"), str(M), str(K), str(B), f("w.bin")] + args, capture_output=True, text=True, timeout=timeout,
-                               env=dict(os.environ, EMU_DEFER_DMA="0"))
-            if r.returncode == 77:
-                import pytest
-                pytest.skip("the environment cannot host the emulation (process / thread limits)")
-            assert r.returncode == 0, (name, r.stderr[-500:])
-        y0 = np.fromfile(f("y0.bin"), np.float32); y1 = np.fromfile(f("y1.bin"), np.float32)
-        got = np.fromfile(f("xh_out.bin"), np.float16).reshape(img.shape)
-    assert np.array_equal(got.view(np.uint16), img.view(np.uint16)), "fp16 image written by the in-launch quantizer"
-    assert np.array_equal(y0.view(np.uint32), y1.view(np.uint32)), "output of the fused launch"
-    return True
-
-
 if __name__ == "__main__":
     M, K, B = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 512, 128)
     S = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-    kern = sys.argv[5] if len(sys.argv) > 5 else "x4l"
+    kern = sys.argv[5] if len(sys.argv) > 5 else "w12"
     exp = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     print("%s kernel source (exp %d) on the CPU vs direct fp16 product, %dx%dx%d split-K %d: rel-L2 %.3e" % (kern, exp, M, K, B, S, run(M, K, B, splitk=S, kernel=kern, exp=exp)))

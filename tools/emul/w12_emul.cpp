@@ -1,5 +1,5 @@
 // w12_emul.cpp — runs the SOURCE of k_gemm_kq_w12<Q4_K, true, EXP> (ggml_amd/csrc/gemm_kq_w12.inc + gemm_w8_epilogue.inc: the
-// shipped 12-wave kernel and its bit-identical experiment variants) on the CPU like x4l_emul.cpp does for the experimental
+// shipped 12-wave kernel and its bit-identical experiment variants) on the CPU (see hip_emul.h); formerly paired with an experimental
 // kernel.  Test infrastructure.
 //   w12_emul M K B w.bin xh.bin y.bin splitk exp xchg_l2 [wtype x.bin nq xh_out.bin]
 // exp 1024 (the activation quantizer inside the launch): xh.bin is only the initial (garbage) content of the image, x.bin holds the
@@ -115,26 +115,6 @@ int main(int argc, char **argv) {
         case 100: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, false, 0>(p); }, nblk, 768); break;      // compute waves unpack the scales themselves
         case 32: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 32>(p); }, nblk, 768); break;        // timing ablations (results are garbage): bounds checks only
         case 480: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 480>(p); }, nblk, 768); break;
-        case 1024: case 3072: case 5120: case 9216: {
-            if (argc < 14) { fprintf(stderr, "exp 1024 / 3072 needs: wtype x.bin nq xh_out.bin\n"); return 2; }
-            std::vector<uint8_t> x0 = slurp(argv[11]);
-            float *xf = (float *)shared_alloc(x0.size()); memcpy(xf, x0.data(), x0.size());
-            unsigned *slots = (unsigned *)shared_alloc(64 * 16 * 4); memset(slots, 0, 64 * 16 * 4);
-            const int ngrp = exp == 9216 ? p.tiles_b * splitk : 1;  // EXP bit 13: one counter per (activation tile, K range) group
-            for (int g = 0; g < ngrp; g++) slots[37 * 16 + g] = 123;  // the words this launch must zero for a later one
-            p.xf = xf; p.xf_row = K; p.qcount = slots + 5 * 16; p.qzero = slots + 37 * 16; p.nq = atoi(argv[12]);
-            if (p.nq < 1 || p.nq > (int)nblk) { fprintf(stderr, "nq out of range\n"); return 2; }
-            if (exp == 3072) emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 3072>(p); }, nblk, 768);
-            else if (exp == 5120) emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 5120>(p); }, nblk, 768);
-            else if (exp == 9216) emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 9216>(p); }, nblk, 768);
-            else emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 1024>(p); }, nblk, 768);
-            for (int g = 0; g < ngrp; g++) {
-                const unsigned want = exp == 9216 ? (unsigned)p.tiles_m : (unsigned)p.nq;
-                if (slots[5 * 16 + g] != want || slots[37 * 16 + g] != 0) { fprintf(stderr, "counter words of group %d: %u (want %u), %u (want 0)\n", g, slots[5 * 16 + g], want, slots[37 * 16 + g]); return 4; }
-            }
-            FILE *fo = fopen(argv[13], "wb"); fwrite(xh, 1, xh0.size(), fo); fclose(fo);
-            break;
-        }
         default: fprintf(stderr, "exp not built into the emulator\n"); return 2;
     }
     FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)B * M, f); fclose(f);
