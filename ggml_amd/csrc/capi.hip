@@ -27,7 +27,7 @@ static ws_view carve(int type, int64_t K, int64_t B, void *base) {
     v.qs = (int8_t *)(p + off); off += align256((size_t)(B * K));
     v.d = (float *)(p + off); off += align256((size_t)(B * (K / qka)) * 4);
     v.bsums = (int16_t *)(p + off); off += align256((size_t)(B * (K / 16)) * 2);
-    v.xh = (void *)(p + off); off += align256((size_t)(B * ((K + 127) / 128 * 128)) * 2);    // whole 128-k panels
+    v.xh = (void *)(p + off); off += align256((size_t)(B * ((K + 127) / 128 * 128)) * 2) + 32768;    // whole 128-k panels; + slack: k_gemm_kq_t64 reads (and discards) up to 127 rows past a ragged last activation tile
     v.total = off;
     return v;
 }

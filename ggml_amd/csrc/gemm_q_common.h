@@ -451,7 +451,7 @@ struct gemm_params {
     int sb_split;                                       // hand-off: superblocks [0, sb_split) -> ks=0, the rest -> ks=1
     int xchg_l2;                                        // split-K exchange through the XCD's L2 (partners co-located) instead of write-through
     int tune;                                           // experiment bits from CDNA4_TUNE (bit0: static s_setprio 1 for the khalf-1 waves)
-    float *partial; unsigned *flags; unsigned epoch;   // split-K = 2 exchange (k_gemm_kq_w8): exported half tiles [tile][ks][64][128], one flag per (tile, ks), this launch's tag
+    float *partial; unsigned *flags;   // split-K = 2 exchange: exported half tiles [tile][ks][64][128]; one flag per (tile, ks): 0 = idle, 16 | XCC id = published (cleared by its READER)
     unsigned long long *trace;   // profiling builds only (k_gemm_kq_w8<TYPE, true>): per-phase s_memtime stamps of block 0
 };
 
@@ -482,5 +482,5 @@ template <> struct WStage<CDNA4_Q6_KS, 2> { static constexpr int NPH = 9; __devi
 
 // host-side helpers shared by the launchers (defined in gemm_q_mfma.hip)
 void *cdna4_gemm_scratch(size_t bytes, int kind);      // per-device scratch, zero-filled when (re)allocated; kind 0: split-K exchange, 1: repacked weights
-unsigned cdna4_gemm_next_epoch();                      // the per-launch tag of the exchange flags (never 0)
 int cdna4_gemm_cu_count();
+int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st);     // gemm_q_t64.hip: 64(m) x 128(b) wave tiles; tm 0 / 128 / 256, splitk 0 / 1 / 2

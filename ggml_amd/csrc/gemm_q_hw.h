@@ -1,4 +1,4 @@
-// gemm_q_hw.h — the statements of the loader-wave GEMM kernel (gemm_kq_w12.inc) that only exist on the GPU — inline assembly for
+// gemm_q_hw.h — the statements of the LDS-DMA GEMM kernels (gemm_kq_w12.inc, gemm_kq_t64.inc) that only exist on the GPU — inline assembly for
 // the LDS-DMA, asynchronous register loads, the counted waits, the LDS base address — as macros.  tools/emul/ defines
 // CDNA4_HW_OVERRIDE and host versions before including the kernel, so that the kernel SOURCE can be executed on the CPU (a
 // functional check of indexing, loop structure, barrier counts and the epilogue variants) with no conditional code in the
@@ -14,4 +14,7 @@
 #define CDNA4_WAIT_VM_TIED2(n, a, b) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(n) : "memory")
 #define CDNA4_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define CDNA4_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// v_permlane32_swap: lanes 32-63 of `a` trade places with lanes 0-31 of `b` (both 32-bit); with a == b on entry every lane l ends
+// with a = the value of lane l % 32 and b = the value of lane 32 + l % 32
+#define CDNA4_SWAP32(a, b) do { auto r_ = __builtin_amdgcn_permlane32_swap((a), (b), false, false); (a) = r_[0]; (b) = r_[1]; } while (0)
 #endif

@@ -19,7 +19,7 @@
 //    k_gemm_kq_w8    8 waves (two per SIMD), 128x128 tile, in-wave unpack/MFMA pipeline, split-K = 2 exchange
 //    k_gemm_kq_w8p   + cross-stage software pipeline (barrier in the middle of the MFMA stream)   (Q5_K default)
 //    k_gemm_kq_w12   + four LDS-DMA loader waves; they also re-lay Q4_0 / Q8_0 / Q6_K blocks while staging (Q4_K default)
-//    k_gemm_kq_x2    256x128 tile, two weight fragments per activation fragment, 1/2/4-way exchange   (huge grids)
+//    (huge grids: k_gemm_kq_t64<.., 256> of gemm_q_t64.hip)
 //    k_repack_*      16-byte-aligned re-layout of Q4_0 / Q8_0 / Q6_K into scratch (shallow-K fallback of the staged path)
 #include "gemm_q_common.h"
 #include "gemm_q_hw.h"
@@ -343,289 +343,6 @@ __global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
 
 #include "gemm_kq_w12.inc"
 
-// ------------------------------------------------------------------------------------------------------------
-// 256(m) x 128(b) work-group tile: the 8-wave in-wave-pipelined kernel with TWO weight fragments per activation
-// fragment.  Wave (mg, kh) owns rows [64 mg, 64 mg + 64) as two 32-row blocks mb = 0, 1, all 128 b, and the kh-th 64-k
-// group of every 128-k stage.  Per MFMA it needs half the activation LDS-DMA pieces, half the activation ds_reads and half
-// the S phase of k_gemm_kq_w8 (those are per activation fragment, now shared by two weight fragments); the unpack VALU per
-// MFMA is unchanged and still hides under the wave's own MFMAs.  128 accumulator registers per lane; the activation
-// fragments are read per MFMA k-step (double-buffered) instead of per stage to stay inside 256 registers.
-// Split-K = S in {1, 2, 4} with a symmetric exchange: work-group ks keeps activation rows [128/S ks, 128/S (ks+1)) and
-// publishes the rest of its partial tile to its S-1 partners (register layout, write-through), adds theirs in fixed order.
-template <int TYPE, int S>
-__global__ __launch_bounds__(512) void k_gemm_kq_x2(const gemm_params p) {
-    typedef WStage<TYPE, 2> WSt;
-    constexpr int BNF = 4, TB = 128, NST = 3, TM = 256;
-    constexpr int RS = 256, XS = TB * RS;
-    constexpr int BLK = QT<TYPE>::BYTES;
-    constexpr int WRS = WSt::NPH * 16, WS = TM * WRS, ST = XS + WS;
-    constexpr int XL = XS / 16 / 512;            // 4
-    constexpr int NWI = TM * WSt::NPH / 64;      // 20 (Q4_K)
-    constexpr int WL = (NWI + 7) / 8;            // 3
-    constexpr int NL = XL + WL;                  // 7
-    constexpr int NS = NL / 2;                   // DMA pieces issued in S, the rest spread over T
-    constexpr int SMEM = NST * ST > 128 * 1024 ? NST * ST : 128 * 1024;      // epilogue: 128 KB (parked partials, then the tile)
-    static_assert(SMEM <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
-    __shared__ int xchg_failed;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int mg = wave & 3, kh = __builtin_amdgcn_readfirstlane(wave >> 2);
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    const int nblk = gridDim.x;
-    int L = blockIdx.x;
-    if ((nblk & 7) == 0) L = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-    const int tile_b = L % p.tiles_b; L /= p.tiles_b;
-    const int ks = L % S, tile_m = L / S;
-    const int m0 = tile_m * TM, b0 = tile_b * TB;
-    // K range of this work-group: superblocks split as evenly as they go (the first K/256 % S work-groups take one more)
-    const int nsb_all = p.K / 256, nsb_base = nsb_all / S, nsb_rem = nsb_all % S;
-    const int nsb = nsb_base + (ks < nsb_rem ? 1 : 0), sb0 = ks * nsb_base + (ks < nsb_rem ? ks : nsb_rem);
-
-    DqConst dq; dq.init();
-    floatx16 acc[2][BNF];
-#pragma unroll
-    for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-        for (int i = 0; i < BNF; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[mb][i][r] = 0.f;
-
-    uint32_t xvoff[XL], wvoff[2][WL];
-#pragma unroll
-    for (int i = 0; i < XL; i++) {
-        const int pc = i * 512 + tid, row = pc >> 4, c = (pc & 15) ^ (row & 15);
-        xvoff[i] = (uint32_t)(min(b0 + row, p.B - 1) - b0) * 256u + c * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < WL; i++) {
-        int idx = wave + 8 * i;
-        if (idx >= NWI) idx -= 8;
-        const int pc = idx * 64 + lane, row = pc / WSt::NPH, c = pc % WSt::NPH;
-        const uint32_t ro = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
-        wvoff[0][i] = ro + WSt::src_piece(c, 0) * 16; wvoff[1][i] = ro + WSt::src_piece(c, 1) * 16;
-    }
-    const char *const xbase = (const char *)p.xh + ((int64_t)sb0 * 2 * p.B + b0) * 256;
-    const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
-    auto dma16 = [&](const char *sbase, uint32_t voff, uint32_t lds_addr) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
-    };
-    auto issue_piece = [&](int i, int sbr, int part, int slot) __attribute__((always_inline)) {
-        const uint32_t l = lds0 + slot * ST;
-        if (i < XL) { dma16(xbase + (int64_t)(sbr * 2 + part) * p.B * 256, xvoff[i], l + (i * 512 + wave_s * 64) * 16); return; }
-        int idx = wave_s + 8 * (i - XL);
-        if (idx >= NWI) idx -= 8;
-        dma16(wbase + (int64_t)sbr * BLK, wvoff[part][i - XL], l + XS + idx * 1024);
-    };
-
-    const int xrow_off = j * RS, xswz = j & 15;
-    Raw<TYPE> raw_s[2];
-    typename Raw<TYPE>::Sc z_s[2];
-    uint32_t cur[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    half8_t xa[2][BNF];                                              // activation fragments of one MFMA k-step, double-buffered
-    auto read_xa = [&](int slot, int kk, int buf) __attribute__((always_inline)) {
-        const uint8_t *xs = smem + slot * ST + xrow_off;
-        const int coff = ((kh * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++) xa[buf][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
-    };
-    auto S_phase = [&](int slot, auto PART, auto LD, int sbr, int slot_l) __attribute__((always_inline)) {
-        constexpr int part = decltype(PART)::value;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++) raw_s[mb].load(smem + slot * ST + XS + (mg * 64 + mb * 32 + j) * WRS, kh, h);
-        read_xa(slot, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (decltype(LD)::value) {
-#pragma unroll
-            for (int i = 0; i < NS; i++) issue_piece(i, sbr, part, slot_l);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++) {
-            if (kh == 0) z_s[mb] = raw_s[mb].scales(part * 2); else z_s[mb] = raw_s[mb].scales(part * 2 + 1);
-#pragma unroll
-            for (int i = 0; i < 4; i++) cur[mb][i] = raw_s[mb].pairbits(0, i, z_s[mb], dq);
-        }
-    };
-    auto T_phase = [&](int slot, auto LD, int sbr, int part, int slot_l) __attribute__((always_inline)) {
-        constexpr bool load = decltype(LD)::value;
-        constexpr int NT = NL - NS;
-        uint32_t nxt[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            if (kk < 3) read_xa(slot, kk + 1, (kk + 1) & 1);
-            half8_t wfk[2];
-#pragma unroll
-            for (int mb = 0; mb < 2; mb++) { const u32x4 cw = {cur[mb][0], cur[mb][1], cur[mb][2], cur[mb][3]}; wfk[mb] = __builtin_bit_cast(half8_t, cw); }
-#pragma unroll
-            for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-                for (int bf = 0; bf < BNF; bf++) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc[mb][bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[kk & 1][bf], wfk[mb], acc[mb][bf], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int n = kk * 8 + mb * 4 + bf;                  // 0..31; one half2 of the next fragments per MFMA
-                    if (kk < 3) nxt[mb][bf] = raw_s[mb].pairbits(kk + 1, bf, z_s[mb], dq);
-                    if (load && (n * NT) / 32 != ((n + 1) * NT) / 32) issue_piece(NS + (n * NT) / 32, sbr, part, slot_l);
-                }
-#pragma unroll
-            for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) cur[mb][i] = nxt[mb][i];
-        }
-    };
-    int slot = 0;
-    auto stage = [&](auto LD, auto PART, int sb) __attribute__((always_inline)) {
-        constexpr bool load = decltype(LD)::value;
-        constexpr int part = decltype(PART)::value;
-        if (load || part == 0) wait_vmcnt<NL>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot >= 1 ? slot - 1 : 2;
-        S_phase(slot, PART, LD, sb + 1, slot2);
-        T_phase(slot, LD, sb + 1, part, slot2);
-        slot = slot1;
-    };
-    typedef std::integral_constant<bool, true> yes_t; typedef std::integral_constant<bool, false> no_t;
-    typedef std::integral_constant<int, 0> p0_t; typedef std::integral_constant<int, 1> p1_t;
-#pragma unroll
-    for (int i = 0; i < NL; i++) issue_piece(i, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NL; i++) issue_piece(i, 0, 1, 1);
-    for (int sb = 0; sb + 1 < nsb; sb++) { stage(yes_t{}, p0_t{}, sb); stage(yes_t{}, p1_t{}, sb); }
-    stage(no_t{}, p0_t{}, nsb - 1); stage(no_t{}, p1_t{}, nsb - 1);
-
-    // ---- epilogue: K-half sum in registers (through LDS), symmetric S-way exchange, [b][m] tile through LDS, wide stores
-    if (tid == 0) xchg_failed = 0;
-    __syncthreads();
-    float4 *red = reinterpret_cast<float4 *>(smem) + (size_t)mg * 2048;   // [2 mb][16 quads][64 lanes] float4 per m-group (128 KB total)
-    if (kh == 1) {
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-            for (int bf = 0; bf < BNF; bf++)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++)
-                    red[((mb * 4 + bf) * 4 + q4) * 64 + lane] = make_float4(acc[mb][bf][4 * q4], acc[mb][bf][4 * q4 + 1], acc[mb][bf][4 * q4 + 2], acc[mb][bf][4 * q4 + 3]);
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-            for (int bf = 0; bf < BNF; bf++)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    const float4 v = red[((mb * 4 + bf) * 4 + q4) * 64 + lane];
-                    acc[mb][bf][4 * q4] += v.x; acc[mb][bf][4 * q4 + 1] += v.y; acc[mb][bf][4 * q4 + 2] += v.z; acc[mb][bf][4 * q4 + 3] += v.w;
-                }
-    }
-    const int tile_id = tile_m * p.tiles_b + tile_b;
-    constexpr int NBF = BNF / S;                                        // accumulator b-blocks kept per work-group
-    if constexpr (S > 1) {
-        constexpr int PF4 = 4 * 2 * NBF * 4 * 64;                        // float4 per (tile, dst, src) partial: [mg][mb][bfl][q4][lane]
-        float4 *pbase = reinterpret_cast<float4 *>(p.partial) + (size_t)tile_id * S * S * PF4;
-        auto exchange = [&](auto KS) __attribute__((always_inline)) {
-            constexpr int me = decltype(KS)::value;
-            if (kh == 0) {
-#pragma unroll
-                for (int d = 0; d < S; d++) {
-                    if (d == me) continue;
-                    float4 *dst = pbase + (size_t)(d * S + me) * PF4;
-                    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, PF4 * 16, 0x00020000);
-#pragma unroll
-                    for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-                        for (int bl = 0; bl < NBF; bl++)
-#pragma unroll
-                            for (int q4 = 0; q4 < 4; q4++) {
-                                const int bf = d * NBF + bl;
-                                const float4 v = make_float4(acc[mb][bf][4 * q4], acc[mb][bf][4 * q4 + 1], acc[mb][bf][4 * q4 + 2], acc[mb][bf][4 * q4 + 3]);
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (((((mg * 2 + mb) * NBF + bl) * 4 + q4) * 64) + lane) * 16, 0, 16);
-                            }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            if (tid == 0) {
-                // same word format as k_gemm_kq_w8's flags (launch tag << 4 | XCC id): the kernels share the flag scratch
-                __hip_atomic_store(p.flags + tile_id * S + me, p.epoch << 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int o = 0; o < S; o++) {
-                    if (o == me) continue;
-                    unsigned spins = 0;
-                    while (((__hip_atomic_load(p.flags + tile_id * S + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ (p.epoch << 4)) >> 4) != 0 && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
-                    if (spins >= (1u << 26)) xchg_failed = 1;             // a partner never showed up (not co-resident): fail LOUDLY, see below
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            __syncthreads();
-            if (kh == 0) {
-#pragma unroll
-                for (int o = 0; o < S; o++) {                            // fixed order: deterministic
-                    if (o == me) continue;
-                    const float4 *src = pbase + (size_t)(me * S + o) * PF4;
-                    float4 t[2 * NBF * 4];
-#pragma unroll
-                    for (int i = 0; i < 2 * NBF * 4; i++) t[i] = src[((mg * 2 * NBF * 4) + i) * 64 + lane];
-                    if (xchg_failed) {                                      // NaN tile instead of a silently wrong sum
-#pragma unroll
-                        for (int i = 0; i < 2 * NBF * 4; i++) t[i].x = __builtin_nanf("");
-                    }
-#pragma unroll
-                    for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-                        for (int bl = 0; bl < NBF; bl++)
-#pragma unroll
-                            for (int q4 = 0; q4 < 4; q4++) {
-                                const float4 v = t[(mb * NBF + bl) * 4 + q4];
-                                const int bf = me * NBF + bl;
-                                acc[mb][bf][4 * q4] += v.x; acc[mb][bf][4 * q4 + 1] += v.y; acc[mb][bf][4 * q4 + 2] += v.z; acc[mb][bf][4 * q4 + 3] += v.w;
-                            }
-                }
-            }
-        };
-        if (ks == 0) exchange(std::integral_constant<int, 0>{});
-        else if (ks == 1) exchange(std::integral_constant<int, 1>{});
-        else if (S > 2 && ks == 2) exchange(std::integral_constant<int, (S > 2 ? 2 : 0)>{});
-        else if (S > 2) exchange(std::integral_constant<int, (S > 2 ? 3 : 0)>{});
-    }
-    // [b][m] tile of the rows this work-group finishes: b rows [row_lo, row_lo + 128/S), 256 m wide (1 KB per row)
-    const int row_lo = (S > 1) ? ks * (128 / S) : 0;
-    constexpr int NROWS = 128 / S, CLD = 256;
-    float *ctile = reinterpret_cast<float *>(smem);                       // the parked partials are dead: [NROWS][256] fp32 <= 128 KB
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-            for (int bf = 0; bf < BNF; bf++) {
-                if (bf * 32 < row_lo || bf * 32 >= row_lo + NROWS) continue;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int bl = bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h - row_lo;
-                    ctile[bl * CLD + mg * 64 + mb * 32 + j] = acc[mb][bf][r];
-                }
-            }
-    }
-    __syncthreads();
-    {
-        const int c4 = tid & 63, r0 = tid >> 6;                             // 64 float4 per row, 8 rows per pass
-#pragma unroll
-        for (int pass = 0; pass < NROWS / 8; pass++) {
-            const int bl = pass * 8 + r0, b = b0 + row_lo + bl, m = m0 + c4 * 4;
-            const float4 v = *reinterpret_cast<const float4 *>(ctile + bl * CLD + c4 * 4);
-            if (b < p.B && m < p.M) {
-                float *dst = p.Y + (int64_t)b * p.y_row + m;
-                if (m + 3 < p.M && ((((uintptr_t)dst) & 15) == 0)) *reinterpret_cast<float4 *>(dst) = v;
-                else { const float e[4] = {v.x, v.y, v.z, v.w}; for (int t = 0; t < 4 && m + t < p.M; t++) dst[t] = e[t]; }
-            }
-        }
-    }
-}
-
 __global__ void k_zero_rows(float *Y, int64_t y_row, int M, int B) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < (int64_t)M * B) Y[(i / M) * y_row + (i % M)] = 0.f;
@@ -642,7 +359,7 @@ bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B) {
 
 template <int TYPE, int BNF, bool WLDS>
 static int launch_variant(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0; p.sb_split = 0;
+    gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.sb_split = 0;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 32 * BNF - 1) / (32 * BNF);
@@ -657,7 +374,7 @@ static int launch_variant(const cdna4_gemm_args &a, int splitk, hipStream_t st) 
 
 template <int TYPE, int BNF>
 static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0; p.sb_split = 0;
+    gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.sb_split = 0;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 32 * BNF - 1) / (32 * BNF);
@@ -673,9 +390,8 @@ static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
 // library-owned scratch for the split-K hand-off (partial tiles + flags), grown on demand like a BLAS workspace
 // (one region per device; launches that use it are assumed to be stream-ordered on that device, as the plug-in's
 // single-stream backend and the one-process-per-GPU bench are).
-static unsigned g_handoff_epoch = 0;        // ONE counter for every kernel instantiation that shares the flag words
-static void *g_scratch[32] = {nullptr}; static size_t g_scratch_bytes[32] = {0};
-static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: split-K exchange buffers, 1: repacked weights
+static void *g_scratch[48] = {nullptr}; static size_t g_scratch_bytes[48] = {0};
+static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: split-K exchange buffers, 1: repacked weights, 2: exchange buffers of gemm_q_t64.hip (reader-reset flags)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
     dev += 16 * kind;
@@ -699,27 +415,24 @@ static int cu_count() {                                            // of the CUR
 }
 
 void *cdna4_gemm_scratch(size_t bytes, int kind) { return get_scratch(bytes, kind); }
-unsigned cdna4_gemm_next_epoch() { if (++g_handoff_epoch == 0) ++g_handoff_epoch; return g_handoff_epoch; }
 int cdna4_gemm_cu_count() { return cu_count(); }
 
 template <int TYPE>
 static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t st, int exp = 0) {
-    gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0; p.sb_split = 0;
+    gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.sb_split = 0;
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 127) / 128;
     p.partial = nullptr; p.flags = nullptr;
     const int ntiles = p.tiles_m * p.tiles_b;
     if (splitk == 2 && ntiles * 2 <= cu_count()) {                    // both halves of every tile are resident at once: hand-off
-        const size_t pbytes = (size_t)ntiles * 128 * 128 * 4;
-        char *sc = (char *)get_scratch(pbytes + (size_t)ntiles * 8 + 256);
+        // exchange slots after a FIXED 64-KB flag area (so that no shape's slots ever overlay another shape's flags).  A flag is
+        // non-zero only between its writer's publication and its reader's reset inside one launch: no per-launch state on the
+        // host, so the launch is graph-capturable once the scratch exists.
+        const size_t pbytes = (size_t)ntiles * 128 * 128 * 4, fbytes = 65536;
+        char *sc = (char *)get_scratch(fbytes + pbytes);
         if (!sc) return cdna4_set_error_msg("gemm_q: cannot allocate split-K scratch");
-        p.partial = (float *)sc; p.flags = (unsigned *)(sc + pbytes);
-        // flags carry a per-launch tag instead of being zeroed by a memset node every call (a 256-byte fill cost ~5 us of
-        // GPU time per step): the scratch is zero-filled when allocated, tags start at 1 and never repeat within 2^32
-        // launches.  (Under HIP-graph replay the tag would be frozen: capture is not used on this path.)
-        if (++g_handoff_epoch == 0) ++g_handoff_epoch;
-        p.epoch = g_handoff_epoch;
+        p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
         // ks=0 share of K in 1/16ths.  The exchange is symmetric (each work-group exports half of its partial tile and
         // finishes the other half), so the even split is the default; CDNA4_SPLIT_NUM overrides it for experiments.
         static const int num = getenv("CDNA4_SPLIT_NUM") ? atoi(getenv("CDNA4_SPLIT_NUM")) : 8;
@@ -783,46 +496,13 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     return 0;
 }
 
-// 256 x 128 tile kernel (Q4_K and the re-laid Q4_0: 80-byte staged rows keep the 3-deep ring inside 160 KB of LDS)
-template <int TYPE>
-static int launch_x2(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.epoch = 0; p.sb_split = 0;
-    p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
-    p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B;
-    p.tiles_m = (a.M + 255) / 256; p.tiles_b = (a.B + 127) / 128;
-    const int ntiles = p.tiles_m * p.tiles_b, nsb = a.K / 256;
-    int S = splitk;
-    if (S <= 0) {                                                       // widest split whose work-groups are all co-resident
-        S = 1;
-        for (int c = 4; c >= 2; c >>= 1) if (ntiles * c <= cu_count() && nsb / c >= 2) { S = c; break; }
-    }
-    if (S != 1 && S != 2 && S != 4) return cdna4_set_error_msg("gemm_q: the 256x128 kernel splits K 1, 2 or 4 ways");
-    if (nsb < S) return cdna4_set_error_msg("gemm_q: fewer superblocks than split-K work-groups");
-    if (S > 1 && ntiles * S > cu_count()) return cdna4_set_error_msg("gemm_q: the split-K exchange needs every work-group resident");
-    p.splitk = S;
-    if (S > 1) {
-        const size_t pbytes = (size_t)ntiles * S * (256 * 128 * 4);      // S x S slots of 128 KB / S each
-        char *sc = (char *)get_scratch(pbytes + (size_t)ntiles * S * 4 + 256);
-        if (!sc) return cdna4_set_error_msg("gemm_q: cannot allocate split-K scratch");
-        p.partial = (float *)sc; p.flags = (unsigned *)(sc + pbytes);
-        if (++g_handoff_epoch == 0) ++g_handoff_epoch;
-        p.epoch = g_handoff_epoch;
-    }
-    const dim3 grid(ntiles * S);
-    if (S == 1) hipLaunchKernelGGL((k_gemm_kq_x2<TYPE, 1>), grid, dim3(512), 0, st, p);
-    else if (S == 2) hipLaunchKernelGGL((k_gemm_kq_x2<TYPE, 2>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((k_gemm_kq_x2<TYPE, 4>), grid, dim3(512), 0, st, p);
-    CDNA4_CHECK_LAUNCH();
-    return 0;
-}
-
 template <int TYPE>
 static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     constexpr bool CAN_LDS = QT<TYPE>::KQ && (QT<TYPE>::BYTES % 16 == 0);
     // variant: bit0 = LDS weight staging (Q4_K/Q5_K only), bit1 = 128-wide activation tile, bit3 = the older
     // slice-per-barrier kernel instead of the pipelined one, bit4 = the 8-wave (two waves per SIMD) 128x128 kernel,
     // bits 5-9 = that kernel's schedule option OPT (see k_gemm_kq_w8; 20 = in-wave pipeline with the DMA pieces split over both phases),
-    // bit10 = the 256x128-tile kernel k_gemm_kq_x2, bit11 = the cross-stage pipelined k_gemm_kq_w8p (the default),
+    // bit11 = the cross-stage pipelined k_gemm_kq_w8p (the default),
     // bit12 = k_gemm_kq_w12 = w8p + four loader waves (the default for Q4_K).
     // 0 = auto: widest tile that the batch fills.
     int variant = a.variant;
@@ -846,14 +526,14 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         if ((variant & 16) && wlds && QT<TYPE>::KQ && tiles * 2 <= cu_count() && (kunits & 1) && kunits >= 7) { splitk = 2; uneven = true; }
     }
     if constexpr (TYPE == CDNA4_Q4_K) {
-        if (wlds && (variant & 1024)) return launch_x2<TYPE>(a, a.splitk, st);
-        // auto: the 256x128 tile kernel needs half the activation bytes per MFMA, but its deeper tiles only pay off once the
-        // grid is at least two full waves of work-groups without any K split (measured: C5 32768x8192x512 272 vs 318 us =
-        // 1.01 vs 0.87 PFLOP/s; 8192x4096x512, 4096x10752x512 and the headline 4096x4096x512 are ties or small losses)
-        static const bool no_x2 = getenv("CDNA4_NO_X2") != nullptr;
-        if (wlds && a.variant <= 0 && a.splitk <= 0 && a.B > 64 && !no_x2) {
+        // bit13 = k_gemm_kq_t64 (gemm_q_t64.hip: 64(m) x 128(b) wave tiles); bit14 / bit15 force its 128- / 256-row tile
+        if (wlds && (variant & 8192)) return cdna4_launch_gemm_t64(a, (variant & 16384) ? 128 : ((variant & 32768) ? 256 : 0), a.splitk, st);
+        // auto: 256-row tiles need half the activation bytes per MFMA, but they only pay off once the grid is at least two full
+        // waves of 256x128 work-groups without any K split (MI355X, round 2: C5 32768x8192x512 242.9 us on k_gemm_kq_t64<256> vs
+        // 265.1 us on the 128-row kernel; 8192x8192x512 — one tile per CU — 71.6 vs 68.9 us, a loss)
+        if (wlds && a.variant <= 0 && a.splitk <= 0 && a.B > 64) {
             const int tx = ((a.M + 255) / 256) * ((a.B + 127) / 128);
-            if (tx >= 2 * cu_count()) return launch_x2<TYPE>(a, 1, st);
+            if (tx >= 2 * cu_count()) return cdna4_launch_gemm_t64(a, 256, 1, st);
         }
     }
     if (splitk < 1 || (kunits % splitk && !uneven)) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");

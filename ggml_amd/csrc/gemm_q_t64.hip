@@ -1,0 +1,44 @@
+// gemm_q_t64.hip — launcher of k_gemm_kq_t64 (gemm_kq_t64.inc): the prefill GEMM with 64(m) x 128(b) wave tiles.
+// Replaces, for Q4_K at B > 64, what ggml_compute_forward_mul_mat does after the activations are quantized
+// (/root/reference/src/ggml-cpu/ggml-cpu.c:7510-7605).
+#include "gemm_q_common.h"
+#include "gemm_q_hw.h"
+#include "gemm_kq_t64.inc"
+
+// tile rows (0 = choose) and split-K (0 = choose; 1 or 2) -> launch.  Returns 0, or a negative status with the error text set.
+int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st) {
+    if (a.type != CDNA4_Q4_K) return cdna4_set_error_msg("gemm_t64: Q4_K only");
+    if (a.K % 256 || a.K < 256) return cdna4_set_error_msg("gemm_t64: K must be a whole number of superblocks");
+    if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) || ((uintptr_t)a.xh & 15)) return cdna4_set_error_msg("gemm_t64: weight rows and the activation image must be 16-byte aligned");
+    const int cus = cdna4_gemm_cu_count(), nsb = a.K / 256;
+    const int tiles_b = (a.B + 127) / 128;
+    if (tm <= 0) tm = (((a.M + 255) / 256) * tiles_b >= cus) ? 256 : 128;         // a 256-row tile per CU at least: half the activation DMA per MFMA
+    if (tm != 128 && tm != 256) return cdna4_set_error_msg("gemm_t64: tile rows are 128 or 256");
+    const int tiles_m = (a.M + tm - 1) / tm, ntiles = tiles_m * tiles_b;
+    if (splitk <= 0) splitk = (ntiles * 2 <= cus && nsb >= 2) ? 2 : 1;             // hand-off split: both work-groups of a tile must be resident
+    if (splitk != 1 && splitk != 2) return cdna4_set_error_msg("gemm_t64: split-K is 1 or 2");
+    if (splitk == 2 && (ntiles * 2 > cus || nsb < 2)) return cdna4_set_error_msg("gemm_t64: the split-K exchange needs every work-group resident and two superblocks");
+    gemm_params p{};
+    p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
+    p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
+    p.tiles_m = tiles_m; p.tiles_b = tiles_b;
+    if (splitk == 2) {
+        // exchange slots: [tile][destination work-group][wave] x 16 KB at most; flags: one word per (tile, work-group), zero
+        // when idle (the READER clears its partner's flag, so there is no per-launch state on the host: graph-capturable).
+        // Scratch kind 2: the older kernels' tagged flags never mix with these.
+        // The flags live at a FIXED place (the first 64 KB) so that no shape's exchange slots ever overlay another shape's flags.
+        const size_t pbytes = (size_t)ntiles * 2 * 8 * 16384, fbytes = 65536;
+        if ((size_t)ntiles * 8 > fbytes) return cdna4_set_error_msg("gemm_t64: too many tiles for the split-K flag area");
+        char *sc = (char *)cdna4_gemm_scratch(fbytes + pbytes, 2);
+        if (!sc) return cdna4_set_error_msg("gemm_t64: cannot allocate split-K scratch");
+        p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
+        p.sb_split = (nsb + 1) / 2;
+        const int nb = ntiles * 2;                                                 // partners share an XCD iff the XCD-aware remap is active and
+        p.xchg_l2 = ((nb & 7) == 0 && ((nb >> 3) % (tiles_b * 2)) == 0) ? 1 : 0;   // each XCD's slice holds whole (tile_b x ks) groups
+    }
+    const dim3 grid(ntiles * splitk);
+    if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256>), grid, dim3(512), 0, st, p);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}

@@ -116,6 +116,7 @@ def ref():
             _fields_ = [("mem_size", C.c_size_t), ("mem_buffer", C.c_void_p), ("no_alloc", C.c_bool)]
         base.ggml_init.restype = C.c_void_p
         base.ggml_init.argtypes = [InitParams]
+        base._InitParams = InitParams
         base.ggml_free.argtypes = [C.c_void_p]
         # first ggml_init fills the fp16->fp32 table the base library's GGML_FP16_TO_FP32 reads (src/ggml.c:1390-1420)
         base.ggml_free(base.ggml_init(InitParams(1 << 20, None, False)))

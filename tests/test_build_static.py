@@ -35,14 +35,12 @@ def _lds(asm, kernel):
     return int(m.group(1))
 
 
-# mangled names: k_gemm_kq_w12<Q4_K, true, 0>, k_gemm_kq_w8p<Q5_K, false>, k_gemm_kq_w8<Q4_K, false, 20>, k_gemm_kq_x2<Q4_K, 1>
+# mangled names: k_gemm_kq_w12<Q4_K, true, 0>, k_gemm_kq_w8p<Q5_K, false>, k_gemm_kq_w8<Q4_K, false, 20>
 SHIPPED = [
     "_Z13k_gemm_kq_w12ILi12ELb1ELi0EEv11gemm_params",
     "_Z13k_gemm_kq_w8pILi13ELb0EEv11gemm_params",
     "_Z13k_gemm_kq_w8pILi12ELb0EEv11gemm_params",
     "_Z12k_gemm_kq_w8ILi12ELb0ELi20EEv11gemm_params",
-    "_Z12k_gemm_kq_x2ILi12ELi1EEv11gemm_params",
-    "_Z12k_gemm_kq_x2ILi12ELi4EEv11gemm_params",
 ]
 
 
@@ -50,6 +48,53 @@ SHIPPED = [
 def test_shipped_gemm_kernels_do_not_spill(gemm_asm, kernel):
     assert _prop(gemm_asm, kernel, "private_seg_size") == 0
     assert _lds(gemm_asm, kernel) <= 160 * 1024
+
+
+def test_64x128_wave_tile_kernel_resources(tmp_path):
+    """gemm_q_t64.hip: 8 waves = 2 per SIMD -> at most 256 registers; no scratch access inside the main loop (the 256-row form
+    parks one float4 in scratch in its EPILOGUE, which costs nothing); ring + reduction area within 160 KB of LDS"""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "t64.s"
+    src = os.path.join(ROOT, "ggml_amd", "csrc", "gemm_q_t64.hip")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=900)
+    asm = out.read_text()
+    for tm, max_scratch in ((128, 0), (256, 32)):
+        k = "_Z13k_gemm_kq_t64ILi12ELi%dEEv11gemm_params" % tm
+        assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= 256
+        assert _prop(asm, k, "private_seg_size") <= max_scratch
+        assert _lds(asm, k) <= 160 * 1024
+        body = re.search(r"^%s:.*?^\.Lfunc_end" % re.escape(k), asm, re.S | re.M).group(0)
+        loop = re.search(r"Inner Loop Header.*?s_cbranch_scc1", body, re.S).group(0)            # the steady-state stage pair
+        assert "scratch_" not in loop and loop.count("v_mfma_f32_32x32x16_f16") == (32 if tm == 128 else 64)
+
+
+@pytest.mark.parametrize("m,k,b,splitk,tm", [(128, 256, 128, 1, 128), (300, 1536, 200, 1, 128), (300, 1536, 200, 1, 256), (513, 1024, 129, 2, 128),
+                                             (256, 1792, 128, 2, 128), (512, 1792, 200, 2, 256), (200, 256, 100, 1, 256)])
+def test_64x128_wave_tile_kernel_source_on_the_cpu(m, k, b, splitk, tm):
+    """tools/emul/t64_emul: the source of k_gemm_kq_t64 executed on the CPU against a direct fp16 product — both tile heights,
+    ragged edges, one-superblock K ranges, even and uneven hand-off splits (the harness also checks that every exchange flag
+    was reset by its reader) — with the LDS-DMA landing immediately and as late as the counted waits allow"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("emul_check", os.path.join(ROOT, "tools", "emul", "emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for defer in (False, True):
+        assert mod.run(m, k, b, seed=m + k, timeout=900, splitk=splitk, kernel="t64", exp=tm, defer_dma=defer) < 1e-6
+
+
+def test_64x128_wave_tile_kernel_counted_waits_are_tight(monkeypatch):
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("emul_check", os.path.join(ROOT, "tools", "emul", "emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setenv("EMU_WEAKEN_WAITS", "1")
+    assert mod.run(300, 1536, 200, seed=3, timeout=900, splitk=1, kernel="t64", exp=128, defer_dma=True) > 1e-3
 
 
 def test_loader_wave_kernel_fits_three_waves_per_simd(gemm_asm):

@@ -1,0 +1,202 @@
+"""-m gpu: the supporting ops and the row converters of include/ggml_cdna4.h called THROUGH THE C-ABI (ctypes, device pointers,
+ggml_cdna4_tensor descriptors) and compared with the unmodified reference CPU backend (tests/refops.py -> oracle/_ref) and the
+C oracle on identical inputs.  Bars: BIT-EXACT for CPY f32 -> Q8_0 / Q4_0 (bytes, against quantize_row_*_ref,
+/root/reference/src/ggml-quants.c:31-66,194-217, which is what the reference's dup path and ggml-cuda's cpy.cu run) and for
+dequantize_row of the five formats (to_float, ggml-quants.c:255,349,1280,1482,1690); <= 2e-6 relative L2 for the float ops
+(norm, rms_norm, soft_max, rope, gelu, diag_mask_inf, get_rows) whose only freedom is fp32 summation order / libm."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import refutil as R
+
+pytestmark = pytest.mark.gpu
+I32 = 26
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    if not R.have_ref():
+        pytest.fail("oracle/_ref is missing from the snapshot (run __graft_entry__.build() where /root/reference exists)")
+    from ggml_amd import native
+    return native.lib()
+
+
+def _desc(t, type_, ne=None, nb=None):
+    """ggml_cdna4_tensor of a torch tensor (contiguous unless ne / nb are given; quantized types: uint8 bytes + explicit ne)"""
+    from ggml_amd import native
+    d = native.Tensor()
+    d.data = t.data_ptr(); d.type = type_; d.reserved = 0
+    if ne is None:
+        shp = list(reversed(t.shape)) + [1] * (4 - t.dim())
+        st = [s * t.element_size() for s in reversed(t.stride())]
+        while len(st) < 4:
+            st.append(st[-1] * shp[len(st) - 1])
+        ne, nb = shp, st
+    for i in range(4):
+        d.ne[i] = int(ne[i]); d.nb[i] = int(nb[i])
+    return d
+
+
+def _qdesc(t, type_, k, rows):
+    rs = R.row_size(type_, k)
+    return _desc(t, type_, [k, rows, 1, 1], [R.TYPE_SIZE[type_], rs, rs * rows, rs * rows])
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ok(L, rc):
+    assert rc == 0, L.ggml_cdna4_last_error().decode()
+
+
+def _data(kind, shape, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return rng.uniform(-1, 1, shape).astype(np.float32)
+    if kind == "normal":
+        return (rng.standard_normal(shape) * 3).astype(np.float32)
+    x = (rng.integers(-254, 255, shape) / 2.0).astype(np.float32)        # exact .5 ties for the rounding rules
+    return x
+
+
+# ------------------------------------------------------------------------------------------------ CPY f32 -> quantized: bytes
+@pytest.mark.parametrize("kind", ["uniform", "normal", "ties"])
+@pytest.mark.parametrize("dst_type", [R.Q8_0, R.Q4_0])
+def test_cpy_f32_to_quantized_is_byte_exact(L, dst_type, kind):
+    import refops as O
+    rows, k = 37, 1024
+    x = _data(kind, (rows, k), 11)
+    x[3, 32:64] = 0                                                     # an all-zero block
+    x[4, 5] = -7.5; x[4, 9] = 7.5                                        # equal |max| of both signs inside one block
+    xd = _dev(x)
+    out = torch.zeros(rows * R.row_size(dst_type, k), dtype=torch.uint8, device="cuda")
+    _ok(L, L.ggml_cdna4_op_cpy(C.byref(_desc(xd, R.F32)), C.byref(_qdesc(out, dst_type, k, rows)), 1, _st()))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    name = "q8_0_ref" if dst_type == R.Q8_0 else "q4_0_ref"
+    want = np.concatenate([R.o_quantize_row(name, x[i]) for i in range(rows)])
+    assert np.array_equal(got, want), "first differing byte %d" % int(np.argmax(got != want))
+    assert np.array_equal(want, O.cpy_quantize(x, dst_type))           # ... and the oracle IS what the reference's CPY writes
+
+
+def test_cpy_f32_to_q8_0_cpu_rounding_variant_is_byte_exact(L):
+    """q8_0_ref_rounding = 0: the AVX2 from_float the CPU backend uses for MUL_MAT activations (ggml-cpu-quants.c:778-815)"""
+    rows, k = 16, 512
+    x = _data("ties", (rows, k), 5)
+    out = torch.zeros(rows * R.row_size(R.Q8_0, k), dtype=torch.uint8, device="cuda")
+    _ok(L, L.ggml_cdna4_op_cpy(C.byref(_desc(_dev(x), R.F32)), C.byref(_qdesc(out, R.Q8_0, k, rows)), 0, _st()))
+    torch.cuda.synchronize()
+    want = np.concatenate([R.o_quantize_row("q8_0_cpu", x[i]) for i in range(rows)])
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------------------------------------ dequantize_row: bit-exact
+@pytest.mark.parametrize("name,t", list(R.QUANT_TYPES.items()))
+def test_dequantize_row_is_bit_exact(L, name, t):
+    rows, k = 9, 2048
+    w = R.random_weights(t, rows, k, seed=int(t) + 1)
+    wd = _dev(w)
+    y = torch.empty(rows * k, dtype=torch.float32, device="cuda")
+    _ok(L, L.ggml_cdna4_dequantize_row(int(t), wd.data_ptr(), y.data_ptr(), rows * k, _st()))
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().reshape(rows, k)
+    assert np.array_equal(got.view(np.uint32), R.o_dequantize(t, w, k).view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), R.r_dequantize(t, w, k).view(np.uint32))
+
+
+@pytest.mark.parametrize("name,t", list(R.QUANT_TYPES.items()))
+def test_cpy_quantized_to_f32_and_get_rows_are_bit_exact(L, name, t):
+    import refops as O
+    rows, k = 21, 1024
+    w = R.random_weights(t, rows, k, seed=int(t) + 3)
+    wd = _dev(w)
+    y = torch.empty((rows, k), dtype=torch.float32, device="cuda")
+    _ok(L, L.ggml_cdna4_op_cpy(C.byref(_qdesc(wd, t, k, rows)), C.byref(_desc(y, R.F32)), 1, _st()))
+    ids = np.array([5, 0, 20, 5, 13], np.int32)
+    idd = _dev(ids)
+    g = torch.empty((ids.size, k), dtype=torch.float32, device="cuda")
+    _ok(L, L.ggml_cdna4_op_get_rows(C.byref(_qdesc(wd, t, k, rows)), C.byref(_desc(idd, I32)), C.byref(_desc(g, R.F32)), _st()))
+    torch.cuda.synchronize()
+    want = R.r_dequantize(t, w, k)
+    assert np.array_equal(y.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(g.cpu().numpy().view(np.uint32), O.get_rows(t, w, k, rows, ids).view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------ float ops vs the CPU backend
+TOL = 2e-6
+
+
+@pytest.mark.parametrize("rms", [0, 1])
+@pytest.mark.parametrize("shape", [(3, 5, 768), (1, 1, 64), (2, 7, 4096)])
+def test_norm_and_rms_norm(L, shape, rms):
+    import refops as O
+    x = _data("normal", shape, 3)
+    xd = _dev(x); y = torch.empty_like(xd)
+    _ok(L, L.ggml_cdna4_op_norm(C.byref(_desc(xd, R.F32)), C.byref(_desc(y, R.F32)), 1e-5, rms, _st()))
+    torch.cuda.synchronize()
+    assert R.rel_l2(y.cpu().numpy(), O.norm(x, 1e-5, bool(rms))) < TOL
+
+
+@pytest.mark.parametrize("mask_dtype,max_bias", [(None, 0.0), (np.float32, 0.0), (np.float16, 0.0), (np.float16, 8.0)])
+def test_soft_max(L, mask_dtype, max_bias):
+    import refops as O
+    n_head, n_q, n_kv = 12, 9, 40
+    x = _data("normal", (1, n_head, n_q, n_kv), 4)
+    mask = None
+    if mask_dtype is not None:
+        m = np.zeros((n_q, n_kv), np.float32)
+        m[np.triu_indices(n_q, 1, n_kv)] = -np.inf                       # causal
+        mask = m.astype(mask_dtype)
+    xd = _dev(x); y = torch.empty_like(xd)
+    md = _dev(mask) if mask is not None else None
+    mt = None if mask is None else C.byref(_desc(md, R.F16 if mask_dtype == np.float16 else R.F32))
+    _ok(L, L.ggml_cdna4_op_soft_max(C.byref(_desc(xd, R.F32)), mt, C.byref(_desc(y, R.F32)), 0.125, max_bias, _st()))
+    torch.cuda.synchronize()
+    assert R.rel_l2(y.cpu().numpy(), O.soft_max(x, mask, 0.125, max_bias)) < TOL
+
+
+@pytest.mark.parametrize("mode,n_dims,ext", [(0, 64, 0.0), (2, 64, 0.0), (0, 32, 0.0), (2, 128, 1.0)])
+def test_rope(L, mode, n_dims, ext):
+    import refops as O
+    hd = max(n_dims, 64)
+    x = _data("uniform", (1, 7, 4, hd), 6)                                # numpy order (ne3, tokens, heads, head_dim)
+    pos = np.array([0, 1, 2, 3, 100, 101, 4000], np.int32)
+    xd = _dev(x); y = torch.empty_like(xd); pd = _dev(pos)
+    args = (n_dims, mode, 4096 if ext else 0, 10000.0, 1.0 if not ext else 0.25, ext, 1.0, 32.0, 1.0)
+    _ok(L, L.ggml_cdna4_op_rope(C.byref(_desc(xd, R.F32)), C.byref(_desc(pd, I32)), None, C.byref(_desc(y, R.F32)), *args, _st()))
+    torch.cuda.synchronize()
+    # sin / cos of the device's libm vs the host's: allow 2e-6 of the vector norm
+    assert R.rel_l2(y.cpu().numpy(), O.rope(x, pos, *args)) < 2e-6
+
+
+@pytest.mark.parametrize("name,op", [("gelu", 0), ("gelu_quick", 1), ("silu", 2)])
+def test_unary(L, name, op):
+    import refops as O
+    x = _data("normal", (5, 333), 8)
+    xd = _dev(x); y = torch.empty_like(xd)
+    _ok(L, L.ggml_cdna4_op_unary(op, C.byref(_desc(xd, R.F32)), C.byref(_desc(y, R.F32)), _st()))
+    torch.cuda.synchronize()
+    got, want = y.cpu().numpy(), O.unary(x, name)
+    if name == "gelu":
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))     # the CPU's fp16 look-up table semantics, bit for bit
+    else:
+        assert R.rel_l2(got, want) < TOL
+
+
+def test_diag_mask_inf(L):
+    import refops as O
+    x = _data("uniform", (2, 6, 11), 9)
+    xd = _dev(x); y = torch.empty_like(xd)
+    _ok(L, L.ggml_cdna4_op_diag_mask_inf(C.byref(_desc(xd, R.F32)), C.byref(_desc(y, R.F32)), 3, _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy().view(np.uint32), O.diag_mask_inf(x, 3).view(np.uint32))

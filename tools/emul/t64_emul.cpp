@@ -1,9 +1,6 @@
-// w12_emul.cpp — runs the SOURCE of k_gemm_kq_w12<Q4_K, true, EXP> (ggml_amd/csrc/gemm_kq_w12.inc + gemm_w8_epilogue.inc: the
-// shipped 12-wave kernel and its bit-identical experiment variants) on the CPU (see hip_emul.h); formerly paired with an experimental
-// kernel.  Test infrastructure.
-//   w12_emul M K B w.bin xh.bin y.bin splitk exp xchg_l2 [wtype x.bin nq xh_out.bin]
-// exp 1024 (the activation quantizer inside the launch): xh.bin is only the initial (garbage) content of the image, x.bin holds the
-// fp32 activations [B][K], nq = number of quantizing work-groups, and the image the kernel wrote is saved to xh_out.bin
+// t64_emul.cpp — runs the SOURCE of k_gemm_kq_t64 (ggml_amd/csrc/gemm_kq_t64.inc: 64(m) x 128(b) wave tiles, TM = 128 / 256) on
+// the CPU like w12_emul.cpp.  Test infrastructure.
+//   t64_emul M K B w.bin xh.bin y.bin splitk tm xchg_l2 [type]
 #include "hip_emul.h"
 #include <signal.h>
 #include <sys/mman.h>
@@ -21,6 +18,10 @@
 #define CDNA4_WAIT_VM_TIED2(n, a, b) emu::vm_wait(n)
 #define CDNA4_WAIT_VM(n) emu::vm_wait(n)
 #define CDNA4_WAIT_LGKM0() ((void)0)
+// v_permlane32_swap through the wave's exchange buffer (all 64 lanes execute it)
+#define CDNA4_SWAP32(a, b) do { emu::WaveState &w_ = emu::my_wave(); const int l_ = emu::t_threadIdx.x & 63; const uint32_t a_ = (a), b_ = (b); \
+    w_.xch[l_] = l_ < 32 ? b_ : a_; pthread_barrier_wait(&w_.bar); const uint32_t o_ = w_.xch[l_ ^ 32]; pthread_barrier_wait(&w_.bar); \
+    if (l_ < 32) (b) = o_; else (a) = o_; } while (0)
 
 namespace emu {
 thread_local dim3 t_threadIdx, t_blockIdx;
@@ -44,9 +45,7 @@ static void *shared_alloc(size_t n) {
 
 #include "../../ggml_amd/csrc/gemm_q_common.h"
 #include "../../ggml_amd/csrc/gemm_q_hw.h"
-#include "../../ggml_amd/csrc/quantize_dev.h"
-void *cdna4_debug_trace = nullptr;
-#include "../../ggml_amd/csrc/gemm_kq_w12.inc"
+#include "../../ggml_amd/csrc/gemm_kq_t64.inc"
 
 template <typename F> static void emu_launch(F body, unsigned nblk, int nthreads) {
     emu::g_gridDim = dim3(nblk); emu::g_blockDim = dim3(nthreads);
@@ -83,41 +82,34 @@ static std::vector<uint8_t> slurp(const char *p) {
     std::vector<uint8_t> v((size_t)n); if (fread(v.data(), 1, (size_t)n, f) != (size_t)n) exit(2); fclose(f); return v;
 }
 int main(int argc, char **argv) {
-    if (argc < 10) { fprintf(stderr, "usage: w12_emul M K B w.bin xh.bin y.bin splitk exp xchg_l2\n"); return 2; }
-    const int M = atoi(argv[1]), K = atoi(argv[2]), B = atoi(argv[3]), splitk = atoi(argv[7]), exp = atoi(argv[8]), l2 = atoi(argv[9]);
+    if (argc < 10) { fprintf(stderr, "usage: t64_emul M K B w.bin xh.bin y.bin splitk tm xchg_l2 [type]\n"); return 2; }
+    const int M = atoi(argv[1]), K = atoi(argv[2]), B = atoi(argv[3]), splitk = atoi(argv[7]), tm = atoi(argv[8]), l2 = atoi(argv[9]);
     std::vector<uint8_t> w0 = slurp(argv[4]), xh0 = slurp(argv[5]);
-    uint8_t *w = (uint8_t *)shared_alloc(w0.size()), *xh = (uint8_t *)shared_alloc(xh0.size());
+    uint8_t *w = (uint8_t *)shared_alloc(w0.size()), *xh = (uint8_t *)shared_alloc(xh0.size() + 32768) ;   // + the slack capi.hip gives the image
     memcpy(w, w0.data(), w0.size()); memcpy(xh, xh0.data(), xh0.size());
     float *y = (float *)shared_alloc((size_t)B * M * 4);
     for (size_t i = 0; i < (size_t)B * M; i++) y[i] = -12345.f;
-    // the parameter block exactly as launch_w8() (gemm_q_mfma.hip) fills it for this kernel
+    // the parameter block exactly as cdna4_launch_gemm_t64() (gemm_q_t64.hip) fills it
     gemm_params p{};
-    p.W = w; p.w_row_bytes = (int64_t)(K / 256) * 144; p.xh = (const half_t *)xh; p.xh_row = K; p.Y = y; p.y_row = M; p.M = M; p.K = K; p.B = B; p.splitk = splitk;
-    p.tiles_m = (M + 127) / 128; p.tiles_b = (B + 127) / 128;
-    const int ntiles = p.tiles_m * p.tiles_b, total = K / 256;
+    p.W = w; p.w_row_bytes = (int64_t)(K / 256) * 144;
+    p.xh = (const half_t *)xh; p.xh_row = K; p.Y = y; p.y_row = M; p.M = M; p.K = K; p.B = B; p.splitk = splitk;
+    if (tm != 128 && tm != 256) { fprintf(stderr, "tm 128 or 256\n"); return 2; }
+    p.tiles_m = (M + tm - 1) / tm; p.tiles_b = (B + 127) / 128;
+    const int ntiles = p.tiles_m * p.tiles_b, nsb = K / 256;
+    unsigned *flags = nullptr;
     if (splitk == 2) {
-        const size_t pbytes = (size_t)ntiles * 128 * 128 * 4, fbytes = 65536;
+        if (nsb < 2) { fprintf(stderr, "split-K needs two superblocks\n"); return 2; }
+        const size_t pbytes = (size_t)ntiles * 2 * 8 * 16384, fbytes = 65536;
         char *sc = (char *)shared_alloc(fbytes + pbytes);
         memset(sc, 0, fbytes);
-        p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
-        int split = (total * 8 + 8) / 16;
-        p.sb_split = split < 1 ? 1 : (split > total - 1 ? total - 1 : split);
+        p.flags = flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
+        p.sb_split = (nsb + 1) / 2;
         p.xchg_l2 = l2;
     } else if (splitk != 1) { fprintf(stderr, "splitk 1 or 2\n"); return 2; }
-    const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
-    if (min_nsb < 3) { fprintf(stderr, "the kernel needs 3 superblocks of K per work-group\n"); return 2; }
     const unsigned nblk = (unsigned)(ntiles * splitk);
-    switch (exp) {
-        case 0: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 0>(p); }, nblk, 768); break;
-        case 1: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 1>(p); }, nblk, 768); break;
-        case 2: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 2>(p); }, nblk, 768); break;
-        case 4: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 4>(p); }, nblk, 768); break;
-        case 6: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 6>(p); }, nblk, 768); break;
-        case 100: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, false, 0>(p); }, nblk, 768); break;      // compute waves unpack the scales themselves
-        case 32: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 32>(p); }, nblk, 768); break;        // timing ablations (results are garbage): bounds checks only
-        case 480: emu_launch([&] { k_gemm_kq_w12<CDNA4_Q4_K, true, 480>(p); }, nblk, 768); break;
-        default: fprintf(stderr, "exp not built into the emulator\n"); return 2;
-    }
+    if (tm == 128) emu_launch([&] { k_gemm_kq_t64<CDNA4_Q4_K, 128>(p); }, nblk, 512);
+    else emu_launch([&] { k_gemm_kq_t64<CDNA4_Q4_K, 256>(p); }, nblk, 512);
+    if (flags) for (int i = 0; i < ntiles * 2; i++) if (flags[i] != 0) { fprintf(stderr, "exchange flag %d was not reset by its reader (%u)\n", i, flags[i]); return 4; }
     FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)B * M, f); fclose(f);
     return 0;
 }

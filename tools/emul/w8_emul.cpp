@@ -96,9 +96,10 @@ int main(int argc, char **argv) {
     p.tiles_m = (M + 127) / 128; p.tiles_b = (B + 127) / 128;
     const int ntiles = p.tiles_m * p.tiles_b, total = K / 256;
     if (splitk == 2) {
-        const size_t pbytes = (size_t)ntiles * 128 * 128 * 4;
-        char *sc = (char *)shared_alloc(pbytes + (size_t)ntiles * 8 + 256);
-        p.partial = (float *)sc; p.flags = (unsigned *)(sc + pbytes); p.epoch = 7;
+        const size_t pbytes = (size_t)ntiles * 128 * 128 * 4, fbytes = 65536;
+        char *sc = (char *)shared_alloc(fbytes + pbytes);
+        memset(sc, 0, fbytes);
+        p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
         int split = (total * 8 + 8) / 16;
         p.sb_split = split < 1 ? 1 : (split > total - 1 ? total - 1 : split);
         p.xchg_l2 = l2;
