@@ -8,38 +8,18 @@
 // Error conventions follow SURVEY.md §8(b): programmer errors abort (GGML_ASSERT), OOM -> NULL buffer,
 // runtime failures -> GGML_STATUS_FAILED.  Unsupported ops are declined in supports_op (the scheduler then
 // places them on the CPU backend); nothing is ever computed on the host here.
-#include "ggml.h"
-#include "ggml-backend.h"
-#include "ggml-backend-impl.h"
-#include "ggml_cdna4.h"
+#include "ggml_cdna4_internal.h"
 #include "ggml_cdna4_ops.h"
 
-#include <hip/hip_runtime.h>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
 
-#define CDNA4_MAX_DEVICES 16
-#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "ggml-cdna4: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); GGML_ABORT("HIP error"); } } while (0)
-
 struct cdna4_device_ctx { int device; std::string name, description; };
 struct cdna4_buft_ctx   { int device; std::string name; };
 struct cdna4_buffer_ctx { int device; void * base; size_t size; };
-struct cdna4_backend_ctx {
-    int device; hipStream_t stream; std::string name;
-    void * ws = nullptr; size_t ws_size = 0;
-    void * need_ws(size_t n) {
-        if (n <= ws_size) return ws;
-        HIP_OK(hipStreamSynchronize(stream));
-        if (ws) HIP_OK(hipFree(ws));
-        ws_size = (n + (8u << 20)) & ~(size_t)((1u << 20) - 1);
-        if (hipMalloc(&ws, ws_size) != hipSuccess) { (void)hipGetLastError(); ws = nullptr; ws_size = 0; }
-        return ws;
-    }
-};
 
 static ggml_backend_reg_t ggml_backend_cdna4_reg(void);
 static ggml_backend_buffer_type_t cdna4_buffer_type(int device);
@@ -61,7 +41,7 @@ static void cdna4_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
     HIP_OK(hipSetDevice(ctx->device));
     HIP_OK(hipMemset((char *)tensor->data + offset, value, size));
-    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipStreamSynchronize(0));
 }
 static void cdna4_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
@@ -71,7 +51,8 @@ static void cdna4_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * 
 static void cdna4_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
     HIP_OK(hipSetDevice(ctx->device));
-    HIP_OK(hipDeviceSynchronize());
+    // (no device-wide synchronize: a blocking copy on the null stream is ordered behind everything the backend's stream — a
+    //  blocking stream — was given before this call)
     HIP_OK(hipMemcpy(data, (const char *)tensor->data + offset, size, hipMemcpyDeviceToHost));
 }
 static bool cdna4_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * src, ggml_tensor * dst) {
@@ -143,6 +124,7 @@ static bool is_qweight(ggml_type t) { return t == GGML_TYPE_Q4_0 || t == GGML_TY
 static bool supports_mul_mat(const ggml_tensor * op) {
     const ggml_tensor * a = op->src[0], * b = op->src[1];
     if (op->type != GGML_TYPE_F32 || !ggml_is_contiguous(op)) return false;
+    if (a->buffer && cdna4_buft_is_split(a->buffer->buft)) return cdna4_split_supports_mul_mat(op);
     if (is_qweight(a->type)) {
         // src1 must be F32 (the CPU backend itself only takes F32 or vec_dot_type, src/ggml-cpu/ggml-cpu.cpp:404-405)
         if (b->type != GGML_TYPE_F32) return false;
@@ -166,6 +148,7 @@ static bool supports_mul_mat_id(const ggml_tensor * op) {
 
 static enum ggml_status compute_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst) {
     const ggml_tensor * a = dst->src[0], * b = dst->src[1];
+    if (a->buffer && cdna4_buft_is_split(a->buffer->buft)) return cdna4_split_mul_mat(ctx, dst);
     if (!is_qweight(a->type)) return cdna4_ops_compute(ctx, dst);
     const int64_t K = a->ne[0], M = a->ne[1], N = b->ne[1];
     const int64_t r2 = b->ne[2] / a->ne[2], r3 = b->ne[3] / a->ne[3];
@@ -211,6 +194,8 @@ static void cdna4_backend_free(ggml_backend_t backend) {
     cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    cdna4_split_free_lanes(ctx);
+    if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     if (ctx->ws) (void)hipFree(ctx->ws);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -242,21 +227,72 @@ static enum ggml_status cdna4_backend_graph_compute(ggml_backend_t backend, ggml
     }
     return GGML_STATUS_SUCCESS;
 }
+// ---- asynchronous tensor access and events: what ggml_backend_sched uses to overlap a split's input copies with the previous
+//      split's compute (src/ggml-backend.cpp:1361-1443); counterparts: ggml-cuda.cu:2353-2406, 2772-2809
+static bool backend_is_cdna4(ggml_backend_t backend);
+static void cdna4_backend_set_tensor_async(ggml_backend_t backend, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
+    ggml_backend_buffer_t buf = tensor->view_src ? tensor->view_src->buffer : tensor->buffer;
+    GGML_ASSERT(buffer_is_cdna4(buf) && "set_tensor_async: the tensor must live in a buffer of this backend");
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipMemcpyAsync((char *)tensor->data + offset, data, size, hipMemcpyHostToDevice, ctx->stream));
+}
+static void cdna4_backend_get_tensor_async(ggml_backend_t backend, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
+    ggml_backend_buffer_t buf = tensor->view_src ? tensor->view_src->buffer : tensor->buffer;
+    GGML_ASSERT(buffer_is_cdna4(buf) && "get_tensor_async: the tensor must live in a buffer of this backend");
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipMemcpyAsync(data, (const char *)tensor->data + offset, size, hipMemcpyDeviceToHost, ctx->stream));
+}
+static bool cdna4_backend_cpy_tensor_async(ggml_backend_t backend_src, ggml_backend_t backend_dst, const ggml_tensor * src, ggml_tensor * dst) {
+    if (!backend_is_cdna4(backend_src) || !backend_is_cdna4(backend_dst)) return false;
+    ggml_backend_buffer_t sbuf = src->view_src ? src->view_src->buffer : src->buffer, dbuf = dst->view_src ? dst->view_src->buffer : dst->buffer;
+    if (!buffer_is_cdna4(sbuf) || !buffer_is_cdna4(dbuf)) return false;
+    cdna4_backend_ctx * sctx = (cdna4_backend_ctx *)backend_src->context, * dctx = (cdna4_backend_ctx *)backend_dst->context;
+    const int sdev = ((cdna4_buffer_ctx *)sbuf->context)->device, ddev = ((cdna4_buffer_ctx *)dbuf->context)->device;
+    if (sdev != sctx->device || ddev != dctx->device) return false;
+    if (backend_src == backend_dst) {
+        HIP_OK(hipSetDevice(sctx->device));
+        HIP_OK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(dst), hipMemcpyDeviceToDevice, sctx->stream));
+        return true;
+    }
+    // the copy runs on the SOURCE stream (behind whatever produced src); the destination stream then waits for it
+    HIP_OK(hipSetDevice(sctx->device));
+    if (sdev == ddev) HIP_OK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(dst), hipMemcpyDeviceToDevice, sctx->stream));
+    else HIP_OK(hipMemcpyPeerAsync(dst->data, ddev, src->data, sdev, ggml_nbytes(dst), sctx->stream));
+    if (!sctx->ev_copy) HIP_OK(hipEventCreateWithFlags(&sctx->ev_copy, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(sctx->ev_copy, sctx->stream));
+    HIP_OK(hipSetDevice(dctx->device));
+    HIP_OK(hipStreamWaitEvent(dctx->stream, sctx->ev_copy, 0));
+    return true;
+}
+static void cdna4_backend_event_record(ggml_backend_t backend, ggml_backend_event_t event) {
+    cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipEventRecord((hipEvent_t)event->context, ctx->stream));
+}
+static void cdna4_backend_event_wait(ggml_backend_t backend, ggml_backend_event_t event) {
+    cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
+    if (!backend_is_cdna4(backend)) GGML_ABORT("event_wait on a foreign backend");
+    HIP_OK(hipSetDevice(ctx->device));
+    HIP_OK(hipStreamWaitEvent(ctx->stream, (hipEvent_t)event->context, 0));
+}
 static const ggml_backend_i cdna4_backend_iface = {
     /* .get_name           = */ cdna4_backend_get_name,
     /* .free               = */ cdna4_backend_free,
-    /* .set_tensor_async   = */ NULL,
-    /* .get_tensor_async   = */ NULL,
-    /* .cpy_tensor_async   = */ NULL,
+    /* .set_tensor_async   = */ cdna4_backend_set_tensor_async,
+    /* .get_tensor_async   = */ cdna4_backend_get_tensor_async,
+    /* .cpy_tensor_async   = */ cdna4_backend_cpy_tensor_async,
     /* .synchronize        = */ cdna4_backend_synchronize,
     /* .graph_plan_create  = */ NULL,
     /* .graph_plan_free    = */ NULL,
     /* .graph_plan_update  = */ NULL,
     /* .graph_plan_compute = */ NULL,
     /* .graph_compute      = */ cdna4_backend_graph_compute,
-    /* .event_record       = */ NULL,
-    /* .event_wait         = */ NULL,
+    /* .event_record       = */ cdna4_backend_event_record,
+    /* .event_wait         = */ cdna4_backend_event_wait,
 };
+static bool backend_is_cdna4(ggml_backend_t backend) { return backend && backend->iface.get_name == cdna4_backend_get_name; }
 static ggml_guid_t cdna4_guid(void) {
     static ggml_guid guid = {0x63, 0x64, 0x6e, 0x61, 0x34, 0x2d, 0x6d, 0x69, 0x33, 0x35, 0x35, 0x78, 0x2d, 0x67, 0x67, 0x01};
     return &guid;
@@ -280,7 +316,7 @@ static void cdna4_dev_get_props(ggml_backend_dev_t dev, ggml_backend_dev_props *
     props->description = cdna4_dev_get_description(dev);
     props->type = GGML_BACKEND_DEVICE_TYPE_GPU;
     cdna4_dev_get_memory(dev, &props->memory_free, &props->memory_total);
-    props->caps = { /* async */ false, /* host_buffer */ false, /* buffer_from_host_ptr */ false, /* events */ false };
+    props->caps = { /* async */ true, /* host_buffer */ true, /* buffer_from_host_ptr */ false, /* events */ true };
 }
 static ggml_backend_t cdna4_dev_init_backend(ggml_backend_dev_t dev, const char *) {
     cdna4_device_ctx * dctx = (cdna4_device_ctx *)dev->context;
@@ -301,6 +337,7 @@ static bool cdna4_dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
     }
 }
 static bool cdna4_dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
+    if (cdna4_buft_is_split(buft)) return buft->device == dev;          // row-split weights: consumed by the backend of their main device
     return buft_is_cdna4(buft) && ((cdna4_buft_ctx *)buft->context)->device == ((cdna4_device_ctx *)dev->context)->device;
 }
 static bool cdna4_dev_offload_op(ggml_backend_dev_t, const ggml_tensor * op) {
@@ -308,6 +345,42 @@ static bool cdna4_dev_offload_op(ggml_backend_dev_t, const ggml_tensor * op) {
     const int64_t batch = op->op == GGML_OP_MUL_MAT_ID ? op->ne[2] : op->ne[1];
     return (op->op == GGML_OP_MUL_MAT || op->op == GGML_OP_MUL_MAT_ID) && batch >= 32;
 }
+// ---- pinned host buffer type: what the scheduler / applications put CPU-side tensors in so that copies to the device are true
+//      DMA transfers (counterpart: ggml_backend_cuda_host_buffer_type, ggml-cuda.cu:1041-1118).  The buffer itself is ggml's
+//      CPU buffer over hipHostMalloc'ed memory.
+static const char * cdna4_host_buft_get_name(ggml_backend_buffer_type_t) { return "CDNA4_Host"; }
+static void cdna4_host_buffer_free(ggml_backend_buffer_t buffer) { HIP_OK(hipHostFree(buffer->context)); }
+static ggml_backend_buffer_t cdna4_host_buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    void * ptr = nullptr;
+    if (hipHostMalloc(&ptr, size > 0 ? size : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return ggml_backend_buft_alloc_buffer(ggml_backend_cpu_buffer_type(), size);      // pageable memory still works, just slower
+    }
+    ggml_backend_buffer_t buffer = ggml_backend_cpu_buffer_from_ptr(ptr, size);
+    buffer->buft = buft;
+    buffer->iface.free_buffer = cdna4_host_buffer_free;
+    return buffer;
+}
+static size_t cdna4_host_buft_get_alignment(ggml_backend_buffer_type_t) { return ggml_backend_buft_get_alignment(ggml_backend_cpu_buffer_type()); }
+static bool cdna4_host_buft_is_host(ggml_backend_buffer_type_t) { return true; }
+static ggml_backend_buffer_type_t cdna4_dev_get_host_buffer_type(ggml_backend_dev_t dev) {
+    static ggml_backend_buffer_type host_buft = {
+        /* .iface   = */ { cdna4_host_buft_get_name, cdna4_host_buft_alloc_buffer, cdna4_host_buft_get_alignment, NULL, NULL, cdna4_host_buft_is_host },
+        /* .device  = */ nullptr,
+        /* .context = */ nullptr,
+    };
+    if (!host_buft.device) host_buft.device = dev;
+    return &host_buft;
+}
+static ggml_backend_event_t cdna4_dev_event_new(ggml_backend_dev_t dev) {
+    HIP_OK(hipSetDevice(((cdna4_device_ctx *)dev->context)->device));
+    hipEvent_t ev = nullptr;
+    HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    return new ggml_backend_event{ /* .device = */ dev, /* .context = */ ev };
+}
+static void cdna4_dev_event_free(ggml_backend_dev_t, ggml_backend_event_t event) { (void)hipEventDestroy((hipEvent_t)event->context); delete event; }
+static void cdna4_dev_event_synchronize(ggml_backend_dev_t, ggml_backend_event_t event) { HIP_OK(hipEventSynchronize((hipEvent_t)event->context)); }
+
 static const ggml_backend_device_i cdna4_device_iface = {
     /* .get_name             = */ cdna4_dev_get_name,
     /* .get_description      = */ cdna4_dev_get_description,
@@ -316,14 +389,14 @@ static const ggml_backend_device_i cdna4_device_iface = {
     /* .get_props            = */ cdna4_dev_get_props,
     /* .init_backend         = */ cdna4_dev_init_backend,
     /* .get_buffer_type      = */ cdna4_dev_get_buffer_type,
-    /* .get_host_buffer_type = */ NULL,
+    /* .get_host_buffer_type = */ cdna4_dev_get_host_buffer_type,
     /* .buffer_from_host_ptr = */ NULL,
     /* .supports_op          = */ cdna4_dev_supports_op,
     /* .supports_buft        = */ cdna4_dev_supports_buft,
     /* .offload_op           = */ cdna4_dev_offload_op,
-    /* .event_new            = */ NULL,
-    /* .event_free           = */ NULL,
-    /* .event_synchronize    = */ NULL,
+    /* .event_new            = */ cdna4_dev_event_new,
+    /* .event_free           = */ cdna4_dev_event_free,
+    /* .event_synchronize    = */ cdna4_dev_event_synchronize,
 };
 
 // ============================================================================================================
@@ -341,6 +414,8 @@ static ggml_backend_buffer_type_t cdna4_buffer_type(int device) {
     GGML_ASSERT(g_reg && device >= 0 && device < g_reg->n);
     return &g_reg->bufts[device];
 }
+int cdna4_reg_device_count(void) { (void)ggml_backend_cdna4_reg(); return g_reg ? g_reg->n : 0; }
+ggml_backend_dev_t cdna4_reg_device(int i) { (void)ggml_backend_cdna4_reg(); GGML_ASSERT(g_reg && i >= 0 && i < g_reg->n); return &g_reg->devices[i]; }
 static const char * cdna4_reg_get_name(ggml_backend_reg_t) { return "CDNA4"; }
 static size_t cdna4_reg_get_device_count(ggml_backend_reg_t reg) { return (size_t)((cdna4_reg_ctx *)reg->context)->n; }
 static ggml_backend_dev_t cdna4_reg_get_device(ggml_backend_reg_t reg, size_t index) {
@@ -352,6 +427,7 @@ static ggml_backend_feature g_features[] = { {"WAVE64", "1"}, {"MFMA_F16", "1"},
 static ggml_backend_feature * cdna4_get_features(ggml_backend_reg_t) { return g_features; }
 static void * cdna4_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (strcmp(name, "ggml_backend_get_features") == 0) return (void *)cdna4_get_features;
+    if (strcmp(name, "ggml_backend_split_buffer_type") == 0) return (void *)cdna4_split_buffer_type;      // ggml_backend_split_buffer_type_t, include/ggml-backend.h:188
     return NULL;
 }
 static const ggml_backend_reg_i cdna4_reg_iface = {

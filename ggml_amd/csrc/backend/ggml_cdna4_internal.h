@@ -1,0 +1,52 @@
+// ggml_cdna4_internal.h — structures shared by the translation units of the plug-in (ggml_cdna4_backend.cpp: the five vtables;
+// ggml_cdna4_split.cpp: the row-split buffer type and its multi-device MUL_MAT).
+#pragma once
+#include "ggml.h"
+#include "ggml-backend.h"
+#include "ggml-backend-impl.h"
+#include "ggml_cdna4.h"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <string>
+
+#define CDNA4_MAX_DEVICES 16
+#define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "ggml-cdna4: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); GGML_ABORT("HIP error"); } } while (0)
+
+// one shard of a row-split MUL_MAT on another device (or, under GGML_CDNA4_SPLIT_SELF, another slice of the same one): its own
+// stream, scratch and staging buffers, created on first use and kept for the life of the backend
+struct cdna4_lane {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    void * x = nullptr;  size_t x_bytes = 0;      // activations copied from the main device
+    void * y = nullptr;  size_t y_bytes = 0;      // this shard's output rows, [B][rows] f32
+    void * ws = nullptr; size_t ws_bytes = 0;     // ggml_cdna4_mul_mat workspace
+};
+
+struct cdna4_backend_ctx {
+    int device; hipStream_t stream; std::string name;
+    void * ws = nullptr; size_t ws_size = 0;
+    hipEvent_t ev_x = nullptr;                    // "activations are ready on the main stream" (split MUL_MAT)
+    hipEvent_t ev_copy = nullptr;                 // cpy_tensor_async between two backends
+    cdna4_lane lanes[CDNA4_MAX_DEVICES];
+    void * need_ws(size_t n) {
+        if (n <= ws_size) return ws;
+        HIP_OK(hipStreamSynchronize(stream));
+        if (ws) HIP_OK(hipFree(ws));
+        ws_size = (n + (8u << 20)) & ~(size_t)((1u << 20) - 1);
+        if (hipMalloc(&ws, ws_size) != hipSuccess) { (void)hipGetLastError(); ws = nullptr; ws_size = 0; }
+        return ws;
+    }
+};
+
+// ---- ggml_cdna4_split.cpp
+// the well-known proc address "ggml_backend_split_buffer_type" (include/ggml-backend.h:188): weights whose rows (output features)
+// are sharded over the node's GPUs; tensor_split = CDNA4_MAX_DEVICES proportions (NULL / all zero: equal shares)
+ggml_backend_buffer_type_t cdna4_split_buffer_type(int main_device, const float * tensor_split);
+bool cdna4_buft_is_split(ggml_backend_buffer_type_t buft);
+bool cdna4_split_supports_mul_mat(const ggml_tensor * op);
+enum ggml_status cdna4_split_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst);
+void cdna4_split_free_lanes(cdna4_backend_ctx * ctx);
+int cdna4_reg_device_count(void);
+ggml_backend_dev_t cdna4_reg_device(int i);

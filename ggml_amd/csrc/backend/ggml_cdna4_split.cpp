@@ -1,0 +1,227 @@
+// ggml_cdna4_split.cpp — the row-split buffer type of the MI355X plug-in and the multi-device MUL_MAT that consumes it.
+//
+// What it replaces: ggml_backend_cuda_split_buffer_type and the `split` path of ggml_cuda_op_mul_mat
+// (/root/reference/src/ggml-cuda/ggml-cuda.cu:714-1040, 1353-1666; typedef include/ggml-backend.h:188).  Semantics kept: a 2-D
+// weight tensor placed in this buffer type has its ROWS (= output features) partitioned into contiguous ranges, one per GPU;
+// it must be written and read whole (set_tensor / get_tensor scatter / gather the ranges); views of it are not supported;
+// only MUL_MAT may consume it, with the activations and the result living on the main device.
+// What is different (MI355X-first): shard boundaries are multiples of 128 rows (the GEMM tile), every shard runs the SAME
+// C-ABI call the single-GPU path runs (ggml_cdna4_mul_mat: activation quantizer + GEMV / MFMA GEMM) on its own stream of its
+// own device — no chunking of the activation columns, no per-chunk events: one peer copy of X in, one strided peer copy of
+// the [B][rows] result out per shard, over xGMI; the main device's shard writes straight into dst.
+// GGML_CDNA4_SPLIT_SELF=N (tests on a one-GPU box): N shards, all on the main device — every code path of the scatter / gather /
+// lane machinery runs, the peer copies become local ones.
+#include "ggml_cdna4_internal.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+struct split_buft_ctx {
+    int main_device; int n_shards; bool self;
+    float bound[CDNA4_MAX_DEVICES + 1];            // cumulative row fractions, bound[0] = 0, bound[n] = 1
+    int shard_dev[CDNA4_MAX_DEVICES];
+    std::string name;
+};
+struct split_tensor {                              // tensor->extra
+    int n = 0;
+    int dev[CDNA4_MAX_DEVICES]; void * data[CDNA4_MAX_DEVICES]; int64_t lo[CDNA4_MAX_DEVICES], hi[CDNA4_MAX_DEVICES];
+};
+struct split_buffer_ctx { std::vector<split_tensor *> tensors; };
+
+static int self_shards() {
+    static const int n = getenv("GGML_CDNA4_SPLIT_SELF") ? atoi(getenv("GGML_CDNA4_SPLIT_SELF")) : 0;
+    return n > CDNA4_MAX_DEVICES ? CDNA4_MAX_DEVICES : n;
+}
+// rows [lo, hi) of shard i: fractions of the row count, rounded DOWN to the 128-row GEMM tile (the last shard takes the rest)
+static void shard_rows(const split_buft_ctx * c, int64_t nrows, int i, int64_t * lo, int64_t * hi) {
+    auto edge = [&](int k) -> int64_t { if (k <= 0) return 0; if (k >= c->n_shards) return nrows; int64_t r = (int64_t)((double)nrows * c->bound[k]); r -= r % 128; return r < 0 ? 0 : (r > nrows ? nrows : r); };
+    *lo = edge(i); *hi = edge(i + 1);
+    if (*hi < *lo) *hi = *lo;
+}
+
+static const char * split_buft_get_name(ggml_backend_buffer_type_t buft) { return ((split_buft_ctx *)buft->context)->name.c_str(); }
+bool cdna4_buft_is_split(ggml_backend_buffer_type_t buft) { return buft && buft->iface.get_name == split_buft_get_name; }
+
+// ---- buffer
+static void split_buffer_free(ggml_backend_buffer_t buffer) {
+    split_buffer_ctx * ctx = (split_buffer_ctx *)buffer->context;
+    for (split_tensor * t : ctx->tensors) {
+        for (int i = 0; i < t->n; i++) if (t->data[i]) { HIP_OK(hipSetDevice(t->dev[i])); HIP_OK(hipDeviceSynchronize()); HIP_OK(hipFree(t->data[i])); }
+        delete t;
+    }
+    delete ctx;
+}
+static void * split_buffer_get_base(ggml_backend_buffer_t) { return (void *)0x1000; }   // never dereferenced: the allocators only do arithmetic on it
+static void split_buffer_init_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor) {
+    GGML_ASSERT(tensor->view_src == nullptr);                       // views of split tensors are not supported (as in the reference)
+    GGML_ASSERT(ggml_is_contiguous(tensor) && tensor->ne[2] == 1 && tensor->ne[3] == 1);
+    split_buffer_ctx * ctx = (split_buffer_ctx *)buffer->context;
+    const split_buft_ctx * bc = (const split_buft_ctx *)buffer->buft->context;
+    split_tensor * st = new split_tensor;
+    st->n = bc->n_shards;
+    const size_t row_bytes = ggml_row_size(tensor->type, tensor->ne[0]);
+    for (int i = 0; i < st->n; i++) {
+        shard_rows(bc, tensor->ne[1], i, &st->lo[i], &st->hi[i]);
+        st->dev[i] = bc->shard_dev[i]; st->data[i] = nullptr;
+        const int64_t rows = st->hi[i] - st->lo[i];
+        if (rows == 0) continue;
+        HIP_OK(hipSetDevice(st->dev[i]));
+        HIP_OK(hipMalloc(&st->data[i], (size_t)rows * row_bytes + 256));   // slack: kernels read whole 16-byte pieces
+    }
+    ctx->tensors.push_back(st);
+    tensor->extra = st;
+}
+static void split_buffer_set_tensor(ggml_backend_buffer_t, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    GGML_ASSERT(offset == 0 && size == ggml_nbytes(tensor));         // split tensors are written whole
+    const split_tensor * st = (const split_tensor *)tensor->extra;
+    const size_t row_bytes = tensor->nb[1];
+    for (int i = 0; i < st->n; i++) {
+        const int64_t rows = st->hi[i] - st->lo[i];
+        if (rows == 0) continue;
+        HIP_OK(hipSetDevice(st->dev[i]));
+        HIP_OK(hipMemcpy(st->data[i], (const char *)data + st->lo[i] * row_bytes, (size_t)rows * row_bytes, hipMemcpyHostToDevice));
+    }
+}
+static void split_buffer_get_tensor(ggml_backend_buffer_t, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    GGML_ASSERT(offset == 0 && size == ggml_nbytes(tensor));
+    const split_tensor * st = (const split_tensor *)tensor->extra;
+    const size_t row_bytes = tensor->nb[1];
+    for (int i = 0; i < st->n; i++) {
+        const int64_t rows = st->hi[i] - st->lo[i];
+        if (rows == 0) continue;
+        HIP_OK(hipSetDevice(st->dev[i]));
+        HIP_OK(hipMemcpy((char *)data + st->lo[i] * row_bytes, st->data[i], (size_t)rows * row_bytes, hipMemcpyDeviceToHost));
+    }
+}
+static void split_buffer_clear(ggml_backend_buffer_t, uint8_t) {}
+static const ggml_backend_buffer_i split_buffer_iface = {
+    /* .free_buffer   = */ split_buffer_free,
+    /* .get_base      = */ split_buffer_get_base,
+    /* .init_tensor   = */ split_buffer_init_tensor,
+    /* .memset_tensor = */ NULL,
+    /* .set_tensor    = */ split_buffer_set_tensor,
+    /* .get_tensor    = */ split_buffer_get_tensor,
+    /* .cpy_tensor    = */ NULL,
+    /* .clear         = */ split_buffer_clear,
+    /* .reset         = */ NULL,
+};
+
+// ---- buffer type
+static ggml_backend_buffer_t split_buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    // the per-device slices are allocated tensor by tensor in init_tensor (the split is only known per tensor)
+    return ggml_backend_buffer_init(buft, split_buffer_iface, new split_buffer_ctx, size);
+}
+static size_t split_buft_get_alignment(ggml_backend_buffer_type_t) { return 256; }
+static size_t split_buft_get_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor * tensor) { return (ggml_nbytes(tensor) + 255) & ~(size_t)255; }
+static bool split_buft_is_host(ggml_backend_buffer_type_t) { return false; }
+static const ggml_backend_buffer_type_i split_buft_iface = {
+    /* .get_name       = */ split_buft_get_name,
+    /* .alloc_buffer   = */ split_buft_alloc_buffer,
+    /* .get_alignment  = */ split_buft_get_alignment,
+    /* .get_max_size   = */ NULL,
+    /* .get_alloc_size = */ split_buft_get_alloc_size,
+    /* .is_host        = */ split_buft_is_host,
+};
+
+ggml_backend_buffer_type_t cdna4_split_buffer_type(int main_device, const float * tensor_split) {
+    static std::mutex mu;
+    static std::map<std::string, ggml_backend_buffer_type *> cache;     // one buffer type per distinct (main device, split)
+    std::lock_guard<std::mutex> lock(mu);
+    const int ndev = cdna4_reg_device_count();
+    if (main_device < 0 || main_device >= ndev) return nullptr;
+    split_buft_ctx c{};
+    c.main_device = main_device;
+    const int self = self_shards();
+    c.self = self > 1;
+    c.n_shards = c.self ? self : ndev;
+    float w[CDNA4_MAX_DEVICES]; float sum = 0.f;
+    for (int i = 0; i < c.n_shards; i++) { w[i] = (tensor_split && !c.self) ? tensor_split[i] : 0.f; if (w[i] < 0.f) w[i] = 0.f; sum += w[i]; }
+    if (sum <= 0.f) { for (int i = 0; i < c.n_shards; i++) w[i] = 1.f; sum = (float)c.n_shards; }      // NULL / all zero: equal shares
+    c.bound[0] = 0.f;
+    for (int i = 0; i < c.n_shards; i++) { c.bound[i + 1] = c.bound[i] + w[i] / sum; c.shard_dev[i] = c.self ? main_device : i; }
+    c.bound[c.n_shards] = 1.f;
+    std::string key = std::to_string(main_device) + (c.self ? "s" : "d");
+    for (int i = 0; i <= c.n_shards; i++) key += ":" + std::to_string(c.bound[i]);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    c.name = "CDNA4_Split";
+    ggml_backend_buffer_type * buft = new ggml_backend_buffer_type{ /* .iface = */ split_buft_iface, /* .device = */ cdna4_reg_device(main_device), /* .context = */ new split_buft_ctx(c) };
+    cache[key] = buft;
+    return buft;
+}
+
+// ---- MUL_MAT with row-split weights
+bool cdna4_split_supports_mul_mat(const ggml_tensor * op) {
+    const ggml_tensor * a = op->src[0], * b = op->src[1];
+    if (a->ne[2] != 1 || a->ne[3] != 1 || !a->extra) return false;                  // one matrix, initialised by init_tensor
+    if (b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !ggml_is_contiguous(b) || !ggml_is_contiguous(op)) return false;
+    return ggml_cdna4_row_size((int)a->type, a->ne[0]) != 0 && ggml_cdna4_mul_mat_workspace_size((int)a->type, a->ne[0], 1) != 0;
+}
+static void * lane_buf(void ** p, size_t * have, size_t want) {
+    if (want <= *have) return *p;
+    if (*p) HIP_OK(hipFree(*p));
+    *have = (want + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+    if (hipMalloc(p, *have) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; *have = 0; }
+    return *p;
+}
+void cdna4_split_free_lanes(cdna4_backend_ctx * ctx) {
+    for (cdna4_lane & l : ctx->lanes) {
+        if (l.device < 0) continue;
+        (void)hipSetDevice(l.device);
+        if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+        if (l.done) (void)hipEventDestroy(l.done);
+        if (l.x) (void)hipFree(l.x); if (l.y) (void)hipFree(l.y); if (l.ws) (void)hipFree(l.ws);
+        l = cdna4_lane{};
+    }
+    if (ctx->ev_x) { (void)hipSetDevice(ctx->device); (void)hipEventDestroy(ctx->ev_x); ctx->ev_x = nullptr; }
+}
+
+enum ggml_status cdna4_split_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst) {
+    const ggml_tensor * a = dst->src[0], * b = dst->src[1];
+    const split_tensor * st = (const split_tensor *)a->extra;
+    const split_buft_ctx * bc = (const split_buft_ctx *)a->buffer->buft->context;
+    const int64_t K = a->ne[0], M = a->ne[1], B = b->ne[1] * b->ne[2] * b->ne[3];       // contiguous b: all activation rows form one matrix
+    const size_t x_bytes = (size_t)B * K * sizeof(float);
+    const size_t ws_need = ggml_cdna4_mul_mat_workspace_size((int)a->type, K, B);
+    HIP_OK(hipSetDevice(ctx->device));
+    if (!ctx->ev_x) HIP_OK(hipEventCreateWithFlags(&ctx->ev_x, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(ctx->ev_x, ctx->stream));                                     // everything that produced X precedes this point
+    enum ggml_status status = GGML_STATUS_SUCCESS;
+    for (int i = 0; i < st->n && status == GGML_STATUS_SUCCESS; i++) {
+        const int64_t rows = st->hi[i] - st->lo[i];
+        if (rows == 0) continue;
+        const int dev = st->dev[i];
+        const bool local = dev == ctx->device && !bc->self;
+        if (local) {                                                                    // the main device's shard: straight into dst, on the main stream
+            void * ws = ctx->need_ws(ws_need);
+            if (!ws) return GGML_STATUS_ALLOC_FAILED;
+            if (ggml_cdna4_mul_mat((int)a->type, st->data[i], (int64_t)a->nb[1], (const float *)b->data, K, (float *)dst->data + st->lo[i], M, rows, K, B,
+                                   ws, ctx->ws_size, GGML_CDNA4_PATH_AUTO, 0, 0, ctx->stream)) { fprintf(stderr, "ggml-cdna4: split MUL_MAT failed: %s\n", ggml_cdna4_last_error()); status = GGML_STATUS_FAILED; }
+            continue;
+        }
+        cdna4_lane & l = ctx->lanes[i];
+        HIP_OK(hipSetDevice(dev));
+        if (l.device < 0) {
+            l.device = dev;
+            HIP_OK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+            if (dev != ctx->device) { const hipError_t e = hipDeviceEnablePeerAccess(ctx->device, 0); if (e != hipSuccess) (void)hipGetLastError(); }   // xGMI peer mapping (already enabled: fine)
+        }
+        if (!lane_buf(&l.x, &l.x_bytes, x_bytes) || !lane_buf(&l.y, &l.y_bytes, (size_t)B * rows * sizeof(float)) || !lane_buf(&l.ws, &l.ws_bytes, ws_need)) { status = GGML_STATUS_ALLOC_FAILED; break; }
+        HIP_OK(hipStreamWaitEvent(l.stream, ctx->ev_x, 0));
+        if (dev != ctx->device) HIP_OK(hipMemcpyPeerAsync(l.x, dev, b->data, ctx->device, x_bytes, l.stream));
+        else HIP_OK(hipMemcpyAsync(l.x, b->data, x_bytes, hipMemcpyDeviceToDevice, l.stream));
+        if (ggml_cdna4_mul_mat((int)a->type, st->data[i], (int64_t)a->nb[1], (const float *)l.x, K, (float *)l.y, rows, rows, K, B,
+                               l.ws, l.ws_bytes, GGML_CDNA4_PATH_AUTO, 0, 0, l.stream)) { fprintf(stderr, "ggml-cdna4: split MUL_MAT failed: %s\n", ggml_cdna4_last_error()); status = GGML_STATUS_FAILED; break; }
+        // the shard's [B][rows] block into columns [lo, hi) of dst's [B][M] rows (a strided copy over xGMI when dev != main)
+        HIP_OK(hipMemcpy2DAsync((float *)dst->data + st->lo[i], (size_t)M * sizeof(float), l.y, (size_t)rows * sizeof(float), (size_t)rows * sizeof(float), (size_t)B,
+                                hipMemcpyDeviceToDevice, l.stream));
+        HIP_OK(hipEventRecord(l.done, l.stream));
+    }
+    HIP_OK(hipSetDevice(ctx->device));
+    for (int i = 0; i < st->n; i++) if (ctx->lanes[i].device >= 0 && st->hi[i] > st->lo[i] && !(st->dev[i] == ctx->device && !bc->self)) HIP_OK(hipStreamWaitEvent(ctx->stream, ctx->lanes[i].done, 0));
+    return status;
+}

@@ -597,6 +597,9 @@ int cdna4_launch_gemv_q_fused_ids(const cdna4_gemv_args &a, const float *x, int6
             return launch_fused_ids<CDNA4_Q6_K>(a, x, x_row_stride, st);
         case CDNA4_Q4_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_ids<CDNA4_Q4_0>(a, x, x_row_stride, st);
         case CDNA4_Q8_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_ids<CDNA4_Q8_0>(a, x, x_row_stride, st);
+        case CDNA4_Q5_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_ids<CDNA4_Q5_0>(a, x, x_row_stride, st);
+        case CDNA4_Q2_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused_ids<CDNA4_Q2_K>(a, x, x_row_stride, st);
+        case CDNA4_Q3_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused_ids<CDNA4_Q3_K>(a, x, x_row_stride, st);
     }
     return cdna4_set_error_msg("gemv_q: unsupported weight type");
 }

@@ -10,6 +10,8 @@
 #   oracle/_ref/cpu_baseline      (oracle/cpu_baseline.cpp: times the reference CPU backend on one MUL_MAT)
 #   oracle/_ref/gpt-2-quantize    (examples/gpt-2/quantize.cpp, unmodified)
 #   oracle/_ref/gpt2_harness      (oracle/gpt2_harness.cpp: includes examples/gpt-2/main-backend.cpp verbatim)
+#   oracle/_ref/sched_harness     (oracle/sched_harness.cpp: includes examples/gpt-2/main-sched.cpp verbatim; ggml_backend_sched)
+#   oracle/_ref/split_harness     (oracle/split_harness.cpp: split buffer type, async copies, events, pinned host buffers via the public API)
 #
 # ISA flags: x86-64-v3 (AVX2+FMA+F16C) instead of the reference's default -march=native so the same
 # binaries run on this container's Xeon and on the GPU box's host CPU.  That selects the AVX2 bodies
@@ -36,7 +38,7 @@ BASE_OBJ := $(patsubst %,$(OUT)/obj/base/%.o,$(BASE_C) $(BASE_CXX))
 CPU_OBJ  := $(patsubst %,$(OUT)/obj/cpu/%.o,$(CPU_C) $(CPU_CXX))
 
 LIBS  := $(OUT)/libggml-base.so $(OUT)/libggml-cpu.so $(OUT)/libggml.so
-BINS  := $(OUT)/test-backend-ops $(OUT)/test-quantize-fns $(OUT)/test-mul-mat $(OUT)/cpu_baseline $(OUT)/gpt-2-quantize $(OUT)/gpt2_harness
+BINS  := $(OUT)/test-backend-ops $(OUT)/test-quantize-fns $(OUT)/test-mul-mat $(OUT)/cpu_baseline $(OUT)/gpt-2-quantize $(OUT)/gpt2_harness $(OUT)/sched_harness $(OUT)/split_harness
 
 all: $(LIBS) $(BINS)
 
@@ -71,6 +73,12 @@ $(OUT)/gpt-2-quantize: $(REF)/examples/gpt-2/quantize.cpp $(EXC) $(LIBS)
 	$(CXX) $(CXXFLAGS_COMMON) -I$(REF)/examples -o $@ $< $(EXC) -L$(OUT) -lggml -lggml-cpu -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN'
 $(OUT)/gpt2_harness: oracle/gpt2_harness.cpp $(EXC) $(LIBS)
 	$(CXX) $(CXXFLAGS_COMMON) -I$(REF) -I$(REF)/examples -o $@ $< $(EXC) -L$(OUT) -lggml -lggml-cpu -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN'
+
+# examples/gpt-2/main-sched.cpp, unmodified, with the plug-in in its (compile-time) GPU slot: see oracle/sched_harness.cpp
+$(OUT)/sched_harness: oracle/sched_harness.cpp $(EXC) $(LIBS)
+	$(CXX) $(CXXFLAGS_COMMON) -DGGML_USE_CUDA -I$(REF) -I$(REF)/examples -o $@ $< $(EXC) -L$(OUT) -lggml -lggml-cpu -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN'
+$(OUT)/split_harness: oracle/split_harness.cpp $(LIBS)
+	$(CXX) $(CXXFLAGS_COMMON) -o $@ $< -L$(OUT) -lggml -lggml-cpu -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN'
 
 clean:
 	rm -rf $(OUT)

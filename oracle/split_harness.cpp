@@ -1,0 +1,132 @@
+// oracle/split_harness.cpp — TEST INFRASTRUCTURE ONLY.  Drives the plug-in's scheduler-facing entry points through ggml's PUBLIC
+// API (include/ggml-backend.h), the way an application such as llama.cpp would, and checks every result against the reference
+// CPU backend on identical data:
+//   split    weights in ggml_backend_split_buffer_type (get_proc_address, include/ggml-backend.h:188), MUL_MAT on the main device
+//            (rows sharded per GGML_CDNA4_SPLIT_SELF on a one-GPU box), whole-tensor set / get round trip
+//   async    ggml_backend_tensor_set_async / get_async / copy_async between two backends of the device + events
+//   host     the pinned host buffer type (ggml_backend_dev_host_buffer_type): allocation, is_host, CPU-visible
+//   split_harness <plugin.so> <type: q4_K|q4_0|q8_0|q5_K|q6_K|f16> <M> <K> <B>      -> one JSON line
+#include "ggml.h"
+#include "ggml-alloc.h"
+#include "ggml-backend.h"
+#include "ggml-cpu.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+static double rel_l2(const std::vector<float> & a, const std::vector<float> & b) {
+    double num = 0, den = 0;
+    for (size_t i = 0; i < a.size(); i++) { num += ((double)a[i] - b[i]) * ((double)a[i] - b[i]); den += (double)b[i] * b[i]; }
+    return std::sqrt(num / (den > 0 ? den : 1));
+}
+static ggml_type parse_type(const std::string & s) {
+    for (int t = 0; t < GGML_TYPE_COUNT; t++) if (s == ggml_type_name((ggml_type)t)) return (ggml_type)t;
+    fprintf(stderr, "unknown type %s\n", s.c_str()); exit(2);
+}
+// Y = mul_mat(W, X) on `backend`, W living in `wbuft`
+static std::vector<float> run_mul_mat(ggml_backend_t backend, ggml_backend_buffer_type_t wbuft, ggml_type type, int64_t M, int64_t K, int64_t B,
+                                      const std::vector<uint8_t> & wq, const std::vector<float> & x, std::vector<uint8_t> * w_back) {
+    ggml_init_params ip = { ggml_tensor_overhead() * 8 + ggml_graph_overhead(), NULL, true };
+    ggml_context * wctx = ggml_init(ip), * cctx = ggml_init(ip);
+    ggml_tensor * W = ggml_new_tensor_2d(wctx, type, K, M);
+    ggml_backend_buffer_t wbuf = ggml_backend_alloc_ctx_tensors_from_buft(wctx, wbuft);
+    if (!wbuf) { fprintf(stderr, "weight buffer allocation failed\n"); exit(1); }
+    ggml_backend_buffer_set_usage(wbuf, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
+    ggml_backend_tensor_set(W, wq.data(), 0, wq.size());
+    if (w_back) { w_back->resize(wq.size()); ggml_backend_tensor_get(W, w_back->data(), 0, wq.size()); }
+    ggml_tensor * X = ggml_new_tensor_2d(cctx, GGML_TYPE_F32, K, B);
+    ggml_tensor * Y = ggml_mul_mat(cctx, W, X);
+    ggml_cgraph * gf = ggml_new_graph(cctx);
+    ggml_build_forward_expand(gf, Y);
+    ggml_gallocr_t ga = ggml_gallocr_new(ggml_backend_get_default_buffer_type(backend));
+    if (!ggml_gallocr_alloc_graph(ga, gf)) { fprintf(stderr, "graph allocation failed\n"); exit(1); }
+    ggml_backend_tensor_set(X, x.data(), 0, x.size() * sizeof(float));
+    if (ggml_backend_graph_compute(backend, gf) != GGML_STATUS_SUCCESS) { fprintf(stderr, "graph_compute failed\n"); exit(1); }
+    // twice: lanes, events and staging buffers are reused
+    if (ggml_backend_graph_compute(backend, gf) != GGML_STATUS_SUCCESS) { fprintf(stderr, "graph_compute failed\n"); exit(1); }
+    std::vector<float> y((size_t)M * B);
+    ggml_backend_tensor_get(Y, y.data(), 0, y.size() * sizeof(float));
+    ggml_gallocr_free(ga); ggml_backend_buffer_free(wbuf); ggml_free(wctx); ggml_free(cctx);
+    return y;
+}
+
+int main(int argc, char ** argv) {
+    if (argc < 6) { fprintf(stderr, "usage: %s plugin type M K B\n", argv[0]); return 2; }
+    const ggml_type type = parse_type(argv[2]);
+    const int64_t M = atoll(argv[3]), K = atoll(argv[4]), B = atoll(argv[5]);
+    ggml_backend_reg_t reg = ggml_backend_load(argv[1]);
+    if (!reg) { fprintf(stderr, "cannot load %s\n", argv[1]); return 1; }
+    ggml_backend_dev_t dev = ggml_backend_reg_dev_get(reg, 0);
+    ggml_backend_t gpu = ggml_backend_dev_init(dev, NULL), gpu2 = ggml_backend_dev_init(dev, NULL);
+    ggml_backend_t cpu = ggml_backend_init_by_type(GGML_BACKEND_DEVICE_TYPE_CPU, NULL);
+    if (!gpu || !gpu2 || !cpu) { fprintf(stderr, "backend init failed\n"); return 1; }
+
+    // data: uniform(-1, 1) through ggml_quantize_chunk, as tests/test-backend-ops.cpp does
+    std::mt19937 rng(1234);
+    std::uniform_real_distribution<float> u(-1.f, 1.f);
+    std::vector<float> wf((size_t)M * K), x((size_t)B * K);
+    for (auto & v : wf) v = u(rng);
+    for (auto & v : x) v = u(rng);
+    std::vector<uint8_t> wq(ggml_row_size(type, K) * M);
+    if (type == GGML_TYPE_F32) memcpy(wq.data(), wf.data(), wq.size());
+    else if (type == GGML_TYPE_F16) ggml_fp32_to_fp16_row(wf.data(), (ggml_fp16_t *)wq.data(), (int64_t)M * K);
+    else ggml_quantize_chunk(type, wf.data(), wq.data(), 0, M, K, NULL);
+
+    // ---- split
+    typedef ggml_backend_buffer_type_t (*split_fn)(int, const float *);
+    split_fn get_split = (split_fn)ggml_backend_reg_get_proc_address(reg, "ggml_backend_split_buffer_type");
+    if (!get_split) { fprintf(stderr, "ggml_backend_split_buffer_type is not exported\n"); return 1; }
+    ggml_backend_buffer_type_t sbuft = get_split(0, NULL);
+    if (!sbuft || !ggml_backend_dev_supports_buft(dev, sbuft) || ggml_backend_buft_is_host(sbuft)) { fprintf(stderr, "split buffer type rejected\n"); return 1; }
+    std::vector<uint8_t> w_back;
+    const std::vector<float> y_split = run_mul_mat(gpu, sbuft, type, M, K, B, wq, x, &w_back);
+    const std::vector<float> y_plain = run_mul_mat(gpu, ggml_backend_dev_buffer_type(dev), type, M, K, B, wq, x, NULL);
+    const std::vector<float> y_cpu = run_mul_mat(cpu, ggml_backend_get_default_buffer_type(cpu), type, M, K, B, wq, x, NULL);
+    const bool roundtrip = w_back == wq;
+    const bool same_as_plain = memcmp(y_split.data(), y_plain.data(), y_plain.size() * 4) == 0;
+
+    // ---- async copies + events between two backends (streams) of the device
+    bool async_ok = true;
+    {
+        ggml_init_params ip = { ggml_tensor_overhead() * 4, NULL, true };
+        ggml_context * c = ggml_init(ip);
+        ggml_tensor * a = ggml_new_tensor_1d(c, GGML_TYPE_F32, 1 << 20), * b = ggml_new_tensor_1d(c, GGML_TYPE_F32, 1 << 20);
+        ggml_backend_buffer_t buf = ggml_backend_alloc_ctx_tensors_from_buft(c, ggml_backend_dev_buffer_type(dev));
+        std::vector<float> src(1 << 20), dst(1 << 20, 0.f);
+        for (size_t i = 0; i < src.size(); i++) src[i] = (float)i * 0.5f;
+        ggml_backend_tensor_set_async(gpu, a, src.data(), 0, src.size() * 4);
+        ggml_backend_tensor_copy_async(gpu, gpu2, a, b);                      // gpu2's stream waits for the copy issued on gpu's
+        ggml_backend_event_t ev = ggml_backend_event_new(dev);
+        if (!ev) async_ok = false;
+        else {
+            ggml_backend_event_record(ev, gpu2);
+            ggml_backend_event_wait(gpu, ev);
+            ggml_backend_tensor_get_async(gpu, b, dst.data(), 0, dst.size() * 4);
+            ggml_backend_synchronize(gpu);
+            ggml_backend_event_synchronize(ev);
+            ggml_backend_event_free(ev);
+            async_ok = dst == src;
+        }
+        ggml_backend_buffer_free(buf); ggml_free(c);
+    }
+    // ---- pinned host buffer type
+    bool host_ok = false;
+    {
+        ggml_backend_buffer_type_t hb = ggml_backend_dev_host_buffer_type(dev);
+        if (hb && ggml_backend_buft_is_host(hb)) {
+            ggml_backend_buffer_t buf = ggml_backend_buft_alloc_buffer(hb, 1 << 20);
+            if (buf) { memset(ggml_backend_buffer_get_base(buf), 0x5a, 1 << 20); host_ok = ((uint8_t *)ggml_backend_buffer_get_base(buf))[12345] == 0x5a; ggml_backend_buffer_free(buf); }
+        }
+    }
+    ggml_backend_dev_props props; ggml_backend_dev_get_props(dev, &props);
+    printf("{\"type\":\"%s\",\"M\":%lld,\"K\":%lld,\"B\":%lld,\"split_vs_cpu_rel_l2\":%.3e,\"plain_vs_cpu_rel_l2\":%.3e,\"split_vs_plain_rel_l2\":%.3e,\"split_bit_identical_to_plain\":%s,"
+           "\"set_get_roundtrip\":%s,\"async_ok\":%s,\"host_buffer_ok\":%s,\"caps_async\":%s,\"caps_host_buffer\":%s,\"caps_events\":%s}\n",
+           ggml_type_name(type), (long long)M, (long long)K, (long long)B, rel_l2(y_split, y_cpu), rel_l2(y_plain, y_cpu), rel_l2(y_split, y_plain), same_as_plain ? "true" : "false",
+           roundtrip ? "true" : "false", async_ok ? "true" : "false", host_ok ? "true" : "false", props.caps.async ? "true" : "false", props.caps.host_buffer ? "true" : "false", props.caps.events ? "true" : "false");
+    ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
+    return 0;
+}

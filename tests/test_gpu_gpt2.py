@@ -95,3 +95,32 @@ def test_gpt2_logits_vs_cpu_backend(model, cpu_self_sensitivity, n_prompt, n_dec
     assert np.isfinite(lg).all()
     assert max(errs) < max(1e-3, 2.0 * cpu_self_sensitivity), (errs, cpu_self_sensitivity)
     assert sum(agree) >= 0.8 * len(agree), agree
+
+
+# ------------------------------------------------------------------------------------------------ ggml_backend_sched
+def _sched(model_path, ngl, out, n_prompt, n_decode, parallel=0):
+    r = subprocess.run([os.path.join(REF, "sched_harness"), model_path, str(ngl), PLUGIN, out, str(n_prompt), str(n_decode), "16", str(parallel)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1]), np.fromfile(out, np.float32).reshape(-1, N_VOCAB)
+
+
+@pytest.mark.parametrize("ngl,parallel", [(99, 0), (6, 0), (99, 1), (6, 1)])
+def test_gpt2_sched_graph_runs_unmodified(model, cpu_self_sensitivity, ngl, parallel):
+    """the reference's examples/gpt-2/main-sched.cpp (included verbatim by oracle/sched_harness.cpp) through
+    ggml_backend_sched_new({CDNA40, CPU}): all layers offloaded (ngl 99), half of them (ngl 6: the scheduler splits the graph and
+    copies activations between the backends), and with parallel = true (4 input copies + the plug-in's events).  Logits against
+    the same program on the CPU backend alone."""
+    if not os.path.exists(os.path.join(REF, "sched_harness")):
+        pytest.fail("prebuilt oracle/_ref/sched_harness missing from the snapshot")
+    q4, d = model
+    tc, lc = _sched(q4, 0, os.path.join(d, "s_cpu.bin"), 24, 3)
+    tg, lg = _sched(q4, ngl, os.path.join(d, "s_gpu.bin"), 24, 3, parallel)
+    assert "CDNA4" in tg["backends"] and "CDNA4" not in tc["backends"]
+    assert lc.shape == lg.shape == (4, N_VOCAB) and np.isfinite(lg).all()
+    errs = [R.rel_l2(lg[i], lc[i]) for i in range(4)]
+    with open(os.path.join(R.ROOT, "gpurun_out", "gpt2_parity.jsonl"), "a") as f:
+        f.write(json.dumps({"mode": "sched", "rel_l2_per_step": errs, "cpu": tc, "gpu": tg, "cpu_self_sensitivity_1e-6": cpu_self_sensitivity}) + "\n")
+    assert max(errs) < max(1e-3, 2.0 * cpu_self_sensitivity), (errs, cpu_self_sensitivity)
+    if ngl == 6:
+        assert tg["n_splits"] >= 2
