@@ -1,27 +1,32 @@
 #!/usr/bin/env python
-"""bench.py — BASELINE.json's metric on MI355X: effective TFLOPS of the Q4_K MUL_MAT hot path.
+"""bench.py — BASELINE.json's metric on MI355X: effective TFLOPS (2*M*N*K) + tokens/s of the Q4_K MUL_MAT hot path.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--variant V --splitk S   (kernel tuning knobs, 0 = auto)]
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config headline|c5] [--variant V --splitk S (kernel knobs, 0 = auto)]
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; one rank per GPU, RCCL)
 
-Workload (config.workload): Q4_K [4096x4096]·[4096x512] per GPU — the configuration the metric is quoted on
-(BASELINE.json "Q4_K mul_mat 4096² × batch{1,512}"); the batch-1 decode GEMV of the same matrix is reported
-beside it under "decode".  One step = one pass of the hot path over one batch with W and the fp32 activations
-already resident in HBM: Q8_K activation quantization (exactly the CPU backend's) + the MFMA GEMM.
-Multi-GPU: the weight rows (output features) are sharded over ranks as the reference's split buffer does
-(src/ggml-cuda/ggml-cuda.cu:729-742); weak scaling — every rank owns 4096 rows (the N-GPU job is the
-[4096N x 4096] matrix); the output stays sharded (the consumer of a row-split layer is the next K-split layer),
-so the timed data path has no collective; an RCCL all-gather of the output shards is timed separately and
-reported as "with_allgather".
-The decode step is also timed as 64 nodes of a replayed HIP graph ("decode.hipgraph", computed in a child process so that it
-cannot affect the main line; added without a GPU at hand — an "error" field there means the leg failed, nothing else).
-The oracle/ reference is used only for the cpu_baseline leg (rank 0, N=1), never inside the timed region.
+config headline (default; the shape the metric is quoted on, BASELINE configs[1] / north-star target):
+    per GPU Q4_K [4096x4096]·[4096x512]; one step = one pass of the hot path over one batch with W and the fp32 activations
+    resident in HBM = Q8_K activation quantization (exactly the CPU backend's) + the fp16-MFMA GEMM, through the C-ABI.
+    N GPUs: the N-GPU job is the [4096 N x 4096] matrix row-split as the reference's split buffer does
+    (src/ggml-cuda/ggml-cuda.cu:729-742) — weak scaling, output left sharded, no collective in the timed path.
+config c5 (BASELINE configs[4]): Q4_K [32768x8192]·[8192x512] STRONG scaling: rank r owns rows [32768 r / N, 32768 (r+1) / N);
+    value = 2*32768*8192*512 / (max-over-ranks time); also reported with the RCCL all-gather of the output (fp32 and fp16) and
+    as the K-split variant (rank r owns whole superblocks [r K/N, (r+1) K/N) of every row, RCCL all-reduce of the partial
+    outputs) whose result is CHECKED against the row-split result.  A default multi-GPU run also carries the c5 numbers ("c5").
+Inputs: W = fp32 uniform(-1,1) from std::mt19937(1234) through the reference's ggml_quantize_chunk, X =
+    uniform(-1,1) from mt19937(4321) — produced by oracle/_ref/synth_data (measurement infrastructure, never in the timed
+    region); when that binary is absent the weights are random VALID blocks and "data" says so.
+Beside the metric: roofline of the dominant kernel (HIP events on the launch stream) with the vendor library's fp16 GEMM of the
+same shape as "library_ceiling", the C3 / C5 shapes, the decode GEMV (4096x4096 and the reference's perf shape 4096x14336),
+all weight formats, the reference CPU backend on the host cores (thread sweep, AVX2 and AVX-512 builds), the stock
+test-backend-ops perf lines for the plug-in.  oracle/ is touched only by the cpu_baseline / synth legs.
 """
 import argparse
 import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -32,25 +37,49 @@ sys.path.insert(0, ROOT)
 
 MFMA_F16_PEAK_TFLOPS = 2516.6      # 256 CU x 2.4 GHz x 4096 flop/clk/CU, dense (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0              # spec; ~6300 achievable
-
-M_PER_GPU, K, B = 4096, 4096, 512
 Q4_K = 12
+HEAD = (4096, 4096, 512)           # M per GPU, K, B
+C5 = (32768, 8192, 512)
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+T_START = time.time()
 
 
-def synth_q4k(m, k, seed):
-    """random but valid Q4_K superblocks (fp16 d/dmin ~ the scale of uniform(-1,1) weights, random 6-bit
-    scales/mins and nibbles) — timing does not depend on the values; parity is tested in tests/."""
+def time_left(budget):
+    return budget - (time.time() - T_START)
+
+
+# ------------------------------------------------------------------------------------------------ synthetic inputs
+def synth_blocks(t, m, k, seed):
+    """fallback only (no oracle/_ref/synth_data): random but VALID blocks with small positive fp16 scales"""
+    geo = {12: (144, 256, (0, 2)), 13: (176, 256, (0, 2)), 14: (210, 256, (208,)), 2: (18, 32, (0,)), 8: (34, 32, (0,))}[t]
     rng = np.random.default_rng(seed)
-    nb = m * k // 256
-    raw = rng.integers(0, 256, (nb, 144), dtype=np.uint8)
-    raw[:, 0:2] = rng.uniform(0.001, 0.004, nb).astype(np.float16).view(np.uint8).reshape(nb, 2)
-    raw[:, 2:4] = rng.uniform(0.01, 0.03, nb).astype(np.float16).view(np.uint8).reshape(nb, 2)
+    nb = m * k // geo[1]
+    raw = rng.integers(0, 256, (nb, geo[0]), dtype=np.uint8)
+    for o in geo[2]:
+        raw[:, o:o + 2] = rng.uniform(0.001, 0.004, nb).astype(np.float16).view(np.uint8).reshape(nb, 2)
     return raw.reshape(-1)
 
 
+TYPE_NAME = {12: "q4_K", 13: "q5_K", 14: "q6_K", 2: "q4_0", 8: "q8_0"}
+
+
+def prescribed(t, m, k, row_lo, row_hi, b):
+    """(W bytes of rows [row_lo, row_hi) of the mt19937(1234) matrix quantized by the reference, X fp32 [b][k], how) — see module doc"""
+    exe = os.path.join(REFDIR, "synth_data")
+    if os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as d:
+            p = os.path.join(d, "s")
+            r = subprocess.run([exe, TYPE_NAME[t], str(m), str(k), str(row_lo), str(row_hi), str(b), p], capture_output=True, text=True, timeout=600)
+            if r.returncode == 0:
+                return np.fromfile(p + ".w.bin", np.uint8), np.fromfile(p + ".x.bin", np.float32).reshape(b, k), "prescribed"
+            print("synth_data failed: %s" % r.stderr[-300:], file=sys.stderr)
+    x = np.random.default_rng(4321).uniform(-1, 1, (b, k)).astype(np.float32)
+    return synth_blocks(t, row_hi - row_lo, k, 1234 + row_lo), x, "random-valid-blocks"
+
+
 def pmc_traffic(kernel_substr):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of the same command
-    (profiles/rNN/pmc_summary.txt: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE); None if absent."""
+    """HBM-side bytes per launch of a kernel from the latest committed PMC passes of this command (profiles/rNN/pmc_summary.txt:
+    FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE); None if absent."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.txt")))
@@ -68,306 +97,269 @@ def pmc_traffic(kernel_substr):
     return None if rd is None or wr is None else rd + wr
 
 
-def cpu_baseline(seconds=12.0):
-    """the reference CPU backend (oracle/_ref, unmodified ggml built by oracle/ref.mk) on the same workload,
-    all host cores; falls back to the C port (oracle/libggml_oracle.so) when the binary is not in the snapshot."""
+# ------------------------------------------------------------------------------------------------ the C-ABI, thinly wrapped
+class Hot:
+    """one weight shard + activations resident in HBM; step() = the hot path through the C-ABI (ggml_cdna4_mul_mat)"""
+
+    def __init__(self, dev, t, w_bytes, m, k, x, variant=0, splitk=0):
+        from ggml_amd import native, ops
+        self.L, self.native, self.ops = native.lib(), native, ops
+        self.dev, self.t, self.m, self.k, self.b = dev, t, m, k, x.shape[0]
+        self.a = ops.QTensor.from_host_bytes(t, k, m, w_bytes, device=dev)
+        self.x = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        self.y = torch.empty((self.b, m), dtype=torch.float32, device=dev)
+        self.ws = torch.empty(self.L.ggml_cdna4_mul_mat_workspace_size(t, k, self.b), dtype=torch.uint8, device=dev)
+        self.stream = torch.cuda.current_stream(dev).cuda_stream
+        self.variant, self.splitk = variant, splitk
+        self.flops = 2.0 * m * k * self.b
+
+    def step(self):
+        self.native.check(self.L.ggml_cdna4_mul_mat(self.t, self.a.data.data_ptr(), self.a.row_bytes, self.x.data_ptr(), self.k, self.y.data_ptr(), self.m,
+                                                    self.m, self.k, self.b, self.ws.data_ptr(), self.ws.numel(), self.ops.PATH_GEMM if self.b > 8 else 0, self.variant, self.splitk, self.stream))
+
+    def prepare(self):
+        self.native.check(self.L.ggml_cdna4_prepare_act(self.t, self.x.data_ptr(), self.k, self.k, self.b, self.ws.data_ptr(), self.ws.numel(), self.ops.PATH_GEMM, self.stream))
+
+    def gemm_only(self):
+        self.native.check(self.L.ggml_cdna4_mul_mat_prepared(self.t, self.a.data.data_ptr(), self.a.row_bytes, self.y.data_ptr(), self.m, self.m, self.k, self.b,
+                                                             self.ws.data_ptr(), self.ws.numel(), self.ops.PATH_GEMM, self.variant, self.splitk, self.stream))
+
+
+def events_us(fn, n, warm=10):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(warm):
+        fn()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+def kernel_name(t, m, k, b):
+    if t == Q4_K and ((m + 255) // 256) * ((b + 127) // 128) >= 512:
+        return "k_gemm_kq_t64<Q4_K, 256> (256x128 tile, 8 waves x 64(m)x128(b), per-lane header loads, no K split)"
+    return "k_gemm_kq_w12<Q4_K> (128x128 tile, 8 compute + 4 loader waves, cross-stage unpack/MFMA pipeline, split-K=2 hand-off on small grids)"
+
+
+# ------------------------------------------------------------------------------------------------ optional legs (rank 0, N = 1)
+def cpu_baseline(m, k, b, seconds=14.0):
+    """the UNMODIFIED reference CPU backend (oracle/_ref, built by oracle/ref.mk) on the headline workload, host cores of this box:
+    a thread sweep over both builds — x86-64-v3 (AVX2: the build the oracle restates) and x86-64-v4 + VNNI (AVX-512: what
+    -march=native selects on this host) — best reported, the sweep attached.  Falls back to the C port when the binaries are absent."""
     cores = os.cpu_count() or 1
-    exe = os.path.join(ROOT, "oracle", "_ref", "cpu_baseline")
-    if os.path.exists(exe):
-        try:
-            best = None
-            cands = sorted({c for c in (cores, cores // 2, cores // 4, 32, 16) if 1 <= c <= cores}, reverse=True)
-            for nt in cands:          # the reference's threadpool is not guaranteed to scale to every SMT thread: report its best
-                out = subprocess.run([exe, "q4_K", str(M_PER_GPU), str(K), str(B), str(seconds / len(cands)), str(nt)], capture_output=True, text=True, timeout=seconds * 4 + 60)
-                j = json.loads(out.stdout.strip().splitlines()[-1])
-                if best is None or j["gflops"] > best["gflops"]:
-                    best = j
-            return {"value": round(best["gflops"] / 1e3, 4), "unit": "TFLOP/s", "cores": best["threads"], "host_cores": cores, "kind": "reference",
-                    "sample": "full workload Q4_K [4096x4096]·[4096x512], ggml-cpu MUL_MAT (unmodified reference, AVX2 build), best of threads=%s: %d runs, %.1f ms/run"
-                              % (cands, best["runs"], best["us_per_run"] / 1e3)}
-        except Exception as e:  # noqa: BLE001
-            print("cpu_baseline(reference) failed: %r" % (e,), file=sys.stderr)
+    sweep, best = [], None
+    builds = [("avx512_vnni", os.path.join(REFDIR, "v4", "cpu_baseline")), ("avx2", os.path.join(REFDIR, "cpu_baseline"))]
+    builds = [(n, e) for n, e in builds if os.path.exists(e)]
+    if builds:
+        cands = sorted({c for c in (cores, cores // 2, cores // 4, 64, 32, 16) if 1 <= c <= cores}, reverse=True)
+        per = max(0.6, seconds / (len(cands) * len(builds)))
+        for name, exe in builds:
+            for nt in cands:
+                try:
+                    out = subprocess.run([exe, "q4_K", str(m), str(k), str(b), str(per), str(nt)], capture_output=True, text=True, timeout=per * 6 + 60)
+                    j = json.loads(out.stdout.strip().splitlines()[-1])
+                    row = {"build": name, "threads": nt, "tflops": round(j["gflops"] / 1e3, 4), "ms_per_run": round(j["us_per_run"] / 1e3, 3), "runs": j["runs"]}
+                    sweep.append(row)
+                    if best is None or row["tflops"] > best["tflops"]:
+                        best = row
+                except Exception as e:  # noqa: BLE001
+                    sweep.append({"build": name, "threads": nt, "error": repr(e)[:120]})
+        if best:
+            return {"value": best["tflops"], "unit": "TFLOP/s", "cores": best["threads"], "host_cores": cores, "kind": "reference", "build": best["build"],
+                    "sample": "full workload Q4_K [%dx%d]·[%dx%d], ggml-cpu MUL_MAT (unmodified reference); best of the sweep: %d runs, %.1f ms/run" % (m, k, k, b, best["runs"], best["ms_per_run"]),
+                    "thread_sweep": sweep,
+                    "note": "the reference's threadpool peaks well below the core count on this shape: 512 activation columns x 4096 rows split into too few chunks for 256 threads (ggml-cpu.c:7560-7590 chunking)"}
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import refutil as R
-    w = synth_q4k(512, K, 7)
-    x = np.random.default_rng(8).uniform(-1, 1, (B, K)).astype(np.float32)
+    w = synth_blocks(Q4_K, 512, k, 7)
+    x = np.random.default_rng(8).uniform(-1, 1, (b, k)).astype(np.float32)
     t0 = time.perf_counter(); n = 0
     while time.perf_counter() - t0 < seconds:
-        R.o_mul_mat(Q4_K, w, x, 512, K); n += 1
+        R.o_mul_mat(Q4_K, w, x, 512, k); n += 1
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(2.0 * 512 * K * B / dt / 1e12, 4), "unit": "TFLOP/s", "cores": cores, "kind": "port",
-            "sample": "512 of 4096 weight rows x full [4096x512] activations, oracle C port (OpenMP)"}
+    return {"value": round(2.0 * 512 * k * b / dt / 1e12, 4), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+            "sample": "512 of %d weight rows x full [%dx%d] activations, oracle C port (OpenMP)" % (m, k, b)}
 
 
-# (type id, name, block bytes, weights per block, byte offset of the fp16 scale(s))
-FORMATS = [(12, "Q4_K", 144, 256, (0, 2)), (13, "Q5_K", 176, 256, (0, 2)), (14, "Q6_K", 210, 256, (208,)), (2, "Q4_0", 18, 32, (0,)), (8, "Q8_0", 34, 32, (0,))]
+def library_ceiling(dev, m, k, b, steps):
+    """the vendor library's dense fp16 GEMM of the same shape on ALREADY-dequantized weights (torch.matmul -> hipBLASLt): not part
+    of the product — the practical ceiling of this shape next to the nominal MFMA roof"""
+    try:
+        wh = torch.empty((m, k), dtype=torch.float16, device=dev).uniform_(-1, 1)
+        xh = torch.empty((b, k), dtype=torch.float16, device=dev).uniform_(-1, 1)
+        yh = torch.empty((b, m), dtype=torch.float16, device=dev)
+        us = events_us(lambda: torch.matmul(xh, wh.t(), out=yh), steps, 20)
+        tf = 2.0 * m * k * b / us / 1e6
+        return {"what": "torch.matmul fp16 [%dx%d]·[%dx%d]^T (hipBLASLt) on pre-dequantized weights (%.1f MB of fp16 W instead of %.1f MB of Q4_K)" % (b, k, k, m, m * k * 2 / 1e6, m * k * 0.5625 / 1e6),
+                "us_per_launch": round(us, 3), "tflops": round(tf, 2), "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4)}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
 
 
-def synth_blocks(m, k, seed, bbytes, bweights, scale_offs):
-    """random but valid blocks of any of the five formats: random payload bytes, small positive fp16 scales"""
-    rng = np.random.default_rng(seed)
-    nb = m * k // bweights
-    raw = rng.integers(0, 256, (nb, bbytes), dtype=np.uint8)
-    for o in scale_offs:
-        raw[:, o:o + 2] = rng.uniform(0.001, 0.004, nb).astype(np.float16).view(np.uint8).reshape(nb, 2)
-    return raw.reshape(-1)
+def shape_row(dev, t, m, k, b, steps):
+    """kernel-only time of the default GEMM route at another shape (activations prepared), same prescribed data"""
+    w, x, how = prescribed(t, m, k, 0, m, b)
+    h = Hot(dev, t, w, m, k, x)
+    h.prepare()
+    us = events_us(h.gemm_only, steps, 20)
+    step_us = events_us(h.step, steps, 10)
+    tf = h.flops / us / 1e6
+    return {"shape": [m, k, b], "gemm_us": round(us, 3), "gemm_tflops": round(tf, 1), "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4), "step_us": round(step_us, 3),
+            "step_tflops": round(h.flops / step_us / 1e6, 1), "kernel": kernel_name(t, m, k, b), "data": how}
 
 
-def format_rows(L, native, ops, dev, stream, x, steps):
-    """secondary rows: every weight format at C3' (B=512, GEMM kernel only, activations prepared) and at
-    C2 (B=1, the one-launch fused decode step, cache-warm), HIP-event timed"""
+def decode_rows(dev, steps):
+    """batch-1 decode (BASELINE configs[1]) and the reference's own perf shape (m = 4096, k = 14336, tests/test-backend-ops.cpp:4340-4346):
+    ONE launch per step (activation quantizer fused into the GEMV), 64 rotating copies of W so that every launch streams from HBM"""
+    from ggml_amd import native, ops
+    L = native.lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
     rows = {}
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    y = torch.empty((B, M_PER_GPU), dtype=torch.float32, device=dev)
-    for tid, name, bb, bw, so in FORMATS:
-        a = ops.QTensor.from_host_bytes(tid, K, M_PER_GPU, synth_blocks(M_PER_GPU, K, 99 + tid, bb, bw, so), device=dev)
-        ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(tid, K, B), dtype=torch.uint8, device=dev)
-        native.check(L.ggml_cdna4_prepare_act(tid, x.data_ptr(), K, K, B, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, stream))
+    for (m, k) in ((4096, 4096), (4096, 14336)):
+        w, x, how = prescribed(Q4_K, m, k, 0, m, 1)
+        a = ops.QTensor.from_host_bytes(Q4_K, k, m, w, device=dev)
+        ncopy = 64 if k == 4096 else 16                                # 604 MB / 528 MB > 256 MB Infinity Cache
+        big = a.data.reshape(-1).repeat(ncopy)
+        row_b, mat_b = a.row_bytes, a.row_bytes * m
+        x1 = torch.from_numpy(x).to(dev)
+        y1 = torch.empty((1, m), dtype=torch.float32, device=dev)
+        ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(Q4_K, k, 1), dtype=torch.uint8, device=dev)
+        cnt = [0]
 
-        def gemm():
-            native.check(L.ggml_cdna4_mul_mat_prepared(tid, a.data.data_ptr(), a.row_bytes, y.data_ptr(), M_PER_GPU, M_PER_GPU, K, B,
-                                                       ws.data_ptr(), ws.numel(), ops.PATH_GEMM, 0, 0, stream))
+        def fused_cold():
+            i = cnt[0] % ncopy; cnt[0] += 1
+            native.check(L.ggml_cdna4_mul_mat(Q4_K, big.data_ptr() + i * mat_b, row_b, x1.data_ptr(), k, y1.data_ptr(), m, m, k, 1, ws.data_ptr(), ws.numel(), 0, 0, 0, st))
 
-        def decode():
-            native.check(L.ggml_cdna4_mul_mat(tid, a.data.data_ptr(), a.row_bytes, x.data_ptr(), K, y.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1,
-                                              ws.data_ptr(), ws.numel(), 0, 0, 0, stream))
-        r = {}
-        for label, fn in (("gemm_b512_us", gemm), ("decode_b1_us_cache_warm", decode)):
-            for _ in range(5):
-                fn()
-            e0.record()
-            for _ in range(steps):
-                fn()
-            e1.record(); e1.synchronize()
-            r[label] = round(e0.elapsed_time(e1) * 1e3 / steps, 3)
-        r["gemm_b512_tflops"] = round(2.0 * M_PER_GPU * K * B / (r["gemm_b512_us"] * 1e-6) / 1e12, 1)
-        r["weight_bytes"] = a.row_bytes * M_PER_GPU
-        rows[name] = r
+        def fused_warm():
+            native.check(L.ggml_cdna4_mul_mat(Q4_K, big.data_ptr(), row_b, x1.data_ptr(), k, y1.data_ptr(), m, m, k, 1, ws.data_ptr(), ws.numel(), 0, 0, 0, st))
+        n = max(steps, 256)
+        cold, warm = events_us(fused_cold, n, 20), events_us(fused_warm, n, 20)
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        for _ in range(500):
+            fused_warm()
+        torch.cuda.synchronize(dev); wall = (time.perf_counter() - t0) / 500 * 1e6
+        # the same 64 / 16 launches captured once into a HIP graph and replayed (how a decode loop issues them)
+        hg = None
+        try:
+            s2 = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s2):
+                st2 = s2.cuda_stream
+                def one(i):
+                    native.check(L.ggml_cdna4_mul_mat(Q4_K, big.data_ptr() + (i % ncopy) * mat_b, row_b, x1.data_ptr(), k, y1.data_ptr(), m, m, k, 1, ws.data_ptr(), ws.numel(), 0, 0, 0, st2))
+                for i in range(ncopy):
+                    one(i)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s2):
+                st2 = torch.cuda.current_stream(dev).cuda_stream
+                for i in range(ncopy):
+                    one(i)
+            hg = events_us(g.replay, 30, 5) / ncopy
+        except Exception as e:  # noqa: BLE001
+            hg = repr(e)[:200]
+        alg = mat_b + k * 4 + m * 4                                     # W + fp32 x + y (the quantized row never leaves LDS)
+        gbs = alg / cold / 1e3
+        rows["%dx%d" % (m, k)] = {"us_per_step": round(cold, 3), "us_per_step_cache_warm": round(warm, 3), "us_per_step_host_wall": round(wall, 3),
+                                   "us_per_step_hipgraph": round(hg, 3) if isinstance(hg, float) else hg, "tokens_per_s": round(1e6 / cold, 1),
+                                   "effective_tflops": round(2.0 * m * k / cold / 1e6, 3),
+                                   "roofline": {"bound": "hbm", "kernel": "k_gemv_q_fused<Q4_K>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                                "traffic": pmc_traffic("k_gemv_q_fused<12") if k == 4096 else None, "algorithmic_bytes_per_launch": alg}, "data": how}
+        del big
     return rows
 
 
-def decode_graph_leg():
-    """`bench.py --decode-graph` (a CHILD process of the main run, so that nothing here can take the main JSON line down):
-    the B = 1 decode step as it runs inside a captured graph — 64 one-launch GEMVs over 64 rotating matrices (604 MB > the
-    Infinity Cache) captured once into a HIP graph and replayed, the way ggml-cuda runs decode
-    (src/ggml-cuda/ggml-cuda.cu:2353-2406).  Prints one JSON object."""
-    from ggml_amd import native, ops
-    L = native.lib()
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    ncopy = 64
-    a = ops.QTensor.from_host_bytes(Q4_K, K, M_PER_GPU, synth_q4k(M_PER_GPU, K, 1234), device=dev)
-    big = torch.from_numpy(np.tile(a.data.cpu().numpy().reshape(-1), ncopy)).to(dev)
-    row_b, mat_b = a.row_bytes, a.row_bytes * M_PER_GPU
-    x1 = torch.from_numpy(np.random.default_rng(4321).uniform(-1, 1, (1, K)).astype(np.float32)).to(dev)
-    y1 = torch.empty((1, M_PER_GPU), dtype=torch.float32, device=dev)
-    ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(Q4_K, K, 1), dtype=torch.uint8, device=dev)
-    st = torch.cuda.Stream(device=dev)
-
-    def fused(i):
-        native.check(L.ggml_cdna4_mul_mat(Q4_K, big.data_ptr() + (i % ncopy) * mat_b, row_b, x1.data_ptr(), K, y1.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1,
-                                          ws.data_ptr(), ws.numel(), 0, 0, 0, torch.cuda.current_stream(dev).cuda_stream))
-    with torch.cuda.stream(st):
-        for i in range(ncopy):
-            fused(i)
-    torch.cuda.synchronize(dev)
-    y_eager = y1.clone()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=st):
-        for i in range(ncopy):
-            fused(i)
-    for _ in range(5):
-        g.replay()
-    torch.cuda.synchronize(dev)
-    same = bool(torch.equal(y1, y_eager))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 50
-    e0.record()
-    for _ in range(reps):
-        g.replay()
-    e1.record(); e1.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (reps * ncopy)
-    print(json.dumps({"us_per_step_hipgraph": round(us, 3), "nodes_per_graph": ncopy, "same_result_as_stream_launches": same}), flush=True)
+def format_rows(dev, steps):
+    """secondary rows: every weight format at the headline shape — GEMM kernel only and the whole step — and at B = 1"""
+    rows = {}
+    m, k, b = HEAD
+    for t in (12, 13, 14, 2, 8):
+        w, x, how = prescribed(t, m, k, 0, m, b)
+        h = Hot(dev, t, w, m, k, x)
+        h.prepare()
+        g = events_us(h.gemm_only, steps, 10)
+        s = events_us(h.step, steps, 10)
+        h1 = Hot(dev, t, w, m, k, x[:1])
+        d = events_us(h1.step, max(steps, 200), 10)
+        rows[TYPE_NAME[t]] = {"gemm_b512_us": round(g, 3), "gemm_b512_tflops": round(h.flops / g / 1e6, 1), "step_b512_us": round(s, 3),
+                              "decode_b1_us_cache_warm": round(d, 3), "weight_bytes": int(w.size), "data": how}
+    return rows
 
 
-T_START = time.time()
-OPTIONAL_BUDGET_S = float(os.environ.get("BENCH_OPTIONAL_BUDGET_S", "200"))   # no optional leg STARTS later than this many seconds into the run
+def stock_perf_lines(timeout=150):
+    """the reference's own perf harness on the plug-in: `test-backend-ops perf -o MUL_MAT -b CDNA40` (unmodified binary, plug-in loaded
+    through GGML_BACKEND_PATH) — its q4_K lines at m = 4096, k = 14336 (tests/test-backend-ops.cpp:4340-4346)"""
+    exe = os.path.join(REFDIR, "test-backend-ops")
+    plugin = os.path.join(ROOT, "ggml_amd", "lib", "libggml-cdna4.so")
+    if not (os.path.exists(exe) and os.path.exists(plugin)):
+        return {"error": "oracle/_ref/test-backend-ops or the plug-in is not in the snapshot"}
+    try:
+        r = subprocess.run([exe, "perf", "-o", "MUL_MAT", "-b", "CDNA40"], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, GGML_BACKEND_PATH=plugin))
+        txt = r.stdout
+    except subprocess.TimeoutExpired as e:
+        txt = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+    lines = [ln.strip() for ln in txt.splitlines() if "type_a=q4_K" in ln and "not supported" not in ln]
+    return {"command": "GGML_BACKEND_PATH=libggml-cdna4.so test-backend-ops perf -o MUL_MAT -b CDNA40", "q4_K": lines[:8]}
 
 
-def optional_time_left():
-    return OPTIONAL_BUDGET_S - (time.time() - T_START)
+# ------------------------------------------------------------------------------------------------ multi-GPU legs
+def c5_leg(dist, dev, rank, world, steps, warmup):
+    """BASELINE configs[4]: Q4_K [32768x8192]·[8192x512], strong scaling over the ranks (see module doc)"""
+    M, K, B = C5
+    lo, hi = M * rank // world, M * (rank + 1) // world
+    w, x, how = prescribed(Q4_K, M, K, lo, hi, B)
+    h = Hot(dev, Q4_K, w, hi - lo, K, x)
 
-
-def diagnostics():
-    """Stand-alone probes of tools/microbench (built by __graft_entry__.build()), shape checks and the opt-in tests of code that
-    was written after the round's GPU budget was spent — each a child process with its own timeout, run after everything that is
-    reported above, most informative first, none started once the optional time budget is spent: what DESIGN.md 7 asks of the
-    next GPU call, recorded with the bench line.  Raw text, trimmed."""
-    mb = os.path.join(ROOT, "tools", "microbench")
-    res = {}
-
-    def tool(name, cmd, env, tmo, slack=0.0):
-        if not os.path.exists(os.path.join(mb, cmd[0])):
-            res[name] = "not built"
-            return
-        if optional_time_left() <= -slack:
-            res[name] = "skipped: time budget of the optional legs"
-            return
-        try:
-            r = subprocess.run(cmd, cwd=mb, capture_output=True, text=True, timeout=tmo, env=dict(os.environ, **env))
-            txt = r.stdout if len(r.stdout) <= 3200 else r.stdout[:1200] + "\n[...]\n" + r.stdout[-2000:]      # (mfma_valu prints its sustained-rate lines first)
-            res[name] = (txt if r.returncode == 0 else "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))
-        except Exception as e:              # noqa: BLE001
-            res[name] = repr(e)[:200]
-
-    def shape(name, spec, env):
-        if optional_time_left() <= 0:
-            res[name] = "skipped: time budget of the optional legs"
-            return
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--shape-check", spec], capture_output=True, text=True, timeout=90, env=dict(os.environ, **env))
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            res[name] = json.loads(line[-1]) if line else {"returncode": r.returncode, "stderr": (r.stderr or "")[-400:]}
-        except Exception as e:              # noqa: BLE001
-            res[name] = repr(e)[:200]
-
-    def tests(name, targs):
-        if optional_time_left() <= 0:
-            res[name] = "skipped: time budget of the optional legs"
-            return
-        try:
-            r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + targs, cwd=ROOT, capture_output=True, text=True, timeout=120,
-                               env=dict(os.environ, CDNA4_TEST_EXPERIMENTAL="1"))
-            res[name] = {"returncode": r.returncode, "tail": r.stdout[-600:]}
-        except Exception as e:              # noqa: BLE001
-            res[name] = repr(e)[:200]
-
-    # bit-identical candidates of the shipped GEMM (ablation build): early table read / balanced epilogue / stores from registers / both
-    tool("w12_candidates", ["./gemm_bench_abl", "4096", "4096", "512", ""], {"GB_VARIANTS": "4119,69655,135191,266263,397335", "GB_SPLITKS": "0"}, 60)
-    # BASELINE configs[2] at its TRUE K = 11008 = 43 superblocks (round 1 measured 10752): today's auto route (no K split for an odd
-    # count: 128 of 256 CUs busy) and the uneven 22 / 21 hand-off split behind CDNA4_ODD_SPLIT=1 (emulator-verified), one process each
-    shape("c3_4096x11008x512", "4096,11008,512", {"CDNA4_ODD_SPLIT": "0"})
-    shape("c3_4096x11008x512_odd_split", "4096,11008,512", {"CDNA4_ODD_SPLIT": "1"})
-    # the opt-in parity tests (tests/ run as tests, in a child pytest with CDNA4_TEST_EXPERIMENTAL=1; only the pass / fail summary is
-    # kept): in-launch quantizer on small and ragged shapes incl. > 64 launches and the refusal paths; Q5_0 / Q2_K / Q3_K through the
-    # GEMV units against the oracle
-    tests("experimental_parity_tests", ["tests/test_gpu_parity.py", "-k", "extra_weight_types or fails_loudly or (in_launch_activation and (256-1024 or 300-1536 or 513-3072))"])
-    # the default route at the shape of DESIGN 4.3's open issue (own process: a GPU fault there ends only that process)
-    shape("default_route_8192x8192x512", "8192,8192,512", {})
-    tool("launch_floor", ["./launch_floor"], {}, 60)                    # empty-kernel launch cost; pure-load floor of the 9.4 MB decode matrix
-    tool("mfma_valu", ["./mfma_valu", "500"], {}, 60)                   # matrix-pipe price of the unpack mix, the clock held, sustained MFMA-only rate
-    tests("experimental_gguf_upload_test", ["tests/test_gguf.py", "-k", "upload"])
-    # very last (nothing follows it but the print of the line): the experimental loader-wave kernels of gemm_q_x4l.hip (256x128 / 4 compute
-    # waves, 128x128, 256x128 / 8 compute waves; emulator-verified, never run on a GPU) beside the default at the headline shape — time and
-    # rel-L2 against the default (must be ~1e-7); one process per form: a fault of one does not hide the others.  (Short: allowed to start
-    # a little past the budget.)
-    for v in (8199, 24583, 40967):
-        tool("x4l_experimental_%d" % v, ["./gemm_bench_abl", "4096", "4096", "512", ""], {"GB_VARIANTS": "4119,%d" % v, "GB_SPLITKS": "0", "GB_ROUNDS": "2"}, 30, slack=30.0)
-    return res
-
-
-def shape_check_leg(spec):
-    """`bench.py --shape-check M,K,B` (a CHILD process): the default GEMM route at a shape against the first, slice-per-barrier
-    kernel (variant 5) through the C-ABI.  Used for 8192 x 8192 x 512 — the shape at which an ablation harness process once died
-    with a GPU fault (open issue) and which no test of round 1 ran on the default route."""
-    from ggml_amd import native, ops
-    L = native.lib()
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    m, k, b = (int(v) for v in spec.split(","))
-    a = ops.QTensor.from_host_bytes(Q4_K, k, m, synth_q4k(m, k, 7), device=dev)
-    x = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (b, k)).astype(np.float32)).to(dev)
-    ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(Q4_K, k, b), dtype=torch.uint8, device=dev)
-    st = torch.cuda.current_stream(dev).cuda_stream
-    ys = {}
-    for variant in (0, 5):
-        y = torch.empty((b, m), dtype=torch.float32, device=dev)
-        native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), a.row_bytes, x.data_ptr(), k, y.data_ptr(), m, m, k, b, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, variant, 0, st))
+    def barrier():
+        if dist is not None:
+            dist.barrier()
         torch.cuda.synchronize(dev)
-        ys[variant] = y.double()
-    y = torch.empty((b, m), dtype=torch.float32, device=dev)
-    native.check(L.ggml_cdna4_prepare_act(Q4_K, x.data_ptr(), k, k, b, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, st))
 
-    def gemm():
-        native.check(L.ggml_cdna4_mul_mat_prepared(Q4_K, a.data.data_ptr(), a.row_bytes, y.data_ptr(), m, m, k, b, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, 0, 0, st))
-    for _ in range(200):
-        gemm()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    best = 1e30
-    for _ in range(3):
-        e0.record()
-        for _ in range(50):
-            gemm()
-        e1.record(); e1.synchronize()
-        best = min(best, e0.elapsed_time(e1) * 1e3 / 50)
-    print(json.dumps({"shape": [m, k, b], "finite": bool(torch.isfinite(ys[0]).all()),
-                      "rel_l2_default_vs_variant5": float((ys[0] - ys[5]).norm() / ys[5].norm()),
-                      "gemm_us_per_launch_default_route": round(best, 3), "tflops": round(2.0 * m * k * b / best / 1e6, 1),
-                      "CDNA4_ODD_SPLIT": os.environ.get("CDNA4_ODD_SPLIT", "")}), flush=True)
-
-
-FUSEQ_PFW_VARIANT = 4119 | (3072 << 16) # + weight pre-touch under the quantizer
-FUSEQ_GRP_VARIANT = 4119 | (9216 << 16)    # one counter per (activation tile, K range) group instead of one for the whole grid
-FUSEQ_WBL2_VARIANT = 4119 | (5120 << 16)   # image published by plain stores + an agent-scope release fence (L2 write-back): the textbook form, as a reference
-FUSEQ_VARIANT = 4119 | (1024 << 16)     # k_gemm_kq_w12<Q4_K> with the Q8_K activation quantizer inside the launch (explicit, experimental)
-
-
-def fuseq_leg(steps):
-    """`bench.py --fuseq-leg` (a CHILD process of the main run: a failure here is recorded in the main JSON line, never
-    propagated): the headline step as ONE launch — the GEMM variant that quantizes its own activations behind a one-way grid
-    barrier (verified on the CPU emulator; whether its cross-XCD publication holds on the hardware is exactly what this leg
-    reports) — beside the default two-launch step, same process, alternating blocks, with a bit-for-bit comparison over
-    fresh activations through the same workspace.  Prints one JSON object."""
-    from ggml_amd import native, ops
-    L = native.lib()
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    a = ops.QTensor.from_host_bytes(Q4_K, K, M_PER_GPU, synth_q4k(M_PER_GPU, K, 1234), device=dev)
-    ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(Q4_K, K, B), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    y = torch.empty((B, M_PER_GPU), dtype=torch.float32, device=dev)
-
-    def run(x, variant):
-        native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), a.row_bytes, x.data_ptr(), K, y.data_ptr(), M_PER_GPU,
-                                          M_PER_GPU, K, B, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, variant, 0, stream))
-    fused = (FUSEQ_VARIANT, FUSEQ_PFW_VARIANT, FUSEQ_WBL2_VARIANT, FUSEQ_GRP_VARIANT)
-    same, finite = {v: True for v in fused}, {v: True for v in fused}
-    rng = np.random.default_rng(99)
-    for it in range(6):                               # fresh activations every time through the SAME workspace: a stale line would show
-        x = torch.from_numpy(rng.uniform(-1, 1, (B, K)).astype(np.float32)).to(dev)
-        run(x, 4119); torch.cuda.synchronize(dev); y0 = y.clone()
-        for v in fused:
-            y.fill_(7.0)
-            run(x, v); torch.cuda.synchronize(dev)
-            finite[v] = finite[v] and bool(torch.isfinite(y).all())
-            same[v] = same[v] and bool(torch.equal(y, y0))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    best = {4119: 1e30, FUSEQ_VARIANT: 1e30, FUSEQ_PFW_VARIANT: 1e30, FUSEQ_WBL2_VARIANT: 1e30, FUSEQ_GRP_VARIANT: 1e30}
-    for _ in range(100):
-        run(x, 4119)
-    for _ in range(4):                                # alternating blocks: no variant owns the warm end of the run
-        for v in (4119,) + fused:
-            for _ in range(10):
-                run(x, v)
-            e0.record()
-            for _ in range(steps):
-                run(x, v)
-            e1.record(); e1.synchronize()
-            best[v] = min(best[v], e0.elapsed_time(e1) * 1e3 / steps)
-    fl = 2.0 * M_PER_GPU * K * B
-    print(json.dumps({"what": "step = fp32 X -> Y of Q4_K [4096x4096]·[4096x512]; two launches (k_quantize_q8_K + k_gemm_kq_w12) vs ONE (k_gemm_kq_w12<Q4_K,true,1024>: in-launch quantizer + grid barrier)",
-                      "bit_identical_to_default": same[FUSEQ_VARIANT], "finite": finite[FUSEQ_VARIANT],
-                      "us_per_step_two_launches": round(best[4119], 3), "us_per_step_one_launch": round(best[FUSEQ_VARIANT], 3),
-                      "tflops_two_launches": round(fl / best[4119] / 1e6, 2), "tflops_one_launch": round(fl / best[FUSEQ_VARIANT] / 1e6, 2),
-                      "with_weight_pretouch": {"what": "EXP bit 11: the loader lanes touch the prologue's weight bytes while the activations are quantized",
-                                               "bit_identical_to_default": same[FUSEQ_PFW_VARIANT], "finite": finite[FUSEQ_PFW_VARIANT],
-                                               "us_per_step_one_launch": round(best[FUSEQ_PFW_VARIANT], 3), "tflops_one_launch": round(fl / best[FUSEQ_PFW_VARIANT] / 1e6, 2)},
-                      "grouped_counters": {"what": "EXP bit 13: one counter per (activation tile, K range) group — 8 counters of 32 arrivals at this shape instead of one word taking 256",
-                                           "bit_identical_to_default": same[FUSEQ_GRP_VARIANT], "finite": finite[FUSEQ_GRP_VARIANT],
-                                           "us_per_step_one_launch": round(best[FUSEQ_GRP_VARIANT], 3), "tflops_one_launch": round(fl / best[FUSEQ_GRP_VARIANT] / 1e6, 2)},
-                      "published_by_l2_writeback_fence": {"what": "EXP bit 12: plain image stores + agent-scope release fence (buffer_wbl2) instead of write-through stores — reference for the publication",
-                                                          "bit_identical_to_default": same[FUSEQ_WBL2_VARIANT], "finite": finite[FUSEQ_WBL2_VARIANT],
-                                                          "us_per_step_one_launch": round(best[FUSEQ_WBL2_VARIANT], 3)}}), flush=True)
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        barrier(); t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier(); el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el / steps * 1e3
+    flops = 2.0 * M * K * B
+    out = {"workload": "Q4_K [32768x8192]·[8192x512] row-sharded over %d GPU(s), strong scaling" % world, "data": how}
+    ms = timed(h.step)
+    out["compute_only"] = {"ms_per_step": round(ms, 5), "tflops": round(flops / ms / 1e9, 2), "frac_of_n_gpu_roof": round(flops / ms / 1e9 / (MFMA_F16_PEAK_TFLOPS * world), 4),
+                           "what": "each rank: quantize + GEMM over its %d rows; output left sharded (the consumer of a row-split layer reads its own shard)" % (hi - lo)}
+    if dist is not None:
+        yfull = torch.empty((world, B, hi - lo), dtype=torch.float32, device=dev)
+        ms = timed(lambda: (h.step(), dist.all_gather_into_tensor(yfull, h.y)))
+        out["with_allgather_fp32"] = {"ms_per_step": round(ms, 5), "tflops": round(flops / ms / 1e9, 2), "collective": "RCCL all_gather_into_tensor, %d B/rank" % (B * (hi - lo) * 4)}
+        y16 = torch.empty((B, hi - lo), dtype=torch.float16, device=dev)
+        yfull16 = torch.empty((world, B, hi - lo), dtype=torch.float16, device=dev)
+        ms = timed(lambda: (h.step(), y16.copy_(h.y), dist.all_gather_into_tensor(yfull16, y16)))
+        out["with_allgather_fp16"] = {"ms_per_step": round(ms, 5), "tflops": round(flops / ms / 1e9, 2), "collective": "fp32 -> fp16 cast + RCCL all_gather_into_tensor, %d B/rank" % (B * (hi - lo) * 2)}
+        # K-split: rank r owns superblocks [r K/N, (r+1) K/N) of EVERY row.  A K range of a block-quantized row is a byte range of
+        # that row (144 B per 256 weights), so the shard is a strided view of the full matrix: built here from the prescribed matrix.
+        sys.path.insert(0, ROOT)
+        from ggml_amd import shard as SH
+        wfull, _, _ = prescribed(Q4_K, M, K, 0, M, B)
+        wk, klo, khi = SH.k_shard_bytes(wfull, M, K, 256, 144, rank, world)
+        del wfull
+        hk = Hot(dev, Q4_K, wk, M, khi - klo, x[:, klo:khi])
+        ms = timed(lambda: (hk.step(), dist.all_reduce(hk.y)))
+        # correctness: the all-reduced K-split result against the all-gathered row-split result (same matrix, same activations)
+        h.step(); dist.all_gather_into_tensor(yfull, h.y)
+        hk.step(); dist.all_reduce(hk.y)
+        torch.cuda.synchronize(dev)
+        yrow = torch.cat([yfull[r] for r in range(world)], dim=1).double()
+        err = float((hk.y.double() - yrow).norm() / yrow.norm())
+        out["ksplit_allreduce"] = {"ms_per_step": round(ms, 5), "tflops": round(flops / ms / 1e9, 2), "collective": "RCCL all_reduce(sum) of the fp32 partial outputs, %d B" % (B * M * 4),
+                                   "rel_l2_vs_row_split": err, "check": "pass" if err < 2e-3 else "FAIL"}
+        out["accounting"] = ("compute_only is the number the >= 6x target of the north star can refer to (output left sharded); gathering the fp32 output moves "
+                             "%.1f MB per rank over xGMI (>= %.0f us at 153 GB/s per link), the fp16 gather half of that" % (B * (hi - lo) * 4 / 1e6, B * (hi - lo) * 4 / 153e3))
+    return out
 
 
 def main():
@@ -375,20 +367,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="headline", choices=["headline", "c5"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--splitk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--decode-graph", action="store_true", help="internal: run only the HIP-graph decode leg and print its JSON")
-    ap.add_argument("--shape-check", default="", help="internal: M,K,B — default GEMM route against variant 5 at that shape, one JSON object")
-    ap.add_argument("--no-diagnostics", action="store_true", help="skip the stand-alone probes of tools/microbench at the end of the run")
-    ap.add_argument("--fuseq-leg", action="store_true", help="internal: run only the one-launch (in-kernel activation quantizer) leg and print its JSON")
+    ap.add_argument("--no-extras", action="store_true", help="only the metric, its roofline, the library ceiling and the CPU baseline")
+    ap.add_argument("--no-diagnostics", action="store_true", help="(accepted for compatibility; same as --no-extras)")
     args = ap.parse_args()
-    if args.decode_graph:
-        return decode_graph_leg()
-    if args.fuseq_leg:
-        return fuseq_leg(max(50, min(args.steps, 200)))
-    if args.shape_check:
-        return shape_check_leg(args.shape_check)
+    extras = not (args.no_extras or args.no_diagnostics)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -403,33 +389,36 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
-    from ggml_amd import native, ops
+    from ggml_amd import native
     native.lib()
-    L = native.lib()
 
-    # this rank's row shard of the [4096*world x 4096] Q4_K matrix, and the (replicated) activations
-    a = ops.QTensor.from_host_bytes(Q4_K, K, M_PER_GPU, synth_q4k(M_PER_GPU, K, 1234 + rank), device=dev)
-    x = torch.from_numpy(np.random.default_rng(4321).uniform(-1, 1, (B, K)).astype(np.float32)).to(dev)
-    y = torch.empty((B, M_PER_GPU), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(Q4_K, K, B), dtype=torch.uint8, device=dev)
+    if args.config == "c5":
+        c5 = c5_leg(dist, dev, rank, world, args.steps, args.warmup)
+        if rank == 0:
+            ms = c5["compute_only"]["ms_per_step"]
+            print(json.dumps({"metric": "effective TFLOPS (2*M*N*K), Q4_K mul_mat [32768x8192]x[8192x512] row-sharded", "value": c5["compute_only"]["tflops"], "unit": "TFLOP/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                              "dtype": "f16", "data": "synthetic (%s)" % c5["data"], "config": {"workload": c5["workload"], "M": C5[0], "K": C5[1], "B": C5[2], "parallelism": "row-split x%d" % world},
+                              "tokens_per_s": round(C5[2] / (ms * 1e-3), 1), "c5": c5}), flush=True)
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
 
-    def step():
-        native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), a.row_bytes, x.data_ptr(), K, y.data_ptr(), M_PER_GPU,
-                                          M_PER_GPU, K, B, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, args.variant, args.splitk, stream))
+    # ---- headline: this rank's row shard of the [4096*world x 4096] matrix, the (replicated) activations
+    M, K, B = HEAD
+    w, x, how = prescribed(Q4_K, M * world, K, M * rank, M * (rank + 1), B)
+    h = Hot(dev, Q4_K, w, M, K, x, args.variant, args.splitk)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
-
     for _ in range(args.warmup):
-        step()
+        h.step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        h.step()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -437,199 +426,67 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    flops_step = 2.0 * M_PER_GPU * K * B * world
+    flops_step = h.flops * world
     value = flops_step / (ms_per_step * 1e-3) / 1e12
 
-    # ---- the dominant kernel alone (activations prepared once), HIP events on the launch stream -------------
-    native.check(L.ggml_cdna4_prepare_act(Q4_K, x.data_ptr(), K, K, B, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, stream))
-
-    base_variant = args.variant & 0xFFFF if (args.variant >> 16) in (1024, 3072) else args.variant   # the in-launch quantizer has no prepared-activation form
-
-    def gemm_only():
-        native.check(L.ggml_cdna4_mul_mat_prepared(Q4_K, a.data.data_ptr(), a.row_bytes, y.data_ptr(), M_PER_GPU, M_PER_GPU, K, B,
-                                                   ws.data_ptr(), ws.numel(), ops.PATH_GEMM, base_variant, args.splitk, stream))
-    for _ in range(5):
-        gemm_only()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(args.steps):
-        gemm_only()
-    e1.record(); e1.synchronize()
-    gemm_us = e0.elapsed_time(e1) * 1e3 / args.steps
-    gemm_tflops = 2.0 * M_PER_GPU * K * B / (gemm_us * 1e-6) / 1e12
-    # the same launches on all-zero operands (zero weight bytes, zero activation image): identical instruction stream and memory
-    # traffic, almost no toggling in the matrix pipe — the gap to the random-data time is what the chip's power management takes
-    # (the working hypothesis for the loop's ceiling).  Not a result: a diagnostic beside the roofline fraction.
-    zero_us = None
-    if rank == 0:
-        try:
-            wz = torch.zeros_like(a.data)
-            wsz = torch.zeros_like(ws)
-            def gemm_zero():
-                native.check(L.ggml_cdna4_mul_mat_prepared(Q4_K, wz.data_ptr(), a.row_bytes, y.data_ptr(), M_PER_GPU, M_PER_GPU, K, B,
-                                                           wsz.data_ptr(), wsz.numel(), ops.PATH_GEMM, base_variant, args.splitk, stream))
-            nz = 40                         # few launches: they carry the same kernel name as the measured ones in a rocprofv3 summary of this run
-            for _ in range(10):
-                gemm_zero()
-            e0.record()
-            for _ in range(nz):
-                gemm_zero()
-            e1.record(); e1.synchronize()
-            zero_us = round(e0.elapsed_time(e1) * 1e3 / nz, 3)
-            del wz, wsz
-        except Exception:               # noqa: BLE001 — optional diagnostic
-            zero_us = None
-
+    # ---- the dominant kernel alone (activations prepared once), HIP events on the launch stream
+    h.prepare()
+    gemm_us = events_us(h.gemm_only, args.steps, 10)
+    gemm_tf = h.flops / gemm_us / 1e6
     out = None
     if rank == 0:
+        # the same launches on all-zero operands: identical instruction stream and traffic, no toggling in the matrix pipe — the gap
+        # is what the chip's power management takes (a diagnostic beside the roofline fraction, not a result)
+        zero_us = None
+        try:
+            hz = Hot(dev, Q4_K, np.zeros_like(w), M, K, np.zeros_like(x), args.variant, args.splitk)
+            hz.ws.zero_()
+            zero_us = round(events_us(hz.gemm_only, 40, 10), 3)
+            del hz
+        except Exception:  # noqa: BLE001
+            pass
         out = {
             "metric": "effective TFLOPS (2*M*N*K), Q4_K mul_mat [4096x4096]x[4096x512]", "value": round(value, 3), "unit": "TFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic (%s)" % how,
             "config": {"workload": "Q4_K MUL_MAT [4096x4096]·[4096x512] per GPU; step = Q8_K activation quantize + fp16-MFMA GEMM, W and fp32 X resident in HBM",
-                       "M_per_gpu": M_PER_GPU, "K": K, "B": B, "parallelism": "row-split x%d, output left sharded" % world,
-                       "gemm_variant": args.variant, "splitk": args.splitk},
+                       "M_per_gpu": M, "K": K, "B": B, "parallelism": "row-split x%d, output left sharded" % world, "gemm_variant": args.variant, "splitk": args.splitk},
             "tokens_per_s": round(B * world / (ms_per_step * 1e-3), 1),
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_kq_w12<Q4_K> (128x128 tile, 8 compute + 4 loader waves, cross-stage unpack/MFMA pipeline, split-K=2 symmetric exchange)" if args.variant in (0, 23, 2071, 4119) else "gemm variant %d" % args.variant, "achieved": round(gemm_tflops, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / MFMA_F16_PEAK_TFLOPS, 4),
-                         "traffic": pmc_traffic("k_gemm_kq_w12<12") if args.variant in (0, 23, 2071, 4119) else None,
+            "roofline": {"bound": "mfma", "kernel": kernel_name(Q4_K, M, K, B) if args.variant == 0 else "gemm variant %d" % args.variant,
+                         "achieved": round(gemm_tf, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tf / MFMA_F16_PEAK_TFLOPS, 4),
+                         "traffic": pmc_traffic("k_gemm_kq_w12<12") if args.variant == 0 else None,
                          "traffic_note": "HBM-side bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) from the rocprofv3 PMC passes of this command, profiles/rNN/pmc_summary.txt",
-                         "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": 2.0 * M_PER_GPU * K * B,
-                         "us_per_launch_all_zero_operands": zero_us},
+                         "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": h.flops, "us_per_launch_all_zero_operands": zero_us},
         }
-
-    # ---- batch-1 decode GEMV of the same matrix (HBM roofline), rank 0 only ------------------------------------
-    if rank == 0:
-        ncopy = 64                                      # 64 x 9.4 MB = 604 MB > 256 MB Infinity Cache: every launch streams from HBM
-        big = torch.from_numpy(np.tile(a.data.cpu().numpy().reshape(-1), ncopy)).to(dev)
-        row_b, mat_b = a.row_bytes, a.row_bytes * M_PER_GPU
-        x1 = x[:1].contiguous()
-        y1 = torch.empty((1, M_PER_GPU), dtype=torch.float32, device=dev)
-        native.check(L.ggml_cdna4_prepare_act(Q4_K, x1.data_ptr(), K, K, 1, ws.data_ptr(), ws.numel(), ops.PATH_GEMV, stream))
-
-        def gemv(i):
-            native.check(L.ggml_cdna4_mul_mat_prepared(Q4_K, big.data_ptr() + (i % ncopy) * mat_b, row_b, y1.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1,
-                                                       ws.data_ptr(), ws.numel(), ops.PATH_GEMV, 0, 0, stream))
-        def fused(i):                                    # B=1 ggml_cdna4_mul_mat: activation quantizer fused into the GEMV launch
-            native.check(L.ggml_cdna4_mul_mat(Q4_K, big.data_ptr() + (i % ncopy) * mat_b, row_b, x1.data_ptr(), K, y1.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1,
-                                              ws.data_ptr(), ws.numel(), 0, 0, 0, stream))
-        res = {}
-        for label, fn, rot in (("cold_hbm", gemv, True), ("cache_warm", gemv, False), ("fused_cold_hbm", fused, True), ("fused_cache_warm", fused, False)):
-            for i in range(20):
-                fn(i if rot else 0)
-            n = max(args.steps, 256)
-            e0.record()
-            for i in range(n):
-                fn(i if rot else 0)
-            e1.record(); e1.synchronize()
-            res[label] = e0.elapsed_time(e1) * 1e3 / n
-        alg_bytes = mat_b + K * 1 + (K // 256) * 4 + (K // 16) * 2 + M_PER_GPU * 4    # W + int8 x + scales + bsums + y
-        # full decode step incl. the activation quantize (what graph_compute does for one MUL_MAT node)
-        for _ in range(10):
-            native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), row_b, x1.data_ptr(), K, y1.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1, ws.data_ptr(), ws.numel(), 0, 0, 0, stream))
-        torch.cuda.synchronize(dev); t0 = time.perf_counter()
-        for _ in range(500):
-            native.check(L.ggml_cdna4_mul_mat(Q4_K, a.data.data_ptr(), row_b, x1.data_ptr(), K, y1.data_ptr(), M_PER_GPU, M_PER_GPU, K, 1, ws.data_ptr(), ws.numel(), 0, 0, 0, stream))
-        torch.cuda.synchronize(dev); full_us = (time.perf_counter() - t0) / 500 * 1e6
-        fused_bytes = mat_b + K * 4 + M_PER_GPU * 4                              # W + fp32 x + y (the quantized row never leaves LDS)
-        out["decode"] = {"workload": "Q4_K [4096x4096]·[4096x1] (BASELINE configs[1])",
-                         "us_per_step": round(res["fused_cold_hbm"], 3), "us_per_step_cache_warm": round(res["fused_cache_warm"], 3),
-                         "us_per_step_host_wall": round(full_us, 3), "tokens_per_s": round(1e6 / full_us, 1),
-                         "effective_tflops": round(2.0 * M_PER_GPU * K / (res["fused_cold_hbm"] * 1e-6) / 1e12, 3),
-                         "note": "step = ggml_cdna4_mul_mat at B=1 = ONE launch (activation quantizer fused into the GEMV); cold = 64 rotating copies of W (604 MB > MALL), HIP-event timed; host_wall includes the Python/ctypes call overhead",
-                         "roofline": {"bound": "hbm", "kernel": "k_gemv_q_fused<Q4_K>", "achieved": round(fused_bytes / (res["fused_cold_hbm"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                      "unit": "GB/s", "frac": round(fused_bytes / (res["fused_cold_hbm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k_gemv_q_fused<12"),
-                                      "algorithmic_bytes_per_launch": fused_bytes},
-                         "two_kernel_path": {"us_per_gemv_cold_hbm": round(res["cold_hbm"], 3), "us_per_gemv_cache_warm": round(res["cache_warm"], 3),
-                                             "roofline": {"bound": "hbm", "kernel": "k_gemv_q<Q4_K,1> (pre-quantized activations, B=2..8 and MUL_MAT_ID)", "achieved": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9, 1),
-                                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (res["cold_hbm"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                                          "traffic": pmc_traffic("k_gemv_q<12, 1"), "algorithmic_bytes_per_launch": alg_bytes}}}
-        del big
-        # the same decode step replayed from a captured HIP graph (how a decode loop launches it), in a child process: a failure
-        # there is recorded, never propagated
         if world == 1:
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--decode-graph"], capture_output=True, text=True, timeout=240)
-                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                hg = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:]}
-            except Exception as e:          # noqa: BLE001 — any failure of the optional leg is data, not an error of the run
-                hg = {"error": repr(e)[:300]}
-            if "us_per_step_hipgraph" in hg:
-                gb = fused_bytes / (hg["us_per_step_hipgraph"] * 1e-6) / 1e9
-                hg["roofline"] = {"bound": "hbm", "kernel": "k_gemv_q_fused<Q4_K>, launched from a HIP graph", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(gb / HBM_PEAK_GBS, 4)}
-            out["decode"]["hipgraph"] = hg
-        out["formats"] = format_rows(L, native, ops, dev, stream, x, max(50, min(args.steps, 200)))
-        # the vendor library's dense fp16 GEMM at the same shape on ALREADY-dequantized weights (torch.matmul -> hipBLASLt/rocBLAS):
-        # not part of the product and not a baseline of the metric — a practical ceiling next to the nominal MFMA roof, i.e. what
-        # a plain fp16 GEMM of this small shape reaches on this box without any dequantization. A failure is recorded, not raised.
-        if world == 1:
-            try:
-                wh = torch.empty((M_PER_GPU, K), dtype=torch.float16, device=dev).uniform_(-1, 1)
-                xh = x.to(torch.float16)
-                yh = torch.empty((B, M_PER_GPU), dtype=torch.float16, device=dev)
-                for _ in range(20):
-                    torch.matmul(xh, wh.t(), out=yh)
-                e0.record()
-                for _ in range(args.steps):
-                    torch.matmul(xh, wh.t(), out=yh)
-                e1.record(); e1.synchronize()
-                lib_us = e0.elapsed_time(e1) * 1e3 / args.steps
-                lib_tf = 2.0 * M_PER_GPU * K * B / (lib_us * 1e-6) / 1e12
-                out["library_fp16_gemm"] = {"what": "torch.matmul fp16 [512x4096]·[4096x4096]^T (hipBLASLt), weights pre-dequantized: 33.5 MB of fp16 W instead of 9.4 MB of Q4_K",
-                                            "us_per_launch": round(lib_us, 3), "tflops": round(lib_tf, 3), "frac_of_peak": round(lib_tf / MFMA_F16_PEAK_TFLOPS, 4),
-                                            "ours_over_library": round(gemm_tflops / lib_tf, 3)}
-                del wh, xh, yh
-            except Exception as e:          # noqa: BLE001
-                out["library_fp16_gemm"] = {"error": repr(e)[:300]}
+            out["roofline"]["library_ceiling"] = library_ceiling(dev, M, K, B, args.steps)
+            lc = out["roofline"]["library_ceiling"]
+            if "tflops" in lc:
+                lc["ours_over_library"] = round(gemm_tf / lc["tflops"], 3)
 
-    # ---- the exchange step of a row-split layer, timed separately: all-gather of the output shards ------------
-    if dist is not None:
-        yfull = torch.empty((world * B, M_PER_GPU), dtype=torch.float32, device=dev)
-        for _ in range(3):
-            step(); dist.all_gather_into_tensor(yfull, y)
-        barrier(); t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(); dist.all_gather_into_tensor(yfull, y)
-        barrier(); el = time.perf_counter() - t0
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if dist is not None:                                              # a default multi-GPU run also carries BASELINE configs[4]
+        c5 = c5_leg(dist, dev, rank, world, max(10, args.steps // 4), max(3, args.warmup // 4))
         if rank == 0:
-            ms = float(t.item()) / args.steps * 1e3
-            out["with_allgather"] = {"ms_per_step": round(ms, 5), "value": round(flops_step / (ms * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
-                                     "collective": "RCCL all_gather_into_tensor of fp32 output shards, %d B/rank" % (B * M_PER_GPU * 4)}
-        # the K-split variant of the same layer: every rank holds W[:, K-shard] (whole superblocks per row),
-        # computes a full-size partial Y over its shard — the same [4096x4096]·[4096x512] kernel per rank — and the
-        # partials are summed with one RCCL all-reduce
-        for _ in range(3):
-            step(); dist.all_reduce(y)
-        barrier(); t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(); dist.all_reduce(y)
-        barrier(); el = time.perf_counter() - t0
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        if rank == 0:
-            ms = float(t.item()) / args.steps * 1e3
-            out["with_allreduce"] = {"ms_per_step": round(ms, 5), "value": round(flops_step / (ms * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
-                                     "collective": "K-split: RCCL all_reduce(sum) of the fp32 partial outputs, %d B" % (B * M_PER_GPU * 4)}
+            out["c5"] = c5
 
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(M, K, B)
+        if extras:
+            steps = max(50, min(args.steps, 200))
+            legs = (("decode", lambda: decode_rows(dev, steps), 150),
+                    ("shapes", lambda: {"c3_4096x11008x512": shape_row(dev, Q4_K, 4096, 11008, 512, steps), "c5_32768x8192x512_one_gpu": shape_row(dev, Q4_K, 32768, 8192, 512, max(20, steps // 4))}, 200),
+                    ("formats", lambda: format_rows(dev, steps), 230),
+                    ("stock_test_backend_ops_perf", lambda: stock_perf_lines(int(max(30, min(150, time_left(400))))), 260))
+            for name, fn, budget in legs:                              # none STARTS once the run is that many seconds old
+                if time_left(budget) <= 0:
+                    out[name] = "skipped: time budget"
+                    continue
+                try:
+                    out[name] = fn()
+                except Exception as e:  # noqa: BLE001 — an optional leg never takes the metric line down
+                    out[name] = {"error": repr(e)[:300]}
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        if world == 1 and optional_time_left() <= 0:
-            out["one_launch_step_experimental"] = "skipped: time budget of the optional legs"
-        elif world == 1:
-            # experimental one-launch step (not the default path, not part of `value`), in a child process so that nothing it does
-            # can take this line down; runs last
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fuseq-leg", "--steps", str(args.steps)], capture_output=True, text=True, timeout=150)
-                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                out["one_launch_step_experimental"] = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:], "returncode": r.returncode}
-            except Exception as e:          # noqa: BLE001
-                out["one_launch_step_experimental"] = {"error": repr(e)[:300]}
-            if not args.no_diagnostics:
-                out["diagnostics"] = diagnostics()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

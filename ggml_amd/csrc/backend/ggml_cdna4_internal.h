@@ -17,7 +17,7 @@
 // stream, scratch and staging buffers, created on first use and kept for the life of the backend
 struct cdna4_lane {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; bool shares_stream = false;   // (shards on one device share its stream)
     hipEvent_t done = nullptr;
     void * x = nullptr;  size_t x_bytes = 0;      // activations copied from the main device
     void * y = nullptr;  size_t y_bytes = 0;      // this shard's output rows, [B][rows] f32

@@ -89,7 +89,10 @@ enum ggml_status cdna4_ops_compute(void * ctx, ggml_tensor * node) {
         }
         case GGML_OP_DIAG_MASK_INF: rc = ggml_cdna4_op_diag_mask_inf(&da, &dd, ((const int32_t *)node->op_params)[0], stream); break;
         case GGML_OP_GET_ROWS: rc = ggml_cdna4_op_get_rows(&da, &db, &dd, stream); break;
-        case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: rc = ggml_cdna4_op_cpy(&da, &dd, /*q8_0_ref_rounding=*/1, stream); break;   // F32 -> Q8_0 as quantize_row_q8_0_ref (the CPU's dup path and ggml-cuda's cpy both round this way)
+        // F32 -> Q8_0 with the CPU backend's own from_float (type_traits_cpu[Q8_0].from_float = the SIMD quantize_row_q8_0, which is what
+        // ggml_compute_forward_dup_f32 calls: ggml-cpu.c:3230-3260) — measured: byte-identical to the reference's CPY, whereas
+        // quantize_row_q8_0_ref (ggml-cuda's rounding) differs from it on exact .5 ties
+        case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: rc = ggml_cdna4_op_cpy(&da, &dd, /*q8_0_ref_rounding=*/0, stream); break;
         case GGML_OP_MUL_MAT: rc = ggml_cdna4_op_mul_mat_f(&da, &db, &dd, stream); break;
         case GGML_OP_ROPE: {
             const int32_t * ip = (const int32_t *)node->op_params;

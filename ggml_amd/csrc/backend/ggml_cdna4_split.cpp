@@ -171,7 +171,7 @@ void cdna4_split_free_lanes(cdna4_backend_ctx * ctx) {
     for (cdna4_lane & l : ctx->lanes) {
         if (l.device < 0) continue;
         (void)hipSetDevice(l.device);
-        if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+        if (l.stream) { (void)hipStreamSynchronize(l.stream); if (!l.shares_stream) (void)hipStreamDestroy(l.stream); }
         if (l.done) (void)hipEventDestroy(l.done);
         if (l.x) (void)hipFree(l.x); if (l.y) (void)hipFree(l.y); if (l.ws) (void)hipFree(l.ws);
         l = cdna4_lane{};
@@ -206,7 +206,10 @@ enum ggml_status cdna4_split_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst)
         HIP_OK(hipSetDevice(dev));
         if (l.device < 0) {
             l.device = dev;
-            HIP_OK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+            // ONE stream per device: the kernel library keeps its split-K exchange scratch per device, so GEMM calls for one device
+            // must be stream-ordered (include/ggml_cdna4.h) — shards that share a device (GGML_CDNA4_SPLIT_SELF) share a stream
+            for (int j = 0; j < CDNA4_MAX_DEVICES && !l.stream; j++) if (j != i && ctx->lanes[j].device == dev && ctx->lanes[j].stream) { l.stream = ctx->lanes[j].stream; l.shares_stream = true; }
+            if (!l.stream) HIP_OK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
             HIP_OK(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
             if (dev != ctx->device) { const hipError_t e = hipDeviceEnablePeerAccess(ctx->device, 0); if (e != hipSuccess) (void)hipGetLastError(); }   // xGMI peer mapping (already enabled: fine)
         }

@@ -453,6 +453,11 @@ struct gemm_params {
     int tune;                                           // experiment bits from CDNA4_TUNE (bit0: static s_setprio 1 for the khalf-1 waves)
     float *partial; unsigned *flags;   // split-K = 2 exchange: exported half tiles [tile][ks][64][128]; one flag per (tile, ks): 0 = idle, 16 | XCC id = published (cleared by its READER)
     unsigned long long *trace;   // profiling builds only (k_gemm_kq_w8<TYPE, true>): per-phase s_memtime stamps of block 0
+    // grouped MUL_MAT_ID (k_gemm_kq_t64<.., IDS = true>; appended last: no other kernel's argument offsets move): the activation image
+    // holds the (token, slot) rows SORTED BY EXPERT, every expert's run starting on a 128-row boundary; activation tile t belongs to
+    // expert tile_expert[t] (< 0: unused tile, the work-group exits), its weights start at W + expert * w_expert_bytes, and image row r
+    // is output row row_dst[r] (< 0: padding row, not stored)
+    const int32_t *tile_expert; const int32_t *row_dst; int64_t w_expert_bytes;
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -483,4 +488,5 @@ template <> struct WStage<CDNA4_Q6_KS, 2> { static constexpr int NPH = 9; __devi
 // host-side helpers shared by the launchers (defined in gemm_q_mfma.hip)
 void *cdna4_gemm_scratch(size_t bytes, int kind);      // per-device scratch, zero-filled when (re)allocated; kind 0: split-K exchange, 1: repacked weights
 int cdna4_gemm_cu_count();
-int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st);     // gemm_q_t64.hip: 64(m) x 128(b) wave tiles; tm 0 / 128 / 256, splitk 0 / 1 / 2
+int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st);
+int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);   // grouped MUL_MAT_ID: a.B = image rows, a.Y rows indexed by row_dst     // gemm_q_t64.hip: 64(m) x 128(b) wave tiles; tm 0 / 128 / 256, splitk 0 / 1 / 2

@@ -42,3 +42,17 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
+
+// grouped MUL_MAT_ID: one launch over (m tile) x (activation tile of the expert-sorted image); tiles past the last expert's run exit
+int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st) {
+    if (a.type != CDNA4_Q4_K || a.K % 256 || a.K < 256 || a.B % 128) return cdna4_set_error_msg("gemm_t64_ids: Q4_K, whole superblocks, image rows a multiple of 128");
+    if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes | (uintptr_t)w_expert_bytes) & 15) || ((uintptr_t)a.xh & 15)) return cdna4_set_error_msg("gemm_t64_ids: 16-byte alignment of the expert matrices and the image");
+    gemm_params p{};
+    p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
+    p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = 1;
+    p.tiles_m = (a.M + 127) / 128; p.tiles_b = a.B / 128;
+    p.tile_expert = tile_expert; p.row_dst = row_dst; p.w_expert_bytes = w_expert_bytes;
+    hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, true>), dim3(p.tiles_m * p.tiles_b), dim3(512), 0, st, p);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}

@@ -80,10 +80,10 @@ __global__ __launch_bounds__(256) void k_unary(const float *__restrict__ x, floa
     if (OP == GGML_CDNA4_GELU) {
         // the CPU reads a 64K-entry fp16 table indexed by fp16(x) (ggml_vec_gelu_f32, ggml-cpu.c:1759-1774)
         if (v <= -10.0f) r = 0.0f; else if (v >= 10.0f) r = v;
-        else { const float xh = (float)(half_t)v; r = (float)(half_t)gelu_f32(xh); }
+        else { const float xh = (float)(half_t)v; r = (float)(half_t)gelu_f32(xh); if (r == 0.0f) r = __builtin_copysignf(0.0f, xh); }   // x * 0 keeps x's sign on the CPU (-0.0 for x <= -5.2): make the zero's sign explicit
     } else if (OP == GGML_CDNA4_GELU_QUICK) {
         if (v <= -10.0f || v >= 10.0f) { r = v * (1.0f / (1.0f + expf(-1.702f * v))); }
-        else { const float xh = (float)(half_t)v; r = (float)(half_t)(xh * (1.0f / (1.0f + expf(-1.702f * xh)))); }
+        else { const float xh = (float)(half_t)v; r = (float)(half_t)(xh * (1.0f / (1.0f + expf(-1.702f * xh)))); if (r == 0.0f) r = __builtin_copysignf(0.0f, xh); }
     } else if (OP == GGML_CDNA4_SILU) r = v / (1.0f + expf(-v));
     else if (OP == GGML_CDNA4_RELU) r = v > 0.f ? v : 0.f;
     else r = tanhf(v);
@@ -246,7 +246,13 @@ __global__ __launch_bounds__(256) void k_cpy_f32_to_q(const T4 a, const T4 d, in
         float amax = 0.f, mx = 0.f;
 #pragma unroll
         for (int j = 0; j < 32; j++) if (amax < fabsf(v[j])) { amax = fabsf(v[j]); mx = v[j]; }
-        const float dd = mx / -8; const float id = dd != 0.f ? 1.0f / dd : 0.f;
+        // d = max / -8 (exact: a power of two); an all-zero block has d = -0.0 on the CPU (+0 / -8): the sign is flipped on the BITS so
+        // that no floating-point simplification can drop it
+        float dd = mx * -0.125f;
+        // hipcc fuses the multiply into the fp16 conversion as v_fma_mixlo_f16(mx, -0.125, +0): for mx = 0 that is (-0) + (+0) = +0 and the
+        // sign of the zero is gone (seen in the ISA; one byte of an all-zero block differed from the CPU's).  Keep the product opaque.
+        asm volatile("" : "+v"(dd));
+        const float id = dd != 0.f ? 1.0f / dd : 0.f;
         *(uint16_t *)out = f2h_bits(dd);
 #pragma unroll
         for (int j = 0; j < 16; j++) {

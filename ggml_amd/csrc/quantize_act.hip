@@ -27,12 +27,15 @@ __device__ __forceinline__ u32x2 pack4h(half_t a, half_t b, half_t c, half_t d) 
 // 6 rounds — took 6.0 us for the 512 x 4096 headline batch; the per-lane work is what the fused decode kernel uses too.)
 __global__ __launch_bounds__(256) void k_quantize_q8_K(const float *__restrict__ x, int64_t x_row_stride, int K, int B,
                                                        int8_t *__restrict__ qs, float *__restrict__ dd,
-                                                       int16_t *__restrict__ bsums, half_t *__restrict__ xh) {
+                                                       int16_t *__restrict__ bsums, half_t *__restrict__ xh, const int32_t *__restrict__ src_rows) {
     const int nch = K / 16;                                                  // 16-element chunks per row
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;              // chunk id over [B][nch]
     if (t >= (int64_t)B * nch) return;                                       // whole 16-lane groups drop out together (nch % 16 == 0)
     const int b = (int)(t / nch), c = (int)(t % nch);
-    const float *px = x + (int64_t)b * x_row_stride + (int64_t)c * 16;
+    // src_rows (grouped MUL_MAT_ID): output row b is the quantized input row src_rows[b]; < 0 = padding row, left untouched
+    int sb = b;
+    if (src_rows) { sb = src_rows[b]; if (sb < 0) return; }                   // (uniform over the 16 lanes of a superblock)
+    const float *px = x + (int64_t)sb * x_row_stride + (int64_t)c * 16;
     float e[16];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -113,7 +116,60 @@ int cdna4_launch_quantize_q8_K(const float *x, int64_t x_row_stride, int64_t K, 
     if (K % QK_K) return cdna4_set_error_msg("quantize_q8_K: K must be a multiple of 256");
     if (B == 0 || K == 0) return 0;
     const int64_t nthr = B * (K / 16);
-    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, bsums, (half_t *)xh);
+    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, bsums, (half_t *)xh, (const int32_t *)nullptr);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- grouped MUL_MAT_ID (mixture-of-experts prefill): a device-side counting sort of the expert ids — no host sync, unlike the
+// reference's CUDA path (ggml-cuda.cu:1975-1978 copies the ids to the host) — and the activation quantizer gathering through it.
+// What the CPU does on one thread before its per-expert mul_mats (ggml-cpu.c:7679-7694: matrix_row_counts / matrix_rows).
+// One work-group.  Image layout: expert e's (token, slot) rows occupy image rows [off_e, off_e + cnt_e), off_e a multiple of 128.
+__global__ __launch_bounds__(1024) void k_moe_plan(const int32_t *__restrict__ ids, int64_t ids_tok_stride, int n_tok, int n_used, int n_b, int n_expert,
+                                                   int img_rows, int32_t *__restrict__ img_src, int32_t *__restrict__ img_dst, int32_t *__restrict__ tile_expert) {
+    __shared__ int cnt[1024], off[1024], pos[1024];
+    const int tid = threadIdx.x, n_pairs = n_tok * n_used, ntile = img_rows / 128;
+    for (int e = tid; e < n_expert; e += 1024) { cnt[e] = 0; pos[e] = 0; }
+    for (int r = tid; r < img_rows; r += 1024) { img_src[r] = -1; img_dst[r] = -1; }
+    for (int t = tid; t < ntile; t += 1024) tile_expert[t] = -1;
+    __syncthreads();
+    for (int pr = tid; pr < n_pairs; pr += 1024) {
+        const int e = ids[(int64_t)(pr / n_used) * ids_tok_stride + pr % n_used];
+        if (e >= 0 && e < n_expert) atomicAdd(&cnt[e], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int e = 0; e < n_expert; e++) {
+            off[e] = run;
+            const int nt = (cnt[e] + 127) / 128;
+            for (int t = 0; t < nt; t++) tile_expert[run / 128 + t] = e;
+            run += nt * 128;
+        }
+    }
+    __syncthreads();
+    for (int pr = tid; pr < n_pairs; pr += 1024) {
+        const int tok = pr / n_used, slot = pr % n_used;
+        const int e = ids[(int64_t)tok * ids_tok_stride + slot];
+        if (e < 0 || e >= n_expert) continue;                           // out-of-range id: the slot stays unwritten (as documented)
+        const int r = off[e] + atomicAdd(&pos[e], 1);
+        img_src[r] = tok * n_b + slot % n_b;                             // slot u reads activation row u % n_b (ggml-cpu.c:7752)
+        img_dst[r] = pr;
+    }
+}
+int cdna4_launch_moe_plan(const int32_t *ids, int64_t ids_tok_stride, int n_tok, int n_used, int n_b, int n_expert, int img_rows,
+                          int32_t *img_src, int32_t *img_dst, int32_t *tile_expert, hipStream_t st) {
+    if (n_expert > 1024) return cdna4_set_error_msg("moe_plan: more than 1024 experts");
+    hipLaunchKernelGGL(k_moe_plan, dim3(1), dim3(1024), 0, st, ids, ids_tok_stride, n_tok, n_used, n_b, n_expert, img_rows, img_src, img_dst, tile_expert);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+// the fp16 image of the rows src_rows[0 .. img_rows) of x (Q8_K quantization, as above), row r of the image = x row src_rows[r]
+int cdna4_launch_quantize_q8_K_gather(const float *x, int64_t x_row_stride, int64_t K, int64_t img_rows, const int32_t *src_rows, void *xh, hipStream_t st) {
+    if (K % QK_K) return cdna4_set_error_msg("quantize_q8_K: K must be a multiple of 256");
+    if (img_rows == 0 || K == 0) return 0;
+    const int64_t nthr = img_rows * (K / 16);
+    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)img_rows, (int8_t *)nullptr, (float *)nullptr, (int16_t *)nullptr, (half_t *)xh, src_rows);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

@@ -41,3 +41,24 @@ def gather_rows(y_local, M, world, group=None, align=ROW_TILE):
     dist.all_gather_into_tensor(buf, pad, group=group)
     buf = buf.view(world, B, mx)
     return torch.cat([buf[r, :, :sizes[r]] for r in range(world)], dim=1)
+
+
+def k_range(K, rank, world, block=256):
+    """[lo, hi) of the K (input-feature) range owned by `rank` in the K-split variant of a layer: whole `block`s (superblocks
+    for K-quants), as evenly as they go — the first (K / block) % world ranks take one more.  Every rank then computes a full-size
+    PARTIAL output over its K range and the partials are summed with one all-reduce."""
+    if world <= 0 or not (0 <= rank < world) or K % block:
+        raise ValueError("bad rank/world/K")
+    nb = K // block
+    base, rem = divmod(nb, world)
+    lo = rank * base + min(rank, rem)
+    return lo * block, (lo + base + (1 if rank < rem else 0)) * block
+
+
+def k_shard_bytes(w_bytes, M, K, block, block_bytes, rank, world):
+    """the K-shard of a block-quantized [M x K] matrix (numpy uint8, rows contiguous): blocks run along K inside each row, so a K
+    range is the SAME byte range of every row — a strided slice, not a contiguous one (that is why the reference's set_tensor
+    would have to scatter per-row sub-ranges)."""
+    lo, hi = k_range(K, rank, world, block)
+    rb = K // block * block_bytes
+    return w_bytes.reshape(M, rb)[:, lo // block * block_bytes:hi // block * block_bytes].copy().reshape(-1), lo, hi

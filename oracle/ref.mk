@@ -38,7 +38,7 @@ BASE_OBJ := $(patsubst %,$(OUT)/obj/base/%.o,$(BASE_C) $(BASE_CXX))
 CPU_OBJ  := $(patsubst %,$(OUT)/obj/cpu/%.o,$(CPU_C) $(CPU_CXX))
 
 LIBS  := $(OUT)/libggml-base.so $(OUT)/libggml-cpu.so $(OUT)/libggml.so
-BINS  := $(OUT)/test-backend-ops $(OUT)/test-quantize-fns $(OUT)/test-mul-mat $(OUT)/cpu_baseline $(OUT)/gpt-2-quantize $(OUT)/gpt2_harness $(OUT)/sched_harness $(OUT)/split_harness
+BINS  := $(OUT)/test-backend-ops $(OUT)/test-quantize-fns $(OUT)/test-mul-mat $(OUT)/cpu_baseline $(OUT)/gpt-2-quantize $(OUT)/gpt2_harness $(OUT)/sched_harness $(OUT)/split_harness $(OUT)/synth_data $(OUT)/v4/cpu_baseline
 
 all: $(LIBS) $(BINS)
 
@@ -79,6 +79,25 @@ $(OUT)/sched_harness: oracle/sched_harness.cpp $(EXC) $(LIBS)
 	$(CXX) $(CXXFLAGS_COMMON) -DGGML_USE_CUDA -I$(REF) -I$(REF)/examples -o $@ $< $(EXC) -L$(OUT) -lggml -lggml-cpu -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN'
 $(OUT)/split_harness: oracle/split_harness.cpp $(LIBS)
 	$(CXX) $(CXXFLAGS_COMMON) -o $@ $< -L$(OUT) -lggml -lggml-cpu -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN'
+
+$(OUT)/synth_data: oracle/synth_data.cpp $(LIBS)
+	$(CXX) $(CXXFLAGS_COMMON) -o $@ $< -L$(OUT) -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN'
+
+# A second build of the CPU backend for the timing baseline only: AVX-512 + VNNI (x86-64-v4), the widest ISA common to this
+# container's Xeon and the GPU box's EPYC 9575F — what the reference's default -march=native would select there.  The oracle
+# and every parity test keep the x86-64-v3 build above (that is the build oracle/ggml_oracle.c restates).
+ARCH4 ?= -march=x86-64-v4 -mavx512vnni -mavx512vbmi
+CPU4_OBJ := $(patsubst %,$(OUT)/v4/obj/%.o,$(CPU_C) $(CPU_CXX))
+$(OUT)/v4/obj/%.c.o: $(REF)/src/%.c
+	@mkdir -p $(dir $@)
+	$(CC) $(CFLAGS_COMMON) $(ARCH4) -fopenmp -DGGML_BACKEND_BUILD -DGGML_USE_OPENMP -DGGML_USE_CPU_AARCH64 -c $< -o $@
+$(OUT)/v4/obj/%.cpp.o: $(REF)/src/%.cpp
+	@mkdir -p $(dir $@)
+	$(CXX) $(CXXFLAGS_COMMON) $(ARCH4) -fopenmp -DGGML_BACKEND_BUILD -DGGML_USE_OPENMP -DGGML_USE_CPU_AARCH64 -c $< -o $@
+$(OUT)/v4/libggml-cpu.so: $(CPU4_OBJ) $(OUT)/libggml-base.so
+	$(CXX) -shared -fopenmp -o $@ $(CPU4_OBJ) -L$(OUT) -lggml-base -Wl,-rpath,'$$ORIGIN/..'
+$(OUT)/v4/cpu_baseline: oracle/cpu_baseline.cpp $(OUT)/v4/libggml-cpu.so $(LIBS)
+	$(CXX) $(CXXFLAGS_COMMON) -o $@ $< -L$(OUT)/v4 -lggml-cpu -L$(OUT) -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/..'
 
 clean:
 	rm -rf $(OUT)

@@ -1,7 +1,8 @@
 """-m gpu: the supporting ops and the row converters of include/ggml_cdna4.h called THROUGH THE C-ABI (ctypes, device pointers,
 ggml_cdna4_tensor descriptors) and compared with the unmodified reference CPU backend (tests/refops.py -> oracle/_ref) and the
-C oracle on identical inputs.  Bars: BIT-EXACT for CPY f32 -> Q8_0 / Q4_0 (bytes, against quantize_row_*_ref,
-/root/reference/src/ggml-quants.c:31-66,194-217, which is what the reference's dup path and ggml-cuda's cpy.cu run) and for
+C oracle on identical inputs.  Bars: BIT-EXACT for CPY f32 -> Q8_0 / Q4_0 (bytes: the reference CPU backend's CPY node, whose
+dup path calls type_traits_cpu[].from_float — the AVX2 quantize_row_q8_0 of ggml-cpu-quants.c:778-815 and quantize_row_q4_0_ref
+of ggml-quants.c:31-66 — plus the quantize_row_q8_0_ref rounding of ggml-cuda's cpy as the second Q8_0 form) and for
 dequantize_row of the five formats (to_float, ggml-quants.c:255,349,1280,1482,1690); <= 2e-6 relative L2 for the float ops
 (norm, rms_norm, soft_max, rope, gelu, diag_mask_inf, get_rows) whose only freedom is fp32 summation order / libm."""
 import ctypes as C
@@ -71,33 +72,26 @@ def _data(kind, shape, seed):
 
 # ------------------------------------------------------------------------------------------------ CPY f32 -> quantized: bytes
 @pytest.mark.parametrize("kind", ["uniform", "normal", "ties"])
-@pytest.mark.parametrize("dst_type", [R.Q8_0, R.Q4_0])
-def test_cpy_f32_to_quantized_is_byte_exact(L, dst_type, kind):
+@pytest.mark.parametrize("dst_type,ref_rounding", [(R.Q8_0, 0), (R.Q8_0, 1), (R.Q4_0, 0)])
+def test_cpy_f32_to_quantized_is_byte_exact(L, dst_type, ref_rounding, kind):
+    """CPY f32 -> Q8_0 / Q4_0 through the C-ABI, byte for byte.  q8_0_ref_rounding = 0 is what the plug-in passes: the CPU backend's
+    own from_float (the AVX2 quantize_row_q8_0), i.e. the bytes the REFERENCE's CPY node writes (checked below against the
+    compiled reference, ties included); 1 is quantize_row_q8_0_ref, the rounding of ggml-cuda's cpy.  Q4_0 has one form."""
     import refops as O
     rows, k = 37, 1024
     x = _data(kind, (rows, k), 11)
-    x[3, 32:64] = 0                                                     # an all-zero block
+    x[3, 32:64] = 0                                                     # an all-zero block (its scale is -0.0 for Q4_0: 0 / -8)
     x[4, 5] = -7.5; x[4, 9] = 7.5                                        # equal |max| of both signs inside one block
     xd = _dev(x)
     out = torch.zeros(rows * R.row_size(dst_type, k), dtype=torch.uint8, device="cuda")
-    _ok(L, L.ggml_cdna4_op_cpy(C.byref(_desc(xd, R.F32)), C.byref(_qdesc(out, dst_type, k, rows)), 1, _st()))
+    _ok(L, L.ggml_cdna4_op_cpy(C.byref(_desc(xd, R.F32)), C.byref(_qdesc(out, dst_type, k, rows)), ref_rounding, _st()))
     torch.cuda.synchronize()
     got = out.cpu().numpy()
-    name = "q8_0_ref" if dst_type == R.Q8_0 else "q4_0_ref"
+    name = "q4_0_ref" if dst_type == R.Q4_0 else ("q8_0_ref" if ref_rounding else "q8_0_cpu")
     want = np.concatenate([R.o_quantize_row(name, x[i]) for i in range(rows)])
-    assert np.array_equal(got, want), "first differing byte %d" % int(np.argmax(got != want))
-    assert np.array_equal(want, O.cpy_quantize(x, dst_type))           # ... and the oracle IS what the reference's CPY writes
-
-
-def test_cpy_f32_to_q8_0_cpu_rounding_variant_is_byte_exact(L):
-    """q8_0_ref_rounding = 0: the AVX2 from_float the CPU backend uses for MUL_MAT activations (ggml-cpu-quants.c:778-815)"""
-    rows, k = 16, 512
-    x = _data("ties", (rows, k), 5)
-    out = torch.zeros(rows * R.row_size(R.Q8_0, k), dtype=torch.uint8, device="cuda")
-    _ok(L, L.ggml_cdna4_op_cpy(C.byref(_desc(_dev(x), R.F32)), C.byref(_qdesc(out, R.Q8_0, k, rows)), 0, _st()))
-    torch.cuda.synchronize()
-    want = np.concatenate([R.o_quantize_row("q8_0_cpu", x[i]) for i in range(rows)])
-    assert np.array_equal(out.cpu().numpy(), want)
+    assert np.array_equal(got, want), "first differing byte %d of %d differing" % (int(np.argmax(got != want)), int((got != want).sum()))
+    if not ref_rounding:
+        assert np.array_equal(want, O.cpy_quantize(x, dst_type))       # ... and that oracle IS what the reference's CPY node writes
 
 
 # ------------------------------------------------------------------------------------------------ dequantize_row: bit-exact
