@@ -175,7 +175,7 @@ static enum ggml_status compute_mul_mat_id(cdna4_backend_ctx * ctx, ggml_tensor 
     const ggml_tensor * as = dst->src[0], * b = dst->src[1], * ids = dst->src[2];
     const int64_t K = as->ne[0], M = as->ne[1], n_expert = as->ne[2];
     const int64_t n_b = b->ne[1], n_tok = b->ne[2], n_used = ids->ne[0];
-    const size_t need = ggml_cdna4_mul_mat_workspace_size((int)as->type, K, n_b * n_tok);
+    const size_t need = ggml_cdna4_mul_mat_id_workspace_size((int)as->type, K, n_expert, n_used, n_b, n_tok);
     void * ws = ctx->need_ws(need);
     if (!ws) return GGML_STATUS_ALLOC_FAILED;
     const int rc = ggml_cdna4_mul_mat_id((int)as->type, as->data, (int64_t)as->nb[1], (int64_t)as->nb[2],

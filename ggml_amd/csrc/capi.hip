@@ -32,6 +32,21 @@ static ws_view carve(int type, int64_t K, int64_t B, void *base) {
     return v;
 }
 
+// workspace of the grouped MUL_MAT_ID path: [img_src i32 R][img_dst i32 R][tile_expert i32 R/128][xh f16 R x K (+ slack)], R = image rows =
+// an upper bound of sum_e ceil(cnt_e / 128) * 128
+struct moe_view { int32_t *img_src, *img_dst, *tile_expert; void *xh; int64_t img_rows; size_t total; };
+static moe_view moe_carve(int64_t K, int64_t n_expert, int64_t n_used, int64_t n_tok, void *base) {
+    moe_view v; uint8_t *p = (uint8_t *)base; size_t off = 0;
+    const int64_t n_pairs = n_tok * n_used;
+    v.img_rows = (n_pairs + 127) / 128 * 128 + 128 * n_expert;
+    v.img_src = (int32_t *)(p + off); off += align256((size_t)v.img_rows * 4);
+    v.img_dst = (int32_t *)(p + off); off += align256((size_t)v.img_rows * 4);
+    v.tile_expert = (int32_t *)(p + off); off += align256((size_t)(v.img_rows / 128) * 4);
+    v.xh = (void *)(p + off); off += align256((size_t)v.img_rows * K * 2) + 32768;
+    v.total = off;
+    return v;
+}
+
 extern "C" {
 
 int ggml_cdna4_api_version(void) { return GGML_CDNA4_API_VERSION; }
@@ -55,6 +70,14 @@ size_t ggml_cdna4_row_size(int type, int64_t k) {
 size_t ggml_cdna4_mul_mat_workspace_size(int type, int64_t K, int64_t n_act_rows) {
     if (!is_q(type) || K <= 0 || n_act_rows <= 0) return 0;
     return carve(type, K, n_act_rows, nullptr).total;
+}
+
+size_t ggml_cdna4_mul_mat_id_workspace_size(int type, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok) {
+    if (!is_q(type) || K <= 0 || n_tok <= 0 || n_used <= 0 || n_b <= 0 || n_expert <= 0) return 0;
+    const size_t plain = carve(type, K, n_tok * n_b, nullptr).total;
+    if (type != CDNA4_Q4_K || n_tok * n_used <= 32) return plain;
+    const size_t grouped = moe_carve(K, n_expert, n_used, n_tok, nullptr).total;
+    return grouped > plain ? grouped : plain;
 }
 
 int ggml_cdna4_quantize_q8_K(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d, int16_t *bsums, void *xh, void *stream) {
@@ -134,6 +157,23 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
     if (dst_tok_stride != n_used * dst_row_stride) return cdna4_set_error_msg("mul_mat_id: dst must be contiguous over (slot, token)");
     if (b_tok_stride != n_b * b_row_stride) return cdna4_set_error_msg("mul_mat_id: b must be contiguous over (row, token)");
     const int64_t nact = n_tok * n_b;
+    // prefill-sized mixture-of-experts batches: group the (token, slot) rows by expert on the device and run ONE MFMA GEMM launch over
+    // the (expert, activation tile) table — every expert's weights are read once per m-tile instead of once per column
+    // (ggml_compute_forward_mul_mat_id groups the same way on the host: ggml-cpu.c:7648-7781)
+    if (type == CDNA4_Q4_K && n_tok * n_used > 32 && n_expert <= 1024 && workspace && !((uintptr_t)workspace & 255) &&
+        !(((uintptr_t)as | (uintptr_t)w_row_bytes | (uintptr_t)w_expert_bytes) & 15) && !(((uintptr_t)b | (uintptr_t)(b_row_stride * 4)) & 15)) {
+        const moe_view mv = moe_carve(K, n_expert, n_used, n_tok, workspace);
+        if (workspace_bytes >= mv.total && mv.img_rows * K * 2 < ((int64_t)1 << 31)) {
+            int rc = cdna4_launch_moe_plan(ids, ids_tok_stride, (int)n_tok, (int)n_used, (int)n_b, (int)n_expert, (int)mv.img_rows, mv.img_src, mv.img_dst, mv.tile_expert, (hipStream_t)stream);
+            if (rc) return rc;
+            rc = cdna4_launch_quantize_q8_K_gather(b, b_row_stride, K, mv.img_rows, mv.img_src, mv.xh, (hipStream_t)stream);
+            if (rc) return rc;
+            cdna4_gemm_args a{};
+            a.type = type; a.W = (const uint8_t *)as; a.w_row_bytes = w_row_bytes; a.xh = mv.xh; a.xh_row_elems = K;
+            a.Y = dst; a.y_row_elems = dst_row_stride; a.M = (int)M; a.K = (int)K; a.B = (int)mv.img_rows;
+            return cdna4_launch_gemm_t64_ids(a, mv.tile_expert, mv.img_dst, w_expert_bytes, (hipStream_t)stream);
+        }
+    }
     if (n_tok == 1 && n_used <= 65535 && cdna4_gemv_fused_supported(type, K, 1) && !(((uintptr_t)b | (uintptr_t)(b_row_stride * 4)) & 15)) {
         // single-token decode of a mixture-of-experts layer: one launch, the activation quantizer runs inside the GEMV
         cdna4_gemv_args g{};

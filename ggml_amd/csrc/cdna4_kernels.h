@@ -44,6 +44,8 @@ struct cdna4_gemm_args {
     int splitk;                                     // 0 = auto
 };
 int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st);
+// gemm_q_t64.hip — grouped MUL_MAT_ID: a.B = rows of the expert-sorted activation image, a.Y rows indexed through row_dst
+int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);
 bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B);
 
 extern void *cdna4_debug_trace;

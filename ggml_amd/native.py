@@ -20,6 +20,7 @@ SYMBOLS = [
     ("ggml_cdna4_mul_mat", _int, [_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _int, _int, _int, _vp]),
     ("ggml_cdna4_prepare_act", _int, [_int, _vp, _i64, _i64, _i64, _vp, _sz, _int, _vp]),
     ("ggml_cdna4_mul_mat_prepared", _int, [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _int, _int, _int, _vp]),
+    ("ggml_cdna4_mul_mat_id_workspace_size", _sz, [_int, _i64, _i64, _i64, _i64, _i64]),
     ("ggml_cdna4_mul_mat_id", _int, [_int, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64,
                                      _i64, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
     ("ggml_cdna4_quantize_q8_K", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -137,7 +137,7 @@ def mul_mat_id(as_: "list[QTensor] | QTensor", b: torch.Tensor, ids: torch.Tenso
     n_used = ids.shape[1]
     M = a.M // n_expert
     out = torch.empty((n_tok, n_used, M), dtype=torch.float32, device=b.device)
-    nws = L.ggml_cdna4_mul_mat_workspace_size(int(a.type), K, n_tok * n_b)
+    nws = L.ggml_cdna4_mul_mat_id_workspace_size(int(a.type), K, n_expert, n_used, n_b, n_tok)
     ws = _workspace(b.device, nws)
     b = b.contiguous()
     ids = ids.to(torch.int32).contiguous()

@@ -95,9 +95,14 @@ int ggml_cdna4_mul_mat_prepared(int type, const void * W, int64_t w_row_bytes,
  *   b  : f32 [n_tok][n_b][K]   (n_used % n_b == 0; slot u reads row u % n_b)     strides in elements
  *   ids: i32 [n_tok][n_used]   (device memory; never copied to the host)        stride in elements
  *   dst: f32 [n_tok][n_used][M]
- * n_tok == 1 (decode) runs as ONE launch with the activation quantizer inside the GEMV (workspace untouched);
- * more tokens quantize the activations into `workspace` first.  Expert ids out of [0, n_expert) leave their slot unwritten.
+ * n_tok == 1 (decode) runs as ONE launch with the activation quantizer inside the GEMV (workspace untouched); a handful of
+ * tokens quantize the activations into `workspace` and run the int8-dot GEMV per (token, slot) column; prefill-sized batches
+ * (Q4_K, n_tok * n_used > 32, workspace >= ggml_cdna4_mul_mat_id_workspace_size) are GROUPED BY EXPERT on the device — a
+ * counting sort of the ids, no host sync — and run as one MFMA GEMM launch over the (expert, activation tile) table, the way
+ * ggml_compute_forward_mul_mat_id groups rows on the host (ggml-cpu.c:7648-7781).  Expert ids out of [0, n_expert) leave
+ * their slot unwritten.
  */
+size_t ggml_cdna4_mul_mat_id_workspace_size(int type, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok);
 int ggml_cdna4_mul_mat_id(int type, const void * as, int64_t w_row_bytes, int64_t w_expert_bytes,
                           const float * b, int64_t b_row_stride, int64_t b_tok_stride,
                           const int32_t * ids, int64_t ids_tok_stride,

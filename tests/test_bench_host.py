@@ -1,32 +1,46 @@
-"""Host-side logic of bench.py that can be checked without a GPU: the optional legs' time budget (a leg that would start
-after the budget says so instead of running) and that what they record serialises into the one JSON line."""
+"""Host-side logic of bench.py that can be checked without a GPU: the optional legs' start deadlines (a leg that would start
+after its deadline says so instead of running; a leg that raises records the error), the prescribed-input generator (the
+reference's own mt19937(1234) + quantize_chunk, oracle/_ref/synth_data) sharding consistently, and the kernel the roofline names."""
 import importlib
 import json
 import os
 import sys
 
+import numpy as np
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(monkeypatch, budget):
-    monkeypatch.setenv("BENCH_OPTIONAL_BUDGET_S", str(budget))
+def _bench():
     sys.path.insert(0, ROOT)
     sys.modules.pop("bench", None)
     return importlib.import_module("bench")
 
 
-def test_optional_legs_respect_the_time_budget(monkeypatch):
-    b = _bench(monkeypatch, -1000)                  # the budget is already spent: nothing may start
-    res = b.diagnostics()
-    json.dumps(res)
-    flat = []
-    for v in res.values():
-        flat += list(v.values()) if isinstance(v, dict) else [v]
-    assert flat and all(v in ("not built",) or str(v).startswith("skipped: time budget") for v in flat), res
+def test_optional_legs_respect_their_start_deadlines():
+    b = _bench()
+    ran = []
+    legs = (("a", lambda: ran.append("a") or {"ok": 1}, 1e9), ("late", lambda: ran.append("late"), -1000), ("boom", lambda: 1 / 0, 1e9))
+    out = b.run_legs(legs, {})
+    json.dumps(out)
+    assert ran == ["a"] and out["a"] == {"ok": 1} and out["late"] == "skipped: time budget" and "ZeroDivisionError" in out["boom"]["error"]
 
 
-def test_experimental_variants_are_distinct_and_explicit(monkeypatch):
-    b = _bench(monkeypatch, 240)
-    vs = {b.FUSEQ_VARIANT, b.FUSEQ_PFW_VARIANT, b.FUSEQ_WBL2_VARIANT, b.FUSEQ_GRP_VARIANT}
-    assert len(vs) == 4 and all(0 < v < 2 ** 31 and (v & 0xFFFF) == 4119 and (v >> 16) in (1024, 3072, 5120, 9216) for v in vs)
-    assert 0 < b.optional_time_left() <= 240   # (the default is 200 s; the env var of this test sets 240)
+def test_prescribed_inputs_shard_consistently():
+    """rows [lo, hi) of the prescribed matrix are the same bytes whether generated alone or as part of the whole (what lets every
+    rank of a row-split run build only its own shard), and the activations do not depend on the shard"""
+    b = _bench()
+    if not os.path.exists(os.path.join(b.REFDIR, "synth_data")):
+        pytest.skip("oracle/_ref/synth_data not built")
+    w_all, x_all, how = b.prescribed(b.Q4_K, 512, 1024, 0, 512, 8)
+    w_hi, x_hi, _ = b.prescribed(b.Q4_K, 512, 1024, 256, 512, 8)
+    assert how == "prescribed" and w_all.size == 512 * 1024 // 256 * 144
+    assert np.array_equal(w_all[w_all.size // 2:], w_hi) and np.array_equal(x_all, x_hi)
+    assert np.abs(x_all).max() <= 1.0 and len(np.unique(w_all)) > 200
+
+
+def test_roofline_names_the_kernel_the_auto_route_launches():
+    b = _bench()
+    assert "k_gemm_kq_w12" in b.kernel_name(b.Q4_K, *b.HEAD)                 # 32 x 4 tiles: the split-K 128x128 kernel
+    assert "k_gemm_kq_t64" in b.kernel_name(b.Q4_K, *b.C5)                   # 128 x 4 256-row tiles = 2 per CU

@@ -332,7 +332,8 @@ def test_mul_mat_id_parity(gu, name, t, n_expert, n_used, n_b_is_one, n_tok):
     y = ops.mul_mat_id(gu.qtensor(t, w, n_expert * m, k), gu.to_dev(xb), gu.to_dev(ids), n_expert=n_expert).cpu().numpy()
     yo = R.o_mul_mat_id(t, w, xb, ids, m, k, n_expert)
     e = R.rel_l2(y, yo); gu.report(test="mul_mat_id", type=name, rel_l2=e)
-    assert e < TOL_GEMV
+    grouped = t == R.Q4_K and n_tok * n_used > 32                  # capi.hip: Q4_K with more than 32 (token, slot) rows takes the grouped GEMM
+    assert e < (TOL_GEMM if grouped else TOL_GEMV)
 
 
 @pytest.mark.parametrize("name,t", WT)
@@ -353,3 +354,47 @@ def test_mul_mat_id_single_token_is_one_fused_launch(gu, name, t, n_expert, n_us
     assert np.array_equal(y1.view(np.uint32), y2[:1].view(np.uint32))
     e = R.rel_l2(y1, R.o_mul_mat_id(t, w, xb[:1], ids[:1], m, k, n_expert)); gu.report(test="mul_mat_id_fused", type=name, rel_l2=e)
     assert e < TOL_GEMV
+
+
+@pytest.mark.parametrize("n_expert,n_used,n_b_is_one,n_tok,m,k", [(8, 2, False, 512, 4096, 4096), (8, 2, False, 96, 512, 512), (4, 4, True, 33, 300, 768),
+                                                                  (16, 2, False, 40, 256, 256), (8, 1, False, 700, 640, 1024), (3, 2, False, 200, 128, 2048)])
+def test_mul_mat_id_grouped_prefill(gu, n_expert, n_used, n_b_is_one, n_tok, m, k):
+    """prefill-sized MUL_MAT_ID on Q4_K (n_tok * n_used > 32): the (token, slot) rows are counting-sorted by expert on the device,
+    quantized through the sort (gather) and multiplied in ONE launch of k_gemm_kq_t64<.., IDS>; ragged per-expert counts, experts
+    that receive no row, an expert id out of range (its slot must stay untouched), b broadcast over the slots (n_b = 1), repeated
+    calls on one workspace.  Against the oracle's MUL_MAT_ID (per-expert mul_mat, ggml-cpu.c:7648-7781) with the GEMM tolerance."""
+    from ggml_amd import ops
+    t = R.Q4_K
+    rng = np.random.default_rng(n_expert * 10 + n_used + n_tok)
+    w = R.random_weights(t, n_expert * m, k, seed=5)
+    n_b = 1 if n_b_is_one else n_used
+    xb = rng.uniform(-1, 1, (n_tok, n_b, k)).astype(np.float32)
+    ids = np.stack([rng.permutation(n_expert)[:n_used] for _ in range(n_tok)]).astype(np.int32)
+    if n_expert == 16:
+        ids[ids == 5] = 6                                            # expert 5 gets no row at all
+    a = gu.qtensor(t, w, n_expert * m, k)
+    y = ops.mul_mat_id(a, gu.to_dev(xb), gu.to_dev(ids), n_expert=n_expert).cpu().numpy()
+    if m * n_tok <= 300000:
+        yo = R.o_mul_mat_id(t, w, xb, ids, m, k, n_expert)
+        e = R.rel_l2(y, yo)
+    else:                                                            # headline-sized experts: a sample of the (token, slot) pairs
+        sel = rng.choice(n_tok, 24, replace=False)
+        yo = R.o_mul_mat_id(t, w, xb[sel], ids[sel], m, k, n_expert)
+        e = R.rel_l2(y[sel], yo)
+    gu.report(test="mul_mat_id_grouped", n_expert=n_expert, n_used=n_used, n_tok=n_tok, m=m, k=k, rel_l2=e)
+    assert np.isfinite(y).all() and e < TOL_GEMM
+    y2 = ops.mul_mat_id(a, gu.to_dev(xb), gu.to_dev(ids), n_expert=n_expert).cpu().numpy()
+    assert np.array_equal(y, y2)                                     # the sort order is not deterministic, the result is
+    # an out-of-range id leaves its slot untouched
+    ids_bad = ids.copy(); ids_bad[3, 0] = n_expert + 7
+    out = torch.full((n_tok, n_used, m), -77.0, dtype=torch.float32, device="cuda")
+    L = __import__("ggml_amd.native", fromlist=["lib"]).lib()
+    nws = L.ggml_cdna4_mul_mat_id_workspace_size(int(t), k, n_expert, n_used, n_b, n_tok)
+    ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+    xd, idd = gu.to_dev(xb), gu.to_dev(ids_bad)
+    rc = L.ggml_cdna4_mul_mat_id(int(t), a.data.data_ptr(), a.row_bytes, m * a.row_bytes, xd.data_ptr(), k, n_b * k, idd.data_ptr(), n_used,
+                                 out.data_ptr(), m, n_used * m, m, k, n_expert, n_used, n_b, n_tok, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, L.ggml_cdna4_last_error().decode()
+    torch.cuda.synchronize()
+    ob = out.cpu().numpy()
+    assert (ob[3, 0] == -77.0).all() and np.array_equal(ob[3, 1:], y[3, 1:]) and np.array_equal(ob[4], y[4])
