@@ -141,9 +141,11 @@ def events_us(fn, n, warm=10):
 
 
 def kernel_name(t, m, k, b):
-    if t == Q4_K and ((m + 255) // 256) * ((b + 127) // 128) >= 512:
-        return "k_gemm_kq_t64<Q4_K, 256> (256x128 tile, 8 waves x 64(m)x128(b), superblock headers through a small LDS area, no K split)"
-    return "k_gemm_kq_w12<Q4_K> (128x128 tile, 8 compute + 4 loader waves, cross-stage unpack/MFMA pipeline, split-K=2 hand-off on small grids)"
+    if t == Q4_K and b > 64:
+        if ((m + 255) // 256) * ((b + 127) // 128) >= 512:
+            return "k_gemm_kq_t64<Q4_K, 256> (256x128 tile, 8 waves x 64(m)x128(b), LDS-DMA by the four older waves in front of the stage barrier, no K split)"
+        return "k_gemm_kq_t64<Q4_K, 128> (128x128 tile, 8 waves x 64(m)x128(b) x K/4, LDS-DMA by the four older waves, split-K=2 hand-off on small grids)"
+    return "k_gemm_kq_w12 / k_gemm_kq_w8p (128x128 tile, cross-stage unpack/MFMA pipeline)"
 
 
 # ------------------------------------------------------------------------------------------------ optional legs (rank 0, N = 1)
@@ -476,7 +478,7 @@ def main():
             "tokens_per_s": round(B * world / (ms_per_step * 1e-3), 1),
             "roofline": {"bound": "mfma", "kernel": kernel_name(Q4_K, M, K, B) if args.variant == 0 else "gemm variant %d" % args.variant,
                          "achieved": round(gemm_tf, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tf / MFMA_F16_PEAK_TFLOPS, 4),
-                         "traffic": pmc_traffic("k_gemm_kq_w12<12") if args.variant == 0 else None,
+                         "traffic": pmc_traffic("k_gemm_kq_t64<12, 128") if args.variant == 0 else None,
                          "traffic_note": "HBM-side bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) from the rocprofv3 PMC passes of this command, profiles/rNN/pmc_summary.txt",
                          "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": h.flops, "us_per_launch_all_zero_operands": zero_us},
         }

@@ -18,7 +18,7 @@
 // around CDNA4_DMA16 makes hipcc merge uniform address arithmetic across the divergent join into VGPRs, which the "s" operands reject
 #define CDNA4_DMA16_LANES(voff, sbase, lds_addr, nlanes) do { uint64_t cdna4_exec_;                                                   \
     asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0" \
-                 : "=&s"(cdna4_exec_) : "v"(voff), "s"(sbase), "s"(lds_addr), "i"((1ull << (nlanes)) - 1) : "memory", "m0"); } while (0)
+                 : "=&s"(cdna4_exec_) : "v"(voff), "s"(sbase), "s"(lds_addr), "i"((nlanes) >= 64 ? -1ll : (long long)((1ull << ((nlanes) & 63)) - 1)) : "memory", "m0"); } while (0)
 // v_permlane32_swap: lanes 32-63 of `a` trade places with lanes 0-31 of `b` (both 32-bit); with a == b on entry every lane l ends
 // with a = the value of lane l % 32 and b = the value of lane 32 + l % 32
 #define CDNA4_SWAP32(a, b) do { auto r_ = __builtin_amdgcn_permlane32_swap((a), (b), false, false); (a) = r_[0]; (b) = r_[1]; } while (0)

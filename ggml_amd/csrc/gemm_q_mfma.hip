@@ -528,13 +528,11 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     if constexpr (TYPE == CDNA4_Q4_K) {
         // bit13 = k_gemm_kq_t64 (gemm_q_t64.hip: 64(m) x 128(b) wave tiles); bit14 / bit15 force its 128- / 256-row tile
         if (wlds && (variant & 8192)) return cdna4_launch_gemm_t64(a, (variant & 16384) ? 128 : ((variant & 32768) ? 256 : 0), a.splitk, st);
-        // auto: 256-row tiles need half the activation bytes per MFMA, but they only pay off once the grid is at least two full
-        // waves of 256x128 work-groups without any K split (MI355X, round 2: C5 32768x8192x512 242.9 us on k_gemm_kq_t64<256> vs
-        // 265.1 us on the 128-row kernel; 8192x8192x512 — one tile per CU — 71.6 vs 68.9 us, a loss)
-        if (wlds && a.variant <= 0 && a.splitk <= 0 && a.B > 64) {
-            const int tx = ((a.M + 255) / 256) * ((a.B + 127) / 128);
-            if (tx >= 2 * cu_count()) return cdna4_launch_gemm_t64(a, 256, 1, st);
-        }
+        // auto (round 2): k_gemm_kq_t64 for every prefill shape — 128-row tiles (hand-off split-K = 2 while both work-groups of a tile
+        // are resident, uneven for odd superblock counts), 256-row tiles once the grid holds two of them per CU.  MI355X, same box, same
+        // data: 4096x4096x512 24.25 vs 24.68 us on k_gemm_kq_w12, 4096x11008x512 50.95 vs 52.57, 8192x4096x512 37.1 vs 38.1,
+        // 32768x8192x512 (256-row tiles) 239-243 vs 265.
+        if (wlds && a.variant <= 0 && a.B > 64 && a.splitk <= 2) return cdna4_launch_gemm_t64(a, 0, a.splitk, st);   // (deeper, atomic splits: the older kernels below)
     }
     if (splitk < 1 || (kunits % splitk && !uneven)) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
     if constexpr (TYPE == CDNA4_Q4_0 || TYPE == CDNA4_Q8_0 || TYPE == CDNA4_Q6_K) {

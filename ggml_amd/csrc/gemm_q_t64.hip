@@ -12,7 +12,9 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) || ((uintptr_t)a.xh & 15)) return cdna4_set_error_msg("gemm_t64: weight rows and the activation image must be 16-byte aligned");
     const int cus = cdna4_gemm_cu_count(), nsb = a.K / 256;
     const int tiles_b = (a.B + 127) / 128;
-    if (tm <= 0) tm = (((a.M + 255) / 256) * tiles_b >= cus) ? 256 : 128;         // a 256-row tile per CU at least: half the activation DMA per MFMA
+    // 256-row tiles move half the activation bytes per MFMA, but only pay once the grid holds two of them per CU (C5 32768x8192x512:
+    // 239 us vs 265 on 128-row tiles; 8192x8192x512 — one per CU — 71.6 vs 68.9, a loss; below that CUs would idle)
+    if (tm <= 0) tm = (((a.M + 255) / 256) * tiles_b >= 2 * cus) ? 256 : 128;
     if (tm != 128 && tm != 256) return cdna4_set_error_msg("gemm_t64: tile rows are 128 or 256");
     const int tiles_m = (a.M + tm - 1) / tm, ntiles = tiles_m * tiles_b;
     if (splitk <= 0) splitk = (ntiles * 2 <= cus && nsb >= 2) ? 2 : 1;             // hand-off split: both work-groups of a tile must be resident
@@ -37,6 +39,14 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
         p.xchg_l2 = ((nb & 7) == 0 && ((nb >> 3) % (tiles_b * 2)) == 0) ? 1 : 0;   // each XCD's slice holds whole (tile_b x ks) groups
     }
     const dim3 grid(ntiles * splitk);
+#ifdef CDNA4_ABLATIONS
+    // gemm_bench_abl: variant bits 16+ pick a timing-only instantiation (gemm_kq_t64.inc: ABL)
+    p.trace = (unsigned long long *)cdna4_debug_trace;
+    const int abl = a.variant >> 16;
+#define T64_ABL(A) if (abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, false, (A)>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256, false, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
+    T64_ABL(1) T64_ABL(3) T64_ABL(4) T64_ABL(8) T64_ABL(15) T64_ABL(32) T64_ABL(256)
+    if (abl) return cdna4_set_error_msg("gemm_t64: ablation not instantiated");
+#endif
     if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256>), grid, dim3(512), 0, st, p);
     CDNA4_CHECK_LAUNCH();

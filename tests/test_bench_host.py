@@ -42,5 +42,5 @@ def test_prescribed_inputs_shard_consistently():
 
 def test_roofline_names_the_kernel_the_auto_route_launches():
     b = _bench()
-    assert "k_gemm_kq_w12" in b.kernel_name(b.Q4_K, *b.HEAD)                 # 32 x 4 tiles: the split-K 128x128 kernel
-    assert "k_gemm_kq_t64" in b.kernel_name(b.Q4_K, *b.C5)                   # 128 x 4 256-row tiles = 2 per CU
+    assert "k_gemm_kq_t64<Q4_K, 128>" in b.kernel_name(b.Q4_K, *b.HEAD)       # 32 x 4 tiles: the split-K 128x128 form
+    assert "k_gemm_kq_t64<Q4_K, 256>" in b.kernel_name(b.Q4_K, *b.C5)         # 128 x 4 256-row tiles = 2 per CU

@@ -73,6 +73,23 @@ int main(int argc, char **argv) {
             const double cyc = (double)(tr[8 * 16 * 8 + 1102] - tr[8 * 16 * 8 + 1100]), ref = (double)(tr[8 * 16 * 8 + 1103] - tr[8 * 16 * 8 + 1101]);
             printf("  variant %d block 0: %.0f s_memtime ticks in %.2f us of s_memrealtime (100 MHz) -> s_memtime runs at %.0f MHz\n", v, cyc, ref / 100.0, cyc / (ref / 100.0));
         }
+        if (v & 8192) {                              // k_gemm_kq_t64 (ablation build): clock + [wave][stage 16..31][phase] stamps of block 0
+            const double cyc = (double)(tr[2] - tr[0]), ref = (double)(tr[3] - tr[1]);
+            if (ref > 0) printf("  t64 variant %d block 0: %.0f s_memtime ticks in %.2f us (s_memrealtime, 100 MHz) -> %.0f MHz\n", v, cyc, ref / 100.0, cyc / (ref / 100.0));
+            const uint32_t *st32 = (const uint32_t *)(tr.data() + 8);
+            printf("  per stage (cycles): issue of the first k-steps | lgkm+vmcnt wait | barrier wait | last k-step = rest;  stage length\n");
+            for (int w = 0; w < 8; w++) {
+                double a[4] = {0, 0, 0, 0}, len = 0; int n = 0;
+                for (int sgi = 0; sgi + 1 < 16; sgi++) {
+                    const uint32_t *q = st32 + (w * 16 + sgi) * 4, *qn = q + 4;
+                    if (!q[0] || !qn[0]) continue;
+                    a[0] += (uint32_t)(q[1] - q[0]); a[1] += (uint32_t)(q[2] - q[1]); a[2] += (uint32_t)(q[3] - q[2]); a[3] += (uint32_t)(qn[0] - q[3]); len += (uint32_t)(qn[0] - q[0]); n++;
+                }
+                if (n) printf("    wave %d (%2d stages): %7.0f | %6.0f | %6.0f | %6.0f ;  %7.0f\n", w, n, a[0] / n, a[1] / n, a[2] / n, a[3] / n, len / n);
+            }
+            for (int w : {0, 4}) { printf("    wave %d stage starts:", w); for (int sgi = 0; sgi < 16; sgi++) printf(" %u", st32[(w * 16 + sgi) * 4] - st32[0]); printf("\n"); }
+            continue;
+        }
         if (v >= 65536) continue;                    // k_gemm_kq_w12 experiments record the clock only
         {   // which XCD did each work-group land on?  (the tile remap assumes blockIdx % 8)
             int nb = 0, mism = 0; for (int b = 0; b < 1024; b++) { const unsigned long long x = tr[8 * 16 * 8 + 32 + b]; if (b < 256 || x) { nb++; if ((int)x != b % 8) mism++; } }
