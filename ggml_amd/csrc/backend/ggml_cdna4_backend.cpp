@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 struct cdna4_device_ctx { int device; std::string name, description; };
@@ -206,14 +207,132 @@ static void cdna4_backend_synchronize(ggml_backend_t backend) {
     HIP_OK(hipSetDevice(ctx->device));
     HIP_OK(hipStreamSynchronize(ctx->stream));
 }
+// ---- graph peepholes: chains every transformer graph contains, run as one launch each (bit-identical to the node-by-node sequence:
+// the fused kernels perform the same separate fp32 operations — include/ggml_cdna4.h).  A chain is taken only if every intermediate
+// result has exactly one reader in this graph (the next link) and is not flagged as a graph output; the last node's tensor receives
+// the result, the intermediates are never written.  GGML_CDNA4_NO_FUSE=1 turns all of it off (tests compare both).
+//   MUL_MAT(quantized) -> ADD(bias) [-> GELU | -> ADD(residual)]     gpt-2: main-backend.cpp:515-521, 595-600, 656-666, 690-698
+//   NORM | RMS_NORM -> MUL(gain) [-> ADD(shift)]                      main-backend.cpp:476-488, 610-622
+//   SCALE -> DIAG_MASK_INF -> SOFT_MAX                                main-backend.cpp:586-596
+struct use_counts {
+    std::unordered_map<const ggml_tensor *, int> n;
+    use_counts(std::nullptr_t, int) {}
+    explicit use_counts(ggml_cgraph * g) {
+        for (int i = 0; i < ggml_graph_n_nodes(g); i++) {
+            const ggml_tensor * t = ggml_graph_node(g, i);
+            for (int j = 0; j < GGML_MAX_SRC; j++) if (t->src[j]) n[t->src[j]]++;
+            if (t->view_src) n[t->view_src]++;
+        }
+    }
+    bool only_reader(const ggml_tensor * t, const ggml_tensor * reader) const {          // t feeds `reader` and nothing else
+        if (t->flags & GGML_TENSOR_FLAG_OUTPUT) return false;
+        auto it = n.find(t);
+        if (it == n.end() || it->second != 1) return false;
+        for (int j = 0; j < GGML_MAX_SRC; j++) if (reader->src[j] == t) return true;
+        return false;
+    }
+};
+static bool is_row_vector_f32(const ggml_tensor * t, int64_t n) {
+    return t && t->type == GGML_TYPE_F32 && t->ne[0] == n && t->ne[1] == 1 && t->ne[2] == 1 && t->ne[3] == 1 && t->nb[0] == sizeof(float) && t->data;
+}
+static const ggml_tensor * other_src(const ggml_tensor * op, const ggml_tensor * t) { return op->src[0] == t ? op->src[1] : (op->src[1] == t ? op->src[0] : nullptr); }
+
+// MUL_MAT at node i with its tail; returns the number of nodes consumed (0 = no chain here)
+static int try_fused_mul_mat(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, const use_counts & uses, enum ggml_status & st) {
+    ggml_tensor * mm = ggml_graph_node(g, i);
+    const ggml_tensor * a = mm->src[0], * b = mm->src[1];
+    const int n_nodes = ggml_graph_n_nodes(g);
+    if (!is_qweight(a->type) || (a->buffer && cdna4_buft_is_split(a->buffer->buft)) || i + 1 >= n_nodes) return 0;
+    if (a->ne[2] != 1 || a->ne[3] != 1 || b->ne[2] != 1 || b->ne[3] != 1 || !ggml_is_contiguous(mm)) return 0;    // plain 2-D products
+    const int64_t M = a->ne[1], K = a->ne[0], B = b->ne[1];
+    ggml_tensor * n1 = ggml_graph_node(g, i + 1);
+    if (n1->op != GGML_OP_ADD || !uses.only_reader(mm, n1) || !ggml_are_same_shape(n1, mm) || !ggml_is_contiguous(n1)) return 0;
+    const ggml_tensor * bias = other_src(n1, mm);
+    if (!is_row_vector_f32(bias, M)) return 0;
+    ggml_tensor * last = n1; int used = 2, act = 0; const ggml_tensor * resid = nullptr;
+    if (i + 2 < n_nodes) {
+        ggml_tensor * n2 = ggml_graph_node(g, i + 2);
+        if (uses.only_reader(n1, n2) && ggml_are_same_shape(n2, n1) && ggml_is_contiguous(n2)) {
+            if (n2->op == GGML_OP_UNARY && ggml_get_unary_op(n2) == GGML_UNARY_OP_GELU && n2->src[0] == n1) { act = 1; last = n2; used = 3; }
+            else if (n2->op == GGML_OP_ADD) {
+                const ggml_tensor * r = other_src(n2, n1);
+                if (r && r != n1 && r->type == GGML_TYPE_F32 && ggml_are_same_shape(r, n1) && r->nb[0] == sizeof(float) && r->nb[1] % sizeof(float) == 0 && r->data) { resid = r; last = n2; used = 3; }
+            }
+        }
+    }
+    void * ws = ctx->need_ws(ggml_cdna4_mul_mat_workspace_size((int)a->type, K, B));
+    if (!ws) { st = GGML_STATUS_ALLOC_FAILED; return used; }
+    const int rc = ggml_cdna4_mul_mat_fused((int)a->type, a->data, (int64_t)a->nb[1], (const float *)b->data, (int64_t)(b->nb[1] / sizeof(float)),
+                                            (float *)last->data, (int64_t)(last->nb[1] / sizeof(float)), M, K, B, (const float *)bias->data, act,
+                                            resid ? (const float *)resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / sizeof(float)) : 0, ws, ctx->ws_size, ctx->stream);
+    if (rc) { fprintf(stderr, "ggml-cdna4: fused MUL_MAT failed: %s\n", ggml_cdna4_last_error()); st = GGML_STATUS_FAILED; }
+    return used;
+}
+static ggml_cdna4_tensor tdesc(const ggml_tensor * t) {
+    ggml_cdna4_tensor d; d.data = t->data; d.type = (int32_t)t->type; d.reserved = 0;
+    for (int k = 0; k < 4; k++) { d.ne[k] = t->ne[k]; d.nb[k] = (int64_t)t->nb[k]; }
+    return d;
+}
+static int try_fused_norm(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, const use_counts & uses, enum ggml_status & st) {
+    ggml_tensor * nm = ggml_graph_node(g, i);
+    const int n_nodes = ggml_graph_n_nodes(g);
+    if (i + 1 >= n_nodes || !cdna4_ops_supports_tensor(nm)) return 0;
+    ggml_tensor * n1 = ggml_graph_node(g, i + 1);
+    if (n1->op != GGML_OP_MUL || !uses.only_reader(nm, n1) || !ggml_are_same_shape(n1, nm) || n1->type != GGML_TYPE_F32 || n1->nb[0] != sizeof(float)) return 0;
+    const ggml_tensor * gain = other_src(n1, nm);
+    if (!is_row_vector_f32(gain, nm->ne[0])) return 0;
+    ggml_tensor * last = n1; int used = 2; const ggml_tensor * shift = nullptr;
+    if (i + 2 < n_nodes) {
+        ggml_tensor * n2 = ggml_graph_node(g, i + 2);
+        if (n2->op == GGML_OP_ADD && uses.only_reader(n1, n2) && ggml_are_same_shape(n2, n1) && n2->type == GGML_TYPE_F32 && n2->nb[0] == sizeof(float)) {
+            const ggml_tensor * sh = other_src(n2, n1);
+            if (is_row_vector_f32(sh, nm->ne[0])) { shift = sh; last = n2; used = 3; }
+        }
+    }
+    float eps; memcpy(&eps, nm->op_params, sizeof(float));
+    const ggml_cdna4_tensor dx = tdesc(nm->src[0]), dg = tdesc(gain), dd = tdesc(last);
+    ggml_cdna4_tensor ds{}; if (shift) ds = tdesc(shift);
+    if (ggml_cdna4_op_norm_affine(&dx, &dg, shift ? &ds : nullptr, &dd, eps, nm->op == GGML_OP_RMS_NORM, ctx->stream)) {
+        fprintf(stderr, "ggml-cdna4: fused NORM failed: %s\n", ggml_cdna4_last_error()); st = GGML_STATUS_FAILED;
+    }
+    return used;
+}
+static int try_fused_soft_max(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, const use_counts & uses, enum ggml_status & st) {
+    ggml_tensor * sc = ggml_graph_node(g, i);
+    if (i + 2 >= ggml_graph_n_nodes(g) || !cdna4_ops_supports_tensor(sc)) return 0;
+    ggml_tensor * dm = ggml_graph_node(g, i + 1), * sm = ggml_graph_node(g, i + 2);
+    if (dm->op != GGML_OP_DIAG_MASK_INF || sm->op != GGML_OP_SOFT_MAX || dm->src[0] != sc || sm->src[0] != dm || sm->src[1]) return 0;
+    if (!uses.only_reader(sc, dm) || !uses.only_reader(dm, sm) || !cdna4_ops_supports_tensor(dm) || !cdna4_ops_supports_tensor(sm)) return 0;
+    float pre, scale, max_bias;
+    memcpy(&pre, sc->op_params, 4); memcpy(&scale, (const float *)sm->op_params + 0, 4); memcpy(&max_bias, (const float *)sm->op_params + 1, 4);
+    const int n_past = ((const int32_t *)dm->op_params)[0];
+    if (n_past < 0) return 0;
+    const ggml_cdna4_tensor dx = tdesc(sc->src[0]), dd = tdesc(sm);
+    if (ggml_cdna4_op_soft_max_ext(&dx, nullptr, &dd, scale, max_bias, 1, pre, n_past, ctx->stream)) {
+        fprintf(stderr, "ggml-cdna4: fused SOFT_MAX failed: %s\n", ggml_cdna4_last_error()); st = GGML_STATUS_FAILED;
+    }
+    return 3;
+}
+
 static enum ggml_status cdna4_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
     cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
     HIP_OK(hipSetDevice(ctx->device));
     const int n_nodes = ggml_graph_n_nodes(cgraph);
+    static const bool no_fuse = getenv("GGML_CDNA4_NO_FUSE") != nullptr;
+    const bool fuse = !no_fuse && n_nodes > 1;
+    const use_counts uses = fuse ? use_counts(cgraph) : use_counts(nullptr, 0);
     for (int i = 0; i < n_nodes; i++) {
         ggml_tensor * node = ggml_graph_node(cgraph, i);
         if (ggml_is_empty(node)) continue;
         enum ggml_status st = GGML_STATUS_SUCCESS;
+        if (fuse) {
+            int used = 0;
+            if (node->op == GGML_OP_MUL_MAT) used = try_fused_mul_mat(ctx, cgraph, i, uses, st);
+            else if (node->op == GGML_OP_NORM || node->op == GGML_OP_RMS_NORM) used = try_fused_norm(ctx, cgraph, i, uses, st);
+            else if (node->op == GGML_OP_SCALE) used = try_fused_soft_max(ctx, cgraph, i, uses, st);
+            if (st != GGML_STATUS_SUCCESS) return st;
+            if (used) { i += used - 1; continue; }
+        }
         switch (node->op) {
             case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
             case GGML_OP_MUL_MAT:    st = compute_mul_mat(ctx, node); break;

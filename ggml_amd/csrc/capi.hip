@@ -127,8 +127,8 @@ int ggml_cdna4_mul_mat_prepared(int type, const void *W, int64_t w_row_bytes, fl
     return cdna4_launch_gemv_q(g, (hipStream_t)stream);
 }
 
-int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
-                       int64_t M, int64_t K, int64_t B, void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, void *stream) {
+static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
+                        int64_t M, int64_t K, int64_t B, void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, const cdna4_epilogue &epi, void *stream) {
     if (!is_q(type)) return cdna4_set_error_msg("mul_mat: unsupported weight type");
     if (M <= 0 || B <= 0) return 0;
     if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat: K is not a whole number of blocks");
@@ -138,12 +138,32 @@ int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float
         // single-token decode: the activation quantizer runs inside the GEMV kernel (workspace untouched)
         cdna4_gemv_args g{};
         g.type = type; g.W = (const uint8_t *)W; g.w_row_bytes = w_row_bytes; g.Y = Y; g.y_col_stride = y_row_stride;
-        g.M = (int)M; g.K = (int)K; g.ncol = 1; g.ids = nullptr;
+        g.M = (int)M; g.K = (int)K; g.ncol = 1; g.ids = nullptr; g.epi = epi;
         return cdna4_launch_gemv_q_fused(g, X, (hipStream_t)stream);
     }
     int rc = ggml_cdna4_prepare_act(type, X, x_row_stride, K, B, workspace, workspace_bytes, path, stream);
     if (rc) return rc;
-    return ggml_cdna4_mul_mat_prepared(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, stream);
+    if (path == GGML_CDNA4_PATH_GEMV) {                                  // a few activation rows: the tail rides in the GEMV's store
+        const ws_view v = carve(type, K, B, workspace);
+        cdna4_gemv_args g{};
+        g.type = type; g.W = (const uint8_t *)W; g.w_row_bytes = w_row_bytes; g.qs = v.qs; g.d = v.d; g.bsums = v.bsums;
+        g.Y = Y; g.y_col_stride = y_row_stride; g.M = (int)M; g.K = (int)K; g.ncol = (int)B; g.ids = nullptr; g.epi = epi;
+        return cdna4_launch_gemv_q(g, (hipStream_t)stream);
+    }
+    rc = ggml_cdna4_mul_mat_prepared(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, stream);
+    if (rc) return rc;
+    return cdna4_launch_epilogue(Y, y_row_stride, M, B, epi, (hipStream_t)stream);       // GEMM path: one element-wise launch for the whole tail
+}
+int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
+                       int64_t M, int64_t K, int64_t B, void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, void *stream) {
+    return mul_mat_impl(type, W, w_row_bytes, X, x_row_stride, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, cdna4_epilogue{}, stream);
+}
+int ggml_cdna4_mul_mat_fused(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
+                             int64_t M, int64_t K, int64_t B, const float *bias, int act, const float *residual, int64_t residual_row_stride,
+                             void *workspace, size_t workspace_bytes, void *stream) {
+    if (act != 0 && act != 1) return cdna4_set_error_msg("mul_mat_fused: act is 0 (none) or 1 (GELU)");
+    cdna4_epilogue e{}; e.bias = bias; e.resid = residual; e.resid_row_stride = residual_row_stride; e.act = act;
+    return mul_mat_impl(type, W, w_row_bytes, X, x_row_stride, Y, y_row_stride, M, K, B, workspace, workspace_bytes, GGML_CDNA4_PATH_AUTO, 0, 0, e, stream);
 }
 
 int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t w_expert_bytes, const float *b, int64_t b_row_stride, int64_t b_tok_stride,

@@ -16,6 +16,14 @@ int cdna4_launch_moe_plan(const int32_t *ids, int64_t ids_tok_stride, int n_tok,
 int cdna4_launch_quantize_q8_K_gather(const float *x, int64_t x_row_stride, int64_t K, int64_t img_rows, const int32_t *src_rows, void *xh, hipStream_t st);
 
 // gemv_q.hip — int8-dot decode path.  Activations are the SoA workspace of quantize_act.hip.
+// the element-wise tail a MUL_MAT may carry (epilogue.h): + bias[m], GELU, + resid[b][m] — in that order, each a separate fp32 operation
+struct cdna4_epilogue {
+    const float *bias;                 // [M] or nullptr
+    const float *resid;                // [B][resid_row_stride], element (b, m) at b * resid_row_stride + m, or nullptr
+    int64_t resid_row_stride;
+    int act;                           // 0 none, 1 GELU (after the bias, before the residual)
+};
+
 struct cdna4_gemv_args {
     int type;
     const uint8_t *W; int64_t w_row_bytes;          // M rows of K weights
@@ -25,7 +33,10 @@ struct cdna4_gemv_args {
     // MUL_MAT_ID: if ids != nullptr, column c = (token t, slot u): expert = ids[t*ids_tok_stride + u],
     // W += expert * w_expert_bytes, activation column = t * n_b + (u % n_b)
     const int32_t *ids; int64_t ids_tok_stride; int64_t w_expert_bytes; int n_used, n_b, n_expert;
+    cdna4_epilogue epi;                             // applied to every stored value (zeroed = none); not with ids
 };
+// Y[b][m] = epilogue(Y[b][m]) in place — the tail of a GEMM-path MUL_MAT, one launch instead of two or three (ops.hip)
+int cdna4_launch_epilogue(float *Y, int64_t y_row_stride, int64_t M, int64_t B, const cdna4_epilogue &e, hipStream_t st);
 int cdna4_launch_gemv_q(const cdna4_gemv_args &a, hipStream_t st);
 // single-column decode with the activation quantizer fused in (x = fp32 row; a.qs/d/bsums unused)
 bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B);

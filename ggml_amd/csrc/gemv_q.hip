@@ -11,6 +11,7 @@
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
 #include "quantize_dev.h"
+#include "epilogue.h"
 #include <stdlib.h>
 
 __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void k_gemv_q(const cdna4_gemv_args a) {
 #pragma unroll
         for (int c = 0; c < NB; c++) {
             const float s = wave_sum(acc[r][c]);
-            if (lane == 0 && row0 + r < a.M) a.Y[(int64_t)ycol[c] * a.y_col_stride + row0 + r] = s;
+            if (lane == 0 && row0 + r < a.M) a.Y[(int64_t)ycol[c] * a.y_col_stride + row0 + r] = epilogue_apply(a.epi, s, row0 + r, ycol[c]);
         }
 }
 
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
         if (lane < nunits) Unit<TYPE, 1>::mac(w0[r], lane, act, col, acc);
         for (int u = lane + 64; u < nunits; u += 64) Unit<TYPE, 1>::dot(wrow[r], u, act, col, acc);
         const float s = wave_sum(acc[0]);
-        if (lane == 0 && row0 + r < a.M) a.Y[row0 + r] = s;
+        if (lane == 0 && row0 + r < a.M) a.Y[row0 + r] = epilogue_apply(a.epi, s, row0 + r, 0);
     }
 }
 

@@ -5,6 +5,7 @@
 #include "../../include/ggml_cdna4.h"
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
+#include "epilogue.h"
 #include <math.h>
 
 typedef ggml_cdna4_tensor T4;
@@ -68,9 +69,6 @@ __global__ __launch_bounds__(256) void k_scale(const float *__restrict__ x, floa
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] = x[i] * s;
 }
-__device__ __forceinline__ float gelu_f32(float x) {           // ggml_gelu_f32, ggml-cpu.c:1753-1755
-    return 0.5f * x * (1.0f + tanhf(0.79788456080286535587989211986876f * x * (1.0f + 0.044715f * x * x)));
-}
 template <int OP>
 __global__ __launch_bounds__(256) void k_unary(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -79,8 +77,7 @@ __global__ __launch_bounds__(256) void k_unary(const float *__restrict__ x, floa
     float r;
     if (OP == GGML_CDNA4_GELU) {
         // the CPU reads a 64K-entry fp16 table indexed by fp16(x) (ggml_vec_gelu_f32, ggml-cpu.c:1759-1774)
-        if (v <= -10.0f) r = 0.0f; else if (v >= 10.0f) r = v;
-        else { const float xh = (float)(half_t)v; r = (float)(half_t)gelu_f32(xh); if (r == 0.0f) r = __builtin_copysignf(0.0f, xh); }   // x * 0 keeps x's sign on the CPU (-0.0 for x <= -5.2): make the zero's sign explicit
+        r = gelu_lut_f32(v);
     } else if (OP == GGML_CDNA4_GELU_QUICK) {
         if (v <= -10.0f || v >= 10.0f) { r = v * (1.0f / (1.0f + expf(-1.702f * v))); }
         else { const float xh = (float)(half_t)v; r = (float)(half_t)(xh * (1.0f / (1.0f + expf(-1.702f * xh)))); if (r == 0.0f) r = __builtin_copysignf(0.0f, xh); }
@@ -92,34 +89,38 @@ __global__ __launch_bounds__(256) void k_unary(const float *__restrict__ x, floa
 
 // ------------------------------------------------------------------------------------------------ norm / rms_norm
 // one 256-thread block per row; the row is re-read from L1/L2 (3 passes) — rows are K floats, a few KB
+// gain / shift (nullptr = none): the MUL and ADD that follow a NORM in every transformer graph (gpt-2: main-backend.cpp:476-488),
+// as the same two separate fp32 operations per element — bit-identical to NORM -> MUL -> ADD
 template <bool RMS>
-__global__ __launch_bounds__(256) void k_norm(const T4 a, const T4 d, float eps) {
+__global__ __launch_bounds__(256) void k_norm(const T4 a, const T4 d, float eps, const float *__restrict__ gain, const float *__restrict__ shift) {
     __shared__ float red[4];
     const int64_t row = blockIdx.x;
     const idx4 x = {0, row % a.ne[1], (row / a.ne[1]) % a.ne[2], row / (a.ne[1] * a.ne[2])};
     const float *src = (const float *)at(a, x);
     float *dst = (float *)at(d, x);
     const int n = (int)a.ne[0];
+    auto put = [&](int i, float v) { if (gain) v = v * gain[i]; if (shift) v = v + shift[i]; dst[i] = v; };
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) { const float v = src[i]; s += RMS ? v * v : v; }
     s = block_sum(s, red);
     const float mean = s / n;
     if (RMS) {
         const float scale = 1.0f / sqrtf(mean + eps);
-        for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i] * scale;
+        for (int i = threadIdx.x; i < n; i += 256) put(i, src[i] * scale);
     } else {
         float s2 = 0.f;
         for (int i = threadIdx.x; i < n; i += 256) { const float v = src[i] - mean; s2 += v * v; }
         s2 = block_sum(s2, red);
         const float scale = 1.0f / sqrtf(s2 / n + eps);
-        for (int i = threadIdx.x; i < n; i += 256) dst[i] = (src[i] - mean) * scale;
+        for (int i = threadIdx.x; i < n; i += 256) put(i, (src[i] - mean) * scale);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ soft_max
 template <int MASK>   // 0 none, 1 f32, 2 f16
 __global__ __launch_bounds__(256) void k_soft_max(const float *__restrict__ x, const void *__restrict__ mask, float *__restrict__ y,
-                                                  int nc, int ne01, int ne02, float scale, float max_bias, float m0, float m1, uint32_t n_head_log2) {
+                                                  int nc, int ne01, int ne02, float scale, float max_bias, float m0, float m1, uint32_t n_head_log2,
+                                                  float pre_scale, int use_pre, int diag_n_past) {
     __shared__ float red[4];
     const int64_t row = blockIdx.x;
     const float *sp = x + row * nc;
@@ -128,7 +129,12 @@ __global__ __launch_bounds__(256) void k_soft_max(const float *__restrict__ x, c
     const float slope = max_bias > 0.0f ? (hh < n_head_log2 ? powf(m0, (float)(hh + 1)) : powf(m1, (float)(2 * (hh - n_head_log2) + 1))) : 1.0f;
     const int64_t moff = (row % ne01) * (int64_t)nc;
     auto val = [&](int i) -> float {
-        float v = sp[i] * scale;
+        // use_pre / diag_n_past >= 0: the SCALE and DIAG_MASK_INF nodes in front of the softmax (gpt-2: main-backend.cpp:586-596), as their
+        // own fp32 operations: (x * pre_scale), -inf right of the diagonal, then the softmax's own scale
+        float v = sp[i];
+        if (use_pre) v = v * pre_scale;
+        if (diag_n_past >= 0 && i > diag_n_past + (int)(row % ne01)) v = -INFINITY;
+        v = v * scale;
         if (MASK == 1) v += slope * ((const float *)mask)[moff + i];
         if (MASK == 2) v += slope * (float)((const half_t *)mask)[moff + i];
         return v;
@@ -328,6 +334,20 @@ __global__ __launch_bounds__(256) void k_rope(const T4 a, const int32_t *__restr
 // ============================================================================================================
 #define NEED(cond, msg) do { if (!(cond)) return cdna4_set_error_msg(msg); } while (0)
 
+// ------------------------------------------------------------------------------------------------ MUL_MAT tail (GEMM path)
+__global__ __launch_bounds__(256) void k_epilogue(float *__restrict__ Y, int64_t y_row_stride, int64_t M, int64_t n, const cdna4_epilogue e) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = i / M, m = i % M;
+    Y[b * y_row_stride + m] = epilogue_apply(e, Y[b * y_row_stride + m], m, b);
+}
+int cdna4_launch_epilogue(float *Y, int64_t y_row_stride, int64_t M, int64_t B, const cdna4_epilogue &e, hipStream_t st) {
+    if (M <= 0 || B <= 0 || (!e.bias && !e.resid && !e.act)) return 0;
+    hipLaunchKernelGGL(k_epilogue, grid1d(M * B), dim3(256), 0, st, Y, y_row_stride, M, M * B, e);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" {
 
 int ggml_cdna4_op_binary(int op, const T4 *a, const T4 *b, const T4 *d, void *stream) {
@@ -374,17 +394,21 @@ int ggml_cdna4_op_unary(int op, const T4 *a, const T4 *d, void *stream) {
     return 0;
 }
 
-int ggml_cdna4_op_norm(const T4 *a, const T4 *d, float eps, int rms, void *stream) {
+int ggml_cdna4_op_norm_affine(const T4 *a, const T4 *gain, const T4 *shift, const T4 *d, float eps, int rms, void *stream) {
     NEED(a->type == CDNA4_F32 && d->type == CDNA4_F32 && same_shape(a, d) && a->nb[0] == 4 && d->nb[0] == 4, "norm: F32 rows only");
+    for (const T4 *g : {gain, shift})
+        NEED(!g || (g->type == CDNA4_F32 && g->nb[0] == 4 && g->ne[0] == a->ne[0] && g->ne[1] == 1 && g->ne[2] == 1 && g->ne[3] == 1), "norm: gain / shift are F32 vectors of ne[0] elements");
     const int64_t nr = nrows(a);
     if (nr == 0 || a->ne[0] == 0) return 0;
-    if (rms) hipLaunchKernelGGL(k_norm<true>, dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps);
-    else hipLaunchKernelGGL(k_norm<false>, dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps);
+    const float *gp = gain ? (const float *)gain->data : nullptr, *sp = shift ? (const float *)shift->data : nullptr;
+    if (rms) hipLaunchKernelGGL(k_norm<true>, dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp);
+    else hipLaunchKernelGGL(k_norm<false>, dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
+int ggml_cdna4_op_norm(const T4 *a, const T4 *d, float eps, int rms, void *stream) { return ggml_cdna4_op_norm_affine(a, nullptr, nullptr, d, eps, rms, stream); }
 
-int ggml_cdna4_op_soft_max(const T4 *a, const T4 *mask, const T4 *d, float scale, float max_bias, void *stream) {
+int ggml_cdna4_op_soft_max_ext(const T4 *a, const T4 *mask, const T4 *d, float scale, float max_bias, int use_pre_scale, float pre_scale, int diag_n_past, void *stream) {
     NEED(a->type == CDNA4_F32 && d->type == CDNA4_F32 && is_contig(a) && is_contig(d) && same_shape(a, d), "soft_max: contiguous F32 only");
     int mt = 0;
     if (mask) {
@@ -399,12 +423,16 @@ int ggml_cdna4_op_soft_max(const T4 *a, const T4 *mask, const T4 *d, float scale
     hipStream_t st = (hipStream_t)stream;
     const float *x = (const float *)a->data; float *y = (float *)d->data; const void *mp = mask ? mask->data : nullptr;
     const int nc = (int)a->ne[0], ne01 = (int)a->ne[1], ne02 = (int)a->ne[2];
-    if (mt == 0) hipLaunchKernelGGL(k_soft_max<0>, dim3((unsigned)nr), dim3(256), 0, st, x, mp, y, nc, ne01, ne02, scale, max_bias, m0, m1, n_head_log2);
-    else if (mt == 1) hipLaunchKernelGGL(k_soft_max<1>, dim3((unsigned)nr), dim3(256), 0, st, x, mp, y, nc, ne01, ne02, scale, max_bias, m0, m1, n_head_log2);
-    else hipLaunchKernelGGL(k_soft_max<2>, dim3((unsigned)nr), dim3(256), 0, st, x, mp, y, nc, ne01, ne02, scale, max_bias, m0, m1, n_head_log2);
+    if (mt == 0) hipLaunchKernelGGL(k_soft_max<0>, dim3((unsigned)nr), dim3(256), 0, st, x, mp, y, nc, ne01, ne02, scale, max_bias, m0, m1, n_head_log2, pre_scale, use_pre_scale, diag_n_past);
+    else if (mt == 1) hipLaunchKernelGGL(k_soft_max<1>, dim3((unsigned)nr), dim3(256), 0, st, x, mp, y, nc, ne01, ne02, scale, max_bias, m0, m1, n_head_log2, pre_scale, use_pre_scale, diag_n_past);
+    else hipLaunchKernelGGL(k_soft_max<2>, dim3((unsigned)nr), dim3(256), 0, st, x, mp, y, nc, ne01, ne02, scale, max_bias, m0, m1, n_head_log2, pre_scale, use_pre_scale, diag_n_past);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
+int ggml_cdna4_op_soft_max(const T4 *a, const T4 *mask, const T4 *d, float scale, float max_bias, void *stream) {
+    return ggml_cdna4_op_soft_max_ext(a, mask, d, scale, max_bias, 0, 1.0f, -1, stream);
+}
+
 
 int ggml_cdna4_op_diag_mask_inf(const T4 *a, const T4 *d, int n_past, void *stream) {
     NEED(a->type == CDNA4_F32 && d->type == CDNA4_F32 && is_contig(a) && is_contig(d) && same_shape(a, d) && n_past >= 0, "diag_mask_inf: contiguous F32 only");

@@ -18,6 +18,7 @@ SYMBOLS = [
     ("ggml_cdna4_row_size", _sz, [_int, _i64]),
     ("ggml_cdna4_mul_mat_workspace_size", _sz, [_int, _i64, _i64]),
     ("ggml_cdna4_mul_mat", _int, [_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _int, _int, _int, _vp]),
+    ("ggml_cdna4_mul_mat_fused", _int, [_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp, _i64, _vp, _sz, _vp]),
     ("ggml_cdna4_prepare_act", _int, [_int, _vp, _i64, _i64, _i64, _vp, _sz, _int, _vp]),
     ("ggml_cdna4_mul_mat_prepared", _int, [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _int, _int, _int, _vp]),
     ("ggml_cdna4_mul_mat_id_workspace_size", _sz, [_int, _i64, _i64, _i64, _i64, _i64]),
@@ -29,7 +30,9 @@ SYMBOLS = [
     ("ggml_cdna4_op_binary", _int, [_int, _vp, _vp, _vp, _vp]),
     ("ggml_cdna4_op_scale", _int, [_vp, _vp, C.c_float, _vp]),
     ("ggml_cdna4_op_norm", _int, [_vp, _vp, C.c_float, _int, _vp]),
+    ("ggml_cdna4_op_norm_affine", _int, [_vp, _vp, _vp, _vp, C.c_float, _int, _vp]),
     ("ggml_cdna4_op_soft_max", _int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp]),
+    ("ggml_cdna4_op_soft_max_ext", _int, [_vp, _vp, _vp, C.c_float, C.c_float, _int, C.c_float, _int, _vp]),
     ("ggml_cdna4_op_diag_mask_inf", _int, [_vp, _vp, _int, _vp]),
     ("ggml_cdna4_op_unary", _int, [_int, _vp, _vp, _vp]),
     ("ggml_cdna4_op_get_rows", _int, [_vp, _vp, _vp, _vp]),

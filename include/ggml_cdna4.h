@@ -110,6 +110,16 @@ int ggml_cdna4_mul_mat_id(int type, const void * as, int64_t w_row_bytes, int64_
                           int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok,
                           void * workspace, size_t workspace_bytes, void * stream);
 
+/* MUL_MAT with its element-wise tail: Y[b][m] = (((W.X)[b][m] + bias[m]) -> GELU if act == 1) + residual[b][m]; bias / residual may be NULL.
+ * What the gpt-2 graphs do in three nodes after every projection — MUL_MAT, ADD(bias), then GELU or ADD(residual)
+ * (/root/reference/examples/gpt-2/main-backend.cpp:515-521, 595-600, 656-666, 690-698).  Each step is the same separate fp32 operation the
+ * stand-alone ops perform (GELU = the CPU's fp16 look-up-table semantics, ggml-cpu.c:1759-1774), so the result is BIT-IDENTICAL to
+ * ggml_cdna4_mul_mat -> ggml_cdna4_op_binary(ADD) -> ggml_cdna4_op_unary(GELU) / ggml_cdna4_op_binary(ADD).  Decode-sized batches apply
+ * the tail in the GEMV's store (one launch); the MFMA GEMM path appends ONE element-wise launch for the whole tail. */
+int ggml_cdna4_mul_mat_fused(int type, const void * W, int64_t w_row_bytes, const float * X, int64_t x_row_stride, float * Y, int64_t y_row_stride,
+                             int64_t M, int64_t K, int64_t B, const float * bias, int act, const float * residual, int64_t residual_row_stride,
+                             void * workspace, size_t workspace_bytes, void * stream);
+
 /* Activation quantizers (bit-exact with the reference); outputs may be NULL to skip them.
  *   qs  int8  [B][K]      d  f32 [B][K/256 | K/32]      bsums int16 [B][K/16] (Q8_K only)
  *   xh  fp16  B*K halves = fp16(d*q) in the MFMA path's private layout: element (b,k) at ((k/128)*B + b)*128 + k%128
@@ -145,9 +155,17 @@ int ggml_cdna4_op_binary(int op, const ggml_cdna4_tensor * src0, const ggml_cdna
 int ggml_cdna4_op_scale(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, float scale, void * stream);
 /* LayerNorm without affine / RMSNorm over ne[0] — ggml-cpu.c:6929-6978, 7000-7046 */
 int ggml_cdna4_op_norm(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, float eps, int rms, void * stream);
+/* NORM / RMS_NORM followed by the MUL(gain) and ADD(shift) of a LayerNorm (either may be NULL; F32 vectors of ne[0] elements):
+ * bit-identical to op_norm -> op_binary(MUL) -> op_binary(ADD) (gpt-2: main-backend.cpp:476-488) */
+int ggml_cdna4_op_norm_affine(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * gain, const ggml_cdna4_tensor * shift, const ggml_cdna4_tensor * dst,
+                              float eps, int rms, void * stream);
 /* softmax(src0*scale + slope*mask) over ne[0]; mask (F32 or F16, [ne0, ne1]) may be NULL; ALiBi slopes from
  * max_bias as ggml-cpu.c:8848-8944 */
 int ggml_cdna4_op_soft_max(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * mask, const ggml_cdna4_tensor * dst, float scale, float max_bias, void * stream);
+/* soft_max with the SCALE (use_pre_scale != 0: x * pre_scale first) and DIAG_MASK_INF (diag_n_past >= 0) nodes that precede it in
+ * causal attention (gpt-2: main-backend.cpp:586-596) folded in, bit-identical to op_scale -> op_diag_mask_inf -> op_soft_max */
+int ggml_cdna4_op_soft_max_ext(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * mask, const ggml_cdna4_tensor * dst, float scale, float max_bias,
+                               int use_pre_scale, float pre_scale, int diag_n_past, void * stream);
 /* dst = src0 with dst[.., j, i] = -inf for i > n_past + j — ggml-cpu.c:8760-8830 */
 int ggml_cdna4_op_diag_mask_inf(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, int n_past, void * stream);
 /* element-wise activations; GELU reproduces the CPU's fp16 lookup-table semantics (ggml-cpu.c:1759-1774) */

@@ -194,3 +194,79 @@ def test_diag_mask_inf(L):
     _ok(L, L.ggml_cdna4_op_diag_mask_inf(C.byref(_desc(xd, R.F32)), C.byref(_desc(y, R.F32)), 3, _st()))
     torch.cuda.synchronize()
     assert np.array_equal(y.cpu().numpy().view(np.uint32), O.diag_mask_inf(x, 3).view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------ fused chains == their node-by-node sequences
+def _bin(L, op, a, b, d):
+    _ok(L, L.ggml_cdna4_op_binary(op, C.byref(_desc(a, R.F32)), C.byref(_desc(b, R.F32)), C.byref(_desc(d, R.F32)), _st()))
+
+
+@pytest.mark.parametrize("tail", ["bias", "bias_gelu", "bias_residual"])
+@pytest.mark.parametrize("b", [1, 5, 96])
+@pytest.mark.parametrize("name,t", [("q4_0", R.Q4_0), ("q4_K", R.Q4_K), ("q8_0", R.Q8_0)])
+def test_mul_mat_fused_equals_the_unfused_sequence_bit_for_bit(L, name, t, b, tail):
+    """ggml_cdna4_mul_mat_fused against ggml_cdna4_mul_mat -> op_binary(ADD bias) -> op_unary(GELU) | op_binary(ADD residual): the
+    one-launch decode form (b = 1), the few-rows GEMV form (b = 5: the tail in the store) and the MFMA GEMM form (b = 96: one
+    element-wise launch behind the GEMM) — same bits in all three."""
+    m, k = 3072, 768                                                     # gpt-2 117M c_fc
+    w = R.random_weights(t, m, k, seed=21)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (b, k)).astype(np.float32)
+    bias = (rng.standard_normal(m) * 3).astype(np.float32)               # spreads the GELU argument over (-10, 10) and beyond
+    bias[:4] = [-11.0, 11.0, -6.0, 0.0]
+    res = rng.standard_normal((b, m)).astype(np.float32)
+    wd, xd, bd, rd = _dev(w), _dev(x), _dev(bias), _dev(res)
+    nws = L.ggml_cdna4_mul_mat_workspace_size(int(t), k, b)
+    ws = torch.empty(max(nws, 256), dtype=torch.uint8, device="cuda")
+    rb = R.row_size(t, k)
+    y0 = torch.empty((b, m), dtype=torch.float32, device="cuda"); y1 = torch.empty_like(y0); y2 = torch.empty_like(y0)
+    _ok(L, L.ggml_cdna4_mul_mat(int(t), wd.data_ptr(), rb, xd.data_ptr(), k, y0.data_ptr(), m, m, k, b, ws.data_ptr(), ws.numel(), 0, 0, 0, _st()))
+    _bin(L, 0, y0, bd, y1)
+    if tail == "bias_gelu":
+        _ok(L, L.ggml_cdna4_op_unary(0, C.byref(_desc(y1, R.F32)), C.byref(_desc(y2, R.F32)), _st()))
+    elif tail == "bias_residual":
+        _bin(L, 0, y1, rd, y2)
+    else:
+        y2 = y1
+    yf = torch.full((b, m), 7.0, dtype=torch.float32, device="cuda")
+    _ok(L, L.ggml_cdna4_mul_mat_fused(int(t), wd.data_ptr(), rb, xd.data_ptr(), k, yf.data_ptr(), m, m, k, b, bd.data_ptr(), 1 if tail == "bias_gelu" else 0,
+                                      rd.data_ptr() if tail == "bias_residual" else None, m, ws.data_ptr(), ws.numel(), _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(yf.cpu().numpy().view(np.uint32), y2.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("rms", [0, 1])
+@pytest.mark.parametrize("with_shift", [False, True])
+def test_norm_affine_equals_norm_mul_add(L, rms, with_shift):
+    x = _data("normal", (2, 9, 768), 31)
+    rng = np.random.default_rng(2)
+    g = rng.uniform(0.5, 1.5, 768).astype(np.float32); sh = rng.standard_normal(768).astype(np.float32)
+    xd, gd, sd = _dev(x), _dev(g), _dev(sh)
+    a = torch.empty_like(xd); b_ = torch.empty_like(xd); c = torch.empty_like(xd); f = torch.empty_like(xd)
+    _ok(L, L.ggml_cdna4_op_norm(C.byref(_desc(xd, R.F32)), C.byref(_desc(a, R.F32)), 1e-5, rms, _st()))
+    _bin(L, 2, a, gd, b_)
+    if with_shift:
+        _bin(L, 0, b_, sd, c)
+    else:
+        c = b_
+    _ok(L, L.ggml_cdna4_op_norm_affine(C.byref(_desc(xd, R.F32)), C.byref(_desc(gd, R.F32)), C.byref(_desc(sd, R.F32)) if with_shift else None,
+                                       C.byref(_desc(f, R.F32)), 1e-5, rms, _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(f.cpu().numpy().view(np.uint32), c.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("n_past,n_q", [(0, 7), (40, 1), (13, 5)])
+def test_soft_max_ext_equals_scale_mask_soft_max(L, n_past, n_q):
+    n_head, n_kv = 12, n_past + n_q
+    x = _data("normal", (1, n_head, n_q, n_kv), 44)
+    xd = _dev(x); a = torch.empty_like(xd); b_ = torch.empty_like(xd); c = torch.empty_like(xd); f = torch.empty_like(xd)
+    _ok(L, L.ggml_cdna4_op_scale(C.byref(_desc(xd, R.F32)), C.byref(_desc(a, R.F32)), 0.125, _st()))
+    _ok(L, L.ggml_cdna4_op_diag_mask_inf(C.byref(_desc(a, R.F32)), C.byref(_desc(b_, R.F32)), n_past, _st()))
+    _ok(L, L.ggml_cdna4_op_soft_max(C.byref(_desc(b_, R.F32)), None, C.byref(_desc(c, R.F32)), 1.0, 0.0, _st()))
+    _ok(L, L.ggml_cdna4_op_soft_max_ext(C.byref(_desc(xd, R.F32)), None, C.byref(_desc(f, R.F32)), 1.0, 0.0, 1, 0.125, n_past, _st()))
+    # ... and in place, as the gpt-2 graph runs it (ggml_scale_inplace / diag_mask_inf_inplace / soft_max_inplace on one buffer)
+    g = xd.clone()
+    _ok(L, L.ggml_cdna4_op_soft_max_ext(C.byref(_desc(g, R.F32)), None, C.byref(_desc(g, R.F32)), 1.0, 0.0, 1, 0.125, n_past, _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(f.cpu().numpy().view(np.uint32), c.cpu().numpy().view(np.uint32))
+    assert np.array_equal(g.cpu().numpy().view(np.uint32), c.cpu().numpy().view(np.uint32))
