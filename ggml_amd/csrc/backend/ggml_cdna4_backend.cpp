@@ -196,6 +196,8 @@ static void cdna4_backend_free(ggml_backend_t backend) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     cdna4_split_free_lanes(ctx);
+    if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "ggml-cdna4: %s: %d HIP-graph captures, %d replays\n", ctx->name.c_str(), ctx->n_graph_captures, ctx->n_graph_launches);
+    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     if (ctx->ws) (void)hipFree(ctx->ws);
     (void)hipStreamDestroy(ctx->stream);
@@ -314,9 +316,32 @@ static int try_fused_soft_max(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, c
     return 3;
 }
 
-static enum ggml_status cdna4_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
-    cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
-    HIP_OK(hipSetDevice(ctx->device));
+// everything a node's launches depend on: op, types, shapes, strides, addresses, parameters — of the node and of its sources
+static uint64_t graph_signature(ggml_cgraph * g) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    auto mix = [&](uint64_t w) { h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; };
+    auto words = [&](const void * p, size_t nbytes) { uint64_t w; for (size_t i = 0; i + 8 <= nbytes; i += 8) { memcpy(&w, (const char *)p + i, 8); mix(w); } };
+    auto tensor = [&](const ggml_tensor * t) {
+        mix((uint64_t)t->type); words(t->ne, sizeof(t->ne)); words(t->nb, sizeof(t->nb)); mix((uint64_t)(uintptr_t)t->data);
+    };
+    const int n = ggml_graph_n_nodes(g);
+    mix((uint64_t)n);
+    for (int i = 0; i < n; i++) {
+        const ggml_tensor * t = ggml_graph_node(g, i);
+        mix(((uint64_t)t->op << 32) | (uint32_t)t->flags); words(t->op_params, sizeof(t->op_params)); tensor(t);
+        for (int j = 0; j < GGML_MAX_SRC; j++) { const ggml_tensor * s = t->src[j]; if (!s) continue; mix((uint64_t)(uintptr_t)s + j); tensor(s); }
+    }
+    return h ? h : 1;
+}
+static bool graph_has_split_weights(ggml_cgraph * g) {
+    for (int i = 0; i < ggml_graph_n_nodes(g); i++) {
+        const ggml_tensor * t = ggml_graph_node(g, i);
+        if (t->op == GGML_OP_MUL_MAT && t->src[0]->buffer && cdna4_buft_is_split(t->src[0]->buffer->buft)) return true;
+    }
+    return false;
+}
+
+static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph) {
     const int n_nodes = ggml_graph_n_nodes(cgraph);
     static const bool no_fuse = getenv("GGML_CDNA4_NO_FUSE") != nullptr;
     const bool fuse = !no_fuse && n_nodes > 1;
@@ -344,6 +369,47 @@ static enum ggml_status cdna4_backend_graph_compute(ggml_backend_t backend, ggml
             return st;
         }
     }
+    return GGML_STATUS_SUCCESS;
+}
+
+// A graph that comes back UNCHANGED (same nodes, shapes, addresses and parameters: graph_signature) is captured into a HIP graph on its
+// second appearance and replayed from then on — one hipGraphLaunch instead of one launch per node (the counterpart of the CUDA-graph
+// path of ggml-cuda.cu:2417-2694, without its parameter patching: a graph that changes, like a decode step whose KV views move every
+// token, simply stays on plain launches).  The first appearance always runs eagerly, which also sizes every workspace, so that the
+// capture itself allocates nothing.  Everything the kernels need is capturable: one stream, no host synchronisation, and the split-K
+// exchange flags are reset by their readers (gemm_w8_epilogue.inc / gemm_kq_t64.inc).  Row-split weights (several streams and devices)
+// stay on plain launches.  GGML_CDNA4_NO_GRAPHS=1 turns it off; a failed capture turns it off for the backend instance.
+static enum ggml_status cdna4_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
+    cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
+    HIP_OK(hipSetDevice(ctx->device));
+    static const bool no_graphs = getenv("GGML_CDNA4_NO_GRAPHS") != nullptr;
+    if (no_graphs || ctx->graphs_off || ggml_graph_n_nodes(cgraph) < 2) return run_nodes(ctx, cgraph);
+    const uint64_t sig = graph_signature(cgraph);
+    if (sig == ctx->graph_exec_sig && ctx->graph_exec) {
+        HIP_OK(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+        ctx->n_graph_launches++;
+        return GGML_STATUS_SUCCESS;
+    }
+    ctx->graph_sig_repeats = sig == ctx->graph_sig ? ctx->graph_sig_repeats + 1 : 0;
+    ctx->graph_sig = sig;
+    if (ctx->graph_sig_repeats < 1 || graph_has_split_weights(cgraph)) return run_nodes(ctx, cgraph);
+    // second appearance in a row: capture, instantiate, launch
+    if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; ctx->graph_exec_sig = 0; }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); ctx->graphs_off = true; return run_nodes(ctx, cgraph); }
+    const enum ggml_status st = run_nodes(ctx, cgraph);
+    const hipError_t ee = hipStreamEndCapture(ctx->stream, &graph);
+    if (st != GGML_STATUS_SUCCESS || ee != hipSuccess || !graph || hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        ctx->graph_exec = nullptr; ctx->graphs_off = true;
+        fprintf(stderr, "ggml-cdna4: HIP-graph capture failed, staying on plain launches\n");
+        return run_nodes(ctx, cgraph);                                     // nothing has run yet: the capture only recorded
+    }
+    (void)hipGraphDestroy(graph);
+    ctx->graph_exec_sig = sig; ctx->n_graph_captures++;
+    HIP_OK(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+    ctx->n_graph_launches++;
     return GGML_STATUS_SUCCESS;
 }
 // ---- asynchronous tensor access and events: what ggml_backend_sched uses to overlap a split's input copies with the previous

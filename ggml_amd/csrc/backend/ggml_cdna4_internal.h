@@ -30,6 +30,11 @@ struct cdna4_backend_ctx {
     hipEvent_t ev_x = nullptr;                    // "activations are ready on the main stream" (split MUL_MAT)
     hipEvent_t ev_copy = nullptr;                 // cpy_tensor_async between two backends
     cdna4_lane lanes[CDNA4_MAX_DEVICES];
+    // HIP-graph replay of a compute graph that comes back unchanged (ggml_cdna4_backend.cpp: graph_compute)
+    uint64_t graph_sig = 0; int graph_sig_repeats = 0;        // signature of the last graph_compute call, how often in a row it was seen
+    hipGraphExec_t graph_exec = nullptr; uint64_t graph_exec_sig = 0;
+    bool graphs_off = false;                                  // a capture failed once: stay on plain launches
+    int n_graph_launches = 0, n_graph_captures = 0;           // (statistics, printed at free under GGML_CDNA4_STATS)
     void * need_ws(size_t n) {
         if (n <= ws_size) return ws;
         HIP_OK(hipStreamSynchronize(stream));

@@ -5,6 +5,9 @@
 //            (rows sharded per GGML_CDNA4_SPLIT_SELF on a one-GPU box), whole-tensor set / get round trip
 //   async    ggml_backend_tensor_set_async / get_async / copy_async between two backends of the device + events
 //   host     the pinned host buffer type (ggml_backend_dev_host_buffer_type): allocation, is_host, CPU-visible
+//   replay   a transformer MLP block (NORM, MUL, ADD, MUL_MAT, ADD, GELU, MUL_MAT, ADD, ADD) computed again and again with changing inputs:
+//            the plug-in replays the unchanged graph from a HIP graph (stderr under GGML_CDNA4_STATS: captures / replays); every result
+//            against the CPU backend, and input A eager == input A replayed, bit for bit
 //   split_harness <plugin.so> <type: q4_K|q4_0|q8_0|q5_K|q6_K|f16> <M> <K> <B>      -> one JSON line
 #include "ggml.h"
 #include "ggml-alloc.h"
@@ -52,6 +55,40 @@ static std::vector<float> run_mul_mat(ggml_backend_t backend, ggml_backend_buffe
     ggml_backend_tensor_get(Y, y.data(), 0, y.size() * sizeof(float));
     ggml_gallocr_free(ga); ggml_backend_buffer_free(wbuf); ggml_free(wctx); ggml_free(cctx);
     return y;
+}
+
+// one MLP block on `backend`: y = x + W2 . gelu(W1 . (norm(x) * g + s) + b1) + b2, computed for each of the inputs in turn on ONE graph
+static std::vector<std::vector<float>> run_block(ggml_backend_t backend, ggml_type type, int64_t D, int64_t H, int64_t B, const std::vector<uint8_t> & w1, const std::vector<uint8_t> & w2,
+                                                 const std::vector<float> & vec, const std::vector<std::vector<float>> & inputs) {
+    ggml_init_params ip = { ggml_tensor_overhead() * 32 + ggml_graph_overhead(), NULL, true };
+    ggml_context * wctx = ggml_init(ip), * cctx = ggml_init(ip);
+    ggml_tensor * W1 = ggml_new_tensor_2d(wctx, type, D, H), * W2 = ggml_new_tensor_2d(wctx, type, H, D);
+    ggml_tensor * g = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, D), * sft = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, D);
+    ggml_tensor * b1 = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, H), * b2 = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, D);
+    ggml_backend_buffer_t wbuf = ggml_backend_alloc_ctx_tensors(wctx, backend);
+    ggml_backend_tensor_set(W1, w1.data(), 0, w1.size()); ggml_backend_tensor_set(W2, w2.data(), 0, w2.size());
+    ggml_backend_tensor_set(g, vec.data(), 0, D * 4); ggml_backend_tensor_set(sft, vec.data() + D, 0, D * 4);
+    ggml_backend_tensor_set(b1, vec.data() + 2 * D, 0, H * 4); ggml_backend_tensor_set(b2, vec.data() + 2 * D + H, 0, D * 4);
+    ggml_tensor * X = ggml_new_tensor_2d(cctx, GGML_TYPE_F32, D, B);
+    ggml_set_input(X);
+    ggml_tensor * cur = ggml_add(cctx, ggml_mul(cctx, ggml_norm(cctx, X, 1e-5f), g), sft);
+    cur = ggml_gelu(cctx, ggml_add(cctx, ggml_mul_mat(cctx, W1, cur), b1));
+    cur = ggml_add(cctx, ggml_add(cctx, ggml_mul_mat(cctx, W2, cur), b2), X);
+    ggml_set_output(cur);
+    ggml_cgraph * gf = ggml_new_graph(cctx);
+    ggml_build_forward_expand(gf, cur);
+    ggml_gallocr_t ga = ggml_gallocr_new(ggml_backend_get_default_buffer_type(backend));
+    if (!ggml_gallocr_alloc_graph(ga, gf)) { fprintf(stderr, "graph allocation failed\n"); exit(1); }
+    std::vector<std::vector<float>> out;
+    for (const auto & x : inputs) {
+        ggml_backend_tensor_set(X, x.data(), 0, x.size() * sizeof(float));
+        if (ggml_backend_graph_compute(backend, gf) != GGML_STATUS_SUCCESS) { fprintf(stderr, "graph_compute failed\n"); exit(1); }
+        std::vector<float> y((size_t)D * B);
+        ggml_backend_tensor_get(cur, y.data(), 0, y.size() * sizeof(float));
+        out.push_back(y);
+    }
+    ggml_gallocr_free(ga); ggml_backend_buffer_free(wbuf); ggml_free(wctx); ggml_free(cctx);
+    return out;
 }
 
 int main(int argc, char ** argv) {
@@ -122,11 +159,30 @@ int main(int argc, char ** argv) {
             if (buf) { memset(ggml_backend_buffer_get_base(buf), 0x5a, 1 << 20); host_ok = ((uint8_t *)ggml_backend_buffer_get_base(buf))[12345] == 0x5a; ggml_backend_buffer_free(buf); }
         }
     }
+    // ---- replay: decode-sized (1 row: one-launch GEMV with the tail in its store) and prefill-sized (96 rows: MFMA GEMM + split-K exchange)
+    bool replay_ok = true; double replay_worst = 0;
+    if (ggml_is_quantized(type)) {
+        const int64_t D = 1024, H = 4096;
+        std::vector<float> f1((size_t)D * H), vec(3 * D + H);
+        for (auto & v : f1) v = u(rng) * 0.05f;
+        for (auto & v : vec) v = u(rng);
+        std::vector<uint8_t> w1(ggml_row_size(type, D) * H), w2(ggml_row_size(type, H) * D);
+        ggml_quantize_chunk(type, f1.data(), w1.data(), 0, H, D, NULL);
+        ggml_quantize_chunk(type, f1.data(), w2.data(), 0, D, H, NULL);
+        for (int64_t Bn : {(int64_t)1, (int64_t)96}) {
+            std::vector<std::vector<float>> in(6, std::vector<float>((size_t)D * Bn));
+            for (int i = 0; i < 6; i++) for (auto & v : in[i]) v = u(rng);
+            in[4] = in[0];                                                     // input A again, after the capture
+            const auto yg = run_block(gpu, type, D, H, Bn, w1, w2, vec, in), yc = run_block(cpu, type, D, H, Bn, w1, w2, vec, in);
+            for (int i = 0; i < 6; i++) { const double e = rel_l2(yg[i], yc[i]); if (e > replay_worst) replay_worst = e; if (!(e < 1e-2)) replay_ok = false; }      // (two chained quantized products and an fp16-table GELU: the CPU's own formats differ at 1e-3)
+            if (memcmp(yg[0].data(), yg[4].data(), yg[0].size() * 4) != 0) replay_ok = false;
+        }
+    }
     ggml_backend_dev_props props; ggml_backend_dev_get_props(dev, &props);
     printf("{\"type\":\"%s\",\"M\":%lld,\"K\":%lld,\"B\":%lld,\"split_vs_cpu_rel_l2\":%.3e,\"plain_vs_cpu_rel_l2\":%.3e,\"split_vs_plain_rel_l2\":%.3e,\"split_bit_identical_to_plain\":%s,"
-           "\"set_get_roundtrip\":%s,\"async_ok\":%s,\"host_buffer_ok\":%s,\"caps_async\":%s,\"caps_host_buffer\":%s,\"caps_events\":%s}\n",
+           "\"set_get_roundtrip\":%s,\"graph_replay_ok\":%s,\"graph_replay_worst_rel_l2\":%.3e,\"async_ok\":%s,\"host_buffer_ok\":%s,\"caps_async\":%s,\"caps_host_buffer\":%s,\"caps_events\":%s}\n",
            ggml_type_name(type), (long long)M, (long long)K, (long long)B, rel_l2(y_split, y_cpu), rel_l2(y_plain, y_cpu), rel_l2(y_split, y_plain), same_as_plain ? "true" : "false",
-           roundtrip ? "true" : "false", async_ok ? "true" : "false", host_ok ? "true" : "false", props.caps.async ? "true" : "false", props.caps.host_buffer ? "true" : "false", props.caps.events ? "true" : "false");
+           roundtrip ? "true" : "false", replay_ok ? "true" : "false", replay_worst, async_ok ? "true" : "false", host_ok ? "true" : "false", props.caps.async ? "true" : "false", props.caps.host_buffer ? "true" : "false", props.caps.events ? "true" : "false");
     ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
     return 0;
 }

@@ -21,12 +21,14 @@ def _run(type_, m, k, b, shards):
         pytest.fail("GPU tests need a GPU")
     if not os.path.exists(EXE):
         pytest.fail("prebuilt oracle/_ref/split_harness missing from the snapshot")
-    env = dict(os.environ)
+    env = dict(os.environ, GGML_CDNA4_STATS="1")
     if shards:
         env["GGML_CDNA4_SPLIT_SELF"] = str(shards)
     r = subprocess.run([EXE, PLUGIN, type_, str(m), str(k), str(b)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     j = json.loads(r.stdout.strip().splitlines()[-1])
+    import re
+    j["graph_captures_replays"] = [[int(a), int(b)] for a, b in re.findall(r"(\d+) HIP-graph captures, (\d+) replays", r.stderr)]
     os.makedirs(os.path.join(R.ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(R.ROOT, "gpurun_out", "split_report.jsonl"), "a") as f:
         f.write(json.dumps(dict(j, shards=shards)) + "\n")
@@ -42,3 +44,16 @@ def test_split_buffer_type_mul_mat(type_, m, k, b, shards):
     assert j["split_vs_plain_rel_l2"] < 2e-6 or b <= 8, j            # same kernels on row sub-ranges: at most a different K split
     assert j["async_ok"] is True and j["host_buffer_ok"] is True
     assert j["caps_async"] is True and j["caps_host_buffer"] is True and j["caps_events"] is True
+
+
+@pytest.mark.parametrize("type_", ["q4_K", "q4_0", "q6_K"])
+def test_unchanged_graph_is_replayed_from_a_hip_graph(type_):
+    """an MLP block (NORM, MUL, ADD, MUL_MAT, ADD, GELU, MUL_MAT, ADD, ADD) computed six times with changing inputs, for 1 and for 96
+    activation rows: the second appearance of the unchanged graph is captured (fused chains, the one-launch GEMV, the MFMA GEMM with its
+    split-K hand-off whose flags are reset by their readers), the remaining four are replays; every result matches the CPU backend and
+    input A replayed == input A computed eagerly, bit for bit.  VERDICT r1 item 6 (capture a split into a HIP graph)."""
+    j = _run(type_, 512, 512, 16, 0)
+    assert j["graph_replay_ok"] is True, j
+    assert j["graph_replay_worst_rel_l2"] < 1e-2
+    caps = j["graph_captures_replays"]
+    assert any(c >= 2 and r >= 10 for c, r in caps), caps            # 2 captures (1 row, 96 rows) + 2 x 5 launches of the captured graphs on the first backend
