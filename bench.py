@@ -397,8 +397,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the metric, its roofline, the library ceiling and the CPU baseline")
     ap.add_argument("--no-diagnostics", action="store_true", help="(accepted for compatibility; same as --no-extras)")
+    ap.add_argument("--lean", action="store_true", help="profiling runs (scripts/gpu_full.sh): the timed loop and the kernel-only loop, nothing else — every launch of the "
+                                                        "dominant kernel in the trace is a headline launch on the prescribed data")
     args = ap.parse_args()
-    extras = not (args.no_extras or args.no_diagnostics)
+    extras = not (args.no_extras or args.no_diagnostics or args.lean)
+    if args.lean:
+        args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -463,6 +467,8 @@ def main():
         # is what the chip's power management takes (a diagnostic beside the roofline fraction, not a result)
         zero_us = None
         try:
+            if args.lean:
+                raise RuntimeError("lean")
             hz = Hot(dev, Q4_K, np.zeros_like(w), M, K, np.zeros_like(x), args.variant, args.splitk)
             hz.ws.zero_()
             zero_us = round(events_us(hz.gemm_only, 40, 10), 3)
@@ -482,7 +488,7 @@ def main():
                          "traffic_note": "HBM-side bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) from the rocprofv3 PMC passes of this command, profiles/rNN/pmc_summary.txt",
                          "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": h.flops, "us_per_launch_all_zero_operands": zero_us},
         }
-        if world == 1:
+        if world == 1 and not args.lean:
             out["roofline"]["library_ceiling"] = library_ceiling(dev, M, K, B, args.steps)
             lc = out["roofline"]["library_ceiling"]
             if "tflops" in lc:

@@ -433,11 +433,10 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         char *sc = (char *)get_scratch(fbytes + pbytes);
         if (!sc) return cdna4_set_error_msg("gemm_q: cannot allocate split-K scratch");
         p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
-        // ks=0 share of K in 1/16ths.  The exchange is symmetric (each work-group exports half of its partial tile and
-        // finishes the other half), so the even split is the default; CDNA4_SPLIT_NUM overrides it for experiments.
-        static const int num = getenv("CDNA4_SPLIT_NUM") ? atoi(getenv("CDNA4_SPLIT_NUM")) : 8;
+        // the exchange is symmetric (each work-group exports half of its partial tile and finishes the other half): even split,
+        // the odd superblock to ks = 0
         const int total = a.K / 256;
-        int split = (total * num + 8) / 16;
+        int split = (total + 1) / 2;
         p.sb_split = split < 1 ? 1 : (split > total - 1 ? total - 1 : split);
     } else if (splitk > 1) {
         const int64_t n = (int64_t)a.M * a.B;
@@ -446,14 +445,10 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     p.trace = (unsigned long long *)cdna4_debug_trace;
     {   // both work-groups of a tile share an XCD iff the XCD-aware remap is active (grid % 8 == 0) and each XCD's slice of the
         // tile order holds whole (tile_b x ks) groups; work-groups go to XCDs round-robin by blockIdx (the kernel verifies it)
-        static const bool l2_env = getenv("CDNA4_XCHG_L2") ? atoi(getenv("CDNA4_XCHG_L2")) != 0 : true;
         const int nb = p.tiles_m * p.tiles_b * splitk;
-        p.xchg_l2 = (l2_env && p.partial && (nb & 7) == 0 && ((nb >> 3) % (p.tiles_b * 2)) == 0) ? 1 : 0;
+        p.xchg_l2 = (p.partial && (nb & 7) == 0 && ((nb >> 3) % (p.tiles_b * 2)) == 0) ? 1 : 0;
     }
-    // bit0: static s_setprio 1 for the later-dispatched khalf-1 waves of k_gemm_kq_w8p (no measurable effect under the
-    // warm-up + round-robin protocol of tools/microbench/gemm_bench: 26.31 vs 26.33 us; off by default)
-    static const int tune_env = getenv("CDNA4_TUNE") ? atoi(getenv("CDNA4_TUNE")) : 0;
-    p.tune = tune_env;
+    p.tune = 0;      // (bit0 = s_setprio 1 for the later-dispatched khalf-1 waves of k_gemm_kq_w8p: measured 26.31 vs 26.33 us, never enabled)
     const dim3 grid(p.tiles_m * p.tiles_b * splitk);
 #define W8_LAUNCH(O) do { if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, true, O>), grid, dim3(512), 0, st, p); \
                           else hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, false, O>), grid, dim3(512), 0, st, p); } while (0)
@@ -463,11 +458,9 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         if ((opt == 64 || opt == 65) && min_nsb < 3) opt = 20;
     }
     if (opt == 65) {                                                      // + loader waves
-        static const bool no_tab = getenv("CDNA4_NO_TAB") != nullptr;       // A/B knob: compute waves unpack the scales themselves
-        // experiment bits of k_gemm_kq_w12 (variant bits 16+ or CDNA4_W12_EXP), built in -DCDNA4_ABLATIONS libraries
+        constexpr bool no_tab = false;                                      // (true: the compute waves unpack the scales themselves; slower)
+        // experiment bits of k_gemm_kq_w12 (variant bits 16+), built in -DCDNA4_ABLATIONS libraries
         // (tools/microbench) only: 1 = early table read (bit-identical, measured: no gain), 16.. = timing-only ablations
-        static const int exp_env = getenv("CDNA4_W12_EXP") ? atoi(getenv("CDNA4_W12_EXP")) : 0;
-        if (exp == 0) exp = exp_env;
         if constexpr (TYPE == CDNA4_Q4_K) {
 #define W12_EXP(E) case E: hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, E>), grid, dim3(768), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0;
             if (exp != 0 && !no_tab) switch (exp) {
@@ -540,9 +533,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         // call: one extra read+write of W, ~5 us at 4096x4096) and run the LDS-DMA pipeline on that — 2.5-3x faster
         // than the per-lane-load kernel below, which stays for small batches and K % 256 != 0.
         constexpr int RT = TYPE == CDNA4_Q4_0 ? CDNA4_Q4_0R : (TYPE == CDNA4_Q8_0 ? CDNA4_Q8_0R : CDNA4_Q6_KR);
-        static const bool no_repack = getenv("CDNA4_NO_REPACK") != nullptr;
-        static const bool no_staged = getenv("CDNA4_NO_STAGED") != nullptr;
-        if (a.variant <= 0 && a.B > 64 && a.K % 256 == 0 && !no_repack && !no_staged) {
+        if (a.variant <= 0 && a.B > 64 && a.K % 256 == 0) {
             // preferred: no copy at all — the loader waves of k_gemm_kq_w12 read the original blocks and re-lay them while
             // staging (needs >= 3 superblocks of K per work-group, like the cross-stage pipeline itself)
             constexpr int ST_ = TYPE == CDNA4_Q4_0 ? CDNA4_Q4_0S : (TYPE == CDNA4_Q8_0 ? CDNA4_Q8_0S : CDNA4_Q6_KS);
@@ -551,7 +542,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
             if (sk <= 0) sk = (tiles * 2 <= cu_count() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
             if (sk >= 1 && nsb % sk == 0 && nsb / sk >= 3) return launch_w8<ST_>(a, sk, 65, st);
         }
-        if (a.variant <= 0 && a.B > 64 && a.K % 256 == 0 && !no_repack) {
+        if (a.variant <= 0 && a.B > 64 && a.K % 256 == 0) {
             const int nsb = a.K / 256;
             const size_t rbytes = (size_t)a.M * nsb * QT<RT>::BYTES;
             uint8_t *rw = (uint8_t *)get_scratch(rbytes + 256, 1);

@@ -365,11 +365,9 @@ __global__ __launch_bounds__(256) void k_gemv_q(const cdna4_gemv_args a) {
 
 template <int TYPE, int NB>
 static void launch_nb(const cdna4_gemv_args &a, hipStream_t st) {
-    // one row per wave.  (4 rows per wave — fewer, fatter waves sharing the activation loads — measured SLOWER on
-    // MI355X: 6.7 vs 5.3 us cold at 4096x4096; CDNA4_GEMV_ROWS=2 selects the 2-row variant for experiments.)
-    static const int rows_env = getenv("CDNA4_GEMV_ROWS") ? atoi(getenv("CDNA4_GEMV_ROWS")) : 1;
-    if (rows_env == 2 && NB <= 2) hipLaunchKernelGGL((k_gemv_q<TYPE, NB, false, 2>), dim3((a.M + 7) / 8, 1), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_gemv_q<TYPE, NB, false, 1>), dim3((a.M + 3) / 4, 1), dim3(256), 0, st, a);
+    // one row per wave.  (2 and 4 rows per wave — fewer, fatter waves sharing the activation loads — measured SLOWER on
+    // MI355X: 6.7 vs 5.3 us cold at 4096x4096.)
+    hipLaunchKernelGGL((k_gemv_q<TYPE, NB, false, 1>), dim3((a.M + 3) / 4, 1), dim3(256), 0, st, a);
 }
 template <int TYPE>
 static int launch_type(const cdna4_gemv_args &a0, hipStream_t st) {
@@ -512,8 +510,7 @@ size_t cdna4_gemv_fused_lds_bytes(int type, int64_t K) {
     return (size_t)(K + (kq ? K / 8 + (K / 256) * 4 : (K / 32) * 4));
 }
 bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B) {
-    static const bool off = getenv("CDNA4_NO_FUSE") != nullptr;
-    return !off && B == 1 && K > 0 && cdna4_gemv_fused_lds_bytes(type, K) <= 64 * 1024;
+    return B == 1 && K > 0 && cdna4_gemv_fused_lds_bytes(type, K) <= 64 * 1024;
 }
 template <int TYPE>
 static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st) {

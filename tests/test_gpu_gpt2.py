@@ -112,6 +112,37 @@ def test_gpt2_graph_peepholes_change_no_bit_and_cut_the_launches(model):
     assert tf["decode_ms_per_token"] <= 1.0, tf
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_gpt2_logits_against_an_fp64_forward(tmp_path, seed):
+    """the logits of BOTH backends against an fp64 forward pass of the same graph on the dequantized weights
+    (tests/gpt2_exact.py), three weight seeds, embedding std 0.08 (logits of std ~2: a spread like a trained model's, so that argmax and
+    relative error mean something).  The plug-in must be as close to the exact result as the reference CPU backend is (which rounds
+    activations to Q8_0 and GELU through an fp16 table): rel-L2(GPU, exact) <= 1.25 x rel-L2(CPU, exact) + 1e-3 at every step."""
+    import gpt2_exact as GX
+    for f in ("gpt-2-quantize", "gpt2_harness"):
+        if not os.path.exists(os.path.join(REF, f)):
+            pytest.fail("prebuilt oracle/_ref/%s missing from the snapshot" % f)
+    f32, q4 = str(tmp_path / "f32.bin"), str(tmp_path / "q4_0.bin")
+    subprocess.run([sys.executable, os.path.join(R.ROOT, "tools", "make_synth_gpt2.py"), f32, "--seed", str(seed), "--wte-std", "0.08"], check=True, timeout=600)
+    subprocess.run([os.path.join(REF, "gpt-2-quantize"), f32, q4, "q4_0"], check=True, timeout=600, capture_output=True)
+    os.remove(f32)
+    n_prompt, n_decode = 24, 3
+    tc, lc = _run(q4, "CPU", str(tmp_path / "cpu.bin"), n_prompt, n_decode)
+    tg, lg = _run(q4, "CDNA40", str(tmp_path / "gpu.bin"), n_prompt, n_decode)
+    hp, T = GX.load_model(q4)
+    toks = GX.harness_tokens(hp["n_vocab"], n_prompt + n_decode)
+    rows = []
+    for i in range(1 + n_decode):
+        ex = GX.forward(hp, T, toks[:n_prompt + i])
+        rows.append({"step": i, "gpu_vs_exact": R.rel_l2(lg[i], ex), "cpu_vs_exact": R.rel_l2(lc[i], ex), "gpu_vs_cpu": R.rel_l2(lg[i], lc[i]),
+                     "logit_std": float(ex.std()), "argmax": [int(np.argmax(ex)), int(np.argmax(lg[i])), int(np.argmax(lc[i]))]})
+    with open(os.path.join(R.ROOT, "gpurun_out", "gpt2_parity.jsonl"), "a") as f:
+        f.write(json.dumps({"mode": "fp64_exact", "seed": seed, "wte_std": 0.08, "n_prompt": n_prompt, "steps": rows}) + "\n")
+    for r in rows:
+        assert r["logit_std"] > 0.5
+        assert r["gpu_vs_exact"] <= 1.25 * r["cpu_vs_exact"] + 1e-3, rows
+
+
 # ------------------------------------------------------------------------------------------------ ggml_backend_sched
 def _sched(model_path, ngl, out, n_prompt, n_decode, parallel=0):
     r = subprocess.run([os.path.join(REF, "sched_harness"), model_path, str(ngl), PLUGIN, out, str(n_prompt), str(n_decode), "16", str(parallel)],

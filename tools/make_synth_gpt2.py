@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--n-ctx", type=int, default=1024)
     ap.add_argument("--n-embd", type=int, default=768)
     ap.add_argument("--n-head", type=int, default=12)
+    ap.add_argument("--wte-std", type=float, default=0.02, help="std of the (tied) embedding / output matrix: 0.08 gives logits of std ~2, a spread like a trained model's")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     E = a.n_embd
@@ -47,7 +48,7 @@ def main():
         def vec(n, mean=0.0, std=0.02):
             return (mean + rng.standard_normal(n) * std).astype(np.float32)
 
-        tensor("model/wte", mat(a.n_vocab, E))
+        tensor("model/wte", mat(a.n_vocab, E, a.wte_std))
         tensor("model/wpe", mat(a.n_ctx, E, 0.01))
         for l in range(a.layers):
             p = "model/h%d/" % l

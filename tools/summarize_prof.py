@@ -19,7 +19,7 @@ if os.path.exists(stats):
     shutil.copy(stats, os.path.join(dst, "rocprofv3_kernel_stats.csv"))
 
 lines = []
-for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+for d in sorted(d_ for d_ in glob.glob(os.path.join(src, "pmc_*")) if os.path.isdir(d_)):
     f = os.path.join(d, "p_counter_collection.csv")
     if not os.path.exists(f):
         continue
@@ -29,7 +29,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for r in csv.DictReader(open(os.path.join(d, "p_kernel_trace.csv"))):
         dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    lines.append("## pass: rocprofv3 --kernel-trace --pmc %s -- python bench.py --steps 30 --warmup 3 --no-cpu-baseline" % os.path.basename(d)[4:].replace("+", " "))
+    lines.append("## pass: rocprofv3 --kernel-trace --pmc %s -- python bench.py --steps 100 --warmup 10 --lean" % os.path.basename(d)[4:].replace("+", " "))
     for k, cs in agg.items():
         if not any(x in k for x in KEYS):
             continue
@@ -44,7 +44,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     lines.append("")
 open(os.path.join(dst, "pmc_summary.txt"), "w").write("\n".join(lines))
 
-for name in ("bench.log", "gemm_bench.txt", "l2_stream.csv", "gpt2_parity.jsonl", "summary.txt", "nproc.txt", "rocminfo.txt"):
+for name in ("bench.log", "gemm_bench.txt", "l2_stream.csv", "gpt2_parity.jsonl", "summary.txt", "nproc.txt", "rocminfo.txt", "t64_ablations.txt", "mfma_valu_probe.txt", "pmc_gemm_bench_sq.txt", "split_report.jsonl"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, name))
