@@ -299,13 +299,19 @@ def stock_perf_lines(timeout=150):
     plugin = os.path.join(ROOT, "ggml_amd", "lib", "libggml-cdna4.so")
     if not (os.path.exists(exe) and os.path.exists(plugin)):
         return {"error": "oracle/_ref/test-backend-ops or the plug-in is not in the snapshot"}
-    try:
-        r = subprocess.run([exe, "perf", "-o", "MUL_MAT", "-b", "CDNA40"], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, GGML_BACKEND_PATH=plugin))
-        txt = r.stdout
-    except subprocess.TimeoutExpired as e:
-        txt = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
-    lines = [ln.strip() for ln in txt.splitlines() if "type_a=q4_K" in ln and "not supported" not in ln]
-    return {"command": "GGML_BACKEND_PATH=libggml-cdna4.so test-backend-ops perf -o MUL_MAT -b CDNA40", "q4_K": lines[:8]}
+    def run(backend, tmo, env):
+        try:
+            r = subprocess.run([exe, "perf", "-o", "MUL_MAT", "-b", backend], capture_output=True, text=True, timeout=tmo, env=env)
+            txt = r.stdout
+        except subprocess.TimeoutExpired as e:
+            txt = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        return [ln.strip() for ln in txt.splitlines() if "type_a=q4_K" in ln and "not supported" not in ln][:8]
+    out = {"command": "GGML_BACKEND_PATH=libggml-cdna4.so test-backend-ops perf -o MUL_MAT -b CDNA40 | -b CPU  (unmodified binary; its q4_K lines, m = 4096, k = 14336)",
+           "q4_K": run("CDNA40", timeout, dict(os.environ, GGML_BACKEND_PATH=plugin))}
+    # the same harness on the reference CPU backend of this box (all host cores, the harness's default): as many q4_K lines as fit the budget
+    cpu_budget = int(max(0, min(90, time_left(420))))
+    out["q4_K_cpu_backend"] = run("CPU", cpu_budget, dict(os.environ)) if cpu_budget >= 20 else "skipped: time budget"
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ multi-GPU legs

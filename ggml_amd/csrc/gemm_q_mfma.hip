@@ -450,20 +450,24 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     }
     p.tune = 0;      // (bit0 = s_setprio 1 for the later-dispatched khalf-1 waves of k_gemm_kq_w8p: measured 26.31 vs 26.33 us, never enabled)
     const dim3 grid(p.tiles_m * p.tiles_b * splitk);
+    // (the s_memtime trace instantiations <.., TRACE = true> exist in the -DCDNA4_ABLATIONS library of tools/microbench only)
+#ifdef CDNA4_ABLATIONS
 #define W8_LAUNCH(O) do { if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, true, O>), grid, dim3(512), 0, st, p); \
                           else hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, false, O>), grid, dim3(512), 0, st, p); } while (0)
+#else
+#define W8_LAUNCH(O) hipLaunchKernelGGL((k_gemm_kq_w8<TYPE, false, O>), grid, dim3(512), 0, st, p)
+#endif
     {   // the cross-stage pipeline is written for K ranges of >= 3 superblocks per work-group; shallower ones take schedule 20
         const int total = a.K / 256;
         const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
         if ((opt == 64 || opt == 65) && min_nsb < 3) opt = 20;
     }
     if (opt == 65) {                                                      // + loader waves
-        constexpr bool no_tab = false;                                      // (true: the compute waves unpack the scales themselves; slower)
         // experiment bits of k_gemm_kq_w12 (variant bits 16+), built in -DCDNA4_ABLATIONS libraries
         // (tools/microbench) only: 1 = early table read (bit-identical, measured: no gain), 16.. = timing-only ablations
         if constexpr (TYPE == CDNA4_Q4_K) {
 #define W12_EXP(E) case E: hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true, E>), grid, dim3(768), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0;
-            if (exp != 0 && !no_tab) switch (exp) {
+            if (exp != 0) switch (exp) {
 #ifdef CDNA4_ABLATIONS
                 W12_EXP(1) W12_EXP(2) W12_EXP(4) W12_EXP(6) W12_EXP(16) W12_EXP(32) W12_EXP(64) W12_EXP(128) W12_EXP(256) W12_EXP(96) W12_EXP(224) W12_EXP(480) W12_EXP(288) W12_EXP(512) W12_EXP(544) W12_EXP(992)
 #endif
@@ -471,19 +475,20 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
             }
 #undef W12_EXP
         }
-        if (TYPE == CDNA4_Q4_K && no_tab) hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, false>), grid, dim3(768), 0, st, p);
-        else hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true>), grid, dim3(768), 0, st, p);
+        hipLaunchKernelGGL((k_gemm_kq_w12<TYPE, true>), grid, dim3(768), 0, st, p);
         CDNA4_CHECK_LAUNCH(); return 0;
     }
     if constexpr (TYPE >= 200) return cdna4_set_error_msg("gemm_q: staged formats run on the loader-wave kernel only");
     if (opt == 64) {                                                      // cross-stage pipeline
-        if (p.trace) hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE, true>), grid, dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE, false>), grid, dim3(512), 0, st, p);
+#ifdef CDNA4_ABLATIONS
+        if (p.trace) { hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE, true>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
+#endif
+        hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE, false>), grid, dim3(512), 0, st, p);
         CDNA4_CHECK_LAUNCH(); return 0;
     }
     else if constexpr (TYPE >= 100) { W8_LAUNCH(20); CDNA4_CHECK_LAUNCH(); return 0; }   // repacked formats: the default schedule only
-    else switch (opt & 31) { case 0: W8_LAUNCH(0); break; case 12: W8_LAUNCH(12); break; case 20: W8_LAUNCH(20); break;
-                        default: return cdna4_set_error_msg("gemm_q: unknown 8-wave schedule option (0, 12 and 20 are built)"); }
+    else if ((opt & 31) == 20) W8_LAUNCH(20);                             // the in-wave pipeline with the DMA pieces split over both phases (shallow-K fallback)
+    else return cdna4_set_error_msg("gemm_q: of the 8-wave in-wave schedules only option 20 is built (variant 663)");
 #undef W8_LAUNCH
     CDNA4_CHECK_LAUNCH();
     return 0;

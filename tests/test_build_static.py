@@ -221,7 +221,9 @@ def test_asynchronous_register_loads_are_not_read_before_their_wait(gemm_asm):
     """k_gemm_kq_w12's loader waves load superblock headers into registers with inline asm and wait for them later with a
     vmcnt wait tied to those registers.  Nothing stops the compiler from copying the registers in between (it did, in a first
     cut of the experimental kernel); the shipped binary must be free of such reads"""
-    for k in ("_Z13k_gemm_kq_w12ILi12ELb1ELi0EEv11gemm_params", "_Z13k_gemm_kq_w12ILi12ELb0ELi0EEv11gemm_params"):
+    ks = re.findall(r"^(_Z13k_gemm_kq_w12ILi\d+ELb1ELi0EEv11gemm_params):", gemm_asm, re.M)
+    assert len(ks) >= 4, ks                                    # Q4_K and the three staged forms (Q4_0, Q8_0, Q6_K re-laid by the loader waves)
+    for k in ks:
         n, bad = _reads_before_wait(gemm_asm, k)
         assert n > 0 and not bad, (k, bad[:3])
 

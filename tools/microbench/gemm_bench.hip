@@ -26,7 +26,7 @@ int main(int argc, char **argv) {
     struct cfg { int variant, splitk, ablate; };
     std::vector<cfg> cfgs;
     // GB_VARIANTS="23,55,151" overrides the variant list (see launch_type() in gemm_q_mfma.hip for the bits)
-    std::vector<int> vars = {0, 5, 23};
+    std::vector<int> vars = {0, 5, 663};
     if (const char *e = getenv("GB_VARIANTS")) { vars.clear(); for (const char *q = e; *q;) { vars.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; } }
     std::vector<int> sks = {1, 2};
     if (const char *e = getenv("GB_SPLITKS")) { sks.clear(); for (const char *q = e; *q;) { sks.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; } }
@@ -57,7 +57,7 @@ int main(int argc, char **argv) {
     }
     // per-phase timeline of the 8-wave kernel's first work-group (stages 4..19), from s_memtime stamps; argv[4] = "23,55,.."
     unsigned long long *dtr; hipMalloc(&dtr, 65536);
-    std::vector<int> tv; for (const char *q = argc > 4 ? argv[4] : "23"; *q;) { tv.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; }
+    std::vector<int> tv; for (const char *q = argc > 4 ? argv[4] : ""; *q;) { tv.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; }
     for (int v : tv) {
         hipMemset(dtr, 0, 65536);
         ggml_cdna4_debug_trace(dtr);
