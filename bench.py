@@ -292,6 +292,38 @@ def format_rows(dev, steps):
     return rows
 
 
+def moe_row(dev, steps):
+    """MUL_MAT_ID at prefill size: 8 experts x 2 used x 512 tokens, Q4_K experts of 4096 x 4096 — the device-side
+    grouping (counting sort of the ids, no host sync) + gather-quantize + ONE grouped GEMM launch; effective flops = 2 M K per
+    (token, slot) pair.  Decode (1 token) beside it: one launch."""
+    from ggml_amd import native, ops
+    L = native.lib()
+    n_expert, n_used, n_tok, m, k = 8, 2, 512, 4096, 4096
+    w, _, how = prescribed(Q4_K, n_expert * m, k, 0, n_expert * m, 1)
+    a = ops.QTensor.from_host_bytes(Q4_K, k, n_expert * m, w, device=dev)
+    rng = np.random.default_rng(7)
+    out = {"shape": {"n_expert": n_expert, "n_used": n_used, "M": m, "K": k}, "data": how}
+    for nt in (n_tok, 1):
+        xb = torch.from_numpy(rng.uniform(-1, 1, (nt, n_used, k)).astype(np.float32)).to(dev)
+        ids = torch.from_numpy(np.stack([rng.permutation(n_expert)[:n_used] for _ in range(nt)]).astype(np.int32)).to(dev)
+        y = torch.empty((nt, n_used, m), dtype=torch.float32, device=dev)
+        ws = torch.empty(L.ggml_cdna4_mul_mat_id_workspace_size(Q4_K, k, n_expert, n_used, n_used, nt), dtype=torch.uint8, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+
+        def call():
+            native.check(L.ggml_cdna4_mul_mat_id(Q4_K, a.data.data_ptr(), a.row_bytes, m * a.row_bytes, xb.data_ptr(), k, n_used * k, ids.data_ptr(), n_used,
+                                                 y.data_ptr(), m, n_used * m, m, k, n_expert, n_used, n_used, nt, ws.data_ptr(), ws.numel(), st))
+        us = events_us(call, max(20, steps // 2), 5)
+        fl = 2.0 * m * k * nt * n_used
+        if nt > 1:
+            out["prefill_512_tokens"] = {"us_per_call": round(us, 2), "effective_tflops": round(fl / us / 1e6, 1), "frac_of_mfma_roof": round(fl / us / 1e6 / MFMA_F16_PEAK_TFLOPS, 4),
+                                         "launches": "plan + gather-quantize + one grouped k_gemm_kq_t64<Q4_K, 128, IDS>", "padded_rows": "each expert's run rounded up to 128 image rows"}
+        else:
+            wbytes = n_used * m * (k // 256) * 144
+            out["decode_1_token"] = {"us_per_call": round(us, 2), "GBps": round(wbytes / us / 1e3, 1), "frac_of_hbm_roof": round(wbytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches": "one (k_gemv_q_fused<.., IDS>)"}
+    return out
+
+
 def stock_perf_lines(timeout=150):
     """the reference's own perf harness on the plug-in: `test-backend-ops perf -o MUL_MAT -b CDNA40` (unmodified binary, plug-in loaded
     through GGML_BACKEND_PATH) — its q4_K lines at m = 4096, k = 14336 (tests/test-backend-ops.cpp:4340-4346)"""
@@ -310,7 +342,7 @@ def stock_perf_lines(timeout=150):
            "q4_K": run("CDNA40", timeout, dict(os.environ, GGML_BACKEND_PATH=plugin))}
     # the same harness on the reference CPU backend of this box (all host cores, the harness's default): as many q4_K lines as fit the budget
     cpu_budget = int(max(0, min(90, time_left(420))))
-    out["q4_K_cpu_backend"] = run("CPU", cpu_budget, dict(os.environ)) if cpu_budget >= 20 else "skipped: time budget"
+    out["q4_K_cpu_backend"] = (run("CPU", cpu_budget, dict(os.environ)) or "no q4_K line finished within %d s (the harness runs every type at every n, all host cores)" % cpu_budget) if cpu_budget >= 20 else "skipped: time budget"
     return out
 
 
@@ -513,6 +545,7 @@ def main():
             legs = (("decode", lambda: decode_rows(dev, steps), 150),
                     ("shapes", lambda: {"c3_4096x11008x512": shape_row(dev, Q4_K, 4096, 11008, 512, steps), "c5_32768x8192x512_one_gpu": shape_row(dev, Q4_K, 32768, 8192, 512, max(20, steps // 4))}, 200),
                     ("formats", lambda: format_rows(dev, steps), 230),
+                    ("mul_mat_id", lambda: moe_row(dev, steps), 245),
                     ("stock_test_backend_ops_perf", lambda: stock_perf_lines(int(max(30, min(150, time_left(400))))), 260))
             run_legs(legs, out)
     if rank == 0:
