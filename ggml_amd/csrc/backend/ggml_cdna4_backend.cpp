@@ -385,7 +385,9 @@ static enum ggml_status cdna4_backend_graph_compute(ggml_backend_t backend, ggml
     static const bool no_graphs = getenv("GGML_CDNA4_NO_GRAPHS") != nullptr;
     if (no_graphs || ctx->graphs_off || ggml_graph_n_nodes(cgraph) < 2) return run_nodes(ctx, cgraph);
     const uint64_t sig = graph_signature(cgraph);
-    if (sig == ctx->graph_exec_sig && ctx->graph_exec) {
+    // addresses the captured launches hold beyond the tensors': this context's workspace and the kernel library's scratch
+    const uint64_t gen = ggml_cdna4_scratch_generation() * 0x9E3779B97F4A7C15ull + ctx->ws_gen;
+    if (sig == ctx->graph_exec_sig && ctx->graph_exec && gen == ctx->graph_exec_gen) {
         HIP_OK(hipGraphLaunch(ctx->graph_exec, ctx->stream));
         ctx->n_graph_launches++;
         return GGML_STATUS_SUCCESS;
@@ -408,6 +410,7 @@ static enum ggml_status cdna4_backend_graph_compute(ggml_backend_t backend, ggml
     }
     (void)hipGraphDestroy(graph);
     ctx->graph_exec_sig = sig; ctx->n_graph_captures++;
+    ctx->graph_exec_gen = ggml_cdna4_scratch_generation() * 0x9E3779B97F4A7C15ull + ctx->ws_gen;     // (the eager first run sized everything: unchanged by the capture)
     HIP_OK(hipGraphLaunch(ctx->graph_exec, ctx->stream));
     ctx->n_graph_launches++;
     return GGML_STATUS_SUCCESS;

@@ -33,11 +33,14 @@ struct cdna4_backend_ctx {
     // HIP-graph replay of a compute graph that comes back unchanged (ggml_cdna4_backend.cpp: graph_compute)
     uint64_t graph_sig = 0; int graph_sig_repeats = 0;        // signature of the last graph_compute call, how often in a row it was seen
     hipGraphExec_t graph_exec = nullptr; uint64_t graph_exec_sig = 0;
+    uint64_t graph_exec_gen = 0;                              // library-scratch generation + this context's workspace generation at capture time
+    uint64_t ws_gen = 0;
     bool graphs_off = false;                                  // a capture failed once: stay on plain launches
     int n_graph_launches = 0, n_graph_captures = 0;           // (statistics, printed at free under GGML_CDNA4_STATS)
     void * need_ws(size_t n) {
         if (n <= ws_size) return ws;
         HIP_OK(hipStreamSynchronize(stream));
+        ws_gen++;                                             // a captured graph holds the old workspace address
         if (ws) HIP_OK(hipFree(ws));
         ws_size = (n + (8u << 20)) & ~(size_t)((1u << 20) - 1);
         if (hipMalloc(&ws, ws_size) != hipSuccess) { (void)hipGetLastError(); ws = nullptr; ws_size = 0; }

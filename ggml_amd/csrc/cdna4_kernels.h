@@ -60,3 +60,4 @@ int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expe
 bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B);
 
 extern void *cdna4_debug_trace;
+uint64_t cdna4_scratch_generation();            // gemm_q_mfma.hip: bumped whenever the library (re)allocates device scratch

@@ -53,6 +53,10 @@ int          ggml_cdna4_set_device(int device);
 /* profiling hook (tools/microbench/gemm_bench only): a 64 KiB device buffer makes the 8-wave GEMM record per-phase
  * s_memtime stamps of its first work-group; NULL (default) selects the uninstrumented kernel */
 void         ggml_cdna4_debug_trace(void * device_buffer);
+/* Library scratch (split-K exchange areas, re-laid weights) is allocated lazily per device and grown on demand; a launch captured into
+ * a HIP graph holds the address it was given.  This counter changes whenever any such allocation is made or moved: a host that replays
+ * captured launches compares it with the value at capture time and re-captures on a mismatch (the plug-in does). */
+uint64_t     ggml_cdna4_scratch_generation(void);
 
 size_t ggml_cdna4_row_size(int type, int64_t k);          /* bytes of one row of k weights; 0 if unsupported */
 

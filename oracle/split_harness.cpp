@@ -57,39 +57,41 @@ static std::vector<float> run_mul_mat(ggml_backend_t backend, ggml_backend_buffe
     return y;
 }
 
-// one MLP block on `backend`: y = x + W2 . gelu(W1 . (norm(x) * g + s) + b1) + b2, computed for each of the inputs in turn on ONE graph
-static std::vector<std::vector<float>> run_block(ggml_backend_t backend, ggml_type type, int64_t D, int64_t H, int64_t B, const std::vector<uint8_t> & w1, const std::vector<uint8_t> & w2,
-                                                 const std::vector<float> & vec, const std::vector<std::vector<float>> & inputs) {
-    ggml_init_params ip = { ggml_tensor_overhead() * 32 + ggml_graph_overhead(), NULL, true };
-    ggml_context * wctx = ggml_init(ip), * cctx = ggml_init(ip);
-    ggml_tensor * W1 = ggml_new_tensor_2d(wctx, type, D, H), * W2 = ggml_new_tensor_2d(wctx, type, H, D);
-    ggml_tensor * g = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, D), * sft = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, D);
-    ggml_tensor * b1 = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, H), * b2 = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, D);
-    ggml_backend_buffer_t wbuf = ggml_backend_alloc_ctx_tensors(wctx, backend);
-    ggml_backend_tensor_set(W1, w1.data(), 0, w1.size()); ggml_backend_tensor_set(W2, w2.data(), 0, w2.size());
-    ggml_backend_tensor_set(g, vec.data(), 0, D * 4); ggml_backend_tensor_set(sft, vec.data() + D, 0, D * 4);
-    ggml_backend_tensor_set(b1, vec.data() + 2 * D, 0, H * 4); ggml_backend_tensor_set(b2, vec.data() + 2 * D + H, 0, D * 4);
-    ggml_tensor * X = ggml_new_tensor_2d(cctx, GGML_TYPE_F32, D, B);
-    ggml_set_input(X);
-    ggml_tensor * cur = ggml_add(cctx, ggml_mul(cctx, ggml_norm(cctx, X, 1e-5f), g), sft);
-    cur = ggml_gelu(cctx, ggml_add(cctx, ggml_mul_mat(cctx, W1, cur), b1));
-    cur = ggml_add(cctx, ggml_add(cctx, ggml_mul_mat(cctx, W2, cur), b2), X);
-    ggml_set_output(cur);
-    ggml_cgraph * gf = ggml_new_graph(cctx);
-    ggml_build_forward_expand(gf, cur);
-    ggml_gallocr_t ga = ggml_gallocr_new(ggml_backend_get_default_buffer_type(backend));
-    if (!ggml_gallocr_alloc_graph(ga, gf)) { fprintf(stderr, "graph allocation failed\n"); exit(1); }
-    std::vector<std::vector<float>> out;
-    for (const auto & x : inputs) {
+// one MLP block on `backend`: y = x + W2 . gelu(W1 . (norm(x) * g + s) + b1) + b2, on ONE graph that is computed again and again
+struct mlp_block {
+    ggml_backend_t backend; int64_t D, B;
+    ggml_context * wctx, * cctx; ggml_backend_buffer_t wbuf; ggml_gallocr_t ga; ggml_cgraph * gf; ggml_tensor * X, * out;
+    mlp_block(ggml_backend_t be, ggml_type type, int64_t D_, int64_t H, int64_t B_, const std::vector<uint8_t> & w1, const std::vector<uint8_t> & w2, const std::vector<float> & vec)
+        : backend(be), D(D_), B(B_) {
+        ggml_init_params ip = { ggml_tensor_overhead() * 32 + ggml_graph_overhead(), NULL, true };
+        wctx = ggml_init(ip); cctx = ggml_init(ip);
+        ggml_tensor * W1 = ggml_new_tensor_2d(wctx, type, D, H), * W2 = ggml_new_tensor_2d(wctx, type, H, D);
+        ggml_tensor * g = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, D), * sft = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, D);
+        ggml_tensor * b1 = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, H), * b2 = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, D);
+        wbuf = ggml_backend_alloc_ctx_tensors(wctx, backend);
+        ggml_backend_tensor_set(W1, w1.data(), 0, w1.size()); ggml_backend_tensor_set(W2, w2.data(), 0, w2.size());
+        ggml_backend_tensor_set(g, vec.data(), 0, D * 4); ggml_backend_tensor_set(sft, vec.data() + D, 0, D * 4);
+        ggml_backend_tensor_set(b1, vec.data() + 2 * D, 0, H * 4); ggml_backend_tensor_set(b2, vec.data() + 2 * D + H, 0, D * 4);
+        X = ggml_new_tensor_2d(cctx, GGML_TYPE_F32, D, B);
+        ggml_set_input(X);
+        ggml_tensor * cur = ggml_add(cctx, ggml_mul(cctx, ggml_norm(cctx, X, 1e-5f), g), sft);
+        cur = ggml_gelu(cctx, ggml_add(cctx, ggml_mul_mat(cctx, W1, cur), b1));
+        out = ggml_add(cctx, ggml_add(cctx, ggml_mul_mat(cctx, W2, cur), b2), X);
+        ggml_set_output(out);
+        gf = ggml_new_graph(cctx);
+        ggml_build_forward_expand(gf, out);
+        ga = ggml_gallocr_new(ggml_backend_get_default_buffer_type(backend));
+        if (!ggml_gallocr_alloc_graph(ga, gf)) { fprintf(stderr, "graph allocation failed\n"); exit(1); }
+    }
+    std::vector<float> compute(const std::vector<float> & x) {
         ggml_backend_tensor_set(X, x.data(), 0, x.size() * sizeof(float));
         if (ggml_backend_graph_compute(backend, gf) != GGML_STATUS_SUCCESS) { fprintf(stderr, "graph_compute failed\n"); exit(1); }
         std::vector<float> y((size_t)D * B);
-        ggml_backend_tensor_get(cur, y.data(), 0, y.size() * sizeof(float));
-        out.push_back(y);
+        ggml_backend_tensor_get(out, y.data(), 0, y.size() * sizeof(float));
+        return y;
     }
-    ggml_gallocr_free(ga); ggml_backend_buffer_free(wbuf); ggml_free(wctx); ggml_free(cctx);
-    return out;
-}
+    ~mlp_block() { ggml_gallocr_free(ga); ggml_backend_buffer_free(wbuf); ggml_free(wctx); ggml_free(cctx); }
+};
 
 int main(int argc, char ** argv) {
     if (argc < 6) { fprintf(stderr, "usage: %s plugin type M K B\n", argv[0]); return 2; }
@@ -173,9 +175,25 @@ int main(int argc, char ** argv) {
             std::vector<std::vector<float>> in(6, std::vector<float>((size_t)D * Bn));
             for (int i = 0; i < 6; i++) for (auto & v : in[i]) v = u(rng);
             in[4] = in[0];                                                     // input A again, after the capture
-            const auto yg = run_block(gpu, type, D, H, Bn, w1, w2, vec, in), yc = run_block(cpu, type, D, H, Bn, w1, w2, vec, in);
+            mlp_block bg(gpu, type, D, H, Bn, w1, w2, vec), bc(cpu, type, D, H, Bn, w1, w2, vec);
+            std::vector<std::vector<float>> yg, yc;
+            for (int i = 0; i < 6; i++) { yg.push_back(bg.compute(in[i])); yc.push_back(bc.compute(in[i])); }
             for (int i = 0; i < 6; i++) { const double e = rel_l2(yg[i], yc[i]); if (e > replay_worst) replay_worst = e; if (!(e < 1e-2)) replay_ok = false; }      // (two chained quantized products and an fp16-table GELU: the CPU's own formats differ at 1e-3)
             if (memcmp(yg[0].data(), yg[4].data(), yg[0].size() * 4) != 0) replay_ok = false;
+        }
+        // a captured graph holds the addresses of the backend's workspace and of the kernel library's scratch: a LARGER graph computed in
+        // between moves both, and the small graph must be re-captured, not replayed with the stale addresses
+        {
+            std::vector<float> xs((size_t)D * 96), xl((size_t)D * 8192);
+            for (auto & v : xs) v = u(rng);
+            for (auto & v : xl) v = u(rng);
+            mlp_block small(gpu2, type, D, H, 96, w1, w2, vec);
+            const std::vector<float> y0 = small.compute(xs); small.compute(xs); small.compute(xs);          // eager, capture, replay
+            { mlp_block large(gpu2, type, D, H, 8192, w1, w2, vec); large.compute(xl); }   // ONE eager run: grows workspace + split-K scratch, the small graph's exec stays cached
+            for (int i = 0; i < 3; i++) {                                                 // stale exec dropped; eager, re-captured, replayed
+                const std::vector<float> y1 = small.compute(xs);
+                if (memcmp(y0.data(), y1.data(), y0.size() * 4) != 0) { replay_ok = false; fprintf(stderr, "replay after a workspace move differs\n"); }
+            }
         }
     }
     ggml_backend_dev_props props; ggml_backend_dev_get_props(dev, &props);
