@@ -135,12 +135,14 @@ static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const floa
     if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat: K is not a whole number of blocks");
     path = resolve_path(type, path, M, K, B);
     if (path == GGML_CDNA4_PATH_GEMM && !cdna4_gemm_q_supported(type, M, K, B)) return cdna4_set_error_msg("mul_mat: GEMM path does not support this shape");
-    if (path == GGML_CDNA4_PATH_GEMV && cdna4_gemv_fused_supported(type, K, B) && !((uintptr_t)X & 15)) {
-        // single-token decode: the activation quantizer runs inside the GEMV kernel (workspace untouched)
+    // one launch while the redundant per-work-group quantization is cheap (B x K up to 32 K values, rounded to the instantiated 2 / 4 / 8 columns)
+    const int64_t nbt = B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8));
+    if (path == GGML_CDNA4_PATH_GEMV && cdna4_gemv_fused_supported(type, K, B) && (B == 1 || nbt * K <= 32768) && !(((uintptr_t)X | (uintptr_t)(B > 1 ? x_row_stride * 4 : 0)) & 15)) {
+        // decode with 1..8 activation rows: the activation quantizer runs inside the GEMV kernel (workspace untouched), ONE launch
         cdna4_gemv_args g{};
         g.type = type; g.W = (const uint8_t *)W; g.w_row_bytes = w_row_bytes; g.Y = Y; g.y_col_stride = y_row_stride;
-        g.M = (int)M; g.K = (int)K; g.ncol = 1; g.ids = nullptr; g.epi = epi;
-        return cdna4_launch_gemv_q_fused(g, X, (hipStream_t)stream);
+        g.M = (int)M; g.K = (int)K; g.ncol = (int)B; g.ids = nullptr; g.epi = epi;
+        return B == 1 ? cdna4_launch_gemv_q_fused(g, X, (hipStream_t)stream) : cdna4_launch_gemv_q_fused_n(g, X, x_row_stride, (hipStream_t)stream);
     }
     int rc = ggml_cdna4_prepare_act(type, X, x_row_stride, K, B, workspace, workspace_bytes, path, stream);
     if (rc) return rc;
@@ -149,6 +151,7 @@ static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const floa
         cdna4_gemv_args g{};
         g.type = type; g.W = (const uint8_t *)W; g.w_row_bytes = w_row_bytes; g.qs = v.qs; g.d = v.d; g.bsums = v.bsums;
         g.Y = Y; g.y_col_stride = y_row_stride; g.M = (int)M; g.K = (int)K; g.ncol = (int)B; g.ids = nullptr; g.epi = epi;
+        if (cdna4_gemv_staged_supported(type, K, B)) return cdna4_launch_gemv_q_staged(g, (hipStream_t)stream);    // 2..8 rows: columns from LDS
         return cdna4_launch_gemv_q(g, (hipStream_t)stream);
     }
     rc = ggml_cdna4_mul_mat_prepared(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, stream);

@@ -41,6 +41,11 @@ int cdna4_launch_gemv_q(const cdna4_gemv_args &a, hipStream_t st);
 // single-column decode with the activation quantizer fused in (x = fp32 row; a.qs/d/bsums unused)
 bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B);
 int cdna4_launch_gemv_q_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st);
+// 2..8 activation rows in one launch (a.ncol rows of x, x_row_stride elements apart; the five main formats)
+int cdna4_launch_gemv_q_fused_n(const cdna4_gemv_args &a, const float *x, int64_t x_row_stride, hipStream_t st);
+// 2..8 pre-quantized activation rows (a.qs / a.d / a.bsums) copied into LDS once per work-group
+bool cdna4_gemv_staged_supported(int type, int64_t K, int64_t B);
+int cdna4_launch_gemv_q_staged(const cdna4_gemv_args &a, hipStream_t st);
 // single-token MUL_MAT_ID in one launch (a.ids set, a.ncol = n_used slots; x rows x_row_stride apart, slot u reads row u % a.n_b)
 int cdna4_launch_gemv_q_fused_ids(const cdna4_gemv_args &a, const float *x, int64_t x_row_stride, hipStream_t st);
 

@@ -408,7 +408,14 @@ struct lds_act { const int8_t *qs; const float *d; const int16_t *bsums; int K; 
 // whole row), so fewer, fatter work-groups pay it less often: <4,1> = 1024 work-groups at M=4096, <8,2> = 256 (one per CU).
 // IDS: single-token MUL_MAT_ID (mixture-of-experts decode): blockIdx.y = slot u, expert = ids[u] read on the device, the
 // slot's activation row x + (u % n_b) * x_row_stride, output column u.
-template <int TYPE, int NW, int ROWS, bool IDS = false>
+// NB > 1: the same for up to NB activation rows at once (small-batch decode, a.ncol <= NB rows x_row_stride apart): the work-group
+// quantizes all of them into LDS and every weight unit, loaded once, meets NB columns that are read from LDS — the two-launch
+// k_gemv_q<.., NB> reads its activations from global memory again for every weight row (512 B of L1 traffic per 36-B weight unit
+// at NB = 8: 43 us at 4096 x 14336 where one pass over the weights takes 10).
+// PREQ: the activation rows arrive already quantized (a.qs / a.d / a.bsums, written once by k_quantize_q8_K / q8_0) and are only COPIED
+// into LDS — for NB x K beyond ~32 K values the redundant per-work-group quantization (and its 4 K bytes of fp32 reads per value row and
+// work-group) costs more than the extra launch: measured 40 us at 8 x 14336 with the quantizer inside.
+template <int TYPE, int NW, int ROWS, bool IDS = false, int NB = 1, bool PREQ = false>
 __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, const float *__restrict__ x, int64_t x_row_stride) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr bool KQ = QT<TYPE>::KQ;
@@ -418,32 +425,37 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
         a.W += (int64_t)e * a.w_expert_bytes; x += (int64_t)(u % a.n_b) * x_row_stride; a.Y += (int64_t)u * a.y_col_stride;
     }
     const int K = a.K, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int8_t *sq = reinterpret_cast<int8_t *>(smem);
-    int16_t *sbs = reinterpret_cast<int16_t *>(smem + K);                   // K/8 bytes (Q8_K only)
-    float *sd = reinterpret_cast<float *>(smem + K + (KQ ? K / 8 : 0));
+    const int nch = K / 16, nqd = K / (KQ ? 256 : 32);                    // 16-value chunks / scales per activation row
+    int8_t *sq = reinterpret_cast<int8_t *>(smem);                          // [NB][K]
+    int16_t *sbs = reinterpret_cast<int16_t *>(smem + NB * K);              // [NB][K/16] (Q8_K only)
+    float *sd = reinterpret_cast<float *>(smem + NB * K + (KQ ? NB * (K / 8) : 0));   // [NB][nqd]
     const int row0 = (blockIdx.x * NW + wave) * ROWS;
-    const int nunits = K / Unit<TYPE, 1>::UK;
+    const int nunits = K / Unit<TYPE, NB>::UK;
+    const int total = NB * nch;                                             // chunk id = col * nch + c; 16 adjacent ids share a column and a superblock
+    auto xrow = [&](int col) -> const float * { return x + (int64_t)(NB == 1 ? 0 : min(col, a.ncol - 1)) * x_row_stride; };   // (padding columns repeat the last row)
     // Order matters: a wave's loads RETURN in issue order.  The activation chunk (L2-resident) is requested first so the
     // quantizer can start as soon as it arrives; the weight rows (HBM) are requested right behind it and stream in under the
     // quantizer.  (Weights first made the quantizer wait for the whole HBM round trip: 5.46 vs 4.82 us cold, same-box A/B.)
     const int c_first = threadIdx.x;
     float4 v_first[4] = {};
     const uint8_t *wrow[ROWS];
-    typename Unit<TYPE, 1>::W w0[ROWS];
-    if (c_first < K / 16) {
+    typename Unit<TYPE, NB>::W w0[ROWS];
+    if (!PREQ && c_first < total) {
+        const float *px = xrow(c_first / nch) + (c_first % nch) * 16;
 #pragma unroll
-        for (int i = 0; i < 4; i++) v_first[i] = *reinterpret_cast<const float4 *>(x + c_first * 16 + 4 * i);
+        for (int i = 0; i < 4; i++) v_first[i] = *reinterpret_cast<const float4 *>(px + 4 * i);
     }
     asm volatile("" ::: "memory");                                          // keep the weight loads below behind the activation loads
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         wrow[r] = a.W + (int64_t)min(row0 + r, a.M - 1) * a.w_row_bytes;
-        w0[r] = Unit<TYPE, 1>::load(wrow[r], min(lane, nunits - 1));
+        w0[r] = Unit<TYPE, NB>::load(wrow[r], min(lane, nunits - 1));
     }
     // One lane quantizes 16 consecutive values (= one bsums entry, one ds_write_b128): a superblock is 16 adjacent lanes
     // (4 butterfly rounds), a Q8_0 block 2 lanes (1 round).  The first cut (one wave per superblock, 4 values per lane,
     // 6 rounds x 3 shuffles, 4 superblocks in sequence per wave) cost ~5 us per work-group and lost to the two-kernel path.
-    auto quantize_chunk = [&](int c, const float4 (&v)[4]) __attribute__((always_inline)) {
+    auto quantize_chunk = [&](int id, const float4 (&v)[4]) __attribute__((always_inline)) {
+        const int col = NB == 1 ? 0 : id / nch, c = NB == 1 ? id : id % nch;
         const float e[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
         int q[16];
         if (KQ) {
@@ -466,8 +478,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
 #pragma unroll
                 for (int i = 0; i < 16; i++) q[i] = 0;
             }
-            sbs[c] = (int16_t)bsum;
-            if ((c & 15) == 0) sd[c >> 4] = d;
+            sbs[col * nch + c] = (int16_t)bsum;
+            if ((c & 15) == 0) sd[col * nqd + (c >> 4)] = d;
         } else {
             // AVX2 body of quantize_row_q8_0 (src/ggml-cpu/ggml-cpu-quants.c:778-815): d = amax/127 -> fp16, id = 127/amax, RNE
             float amax = 0.f;
@@ -477,31 +489,52 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
             const float d = amax / 127.f, id = amax != 0.f ? 127.f / amax : 0.f;
 #pragma unroll
             for (int i = 0; i < 16; i++) q[i] = (int)__builtin_rintf(e[i] * id);
-            if ((c & 1) == 0) sd[c >> 1] = h2f(f2h_bits(d));
+            if ((c & 1) == 0) sd[col * nqd + (c >> 1)] = h2f(f2h_bits(d));
         }
         u32x4 pk;
         { const int q0[4] = {q[0], q[1], q[2], q[3]}, q1[4] = {q[4], q[5], q[6], q[7]}, q2[4] = {q[8], q[9], q[10], q[11]}, q3[4] = {q[12], q[13], q[14], q[15]};
           pk.x = pack4i8(q0); pk.y = pack4i8(q1); pk.z = pack4i8(q2); pk.w = pack4i8(q3); }
-        *reinterpret_cast<u32x4 *>(sq + c * 16) = pk;
+        *reinterpret_cast<u32x4 *>(sq + col * K + c * 16) = pk;
     };
-    if (c_first < K / 16) quantize_chunk(c_first, v_first);
-    for (int c = c_first + NW * 64; c < K / 16; c += NW * 64) {           // K > 16 * (work-group size): the remaining chunks
+    if constexpr (PREQ) {
+        // 16-byte copies: int8 rows (K bytes each), then bsums (K/8 bytes each), then scales (4 nqd bytes each; nqd % 4 == 0 is required)
+        for (int id = threadIdx.x; id < total; id += NW * 64) {
+            const int col = id / nch, c = id % nch, sc = min(col, a.ncol - 1);
+            *reinterpret_cast<u32x4 *>(sq + col * K + c * 16) = *reinterpret_cast<const u32x4 *>(a.qs + (int64_t)sc * K + c * 16);
+        }
+        if (KQ) for (int id = threadIdx.x; id < NB * (nch / 8); id += NW * 64) {
+            const int col = id / (nch / 8), c = id % (nch / 8), sc = min(col, a.ncol - 1);
+            *reinterpret_cast<u32x4 *>(sbs + col * nch + c * 8) = *reinterpret_cast<const u32x4 *>(a.bsums + (int64_t)sc * nch + c * 8);
+        }
+        for (int id = threadIdx.x; id < NB * nqd; id += NW * 64) { const int col = id / nqd, c = id % nqd; sd[col * nqd + c] = a.d[(int64_t)min(col, a.ncol - 1) * nqd + c]; }
+    } else {
+    if (c_first < total) quantize_chunk(c_first, v_first);
+    for (int id = c_first + NW * 64; id < total; id += NW * 64) {          // more chunks than threads: the remaining ones
+        const float *px = xrow(id / nch) + (id % nch) * 16;
         float4 v[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const float4 *>(x + c * 16 + 4 * i);
-        quantize_chunk(c, v);
+        for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const float4 *>(px + 4 * i);
+        quantize_chunk(id, v);
+    }
     }
     __syncthreads();
     if (row0 >= a.M) return;
     const lds_act act{sq, sd, sbs, K};
-    const int col[1] = {0};
+    int col[NB];
+#pragma unroll
+    for (int c = 0; c < NB; c++) col[c] = c;
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
-        float acc[1] = {0.f};
-        if (lane < nunits) Unit<TYPE, 1>::mac(w0[r], lane, act, col, acc);
-        for (int u = lane + 64; u < nunits; u += 64) Unit<TYPE, 1>::dot(wrow[r], u, act, col, acc);
-        const float s = wave_sum(acc[0]);
-        if (lane == 0 && row0 + r < a.M) a.Y[row0 + r] = epilogue_apply(a.epi, s, row0 + r, 0);
+        float acc[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) acc[c] = 0.f;
+        if (lane < nunits) Unit<TYPE, NB>::mac(w0[r], lane, act, col, acc);
+        for (int u = lane + 64; u < nunits; u += 64) Unit<TYPE, NB>::dot(wrow[r], u, act, col, acc);
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            const float s = wave_sum(acc[c]);
+            if (lane == 0 && row0 + r < a.M && c < (NB == 1 ? 1 : a.ncol)) a.Y[(int64_t)c * a.y_col_stride + row0 + r] = epilogue_apply(a.epi, s, row0 + r, c);
+        }
     }
 }
 
@@ -509,8 +542,12 @@ size_t cdna4_gemv_fused_lds_bytes(int type, int64_t K) {
     const bool kq = type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K || type == CDNA4_Q2_K || type == CDNA4_Q3_K;
     return (size_t)(K + (kq ? K / 8 + (K / 256) * 4 : (K / 32) * 4));
 }
+static int fused_nb(int64_t B) { return B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8)); }      // instantiated column counts
 bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B) {
-    return B == 1 && K > 0 && cdna4_gemv_fused_lds_bytes(type, K) <= 64 * 1024;
+    if (K <= 0 || B < 1 || B > 8) return false;
+    if (B == 1) return cdna4_gemv_fused_lds_bytes(type, K) <= 64 * 1024;
+    const bool main5 = type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K || type == CDNA4_Q4_0 || type == CDNA4_Q8_0;
+    return main5 && (size_t)fused_nb(B) * cdna4_gemv_fused_lds_bytes(type, K) <= 150 * 1024;
 }
 template <int TYPE>
 static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st) {
@@ -526,6 +563,69 @@ static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st
     else hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 1>), dim3((a.M + 3) / 4), dim3(256), lds, st, a, x, (int64_t)0);
     CDNA4_CHECK_LAUNCH();
     return 0;
+}
+// 2..8 activation rows: 8 waves x 2 rows per work-group; more than 64 KB of LDS needs the attribute once per kernel
+template <int TYPE, int NB>
+static int launch_fused_nb(const cdna4_gemv_args &a, const float *x, int64_t x_row_stride, hipStream_t st) {
+    const size_t lds = (size_t)NB * cdna4_gemv_fused_lds_bytes(TYPE, a.K);
+    static bool raised = false;
+    if (!raised) { if (hipFuncSetAttribute((const void *)k_gemv_q_fused<TYPE, 8, 2, false, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { (void)hipGetLastError(); return cdna4_set_error_msg("gemv_q_fused: cannot raise the dynamic LDS limit"); } raised = true; }
+    hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2, false, NB>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x, x_row_stride);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+template <int TYPE>
+static int launch_fused_n(const cdna4_gemv_args &a, const float *x, int64_t x_row_stride, hipStream_t st) {
+    switch (fused_nb(a.ncol)) { case 2: return launch_fused_nb<TYPE, 2>(a, x, x_row_stride, st); case 4: return launch_fused_nb<TYPE, 4>(a, x, x_row_stride, st); default: return launch_fused_nb<TYPE, 8>(a, x, x_row_stride, st); }
+}
+template <int TYPE, int NB>
+static int launch_staged_nb(const cdna4_gemv_args &a, hipStream_t st) {
+    const size_t lds = (size_t)NB * cdna4_gemv_fused_lds_bytes(TYPE, a.K);
+    static bool raised = false;
+    if (!raised) { if (hipFuncSetAttribute((const void *)k_gemv_q_fused<TYPE, 8, 2, false, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { (void)hipGetLastError(); return cdna4_set_error_msg("gemv_q_staged: cannot raise the dynamic LDS limit"); } raised = true; }
+    hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2, false, NB, true>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, (const float *)nullptr, (int64_t)0);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+template <int TYPE>
+static int launch_staged(const cdna4_gemv_args &a, hipStream_t st) {
+    switch (fused_nb(a.ncol)) { case 2: return launch_staged_nb<TYPE, 2>(a, st); case 4: return launch_staged_nb<TYPE, 4>(a, st); default: return launch_staged_nb<TYPE, 8>(a, st); }
+}
+// 2..8 PRE-QUANTIZED activation rows (a.qs / a.d / a.bsums as ggml_cdna4_prepare_act lays them out), staged into LDS once per work-group
+bool cdna4_gemv_staged_supported(int type, int64_t K, int64_t B) {
+    const int64_t nqd = K / ((type == CDNA4_Q4_0 || type == CDNA4_Q8_0) ? 32 : 256);
+    return B >= 2 && cdna4_gemv_fused_supported(type, K, B) && K % 128 == 0 && nqd > 0;
+}
+int cdna4_launch_gemv_q_staged(const cdna4_gemv_args &a, hipStream_t st) {
+    if (a.M <= 0) return 0;
+    if (!cdna4_gemv_staged_supported(a.type, a.K, a.ncol) || a.ids) return cdna4_set_error_msg("gemv_q_staged: unsupported shape");
+    if (((uintptr_t)a.qs | (uintptr_t)a.bsums) & 15) return cdna4_set_error_msg("gemv_q_staged: quantized activations must be 16-byte aligned");
+    switch (a.type) {
+        case CDNA4_Q4_K: case CDNA4_Q5_K:
+            if (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) return cdna4_set_error_msg("gemv_q: Q4_K/Q5_K rows must be 16-byte aligned");
+            return a.type == CDNA4_Q4_K ? launch_staged<CDNA4_Q4_K>(a, st) : launch_staged<CDNA4_Q5_K>(a, st);
+        case CDNA4_Q6_K: return launch_staged<CDNA4_Q6_K>(a, st);
+        case CDNA4_Q4_0: return launch_staged<CDNA4_Q4_0>(a, st);
+        case CDNA4_Q8_0: return launch_staged<CDNA4_Q8_0>(a, st);
+    }
+    return cdna4_set_error_msg("gemv_q_staged: unsupported weight type");
+}
+// a.ncol = 2..8 rows of x (fp32, 16-byte aligned, x_row_stride elements apart), quantized in LDS; Y column c at a.Y + c * a.y_col_stride
+int cdna4_launch_gemv_q_fused_n(const cdna4_gemv_args &a, const float *x, int64_t x_row_stride, hipStream_t st) {
+    if (a.M <= 0) return 0;
+    if (a.ncol < 2 || !cdna4_gemv_fused_supported(a.type, a.K, a.ncol)) return cdna4_set_error_msg("gemv_q_fused_n: unsupported shape");
+    if (((uintptr_t)x | (uintptr_t)(x_row_stride * 4)) & 15) return cdna4_set_error_msg("gemv_q_fused_n: x rows must be 16-byte aligned");
+    if (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 1) return cdna4_set_error_msg("gemv_q: misaligned operands");
+    switch (a.type) {
+        case CDNA4_Q4_K: case CDNA4_Q5_K:
+            if (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) return cdna4_set_error_msg("gemv_q: Q4_K/Q5_K rows must be 16-byte aligned");
+            if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256");
+            return a.type == CDNA4_Q4_K ? launch_fused_n<CDNA4_Q4_K>(a, x, x_row_stride, st) : launch_fused_n<CDNA4_Q5_K>(a, x, x_row_stride, st);
+        case CDNA4_Q6_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused_n<CDNA4_Q6_K>(a, x, x_row_stride, st);
+        case CDNA4_Q4_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_n<CDNA4_Q4_0>(a, x, x_row_stride, st);
+        case CDNA4_Q8_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_n<CDNA4_Q8_0>(a, x, x_row_stride, st);
+    }
+    return cdna4_set_error_msg("gemv_q_fused_n: unsupported weight type");
 }
 
 int cdna4_launch_gemv_q(const cdna4_gemv_args &a, hipStream_t st) {

@@ -228,6 +228,23 @@ def test_asynchronous_register_loads_are_not_read_before_their_wait(gemm_asm):
         assert n > 0 and not bad, (k, bad[:3])
 
 
+@pytest.mark.parametrize("ncol", [2, 3, 8])
+@pytest.mark.parametrize("t", [12, 13, 14, 2, 8])
+def test_small_batch_decode_kernel_source_on_the_cpu(t, ncol):
+    """tools/emul/gemv_emul: k_gemv_q_fused<.., NB> for 2..8 activation rows in ONE launch (every work-group quantizes the rows into
+    LDS — bit-exact quantizer bodies — and each weight unit meets all columns from there), the five main formats, against the oracle;
+    3 rows run the 4-column instantiation with its padding column repeating the last row"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gemv_emul_check", os.path.join(ROOT, "tools", "emul", "gemv_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(t, 37, 2048, seed=t + ncol, ncol=ncol) < 1e-5
+    # ... and the form that is handed pre-quantized rows (one quantize launch for all work-groups) and only copies them into LDS
+    assert mod.run_cols(t, 37, 2048, ncol, seed=t + ncol, staged=True) < 1e-5
+
+
 @pytest.mark.parametrize("cfg", [0, 1])                       # 4 waves x 1 row, 8 waves x 2 rows (the M >= 4096 default)
 @pytest.mark.parametrize("t", [12, 13, 14, 2, 8, 6, 10, 11])  # Q4_K, Q5_K, Q6_K, Q4_0, Q8_0 + the units not yet behind the C-ABI: Q5_0, Q2_K, Q3_K
 def test_decode_kernel_source_on_the_cpu(t, cfg):

@@ -144,6 +144,28 @@ def test_fused_decode_equals_two_kernel_path(gu, name, t, m, k):
 
 
 @pytest.mark.parametrize("name,t", WT)
+@pytest.mark.parametrize("m,k,b", [(130, 4096, 2), (300, 2048, 3), (64, 14336, 8), (4100, 1024, 5), (9, 512, 7)])
+def test_small_batch_decode_is_one_launch_and_equals_the_two_kernel_path(gu, name, t, m, k, b):
+    """2..8 activation rows: ggml_cdna4_mul_mat quantizes all of them inside ONE GEMV launch (k_gemv_q_fused<.., NB>, columns read from
+    LDS; 3 rows run the 4-column form whose padding column repeats the last row; K = 14336 x 8 rows = 130 KB of LDS); bit for bit the
+    quantize-then-k_gemv_q pair, and the oracle to 1e-5.  A strided activation view (row stride > K) goes through the same launch."""
+    from ggml_amd import ops
+    w = R.random_weights(t, m, k, seed=3 * m + k + b)
+    x = _x(abs(k - m) + b, b, k, "normal")
+    a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
+    y_one = ops.mul_mat(a, xd).cpu().numpy()
+    y_two = ops.mul_mat_prepared(a, ops.PreparedAct(t, xd, path=ops.PATH_GEMV)).cpu().numpy()
+    assert np.array_equal(y_one.view(np.uint32), y_two.view(np.uint32))
+    e = R.rel_l2(y_one, R.o_mul_mat(t, w, x, m, k)); gu.report(test="gemv_small_batch", type=name, m=m, k=k, b=b, rel_l2=e)
+    assert e < TOL_GEMV
+    import torch
+    wide = torch.zeros((b, k + 64), dtype=torch.float32, device="cuda")
+    wide[:, :k] = xd
+    y_view = ops.mul_mat(a, wide[:, :k]).cpu().numpy()
+    assert np.array_equal(y_view.view(np.uint32), y_one.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,t", WT)
 def test_gemv_many_columns_and_32_block_k(gu, name, t):
     """B > 8 through the GEMV path (column groups), and K = one block for the 32-block formats"""
     from ggml_amd import ops

@@ -82,21 +82,22 @@ static int main_cols(int argc, char **argv) {
     for (int i = 0; i < M * ncol; i++) y[i] = -12345.f;
     cdna4_gemv_args a{};
     a.type = type; a.W = w; a.w_row_bytes = (int64_t)(w0.size() / (size_t)M); a.qs = qs; a.d = d; a.bsums = bs; a.Y = y; a.y_col_stride = M; a.M = M; a.K = K; a.ncol = ncol;
-    if (cdna4_launch_gemv_q(a, nullptr) != 0) return 1;
+    // EMU_STAGED=1: the form that copies the pre-quantized rows into LDS once per work-group (k_gemv_q_fused<.., NB, PREQ>)
+    if ((getenv("EMU_STAGED") ? cdna4_launch_gemv_q_staged(a, nullptr) : cdna4_launch_gemv_q(a, nullptr)) != 0) return 1;
     FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)M * ncol, f); fclose(f);
     return 0;
 }
 int main(int argc, char **argv) {
     if (argc >= 10) return main_cols(argc, argv);
-    if (argc < 7) { fprintf(stderr, "usage: gemv_emul type M K w.bin x.bin y.bin   |   gemv_emul type M K w.bin qs.bin y.bin ncol d.bin bsums.bin\n"); return 2; }
-    const int type = atoi(argv[1]), M = atoi(argv[2]), K = atoi(argv[3]);
+    if (argc < 7) { fprintf(stderr, "usage: gemv_emul type M K w.bin x.bin y.bin [ncol]   |   gemv_emul type M K w.bin qs.bin y.bin ncol d.bin bsums.bin\n"); return 2; }
+    const int type = atoi(argv[1]), M = atoi(argv[2]), K = atoi(argv[3]), ncol = argc > 7 ? atoi(argv[7]) : 1;      // ncol rows of x: the one-launch small-batch form
     std::vector<uint8_t> w0 = slurp(argv[4]), x0 = slurp(argv[5]);
-    uint8_t *w = (uint8_t *)shared_alloc(w0.size()); float *x = (float *)shared_alloc(x0.size()), *y = (float *)shared_alloc((size_t)M * 4);
+    uint8_t *w = (uint8_t *)shared_alloc(w0.size()); float *x = (float *)shared_alloc(x0.size()), *y = (float *)shared_alloc((size_t)M * ncol * 4);
     memcpy(w, w0.data(), w0.size()); memcpy(x, x0.data(), x0.size());
-    for (int i = 0; i < M; i++) y[i] = -12345.f;
+    for (int i = 0; i < M * ncol; i++) y[i] = -12345.f;
     cdna4_gemv_args a{};
-    a.type = type; a.W = w; a.w_row_bytes = (int64_t)(w0.size() / (size_t)M); a.Y = y; a.y_col_stride = M; a.M = M; a.K = K; a.ncol = 1;
-    if (cdna4_launch_gemv_q_fused(a, x, nullptr) != 0) return 1;
-    FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)M, f); fclose(f);
+    a.type = type; a.W = w; a.w_row_bytes = (int64_t)(w0.size() / (size_t)M); a.Y = y; a.y_col_stride = M; a.M = M; a.K = K; a.ncol = ncol;
+    if ((ncol == 1 ? cdna4_launch_gemv_q_fused(a, x, nullptr) : cdna4_launch_gemv_q_fused_n(a, x, K, nullptr)) != 0) return 1;
+    FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)M * ncol, f); fclose(f);
     return 0;
 }

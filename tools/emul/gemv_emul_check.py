@@ -28,14 +28,16 @@ def build():
     return exe
 
 
-def run(t, M, K, seed=1, timeout=600, env=None):
+def run(t, M, K, seed=1, timeout=600, env=None, ncol=1):
+    """ncol > 1: the one-launch small-batch form (ncol activation rows quantized in LDS by every work-group)"""
     assert K % 1024 == 0, "wave-collective shuffles: the quantizer's lanes must fill whole waves"
     w = R.random_weights(t, M, K, seed)
-    x = np.random.default_rng(seed + 1).uniform(-1, 1, (1, K)).astype(np.float32)
-    want = R.o_mul_mat(t, w, x, M, K)[0]
+    x = np.random.default_rng(seed + 1).uniform(-1, 1, (ncol, K)).astype(np.float32)
+    want = R.o_mul_mat(t, w, x, M, K)
+    want = want[0] if ncol == 1 else want.reshape(-1)
     with tempfile.TemporaryDirectory() as d:
         w.tofile(os.path.join(d, "w.bin")); x.tofile(os.path.join(d, "x.bin"))
-        r = subprocess.run([build(), str(t), str(M), str(K), os.path.join(d, "w.bin"), os.path.join(d, "x.bin"), os.path.join(d, "y.bin")],
+        r = subprocess.run([build(), str(t), str(M), str(K), os.path.join(d, "w.bin"), os.path.join(d, "x.bin"), os.path.join(d, "y.bin")] + ([str(ncol)] if ncol > 1 else []),
                            capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
         if r.returncode == 77:
             import pytest
@@ -45,7 +47,7 @@ def run(t, M, K, seed=1, timeout=600, env=None):
     return R.rel_l2(y, want)
 
 
-def run_cols(t, M, K, ncol, seed=1, timeout=600):
+def run_cols(t, M, K, ncol, seed=1, timeout=600, staged=False):
     """the multi-column GEMV (B = 2 .. 8) on activations quantized by the oracle, against the oracle's MUL_MAT"""
     w = R.random_weights(t, M, K, seed)
     x = np.random.default_rng(seed + 1).uniform(-1, 1, (ncol, K)).astype(np.float32)
@@ -64,7 +66,8 @@ def run_cols(t, M, K, ncol, seed=1, timeout=600):
     with tempfile.TemporaryDirectory() as dd:
         f = lambda n: os.path.join(dd, n)
         w.tofile(f("w.bin")); qs.tofile(f("qs.bin")); d.tofile(f("d.bin")); bs.tofile(f("bs.bin"))
-        r = subprocess.run([build(), str(t), str(M), str(K), f("w.bin"), f("qs.bin"), f("y.bin"), str(ncol), f("d.bin"), f("bs.bin")], capture_output=True, text=True, timeout=timeout)
+        r = subprocess.run([build(), str(t), str(M), str(K), f("w.bin"), f("qs.bin"), f("y.bin"), str(ncol), f("d.bin"), f("bs.bin")], capture_output=True, text=True, timeout=timeout,
+                           env=dict(os.environ, EMU_STAGED="1") if staged else None)
         if r.returncode == 77:
             import pytest
             pytest.skip("the environment cannot host the emulation (process / thread limits)")
