@@ -15,7 +15,7 @@
 //    XOR-swizzled on the SOURCE address so the fragment ds_read_b128s are conflict-free); XCD-aware tile order.
 // Kernels, oldest to newest (launch_type() picks; DESIGN.md 4.3 has the measurements):
 //    k_gemm_q        4 waves, slice-per-barrier, per-lane weight loads — any format, small batches, K % 256 != 0
-//    k_gemm_kq_pipe  4 waves, superblock stages, counted vmcnt                      (Q4_K / Q5_K, 8 < B <= 64)
+//    k_gemm_kq_pipe  4 waves, superblock stages, counted vmcnt                      (Q4_K / Q5_K; explicit variants only since round 2)
 //    k_gemm_kq_w8    8 waves (two per SIMD), 128x128 tile, in-wave unpack/MFMA pipeline, split-K = 2 exchange
 //    k_gemm_kq_w8p   + cross-stage software pipeline (barrier in the middle of the MFMA stream)   (Q5_K default)
 //    k_gemm_kq_w12   + four LDS-DMA loader waves; they also re-lay Q4_0 / Q8_0 / Q6_K blocks while staging (Q4_K default)
@@ -509,7 +509,10 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     // 0 = auto: widest tile that the batch fills.
     int variant = a.variant;
     // (Q5_K on the loader-wave kernel: 31.0 vs 30.65 us — its larger Raw<> spills 32 B at 168 VGPRs — so it stays on k_gemm_kq_w8p)
-    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | (a.B > 64 ? 2 : 0) | (CAN_LDS && a.B > 64 ? (16 | (TYPE == CDNA4_Q4_K ? 4096 : 2048)) : 0);   // cross-stage pipeline; Q4_K: + loader waves (k_gemm_kq_w12: 168 VGPRs without spills only for this format)
+    // Every batch the GEMM path is given (B > 8) takes the 128-wide activation tile and the 8-wave kernels: the 64-wide 4-wave kernels
+    // put ONE work-group on every eighth CU at M = 4096 and have no K split — measured (Q4_K, MI355X) 31 us at 4096 x 4096 and 94 us
+    // at 4096 x 14336 for every B in 9..64 against 21 / 47 us for B = 65 on a mostly empty 128-wide tile.
+    if (variant <= 0) variant = 4 | (CAN_LDS ? 1 : 0) | 2 | (CAN_LDS ? (16 | (TYPE == CDNA4_Q4_K ? 4096 : 2048)) : 0);   // cross-stage pipeline; Q4_K: + loader waves (k_gemm_kq_w12: 168 VGPRs without spills only for this format)
     const bool wlds = (variant & 1) && CAN_LDS && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0);
     const bool wide = (variant & 2) != 0;
     // split-K: K-quants split at superblock granularity, 32-block formats at 64-k slices
@@ -534,7 +537,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         // are resident, uneven for odd superblock counts), 256-row tiles once the grid holds two of them per CU.  MI355X, same box, same
         // data: 4096x4096x512 24.25 vs 24.68 us on k_gemm_kq_w12, 4096x11008x512 50.95 vs 52.57, 8192x4096x512 37.1 vs 38.1,
         // 32768x8192x512 (256-row tiles) 239-243 vs 265.
-        if (wlds && a.variant <= 0 && a.B > 64 && a.splitk <= 2) return cdna4_launch_gemm_t64(a, 0, a.splitk, st);   // (deeper, atomic splits: the older kernels below)
+        if (wlds && a.variant <= 0 && a.splitk <= 2) return cdna4_launch_gemm_t64(a, 0, a.splitk, st);   // (deeper, atomic splits: the older kernels below)
     }
     if (splitk < 1 || (kunits % splitk && !uneven)) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
     if constexpr (TYPE == CDNA4_Q4_0 || TYPE == CDNA4_Q8_0 || TYPE == CDNA4_Q6_K) {
@@ -542,7 +545,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         // call: one extra read+write of W, ~5 us at 4096x4096) and run the LDS-DMA pipeline on that — 2.5-3x faster
         // than the per-lane-load kernel below, which stays for small batches and K % 256 != 0.
         constexpr int RT = TYPE == CDNA4_Q4_0 ? CDNA4_Q4_0R : (TYPE == CDNA4_Q8_0 ? CDNA4_Q8_0R : CDNA4_Q6_KR);
-        if (a.variant <= 0 && a.B > 64 && a.K % 256 == 0) {
+        if (a.variant <= 0 && a.K % 256 == 0) {
             // preferred: no copy at all — the loader waves of k_gemm_kq_w12 read the original blocks and re-lay them while
             // staging (needs >= 3 superblocks of K per work-group, like the cross-stage pipeline itself)
             constexpr int ST_ = TYPE == CDNA4_Q4_0 ? CDNA4_Q4_0S : (TYPE == CDNA4_Q8_0 ? CDNA4_Q8_0S : CDNA4_Q6_KS);
@@ -551,7 +554,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
             if (sk <= 0) sk = (tiles * 2 <= cu_count() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
             if (sk >= 1 && nsb % sk == 0 && nsb / sk >= 3) return launch_w8<ST_>(a, sk, 65, st);
         }
-        if (a.variant <= 0 && a.B > 64 && a.K % 256 == 0) {
+        if (a.variant <= 0 && a.K % 256 == 0) {
             const int nsb = a.K / 256;
             const size_t rbytes = (size_t)a.M * nsb * QT<RT>::BYTES;
             uint8_t *rw = (uint8_t *)get_scratch(rbytes + 256, 1);

@@ -1,5 +1,5 @@
 // gemm_q_t64.hip — launcher of k_gemm_kq_t64 (gemm_kq_t64.inc): the prefill GEMM with 64(m) x 128(b) wave tiles.
-// Replaces, for Q4_K at B > 64, what ggml_compute_forward_mul_mat does after the activations are quantized
+// Replaces, for Q4_K at B > 8, what ggml_compute_forward_mul_mat does after the activations are quantized
 // (/root/reference/src/ggml-cpu/ggml-cpu.c:7510-7605).
 #include "gemm_q_common.h"
 #include "gemm_q_hw.h"
