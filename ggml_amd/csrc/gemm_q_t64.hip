@@ -17,26 +17,33 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     if (tm <= 0) tm = (((a.M + 255) / 256) * tiles_b >= 2 * cus) ? 256 : 128;
     if (tm != 128 && tm != 256) return cdna4_set_error_msg("gemm_t64: tile rows are 128 or 256");
     const int tiles_m = (a.M + tm - 1) / tm, ntiles = tiles_m * tiles_b;
-    if (splitk <= 0) splitk = (ntiles * 2 <= cus && nsb >= 2) ? 2 : 1;             // hand-off split: both work-groups of a tile must be resident
-    if (splitk != 1 && splitk != 2) return cdna4_set_error_msg("gemm_t64: split-K is 1 or 2");
-    if (splitk == 2 && (ntiles * 2 > cus || nsb < 2)) return cdna4_set_error_msg("gemm_t64: the split-K exchange needs every work-group resident and two superblocks");
+    // split-K: 2 = the hand-off between the two co-resident work-groups of a tile; 4 / 8 = deep split for grids far below the chip
+    // (a few activation rows over a tall matrix), every work-group >= 2 superblocks, summed in fixed order by the last one to arrive
+    if (splitk <= 0) {
+        splitk = (ntiles * 2 <= cus && nsb >= 2) ? 2 : 1;
+        if (tm == 128 && ntiles * 4 <= cus && nsb >= 8) splitk = 4;
+        if (tm == 128 && ntiles * 8 <= cus && nsb >= 16) splitk = 8;
+    }
+    if (splitk != 1 && splitk != 2 && splitk != 4 && splitk != 8) return cdna4_set_error_msg("gemm_t64: split-K is 1, 2, 4 or 8");
+    if (splitk == 2 && (ntiles * 2 > cus || nsb < 2)) return cdna4_set_error_msg("gemm_t64: the split-K hand-off needs every work-group resident and two superblocks");
+    if (splitk > 2 && (nsb < splitk || tm != 128)) return cdna4_set_error_msg("gemm_t64: the deep K split is built for 128-row tiles and needs a superblock per work-group");
     gemm_params p{};
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = tiles_m; p.tiles_b = tiles_b;
-    if (splitk == 2) {
-        // exchange slots: [tile][destination work-group][wave] x 16 KB at most; flags: one word per (tile, work-group), zero
-        // when idle (the READER clears its partner's flag, so there is no per-launch state on the host: graph-capturable).
-        // Scratch kind 2: the older kernels' tagged flags never mix with these.
-        // The flags live at a FIXED place (the first 64 KB) so that no shape's exchange slots ever overlay another shape's flags.
-        const size_t pbytes = (size_t)ntiles * 2 * 8 * 16384, fbytes = 65536;
-        if ((size_t)ntiles * 8 > fbytes) return cdna4_set_error_msg("gemm_t64: too many tiles for the split-K flag area");
+    if (splitk >= 2) {
+        // exchange slots: [tile][work-group of the tile][wave] x 16 KB at most; flag words: hand-off flags [tile][ks] in the first 32 KB,
+        // deep-split ticket counters [tile] behind them; both zero when idle and reset by their last user — no per-launch state on the
+        // host: graph-capturable.  Scratch kind 2: the older kernels' areas never mix with these.
+        // The words live at a FIXED place (the first 64 KB) so that no shape's exchange slots ever overlay another shape's flags.
+        const size_t pbytes = (size_t)ntiles * splitk * 8 * 16384, fbytes = 65536;
+        if ((size_t)ntiles * 8 > 32768) return cdna4_set_error_msg("gemm_t64: too many tiles for the split-K flag area");
         char *sc = (char *)cdna4_gemm_scratch(fbytes + pbytes, 2);
         if (!sc) return cdna4_set_error_msg("gemm_t64: cannot allocate split-K scratch");
         p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
         p.sb_split = (nsb + 1) / 2;
         const int nb = ntiles * 2;                                                 // partners share an XCD iff the XCD-aware remap is active and
-        p.xchg_l2 = ((nb & 7) == 0 && ((nb >> 3) % (tiles_b * 2)) == 0) ? 1 : 0;   // each XCD's slice holds whole (tile_b x ks) groups
+        p.xchg_l2 = (splitk == 2 && (nb & 7) == 0 && ((nb >> 3) % (tiles_b * 2)) == 0) ? 1 : 0;   // each XCD's slice holds whole (tile_b x ks) groups
     }
     const dim3 grid(ntiles * splitk);
 #ifdef CDNA4_ABLATIONS

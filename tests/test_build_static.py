@@ -79,7 +79,8 @@ def test_64x128_wave_tile_kernel_resources(tmp_path):
 
 
 @pytest.mark.parametrize("m,k,b,splitk,tm", [(128, 256, 128, 1, 128), (300, 1536, 200, 1, 128), (300, 1536, 200, 1, 256), (513, 1024, 129, 2, 128),
-                                             (256, 1792, 128, 2, 128), (512, 1792, 200, 2, 256), (200, 256, 100, 1, 256)])
+                                             (256, 1792, 128, 2, 128), (512, 1792, 200, 2, 256), (200, 256, 100, 1, 256),
+                                             (200, 2304, 40, 4, 128), (128, 4352, 9, 8, 128), (300, 2048, 130, 8, 128)])      # deep split: 9 / 17 / 8 superblocks over 4 / 8 / 8 work-groups
 def test_64x128_wave_tile_kernel_source_on_the_cpu(m, k, b, splitk, tm):
     """tools/emul/t64_emul: the source of k_gemm_kq_t64 executed on the CPU against a direct fp16 product — both tile heights,
     ragged edges, one-superblock K ranges, even and uneven hand-off splits (the harness also checks that every exchange flag

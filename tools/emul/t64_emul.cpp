@@ -98,19 +98,20 @@ int main(int argc, char **argv) {
     p.tiles_m = (M + tm - 1) / tm; p.tiles_b = (B + 127) / 128;
     const int ntiles = p.tiles_m * p.tiles_b, nsb = K / 256;
     unsigned *flags = nullptr;
-    if (splitk == 2) {
-        if (nsb < 2) { fprintf(stderr, "split-K needs two superblocks\n"); return 2; }
-        const size_t pbytes = (size_t)ntiles * 2 * 8 * 16384, fbytes = 65536;
+    if (splitk >= 2) {
+        if (nsb < splitk) { fprintf(stderr, "split-K needs a superblock per work-group\n"); return 2; }
+        const size_t pbytes = (size_t)ntiles * splitk * 8 * 16384, fbytes = 65536;
         char *sc = (char *)shared_alloc(fbytes + pbytes);
         memset(sc, 0, fbytes);
         p.flags = flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
         p.sb_split = (nsb + 1) / 2;
-        p.xchg_l2 = l2;
-    } else if (splitk != 1) { fprintf(stderr, "splitk 1 or 2\n"); return 2; }
+        p.xchg_l2 = splitk == 2 ? l2 : 0;
+        if (splitk != 2 && splitk != 4 && splitk != 8) { fprintf(stderr, "splitk 1, 2, 4 or 8\n"); return 2; }
+    } else if (splitk != 1) { fprintf(stderr, "splitk 1, 2, 4 or 8\n"); return 2; }
     const unsigned nblk = (unsigned)(ntiles * splitk);
     if (tm == 128) emu_launch([&] { k_gemm_kq_t64<CDNA4_Q4_K, 128>(p); }, nblk, 512);
     else emu_launch([&] { k_gemm_kq_t64<CDNA4_Q4_K, 256>(p); }, nblk, 512);
-    if (flags) for (int i = 0; i < ntiles * 2; i++) if (flags[i] != 0) { fprintf(stderr, "exchange flag %d was not reset by its reader (%u)\n", i, flags[i]); return 4; }
+    if (flags) for (int i = 0; i < 16384; i++) if (flags[i] != 0) { fprintf(stderr, "exchange flag / ticket word %d was not reset by its last user (%u)\n", i, flags[i]); return 4; }
     FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)B * M, f); fclose(f);
     return 0;
 }
