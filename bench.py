@@ -292,6 +292,24 @@ def format_rows(dev, steps):
     return rows
 
 
+def batch_sweep(dev, steps):
+    """µs per MUL_MAT call (activation quantize included, HIP events) from decode to prefill batch sizes — one-launch GEMV (1..8 rows,
+    columns from LDS), then k_gemm_kq_t64 with the deep K split while the grid is far below the chip — at the headline matrix and at
+    the reference's perf shape (tests/test-backend-ops.cpp:4340-4346)"""
+    from ggml_amd import ops
+    out = {}
+    for (m, k) in ((4096, 4096), (4096, 14336)):
+        w, _, how = prescribed(Q4_K, m, k, 0, m, 1)
+        a = ops.QTensor.from_host_bytes(Q4_K, k, m, w, device=dev)
+        row = {}
+        for b in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+            x = torch.from_numpy(np.random.default_rng(b).uniform(-1, 1, (b, k)).astype(np.float32)).to(dev)
+            y = torch.empty((b, m), dtype=torch.float32, device=dev)
+            row[str(b)] = round(events_us(lambda: ops.mul_mat(a, x, out=y), max(50, steps // 2), 10), 2)
+        out["%dx%d" % (m, k)] = {"us_per_call_by_rows": row, "data": how}
+    return out
+
+
 def moe_row(dev, steps):
     """MUL_MAT_ID at prefill size: 8 experts x 2 used x 512 tokens, Q4_K experts of 4096 x 4096 — the device-side
     grouping (counting sort of the ids, no host sync) + gather-quantize + ONE grouped GEMM launch; effective flops = 2 M K per
@@ -546,6 +564,7 @@ def main():
                     ("shapes", lambda: {"c3_4096x11008x512": shape_row(dev, Q4_K, 4096, 11008, 512, steps), "c5_32768x8192x512_one_gpu": shape_row(dev, Q4_K, 32768, 8192, 512, max(20, steps // 4))}, 200),
                     ("formats", lambda: format_rows(dev, steps), 230),
                     ("mul_mat_id", lambda: moe_row(dev, steps), 245),
+                    ("batch_sweep", lambda: batch_sweep(dev, steps), 250),
                     ("stock_test_backend_ops_perf", lambda: stock_perf_lines(int(max(30, min(150, time_left(400))))), 260))
             run_legs(legs, out)
     if rank == 0:
