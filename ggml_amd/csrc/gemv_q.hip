@@ -18,6 +18,16 @@ __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __bu
 
 template <int TYPE, int NB> struct Unit;
 
+// The quantized activations a unit meets: in global memory (cdna4_gemv_args: the workspace ggml_cdna4_prepare_act filled) or in LDS (lds_act:
+// the one-launch and staged forms).  In LDS a lane reads the 16-byte chunks of ITS unit, i.e. lanes stride 64 (K-quants) or 32 bytes: 4-way /
+// 2-way bank conflicts on every ds_read_b128 (the 16 lanes of a read group would share a quarter / half of the 64 banks).  So the int8 row
+// is stored with its chunk index XOR-swizzled, c -> c ^ ((c >> 4) & 3): conflict-free for both unit sizes under the read groups of
+// MI355X_MICROARCH.md (checked by brute force); writers (quantizer, staging copy) and readers go through lds_swz().
+struct lds_act { const int8_t *qs; const float *d; const int16_t *bsums; int K; };
+__device__ __forceinline__ int lds_swz(int byte_off) { const int c = byte_off >> 4; return ((c ^ ((c >> 4) & 3)) << 4) | (byte_off & 15); }
+template <typename ACT> __device__ __forceinline__ u32x4 act_ld16(const ACT &, const int8_t *row, int off) { return ld_u32x4(row + off); }
+__device__ __forceinline__ u32x4 act_ld16(const lds_act &, const int8_t *row, int off) { return ld_u32x4(row + lds_swz(off)); }
+
 // Every unit is split into load() — all of the unit's weight bytes into registers, no activation dependence — and
 // mac() — the integer dots against the quantized activations.  dot() = mac(load()).  The fused decode kernel calls
 // load() BEFORE it quantizes the activation row, so the weight stream's HBM latency overlaps the quantizer.
@@ -43,8 +53,8 @@ template <int NB> struct Unit<CDNA4_Q4_K, NB> {
         const uint32_t w[8] = {wr.q0.x, wr.q0.y, wr.q0.z, wr.q0.w, wr.q1.x, wr.q1.y, wr.q1.z, wr.q1.w};
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            const int8_t *y = a.qs + (int64_t)col[c] * a.K + sb * 256 + 64 * g;
-            const u32x4 y0 = ld_u32x4(y), y1 = ld_u32x4(y + 16), y2 = ld_u32x4(y + 32), y3 = ld_u32x4(y + 48);
+            const int8_t *yr = a.qs + (int64_t)col[c] * a.K; const int yo = sb * 256 + 64 * g;
+            const u32x4 y0 = act_ld16(a, yr, yo), y1 = act_ld16(a, yr, yo + 16), y2 = act_ld16(a, yr, yo + 32), y3 = act_ld16(a, yr, yo + 48);
             const uint32_t yl[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
             const uint32_t yh[8] = {y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
             int sl = 0, sh = 0;
@@ -88,8 +98,8 @@ template <int NB> struct Unit<CDNA4_Q5_K, NB> {
         }
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            const int8_t *y = a.qs + (int64_t)col[c] * a.K + sb * 256 + 64 * g;
-            const u32x4 y0 = ld_u32x4(y), y1 = ld_u32x4(y + 16), y2 = ld_u32x4(y + 32), y3 = ld_u32x4(y + 48);
+            const int8_t *yr = a.qs + (int64_t)col[c] * a.K; const int yo = sb * 256 + 64 * g;
+            const u32x4 y0 = act_ld16(a, yr, yo), y1 = act_ld16(a, yr, yo + 16), y2 = act_ld16(a, yr, yo + 32), y3 = act_ld16(a, yr, yo + 48);
             const uint32_t yl[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
             const uint32_t yh[8] = {y2.x, y2.y, y2.z, y2.w, y3.x, y3.y, y3.z, y3.w};
             int sl = 0, sh = 0;
@@ -131,12 +141,12 @@ template <int NB> struct Unit<CDNA4_Q6_K, NB> {
         const int sb = u >> 2, n = (u >> 1) & 1, lb = u & 1;
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            const int8_t *y = a.qs + (int64_t)col[c] * a.K + sb * 256 + 128 * n + 16 * lb;
+            const int8_t *yr = a.qs + (int64_t)col[c] * a.K; const int yo = sb * 256 + 128 * n + 16 * lb;
             const int16_t *bs = a.bsums + (int64_t)col[c] * (a.K / 16) + sb * 16 + 8 * n + lb;
             int isum = 0;
 #pragma unroll
             for (int qd = 0; qd < 4; qd++) {
-                const u32x4 yv = ld_u32x4(y + 32 * qd);
+                const u32x4 yv = act_ld16(a, yr, yo + 32 * qd);
                 int s = dot4(wr.q[qd][0], yv.x, 0); s = dot4(wr.q[qd][1], yv.y, s); s = dot4(wr.q[qd][2], yv.z, s); s = dot4(wr.q[qd][3], yv.w, s);
                 isum += wr.sc[qd] * (s - 32 * (int)bs[2 * qd]);             // sum (q-32)*y = sum q*y - 32*bsum
             }
@@ -172,8 +182,8 @@ template <int NB> struct Unit<CDNA4_Q5_0, NB> {
         }
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            const int8_t *y = a.qs + (int64_t)col[c] * a.K + u * 32;
-            const u32x4 y0 = ld_u32x4(y), y1 = ld_u32x4(y + 16);
+            const int8_t *yr = a.qs + (int64_t)col[c] * a.K; const int yo = u * 32;
+            const u32x4 y0 = act_ld16(a, yr, yo), y1 = act_ld16(a, yr, yo + 16);
             const uint32_t yl[4] = {y0.x, y0.y, y0.z, y0.w}, yh[4] = {y1.x, y1.y, y1.z, y1.w};
             int s = 0, ys = 0;
 #pragma unroll
@@ -204,13 +214,13 @@ template <int NB> struct Unit<CDNA4_Q2_K, NB> {
         const int sb = u >> 2, idx = u & 3, j = u & 1;
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            const int8_t *y = a.qs + (int64_t)col[c] * a.K + sb * 256 + 64 * idx;
+            const int8_t *yr = a.qs + (int64_t)col[c] * a.K; const int yo = sb * 256 + 64 * idx;
             const int16_t *bs = a.bsums + (int64_t)col[c] * (a.K / 16) + sb * 16 + 4 * idx;
             int isum = 0, summs = 0;
 #pragma unroll
             for (int t = 0; t < 4; t++) {                                   // sub-block t = (shift 2j + (t >> 1), byte half t & 1): k 16 t .. 16 t + 15 of the unit
                 const int sh = 2 * (2 * j + (t >> 1)), half = t & 1;
-                const u32x4 yv = ld_u32x4(y + 16 * t);
+                const u32x4 yv = act_ld16(a, yr, yo + 16 * t);
                 const uint32_t yy[4] = {yv.x, yv.y, yv.z, yv.w};
                 int s = 0;
 #pragma unroll
@@ -245,13 +255,13 @@ template <int NB> struct Unit<CDNA4_Q3_K, NB> {
         const int sb = u >> 2, idx = u & 3, n = (u >> 1) & 1, j = u & 1;
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            const int8_t *y = a.qs + (int64_t)col[c] * a.K + sb * 256 + 64 * idx;
+            const int8_t *yr = a.qs + (int64_t)col[c] * a.K; const int yo = sb * 256 + 64 * idx;
             const int16_t *bs = a.bsums + (int64_t)col[c] * (a.K / 16) + sb * 16 + 4 * idx;
             int isum = 0;
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int s2 = 2 * j + (t >> 1), half = t & 1;               // shift index 0..3 within the 128-half; hmask bit 4n + s2
-                const u32x4 yv = ld_u32x4(y + 16 * t);
+                const u32x4 yv = act_ld16(a, yr, yo + 16 * t);
                 const uint32_t yy[4] = {yv.x, yv.y, yv.z, yv.w};
                 int s = 0;
 #pragma unroll
@@ -281,8 +291,8 @@ template <int NB> struct Unit<CDNA4_Q4_0, NB> {
     template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            const int8_t *y = a.qs + (int64_t)col[c] * a.K + u * 32;
-            const u32x4 y0 = ld_u32x4(y), y1 = ld_u32x4(y + 16);
+            const int8_t *yr = a.qs + (int64_t)col[c] * a.K; const int yo = u * 32;
+            const u32x4 y0 = act_ld16(a, yr, yo), y1 = act_ld16(a, yr, yo + 16);
             const uint32_t yl[4] = {y0.x, y0.y, y0.z, y0.w}, yh[4] = {y1.x, y1.y, y1.z, y1.w};
             int s = 0, ys = 0;
 #pragma unroll
@@ -310,8 +320,8 @@ template <int NB> struct Unit<CDNA4_Q8_0, NB> {
     template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            const int8_t *y = a.qs + (int64_t)col[c] * a.K + u * 32;
-            const u32x4 y0 = ld_u32x4(y), y1 = ld_u32x4(y + 16);
+            const int8_t *yr = a.qs + (int64_t)col[c] * a.K; const int yo = u * 32;
+            const u32x4 y0 = act_ld16(a, yr, yo), y1 = act_ld16(a, yr, yo + 16);
             const uint32_t yv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
             int s = 0;
 #pragma unroll
@@ -402,7 +412,6 @@ static int launch_type(const cdna4_gemv_args &a0, hipStream_t st) {
 // workgroup touched it), then its four waves run the same Unit::dot bodies against LDS.  The redundant
 // quantization costs ~0.5 us of VALU per workgroup and saves a ~3 us kernel plus the launch gap.
 // (Touching the wave's weight row before the quantization to overlap its HBM latency was measured SLOWER: 7.2 vs 6.1 us.)
-struct lds_act { const int8_t *qs; const float *d; const int16_t *bsums; int K; };
 
 // NW waves per work-group, ROWS weight rows per wave.  The quantizer's cost is per WORK-GROUP (every work-group redoes the
 // whole row), so fewer, fatter work-groups pay it less often: <4,1> = 1024 work-groups at M=4096, <8,2> = 256 (one per CU).
@@ -494,13 +503,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
         u32x4 pk;
         { const int q0[4] = {q[0], q[1], q[2], q[3]}, q1[4] = {q[4], q[5], q[6], q[7]}, q2[4] = {q[8], q[9], q[10], q[11]}, q3[4] = {q[12], q[13], q[14], q[15]};
           pk.x = pack4i8(q0); pk.y = pack4i8(q1); pk.z = pack4i8(q2); pk.w = pack4i8(q3); }
-        *reinterpret_cast<u32x4 *>(sq + col * K + c * 16) = pk;
+        *reinterpret_cast<u32x4 *>(sq + col * K + lds_swz(c * 16)) = pk;
     };
     if constexpr (PREQ) {
         // 16-byte copies: int8 rows (K bytes each), then bsums (K/8 bytes each), then scales (4 nqd bytes each; nqd % 4 == 0 is required)
         for (int id = threadIdx.x; id < total; id += NW * 64) {
             const int col = id / nch, c = id % nch, sc = min(col, a.ncol - 1);
-            *reinterpret_cast<u32x4 *>(sq + col * K + c * 16) = *reinterpret_cast<const u32x4 *>(a.qs + (int64_t)sc * K + c * 16);
+            *reinterpret_cast<u32x4 *>(sq + col * K + lds_swz(c * 16)) = *reinterpret_cast<const u32x4 *>(a.qs + (int64_t)sc * K + c * 16);
         }
         if (KQ) for (int id = threadIdx.x; id < NB * (nch / 8); id += NW * 64) {
             const int col = id / (nch / 8), c = id % (nch / 8), sc = min(col, a.ncol - 1);
