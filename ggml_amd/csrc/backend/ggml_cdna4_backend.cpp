@@ -237,6 +237,14 @@ struct use_counts {
 static bool is_row_vector_f32(const ggml_tensor * t, int64_t n) {
     return t && t->type == GGML_TYPE_F32 && t->ne[0] == n && t->ne[1] == 1 && t->ne[2] == 1 && t->ne[3] == 1 && t->nb[0] == sizeof(float) && t->data;
 }
+// The graph allocator hands the memory of a tensor whose last reader has been scheduled to later nodes — node by node that is safe; a
+// fused launch reads the chain's INPUT while it writes the chain's LAST node, so the two must not share memory (an exact alias is fine for
+// the row-local kernels — each element / row is read by the thread that writes it — never for MUL_MAT, whose every output reads all of X).
+static bool mem_overlap(const ggml_tensor * a, const ggml_tensor * b) {
+    const char * pa = (const char *)a->data, * pb = (const char *)b->data;
+    return pa < pb + ggml_nbytes(b) && pb < pa + ggml_nbytes(a);
+}
+static bool alias_or_disjoint(const ggml_tensor * in, const ggml_tensor * out) { return in->data == out->data || !mem_overlap(in, out); }
 static const ggml_tensor * other_src(const ggml_tensor * op, const ggml_tensor * t) { return op->src[0] == t ? op->src[1] : (op->src[1] == t ? op->src[0] : nullptr); }
 
 // MUL_MAT at node i with its tail; returns the number of nodes consumed (0 = no chain here)
@@ -262,6 +270,8 @@ static int try_fused_mul_mat(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, co
             }
         }
     }
+    if (mem_overlap(last, b) || mem_overlap(last, a) || mem_overlap(last, bias)) return 0;       // (see mem_overlap)
+    if (resid && !alias_or_disjoint(resid, last)) return 0;
     void * ws = ctx->need_ws(ggml_cdna4_mul_mat_workspace_size((int)a->type, K, B));
     if (!ws) { st = GGML_STATUS_ALLOC_FAILED; return used; }
     const int rc = ggml_cdna4_mul_mat_fused((int)a->type, a->data, (int64_t)a->nb[1], (const float *)b->data, (int64_t)(b->nb[1] / sizeof(float)),
@@ -291,6 +301,7 @@ static int try_fused_norm(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, const
             if (is_row_vector_f32(sh, nm->ne[0])) { shift = sh; last = n2; used = 3; }
         }
     }
+    if (!alias_or_disjoint(nm->src[0], last) || mem_overlap(last, gain) || (shift && mem_overlap(last, shift))) return 0;
     float eps; memcpy(&eps, nm->op_params, sizeof(float));
     const ggml_cdna4_tensor dx = tdesc(nm->src[0]), dg = tdesc(gain), dd = tdesc(last);
     ggml_cdna4_tensor ds{}; if (shift) ds = tdesc(shift);
@@ -308,7 +319,7 @@ static int try_fused_soft_max(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, c
     float pre, scale, max_bias;
     memcpy(&pre, sc->op_params, 4); memcpy(&scale, (const float *)sm->op_params + 0, 4); memcpy(&max_bias, (const float *)sm->op_params + 1, 4);
     const int n_past = ((const int32_t *)dm->op_params)[0];
-    if (n_past < 0) return 0;
+    if (n_past < 0 || !alias_or_disjoint(sc->src[0], sm)) return 0;
     const ggml_cdna4_tensor dx = tdesc(sc->src[0]), dd = tdesc(sm);
     if (ggml_cdna4_op_soft_max_ext(&dx, nullptr, &dd, scale, max_bias, 1, pre, n_past, ctx->stream)) {
         fprintf(stderr, "ggml-cdna4: fused SOFT_MAX failed: %s\n", ggml_cdna4_last_error()); st = GGML_STATUS_FAILED;
