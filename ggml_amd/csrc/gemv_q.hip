@@ -577,7 +577,9 @@ static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st
 template <int TYPE, int NB>
 static int launch_fused_nb(const cdna4_gemv_args &a, const float *x, int64_t x_row_stride, hipStream_t st) {
     const size_t lds = (size_t)NB * cdna4_gemv_fused_lds_bytes(TYPE, a.K);
-    static bool raised = false;
+    static bool raised_[16] = {};                                       // (a function attribute is per device)
+    int dev_ = 0; if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 16) { (void)hipGetLastError(); dev_ = 0; }
+    bool &raised = raised_[dev_];
     if (!raised) { if (hipFuncSetAttribute((const void *)k_gemv_q_fused<TYPE, 8, 2, false, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { (void)hipGetLastError(); return cdna4_set_error_msg("gemv_q_fused: cannot raise the dynamic LDS limit"); } raised = true; }
     hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2, false, NB>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x, x_row_stride);
     CDNA4_CHECK_LAUNCH();
@@ -590,7 +592,9 @@ static int launch_fused_n(const cdna4_gemv_args &a, const float *x, int64_t x_ro
 template <int TYPE, int NB>
 static int launch_staged_nb(const cdna4_gemv_args &a, hipStream_t st) {
     const size_t lds = (size_t)NB * cdna4_gemv_fused_lds_bytes(TYPE, a.K);
-    static bool raised = false;
+    static bool raised_[16] = {};                                       // (a function attribute is per device)
+    int dev_ = 0; if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 16) { (void)hipGetLastError(); dev_ = 0; }
+    bool &raised = raised_[dev_];
     if (!raised) { if (hipFuncSetAttribute((const void *)k_gemv_q_fused<TYPE, 8, 2, false, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { (void)hipGetLastError(); return cdna4_set_error_msg("gemv_q_staged: cannot raise the dynamic LDS limit"); } raised = true; }
     hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2, false, NB, true>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, (const float *)nullptr, (int64_t)0);
     CDNA4_CHECK_LAUNCH();

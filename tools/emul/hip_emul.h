@@ -32,6 +32,7 @@ struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 template <typename F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return 0; }
 
