@@ -95,6 +95,21 @@ def test_64x128_wave_tile_kernel_source_on_the_cpu(m, k, b, splitk, tm):
         assert mod.run(m, k, b, seed=m + k, timeout=900, splitk=splitk, kernel="t64", exp=tm, defer_dma=defer) < 1e-6
 
 
+@pytest.mark.parametrize("m,k,b,e", [(128, 512, 384, 2), (256, 1024, 512, 3)])
+def test_grouped_mul_mat_id_kernel_source_on_the_cpu(m, k, b, e):
+    """k_gemm_kq_t64<Q4_K, 128, IDS> (the grouped MUL_MAT_ID launch): per-tile expert matrices, an unused tile whose work-groups exit, padding
+    rows that are not stored, output rows scattered through row_dst — against the per-expert fp16 product, DMA landing immediately and late"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("emul_check", os.path.join(ROOT, "tools", "emul", "emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for defer in (False, True):
+        err, untouched = mod.run_ids(m, k, b, e, seed=m + e, defer_dma=defer)
+        assert err < 1e-6 and untouched
+
+
 def test_64x128_wave_tile_kernel_counted_waits_are_tight(monkeypatch):
     if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
         pytest.skip("ROCm clang not available")

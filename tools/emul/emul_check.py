@@ -74,6 +74,46 @@ def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="w12", exp=0, xchg_l2=1, 
 
 
 
+def run_ids(M, K, B, E, seed=1, timeout=900, defer_dma=False):
+    """the grouped MUL_MAT_ID form of k_gemm_kq_t64 (IDS = true): E stacked Q4_K experts of M rows, an expert-sorted activation image of
+    B rows (tile t -> expert t % E, tile 1 unused, every 7th row padding, output row = B - 1 - r: the tables t64_emul builds under EMU_IDS);
+    returns (rel-L2 over the written rows, whether every other output element was left untouched)"""
+    rng = np.random.default_rng(seed)
+    nsb = K // 256
+    w = R.random_weights(R.Q4_K, E * M, K, seed).reshape(E * M, nsb, 144)
+    xh = rng.uniform(-1, 1, (B, K)).astype(np.float16)
+    img = np.zeros((K // 128, B, 128), np.float16)
+    for p in range(128):
+        img[:, :, p] = xh[:, [pan * 128 + (p & ~3) + LC.PERM[p & 3] for pan in range(K // 128)]].T
+    wd = np.zeros((E * M, K), np.float64)
+    for m in range(E * M):
+        for sb in range(nsb):
+            for G in range(4):
+                sl, cl, sh, ch = LC.table_entry(w[m, sb], G, 8.0)
+                qs = w[m, sb, 16 + 32 * G:][:32]
+                wd[m, sb * 256 + 64 * G:][:32] = ((qs & 15).astype(np.float64) - 8.0) * np.float64(sl) + np.float64(cl)
+                wd[m, sb * 256 + 64 * G + 32:][:32] = ((qs >> 4).astype(np.float64) - 8.0) * np.float64(sh) + np.float64(ch)
+    wd = wd.astype(np.float16).astype(np.float64)
+    want = np.full((B, M), -12345.0)
+    for r in range(B):
+        t = r // 128
+        if t == 1 or r % 7 == 3:
+            continue
+        e = t % E
+        want[B - 1 - r] = xh[r].astype(np.float64) @ wd[e * M:(e + 1) * M].T
+    with tempfile.TemporaryDirectory() as d:
+        w.tofile(os.path.join(d, "w.bin")); img.tofile(os.path.join(d, "xh.bin"))
+        r = subprocess.run([build("t64"), str(M), str(K), str(B), os.path.join(d, "w.bin"), os.path.join(d, "xh.bin"), os.path.join(d, "y.bin"), "1", "128", "0", str(R.Q4_K)],
+                           capture_output=True, text=True, timeout=timeout, env=dict(os.environ, EMU_IDS=str(E), EMU_DEFER_DMA="1" if defer_dma else "0"))
+        if r.returncode == 77:
+            import pytest
+            pytest.skip("the environment cannot host the emulation (process / thread limits)")
+        assert r.returncode == 0, r.stderr[-500:]
+        y = np.fromfile(os.path.join(d, "y.bin"), np.float32).reshape(B, M).astype(np.float64)
+    written = want != -12345.0
+    return np.linalg.norm(y[written] - want[written]) / np.linalg.norm(want[written]), bool(np.array_equal(y[~written], want[~written]))
+
+
 if __name__ == "__main__":
     M, K, B = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 512, 128)
     S = int(sys.argv[4]) if len(sys.argv) > 4 else 1

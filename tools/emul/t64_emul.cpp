@@ -108,6 +108,19 @@ int main(int argc, char **argv) {
         p.xchg_l2 = splitk == 2 ? l2 : 0;
         if (splitk != 2 && splitk != 4 && splitk != 8) { fprintf(stderr, "splitk 1, 2, 4 or 8\n"); return 2; }
     } else if (splitk != 1) { fprintf(stderr, "splitk 1, 2, 4 or 8\n"); return 2; }
+    if (const char *e_ = getenv("EMU_IDS")) {
+        // grouped MUL_MAT_ID form: the weight file holds E stacked expert matrices of M rows; image tile t (128 rows) belongs to expert
+        // t % E, except tile 1 which is unused (-1: its work-groups exit); image row r is output row B - 1 - r, every 7th row is padding (-1)
+        const int E = atoi(e_);
+        if (B % 128 || M % 128 || splitk != 1 || tm != 128) { fprintf(stderr, "IDS: B, M multiples of 128, no split\n"); return 2; }
+        int32_t *te = (int32_t *)shared_alloc((size_t)(B / 128) * 4), *rd = (int32_t *)shared_alloc((size_t)B * 4);
+        for (int t = 0; t < B / 128; t++) te[t] = t == 1 ? -1 : t % E;
+        for (int r = 0; r < B; r++) rd[r] = r % 7 == 3 ? -1 : B - 1 - r;
+        p.tiles_m = M / 128; p.tiles_b = B / 128; p.tile_expert = te; p.row_dst = rd; p.w_expert_bytes = (int64_t)M * p.w_row_bytes;
+        emu_launch([&] { k_gemm_kq_t64<CDNA4_Q4_K, 128, true>(p); }, (unsigned)(p.tiles_m * p.tiles_b), 512);
+        FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)B * M, f); fclose(f);
+        return 0;
+    }
     const unsigned nblk = (unsigned)(ntiles * splitk);
     if (tm == 128) emu_launch([&] { k_gemm_kq_t64<CDNA4_Q4_K, 128>(p); }, nblk, 512);
     else emu_launch([&] { k_gemm_kq_t64<CDNA4_Q4_K, 256>(p); }, nblk, 512);
