@@ -197,7 +197,7 @@ static void cdna4_backend_free(ggml_backend_t backend) {
     (void)hipStreamSynchronize(ctx->stream);
     cdna4_split_free_lanes(ctx);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "ggml-cdna4: %s: %d HIP-graph captures, %d replays\n", ctx->name.c_str(), ctx->n_graph_captures, ctx->n_graph_launches);
-    if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+    for (auto & gs : ctx->graph_slots) if (gs.exec) (void)hipGraphExecDestroy(gs.exec);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     if (ctx->ws) (void)hipFree(ctx->ws);
     (void)hipStreamDestroy(ctx->stream);
@@ -386,43 +386,59 @@ static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph)
 // A graph that comes back UNCHANGED (same nodes, shapes, addresses and parameters: graph_signature) is captured into a HIP graph on its
 // second appearance and replayed from then on — one hipGraphLaunch instead of one launch per node (the counterpart of the CUDA-graph
 // path of ggml-cuda.cu:2417-2694, without its parameter patching: a graph that changes, like a decode step whose KV views move every
-// token, simply stays on plain launches).  The first appearance always runs eagerly, which also sizes every workspace, so that the
-// capture itself allocates nothing.  Everything the kernels need is capturable: one stream, no host synchronisation, and the split-K
-// exchange flags are reset by their readers (gemm_w8_epilogue.inc / gemm_kq_t64.inc).  Row-split weights (several streams and devices)
-// stay on plain launches.  GGML_CDNA4_NO_GRAPHS=1 turns it off; a failed capture turns it off for the backend instance.
+// token, simply stays on plain launches).  CDNA4_GRAPH_SLOTS graphs are remembered at a time, the least recently used one replaced,
+// so that the splits ggml_backend_sched cuts one model graph into (each its own graph_compute call, in turn) all replay.  The first
+// appearance always runs eagerly, which also sizes every workspace, so that the capture itself allocates nothing.  Everything the
+// kernels need is capturable: one stream, no host synchronisation, and the split-K exchange flags are reset by their readers
+// (gemm_w8_epilogue.inc / gemm_kq_t64.inc).  Row-split weights (several streams and devices) stay on plain launches.
+// GGML_CDNA4_NO_GRAPHS=1 turns it off; a failed capture turns it off for the backend instance.
 static enum ggml_status cdna4_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
     cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
     HIP_OK(hipSetDevice(ctx->device));
     static const bool no_graphs = getenv("GGML_CDNA4_NO_GRAPHS") != nullptr;
     if (no_graphs || ctx->graphs_off || ggml_graph_n_nodes(cgraph) < 2) return run_nodes(ctx, cgraph);
-    const uint64_t sig = graph_signature(cgraph);
+    uint64_t sig = graph_signature(cgraph);
+    if (sig == 0) sig = 1;                                                     // (0 marks an unused slot)
     // addresses the captured launches hold beyond the tensors': this context's workspace and the kernel library's scratch
     const uint64_t gen = ggml_cdna4_scratch_generation() * 0x9E3779B97F4A7C15ull + ctx->ws_gen;
-    if (sig == ctx->graph_exec_sig && ctx->graph_exec && gen == ctx->graph_exec_gen) {
-        HIP_OK(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+    cdna4_backend_ctx::graph_slot * slot = nullptr, * lru = &ctx->graph_slots[0];
+    for (auto & gs : ctx->graph_slots) {
+        if (gs.sig == sig) { slot = &gs; break; }
+        if (gs.last_use < lru->last_use) lru = &gs;
+    }
+    const uint64_t now = ++ctx->graph_clock;
+    if (slot && slot->exec && slot->gen == gen) {
+        slot->last_use = now;
+        HIP_OK(hipGraphLaunch(slot->exec, ctx->stream));
         ctx->n_graph_launches++;
         return GGML_STATUS_SUCCESS;
     }
-    ctx->graph_sig_repeats = sig == ctx->graph_sig ? ctx->graph_sig_repeats + 1 : 0;
-    ctx->graph_sig = sig;
-    if (ctx->graph_sig_repeats < 1 || graph_has_split_weights(cgraph)) return run_nodes(ctx, cgraph);
-    // second appearance in a row: capture, instantiate, launch
-    if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; ctx->graph_exec_sig = 0; }
+    if (!slot) {                                                               // first appearance: remember it, run it eagerly
+        if (lru->exec) { (void)hipGraphExecDestroy(lru->exec); lru->exec = nullptr; }
+        lru->sig = sig; lru->last_use = now;
+        return run_nodes(ctx, cgraph);
+    }
+    slot->last_use = now;
+    // captured against a workspace or scratch block that has moved since (both only ever grow, and this graph has run before: the
+    // new capture allocates nothing)
+    if (slot->exec) { (void)hipGraphExecDestroy(slot->exec); slot->exec = nullptr; }
+    if (graph_has_split_weights(cgraph)) return run_nodes(ctx, cgraph);
+    // second appearance: capture, instantiate, launch
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); ctx->graphs_off = true; return run_nodes(ctx, cgraph); }
     const enum ggml_status st = run_nodes(ctx, cgraph);
     const hipError_t ee = hipStreamEndCapture(ctx->stream, &graph);
-    if (st != GGML_STATUS_SUCCESS || ee != hipSuccess || !graph || hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    if (st != GGML_STATUS_SUCCESS || ee != hipSuccess || !graph || hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
         (void)hipGetLastError();
         if (graph) (void)hipGraphDestroy(graph);
-        ctx->graph_exec = nullptr; ctx->graphs_off = true;
+        slot->exec = nullptr; ctx->graphs_off = true;
         fprintf(stderr, "ggml-cdna4: HIP-graph capture failed, staying on plain launches\n");
         return run_nodes(ctx, cgraph);                                     // nothing has run yet: the capture only recorded
     }
     (void)hipGraphDestroy(graph);
-    ctx->graph_exec_sig = sig; ctx->n_graph_captures++;
-    ctx->graph_exec_gen = ggml_cdna4_scratch_generation() * 0x9E3779B97F4A7C15ull + ctx->ws_gen;     // (the eager first run sized everything: unchanged by the capture)
-    HIP_OK(hipGraphLaunch(ctx->graph_exec, ctx->stream));
+    ctx->n_graph_captures++;
+    slot->gen = ggml_cdna4_scratch_generation() * 0x9E3779B97F4A7C15ull + ctx->ws_gen;     // (the eager first run sized everything: unchanged by the capture)
+    HIP_OK(hipGraphLaunch(slot->exec, ctx->stream));
     ctx->n_graph_launches++;
     return GGML_STATUS_SUCCESS;
 }

@@ -24,6 +24,7 @@ struct cdna4_lane {
     void * ws = nullptr; size_t ws_bytes = 0;     // ggml_cdna4_mul_mat workspace
 };
 
+#define CDNA4_GRAPH_SLOTS 4
 struct cdna4_backend_ctx {
     int device; hipStream_t stream; std::string name;
     void * ws = nullptr; size_t ws_size = 0;
@@ -31,9 +32,14 @@ struct cdna4_backend_ctx {
     hipEvent_t ev_copy = nullptr;                 // cpy_tensor_async between two backends
     cdna4_lane lanes[CDNA4_MAX_DEVICES];
     // HIP-graph replay of a compute graph that comes back unchanged (ggml_cdna4_backend.cpp: graph_compute)
-    uint64_t graph_sig = 0; int graph_sig_repeats = 0;        // signature of the last graph_compute call, how often in a row it was seen
-    hipGraphExec_t graph_exec = nullptr; uint64_t graph_exec_sig = 0;
-    uint64_t graph_exec_gen = 0;                              // library-scratch generation + this context's workspace generation at capture time
+    // a few graphs at a time (a ggml_backend_sched graph reaches one backend as several splits, in turn), least recently used replaced
+    struct graph_slot {
+        uint64_t sig = 0;                                     // graph_signature of the graph seen (0: slot unused)
+        uint64_t gen = 0;                                     // library-scratch generation + this context's workspace generation at capture time
+        uint64_t last_use = 0;
+        hipGraphExec_t exec = nullptr;                        // null: seen once, not captured yet
+    } graph_slots[CDNA4_GRAPH_SLOTS];
+    uint64_t graph_clock = 0;
     uint64_t ws_gen = 0;
     bool graphs_off = false;                                  // a capture failed once: stay on plain launches
     int n_graph_launches = 0, n_graph_captures = 0;           // (statistics, printed at free under GGML_CDNA4_STATS)

@@ -181,6 +181,18 @@ int main(int argc, char ** argv) {
             for (int i = 0; i < 6; i++) { const double e = rel_l2(yg[i], yc[i]); if (e > replay_worst) replay_worst = e; if (!(e < 1e-2)) replay_ok = false; }      // (two chained quantized products and an fp16-table GELU: the CPU's own formats differ at 1e-3)
             if (memcmp(yg[0].data(), yg[4].data(), yg[0].size() * 4) != 0) replay_ok = false;
         }
+        // two graphs taking turns on one backend (what ggml_backend_sched's splits look like to it): both are captured on their second
+        // appearance and replayed on the third, each from its own slot
+        {
+            std::vector<float> xa((size_t)D * 2), xb((size_t)D * 160);
+            for (auto & v : xa) v = u(rng);
+            for (auto & v : xb) v = u(rng);
+            mlp_block a(gpu, type, D, H, 2, w1, w2, vec), b(gpu, type, D, H, 160, w1, w2, vec);
+            std::vector<float> ya[3], yb[3];
+            for (int i = 0; i < 3; i++) { ya[i] = a.compute(xa); yb[i] = b.compute(xb); }                     // eager, captured, replayed
+            for (int i = 1; i < 3; i++)
+                if (memcmp(ya[0].data(), ya[i].data(), ya[0].size() * 4) != 0 || memcmp(yb[0].data(), yb[i].data(), yb[0].size() * 4) != 0) { replay_ok = false; fprintf(stderr, "alternating graphs: replay differs\n"); }
+        }
         // a captured graph holds the addresses of the backend's workspace and of the kernel library's scratch: a LARGER graph computed in
         // between moves both, and the small graph must be re-captured, not replayed with the stale addresses
         {
@@ -190,7 +202,7 @@ int main(int argc, char ** argv) {
             mlp_block small(gpu2, type, D, H, 96, w1, w2, vec);
             const std::vector<float> y0 = small.compute(xs); small.compute(xs); small.compute(xs);          // eager, capture, replay
             { mlp_block large(gpu2, type, D, H, 8192, w1, w2, vec); large.compute(xl); }   // ONE eager run: grows workspace + split-K scratch, the small graph's exec stays cached
-            for (int i = 0; i < 3; i++) {                                                 // stale exec dropped; eager, re-captured, replayed
+            for (int i = 0; i < 3; i++) {                                                 // stale exec dropped: re-captured at once (nothing left to size), replayed, replayed
                 const std::vector<float> y1 = small.compute(xs);
                 if (memcmp(y0.data(), y1.data(), y0.size() * 4) != 0) { replay_ok = false; fprintf(stderr, "replay after a workspace move differs\n"); }
             }
