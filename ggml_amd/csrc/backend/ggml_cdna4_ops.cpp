@@ -92,6 +92,9 @@ enum ggml_status cdna4_ops_compute(void * ctx, ggml_tensor * node) {
         // F32 -> Q8_0 with the CPU backend's own from_float (type_traits_cpu[Q8_0].from_float = the SIMD quantize_row_q8_0, which is what
         // ggml_compute_forward_dup_f32 calls: ggml-cpu.c:3230-3260) — measured: byte-identical to the reference's CPY, whereas
         // quantize_row_q8_0_ref (ggml-cuda's rounding) differs from it on exact .5 ties
+        // F32 -> Q8_0: the rounding of the CPU backend's from_float on the oracle's x86 hosts (ggml-cpu.c:2965 -> quantize_row_q8_0,
+        // AVX2 form: id = 127 / amax, nearest-even), which is also what the activation quantizer uses; quantize_row_q8_0_ref and
+        // ggml-cuda/cpy.cu:61 use id = 1 / d with roundf instead (C-ABI callers get that with q8_0_ref_rounding = 1)
         case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: rc = ggml_cdna4_op_cpy(&da, &dd, /*q8_0_ref_rounding=*/0, stream); break;
         case GGML_OP_MUL_MAT: rc = ggml_cdna4_op_mul_mat_f(&da, &db, &dd, stream); break;
         case GGML_OP_ROPE: {
