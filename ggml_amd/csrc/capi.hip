@@ -15,7 +15,8 @@ int cdna4_set_error(hipError_t e, const char *file, int line) {
 int cdna4_set_error_msg(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); return -1; }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-// Q5_0 / Q2_K / Q3_K run through the int8-dot GEMV units of gemv_q.hip at every batch size (no MFMA GEMM for them yet)
+// Q5_0 / Q3_K: int8-dot GEMV units of gemv_q.hip for up to 8 activation rows, above that the Q8_0 / Q6_K MFMA GEMM on an exact
+// re-encoding of the weights (convert_w.hip).  Q2_K: the GEMV units at every batch size (no MFMA GEMM yet)
 static inline bool is_kq(int t) { return t == CDNA4_Q4_K || t == CDNA4_Q5_K || t == CDNA4_Q6_K || t == CDNA4_Q2_K || t == CDNA4_Q3_K; }
 static inline bool is_q(int t) { return is_kq(t) || t == CDNA4_Q4_0 || t == CDNA4_Q8_0 || t == CDNA4_Q5_0; }
 
@@ -64,6 +65,7 @@ size_t ggml_cdna4_row_size(int type, int64_t k) {
         case CDNA4_Q6_K: return k % 256 ? 0 : (size_t)(k / 256) * 210;
         case CDNA4_Q5_0: return k % 32 ? 0 : (size_t)(k / 32) * 22; case CDNA4_Q2_K: return k % 256 ? 0 : (size_t)(k / 256) * 84;
         case CDNA4_Q3_K: return k % 256 ? 0 : (size_t)(k / 256) * 110;
+        case CDNA4_Q4_1: return k % 32 ? 0 : (size_t)(k / 32) * 20; case CDNA4_Q5_1: return k % 32 ? 0 : (size_t)(k / 32) * 24;
     }
     return 0;
 }
@@ -79,6 +81,19 @@ size_t ggml_cdna4_mul_mat_id_workspace_size(int type, int64_t K, int64_t n_exper
     if (type != CDNA4_Q4_K || n_tok * n_used <= 32) return plain;
     const size_t grouped = moe_carve(K, n_expert, n_used, n_tok, nullptr).total;
     return grouped > plain ? grouped : plain;
+}
+
+int ggml_cdna4_convert_weights_target(int type) { return cdna4_convert_weights_target(type); }
+size_t ggml_cdna4_convert_weights_size(int type, int64_t M, int64_t K) {
+    if (cdna4_convert_weights_target(type) < 0 || M <= 0 || K <= 0 || ggml_cdna4_row_size(type, K) == 0) return 0;
+    return cdna4_convert_weights_bytes(type, M, K);
+}
+int ggml_cdna4_convert_weights(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, void *out, void *stream) {
+    if (cdna4_convert_weights_target(type) < 0) return cdna4_set_error_msg("convert_weights: no exact target format for this type");
+    if (M <= 0) return 0;
+    if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("convert_weights: K is not a whole number of blocks");
+    if (!W || !out || w_row_bytes < (int64_t)ggml_cdna4_row_size(type, K)) return cdna4_set_error_msg("convert_weights: bad pointers or row stride");
+    return cdna4_launch_convert_weights(type, (const uint8_t *)W, w_row_bytes, M, K, (uint8_t *)out, (hipStream_t)stream);
 }
 
 int ggml_cdna4_quantize_q8_K(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d, int16_t *bsums, void *xh, void *stream) {

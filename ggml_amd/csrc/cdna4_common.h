@@ -12,8 +12,10 @@
 enum cdna4_type : int {
     CDNA4_F32 = 0, CDNA4_F16 = 1, CDNA4_Q4_0 = 2, CDNA4_Q8_0 = 8,
     CDNA4_Q4_K = 12, CDNA4_Q5_K = 13, CDNA4_Q6_K = 14, CDNA4_Q8_K = 15, CDNA4_I32 = 26,
-    // GEMV units exist (gemv_q.hip, verified on the CPU emulator only so far); accepted by the C-ABI under CDNA4_EXTRA_TYPES=1 only
+    // MUL_MAT / MUL_MAT_ID through the GEMV units of gemv_q.hip; prefill GEMM of Q5_0 / Q3_K through convert_w.hip; to_float in ops.hip
     CDNA4_Q5_0 = 6, CDNA4_Q2_K = 10, CDNA4_Q3_K = 11,
+    // to_float only (GET_ROWS, CPY -> F32, dequantize_row)
+    CDNA4_Q4_1 = 3, CDNA4_Q5_1 = 7,
 };
 
 // bytes per block / weights per block

@@ -1,0 +1,103 @@
+// convert_w.hip — EXACT re-encodings of weight formats that have no MFMA prefill kernel of their own into one that has
+// ("other formats reuse the GEMV/GEMM skeleton"):
+//
+//    Q5_0 -> Q8_0   w = d (q5 - 16)              = d q8,                 q8 = q5 - 16 in [-16, 15]         (same fp16 d)
+//    Q3_K -> Q6_K   w = d (sc6 - 32) (q3 - 4)    = d sc8 (q6 - 32),      sc8 = sc6 - 32 in [-32, 31],
+//                                                                         q6 = q3 + 28 in [28, 35]          (same fp16 d, same 16-weight groups)
+//
+// Every weight keeps its value bit for bit (dequantize_row_q5_0 / _q3_K of the source == dequantize_row_q8_0 / _q6_K of the result,
+// src/ggml-quants.c:307-331, 1139-1188 vs :349-363, 1690-1719), and source and target share their activation format on the CPU
+// (vec_dot_type Q8_0 for Q5_0 / Q8_0, Q8_K for Q3_K / Q6_K: src/ggml-cpu/ggml-cpu.c:277-302, 318-341), so the prefill product through
+// the target's GEMM is the product the reference defines for the source format.  The conversion runs per call into library scratch
+// (one read of W + one write of the larger encoding, a few microseconds at 4096 x 4096) — against 64 passes of the 8-column GEMV
+// over the weights at B = 512 without it.
+#include "cdna4_common.h"
+#include "cdna4_kernels.h"
+
+// one thread per 32-weight block: 22 bytes {fp16 d, qh[4], qs[16]} in, 34 bytes {fp16 d, int8 qs[32]} out (both 2-byte aligned)
+__global__ __launch_bounds__(256) void k_convert_q5_0_q8_0(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nblk, uint8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)M * nblk) return;
+    const int row = (int)(t / nblk), b = (int)(t % nblk);
+    const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)b * 22;
+    uint8_t *dst = out + ((int64_t)row * nblk + b) * 34;
+    const uint32_t qh = ld_u32_a2(src + 2);
+    uint32_t lo[4], hi[4];                                             // weights 4i..4i+3 / 16+4i..16+4i+3 as int8 bytes
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t q = ld_u32_a2(src + 6 + 4 * i);
+        // h0 / h1: bit (4i + e) / (16 + 4i + e) of qh in bit 0 of byte e.  Byte-wise (nibble | h << 4) - 16 as int8:
+        // h = 1: the nibble itself (0..15); h = 0: nibble - 16 = 0xF0 | nibble
+        const uint32_t h0 = ((qh >> (4 * i)) & 0xFu) * 0x00204081u & 0x01010101u, h1 = ((qh >> (16 + 4 * i)) & 0xFu) * 0x00204081u & 0x01010101u;
+        const uint32_t v0 = q & 0x0F0F0F0Fu, v1 = (q >> 4) & 0x0F0F0F0Fu;
+        lo[i] = v0 | (((h0 ^ 0x01010101u) * 0xF0u));
+        hi[i] = v1 | (((h1 ^ 0x01010101u) * 0xF0u));
+    }
+    *reinterpret_cast<uint16_t *>(dst) = ld_u16(src);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        *reinterpret_cast<uint16_t *>(dst + 2 + 4 * i) = (uint16_t)lo[i]; *reinterpret_cast<uint16_t *>(dst + 4 + 4 * i) = (uint16_t)(lo[i] >> 16);
+        *reinterpret_cast<uint16_t *>(dst + 18 + 4 * i) = (uint16_t)hi[i]; *reinterpret_cast<uint16_t *>(dst + 20 + 4 * i) = (uint16_t)(hi[i] >> 16);
+    }
+}
+
+// 18 threads per superblock: 110 bytes {hmask[32], qs[64], scales[12], fp16 d} in, 210 bytes {ql[128], qh[64], int8 scales[16], fp16 d} out.
+// Threads 0..15: (128-half n = t >> 3, bytes l = 4 (t & 7) .. + 3): weight 128 n + 32 j + l is Q3_K's (qs[32 n + l] >> 2 j) & 3 with hmask bit
+// 4 n + j of hmask[l], and Q6_K's q_(j+1) of the same (n, l): low nibbles in ql[64 n + 32 (j & 1) + l] (high half of the byte for j >= 2),
+// bits 4-5 in qh[32 n + l] >> 2 j.   Thread 16: the sixteen scales.   Thread 17: d.
+__global__ __launch_bounds__(256) void k_convert_q3_K_q6_K(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nsb, uint8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)M * nsb * 18) return;
+    const int pc = (int)(t % 18); const int64_t u = t / 18;
+    const int row = (int)(u / nsb), sb = (int)(u % nsb);
+    const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)sb * 110;
+    uint8_t *dst = out + ((int64_t)row * nsb + sb) * 210;
+    auto st32 = [](uint8_t *p, uint32_t v) { *reinterpret_cast<uint16_t *>(p) = (uint16_t)v; *reinterpret_cast<uint16_t *>(p + 2) = (uint16_t)(v >> 16); };
+    if (pc < 16) {
+        const int n = pc >> 3, l = 4 * (pc & 7);
+        const uint32_t q = ld_u32_a2(src + 32 + 32 * n + l), hm = ld_u32_a2(src + l);
+        uint32_t v[4];                                                  // q6 = (2 bits | hmask bit << 2) + 28, four bytes at a time
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = (((q >> (2 * j)) & 0x03030303u) | (((hm >> (4 * n + j)) & 0x01010101u) << 2)) + 0x1C1C1C1Cu;
+        st32(dst + 64 * n + l, (v[0] & 0x0F0F0F0Fu) | ((v[2] & 0x0F0F0F0Fu) << 4));
+        st32(dst + 64 * n + 32 + l, (v[1] & 0x0F0F0F0Fu) | ((v[3] & 0x0F0F0F0Fu) << 4));
+        st32(dst + 128 + 32 * n + l, ((v[0] >> 4) & 0x03030303u) | (((v[1] >> 4) & 0x03030303u) << 2) | (((v[2] >> 4) & 0x03030303u) << 4) | (((v[3] >> 4) & 0x03030303u) << 6));
+    } else if (pc == 16) {
+        // scale i: low nibble = scales[i] & 0xF (i < 8) or scales[i - 8] >> 4; bits 4-5 = (scales[8 + i % 4] >> 2 (i / 4)) & 3; stored - 32
+        const uint32_t a = ld_u32_a2(src + 96), b = ld_u32_a2(src + 100), c = ld_u32_a2(src + 104);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {                                   // scales 4 g .. 4 g + 3
+            const uint32_t lo = g == 0 ? (a & 0x0F0F0F0Fu) : (g == 1 ? (b & 0x0F0F0F0Fu) : (g == 2 ? ((a >> 4) & 0x0F0F0F0Fu) : ((b >> 4) & 0x0F0F0F0Fu)));
+            const uint32_t s6 = lo | (((c >> (2 * g)) & 0x03030303u) << 4);
+            // byte-wise s6 - 32 (0..63 -> -32..31): s6 >= 32: s6 - 32 = s6 & 0x1F; s6 < 32: 0xE0 | s6
+            const uint32_t ge = (s6 >> 5) & 0x01010101u;
+            st32(dst + 192 + 4 * g, (s6 & 0x1F1F1F1Fu) | ((ge ^ 0x01010101u) * 0xE0u));
+        }
+    } else {
+        *reinterpret_cast<uint16_t *>(dst + 208) = ld_u16(src + 108);
+    }
+}
+
+size_t cdna4_convert_weights_bytes(int type, int64_t M, int64_t K) {
+    if (type == CDNA4_Q5_0) return (size_t)M * (K / 32) * 34;
+    if (type == CDNA4_Q3_K) return (size_t)M * (K / 256) * 210;
+    return 0;
+}
+int cdna4_convert_weights_target(int type) { return type == CDNA4_Q5_0 ? CDNA4_Q8_0 : (type == CDNA4_Q3_K ? CDNA4_Q6_K : -1); }
+
+// W [M rows, w_row_bytes apart] of `type` -> `out` (contiguous rows of the target format); 2-byte aligned source rows
+int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes, int64_t M, int64_t K, uint8_t *out, hipStream_t st) {
+    if (M <= 0 || K <= 0) return 0;
+    if (((uintptr_t)W | (uintptr_t)w_row_bytes | (uintptr_t)out) & 1) return cdna4_set_error_msg("convert_weights: rows must be 2-byte aligned");
+    if (type == CDNA4_Q5_0) {
+        if (K % 32) return cdna4_set_error_msg("convert_weights: K must be a multiple of 32");
+        const int64_t n = M * (K / 32);
+        hipLaunchKernelGGL(k_convert_q5_0_q8_0, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 32), out);
+    } else if (type == CDNA4_Q3_K) {
+        if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");
+        const int64_t n = M * (K / 256) * 18;
+        hipLaunchKernelGGL(k_convert_q3_K_q6_K, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out);
+    } else return cdna4_set_error_msg("convert_weights: no exact target format for this type");
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}

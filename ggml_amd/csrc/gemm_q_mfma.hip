@@ -354,6 +354,8 @@ bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B) {
     switch (type) {
         case CDNA4_Q4_K: case CDNA4_Q5_K: case CDNA4_Q6_K: return K > 0 && K % 256 == 0;
         case CDNA4_Q4_0: case CDNA4_Q8_0: return K > 0 && K % 64 == 0;
+        case CDNA4_Q5_0: return K > 0 && K % 64 == 0;               // as Q8_0, after the exact re-encoding of convert_w.hip
+        case CDNA4_Q3_K: return K > 0 && K % 256 == 0;              // as Q6_K
     }
     return false;
 }
@@ -391,10 +393,10 @@ static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
 // library-owned scratch for the split-K hand-off (partial tiles + flags), grown on demand like a BLAS workspace
 // (one region per device; launches that use it are assumed to be stream-ordered on that device, as the plug-in's
 // single-stream backend and the one-process-per-GPU bench are).
-static void *g_scratch[48] = {nullptr}; static size_t g_scratch_bytes[48] = {0};
+static void *g_scratch[64] = {nullptr}; static size_t g_scratch_bytes[64] = {0};
 static std::atomic<uint64_t> g_scratch_generation{0};
 uint64_t cdna4_scratch_generation() { return g_scratch_generation.load(); }
-static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: split-K exchange buffers, 1: repacked weights, 2: exchange buffers of gemm_q_t64.hip (reader-reset flags)
+static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: split-K exchange buffers, 1: repacked weights, 2: exchange buffers of gemm_q_t64.hip (reader-reset flags), 3: re-encoded weights (convert_w.hip)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
     dev += 16 * kind;
@@ -587,6 +589,16 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
     if (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 1) return cdna4_set_error_msg("gemm_q: weight rows must be 2-byte aligned");
     if ((a.type == CDNA4_Q4_K || a.type == CDNA4_Q5_K) && (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15))
         return cdna4_set_error_msg("gemm_q: Q4_K/Q5_K rows must be 16-byte aligned");
+    if (a.type == CDNA4_Q5_0 || a.type == CDNA4_Q3_K) {
+        // no MFMA kernel of their own: re-encode EXACTLY as Q8_0 / Q6_K into scratch (convert_w.hip) and run that format's GEMM
+        uint8_t *cw = (uint8_t *)get_scratch(cdna4_convert_weights_bytes(a.type, a.M, a.K) + 256, 3);
+        if (!cw) return cdna4_set_error_msg("gemm_q: cannot allocate the weight re-encoding scratch");
+        const int rc = cdna4_launch_convert_weights(a.type, a.W, a.w_row_bytes, a.M, a.K, cw, st);
+        if (rc) return rc;
+        cdna4_gemm_args c = a; c.W = cw;
+        if (a.type == CDNA4_Q5_0) { c.type = CDNA4_Q8_0; c.w_row_bytes = (int64_t)(a.K / 32) * 34; return launch_type<CDNA4_Q8_0>(c, st); }
+        c.type = CDNA4_Q6_K; c.w_row_bytes = (int64_t)(a.K / 256) * 210; return launch_type<CDNA4_Q6_K>(c, st);
+    }
     switch (a.type) {
         case CDNA4_Q4_K: return launch_type<CDNA4_Q4_K>(a, st);
         case CDNA4_Q5_K: return launch_type<CDNA4_Q5_K>(a, st);

@@ -14,11 +14,13 @@ static inline int64_t nelem(const T4 *t) { return t->ne[0] * t->ne[1] * t->ne[2]
 static inline int64_t nrows(const T4 *t) { return t->ne[1] * t->ne[2] * t->ne[3]; }
 static inline size_t tsize(int type) {
     switch (type) { case CDNA4_F32: case CDNA4_I32: return 4; case CDNA4_F16: return 2; case CDNA4_Q4_0: return 18; case CDNA4_Q8_0: return 34;
-                    case CDNA4_Q4_K: return 144; case CDNA4_Q5_K: return 176; case CDNA4_Q6_K: return 210; }
+                    case CDNA4_Q4_K: return 144; case CDNA4_Q5_K: return 176; case CDNA4_Q6_K: return 210;
+                    case CDNA4_Q4_1: return 20; case CDNA4_Q5_0: return 22; case CDNA4_Q5_1: return 24; case CDNA4_Q2_K: return 84; case CDNA4_Q3_K: return 110; }
     return 0;
 }
 static inline int bsize(int type) {
-    switch (type) { case CDNA4_Q4_0: case CDNA4_Q8_0: return 32; case CDNA4_Q4_K: case CDNA4_Q5_K: case CDNA4_Q6_K: return 256; }
+    switch (type) { case CDNA4_Q4_0: case CDNA4_Q8_0: case CDNA4_Q4_1: case CDNA4_Q5_0: case CDNA4_Q5_1: return 32;
+                    case CDNA4_Q4_K: case CDNA4_Q5_K: case CDNA4_Q6_K: case CDNA4_Q2_K: case CDNA4_Q3_K: return 256; }
     return 1;
 }
 static inline bool is_contig(const T4 *t) {      // ggml_is_contiguous
@@ -196,6 +198,42 @@ template <> __device__ __forceinline__ float deq_elem<CDNA4_Q6_K>(const uint8_t 
     const float d = h2f(ld_u16(b + 208));
     const int8_t sc = ((const int8_t *)b)[192 + 8 * n + (l >> 4) + 2 * qd];
     return d * sc * q;
+}
+// Q4_1 {fp16 d, fp16 m, qs[16]}: q * d + m (src/ggml-quants.c:275-293)
+template <> __device__ __forceinline__ float deq_elem<CDNA4_Q4_1>(const uint8_t *row, int64_t k) {
+    const uint8_t *b = row + (k >> 5) * 20; const int j = (int)(k & 31);
+    const float d = h2f(ld_u16(b)), m = h2f(ld_u16(b + 2)); const uint8_t q = b[4 + (j & 15)];
+    return (float)(j < 16 ? (q & 0x0F) : (q >> 4)) * d + m;
+}
+// Q5_0 {fp16 d, qh[4], qs[16]}: bit j of qh is the fifth bit of weight j; (q - 16) * d (src/ggml-quants.c:295-319)
+template <> __device__ __forceinline__ float deq_elem<CDNA4_Q5_0>(const uint8_t *row, int64_t k) {
+    const uint8_t *b = row + (k >> 5) * 22; const int j = (int)(k & 31);
+    const float d = h2f(ld_u16(b)); const uint32_t qh = ld_u32_a2(b + 2); const uint8_t q = b[6 + (j & 15)];
+    return (float)((int)((j < 16 ? (q & 0x0F) : (q >> 4)) | (((qh >> j) & 1) << 4)) - 16) * d;
+}
+// Q5_1 {fp16 d, fp16 m, qh[4], qs[16]}: q * d + m (src/ggml-quants.c:321-347)
+template <> __device__ __forceinline__ float deq_elem<CDNA4_Q5_1>(const uint8_t *row, int64_t k) {
+    const uint8_t *b = row + (k >> 5) * 24; const int j = (int)(k & 31);
+    const float d = h2f(ld_u16(b)), m = h2f(ld_u16(b + 2)); const uint32_t qh = ld_u32_a2(b + 4); const uint8_t q = b[8 + (j & 15)];
+    return (float)((j < 16 ? (q & 0x0F) : (q >> 4)) | (((qh >> j) & 1) << 4)) * d + m;
+}
+// Q2_K {scales[16], qs[64], fp16 d, fp16 dmin}: weight 128 n + 32 sh + l is (qs[32 n + l] >> 2 sh) & 3 of sub-block 8 n + 2 sh + (l >> 4);
+// d * (scale & 15) * q - dmin * (scale >> 4) (src/ggml-quants.c:712-744)
+template <> __device__ __forceinline__ float deq_elem<CDNA4_Q2_K>(const uint8_t *row, int64_t k) {
+    const uint8_t *b = row + (k >> 8) * 84; const int j = (int)(k & 255), n = j >> 7, sh = (j >> 5) & 3, l = j & 31;
+    const uint8_t sc = b[8 * n + 2 * sh + (l >> 4)];
+    const float dl = h2f(ld_u16(b + 80)) * (float)(sc & 0xF), ml = h2f(ld_u16(b + 82)) * (float)(sc >> 4);
+    return dl * (float)((b[16 + 32 * n + l] >> (2 * sh)) & 3) - ml;
+}
+// Q3_K {hmask[32], qs[64], scales[12], fp16 d}: same walk; the third bit is bit 4 n + sh of hmask[l], CLEAR means -4; sixteen 6-bit scales
+// (low 4 bits two per byte in scales[0..7], high 2 bits in scales[8..11]) minus 32 (src/ggml-quants.c:1056-1104)
+template <> __device__ __forceinline__ float deq_elem<CDNA4_Q3_K>(const uint8_t *row, int64_t k) {
+    const uint8_t *b = row + (k >> 8) * 110; const int j = (int)(k & 255), n = j >> 7, sh = (j >> 5) & 3, l = j & 31, g = 8 * n + 2 * sh + (l >> 4);
+    const uint8_t *sc = b + 96;
+    const int s6 = (g < 8 ? (sc[g] & 0xF) : (sc[g - 8] >> 4)) | (((sc[8 + (g & 3)] >> (2 * (g >> 2))) & 3) << 4);
+    const float dl = h2f(ld_u16(b + 108)) * (float)(s6 - 32);
+    const int q = (int)((b[32 + 32 * n + l] >> (2 * sh)) & 3) - ((b[l] >> (4 * n + sh)) & 1 ? 0 : 4);
+    return dl * (float)q;
 }
 
 // ------------------------------------------------------------------------------------------------ get_rows
@@ -454,6 +492,7 @@ int ggml_cdna4_op_get_rows(const T4 *a, const T4 *ids, const T4 *d, void *stream
     switch (a->type) {
         case CDNA4_F32: GR(CDNA4_F32); case CDNA4_F16: GR(CDNA4_F16); case CDNA4_Q4_0: GR(CDNA4_Q4_0); case CDNA4_Q8_0: GR(CDNA4_Q8_0);
         case CDNA4_Q4_K: GR(CDNA4_Q4_K); case CDNA4_Q5_K: GR(CDNA4_Q5_K); case CDNA4_Q6_K: GR(CDNA4_Q6_K);
+        case CDNA4_Q4_1: GR(CDNA4_Q4_1); case CDNA4_Q5_0: GR(CDNA4_Q5_0); case CDNA4_Q5_1: GR(CDNA4_Q5_1); case CDNA4_Q2_K: GR(CDNA4_Q2_K); case CDNA4_Q3_K: GR(CDNA4_Q3_K);
         default: return cdna4_set_error_msg("get_rows: unsupported source type");
     }
 #undef GR
@@ -480,6 +519,7 @@ int ggml_cdna4_op_cpy(const T4 *a, const T4 *d, int q8_0_ref_rounding, void *str
         NEED(a->nb[0] == (int64_t)tsize(ta), "cpy: quantized source rows must be contiguous");
 #define CQ(T) hipLaunchKernelGGL(k_cpy_q_to_f32<T>, grid1d(n), dim3(256), 0, st, *a, *d, n); break
         switch (ta) { case CDNA4_Q4_0: CQ(CDNA4_Q4_0); case CDNA4_Q8_0: CQ(CDNA4_Q8_0); case CDNA4_Q4_K: CQ(CDNA4_Q4_K); case CDNA4_Q5_K: CQ(CDNA4_Q5_K); case CDNA4_Q6_K: CQ(CDNA4_Q6_K);
+                      case CDNA4_Q4_1: CQ(CDNA4_Q4_1); case CDNA4_Q5_0: CQ(CDNA4_Q5_0); case CDNA4_Q5_1: CQ(CDNA4_Q5_1); case CDNA4_Q2_K: CQ(CDNA4_Q2_K); case CDNA4_Q3_K: CQ(CDNA4_Q3_K);
                       default: return cdna4_set_error_msg("cpy: unsupported quantized source"); }
 #undef CQ
     } else if (ta == CDNA4_F32 && (td == CDNA4_Q8_0 || td == CDNA4_Q4_0)) {

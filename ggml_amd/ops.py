@@ -177,3 +177,18 @@ def quantize_row_q8_0(x: torch.Tensor, ref_rounding=False, want_f16=False):
     native.check(L.ggml_cdna4_quantize_q8_0(x.data_ptr(), x.stride(0), K, B, qs.data_ptr(), d.data_ptr(),
                                             xh.data_ptr() if want_f16 else None, 1 if ref_rounding else 0, _stream(x.device)))
     return (qs, d, xh) if want_f16 else (qs, d)
+
+
+def convert_weights(a: QTensor) -> QTensor:
+    """exact re-encoding of a Q5_0 / Q3_K matrix as Q8_0 / Q6_K (ggml_cdna4_convert_weights): same dequantized values bit for bit, and
+    the MFMA prefill GEMM of the target format.  mul_mat does this per call for more than 8 activation rows; converting once trades
+    HBM (34/22 resp. 210/110 of the bytes) for the conversion pass."""
+    L = native.lib()
+    tgt = L.ggml_cdna4_convert_weights_target(int(a.type))
+    if tgt < 0:
+        raise ValueError("%s has no exact target format" % a.type.name)
+    dev = a.data.device
+    out = torch.empty(L.ggml_cdna4_convert_weights_size(int(a.type), a.M, a.K), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        native.check(L.ggml_cdna4_convert_weights(int(a.type), a.data.data_ptr(), a.row_bytes, a.M, a.K, out.data_ptr(), _stream(dev)))
+    return QTensor(tgt, a.K, a.M, out)

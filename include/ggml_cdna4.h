@@ -35,8 +35,11 @@ extern "C" {
 enum ggml_cdna4_type {
     GGML_CDNA4_TYPE_F32 = 0, GGML_CDNA4_TYPE_F16 = 1, GGML_CDNA4_TYPE_Q4_0 = 2, GGML_CDNA4_TYPE_Q8_0 = 8,
     GGML_CDNA4_TYPE_Q4_K = 12, GGML_CDNA4_TYPE_Q5_K = 13, GGML_CDNA4_TYPE_Q6_K = 14,
-    /* MUL_MAT / MUL_MAT_ID only, through the int8-dot GEMV units at every batch size (no MFMA GEMM, no dequantize_row yet) */
+    /* MUL_MAT / MUL_MAT_ID through the int8-dot GEMV units; above 8 activation rows Q5_0 / Q3_K take the MFMA GEMM of Q8_0 / Q6_K on an
+     * exact re-encoding of the weights (ggml_cdna4_convert_weights), Q2_K stays on the GEMV units */
     GGML_CDNA4_TYPE_Q5_0 = 6, GGML_CDNA4_TYPE_Q2_K = 10, GGML_CDNA4_TYPE_Q3_K = 11,
+    /* to_float only: ggml_cdna4_dequantize_row, GET_ROWS, CPY -> F32 */
+    GGML_CDNA4_TYPE_Q4_1 = 3, GGML_CDNA4_TYPE_Q5_1 = 7,
 };
 
 /* which kernel family ggml_cdna4_mul_mat uses */
@@ -191,6 +194,16 @@ int ggml_cdna4_op_rope(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor *
                        float beta_fast, float beta_slow, void * stream);
 /* to_float of a quantized row buffer: y[k] f32 <- x (type) — dequantize_row_*, src/ggml-quants.c */
 int ggml_cdna4_dequantize_row(int type, const void * x, float * y, int64_t k, void * stream);
+
+/* Exact re-encoding of a weight matrix into the format whose MFMA prefill GEMM it shares: Q5_0 -> Q8_0 (q8 = q5 - 16, same d) and
+ * Q3_K -> Q6_K (q6 = q3 + 28, int8 scale = 6-bit scale - 32, same d).  dequantize_row of the result equals dequantize_row of the source bit
+ * for bit (src/ggml-quants.c:295-319 vs 349-363, 1056-1104 vs 1690-1719), and both members of a pair use the same activation format on the
+ * CPU (type_traits_cpu[].vec_dot_type, src/ggml-cpu/ggml-cpu.c:277-341).  ggml_cdna4_mul_mat does this per call into library scratch; a
+ * host that keeps prefill weights resident can convert once and call ggml_cdna4_mul_mat with the target type instead.
+ * _target: the target type id or -1; _size: bytes of the result (rows contiguous) or 0. */
+int    ggml_cdna4_convert_weights_target(int type);
+size_t ggml_cdna4_convert_weights_size(int type, int64_t M, int64_t K);
+int    ggml_cdna4_convert_weights(int type, const void * W, int64_t w_row_bytes, int64_t M, int64_t K, void * out, void * stream);
 
 #ifdef __cplusplus
 }

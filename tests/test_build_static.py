@@ -317,3 +317,27 @@ def test_multi_column_gemv_source_on_the_cpu(t):
     spec.loader.exec_module(mod)
     assert mod.run_cols(t, 33, 2048, 3, seed=t) < 1e-5
     assert mod.run_cols(t, 16, 1024, 8, seed=t + 1) < 1e-5
+
+
+def _emul_module(name):
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", "emul", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("t,m,k", [(6, 8, 1024), (6, 33, 64), (11, 8, 1024), (11, 33, 512)])
+def test_weight_reencoding_sources_on_the_cpu_are_exact(t, m, k):
+    """tools/emul/convert_emul: k_convert_q5_0_q8_0 / k_convert_q3_K_q6_K (the prefill route of Q5_0 / Q3_K) executed on the CPU: the oracle's
+    dequantize_row of the re-encoded matrix equals its dequantize_row of the source bit for bit, on fully random block bytes"""
+    assert _emul_module("convert_emul_check").run(t, m, k, seed=t + k)
+
+
+@pytest.mark.parametrize("t", [2, 3, 6, 7, 8, 10, 11, 12, 13, 14])
+def test_to_float_sources_on_the_cpu_bit_exact(t):
+    """tools/emul/deq_emul: deq_elem of ops.hip (dequantize_row, GET_ROWS, CPY -> F32) executed on the CPU equals the oracle's dequantize_row_*
+    bit for bit for all ten block formats, on fully random block bytes"""
+    assert _emul_module("deq_emul_check").run(t, 32 * 256 if t > 9 else 32 * 24, seed=t)

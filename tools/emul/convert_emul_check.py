@@ -1,0 +1,65 @@
+"""Runs the SOURCE of the exact weight re-encodings (convert_w.hip: Q5_0 -> Q8_0, Q3_K -> Q6_K) on the CPU (tools/emul/convert_emul) and checks
+that the oracle's dequantize_row of the RESULT equals its dequantize_row of the SOURCE bit for bit — every 5-bit / 3-bit code, both hmask
+polarities, all 64 six-bit scales, any fp16 d (the prefill GEMM of Q5_0 / Q3_K is the Q8_0 / Q6_K GEMM on the re-encoded weights).
+
+    python tools/emul/convert_emul_check.py [type M K]        type 6 = Q5_0, 11 = Q3_K
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import refutil as R  # noqa: E402
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+Q5_0, Q8_0, Q3_K, Q6_K = 6, 8, 11, 14
+
+
+def build():
+    exe = os.path.join(HERE, "convert_emul")
+    srcs = [os.path.join(HERE, "convert_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(ROOT, "ggml_amd", "csrc", f)
+            for f in ("convert_w.hip", "cdna4_common.h", "cdna4_kernels.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
+        subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-ffp-contract=off", "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "ggml_amd", "csrc"),
+                        "-Wno-unused-value", "-o", exe, srcs[0]], check=True, capture_output=True, timeout=600)
+    return exe
+
+
+def source_bytes(t, m, k, seed):
+    """fully random block bytes (every code, mask and scale pattern) with finite fp16 scales of both signs, one zero and one subnormal"""
+    rng = np.random.default_rng(seed)
+    bs, blk, doff = (22, 32, 0) if t == Q5_0 else (110, 256, 108)
+    nb = m * k // blk
+    raw = rng.integers(0, 256, (nb, bs), dtype=np.uint8)
+    d = rng.uniform(-0.3, 0.3, nb).astype(np.float16)
+    d[0] = 0.0
+    d[-1] = np.float16(3e-7)
+    raw[:, doff:doff + 2] = d.view(np.uint8).reshape(nb, 2)
+    return raw.reshape(-1)
+
+
+def run(t, m, k, seed=1):
+    w = source_bytes(t, m, k, seed)
+    tgt = Q8_0 if t == Q5_0 else Q6_K
+    with tempfile.TemporaryDirectory() as d:
+        f = lambda n: os.path.join(d, n)
+        w.tofile(f("w.bin"))
+        r = subprocess.run([build(), str(t), str(m), str(k), f("w.bin"), f("o.bin")], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        out = np.fromfile(f("o.bin"), np.uint8)
+    assert out.size == m * R.row_size(tgt, k), "size of the re-encoded matrix"
+    a = R.o_dequantize(t, w, k)
+    b = R.o_dequantize(tgt, out, k)
+    assert a.shape == b.shape == (m, k)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "dequantize(source) != dequantize(re-encoded)"
+    return True
+
+
+if __name__ == "__main__":
+    t, m, k = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (Q5_0, 8, 1024)
+    print("re-encoding source on the CPU, type %d, M=%d, K=%d: exact =" % (t, m, k), run(t, m, k))

@@ -1,0 +1,37 @@
+// deq_emul.cpp — runs the SOURCE of the to_float kernels (ggml_amd/csrc/ops.hip: k_cpy_q_to_f32 / deq_elem behind ggml_cdna4_dequantize_row) on
+// the CPU.  Test infrastructure.  These kernels have no barriers and no cross-lane traffic: the GPU threads run one after the other.
+//   deq_emul type K rows.bin out.bin            one quantized row buffer of K weights -> K floats
+#include "hip_emul.h"
+#include <vector>
+
+namespace emu {
+thread_local dim3 t_threadIdx, t_blockIdx;
+dim3 g_gridDim, g_blockDim;
+pthread_barrier_t g_wg_barrier;
+WaveState *g_waves;
+thread_local std::vector<Pending> t_vmq;
+bool g_defer_dma = false;
+size_t g_weaken = 0;
+}
+int cdna4_set_error_msg(const char *m) { fprintf(stderr, "error: %s\n", m); return -1; }
+int cdna4_set_error(hipError_t, const char *, int) { return -1; }
+#define hipMemcpyDeviceToDevice 0
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    do { const dim3 g_ = (grid), b_ = (block); emu::g_gridDim = g_; emu::g_blockDim = b_; \
+         for (unsigned bi = 0; bi < g_.x; bi++) for (unsigned ti = 0; ti < b_.x; ti++) { emu::t_blockIdx = dim3(bi); emu::t_threadIdx = dim3(ti); kernel(__VA_ARGS__); } } while (0)
+
+#include "../../ggml_amd/csrc/ops.hip"
+
+int main(int argc, char **argv) {
+    if (argc < 5) { fprintf(stderr, "usage: deq_emul type K rows.bin out.bin\n"); return 2; }
+    const int type = atoi(argv[1]); const int64_t K = atoll(argv[2]);
+    FILE *f = fopen(argv[3], "rb"); if (!f) { perror(argv[3]); return 2; }
+    fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> w((size_t)n); if (fread(w.data(), 1, w.size(), f) != w.size()) return 2; fclose(f);
+    std::vector<float> y((size_t)K);
+    if (ggml_cdna4_dequantize_row(type, w.data(), y.data(), K, nullptr)) return 1;
+    f = fopen(argv[4], "wb"); fwrite(y.data(), 4, y.size(), f); fclose(f);
+    return 0;
+}

@@ -1,0 +1,55 @@
+"""Runs the SOURCE of the to_float kernels (ops.hip: deq_elem behind ggml_cdna4_dequantize_row / GET_ROWS / CPY -> F32) on the CPU
+(tools/emul/deq_emul) and compares BIT FOR BIT with the CPU oracle's dequantize_row_* on fully random block bytes.
+
+    python tools/emul/deq_emul_check.py [type K]
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import refutil as R  # noqa: E402
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+# type id -> byte offsets of the fp16 fields of a block (everything else may be any bit pattern)
+F16_FIELDS = {R.Q4_0: [0], R.Q4_1: [0, 2], R.Q5_0: [0], R.Q5_1: [0, 2], R.Q8_0: [0], R.Q2_K: [80, 82], R.Q3_K: [108], R.Q4_K: [0, 2], R.Q5_K: [0, 2], R.Q6_K: [208]}
+
+
+def build():
+    exe = os.path.join(HERE, "deq_emul")
+    csrc = os.path.join(ROOT, "ggml_amd", "csrc")
+    srcs = [os.path.join(HERE, "deq_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(csrc, f) for f in ("ops.hip", "cdna4_common.h", "cdna4_kernels.h", "epilogue.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
+        subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-ffp-contract=off", "-I" + os.path.join(HERE, "shim"), "-I" + csrc, "-I" + os.path.join(ROOT, "include"),
+                        "-Wno-unused-value", "-o", exe, srcs[0]], check=True, capture_output=True, timeout=600)
+    return exe
+
+
+def run(t, k, seed=1):
+    rng = np.random.default_rng(seed)
+    nb = k // R.BLCK[t]
+    raw = rng.integers(0, 256, (nb, R.TYPE_SIZE[t]), dtype=np.uint8)
+    for o in F16_FIELDS[t]:
+        d = rng.uniform(-0.3, 0.3, nb).astype(np.float16)
+        d[0] = 0.0
+        raw[:, o:o + 2] = d.view(np.uint8).reshape(nb, 2)
+    w = raw.reshape(-1)
+    with tempfile.TemporaryDirectory() as d:
+        f = lambda n: os.path.join(d, n)
+        w.tofile(f("w.bin"))
+        r = subprocess.run([build(), str(int(t)), str(k), f("w.bin"), f("y.bin")], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        y = np.fromfile(f("y.bin"), np.float32)
+    want = R.o_dequantize(t, w, k)[0]
+    assert np.array_equal(y.view(np.uint32), want.view(np.uint32)), "to_float differs from the oracle"
+    return True
+
+
+if __name__ == "__main__":
+    t, k = (int(a) for a in sys.argv[1:3]) if len(sys.argv) > 2 else (R.Q3_K, 2048)
+    print("to_float source on the CPU, type %d, K=%d: bit-exact =" % (t, k), run(t, k))
