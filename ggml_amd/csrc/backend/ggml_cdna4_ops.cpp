@@ -60,6 +60,16 @@ bool cdna4_ops_supports_tensor(const ggml_tensor * op) {
                 return a->nb[0] == sizeof(float) && a->ne[0] % 32 == 0 && ggml_is_contiguous(op);
             return false;
         }
+        case GGML_OP_FLASH_ATTN_EXT: {
+            // q F32, k / v F16 with 16-byte aligned rows, mask F16 contiguous or absent, head sizes 64 / 128 / 256 (fattn.hip)
+            const ggml_tensor * k = op->src[1], * v = op->src[2], * m = op->src[3];
+            if (!f32(a) || !f32(op) || !k || !v || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16) return false;
+            if (!ggml_cdna4_op_flash_attn_ext_supported(a->ne[0], (int)k->type) || k->ne[0] != a->ne[0] || v->ne[0] != a->ne[0]) return false;
+            if (a->nb[0] != sizeof(float) || k->nb[0] != 2 || v->nb[0] != 2 || !ggml_is_contiguous(op)) return false;
+            for (int i = 1; i < 4; i++) if (k->nb[i] % 16 || v->nb[i] % 16 || a->nb[i] % 4) return false;
+            if (m && (m->type != GGML_TYPE_F16 || !ggml_is_contiguous(m))) return false;
+            return a->ne[2] <= 65535 && a->ne[3] <= 65535;
+        }
         case GGML_OP_ROPE: {
             const int mode = ((const int32_t *)op->op_params)[2];
             return f32(a) && f32(op) && b->type == GGML_TYPE_I32 && (mode & ~2) == 0 && (!op->src[2] || op->src[2]->type == GGML_TYPE_F32);
@@ -99,6 +109,12 @@ enum ggml_status cdna4_ops_compute(void * ctx, ggml_tensor * node) {
         // ggml-cuda/cpy.cu:61 use id = 1 / d with roundf instead (C-ABI callers get that with q8_0_ref_rounding = 1)
         case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: rc = ggml_cdna4_op_cpy(&da, &dd, /*q8_0_ref_rounding=*/0, stream); break;
         case GGML_OP_MUL_MAT: rc = ggml_cdna4_op_mul_mat_f(&da, &db, &dd, stream); break;
+        case GGML_OP_FLASH_ATTN_EXT: {
+            float scale, max_bias, softcap;
+            memcpy(&scale, (const float *)node->op_params + 0, 4); memcpy(&max_bias, (const float *)node->op_params + 1, 4); memcpy(&softcap, (const float *)node->op_params + 2, 4);
+            ggml_cdna4_tensor dv = desc(node->src[2]), dm = node->src[3] ? desc(node->src[3]) : ggml_cdna4_tensor{};
+            rc = ggml_cdna4_op_flash_attn_ext(&da, &db, &dv, node->src[3] ? &dm : nullptr, &dd, scale, max_bias, softcap, stream); break;
+        }
         case GGML_OP_ROPE: {
             const int32_t * ip = (const int32_t *)node->op_params;
             float fb, fs, ef, af, bf, bs;

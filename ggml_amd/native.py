@@ -40,6 +40,8 @@ SYMBOLS = [
     ("ggml_cdna4_op_cpy", _int, [_vp, _vp, _int, _vp]),
     ("ggml_cdna4_op_mul_mat_f", _int, [_vp, _vp, _vp, _vp]),
     ("ggml_cdna4_op_rope", _int, [_vp, _vp, _vp, _vp, _int, _int, _int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
+    ("ggml_cdna4_op_flash_attn_ext_supported", _int, [_i64, _int]),
+    ("ggml_cdna4_op_flash_attn_ext", _int, [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _vp]),
     ("ggml_cdna4_dequantize_row", _int, [_int, _vp, _vp, _i64, _vp]),
     ("ggml_cdna4_convert_weights_target", _int, [_int]),
     ("ggml_cdna4_convert_weights_size", _sz, [_int, _i64, _i64]),

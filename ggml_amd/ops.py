@@ -192,3 +192,38 @@ def convert_weights(a: QTensor) -> QTensor:
     with torch.cuda.device(dev):
         native.check(L.ggml_cdna4_convert_weights(int(a.type), a.data.data_ptr(), a.row_bytes, a.M, a.K, out.data_ptr(), _stream(dev)))
     return QTensor(tgt, a.K, a.M, out)
+
+
+def _tensor_desc(t: torch.Tensor, type_):
+    """ggml_cdna4_tensor of a 4-D torch tensor: ggml's ne / nb are torch's shape / strides reversed (strides in bytes)"""
+    d = native.Tensor()
+    d.data = t.data_ptr(); d.type = int(type_); d.reserved = 0
+    for i in range(4):
+        d.ne[i] = int(t.shape[3 - i]); d.nb[i] = int(t.stride(3 - i)) * t.element_size()
+    return d
+
+
+def flash_attn_ext(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask=None, scale=1.0, max_bias=0.0, logit_softcap=0.0):
+    """ggml_flash_attn_ext (include/ggml.h:1758-1767; CPU: ggml-cpu.c:10805-11016).  q f32 (batch, n_head, n_q, D) — any strides with
+    contiguous rows, e.g. a permuted view; k, v fp16 (batch_kv, n_head_kv, n_kv, D); mask fp16 (>= n_q, n_kv) or None.
+    Returns f32 (batch, n_q, n_head, D) like ggml's result (ne = D, n_head, n_q, batch)."""
+    import ctypes as C
+    L = native.lib()
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        _need_gpu(t, name)
+        if t.dim() != 4 or t.stride(3) != 1:
+            raise ValueError("%s must be 4-D with contiguous rows" % name)
+    if q.dtype != torch.float32 or k.dtype != torch.float16 or v.dtype != torch.float16:
+        raise ValueError("q must be float32, k and v float16")
+    dev = q.device
+    _same_device(dev, k=k, v=v, mask=mask)
+    if mask is not None and (mask.dtype != torch.float16 or mask.dim() != 2 or not mask.is_contiguous()):
+        raise ValueError("mask must be a contiguous float16 (>= n_q, n_kv) matrix")
+    B3, H, N, D = q.shape
+    out = torch.empty((B3, N, H, D), dtype=torch.float32, device=dev)
+    dm = _tensor_desc(mask.view(1, 1, *mask.shape), GGMLType.F16) if mask is not None else None
+    dq, dk, dv, dd = _tensor_desc(q, GGMLType.F32), _tensor_desc(k, GGMLType.F16), _tensor_desc(v, GGMLType.F16), _tensor_desc(out, GGMLType.F32)
+    with torch.cuda.device(dev):
+        native.check(L.ggml_cdna4_op_flash_attn_ext(C.byref(dq), C.byref(dk), C.byref(dv), C.byref(dm) if dm is not None else None, C.byref(dd),
+                                                    float(scale), float(max_bias), float(logit_softcap), _stream(dev)))
+    return out

@@ -192,6 +192,14 @@ int ggml_cdna4_op_mul_mat_f(const ggml_cdna4_tensor * src0, const ggml_cdna4_ten
 int ggml_cdna4_op_rope(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * pos, const ggml_cdna4_tensor * freq_factors, const ggml_cdna4_tensor * dst,
                        int n_dims, int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor, float attn_factor,
                        float beta_fast, float beta_slow, void * stream);
+/* GGML_OP_FLASH_ATTN_EXT — ggml_compute_forward_flash_attn_ext_f16, src/ggml-cpu/ggml-cpu.c:10805-11016 (ggml-cuda: fattn*.cu).
+ * q F32 [head_size, n_q, n_head, batch] (any row strides), k / v F16 [head_size, n_kv, n_head_kv, batch_kv] (rows 16-byte aligned; heads and
+ * batches broadcast as q's over k's), mask F16 [n_kv, >= n_q] or NULL, dst F32 contiguous [head_size, n_head, n_q, batch].
+ * scale / max_bias (ALiBi) / logit_softcap as in op_params 0..2.  fp16 operands on the matrix cores, fp32 softmax statistics and
+ * accumulation.  _supported: head sizes 64 / 128 / 256 with F16 k / v. */
+int ggml_cdna4_op_flash_attn_ext_supported(int64_t head_size, int kv_type);
+int ggml_cdna4_op_flash_attn_ext(const ggml_cdna4_tensor * q, const ggml_cdna4_tensor * k, const ggml_cdna4_tensor * v, const ggml_cdna4_tensor * mask,
+                                 const ggml_cdna4_tensor * dst, float scale, float max_bias, float logit_softcap, void * stream);
 /* to_float of a quantized row buffer: y[k] f32 <- x (type) — dequantize_row_*, src/ggml-quants.c */
 int ggml_cdna4_dequantize_row(int type, const void * x, float * y, int64_t k, void * stream);
 

@@ -624,3 +624,55 @@ void oracle_mul_mat_id(int wtype, const void *as, const float *b, const int32_t 
         }
     free(act);
 }
+
+/* ============================ FLASH_ATTN_EXT ============================ */
+/* ggml_compute_forward_flash_attn_ext_f16, src/ggml-cpu/ggml-cpu.c:10805-11016, for F16 K and V (contiguous tensors):
+ *   q    [n_batch][n_head][n_q][D]        f32      (ggml ne = D, n_q, n_head, n_batch)
+ *   k, v [n_batch_kv][n_head_kv][n_kv][D] fp16 bits
+ *   mask [>= n_q][n_kv]                   fp16 bits or NULL
+ *   dst  [n_batch][n_q][n_head][D]        f32      (the permute(0, 2, 1, 3) of :11012)
+ * Per query row: Q -> fp16 (:10929, from_float of the F16 vec_dot_type), s = ggml_vec_dot_f16(k, Q) (src/ggml-cpu/ggml-cpu.c:1457-1497: fp32 products,
+ * here summed in double like its scalar tail) * scale [softcap * tanhf] + slope * mask, -inf mask entries skipped (:10935-10938), online
+ * softmax with the O accumulator kept in FP16 (:10960-10974: ggml_vec_scale_f16 / ggml_vec_mad_f16 compute in fp32 per element — fused
+ * multiply-add on the x86 F16C paths, ggml-cpu.c:1585-1614,1700-1727 with GGML_F16_VEC_FMA = _mm512/_mm256_fmadd_ps :619,664 — and round
+ * back to fp16), V /= S (:11001-11003). */
+void oracle_flash_attn_ext_f16(const float *q, const uint16_t *k, const uint16_t *v, const uint16_t *mask, float *dst,
+                               int64_t D, int64_t n_q, int64_t n_head, int64_t n_batch, int64_t n_kv, int64_t n_head_kv, int64_t n_batch_kv,
+                               float scale, float max_bias, float logit_softcap) {
+    if (logit_softcap != 0) scale /= logit_softcap;                                              /* :10876-10878 */
+    const uint32_t n_head_log2 = 1u << (uint32_t)floor(log2((double)n_head));                    /* :10880-10884 */
+    const float m0 = powf(2.0f, -(max_bias) / n_head_log2), m1 = powf(2.0f, -(max_bias / 2.0f) / n_head_log2);
+    const int64_t rk2 = n_head / n_head_kv, rk3 = n_batch / n_batch_kv;
+    uint16_t *Qh = malloc((size_t)D * 2), *acc = malloc((size_t)D * 2);
+    for (int64_t i3 = 0; i3 < n_batch; i3++)
+        for (int64_t i2 = 0; i2 < n_head; i2++)
+            for (int64_t i1 = 0; i1 < n_q; i1++) {
+                const uint32_t h = (uint32_t)i2;
+                const float slope = (max_bias > 0.0f) ? (h < n_head_log2 ? powf(m0, h + 1) : powf(m1, 2 * (h - n_head_log2) + 1)) : 1.0f;   /* :10902 */
+                const float *pq = q + ((i3 * n_head + i2) * n_q + i1) * D;
+                for (int64_t d = 0; d < D; d++) { Qh[d] = fp32_to_fp16(pq[d]); acc[d] = 0; }
+                const uint16_t *kh = k + ((i3 / rk3) * n_head_kv + (i2 / rk2)) * n_kv * D, *vh = v + ((i3 / rk3) * n_head_kv + (i2 / rk2)) * n_kv * D;
+                float S = 0.0f, M = -INFINITY;
+                for (int64_t ic = 0; ic < n_kv; ic++) {
+                    const float mv = mask ? slope * fp16_to_fp32(mask[i1 * n_kv + ic]) : 0.0f;
+                    if (mv == -INFINITY) continue;
+                    double sd = 0;
+                    for (int64_t d = 0; d < D; d++) sd += (double)(fp16_to_fp32(kh[ic * D + d]) * fp16_to_fp32(Qh[d]));
+                    float s = (float)sd * scale;
+                    if (logit_softcap != 0.0f) s = logit_softcap * tanhf(s);
+                    s += mv;
+                    const float Mold = M;
+                    float ms = 1.0f, vs = 1.0f;
+                    if (s > M) {
+                        M = s; ms = expf(Mold - M);
+                        for (int64_t d = 0; d < D; d++) acc[d] = fp32_to_fp16(fp16_to_fp32(acc[d]) * ms);
+                    } else vs = expf(s - M);
+                    for (int64_t d = 0; d < D; d++) acc[d] = fp32_to_fp16(fmaf(fp16_to_fp32(vh[ic * D + d]), vs, fp16_to_fp32(acc[d])));
+                    S = S * ms + vs;
+                }
+                const float S_inv = 1.0f / S;
+                float *out = dst + ((i3 * n_q + i1) * n_head + i2) * D;
+                for (int64_t d = 0; d < D; d++) out[d] = fp16_to_fp32(acc[d]) * S_inv;
+            }
+    free(Qh); free(acc);
+}

@@ -25,7 +25,8 @@ class Ref:
                                ("ggml_rope_ext", [vp, vp, vp, vp, i32, i32, i32, f, f, f, f, f, f]), ("ggml_cpy", [vp, vp, vp]),
                                ("ggml_gelu", [vp, vp]), ("ggml_gelu_quick", [vp, vp]), ("ggml_silu", [vp, vp]), ("ggml_get_rows", [vp, vp, vp]),
                                ("ggml_diag_mask_inf", [vp, vp, i32]), ("ggml_add", [vp, vp, vp]), ("ggml_mul", [vp, vp, vp]), ("ggml_scale", [vp, vp, f]),
-                               ("ggml_mul_mat", [vp, vp, vp]), ("ggml_cont", [vp, vp]), ("ggml_permute", [vp, vp, i32, i32, i32, i32])):
+                               ("ggml_mul_mat", [vp, vp, vp]), ("ggml_cont", [vp, vp]), ("ggml_permute", [vp, vp, i32, i32, i32, i32]),
+                               ("ggml_flash_attn_ext", [vp, vp, vp, vp, vp, f, f, f])):
                 fn = getattr(b, name); fn.restype = vp; fn.argtypes = args
             b.ggml_new_graph.restype = vp; b.ggml_new_graph.argtypes = [vp]
             b.ggml_build_forward_expand.argtypes = [vp, vp]
@@ -140,3 +141,17 @@ def diag_mask_inf(x, n_past):
         a = r.tensor(R.F32, list(reversed(x.shape)), x.astype(np.float32))
         t = r.base.ggml_diag_mask_inf(r.ctx, a, n_past)
         return r.read(r.compute(t), R.F32, x.shape)
+
+
+def flash_attn_ext(q, k, v, mask, scale, max_bias=0.0, logit_softcap=0.0, n_threads=4):
+    """ggml_flash_attn_ext (include/ggml.h:1758-1767) on the reference CPU backend.  q f32 (n_batch, n_head, n_q, D); k, v fp16
+    (n_batch_kv, n_head_kv, n_kv, D); mask fp16 (GGML_PAD(n_q, GGML_KQ_MASK_PAD = 64), n_kv) or None -> f32 (n_batch, n_q, n_head, D)"""
+    nb, nh, nq, D = q.shape
+    with Ref(mem=1 << 30) as r:
+        tq = r.tensor(R.F32, list(reversed(q.shape)), q.astype(np.float32))
+        tk = r.tensor(R.F16, list(reversed(k.shape)), k.astype(np.float16))
+        tv = r.tensor(R.F16, list(reversed(v.shape)), v.astype(np.float16))
+        tm = r.tensor(R.F16, list(reversed(mask.shape)), mask.astype(np.float16)) if mask is not None else None
+        t = r.base.ggml_flash_attn_ext(r.ctx, tq, tk, tv, tm, C.c_float(scale), C.c_float(max_bias), C.c_float(logit_softcap))
+        r.compute(t, n_threads)
+        return r.read(t, R.F32, (nb, nq, nh, D))

@@ -95,6 +95,52 @@ def o_mul_mat_id(t, w, x, ids, m, k, n_expert):
     return y
 
 
+def o_flash_attn_ext(q, k, v, mask, scale, max_bias=0.0, logit_softcap=0.0):
+    """oracle_flash_attn_ext_f16: q f32 (n_batch, n_head, n_q, D); k, v fp16 (n_batch_kv, n_head_kv, n_kv, D); mask fp16 (>= n_q, n_kv) or None
+    -> f32 (n_batch, n_q, n_head, D)  (ggml_compute_forward_flash_attn_ext_f16, ggml-cpu.c:10805-11016)"""
+    nb, nh, nq, D = q.shape
+    nbk, nhk, nkv, _ = k.shape
+    q = np.ascontiguousarray(q, np.float32); k = np.ascontiguousarray(k, np.float16); v = np.ascontiguousarray(v, np.float16)
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, np.float16)
+        assert mask.shape[1] == nkv and mask.shape[0] >= nq
+    y = np.empty((nb, nq, nh, D), np.float32)
+    oracle().oracle_flash_attn_ext_f16(_p(q), _p(k), _p(v), _p(mask) if mask is not None else None, _p(y), C.c_int64(D), C.c_int64(nq), C.c_int64(nh),
+                                       C.c_int64(nb), C.c_int64(nkv), C.c_int64(nhk), C.c_int64(nbk), C.c_float(scale), C.c_float(max_bias), C.c_float(logit_softcap))
+    return y
+
+
+def alibi_slopes(n_head, max_bias):
+    """ggml-cpu.c:10880-10902"""
+    if max_bias <= 0:
+        return np.ones(n_head)
+    n2 = 1 << int(np.floor(np.log2(n_head)))
+    m0, m1 = 2.0 ** (-max_bias / n2), 2.0 ** (-(max_bias / 2.0) / n2)
+    return np.array([m0 ** (h + 1) if h < n2 else m1 ** (2 * (h - n2) + 1) for h in range(n_head)])
+
+
+def exact_flash_attn_ext(q, k, v, mask, scale, max_bias=0.0, logit_softcap=0.0):
+    """the same operator in float64 on the fp16-rounded Q, K, V (what both the CPU and the GPU path start from): the yardstick that shows
+    which side's rounding a difference comes from"""
+    nb, nh, nq, D = q.shape
+    nbk, nhk, nkv, _ = k.shape
+    qd = q.astype(np.float16).astype(np.float64); kd = k.astype(np.float64); vd = v.astype(np.float64)
+    sl = alibi_slopes(nh, max_bias)
+    y = np.empty((nb, nq, nh, D), np.float64)
+    for b in range(nb):
+        for h in range(nh):
+            kk, vv = kd[b // (nb // nbk), h // (nh // nhk)], vd[b // (nb // nbk), h // (nh // nhk)]
+            s = qd[b, h] @ kk.T * (scale / logit_softcap if logit_softcap else scale)
+            if logit_softcap:
+                s = logit_softcap * np.tanh(s)
+            if mask is not None:
+                s = s + sl[h] * mask[:nq].astype(np.float64)
+            s = s - s.max(axis=1, keepdims=True)
+            pr = np.exp(s)
+            y[b, :, h] = (pr / pr.sum(axis=1, keepdims=True)) @ vv
+    return y
+
+
 # ---------------------------------------------------------------------------------------------
 # the unmodified reference (oracle/_ref), when built
 _ref = None

@@ -341,3 +341,21 @@ def test_to_float_sources_on_the_cpu_bit_exact(t):
     """tools/emul/deq_emul: deq_elem of ops.hip (dequantize_row, GET_ROWS, CPY -> F32) executed on the CPU equals the oracle's dequantize_row_*
     bit for bit for all ten block formats, on fully random block bytes"""
     assert _emul_module("deq_emul_check").run(t, 32 * 256 if t > 9 else 32 * 24, seed=t)
+
+
+FATTN_EMUL_CASES = [dict(D=64, n_q=5, n_head=2, n_kv=96), dict(D=128, n_q=35, n_head=4, n_kv=200, n_head_kv=2, max_bias=8.0), dict(D=128, n_q=3, n_head=2, n_kv=64, softcap=10.0),
+                    dict(D=256, n_q=33, n_head=2, n_kv=130, n_head_kv=1, mask=False), dict(D=64, n_q=1, n_head=3, n_kv=517, inf_every=7),
+                    dict(D=128, n_q=40, n_head=2, n_kv=300, n_batch=2, permuted=True), dict(D=64, n_q=32, n_head=2, n_kv=31),
+                    dict(D=256, n_q=1, n_head=2, n_kv=1024, max_bias=8.0, inf_every=5)]
+
+
+@pytest.mark.parametrize("kw", FATTN_EMUL_CASES)
+def test_flash_attn_source_on_the_cpu(kw):
+    """tools/emul/fattn_emul: k_flash_attn_f16 (S^T = K.Q^T, V transposed on the matrix core, O^T += Vt^T.P^T, four-wave key split merged in
+    LDS) executed on the CPU with the MFMA emulated lane for lane: <= 5e-4 from a float64 evaluation of the operator, <= 6e-3 from the
+    oracle (whose FP16 accumulator — the reference's, ggml-cpu.c:10960-10974 — is the larger part of that distance).  Grouped-query heads,
+    ALiBi, softcap, no mask, -inf mask entries incl. a fully masked stretch, batches, permuted operands, ragged n_q / n_kv."""
+    r = _emul_module("fattn_emul_check").run(**kw)
+    if r is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert r[0] < 5e-4 and r[1] < 6e-3, r

@@ -86,3 +86,24 @@ def test_fp16_roundtrip_all_values():
         want = xs.astype(np.float16).view(np.uint16)
     for x, w in zip(xs, want):
         assert o.oracle_fp32_to_fp16(float(x)) == w, (x, w)
+
+
+@pytest.mark.parametrize("D,nh,nhk,nq,nkv,max_bias,softcap,use_mask", [(64, 4, 4, 5, 96, 0.0, 0.0, True), (128, 4, 2, 35, 200, 8.0, 0.0, True), (128, 2, 2, 3, 64, 0.0, 10.0, True),
+                                                                        (256, 2, 1, 33, 130, 0.0, 0.0, False), (80, 3, 3, 7, 64, 0.0, 0.0, True)])
+def test_flash_attn_ext_oracle_vs_reference(D, nh, nhk, nq, nkv, max_bias, softcap, use_mask):
+    """oracle_flash_attn_ext_f16 against ggml_flash_attn_ext on the reference CPU backend: same fp16 Q / accumulator roundings, only the
+    summation order inside the K.Q dot differs (an fp16 accumulator turns that into occasional 1-ulp(fp16) flips): rel-L2 <= 2e-4.
+    And the reference itself is 1-3e-3 from a float64 evaluation — the number the GPU bars in test_gpu_widening.py are set against."""
+    import refops as O
+    rng = np.random.default_rng(D + nq)
+    q = rng.uniform(-1, 1, (1, nh, nq, D)).astype(np.float32)
+    k = rng.uniform(-1, 1, (1, nhk, nkv, D)).astype(np.float16); v = rng.uniform(-1, 1, (1, nhk, nkv, D)).astype(np.float16)
+    m = rng.uniform(-1, 1, ((nq + 63) // 64 * 64, nkv)).astype(np.float16) if use_mask else None
+    if use_mask:
+        m[:, ::7] = -np.inf
+    scale = float(1 / np.sqrt(D))
+    yo = R.o_flash_attn_ext(q, k, v, m, scale, max_bias, softcap)
+    yr = O.flash_attn_ext(q, k, v, m, scale, max_bias, softcap)
+    assert R.rel_l2(yo, yr) < 2e-4
+    ye = R.exact_flash_attn_ext(q, k, v, m, scale, max_bias, softcap)
+    assert 2e-4 < R.rel_l2(yr, ye) < 6e-3

@@ -1,0 +1,64 @@
+"""Runs the SOURCE of the FLASH_ATTN_EXT kernel (fattn.hip) on the CPU (tools/emul/fattn_emul) and compares with the CPU oracle
+(oracle_flash_attn_ext_f16, the reference's fp16-accumulator semantics) and with a float64 evaluation of the same operator.
+
+    python tools/emul/fattn_emul_check.py [D n_q n_head n_kv]
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import refutil as R  # noqa: E402
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def build():
+    exe = os.path.join(HERE, "fattn_emul")
+    csrc = os.path.join(ROOT, "ggml_amd", "csrc")
+    srcs = [os.path.join(HERE, "fattn_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(csrc, f) for f in ("fattn.hip", "cdna4_common.h", "cdna4_kernels.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
+        subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-ffp-contract=off", "-I" + os.path.join(HERE, "shim"), "-I" + csrc, "-I" + os.path.join(ROOT, "include"),
+                        "-Wno-unused-value", "-o", exe, srcs[0]], check=True, capture_output=True, timeout=600)
+    return exe
+
+
+def run(D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max_bias=0.0, softcap=0.0, permuted=False, inf_every=0, seed=1, timeout=1200):
+    """returns (rel-L2 vs the float64 operator, rel-L2 vs the oracle)"""
+    n_head_kv = n_head_kv or n_head
+    rng = np.random.default_rng(seed)
+    q = rng.uniform(-1, 1, (n_batch, n_head, n_q, D)).astype(np.float32)
+    k = rng.uniform(-1, 1, (n_batch, n_head_kv, n_kv, D)).astype(np.float16)
+    v = rng.uniform(-1, 1, (n_batch, n_head_kv, n_kv, D)).astype(np.float16)
+    mrows = (n_q + 63) // 64 * 64
+    m = rng.uniform(-1, 1, (mrows, n_kv)).astype(np.float16) if mask else None
+    if mask and inf_every:
+        m[:, ::inf_every] = -np.inf
+        m[0, : n_kv // 2] = -np.inf                    # a query row whose first chunks are masked entirely
+    scale = 1.0 / np.sqrt(D)
+    lay = (lambda a: np.ascontiguousarray(a.transpose(0, 2, 1, 3))) if permuted else (lambda a: a)
+    with tempfile.TemporaryDirectory() as d:
+        f = lambda n: os.path.join(d, n)
+        lay(q).tofile(f("q")); lay(k).tofile(f("k")); lay(v).tofile(f("v"))
+        if mask:
+            m.tofile(f("m"))
+        r = subprocess.run([build()] + [str(x) for x in (D, n_q, n_head, n_batch, n_kv, n_head_kv, n_batch, int(mask), mrows, repr(float(scale)), max_bias, softcap, int(permuted))] +
+                           [f("q"), f("k"), f("v"), f("m"), f("o")], capture_output=True, text=True, timeout=timeout)
+        if r.returncode == 77:
+            return None
+        assert r.returncode == 0, r.stderr
+        y = np.fromfile(f("o"), np.float32).reshape(n_batch, n_q, n_head, D)
+    assert np.isfinite(y).all()
+    ye = R.exact_flash_attn_ext(q, k, v, m, scale, max_bias, softcap)
+    yo = R.o_flash_attn_ext(q, k, v, m, scale, max_bias, softcap)
+    return R.rel_l2(y, ye), R.rel_l2(y, yo)
+
+
+if __name__ == "__main__":
+    D, nq, nh, nkv = (int(a) for a in sys.argv[1:5]) if len(sys.argv) > 4 else (64, 5, 2, 96)
+    print("flash-attn source on the CPU, D=%d n_q=%d n_head=%d n_kv=%d: rel-L2 vs float64 / vs oracle =" % (D, nq, nh, nkv), run(D, nq, nh, nkv))
