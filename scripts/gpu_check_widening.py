@@ -1,0 +1,214 @@
+"""Torch-free hardware check of the round's widening rows (remaining formats, FLASH_ATTN_EXT) through the C-ABI: device memory straight from
+the HIP runtime over ctypes (no 1-2 minute `import torch` on a fresh box), the oracle as the checker.  Writes gpurun_out/widening_check.jsonl.
+The pytest versions of the same checks live in tests/test_gpu_widening.py.
+
+    python scripts/gpu_check_widening.py
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import refutil as R  # noqa: E402
+
+hip = C.CDLL("/opt/rocm/lib/libamdhip64.so", mode=C.RTLD_GLOBAL)
+L = C.CDLL(os.path.join(ROOT, "ggml_amd", "lib", "libcdna4_kernels.so"))
+L.ggml_cdna4_last_error.restype = C.c_char_p
+L.ggml_cdna4_mul_mat_workspace_size.restype = C.c_size_t
+L.ggml_cdna4_convert_weights_size.restype = C.c_size_t
+OUT = os.path.join(ROOT, "gpurun_out", "widening_check.jsonl")
+os.makedirs(os.path.dirname(OUT), exist_ok=True)
+fails = []
+
+
+class Tensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("type", C.c_int32), ("reserved", C.c_int32), ("ne", C.c_int64 * 4), ("nb", C.c_int64 * 4)]
+
+
+def ok(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s: %s" % (what, (L.ggml_cdna4_last_error() or b"").decode()))
+
+
+def dmalloc(n):
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), C.c_size_t(max(int(n), 256))) == 0
+    return p
+
+
+def to_dev(a):
+    a = np.ascontiguousarray(a)
+    p = dmalloc(a.nbytes)
+    assert hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0
+    return p
+
+
+def to_host(p, shape, dtype):
+    a = np.empty(shape, dtype)
+    assert hip.hipDeviceSynchronize() == 0
+    assert hip.hipMemcpy(a.ctypes.data_as(C.c_void_p), p, C.c_size_t(a.nbytes), 2) == 0
+    return a
+
+
+def report(**kw):
+    with open(OUT, "a") as f:
+        f.write(json.dumps(kw) + "\n")
+    print(json.dumps(kw), flush=True)
+    if not kw.get("ok", True):
+        fails.append(kw)
+
+
+def mul_mat(t, wd, m, k, xd, b, path=0):
+    nws = L.ggml_cdna4_mul_mat_workspace_size(C.c_int(t), C.c_int64(k), C.c_int64(b))
+    ws, y = dmalloc(nws), dmalloc(4 * m * b)
+    ok(L.ggml_cdna4_mul_mat(C.c_int(t), wd, C.c_int64(R.row_size(t, k)), xd, C.c_int64(k), y, C.c_int64(m), C.c_int64(m), C.c_int64(k), C.c_int64(b),
+                            ws, C.c_size_t(nws), C.c_int(path), C.c_int(0), C.c_int(0), None), "mul_mat")
+    out = to_host(y, (b, m), np.float32)
+    hip.hipFree(ws); hip.hipFree(y)
+    return out
+
+
+def check_formats():
+    rng = np.random.default_rng(1)
+    for name, t, tgt in (("q5_0", R.Q5_0, R.Q8_0), ("q3_K", R.Q3_K, R.Q6_K)):
+        for m, k, b in ((16, 256, 9), (130, 768, 33), (512, 2048, 128), (4096, 4096, 512)):
+            w = R.random_weights(t, m, k, seed=5 * m + k)
+            x = rng.uniform(-1, 1, (b, k)).astype(np.float32)
+            wd, xd = to_dev(w), to_dev(x)
+            y = mul_mat(t, wd, m, k, xd, b)
+            rows = np.arange(m) if m <= 512 else np.random.default_rng(0).choice(m, 64, replace=False)
+            rs = R.row_size(t, k)
+            wsub = np.concatenate([w[r * rs:(r + 1) * rs] for r in rows])
+            e = R.rel_l2(y[:, rows], R.o_mul_mat(t, wsub, x, len(rows), k))
+            # the re-encoding itself, and the target format's GEMM on weights converted up front
+            n = L.ggml_cdna4_convert_weights_size(C.c_int(t), C.c_int64(m), C.c_int64(k))
+            cd = dmalloc(n)
+            ok(L.ggml_cdna4_convert_weights(C.c_int(t), wd, C.c_int64(rs), C.c_int64(m), C.c_int64(k), cd, None), "convert_weights")
+            cw = to_host(cd, (n,), np.uint8)
+            exact = bool(np.array_equal(R.o_dequantize(tgt, cw, k).view(np.uint32), R.o_dequantize(t, w, k).view(np.uint32))) if m <= 512 else None
+            y2 = mul_mat(tgt, cd, m, k, xd, b)
+            report(test="more_formats_gemm", type=name, m=m, k=k, b=b, rel_l2=e, reencoding_exact=exact, same_as_target_gemm=bool(np.array_equal(y, y2)),
+                   ok=bool(np.isfinite(y).all() and e < 1e-3 and exact is not False and np.array_equal(y, y2)))
+            for p in (wd, xd, cd):
+                hip.hipFree(p)
+    for name, t in (("q5_0", R.Q5_0), ("q2_K", R.Q2_K), ("q3_K", R.Q3_K)):
+        m, k, b = 256, 4096, 5
+        w = R.random_weights(t, m, k, seed=m + k); x = rng.uniform(-1, 1, (b, k)).astype(np.float32)
+        wd, xd = to_dev(w), to_dev(x)
+        e = R.rel_l2(mul_mat(t, wd, m, k, xd, b, path=1), R.o_mul_mat(t, w, x, m, k))
+        report(test="more_formats_gemv", type=name, m=m, k=k, b=b, rel_l2=e, ok=bool(e < 1e-5))
+    for name, t in (("q4_1", R.Q4_1), ("q5_0", R.Q5_0), ("q5_1", R.Q5_1), ("q2_K", R.Q2_K), ("q3_K", R.Q3_K)):
+        rows, k = 9, 2048
+        w = R.random_weights(t, rows, k, seed=int(t) + 1)
+        wd, yd = to_dev(w), dmalloc(4 * rows * k)
+        ok(L.ggml_cdna4_dequantize_row(C.c_int(t), wd, yd, C.c_int64(rows * k), None), "dequantize_row")
+        got = to_host(yd, (rows, k), np.float32)
+        report(test="to_float", type=name, ok=bool(np.array_equal(got.view(np.uint32), R.o_dequantize(t, w, k).view(np.uint32))))
+
+
+def desc(p, type_, es, shape, strides=None):
+    """shape / strides in numpy order (slowest first), strides in elements"""
+    d = Tensor(); d.data = p.value; d.type = type_; d.reserved = 0
+    if strides is None:
+        strides = [int(np.prod(shape[i + 1:])) for i in range(4)]
+    for i in range(4):
+        d.ne[i] = int(shape[3 - i]); d.nb[i] = int(strides[3 - i]) * es
+    return d
+
+
+def check_flash_attn():
+    cases = [dict(D=64, n_q=1, n_head=32, n_kv=512), dict(D=128, n_q=35, n_head=32, n_kv=1024), dict(D=256, n_q=32, n_head=32, n_kv=512),
+             dict(D=128, n_q=35, n_head=8, n_kv=200, n_head_kv=2, max_bias=8.0), dict(D=128, n_q=3, n_head=4, n_kv=64, softcap=10.0),
+             dict(D=256, n_q=33, n_head=4, n_kv=130, n_head_kv=1, mask=False), dict(D=64, n_q=1, n_head=6, n_kv=517, inf_every=7),
+             dict(D=128, n_q=40, n_head=4, n_kv=300, n_batch=2, permuted=True), dict(D=128, n_q=512, n_head=8, n_kv=512, n_head_kv=2)]
+    for c in cases:
+        D, n_q, n_head, n_kv = c["D"], c["n_q"], c["n_head"], c["n_kv"]
+        n_head_kv, n_batch = c.get("n_head_kv", n_head), c.get("n_batch", 1)
+        mask, max_bias, softcap, permuted, inf_every = c.get("mask", True), c.get("max_bias", 0.0), c.get("softcap", 0.0), c.get("permuted", False), c.get("inf_every", 0)
+        rng = np.random.default_rng(D + n_q + n_kv)
+        q = rng.uniform(-1, 1, (n_batch, n_head, n_q, D)).astype(np.float32)
+        k = rng.uniform(-1, 1, (n_batch, n_head_kv, n_kv, D)).astype(np.float16); v = rng.uniform(-1, 1, (n_batch, n_head_kv, n_kv, D)).astype(np.float16)
+        mrows = (n_q + 63) // 64 * 64
+        m = rng.uniform(-1, 1, (mrows, n_kv)).astype(np.float16) if mask else None
+        if mask and inf_every:
+            m[:, ::inf_every] = -np.inf; m[0, : n_kv // 2] = -np.inf
+        scale = float(1.0 / np.sqrt(D))
+
+        def put(a, type_, es):
+            if not permuted:
+                return desc(to_dev(a), type_, es, a.shape)
+            b_, h_, n_, d_ = a.shape                        # memory order (batch, n, head, D), described as (batch, head, n, D)
+            return desc(to_dev(np.ascontiguousarray(a.transpose(0, 2, 1, 3))), type_, es, a.shape, [n_ * h_ * d_, d_, h_ * d_, 1])
+        dq, dk, dv = put(q, 0, 4), put(k, 1, 2), put(v, 1, 2)
+        dm = desc(to_dev(m), 1, 2, (1, 1, mrows, n_kv)) if mask else None
+        od = dmalloc(4 * n_batch * n_q * n_head * D)
+        dd = desc(od, 0, 4, (n_batch, n_q, n_head, D))
+        t0 = time.time()
+        ok(L.ggml_cdna4_op_flash_attn_ext(C.byref(dq), C.byref(dk), C.byref(dv), C.byref(dm) if mask else None, C.byref(dd),
+                                          C.c_float(scale), C.c_float(max_bias), C.c_float(softcap), None), "flash_attn_ext")
+        y = to_host(od, (n_batch, n_q, n_head, D), np.float32)
+        ee = R.rel_l2(y, R.exact_flash_attn_ext(q, k, v, m, scale, max_bias, softcap))
+        eo = R.rel_l2(y, R.o_flash_attn_ext(q, k, v, m, scale, max_bias, softcap))
+        report(test="flash_attn_ext", **c, rel_l2_float64=ee, rel_l2_oracle=eo, first_call_s=round(time.time() - t0, 3), ok=bool(np.isfinite(y).all() and ee < 1e-3 and eo < 6e-3))
+
+
+def timed(fn, iters=20):
+    """average microseconds per call between two HIP events on the null stream"""
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    hip.hipEventCreate(C.byref(e0)); hip.hipEventCreate(C.byref(e1))
+    for _ in range(3):
+        fn()
+    hip.hipEventRecord(e0, None)
+    for _ in range(iters):
+        fn()
+    hip.hipEventRecord(e1, None); hip.hipEventSynchronize(e1)
+    ms = C.c_float()
+    hip.hipEventElapsedTime(C.byref(ms), e0, e1)
+    return ms.value * 1000.0 / iters
+
+
+def timings():
+    rng = np.random.default_rng(2)
+    m = k = 4096; b = 512
+    xd = to_dev(rng.uniform(-1, 1, (b, k)).astype(np.float32))
+    for name, t in (("q8_0", R.Q8_0), ("q5_0", R.Q5_0), ("q6_K", R.Q6_K), ("q3_K", R.Q3_K), ("q4_K", R.Q4_K)):
+        wd = to_dev(R.random_weights(t, m, k, seed=7))
+        nws = L.ggml_cdna4_mul_mat_workspace_size(C.c_int(t), C.c_int64(k), C.c_int64(b))
+        ws, y = dmalloc(nws), dmalloc(4 * m * b)
+        us = timed(lambda: ok(L.ggml_cdna4_mul_mat(C.c_int(t), wd, C.c_int64(R.row_size(t, k)), xd, C.c_int64(k), y, C.c_int64(m), C.c_int64(m), C.c_int64(k), C.c_int64(b),
+                                                   ws, C.c_size_t(nws), C.c_int(0), C.c_int(0), C.c_int(0), None), "mul_mat"))
+        report(test="time_mul_mat_step", type=name, m=m, k=k, b=b, us_per_call=round(us, 2), effective_tflops=round(2.0 * m * k * b / us / 1e6, 1))
+        for p in (wd, ws, y):
+            hip.hipFree(p)
+    for D, n_q, n_head, n_kv in ((128, 512, 32, 512), (128, 512, 32, 4096), (128, 1, 32, 4096), (128, 1, 32, 32768), (64, 512, 32, 1024), (256, 512, 16, 1024)):
+        q = to_dev(rng.uniform(-1, 1, (1, n_head, n_q, D)).astype(np.float32))
+        kk = to_dev(rng.uniform(-1, 1, (1, n_head, n_kv, D)).astype(np.float16)); vv = to_dev(rng.uniform(-1, 1, (1, n_head, n_kv, D)).astype(np.float16))
+        mrows = (n_q + 63) // 64 * 64
+        mm = to_dev(rng.uniform(-1, 1, (mrows, n_kv)).astype(np.float16))
+        od = dmalloc(4 * n_q * n_head * D)
+        dq, dk, dv = desc(q, 0, 4, (1, n_head, n_q, D)), desc(kk, 1, 2, (1, n_head, n_kv, D)), desc(vv, 1, 2, (1, n_head, n_kv, D))
+        dm, dd = desc(mm, 1, 2, (1, 1, mrows, n_kv)), desc(od, 0, 4, (1, n_q, n_head, D))
+        us = timed(lambda: ok(L.ggml_cdna4_op_flash_attn_ext(C.byref(dq), C.byref(dk), C.byref(dv), C.byref(dm), C.byref(dd), C.c_float(0.088), C.c_float(0.0), C.c_float(0.0), None), "fattn"))
+        flops = 4.0 * n_head * n_q * n_kv * D
+        byts = 2.0 * n_head * n_kv * D * 2 + n_head * n_q * D * 8 + mrows * n_kv * 2
+        report(test="time_flash_attn_ext", D=D, n_q=n_q, n_head=n_head, n_kv=n_kv, us_per_call=round(us, 2), tflops=round(flops / us / 1e6, 2), algorithmic_GBps=round(byts / us / 1e3, 1))
+        for p in (q, kk, vv, mm, od):
+            hip.hipFree(p)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["formats", "fattn"]
+    for w, fn in (("formats", check_formats), ("fattn", check_flash_attn), ("timings", timings)):
+        if w in which:
+            try:
+                fn()
+            except Exception as e:   # noqa: BLE001 — keep going: the other half of the check still says something
+                report(test=w, error=repr(e), ok=False)
+    print("FAILED: %d" % len(fails) if fails else "ALL OK")
+    sys.exit(1 if fails else 0)
