@@ -3,56 +3,113 @@
 //     s = scale * <fp16(q), k>  [-> softcap * tanh(s)]  + slope(head) * mask[q][kv]
 // and the softmax-weighted sum of the value rows.  Head sizes 64 / 128 / 256.
 //
-// One work-group = 32 query rows of one head; its four waves (one per SIMD) each take every fourth 32-key chunk and keep
-// their own running (max, sum, O) — the partial results meet once at the end (in LDS, merged by wave 0).  Decode (1 query row) and
-// prefill run the same code: with few query rows the four waves still split the keys.
-//
 // Everything is held in the accumulator layout of v_mfma_f32_32x32x16_f16 with the QUERY on the column (lane) axis:
-//     S^T [32 kv x 32 q]  = K  [32 kv x hs]      . Q^T      A = 16-byte loads of K rows straight from HBM, B = fp16 Q held in registers
-//     Vt  [32 kv x 32 d]  = V  [32 kv x 32 d]    . I        the matrix core as a transposer: A = 16-byte loads of V rows, B = 0/1 selection
+//     S^T [32 kv x 32 q]  = K  [32 kv x hs]      . Q^T      A = 16-byte reads of K rows, B = fp16 Q held in registers
+//     Vt  [32 kv x 32 d]  = V  [32 kv x 32 d]    . I        the matrix core as a transposer: A = 16-byte reads of V rows, B = 0/1 selection
 //     O^T [32 d  x 32 q] += Vt^T[32 d x 32 kv]   . P^T      A = fp16(Vt) as it sits in the registers, B = fp16(P) as it sits in the registers
 // Lane (q = lane % 32, h = lane / 32) holds accumulator rows rho(r, h) = (r & 3) + 8 (r >> 2) + 4 h, r = 0..15, of its column: the softmax
 // statistics of a query row live in ONE lane pair (lane, lane ^ 32), rescaling O^T is a per-lane multiply, and the k-slots of the third
 // product (8 h + j of step t <-> register 8 t + j) name the same key rho(8 t + j, h) on both operands because both came out of an
-// accumulator whose rows are keys.  V is never gathered with 2-byte loads and nothing goes through LDS in the loop; the price is
-// hs / 16 more MFMAs per chunk (V x identity is exact: products with 1.0, sums with 0.0, fp32 -> fp16 of an fp16 value).
-// Precision: fp16 operands, fp32 accumulation (the CPU accumulates O in fp16 when V is F16: ours is the more accurate side).
+// accumulator whose rows are keys.  V is never gathered with 2-byte accesses (V x identity is exact: products with 1.0, sums with 0.0,
+// fp32 -> fp16 of an fp16 value).  Precision: fp16 operands, fp32 statistics and accumulation (the CPU accumulates O in fp16 when V is
+// F16: ours is the more accurate side).
+//
+// Two kernels share that arithmetic:
+//   k_flash_attn_split  up to 32 query rows per work-group (decode, small batches): the KEYS are split — over `nsplit` work-groups per
+//                       query tile (so that a handful of heads still fills 256 CUs) and, inside a work-group, over its four waves (every
+//                       fourth 32-key chunk).  K / V rows are read straight from HBM / L2 (each byte once per query tile).  The four
+//                       waves' partial (max, sum, O) meet in LDS; with nsplit > 1 the work-group's partial goes to scratch and
+//                       k_flash_attn_merge combines the splits in fixed order (no atomics: deterministic).
+//   k_flash_attn_wide   128 query rows per work-group (prefill): every wave owns 32 query rows and ALL waves walk the same key chunks,
+//                       staged once per work-group into LDS (coalesced 16-byte global loads into registers one chunk ahead, so the HBM
+//                       latency hides behind the MFMAs of the current chunk), K / V traffic per query row a quarter of the split kernel's;
+//                       the transposed V fragments are produced once per work-group (each wave transposes a quarter of the head
+//                       dimension) and shared through LDS: 2 + hs / 16 ... MFMAs per wave and chunk instead of 3 hs / 16.
 #include "../../include/ggml_cdna4.h"
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
 #include <math.h>
+
+void *cdna4_gemm_scratch(size_t bytes, int kind);      // gemm_q_mfma.hip: per-device scratch (kind 4 = partial results of the key split)
+int cdna4_gemm_cu_count();
 
 struct fattn_params {
     const char *q, *k, *v, *mask; float *dst;
     int64_t q_nb1, q_nb2, q_nb3, k_nb1, k_nb2, k_nb3, v_nb1, v_nb2, v_nb3, mask_nb1;       // bytes
     int n_q, n_head, n_kv, rk2, rk3, rv2, rv3;
     float scale, max_bias, logit_softcap, m0, m1; uint32_t n_head_log2;
+    int nsplit, chunks_per_split;                  // key split over work-groups (k_flash_attn_split)
+    float *part;                                   // nsplit > 1: [batch][head][q tile][split][(2 + HS) x 32] floats
 };
 
-template <int HS>
-__global__ __launch_bounds__(256) void k_flash_attn_f16(const fattn_params p) {
-    constexpr int NS = HS / 16, NB = HS / 32;                     // k-steps of Q.K, 32-wide blocks of the head dimension
-    __shared__ float Os[HS * 32];                                 // one wave's O^T at a time: [d][q]
-    __shared__ float Ms[32], Ss[32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * 32, head = blockIdx.y, b3 = blockIdx.z;
-    const int qi = min(q0 + n, p.n_q - 1);                        // rows past the end repeat the last one and are not stored
-
-    // this lane's query row as fp16 B fragments: Q[qi][16 s + 8 h + e]  (q_to_vec_dot = fp32 -> fp16 row, ggml-cpu.c:10929)
+__device__ __forceinline__ float fa_slope(const fattn_params &p, int head) {      // ggml-cpu.c:10902
+    return p.max_bias > 0.0f ? ((uint32_t)head < p.n_head_log2 ? powf(p.m0, (float)(head + 1)) : powf(p.m1, (float)(2 * (head - (int)p.n_head_log2) + 1))) : 1.0f;
+}
+// this lane's query row as fp16 B fragments: Q[qi][16 s + 8 h + e]  (q_to_vec_dot = fp32 -> fp16 row, ggml-cpu.c:10929)
+template <int NS> __device__ __forceinline__ void fa_load_q(const fattn_params &p, int qi, int head, int b3, int h, half8_t (&qf)[NS]) {
     const float *qrow = (const float *)(p.q + (int64_t)qi * p.q_nb1 + (int64_t)head * p.q_nb2 + (int64_t)b3 * p.q_nb3);
-    half8_t qf[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++)
 #pragma unroll
         for (int e = 0; e < 8; e++) qf[s][e] = (half_t)qrow[16 * s + 8 * h + e];
-    // selection operands of the transposing product: B[k-slot 8 h + j][column n] = (n == 16 u + 8 h + j)
-    half8_t sel[2];
+}
+// selection operands of the transposing product: B[k-slot 8 h + j][column n] = (n == 16 u + 8 h + j)
+__device__ __forceinline__ void fa_selectors(int n, int h, half8_t (&sel)[2]) {
 #pragma unroll
     for (int u = 0; u < 2; u++)
 #pragma unroll
         for (int j = 0; j < 8; j++) sel[u][j] = (n == 16 * u + 8 * h + j) ? (half_t)1.0f : (half_t)0.0f;
+}
+// one chunk's scores (accumulator layout) -> scale, softcap, mask; online-softmax update of (M, S); P as fp16 B fragments; returns the
+// factor the O accumulator must be multiplied with
+__device__ __forceinline__ float fa_softmax_step(const fattn_params &p, floatx16 &s, int kv0, int h, const half_t *mrow, float slope, float &M, float &S, half8_t (&pf)[2]) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float x = s[r] * p.scale;
+        if (p.logit_softcap != 0.0f) x = p.logit_softcap * tanhf(x);
+        if (kv < p.n_kv) { if (mrow) x += slope * (float)mrow[kv]; } else x = -INFINITY;
+        s[r] = x; mx = fmaxf(mx, x);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float Mn = fmaxf(M, mx);
+    // everything masked so far: keep (M, S, O) = (-inf, 0, 0) — the CPU skips -inf entries (ggml-cpu.c:10935-10938)
+    const float ms = (M == -INFINITY) ? 0.0f : expf(M - Mn);
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float e = (Mn == -INFINITY) ? 0.0f : expf(s[r] - Mn);
+        sum += e; pf[r >> 3][r & 7] = (half_t)e;
+    }
+    sum += __shfl_xor(sum, 32);
+    S = S * ms + sum; M = Mn;
+    return ms;
+}
+// V /= S and the store: dst is [hs, n_head, n_q, batch] (the permute(0, 2, 1, 3) of ggml-cpu.c:11012); lane (q, h) holds d = 32 b + 8 g + 4 h + 0..3
+template <int NB> __device__ __forceinline__ void fa_store(float *out, const floatx16 (&o)[NB], float inv, int h) {
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            *reinterpret_cast<float4 *>(out + 32 * b + 8 * g + 4 * h) = make_float4(o[b][4 * g] * inv, o[b][4 * g + 1] * inv, o[b][4 * g + 2] * inv, o[b][4 * g + 3] * inv);
+}
 
-    const float slope = p.max_bias > 0.0f ? ((uint32_t)head < p.n_head_log2 ? powf(p.m0, (float)(head + 1)) : powf(p.m1, (float)(2 * (head - (int)p.n_head_log2) + 1))) : 1.0f;
+// ------------------------------------------------------------------------------------------------ key-split kernel (decode, <= 32 query rows per tile)
+template <int HS>
+__global__ __launch_bounds__(256) void k_flash_attn_split(const fattn_params p) {
+    constexpr int NS = HS / 16, NB = HS / 32;                     // k-steps of Q.K, 32-wide blocks of the head dimension
+    __shared__ float Os[HS * 32];                                 // one wave's O^T at a time: [d][q]
+    __shared__ float Ms[32], Ss[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+    const int qt = blockIdx.x / p.nsplit, split = blockIdx.x % p.nsplit;
+    const int q0 = qt * 32, head = blockIdx.y, b3 = blockIdx.z;
+    const int qi = min(q0 + n, p.n_q - 1);                        // rows past the end repeat the last one and are not stored
+
+    half8_t qf[NS], sel[2];
+    fa_load_q<NS>(p, qi, head, b3, h, qf);
+    fa_selectors(n, h, sel);
+    const float slope = fa_slope(p, head);
     const char *kbase = p.k + (int64_t)(head / p.rk2) * p.k_nb2 + (int64_t)(b3 / p.rk3) * p.k_nb3;
     const char *vbase = p.v + (int64_t)(head / p.rv2) * p.v_nb2 + (int64_t)(b3 / p.rv3) * p.v_nb3;
     const half_t *mrow = p.mask ? (const half_t *)(p.mask + (int64_t)qi * p.mask_nb1) : nullptr;
@@ -65,41 +122,19 @@ __global__ __launch_bounds__(256) void k_flash_attn_f16(const fattn_params p) {
         for (int r = 0; r < 16; r++) o[b][r] = 0.0f;
 
     const int nchunk = (p.n_kv + 31) / 32;
-    for (int c = wave; c < nchunk; c += 4) {
+    const int c_lo = split * p.chunks_per_split, c_hi = min(nchunk, c_lo + p.chunks_per_split);
+    for (int c = c_lo + wave; c < c_hi; c += 4) {
         const int kv0 = 32 * c;
         const int64_t row = min(kv0 + n, p.n_kv - 1);             // A row n of this lane = key kv0 + n (past the end: repeated, masked below)
-        // ---- S^T = K . Q^T
-        const char *kp = kbase + row * p.k_nb1 + 16 * h;
+        const char *kp = kbase + row * p.k_nb1 + 16 * h, *vp = vbase + row * p.v_nb1 + 16 * h;
         floatx16 s;
 #pragma unroll
         for (int r = 0; r < 16; r++) s[r] = 0.0f;
 #pragma unroll
         for (int st = 0; st < NS; st++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(kp + 32 * st), qf[st], s, 0, 0, 0);
-        // ---- scale, softcap, mask; chunk maximum of this query row
-        float mx = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            float x = s[r] * p.scale;
-            if (p.logit_softcap != 0.0f) x = p.logit_softcap * tanhf(x);
-            if (kv < p.n_kv) { if (mrow) x += slope * (float)mrow[kv]; } else x = -INFINITY;
-            s[r] = x; mx = fmaxf(mx, x);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float Mn = fmaxf(M, mx);
-        // everything masked so far: keep (M, S, O) = (-inf, 0, 0) — the CPU skips -inf entries (ggml-cpu.c:10935-10938)
-        const float ms = (M == -INFINITY) ? 0.0f : expf(M - Mn);
-        float sum = 0.0f;
         half8_t pf[2];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float e = (Mn == -INFINITY) ? 0.0f : expf(s[r] - Mn);
-            sum += e; pf[r >> 3][r & 7] = (half_t)e;
-        }
-        sum += __shfl_xor(sum, 32);
-        S = S * ms + sum; M = Mn;
-        // ---- O^T = O^T * ms + Vt^T . P^T, one 32-wide block of the head dimension at a time
-        const char *vp = vbase + row * p.v_nb1 + 16 * h;
+        const float ms = fa_softmax_step(p, s, kv0, h, mrow, slope, M, S, pf);
+        // O^T = O^T * ms + Vt^T . P^T, one 32-wide block of the head dimension at a time
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             floatx16 vt;
@@ -115,8 +150,8 @@ __global__ __launch_bounds__(256) void k_flash_attn_f16(const fattn_params p) {
         }
     }
 
-    // ---- the four partial results meet: waves 1..3 hand theirs to wave 0 one after the other through LDS (same lane <-> element
-    // mapping on both sides: Os[d][q], q = lane % 32 — conflict-free)
+    // the four partial results meet: waves 1..3 hand theirs to wave 0 one after the other through LDS (same lane <-> element mapping on
+    // both sides: Os[d][q], q = lane % 32 — conflict-free)
     for (int w = 1; w < 4; w++) {
         __syncthreads();
         if (wave == w) {
@@ -137,16 +172,123 @@ __global__ __launch_bounds__(256) void k_flash_attn_f16(const fattn_params p) {
             S = S * a0 + Sw * aw; M = Mn;
         }
     }
-    // ---- V /= S; dst is [hs, n_head, n_q, batch] (the permute(0, 2, 1, 3) of ggml-cpu.c:11012)
-    if (wave == 0 && q0 + n < p.n_q) {
-        const float inv = 1.0f / S;
-        float *out = p.dst + (((int64_t)b3 * p.n_q + (q0 + n)) * p.n_head + head) * HS;
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-                *reinterpret_cast<float4 *>(out + 32 * b + 8 * g + 4 * h) = make_float4(o[b][4 * g] * inv, o[b][4 * g + 1] * inv, o[b][4 * g + 2] * inv, o[b][4 * g + 3] * inv);
+    if (wave != 0 || q0 + n >= p.n_q) return;
+    if (p.nsplit == 1) {
+        fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + (q0 + n)) * p.n_head + head) * HS, o, 1.0f / S, h);
+    } else {
+        // this split's unnormalized (M, S, O) for k_flash_attn_merge: [.. tile][split][q][2 + HS] — the rows that exist, contiguous
+        float *pt = p.part + ((((int64_t)b3 * p.n_head + head) * gridDim.x + blockIdx.x) * 32 + n) * (HS + 4);
+        if (h == 0) { pt[0] = M; pt[1] = S; }
+        fa_store<NB>(pt + 4, o, 1.0f, h);
     }
+}
+
+// out[q][d] = sum_s O_s[q][d] e^(M_s - M*) / sum_s S_s e^(M_s - M*), splits in index order.  One work-group per (query tile, head, batch).
+template <int HS>
+__global__ __launch_bounds__(256) void k_flash_attn_merge(const fattn_params p) {
+    const int qt = blockIdx.x, head = blockIdx.y, b3 = blockIdx.z;
+    const float *base = p.part + (((int64_t)b3 * p.n_head + head) * (gridDim.x * p.nsplit) + (int64_t)qt * p.nsplit) * 32 * (HS + 4);
+    for (int i = threadIdx.x; i < 32 * HS; i += 256) {
+        const int q = i / HS, d = i % HS;
+        if (qt * 32 + q >= p.n_q) break;
+        float Mx = -INFINITY;
+        for (int s = 0; s < p.nsplit; s++) Mx = fmaxf(Mx, base[((int64_t)s * 32 + q) * (HS + 4)]);
+        float num = 0.0f, den = 0.0f;
+        for (int s = 0; s < p.nsplit; s++) {
+            const float *pt = base + ((int64_t)s * 32 + q) * (HS + 4);
+            const float a = (pt[0] == -INFINITY) ? 0.0f : expf(pt[0] - Mx);
+            num += pt[4 + d] * a; den += pt[1] * a;
+        }
+        p.dst[(((int64_t)b3 * p.n_q + (qt * 32 + q)) * p.n_head + head) * HS + d] = num * (1.0f / den);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ wide kernel (prefill, 128 query rows per work-group)
+template <int HS>
+__global__ __launch_bounds__(256) void k_flash_attn_wide(const fattn_params p) {
+    constexpr int NS = HS / 16, NB = HS / 32;
+    constexpr int RS = (HS + 8) * 2;                              // bytes of a staged K / V row: 16 bytes of padding spread the rows over the banks
+    constexpr int PIECES = 32 * HS / 8, PL = PIECES / 256;        // 16-byte pieces of one 32-row chunk, per thread
+    __shared__ __attribute__((aligned(16))) uint8_t Ks[32 * RS], Vs[32 * RS];
+    __shared__ __attribute__((aligned(16))) uint8_t Vt[NB * 2 * 64 * 16];     // transposed V as A fragments: [block][step][lane] x 16 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 128 + 32 * wave, head = blockIdx.y, b3 = blockIdx.z;
+    const bool active = q0 < p.n_q;                               // a wave whose 32 rows are all past the end only helps with the staging
+    const int qi = min(q0 + n, p.n_q - 1);
+
+    half8_t qf[NS], sel[2];
+    fa_load_q<NS>(p, qi, head, b3, h, qf);
+    fa_selectors(n, h, sel);
+    const float slope = fa_slope(p, head);
+    const char *kbase = p.k + (int64_t)(head / p.rk2) * p.k_nb2 + (int64_t)(b3 / p.rk3) * p.k_nb3;
+    const char *vbase = p.v + (int64_t)(head / p.rv2) * p.v_nb2 + (int64_t)(b3 / p.rv3) * p.v_nb3;
+    const half_t *mrow = p.mask ? (const half_t *)(p.mask + (int64_t)qi * p.mask_nb1) : nullptr;
+
+    float M = -INFINITY, S = 0.0f;
+    floatx16 o[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[b][r] = 0.0f;
+
+    // staging: piece pc = tid + 256 i of a chunk = (row pc / (HS / 8), 16-byte column pc % (HS / 8)): a wave reads whole rows, coalesced
+    u32x4 kreg[PL], vreg[PL];
+    auto fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PL; i++) {
+            const int pc = tid + 256 * i, row = pc / (HS / 8), col = pc % (HS / 8);
+            const int64_t kr = min(32 * c + row, p.n_kv - 1);     // past the end: repeated, masked in the softmax
+            kreg[i] = *reinterpret_cast<const u32x4 *>(kbase + kr * p.k_nb1 + 16 * col);
+            vreg[i] = *reinterpret_cast<const u32x4 *>(vbase + kr * p.v_nb1 + 16 * col);
+        }
+    };
+    const int nchunk = (p.n_kv + 31) / 32;
+    fetch(0);
+    for (int c = 0; c < nchunk; c++) {
+        __syncthreads();                                          // every wave is done with the previous chunk's Ks / Vs / Vt
+#pragma unroll
+        for (int i = 0; i < PL; i++) {
+            const int pc = tid + 256 * i, row = pc / (HS / 8), col = pc % (HS / 8);
+            *reinterpret_cast<u32x4 *>(Ks + row * RS + 16 * col) = kreg[i];
+            *reinterpret_cast<u32x4 *>(Vs + row * RS + 16 * col) = vreg[i];
+        }
+        __syncthreads();
+        if (c + 1 < nchunk) fetch(c + 1);                         // in flight while this chunk is computed
+        // this wave's share of the transposed V fragments (blocks wave, wave + 4, ..)
+        for (int b = wave; b < NB; b += 4) {
+            floatx16 vt;
+#pragma unroll
+            for (int r = 0; r < 16; r++) vt[r] = 0.0f;
+            vt = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Vs + n * RS + 64 * b + 16 * h), sel[0], vt, 0, 0, 0);
+            vt = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Vs + n * RS + 64 * b + 32 + 16 * h), sel[1], vt, 0, 0, 0);
+            half8_t vf[2];
+#pragma unroll
+            for (int r = 0; r < 16; r++) vf[r >> 3][r & 7] = (half_t)vt[r];
+            *reinterpret_cast<half8_t *>(Vt + ((b * 2 + 0) * 64 + lane) * 16) = vf[0];
+            *reinterpret_cast<half8_t *>(Vt + ((b * 2 + 1) * 64 + lane) * 16) = vf[1];
+        }
+        half8_t pf[2];
+        float ms = 1.0f;
+        if (active) {
+            floatx16 s;
+#pragma unroll
+            for (int r = 0; r < 16; r++) s[r] = 0.0f;
+#pragma unroll
+            for (int st = 0; st < NS; st++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Ks + n * RS + 32 * st + 16 * h), qf[st], s, 0, 0, 0);
+            ms = fa_softmax_step(p, s, 32 * c, h, mrow, slope, M, S, pf);
+        }
+        __syncthreads();                                          // Vt is complete
+        if (active) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[b][r] *= ms;
+                o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Vt + ((b * 2 + 0) * 64 + lane) * 16), pf[0], o[b], 0, 0, 0);
+                o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Vt + ((b * 2 + 1) * 64 + lane) * 16), pf[1], o[b], 0, 0, 0);
+            }
+        }
+    }
+    if (q0 + n < p.n_q) fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + (q0 + n)) * p.n_head + head) * HS, o, 1.0f / S, h);
 }
 
 #define NEED(cond, msg) do { if (!(cond)) return cdna4_set_error_msg(msg); } while (0)
@@ -188,12 +330,39 @@ extern "C" int ggml_cdna4_op_flash_attn_ext(const T4 *q, const T4 *k, const T4 *
     p.scale = logit_softcap != 0.0f ? scale / logit_softcap : scale; p.max_bias = max_bias; p.logit_softcap = logit_softcap;
     p.n_head_log2 = 1u << (uint32_t)floorf(log2f((float)H));
     p.m0 = powf(2.0f, -(max_bias) / p.n_head_log2); p.m1 = powf(2.0f, -(max_bias / 2.0f) / p.n_head_log2);
-
-    const dim3 grid((unsigned)((N + 31) / 32), (unsigned)H, (unsigned)B3);
+    p.nsplit = 1; p.chunks_per_split = (int)((KV + 31) / 32); p.part = nullptr;
     hipStream_t st = (hipStream_t)stream;
-    if (D == 64) hipLaunchKernelGGL(k_flash_attn_f16<64>, grid, dim3(256), 0, st, p);
-    else if (D == 128) hipLaunchKernelGGL(k_flash_attn_f16<128>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(k_flash_attn_f16<256>, grid, dim3(256), 0, st, p);
+
+    if (N > 32) {                                                 // prefill: 128 query rows per work-group, K / V staged through LDS
+        const dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B3);
+        if (D == 64) hipLaunchKernelGGL(k_flash_attn_wide<64>, grid, dim3(256), 0, st, p);
+        else if (D == 128) hipLaunchKernelGGL(k_flash_attn_wide<128>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_flash_attn_wide<256>, grid, dim3(256), 0, st, p);
+        CDNA4_CHECK_LAUNCH();
+        return 0;
+    }
+    // decode / small batches: split the keys over work-groups until the chip is full (two work-groups per CU), each split >= 8 chunks
+    const int64_t nchunk = (KV + 31) / 32, tiles = H * B3;
+    int64_t want = (2 * (int64_t)cdna4_gemm_cu_count() + tiles - 1) / tiles;
+    if (want > nchunk / 8) want = nchunk / 8;
+    if (want < 1) want = 1;
+    p.chunks_per_split = (int)((nchunk + want - 1) / want);
+    p.nsplit = (int)((nchunk + p.chunks_per_split - 1) / p.chunks_per_split);
+    if (p.nsplit > 1) {
+        p.part = (float *)cdna4_gemm_scratch((size_t)tiles * p.nsplit * 32 * (D + 4) * 4 + 256, 4);
+        NEED(p.part, "flash_attn_ext: cannot allocate the key-split scratch");
+    }
+    const dim3 grid((unsigned)p.nsplit, (unsigned)H, (unsigned)B3);
+    if (D == 64) hipLaunchKernelGGL(k_flash_attn_split<64>, grid, dim3(256), 0, st, p);
+    else if (D == 128) hipLaunchKernelGGL(k_flash_attn_split<128>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(k_flash_attn_split<256>, grid, dim3(256), 0, st, p);
     CDNA4_CHECK_LAUNCH();
+    if (p.nsplit > 1) {
+        const dim3 mgrid(1, (unsigned)H, (unsigned)B3);
+        if (D == 64) hipLaunchKernelGGL(k_flash_attn_merge<64>, mgrid, dim3(256), 0, st, p);
+        else if (D == 128) hipLaunchKernelGGL(k_flash_attn_merge<128>, mgrid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_flash_attn_merge<256>, mgrid, dim3(256), 0, st, p);
+        CDNA4_CHECK_LAUNCH();
+    }
     return 0;
 }

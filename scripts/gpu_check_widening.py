@@ -126,7 +126,9 @@ def check_flash_attn():
     cases = [dict(D=64, n_q=1, n_head=32, n_kv=512), dict(D=128, n_q=35, n_head=32, n_kv=1024), dict(D=256, n_q=32, n_head=32, n_kv=512),
              dict(D=128, n_q=35, n_head=8, n_kv=200, n_head_kv=2, max_bias=8.0), dict(D=128, n_q=3, n_head=4, n_kv=64, softcap=10.0),
              dict(D=256, n_q=33, n_head=4, n_kv=130, n_head_kv=1, mask=False), dict(D=64, n_q=1, n_head=6, n_kv=517, inf_every=7),
-             dict(D=128, n_q=40, n_head=4, n_kv=300, n_batch=2, permuted=True), dict(D=128, n_q=512, n_head=8, n_kv=512, n_head_kv=2)]
+             dict(D=128, n_q=40, n_head=4, n_kv=300, n_batch=2, permuted=True), dict(D=128, n_q=512, n_head=8, n_kv=512, n_head_kv=2),
+             dict(D=64, n_q=130, n_head=4, n_kv=257, inf_every=4), dict(D=256, n_q=200, n_head=2, n_kv=96, n_batch=2), dict(D=128, n_q=2, n_head=4, n_kv=8192, inf_every=3),
+             dict(D=64, n_q=1, n_head=2, n_kv=32768), dict(D=256, n_q=300, n_head=3, n_kv=1000, n_head_kv=1, max_bias=8.0), dict(D=128, n_q=32, n_head=32, n_kv=1024)]
     for c in cases:
         D, n_q, n_head, n_kv = c["D"], c["n_q"], c["n_head"], c["n_kv"]
         n_head_kv, n_batch = c.get("n_head_kv", n_head), c.get("n_batch", 1)

@@ -1,4 +1,4 @@
-// fattn_emul.cpp — runs the SOURCE of the FLASH_ATTN_EXT kernel (ggml_amd/csrc/fattn.hip: k_flash_attn_f16<64 / 128 / 256>) on the CPU, one OS
+// fattn_emul.cpp — runs the SOURCE of the FLASH_ATTN_EXT kernels (ggml_amd/csrc/fattn.hip: k_flash_attn_split / _merge / _wide <64 / 128 / 256>) on the CPU, one OS
 // thread per GPU thread, the 32x32x16 fp16 MFMA emulated lane for lane (hip_emul.h).  Test infrastructure.
 //   fattn_emul D n_q n_head n_batch n_kv n_head_kv n_batch_kv has_mask mask_rows scale max_bias softcap permuted q.bin k.bin v.bin mask.bin out.bin
 // q f32 [n_batch][n_head][n_q][D] (permuted = 1: stored [n_batch][n_q][n_head][D] and described through strides, like the stock test's
@@ -60,6 +60,10 @@ template <typename F> static void emu_launch(F body, dim3 grid, dim3 block) {
     if (failed) { fprintf(stderr, "work-group process failed\n"); exit(3); }
     if (cannot) { fprintf(stderr, "the environment cannot host the emulation\n"); exit(77); }
 }
+
+// the library's per-device scratch (gemm_q_mfma.hip) and CU count, as far as fattn.hip needs them; EMU_CUS sets the CU count the key split is sized for
+void *cdna4_gemm_scratch(size_t bytes, int) { static void *p = nullptr; static size_t n = 0; if (bytes > n) { p = shared_alloc(bytes); n = bytes; } return p; }
+int cdna4_gemm_cu_count() { const char *e = getenv("EMU_CUS"); return e ? atoi(e) : 256; }
 
 #include "../../ggml_amd/csrc/fattn.hip"
 
