@@ -175,9 +175,16 @@ def timed(fn, iters=20):
     return ms.value * 1000.0 / iters
 
 
-def timings():
+def timings(formats=True):
     rng = np.random.default_rng(2)
     m = k = 4096; b = 512
+    if formats:
+        timings_formats(rng, m, k, b)
+    for D, n_q, n_head, n_kv in ((128, 512, 32, 512), (128, 512, 32, 4096), (128, 4096, 32, 4096), (128, 1, 32, 4096), (128, 1, 32, 32768), (128, 8, 32, 4096), (64, 512, 32, 1024), (256, 512, 16, 1024)):
+        time_fa(rng, D, n_q, n_head, n_kv)
+
+
+def timings_formats(rng, m, k, b):
     xd = to_dev(rng.uniform(-1, 1, (b, k)).astype(np.float32))
     for name, t in (("q8_0", R.Q8_0), ("q5_0", R.Q5_0), ("q6_K", R.Q6_K), ("q3_K", R.Q3_K), ("q4_K", R.Q4_K)):
         wd = to_dev(R.random_weights(t, m, k, seed=7))
@@ -188,7 +195,10 @@ def timings():
         report(test="time_mul_mat_step", type=name, m=m, k=k, b=b, us_per_call=round(us, 2), effective_tflops=round(2.0 * m * k * b / us / 1e6, 1))
         for p in (wd, ws, y):
             hip.hipFree(p)
-    for D, n_q, n_head, n_kv in ((128, 512, 32, 512), (128, 512, 32, 4096), (128, 1, 32, 4096), (128, 1, 32, 32768), (64, 512, 32, 1024), (256, 512, 16, 1024)):
+
+
+def time_fa(rng, D, n_q, n_head, n_kv):
+    if True:
         q = to_dev(rng.uniform(-1, 1, (1, n_head, n_q, D)).astype(np.float32))
         kk = to_dev(rng.uniform(-1, 1, (1, n_head, n_kv, D)).astype(np.float16)); vv = to_dev(rng.uniform(-1, 1, (1, n_head, n_kv, D)).astype(np.float16))
         mrows = (n_q + 63) // 64 * 64
@@ -206,7 +216,7 @@ def timings():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["formats", "fattn"]
-    for w, fn in (("formats", check_formats), ("fattn", check_flash_attn), ("timings", timings)):
+    for w, fn in (("formats", check_formats), ("fattn", check_flash_attn), ("timings", timings), ("timings_fa", lambda: timings(False))):
         if w in which:
             try:
                 fn()
