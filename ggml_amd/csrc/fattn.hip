@@ -15,7 +15,7 @@
 // F16: ours is the more accurate side).
 //
 // Two kernels share that arithmetic:
-//   k_flash_attn_split  up to 32 query rows per work-group (decode, small batches): the KEYS are split — over `nsplit` work-groups per
+//   k_flash_attn_split  32 query rows per work-group (decode, small batches, prefill too small to fill the chip with 128-row tiles): the KEYS are split — over `nsplit` work-groups per
 //                       query tile (so that a handful of heads still fills 256 CUs) and, inside a work-group, over its four waves (every
 //                       fourth 32-key chunk).  K / V rows are read straight from HBM / L2 (each byte once per query tile).  The four
 //                       waves' partial (max, sum, O) meet in LDS; with nsplit > 1 the work-group's partial goes to scratch and
@@ -38,6 +38,7 @@ struct fattn_params {
     int64_t q_nb1, q_nb2, q_nb3, k_nb1, k_nb2, k_nb3, v_nb1, v_nb2, v_nb3, mask_nb1;       // bytes
     int n_q, n_head, n_kv, rk2, rk3, rv2, rv3;
     float scale, max_bias, logit_softcap, m0, m1; uint32_t n_head_log2;
+    int mask_vec;                                  // mask rows are 16-byte aligned: whole chunks take the vector path of fa_softmax_step
     int nsplit, chunks_per_split;                  // key split over work-groups (k_flash_attn_split)
     float *part;                                   // nsplit > 1: [batch][head][q tile][split][(2 + HS) x 32] floats
 };
@@ -61,15 +62,35 @@ __device__ __forceinline__ void fa_selectors(int n, int h, half8_t (&sel)[2]) {
         for (int j = 0; j < 8; j++) sel[u][j] = (n == 16 * u + 8 * h + j) ? (half_t)1.0f : (half_t)0.0f;
 }
 // one chunk's scores (accumulator layout) -> scale, softcap, mask; online-softmax update of (M, S); P as fp16 B fragments; returns the
-// factor the O accumulator must be multiplied with
-__device__ __forceinline__ float fa_softmax_step(const fattn_params &p, floatx16 &s, int kv0, int h, const half_t *mrow, float slope, float &M, float &S, half8_t (&pf)[2]) {
+// factor the O accumulator must be multiplied with.
+// The mask tile [32 q x 32 kv] is wanted TRANSPOSED (keys on the accumulator rows).  Whole chunks of a 16-byte aligned mask are read as B
+// fragments — 16 contiguous bytes of this lane's mask row per k-step — and transposed by the matrix core against the same 0/1 selection
+// operands the V transposition uses (exact; -inf is clamped to the largest finite fp16 in front of the product, 0 x inf being NaN, and
+// restored behind it).  Ragged chunks and unaligned masks read the sixteen values one by one.
+__device__ __forceinline__ float fa_softmax_step(const fattn_params &p, floatx16 &s, int kv0, int n, int h, const half_t *mrow, float slope, const half8_t (&sel)[2],
+                                                 float &M, float &S, half8_t (&pf)[2]) {
+    const bool vec = mrow && p.mask_vec && kv0 + 32 <= p.n_kv;                 // wave-uniform
+    floatx16 mt;
+    if (vec) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) mt[r] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            half8_t mb = *reinterpret_cast<const half8_t *>(mrow + kv0 + 16 * u + 8 * h);
+#pragma unroll
+            for (int e = 0; e < 8; e++) mb[e] = mb[e] < (half_t)-65504.0f ? (half_t)-65504.0f : mb[e];
+            mt = __builtin_amdgcn_mfma_f32_32x32x16_f16(sel[u], mb, mt, 0, 0, 0);
+        }
+    }
+    (void)n;
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         float x = s[r] * p.scale;
         if (p.logit_softcap != 0.0f) x = p.logit_softcap * tanhf(x);
-        if (kv < p.n_kv) { if (mrow) x += slope * (float)mrow[kv]; } else x = -INFINITY;
+        if (vec) x += mt[r] <= -65504.0f ? -INFINITY : slope * mt[r];
+        else if (kv < p.n_kv) { if (mrow) x += slope * (float)mrow[kv]; } else x = -INFINITY;
         s[r] = x; mx = fmaxf(mx, x);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -97,7 +118,7 @@ template <int NB> __device__ __forceinline__ void fa_store(float *out, const flo
 
 // ------------------------------------------------------------------------------------------------ key-split kernel (decode, <= 32 query rows per tile)
 template <int HS>
-__global__ __launch_bounds__(256) void k_flash_attn_split(const fattn_params p) {
+__global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_split(const fattn_params p) {
     constexpr int NS = HS / 16, NB = HS / 32;                     // k-steps of Q.K, 32-wide blocks of the head dimension
     __shared__ float Os[HS * 32];                                 // one wave's O^T at a time: [d][q]
     __shared__ float Ms[32], Ss[32];
@@ -133,7 +154,7 @@ __global__ __launch_bounds__(256) void k_flash_attn_split(const fattn_params p) 
 #pragma unroll
         for (int st = 0; st < NS; st++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(kp + 32 * st), qf[st], s, 0, 0, 0);
         half8_t pf[2];
-        const float ms = fa_softmax_step(p, s, kv0, h, mrow, slope, M, S, pf);
+        const float ms = fa_softmax_step(p, s, kv0, n, h, mrow, slope, sel, M, S, pf);
         // O^T = O^T * ms + Vt^T . P^T, one 32-wide block of the head dimension at a time
 #pragma unroll
         for (int b = 0; b < NB; b++) {
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(256) void k_flash_attn_merge(const fattn_params p) 
 
 // ------------------------------------------------------------------------------------------------ wide kernel (prefill, 128 query rows per work-group)
 template <int HS>
-__global__ __launch_bounds__(256) void k_flash_attn_wide(const fattn_params p) {
+__global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_wide(const fattn_params p) {
     constexpr int NS = HS / 16, NB = HS / 32;
     constexpr int RS = (HS + 8) * 2;                              // bytes of a staged K / V row: 16 bytes of padding spread the rows over the banks
     constexpr int PIECES = 32 * HS / 8, PL = PIECES / 256;        // 16-byte pieces of one 32-row chunk, per thread
@@ -275,7 +296,7 @@ __global__ __launch_bounds__(256) void k_flash_attn_wide(const fattn_params p) {
             for (int r = 0; r < 16; r++) s[r] = 0.0f;
 #pragma unroll
             for (int st = 0; st < NS; st++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Ks + n * RS + 32 * st + 16 * h), qf[st], s, 0, 0, 0);
-            ms = fa_softmax_step(p, s, 32 * c, h, mrow, slope, M, S, pf);
+            ms = fa_softmax_step(p, s, 32 * c, n, h, mrow, slope, sel, M, S, pf);
         }
         __syncthreads();                                          // Vt is complete
         if (active) {
@@ -333,7 +354,9 @@ extern "C" int ggml_cdna4_op_flash_attn_ext(const T4 *q, const T4 *k, const T4 *
     p.nsplit = 1; p.chunks_per_split = (int)((KV + 31) / 32); p.part = nullptr;
     hipStream_t st = (hipStream_t)stream;
 
-    if (N > 32) {                                                 // prefill: 128 query rows per work-group, K / V staged through LDS
+    p.mask_vec = mask && !(((uintptr_t)mask->data | (uintptr_t)mask->nb[1]) & 15);
+    const int64_t cus = cdna4_gemm_cu_count();
+    if (N > 32 && ((N + 127) / 128) * H * B3 >= cus) {           // prefill that fills the chip: 128 query rows per work-group, K / V staged through LDS
         const dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B3);
         if (D == 64) hipLaunchKernelGGL(k_flash_attn_wide<64>, grid, dim3(256), 0, st, p);
         else if (D == 128) hipLaunchKernelGGL(k_flash_attn_wide<128>, grid, dim3(256), 0, st, p);
@@ -341,9 +364,10 @@ extern "C" int ggml_cdna4_op_flash_attn_ext(const T4 *q, const T4 *k, const T4 *
         CDNA4_CHECK_LAUNCH();
         return 0;
     }
-    // decode / small batches: split the keys over work-groups until the chip is full (two work-groups per CU), each split >= 8 chunks
-    const int64_t nchunk = (KV + 31) / 32, tiles = H * B3;
-    int64_t want = (2 * (int64_t)cdna4_gemm_cu_count() + tiles - 1) / tiles;
+    // decode / small batches: 32-row query tiles, the keys split over work-groups until the chip is full (two work-groups per CU), each split
+    // >= 8 chunks
+    const int64_t nchunk = (KV + 31) / 32, qtiles = (N + 31) / 32, tiles = qtiles * H * B3;
+    int64_t want = (2 * cus + tiles - 1) / tiles;
     if (want > nchunk / 8) want = nchunk / 8;
     if (want < 1) want = 1;
     p.chunks_per_split = (int)((nchunk + want - 1) / want);
@@ -352,13 +376,13 @@ extern "C" int ggml_cdna4_op_flash_attn_ext(const T4 *q, const T4 *k, const T4 *
         p.part = (float *)cdna4_gemm_scratch((size_t)tiles * p.nsplit * 32 * (D + 4) * 4 + 256, 4);
         NEED(p.part, "flash_attn_ext: cannot allocate the key-split scratch");
     }
-    const dim3 grid((unsigned)p.nsplit, (unsigned)H, (unsigned)B3);
+    const dim3 grid((unsigned)(qtiles * p.nsplit), (unsigned)H, (unsigned)B3);
     if (D == 64) hipLaunchKernelGGL(k_flash_attn_split<64>, grid, dim3(256), 0, st, p);
     else if (D == 128) hipLaunchKernelGGL(k_flash_attn_split<128>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(k_flash_attn_split<256>, grid, dim3(256), 0, st, p);
     CDNA4_CHECK_LAUNCH();
     if (p.nsplit > 1) {
-        const dim3 mgrid(1, (unsigned)H, (unsigned)B3);
+        const dim3 mgrid((unsigned)qtiles, (unsigned)H, (unsigned)B3);
         if (D == 64) hipLaunchKernelGGL(k_flash_attn_merge<64>, mgrid, dim3(256), 0, st, p);
         else if (D == 128) hipLaunchKernelGGL(k_flash_attn_merge<128>, mgrid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_flash_attn_merge<256>, mgrid, dim3(256), 0, st, p);

@@ -343,17 +343,21 @@ def test_to_float_sources_on_the_cpu_bit_exact(t):
     assert _emul_module("deq_emul_check").run(t, 32 * 256 if t > 9 else 32 * 24, seed=t)
 
 
-FATTN_EMUL_CASES = [dict(D=64, n_q=5, n_head=2, n_kv=96), dict(D=128, n_q=35, n_head=4, n_kv=200, n_head_kv=2, max_bias=8.0), dict(D=128, n_q=3, n_head=2, n_kv=64, softcap=10.0),
-                    dict(D=256, n_q=33, n_head=2, n_kv=130, n_head_kv=1, mask=False), dict(D=64, n_q=1, n_head=3, n_kv=517, inf_every=7),
-                    dict(D=128, n_q=40, n_head=2, n_kv=300, n_batch=2, permuted=True), dict(D=64, n_q=32, n_head=2, n_kv=31),
-                    dict(D=256, n_q=1, n_head=2, n_kv=1024, max_bias=8.0, inf_every=5), dict(D=128, n_q=2, n_head=2, n_kv=2048, inf_every=3),
-                    dict(D=64, n_q=130, n_head=2, n_kv=257, inf_every=4), dict(D=256, n_q=200, n_head=1, n_kv=96, n_batch=2), dict(D=128, n_q=512, n_head=2, n_kv=512, n_head_kv=1)]
+FATTN_EMUL_CASES = [dict(D=64, n_q=5, n_head=2, n_kv=96), dict(D=128, n_q=35, n_head=4, n_kv=200, n_head_kv=2, max_bias=8.0), dict(D=128, n_q=35, n_head=4, n_kv=200, n_head_kv=2, max_bias=8.0, cus=2),
+                    dict(D=128, n_q=3, n_head=2, n_kv=64, softcap=10.0), dict(D=256, n_q=33, n_head=2, n_kv=130, n_head_kv=1, mask=False, cus=1),
+                    dict(D=64, n_q=1, n_head=3, n_kv=517, inf_every=7), dict(D=128, n_q=40, n_head=2, n_kv=300, n_batch=2, permuted=True, cus=4),
+                    dict(D=64, n_q=32, n_head=2, n_kv=31), dict(D=256, n_q=1, n_head=2, n_kv=1024, max_bias=8.0, inf_every=5), dict(D=128, n_q=2, n_head=2, n_kv=2048, inf_every=3),
+                    dict(D=64, n_q=130, n_head=2, n_kv=257, inf_every=4), dict(D=64, n_q=130, n_head=2, n_kv=256, inf_every=4, cus=2),
+                    dict(D=64, n_q=70, n_head=2, n_kv=1024, inf_every=4, max_bias=8.0), dict(D=256, n_q=200, n_head=1, n_kv=96, n_batch=2, cus=2),
+                    dict(D=128, n_q=512, n_head=2, n_kv=512, n_head_kv=1, cus=8, inf_every=3)]
 
 
 @pytest.mark.parametrize("kw", FATTN_EMUL_CASES)
 def test_flash_attn_source_on_the_cpu(kw):
-    """tools/emul/fattn_emul: k_flash_attn_split (+ k_flash_attn_merge when the keys are split over work-groups: the n_kv >= 512 cases) and
-    k_flash_attn_wide (n_q > 32: K / V chunks and the transposed V fragments shared through LDS) — S^T = K.Q^T, V transposed on the matrix
+    """tools/emul/fattn_emul: k_flash_attn_split (+ k_flash_attn_merge when the keys are split over work-groups: the n_kv >= 512 cases; one or
+    several 32-row query tiles) and k_flash_attn_wide (the `cus` cases — chosen when 128-row tiles fill the chip: K / V chunks and the
+    transposed V fragments shared through LDS); masks on the vector path (16-byte aligned rows, transposed by the matrix core, -inf
+    included) and on the element path (n_kv not a multiple of 8, ragged last chunk) — S^T = K.Q^T, V transposed on the matrix
     core, O^T += Vt^T.P^T — executed on the CPU with the MFMA emulated lane for lane: <= 5e-4 from a float64 evaluation of the operator, <= 6e-3 from the
     oracle (whose FP16 accumulator — the reference's, ggml-cpu.c:10960-10974 — is the larger part of that distance).  Grouped-query heads,
     ALiBi, softcap, no mask, -inf mask entries incl. a fully masked stretch, batches, permuted operands, ragged n_q / n_kv."""

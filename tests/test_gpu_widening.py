@@ -99,9 +99,11 @@ def test_more_formats_to_float_is_bit_exact(gu, name, t):
 # ------------------------------------------------------------------------------------------------ FLASH_ATTN_EXT
 # Bars.  The reference keeps its O accumulator in FP16 when V is F16 (ggml-cpu.c:10960-10974) and lands 1-3e-3 (relative L2) from a float64
 # evaluation of the operator; the HIP kernel accumulates in fp32 and lands ~2e-4 from it (CPU emulation of the kernel source).  So:
-# <= 1e-3 against float64, <= 6e-3 against the oracle (= the reference's arithmetic, pinned in test_oracle_vs_ref.py); the stock
-# harness's own gate for this op is NMSE 5e-4 = 2.2e-2 relative L2 (tests/test-backend-ops.cpp:3136-3138).
-TOL_FA_EXACT, TOL_FA_ORACLE = 1e-3, 6e-3
+# <= 1e-3 against float64, and against the oracle (= the reference's arithmetic, pinned in test_oracle_vs_ref.py) no further than the oracle
+# itself is from float64 plus that 1e-3 — the reference's FP16 accumulator error grows with the number of keys (measured on MI355X: 3e-3 at
+# 1 K keys, 9e-3 at 8 K, 2.4e-2 at 32 K, the HIP kernel staying at 1.9e-4).  The stock harness's own gate for this op is NMSE 5e-4 = 2.2e-2
+# relative L2 (tests/test-backend-ops.cpp:3136-3138).
+TOL_FA_EXACT = 1e-3
 
 
 def _fa_case(gu, D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max_bias=0.0, softcap=0.0, permuted=False, inf_every=0, seed=1):
@@ -122,11 +124,11 @@ def _fa_case(gu, D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max
         dev = gu.to_dev
     y = ops.flash_attn_ext(dev(q), dev(k), dev(v), gu.to_dev(m) if mask else None, scale, max_bias, softcap).cpu().numpy()
     assert np.isfinite(y).all()
-    ee = R.rel_l2(y, R.exact_flash_attn_ext(q, k, v, m, scale, max_bias, softcap))
-    eo = R.rel_l2(y, R.o_flash_attn_ext(q, k, v, m, scale, max_bias, softcap))
+    ye, yo = R.exact_flash_attn_ext(q, k, v, m, scale, max_bias, softcap), R.o_flash_attn_ext(q, k, v, m, scale, max_bias, softcap)
+    ee, eo, eoe = R.rel_l2(y, ye), R.rel_l2(y, yo), R.rel_l2(yo, ye)
     gu.report(test="flash_attn_ext", D=D, n_q=n_q, n_head=n_head, n_kv=n_kv, n_head_kv=n_head_kv, mask=mask, max_bias=max_bias, softcap=softcap,
-              permuted=permuted, rel_l2_float64=ee, rel_l2_oracle=eo)
-    assert ee < TOL_FA_EXACT and eo < TOL_FA_ORACLE, (ee, eo)
+              permuted=permuted, rel_l2_float64=ee, rel_l2_oracle=eo, oracle_rel_l2_float64=eoe)
+    assert ee < TOL_FA_EXACT and eo < eoe + TOL_FA_EXACT, (ee, eo, eoe)
     return y
 
 

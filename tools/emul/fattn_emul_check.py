@@ -28,8 +28,9 @@ def build():
     return exe
 
 
-def run(D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max_bias=0.0, softcap=0.0, permuted=False, inf_every=0, seed=1, timeout=1200):
-    """returns (rel-L2 vs the float64 operator, rel-L2 vs the oracle)"""
+def run(D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max_bias=0.0, softcap=0.0, permuted=False, inf_every=0, seed=1, timeout=1200, cus=256, mask_unaligned=False):
+    """returns (rel-L2 vs the float64 operator, rel-L2 vs the oracle).  cus: the CU count the launcher sizes its grids for (the 128-row
+    prefill kernel is chosen when its grid fills the chip: small values select it at test sizes)"""
     n_head_kv = n_head_kv or n_head
     rng = np.random.default_rng(seed)
     q = rng.uniform(-1, 1, (n_batch, n_head, n_q, D)).astype(np.float32)
@@ -48,7 +49,7 @@ def run(D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max_bias=0.0
         if mask:
             m.tofile(f("m"))
         r = subprocess.run([build()] + [str(x) for x in (D, n_q, n_head, n_batch, n_kv, n_head_kv, n_batch, int(mask), mrows, repr(float(scale)), max_bias, softcap, int(permuted))] +
-                           [f("q"), f("k"), f("v"), f("m"), f("o")], capture_output=True, text=True, timeout=timeout)
+                           [f("q"), f("k"), f("v"), f("m"), f("o")], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, EMU_CUS=str(cus)))
         if r.returncode == 77:
             return None
         assert r.returncode == 0, r.stderr
