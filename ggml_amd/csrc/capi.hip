@@ -15,8 +15,8 @@ int cdna4_set_error(hipError_t e, const char *file, int line) {
 int cdna4_set_error_msg(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); return -1; }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-// Q5_0 / Q3_K: int8-dot GEMV units of gemv_q.hip for up to 8 activation rows, above that the Q8_0 / Q6_K MFMA GEMM on an exact
-// re-encoding of the weights (convert_w.hip).  Q2_K: the GEMV units at every batch size (no MFMA GEMM yet)
+// Q5_0 / Q3_K / Q2_K: int8-dot GEMV units of gemv_q.hip for up to 8 activation rows, above that the Q8_0 / Q6_K MFMA GEMM on an exact
+// re-encoding of the weights (convert_w.hip; Q2_K as [scale part | minimum part] against a doubled activation image)
 static inline bool is_kq(int t) { return t == CDNA4_Q4_K || t == CDNA4_Q5_K || t == CDNA4_Q6_K || t == CDNA4_Q2_K || t == CDNA4_Q3_K; }
 static inline bool is_q(int t) { return is_kq(t) || t == CDNA4_Q4_0 || t == CDNA4_Q8_0 || t == CDNA4_Q5_0; }
 
@@ -28,7 +28,8 @@ static ws_view carve(int type, int64_t K, int64_t B, void *base) {
     v.qs = (int8_t *)(p + off); off += align256((size_t)(B * K));
     v.d = (float *)(p + off); off += align256((size_t)(B * (K / qka)) * 4);
     v.bsums = (int16_t *)(p + off); off += align256((size_t)(B * (K / 16)) * 2);
-    v.xh = (void *)(p + off); off += align256((size_t)(B * ((K + 127) / 128 * 128)) * 2) + 32768;    // whole 128-k panels; + slack: k_gemm_kq_t64 reads (and discards) up to 127 rows past a ragged last activation tile
+    const int64_t kh = K * cdna4_convert_weights_kmul(type);       // Q2_K's GEMM reads the image twice in a row (convert_w.hip)
+    v.xh = (void *)(p + off); off += align256((size_t)(B * ((kh + 127) / 128 * 128)) * 2) + 32768;    // whole 128-k panels; + slack: k_gemm_kq_t64 reads (and discards) up to 127 rows past a ragged last activation tile
     v.total = off;
     return v;
 }
@@ -83,13 +84,15 @@ size_t ggml_cdna4_mul_mat_id_workspace_size(int type, int64_t K, int64_t n_exper
     return grouped > plain ? grouped : plain;
 }
 
-int ggml_cdna4_convert_weights_target(int type) { return cdna4_convert_weights_target(type); }
+// the public re-encodings keep the shape (Q2_K's two-part form needs the doubled activation image: library-internal)
+static inline int public_convert_target(int type) { return cdna4_convert_weights_kmul(type) == 1 ? cdna4_convert_weights_target(type) : -1; }
+int ggml_cdna4_convert_weights_target(int type) { return public_convert_target(type); }
 size_t ggml_cdna4_convert_weights_size(int type, int64_t M, int64_t K) {
-    if (cdna4_convert_weights_target(type) < 0 || M <= 0 || K <= 0 || ggml_cdna4_row_size(type, K) == 0) return 0;
+    if (public_convert_target(type) < 0 || M <= 0 || K <= 0 || ggml_cdna4_row_size(type, K) == 0) return 0;
     return cdna4_convert_weights_bytes(type, M, K);
 }
 int ggml_cdna4_convert_weights(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, void *out, void *stream) {
-    if (cdna4_convert_weights_target(type) < 0) return cdna4_set_error_msg("convert_weights: no exact target format for this type");
+    if (public_convert_target(type) < 0) return cdna4_set_error_msg("convert_weights: no exact target format for this type");
     if (M <= 0) return 0;
     if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("convert_weights: K is not a whole number of blocks");
     if (!W || !out || w_row_bytes < (int64_t)ggml_cdna4_row_size(type, K)) return cdna4_set_error_msg("convert_weights: bad pointers or row stride");
@@ -119,7 +122,13 @@ int ggml_cdna4_prepare_act(int type, const float *X, int64_t x_row_stride, int64
     const ws_view v = carve(type, K, B, workspace);
     if (workspace_bytes < v.total) return cdna4_set_error_msg("prepare_act: workspace too small");
     const bool want_i8 = path != GGML_CDNA4_PATH_GEMM, want_h = path != GGML_CDNA4_PATH_GEMV;
-    if (is_kq(type)) return ggml_cdna4_quantize_q8_K(X, x_row_stride, K, B, want_i8 ? v.qs : nullptr, v.d, v.bsums, want_h ? v.xh : nullptr, stream);
+    if (is_kq(type)) {
+        const int rc = ggml_cdna4_quantize_q8_K(X, x_row_stride, K, B, want_i8 ? v.qs : nullptr, v.d, v.bsums, want_h ? v.xh : nullptr, stream);
+        if (rc || !want_h || cdna4_convert_weights_kmul(type) == 1) return rc;
+        // the image is k-panel-major ([K / 128][B][128] fp16): k-panels K / 128 .. 2 K / 128 - 1 of the doubled image are a copy of the first B K halves
+        const hipError_t e = hipMemcpyAsync((char *)v.xh + (size_t)B * K * 2, v.xh, (size_t)B * K * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        return e == hipSuccess ? 0 : cdna4_set_error(e, __FILE__, __LINE__);
+    }
     return ggml_cdna4_quantize_q8_0(X, x_row_stride, K, B, want_i8 ? v.qs : nullptr, v.d, want_h ? v.xh : nullptr, 0, stream);
 }
 

@@ -63,9 +63,11 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st);
 // gemm_q_t64.hip — grouped MUL_MAT_ID: a.B = rows of the expert-sorted activation image, a.Y rows indexed through row_dst
 int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);
 bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B);
-// convert_w.hip: exact re-encodings Q5_0 -> Q8_0 and Q3_K -> Q6_K (prefill GEMM of the source format = GEMM of the target format)
+// convert_w.hip: exact re-encodings Q5_0 -> Q8_0, Q3_K -> Q6_K (prefill GEMM of the source format = GEMM of the target format) and
+// Q2_K -> [scale part | minimum part] as Q6_K with 2 K columns (kmul = 2: the activation image must hold x twice)
 size_t cdna4_convert_weights_bytes(int type, int64_t M, int64_t K);
 int cdna4_convert_weights_target(int type);
+int cdna4_convert_weights_kmul(int type);
 int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes, int64_t M, int64_t K, uint8_t *out, hipStream_t st);
 
 extern void *cdna4_debug_trace;

@@ -4,6 +4,7 @@
 //    Q5_0 -> Q8_0   w = d (q5 - 16)              = d q8,                 q8 = q5 - 16 in [-16, 15]         (same fp16 d)
 //    Q3_K -> Q6_K   w = d (sc6 - 32) (q3 - 4)    = d sc8 (q6 - 32),      sc8 = sc6 - 32 in [-32, 31],
 //                                                                         q6 = q3 + 28 in [28, 35]          (same fp16 d, same 16-weight groups)
+//    Q2_K -> Q6_K + Q6_K   w = d sc4 q2 - dmin m4 = d sc4 (qa - 32)  +  dmin (-m4) (33 - 32)             (library-internal: see below)
 //
 // Every weight keeps its value bit for bit (dequantize_row_q5_0 / _q3_K of the source == dequantize_row_q8_0 / _q6_K of the result,
 // src/ggml-quants.c:307-331, 1139-1188 vs :349-363, 1690-1719), and source and target share their activation format on the CPU
@@ -11,6 +12,15 @@
 // the target's GEMM is the product the reference defines for the source format.  The conversion runs per call into library scratch
 // (one read of W + one write of the larger encoding, a few microseconds at 4096 x 4096) — against 64 passes of the 8-column GEMV
 // over the weights at B = 512 without it.
+//
+// Q2_K has a second multiplier (dmin) that no single Q6_K superblock can carry, but the two TERMS of a Q2_K weight are each a Q6_K weight:
+// the scale term with q6 = q2 + 32 and int8 scale sc4, and the minimum term — constant over a 16-weight group — with q6 = 33 ("1"), int8
+// scale -m4 and dmin in the place of d.  dequantize_row_q2_K computes dl * q - ml with dl = d * sc4, ml = dmin * m4
+// (src/ggml-quants.c:712-744); dequantize_row_q6_K of the two parts gives d * sc4 * q and dmin * (-m4) * 1 = -ml, and x + (-y) = x - y in
+// IEEE arithmetic (value for value; only a ZERO result can carry the other sign).  So W.x = [A | B].[x ; x]: the re-encoded matrix has 2 K columns (row = the K / 256 scale superblocks followed by the
+// K / 256 minimum superblocks) and multiplies an activation image in which x appears twice (capi.hip duplicates the fp16 image; it is
+// panel-major in k, so the copy is one contiguous block).  Kept inside the library: the public ggml_cdna4_convert_weights offers only the
+// same-shape re-encodings.
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
 
@@ -78,12 +88,47 @@ __global__ __launch_bounds__(256) void k_convert_q3_K_q6_K(const uint8_t *__rest
     }
 }
 
+// 18 threads per source superblock {scales[16], qs[64], fp16 d, fp16 dmin} (84 bytes) -> superblock sb of the row's scale part and superblock
+// nsb + sb of its minimum part.  Threads 0..15 as above (weight 128 n + 32 j + l is (qs[32 n + l] >> 2 j) & 3); thread 16: the scales; 17: d, dmin.
+__global__ __launch_bounds__(256) void k_convert_q2_K_q6_K2(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nsb, uint8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)M * nsb * 18) return;
+    const int pc = (int)(t % 18); const int64_t u = t / 18;
+    const int row = (int)(u / nsb), sb = (int)(u % nsb);
+    const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)sb * 84;
+    uint8_t *da = out + ((int64_t)row * 2 * nsb + sb) * 210, *db = da + (int64_t)nsb * 210;
+    auto st32 = [](uint8_t *p, uint32_t v) { *reinterpret_cast<uint16_t *>(p) = (uint16_t)v; *reinterpret_cast<uint16_t *>(p + 2) = (uint16_t)(v >> 16); };
+    if (pc < 16) {
+        const int n = pc >> 3, l = 4 * (pc & 7);
+        const uint32_t q = ld_u32_a2(src + 16 + 32 * n + l);
+        // q6 = q2 + 32 = 0x20 | q2: low nibble q2, bits 4-5 = 2.   q6 = 33 = 0x21: low nibble 1, bits 4-5 = 2
+        st32(da + 64 * n + l, (q & 0x03030303u) | (((q >> 4) & 0x03030303u) << 4));
+        st32(da + 64 * n + 32 + l, ((q >> 2) & 0x03030303u) | (((q >> 6) & 0x03030303u) << 4));
+        st32(da + 128 + 32 * n + l, 0xAAAAAAAAu);
+        st32(db + 64 * n + l, 0x11111111u); st32(db + 64 * n + 32 + l, 0x11111111u); st32(db + 128 + 32 * n + l, 0xAAAAAAAAu);
+    } else if (pc == 16) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t s = ld_u32_a2(src + 4 * g), m = (s >> 4) & 0x0F0F0F0Fu;
+            st32(da + 192 + 4 * g, s & 0x0F0F0F0Fu);
+            // byte-wise -m for m in 0..15: 0 -> 0, else 0xF0 | (16 - m)
+            const uint32_t tt = 0x10101010u - m, nz = ((m + 0x0F0F0F0Fu) >> 4) & 0x01010101u;
+            st32(db + 192 + 4 * g, (tt & 0x0F0F0F0Fu) | (nz * 0xF0u));
+        }
+    } else {
+        *reinterpret_cast<uint16_t *>(da + 208) = ld_u16(src + 80);
+        *reinterpret_cast<uint16_t *>(db + 208) = ld_u16(src + 82);
+    }
+}
+
 size_t cdna4_convert_weights_bytes(int type, int64_t M, int64_t K) {
+    if (type == CDNA4_Q2_K) return (size_t)M * 2 * (K / 256) * 210;
     if (type == CDNA4_Q5_0) return (size_t)M * (K / 32) * 34;
     if (type == CDNA4_Q3_K) return (size_t)M * (K / 256) * 210;
     return 0;
 }
-int cdna4_convert_weights_target(int type) { return type == CDNA4_Q5_0 ? CDNA4_Q8_0 : (type == CDNA4_Q3_K ? CDNA4_Q6_K : -1); }
+int cdna4_convert_weights_target(int type) { return type == CDNA4_Q5_0 ? CDNA4_Q8_0 : ((type == CDNA4_Q3_K || type == CDNA4_Q2_K) ? CDNA4_Q6_K : -1); }
+int cdna4_convert_weights_kmul(int type) { return type == CDNA4_Q2_K ? 2 : 1; }       // columns of the result per column of the source
 
 // W [M rows, w_row_bytes apart] of `type` -> `out` (contiguous rows of the target format); 2-byte aligned source rows
 int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes, int64_t M, int64_t K, uint8_t *out, hipStream_t st) {
@@ -97,6 +142,10 @@ int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes
         if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");
         const int64_t n = M * (K / 256) * 18;
         hipLaunchKernelGGL(k_convert_q3_K_q6_K, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out);
+    } else if (type == CDNA4_Q2_K) {
+        if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");
+        const int64_t n = M * (K / 256) * 18;
+        hipLaunchKernelGGL(k_convert_q2_K_q6_K2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out);
     } else return cdna4_set_error_msg("convert_weights: no exact target format for this type");
     CDNA4_CHECK_LAUNCH();
     return 0;

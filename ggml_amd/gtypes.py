@@ -23,7 +23,7 @@ _TYPE_SIZE = {GGMLType.F32: 4, GGMLType.F16: 2, GGMLType.Q4_0: 18, GGMLType.Q8_0
 _BLCK = {GGMLType.F32: 1, GGMLType.F16: 1, GGMLType.Q4_0: 32, GGMLType.Q8_0: 32, GGMLType.Q4_K: 256,
          GGMLType.Q5_K: 256, GGMLType.Q6_K: 256, GGMLType.Q8_K: 256, GGMLType.I32: 1,
          GGMLType.Q5_0: 32, GGMLType.Q2_K: 256, GGMLType.Q3_K: 256}
-# Q5_0 / Q2_K / Q3_K: int8-dot GEMV units only (every batch size takes the GEMV path)
+# Q5_0 / Q2_K / Q3_K: int8-dot GEMV units up to 8 activation rows, above that the Q8_0 / Q6_K MFMA GEMM on exactly re-encoded weights (convert_w.hip)
 QUANT_WEIGHT_TYPES = (GGMLType.Q4_0, GGMLType.Q8_0, GGMLType.Q4_K, GGMLType.Q5_K, GGMLType.Q6_K, GGMLType.Q5_0, GGMLType.Q2_K, GGMLType.Q3_K)
 
 

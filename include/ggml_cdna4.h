@@ -35,8 +35,9 @@ extern "C" {
 enum ggml_cdna4_type {
     GGML_CDNA4_TYPE_F32 = 0, GGML_CDNA4_TYPE_F16 = 1, GGML_CDNA4_TYPE_Q4_0 = 2, GGML_CDNA4_TYPE_Q8_0 = 8,
     GGML_CDNA4_TYPE_Q4_K = 12, GGML_CDNA4_TYPE_Q5_K = 13, GGML_CDNA4_TYPE_Q6_K = 14,
-    /* MUL_MAT / MUL_MAT_ID through the int8-dot GEMV units; above 8 activation rows Q5_0 / Q3_K take the MFMA GEMM of Q8_0 / Q6_K on an
-     * exact re-encoding of the weights (ggml_cdna4_convert_weights), Q2_K stays on the GEMV units */
+    /* MUL_MAT / MUL_MAT_ID through the int8-dot GEMV units; above 8 activation rows MUL_MAT takes the MFMA GEMM of Q8_0 / Q6_K on an exact
+     * re-encoding of the weights (Q5_0 / Q3_K: ggml_cdna4_convert_weights; Q2_K: scale part and minimum part as two Q6_K column blocks
+     * against a doubled activation image, inside the library) */
     GGML_CDNA4_TYPE_Q5_0 = 6, GGML_CDNA4_TYPE_Q2_K = 10, GGML_CDNA4_TYPE_Q3_K = 11,
     /* to_float only: ggml_cdna4_dequantize_row, GET_ROWS, CPY -> F32 */
     GGML_CDNA4_TYPE_Q4_1 = 3, GGML_CDNA4_TYPE_Q5_1 = 7,

@@ -329,10 +329,11 @@ def _emul_module(name):
     return mod
 
 
-@pytest.mark.parametrize("t,m,k", [(6, 8, 1024), (6, 33, 64), (11, 8, 1024), (11, 33, 512)])
+@pytest.mark.parametrize("t,m,k", [(6, 8, 1024), (6, 33, 64), (11, 8, 1024), (11, 33, 512), (10, 8, 1024), (10, 33, 512), (10, 5, 256)])
 def test_weight_reencoding_sources_on_the_cpu_are_exact(t, m, k):
-    """tools/emul/convert_emul: k_convert_q5_0_q8_0 / k_convert_q3_K_q6_K (the prefill route of Q5_0 / Q3_K) executed on the CPU: the oracle's
-    dequantize_row of the re-encoded matrix equals its dequantize_row of the source bit for bit, on fully random block bytes"""
+    """tools/emul/convert_emul: k_convert_q5_0_q8_0 / k_convert_q3_K_q6_K / k_convert_q2_K_q6_K2 (the prefill route of Q5_0 / Q3_K / Q2_K)
+    executed on the CPU: the oracle's dequantize_row of the re-encoded matrix equals its dequantize_row of the source bit for bit, on fully
+    random block bytes; for Q2_K the sum of its two parts (scale part + minimum part, 2 K columns) equals it value for value"""
     assert _emul_module("convert_emul_check").run(t, m, k, seed=t + k)
 
 

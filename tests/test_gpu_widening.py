@@ -79,6 +79,32 @@ def test_more_formats_prefill_gemm(gu, name, t, tgt, m, k, b):
     assert np.array_equal(ops.mul_mat(a3, xd).cpu().numpy(), ops.mul_mat(ops.convert_weights(a3), xd).cpu().numpy())
 
 
+@pytest.mark.parametrize("m,k,b", [(16, 256, 9), (16, 256, 16), (200, 1024, 100), (130, 768, 33), (512, 2048, 128), (4096, 4096, 512)])
+def test_q2_K_prefill_gemm(gu, m, k, b):
+    """above 8 activation rows Q2_K runs as ONE Q6_K GEMM with 2 K columns: [scale part | minimum part] of the weights (convert_w.hip) against
+    the activation image repeated twice — within the GEMM bar of the oracle's MUL_MAT for Q2_K, equal to the GEMV units' result to the same bar,
+    deterministic, and a second matrix of the same shape does not see the first one's re-encoded weights"""
+    from ggml_amd import ops
+    t = R.Q2_K
+    w = R.random_weights(t, m, k, seed=5 * m + k)
+    x = _x(b * 7 + k, b, k)
+    a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
+    y = ops.mul_mat(a, xd).cpu().numpy()
+    assert np.isfinite(y).all()
+    rows = np.arange(m) if m <= 512 else np.random.default_rng(0).choice(m, 64, replace=False)
+    rs = R.row_size(t, k)
+    wsub = np.concatenate([w[r * rs:(r + 1) * rs] for r in rows])
+    e = R.rel_l2(y[:, rows], R.o_mul_mat(t, wsub, x, len(rows), k)); gu.report(test="q2_K_gemm", m=m, k=k, b=b, rel_l2=e)
+    assert e < TOL_GEMM
+    assert np.array_equal(y, ops.mul_mat(a, xd).cpu().numpy())
+    if m <= 512:
+        assert R.rel_l2(y, ops.mul_mat(a, xd, path=ops.PATH_GEMV).cpu().numpy()) < TOL_GEMM
+    w3 = R.random_weights(t, m, k, seed=991)
+    y3 = ops.mul_mat(gu.qtensor(t, w3, m, k), xd).cpu().numpy()
+    wsub3 = np.concatenate([w3[r * rs:(r + 1) * rs] for r in rows])
+    assert R.rel_l2(y3[:, rows], R.o_mul_mat(t, wsub3, x, len(rows), k)) < TOL_GEMM
+
+
 @pytest.mark.parametrize("name,t", TOFLOAT_TYPES)
 def test_more_formats_to_float_is_bit_exact(gu, name, t):
     """ggml_cdna4_dequantize_row for Q4_1 / Q5_0 / Q5_1 / Q2_K / Q3_K against the oracle and the compiled reference (dequantize_row_*)"""

@@ -1,8 +1,8 @@
-"""Runs the SOURCE of the exact weight re-encodings (convert_w.hip: Q5_0 -> Q8_0, Q3_K -> Q6_K) on the CPU (tools/emul/convert_emul) and checks
+"""Runs the SOURCE of the exact weight re-encodings (convert_w.hip: Q5_0 -> Q8_0, Q3_K -> Q6_K, Q2_K -> Q6_K scale part | Q6_K minimum part) on the CPU (tools/emul/convert_emul) and checks
 that the oracle's dequantize_row of the RESULT equals its dequantize_row of the SOURCE bit for bit — every 5-bit / 3-bit code, both hmask
 polarities, all 64 six-bit scales, any fp16 d (the prefill GEMM of Q5_0 / Q3_K is the Q8_0 / Q6_K GEMM on the re-encoded weights).
 
-    python tools/emul/convert_emul_check.py [type M K]        type 6 = Q5_0, 11 = Q3_K
+    python tools/emul/convert_emul_check.py [type M K]        type 6 = Q5_0, 11 = Q3_K, 10 = Q2_K
 """
 import os
 import subprocess
@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import refutil as R  # noqa: E402
 
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-Q5_0, Q8_0, Q3_K, Q6_K = 6, 8, 11, 14
+Q5_0, Q8_0, Q2_K, Q3_K, Q6_K = 6, 8, 10, 11, 14
 
 
 def build():
@@ -33,13 +33,14 @@ def build():
 def source_bytes(t, m, k, seed):
     """fully random block bytes (every code, mask and scale pattern) with finite fp16 scales of both signs, one zero and one subnormal"""
     rng = np.random.default_rng(seed)
-    bs, blk, doff = (22, 32, 0) if t == Q5_0 else (110, 256, 108)
+    bs, blk, doffs = {Q5_0: (22, 32, [0]), Q3_K: (110, 256, [108]), Q2_K: (84, 256, [80, 82])}[t]
     nb = m * k // blk
     raw = rng.integers(0, 256, (nb, bs), dtype=np.uint8)
-    d = rng.uniform(-0.3, 0.3, nb).astype(np.float16)
-    d[0] = 0.0
-    d[-1] = np.float16(3e-7)
-    raw[:, doff:doff + 2] = d.view(np.uint8).reshape(nb, 2)
+    for doff in doffs:
+        d = rng.uniform(-0.3, 0.3, nb).astype(np.float16)
+        d[0] = 0.0
+        d[-1] = np.float16(3e-7)
+        raw[:, doff:doff + 2] = d.view(np.uint8).reshape(nb, 2)
     return raw.reshape(-1)
 
 
@@ -52,11 +53,19 @@ def run(t, m, k, seed=1):
         r = subprocess.run([build(), str(t), str(m), str(k), f("w.bin"), f("o.bin")], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr
         out = np.fromfile(f("o.bin"), np.uint8)
-    assert out.size == m * R.row_size(tgt, k), "size of the re-encoded matrix"
     a = R.o_dequantize(t, w, k)
-    b = R.o_dequantize(tgt, out, k)
+    if t == Q2_K:           # [scale part | minimum part]: 2 K columns per row; dequantize(scale part) + dequantize(minimum part) = dequantize_row_q2_K
+        assert out.size == m * R.row_size(Q6_K, 2 * k), "size of the re-encoded matrix"
+        both = R.o_dequantize(Q6_K, out, 2 * k)
+        b = both[:, :k] + both[:, k:]
+    else:
+        assert out.size == m * R.row_size(tgt, k), "size of the re-encoded matrix"
+        b = R.o_dequantize(tgt, out, k)
     assert a.shape == b.shape == (m, k)
-    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "dequantize(source) != dequantize(re-encoded)"
+    if t == Q2_K:           # value for value: the sum of the two parts can carry the other sign on a ZERO (x - 0 keeps the sign of x, x + (-0) need not)
+        assert np.array_equal(a, b) and np.isfinite(b).all(), "dequantize(source) != dequantize(scale part) + dequantize(minimum part)"
+    else:
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "dequantize(source) != dequantize(re-encoded)"
     return True
 
 
