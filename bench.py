@@ -51,7 +51,8 @@ def time_left(budget):
 # ------------------------------------------------------------------------------------------------ synthetic inputs
 def synth_blocks(t, m, k, seed):
     """fallback only (no oracle/_ref/synth_data): random but VALID blocks with small positive fp16 scales"""
-    geo = {12: (144, 256, (0, 2)), 13: (176, 256, (0, 2)), 14: (210, 256, (208,)), 2: (18, 32, (0,)), 8: (34, 32, (0,))}[t]
+    geo = {12: (144, 256, (0, 2)), 13: (176, 256, (0, 2)), 14: (210, 256, (208,)), 2: (18, 32, (0,)), 8: (34, 32, (0,)),
+           6: (22, 32, (0,)), 10: (84, 256, (80, 82)), 11: (110, 256, (108,))}[t]
     rng = np.random.default_rng(seed)
     nb = m * k // geo[1]
     raw = rng.integers(0, 256, (nb, geo[0]), dtype=np.uint8)
@@ -60,7 +61,7 @@ def synth_blocks(t, m, k, seed):
     return raw.reshape(-1)
 
 
-TYPE_NAME = {12: "q4_K", 13: "q5_K", 14: "q6_K", 2: "q4_0", 8: "q8_0"}
+TYPE_NAME = {12: "q4_K", 13: "q5_K", 14: "q6_K", 2: "q4_0", 8: "q8_0", 6: "q5_0", 10: "q2_K", 11: "q3_K"}
 
 
 def prescribed(t, m, k, row_lo, row_hi, b):
@@ -342,6 +343,49 @@ def moe_row(dev, steps):
     return out
 
 
+def widening_rows(dev, steps):
+    """the rows SURVEY 8(f) ranks after the five formats.  (1) Q5_0 / Q3_K / Q2_K at the headline shape: the whole MUL_MAT
+    step (activation quantize + per-call exact re-encoding into Q8_0 / Q6_K + that format's MFMA GEMM) and the one-launch decode.
+    (2) FLASH_ATTN_EXT, F16 K / V, head size 128, 32 heads, with a mask: prefill rows against the fp16 MFMA roof (4 n_head n_q n_kv hs
+    flops), decode rows against the HBM roof (K + V read once)."""
+    import ctypes as C
+    from ggml_amd import native, ops
+    out = {"formats": {}, "flash_attn_ext": {}}
+    m, k, b = HEAD
+    for t in (6, 11, 10):
+        w, x, how = prescribed(t, m, k, 0, m, b)
+        a = ops.QTensor.from_host_bytes(t, k, m, w, device=dev)
+        xd = torch.from_numpy(x).to(dev)
+        y = torch.empty((b, m), dtype=torch.float32, device=dev)
+        s_us = events_us(lambda: ops.mul_mat(a, xd, out=y), steps, 10)
+        y1 = torch.empty((1, m), dtype=torch.float32, device=dev)
+        x1 = xd[:1].contiguous()
+        d_us = events_us(lambda: ops.mul_mat(a, x1, out=y1), max(steps, 200), 10)
+        out["formats"][TYPE_NAME[t]] = {"step_b512_us": round(s_us, 3), "step_b512_tflops": round(2.0 * m * k * b / s_us / 1e6, 1), "decode_b1_us_cache_warm": round(d_us, 3),
+                                        "weight_bytes": int(w.size), "data": how}
+    rng = np.random.default_rng(11)
+    hs, nh = 128, 32
+    for n_q, n_kv in ((4096, 4096), (512, 512), (1, 4096), (1, 32768)):
+        q = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_q, hs)).astype(np.float32)).to(dev)
+        kk = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_kv, hs)).astype(np.float16)).to(dev)
+        vv = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_kv, hs)).astype(np.float16)).to(dev)
+        mk = torch.from_numpy(rng.uniform(-1, 1, ((n_q + 63) // 64 * 64, n_kv)).astype(np.float16)).to(dev)
+        o = ops.flash_attn_ext(q, kk, vv, mk, 1.0 / np.sqrt(hs))                                   # checks the arguments once; the timed calls go
+        dq, dk, dv, dd = (ops._tensor_desc(t_, ty) for t_, ty in ((q, 0), (kk, 1), (vv, 1), (o, 0)))      # straight to the C-ABI (python's part
+        dm = ops._tensor_desc(mk.view(1, 1, *mk.shape), 1)                                          # of a call would exceed the decode kernel)
+        st, L, sc = torch.cuda.current_stream(dev).cuda_stream, native.lib(), float(1.0 / np.sqrt(hs))
+        us = events_us(lambda: native.check(L.ggml_cdna4_op_flash_attn_ext(C.byref(dq), C.byref(dk), C.byref(dv), C.byref(dm), C.byref(dd), sc, 0.0, 0.0, st)), max(20, steps // 4), 5)
+        row = {"us_per_call": round(us, 2)}
+        if n_q > 32:
+            tf = 4.0 * nh * n_q * n_kv * hs / us / 1e6
+            row.update(tflops=round(tf, 1), frac_of_mfma_roof=round(tf / MFMA_F16_PEAK_TFLOPS, 4), kernel="k_flash_attn_wide<128>" if (n_q + 127) // 128 * nh >= 256 else "k_flash_attn_split<128>")
+        else:
+            gb = 4.0 * nh * n_kv * hs / us / 1e3
+            row.update(kv_GBps=round(gb, 1), frac_of_hbm_roof=round(gb / HBM_PEAK_GBS, 4), kernel="k_flash_attn_split<128> + k_flash_attn_merge<128>")
+        out["flash_attn_ext"]["hs128_h32_q%d_kv%d" % (n_q, n_kv)] = row
+    return out
+
+
 def stock_perf_lines(timeout=150):
     """the reference's own perf harness on the plug-in: `test-backend-ops perf -o MUL_MAT -b CDNA40` (unmodified binary, plug-in loaded
     through GGML_BACKEND_PATH) — its q4_K lines at m = 4096, k = 14336 (tests/test-backend-ops.cpp:4340-4346)"""
@@ -565,7 +609,8 @@ def main():
                     ("formats", lambda: format_rows(dev, steps), 230),
                     ("mul_mat_id", lambda: moe_row(dev, steps), 245),
                     ("batch_sweep", lambda: batch_sweep(dev, steps), 250),
-                    ("stock_test_backend_ops_perf", lambda: stock_perf_lines(int(max(30, min(150, time_left(400))))), 260))
+                    ("widening", lambda: widening_rows(dev, steps), 255),
+                    ("stock_test_backend_ops_perf", lambda: stock_perf_lines(int(max(30, min(150, time_left(400))))), 280))
             run_legs(legs, out)
     if rank == 0:
         print(json.dumps(out), flush=True)
