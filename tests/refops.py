@@ -33,7 +33,9 @@ class Ref:
             self.cpu.ggml_graph_compute_with_ctx.restype = i32; self.cpu.ggml_graph_compute_with_ctx.argtypes = [vp, vp, i32]
             b._refops_ready = True
 
-        self.ctx = b.ggml_init(b._InitParams(mem, None, False))
+        # tests/ggufref.py binds ggml_init on the same library object with its own (identical) structure class: use whichever is bound
+        params_t = (b.ggml_init.argtypes or [b._InitParams])[0]
+        self.ctx = b.ggml_init(params_t(mem, None, False))
         assert self.ctx
 
     def close(self):
