@@ -18,7 +18,9 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Q5_0 / Q3_K / Q2_K: int8-dot GEMV units of gemv_q.hip for up to 8 activation rows, above that the Q8_0 / Q6_K MFMA GEMM on an exact
 // re-encoding of the weights (convert_w.hip; Q2_K as [scale part | minimum part] against a doubled activation image)
 static inline bool is_kq(int t) { return t == CDNA4_Q4_K || t == CDNA4_Q5_K || t == CDNA4_Q6_K || t == CDNA4_Q2_K || t == CDNA4_Q3_K; }
-static inline bool is_q(int t) { return is_kq(t) || t == CDNA4_Q4_0 || t == CDNA4_Q8_0 || t == CDNA4_Q5_0; }
+// Q4_1 / Q5_1 (Q8_1 activations: s in the place of the bsums) and IQ4_NL: GEMV units; above 8 rows the Q8_0 GEMM on the re-encoding
+// (Q4_1 / Q5_1 as [d q | m 1] against a doubled activation image, like Q2_K)
+static inline bool is_q(int t) { return is_kq(t) || t == CDNA4_Q4_0 || t == CDNA4_Q8_0 || t == CDNA4_Q5_0 || t == CDNA4_Q4_1 || t == CDNA4_Q5_1 || t == CDNA4_IQ4_NL; }
 
 // workspace carve: [qs int8 B*K][d f32 B*K/qka][bsums i16 B*K/16][xh f16 B*K]
 struct ws_view { int8_t *qs; float *d; int16_t *bsums; void *xh; size_t total; };
@@ -67,6 +69,7 @@ size_t ggml_cdna4_row_size(int type, int64_t k) {
         case CDNA4_Q5_0: return k % 32 ? 0 : (size_t)(k / 32) * 22; case CDNA4_Q2_K: return k % 256 ? 0 : (size_t)(k / 256) * 84;
         case CDNA4_Q3_K: return k % 256 ? 0 : (size_t)(k / 256) * 110;
         case CDNA4_Q4_1: return k % 32 ? 0 : (size_t)(k / 32) * 20; case CDNA4_Q5_1: return k % 32 ? 0 : (size_t)(k / 32) * 24;
+        case CDNA4_IQ4_NL: return k % 32 ? 0 : (size_t)(k / 32) * 18;
     }
     return 0;
 }
@@ -129,7 +132,14 @@ int ggml_cdna4_prepare_act(int type, const float *X, int64_t x_row_stride, int64
         const hipError_t e = hipMemcpyAsync((char *)v.xh + (size_t)B * K * 2, v.xh, (size_t)B * K * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream);
         return e == hipSuccess ? 0 : cdna4_set_error(e, __FILE__, __LINE__);
     }
-    return ggml_cdna4_quantize_q8_0(X, x_row_stride, K, B, want_i8 ? v.qs : nullptr, v.d, want_h ? v.xh : nullptr, 0, stream);
+    if (!cdna4_is_q81(type)) return ggml_cdna4_quantize_q8_0(X, x_row_stride, K, B, want_i8 ? v.qs : nullptr, v.d, want_h ? v.xh : nullptr, 0, stream);
+    // Q4_1 / Q5_1: Q8_1 activations — s = fp16(d * sum q) per 32-block as fp32 where the K-quants keep their bsums (same byte count); the GEMM reads the
+    // fp16 image twice in a row ([d q | m 1] weights): whole 128-k panels only (cdna4_gemm_q_supported)
+    if (((uintptr_t)X | (uintptr_t)(x_row_stride * 4)) & 15) return cdna4_set_error_msg("quantize_q8_1: x must be 16-byte aligned");
+    const int rc = cdna4_launch_quantize_q8_1(X, x_row_stride, K, B, want_i8 ? v.qs : nullptr, v.d, reinterpret_cast<float *>(v.bsums), want_h ? v.xh : nullptr, (hipStream_t)stream);
+    if (rc || !want_h || K % 128) return rc;                           // (a ragged last panel: no GEMM form, cdna4_gemm_q_supported says so)
+    const hipError_t e = hipMemcpyAsync((char *)v.xh + (size_t)B * K * 2, v.xh, (size_t)B * K * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : cdna4_set_error(e, __FILE__, __LINE__);
 }
 
 int ggml_cdna4_mul_mat_prepared(int type, const void *W, int64_t w_row_bytes, float *Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,

@@ -14,9 +14,14 @@ enum cdna4_type : int {
     CDNA4_Q4_K = 12, CDNA4_Q5_K = 13, CDNA4_Q6_K = 14, CDNA4_Q8_K = 15, CDNA4_I32 = 26,
     // MUL_MAT / MUL_MAT_ID through the GEMV units of gemv_q.hip; prefill GEMM of Q5_0 / Q3_K through convert_w.hip; to_float in ops.hip
     CDNA4_Q5_0 = 6, CDNA4_Q2_K = 10, CDNA4_Q3_K = 11,
-    // to_float only (GET_ROWS, CPY -> F32, dequantize_row)
+    // the same (GEMV units on Q8_1 activations; prefill GEMM as [d q | m 1] in Q8_0 against a doubled activation image)
     CDNA4_Q4_1 = 3, CDNA4_Q5_1 = 7,
+    // the same: non-linear 4-bit codebook (kvalues_iq4nl, src/ggml-quants.c:2434), Q8_0 activations; prefill GEMM as Q8_0 (q8 = codebook value)
+    CDNA4_IQ4_NL = 20,
 };
+// weight types whose CPU vec_dot runs on Q8_1 activations (type_traits_cpu[].vec_dot_type, src/ggml-cpu/ggml-cpu.c:271-296): the activation
+// workspace then carries, in the place of the Q8_K bsums, one fp32 per 32-block holding s = fp16(d * sum of the quants) (block_q8_1.s)
+constexpr bool cdna4_is_q81(int t) { return t == CDNA4_Q4_1 || t == CDNA4_Q5_1; }
 
 // bytes per block / weights per block
 template <int T> struct QT;
@@ -28,6 +33,9 @@ template <> struct QT<CDNA4_Q6_K> { static constexpr int BYTES = 210, QK = 256; 
 template <> struct QT<CDNA4_Q5_0> { static constexpr int BYTES = 22,  QK = 32;  static constexpr bool KQ = false; };
 template <> struct QT<CDNA4_Q2_K> { static constexpr int BYTES = 84,  QK = 256; static constexpr bool KQ = true; };
 template <> struct QT<CDNA4_Q3_K> { static constexpr int BYTES = 110, QK = 256; static constexpr bool KQ = true; };
+template <> struct QT<CDNA4_Q4_1> { static constexpr int BYTES = 20,  QK = 32;  static constexpr bool KQ = false; };
+template <> struct QT<CDNA4_Q5_1> { static constexpr int BYTES = 24,  QK = 32;  static constexpr bool KQ = false; };
+template <> struct QT<CDNA4_IQ4_NL> { static constexpr int BYTES = 18, QK = 32;  static constexpr bool KQ = false; };
 // library-private re-layouts of the 2-byte-aligned formats into 16-byte-aligned 256-weight superblocks, produced per call
 // into scratch by gemm_q_mfma.hip's repack kernels so that the LDS-DMA pipeline (16-byte pieces) can stage them:
 //   Q4_0R 144 B: fp16 d[8] | 4 x 32 B nibbles in Q4_K order (byte l of group g: low = k 64g+l, high = k 64g+32+l)
@@ -62,6 +70,19 @@ __device__ __forceinline__ u32x4 ld_u32x4(const void *p) { return *reinterpret_c
 
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(half_t, h); }
 __device__ __forceinline__ uint16_t f2h_bits(float f) { return __builtin_bit_cast(uint16_t, (half_t)f); }   // RNE
+// four 4-bit codes (one per byte, 0..15) -> their four int8 codebook values kvalues_iq4nl[] = {-127, -104, -83, -65, -49, -35, -22, -10,
+// 1, 13, 25, 38, 53, 69, 89, 113} (src/ggml-quants.c:2434), packed the same way.  Plain shifts of the table held in two 64-bit constants.
+__device__ __forceinline__ uint32_t iq4nl_lut4(uint32_t codes) {
+    constexpr uint64_t T_LO = 0xF6EADDCFBFAD9881ull, T_HI = 0x7159453526190D01ull;         // entries 0..7 / 8..15, entry i in byte i & 7
+    uint32_t r = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const uint32_t c = (codes >> (8 * e)) & 0xFu;
+        const uint64_t t = (c & 8u) ? T_HI : T_LO;
+        r |= ((uint32_t)(t >> (8 * (c & 7u))) & 0xFFu) << (8 * e);
+    }
+    return r;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

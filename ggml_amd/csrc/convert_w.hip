@@ -5,6 +5,8 @@
 //    Q3_K -> Q6_K   w = d (sc6 - 32) (q3 - 4)    = d sc8 (q6 - 32),      sc8 = sc6 - 32 in [-32, 31],
 //                                                                         q6 = q3 + 28 in [28, 35]          (same fp16 d, same 16-weight groups)
 //    Q2_K -> Q6_K + Q6_K   w = d sc4 q2 - dmin m4 = d sc4 (qa - 32)  +  dmin (-m4) (33 - 32)             (library-internal: see below)
+//    IQ4_NL -> Q8_0 w = d kvalues[code]          = d q8,                 q8 = kvalues_iq4nl[code] in [-127, 113]  (same fp16 d)
+//    Q4_1 / Q5_1 -> Q8_0 + Q8_0   w = d q + m    = d q8  +  m 1,         q8 = q in [0, 15] / [0, 31]       (library-internal, like Q2_K)
 //
 // Every weight keeps its value bit for bit (dequantize_row_q5_0 / _q3_K of the source == dequantize_row_q8_0 / _q6_K of the result,
 // src/ggml-quants.c:307-331, 1139-1188 vs :349-363, 1690-1719), and source and target share their activation format on the CPU
@@ -48,6 +50,50 @@ __global__ __launch_bounds__(256) void k_convert_q5_0_q8_0(const uint8_t *__rest
     for (int i = 0; i < 4; i++) {
         *reinterpret_cast<uint16_t *>(dst + 2 + 4 * i) = (uint16_t)lo[i]; *reinterpret_cast<uint16_t *>(dst + 4 + 4 * i) = (uint16_t)(lo[i] >> 16);
         *reinterpret_cast<uint16_t *>(dst + 18 + 4 * i) = (uint16_t)hi[i]; *reinterpret_cast<uint16_t *>(dst + 20 + 4 * i) = (uint16_t)(hi[i] >> 16);
+    }
+}
+
+// Q4_1 / Q5_1 (FIVE): one thread per 32-weight block {fp16 d, fp16 m, [qh[4],] qs[16]} -> block b of the row's scale part {d, int8 q} and block
+// nblk + b of its minimum part {m, thirty-two 1s}: w = q d + m = d q8 + m 1 (dequantize_row_q4_1 / _q5_1, src/ggml-quants.c:275-293, 321-347, compute
+// q * d + m; dequantize_row_q8_0 of the two parts gives q * d and 1 * m, and their sum is the same fp32 addition).  2 K columns per row, against an
+// activation image that holds x twice — library-internal like Q2_K's form.
+template <bool FIVE>
+__global__ __launch_bounds__(256) void k_convert_q41_q8_0x2(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nblk, uint8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)M * nblk) return;
+    const int row = (int)(t / nblk), b = (int)(t % nblk);
+    const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)b * (FIVE ? 24 : 20);
+    uint8_t *da = out + ((int64_t)row * 2 * nblk + b) * 34, *db = da + (int64_t)nblk * 34;
+    const uint32_t qh = FIVE ? ld_u32_a2(src + 4) : 0u;
+    *reinterpret_cast<uint16_t *>(da) = ld_u16(src);
+    *reinterpret_cast<uint16_t *>(db) = ld_u16(src + 2);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t q = ld_u32_a2(src + (FIVE ? 8 : 4) + 4 * i);
+        const uint32_t h0 = ((qh >> (4 * i)) & 0xFu) * 0x00204081u & 0x01010101u, h1 = ((qh >> (16 + 4 * i)) & 0xFu) * 0x00204081u & 0x01010101u;
+        const uint32_t lo = (q & 0x0F0F0F0Fu) | (h0 << 4), hi = ((q >> 4) & 0x0F0F0F0Fu) | (h1 << 4);      // weights 4i.. / 16+4i.. as bytes 0..15 / 0..31
+        *reinterpret_cast<uint16_t *>(da + 2 + 4 * i) = (uint16_t)lo; *reinterpret_cast<uint16_t *>(da + 4 + 4 * i) = (uint16_t)(lo >> 16);
+        *reinterpret_cast<uint16_t *>(da + 18 + 4 * i) = (uint16_t)hi; *reinterpret_cast<uint16_t *>(da + 20 + 4 * i) = (uint16_t)(hi >> 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) *reinterpret_cast<uint16_t *>(db + 2 + 2 * i) = (uint16_t)0x0101u;
+}
+
+// IQ4_NL: one thread per 32-weight block {fp16 d, qs[16]} -> {d, int8 qs[32]} with q8 = kvalues_iq4nl[code]: w = d * kvalues[code]
+// (dequantize_row_iq4_nl, src/ggml-quants.c:2436-2452) = d * q8 (dequantize_row_q8_0), same fp16 d, same fp32 product
+__global__ __launch_bounds__(256) void k_convert_iq4_nl_q8_0(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nblk, uint8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)M * nblk) return;
+    const int row = (int)(t / nblk), b = (int)(t % nblk);
+    const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)b * 18;
+    uint8_t *dst = out + ((int64_t)row * nblk + b) * 34;
+    *reinterpret_cast<uint16_t *>(dst) = ld_u16(src);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t q = ld_u32_a2(src + 2 + 4 * i);
+        const uint32_t lo = iq4nl_lut4(q & 0x0F0F0F0Fu), hi = iq4nl_lut4((q >> 4) & 0x0F0F0F0Fu);
+        *reinterpret_cast<uint16_t *>(dst + 2 + 4 * i) = (uint16_t)lo; *reinterpret_cast<uint16_t *>(dst + 4 + 4 * i) = (uint16_t)(lo >> 16);
+        *reinterpret_cast<uint16_t *>(dst + 18 + 4 * i) = (uint16_t)hi; *reinterpret_cast<uint16_t *>(dst + 20 + 4 * i) = (uint16_t)(hi >> 16);
     }
 }
 
@@ -123,12 +169,16 @@ __global__ __launch_bounds__(256) void k_convert_q2_K_q6_K2(const uint8_t *__res
 
 size_t cdna4_convert_weights_bytes(int type, int64_t M, int64_t K) {
     if (type == CDNA4_Q2_K) return (size_t)M * 2 * (K / 256) * 210;
-    if (type == CDNA4_Q5_0) return (size_t)M * (K / 32) * 34;
+    if (type == CDNA4_Q5_0 || type == CDNA4_IQ4_NL) return (size_t)M * (K / 32) * 34;
+    if (type == CDNA4_Q4_1 || type == CDNA4_Q5_1) return (size_t)M * 2 * (K / 32) * 34;
     if (type == CDNA4_Q3_K) return (size_t)M * (K / 256) * 210;
     return 0;
 }
-int cdna4_convert_weights_target(int type) { return type == CDNA4_Q5_0 ? CDNA4_Q8_0 : ((type == CDNA4_Q3_K || type == CDNA4_Q2_K) ? CDNA4_Q6_K : -1); }
-int cdna4_convert_weights_kmul(int type) { return type == CDNA4_Q2_K ? 2 : 1; }       // columns of the result per column of the source
+int cdna4_convert_weights_target(int type) {
+    if (type == CDNA4_Q5_0 || type == CDNA4_IQ4_NL || type == CDNA4_Q4_1 || type == CDNA4_Q5_1) return CDNA4_Q8_0;
+    return (type == CDNA4_Q3_K || type == CDNA4_Q2_K) ? CDNA4_Q6_K : -1;
+}
+int cdna4_convert_weights_kmul(int type) { return (type == CDNA4_Q2_K || type == CDNA4_Q4_1 || type == CDNA4_Q5_1) ? 2 : 1; }       // columns of the result per column of the source
 
 // W [M rows, w_row_bytes apart] of `type` -> `out` (contiguous rows of the target format); 2-byte aligned source rows
 int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes, int64_t M, int64_t K, uint8_t *out, hipStream_t st) {
@@ -138,6 +188,13 @@ int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes
         if (K % 32) return cdna4_set_error_msg("convert_weights: K must be a multiple of 32");
         const int64_t n = M * (K / 32);
         hipLaunchKernelGGL(k_convert_q5_0_q8_0, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 32), out);
+    } else if (type == CDNA4_Q4_1 || type == CDNA4_Q5_1 || type == CDNA4_IQ4_NL) {
+        if (K % 32) return cdna4_set_error_msg("convert_weights: K must be a multiple of 32");
+        const int64_t n = M * (K / 32);
+        const dim3 grid((unsigned)((n + 255) / 256));
+        if (type == CDNA4_Q4_1) hipLaunchKernelGGL(k_convert_q41_q8_0x2<false>, grid, dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 32), out);
+        else if (type == CDNA4_Q5_1) hipLaunchKernelGGL(k_convert_q41_q8_0x2<true>, grid, dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 32), out);
+        else hipLaunchKernelGGL(k_convert_iq4_nl_q8_0, grid, dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 32), out);
     } else if (type == CDNA4_Q3_K) {
         if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");
         const int64_t n = M * (K / 256) * 18;

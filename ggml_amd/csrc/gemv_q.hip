@@ -157,8 +157,8 @@ template <int NB> struct Unit<CDNA4_Q6_K, NB> {
     template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
 };
 
-// ---- formats beyond the five of the C-ABI: units written against the CPU oracle and run only on the CPU
-// ---- emulator so far (tools/emul/gemv_emul); the C-ABI does not accept these types yet -------------------------------
+// ---- formats beyond the five headline ones: Q5_0 / Q2_K / Q3_K (hardware-verified in round 2), Q4_1 / Q5_1 / IQ4_NL
+// ---- (written against the CPU oracle, verified on the CPU emulator: tools/emul/gemv_emul) ----------------------------
 // bits 0..3 of x -> bit 0 of bytes 0..3
 __device__ __forceinline__ uint32_t spread4(uint32_t x) { return ((x & 0xFu) * 0x00204081u) & 0x01010101u; }
 
@@ -192,6 +192,96 @@ template <int NB> struct Unit<CDNA4_Q5_0, NB> {
                 ys = dot4(0x01010101u, yl[i], ys); ys = dot4(0x01010101u, yh[i], ys);
             }
             acc[c] += (float)(s - 16 * ys) * wr.d * a.d[(int64_t)col[c] * (a.K / 32) + u];
+        }
+    }
+    template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
+};
+
+// ---- Q4_1 / Q5_1: Q8_1 activations (vec_dot_q4_1_q8_1 / q5_1_q8_1, src/ggml-cpu/ggml-cpu-quants.c:2585-2601, 3309-3331):
+// ---- per 32-block (d_w * d_y) * sum(q_w q_y) + m_w * s_y, s_y = fp16(d * sum q_y) written by the activation quantizer where the
+// ---- K-quants keep their bsums (one fp32 per block: act_s())
+template <typename ACT> __device__ __forceinline__ float act_s(const ACT &a, int64_t col, int u) { return reinterpret_cast<const float *>(a.bsums)[col * (a.K / 32) + u]; }
+
+// Q4_1: 20-byte block {fp16 d, fp16 m, qs[16]}: nibble j -> k j (low), j+16 (high), value q d + m
+template <int NB> struct Unit<CDNA4_Q4_1, NB> {
+    static constexpr int UK = 32;
+    struct W { float d, m; uint32_t w[4]; };
+    __device__ static W load(const uint8_t *wrow, int u) {
+        const uint8_t *blk = wrow + (int64_t)u * 20;
+        W r; r.d = h2f(ld_u16(blk)); r.m = h2f(ld_u16(blk + 2));
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.w[i] = ld_u32_a2(blk + 4 + 4 * i);
+        return r;
+    }
+    template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            const int8_t *yr = a.qs + (int64_t)col[c] * a.K; const int yo = u * 32;
+            const u32x4 y0 = act_ld16(a, yr, yo), y1 = act_ld16(a, yr, yo + 16);
+            const uint32_t yl[4] = {y0.x, y0.y, y0.z, y0.w}, yh[4] = {y1.x, y1.y, y1.z, y1.w};
+            int s = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { s = dot4(wr.w[i] & 0x0F0F0F0Fu, yl[i], s); s = dot4((wr.w[i] >> 4) & 0x0F0F0F0Fu, yh[i], s); }
+            acc[c] += (wr.d * a.d[(int64_t)col[c] * (a.K / 32) + u]) * (float)s + wr.m * act_s(a, col[c], u);
+        }
+    }
+    template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
+};
+
+// Q5_1: 24-byte block {fp16 d, fp16 m, qh[4], qs[16]}: Q4_1 plus a fifth bit (bit j of qh: weight j; bit j+16: weight j+16)
+template <int NB> struct Unit<CDNA4_Q5_1, NB> {
+    static constexpr int UK = 32;
+    struct W { float d, m; uint32_t qh; uint32_t w[4]; };
+    __device__ static W load(const uint8_t *wrow, int u) {
+        const uint8_t *blk = wrow + (int64_t)u * 24;
+        W r; r.d = h2f(ld_u16(blk)); r.m = h2f(ld_u16(blk + 2)); r.qh = ld_u32_a2(blk + 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.w[i] = ld_u32_a2(blk + 8 + 4 * i);
+        return r;
+    }
+    template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
+        uint32_t wl[4], wh[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            wl[i] = (wr.w[i] & 0x0F0F0F0Fu) | (spread4(wr.qh >> (4 * i)) << 4);
+            wh[i] = ((wr.w[i] >> 4) & 0x0F0F0F0Fu) | (spread4(wr.qh >> (16 + 4 * i)) << 4);
+        }
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            const int8_t *yr = a.qs + (int64_t)col[c] * a.K; const int yo = u * 32;
+            const u32x4 y0 = act_ld16(a, yr, yo), y1 = act_ld16(a, yr, yo + 16);
+            const uint32_t yl[4] = {y0.x, y0.y, y0.z, y0.w}, yh[4] = {y1.x, y1.y, y1.z, y1.w};
+            int s = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { s = dot4(wl[i], yl[i], s); s = dot4(wh[i], yh[i], s); }
+            acc[c] += (wr.d * a.d[(int64_t)col[c] * (a.K / 32) + u]) * (float)s + wr.m * act_s(a, col[c], u);
+        }
+    }
+    template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
+};
+
+// IQ4_NL: 18-byte block {fp16 d, qs[16]} — Q4_0's layout with the 4-bit codes looked up in the non-linear codebook kvalues_iq4nl
+// (vec_dot_iq4_nl_q8_0, src/ggml-cpu/ggml-cpu-quants.c:10370-10561): Q8_0 activations, d_w d_y sum(kvalues[code] q_y)
+template <int NB> struct Unit<CDNA4_IQ4_NL, NB> {
+    static constexpr int UK = 32;
+    struct W { float d; uint32_t wl[4], wh[4]; };
+    __device__ static W load(const uint8_t *wrow, int u) {
+        const uint8_t *blk = wrow + (int64_t)u * 18;
+        W r; r.d = h2f(ld_u16(blk));
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const uint32_t q = ld_u32_a2(blk + 2 + 4 * i); r.wl[i] = iq4nl_lut4(q & 0x0F0F0F0Fu); r.wh[i] = iq4nl_lut4((q >> 4) & 0x0F0F0F0Fu); }
+        return r;
+    }
+    template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            const int8_t *yr = a.qs + (int64_t)col[c] * a.K; const int yo = u * 32;
+            const u32x4 y0 = act_ld16(a, yr, yo), y1 = act_ld16(a, yr, yo + 16);
+            const uint32_t yl[4] = {y0.x, y0.y, y0.z, y0.w}, yh[4] = {y1.x, y1.y, y1.z, y1.w};
+            int s = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { s = dot4(wr.wl[i], yl[i], s); s = dot4(wr.wh[i], yh[i], s); }
+            acc[c] += (wr.d * a.d[(int64_t)col[c] * (a.K / 32) + u]) * (float)s;
         }
     }
     template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
@@ -436,8 +526,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
     const int K = a.K, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = K / 16, nqd = K / (KQ ? 256 : 32);                    // 16-value chunks / scales per activation row
     int8_t *sq = reinterpret_cast<int8_t *>(smem);                          // [NB][K]
+    constexpr bool Q81 = cdna4_is_q81(TYPE);                                // Q8_1 activations: fp32 s[NB][K/32] in the place of the bsums
     int16_t *sbs = reinterpret_cast<int16_t *>(smem + NB * K);              // [NB][K/16] (Q8_K only)
-    float *sd = reinterpret_cast<float *>(smem + NB * K + (KQ ? NB * (K / 8) : 0));   // [NB][nqd]
+    float *sd = reinterpret_cast<float *>(smem + NB * K + ((KQ || Q81) ? NB * (K / 8) : 0));   // [NB][nqd]
     const int row0 = (blockIdx.x * NW + wave) * ROWS;
     const int nunits = K / Unit<TYPE, NB>::UK;
     const int total = NB * nch;                                             // chunk id = col * nch + c; 16 adjacent ids share a column and a superblock
@@ -499,6 +590,14 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
 #pragma unroll
             for (int i = 0; i < 16; i++) q[i] = (int)__builtin_rintf(e[i] * id);
             if ((c & 1) == 0) sd[col * nqd + (c >> 1)] = h2f(f2h_bits(d));
+            if constexpr (Q81) {
+                // quantize_row_q8_1 (AVX2 body, src/ggml-cpu/ggml-cpu-quants.c:1076-1119): s = fp16(d * sum of the 32 quants), d still in fp32
+                int sum = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) sum += q[i];
+                sum += __shfl_xor(sum, 1, 64);
+                if ((c & 1) == 0) reinterpret_cast<float *>(sbs)[col * nqd + (c >> 1)] = h2f(f2h_bits(d * (float)sum));
+            }
         }
         u32x4 pk;
         { const int q0[4] = {q[0], q[1], q[2], q[3]}, q1[4] = {q[4], q[5], q[6], q[7]}, q2[4] = {q[8], q[9], q[10], q[11]}, q3[4] = {q[12], q[13], q[14], q[15]};
@@ -549,7 +648,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
 
 size_t cdna4_gemv_fused_lds_bytes(int type, int64_t K) {
     const bool kq = type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K || type == CDNA4_Q2_K || type == CDNA4_Q3_K;
-    return (size_t)(K + (kq ? K / 8 + (K / 256) * 4 : (K / 32) * 4));
+    return (size_t)(K + (kq ? K / 8 + (K / 256) * 4 : (K / 32) * 4) + (cdna4_is_q81(type) ? K / 8 : 0));
 }
 static int fused_nb(int64_t B) { return B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8)); }      // instantiated column counts
 bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B) {
@@ -656,6 +755,9 @@ int cdna4_launch_gemv_q(const cdna4_gemv_args &a, hipStream_t st) {
         case CDNA4_Q4_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_type<CDNA4_Q4_0>(a, st);
         case CDNA4_Q8_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_type<CDNA4_Q8_0>(a, st);
         case CDNA4_Q5_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_type<CDNA4_Q5_0>(a, st);
+        case CDNA4_Q4_1: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_type<CDNA4_Q4_1>(a, st);
+        case CDNA4_Q5_1: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_type<CDNA4_Q5_1>(a, st);
+        case CDNA4_IQ4_NL: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_type<CDNA4_IQ4_NL>(a, st);
         case CDNA4_Q2_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_type<CDNA4_Q2_K>(a, st);
         case CDNA4_Q3_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_type<CDNA4_Q3_K>(a, st);
     }
@@ -679,6 +781,9 @@ int cdna4_launch_gemv_q_fused(const cdna4_gemv_args &a, const float *x, hipStrea
         case CDNA4_Q4_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_Q4_0>(a, x, st);
         case CDNA4_Q8_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_Q8_0>(a, x, st);
         case CDNA4_Q5_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_Q5_0>(a, x, st);
+        case CDNA4_Q4_1: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_Q4_1>(a, x, st);
+        case CDNA4_Q5_1: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_Q5_1>(a, x, st);
+        case CDNA4_IQ4_NL: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_IQ4_NL>(a, x, st);
         case CDNA4_Q2_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused<CDNA4_Q2_K>(a, x, st);
         case CDNA4_Q3_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused<CDNA4_Q3_K>(a, x, st);
     }
@@ -709,6 +814,9 @@ int cdna4_launch_gemv_q_fused_ids(const cdna4_gemv_args &a, const float *x, int6
         case CDNA4_Q4_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_ids<CDNA4_Q4_0>(a, x, x_row_stride, st);
         case CDNA4_Q8_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_ids<CDNA4_Q8_0>(a, x, x_row_stride, st);
         case CDNA4_Q5_0: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_ids<CDNA4_Q5_0>(a, x, x_row_stride, st);
+        case CDNA4_Q4_1: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_ids<CDNA4_Q4_1>(a, x, x_row_stride, st);
+        case CDNA4_Q5_1: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_ids<CDNA4_Q5_1>(a, x, x_row_stride, st);
+        case CDNA4_IQ4_NL: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_ids<CDNA4_IQ4_NL>(a, x, x_row_stride, st);
         case CDNA4_Q2_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused_ids<CDNA4_Q2_K>(a, x, x_row_stride, st);
         case CDNA4_Q3_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused_ids<CDNA4_Q3_K>(a, x, x_row_stride, st);
     }

@@ -111,6 +111,40 @@ __global__ __launch_bounds__(256) void k_quantize_q8_0(const float *__restrict__
     }
 }
 
+// Q8_1 — what the CPU backend quantizes the activations of Q4_1 / Q5_1 weights to (AVX2 body of quantize_row_q8_1,
+// src/ggml-cpu/ggml-cpu-quants.c:1076-1119): the block of k_quantize_q8_0<false> plus ss = fp16(d * sum of the 32 quants) with d still
+// in fp32 (block_q8_1.s, src/ggml-common.h:210-222), stored as fp32 like dd.  The fp16 image is that of Q8_0.
+__global__ __launch_bounds__(256) void k_quantize_q8_1(const float *__restrict__ x, int64_t x_row_stride, int K, int B,
+                                                       int8_t *__restrict__ qs, float *__restrict__ dd, float *__restrict__ ss, half_t *__restrict__ xh) {
+    const int nb = K / 32;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;             // one thread per 4 elements
+    const int64_t blk = t >> 3;
+    if (blk >= (int64_t)B * nb) return;                                     // whole 8-lane groups drop out together
+    const int b = (int)(blk / nb), ib = (int)(blk % nb), sub = (int)(t & 7);
+    const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t)b * x_row_stride + (int64_t)ib * 32 + sub * 4);
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    float amax = fmaxf(fmaxf(fabsf(e[0]), fabsf(e[1])), fmaxf(fabsf(e[2]), fabsf(e[3])));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const float d = amax / 127.f, id = amax != 0.f ? 127.f / amax : 0.f;
+    int q[4], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { q[i] = (int)__builtin_rintf(e[i] * id); sum += q[i]; }
+    sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+    const float dh = h2f(f2h_bits(d));
+    const int64_t base = (int64_t)b * K + (int64_t)ib * 32 + sub * 4;
+    if (qs) {
+        *reinterpret_cast<uint32_t *>(qs + base) = pack4i8(q);
+        if (sub == 0) { dd[(int64_t)b * nb + ib] = dh; ss[(int64_t)b * nb + ib] = h2f(f2h_bits(d * (float)sum)); }
+    }
+    if (xh) {
+        half_t h[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) h[i] = (half_t)(dh * (float)q[i]);
+        const int64_t k = (int64_t)ib * 32 + sub * 4;
+        *reinterpret_cast<u32x2 *>(xh + ((k >> 7) * B + b) * 128 + (k & 127)) = pack4h(h[0], h[2], h[1], h[3]);
+    }
+}
+
 int cdna4_launch_quantize_q8_K(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d,
                                int16_t *bsums, void *xh, hipStream_t st) {
     if (K % QK_K) return cdna4_set_error_msg("quantize_q8_K: K must be a multiple of 256");
@@ -181,6 +215,15 @@ int cdna4_launch_quantize_q8_0(const float *x, int64_t x_row_stride, int64_t K, 
     const dim3 grid((unsigned)((nthr + 255) / 256));
     if (ref_rounding) hipLaunchKernelGGL(k_quantize_q8_0<true>, grid, dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, (half_t *)xh);
     else hipLaunchKernelGGL(k_quantize_q8_0<false>, grid, dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, (half_t *)xh);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+int cdna4_launch_quantize_q8_1(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d, float *s, void *xh, hipStream_t st) {
+    if (K % 32) return cdna4_set_error_msg("quantize_q8_1: K must be a multiple of 32");
+    if (qs && (!d || !s)) return cdna4_set_error_msg("quantize_q8_1: qs needs d and s");
+    if (B == 0 || K == 0) return 0;
+    const int64_t nthr = B * (K / 4);
+    hipLaunchKernelGGL(k_quantize_q8_1, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, s, (half_t *)xh);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

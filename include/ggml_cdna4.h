@@ -39,8 +39,10 @@ enum ggml_cdna4_type {
      * re-encoding of the weights (Q5_0 / Q3_K: ggml_cdna4_convert_weights; Q2_K: scale part and minimum part as two Q6_K column blocks
      * against a doubled activation image, inside the library) */
     GGML_CDNA4_TYPE_Q5_0 = 6, GGML_CDNA4_TYPE_Q2_K = 10, GGML_CDNA4_TYPE_Q3_K = 11,
-    /* to_float only: ggml_cdna4_dequantize_row, GET_ROWS, CPY -> F32 */
-    GGML_CDNA4_TYPE_Q4_1 = 3, GGML_CDNA4_TYPE_Q5_1 = 7,
+    /* the same.  Q4_1 / Q5_1: Q8_1 activations (the CPU's vec_dot_type, src/ggml-cpu/ggml-cpu.c:271-296), prefill as [d q | m 1] in Q8_0 against a
+     * doubled activation image (inside the library, K a multiple of 128).  IQ4_NL: the codebook values are int8, so the weights re-encode
+     * exactly as Q8_0 (ggml_cdna4_convert_weights) */
+    GGML_CDNA4_TYPE_Q4_1 = 3, GGML_CDNA4_TYPE_Q5_1 = 7, GGML_CDNA4_TYPE_IQ4_NL = 20,
 };
 
 /* which kernel family ggml_cdna4_mul_mat uses */
@@ -69,7 +71,8 @@ size_t ggml_cdna4_mul_mat_workspace_size(int type, int64_t K, int64_t n_act_rows
 
 /*
  * Y[b * y_row_stride + m] = sum_k W[m][k] * X[b * x_row_stride + k],  m < M, b < B.
- *   W: M rows of K block-quantized weights (type in {Q4_0,Q8_0,Q4_K,Q5_K,Q6_K} + GEMV-only {Q5_0,Q2_K,Q3_K}), row stride w_row_bytes.
+ *   W: M rows of K block-quantized weights (type in {Q4_0,Q8_0,Q4_K,Q5_K,Q6_K} + {Q5_0,Q2_K,Q3_K,Q4_1,Q5_1,IQ4_NL}: GEMV units of their own,
+ *      prefill through an exact re-encoding into Q8_0 / Q6_K), row stride w_row_bytes.
  *   X: f32, Y: f32; strides in ELEMENTS.  workspace: >= ggml_cdna4_mul_mat_workspace_size(type, K, B) bytes,
  *   256-byte aligned.  path: enum ggml_cdna4_path.  gemm_variant / splitk: 0 = auto (tuning knobs; the bit
  *   layout of gemm_variant is documented at launch_type() in ggml_amd/csrc/gemm_q_mfma.hip).
@@ -204,8 +207,8 @@ int ggml_cdna4_op_flash_attn_ext(const ggml_cdna4_tensor * q, const ggml_cdna4_t
 /* to_float of a quantized row buffer: y[k] f32 <- x (type) — dequantize_row_*, src/ggml-quants.c */
 int ggml_cdna4_dequantize_row(int type, const void * x, float * y, int64_t k, void * stream);
 
-/* Exact re-encoding of a weight matrix into the format whose MFMA prefill GEMM it shares: Q5_0 -> Q8_0 (q8 = q5 - 16, same d) and
- * Q3_K -> Q6_K (q6 = q3 + 28, int8 scale = 6-bit scale - 32, same d).  dequantize_row of the result equals dequantize_row of the source bit
+/* Exact re-encoding of a weight matrix into the format whose MFMA prefill GEMM it shares: Q5_0 -> Q8_0 (q8 = q5 - 16, same d),
+ * IQ4_NL -> Q8_0 (q8 = kvalues_iq4nl[code], same d) and Q3_K -> Q6_K (q6 = q3 + 28, int8 scale = 6-bit scale - 32, same d).  dequantize_row of the result equals dequantize_row of the source bit
  * for bit (src/ggml-quants.c:295-319 vs 349-363, 1056-1104 vs 1690-1719), and both members of a pair use the same activation format on the
  * CPU (type_traits_cpu[].vec_dot_type, src/ggml-cpu/ggml-cpu.c:277-341).  ggml_cdna4_mul_mat does this per call into library scratch; a
  * host that keeps prefill weights resident can convert once and call ggml_cdna4_mul_mat with the target type instead.

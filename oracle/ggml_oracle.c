@@ -11,7 +11,7 @@
  * BIT-EXACT against the compiled reference (oracle/_ref, built by oracle/ref.mk) in
  * tests/test_oracle_vs_ref.py and against tests/golden/ fixtures generated from it.
  *
- * Formats: the five of the HIP path (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K) and, ahead of their kernels, Q4_1, Q5_0, Q5_1, Q2_K, Q3_K.
+ * Formats: the five of the HIP path (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K) and the widening formats Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, IQ4_NL, IQ4_XS.
  * Parity status: PINNED (bit-exact for quantize/dequantize rows, rel-L2 <= 2e-6 for mul_mat) against
  * the reference compiled here from /root/reference; the reference ships no stored golden vectors for
  * quantized MUL_MAT, so the fixtures under tests/golden/ were produced by running the
@@ -27,7 +27,7 @@
 
 /* ggml type ids — include/ggml.h:351-390 */
 enum { T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q4_1 = 3, T_Q5_0 = 6, T_Q5_1 = 7, T_Q8_0 = 8, T_Q8_1 = 9, T_Q2_K = 10, T_Q3_K = 11,
-       T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15 };
+       T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15, T_IQ4_NL = 20, T_IQ4_XS = 23 };
 
 /* ---- block formats: src/ggml-common.h:161-328 ------------------------------------------------ */
 #pragma pack(push, 1)
@@ -44,6 +44,8 @@ typedef struct { uint16_t d, m; uint8_t qh[4]; uint8_t qs[16]; } block_q5_1;    
 typedef struct { uint16_t d, s; int8_t qs[32]; } block_q8_1;                                  /* :210-222 */
 typedef struct { uint8_t scales[QK_K / 16]; uint8_t qs[QK_K / 4]; uint16_t d, dmin; } block_q2_K; /* :247-260 */
 typedef struct { uint8_t hmask[QK_K / 8]; uint8_t qs[QK_K / 4]; uint8_t scales[12]; uint16_t d; } block_q3_K; /* :267-273 */
+typedef struct { uint16_t d; uint8_t qs[16]; } block_iq4_nl;                                  /* :400-403 */
+typedef struct { uint16_t d; uint16_t scales_h; uint8_t scales_l[QK_K / 64]; uint8_t qs[QK_K / 2]; } block_iq4_xs; /* :406-411 */
 #pragma pack(pop)
 
 /* ---- fp16 <-> fp32, IEEE round-to-nearest-even (semantics of GGML_FP32_TO_FP16 / _FP16_TO_FP32,
@@ -104,14 +106,15 @@ size_t oracle_type_size(int type) {      /* src/ggml.c type_traits table :568-..
         case T_Q6_K: return sizeof(block_q6_K); case T_Q8_K: return sizeof(block_q8_K);
         case T_Q4_1: return sizeof(block_q4_1); case T_Q5_0: return sizeof(block_q5_0); case T_Q5_1: return sizeof(block_q5_1);
         case T_Q8_1: return sizeof(block_q8_1); case T_Q2_K: return sizeof(block_q2_K); case T_Q3_K: return sizeof(block_q3_K);
+        case T_IQ4_NL: return sizeof(block_iq4_nl); case T_IQ4_XS: return sizeof(block_iq4_xs);
     }
     return 0;
 }
 int oracle_blck_size(int type) {
     switch (type) {
         case T_F32: case T_F16: return 1;
-        case T_Q4_0: case T_Q8_0: case T_Q4_1: case T_Q5_0: case T_Q5_1: case T_Q8_1: return 32;
-        case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_Q8_K: case T_Q2_K: case T_Q3_K: return QK_K;
+        case T_Q4_0: case T_Q8_0: case T_Q4_1: case T_Q5_0: case T_Q5_1: case T_Q8_1: case T_IQ4_NL: return 32;
+        case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_Q8_K: case T_Q2_K: case T_Q3_K: case T_IQ4_XS: return QK_K;
     }
     return 0;
 }
@@ -265,8 +268,32 @@ void oracle_dequantize_row_q3_K(const void *vx, float *y, int64_t k) {
                 }
     }
 }
+/* the non-linear 4-bit codebook, src/ggml-quants.c:2434 */
+static const int8_t kvalues_iq4nl[16] = {-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113};
+/* src/ggml-quants.c:2436-2452 */
+void oracle_dequantize_row_iq4_nl(const void *vx, float *y, int64_t k) {
+    const block_iq4_nl *x = vx;
+    for (int64_t i = 0; i < k / 32; i++) {
+        const float d = fp16_to_fp32(x[i].d);
+        for (int j = 0; j < 16; ++j) { y[i * 32 + j] = d * kvalues_iq4nl[x[i].qs[j] & 0xf]; y[i * 32 + j + 16] = d * kvalues_iq4nl[x[i].qs[j] >> 4]; }
+    }
+}
+/* src/ggml-quants.c:2454-2475: eight 32-weight sub-blocks with 6-bit scales ls (low 4 bits in scales_l, high 2 in scales_h), dl = d * (ls - 32) */
+void oracle_dequantize_row_iq4_xs(const void *vx, float *y, int64_t k) {
+    const block_iq4_xs *x = vx;
+    for (int64_t i = 0; i < k / QK_K; i++) {
+        const float d = fp16_to_fp32(x[i].d);
+        for (int ib = 0; ib < QK_K / 32; ++ib) {
+            const int ls = ((x[i].scales_l[ib / 2] >> 4 * (ib % 2)) & 0xf) | (((x[i].scales_h >> 2 * ib) & 3) << 4);
+            const float dl = d * (ls - 32);
+            const uint8_t *qs = x[i].qs + 16 * ib;
+            for (int j = 0; j < 16; ++j) { y[i * QK_K + 32 * ib + j] = dl * kvalues_iq4nl[qs[j] & 0xf]; y[i * QK_K + 32 * ib + j + 16] = dl * kvalues_iq4nl[qs[j] >> 4]; }
+        }
+    }
+}
 void oracle_dequantize_row(int type, const void *x, float *y, int64_t k) {
     switch (type) {
+        case T_IQ4_NL: oracle_dequantize_row_iq4_nl(x, y, k); break; case T_IQ4_XS: oracle_dequantize_row_iq4_xs(x, y, k); break;
         case T_Q4_0: oracle_dequantize_row_q4_0(x, y, k); break; case T_Q8_0: oracle_dequantize_row_q8_0(x, y, k); break;
         case T_Q4_K: oracle_dequantize_row_q4_K(x, y, k); break; case T_Q5_K: oracle_dequantize_row_q5_K(x, y, k); break;
         case T_Q6_K: oracle_dequantize_row_q6_K(x, y, k); break; case T_Q8_K: oracle_dequantize_row_q8_K(x, y, k); break;
@@ -549,11 +576,48 @@ float oracle_vec_dot_q3_K_q8_K(int n, const void *vx, const void *vy) {
     return sumf;
 }
 
+/* src/ggml-cpu/ggml-cpu-quants.c:10370-10561 (scalar tail :10550-10559) */
+float oracle_vec_dot_iq4_nl_q8_0(int n, const void *vx, const void *vy) {
+    const block_iq4_nl *x = vx; const block_q8_0 *y = vy; float sumf = 0;
+    for (int ib = 0; ib < n / 32; ++ib) {
+        const float d = fp16_to_fp32(y[ib].d) * fp16_to_fp32(x[ib].d);
+        int sumi1 = 0, sumi2 = 0;
+        for (int j = 0; j < 16; ++j) { sumi1 += y[ib].qs[j] * kvalues_iq4nl[x[ib].qs[j] & 0xf]; sumi2 += y[ib].qs[j + 16] * kvalues_iq4nl[x[ib].qs[j] >> 4]; }
+        sumf += d * (sumi1 + sumi2);
+    }
+    return sumf;
+}
+/* src/ggml-cpu/ggml-cpu-quants.c:10563-10898 (scalar body :10866-10896): per superblock d4d8 = d * y.d, per 32-sub-block the two 16-halves
+ * accumulated separately, sumf += d4d8 * (ls - 32) * (sumi1 + sumi2) */
+float oracle_vec_dot_iq4_xs_q8_K(int n, const void *vx, const void *vy) {
+    const block_iq4_xs *x = vx; const block_q8_K *y = vy; float sumf = 0;
+    for (int ibl = 0; ibl < n / QK_K; ++ibl) {
+        const float d4d8 = fp16_to_fp32(x[ibl].d) * y[ibl].d;
+        uint16_t h = x[ibl].scales_h;
+        const uint8_t *qs = x[ibl].qs; const int8_t *q8 = y[ibl].qs;
+        for (int ib = 0; ib < QK_K / 32; ib += 2) {
+            const uint8_t ls1 = (x[ibl].scales_l[ib / 2] & 0xf) | ((h << 4) & 0x30);
+            const uint8_t ls2 = (x[ibl].scales_l[ib / 2] >> 4) | ((h << 2) & 0x30);
+            h >>= 4;
+            const float d1 = d4d8 * (ls1 - 32), d2 = d4d8 * (ls2 - 32);
+            int sumi1 = 0, sumi2 = 0;
+            for (int j = 0; j < 16; ++j) { sumi1 += q8[j] * kvalues_iq4nl[qs[j] & 0xf]; sumi2 += q8[j + 16] * kvalues_iq4nl[qs[j] >> 4]; }
+            sumf += d1 * (sumi1 + sumi2);
+            qs += 16; q8 += 32;
+            sumi1 = sumi2 = 0;
+            for (int j = 0; j < 16; ++j) { sumi1 += q8[j] * kvalues_iq4nl[qs[j] & 0xf]; sumi2 += q8[j + 16] * kvalues_iq4nl[qs[j] >> 4]; }
+            sumf += d2 * (sumi1 + sumi2);
+            qs += 16; q8 += 32;
+        }
+    }
+    return sumf;
+}
+
 /* type_traits_cpu[]: weight type -> (vec_dot, vec_dot_type) — src/ggml-cpu/ggml-cpu.c:253-418 */
 int oracle_vec_dot_type(int type) {
     switch (type) {
-        case T_Q4_0: case T_Q8_0: case T_Q5_0: return T_Q8_0; case T_Q4_1: case T_Q5_1: return T_Q8_1;
-        case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_Q2_K: case T_Q3_K: return T_Q8_K;
+        case T_Q4_0: case T_Q8_0: case T_Q5_0: case T_IQ4_NL: return T_Q8_0; case T_Q4_1: case T_Q5_1: return T_Q8_1;
+        case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_Q2_K: case T_Q3_K: case T_IQ4_XS: return T_Q8_K;
     }
     return -1;
 }
@@ -569,6 +633,7 @@ float oracle_vec_dot(int wtype, int n, const void *vx, const void *vy) {
         case T_Q4_1: return oracle_vec_dot_q4_1_q8_1(n, vx, vy); case T_Q5_0: return oracle_vec_dot_q5_0_q8_0(n, vx, vy);
         case T_Q5_1: return oracle_vec_dot_q5_1_q8_1(n, vx, vy); case T_Q2_K: return oracle_vec_dot_q2_K_q8_K(n, vx, vy);
         case T_Q3_K: return oracle_vec_dot_q3_K_q8_K(n, vx, vy);
+        case T_IQ4_NL: return oracle_vec_dot_iq4_nl_q8_0(n, vx, vy); case T_IQ4_XS: return oracle_vec_dot_iq4_xs_q8_K(n, vx, vy);
     }
     return NAN;
 }

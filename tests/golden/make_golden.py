@@ -48,7 +48,7 @@ for name, t in (("q4_K", R.Q4_K), ("q8_0", R.Q8_0), ("q4_0", R.Q4_0), ("q5_K", R
             y[tk, u] = R.r_mul_mat(t, w[e * Mi * rs:(e + 1) * Mi * rs], xb[tk, u:u + 1], Mi, Ki)[0]
     mm[name + "_w"], mm[name + "_x"], mm[name + "_y"] = w, xb, y
 np.savez_compressed(os.path.join(HERE, "mul_mat_id_small.npz"), n_expert=n_expert, n_used=n_used, n_tok=n_tok, M=Mi, K=Ki, ids=ids, **mm)
-# the formats only the oracle knows so far (Q4_1 / Q5_0 / Q5_1 / Q2_K / Q3_K): same recipe, separate file
+# the widening formats (Q4_1 / Q5_0 / Q5_1 / Q2_K / Q3_K / IQ4_NL / IQ4_XS): same recipe, separate file
 more = {}
 for name, t in R.ORACLE_ONLY_TYPES.items():
     rng = np.random.default_rng(1000 + t)

@@ -10,11 +10,12 @@ REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 
 # ggml type ids (include/ggml.h:351-390)
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 8, 12, 13, 14, 15
-Q4_1, Q5_0, Q5_1, Q8_1, Q2_K, Q3_K = 3, 6, 7, 9, 10, 11        # Q5_0 / Q2_K / Q3_K have GEMV units (Q5_0 / Q3_K also the GEMM), Q4_1 / Q5_1 to_float only
+Q4_1, Q5_0, Q5_1, Q8_1, Q2_K, Q3_K = 3, 6, 7, 9, 10, 11        # GEMV units + an MFMA prefill path through exact re-encodings
+IQ4_NL, IQ4_XS = 20, 23                                         # IQ4_NL: the same; IQ4_XS: oracle only
 QUANT_TYPES = {"q4_0": Q4_0, "q8_0": Q8_0, "q4_K": Q4_K, "q5_K": Q5_K, "q6_K": Q6_K}          # the formats of the HIP path
-ORACLE_ONLY_TYPES = {"q4_1": Q4_1, "q5_0": Q5_0, "q5_1": Q5_1, "q2_K": Q2_K, "q3_K": Q3_K}
-TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292, Q4_1: 20, Q5_0: 22, Q5_1: 24, Q8_1: 36, Q2_K: 84, Q3_K: 110}
-BLCK = {F32: 1, F16: 1, Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256, Q4_1: 32, Q5_0: 32, Q5_1: 32, Q8_1: 32, Q2_K: 256, Q3_K: 256}
+ORACLE_ONLY_TYPES = {"q4_1": Q4_1, "q5_0": Q5_0, "q5_1": Q5_1, "q2_K": Q2_K, "q3_K": Q3_K, "iq4_nl": IQ4_NL, "iq4_xs": IQ4_XS}
+TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292, Q4_1: 20, Q5_0: 22, Q5_1: 24, Q8_1: 36, Q2_K: 84, Q3_K: 110, IQ4_NL: 18, IQ4_XS: 136}
+BLCK = {F32: 1, F16: 1, Q4_0: 32, Q8_0: 32, Q4_K: 256, Q5_K: 256, Q6_K: 256, Q8_K: 256, Q4_1: 32, Q5_0: 32, Q5_1: 32, Q8_1: 32, Q2_K: 256, Q3_K: 256, IQ4_NL: 32, IQ4_XS: 256}
 
 
 def row_size(t, k):
@@ -53,7 +54,7 @@ def o_dequantize(t, wbytes, k):
 
 def act_type(wtype):
     """type_traits_cpu[wtype].vec_dot_type (src/ggml-cpu/ggml-cpu.c:253-418)"""
-    return Q8_0 if wtype in (Q4_0, Q8_0, Q5_0) else (Q8_1 if wtype in (Q4_1, Q5_1) else Q8_K)
+    return Q8_0 if wtype in (Q4_0, Q8_0, Q5_0, IQ4_NL) else (Q8_1 if wtype in (Q4_1, Q5_1) else Q8_K)
 
 
 def o_quantize_act(wtype, x):
@@ -185,7 +186,8 @@ def r_quantize(t, x):
 
 _DEQ = {Q4_0: "dequantize_row_q4_0", Q8_0: "dequantize_row_q8_0", Q4_K: "dequantize_row_q4_K",
         Q5_K: "dequantize_row_q5_K", Q6_K: "dequantize_row_q6_K", Q8_K: "dequantize_row_q8_K",
-        Q4_1: "dequantize_row_q4_1", Q5_0: "dequantize_row_q5_0", Q5_1: "dequantize_row_q5_1", Q2_K: "dequantize_row_q2_K", Q3_K: "dequantize_row_q3_K"}
+        Q4_1: "dequantize_row_q4_1", Q5_0: "dequantize_row_q5_0", Q5_1: "dequantize_row_q5_1", Q2_K: "dequantize_row_q2_K", Q3_K: "dequantize_row_q3_K",
+        IQ4_NL: "dequantize_row_iq4_nl", IQ4_XS: "dequantize_row_iq4_xs"}
 
 
 def r_dequantize(t, wbytes, k):
@@ -218,7 +220,8 @@ def r_quantize_act(wtype, x):
 
 _VD = {Q4_0: "ggml_vec_dot_q4_0_q8_0", Q8_0: "ggml_vec_dot_q8_0_q8_0", Q4_K: "ggml_vec_dot_q4_K_q8_K",
        Q5_K: "ggml_vec_dot_q5_K_q8_K", Q6_K: "ggml_vec_dot_q6_K_q8_K", Q4_1: "ggml_vec_dot_q4_1_q8_1", Q5_0: "ggml_vec_dot_q5_0_q8_0",
-       Q5_1: "ggml_vec_dot_q5_1_q8_1", Q2_K: "ggml_vec_dot_q2_K_q8_K", Q3_K: "ggml_vec_dot_q3_K_q8_K"}
+       Q5_1: "ggml_vec_dot_q5_1_q8_1", Q2_K: "ggml_vec_dot_q2_K_q8_K", Q3_K: "ggml_vec_dot_q3_K_q8_K",
+       IQ4_NL: "ggml_vec_dot_iq4_nl_q8_0", IQ4_XS: "ggml_vec_dot_iq4_xs_q8_K"}
 
 
 def r_mul_mat(t, w, x, m, k):
@@ -258,8 +261,10 @@ def random_block_bytes(t, m, k, rng):
     raw = rng.integers(0, 256, (nb, TYPE_SIZE[t]), dtype=np.uint8)
     def f16(lo, hi, n):
         return rng.uniform(lo, hi, n).astype(np.float16).view(np.uint8).reshape(n, 2)
-    if t in (Q4_0, Q8_0):
+    if t in (Q4_0, Q8_0, IQ4_NL):
         raw[:, 0:2] = f16(-0.2, 0.2, nb)
+    elif t == IQ4_XS:
+        raw[:, 0:2] = f16(-0.01, 0.01, nb)
     elif t in (Q4_K, Q5_K):
         raw[:, 0:2] = f16(0.001, 0.02, nb); raw[:, 2:4] = f16(0.001, 0.02, nb)
     elif t == Q6_K:

@@ -58,6 +58,11 @@ def run_cols(t, M, K, ncol, seed=1, timeout=600, staged=False):
         d = blk[:, :, 0:4].copy().view(np.float32).reshape(ncol, K // 256)
         qs = blk[:, :, 4:260].copy().view(np.int8).reshape(ncol, K)
         bs = blk[:, :, 260:292].copy().view(np.int16).reshape(ncol, K // 16)
+    elif R.act_type(t) == R.Q8_1:                    # {fp16 d, fp16 s, qs[32]}: s travels as fp32 where the K-quants keep their bsums
+        blk = act.reshape(ncol, K // 32, 36)
+        d = blk[:, :, 0:2].copy().view(np.float16).astype(np.float32).reshape(ncol, K // 32)
+        qs = blk[:, :, 4:36].copy().view(np.int8).reshape(ncol, K)
+        bs = blk[:, :, 2:4].copy().view(np.float16).astype(np.float32).reshape(ncol, K // 32).view(np.int16)
     else:
         blk = act.reshape(ncol, K // 32, 34)
         d = blk[:, :, 0:2].copy().view(np.float16).astype(np.float32).reshape(ncol, K // 32)

@@ -1,7 +1,8 @@
 // quant_emul.cpp — runs the SOURCE of the activation quantizers (ggml_amd/csrc/quantize_act.hip: k_quantize_q8_K, k_quantize_q8_0) on
 // the CPU.  Test infrastructure.
-//   quant_emul kind K B x.bin qs.bin d.bin bsums.bin xh.bin      kind: 0 = Q8_K, 1 = Q8_0 (AVX2 rounding), 2 = Q8_0 (_ref rounding)
-// Outputs: int8 qs[B][K], float d[B][K/QK], int16 bsums[B][K/16] (Q8_K), and the fp16 activation image of the MFMA GEMM.
+//   quant_emul kind K B x.bin qs.bin d.bin bsums.bin xh.bin      kind: 0 = Q8_K, 1 = Q8_0 (AVX2 rounding), 2 = Q8_0 (_ref rounding), 3 = Q8_1
+// Outputs: int8 qs[B][K], float d[B][K/QK], int16 bsums[B][K/16] (Q8_K; Q8_1: float s[B][K/32] in the same bytes), and the fp16 activation
+// image of the MFMA GEMM.
 #include "hip_emul.h"
 #include <signal.h>
 #include <sys/mman.h>
@@ -76,7 +77,8 @@ int main(int argc, char **argv) {
     const int64_t qk = kind == 0 ? 256 : 32;
     int8_t *qs = (int8_t *)shared_alloc((size_t)(B * K)); float *d = (float *)shared_alloc((size_t)(B * (K / qk)) * 4);
     int16_t *bs = (int16_t *)shared_alloc((size_t)(B * (K / 16)) * 2); uint8_t *xh = (uint8_t *)shared_alloc((size_t)(B * K) * 2);
-    int rc = kind == 0 ? cdna4_launch_quantize_q8_K(x, K, K, B, qs, d, bs, xh, nullptr) : cdna4_launch_quantize_q8_0(x, K, K, B, qs, d, xh, kind == 2, nullptr);
+    int rc = kind == 0 ? cdna4_launch_quantize_q8_K(x, K, K, B, qs, d, bs, xh, nullptr) :
+             kind == 3 ? cdna4_launch_quantize_q8_1(x, K, K, B, qs, d, reinterpret_cast<float *>(bs), xh, nullptr) : cdna4_launch_quantize_q8_0(x, K, K, B, qs, d, xh, kind == 2, nullptr);
     if (rc != 0) return 1;
     dump(argv[5], qs, (size_t)(B * K)); dump(argv[6], d, (size_t)(B * (K / qk)) * 4); dump(argv[7], bs, (size_t)(B * (K / 16)) * 2); dump(argv[8], xh, (size_t)(B * K) * 2);
     return 0;

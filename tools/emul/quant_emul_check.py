@@ -2,7 +2,7 @@
 CPU oracle's quantize_row_q8_K / quantize_row_q8_0 (AVX2 and _ref roundings), and the fp16 activation image of the MFMA GEMM
 with fp16(d * q) in its panel-major, pair-interleaved layout.
 
-    python tools/emul/quant_emul_check.py [kind K B]        kind 0 = Q8_K, 1 = Q8_0 (AVX2 rounding), 2 = Q8_0 (_ref rounding)
+    python tools/emul/quant_emul_check.py [kind K B]        kind 0 = Q8_K, 1 = Q8_0 (AVX2 rounding), 2 = Q8_0 (_ref rounding), 3 = Q8_1
 """
 import os
 import subprocess
@@ -62,6 +62,12 @@ def run(kind, K, B, dist="uniform", seed=1, timeout=900):
         rq = ref[:, :, 4:260].copy().view(np.int8).reshape(B, K)
         rb = ref[:, :, 260:292].copy().view(np.int16).reshape(B, K // 16)
         assert np.array_equal(bs, rb), "bsums"
+    elif kind == 3:                                  # Q8_1 (activations of Q4_1 / Q5_1 weights): block {fp16 d, fp16 s, qs[32]}
+        ref = R.o_quantize_act(R.Q4_1, x).reshape(B, K // 32, 36)
+        rd = ref[:, :, 0:2].copy().view(np.float16).astype(np.float32).reshape(B, K // 32)
+        rs = ref[:, :, 2:4].copy().view(np.float16).astype(np.float32).reshape(B, K // 32)
+        rq = ref[:, :, 4:36].copy().view(np.int8).reshape(B, K)
+        assert np.array_equal(bs.reshape(-1).view(np.float32).reshape(B, K // 32).view(np.uint32), rs.view(np.uint32)), "s = fp16(d * sum q)"
     else:
         ref = R.o_quantize_row("q8_0_cpu" if kind == 1 else "q8_0_ref", x).reshape(B, K // 32, 34)
         rd = ref[:, :, 0:2].copy().view(np.float16).astype(np.float32).reshape(B, K // 32)
