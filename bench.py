@@ -52,7 +52,7 @@ def time_left(budget):
 def synth_blocks(t, m, k, seed):
     """fallback only (no oracle/_ref/synth_data): random but VALID blocks with small positive fp16 scales"""
     geo = {12: (144, 256, (0, 2)), 13: (176, 256, (0, 2)), 14: (210, 256, (208,)), 2: (18, 32, (0,)), 8: (34, 32, (0,)),
-           6: (22, 32, (0,)), 10: (84, 256, (80, 82)), 11: (110, 256, (108,))}[t]
+           6: (22, 32, (0,)), 10: (84, 256, (80, 82)), 11: (110, 256, (108,)), 3: (20, 32, (0, 2)), 7: (24, 32, (0, 2)), 20: (18, 32, (0,))}[t]
     rng = np.random.default_rng(seed)
     nb = m * k // geo[1]
     raw = rng.integers(0, 256, (nb, geo[0]), dtype=np.uint8)
@@ -61,7 +61,7 @@ def synth_blocks(t, m, k, seed):
     return raw.reshape(-1)
 
 
-TYPE_NAME = {12: "q4_K", 13: "q5_K", 14: "q6_K", 2: "q4_0", 8: "q8_0", 6: "q5_0", 10: "q2_K", 11: "q3_K"}
+TYPE_NAME = {12: "q4_K", 13: "q5_K", 14: "q6_K", 2: "q4_0", 8: "q8_0", 6: "q5_0", 10: "q2_K", 11: "q3_K", 3: "q4_1", 7: "q5_1", 20: "iq4_nl"}
 
 
 def prescribed(t, m, k, row_lo, row_hi, b):
@@ -344,7 +344,7 @@ def moe_row(dev, steps):
 
 
 def widening_rows(dev, steps):
-    """the rows SURVEY 8(f) ranks after the five formats.  (1) Q5_0 / Q3_K / Q2_K at the headline shape: the whole MUL_MAT
+    """the rows SURVEY 8(f) ranks after the five formats.  (1) Q5_0 / Q3_K / Q2_K (+ IQ4_NL / Q4_1 / Q5_1) at the headline shape: the whole MUL_MAT
     step (activation quantize + per-call exact re-encoding into Q8_0 / Q6_K + that format's MFMA GEMM) and the one-launch decode.
     (2) FLASH_ATTN_EXT, F16 K / V, head size 128, 32 heads, with a mask: prefill rows against the fp16 MFMA roof (4 n_head n_q n_kv hs
     flops), decode rows against the HBM roof (K + V read once)."""
@@ -352,7 +352,7 @@ def widening_rows(dev, steps):
     from ggml_amd import native, ops
     out = {"formats": {}, "flash_attn_ext": {}}
     m, k, b = HEAD
-    for t in (6, 11, 10):
+    def fmt(t):
         w, x, how = prescribed(t, m, k, 0, m, b)
         a = ops.QTensor.from_host_bytes(t, k, m, w, device=dev)
         xd = torch.from_numpy(x).to(dev)
@@ -363,6 +363,9 @@ def widening_rows(dev, steps):
         d_us = events_us(lambda: ops.mul_mat(a, x1, out=y1), max(steps, 200), 10)
         out["formats"][TYPE_NAME[t]] = {"step_b512_us": round(s_us, 3), "step_b512_tflops": round(2.0 * m * k * b / s_us / 1e6, 1), "decode_b1_us_cache_warm": round(d_us, 3),
                                         "weight_bytes": int(w.size), "data": how}
+        leg_row("formats", TYPE_NAME[t], out["formats"][TYPE_NAME[t]])
+    for t in (6, 11, 10):
+        fmt(t)
     rng = np.random.default_rng(11)
     hs, nh = 128, 32
     for n_q, n_kv in ((4096, 4096), (512, 512), (1, 4096), (1, 32768)):
@@ -383,6 +386,9 @@ def widening_rows(dev, steps):
             gb = 4.0 * nh * n_kv * hs / us / 1e3
             row.update(kv_GBps=round(gb, 1), frac_of_hbm_roof=round(gb / HBM_PEAK_GBS, 4), kernel="k_flash_attn_split<128> + k_flash_attn_merge<128>")
         out["flash_attn_ext"]["hs128_h32_q%d_kv%d" % (n_q, n_kv)] = row
+        leg_row("flash_attn_ext", "hs128_h32_q%d_kv%d" % (n_q, n_kv), row)
+    for t in (20, 3, 7):                   # IQ4_NL / Q4_1 / Q5_1: no hardware session of their own before this run (tests/test_gpu_widening.py) — last
+        fmt(t)
     return out
 
 
@@ -472,6 +478,33 @@ def c5_leg(dist, dev, rank, world, steps, warmup):
     return out
 
 
+def leg_in_child(name, steps, timeout):
+    """one optional leg in a process of its own (python bench.py --leg NAME): its result — the rows that were finished when it ended, if it
+    was cut short (the child prints every row as soon as it has it) — plus what went wrong, if anything did"""
+    note, txt, rc = None, "", 0
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", name, "--steps", str(steps)], capture_output=True, text=True, timeout=timeout)
+        txt, rc = r.stdout, r.returncode
+        if rc:
+            note = "leg '%s' exited with %d after the rows below: %s" % (name, rc, (r.stderr or "")[-300:])
+    except subprocess.TimeoutExpired as e:
+        txt = (e.stdout.decode() if isinstance(e.stdout, bytes) else e.stdout) or ""
+        note = "leg '%s' was stopped after %d s; rows finished by then are below" % (name, timeout)
+    out = {}
+    for ln in txt.splitlines():
+        if ln.startswith("LEG_ROW "):
+            _, group, key, body = ln.split(" ", 3)
+            out.setdefault(group, {})[key] = json.loads(body)
+    if note:
+        out["error"] = note
+    return out
+
+
+def leg_row(group, key, row):
+    """(child side) one finished row, printed at once"""
+    print("LEG_ROW %s %s %s" % (group, key, json.dumps(row)), flush=True)
+
+
 def run_legs(legs, out):
     """the optional legs (name, thunk, latest start in seconds after the run began): none STARTS once the run is that old, and a leg
     that raises records the error instead of taking the metric line down"""
@@ -497,6 +530,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the metric, its roofline, the library ceiling and the CPU baseline")
     ap.add_argument("--no-diagnostics", action="store_true", help="(accepted for compatibility; same as --no-extras)")
+    ap.add_argument("--leg", default=None, help="(internal) run ONE optional leg in this process and print its JSON: the parent runs legs that touch "
+                                                "paths without a hardware session of their own this way, so that a device fault there cannot take the metric line down")
     ap.add_argument("--lean", action="store_true", help="profiling runs (scripts/gpu_full.sh): the timed loop and the kernel-only loop, nothing else — every launch of the "
                                                         "dominant kernel in the trace is a headline launch on the prescribed data")
     args = ap.parse_args()
@@ -519,6 +554,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     from ggml_amd import native
     native.lib()
+
+    if args.leg is not None:
+        fn = {"widening": lambda: widening_rows(dev, max(50, min(args.steps, 200)))}[args.leg]
+        fn()                                                             # prints its rows itself (leg_row)
+        return
 
     if args.config == "c5":
         c5 = c5_leg(dist, dev, rank, world, args.steps, args.warmup)
@@ -609,7 +649,7 @@ def main():
                     ("formats", lambda: format_rows(dev, steps), 230),
                     ("mul_mat_id", lambda: moe_row(dev, steps), 245),
                     ("batch_sweep", lambda: batch_sweep(dev, steps), 250),
-                    ("widening", lambda: widening_rows(dev, steps), 255),
+                    ("widening", lambda: leg_in_child("widening", steps, int(max(30, min(120, time_left(330))))), 255),
                     ("stock_test_backend_ops_perf", lambda: stock_perf_lines(int(max(30, min(150, time_left(400))))), 280))
             run_legs(legs, out)
     if rank == 0:
