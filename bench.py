@@ -52,7 +52,7 @@ def time_left(budget):
 def synth_blocks(t, m, k, seed):
     """fallback only (no oracle/_ref/synth_data): random but VALID blocks with small positive fp16 scales"""
     geo = {12: (144, 256, (0, 2)), 13: (176, 256, (0, 2)), 14: (210, 256, (208,)), 2: (18, 32, (0,)), 8: (34, 32, (0,)),
-           6: (22, 32, (0,)), 10: (84, 256, (80, 82)), 11: (110, 256, (108,)), 3: (20, 32, (0, 2)), 7: (24, 32, (0, 2)), 20: (18, 32, (0,))}[t]
+           6: (22, 32, (0,)), 10: (84, 256, (80, 82)), 11: (110, 256, (108,)), 3: (20, 32, (0, 2)), 7: (24, 32, (0, 2)), 20: (18, 32, (0,)), 23: (136, 256, (0,))}[t]
     rng = np.random.default_rng(seed)
     nb = m * k // geo[1]
     raw = rng.integers(0, 256, (nb, geo[0]), dtype=np.uint8)
@@ -61,7 +61,7 @@ def synth_blocks(t, m, k, seed):
     return raw.reshape(-1)
 
 
-TYPE_NAME = {12: "q4_K", 13: "q5_K", 14: "q6_K", 2: "q4_0", 8: "q8_0", 6: "q5_0", 10: "q2_K", 11: "q3_K", 3: "q4_1", 7: "q5_1", 20: "iq4_nl"}
+TYPE_NAME = {12: "q4_K", 13: "q5_K", 14: "q6_K", 2: "q4_0", 8: "q8_0", 6: "q5_0", 10: "q2_K", 11: "q3_K", 3: "q4_1", 7: "q5_1", 20: "iq4_nl", 23: "iq4_xs"}
 
 
 def prescribed(t, m, k, row_lo, row_hi, b):
@@ -344,7 +344,7 @@ def moe_row(dev, steps):
 
 
 def widening_rows(dev, steps):
-    """the rows SURVEY 8(f) ranks after the five formats.  (1) Q5_0 / Q3_K / Q2_K (+ IQ4_NL / Q4_1 / Q5_1) at the headline shape: the whole MUL_MAT
+    """the rows SURVEY 8(f) ranks after the five formats.  (1) Q5_0 / Q3_K / Q2_K (+ IQ4_NL / IQ4_XS / Q4_1 / Q5_1) at the headline shape: the whole MUL_MAT
     step (activation quantize + per-call exact re-encoding into Q8_0 / Q6_K + that format's MFMA GEMM) and the one-launch decode.
     (2) FLASH_ATTN_EXT, F16 K / V, head size 128, 32 heads, with a mask: prefill rows against the fp16 MFMA roof (4 n_head n_q n_kv hs
     flops), decode rows against the HBM roof (K + V read once)."""
@@ -387,7 +387,7 @@ def widening_rows(dev, steps):
             row.update(kv_GBps=round(gb, 1), frac_of_hbm_roof=round(gb / HBM_PEAK_GBS, 4), kernel="k_flash_attn_split<128> + k_flash_attn_merge<128>")
         out["flash_attn_ext"]["hs128_h32_q%d_kv%d" % (n_q, n_kv)] = row
         leg_row("flash_attn_ext", "hs128_h32_q%d_kv%d" % (n_q, n_kv), row)
-    for t in (20, 3, 7):                   # IQ4_NL / Q4_1 / Q5_1: no hardware session of their own before this run (tests/test_gpu_widening.py) — last
+    for t in (20, 23, 3, 7):               # IQ4_NL / IQ4_XS / Q4_1 / Q5_1: no hardware session of their own before this run (tests/test_gpu_widening.py) — last
         fmt(t)
     return out
 

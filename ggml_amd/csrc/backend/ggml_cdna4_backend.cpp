@@ -121,7 +121,7 @@ static bool buft_is_cdna4(ggml_backend_buffer_type_t buft) { return buft && buft
 // every type here has int8-dot GEMV units and an MFMA prefill path (its own kernel, or an exact re-encoding into a format that has one: ggml_cdna4.h)
 static bool is_qweight(ggml_type t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K ||
                                              t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K ||
-                                             t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_IQ4_NL; }
+                                             t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_IQ4_NL || t == GGML_TYPE_IQ4_XS; }
 
 static bool supports_mul_mat(const ggml_tensor * op) {
     const ggml_tensor * a = op->src[0], * b = op->src[1];

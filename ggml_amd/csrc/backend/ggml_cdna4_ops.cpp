@@ -15,7 +15,7 @@ static ggml_cdna4_tensor desc(const ggml_tensor * t) {
 static bool f32(const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32; }
 // quantized sources of GET_ROWS / CPY -> F32 (to_float of ops.hip)
 static bool qsrc(ggml_type t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_K || t == GGML_TYPE_Q5_K || t == GGML_TYPE_Q6_K ||
-                                       t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K || t == GGML_TYPE_IQ4_NL; }
+                                       t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q2_K || t == GGML_TYPE_Q3_K || t == GGML_TYPE_IQ4_NL || t == GGML_TYPE_IQ4_XS; }
 static bool ff16(ggml_type t) { return t == GGML_TYPE_F32 || t == GGML_TYPE_F16; }
 
 static int unary_id(const ggml_tensor * op) {

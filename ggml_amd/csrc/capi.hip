@@ -17,7 +17,7 @@ int cdna4_set_error_msg(const char *msg) { snprintf(g_err, sizeof g_err, "%s", m
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Q5_0 / Q3_K / Q2_K: int8-dot GEMV units of gemv_q.hip for up to 8 activation rows, above that the Q8_0 / Q6_K MFMA GEMM on an exact
 // re-encoding of the weights (convert_w.hip; Q2_K as [scale part | minimum part] against a doubled activation image)
-static inline bool is_kq(int t) { return t == CDNA4_Q4_K || t == CDNA4_Q5_K || t == CDNA4_Q6_K || t == CDNA4_Q2_K || t == CDNA4_Q3_K; }
+static inline bool is_kq(int t) { return t == CDNA4_Q4_K || t == CDNA4_Q5_K || t == CDNA4_Q6_K || t == CDNA4_Q2_K || t == CDNA4_Q3_K || t == CDNA4_IQ4_XS; }
 // Q4_1 / Q5_1 (Q8_1 activations: s in the place of the bsums) and IQ4_NL: GEMV units; above 8 rows the Q8_0 GEMM on the re-encoding
 // (Q4_1 / Q5_1 as [d q | m 1] against a doubled activation image, like Q2_K)
 static inline bool is_q(int t) { return is_kq(t) || t == CDNA4_Q4_0 || t == CDNA4_Q8_0 || t == CDNA4_Q5_0 || t == CDNA4_Q4_1 || t == CDNA4_Q5_1 || t == CDNA4_IQ4_NL; }
@@ -69,7 +69,7 @@ size_t ggml_cdna4_row_size(int type, int64_t k) {
         case CDNA4_Q5_0: return k % 32 ? 0 : (size_t)(k / 32) * 22; case CDNA4_Q2_K: return k % 256 ? 0 : (size_t)(k / 256) * 84;
         case CDNA4_Q3_K: return k % 256 ? 0 : (size_t)(k / 256) * 110;
         case CDNA4_Q4_1: return k % 32 ? 0 : (size_t)(k / 32) * 20; case CDNA4_Q5_1: return k % 32 ? 0 : (size_t)(k / 32) * 24;
-        case CDNA4_IQ4_NL: return k % 32 ? 0 : (size_t)(k / 32) * 18;
+        case CDNA4_IQ4_NL: return k % 32 ? 0 : (size_t)(k / 32) * 18; case CDNA4_IQ4_XS: return k % 256 ? 0 : (size_t)(k / 256) * 136;
     }
     return 0;
 }

@@ -18,6 +18,9 @@ enum cdna4_type : int {
     CDNA4_Q4_1 = 3, CDNA4_Q5_1 = 7,
     // the same: non-linear 4-bit codebook (kvalues_iq4nl, src/ggml-quants.c:2434), Q8_0 activations; prefill GEMM as Q8_0 (q8 = codebook value)
     CDNA4_IQ4_NL = 20,
+    // the same with 256-weight superblocks and 6-bit sub-block scales (Q8_K activations); prefill GEMM as Q6_K with 2 K columns (codebook value =
+    // 4 h + l: the h part with int8 scale 4 (ls - 32), the l part with ls - 32)
+    CDNA4_IQ4_XS = 23,
 };
 // weight types whose CPU vec_dot runs on Q8_1 activations (type_traits_cpu[].vec_dot_type, src/ggml-cpu/ggml-cpu.c:271-296): the activation
 // workspace then carries, in the place of the Q8_K bsums, one fp32 per 32-block holding s = fp16(d * sum of the quants) (block_q8_1.s)
@@ -36,6 +39,7 @@ template <> struct QT<CDNA4_Q3_K> { static constexpr int BYTES = 110, QK = 256; 
 template <> struct QT<CDNA4_Q4_1> { static constexpr int BYTES = 20,  QK = 32;  static constexpr bool KQ = false; };
 template <> struct QT<CDNA4_Q5_1> { static constexpr int BYTES = 24,  QK = 32;  static constexpr bool KQ = false; };
 template <> struct QT<CDNA4_IQ4_NL> { static constexpr int BYTES = 18, QK = 32;  static constexpr bool KQ = false; };
+template <> struct QT<CDNA4_IQ4_XS> { static constexpr int BYTES = 136, QK = 256; static constexpr bool KQ = true; };
 // library-private re-layouts of the 2-byte-aligned formats into 16-byte-aligned 256-weight superblocks, produced per call
 // into scratch by gemm_q_mfma.hip's repack kernels so that the LDS-DMA pipeline (16-byte pieces) can stage them:
 //   Q4_0R 144 B: fp16 d[8] | 4 x 32 B nibbles in Q4_K order (byte l of group g: low = k 64g+l, high = k 64g+32+l)

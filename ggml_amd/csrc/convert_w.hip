@@ -7,6 +7,7 @@
 //    Q2_K -> Q6_K + Q6_K   w = d sc4 q2 - dmin m4 = d sc4 (qa - 32)  +  dmin (-m4) (33 - 32)             (library-internal: see below)
 //    IQ4_NL -> Q8_0 w = d kvalues[code]          = d q8,                 q8 = kvalues_iq4nl[code] in [-127, 113]  (same fp16 d)
 //    Q4_1 / Q5_1 -> Q8_0 + Q8_0   w = d q + m    = d q8  +  m 1,         q8 = q in [0, 15] / [0, 31]       (library-internal, like Q2_K)
+//    IQ4_XS -> Q6_K + Q6_K   w = d (ls - 32) kvalues[code] = d (4 (ls - 32)) (qa - 32) + d (ls - 32) (qb - 32),  kvalues = 4 (qa - 32) + (qb - 32)   (the same)
 //
 // Every weight keeps its value bit for bit (dequantize_row_q5_0 / _q3_K of the source == dequantize_row_q8_0 / _q6_K of the result,
 // src/ggml-quants.c:307-331, 1139-1188 vs :349-363, 1690-1719), and source and target share their activation format on the CPU
@@ -167,8 +168,53 @@ __global__ __launch_bounds__(256) void k_convert_q2_K_q6_K2(const uint8_t *__res
     }
 }
 
+// IQ4_XS -> [h part | l part] as Q6_K: codebook value kv = 4 h + l with h = kv >> 2 in [-32, 28] and l = kv & 3, so
+// w = d (ls - 32) kv = d (4 (ls - 32)) h + d (ls - 32) l: two Q6_K weights with int8 scales 4 (ls - 32) in [-128, 124] and ls - 32, q6 = h + 32 and
+// l + 32, the same fp16 d.  d (ls - 32) has at most 17 significant bits, so both products and their sum are exact in fp32: the sum of the two
+// parts' dequantize_row_q6_K equals dequantize_row_iq4_xs (src/ggml-quants.c:2454-2475) value for value.  18 threads per superblock as above:
+// threads 0..15 (128-half n = pc >> 3, l = 4 (pc & 7) .. + 3): weight 128 n + 32 j + l is code (l & 15) (low codes for l < 16, high above) of
+// sub-block 4 n + j; thread 16: the sixteen scales of each part (sub-block ib = 16-weight groups 2 ib, 2 ib + 1); thread 17: d.
+__global__ __launch_bounds__(256) void k_convert_iq4_xs_q6_K2(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nsb, uint8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)M * nsb * 18) return;
+    const int pc = (int)(t % 18); const int64_t u = t / 18;
+    const int row = (int)(u / nsb), sb = (int)(u % nsb);
+    const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)sb * 136;
+    uint8_t *da = out + ((int64_t)row * 2 * nsb + sb) * 210, *db = da + (int64_t)nsb * 210;
+    auto st32 = [](uint8_t *p, uint32_t v) { *reinterpret_cast<uint16_t *>(p) = (uint16_t)v; *reinterpret_cast<uint16_t *>(p + 2) = (uint16_t)(v >> 16); };
+    if (pc < 16) {
+        const int n = pc >> 3, l = 4 * (pc & 7);
+        uint32_t a[4], b[4];                                             // q6 of the h part / the l part for j = 0..3, one weight per byte
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t q = ld_u32_a2(src + 8 + 16 * (4 * n + j) + (l & 15));
+            const uint32_t kv = iq4nl_lut4(l < 16 ? (q & 0x0F0F0F0Fu) : ((q >> 4) & 0x0F0F0F0Fu));
+            a[j] = ((kv ^ 0x80808080u) >> 2) & 0x3F3F3F3Fu;              // (kv + 128) / 4 = (kv >> 2) + 32
+            b[j] = (kv & 0x03030303u) | 0x20202020u;                     // (kv & 3) + 32
+        }
+        st32(da + 64 * n + l, (a[0] & 0x0F0F0F0Fu) | ((a[2] & 0x0F0F0F0Fu) << 4));
+        st32(da + 64 * n + 32 + l, (a[1] & 0x0F0F0F0Fu) | ((a[3] & 0x0F0F0F0Fu) << 4));
+        st32(da + 128 + 32 * n + l, ((a[0] >> 4) & 0x03030303u) | (((a[1] >> 4) & 0x03030303u) << 2) | (((a[2] >> 4) & 0x03030303u) << 4) | (((a[3] >> 4) & 0x03030303u) << 6));
+        st32(db + 64 * n + l, (b[0] & 0x0F0F0F0Fu) | ((b[2] & 0x0F0F0F0Fu) << 4));
+        st32(db + 64 * n + 32 + l, (b[1] & 0x0F0F0F0Fu) | ((b[3] & 0x0F0F0F0Fu) << 4));
+        st32(db + 128 + 32 * n + l, 0xAAAAAAAAu);                        // bits 4-5 of every l-part q6 are 2
+    } else if (pc == 16) {
+        const uint32_t sh = ld_u16(src + 2);
+#pragma unroll
+        for (int ib = 0; ib < 8; ib++) {
+            const int ls = (int)(((src[4 + (ib >> 1)] >> (4 * (ib & 1))) & 0xFu) | (((sh >> (2 * ib)) & 3u) << 4)) - 32;
+            const uint32_t sa = (uint32_t)(4 * ls) & 0xFFu, sbv = (uint32_t)ls & 0xFFu;
+            *reinterpret_cast<uint16_t *>(da + 192 + 2 * ib) = (uint16_t)(sa | (sa << 8));
+            *reinterpret_cast<uint16_t *>(db + 192 + 2 * ib) = (uint16_t)(sbv | (sbv << 8));
+        }
+    } else {
+        *reinterpret_cast<uint16_t *>(da + 208) = ld_u16(src);
+        *reinterpret_cast<uint16_t *>(db + 208) = ld_u16(src);
+    }
+}
+
 size_t cdna4_convert_weights_bytes(int type, int64_t M, int64_t K) {
-    if (type == CDNA4_Q2_K) return (size_t)M * 2 * (K / 256) * 210;
+    if (type == CDNA4_Q2_K || type == CDNA4_IQ4_XS) return (size_t)M * 2 * (K / 256) * 210;
     if (type == CDNA4_Q5_0 || type == CDNA4_IQ4_NL) return (size_t)M * (K / 32) * 34;
     if (type == CDNA4_Q4_1 || type == CDNA4_Q5_1) return (size_t)M * 2 * (K / 32) * 34;
     if (type == CDNA4_Q3_K) return (size_t)M * (K / 256) * 210;
@@ -176,9 +222,9 @@ size_t cdna4_convert_weights_bytes(int type, int64_t M, int64_t K) {
 }
 int cdna4_convert_weights_target(int type) {
     if (type == CDNA4_Q5_0 || type == CDNA4_IQ4_NL || type == CDNA4_Q4_1 || type == CDNA4_Q5_1) return CDNA4_Q8_0;
-    return (type == CDNA4_Q3_K || type == CDNA4_Q2_K) ? CDNA4_Q6_K : -1;
+    return (type == CDNA4_Q3_K || type == CDNA4_Q2_K || type == CDNA4_IQ4_XS) ? CDNA4_Q6_K : -1;
 }
-int cdna4_convert_weights_kmul(int type) { return (type == CDNA4_Q2_K || type == CDNA4_Q4_1 || type == CDNA4_Q5_1) ? 2 : 1; }       // columns of the result per column of the source
+int cdna4_convert_weights_kmul(int type) { return (type == CDNA4_Q2_K || type == CDNA4_Q4_1 || type == CDNA4_Q5_1 || type == CDNA4_IQ4_XS) ? 2 : 1; }       // columns of the result per column of the source
 
 // W [M rows, w_row_bytes apart] of `type` -> `out` (contiguous rows of the target format); 2-byte aligned source rows
 int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes, int64_t M, int64_t K, uint8_t *out, hipStream_t st) {
@@ -199,6 +245,10 @@ int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes
         if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");
         const int64_t n = M * (K / 256) * 18;
         hipLaunchKernelGGL(k_convert_q3_K_q6_K, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out);
+    } else if (type == CDNA4_IQ4_XS) {
+        if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");
+        const int64_t n = M * (K / 256) * 18;
+        hipLaunchKernelGGL(k_convert_iq4_xs_q6_K2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out);
     } else if (type == CDNA4_Q2_K) {
         if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");
         const int64_t n = M * (K / 256) * 18;

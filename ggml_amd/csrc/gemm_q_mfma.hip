@@ -356,7 +356,7 @@ bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B) {
         case CDNA4_Q4_0: case CDNA4_Q8_0: return K > 0 && K % 64 == 0;
         case CDNA4_Q5_0: case CDNA4_IQ4_NL: return K > 0 && K % 64 == 0;        // as Q8_0, after the exact re-encoding of convert_w.hip
         case CDNA4_Q4_1: case CDNA4_Q5_1: return K > 0 && K % 128 == 0;        // as Q8_0 with 2 K columns ([d q | m 1]) against a doubled activation image: whole 128-k panels
-        case CDNA4_Q3_K: case CDNA4_Q2_K: return K > 0 && K % 256 == 0;     // as Q6_K (Q2_K: 2 K columns against a doubled activation image)
+        case CDNA4_Q3_K: case CDNA4_Q2_K: case CDNA4_IQ4_XS: return K > 0 && K % 256 == 0;     // as Q6_K (Q2_K / IQ4_XS: 2 K columns against a doubled activation image)
     }
     return false;
 }
@@ -590,7 +590,7 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
     if (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 1) return cdna4_set_error_msg("gemm_q: weight rows must be 2-byte aligned");
     if ((a.type == CDNA4_Q4_K || a.type == CDNA4_Q5_K) && (((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15))
         return cdna4_set_error_msg("gemm_q: Q4_K/Q5_K rows must be 16-byte aligned");
-    if (a.type == CDNA4_Q5_0 || a.type == CDNA4_Q3_K || a.type == CDNA4_Q2_K || a.type == CDNA4_Q4_1 || a.type == CDNA4_Q5_1 || a.type == CDNA4_IQ4_NL) {
+    if (a.type == CDNA4_Q5_0 || a.type == CDNA4_Q3_K || a.type == CDNA4_Q2_K || a.type == CDNA4_Q4_1 || a.type == CDNA4_Q5_1 || a.type == CDNA4_IQ4_NL || a.type == CDNA4_IQ4_XS) {
         // no MFMA kernel of their own: re-encode EXACTLY as Q8_0 / Q6_K into scratch (convert_w.hip) and run that format's GEMM
         uint8_t *cw = (uint8_t *)get_scratch(cdna4_convert_weights_bytes(a.type, a.M, a.K) + 256, 3);
         if (!cw) return cdna4_set_error_msg("gemm_q: cannot allocate the weight re-encoding scratch");
@@ -602,7 +602,7 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
             c.type = CDNA4_Q8_0; c.K = a.K * cdna4_convert_weights_kmul(a.type); c.xh_row_elems = c.K; c.w_row_bytes = (int64_t)(c.K / 32) * 34;
             return launch_type<CDNA4_Q8_0>(c, st);
         }
-        // Q2_K: scale part and minimum part side by side, a.xh holds the activation image twice (capi.hip: prepare_act)
+        // Q3_K: same shape.  Q2_K (scale part | minimum part) and IQ4_XS (h part | l part): two column blocks, a.xh holds the activation image twice (capi.hip: prepare_act)
         c.type = CDNA4_Q6_K; c.K = a.K * cdna4_convert_weights_kmul(a.type); c.xh_row_elems = c.K; c.w_row_bytes = (int64_t)(c.K / 256) * 210;
         return launch_type<CDNA4_Q6_K>(c, st);
     }

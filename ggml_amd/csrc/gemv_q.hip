@@ -157,7 +157,7 @@ template <int NB> struct Unit<CDNA4_Q6_K, NB> {
     template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
 };
 
-// ---- formats beyond the five headline ones: Q5_0 / Q2_K / Q3_K (hardware-verified in round 2), Q4_1 / Q5_1 / IQ4_NL
+// ---- formats beyond the five headline ones: Q5_0 / Q2_K / Q3_K (hardware-verified in round 2), Q4_1 / Q5_1 / IQ4_NL / IQ4_XS
 // ---- (written against the CPU oracle, verified on the CPU emulator: tools/emul/gemv_emul) ----------------------------
 // bits 0..3 of x -> bit 0 of bytes 0..3
 __device__ __forceinline__ uint32_t spread4(uint32_t x) { return ((x & 0xFu) * 0x00204081u) & 0x01010101u; }
@@ -282,6 +282,50 @@ template <int NB> struct Unit<CDNA4_IQ4_NL, NB> {
 #pragma unroll
             for (int i = 0; i < 4; i++) { s = dot4(wr.wl[i], yl[i], s); s = dot4(wr.wh[i], yh[i], s); }
             acc[c] += (wr.d * a.d[(int64_t)col[c] * (a.K / 32) + u]) * (float)s;
+        }
+    }
+    template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
+};
+
+// ---- IQ4_XS: 136-byte superblock {fp16 d, u16 scales_h, scales_l[4], qs[128]}: eight 32-weight sub-blocks laid out like IQ4_NL blocks, 6-bit
+// ---- scale ls of sub-block ib = (scales_l[ib / 2] >> 4 (ib % 2)) & 15 | ((scales_h >> 2 ib) & 3) << 4, weight = d (ls - 32) kvalues[code]
+// ---- (vec_dot_iq4_xs_q8_K, src/ggml-cpu/ggml-cpu-quants.c:10563-10898: Q8_K activations, per sub-block (d d_y) (ls - 32) * sum).
+// ---- Unit = 64 consecutive k = sub-blocks 2g, 2g+1 of superblock sb (32 bytes of qs)
+template <int NB> struct Unit<CDNA4_IQ4_XS, NB> {
+    static constexpr int UK = 64;
+    struct W { float d; int ls0, ls1; uint32_t w[4][4]; };      // w[2 s + h][i]: sub-block 2g+s, low (h = 0: k 0..15) / high (k 16..31) codes as int8 codebook values
+    __device__ static W load(const uint8_t *wrow, int u) {
+        const int sb = u >> 2, g = u & 3;
+        const uint8_t *blk = wrow + (int64_t)sb * 136;
+        W r; r.d = h2f(ld_u16(blk));
+        const uint32_t sh = ld_u16(blk + 2), sl = blk[4 + g];
+        r.ls0 = (int)((sl & 0xFu) | (((sh >> (4 * g)) & 3u) << 4)) - 32;
+        r.ls1 = (int)((sl >> 4) | (((sh >> (4 * g + 2)) & 3u) << 4)) - 32;
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t q = ld_u32_a2(blk + 8 + 32 * g + 16 * s + 4 * i);
+                r.w[2 * s][i] = iq4nl_lut4(q & 0x0F0F0F0Fu); r.w[2 * s + 1][i] = iq4nl_lut4((q >> 4) & 0x0F0F0F0Fu);
+            }
+        return r;
+    }
+    template <typename ACT> __device__ static void mac(const W &wr, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) {
+        const int sb = u >> 2, g = u & 3;
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            const int8_t *yr = a.qs + (int64_t)col[c] * a.K; const int yo = sb * 256 + 64 * g;
+            const u32x4 y[4] = {act_ld16(a, yr, yo), act_ld16(a, yr, yo + 16), act_ld16(a, yr, yo + 32), act_ld16(a, yr, yo + 48)};
+            int s0 = 0, s1 = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t ya[4] = {y[h].x, y[h].y, y[h].z, y[h].w}, yb[4] = {y[2 + h].x, y[2 + h].y, y[2 + h].z, y[2 + h].w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) { s0 = dot4(wr.w[h][i], ya[i], s0); s1 = dot4(wr.w[2 + h][i], yb[i], s1); }
+            }
+            const float d4d8 = wr.d * a.d[(int64_t)col[c] * (a.K / 256) + sb];
+            acc[c] += (d4d8 * (float)wr.ls0) * (float)s0;
+            acc[c] += (d4d8 * (float)wr.ls1) * (float)s1;
         }
     }
     template <typename ACT> __device__ static void dot(const uint8_t *wrow, int u, const ACT &a, const int (&col)[NB], float (&acc)[NB]) { mac(load(wrow, u), u, a, col, acc); }
@@ -647,7 +691,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
 }
 
 size_t cdna4_gemv_fused_lds_bytes(int type, int64_t K) {
-    const bool kq = type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K || type == CDNA4_Q2_K || type == CDNA4_Q3_K;
+    const bool kq = type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K || type == CDNA4_Q2_K || type == CDNA4_Q3_K || type == CDNA4_IQ4_XS;
     return (size_t)(K + (kq ? K / 8 + (K / 256) * 4 : (K / 32) * 4) + (cdna4_is_q81(type) ? K / 8 : 0));
 }
 static int fused_nb(int64_t B) { return B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8)); }      // instantiated column counts
@@ -760,6 +804,7 @@ int cdna4_launch_gemv_q(const cdna4_gemv_args &a, hipStream_t st) {
         case CDNA4_IQ4_NL: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_type<CDNA4_IQ4_NL>(a, st);
         case CDNA4_Q2_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_type<CDNA4_Q2_K>(a, st);
         case CDNA4_Q3_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_type<CDNA4_Q3_K>(a, st);
+        case CDNA4_IQ4_XS: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_type<CDNA4_IQ4_XS>(a, st);
     }
     return cdna4_set_error_msg("gemv_q: unsupported weight type");
 }
@@ -786,6 +831,7 @@ int cdna4_launch_gemv_q_fused(const cdna4_gemv_args &a, const float *x, hipStrea
         case CDNA4_IQ4_NL: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused<CDNA4_IQ4_NL>(a, x, st);
         case CDNA4_Q2_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused<CDNA4_Q2_K>(a, x, st);
         case CDNA4_Q3_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused<CDNA4_Q3_K>(a, x, st);
+        case CDNA4_IQ4_XS: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused<CDNA4_IQ4_XS>(a, x, st);
     }
     return cdna4_set_error_msg("gemv_q: unsupported weight type");
 }
@@ -819,6 +865,7 @@ int cdna4_launch_gemv_q_fused_ids(const cdna4_gemv_args &a, const float *x, int6
         case CDNA4_IQ4_NL: if (a.K % 32) return cdna4_set_error_msg("gemv_q: K must be a multiple of 32"); return launch_fused_ids<CDNA4_IQ4_NL>(a, x, x_row_stride, st);
         case CDNA4_Q2_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused_ids<CDNA4_Q2_K>(a, x, x_row_stride, st);
         case CDNA4_Q3_K: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused_ids<CDNA4_Q3_K>(a, x, x_row_stride, st);
+        case CDNA4_IQ4_XS: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused_ids<CDNA4_IQ4_XS>(a, x, x_row_stride, st);
     }
     return cdna4_set_error_msg("gemv_q: unsupported weight type");
 }

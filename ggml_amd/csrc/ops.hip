@@ -16,12 +16,12 @@ static inline size_t tsize(int type) {
     switch (type) { case CDNA4_F32: case CDNA4_I32: return 4; case CDNA4_F16: return 2; case CDNA4_Q4_0: return 18; case CDNA4_Q8_0: return 34;
                     case CDNA4_Q4_K: return 144; case CDNA4_Q5_K: return 176; case CDNA4_Q6_K: return 210;
                     case CDNA4_Q4_1: return 20; case CDNA4_Q5_0: return 22; case CDNA4_Q5_1: return 24; case CDNA4_Q2_K: return 84; case CDNA4_Q3_K: return 110;
-                    case CDNA4_IQ4_NL: return 18; }
+                    case CDNA4_IQ4_NL: return 18; case CDNA4_IQ4_XS: return 136; }
     return 0;
 }
 static inline int bsize(int type) {
     switch (type) { case CDNA4_Q4_0: case CDNA4_Q8_0: case CDNA4_Q4_1: case CDNA4_Q5_0: case CDNA4_Q5_1: case CDNA4_IQ4_NL: return 32;
-                    case CDNA4_Q4_K: case CDNA4_Q5_K: case CDNA4_Q6_K: case CDNA4_Q2_K: case CDNA4_Q3_K: return 256; }
+                    case CDNA4_Q4_K: case CDNA4_Q5_K: case CDNA4_Q6_K: case CDNA4_Q2_K: case CDNA4_Q3_K: case CDNA4_IQ4_XS: return 256; }
     return 1;
 }
 static inline bool is_contig(const T4 *t) {      // ggml_is_contiguous
@@ -211,6 +211,16 @@ template <> __device__ __forceinline__ float deq_elem<CDNA4_IQ4_NL>(const uint8_
     const uint8_t *b = row + (k >> 5) * 18; const int j = (int)(k & 31);
     const float d = h2f(ld_u16(b)); const uint8_t q = b[2 + (j & 15)];
     return d * (float)(int8_t)(iq4nl_lut4(j < 16 ? (q & 0x0Fu) : (q >> 4)) & 0xFFu);
+}
+// IQ4_XS {fp16 d, u16 scales_h, scales_l[4], qs[128]}: eight IQ4_NL-shaped sub-blocks, dl = d * (ls - 32) with the 6-bit ls, dl * kvalues_iq4nl[code]
+// (src/ggml-quants.c:2454-2475)
+template <> __device__ __forceinline__ float deq_elem<CDNA4_IQ4_XS>(const uint8_t *row, int64_t k) {
+    const uint8_t *b = row + (k >> 8) * 136; const int e = (int)(k & 255), ib = e >> 5, j = e & 31;
+    const uint32_t sh = ld_u16(b + 2);
+    const int ls = (int)(((b[4 + (ib >> 1)] >> (4 * (ib & 1))) & 0xFu) | (((sh >> (2 * ib)) & 3u) << 4));
+    const float dl = h2f(ld_u16(b)) * (float)(ls - 32);
+    const uint8_t q = b[8 + 16 * ib + (j & 15)];
+    return dl * (float)(int8_t)(iq4nl_lut4(j < 16 ? (q & 0x0Fu) : (q >> 4)) & 0xFFu);
 }
 // Q5_0 {fp16 d, qh[4], qs[16]}: bit j of qh is the fifth bit of weight j; (q - 16) * d (src/ggml-quants.c:295-319)
 template <> __device__ __forceinline__ float deq_elem<CDNA4_Q5_0>(const uint8_t *row, int64_t k) {
@@ -499,7 +509,7 @@ int ggml_cdna4_op_get_rows(const T4 *a, const T4 *ids, const T4 *d, void *stream
     switch (a->type) {
         case CDNA4_F32: GR(CDNA4_F32); case CDNA4_F16: GR(CDNA4_F16); case CDNA4_Q4_0: GR(CDNA4_Q4_0); case CDNA4_Q8_0: GR(CDNA4_Q8_0);
         case CDNA4_Q4_K: GR(CDNA4_Q4_K); case CDNA4_Q5_K: GR(CDNA4_Q5_K); case CDNA4_Q6_K: GR(CDNA4_Q6_K);
-        case CDNA4_Q4_1: GR(CDNA4_Q4_1); case CDNA4_Q5_0: GR(CDNA4_Q5_0); case CDNA4_Q5_1: GR(CDNA4_Q5_1); case CDNA4_Q2_K: GR(CDNA4_Q2_K); case CDNA4_Q3_K: GR(CDNA4_Q3_K); case CDNA4_IQ4_NL: GR(CDNA4_IQ4_NL);
+        case CDNA4_Q4_1: GR(CDNA4_Q4_1); case CDNA4_Q5_0: GR(CDNA4_Q5_0); case CDNA4_Q5_1: GR(CDNA4_Q5_1); case CDNA4_Q2_K: GR(CDNA4_Q2_K); case CDNA4_Q3_K: GR(CDNA4_Q3_K); case CDNA4_IQ4_NL: GR(CDNA4_IQ4_NL); case CDNA4_IQ4_XS: GR(CDNA4_IQ4_XS);
         default: return cdna4_set_error_msg("get_rows: unsupported source type");
     }
 #undef GR
@@ -526,7 +536,7 @@ int ggml_cdna4_op_cpy(const T4 *a, const T4 *d, int q8_0_ref_rounding, void *str
         NEED(a->nb[0] == (int64_t)tsize(ta), "cpy: quantized source rows must be contiguous");
 #define CQ(T) hipLaunchKernelGGL(k_cpy_q_to_f32<T>, grid1d(n), dim3(256), 0, st, *a, *d, n); break
         switch (ta) { case CDNA4_Q4_0: CQ(CDNA4_Q4_0); case CDNA4_Q8_0: CQ(CDNA4_Q8_0); case CDNA4_Q4_K: CQ(CDNA4_Q4_K); case CDNA4_Q5_K: CQ(CDNA4_Q5_K); case CDNA4_Q6_K: CQ(CDNA4_Q6_K);
-                      case CDNA4_Q4_1: CQ(CDNA4_Q4_1); case CDNA4_Q5_0: CQ(CDNA4_Q5_0); case CDNA4_Q5_1: CQ(CDNA4_Q5_1); case CDNA4_Q2_K: CQ(CDNA4_Q2_K); case CDNA4_Q3_K: CQ(CDNA4_Q3_K); case CDNA4_IQ4_NL: CQ(CDNA4_IQ4_NL);
+                      case CDNA4_Q4_1: CQ(CDNA4_Q4_1); case CDNA4_Q5_0: CQ(CDNA4_Q5_0); case CDNA4_Q5_1: CQ(CDNA4_Q5_1); case CDNA4_Q2_K: CQ(CDNA4_Q2_K); case CDNA4_Q3_K: CQ(CDNA4_Q3_K); case CDNA4_IQ4_NL: CQ(CDNA4_IQ4_NL); case CDNA4_IQ4_XS: CQ(CDNA4_IQ4_XS);
                       default: return cdna4_set_error_msg("cpy: unsupported quantized source"); }
 #undef CQ
     } else if (ta == CDNA4_F32 && (td == CDNA4_Q8_0 || td == CDNA4_Q4_0)) {

@@ -43,6 +43,8 @@ enum ggml_cdna4_type {
      * doubled activation image (inside the library, K a multiple of 128).  IQ4_NL: the codebook values are int8, so the weights re-encode
      * exactly as Q8_0 (ggml_cdna4_convert_weights) */
     GGML_CDNA4_TYPE_Q4_1 = 3, GGML_CDNA4_TYPE_Q5_1 = 7, GGML_CDNA4_TYPE_IQ4_NL = 20,
+    /* the same; prefill as two Q6_K column blocks (codebook value = 4 h + l) against a doubled activation image, inside the library */
+    GGML_CDNA4_TYPE_IQ4_XS = 23,
 };
 
 /* which kernel family ggml_cdna4_mul_mat uses */
@@ -71,7 +73,7 @@ size_t ggml_cdna4_mul_mat_workspace_size(int type, int64_t K, int64_t n_act_rows
 
 /*
  * Y[b * y_row_stride + m] = sum_k W[m][k] * X[b * x_row_stride + k],  m < M, b < B.
- *   W: M rows of K block-quantized weights (type in {Q4_0,Q8_0,Q4_K,Q5_K,Q6_K} + {Q5_0,Q2_K,Q3_K,Q4_1,Q5_1,IQ4_NL}: GEMV units of their own,
+ *   W: M rows of K block-quantized weights (type in {Q4_0,Q8_0,Q4_K,Q5_K,Q6_K} + {Q5_0,Q2_K,Q3_K,Q4_1,Q5_1,IQ4_NL,IQ4_XS}: GEMV units of their own,
  *      prefill through an exact re-encoding into Q8_0 / Q6_K), row stride w_row_bytes.
  *   X: f32, Y: f32; strides in ELEMENTS.  workspace: >= ggml_cdna4_mul_mat_workspace_size(type, K, B) bytes,
  *   256-byte aligned.  path: enum ggml_cdna4_path.  gemm_variant / splitk: 0 = auto (tuning knobs; the bit

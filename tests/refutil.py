@@ -11,7 +11,7 @@ REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 # ggml type ids (include/ggml.h:351-390)
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K = 0, 1, 2, 8, 12, 13, 14, 15
 Q4_1, Q5_0, Q5_1, Q8_1, Q2_K, Q3_K = 3, 6, 7, 9, 10, 11        # GEMV units + an MFMA prefill path through exact re-encodings
-IQ4_NL, IQ4_XS = 20, 23                                         # IQ4_NL: the same; IQ4_XS: oracle only
+IQ4_NL, IQ4_XS = 20, 23                                         # the same
 QUANT_TYPES = {"q4_0": Q4_0, "q8_0": Q8_0, "q4_K": Q4_K, "q5_K": Q5_K, "q6_K": Q6_K}          # the formats of the HIP path
 ORACLE_ONLY_TYPES = {"q4_1": Q4_1, "q5_0": Q5_0, "q5_1": Q5_1, "q2_K": Q2_K, "q3_K": Q3_K, "iq4_nl": IQ4_NL, "iq4_xs": IQ4_XS}
 TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 18, Q8_0: 34, Q4_K: 144, Q5_K: 176, Q6_K: 210, Q8_K: 292, Q4_1: 20, Q5_0: 22, Q5_1: 24, Q8_1: 36, Q2_K: 84, Q3_K: 110, IQ4_NL: 18, IQ4_XS: 136}

@@ -262,7 +262,7 @@ def test_small_batch_decode_kernel_source_on_the_cpu(t, ncol):
 
 
 @pytest.mark.parametrize("cfg", [0, 1])                       # 4 waves x 1 row, 8 waves x 2 rows (the M >= 4096 default)
-@pytest.mark.parametrize("t", [12, 13, 14, 2, 8, 6, 10, 11, 3, 7, 20])  # Q4_K, Q5_K, Q6_K, Q4_0, Q8_0, Q5_0, Q2_K, Q3_K, Q4_1, Q5_1 (in-launch Q8_1 quantizer), IQ4_NL
+@pytest.mark.parametrize("t", [12, 13, 14, 2, 8, 6, 10, 11, 3, 7, 20, 23])  # Q4_K, Q5_K, Q6_K, Q4_0, Q8_0, Q5_0, Q2_K, Q3_K, Q4_1, Q5_1 (in-launch Q8_1 quantizer), IQ4_NL, IQ4_XS
 def test_decode_kernel_source_on_the_cpu(t, cfg):
     """tools/emul/gemv_emul: the source of the one-launch decode step (k_gemv_q_fused: in-kernel Q8_K / Q8_0 activation quantizer,
     int8 dots, wave reduction) executed on the CPU against the oracle's MUL_MAT — a GPU-free regression check of the B = 1 path"""
@@ -306,7 +306,7 @@ def test_activation_quantizer_sources_on_the_cpu_bit_exact(kind, k, b, dist):
     assert mod.run(kind, k, b, dist=dist, seed=kind + k)
 
 
-@pytest.mark.parametrize("t", [12, 13, 14, 2, 8, 6, 10, 11, 3, 7, 20])
+@pytest.mark.parametrize("t", [12, 13, 14, 2, 8, 6, 10, 11, 3, 7, 20, 23])
 def test_multi_column_gemv_source_on_the_cpu(t):
     """tools/emul/gemv_emul: k_gemv_q (2 <= B <= 8 columns share one pass over the weights) on activations quantized by the
     oracle, against the oracle's MUL_MAT"""
@@ -331,19 +331,20 @@ def _emul_module(name):
 
 
 @pytest.mark.parametrize("t,m,k", [(6, 8, 1024), (6, 33, 64), (11, 8, 1024), (11, 33, 512), (10, 8, 1024), (10, 33, 512), (10, 5, 256),
-                                   (20, 8, 1024), (20, 33, 64), (3, 8, 1024), (3, 33, 128), (7, 8, 1024), (7, 33, 128)])
+                                   (20, 8, 1024), (20, 33, 64), (3, 8, 1024), (3, 33, 128), (7, 8, 1024), (7, 33, 128), (23, 8, 1024), (23, 33, 256)])
 def test_weight_reencoding_sources_on_the_cpu_are_exact(t, m, k):
     """tools/emul/convert_emul: k_convert_q5_0_q8_0 / k_convert_q3_K_q6_K / k_convert_q2_K_q6_K2 (the prefill route of Q5_0 / Q3_K / Q2_K)
     executed on the CPU: the oracle's dequantize_row of the re-encoded matrix equals its dequantize_row of the source bit for bit, on fully
     random block bytes; for Q2_K the sum of its two parts (scale part + minimum part, 2 K columns) equals it value for value.  Likewise IQ4_NL -> Q8_0
-    (k_convert_iq4_nl_q8_0) and Q4_1 / Q5_1 -> [d q | m 1] in Q8_0 (k_convert_q41_q8_0x2: the sum of the two parts bit for bit)"""
+    (k_convert_iq4_nl_q8_0), Q4_1 / Q5_1 -> [d q | m 1] in Q8_0 (k_convert_q41_q8_0x2: the sum of the two parts bit for bit) and IQ4_XS -> [h part | l part]
+    in Q6_K (k_convert_iq4_xs_q6_K2: value for value)"""
     assert _emul_module("convert_emul_check").run(t, m, k, seed=t + k)
 
 
-@pytest.mark.parametrize("t", [2, 3, 6, 7, 8, 10, 11, 12, 13, 14, 20])
+@pytest.mark.parametrize("t", [2, 3, 6, 7, 8, 10, 11, 12, 13, 14, 20, 23])
 def test_to_float_sources_on_the_cpu_bit_exact(t):
     """tools/emul/deq_emul: deq_elem of ops.hip (dequantize_row, GET_ROWS, CPY -> F32) executed on the CPU equals the oracle's dequantize_row_*
-    bit for bit for all eleven block formats, on fully random block bytes"""
+    bit for bit for all twelve block formats, on fully random block bytes"""
     assert _emul_module("deq_emul_check").run(t, 32 * 256 if t > 9 else 32 * 24, seed=t)
 
 

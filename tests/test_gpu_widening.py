@@ -203,19 +203,21 @@ def test_stock_harness_flash_attn_ext():
     assert n_ok >= 90, "suspiciously few supported cases ran: %d\n%s" % (n_ok, txt[-2000:])
 
 
-# ------------------------------------------------------------------------------------------------ Q4_1 / Q5_1 / IQ4_NL
+# ------------------------------------------------------------------------------------------------ Q4_1 / Q5_1 / IQ4_NL / IQ4_XS
 # Added after the round's last hardware session: kernel sources verified on the CPU emulator only (tools/emul: GEMV units incl. the in-launch
 # Q8_1 quantizer 1-2e-7 from the oracle, k_quantize_q8_1 / to_float / re-encodings bit-exact); every pre-existing kernel's ISA is unchanged.
 # They sort last in the file on purpose.
-NEW_TYPES = [("q4_1", R.Q4_1), ("q5_1", R.Q5_1), ("iq4_nl", R.IQ4_NL)]
+NEW_TYPES = [("q4_1", R.Q4_1), ("q5_1", R.Q5_1), ("iq4_nl", R.IQ4_NL), ("iq4_xs", R.IQ4_XS)]
 
 
 @pytest.mark.parametrize("name,t", NEW_TYPES)
 @pytest.mark.parametrize("m,k,b", [(16, 256, 1), (48, 1024, 8), (33, 2048, 5), (256, 4096, 2), (20, 544, 7), (4096, 4096, 1)])
 def test_q4_1_q5_1_iq4_nl_gemv_parity(gu, name, t, m, k, b):
-    """vec_dot_q4_1_q8_1 / q5_1_q8_1 (Q8_1 activations: d and s = fp16(d * sum q)) and vec_dot_iq4_nl_q8_0 through the GEMV units: the
-    one-launch form (b = 1, quantizer inside) and the quantize + GEMV pair (b = 2..8)"""
+    """vec_dot_q4_1_q8_1 / q5_1_q8_1 (Q8_1 activations: d and s = fp16(d * sum q)), vec_dot_iq4_nl_q8_0 and vec_dot_iq4_xs_q8_K through the GEMV
+    units: the one-launch form (b = 1, quantizer inside) and the quantize + GEMV pair (b = 2..8)"""
     from ggml_amd import ops
+    if k % R.BLCK[t]:
+        pytest.skip("K is not a whole number of %s blocks" % name)
     w = R.random_weights(t, m, k, seed=m + k)
     x = _x(b + k, b, k)
     y = ops.mul_mat(gu.qtensor(t, w, m, k), gu.to_dev(x), path=ops.PATH_GEMV).cpu().numpy()
@@ -229,8 +231,8 @@ def test_q4_1_q5_1_iq4_nl_gemv_parity(gu, name, t, m, k, b):
 @pytest.mark.parametrize("name,t", NEW_TYPES)
 @pytest.mark.parametrize("m,k,b", [(16, 256, 9), (200, 1024, 100), (130, 768, 33), (512, 2048, 128), (4096, 4096, 512)])
 def test_q4_1_q5_1_iq4_nl_prefill_gemm(gu, name, t, m, k, b):
-    """above 8 activation rows: ONE Q8_0 MFMA GEMM on the re-encoded weights — IQ4_NL with q8 = codebook value; Q4_1 / Q5_1 as
-    [d q | m 1] (2 K columns) against the activation image repeated twice.  Within the GEMM bar of the oracle's MUL_MAT for the SOURCE
+    """above 8 activation rows: ONE Q8_0 / Q6_K MFMA GEMM on the re-encoded weights — IQ4_NL with q8 = codebook value; Q4_1 / Q5_1 as
+    [d q | m 1], IQ4_XS as [h part | l part] (codebook value = 4 h + l) — 2 K columns against the activation image repeated twice.  Within the GEMM bar of the oracle's MUL_MAT for the SOURCE
     format, equal to the GEMV units' result to the same bar, deterministic, no stale scratch from a previous matrix."""
     from ggml_amd import ops
     w = R.random_weights(t, m, k, seed=5 * m + k)
@@ -277,13 +279,14 @@ def test_iq4_nl_reencoding_is_exact_and_public(gu):
     xd = gu.to_dev(_x(4, 64, k))
     assert np.array_equal(ops.mul_mat(a, xd).cpu().numpy(), ops.mul_mat(c, xd).cpu().numpy())
     L = native.lib()
-    assert L.ggml_cdna4_convert_weights_target(int(R.Q4_1)) == -1 and L.ggml_cdna4_convert_weights_target(int(R.Q5_1)) == -1
+    assert all(L.ggml_cdna4_convert_weights_target(int(x)) == -1 for x in (R.Q4_1, R.Q5_1, R.IQ4_XS, R.Q2_K))
 
 
-def test_iq4_nl_to_float_is_bit_exact(gu):
+@pytest.mark.parametrize("t", [R.IQ4_NL, R.IQ4_XS])
+def test_iq4_to_float_is_bit_exact(gu, t):
     from ggml_amd import native
     L = native.lib()
-    t, rows, k = R.IQ4_NL, 9, 2048
+    rows, k = 9, 2048
     w = R.random_weights(t, rows, k, seed=21)
     wd = gu.to_dev(w)
     y = torch.empty(rows * k, dtype=torch.float32, device="cuda")
@@ -312,11 +315,11 @@ def test_q4_1_q5_1_iq4_nl_mul_mat_id(gu, name, t, n_expert, n_used, n_b_is_one, 
 
 
 def test_stock_harness_mul_mat_with_the_new_formats():
-    """the UNMODIFIED reference harness: its q4_1 / q5_1 / iq4_nl MUL_MAT and MUL_MAT_ID cases now run on the plug-in (supports_op) and pass its NMSE gate"""
+    """the UNMODIFIED reference harness: its q4_1 / q5_1 / iq4_nl / iq4_xs MUL_MAT and MUL_MAT_ID cases now run on the plug-in (supports_op) and pass its NMSE gate"""
     import re
     import test_gpu_backend_plugin as P
     for op in ("MUL_MAT", "MUL_MAT_ID"):
         rc, txt = P._run(op)
         assert rc == 0 and "FAIL" not in txt, txt[-4000:]
-        for name in ("q4_1", "q5_1", "iq4_nl"):
+        for name in ("q4_1", "q5_1", "iq4_nl", "iq4_xs"):
             assert len(re.findall(r"type_a=%s,.*: OK$" % name, txt, re.M)) >= 1, "no %s case of %s ran on the plug-in\n%s" % (name, op, txt[-1500:])

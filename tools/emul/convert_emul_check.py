@@ -2,7 +2,7 @@
 that the oracle's dequantize_row of the RESULT equals its dequantize_row of the SOURCE bit for bit — every 5-bit / 3-bit code, both hmask
 polarities, all 64 six-bit scales, any fp16 d (the prefill GEMM of Q5_0 / Q3_K is the Q8_0 / Q6_K GEMM on the re-encoded weights).
 
-    python tools/emul/convert_emul_check.py [type M K]        type 6 = Q5_0, 11 = Q3_K, 10 = Q2_K, 20 = IQ4_NL, 3 / 7 = Q4_1 / Q5_1
+    python tools/emul/convert_emul_check.py [type M K]        type 6 = Q5_0, 11 = Q3_K, 10 = Q2_K, 20 = IQ4_NL, 3 / 7 = Q4_1 / Q5_1, 23 = IQ4_XS
 """
 import os
 import subprocess
@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import refutil as R  # noqa: E402
 
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-Q5_0, Q8_0, Q2_K, Q3_K, Q6_K, Q4_1, Q5_1, IQ4_NL = 6, 8, 10, 11, 14, 3, 7, 20
+Q5_0, Q8_0, Q2_K, Q3_K, Q6_K, Q4_1, Q5_1, IQ4_NL, IQ4_XS = 6, 8, 10, 11, 14, 3, 7, 20, 23
 
 
 def build():
@@ -33,7 +33,7 @@ def build():
 def source_bytes(t, m, k, seed):
     """fully random block bytes (every code, mask and scale pattern) with finite fp16 scales of both signs, one zero and one subnormal"""
     rng = np.random.default_rng(seed)
-    bs, blk, doffs = {Q5_0: (22, 32, [0]), Q3_K: (110, 256, [108]), Q2_K: (84, 256, [80, 82]), Q4_1: (20, 32, [0, 2]), Q5_1: (24, 32, [0, 2]), IQ4_NL: (18, 32, [0])}[t]
+    bs, blk, doffs = {Q5_0: (22, 32, [0]), Q3_K: (110, 256, [108]), Q2_K: (84, 256, [80, 82]), Q4_1: (20, 32, [0, 2]), Q5_1: (24, 32, [0, 2]), IQ4_NL: (18, 32, [0]), IQ4_XS: (136, 256, [0])}[t]
     nb = m * k // blk
     raw = rng.integers(0, 256, (nb, bs), dtype=np.uint8)
     for doff in doffs:
@@ -54,11 +54,11 @@ def run(t, m, k, seed=1):
         assert r.returncode == 0, r.stderr
         out = np.fromfile(f("o.bin"), np.uint8)
     a = R.o_dequantize(t, w, k)
-    if t in (Q2_K, Q4_1, Q5_1):   # [scale part | minimum part]: 2 K columns per row; dequantize(scale part) + dequantize(minimum part) = dequantize_row of the source
+    if t in (Q2_K, Q4_1, Q5_1, IQ4_XS):   # [scale part | minimum part]: 2 K columns per row; dequantize(scale part) + dequantize(minimum part) = dequantize_row of the source
         assert out.size == m * R.row_size(tgt, 2 * k), "size of the re-encoded matrix"
         both = R.o_dequantize(tgt, out, 2 * k)
         b = both[:, :k] + both[:, k:]
-        if t != Q2_K:             # the minimum part is the block's m itself, in every column
+        if t in (Q4_1, Q5_1):     # the minimum part is the block's m itself, in every column
             mm = np.repeat(w.reshape(m, k // 32, -1)[:, :, 2:4].copy().view(np.float16).astype(np.float32).reshape(m, k // 32), 32, axis=1)
             assert np.array_equal(both[:, k:].view(np.uint32), mm.view(np.uint32)), "minimum part"
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "dequantize(source) != dequantize(scale part) + dequantize(minimum part), bit for bit" 
@@ -66,7 +66,7 @@ def run(t, m, k, seed=1):
         assert out.size == m * R.row_size(tgt, k), "size of the re-encoded matrix"
         b = R.o_dequantize(tgt, out, k)
     assert a.shape == b.shape == (m, k)
-    if t == Q2_K:           # value for value: the sum of the two parts can carry the other sign on a ZERO (x - 0 keeps the sign of x, x + (-0) need not)
+    if t in (Q2_K, IQ4_XS): # value for value: the sum of the two parts can carry the other sign on a ZERO (x - 0 keeps the sign of x, x + (-0) need not)
         assert np.array_equal(a, b) and np.isfinite(b).all(), "dequantize(source) != dequantize(scale part) + dequantize(minimum part)"
     else:
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "dequantize(source) != dequantize(re-encoded)"

@@ -17,7 +17,7 @@ import refutil as R  # noqa: E402
 
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 # type id -> byte offsets of the fp16 fields of a block (everything else may be any bit pattern)
-F16_FIELDS = {R.Q4_0: [0], R.Q4_1: [0, 2], R.Q5_0: [0], R.Q5_1: [0, 2], R.Q8_0: [0], R.Q2_K: [80, 82], R.Q3_K: [108], R.Q4_K: [0, 2], R.Q5_K: [0, 2], R.Q6_K: [208], R.IQ4_NL: [0]}
+F16_FIELDS = {R.Q4_0: [0], R.Q4_1: [0, 2], R.Q5_0: [0], R.Q5_1: [0, 2], R.Q8_0: [0], R.Q2_K: [80, 82], R.Q3_K: [108], R.Q4_K: [0, 2], R.Q5_K: [0, 2], R.Q6_K: [208], R.IQ4_NL: [0], R.IQ4_XS: [0]}
 
 
 def build():
