@@ -112,6 +112,34 @@ def check_formats():
         report(test="to_float", type=name, ok=bool(np.array_equal(got.view(np.uint32), R.o_dequantize(t, w, k).view(np.uint32))))
 
 
+def check_formats2():
+    """the formats added after round 2's last hardware session: Q2_K prefill (two-part Q6_K), Q4_1 / Q5_1 (Q8_1 activations; two-part Q8_0 prefill),
+    IQ4_NL (Q8_0 re-encoding), IQ4_XS (two-part Q6_K): GEMV units at 1 / 5 rows, the prefill GEMM, to_float, MUL_MAT_ID decode"""
+    rng = np.random.default_rng(2)
+    for name, t in (("q2_K", R.Q2_K), ("q4_1", R.Q4_1), ("q5_1", R.Q5_1), ("iq4_nl", R.IQ4_NL), ("iq4_xs", R.IQ4_XS)):
+        for m, k, b in ((256, 4096, 1), (256, 4096, 5), (16, 256, 9), (130, 768, 33), (512, 2048, 128), (4096, 4096, 512)):
+            w = R.random_weights(t, m, k, seed=5 * m + k)
+            x = rng.uniform(-1, 1, (b, k)).astype(np.float32)
+            wd, xd = to_dev(w), to_dev(x)
+            y = mul_mat(t, wd, m, k, xd, b)
+            rows = np.arange(m) if m <= 512 else np.random.default_rng(0).choice(m, 64, replace=False)
+            rs = R.row_size(t, k)
+            wsub = np.concatenate([w[r * rs:(r + 1) * rs] for r in rows])
+            e = R.rel_l2(y[:, rows], R.o_mul_mat(t, wsub, x, len(rows), k))
+            y2 = mul_mat(t, wd, m, k, xd, b)
+            report(test="formats2_mul_mat", type=name, m=m, k=k, b=b, rel_l2=e, deterministic=bool(np.array_equal(y, y2)),
+                   ok=bool(np.isfinite(y).all() and e < (1e-5 if b <= 8 else 1e-3) and np.array_equal(y, y2)))
+            for p in (wd, xd):
+                hip.hipFree(p)
+        if t in (R.IQ4_NL, R.IQ4_XS):
+            rows, k = 9, 2048
+            w = R.random_weights(t, rows, k, seed=int(t) + 1)
+            wd, yd = to_dev(w), dmalloc(4 * rows * k)
+            ok(L.ggml_cdna4_dequantize_row(C.c_int(t), wd, yd, C.c_int64(rows * k), None), "dequantize_row")
+            got = to_host(yd, (rows, k), np.float32)
+            report(test="to_float", type=name, ok=bool(np.array_equal(got.view(np.uint32), R.o_dequantize(t, w, k).view(np.uint32))))
+
+
 def desc(p, type_, es, shape, strides=None):
     """shape / strides in numpy order (slowest first), strides in elements"""
     d = Tensor(); d.data = p.value; d.type = type_; d.reserved = 0
@@ -217,7 +245,7 @@ def time_fa(rng, D, n_q, n_head, n_kv):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["formats", "fattn"]
-    for w, fn in (("formats", check_formats), ("fattn", check_flash_attn), ("timings", timings), ("timings_fa", lambda: timings(False))):
+    for w, fn in (("formats", check_formats), ("formats2", check_formats2), ("fattn", check_flash_attn), ("timings", timings), ("timings_fa", lambda: timings(False))):
         if w in which:
             try:
                 fn()
