@@ -184,10 +184,10 @@ int ggml_cdna4_op_diag_mask_inf(const ggml_cdna4_tensor * src0, const ggml_cdna4
 /* element-wise activations; GELU reproduces the CPU's fp16 lookup-table semantics (ggml-cpu.c:1759-1774) */
 int ggml_cdna4_op_unary(int op, const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, void * stream);
 /* dst[.., i10, :] = to_float(src0 row ids[i10, i11, i12]) — ggml_compute_forward_get_rows, ggml-cpu.c:8353-8560;
- * src0 in {F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K} */
+ * src0 in {F32, F16} or any of the twelve block formats of enum ggml_cdna4_type */
 int ggml_cdna4_op_get_rows(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * ids, const ggml_cdna4_tensor * dst, void * stream);
 /* CPY / DUP / CONT: copy with conversion between tensors of equal element count — ggml_compute_forward_dup,
- * ggml-cpu.c:2860-4050.  Pairs: {F32,F16}->{F32,F16}; F32->{Q8_0,Q4_0}; {Q4_0,Q8_0,Q4_K,Q5_K,Q6_K}->F32.
+ * ggml-cpu.c:2860-4050.  Pairs: {F32,F16}->{F32,F16}; F32->{Q8_0,Q4_0}; any block format of enum ggml_cdna4_type -> F32.
  * q8_0_ref_rounding: 0 = the CPU backend's from_float (AVX2 body), 1 = quantize_row_q8_0_ref. */
 int ggml_cdna4_op_cpy(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, int q8_0_ref_rounding, void * stream);
 /* MUL_MAT with F32 or F16 weights and F32 activations, any strides / batch broadcast —
