@@ -61,12 +61,14 @@ bool cdna4_ops_supports_tensor(const ggml_tensor * op) {
             return false;
         }
         case GGML_OP_FLASH_ATTN_EXT: {
-            // q F32, k / v F16 with 16-byte aligned rows, mask F16 contiguous or absent, head sizes 64 / 128 / 256 (fattn.hip)
+            // q F32, k / v F16 with 16-byte aligned rows or block-quantized, mask F16 contiguous or absent, head sizes 64 / 128 / 256 (fattn.hip)
             const ggml_tensor * k = op->src[1], * v = op->src[2], * m = op->src[3];
-            if (!f32(a) || !f32(op) || !k || !v || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16) return false;
-            if (!ggml_cdna4_op_flash_attn_ext_supported(a->ne[0], (int)k->type) || k->ne[0] != a->ne[0] || v->ne[0] != a->ne[0]) return false;
-            if (a->nb[0] != sizeof(float) || k->nb[0] != 2 || v->nb[0] != 2 || !ggml_is_contiguous(op)) return false;
-            for (int i = 1; i < 4; i++) if (k->nb[i] % 16 || v->nb[i] % 16 || a->nb[i] % 4) return false;
+            // (a quantized k / v — Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0 — is copied out as fp16 first: any strides, contiguous rows)
+            if (!f32(a) || !f32(op) || !k || !v) return false;
+            if (!ggml_cdna4_op_flash_attn_ext_supported(a->ne[0], (int)k->type) || !ggml_cdna4_op_flash_attn_ext_supported(a->ne[0], (int)v->type)) return false;
+            if (k->ne[0] != a->ne[0] || v->ne[0] != a->ne[0]) return false;
+            if (a->nb[0] != sizeof(float) || k->nb[0] != ggml_type_size(k->type) || v->nb[0] != ggml_type_size(v->type) || !ggml_is_contiguous(op)) return false;
+            for (int i = 1; i < 4; i++) if ((k->type == GGML_TYPE_F16 && k->nb[i] % 16) || (v->type == GGML_TYPE_F16 && v->nb[i] % 16) || a->nb[i] % 4) return false;
             if (m && (m->type != GGML_TYPE_F16 || !ggml_is_contiguous(m))) return false;
             return a->ne[2] <= 65535 && a->ne[3] <= 65535;
         }

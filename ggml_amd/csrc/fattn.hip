@@ -316,12 +316,36 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_wide(cons
 typedef ggml_cdna4_tensor T4;
 
 extern "C" int ggml_cdna4_op_flash_attn_ext_supported(int64_t head_size, int kv_type) {
-    return (head_size == 64 || head_size == 128 || head_size == 256) && kv_type == CDNA4_F16;
+    return (head_size == 64 || head_size == 128 || head_size == 256) && (kv_type == CDNA4_F16 || cdna4_to_f16_dense_supported(kv_type));
 }
 
+static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T4 *d, float scale, float max_bias, float logit_softcap, void *stream);
+
+// A quantized K / V (Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0 — a quantized KV cache) is first written out as fp16 (to_float of every element rounded to
+// fp16, dense [batch][head][n_kv][head_size] in library scratch: one pass over the cache), then the F16 kernels run on the copy.  The CPU
+// instead quantizes q to the K type's vec_dot_type and takes integer dots (ggml-cpu.c:10921-10960); both are approximations of the same
+// product, ours keeps q in fp16 like ggml-cuda's kernels do — inside the stock harness's gate, and closer to a float64 evaluation.
 extern "C" int ggml_cdna4_op_flash_attn_ext(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T4 *d,
                                             float scale, float max_bias, float logit_softcap, void *stream) {
     NEED(q && k && v && d, "flash_attn_ext: q, k, v and dst are required");
+    if (k->type == CDNA4_F16 && v->type == CDNA4_F16) return fa_f16(q, k, v, mask, d, scale, max_bias, logit_softcap, stream);
+    T4 kv[2] = {*k, *v};
+    for (int i = 0; i < 2; i++) {
+        T4 &t = kv[i];
+        if (t.type == CDNA4_F16) continue;
+        NEED(cdna4_to_f16_dense_supported(t.type), "flash_attn_ext: k / v must be F16 or Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0");
+        NEED(t.ne[0] > 0 && t.ne[0] % 32 == 0 && t.ne[1] > 0 && t.ne[2] > 0 && t.ne[3] > 0, "flash_attn_ext: bad quantized k / v shape");
+        void *dense = cdna4_gemm_scratch((size_t)(t.ne[0] * t.ne[1] * t.ne[2] * t.ne[3]) * 2 + 256, 5 + i);
+        NEED(dense, "flash_attn_ext: cannot allocate the fp16 copy of a quantized k / v");
+        const int rc = cdna4_launch_to_f16_dense(&t, dense, (hipStream_t)stream);
+        if (rc) return rc;
+        t.data = dense; t.type = CDNA4_F16;
+        t.nb[0] = 2; t.nb[1] = 2 * t.ne[0]; t.nb[2] = t.nb[1] * t.ne[1]; t.nb[3] = t.nb[2] * t.ne[2];
+    }
+    return fa_f16(q, &kv[0], &kv[1], mask, d, scale, max_bias, logit_softcap, stream);
+}
+
+static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T4 *d, float scale, float max_bias, float logit_softcap, void *stream) {
     NEED(q->type == CDNA4_F32 && d->type == CDNA4_F32 && k->type == CDNA4_F16 && v->type == CDNA4_F16, "flash_attn_ext: F32 q / dst and F16 k / v only");
     const int64_t D = q->ne[0], N = q->ne[1], H = q->ne[2], B3 = q->ne[3], KV = k->ne[1];
     NEED(ggml_cdna4_op_flash_attn_ext_supported(D, k->type), "flash_attn_ext: head size must be 64, 128 or 256");

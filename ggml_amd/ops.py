@@ -8,7 +8,7 @@ current HIP stream; all arithmetic happens in libcdna4_kernels.so.  No CPU path 
 import torch
 
 from . import native
-from .gtypes import GGMLType, row_size, QUANT_WEIGHT_TYPES
+from .gtypes import GGMLType, row_size, type_size, QUANT_WEIGHT_TYPES
 
 PATH_AUTO, PATH_GEMV, PATH_GEMM = 0, 1, 2
 
@@ -203,9 +203,22 @@ def _tensor_desc(t: torch.Tensor, type_):
     return d
 
 
-def flash_attn_ext(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask=None, scale=1.0, max_bias=0.0, logit_softcap=0.0):
+def _qrows_desc(t: torch.Tensor, type_, D):
+    """ggml_cdna4_tensor of block-quantized rows held as uint8 (batch, n_head_kv, n_kv, row_size(type, D)): ne = (D, n_kv, n_head_kv, batch)"""
+    if t.dtype != torch.uint8 or t.dim() != 4 or t.stride(3) != 1 or t.shape[3] != row_size(type_, D):
+        raise ValueError("quantized k / v: uint8 (batch, n_head_kv, n_kv, %d) with contiguous rows" % row_size(type_, D))
+    d = native.Tensor()
+    d.data = t.data_ptr(); d.type = int(type_); d.reserved = 0
+    d.ne[0] = int(D); d.nb[0] = type_size(type_)
+    for i in range(1, 4):
+        d.ne[i] = int(t.shape[3 - i]); d.nb[i] = int(t.stride(3 - i))
+    return d
+
+
+def flash_attn_ext(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask=None, scale=1.0, max_bias=0.0, logit_softcap=0.0, kv_type=None):
     """ggml_flash_attn_ext (include/ggml.h:1758-1767; CPU: ggml-cpu.c:10805-11016).  q f32 (batch, n_head, n_q, D) — any strides with
     contiguous rows, e.g. a permuted view; k, v fp16 (batch_kv, n_head_kv, n_kv, D); mask fp16 (>= n_q, n_kv) or None.
+    kv_type (Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0): k, v are block-quantized rows as uint8 (batch_kv, n_head_kv, n_kv, row_size(kv_type, D)).
     Returns f32 (batch, n_q, n_head, D) like ggml's result (ne = D, n_head, n_q, batch)."""
     import ctypes as C
     L = native.lib()
@@ -213,8 +226,8 @@ def flash_attn_ext(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask=None,
         _need_gpu(t, name)
         if t.dim() != 4 or t.stride(3) != 1:
             raise ValueError("%s must be 4-D with contiguous rows" % name)
-    if q.dtype != torch.float32 or k.dtype != torch.float16 or v.dtype != torch.float16:
-        raise ValueError("q must be float32, k and v float16")
+    if q.dtype != torch.float32 or (kv_type is None and (k.dtype != torch.float16 or v.dtype != torch.float16)):
+        raise ValueError("q must be float32, k and v float16 (or uint8 block rows with kv_type)")
     dev = q.device
     _same_device(dev, k=k, v=v, mask=mask)
     if mask is not None and (mask.dtype != torch.float16 or mask.dim() != 2 or not mask.is_contiguous()):
@@ -222,7 +235,8 @@ def flash_attn_ext(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask=None,
     B3, H, N, D = q.shape
     out = torch.empty((B3, N, H, D), dtype=torch.float32, device=dev)
     dm = _tensor_desc(mask.view(1, 1, *mask.shape), GGMLType.F16) if mask is not None else None
-    dq, dk, dv, dd = _tensor_desc(q, GGMLType.F32), _tensor_desc(k, GGMLType.F16), _tensor_desc(v, GGMLType.F16), _tensor_desc(out, GGMLType.F32)
+    dq, dd = _tensor_desc(q, GGMLType.F32), _tensor_desc(out, GGMLType.F32)
+    dk, dv = (_tensor_desc(k, GGMLType.F16), _tensor_desc(v, GGMLType.F16)) if kv_type is None else (_qrows_desc(k, kv_type, D), _qrows_desc(v, kv_type, D))
     with torch.cuda.device(dev):
         native.check(L.ggml_cdna4_op_flash_attn_ext(C.byref(dq), C.byref(dk), C.byref(dv), C.byref(dm) if dm is not None else None, C.byref(dd),
                                                     float(scale), float(max_bias), float(logit_softcap), _stream(dev)))

@@ -202,7 +202,8 @@ int ggml_cdna4_op_rope(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor *
  * q F32 [head_size, n_q, n_head, batch] (any row strides), k / v F16 [head_size, n_kv, n_head_kv, batch_kv] (rows 16-byte aligned; heads and
  * batches broadcast as q's over k's), mask F16 [n_kv, >= n_q] or NULL, dst F32 contiguous [head_size, n_head, n_q, batch].
  * scale / max_bias (ALiBi) / logit_softcap as in op_params 0..2.  fp16 operands on the matrix cores, fp32 softmax statistics and
- * accumulation.  _supported: head sizes 64 / 128 / 256 with F16 k / v. */
+ * accumulation.  k / v may also be block-quantized (Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0: a quantized KV cache; rows contiguous, any strides): they are
+ * written out as fp16 into library scratch first (one pass), then the same kernels run.  _supported: head sizes 64 / 128 / 256 with such k / v. */
 int ggml_cdna4_op_flash_attn_ext_supported(int64_t head_size, int kv_type);
 int ggml_cdna4_op_flash_attn_ext(const ggml_cdna4_tensor * q, const ggml_cdna4_tensor * k, const ggml_cdna4_tensor * v, const ggml_cdna4_tensor * mask,
                                  const ggml_cdna4_tensor * dst, float scale, float max_bias, float logit_softcap, void * stream);

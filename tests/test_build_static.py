@@ -341,6 +341,13 @@ def test_weight_reencoding_sources_on_the_cpu_are_exact(t, m, k):
     assert _emul_module("convert_emul_check").run(t, m, k, seed=t + k)
 
 
+@pytest.mark.parametrize("t", [2, 3, 6, 7, 8])
+def test_fp16_copy_of_a_quantized_kv_source_on_the_cpu_bit_exact(t):
+    """tools/emul/deq_emul f16: k_q_to_f16_dense (the pass in front of FLASH_ATTN_EXT when K / V arrive quantized) on strided rows equals
+    fp16(oracle to_float) bit for bit, densely packed"""
+    assert _emul_module("deq_emul_check").run_f16(t, 128, seed=t) and _emul_module("deq_emul_check").run_f16(t, 64, nrows=4, gap=0, seed=t + 1)
+
+
 @pytest.mark.parametrize("t", [2, 3, 6, 7, 8, 10, 11, 12, 13, 14, 20, 23])
 def test_to_float_sources_on_the_cpu_bit_exact(t):
     """tools/emul/deq_emul: deq_elem of ops.hip (dequantize_row, GET_ROWS, CPY -> F32) executed on the CPU equals the oracle's dequantize_row_*

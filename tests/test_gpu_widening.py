@@ -193,8 +193,8 @@ def test_flash_attn_ext_is_deterministic_and_row_independent(gu):
 
 
 def test_stock_harness_flash_attn_ext():
-    """the UNMODIFIED reference harness on FLASH_ATTN_EXT: F16 K / V cases with head sizes 64 / 128 / 256 run on the plug-in and pass its NMSE gate,
-    the rest (head size 80, BF16 / quantized K / V) is declined by supports_op"""
+    """the UNMODIFIED reference harness on FLASH_ATTN_EXT: F16 (and, since the conversion pass, Q8_0 / Q4_0) K / V cases with head sizes
+    64 / 128 / 256 run on the plug-in and pass its NMSE gate, the rest (head sizes 80 / 96 / 112, BF16 K / V) is declined by supports_op"""
     import test_gpu_backend_plugin as P
     rc, txt = P._run("FLASH_ATTN_EXT")
     import re
@@ -323,3 +323,30 @@ def test_stock_harness_mul_mat_with_the_new_formats():
         assert rc == 0 and "FAIL" not in txt, txt[-4000:]
         for name in ("q4_1", "q5_1", "iq4_nl", "iq4_xs"):
             assert len(re.findall(r"type_a=%s,.*: OK$" % name, txt, re.M)) >= 1, "no %s case of %s ran on the plug-in\n%s" % (name, op, txt[-1500:])
+
+
+# ------------------------------------------------------------------------------------------------ FLASH_ATTN_EXT on a quantized K / V
+# (also written after the last hardware session: a conversion pass — emulator-verified, tools/emul/deq_emul f16 — in front of the hardware-verified
+# F16 kernels, whose ISA is unchanged)
+@pytest.mark.parametrize("name,t", [("q8_0", R.Q8_0), ("q4_0", R.Q4_0), ("q4_1", R.Q4_1), ("q5_0", R.Q5_0), ("q5_1", R.Q5_1)])
+@pytest.mark.parametrize("D,n_q,n_head,n_kv,n_head_kv", [(128, 1, 8, 1024, 2), (64, 35, 4, 300, 4), (256, 3, 4, 512, 1), (128, 200, 8, 512, 8)])
+def test_flash_attn_ext_quantized_kv(gu, name, t, D, n_q, n_head, n_kv, n_head_kv):
+    """K / V as block-quantized rows (a quantized KV cache): written out as fp16 once, then the F16 kernels.  Against a float64 evaluation of the
+    operator on the DEQUANTIZED K / V (<= 1e-3, the bar of the F16 cases: fp16(to_float) is the same rounding an F16 cache has), and equal bit for
+    bit to the F16 path on a cache holding fp16(to_float(K)), fp16(to_float(V))"""
+    from ggml_amd import ops
+    rng = np.random.default_rng(D + n_q + n_kv + int(t))
+    q = rng.uniform(-1, 1, (1, n_head, n_q, D)).astype(np.float32)
+    rows = n_head_kv * n_kv
+    kb, vb = R.random_weights(t, rows, D, seed=int(t) + D), R.random_weights(t, rows, D, seed=int(t) + D + 1)
+    kf = R.o_dequantize(t, kb, D).reshape(1, n_head_kv, n_kv, D); vf = R.o_dequantize(t, vb, D).reshape(1, n_head_kv, n_kv, D)
+    m = rng.uniform(-1, 1, ((n_q + 63) // 64 * 64, n_kv)).astype(np.float16)
+    scale = float(1.0 / np.sqrt(D))
+    rb = R.row_size(t, D)
+    kd, vd = gu.to_dev(kb.reshape(1, n_head_kv, n_kv, rb)), gu.to_dev(vb.reshape(1, n_head_kv, n_kv, rb))
+    y = ops.flash_attn_ext(gu.to_dev(q), kd, vd, gu.to_dev(m), scale, kv_type=t).cpu().numpy()
+    assert np.isfinite(y).all()
+    e = R.rel_l2(y, R.exact_flash_attn_ext(q, kf, vf, m, scale)); gu.report(test="flash_attn_ext_quantized_kv", type=name, D=D, n_q=n_q, n_kv=n_kv, rel_l2_float64=e)
+    assert e < TOL_FA_EXACT
+    y16 = ops.flash_attn_ext(gu.to_dev(q), gu.to_dev(kf.astype(np.float16)), gu.to_dev(vf.astype(np.float16)), gu.to_dev(m), scale).cpu().numpy()
+    assert np.array_equal(y, y16)

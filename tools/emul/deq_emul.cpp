@@ -24,7 +24,24 @@ static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
 
 #include "../../ggml_amd/csrc/ops.hip"
 
+// deq_emul f16 type K nrows gap rows.bin out.bin : k_q_to_f16_dense (the fp16 copy of a quantized K / V in front of FLASH_ATTN_EXT) on nrows rows of K
+// weights that lie `gap` bytes further apart than their size, as ne = (K, nrows / 2, 2, 1) -> nrows * K halves, dense
+static int main_f16(int argc, char **argv) {
+    const int type = atoi(argv[2]); const int64_t K = atoll(argv[3]), nrows = atoll(argv[4]), gap = atoll(argv[5]);
+    FILE *f = fopen(argv[6], "rb"); if (!f) { perror(argv[6]); return 2; }
+    fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> w((size_t)n); if (fread(w.data(), 1, w.size(), f) != w.size()) return 2; fclose(f);
+    const int64_t rb = (int64_t)(K / bsize(type)) * (int64_t)tsize(type);
+    if ((int64_t)w.size() != nrows * (rb + gap) || nrows % 2) { fprintf(stderr, "bad input size\n"); return 2; }
+    T4 a{}; a.data = w.data(); a.type = type; a.ne[0] = K; a.ne[1] = nrows / 2; a.ne[2] = 2; a.ne[3] = 1;
+    a.nb[0] = (int64_t)tsize(type); a.nb[1] = rb + gap; a.nb[2] = a.nb[1] * a.ne[1]; a.nb[3] = a.nb[2] * 2;
+    std::vector<uint16_t> y((size_t)(nrows * K), 0xAAAA);
+    if (cdna4_launch_to_f16_dense(&a, y.data(), nullptr)) return 1;
+    f = fopen(argv[7], "wb"); fwrite(y.data(), 2, y.size(), f); fclose(f);
+    return 0;
+}
 int main(int argc, char **argv) {
+    if (argc >= 8 && !strcmp(argv[1], "f16")) return main_f16(argc, argv);
     if (argc < 5) { fprintf(stderr, "usage: deq_emul type K rows.bin out.bin\n"); return 2; }
     const int type = atoi(argv[1]); const int64_t K = atoll(argv[2]);
     FILE *f = fopen(argv[3], "rb"); if (!f) { perror(argv[3]); return 2; }

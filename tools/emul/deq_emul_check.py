@@ -50,6 +50,28 @@ def run(t, k, seed=1):
     return True
 
 
+def run_f16(t, k, nrows=6, gap=10, seed=1):
+    """k_q_to_f16_dense: rows with a gap between them (a strided quantized K / V) -> dense fp16(to_float), bit for bit"""
+    rng = np.random.default_rng(seed)
+    nb = k // R.BLCK[t]
+    raw = rng.integers(0, 256, (nrows, nb, R.TYPE_SIZE[t]), dtype=np.uint8)
+    for o in F16_FIELDS[t]:
+        d = rng.uniform(-0.3, 0.3, (nrows, nb)).astype(np.float16)
+        d[0, 0] = 0.0
+        raw[:, :, o:o + 2] = d.view(np.uint8).reshape(nrows, nb, 2)
+    rows = raw.reshape(nrows, -1)
+    padded = np.concatenate([rows, np.full((nrows, gap), 0x5A, np.uint8)], axis=1)
+    with tempfile.TemporaryDirectory() as d:
+        f = lambda n: os.path.join(d, n)
+        padded.tofile(f("w.bin"))
+        r = subprocess.run([build(), "f16", str(int(t)), str(k), str(nrows), str(gap), f("w.bin"), f("y.bin")], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        y = np.fromfile(f("y.bin"), np.float16).reshape(nrows, k)
+    want = R.o_dequantize(t, rows.reshape(-1), k).astype(np.float16)
+    assert np.array_equal(y.view(np.uint16), want.view(np.uint16)), "fp16 copy differs from fp16(oracle to_float)"
+    return True
+
+
 if __name__ == "__main__":
     t, k = (int(a) for a in sys.argv[1:3]) if len(sys.argv) > 2 else (R.Q3_K, 2048)
     print("to_float source on the CPU, type %d, K=%d: bit-exact =" % (t, k), run(t, k))
