@@ -377,3 +377,28 @@ def test_flash_attn_source_on_the_cpu(kw):
     if r is None:
         pytest.skip("the environment cannot host the emulation")
     assert r[0] < 5e-4 and r[1] < 6e-3, r
+
+
+def test_hardware_verified_kernels_are_unchanged():
+    """tools/isa_manifest.py: the ISA of every kernel that was part of a build with a green hardware session (profiles/rNN/isa_manifest.json,
+    `hw`: true) is what hipcc emits for it today — so what was added since (listed there as `hw`: false, or new) cannot have changed the
+    kernels the MI355X numbers and parity results belong to.  Comparable only under the compiler that wrote the record."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    import glob
+    import importlib.util
+    mans = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "isa_manifest.json")))
+    assert mans, "no profiles/rNN/isa_manifest.json"
+    spec = importlib.util.spec_from_file_location("isa_manifest", os.path.join(ROOT, "tools", "isa_manifest.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ok, changed_hw, changed, new, gone = mod.check(mans[-1])
+    if not ok:
+        pytest.skip("the manifest was written under another compiler version")
+    assert not changed_hw, "hardware-verified kernels whose ISA changed: %s" % changed_hw[:8]
+    assert not [g for g in gone if json_hw(mans[-1], g)], "hardware-verified kernels that no longer exist: %s" % gone[:8]
+
+
+def json_hw(path, fk):
+    import json
+    return json.load(open(path))["kernels"][fk[0]][fk[1]]["hw"]

@@ -1,0 +1,92 @@
+"""Per-kernel fingerprints of the gfx950 ISA hipcc emits for the kernel sources, so that "this change did not touch a hardware-verified
+kernel" is a checkable statement in sessions without a GPU.
+
+    python tools/isa_manifest.py --write profiles/rNN/isa_manifest.json     # after a hardware session: record what was verified
+    python tools/isa_manifest.py --check profiles/rNN/isa_manifest.json     # later: which recorded kernels changed, which are new
+
+A fingerprint is the sha256 of a kernel's assembly body (comments, label numbers and spacing removed), compiled with the flags of
+ggml_amd/build.py.  `hw` says whether the kernel had run on an MI355X (parity-green) when the manifest was written; tests/test_build_static.py
+asserts that no `hw` kernel differs from its record.  The record is only comparable under the same compiler (its version is stored)."""
+import hashlib
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ggml_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+FILES = ["quantize_act.hip", "gemv_q.hip", "gemm_q_mfma.hip", "gemm_q_t64.hip", "convert_w.hip", "ops.hip", "fattn.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm", "-S", "--cuda-device-only"]
+# kernels written after round 2's last hardware session (emulator-verified only): everything else in the round-2 manifest is hw = true
+NOT_ON_HARDWARE_YET = [r"k_convert_q2_K_q6_K2", r"k_convert_q41_q8_0x2", r"k_convert_iq4_", r"k_quantize_q8_1", r"k_q_to_f16_dense",
+                       r"k_gemv_q(_fused)?ILi(3|7|20|23)E", r"k_(get_rows|cpy_q_to_f32)ILi(20|23)E"]
+
+
+def compiler_version():
+    return subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.strip().splitlines()[0:2]
+
+
+def fingerprints(files=FILES, jobs=4):
+    def one(f):
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "k.s")
+            subprocess.run([HIPCC] + FLAGS + ["-o", out, os.path.join(CSRC, f)], check=True, capture_output=True, timeout=1500)
+            txt = open(out).read()
+        res = {}
+        for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", txt, re.S | re.M):
+            body = re.sub(r";.*", "", m.group(2))
+            body = re.sub(r"\.LBB\d+_\d+", "L", body)
+            body = re.sub(r"\.Ltmp\d+", "T", body)
+            body = re.sub(r"[ \t]+", " ", body)
+            res[m.group(1)] = hashlib.sha256(body.encode()).hexdigest()[:24]
+        return f, res
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        return dict(ex.map(one, files))
+
+
+def write(path):
+    fp = fingerprints()
+    man = {"compiler": compiler_version(), "flags": FLAGS, "kernels": {}}
+    for f, ks in fp.items():
+        man["kernels"][f] = {k: {"sha": v, "hw": not any(re.search(p, k) for p in NOT_ON_HARDWARE_YET)} for k, v in sorted(ks.items())}
+    json.dump(man, open(path, "w"), indent=0, sort_keys=True)
+    n = sum(len(v) for v in man["kernels"].values()); nhw = sum(e["hw"] for v in man["kernels"].values() for e in v.values())
+    print("wrote %s: %d kernels, %d marked hardware-verified" % (path, n, nhw))
+
+
+def check(path, files=None):
+    """-> (comparable, changed hw kernels, changed other kernels, new kernels, gone kernels)"""
+    man = json.load(open(path))
+    if man["compiler"] != compiler_version():
+        return False, [], [], [], []
+    fp = fingerprints(files or [f for f in FILES if f in man["kernels"]])
+    changed_hw, changed, new, gone = [], [], [], []
+    for f, ks in fp.items():
+        rec = man["kernels"].get(f, {})
+        for k, sha in ks.items():
+            if k not in rec:
+                new.append((f, k))
+            elif rec[k]["sha"] != sha:
+                (changed_hw if rec[k]["hw"] else changed).append((f, k))
+        gone += [(f, k) for k in rec if k not in ks]
+    return True, changed_hw, changed, new, gone
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--write":
+        write(sys.argv[2])
+    elif len(sys.argv) == 3 and sys.argv[1] == "--check":
+        ok, chw, ch, new, gone = check(sys.argv[2])
+        if not ok:
+            print("not comparable: the manifest was written under another compiler"); sys.exit(2)
+        print("hardware-verified kernels changed: %d; other recorded kernels changed: %d; new: %d; gone: %d" % (len(chw), len(ch), len(new), len(gone)))
+        for f, k in chw:
+            print("  CHANGED (hw):", f, k)
+        sys.exit(1 if chw else 0)
+    else:
+        print(__doc__)
