@@ -379,6 +379,18 @@ def test_flash_attn_source_on_the_cpu(kw):
     assert r[0] < 5e-4 and r[1] < 6e-3, r
 
 
+@pytest.mark.parametrize("t,kw", [(8, dict(D=64, n_q=5, n_head=2, n_kv=96)), (2, dict(D=128, n_q=3, n_head=4, n_kv=70, n_head_kv=2, permuted=True)),
+                                  (3, dict(D=256, n_q=40, n_head=2, n_kv=200, cus=1)), (6, dict(D=128, n_q=1, n_head=4, n_kv=1024, n_head_kv=1)), (7, dict(D=64, n_q=33, n_head=2, n_kv=130))])
+def test_flash_attn_on_a_quantized_kv_end_to_end_on_the_cpu(t, kw):
+    """tools/emul/fattn_emul with a block-quantized K / V: ggml_cdna4_op_flash_attn_ext's own host code (scratch, descriptors), the conversion pass
+    k_q_to_f16_dense and the F16 kernels, all from source on the CPU — <= 5e-4 from a float64 evaluation on the dequantized K / V and bit-identical
+    to the F16 path on a cache that holds fp16(to_float(K)), fp16(to_float(V)); strided (permuted) rows, grouped-query heads, both kernels"""
+    r = _emul_module("fattn_emul_check").run_quantized(t, seed=t, **kw)
+    if r is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert r[0] < 5e-4 and r[1] is True, r
+
+
 def test_hardware_verified_kernels_are_unchanged():
     """tools/isa_manifest.py: the ISA of every kernel that was part of a build with a green hardware session (profiles/rNN/isa_manifest.json,
     `hw`: true) is what hipcc emits for it today — so what was added since (listed there as `hw`: false, or new) cannot have changed the

@@ -1,6 +1,7 @@
 // fattn_emul.cpp — runs the SOURCE of the FLASH_ATTN_EXT kernels (ggml_amd/csrc/fattn.hip: k_flash_attn_split / _merge / _wide <64 / 128 / 256>) on the CPU, one OS
 // thread per GPU thread, the 32x32x16 fp16 MFMA emulated lane for lane (hip_emul.h).  Test infrastructure.
-//   fattn_emul D n_q n_head n_batch n_kv n_head_kv n_batch_kv has_mask mask_rows scale max_bias softcap permuted q.bin k.bin v.bin mask.bin out.bin
+//   fattn_emul D n_q n_head n_batch n_kv n_head_kv n_batch_kv has_mask mask_rows scale max_bias softcap permuted q.bin k.bin v.bin mask.bin out.bin [kv_type]
+// kv_type (default 1 = F16): a ggml block type (2, 3, 6, 7, 8) makes k.bin / v.bin block-quantized rows (the conversion pass in front of the kernels runs too)
 // q f32 [n_batch][n_head][n_q][D] (permuted = 1: stored [n_batch][n_q][n_head][D] and described through strides, like the stock test's
 // ggml_permute(0, 2, 1, 3) case; likewise k / v), k / v fp16, mask fp16 [mask_rows][n_kv]; out f32 [n_batch][n_q][n_head][D]
 #include "hip_emul.h"
@@ -62,9 +63,15 @@ template <typename F> static void emu_launch(F body, dim3 grid, dim3 block) {
 }
 
 // the library's per-device scratch (gemm_q_mfma.hip) and CU count, as far as fattn.hip needs them; EMU_CUS sets the CU count the key split is sized for
-void *cdna4_gemm_scratch(size_t bytes, int) { static void *p = nullptr; static size_t n = 0; if (bytes > n) { p = shared_alloc(bytes); n = bytes; } return p; }
+void *cdna4_gemm_scratch(size_t bytes, int kind) { static void *p[8] = {}; static size_t n[8] = {}; if (bytes > n[kind & 7]) { p[kind & 7] = shared_alloc(bytes); n[kind & 7] = bytes; } return p[kind & 7]; }    // one area per kind, like the library
 int cdna4_gemm_cu_count() { const char *e = getenv("EMU_CUS"); return e ? atoi(e) : 256; }
 
+// a quantized K / V goes through ops.hip's k_q_to_f16_dense first (the same TU here: ops.hip needs these two runtime calls)
+#define hipMemcpyDeviceToDevice 0
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+#include "../../ggml_amd/csrc/ops.hip"
+#undef NEED
 #include "../../ggml_amd/csrc/fattn.hip"
 
 static void slurp(const char *p, void *dst, size_t n) {
@@ -75,7 +82,9 @@ int main(int argc, char **argv) {
     const int64_t D = atoll(argv[1]), NQ = atoll(argv[2]), H = atoll(argv[3]), B3 = atoll(argv[4]), KV = atoll(argv[5]), HK = atoll(argv[6]), BK = atoll(argv[7]);
     const int has_mask = atoi(argv[8]); const int64_t MR = atoll(argv[9]);
     const float scale = (float)atof(argv[10]), max_bias = (float)atof(argv[11]), softcap = (float)atof(argv[12]); const int permuted = atoi(argv[13]);
-    const size_t nq = (size_t)(B3 * H * NQ * D) * 4, nk = (size_t)(BK * HK * KV * D) * 2, nm = (size_t)(MR * KV) * 2, no = (size_t)(B3 * NQ * H * D) * 4;
+    const int kvt = argc > 19 ? atoi(argv[19]) : CDNA4_F16;
+    const int64_t kes = kvt == CDNA4_F16 ? 2 : (int64_t)tsize(kvt), kn0 = kvt == CDNA4_F16 ? D : D / bsize(kvt);      // element size / elements per row in the stride arithmetic below
+    const size_t nq = (size_t)(B3 * H * NQ * D) * 4, nk = (size_t)(BK * HK * KV * kn0) * kes, nm = (size_t)(MR * KV) * 2, no = (size_t)(B3 * NQ * H * D) * 4;
     void *q = shared_alloc(nq), *k = shared_alloc(nk), *v = shared_alloc(nk), *m = has_mask ? shared_alloc(nm) : nullptr, *o = shared_alloc(no);
     slurp(argv[14], q, nq); slurp(argv[15], k, nk); slurp(argv[16], v, nk); if (has_mask) slurp(argv[17], m, nm);
     memset(o, 0xFF, no);
@@ -85,7 +94,8 @@ int main(int argc, char **argv) {
         t.nb[0] = es; t.nb[3] = es * n0 * n1 * n2;
         if (!perm) { t.nb[1] = es * n0; t.nb[2] = es * n0 * n1; } else { t.nb[2] = es * n0; t.nb[1] = es * n0 * n2; }      // memory order [n3][n1][n2][n0]
     };
-    fill(tq, q, CDNA4_F32, 4, D, NQ, H, B3, permuted); fill(tk, k, CDNA4_F16, 2, D, KV, HK, BK, permuted); fill(tv, v, CDNA4_F16, 2, D, KV, HK, BK, permuted);
+    fill(tq, q, CDNA4_F32, 4, D, NQ, H, B3, permuted); fill(tk, k, kvt, kes, kn0, KV, HK, BK, permuted); fill(tv, v, kvt, kes, kn0, KV, HK, BK, permuted);
+    tk.ne[0] = tv.ne[0] = D;                                            // (fill() computed the strides from blocks per row)
     if (has_mask) fill(tm, m, CDNA4_F16, 2, KV, MR, 1, 1, false);
     fill(td, o, CDNA4_F32, 4, D, H, NQ, B3, false);
     if (ggml_cdna4_op_flash_attn_ext(&tq, &tk, &tv, has_mask ? &tm : nullptr, &td, scale, max_bias, softcap, nullptr)) return 1;

@@ -21,7 +21,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 def build():
     exe = os.path.join(HERE, "fattn_emul")
     csrc = os.path.join(ROOT, "ggml_amd", "csrc")
-    srcs = [os.path.join(HERE, "fattn_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(csrc, f) for f in ("fattn.hip", "cdna4_common.h", "cdna4_kernels.h")]
+    srcs = [os.path.join(HERE, "fattn_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(csrc, f) for f in ("fattn.hip", "ops.hip", "cdna4_common.h", "cdna4_kernels.h", "epilogue.h")]
     if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
         subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-ffp-contract=off", "-I" + os.path.join(HERE, "shim"), "-I" + csrc, "-I" + os.path.join(ROOT, "include"),
                         "-Wno-unused-value", "-o", exe, srcs[0]], check=True, capture_output=True, timeout=600)
@@ -58,6 +58,34 @@ def run(D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max_bias=0.0
     ye = R.exact_flash_attn_ext(q, k, v, m, scale, max_bias, softcap)
     yo = R.o_flash_attn_ext(q, k, v, m, scale, max_bias, softcap)
     return R.rel_l2(y, ye), R.rel_l2(y, yo)
+
+
+def run_quantized(t, D, n_q, n_head, n_kv, n_head_kv=None, permuted=False, seed=1, timeout=1200, cus=256):
+    """K / V as block-quantized rows of ggml type t (the conversion pass k_q_to_f16_dense + the F16 kernels through ggml_cdna4_op_flash_attn_ext):
+    returns (rel-L2 vs the float64 operator on the dequantized K / V, bit-identity with the F16 path on fp16(to_float(K)), fp16(to_float(V)))"""
+    n_head_kv = n_head_kv or n_head
+    rng = np.random.default_rng(seed)
+    q = rng.uniform(-1, 1, (1, n_head, n_q, D)).astype(np.float32)
+    rows, rb = n_head_kv * n_kv, R.row_size(t, D)
+    kb, vb = R.random_weights(t, rows, D, seed=seed + 1), R.random_weights(t, rows, D, seed=seed + 2)
+    kf, vf = R.o_dequantize(t, kb, D).reshape(1, n_head_kv, n_kv, D), R.o_dequantize(t, vb, D).reshape(1, n_head_kv, n_kv, D)
+    mrows = (n_q + 63) // 64 * 64
+    m = rng.uniform(-1, 1, (mrows, n_kv)).astype(np.float16)
+    scale = 1.0 / np.sqrt(D)
+    lay = (lambda a: np.ascontiguousarray(a.transpose(0, 2, 1, 3))) if permuted else (lambda a: a)
+    outs = []
+    for kv_type, kk, vv in ((int(t), kb.reshape(1, n_head_kv, n_kv, rb), vb.reshape(1, n_head_kv, n_kv, rb)), (1, kf.astype(np.float16), vf.astype(np.float16))):
+        with tempfile.TemporaryDirectory() as d:
+            f = lambda n: os.path.join(d, n)
+            lay(q).tofile(f("q")); lay(kk).tofile(f("k")); lay(vv).tofile(f("v")); m.tofile(f("m"))
+            r = subprocess.run([build()] + [str(x) for x in (D, n_q, n_head, 1, n_kv, n_head_kv, 1, 1, mrows, repr(float(scale)), 0.0, 0.0, int(permuted))] +
+                               [f("q"), f("k"), f("v"), f("m"), f("o"), str(kv_type)], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, EMU_CUS=str(cus)))
+            if r.returncode == 77:
+                return None
+            assert r.returncode == 0, r.stderr
+            outs.append(np.fromfile(f("o"), np.float32).reshape(1, n_q, n_head, D))
+    assert np.isfinite(outs[0]).all()
+    return R.rel_l2(outs[0], R.exact_flash_attn_ext(q, kf, vf, m, scale)), bool(np.array_equal(outs[0], outs[1]))
 
 
 if __name__ == "__main__":
