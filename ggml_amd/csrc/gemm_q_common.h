@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#include "gemm_q_hw.h"            // the GPU-only statements as macros (tools/emul supplies host versions)
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 __device__ __forceinline__ void glds16(const void *g, void *l_wave_base) {
@@ -460,7 +462,7 @@ struct gemm_params {
     const int32_t *tile_expert; const int32_t *row_dst; int64_t w_expert_bytes;
 };
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { CDNA4_WAIT_VM(N); }
 
 template <int TYPE, int SKG> struct WStage {        // which 16-B pieces of a superblock a stage needs
     static constexpr int NP = QT<TYPE>::BYTES / 16;

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_gemm_q(const gemm_params p) {
         const int sb0 = kstep0 >> 2, nsb = ksteps >> 2;
         stage_x(0, 0);
         stage_w(sb0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CDNA4_WAIT_VM(0);
         __syncthreads();
         for (int s = 0; s < nsb; s++) {
 #pragma unroll
@@ -162,20 +162,20 @@ __global__ __launch_bounds__(256) void k_gemm_q(const gemm_params p) {
                 if (WLDS) raw.load(Ws + (s & 1) * WS + (wave * 32 + j) * BLK, g, h);
                 else raw.load(wrow + (int64_t)(sb0 + s) * BLK, g, h);
                 compute(raw, g, step & 1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                CDNA4_WAIT_VM(0);
                 __syncthreads();
             }
         }
     } else {
         stage_x(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CDNA4_WAIT_VM(0);
         __syncthreads();
         for (int step = 0; step < ksteps; step++) {
             if (step + 1 < ksteps) stage_x(step + 1, (step + 1) & 1);
             Raw<TYPE> raw;
             raw.load(wrow + (int64_t)(2 * (kstep0 + step) + h) * BLK, 0, h);
             compute(raw, 0, step & 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CDNA4_WAIT_VM(0);
             __syncthreads();
         }
     }

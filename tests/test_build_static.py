@@ -414,3 +414,46 @@ def test_hardware_verified_kernels_are_unchanged():
 def json_hw(path, fk):
     import json
     return json.load(open(path))["kernels"][fk[0]][fk[1]]["hw"]
+
+
+# ---- the WHOLE library on the CPU (tools/emul/lib_emul.h): ggml_cdna4_mul_mat / _mul_mat_id through the C-ABI of a host build of the product's own sources.
+# Shapes keep the activation quantizers' lanes in whole waves (the emulator's wave-collective shuffles): B * K a multiple of 1024 for the K-quants' GEMM
+# route, K a multiple of 1024 where the quantizer runs inside the GEMV launch.
+LIB_TYPES = [("q4_0", 2), ("q4_1", 3), ("q5_0", 6), ("q5_1", 7), ("q8_0", 8), ("q2_K", 10), ("q3_K", 11), ("q4_K", 12), ("q5_K", 13), ("q6_K", 14), ("iq4_nl", 20), ("iq4_xs", 23)]
+
+
+@pytest.mark.parametrize("name,t", LIB_TYPES)
+def test_whole_library_mul_mat_on_the_cpu(name, t):
+    """every accepted weight type through ggml_cdna4_mul_mat on the CPU, the three regimes of the AUTO route: one row (quantizer inside the GEMV
+    launch), four rows (quantize + GEMV; Q8_1 activations for Q4_1 / Q5_1), 32 rows (the MFMA GEMM: its own kernel for the five headline formats —
+    k_gemm_kq_t64 / w8p / the staging w12 with a split-K hand-off —, an exact re-encoding for the others: Q5_0 / IQ4_NL -> Q8_0, Q3_K -> Q6_K, and
+    the two-part forms of Q2_K / Q4_1 / Q5_1 / IQ4_XS against the doubled activation image) — the host code between the C-ABI and the kernels
+    included.  GEMV <= 1e-5, GEMM <= 1e-3 from the oracle's MUL_MAT of that type."""
+    mod = _emul_module("lib_emul_check")
+    for m, k, b, bar in ((40, 1024, 1, 1e-5), (24, 1024, 4, 1e-5), (130, 768, 32, 1e-3)):
+        r = mod.mul_mat(t, m, k, b, seed=t + b, timeout=300)
+        if r is None:
+            pytest.skip("the environment cannot host the emulation")
+        assert r[0] < bar, (name, m, k, b, r[0])
+
+
+@pytest.mark.parametrize("name,t", [("q4_1", 3), ("iq4_nl", 20), ("iq4_xs", 23), ("q2_K", 10)])
+def test_whole_library_small_k_gemm_route_on_the_cpu(name, t):
+    """K = 256: the re-encoded matrix is too shallow for the staging kernel (2 superblocks of the target format) and takes the re-layout + 8-wave
+    kernel; the shape of the stock harness's MUL_MAT cases (m = 16, k = 256, n = 16 -> here 32 activation rows for whole waves)"""
+    r = _emul_module("lib_emul_check").mul_mat(t, 16, 256, 32, seed=t, timeout=300)
+    if r is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert r[0] < 1e-3, r[0]
+
+
+@pytest.mark.parametrize("name,t", [("q4_1", 3), ("q5_1", 7), ("iq4_nl", 20), ("iq4_xs", 23), ("q4_K", 12)])
+def test_whole_library_mul_mat_id_on_the_cpu(name, t):
+    """ggml_cdna4_mul_mat_id on the CPU: one token (one launch, quantizer inside, ids read on the device) and four tokens with a broadcast
+    activation row (quantize + GEMV with per-column experts)"""
+    mod = _emul_module("lib_emul_check")
+    for n_b, n_tok in ((2, 1), (1, 4)):
+        r = mod.mul_mat_id(t, 64, 1024, 4, 2, n_b, n_tok, seed=t + n_tok, timeout=300)
+        if r is None:
+            pytest.skip("the environment cannot host the emulation")
+        assert r < 1e-5, (name, n_b, n_tok, r)

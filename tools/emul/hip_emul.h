@@ -79,7 +79,8 @@ template <typename T> static inline T __shfl_xor(T v, int o, int = 64) {
 }
 static inline int emu_sdot4(int a, int b, int c) { for (int i = 0; i < 4; i++) c += (int)(int8_t)(a >> (8 * i)) * (int)(int8_t)(b >> (8 * i)); return c; }
 #define __builtin_amdgcn_sdot4(a, b, c, clamp) emu_sdot4(a, b, c)
-#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) ((void)0)
+// LDS-DMA, builtin form: every lane copies `size` bytes from ITS global address to the wave's LDS base + lane * size (performed at once)
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) memcpy((char *)(uintptr_t)(l) + (off) + (emu::t_threadIdx.x & 63) * (size), (const void *)(uintptr_t)(g), (size))
 // buffer resources (split-K exchange): a descriptor is just the base pointer here
 typedef void *__amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_make_buffer_rsrc(ptr, stride, num, flags) ((void *)(ptr))
