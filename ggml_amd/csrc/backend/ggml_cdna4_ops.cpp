@@ -56,7 +56,7 @@ bool cdna4_ops_supports_tensor(const ggml_tensor * op) {
             const ggml_type ta = a->type, td = op->type;
             if (ff16(ta) && ff16(td)) return true;
             if (qsrc(ta) && td == GGML_TYPE_F32) return a->nb[0] == ggml_type_size(ta);
-            if (ta == GGML_TYPE_F32 && (td == GGML_TYPE_Q8_0 || td == GGML_TYPE_Q4_0))
+            if (ta == GGML_TYPE_F32 && (td == GGML_TYPE_Q8_0 || td == GGML_TYPE_Q4_0 || td == GGML_TYPE_Q4_1 || td == GGML_TYPE_Q5_0 || td == GGML_TYPE_Q5_1))
                 return a->nb[0] == sizeof(float) && a->ne[0] % 32 == 0 && ggml_is_contiguous(op);
             return false;
         }

@@ -334,6 +334,53 @@ __global__ __launch_bounds__(256) void k_cpy_f32_to_q(const T4 a, const T4 d, in
     }
 }
 
+// F32 -> Q4_1 / Q5_0 / Q5_1 (a quantized KV cache written by CPY): quantize_row_q4_1_ref / _q5_0_ref / _q5_1_ref, src/ggml-quants.c:68-193 — what
+// type_traits_cpu[].from_float is for these types (ggml-cpu.c:271-296).  Same block walk as k_cpy_f32_to_q.
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_cpy_f32_to_q45(const T4 a, const T4 d, int64_t nblocks) {
+    constexpr int BS = TYPE == CDNA4_Q4_1 ? 20 : (TYPE == CDNA4_Q5_0 ? 22 : 24);
+    constexpr bool MINMAX = TYPE != CDNA4_Q5_0, FIVE = TYPE != CDNA4_Q4_1;
+    const int64_t ib = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (ib >= nblocks) return;
+    const int64_t e0 = ib * 32;
+    const float *src = (const float *)at(a, unravel(e0, a.ne));
+    const int64_t bpr = d.ne[0] / 32;
+    const idx4 dr = {0, (ib / bpr) % d.ne[1], (ib / (bpr * d.ne[1])) % d.ne[2], ib / (bpr * d.ne[1] * d.ne[2])};
+    uint8_t *out = (uint8_t *)d.data + dr.i1 * d.nb[1] + dr.i2 * d.nb[2] + dr.i3 * d.nb[3] + (ib % bpr) * BS;
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) v[j] = src[j];
+    float dd, sub, add;                                                 // q = (int8)((x - sub) * id + add), clamped
+    if (MINMAX) {
+        float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+#pragma unroll
+        for (int j = 0; j < 32; j++) { if (v[j] < mn) mn = v[j]; if (v[j] > mx) mx = v[j]; }
+        dd = (mx - mn) / (float)(FIVE ? 31 : 15); sub = mn; add = 0.5f;
+        *(uint16_t *)(out + 2) = f2h_bits(mn);
+    } else {
+        float amax = 0.f, mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; j++) if (amax < fabsf(v[j])) { amax = fabsf(v[j]); mx = v[j]; }
+        dd = mx * -0.0625f;                                              // max / -16, exact; the sign of a zero kept on the bits (see k_cpy_f32_to_q)
+        asm volatile("" : "+v"(dd));
+        sub = 0.f; add = 16.5f;
+    }
+    const float id = dd != 0.f ? 1.0f / dd : 0.f;
+    *(uint16_t *)out = f2h_bits(dd);
+    uint32_t qh = 0;
+    uint8_t *qs = out + (FIVE ? (MINMAX ? 8 : 6) : 4);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float x0 = MINMAX ? (v[j] - sub) * id : v[j] * id, x1 = MINMAX ? (v[16 + j] - sub) * id : v[16 + j] * id;
+        int a0, a1;
+        if (TYPE == CDNA4_Q5_1) { a0 = (int)(uint8_t)(x0 + add); a1 = (int)(uint8_t)(x1 + add); }              // (uint8_t)(x + 0.5f), no clamp (:176-177)
+        else { a0 = (int)(int8_t)(x0 + add); a1 = (int)(int8_t)(x1 + add); const int top = FIVE ? 31 : 15; a0 = a0 < top ? a0 : top; a1 = a1 < top ? a1 : top; }
+        qs[j] = (uint8_t)((a0 & 0x0F) | ((a1 & 0x0F) << 4));
+        if (FIVE) { qh |= (uint32_t)((a0 & 0x10) >> 4) << j; qh |= (uint32_t)((a1 & 0x10) >> 4) << (j + 16); }
+    }
+    if (FIVE) { uint8_t *ph = out + (MINMAX ? 4 : 2); *(uint16_t *)ph = (uint16_t)qh; *(uint16_t *)(ph + 2) = (uint16_t)(qh >> 16); }
+}
+
 // ------------------------------------------------------------------------------------------------ mul_mat F32/F16
 // one wave per output element (m, n, batch): lanes stride over k (both operands contiguous in k)
 template <typename TW>
@@ -554,6 +601,12 @@ int ggml_cdna4_op_cpy(const T4 *a, const T4 *d, int q8_0_ref_rounding, void *str
         if (td == CDNA4_Q4_0) hipLaunchKernelGGL((k_cpy_f32_to_q<CDNA4_Q4_0, true>), grid1d(nbk), dim3(256), 0, st, *a, *d, nbk);
         else if (q8_0_ref_rounding) hipLaunchKernelGGL((k_cpy_f32_to_q<CDNA4_Q8_0, true>), grid1d(nbk), dim3(256), 0, st, *a, *d, nbk);
         else hipLaunchKernelGGL((k_cpy_f32_to_q<CDNA4_Q8_0, false>), grid1d(nbk), dim3(256), 0, st, *a, *d, nbk);
+    } else if (ta == CDNA4_F32 && (td == CDNA4_Q4_1 || td == CDNA4_Q5_0 || td == CDNA4_Q5_1)) {
+        NEED(a->nb[0] == 4 && a->ne[0] % 32 == 0 && d->ne[0] % 32 == 0 && d->nb[0] == (int64_t)tsize(td), "cpy: f32->q needs whole 32-blocks per row");
+        const int64_t nbk = n / 32;
+        if (td == CDNA4_Q4_1) hipLaunchKernelGGL(k_cpy_f32_to_q45<CDNA4_Q4_1>, grid1d(nbk), dim3(256), 0, st, *a, *d, nbk);
+        else if (td == CDNA4_Q5_0) hipLaunchKernelGGL(k_cpy_f32_to_q45<CDNA4_Q5_0>, grid1d(nbk), dim3(256), 0, st, *a, *d, nbk);
+        else hipLaunchKernelGGL(k_cpy_f32_to_q45<CDNA4_Q5_1>, grid1d(nbk), dim3(256), 0, st, *a, *d, nbk);
     } else return cdna4_set_error_msg("cpy: unsupported type pair");
     CDNA4_CHECK_LAUNCH();
     return 0;

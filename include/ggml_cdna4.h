@@ -187,7 +187,7 @@ int ggml_cdna4_op_unary(int op, const ggml_cdna4_tensor * src0, const ggml_cdna4
  * src0 in {F32, F16} or any of the twelve block formats of enum ggml_cdna4_type */
 int ggml_cdna4_op_get_rows(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * ids, const ggml_cdna4_tensor * dst, void * stream);
 /* CPY / DUP / CONT: copy with conversion between tensors of equal element count — ggml_compute_forward_dup,
- * ggml-cpu.c:2860-4050.  Pairs: {F32,F16}->{F32,F16}; F32->{Q8_0,Q4_0}; any block format of enum ggml_cdna4_type -> F32.
+ * ggml-cpu.c:2860-4050.  Pairs: {F32,F16}->{F32,F16}; F32->{Q8_0,Q4_0,Q4_1,Q5_0,Q5_1} (from_float of the type); any block format of enum ggml_cdna4_type -> F32.
  * q8_0_ref_rounding: 0 = the CPU backend's from_float (AVX2 body), 1 = quantize_row_q8_0_ref. */
 int ggml_cdna4_op_cpy(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, int q8_0_ref_rounding, void * stream);
 /* MUL_MAT with F32 or F16 weights and F32 activations, any strides / batch broadcast —

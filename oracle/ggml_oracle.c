@@ -322,6 +322,57 @@ void oracle_quantize_row_q4_0_ref(const float *x, void *vy, int64_t k) {
     }
 }
 /* src/ggml-quants.c:194-217 — the `_ref` (roundf, id = 1/d) variant */
+/* src/ggml-quants.c:68-101 */
+void oracle_quantize_row_q4_1_ref(const float *x, void *vy, int64_t k) {
+    block_q4_1 *y = vy;
+    for (int64_t i = 0; i < k / 32; i++) {
+        float min = 3.402823466e+38f, max = -3.402823466e+38f;
+        for (int j = 0; j < 32; j++) { const float v = x[i * 32 + j]; if (v < min) min = v; if (v > max) max = v; }
+        const float d = (max - min) / ((1 << 4) - 1), id = d ? 1.0f / d : 0.0f;
+        y[i].d = fp32_to_fp16(d); y[i].m = fp32_to_fp16(min);
+        for (int j = 0; j < 16; ++j) {
+            const float x0 = (x[i * 32 + j] - min) * id, x1 = (x[i * 32 + 16 + j] - min) * id;
+            const uint8_t xi0 = MIN(15, (int8_t)(x0 + 0.5f)), xi1 = MIN(15, (int8_t)(x1 + 0.5f));
+            y[i].qs[j] = xi0 | (xi1 << 4);
+        }
+    }
+}
+/* src/ggml-quants.c:103-145 */
+void oracle_quantize_row_q5_0_ref(const float *x, void *vy, int64_t k) {
+    block_q5_0 *y = vy;
+    for (int64_t i = 0; i < k / 32; i++) {
+        float amax = 0.0f, max = 0.0f;
+        for (int j = 0; j < 32; j++) { const float v = x[i * 32 + j]; if (amax < fabsf(v)) { amax = fabsf(v); max = v; } }
+        const float d = max / -16, id = d ? 1.0f / d : 0.0f;
+        y[i].d = fp32_to_fp16(d);
+        uint32_t qh = 0;
+        for (int j = 0; j < 16; ++j) {
+            const float x0 = x[i * 32 + j] * id, x1 = x[i * 32 + 16 + j] * id;
+            const uint8_t xi0 = MIN(31, (int8_t)(x0 + 16.5f)), xi1 = MIN(31, (int8_t)(x1 + 16.5f));
+            y[i].qs[j] = (xi0 & 0x0F) | ((xi1 & 0x0F) << 4);
+            qh |= ((xi0 & 0x10u) >> 4) << (j + 0); qh |= ((xi1 & 0x10u) >> 4) << (j + 16);
+        }
+        memcpy(y[i].qh, &qh, 4);
+    }
+}
+/* src/ggml-quants.c:147-192 */
+void oracle_quantize_row_q5_1_ref(const float *x, void *vy, int64_t k) {
+    block_q5_1 *y = vy;
+    for (int64_t i = 0; i < k / 32; i++) {
+        float min = 3.402823466e+38f, max = -3.402823466e+38f;
+        for (int j = 0; j < 32; j++) { const float v = x[i * 32 + j]; if (v < min) min = v; if (v > max) max = v; }
+        const float d = (max - min) / ((1 << 5) - 1), id = d ? 1.0f / d : 0.0f;
+        y[i].d = fp32_to_fp16(d); y[i].m = fp32_to_fp16(min);
+        uint32_t qh = 0;
+        for (int j = 0; j < 16; ++j) {
+            const float x0 = (x[i * 32 + j] - min) * id, x1 = (x[i * 32 + 16 + j] - min) * id;
+            const uint8_t xi0 = (uint8_t)(x0 + 0.5f), xi1 = (uint8_t)(x1 + 0.5f);
+            y[i].qs[j] = (xi0 & 0x0F) | ((xi1 & 0x0F) << 4);
+            qh |= ((xi0 & 0x10u) >> 4) << (j + 0); qh |= ((xi1 & 0x10u) >> 4) << (j + 16);
+        }
+        memcpy(y[i].qh, &qh, 4);
+    }
+}
 void oracle_quantize_row_q8_0_ref(const float *x, void *vy, int64_t k) {
     block_q8_0 *y = vy;
     for (int64_t i = 0; i < k / 32; i++) {

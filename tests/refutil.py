@@ -70,7 +70,7 @@ def o_quantize_act(wtype, x):
 
 def o_quantize_row(name, x):
     x = np.ascontiguousarray(x, np.float32).reshape(-1)
-    t = {"q4_0_ref": Q4_0, "q8_0_ref": Q8_0, "q8_0_cpu": Q8_0, "q8_K": Q8_K}[name]
+    t = {"q4_0_ref": Q4_0, "q8_0_ref": Q8_0, "q8_0_cpu": Q8_0, "q8_K": Q8_K, "q4_1_ref": Q4_1, "q5_0_ref": Q5_0, "q5_1_ref": Q5_1}[name]
     out = np.zeros(row_size(t, x.size), np.uint8)
     getattr(oracle(), "oracle_quantize_row_" + name)(_p(x), _p(out), C.c_int64(x.size))
     return out

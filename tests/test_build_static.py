@@ -348,6 +348,14 @@ def test_fp16_copy_of_a_quantized_kv_source_on_the_cpu_bit_exact(t):
     assert _emul_module("deq_emul_check").run_f16(t, 128, seed=t) and _emul_module("deq_emul_check").run_f16(t, 64, nrows=4, gap=0, seed=t + 1)
 
 
+@pytest.mark.parametrize("t", [2, 8, 3, 6, 7])
+def test_cpy_quantizer_sources_on_the_cpu_byte_exact(t):
+    """tools/emul/deq_emul cpyq: ggml_cdna4_op_cpy F32 -> Q4_0 / Q8_0 / Q4_1 / Q5_0 / Q5_1 (k_cpy_f32_to_q, k_cpy_f32_to_q45) executed on the CPU equals the
+    oracle's quantize_row_*_ref byte for byte (all-zero, constant and negative-maximum blocks included)"""
+    mod = _emul_module("deq_emul_check")
+    assert mod.run_cpyq(t, seed=t) and mod.run_cpyq(t, 512, 7, "normal", seed=t + 1)
+
+
 @pytest.mark.parametrize("t", [2, 3, 6, 7, 8, 10, 11, 12, 13, 14, 20, 23])
 def test_to_float_sources_on_the_cpu_bit_exact(t):
     """tools/emul/deq_emul: deq_elem of ops.hip (dequantize_row, GET_ROWS, CPY -> F32) executed on the CPU equals the oracle's dequantize_row_*

@@ -350,3 +350,29 @@ def test_flash_attn_ext_quantized_kv(gu, name, t, D, n_q, n_head, n_kv, n_head_k
     assert e < TOL_FA_EXACT
     y16 = ops.flash_attn_ext(gu.to_dev(q), gu.to_dev(kf.astype(np.float16)), gu.to_dev(vf.astype(np.float16)), gu.to_dev(m), scale).cpu().numpy()
     assert np.array_equal(y, y16)
+
+
+# ------------------------------------------------------------------------------------------------ CPY F32 -> Q4_1 / Q5_0 / Q5_1 (writing a quantized KV cache)
+@pytest.mark.parametrize("kind", ["uniform", "normal", "ties"])
+@pytest.mark.parametrize("name,t", [("q4_1", R.Q4_1), ("q5_0", R.Q5_0), ("q5_1", R.Q5_1)])
+def test_cpy_f32_to_q4_1_q5_0_q5_1_is_byte_exact(gu, name, t, kind):
+    """CPY f32 -> Q4_1 / Q5_0 / Q5_1 through the C-ABI, byte for byte: quantize_row_q4_1_ref / _q5_0_ref / _q5_1_ref (from_float of these types on the
+    CPU, src/ggml-quants.c:68-192) — the oracle's restatement, and the bytes the REFERENCE's own CPY node writes (tests/refops.py)"""
+    import ctypes as C
+    import refops as O
+    import test_gpu_cabi_ops as T
+    from ggml_amd import native
+    L = native.lib()
+    rows, k = 37, 1024
+    x = T._data(kind, (rows, k), 11)
+    x[3, 32:64] = 0
+    x[4, 5] = -7.5; x[4, 9] = 7.5
+    x[5, 64:96] = 0.3                                                   # a constant block: max == min, d = 0
+    xd = T._dev(x)
+    out = torch.zeros(rows * R.row_size(t, k), dtype=torch.uint8, device="cuda")
+    T._ok(L, L.ggml_cdna4_op_cpy(C.byref(T._desc(xd, R.F32)), C.byref(T._qdesc(out, t, k, rows)), 0, T._st()))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    want = np.concatenate([R.o_quantize_row(name + "_ref", x[i]) for i in range(rows)])
+    assert np.array_equal(got, want), "first differing byte %d of %d differing" % (int(np.argmax(got != want)), int((got != want).sum()))
+    assert np.array_equal(want, O.cpy_quantize(x, t))

@@ -51,7 +51,8 @@ def test_q8_0_ref_and_q4_0_ref_bit_exact():
     import ctypes as C
     base, _ = R.ref()
     x = _data(11, (1, 4096), "normal")
-    for name, t, sym in [("q8_0_ref", R.Q8_0, "quantize_row_q8_0_ref"), ("q4_0_ref", R.Q4_0, "quantize_row_q4_0_ref")]:
+    for name, t, sym in [("q8_0_ref", R.Q8_0, "quantize_row_q8_0_ref"), ("q4_0_ref", R.Q4_0, "quantize_row_q4_0_ref"), ("q4_1_ref", R.Q4_1, "quantize_row_q4_1_ref"),
+                         ("q5_0_ref", R.Q5_0, "quantize_row_q5_0_ref"), ("q5_1_ref", R.Q5_1, "quantize_row_q5_1_ref")]:
         out = np.zeros(R.row_size(t, 4096), np.uint8)
         getattr(base, sym)(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int64(4096))
         assert np.array_equal(out, R.o_quantize_row(name, x)), name

@@ -40,8 +40,23 @@ static int main_f16(int argc, char **argv) {
     f = fopen(argv[7], "wb"); fwrite(y.data(), 2, y.size(), f); fclose(f);
     return 0;
 }
+// deq_emul cpyq type K nrows x.bin out.bin : ggml_cdna4_op_cpy F32 [K, nrows] -> block type (the CPY quantizers: from_float of the type)
+static int main_cpyq(int argc, char **argv) {
+    const int type = atoi(argv[2]); const int64_t K = atoll(argv[3]), nrows = atoll(argv[4]);
+    std::vector<float> x((size_t)(K * nrows));
+    FILE *f = fopen(argv[5], "rb"); if (!f || fread(x.data(), 4, x.size(), f) != x.size()) { perror(argv[5]); return 2; } fclose(f);
+    const int64_t rb = (int64_t)(K / bsize(type)) * (int64_t)tsize(type);
+    std::vector<uint8_t> y((size_t)(rb * nrows), 0xAA);
+    T4 a{}, d{};
+    a.data = x.data(); a.type = CDNA4_F32; a.ne[0] = K; a.ne[1] = nrows; a.ne[2] = a.ne[3] = 1; a.nb[0] = 4; a.nb[1] = 4 * K; a.nb[2] = a.nb[3] = 4 * K * nrows;
+    d.data = y.data(); d.type = type; d.ne[0] = K; d.ne[1] = nrows; d.ne[2] = d.ne[3] = 1; d.nb[0] = (int64_t)tsize(type); d.nb[1] = rb; d.nb[2] = d.nb[3] = rb * nrows;
+    if (ggml_cdna4_op_cpy(&a, &d, 1, nullptr)) return 1;
+    f = fopen(argv[6], "wb"); fwrite(y.data(), 1, y.size(), f); fclose(f);
+    return 0;
+}
 int main(int argc, char **argv) {
     if (argc >= 8 && !strcmp(argv[1], "f16")) return main_f16(argc, argv);
+    if (argc >= 7 && !strcmp(argv[1], "cpyq")) return main_cpyq(argc, argv);
     if (argc < 5) { fprintf(stderr, "usage: deq_emul type K rows.bin out.bin\n"); return 2; }
     const int type = atoi(argv[1]); const int64_t K = atoll(argv[2]);
     FILE *f = fopen(argv[3], "rb"); if (!f) { perror(argv[3]); return 2; }

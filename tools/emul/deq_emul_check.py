@@ -72,6 +72,25 @@ def run_f16(t, k, nrows=6, gap=10, seed=1):
     return True
 
 
+def run_cpyq(t, k=256, nrows=5, dist="uniform", seed=1):
+    """the CPY quantizers (k_cpy_f32_to_q / k_cpy_f32_to_q45: F32 -> Q4_0 / Q8_0 / Q4_1 / Q5_0 / Q5_1) against the oracle's quantize_row_*_ref, byte for byte"""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (nrows, k)).astype(np.float32) if dist == "uniform" else (rng.standard_normal((nrows, k)) * 3).astype(np.float32)
+    x[0, :32] = 0.0                                   # an all-zero block
+    x[1, 32:64] = 0.75                                # a constant block (max == min)
+    x[2, 5] = -np.abs(x[2, :32]).max() * 2            # a negative maximum
+    with tempfile.TemporaryDirectory() as d:
+        f = lambda n: os.path.join(d, n)
+        x.tofile(f("x.bin"))
+        r = subprocess.run([build(), "cpyq", str(int(t)), str(k), str(nrows), f("x.bin"), f("y.bin")], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        y = np.fromfile(f("y.bin"), np.uint8)
+    name = {R.Q4_0: "q4_0_ref", R.Q8_0: "q8_0_ref", R.Q4_1: "q4_1_ref", R.Q5_0: "q5_0_ref", R.Q5_1: "q5_1_ref"}[t]
+    want = np.concatenate([R.o_quantize_row(name, x[i]) for i in range(nrows)])
+    assert np.array_equal(y, want), "CPY quantizer differs from the oracle's %s" % name
+    return True
+
+
 if __name__ == "__main__":
     t, k = (int(a) for a in sys.argv[1:3]) if len(sys.argv) > 2 else (R.Q3_K, 2048)
     print("to_float source on the CPU, type %d, K=%d: bit-exact =" % (t, k), run(t, k))

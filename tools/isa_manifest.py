@@ -24,7 +24,7 @@ FILES = ["quantize_act.hip", "gemv_q.hip", "gemm_q_mfma.hip", "gemm_q_t64.hip", 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm", "-S", "--cuda-device-only"]
 # kernels written after round 2's last hardware session (emulator-verified only): everything else in the round-2 manifest is hw = true
 NOT_ON_HARDWARE_YET = [r"k_convert_q2_K_q6_K2", r"k_convert_q41_q8_0x2", r"k_convert_iq4_", r"k_quantize_q8_1", r"k_q_to_f16_dense",
-                       r"k_gemv_q(_fused)?ILi(3|7|20|23)E", r"k_(get_rows|cpy_q_to_f32)ILi(20|23)E"]
+                       r"k_gemv_q(_fused)?ILi(3|7|20|23)E", r"k_(get_rows|cpy_q_to_f32)ILi(20|23)E", r"k_cpy_f32_to_q45"]
 
 
 def compiler_version():
