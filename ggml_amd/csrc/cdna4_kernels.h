@@ -39,11 +39,11 @@ struct cdna4_gemv_args {
 };
 // Y[b][m] = epilogue(Y[b][m]) in place — the tail of a GEMM-path MUL_MAT, one launch instead of two or three (ops.hip)
 int cdna4_launch_epilogue(float *Y, int64_t y_row_stride, int64_t M, int64_t B, const cdna4_epilogue &e, hipStream_t st);
-// to_float of a block-quantized tensor (rows contiguous, any row / batch strides) rounded to fp16, written densely in logical order
-// ([ne3][ne2][ne1][ne0] halves) — the K / V operands of FLASH_ATTN_EXT when they arrive quantized (ops.hip)
+// to_float of a block-quantized tensor (rows contiguous, any row / batch strides) rounded to fp16, written in logical order as
+// [ne3][ne2][ne1] rows dst_row >= ne0 halves apart — the K / V operands of FLASH_ATTN_EXT when they arrive quantized (ops.hip)
 struct ggml_cdna4_tensor;
 bool cdna4_to_f16_dense_supported(int type);
-int cdna4_launch_to_f16_dense(const ggml_cdna4_tensor *a, void *dst, hipStream_t st);
+int cdna4_launch_to_f16_dense(const ggml_cdna4_tensor *a, void *dst, int64_t dst_row, hipStream_t st);
 int cdna4_launch_gemv_q(const cdna4_gemv_args &a, hipStream_t st);
 // single-column decode with the activation quantizer fused in (x = fp32 row; a.qs/d/bsums unused)
 bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B);

@@ -315,8 +315,11 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_wide(cons
 #define NEED(cond, msg) do { if (!(cond)) return cdna4_set_error_msg(msg); } while (0)
 typedef ggml_cdna4_tensor T4;
 
+// the kernels exist for head sizes 64 / 128 / 256; any other head size up to 256 runs zero-padded to the next of them (copies, see below)
+static inline bool fa_kernel_head_size(int64_t hs) { return hs == 64 || hs == 128 || hs == 256; }
 extern "C" int ggml_cdna4_op_flash_attn_ext_supported(int64_t head_size, int kv_type) {
-    return (head_size == 64 || head_size == 128 || head_size == 256) && (kv_type == CDNA4_F16 || cdna4_to_f16_dense_supported(kv_type));
+    if (head_size <= 0 || head_size > 256) return 0;
+    return kv_type == CDNA4_F16 || (cdna4_to_f16_dense_supported(kv_type) && head_size % 32 == 0);
 }
 
 static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T4 *d, float scale, float max_bias, float logit_softcap, void *stream);
@@ -328,19 +331,47 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
 extern "C" int ggml_cdna4_op_flash_attn_ext(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T4 *d,
                                             float scale, float max_bias, float logit_softcap, void *stream) {
     NEED(q && k && v && d, "flash_attn_ext: q, k, v and dst are required");
-    if (k->type == CDNA4_F16 && v->type == CDNA4_F16) return fa_f16(q, k, v, mask, d, scale, max_bias, logit_softcap, stream);
-    T4 kv[2] = {*k, *v};
+    // Head sizes without a kernel of their own (80, 96, 112, ...) run ZERO-PADDED to the next of 64 / 128 / 256: the padded components of q and k
+    // add 0 to every score, the padded columns of v produce output columns that are dropped.  q, k, v are copied into padded scratch (k / v as
+    // fp16), the result is computed into padded scratch and its first head_size columns copied out — four extra passes, all plain strided copies.
+    const int64_t D = q->ne[0], Dp = D <= 64 ? 64 : (D <= 128 ? 128 : 256);
+    NEED(D > 0 && D <= 256, "flash_attn_ext: head size must be 1..256");
+    const bool pad = !fa_kernel_head_size(D);
+    if (!pad && k->type == CDNA4_F16 && v->type == CDNA4_F16) return fa_f16(q, k, v, mask, d, scale, max_bias, logit_softcap, stream);
+    hipStream_t st = (hipStream_t)stream;
+    T4 kv[2] = {*k, *v}, qq = *q, dd = *d;
     for (int i = 0; i < 2; i++) {
         T4 &t = kv[i];
-        if (t.type == CDNA4_F16) continue;
-        NEED(cdna4_to_f16_dense_supported(t.type), "flash_attn_ext: k / v must be F16 or Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0");
-        NEED(t.ne[0] > 0 && t.ne[0] % 32 == 0 && t.ne[1] > 0 && t.ne[2] > 0 && t.ne[3] > 0, "flash_attn_ext: bad quantized k / v shape");
-        void *dense = cdna4_gemm_scratch((size_t)(t.ne[0] * t.ne[1] * t.ne[2] * t.ne[3]) * 2 + 256, 5 + i);
-        NEED(dense, "flash_attn_ext: cannot allocate the fp16 copy of a quantized k / v");
-        const int rc = cdna4_launch_to_f16_dense(&t, dense, (hipStream_t)stream);
+        if (t.type == CDNA4_F16 && !pad) continue;
+        NEED(t.type == CDNA4_F16 || cdna4_to_f16_dense_supported(t.type), "flash_attn_ext: k / v must be F16 or Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0");
+        NEED(t.ne[0] == D && (t.type == CDNA4_F16 || D % 32 == 0) && t.ne[1] > 0 && t.ne[2] > 0 && t.ne[3] > 0, "flash_attn_ext: bad k / v shape");
+        const size_t bytes = (size_t)(Dp * t.ne[1] * t.ne[2] * t.ne[3]) * 2;
+        void *dense = cdna4_gemm_scratch(bytes + 256, 5 + i);
+        NEED(dense, "flash_attn_ext: cannot allocate the fp16 copy of k / v");
+        if (pad && hipMemsetAsync(dense, 0, bytes, st) != hipSuccess) { (void)hipGetLastError(); return cdna4_set_error_msg("flash_attn_ext: memset failed"); }
+        T4 c = t;                                                      // the copy: head_size columns of rows Dp halves apart
+        c.data = dense; c.type = CDNA4_F16; c.nb[0] = 2; c.nb[1] = 2 * Dp; c.nb[2] = c.nb[1] * c.ne[1]; c.nb[3] = c.nb[2] * c.ne[2];
+        const int rc = t.type == CDNA4_F16 ? ggml_cdna4_op_cpy(&t, &c, 0, stream) : cdna4_launch_to_f16_dense(&t, dense, Dp, st);
         if (rc) return rc;
-        t.data = dense; t.type = CDNA4_F16;
-        t.nb[0] = 2; t.nb[1] = 2 * t.ne[0]; t.nb[2] = t.nb[1] * t.ne[1]; t.nb[3] = t.nb[2] * t.ne[2];
+        t = c; t.ne[0] = Dp;
+    }
+    if (pad) {
+        const int64_t N = q->ne[1], H = q->ne[2], B3 = q->ne[3];
+        NEED(q->type == CDNA4_F32 && d->type == CDNA4_F32 && N > 0 && H > 0 && B3 > 0, "flash_attn_ext: F32 q / dst");
+        NEED(d->ne[0] == D && d->ne[1] == H && d->ne[2] == N && d->ne[3] == B3, "flash_attn_ext: dst must be [head_size, n_head, n_q, batch]");
+        const size_t nel = (size_t)(Dp * N * H * B3);
+        float *qp = (float *)cdna4_gemm_scratch(nel * 4 + 256, 7), *dp = (float *)cdna4_gemm_scratch(nel * 4 + 256, 8);
+        NEED(qp && dp, "flash_attn_ext: cannot allocate the padded q / dst");
+        if (hipMemsetAsync(qp, 0, nel * 4, st) != hipSuccess) { (void)hipGetLastError(); return cdna4_set_error_msg("flash_attn_ext: memset failed"); }
+        T4 c = *q; c.data = qp; c.nb[0] = 4; c.nb[1] = 4 * Dp; c.nb[2] = c.nb[1] * N; c.nb[3] = c.nb[2] * H;
+        int rc = ggml_cdna4_op_cpy(q, &c, 0, stream);
+        if (rc) return rc;
+        qq = c; qq.ne[0] = Dp;
+        dd = *d; dd.data = dp; dd.ne[0] = Dp; dd.nb[0] = 4; dd.nb[1] = 4 * Dp; dd.nb[2] = dd.nb[1] * H; dd.nb[3] = dd.nb[2] * N;
+        rc = fa_f16(&qq, &kv[0], &kv[1], mask, &dd, scale, max_bias, logit_softcap, stream);
+        if (rc) return rc;
+        T4 view = dd; view.ne[0] = D;                                  // the first head_size columns of every padded output row
+        return ggml_cdna4_op_cpy(&view, d, 0, stream);
     }
     return fa_f16(q, &kv[0], &kv[1], mask, d, scale, max_bias, logit_softcap, stream);
 }
@@ -348,7 +379,7 @@ extern "C" int ggml_cdna4_op_flash_attn_ext(const T4 *q, const T4 *k, const T4 *
 static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T4 *d, float scale, float max_bias, float logit_softcap, void *stream) {
     NEED(q->type == CDNA4_F32 && d->type == CDNA4_F32 && k->type == CDNA4_F16 && v->type == CDNA4_F16, "flash_attn_ext: F32 q / dst and F16 k / v only");
     const int64_t D = q->ne[0], N = q->ne[1], H = q->ne[2], B3 = q->ne[3], KV = k->ne[1];
-    NEED(ggml_cdna4_op_flash_attn_ext_supported(D, k->type), "flash_attn_ext: head size must be 64, 128 or 256");
+    NEED(fa_kernel_head_size(D), "flash_attn_ext: head size must be 64, 128 or 256");
     NEED(k->ne[0] == D && v->ne[0] == D && v->ne[1] == KV && k->ne[2] == v->ne[2] && k->ne[3] == v->ne[3], "flash_attn_ext: k / v shape mismatch");
     NEED(k->ne[2] > 0 && k->ne[3] > 0 && H % k->ne[2] == 0 && B3 % k->ne[3] == 0, "flash_attn_ext: heads / batch not broadcastable over k / v");
     NEED(d->ne[0] == D && d->ne[1] == H && d->ne[2] == N && d->ne[3] == B3, "flash_attn_ext: dst must be [head_size, n_head, n_q, batch]");

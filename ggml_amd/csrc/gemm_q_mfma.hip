@@ -394,10 +394,10 @@ static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
 // library-owned scratch for the split-K hand-off (partial tiles + flags), grown on demand like a BLAS workspace
 // (one region per device; launches that use it are assumed to be stream-ordered on that device, as the plug-in's
 // single-stream backend and the one-process-per-GPU bench are).
-static void *g_scratch[112] = {nullptr}; static size_t g_scratch_bytes[112] = {0};
+static void *g_scratch[144] = {nullptr}; static size_t g_scratch_bytes[144] = {0};
 static std::atomic<uint64_t> g_scratch_generation{0};
 uint64_t cdna4_scratch_generation() { return g_scratch_generation.load(); }
-static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: split-K exchange buffers, 1: repacked weights, 2: exchange buffers of gemm_q_t64.hip (reader-reset flags), 3: re-encoded weights (convert_w.hip), 4: partial results of the key-split FLASH_ATTN_EXT (fattn.hip), 5 / 6: fp16 copies of a quantized K / V in front of FLASH_ATTN_EXT
+static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: split-K exchange buffers, 1: repacked weights, 2: exchange buffers of gemm_q_t64.hip (reader-reset flags), 3: re-encoded weights (convert_w.hip), 4: partial results of the key-split FLASH_ATTN_EXT (fattn.hip), 5 / 6: fp16 copies of a quantized (or head-size-padded) K / V in front of FLASH_ATTN_EXT, 7 / 8: its padded q / dst
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
     dev += 16 * kind;

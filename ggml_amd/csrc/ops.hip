@@ -283,12 +283,12 @@ __global__ __launch_bounds__(256) void k_cpy_q_to_f32(const T4 a, const T4 d, in
 }
 // the same rounded to fp16 into a dense buffer (element i of the logical order at dst[i]): a quantized K / V cache in front of FLASH_ATTN_EXT
 template <int TYPE>
-__global__ __launch_bounds__(256) void k_q_to_f16_dense(const T4 a, half_t *__restrict__ dst, int64_t n) {
+__global__ __launch_bounds__(256) void k_q_to_f16_dense(const T4 a, half_t *__restrict__ dst, int64_t n, int64_t dst_row) {      // dst rows dst_row >= ne[0] halves apart
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const idx4 x = unravel(i, a.ne);
     const uint8_t *row = (const uint8_t *)a.data + x.i1 * a.nb[1] + x.i2 * a.nb[2] + x.i3 * a.nb[3];
-    dst[i] = (half_t)deq_elem<TYPE>(row, x.i0);
+    dst[(i / a.ne[0]) * dst_row + x.i0] = (half_t)deq_elem<TYPE>(row, x.i0);
 }
 // F32 -> Q4_0 / Q8_0: one thread per 32-block; src rows contiguous in ne[0], dst blocks enumerated in logical order
 template <int TYPE, bool REF>
@@ -614,12 +614,13 @@ int ggml_cdna4_op_cpy(const T4 *a, const T4 *d, int q8_0_ref_rounding, void *str
 
 }  // extern "C"
 bool cdna4_to_f16_dense_supported(int type) { return type == CDNA4_Q4_0 || type == CDNA4_Q4_1 || type == CDNA4_Q5_0 || type == CDNA4_Q5_1 || type == CDNA4_Q8_0; }
-int cdna4_launch_to_f16_dense(const T4 *a, void *dst, hipStream_t st) {
+int cdna4_launch_to_f16_dense(const T4 *a, void *dst, int64_t dst_row, hipStream_t st) {
     NEED(cdna4_to_f16_dense_supported(a->type), "to_f16_dense: unsupported source type");
     NEED(a->nb[0] == (int64_t)tsize(a->type) && a->ne[0] % bsize(a->type) == 0, "to_f16_dense: quantized source rows must be contiguous");
     const int64_t n = nelem(a);
     if (n == 0) return 0;
-#define TF(T) hipLaunchKernelGGL(k_q_to_f16_dense<T>, grid1d(n), dim3(256), 0, st, *a, (half_t *)dst, n); break
+    NEED(dst_row >= a->ne[0], "to_f16_dense: destination rows overlap");
+#define TF(T) hipLaunchKernelGGL(k_q_to_f16_dense<T>, grid1d(n), dim3(256), 0, st, *a, (half_t *)dst, n, dst_row); break
     switch (a->type) { case CDNA4_Q4_0: TF(CDNA4_Q4_0); case CDNA4_Q4_1: TF(CDNA4_Q4_1); case CDNA4_Q5_0: TF(CDNA4_Q5_0); case CDNA4_Q5_1: TF(CDNA4_Q5_1); default: TF(CDNA4_Q8_0); }
 #undef TF
     CDNA4_CHECK_LAUNCH();

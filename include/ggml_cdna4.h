@@ -203,7 +203,9 @@ int ggml_cdna4_op_rope(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor *
  * batches broadcast as q's over k's), mask F16 [n_kv, >= n_q] or NULL, dst F32 contiguous [head_size, n_head, n_q, batch].
  * scale / max_bias (ALiBi) / logit_softcap as in op_params 0..2.  fp16 operands on the matrix cores, fp32 softmax statistics and
  * accumulation.  k / v may also be block-quantized (Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0: a quantized KV cache; rows contiguous, any strides): they are
- * written out as fp16 into library scratch first (one pass), then the same kernels run.  _supported: head sizes 64 / 128 / 256 with such k / v. */
+ * written out as fp16 into library scratch first (one pass), then the same kernels run.  Head sizes other than 64 / 128 / 256 (80, 96, 112, ...; up
+ * to 256) run zero-padded to the next of them through padded copies of q / k / v and of the result.  _supported: head size 1..256 with F16 k / v,
+ * a multiple of 32 with quantized k / v. */
 int ggml_cdna4_op_flash_attn_ext_supported(int64_t head_size, int kv_type);
 int ggml_cdna4_op_flash_attn_ext(const ggml_cdna4_tensor * q, const ggml_cdna4_tensor * k, const ggml_cdna4_tensor * v, const ggml_cdna4_tensor * mask,
                                  const ggml_cdna4_tensor * dst, float scale, float max_bias, float logit_softcap, void * stream);

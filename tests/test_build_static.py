@@ -399,6 +399,26 @@ def test_flash_attn_on_a_quantized_kv_end_to_end_on_the_cpu(t, kw):
     assert r[0] < 5e-4 and r[1] is True, r
 
 
+@pytest.mark.parametrize("kw", [dict(D=80, n_q=5, n_head=2, n_kv=96), dict(D=80, n_q=35, n_head=4, n_kv=200, n_head_kv=2, max_bias=8.0, cus=2), dict(D=80, n_q=3, n_head=2, n_kv=70, permuted=True, n_batch=2),
+                                dict(D=96, n_q=33, n_head=2, n_kv=130, mask=False), dict(D=112, n_q=1, n_head=3, n_kv=517, inf_every=7), dict(D=40, n_q=4, n_head=2, n_kv=64), dict(D=200, n_q=7, n_head=2, n_kv=90)])
+def test_flash_attn_padded_head_sizes_end_to_end_on_the_cpu(kw):
+    """head sizes without a kernel of their own (80 — the stock harness's —, 96, 112, 40, 200) run zero-padded to 64 / 128 / 256: the op's host code
+    (padded copies of q / k / v, the result copied back) and the kernels from source on the CPU, same bars as the native head sizes"""
+    r = _emul_module("fattn_emul_check").run(**kw)
+    if r is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert r[0] < 5e-4 and r[1] < 6e-3, r
+
+
+def test_flash_attn_padded_head_size_with_a_quantized_kv_on_the_cpu():
+    mod = _emul_module("fattn_emul_check")
+    for t, D in ((8, 96), (2, 96), (7, 160)):
+        r = mod.run_quantized(t, D, 5, 2, 96, seed=t)
+        if r is None:
+            pytest.skip("the environment cannot host the emulation")
+        assert r[0] < 5e-4 and r[1] is True, (t, D, r)
+
+
 def test_hardware_verified_kernels_are_unchanged():
     """tools/isa_manifest.py: the ISA of every kernel that was part of a build with a green hardware session (profiles/rNN/isa_manifest.json,
     `hw`: true) is what hipcc emits for it today — so what was added since (listed there as `hw`: false, or new) cannot have changed the

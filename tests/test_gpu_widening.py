@@ -194,7 +194,7 @@ def test_flash_attn_ext_is_deterministic_and_row_independent(gu):
 
 def test_stock_harness_flash_attn_ext():
     """the UNMODIFIED reference harness on FLASH_ATTN_EXT: F16 (and, since the conversion pass, Q8_0 / Q4_0) K / V cases with head sizes
-    64 / 128 / 256 run on the plug-in and pass its NMSE gate, the rest (head sizes 80 / 96 / 112, BF16 K / V) is declined by supports_op"""
+    64 / 80 / 128 / 256 (80 zero-padded) run on the plug-in and pass its NMSE gate, BF16 K / V is declined by supports_op"""
     import test_gpu_backend_plugin as P
     rc, txt = P._run("FLASH_ATTN_EXT")
     import re
@@ -376,3 +376,12 @@ def test_cpy_f32_to_q4_1_q5_0_q5_1_is_byte_exact(gu, name, t, kind):
     want = np.concatenate([R.o_quantize_row(name + "_ref", x[i]) for i in range(rows)])
     assert np.array_equal(got, want), "first differing byte %d of %d differing" % (int(np.argmax(got != want)), int((got != want).sum()))
     assert np.array_equal(want, O.cpy_quantize(x, t))
+
+
+# ------------------------------------------------------------------------------------------------ FLASH_ATTN_EXT: head sizes without a kernel of their own
+@pytest.mark.parametrize("kw", [dict(D=80, n_q=35, n_head=8, n_kv=512), dict(D=80, n_q=1, n_head=32, n_kv=1024, max_bias=8.0), dict(D=96, n_q=3, n_head=4, n_kv=200, n_head_kv=2),
+                                dict(D=112, n_q=40, n_head=4, n_kv=300, n_batch=2, permuted=True), dict(D=80, n_q=512, n_head=8, n_kv=512, n_head_kv=2), dict(D=40, n_q=5, n_head=2, n_kv=64, mask=False)])
+def test_flash_attn_ext_padded_head_sizes(gu, kw):
+    """head size 80 (the stock harness's fourth size), 96, 112, 40: zero-padded to 64 / 128 through padded copies of q / k / v and of the result
+    (emulator-verified end to end; the kernels are the hardware-verified ones)"""
+    _fa_case(gu, **kw)

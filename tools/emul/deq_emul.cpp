@@ -36,7 +36,7 @@ static int main_f16(int argc, char **argv) {
     T4 a{}; a.data = w.data(); a.type = type; a.ne[0] = K; a.ne[1] = nrows / 2; a.ne[2] = 2; a.ne[3] = 1;
     a.nb[0] = (int64_t)tsize(type); a.nb[1] = rb + gap; a.nb[2] = a.nb[1] * a.ne[1]; a.nb[3] = a.nb[2] * 2;
     std::vector<uint16_t> y((size_t)(nrows * K), 0xAAAA);
-    if (cdna4_launch_to_f16_dense(&a, y.data(), nullptr)) return 1;
+    if (cdna4_launch_to_f16_dense(&a, y.data(), K, nullptr)) return 1;
     f = fopen(argv[7], "wb"); fwrite(y.data(), 2, y.size(), f); fclose(f);
     return 0;
 }
