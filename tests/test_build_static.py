@@ -12,6 +12,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _emulators_built_in_parallel():
+    """the CPU emulators (tools/emul) are built on demand by their check modules, one after the other; on a fresh checkout that is most of this
+    file's run time, so build all of them here at once (each build is a no-op when its binary is newer than its sources)"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        return
+    import importlib.util
+    from concurrent.futures import ThreadPoolExecutor
+
+    def mod(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", "emul", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    jobs = [lambda: mod("emul_check").build("w12"), lambda: mod("emul_check").build("w8"), lambda: mod("emul_check").build("t64")]
+    jobs += [mod(n).build for n in ("gemv_emul_check", "quant_emul_check", "convert_emul_check", "deq_emul_check", "fattn_emul_check", "lib_emul_check")]
+    with ThreadPoolExecutor(max_workers=9) as ex:
+        for f in [ex.submit(j) for j in jobs]:
+            try:
+                f.result()
+            except Exception:  # noqa: BLE001 — the test that needs this emulator reports the build error
+                pass
+
+
 @pytest.fixture(scope="module")
 def gemm_asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
