@@ -1,6 +1,7 @@
 """-m gpu parity tests of the rows SURVEY.md 8(f) ranks after the five headline formats: the remaining block formats (rank 4).
 Same bars as test_gpu_parity.py: rel-L2 <= 1e-5 for the int8-dot GEMV units, <= 1e-3 for the fp16-MFMA GEMM, bit-exact for to_float and
 for the weight re-encodings.  (This file sorts last on purpose: what it covers is newer than the five-format path.)"""
+import os
 import numpy as np
 import pytest
 import torch
@@ -385,3 +386,29 @@ def test_flash_attn_ext_padded_head_sizes(gu, kw):
     """head size 80 (the stock harness's fourth size), 96, 112, 40: zero-padded to 64 / 128 through padded copies of q / k / v and of the result
     (emulator-verified end to end; the kernels are the hardware-verified ones)"""
     _fa_case(gu, **kw)
+
+
+# ------------------------------------------------------------------------------------------------ the gpt-2 graph on Q4_1 / Q5_1 / Q5_0 weights
+@pytest.mark.parametrize("qname", ["q4_1", "q5_1", "q5_0"])
+def test_gpt2_per_op_parity_with_the_other_quantizations(tmp_path, qname):
+    """the reference's own gpt-2 graph (examples/gpt-2/main-backend.cpp through oracle/gpt2_harness, unmodified) on a synthetic 117M-shaped model
+    quantized by the reference's gpt-2-quantize to the types it offers besides q4_0 / q8_0: every node evaluated by the CPU backend and by the
+    plug-in on identical inputs (RESYNC) — a 64-token prompt (the two-part Q8_0 GEMM for q4_1 / q5_1, the re-encoded one for q5_0, with the
+    plug-in's bias / GELU / residual fusions around them) and one decoded token (the GEMV units).  Bars of tests/test_gpu_gpt2.py."""
+    import re
+    import subprocess
+    import sys
+    import test_gpu_gpt2 as G
+    f32, qf = str(tmp_path / "f32.bin"), str(tmp_path / (qname + ".bin"))
+    subprocess.run([sys.executable, os.path.join(R.ROOT, "tools", "make_synth_gpt2.py"), f32], check=True, timeout=600)
+    subprocess.run([os.path.join(G.REF, "gpt-2-quantize"), f32, qf, qname], check=True, timeout=600, capture_output=True)
+    os.remove(f32)
+    out = G._harness([qf, "CDNA40", G.PLUGIN, "RESYNC", 64, 1, 16])
+    rows = re.findall(r"node\s+(\d+)\s+(\S+)\s+.*?\[\s*(\d+),\s*(\d+),\s*(\d+)\] rel_l2=(\S+?)( NONFINITE-MISMATCH)?$", out, re.M)
+    assert len(rows) > 300, out[-2000:]
+    worst = {}
+    for _, op, _, _, _, err, bad in rows:
+        assert not bad, (op, err)
+        worst[op] = max(worst.get(op, 0.0), float(err))
+    for op, e in worst.items():
+        assert e < (1e-3 if op == "MUL_MAT" else 1e-4), (qname, worst)
