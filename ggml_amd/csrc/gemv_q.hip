@@ -697,6 +697,10 @@ size_t cdna4_gemv_fused_lds_bytes(int type, int64_t K) {
 static int fused_nb(int64_t B) { return B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8)); }      // instantiated column counts
 bool cdna4_gemv_fused_supported(int type, int64_t K, int64_t B) {
     if (K <= 0 || B < 1 || B > 8) return false;
+    // lds_swz() permutes the 16-byte chunks of an activation row inside groups of four (chunk c -> c ^ ((c >> 4) & 3)): a row that is not a
+    // whole number of 64-byte groups (32-weight formats with K % 64 == 32) would have its last two chunks land PAST the row for K mod 1024 >=
+    // 512 — on the row's scales.  Found by the CPU emulation of the whole library (K = 544); such K take the quantize + GEMV pair instead.
+    if (K % 64) return false;
     if (B == 1) return cdna4_gemv_fused_lds_bytes(type, K) <= 64 * 1024;
     const bool main5 = type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K || type == CDNA4_Q4_0 || type == CDNA4_Q8_0;
     return main5 && (size_t)fused_nb(B) * cdna4_gemv_fused_lds_bytes(type, K) <= 150 * 1024;

@@ -469,8 +469,7 @@ def json_hw(path, fk):
 
 
 # ---- the WHOLE library on the CPU (tools/emul/lib_emul.h): ggml_cdna4_mul_mat / _mul_mat_id through the C-ABI of a host build of the product's own sources.
-# Shapes keep the activation quantizers' lanes in whole waves (the emulator's wave-collective shuffles): B * K a multiple of 1024 for the K-quants' GEMM
-# route, K a multiple of 1024 where the quantizer runs inside the GEMV launch.
+# (Wave-collectives complete among the lanes that execute them — tools/emul/hip_emul.h, Sync — so any shape runs, partial waves included.)
 LIB_TYPES = [("q4_0", 2), ("q4_1", 3), ("q5_0", 6), ("q5_1", 7), ("q8_0", 8), ("q2_K", 10), ("q3_K", 11), ("q4_K", 12), ("q5_K", 13), ("q6_K", 14), ("iq4_nl", 20), ("iq4_xs", 23)]
 
 
@@ -509,3 +508,29 @@ def test_whole_library_mul_mat_id_on_the_cpu(name, t):
         if r is None:
             pytest.skip("the environment cannot host the emulation")
         assert r < 1e-5, (name, n_b, n_tok, r)
+
+
+@pytest.mark.parametrize("name,t", LIB_TYPES)
+def test_whole_library_stock_harness_shapes_on_the_cpu(name, t):
+    """the shapes of the reference's test-backend-ops MUL_MAT sweep (m = 16, k = 256, n = 1 / 9 / 16: tests/test-backend-ops.cpp:4005-4081) through the
+    C-ABI on the CPU — quantizers with partly filled waves, the shallow-K GEMM routes, the two-part forms at their smallest size"""
+    mod = _emul_module("lib_emul_check")
+    for b in (1, 9, 16):
+        r = mod.mul_mat(t, 16, 256, b, seed=t + b, timeout=300)
+        if r is None:
+            pytest.skip("the environment cannot host the emulation")
+        assert r[0] < (1e-5 if b <= 8 else 1e-3), (name, b, r[0])
+
+
+@pytest.mark.parametrize("name,t", [("q4_0", 2), ("q8_0", 8), ("q5_0", 6), ("q4_1", 3), ("q5_1", 7), ("iq4_nl", 20)])
+@pytest.mark.parametrize("k", [544, 992, 96])
+def test_32_weight_formats_with_k_not_a_multiple_of_64_on_the_cpu(name, t, k):
+    """a bug of round 2's decode kernel that only the whole-library emulation showed: lds_swz() permutes 16-byte chunks of the int8 activation row
+    inside groups of four, so with K % 64 == 32 and K mod 1024 >= 512 the row's last two chunks landed on its scales (K = 544: rel-L2 1e27).  Such
+    K now take the quantize + GEMV pair (cdna4_gemv_fused_supported); one row, and MUL_MAT_ID's single-token form, through the C-ABI"""
+    mod = _emul_module("lib_emul_check")
+    r = mod.mul_mat(t, 16, k, 1, seed=k, timeout=300)
+    if r is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert r[0] < 1e-5, (name, k, r[0])
+    assert mod.mul_mat_id(t, 32, k, 4, 2, 2, 1, seed=k + 1, timeout=300) < 1e-5

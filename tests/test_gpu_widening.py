@@ -412,3 +412,18 @@ def test_gpt2_per_op_parity_with_the_other_quantizations(tmp_path, qname):
         worst[op] = max(worst.get(op, 0.0), float(err))
     for op, e in worst.items():
         assert e < (1e-3 if op == "MUL_MAT" else 1e-4), (qname, worst)
+
+
+# ------------------------------------------------------------------------------------------------ K % 64 == 32 (32-weight formats), one activation row
+@pytest.mark.parametrize("name,t", [("q4_0", R.Q4_0), ("q8_0", R.Q8_0), ("q5_0", R.Q5_0), ("q4_1", R.Q4_1), ("q5_1", R.Q5_1), ("iq4_nl", R.IQ4_NL)])
+@pytest.mark.parametrize("k", [544, 992, 1568, 96])
+def test_decode_with_k_not_a_multiple_of_64(gu, name, t, k):
+    """K % 64 == 32 with K mod 1024 >= 512 sent the last two chunks of the in-LDS activation row onto its scales (the chunk swizzle of the
+    one-launch decode kernel; found on the CPU emulation of the whole library): such K now take the quantize + GEMV pair.  One row, AUTO route."""
+    from ggml_amd import ops
+    m = 48
+    w = R.random_weights(t, m, k, seed=k)
+    x = _x(k + 1, 1, k)
+    y = ops.mul_mat(gu.qtensor(t, w, m, k), gu.to_dev(x)).cpu().numpy()
+    e = R.rel_l2(y, R.o_mul_mat(t, w, x, m, k)); gu.report(test="decode_k_mod_64", type=name, k=k, rel_l2=e)
+    assert np.isfinite(y).all() and e < TOL_GEMV

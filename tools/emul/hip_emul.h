@@ -43,9 +43,68 @@ extern dim3 g_gridDim, g_blockDim;
 extern pthread_barrier_t g_wg_barrier;
 extern WaveState *g_waves;                // one per wave of the running work-group
 inline WaveState &my_wave() { return g_waves[t_threadIdx.x >> 6]; }
-inline void wg_barrier() { pthread_barrier_wait(&g_wg_barrier); }
+
+// ---- synchronisation with SIMT semantics.  One OS thread per lane means that a lane which branches AROUND a wave-collective (shuffle, MFMA,
+// permlane swap) or leaves the kernel never arrives at it, where the GPU simply runs the collective with the lanes that are active.  So a
+// wave-collective completes when every lane of the wave has either arrived at it, is waiting at the work-group barrier, or has left the kernel —
+// i.e. when nobody else can still come; the work-group barrier likewise counts lanes that have left.  (Lanes that skip a collective reach the
+// next barrier or the end of the kernel, which is what tells the others not to wait for them.)  One lock and condition per wave, one for the barrier.
+struct WaveSync { pthread_mutex_t m = PTHREAD_MUTEX_INITIALIZER; pthread_cond_t cv = PTHREAD_COND_INITIALIZER; int arrived = 0, at_bar = 0, exited = 0; unsigned gen = 0, at_bar_gen = 0; };
+struct Sync {
+    WaveSync w[16];
+    pthread_mutex_t mb = PTHREAD_MUTEX_INITIALIZER; pthread_cond_t cb = PTHREAD_COND_INITIALIZER;
+    int b_arrived = 0, exited = 0; unsigned b_gen = 0;                  // b_gen is read without mb (atomically) by the waves
+};
+inline Sync g_sync;
+inline int n_threads() { return (int)(g_blockDim.x * g_blockDim.y * g_blockDim.z); }
+inline int wave_lanes(int w) { const int n = n_threads() - 64 * w; return n < 64 ? n : 64; }
+// (with ws.m held) lanes marked "at the barrier" count only while that barrier instance has not been released: the mark carries its generation
+inline void try_release_wave(Sync &s, int w) {
+    WaveSync &ws = s.w[w];
+    const int at_bar = ws.at_bar_gen == __atomic_load_n(&s.b_gen, __ATOMIC_ACQUIRE) ? ws.at_bar : 0;
+    if (ws.arrived > 0 && ws.arrived + at_bar + ws.exited == wave_lanes(w)) { ws.arrived = 0; ws.gen++; pthread_cond_broadcast(&ws.cv); }
+}
+inline void wave_sync() {
+    Sync &s = g_sync; const int w = (int)(t_threadIdx.x >> 6); WaveSync &ws = s.w[w];
+    pthread_mutex_lock(&ws.m);
+    const unsigned g = ws.gen; ws.arrived++; try_release_wave(s, w);
+    while (ws.gen == g) pthread_cond_wait(&ws.cv, &ws.m);
+    pthread_mutex_unlock(&ws.m);
+}
+inline void wg_barrier() {
+    Sync &s = g_sync; const int w = (int)(t_threadIdx.x >> 6); WaveSync &ws = s.w[w];
+    pthread_mutex_lock(&ws.m);
+    const unsigned bg = __atomic_load_n(&s.b_gen, __ATOMIC_ACQUIRE);
+    if (ws.at_bar_gen != bg) { ws.at_bar = 0; ws.at_bar_gen = bg; }
+    ws.at_bar++; try_release_wave(s, w);
+    pthread_mutex_unlock(&ws.m);
+    pthread_mutex_lock(&s.mb);
+    const unsigned g = s.b_gen;
+    if (++s.b_arrived + s.exited == n_threads()) { s.b_arrived = 0; __atomic_store_n(&s.b_gen, g + 1, __ATOMIC_RELEASE); pthread_cond_broadcast(&s.cb); }
+    else while (s.b_gen == g) pthread_cond_wait(&s.cb, &s.mb);
+    pthread_mutex_unlock(&s.mb);
+}
+struct LaneGuard {                       // armed by the lane's first read of threadIdx; its destructor runs when the lane's OS thread ends
+    int wave = -1;
+    ~LaneGuard() {
+        if (wave < 0) return;
+        Sync &s = g_sync; WaveSync &ws = s.w[wave];
+        pthread_mutex_lock(&ws.m); ws.exited++; try_release_wave(s, wave); pthread_mutex_unlock(&ws.m);
+        pthread_mutex_lock(&s.mb);
+        s.exited++;
+        if (s.b_arrived > 0 && s.b_arrived + s.exited == n_threads()) { s.b_arrived = 0; __atomic_store_n(&s.b_gen, s.b_gen + 1, __ATOMIC_RELEASE); pthread_cond_broadcast(&s.cb); }
+        if (s.exited == n_threads()) {                                  // the last lane out: the next work-group of this process starts clean
+            for (int w = 0; w < 16; w++) { s.w[w].arrived = s.w[w].at_bar = s.w[w].exited = 0; }
+            s.b_arrived = s.exited = 0;
+        }
+        pthread_mutex_unlock(&s.mb);
+    }
+};
+inline dim3 &tid_ref() { static thread_local LaneGuard guard; if (guard.wave < 0) guard.wave = (int)(t_threadIdx.x >> 6); return t_threadIdx; }
+inline int sync_point(pthread_barrier_t *b) { if (b == &g_wg_barrier) wg_barrier(); else wave_sync(); return 0; }
 }  // namespace emu
-#define threadIdx emu::t_threadIdx
+#define pthread_barrier_wait(b) emu::sync_point(b)      // (the harnesses' pthread barriers stay initialised but idle)
+#define threadIdx emu::tid_ref()
 #define blockIdx emu::t_blockIdx
 #define gridDim emu::g_gridDim
 #define blockDim emu::g_blockDim
@@ -65,8 +124,7 @@ static inline void emu_sleep() { static thread_local unsigned n = 0; usleep(200)
 #define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, order)
 // cross-lane helpers the shared headers declare but the emulated kernels never call
-// __shfl_xor: wave-collective through a per-wave exchange buffer — ALL 64 lanes of the wave must execute it (the emulated
-// kernels only shuffle in wave-uniform control flow for the shapes the tests use)
+// __shfl_xor: wave-collective through a per-wave exchange buffer among the lanes that execute it (see Sync above)
 template <typename T> static inline T __shfl_xor(T v, int o, int = 64) {
     static_assert(sizeof(T) == 4, "32-bit shuffles only");
     emu::WaveState &w = emu::my_wave();
