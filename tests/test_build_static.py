@@ -534,3 +534,13 @@ def test_32_weight_formats_with_k_not_a_multiple_of_64_on_the_cpu(name, t, k):
         pytest.skip("the environment cannot host the emulation")
     assert r[0] < 1e-5, (name, k, r[0])
     assert mod.mul_mat_id(t, 32, k, 4, 2, 2, 1, seed=k + 1, timeout=300) < 1e-5
+
+
+@pytest.mark.parametrize("m,k,ne,nu,nb,nt", [(128, 512, 4, 2, 2, 32), (64, 256, 8, 2, 1, 40), (130, 768, 3, 2, 2, 70)])
+def test_whole_library_grouped_mul_mat_id_on_the_cpu(m, k, ne, nu, nb, nt):
+    """prefill-sized MUL_MAT_ID on Q4_K through the C-ABI on the CPU: the device-side counting sort of the expert ids (k_moe_plan), the gathering
+    activation quantizer and the grouped k_gemm_kq_t64 launch — ragged per-expert counts, padding rows, broadcast activation rows"""
+    r = _emul_module("lib_emul_check").mul_mat_id(12, m, k, ne, nu, nb, nt, seed=5, timeout=300)
+    if r is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert r < 1e-3, r

@@ -24,11 +24,11 @@ def main(n, seed):
         cus = int(rng.choice([256, 256, 8, 1]))                     # the CU count the launchers size their grids / K splits for
         if rng.random() < 0.3:
             ne, nu = int(rng.choice([2, 4, 8])), int(rng.choice([1, 2]))
-            nb, nt = int(rng.choice([1, nu])), int(rng.choice([1, 1, 2, 5]))
+            nb, nt = int(rng.choice([1, nu])), int(rng.choice([1, 1, 2, 5, 20, 40, 70]))
             t0 = time.time()
             try:
                 e = L.mul_mat_id(t, min(m, 64), k, ne, nu, nb, nt, seed=i, cus=cus, timeout=240)
-                ok = e is None or e < 1e-5
+                ok = e is None or e < (1e-3 if (t == R.Q4_K and nt * nu > 32) else 1e-5)        # Q4_K with more than 32 (token, slot) rows: the grouped MFMA GEMM
             except Exception as ex:  # noqa: BLE001
                 e, ok = repr(ex)[-200:], False
             print("%s id  type %2d m %3d k %4d experts %d used %d n_b %d tok %d  %s  %.0fs" % ("ok  " if ok else "FAIL", t, min(m, 64), k, ne, nu, nb, nt, e, time.time() - t0), flush=True)
