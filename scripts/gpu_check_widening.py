@@ -116,7 +116,7 @@ def check_formats2():
     """the formats added after round 2's last hardware session: Q2_K prefill (two-part Q6_K), Q4_1 / Q5_1 (Q8_1 activations; two-part Q8_0 prefill),
     IQ4_NL (Q8_0 re-encoding), IQ4_XS (two-part Q6_K): GEMV units at 1 / 5 rows, the prefill GEMM, to_float, MUL_MAT_ID decode"""
     rng = np.random.default_rng(2)
-    for name, t in (("q2_K", R.Q2_K), ("q4_1", R.Q4_1), ("q5_1", R.Q5_1), ("iq4_nl", R.IQ4_NL), ("iq4_xs", R.IQ4_XS)):
+    for name, t in (("q2_K", R.Q2_K), ("q4_1", R.Q4_1), ("q5_1", R.Q5_1), ("iq4_nl", R.IQ4_NL), ("iq4_xs", R.IQ4_XS), ("q4_0", R.Q4_0), ("q8_0", R.Q8_0)):
         for m, k, b in ((256, 4096, 1), (256, 4096, 5), (16, 256, 9), (130, 768, 33), (512, 2048, 128), (4096, 4096, 512)):
             w = R.random_weights(t, m, k, seed=5 * m + k)
             x = rng.uniform(-1, 1, (b, k)).astype(np.float32)
@@ -131,6 +131,12 @@ def check_formats2():
                    ok=bool(np.isfinite(y).all() and e < (1e-5 if b <= 8 else 1e-3) and np.array_equal(y, y2)))
             for p in (wd, xd):
                 hip.hipFree(p)
+        if R.BLCK[t] == 32:                              # K % 64 == 32: the routing fix of the one-launch decode kernel
+            for k in (544, 992):
+                w = R.random_weights(t, 48, k, seed=k); x = rng.uniform(-1, 1, (1, k)).astype(np.float32)
+                wd, xd = to_dev(w), to_dev(x)
+                e = R.rel_l2(mul_mat(t, wd, 48, k, xd, 1), R.o_mul_mat(t, w, x, 48, k))
+                report(test="formats2_decode_k_mod_64", type=name, k=k, rel_l2=e, ok=bool(e < 1e-5))
         if t in (R.IQ4_NL, R.IQ4_XS):
             rows, k = 9, 2048
             w = R.random_weights(t, rows, k, seed=int(t) + 1)
@@ -189,6 +195,38 @@ def check_flash_attn():
                ok=bool(np.isfinite(y).all() and ee < 1e-3 and eo < eoe + 1e-3))
 
 
+def check_flash_attn2():
+    """FLASH_ATTN_EXT paths added after round 2's last hardware session: a block-quantized K / V (one conversion pass in front of the F16 kernels) and
+    head sizes without a kernel of their own (zero-padded); against a float64 evaluation on the dequantized K / V"""
+    cases = [dict(D=128, n_q=1, n_head=8, n_kv=1024, n_head_kv=2, t=R.Q8_0), dict(D=64, n_q=35, n_head=4, n_kv=300, t=R.Q4_0), dict(D=256, n_q=3, n_head=4, n_kv=512, n_head_kv=1, t=R.Q5_1),
+             dict(D=128, n_q=200, n_head=8, n_kv=512, t=R.Q4_1), dict(D=80, n_q=35, n_head=8, n_kv=512), dict(D=80, n_q=1, n_head=32, n_kv=1024), dict(D=96, n_q=3, n_head=4, n_kv=200, n_head_kv=2, t=R.Q8_0),
+             dict(D=112, n_q=40, n_head=4, n_kv=300), dict(D=80, n_q=512, n_head=8, n_kv=512, n_head_kv=2)]
+    for c in cases:
+        D, n_q, n_head, n_kv, t = c["D"], c["n_q"], c["n_head"], c["n_kv"], c.get("t")
+        n_head_kv = c.get("n_head_kv", n_head)
+        rng = np.random.default_rng(D + n_q + n_kv)
+        q = rng.uniform(-1, 1, (1, n_head, n_q, D)).astype(np.float32)
+        mrows = (n_q + 63) // 64 * 64
+        m = rng.uniform(-1, 1, (mrows, n_kv)).astype(np.float16)
+        scale = float(1.0 / np.sqrt(D))
+        if t is None:
+            kf = rng.uniform(-1, 1, (1, n_head_kv, n_kv, D)).astype(np.float16); vf = rng.uniform(-1, 1, (1, n_head_kv, n_kv, D)).astype(np.float16)
+            dk, dv = desc(to_dev(kf), 1, 2, kf.shape), desc(to_dev(vf), 1, 2, vf.shape)
+        else:
+            rows, rb = n_head_kv * n_kv, R.row_size(t, D)
+            kb, vb = R.random_weights(t, rows, D, seed=int(t) + D), R.random_weights(t, rows, D, seed=int(t) + D + 1)
+            kf, vf = R.o_dequantize(t, kb, D).reshape(1, n_head_kv, n_kv, D), R.o_dequantize(t, vb, D).reshape(1, n_head_kv, n_kv, D)
+            dk, dv = desc(to_dev(kb), int(t), R.TYPE_SIZE[t], (1, n_head_kv, n_kv, D // 32)), desc(to_dev(vb), int(t), R.TYPE_SIZE[t], (1, n_head_kv, n_kv, D // 32))
+            dk.ne[0] = dv.ne[0] = D                                       # (desc() computed the strides from blocks per row)
+        dq, dm = desc(to_dev(q), 0, 4, q.shape), desc(to_dev(m), 1, 2, (1, 1, mrows, n_kv))
+        od = dmalloc(4 * n_q * n_head * D)
+        dd = desc(od, 0, 4, (1, n_q, n_head, D))
+        ok(L.ggml_cdna4_op_flash_attn_ext(C.byref(dq), C.byref(dk), C.byref(dv), C.byref(dm), C.byref(dd), C.c_float(scale), C.c_float(0.0), C.c_float(0.0), None), "flash_attn_ext")
+        y = to_host(od, (1, n_q, n_head, D), np.float32)
+        ee = R.rel_l2(y, R.exact_flash_attn_ext(q, kf, vf, m, scale))
+        report(test="flash_attn_ext2", D=D, n_q=n_q, n_head=n_head, n_kv=n_kv, kv_type=None if t is None else int(t), rel_l2_float64=ee, ok=bool(np.isfinite(y).all() and ee < 1e-3))
+
+
 def timed(fn, iters=20):
     """average microseconds per call between two HIP events on the null stream"""
     e0, e1 = C.c_void_p(), C.c_void_p()
@@ -245,7 +283,7 @@ def time_fa(rng, D, n_q, n_head, n_kv):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["formats", "fattn"]
-    for w, fn in (("formats", check_formats), ("formats2", check_formats2), ("fattn", check_flash_attn), ("timings", timings), ("timings_fa", lambda: timings(False))):
+    for w, fn in (("formats", check_formats), ("formats2", check_formats2), ("fattn", check_flash_attn), ("fattn2", check_flash_attn2), ("timings", timings), ("timings_fa", lambda: timings(False))):
         if w in which:
             try:
                 fn()
