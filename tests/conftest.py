@@ -8,6 +8,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("CDNA4_TESTS_ON_EMULATOR") == "1":
+        # tests/test_gpu_tests_on_the_emulator.py: selected -m gpu tests, unchanged, against the whole-library CPU emulation (tests/emul_torch.py)
+        import emul_torch
+        emul_torch.activate()
 
 
 def pytest_collection_modifyitems(config, items):

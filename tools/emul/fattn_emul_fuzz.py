@@ -18,7 +18,7 @@ def main(n, seed):
         nh_kv = int(rng.choice([1, 2, 3]))
         nh = nh_kv * int(rng.choice([1, 2, 4]))
         n_q = int(rng.choice([1, 1, 2, 3, 7, 31, 32, 33, 64, 65, 130]))
-        n_kv = int(rng.choice([1, 5, 31, 32, 33, 64, 96, 100, 255, 256, 257, 511, 700, 1025]))
+        n_kv = int(rng.choice([1, 5, 31, 32, 33, 64, 96, 100, 255, 256, 257, 511, 700, 1025, 2049, 4100]))
         kw = dict(D=D, n_q=n_q, n_head=nh, n_kv=n_kv, n_head_kv=nh_kv, n_batch=int(rng.choice([1, 1, 2])), mask=bool(rng.random() < 0.8), permuted=bool(rng.random() < 0.3),
                   cus=int(rng.choice([1, 2, 8, 256])), seed=i)
         if kw["mask"]:

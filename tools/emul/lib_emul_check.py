@@ -47,6 +47,31 @@ def build():
     return exe
 
 
+def build_so():
+    """the same build as a shared library with the library's C-ABI (+ fattn.hip, + cdna4_emul_alloc): tests/emul_torch.py"""
+    pic = os.path.join(OBJ, "pic")
+    os.makedirs(pic, exist_ok=True)
+    out = os.path.join(OBJ, "libcdna4_emul.so")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + [os.path.join(HERE, "lib_emul.h"), os.path.join(HERE, "hip_emul.h"), os.path.join(ROOT, "include", "ggml_cdna4.h")]
+    newest = max(os.path.getmtime(d) for d in deps)
+    tus = TUS + ["fattn.hip", "lib_emul_so.cpp"]
+
+    def one(f):
+        src = os.path.join(CSRC, f) if f.endswith(".hip") else os.path.join(HERE, f)
+        obj = os.path.join(pic, f + ".o")
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(newest, os.path.getmtime(src)):
+            extra = ["-DEMU_DYNAMIC_LDS"] if f == "gemv_q.hip" else []
+            inc = ["-x", "c++", "-include", os.path.join(HERE, "lib_emul.h")] if f.endswith(".hip") else []
+            subprocess.run([CLANG] + FLAGS + ["-fPIC"] + extra + inc + ["-c", src, "-o", obj], check=True, capture_output=True, timeout=900)
+            return True
+        return False
+    with ThreadPoolExecutor(max_workers=9) as ex:
+        rebuilt = any(list(ex.map(one, tus)))
+    if rebuilt or not os.path.exists(out):
+        subprocess.run([CLANG, "-shared", "-pthread", "-o", out] + [os.path.join(pic, f + ".o") for f in tus], check=True, capture_output=True, timeout=300)
+    return out
+
+
 def _run(args, env, timeout):
     r = subprocess.run(args, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **{k: str(v) for k, v in (env or {}).items()}))
     if r.returncode == 77:
