@@ -1,6 +1,6 @@
 """The -m gpu tests, UNCHANGED, against the whole-library CPU emulation: tests/emul_torch.py swaps tools/emul/lib_emul's shared library (the product's
 own kernel and host sources behind the same C-ABI) in for the GPU library and backs "cuda" tensors with shared mappings, so ggml_amd/ops.py, the
-ctypes binding, the test logic and every kernel on the route run on the CPU.  Here: a selection that finishes in about a minute (prefill GEMM and FLASH_ATTN_EXT cases are in the long run below; their
+ctypes binding, the test logic and every kernel on the route run on the CPU.  Here: a selection that finishes in under a minute (prefill GEMM and FLASH_ATTN_EXT cases are in the long run below; their
 kernels and host code are covered by test_build_static.py's whole-library and fattn harness tests).  The whole of
 tests/test_gpu_widening.py minus the full-size shapes and the tests that need the plug-in (190 tests) takes ~25 minutes:
 
@@ -15,8 +15,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SELECTION = ("(test_q4_1_q5_1_iq4_nl_gemv_parity and not 4096) or test_two_part_gemm_needs_whole_panels or test_iq4_to_float_is_bit_exact "
-             "or (test_q4_1_q5_1_iq4_nl_mul_mat_id and (4-1-False-1 or 8-4-True-5)) or (test_decode_with_k_not_a_multiple_of_64 and 544) "
+SELECTION = ("(test_q4_1_q5_1_iq4_nl_gemv_parity and (16-256-1 or 20-544-7 or 48-1024-8)) or test_two_part_gemm_needs_whole_panels or test_iq4_to_float_is_bit_exact "
+             "or (test_q4_1_q5_1_iq4_nl_mul_mat_id and (4-1-False-1 or 8-2-False-1)) or (test_decode_with_k_not_a_multiple_of_64 and 544) "
              "or (test_cpy_f32_to_q4_1_q5_0_q5_1_is_byte_exact and uniform) or (test_weight_reencoding_is_exact and 9-512) or (test_q4_1_q5_1_iq4_nl_prefill_gemm and 16-256-9)")
 
 
@@ -32,4 +32,4 @@ def test_selected_gpu_tests_pass_on_the_emulator():
     assert r.returncode == 0, tail
     import re
     m = re.search(r"(\d+) passed", r.stdout)
-    assert m and int(m.group(1)) >= 40, tail
+    assert m and int(m.group(1)) >= 30, tail
