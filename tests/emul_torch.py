@@ -67,7 +67,15 @@ def activate():
             return to_shared(self)                    # `.to(b.device)` inside the wrappers: stay in shared memory
         return real_to(self, *a, **k)
     torch.empty, torch.zeros = empty, empty
+    def full(size, fill_value, dtype=None, device=None, **kw):
+        t = _shared_tensor(_size((size,)) if isinstance(size, int) else tuple(size), dtype or torch.float32)
+        t.fill_(fill_value)
+        return t
+    torch.full = full
+    torch.ones = lambda *size, dtype=None, device=None, **kw: full(_size(size), 1, dtype=dtype)
+    torch.empty_like = torch.zeros_like = lambda t, dtype=None, **kw: _shared_tensor(t.shape, dtype or t.dtype)
     torch.Tensor.cuda = lambda self, *a, **k: to_shared(self)
+    torch.Tensor.clone = lambda self, *a, **k: to_shared(self)
     torch.Tensor.to = to
     torch.Tensor.is_cuda = property(lambda self: True)
 
