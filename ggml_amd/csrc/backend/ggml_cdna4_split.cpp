@@ -196,6 +196,7 @@ enum ggml_status cdna4_split_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst)
         const int dev = st->dev[i];
         const bool local = dev == ctx->device && !bc->self;
         if (local) {                                                                    // the main device's shard: straight into dst, on the main stream
+            HIP_OK(hipSetDevice(ctx->device));                                          // (a remote shard in front of it left ITS device current: main_device > 0)
             void * ws = ctx->need_ws(ws_need);
             if (!ws) return GGML_STATUS_ALLOC_FAILED;
             if (ggml_cdna4_mul_mat((int)a->type, st->data[i], (int64_t)a->nb[1], (const float *)b->data, K, (float *)dst->data + st->lo[i], M, rows, K, B,

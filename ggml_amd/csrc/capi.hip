@@ -113,6 +113,11 @@ int ggml_cdna4_quantize_q8_0(const float *x, int64_t x_row_stride, int64_t K, in
     return cdna4_launch_quantize_q8_0(x, x_row_stride, K, B, qs, d, xh, ref_rounding != 0, (hipStream_t)stream);
 }
 
+int ggml_cdna4_quantize_q8_1(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d, float *s, void *xh, void *stream) {
+    if (((uintptr_t)x | (uintptr_t)(x_row_stride * 4)) & 15) return cdna4_set_error_msg("quantize_q8_1: x must be 16-byte aligned");
+    return cdna4_launch_quantize_q8_1(x, x_row_stride, K, B, qs, d, s, xh, (hipStream_t)stream);
+}
+
 static int resolve_path(int type, int path, int64_t M, int64_t K, int64_t B) {
     if (path == GGML_CDNA4_PATH_AUTO) return (B > 8 && cdna4_gemm_q_supported(type, M, K, B)) ? GGML_CDNA4_PATH_GEMM : GGML_CDNA4_PATH_GEMV;
     return path;
@@ -196,10 +201,21 @@ int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float
                        int64_t M, int64_t K, int64_t B, void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, void *stream) {
     return mul_mat_impl(type, W, w_row_bytes, X, x_row_stride, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, cdna4_epilogue{}, stream);
 }
+// the GEMV routes (B <= 8) apply the tail where the element is reduced; the MFMA GEMM route writes the product first (k_epilogue behind it)
+int ggml_cdna4_mul_mat_fused_residual_may_alias(int type, int64_t M, int64_t K, int64_t B) {
+    return resolve_path(type, GGML_CDNA4_PATH_AUTO, M, K, B) == GGML_CDNA4_PATH_GEMV ? 1 : 0;
+}
 int ggml_cdna4_mul_mat_fused(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
                              int64_t M, int64_t K, int64_t B, const float *bias, int act, const float *residual, int64_t residual_row_stride,
                              void *workspace, size_t workspace_bytes, void *stream) {
     if (act != 0 && act != 1) return cdna4_set_error_msg("mul_mat_fused: act is 0 (none) or 1 (GELU)");
+    if (residual && M > 0 && B > 0) {
+        const char *r0 = (const char *)residual, *r1 = (const char *)(residual + (B - 1) * residual_row_stride + M);
+        const char *y0 = (const char *)Y, *y1 = (const char *)(Y + (B - 1) * y_row_stride + M);
+        const bool overlap = r0 < y1 && y0 < r1, exact = residual == Y && residual_row_stride == y_row_stride;
+        if (overlap && !(exact && ggml_cdna4_mul_mat_fused_residual_may_alias(type, M, K, B)))
+            return cdna4_set_error_msg("mul_mat_fused: residual overlaps Y (only an exact alias is allowed, and only where ggml_cdna4_mul_mat_fused_residual_may_alias says so)");
+    }
     cdna4_epilogue e{}; e.bias = bias; e.resid = residual; e.resid_row_stride = residual_row_stride; e.act = act;
     return mul_mat_impl(type, W, w_row_bytes, X, x_row_stride, Y, y_row_stride, M, K, B, workspace, workspace_bytes, GGML_CDNA4_PATH_AUTO, 0, 0, e, stream);
 }

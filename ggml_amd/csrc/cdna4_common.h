@@ -73,7 +73,12 @@ __device__ __forceinline__ uint16_t ld_u16(const uint8_t *p) { return *reinterpr
 __device__ __forceinline__ u32x4 ld_u32x4(const void *p) { return *reinterpret_cast<const u32x4 *>(p); }
 
 __device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(half_t, h); }
-__device__ __forceinline__ uint16_t f2h_bits(float f) { return __builtin_bit_cast(uint16_t, (half_t)f); }   // RNE
+// fp32 -> fp16 bits, RNE, of the fp32 VALUE f.  The empty asm keeps f opaque: hipcc otherwise folds a producing multiply into the conversion
+// (v_fma_mixlo_f16 a, b, 0 — ONE rounding of the exact product) where the CPU rounds the product to fp32 first and that to fp16; the two
+// differ by one fp16 ulp when the fp32 rounding lands on an fp16 tie.  Seen on MI355X as block_q8_1.s = fp16(d * sum) one ulp off the
+// reference in one block of 256 (round 2's only hardware parity failure); the CPU emulator, which converts in two steps, could not see it.
+__device__ __forceinline__ float opaque_f32(float f) { asm("" : "+v"(f)); return f; }
+__device__ __forceinline__ uint16_t f2h_bits(float f) { return __builtin_bit_cast(uint16_t, (half_t)opaque_f32(f)); }
 // four 4-bit codes (one per byte, 0..15) -> their four int8 codebook values kvalues_iq4nl[] = {-127, -104, -83, -65, -49, -35, -22, -10,
 // 1, 13, 25, 38, 53, 69, 89, 113} (src/ggml-quants.c:2434), packed the same way.  Plain shifts of the table held in two 64-bit constants.
 __device__ __forceinline__ uint32_t iq4nl_lut4(uint32_t codes) {

@@ -15,7 +15,7 @@ __device__ __forceinline__ float gelu_lut_f32(float v) {
     if (v <= -10.0f) return 0.0f;
     if (v >= 10.0f) return v;
     const float xh = (float)(half_t)v;
-    float r = (float)(half_t)gelu_f32(xh);
+    float r = (float)(half_t)opaque_f32(gelu_f32(xh));     // the table entry is fp16 of the fp32 VALUE (no multiply folded into the conversion)
     if (r == 0.0f) r = __builtin_copysignf(0.0f, xh);          // x * 0 keeps x's sign on the CPU (-0.0 for x <= -5.2): make the zero's sign explicit
     return r;
 }

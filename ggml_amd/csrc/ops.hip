@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_unary(const float *__restrict__ x, floa
         r = gelu_lut_f32(v);
     } else if (OP == GGML_CDNA4_GELU_QUICK) {
         if (v <= -10.0f || v >= 10.0f) { r = v * (1.0f / (1.0f + expf(-1.702f * v))); }
-        else { const float xh = (float)(half_t)v; r = (float)(half_t)(xh * (1.0f / (1.0f + expf(-1.702f * xh)))); if (r == 0.0f) r = __builtin_copysignf(0.0f, xh); }
+        else { const float xh = (float)(half_t)v; r = (float)(half_t)opaque_f32(xh * (1.0f / (1.0f + expf(-1.702f * xh)))); if (r == 0.0f) r = __builtin_copysignf(0.0f, xh); }
     } else if (OP == GGML_CDNA4_SILU) r = v / (1.0f + expf(-v));
     else if (OP == GGML_CDNA4_RELU) r = v > 0.f ? v : 0.f;
     else r = tanhf(v);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_q_to_f16_dense(const T4 a, half_t *__re
     if (i >= n) return;
     const idx4 x = unravel(i, a.ne);
     const uint8_t *row = (const uint8_t *)a.data + x.i1 * a.nb[1] + x.i2 * a.nb[2] + x.i3 * a.nb[3];
-    dst[(i / a.ne[0]) * dst_row + x.i0] = (half_t)deq_elem<TYPE>(row, x.i0);
+    dst[(i / a.ne[0]) * dst_row + x.i0] = (half_t)opaque_f32(deq_elem<TYPE>(row, x.i0));     // fp16 of the fp32 VALUE to_float gives (two roundings, like the CPU)
 }
 // F32 -> Q4_0 / Q8_0: one thread per 32-block; src rows contiguous in ne[0], dst blocks enumerated in logical order
 template <int TYPE, bool REF>

@@ -20,6 +20,7 @@ SYMBOLS = [
     ("ggml_cdna4_mul_mat_workspace_size", _sz, [_int, _i64, _i64]),
     ("ggml_cdna4_mul_mat", _int, [_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _int, _int, _int, _vp]),
     ("ggml_cdna4_mul_mat_fused", _int, [_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp, _i64, _vp, _sz, _vp]),
+    ("ggml_cdna4_mul_mat_fused_residual_may_alias", _int, [_int, _i64, _i64, _i64]),
     ("ggml_cdna4_prepare_act", _int, [_int, _vp, _i64, _i64, _i64, _vp, _sz, _int, _vp]),
     ("ggml_cdna4_mul_mat_prepared", _int, [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _int, _int, _int, _vp]),
     ("ggml_cdna4_mul_mat_id_workspace_size", _sz, [_int, _i64, _i64, _i64, _i64, _i64]),
@@ -27,6 +28,7 @@ SYMBOLS = [
                                      _i64, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
     ("ggml_cdna4_quantize_q8_K", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     ("ggml_cdna4_quantize_q8_0", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp]),
+    ("ggml_cdna4_quantize_q8_1", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     # supporting ops: tensors are POINTER(Tensor) descriptors
     ("ggml_cdna4_op_binary", _int, [_int, _vp, _vp, _vp, _vp]),
     ("ggml_cdna4_op_scale", _int, [_vp, _vp, C.c_float, _vp]),

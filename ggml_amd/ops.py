@@ -179,6 +179,22 @@ def quantize_row_q8_0(x: torch.Tensor, ref_rounding=False, want_f16=False):
     return (qs, d, xh) if want_f16 else (qs, d)
 
 
+def quantize_row_q8_1(x: torch.Tensor, want_f16=False):
+    """from_float of GGML_TYPE_Q8_1 as the CPU backend runs it for the activations of Q4_1 / Q5_1 weights (AVX2 body of quantize_row_q8_1,
+    src/ggml-cpu/ggml-cpu-quants.c:1076-1119).  Returns (qs int8 (B,K), d f32 (B,K/32) = the fp16-rounded scale, s f32 (B,K/32) =
+    fp16(d * sum q) with d still in fp32[, xh])."""
+    L = native.lib()
+    _need_gpu(x, "x")
+    B, K = x.shape
+    qs = torch.empty((B, K), dtype=torch.int8, device=x.device)
+    d = torch.empty((B, K // 32), dtype=torch.float32, device=x.device)
+    s = torch.empty((B, K // 32), dtype=torch.float32, device=x.device)
+    xh = torch.empty((B, (K + 127) // 128 * 128), dtype=torch.float16, device=x.device) if want_f16 else None
+    native.check(L.ggml_cdna4_quantize_q8_1(x.data_ptr(), x.stride(0), K, B, qs.data_ptr(), d.data_ptr(), s.data_ptr(),
+                                            xh.data_ptr() if want_f16 else None, _stream(x.device)))
+    return (qs, d, s, xh) if want_f16 else (qs, d, s)
+
+
 def convert_weights(a: QTensor) -> QTensor:
     """exact re-encoding of a Q5_0 / Q3_K matrix as Q8_0 / Q6_K (ggml_cdna4_convert_weights): same dequantized values bit for bit, and
     the MFMA prefill GEMM of the target format.  mul_mat does this per call for more than 8 activation rows; converting once trades

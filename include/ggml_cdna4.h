@@ -18,6 +18,8 @@
  *   ggml_cdna4_quantize_q8_K    quantize_row_q8_K (from_float of Q8_K) src/ggml-quants.c:2479-2516
  *   ggml_cdna4_quantize_q8_0    quantize_row_q8_0 (AVX2 body / _ref)   src/ggml-cpu/ggml-cpu-quants.c:778-815,
  *                                                                       src/ggml-quants.c:194-217
+ *   ggml_cdna4_quantize_q8_1    quantize_row_q8_1 (AVX2 body)          src/ggml-cpu/ggml-cpu-quants.c:1076-1119
+ *                               (from_float of Q8_1 = vec_dot_type of Q4_1 / Q5_1: src/ggml-cpu/ggml-cpu.c:271-296)
  *   ggml_cdna4_dequantize_row   type_traits[].to_float                 src/ggml-quants.c:255,349,1280,1482,1690
  *   ggml_cdna4_row_size         ggml_row_size                          src/ggml.c:1176-1179
  */
@@ -132,6 +134,11 @@ int ggml_cdna4_mul_mat_id(int type, const void * as, int64_t w_row_bytes, int64_
 int ggml_cdna4_mul_mat_fused(int type, const void * W, int64_t w_row_bytes, const float * X, int64_t x_row_stride, float * Y, int64_t y_row_stride,
                              int64_t M, int64_t K, int64_t B, const float * bias, int act, const float * residual, int64_t residual_row_stride,
                              void * workspace, size_t workspace_bytes, void * stream);
+/* `residual` may alias Y EXACTLY (same pointer and row stride: an in-place ADD) only when the tail is applied by the store that produces the
+ * element; this says whether that holds for a call of this shape (1) or whether residual and Y must not overlap at all (0: the product is
+ * written first and the tail is a pass over Y — an aliased residual would already be overwritten).  ggml_cdna4_mul_mat_fused returns an error
+ * for an overlap it cannot honour; partial overlaps are always an error. */
+int ggml_cdna4_mul_mat_fused_residual_may_alias(int type, int64_t M, int64_t K, int64_t B);
 
 /* Activation quantizers (bit-exact with the reference); outputs may be NULL to skip them.
  *   qs  int8  [B][K]      d  f32 [B][K/256 | K/32]      bsums int16 [B][K/16] (Q8_K only)
@@ -141,6 +148,10 @@ int ggml_cdna4_quantize_q8_K(const float * x, int64_t x_row_stride, int64_t K, i
                              int8_t * qs, float * d, int16_t * bsums, void * xh, void * stream);
 int ggml_cdna4_quantize_q8_0(const float * x, int64_t x_row_stride, int64_t K, int64_t B,
                              int8_t * qs, float * d, void * xh, int ref_rounding, void * stream);
+/* Q8_1 (activations of Q4_1 / Q5_1 weights): the Q8_0 block of the AVX2 body plus s f32 [B][K/32] holding block_q8_1.s =
+ * fp16(d * sum of the block's 32 quants) with d still in fp32 (two roundings: fp32 product, then fp16), widened to fp32 like d */
+int ggml_cdna4_quantize_q8_1(const float * x, int64_t x_row_stride, int64_t K, int64_t B,
+                             int8_t * qs, float * d, float * s, void * xh, void * stream);
 
 
 /* ---------------------------------------------------------------------------------------------------------

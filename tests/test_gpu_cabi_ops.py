@@ -235,6 +235,40 @@ def test_mul_mat_fused_equals_the_unfused_sequence_bit_for_bit(L, name, t, b, ta
     assert np.array_equal(yf.cpu().numpy().view(np.uint32), y2.cpu().numpy().view(np.uint32))
 
 
+@pytest.mark.parametrize("b", [1, 5, 96, 512])
+@pytest.mark.parametrize("name,t", [("q4_0", R.Q4_0), ("q4_K", R.Q4_K), ("q6_K", R.Q6_K)])
+def test_mul_mat_fused_with_the_residual_in_place(L, name, t, b):
+    """residual == Y (ggml_add_inplace(resid, cur), or the graph allocator placing the ADD onto its residual — ADVICE r2, high): where
+    ggml_cdna4_mul_mat_fused_residual_may_alias says 1 the in-place call equals the out-of-place one bit for bit; where it says 0 the call is
+    refused (never a silently doubled product); a partial overlap is always refused"""
+    m, k = 768, 768
+    w = R.random_weights(t, m, k, seed=22)
+    rng = np.random.default_rng(6)
+    x = rng.uniform(-1, 1, (b, k)).astype(np.float32)
+    bias = rng.standard_normal(m).astype(np.float32)
+    res = rng.standard_normal((b + 1, m)).astype(np.float32)
+    wd, xd, bd, rd = _dev(w), _dev(x), _dev(bias), _dev(res)
+    ws = torch.empty(max(L.ggml_cdna4_mul_mat_workspace_size(int(t), k, b), 256), dtype=torch.uint8, device="cuda")
+    rb = R.row_size(t, k)
+    y = torch.empty((b, m), dtype=torch.float32, device="cuda")
+    _ok(L, L.ggml_cdna4_mul_mat_fused(int(t), wd.data_ptr(), rb, xd.data_ptr(), k, y.data_ptr(), m, m, k, b, bd.data_ptr(), 0, rd.data_ptr(), m, ws.data_ptr(), ws.numel(), _st()))
+    inplace = rd.clone()
+    rc = L.ggml_cdna4_mul_mat_fused(int(t), wd.data_ptr(), rb, xd.data_ptr(), k, inplace.data_ptr(), m, m, k, b, bd.data_ptr(), 0, inplace.data_ptr(), m, ws.data_ptr(), ws.numel(), _st())
+    torch.cuda.synchronize()
+    if L.ggml_cdna4_mul_mat_fused_residual_may_alias(int(t), m, k, b):
+        assert rc == 0, L.ggml_cdna4_last_error()
+        assert np.array_equal(inplace[:b].cpu().numpy().view(np.uint32), y.cpu().numpy().view(np.uint32))
+    else:
+        assert rc != 0 and b"residual" in L.ggml_cdna4_last_error()
+        assert np.array_equal(inplace.cpu().numpy(), res)                       # refused before anything was written
+    # shifted by one row: partial overlap, refused in every regime
+    sh = rd.clone()
+    rc = L.ggml_cdna4_mul_mat_fused(int(t), wd.data_ptr(), rb, xd.data_ptr(), k, sh.data_ptr(), m, m, k, b, bd.data_ptr(), 0, sh.data_ptr() + 4 * m, m, ws.data_ptr(), ws.numel(), _st())
+    if b > 1:
+        assert rc != 0
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("rms", [0, 1])
 @pytest.mark.parametrize("with_shift", [False, True])
 def test_norm_affine_equals_norm_mul_add(L, rms, with_shift):

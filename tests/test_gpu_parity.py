@@ -81,6 +81,27 @@ def test_quantize_q8_0_bit_exact(gu, kind, ref_rounding):
     _same_f16(gu.uninterleave(xh), want)
 
 
+@pytest.mark.parametrize("kind", ["uniform", "normal", "ties", "cos"])
+def test_quantize_q8_1_bit_exact(gu, kind):
+    """block_q8_1 of the CPU backend (AVX2 body, ggml-cpu-quants.c:1076-1119) bit for bit: quants, d, and s = fp16(fp32(d * sum q)) — the
+    product rounded to fp32 FIRST (round 2: hipcc folded the multiply into the conversion, one rounding, one fp16 ulp off in ~1 block of 256).
+    8192 blocks per case so that a folded conversion cannot hide."""
+    from ggml_amd import ops
+    x = _x(7, 64, 4096, kind)
+    x[2, 32:64] = 0
+    qs, d, s, xh = [t.cpu().numpy() for t in ops.quantize_row_q8_1(gu.to_dev(x), want_f16=True)]
+    ref = R.o_quantize_act(R.Q4_1, x).reshape(64, -1, 36)
+    rd = ref[:, :, 0:2].copy().view(np.float16).astype(np.float32).reshape(64, -1)
+    rs = ref[:, :, 2:4].copy().view(np.float16).astype(np.float32).reshape(64, -1)
+    rq = ref[:, :, 4:36].copy().view(np.int8).reshape(64, -1)
+    assert np.array_equal(qs, rq)
+    assert np.array_equal(d, rd)
+    bad = np.argwhere(s != rs)
+    assert bad.size == 0, "%d of %d s values differ, first at %s: got %r want %r" % (len(bad), s.size, bad[0], s[tuple(bad[0])], rs[tuple(bad[0])])
+    want = (np.repeat(rd, 32, axis=1) * rq.astype(np.float32)).astype(np.float16)
+    _same_f16(gu.uninterleave(xh), want)
+
+
 # ------------------------------------------------------------------------------------------------ golden
 @pytest.mark.parametrize("name,t", WT)
 def test_golden_fixture_gemv_and_gemm(gu, name, t):
