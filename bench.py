@@ -212,8 +212,12 @@ def shape_row(dev, t, m, k, b, steps):
     us = events_us(h.gemm_only, steps, 20)
     step_us = events_us(h.step, steps, 10)
     tf = h.flops / us / 1e6
-    return {"shape": [m, k, b], "gemm_us": round(us, 3), "gemm_tflops": round(tf, 1), "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4), "step_us": round(step_us, 3),
-            "step_tflops": round(h.flops / step_us / 1e6, 1), "kernel": kernel_name(t, m, k, b), "data": how}
+    row = {"shape": [m, k, b], "gemm_us": round(us, 3), "gemm_tflops": round(tf, 1), "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4), "step_us": round(step_us, 3),
+           "step_tflops": round(h.flops / step_us / 1e6, 1), "kernel": kernel_name(t, m, k, b), "data": how}
+    del h
+    lc = library_ceiling(dev, m, k, b, max(10, steps // 2))             # what the vendor library makes of this shape on fp16 weights (is 0.70 attainable here?)
+    row["library_ceiling"] = {kk: lc[kk] for kk in ("us_per_launch", "tflops", "frac", "error") if kk in lc}
+    return row
 
 
 def decode_rows(dev, steps):

@@ -147,8 +147,24 @@ int ggml_cdna4_prepare_act(int type, const float *X, int64_t x_row_stride, int64
     return e == hipSuccess ? 0 : cdna4_set_error(e, __FILE__, __LINE__);
 }
 
+static cdna4_gemm_args gemm_args_of(int type, const void *W, int64_t w_row_bytes, const void *xh, float *Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,
+                                    int gemm_variant, int splitk, const cdna4_epilogue &epi) {
+    cdna4_gemm_args a{};
+    a.type = type; a.W = (const uint8_t *)W; a.w_row_bytes = w_row_bytes; a.xh = xh; a.xh_row_elems = K;
+    a.Y = Y; a.y_row_elems = y_row_stride; a.M = (int)M; a.K = (int)K; a.B = (int)B; a.variant = gemm_variant; a.splitk = splitk; a.epi = epi;
+    return a;
+}
+// epi: the MUL_MAT's tail; *tail_done says whether the launch applied it (GEMM route on k_gemm_kq_t64) — otherwise the caller appends k_epilogue
+static int mul_mat_prepared_impl(int type, const void *W, int64_t w_row_bytes, float *Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,
+                                 const void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, const cdna4_epilogue &epi, bool *tail_done, void *stream);
 int ggml_cdna4_mul_mat_prepared(int type, const void *W, int64_t w_row_bytes, float *Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,
                                 const void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, void *stream) {
+    bool done = false;
+    return mul_mat_prepared_impl(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, cdna4_epilogue{}, &done, stream);
+}
+static int mul_mat_prepared_impl(int type, const void *W, int64_t w_row_bytes, float *Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,
+                                 const void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, const cdna4_epilogue &epi, bool *tail_done, void *stream) {
+    *tail_done = false;
     if (!is_q(type)) return cdna4_set_error_msg("mul_mat: unsupported weight type");
     if (M <= 0 || B <= 0) return 0;
     if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat: K is not a whole number of blocks");
@@ -156,14 +172,14 @@ int ggml_cdna4_mul_mat_prepared(int type, const void *W, int64_t w_row_bytes, fl
     if (workspace_bytes < v.total) return cdna4_set_error_msg("mul_mat: workspace too small");
     path = resolve_path(type, path, M, K, B);
     if (path == GGML_CDNA4_PATH_GEMM) {
-        cdna4_gemm_args a{};
-        a.type = type; a.W = (const uint8_t *)W; a.w_row_bytes = w_row_bytes; a.xh = v.xh; a.xh_row_elems = K;
-        a.Y = Y; a.y_row_elems = y_row_stride; a.M = (int)M; a.K = (int)K; a.B = (int)B; a.variant = gemm_variant; a.splitk = splitk;
+        const cdna4_gemm_args a = gemm_args_of(type, W, w_row_bytes, v.xh, Y, y_row_stride, M, K, B, gemm_variant, splitk, epi);
+        *tail_done = cdna4_gemm_q_fuses_tail(a);
         return cdna4_launch_gemm_q(a, (hipStream_t)stream);
     }
     cdna4_gemv_args g{};
     g.type = type; g.W = (const uint8_t *)W; g.w_row_bytes = w_row_bytes; g.qs = v.qs; g.d = v.d; g.bsums = v.bsums;
-    g.Y = Y; g.y_col_stride = y_row_stride; g.M = (int)M; g.K = (int)K; g.ncol = (int)B; g.ids = nullptr;
+    g.Y = Y; g.y_col_stride = y_row_stride; g.M = (int)M; g.K = (int)K; g.ncol = (int)B; g.ids = nullptr; g.epi = epi;
+    *tail_done = true;
     return cdna4_launch_gemv_q(g, (hipStream_t)stream);
 }
 
@@ -193,17 +209,20 @@ static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const floa
         if (cdna4_gemv_staged_supported(type, K, B)) return cdna4_launch_gemv_q_staged(g, (hipStream_t)stream);    // 2..8 rows: columns from LDS
         return cdna4_launch_gemv_q(g, (hipStream_t)stream);
     }
-    rc = ggml_cdna4_mul_mat_prepared(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, stream);
-    if (rc) return rc;
-    return cdna4_launch_epilogue(Y, y_row_stride, M, B, epi, (hipStream_t)stream);       // GEMM path: one element-wise launch for the whole tail
+    bool tail_done = false;
+    rc = mul_mat_prepared_impl(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, epi, &tail_done, stream);
+    if (rc || tail_done) return rc;                                      // Q4_K: the tail went out with k_gemm_kq_t64's store
+    return cdna4_launch_epilogue(Y, y_row_stride, M, B, epi, (hipStream_t)stream);       // the older GEMM kernels: one element-wise launch for the whole tail
 }
 int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
                        int64_t M, int64_t K, int64_t B, void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, void *stream) {
     return mul_mat_impl(type, W, w_row_bytes, X, x_row_stride, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, cdna4_epilogue{}, stream);
 }
-// the GEMV routes (B <= 8) apply the tail where the element is reduced; the MFMA GEMM route writes the product first (k_epilogue behind it)
+// the GEMV routes (B <= 8) apply the tail where the element is reduced, and so does the Q4_K GEMM (k_gemm_kq_t64, on 16-byte-aligned rows: what every
+// ggml buffer of the plug-in and every torch allocation gives); the older MFMA GEMM kernels write the product first (k_epilogue behind them)
 int ggml_cdna4_mul_mat_fused_residual_may_alias(int type, int64_t M, int64_t K, int64_t B) {
-    return resolve_path(type, GGML_CDNA4_PATH_AUTO, M, K, B) == GGML_CDNA4_PATH_GEMV ? 1 : 0;
+    if (resolve_path(type, GGML_CDNA4_PATH_AUTO, M, K, B) == GGML_CDNA4_PATH_GEMV) return 1;
+    return (type == CDNA4_Q4_K && K % 256 == 0) ? 1 : 0;
 }
 int ggml_cdna4_mul_mat_fused(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
                              int64_t M, int64_t K, int64_t B, const float *bias, int act, const float *residual, int64_t residual_row_stride,
@@ -213,7 +232,10 @@ int ggml_cdna4_mul_mat_fused(int type, const void *W, int64_t w_row_bytes, const
         const char *r0 = (const char *)residual, *r1 = (const char *)(residual + (B - 1) * residual_row_stride + M);
         const char *y0 = (const char *)Y, *y1 = (const char *)(Y + (B - 1) * y_row_stride + M);
         const bool overlap = r0 < y1 && y0 < r1, exact = residual == Y && residual_row_stride == y_row_stride;
-        if (overlap && !(exact && ggml_cdna4_mul_mat_fused_residual_may_alias(type, M, K, B)))
+        bool ok = exact && ggml_cdna4_mul_mat_fused_residual_may_alias(type, M, K, B);
+        if (ok && resolve_path(type, GGML_CDNA4_PATH_AUTO, M, K, B) == GGML_CDNA4_PATH_GEMM)     // the query cannot see the pointers: the fused GEMM needs aligned rows
+            ok = cdna4_gemm_q_fuses_tail(gemm_args_of(type, W, w_row_bytes, workspace, Y, y_row_stride, M, K, B, 0, 0, cdna4_epilogue{}));
+        if (overlap && !ok)
             return cdna4_set_error_msg("mul_mat_fused: residual overlaps Y (only an exact alias is allowed, and only where ggml_cdna4_mul_mat_fused_residual_may_alias says so)");
     }
     cdna4_epilogue e{}; e.bias = bias; e.resid = residual; e.resid_row_stride = residual_row_stride; e.act = act;

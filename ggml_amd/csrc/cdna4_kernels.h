@@ -65,8 +65,12 @@ struct cdna4_gemm_args {
     int M, K, B;
     int variant;                                    // 0 = auto; see gemm_q_mfma.hip
     int splitk;                                     // 0 = auto
+    cdna4_epilogue epi;                             // the MUL_MAT's element-wise tail (zeroed = none): applied IN THE STORE by the kernels for which
+                                                    // cdna4_gemm_q_fuses_tail() holds; the others ignore it (the caller appends cdna4_launch_epilogue)
 };
 int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st);
+// does cdna4_launch_gemm_q(a) apply a.epi itself (bias / GELU / residual in the store of k_gemm_kq_t64)?  Then a residual may alias Y exactly.
+bool cdna4_gemm_q_fuses_tail(const cdna4_gemm_args &a);
 // gemm_q_t64.hip — grouped MUL_MAT_ID: a.B = rows of the expert-sorted activation image, a.Y rows indexed through row_dst
 int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);
 bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B);

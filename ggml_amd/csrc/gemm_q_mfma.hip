@@ -583,6 +583,14 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     return wide ? launch_variant<TYPE, 4, false>(a, splitk, st) : launch_variant<TYPE, 2, false>(a, splitk, st);
 }
 
+// the launches below that end in k_gemm_kq_t64 apply a.epi in their store (gemm_kq_t64.inc): Q4_K on 16-byte-aligned rows, auto or forced-t64 variant,
+// the deterministic K splits.  MUST mirror launch_type<CDNA4_Q4_K>'s routing.
+bool cdna4_gemm_q_fuses_tail(const cdna4_gemm_args &a) {
+    if (a.type != CDNA4_Q4_K || a.M <= 0 || a.B <= 0 || a.K % 256 || a.K < 256) return false;
+    if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) || ((uintptr_t)a.xh & 15)) return false;
+    return (a.variant > 0 && (a.variant & 8192)) || (a.variant <= 0 && a.splitk <= 2);
+}
+
 int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
     if (a.M <= 0 || a.B <= 0) return 0;
     if (!cdna4_gemm_q_supported(a.type, a.M, a.K, a.B)) return cdna4_set_error_msg("gemm_q: unsupported type / shape");

@@ -14,8 +14,10 @@
 //    for contiguous 32 KiB stage blocks (tools/microbench/l2_stream.hip).  Panel-major makes a stage contiguous.
 // Compiled with -ffp-contract=off: iscale*x must round before the integer conversion, as on the CPU.
 #include "cdna4_common.h"
+#include <stdlib.h>
 #include "cdna4_kernels.h"
 #include "quantize_dev.h"
+#include "gemm_q_hw.h"
 
 __device__ __forceinline__ u32x2 pack4h(half_t a, half_t b, half_t c, half_t d) {
     const half2_t lo = {a, b}, hi = {c, d};
@@ -27,7 +29,7 @@ __device__ __forceinline__ u32x2 pack4h(half_t a, half_t b, half_t c, half_t d) 
 // 6 rounds — took 6.0 us for the 512 x 4096 headline batch; the per-lane work is what the fused decode kernel uses too.)
 __global__ __launch_bounds__(256) void k_quantize_q8_K(const float *__restrict__ x, int64_t x_row_stride, int K, int B,
                                                        int8_t *__restrict__ qs, float *__restrict__ dd,
-                                                       int16_t *__restrict__ bsums, half_t *__restrict__ xh, const int32_t *__restrict__ src_rows) {
+                                                       int16_t *__restrict__ bsums, half_t *__restrict__ xh, const int32_t *__restrict__ src_rows, int store_mode) {
     const int nch = K / 16;                                                  // 16-element chunks per row
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;              // chunk id over [B][nch]
     if (t >= (int64_t)B * nch) return;                                       // whole 16-lane groups drop out together (nch % 16 == 0)
@@ -79,7 +81,10 @@ __global__ __launch_bounds__(256) void k_quantize_q8_K(const float *__restrict__
         { const u32x2 a0 = pack4h(hv[0], hv[2], hv[1], hv[3]), a1 = pack4h(hv[4], hv[6], hv[5], hv[7]);
           const u32x2 a2 = pack4h(hv[8], hv[10], hv[9], hv[11]), a3 = pack4h(hv[12], hv[14], hv[13], hv[15]);
           lo.x = a0.x; lo.y = a0.y; lo.z = a1.x; lo.w = a1.y; hi.x = a2.x; hi.y = a2.y; hi.z = a3.x; hi.w = a3.y; }
-        *reinterpret_cast<u32x4 *>(dst) = lo; *reinterpret_cast<u32x4 *>(dst + 8) = hi;
+        // store_mode 1 (experiment, CDNA4_QUANT_STORE): write-through — the image is read next by work-groups on all eight XCDs, i.e. from memory
+        // anyway; leaving no dirty lines in this XCD's L2 shortens the kernel boundary in front of the GEMM
+        if (store_mode & 1) { CDNA4_STORE_B128_SC1(reinterpret_cast<u32x4 *>(dst), lo); CDNA4_STORE_B128_SC1(reinterpret_cast<u32x4 *>(dst + 8), hi); }
+        else { *reinterpret_cast<u32x4 *>(dst) = lo; *reinterpret_cast<u32x4 *>(dst + 8) = hi; }
     }
 }
 
@@ -150,7 +155,8 @@ int cdna4_launch_quantize_q8_K(const float *x, int64_t x_row_stride, int64_t K, 
     if (K % QK_K) return cdna4_set_error_msg("quantize_q8_K: K must be a multiple of 256");
     if (B == 0 || K == 0) return 0;
     const int64_t nthr = B * (K / 16);
-    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, bsums, (half_t *)xh, (const int32_t *)nullptr);
+    static const int sm = getenv("CDNA4_QUANT_STORE") ? atoi(getenv("CDNA4_QUANT_STORE")) : 0;
+    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, bsums, (half_t *)xh, (const int32_t *)nullptr, sm);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
@@ -203,7 +209,7 @@ int cdna4_launch_quantize_q8_K_gather(const float *x, int64_t x_row_stride, int6
     if (K % QK_K) return cdna4_set_error_msg("quantize_q8_K: K must be a multiple of 256");
     if (img_rows == 0 || K == 0) return 0;
     const int64_t nthr = img_rows * (K / 16);
-    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)img_rows, (int8_t *)nullptr, (float *)nullptr, (int16_t *)nullptr, (half_t *)xh, src_rows);
+    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)img_rows, (int8_t *)nullptr, (float *)nullptr, (int16_t *)nullptr, (half_t *)xh, src_rows, 0);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

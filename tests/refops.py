@@ -157,3 +157,20 @@ def flash_attn_ext(q, k, v, mask, scale, max_bias=0.0, logit_softcap=0.0, n_thre
         t = r.base.ggml_flash_attn_ext(r.ctx, tq, tk, tv, tm, C.c_float(scale), C.c_float(max_bias), C.c_float(logit_softcap))
         r.compute(t, n_threads)
         return r.read(t, R.F32, (nb, nq, nh, D))
+
+
+def mul_mat_tail(wtype, w_bytes, m, k, x, bias, gelu, resid, n_threads=8):
+    """the chain the gpt-2 graphs put behind every projection (examples/gpt-2/main-backend.cpp:515-521, 656-666), evaluated node by node on the
+    reference CPU backend: ggml_mul_mat(W, x) -> ggml_add(bias) -> ggml_gelu | ggml_add(residual).  x (B, K) f32 -> (B, M) f32"""
+    b = x.shape[0]
+    with Ref(mem=(1 << 28) + w_bytes.size + 16 * b * (m + k)) as r:
+        tw = r.tensor(wtype, [k, m], w_bytes)
+        tx = r.tensor(R.F32, [k, b], x.astype(np.float32))
+        t = r.base.ggml_mul_mat(r.ctx, tw, tx)
+        if bias is not None:
+            t = r.base.ggml_add(r.ctx, t, r.tensor(R.F32, [m], bias.astype(np.float32)))
+        if gelu:
+            t = r.base.ggml_gelu(r.ctx, t)
+        if resid is not None:
+            t = r.base.ggml_add(r.ctx, t, r.tensor(R.F32, [m, b], resid.astype(np.float32)))
+        return r.read(r.compute(t, n_threads), R.F32, (b, m))

@@ -6,6 +6,7 @@ of ggml-quants.c:31-66 — plus the quantize_row_q8_0_ref rounding of ggml-cuda'
 dequantize_row of the five formats (to_float, ggml-quants.c:255,349,1280,1482,1690); <= 2e-6 relative L2 for the float ops
 (norm, rms_norm, soft_max, rope, gelu, diag_mask_inf, get_rows) whose only freedom is fp32 summation order / libm."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -233,6 +234,34 @@ def test_mul_mat_fused_equals_the_unfused_sequence_bit_for_bit(L, name, t, b, ta
                                       rd.data_ptr() if tail == "bias_residual" else None, m, ws.data_ptr(), ws.numel(), _st()))
     torch.cuda.synchronize()
     assert np.array_equal(yf.cpu().numpy().view(np.uint32), y2.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("tail", ["bias_gelu", "bias_residual"])
+@pytest.mark.parametrize("b", [1, 96, 512])
+@pytest.mark.parametrize("name,t", [("q4_K", R.Q4_K), ("q4_0", R.Q4_0)])
+def test_mul_mat_fused_against_the_reference_cpu_backend(L, name, t, b, tail):
+    """ggml_cdna4_mul_mat_fused against the SAME chain on the unmodified reference CPU backend (tests/refops.py: MUL_MAT -> ADD -> GELU | ADD), not
+    only against the unfused HIP sequence.  Q4_K at b = 96 / 512: the tail rides in k_gemm_kq_t64's store — ONE launch per node
+    chain; Q4_0: the older GEMM kernels + k_epilogue.  Bar: the MUL_MAT's own bar (GEMV 1e-5 / GEMM 1e-3, relative L2 over the chain's result)."""
+    if not os.path.exists(os.path.join(R.REF_DIR, "libggml-cpu.so")):
+        pytest.skip("oracle/_ref not built")
+    import refops as O
+    m, k = 3072, 768
+    w = R.random_weights(t, m, k, seed=23)
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, (b, k)).astype(np.float32)
+    bias = rng.standard_normal(m).astype(np.float32)
+    res = rng.standard_normal((b, m)).astype(np.float32) if tail == "bias_residual" else None
+    want = O.mul_mat_tail(t, w, m, k, x, bias, tail == "bias_gelu", res)
+    wd, xd, bd = _dev(w), _dev(x), _dev(bias)
+    rd = _dev(res) if res is not None else None
+    ws = torch.empty(max(L.ggml_cdna4_mul_mat_workspace_size(int(t), k, b), 256), dtype=torch.uint8, device="cuda")
+    y = torch.empty((b, m), dtype=torch.float32, device="cuda")
+    _ok(L, L.ggml_cdna4_mul_mat_fused(int(t), wd.data_ptr(), R.row_size(t, k), xd.data_ptr(), k, y.data_ptr(), m, m, k, b, bd.data_ptr(), 1 if tail == "bias_gelu" else 0,
+                                      rd.data_ptr() if rd is not None else None, m, ws.data_ptr(), ws.numel(), _st()))
+    torch.cuda.synchronize()
+    e = R.rel_l2(y.cpu().numpy(), want)
+    assert e < (1e-5 if b <= 8 else 1e-3), e
 
 
 @pytest.mark.parametrize("b", [1, 5, 96, 512])

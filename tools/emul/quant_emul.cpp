@@ -61,6 +61,7 @@ template <typename F> static void emu_launch(F body, dim3 grid, dim3 block) {
     if (cannot) { fprintf(stderr, "the environment cannot host the emulation\n"); exit(77); }
 }
 
+#define CDNA4_HW_OVERRIDE
 #include "../../ggml_amd/csrc/quantize_act.hip"
 
 static std::vector<uint8_t> slurp(const char *p) {
