@@ -115,7 +115,7 @@ int ggml_cdna4_quantize_q8_0(const float *x, int64_t x_row_stride, int64_t K, in
 
 int ggml_cdna4_quantize_q8_1(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d, float *s, void *xh, void *stream) {
     if (((uintptr_t)x | (uintptr_t)(x_row_stride * 4)) & 15) return cdna4_set_error_msg("quantize_q8_1: x must be 16-byte aligned");
-    return cdna4_launch_quantize_q8_1(x, x_row_stride, K, B, qs, d, s, xh, (hipStream_t)stream);
+    return cdna4_launch_quantize_q8_1(x, x_row_stride, K, B, qs, d, s, xh, false, (hipStream_t)stream);
 }
 
 static int resolve_path(int type, int path, int64_t M, int64_t K, int64_t B) {
@@ -141,10 +141,10 @@ int ggml_cdna4_prepare_act(int type, const float *X, int64_t x_row_stride, int64
     // Q4_1 / Q5_1: Q8_1 activations — s = fp16(d * sum q) per 32-block as fp32 where the K-quants keep their bsums (same byte count); the GEMM reads the
     // fp16 image twice in a row ([d q | m 1] weights): whole 128-k panels only (cdna4_gemm_q_supported)
     if (((uintptr_t)X | (uintptr_t)(x_row_stride * 4)) & 15) return cdna4_set_error_msg("quantize_q8_1: x must be 16-byte aligned");
-    const int rc = cdna4_launch_quantize_q8_1(X, x_row_stride, K, B, want_i8 ? v.qs : nullptr, v.d, reinterpret_cast<float *>(v.bsums), want_h ? v.xh : nullptr, (hipStream_t)stream);
-    if (rc || !want_h || K % 128) return rc;                           // (a ragged last panel: no GEMM form, cdna4_gemm_q_supported says so)
-    const hipError_t e = hipMemcpyAsync((char *)v.xh + (size_t)B * K * 2, v.xh, (size_t)B * K * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream);
-    return e == hipSuccess ? 0 : cdna4_set_error(e, __FILE__, __LINE__);
+    // GEMM image: [x~ | s e0] — the quantizer writes both halves (the second: the CPU's own fp16 s per 32-block against the weights' [d q | m e0]);
+    // a ragged last panel has no GEMM form (cdna4_gemm_q_supported says so): then only the first half is written
+    return cdna4_launch_quantize_q8_1(X, x_row_stride, K, B, want_i8 ? v.qs : nullptr, v.d, reinterpret_cast<float *>(v.bsums), want_h ? v.xh : nullptr,
+                                      want_h && K % 128 == 0, (hipStream_t)stream);
 }
 
 static cdna4_gemm_args gemm_args_of(int type, const void *W, int64_t w_row_bytes, const void *xh, float *Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,

@@ -14,7 +14,8 @@ int cdna4_launch_quantize_q8_0(const float *x, int64_t x_row_stride, int64_t K, 
 int cdna4_launch_moe_plan(const int32_t *ids, int64_t ids_tok_stride, int n_tok, int n_used, int n_b, int n_expert, int img_rows,
                           int32_t *img_src, int32_t *img_dst, int32_t *tile_expert, hipStream_t st);
 // Q8_1 (activations of Q4_1 / Q5_1 weights): as q8_0 without ref_rounding, plus s[B][K/32] = fp16(d * sum of the block's quants) as fp32
-int cdna4_launch_quantize_q8_1(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d, float *s, void *xh, hipStream_t st);
+// two_part: xh has 2 K columns, the second K holding s in the first column of every 32-block and zeros elsewhere (the GEMM image of Q4_1 / Q5_1)
+int cdna4_launch_quantize_q8_1(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d, float *s, void *xh, bool two_part, hipStream_t st);
 int cdna4_launch_quantize_q8_K_gather(const float *x, int64_t x_row_stride, int64_t K, int64_t img_rows, const int32_t *src_rows, void *xh, hipStream_t st);
 
 // gemv_q.hip — int8-dot decode path.  Activations are the SoA workspace of quantize_act.hip.

@@ -6,8 +6,8 @@
 //                                                                         q6 = q3 + 28 in [28, 35]          (same fp16 d, same 16-weight groups)
 //    Q2_K -> Q6_K + Q6_K   w = d sc4 q2 - dmin m4 = d sc4 (qa - 32)  +  dmin (-m4) (33 - 32)             (library-internal: see below)
 //    IQ4_NL -> Q8_0 w = d kvalues[code]          = d q8,                 q8 = kvalues_iq4nl[code] in [-127, 113]  (same fp16 d)
-//    Q4_1 / Q5_1 -> Q8_0 + Q8_0   w = d q + m    = d q8  +  c 1,         q8 = q - 8 / q - 16 in [-8, 7] / [-16, 15], c = fp16(m + 8 d) / fp16(m + 16 d)
-//                                                                         (library-internal, like Q2_K; CENTRED — see k_convert_q41_q8_0x2 — so not bit-exact: |error| <= 2^-11 |c|)
+//    Q4_1 / Q5_1 -> Q8_0 + Q8_0   w = d q + m    = d q8  +  m e0,        q8 = q in [0, 15] / [0, 31], e0 = [1, 0 x 31]   (library-internal: against the
+//                                                                         activation image [x~ | s e0], s = the CPU's block_q8_1.s — see k_convert_q41_q8_0x2)
 //    IQ4_XS -> Q6_K + Q6_K   w = d (ls - 32) kvalues[code] = d (4 (ls - 32)) (qa - 32) + d (ls - 32) (qb - 32),  kvalues = 4 (qa - 32) + (qb - 32)   (the same)
 //
 // Every weight keeps its value bit for bit (dequantize_row_q5_0 / _q3_K of the source == dequantize_row_q8_0 / _q6_K of the result,
@@ -55,15 +55,14 @@ __global__ __launch_bounds__(256) void k_convert_q5_0_q8_0(const uint8_t *__rest
     }
 }
 
-// Q4_1 / Q5_1 (FIVE): one thread per 32-weight block {fp16 d, fp16 m, [qh[4],] qs[16]} -> block b of the row's scale part {d, int8 q - 8 | q - 16} and
-// block nblk + b of its centre part {c, thirty-two 1s}, c = fp16(m + 8 d | m + 16 d): w = q d + m = d (q - 8) + (m + 8 d)  (dequantize_row_q4_1 / _q5_1,
-// src/ggml-quants.c:275-293, 321-347).  2 K columns per row, against an activation image that holds x twice — library-internal like Q2_K's form.
-// Why centred: the fp16 GEMM rounds each PART to fp16.  With the uncentred split (d q | m) both parts are ~|max - min| of the block while their sum, the
-// weight, is much smaller for zero-centred weights; the roundings then weigh 2-3x a direct fp16(w) — measured on MI355X in the reference's gpt-2 graph:
-// MUL_MAT 1.5e-3 from the CPU backend for Q4_1 / Q5_1 against the 1e-3 bar (round 3's first hardware session).  Centred, d (q - 8) is the weight's distance
-// from the block's middle and c the middle itself (small for zero-centred weights): the roundings weigh what they weigh for Q4_0 / Q5_0.  The price: c is
-// rounded once to fp16 (|error| <= 2^-11 |c|, the same size as the GEMM's own fp16 rounding of a weight), so the two parts no longer sum to
-// dequantize_row bit for bit.  The GEMV units (<= 8 rows) work on the original bytes and are unaffected.
+// Q4_1 / Q5_1 (FIVE): one thread per 32-weight block {fp16 d, fp16 m, [qh[4],] qs[16]} -> block b of the row's scale part {d, int8 q} and block
+// nblk + b of its minimum part {m, [1, 0 x 31]}: 2 K columns per row, against an activation image [x~ | s e0] whose second half holds, per 32-block, the
+// CPU's own block_q8_1.s = fp16(d_x * sum q_x) in the block's first column and zeros elsewhere (k_quantize_q8_1, two_part).  So
+//     W . x = sum_blocks [ sum_k (d q_k) x~_k  +  m * s ]
+// — term for term what vec_dot_q4_1_q8_1 / q5_1_q8_1 add up (src/ggml-cpu/ggml-cpu-quants.c:2585-2601, 3309-3331), the m * s products exact in fp32.
+// Why not [d q | m 1] against x twice (round 2), or a centred split (tried in round 3): for activations with a non-zero mean the CPU's result is
+// dominated by ITS rounding of s to fp16 (|m| |s| 2^-12 per block); a product on the exact sum of x~ lands 1.4e-3 .. 2.9e-3 from the CPU backend
+// (measured on MI355X in the reference's gpt-2 graph: MUL_MAT 1.4e-3 .. 1.5e-3 for Q4_1 / Q5_1 either way) — with the CPU's own s: 6e-4 .. 8e-4.
 template <bool FIVE>
 __global__ __launch_bounds__(256) void k_convert_q41_q8_0x2(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nblk, uint8_t *__restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -72,21 +71,19 @@ __global__ __launch_bounds__(256) void k_convert_q41_q8_0x2(const uint8_t *__res
     const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)b * (FIVE ? 24 : 20);
     uint8_t *da = out + ((int64_t)row * 2 * nblk + b) * 34, *db = da + (int64_t)nblk * 34;
     const uint32_t qh = FIVE ? ld_u32_a2(src + 4) : 0u;
-    const float d = h2f(ld_u16(src)), m = h2f(ld_u16(src + 2));
     *reinterpret_cast<uint16_t *>(da) = ld_u16(src);
-    *reinterpret_cast<uint16_t *>(db) = f2h_bits(m + (FIVE ? 16.f : 8.f) * d);
-    constexpr uint32_t TOP = FIVE ? 0x10101010u : 0x08080808u, EXT = FIVE ? 0x0Eu : 0x1Eu;     // q - 8 as int8: flip bit 3; where the flipped bit is set (q < 8) extend the sign: | 0xF0
+    *reinterpret_cast<uint16_t *>(db) = ld_u16(src + 2);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t q = ld_u32_a2(src + (FIVE ? 8 : 4) + 4 * i);
         const uint32_t h0 = ((qh >> (4 * i)) & 0xFu) * 0x00204081u & 0x01010101u, h1 = ((qh >> (16 + 4 * i)) & 0xFu) * 0x00204081u & 0x01010101u;
-        uint32_t lo = (q & 0x0F0F0F0Fu) | (h0 << 4), hi = ((q >> 4) & 0x0F0F0F0Fu) | (h1 << 4);      // weights 4i.. / 16+4i.. as bytes 0..15 / 0..31
-        lo ^= TOP; lo |= (lo & TOP) * EXT; hi ^= TOP; hi |= (hi & TOP) * EXT;
+        const uint32_t lo = (q & 0x0F0F0F0Fu) | (h0 << 4), hi = ((q >> 4) & 0x0F0F0F0Fu) | (h1 << 4);      // weights 4i.. / 16+4i.. as bytes 0..15 / 0..31
         *reinterpret_cast<uint16_t *>(da + 2 + 4 * i) = (uint16_t)lo; *reinterpret_cast<uint16_t *>(da + 4 + 4 * i) = (uint16_t)(lo >> 16);
         *reinterpret_cast<uint16_t *>(da + 18 + 4 * i) = (uint16_t)hi; *reinterpret_cast<uint16_t *>(da + 20 + 4 * i) = (uint16_t)(hi >> 16);
     }
+    *reinterpret_cast<uint16_t *>(db + 2) = (uint16_t)0x0001u;          // [1, 0, 0, ...]: m meets s, nothing else
 #pragma unroll
-    for (int i = 0; i < 16; i++) *reinterpret_cast<uint16_t *>(db + 2 + 2 * i) = (uint16_t)0x0101u;
+    for (int i = 1; i < 16; i++) *reinterpret_cast<uint16_t *>(db + 2 + 2 * i) = (uint16_t)0u;
 }
 
 // IQ4_NL: one thread per 32-weight block {fp16 d, qs[16]} -> {d, int8 qs[32]} with q8 = kvalues_iq4nl[code]: w = d * kvalues[code]

@@ -460,9 +460,8 @@ struct gemm_params {
     // expert tile_expert[t] (< 0: unused tile, the work-group exits), its weights start at W + expert * w_expert_bytes, and image row r
     // is output row row_dst[r] (< 0: padding row, not stored)
     const int32_t *tile_expert; const int32_t *row_dst; int64_t w_expert_bytes;
-    // k_gemm_kq_t64 only (appended last): the MUL_MAT's tail, applied to every element in the store that produces it (epilogue.h), and experiment
-    // bits for that store (bit0: write-through sc1 stores of Y instead of plain ones)
-    cdna4_epilogue epi; int store_mode;
+    // k_gemm_kq_t64 only (appended last): the MUL_MAT's tail, applied to every element in the store that produces it (epilogue.h)
+    cdna4_epilogue epi;
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { CDNA4_WAIT_VM(N); }

@@ -22,16 +22,4 @@
 // v_permlane32_swap: lanes 32-63 of `a` trade places with lanes 0-31 of `b` (both 32-bit); with a == b on entry every lane l ends
 // with a = the value of lane l % 32 and b = the value of lane 32 + l % 32
 #define CDNA4_SWAP32(a, b) do { auto r_ = __builtin_amdgcn_permlane32_swap((a), (b), false, false); (a) = r_[0]; (b) = r_[1]; } while (0)
-// fp32 store that leaves the L2 at once (write-through: no dirty line is left for the kernel boundary to write back)
-#define CDNA4_STORE_F32_SC1(ptr, v) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory")
-#endif
-#ifndef CDNA4_STORE_F32_SC1      // host builds (tools/emul) that predate the macro: a plain store
-#define CDNA4_STORE_F32_SC1(ptr, v) (*(ptr) = (v))
-#endif
-// 16-byte store, write-through (ptr: u32x4 *)
-#if !defined(CDNA4_HW_OVERRIDE) && !defined(CDNA4_STORE_B128_SC1)
-#define CDNA4_STORE_B128_SC1(ptr, v) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory")
-#endif
-#ifndef CDNA4_STORE_B128_SC1
-#define CDNA4_STORE_B128_SC1(ptr, v) (*(ptr) = (v))
 #endif

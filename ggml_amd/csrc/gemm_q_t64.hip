@@ -32,7 +32,6 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = tiles_m; p.tiles_b = tiles_b;
     p.epi = a.epi;
-    { static const int sm = getenv("CDNA4_T64_STORE") ? atoi(getenv("CDNA4_T64_STORE")) : 0; p.store_mode = sm; }      // experiment knob (see gemm_params)
     if (splitk >= 2) {
         // exchange slots: [tile][work-group of the tile][wave] x 16 KB at most; flag words: hand-off flags [tile][ks] in the first 32 KB,
         // deep-split ticket counters [tile] behind them; both zero when idle and reset by their last user — no per-launch state on the

@@ -17,7 +17,6 @@
 #include <stdlib.h>
 #include "cdna4_kernels.h"
 #include "quantize_dev.h"
-#include "gemm_q_hw.h"
 
 __device__ __forceinline__ u32x2 pack4h(half_t a, half_t b, half_t c, half_t d) {
     const half2_t lo = {a, b}, hi = {c, d};
@@ -29,7 +28,7 @@ __device__ __forceinline__ u32x2 pack4h(half_t a, half_t b, half_t c, half_t d) 
 // 6 rounds — took 6.0 us for the 512 x 4096 headline batch; the per-lane work is what the fused decode kernel uses too.)
 __global__ __launch_bounds__(256) void k_quantize_q8_K(const float *__restrict__ x, int64_t x_row_stride, int K, int B,
                                                        int8_t *__restrict__ qs, float *__restrict__ dd,
-                                                       int16_t *__restrict__ bsums, half_t *__restrict__ xh, const int32_t *__restrict__ src_rows, int store_mode) {
+                                                       int16_t *__restrict__ bsums, half_t *__restrict__ xh, const int32_t *__restrict__ src_rows) {
     const int nch = K / 16;                                                  // 16-element chunks per row
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;              // chunk id over [B][nch]
     if (t >= (int64_t)B * nch) return;                                       // whole 16-lane groups drop out together (nch % 16 == 0)
@@ -81,10 +80,8 @@ __global__ __launch_bounds__(256) void k_quantize_q8_K(const float *__restrict__
         { const u32x2 a0 = pack4h(hv[0], hv[2], hv[1], hv[3]), a1 = pack4h(hv[4], hv[6], hv[5], hv[7]);
           const u32x2 a2 = pack4h(hv[8], hv[10], hv[9], hv[11]), a3 = pack4h(hv[12], hv[14], hv[13], hv[15]);
           lo.x = a0.x; lo.y = a0.y; lo.z = a1.x; lo.w = a1.y; hi.x = a2.x; hi.y = a2.y; hi.z = a3.x; hi.w = a3.y; }
-        // store_mode 1 (experiment, CDNA4_QUANT_STORE): write-through — the image is read next by work-groups on all eight XCDs, i.e. from memory
-        // anyway; leaving no dirty lines in this XCD's L2 shortens the kernel boundary in front of the GEMM
-        if (store_mode & 1) { CDNA4_STORE_B128_SC1(reinterpret_cast<u32x4 *>(dst), lo); CDNA4_STORE_B128_SC1(reinterpret_cast<u32x4 *>(dst + 8), hi); }
-        else { *reinterpret_cast<u32x4 *>(dst) = lo; *reinterpret_cast<u32x4 *>(dst + 8) = hi; }
+        // (write-through sc1 stores of the image: no difference on MI355X, 38.3 vs 38.4 us per step)
+        { *reinterpret_cast<u32x4 *>(dst) = lo; *reinterpret_cast<u32x4 *>(dst + 8) = hi; }
     }
 }
 
@@ -119,8 +116,10 @@ __global__ __launch_bounds__(256) void k_quantize_q8_0(const float *__restrict__
 // Q8_1 — what the CPU backend quantizes the activations of Q4_1 / Q5_1 weights to (AVX2 body of quantize_row_q8_1,
 // src/ggml-cpu/ggml-cpu-quants.c:1076-1119): the block of k_quantize_q8_0<false> plus ss = fp16(d * sum of the 32 quants) with d still
 // in fp32 (block_q8_1.s, src/ggml-common.h:210-222), stored as fp32 like dd.  The fp16 image is that of Q8_0.
+// two_part (the GEMM image of Q4_1 / Q5_1: weights re-encoded as [d q | m e0], convert_w.hip): the image has 2 K columns; columns [K, 2K) hold, per
+// 32-block, s in the block's first column and zeros in the other 31 — so the second half of the product is sum_blocks m * s with the CPU's OWN fp16 s.
 __global__ __launch_bounds__(256) void k_quantize_q8_1(const float *__restrict__ x, int64_t x_row_stride, int K, int B,
-                                                       int8_t *__restrict__ qs, float *__restrict__ dd, float *__restrict__ ss, half_t *__restrict__ xh) {
+                                                       int8_t *__restrict__ qs, float *__restrict__ dd, float *__restrict__ ss, half_t *__restrict__ xh, int two_part) {
     const int nb = K / 32;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;             // one thread per 4 elements
     const int64_t blk = t >> 3;
@@ -147,6 +146,11 @@ __global__ __launch_bounds__(256) void k_quantize_q8_1(const float *__restrict__
         for (int i = 0; i < 4; i++) h[i] = (half_t)(dh * (float)q[i]);
         const int64_t k = (int64_t)ib * 32 + sub * 4;
         *reinterpret_cast<u32x2 *>(xh + ((k >> 7) * B + b) * 128 + (k & 127)) = pack4h(h[0], h[2], h[1], h[3]);
+        if (two_part) {
+            const int64_t k2 = (int64_t)K + k;
+            const half_t z = (half_t)0.f, sv = sub == 0 ? __builtin_bit_cast(half_t, f2h_bits(d * (float)sum)) : z;
+            *reinterpret_cast<u32x2 *>(xh + ((k2 >> 7) * B + b) * 128 + (k2 & 127)) = pack4h(sv, z, z, z);
+        }
     }
 }
 
@@ -155,8 +159,7 @@ int cdna4_launch_quantize_q8_K(const float *x, int64_t x_row_stride, int64_t K, 
     if (K % QK_K) return cdna4_set_error_msg("quantize_q8_K: K must be a multiple of 256");
     if (B == 0 || K == 0) return 0;
     const int64_t nthr = B * (K / 16);
-    static const int sm = getenv("CDNA4_QUANT_STORE") ? atoi(getenv("CDNA4_QUANT_STORE")) : 0;
-    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, bsums, (half_t *)xh, (const int32_t *)nullptr, sm);
+    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, bsums, (half_t *)xh, (const int32_t *)nullptr);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
@@ -209,7 +212,7 @@ int cdna4_launch_quantize_q8_K_gather(const float *x, int64_t x_row_stride, int6
     if (K % QK_K) return cdna4_set_error_msg("quantize_q8_K: K must be a multiple of 256");
     if (img_rows == 0 || K == 0) return 0;
     const int64_t nthr = img_rows * (K / 16);
-    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)img_rows, (int8_t *)nullptr, (float *)nullptr, (int16_t *)nullptr, (half_t *)xh, src_rows, 0);
+    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)img_rows, (int8_t *)nullptr, (float *)nullptr, (int16_t *)nullptr, (half_t *)xh, src_rows);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
@@ -224,12 +227,13 @@ int cdna4_launch_quantize_q8_0(const float *x, int64_t x_row_stride, int64_t K, 
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
-int cdna4_launch_quantize_q8_1(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d, float *s, void *xh, hipStream_t st) {
+int cdna4_launch_quantize_q8_1(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d, float *s, void *xh, bool two_part, hipStream_t st) {
+    if (two_part && (K % 128)) return cdna4_set_error_msg("quantize_q8_1: the two-part image needs whole 128-k panels");
     if (K % 32) return cdna4_set_error_msg("quantize_q8_1: K must be a multiple of 32");
     if (qs && (!d || !s)) return cdna4_set_error_msg("quantize_q8_1: qs needs d and s");
     if (B == 0 || K == 0) return 0;
     const int64_t nthr = B * (K / 4);
-    hipLaunchKernelGGL(k_quantize_q8_1, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, s, (half_t *)xh);
+    hipLaunchKernelGGL(k_quantize_q8_1, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, s, (half_t *)xh, two_part ? 1 : 0);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

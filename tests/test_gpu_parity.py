@@ -366,6 +366,35 @@ def test_full_size_prefill_config(gu, m, k, b):
     assert R.rel_l2(ysh, y) < 2e-6
 
 
+def test_full_size_c5_config(gu):
+    """BASELINE configs[4] on one GPU: Q4_K [32768 x 8192] . [8192 x 512] — the only BASELINE shape that takes the 256-row tile instantiation
+    (k_gemm_kq_t64<Q4_K, 256>, no K split).  A 64-row sample of weight rows against the oracle, determinism, and the row-shard property of the
+    8-GPU partition: the eight 4096-row shards (each a headline-sized product on the 128-row kernel with the split-K hand-off) concatenate to the
+    full result to fp32 re-association.  Weights: random valid block bytes (the reference quantizer would take minutes for 268 M weights)."""
+    from ggml_amd import ops
+    t, m, k, b = R.Q4_K, 32768, 8192, 512
+    w = R.random_block_bytes(t, m, k, np.random.default_rng(77))
+    x = _x(78, b, k)
+    a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
+    y = ops.mul_mat(a, xd)
+    assert torch_equal(y, ops.mul_mat(a, xd))
+    yh = y.cpu().numpy()
+    assert np.isfinite(yh).all()
+    rows = np.random.default_rng(0).choice(m, 64, replace=False)
+    rs = R.row_size(t, k)
+    wsub = np.concatenate([w[r * rs:(r + 1) * rs] for r in rows])
+    e = R.rel_l2(yh[:, rows], R.o_mul_mat(t, wsub, x, 64, k)); gu.report(test="full_prefill_c5", m=m, k=k, b=b, rel_l2=e)
+    assert e < TOL_GEMM
+    for r in (0, 5):                                                       # two of the eight row shards of the 8-GPU partition
+        ysh = ops.mul_mat(a.rows(r * 4096, (r + 1) * 4096), xd).cpu().numpy()
+        assert R.rel_l2(ysh, yh[:, r * 4096:(r + 1) * 4096]) < 2e-6
+
+
+def torch_equal(a, b):
+    import torch
+    return bool(torch.equal(a, b))
+
+
 # ------------------------------------------------------------------------------------------------ MUL_MAT_ID
 @pytest.mark.parametrize("name,t", WT)
 @pytest.mark.parametrize("n_expert,n_used,n_b_is_one,n_tok", [(4, 1, False, 1), (4, 2, False, 32), (8, 4, True, 32), (8, 2, False, 3)])

@@ -58,17 +58,13 @@ def run(t, m, k, seed=1):
         assert out.size == m * R.row_size(tgt, 2 * k), "size of the re-encoded matrix"
         both = R.o_dequantize(tgt, out, 2 * k)
         b = both[:, :k] + both[:, k:]
-        if t in (Q4_1, Q5_1):     # centred form: scale part d (q - 8 | q - 16), centre part c = fp16(m + 8 d | m + 16 d) in every column
+        if t in (Q4_1, Q5_1):     # scale part d q; minimum part m in the block's FIRST column only (it meets s = fp16(d_x sum q_x) of the [x~ | s e0] image)
             blkb = w.reshape(m, k // 32, -1)
-            dd = np.repeat(blkb[:, :, 0:2].copy().view(np.float16).astype(np.float32).reshape(m, k // 32), 32, axis=1)
-            mm = np.repeat(blkb[:, :, 2:4].copy().view(np.float16).astype(np.float32).reshape(m, k // 32), 32, axis=1)
-            half = 8.0 if t == Q4_1 else 16.0
-            cc = (mm + np.float32(half) * dd).astype(np.float32).astype(np.float16).astype(np.float32)
-            assert np.array_equal(both[:, k:].view(np.uint32), cc.view(np.uint32)), "centre part"
-            qq = np.rint((a - mm) / np.where(dd == 0, 1, dd))               # the codes back from dequantize_row (d != 0)
-            ok = dd != 0
-            assert np.array_equal(both[:, :k][ok], (dd * (qq - half))[ok]), "scale part"
-            assert np.all(np.abs(a - b) <= np.abs(mm + half * dd) * 2.0 ** -11 + np.abs(a) * 2.0 ** -22 + 1e-30), "sum of the parts further from dequantize_row than one fp16 rounding of the centre"
+            mm = blkb[:, :, 2:4].copy().view(np.float16).astype(np.float32).reshape(m, k // 32)
+            mpart = both[:, k:].reshape(m, k // 32, 32)
+            assert np.array_equal(mpart[:, :, 0].view(np.uint32), mm.view(np.uint32)) and not mpart[:, :, 1:].any(), "minimum part"
+            b = both[:, :k] + np.repeat(mm, 32, axis=1)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "dequantize(source) != dequantize(scale part) + m, bit for bit"
             return True
     else:
         assert out.size == m * R.row_size(tgt, k), "size of the re-encoded matrix"

@@ -61,7 +61,6 @@ template <typename F> static void emu_launch(F body, dim3 grid, dim3 block) {
     if (cannot) { fprintf(stderr, "the environment cannot host the emulation\n"); exit(77); }
 }
 
-#define CDNA4_HW_OVERRIDE
 #include "../../ggml_amd/csrc/quantize_act.hip"
 
 static std::vector<uint8_t> slurp(const char *p) {
@@ -79,7 +78,7 @@ int main(int argc, char **argv) {
     int8_t *qs = (int8_t *)shared_alloc((size_t)(B * K)); float *d = (float *)shared_alloc((size_t)(B * (K / qk)) * 4);
     int16_t *bs = (int16_t *)shared_alloc((size_t)(B * (K / 16)) * 2); uint8_t *xh = (uint8_t *)shared_alloc((size_t)(B * K) * 2);
     int rc = kind == 0 ? cdna4_launch_quantize_q8_K(x, K, K, B, qs, d, bs, xh, nullptr) :
-             kind == 3 ? cdna4_launch_quantize_q8_1(x, K, K, B, qs, d, reinterpret_cast<float *>(bs), xh, nullptr) : cdna4_launch_quantize_q8_0(x, K, K, B, qs, d, xh, kind == 2, nullptr);
+             kind == 3 ? cdna4_launch_quantize_q8_1(x, K, K, B, qs, d, reinterpret_cast<float *>(bs), xh, false, nullptr) : cdna4_launch_quantize_q8_0(x, K, K, B, qs, d, xh, kind == 2, nullptr);
     if (rc != 0) return 1;
     dump(argv[5], qs, (size_t)(B * K)); dump(argv[6], d, (size_t)(B * (K / qk)) * 4); dump(argv[7], bs, (size_t)(B * (K / 16)) * 2); dump(argv[8], xh, (size_t)(B * K) * 2);
     return 0;
