@@ -72,7 +72,7 @@ EXC := $(REF)/examples/common.cpp $(REF)/examples/common-ggml.cpp
 $(OUT)/gpt-2-quantize: $(REF)/examples/gpt-2/quantize.cpp $(EXC) $(LIBS)
 	$(CXX) $(CXXFLAGS_COMMON) -I$(REF)/examples -o $@ $< $(EXC) -L$(OUT) -lggml -lggml-cpu -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN'
 $(OUT)/gpt2_harness: oracle/gpt2_harness.cpp $(EXC) $(LIBS)
-	$(CXX) $(CXXFLAGS_COMMON) -I$(REF) -I$(REF)/examples -o $@ $< $(EXC) -L$(OUT) -lggml -lggml-cpu -lggml-base -lpthread -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(CXXFLAGS_COMMON) -I$(REF) -I$(REF)/examples -o $@ $< $(EXC) -L$(OUT) -lggml -lggml-cpu -lggml-base -lpthread -ldl -Wl,-rpath,'$$ORIGIN'
 
 # examples/gpt-2/main-sched.cpp, unmodified, with the plug-in in its (compile-time) GPU slot: see oracle/sched_harness.cpp
 $(OUT)/sched_harness: oracle/sched_harness.cpp $(EXC) $(LIBS)

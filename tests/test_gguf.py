@@ -246,9 +246,10 @@ def test_gguf_weights_through_the_hip_path(gg):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("CDNA4_TEST_EXPERIMENTAL") != "1", reason="upload path not yet GPU-verified, opt-in: CDNA4_TEST_EXPERIMENTAL=1")
 def test_gguf_upload_through_pinned_staging(gg, tmp_path):
-    """ggml_cdna4_gguf_upload: payloads larger and smaller than the 16-MiB staging chunk arrive in HBM byte for byte"""
+    """ggml_cdna4_gguf_upload: payloads larger and smaller than the 16-MiB staging chunk arrive in HBM byte for byte; the rate of the 256-MiB
+    payload (mapping -> two pinned staging buffers -> HBM) goes to the parity report"""
+    import time
     import torch
     rng = np.random.default_rng(9)
     big = rng.integers(0, 256, 40 * (1 << 20) + 4096, dtype=np.uint8)           # 2.5 chunks of I8
@@ -263,6 +264,41 @@ def test_gguf_upload_through_pinned_staging(gg, tmp_path):
             assert np.array_equal(dst.cpu().numpy(), ref), name
         with pytest.raises(gg.GGUFError, match="too small"):
             f.upload("big", torch.zeros(16, dtype=torch.uint8, device="cuda"))
+    huge = rng.integers(0, 256, 256 << 20, dtype=np.uint8)
+    p2 = str(tmp_path / "huge.gguf")
+    open(p2, "wb").write(G.py_serialize([], [("huge", 24, (huge.size,), huge.tobytes())]))
+    with gg.GGUFFile(p2) as f:
+        dst = torch.zeros(huge.size, dtype=torch.uint8, device="cuda")
+        f.upload("huge", dst, torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()      # first pass: page cache + staging buffers warm
+        t0 = time.perf_counter()
+        f.upload("huge", dst, torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert np.array_equal(dst.cpu().numpy(), huge)
+    import gpu_util
+    gpu_util.report(test="gguf_upload", bytes=int(huge.size), seconds=dt, GBps=huge.size / dt / 1e9)
+
+
+def test_gpt2_model_as_gguf_on_the_cpu_backend(tmp_path):
+    """BASELINE configs[3] says "gpt-2 117M GGUF Q4_0": the reference's .bin model written as GGUF by the reference's own writer (oracle/gpt2_harness
+    TOGGUF), read back through THIS library's reader into the reference's unmodified gpt-2 graph — logits bit-identical to the .bin-loaded run.  CPU
+    backend and a 2-layer model here (the -m gpu twin runs all 12 layers on the plug-in, uploading through ggml_cdna4_gguf_upload)."""
+    import subprocess
+    import sys
+    H = os.path.join(R.REF_DIR, "gpt2_harness")
+    if not os.path.exists(H):
+        pytest.skip("oracle/_ref not built")
+    import ggml_amd.native as N
+    f32, q4, gguf = (str(tmp_path / n) for n in ("f32.bin", "q4_0.bin", "model.gguf"))
+    subprocess.run([sys.executable, os.path.join(R.ROOT, "tools", "make_synth_gpt2.py"), f32, "--layers", "2"], check=True, timeout=600)
+    subprocess.run([os.path.join(R.REF_DIR, "gpt-2-quantize"), f32, q4, "q4_0"], check=True, timeout=600, capture_output=True)
+    os.remove(f32)
+    subprocess.run([H, q4, "CPU", "-", "TOGGUF:" + gguf, "0", "0", "1"], check=True, timeout=600, capture_output=True)
+    env = dict(os.environ, CDNA4_KERNELS_SO=N.LIB_PATH)
+    for model, out in ((q4, "a.bin"), (gguf, "b.bin")):
+        r = subprocess.run([H, model, "CPU", "-", str(tmp_path / out), "8", "2", "4"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    a, b = np.fromfile(str(tmp_path / "a.bin"), np.uint32), np.fromfile(str(tmp_path / "b.bin"), np.uint32)
+    assert a.size == 3 * 50257 and np.array_equal(a, b)
 
 
 def test_header_with_many_keys_opens_in_linear_time(gg, tmp_path):

@@ -170,3 +170,27 @@ def test_gpt2_sched_graph_runs_unmodified(model, cpu_self_sensitivity, ngl, para
     assert max(errs) < max(1e-3, 2.0 * cpu_self_sensitivity), (errs, cpu_self_sensitivity)
     if ngl == 6:
         assert tg["n_splits"] >= 2
+
+
+def test_gpt2_from_gguf_equals_gpt2_from_bin(model):
+    """BASELINE configs[3] "gpt-2 117M GGUF Q4_0 end-to-end on the new backend": the Q4_0 model written as GGUF by the reference's writer (harness
+    TOGGUF), loaded through the product's reader and ggml_cdna4_gguf_upload (mapping -> pinned staging -> the plug-in's HBM buffer), run through the
+    reference's unmodified graph on the plug-in: logits bit-identical to the .bin-loaded run on the plug-in (prompt 64 + 4 decoded tokens); the
+    upload rate goes to the report."""
+    import re
+    q4, d = model
+    gguf = os.path.join(d, "model.gguf")
+    _harness([q4, "CPU", "-", "TOGGUF:" + gguf, 0, 0, 1])
+    from ggml_amd import native
+    _, la = _run(q4, "CDNA40", os.path.join(d, "gg_a.bin"), 64, 4)
+    r = subprocess.run([os.path.join(REF, "gpt2_harness"), gguf, "CDNA40", PLUGIN, os.path.join(d, "gg_b.bin"), "64", "4", "16"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, CDNA4_KERNELS_SO=native.LIB_PATH))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lb = np.fromfile(os.path.join(d, "gg_b.bin"), np.float32).reshape(-1, N_VOCAB)
+    assert la.shape == lb.shape == (5, N_VOCAB) and np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    m = re.search(r"\{\"gguf_load\".*\}", r.stderr)
+    assert m, r.stderr[-1500:]
+    rec = json.loads(m.group(0))
+    assert "pinned staging" in rec["path"]
+    with open(os.path.join(R.ROOT, "gpurun_out", "gpt2_parity.jsonl"), "a") as f:
+        f.write(json.dumps(dict(rec, mode="gguf_vs_bin", identical=True)) + "\n")
