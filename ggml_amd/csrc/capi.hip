@@ -82,7 +82,7 @@ size_t ggml_cdna4_mul_mat_workspace_size(int type, int64_t K, int64_t n_act_rows
 size_t ggml_cdna4_mul_mat_id_workspace_size(int type, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok) {
     if (!is_q(type) || K <= 0 || n_tok <= 0 || n_used <= 0 || n_b <= 0 || n_expert <= 0) return 0;
     const size_t plain = carve(type, K, n_tok * n_b, nullptr).total;
-    if (type != CDNA4_Q4_K || n_tok * n_used <= 32) return plain;
+    if (!cdna4_gemm_ids_supported(type, K) || n_tok * n_used <= 32) return plain;
     const size_t grouped = moe_carve(K, n_expert, n_used, n_tok, nullptr).total;
     return grouped > plain ? grouped : plain;
 }
@@ -256,18 +256,19 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
     // prefill-sized mixture-of-experts batches: group the (token, slot) rows by expert on the device and run ONE MFMA GEMM launch over
     // the (expert, activation tile) table — every expert's weights are read once per m-tile instead of once per column
     // (ggml_compute_forward_mul_mat_id groups the same way on the host: ggml-cpu.c:7648-7781)
-    if (type == CDNA4_Q4_K && n_tok * n_used > 32 && n_expert <= 1024 && workspace && !((uintptr_t)workspace & 255) &&
-        !(((uintptr_t)as | (uintptr_t)w_row_bytes | (uintptr_t)w_expert_bytes) & 15) && !(((uintptr_t)b | (uintptr_t)(b_row_stride * 4)) & 15)) {
+    if (cdna4_gemm_ids_supported(type, K) && n_tok * n_used > 32 && n_expert <= 1024 && workspace && !((uintptr_t)workspace & 255) &&
+        !(((uintptr_t)as | (uintptr_t)w_row_bytes | (uintptr_t)w_expert_bytes) & 1) && !(((uintptr_t)b | (uintptr_t)(b_row_stride * 4)) & 15)) {
         const moe_view mv = moe_carve(K, n_expert, n_used, n_tok, workspace);
         if (workspace_bytes >= mv.total && mv.img_rows * K * 2 < ((int64_t)1 << 31)) {
             int rc = cdna4_launch_moe_plan(ids, ids_tok_stride, (int)n_tok, (int)n_used, (int)n_b, (int)n_expert, (int)mv.img_rows, mv.img_src, mv.img_dst, mv.tile_expert, (hipStream_t)stream);
             if (rc) return rc;
-            rc = cdna4_launch_quantize_q8_K_gather(b, b_row_stride, K, mv.img_rows, mv.img_src, mv.xh, (hipStream_t)stream);
+            rc = is_kq(type) ? cdna4_launch_quantize_q8_K_gather(b, b_row_stride, K, mv.img_rows, mv.img_src, mv.xh, (hipStream_t)stream)
+                             : cdna4_launch_quantize_q8_0_gather(b, b_row_stride, K, mv.img_rows, mv.img_src, mv.xh, (hipStream_t)stream);
             if (rc) return rc;
             cdna4_gemm_args a{};
             a.type = type; a.W = (const uint8_t *)as; a.w_row_bytes = w_row_bytes; a.xh = mv.xh; a.xh_row_elems = K;
             a.Y = dst; a.y_row_elems = dst_row_stride; a.M = (int)M; a.K = (int)K; a.B = (int)mv.img_rows;
-            return cdna4_launch_gemm_t64_ids(a, mv.tile_expert, mv.img_dst, w_expert_bytes, (hipStream_t)stream);
+            return cdna4_launch_gemm_ids(a, mv.tile_expert, mv.img_dst, w_expert_bytes, (hipStream_t)stream);   // Q4_K: k_gemm_kq_t64<.., IDS>; Q5_K / Q6_K / Q4_0 / Q8_0: k_gemm_q<.., IDS>
         }
     }
     if (n_tok == 1 && n_used <= 65535 && cdna4_gemv_fused_supported(type, K, 1) && !(((uintptr_t)b | (uintptr_t)(b_row_stride * 4)) & 15)) {

@@ -93,10 +93,41 @@ __device__ __forceinline__ uint32_t iq4nl_lut4(uint32_t codes) {
     return r;
 }
 
+// ---- cross-lane moves on the VALU (DPP) instead of the LDS crossbar: __shfl_xor compiles to ds_bpermute_b32 (~100 cycles issue -> use; a
+// 16-lane butterfly of three values is a dependent chain of 12 of them, ~0.5 us in the decode kernel's quantizer).  gfx950's DPP has no xor-4 /
+// xor-8 pattern, but for ALL-REDUCES (every lane wants the group's result) quad_perm + row_half_mirror + row_mirror do: after the two
+// quad steps the lanes of a quad agree, and the mirrors pair every quad with the other one(s) of its half / row.
+//   ctrl: 0xB1 quad_perm [1,0,3,2]   0x4E quad_perm [2,3,0,1]   0x141 row_half_mirror   0x140 row_mirror   0x142 row_bcast:15   0x143 row_bcast:31
+#if defined(__HIPCC__)
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ int dpp_i32(int v, int old = 0) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF); }
+#else   // host builds of the kernel sources (tools/emul): the same lane mapping through the emulated wave shuffle
+template <int CTRL, int ROW_MASK = 0xF> static inline int dpp_i32(int v, int old = 0) {
+    const int l = (int)(threadIdx.x & 63), r = l >> 4, i = l & 15;
+    int src = l; bool writes = (ROW_MASK >> r) & 1;
+    if (CTRL < 0x100) src = (l & ~3) | ((CTRL >> (2 * (l & 3))) & 3);
+    else if (CTRL == 0x141) src = (l & ~7) | (7 - (l & 7));
+    else if (CTRL == 0x140) src = (l & ~15) | (15 - i);
+    else if (CTRL == 0x142) { src = ((r - 1) << 4) | 15; writes = writes && r > 0; }
+    else if (CTRL == 0x143) { src = 31; writes = writes && r >= 2; }
+    const int got = emu_shfl_idx(v, src < 0 ? 0 : src);
+    return writes ? got : old;
+}
+#endif
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp_f32(float v, float old = 0.f) {
+    return __builtin_bit_cast(float, dpp_i32<CTRL, ROW_MASK>(__builtin_bit_cast(int, v), __builtin_bit_cast(int, old)));
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+// sum of v over the 64 lanes, returned in every lane: rows of 16 by DPP all-reduce, then row_bcast:15 / :31 carry the row totals into lane 63.
+// ALL 64 lanes must be active (v_readlane of an inactive lane reads a stale register).  Used by the decode kernels (gemv_q.hip).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_f32<0xB1>(v); v += dpp_f32<0x4E>(v); v += dpp_f32<0x141>(v); v += dpp_f32<0x140>(v);        // every lane: its row's sum
+    v += dpp_f32<0x142, 0xA>(v);                                                                         // rows 1, 3 += rows 0, 2
+    v += dpp_f32<0x143, 0xC>(v);                                                                         // rows 2, 3 += row 1 (= rows 0 + 1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

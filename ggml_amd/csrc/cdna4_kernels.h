@@ -74,6 +74,11 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st);
 bool cdna4_gemm_q_fuses_tail(const cdna4_gemm_args &a);
 // gemm_q_t64.hip — grouped MUL_MAT_ID: a.B = rows of the expert-sorted activation image, a.Y rows indexed through row_dst
 int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);
+// the same for any of the five headline formats (gemm_q_mfma.hip): Q4_K on aligned rows -> k_gemm_kq_t64<.., IDS>, the others -> k_gemm_q<.., IDS>
+bool cdna4_gemm_ids_supported(int type, int64_t K);
+int cdna4_launch_gemm_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);
+// the activation image of the rows src_rows[0 .. img_rows) for the grouped MUL_MAT_ID (quantize_act.hip): Q8_K (K-quants) or Q8_0 quantization
+int cdna4_launch_quantize_q8_0_gather(const float *x, int64_t x_row_stride, int64_t K, int64_t img_rows, const int32_t *src_rows, void *xh, hipStream_t st);
 bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B);
 // convert_w.hip: exact re-encodings Q5_0 -> Q8_0, Q3_K -> Q6_K (prefill GEMM of the source format = GEMM of the target format) and
 // Q2_K -> [scale part | minimum part] as Q6_K with 2 K columns (kmul = 2: the activation image must hold x twice)

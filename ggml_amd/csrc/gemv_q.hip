@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void k_gemv_q(const cdna4_gemv_args a) {
     for (int r = 0; r < ROWS; r++)
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            const float s = wave_sum(acc[r][c]);
+            const float s = wave_sum_dpp(acc[r][c]);
             if (lane == 0 && row0 + r < a.M) a.Y[(int64_t)ycol[c] * a.y_col_stride + row0 + r] = epilogue_apply(a.epi, s, row0 + r, ycol[c]);
         }
 }
@@ -607,11 +607,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
             float amax = 0.f, mx = 0.f; int idx = 0;
 #pragma unroll
             for (int i = 0; i < 16; i++) { const float ax = fabsf(e[i]); if (ax > amax) { amax = ax; mx = e[i]; idx = (c & 15) * 16 + i; } }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const float oa = __shfl_xor(amax, o, 64), om = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(idx, o, 64);
-                if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
-            }
+            // 16-lane all-reduce on the VALU (cdna4_common.h: dpp_*): the selection (largest |x|, then smallest index) is commutative and associative
+            auto take = [&](float oa, float om, int oi) __attribute__((always_inline)) { if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; } };
+            take(dpp_f32<0xB1>(amax), dpp_f32<0xB1>(mx), dpp_i32<0xB1>(idx));
+            take(dpp_f32<0x4E>(amax), dpp_f32<0x4E>(mx), dpp_i32<0x4E>(idx));
+            take(dpp_f32<0x141>(amax), dpp_f32<0x141>(mx), dpp_i32<0x141>(idx));
+            take(dpp_f32<0x140>(amax), dpp_f32<0x140>(mx), dpp_i32<0x140>(idx));
             float d = 0.f; int bsum = 0;
             if (amax != 0.f) {
                 const float iscale = -127.f / mx;
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
             float amax = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; i++) amax = fmaxf(amax, fabsf(e[i]));
-            amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+            amax = fmaxf(amax, dpp_f32<0xB1>(amax));                        // the block's other 16 values: the neighbouring lane
             const float d = amax / 127.f, id = amax != 0.f ? 127.f / amax : 0.f;
 #pragma unroll
             for (int i = 0; i < 16; i++) q[i] = (int)__builtin_rintf(e[i] * id);
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
                 int sum = 0;
 #pragma unroll
                 for (int i = 0; i < 16; i++) sum += q[i];
-                sum += __shfl_xor(sum, 1, 64);
+                sum += dpp_i32<0xB1>(sum);
                 if ((c & 1) == 0) reinterpret_cast<float *>(sbs)[col * nqd + (c >> 1)] = h2f(f2h_bits(d * (float)sum));
             }
         }
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
     for (int r = 0; r < ROWS; r++)
 #pragma unroll
         for (int c = 0; c < NB; c++) {
-            const float s = wave_sum(acc[r][c]);
+            const float s = wave_sum_dpp(acc[r][c]);
             if (lane == 0 && row0 + r < a.M && c < (NB == 1 ? 1 : a.ncol)) a.Y[(int64_t)c * a.y_col_stride + row0 + r] = epilogue_apply(a.epi, s, row0 + r, c);
         }
 }

@@ -89,13 +89,16 @@ __global__ __launch_bounds__(256) void k_quantize_q8_K(const float *__restrict__
 // (d = amax/127 -> fp16, id = 127/amax, RNE); REF=true: _ref semantics (id = 1/d, roundf ties away).
 template <bool REF>
 __global__ __launch_bounds__(256) void k_quantize_q8_0(const float *__restrict__ x, int64_t x_row_stride, int K, int B,
-                                                       int8_t *__restrict__ qs, float *__restrict__ dd, half_t *__restrict__ xh) {
+                                                       int8_t *__restrict__ qs, float *__restrict__ dd, half_t *__restrict__ xh, const int32_t *__restrict__ src_rows) {
     const int nb = K / 32;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;             // one thread per 4 elements
     const int64_t blk = t >> 3;
     if (blk >= (int64_t)B * nb) return;                                     // whole 8-lane groups drop out together
     const int b = (int)(blk / nb), ib = (int)(blk % nb), sub = (int)(t & 7);
-    const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t)b * x_row_stride + (int64_t)ib * 32 + sub * 4);
+    // src_rows (grouped MUL_MAT_ID): output row b is the quantized input row src_rows[b]; < 0 = padding row, left untouched (uniform over the block's 8 lanes)
+    int sb = b;
+    if (src_rows) { sb = src_rows[b]; if (sb < 0) return; }
+    const float4 v = *reinterpret_cast<const float4 *>(x + (int64_t)sb * x_row_stride + (int64_t)ib * 32 + sub * 4);
     const float e[4] = {v.x, v.y, v.z, v.w};
     int q[4]; float dh;
     q8_0_block<REF>(e, q, dh);
@@ -216,14 +219,22 @@ int cdna4_launch_quantize_q8_K_gather(const float *x, int64_t x_row_stride, int6
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
+int cdna4_launch_quantize_q8_0_gather(const float *x, int64_t x_row_stride, int64_t K, int64_t img_rows, const int32_t *src_rows, void *xh, hipStream_t st) {
+    if (K % 32) return cdna4_set_error_msg("quantize_q8_0: K must be a multiple of 32");
+    if (img_rows == 0 || K == 0) return 0;
+    const int64_t nthr = img_rows * (K / 4);
+    hipLaunchKernelGGL(k_quantize_q8_0<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)img_rows, (int8_t *)nullptr, (float *)nullptr, (half_t *)xh, src_rows);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
 int cdna4_launch_quantize_q8_0(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d,
                                void *xh, bool ref_rounding, hipStream_t st) {
     if (K % 32) return cdna4_set_error_msg("quantize_q8_0: K must be a multiple of 32");
     if (B == 0 || K == 0) return 0;
     const int64_t nthr = B * (K / 4);
     const dim3 grid((unsigned)((nthr + 255) / 256));
-    if (ref_rounding) hipLaunchKernelGGL(k_quantize_q8_0<true>, grid, dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, (half_t *)xh);
-    else hipLaunchKernelGGL(k_quantize_q8_0<false>, grid, dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, (half_t *)xh);
+    if (ref_rounding) hipLaunchKernelGGL(k_quantize_q8_0<true>, grid, dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, (half_t *)xh, (const int32_t *)nullptr);
+    else hipLaunchKernelGGL(k_quantize_q8_0<false>, grid, dim3(256), 0, st, x, x_row_stride, (int)K, (int)B, qs, d, (half_t *)xh, (const int32_t *)nullptr);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

@@ -84,7 +84,7 @@ def test_64x128_wave_tile_kernel_resources(tmp_path):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm", "-S", "--cuda-device-only", "-o", str(out), src],
                    check=True, capture_output=True, timeout=900)
     asm = out.read_text()
-    for tm, max_scratch in ((128, 0), (256, 128)):
+    for tm, max_scratch in ((128, 0), (256, 192)):        # (256-row form: loader-only address registers + epilogue temporaries parked AROUND the loops)
         k = "_Z13k_gemm_kq_t64ILi12ELi%dELb0ELi0EEv11gemm_params" % tm
         assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= 256
         assert _prop(asm, k, "private_seg_size") <= max_scratch
@@ -540,11 +540,13 @@ def test_32_weight_formats_with_k_not_a_multiple_of_64_on_the_cpu(name, t, k):
     assert mod.mul_mat_id(t, 32, k, 4, 2, 2, 1, seed=k + 1, timeout=300) < 1e-5
 
 
-@pytest.mark.parametrize("m,k,ne,nu,nb,nt", [(128, 512, 4, 2, 2, 32), (64, 256, 8, 2, 1, 40), (130, 768, 3, 2, 2, 70)])
-def test_whole_library_grouped_mul_mat_id_on_the_cpu(m, k, ne, nu, nb, nt):
-    """prefill-sized MUL_MAT_ID on Q4_K through the C-ABI on the CPU: the device-side counting sort of the expert ids (k_moe_plan), the gathering
-    activation quantizer and the grouped k_gemm_kq_t64 launch — ragged per-expert counts, padding rows, broadcast activation rows"""
-    r = _emul_module("lib_emul_check").mul_mat_id(12, m, k, ne, nu, nb, nt, seed=5, timeout=300)
+@pytest.mark.parametrize("t,m,k,ne,nu,nb,nt", [(12, 128, 512, 4, 2, 2, 32), (12, 64, 256, 8, 2, 1, 40), (12, 130, 768, 3, 2, 2, 70),
+                                                (13, 130, 512, 3, 2, 2, 40), (14, 64, 256, 4, 2, 1, 40), (2, 130, 384, 3, 2, 2, 40), (8, 64, 256, 4, 2, 2, 33)])
+def test_whole_library_grouped_mul_mat_id_on_the_cpu(t, m, k, ne, nu, nb, nt):
+    """prefill-sized MUL_MAT_ID through the C-ABI on the CPU: the device-side counting sort of the expert ids (k_moe_plan), the gathering
+    activation quantizer (Q8_K / Q8_0) and the grouped launch — k_gemm_kq_t64<.., IDS> for Q4_K, k_gemm_q<.., IDS> for Q5_K / Q6_K / Q4_0 / Q8_0 —
+    ragged per-expert counts, padding rows, broadcast activation rows"""
+    r = _emul_module("lib_emul_check").mul_mat_id(t, m, k, ne, nu, nb, nt, seed=5, timeout=300)
     if r is None:
         pytest.skip("the environment cannot host the emulation")
     assert r < 1e-3, r

@@ -434,15 +434,18 @@ def test_mul_mat_id_single_token_is_one_fused_launch(gu, name, t, n_expert, n_us
     assert e < TOL_GEMV
 
 
+@pytest.mark.parametrize("name,t", WT)
 @pytest.mark.parametrize("n_expert,n_used,n_b_is_one,n_tok,m,k", [(8, 2, False, 512, 4096, 4096), (8, 2, False, 96, 512, 512), (4, 4, True, 33, 300, 768),
                                                                   (16, 2, False, 40, 256, 256), (8, 1, False, 700, 640, 1024), (3, 2, False, 200, 128, 2048)])
-def test_mul_mat_id_grouped_prefill(gu, n_expert, n_used, n_b_is_one, n_tok, m, k):
-    """prefill-sized MUL_MAT_ID on Q4_K (n_tok * n_used > 32): the (token, slot) rows are counting-sorted by expert on the device,
-    quantized through the sort (gather) and multiplied in ONE launch of k_gemm_kq_t64<.., IDS>; ragged per-expert counts, experts
-    that receive no row, an expert id out of range (its slot must stay untouched), b broadcast over the slots (n_b = 1), repeated
-    calls on one workspace.  Against the oracle's MUL_MAT_ID (per-expert mul_mat, ggml-cpu.c:7648-7781) with the GEMM tolerance."""
+def test_mul_mat_id_grouped_prefill(gu, name, t, n_expert, n_used, n_b_is_one, n_tok, m, k):
+    """prefill-sized MUL_MAT_ID (n_tok * n_used > 32) on all five formats: the (token, slot) rows are counting-sorted by expert on the device,
+    quantized through the sort (gather: Q8_K / Q8_0) and multiplied in ONE launch — k_gemm_kq_t64<.., IDS> for Q4_K, k_gemm_q<.., IDS> (per-lane loads
+    of the original blocks) for Q5_K / Q6_K / Q4_0 / Q8_0; ragged per-expert counts, experts that receive no row, an expert id out of range (its
+    slot must stay untouched), b broadcast over the slots (n_b = 1), repeated calls on one workspace.  Against the oracle's MUL_MAT_ID (per-expert
+    mul_mat, ggml-cpu.c:7648-7781) with the GEMM tolerance."""
     from ggml_amd import ops
-    t = R.Q4_K
+    if m >= 4096 and t != R.Q4_K and t != R.Q6_K:
+        pytest.skip("headline-sized experts: Q4_K and one per-lane-load format")
     rng = np.random.default_rng(n_expert * 10 + n_used + n_tok)
     w = R.random_weights(t, n_expert * m, k, seed=5)
     n_b = 1 if n_b_is_one else n_used

@@ -135,6 +135,18 @@ template <typename T> static inline T __shfl_xor(T v, int o, int = 64) {
     pthread_barrier_wait(&w.bar);
     return r;
 }
+// value of lane `src` (any lane of the wave): the fallback of cdna4_common.h's DPP helpers and of v_readlane
+template <typename T> static inline T emu_shfl_idx(T v, int src) {
+    static_assert(sizeof(T) == 4, "32-bit shuffles only");
+    emu::WaveState &w = emu::my_wave();
+    const int l = emu::t_threadIdx.x & 63;
+    memcpy(&w.xch[l], &v, 4);
+    pthread_barrier_wait(&w.bar);
+    T r; memcpy(&r, &w.xch[src & 63], 4);
+    pthread_barrier_wait(&w.bar);
+    return r;
+}
+#define __builtin_amdgcn_readlane(v, lane_) emu_shfl_idx((int)(v), (lane_))
 static inline int emu_sdot4(int a, int b, int c) { for (int i = 0; i < 4; i++) c += (int)(int8_t)(a >> (8 * i)) * (int)(int8_t)(b >> (8 * i)); return c; }
 #define __builtin_amdgcn_sdot4(a, b, c, clamp) emu_sdot4(a, b, c)
 // LDS-DMA, builtin form: every lane copies `size` bytes from ITS global address to the wave's LDS base + lane * size (performed at once)
