@@ -118,8 +118,17 @@ int ggml_cdna4_quantize_q8_1(const float *x, int64_t x_row_stride, int64_t K, in
     return cdna4_launch_quantize_q8_1(x, x_row_stride, K, B, qs, d, s, xh, false, (hipStream_t)stream);
 }
 
+// AUTO: one row -> the one-launch decode GEMV; 2 .. 64 rows of a format the int8 matrix-core kernel takes (mmq_i8.hip) -> that (an integer-dot
+// path like the GEMV: PATH_GEMV family, workspace = the int8 SoA); above 8 rows otherwise, and above 64 always -> the fp16 MFMA GEMM
+static bool use_mmq(int type, int64_t M, int64_t K, int64_t B) {
+    static const bool off = getenv("CDNA4_NO_MMQ") && atoi(getenv("CDNA4_NO_MMQ")) != 0;
+    return !off && cdna4_mmq_supported(type, M, K, B);
+}
 static int resolve_path(int type, int path, int64_t M, int64_t K, int64_t B) {
-    if (path == GGML_CDNA4_PATH_AUTO) return (B > 8 && cdna4_gemm_q_supported(type, M, K, B)) ? GGML_CDNA4_PATH_GEMM : GGML_CDNA4_PATH_GEMV;
+    if (path == GGML_CDNA4_PATH_AUTO) {
+        if (use_mmq(type, M, K, B)) return GGML_CDNA4_PATH_GEMV;
+        return (B > 8 && cdna4_gemm_q_supported(type, M, K, B)) ? GGML_CDNA4_PATH_GEMM : GGML_CDNA4_PATH_GEMV;
+    }
     return path;
 }
 
@@ -170,6 +179,7 @@ static int mul_mat_prepared_impl(int type, const void *W, int64_t w_row_bytes, f
     if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat: K is not a whole number of blocks");
     const ws_view v = carve(type, K, B, (void *)workspace);
     if (workspace_bytes < v.total) return cdna4_set_error_msg("mul_mat: workspace too small");
+    const bool mmq = path == GGML_CDNA4_PATH_AUTO && use_mmq(type, M, K, B) && !(((uintptr_t)W | (uintptr_t)w_row_bytes) & 15);
     path = resolve_path(type, path, M, K, B);
     if (path == GGML_CDNA4_PATH_GEMM) {
         const cdna4_gemm_args a = gemm_args_of(type, W, w_row_bytes, v.xh, Y, y_row_stride, M, K, B, gemm_variant, splitk, epi);
@@ -180,6 +190,7 @@ static int mul_mat_prepared_impl(int type, const void *W, int64_t w_row_bytes, f
     g.type = type; g.W = (const uint8_t *)W; g.w_row_bytes = w_row_bytes; g.qs = v.qs; g.d = v.d; g.bsums = v.bsums;
     g.Y = Y; g.y_col_stride = y_row_stride; g.M = (int)M; g.K = (int)K; g.ncol = (int)B; g.ids = nullptr; g.epi = epi;
     *tail_done = true;
+    if (mmq) return cdna4_launch_mmq(g, (hipStream_t)stream);
     return cdna4_launch_gemv_q(g, (hipStream_t)stream);
 }
 
@@ -188,11 +199,13 @@ static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const floa
     if (!is_q(type)) return cdna4_set_error_msg("mul_mat: unsupported weight type");
     if (M <= 0 || B <= 0) return 0;
     if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat: K is not a whole number of blocks");
+    // the int8 matrix-core kernel: AUTO only (an explicit PATH_GEMV keeps the v_dot4 units — tests compare the two), aligned Q4_K rows
+    const bool mmq = path == GGML_CDNA4_PATH_AUTO && use_mmq(type, M, K, B) && !(((uintptr_t)W | (uintptr_t)w_row_bytes) & 15);
     path = resolve_path(type, path, M, K, B);
     if (path == GGML_CDNA4_PATH_GEMM && !cdna4_gemm_q_supported(type, M, K, B)) return cdna4_set_error_msg("mul_mat: GEMM path does not support this shape");
     // one launch while the redundant per-work-group quantization is cheap (B x K up to 32 K values, rounded to the instantiated 2 / 4 / 8 columns)
     const int64_t nbt = B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8));
-    if (path == GGML_CDNA4_PATH_GEMV && cdna4_gemv_fused_supported(type, K, B) && (B == 1 || nbt * K <= 32768) && !(((uintptr_t)X | (uintptr_t)(B > 1 ? x_row_stride * 4 : 0)) & 15)) {
+    if (!mmq && path == GGML_CDNA4_PATH_GEMV && cdna4_gemv_fused_supported(type, K, B) && (B == 1 || nbt * K <= 32768) && !(((uintptr_t)X | (uintptr_t)(B > 1 ? x_row_stride * 4 : 0)) & 15)) {
         // decode with 1..8 activation rows: the activation quantizer runs inside the GEMV kernel (workspace untouched), ONE launch
         cdna4_gemv_args g{};
         g.type = type; g.W = (const uint8_t *)W; g.w_row_bytes = w_row_bytes; g.Y = Y; g.y_col_stride = y_row_stride;
@@ -206,6 +219,7 @@ static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const floa
         cdna4_gemv_args g{};
         g.type = type; g.W = (const uint8_t *)W; g.w_row_bytes = w_row_bytes; g.qs = v.qs; g.d = v.d; g.bsums = v.bsums;
         g.Y = Y; g.y_col_stride = y_row_stride; g.M = (int)M; g.K = (int)K; g.ncol = (int)B; g.ids = nullptr; g.epi = epi;
+        if (mmq) return cdna4_launch_mmq(g, (hipStream_t)stream);                                                   // 2..64 rows: int8 MFMA
         if (cdna4_gemv_staged_supported(type, K, B)) return cdna4_launch_gemv_q_staged(g, (hipStream_t)stream);    // 2..8 rows: columns from LDS
         return cdna4_launch_gemv_q(g, (hipStream_t)stream);
     }

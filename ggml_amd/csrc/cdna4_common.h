@@ -113,6 +113,13 @@ template <int CTRL, int ROW_MASK = 0xF> static inline int dpp_i32(int v, int old
     return writes ? got : old;
 }
 #endif
+// LDS traffic between the lanes of ONE wave needs no barrier on the GPU (a wave's LDS operations execute in order) — only the compiler must
+// not move the reads over the writes; on the host build every lane is an OS thread and has to wait for its wave
+#if defined(__HIPCC__)
+#define CDNA4_WAVE_LDS_SYNC() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define CDNA4_WAVE_LDS_SYNC() emu::wave_sync()
+#endif
 template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp_f32(float v, float old = 0.f) {
     return __builtin_bit_cast(float, dpp_i32<CTRL, ROW_MASK>(__builtin_bit_cast(int, v), __builtin_bit_cast(int, old)));
 }

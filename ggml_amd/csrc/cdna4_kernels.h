@@ -57,6 +57,11 @@ int cdna4_launch_gemv_q_staged(const cdna4_gemv_args &a, hipStream_t st);
 // single-token MUL_MAT_ID in one launch (a.ids set, a.ncol = n_used slots; x rows x_row_stride apart, slot u reads row u % a.n_b)
 int cdna4_launch_gemv_q_fused_ids(const cdna4_gemv_args &a, const float *x, int64_t x_row_stride, hipStream_t st);
 
+// mmq_i8.hip — 2 .. 64 activation rows on the int8 matrix cores (v_mfma_i32_16x16x32_i8): the GEMV's integer block dots, sixteen columns at a time;
+// a.qs / a.d / a.bsums as for cdna4_launch_gemv_q (Q8_K workspace), a.epi applied in the store
+bool cdna4_mmq_supported(int type, int64_t M, int64_t K, int64_t B);
+int cdna4_launch_mmq(const cdna4_gemv_args &a, hipStream_t st);
+
 // gemm_q_mfma.hip — fp16 MFMA prefill path.  xh = pair-interleaved fp16 activations [B][K].
 struct cdna4_gemm_args {
     int type;

@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 3, session 7: compact store loop of k_gemm_kq_t64 (code size), the int8 matrix-core small-batch kernel, grouped MUL_MAT_ID tolerances
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+for shape in "4096 4096 512" "4096 11008 512" "32768 8192 512"; do GB_VARIANTS=0 GB_SPLITKS=0 GB_ROUNDS=3 timeout 120 tools/microbench/gemm_bench $shape 2>&1 | grep -E "variant|M=" ; done
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_cabi_ops.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/s7_pytest.log 2>&1
+echo "pytest rc=$?"; grep -E "^(FAILED|ERROR)|^E  " gpurun_out/s7_pytest.log | head -20; tail -2 gpurun_out/s7_pytest.log
+timeout 400 python - <<'PY'
+import json, torch, bench
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+from ggml_amd import native; native.lib()
+print("batch_sweep", json.dumps(bench.batch_sweep(dev, 100)))
+print("decode", json.dumps({k: v.get("us_per_step") for k, v in bench.decode_rows(dev, 200).items()}))
+PY
+timeout 200 python bench.py --lean --steps 300 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench lean: step_us %.2f gemm_us %.2f value %.1f' % (d['ms_per_step']*1e3, d['roofline']['us_per_launch'], d['value']))"

@@ -366,6 +366,30 @@ def test_full_size_prefill_config(gu, m, k, b):
     assert R.rel_l2(ysh, y) < 2e-6
 
 
+@pytest.mark.parametrize("m,k,b", [(48, 1024, 2), (100, 512, 5), (512, 2048, 8), (37, 768, 9), (256, 4096, 16), (130, 1024, 17), (64, 2304, 33), (4096, 4096, 64),
+                                   (4096, 14336, 8), (4096, 14336, 40)])
+def test_small_batches_on_the_int8_matrix_cores(gu, m, k, b):
+    """2 .. 64 activation rows of a Q4_K MUL_MAT take k_mmq_q4_K (mmq_i8.hip: v_mfma_i32_16x16x32_i8 on the Q8_K-quantized activations — the integer
+    block dots of ggml_vec_dot_q4_K_q8_K): within the GEMV bar of the oracle (the fp16 GEMM these sizes used to take above 8 rows sits at 3e-4),
+    equal to the v_dot4 GEMV units to fp32 summation order, deterministic, weight-row counts that are no multiple of 16, more rows than one
+    16-column group."""
+    from ggml_amd import ops
+    t = R.Q4_K
+    w = R.random_weights(t, m, k, seed=m + k + b) if m * k <= (1 << 24) else R.random_block_bytes(t, m, k, np.random.default_rng(m + k + b))
+    x = _x(b + 3 * k, b, k)
+    a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
+    y = ops.mul_mat(a, xd).cpu().numpy()
+    assert np.isfinite(y).all()
+    rows = np.arange(m) if m <= 512 else np.random.default_rng(0).choice(m, 64, replace=False)
+    rs = R.row_size(t, k)
+    wsub = np.concatenate([w[r * rs:(r + 1) * rs] for r in rows])
+    e = R.rel_l2(y[:, rows], R.o_mul_mat(t, wsub, x, len(rows), k)); gu.report(test="mmq_i8", m=m, k=k, b=b, rel_l2=e)
+    assert e < TOL_GEMV
+    assert np.array_equal(y, ops.mul_mat(a, xd).cpu().numpy())
+    if b <= 16:
+        assert R.rel_l2(y, ops.mul_mat(a, xd, path=ops.PATH_GEMV).cpu().numpy()) < 2e-6
+
+
 def test_full_size_c5_config(gu):
     """BASELINE configs[4] on one GPU: Q4_K [32768 x 8192] . [8192 x 512] — the only BASELINE shape that takes the 256-row tile instantiation
     (k_gemm_kq_t64<Q4_K, 256>, no K split).  A 64-row sample of weight rows against the oracle, determinism, and the row-shard property of the
@@ -410,7 +434,7 @@ def test_mul_mat_id_parity(gu, name, t, n_expert, n_used, n_b_is_one, n_tok):
     y = ops.mul_mat_id(gu.qtensor(t, w, n_expert * m, k), gu.to_dev(xb), gu.to_dev(ids), n_expert=n_expert).cpu().numpy()
     yo = R.o_mul_mat_id(t, w, xb, ids, m, k, n_expert)
     e = R.rel_l2(y, yo); gu.report(test="mul_mat_id", type=name, rel_l2=e)
-    grouped = t == R.Q4_K and n_tok * n_used > 32                  # capi.hip: Q4_K with more than 32 (token, slot) rows takes the grouped GEMM
+    grouped = n_tok * n_used > 32                                   # capi.hip: more than 32 (token, slot) rows take the grouped fp16 GEMM (all five formats since round 3)
     assert e < (TOL_GEMM if grouped else TOL_GEMV)
 
 

@@ -207,3 +207,25 @@ static inline emu_floatx16 emu_mfma_32x32x16_f16(emu_half8 a, emu_half8 b, emu_f
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16_f16(a, b, c)
+// v_mfma_i32_16x16x32_i8, wave-collective: lane l supplies A[row l % 16][k 8 (l / 16) .. + 7] and B[k ..][col l % 16] (eight int8 in a 64-bit
+// operand each) and receives D[row 4 (l / 16) + v][col l % 16] for v = 0 .. 3
+typedef int emu_intx4 __attribute__((ext_vector_type(4)));
+static inline emu_intx4 emu_mfma_i32_16x16x32_i8(long a, long b, emu_intx4 c) {
+    emu::WaveState &w = emu::my_wave();
+    const int l = emu::t_threadIdx.x & 63;
+    static_assert(sizeof(w.A[0]) >= 8 && sizeof(w.B[0]) >= 8, "operand staging");
+    memcpy(&w.A[l][0], &a, 8); memcpy(&w.B[l][0], &b, 8);
+    pthread_barrier_wait(&w.bar);
+    const int n = l & 15, g = l >> 4;
+    for (int v = 0; v < 4; v++) {
+        const int i = 4 * g + v; int s = 0;
+        for (int kg = 0; kg < 4; kg++) {
+            int8_t ra[8], rb[8]; memcpy(ra, &w.A[i + 16 * kg][0], 8); memcpy(rb, &w.B[n + 16 * kg][0], 8);
+            for (int e = 0; e < 8; e++) s += (int)ra[e] * (int)rb[e];
+        }
+        c[v] += s;
+    }
+    pthread_barrier_wait(&w.bar);
+    return c;
+}
+#define __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b, c, x, y, z) emu_mfma_i32_16x16x32_i8(a, b, c)

@@ -20,7 +20,7 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ggml_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-FILES = ["quantize_act.hip", "gemv_q.hip", "gemm_q_mfma.hip", "gemm_q_t64.hip", "convert_w.hip", "ops.hip", "fattn.hip"]
+FILES = ["quantize_act.hip", "gemv_q.hip", "mmq_i8.hip", "gemm_q_mfma.hip", "gemm_q_t64.hip", "convert_w.hip", "ops.hip", "fattn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm", "-S", "--cuda-device-only"]
 # kernels written after round 2's last hardware session (emulator-verified only): everything else in the round-2 manifest is hw = true
 NOT_ON_HARDWARE_YET = [r"k_convert_q2_K_q6_K2", r"k_convert_q41_q8_0x2", r"k_convert_iq4_", r"k_quantize_q8_1", r"k_q_to_f16_dense",
