@@ -55,7 +55,11 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     T64_ABL(1) T64_ABL(3) T64_ABL(4) T64_ABL(8) T64_ABL(15) T64_ABL(32) T64_ABL(256)
     if (abl) return cdna4_set_error_msg("gemm_t64: ablation not instantiated");
 #endif
-    if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128>), grid, dim3(512), 0, st, p);
+    const bool tail = p.epi.bias != nullptr || p.epi.act != 0 || p.epi.resid != nullptr;
+    if (tail) {
+        if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, false, 0, true>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256, false, 0, true>), grid, dim3(512), 0, st, p);
+    } else if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256>), grid, dim3(512), 0, st, p);
     CDNA4_CHECK_LAUNCH();
     return 0;

@@ -36,6 +36,12 @@ struct mmq_args {
 };
 
 __device__ __forceinline__ u32x2 ld_u32x2_a4(const void *p) { return *reinterpret_cast<const u32x2 *>(p); }
+// 24-bit integer multiply (v_mul_i32_i24: full rate; the 32-bit v_mul_lo_u32 is a quarter of it) — both factors fit by construction here
+#if defined(__HIPCC__)
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+#else
+static inline int mul24(int a, int b) { return a * b; }
+#endif
 __device__ __forceinline__ long as_i64(uint32_t lo, uint32_t hi) { return (long)(((uint64_t)hi << 32) | lo); }
 
 // NCG column groups of 16 activation rows each (B <= 16 NCG)
@@ -58,7 +64,11 @@ __global__ __launch_bounds__(512) void k_mmq_q4_K(const mmq_args a) {
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[g][i] = 0.f;
 
+    // everything a superblock needs from memory, requested one superblock AHEAD (cur / nxt): this row's weights, and per 16-column group the eight
+    // activation fragments, four bsums and the column's d — the first version loaded the activation side at its use and spent a full L2 round trip
+    // per fragment (24 us at 4096 x 14336 x 16 where the weights stream in 5)
     struct WSb { u32x4 hdr; u32x2 q[4]; };
+    struct XSb { u32x2 xl[4], xh[4], bs; float dy; };
     auto load_w = [&](int sb) __attribute__((always_inline)) {
         WSb w; const uint8_t *blk = wrow + (int64_t)sb * 144;
         w.hdr = ld_u32x4(blk);
@@ -66,20 +76,40 @@ __global__ __launch_bounds__(512) void k_mmq_q4_K(const mmq_args a) {
         for (int g = 0; g < 4; g++) w.q[g] = ld_u32x2_a4(blk + 16 + 32 * g + 8 * grp);
         return w;
     };
-    WSb cur{};
-    if (wave < nsb) cur = load_w(wave);
+    auto load_x = [&](int sb, int g) __attribute__((always_inline)) {
+        XSb x; const int b = min(g * 16 + col, a.B - 1);
+        const int8_t *xq = a.qs + (int64_t)b * a.K + sb * 256 + 8 * grp;
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) { x.xl[gq] = ld_u32x2_a4(xq + 64 * gq); x.xh[gq] = ld_u32x2_a4(xq + 64 * gq + 32); }
+        x.bs = ld_u32x2_a4(a.bsums + (int64_t)b * (a.K / 16) + sb * 16 + 4 * grp);
+        x.dy = a.d[(int64_t)b * nsb + sb];
+        return x;
+    };
+    WSb cur{}; XSb xc[NCG];
+#pragma unroll
+    for (int g = 0; g < NCG; g++) xc[g] = XSb{};
+    if (wave < nsb) {
+        cur = load_w(wave);
+#pragma unroll
+        for (int g = 0; g < NCG; g++) xc[g] = load_x(wave, g);
+    }
     for (int sb = wave; sb < nsb; sb += NW) {
-        WSb nxt{};
-        if (sb + NW < nsb) nxt = load_w(sb + NW);
+        WSb nxt{}; XSb xn[NCG];
+#pragma unroll
+        for (int g = 0; g < NCG; g++) xn[g] = XSb{};
+        if (sb + NW < nsb) {
+            nxt = load_w(sb + NW);
+#pragma unroll
+            for (int g = 0; g < NCG; g++) xn[g] = load_x(sb + NW, g);
+        }
         // ---- activation metadata of this superblock -> the wave's LDS slot: lane (b = col, part = grp) adds bsums 4 part .. 4 part + 3 in pairs
         CDNA4_WAVE_LDS_SYNC();                                           // the previous superblock's reads of the slot are over
 #pragma unroll
         for (int g = 0; g < NCG; g++) {
-            const int b = min(g * 16 + col, a.B - 1);
-            const u32x2 bs = ld_u32x2_a4(a.bsums + (int64_t)b * (a.K / 16) + sb * 16 + 4 * grp);
+            const u32x2 bs = xc[g].bs;
             const int p0 = (int)(int16_t)(bs.x & 0xFFFF) + (int)(int16_t)(bs.x >> 16), p1 = (int)(int16_t)(bs.y & 0xFFFF) + (int)(int16_t)(bs.y >> 16);
             *reinterpret_cast<uint32_t *>(meta + (g * 16 + col) * 32 + 4 * grp) = (uint32_t)(p0 & 0xFFFF) | ((uint32_t)p1 << 16);
-            if (grp == 0) *reinterpret_cast<float *>(meta + (g * 16 + col) * 32 + 16) = a.d[(int64_t)b * nsb + sb];
+            if (grp == 0) *reinterpret_cast<float *>(meta + (g * 16 + col) * 32 + 16) = xc[g].dy;
         }
         CDNA4_WAVE_LDS_SYNC();                                           // the slot is written: other lanes' entries may be read
         // ---- this row's scales and minima (get_scale_min_k4, src/ggml-quants.c:631-638), d and dmin
@@ -92,14 +122,13 @@ __global__ __launch_bounds__(512) void k_mmq_q4_K(const mmq_args a) {
             intx4 sumi = {0, 0, 0, 0};
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {                             // 64-weight group gq: sub-blocks 2 gq (low nibbles) and 2 gq + 1 (high)
-                const int b = min(g * 16 + col, a.B - 1);
-                const int8_t *xq = a.qs + (int64_t)b * a.K + sb * 256 + 64 * gq + 8 * grp;
-                const u32x2 xl = ld_u32x2_a4(xq), xh = ld_u32x2_a4(xq + 32);
+                const u32x2 xl = xc[g].xl[gq], xh = xc[g].xh[gq];
                 const intx4 z = {0, 0, 0, 0};
                 const intx4 sl = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xl.x, xl.y), as_i64(cur.q[gq].x & 0x0F0F0F0Fu, cur.q[gq].y & 0x0F0F0F0Fu), z, 0, 0, 0);
                 const intx4 sh = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xh.x, xh.y), as_i64((cur.q[gq].x >> 4) & 0x0F0F0F0Fu, (cur.q[gq].y >> 4) & 0x0F0F0F0Fu), z, 0, 0, 0);
+                // |S| <= 32 * 15 * 127 and sc < 64: 24-bit multiplies (full rate; v_mul_lo_u32 is a quarter of it)
 #pragma unroll
-                for (int i = 0; i < 4; i++) sumi[i] += sc[2 * gq] * sl[i] + sc[2 * gq + 1] * sh[i];
+                for (int i = 0; i < 4; i++) sumi[i] += mul24(sc[2 * gq], sl[i]) + mul24(sc[2 * gq + 1], sh[i]);
             }
             // minimum term and the fp32 scale products: rows b = 4 grp + i of this column group
 #pragma unroll
@@ -110,11 +139,13 @@ __global__ __launch_bounds__(512) void k_mmq_q4_K(const mmq_args a) {
                 const uint32_t pw[4] = {ps.x, ps.y, ps.z, ps.w};
                 int summs = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) summs += mn[2 * j] * (int)(int16_t)(pw[j] & 0xFFFF) + mn[2 * j + 1] * (int)(int16_t)(pw[j] >> 16);
+                for (int j = 0; j < 4; j++) summs += mul24(mn[2 * j], (int)(int16_t)(pw[j] & 0xFFFF)) + mul24(mn[2 * j + 1], (int)(int16_t)(pw[j] >> 16));
                 acc[g][i] += (dw * dy) * (float)sumi[i] - (dmin * dy) * (float)summs;
             }
         }
         cur = nxt;
+#pragma unroll
+        for (int g = 0; g < NCG; g++) xc[g] = xn[g];
     }
     // ---- the eight waves' partial tiles meet in LDS: [wave][group][4][64 lanes]
     __syncthreads();
