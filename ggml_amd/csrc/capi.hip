@@ -122,11 +122,15 @@ int ggml_cdna4_quantize_q8_1(const float *x, int64_t x_row_stride, int64_t K, in
 // path like the GEMV: PATH_GEMV family, workspace = the int8 SoA); above 8 rows otherwise, and above 64 always -> the fp16 MFMA GEMM
 static bool use_mmq(int type, int64_t M, int64_t K, int64_t B) {
     static const bool off = getenv("CDNA4_NO_MMQ") && atoi(getenv("CDNA4_NO_MMQ")) != 0;
-    // 2 .. 8 rows stay on the one-launch / staged GEMV (measured faster there: 10.6 / 10.4 / 14.0 us at 4096^2 for 2 / 4 / 8 rows against 13.2 / 13.7 / 13.8)
-    // and above 16 rows (32 for K <= 4096) the fp16 GEMM wins again: the kernel's 8-byte-per-lane operand loads (16 rows x 32 B per instruction) bind it
-    // to the address coalescer, not to HBM — MI355X, us per call incl. the quantizer: 4096^2: 16 rows 13.0 (GEMM 22.3), 32: 18.5 (23.7), 64: 34.0 (24.4);
-    // 4096 x 14336: 16: 30.0 (33.1), 32: 48.8 (35.3)
-    return !off && B >= 9 && (B <= 16 || (B <= 32 && K <= 4096)) && cdna4_mmq_supported(type, M, K, B);
+    static const int minb = getenv("CDNA4_MMQ_MINB") ? atoi(getenv("CDNA4_MMQ_MINB")) : 0, maxb = getenv("CDNA4_MMQ_MAXB") ? atoi(getenv("CDNA4_MMQ_MAXB")) : 0;   // measurement knobs
+    if (off || !cdna4_mmq_supported(type, M, K, B)) return false;
+    if (maxb > 0) return B >= (minb > 0 ? minb : 2) && B <= maxb;
+    // Where it wins on MI355X (us per call, quantizer launch included; profiles/r03/batch_sweep.txt): against the fp16 GEMM for 9 .. 32 rows
+    // (4096 x 14336: 14.3 / 21.2 vs 28.6 / 29.0 at 16 / 32 rows; 4096^2: 13.9 / 13.4 vs 19.5 / 19.8; at 64 rows the GEMM is level or ahead), and
+    // against the v_dot4 GEMV for 3 .. 8 rows once the matrix is large — the two launches cost ~13.5 us whatever the size, the one-launch GEMV 10.3
+    // at 4096^2 but 17.5 / 25.6 at 4096 x 14336 for 4 / 8 rows (mmq: 14.1 / 14.2).  Two rows stay on the GEMV everywhere.
+    if (B >= 9) return B <= 32;
+    return B >= 3 && M * K >= ((int64_t)1 << 25);
 }
 static int resolve_path(int type, int path, int64_t M, int64_t K, int64_t B) {
     if (path == GGML_CDNA4_PATH_AUTO) {

@@ -44,19 +44,25 @@ static inline int mul24(int a, int b) { return a * b; }
 #endif
 __device__ __forceinline__ long as_i64(uint32_t lo, uint32_t hi) { return (long)(((uint64_t)hi << 32) | lo); }
 
-// NCG column groups of 16 activation rows each (B <= 16 NCG)
-template <int NCG>
-__global__ __launch_bounds__(512) void k_mmq_q4_K(const mmq_args a) {
-    constexpr int NW = 8;
-    __shared__ __attribute__((aligned(16))) uint8_t smem[NW * NCG * 1024];
+// NCG column groups of 16 activation rows each (B <= 16 NCG); NW waves per work-group share the 16 weight rows and split the superblocks.
+// Memory side (second version; the first loaded every MFMA operand straight into its lane — 8 bytes per lane, sixteen rows 32 bytes each per
+// instruction — and was bound by the address coalescer: 25 us at 4096 x 14336 x 16): per superblock a wave fetches its slab with COALESCED 16-byte
+// loads — the sixteen columns' 256 quants (4 instructions per column group), their bsums and d, the sixteen rows' 144-byte superblocks (3
+// instructions) — one superblock AHEAD into registers, parks it in a private LDS area and reads the MFMA fragments from there (ds_read_b64, row
+// strides 272 / 144 bytes: conflict-free).
+template <int NCG, int NW>
+__global__ __launch_bounds__(NW * 64) void k_mmq_q4_K(const mmq_args a) {
+    constexpr int XROW = 272, XS = 16 * XROW, MS = 16 * 32, WSZ = 16 * 144;        // per wave: NCG x (quants | pair sums + d), then the weights
+    constexpr int SLAB = NCG * (XS + MS) + WSZ;
+    constexpr int SMEM = NW * SLAB > NW * NCG * 1024 ? NW * SLAB : NW * NCG * 1024;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, grp = lane >> 4;                        // MFMA lane roles: row / column l % 16, k-group l / 16
     const int m0 = blockIdx.x * 16;
-    const int mrow = min(m0 + col, a.M - 1);
-    const uint8_t *wrow = a.W + (int64_t)mrow * a.w_row_bytes;
     const int nsb = a.K / 256;
-    // per wave and column group: [16 columns][8 pair sums int16 | float d | pad] = 32 bytes per column (16-byte aligned reads)
-    uint8_t *meta = smem + wave * (NCG * 16 * 32);
+    uint8_t *slab = smem + wave * SLAB;
+    uint8_t *wl = slab + NCG * (XS + MS);
 
     float acc[NCG][4];
 #pragma unroll
@@ -64,68 +70,73 @@ __global__ __launch_bounds__(512) void k_mmq_q4_K(const mmq_args a) {
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[g][i] = 0.f;
 
-    // everything a superblock needs from memory, requested one superblock AHEAD (cur / nxt): this row's weights, and per 16-column group the eight
-    // activation fragments, four bsums and the column's d — the first version loaded the activation side at its use and spent a full L2 round trip
-    // per fragment (24 us at 4096 x 14336 x 16 where the weights stream in 5)
-    struct WSb { u32x4 hdr; u32x2 q[4]; };
-    struct XSb { u32x2 xl[4], xh[4], bs; float dy; };
-    auto load_w = [&](int sb) __attribute__((always_inline)) {
-        WSb w; const uint8_t *blk = wrow + (int64_t)sb * 144;
-        w.hdr = ld_u32x4(blk);
-#pragma unroll
-        for (int g = 0; g < 4; g++) w.q[g] = ld_u32x2_a4(blk + 16 + 32 * g + 8 * grp);
-        return w;
-    };
-    auto load_x = [&](int sb, int g) __attribute__((always_inline)) {
-        XSb x; const int b = min(g * 16 + col, a.B - 1);
-        const int8_t *xq = a.qs + (int64_t)b * a.K + sb * 256 + 8 * grp;
-#pragma unroll
-        for (int gq = 0; gq < 4; gq++) { x.xl[gq] = ld_u32x2_a4(xq + 64 * gq); x.xh[gq] = ld_u32x2_a4(xq + 64 * gq + 32); }
-        x.bs = ld_u32x2_a4(a.bsums + (int64_t)b * (a.K / 16) + sb * 16 + 4 * grp);
-        x.dy = a.d[(int64_t)b * nsb + sb];
-        return x;
-    };
-    WSb cur{}; XSb xc[NCG];
-#pragma unroll
-    for (int g = 0; g < NCG; g++) xc[g] = XSb{};
-    if (wave < nsb) {
-        cur = load_w(wave);
-#pragma unroll
-        for (int g = 0; g < NCG; g++) xc[g] = load_x(wave, g);
-    }
-    for (int sb = wave; sb < nsb; sb += NW) {
-        WSb nxt{}; XSb xn[NCG];
-#pragma unroll
-        for (int g = 0; g < NCG; g++) xn[g] = XSb{};
-        if (sb + NW < nsb) {
-            nxt = load_w(sb + NW);
-#pragma unroll
-            for (int g = 0; g < NCG; g++) xn[g] = load_x(sb + NW, g);
-        }
-        // ---- activation metadata of this superblock -> the wave's LDS slot: lane (b = col, part = grp) adds bsums 4 part .. 4 part + 3 in pairs
-        CDNA4_WAVE_LDS_SYNC();                                           // the previous superblock's reads of the slot are over
+    // ---- the slab of one superblock in registers: lane roles of the LOADS (coalesced), not of the MFMA
+    struct Slab { u32x4 x[NCG][4]; u32x4 bs[NCG]; float dy[NCG]; u32x4 w[3]; };
+    auto fetch = [&](int sb) __attribute__((always_inline)) {
+        Slab r;
 #pragma unroll
         for (int g = 0; g < NCG; g++) {
-            const u32x2 bs = xc[g].bs;
-            const int p0 = (int)(int16_t)(bs.x & 0xFFFF) + (int)(int16_t)(bs.x >> 16), p1 = (int)(int16_t)(bs.y & 0xFFFF) + (int)(int16_t)(bs.y >> 16);
-            *reinterpret_cast<uint32_t *>(meta + (g * 16 + col) * 32 + 4 * grp) = (uint32_t)(p0 & 0xFFFF) | ((uint32_t)p1 << 16);
-            if (grp == 0) *reinterpret_cast<float *>(meta + (g * 16 + col) * 32 + 16) = xc[g].dy;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {                                // piece i * 64 + lane: column 4 i + lane / 16, 16-byte chunk lane % 16
+                const int b = min(g * 16 + 4 * i + (lane >> 4), a.B - 1);
+                r.x[g][i] = ld_u32x4(a.qs + (int64_t)b * a.K + sb * 256 + (lane & 15) * 16);
+            }
+            const int bb = min(g * 16 + (lane >> 1), a.B - 1), bd = min(g * 16 + (lane & 15), a.B - 1);
+            r.bs[g] = lane < 32 ? ld_u32x4(a.bsums + (int64_t)bb * (a.K / 16) + sb * 16 + (lane & 1) * 8) : u32x4{0, 0, 0, 0};
+            r.dy[g] = a.d[(int64_t)bd * nsb + sb];
         }
-        CDNA4_WAVE_LDS_SYNC();                                           // the slot is written: other lanes' entries may be read
-        // ---- this row's scales and minima (get_scale_min_k4, src/ggml-quants.c:631-638), d and dmin
-        const float dw = h2f(cur.hdr.x & 0xFFFF), dmin = h2f(cur.hdr.x >> 16);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {                                    // piece i * 64 + lane of 144: row piece / 9, chunk piece % 9
+            const int pc = min(i * 64 + lane, 143), row = pc / 9, c = pc - row * 9;
+            r.w[i] = ld_u32x4(a.W + (int64_t)min(m0 + row, a.M - 1) * a.w_row_bytes + (int64_t)sb * 144 + c * 16);
+        }
+        return r;
+    };
+    auto park = [&](const Slab &r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < NCG; g++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) *reinterpret_cast<u32x4 *>(slab + g * (XS + MS) + (4 * i + (lane >> 4)) * XROW + (lane & 15) * 16) = r.x[g][i];
+            if (lane < 32) {                                             // eight bsums -> four pair sums (bsums[2j] + bsums[2j+1]: what a sub-block's minimum multiplies)
+                const uint32_t v[4] = {r.bs[g].x, r.bs[g].y, r.bs[g].z, r.bs[g].w};
+                int ps[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) ps[t] = (int)(int16_t)(v[t] & 0xFFFF) + (int)(int16_t)(v[t] >> 16);
+                *reinterpret_cast<u32x2 *>(slab + g * (XS + MS) + XS + (lane >> 1) * 32 + (lane & 1) * 8) =
+                    u32x2{(uint32_t)(ps[0] & 0xFFFF) | ((uint32_t)ps[1] << 16), (uint32_t)(ps[2] & 0xFFFF) | ((uint32_t)ps[3] << 16)};
+            }
+            if (lane < 16) *reinterpret_cast<float *>(slab + g * (XS + MS) + XS + lane * 32 + 16) = r.dy[g];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) if (i * 64 + lane < 144) *reinterpret_cast<u32x4 *>(wl + (i * 64 + lane) * 16) = r.w[i];
+    };
+
+    Slab cur{};
+    if (wave < nsb) cur = fetch(wave);
+    for (int sb = wave; sb < nsb; sb += NW) {
+        CDNA4_WAVE_LDS_SYNC();                                           // the previous superblock's fragment reads are over
+        park(cur);
+        CDNA4_WAVE_LDS_SYNC();
+        if (sb + NW < nsb) cur = fetch(sb + NW);                         // the next slab streams in under this one's arithmetic
+        // ---- this lane's weight row (column col of the MFMA's B operand): header, scales and minima (get_scale_min_k4, ggml-quants.c:631-638)
+        const u32x4 hdr = *reinterpret_cast<const u32x4 *>(wl + col * 144);
+        u32x2 wq[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) wq[gq] = *reinterpret_cast<const u32x2 *>(wl + col * 144 + 16 + 32 * gq + 8 * grp);
+        const float dw = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
         int sc[8], mn[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) k4_scale_min_rt(cur.hdr.y, cur.hdr.z, cur.hdr.w, j, sc[j], mn[j]);
+        for (int j = 0; j < 8; j++) k4_scale_min_rt(hdr.y, hdr.z, hdr.w, j, sc[j], mn[j]);
 #pragma unroll
         for (int g = 0; g < NCG; g++) {
+            const uint8_t *xs = slab + g * (XS + MS) + col * XROW + 8 * grp;
             intx4 sumi = {0, 0, 0, 0};
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {                             // 64-weight group gq: sub-blocks 2 gq (low nibbles) and 2 gq + 1 (high)
-                const u32x2 xl = xc[g].xl[gq], xh = xc[g].xh[gq];
+                const u32x2 xl = *reinterpret_cast<const u32x2 *>(xs + 64 * gq), xh = *reinterpret_cast<const u32x2 *>(xs + 64 * gq + 32);
                 const intx4 z = {0, 0, 0, 0};
-                const intx4 sl = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xl.x, xl.y), as_i64(cur.q[gq].x & 0x0F0F0F0Fu, cur.q[gq].y & 0x0F0F0F0Fu), z, 0, 0, 0);
-                const intx4 sh = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xh.x, xh.y), as_i64((cur.q[gq].x >> 4) & 0x0F0F0F0Fu, (cur.q[gq].y >> 4) & 0x0F0F0F0Fu), z, 0, 0, 0);
+                const intx4 sl = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xl.x, xl.y), as_i64(wq[gq].x & 0x0F0F0F0Fu, wq[gq].y & 0x0F0F0F0Fu), z, 0, 0, 0);
+                const intx4 sh = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xh.x, xh.y), as_i64((wq[gq].x >> 4) & 0x0F0F0F0Fu, (wq[gq].y >> 4) & 0x0F0F0F0Fu), z, 0, 0, 0);
                 // |S| <= 32 * 15 * 127 and sc < 64: 24-bit multiplies (full rate; v_mul_lo_u32 is a quarter of it)
 #pragma unroll
                 for (int i = 0; i < 4; i++) sumi[i] += mul24(sc[2 * gq], sl[i]) + mul24(sc[2 * gq + 1], sh[i]);
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(512) void k_mmq_q4_K(const mmq_args a) {
             // minimum term and the fp32 scale products: rows b = 4 grp + i of this column group
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint8_t *mb = meta + (g * 16 + 4 * grp + i) * 32;
+                const uint8_t *mb = slab + g * (XS + MS) + XS + (4 * grp + i) * 32;
                 const u32x4 ps = *reinterpret_cast<const u32x4 *>(mb);
                 const float dy = *reinterpret_cast<const float *>(mb + 16);
                 const uint32_t pw[4] = {ps.x, ps.y, ps.z, ps.w};
@@ -143,11 +154,8 @@ __global__ __launch_bounds__(512) void k_mmq_q4_K(const mmq_args a) {
                 acc[g][i] += (dw * dy) * (float)sumi[i] - (dmin * dy) * (float)summs;
             }
         }
-        cur = nxt;
-#pragma unroll
-        for (int g = 0; g < NCG; g++) xc[g] = xn[g];
     }
-    // ---- the eight waves' partial tiles meet in LDS: [wave][group][4][64 lanes]
+    // ---- the waves' partial tiles meet in LDS: [wave][group][4][64 lanes]
     __syncthreads();
     float *red = reinterpret_cast<float *>(smem);
 #pragma unroll
@@ -176,16 +184,16 @@ bool cdna4_mmq_supported(int type, int64_t M, int64_t K, int64_t B) {
 int cdna4_launch_mmq(const cdna4_gemv_args &g, hipStream_t st) {
     if (!cdna4_mmq_supported(g.type, g.M, g.K, g.ncol) || g.ids) return cdna4_set_error_msg("mmq: unsupported type / shape");
     if (((uintptr_t)g.W | (uintptr_t)g.w_row_bytes) & 15) return cdna4_set_error_msg("mmq: Q4_K rows must be 16-byte aligned");
-    if (((uintptr_t)g.qs | (uintptr_t)g.bsums) & 7) return cdna4_set_error_msg("mmq: quantized activations must be 8-byte aligned");
+    if (((uintptr_t)g.qs | (uintptr_t)g.bsums) & 15) return cdna4_set_error_msg("mmq: quantized activations must be 16-byte aligned");
     mmq_args a{};
     a.W = g.W; a.w_row_bytes = g.w_row_bytes; a.qs = g.qs; a.d = g.d; a.bsums = g.bsums; a.Y = g.Y; a.y_row = g.y_col_stride;
     a.M = g.M; a.K = g.K; a.B = g.ncol; a.epi = g.epi;
     const dim3 grid((g.M + 15) / 16);
     const int ncg = (g.ncol + 15) / 16;
-    if (ncg == 1) hipLaunchKernelGGL(k_mmq_q4_K<1>, grid, dim3(512), 0, st, a);
-    else if (ncg == 2) hipLaunchKernelGGL(k_mmq_q4_K<2>, grid, dim3(512), 0, st, a);
-    else if (ncg == 3) hipLaunchKernelGGL(k_mmq_q4_K<3>, grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(k_mmq_q4_K<4>, grid, dim3(512), 0, st, a);
+    if (ncg == 1) hipLaunchKernelGGL((k_mmq_q4_K<1, 8>), grid, dim3(512), 0, st, a);
+    else if (ncg == 2) hipLaunchKernelGGL((k_mmq_q4_K<2, 8>), grid, dim3(512), 0, st, a);
+    else if (ncg == 3) hipLaunchKernelGGL((k_mmq_q4_K<3, 8>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_mmq_q4_K<4, 4>), grid, dim3(256), 0, st, a);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

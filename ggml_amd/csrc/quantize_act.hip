@@ -47,11 +47,13 @@ __global__ __launch_bounds__(256) void k_quantize_q8_K(const float *__restrict__
     float amax = 0.f, mx = 0.f; int idx = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) { const float ax = fabsf(e[i]); if (ax > amax) { amax = ax; mx = e[i]; idx = (c & 15) * 16 + i; } }
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        const float oa = __shfl_xor(amax, o, 64), om = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(idx, o, 64);
-        if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; }
-    }
+    // 16-lane all-reduce on the VALU (cdna4_common.h: dpp_*; twelve ds_bpermute_b32 in a dependent chain before): the selection — largest |x|,
+    // then smallest index — is commutative and associative, so every lane ends with the superblock's winner whatever the pairing order
+    auto take = [&](float oa, float om, int oi) __attribute__((always_inline)) { if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; } };
+    take(dpp_f32<0xB1>(amax), dpp_f32<0xB1>(mx), dpp_i32<0xB1>(idx));
+    take(dpp_f32<0x4E>(amax), dpp_f32<0x4E>(mx), dpp_i32<0x4E>(idx));
+    take(dpp_f32<0x141>(amax), dpp_f32<0x141>(mx), dpp_i32<0x141>(idx));
+    take(dpp_f32<0x140>(amax), dpp_f32<0x140>(mx), dpp_i32<0x140>(idx));
     int q[16]; float d = 0.f; int bsum = 0;
     if (amax != 0.f) {
         const float iscale = -127.f / mx;

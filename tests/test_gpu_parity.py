@@ -369,7 +369,7 @@ def test_full_size_prefill_config(gu, m, k, b):
 @pytest.mark.parametrize("m,k,b", [(48, 1024, 2), (100, 512, 5), (512, 2048, 8), (37, 768, 9), (256, 4096, 16), (130, 1024, 17), (64, 2304, 33), (4096, 4096, 64),
                                    (4096, 14336, 8), (4096, 14336, 40)])
 def test_small_batches_on_the_int8_matrix_cores(gu, m, k, b):
-    """9 .. 16 activation rows (.. 32 for K <= 4096) of a Q4_K MUL_MAT take k_mmq_q4_K (mmq_i8.hip: v_mfma_i32_16x16x32_i8 on the Q8_K-quantized activations — the integer
+    """9 .. 32 activation rows (and 3 .. 8 over large matrices) of a Q4_K MUL_MAT take k_mmq_q4_K (mmq_i8.hip: v_mfma_i32_16x16x32_i8 on the Q8_K-quantized activations — the integer
     block dots of ggml_vec_dot_q4_K_q8_K): within the GEMV bar of the oracle (the fp16 GEMM these sizes used to take above 8 rows sits at 3e-4),
     equal to the v_dot4 GEMV units to fp32 summation order, deterministic, weight-row counts that are no multiple of 16, more rows than one
     16-column group."""
@@ -384,11 +384,23 @@ def test_small_batches_on_the_int8_matrix_cores(gu, m, k, b):
     rs = R.row_size(t, k)
     wsub = np.concatenate([w[r * rs:(r + 1) * rs] for r in rows])
     e = R.rel_l2(y[:, rows], R.o_mul_mat(t, wsub, x, len(rows), k)); gu.report(test="mmq_i8", m=m, k=k, b=b, rel_l2=e)
-    int8_route = b <= 8 or b <= 16 or (b <= 32 and k <= 4096)          # capi.hip: use_mmq (above that the fp16 GEMM is faster on MI355X and takes over)
+    int8_route = b <= 32                                               # capi.hip: use_mmq (GEMV or int8 MFMA up to 32 rows; above that the fp16 GEMM is faster on MI355X)
     assert e < (TOL_GEMV if int8_route else TOL_GEMM)
     assert np.array_equal(y, ops.mul_mat(a, xd).cpu().numpy())
     if b <= 16:
         assert R.rel_l2(y, ops.mul_mat(a, xd, path=ops.PATH_GEMV).cpu().numpy()) < 2e-6
+    # the tail rides in the kernel's store: bit-identical to the product followed by ADD(bias) -> ADD(residual)
+    if 9 <= b <= 32:
+        import ctypes as C
+        from ggml_amd import native
+        L = native.lib()
+        bias = gu.to_dev(np.random.default_rng(1).standard_normal(m).astype(np.float32)); res = gu.to_dev(np.random.default_rng(2).standard_normal((b, m)).astype(np.float32))
+        yt = ops.mul_mat(a, xd); yf = torch.empty_like(yt)
+        ws = torch.empty(max(L.ggml_cdna4_mul_mat_workspace_size(int(t), k, b), 256), dtype=torch.uint8, device="cuda")
+        native.check(L.ggml_cdna4_mul_mat_fused(int(t), a.data.data_ptr(), a.row_bytes, xd.data_ptr(), k, yf.data_ptr(), m, m, k, b, bias.data_ptr(), 0, res.data_ptr(), m,
+                                                ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.equal(yf, (yt + bias) + res)
 
 
 def test_full_size_c5_config(gu):
