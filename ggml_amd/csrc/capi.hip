@@ -129,7 +129,9 @@ static bool use_mmq(int type, int64_t M, int64_t K, int64_t B) {
     // (4096 x 14336: 14.3 / 21.2 vs 28.6 / 29.0 at 16 / 32 rows; 4096^2: 13.9 / 13.4 vs 19.5 / 19.8; at 64 rows the GEMM is level or ahead), and
     // against the v_dot4 GEMV for 3 .. 8 rows once the matrix is large — the two launches cost ~13.5 us whatever the size, the one-launch GEMV 10.3
     // at 4096^2 but 17.5 / 25.6 at 4096 x 14336 for 4 / 8 rows (mmq: 14.1 / 14.2).  Two rows stay on the GEMV everywhere.
-    if (B >= 9) return B <= 32;
+    // (small matrices — the gpt-2 117M projections — are launch-bound either way: they take the integer path up to 64 rows, which keeps a whole
+    // short prompt on the CPU's own arithmetic instead of the fp16 GEMM's 3e-4)
+    if (B >= 9) return B <= 32 || M * K <= ((int64_t)1 << 24);
     return B >= 3 && M * K >= ((int64_t)1 << 25);
 }
 static int resolve_path(int type, int path, int64_t M, int64_t K, int64_t B) {

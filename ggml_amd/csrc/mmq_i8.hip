@@ -50,9 +50,12 @@ __device__ __forceinline__ long as_i64(uint32_t lo, uint32_t hi) { return (long)
 // loads — the sixteen columns' 256 quants (4 instructions per column group), their bsums and d, the sixteen rows' 144-byte superblocks (3
 // instructions) — one superblock AHEAD into registers, parks it in a private LDS area and reads the MFMA fragments from there (ds_read_b64, row
 // strides 272 / 144 bytes: conflict-free).
-template <int NCG, int NW>
+// FIVE: Q5_K — the same superblock with 32 bytes of fifth bits behind the header (bit 2 gq of qh[l]: sub-block 2 gq's weight l, bit 2 gq + 1: sub-block
+// 2 gq + 1's; src/ggml-quants.c:1482-1507): 176-byte rows, weights 0 .. 31 instead of 0 .. 15, everything else as Q4_K (ggml_vec_dot_q5_K_q8_K)
+template <int NCG, int NW, bool FIVE = false>
 __global__ __launch_bounds__(NW * 64) void k_mmq_q4_K(const mmq_args a) {
-    constexpr int XROW = 272, XS = 16 * XROW, MS = 16 * 32, WSZ = 16 * 144;        // per wave: NCG x (quants | pair sums + d), then the weights
+    constexpr int WB = FIVE ? 176 : 144, WP = WB / 16, NWI = (16 * WP + 63) / 64, QO = FIVE ? 48 : 16;
+    constexpr int XROW = 272, XS = 16 * XROW, MS = 16 * 32, WSZ = 16 * WB;        // per wave: NCG x (quants | pair sums + d), then the weights
     constexpr int SLAB = NCG * (XS + MS) + WSZ;
     constexpr int SMEM = NW * SLAB > NW * NCG * 1024 ? NW * SLAB : NW * NCG * 1024;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(NW * 64) void k_mmq_q4_K(const mmq_args a) {
         for (int i = 0; i < 4; i++) acc[g][i] = 0.f;
 
     // ---- the slab of one superblock in registers: lane roles of the LOADS (coalesced), not of the MFMA
-    struct Slab { u32x4 x[NCG][4]; u32x4 bs[NCG]; float dy[NCG]; u32x4 w[3]; };
+    struct Slab { u32x4 x[NCG][4]; u32x4 bs[NCG]; float dy[NCG]; u32x4 w[NWI]; };
     auto fetch = [&](int sb) __attribute__((always_inline)) {
         Slab r;
 #pragma unroll
@@ -86,9 +89,9 @@ __global__ __launch_bounds__(NW * 64) void k_mmq_q4_K(const mmq_args a) {
             r.dy[g] = a.d[(int64_t)bd * nsb + sb];
         }
 #pragma unroll
-        for (int i = 0; i < 3; i++) {                                    // piece i * 64 + lane of 144: row piece / 9, chunk piece % 9
-            const int pc = min(i * 64 + lane, 143), row = pc / 9, c = pc - row * 9;
-            r.w[i] = ld_u32x4(a.W + (int64_t)min(m0 + row, a.M - 1) * a.w_row_bytes + (int64_t)sb * 144 + c * 16);
+        for (int i = 0; i < NWI; i++) {                                  // piece i * 64 + lane of 16 WP: row piece / WP, chunk piece % WP
+            const int pc = min(i * 64 + lane, 16 * WP - 1), row = pc / WP, c = pc - row * WP;
+            r.w[i] = ld_u32x4(a.W + (int64_t)min(m0 + row, a.M - 1) * a.w_row_bytes + (int64_t)sb * WB + c * 16);
         }
         return r;
     };
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(NW * 64) void k_mmq_q4_K(const mmq_args a) {
             if (lane < 16) *reinterpret_cast<float *>(slab + g * (XS + MS) + XS + lane * 32 + 16) = r.dy[g];
         }
 #pragma unroll
-        for (int i = 0; i < 3; i++) if (i * 64 + lane < 144) *reinterpret_cast<u32x4 *>(wl + (i * 64 + lane) * 16) = r.w[i];
+        for (int i = 0; i < NWI; i++) if (i * 64 + lane < 16 * WP) *reinterpret_cast<u32x4 *>(wl + (i * 64 + lane) * 16) = r.w[i];
     };
 
     Slab cur{};
@@ -119,10 +122,11 @@ __global__ __launch_bounds__(NW * 64) void k_mmq_q4_K(const mmq_args a) {
         CDNA4_WAVE_LDS_SYNC();
         if (sb + NW < nsb) cur = fetch(sb + NW);                         // the next slab streams in under this one's arithmetic
         // ---- this lane's weight row (column col of the MFMA's B operand): header, scales and minima (get_scale_min_k4, ggml-quants.c:631-638)
-        const u32x4 hdr = *reinterpret_cast<const u32x4 *>(wl + col * 144);
-        u32x2 wq[4];
+        const u32x4 hdr = *reinterpret_cast<const u32x4 *>(wl + col * WB);
+        u32x2 wq[4], qh = {0, 0};
 #pragma unroll
-        for (int gq = 0; gq < 4; gq++) wq[gq] = *reinterpret_cast<const u32x2 *>(wl + col * 144 + 16 + 32 * gq + 8 * grp);
+        for (int gq = 0; gq < 4; gq++) wq[gq] = *reinterpret_cast<const u32x2 *>(wl + col * WB + QO + 32 * gq + 8 * grp);
+        if constexpr (FIVE) qh = *reinterpret_cast<const u32x2 *>(wl + col * WB + 16 + 8 * grp);
         const float dw = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
         int sc[8], mn[8];
 #pragma unroll
@@ -135,9 +139,14 @@ __global__ __launch_bounds__(NW * 64) void k_mmq_q4_K(const mmq_args a) {
             for (int gq = 0; gq < 4; gq++) {                             // 64-weight group gq: sub-blocks 2 gq (low nibbles) and 2 gq + 1 (high)
                 const u32x2 xl = *reinterpret_cast<const u32x2 *>(xs + 64 * gq), xh = *reinterpret_cast<const u32x2 *>(xs + 64 * gq + 32);
                 const intx4 z = {0, 0, 0, 0};
-                const intx4 sl = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xl.x, xl.y), as_i64(wq[gq].x & 0x0F0F0F0Fu, wq[gq].y & 0x0F0F0F0Fu), z, 0, 0, 0);
-                const intx4 sh = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xh.x, xh.y), as_i64((wq[gq].x >> 4) & 0x0F0F0F0Fu, (wq[gq].y >> 4) & 0x0F0F0F0Fu), z, 0, 0, 0);
-                // |S| <= 32 * 15 * 127 and sc < 64: 24-bit multiplies (full rate; v_mul_lo_u32 is a quarter of it)
+                uint32_t l0 = wq[gq].x & 0x0F0F0F0Fu, l1 = wq[gq].y & 0x0F0F0F0Fu, h0 = (wq[gq].x >> 4) & 0x0F0F0F0Fu, h1 = (wq[gq].y >> 4) & 0x0F0F0F0Fu;
+                if constexpr (FIVE) {
+                    l0 |= ((qh.x >> (2 * gq)) & 0x01010101u) << 4; l1 |= ((qh.y >> (2 * gq)) & 0x01010101u) << 4;
+                    h0 |= ((qh.x >> (2 * gq + 1)) & 0x01010101u) << 4; h1 |= ((qh.y >> (2 * gq + 1)) & 0x01010101u) << 4;
+                }
+                const intx4 sl = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xl.x, xl.y), as_i64(l0, l1), z, 0, 0, 0);
+                const intx4 sh = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xh.x, xh.y), as_i64(h0, h1), z, 0, 0, 0);
+                // |S| <= 32 * 31 * 127 and sc < 64: 24-bit multiplies (full rate; v_mul_lo_u32 is a quarter of it)
 #pragma unroll
                 for (int i = 0; i < 4; i++) sumi[i] += mul24(sc[2 * gq], sl[i]) + mul24(sc[2 * gq + 1], sh[i]);
             }
@@ -177,20 +186,159 @@ __global__ __launch_bounds__(NW * 64) void k_mmq_q4_K(const mmq_args a) {
     }
 }
 
-bool cdna4_mmq_supported(int type, int64_t M, int64_t K, int64_t B) {
-    return type == CDNA4_Q4_K && M > 0 && K >= 256 && K % 256 == 0 && B >= 2 && B <= 64;
+// ---- Q4_0 / Q8_0 weights: Q8_0 activations (d per 32-block on both sides, no minima): per block and MFMA acc += (d_w d_y) S, the association of
+// ggml_vec_dot_q4_0_q8_0 / q8_0_q8_0's scalar bodies (src/ggml-cpu/ggml-cpu-quants.c:2293-2310, 3335-...).  Same staging: eight 18- / 34-byte blocks
+// of a row are 144 / 272 contiguous bytes (16-byte aligned for K % 256 == 0); the quants of a block sit 2 bytes behind its d, so a lane's eight
+// bytes are either 4-byte aligned (odd blocks) or straddle three dwords (even blocks: v_alignbit).
+template <int TYPE, int NCG, int NW>
+__global__ __launch_bounds__(NW * 64) void k_mmq_q8_0act(const mmq_args a) {
+    constexpr int BB = TYPE == CDNA4_Q4_0 ? 18 : 34, WROW = 8 * BB, WP = WROW / 16;      // bytes per block, per 256 weights of a row; 16-byte pieces: 9 / 17
+    constexpr int XROW = 272, XS = 16 * XROW, MS = 16 * 32, WSZ = 16 * WROW;
+    constexpr int SLAB = NCG * (XS + MS) + WSZ, NWI = (16 * WP + 63) / 64;               // weight load instructions per slab: 3 / 5
+    constexpr int SMEM = NW * SLAB > NW * NCG * 1024 ? NW * SLAB : NW * NCG * 1024;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, grp = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int nsb = a.K / 256;
+    uint8_t *slab = smem + wave * SLAB;
+    uint8_t *wl = slab + NCG * (XS + MS);
+
+    float acc[NCG][4];
+#pragma unroll
+    for (int g = 0; g < NCG; g++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[g][i] = 0.f;
+
+    struct Slab { u32x4 x[NCG][4]; u32x4 dy[NCG]; u32x4 w[NWI]; };
+    auto fetch = [&](int sb) __attribute__((always_inline)) {
+        Slab r;
+#pragma unroll
+        for (int g = 0; g < NCG; g++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int b = min(g * 16 + 4 * i + (lane >> 4), a.B - 1);
+                r.x[g][i] = ld_u32x4(a.qs + (int64_t)b * a.K + sb * 256 + (lane & 15) * 16);
+            }
+            const int bb = min(g * 16 + (lane >> 1), a.B - 1);                       // the column's eight block scales: 32 bytes, two lanes
+            r.dy[g] = lane < 32 ? ld_u32x4(a.d + (int64_t)bb * (a.K / 32) + sb * 8 + (lane & 1) * 4) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < NWI; i++) {
+            const int pc = min(i * 64 + lane, 16 * WP - 1), row = pc / WP, c = pc - row * WP;
+            r.w[i] = ld_u32x4(a.W + (int64_t)min(m0 + row, a.M - 1) * a.w_row_bytes + (int64_t)sb * WROW + c * 16);
+        }
+        return r;
+    };
+    auto park = [&](const Slab &r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < NCG; g++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) *reinterpret_cast<u32x4 *>(slab + g * (XS + MS) + (4 * i + (lane >> 4)) * XROW + (lane & 15) * 16) = r.x[g][i];
+            if (lane < 32) *reinterpret_cast<u32x4 *>(slab + g * (XS + MS) + XS + (lane >> 1) * 32 + (lane & 1) * 16) = r.dy[g];
+        }
+#pragma unroll
+        for (int i = 0; i < NWI; i++) if (i * 64 + lane < 16 * WP) *reinterpret_cast<u32x4 *>(wl + (i * 64 + lane) * 16) = r.w[i];
+    };
+    // eight bytes at a 2-byte-aligned LDS offset: two aligned dwords, or three and a 16-bit funnel shift
+    auto ld8_a2 = [&](const uint8_t *p, int off) __attribute__((always_inline)) -> u32x2 {
+        if ((off & 3) == 0) return u32x2{*reinterpret_cast<const uint32_t *>(p + off), *reinterpret_cast<const uint32_t *>(p + off + 4)};
+        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(p + off - 2), w1 = *reinterpret_cast<const uint32_t *>(p + off + 2), w2 = *reinterpret_cast<const uint32_t *>(p + off + 6);
+        return u32x2{(w0 >> 16) | (w1 << 16), (w1 >> 16) | (w2 << 16)};
+    };
+
+    Slab cur{};
+    if (wave < nsb) cur = fetch(wave);
+    for (int sb = wave; sb < nsb; sb += NW) {
+        CDNA4_WAVE_LDS_SYNC();
+        park(cur);
+        CDNA4_WAVE_LDS_SYNC();
+        if (sb + NW < nsb) cur = fetch(sb + NW);
+        const uint8_t *wr = wl + col * WROW;
+#pragma unroll
+        for (int blk = 0; blk < 8; blk++) {
+            const float dw = h2f(*reinterpret_cast<const uint16_t *>(wr + blk * BB));
+            u32x2 wv;
+            if constexpr (TYPE == CDNA4_Q4_0) {
+                // nibble j low -> weight j, high -> weight j + 16 (src/ggml-quants.c:255-273): k-groups 0, 1 = low nibbles of bytes 0-7 / 8-15, groups 2, 3 = the high ones
+                const int o0 = blk * BB + 2;                             // (blk * 18 + 2) % 4 is 2 for even blocks, 0 for odd ones: both forms, selected per lane by its group
+                const u32x2 lo8 = ld8_a2(wr, o0), hi8 = ld8_a2(wr, o0 + 8);
+                const u32x2 raw = (grp & 1) ? hi8 : lo8;
+                const uint32_t sh = (grp & 2) ? 4u : 0u;
+                uint32_t t0 = ((raw.x >> sh) & 0x0F0F0F0Fu) ^ 0x08080808u, t1 = ((raw.y >> sh) & 0x0F0F0F0Fu) ^ 0x08080808u;
+                wv = u32x2{t0 | ((t0 & 0x08080808u) * 0x1Eu), t1 | ((t1 & 0x08080808u) * 0x1Eu)};        // q - 8 as int8 (see convert_w.hip: flip bit 3, extend the sign)
+            } else {
+                // one of the four 8-byte pieces of the block's 32 int8 (offset 2 + 8 grp): the offset's alignment depends on the lane's group — read both
+                // candidates' dwords once (five aligned dwords cover bytes [blk BB, blk BB + 36) from the nearest 4-byte boundary) and select
+                const int o = blk * BB + 2;
+                const u32x2 p0 = ld8_a2(wr, o), p1 = ld8_a2(wr, o + 8), p2 = ld8_a2(wr, o + 16), p3 = ld8_a2(wr, o + 24);
+                wv = grp == 0 ? p0 : (grp == 1 ? p1 : (grp == 2 ? p2 : p3));
+            }
+#pragma unroll
+            for (int g = 0; g < NCG; g++) {
+                const u32x2 xv = *reinterpret_cast<const u32x2 *>(slab + g * (XS + MS) + col * XROW + 32 * blk + 8 * grp);
+                const intx4 z = {0, 0, 0, 0};
+                const intx4 sv = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xv.x, xv.y), as_i64(wv.x, wv.y), z, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float dy = *reinterpret_cast<const float *>(slab + g * (XS + MS) + XS + (4 * grp + i) * 32 + 4 * blk);
+                    acc[g][i] += (float)sv[i] * (dw * dy);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int g = 0; g < NCG; g++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) red[((wave * NCG + g) * 4 + i) * 64 + lane] = acc[g][i];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int g = 0; g < NCG; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; w++) s += red[((w * NCG + g) * 4 + i) * 64 + lane];
+                const int b = g * 16 + 4 * grp + i, m = m0 + col;
+                if (b < a.B && m < a.M) a.Y[(int64_t)b * a.y_row + m] = epilogue_apply(a.epi, s, m, b);
+            }
+    }
 }
-// a.qs / a.d / a.bsums: the Q8_K workspace ggml_cdna4_prepare_act fills (path GEMV)
+
+bool cdna4_mmq_supported(int type, int64_t M, int64_t K, int64_t B) {
+    return (type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q4_0 || type == CDNA4_Q8_0) && M > 0 && K >= 256 && K % 256 == 0 && B >= 2 && B <= 64;
+}
+template <int TYPE>
+static void launch_q80act(const mmq_args &a, int ncg, dim3 grid, hipStream_t st) {
+    if (ncg == 1) hipLaunchKernelGGL((k_mmq_q8_0act<TYPE, 1, 8>), grid, dim3(512), 0, st, a);
+    else if (ncg == 2) hipLaunchKernelGGL((k_mmq_q8_0act<TYPE, 2, 8>), grid, dim3(512), 0, st, a);
+    else if (ncg == 3) hipLaunchKernelGGL((k_mmq_q8_0act<TYPE, 3, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_mmq_q8_0act<TYPE, 4, 4>), grid, dim3(256), 0, st, a);
+}
+// a.qs / a.d / a.bsums: the Q8_K (Q4_K) or Q8_0 (Q4_0 / Q8_0) workspace ggml_cdna4_prepare_act fills (path GEMV)
 int cdna4_launch_mmq(const cdna4_gemv_args &g, hipStream_t st) {
     if (!cdna4_mmq_supported(g.type, g.M, g.K, g.ncol) || g.ids) return cdna4_set_error_msg("mmq: unsupported type / shape");
-    if (((uintptr_t)g.W | (uintptr_t)g.w_row_bytes) & 15) return cdna4_set_error_msg("mmq: Q4_K rows must be 16-byte aligned");
-    if (((uintptr_t)g.qs | (uintptr_t)g.bsums) & 15) return cdna4_set_error_msg("mmq: quantized activations must be 16-byte aligned");
+    if (((uintptr_t)g.W | (uintptr_t)g.w_row_bytes) & 15) return cdna4_set_error_msg("mmq: weight rows must be 16-byte aligned");
+    if (((uintptr_t)g.qs | (uintptr_t)g.d) & 15) return cdna4_set_error_msg("mmq: quantized activations must be 16-byte aligned");
+    if ((g.type == CDNA4_Q4_K || g.type == CDNA4_Q5_K) && ((uintptr_t)g.bsums & 15)) return cdna4_set_error_msg("mmq: quantized activations must be 16-byte aligned");
     mmq_args a{};
     a.W = g.W; a.w_row_bytes = g.w_row_bytes; a.qs = g.qs; a.d = g.d; a.bsums = g.bsums; a.Y = g.Y; a.y_row = g.y_col_stride;
     a.M = g.M; a.K = g.K; a.B = g.ncol; a.epi = g.epi;
     const dim3 grid((g.M + 15) / 16);
     const int ncg = (g.ncol + 15) / 16;
-    if (ncg == 1) hipLaunchKernelGGL((k_mmq_q4_K<1, 8>), grid, dim3(512), 0, st, a);
+    if (g.type == CDNA4_Q4_0) launch_q80act<CDNA4_Q4_0>(a, ncg, grid, st);
+    else if (g.type == CDNA4_Q8_0) launch_q80act<CDNA4_Q8_0>(a, ncg, grid, st);
+    else if (g.type == CDNA4_Q5_K) {
+        if (ncg == 1) hipLaunchKernelGGL((k_mmq_q4_K<1, 8, true>), grid, dim3(512), 0, st, a);
+        else if (ncg == 2) hipLaunchKernelGGL((k_mmq_q4_K<2, 8, true>), grid, dim3(512), 0, st, a);
+        else if (ncg == 3) hipLaunchKernelGGL((k_mmq_q4_K<3, 8, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_mmq_q4_K<4, 4, true>), grid, dim3(256), 0, st, a);
+    }
+    else if (ncg == 1) hipLaunchKernelGGL((k_mmq_q4_K<1, 8>), grid, dim3(512), 0, st, a);
     else if (ncg == 2) hipLaunchKernelGGL((k_mmq_q4_K<2, 8>), grid, dim3(512), 0, st, a);
     else if (ncg == 3) hipLaunchKernelGGL((k_mmq_q4_K<3, 8>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((k_mmq_q4_K<4, 4>), grid, dim3(256), 0, st, a);
