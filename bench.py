@@ -220,6 +220,25 @@ def shape_row(dev, t, m, k, b, steps):
     return row
 
 
+def pmc_decode_traffic():
+    """HBM-side bytes per launch of the one-launch decode kernel at 4096 x 14336 from the latest committed PMC passes
+    (profiles/rNN/pmc_decode_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over scripts/decode_loop.py; FETCH_SIZE in KB, x2 on gfx950)"""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_decode_summary.txt")))
+    if not files:
+        return None
+    rd = wr = None
+    for ln in open(files[-1]):
+        m = re.search(r"'FETCH_SIZE': ([0-9.]+)", ln)
+        if m and "gemv" in ln:
+            rd = float(m.group(1)) * 1024 * 2
+        m = re.search(r"'WRITE_SIZE': ([0-9.]+)", ln)
+        if m and "gemv" in ln:
+            wr = float(m.group(1)) * 1024
+    return None if rd is None or wr is None else rd + wr
+
+
 def decode_rows(dev, steps):
     """batch-1 decode (BASELINE configs[1]) and the reference's own perf shape (m = 4096, k = 14336, tests/test-backend-ops.cpp:4340-4346):
     ONE launch per step (activation quantizer fused into the GEMV), 64 rotating copies of W so that every launch streams from HBM"""
@@ -275,7 +294,7 @@ def decode_rows(dev, steps):
                                    "us_per_step_hipgraph": round(hg, 3) if isinstance(hg, float) else hg, "tokens_per_s": round(1e6 / cold, 1),
                                    "effective_tflops": round(2.0 * m * k / cold / 1e6, 3),
                                    "roofline": {"bound": "hbm", "kernel": "k_gemv_q_fused<Q4_K>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                                "traffic": pmc_traffic("k_gemv_q_fused<12") if k == 4096 else None, "algorithmic_bytes_per_launch": alg}, "data": how}
+                                                "traffic": pmc_decode_traffic() if k == 14336 else None, "algorithmic_bytes_per_launch": alg}, "data": how}
         del big
     return rows
 
@@ -299,8 +318,9 @@ def format_rows(dev, steps):
 
 def batch_sweep(dev, steps):
     """µs per MUL_MAT call (activation quantize included, HIP events) from decode to prefill batch sizes — one-launch GEMV (1..8 rows,
-    columns from LDS), then k_gemm_kq_t64 with the deep K split while the grid is far below the chip — at the headline matrix and at
-    the reference's perf shape (tests/test-backend-ops.cpp:4340-4346)"""
+    columns from LDS; 3..8 rows over large matrices: the int8 matrix-core kernel), k_mmq_q4_K for 9..32 rows (mmq_i8.hip: v_mfma_i32_16x16x32_i8),
+    then k_gemm_kq_t64 with the deep K split while the grid is far below the chip — at the headline matrix and at the reference's perf
+    shape (tests/test-backend-ops.cpp:4340-4346)"""
     from ggml_amd import ops
     out = {}
     for (m, k) in ((4096, 4096), (4096, 14336)):
