@@ -61,7 +61,7 @@ bool cdna4_ops_supports_tensor(const ggml_tensor * op) {
             return false;
         }
         case GGML_OP_FLASH_ATTN_EXT: {
-            // q F32, k / v F16 with 16-byte aligned rows or block-quantized, mask F16 contiguous or absent, head sizes up to 256 (64 / 128 / 256 directly,
+            // q F32, k / v F16 with 16-byte aligned rows, BF16 or block-quantized, mask F16 contiguous or absent, head sizes up to 256 (64 / 128 / 256 directly,
             // others zero-padded: fattn.hip)
             const ggml_tensor * k = op->src[1], * v = op->src[2], * m = op->src[3];
             // (a quantized k / v — Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0 — is copied out as fp16 first: any strides, contiguous rows)

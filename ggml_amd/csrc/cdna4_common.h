@@ -21,6 +21,8 @@ enum cdna4_type : int {
     // the same with 256-weight superblocks and 6-bit sub-block scales (Q8_K activations); prefill GEMM as Q6_K with 2 K columns (codebook value =
     // 4 h + l: the h part with int8 scale 4 (ls - 32), the l part with ls - 32)
     CDNA4_IQ4_XS = 23,
+    // K / V of FLASH_ATTN_EXT only (a bf16 KV cache; written out as fp16 like the quantized ones, ops.hip: k_q_to_f16_dense)
+    CDNA4_BF16 = 30,
 };
 // weight types whose CPU vec_dot runs on Q8_1 activations (type_traits_cpu[].vec_dot_type, src/ggml-cpu/ggml-cpu.c:271-296): the activation
 // workspace then carries, in the place of the Q8_K bsums, one fp32 per 32-block holding s = fp16(d * sum of the quants) (block_q8_1.s)

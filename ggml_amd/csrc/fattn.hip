@@ -319,11 +319,13 @@ typedef ggml_cdna4_tensor T4;
 static inline bool fa_kernel_head_size(int64_t hs) { return hs == 64 || hs == 128 || hs == 256; }
 extern "C" int ggml_cdna4_op_flash_attn_ext_supported(int64_t head_size, int kv_type) {
     if (head_size <= 0 || head_size > 256) return 0;
-    return kv_type == CDNA4_F16 || (cdna4_to_f16_dense_supported(kv_type) && head_size % 32 == 0);
+    return kv_type == CDNA4_F16 || kv_type == CDNA4_BF16 || (cdna4_to_f16_dense_supported(kv_type) && head_size % 32 == 0);
 }
 
 static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T4 *d, float scale, float max_bias, float logit_softcap, void *stream);
 
+// A BF16 K / V takes the same route (bf16 -> fp16: exact for |x| in [2^-14, 65504], the range a KV cache lives in; the CPU rounds q to bf16 instead,
+// ggml-cpu.c:10929 with vec_dot_type BF16 — eight bits of mantissa — so ours is again the more accurate side).
 // A quantized K / V (Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0 — a quantized KV cache) is first written out as fp16 (to_float of every element rounded to
 // fp16, dense [batch][head][n_kv][head_size] in library scratch: one pass over the cache), then the F16 kernels run on the copy.  The CPU
 // instead quantizes q to the K type's vec_dot_type and takes integer dots (ggml-cpu.c:10921-10960); both are approximations of the same
@@ -343,8 +345,8 @@ extern "C" int ggml_cdna4_op_flash_attn_ext(const T4 *q, const T4 *k, const T4 *
     for (int i = 0; i < 2; i++) {
         T4 &t = kv[i];
         if (t.type == CDNA4_F16 && !pad) continue;
-        NEED(t.type == CDNA4_F16 || cdna4_to_f16_dense_supported(t.type), "flash_attn_ext: k / v must be F16 or Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0");
-        NEED(t.ne[0] == D && (t.type == CDNA4_F16 || D % 32 == 0) && t.ne[1] > 0 && t.ne[2] > 0 && t.ne[3] > 0, "flash_attn_ext: bad k / v shape");
+        NEED(t.type == CDNA4_F16 || cdna4_to_f16_dense_supported(t.type), "flash_attn_ext: k / v must be F16, BF16 or Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0");
+        NEED(t.ne[0] == D && (t.type == CDNA4_F16 || t.type == CDNA4_BF16 || D % 32 == 0) && t.ne[1] > 0 && t.ne[2] > 0 && t.ne[3] > 0, "flash_attn_ext: bad k / v shape");
         const size_t bytes = (size_t)(Dp * t.ne[1] * t.ne[2] * t.ne[3]) * 2;
         void *dense = cdna4_gemm_scratch(bytes + 256, 5 + i);
         NEED(dense, "flash_attn_ext: cannot allocate the fp16 copy of k / v");

@@ -13,7 +13,7 @@ typedef ggml_cdna4_tensor T4;
 static inline int64_t nelem(const T4 *t) { return t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
 static inline int64_t nrows(const T4 *t) { return t->ne[1] * t->ne[2] * t->ne[3]; }
 static inline size_t tsize(int type) {
-    switch (type) { case CDNA4_F32: case CDNA4_I32: return 4; case CDNA4_F16: return 2; case CDNA4_Q4_0: return 18; case CDNA4_Q8_0: return 34;
+    switch (type) { case CDNA4_F32: case CDNA4_I32: return 4; case CDNA4_F16: case CDNA4_BF16: return 2; case CDNA4_Q4_0: return 18; case CDNA4_Q8_0: return 34;
                     case CDNA4_Q4_K: return 144; case CDNA4_Q5_K: return 176; case CDNA4_Q6_K: return 210;
                     case CDNA4_Q4_1: return 20; case CDNA4_Q5_0: return 22; case CDNA4_Q5_1: return 24; case CDNA4_Q2_K: return 84; case CDNA4_Q3_K: return 110;
                     case CDNA4_IQ4_NL: return 18; case CDNA4_IQ4_XS: return 136; }
@@ -165,6 +165,9 @@ __global__ __launch_bounds__(256) void k_diag_mask_inf(const float *__restrict__
 template <int TYPE> __device__ __forceinline__ float deq_elem(const uint8_t *row, int64_t k);
 template <> __device__ __forceinline__ float deq_elem<CDNA4_F32>(const uint8_t *row, int64_t k) { return ((const float *)row)[k]; }
 template <> __device__ __forceinline__ float deq_elem<CDNA4_F16>(const uint8_t *row, int64_t k) { return (float)((const half_t *)row)[k]; }
+template <> __device__ __forceinline__ float deq_elem<CDNA4_BF16>(const uint8_t *row, int64_t k) {      // ggml_compute_bf16_to_fp32: the 16 bits are the upper half of the fp32
+    const uint32_t b = (uint32_t)((const uint16_t *)row)[k] << 16; return __builtin_bit_cast(float, b);
+}
 template <> __device__ __forceinline__ float deq_elem<CDNA4_Q4_0>(const uint8_t *row, int64_t k) {
     const uint8_t *b = row + (k >> 5) * 18; const int j = (int)(k & 31);
     const float d = h2f(ld_u16(b)); const uint8_t q = b[2 + (j & 15)];
@@ -613,7 +616,7 @@ int ggml_cdna4_op_cpy(const T4 *a, const T4 *d, int q8_0_ref_rounding, void *str
 }
 
 }  // extern "C"
-bool cdna4_to_f16_dense_supported(int type) { return type == CDNA4_Q4_0 || type == CDNA4_Q4_1 || type == CDNA4_Q5_0 || type == CDNA4_Q5_1 || type == CDNA4_Q8_0; }
+bool cdna4_to_f16_dense_supported(int type) { return type == CDNA4_BF16 || type == CDNA4_Q4_0 || type == CDNA4_Q4_1 || type == CDNA4_Q5_0 || type == CDNA4_Q5_1 || type == CDNA4_Q8_0; }
 int cdna4_launch_to_f16_dense(const T4 *a, void *dst, int64_t dst_row, hipStream_t st) {
     NEED(cdna4_to_f16_dense_supported(a->type), "to_f16_dense: unsupported source type");
     NEED(a->nb[0] == (int64_t)tsize(a->type) && a->ne[0] % bsize(a->type) == 0, "to_f16_dense: quantized source rows must be contiguous");
@@ -621,7 +624,7 @@ int cdna4_launch_to_f16_dense(const T4 *a, void *dst, int64_t dst_row, hipStream
     if (n == 0) return 0;
     NEED(dst_row >= a->ne[0], "to_f16_dense: destination rows overlap");
 #define TF(T) hipLaunchKernelGGL(k_q_to_f16_dense<T>, grid1d(n), dim3(256), 0, st, *a, (half_t *)dst, n, dst_row); break
-    switch (a->type) { case CDNA4_Q4_0: TF(CDNA4_Q4_0); case CDNA4_Q4_1: TF(CDNA4_Q4_1); case CDNA4_Q5_0: TF(CDNA4_Q5_0); case CDNA4_Q5_1: TF(CDNA4_Q5_1); default: TF(CDNA4_Q8_0); }
+    switch (a->type) { case CDNA4_BF16: TF(CDNA4_BF16); case CDNA4_Q4_0: TF(CDNA4_Q4_0); case CDNA4_Q4_1: TF(CDNA4_Q4_1); case CDNA4_Q5_0: TF(CDNA4_Q5_0); case CDNA4_Q5_1: TF(CDNA4_Q5_1); default: TF(CDNA4_Q8_0); }
 #undef TF
     CDNA4_CHECK_LAUNCH();
     return 0;

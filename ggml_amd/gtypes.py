@@ -19,12 +19,13 @@ class GGMLType(enum.IntEnum):
     IQ4_NL = 20
     IQ4_XS = 23
     I32 = 26
+    BF16 = 30          # K / V of FLASH_ATTN_EXT only
 
 
-_TYPE_SIZE = {GGMLType.F32: 4, GGMLType.F16: 2, GGMLType.Q4_0: 18, GGMLType.Q8_0: 34, GGMLType.Q4_K: 144,
+_TYPE_SIZE = {GGMLType.F32: 4, GGMLType.F16: 2, GGMLType.BF16: 2, GGMLType.Q4_0: 18, GGMLType.Q8_0: 34, GGMLType.Q4_K: 144,
               GGMLType.Q5_K: 176, GGMLType.Q6_K: 210, GGMLType.Q8_K: 292, GGMLType.I32: 4,
               GGMLType.Q5_0: 22, GGMLType.Q2_K: 84, GGMLType.Q3_K: 110, GGMLType.Q4_1: 20, GGMLType.Q5_1: 24, GGMLType.IQ4_NL: 18, GGMLType.IQ4_XS: 136}
-_BLCK = {GGMLType.F32: 1, GGMLType.F16: 1, GGMLType.Q4_0: 32, GGMLType.Q8_0: 32, GGMLType.Q4_K: 256,
+_BLCK = {GGMLType.F32: 1, GGMLType.F16: 1, GGMLType.BF16: 1, GGMLType.Q4_0: 32, GGMLType.Q8_0: 32, GGMLType.Q4_K: 256,
          GGMLType.Q5_K: 256, GGMLType.Q6_K: 256, GGMLType.Q8_K: 256, GGMLType.I32: 1,
          GGMLType.Q5_0: 32, GGMLType.Q2_K: 256, GGMLType.Q3_K: 256, GGMLType.Q4_1: 32, GGMLType.Q5_1: 32, GGMLType.IQ4_NL: 32, GGMLType.IQ4_XS: 256}
 # Q5_0 / Q2_K / Q3_K / Q4_1 / Q5_1 / IQ4_NL / IQ4_XS: int8-dot GEMV units up to 8 activation rows, above that the Q8_0 / Q6_K MFMA GEMM on exactly re-encoded weights (convert_w.hip)

@@ -233,7 +233,7 @@ def _qrows_desc(t: torch.Tensor, type_, D):
 
 def flash_attn_ext(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask=None, scale=1.0, max_bias=0.0, logit_softcap=0.0, kv_type=None):
     """ggml_flash_attn_ext (include/ggml.h:1758-1767; CPU: ggml-cpu.c:10805-11016).  q f32 (batch, n_head, n_q, D) — any strides with
-    contiguous rows, e.g. a permuted view; k, v fp16 (batch_kv, n_head_kv, n_kv, D); mask fp16 (>= n_q, n_kv) or None.
+    contiguous rows, e.g. a permuted view; k, v fp16 or bf16 (batch_kv, n_head_kv, n_kv, D); mask fp16 (>= n_q, n_kv) or None.
     kv_type (Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0): k, v are block-quantized rows as uint8 (batch_kv, n_head_kv, n_kv, row_size(kv_type, D)).
     Returns f32 (batch, n_q, n_head, D) like ggml's result (ne = D, n_head, n_q, batch)."""
     import ctypes as C
@@ -242,8 +242,9 @@ def flash_attn_ext(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask=None,
         _need_gpu(t, name)
         if t.dim() != 4 or t.stride(3) != 1:
             raise ValueError("%s must be 4-D with contiguous rows" % name)
-    if q.dtype != torch.float32 or (kv_type is None and (k.dtype != torch.float16 or v.dtype != torch.float16)):
-        raise ValueError("q must be float32, k and v float16 (or uint8 block rows with kv_type)")
+    kv16 = {torch.float16: GGMLType.F16, torch.bfloat16: GGMLType.BF16}
+    if q.dtype != torch.float32 or (kv_type is None and (k.dtype not in kv16 or v.dtype not in kv16)):
+        raise ValueError("q must be float32, k and v float16 / bfloat16 (or uint8 block rows with kv_type)")
     dev = q.device
     _same_device(dev, k=k, v=v, mask=mask)
     if mask is not None and (mask.dtype != torch.float16 or mask.dim() != 2 or not mask.is_contiguous()):
@@ -252,7 +253,7 @@ def flash_attn_ext(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask=None,
     out = torch.empty((B3, N, H, D), dtype=torch.float32, device=dev)
     dm = _tensor_desc(mask.view(1, 1, *mask.shape), GGMLType.F16) if mask is not None else None
     dq, dd = _tensor_desc(q, GGMLType.F32), _tensor_desc(out, GGMLType.F32)
-    dk, dv = (_tensor_desc(k, GGMLType.F16), _tensor_desc(v, GGMLType.F16)) if kv_type is None else (_qrows_desc(k, kv_type, D), _qrows_desc(v, kv_type, D))
+    dk, dv = (_tensor_desc(k, kv16[k.dtype]), _tensor_desc(v, kv16[v.dtype])) if kv_type is None else (_qrows_desc(k, kv_type, D), _qrows_desc(v, kv_type, D))
     with torch.cuda.device(dev):
         native.check(L.ggml_cdna4_op_flash_attn_ext(C.byref(dq), C.byref(dk), C.byref(dv), C.byref(dm) if dm is not None else None, C.byref(dd),
                                                     float(scale), float(max_bias), float(logit_softcap), _stream(dev)))

@@ -353,6 +353,27 @@ def test_flash_attn_ext_quantized_kv(gu, name, t, D, n_q, n_head, n_kv, n_head_k
     assert np.array_equal(y, y16)
 
 
+@pytest.mark.parametrize("D,n_q,n_head,n_kv,n_head_kv", [(128, 1, 8, 1024, 2), (64, 35, 4, 300, 4), (256, 3, 4, 512, 1), (128, 200, 8, 512, 8), (80, 5, 4, 200, 2)])
+def test_flash_attn_ext_bf16_kv(gu, D, n_q, n_head, n_kv, n_head_kv):
+    """K / V as BF16 (type_KV = GGML_TYPE_BF16 of the reference's sweep, tests/test-backend-ops.cpp:4284): written out as fp16 once, then the F16
+    kernels.  Against a float64 evaluation on the bf16 values, and bit for bit equal to the F16 path on a cache holding fp16(bf16 value)"""
+    import torch
+    from ggml_amd import ops
+    rng = np.random.default_rng(D + n_q + n_kv)
+    q = rng.uniform(-1, 1, (1, n_head, n_q, D)).astype(np.float32)
+    kb = torch.from_numpy(rng.uniform(-1, 1, (1, n_head_kv, n_kv, D)).astype(np.float32)).to(torch.bfloat16)
+    vb = torch.from_numpy(rng.uniform(-1, 1, (1, n_head_kv, n_kv, D)).astype(np.float32)).to(torch.bfloat16)
+    kf, vf = kb.to(torch.float32).numpy(), vb.to(torch.float32).numpy()
+    m = rng.uniform(-1, 1, ((n_q + 63) // 64 * 64, n_kv)).astype(np.float16)
+    scale = float(1.0 / np.sqrt(D))
+    y = ops.flash_attn_ext(gu.to_dev(q), kb.cuda(), vb.cuda(), gu.to_dev(m), scale).cpu().numpy()
+    assert np.isfinite(y).all()
+    e = R.rel_l2(y, R.exact_flash_attn_ext(q, kf, vf, m, scale)); gu.report(test="flash_attn_ext_bf16_kv", D=D, n_q=n_q, n_kv=n_kv, rel_l2_float64=e)
+    assert e < TOL_FA_EXACT
+    y16 = ops.flash_attn_ext(gu.to_dev(q), gu.to_dev(kf.astype(np.float16)), gu.to_dev(vf.astype(np.float16)), gu.to_dev(m), scale).cpu().numpy()
+    assert np.array_equal(y, y16)
+
+
 # ------------------------------------------------------------------------------------------------ CPY F32 -> Q4_1 / Q5_0 / Q5_1 (writing a quantized KV cache)
 @pytest.mark.parametrize("kind", ["uniform", "normal", "ties"])
 @pytest.mark.parametrize("name,t", [("q4_1", R.Q4_1), ("q5_0", R.Q5_0), ("q5_1", R.Q5_1)])
