@@ -63,6 +63,7 @@ template <> struct QT<CDNA4_Q6_KR> { static constexpr int BYTES = 224, QK = 256;
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -137,6 +138,16 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     v += dpp_f32<0x142, 0xA>(v);                                                                         // rows 1, 3 += rows 0, 2
     v += dpp_f32<0x143, 0xC>(v);                                                                         // rows 2, 3 += row 1 (= rows 0 + 1)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// true in every lane iff the predicate holds in some ACTIVE lane of the wave
+__device__ __forceinline__ bool wave_any(bool pred) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(pred) != 0;
+#else
+    int v = pred ? 1 : 0;                                  // (tools/emul: all 64 lanes of the wave execute this)
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v != 0;
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -63,44 +63,52 @@ __device__ __forceinline__ void fa_selectors(int n, int h, half8_t (&sel)[2]) {
 }
 // one chunk's scores (accumulator layout) -> scale, softcap, mask; online-softmax update of (M, S); P as fp16 B fragments; returns the
 // factor the O accumulator must be multiplied with.
-// The mask tile [32 q x 32 kv] is wanted TRANSPOSED (keys on the accumulator rows).  Whole chunks of a 16-byte aligned mask are read as B
-// fragments — 16 contiguous bytes of this lane's mask row per k-step — and transposed by the matrix core against the same 0/1 selection
-// operands the V transposition uses (exact; -inf is clamped to the largest finite fp16 in front of the product, 0 x inf being NaN, and
-// restored behind it).  Ragged chunks and unaligned masks read the sixteen values one by one.
-__device__ __forceinline__ float fa_softmax_step(const fattn_params &p, floatx16 &s, int kv0, int n, int h, const half_t *mrow, float slope, const half8_t (&sel)[2],
+// Everything behind the softcap lives in the LOG2 domain (scores, mask term and the running maximum M carry a factor log2(e)):
+// e^(x - M) = 2^(x2 - M2) is then one v_exp_f32 per score instead of expf's range reduction, and scale * log2(e) is one constant.
+// Accumulator register r = 4 g + j of lane (q, h) is key kv0 + 8 g + 4 h + j: the four mask values a register group needs are 8 contiguous
+// bytes of this lane's mask row — read as such (whole chunks of a 16-byte aligned mask; fp16 -inf converts to -inf, no clamping), the conversion
+// folded into the multiply-add.  Ragged chunks, unaligned masks and the softcap take the element-wise path.
+__device__ __forceinline__ float fa_softmax_step(const fattn_params &p, floatx16 &s, int kv0, int h, const half_t *mrow, float slope2,
                                                  float &M, float &S, half8_t (&pf)[2]) {
-    const bool vec = mrow && p.mask_vec && kv0 + 32 <= p.n_kv;                 // wave-uniform
-    floatx16 mt;
-    if (vec) {
+    constexpr float LOG2E = 1.4426950408889634f;
+    const bool whole = kv0 + 32 <= p.n_kv;                                      // wave-uniform
+    if (whole && p.logit_softcap == 0.0f && (!mrow || p.mask_vec)) {
+        const float c2 = p.scale * LOG2E;
+        if (mrow) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) mt[r] = 0.0f;
+            for (int g = 0; g < 4; g++) {
+                const half4_t mv = *reinterpret_cast<const half4_t *>(mrow + kv0 + 8 * g + 4 * h);
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            half8_t mb = *reinterpret_cast<const half8_t *>(mrow + kv0 + 16 * u + 8 * h);
+                for (int j = 0; j < 4; j++) s[4 * g + j] = __builtin_fmaf((float)mv[j], slope2, s[4 * g + j] * c2);
+            }
+        } else {
 #pragma unroll
-            for (int e = 0; e < 8; e++) mb[e] = mb[e] < (half_t)-65504.0f ? (half_t)-65504.0f : mb[e];
-            mt = __builtin_amdgcn_mfma_f32_32x32x16_f16(sel[u], mb, mt, 0, 0, 0);
+            for (int r = 0; r < 16; r++) s[r] *= c2;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float x = s[r] * p.scale;
+            if (p.logit_softcap != 0.0f) x = p.logit_softcap * tanhf(x);
+            x *= LOG2E;
+            if (kv < p.n_kv) { if (mrow) x += slope2 * (float)mrow[kv]; } else x = -INFINITY;
+            s[r] = x;
         }
     }
-    (void)n;
-    float mx = -INFINITY;
+    float mx = s[0];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        float x = s[r] * p.scale;
-        if (p.logit_softcap != 0.0f) x = p.logit_softcap * tanhf(x);
-        if (vec) x += mt[r] <= -65504.0f ? -INFINITY : slope * mt[r];
-        else if (kv < p.n_kv) { if (mrow) x += slope * (float)mrow[kv]; } else x = -INFINITY;
-        s[r] = x; mx = fmaxf(mx, x);
-    }
+    for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float Mn = fmaxf(M, mx);
-    // everything masked so far: keep (M, S, O) = (-inf, 0, 0) — the CPU skips -inf entries (ggml-cpu.c:10935-10938)
-    const float ms = (M == -INFINITY) ? 0.0f : expf(M - Mn);
+    // everything masked so far (Mn = -inf): subtract 0 instead — every 2^(-inf) below is 0 and (M, S, O) stay (-inf, 0, 0), as the CPU's
+    // skipping of -inf entries leaves them (ggml-cpu.c:10935-10938); no (-inf) - (-inf) anywhere
+    const float Ms = (Mn == -INFINITY) ? 0.0f : Mn;
+    const float ms = __builtin_amdgcn_exp2f(M - Ms);
     float sum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const float e = (Mn == -INFINITY) ? 0.0f : expf(s[r] - Mn);
+        const float e = __builtin_amdgcn_exp2f(s[r] - Ms);
         sum += e; pf[r >> 3][r & 7] = (half_t)e;
     }
     sum += __shfl_xor(sum, 32);
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_split(con
     half8_t qf[NS], sel[2];
     fa_load_q<NS>(p, qi, head, b3, h, qf);
     fa_selectors(n, h, sel);
-    const float slope = fa_slope(p, head);
+    const float slope2 = fa_slope(p, head) * 1.4426950408889634f;                 // log2 domain (fa_softmax_step)
     const char *kbase = p.k + (int64_t)(head / p.rk2) * p.k_nb2 + (int64_t)(b3 / p.rk3) * p.k_nb3;
     const char *vbase = p.v + (int64_t)(head / p.rv2) * p.v_nb2 + (int64_t)(b3 / p.rv3) * p.v_nb3;
     const half_t *mrow = p.mask ? (const half_t *)(p.mask + (int64_t)qi * p.mask_nb1) : nullptr;
@@ -154,7 +162,15 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_split(con
 #pragma unroll
         for (int st = 0; st < NS; st++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(kp + 32 * st), qf[st], s, 0, 0, 0);
         half8_t pf[2];
-        const float ms = fa_softmax_step(p, s, kv0, n, h, mrow, slope, sel, M, S, pf);
+        const float ms = fa_softmax_step(p, s, kv0, h, mrow, slope2, M, S, pf);
+        // O^T *= ms, skipped while no row of the wave moved its maximum (x 1.0 is exact).  ONE branch in front of the block loop: with the test
+        // inside the loop hipcc (ROCm 7.2) branched on a stale SGPR pair for blocks 1..3 — wrong results on MI355X, invisible to the CPU emulation
+        if (wave_any(ms != 1.0f)) {
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[b][r] *= ms;
+        }
         // O^T = O^T * ms + Vt^T . P^T, one 32-wide block of the head dimension at a time
 #pragma unroll
         for (int b = 0; b < NB; b++) {
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_split(con
             vt = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(vp + 64 * b + 32), sel[1], vt, 0, 0, 0);
             half8_t vf[2];
 #pragma unroll
-            for (int r = 0; r < 16; r++) { vf[r >> 3][r & 7] = (half_t)vt[r]; o[b][r] *= ms; }
+            for (int r = 0; r < 16; r++) vf[r >> 3][r & 7] = (half_t)vt[r];
             o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], pf[0], o[b], 0, 0, 0);
             o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1], pf[1], o[b], 0, 0, 0);
         }
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_split(con
         __syncthreads();
         if (wave == 0) {
             const float Mw = Ms[n], Sw = Ss[n], Mn = fmaxf(M, Mw);
-            const float a0 = (M == -INFINITY) ? 0.0f : expf(M - Mn), aw = (Mw == -INFINITY) ? 0.0f : expf(Mw - Mn);
+            const float a0 = (M == -INFINITY) ? 0.0f : exp2f(M - Mn), aw = (Mw == -INFINITY) ? 0.0f : exp2f(Mw - Mn);      // (M in the log2 domain)
 #pragma unroll
             for (int b = 0; b < NB; b++)
 #pragma unroll
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(256) void k_flash_attn_merge(const fattn_params p) 
         float num = 0.0f, den = 0.0f;
         for (int s = 0; s < p.nsplit; s++) {
             const float *pt = base + ((int64_t)s * 32 + q) * (HS + 4);
-            const float a = (pt[0] == -INFINITY) ? 0.0f : expf(pt[0] - Mx);
+            const float a = (pt[0] == -INFINITY) ? 0.0f : exp2f(pt[0] - Mx);      // (M in the log2 domain)
             num += pt[4 + d] * a; den += pt[1] * a;
         }
         p.dst[(((int64_t)b3 * p.n_q + (qt * 32 + q)) * p.n_head + head) * HS + d] = num * (1.0f / den);
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_wide(cons
     half8_t qf[NS], sel[2];
     fa_load_q<NS>(p, qi, head, b3, h, qf);
     fa_selectors(n, h, sel);
-    const float slope = fa_slope(p, head);
+    const float slope2 = fa_slope(p, head) * 1.4426950408889634f;                 // log2 domain (fa_softmax_step)
     const char *kbase = p.k + (int64_t)(head / p.rk2) * p.k_nb2 + (int64_t)(b3 / p.rk3) * p.k_nb3;
     const char *vbase = p.v + (int64_t)(head / p.rv2) * p.v_nb2 + (int64_t)(b3 / p.rv3) * p.v_nb3;
     const half_t *mrow = p.mask ? (const half_t *)(p.mask + (int64_t)qi * p.mask_nb1) : nullptr;
@@ -296,14 +312,18 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_wide(cons
             for (int r = 0; r < 16; r++) s[r] = 0.0f;
 #pragma unroll
             for (int st = 0; st < NS; st++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Ks + n * RS + 32 * st + 16 * h), qf[st], s, 0, 0, 0);
-            ms = fa_softmax_step(p, s, 32 * c, n, h, mrow, slope, sel, M, S, pf);
+            ms = fa_softmax_step(p, s, 32 * c, h, mrow, slope2, M, S, pf);
         }
         __syncthreads();                                          // Vt is complete
         if (active) {
+            if (wave_any(ms != 1.0f)) {                                 // after the first chunks the running maximum rarely moves: x 1.0 skipped (exact; one branch, see above)
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) o[b][r] *= ms;
+            }
 #pragma unroll
             for (int b = 0; b < NB; b++) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[b][r] *= ms;
                 o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Vt + ((b * 2 + 0) * 64 + lane) * 16), pf[0], o[b], 0, 0, 0);
                 o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Vt + ((b * 2 + 1) * 64 + lane) * 16), pf[1], o[b], 0, 0, 0);
             }

@@ -117,6 +117,7 @@ inline int sync_point(pthread_barrier_t *b) { if (b == &g_wg_barrier) wg_barrier
 static inline void emu_sleep() { static thread_local unsigned n = 0; usleep(200); if (++n > 600000u) { fprintf(stderr, "emulated spin loop gave up\n"); _exit(9); } }
 #define __builtin_amdgcn_s_sleep(x) emu_sleep()
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)             // v_exp_f32
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_s_memrealtime() 0ull
 #define __HIP_MEMORY_SCOPE_AGENT 0
