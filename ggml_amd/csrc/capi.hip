@@ -209,6 +209,20 @@ static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const floa
     if (!is_q(type)) return cdna4_set_error_msg("mul_mat: unsupported weight type");
     if (M <= 0 || B <= 0) return 0;
     if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat: K is not a whole number of blocks");
+    // Formats that reach the MFMA kernels through an exact re-encoding (Q5_0 / IQ4_NL -> Q8_0, convert_w.hip) follow their TARGET format onto the int8
+    // matrix-core kernel at the batch sizes where that one is chosen: re-encode into scratch, then the target's route (its integer dots on Q8_0
+    // activations are the CPU's own arithmetic for the source format: vec_dot_q5_0_q8_0 / vec_dot_iq4_nl_q8_0 on the same quants).  Same result as
+    // ggml_cdna4_convert_weights up front + ggml_cdna4_mul_mat on the target format (tests/test_gpu_widening.py).
+    if (path == GGML_CDNA4_PATH_AUTO && cdna4_convert_weights_kmul(type) == 1) {
+        const int tgt = cdna4_convert_weights_target(type);
+        if (tgt >= 0 && tgt != type && use_mmq(tgt, M, K, B)) {
+            uint8_t *cw = (uint8_t *)cdna4_gemm_scratch(cdna4_convert_weights_bytes(type, M, K) + 256, 3);
+            if (!cw) return cdna4_set_error_msg("mul_mat: cannot allocate the re-encoded weights");
+            const int rc = cdna4_launch_convert_weights(type, (const uint8_t *)W, w_row_bytes, M, K, cw, (hipStream_t)stream);
+            if (rc) return rc;
+            return mul_mat_impl(tgt, cw, (int64_t)ggml_cdna4_row_size(tgt, K), X, x_row_stride, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, epi, stream);
+        }
+    }
     // the int8 matrix-core kernel: AUTO only (an explicit PATH_GEMV keeps the v_dot4 units — tests compare the two), aligned Q4_K rows
     const bool mmq = path == GGML_CDNA4_PATH_AUTO && use_mmq(type, M, K, B) && !(((uintptr_t)W | (uintptr_t)w_row_bytes) & 15);
     path = resolve_path(type, path, M, K, B);

@@ -87,6 +87,7 @@ int cdna4_launch_quantize_q8_0_gather(const float *x, int64_t x_row_stride, int6
 bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B);
 // convert_w.hip: exact re-encodings Q5_0 -> Q8_0, Q3_K -> Q6_K (prefill GEMM of the source format = GEMM of the target format) and
 // Q2_K -> [scale part | minimum part] as Q6_K with 2 K columns (kmul = 2: the activation image must hold x twice)
+void *cdna4_gemm_scratch(size_t bytes, int kind);      // gemm_q_mfma.hip: per-device library scratch by kind (3 = re-encoded weights)
 size_t cdna4_convert_weights_bytes(int type, int64_t M, int64_t K);
 int cdna4_convert_weights_target(int type);
 int cdna4_convert_weights_kmul(int type);

@@ -332,6 +332,172 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_wide(cons
     if (q0 + n < p.n_q) fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + (q0 + n)) * p.n_head + head) * HS, o, 1.0f / S, h);
 }
 
+// ------------------------------------------------------------------------------------------------ wide kernel, 64-key chunks (head sizes 64 / 128)
+// The same arithmetic as k_flash_attn_wide over TWO 32-key blocks per step: one online-softmax update (one maximum, one rescaling of O) and TWO
+// barriers per 64 keys instead of three per 32 —
+//   top of chunk c : the registers fetched during chunk c - 1 go to Ks / Vs (free: every wave has passed B2 of chunk c - 1, i.e. finished its
+//                    score products and its share of the V transposition; only Vt may still be read, by the P.V products of chunk c - 1)
+//   B1             : Ks / Vs of chunk c are visible, every wave is done with Vt of chunk c - 1
+//                    K / V of chunk c + 1 are requested; this wave's (key block, head block) units are transposed into Vt; scores, softmax;
+//                    the mask groups of chunk c + 1 are requested (their registers are free now)
+//   B2             : Vt is complete                       P.V products
+// The mask values of a whole chunk arrive a chunk ahead in registers (8 x 8 bytes per lane) like K / V do, so the softmax never waits for L2.
+template <int NKB>
+__device__ __forceinline__ float fa_softmax_blocks(const fattn_params &p, floatx16 (&s)[NKB], int kv0, int h, const half_t *mrow, float slope2, const half4_t (&mreg)[NKB * 4],
+                                                   float &M, float &S, half8_t (&pf)[NKB * 2]) {
+    constexpr float LOG2E = 1.4426950408889634f;
+    const bool whole = kv0 + 32 * NKB <= p.n_kv;                                // wave-uniform
+    if (whole && p.logit_softcap == 0.0f && (!mrow || p.mask_vec)) {           // (with a mask: exactly the condition under which the caller filled mreg)
+        const float c2 = p.scale * LOG2E;
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++) {
+            if (mrow) {
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) s[kb][4 * g + j] = __builtin_fmaf((float)mreg[kb * 4 + g][j], slope2, s[kb][4 * g + j] * c2);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) s[kb][r] *= c2;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int kv = kv0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float x = s[kb][r] * p.scale;
+                if (p.logit_softcap != 0.0f) x = p.logit_softcap * tanhf(x);
+                x *= LOG2E;
+                if (kv < p.n_kv) { if (mrow) x += slope2 * (float)mrow[kv]; } else x = -INFINITY;
+                s[kb][r] = x;
+            }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float Mn = fmaxf(M, mx);
+    const float Ms = (Mn == -INFINITY) ? 0.0f : Mn;                             // (see fa_softmax_step)
+    const float ms = __builtin_amdgcn_exp2f(M - Ms);
+    float sum = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float e = __builtin_amdgcn_exp2f(s[kb][r] - Ms);
+            sum += e; pf[kb * 2 + (r >> 3)][r & 7] = (half_t)e;
+        }
+    sum += __shfl_xor(sum, 32);
+    S = S * ms + sum; M = Mn;
+    return ms;
+}
+
+template <int HS>
+__global__ __launch_bounds__(256, 2) void k_flash_attn_wide64(const fattn_params p) {
+    constexpr int NS = HS / 16, NB = HS / 32, NKB = 2, CK = 32 * NKB;
+    constexpr int RS = (HS + 8) * 2;                              // bytes of a staged K / V row (16 bytes of padding spread the rows over the banks)
+    constexpr int PL = CK * HS / 8 / 256;                         // 16-byte pieces of one chunk per thread and matrix
+    __shared__ __attribute__((aligned(16))) uint8_t Ks[CK * RS], Vs[CK * RS];
+    __shared__ __attribute__((aligned(16))) uint8_t Vt[NB * NKB * 2 * 64 * 16];   // transposed V as A fragments: [head block][key block][k-step][lane] x 16 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 128 + 32 * wave, head = blockIdx.y, b3 = blockIdx.z;
+    const bool active = q0 < p.n_q;                               // a wave whose 32 rows are all past the end only helps with the staging
+    const int qi = min(q0 + n, p.n_q - 1);
+
+    half8_t qf[NS], sel[2];
+    fa_load_q<NS>(p, qi, head, b3, h, qf);
+    fa_selectors(n, h, sel);
+    const float slope2 = fa_slope(p, head) * 1.4426950408889634f;
+    const char *kbase = p.k + (int64_t)(head / p.rk2) * p.k_nb2 + (int64_t)(b3 / p.rk3) * p.k_nb3;
+    const char *vbase = p.v + (int64_t)(head / p.rv2) * p.v_nb2 + (int64_t)(b3 / p.rv3) * p.v_nb3;
+    const half_t *mrow = p.mask ? (const half_t *)(p.mask + (int64_t)qi * p.mask_nb1) : nullptr;
+
+    float M = -INFINITY, S = 0.0f;
+    floatx16 o[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[b][r] = 0.0f;
+
+    u32x4 kreg[PL], vreg[PL];
+    half4_t mreg[NKB * 4] = {};
+    auto fetch_kv = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PL; i++) {
+            const int pc = tid + 256 * i, row = pc / (HS / 8), col = pc % (HS / 8);
+            const int64_t kr = min(CK * c + row, p.n_kv - 1);     // past the end: repeated, masked in the softmax
+            kreg[i] = *reinterpret_cast<const u32x4 *>(kbase + kr * p.k_nb1 + 16 * col);
+            vreg[i] = *reinterpret_cast<const u32x4 *>(vbase + kr * p.v_nb1 + 16 * col);
+        }
+    };
+    auto fetch_mask = [&](int c) __attribute__((always_inline)) {
+        if (active && mrow && p.mask_vec && CK * c + CK <= p.n_kv) {   // (wave-uniform)
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) mreg[kb * 4 + g] = *reinterpret_cast<const half4_t *>(mrow + CK * c + 32 * kb + 8 * g + 4 * h);
+        }
+    };
+    const int nchunk = (p.n_kv + CK - 1) / CK;
+    fetch_kv(0); fetch_mask(0);
+    for (int c = 0; c < nchunk; c++) {
+#pragma unroll
+        for (int i = 0; i < PL; i++) {
+            const int pc = tid + 256 * i, row = pc / (HS / 8), col = pc % (HS / 8);
+            *reinterpret_cast<u32x4 *>(Ks + row * RS + 16 * col) = kreg[i];
+            *reinterpret_cast<u32x4 *>(Vs + row * RS + 16 * col) = vreg[i];
+        }
+        __syncthreads();                                          // B1
+        if (c + 1 < nchunk) fetch_kv(c + 1);                      // in flight while this chunk is computed
+        for (int u = wave; u < NKB * NB; u += 4) {               // this wave's share of the transposed V fragments
+            const int kb = u / NB, b = u % NB;
+            floatx16 vt;
+#pragma unroll
+            for (int r = 0; r < 16; r++) vt[r] = 0.0f;
+            vt = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Vs + (32 * kb + n) * RS + 64 * b + 16 * h), sel[0], vt, 0, 0, 0);
+            vt = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Vs + (32 * kb + n) * RS + 64 * b + 32 + 16 * h), sel[1], vt, 0, 0, 0);
+            half8_t vf[2];
+#pragma unroll
+            for (int r = 0; r < 16; r++) vf[r >> 3][r & 7] = (half_t)vt[r];
+            *reinterpret_cast<half8_t *>(Vt + (((b * NKB + kb) * 2 + 0) * 64 + lane) * 16) = vf[0];
+            *reinterpret_cast<half8_t *>(Vt + (((b * NKB + kb) * 2 + 1) * 64 + lane) * 16) = vf[1];
+        }
+        half8_t pf[NKB * 2];
+        float ms = 1.0f;
+        if (active) {
+            floatx16 s[NKB];
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) s[kb][r] = 0.0f;
+#pragma unroll
+                for (int st = 0; st < NS; st++) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Ks + (32 * kb + n) * RS + 32 * st + 16 * h), qf[st], s[kb], 0, 0, 0);
+            }
+            ms = fa_softmax_blocks<NKB>(p, s, CK * c, h, mrow, slope2, mreg, M, S, pf);
+        }
+        if (c + 1 < nchunk) fetch_mask(c + 1);
+        __syncthreads();                                          // B2
+        if (active) {
+            if (wave_any(ms != 1.0f)) {                             // (one branch in front of the block loop: see k_flash_attn_split)
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) o[b][r] *= ms;
+            }
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int kt = 0; kt < NKB * 2; kt++)
+                    o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Vt + ((b * NKB * 2 + kt) * 64 + lane) * 16), pf[kt], o[b], 0, 0, 0);
+        }
+    }
+    if (q0 + n < p.n_q) fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + (q0 + n)) * p.n_head + head) * HS, o, 1.0f / S, h);
+}
+
 #define NEED(cond, msg) do { if (!(cond)) return cdna4_set_error_msg(msg); } while (0)
 typedef ggml_cdna4_tensor T4;
 
@@ -435,7 +601,10 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
     const int64_t cus = cdna4_gemm_cu_count();
     if (N > 32 && ((N + 127) / 128) * H * B3 >= cus) {           // prefill that fills the chip: 128 query rows per work-group, K / V staged through LDS
         const dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B3);
-        if (D == 64) hipLaunchKernelGGL(k_flash_attn_wide<64>, grid, dim3(256), 0, st, p);
+        static const bool chunks32 = getenv("CDNA4_FA_WIDE32") != nullptr;      // A/B knob: the 32-key-chunk kernel for every head size
+        if (D == 64 && !chunks32) hipLaunchKernelGGL(k_flash_attn_wide64<64>, grid, dim3(256), 0, st, p);
+        else if (D == 128 && !chunks32) hipLaunchKernelGGL(k_flash_attn_wide64<128>, grid, dim3(256), 0, st, p);
+        else if (D == 64) hipLaunchKernelGGL(k_flash_attn_wide<64>, grid, dim3(256), 0, st, p);
         else if (D == 128) hipLaunchKernelGGL(k_flash_attn_wide<128>, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_flash_attn_wide<256>, grid, dim3(256), 0, st, p);
         CDNA4_CHECK_LAUNCH();
