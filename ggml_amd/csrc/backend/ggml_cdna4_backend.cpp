@@ -308,9 +308,9 @@ static int try_fused_norm(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, const
     float eps; memcpy(&eps, nm->op_params, sizeof(float));
     const ggml_cdna4_tensor dx = tdesc(nm->src[0]), dg = tdesc(gain), dd = tdesc(last);
     ggml_cdna4_tensor ds{}; if (shift) ds = tdesc(shift);
-    if (ggml_cdna4_op_norm_affine(&dx, &dg, shift ? &ds : nullptr, &dd, eps, nm->op == GGML_OP_RMS_NORM, ctx->stream)) {
-        fprintf(stderr, "ggml-cdna4: fused NORM failed: %s\n", ggml_cdna4_last_error()); st = GGML_STATUS_FAILED;
-    }
+    // the fused entry point validates shapes and strides BEFORE its launch: a rejection has written nothing, and the nodes run one by one instead
+    // (a layout each separate kernel accepts must not abort a graph that ran before the peephole existed)
+    if (ggml_cdna4_op_norm_affine(&dx, &dg, shift ? &ds : nullptr, &dd, eps, nm->op == GGML_OP_RMS_NORM, ctx->stream)) { (void)st; return 0; }
     return used;
 }
 static int try_fused_soft_max(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, const use_counts & uses, enum ggml_status & st) {
@@ -324,9 +324,7 @@ static int try_fused_soft_max(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, c
     const int n_past = ((const int32_t *)dm->op_params)[0];
     if (n_past < 0 || !alias_or_disjoint(sc->src[0], sm)) return 0;
     const ggml_cdna4_tensor dx = tdesc(sc->src[0]), dd = tdesc(sm);
-    if (ggml_cdna4_op_soft_max_ext(&dx, nullptr, &dd, scale, max_bias, 1, pre, n_past, ctx->stream)) {
-        fprintf(stderr, "ggml-cdna4: fused SOFT_MAX failed: %s\n", ggml_cdna4_last_error()); st = GGML_STATUS_FAILED;
-    }
+    if (ggml_cdna4_op_soft_max_ext(&dx, nullptr, &dd, scale, max_bias, 1, pre, n_past, ctx->stream)) { (void)st; return 0; }      // (rejected before any launch: node by node, as above)
     return 3;
 }
 
