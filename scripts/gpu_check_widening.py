@@ -249,6 +249,9 @@ def timings(formats=True):
         timings_formats(rng, m, k, b)
     for D, n_q, n_head, n_kv in ((128, 512, 32, 512), (128, 512, 32, 4096), (128, 2048, 32, 2048), (128, 4096, 32, 4096), (128, 1, 32, 4096), (128, 1, 32, 32768), (128, 8, 32, 4096), (64, 512, 32, 1024), (256, 512, 16, 1024)):
         time_fa(rng, D, n_q, n_head, n_kv)
+    for name, t in (("q8_0", R.Q8_0), ("q4_0", R.Q4_0)):
+        for n_q, n_kv in ((1, 32768), (1, 4096), (8, 4096)):
+            time_fa_qkv(rng, 128, n_q, 32, n_kv, name, t)
 
 
 def timings_formats(rng, m, k, b):
@@ -262,6 +265,33 @@ def timings_formats(rng, m, k, b):
         report(test="time_mul_mat_step", type=name, m=m, k=k, b=b, us_per_call=round(us, 2), effective_tflops=round(2.0 * m * k * b / us / 1e6, 1))
         for p in (wd, ws, y):
             hip.hipFree(p)
+
+
+def time_fa_qkv(rng, D, n_q, n_head, n_kv, name, t):
+    """decode over a quantized KV cache: the dequantizing operand loads of the key-split kernel against the fp16 copy of round 2 (CDNA4_FA_KV_COPY=1)"""
+    q = to_dev(rng.uniform(-1, 1, (1, n_head, n_q, D)).astype(np.float32))
+    rb = R.row_size(t, D)
+    kk = to_dev(R.random_weights(t, n_head * n_kv, D, seed=3)); vv = to_dev(R.random_weights(t, n_head * n_kv, D, seed=4))
+    mrows = (n_q + 63) // 64 * 64
+    mm = to_dev(rng.uniform(-1, 1, (mrows, n_kv)).astype(np.float16))
+    od = dmalloc(4 * n_q * n_head * D)
+    dq, dm, dd = desc(q, 0, 4, (1, n_head, n_q, D)), desc(mm, 1, 2, (1, 1, mrows, n_kv)), desc(od, 0, 4, (1, n_q, n_head, D))
+    dk, dv = desc(kk, int(t), rb, (1, n_head, n_kv, 1)), desc(vv, int(t), rb, (1, n_head, n_kv, 1))
+    for dsc in (dk, dv):
+        dsc.ne[0] = D; dsc.nb[0] = R.type_size(t) if hasattr(R, "type_size") else {int(R.Q8_0): 34, int(R.Q4_0): 18}[int(t)]
+    res = {}
+    for mode in ("direct", "copy"):
+        if mode == "copy":
+            os.environ["CDNA4_FA_KV_COPY"] = "1"
+        else:
+            os.environ.pop("CDNA4_FA_KV_COPY", None)
+        res[mode] = timed(lambda: ok(L.ggml_cdna4_op_flash_attn_ext(C.byref(dq), C.byref(dk), C.byref(dv), C.byref(dm), C.byref(dd), C.c_float(0.088), C.c_float(0.0), C.c_float(0.0), None), "fattn"))
+    os.environ.pop("CDNA4_FA_KV_COPY", None)
+    byts = 2.0 * n_head * n_kv * rb
+    report(test="time_flash_attn_ext_quantized_kv", type=name, D=D, n_q=n_q, n_head=n_head, n_kv=n_kv, us_direct=round(res["direct"], 2), us_with_fp16_copy=round(res["copy"], 2),
+           cache_GBps_direct=round(byts / res["direct"] / 1e3, 1))
+    for p in (q, kk, vv, mm, od):
+        hip.hipFree(p)
 
 
 def time_fa(rng, D, n_q, n_head, n_kv):
