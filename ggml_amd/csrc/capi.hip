@@ -189,7 +189,7 @@ static int mul_mat_prepared_impl(int type, const void *W, int64_t w_row_bytes, f
     if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat: K is not a whole number of blocks");
     const ws_view v = carve(type, K, B, (void *)workspace);
     if (workspace_bytes < v.total) return cdna4_set_error_msg("mul_mat: workspace too small");
-    const bool mmq = path == GGML_CDNA4_PATH_AUTO && use_mmq(type, M, K, B) && !(((uintptr_t)W | (uintptr_t)w_row_bytes) & 15);
+    const bool mmq = path == GGML_CDNA4_PATH_AUTO && use_mmq(type, M, K, B) && !(((uintptr_t)W | (uintptr_t)w_row_bytes) & (type == CDNA4_Q6_K ? 1 : 15));
     path = resolve_path(type, path, M, K, B);
     if (path == GGML_CDNA4_PATH_GEMM) {
         const cdna4_gemm_args a = gemm_args_of(type, W, w_row_bytes, v.xh, Y, y_row_stride, M, K, B, gemm_variant, splitk, epi);
@@ -224,7 +224,7 @@ static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const floa
         }
     }
     // the int8 matrix-core kernel: AUTO only (an explicit PATH_GEMV keeps the v_dot4 units — tests compare the two), aligned Q4_K rows
-    const bool mmq = path == GGML_CDNA4_PATH_AUTO && use_mmq(type, M, K, B) && !(((uintptr_t)W | (uintptr_t)w_row_bytes) & 15);
+    const bool mmq = path == GGML_CDNA4_PATH_AUTO && use_mmq(type, M, K, B) && !(((uintptr_t)W | (uintptr_t)w_row_bytes) & (type == CDNA4_Q6_K ? 1 : 15));
     path = resolve_path(type, path, M, K, B);
     if (path == GGML_CDNA4_PATH_GEMM && !cdna4_gemm_q_supported(type, M, K, B)) return cdna4_set_error_msg("mul_mat: GEMM path does not support this shape");
     // one launch while the redundant per-work-group quantization is cheap (B x K up to 32 K values, rounded to the instantiated 2 / 4 / 8 columns)

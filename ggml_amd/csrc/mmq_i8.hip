@@ -309,8 +309,153 @@ __global__ __launch_bounds__(NW * 64) void k_mmq_q8_0act(const mmq_args a) {
     }
 }
 
+// ---- Q6_K weights (Q8_K activations): ggml_vec_dot_q6_K_q8_K (src/ggml-cpu/ggml-cpu-quants.c:6944-...): per 16-weight sub-block j the integer dot of
+// (q6 - 32) with the activation quants, times the sub-block's int8 scale, summed over the superblock in int32, then x (d_w d_y) in fp32.
+// Differences to the kernels above: (1) a superblock is 210 bytes (ql[128] qh[64] scales[16] d), 2-byte aligned only — the slab is fetched as the
+// fourteen 16-byte ALIGNED pieces that cover each row's run (never touching a 16-byte line the run does not touch, so never a page the tensor does
+// not own) and every field is read from LDS at its 2-byte-aligned place through aligned dwords and a funnel shift; (2) the scale changes every
+// SIXTEEN weights, and the MFMA contracts 32: each 32-weight block is multiplied twice, with the other half's weight bytes zeroed (k-groups 0, 1 =
+// the first sub-block, 2, 3 = the second) — 16 MFMAs per superblock and column group; the matrix core has the time; (3) q6 - 32 is built as a signed
+// byte (flip bit 5, extend the sign: t | (t & 0x20) * 7), so there is no minimum term and the bsums are not read.
+template <int NCG, int NW>
+__global__ __launch_bounds__(NW * 64) void k_mmq_q6_K(const mmq_args a) {
+    constexpr int WB = 210, NPC = 14, WROW = 240;                      // bytes per superblock; aligned pieces covering any 2-byte-aligned run of 210; LDS row slot
+    constexpr int NWI = (16 * NPC + 63) / 64;                          // 4 load instructions per slab
+    constexpr int XROW = 272, XS = 16 * XROW, MS = 16 * 32, WSZ = 16 * WROW;
+    constexpr int SLAB = NCG * (XS + MS) + WSZ;
+    constexpr int SMEM = NW * SLAB > NW * NCG * 1024 ? NW * SLAB : NW * NCG * 1024;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, grp = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int nsb = a.K / 256;
+    uint8_t *slab = smem + wave * SLAB;
+    uint8_t *wl = slab + NCG * (XS + MS);
+    const uint8_t *wrow_g = a.W + (int64_t)min(m0 + col, a.M - 1) * a.w_row_bytes;     // this lane's weight row (MFMA role)
+
+    float acc[NCG][4];
+#pragma unroll
+    for (int g = 0; g < NCG; g++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[g][i] = 0.f;
+
+    struct Slab { u32x4 x[NCG][4]; float dy[NCG]; u32x4 w[NWI]; };
+    auto fetch = [&](int sb) __attribute__((always_inline)) {
+        Slab r;
+#pragma unroll
+        for (int g = 0; g < NCG; g++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int b = min(g * 16 + 4 * i + (lane >> 4), a.B - 1);
+                r.x[g][i] = ld_u32x4(a.qs + (int64_t)b * a.K + sb * 256 + (lane & 15) * 16);
+            }
+            r.dy[g] = a.d[(int64_t)min(g * 16 + (lane & 15), a.B - 1) * nsb + sb];
+        }
+#pragma unroll
+        for (int i = 0; i < NWI; i++) {                                  // piece i * 64 + lane of 16 x 14: row piece / 14, aligned piece piece % 14 of that row's run
+            const int pc = min(i * 64 + lane, 16 * NPC - 1), row = pc / NPC, c = pc - row * NPC;
+            const uintptr_t start = (uintptr_t)(a.W + (int64_t)min(m0 + row, a.M - 1) * a.w_row_bytes + (int64_t)sb * WB);
+            r.w[i] = ld_u32x4(reinterpret_cast<const uint8_t *>((start & ~(uintptr_t)15) + 16 * c));
+        }
+        return r;
+    };
+    auto park = [&](const Slab &r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < NCG; g++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) *reinterpret_cast<u32x4 *>(slab + g * (XS + MS) + (4 * i + (lane >> 4)) * XROW + (lane & 15) * 16) = r.x[g][i];
+            if (lane < 16) *reinterpret_cast<float *>(slab + g * (XS + MS) + XS + lane * 32 + 16) = r.dy[g];
+        }
+#pragma unroll
+        for (int i = 0; i < NWI; i++) {
+            const int pc = i * 64 + lane, row = pc / NPC, c = pc - row * NPC;
+            if (pc < 16 * NPC) *reinterpret_cast<u32x4 *>(wl + row * WROW + c * 16) = r.w[i];
+        }
+    };
+    auto ld8_a2 = [&](const uint8_t *p, int off) __attribute__((always_inline)) -> u32x2 {
+        if ((off & 3) == 0) return u32x2{*reinterpret_cast<const uint32_t *>(p + off), *reinterpret_cast<const uint32_t *>(p + off + 4)};
+        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(p + off - 2), w1 = *reinterpret_cast<const uint32_t *>(p + off + 2), w2 = *reinterpret_cast<const uint32_t *>(p + off + 6);
+        return u32x2{(w0 >> 16) | (w1 << 16), (w1 >> 16) | (w2 << 16)};
+    };
+
+    Slab cur{};
+    if (wave < nsb) cur = fetch(wave);
+    for (int sb = wave; sb < nsb; sb += NW) {
+        CDNA4_WAVE_LDS_SYNC();
+        park(cur);
+        CDNA4_WAVE_LDS_SYNC();
+        if (sb + NW < nsb) cur = fetch(sb + NW);
+        // this lane's row inside its slot: the run starts (address & 15) bytes into the first piece
+        const int o = (int)((uintptr_t)(wrow_g + (int64_t)sb * WB) & 15);
+        const uint8_t *wr = wl + col * WROW;
+        const u32x2 s01 = ld8_a2(wr, o + 192), s23 = ld8_a2(wr, o + 200);              // the sixteen int8 sub-block scales
+        const uint32_t scw[4] = {s01.x, s01.y, s23.x, s23.y};
+        const uint32_t dword = (o & 3) == 0 ? *reinterpret_cast<const uint32_t *>(wr + o + 208) : *reinterpret_cast<const uint32_t *>(wr + o + 206) >> 16;
+        const float dw = h2f(dword & 0xFFFF);
+        intx4 sumi[NCG];
+#pragma unroll
+        for (int g = 0; g < NCG; g++) sumi[g] = intx4{0, 0, 0, 0};
+#pragma unroll
+        for (int n = 0; n < 2; n++) {                                    // 128-weight halves (dequantize_row_q6_K, src/ggml-quants.c:1690-1716)
+            const u32x2 qh = ld8_a2(wr, o + 128 + 32 * n + 8 * grp);     // qh[l], l = 8 grp .. 8 grp + 7: two bits for each of the half's four 32-weight blocks
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++) {
+                const u32x2 ql = ld8_a2(wr, o + 64 * n + 32 * pp + 8 * grp);             // ql[32 pp + l]: low nibbles -> block pp, high nibbles -> block pp + 2
+#pragma unroll
+                for (int hi = 0; hi < 2; hi++) {
+                    const int quad = pp + 2 * hi, jj = 4 * n + quad;     // 32-weight block jj of the superblock = sub-blocks 2 jj, 2 jj + 1
+                    uint32_t v0 = ((ql.x >> (4 * hi)) & 0x0F0F0F0Fu) | (((qh.x >> (2 * quad)) & 0x03030303u) << 4);
+                    uint32_t v1 = ((ql.y >> (4 * hi)) & 0x0F0F0F0Fu) | (((qh.y >> (2 * quad)) & 0x03030303u) << 4);
+                    v0 ^= 0x20202020u; v1 ^= 0x20202020u;                // q6 - 32 as int8: flip bit 5 ...
+                    v0 |= (v0 & 0x20202020u) * 7u; v1 |= (v1 & 0x20202020u) * 7u;       // ... and extend the sign (0x20 x 7 = 0xE0: no carry between bytes)
+                    const uint32_t a0 = grp < 2 ? v0 : 0u, a1 = grp < 2 ? v1 : 0u, b0 = grp < 2 ? 0u : v0, b1 = grp < 2 ? 0u : v1;
+                    const int sca = (int)(int8_t)((scw[jj >> 1] >> (16 * (jj & 1))) & 0xFF), scb = (int)(int8_t)((scw[jj >> 1] >> (16 * (jj & 1) + 8)) & 0xFF);
+#pragma unroll
+                    for (int g = 0; g < NCG; g++) {
+                        const u32x2 xv = *reinterpret_cast<const u32x2 *>(slab + g * (XS + MS) + col * XROW + 32 * jj + 8 * grp);
+                        const intx4 z = {0, 0, 0, 0};
+                        const intx4 sa = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xv.x, xv.y), as_i64(a0, a1), z, 0, 0, 0);
+                        const intx4 sb2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xv.x, xv.y), as_i64(b0, b1), z, 0, 0, 0);
+                        // |S| <= 16 * 32 * 127 = 65,024 and |sc| <= 128: the products fit 24 bits (8,323,072 < 2^23)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) sumi[g][i] += mul24(sca, sa[i]) + mul24(scb, sb2[i]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NCG; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float dy = *reinterpret_cast<const float *>(slab + g * (XS + MS) + XS + (4 * grp + i) * 32 + 16);
+                acc[g][i] += (dw * dy) * (float)sumi[g][i];
+            }
+    }
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int g = 0; g < NCG; g++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) red[((wave * NCG + g) * 4 + i) * 64 + lane] = acc[g][i];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int g = 0; g < NCG; g++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; w++) s += red[((w * NCG + g) * 4 + i) * 64 + lane];
+                const int b = g * 16 + 4 * grp + i, m = m0 + col;
+                if (b < a.B && m < a.M) a.Y[(int64_t)b * a.y_row + m] = epilogue_apply(a.epi, s, m, b);
+            }
+    }
+}
+
 bool cdna4_mmq_supported(int type, int64_t M, int64_t K, int64_t B) {
-    return (type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q4_0 || type == CDNA4_Q8_0) && M > 0 && K >= 256 && K % 256 == 0 && B >= 2 && B <= 64;
+    if (type == CDNA4_Q6_K && B > 32) return false;                   // (its three- and four-group forms spill: two accumulator sets per block pair)
+    return (type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K || type == CDNA4_Q4_0 || type == CDNA4_Q8_0) && M > 0 && K >= 256 && K % 256 == 0 && B >= 2 && B <= 64;
 }
 template <int TYPE>
 static void launch_q80act(const mmq_args &a, int ncg, dim3 grid, hipStream_t st) {
@@ -322,7 +467,7 @@ static void launch_q80act(const mmq_args &a, int ncg, dim3 grid, hipStream_t st)
 // a.qs / a.d / a.bsums: the Q8_K (Q4_K) or Q8_0 (Q4_0 / Q8_0) workspace ggml_cdna4_prepare_act fills (path GEMV)
 int cdna4_launch_mmq(const cdna4_gemv_args &g, hipStream_t st) {
     if (!cdna4_mmq_supported(g.type, g.M, g.K, g.ncol) || g.ids) return cdna4_set_error_msg("mmq: unsupported type / shape");
-    if (((uintptr_t)g.W | (uintptr_t)g.w_row_bytes) & 15) return cdna4_set_error_msg("mmq: weight rows must be 16-byte aligned");
+    if (((uintptr_t)g.W | (uintptr_t)g.w_row_bytes) & (g.type == CDNA4_Q6_K ? 1 : 15)) return cdna4_set_error_msg("mmq: weight rows must be 16-byte aligned (Q6_K: 2-byte)");
     if (((uintptr_t)g.qs | (uintptr_t)g.d) & 15) return cdna4_set_error_msg("mmq: quantized activations must be 16-byte aligned");
     if ((g.type == CDNA4_Q4_K || g.type == CDNA4_Q5_K) && ((uintptr_t)g.bsums & 15)) return cdna4_set_error_msg("mmq: quantized activations must be 16-byte aligned");
     mmq_args a{};
@@ -332,6 +477,10 @@ int cdna4_launch_mmq(const cdna4_gemv_args &g, hipStream_t st) {
     const int ncg = (g.ncol + 15) / 16;
     if (g.type == CDNA4_Q4_0) launch_q80act<CDNA4_Q4_0>(a, ncg, grid, st);
     else if (g.type == CDNA4_Q8_0) launch_q80act<CDNA4_Q8_0>(a, ncg, grid, st);
+    else if (g.type == CDNA4_Q6_K) {
+        if (ncg == 1) hipLaunchKernelGGL((k_mmq_q6_K<1, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_mmq_q6_K<2, 8>), grid, dim3(512), 0, st, a);
+    }
     else if (g.type == CDNA4_Q5_K) {
         if (ncg == 1) hipLaunchKernelGGL((k_mmq_q4_K<1, 8, true>), grid, dim3(512), 0, st, a);
         else if (ncg == 2) hipLaunchKernelGGL((k_mmq_q4_K<2, 8, true>), grid, dim3(512), 0, st, a);

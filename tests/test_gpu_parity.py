@@ -366,7 +366,7 @@ def test_full_size_prefill_config(gu, m, k, b):
     assert R.rel_l2(ysh, y) < 2e-6
 
 
-@pytest.mark.parametrize("name,t", [("q4_K", R.Q4_K), ("q5_K", R.Q5_K), ("q4_0", R.Q4_0), ("q8_0", R.Q8_0)])
+@pytest.mark.parametrize("name,t", [("q4_K", R.Q4_K), ("q5_K", R.Q5_K), ("q6_K", R.Q6_K), ("q4_0", R.Q4_0), ("q8_0", R.Q8_0)])
 @pytest.mark.parametrize("m,k,b", [(48, 1024, 2), (100, 512, 5), (512, 2048, 8), (37, 768, 9), (256, 4096, 16), (130, 1024, 17), (64, 2304, 33), (3072, 768, 64), (4096, 4096, 64),
                                    (4096, 14336, 8), (4096, 14336, 40)])
 def test_small_batches_on_the_int8_matrix_cores(gu, name, t, m, k, b):
@@ -386,7 +386,7 @@ def test_small_batches_on_the_int8_matrix_cores(gu, name, t, m, k, b):
     rs = R.row_size(t, k)
     wsub = np.concatenate([w[r * rs:(r + 1) * rs] for r in rows])
     e = R.rel_l2(y[:, rows], R.o_mul_mat(t, wsub, x, len(rows), k)); gu.report(test="mmq_i8", type=name, m=m, k=k, b=b, rel_l2=e)
-    int8_route = b <= 32 or m * k <= (1 << 24)                         # capi.hip: use_mmq (GEMV or int8 MFMA up to 32 rows, 64 over small matrices; above that the fp16 GEMM)
+    int8_route = b <= 32 or (m * k <= (1 << 24) and t != R.Q6_K)      # capi.hip: use_mmq (GEMV or int8 MFMA up to 32 rows, 64 over small matrices — Q6_K: 32 —; above that the fp16 GEMM)
     assert e < (TOL_GEMV if int8_route else TOL_GEMM)
     assert np.array_equal(y, ops.mul_mat(a, xd).cpu().numpy())
     if b <= 16:
