@@ -405,12 +405,33 @@ def widening_rows(dev, steps):
         row = {"us_per_call": round(us, 2)}
         if n_q > 32:
             tf = 4.0 * nh * n_q * n_kv * hs / us / 1e6
-            row.update(tflops=round(tf, 1), frac_of_mfma_roof=round(tf / MFMA_F16_PEAK_TFLOPS, 4), kernel="k_flash_attn_wide<128>" if (n_q + 127) // 128 * nh >= 256 else "k_flash_attn_split<128>")
+            row.update(tflops=round(tf, 1), frac_of_mfma_roof=round(tf / MFMA_F16_PEAK_TFLOPS, 4), kernel="k_flash_attn_wide64<128>" if (n_q + 127) // 128 * nh >= 256 else "k_flash_attn_split<128>")
         else:
             gb = 4.0 * nh * n_kv * hs / us / 1e3
             row.update(kv_GBps=round(gb, 1), frac_of_hbm_roof=round(gb / HBM_PEAK_GBS, 4), kernel="k_flash_attn_split<128> + k_flash_attn_merge<128>")
         out["flash_attn_ext"]["hs128_h32_q%d_kv%d" % (n_q, n_kv)] = row
         leg_row("flash_attn_ext", "hs128_h32_q%d_kv%d" % (n_q, n_kv), row)
+    # decode over a QUANTIZED KV cache (Q8_0 / Q4_0 rows read by the key-split kernel's dequantizing operand loads): against the HBM roof on the
+    # cache bytes actually read (34 / 18 bytes per 32 elements, K + V once)
+    def block_rows(bb, nrows):                                        # random block rows: fp16 d = 1/64 in front of bb - 2 random quant bytes per 32 elements
+        a = rng.integers(0, 256, (nrows, hs // 32, bb), dtype=np.uint8)
+        a[:, :, 0:2] = np.frombuffer(np.float16(1.0 / 64).tobytes(), dtype=np.uint8)
+        return a.reshape(nrows, hs // 32 * bb)
+    for tname, t, bb in (("q8_0", 8, 34), ("q4_0", 2, 18)):
+        n_q, n_kv = 1, 32768
+        rb = hs // 32 * bb
+        q = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_q, hs)).astype(np.float32)).to(dev)
+        kk = torch.from_numpy(block_rows(bb, nh * n_kv).reshape(1, nh, n_kv, rb)).to(dev)
+        vv = torch.from_numpy(block_rows(bb, nh * n_kv).reshape(1, nh, n_kv, rb)).to(dev)
+        mk = torch.from_numpy(rng.uniform(-1, 1, (64, n_kv)).astype(np.float16)).to(dev)
+        sc = float(1.0 / np.sqrt(hs))
+        ops.flash_attn_ext(q, kk, vv, mk, sc, kv_type=t)
+        us = events_us(lambda: ops.flash_attn_ext(q, kk, vv, mk, sc, kv_type=t), max(20, steps // 4), 5)
+        gb = 2.0 * nh * n_kv * rb / us / 1e3
+        row = {"us_per_call": round(us, 2), "cache_GBps": round(gb, 1), "frac_of_hbm_roof": round(gb / HBM_PEAK_GBS, 4), "kernel": "k_flash_attn_split<128, %s> + k_flash_attn_merge<128>" % tname,
+               "note": "includes python's share of a call (a few us)"}
+        out["flash_attn_ext"]["hs128_h32_q1_kv32768_%s_cache" % tname] = row
+        leg_row("flash_attn_ext", "hs128_h32_q1_kv32768_%s_cache" % tname, row)
     for t in (20, 23, 3, 7):               # IQ4_NL / IQ4_XS / Q4_1 / Q5_1: no hardware session of their own before this run (tests/test_gpu_widening.py) — last
         fmt(t)
     return out
