@@ -136,7 +136,14 @@ __device__ __forceinline__ u32x2 fa_ld8_a2(const char *p) {
 }
 template <int KVT> __device__ __forceinline__ half8_t fa_kv_frag(const char *row, int e0) {
     if constexpr (KVT == CDNA4_F16) return *reinterpret_cast<const half8_t *>(row + 2 * e0);
-    else {
+    else if constexpr (KVT == CDNA4_BF16) {                                 // bf16 -> fp32 (the 16 bits are the upper half) -> fp16: what k_q_to_f16_dense<BF16> writes
+        const u32x4 w = *reinterpret_cast<const u32x4 *>(row + 2 * e0);
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+        half8_t out;
+#pragma unroll
+        for (int j = 0; j < 8; j++) out[j] = (half_t)opaque_f32(__builtin_bit_cast(float, (ww[j >> 1] >> (16 * (j & 1))) << 16));
+        return out;
+    } else {
         constexpr int BB = KVT == CDNA4_Q8_0 ? 34 : 18;
         const char *blk = row + (e0 >> 5) * BB;
         const float d = (float)*reinterpret_cast<const half_t *>(blk);
@@ -559,10 +566,10 @@ extern "C" int ggml_cdna4_op_flash_attn_ext(const T4 *q, const T4 *k, const T4 *
     NEED(D > 0 && D <= 256, "flash_attn_ext: head size must be 1..256");
     const bool pad = !fa_kernel_head_size(D);
     if (!pad && k->type == CDNA4_F16 && v->type == CDNA4_F16) return fa_f16(q, k, v, mask, d, scale, max_bias, logit_softcap, stream);
-    // a Q8_0 / Q4_0 cache under the key-split kernel (decode, small batches): dequantized in the operand loads, no fp16 copy (fa_kv_frag)
-    if (!pad && k->type == v->type && (k->type == CDNA4_Q8_0 || k->type == CDNA4_Q4_0) && q->ne[1] > 0 && q->ne[2] > 0 && q->ne[3] > 0 &&
+    // a Q8_0 / Q4_0 / BF16 cache under the key-split kernel (decode, small batches): converted in the operand loads, no fp16 copy (fa_kv_frag)
+    if (!pad && k->type == v->type && (k->type == CDNA4_Q8_0 || k->type == CDNA4_Q4_0 || k->type == CDNA4_BF16) && q->ne[1] > 0 && q->ne[2] > 0 && q->ne[3] > 0 &&
         !fa_takes_wide(q->ne[1], q->ne[2], q->ne[3]) && !getenv("CDNA4_FA_KV_COPY") &&
-        !(((uintptr_t)k->data | (uintptr_t)v->data | (uintptr_t)k->nb[1] | (uintptr_t)k->nb[2] | (uintptr_t)k->nb[3] | (uintptr_t)v->nb[1] | (uintptr_t)v->nb[2] | (uintptr_t)v->nb[3]) & 3))
+        !(((uintptr_t)k->data | (uintptr_t)v->data | (uintptr_t)k->nb[1] | (uintptr_t)k->nb[2] | (uintptr_t)k->nb[3] | (uintptr_t)v->nb[1] | (uintptr_t)v->nb[2] | (uintptr_t)v->nb[3]) & (k->type == CDNA4_BF16 ? 15 : 3)))
         return fa_f16(q, k, v, mask, d, scale, max_bias, logit_softcap, stream);
     hipStream_t st = (hipStream_t)stream;
     T4 kv[2] = {*k, *v}, qq = *q, dd = *d;
@@ -605,7 +612,7 @@ extern "C" int ggml_cdna4_op_flash_attn_ext(const T4 *q, const T4 *k, const T4 *
 static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T4 *d, float scale, float max_bias, float logit_softcap, void *stream) {
     const int kvt = k->type;                                      // F16, or Q8_0 / Q4_0 (key-split kernel only: ggml_cdna4_op_flash_attn_ext decides)
     const bool kvq = kvt == CDNA4_Q8_0 || kvt == CDNA4_Q4_0;
-    NEED(q->type == CDNA4_F32 && d->type == CDNA4_F32 && v->type == kvt && (kvt == CDNA4_F16 || kvq), "flash_attn_ext: F32 q / dst and F16 k / v only");
+    NEED(q->type == CDNA4_F32 && d->type == CDNA4_F32 && v->type == kvt && (kvt == CDNA4_F16 || kvt == CDNA4_BF16 || kvq), "flash_attn_ext: F32 q / dst and F16 k / v only");
     const int64_t D = q->ne[0], N = q->ne[1], H = q->ne[2], B3 = q->ne[3], KV = k->ne[1];
     NEED(fa_kernel_head_size(D), "flash_attn_ext: head size must be 64, 128 or 256");
     NEED(k->ne[0] == D && v->ne[0] == D && v->ne[1] == KV && k->ne[2] == v->ne[2] && k->ne[3] == v->ne[3], "flash_attn_ext: k / v shape mismatch");
@@ -640,7 +647,7 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
     p.mask_vec = mask && !(((uintptr_t)mask->data | (uintptr_t)mask->nb[1]) & 15);
     const int64_t cus = cdna4_gemm_cu_count();
     if (fa_takes_wide(N, H, B3)) {                                 // prefill that fills the chip: 128 query rows per work-group, K / V staged through LDS
-        NEED(!kvq, "flash_attn_ext: the 128-row kernels take an F16 K / V");
+        NEED(kvt == CDNA4_F16, "flash_attn_ext: the 128-row kernels take an F16 K / V");
         const dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B3);
         static const bool chunks32 = getenv("CDNA4_FA_WIDE32") != nullptr;      // A/B knob: the 32-key-chunk kernel for every head size
         if (D == 64 && !chunks32) hipLaunchKernelGGL(k_flash_attn_wide64<64>, grid, dim3(256), 0, st, p);
@@ -667,7 +674,7 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
 #define FA_SPLIT(T) do { if (D == 64) hipLaunchKernelGGL((k_flash_attn_split<64, T>), grid, dim3(256), 0, st, p); \
                          else if (D == 128) hipLaunchKernelGGL((k_flash_attn_split<128, T>), grid, dim3(256), 0, st, p); \
                          else hipLaunchKernelGGL((k_flash_attn_split<256, T>), grid, dim3(256), 0, st, p); } while (0)
-    if (kvt == CDNA4_Q8_0) FA_SPLIT(CDNA4_Q8_0); else if (kvt == CDNA4_Q4_0) FA_SPLIT(CDNA4_Q4_0); else FA_SPLIT(CDNA4_F16);
+    if (kvt == CDNA4_Q8_0) FA_SPLIT(CDNA4_Q8_0); else if (kvt == CDNA4_Q4_0) FA_SPLIT(CDNA4_Q4_0); else if (kvt == CDNA4_BF16) FA_SPLIT(CDNA4_BF16); else FA_SPLIT(CDNA4_F16);
 #undef FA_SPLIT
     CDNA4_CHECK_LAUNCH();
     if (p.nsplit > 1) {
