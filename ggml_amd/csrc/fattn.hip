@@ -548,7 +548,11 @@ extern "C" int ggml_cdna4_op_flash_attn_ext_supported(int64_t head_size, int kv_
 
 static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T4 *d, float scale, float max_bias, float logit_softcap, void *stream);
 // prefill that fills the chip takes the 128-row kernels (K / V staged through LDS as fp16), everything else the key-split kernel
-static bool fa_takes_wide(int64_t N, int64_t H, int64_t B3) { return N > 32 && ((N + 127) / 128) * H * B3 >= cdna4_gemm_cu_count(); }
+// (CDNA4_FA_WIDE_MIN: measurement knob — the smallest number of 128-row work-groups that takes them; default: one per CU)
+static bool fa_takes_wide(int64_t N, int64_t H, int64_t B3) {
+    static const int64_t min_wgs = getenv("CDNA4_FA_WIDE_MIN") ? atoll(getenv("CDNA4_FA_WIDE_MIN")) : 0;
+    return N > 32 && ((N + 127) / 128) * H * B3 >= (min_wgs > 0 ? min_wgs : (int64_t)cdna4_gemm_cu_count());
+}
 
 // A BF16 K / V takes the same route (bf16 -> fp16: exact for |x| in [2^-14, 65504], the range a KV cache lives in; the CPU rounds q to bf16 instead,
 // ggml-cpu.c:10929 with vec_dot_type BF16 — eight bits of mantissa — so ours is again the more accurate side).
