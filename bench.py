@@ -450,7 +450,7 @@ def stock_perf_lines(timeout=150):
             txt = r.stdout
         except subprocess.TimeoutExpired as e:
             txt = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
-        return [ln.strip() for ln in txt.splitlines() if "type_a=q4_K" in ln and "not supported" not in ln][:8]
+        return [ln.strip() for ln in txt.splitlines() if "type_a=q4_K" in ln and "not supported" not in ln and "us/run" in ln][:8]      # (a line cut off by the time budget has no figures)
     out = {"command": "GGML_BACKEND_PATH=libggml-cdna4.so test-backend-ops perf -o MUL_MAT -b CDNA40 | -b CPU  (unmodified binary; its q4_K lines, m = 4096, k = 14336)",
            "q4_K": run("CDNA40", timeout, dict(os.environ, GGML_BACKEND_PATH=plugin))}
     # the same harness on the reference CPU backend of this box (all host cores, the harness's default): as many q4_K lines as fit the budget
