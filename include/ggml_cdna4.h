@@ -213,10 +213,12 @@ int ggml_cdna4_op_rope(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor *
  * q F32 [head_size, n_q, n_head, batch] (any row strides), k / v F16 [head_size, n_kv, n_head_kv, batch_kv] (rows 16-byte aligned; heads and
  * batches broadcast as q's over k's), mask F16 [n_kv, >= n_q] or NULL, dst F32 contiguous [head_size, n_head, n_q, batch].
  * scale / max_bias (ALiBi) / logit_softcap as in op_params 0..2.  fp16 operands on the matrix cores, fp32 softmax statistics and
- * accumulation.  k / v may also be block-quantized (Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0: a quantized KV cache; rows contiguous, any strides): they are
- * written out as fp16 into library scratch first (one pass), then the same kernels run.  Head sizes other than 64 / 128 / 256 (80, 96, 112, ...; up
- * to 256) run zero-padded to the next of them through padded copies of q / k / v and of the result.  _supported: head size 1..256 with F16 k / v,
- * a multiple of 32 with quantized k / v. */
+ * accumulation.  k / v may also be BF16 (type 30) or block-quantized (Q4_0 / Q4_1 / Q5_0 / Q5_1 / Q8_0: a quantized KV cache; rows contiguous, any
+ * strides).  Decode-sized calls (the key-split kernel: up to 32 query rows, or a grid of 128-row tiles that would not fill the chip) read a
+ * Q8_0 / Q4_0 / BF16 cache DIRECTLY — fp16(to_float(element)) in the operand loads, k and v of the same type, rows 4-byte (BF16: 16-byte) aligned;
+ * everything else is written out as fp16 into library scratch first (one pass), then the same kernels run: bit-identical either way.  Head sizes
+ * other than 64 / 128 / 256 (80, 96, 112, ...; up to 256) run zero-padded to the next of them through padded copies of q / k / v and of the result.
+ * _supported: head size 1..256 with F16 / BF16 k / v, a multiple of 32 with quantized k / v. */
 int ggml_cdna4_op_flash_attn_ext_supported(int64_t head_size, int kv_type);
 int ggml_cdna4_op_flash_attn_ext(const ggml_cdna4_tensor * q, const ggml_cdna4_tensor * k, const ggml_cdna4_tensor * v, const ggml_cdna4_tensor * mask,
                                  const ggml_cdna4_tensor * dst, float scale, float max_bias, float logit_softcap, void * stream);
