@@ -33,3 +33,26 @@ def test_selected_gpu_tests_pass_on_the_emulator():
     import re
     m = re.search(r"(\d+) passed", r.stdout)
     assert m and int(m.group(1)) >= 30, tail
+
+
+# round 3's routes (int8 matrix-core kernel for the five formats, Q5_0 / IQ4_NL following their Q8_0 target onto it, BF16 and directly read Q8_0 / Q4_0
+# K / V under FLASH_ATTN_EXT): the small cases of their GPU tests — each asserts bit-identity between two routes, which is host logic as much as kernel
+SELECTION_R3 = [("test_gpu_parity.py", "test_small_batches_on_the_int8_matrix_cores and (37-768-9 or 130-1024-17 or 100-512-5)", 15),
+                ("test_gpu_widening.py", "(test_more_formats_prefill_gemm and (16-256-9 or 130-768-33)) or test_iq4_nl_reencoding_is_exact_and_public "
+                                         "or (test_flash_attn_ext_bf16_kv and (64-35 or 80-5)) or (test_flash_attn_ext_quantized_kv and 64-35 and (q8_0 or q4_0))", 9)]
+
+
+@pytest.mark.parametrize("fname,sel,at_least", SELECTION_R3)
+def test_round3_routes_pass_on_the_emulator(fname, sel, at_least):
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    env = dict(os.environ, CDNA4_TESTS_ON_EMULATOR="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", fname), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", sel],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    tail = (r.stdout + r.stderr)[-3000:]
+    if "cannot host the emulation" in tail:
+        pytest.skip("the environment cannot host the emulation")
+    assert r.returncode == 0, tail
+    import re
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= at_least, tail
