@@ -37,9 +37,9 @@ def test_selected_gpu_tests_pass_on_the_emulator():
 
 # round 3's routes (int8 matrix-core kernel for the five formats, Q5_0 / IQ4_NL following their Q8_0 target onto it, BF16 and directly read Q8_0 / Q4_0
 # K / V under FLASH_ATTN_EXT): the small cases of their GPU tests — each asserts bit-identity between two routes, which is host logic as much as kernel
-SELECTION_R3 = [("test_gpu_parity.py", "test_small_batches_on_the_int8_matrix_cores and (37-768-9 or 130-1024-17 or 100-512-5)", 15),
-                ("test_gpu_widening.py", "(test_more_formats_prefill_gemm and (16-256-9 or 130-768-33)) or test_iq4_nl_reencoding_is_exact_and_public "
-                                         "or (test_flash_attn_ext_bf16_kv and (64-35 or 80-5)) or (test_flash_attn_ext_quantized_kv and 64-35 and (q8_0 or q4_0))", 9)]
+SELECTION_R3 = [("test_gpu_parity.py", "test_small_batches_on_the_int8_matrix_cores and (37-768-9 or 100-512-5)", 10),
+                ("test_gpu_widening.py", "(test_more_formats_prefill_gemm and 16-256-9) or test_iq4_nl_reencoding_is_exact_and_public "
+                                         "or (test_flash_attn_ext_bf16_kv and 64-35) or (test_flash_attn_ext_quantized_kv and 64-35 and q8_0)", 5)]
 
 
 @pytest.mark.parametrize("fname,sel,at_least", SELECTION_R3)
