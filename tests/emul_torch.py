@@ -35,6 +35,10 @@ def activate():
     global _so
     if _so is not None:
         return
+    # never on a box with a GPU: the emulation is a lint for sessions without hardware, not a substitute for it — with a device
+    # present the -m gpu tests must run the product's library on it
+    if torch.cuda.is_available():
+        raise RuntimeError("CDNA4_TESTS_ON_EMULATOR is refused on a box with a GPU: run the tests on the device")
     sys.path.insert(0, os.path.join(ROOT, "tools", "emul"))
     import lib_emul_check
     from ggml_amd import native
