@@ -23,6 +23,9 @@ SELECTION = ("(test_q4_1_q5_1_iq4_nl_gemv_parity and (16-256-1 or 20-544-7 or 48
 def test_selected_gpu_tests_pass_on_the_emulator():
     if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
         pytest.skip("ROCm clang not available")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the -m gpu tests run on it, the emulation is refused (tests/emul_torch.py)")
     env = dict(os.environ, CDNA4_TESTS_ON_EMULATOR="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_widening.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", SELECTION],
                        capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
@@ -46,6 +49,9 @@ SELECTION_R3 = [("test_gpu_parity.py", "test_small_batches_on_the_int8_matrix_co
 def test_round3_routes_pass_on_the_emulator(fname, sel, at_least):
     if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
         pytest.skip("ROCm clang not available")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the -m gpu tests run on it, the emulation is refused (tests/emul_torch.py)")
     env = dict(os.environ, CDNA4_TESTS_ON_EMULATOR="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", fname), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", sel],
                        capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
