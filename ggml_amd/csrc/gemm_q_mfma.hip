@@ -23,6 +23,7 @@
 //    k_repack_*      16-byte-aligned re-layout of Q4_0 / Q8_0 / Q6_K into scratch (shallow-K fallback of the staged path)
 #include "gemm_q_common.h"
 #include <atomic>
+#include <mutex>
 #include "gemm_q_hw.h"
 #include "quantize_dev.h"
 
@@ -412,12 +413,14 @@ static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
 // (one region per device; launches that use it are assumed to be stream-ordered on that device, as the plug-in's
 // single-stream backend and the one-process-per-GPU bench are).
 static void *g_scratch[144] = {nullptr}; static size_t g_scratch_bytes[144] = {0};
+static std::mutex g_scratch_mu;                                     // the bookkeeping below, against host threads driving different devices; USE of an area stays stream-ordered per device
 static std::atomic<uint64_t> g_scratch_generation{0};
 uint64_t cdna4_scratch_generation() { return g_scratch_generation.load(); }
 static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: split-K exchange buffers, 1: repacked weights, 2: exchange buffers of gemm_q_t64.hip (reader-reset flags), 3: re-encoded weights (convert_w.hip), 4: partial results of the key-split FLASH_ATTN_EXT (fattn.hip), 5 / 6: fp16 copies of a quantized (or head-size-padded) K / V in front of FLASH_ATTN_EXT, 7 / 8: its padded q / dst
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
     dev += 16 * kind;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
     if (bytes <= g_scratch_bytes[dev]) return g_scratch[dev];
     g_scratch_generation++;                                          // captured launches hold the old address: see ggml_cdna4_scratch_generation()
     (void)hipDeviceSynchronize();
