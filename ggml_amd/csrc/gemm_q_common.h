@@ -493,3 +493,5 @@ template <> struct WStage<CDNA4_Q6_KS, 2> { static constexpr int NPH = 9; __devi
 void *cdna4_gemm_scratch(size_t bytes, int kind);      // per-device scratch, zero-filled when (re)allocated; kind 0: split-K exchange, 1: repacked weights
 int cdna4_gemm_cu_count();
 int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st);     // gemm_q_t64.hip: 64(m) x 128(b) wave tiles; tm 0 / 128 / 256, splitk 0 / 1 / 2
+bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a);                                     // gemm_q_lds.hip: weights dequantized into fp16 LDS tiles, 256-wide activation tile
+int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st);     //   tm 0 / 128 / 256, splitk 0 = choose

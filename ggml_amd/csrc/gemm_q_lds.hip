@@ -1,0 +1,56 @@
+// gemm_q_lds.hip — launcher of k_gemm_lds (gemm_lds.inc): the prefill GEMM that dequantizes the weights once per 256-wide activation tile into
+// fp16 LDS tiles and feeds them to a format-agnostic MFMA consumer loop.  Replaces, at B > 8, what ggml_compute_forward_mul_mat does after the
+// activations are quantized (/root/reference/src/ggml-cpu/ggml-cpu.c:7510-7605).
+#include "gemm_q_common.h"
+#include "gemm_q_hw.h"
+#include "gemm_lds.inc"
+
+bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a) {
+    if (a.type != CDNA4_Q4_K) return false;
+    if (a.M <= 0 || a.B <= 0 || a.K % 256 || a.K < 256) return false;
+    if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) || ((uintptr_t)a.xh & 15)) return false;
+    return true;
+}
+
+// tile rows (0 = choose; 128 / 256) and split-K (0 = choose) -> launch.  Returns 0, or a negative status with the error text set.
+int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st) {
+    if (!cdna4_gemm_lds_supported(a)) return cdna4_set_error_msg("gemm_lds: Q4_K on 16-byte-aligned rows, whole superblocks");
+    const int cus = cdna4_gemm_cu_count(), nsb = a.K / 256;
+    const int tiles_b = (a.B + 255) / 256;
+    if (tm <= 0) tm = (((a.M + 255) / 256) * tiles_b >= cus) ? 256 : 128;
+    if (tm != 128 && tm != 256) return cdna4_set_error_msg("gemm_lds: tile rows are 128 or 256");
+    const int tiles_m = (a.M + tm - 1) / tm, ntiles = tiles_m * tiles_b;
+    // split-K: S co-resident work-groups per tile reduce-scatter their partial tiles (gemm_lds.inc, epilogue (2)); needs every work-group resident
+    // (one per CU) and S to divide the 4 / 8 accumulator fragments of a wave.  Deterministic (fixed summation order).
+    const int nfr = tm == 256 ? 8 : 4;
+    if (splitk <= 0) {
+        splitk = 1;
+        for (int s = 2; s <= nfr; s *= 2) if (ntiles * s <= cus && nsb >= 2 * s) splitk = s;
+    }
+    if (splitk < 1 || nfr % splitk || (splitk > 1 && ntiles * splitk > cus) || nsb < splitk) return cdna4_set_error_msg("gemm_lds: split-K must divide the wave's fragments, leave a superblock per work-group and keep every work-group resident");
+    gemm_params p{};
+    p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
+    p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
+    p.tiles_m = tiles_m; p.tiles_b = tiles_b;
+    p.epi = a.epi;
+    if (splitk > 1) {
+        // counters [tile][arrivals, departures] in a fixed 64-KB area, slots [tile][dst][src][wave][fragment] x 4 KB behind it; scratch kind 9 (this kernel's own)
+        const size_t pbytes = (size_t)ntiles * splitk * splitk * 8 * (nfr / splitk) * 4096, fbytes = 65536;
+        if ((size_t)ntiles * 2 > 16384) return cdna4_set_error_msg("gemm_lds: too many tiles for the split-K counter area");
+        char *sc = (char *)cdna4_gemm_scratch(fbytes + pbytes, 9);
+        if (!sc) return cdna4_set_error_msg("gemm_lds: cannot allocate split-K scratch");
+        p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
+    }
+    const dim3 grid(ntiles * splitk);
+#ifdef CDNA4_ABLATIONS
+    p.trace = (unsigned long long *)cdna4_debug_trace;
+    const int abl = (a.variant >> 16) & 0xFFF;
+#define LDS_ABL(A) if (abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 128, false, (A)>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 256, false, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
+    LDS_ABL(1) LDS_ABL(2) LDS_ABL(3) LDS_ABL(4) LDS_ABL(8) LDS_ABL(16) LDS_ABL(32) LDS_ABL(64) LDS_ABL(15) LDS_ABL(256)
+    if (abl) return cdna4_set_error_msg("gemm_lds: ablation not instantiated");
+#endif
+    if (tm == 128) hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 128>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 256>), grid, dim3(512), 0, st, p);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}

@@ -412,11 +412,11 @@ static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
 // library-owned scratch for the split-K hand-off (partial tiles + flags), grown on demand like a BLAS workspace
 // (one region per device; launches that use it are assumed to be stream-ordered on that device, as the plug-in's
 // single-stream backend and the one-process-per-GPU bench are).
-static void *g_scratch[144] = {nullptr}; static size_t g_scratch_bytes[144] = {0};
+static void *g_scratch[160] = {nullptr}; static size_t g_scratch_bytes[160] = {0};
 static std::mutex g_scratch_mu;                                     // the bookkeeping below, against host threads driving different devices; USE of an area stays stream-ordered per device
 static std::atomic<uint64_t> g_scratch_generation{0};
 uint64_t cdna4_scratch_generation() { return g_scratch_generation.load(); }
-static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: split-K exchange buffers, 1: repacked weights, 2: exchange buffers of gemm_q_t64.hip (reader-reset flags), 3: re-encoded weights (convert_w.hip), 4: partial results of the key-split FLASH_ATTN_EXT (fattn.hip), 5 / 6: fp16 copies of a quantized (or head-size-padded) K / V in front of FLASH_ATTN_EXT, 7 / 8: its padded q / dst
+static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: split-K exchange buffers, 1: repacked weights, 2: exchange buffers of gemm_q_t64.hip (reader-reset flags), 3: re-encoded weights (convert_w.hip), 4: partial results of the key-split FLASH_ATTN_EXT (fattn.hip), 5 / 6: fp16 copies of a quantized (or head-size-padded) K / V in front of FLASH_ATTN_EXT, 7 / 8: its padded q / dst, 9: split-K exchange of gemm_q_lds.hip
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
     dev += 16 * kind;
@@ -675,6 +675,8 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
         c.type = CDNA4_Q6_K; c.K = a.K * cdna4_convert_weights_kmul(a.type); c.xh_row_elems = c.K; c.w_row_bytes = (int64_t)(c.K / 256) * 210;
         return launch_type<CDNA4_Q6_K>(c, st);
     }
+    // variant bit 28 = k_gemm_lds (gemm_q_lds.hip); bits 29 / 30 force its 128- / 256-row tile (bits 16-27: ablation mask of -DCDNA4_ABLATIONS builds)
+    if (a.variant > 0 && (a.variant & (1 << 28))) return cdna4_launch_gemm_lds(a, (a.variant & (1 << 29)) ? 128 : ((a.variant & (1 << 30)) ? 256 : 0), a.splitk, st);
     switch (a.type) {
         case CDNA4_Q4_K: return launch_type<CDNA4_Q4_K>(a, st);
         case CDNA4_Q5_K: return launch_type<CDNA4_Q5_K>(a, st);
