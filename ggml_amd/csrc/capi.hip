@@ -88,7 +88,10 @@ size_t ggml_cdna4_mul_mat_id_workspace_size(int type, int64_t K, int64_t n_exper
 }
 
 // the public re-encodings keep the shape (Q2_K's two-part form needs the doubled activation image: library-internal)
-static inline int public_convert_target(int type) { return cdna4_convert_weights_kmul(type) == 1 ? cdna4_convert_weights_target(type) : -1; }
+static inline int public_convert_target(int type) {
+    static const bool any = getenv("CDNA4_DIAG_CONVERT_ANY") && atoi(getenv("CDNA4_DIAG_CONVERT_ANY")) != 0;      // diagnosis only (scripts/gpu_diag_iq4xs2.py): the two-part forms too
+    return (any || cdna4_convert_weights_kmul(type) == 1) ? cdna4_convert_weights_target(type) : -1;
+}
 int ggml_cdna4_convert_weights_target(int type) { return public_convert_target(type); }
 size_t ggml_cdna4_convert_weights_size(int type, int64_t M, int64_t K) {
     if (public_convert_target(type) < 0 || M <= 0 || K <= 0 || ggml_cdna4_row_size(type, K) == 0) return 0;
