@@ -180,6 +180,11 @@ __global__ __launch_bounds__(256) void k_convert_q2_K_q6_K2(const uint8_t *__res
 // parts' dequantize_row_q6_K equals dequantize_row_iq4_xs (src/ggml-quants.c:2454-2475) value for value.  18 threads per superblock as above:
 // threads 0..15 (128-half n = pc >> 3, l = 4 (pc & 7) .. + 3): weight 128 n + 32 j + l is code (l & 15) (low codes for l < 16, high above) of
 // sub-block 4 n + j; thread 16: the sixteen scales of each part (sub-block ib = 16-weight groups 2 ib, 2 ib + 1); thread 17: d.
+// VAR (diagnosis of the round-3 instability, scripts/gpu_diag_iq4xs3.py): 0 = as shipped in round 3; 1 = 16-bit stores only (volatile: never merged into the
+// 2-byte-aligned dword / dwordx4 stores hipcc makes of st32); 2 = codebook from a __constant__ table instead of the 64-bit shift LUT; 4 = every load waited
+// for before the first use; combinations by OR
+__device__ const int8_t k_iq4nl_values[16] = {-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113};
+template <int VAR>
 __global__ __launch_bounds__(256) void k_convert_iq4_xs_q6_K2(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nsb, uint8_t *__restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (int64_t)M * nsb * 18) return;
@@ -187,14 +192,29 @@ __global__ __launch_bounds__(256) void k_convert_iq4_xs_q6_K2(const uint8_t *__r
     const int row = (int)(u / nsb), sb = (int)(u % nsb);
     const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)sb * 136;
     uint8_t *da = out + ((int64_t)row * 2 * nsb + sb) * 210, *db = da + (int64_t)nsb * 210;
-    auto st32 = [](uint8_t *p, uint32_t v) { *reinterpret_cast<uint16_t *>(p) = (uint16_t)v; *reinterpret_cast<uint16_t *>(p + 2) = (uint16_t)(v >> 16); };
+    auto st32 = [](uint8_t *p, uint32_t v) {
+        if constexpr ((VAR & 1) != 0) { *reinterpret_cast<volatile uint16_t *>(p) = (uint16_t)v; *reinterpret_cast<volatile uint16_t *>(p + 2) = (uint16_t)(v >> 16); }
+        else { *reinterpret_cast<uint16_t *>(p) = (uint16_t)v; *reinterpret_cast<uint16_t *>(p + 2) = (uint16_t)(v >> 16); }
+    };
     if (pc < 16) {
         const int n = pc >> 3, l = 4 * (pc & 7);
         uint32_t a[4], b[4];                                             // q6 of the h part / the l part for j = 0..3, one weight per byte
+        uint32_t qq[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) qq[j] = ld_u32_a2(src + 8 + 16 * (4 * n + j) + (l & 15));
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr ((VAR & 4) != 0) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(qq[0]), "+v"(qq[1]), "+v"(qq[2]), "+v"(qq[3])::"memory"); }
+#endif
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t q = ld_u32_a2(src + 8 + 16 * (4 * n + j) + (l & 15));
-            const uint32_t kv = iq4nl_lut4(l < 16 ? (q & 0x0F0F0F0Fu) : ((q >> 4) & 0x0F0F0F0Fu));
+            const uint32_t q = qq[j];
+            const uint32_t codes = l < 16 ? (q & 0x0F0F0F0Fu) : ((q >> 4) & 0x0F0F0F0Fu);
+            uint32_t kv;
+            if constexpr ((VAR & 2) != 0) {
+                kv = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) kv |= (uint32_t)(uint8_t)k_iq4nl_values[(codes >> (8 * e)) & 0xFu] << (8 * e);
+            } else kv = iq4nl_lut4(codes);
             a[j] = ((kv ^ 0x80808080u) >> 2) & 0x3F3F3F3Fu;              // (kv + 128) / 4 = (kv >> 2) + 32
             b[j] = (kv & 0x03030303u) | 0x20202020u;                     // (kv & 3) + 32
         }
@@ -254,7 +274,11 @@ int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes
     } else if (type == CDNA4_IQ4_XS) {
         if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");
         const int64_t n = M * (K / 256) * 18;
-        hipLaunchKernelGGL(k_convert_iq4_xs_q6_K2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out);
+        static const int var = getenv("CDNA4_DIAG_CONV") ? atoi(getenv("CDNA4_DIAG_CONV")) : 0;
+        const dim3 grid((unsigned)((n + 255) / 256));
+#define IQ4XS_CONV(V) case V: hipLaunchKernelGGL(k_convert_iq4_xs_q6_K2<V>, grid, dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out); break;
+        switch (var) { IQ4XS_CONV(1) IQ4XS_CONV(2) IQ4XS_CONV(3) IQ4XS_CONV(4) IQ4XS_CONV(5) IQ4XS_CONV(7) default: hipLaunchKernelGGL(k_convert_iq4_xs_q6_K2<0>, grid, dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out); }
+#undef IQ4XS_CONV
     } else if (type == CDNA4_Q2_K) {
         if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");
         const int64_t n = M * (K / 256) * 18;
