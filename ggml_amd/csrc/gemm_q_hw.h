@@ -14,6 +14,9 @@
 #define CDNA4_WAIT_VM_TIED2(n, a, b) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(n) : "memory")
 #define CDNA4_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define CDNA4_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// the same as an instruction the compiler's own wait-count pass SEES (vmcnt 63, expcnt 7, lgkmcnt 0): behind it hipcc knows every ds_read has returned and
+// inserts no lgkmcnt wait of its own in front of the MFMAs that use fragments requested a phase earlier (k_gemm_lds; it cannot see an asm wait)
+#define CDNA4_WAIT_LGKM0_VISIBLE() do { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); } while (0)
 // the same with only lanes [0, nlanes) active (nlanes = 16 / 32, a literal).  EXEC is narrowed INSIDE the statement: an `if (lane < n)`
 // around CDNA4_DMA16 makes hipcc merge uniform address arithmetic across the divergent join into VGPRs, which the "s" operands reject
 #define CDNA4_DMA16_LANES(voff, sbase, lds_addr, nlanes) do { uint64_t cdna4_exec_;                                                   \

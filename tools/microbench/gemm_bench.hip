@@ -77,11 +77,12 @@ int main(int argc, char **argv) {
             const double cyc = (double)(tr[2] - tr[0]), ref = (double)(tr[3] - tr[1]);
             if (ref > 0) printf("  lds variant %d block 0: %.0f s_memtime ticks in %.2f us (s_memrealtime, 100 MHz) -> %.0f MHz\n", v, cyc, ref / 100.0, cyc / (ref / 100.0));
             printf("  per phase (cycles, mean over periods 8..15): L part | wait at barrier A | M part (8 MFMAs) | wait at barrier B ;  phase length\n");
-            for (int w = 0; w < 8; w++) for (int ph = 0; ph < 4; ph++) {
+            const int nkk = (v & (1 << 29)) ? 2 : 4;                 // phases per K tile: the 128-row form has two
+            for (int w = 0; w < 8; w++) for (int ph = 0; ph < nkk; ph++) {
                 double a[4] = {0, 0, 0, 0}; int n = 0;
                 for (int tt = 0; tt < 8; tt++) {
                     const unsigned long long *q = tr.data() + 16 + ((w * 8 + tt) * 4 + ph) * 4;
-                    const unsigned long long *qn = ph < 3 ? q + 4 : (tt < 7 ? tr.data() + 16 + ((w * 8 + tt + 1) * 4) * 4 : nullptr);
+                    const unsigned long long *qn = ph + 1 < nkk ? q + 4 : (tt < 7 ? tr.data() + 16 + ((w * 8 + tt + 1) * 4) * 4 : nullptr);
                     if (!q[0] || !q[3] || !qn || !qn[0]) continue;
                     a[0] += (double)(q[1] - q[0]); a[1] += (double)(q[2] - q[1]); a[2] += (double)(q[3] - q[2]); a[3] += (double)(qn[0] - q[3]); n++;
                 }
