@@ -224,6 +224,9 @@ __global__ __launch_bounds__(256) void k_convert_iq4_xs_q6_K2(const uint8_t *__r
         st32(db + 64 * n + l, (b[0] & 0x0F0F0F0Fu) | ((b[2] & 0x0F0F0F0Fu) << 4));
         st32(db + 64 * n + 32 + l, (b[1] & 0x0F0F0F0Fu) | ((b[3] & 0x0F0F0F0Fu) << 4));
         st32(db + 128 + 32 * n + l, 0xAAAAAAAAu);                        // bits 4-5 of every l-part q6 are 2
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr ((VAR & 8) != 0) { const uint8_t *keep = src + 8 + 64 * n + (l & 15); asm volatile("" ::"v"(keep)); }      // the loads' address registers stay untouched to the end
+#endif
     } else if (pc == 16) {
         const uint32_t sh = ld_u16(src + 2);
 #pragma unroll
@@ -274,10 +277,10 @@ int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes
     } else if (type == CDNA4_IQ4_XS) {
         if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");
         const int64_t n = M * (K / 256) * 18;
-        static const int var = getenv("CDNA4_DIAG_CONV") ? atoi(getenv("CDNA4_DIAG_CONV")) : 0;
+        static const int var = getenv("CDNA4_DIAG_CONV") ? atoi(getenv("CDNA4_DIAG_CONV")) : 4;      // 4 = the shipped form: every load waited for before its first use
         const dim3 grid((unsigned)((n + 255) / 256));
 #define IQ4XS_CONV(V) case V: hipLaunchKernelGGL(k_convert_iq4_xs_q6_K2<V>, grid, dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out); break;
-        switch (var) { IQ4XS_CONV(1) IQ4XS_CONV(2) IQ4XS_CONV(3) IQ4XS_CONV(4) IQ4XS_CONV(5) IQ4XS_CONV(7) default: hipLaunchKernelGGL(k_convert_iq4_xs_q6_K2<0>, grid, dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out); }
+        switch (var) { IQ4XS_CONV(1) IQ4XS_CONV(2) IQ4XS_CONV(3) IQ4XS_CONV(4) IQ4XS_CONV(5) IQ4XS_CONV(7) IQ4XS_CONV(8) default: hipLaunchKernelGGL(k_convert_iq4_xs_q6_K2<0>, grid, dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out); }
 #undef IQ4XS_CONV
     } else if (type == CDNA4_Q2_K) {
         if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");

@@ -16,6 +16,9 @@
 #define CDNA4_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // the same as an instruction the compiler's own wait-count pass SEES (vmcnt 63, expcnt 7, lgkmcnt 0): behind it hipcc knows every ds_read has returned and
 // inserts no lgkmcnt wait of its own in front of the MFMAs that use fragments requested a phase earlier (k_gemm_lds; it cannot see an asm wait)
+// keeps a 32-bit value materialized HERE: without it hipcc sinks arithmetic whose result is only used behind a later branch or barrier down to that use
+// (seen in k_gemm_lds: the dequantizer pieces meant for the MFMA gaps were moved into the next phase's conditional ds_write block)
+#define CDNA4_PIN(x) asm volatile("" : "+v"(x))
 #define CDNA4_WAIT_LGKM0_VISIBLE() do { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("" ::: "memory"); } while (0)
 // the same with only lanes [0, nlanes) active (nlanes = 16 / 32, a literal).  EXEC is narrowed INSIDE the statement: an `if (lane < n)`
 // around CDNA4_DMA16 makes hipcc merge uniform address arithmetic across the divergent join into VGPRs, which the "s" operands reject
