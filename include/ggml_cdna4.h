@@ -204,6 +204,23 @@ int ggml_cdna4_op_cpy(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * 
 /* MUL_MAT with F32 or F16 weights and F32 activations, any strides / batch broadcast —
  * ggml_compute_forward_mul_mat with vec_dot_f32 / vec_dot_f16 (ggml-cpu.c:7428-7605) */
 int ggml_cdna4_op_mul_mat_f(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * src1, const ggml_cdna4_tensor * dst, void * stream);
+
+/* ---- reference-ORDER forms (ggml_amd/csrc/exact.hip), opt-in through the plug-in's GGML_CDNA4_EXACT=1: the ops of a gpt-2 graph whose fp32 summation order
+ * differs from the CPU backend's by default, computed in the order of the x86-64-v3 (AVX2 + FMA) build of the reference, so that a whole graph reproduces the
+ * CPU backend's logits bit for bit (BASELINE.json configs[3]).  Verification mode: order costs speed.
+ * MUL_MAT, Q4_0 / Q8_0 weights: quantize_row_q8_0 (AVX2 body) + ggml_vec_dot_q4_0_q8_0 / _q8_0_q8_0 with eight lane accumulators and hsum_float_8
+ * (src/ggml-cpu/ggml-cpu-quants.c:778-815, 2005-2028, 3520-3536, 49-55); workspace >= ggml_cdna4_mul_mat_exact_workspace_size, 256-byte aligned */
+int    ggml_cdna4_mul_mat_exact_supported(int type, int64_t K);
+size_t ggml_cdna4_mul_mat_exact_workspace_size(int type, int64_t K, int64_t B);
+int    ggml_cdna4_mul_mat_exact(int type, const void * W, int64_t w_row_bytes, const float * X, int64_t x_row_stride, float * Y, int64_t y_row_stride,
+                                int64_t M, int64_t K, int64_t B, void * workspace, size_t workspace_bytes, void * stream);
+/* MUL_MAT F32 x F32 as ggml_vec_dot_f32 (src/ggml-cpu/ggml-cpu.c:1346-1377, GGML_F32x8_REDUCE :670-688, gcc's leftover loop) */
+int    ggml_cdna4_op_mul_mat_f_exact(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * src1, const ggml_cdna4_tensor * dst, void * stream);
+/* NORM with sequential double sums (ggml_compute_forward_norm_f32, ggml-cpu.c:6929-6978) */
+int    ggml_cdna4_op_norm_exact(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, float eps, void * stream);
+/* SOFT_MAX without mask / ALiBi on contiguous rows: ggml_v_expf per chunk of 8, the chunk sums in the AVX2 shuffle order accumulated in double, glibc's expf
+ * on the tail (ggml_compute_forward_soft_max_f32, ggml-cpu.c:8848-8944, 2041-2092, 1912-1949) */
+int    ggml_cdna4_op_soft_max_exact(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, float scale, void * stream);
 /* rotary embedding, modes NORMAL (0) and NEOX (2), with freq_base/freq_scale/ext_factor(yarn)/attn_factor and
  * optional freq_factors — ggml_compute_forward_rope_f32, ggml-cpu.c:9255-9625 */
 int ggml_cdna4_op_rope(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * pos, const ggml_cdna4_tensor * freq_factors, const ggml_cdna4_tensor * dst,
