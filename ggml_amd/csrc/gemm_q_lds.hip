@@ -4,6 +4,7 @@
 #include "gemm_q_common.h"
 #include "gemm_q_hw.h"
 #include "gemm_lds.inc"
+#include "gemm_w4.inc"
 
 bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a) {
     if (a.type != CDNA4_Q4_K) return false;
@@ -13,7 +14,8 @@ bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a) {
 }
 
 // tile rows (0 = choose; 128 / 256) and split-K (0 = choose) -> launch.  Returns 0, or a negative status with the error text set.
-int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st) {
+// form 0: k_gemm_lds (two waves per SIMD, ping-pong phases); form 1: k_gemm_w4 (one wave per SIMD)
+int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st, int form) {
     if (!cdna4_gemm_lds_supported(a)) return cdna4_set_error_msg("gemm_lds: Q4_K on 16-byte-aligned rows, whole superblocks");
     const int cus = cdna4_gemm_cu_count(), nsb = a.K / 256;
     const int tiles_b = (a.B + 255) / 256;
@@ -22,10 +24,10 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     const int tiles_m = (a.M + tm - 1) / tm, ntiles = tiles_m * tiles_b;
     // split-K: S co-resident work-groups per tile reduce-scatter their partial tiles (gemm_lds.inc, epilogue (2)); needs every work-group resident
     // (one per CU) and S to divide the 4 / 8 accumulator fragments of a wave.  Deterministic (fixed summation order).
-    const int nfr = tm == 256 ? 8 : 4;
+    const int nfr = form == 1 ? (tm == 256 ? 16 : 8) : (tm == 256 ? 8 : 4), nwv = form == 1 ? 4 : 8;
     if (splitk <= 0) {
         splitk = 1;
-        for (int s = 2; s <= nfr; s *= 2) if (ntiles * s <= cus && nsb >= 2 * s) splitk = s;
+        for (int s = 2; s <= 8; s *= 2) if (ntiles * s <= cus && nsb >= 2 * s) splitk = s;
     }
     if (splitk < 1 || nfr % splitk || (splitk > 1 && ntiles * splitk > cus) || nsb < splitk) return cdna4_set_error_msg("gemm_lds: split-K must divide the wave's fragments, leave a superblock per work-group and keep every work-group resident");
     gemm_params p{};
@@ -35,7 +37,7 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     p.epi = a.epi;
     if (splitk > 1) {
         // counters [tile][arrivals, departures] in a fixed 64-KB area, slots [tile][dst][src][wave][fragment] x 4 KB behind it; scratch kind 9 (this kernel's own)
-        const size_t pbytes = (size_t)ntiles * splitk * splitk * 8 * (nfr / splitk) * 4096, fbytes = 65536;
+        const size_t pbytes = (size_t)ntiles * splitk * splitk * nwv * (nfr / splitk) * 4096, fbytes = 65536;
         if ((size_t)ntiles * 2 > 16384) return cdna4_set_error_msg("gemm_lds: too many tiles for the split-K counter area");
         char *sc = (char *)cdna4_gemm_scratch(fbytes + pbytes, 9);
         if (!sc) return cdna4_set_error_msg("gemm_lds: cannot allocate split-K scratch");
@@ -44,11 +46,20 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     const dim3 grid(ntiles * splitk);
 #ifdef CDNA4_ABLATIONS
     p.trace = (unsigned long long *)cdna4_debug_trace;
-    const int abl = (a.variant >> 16) & 0xFFF;
+    const int abl = (a.variant >> 16) & 0x1FF;
+#define W4_ABL(A) if (form == 1 && abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 128, (A)>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 256, (A)>), grid, dim3(256), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
+    W4_ABL(1) W4_ABL(2) W4_ABL(3) W4_ABL(4) W4_ABL(8) W4_ABL(16) W4_ABL(32) W4_ABL(15)
+    if (form == 1 && abl) return cdna4_set_error_msg("gemm_w4: ablation not instantiated");
 #define LDS_ABL(A) if (abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 128, false, (A)>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 256, false, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
     LDS_ABL(1) LDS_ABL(2) LDS_ABL(3) LDS_ABL(4) LDS_ABL(8) LDS_ABL(16) LDS_ABL(32) LDS_ABL(64) LDS_ABL(15) LDS_ABL(256)
     if (abl) return cdna4_set_error_msg("gemm_lds: ablation not instantiated");
 #endif
+    if (form == 1) {
+        if (tm == 128) hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 128>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 256>), grid, dim3(256), 0, st, p);
+        CDNA4_CHECK_LAUNCH();
+        return 0;
+    }
     if (tm == 128) hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 128>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 256>), grid, dim3(512), 0, st, p);
     CDNA4_CHECK_LAUNCH();

@@ -676,7 +676,8 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
         return launch_type<CDNA4_Q6_K>(c, st);
     }
     // variant bit 28 = k_gemm_lds (gemm_q_lds.hip); bits 29 / 30 force its 128- / 256-row tile (bits 16-27: ablation mask of -DCDNA4_ABLATIONS builds)
-    if (a.variant > 0 && (a.variant & (1 << 28))) return cdna4_launch_gemm_lds(a, (a.variant & (1 << 29)) ? 128 : ((a.variant & (1 << 30)) ? 256 : 0), a.splitk, st);
+    // bit 25 with bit 28: its one-wave-per-SIMD form k_gemm_w4
+    if (a.variant > 0 && (a.variant & (1 << 28))) return cdna4_launch_gemm_lds(a, (a.variant & (1 << 29)) ? 128 : ((a.variant & (1 << 30)) ? 256 : 0), a.splitk, st, (a.variant & (1 << 25)) ? 1 : 0);
     switch (a.type) {
         case CDNA4_Q4_K: return launch_type<CDNA4_Q4_K>(a, st);
         case CDNA4_Q5_K: return launch_type<CDNA4_Q5_K>(a, st);

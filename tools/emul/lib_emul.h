@@ -23,6 +23,8 @@
 #define CDNA4_WAIT_VM_TIED2(n, a, b) emu::vm_wait(n)
 #define CDNA4_WAIT_VM(n) emu::vm_wait(n)
 #define CDNA4_WAIT_LGKM0() ((void)0)
+#define CDNA4_WAIT_LGKM0_VISIBLE() ((void)0)
+#define CDNA4_PIN(x) ((void)0)
 #define CDNA4_DMA16_LANES(voff, sbase, lds_addr, nlanes) do { if (lane < (nlanes)) emu::vm_issue(smem + (lds_addr) + 16 * lane, (sbase) + (voff)); else emu::vm_issue_done(); } while (0)
 #define CDNA4_SWAP32(a, b) do { emu::WaveState &w_ = emu::my_wave(); const int l_ = emu::t_threadIdx.x & 63; const uint32_t a_ = (a), b_ = (b); \
     w_.xch[l_] = l_ < 32 ? b_ : a_; pthread_barrier_wait(&w_.bar); const uint32_t o_ = w_.xch[l_ ^ 32]; pthread_barrier_wait(&w_.bar); \
