@@ -174,3 +174,21 @@ def mul_mat_tail(wtype, w_bytes, m, k, x, bias, gelu, resid, n_threads=8):
         if resid is not None:
             t = r.base.ggml_add(r.ctx, t, r.tensor(R.F32, [m, b], resid.astype(np.float32)))
         return r.read(r.compute(t, n_threads), R.F32, (b, m))
+
+
+def mul_mat(wtype, w_bytes, m, k, x, n_threads=8):
+    """ggml_mul_mat(W [k, m] of wtype, x [k, b] f32) on the reference CPU backend -> (b, m) f32 (w_bytes: raw block bytes, or f32 / f16 values)"""
+    b = x.shape[0]
+    with Ref(mem=(1 << 28) + int(np.asarray(w_bytes).nbytes) + 16 * b * (m + k)) as r:
+        tw = r.tensor(wtype, [k, m], w_bytes)
+        tx = r.tensor(R.F32, [k, b], x.astype(np.float32))
+        return r.read(r.compute(r.base.ggml_mul_mat(r.ctx, tw, tx), n_threads), R.F32, (b, m))
+
+
+def mul_mat_f32_batched(a, b, n_threads=4):
+    """ggml_mul_mat of two f32 tensors with batch dims: a (n3a, n2a, m, k), b (n3, n2, n, k) numpy (slowest first) -> (n3, n2, n, m)"""
+    with Ref() as r:
+        ta = r.tensor(R.F32, list(reversed(a.shape)), a.astype(np.float32))
+        tb = r.tensor(R.F32, list(reversed(b.shape)), b.astype(np.float32))
+        t = r.compute(r.base.ggml_mul_mat(r.ctx, ta, tb), n_threads)
+        return r.read(t, R.F32, (b.shape[0], b.shape[1], b.shape[2], a.shape[2]))
