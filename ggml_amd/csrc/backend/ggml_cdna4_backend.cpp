@@ -154,11 +154,12 @@ static enum ggml_status compute_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * d
     if (!is_qweight(a->type)) return cdna4_ops_compute(ctx, dst);
     const int64_t K = a->ne[0], M = a->ne[1], N = b->ne[1];
     const int64_t r2 = b->ne[2] / a->ne[2], r3 = b->ne[3] / a->ne[3];
+    const bool exact = cdna4_exact_mode() && ggml_cdna4_mul_mat_exact_supported((int)a->type, K);      // GGML_CDNA4_EXACT=1: the CPU backend's own summation order (exact.hip)
     // all activation rows form one matrix when src0 has no batch dims and src1's batch dims are laid out row after row
     const bool collapse = a->ne[2] == 1 && a->ne[3] == 1 && b->nb[2] == (size_t)N * b->nb[1] && b->nb[3] == (size_t)b->ne[2] * b->nb[2];
     const int64_t nbatch = collapse ? 1 : b->ne[2] * b->ne[3];
     const int64_t Bc = collapse ? N * b->ne[2] * b->ne[3] : N;
-    const size_t need = ggml_cdna4_mul_mat_workspace_size((int)a->type, K, Bc);
+    const size_t need = exact ? ggml_cdna4_mul_mat_exact_workspace_size((int)a->type, K, Bc) : ggml_cdna4_mul_mat_workspace_size((int)a->type, K, Bc);
     void * ws = ctx->need_ws(need);
     if (!ws) return GGML_STATUS_ALLOC_FAILED;
     for (int64_t ib = 0; ib < nbatch; ib++) {
@@ -166,8 +167,10 @@ static enum ggml_status compute_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * d
         const char * W = (const char *)a->data + (i12 / r2) * a->nb[2] + (i13 / r3) * a->nb[3];
         const float * X = (const float *)((const char *)b->data + i12 * b->nb[2] + i13 * b->nb[3]);
         float * Y = (float *)((char *)dst->data + i12 * dst->nb[2] + i13 * dst->nb[3]);
-        const int rc = ggml_cdna4_mul_mat((int)a->type, W, (int64_t)a->nb[1], X, (int64_t)(b->nb[1] / sizeof(float)), Y, (int64_t)(dst->nb[1] / sizeof(float)),
-                                          M, K, Bc, ws, ctx->ws_size, GGML_CDNA4_PATH_AUTO, 0, 0, ctx->stream);
+        const int rc = exact ? ggml_cdna4_mul_mat_exact((int)a->type, W, (int64_t)a->nb[1], X, (int64_t)(b->nb[1] / sizeof(float)), Y, (int64_t)(dst->nb[1] / sizeof(float)),
+                                                        M, K, Bc, ws, ctx->ws_size, ctx->stream)
+                             : ggml_cdna4_mul_mat((int)a->type, W, (int64_t)a->nb[1], X, (int64_t)(b->nb[1] / sizeof(float)), Y, (int64_t)(dst->nb[1] / sizeof(float)),
+                                                  M, K, Bc, ws, ctx->ws_size, GGML_CDNA4_PATH_AUTO, 0, 0, ctx->stream);
         if (rc) { fprintf(stderr, "ggml-cdna4: MUL_MAT failed: %s\n", ggml_cdna4_last_error()); return GGML_STATUS_FAILED; }
     }
     return GGML_STATUS_SUCCESS;
@@ -355,7 +358,7 @@ static bool graph_has_split_weights(ggml_cgraph * g) {
 
 static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph) {
     const int n_nodes = ggml_graph_n_nodes(cgraph);
-    static const bool no_fuse = getenv("GGML_CDNA4_NO_FUSE") != nullptr;
+    static const bool no_fuse = getenv("GGML_CDNA4_NO_FUSE") != nullptr || cdna4_exact_mode();      // (exact mode runs node by node: its kernels have no fused forms)
     const bool fuse = !no_fuse && n_nodes > 1;
     const use_counts uses = fuse ? use_counts(cgraph) : use_counts(nullptr, 0);
     for (int i = 0; i < n_nodes; i++) {

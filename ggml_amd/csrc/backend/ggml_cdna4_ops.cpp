@@ -2,6 +2,7 @@
 // (ggml_cdna4_tensor) -> kernels of libcdna4_kernels.so.  supports_* mirrors exactly what the kernels accept;
 // everything else is declined so the scheduler leaves it on the CPU backend.
 #include "ggml_cdna4_ops.h"
+#include <stdlib.h>
 #include "ggml_cdna4.h"
 #include <cstdio>
 #include <cstring>
@@ -82,6 +83,10 @@ bool cdna4_ops_supports_tensor(const ggml_tensor * op) {
     }
 }
 
+// GGML_CDNA4_EXACT=1: the ops whose fp32 summation order differs from the CPU backend's by default run in the CPU's own order (exact.hip); a whole gpt-2
+// graph then reproduces the CPU backend's logits bit for bit (tests/test_gpu_gpt2.py).  Verification mode: slower.
+bool cdna4_exact_mode() { static const bool on = getenv("GGML_CDNA4_EXACT") && atoi(getenv("GGML_CDNA4_EXACT")) != 0; return on; }
+
 enum ggml_status cdna4_ops_compute(void * ctx, ggml_tensor * node) {
     void * stream = cdna4_backend_stream(ctx);
     const ggml_tensor * a = node->src[0], * b = node->src[1];
@@ -96,11 +101,15 @@ enum ggml_status cdna4_ops_compute(void * ctx, ggml_tensor * node) {
         case GGML_OP_UNARY: rc = ggml_cdna4_op_unary(unary_id(node), &da, &dd, stream); break;
         case GGML_OP_NORM: case GGML_OP_RMS_NORM: {
             float eps; memcpy(&eps, node->op_params, sizeof(float));
-            rc = ggml_cdna4_op_norm(&da, &dd, eps, node->op == GGML_OP_RMS_NORM, stream); break;
+            if (cdna4_exact_mode() && node->op == GGML_OP_NORM) rc = ggml_cdna4_op_norm_exact(&da, &dd, eps, stream);
+            else rc = ggml_cdna4_op_norm(&da, &dd, eps, node->op == GGML_OP_RMS_NORM, stream);
+            break;
         }
         case GGML_OP_SOFT_MAX: {
             float scale, max_bias; memcpy(&scale, (const float *)node->op_params + 0, 4); memcpy(&max_bias, (const float *)node->op_params + 1, 4);
-            rc = ggml_cdna4_op_soft_max(&da, b ? &db : nullptr, &dd, scale, max_bias, stream); break;
+            if (cdna4_exact_mode() && !b && max_bias == 0.0f && ggml_is_contiguous(a) && ggml_is_contiguous(node)) rc = ggml_cdna4_op_soft_max_exact(&da, &dd, scale, stream);
+            else rc = ggml_cdna4_op_soft_max(&da, b ? &db : nullptr, &dd, scale, max_bias, stream);
+            break;
         }
         case GGML_OP_DIAG_MASK_INF: rc = ggml_cdna4_op_diag_mask_inf(&da, &dd, ((const int32_t *)node->op_params)[0], stream); break;
         case GGML_OP_GET_ROWS: rc = ggml_cdna4_op_get_rows(&da, &db, &dd, stream); break;
@@ -111,7 +120,10 @@ enum ggml_status cdna4_ops_compute(void * ctx, ggml_tensor * node) {
         // AVX2 form: id = 127 / amax, nearest-even), which is also what the activation quantizer uses; quantize_row_q8_0_ref and
         // ggml-cuda/cpy.cu:61 use id = 1 / d with roundf instead (C-ABI callers get that with q8_0_ref_rounding = 1)
         case GGML_OP_CPY: case GGML_OP_DUP: case GGML_OP_CONT: rc = ggml_cdna4_op_cpy(&da, &dd, /*q8_0_ref_rounding=*/0, stream); break;
-        case GGML_OP_MUL_MAT: rc = ggml_cdna4_op_mul_mat_f(&da, &db, &dd, stream); break;
+        case GGML_OP_MUL_MAT:
+            if (cdna4_exact_mode() && a->type == GGML_TYPE_F32) rc = ggml_cdna4_op_mul_mat_f_exact(&da, &db, &dd, stream);
+            else rc = ggml_cdna4_op_mul_mat_f(&da, &db, &dd, stream);
+            break;
         case GGML_OP_FLASH_ATTN_EXT: {
             float scale, max_bias, softcap;
             memcpy(&scale, (const float *)node->op_params + 0, 4); memcpy(&max_bias, (const float *)node->op_params + 1, 4); memcpy(&softcap, (const float *)node->op_params + 2, 4);

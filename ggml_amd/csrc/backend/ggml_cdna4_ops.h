@@ -11,5 +11,8 @@ bool cdna4_ops_supports_matmul(const ggml_tensor * op);
 // run one node on the backend's stream; backend_ctx is the opaque cdna4_backend_ctx
 enum ggml_status cdna4_ops_compute(void * backend_ctx, ggml_tensor * node);
 
+// GGML_CDNA4_EXACT=1 (reference-order kernels of exact.hip; peepholes and HIP-graph replay stay off)
+bool cdna4_exact_mode();
+
 extern "C" void * cdna4_backend_stream(void * backend_ctx);
 extern "C" void * cdna4_backend_scratch(void * backend_ctx, size_t nbytes);
