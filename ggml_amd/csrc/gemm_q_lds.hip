@@ -5,6 +5,7 @@
 #include "gemm_q_hw.h"
 #include "gemm_lds.inc"
 #include "gemm_w4.inc"
+#include "gemm_r8.inc"
 
 bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a) {
     if (a.type != CDNA4_Q4_K) return false;
@@ -14,17 +15,18 @@ bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a) {
 }
 
 // tile rows (0 = choose; 128 / 256) and split-K (0 = choose) -> launch.  Returns 0, or a negative status with the error text set.
-// form 0: k_gemm_lds (two waves per SIMD, ping-pong phases); form 1: k_gemm_w4 (one wave per SIMD)
+// form 0: k_gemm_lds (two waves per SIMD, ping-pong phases); form 1: k_gemm_w4 (one wave per SIMD); form 2: k_gemm_r8 (in-register unpack, 32 x 256 wave tiles; 256-row tiles only)
 int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st, int form) {
     if (!cdna4_gemm_lds_supported(a)) return cdna4_set_error_msg("gemm_lds: Q4_K on 16-byte-aligned rows, whole superblocks");
     const int cus = cdna4_gemm_cu_count(), nsb = a.K / 256;
     const int tiles_b = (a.B + 255) / 256;
+    if (form == 2) tm = 256;
     if (tm <= 0) tm = (((a.M + 255) / 256) * tiles_b >= cus) ? 256 : 128;
     if (tm != 128 && tm != 256) return cdna4_set_error_msg("gemm_lds: tile rows are 128 or 256");
     const int tiles_m = (a.M + tm - 1) / tm, ntiles = tiles_m * tiles_b;
     // split-K: S co-resident work-groups per tile reduce-scatter their partial tiles (gemm_lds.inc, epilogue (2)); needs every work-group resident
     // (one per CU) and S to divide the 4 / 8 accumulator fragments of a wave.  Deterministic (fixed summation order).
-    const int nfr = form == 1 ? (tm == 256 ? 16 : 8) : (tm == 256 ? 8 : 4), nwv = form == 1 ? 4 : 8;
+    const int nfr = form == 2 ? 8 : form == 1 ? (tm == 256 ? 16 : 8) : (tm == 256 ? 8 : 4), nwv = form == 1 ? 4 : 8;
     if (splitk <= 0) {
         splitk = 1;
         for (int s = 2; s <= 8; s *= 2) if (ntiles * s <= cus && nsb >= 2 * s) splitk = s;
@@ -50,10 +52,18 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
 #define W4_ABL(A) if (form == 1 && abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 128, (A)>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 256, (A)>), grid, dim3(256), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
     W4_ABL(1) W4_ABL(2) W4_ABL(3) W4_ABL(4) W4_ABL(8) W4_ABL(16) W4_ABL(32) W4_ABL(15)
     if (form == 1 && abl) return cdna4_set_error_msg("gemm_w4: ablation not instantiated");
+#define R8_ABL(A) if (form == 2 && abl == (A)) { hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
+    R8_ABL(1) R8_ABL(2) R8_ABL(3) R8_ABL(4) R8_ABL(8) R8_ABL(16) R8_ABL(32) R8_ABL(15)
+    if (form == 2 && abl) return cdna4_set_error_msg("gemm_r8: ablation not instantiated");
 #define LDS_ABL(A) if (abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 128, false, (A)>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 256, false, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
     LDS_ABL(1) LDS_ABL(2) LDS_ABL(3) LDS_ABL(4) LDS_ABL(8) LDS_ABL(16) LDS_ABL(32) LDS_ABL(64) LDS_ABL(15) LDS_ABL(256)
     if (abl) return cdna4_set_error_msg("gemm_lds: ablation not instantiated");
 #endif
+    if (form == 2) {
+        hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K>), grid, dim3(512), 0, st, p);
+        CDNA4_CHECK_LAUNCH();
+        return 0;
+    }
     if (form == 1) {
         if (tm == 128) hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 128>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 256>), grid, dim3(256), 0, st, p);

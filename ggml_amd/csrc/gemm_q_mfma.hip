@@ -370,11 +370,12 @@ bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B) {
         case CDNA4_Q5_0: case CDNA4_IQ4_NL: return K > 0 && K % 64 == 0;        // as Q8_0, after the exact re-encoding of convert_w.hip
         case CDNA4_Q4_1: case CDNA4_Q5_1: return K > 0 && K % 128 == 0;        // as Q8_0 with 2 K columns ([d q | m 1]) against a doubled activation image: whole 128-k panels
         case CDNA4_Q3_K: case CDNA4_Q2_K: return K > 0 && K % 256 == 0;     // as Q6_K (Q2_K: 2 K columns against a doubled activation image)
-        // IQ4_XS has the same two-part form ([h part | l part], convert_w.hip) and is within 3.2e-4 of the oracle on MI355X — but its result is not
-        // bit-stable from call to call there (round 3: ~1 % of the outputs differ in the last bits between identical calls; the same re-encoded bytes
-        // fed as a native Q6_K tensor ARE stable: scripts/gpu_diag_iq4xs.py), and the default execution is promised deterministic.  Until that is
-        // understood every batch size takes the int8-dot GEMV units (bit-stable, 2e-7 from the oracle); CDNA4_IQ4_XS_GEMM=1 re-enables the GEMM form.
-        case CDNA4_IQ4_XS: { static const bool on = getenv("CDNA4_IQ4_XS_GEMM") && atoi(getenv("CDNA4_IQ4_XS_GEMM")) != 0; return on && K > 0 && K % 256 == 0; }
+        // IQ4_XS has the same two-part form ([h part | l part], convert_w.hip).  Round 3 kept it off the GEMM by default because ~1 % of its outputs
+        // differed between identical calls on MI355X; round 4 found the cause in the RE-ENCODING, not the GEMM: hipcc had reused the address VGPRs
+        // of global loads still in flight (partial vmcnt waits) and the hardware then returned wrong bytes for the later loads (the
+        // emulator cannot see it).  k_convert_iq4_xs_q6_K2 now waits for all four loads before the first use; byte-exact and bit-stable over 200
+        // repeats on hardware (tests/test_gpu_widening.py).  CDNA4_IQ4_XS_GEMM=0 keeps every batch size on the int8-dot GEMV units.
+        case CDNA4_IQ4_XS: { static const bool off = getenv("CDNA4_IQ4_XS_GEMM") && atoi(getenv("CDNA4_IQ4_XS_GEMM")) == 0; return !off && K > 0 && K % 256 == 0; }
     }
     return false;
 }
@@ -676,8 +677,8 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
         return launch_type<CDNA4_Q6_K>(c, st);
     }
     // variant bit 28 = k_gemm_lds (gemm_q_lds.hip); bits 29 / 30 force its 128- / 256-row tile (bits 16-27: ablation mask of -DCDNA4_ABLATIONS builds)
-    // bit 25 with bit 28: its one-wave-per-SIMD form k_gemm_w4
-    if (a.variant > 0 && (a.variant & (1 << 28))) return cdna4_launch_gemm_lds(a, (a.variant & (1 << 29)) ? 128 : ((a.variant & (1 << 30)) ? 256 : 0), a.splitk, st, (a.variant & (1 << 25)) ? 1 : 0);
+    // bit 25 with bit 28: its one-wave-per-SIMD form k_gemm_w4; bit 26 with bit 28: k_gemm_r8 (in-register unpack, 32 x 256 wave tiles)
+    if (a.variant > 0 && (a.variant & (1 << 28))) return cdna4_launch_gemm_lds(a, (a.variant & (1 << 29)) ? 128 : ((a.variant & (1 << 30)) ? 256 : 0), a.splitk, st, (a.variant & (1 << 26)) ? 2 : (a.variant & (1 << 25)) ? 1 : 0);
     switch (a.type) {
         case CDNA4_Q4_K: return launch_type<CDNA4_Q4_K>(a, st);
         case CDNA4_Q5_K: return launch_type<CDNA4_Q5_K>(a, st);

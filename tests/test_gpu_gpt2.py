@@ -24,6 +24,8 @@ pytestmark = pytest.mark.gpu
 REF = R.REF_DIR
 PLUGIN = os.path.join(R.ROOT, "ggml_amd", "lib", "libggml-cdna4.so")
 N_VOCAB = 50257
+# max rel-L2(plug-in, CPU backend) per prompt length, default mode, MI355X, round 3 (profiles/r03/gpt2_parity.jsonl)
+MEASURED_R3 = {8: 1.40e-2, 64: 1.53e-2, 200: 1.62e-2}
 
 
 @pytest.fixture(scope="module")
@@ -93,8 +95,49 @@ def test_gpt2_logits_vs_cpu_backend(model, cpu_self_sensitivity, n_prompt, n_dec
         f.write(json.dumps({"n_prompt": n_prompt, "n_decode": n_decode, "rel_l2_per_step": errs, "cpu_self_sensitivity_1e-6": cpu_self_sensitivity,
                             "cpu": tc, "gpu": tg, "argmax_agree": agree}) + "\n")
     assert np.isfinite(lg).all()
-    assert max(errs) < max(1e-3, 2.0 * cpu_self_sensitivity), (errs, cpu_self_sensitivity)
+    # default (fast) mode: a different-but-correct fp32 order, amplified by the reference's own Q8_0 chain.  Bound = 1.25 x the value
+    # measured for this case on MI355X in round 3 (profiles/r03/gpt2_parity.jsonl) + 1e-3, so a real 1e-2 regression is visible
+    # (VERDICT r3 item 3); the reference-order mode below is the one that meets north_star's 1e-3.
+    assert max(errs) < 1.25 * MEASURED_R3[n_prompt] + 1e-3, (errs, cpu_self_sensitivity)
     assert sum(agree) >= 0.8 * len(agree), agree
+
+
+@pytest.mark.parametrize("n_prompt,n_decode", [(8, 6), (64, 4), (200, 2)])
+def test_gpt2_logits_vs_cpu_backend_reference_order_mode(model, n_prompt, n_decode):
+    """north_star / configs[3]: "gpt-2 117M Q4_0 logits vs the CPU backend <= 1e-3".  GGML_CDNA4_EXACT=1 makes the plug-in evaluate
+    MUL_MAT (Q4_0 x Q8_0 and F32), NORM and SOFT_MAX in the CPU backend's own summation order (ggml-cpu/arch/x86/quants.c AVX2 path,
+    ggml-cpu/vec.cpp ggml_vec_dot_f32, ggml-cpu/ops.cpp norm / soft_max) -- the only ops of this graph that were not already
+    bit-identical -- so the ill-conditioned Q8_0 chain sees the same bits."""
+    q4, d = model
+    tc, lc = _run(q4, "CPU", os.path.join(d, "cpu_e.bin"), n_prompt, n_decode)
+    tg, lg = _run(q4, "CDNA40", os.path.join(d, "gpu_e.bin"), n_prompt, n_decode, env={"GGML_CDNA4_EXACT": "1"})
+    assert "CDNA4" in tg["backend"] and lc.shape == lg.shape == (1 + n_decode, N_VOCAB)
+    errs = [R.rel_l2(lg[i], lc[i]) for i in range(lc.shape[0])]
+    ident = bool(np.array_equal(lg.view(np.uint32), lc.view(np.uint32)))
+    with open(os.path.join(R.ROOT, "gpurun_out", "gpt2_parity.jsonl"), "a") as f:
+        f.write(json.dumps({"mode": "reference_order", "n_prompt": n_prompt, "n_decode": n_decode, "rel_l2_per_step": errs, "bit_identical": ident,
+                            "cpu": tc, "gpu": tg}) + "\n")
+    assert max(errs) < 1e-3, errs
+
+
+def test_gpt2_per_op_parity_reference_order_mode_is_bit_exact(model):
+    """RESYNC (every node evaluated by both backends on identical inputs) under GGML_CDNA4_EXACT=1: every op of the graph, MUL_MAT /
+    NORM / SOFT_MAX included, reproduces the CPU backend's bits."""
+    import re
+    q4, _ = model
+    r = subprocess.run([os.path.join(REF, "gpt2_harness"), q4, "CDNA40", PLUGIN, "RESYNC", "8", "1", "16"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, GGML_CDNA4_EXACT="1"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    open(os.path.join(R.ROOT, "gpurun_out", "gpt2_resync_exact_8.log"), "w").write(r.stdout)
+    rows = re.findall(r"node\s+(\d+)\s+(\S+)\s+.*?\[\s*(\d+),\s*(\d+),\s*(\d+)\] rel_l2=(\S+?)( NONFINITE-MISMATCH)?$", r.stdout, re.M)
+    assert len(rows) > 300, r.stdout[-2000:]
+    worst = {}
+    for _, op, _, _, _, err, bad in rows:
+        assert not bad, (op, err)
+        worst[op] = max(worst.get(op, 0.0), float(err))
+    with open(os.path.join(R.ROOT, "gpurun_out", "gpt2_parity.jsonl"), "a") as f:
+        f.write(json.dumps({"mode": "resync_reference_order", "n_prompt": 8, "worst_rel_l2_per_op": worst}) + "\n")
+    assert all(e == 0.0 for e in worst.values()), worst
 
 
 def test_gpt2_graph_peepholes_change_no_bit_and_cut_the_launches(model):
@@ -167,7 +210,7 @@ def test_gpt2_sched_graph_runs_unmodified(model, cpu_self_sensitivity, ngl, para
     errs = [R.rel_l2(lg[i], lc[i]) for i in range(4)]
     with open(os.path.join(R.ROOT, "gpurun_out", "gpt2_parity.jsonl"), "a") as f:
         f.write(json.dumps({"mode": "sched", "rel_l2_per_step": errs, "cpu": tc, "gpu": tg, "cpu_self_sensitivity_1e-6": cpu_self_sensitivity}) + "\n")
-    assert max(errs) < max(1e-3, 2.0 * cpu_self_sensitivity), (errs, cpu_self_sensitivity)
+    assert max(errs) < 1.25 * 1.63e-2 + 1e-3, (errs, cpu_self_sensitivity)          # 1.25 x measured (round 3) + 1e-3
     if ngl == 6:
         assert tg["n_splits"] >= 2
 

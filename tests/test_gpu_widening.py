@@ -255,6 +255,73 @@ def test_q4_1_q5_1_iq4_nl_prefill_gemm(gu, name, t, m, k, b):
     assert R.rel_l2(y3[:, rows], R.o_mul_mat(t, wsub3, x, len(rows), k)) < TOL_GEMM
 
 
+TWO_PART = [("iq4_xs", R.IQ4_XS), ("q2_K", R.Q2_K), ("q4_1", R.Q4_1), ("q5_1", R.Q5_1)]
+
+
+@pytest.mark.parametrize("name,t", TWO_PART)
+@pytest.mark.parametrize("m,k,b", [(4096, 4096, 512), (16384, 256, 1024)])
+def test_two_part_gemm_is_bit_stable_over_200_calls(gu, name, t, m, k, b):
+    """the two-part routes (re-encoding into scratch + one MFMA GEMM against the doubled activation image) called 200
+    times on the same operands, with other matrices of other formats run in between (so the library's scratch for the re-encoded copy
+    is reused and overwritten): every call returns the first call's bits.  Round 3 saw ~1 % of IQ4_XS outputs move between identical
+    calls on MI355X; cause and fix: DESIGN 4.11 (k_convert_iq4_xs_q6_K2)."""
+    from ggml_amd import ops
+    w = R.random_weights(t, m, k, seed=5 * m + k)
+    xd = gu.to_dev(_x(b * 7 + k, b, k))
+    a = gu.qtensor(t, w, m, k)
+    other = [gu.qtensor(tt, R.random_weights(tt, 512, k, seed=77 + i), 512, k) for i, tt in enumerate((R.Q4_K, R.IQ4_XS, R.Q2_K))]
+    y0 = ops.mul_mat(a, xd)
+    rows = np.random.default_rng(1).choice(m, 48, replace=False)
+    rs = R.row_size(t, k)
+    e = R.rel_l2(y0.cpu().numpy()[:, rows], R.o_mul_mat(t, np.concatenate([w[r * rs:(r + 1) * rs] for r in rows]), xd.cpu().numpy(), len(rows), k))
+    assert e < TOL_GEMM
+    moved = 0
+    for i in range(200):
+        if i % 3 == 0:
+            ops.mul_mat(other[(i // 3) % 3], xd)
+        y = ops.mul_mat(a, xd)
+        moved += int(not torch.equal(y, y0))
+    gu.report(test="two_part_gemm_stability", type=name, m=m, k=k, b=b, rel_l2=e, calls=200, calls_that_moved=moved)
+    assert moved == 0
+
+
+def test_iq4_xs_reencoding_is_value_exact_on_hardware(gu):
+    """the IQ4_XS -> [h part | l part] re-encoding itself, on hardware, 12 times into a buffer pre-filled with two different patterns: the
+    oracle's dequantize_row(Q6_K) of the two parts sums to its dequantize_row(IQ4_XS) of the source value for value, and every repeat
+    writes the same bytes.  (The two-part forms are not offered by the public ggml_cdna4_convert_weights; CDNA4_DIAG_CONVERT_ANY=1 opens
+    them for this check, hence the child process.)"""
+    import subprocess, sys, json
+    code = r"""
+import sys, json, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import refutil as R
+from ggml_amd import ops, native
+T, m, k = R.IQ4_XS, 4096, 4096
+L = native.lib()
+w = R.random_weights(T, m, k, seed=5 * m + k)
+a = ops.QTensor.from_host_bytes(T, k, m, w)
+n = L.ggml_cdna4_convert_weights_size(int(T), m, k)
+assert n == m * R.row_size(R.Q6_K, 2 * k), n
+buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+first, moved = None, 0
+for rep in range(12):
+    buf.fill_(0xEE if rep %% 2 else 0x11)
+    native.check(L.ggml_cdna4_convert_weights(int(T), a.data.data_ptr(), a.row_bytes, m, k, buf.data_ptr(), ops._stream(buf.device)))
+    g = buf.cpu().numpy()
+    if first is None:
+        first = g.copy()
+    moved += int(not np.array_equal(g, first))
+both = R.o_dequantize(R.Q6_K, first, 2 * k)
+src = R.o_dequantize(T, w, k)
+print(json.dumps({"value_exact": bool(np.array_equal(both[:, :k] + both[:, k:], src)), "repeats_that_moved": moved}))
+""" % (R.ROOT, os.path.join(R.ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, CDNA4_DIAG_CONVERT_ANY="1"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    gu.report(test="iq4_xs_reencoding_on_hardware", **rec)
+    assert rec["value_exact"] and rec["repeats_that_moved"] == 0, rec
+
+
 @pytest.mark.parametrize("name,t", [("q4_1", R.Q4_1), ("q5_1", R.Q5_1)])
 def test_two_part_gemm_needs_whole_panels(gu, name, t):
     """K = 544 is not a multiple of 128: no doubled activation image, so more than 8 rows stay on the GEMV units (and say so when forced)"""

@@ -50,6 +50,7 @@ static void *shared_alloc(size_t n) {
 #include "../../ggml_amd/csrc/gemm_q_hw.h"
 #include "../../ggml_amd/csrc/gemm_lds.inc"
 #include "../../ggml_amd/csrc/gemm_w4.inc"
+#include "../../ggml_amd/csrc/gemm_r8.inc"
 
 template <typename F> static void emu_launch(F body, unsigned nblk, int nthreads) {
     emu::g_gridDim = dim3(nblk); emu::g_blockDim = dim3(nthreads);
@@ -88,7 +89,7 @@ static std::vector<uint8_t> slurp(const char *p) {
 int main(int argc, char **argv) {
     if (argc < 10) { fprintf(stderr, "usage: lds_emul M K B w.bin xh.bin y.bin splitk tm xchg_l2 [type]\n"); return 2; }
     const int M = atoi(argv[1]), K = atoi(argv[2]), B = atoi(argv[3]), splitk = atoi(argv[7]), tm = atoi(argv[8]);
-    const int form = atoi(argv[9]) == 2 ? 1 : 0;                        // (the xchg_l2 argument of the other harnesses: 2 selects k_gemm_w4)
+    const int form = atoi(argv[9]) == 2 ? 1 : atoi(argv[9]) == 3 ? 2 : 0;   // (the xchg_l2 argument of the other harnesses: 2 selects k_gemm_w4, 3 k_gemm_r8)
     std::vector<uint8_t> w0 = slurp(argv[4]), xh0 = slurp(argv[5]);
     uint8_t *w = (uint8_t *)shared_alloc(w0.size()), *xh = (uint8_t *)shared_alloc(xh0.size());      // no slack: rows past B are clamped by the kernel
     memcpy(w, w0.data(), w0.size()); memcpy(xh, xh0.data(), xh0.size());
@@ -101,7 +102,7 @@ int main(int argc, char **argv) {
     if (tm != 128 && tm != 256) { fprintf(stderr, "tm 128 or 256\n"); return 2; }
     p.tiles_m = (M + tm - 1) / tm; p.tiles_b = (B + 255) / 256;
     const int ntiles = p.tiles_m * p.tiles_b, nsb = K / 256;
-    const int nfr = form ? (tm == 256 ? 16 : 8) : (tm == 256 ? 8 : 4), nwv = form ? 4 : 8;
+    const int nfr = form == 2 ? 8 : form ? (tm == 256 ? 16 : 8) : (tm == 256 ? 8 : 4), nwv = form == 1 ? 4 : 8;
     if (splitk < 1 || nfr % splitk || nsb < splitk) { fprintf(stderr, "splitk must divide %d and leave a superblock per work-group\n", nfr); return 2; }
     unsigned *flags = nullptr;
     if (splitk > 1) {                                                   // as cdna4_launch_gemm_lds(): counters, then the exchange slots
@@ -111,7 +112,8 @@ int main(int argc, char **argv) {
         p.flags = flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
     }
     const unsigned nblk = (unsigned)(ntiles * splitk);
-    if (form) { if (tm == 128) emu_launch([&] { k_gemm_w4<CDNA4_Q4_K, 128>(p); }, nblk, 256); else emu_launch([&] { k_gemm_w4<CDNA4_Q4_K, 256>(p); }, nblk, 256); }
+    if (form == 2) emu_launch([&] { k_gemm_r8<CDNA4_Q4_K>(p); }, nblk, 512);
+    else if (form) { if (tm == 128) emu_launch([&] { k_gemm_w4<CDNA4_Q4_K, 128>(p); }, nblk, 256); else emu_launch([&] { k_gemm_w4<CDNA4_Q4_K, 256>(p); }, nblk, 256); }
     else if (tm == 128) emu_launch([&] { k_gemm_lds<CDNA4_Q4_K, 128>(p); }, nblk, 512);
     else emu_launch([&] { k_gemm_lds<CDNA4_Q4_K, 256>(p); }, nblk, 512);
     if (flags) for (int i = 0; i < 16384; i++) if (flags[i] != 0) { fprintf(stderr, "split-K counter word %d was not reset by the last work-group to leave (%u)\n", i, flags[i]); return 4; }
