@@ -642,7 +642,8 @@ def main():
     flops_step = h.flops * world
     value = flops_step / (ms_per_step * 1e-3) / 1e12
 
-    # ---- the dominant kernel alone (activations prepared once), HIP events on the launch stream
+    # ---- the dominant kernel alone (activations prepared once), HIP events on the launch stream; likewise the activation quantizer alone
+    quant_us = events_us(h.prepare, args.steps, 10)
     h.prepare()
     gemm_us = events_us(h.gemm_only, args.steps, 10)
     gemm_tf = h.flops / gemm_us / 1e6
@@ -671,8 +672,15 @@ def main():
                          "achieved": round(gemm_tf, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tf / MFMA_F16_PEAK_TFLOPS, 4),
                          "traffic": pmc_traffic("k_gemm_kq_t64<12, 128") if args.variant == 0 else None,
                          "traffic_note": "HBM-side bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) from the rocprofv3 PMC passes of this command, profiles/rNN/pmc_summary.txt",
-                         "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": h.flops, "us_per_launch_all_zero_operands": zero_us},
+                         "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": h.flops, "us_per_launch_all_zero_operands": zero_us,
+                         # the whole step (quantizer + GEMM + the launch gap between them) against the same roof: value / peak
+                         "step_frac": round(value / world / MFMA_F16_PEAK_TFLOPS, 4)},
         }
+        # the step's other kernel, HBM-bound: reads the fp32 activations once, writes the pair-interleaved fp16 image + per-256 scale and per-16 sums
+        qbytes = B * K * 4 + B * K * 2 + B * (K // 256) * 4 + B * (K // 16) * 2
+        out["quantizer"] = {"kernel": "k_quantize_q8_K (fp32 rows -> fp16 GEMM image of the Q8_K-rounded activations, d, bsums)", "bound": "hbm", "us_per_launch": round(quant_us, 3),
+                            "algorithmic_bytes_per_launch": qbytes, "achieved": round(qbytes / quant_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(qbytes / quant_us / 1e3 / HBM_PEAK_GBS, 4)}
         if world == 1 and not args.lean:
             out["roofline"]["library_ceiling"] = library_ceiling(dev, M, K, B, args.steps)
             lc = out["roofline"]["library_ceiling"]

@@ -494,4 +494,5 @@ void *cdna4_gemm_scratch(size_t bytes, int kind);      // per-device scratch, ze
 int cdna4_gemm_cu_count();
 int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st);     // gemm_q_t64.hip: 64(m) x 128(b) wave tiles; tm 0 / 128 / 256, splitk 0 / 1 / 2
 bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a);                                     // gemm_q_lds.hip: weights dequantized into fp16 LDS tiles, 256-wide activation tile
-int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st, int form = 0);     //   tm 0 / 128 / 256, splitk 0 = choose; form 1 = k_gemm_w4 (one wave per SIMD)
+int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st, int form = 0);     //   tm 0 / 128 / 256, splitk 0 = choose; form 1 = k_gemm_w4 (one wave per SIMD); form 2 = k_gemm_r8 (32 x 256 wave tiles)
+bool cdna4_gemm_r8_preferred(const cdna4_gemm_args &a);                                      //   AUTO takes k_gemm_r8 for this call (large grids of 256 x 256 tiles)

@@ -14,6 +14,20 @@ bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a) {
     return true;
 }
 
+// AUTO routing (gemm_q_mfma.hip: launch_type<Q4_K>, cdna4_gemm_q_fuses_tail): k_gemm_r8 where its 256 x 256 tiles fill at least half the chip — with
+// split-K = 2 then — measured on MI355X, one box, us per call, r8 vs k_gemm_kq_t64 (profiles/r04/gemm_bench.txt): 32768 x 8192 x 512 216 vs 238,
+// 16384 x 8192 x 512 119 vs 130, 8192 x 8192 x 1024 121 vs 131, 32768 x 4096 x 512 115 vs 127, 4096 x 4096 x 2048 70 vs 74, 16384 x 4096 x 512 69 vs 70;
+// below that (32 tiles: 4096 x 4096 x 512 39 vs 25, 4096 x 11008 x 512 59 vs 50) the 8-way exchange costs more than the leaner loop saves.
+bool cdna4_gemm_r8_preferred(const cdna4_gemm_args &a) {
+    static const bool off = getenv("CDNA4_NO_R8") && atoi(getenv("CDNA4_NO_R8")) != 0;
+    if (off || !cdna4_gemm_lds_supported(a)) return false;
+    const int cus = cdna4_gemm_cu_count(), ntiles = ((a.M + 255) / 256) * ((a.B + 255) / 256), nsb = a.K / 256;
+    if (ntiles * 2 < cus) return false;
+    const int s = (ntiles * 2 <= cus && nsb >= 4) ? 2 : 1;              // what cdna4_launch_gemm_lds() will choose (split-K = 2 needs two superblocks per work-group)
+    const int wgs = ntiles * s, rounds = (wgs + cus - 1) / cus;
+    return wgs * 10 >= rounds * cus * 9;                                // whole rounds of work-groups (>= 90 % of the last one): the tiles are large
+}
+
 // tile rows (0 = choose; 128 / 256) and split-K (0 = choose) -> launch.  Returns 0, or a negative status with the error text set.
 // form 0: k_gemm_lds (two waves per SIMD, ping-pong phases); form 1: k_gemm_w4 (one wave per SIMD); form 2: k_gemm_r8 (in-register unpack, 32 x 256 wave tiles; 256-row tiles only)
 int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st, int form) {
@@ -60,7 +74,8 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     if (abl) return cdna4_set_error_msg("gemm_lds: ablation not instantiated");
 #endif
     if (form == 2) {
-        hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K>), grid, dim3(512), 0, st, p);
+        if (a.epi.bias || a.epi.act || a.epi.resid) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K, 0, true>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K>), grid, dim3(512), 0, st, p);
         CDNA4_CHECK_LAUNCH();
         return 0;
     }

@@ -492,6 +492,16 @@ def test_whole_library_mul_mat_on_the_cpu(name, t):
         assert r[0] < bar, (name, m, k, b, r[0])
 
 
+@pytest.mark.parametrize("m,k,b,cus", [(512, 1024, 256, 4), (300, 512, 300, 2), (256, 2048, 200, 2)])
+def test_whole_library_large_grid_route_on_the_cpu(m, k, b, cus):
+    """Q4_K where the 256 x 256 tiles of k_gemm_r8 fill (a pretend chip of `cus` CUs): AUTO takes that kernel — two tiles x split-K 2 through the
+    reduce-scatter exchange on 4 CUs; four ragged tiles unsplit on 2 CUs; one tile x split-K 2 — through the C-ABI on the CPU, within the GEMM bar of the oracle"""
+    r = _emul_module("lib_emul_check").mul_mat(12, m, k, b, seed=m + b, cus=cus, timeout=900)
+    if r is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert r[0] < 1e-3, r[0]
+
+
 @pytest.mark.parametrize("name,t", [("q4_1", 3), ("iq4_nl", 20), ("iq4_xs", 23), ("q2_K", 10)])
 def test_whole_library_small_k_gemm_route_on_the_cpu(name, t):
     """K = 256: the re-encoded matrix is too shallow for the staging kernel (2 superblocks of the target format) and takes the re-layout + 8-wave

@@ -264,6 +264,41 @@ def test_mul_mat_fused_against_the_reference_cpu_backend(L, name, t, b, tail):
     assert e < (1e-5 if b <= 8 else 1e-3), e
 
 
+@pytest.mark.parametrize("tail", ["bias_gelu", "bias_residual", "bias_residual_in_place"])
+@pytest.mark.parametrize("m,k,b", [(8192, 1024, 1024), (16384, 512, 2048)])
+def test_mul_mat_fused_on_the_large_grid_route(L, m, k, b, tail):
+    """Q4_K shapes whose 256 x 256 tiles fill the chip take k_gemm_r8 in AUTO (128 tiles x split-K 2 with the reduce-scatter exchange; 512 tiles unsplit):
+    the tail rides in ITS store — same bits as MUL_MAT -> ADD -> GELU | ADD on the same route, the product within the GEMM bar of the oracle on sampled
+    weight rows, the in-place residual allowed and bit-identical."""
+    t = R.Q4_K
+    w = R.random_weights(t, m, k, seed=31)
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, (b, k)).astype(np.float32)
+    bias = (rng.standard_normal(m) * 3).astype(np.float32)
+    res = rng.standard_normal((b, m)).astype(np.float32)
+    wd, xd, bd, rd = _dev(w), _dev(x), _dev(bias), _dev(res)
+    ws = torch.empty(max(L.ggml_cdna4_mul_mat_workspace_size(int(t), k, b), 256), dtype=torch.uint8, device="cuda")
+    rb = R.row_size(t, k)
+    y0 = torch.empty((b, m), dtype=torch.float32, device="cuda"); y1 = torch.empty_like(y0); y2 = torch.empty_like(y0)
+    _ok(L, L.ggml_cdna4_mul_mat(int(t), wd.data_ptr(), rb, xd.data_ptr(), k, y0.data_ptr(), m, m, k, b, ws.data_ptr(), ws.numel(), 0, 0, 0, _st()))
+    rows = np.random.default_rng(2).choice(m, 40, replace=False)
+    wsub = np.concatenate([w[r * rb:(r + 1) * rb] for r in rows])
+    assert R.rel_l2(y0.cpu().numpy()[:, rows], R.o_mul_mat(t, wsub, x, len(rows), k)) < 1e-3
+    _bin(L, 0, y0, bd, y1)
+    if tail == "bias_gelu":
+        _ok(L, L.ggml_cdna4_op_unary(0, C.byref(_desc(y1, R.F32)), C.byref(_desc(y2, R.F32)), _st()))
+    else:
+        _bin(L, 0, y1, rd, y2)
+    yf = rd.clone() if tail == "bias_residual_in_place" else torch.full((b, m), 7.0, dtype=torch.float32, device="cuda")
+    if tail == "bias_residual_in_place":
+        assert L.ggml_cdna4_mul_mat_fused_residual_may_alias(int(t), m, k, b) == 1
+    rp = None if tail == "bias_gelu" else (yf.data_ptr() if tail == "bias_residual_in_place" else rd.data_ptr())
+    _ok(L, L.ggml_cdna4_mul_mat_fused(int(t), wd.data_ptr(), rb, xd.data_ptr(), k, yf.data_ptr(), m, m, k, b, bd.data_ptr(), 1 if tail == "bias_gelu" else 0, rp, m,
+                                      ws.data_ptr(), ws.numel(), _st()))
+    torch.cuda.synchronize()
+    assert np.array_equal(yf.cpu().numpy().view(np.uint32), y2.cpu().numpy().view(np.uint32))
+
+
 @pytest.mark.parametrize("b", [1, 5, 96, 512])
 @pytest.mark.parametrize("name,t", [("q4_0", R.Q4_0), ("q4_K", R.Q4_K), ("q6_K", R.Q6_K)])
 def test_mul_mat_fused_with_the_residual_in_place(L, name, t, b):
