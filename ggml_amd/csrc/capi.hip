@@ -195,8 +195,9 @@ static int mul_mat_prepared_impl(int type, const void *W, int64_t w_row_bytes, f
     const bool mmq = path == GGML_CDNA4_PATH_AUTO && use_mmq(type, M, K, B) && !(((uintptr_t)W | (uintptr_t)w_row_bytes) & (type == CDNA4_Q6_K ? 1 : 15));
     path = resolve_path(type, path, M, K, B);
     if (path == GGML_CDNA4_PATH_GEMM) {
-        const cdna4_gemm_args a = gemm_args_of(type, W, w_row_bytes, v.xh, Y, y_row_stride, M, K, B, gemm_variant, splitk, epi);
-        *tail_done = cdna4_gemm_q_fuses_tail(a);
+        cdna4_gemm_args a = gemm_args_of(type, W, w_row_bytes, v.xh, Y, y_row_stride, M, K, B, gemm_variant, splitk, epi);
+        *tail_done = cdna4_gemm_q_fuses_tail(a);                     // (the routing itself, probed: gemm_q_mfma.hip)
+        if (!*tail_done) a.epi = cdna4_epilogue{};                      // this route stores the plain product: the caller appends k_epilogue
         return cdna4_launch_gemm_q(a, (hipStream_t)stream);
     }
     cdna4_gemv_args g{};
@@ -263,7 +264,10 @@ int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float
 // ggml buffer of the plug-in and every torch allocation gives); the older MFMA GEMM kernels write the product first (k_epilogue behind them)
 int ggml_cdna4_mul_mat_fused_residual_may_alias(int type, int64_t M, int64_t K, int64_t B) {
     if (resolve_path(type, GGML_CDNA4_PATH_AUTO, M, K, B) == GGML_CDNA4_PATH_GEMV) return 1;
-    return (type == CDNA4_Q4_K && K % 256 == 0) ? 1 : 0;
+    // GEMM route: yes where the kernel AUTO picks carries the tail in its store (every element is read and written by the same lane) — asked of the routing
+    // itself, for contiguous 256-byte-aligned operands (the call re-checks with the real pointers)
+    cdna4_epilogue e{}; e.act = 1;
+    return cdna4_gemm_q_fuses_tail(gemm_args_of(type, (const void *)(uintptr_t)256, (int64_t)ggml_cdna4_row_size(type, K), (const void *)(uintptr_t)256, (float *)(uintptr_t)256, M, M, K, B, 0, 0, e)) ? 1 : 0;
 }
 int ggml_cdna4_mul_mat_fused(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
                              int64_t M, int64_t K, int64_t B, const float *bias, int act, const float *residual, int64_t residual_row_stride,

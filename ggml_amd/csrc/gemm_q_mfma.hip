@@ -26,6 +26,7 @@
 #include <mutex>
 #include "gemm_q_hw.h"
 #include "quantize_dev.h"
+#include "epilogue.h"
 
 // repack kernels: one thread per 16-byte OUTPUT piece (coalesced stores; the 2-byte-aligned source bytes of a superblock
 // are read by the 9 / 17 / 14 adjacent threads that build it)
@@ -450,6 +451,11 @@ static int cu_count() {                                            // of the CUR
 void *cdna4_gemm_scratch(size_t bytes, int kind) { return get_scratch(bytes, kind); }
 int cdna4_gemm_cu_count() { return cu_count(); }
 
+// Route probe (the tail predictor must not be a hand-kept copy of the routing): cdna4_gemm_q_fuses_tail() runs the SAME routing code with the
+// probe armed; every route ends in ROUTE_END(does this kernel apply a.epi in its store?) in front of its first side effect (scratch, zero-fill, launch).
+static thread_local struct { bool active, fuses; } g_probe = {false, false};
+#define ROUTE_END(f) do { if (g_probe.active) { g_probe.fuses = (f); return 0; } } while (0)
+
 template <int TYPE>
 static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t st, int exp = 0) {
     gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.sb_split = 0;
@@ -457,7 +463,10 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 127) / 128;
     p.partial = nullptr; p.flags = nullptr;
+    p.epi = a.epi;                                                        // gemm_w8_epilogue.inc applies it in the tile's store (not on the atomic-sum path)
     const int ntiles = p.tiles_m * p.tiles_b;
+    ROUTE_END(splitk == 1 || (splitk == 2 && ntiles * 2 <= cu_count()));
+    if (splitk > 2 || (splitk == 2 && ntiles * 2 > cu_count())) p.epi = cdna4_epilogue{};
     if (splitk == 2 && ntiles * 2 <= cu_count()) {                    // both halves of every tile are resident at once: hand-off
         // exchange slots after a FIXED 64-KB flag area (so that no shape's slots ever overlay another shape's flags).  A flag is
         // non-zero only between its writer's publication and its reader's reset inside one launch: no per-launch state on the
@@ -561,14 +570,14 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     }
     if constexpr (TYPE == CDNA4_Q4_K) {
         // bit13 = k_gemm_kq_t64 (gemm_q_t64.hip: 64(m) x 128(b) wave tiles); bit14 / bit15 force its 128- / 256-row tile
-        if (wlds && (variant & 8192)) return cdna4_launch_gemm_t64(a, (variant & 16384) ? 128 : ((variant & 32768) ? 256 : 0), a.splitk, st);
+        if (wlds && (variant & 8192)) { ROUTE_END(true); return cdna4_launch_gemm_t64(a, (variant & 16384) ? 128 : ((variant & 32768) ? 256 : 0), a.splitk, st); }
         // auto (round 2): k_gemm_kq_t64 for every prefill shape — 128-row tiles (hand-off split-K = 2 while both work-groups of a tile
         // are resident, uneven for odd superblock counts), 256-row tiles once the grid holds two of them per CU.  MI355X, same box, same
         // data: 4096x4096x512 24.25 vs 24.68 us on k_gemm_kq_w12, 4096x11008x512 50.95 vs 52.57, 8192x4096x512 37.1 vs 38.1,
         // 32768x8192x512 (256-row tiles) 239-243 vs 265.
         // auto (round 4): k_gemm_r8 (gemm_r8.inc: 32 x 256 wave tiles, half the unpack VALU per MFMA) where its 256 x 256 tiles fill the chip — 8-9 % ahead there
-        if (wlds && a.variant <= 0 && a.splitk <= 0 && cdna4_gemm_r8_preferred(a)) return cdna4_launch_gemm_lds(a, 256, 0, st, 2);
-        if (wlds && a.variant <= 0 && a.splitk <= 2) return cdna4_launch_gemm_t64(a, 0, a.splitk, st);   // (deeper, atomic splits: the older kernels below)
+        if (wlds && a.variant <= 0 && a.splitk <= 0 && cdna4_gemm_r8_preferred(a)) { ROUTE_END(true); return cdna4_launch_gemm_lds(a, 256, 0, st, 2); }
+        if (wlds && a.variant <= 0 && a.splitk <= 2) { ROUTE_END(true); return cdna4_launch_gemm_t64(a, 0, a.splitk, st); }   // (deeper, atomic splits: the older kernels below)
     }
     if (splitk < 1 || (kunits % splitk && !uneven)) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
     if constexpr (TYPE == CDNA4_Q4_0 || TYPE == CDNA4_Q8_0 || TYPE == CDNA4_Q6_K) {
@@ -588,6 +597,13 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         if (a.variant <= 0 && a.K % 256 == 0) {
             const int nsb = a.K / 256;
             const size_t rbytes = (size_t)a.M * nsb * QT<RT>::BYTES;
+            if (g_probe.active) {                                        // (the same terminal, without the re-layout pass in front of it)
+                const int tiles = ((a.M + 127) / 128) * ((a.B + 127) / 128);
+                int sk = a.splitk;
+                if (sk <= 0) sk = (tiles * 2 <= cu_count() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
+                if (sk < 1 || nsb % sk) return 0;
+                return launch_w8<RT>(a, sk, 64, st);
+            }
             uint8_t *rw = (uint8_t *)get_scratch(rbytes + 256, 1);
             if (!rw) return cdna4_set_error_msg("gemm_q: cannot allocate the repack scratch");
             const dim3 grid((unsigned)(((int64_t)a.M * nsb * (QT<RT>::BYTES / 16) + 255) / 256));
@@ -605,6 +621,9 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     }
     if constexpr (CAN_LDS) {
         if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant & 4096) ? 65 : ((variant & 2048) ? 64 : ((variant >> 5) & 31)), st, variant >> 16);
+    }
+    ROUTE_END(false);                                                    // the older kernels below store the plain product (k_epilogue behind them)
+    if constexpr (CAN_LDS) {
         if (wlds && !(variant & 8)) return wide ? launch_pipe<TYPE, 4>(a, splitk, st) : launch_pipe<TYPE, 2>(a, splitk, st);
         if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
     }
@@ -647,12 +666,14 @@ int cdna4_launch_gemm_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, 
     return cdna4_set_error_msg("gemm_ids: unsupported weight type");
 }
 
-// the launches below that end in k_gemm_kq_t64 apply a.epi in their store (gemm_kq_t64.inc): Q4_K on 16-byte-aligned rows, auto or forced-t64 variant,
-// the deterministic K splits.  MUST mirror launch_type<CDNA4_Q4_K>'s routing.
+int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st);
+// does the route cdna4_launch_gemm_q() takes for these arguments apply a.epi in its store?  (k_gemm_kq_t64, k_gemm_r8 and the 128 x 128-tile kernels of
+// gemm_w8_epilogue.inc outside their atomic-sum split; also behind the exact re-encodings.)  Runs the routing itself with the probe armed: no side effects.
 bool cdna4_gemm_q_fuses_tail(const cdna4_gemm_args &a) {
-    if (a.type != CDNA4_Q4_K || a.M <= 0 || a.B <= 0 || a.K % 256 || a.K < 256) return false;
-    if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) || ((uintptr_t)a.xh & 15)) return false;
-    return (a.variant > 0 && (a.variant & 8192)) || (a.variant <= 0 && a.splitk <= 2);       // (k_gemm_r8, where AUTO prefers it, carries the tail too)
+    g_probe.active = true; g_probe.fuses = false;
+    const int rc = cdna4_launch_gemm_q(a, nullptr);
+    g_probe.active = false;
+    return rc == 0 && g_probe.fuses;
 }
 
 int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
@@ -664,10 +685,13 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
         return cdna4_set_error_msg("gemm_q: Q4_K/Q5_K rows must be 16-byte aligned");
     if (a.type == CDNA4_Q5_0 || a.type == CDNA4_Q3_K || a.type == CDNA4_Q2_K || a.type == CDNA4_Q4_1 || a.type == CDNA4_Q5_1 || a.type == CDNA4_IQ4_NL || a.type == CDNA4_IQ4_XS) {
         // no MFMA kernel of their own: re-encode EXACTLY as Q8_0 / Q6_K into scratch (convert_w.hip) and run that format's GEMM
-        uint8_t *cw = (uint8_t *)get_scratch(cdna4_convert_weights_bytes(a.type, a.M, a.K) + 256, 3);
-        if (!cw) return cdna4_set_error_msg("gemm_q: cannot allocate the weight re-encoding scratch");
-        const int rc = cdna4_launch_convert_weights(a.type, a.W, a.w_row_bytes, a.M, a.K, cw, st);
-        if (rc) return rc;
+        uint8_t *cw = (uint8_t *)(uintptr_t)256;                         // (route probe: an aligned stand-in, never dereferenced)
+        if (!g_probe.active) {
+            cw = (uint8_t *)get_scratch(cdna4_convert_weights_bytes(a.type, a.M, a.K) + 256, 3);
+            if (!cw) return cdna4_set_error_msg("gemm_q: cannot allocate the weight re-encoding scratch");
+            const int rc = cdna4_launch_convert_weights(a.type, a.W, a.w_row_bytes, a.M, a.K, cw, st);
+            if (rc) return rc;
+        }
         cdna4_gemm_args c = a; c.W = cw;
         if (cdna4_convert_weights_target(a.type) == CDNA4_Q8_0) {
             // Q5_0 / IQ4_NL: same shape.  Q4_1 / Q5_1: scale part and minimum part side by side, a.xh holds the activation image twice (capi.hip: prepare_act)
@@ -680,6 +704,7 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
     }
     // variant bit 28 = k_gemm_lds (gemm_q_lds.hip); bits 29 / 30 force its 128- / 256-row tile (bits 16-27: ablation mask of -DCDNA4_ABLATIONS builds)
     // bit 25 with bit 28: its one-wave-per-SIMD form k_gemm_w4; bit 26 with bit 28: k_gemm_r8 (in-register unpack, 32 x 256 wave tiles)
+    if (a.variant > 0 && (a.variant & (1 << 28))) { ROUTE_END((a.variant & (1 << 26)) != 0); }
     if (a.variant > 0 && (a.variant & (1 << 28))) return cdna4_launch_gemm_lds(a, (a.variant & (1 << 29)) ? 128 : ((a.variant & (1 << 30)) ? 256 : 0), a.splitk, st, (a.variant & (1 << 26)) ? 2 : (a.variant & (1 << 25)) ? 1 : 0);
     switch (a.type) {
         case CDNA4_Q4_K: return launch_type<CDNA4_Q4_K>(a, st);
