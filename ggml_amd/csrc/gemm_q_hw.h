@@ -14,6 +14,16 @@
 #define CDNA4_WAIT_VM_TIED2(n, a, b) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(n) : "memory")
 #define CDNA4_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define CDNA4_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// counted wait with a wave-uniform RUN-TIME count (s_waitcnt takes an immediate: a scalar branch ladder; counts above 24 wait for 24, which is stricter)
+#define CDNA4_WAIT_VM_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+__device__ __forceinline__ void cdna4_wait_vm_rt(int n) {
+    switch (n < 0 ? 0 : (n > 24 ? 24 : n)) {
+        CDNA4_WAIT_VM_CASE(0) CDNA4_WAIT_VM_CASE(1) CDNA4_WAIT_VM_CASE(2) CDNA4_WAIT_VM_CASE(3) CDNA4_WAIT_VM_CASE(4) CDNA4_WAIT_VM_CASE(5) CDNA4_WAIT_VM_CASE(6)
+        CDNA4_WAIT_VM_CASE(7) CDNA4_WAIT_VM_CASE(8) CDNA4_WAIT_VM_CASE(9) CDNA4_WAIT_VM_CASE(10) CDNA4_WAIT_VM_CASE(11) CDNA4_WAIT_VM_CASE(12) CDNA4_WAIT_VM_CASE(13)
+        CDNA4_WAIT_VM_CASE(14) CDNA4_WAIT_VM_CASE(15) CDNA4_WAIT_VM_CASE(16) CDNA4_WAIT_VM_CASE(17) CDNA4_WAIT_VM_CASE(18) CDNA4_WAIT_VM_CASE(19) CDNA4_WAIT_VM_CASE(20)
+        CDNA4_WAIT_VM_CASE(21) CDNA4_WAIT_VM_CASE(22) CDNA4_WAIT_VM_CASE(23) CDNA4_WAIT_VM_CASE(24)
+    }
+}
 // the same as an instruction the compiler's own wait-count pass SEES (vmcnt 63, expcnt 7, lgkmcnt 0): behind it hipcc knows every ds_read has returned and
 // inserts no lgkmcnt wait of its own in front of the MFMAs that use fragments requested a phase earlier (k_gemm_lds; it cannot see an asm wait)
 // keeps a 32-bit value materialized HERE: without it hipcc sinks arithmetic whose result is only used behind a later branch or barrier down to that use

@@ -12,6 +12,7 @@
 #include "cdna4_kernels.h"
 #include "quantize_dev.h"
 #include "epilogue.h"
+#include "gemm_q_hw.h"
 #include <stdlib.h>
 
 __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
@@ -540,6 +541,9 @@ static int launch_type(const cdna4_gemv_args &a0, hipStream_t st) {
 }
 
 
+// cdna4_gemv_fused_lds_bytes() for the K-quants, on the device (the DMA form places the weight rows behind the activation area)
+template <int TYPE> __device__ __forceinline__ int cdna4_gemv_fused_lds_bytes_dev(int K) { return K + K / 8 + (K / 256) * 4; }
+
 // ---- fused activation-quantize + GEMV (single-column decode) ------------------------------------------------
 // One launch instead of two for the B=1 MUL_MAT: every workgroup re-quantizes the whole activation row into
 // LDS (K bytes of int8 + scales + bsums; the row is 16 KiB at K=4096 and L2-resident after the first
@@ -558,8 +562,16 @@ static int launch_type(const cdna4_gemv_args &a0, hipStream_t st) {
 // PREQ: the activation rows arrive already quantized (a.qs / a.d / a.bsums, written once by k_quantize_q8_K / q8_0) and are only COPIED
 // into LDS — for NB x K beyond ~32 K values the redundant per-work-group quantization (and its 4 K bytes of fp32 reads per value row and
 // work-group) costs more than the extra launch: measured 40 us at 8 x 14336 with the quantizer inside.
-template <int TYPE, int NW, int ROWS, bool IDS = false, int NB = 1, bool PREQ = false>
+// DMA (one activation row, 16-byte-aligned block formats): the wave's weight rows are not loaded into registers round by round but requested WHOLE, by
+// LDS-DMA, in the kernel's first instructions — K = 14336 is 3.5 rounds of 64 units per row, and with two rounds of registers the stream stood still while
+// the quantizer ran ("keep >= 2 rounds of weights in flight from the first instruction").  Full-line requests (a wave instruction fetches
+// 1 KB of consecutive bytes instead of 16 bytes out of each of 64 lines), the units then read their bytes from LDS; per row the units are still added in the
+// order u = lane, lane + 64, ..: bit-identical to the register form.  Two DMA groups: the first two KB of every row go out right behind the activation
+// loads (hipcc's wait for those loads covers them: they arrive together), the rest as soon as the activations are in registers; each round of units then
+// waits (counted vmcnt) for the pieces it reads.
+template <int TYPE, int NW, int ROWS, bool IDS = false, int NB = 1, bool PREQ = false, bool DMA = false>
 __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, const float *__restrict__ x, int64_t x_row_stride) {
+    static_assert(!DMA || (NB == 1 && !IDS && !PREQ && QT<TYPE>::KQ && QT<TYPE>::BYTES % 16 == 0), "the DMA form: one row, Q4_K / Q5_K");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr bool KQ = QT<TYPE>::KQ;
     if (IDS) {
@@ -581,7 +593,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
     // quantizer can start as soon as it arrives; the weight rows (HBM) are requested right behind it and stream in under the
     // quantizer.  (Weights first made the quantizer wait for the whole HBM round trip: 5.46 vs 4.82 us cold, same-box A/B.)
     const int c_first = threadIdx.x;
-    float4 v_first[4] = {};
+    float4 v_first[4] = {}, v_second[4] = {};
     const uint8_t *wrow[ROWS];
     typename Unit<TYPE, NB>::W w0[ROWS];
     if (!PREQ && c_first < total) {
@@ -589,11 +601,37 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
 #pragma unroll
         for (int i = 0; i < 4; i++) v_first[i] = *reinterpret_cast<const float4 *>(px + 4 * i);
     }
+    if (DMA && c_first + NW * 64 < total) {                                 // (the launcher guarantees total <= 2 NW 64)
+        const float *px = x + (c_first + NW * 64) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; i++) v_second[i] = *reinterpret_cast<const float4 *>(px + 4 * i);
+    }
     asm volatile("" ::: "memory");                                          // keep the weight loads below behind the activation loads
+    // DMA form: row bytes rowb = (K / 256) blocks, np pieces of 1 KB per row (the last one clamped: its tail lanes re-fetch the row's last 16 bytes),
+    // LDS region of wave w, row r, piece i at o_w + ((w ROWS + r) np + i) KB; issue order piece-major (piece i of every row, then i + 1)
+    [[maybe_unused]] const int rowb = (K / 256) * QT<TYPE>::BYTES, np = (rowb + 1023) >> 10;
+    [[maybe_unused]] const uint32_t o_w = (uint32_t)((cdna4_gemv_fused_lds_bytes_dev<TYPE>(K) + 1023) & ~1023);
+    [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    [[maybe_unused]] auto dma_piece = [&](int i) __attribute__((always_inline)) {
+        if constexpr (DMA) {
+            const uint32_t voff = (uint32_t)min(i * 1024 + lane * 16, rowb - 16);
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const uint8_t *src = a.W + (int64_t)min((int)(blockIdx.x * NW + wave_u) * ROWS + r, a.M - 1) * a.w_row_bytes;
+                CDNA4_DMA16(voff, src, CDNA4_LDS_BASE(smem) + o_w + (uint32_t)(((wave_u * ROWS + r) * np + i) << 10));
+            }
+        }
+    };
+    if constexpr (DMA) {
+        dma_piece(0); dma_piece(min(1, np - 1));                            // group 1 (np = 1: the second is a duplicate of the first)
+        asm volatile("" : "+v"(v_first[0].x), "+v"(v_first[3].w), "+v"(v_second[0].x), "+v"(v_second[3].w));   // the activations are in registers (hipcc waits here)
+        for (int i = 2; i < np; i++) dma_piece(i);                          // group 2
+    } else {
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         wrow[r] = a.W + (int64_t)min(row0 + r, a.M - 1) * a.w_row_bytes;
         w0[r] = Unit<TYPE, NB>::load(wrow[r], min(lane, nunits - 1));
+    }
     }
     // One lane quantizes 16 consecutive values (= one bsums entry, one ds_write_b128): a superblock is 16 adjacent lanes
     // (4 butterfly rounds), a Q8_0 block 2 lanes (1 round).  The first cut (one wave per superblock, 4 values per lane,
@@ -660,6 +698,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
             *reinterpret_cast<u32x4 *>(sbs + col * nch + c * 8) = *reinterpret_cast<const u32x4 *>(a.bsums + (int64_t)sc * nch + c * 8);
         }
         for (int id = threadIdx.x; id < NB * nqd; id += NW * 64) { const int col = id / nqd, c = id % nqd; sd[col * nqd + c] = a.d[(int64_t)min(col, a.ncol - 1) * nqd + c]; }
+    } else if constexpr (DMA) {
+        if (c_first < total) quantize_chunk(c_first, v_first);
+        if (c_first + NW * 64 < total) quantize_chunk(c_first + NW * 64, v_second);
     } else {
     if (c_first < total) quantize_chunk(c_first, v_first);
     for (int id = c_first + NW * 64; id < total; id += NW * 64) {          // more chunks than threads: the remaining ones
@@ -685,10 +726,25 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
     for (int r = 0; r < ROWS; r++)
 #pragma unroll
         for (int c = 0; c < NB; c++) acc[r][c] = 0.f;
+    if constexpr (DMA) {
+        const int nissued = max(np, 2);                                     // pieces issued per row (group 1 is always two)
+        const uint8_t *wl = smem + o_w + (size_t)(wave_u * ROWS) * np * 1024;
+        for (int u = lane, rd = 0; rd * 64 < nunits; u += 64, rd++) {
+            // the round's last unit ends at byte `end` of its row: pieces [0, need) must have landed; vector-memory operations complete in issue order
+            const int ul = min(rd * 64 + 63, nunits - 1), end = (ul >> 2) * QT<TYPE>::BYTES + QT<TYPE>::BYTES;
+            const int need = min((end + 1023) >> 10, np);
+            cdna4_wait_vm_rt((nissued - max(need, np == 1 ? 2 : need)) * ROWS);
+            CDNA4_WAVE_LDS_SYNC();
+            if (u < nunits) {
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) Unit<TYPE, NB>::mac(Unit<TYPE, NB>::load(wl + (size_t)r * np * 1024, u), u, act, col, acc[r]);
+            }
+        }
+    }
     typename Unit<TYPE, NB>::W cur[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; r++) cur[r] = w0[r];
-    constexpr bool PIPE = NB <= 2;                                          // (4 and 8 columns: the second set of weight registers spills, and those forms are bound by their integer dots)
+    constexpr bool PIPE = NB <= 2 && !DMA;                                          // (4 and 8 columns: the second set of weight registers spills, and those forms are bound by their integer dots)
     if constexpr (PIPE) {
         for (int u = lane; u < nunits; u += 64) {
             typename Unit<TYPE, NB>::W nxt[ROWS];
@@ -704,7 +760,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
                 for (int r = 0; r < ROWS; r++) cur[r] = nxt[r];
             }
         }
-    } else {
+    } else if constexpr (!DMA) {
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             if (lane < nunits) Unit<TYPE, NB>::mac(cur[r], lane, act, col, acc[r]);
@@ -743,6 +799,24 @@ static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st
     // CU at M = 4096: the quantizer is paid once per CU) when that still gives every CU a work-group, else 8 x 1, else 4 x 1.
     static const int cfg_env = getenv("CDNA4_FUSED_CFG") ? atoi(getenv("CDNA4_FUSED_CFG")) : -1;
     const int cfg = cfg_env >= 0 ? cfg_env : (a.M >= 4096 ? 1 : (a.M >= 2048 ? 3 : 0));
+    if constexpr (TYPE == CDNA4_Q4_K || TYPE == CDNA4_Q5_K) {
+        // the DMA form of the 8 x 2 configuration (whole weight rows requested up front): rows of more than one round of 64 units (K > 4096), at most two
+        // activation chunks per thread (K <= 16384), activations + 16 rows within the 160 KB of LDS.  CDNA4_DECODE_DMA=0 disables it, =1 takes it for every K.
+        static const int dma_env = getenv("CDNA4_DECODE_DMA") ? atoi(getenv("CDNA4_DECODE_DMA")) : -1;
+        const int rowb = (int)(a.K / 256) * QT<TYPE>::BYTES, np = (rowb + 1023) >> 10;
+        const size_t need = ((lds + 1023) & ~(size_t)1023) + (size_t)16 * np * 1024;
+        if (cfg == 1 && dma_env != 0 && (dma_env == 1 || a.K > 4096) && a.K <= 16384 && need <= 160 * 1024 && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0)) {
+            static bool raised_[16] = {};
+            int dev_ = 0; if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 16) { (void)hipGetLastError(); dev_ = 0; }
+            if (!raised_[dev_]) {
+                if (hipFuncSetAttribute((const void *)k_gemv_q_fused<TYPE, 8, 2, false, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return cdna4_set_error_msg("gemv_q_fused: cannot raise the dynamic LDS limit"); }
+                raised_[dev_] = true;
+            }
+            hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2, false, 1, false, true>), dim3((a.M + 15) / 16), dim3(512), need, st, a, x, (int64_t)0);
+            CDNA4_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (cfg == 1) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x, (int64_t)0);
     else if (cfg == 2) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 2>), dim3((a.M + 7) / 8), dim3(256), lds, st, a, x, (int64_t)0);
     else if (cfg == 3) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 1>), dim3((a.M + 7) / 8), dim3(512), lds, st, a, x, (int64_t)0);

@@ -283,17 +283,19 @@ def test_gemm_64x128_wave_tile_kernel(gu, m, k, b, splitk, variant):
         assert np.array_equal(y, y2)                                # deterministic
 
 
-def test_gemm_auto_picks_256x128_kernel_on_huge_grids(gu):
-    """>= 2 x #CUs tiles of 256x128 (the C5-like regime): the auto path is k_gemm_kq_t64 with 256-row tiles and no K split —
-    bit-identical to asking for it explicitly, and within tolerance of the oracle on a row sample"""
+def test_gemm_auto_picks_the_large_tile_kernel_on_huge_grids(gu):
+    """256 x 256 tiles that fill the chip (the C5-like regime): the auto path is k_gemm_r8 (round 4; 32 x 256 wave tiles, no K split here) —
+    bit-identical to asking for it explicitly, within 2e-6 of k_gemm_kq_t64's 256-row form (same per-weight arithmetic, another summation order over k)
+    and within tolerance of the oracle on a row sample"""
     from ggml_amd import ops
     t, m, k, b = R.Q4_K, 16384, 256, 1024
     w = R.random_weights(t, m, k, seed=3)
     x = _x(8, b, k)
     a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
     y = ops.mul_mat(a, xd).cpu().numpy()
-    yx = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=T64_256, splitk=1).cpu().numpy()
+    yx = ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=(1 << 28) | (1 << 26), splitk=0).cpu().numpy()
     assert np.array_equal(y, yx)
+    assert R.rel_l2(y, ops.mul_mat(a, xd, path=ops.PATH_GEMM, gemm_variant=T64_256, splitk=1).cpu().numpy()) < 2e-6
     rows = np.random.default_rng(0).choice(m, 64, replace=False)
     rs = R.row_size(t, k)
     wsub = np.concatenate([w[r * rs:(r + 1) * rs] for r in rows])

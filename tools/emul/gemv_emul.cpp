@@ -12,7 +12,7 @@
 #include <vector>
 #undef __shared__
 #define __shared__                         // the kernel's only shared array is the dynamic one: `extern uint8_t smem[]` below
-__attribute__((aligned(16))) uint8_t smem[64 * 1024];
+__attribute__((aligned(16))) uint8_t smem[160 * 1024];
 
 namespace emu {
 thread_local dim3 t_threadIdx, t_blockIdx;
@@ -65,6 +65,14 @@ template <typename F> static void emu_launch(F body, dim3 grid, dim3 block) {
     if (cannot) { fprintf(stderr, "the environment cannot host the emulation\n"); exit(77); }
 }
 
+#define CDNA4_HW_OVERRIDE
+#define CDNA4_LDS_BASE(smem_) 0u
+#define CDNA4_DMA16(voff, sbase, lds_addr) emu::vm_issue(smem + (lds_addr) + 16 * lane, (sbase) + (voff))
+#define CDNA4_WAIT_VM(n) emu::vm_wait(n)
+#define cdna4_wait_vm_rt(n) emu::vm_wait(n)
+#define CDNA4_WAIT_LGKM0() ((void)0)
+#define CDNA4_WAIT_LGKM0_VISIBLE() ((void)0)
+#define CDNA4_PIN(x) ((void)0)
 #include "../../ggml_amd/csrc/gemv_q.hip"
 
 static std::vector<uint8_t> slurp(const char *p) {

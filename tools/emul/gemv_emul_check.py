@@ -21,7 +21,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 def build():
     exe = os.path.join(HERE, "gemv_emul")
     srcs = [os.path.join(HERE, "gemv_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(ROOT, "ggml_amd", "csrc", f)
-            for f in ("gemv_q.hip", "quantize_dev.h", "cdna4_common.h", "cdna4_kernels.h")]
+            for f in ("gemv_q.hip", "gemm_q_hw.h", "quantize_dev.h", "cdna4_common.h", "cdna4_kernels.h")]
     if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
         subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "ggml_amd", "csrc"),
                         "-Wno-unused-value", "-o", exe, srcs[0]], check=True, capture_output=True, timeout=600)

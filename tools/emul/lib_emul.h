@@ -22,6 +22,7 @@
 #define CDNA4_WAIT_VM_TIED1(n, a) emu::vm_wait(n)
 #define CDNA4_WAIT_VM_TIED2(n, a, b) emu::vm_wait(n)
 #define CDNA4_WAIT_VM(n) emu::vm_wait(n)
+#define cdna4_wait_vm_rt(n) emu::vm_wait(n)
 #define CDNA4_WAIT_LGKM0() ((void)0)
 #define CDNA4_WAIT_LGKM0_VISIBLE() ((void)0)
 #define CDNA4_PIN(x) ((void)0)

@@ -17,6 +17,7 @@
 #define CDNA4_WAIT_VM_TIED1(n, a) emu::vm_wait(n)
 #define CDNA4_WAIT_VM_TIED2(n, a, b) emu::vm_wait(n)
 #define CDNA4_WAIT_VM(n) emu::vm_wait(n)
+#define cdna4_wait_vm_rt(n) emu::vm_wait(n)
 #define CDNA4_WAIT_LGKM0() ((void)0)
 #define CDNA4_DMA16_LANES(voff, sbase, lds_addr, nlanes) do { if (lane < (nlanes)) emu::vm_issue(smem + (lds_addr) + 16 * lane, (sbase) + (voff)); else emu::vm_issue_done(); } while (0)
 // v_permlane32_swap through the wave's exchange buffer (all 64 lanes execute it)
