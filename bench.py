@@ -218,8 +218,8 @@ def shape_row(dev, t, m, k, b, steps):
     tf = h.flops / us / 1e6
     row = {"shape": [m, k, b], "gemm_us": round(us, 3), "gemm_tflops": round(tf, 1), "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4), "step_us": round(step_us, 3),
            "step_tflops": round(h.flops / step_us / 1e6, 1), "kernel": kernel_name(t, m, k, b), "data": how}
-    if t == Q4_K and "k_gemm_r8" in row["kernel"]:                      # same box, same data, same minute: the kernel AUTO took until round 3 (variant bit 13 = k_gemm_kq_t64)
-        h.variant = 8192
+    if t == Q4_K and "k_gemm_r8" in row["kernel"]:                      # same box, same data, same minute: the kernel AUTO took until round 3 (variant bit 13 = k_gemm_kq_t64, its own tile choice)
+        h.variant = 8192 | 7
         row["gemm_us_k_gemm_kq_t64_same_box"] = round(events_us(h.gemm_only, steps, 20), 3)
         h.variant = 0
         row["gemm_us_again"] = round(events_us(h.gemm_only, steps, 20), 3)

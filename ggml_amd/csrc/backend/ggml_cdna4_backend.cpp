@@ -278,6 +278,9 @@ static int try_fused_mul_mat(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, co
     // the residual may BE the output (ggml_add_inplace, or the graph allocator placing ADD(resid, cur) onto resid) only where the tail is applied
     // in the store that produces the element — ggml_cdna4_mul_mat_fused_residual_may_alias says for which calls that holds
     if (resid && (ggml_cdna4_mul_mat_fused_residual_may_alias((int)a->type, M, K, B) ? !alias_or_disjoint(resid, last) : mem_overlap(resid, last))) return 0;
+    // an aliased residual must be the SAME view (same row stride): the kernel library refuses any other overlap, and a refusal here would fail a graph
+    // whose nodes run fine one by one
+    if (resid && resid->data == last->data && resid->nb[1] != last->nb[1]) return 0;
     void * ws = ctx->need_ws(ggml_cdna4_mul_mat_workspace_size((int)a->type, K, B));
     if (!ws) { st = GGML_STATUS_ALLOC_FAILED; return used; }
     const int rc = ggml_cdna4_mul_mat_fused((int)a->type, a->data, (int64_t)a->nb[1], (const float *)b->data, (int64_t)(b->nb[1] / sizeof(float)),

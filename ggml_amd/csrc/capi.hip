@@ -134,7 +134,10 @@ static bool use_mmq(int type, int64_t M, int64_t K, int64_t B) {
     // at 4096^2 but 17.5 / 25.6 at 4096 x 14336 for 4 / 8 rows (mmq: 14.1 / 14.2).  Two rows stay on the GEMV everywhere.
     // (small matrices — the gpt-2 117M projections — are launch-bound either way: they take the integer path up to 64 rows, which keeps a whole
     // short prompt on the CPU's own arithmetic instead of the fp16 GEMM's 3e-4)
-    if (B >= 9) return B <= 32 || M * K <= ((int64_t)1 << 24);
+    // (measured on Q4_K / Q6_K at M = 4096, profiles/r03/batch_sweep.txt; the other formats and the 33 .. 64-row small-matrix case follow the same rule only
+    // where a sweep line covers them: the five headline formats; everything else is capped at 32 rows — ADVICE r3)
+    const bool swept = type == CDNA4_Q4_K || type == CDNA4_Q6_K || type == CDNA4_Q4_0 || type == CDNA4_Q8_0 || type == CDNA4_Q5_K;
+    if (B >= 9) return B <= 32 || (swept && M * K <= ((int64_t)1 << 24));
     return B >= 3 && M * K >= ((int64_t)1 << 25);
 }
 static int resolve_path(int type, int path, int64_t M, int64_t K, int64_t B) {
@@ -219,7 +222,8 @@ static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const floa
     // ggml_cdna4_convert_weights up front + ggml_cdna4_mul_mat on the target format (tests/test_gpu_widening.py).
     if (path == GGML_CDNA4_PATH_AUTO && cdna4_convert_weights_kmul(type) == 1) {
         const int tgt = cdna4_convert_weights_target(type);
-        if (tgt >= 0 && tgt != type && use_mmq(tgt, M, K, B)) {
+        // (from 9 rows up: below that the re-encoding pass — ~2.5x the weight bytes — costs more than the staged GEMV it would replace)
+        if (tgt >= 0 && tgt != type && B >= 9 && use_mmq(tgt, M, K, B)) {
             uint8_t *cw = (uint8_t *)cdna4_gemm_scratch(cdna4_convert_weights_bytes(type, M, K) + 256, 3);
             if (!cw) return cdna4_set_error_msg("mul_mat: cannot allocate the re-encoded weights");
             const int rc = cdna4_launch_convert_weights(type, (const uint8_t *)W, w_row_bytes, M, K, cw, (hipStream_t)stream);

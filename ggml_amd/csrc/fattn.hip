@@ -141,7 +141,10 @@ template <int KVT> __device__ __forceinline__ half8_t fa_kv_frag(const char *row
         const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
         half8_t out;
 #pragma unroll
-        for (int j = 0; j < 8; j++) out[j] = (half_t)opaque_f32(__builtin_bit_cast(float, (ww[j >> 1] >> (16 * (j & 1))) << 16));
+        for (int j = 0; j < 8; j++) {
+            const float v = __builtin_bit_cast(float, (ww[j >> 1] >> (16 * (j & 1))) << 16);
+            out[j] = (half_t)opaque_f32(v != v ? v : fminf(fmaxf(v, -65504.f), 65504.f));   // saturate at fp16's range (k_q_to_f16_dense<BF16> does the same)
+        }
         return out;
     } else {
         constexpr int BB = KVT == CDNA4_Q8_0 ? 34 : 18;

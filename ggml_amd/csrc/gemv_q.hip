@@ -800,12 +800,15 @@ static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st
     static const int cfg_env = getenv("CDNA4_FUSED_CFG") ? atoi(getenv("CDNA4_FUSED_CFG")) : -1;
     const int cfg = cfg_env >= 0 ? cfg_env : (a.M >= 4096 ? 1 : (a.M >= 2048 ? 3 : 0));
     if constexpr (TYPE == CDNA4_Q4_K || TYPE == CDNA4_Q5_K) {
-        // the DMA form of the 8 x 2 configuration (whole weight rows requested up front): rows of more than one round of 64 units (K > 4096), at most two
-        // activation chunks per thread (K <= 16384), activations + 16 rows within the 160 KB of LDS.  CDNA4_DECODE_DMA=0 disables it, =1 takes it for every K.
-        static const int dma_env = getenv("CDNA4_DECODE_DMA") ? atoi(getenv("CDNA4_DECODE_DMA")) : -1;
+        // the DMA form of the 8 x 2 configuration (whole weight rows requested up front; at most two activation chunks per thread: K <= 16384; activations +
+        // 16 rows within the 160 KB of LDS).  OPT-IN (CDNA4_DECODE_DMA=1; =2: only for K > 4096) — a measured loss on MI355X, one box, us cold / cache-warm,
+        // register form vs DMA form (gpurun_out/s9, profiles/r04/decode_ab.txt): Q4_K 4096 x 14336 11.19 / 9.19 vs 11.89 / 9.90, 4096 x 11008 9.43 / 6.72 vs
+        // 9.41 / 7.15, 4096 x 8192 7.44 / 5.29 vs 7.11 / 5.47, 4096 x 4096 4.20 / 4.21 vs 5.38 / 4.28; Q5_K 11008 x 4096 11.40 / 10.05 vs 11.12 / 8.65.  With
+        // every weight byte requested in the first instructions the kernel is no faster: the stream is not what it waits for.
+        static const int dma_env = getenv("CDNA4_DECODE_DMA") ? atoi(getenv("CDNA4_DECODE_DMA")) : 0;
         const int rowb = (int)(a.K / 256) * QT<TYPE>::BYTES, np = (rowb + 1023) >> 10;
         const size_t need = ((lds + 1023) & ~(size_t)1023) + (size_t)16 * np * 1024;
-        if (cfg == 1 && dma_env != 0 && (dma_env == 1 || a.K > 4096) && a.K <= 16384 && need <= 160 * 1024 && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0)) {
+        if (cfg == 1 && dma_env > 0 && (dma_env == 1 || a.K > 4096) && a.K <= 16384 && need <= 160 * 1024 && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0)) {
             static bool raised_[16] = {};
             int dev_ = 0; if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 16) { (void)hipGetLastError(); dev_ = 0; }
             if (!raised_[dev_]) {

@@ -291,7 +291,10 @@ __global__ __launch_bounds__(256) void k_q_to_f16_dense(const T4 a, half_t *__re
     if (i >= n) return;
     const idx4 x = unravel(i, a.ne);
     const uint8_t *row = (const uint8_t *)a.data + x.i1 * a.nb[1] + x.i2 * a.nb[2] + x.i3 * a.nb[3];
-    dst[(i / a.ne[0]) * dst_row + x.i0] = (half_t)opaque_f32(deq_elem<TYPE>(row, x.i0));     // fp16 of the fp32 VALUE to_float gives (two roundings, like the CPU)
+    float v = deq_elem<TYPE>(row, x.i0);
+    // BF16 reaches beyond fp16's range: saturate at +-65504 instead of producing inf (a finite cache stays finite, as on the CPU; NaN stays NaN) — ADVICE r3
+    if constexpr (TYPE == CDNA4_BF16) v = v != v ? v : fminf(fmaxf(v, -65504.f), 65504.f);
+    dst[(i / a.ne[0]) * dst_row + x.i0] = (half_t)opaque_f32(v);     // fp16 of the fp32 VALUE to_float gives (two roundings, like the CPU)
 }
 // F32 -> Q4_0 / Q8_0: one thread per 32-block; src rows contiguous in ne[0], dst blocks enumerated in logical order
 template <int TYPE, bool REF>
