@@ -649,6 +649,7 @@ static ggml_backend_feature g_features[] = { {"WAVE64", "1"}, {"MFMA_F16", "1"},
 static ggml_backend_feature * cdna4_get_features(ggml_backend_reg_t) { return g_features; }
 static void * cdna4_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (strcmp(name, "ggml_backend_get_features") == 0) return (void *)cdna4_get_features;
+    if (strcmp(name, "ggml_backend_cdna4_ksplit_buffer_type") == 0) return (void *)cdna4_ksplit_buffer_type;   // the K-split counterpart (no reference equivalent; ggml_cdna4_split.cpp)
     if (strcmp(name, "ggml_backend_split_buffer_type") == 0) return (void *)cdna4_split_buffer_type;      // ggml_backend_split_buffer_type_t, include/ggml-backend.h:188
     return NULL;
 }

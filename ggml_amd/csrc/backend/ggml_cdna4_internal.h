@@ -22,6 +22,7 @@ struct cdna4_lane {
     void * x = nullptr;  size_t x_bytes = 0;      // activations copied from the main device
     void * y = nullptr;  size_t y_bytes = 0;      // this shard's output rows, [B][rows] f32
     void * ws = nullptr; size_t ws_bytes = 0;     // ggml_cdna4_mul_mat workspace
+    void * ym = nullptr; size_t ym_bytes = 0;     // K split without RCCL: this shard's partial [B][M], copied to the MAIN device for the sum
 };
 
 #define CDNA4_GRAPH_SLOTS 4
@@ -58,6 +59,9 @@ struct cdna4_backend_ctx {
 // the well-known proc address "ggml_backend_split_buffer_type" (include/ggml-backend.h:188): weights whose rows (output features)
 // are sharded over the node's GPUs; tensor_split = CDNA4_MAX_DEVICES proportions (NULL / all zero: equal shares)
 ggml_backend_buffer_type_t cdna4_split_buffer_type(int main_device, const float * tensor_split);
+// "ggml_backend_cdna4_ksplit_buffer_type" (same signature; no reference counterpart): the reduction dimension K sharded instead of the rows, the partial
+// outputs summed by one RCCL all-reduce (ggml_cdna4_split.cpp)
+ggml_backend_buffer_type_t cdna4_ksplit_buffer_type(int main_device, const float * tensor_split);
 bool cdna4_buft_is_split(ggml_backend_buffer_type_t buft);
 bool cdna4_split_supports_mul_mat(const ggml_tensor * op);
 enum ggml_status cdna4_split_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst);

@@ -11,7 +11,17 @@
 // the [B][rows] result out per shard, over xGMI; the main device's shard writes straight into dst.
 // GGML_CDNA4_SPLIT_SELF=N (tests on a one-GPU box): N shards, all on the main device — every code path of the scatter / gather /
 // lane machinery runs, the peer copies become local ones.
+//
+// K-SPLIT (round 4; proc address "ggml_backend_cdna4_ksplit_buffer_type", same signature): the north star's "all-reduce on the activations".  The
+// reduction dimension K is partitioned instead of the rows: shard i holds columns [klo_i, khi_i) of EVERY row (whole 256-weight superblocks: a byte
+// range of each block-quantized row, scattered by set_tensor with one 2-D copy per shard), multiplies them with its slice of the activations — no
+// copy at all on the main device: the kernel library takes a row stride — and produces a full-size partial [B][M]; the partials are summed by ONE
+// RCCL all-reduce over xGMI (librccl loaded at run time; the main device receives straight into dst), or, where the shards share a device
+// (GGML_CDNA4_SPLIT_SELF) or RCCL is absent, by peer copies + ggml_cdna4_sum_partials in shard order.  A row-split layer followed by a K-split layer
+// needs no collective in between (the first one's output shard IS the second one's activation slice); this type is the second half of such a pair.
 #include "ggml_cdna4_internal.h"
+
+#include <dlfcn.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -20,13 +30,13 @@
 #include <vector>
 
 struct split_buft_ctx {
-    int main_device; int n_shards; bool self;
+    int main_device; int n_shards; bool self; bool ksplit;
     float bound[CDNA4_MAX_DEVICES + 1];            // cumulative row fractions, bound[0] = 0, bound[n] = 1
     int shard_dev[CDNA4_MAX_DEVICES];
     std::string name;
 };
-struct split_tensor {                              // tensor->extra
-    int n = 0;
+struct split_tensor {                              // tensor->extra; lo / hi: row range (row split) or K range (K split) of the shard
+    int n = 0; bool ksplit = false;
     int dev[CDNA4_MAX_DEVICES]; void * data[CDNA4_MAX_DEVICES]; int64_t lo[CDNA4_MAX_DEVICES], hi[CDNA4_MAX_DEVICES];
 };
 struct split_buffer_ctx { std::vector<split_tensor *> tensors; };
@@ -38,6 +48,13 @@ static int self_shards() {
 // rows [lo, hi) of shard i: fractions of the row count, rounded DOWN to the 128-row GEMM tile (the last shard takes the rest)
 static void shard_rows(const split_buft_ctx * c, int64_t nrows, int i, int64_t * lo, int64_t * hi) {
     auto edge = [&](int k) -> int64_t { if (k <= 0) return 0; if (k >= c->n_shards) return nrows; int64_t r = (int64_t)((double)nrows * c->bound[k]); r -= r % 128; return r < 0 ? 0 : (r > nrows ? nrows : r); };
+    *lo = edge(i); *hi = edge(i + 1);
+    if (*hi < *lo) *hi = *lo;
+}
+
+// K range [lo, hi) of shard i: fractions of K rounded DOWN to whole 256-weight superblocks (every format's GEMM granule; the last shard takes the rest)
+static void shard_k(const split_buft_ctx * c, int64_t K, int i, int64_t * lo, int64_t * hi) {
+    auto edge = [&](int k) -> int64_t { if (k <= 0) return 0; if (k >= c->n_shards) return K; int64_t r = (int64_t)((double)K * c->bound[k]); r -= r % 256; return r < 0 ? 0 : (r > K ? K : r); };
     *lo = edge(i); *hi = edge(i + 1);
     if (*hi < *lo) *hi = *lo;
 }
@@ -61,15 +78,17 @@ static void split_buffer_init_tensor(ggml_backend_buffer_t buffer, ggml_tensor *
     split_buffer_ctx * ctx = (split_buffer_ctx *)buffer->context;
     const split_buft_ctx * bc = (const split_buft_ctx *)buffer->buft->context;
     split_tensor * st = new split_tensor;
-    st->n = bc->n_shards;
+    st->n = bc->n_shards; st->ksplit = bc->ksplit;
     const size_t row_bytes = ggml_row_size(tensor->type, tensor->ne[0]);
+    GGML_ASSERT(!bc->ksplit || tensor->ne[0] % 256 == 0);         // K split: whole superblocks
     for (int i = 0; i < st->n; i++) {
-        shard_rows(bc, tensor->ne[1], i, &st->lo[i], &st->hi[i]);
+        if (bc->ksplit) shard_k(bc, tensor->ne[0], i, &st->lo[i], &st->hi[i]); else shard_rows(bc, tensor->ne[1], i, &st->lo[i], &st->hi[i]);
         st->dev[i] = bc->shard_dev[i]; st->data[i] = nullptr;
-        const int64_t rows = st->hi[i] - st->lo[i];
-        if (rows == 0) continue;
+        const int64_t span = st->hi[i] - st->lo[i];
+        if (span == 0) continue;
         HIP_OK(hipSetDevice(st->dev[i]));
-        HIP_OK(hipMalloc(&st->data[i], (size_t)rows * row_bytes + 256));   // slack: kernels read whole 16-byte pieces
+        const size_t bytes = bc->ksplit ? (size_t)tensor->ne[1] * ggml_row_size(tensor->type, span) : (size_t)span * row_bytes;
+        HIP_OK(hipMalloc(&st->data[i], bytes + 256));              // slack: kernels read whole 16-byte pieces
     }
     ctx->tensors.push_back(st);
     tensor->extra = st;
@@ -82,7 +101,10 @@ static void split_buffer_set_tensor(ggml_backend_buffer_t, ggml_tensor * tensor,
         const int64_t rows = st->hi[i] - st->lo[i];
         if (rows == 0) continue;
         HIP_OK(hipSetDevice(st->dev[i]));
-        HIP_OK(hipMemcpy(st->data[i], (const char *)data + st->lo[i] * row_bytes, (size_t)rows * row_bytes, hipMemcpyHostToDevice));
+        if (st->ksplit) {   // columns [lo, hi) of every row: a byte range of each block-quantized row (blocks run along K inside a row)
+            const size_t off = ggml_row_size(tensor->type, st->lo[i]), wid = ggml_row_size(tensor->type, rows);
+            HIP_OK(hipMemcpy2D(st->data[i], wid, (const char *)data + off, row_bytes, wid, (size_t)tensor->ne[1], hipMemcpyHostToDevice));
+        } else HIP_OK(hipMemcpy(st->data[i], (const char *)data + st->lo[i] * row_bytes, (size_t)rows * row_bytes, hipMemcpyHostToDevice));
     }
 }
 static void split_buffer_get_tensor(ggml_backend_buffer_t, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
@@ -93,7 +115,10 @@ static void split_buffer_get_tensor(ggml_backend_buffer_t, const ggml_tensor * t
         const int64_t rows = st->hi[i] - st->lo[i];
         if (rows == 0) continue;
         HIP_OK(hipSetDevice(st->dev[i]));
-        HIP_OK(hipMemcpy((char *)data + st->lo[i] * row_bytes, st->data[i], (size_t)rows * row_bytes, hipMemcpyDeviceToHost));
+        if (st->ksplit) {
+            const size_t off = ggml_row_size(tensor->type, st->lo[i]), wid = ggml_row_size(tensor->type, rows);
+            HIP_OK(hipMemcpy2D((char *)data + off, row_bytes, st->data[i], wid, wid, (size_t)tensor->ne[1], hipMemcpyDeviceToHost));
+        } else HIP_OK(hipMemcpy((char *)data + st->lo[i] * row_bytes, st->data[i], (size_t)rows * row_bytes, hipMemcpyDeviceToHost));
     }
 }
 static void split_buffer_clear(ggml_backend_buffer_t, uint8_t) {}
@@ -126,14 +151,14 @@ static const ggml_backend_buffer_type_i split_buft_iface = {
     /* .is_host        = */ split_buft_is_host,
 };
 
-ggml_backend_buffer_type_t cdna4_split_buffer_type(int main_device, const float * tensor_split) {
+static ggml_backend_buffer_type_t make_split_buffer_type(int main_device, const float * tensor_split, bool ksplit) {
     static std::mutex mu;
     static std::map<std::string, ggml_backend_buffer_type *> cache;     // one buffer type per distinct (main device, split)
     std::lock_guard<std::mutex> lock(mu);
     const int ndev = cdna4_reg_device_count();
     if (main_device < 0 || main_device >= ndev) return nullptr;
     split_buft_ctx c{};
-    c.main_device = main_device;
+    c.main_device = main_device; c.ksplit = ksplit;
     const int self = self_shards();
     c.self = self > 1;
     c.n_shards = c.self ? self : ndev;
@@ -143,20 +168,63 @@ ggml_backend_buffer_type_t cdna4_split_buffer_type(int main_device, const float 
     c.bound[0] = 0.f;
     for (int i = 0; i < c.n_shards; i++) { c.bound[i + 1] = c.bound[i] + w[i] / sum; c.shard_dev[i] = c.self ? main_device : i; }
     c.bound[c.n_shards] = 1.f;
-    std::string key = std::to_string(main_device) + (c.self ? "s" : "d");
+    std::string key = std::to_string(main_device) + (c.self ? "s" : "d") + (ksplit ? "k" : "r");
     for (int i = 0; i <= c.n_shards; i++) key += ":" + std::to_string(c.bound[i]);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    c.name = "CDNA4_Split";
+    c.name = ksplit ? "CDNA4_KSplit" : "CDNA4_Split";
     ggml_backend_buffer_type * buft = new ggml_backend_buffer_type{ /* .iface = */ split_buft_iface, /* .device = */ cdna4_reg_device(main_device), /* .context = */ new split_buft_ctx(c) };
     cache[key] = buft;
     return buft;
+}
+
+ggml_backend_buffer_type_t cdna4_split_buffer_type(int main_device, const float * tensor_split) { return make_split_buffer_type(main_device, tensor_split, false); }
+ggml_backend_buffer_type_t cdna4_ksplit_buffer_type(int main_device, const float * tensor_split) { return make_split_buffer_type(main_device, tensor_split, true); }
+
+// ---- RCCL, loaded at run time (the plug-in has no link-time dependency on it; absent or failing -> peer copies + ggml_cdna4_sum_partials)
+namespace {
+typedef void * nccl_comm_t;
+struct rccl_api {
+    bool tried = false, ok = false;
+    int (*CommInitAll)(nccl_comm_t *, int, const int *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;
+    const char * (*GetErrorString)(int) = nullptr;
+    nccl_comm_t comms[CDNA4_MAX_DEVICES] = {}; int ncomm = 0;
+};
+rccl_api g_rccl;
+std::mutex g_rccl_mu;
+// communicators over devices 0 .. ndev-1 (rccl.h:236 ncclCommInitAll: one process driving all GPUs of the node)
+bool rccl_ready(int ndev) {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.tried) return g_rccl.ok && g_rccl.ncomm == ndev;
+    g_rccl.tried = true;
+    if (getenv("GGML_CDNA4_NO_RCCL") && atoi(getenv("GGML_CDNA4_NO_RCCL")) != 0) return false;
+    void * h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return false;
+    g_rccl.CommInitAll = (int (*)(nccl_comm_t *, int, const int *))dlsym(h, "ncclCommInitAll");
+    g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t))dlsym(h, "ncclAllReduce");
+    g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart"); g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+    g_rccl.GetErrorString = (const char * (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.CommInitAll || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd) return false;
+    int devs[CDNA4_MAX_DEVICES];
+    for (int i = 0; i < ndev; i++) devs[i] = i;
+    int cur = 0; (void)hipGetDevice(&cur);
+    const int rc = g_rccl.CommInitAll(g_rccl.comms, ndev, devs);
+    (void)hipSetDevice(cur);
+    if (rc != 0) { fprintf(stderr, "ggml-cdna4: ncclCommInitAll failed (%s): K-split falls back to peer copies\n", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return false; }
+    g_rccl.ncomm = ndev; g_rccl.ok = true;
+    return true;
+}
 }
 
 // ---- MUL_MAT with row-split weights
 bool cdna4_split_supports_mul_mat(const ggml_tensor * op) {
     const ggml_tensor * a = op->src[0], * b = op->src[1];
     if (a->ne[2] != 1 || a->ne[3] != 1 || !a->extra) return false;                  // one matrix, initialised by init_tensor
+    if (((const split_tensor *)a->extra)->ksplit && !ggml_is_quantized(a->type)) return false;                         // K split: the block-quantized formats (whole superblocks per shard)
     if (b->type != GGML_TYPE_F32 || op->type != GGML_TYPE_F32 || !ggml_is_contiguous(b) || !ggml_is_contiguous(op)) return false;
     return ggml_cdna4_row_size((int)a->type, a->ne[0]) != 0 && ggml_cdna4_mul_mat_workspace_size((int)a->type, a->ne[0], 1) != 0;
 }
@@ -174,14 +242,104 @@ void cdna4_split_free_lanes(cdna4_backend_ctx * ctx) {
         if (l.stream) { (void)hipStreamSynchronize(l.stream); if (!l.shares_stream) (void)hipStreamDestroy(l.stream); }
         if (l.done) (void)hipEventDestroy(l.done);
         if (l.x) (void)hipFree(l.x); if (l.y) (void)hipFree(l.y); if (l.ws) (void)hipFree(l.ws);
+        if (l.ym) { (void)hipSetDevice(ctx->device); (void)hipFree(l.ym); }
         l = cdna4_lane{};
     }
     if (ctx->ev_x) { (void)hipSetDevice(ctx->device); (void)hipEventDestroy(ctx->ev_x); ctx->ev_x = nullptr; }
 }
 
+// the lane (stream, event, staging buffers) of shard i on device dev
+static cdna4_lane & lane_of(cdna4_backend_ctx * ctx, int i, int dev) {
+    cdna4_lane & l = ctx->lanes[i];
+    if (l.device < 0) {
+        l.device = dev;
+        // ONE stream per device: the kernel library keeps its split-K exchange scratch per device, so GEMM calls for one device
+        // must be stream-ordered (include/ggml_cdna4.h) — shards that share a device (GGML_CDNA4_SPLIT_SELF) share a stream
+        for (int j = 0; j < CDNA4_MAX_DEVICES && !l.stream; j++) if (j != i && ctx->lanes[j].device == dev && ctx->lanes[j].stream) { l.stream = ctx->lanes[j].stream; l.shares_stream = true; }
+        if (!l.stream) HIP_OK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+        if (dev != ctx->device) { const hipError_t e = hipDeviceEnablePeerAccess(ctx->device, 0); if (e != hipSuccess) (void)hipGetLastError(); }   // xGMI peer mapping (already enabled: fine)
+    }
+    return l;
+}
+
+// ---- MUL_MAT with K-split weights: per shard one ggml_cdna4_mul_mat over its K range -> a full-size partial [B][M]; then the sum
+static enum ggml_status ksplit_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst) {
+    const ggml_tensor * a = dst->src[0], * b = dst->src[1];
+    const split_tensor * st = (const split_tensor *)a->extra;
+    const split_buft_ctx * bc = (const split_buft_ctx *)a->buffer->buft->context;
+    const int64_t K = a->ne[0], M = a->ne[1], B = b->ne[1] * b->ne[2] * b->ne[3];
+    const size_t y_bytes = (size_t)B * M * sizeof(float);
+    HIP_OK(hipSetDevice(ctx->device));
+    if (!ctx->ev_x) HIP_OK(hipEventCreateWithFlags(&ctx->ev_x, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(ctx->ev_x, ctx->stream));
+    int active[CDNA4_MAX_DEVICES], n_active = 0; bool every_device = !bc->self;
+    for (int i = 0; i < st->n; i++) { if (st->hi[i] > st->lo[i]) active[n_active++] = i; else every_device = false; }
+    if (n_active == 0) { HIP_OK(hipMemsetAsync(dst->data, 0, y_bytes, ctx->stream)); return GGML_STATUS_SUCCESS; }
+    // one RCCL all-reduce when every device of the node holds a shard (the communicator spans them all); GGML_CDNA4_KSPLIT_RCCL=0 forces the fall-back
+    static const bool rccl_off = getenv("GGML_CDNA4_KSPLIT_RCCL") && atoi(getenv("GGML_CDNA4_KSPLIT_RCCL")) == 0;
+    const bool use_rccl = every_device && !rccl_off && rccl_ready(st->n);
+    enum ggml_status status = GGML_STATUS_SUCCESS;
+    for (int q = 0; q < n_active && status == GGML_STATUS_SUCCESS; q++) {
+        const int i = active[q], dev = st->dev[i];
+        const int64_t klo = st->lo[i], klen = st->hi[i] - st->lo[i];
+        const size_t ws_need = ggml_cdna4_mul_mat_workspace_size((int)a->type, klen, B);
+        HIP_OK(hipSetDevice(dev));
+        cdna4_lane & l = lane_of(ctx, i, dev);
+        if (!lane_buf(&l.y, &l.y_bytes, y_bytes) || !lane_buf(&l.ws, &l.ws_bytes, ws_need)) { status = GGML_STATUS_ALLOC_FAILED; break; }
+        HIP_OK(hipStreamWaitEvent(l.stream, ctx->ev_x, 0));
+        const float * xp = (const float *)b->data + klo; int64_t xs = K;        // same device: the K range of X in place (the kernel library takes a row stride)
+        if (dev != ctx->device) {                                                 // another GPU: its K columns of X over xGMI, densely packed
+            if (!lane_buf(&l.x, &l.x_bytes, (size_t)B * klen * sizeof(float))) { status = GGML_STATUS_ALLOC_FAILED; break; }
+            HIP_OK(hipMemcpy2DAsync(l.x, (size_t)klen * sizeof(float), xp, (size_t)K * sizeof(float), (size_t)klen * sizeof(float), (size_t)B, hipMemcpyDeviceToDevice, l.stream));
+            xp = (const float *)l.x; xs = klen;
+        }
+        if (ggml_cdna4_mul_mat((int)a->type, st->data[i], (int64_t)ggml_row_size(a->type, klen), xp, xs, (float *)l.y, M, M, klen, B,
+                               l.ws, l.ws_bytes, GGML_CDNA4_PATH_AUTO, 0, 0, l.stream)) { fprintf(stderr, "ggml-cdna4: K-split MUL_MAT failed: %s\n", ggml_cdna4_last_error()); status = GGML_STATUS_FAILED; break; }
+    }
+    if (status != GGML_STATUS_SUCCESS) { HIP_OK(hipSetDevice(ctx->device)); return status; }
+    if (use_rccl) {
+        // every rank sums all partials; the main device's rank receives into dst (ncclAllReduce, rccl.h:611; one call per device inside a group)
+        int rc = g_rccl.GroupStart();
+        for (int q = 0; q < n_active && rc == 0; q++) {
+            const int i = active[q], dev = st->dev[i];
+            HIP_OK(hipSetDevice(dev));
+            cdna4_lane & l = ctx->lanes[i];
+            rc = g_rccl.AllReduce(l.y, dev == ctx->device ? dst->data : l.y, (size_t)B * M, /* ncclFloat32 */ 7, /* ncclSum */ 0, g_rccl.comms[dev], l.stream);
+        }
+        const int rc2 = g_rccl.GroupEnd();
+        if (rc != 0 || rc2 != 0) { fprintf(stderr, "ggml-cdna4: ncclAllReduce failed (%s)\n", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "?"); HIP_OK(hipSetDevice(ctx->device)); return GGML_STATUS_FAILED; }
+        for (int q = 0; q < n_active; q++) { const int i = active[q]; HIP_OK(hipSetDevice(st->dev[i])); HIP_OK(hipEventRecord(ctx->lanes[i].done, ctx->lanes[i].stream)); }
+        HIP_OK(hipSetDevice(ctx->device));
+        for (int q = 0; q < n_active; q++) HIP_OK(hipStreamWaitEvent(ctx->stream, ctx->lanes[active[q]].done, 0));
+        return GGML_STATUS_SUCCESS;
+    }
+    // fall-back: the partials meet on the main device and are added there in shard order (deterministic)
+    const float * parts[CDNA4_MAX_DEVICES];
+    for (int q = 0; q < n_active; q++) {
+        const int i = active[q], dev = st->dev[i];
+        cdna4_lane & l = ctx->lanes[i];
+        parts[q] = (const float *)l.y;
+        if (dev != ctx->device) {
+            HIP_OK(hipSetDevice(ctx->device));
+            if (!lane_buf(&l.ym, &l.ym_bytes, y_bytes)) return GGML_STATUS_ALLOC_FAILED;
+            HIP_OK(hipSetDevice(dev));
+            HIP_OK(hipMemcpyPeerAsync(l.ym, ctx->device, l.y, dev, y_bytes, l.stream));
+            parts[q] = (const float *)l.ym;
+        }
+        HIP_OK(hipSetDevice(dev));
+        HIP_OK(hipEventRecord(l.done, l.stream));
+    }
+    HIP_OK(hipSetDevice(ctx->device));
+    for (int q = 0; q < n_active; q++) HIP_OK(hipStreamWaitEvent(ctx->stream, ctx->lanes[active[q]].done, 0));
+    if (ggml_cdna4_sum_partials((float *)dst->data, parts, n_active, B * M, ctx->stream)) { fprintf(stderr, "ggml-cdna4: K-split sum failed: %s\n", ggml_cdna4_last_error()); return GGML_STATUS_FAILED; }
+    return GGML_STATUS_SUCCESS;
+}
+
 enum ggml_status cdna4_split_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst) {
     const ggml_tensor * a = dst->src[0], * b = dst->src[1];
     const split_tensor * st = (const split_tensor *)a->extra;
+    if (st->ksplit) return ksplit_mul_mat(ctx, dst);
     const split_buft_ctx * bc = (const split_buft_ctx *)a->buffer->buft->context;
     const int64_t K = a->ne[0], M = a->ne[1], B = b->ne[1] * b->ne[2] * b->ne[3];       // contiguous b: all activation rows form one matrix
     const size_t x_bytes = (size_t)B * K * sizeof(float);
@@ -203,17 +361,8 @@ enum ggml_status cdna4_split_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst)
                                    ws, ctx->ws_size, GGML_CDNA4_PATH_AUTO, 0, 0, ctx->stream)) { fprintf(stderr, "ggml-cdna4: split MUL_MAT failed: %s\n", ggml_cdna4_last_error()); status = GGML_STATUS_FAILED; }
             continue;
         }
-        cdna4_lane & l = ctx->lanes[i];
         HIP_OK(hipSetDevice(dev));
-        if (l.device < 0) {
-            l.device = dev;
-            // ONE stream per device: the kernel library keeps its split-K exchange scratch per device, so GEMM calls for one device
-            // must be stream-ordered (include/ggml_cdna4.h) — shards that share a device (GGML_CDNA4_SPLIT_SELF) share a stream
-            for (int j = 0; j < CDNA4_MAX_DEVICES && !l.stream; j++) if (j != i && ctx->lanes[j].device == dev && ctx->lanes[j].stream) { l.stream = ctx->lanes[j].stream; l.shares_stream = true; }
-            if (!l.stream) HIP_OK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-            HIP_OK(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
-            if (dev != ctx->device) { const hipError_t e = hipDeviceEnablePeerAccess(ctx->device, 0); if (e != hipSuccess) (void)hipGetLastError(); }   // xGMI peer mapping (already enabled: fine)
-        }
+        cdna4_lane & l = lane_of(ctx, i, dev);
         if (!lane_buf(&l.x, &l.x_bytes, x_bytes) || !lane_buf(&l.y, &l.y_bytes, (size_t)B * rows * sizeof(float)) || !lane_buf(&l.ws, &l.ws_bytes, ws_need)) { status = GGML_STATUS_ALLOC_FAILED; break; }
         HIP_OK(hipStreamWaitEvent(l.stream, ctx->ev_x, 0));
         if (dev != ctx->device) HIP_OK(hipMemcpyPeerAsync(l.x, dev, b->data, ctx->device, x_bytes, l.stream));

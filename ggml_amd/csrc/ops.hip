@@ -485,6 +485,32 @@ int ggml_cdna4_op_binary(int op, const T4 *a, const T4 *b, const T4 *d, void *st
     return 0;
 }
 
+// dst[i] = parts[0][i] + parts[1][i] + .. in THAT order (deterministic): the reduction behind a K-split MUL_MAT whose shards share a device, and the fall-back
+// of the plug-in's RCCL all-reduce (ggml_cdna4_split.cpp).  Up to 16 parts; dst may be parts[0].
+struct sum_parts_t { const float *p[16]; };
+__global__ __launch_bounds__(256) void k_sum_partials(float *__restrict__ dst, const sum_parts_t parts, int n, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (4 * i + 3 < count) {
+        float4 s = reinterpret_cast<const float4 *>(parts.p[0])[i];
+        for (int k = 1; k < n; k++) { const float4 v = reinterpret_cast<const float4 *>(parts.p[k])[i]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        reinterpret_cast<float4 *>(dst)[i] = s;
+    } else for (int64_t e = 4 * i; e < count; e++) {                    // (the last, partial quad)
+        float s = parts.p[0][e];
+        for (int k = 1; k < n; k++) s += parts.p[k][e];
+        dst[e] = s;
+    }
+}
+int ggml_cdna4_sum_partials(float *dst, const float *const *parts, int n, int64_t count, void *stream) {
+    NEED(n >= 1 && n <= 16 && count >= 0, "sum_partials: 1 .. 16 parts");
+    NEED((((uintptr_t)dst) & 15) == 0, "sum_partials: pointers must be 16-byte aligned");
+    sum_parts_t sp{};
+    for (int k = 0; k < n; k++) { NEED(parts[k] && (((uintptr_t)parts[k]) & 15) == 0, "sum_partials: pointers must be 16-byte aligned"); sp.p[k] = parts[k]; }
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(k_sum_partials, grid1d((count + 3) / 4), dim3(256), 0, (hipStream_t)stream, dst, sp, n, count);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
 int ggml_cdna4_op_scale(const T4 *a, const T4 *d, float scale, void *stream) {
     NEED(a->type == CDNA4_F32 && d->type == CDNA4_F32 && is_contig(a) && is_contig(d) && nelem(a) == nelem(d), "scale: contiguous F32 only");
     const int64_t n = nelem(d);

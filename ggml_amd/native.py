@@ -31,6 +31,7 @@ SYMBOLS = [
     ("ggml_cdna4_quantize_q8_1", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     # supporting ops: tensors are POINTER(Tensor) descriptors
     ("ggml_cdna4_op_binary", _int, [_int, _vp, _vp, _vp, _vp]),
+    ("ggml_cdna4_sum_partials", _int, [_vp, _vp, _int, _i64, _vp]),
     ("ggml_cdna4_op_scale", _int, [_vp, _vp, C.c_float, _vp]),
     ("ggml_cdna4_op_norm", _int, [_vp, _vp, C.c_float, _int, _vp]),
     ("ggml_cdna4_op_norm_affine", _int, [_vp, _vp, _vp, _vp, C.c_float, _int, _vp]),

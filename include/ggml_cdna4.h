@@ -176,6 +176,10 @@ enum ggml_cdna4_unary_op  { GGML_CDNA4_GELU = 0, GGML_CDNA4_GELU_QUICK = 1, GGML
 /* dst = src0 (op) broadcast(src1), all F32 — ggml_compute_forward_add/sub/mul/div, ggml-cpu.c:4052-5260 */
 int ggml_cdna4_op_binary(int op, const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * src1, const ggml_cdna4_tensor * dst, void * stream);
 /* dst = src0 * scale — ggml_compute_forward_scale, ggml-cpu.c:8047-8100 */
+/* dst[i] = parts[0][i] + parts[1][i] + .. + parts[n-1][i], in that order (1 <= n <= 16; 16-byte aligned; dst may be parts[0]).
+ * The deterministic reduction of a K-split MUL_MAT's partial outputs — what ggml_cuda_op_mul_mat leaves to its caller for a row split and what
+ * the north star's "all-reduce on the activations" is when the shards share a device (the plug-in uses RCCL across devices: ggml_cdna4_split.cpp). */
+int ggml_cdna4_sum_partials(float * dst, const float * const * parts, int n, int64_t count, void * stream);
 int ggml_cdna4_op_scale(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, float scale, void * stream);
 /* LayerNorm without affine / RMSNorm over ne[0] — ggml-cpu.c:6929-6978, 7000-7046 */
 int ggml_cdna4_op_norm(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, float eps, int rms, void * stream);

@@ -127,6 +127,20 @@ int main(int argc, char ** argv) {
     const std::vector<float> y_cpu = run_mul_mat(cpu, ggml_backend_get_default_buffer_type(cpu), type, M, K, B, wq, x, NULL);
     const bool roundtrip = w_back == wq;
     const bool same_as_plain = memcmp(y_split.data(), y_plain.data(), y_plain.size() * 4) == 0;
+    // ---- K split (the plug-in's own proc address; quantized types with whole superblocks per shard): partial products over K ranges + their sum
+    //      (RCCL all-reduce across devices, ggml_cdna4_sum_partials where the shards share a device)
+    double ks_vs_cpu = -1, ks_vs_plain = -1; bool ks_roundtrip = false, ks_repeat = false;
+    split_fn get_ksplit = (split_fn)ggml_backend_reg_get_proc_address(reg, "ggml_backend_cdna4_ksplit_buffer_type");
+    if (get_ksplit && ggml_is_quantized(type) && K % 256 == 0) {
+        ggml_backend_buffer_type_t kbuft = get_ksplit(0, NULL);
+        if (!kbuft || !ggml_backend_dev_supports_buft(dev, kbuft) || ggml_backend_buft_is_host(kbuft)) { fprintf(stderr, "K-split buffer type rejected\n"); return 1; }
+        std::vector<uint8_t> kw_back;
+        const std::vector<float> y_k = run_mul_mat(gpu, kbuft, type, M, K, B, wq, x, &kw_back);
+        const std::vector<float> y_k2 = run_mul_mat(gpu, kbuft, type, M, K, B, wq, x, NULL);
+        ks_roundtrip = kw_back == wq;
+        ks_repeat = memcmp(y_k.data(), y_k2.data(), y_k.size() * 4) == 0;
+        ks_vs_cpu = rel_l2(y_k, y_cpu); ks_vs_plain = rel_l2(y_k, y_plain);
+    }
 
     // ---- async copies + events between two backends (streams) of the device
     bool async_ok = true;
@@ -209,7 +223,8 @@ int main(int argc, char ** argv) {
         }
     }
     ggml_backend_dev_props props; ggml_backend_dev_get_props(dev, &props);
-    printf("{\"type\":\"%s\",\"M\":%lld,\"K\":%lld,\"B\":%lld,\"split_vs_cpu_rel_l2\":%.3e,\"plain_vs_cpu_rel_l2\":%.3e,\"split_vs_plain_rel_l2\":%.3e,\"split_bit_identical_to_plain\":%s,"
+    printf("{\"ksplit_vs_cpu_rel_l2\":%.3e,\"ksplit_vs_plain_rel_l2\":%.3e,\"ksplit_set_get_roundtrip\":%s,\"ksplit_deterministic\":%s,", ks_vs_cpu, ks_vs_plain, ks_roundtrip ? "true" : "false", ks_repeat ? "true" : "false");
+    printf("\"type\":\"%s\",\"M\":%lld,\"K\":%lld,\"B\":%lld,\"split_vs_cpu_rel_l2\":%.3e,\"plain_vs_cpu_rel_l2\":%.3e,\"split_vs_plain_rel_l2\":%.3e,\"split_bit_identical_to_plain\":%s,"
            "\"set_get_roundtrip\":%s,\"graph_replay_ok\":%s,\"graph_replay_worst_rel_l2\":%.3e,\"async_ok\":%s,\"host_buffer_ok\":%s,\"caps_async\":%s,\"caps_host_buffer\":%s,\"caps_events\":%s}\n",
            ggml_type_name(type), (long long)M, (long long)K, (long long)B, rel_l2(y_split, y_cpu), rel_l2(y_plain, y_cpu), rel_l2(y_split, y_plain), same_as_plain ? "true" : "false",
            roundtrip ? "true" : "false", replay_ok ? "true" : "false", replay_worst, async_ok ? "true" : "false", host_ok ? "true" : "false", props.caps.async ? "true" : "false", props.caps.host_buffer ? "true" : "false", props.caps.events ? "true" : "false");

@@ -46,6 +46,31 @@ def test_split_buffer_type_mul_mat(type_, m, k, b, shards):
     assert j["caps_async"] is True and j["caps_host_buffer"] is True and j["caps_events"] is True
 
 
+@pytest.mark.parametrize("shards,rccl", [(0, "1"), (0, "0"), (2, "1"), (8, "1"), (3, "1")])
+@pytest.mark.parametrize("type_,m,k,b", [("q4_K", 4096, 4096, 512), ("q4_K", 1000, 2048, 1), ("q4_0", 2048, 1024, 33), ("q6_K", 640, 512, 7), ("q8_0", 300, 256, 130), ("q5_K", 4096, 1024, 64)])
+def test_ksplit_buffer_type_mul_mat(type_, m, k, b, shards, rccl):
+    """the K-split buffer type ("ggml_backend_cdna4_ksplit_buffer_type": the north star's all-reduce variant): columns [klo, khi) of
+    every row per shard (2-D scatter / gather of byte ranges of the block rows: whole-tensor round trip), one ggml_cdna4_mul_mat per shard on ITS slice of
+    the activations, the partial [B][M] outputs summed — by the RCCL all-reduce when every device holds a shard (shards = 0 on a one-GPU box: a
+    communicator of one rank, the plumbing a node would run; rccl = "0": the peer-copy + ggml_cdna4_sum_partials fall-back), by the in-order sum where the
+    shards share the device (2 / 8 / 3 slices; 3 does not divide the superblock count evenly; K = 256 leaves all but one shard empty).  Against the
+    CPU backend and the unsplit product; deterministic."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    env_before = os.environ.get("GGML_CDNA4_KSPLIT_RCCL")
+    os.environ["GGML_CDNA4_KSPLIT_RCCL"] = rccl
+    try:
+        j = _run(type_, m, k, b, shards)
+    finally:
+        if env_before is None:
+            os.environ.pop("GGML_CDNA4_KSPLIT_RCCL", None)
+        else:
+            os.environ["GGML_CDNA4_KSPLIT_RCCL"] = env_before
+    assert j["ksplit_set_get_roundtrip"] is True and j["ksplit_deterministic"] is True, j
+    assert 0 <= j["ksplit_vs_cpu_rel_l2"] < (1e-3 if b > 8 else 1e-5), j
+    assert j["ksplit_vs_plain_rel_l2"] < (5e-4 if b > 8 else 2e-6), j   # GEMM path: per-shard fp16 rounding of other partial sums; GEMV: fp32 order only
+
+
 @pytest.mark.parametrize("type_", ["q4_K", "q4_0", "q6_K"])
 def test_unchanged_graph_is_replayed_from_a_hip_graph(type_):
     """an MLP block (NORM, MUL, ADD, MUL_MAT, ADD, GELU, MUL_MAT, ADD, ADD) computed six times with changing inputs, for 1 and for 96
