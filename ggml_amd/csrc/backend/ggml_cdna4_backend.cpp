@@ -201,6 +201,7 @@ static void cdna4_backend_free(ggml_backend_t backend) {
     (void)hipStreamSynchronize(ctx->stream);
     cdna4_split_free_lanes(ctx);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "ggml-cdna4: %s: %d HIP-graph captures, %d replays\n", ctx->name.c_str(), ctx->n_graph_captures, ctx->n_graph_launches);
+    if (getenv("GGML_CDNA4_STATS") && (ctx->n_ksplit_rccl || ctx->n_ksplit_sum)) fprintf(stderr, "ggml-cdna4: %s: K-split MUL_MAT: %d RCCL all-reduces, %d in-order sums\n", ctx->name.c_str(), ctx->n_ksplit_rccl, ctx->n_ksplit_sum);
     for (auto & gs : ctx->graph_slots) if (gs.exec) (void)hipGraphExecDestroy(gs.exec);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     if (ctx->ws) (void)hipFree(ctx->ws);

@@ -44,6 +44,7 @@ struct cdna4_backend_ctx {
     uint64_t ws_gen = 0;
     bool graphs_off = false;                                  // a capture failed once: stay on plain launches
     int n_graph_launches = 0, n_graph_captures = 0;           // (statistics, printed at free under GGML_CDNA4_STATS)
+    int n_ksplit_rccl = 0, n_ksplit_sum = 0;                  // K-split MUL_MATs reduced by an RCCL all-reduce / by the in-order sum
     void * need_ws(size_t n) {
         if (n <= ws_size) return ws;
         HIP_OK(hipStreamSynchronize(stream));

@@ -312,6 +312,7 @@ static enum ggml_status ksplit_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * ds
         for (int q = 0; q < n_active; q++) { const int i = active[q]; HIP_OK(hipSetDevice(st->dev[i])); HIP_OK(hipEventRecord(ctx->lanes[i].done, ctx->lanes[i].stream)); }
         HIP_OK(hipSetDevice(ctx->device));
         for (int q = 0; q < n_active; q++) HIP_OK(hipStreamWaitEvent(ctx->stream, ctx->lanes[active[q]].done, 0));
+        ctx->n_ksplit_rccl++;
         return GGML_STATUS_SUCCESS;
     }
     // fall-back: the partials meet on the main device and are added there in shard order (deterministic)
@@ -332,6 +333,7 @@ static enum ggml_status ksplit_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * ds
     }
     HIP_OK(hipSetDevice(ctx->device));
     for (int q = 0; q < n_active; q++) HIP_OK(hipStreamWaitEvent(ctx->stream, ctx->lanes[active[q]].done, 0));
+    ctx->n_ksplit_sum++;
     if (ggml_cdna4_sum_partials((float *)dst->data, parts, n_active, B * M, ctx->stream)) { fprintf(stderr, "ggml-cdna4: K-split sum failed: %s\n", ggml_cdna4_last_error()); return GGML_STATUS_FAILED; }
     return GGML_STATUS_SUCCESS;
 }

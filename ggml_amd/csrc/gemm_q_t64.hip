@@ -2,6 +2,7 @@
 // Replaces, for Q4_K at B > 8, what ggml_compute_forward_mul_mat does after the activations are quantized
 // (/root/reference/src/ggml-cpu/ggml-cpu.c:7510-7605).
 #include "gemm_q_common.h"
+#include <stdlib.h>
 #include "gemm_q_hw.h"
 #include "gemm_kq_t64.inc"
 
@@ -74,7 +75,17 @@ int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expe
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = 1;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = a.B / 128;
     p.tile_expert = tile_expert; p.row_dst = row_dst; p.w_expert_bytes = w_expert_bytes;
-    hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, true>), dim3(p.tiles_m * p.tiles_b), dim3(512), 0, st, p);
+    // K split in two with the TICKETED sum (the last of a tile's two work-groups to arrive adds both partial tiles, in the order ks = 0, 1, and stores): the
+    // grouped grid is a few hundred 30-us tiles on 256 CUs — 384 of them take two rounds, 768 halves take three rounds of half the length (8 x 2 x 512 x 4096^2:
+    // 85 -> 7x us, profiles/r04).  CDNA4_MOE_SPLITK=1 keeps the unsplit launch.
+    static const int sk_env = getenv("CDNA4_MOE_SPLITK") ? atoi(getenv("CDNA4_MOE_SPLITK")) : 0;
+    const int ntiles = p.tiles_m * p.tiles_b, cus = cdna4_gemm_cu_count();
+    if (sk_env != 1 && a.K / 256 >= 4 && ntiles * 2 > cus && (size_t)ntiles * 8 <= 32768) {
+        const size_t pbytes = (size_t)ntiles * 2 * 8 * 16384, fbytes = 65536;
+        char *sc = (char *)cdna4_gemm_scratch(fbytes + pbytes, 2);
+        if (sc) { p.splitk = 2; p.tune = 2; p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes); }
+    }
+    hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, true>), dim3(p.tiles_m * p.tiles_b * p.splitk), dim3(512), 0, st, p);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

@@ -524,6 +524,18 @@ def test_whole_library_mul_mat_id_on_the_cpu(name, t):
         assert r < 1e-5, (name, n_b, n_tok, r)
 
 
+@pytest.mark.parametrize("m,k,ne,nu,nb,nt", [(130, 1024, 3, 2, 2, 70), (256, 2048, 4, 2, 1, 40)])
+def test_whole_library_grouped_mul_mat_id_with_the_ticketed_k_split_on_the_cpu(m, k, ne, nu, nb, nt):
+    """the grouped Q4_K launch where its tiles outnumber (a pretend chip of 2) CUs: every tile is computed by TWO work-groups over half of K each; the
+    last one to arrive adds both partial tiles in the order ks = 0, 1 and stores (nobody waits: the tiles need not be co-resident); ticket counters
+    back at zero afterwards (the next call of the same process — the second size — starts from them)"""
+    mod = _emul_module("lib_emul_check")
+    r = mod.mul_mat_id(12, m, k, ne, nu, nb, nt, seed=5, cus=2, timeout=900)
+    if r is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert r < 1e-3, r
+
+
 @pytest.mark.parametrize("name,t", LIB_TYPES)
 def test_whole_library_stock_harness_shapes_on_the_cpu(name, t):
     """the shapes of the reference's test-backend-ops MUL_MAT sweep (m = 16, k = 256, n = 1 / 9 / 16: tests/test-backend-ops.cpp:4005-4081) through the

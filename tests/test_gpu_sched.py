@@ -29,6 +29,7 @@ def _run(type_, m, k, b, shards):
     j = json.loads(r.stdout.strip().splitlines()[-1])
     import re
     j["graph_captures_replays"] = [[int(a), int(b)] for a, b in re.findall(r"(\d+) HIP-graph captures, (\d+) replays", r.stderr)]
+    j["ksplit_rccl_sums"] = [[int(a), int(b)] for a, b in re.findall(r"K-split MUL_MAT: (\d+) RCCL all-reduces, (\d+) in-order sums", r.stderr)]
     os.makedirs(os.path.join(R.ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(R.ROOT, "gpurun_out", "split_report.jsonl"), "a") as f:
         f.write(json.dumps(dict(j, shards=shards)) + "\n")
@@ -66,6 +67,12 @@ def test_ksplit_buffer_type_mul_mat(type_, m, k, b, shards, rccl):
             os.environ.pop("GGML_CDNA4_KSPLIT_RCCL", None)
         else:
             os.environ["GGML_CDNA4_KSPLIT_RCCL"] = env_before
+    red = j["ksplit_rccl_sums"]
+    assert red and sum(a + b for a, b in red) >= 4, j                 # two graphs x two computes went through the K-split path
+    if shards == 0 and rccl == "1":
+        assert sum(a for a, _ in red) >= 4 and sum(b for _, b in red) == 0, j      # the RCCL communicator did the reduction (one rank on this box)
+    else:
+        assert sum(a for a, _ in red) == 0, j
     assert j["ksplit_set_get_roundtrip"] is True and j["ksplit_deterministic"] is True, j
     assert 0 <= j["ksplit_vs_cpu_rel_l2"] < (1e-3 if b > 8 else 1e-5), j
     assert j["ksplit_vs_plain_rel_l2"] < (5e-4 if b > 8 else 2e-6), j   # GEMM path: per-shard fp16 rounding of other partial sums; GEMV: fp32 order only
