@@ -57,6 +57,7 @@ int ggml_cdna4_api_version(void) { return GGML_CDNA4_API_VERSION; }
 void ggml_cdna4_debug_trace(void *device_buffer) { cdna4_debug_trace = device_buffer; }
 uint64_t ggml_cdna4_scratch_generation(void) { return cdna4_scratch_generation(); }
 const char *ggml_cdna4_last_error(void) { return g_err; }
+int ggml_cdna4_set_shared_device(int shared) { return cdna4_gemm_set_shared_device(shared); }
 int ggml_cdna4_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 int ggml_cdna4_set_device(int device) { hipError_t e = hipSetDevice(device); return e == hipSuccess ? 0 : cdna4_set_error(e, __FILE__, __LINE__); }
 

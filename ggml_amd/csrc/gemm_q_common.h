@@ -493,6 +493,9 @@ template <> struct WStage<CDNA4_Q6_KS, 2> { static constexpr int NPH = 9; __devi
 void *cdna4_gemm_scratch(size_t bytes, int kind);      // per-device scratch, zero-filled when (re)allocated; kind 0: split-K exchange, 1: repacked weights
 int cdna4_gemm_cu_count();
 int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st);     // gemm_q_t64.hip: 64(m) x 128(b) wave tiles; tm 0 / 128 / 256, splitk 0 / 1 / 2
+int cdna4_gemm_shared_device();                         // 1: the AUTO routes must not choose an exchange that spins on a co-resident partner (gemm_q_mfma.hip)
+int cdna4_gemm_set_shared_device(int shared);
+int cdna4_gemm_coresident_cus();                        // CUs that may be assumed to hold a grid all at once: the device's, or 0 in shared mode
 bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a);                                     // gemm_q_lds.hip: weights dequantized into fp16 LDS tiles, 256-wide activation tile
 int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st, int form = 0);     //   tm 0 / 128 / 256, splitk 0 = choose; form 1 = k_gemm_w4 (one wave per SIMD); form 2 = k_gemm_r8 (32 x 256 wave tiles)
 bool cdna4_gemm_r8_preferred(const cdna4_gemm_args &a);                                      //   AUTO takes k_gemm_r8 for this call (large grids of 256 x 256 tiles)

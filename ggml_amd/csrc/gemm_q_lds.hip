@@ -23,7 +23,7 @@ bool cdna4_gemm_r8_preferred(const cdna4_gemm_args &a) {
     if (off || !cdna4_gemm_lds_supported(a)) return false;
     const int cus = cdna4_gemm_cu_count(), ntiles = ((a.M + 255) / 256) * ((a.B + 255) / 256), nsb = a.K / 256;
     if (ntiles * 2 < cus) return false;
-    const int s = (ntiles * 2 <= cus && nsb >= 4) ? 2 : 1;              // what cdna4_launch_gemm_lds() will choose (split-K = 2 needs two superblocks per work-group)
+    const int s = (ntiles * 2 <= cdna4_gemm_coresident_cus() && nsb >= 4) ? 2 : 1;      // what cdna4_launch_gemm_lds() will choose (its reduce-scatter spins: co-resident grids only)
     const int wgs = ntiles * s, rounds = (wgs + cus - 1) / cus;
     return wgs * 10 >= rounds * cus * 9;                                // whole rounds of work-groups (>= 90 % of the last one): the tiles are large
 }
@@ -43,7 +43,7 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     const int nfr = form == 2 ? 8 : form == 1 ? (tm == 256 ? 16 : 8) : (tm == 256 ? 8 : 4), nwv = form == 1 ? 4 : 8;
     if (splitk <= 0) {
         splitk = 1;
-        for (int s = 2; s <= 8; s *= 2) if (ntiles * s <= cus && nsb >= 2 * s) splitk = s;
+        for (int s = 2; s <= 8; s *= 2) if (ntiles * s <= cdna4_gemm_coresident_cus() && nsb >= 2 * s) splitk = s;
     }
     if (splitk < 1 || nfr % splitk || (splitk > 1 && ntiles * splitk > cus) || nsb < splitk) return cdna4_set_error_msg("gemm_lds: split-K must divide the wave's fragments, leave a superblock per work-group and keep every work-group resident");
     gemm_params p{};

@@ -450,6 +450,20 @@ static int cu_count() {                                            // of the CUR
 
 void *cdna4_gemm_scratch(size_t bytes, int kind) { return get_scratch(bytes, kind); }
 int cdna4_gemm_cu_count() { return cu_count(); }
+// The split-K exchanges that SPIN on a partner work-group (the hand-off of k_gemm_kq_t64 / the 128 x 128-tile kernels, k_gemm_r8's reduce-scatter) are only
+// chosen while every work-group of the grid is resident at once — true when the caller owns the device, not when another process or stream holds CUs
+// (a starved partner would run into the bounded spin and poison the tile with NaN).  ggml_cdna4_set_shared_device(1) (or GGML_CDNA4_SHARED_DEVICE=1) makes
+// the AUTO routes assume NO co-residency: no spinning exchange is ever chosen; small grids take the ticketed split (the last work-group to arrive sums,
+// nobody waits) or no split.  VERDICT r3 item 7(d).
+static std::atomic<int> g_shared_device{-1};
+int cdna4_gemm_shared_device() {
+    int v = g_shared_device.load(std::memory_order_relaxed);
+    if (v < 0) { v = (getenv("GGML_CDNA4_SHARED_DEVICE") && atoi(getenv("GGML_CDNA4_SHARED_DEVICE")) != 0) ? 1 : 0; g_shared_device.store(v, std::memory_order_relaxed); }
+    return v;
+}
+int cdna4_gemm_set_shared_device(int shared) { const int old = cdna4_gemm_shared_device(); g_shared_device.store(shared ? 1 : 0, std::memory_order_relaxed); return old; }
+int cdna4_gemm_coresident_cus() { return cdna4_gemm_shared_device() ? 0 : cu_count(); }
+static int co_cus() { return cdna4_gemm_coresident_cus(); }
 
 // Route probe (the tail predictor must not be a hand-kept copy of the routing): cdna4_gemm_q_fuses_tail() runs the SAME routing code with the
 // probe armed; every route ends in ROUTE_END(does this kernel apply a.epi in its store?) in front of its first side effect (scratch, zero-fill, launch).
@@ -465,9 +479,9 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     p.partial = nullptr; p.flags = nullptr;
     p.epi = a.epi;                                                        // gemm_w8_epilogue.inc applies it in the tile's store (not on the atomic-sum path)
     const int ntiles = p.tiles_m * p.tiles_b;
-    ROUTE_END(splitk == 1 || (splitk == 2 && ntiles * 2 <= cu_count()));
-    if (splitk > 2 || (splitk == 2 && ntiles * 2 > cu_count())) p.epi = cdna4_epilogue{};
-    if (splitk == 2 && ntiles * 2 <= cu_count()) {                    // both halves of every tile are resident at once: hand-off
+    ROUTE_END(splitk == 1 || (splitk == 2 && ntiles * 2 <= co_cus()));
+    if (splitk > 2 || (splitk == 2 && ntiles * 2 > co_cus())) p.epi = cdna4_epilogue{};
+    if (splitk == 2 && ntiles * 2 <= co_cus()) {                    // both halves of every tile are resident at once: hand-off
         // exchange slots after a FIXED 64-KB flag area (so that no shape's slots ever overlay another shape's flags).  A flag is
         // non-zero only between its writer's publication and its reader's reset inside one launch: no per-launch state on the
         // host, so the launch is graph-capturable once the scratch exists.
@@ -561,12 +575,12 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         // auto: at most 2.  Two fp32 contributions added to a zeroed output are order-independent (a+b == b+a), so the
         // result stays deterministic; deeper splits (atomic sums of >2 terms) are opt-in only.
         const int tiles = ((a.M + 127) / 128) * ((a.B + (wide ? 127 : 63)) / (wide ? 128 : 64));
-        if (variant & 16) splitk = (tiles * 2 <= cu_count() && kunits % 2 == 0 && kunits >= 4) ? 2 : 1;   // hand-off split: only if co-resident
+        if (variant & 16) splitk = (tiles * 2 <= co_cus() && kunits % 2 == 0 && kunits >= 4) ? 2 : 1;   // hand-off split: only if co-resident
         else splitk = 1;
         // An ODD number of superblocks — K = 11008 = 43 x 256, BASELINE configs[2] — also takes the hand-off split: its two
         // work-groups get sb_split / total - sb_split superblocks (22 / 21), which the exchange was written for (launch_w8:
         // p.sb_split).  Measured on MI355X (round-1 driver run): rel-L2 7.2e-7 vs the unsplit kernel, 59.7 vs 69.6 us.
-        if ((variant & 16) && wlds && QT<TYPE>::KQ && tiles * 2 <= cu_count() && (kunits & 1) && kunits >= 7) { splitk = 2; uneven = true; }
+        if ((variant & 16) && wlds && QT<TYPE>::KQ && tiles * 2 <= co_cus() && (kunits & 1) && kunits >= 7) { splitk = 2; uneven = true; }
     }
     if constexpr (TYPE == CDNA4_Q4_K) {
         // bit13 = k_gemm_kq_t64 (gemm_q_t64.hip: 64(m) x 128(b) wave tiles); bit14 / bit15 force its 128- / 256-row tile
@@ -591,7 +605,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
             constexpr int ST_ = TYPE == CDNA4_Q4_0 ? CDNA4_Q4_0S : (TYPE == CDNA4_Q8_0 ? CDNA4_Q8_0S : CDNA4_Q6_KS);
             const int nsb = a.K / 256, tiles = ((a.M + 127) / 128) * ((a.B + 127) / 128);
             int sk = a.splitk;
-            if (sk <= 0) sk = (tiles * 2 <= cu_count() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
+            if (sk <= 0) sk = (tiles * 2 <= co_cus() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
             if (sk >= 1 && nsb % sk == 0 && nsb / sk >= 3) return launch_w8<ST_>(a, sk, 65, st);
         }
         if (a.variant <= 0 && a.K % 256 == 0) {
@@ -600,7 +614,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
             if (g_probe.active) {                                        // (the same terminal, without the re-layout pass in front of it)
                 const int tiles = ((a.M + 127) / 128) * ((a.B + 127) / 128);
                 int sk = a.splitk;
-                if (sk <= 0) sk = (tiles * 2 <= cu_count() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
+                if (sk <= 0) sk = (tiles * 2 <= co_cus() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
                 if (sk < 1 || nsb % sk) return 0;
                 return launch_w8<RT>(a, sk, 64, st);
             }
@@ -614,7 +628,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
             cdna4_gemm_args r = a; r.W = rw; r.w_row_bytes = (int64_t)nsb * QT<RT>::BYTES;
             const int tiles = ((a.M + 127) / 128) * ((a.B + 127) / 128);
             int sk = a.splitk;
-            if (sk <= 0) sk = (tiles * 2 <= cu_count() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
+            if (sk <= 0) sk = (tiles * 2 <= co_cus() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
             if (sk < 1 || nsb % sk) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
             return launch_w8<RT>(r, sk, 64, st);
         }

@@ -20,8 +20,10 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     const int tiles_m = (a.M + tm - 1) / tm, ntiles = tiles_m * tiles_b;
     // split-K: 2 = the hand-off between the two co-resident work-groups of a tile; 4 / 8 = deep split for grids far below the chip
     // (a few activation rows over a tall matrix), every work-group >= 2 superblocks, summed in fixed order by the last one to arrive
+    bool ticketed2 = false;                                              // split in two with the ticketed sum instead of the (spinning) hand-off
     if (splitk <= 0) {
         splitk = (ntiles * 2 <= cus && nsb >= 2) ? 2 : 1;
+        if (splitk == 2 && cdna4_gemm_shared_device()) { if (tm == 128) ticketed2 = true; else splitk = 1; }     // shared device: nobody may wait for a partner
         if (tm == 128 && ntiles * 4 <= cus && nsb >= 8) splitk = 4;
         if (tm == 128 && ntiles * 8 <= cus && nsb >= 16) splitk = 8;
     }
@@ -44,6 +46,7 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
         if (!sc) return cdna4_set_error_msg("gemm_t64: cannot allocate split-K scratch");
         p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
         p.sb_split = (nsb + 1) / 2;
+        if (ticketed2) p.tune = 2;
         const int nb = ntiles * 2;                                                 // partners share an XCD iff the XCD-aware remap is active and
         p.xchg_l2 = (splitk == 2 && (nb & 7) == 0 && ((nb >> 3) % (tiles_b * 2)) == 0) ? 1 : 0;   // each XCD's slice holds whole (tile_b x ks) groups
     }
@@ -75,12 +78,13 @@ int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expe
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = 1;
     p.tiles_m = (a.M + 127) / 128; p.tiles_b = a.B / 128;
     p.tile_expert = tile_expert; p.row_dst = row_dst; p.w_expert_bytes = w_expert_bytes;
-    // K split in two with the TICKETED sum (the last of a tile's two work-groups to arrive adds both partial tiles, in the order ks = 0, 1, and stores): the
-    // grouped grid is a few hundred 30-us tiles on 256 CUs — 384 of them take two rounds, 768 halves take three rounds of half the length (8 x 2 x 512 x 4096^2:
-    // 85 -> 7x us, profiles/r04).  CDNA4_MOE_SPLITK=1 keeps the unsplit launch.
-    static const int sk_env = getenv("CDNA4_MOE_SPLITK") ? atoi(getenv("CDNA4_MOE_SPLITK")) : 0;
+    // K split in two with the TICKETED sum (the last of a tile's two work-groups to arrive adds both partial tiles, in the order ks = 0, 1, and stores):
+    // OPT-IN (CDNA4_MOE_SPLITK=2) — a measured loss: the grouped grid is 384 30-us tiles on 256 CUs (two rounds) and 768 halves would be three rounds of half
+    // the length, but every half tile also parks 64 KB write-through and the last arrival reads its partner's: 8 x 2 x 512 x 4096^2 on one MI355X box,
+    // 82.0 us unsplit vs 96.4 us split (gpurun_out/s11, profiles/r04/moe_ab.txt).
+    static const int sk_env = getenv("CDNA4_MOE_SPLITK") ? atoi(getenv("CDNA4_MOE_SPLITK")) : 1;
     const int ntiles = p.tiles_m * p.tiles_b, cus = cdna4_gemm_cu_count();
-    if (sk_env != 1 && a.K / 256 >= 4 && ntiles * 2 > cus && (size_t)ntiles * 8 <= 32768) {
+    if (sk_env == 2 && a.K / 256 >= 4 && ntiles * 2 > cus && (size_t)ntiles * 8 <= 32768) {
         const size_t pbytes = (size_t)ntiles * 2 * 8 * 16384, fbytes = 65536;
         char *sc = (char *)cdna4_gemm_scratch(fbytes + pbytes, 2);
         if (sc) { p.splitk = 2; p.tune = 2; p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes); }

@@ -59,6 +59,11 @@ enum ggml_cdna4_path {
 int          ggml_cdna4_api_version(void);
 const char * ggml_cdna4_last_error(void);                 /* thread-local, never NULL */
 int          ggml_cdna4_device_count(void);               /* number of visible HIP devices (0 if none) */
+/* 1: other work may hold CUs of this device while our kernels run (another process, another stream): the AUTO routes then never choose a split-K
+ * exchange that SPINS on a co-resident partner work-group (k_gemm_kq_t64's hand-off, k_gemm_r8's reduce-scatter, the 128x128-tile kernels' hand-off) —
+ * small grids take the ticketed split (the last work-group to arrive sums; nobody waits) or no split: slower at M = 4096, never a timed-out exchange.
+ * 0 (default, or GGML_CDNA4_SHARED_DEVICE unset): the caller owns the device, as ggml_backend_sched does for its streams.  Returns the previous value. */
+int          ggml_cdna4_set_shared_device(int shared);
 int          ggml_cdna4_set_device(int device);
 /* profiling hook (tools/microbench/gemm_bench only): a 64 KiB device buffer makes the 8-wave GEMM record per-phase
  * s_memtime stamps of its first work-group; NULL (default) selects the uninstrumented kernel */

@@ -530,7 +530,11 @@ def test_whole_library_grouped_mul_mat_id_with_the_ticketed_k_split_on_the_cpu(m
     last one to arrive adds both partial tiles in the order ks = 0, 1 and stores (nobody waits: the tiles need not be co-resident); ticket counters
     back at zero afterwards (the next call of the same process — the second size — starts from them)"""
     mod = _emul_module("lib_emul_check")
-    r = mod.mul_mat_id(12, m, k, ne, nu, nb, nt, seed=5, cus=2, timeout=900)
+    os.environ["CDNA4_MOE_SPLITK"] = "2"                             # (opt-in: a measured loss on MI355X, gemm_q_t64.hip)
+    try:
+        r = mod.mul_mat_id(12, m, k, ne, nu, nb, nt, seed=5, cus=2, timeout=900)
+    finally:
+        os.environ.pop("CDNA4_MOE_SPLITK", None)
     if r is None:
         pytest.skip("the environment cannot host the emulation")
     assert r < 1e-3, r

@@ -520,3 +520,41 @@ def test_mul_mat_id_grouped_prefill(gu, name, t, n_expert, n_used, n_b_is_one, n
     torch.cuda.synchronize()
     ob = out.cpu().numpy()
     assert (ob[3, 0] == -77.0).all() and np.array_equal(ob[3, 1:], y[3, 1:]) and np.array_equal(ob[4], y[4])
+
+def test_shared_device_mode_never_spins_and_agrees(gu):
+    """GGML_CDNA4_SHARED_DEVICE=1 (ggml_cdna4_set_shared_device): the AUTO routes choose no split-K exchange that waits for a co-resident partner —
+    k_gemm_kq_t64 takes the ticketed split in two at M = 4096 (uneven for K = 11008), the large-grid shapes drop k_gemm_r8's split, the 128 x 128-tile
+    kernels run unsplit — and every product stays within the fp32 summation-order distance of the default route.  Timings of both
+    modes go to the report."""
+    import subprocess, sys, json
+    code = r"""
+import sys, json, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import refutil as R
+from ggml_amd import ops, native
+L = native.lib()
+out = {}
+for (t, m, k, b) in ((R.Q4_K, 4096, 4096, 512), (R.Q4_K, 4096, 11008, 512), (R.Q4_K, 16384, 4096, 512), (R.Q4_0, 4096, 4096, 512), (R.Q6_K, 2048, 4096, 128)):
+    w = R.random_weights(t, m, k, seed=m + k)
+    a = ops.QTensor.from_host_bytes(t, k, m, w)
+    xd = torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, (b, k)).astype(np.float32)).cuda()
+    ys, us = [], []
+    for shared in (0, 1, 0):
+        L.ggml_cdna4_set_shared_device(shared)
+        y = ops.mul_mat(a, xd); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(20): ops.mul_mat(a, xd)
+        e0.record()
+        for _ in range(50): ops.mul_mat(a, xd)
+        e1.record(); e1.synchronize()
+        ys.append(y.cpu().numpy()); us.append(e0.elapsed_time(e1) * 20.0)
+    out["%%d %%dx%%dx%%d" %% (t, m, k, b)] = {"rel_l2_shared_vs_default": R.rel_l2(ys[1], ys[0]), "default_again_identical": bool(np.array_equal(ys[0], ys[2])),
+                                          "finite": bool(np.isfinite(ys[1]).all()), "us_default": round(us[0], 2), "us_shared": round(us[1], 2)}
+print(json.dumps(out))
+""" % (R.ROOT, os.path.join(R.ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    gu.report(test="shared_device_mode", **{k.replace(" ", "_"): v for k, v in rec.items()})
+    for k, v in rec.items():
+        assert v["finite"] and v["default_again_identical"] and v["rel_l2_shared_vs_default"] < 2e-6, (k, v)
