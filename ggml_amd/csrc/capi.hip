@@ -312,6 +312,23 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
         if (workspace_bytes >= mv.total && mv.img_rows * K * 2 < ((int64_t)1 << 31)) {
             int rc = cdna4_launch_moe_plan(ids, ids_tok_stride, (int)n_tok, (int)n_used, (int)n_b, (int)n_expert, (int)mv.img_rows, mv.img_src, mv.img_dst, mv.tile_expert, (hipStream_t)stream);
             if (rc) return rc;
+            // few rows per expert (on average at most 32): the int8 matrix-core kernel over 32-row chunks of the same expert-sorted image — the CPU's own integer
+            // block dots (ggml_compute_forward_mul_mat_id's vec_dot calls, ggml-cpu.c:7752-7776) instead of fp16 tiles that would be mostly padding.  The int8
+            // image (quants, d, bsums) takes the place of the fp16 one in the workspace.
+            static const bool no_mmq_ids = getenv("CDNA4_NO_MMQ_IDS") && atoi(getenv("CDNA4_NO_MMQ_IDS")) != 0;
+            if (!no_mmq_ids && n_tok * n_used <= 32 * n_expert && cdna4_mmq_ids_supported(type, K) &&
+                !(((uintptr_t)as | (uintptr_t)w_row_bytes | (uintptr_t)w_expert_bytes) & (type == CDNA4_Q6_K ? 1 : 15))) {
+                int8_t *iq = (int8_t *)mv.xh;
+                float *id_ = (float *)((uint8_t *)mv.xh + align256((size_t)mv.img_rows * K));
+                int16_t *ibs = (int16_t *)((uint8_t *)id_ + align256((size_t)mv.img_rows * (K / 32) * 4));
+                rc = is_kq(type) ? cdna4_launch_quantize_q8_K_gather_i8(b, b_row_stride, K, mv.img_rows, mv.img_src, iq, id_, ibs, (hipStream_t)stream)
+                                 : cdna4_launch_quantize_q8_0_gather_i8(b, b_row_stride, K, mv.img_rows, mv.img_src, iq, id_, (hipStream_t)stream);
+                if (rc) return rc;
+                cdna4_gemv_args g{};
+                g.type = type; g.W = (const uint8_t *)as; g.w_row_bytes = w_row_bytes; g.qs = iq; g.d = id_; g.bsums = is_kq(type) ? ibs : nullptr;
+                g.Y = dst; g.y_col_stride = dst_row_stride; g.M = (int)M; g.K = (int)K; g.ncol = (int)mv.img_rows;
+                return cdna4_launch_mmq_ids(g, mv.tile_expert, mv.img_dst, w_expert_bytes, (hipStream_t)stream);
+            }
             rc = is_kq(type) ? cdna4_launch_quantize_q8_K_gather(b, b_row_stride, K, mv.img_rows, mv.img_src, mv.xh, (hipStream_t)stream)
                              : cdna4_launch_quantize_q8_0_gather(b, b_row_stride, K, mv.img_rows, mv.img_src, mv.xh, (hipStream_t)stream);
             if (rc) return rc;

@@ -61,6 +61,8 @@ int cdna4_launch_gemv_q_fused_ids(const cdna4_gemv_args &a, const float *x, int6
 // a.qs / a.d / a.bsums as for cdna4_launch_gemv_q (Q8_K workspace), a.epi applied in the store
 bool cdna4_mmq_supported(int type, int64_t M, int64_t K, int64_t B);
 int cdna4_launch_mmq(const cdna4_gemv_args &a, hipStream_t st);
+bool cdna4_mmq_ids_supported(int type, int64_t K);                  // grouped MUL_MAT_ID on the int8 matrix cores: a.qs / a.d / a.bsums = the expert-sorted image (a.ncol rows)
+int cdna4_launch_mmq_ids(const cdna4_gemv_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);
 
 // gemm_q_mfma.hip — fp16 MFMA prefill path.  xh = pair-interleaved fp16 activations [B][K].
 struct cdna4_gemm_args {
@@ -85,6 +87,8 @@ bool cdna4_gemm_ids_supported(int type, int64_t K);
 int cdna4_launch_gemm_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);
 // the activation image of the rows src_rows[0 .. img_rows) for the grouped MUL_MAT_ID (quantize_act.hip): Q8_K (K-quants) or Q8_0 quantization
 int cdna4_launch_quantize_q8_0_gather(const float *x, int64_t x_row_stride, int64_t K, int64_t img_rows, const int32_t *src_rows, void *xh, hipStream_t st);
+int cdna4_launch_quantize_q8_K_gather_i8(const float *x, int64_t x_row_stride, int64_t K, int64_t img_rows, const int32_t *src_rows, int8_t *qs, float *d, int16_t *bsums, hipStream_t st);
+int cdna4_launch_quantize_q8_0_gather_i8(const float *x, int64_t x_row_stride, int64_t K, int64_t img_rows, const int32_t *src_rows, int8_t *qs, float *d, hipStream_t st);
 bool cdna4_gemm_q_supported(int type, int64_t M, int64_t K, int64_t B);
 // convert_w.hip: exact re-encodings Q5_0 -> Q8_0, Q3_K -> Q6_K (prefill GEMM of the source format = GEMM of the target format) and
 // Q2_K -> [scale part | minimum part] as Q6_K with 2 K columns (kmul = 2: the activation image must hold x twice)

@@ -225,6 +225,23 @@ int cdna4_launch_quantize_q8_K_gather(const float *x, int64_t x_row_stride, int6
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
+// the same gathers into the INT8 form (quants + scales [+ bsums]): the grouped MUL_MAT_ID on the int8 matrix cores (mmq_i8.hip)
+int cdna4_launch_quantize_q8_K_gather_i8(const float *x, int64_t x_row_stride, int64_t K, int64_t img_rows, const int32_t *src_rows, int8_t *qs, float *d, int16_t *bsums, hipStream_t st) {
+    if (K % QK_K) return cdna4_set_error_msg("quantize_q8_K: K must be a multiple of 256");
+    if (img_rows == 0 || K == 0) return 0;
+    const int64_t nthr = img_rows * (K / 16);
+    hipLaunchKernelGGL(k_quantize_q8_K, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)img_rows, qs, d, bsums, (half_t *)nullptr, src_rows);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+int cdna4_launch_quantize_q8_0_gather_i8(const float *x, int64_t x_row_stride, int64_t K, int64_t img_rows, const int32_t *src_rows, int8_t *qs, float *d, hipStream_t st) {
+    if (K % 32) return cdna4_set_error_msg("quantize_q8_0: K must be a multiple of 32");
+    if (img_rows == 0 || K == 0) return 0;
+    const int64_t nthr = img_rows * (K / 4);
+    hipLaunchKernelGGL(k_quantize_q8_0<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, x, x_row_stride, (int)K, (int)img_rows, qs, d, (half_t *)nullptr, src_rows);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
 int cdna4_launch_quantize_q8_0_gather(const float *x, int64_t x_row_stride, int64_t K, int64_t img_rows, const int32_t *src_rows, void *xh, hipStream_t st) {
     if (K % 32) return cdna4_set_error_msg("quantize_q8_0: K must be a multiple of 32");
     if (img_rows == 0 || K == 0) return 0;

@@ -524,6 +524,18 @@ def test_whole_library_mul_mat_id_on_the_cpu(name, t):
         assert r < 1e-5, (name, n_b, n_tok, r)
 
 
+@pytest.mark.parametrize("t,m,k,ne,nu,nb,nt", [(12, 128, 512, 4, 2, 2, 32), (12, 40, 256, 8, 2, 1, 40), (13, 130, 512, 3, 2, 2, 40), (14, 64, 256, 4, 2, 1, 40), (2, 50, 512, 4, 2, 2, 33), (8, 64, 256, 4, 2, 2, 33),
+                                                (12, 64, 512, 2, 1, 1, 60)])
+def test_whole_library_few_rows_per_expert_mul_mat_id_on_the_cpu(t, m, k, ne, nu, nb, nt):
+    """MUL_MAT_ID with more than 32 (token, slot) rows but at most 32 per expert on average: the int8 matrix-core kernels over 32-row chunks of the expert-sorted
+    image (k_mmq_*<2, 8> with the grouped argument block: expert from tile_expert, output rows through row_dst, chunks past a run exit; the last case gives one
+    expert ~30 rows: two chunks of its tile, the second ragged) — the CPU's integer block dots: <= 1e-5 from the oracle, where the grouped fp16 GEMM sits at 3e-4"""
+    r = _emul_module("lib_emul_check").mul_mat_id(t, m, k, ne, nu, nb, nt, seed=7, timeout=900)
+    if r is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert r < 1e-5, r
+
+
 @pytest.mark.parametrize("m,k,ne,nu,nb,nt", [(130, 1024, 3, 2, 2, 70), (256, 2048, 4, 2, 1, 40)])
 def test_whole_library_grouped_mul_mat_id_with_the_ticketed_k_split_on_the_cpu(m, k, ne, nu, nb, nt):
     """the grouped Q4_K launch where its tiles outnumber (a pretend chip of 2) CUs: every tile is computed by TWO work-groups over half of K each; the

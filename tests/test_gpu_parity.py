@@ -431,6 +431,56 @@ def test_full_size_c5_config(gu):
         assert R.rel_l2(ysh, yh[:, r * 4096:(r + 1) * 4096]) < 2e-6
 
 
+def test_headline_shape_against_the_oracle_full_matrix(gu):
+    """the headline product, Q4_K [4096 x 4096] . [4096 x 512], ALL 2,097,152 outputs against the oracle's MUL_MAT (its
+    OpenMP build finishes in seconds), on the PRESCRIBED inputs bench.py times (reference-quantized mt19937(1234) weights through oracle/_ref/synth_data when
+    present, random valid blocks otherwise): rel-L2 over the whole matrix and the worst single output column, through AUTO (k_gemm_kq_t64, hand-off split) and
+    through the shared-device route (ticketed split)."""
+    import bench as B
+    from ggml_amd import ops, native
+    t, m, k, b = R.Q4_K, 4096, 4096, 512
+    w, x, how = B.prescribed(t, m, k, 0, m, b)
+    a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
+    want = R.o_mul_mat(t, w, x, m, k)
+    L = native.lib()
+    for shared in (0, 1):
+        old = L.ggml_cdna4_set_shared_device(shared)
+        try:
+            y = ops.mul_mat(a, xd).cpu().numpy()
+        finally:
+            L.ggml_cdna4_set_shared_device(old)
+        e = R.rel_l2(y, want)
+        col = float(np.max(np.linalg.norm(y - want, axis=0) / np.maximum(np.linalg.norm(want, axis=0), 1e-30)))
+        gu.report(test="headline_full_matrix", data=how, shared_device=shared, rel_l2=e, worst_column_rel_l2=col)
+        assert np.isfinite(y).all() and e < TOL_GEMM and col < 2 * TOL_GEMM, (shared, e, col)
+
+
+def test_c5_shape_on_reference_quantized_rows(gu):
+    """item 7(c), second half: BASELINE configs[4] [32768 x 8192] . [8192 x 512] with weight rows the REFERENCE quantized (synth_data slices the prescribed
+    mt19937(1234) matrix by rows): 16 slices of 256 rows spread over the matrix are multiplied INSIDE the full-size launch (the other rows random valid
+    blocks, so the launch is the real C5 grid on k_gemm_r8) and all 4096 of them are compared with the oracle."""
+    import bench as B
+    from ggml_amd import ops
+    if not os.path.exists(os.path.join(R.REF_DIR, "synth_data")):
+        pytest.skip("oracle/_ref/synth_data not built")
+    t, m, k, b = R.Q4_K, 32768, 8192, 512
+    rs = R.row_size(t, k)
+    w = R.random_block_bytes(t, m, k, np.random.default_rng(5)).copy()
+    x = None; rows = []
+    for i in range(16):
+        lo = i * 2048 + 512
+        ws, xs, how = B.prescribed(t, m, k, lo, lo + 256, b)
+        assert how == "prescribed"
+        w[lo * rs:(lo + 256) * rs] = ws
+        x = xs; rows.extend(range(lo, lo + 256))
+    a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
+    y = ops.mul_mat(a, xd).cpu().numpy()
+    rows = np.array(rows)
+    wsub = np.concatenate([w[r * rs:(r + 1) * rs] for r in rows])
+    e = R.rel_l2(y[:, rows], R.o_mul_mat(t, wsub, x, len(rows), k)); gu.report(test="c5_reference_quantized_rows", rows=len(rows), rel_l2=e)
+    assert np.isfinite(y).all() and e < TOL_GEMM
+
+
 def torch_equal(a, b):
     import torch
     return bool(torch.equal(a, b))
@@ -473,6 +523,36 @@ def test_mul_mat_id_single_token_is_one_fused_launch(gu, name, t, n_expert, n_us
     assert np.array_equal(y1.view(np.uint32), y2[:1].view(np.uint32))
     e = R.rel_l2(y1, R.o_mul_mat_id(t, w, xb[:1], ids[:1], m, k, n_expert)); gu.report(test="mul_mat_id_fused", type=name, rel_l2=e)
     assert e < TOL_GEMV
+
+
+@pytest.mark.parametrize("name,t", WT)
+@pytest.mark.parametrize("n_expert,n_used,n_tok,m,k", [(8, 2, 64, 4096, 4096), (8, 2, 96, 512, 512), (16, 2, 40, 256, 256), (64, 4, 24, 256, 512)])
+def test_mul_mat_id_few_rows_per_expert_takes_the_integer_path(gu, name, t, n_expert, n_used, n_tok, m, k):
+    """more than 32 (token, slot) rows, at most 32 per expert on average (a short MoE prompt: 64 tokens x 2 of 8 experts of 4096^2): k_mmq_* over 32-row chunks of
+    the expert-sorted image (VERDICT r3 "missing 4") — the CPU's own integer block dots: the GEMV bar (1e-5) against the oracle's MUL_MAT_ID, deterministic,
+    and the time of the call beside the padded fp16 grouped GEMM it replaces goes to the report (headline-sized experts only)."""
+    from ggml_amd import ops
+    if m >= 4096 and t not in (R.Q4_K, R.Q6_K, R.Q8_0):
+        pytest.skip("headline-sized experts: three formats")
+    rng = np.random.default_rng(n_expert + n_tok)
+    w = R.random_weights(t, n_expert * m, k, seed=6)
+    xb = rng.uniform(-1, 1, (n_tok, n_used, k)).astype(np.float32)
+    ids = np.stack([rng.permutation(n_expert)[:n_used] for _ in range(n_tok)]).astype(np.int32)
+    a, xd, idd = gu.qtensor(t, w, n_expert * m, k), gu.to_dev(xb), gu.to_dev(ids)
+    y = ops.mul_mat_id(a, xd, idd, n_expert=n_expert)
+    sel = rng.choice(n_tok, min(n_tok, 16), replace=False)
+    e = R.rel_l2(y.cpu().numpy()[sel], R.o_mul_mat_id(t, w, xb[sel], ids[sel], m, k, n_expert))
+    assert torch.equal(y, ops.mul_mat_id(a, xd, idd, n_expert=n_expert))
+    us = None
+    if m >= 4096:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(10): ops.mul_mat_id(a, xd, idd, n_expert=n_expert)
+        e0.record()
+        for _ in range(30): ops.mul_mat_id(a, xd, idd, n_expert=n_expert)
+        e1.record(); e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 30
+    gu.report(test="mul_mat_id_few_rows_per_expert", type=name, n_expert=n_expert, n_used=n_used, n_tok=n_tok, m=m, k=k, rel_l2=e, us_per_call=us)
+    assert e < TOL_GEMV, e
 
 
 @pytest.mark.parametrize("name,t", WT)
