@@ -144,9 +144,8 @@ def events_us(fn, n, warm=10):
 def kernel_name(t, m, k, b):
     if t == Q4_K and b > 64:
         nt = ((m + 255) // 256) * ((b + 255) // 256)                   # cdna4_gemm_r8_preferred (gemm_q_lds.hip) on a 256-CU part
-        sk = 2 if (nt * 2 <= 256 and k // 256 >= 4) else 1
-        if k % 256 == 0 and nt * 2 >= 256 and nt * sk * 10 >= -(-nt * sk // 256) * 256 * 9:
-            return "k_gemm_r8<Q4_K> (256x256 tile, 8 waves x 32(m)x256(b), in-register unpack, K tile 64, split-K %d reduce-scatter)" % sk
+        if k % 256 == 0 and nt >= 256 and nt * 10 >= -(-nt // 256) * 256 * 9:
+            return "k_gemm_r8<Q4_K> (256x256 tile, 8 waves x 32(m)x256(b), in-register unpack, K tile 64, no K split)"
         if ((m + 255) // 256) * ((b + 127) // 128) >= 512:
             return "k_gemm_kq_t64<Q4_K, 256> (256x128 tile, 8 waves x 64(m)x128(b), LDS-DMA by the four older waves in front of the stage barrier, no K split)"
         return "k_gemm_kq_t64<Q4_K, 128> (128x128 tile, 8 waves x 64(m)x128(b) x K/4, LDS-DMA by the four older waves, split-K=2 hand-off on small grids)"

@@ -14,18 +14,19 @@ bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a) {
     return true;
 }
 
-// AUTO routing (gemm_q_mfma.hip: launch_type<Q4_K>, cdna4_gemm_q_fuses_tail): k_gemm_r8 where its 256 x 256 tiles fill at least half the chip — with
-// split-K = 2 then — measured on MI355X, one box, us per call, r8 vs k_gemm_kq_t64 (profiles/r04/gemm_bench.txt): 32768 x 8192 x 512 216 vs 238,
-// 16384 x 8192 x 512 119 vs 130, 8192 x 8192 x 1024 121 vs 131, 32768 x 4096 x 512 115 vs 127, 4096 x 4096 x 2048 70 vs 74, 16384 x 4096 x 512 69 vs 70;
-// below that (32 tiles: 4096 x 4096 x 512 39 vs 25, 4096 x 11008 x 512 59 vs 50) the 8-way exchange costs more than the leaner loop saves.
+// AUTO routing (gemm_q_mfma.hip: launch_type<Q4_K>, cdna4_gemm_q_fuses_tail): k_gemm_r8 where its 256 x 256 tiles fill the chip UNSPLIT, in whole rounds of
+// work-groups (>= 90 % of the last one).  Measured on MI355X, us per call, r8 vs k_gemm_kq_t64's 256-row form, two boxes (profiles/r04/gemm_bench*.txt):
+// 32768 x 8192 x 512 216 / 221 vs 238 / 243, 32768 x 4096 x 512 115 / 118 vs 127 / 131 — 9-10 % ahead.  At 128 tiles (16384 x 8192 x 512, 8192 x 8192 x 1024,
+// 16384 x 4096 x 512, 4096 x 4096 x 2048) r8 needs split-K = 2 through its reduce-scatter exchange and is level with t64's 256-row tiles on one box (123.4 vs
+// 123.7, 123.4 vs 123.5) and 5 % behind on the K = 4096 shapes (71.6 vs 68.0, 72.2 vs 68.6): those grids stay on t64.  Below that (32 tiles: 4096 x 4096 x 512
+// 39 vs 25, 4096 x 11008 x 512 59-61 vs 50-52) the 8-way exchange costs far more than the leaner loop saves.
 bool cdna4_gemm_r8_preferred(const cdna4_gemm_args &a) {
     static const bool off = getenv("CDNA4_NO_R8") && atoi(getenv("CDNA4_NO_R8")) != 0;
     if (off || !cdna4_gemm_lds_supported(a)) return false;
-    const int cus = cdna4_gemm_cu_count(), ntiles = ((a.M + 255) / 256) * ((a.B + 255) / 256), nsb = a.K / 256;
-    if (ntiles * 2 < cus) return false;
-    const int s = (ntiles * 2 <= cdna4_gemm_coresident_cus() && nsb >= 4) ? 2 : 1;      // what cdna4_launch_gemm_lds() will choose (its reduce-scatter spins: co-resident grids only)
-    const int wgs = ntiles * s, rounds = (wgs + cus - 1) / cus;
-    return wgs * 10 >= rounds * cus * 9;                                // whole rounds of work-groups (>= 90 % of the last one): the tiles are large
+    const int cus = cdna4_gemm_cu_count(), ntiles = ((a.M + 255) / 256) * ((a.B + 255) / 256);
+    if (ntiles < cus) return false;
+    const int rounds = (ntiles + cus - 1) / cus;
+    return ntiles * 10 >= rounds * cus * 9;                             // whole rounds of work-groups (>= 90 % of the last one): the tiles are large
 }
 
 // tile rows (0 = choose; 128 / 256) and split-K (0 = choose) -> launch.  Returns 0, or a negative status with the error text set.

@@ -589,8 +589,8 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         // are resident, uneven for odd superblock counts), 256-row tiles once the grid holds two of them per CU.  MI355X, same box, same
         // data: 4096x4096x512 24.25 vs 24.68 us on k_gemm_kq_w12, 4096x11008x512 50.95 vs 52.57, 8192x4096x512 37.1 vs 38.1,
         // 32768x8192x512 (256-row tiles) 239-243 vs 265.
-        // auto (round 4): k_gemm_r8 (gemm_r8.inc: 32 x 256 wave tiles, half the unpack VALU per MFMA) where its 256 x 256 tiles fill the chip — 8-9 % ahead there
-        if (wlds && a.variant <= 0 && a.splitk <= 0 && cdna4_gemm_r8_preferred(a)) { ROUTE_END(true); return cdna4_launch_gemm_lds(a, 256, 0, st, 2); }
+        // auto (round 4): k_gemm_r8 (gemm_r8.inc: 32 x 256 wave tiles, half the unpack VALU per MFMA) where its 256 x 256 tiles fill the chip unsplit — 9-10 % ahead there
+        if (wlds && a.variant <= 0 && a.splitk <= 0 && cdna4_gemm_r8_preferred(a)) { ROUTE_END(true); return cdna4_launch_gemm_lds(a, 256, 1, st, 2); }
         if (wlds && a.variant <= 0 && a.splitk <= 2) { ROUTE_END(true); return cdna4_launch_gemm_t64(a, 0, a.splitk, st); }   // (deeper, atomic splits: the older kernels below)
     }
     if (splitk < 1 || (kunits % splitk && !uneven)) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
