@@ -146,7 +146,7 @@ def kernel_name(t, m, k, b):
         nt = ((m + 255) // 256) * ((b + 255) // 256)                   # cdna4_gemm_r8_preferred (gemm_q_lds.hip) on a 256-CU part
         if k % 256 == 0 and nt >= 256 and nt * 10 >= -(-nt // 256) * 256 * 9:
             return "k_gemm_r8<Q4_K> (256x256 tile, 8 waves x 32(m)x256(b), in-register unpack, K tile 64, no K split)"
-        if ((m + 255) // 256) * ((b + 127) // 128) >= 512:
+        if ((m + 255) // 256) * ((b + 127) // 128) >= 256:
             return "k_gemm_kq_t64<Q4_K, 256> (256x128 tile, 8 waves x 64(m)x128(b), LDS-DMA by the four older waves in front of the stage barrier, no K split)"
         return "k_gemm_kq_t64<Q4_K, 128> (128x128 tile, 8 waves x 64(m)x128(b) x K/4, LDS-DMA by the four older waves, split-K=2 hand-off on small grids)"
     return "k_gemm_kq_w12 / k_gemm_kq_w8p (128x128 tile, cross-stage unpack/MFMA pipeline)"

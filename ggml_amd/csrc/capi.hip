@@ -314,9 +314,13 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
             if (rc) return rc;
             // few rows per expert (on average at most 32): the int8 matrix-core kernel over 32-row chunks of the same expert-sorted image — the CPU's own integer
             // block dots (ggml_compute_forward_mul_mat_id's vec_dot calls, ggml-cpu.c:7752-7776) instead of fp16 tiles that would be mostly padding.  The int8
-            // image (quants, d, bsums) takes the place of the fp16 one in the workspace.
+            // image (quants, d, bsums) takes the place of the fp16 one in the workspace.  Where it wins (MI355X, one box, 8 experts x 2 used x 4096^2, us per call at
+            // 32 / 64 / 128 tokens, profiles/r04/moe64_ab.txt): Q6_K 95 / 96 / 125 vs 158 / 158 / 160 and Q8_0 91 / 92 / 133 vs 144 / 144 / 147 on the grouped per-lane-load
+            // GEMM these formats have; NOT Q4_K, whose grouped k_gemm_kq_t64 takes 45 / 46 / 51 against 82 / 83 / 115 (CDNA4_MMQ_IDS=2 forces it there: 2e-7 from the
+            // oracle instead of 3e-4).  CDNA4_NO_MMQ_IDS=1 turns the route off.
             static const bool no_mmq_ids = getenv("CDNA4_NO_MMQ_IDS") && atoi(getenv("CDNA4_NO_MMQ_IDS")) != 0;
-            if (!no_mmq_ids && n_tok * n_used <= 32 * n_expert && cdna4_mmq_ids_supported(type, K) &&
+            static const bool all_mmq_ids = getenv("CDNA4_MMQ_IDS") && atoi(getenv("CDNA4_MMQ_IDS")) == 2;
+            if (!no_mmq_ids && (type != CDNA4_Q4_K || all_mmq_ids) && n_tok * n_used <= 32 * n_expert && cdna4_mmq_ids_supported(type, K) &&
                 !(((uintptr_t)as | (uintptr_t)w_row_bytes | (uintptr_t)w_expert_bytes) & (type == CDNA4_Q6_K ? 1 : 15))) {
                 int8_t *iq = (int8_t *)mv.xh;
                 float *id_ = (float *)((uint8_t *)mv.xh + align256((size_t)mv.img_rows * K));

@@ -13,9 +13,11 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) || ((uintptr_t)a.xh & 15)) return cdna4_set_error_msg("gemm_t64: weight rows and the activation image must be 16-byte aligned");
     const int cus = cdna4_gemm_cu_count(), nsb = a.K / 256;
     const int tiles_b = (a.B + 127) / 128;
-    // 256-row tiles move half the activation bytes per MFMA, but only pay once the grid holds two of them per CU (C5 32768x8192x512:
-    // 239 us vs 265 on 128-row tiles; 8192x8192x512 — one per CU — 71.6 vs 68.9, a loss; below that CUs would idle)
-    if (tm <= 0) tm = (((a.M + 255) / 256) * tiles_b >= 2 * cus) ? 256 : 128;
+    // 256-row tiles move half the activation bytes per MFMA and need no K reduction across four waves: they pay as soon as the grid holds ONE of them per CU.
+    // Round 4, one box, us per call, 128- vs 256-row tiles (profiles/r04/t64_tiles.txt): 16384x8192x512 137.8 vs 125.4, 16384x4096x512 76.7 vs 68.5,
+    // 4096x4096x2048 78.2 vs 69.1, 8192x8192x1024 138.1 vs 125.8, 8192x4096x1024 76.6 vs 68.5, 16384x11008x512 178.9 vs 164.8 (9-12 %); C5 (two per CU) 239 vs
+    // 265 since round 2.  Half a tile per CU (8192x8192x512: 71.6 vs 68.9, round 3) is a loss: CUs idle.  (Until round 4 the rule asked for two per CU.)
+    if (tm <= 0) tm = (((a.M + 255) / 256) * tiles_b >= cus) ? 256 : 128;
     if (tm != 128 && tm != 256) return cdna4_set_error_msg("gemm_t64: tile rows are 128 or 256");
     const int tiles_m = (a.M + tm - 1) / tm, ntiles = tiles_m * tiles_b;
     // split-K: 2 = the hand-off between the two co-resident work-groups of a tile; 4 / 8 = deep split for grids far below the chip
@@ -23,7 +25,12 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     bool ticketed2 = false;                                              // split in two with the ticketed sum instead of the (spinning) hand-off
     if (splitk <= 0) {
         splitk = (ntiles * 2 <= cus && nsb >= 2) ? 2 : 1;
-        if (splitk == 2 && cdna4_gemm_shared_device()) { if (tm == 128) ticketed2 = true; else splitk = 1; }     // shared device: nobody may wait for a partner
+        // AUTO splits in two with the TICKETED sum (each work-group parks its finished blocks, the last of a tile's two to arrive adds both in the order ks = 0, 1;
+        // nobody waits, no co-residency assumed) — since round 4 the default: same-box, kernel only, hand-off vs ticketed (profiles/r04/handoff_vs_ticketed.txt):
+        // 4096x4096x512 26.3-26.7 vs 26.7, 4096x11008x512 52.6-52.7 vs 52.1-52.2, 8192x4096x512 39.0 vs 38.8, 2048x4096x512 20.5-21.1 vs 20.6-20.8 us: level,
+        // and bit-identical for even superblock counts (two fp32 terms).  The spinning hand-off stays behind an explicit splitk = 2 (and CDNA4_T64_HANDOFF=1).
+        static const bool handoff_env = getenv("CDNA4_T64_HANDOFF") && atoi(getenv("CDNA4_T64_HANDOFF")) != 0;
+        if (splitk == 2 && (!handoff_env || cdna4_gemm_shared_device())) { if (tm == 128) ticketed2 = true; else splitk = 1; }
         if (tm == 128 && ntiles * 4 <= cus && nsb >= 8) splitk = 4;
         if (tm == 128 && ntiles * 8 <= cus && nsb >= 16) splitk = 8;
     }

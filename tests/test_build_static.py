@@ -530,7 +530,11 @@ def test_whole_library_few_rows_per_expert_mul_mat_id_on_the_cpu(t, m, k, ne, nu
     """MUL_MAT_ID with more than 32 (token, slot) rows but at most 32 per expert on average: the int8 matrix-core kernels over 32-row chunks of the expert-sorted
     image (k_mmq_*<2, 8> with the grouped argument block: expert from tile_expert, output rows through row_dst, chunks past a run exit; the last case gives one
     expert ~30 rows: two chunks of its tile, the second ragged) — the CPU's integer block dots: <= 1e-5 from the oracle, where the grouped fp16 GEMM sits at 3e-4"""
-    r = _emul_module("lib_emul_check").mul_mat_id(t, m, k, ne, nu, nb, nt, seed=7, timeout=900)
+    os.environ["CDNA4_MMQ_IDS"] = "2"                                 # (Q4_K keeps its grouped fp16 GEMM in AUTO — faster on MI355X, capi.hip; forced here so that its kernel is covered too)
+    try:
+        r = _emul_module("lib_emul_check").mul_mat_id(t, m, k, ne, nu, nb, nt, seed=7, timeout=900)
+    finally:
+        os.environ.pop("CDNA4_MMQ_IDS", None)
     if r is None:
         pytest.skip("the environment cannot host the emulation")
     assert r < 1e-5, r

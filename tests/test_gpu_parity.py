@@ -529,7 +529,7 @@ def test_mul_mat_id_single_token_is_one_fused_launch(gu, name, t, n_expert, n_us
 @pytest.mark.parametrize("n_expert,n_used,n_tok,m,k", [(8, 2, 64, 4096, 4096), (8, 2, 96, 512, 512), (16, 2, 40, 256, 256), (64, 4, 24, 256, 512)])
 def test_mul_mat_id_few_rows_per_expert_takes_the_integer_path(gu, name, t, n_expert, n_used, n_tok, m, k):
     """more than 32 (token, slot) rows, at most 32 per expert on average (a short MoE prompt: 64 tokens x 2 of 8 experts of 4096^2): k_mmq_* over 32-row chunks of
-    the expert-sorted image (VERDICT r3 "missing 4") — the CPU's own integer block dots: the GEMV bar (1e-5) against the oracle's MUL_MAT_ID, deterministic,
+    the expert-sorted image (VERDICT r3 "missing 4") for Q5_K / Q6_K / Q4_0 / Q8_0 — the CPU's own integer block dots: the GEMV bar (1e-5) against the oracle's MUL_MAT_ID, deterministic,
     and the time of the call beside the padded fp16 grouped GEMM it replaces goes to the report (headline-sized experts only)."""
     from ggml_amd import ops
     if m >= 4096 and t not in (R.Q4_K, R.Q6_K, R.Q8_0):
@@ -552,7 +552,7 @@ def test_mul_mat_id_few_rows_per_expert_takes_the_integer_path(gu, name, t, n_ex
         e1.record(); e1.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 30
     gu.report(test="mul_mat_id_few_rows_per_expert", type=name, n_expert=n_expert, n_used=n_used, n_tok=n_tok, m=m, k=k, rel_l2=e, us_per_call=us)
-    assert e < TOL_GEMV, e
+    assert e < (TOL_GEMM if t == R.Q4_K else TOL_GEMV), e           # (Q4_K stays on its grouped fp16 GEMM: 45 vs 82 us at 64 tokens of 8 x 4096^2; the others take the integer path)
 
 
 @pytest.mark.parametrize("name,t", WT)
