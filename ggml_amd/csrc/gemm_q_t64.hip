@@ -83,8 +83,18 @@ int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expe
     gemm_params p{};
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = 1;
-    p.tiles_m = (a.M + 127) / 128; p.tiles_b = a.B / 128;
+    // 256-row tiles (no K ways, half the activation bytes per MFMA: 9-12 % at one tile per CU, above) once the grouped grid offers at least 3/4 of a tile per CU;
+    // CDNA4_MOE_TM = 128 / 256 forces the form (A/B: profiles/r04/moe_tm_ab.txt)
+    static const int tm_env = getenv("CDNA4_MOE_TM") ? atoi(getenv("CDNA4_MOE_TM")) : 0;
+    const int cus0 = cdna4_gemm_cu_count();
+    const int tm = tm_env == 128 || tm_env == 256 ? tm_env : ((((a.M + 255) / 256) * (a.B / 128)) * 4 >= cus0 * 3 ? 256 : 128);
+    p.tiles_m = (a.M + tm - 1) / tm; p.tiles_b = a.B / 128;
     p.tile_expert = tile_expert; p.row_dst = row_dst; p.w_expert_bytes = w_expert_bytes;
+    if (tm == 256) {
+        hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256, true>), dim3(p.tiles_m * p.tiles_b), dim3(512), 0, st, p);
+        CDNA4_CHECK_LAUNCH();
+        return 0;
+    }
     // K split in two with the TICKETED sum (the last of a tile's two work-groups to arrive adds both partial tiles, in the order ks = 0, 1, and stores):
     // OPT-IN (CDNA4_MOE_SPLITK=2) — a measured loss: the grouped grid is 384 30-us tiles on 256 CUs (two rounds) and 768 halves would be three rounds of half
     // the length, but every half tile also parks 64 KB write-through and the last arrival reads its partner's: 8 x 2 x 512 x 4096^2 on one MI355X box,

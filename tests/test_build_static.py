@@ -540,6 +540,16 @@ def test_whole_library_few_rows_per_expert_mul_mat_id_on_the_cpu(t, m, k, ne, nu
     assert r < 1e-5, r
 
 
+@pytest.mark.parametrize("m,k,ne,nu,nb,nt,cus", [(300, 512, 3, 2, 2, 70, 2), (256, 1024, 4, 2, 1, 90, 4)])
+def test_whole_library_grouped_mul_mat_id_on_256_row_tiles_on_the_cpu(m, k, ne, nu, nb, nt, cus):
+    """the grouped Q4_K launch on k_gemm_kq_t64<.., 256, IDS> (taken once the grouped grid offers 3/4 of a 256-row tile per CU of a pretend small chip): ragged m, padding rows,
+    broadcast activation rows — within the GEMM bar of the oracle's MUL_MAT_ID"""
+    r = _emul_module("lib_emul_check").mul_mat_id(12, m, k, ne, nu, nb, nt, seed=3, cus=cus, timeout=900)
+    if r is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert r < 1e-3, r
+
+
 @pytest.mark.parametrize("m,k,ne,nu,nb,nt", [(130, 1024, 3, 2, 2, 70), (256, 2048, 4, 2, 1, 40)])
 def test_whole_library_grouped_mul_mat_id_with_the_ticketed_k_split_on_the_cpu(m, k, ne, nu, nb, nt):
     """the grouped Q4_K launch where its tiles outnumber (a pretend chip of 2) CUs: every tile is computed by TWO work-groups over half of K each; the
