@@ -146,7 +146,9 @@ def kernel_name(t, m, k, b):
         nt = ((m + 255) // 256) * ((b + 255) // 256)                   # cdna4_gemm_r8_preferred (gemm_q_lds.hip) on a 256-CU part
         if k % 256 == 0 and nt >= 256 and nt * 10 >= -(-nt // 256) * 256 * 9:
             return "k_gemm_r8<Q4_K> (256x256 tile, 8 waves x 32(m)x256(b), in-register unpack, K tile 64, no K split)"
-        if ((m + 255) // 256) * ((b + 127) // 128) >= 256:
+        t256, t128 = ((m + 255) // 256) * ((b + 127) // 128), ((m + 127) // 128) * ((b + 127) // 128)
+        eff = lambda n: n / (-(-n // 256) * 256)                        # cdna4_launch_gemm_t64's tile rule on a 256-CU part
+        if t256 * 2 > 256 and eff(t256) * 1.10 >= eff(t128):
             return "k_gemm_kq_t64<Q4_K, 256> (256x128 tile, 8 waves x 64(m)x128(b), LDS-DMA by the four older waves in front of the stage barrier, no K split)"
         return "k_gemm_kq_t64<Q4_K, 128> (128x128 tile, 8 waves x 64(m)x128(b) x K/4, LDS-DMA by the four older waves, split-K=2 hand-off on small grids)"
     return "k_gemm_kq_w12 / k_gemm_kq_w8p (128x128 tile, cross-stage unpack/MFMA pipeline)"
@@ -368,7 +370,7 @@ def moe_row(dev, steps):
         fl = 2.0 * m * k * nt * n_used
         if nt > 1:
             out["prefill_512_tokens"] = {"us_per_call": round(us, 2), "effective_tflops": round(fl / us / 1e6, 1), "frac_of_mfma_roof": round(fl / us / 1e6 / MFMA_F16_PEAK_TFLOPS, 4),
-                                         "launches": "plan + gather-quantize + one grouped k_gemm_kq_t64<Q4_K, 128, IDS>", "padded_rows": "each expert's run rounded up to 128 image rows"}
+                                         "launches": "plan + gather-quantize + one grouped k_gemm_kq_t64<Q4_K, 256, IDS>", "padded_rows": "each expert's run rounded up to 128 image rows"}
         else:
             wbytes = n_used * m * (k // 256) * 144
             out["decode_1_token"] = {"us_per_call": round(us, 2), "GBps": round(wbytes / us / 1e3, 1), "frac_of_hbm_roof": round(wbytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches": "one (k_gemv_q_fused<.., IDS>)"}

@@ -17,7 +17,14 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     // Round 4, one box, us per call, 128- vs 256-row tiles (profiles/r04/t64_tiles.txt): 16384x8192x512 137.8 vs 125.4, 16384x4096x512 76.7 vs 68.5,
     // 4096x4096x2048 78.2 vs 69.1, 8192x8192x1024 138.1 vs 125.8, 8192x4096x1024 76.6 vs 68.5, 16384x11008x512 178.9 vs 164.8 (9-12 %); C5 (two per CU) 239 vs
     // 265 since round 2.  Half a tile per CU (8192x8192x512: 71.6 vs 68.9, round 3) is a loss: CUs idle.  (Until round 4 the rule asked for two per CU.)
-    if (tm <= 0) tm = (((a.M + 255) / 256) * tiles_b >= cus) ? 256 : 128;
+    // Between whole rounds the better-filled last round wins: 24576x4096x512 (1.5 tiles of 256 rows per CU: 2 rounds, against 3 full rounds of 128-row tiles) 111.1 vs
+    // 108.0; 3/4 of a tile per CU (both forms fill 3/4 of the chip once) 12288x4096x512 62.8 vs 54.4, 12288x8192x512 113.3 vs 98.5, 6144x4096x1024 64.5 vs 55.6
+    // (profiles/r04/t64_tiles_075.txt).  Rule: 256-row tiles when their round efficiency is within 10 % of the 128-row tiles' (they are ~10 % faster per flop).
+    if (tm <= 0) {
+        const int t256 = ((a.M + 255) / 256) * tiles_b, t128 = ((a.M + 127) / 128) * tiles_b;
+        auto eff = [&](int n) { return (double)n / (double)(((n + cus - 1) / cus) * cus); };
+        tm = (t256 * 2 > cus && eff(t256) * 1.10 >= eff(t128)) ? 256 : 128;
+    }
     if (tm != 128 && tm != 256) return cdna4_set_error_msg("gemm_t64: tile rows are 128 or 256");
     const int tiles_m = (a.M + tm - 1) / tm, ntiles = tiles_m * tiles_b;
     // split-K: 2 = the hand-off between the two co-resident work-groups of a tile; 4 / 8 = deep split for grids far below the chip
@@ -84,7 +91,8 @@ int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expe
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = 1;
     // 256-row tiles (no K ways, half the activation bytes per MFMA: 9-12 % at one tile per CU, above) once the grouped grid offers at least 3/4 of a tile per CU;
-    // CDNA4_MOE_TM = 128 / 256 forces the form (A/B: profiles/r04/moe_tm_ab.txt)
+    // CDNA4_MOE_TM = 128 / 256 forces the form.  8 experts x 2 used x 512 tokens x 4096^2, one box, two alternations: 83.9-84.1 us on 128-row tiles, 74.1-74.2 on 256-row
+    // tiles (profiles/r04/moe_tm_ab.txt)
     static const int tm_env = getenv("CDNA4_MOE_TM") ? atoi(getenv("CDNA4_MOE_TM")) : 0;
     const int cus0 = cdna4_gemm_cu_count();
     const int tm = tm_env == 128 || tm_env == 256 ? tm_env : ((((a.M + 255) / 256) * (a.B / 128)) * 4 >= cus0 * 3 ? 256 : 128);
