@@ -479,13 +479,18 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     p.partial = nullptr; p.flags = nullptr;
     p.epi = a.epi;                                                        // gemm_w8_epilogue.inc applies it in the tile's store (not on the atomic-sum path)
     const int ntiles = p.tiles_m * p.tiles_b;
-    ROUTE_END(splitk == 1 || (splitk == 2 && ntiles * 2 <= co_cus()));
-    if (splitk > 2 || (splitk == 2 && ntiles * 2 > co_cus())) p.epi = cdna4_epilogue{};
-    if (splitk == 2 && ntiles * 2 <= co_cus()) {                    // both halves of every tile are resident at once: hand-off
+    // split in two: AUTO (a.splitk <= 0) takes the TICKETED sum of gemm_w8_epilogue.inc (the last of a tile's two work-groups adds both partial tiles; nobody
+    // waits, no co-residency assumed — round 4); an explicit splitk = 2 keeps the spinning hand-off where both halves of every tile are resident at once, and
+    // falls back to a zero fill + fp32 atomics otherwise
+    const bool ticketed = splitk == 2 && a.splitk <= 0 && (size_t)ntiles <= 8192;
+    const bool exchange = ticketed || (splitk == 2 && ntiles * 2 <= co_cus());
+    ROUTE_END(splitk == 1 || exchange);
+    if (splitk > 1 && !exchange) p.epi = cdna4_epilogue{};
+    if (exchange) {
         // exchange slots after a FIXED 64-KB flag area (so that no shape's slots ever overlay another shape's flags).  A flag is
         // non-zero only between its writer's publication and its reader's reset inside one launch: no per-launch state on the
         // host, so the launch is graph-capturable once the scratch exists.
-        const size_t pbytes = (size_t)ntiles * 128 * 128 * 4, fbytes = 65536;
+        const size_t pbytes = (size_t)ntiles * 128 * 128 * 4 * (ticketed ? 2 : 1), fbytes = 65536;      // hand-off: two half tiles per tile; ticketed: two whole ones
         char *sc = (char *)get_scratch(fbytes + pbytes);
         if (!sc) return cdna4_set_error_msg("gemm_q: cannot allocate split-K scratch");
         p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
@@ -504,7 +509,7 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         const int nb = p.tiles_m * p.tiles_b * splitk;
         p.xchg_l2 = (p.partial && (nb & 7) == 0 && ((nb >> 3) % (p.tiles_b * 2)) == 0) ? 1 : 0;
     }
-    p.tune = 0;      // (bit0 = s_setprio 1 for the later-dispatched khalf-1 waves of k_gemm_kq_w8p: measured 26.31 vs 26.33 us, never enabled)
+    p.tune = ticketed ? 2 : 0;      // bit1 = the ticketed split (gemm_w8_epilogue.inc); (bit0 = s_setprio 1 for the later-dispatched khalf-1 waves of k_gemm_kq_w8p: measured 26.31 vs 26.33 us, never enabled)
     const dim3 grid(p.tiles_m * p.tiles_b * splitk);
     // (the s_memtime trace instantiations <.., TRACE = true> exist in the -DCDNA4_ABLATIONS library of tools/microbench only)
 #ifdef CDNA4_ABLATIONS
@@ -575,12 +580,12 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         // auto: at most 2.  Two fp32 contributions added to a zeroed output are order-independent (a+b == b+a), so the
         // result stays deterministic; deeper splits (atomic sums of >2 terms) are opt-in only.
         const int tiles = ((a.M + 127) / 128) * ((a.B + (wide ? 127 : 63)) / (wide ? 128 : 64));
-        if (variant & 16) splitk = (tiles * 2 <= co_cus() && kunits % 2 == 0 && kunits >= 4) ? 2 : 1;   // hand-off split: only if co-resident
+        if (variant & 16) splitk = (tiles * 2 <= cu_count() && kunits % 2 == 0 && kunits >= 4) ? 2 : 1;   // hand-off split: only if co-resident
         else splitk = 1;
         // An ODD number of superblocks — K = 11008 = 43 x 256, BASELINE configs[2] — also takes the hand-off split: its two
         // work-groups get sb_split / total - sb_split superblocks (22 / 21), which the exchange was written for (launch_w8:
         // p.sb_split).  Measured on MI355X (round-1 driver run): rel-L2 7.2e-7 vs the unsplit kernel, 59.7 vs 69.6 us.
-        if ((variant & 16) && wlds && QT<TYPE>::KQ && tiles * 2 <= co_cus() && (kunits & 1) && kunits >= 7) { splitk = 2; uneven = true; }
+        if ((variant & 16) && wlds && QT<TYPE>::KQ && tiles * 2 <= cu_count() && (kunits & 1) && kunits >= 7) { splitk = 2; uneven = true; }
     }
     if constexpr (TYPE == CDNA4_Q4_K) {
         // bit13 = k_gemm_kq_t64 (gemm_q_t64.hip: 64(m) x 128(b) wave tiles); bit14 / bit15 force its 128- / 256-row tile
@@ -605,7 +610,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
             constexpr int ST_ = TYPE == CDNA4_Q4_0 ? CDNA4_Q4_0S : (TYPE == CDNA4_Q8_0 ? CDNA4_Q8_0S : CDNA4_Q6_KS);
             const int nsb = a.K / 256, tiles = ((a.M + 127) / 128) * ((a.B + 127) / 128);
             int sk = a.splitk;
-            if (sk <= 0) sk = (tiles * 2 <= co_cus() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
+            if (sk <= 0) sk = (tiles * 2 <= cu_count() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
             if (sk >= 1 && nsb % sk == 0 && nsb / sk >= 3) return launch_w8<ST_>(a, sk, 65, st);
         }
         if (a.variant <= 0 && a.K % 256 == 0) {
@@ -614,7 +619,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
             if (g_probe.active) {                                        // (the same terminal, without the re-layout pass in front of it)
                 const int tiles = ((a.M + 127) / 128) * ((a.B + 127) / 128);
                 int sk = a.splitk;
-                if (sk <= 0) sk = (tiles * 2 <= co_cus() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
+                if (sk <= 0) sk = (tiles * 2 <= cu_count() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
                 if (sk < 1 || nsb % sk) return 0;
                 return launch_w8<RT>(a, sk, 64, st);
             }
@@ -628,7 +633,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
             cdna4_gemm_args r = a; r.W = rw; r.w_row_bytes = (int64_t)nsb * QT<RT>::BYTES;
             const int tiles = ((a.M + 127) / 128) * ((a.B + 127) / 128);
             int sk = a.splitk;
-            if (sk <= 0) sk = (tiles * 2 <= co_cus() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
+            if (sk <= 0) sk = (tiles * 2 <= cu_count() && nsb % 2 == 0 && nsb >= 4) ? 2 : 1;
             if (sk < 1 || nsb % sk) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
             return launch_w8<RT>(r, sk, 64, st);
         }
