@@ -482,7 +482,8 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     // split in two: AUTO (a.splitk <= 0) takes the TICKETED sum of gemm_w8_epilogue.inc (the last of a tile's two work-groups adds both partial tiles; nobody
     // waits, no co-residency assumed — round 4); an explicit splitk = 2 keeps the spinning hand-off where both halves of every tile are resident at once, and
     // falls back to a zero fill + fp32 atomics otherwise
-    const bool ticketed = splitk == 2 && a.splitk <= 0 && (size_t)ntiles <= 8192;
+    static const bool handoff_env = getenv("CDNA4_W8_HANDOFF") && atoi(getenv("CDNA4_W8_HANDOFF")) != 0;     // (A/B: the spinning hand-off for AUTO splits too)
+    const bool ticketed = splitk == 2 && a.splitk <= 0 && (size_t)ntiles <= 8192 && !handoff_env;
     const bool exchange = ticketed || (splitk == 2 && ntiles * 2 <= co_cus());
     ROUTE_END(splitk == 1 || exchange);
     if (splitk > 1 && !exchange) p.epi = cdna4_epilogue{};
