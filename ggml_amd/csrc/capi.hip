@@ -129,17 +129,21 @@ static bool use_mmq(int type, int64_t M, int64_t K, int64_t B) {
     static const int minb = getenv("CDNA4_MMQ_MINB") ? atoi(getenv("CDNA4_MMQ_MINB")) : 0, maxb = getenv("CDNA4_MMQ_MAXB") ? atoi(getenv("CDNA4_MMQ_MAXB")) : 0;   // measurement knobs
     if (off || !cdna4_mmq_supported(type, M, K, B)) return false;
     if (maxb > 0) return B >= (minb > 0 ? minb : 2) && B <= maxb;
-    // Where it wins on MI355X (us per call, quantizer launch included; profiles/r03/batch_sweep.txt): against the fp16 GEMM for 9 .. 32 rows
-    // (4096 x 14336: 14.3 / 21.2 vs 28.6 / 29.0 at 16 / 32 rows; 4096^2: 13.9 / 13.4 vs 19.5 / 19.8; at 64 rows the GEMM is level or ahead), and
-    // against the v_dot4 GEMV for 3 .. 8 rows once the matrix is large — the two launches cost ~13.5 us whatever the size, the one-launch GEMV 10.3
-    // at 4096^2 but 17.5 / 25.6 at 4096 x 14336 for 4 / 8 rows (mmq: 14.1 / 14.2).  Two rows stay on the GEMV everywhere.
-    // (small matrices — the gpt-2 117M projections — are launch-bound either way: they take the integer path up to 64 rows, which keeps a whole
-    // short prompt on the CPU's own arithmetic instead of the fp16 GEMM's 3e-4)
-    // (measured on Q4_K / Q6_K at M = 4096, profiles/r03/batch_sweep.txt; the other formats and the 33 .. 64-row small-matrix case follow the same rule only
-    // where a sweep line covers them: the five headline formats; everything else is capped at 32 rows — ADVICE r3)
-    const bool swept = type == CDNA4_Q4_K || type == CDNA4_Q6_K || type == CDNA4_Q4_0 || type == CDNA4_Q8_0 || type == CDNA4_Q5_K;
-    if (B >= 9) return B <= 32 || (swept && M * K <= ((int64_t)1 << 24));
-    return B >= 3 && M * K >= ((int64_t)1 << 25);
+    // Where it wins on MI355X — round 4: DEVICE time (HIP-graph replay of 40 calls, quantizer launch included; scripts/gpu_batch_sweep.py ->
+    // profiles/r04/batch_sweep.txt: five formats x {4096^2, 4096 x 14336, 3072 x 768} x 2 .. 64 rows x {AUTO, kernel off, kernel forced}; round 3's sweep was
+    // taken through a Python loop whose host time hid the differences below ~14 us).  us per call, int8 matrix cores vs the alternative:
+    //   2 rows      GEMV everywhere (Q4_K 4096^2 4.8 vs 7.6)
+    //   3 .. 4      GEMV unless the matrix is large: 4096^2 6.8 / 7.1 vs 7.8 / 7.9, 4096 x 14336 17.0 / 17.4 (GEMV) vs 13.8 / 14.0
+    //   5 .. 8      the matrix cores EVERYWHERE: the 8-column GEMV forms take 11.2 / 11.5 us at 4096^2 (3072 x 768: 7.7 / 7.9) against 7.9 (5.9)      [new in round 4]
+    //   9 .. 32     the matrix cores: 7.9 .. 11.0 vs 19.7 .. 20.6 on the fp16 GEMM at 4096^2; Q6_K 4096 x 14336 20.5 .. 27.9 vs 79
+    //   33 .. 48    the matrix cores (not Q6_K: its three-group form spills): 4096^2 14.0 vs 21.1; 4096 x 14336 Q4_K 29.4 vs 31.4, Q4_0 40.1 vs 50.3, Q8_0 48.0 vs
+    //               76.8, Q5_K 29.8 vs 63.6                                                                                                        [new in round 4]
+    //   49 .. 64    small matrices (4096^2: 20.0 vs 21.0; 3072 x 768: 10.1 vs 13.7), and Q8_0 / Q5_K at any size (4096 x 14336: 59.9 vs 77.3, 48.3 vs 64.3); Q4_K / Q4_0
+    //               on large matrices stay on the fp16 GEMM (49.0 vs 31.7, 52.8 vs 50.9)
+    if (B >= 5 && B <= 48) return true;
+    if (B >= 3 && B <= 4) return M * K >= ((int64_t)1 << 25);
+    if (B >= 49) return M * K <= ((int64_t)1 << 24) || type == CDNA4_Q8_0 || type == CDNA4_Q5_K;
+    return false;
 }
 static int resolve_path(int type, int path, int64_t M, int64_t K, int64_t B) {
     if (path == GGML_CDNA4_PATH_AUTO) {

@@ -176,7 +176,12 @@ def test_small_batch_decode_is_one_launch_and_equals_the_two_kernel_path(gu, nam
     a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
     y_one = ops.mul_mat(a, xd).cpu().numpy()
     y_two = ops.mul_mat_prepared(a, ops.PreparedAct(t, xd, path=ops.PATH_GEMV)).cpu().numpy()
-    assert np.array_equal(y_one.view(np.uint32), y_two.view(np.uint32))
+    if b >= 5 and k % 256 == 0:
+        # since round 4 five and more rows take the int8 matrix-core kernel in AUTO (7.9 vs 11.2 us at 4096^2, profiles/r04/batch_sweep.txt): the same integer block
+        # sums, the fp32 scale products in another association — not bit for bit, but to fp32 re-association
+        assert R.rel_l2(y_one, y_two) < 2e-6
+    else:
+        assert np.array_equal(y_one.view(np.uint32), y_two.view(np.uint32))
     e = R.rel_l2(y_one, R.o_mul_mat(t, w, x, m, k)); gu.report(test="gemv_small_batch", type=name, m=m, k=k, b=b, rel_l2=e)
     assert e < TOL_GEMV
     import torch
