@@ -7,12 +7,14 @@
 #include "gemm_w4.inc"
 #include "gemm_r8.inc"
 
-bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a) {
-    if (a.type != CDNA4_Q4_K) return false;
+// (form 2, k_gemm_r8, also takes Q5_K)
+static bool lds_supported_t(const cdna4_gemm_args &a, bool five_ok) {
+    if (a.type != CDNA4_Q4_K && !(five_ok && a.type == CDNA4_Q5_K)) return false;
     if (a.M <= 0 || a.B <= 0 || a.K % 256 || a.K < 256) return false;
     if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) || ((uintptr_t)a.xh & 15)) return false;
     return true;
 }
+bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a) { return lds_supported_t(a, false); }
 
 // AUTO routing (gemm_q_mfma.hip: launch_type<Q4_K>, cdna4_gemm_q_fuses_tail): k_gemm_r8 where its 256 x 256 tiles fill the chip UNSPLIT, in whole rounds of
 // work-groups (>= 90 % of the last one).  Measured on MI355X, us per call, r8 vs k_gemm_kq_t64's 256-row form, two boxes (profiles/r04/gemm_bench*.txt):
@@ -22,7 +24,7 @@ bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a) {
 // 39 vs 25, 4096 x 11008 x 512 59-61 vs 50-52) the 8-way exchange costs far more than the leaner loop saves.
 bool cdna4_gemm_r8_preferred(const cdna4_gemm_args &a) {
     static const bool off = getenv("CDNA4_NO_R8") && atoi(getenv("CDNA4_NO_R8")) != 0;
-    if (off || !cdna4_gemm_lds_supported(a)) return false;
+    if (off || !lds_supported_t(a, true)) return false;
     const int cus = cdna4_gemm_cu_count(), ntiles = ((a.M + 255) / 256) * ((a.B + 255) / 256);
     if (ntiles < cus) return false;
     const int rounds = (ntiles + cus - 1) / cus;
@@ -32,7 +34,7 @@ bool cdna4_gemm_r8_preferred(const cdna4_gemm_args &a) {
 // tile rows (0 = choose; 128 / 256) and split-K (0 = choose) -> launch.  Returns 0, or a negative status with the error text set.
 // form 0: k_gemm_lds (two waves per SIMD, ping-pong phases); form 1: k_gemm_w4 (one wave per SIMD); form 2: k_gemm_r8 (in-register unpack, 32 x 256 wave tiles; 256-row tiles only)
 int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st, int form) {
-    if (!cdna4_gemm_lds_supported(a)) return cdna4_set_error_msg("gemm_lds: Q4_K on 16-byte-aligned rows, whole superblocks");
+    if (!lds_supported_t(a, form == 2)) return cdna4_set_error_msg("gemm_lds: Q4_K (k_gemm_r8: or Q5_K) on 16-byte-aligned rows, whole superblocks");
     const int cus = cdna4_gemm_cu_count(), nsb = a.K / 256;
     const int tiles_b = (a.B + 255) / 256;
     if (form == 2) tm = 256;
@@ -67,7 +69,7 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
 #define W4_ABL(A) if (form == 1 && abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 128, (A)>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 256, (A)>), grid, dim3(256), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
     W4_ABL(1) W4_ABL(2) W4_ABL(3) W4_ABL(4) W4_ABL(8) W4_ABL(16) W4_ABL(32) W4_ABL(15)
     if (form == 1 && abl) return cdna4_set_error_msg("gemm_w4: ablation not instantiated");
-#define R8_ABL(A) if (form == 2 && abl == (A)) { hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
+#define R8_ABL(A) if (form == 2 && a.type == CDNA4_Q4_K && abl == (A)) { hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
     R8_ABL(1) R8_ABL(2) R8_ABL(3) R8_ABL(4) R8_ABL(8) R8_ABL(16) R8_ABL(32) R8_ABL(15)
     if (form == 2 && abl) return cdna4_set_error_msg("gemm_r8: ablation not instantiated");
 #define LDS_ABL(A) if (abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 128, false, (A)>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 256, false, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
@@ -75,7 +77,9 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     if (abl) return cdna4_set_error_msg("gemm_lds: ablation not instantiated");
 #endif
     if (form == 2) {
-        if (a.epi.bias || a.epi.act || a.epi.resid) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K, 0, true>), grid, dim3(512), 0, st, p);
+        const bool tail = a.epi.bias || a.epi.act || a.epi.resid;
+        if (a.type == CDNA4_Q5_K) { if (tail) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q5_K, 0, true>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q5_K>), grid, dim3(512), 0, st, p); }
+        else if (tail) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K, 0, true>), grid, dim3(512), 0, st, p);
         else hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K>), grid, dim3(512), 0, st, p);
         CDNA4_CHECK_LAUNCH();
         return 0;

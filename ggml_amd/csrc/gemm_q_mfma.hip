@@ -599,6 +599,11 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         if (wlds && a.variant <= 0 && a.splitk <= 0 && cdna4_gemm_r8_preferred(a)) { ROUTE_END(true); return cdna4_launch_gemm_lds(a, 256, 1, st, 2); }
         if (wlds && a.variant <= 0 && a.splitk <= 2) { ROUTE_END(true); return cdna4_launch_gemm_t64(a, 0, a.splitk, st); }   // (deeper, atomic splits: the older kernels below)
     }
+    if constexpr (TYPE == CDNA4_Q5_K) {
+        // round 4: k_gemm_r8 also unpacks Q5_K (its fifth bits cost 4-5 VALU per half2 pair: the format that gains most from one fragment meeting eight activation
+        // fragments) — the same rule as Q4_K: grids of at least one 256 x 256 tile per CU, unsplit
+        if (wlds && a.variant <= 0 && a.splitk <= 0 && cdna4_gemm_r8_preferred(a)) { ROUTE_END(true); return cdna4_launch_gemm_lds(a, 256, 1, st, 2); }
+    }
     if (splitk < 1 || (kunits % splitk && !uneven)) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
     if constexpr (TYPE == CDNA4_Q4_0 || TYPE == CDNA4_Q8_0 || TYPE == CDNA4_Q6_K) {
         // 2-byte-aligned formats at prefill batch sizes: re-lay the weights into 16-byte-aligned superblocks (scratch, per

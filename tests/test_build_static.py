@@ -492,11 +492,12 @@ def test_whole_library_mul_mat_on_the_cpu(name, t):
         assert r[0] < bar, (name, m, k, b, r[0])
 
 
+@pytest.mark.parametrize("t", [12, 13])
 @pytest.mark.parametrize("m,k,b,cus", [(512, 1024, 256, 2), (300, 512, 300, 2), (256, 2048, 200, 1)])
-def test_whole_library_large_grid_route_on_the_cpu(m, k, b, cus):
-    """Q4_K where the 256 x 256 tiles of k_gemm_r8 fill (a pretend chip of `cus` CUs): AUTO takes that kernel, unsplit — two tiles on 2 CUs, four
+def test_whole_library_large_grid_route_on_the_cpu(m, k, b, cus, t):
+    """Q4_K / Q5_K where the 256 x 256 tiles of k_gemm_r8 fill (a pretend chip of `cus` CUs): AUTO takes that kernel, unsplit — two tiles on 2 CUs, four
     ragged tiles on 2 CUs, one tile on 1 CU (its split-K exchange: tools/emul/emul_check.py, kernel="lds") — through the C-ABI on the CPU, within the GEMM bar of the oracle"""
-    r = _emul_module("lib_emul_check").mul_mat(12, m, k, b, seed=m + b, cus=cus, timeout=900)
+    r = _emul_module("lib_emul_check").mul_mat(t, m, k, b, seed=m + b, cus=cus, timeout=900)
     if r is None:
         pytest.skip("the environment cannot host the emulation")
     assert r[0] < 1e-3, r[0]

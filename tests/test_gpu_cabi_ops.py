@@ -265,12 +265,12 @@ def test_mul_mat_fused_against_the_reference_cpu_backend(L, name, t, b, tail):
 
 
 @pytest.mark.parametrize("tail", ["bias_gelu", "bias_residual", "bias_residual_in_place"])
+@pytest.mark.parametrize("t", [R.Q4_K, R.Q5_K])
 @pytest.mark.parametrize("m,k,b", [(16384, 1024, 1024), (16384, 512, 2048)])
-def test_mul_mat_fused_on_the_large_grid_route(L, m, k, b, tail):
-    """Q4_K shapes whose 256 x 256 tiles fill the chip take k_gemm_r8 in AUTO (256 and 512 tiles, unsplit):
+def test_mul_mat_fused_on_the_large_grid_route(L, m, k, b, tail, t):
+    """Q4_K / Q5_K shapes whose 256 x 256 tiles fill the chip take k_gemm_r8 in AUTO (256 and 512 tiles, unsplit):
     the tail rides in ITS store — same bits as MUL_MAT -> ADD -> GELU | ADD on the same route, the product within the GEMM bar of the oracle on sampled
     weight rows, the in-place residual allowed and bit-identical."""
-    t = R.Q4_K
     w = R.random_weights(t, m, k, seed=31)
     rng = np.random.default_rng(9)
     x = rng.uniform(-1, 1, (b, k)).astype(np.float32)

@@ -98,7 +98,7 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < (size_t)B * M; i++) y[i] = -12345.f;
     // the parameter block exactly as cdna4_launch_gemm_lds() (gemm_q_lds.hip) fills it
     gemm_params p{};
-    p.W = w; p.w_row_bytes = (int64_t)(K / 256) * 144;
+    p.W = w; p.w_row_bytes = (int64_t)(K / 256) * ((argc > 10 && atoi(argv[10]) == 13) ? 176 : 144);
     p.xh = (const half_t *)xh; p.xh_row = K; p.Y = y; p.y_row = M; p.M = M; p.K = K; p.B = B; p.splitk = splitk;
     if (tm != 128 && tm != 256) { fprintf(stderr, "tm 128 or 256\n"); return 2; }
     p.tiles_m = (M + tm - 1) / tm; p.tiles_b = (B + 255) / 256;
@@ -113,7 +113,8 @@ int main(int argc, char **argv) {
         p.flags = flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
     }
     const unsigned nblk = (unsigned)(ntiles * splitk);
-    if (form == 2) emu_launch([&] { k_gemm_r8<CDNA4_Q4_K>(p); }, nblk, 512);
+    if (form == 2 && argc > 10 && atoi(argv[10]) == 13) emu_launch([&] { k_gemm_r8<CDNA4_Q5_K>(p); }, nblk, 512);
+    else if (form == 2) emu_launch([&] { k_gemm_r8<CDNA4_Q4_K>(p); }, nblk, 512);
     else if (form) { if (tm == 128) emu_launch([&] { k_gemm_w4<CDNA4_Q4_K, 128>(p); }, nblk, 256); else emu_launch([&] { k_gemm_w4<CDNA4_Q4_K, 256>(p); }, nblk, 256); }
     else if (tm == 128) emu_launch([&] { k_gemm_lds<CDNA4_Q4_K, 128>(p); }, nblk, 512);
     else emu_launch([&] { k_gemm_lds<CDNA4_Q4_K, 256>(p); }, nblk, 512);
