@@ -48,6 +48,7 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
         splitk = 1;
         for (int s = 2; s <= 8; s *= 2) if (ntiles * s <= cdna4_gemm_coresident_cus() && nsb >= 2 * s) splitk = s;
     }
+    if (splitk > 1 && cdna4_gemm_shared_device()) return cdna4_set_error_msg("gemm_lds: the split-K exchange of these kernels waits for co-resident work-groups; not on a shared device (ggml_cdna4_set_shared_device)");
     if (splitk < 1 || nfr % splitk || (splitk > 1 && ntiles * splitk > cus) || nsb < splitk) return cdna4_set_error_msg("gemm_lds: split-K must divide the wave's fragments, leave a superblock per work-group and keep every work-group resident");
     gemm_params p{};
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;

@@ -41,6 +41,7 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
         if (tm == 128 && ntiles * 4 <= cus && nsb >= 8) splitk = 4;
         if (tm == 128 && ntiles * 8 <= cus && nsb >= 16) splitk = 8;
     }
+    if (splitk == 2 && tm == 128 && cdna4_gemm_shared_device()) ticketed2 = true;      // shared device: an EXPLICIT split in two takes the ticketed sum as well
     if (splitk != 1 && splitk != 2 && splitk != 4 && splitk != 8) return cdna4_set_error_msg("gemm_t64: split-K is 1, 2, 4 or 8");
     if (splitk == 2 && (ntiles * 2 > cus || nsb < 2)) return cdna4_set_error_msg("gemm_t64: the split-K hand-off needs every work-group resident and two superblocks");
     if (splitk > 2 && (nsb < splitk || tm != 128)) return cdna4_set_error_msg("gemm_t64: the deep K split is built for 128-row tiles and needs a superblock per work-group");
