@@ -798,7 +798,14 @@ static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st
     // issued first, cold HBM / host wall us: 5.80/5.22, 4.35/4.29, 5.38/4.76, 4.83/4.45 -> 8 waves x 2 rows (one work-group per
     // CU at M = 4096: the quantizer is paid once per CU) when that still gives every CU a work-group, else 8 x 1, else 4 x 1.
     static const int cfg_env = getenv("CDNA4_FUSED_CFG") ? atoi(getenv("CDNA4_FUSED_CFG")) : -1;
-    const int cfg = cfg_env >= 0 ? cfg_env : (a.M >= 4096 ? 1 : (a.M >= 2048 ? 3 : 0));
+    // Round 4 (profiles/r04/decode_cfg.txt, one box, us cold, 8 x 2 vs 8 x 1): rows longer than one round of 64 units stream better from twice as many, half as fat
+    // work-groups — Q4_K 4096 x 14336 11.22 vs 10.64, 4096 x 11008 9.41 vs 8.49, 4096 x 8192 7.41 vs 6.68, 14336 x 4096 10.31 vs 9.45 (4096^2: 4.24 vs 4.56, 11008 x 4096 8.10
+    // vs 8.25: stay); Q6_K 14336 x 4096 17.67 vs 14.48, 11008 x 4096 13.88 vs 12.17 (its K-long shapes: level); Q4_0: 8 x 2 everywhere.
+    int cfg = cfg_env >= 0 ? cfg_env : (a.M >= 4096 ? 1 : (a.M >= 2048 ? 3 : 0));
+    if (cfg_env < 0 && cfg == 1) {
+        if (TYPE == CDNA4_Q4_K && (a.K >= 8192 || a.M >= 12288)) cfg = 3;
+        if (TYPE == CDNA4_Q6_K && a.M >= 8192) cfg = 3;
+    }
     if constexpr (TYPE == CDNA4_Q4_K || TYPE == CDNA4_Q5_K) {
         // the DMA form of the 8 x 2 configuration (whole weight rows requested up front; at most two activation chunks per thread: K <= 16384; activations +
         // 16 rows within the 160 KB of LDS).  OPT-IN (CDNA4_DECODE_DMA=1; =2: only for K > 4096) — a measured loss on MI355X, one box, us cold / cache-warm,
