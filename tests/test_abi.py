@@ -75,6 +75,24 @@ def test_workspace_size_is_monotonic_and_aligned(built):
     assert L.ggml_cdna4_mul_mat_workspace_size(0, 4096, 8) == 0     # F32 is not a quantized weight type
 
 
+def test_tail_predictor_is_the_routing_itself_and_needs_no_device(built):
+    """ggml_cdna4_mul_mat_fused_residual_may_alias asks the ROUTING (gemm_q_mfma.hip: cdna4_gemm_q_fuses_tail runs cdna4_launch_gemm_q with a probe armed — no scratch, no
+    launch) whether the kernel AUTO would take applies the tail in its store; host logic, callable without a GPU.  Pinned here: every route that stores whole finished tiles says
+    1 — the GEMV / int8 matrix-core family at small batches, k_gemm_kq_t64 / k_gemm_r8 (Q4_K, Q5_K), the 128 x 128-tile kernels of Q5_K / Q6_K / Q4_0 / Q8_0, and the GEMMs behind the
+    exact re-encodings (Q5_0, Q2_K, IQ4_NL, IQ4_XS ...) — and the older per-lane-load kernels (32-weight formats with K not a multiple of 256) say 0: there the call with an aliased
+    residual is refused instead of computing 2 (W x) + b."""
+    import ctypes as C
+    L = C.CDLL(os.path.join(ROOT, "ggml_amd", "lib", "libcdna4_kernels.so"))
+    f = L.ggml_cdna4_mul_mat_fused_residual_may_alias
+    f.restype, f.argtypes = C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64]
+    for t in (12, 13, 14, 2, 8, 6, 10, 11, 3, 7, 20, 23):
+        for (m, k, b) in ((4096, 4096, 1), (4096, 4096, 4), (4096, 4096, 16), (4096, 4096, 96), (4096, 4096, 512), (32768, 8192, 512), (3072, 768, 64)):
+            assert f(t, m, k, b) == 1, (t, m, k, b)
+    for t in (2, 8, 6):                                                      # K % 256 != 0: k_gemm_q stores the plain product (k_epilogue behind it)
+        assert f(t, 4096, 4032, 96) == 0 and f(t, 4096, 4160, 512) == 0, t
+        assert f(t, 4096, 4032, 4) == 1                                        # (few rows: the GEMV's store)
+
+
 def test_no_cpu_fallback(built):
     """without a GPU the product must raise, not compute on the host"""
     import torch
