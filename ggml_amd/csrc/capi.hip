@@ -278,6 +278,23 @@ int ggml_cdna4_mul_mat_fused_residual_may_alias(int type, int64_t M, int64_t K, 
     cdna4_epilogue e{}; e.act = 1;
     return cdna4_gemm_q_fuses_tail(gemm_args_of(type, (const void *)(uintptr_t)256, (int64_t)ggml_cdna4_row_size(type, K), (const void *)(uintptr_t)256, (float *)(uintptr_t)256, M, M, K, B, 0, 0, e)) ? 1 : 0;
 }
+// the route ggml_cdna4_mul_mat(path = AUTO) takes for a contiguous, 256-byte-aligned call of this shape on the current device — host logic only, no launch, no scratch:
+//   1 one launch (activation quantizer inside the GEMV)     2 quantize + GEMV (columns staged in LDS)     3 quantize + int8 matrix-core kernel
+//   10 quantize + k_gemm_kq_t64     12 + k_gemm_r8     13 + a 128 x 128-tile kernel     14 + an older per-lane-load GEMM;   + 100: behind an exact re-encoding of the weights
+int ggml_cdna4_mul_mat_route(int type, int64_t M, int64_t K, int64_t B) {
+    if (!is_q(type) || M <= 0 || B <= 0 || K <= 0 || ggml_cdna4_row_size(type, K) == 0) return 0;
+    if (cdna4_convert_weights_kmul(type) == 1) {
+        const int tgt = cdna4_convert_weights_target(type);
+        if (tgt >= 0 && tgt != type && B >= 9 && use_mmq(tgt, M, K, B)) return 103;
+    }
+    if (use_mmq(type, M, K, B)) return 3;
+    const int path = resolve_path(type, GGML_CDNA4_PATH_AUTO, M, K, B);
+    if (path == GGML_CDNA4_PATH_GEMV) {
+        const int64_t nbt = B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8));
+        return (cdna4_gemv_fused_supported(type, K, B) && (B == 1 || nbt * K <= 32768)) ? 1 : 2;
+    }
+    return cdna4_gemm_q_route(gemm_args_of(type, (const void *)(uintptr_t)256, (int64_t)ggml_cdna4_row_size(type, K), (const void *)(uintptr_t)256, (float *)(uintptr_t)256, M, M, K, B, 0, 0, cdna4_epilogue{}));
+}
 int ggml_cdna4_mul_mat_fused(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
                              int64_t M, int64_t K, int64_t B, const float *bias, int act, const float *residual, int64_t residual_row_stride,
                              void *workspace, size_t workspace_bytes, void *stream) {

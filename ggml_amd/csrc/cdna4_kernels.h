@@ -79,6 +79,7 @@ struct cdna4_gemm_args {
 int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st);
 // does cdna4_launch_gemm_q(a) apply a.epi itself (bias / GELU / residual in the store of k_gemm_kq_t64)?  Then a residual may alias Y exactly.
 bool cdna4_gemm_q_fuses_tail(const cdna4_gemm_args &a);
+int cdna4_gemm_q_route(const cdna4_gemm_args &a);              // the prefill kernel AUTO (or the given variant) would launch: ids in gemm_q_mfma.hip; no side effects
 int cdna4_gemm_set_shared_device(int shared);          // gemm_q_mfma.hip: 1 = never choose a split-K exchange that spins on a co-resident partner; returns the old value
 // gemm_q_t64.hip — grouped MUL_MAT_ID: a.B = rows of the expert-sorted activation image, a.Y rows indexed through row_dst
 int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);

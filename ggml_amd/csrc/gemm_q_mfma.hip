@@ -443,7 +443,12 @@ static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: sp
 static int cu_count() {                                            // of the CURRENT device (cached per device)
     static int n[16] = {0};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 1; }
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+        // no device (the CPU test suite asking ggml_cdna4_mul_mat_route which kernel a shape would take): CDNA4_ASSUME_CUS names the part to answer for
+        (void)hipGetLastError();
+        static const int assumed = getenv("CDNA4_ASSUME_CUS") ? atoi(getenv("CDNA4_ASSUME_CUS")) : 1;
+        return assumed > 0 ? assumed : 1;
+    }
     if (!n[dev]) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n[dev] = pr.multiProcessorCount; else { (void)hipGetLastError(); n[dev] = 1; } }
     return n[dev];
 }
@@ -467,8 +472,11 @@ static int co_cus() { return cdna4_gemm_coresident_cus(); }
 
 // Route probe (the tail predictor must not be a hand-kept copy of the routing): cdna4_gemm_q_fuses_tail() runs the SAME routing code with the
 // probe armed; every route ends in ROUTE_END(does this kernel apply a.epi in its store?) in front of its first side effect (scratch, zero-fill, launch).
-static thread_local struct { bool active, fuses; } g_probe = {false, false};
-#define ROUTE_END(f) do { if (g_probe.active) { g_probe.fuses = (f); return 0; } } while (0)
+static thread_local struct { bool active, fuses; int kernel, reencoded; } g_probe = {false, false, 0, 0};
+// kernel ids (ggml_cdna4_mul_mat_route, include/ggml_cdna4.h): 10 k_gemm_kq_t64, 12 k_gemm_r8, 13 the 128 x 128-tile kernels (k_gemm_kq_w8 / _w8p / _w12), 14 the older per-lane-load
+// kernels (k_gemm_q, k_gemm_kq_pipe), 15 k_gemm_lds / k_gemm_w4 (explicit variants only)
+#define ROUTE_END_K(f, kid) do { if (g_probe.active) { g_probe.fuses = (f); g_probe.kernel = (kid); return 0; } } while (0)
+#define ROUTE_END(f) ROUTE_END_K(f, 0)
 
 template <int TYPE>
 static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t st, int exp = 0) {
@@ -485,7 +493,7 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
     static const bool handoff_env = getenv("CDNA4_W8_HANDOFF") && atoi(getenv("CDNA4_W8_HANDOFF")) != 0;     // (A/B: the spinning hand-off for AUTO splits too)
     const bool ticketed = splitk == 2 && a.splitk <= 0 && (size_t)ntiles <= 8192 && !handoff_env;
     const bool exchange = ticketed || (splitk == 2 && ntiles * 2 <= co_cus());
-    ROUTE_END(splitk == 1 || exchange);
+    ROUTE_END_K(splitk == 1 || exchange, 13);
     if (splitk > 1 && !exchange) p.epi = cdna4_epilogue{};
     if (exchange) {
         // exchange slots after a FIXED 64-KB flag area (so that no shape's slots ever overlay another shape's flags).  A flag is
@@ -590,19 +598,19 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     }
     if constexpr (TYPE == CDNA4_Q4_K) {
         // bit13 = k_gemm_kq_t64 (gemm_q_t64.hip: 64(m) x 128(b) wave tiles); bit14 / bit15 force its 128- / 256-row tile
-        if (wlds && (variant & 8192)) { ROUTE_END(true); return cdna4_launch_gemm_t64(a, (variant & 16384) ? 128 : ((variant & 32768) ? 256 : 0), a.splitk, st); }
+        if (wlds && (variant & 8192)) { ROUTE_END_K(true, 10); return cdna4_launch_gemm_t64(a, (variant & 16384) ? 128 : ((variant & 32768) ? 256 : 0), a.splitk, st); }
         // auto (round 2): k_gemm_kq_t64 for every prefill shape — 128-row tiles (hand-off split-K = 2 while both work-groups of a tile
         // are resident, uneven for odd superblock counts), 256-row tiles once the grid holds two of them per CU.  MI355X, same box, same
         // data: 4096x4096x512 24.25 vs 24.68 us on k_gemm_kq_w12, 4096x11008x512 50.95 vs 52.57, 8192x4096x512 37.1 vs 38.1,
         // 32768x8192x512 (256-row tiles) 239-243 vs 265.
         // auto (round 4): k_gemm_r8 (gemm_r8.inc: 32 x 256 wave tiles, half the unpack VALU per MFMA) where its 256 x 256 tiles fill the chip unsplit — 9-10 % ahead there
-        if (wlds && a.variant <= 0 && a.splitk <= 0 && cdna4_gemm_r8_preferred(a)) { ROUTE_END(true); return cdna4_launch_gemm_lds(a, 256, 1, st, 2); }
-        if (wlds && a.variant <= 0 && a.splitk <= 2) { ROUTE_END(true); return cdna4_launch_gemm_t64(a, 0, a.splitk, st); }   // (deeper, atomic splits: the older kernels below)
+        if (wlds && a.variant <= 0 && a.splitk <= 0 && cdna4_gemm_r8_preferred(a)) { ROUTE_END_K(true, 12); return cdna4_launch_gemm_lds(a, 256, 1, st, 2); }
+        if (wlds && a.variant <= 0 && a.splitk <= 2) { ROUTE_END_K(true, 10); return cdna4_launch_gemm_t64(a, 0, a.splitk, st); }   // (deeper, atomic splits: the older kernels below)
     }
     if constexpr (TYPE == CDNA4_Q5_K) {
         // round 4: k_gemm_r8 also unpacks Q5_K (its fifth bits cost 4-5 VALU per half2 pair: the format that gains most from one fragment meeting eight activation
         // fragments) — the same rule as Q4_K: grids of at least one 256 x 256 tile per CU, unsplit
-        if (wlds && a.variant <= 0 && a.splitk <= 0 && cdna4_gemm_r8_preferred(a)) { ROUTE_END(true); return cdna4_launch_gemm_lds(a, 256, 1, st, 2); }
+        if (wlds && a.variant <= 0 && a.splitk <= 0 && cdna4_gemm_r8_preferred(a)) { ROUTE_END_K(true, 12); return cdna4_launch_gemm_lds(a, 256, 1, st, 2); }
     }
     if (splitk < 1 || (kunits % splitk && !uneven)) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
     if constexpr (TYPE == CDNA4_Q4_0 || TYPE == CDNA4_Q8_0 || TYPE == CDNA4_Q6_K) {
@@ -647,7 +655,7 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     if constexpr (CAN_LDS) {
         if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant & 4096) ? 65 : ((variant & 2048) ? 64 : ((variant >> 5) & 31)), st, variant >> 16);
     }
-    ROUTE_END(false);                                                    // the older kernels below store the plain product (k_epilogue behind them)
+    ROUTE_END_K(false, 14);                                              // the older kernels below store the plain product (k_epilogue behind them)
     if constexpr (CAN_LDS) {
         if (wlds && !(variant & 8)) return wide ? launch_pipe<TYPE, 4>(a, splitk, st) : launch_pipe<TYPE, 2>(a, splitk, st);
         if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
@@ -695,10 +703,17 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st);
 // does the route cdna4_launch_gemm_q() takes for these arguments apply a.epi in its store?  (k_gemm_kq_t64, k_gemm_r8 and the 128 x 128-tile kernels of
 // gemm_w8_epilogue.inc outside their atomic-sum split; also behind the exact re-encodings.)  Runs the routing itself with the probe armed: no side effects.
 bool cdna4_gemm_q_fuses_tail(const cdna4_gemm_args &a) {
-    g_probe.active = true; g_probe.fuses = false;
+    g_probe.active = true; g_probe.fuses = false; g_probe.kernel = 0; g_probe.reencoded = 0;
     const int rc = cdna4_launch_gemm_q(a, nullptr);
     g_probe.active = false;
     return rc == 0 && g_probe.fuses;
+}
+// which prefill kernel would cdna4_launch_gemm_q() launch for these arguments (ids above; + 100 behind an exact re-encoding; 0: none / error)?  No side effects.
+int cdna4_gemm_q_route(const cdna4_gemm_args &a) {
+    g_probe.active = true; g_probe.fuses = false; g_probe.kernel = 0; g_probe.reencoded = 0;
+    const int rc = cdna4_launch_gemm_q(a, nullptr);
+    g_probe.active = false;
+    return rc == 0 && g_probe.kernel ? g_probe.kernel + 100 * g_probe.reencoded : 0;
 }
 
 int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
@@ -711,6 +726,7 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
     if (a.type == CDNA4_Q5_0 || a.type == CDNA4_Q3_K || a.type == CDNA4_Q2_K || a.type == CDNA4_Q4_1 || a.type == CDNA4_Q5_1 || a.type == CDNA4_IQ4_NL || a.type == CDNA4_IQ4_XS) {
         // no MFMA kernel of their own: re-encode EXACTLY as Q8_0 / Q6_K into scratch (convert_w.hip) and run that format's GEMM
         uint8_t *cw = (uint8_t *)(uintptr_t)256;                         // (route probe: an aligned stand-in, never dereferenced)
+        if (g_probe.active) g_probe.reencoded = 1;
         if (!g_probe.active) {
             cw = (uint8_t *)get_scratch(cdna4_convert_weights_bytes(a.type, a.M, a.K) + 256, 3);
             if (!cw) return cdna4_set_error_msg("gemm_q: cannot allocate the weight re-encoding scratch");
@@ -729,7 +745,7 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
     }
     // variant bit 28 = k_gemm_lds (gemm_q_lds.hip); bits 29 / 30 force its 128- / 256-row tile (bits 16-27: ablation mask of -DCDNA4_ABLATIONS builds)
     // bit 25 with bit 28: its one-wave-per-SIMD form k_gemm_w4; bit 26 with bit 28: k_gemm_r8 (in-register unpack, 32 x 256 wave tiles)
-    if (a.variant > 0 && (a.variant & (1 << 28))) { ROUTE_END((a.variant & (1 << 26)) != 0); }
+    if (a.variant > 0 && (a.variant & (1 << 28))) { ROUTE_END_K((a.variant & (1 << 26)) != 0, (a.variant & (1 << 26)) ? 12 : 15); }
     if (a.variant > 0 && (a.variant & (1 << 28))) return cdna4_launch_gemm_lds(a, (a.variant & (1 << 29)) ? 128 : ((a.variant & (1 << 30)) ? 256 : 0), a.splitk, st, (a.variant & (1 << 26)) ? 2 : (a.variant & (1 << 25)) ? 1 : 0);
     switch (a.type) {
         case CDNA4_Q4_K: return launch_type<CDNA4_Q4_K>(a, st);

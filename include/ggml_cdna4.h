@@ -64,6 +64,12 @@ int          ggml_cdna4_device_count(void);               /* number of visible H
  * small grids take the ticketed split (the last work-group to arrive sums; nobody waits) or no split: slower at M = 4096, never a timed-out exchange.
  * 0 (default, or GGML_CDNA4_SHARED_DEVICE unset): the caller owns the device, as ggml_backend_sched does for its streams.  Returns the previous value. */
 int          ggml_cdna4_set_shared_device(int shared);
+/* Which route does ggml_cdna4_mul_mat(path = AUTO) take for a contiguous, 256-byte-aligned call of this shape on the current device?  Host logic only (no launch):
+ *   1 one launch, activation quantizer inside the GEMV      2 quantize + GEMV      3 quantize + int8 matrix-core kernel (3..64 rows)
+ *   10 quantize + k_gemm_kq_t64      12 quantize + k_gemm_r8      13 quantize + a 128x128-tile kernel      14 quantize + an older per-lane-load GEMM
+ *   + 100: behind an exact re-encoding of the weights (ggml_cdna4_convert_weights);  0: not a supported call.
+ * For hosts that want to know what a shape costs before they choose a batch size, and for the tests that pin the route table (profiles/r04/batch_sweep.txt). */
+int          ggml_cdna4_mul_mat_route(int type, int64_t M, int64_t K, int64_t B);
 int          ggml_cdna4_set_device(int device);
 /* profiling hook (tools/microbench/gemm_bench only): a 64 KiB device buffer makes the 8-wave GEMM record per-phase
  * s_memtime stamps of its first work-group; NULL (default) selects the uninstrumented kernel */

@@ -93,6 +93,35 @@ def test_tail_predictor_is_the_routing_itself_and_needs_no_device(built):
         assert f(t, 4096, 4032, 4) == 1                                        # (few rows: the GEMV's store)
 
 
+def test_route_table_for_a_256_cu_part(built):
+    """ggml_cdna4_mul_mat_route: the kernel AUTO takes per (format, shape), answered by the routing code itself without a device (CDNA4_ASSUME_CUS names the part).  Pins what the
+    device-time sweeps of round 4 derived (profiles/r04/batch_sweep.txt, gemm_bench.txt, t64_tiles.txt): 1..4 rows one-launch GEMV, 5..48 rows the int8 matrix cores (Q6_K to 32;
+    49..64 for small matrices and Q8_0 / Q5_K), above that k_gemm_kq_t64 for Q4_K — k_gemm_r8 once 256 x 256 tiles fill the chip, also for Q5_K —, the 128 x 128-tile kernels for
+    the other formats, the older per-lane-load GEMM only for K % 256 != 0; re-encoded formats follow their target (+ 100)."""
+    import subprocess, sys, json
+    code = r"""
+import ctypes as C, json, sys
+L = C.CDLL(sys.argv[1])
+f = L.ggml_cdna4_mul_mat_route; f.restype = C.c_int; f.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64]
+out = {}
+for t in (12, 13, 14, 2, 8, 6, 10, 23):
+    out[t] = [f(t, 4096, 4096, b) for b in (1, 2, 4, 6, 16, 48, 64, 96, 512)] + [f(t, 32768, 8192, 512), f(t, 4096, 14336, 64), f(t, 4096, 4032, 96), f(t, 16384, 8192, 512), f(t, 4096, 14336, 4)]
+print(json.dumps(out))
+"""
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "ggml_amd", "lib", "libcdna4_kernels.so")], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, CDNA4_ASSUME_CUS="256", HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1"))
+    assert r.returncode == 0, r.stderr[-800:]
+    got = {int(k): v for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items()}
+    #            rows at 4096^2:  1  2  4  6  16  48  64  96  512 |  C5  4096x14336x64  K=4032x96  16384x8192x512  4096x14336x4
+    assert got[12] == [1, 1, 1, 3, 3, 3, 3, 10, 10, 12, 10, 0, 10, 3]
+    assert got[13] == [1, 1, 1, 3, 3, 3, 3, 13, 13, 12, 3, 0, 13, 3]
+    assert got[14] == [1, 1, 1, 3, 3, 13, 13, 13, 13, 13, 13, 0, 13, 3]
+    assert got[2] == [1, 1, 1, 3, 3, 3, 3, 13, 13, 13, 13, 14, 13, 3]
+    assert got[8] == [1, 1, 1, 3, 3, 3, 3, 13, 13, 13, 3, 14, 13, 3]
+    assert got[6] == [1, 2, 2, 2, 103, 103, 103, 113, 113, 113, 103, 114, 113, 2]
+    assert got[10][:9] == [1, 2, 2, 2, 113, 113, 113, 113, 113] and got[23][9] == 113
+
+
 def test_no_cpu_fallback(built):
     """without a GPU the product must raise, not compute on the host"""
     import torch
