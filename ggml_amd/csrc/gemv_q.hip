@@ -802,7 +802,8 @@ static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st
     // work-groups — Q4_K 4096 x 14336 11.22 vs 10.64, 4096 x 11008 9.41 vs 8.49, 4096 x 8192 7.41 vs 6.68, 14336 x 4096 10.31 vs 9.45 (4096^2: 4.24 vs 4.56, 11008 x 4096 8.10
     // vs 8.25: stay); Q6_K 14336 x 4096 17.67 vs 14.48, 11008 x 4096 13.88 vs 12.17 (its K-long shapes: level); Q4_0: 8 x 2 everywhere.
     int cfg = cfg_env >= 0 ? cfg_env : (a.M >= 4096 ? 1 : (a.M >= 2048 ? 3 : 0));
-    if (cfg_env < 0 && cfg == 1) {
+    static const int dma_knob = getenv("CDNA4_DECODE_DMA") ? atoi(getenv("CDNA4_DECODE_DMA")) : 0;      // (the opt-in DMA form below is a form of the 8 x 2 configuration)
+    if (cfg_env < 0 && cfg == 1 && dma_knob <= 0) {
         if (TYPE == CDNA4_Q4_K && (a.K >= 8192 || a.M >= 12288)) cfg = 3;
         if (TYPE == CDNA4_Q6_K && a.M >= 8192) cfg = 3;
     }
