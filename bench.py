@@ -163,7 +163,17 @@ def graph_us(dev, fn, n=40):
         return events_us(fn, 100, 10)
 
 
-def kernel_name(t, m, k, b):
+def one_launch(t, m, k, b):
+    """does ggml_cdna4_mul_mat take this shape as ONE launch (route 11: the activation quantizer and a grid barrier inside k_gemm_kq_t64<.., FQ>)?  Asked of the library's own routing."""
+    from ggml_amd import native
+    return native.lib().ggml_cdna4_mul_mat_route(t, m, k, b) == 11
+
+
+def kernel_name(t, m, k, b, fused=False):
+    if fused:
+        return ("k_gemm_kq_t64<Q4_K, 128, FQ> — ONE launch per step: every work-group quantizes its share of the fp32 activations to the Q8_K-rounded fp16 image (write-through), "
+                "grid barrier with the first weight stages already in flight, then the 128x128-tile loop (8 waves x 64(m)x128(b) x K/4, LDS-DMA by the four older waves; split in two by hand-off "
+                "inside the resident grid)")
     if t == Q4_K and b > 64:
         nt = ((m + 255) // 256) * ((b + 255) // 256)                   # cdna4_gemm_r8_preferred (gemm_q_lds.hip) on a 256-CU part
         if k % 256 == 0 and nt >= 256 and nt * 10 >= -(-nt // 256) * 256 * 9:
@@ -172,7 +182,7 @@ def kernel_name(t, m, k, b):
         eff = lambda n: n / (-(-n // 256) * 256)                        # cdna4_launch_gemm_t64's tile rule on a 256-CU part
         if t256 * 2 > 256 and eff(t256) * 1.10 >= eff(t128):
             return "k_gemm_kq_t64<Q4_K, 256> (256x128 tile, 8 waves x 64(m)x128(b), LDS-DMA by the four older waves in front of the stage barrier, no K split)"
-        return "k_gemm_kq_t64<Q4_K, 128> (128x128 tile, 8 waves x 64(m)x128(b) x K/4, LDS-DMA by the four older waves, split-K=2 hand-off on small grids)"
+        return "k_gemm_kq_t64<Q4_K, 128> (128x128 tile, 8 waves x 64(m)x128(b) x K/4, LDS-DMA by the four older waves; small grids split in two with the ticketed sum)"
     return "k_gemm_kq_w12 / k_gemm_kq_w8p (128x128 tile, cross-stage unpack/MFMA pipeline)"
 
 
@@ -674,10 +684,13 @@ def main():
     flops_step = h.flops * world
     value = flops_step / (ms_per_step * 1e-3) / 1e12
 
-    # ---- the dominant kernel alone (activations prepared once), HIP events on the launch stream; likewise the activation quantizer alone
+    # ---- the dominant kernel alone, HIP events on the launch stream.  Where the step is ONE launch (route 11) that launch IS the dominant kernel and its duration is the
+    # step's; the two launches it replaces (activation quantizer alone, GEMM alone on prepared activations) are timed beside it for the record
+    fused = args.variant == 0 and args.splitk == 0 and one_launch(Q4_K, M, K, B)
     quant_us = events_us(h.prepare, args.steps, 10)
     h.prepare()
-    gemm_us = events_us(h.gemm_only, args.steps, 10)
+    gemm2_us = events_us(h.gemm_only, args.steps, 10)
+    gemm_us = events_us(h.step, args.steps, 10) if fused else gemm2_us
     gemm_tf = h.flops / gemm_us / 1e6
     out = None
     if rank == 0:
@@ -689,7 +702,7 @@ def main():
                 raise RuntimeError("lean")
             hz = Hot(dev, Q4_K, np.zeros_like(w), M, K, np.zeros_like(x), args.variant, args.splitk)
             hz.ws.zero_()
-            zero_us = round(events_us(hz.gemm_only, 40, 10), 3)
+            zero_us = round(events_us(hz.step if fused else hz.gemm_only, 40, 10), 3)
             del hz
         except Exception:  # noqa: BLE001
             pass
@@ -700,13 +713,16 @@ def main():
             "config": {"workload": "Q4_K MUL_MAT [4096x4096]·[4096x512] per GPU; step = Q8_K activation quantize + fp16-MFMA GEMM, W and fp32 X resident in HBM",
                        "M_per_gpu": M, "K": K, "B": B, "parallelism": "row-split x%d, output left sharded" % world, "gemm_variant": args.variant, "splitk": args.splitk},
             "tokens_per_s": round(B * world / (ms_per_step * 1e-3), 1),
-            "roofline": {"bound": "mfma", "kernel": kernel_name(Q4_K, M, K, B) if args.variant == 0 else "gemm variant %d" % args.variant,
+            "roofline": {"bound": "mfma", "kernel": kernel_name(Q4_K, M, K, B, fused) if args.variant == 0 else "gemm variant %d" % args.variant,
                          "achieved": round(gemm_tf, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tf / MFMA_F16_PEAK_TFLOPS, 4),
-                         "traffic": pmc_traffic("k_gemm_kq_t64<12, 128") if args.variant == 0 else None,
+                         "traffic": pmc_traffic("k_gemm_kq_t64<12, 128, false, 0, false, true>" if fused else "k_gemm_kq_t64<12, 128, false, 0, false, false>") if args.variant == 0 else None,
                          "traffic_note": "HBM-side bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) from the rocprofv3 PMC passes of this command, profiles/rNN/pmc_summary.txt",
                          "us_per_launch": round(gemm_us, 3), "algorithmic_flops_per_launch": h.flops, "us_per_launch_all_zero_operands": zero_us,
-                         # the whole step (quantizer + GEMM + the launch gap between them) against the same roof: value / peak
-                         "step_frac": round(value / world / MFMA_F16_PEAK_TFLOPS, 4)},
+                         # the whole step as the host loop times it (one launch, or quantizer + GEMM + the gap between them) against the same roof: value / peak
+                         "step_frac": round(value / world / MFMA_F16_PEAK_TFLOPS, 4),
+                         "launches_per_step": 1 if fused else 2,
+                         # the two launches the one-launch step replaces, each alone: the activation quantizer and the GEMM on prepared activations (AUTO's ticketed split)
+                         "two_launch_components_us": {"k_quantize_q8_K": round(quant_us, 3), "k_gemm_kq_t64<Q4_K, 128>": round(gemm2_us, 3)}},
         }
         # the step's other kernel, HBM-bound: reads the fp32 activations once, writes the pair-interleaved fp16 image + per-256 scale and per-16 sums
         qbytes = B * K * 4 + B * K * 2 + B * (K // 256) * 4 + B * (K // 16) * 2

@@ -249,6 +249,22 @@ static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const floa
         g.M = (int)M; g.K = (int)K; g.ncol = (int)B; g.ids = nullptr; g.epi = epi;
         return B == 1 ? cdna4_launch_gemv_q_fused(g, X, (hipStream_t)stream) : cdna4_launch_gemv_q_fused_n(g, X, x_row_stride, (hipStream_t)stream);
     }
+    if (path == GGML_CDNA4_PATH_GEMM && workspace && !((uintptr_t)workspace & 255)) {
+        // ONE launch for the whole step where the routing says so (k_gemm_kq_t64<.., FQ>: every work-group quantizes its share of X into the image in the workspace,
+        // a grid barrier, then the multiply — what ggml_compute_forward_mul_mat does inside one op, ggml-cpu.c:7490-7509 + :7428-7605); same sums, same order as the
+        // two launches below.  The routing code itself answers (probed: no side effects).
+        const ws_view v = carve(type, K, B, workspace);
+        if (workspace_bytes < v.total) return cdna4_set_error_msg("mul_mat: workspace too small");
+        cdna4_gemm_args a = gemm_args_of(type, W, w_row_bytes, v.xh, Y, y_row_stride, M, K, B, gemm_variant, splitk, epi);
+        a.xf = X; a.xf_row_elems = x_row_stride;
+        if (cdna4_gemm_q_fuses_quantizer(a)) {
+            const bool tail_done = cdna4_gemm_q_fuses_tail(a);
+            if (!tail_done) a.epi = cdna4_epilogue{};
+            const int rc1 = cdna4_launch_gemm_q(a, (hipStream_t)stream);
+            if (rc1 || tail_done) return rc1;
+            return cdna4_launch_epilogue(Y, y_row_stride, M, B, epi, (hipStream_t)stream);
+        }
+    }
     int rc = ggml_cdna4_prepare_act(type, X, x_row_stride, K, B, workspace, workspace_bytes, path, stream);
     if (rc) return rc;
     if (path == GGML_CDNA4_PATH_GEMV) {                                  // a few activation rows: the tail rides in the GEMV's store
@@ -280,7 +296,7 @@ int ggml_cdna4_mul_mat_fused_residual_may_alias(int type, int64_t M, int64_t K, 
 }
 // the route ggml_cdna4_mul_mat(path = AUTO) takes for a contiguous, 256-byte-aligned call of this shape on the current device — host logic only, no launch, no scratch:
 //   1 one launch (activation quantizer inside the GEMV)     2 quantize + GEMV (columns staged in LDS)     3 quantize + int8 matrix-core kernel
-//   10 quantize + k_gemm_kq_t64     12 + k_gemm_r8     13 + a 128 x 128-tile kernel     14 + an older per-lane-load GEMM;   + 100: behind an exact re-encoding of the weights
+//   10 quantize + k_gemm_kq_t64     11 ONE launch: the quantizer inside k_gemm_kq_t64 (resident grids on an owned device)     12 + k_gemm_r8     13 + a 128 x 128-tile kernel     14 + an older per-lane-load GEMM;   + 100: behind an exact re-encoding of the weights
 int ggml_cdna4_mul_mat_route(int type, int64_t M, int64_t K, int64_t B) {
     if (!is_q(type) || M <= 0 || B <= 0 || K <= 0 || ggml_cdna4_row_size(type, K) == 0) return 0;
     if (cdna4_convert_weights_kmul(type) == 1) {
@@ -293,7 +309,9 @@ int ggml_cdna4_mul_mat_route(int type, int64_t M, int64_t K, int64_t B) {
         const int64_t nbt = B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8));
         return (cdna4_gemv_fused_supported(type, K, B) && (B == 1 || nbt * K <= 32768)) ? 1 : 2;
     }
-    return cdna4_gemm_q_route(gemm_args_of(type, (const void *)(uintptr_t)256, (int64_t)ggml_cdna4_row_size(type, K), (const void *)(uintptr_t)256, (float *)(uintptr_t)256, M, M, K, B, 0, 0, cdna4_epilogue{}));
+    cdna4_gemm_args ra = gemm_args_of(type, (const void *)(uintptr_t)256, (int64_t)ggml_cdna4_row_size(type, K), (const void *)(uintptr_t)256, (float *)(uintptr_t)256, M, M, K, B, 0, 0, cdna4_epilogue{});
+    ra.xf = (const float *)(uintptr_t)256; ra.xf_row_elems = K;       // (the call hands its fp32 rows over: the one-launch step is a candidate)
+    return cdna4_gemm_q_route(ra);
 }
 int ggml_cdna4_mul_mat_fused(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
                              int64_t M, int64_t K, int64_t B, const float *bias, int act, const float *residual, int64_t residual_row_stride,

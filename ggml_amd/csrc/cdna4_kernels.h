@@ -75,10 +75,16 @@ struct cdna4_gemm_args {
     int splitk;                                     // 0 = auto
     cdna4_epilogue epi;                             // the MUL_MAT's element-wise tail (zeroed = none): applied IN THE STORE by the kernels for which
                                                     // cdna4_gemm_q_fuses_tail() holds; the others ignore it (the caller appends cdna4_launch_epilogue)
+    // the fp32 activation rows (rows xf_row_elems apart), or nullptr: when given, a route for which cdna4_gemm_q_fuses_quantizer() holds writes the image `xh` ITSELF
+    // (the one-launch step: k_gemm_kq_t64<.., FQ>); every other route ignores them and expects `xh` prepared (ggml_cdna4_prepare_act)
+    const float *xf; int64_t xf_row_elems;
 };
 int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st);
 // does cdna4_launch_gemm_q(a) apply a.epi itself (bias / GELU / residual in the store of k_gemm_kq_t64)?  Then a residual may alias Y exactly.
 bool cdna4_gemm_q_fuses_tail(const cdna4_gemm_args &a);
+// does that route quantize a.xf itself (then the caller skips the activation quantizer's launch)?  The routing code itself, probed: no side effects.
+bool cdna4_gemm_q_fuses_quantizer(const cdna4_gemm_args &a);
+bool cdna4_gemm_t64_fuses_quantizer(const cdna4_gemm_args &a, int tm, int splitk);      // gemm_q_t64.hip: the launcher's own plan
 int cdna4_gemm_q_route(const cdna4_gemm_args &a);              // the prefill kernel AUTO (or the given variant) would launch: ids in gemm_q_mfma.hip; no side effects
 int cdna4_gemm_set_shared_device(int shared);          // gemm_q_mfma.hip: 1 = never choose a split-K exchange that spins on a co-resident partner; returns the old value
 // gemm_q_t64.hip — grouped MUL_MAT_ID: a.B = rows of the expert-sorted activation image, a.Y rows indexed through row_dst

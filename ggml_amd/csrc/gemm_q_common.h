@@ -462,7 +462,37 @@ struct gemm_params {
     const int32_t *tile_expert; const int32_t *row_dst; int64_t w_expert_bytes;
     // k_gemm_kq_t64 only (appended last): the MUL_MAT's tail, applied to every element in the store that produces it (epilogue.h)
     cdna4_epilogue epi;
+    // k_gemm_kq_t64<.., FQ> only (appended last): the ONE-LAUNCH step — the fp32 activation rows (xf, rows xf_row elements apart) are quantized to the Q8_K-rounded
+    // fp16 image `xh` by the work-groups themselves in front of a grid barrier (gbar: its words, see cdna4_grid_barrier)
+    const float *xf; int64_t xf_row; unsigned *gbar;
 };
+
+// Grid-wide barrier of a launch whose work-groups are ALL resident (the launcher's condition; one thread per work-group calls it, behind a __syncthreads()
+// that follows every wave's `s_waitcnt vmcnt(0)` on its write-through stores).  Two levels so that no word takes more than 32 + 8 arrivals: work-group b arrives
+// at the counter of group b & 7 (dispatch puts block b on XCD b % 8 — a speed assumption only), the last of a group at the top counter, the last of those bumps every
+// group's generation word, which is what the others poll (relaxed agent-scope loads, s_sleep between polls).  Counters are back at zero when the launch ends and the
+// generations only ever grow: no per-launch state on the host, so the launch replays from a HIP graph.  Words (each on its own 128-byte line): gb[32 g] arrivals of
+// group g, gb[256] top, gb[288 + 32 g] generation of group g.  Returns false when the partners never arrived (a grid that was not resident after all): the
+// caller poisons its output.  Data published before the barrier must have been stored write-through (sc1) and is read behind it with sc1 loads
+// (MI355X_MICROARCH.md "inter-workgroup visibility": {sc1 stores + vmcnt(0) + flag | sc1 loads} needs no fence on either side).
+__device__ __forceinline__ bool cdna4_grid_barrier(unsigned *gb, unsigned nblk) {
+    const unsigned g = blockIdx.x & 7u, ngrp = nblk < 8u ? nblk : 8u, members = (nblk - g + 7u) / 8u;
+    unsigned *gen = gb + 288 + 32 * g;
+    unsigned gen0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(__HIPCC__)
+    asm volatile("" : "+v"(gen0) :: "memory");                        // the generation is in a register BEFORE this work-group arrives (two relaxed operations on different words may pass each other)
+#endif
+    if (__hip_atomic_fetch_add(gb + 32 * g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+        __hip_atomic_store(gb + 32 * g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(gb + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1u) {
+            __hip_atomic_store(gb + 256, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (unsigned k = 0; k < ngrp; k++) __hip_atomic_fetch_add(gb + 288 + 32 * k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    unsigned spins = 0;
+    while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0 && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+    return spins < (1u << 22);
+}
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { CDNA4_WAIT_VM(N); }
 

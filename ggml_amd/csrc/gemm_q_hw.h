@@ -8,6 +8,9 @@
 #define CDNA4_LDS_BASE(smem_) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)(smem_))
 // one LDS-DMA wave-piece: lane L copies 16 bytes from sbase + voff to LDS address lds_addr + 16 L (scalar-base form, M0 = LDS address)
 #define CDNA4_DMA16(voff, sbase, lds_addr) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0")
+// the same with the sc1 cache policy: served by the L2 / memory side, never by this CU's L1 — for bytes another work-group of the SAME launch stored write-through
+// (the activation image of the one-launch step, k_gemm_kq_t64<.., FQ>)
+#define CDNA4_DMA16_SC1(voff, sbase, lds_addr) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0")
 // 16-byte global load into registers from a per-lane pointer; asynchronous: valid after a vmcnt wait tied to the destination
 #define CDNA4_GLOAD16_PTR(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
 #define CDNA4_WAIT_VM_TIED1(n, a) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(n) : "memory")

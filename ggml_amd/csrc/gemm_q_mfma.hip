@@ -472,7 +472,7 @@ static int co_cus() { return cdna4_gemm_coresident_cus(); }
 
 // Route probe (the tail predictor must not be a hand-kept copy of the routing): cdna4_gemm_q_fuses_tail() runs the SAME routing code with the
 // probe armed; every route ends in ROUTE_END(does this kernel apply a.epi in its store?) in front of its first side effect (scratch, zero-fill, launch).
-static thread_local struct { bool active, fuses; int kernel, reencoded; } g_probe = {false, false, 0, 0};
+static thread_local struct { bool active, fuses; int kernel, reencoded; bool fuseq; } g_probe = {false, false, 0, 0, false};
 // kernel ids (ggml_cdna4_mul_mat_route, include/ggml_cdna4.h): 10 k_gemm_kq_t64, 12 k_gemm_r8, 13 the 128 x 128-tile kernels (k_gemm_kq_w8 / _w8p / _w12), 14 the older per-lane-load
 // kernels (k_gemm_q, k_gemm_kq_pipe), 15 k_gemm_lds / k_gemm_w4 (explicit variants only)
 #define ROUTE_END_K(f, kid) do { if (g_probe.active) { g_probe.fuses = (f); g_probe.kernel = (kid); return 0; } } while (0)
@@ -598,14 +598,14 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
     }
     if constexpr (TYPE == CDNA4_Q4_K) {
         // bit13 = k_gemm_kq_t64 (gemm_q_t64.hip: 64(m) x 128(b) wave tiles); bit14 / bit15 force its 128- / 256-row tile
-        if (wlds && (variant & 8192)) { ROUTE_END_K(true, 10); return cdna4_launch_gemm_t64(a, (variant & 16384) ? 128 : ((variant & 32768) ? 256 : 0), a.splitk, st); }
+        if (wlds && (variant & 8192)) { if (g_probe.active) g_probe.fuseq = cdna4_gemm_t64_fuses_quantizer(a, (variant & 16384) ? 128 : ((variant & 32768) ? 256 : 0), a.splitk); ROUTE_END_K(true, 10); return cdna4_launch_gemm_t64(a, (variant & 16384) ? 128 : ((variant & 32768) ? 256 : 0), a.splitk, st); }
         // auto (round 2): k_gemm_kq_t64 for every prefill shape — 128-row tiles (hand-off split-K = 2 while both work-groups of a tile
         // are resident, uneven for odd superblock counts), 256-row tiles once the grid holds two of them per CU.  MI355X, same box, same
         // data: 4096x4096x512 24.25 vs 24.68 us on k_gemm_kq_w12, 4096x11008x512 50.95 vs 52.57, 8192x4096x512 37.1 vs 38.1,
         // 32768x8192x512 (256-row tiles) 239-243 vs 265.
         // auto (round 4): k_gemm_r8 (gemm_r8.inc: 32 x 256 wave tiles, half the unpack VALU per MFMA) where its 256 x 256 tiles fill the chip unsplit — 9-10 % ahead there
         if (wlds && a.variant <= 0 && a.splitk <= 0 && cdna4_gemm_r8_preferred(a)) { ROUTE_END_K(true, 12); return cdna4_launch_gemm_lds(a, 256, 1, st, 2); }
-        if (wlds && a.variant <= 0 && a.splitk <= 2) { ROUTE_END_K(true, 10); return cdna4_launch_gemm_t64(a, 0, a.splitk, st); }   // (deeper, atomic splits: the older kernels below)
+        if (wlds && a.variant <= 0 && a.splitk <= 2) { if (g_probe.active) g_probe.fuseq = cdna4_gemm_t64_fuses_quantizer(a, 0, a.splitk); ROUTE_END_K(true, 10); return cdna4_launch_gemm_t64(a, 0, a.splitk, st); }   // (deeper, atomic splits: the older kernels below)
     }
     if constexpr (TYPE == CDNA4_Q5_K) {
         // round 4: k_gemm_r8 also unpacks Q5_K (its fifth bits cost 4-5 VALU per half2 pair: the format that gains most from one fragment meeting eight activation
@@ -702,17 +702,24 @@ int cdna4_launch_gemm_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, 
 int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st);
 // does the route cdna4_launch_gemm_q() takes for these arguments apply a.epi in its store?  (k_gemm_kq_t64, k_gemm_r8 and the 128 x 128-tile kernels of
 // gemm_w8_epilogue.inc outside their atomic-sum split; also behind the exact re-encodings.)  Runs the routing itself with the probe armed: no side effects.
+bool cdna4_gemm_q_fuses_quantizer(const cdna4_gemm_args &a) {
+    g_probe.active = true; g_probe.fuses = false; g_probe.kernel = 0; g_probe.reencoded = 0; g_probe.fuseq = false;
+    const int rc = cdna4_launch_gemm_q(a, nullptr);
+    g_probe.active = false;
+    return rc == 0 && g_probe.fuseq;
+}
 bool cdna4_gemm_q_fuses_tail(const cdna4_gemm_args &a) {
-    g_probe.active = true; g_probe.fuses = false; g_probe.kernel = 0; g_probe.reencoded = 0;
+    g_probe.active = true; g_probe.fuses = false; g_probe.kernel = 0; g_probe.reencoded = 0; g_probe.fuseq = false;
     const int rc = cdna4_launch_gemm_q(a, nullptr);
     g_probe.active = false;
     return rc == 0 && g_probe.fuses;
 }
 // which prefill kernel would cdna4_launch_gemm_q() launch for these arguments (ids above; + 100 behind an exact re-encoding; 0: none / error)?  No side effects.
 int cdna4_gemm_q_route(const cdna4_gemm_args &a) {
-    g_probe.active = true; g_probe.fuses = false; g_probe.kernel = 0; g_probe.reencoded = 0;
+    g_probe.active = true; g_probe.fuses = false; g_probe.kernel = 0; g_probe.reencoded = 0; g_probe.fuseq = false;
     const int rc = cdna4_launch_gemm_q(a, nullptr);
     g_probe.active = false;
+    if (rc == 0 && g_probe.kernel == 10 && g_probe.fuseq) return 11;                 // ONE launch: the activation quantizer inside k_gemm_kq_t64
     return rc == 0 && g_probe.kernel ? g_probe.kernel + 100 * g_probe.reencoded : 0;
 }
 

@@ -6,8 +6,87 @@
 #include "gemm_q_hw.h"
 #include "gemm_kq_t64.inc"
 
+// The one-launch step (k_gemm_kq_t64<.., FQ>: quantize -> grid barrier -> multiply): would a launch of `nblk` work-groups take it for these arguments?
+//  * the caller handed over the fp32 rows (a.xf; 16-byte aligned rows) next to the image workspace,
+//  * every work-group is resident at once — one per CU (132 / 152 KB of LDS) on a device the caller owns (not ggml_cdna4_set_shared_device), and the grid fills more
+//    than half the chip (fewer work-groups would quantize longer than the launch they save),
+//  * 32-bit byte offsets reach the whole image.    CDNA4_NO_FUSEQ=1 turns it off (A/B, and the two-launch reference of the parity tests).
+static bool t64_fuses_quantizer(const cdna4_gemm_args &a, int nblk) {
+    static const bool off = getenv("CDNA4_NO_FUSEQ") && atoi(getenv("CDNA4_NO_FUSEQ")) != 0;
+    if (off || !a.xf || cdna4_gemm_shared_device()) return false;
+    if ((((uintptr_t)a.xf) | (uintptr_t)(a.xf_row_elems * 4)) & 15) return false;
+    if ((int64_t)a.B * a.K * 2 + 32768 >= ((int64_t)1 << 31) || (int64_t)a.B * (a.K / 256) >= ((int64_t)1 << 30)) return false;
+    const int cus = cdna4_gemm_cu_count();
+    return nblk <= cus && nblk * 2 > cus;
+}
+
+// tile rows and split of the launch AUTO (or the given tm / splitk) takes: shared by the launcher and the route probe (`fq`: the quantizer rides inside)
+struct t64_plan { int tm, splitk, ntiles; bool ticketed2, fq; };
+static int t64_make_plan(const cdna4_gemm_args &a, int tm, int splitk, t64_plan &pl);
+
+bool cdna4_gemm_t64_fuses_quantizer(const cdna4_gemm_args &a, int tm, int splitk) {
+    t64_plan pl;
+    return t64_make_plan(a, tm, splitk, pl) == 0 && pl.fq;
+}
+
 // tile rows (0 = choose) and split-K (0 = choose; 1 or 2) -> launch.  Returns 0, or a negative status with the error text set.
 int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st) {
+    t64_plan pl;
+    const int prc = t64_make_plan(a, tm, splitk, pl);
+    if (prc) return prc;
+    tm = pl.tm; splitk = pl.splitk;
+    const bool ticketed2 = pl.ticketed2, fq = pl.fq;
+    const int cus = cdna4_gemm_cu_count(), nsb = a.K / 256;
+    const int tiles_b = (a.B + 127) / 128;
+    const int tiles_m = (a.M + tm - 1) / tm, ntiles = tiles_m * tiles_b;
+    (void)cus;
+    gemm_params p{};
+    p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
+    p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
+    p.tiles_m = tiles_m; p.tiles_b = tiles_b;
+    p.epi = a.epi;
+    if (splitk >= 2 || fq) {
+        // exchange slots: [tile][work-group of the tile][wave] x 16 KB at most; flag words: hand-off flags [tile][ks] in the first 32 KB,
+        // deep-split ticket counters [tile] behind them, the grid barrier's words (FQ) at 48 KB; all zero when idle and reset by their last user — no per-launch state on the
+        // host: graph-capturable.  Scratch kind 2: the older kernels' areas never mix with these.
+        // The words live at a FIXED place (the first 64 KB) so that no shape's exchange slots ever overlay another shape's flags.
+        const size_t pbytes = splitk >= 2 ? (size_t)ntiles * splitk * 8 * 16384 : 0, fbytes = 65536;
+        if ((size_t)ntiles * 8 > 32768) return cdna4_set_error_msg("gemm_t64: too many tiles for the split-K flag area");
+        char *sc = (char *)cdna4_gemm_scratch(fbytes + pbytes, 2);
+        if (!sc) return cdna4_set_error_msg("gemm_t64: cannot allocate split-K scratch");
+        p.flags = (unsigned *)sc; p.gbar = (unsigned *)(sc + 49152);
+        if (splitk >= 2) {
+            p.partial = (float *)(sc + fbytes);
+            p.sb_split = (nsb + 1) / 2;
+            if (ticketed2) p.tune = 2;
+            const int nb = ntiles * 2;                                                 // partners share an XCD iff the XCD-aware remap is active and
+            p.xchg_l2 = (splitk == 2 && (nb & 7) == 0 && ((nb >> 3) % (tiles_b * 2)) == 0) ? 1 : 0;   // each XCD's slice holds whole (tile_b x ks) groups
+        }
+    }
+    if (fq) { p.xf = a.xf; p.xf_row = a.xf_row_elems; }
+    const dim3 grid(ntiles * splitk);
+#ifdef CDNA4_ABLATIONS
+    // gemm_bench_abl: variant bits 16+ pick a timing-only instantiation (gemm_kq_t64.inc: ABL)
+    p.trace = (unsigned long long *)cdna4_debug_trace;
+    const int abl = a.variant >> 16;
+#define T64_ABL(A) if (abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, false, (A)>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256, false, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
+    T64_ABL(1) T64_ABL(3) T64_ABL(4) T64_ABL(8) T64_ABL(15) T64_ABL(32) T64_ABL(256)
+    if (abl) return cdna4_set_error_msg("gemm_t64: ablation not instantiated");
+#endif
+    const bool tail = p.epi.bias != nullptr || p.epi.act != 0 || p.epi.resid != nullptr;
+    if (fq) {                                                            // (128-row tiles only: t64_make_plan)
+        if (tail) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, false, 0, true, true>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, false, 0, false, true>), grid, dim3(512), 0, st, p);
+    } else if (tail) {
+        if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, false, 0, true>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256, false, 0, true>), grid, dim3(512), 0, st, p);
+    } else if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256>), grid, dim3(512), 0, st, p);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+
+static int t64_make_plan(const cdna4_gemm_args &a, int tm, int splitk, t64_plan &pl) {
     if (a.type != CDNA4_Q4_K) return cdna4_set_error_msg("gemm_t64: Q4_K only");
     if (a.K % 256 || a.K < 256) return cdna4_set_error_msg("gemm_t64: K must be a whole number of superblocks");
     if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) || ((uintptr_t)a.xh & 15)) return cdna4_set_error_msg("gemm_t64: weight rows and the activation image must be 16-byte aligned");
@@ -45,42 +124,15 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     if (splitk != 1 && splitk != 2 && splitk != 4 && splitk != 8) return cdna4_set_error_msg("gemm_t64: split-K is 1, 2, 4 or 8");
     if (splitk == 2 && (ntiles * 2 > cus || nsb < 2)) return cdna4_set_error_msg("gemm_t64: the split-K hand-off needs every work-group resident and two superblocks");
     if (splitk > 2 && (nsb < splitk || tm != 128)) return cdna4_set_error_msg("gemm_t64: the deep K split is built for 128-row tiles and needs a superblock per work-group");
-    gemm_params p{};
-    p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
-    p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
-    p.tiles_m = tiles_m; p.tiles_b = tiles_b;
-    p.epi = a.epi;
-    if (splitk >= 2) {
-        // exchange slots: [tile][work-group of the tile][wave] x 16 KB at most; flag words: hand-off flags [tile][ks] in the first 32 KB,
-        // deep-split ticket counters [tile] behind them; both zero when idle and reset by their last user — no per-launch state on the
-        // host: graph-capturable.  Scratch kind 2: the older kernels' areas never mix with these.
-        // The words live at a FIXED place (the first 64 KB) so that no shape's exchange slots ever overlay another shape's flags.
-        const size_t pbytes = (size_t)ntiles * splitk * 8 * 16384, fbytes = 65536;
-        if ((size_t)ntiles * 8 > 32768) return cdna4_set_error_msg("gemm_t64: too many tiles for the split-K flag area");
-        char *sc = (char *)cdna4_gemm_scratch(fbytes + pbytes, 2);
-        if (!sc) return cdna4_set_error_msg("gemm_t64: cannot allocate split-K scratch");
-        p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
-        p.sb_split = (nsb + 1) / 2;
-        if (ticketed2) p.tune = 2;
-        const int nb = ntiles * 2;                                                 // partners share an XCD iff the XCD-aware remap is active and
-        p.xchg_l2 = (splitk == 2 && (nb & 7) == 0 && ((nb >> 3) % (tiles_b * 2)) == 0) ? 1 : 0;   // each XCD's slice holds whole (tile_b x ks) groups
-    }
-    const dim3 grid(ntiles * splitk);
-#ifdef CDNA4_ABLATIONS
-    // gemm_bench_abl: variant bits 16+ pick a timing-only instantiation (gemm_kq_t64.inc: ABL)
-    p.trace = (unsigned long long *)cdna4_debug_trace;
-    const int abl = a.variant >> 16;
-#define T64_ABL(A) if (abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, false, (A)>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256, false, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
-    T64_ABL(1) T64_ABL(3) T64_ABL(4) T64_ABL(8) T64_ABL(15) T64_ABL(32) T64_ABL(256)
-    if (abl) return cdna4_set_error_msg("gemm_t64: ablation not instantiated");
-#endif
-    const bool tail = p.epi.bias != nullptr || p.epi.act != 0 || p.epi.resid != nullptr;
-    if (tail) {
-        if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, false, 0, true>), grid, dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256, false, 0, true>), grid, dim3(512), 0, st, p);
-    } else if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256>), grid, dim3(512), 0, st, p);
-    CDNA4_CHECK_LAUNCH();
+    // the split in two of a launch that carries the quantizer: its grid is resident by construction (t64_fuses_quantizer), so the hand-off — half tiles exchanged,
+    // both work-groups store — is legitimate there and halves the parked bytes (the ticketed default parks whole tiles: WRITE_SIZE 25.2 MB for an 8.4 MB result,
+    // profiles/r04/pmc_summary.txt).  CDNA4_FQ_TICKETED=1 keeps the ticketed sum (A/B).
+    pl.tm = tm; pl.splitk = splitk; pl.ntiles = ntiles; pl.ticketed2 = ticketed2;
+    // (the 128-row form only: with the quantizer's prologue in front of it the 256-row form — 32 registers over budget as it is — reloads spilled values INSIDE its loop,
+    //  where a scratch access also breaks the counted vmcnt waits; tests/test_build_static.py pins that the 128-row form's loop has none)
+    pl.fq = tm == 128 && t64_fuses_quantizer(a, ntiles * splitk);
+    static const bool fq_ticketed = getenv("CDNA4_FQ_TICKETED") && atoi(getenv("CDNA4_FQ_TICKETED")) != 0;
+    if (pl.fq && splitk == 2 && tm == 128 && !fq_ticketed) pl.ticketed2 = false;
     return 0;
 }
 

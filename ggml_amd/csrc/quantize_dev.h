@@ -70,3 +70,32 @@ __device__ __forceinline__ void q8_K_chunk16_image(const float (&e)[16], int c15
     lo.x = pk(hv[0], hv[2]); lo.y = pk(hv[1], hv[3]); lo.z = pk(hv[4], hv[6]); lo.w = pk(hv[5], hv[7]);
     hi.x = pk(hv[8], hv[10]); hi.y = pk(hv[9], hv[11]); hi.z = pk(hv[12], hv[14]); hi.w = pk(hv[13], hv[15]);
 }
+
+// One Q8_K superblock by the 16 adjacent lanes of a DPP row -> its 512 bytes of the GEMM's k-panel-major, pair-interleaved fp16 image, as two 16-byte pieces per
+// lane: lane l16 holds the elements 8 l16 .. + 7 (e[0..7]: piece o0, panel 2 sb) and 128 + 8 l16 .. + 7 (e[8..15]: piece o1, panel 2 sb + 1), so the sixteen lanes
+// read two 512-byte runs and write two whole 256-byte panel rows.  The arithmetic — and therefore every bit of the image — is k_quantize_q8_K's
+// (quantize_act.hip; quantize_row_q8_K_ref, src/ggml-quants.c:2479-2516): the selection of the largest |x| (signed value kept, first index wins) is commutative
+// and associative, so it does not care which elements a lane scans as long as it scans them in rising index order.  Used by the one-launch prefill step
+// (k_gemm_kq_t64<.., FQ>, gemm_kq_t64.inc): every work-group quantizes its share of the activation rows in front of the grid barrier.
+__device__ __forceinline__ void q8_K_group16_image(const float (&e)[16], int l16, u32x4 &o0, u32x4 &o1) {
+    float amax = 0.f, mx = 0.f; int idx = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { const float ax = fabsf(e[i]); if (ax > amax) { amax = ax; mx = e[i]; idx = 128 * (i >> 3) + 8 * l16 + (i & 7); } }
+    auto take = [&](float oa, float om, int oi) __attribute__((always_inline)) { if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; } };
+    take(dpp_f32<0xB1>(amax), dpp_f32<0xB1>(mx), dpp_i32<0xB1>(idx));
+    take(dpp_f32<0x4E>(amax), dpp_f32<0x4E>(mx), dpp_i32<0x4E>(idx));
+    take(dpp_f32<0x141>(amax), dpp_f32<0x141>(mx), dpp_i32<0x141>(idx));
+    take(dpp_f32<0x140>(amax), dpp_f32<0x140>(mx), dpp_i32<0x140>(idx));
+    half_t hv[16];
+    if (amax != 0.f) {
+        const float iscale = -127.f / mx, d = 1.0f / iscale;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const int v = (int)__builtin_rintf(iscale * e[i]); const int q = v < 127 ? v : 127; hv[i] = (half_t)(d * (float)q); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) hv[i] = (half_t)0.f;
+    }
+    auto pk = [](half_t a, half_t b) __attribute__((always_inline)) { const half2_t t = {a, b}; return __builtin_bit_cast(uint32_t, t); };
+    o0.x = pk(hv[0], hv[2]); o0.y = pk(hv[1], hv[3]); o0.z = pk(hv[4], hv[6]); o0.w = pk(hv[5], hv[7]);
+    o1.x = pk(hv[8], hv[10]); o1.y = pk(hv[9], hv[11]); o1.z = pk(hv[12], hv[14]); o1.w = pk(hv[13], hv[15]);
+}

@@ -84,22 +84,33 @@ def test_64x128_wave_tile_kernel_resources(tmp_path):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm", "-S", "--cuda-device-only", "-o", str(out), src],
                    check=True, capture_output=True, timeout=900)
     asm = out.read_text()
-    for tm, max_scratch in ((128, 0), (256, 128)):
-        k = "_Z13k_gemm_kq_t64ILi12ELi%dELb0ELi0ELb0EEv11gemm_params" % tm          # the plain product (TAIL = false); the tail-carrying twin shares the main loop
+    # the plain product (TAIL = false; the tail-carrying twin shares the main loop) and — round 5 — the one-launch step that carries the activation quantizer and the
+    # grid barrier in its prologue (FQ = true): the loop must be the same loop, in particular without a scratch access in it (a spill there would also break the
+    # kernel's counted vmcnt waits, which assume that LDS-DMA is the only vector-memory traffic of the loop)
+    for tm, fq, max_scratch in ((128, 0, 0), (256, 0, 128), (128, 1, 0)):
+        k = "_Z13k_gemm_kq_t64ILi12ELi%dELb0ELi0ELb0ELb%dEEv11gemm_params" % (tm, fq)
         assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= 256
         assert _prop(asm, k, "private_seg_size") <= max_scratch
         assert _lds(asm, k) <= 160 * 1024
         body = re.search(r"^%s:.*?^\.Lfunc_end" % re.escape(k), asm, re.S | re.M).group(0)
         # the steady-state stage pairs — one copy of the loop for the four loader waves, one for the others: no scratch access inside
         # (the 256-row form parks a few loader-only address registers in scratch AROUND the loops), 32 / 64 MFMAs each
-        loops = [m.group(0) for m in re.finditer(r"Loop Header: Depth=1.*?s_cbranch_scc1", body, re.S)]
+        # (a loop = from its header to the first backward branch BEFORE the next loop's header: the quantizer's rolled loop in the FQ prologue ends in another branch form)
+        loops = [m.group(0) for chunk in body.split("Loop Header: Depth=1")[1:] for m in [re.search(r".*?s_cbranch_scc1", chunk, re.S)] if m]
         main = [lp for lp in loops if lp.count("v_mfma_f32_32x32x16_f16") == (32 if tm == 128 else 64)]
         assert len(main) == 2 and all("scratch_" not in lp for lp in main)
         assert sorted(lp.count("global_load_lds_dwordx4") for lp in main)[0] == 0        # the non-loader copy issues no LDS-DMA at all
     # nothing in this file loads into registers asynchronously: round 2's first version did (superblock headers, inline-asm
     # global_load_dwordx4 waited for a stage later) and hipcc copied the in-flight registers before the wait — one wave in a few
     # thousand got garbage constants on the GPU, invisibly to the CPU emulator.  Headers go through LDS (DMA) now.
-    assert "global_load_dwordx4 v" not in asm and "global_load_dwordx2 v" not in asm
+    # (round 5: the one-launch step's prologue loads the fp32 activations into registers — compiler-issued, compiler-counted loads in front of the grid barrier, never
+    #  beside the loop's hand-counted LDS-DMA: every one of them precedes the kernel's first MFMA; the kernels without the quantizer still have none)
+    for name, kbody in re.findall(r"^(_Z13k_gemm_kq_t64\w+):(.*?)^\.Lfunc_end", asm, re.S | re.M):
+        regloads = [m.start() for m in re.finditer(r"global_load_dwordx[24] v", kbody)]
+        if name.endswith("ELb1EEv11gemm_params"):
+            assert regloads and max(regloads) < kbody.index("v_mfma_f32_32x32x16_f16"), name
+        else:
+            assert not regloads, name
 
 
 @pytest.mark.parametrize("m,k,b,splitk,tm", [(128, 256, 128, 1, 128), (300, 1536, 200, 1, 128), (300, 1536, 200, 1, 256), (513, 1024, 129, 2, 128),

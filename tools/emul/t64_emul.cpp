@@ -13,6 +13,7 @@
 #define CDNA4_HW_OVERRIDE
 #define CDNA4_LDS_BASE(smem_) 0u
 #define CDNA4_DMA16(voff, sbase, lds_addr) emu::vm_issue(smem + (lds_addr) + 16 * lane, (sbase) + (voff))
+#define CDNA4_DMA16_SC1(voff, sbase, lds_addr) CDNA4_DMA16(voff, sbase, lds_addr)
 #define CDNA4_GLOAD16_PTR(dst, ptr) (memcpy(&(dst), (ptr), 16), emu::vm_issue_done())
 #define CDNA4_WAIT_VM_TIED1(n, a) emu::vm_wait(n)
 #define CDNA4_WAIT_VM_TIED2(n, a, b) emu::vm_wait(n)
