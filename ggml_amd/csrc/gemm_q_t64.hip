@@ -17,7 +17,14 @@ static bool t64_fuses_quantizer(const cdna4_gemm_args &a, int nblk) {
     if ((((uintptr_t)a.xf) | (uintptr_t)(a.xf_row_elems * 4)) & 15) return false;
     if ((int64_t)a.B * a.K * 2 + 32768 >= ((int64_t)1 << 31) || (int64_t)a.B * (a.K / 256) >= ((int64_t)1 << 30)) return false;
     const int cus = cdna4_gemm_cu_count();
-    return nblk <= cus && nblk * 2 > cus;
+    if (!(nblk <= cus && nblk * 2 > cus)) return false;
+    // ... and the quantizer's share is ONE pass of the work-groups' 32 sixteen-lane groups, at least half full.  Measured on MI355X (profiles/r05/onelaunch_ab.txt, us per call,
+    // two launches vs one, same box): 4096x4096x512 (one full pass) 33.0-33.6 vs 32.1-33.0 on three boxes — ahead by 0.4-0.7; 8192x4096x512 (one pass) 45.8-46.9 vs 46.3: level;
+    // 4096x11008x512 (2.7 passes: three serial load -> quantize -> write-through rounds) 59.7-61.9 vs 61.4-63.0: BEHIND by 1-1.5; 4096x4096x128 (a quarter pass) 23.5 vs 24.4: behind.
+    // Why the gain is this small: in-launch, quantizing costs 3.9 us and the grid barrier 1.2-2.4 us (timing-only ablations) — a chain of memory round trips (fp32 load ->
+    // write-through store acknowledged -> arrival -> release -> poll -> first activation DMA) as long as the quantizer's own launch + the kernel boundary it replaces (5.7 us).
+    const int64_t units = (int64_t)a.B * (a.K / 256), pass = (int64_t)nblk * 32;
+    return units <= pass && units * 2 > pass;
 }
 
 // tile rows and split of the launch AUTO (or the given tm / splitk) takes: shared by the launcher and the route probe (`fq`: the quantizer rides inside)
@@ -63,7 +70,11 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
             p.xchg_l2 = (splitk == 2 && (nb & 7) == 0 && ((nb >> 3) % (tiles_b * 2)) == 0) ? 1 : 0;   // each XCD's slice holds whole (tile_b x ks) groups
         }
     }
-    if (fq) { p.xf = a.xf; p.xf_row = a.xf_row_elems; }
+    if (fq) {
+        p.xf = a.xf; p.xf_row = a.xf_row_elems;
+        const int fq_abl = getenv("CDNA4_FQ_ABL") ? atoi(getenv("CDNA4_FQ_ABL")) : 0;      // timing-only, read per call: 4 = no grid barrier, 8 = no quantizer (the image of an earlier call is multiplied)
+        p.tune |= fq_abl & 12;
+    }
     const dim3 grid(ntiles * splitk);
 #ifdef CDNA4_ABLATIONS
     // gemm_bench_abl: variant bits 16+ pick a timing-only instantiation (gemm_kq_t64.inc: ABL)

@@ -41,9 +41,10 @@ def _two_launches(L, native, ops, a, x, ws, y, stream, splitk=0):
     native.check(L.ggml_cdna4_mul_mat_prepared(int(a.type), a.data.data_ptr(), a.row_bytes, y.data_ptr(), m, m, k, b, ws.data_ptr(), ws.numel(), ops.PATH_GEMM, 0, splitk, stream))
 
 
-# (M, K, B): headline (split in two, hand-off inside the resident grid) | C3's odd superblock count 43 = 22 + 21 | deep split x 8 | deep split x 4 | unsplit 256 tiles |
-# ragged activation rows and weight rows | a small batch just above the int8 route
-SHAPES = [(4096, 4096, 512), (4096, 11008, 512), (4096, 4096, 128), (2048, 4096, 512), (8192, 4096, 512), (4000, 2048, 500), (4096, 4096, 72)]
+# (M, K, B) that take the one-launch step on a 256-CU part (a resident grid, the quantizer's share one pass at most and at least half of one — gemm_q_t64.hip:
+# t64_fuses_quantizer): headline (split in two, hand-off inside the resident grid) | an odd superblock count 15 = 8 + 7 | deep split x 4 (two shapes) | unsplit, 256 tiles |
+# ragged activation rows and weight rows
+SHAPES = [(4096, 4096, 512), (4096, 3840, 512), (2048, 4096, 512), (4096, 8192, 256), (8192, 4096, 512), (4000, 4096, 500)]
 
 
 @pytest.mark.parametrize("m,k,b", SHAPES)

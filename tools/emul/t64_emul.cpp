@@ -20,6 +20,7 @@
 #define CDNA4_WAIT_VM(n) emu::vm_wait(n)
 #define cdna4_wait_vm_rt(n) emu::vm_wait(n)
 #define CDNA4_WAIT_LGKM0() ((void)0)
+#define CDNA4_PIN(x) ((void)0)
 #define CDNA4_DMA16_LANES(voff, sbase, lds_addr, nlanes) do { if (lane < (nlanes)) emu::vm_issue(smem + (lds_addr) + 16 * lane, (sbase) + (voff)); else emu::vm_issue_done(); } while (0)
 // v_permlane32_swap through the wave's exchange buffer (all 64 lanes execute it)
 #define CDNA4_SWAP32(a, b) do { emu::WaveState &w_ = emu::my_wave(); const int l_ = emu::t_threadIdx.x & 63; const uint32_t a_ = (a), b_ = (b); \
