@@ -173,6 +173,21 @@ __device__ __forceinline__ void k4_scale_min_rt(uint32_t a, uint32_t b, uint32_t
            m = (k4_byte_rt(a, b, c, j + 4) >> 4) | ((k4_byte_rt(a, b, c, j) >> 6) << 4); }
 }
 
+// the (scale, min) pairs of the TWO sub-blocks 2 g and 2 g + 1 of a Q4_K / Q5_K superblock — what a decode unit (one 64-weight group g) needs — from the 12 scale bytes
+// a, b, c: bit fields at ONE run-time shift (16 (g & 1)) instead of the byte-select chains of k4_scale_min_rt (about 20 VALU for the four values instead of about 50; the decode
+// kernels are instruction-bound, profiles/r04/pmc_decode_counters.txt).  Same values as get_scale_min_k4(2 g | 2 g + 1), src/ggml-quants.c:631-638: for j < 4 the low six
+// bits of bytes j / j + 4; for j >= 4 the nibbles of byte j + 4 topped by the two high bits of bytes j - 4 / j.
+__device__ __forceinline__ void k4_scale_min_pair(uint32_t a, uint32_t b, uint32_t c, int g, int &sc0, int &m0, int &sc1, int &m1) {
+    const uint32_t sh = 16u * (uint32_t)(g & 1);
+    const uint32_t ya = a >> sh, yb = b >> sh, yc = c >> sh;             // bytes (2 g & 3) and (2 g & 3) + 1 in the low half
+    if (g < 2) {
+        sc0 = (int)(ya & 63u); m0 = (int)(yb & 63u); sc1 = (int)((ya >> 8) & 63u); m1 = (int)((yb >> 8) & 63u);
+    } else {
+        sc0 = (int)((yc & 0xFu) | (((ya >> 6) & 3u) << 4)); m0 = (int)(((yc >> 4) & 0xFu) | (((yb >> 6) & 3u) << 4));
+        sc1 = (int)(((yc >> 8) & 0xFu) | (((ya >> 14) & 3u) << 4)); m1 = (int)(((yc >> 12) & 0xFu) | (((yb >> 14) & 3u) << 4));
+    }
+}
+
 #define CDNA4_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return cdna4_set_error(e_, __FILE__, __LINE__); } while (0)
 int cdna4_set_error(hipError_t e, const char *file, int line);
 int cdna4_set_error_msg(const char *msg);

@@ -14,6 +14,7 @@
 #include "epilogue.h"
 #include "gemm_q_hw.h"
 #include <stdlib.h>
+int cdna4_gemm_cu_count();                                          // gemm_q_mfma.hip
 
 __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
 
@@ -49,8 +50,7 @@ template <int NB> struct Unit<CDNA4_Q4_K, NB> {
         const u32x4 hdr = wr.hdr;
         const float d = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
         int sc_lo, m_lo, sc_hi, m_hi;
-        k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g, sc_lo, m_lo);
-        k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g + 1, sc_hi, m_hi);
+        k4_scale_min_pair(hdr.y, hdr.z, hdr.w, g, sc_lo, m_lo, sc_hi, m_hi);
         const uint32_t w[8] = {wr.q0.x, wr.q0.y, wr.q0.z, wr.q0.w, wr.q1.x, wr.q1.y, wr.q1.z, wr.q1.w};
 #pragma unroll
         for (int c = 0; c < NB; c++) {
@@ -87,8 +87,7 @@ template <int NB> struct Unit<CDNA4_Q5_K, NB> {
         const u32x4 hdr = wr.hdr;
         const float d = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
         int sc_lo, m_lo, sc_hi, m_hi;
-        k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g, sc_lo, m_lo);
-        k4_scale_min_rt(hdr.y, hdr.z, hdr.w, 2 * g + 1, sc_hi, m_hi);
+        k4_scale_min_pair(hdr.y, hdr.z, hdr.w, g, sc_lo, m_lo, sc_hi, m_hi);
         const uint32_t qh[8] = {wr.h0.x, wr.h0.y, wr.h0.z, wr.h0.w, wr.h1.x, wr.h1.y, wr.h1.z, wr.h1.w};
         const uint32_t w[8] = {wr.q0.x, wr.q0.y, wr.q0.z, wr.q0.w, wr.q1.x, wr.q1.y, wr.q1.z, wr.q1.w};
         uint32_t wl[8], wh[8];
@@ -745,7 +744,32 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
 #pragma unroll
     for (int r = 0; r < ROWS; r++) cur[r] = w0[r];
     constexpr bool PIPE = NB <= 2 && !DMA;                                          // (4 and 8 columns: the second set of weight registers spills, and those forms are bound by their integer dots)
-    if constexpr (PIPE) {
+    // SWAP: two rounds per trip with the two register sets trading places, where that does not cost occupancy: with one row per wave in 4- / 8-wave work-groups (several per
+    // CU on tall matrices) the swapped form takes 81 instead of 61-64 registers for Q4_K and 14336 x 4096 went from 9.5 to 11.0 us (round 5, one box); with two rows per wave it
+    // takes FEWER (115 vs 128) and 4096 x 14336 on 8 x 2 went from 11.2 to 10.3 us; 16-wave work-groups run one per CU, four waves per SIMD, whatever the count
+    constexpr bool SWAP = PIPE && (ROWS == 2 || NW == 16);
+    if constexpr (SWAP) {
+        // two rounds per trip with the two register sets trading places (round 4 copied `nxt` into `cur` every round: 13 register moves per row and round in an
+        // instruction-bound kernel, profiles/r04/pmc_decode_counters.txt); the units of a row are still added in the order u = lane, lane + 64, ..
+        typename Unit<TYPE, NB>::W alt[ROWS];
+        for (int u = lane; u < nunits; u += 128) {
+            const int u1 = u + 64, u2 = u + 128;
+            if (u1 < nunits) {
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) alt[r] = Unit<TYPE, NB>::load(wrow[r], u1);
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) Unit<TYPE, NB>::mac(cur[r], u, act, col, acc[r]);
+            if (u1 < nunits) {
+                if (u2 < nunits) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) cur[r] = Unit<TYPE, NB>::load(wrow[r], u2);
+                }
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) Unit<TYPE, NB>::mac(alt[r], u1, act, col, acc[r]);
+            }
+        }
+    } else if constexpr (PIPE) {
         for (int u = lane; u < nunits; u += 64) {
             typename Unit<TYPE, NB>::W nxt[ROWS];
             const int un = u + 64;
@@ -807,6 +831,12 @@ static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st
         if (TYPE == CDNA4_Q4_K && (a.K >= 8192 || a.M >= 12288)) cfg = 3;
         if (TYPE == CDNA4_Q6_K && a.M >= 8192) cfg = 3;
     }
+    // Round 5: 16 waves x 1 row (cfg 4: 1024-thread work-groups, the quantizer still paid once per 16 rows like 8 x 2, but every wave has ONE row to multiply and the
+    // activation row is quantized by twice as many lanes) wherever that is one work-group per CU at most.  One box, us cold, the launcher's earlier choice vs 16 x 1
+    // (profiles/r05/decode_cfg.txt): Q4_K 4096 x 14336 10.67 vs 9.65, 4096 x 11008 8.78 vs 8.01, 4096 x 8192 6.90 vs 6.46, 4096^2 4.17 vs 4.12; Q5_K 12.62 vs 11.30, 9.91 vs 9.17,
+    // 8.01 vs 7.26, 4.78 vs 4.28; Q6_K 15.09 vs 14.98, 11.83 vs 11.45, 9.21 vs 8.54, 5.67 vs 5.65.  Taller matrices (several work-groups per CU) keep the rules above.
+    // Q4_0: 4.55 vs 4.42, 10.81 vs 10.60, 9.34 vs 9.03, 7.11 vs 6.84 (same order of shapes); Q8_0 keeps 8 x 2 (long rows lose: 16.6 vs 17.3 at 4096 x 14336).
+    if (cfg_env < 0 && dma_knob <= 0 && (QT<TYPE>::KQ || TYPE == CDNA4_Q4_0) && (a.M + 15) / 16 <= cdna4_gemm_cu_count() && a.M >= 2048) cfg = 4;
     if constexpr (TYPE == CDNA4_Q4_K || TYPE == CDNA4_Q5_K) {
         // the DMA form of the 8 x 2 configuration (whole weight rows requested up front; at most two activation chunks per thread: K <= 16384; activations +
         // 16 rows within the 160 KB of LDS).  OPT-IN (CDNA4_DECODE_DMA=1; =2: only for K > 4096) — a measured loss on MI355X, one box, us cold / cache-warm,
@@ -828,7 +858,8 @@ static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st
             return 0;
         }
     }
-    if (cfg == 1) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x, (int64_t)0);
+    if (cfg == 4) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 16, 1>), dim3((a.M + 15) / 16), dim3(1024), lds, st, a, x, (int64_t)0);
+    else if (cfg == 1) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x, (int64_t)0);
     else if (cfg == 2) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 2>), dim3((a.M + 7) / 8), dim3(256), lds, st, a, x, (int64_t)0);
     else if (cfg == 3) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 1>), dim3((a.M + 7) / 8), dim3(512), lds, st, a, x, (int64_t)0);
     else hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 1>), dim3((a.M + 3) / 4), dim3(256), lds, st, a, x, (int64_t)0);

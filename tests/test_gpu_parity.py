@@ -335,6 +335,23 @@ def test_full_size_decode_config(gu, name, t):
     assert e < TOL_GEMV
 
 
+@pytest.mark.parametrize("name,t", [(n, t) for n, t in WT if n in ("q4_K", "q5_K", "q6_K", "q4_0")])
+@pytest.mark.parametrize("m,k", [(4096, 14336), (2048, 8192), (14336, 4096)])
+def test_decode_configurations_of_long_rows_and_tall_matrices(gu, name, t, m, k):
+    """the launcher's decode configurations beyond 4096^2 (gemv_q.hip: launch_fused — 16 waves x 1 row where that is one work-group per CU (round 5), 8 x 1 / 8 x 2 on
+    taller matrices; rows of several rounds of 64 units: the register sets trade places every round): bit for bit the quantize-then-GEMV pair, whole output against the
+    oracle (pin the configurations the route table chooses at 4096 x 14336 and 14336 x 4096)"""
+    from ggml_amd import ops
+    w = R.random_weights(t, m, k, seed=m + 7 * k)
+    x = _x(k + m, 1, k, "normal")
+    a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
+    y_fused = ops.mul_mat(a, xd).cpu().numpy()
+    y_two = ops.mul_mat_prepared(a, ops.PreparedAct(t, xd, path=ops.PATH_GEMV)).cpu().numpy()
+    assert np.array_equal(y_fused.view(np.uint32), y_two.view(np.uint32))
+    e = R.rel_l2(y_fused, R.o_mul_mat(t, w, x, m, k)); gu.report(test="gemv_fused_long", type=name, m=m, k=k, rel_l2=e)
+    assert e < TOL_GEMV
+
+
 @pytest.mark.parametrize("m,k,b", [(4096, 4096, 512), (4096, 11008, 512)])
 def test_full_size_prefill_config(gu, m, k, b):
     """BASELINE headline / configs[2] shapes (K = 11008 = 43 whole Q4_K superblocks — an ODD count, so the auto route runs it
