@@ -180,7 +180,7 @@ def kernel_name(t, m, k, b, fused=False):
             return "k_gemm_r8<Q4_K> (256x256 tile, 8 waves x 32(m)x256(b), in-register unpack, K tile 64, no K split)"
         t256, t128 = ((m + 255) // 256) * ((b + 127) // 128), ((m + 127) // 128) * ((b + 127) // 128)
         eff = lambda n: n / (-(-n // 256) * 256)                        # cdna4_launch_gemm_t64's tile rule on a 256-CU part
-        if t256 * 2 > 256 and eff(t256) * 1.10 >= eff(t128):
+        if t256 * 4 >= 256 * 3 and eff(t256) * 1.10 >= eff(t128):
             return "k_gemm_kq_t64<Q4_K, 256> (256x128 tile, 8 waves x 64(m)x128(b), LDS-DMA by the four older waves in front of the stage barrier, no K split)"
         return "k_gemm_kq_t64<Q4_K, 128> (128x128 tile, 8 waves x 64(m)x128(b) x K/4, LDS-DMA by the four older waves; small grids split in two with the ticketed sum)"
     return "k_gemm_kq_w12 / k_gemm_kq_w8p (128x128 tile, cross-stage unpack/MFMA pipeline)"

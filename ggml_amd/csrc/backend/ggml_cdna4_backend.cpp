@@ -403,7 +403,7 @@ static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph)
 static enum ggml_status cdna4_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
     cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
     HIP_OK(hipSetDevice(ctx->device));
-    static const bool no_graphs = getenv("GGML_CDNA4_NO_GRAPHS") != nullptr;
+    static const bool no_graphs = getenv("GGML_CDNA4_NO_GRAPHS") != nullptr || cdna4_exact_mode();      // (the parity mode runs node by node, as ggml_cdna4_ops.h and exact.hip say: ADVICE r4)
     if (no_graphs || ctx->graphs_off || ggml_graph_n_nodes(cgraph) < 2) return run_nodes(ctx, cgraph);
     uint64_t sig = graph_signature(cgraph);
     if (sig == 0) sig = 1;                                                     // (0 marks an unused slot)
@@ -652,6 +652,7 @@ static void * cdna4_reg_get_proc_address(ggml_backend_reg_t, const char * name) 
     if (strcmp(name, "ggml_backend_get_features") == 0) return (void *)cdna4_get_features;
     if (strcmp(name, "ggml_backend_cdna4_ksplit_buffer_type") == 0) return (void *)cdna4_ksplit_buffer_type;   // the K-split counterpart (no reference equivalent; ggml_cdna4_split.cpp)
     if (strcmp(name, "ggml_backend_split_buffer_type") == 0) return (void *)cdna4_split_buffer_type;      // ggml_backend_split_buffer_type_t, include/ggml-backend.h:188
+    if (strcmp(name, "ggml_backend_cdna4_split_ranges") == 0) return (void *)ggml_backend_cdna4_split_ranges;   // the partition of either split, as pure arithmetic (ggml_cdna4_split.cpp)
     return NULL;
 }
 static const ggml_backend_reg_i cdna4_reg_iface = {

@@ -63,6 +63,8 @@ ggml_backend_buffer_type_t cdna4_split_buffer_type(int main_device, const float 
 // "ggml_backend_cdna4_ksplit_buffer_type" (same signature; no reference counterpart): the reduction dimension K sharded instead of the rows, the partial
 // outputs summed by one RCCL all-reduce (ggml_cdna4_split.cpp)
 ggml_backend_buffer_type_t cdna4_ksplit_buffer_type(int main_device, const float * tensor_split);
+// the partition either split buffer type gives a tensor (pure arithmetic; exported as a symbol and through get_proc_address): ggml_cdna4_split.cpp
+extern "C" int ggml_backend_cdna4_split_ranges(int ksplit, int main_device, int n_devices, const float * tensor_split, int64_t n, int64_t * lo, int64_t * hi, int * dev);
 bool cdna4_buft_is_split(ggml_backend_buffer_type_t buft);
 bool cdna4_split_supports_mul_mat(const ggml_tensor * op);
 enum ggml_status cdna4_split_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst);

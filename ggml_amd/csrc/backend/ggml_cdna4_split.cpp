@@ -80,7 +80,8 @@ static void split_buffer_init_tensor(ggml_backend_buffer_t buffer, ggml_tensor *
     split_tensor * st = new split_tensor;
     st->n = bc->n_shards; st->ksplit = bc->ksplit;
     const size_t row_bytes = ggml_row_size(tensor->type, tensor->ne[0]);
-    GGML_ASSERT(!bc->ksplit || tensor->ne[0] % 256 == 0);         // K split: whole superblocks
+    // K split: shard edges are multiples of 256 (shard_k), the last shard runs to K — for the 32-weight block formats a K that is not a multiple of 256 leaves that shard a
+    // ragged (multiple-of-32) tail, which ggml_cdna4_mul_mat takes; nothing to refuse here (this was a process-aborting GGML_ASSERT)
     for (int i = 0; i < st->n; i++) {
         if (bc->ksplit) shard_k(bc, tensor->ne[0], i, &st->lo[i], &st->hi[i]); else shard_rows(bc, tensor->ne[1], i, &st->lo[i], &st->hi[i]);
         st->dev[i] = bc->shard_dev[i]; st->data[i] = nullptr;
@@ -151,6 +152,31 @@ static const ggml_backend_buffer_type_i split_buft_iface = {
     /* .is_host        = */ split_buft_is_host,
 };
 
+namespace { bool rccl_ready(int ndev); }                            // (below)
+// cumulative fractions and shard devices of a split over c->n_shards shards (NULL / all-zero tensor_split: equal shares; self-sharding: every shard on the main device)
+static void fill_bounds(split_buft_ctx * c, const float * tensor_split) {
+    float w[CDNA4_MAX_DEVICES]; float sum = 0.f;
+    for (int i = 0; i < c->n_shards; i++) { w[i] = (tensor_split && !c->self) ? tensor_split[i] : 0.f; if (w[i] < 0.f) w[i] = 0.f; sum += w[i]; }
+    if (sum <= 0.f) { for (int i = 0; i < c->n_shards; i++) w[i] = 1.f; sum = (float)c->n_shards; }      // NULL / all zero: equal shares
+    c->bound[0] = 0.f;
+    for (int i = 0; i < c->n_shards; i++) { c->bound[i + 1] = c->bound[i] + w[i] / sum; c->shard_dev[i] = c->self ? c->main_device : i; }
+    c->bound[c->n_shards] = 1.f;
+}
+// The partition a split buffer type of `n_devices` devices gives a tensor with `n` rows (row split) or K = `n` (K split): lo / hi / dev per shard.  Pure host arithmetic —
+// the SAME functions init_tensor uses — exported (symbol + get_proc_address) so that hosts can plan a layout, and so that the partition is testable without a multi-GPU
+// node (tests/test_split_ranges.py: main_device != 0, uneven and zero shares, ragged K).  Returns the number of shards, or -1 for bad arguments.
+extern "C" __attribute__((visibility("default"))) int ggml_backend_cdna4_split_ranges(int ksplit, int main_device, int n_devices, const float * tensor_split, int64_t n,
+                                                                                     int64_t * lo, int64_t * hi, int * dev) {
+    if (n_devices < 1 || n_devices > CDNA4_MAX_DEVICES || main_device < 0 || main_device >= n_devices || n < 0 || !lo || !hi) return -1;
+    split_buft_ctx c{};
+    c.main_device = main_device; c.ksplit = ksplit != 0; c.self = false; c.n_shards = n_devices;
+    fill_bounds(&c, tensor_split);
+    for (int i = 0; i < c.n_shards; i++) {
+        if (c.ksplit) shard_k(&c, n, i, &lo[i], &hi[i]); else shard_rows(&c, n, i, &lo[i], &hi[i]);
+        if (dev) dev[i] = c.shard_dev[i];
+    }
+    return c.n_shards;
+}
 static ggml_backend_buffer_type_t make_split_buffer_type(int main_device, const float * tensor_split, bool ksplit) {
     static std::mutex mu;
     static std::map<std::string, ggml_backend_buffer_type *> cache;     // one buffer type per distinct (main device, split)
@@ -162,17 +188,16 @@ static ggml_backend_buffer_type_t make_split_buffer_type(int main_device, const 
     const int self = self_shards();
     c.self = self > 1;
     c.n_shards = c.self ? self : ndev;
-    float w[CDNA4_MAX_DEVICES]; float sum = 0.f;
-    for (int i = 0; i < c.n_shards; i++) { w[i] = (tensor_split && !c.self) ? tensor_split[i] : 0.f; if (w[i] < 0.f) w[i] = 0.f; sum += w[i]; }
-    if (sum <= 0.f) { for (int i = 0; i < c.n_shards; i++) w[i] = 1.f; sum = (float)c.n_shards; }      // NULL / all zero: equal shares
-    c.bound[0] = 0.f;
-    for (int i = 0; i < c.n_shards; i++) { c.bound[i + 1] = c.bound[i] + w[i] / sum; c.shard_dev[i] = c.self ? main_device : i; }
-    c.bound[c.n_shards] = 1.f;
+    fill_bounds(&c, tensor_split);
     std::string key = std::to_string(main_device) + (c.self ? "s" : "d") + (ksplit ? "k" : "r");
     for (int i = 0; i <= c.n_shards; i++) key += ":" + std::to_string(c.bound[i]);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     c.name = ksplit ? "CDNA4_KSplit" : "CDNA4_Split";
+    // the K split's collective: communicators are created HERE, when the host asks for the buffer type (model load), not inside the first graph_compute (a multi-second
+    // stall there: ADVICE r4).  EXPERIMENTAL until it has run on a node: the multi-rank exchange has only ever executed as a world of one (no multi-GPU box in any round's pool);
+    // GGML_CDNA4_KSPLIT_RCCL=0 keeps the peer-copy + ggml_cdna4_sum_partials path, which is what one-GPU boxes and GGML_CDNA4_SPLIT_SELF exercise.
+    if (ksplit && !c.self && ndev > 1 && !(getenv("GGML_CDNA4_KSPLIT_RCCL") && atoi(getenv("GGML_CDNA4_KSPLIT_RCCL")) == 0)) (void)rccl_ready(ndev);
     ggml_backend_buffer_type * buft = new ggml_backend_buffer_type{ /* .iface = */ split_buft_iface, /* .device = */ cdna4_reg_device(main_device), /* .context = */ new split_buft_ctx(c) };
     cache[key] = buft;
     return buft;
@@ -188,6 +213,8 @@ struct rccl_api {
     bool tried = false, ok = false;
     int (*CommInitAll)(nccl_comm_t *, int, const int *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Reduce)(const void *, void *, size_t, int, int, int, nccl_comm_t, hipStream_t) = nullptr;       // rccl.h ncclReduce(send, recv, count, type, op, root, comm, stream)
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
     int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;
     const char * (*GetErrorString)(int) = nullptr;
     nccl_comm_t comms[CDNA4_MAX_DEVICES] = {}; int ncomm = 0;
@@ -208,6 +235,8 @@ bool rccl_ready(int ndev) {
     g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t))dlsym(h, "ncclAllReduce");
     g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart"); g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
     g_rccl.GetErrorString = (const char * (*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.Reduce = (int (*)(const void *, void *, size_t, int, int, int, nccl_comm_t, hipStream_t))dlsym(h, "ncclReduce");
+    g_rccl.CommDestroy = (int (*)(nccl_comm_t))dlsym(h, "ncclCommDestroy");
     if (!g_rccl.CommInitAll || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd) return false;
     int devs[CDNA4_MAX_DEVICES];
     for (int i = 0; i < ndev; i++) devs[i] = i;
@@ -216,6 +245,10 @@ bool rccl_ready(int ndev) {
     (void)hipSetDevice(cur);
     if (rc != 0) { fprintf(stderr, "ggml-cdna4: ncclCommInitAll failed (%s): K-split falls back to peer copies\n", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"); return false; }
     g_rccl.ncomm = ndev; g_rccl.ok = true;
+    atexit([] {                                                          // the communicators live as long as the process (buffer types are cached for its lifetime): released at exit
+        if (!g_rccl.CommDestroy) return;
+        for (int i = 0; i < g_rccl.ncomm; i++) if (g_rccl.comms[i]) { (void)g_rccl.CommDestroy(g_rccl.comms[i]); g_rccl.comms[i] = nullptr; }
+    });
     return true;
 }
 }
@@ -299,13 +332,15 @@ static enum ggml_status ksplit_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * ds
     }
     if (status != GGML_STATUS_SUCCESS) { HIP_OK(hipSetDevice(ctx->device)); return status; }
     if (use_rccl) {
-        // every rank sums all partials; the main device's rank receives into dst (ncclAllReduce, rccl.h:611; one call per device inside a group)
+        // only the main device consumes the sum: ncclReduce to its rank (rank = device index: ncclCommInitAll over devices 0 .. n-1), one call per device inside a group —
+        // 1/n of an all-reduce's incoming traffic on every other device; ncclAllReduce where the library lacks the symbol
         int rc = g_rccl.GroupStart();
         for (int q = 0; q < n_active && rc == 0; q++) {
             const int i = active[q], dev = st->dev[i];
             HIP_OK(hipSetDevice(dev));
             cdna4_lane & l = ctx->lanes[i];
-            rc = g_rccl.AllReduce(l.y, dev == ctx->device ? dst->data : l.y, (size_t)B * M, /* ncclFloat32 */ 7, /* ncclSum */ 0, g_rccl.comms[dev], l.stream);
+            if (g_rccl.Reduce) rc = g_rccl.Reduce(l.y, dev == ctx->device ? dst->data : l.y, (size_t)B * M, /* ncclFloat32 */ 7, /* ncclSum */ 0, /* root */ ctx->device, g_rccl.comms[dev], l.stream);
+            else rc = g_rccl.AllReduce(l.y, dev == ctx->device ? dst->data : l.y, (size_t)B * M, /* ncclFloat32 */ 7, /* ncclSum */ 0, g_rccl.comms[dev], l.stream);
         }
         const int rc2 = g_rccl.GroupEnd();
         if (rc != 0 || rc2 != 0) { fprintf(stderr, "ggml-cdna4: ncclAllReduce failed (%s)\n", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "?"); HIP_OK(hipSetDevice(ctx->device)); return GGML_STATUS_FAILED; }

@@ -1,10 +1,9 @@
-// gemm_q_lds.hip — launcher of k_gemm_lds (gemm_lds.inc): the prefill GEMM that dequantizes the weights once per 256-wide activation tile into
-// fp16 LDS tiles and feeds them to a format-agnostic MFMA consumer loop.  Replaces, at B > 8, what ggml_compute_forward_mul_mat does after the
-// activations are quantized (/root/reference/src/ggml-cpu/ggml-cpu.c:7510-7605).
+// gemm_q_lds.hip — launcher of k_gemm_r8 (gemm_r8.inc): the prefill GEMM with 32(m) x 256(b) wave tiles and in-register unpack, for grids of at least one 256 x 256
+// tile per CU.  Replaces, at B > 8, what ggml_compute_forward_mul_mat does after the activations are quantized (/root/reference/src/ggml-cpu/ggml-cpu.c:7510-7605).
+// (Round 4 built two more kernels on this launcher — k_gemm_lds, the dequantize-into-LDS structure with two waves per SIMD, and k_gemm_w4, the same with one wave per SIMD;
+//  both measured behind k_gemm_r8 / k_gemm_kq_t64 at every shape (profiles/r04/gemm_bench.txt) and were removed in round 5: git show 5eb5f7c:ggml_amd/csrc/gemm_lds.inc, gemm_w4.inc.)
 #include "gemm_q_common.h"
 #include "gemm_q_hw.h"
-#include "gemm_lds.inc"
-#include "gemm_w4.inc"
 #include "gemm_r8.inc"
 
 // (form 2, k_gemm_r8, also takes Q5_K)
@@ -32,9 +31,10 @@ bool cdna4_gemm_r8_preferred(const cdna4_gemm_args &a) {
 }
 
 // tile rows (0 = choose; 128 / 256) and split-K (0 = choose) -> launch.  Returns 0, or a negative status with the error text set.
-// form 0: k_gemm_lds (two waves per SIMD, ping-pong phases); form 1: k_gemm_w4 (one wave per SIMD); form 2: k_gemm_r8 (in-register unpack, 32 x 256 wave tiles; 256-row tiles only)
+// form: 2 = k_gemm_r8 (the only one left; 256-row tiles only)
 int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st, int form) {
-    if (!lds_supported_t(a, form == 2)) return cdna4_set_error_msg("gemm_lds: Q4_K (k_gemm_r8: or Q5_K) on 16-byte-aligned rows, whole superblocks");
+    if (form != 2) return cdna4_set_error_msg("gemm_lds: k_gemm_lds / k_gemm_w4 were measured behind k_gemm_r8 and removed in round 5 (gemm_variant bit 26 selects k_gemm_r8)");
+    if (!lds_supported_t(a, form == 2)) return cdna4_set_error_msg("gemm_r8: Q4_K or Q5_K on 16-byte-aligned rows, whole superblocks");
     const int cus = cdna4_gemm_cu_count(), nsb = a.K / 256;
     const int tiles_b = (a.B + 255) / 256;
     if (form == 2) tm = 256;
@@ -43,7 +43,7 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     const int tiles_m = (a.M + tm - 1) / tm, ntiles = tiles_m * tiles_b;
     // split-K: S co-resident work-groups per tile reduce-scatter their partial tiles (gemm_lds.inc, epilogue (2)); needs every work-group resident
     // (one per CU) and S to divide the 4 / 8 accumulator fragments of a wave.  Deterministic (fixed summation order).
-    const int nfr = form == 2 ? 8 : form == 1 ? (tm == 256 ? 16 : 8) : (tm == 256 ? 8 : 4), nwv = form == 1 ? 4 : 8;
+    const int nfr = 8, nwv = 8;
     if (splitk <= 0) {
         splitk = 1;
         for (int s = 2; s <= 8; s *= 2) if (ntiles * s <= cdna4_gemm_coresident_cus() && nsb >= 2 * s) splitk = s;
@@ -67,15 +67,9 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
 #ifdef CDNA4_ABLATIONS
     p.trace = (unsigned long long *)cdna4_debug_trace;
     const int abl = (a.variant >> 16) & 0x1FF;
-#define W4_ABL(A) if (form == 1 && abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 128, (A)>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 256, (A)>), grid, dim3(256), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
-    W4_ABL(1) W4_ABL(2) W4_ABL(3) W4_ABL(4) W4_ABL(8) W4_ABL(16) W4_ABL(32) W4_ABL(15)
-    if (form == 1 && abl) return cdna4_set_error_msg("gemm_w4: ablation not instantiated");
 #define R8_ABL(A) if (form == 2 && a.type == CDNA4_Q4_K && abl == (A)) { hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
     R8_ABL(1) R8_ABL(2) R8_ABL(3) R8_ABL(4) R8_ABL(8) R8_ABL(16) R8_ABL(32) R8_ABL(15)
     if (form == 2 && abl) return cdna4_set_error_msg("gemm_r8: ablation not instantiated");
-#define LDS_ABL(A) if (abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 128, false, (A)>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 256, false, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
-    LDS_ABL(1) LDS_ABL(2) LDS_ABL(3) LDS_ABL(4) LDS_ABL(8) LDS_ABL(16) LDS_ABL(32) LDS_ABL(64) LDS_ABL(15) LDS_ABL(256)
-    if (abl) return cdna4_set_error_msg("gemm_lds: ablation not instantiated");
 #endif
     if (form == 2) {
         const bool tail = a.epi.bias || a.epi.act || a.epi.resid;
@@ -85,14 +79,5 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
         CDNA4_CHECK_LAUNCH();
         return 0;
     }
-    if (form == 1) {
-        if (tm == 128) hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 128>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_gemm_w4<CDNA4_Q4_K, 256>), grid, dim3(256), 0, st, p);
-        CDNA4_CHECK_LAUNCH();
-        return 0;
-    }
-    if (tm == 128) hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 128>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((k_gemm_lds<CDNA4_Q4_K, 256>), grid, dim3(512), 0, st, p);
-    CDNA4_CHECK_LAUNCH();
-    return 0;
+    return cdna4_set_error_msg("gemm_lds: unknown form");
 }

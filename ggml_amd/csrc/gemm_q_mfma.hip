@@ -14,9 +14,8 @@
 //  * packed weights and fp16 activations are staged through a 3-slot LDS ring (global_load_lds_dwordx4, 16-byte chunks
 //    XOR-swizzled on the SOURCE address so the fragment ds_read_b128s are conflict-free); XCD-aware tile order.
 // Kernels, oldest to newest (launch_type() picks; DESIGN.md 4.3 has the measurements):
-//    k_gemm_q        4 waves, slice-per-barrier, per-lane weight loads — any format, small batches, K % 256 != 0
-//    k_gemm_kq_pipe  4 waves, superblock stages, counted vmcnt                      (Q4_K / Q5_K; explicit variants only since round 2)
-//    k_gemm_kq_w8    8 waves (two per SIMD), 128x128 tile, in-wave unpack/MFMA pipeline, split-K = 2 exchange
+//    k_gemm_q        4 waves, slice-per-barrier, per-lane weight loads, 128-wide activation tile — any format; K % 256 != 0, and (IDS) the grouped MUL_MAT_ID of Q5_K / Q6_K / Q4_0 / Q8_0
+//    k_gemm_kq_w8    8 waves (two per SIMD), 128x128 tile, in-wave unpack/MFMA pipeline, split-K = 2 exchange — the shallow-K (< 3 superblocks per work-group) form of the next two
 //    k_gemm_kq_w8p   + cross-stage software pipeline (barrier in the middle of the MFMA stream)   (Q5_K default)
 //    k_gemm_kq_w12   + four LDS-DMA loader waves; they also re-lay Q4_0 / Q8_0 / Q6_K blocks while staging (Q4_K default)
 //    (huge grids: k_gemm_kq_t64<.., 256> of gemm_q_t64.hip)
@@ -211,149 +210,6 @@ __global__ __launch_bounds__(256) void k_gemm_q(const gemm_params p) {
 }
 
 
-// ------------------------------------------------------------------------------------------------------------
-// Pipelined K-quant kernel (Q4_K / Q5_K).  PMC on the first version showed the waves ISSUE-bound, not latency-bound
-// (SQ_ACTIVE_INST_ANY 62 % vs MFMA busy 18 % at one wave per SIMD): the ~20 VALU ops that unpack 8 weights must be
-// amortised over more MFMAs.  Hence the 128-wide activation tile: every dequantized B fragment feeds BNF = 4 MFMAs.
-//   * stage = SKG 64-k groups of the superblock (SKG = 2 for the 128-wide tile, 4 for the 64-wide one):
-//       X: TB rows x SKG*128 B, 16-B chunks XOR-swizzled by (row & 15) on the SOURCE address (conflict-free b128)
-//       W: 128 rows x NPH 16-B pieces copied HBM->LDS untouched: header (+qh for Q5_K) + this stage's nibbles;
-//          row strides 80/112/144/176 B are all bank-conflict-free for ds_read_b128
-//   * 3-deep LDS ring, loads issued two stages ahead by global_load_lds; `s_waitcnt vmcnt(NL)` + raw s_barrier keep
-//     the next stage's NL DMA instructions in flight across the barrier (never vmcnt(0) in the main loop).
-template <int TYPE, int BNF, int SKG>
-__global__ __launch_bounds__(256) void k_gemm_kq_pipe(const gemm_params p) {
-    typedef WStage<TYPE, SKG> WSt;
-    constexpr int NST = 3;
-    constexpr int TB = 32 * BNF;
-    constexpr int RS = SKG * 128;                // X row stride in a stage (bytes)
-    constexpr int XS = TB * RS;                  // X bytes per stage
-    constexpr int BLK = QT<TYPE>::BYTES;
-    constexpr int WRS = WSt::NPH * 16;           // W row stride in a stage
-    constexpr int WS = 128 * WRS;
-    constexpr int ST = XS + WS;                  // one ring slot
-    constexpr int XL = XS / 16 / 256;            // X DMA instructions per thread per stage
-    constexpr int NWI = 128 * WSt::NPH / 64;     // W DMA wave-instructions per stage
-    constexpr int WL = (NWI + 3) / 4;            // ... per wave (the tail re-loads earlier pieces)
-    constexpr int NL = XL + WL;
-    constexpr int PARTS = 4 / SKG;               // stages per superblock
-    static_assert(NST * ST <= 160 * 1024, "LDS ring does not fit");
-    static_assert(SKG == 2, "stage = one 128-k panel of the activation image");
-    __shared__ __attribute__((aligned(16))) uint8_t smem[NST * ST];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int nblk = gridDim.x;
-    int L = blockIdx.x;
-    if ((nblk & 7) == 0) L = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-    const int tile_b = L % p.tiles_b; L /= p.tiles_b;
-    const int ks = L % p.splitk, tile_m = L / p.splitk;
-    const int m0 = tile_m * 128, b0 = tile_b * TB;
-    const int nsb = p.K / 256 / p.splitk, sb0 = ks * nsb;
-    const int nstage = nsb * PARTS;
-
-    DqConst dq; dq.init();
-    floatx16 acc[BNF];
-#pragma unroll
-    for (int i = 0; i < BNF; i++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-
-    // DMA source addresses = wave-uniform 64-bit base (SGPRs, advanced by scalar adds per stage) + a per-lane 32-bit
-    // byte offset that never changes: no vector address arithmetic inside the main loop.
-    uint32_t xvoff[XL], wvoff[PARTS][WL];
-#pragma unroll
-    for (int i = 0; i < XL; i++) {
-        const int pc = i * 256 + tid, row = pc / (SKG * 8), c = (pc % (SKG * 8)) ^ (row & 15);
-        xvoff[i] = (uint32_t)(min(b0 + row, p.B - 1) - b0) * 256u + c * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < WL; i++) {
-        int idx = wave + 4 * i;
-        if (idx >= NWI) idx -= 4;                                        // wave-uniform: re-load this wave's previous piece
-        const int pc = idx * 64 + lane, row = pc / WSt::NPH, c = pc % WSt::NPH;
-        const uint32_t ro = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.w_row_bytes;
-#pragma unroll
-        for (int part = 0; part < PARTS; part++) wvoff[part][i] = ro + WSt::src_piece(c, part) * 16;
-    }
-    const char *const xbase = (const char *)p.xh + ((int64_t)sb0 * 2 * p.B + b0) * 256;    // panel (2*sb0), row b0
-    const char *const wbase = (const char *)p.W + (int64_t)m0 * p.w_row_bytes + (int64_t)sb0 * BLK;
-
-    auto issue = [&](int sbr, int part, int slot) {                      // sbr = superblock relative to sb0
-        uint8_t *xs = smem + slot * ST, *ws = xs + XS;
-        const char *xsrc = xbase + (int64_t)(sbr * PARTS + part) * p.B * 256;                // one 128-k panel = B rows x 256 B
-        const char *wsrc = wbase + (int64_t)sbr * BLK;
-#pragma unroll
-        for (int i = 0; i < XL; i++) glds16(xsrc + xvoff[i], xs + (i * 256 + wave * 64) * 16);
-#pragma unroll
-        for (int i = 0; i < WL; i++) {
-            int idx = wave + 4 * i;
-            if (idx >= NWI) idx -= 4;
-            glds16(wsrc + wvoff[part][i], ws + idx * 1024);
-        }
-    };
-
-    const int xrow_off = j * RS, xswz = j & 15;
-    // One 64-k group = 2-3 packed-weight reads + 4*BNF activation-fragment reads, ALL issued before the first use, then the
-    // VALU unpack (which only needs the weight bytes) runs while the fragment reads are in flight, then 4*BNF MFMAs
-    // back to back.  With just-in-time reads (ds_read; s_waitcnt lgkmcnt(0); mfma) every MFMA pair paid a full LDS
-    // round trip: PMC showed the waves parked in s_waitcnt 56-62 % of the time at one and at two waves per SIMD.
-    auto compute = [&](int slot, int part) {                             // `part` is a compile-time constant at every call site
-        const uint8_t *xs = smem + slot * ST + xrow_off;
-        const uint8_t *wrow = smem + slot * ST + XS + (wave * 32 + j) * WRS;
-#pragma unroll
-        for (int gl = 0; gl < SKG; gl++) {
-            Raw<TYPE> raw;
-            raw.load(wrow, gl, h);
-            half8_t xa[4][BNF];
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const int coff = ((gl * 8 + chunk_of<TYPE>(kk, h)) ^ xswz) << 4;
-#pragma unroll
-                for (int bf = 0; bf < BNF; bf++) xa[kk][bf] = *reinterpret_cast<const half8_t *>(xs + bf * 32 * RS + coff);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            half8_t wf[4];
-            raw.frags(part * SKG + gl, h, wf, dq);
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-#pragma unroll
-                for (int bf = 0; bf < BNF; bf++) acc[bf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[kk][bf], wf[kk], acc[bf], 0, 0, 0);
-        }
-    };
-
-    // stage s = (superblock s / PARTS, part s % PARTS); ring slot = s % 3; loads run two stages ahead
-    issue(0, 0, 0);
-    if (nstage > 1) issue(1 / PARTS, 1 % PARTS, 1);
-    int slot = 0;
-    for (int sb = 0; sb < nsb; sb++) {
-#pragma unroll
-        for (int part = 0; part < PARTS; part++) {
-            const int s = sb * PARTS + part;
-            if (s + 1 < nstage) wait_vmcnt<NL>(); else wait_vmcnt<0>();  // stage s+1 may stay in flight
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const int slot2 = slot >= 1 ? slot - 1 : 2;                   // (slot + 2) % 3
-            if (s + 2 < nstage) issue(sb + (part + 2) / PARTS, (part + 2) % PARTS, slot2);
-            compute(slot, part);
-            slot = slot == 2 ? 0 : slot + 1;
-        }
-    }
-
-    const int m = m0 + wave * 32 + j;
-    if (m < p.M) {
-#pragma unroll
-        for (int bf = 0; bf < BNF; bf++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int b = b0 + bf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (b < p.B) {
-                    float *dst = p.Y + (int64_t)b * p.y_row + m;
-                    if (p.splitk > 1) unsafeAtomicAdd(dst, acc[bf][r]); else *dst = acc[bf][r];
-                }
-            }
-    }
-}
-
 #include "gemm_kq_w8.inc"
 
 #include "gemm_kq_w12.inc"
@@ -392,21 +248,6 @@ static int launch_variant(const cdna4_gemm_args &a, int splitk, hipStream_t st) 
         hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.Y, a.y_row_elems, a.M, a.B);
     }
     hipLaunchKernelGGL((k_gemm_q<TYPE, BNF, WLDS>), dim3(p.tiles_m * p.tiles_b * splitk), dim3(256), 0, st, p);
-    CDNA4_CHECK_LAUNCH();
-    return 0;
-}
-
-template <int TYPE, int BNF>
-static int launch_pipe(const cdna4_gemm_args &a, int splitk, hipStream_t st) {
-    gemm_params p{}; p.trace = nullptr; p.partial = nullptr; p.flags = nullptr; p.sb_split = 0;
-    p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
-    p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.splitk = splitk;
-    p.tiles_m = (a.M + 127) / 128; p.tiles_b = (a.B + 32 * BNF - 1) / (32 * BNF);
-    if (splitk > 1) {
-        const int64_t n = (int64_t)a.M * a.B;
-        hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.Y, a.y_row_elems, a.M, a.B);
-    }
-    hipLaunchKernelGGL((k_gemm_kq_pipe<TYPE, BNF, 2>), dim3(p.tiles_m * p.tiles_b * splitk), dim3(256), 0, st, p);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
@@ -474,7 +315,7 @@ static int co_cus() { return cdna4_gemm_coresident_cus(); }
 // probe armed; every route ends in ROUTE_END(does this kernel apply a.epi in its store?) in front of its first side effect (scratch, zero-fill, launch).
 static thread_local struct { bool active, fuses; int kernel, reencoded; bool fuseq; } g_probe = {false, false, 0, 0, false};
 // kernel ids (ggml_cdna4_mul_mat_route, include/ggml_cdna4.h): 10 k_gemm_kq_t64, 12 k_gemm_r8, 13 the 128 x 128-tile kernels (k_gemm_kq_w8 / _w8p / _w12), 14 the older per-lane-load
-// kernels (k_gemm_q, k_gemm_kq_pipe), 15 k_gemm_lds / k_gemm_w4 (explicit variants only)
+// kernel (k_gemm_q)
 #define ROUTE_END_K(f, kid) do { if (g_probe.active) { g_probe.fuses = (f); g_probe.kernel = (kid); return 0; } } while (0)
 #define ROUTE_END(f) ROUTE_END_K(f, 0)
 
@@ -656,11 +497,12 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         if (wlds && (variant & 16)) return launch_w8<TYPE>(a, splitk, (variant & 4096) ? 65 : ((variant & 2048) ? 64 : ((variant >> 5) & 31)), st, variant >> 16);
     }
     ROUTE_END_K(false, 14);                                              // the older kernels below store the plain product (k_epilogue behind them)
+    // (round 5: the 4-wave pipelined k_gemm_kq_pipe and the 64-wide forms of k_gemm_q — explicit variants only since round 2 — are gone; bits 1 and 3 of a variant are ignored)
+    (void)wide;
     if constexpr (CAN_LDS) {
-        if (wlds && !(variant & 8)) return wide ? launch_pipe<TYPE, 4>(a, splitk, st) : launch_pipe<TYPE, 2>(a, splitk, st);
-        if (wlds) return wide ? launch_variant<TYPE, 4, true>(a, splitk, st) : launch_variant<TYPE, 2, true>(a, splitk, st);
+        if (wlds) return launch_variant<TYPE, 4, true>(a, splitk, st);
     }
-    return wide ? launch_variant<TYPE, 4, false>(a, splitk, st) : launch_variant<TYPE, 2, false>(a, splitk, st);
+    return launch_variant<TYPE, 4, false>(a, splitk, st);
 }
 
 // grouped MUL_MAT_ID for Q5_K / Q6_K / Q4_0 / Q8_0: one launch of k_gemm_q<.., IDS> over (m tile) x (128-row activation tile of the expert-sorted
@@ -750,10 +592,12 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
         c.type = CDNA4_Q6_K; c.K = a.K * cdna4_convert_weights_kmul(a.type); c.xh_row_elems = c.K; c.w_row_bytes = (int64_t)(c.K / 256) * 210;
         return launch_type<CDNA4_Q6_K>(c, st);
     }
-    // variant bit 28 = k_gemm_lds (gemm_q_lds.hip); bits 29 / 30 force its 128- / 256-row tile (bits 16-27: ablation mask of -DCDNA4_ABLATIONS builds)
-    // bit 25 with bit 28: its one-wave-per-SIMD form k_gemm_w4; bit 26 with bit 28: k_gemm_r8 (in-register unpack, 32 x 256 wave tiles)
-    if (a.variant > 0 && (a.variant & (1 << 28))) { ROUTE_END_K((a.variant & (1 << 26)) != 0, (a.variant & (1 << 26)) ? 12 : 15); }
-    if (a.variant > 0 && (a.variant & (1 << 28))) return cdna4_launch_gemm_lds(a, (a.variant & (1 << 29)) ? 128 : ((a.variant & (1 << 30)) ? 256 : 0), a.splitk, st, (a.variant & (1 << 26)) ? 2 : (a.variant & (1 << 25)) ? 1 : 0);
+    // variant bits 28 + 26 = k_gemm_r8 (gemm_q_lds.hip: in-register unpack, 32 x 256 wave tiles) explicitly (bits 16-24: ablation mask of -DCDNA4_ABLATIONS builds)
+    if (a.variant > 0 && (a.variant & (1 << 28))) {
+        if (!(a.variant & (1 << 26))) return cdna4_set_error_msg("gemm_q: variant bit 28 without bit 26 named k_gemm_lds / k_gemm_w4, removed in round 5 (measured losses: profiles/r04/gemm_bench.txt)");
+        ROUTE_END_K(true, 12);
+        return cdna4_launch_gemm_lds(a, 256, a.splitk, st, 2);
+    }
     switch (a.type) {
         case CDNA4_Q4_K: return launch_type<CDNA4_Q4_K>(a, st);
         case CDNA4_Q5_K: return launch_type<CDNA4_Q5_K>(a, st);

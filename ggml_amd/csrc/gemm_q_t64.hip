@@ -113,7 +113,8 @@ static int t64_make_plan(const cdna4_gemm_args &a, int tm, int splitk, t64_plan 
     if (tm <= 0) {
         const int t256 = ((a.M + 255) / 256) * tiles_b, t128 = ((a.M + 127) / 128) * tiles_b;
         auto eff = [&](int n) { return (double)n / (double)(((n + cus - 1) / cus) * cus); };
-        tm = (t256 * 2 > cus && eff(t256) * 1.10 >= eff(t128)) ? 256 : 128;
+        // (from 3/4 of a tile per CU: what was measured — 0.75 and above are wins, exactly 0.5 is a loss, the band between them was never run: ADVICE r4)
+        tm = (t256 * 4 >= cus * 3 && eff(t256) * 1.10 >= eff(t128)) ? 256 : 128;
     }
     if (tm != 128 && tm != 256) return cdna4_set_error_msg("gemm_t64: tile rows are 128 or 256");
     const int tiles_m = (a.M + tm - 1) / tm, ntiles = tiles_m * tiles_b;

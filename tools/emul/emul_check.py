@@ -25,7 +25,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 def build(name="w12"):
     exe = os.path.join(HERE, name + "_emul")
     srcs = [os.path.join(HERE, name + "_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(ROOT, "ggml_amd", "csrc", f)
-            for f in ("gemm_lds.inc", "gemm_w4.inc", "gemm_r8.inc", "gemm_kq_t64.inc", "gemm_kq_w12.inc", "gemm_kq_w8.inc", "gemm_w8_epilogue.inc", "gemm_q_hw.h", "gemm_q_common.h", "cdna4_common.h", "cdna4_kernels.h", "quantize_dev.h")]
+            for f in ("gemm_r8.inc", "gemm_kq_t64.inc", "gemm_kq_w12.inc", "gemm_kq_w8.inc", "gemm_w8_epilogue.inc", "gemm_q_hw.h", "gemm_q_common.h", "cdna4_common.h", "cdna4_kernels.h", "quantize_dev.h")]
     if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
         subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "ggml_amd", "csrc"),
                         "-Wno-unused-value", "-o", exe, srcs[0]], check=True, capture_output=True, timeout=600)

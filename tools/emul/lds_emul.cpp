@@ -1,5 +1,5 @@
-// lds_emul.cpp — runs the SOURCE of k_gemm_lds (ggml_amd/csrc/gemm_lds.inc: weights dequantized into fp16 LDS tiles, 256-wide activation tile,
-// TM = 128 / 256) on the CPU like t64_emul.cpp.  Test infrastructure.
+// lds_emul.cpp — runs the SOURCE of k_gemm_r8 (ggml_amd/csrc/gemm_r8.inc: 32 x 256 wave tiles, in-register unpack, 256 x 256 work-group tiles; the harness of the
+// dequantize-into-LDS kernels of round 4, which were removed in round 5) on the CPU like t64_emul.cpp.  Test infrastructure.
 //   lds_emul M K B w.bin xh.bin y.bin splitk tm xchg_l2 [type]
 #include "hip_emul.h"
 #include <signal.h>
@@ -49,8 +49,6 @@ static void *shared_alloc(size_t n) {
 
 #include "../../ggml_amd/csrc/gemm_q_common.h"
 #include "../../ggml_amd/csrc/gemm_q_hw.h"
-#include "../../ggml_amd/csrc/gemm_lds.inc"
-#include "../../ggml_amd/csrc/gemm_w4.inc"
 #include "../../ggml_amd/csrc/gemm_r8.inc"
 
 template <typename F> static void emu_launch(F body, unsigned nblk, int nthreads) {
@@ -113,11 +111,9 @@ int main(int argc, char **argv) {
         p.flags = flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
     }
     const unsigned nblk = (unsigned)(ntiles * splitk);
-    if (form == 2 && argc > 10 && atoi(argv[10]) == 13) emu_launch([&] { k_gemm_r8<CDNA4_Q5_K>(p); }, nblk, 512);
-    else if (form == 2) emu_launch([&] { k_gemm_r8<CDNA4_Q4_K>(p); }, nblk, 512);
-    else if (form) { if (tm == 128) emu_launch([&] { k_gemm_w4<CDNA4_Q4_K, 128>(p); }, nblk, 256); else emu_launch([&] { k_gemm_w4<CDNA4_Q4_K, 256>(p); }, nblk, 256); }
-    else if (tm == 128) emu_launch([&] { k_gemm_lds<CDNA4_Q4_K, 128>(p); }, nblk, 512);
-    else emu_launch([&] { k_gemm_lds<CDNA4_Q4_K, 256>(p); }, nblk, 512);
+    if (form != 2) { fprintf(stderr, "k_gemm_lds / k_gemm_w4 were removed in round 5; pass 3 as the ninth argument (k_gemm_r8)\n"); return 2; }
+    if (argc > 10 && atoi(argv[10]) == 13) emu_launch([&] { k_gemm_r8<CDNA4_Q5_K>(p); }, nblk, 512);
+    else emu_launch([&] { k_gemm_r8<CDNA4_Q4_K>(p); }, nblk, 512);
     if (flags) for (int i = 0; i < 16384; i++) if (flags[i] != 0) { fprintf(stderr, "split-K counter word %d was not reset by the last work-group to leave (%u)\n", i, flags[i]); return 4; }
     FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)B * M, f); fclose(f);
     return 0;
