@@ -36,7 +36,7 @@ static ws_view carve(int type, int64_t K, int64_t B, void *base) {
     return v;
 }
 
-// workspace of the grouped MUL_MAT_ID path: [img_src i32 R][img_dst i32 R][tile_expert i32 R/128][xh f16 R x K (+ slack)], R = image rows =
+// workspace of the grouped MUL_MAT_ID path: [img_src i32 R][img_dst i32 R][tile_expert | tile_order | tile_nfrag: 3 x i32 R/128][xh f16 R x K (+ slack)], R = image rows =
 // an upper bound of sum_e ceil(cnt_e / 128) * 128
 struct moe_view { int32_t *img_src, *img_dst, *tile_expert; void *xh; int64_t img_rows; size_t total; };
 static moe_view moe_carve(int64_t K, int64_t n_expert, int64_t n_used, int64_t n_tok, void *base) {
@@ -45,7 +45,7 @@ static moe_view moe_carve(int64_t K, int64_t n_expert, int64_t n_used, int64_t n
     v.img_rows = (n_pairs + 127) / 128 * 128 + 128 * n_expert;
     v.img_src = (int32_t *)(p + off); off += align256((size_t)v.img_rows * 4);
     v.img_dst = (int32_t *)(p + off); off += align256((size_t)v.img_rows * 4);
-    v.tile_expert = (int32_t *)(p + off); off += align256((size_t)(v.img_rows / 128) * 4);
+    v.tile_expert = (int32_t *)(p + off); off += align256((size_t)(v.img_rows / 128) * 4 * 3);     // [tile_expert | tile_order | tile_nfrag] (k_moe_plan writes all three)
     v.xh = (void *)(p + off); off += align256((size_t)v.img_rows * K * 2) + 32768;
     v.total = off;
     return v;

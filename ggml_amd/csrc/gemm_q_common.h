@@ -465,6 +465,9 @@ struct gemm_params {
     // k_gemm_kq_t64<.., FQ> only (appended last): the ONE-LAUNCH step — the fp32 activation rows (xf, rows xf_row elements apart) are quantized to the Q8_K-rounded
     // fp16 image `xh` by the work-groups themselves in front of a grid barrier (gbar: its words, see cdna4_grid_barrier)
     const float *xf; int64_t xf_row; unsigned *gbar;
+    // k_gemm_kq_t64<.., 128, IDS> only (appended last; either may be null): tile_order[j] = the image tile the j-th group of tiles_m work-groups takes (fullest first),
+    // tile_nfrag[t] = how many of tile t's four 32-row fragments hold rows (k_moe_plan, quantize_act.hip)
+    const int32_t *tile_order; const int32_t *tile_nfrag;
 };
 
 // Grid-wide barrier of a launch whose work-groups are ALL resident (the launcher's condition; one thread per work-group calls it, behind a __syncthreads()

@@ -160,9 +160,16 @@ int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expe
     // tiles (profiles/r04/moe_tm_ab.txt)
     static const int tm_env = getenv("CDNA4_MOE_TM") ? atoi(getenv("CDNA4_MOE_TM")) : 0;
     const int cus0 = cdna4_gemm_cu_count();
+    // Round 5: the plan also writes a tile ORDER (fullest image tiles first) and per-tile fragment counts (k_moe_plan): the 128-row form starts its tiles in that order and
+    // issues no MFMAs for the empty 32-row fragments of an expert's last tile.  Measured at 8 x 2 x 512 x 4096^2, one box, us per call (profiles/r05/moe_ab.txt): 128-row tiles
+    // 93.5-94.2 without the tables, 92.3-92.7 with them — and 84.0 on 256-row tiles, which stay the choice there: a full-K 128 x 128 tile takes ~40 us (not the 27 us of the
+    // headline's half-K tiles), so the eight full tiles x 32 m-tiles are one 40-us round and the light tiles a second of ~30; the 256-row form is ONE round.  The tables
+    // therefore serve the grids that take 128-row tiles by the rule below (CDNA4_MOE_PLAN=0: without them).
+    static const bool plan_off = getenv("CDNA4_MOE_PLAN") && atoi(getenv("CDNA4_MOE_PLAN")) == 0;
     const int tm = tm_env == 128 || tm_env == 256 ? tm_env : ((((a.M + 255) / 256) * (a.B / 128)) * 4 >= cus0 * 3 ? 256 : 128);
     p.tiles_m = (a.M + tm - 1) / tm; p.tiles_b = a.B / 128;
     p.tile_expert = tile_expert; p.row_dst = row_dst; p.w_expert_bytes = w_expert_bytes;
+    if (!plan_off && tm == 128) { p.tile_order = tile_expert + p.tiles_b; p.tile_nfrag = tile_expert + 2 * p.tiles_b; }      // (k_moe_plan wrote them behind tile_expert: capi.hip moe_carve)
     if (tm == 256) {
         hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256, true>), dim3(p.tiles_m * p.tiles_b), dim3(512), 0, st, p);
         CDNA4_CHECK_LAUNCH();
@@ -175,6 +182,7 @@ int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expe
     static const int sk_env = getenv("CDNA4_MOE_SPLITK") ? atoi(getenv("CDNA4_MOE_SPLITK")) : 1;
     const int ntiles = p.tiles_m * p.tiles_b, cus = cdna4_gemm_cu_count();
     if (sk_env == 2 && a.K / 256 >= 4 && ntiles * 2 > cus && (size_t)ntiles * 8 <= 32768) {
+        p.tile_order = nullptr; p.tile_nfrag = nullptr;                  // (the split's (tile, ks) mapping is the table-free one)
         const size_t pbytes = (size_t)ntiles * 2 * 8 * 16384, fbytes = 65536;
         char *sc = (char *)cdna4_gemm_scratch(fbytes + pbytes, 2);
         if (sc) { p.splitk = 2; p.tune = 2; p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes); }

@@ -183,7 +183,11 @@ __global__ __launch_bounds__(1024) void k_moe_plan(const int32_t *__restrict__ i
     const int tid = threadIdx.x, n_pairs = n_tok * n_used, ntile = img_rows / 128;
     for (int e = tid; e < n_expert; e += 1024) { cnt[e] = 0; pos[e] = 0; }
     for (int r = tid; r < img_rows; r += 1024) { img_src[r] = -1; img_dst[r] = -1; }
-    for (int t = tid; t < ntile; t += 1024) tile_expert[t] = -1;
+    // behind tile_expert[ntile]: tile_order[ntile] — the image tiles in the order the grouped GEMM should START them, fullest first (the grid is a few rounds of
+    // work-groups: the nearly empty second tiles of the experts fill the tail instead of holding a round open) — and tile_nfrag[ntile], the 32-row fragments of a tile
+    // that hold rows (1 .. 4; k_gemm_kq_t64<.., IDS> issues no MFMA for the others)
+    int32_t *tile_order = tile_expert + ntile, *tile_nfrag = tile_expert + 2 * ntile;
+    for (int t = tid; t < ntile; t += 1024) { tile_expert[t] = -1; tile_order[t] = t; tile_nfrag[t] = 0; }
     __syncthreads();
     for (int pr = tid; pr < n_pairs; pr += 1024) {
         const int e = ids[(int64_t)(pr / n_used) * ids_tok_stride + pr % n_used];
@@ -195,9 +199,17 @@ __global__ __launch_bounds__(1024) void k_moe_plan(const int32_t *__restrict__ i
         for (int e = 0; e < n_expert; e++) {
             off[e] = run;
             const int nt = (cnt[e] + 127) / 128;
-            for (int t = 0; t < nt; t++) tile_expert[run / 128 + t] = e;
+            for (int t = 0; t < nt; t++) {
+                tile_expert[run / 128 + t] = e;
+                const int rows = min(128, cnt[e] - 128 * t);
+                tile_nfrag[run / 128 + t] = (rows + 31) / 32;
+            }
             run += nt * 128;
         }
+        // counting sort of the tiles by fragments, descending (unused tiles, nfrag 0, last); stable within a class
+        int at = 0;
+        for (int f = 4; f >= 0; f--)
+            for (int t = 0; t < ntile; t++) if (tile_nfrag[t] == f) tile_order[at++] = t;
     }
     __syncthreads();
     for (int pr = tid; pr < n_pairs; pr += 1024) {
