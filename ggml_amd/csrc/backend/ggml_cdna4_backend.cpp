@@ -19,8 +19,10 @@
 #include <vector>
 
 struct cdna4_device_ctx { int device; std::string name, description; };
-struct cdna4_buft_ctx   { int device; std::string name; };
-struct cdna4_buffer_ctx { int device; void * base; size_t size; };
+struct cdna4_buft_ctx   { int device; std::string name; bool resident = false; };
+// resident: the buffer keeps, beside every eligible weight matrix, its kernel-native image (ggml_cdna4_resident_image_*): see the CDNA4_Resident buffer type below
+struct cdna4_resident_tensor { ggml_tensor * tensor; void * image; size_t written; bool registered; };
+struct cdna4_buffer_ctx { int device; void * base; size_t size; bool resident = false; std::vector<cdna4_resident_tensor> res; };
 
 static ggml_backend_reg_t ggml_backend_cdna4_reg(void);
 static ggml_backend_buffer_type_t cdna4_buffer_type(int device);
@@ -32,22 +34,63 @@ static void cdna4_buffer_free(ggml_backend_buffer_t buffer) {
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
     HIP_OK(hipSetDevice(ctx->device));
     HIP_OK(hipDeviceSynchronize());
+    for (cdna4_resident_tensor & r : ctx->res) {
+        if (r.registered) (void)ggml_cdna4_resident_image_unregister(r.tensor->data);
+        if (r.image) HIP_OK(hipFree(r.image));
+    }
     HIP_OK(hipFree(ctx->base));
     delete ctx;
 }
 static void * cdna4_buffer_get_base(ggml_backend_buffer_t buffer) { return ((cdna4_buffer_ctx *)buffer->context)->base; }
 static bool buffer_is_cdna4(ggml_backend_buffer_t buffer) { return buffer && buffer->iface.get_base == cdna4_buffer_get_base; }
 
+static void resident_written(cdna4_buffer_ctx * ctx, ggml_tensor * tensor, size_t offset, size_t size);      // (below: CDNA4_Resident)
 static void cdna4_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
     HIP_OK(hipSetDevice(ctx->device));
     HIP_OK(hipMemset((char *)tensor->data + offset, value, size));
     HIP_OK(hipStreamSynchronize(0));
+    resident_written(ctx, tensor, offset, size);
+}
+// ---- CDNA4_Resident: a weight written into such a buffer gets its kernel-native image built ONCE, when its last byte has arrived (set_tensor / cpy_tensor: the
+// reference repacks at the same moment, src/ggml-cpu/ggml-cpu-aarch64.cpp:4144-4172) — built twice and compared (a re-encoding that is not bit-stable is refused: the tensor
+// then simply has no image and every call re-encodes as before).  The original bytes stay in the buffer: get_tensor is the plain copy, decode reads them, views work.
+static cdna4_resident_tensor * resident_find(cdna4_buffer_ctx * ctx, const ggml_tensor * tensor) {
+    for (cdna4_resident_tensor & r : ctx->res) if (r.tensor == tensor || r.tensor->data == tensor->data) return &r;
+    return nullptr;
+}
+static void resident_invalidate(cdna4_resident_tensor * r) {
+    if (r->registered) { (void)ggml_cdna4_resident_image_unregister(r->tensor->data); r->registered = false; }
+}
+static void resident_written(cdna4_buffer_ctx * ctx, ggml_tensor * tensor, size_t offset, size_t size) {
+    if (!ctx->resident) return;
+    cdna4_resident_tensor * r = resident_find(ctx, tensor);
+    if (!r) return;
+    resident_invalidate(r);
+    const size_t total = ggml_nbytes(r->tensor);
+    r->written = (offset == 0 && size >= total) ? total : r->written + size;       // (loaders write whole tensors; pieces are counted until they add up)
+    if (r->written < total) return;
+    r->written = 0;
+    const ggml_tensor * t = r->tensor;
+    if (ggml_cdna4_resident_image_register((int)t->type, t->data, (int64_t)t->nb[1], t->ne[1], t->ne[0], r->image, 1, nullptr) == 0) r->registered = true;
+    else fprintf(stderr, "ggml-cdna4: no resident image for %s: %s\n", t->name, ggml_cdna4_last_error());
+}
+static void cdna4_resident_init_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor) {
+    cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
+    if (tensor->view_src || tensor->ne[2] != 1 || tensor->ne[3] != 1 || !ggml_is_contiguous(tensor)) return;
+    const size_t bytes = ggml_cdna4_resident_image_size((int)tensor->type, tensor->ne[1], tensor->ne[0]);
+    if (bytes == 0) return;                                                         // a type that needs no image (or no MUL_MAT weight at all)
+    if (resident_find(ctx, tensor)) return;
+    HIP_OK(hipSetDevice(ctx->device));
+    void * img = nullptr;
+    if (hipMalloc(&img, bytes) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "ggml-cdna4: no memory for the resident image of %s (per-call re-encoding stays)\n", tensor->name); return; }
+    ctx->res.push_back(cdna4_resident_tensor{tensor, img, 0, false});
 }
 static void cdna4_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
     HIP_OK(hipSetDevice(ctx->device));
     HIP_OK(hipMemcpy((char *)tensor->data + offset, data, size, hipMemcpyHostToDevice));
+    resident_written(ctx, tensor, offset, size);
 }
 static void cdna4_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
@@ -65,6 +108,7 @@ static bool cdna4_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_ten
     if (sctx->device == dctx->device) HIP_OK(hipMemcpy(dst->data, src->data, ggml_nbytes(src), hipMemcpyDeviceToDevice));
     else HIP_OK(hipMemcpyPeer(dst->data, dctx->device, src->data, sctx->device, ggml_nbytes(src)));
     HIP_OK(hipDeviceSynchronize());
+    resident_written(dctx, dst, 0, ggml_nbytes(src));
     return true;
 }
 static void cdna4_buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
@@ -72,11 +116,23 @@ static void cdna4_buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
     HIP_OK(hipSetDevice(ctx->device));
     HIP_OK(hipMemset(ctx->base, value, ctx->size));
     HIP_OK(hipDeviceSynchronize());
+    for (cdna4_resident_tensor & r : ctx->res) { resident_invalidate(&r); r.written = 0; }       // (the images follow the next whole write)
 }
 static const ggml_backend_buffer_i cdna4_buffer_iface = {
     /* .free_buffer   = */ cdna4_buffer_free,
     /* .get_base      = */ cdna4_buffer_get_base,
     /* .init_tensor   = */ NULL,
+    /* .memset_tensor = */ cdna4_buffer_memset_tensor,
+    /* .set_tensor    = */ cdna4_buffer_set_tensor,
+    /* .get_tensor    = */ cdna4_buffer_get_tensor,
+    /* .cpy_tensor    = */ cdna4_buffer_cpy_tensor,
+    /* .clear         = */ cdna4_buffer_clear,
+    /* .reset         = */ NULL,
+};
+static const ggml_backend_buffer_i cdna4_resident_buffer_iface = {
+    /* .free_buffer   = */ cdna4_buffer_free,
+    /* .get_base      = */ cdna4_buffer_get_base,
+    /* .init_tensor   = */ cdna4_resident_init_tensor,
     /* .memset_tensor = */ cdna4_buffer_memset_tensor,
     /* .set_tensor    = */ cdna4_buffer_set_tensor,
     /* .get_tensor    = */ cdna4_buffer_get_tensor,
@@ -99,7 +155,8 @@ static ggml_backend_buffer_t cdna4_buft_alloc_buffer(ggml_backend_buffer_type_t 
         return NULL;
     }
     cdna4_buffer_ctx * ctx = new cdna4_buffer_ctx{bctx->device, base, alloc};
-    return ggml_backend_buffer_init(buft, cdna4_buffer_iface, ctx, size);
+    ctx->resident = bctx->resident;
+    return ggml_backend_buffer_init(buft, bctx->resident ? cdna4_resident_buffer_iface : cdna4_buffer_iface, ctx, size);
 }
 static size_t cdna4_buft_get_alignment(ggml_backend_buffer_type_t) { return 256; }
 static size_t cdna4_buft_get_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor * tensor) {
@@ -459,6 +516,8 @@ static void cdna4_backend_set_tensor_async(ggml_backend_t backend, ggml_tensor *
     GGML_ASSERT(buffer_is_cdna4(buf) && "set_tensor_async: the tensor must live in a buffer of this backend");
     HIP_OK(hipSetDevice(ctx->device));
     HIP_OK(hipMemcpyAsync((char *)tensor->data + offset, data, size, hipMemcpyHostToDevice, ctx->stream));
+    cdna4_buffer_ctx * bctx = (cdna4_buffer_ctx *)buf->context;
+    if (bctx->resident && resident_find(bctx, tensor)) { HIP_OK(hipStreamSynchronize(ctx->stream)); resident_written(bctx, tensor, offset, size); }   // (a weight with an image: the image follows its bytes)
 }
 static void cdna4_backend_get_tensor_async(ggml_backend_t backend, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
@@ -629,6 +688,9 @@ struct cdna4_reg_ctx {
     std::vector<cdna4_device_ctx> dctx;
     ggml_backend_buffer_type bufts[CDNA4_MAX_DEVICES];
     cdna4_buft_ctx buft_ctx[CDNA4_MAX_DEVICES];
+    ggml_backend_buffer_type res_bufts[CDNA4_MAX_DEVICES];              // CDNA4_Resident<i>: weights + their kernel-native images
+    cdna4_buft_ctx res_buft_ctx[CDNA4_MAX_DEVICES];
+    ggml_backend_buffer_type_t extra[CDNA4_MAX_DEVICES][2];             // what ggml_backend_dev_get_extra_bufts returns per device (NULL-terminated)
     int n = 0;
 };
 static cdna4_reg_ctx * g_reg = nullptr;
@@ -648,7 +710,14 @@ static ggml_backend_dev_t cdna4_reg_get_device(ggml_backend_reg_t reg, size_t in
 }
 static ggml_backend_feature g_features[] = { {"WAVE64", "1"}, {"MFMA_F16", "1"}, {"INT8_DOT", "1"}, {nullptr, nullptr} };
 static ggml_backend_feature * cdna4_get_features(ggml_backend_reg_t) { return g_features; }
+// the device's extra buffer types (ggml_backend_dev_get_extra_bufts_t, include/ggml-backend.h:192; the CPU backend's: src/ggml-cpu/ggml-cpu.cpp:581-582): hosts try them
+// for weights first.  Ours is CDNA4_Resident<i>: an ordinary device buffer whose re-encoded formats (Q5_0 / IQ4_NL / Q4_1 / Q5_1 / Q3_K / Q2_K / IQ4_XS) also keep their
+// kernel-native image, built once at set_tensor — prefill launches no conversion any more; everything else about the buffer is the default type's.
+static ggml_backend_buffer_type_t * cdna4_dev_get_extra_bufts(ggml_backend_dev_t dev) { return g_reg->extra[((cdna4_device_ctx *)dev->context)->device]; }
+static ggml_backend_buffer_type_t cdna4_resident_buffer_type(int device) { (void)ggml_backend_cdna4_reg(); return (g_reg && device >= 0 && device < g_reg->n) ? &g_reg->res_bufts[device] : nullptr; }
 static void * cdna4_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
+    if (strcmp(name, "ggml_backend_dev_get_extra_bufts") == 0) return (void *)cdna4_dev_get_extra_bufts;
+    if (strcmp(name, "ggml_backend_cdna4_resident_buffer_type") == 0) return (void *)cdna4_resident_buffer_type;     // (int device) -> the buffer type directly
     if (strcmp(name, "ggml_backend_get_features") == 0) return (void *)cdna4_get_features;
     if (strcmp(name, "ggml_backend_cdna4_ksplit_buffer_type") == 0) return (void *)cdna4_ksplit_buffer_type;   // the K-split counterpart (no reference equivalent; ggml_cdna4_split.cpp)
     if (strcmp(name, "ggml_backend_split_buffer_type") == 0) return (void *)cdna4_split_buffer_type;      // ggml_backend_split_buffer_type_t, include/ggml-backend.h:188
@@ -680,6 +749,9 @@ static ggml_backend_reg_t ggml_backend_cdna4_reg(void) {
             ctx->devices[i] = ggml_backend_device{ /* .iface = */ cdna4_device_iface, /* .reg = */ &reg, /* .context = */ &ctx->dctx[i] };
             ctx->buft_ctx[i] = cdna4_buft_ctx{i, "CDNA4" + std::to_string(i)};
             ctx->bufts[i] = ggml_backend_buffer_type{ /* .iface = */ cdna4_buft_iface, /* .device = */ &ctx->devices[i], /* .context = */ &ctx->buft_ctx[i] };
+            ctx->res_buft_ctx[i] = cdna4_buft_ctx{i, "CDNA4_Resident" + std::to_string(i), true};
+            ctx->res_bufts[i] = ggml_backend_buffer_type{ /* .iface = */ cdna4_buft_iface, /* .device = */ &ctx->devices[i], /* .context = */ &ctx->res_buft_ctx[i] };
+            ctx->extra[i][0] = &ctx->res_bufts[i]; ctx->extra[i][1] = nullptr;
         }
         g_reg = ctx;
     });

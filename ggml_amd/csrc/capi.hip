@@ -106,6 +106,55 @@ int ggml_cdna4_convert_weights(int type, const void *W, int64_t w_row_bytes, int
     return cdna4_launch_convert_weights(type, (const uint8_t *)W, w_row_bytes, M, K, (uint8_t *)out, (hipStream_t)stream);
 }
 
+// ---- resident kernel-native images (see gemm_q_mfma.hip: cdna4_resident_*)
+size_t ggml_cdna4_resident_image_size(int type, int64_t M, int64_t K) {
+    if (cdna4_convert_weights_target(type) < 0 || M <= 0 || K <= 0 || ggml_cdna4_row_size(type, K) == 0) return 0;
+    return cdna4_convert_weights_bytes(type, M, K) + 256;              // + slack: the kernels read whole 16-byte pieces
+}
+__global__ void k_count_diff16(const u32x4 *__restrict__ a, const u32x4 *__restrict__ b, int64_t n16, unsigned *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const u32x4 x = a[i], y = b[i];
+    if (x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w) atomicAdd(out, 1u);
+}
+int ggml_cdna4_resident_image_register(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, void *image, int verify, void *stream) {
+    const size_t need = ggml_cdna4_resident_image_size(type, M, K);
+    if (need == 0) return cdna4_set_error_msg("resident_image: this type has no kernel-native image");
+    if (!W || !image || w_row_bytes < (int64_t)ggml_cdna4_row_size(type, K) || ((uintptr_t)image & 255)) return cdna4_set_error_msg("resident_image: bad pointers, row stride or image alignment (256 bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = cdna4_launch_convert_weights(type, (const uint8_t *)W, w_row_bytes, M, K, (uint8_t *)image, st);
+    if (rc) return rc;
+    if (verify) {
+        // the re-encoding a second time, into library scratch, compared byte for byte: a conversion that is not bit-stable on this device (round 3 saw ~1 % of an IQ4_XS
+        // product differ between identical calls; its cause was traced to the re-encoding kernel) is refused HERE, at load time
+        const size_t bytes = cdna4_convert_weights_bytes(type, M, K), n16 = bytes / 16;
+        uint8_t *again = (uint8_t *)cdna4_gemm_scratch(bytes + 512, 3);
+        if (!again) return cdna4_set_error_msg("resident_image: cannot allocate the verification scratch");
+        unsigned *cnt = (unsigned *)(again + ((bytes + 255) & ~(size_t)255));
+        hipError_t e = hipMemsetAsync(cnt, 0, 4, st);
+        if (e != hipSuccess) return cdna4_set_error(e, __FILE__, __LINE__);
+        rc = cdna4_launch_convert_weights(type, (const uint8_t *)W, w_row_bytes, M, K, again, st);
+        if (rc) return rc;
+        if (n16) hipLaunchKernelGGL(k_count_diff16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const u32x4 *)image, (const u32x4 *)again, (int64_t)n16, cnt);
+        CDNA4_CHECK_LAUNCH();
+        unsigned bad = 0;
+        e = hipMemcpyAsync(&bad, cnt, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return cdna4_set_error(e, __FILE__, __LINE__);
+        if (bad) { snprintf(g_err, sizeof g_err, "resident_image: two re-encodings of the same matrix differ in %u 16-byte pieces (type %d, %lld x %lld): image not registered", bad, type, (long long)M, (long long)K); return -1; }
+    } else {
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return cdna4_set_error(e, __FILE__, __LINE__);
+    }
+    return cdna4_resident_register(type, W, w_row_bytes, M, K, image);
+}
+int ggml_cdna4_resident_image_unregister(const void *W) { return cdna4_resident_unregister(W); }
+int ggml_cdna4_resident_image_lookup(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, const void **image) {
+    const uint8_t *r = cdna4_resident_lookup(type, W, w_row_bytes, M, K);
+    if (image) *image = r;
+    return r ? 1 : 0;
+}
+
 int ggml_cdna4_quantize_q8_K(const float *x, int64_t x_row_stride, int64_t K, int64_t B, int8_t *qs, float *d, int16_t *bsums, void *xh, void *stream) {
     if (((uintptr_t)x | (uintptr_t)(x_row_stride * 4)) & 15) return cdna4_set_error_msg("quantize_q8_K: x must be 16-byte aligned");
     if (qs && (!d || !bsums)) return cdna4_set_error_msg("quantize_q8_K: qs needs d and bsums");
@@ -229,10 +278,13 @@ static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const floa
         const int tgt = cdna4_convert_weights_target(type);
         // (from 9 rows up: below that the re-encoding pass — ~2.5x the weight bytes — costs more than the staged GEMV it would replace)
         if (tgt >= 0 && tgt != type && B >= 9 && use_mmq(tgt, M, K, B)) {
-            uint8_t *cw = (uint8_t *)cdna4_gemm_scratch(cdna4_convert_weights_bytes(type, M, K) + 256, 3);
-            if (!cw) return cdna4_set_error_msg("mul_mat: cannot allocate the re-encoded weights");
-            const int rc = cdna4_launch_convert_weights(type, (const uint8_t *)W, w_row_bytes, M, K, cw, (hipStream_t)stream);
-            if (rc) return rc;
+            uint8_t *cw = const_cast<uint8_t *>(cdna4_resident_lookup(type, W, w_row_bytes, M, K));      // a resident image (built once at load): no conversion launch
+            if (!cw) {
+                cw = (uint8_t *)cdna4_gemm_scratch(cdna4_convert_weights_bytes(type, M, K) + 256, 3);
+                if (!cw) return cdna4_set_error_msg("mul_mat: cannot allocate the re-encoded weights");
+                const int rc = cdna4_launch_convert_weights(type, (const uint8_t *)W, w_row_bytes, M, K, cw, (hipStream_t)stream);
+                if (rc) return rc;
+            }
             return mul_mat_impl(tgt, cw, (int64_t)ggml_cdna4_row_size(tgt, K), X, x_row_stride, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, epi, stream);
         }
     }

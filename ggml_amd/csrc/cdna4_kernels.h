@@ -105,5 +105,10 @@ int cdna4_convert_weights_target(int type);
 int cdna4_convert_weights_kmul(int type);
 int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes, int64_t M, int64_t K, uint8_t *out, hipStream_t st);
 
+// resident kernel-native images of the re-encoded formats (gemm_q_mfma.hip): registry keyed by the weight pointer
+int cdna4_resident_register(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, const void *image);
+int cdna4_resident_unregister(const void *W);
+const uint8_t *cdna4_resident_lookup(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K);
+
 extern void *cdna4_debug_trace;
 uint64_t cdna4_scratch_generation();            // gemm_q_mfma.hip: bumped whenever the library (re)allocates device scratch

@@ -295,6 +295,49 @@ static int cu_count() {                                            // of the CUR
 }
 
 void *cdna4_gemm_scratch(size_t bytes, int kind) { return get_scratch(bytes, kind); }
+
+// ---- resident kernel-native images (round 5; the kernel-library half of the plug-in's CDNA4_Resident buffer type).  The formats that reach the matrix cores through an
+// exact re-encoding (Q5_0 / IQ4_NL / Q4_1 / Q5_1 -> Q8_0, Q3_K / Q2_K / IQ4_XS -> Q6_K; convert_w.hip) were re-encoded PER CALL into library scratch (VERDICT r4 item 3,
+// ADVICE r3 / r4).  A host that keeps a weight matrix resident can have the image built ONCE (ggml_cdna4_resident_image_register, capi.hip — built twice and compared
+// byte for byte, so a re-encoding that is not bit-stable on this device is refused at load time instead of surfacing as a wrong product) and registers (base, image) here;
+// every prefill route that needs the re-encoding then finds it by the weight pointer — whole matrices and row slices alike — and launches no conversion.  The reference
+// has the same mechanism as a repacking buffer type: src/ggml-cpu/ggml-cpu-aarch64.cpp:4144-4172 (ggml_backend_cpu_aarch64_buffer_set_tensor repacks at load).
+#include <map>
+#include <shared_mutex>
+namespace {
+struct resident_entry { size_t bytes; const uint8_t *image; int type; int64_t M, K, row_bytes, image_row_bytes; };
+std::map<uintptr_t, resident_entry> g_resident;
+std::shared_mutex g_resident_mu;
+std::atomic<int> g_resident_n{0};
+}
+int cdna4_resident_register(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, const void *image) {
+    const size_t ib = cdna4_convert_weights_bytes(type, 1, K);
+    if (!W || !image || M <= 0 || ib == 0 || w_row_bytes <= 0) return cdna4_set_error_msg("resident_image: bad arguments");
+    std::unique_lock<std::shared_mutex> lock(g_resident_mu);
+    g_resident[(uintptr_t)W] = resident_entry{(size_t)(M * w_row_bytes), (const uint8_t *)image, type, M, K, w_row_bytes, (int64_t)ib};
+    g_resident_n.store((int)g_resident.size());
+    return 0;
+}
+int cdna4_resident_unregister(const void *W) {
+    std::unique_lock<std::shared_mutex> lock(g_resident_mu);
+    const size_t n = g_resident.erase((uintptr_t)W);
+    g_resident_n.store((int)g_resident.size());
+    return n ? 0 : -1;
+}
+// the image rows of the M rows that start at W (a registered matrix or a row slice of one), or nullptr
+const uint8_t *cdna4_resident_lookup(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K) {
+    if (g_resident_n.load(std::memory_order_relaxed) == 0) return nullptr;
+    std::shared_lock<std::shared_mutex> lock(g_resident_mu);
+    auto it = g_resident.upper_bound((uintptr_t)W);
+    if (it == g_resident.begin()) return nullptr;
+    --it;
+    const resident_entry &e = it->second;
+    const uintptr_t off = (uintptr_t)W - it->first;
+    if (off >= e.bytes || e.type != type || e.K != K || e.row_bytes != w_row_bytes || off % (uintptr_t)e.row_bytes) return nullptr;
+    const int64_t row0 = (int64_t)(off / (uintptr_t)e.row_bytes);
+    if (row0 + M > e.M) return nullptr;
+    return e.image + row0 * e.image_row_bytes;
+}
 int cdna4_gemm_cu_count() { return cu_count(); }
 // The split-K exchanges that SPIN on a partner work-group (the hand-off of k_gemm_kq_t64 / the 128 x 128-tile kernels, k_gemm_r8's reduce-scatter) are only
 // chosen while every work-group of the grid is resident at once — true when the caller owns the device, not when another process or stream holds CUs
@@ -577,10 +620,14 @@ int cdna4_launch_gemm_q(const cdna4_gemm_args &a, hipStream_t st) {
         uint8_t *cw = (uint8_t *)(uintptr_t)256;                         // (route probe: an aligned stand-in, never dereferenced)
         if (g_probe.active) g_probe.reencoded = 1;
         if (!g_probe.active) {
-            cw = (uint8_t *)get_scratch(cdna4_convert_weights_bytes(a.type, a.M, a.K) + 256, 3);
-            if (!cw) return cdna4_set_error_msg("gemm_q: cannot allocate the weight re-encoding scratch");
-            const int rc = cdna4_launch_convert_weights(a.type, a.W, a.w_row_bytes, a.M, a.K, cw, st);
-            if (rc) return rc;
+            const uint8_t *res = cdna4_resident_lookup(a.type, a.W, a.w_row_bytes, a.M, a.K);      // built once at load (CDNA4_Resident buffers): no conversion launch
+            if (res) cw = const_cast<uint8_t *>(res);
+            else {
+                cw = (uint8_t *)get_scratch(cdna4_convert_weights_bytes(a.type, a.M, a.K) + 256, 3);
+                if (!cw) return cdna4_set_error_msg("gemm_q: cannot allocate the weight re-encoding scratch");
+                const int rc = cdna4_launch_convert_weights(a.type, a.W, a.w_row_bytes, a.M, a.K, cw, st);
+                if (rc) return rc;
+            }
         }
         cdna4_gemm_args c = a; c.W = cw;
         if (cdna4_convert_weights_target(a.type) == CDNA4_Q8_0) {

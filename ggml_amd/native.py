@@ -57,6 +57,10 @@ SYMBOLS = [
     ("ggml_cdna4_convert_weights_target", _int, [_int]),
     ("ggml_cdna4_convert_weights_size", _sz, [_int, _i64, _i64]),
     ("ggml_cdna4_convert_weights", _int, [_int, _vp, _i64, _i64, _i64, _vp, _vp]),
+    ("ggml_cdna4_resident_image_size", _sz, [_int, _i64, _i64]),
+    ("ggml_cdna4_resident_image_register", _int, [_int, _vp, _i64, _i64, _i64, _vp, _int, _vp]),
+    ("ggml_cdna4_resident_image_unregister", _int, [_vp]),
+    ("ggml_cdna4_resident_image_lookup", _int, [_int, _vp, _i64, _i64, _i64, C.POINTER(_vp)]),
 ]
 
 

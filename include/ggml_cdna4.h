@@ -267,6 +267,19 @@ int    ggml_cdna4_convert_weights_target(int type);
 size_t ggml_cdna4_convert_weights_size(int type, int64_t M, int64_t K);
 int    ggml_cdna4_convert_weights(int type, const void * W, int64_t w_row_bytes, int64_t M, int64_t K, void * out, void * stream);
 
+/* Resident kernel-native images (round 5).  ggml_cdna4_mul_mat re-encodes Q5_0 / IQ4_NL / Q4_1 / Q5_1 (-> Q8_0) and Q3_K / Q2_K / IQ4_XS (-> Q6_K; the two-part forms of
+ * Q2_K / Q4_1 / Q5_1 / IQ4_XS included) into library scratch on EVERY prefill call.  A host that keeps a weight matrix resident registers an image instead: built once into
+ * memory the host owns (_size bytes, 256-byte aligned, same device), with verify != 0 built TWICE and compared byte for byte — a re-encoding that is not bit-stable on this
+ * device is refused here, at load time — and from then on every ggml_cdna4_mul_mat / _mul_mat_fused / _mul_mat_prepared call whose W is that matrix (or a row slice of it,
+ * same type, K and row stride) finds the image by the pointer and launches no conversion.  The original bytes stay what they are: decode-sized calls read them as before
+ * (their integer-dot units are the CPU's own arithmetic on the source format), get_tensor needs no inverse.  Synchronous: returns when the image is complete.
+ * What the reference does with a repacking buffer type: src/ggml-cpu/ggml-cpu-aarch64.cpp:4144-4172 (repack at set_tensor), src/ggml-cpu/ggml-cpu.cpp:581-582.
+ * _size: 0 = the type has no image.  _unregister before the weights or the image are freed.  _lookup: 1 and *image if a call with these arguments would use one. */
+size_t ggml_cdna4_resident_image_size(int type, int64_t M, int64_t K);
+int    ggml_cdna4_resident_image_register(int type, const void * W, int64_t w_row_bytes, int64_t M, int64_t K, void * image, int verify, void * stream);
+int    ggml_cdna4_resident_image_unregister(const void * W);
+int    ggml_cdna4_resident_image_lookup(int type, const void * W, int64_t w_row_bytes, int64_t M, int64_t K, const void ** image);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,8 @@
 //   replay   a transformer MLP block (NORM, MUL, ADD, MUL_MAT, ADD, GELU, MUL_MAT, ADD, ADD) computed again and again with changing inputs:
 //            the plug-in replays the unchanged graph from a HIP graph (stderr under GGML_CDNA4_STATS: captures / replays); every result
 //            against the CPU backend, and input A eager == input A replayed, bit for bit
-//   split_harness <plugin.so> <type: q4_K|q4_0|q8_0|q5_K|q6_K|f16> <M> <K> <B>      -> one JSON line
+//   split_harness <plugin.so> <type: q4_K|q4_0|q8_0|q5_K|q6_K|f16> <M> <K> <B> [resident]     -> one JSON line
+//   resident weights in the extra buffer type CDNA4_Resident (kernel-native images of the re-encoded formats, built once): types q5_0 q3_K q2_K q4_1 q5_1 iq4_nl iq4_xs
 #include "ggml.h"
 #include "ggml-alloc.h"
 #include "ggml-backend.h"
@@ -114,6 +115,37 @@ int main(int argc, char ** argv) {
     if (type == GGML_TYPE_F32) memcpy(wq.data(), wf.data(), wq.size());
     else if (type == GGML_TYPE_F16) ggml_fp32_to_fp16_row(wf.data(), (ggml_fp16_t *)wq.data(), (int64_t)M * K);
     else ggml_quantize_chunk(type, wf.data(), wq.data(), 0, M, K, NULL);
+
+    // ---- resident (argv[6] == "resident": only this section): weights in the device's first EXTRA buffer type ("ggml_backend_dev_get_extra_bufts", include/ggml-backend.h:192 —
+    //      the plug-in's CDNA4_Resident: the re-encoded formats keep a kernel-native image built once at set_tensor) against the default buffer type and the CPU backend,
+    //      at the given B (prefill) and at one row (decode reads the original bytes); set / get round trip; a second write of other weights rebuilds the image
+    if (argc > 6 && std::string(argv[6]) == "resident") {
+        typedef ggml_backend_buffer_type_t * (*extra_fn)(ggml_backend_dev_t);
+        extra_fn get_extra = (extra_fn)ggml_backend_reg_get_proc_address(reg, "ggml_backend_dev_get_extra_bufts");
+        if (!get_extra || !get_extra(dev) || !get_extra(dev)[0]) { fprintf(stderr, "no extra buffer types\n"); return 1; }
+        ggml_backend_buffer_type_t rbuft = get_extra(dev)[0];
+        if (!ggml_backend_dev_supports_buft(dev, rbuft) || ggml_backend_buft_is_host(rbuft)) { fprintf(stderr, "extra buffer type rejected\n"); return 1; }
+        std::vector<uint8_t> rw_back;
+        const std::vector<float> y_res = run_mul_mat(gpu, rbuft, type, M, K, B, wq, x, &rw_back);
+        const std::vector<float> y_def = run_mul_mat(gpu, ggml_backend_dev_buffer_type(dev), type, M, K, B, wq, x, NULL);
+        const std::vector<float> y_ref = run_mul_mat(cpu, ggml_backend_get_default_buffer_type(cpu), type, M, K, B, wq, x, NULL);
+        std::vector<float> x1(x.begin(), x.begin() + K);
+        const std::vector<float> y_res1 = run_mul_mat(gpu, rbuft, type, M, K, 1, wq, x1, NULL);
+        const std::vector<float> y_def1 = run_mul_mat(gpu, ggml_backend_dev_buffer_type(dev), type, M, K, 1, wq, x1, NULL);
+        // other weights through the same buffer type: the image must follow the bytes
+        std::vector<float> wf2((size_t)M * K);
+        for (auto & v : wf2) v = u(rng);
+        std::vector<uint8_t> wq2(wq.size());
+        ggml_quantize_chunk(type, wf2.data(), wq2.data(), 0, M, K, NULL);
+        const std::vector<float> y_res2 = run_mul_mat(gpu, rbuft, type, M, K, B, wq2, x, NULL);
+        const std::vector<float> y_def2 = run_mul_mat(gpu, ggml_backend_dev_buffer_type(dev), type, M, K, B, wq2, x, NULL);
+        printf("{\"type\":\"%s\",\"M\":%lld,\"K\":%lld,\"B\":%lld,\"buft\":\"%s\",\"resident_vs_cpu_rel_l2\":%.3e,\"resident_bit_identical_to_default\":%s,\"decode_bit_identical_to_default\":%s,"
+               "\"rewritten_bit_identical_to_default\":%s,\"set_get_roundtrip\":%s}\n", ggml_type_name(type), (long long)M, (long long)K, (long long)B, ggml_backend_buft_name(rbuft), rel_l2(y_res, y_ref),
+               memcmp(y_res.data(), y_def.data(), y_def.size() * 4) == 0 ? "true" : "false", memcmp(y_res1.data(), y_def1.data(), y_def1.size() * 4) == 0 ? "true" : "false",
+               memcmp(y_res2.data(), y_def2.data(), y_def2.size() * 4) == 0 ? "true" : "false", rw_back == wq ? "true" : "false");
+        ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
+        return 0;
+    }
 
     // ---- split
     typedef ggml_backend_buffer_type_t (*split_fn)(int, const float *);

@@ -113,7 +113,9 @@ print(json.dumps(out))
     assert r.returncode == 0, r.stderr[-800:]
     got = {int(k): v for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items()}
     #            rows at 4096^2:  1  2  4  6  16  48  64  96  512 |  C5  4096x14336x64  K=4032x96  16384x8192x512  4096x14336x4
-    assert got[12] == [1, 1, 1, 3, 3, 3, 3, 10, 10, 12, 10, 0, 10, 3]
+    # (round 5: 11 = ONE launch — the activation quantizer and a grid barrier inside k_gemm_kq_t64<.., FQ> — where the grid is resident and the quantizer's share is one
+    #  pass of the work-groups: the headline shape; gemm_q_t64.hip: t64_fuses_quantizer)
+    assert got[12] == [1, 1, 1, 3, 3, 3, 3, 10, 11, 12, 10, 0, 10, 3]
     assert got[13] == [1, 1, 1, 3, 3, 3, 3, 13, 13, 12, 3, 0, 13, 3]
     assert got[14] == [1, 1, 1, 3, 3, 13, 13, 13, 13, 13, 13, 0, 13, 3]
     assert got[2] == [1, 1, 1, 3, 3, 3, 3, 13, 13, 13, 13, 14, 13, 3]
