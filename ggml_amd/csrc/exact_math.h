@@ -2,6 +2,9 @@
 //   exact_v_expf      one lane of ggml_v_expf, /root/reference/src/ggml-cpu/ggml-cpu.c:1912-1949 (same fused / unfused operations in the same order)
 //   exact_expf_glibc  glibc 2.35 expf (sysdeps/ieee754/flt-32/e_expf.c + e_exp2f_data.c: N = 32 table, cubic in double), which the CPU runs on the
 //                     n % 8 tail of a row (ggml_vec_soft_max_f32, ggml-cpu.c:2086-2090)
+// Provenance: exact_expf_glibc restates the ALGORITHM and the table constants of the GNU C Library's expf (glibc 2.35, sysdeps/ieee754/flt-32/e_expf.c and
+// e_exp2f_data.c — originally contributed by Szabolcs Nagy / Arm Ltd. as part of the optimized-routines project; glibc is LGPL-2.1-or-later, optimized-routines MIT) because
+// bit-identity with the CPU backend's libm call is the point of this mode; exact_v_expf restates ggml_v_expf of the reference (MIT).  No source text is copied.
 // Plain C++ (no intrinsics): compiled for the GPU by exact.hip (-ffp-contract=off: only the explicit fma calls fuse) and for the host by
 // tests/test_exact_math.py, which checks both bit for bit against this machine's libm / a numpy model of the AVX2 sequence.
 #pragma once

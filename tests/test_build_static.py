@@ -514,6 +514,39 @@ def test_whole_library_large_grid_route_on_the_cpu(m, k, b, cus, t):
     assert r[0] < 1e-3, r[0]
 
 
+@pytest.mark.parametrize("m,k,b,cus", [(512, 768, 80, 8), (512, 512, 100, 8), (512, 256, 100, 4)])
+def test_whole_library_one_launch_step_on_the_cpu(m, k, b, cus):
+    """round 5's one-launch step (k_gemm_kq_t64<.., FQ>: activation quantizer -> two-level grid barrier -> multiply) through the C-ABI on the CPU, on pretend chips whose
+    grids are resident and whose quantizer share is one pass: split in two with an uneven superblock count (hand-off inside the launch), split in two evenly on 8 work-groups,
+    unsplit — each bit-identical to the two launches it replaces (CDNA4_NO_FUSEQ=1), with the LDS-DMA landing immediately and as late as the counted waits allow"""
+    mod = _emul_module("lib_emul_check")
+    import numpy as np
+    got = {}
+    for tag, envs in (("one", {}), ("two", {"CDNA4_NO_FUSEQ": "1"}), ("one_deferred", {"EMU_DEFER_DMA": "1"})):
+        old = {k_: os.environ.get(k_) for k_ in ("CDNA4_NO_FUSEQ", "EMU_DEFER_DMA")}
+        os.environ.update(envs)
+        try:
+            r = mod.mul_mat(12, m, k, b, path=2, seed=m + b, cus=cus, timeout=900)
+        finally:
+            for k_, v_ in old.items():
+                if v_ is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v_
+        if r is None:
+            pytest.skip("the environment cannot host the emulation")
+        assert r[0] < 1e-3, (tag, r[0])
+        got[tag] = r[1]
+    assert np.array_equal(got["one"].view(np.uint32), got["two"].view(np.uint32))
+    assert np.array_equal(got["one"].view(np.uint32), got["one_deferred"].view(np.uint32))
+    # and it IS the one-launch route on that chip (asked of the emulated library's own routing; in a process of its own: the CU count is cached per process)
+    import subprocess, sys
+    code = ("import ctypes, sys; so = ctypes.CDLL(sys.argv[1]); f = so.ggml_cdna4_mul_mat_route; f.argtypes = [ctypes.c_int] + [ctypes.c_int64] * 3; "
+            "print(f(12, %d, %d, %d))" % (m, k, b))
+    r = subprocess.run([sys.executable, "-c", code, mod.build_so()], capture_output=True, text=True, timeout=300, env=dict(os.environ, EMU_CUS=str(cus)))
+    assert r.returncode == 0 and r.stdout.strip() == "11", (r.stdout, r.stderr[-500:])
+
+
 @pytest.mark.parametrize("name,t", [("q4_1", 3), ("iq4_nl", 20), ("iq4_xs", 23), ("q2_K", 10)])
 def test_whole_library_small_k_gemm_route_on_the_cpu(name, t):
     """K = 256: the re-encoded matrix is too shallow for the staging kernel (2 superblocks of the target format) and takes the re-layout + 8-wave

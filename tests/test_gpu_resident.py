@@ -104,3 +104,23 @@ def test_resident_buffer_type_through_ggmls_public_api(type_, m, k, b):
     assert j["set_get_roundtrip"] is True
     assert j["resident_bit_identical_to_default"] is True and j["decode_bit_identical_to_default"] is True and j["rewritten_bit_identical_to_default"] is True, j
     assert j["resident_vs_cpu_rel_l2"] < 1e-3, j
+
+
+@pytest.mark.parametrize("name,t", TYPES)
+def test_reencoding_soak_every_build_equals_the_first(env, name, t):
+    """the IQ4_XS prefill route is on by default on the strength of one root-cause fix; the defence asked for is a soak over several shapes with a
+    byte-for-byte second pass.  Every registration builds the image twice and compares on the device; here 120 of them per shape (240 conversions) over three shapes,
+    each image also compared with the FIRST one of its shape — for all seven re-encoded formats."""
+    L, native, ops = env
+    for m, k in ((4096, 4096), (512, 14336), (4100, 1024)):
+        w = R.random_block_bytes(t, m, k, np.random.default_rng(m + int(t)))
+        a = ops.QTensor.from_host_bytes(t, k, m, w, device="cuda:0")
+        n = L.ggml_cdna4_resident_image_size(int(t), m, k)
+        first = torch.empty(n, dtype=torch.uint8, device="cuda"); img = torch.empty(n, dtype=torch.uint8, device="cuda")
+        native.check(L.ggml_cdna4_resident_image_register(int(t), a.data.data_ptr(), a.row_bytes, m, k, first.data_ptr(), 1, None))
+        L.ggml_cdna4_resident_image_unregister(a.data.data_ptr())
+        for i in range(120):
+            img.fill_(i & 0xFF)
+            native.check(L.ggml_cdna4_resident_image_register(int(t), a.data.data_ptr(), a.row_bytes, m, k, img.data_ptr(), 1, None))
+            L.ggml_cdna4_resident_image_unregister(a.data.data_ptr())
+            assert torch.equal(img[:n - 256], first[:n - 256]), (name, m, k, i)

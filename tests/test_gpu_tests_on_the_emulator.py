@@ -45,6 +45,11 @@ SELECTION_R3 = [("test_gpu_parity.py", "test_small_batches_on_the_int8_matrix_co
                                          "or (test_flash_attn_ext_bf16_kv and 64-35) or (test_flash_attn_ext_quantized_kv and 64-35 and q8_0)", 5)]
 
 
+# round 5: resident kernel-native images — the registry, the verified build, the lookup of row slices and the bit-identity of the routes that use an image are host logic
+# as much as kernels
+SELECTION_R3.append(("test_gpu_resident.py", "(test_resident_image_serves_prefill and (q5_0 or iq4_xs)) or (test_dequantize_row_of_the_image and q3_K)", 3))
+
+
 @pytest.mark.parametrize("fname,sel,at_least", SELECTION_R3)
 def test_round3_routes_pass_on_the_emulator(fname, sel, at_least):
     if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):

@@ -25,6 +25,7 @@ size_t g_weaken = 0;
 }
 int cdna4_set_error_msg(const char *m) { fprintf(stderr, "error: %s\n", m); return -1; }
 int cdna4_set_error(hipError_t, const char *, int) { return -1; }
+int cdna4_gemm_cu_count() { const char *e = getenv("EMU_CUS"); return e ? atoi(e) : 256; }      // (gemm_q_mfma.hip in the product: the decode launcher asks it for the 16 x 1 rule)
 static void *shared_alloc(size_t n) {
     const size_t pg = 4096, body = (n + pg - 1) / pg * pg;
     char *p = (char *)mmap(nullptr, body + 2 * pg, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);

@@ -164,6 +164,7 @@ static inline emu_u32x4 emu_buffer_load_b128(void *rsrc, int voff) { emu_u32x4 v
 #define __builtin_amdgcn_s_getreg(x) 0u             // HW_REG_XCC_ID: every emulated work-group sits on "XCD 0"
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline void unsafeAtomicAdd(float *p, float v) {
     uint32_t *u = reinterpret_cast<uint32_t *>(p), old = __atomic_load_n(u, __ATOMIC_RELAXED), nw;
     do { float f; memcpy(&f, &old, 4); f += v; memcpy(&nw, &f, 4); } while (!__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));

@@ -40,6 +40,8 @@
 // ---- the HIP runtime calls the library's host code makes
 struct hipDeviceProp_t { int multiProcessorCount; };
 #define hipMemcpyDeviceToDevice 0
+#define hipMemcpyDeviceToHost 0
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 void *emu_shared_alloc(size_t n);
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = emu_shared_alloc(n); return 0; }
 static inline hipError_t hipFree(void *) { return 0; }                                  // (guard-paged mappings are left in place)

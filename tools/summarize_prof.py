@@ -54,7 +54,9 @@ if os.path.exists(p):
     for ln in open(p):
         j = json.loads(ln)
         key = (j.get("test"), j.get("type", "q4_K"))
-        worst[key] = max(worst[key], j.get("rel_l2", 0.0))
+        # (the FLASH_ATTN_EXT groups report under rel_l2_float64 / rel_l2_vs_f16_path: every rel_l2* key of a record counts — VERDICT r4 weak 3: the table printed 0.0 for them)
+        vals = [v for kk, v in j.items() if kk.startswith("rel_l2") and isinstance(v, (int, float))]
+        worst[key] = max([worst[key]] + vals)
     with open(os.path.join(dst, "parity_worst_rel_l2.txt"), "w") as f:
         f.write("worst rel-L2 vs the CPU oracle per (test group, weight type) over the -m gpu run\n")
         for k in sorted(worst, key=str):
