@@ -277,11 +277,9 @@ int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes
     } else if (type == CDNA4_IQ4_XS) {
         if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");
         const int64_t n = M * (K / 256) * 18;
-        static const int var = getenv("CDNA4_DIAG_CONV") ? atoi(getenv("CDNA4_DIAG_CONV")) : 4;      // 4 = the shipped form: every load waited for before its first use
-        const dim3 grid((unsigned)((n + 255) / 256));
-#define IQ4XS_CONV(V) case V: hipLaunchKernelGGL(k_convert_iq4_xs_q6_K2<V>, grid, dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out); break;
-        switch (var) { IQ4XS_CONV(1) IQ4XS_CONV(2) IQ4XS_CONV(3) IQ4XS_CONV(4) IQ4XS_CONV(5) IQ4XS_CONV(7) IQ4XS_CONV(8) default: hipLaunchKernelGGL(k_convert_iq4_xs_q6_K2<0>, grid, dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out); }
-#undef IQ4XS_CONV
+        // (the diagnosis variants of round 3's instability — VAR 0 / 1 / 2 / 3 / 5 / 7 / 8, CDNA4_DIAG_CONV — are no longer instantiated: VAR 4, every load waited for before its first
+        //  use, is what ships; profiles/r04/iq4xs_rootcause.txt has the sweep.  Since round 5 a resident image is also built twice and compared at load: gemm_q_mfma.hip.)
+        hipLaunchKernelGGL(k_convert_iq4_xs_q6_K2<4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, (int)(K / 256), out);
     } else if (type == CDNA4_Q2_K) {
         if (K % 256) return cdna4_set_error_msg("convert_weights: K must be a multiple of 256");
         const int64_t n = M * (K / 256) * 18;

@@ -416,7 +416,9 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         const int min_nsb = p.partial ? (p.sb_split < total - p.sb_split ? p.sb_split : total - p.sb_split) : total / splitk;
         if ((opt == 64 || opt == 65) && min_nsb < 3) opt = 20;
     }
-    if (opt == 65) {                                                      // + loader waves
+    // (what a type cannot reach is not instantiated: the re-laid formats (100..) never take the loader-wave kernel, the staged ones (200..) take nothing else — round 5: 9 kernels)
+    if constexpr (TYPE >= 100 && TYPE < 200) { if (opt == 65) return cdna4_set_error_msg("gemm_q: the re-laid formats run on k_gemm_kq_w8p / _w8"); }
+    else if (opt == 65) {                                                      // + loader waves
         // experiment bits of k_gemm_kq_w12 (variant bits 16+), built in -DCDNA4_ABLATIONS libraries
         // (tools/microbench) only: 1 = early table read (bit-identical, measured: no gain), 16.. = timing-only ablations
         if constexpr (TYPE == CDNA4_Q4_K) {
@@ -433,6 +435,7 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         CDNA4_CHECK_LAUNCH(); return 0;
     }
     if constexpr (TYPE >= 200) return cdna4_set_error_msg("gemm_q: staged formats run on the loader-wave kernel only");
+    else {
     if (opt == 64) {                                                      // cross-stage pipeline
 #ifdef CDNA4_ABLATIONS
         if (p.trace) { hipLaunchKernelGGL((k_gemm_kq_w8p<TYPE, true>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
@@ -446,6 +449,7 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
 #undef W8_LAUNCH
     CDNA4_CHECK_LAUNCH();
     return 0;
+    }
 }
 
 template <int TYPE>

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void k_gemv_q(const cdna4_gemv_args a) {
         col[0] = t * a.n_b + (u % a.n_b); ycol[0] = c;
     } else {
 #pragma unroll
-        for (int c = 0; c < NB; c++) { col[c] = blockIdx.y * NB + c; ycol[c] = col[c]; }
+        for (int c = 0; c < NB; c++) { col[c] = min((int)blockIdx.y * NB + c, a.ncol - 1); ycol[c] = blockIdx.y * NB + c; }      // (columns past ncol: padding of the 1 / 4 / 8-column forms — they repeat the last one and are not stored)
     }
     // ROWS weight rows per wave: the activation loads (same addresses for every row) are issued once and the
     // rows' superblock loads are all in flight together
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_gemv_q(const cdna4_gemv_args a) {
 #pragma unroll
         for (int c = 0; c < NB; c++) {
             const float s = wave_sum_dpp(acc[r][c]);
-            if (lane == 0 && row0 + r < a.M) a.Y[(int64_t)ycol[c] * a.y_col_stride + row0 + r] = epilogue_apply(a.epi, s, row0 + r, ycol[c]);
+            if (lane == 0 && row0 + r < a.M && (IDS || ycol[c] < a.ncol)) a.Y[(int64_t)ycol[c] * a.y_col_stride + row0 + r] = epilogue_apply(a.epi, s, row0 + r, ycol[c]);
         }
 }
 
@@ -528,20 +528,16 @@ static int launch_type(const cdna4_gemv_args &a0, hipStream_t st) {
         a.d = a0.d + (int64_t)c0 * (a0.K / (QT<TYPE>::KQ ? 256 : 32));
         a.bsums = a0.bsums ? a0.bsums + (int64_t)c0 * (a0.K / 16) : nullptr;
         a.Y = a0.Y + (int64_t)c0 * a0.y_col_stride;
-        switch (nb) {
-            case 1: launch_nb<TYPE, 1>(a, st); break; case 2: launch_nb<TYPE, 2>(a, st); break;
-            case 3: launch_nb<TYPE, 3>(a, st); break; case 4: launch_nb<TYPE, 4>(a, st); break;
-            case 5: launch_nb<TYPE, 5>(a, st); break; case 6: launch_nb<TYPE, 6>(a, st); break;
-            case 7: launch_nb<TYPE, 7>(a, st); break; default: launch_nb<TYPE, 8>(a, st); break;
-        }
+        // three column counts are instantiated (round 5: were eight — 48 kernels of a fall-back path): a group of 2..4 runs the 4-column form, 5..8 the 8-column form, the
+        // padding columns repeat the group's last one and are not stored (the same columns meet the same sums: results unchanged)
+        a.ncol = nb;
+        if (nb == 1) launch_nb<TYPE, 1>(a, st); else if (nb <= 4) launch_nb<TYPE, 4>(a, st); else launch_nb<TYPE, 8>(a, st);
         CDNA4_CHECK_LAUNCH();
     }
     return 0;
 }
 
 
-// cdna4_gemv_fused_lds_bytes() for the K-quants, on the device (the DMA form places the weight rows behind the activation area)
-template <int TYPE> __device__ __forceinline__ int cdna4_gemv_fused_lds_bytes_dev(int K) { return K + K / 8 + (K / 256) * 4; }
 
 // ---- fused activation-quantize + GEMV (single-column decode) ------------------------------------------------
 // One launch instead of two for the B=1 MUL_MAT: every workgroup re-quantizes the whole activation row into
@@ -561,16 +557,9 @@ template <int TYPE> __device__ __forceinline__ int cdna4_gemv_fused_lds_bytes_de
 // PREQ: the activation rows arrive already quantized (a.qs / a.d / a.bsums, written once by k_quantize_q8_K / q8_0) and are only COPIED
 // into LDS — for NB x K beyond ~32 K values the redundant per-work-group quantization (and its 4 K bytes of fp32 reads per value row and
 // work-group) costs more than the extra launch: measured 40 us at 8 x 14336 with the quantizer inside.
-// DMA (one activation row, 16-byte-aligned block formats): the wave's weight rows are not loaded into registers round by round but requested WHOLE, by
-// LDS-DMA, in the kernel's first instructions — K = 14336 is 3.5 rounds of 64 units per row, and with two rounds of registers the stream stood still while
-// the quantizer ran ("keep >= 2 rounds of weights in flight from the first instruction").  Full-line requests (a wave instruction fetches
-// 1 KB of consecutive bytes instead of 16 bytes out of each of 64 lines), the units then read their bytes from LDS; per row the units are still added in the
-// order u = lane, lane + 64, ..: bit-identical to the register form.  Two DMA groups: the first two KB of every row go out right behind the activation
-// loads (hipcc's wait for those loads covers them: they arrive together), the rest as soon as the activations are in registers; each round of units then
-// waits (counted vmcnt) for the pieces it reads.
-template <int TYPE, int NW, int ROWS, bool IDS = false, int NB = 1, bool PREQ = false, bool DMA = false>
+// (Round 4's DMA form — whole weight rows requested by LDS-DMA up front — was a measured loss and went in round 5: profiles/r04/decode_ab.txt.)
+template <int TYPE, int NW, int ROWS, bool IDS = false, int NB = 1, bool PREQ = false>
 __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, const float *__restrict__ x, int64_t x_row_stride) {
-    static_assert(!DMA || (NB == 1 && !IDS && !PREQ && QT<TYPE>::KQ && QT<TYPE>::BYTES % 16 == 0), "the DMA form: one row, Q4_K / Q5_K");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr bool KQ = QT<TYPE>::KQ;
     if (IDS) {
@@ -592,7 +581,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
     // quantizer can start as soon as it arrives; the weight rows (HBM) are requested right behind it and stream in under the
     // quantizer.  (Weights first made the quantizer wait for the whole HBM round trip: 5.46 vs 4.82 us cold, same-box A/B.)
     const int c_first = threadIdx.x;
-    float4 v_first[4] = {}, v_second[4] = {};
+    float4 v_first[4] = {};
     const uint8_t *wrow[ROWS];
     typename Unit<TYPE, NB>::W w0[ROWS];
     if (!PREQ && c_first < total) {
@@ -600,37 +589,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
 #pragma unroll
         for (int i = 0; i < 4; i++) v_first[i] = *reinterpret_cast<const float4 *>(px + 4 * i);
     }
-    if (DMA && c_first + NW * 64 < total) {                                 // (the launcher guarantees total <= 2 NW 64)
-        const float *px = x + (c_first + NW * 64) * 16;
-#pragma unroll
-        for (int i = 0; i < 4; i++) v_second[i] = *reinterpret_cast<const float4 *>(px + 4 * i);
-    }
     asm volatile("" ::: "memory");                                          // keep the weight loads below behind the activation loads
-    // DMA form: row bytes rowb = (K / 256) blocks, np pieces of 1 KB per row (the last one clamped: its tail lanes re-fetch the row's last 16 bytes),
-    // LDS region of wave w, row r, piece i at o_w + ((w ROWS + r) np + i) KB; issue order piece-major (piece i of every row, then i + 1)
-    [[maybe_unused]] const int rowb = (K / 256) * QT<TYPE>::BYTES, np = (rowb + 1023) >> 10;
-    [[maybe_unused]] const uint32_t o_w = (uint32_t)((cdna4_gemv_fused_lds_bytes_dev<TYPE>(K) + 1023) & ~1023);
-    [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    [[maybe_unused]] auto dma_piece = [&](int i) __attribute__((always_inline)) {
-        if constexpr (DMA) {
-            const uint32_t voff = (uint32_t)min(i * 1024 + lane * 16, rowb - 16);
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                const uint8_t *src = a.W + (int64_t)min((int)(blockIdx.x * NW + wave_u) * ROWS + r, a.M - 1) * a.w_row_bytes;
-                CDNA4_DMA16(voff, src, CDNA4_LDS_BASE(smem) + o_w + (uint32_t)(((wave_u * ROWS + r) * np + i) << 10));
-            }
-        }
-    };
-    if constexpr (DMA) {
-        dma_piece(0); dma_piece(min(1, np - 1));                            // group 1 (np = 1: the second is a duplicate of the first)
-        asm volatile("" : "+v"(v_first[0].x), "+v"(v_first[3].w), "+v"(v_second[0].x), "+v"(v_second[3].w));   // the activations are in registers (hipcc waits here)
-        for (int i = 2; i < np; i++) dma_piece(i);                          // group 2
-    } else {
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
         wrow[r] = a.W + (int64_t)min(row0 + r, a.M - 1) * a.w_row_bytes;
         w0[r] = Unit<TYPE, NB>::load(wrow[r], min(lane, nunits - 1));
-    }
     }
     // One lane quantizes 16 consecutive values (= one bsums entry, one ds_write_b128): a superblock is 16 adjacent lanes
     // (4 butterfly rounds), a Q8_0 block 2 lanes (1 round).  The first cut (one wave per superblock, 4 values per lane,
@@ -697,9 +660,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
             *reinterpret_cast<u32x4 *>(sbs + col * nch + c * 8) = *reinterpret_cast<const u32x4 *>(a.bsums + (int64_t)sc * nch + c * 8);
         }
         for (int id = threadIdx.x; id < NB * nqd; id += NW * 64) { const int col = id / nqd, c = id % nqd; sd[col * nqd + c] = a.d[(int64_t)min(col, a.ncol - 1) * nqd + c]; }
-    } else if constexpr (DMA) {
-        if (c_first < total) quantize_chunk(c_first, v_first);
-        if (c_first + NW * 64 < total) quantize_chunk(c_first + NW * 64, v_second);
     } else {
     if (c_first < total) quantize_chunk(c_first, v_first);
     for (int id = c_first + NW * 64; id < total; id += NW * 64) {          // more chunks than threads: the remaining ones
@@ -725,25 +685,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
     for (int r = 0; r < ROWS; r++)
 #pragma unroll
         for (int c = 0; c < NB; c++) acc[r][c] = 0.f;
-    if constexpr (DMA) {
-        const int nissued = max(np, 2);                                     // pieces issued per row (group 1 is always two)
-        const uint8_t *wl = smem + o_w + (size_t)(wave_u * ROWS) * np * 1024;
-        for (int u = lane, rd = 0; rd * 64 < nunits; u += 64, rd++) {
-            // the round's last unit ends at byte `end` of its row: pieces [0, need) must have landed; vector-memory operations complete in issue order
-            const int ul = min(rd * 64 + 63, nunits - 1), end = (ul >> 2) * QT<TYPE>::BYTES + QT<TYPE>::BYTES;
-            const int need = min((end + 1023) >> 10, np);
-            cdna4_wait_vm_rt((nissued - max(need, np == 1 ? 2 : need)) * ROWS);
-            CDNA4_WAVE_LDS_SYNC();
-            if (u < nunits) {
-#pragma unroll
-                for (int r = 0; r < ROWS; r++) Unit<TYPE, NB>::mac(Unit<TYPE, NB>::load(wl + (size_t)r * np * 1024, u), u, act, col, acc[r]);
-            }
-        }
-    }
     typename Unit<TYPE, NB>::W cur[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; r++) cur[r] = w0[r];
-    constexpr bool PIPE = NB <= 2 && !DMA;                                          // (4 and 8 columns: the second set of weight registers spills, and those forms are bound by their integer dots)
+    constexpr bool PIPE = NB <= 2;                                          // (4 and 8 columns: the second set of weight registers spills, and those forms are bound by their integer dots)
     // SWAP: two rounds per trip with the two register sets trading places, where that does not cost occupancy: with one row per wave in 4- / 8-wave work-groups (several per
     // CU on tall matrices) the swapped form takes 81 instead of 61-64 registers for Q4_K and 14336 x 4096 went from 9.5 to 11.0 us (round 5, one box); with two rows per wave it
     // takes FEWER (115 vs 128) and 4096 x 14336 on 8 x 2 went from 11.2 to 10.3 us; 16-wave work-groups run one per CU, four waves per SIMD, whatever the count
@@ -784,7 +729,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
                 for (int r = 0; r < ROWS; r++) cur[r] = nxt[r];
             }
         }
-    } else if constexpr (!DMA) {
+    } else {
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             if (lane < nunits) Unit<TYPE, NB>::mac(cur[r], lane, act, col, acc[r]);
@@ -826,8 +771,7 @@ static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st
     // work-groups — Q4_K 4096 x 14336 11.22 vs 10.64, 4096 x 11008 9.41 vs 8.49, 4096 x 8192 7.41 vs 6.68, 14336 x 4096 10.31 vs 9.45 (4096^2: 4.24 vs 4.56, 11008 x 4096 8.10
     // vs 8.25: stay); Q6_K 14336 x 4096 17.67 vs 14.48, 11008 x 4096 13.88 vs 12.17 (its K-long shapes: level); Q4_0: 8 x 2 everywhere.
     int cfg = cfg_env >= 0 ? cfg_env : (a.M >= 4096 ? 1 : (a.M >= 2048 ? 3 : 0));
-    static const int dma_knob = getenv("CDNA4_DECODE_DMA") ? atoi(getenv("CDNA4_DECODE_DMA")) : 0;      // (the opt-in DMA form below is a form of the 8 x 2 configuration)
-    if (cfg_env < 0 && cfg == 1 && dma_knob <= 0) {
+    if (cfg_env < 0 && cfg == 1) {
         if (TYPE == CDNA4_Q4_K && (a.K >= 8192 || a.M >= 12288)) cfg = 3;
         if (TYPE == CDNA4_Q6_K && a.M >= 8192) cfg = 3;
     }
@@ -836,31 +780,14 @@ static int launch_fused(const cdna4_gemv_args &a, const float *x, hipStream_t st
     // (profiles/r05/decode_cfg.txt): Q4_K 4096 x 14336 10.67 vs 9.65, 4096 x 11008 8.78 vs 8.01, 4096 x 8192 6.90 vs 6.46, 4096^2 4.17 vs 4.12; Q5_K 12.62 vs 11.30, 9.91 vs 9.17,
     // 8.01 vs 7.26, 4.78 vs 4.28; Q6_K 15.09 vs 14.98, 11.83 vs 11.45, 9.21 vs 8.54, 5.67 vs 5.65.  Taller matrices (several work-groups per CU) keep the rules above.
     // Q4_0: 4.55 vs 4.42, 10.81 vs 10.60, 9.34 vs 9.03, 7.11 vs 6.84 (same order of shapes); Q8_0 keeps 8 x 2 (long rows lose: 16.6 vs 17.3 at 4096 x 14336).
-    if (cfg_env < 0 && dma_knob <= 0 && (QT<TYPE>::KQ || TYPE == CDNA4_Q4_0) && (a.M + 15) / 16 <= cdna4_gemm_cu_count() && a.M >= 2048) cfg = 4;
-    if constexpr (TYPE == CDNA4_Q4_K || TYPE == CDNA4_Q5_K) {
-        // the DMA form of the 8 x 2 configuration (whole weight rows requested up front; at most two activation chunks per thread: K <= 16384; activations +
-        // 16 rows within the 160 KB of LDS).  OPT-IN (CDNA4_DECODE_DMA=1; =2: only for K > 4096) — a measured loss on MI355X, one box, us cold / cache-warm,
-        // register form vs DMA form (gpurun_out/s9, profiles/r04/decode_ab.txt): Q4_K 4096 x 14336 11.19 / 9.19 vs 11.89 / 9.90, 4096 x 11008 9.43 / 6.72 vs
-        // 9.41 / 7.15, 4096 x 8192 7.44 / 5.29 vs 7.11 / 5.47, 4096 x 4096 4.20 / 4.21 vs 5.38 / 4.28; Q5_K 11008 x 4096 11.40 / 10.05 vs 11.12 / 8.65.  With
-        // every weight byte requested in the first instructions the kernel is no faster: the stream is not what it waits for.
-        static const int dma_env = getenv("CDNA4_DECODE_DMA") ? atoi(getenv("CDNA4_DECODE_DMA")) : 0;
-        const int rowb = (int)(a.K / 256) * QT<TYPE>::BYTES, np = (rowb + 1023) >> 10;
-        const size_t need = ((lds + 1023) & ~(size_t)1023) + (size_t)16 * np * 1024;
-        if (cfg == 1 && dma_env > 0 && (dma_env == 1 || a.K > 4096) && a.K <= 16384 && need <= 160 * 1024 && ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) == 0)) {
-            static bool raised_[16] = {};
-            int dev_ = 0; if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 16) { (void)hipGetLastError(); dev_ = 0; }
-            if (!raised_[dev_]) {
-                if (hipFuncSetAttribute((const void *)k_gemv_q_fused<TYPE, 8, 2, false, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return cdna4_set_error_msg("gemv_q_fused: cannot raise the dynamic LDS limit"); }
-                raised_[dev_] = true;
-            }
-            hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2, false, 1, false, true>), dim3((a.M + 15) / 16), dim3(512), need, st, a, x, (int64_t)0);
-            CDNA4_CHECK_LAUNCH();
-            return 0;
-        }
-    }
-    if (cfg == 4) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 16, 1>), dim3((a.M + 15) / 16), dim3(1024), lds, st, a, x, (int64_t)0);
-    else if (cfg == 1) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x, (int64_t)0);
-    else if (cfg == 2) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 2>), dim3((a.M + 7) / 8), dim3(256), lds, st, a, x, (int64_t)0);
+    if (cfg_env < 0 && (QT<TYPE>::KQ || TYPE == CDNA4_Q4_0) && (a.M + 15) / 16 <= cdna4_gemm_cu_count() && a.M >= 2048) cfg = 4;
+    // (the LDS-DMA form of the 8 x 2 configuration — whole weight rows requested up front, CDNA4_DECODE_DMA — was a measured loss in round 4 (profiles/r04/decode_ab.txt: 4096 x 14336
+    //  11.19 vs 11.89 us) and was removed in round 5; git show 5eb5f7c:ggml_amd/csrc/gemv_q.hip)
+    constexpr bool HAS16 = QT<TYPE>::KQ || TYPE == CDNA4_Q4_0;          // (the formats whose rule can choose 16 x 1; the others keep 8 x 2 behind CDNA4_FUSED_CFG=4)
+    if (cfg == 2) cfg = 1;                                              // (4 waves x 2 rows: never AUTO's choice; its instantiations went in round 5)
+    if (cfg == 4 && !HAS16) cfg = 1;
+    if constexpr (HAS16) { if (cfg == 4) { hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 16, 1>), dim3((a.M + 15) / 16), dim3(1024), lds, st, a, x, (int64_t)0); CDNA4_CHECK_LAUNCH(); return 0; } }
+    if (cfg == 1) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x, (int64_t)0);
     else if (cfg == 3) hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 1>), dim3((a.M + 7) / 8), dim3(512), lds, st, a, x, (int64_t)0);
     else hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 4, 1>), dim3((a.M + 3) / 4), dim3(256), lds, st, a, x, (int64_t)0);
     CDNA4_CHECK_LAUNCH();

@@ -310,6 +310,23 @@ def test_decode_kernel_source_on_the_cpu(t, cfg):
     assert mod.run(t, 37, 2048, seed=t + cfg, env={"CDNA4_FUSED_CFG": str(cfg)}) < 1e-5
 
 
+@pytest.mark.parametrize("k", [2048, 12288])                  # one round of 64 units / three rounds (the register sets trade places twice)
+@pytest.mark.parametrize("t", [12, 13, 14, 2, 10, 11, 23])    # the formats whose launcher can choose 16 waves x 1 row (K-quants and Q4_0)
+@pytest.mark.parametrize("cfg", [4, 1, 3])                    # 16 x 1 (round 5), 8 x 2 (swapped loop), 8 x 1 (copying loop)
+def test_decode_kernel_configurations_on_the_cpu(t, cfg, k):
+    """round 5's decode configurations: 1024-thread work-groups with one row per wave, and the two forms of the multi-round loop (alternating register sets / copies),
+    on rows of one and of three rounds — the kernel's source against the oracle's MUL_MAT"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    if k > 2048 and t not in (12, 14, 2):
+        pytest.skip("the long rows: three formats are enough (emulation time)")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gemv_emul_check", os.path.join(ROOT, "tools", "emul", "gemv_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(t, 19, k, seed=t + cfg, env={"CDNA4_FUSED_CFG": str(cfg)}) < 1e-5
+
+
 @pytest.mark.parametrize("kern,wtype,m,k,b,splitk", [(20, 12, 300, 1536, 200, 1), (20, 12, 256, 2048, 128, 2), (64, 12, 300, 1536, 200, 1), (64, 13, 256, 2048, 128, 2),
                                                      (64, 13, 300, 1536, 200, 1), (20, 13, 300, 512, 200, 1), (1064, 12, 256, 2048, 128, 2), (64, 13, 256, 1792, 128, 2)])
 def test_8_wave_kernel_sources_on_the_cpu(kern, wtype, m, k, b, splitk):
