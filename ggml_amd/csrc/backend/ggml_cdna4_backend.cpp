@@ -22,7 +22,7 @@ struct cdna4_device_ctx { int device; std::string name, description; };
 struct cdna4_buft_ctx   { int device; std::string name; bool resident = false; };
 // resident: the buffer keeps, beside every eligible weight matrix, its kernel-native image (ggml_cdna4_resident_image_*): see the CDNA4_Resident buffer type below
 struct cdna4_resident_tensor { ggml_tensor * tensor; void * image; size_t written; bool registered; };
-struct cdna4_buffer_ctx { int device; void * base; size_t size; bool resident = false; std::vector<cdna4_resident_tensor> res; };
+struct cdna4_buffer_ctx { int device; void * base; size_t size; bool resident = false; std::vector<cdna4_resident_tensor> res; bool host_registered = false; };
 
 static ggml_backend_reg_t ggml_backend_cdna4_reg(void);
 static ggml_backend_buffer_type_t cdna4_buffer_type(int device);
@@ -38,6 +38,7 @@ static void cdna4_buffer_free(ggml_backend_buffer_t buffer) {
         if (r.registered) (void)ggml_cdna4_resident_image_unregister(r.tensor->data);
         if (r.image) HIP_OK(hipFree(r.image));
     }
+    if (ctx->host_registered) { HIP_OK(hipHostUnregister(ctx->base)); delete ctx; return; }      // (buffer_from_host_ptr: the memory is the host's)
     HIP_OK(hipFree(ctx->base));
     delete ctx;
 }
@@ -48,6 +49,7 @@ static void resident_written(cdna4_buffer_ctx * ctx, ggml_tensor * tensor, size_
 static void cdna4_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
     HIP_OK(hipSetDevice(ctx->device));
+    if (ctx->host_registered) { HIP_OK(hipDeviceSynchronize()); memset((char *)tensor->data + offset, value, size); return; }      // (the host's own memory)
     HIP_OK(hipMemset((char *)tensor->data + offset, value, size));
     HIP_OK(hipStreamSynchronize(0));
     resident_written(ctx, tensor, offset, size);
@@ -89,6 +91,7 @@ static void cdna4_resident_init_tensor(ggml_backend_buffer_t buffer, ggml_tensor
 static void cdna4_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
     HIP_OK(hipSetDevice(ctx->device));
+    if (ctx->host_registered) { HIP_OK(hipDeviceSynchronize()); memcpy((char *)tensor->data + offset, data, size); return; }
     HIP_OK(hipMemcpy((char *)tensor->data + offset, data, size, hipMemcpyHostToDevice));
     resident_written(ctx, tensor, offset, size);
 }
@@ -97,6 +100,7 @@ static void cdna4_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_ten
     HIP_OK(hipSetDevice(ctx->device));
     // (no device-wide synchronize: a blocking copy on the null stream is ordered behind everything the backend's stream — a
     //  blocking stream — was given before this call)
+    if (ctx->host_registered) { HIP_OK(hipDeviceSynchronize()); memcpy(data, (const char *)tensor->data + offset, size); return; }
     HIP_OK(hipMemcpy(data, (const char *)tensor->data + offset, size, hipMemcpyDeviceToHost));
 }
 static bool cdna4_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * src, ggml_tensor * dst) {
@@ -105,7 +109,8 @@ static bool cdna4_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_ten
     cdna4_buffer_ctx * dctx = (cdna4_buffer_ctx *)buffer->context;
     HIP_OK(hipSetDevice(sctx->device)); HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipSetDevice(dctx->device));
-    if (sctx->device == dctx->device) HIP_OK(hipMemcpy(dst->data, src->data, ggml_nbytes(src), hipMemcpyDeviceToDevice));
+    if (sctx->host_registered || dctx->host_registered) HIP_OK(hipMemcpy(dst->data, src->data, ggml_nbytes(src), hipMemcpyDefault));
+    else if (sctx->device == dctx->device) HIP_OK(hipMemcpy(dst->data, src->data, ggml_nbytes(src), hipMemcpyDeviceToDevice));
     else HIP_OK(hipMemcpyPeer(dst->data, dctx->device, src->data, sctx->device, ggml_nbytes(src)));
     HIP_OK(hipDeviceSynchronize());
     resident_written(dctx, dst, 0, ggml_nbytes(src));
@@ -114,6 +119,7 @@ static bool cdna4_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_ten
 static void cdna4_buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
     HIP_OK(hipSetDevice(ctx->device));
+    if (ctx->host_registered) { HIP_OK(hipDeviceSynchronize()); memset(ctx->base, value, ctx->size); return; }
     HIP_OK(hipMemset(ctx->base, value, ctx->size));
     HIP_OK(hipDeviceSynchronize());
     for (cdna4_resident_tensor & r : ctx->res) { resident_invalidate(&r); r.written = 0; }       // (the images follow the next whole write)
@@ -598,7 +604,7 @@ static void cdna4_dev_get_props(ggml_backend_dev_t dev, ggml_backend_dev_props *
     props->description = cdna4_dev_get_description(dev);
     props->type = GGML_BACKEND_DEVICE_TYPE_GPU;
     cdna4_dev_get_memory(dev, &props->memory_free, &props->memory_total);
-    props->caps = { /* async */ true, /* host_buffer */ true, /* buffer_from_host_ptr */ false, /* events */ true };
+    props->caps = { /* async */ true, /* host_buffer */ true, /* buffer_from_host_ptr */ true, /* events */ true };
 }
 static ggml_backend_t cdna4_dev_init_backend(ggml_backend_dev_t dev, const char *) {
     cdna4_device_ctx * dctx = (cdna4_device_ctx *)dev->context;
@@ -654,6 +660,20 @@ static ggml_backend_buffer_type_t cdna4_dev_get_host_buffer_type(ggml_backend_de
     if (!host_buft.device) host_buft.device = dev;
     return &host_buft;
 }
+// ---- buffer_from_host_ptr (src/ggml-backend-impl.h:163): a buffer over memory the HOST owns — e.g. the mapping of a model file — registered for device access
+// (hipHostRegister: the kernels read it in place over the host link; no copy, no second footprint).  ggml places tensors in such a buffer by HOST address, so the device
+// must see the range at the same address: where hipHostGetDevicePointer answers otherwise the request is declined (NULL: the caller falls back to a device buffer + copies).
+// Meant for weights that are read rarely or must not be duplicated; prefill over the host link is bound by it (PCIe Gen5 x16: 63 GB/s).
+static ggml_backend_buffer_t cdna4_dev_buffer_from_host_ptr(ggml_backend_dev_t dev, void * ptr, size_t size, size_t /* max_tensor_size */) {
+    const int device = ((cdna4_device_ctx *)dev->context)->device;
+    if (!ptr || size == 0 || hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return NULL; }
+    if (hipHostRegister(ptr, size, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return NULL; }
+    void * dptr = nullptr;
+    if (hipHostGetDevicePointer(&dptr, ptr, 0) != hipSuccess || dptr != ptr) { (void)hipGetLastError(); (void)hipHostUnregister(ptr); return NULL; }
+    cdna4_buffer_ctx * ctx = new cdna4_buffer_ctx{device, ptr, size};
+    ctx->host_registered = true;
+    return ggml_backend_buffer_init(cdna4_buffer_type(device), cdna4_buffer_iface, ctx, size);
+}
 static ggml_backend_event_t cdna4_dev_event_new(ggml_backend_dev_t dev) {
     HIP_OK(hipSetDevice(((cdna4_device_ctx *)dev->context)->device));
     hipEvent_t ev = nullptr;
@@ -672,7 +692,7 @@ static const ggml_backend_device_i cdna4_device_iface = {
     /* .init_backend         = */ cdna4_dev_init_backend,
     /* .get_buffer_type      = */ cdna4_dev_get_buffer_type,
     /* .get_host_buffer_type = */ cdna4_dev_get_host_buffer_type,
-    /* .buffer_from_host_ptr = */ NULL,
+    /* .buffer_from_host_ptr = */ cdna4_dev_buffer_from_host_ptr,
     /* .supports_op          = */ cdna4_dev_supports_op,
     /* .supports_buft        = */ cdna4_dev_supports_buft,
     /* .offload_op           = */ cdna4_dev_offload_op,

@@ -147,6 +147,41 @@ int main(int argc, char ** argv) {
         return 0;
     }
 
+    // ---- hostptr (argv[6] == "hostptr": only this section): ggml_backend_dev_buffer_from_host_ptr (include/ggml-backend.h:170) over page-aligned memory of this process — the
+    //      weight tensor is placed in it by HOST address, filled with a plain memcpy, and multiplied in place by the device; against the default buffer type (bit for bit)
+    if (argc > 6 && std::string(argv[6]) == "hostptr") {
+        ggml_backend_dev_props props; ggml_backend_dev_get_props(dev, &props);
+        const size_t bytes = (wq.size() + 4095) / 4096 * 4096 + 4096;
+        void * host = nullptr;
+        if (posix_memalign(&host, 4096, bytes) != 0) { fprintf(stderr, "posix_memalign failed\n"); return 1; }
+        ggml_backend_buffer_t hbuf = props.caps.buffer_from_host_ptr ? ggml_backend_dev_buffer_from_host_ptr(dev, host, bytes, bytes) : NULL;
+        if (!hbuf) { printf("{\"type\":\"%s\",\"caps_buffer_from_host_ptr\":%s,\"declined\":true}\n", ggml_type_name(type), props.caps.buffer_from_host_ptr ? "true" : "false"); free(host); return 0; }
+        ggml_init_params ip = { ggml_tensor_overhead() * 8 + ggml_graph_overhead(), NULL, true };
+        ggml_context * wctx = ggml_init(ip), * cctx = ggml_init(ip);
+        ggml_tensor * W = ggml_new_tensor_2d(wctx, type, K, M);
+        ggml_tallocr ta = ggml_tallocr_new(hbuf);
+        ggml_tallocr_alloc(&ta, W);
+        const bool in_place = W->data == ggml_backend_buffer_get_base(hbuf) && (char *)W->data >= (char *)host && (char *)W->data < (char *)host + bytes;
+        memcpy(W->data, wq.data(), wq.size());                                    // the host writes its own memory
+        std::vector<uint8_t> back(wq.size()); ggml_backend_tensor_get(W, back.data(), 0, back.size());
+        ggml_tensor * X = ggml_new_tensor_2d(cctx, GGML_TYPE_F32, K, B);
+        ggml_tensor * Y = ggml_mul_mat(cctx, W, X);
+        ggml_cgraph * gf = ggml_new_graph(cctx);
+        ggml_build_forward_expand(gf, Y);
+        ggml_gallocr_t ga = ggml_gallocr_new(ggml_backend_get_default_buffer_type(gpu));
+        if (!ggml_gallocr_alloc_graph(ga, gf)) { fprintf(stderr, "graph allocation failed\n"); return 1; }
+        ggml_backend_tensor_set(X, x.data(), 0, x.size() * sizeof(float));
+        if (ggml_backend_graph_compute(gpu, gf) != GGML_STATUS_SUCCESS) { fprintf(stderr, "graph_compute failed\n"); return 1; }
+        std::vector<float> y_host((size_t)M * B);
+        ggml_backend_tensor_get(Y, y_host.data(), 0, y_host.size() * sizeof(float));
+        const std::vector<float> y_def = run_mul_mat(gpu, ggml_backend_dev_buffer_type(dev), type, M, K, B, wq, x, NULL);
+        printf("{\"type\":\"%s\",\"M\":%lld,\"K\":%lld,\"B\":%lld,\"caps_buffer_from_host_ptr\":true,\"declined\":false,\"tensor_in_host_range\":%s,\"get_roundtrip\":%s,\"bit_identical_to_default\":%s}\n",
+               ggml_type_name(type), (long long)M, (long long)K, (long long)B, in_place ? "true" : "false", back == wq ? "true" : "false", memcmp(y_host.data(), y_def.data(), y_def.size() * 4) == 0 ? "true" : "false");
+        ggml_gallocr_free(ga); ggml_backend_buffer_free(hbuf); ggml_free(wctx); ggml_free(cctx); free(host);
+        ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
+        return 0;
+    }
+
     // ---- split
     typedef ggml_backend_buffer_type_t (*split_fn)(int, const float *);
     split_fn get_split = (split_fn)ggml_backend_reg_get_proc_address(reg, "ggml_backend_split_buffer_type");

@@ -124,3 +124,21 @@ def test_reencoding_soak_every_build_equals_the_first(env, name, t):
             native.check(L.ggml_cdna4_resident_image_register(int(t), a.data.data_ptr(), a.row_bytes, m, k, img.data_ptr(), 1, None))
             L.ggml_cdna4_resident_image_unregister(a.data.data_ptr())
             assert torch.equal(img[:n - 256], first[:n - 256]), (name, m, k, i)
+
+
+@pytest.mark.parametrize("type_,m,k,b", [("q4_K", 512, 1024, 96), ("q4_K", 1024, 4096, 1), ("q8_0", 300, 256, 33)])
+def test_buffer_from_host_ptr_through_ggmls_public_api(type_, m, k, b):
+    """ggml_backend_dev_buffer_from_host_ptr (src/ggml-backend-impl.h:163; NULL in the plug-in until round 5, like the reference's CUDA backend): a weight placed by host address
+    in registered host memory, filled with a plain memcpy, multiplied in place — bit for bit the default buffer type's result.  A device that cannot see the range at the
+    host's address declines (NULL) and the harness reports it: then only the report is checked."""
+    if not os.path.exists(EXE):
+        pytest.fail("prebuilt oracle/_ref/split_harness missing from the snapshot")
+    r = subprocess.run([EXE, PLUGIN, type_, str(m), str(k), str(b), "hostptr"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    with open(os.path.join(R.ROOT, "gpurun_out", "split_report.jsonl"), "a") as f:
+        f.write(json.dumps(j) + "\n")
+    assert j["caps_buffer_from_host_ptr"] is True
+    if j["declined"]:
+        pytest.skip("the device does not map registered host memory at the host's address: buffer_from_host_ptr declines (the caller keeps device buffers)")
+    assert j["tensor_in_host_range"] is True and j["get_roundtrip"] is True and j["bit_identical_to_default"] is True, j
