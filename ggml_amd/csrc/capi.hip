@@ -108,8 +108,9 @@ int ggml_cdna4_convert_weights(int type, const void *W, int64_t w_row_bytes, int
 
 // ---- resident kernel-native images (see gemm_q_mfma.hip: cdna4_resident_*)
 size_t ggml_cdna4_resident_image_size(int type, int64_t M, int64_t K) {
-    if (cdna4_convert_weights_target(type) < 0 || M <= 0 || K <= 0 || ggml_cdna4_row_size(type, K) == 0) return 0;
-    return cdna4_convert_weights_bytes(type, M, K) + 256;              // + slack: the kernels read whole 16-byte pieces
+    if (M <= 0 || K <= 0 || ggml_cdna4_row_size(type, K) == 0) return 0;
+    const size_t rb = cdna4_resident_image_row_bytes(type, K);
+    return rb ? (size_t)M * rb + 256 : 0;                              // + slack: the kernels read whole 16-byte pieces
 }
 __global__ void k_count_diff16(const u32x4 *__restrict__ a, const u32x4 *__restrict__ b, int64_t n16, unsigned *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -122,18 +123,18 @@ int ggml_cdna4_resident_image_register(int type, const void *W, int64_t w_row_by
     if (need == 0) return cdna4_set_error_msg("resident_image: this type has no kernel-native image");
     if (!W || !image || w_row_bytes < (int64_t)ggml_cdna4_row_size(type, K) || ((uintptr_t)image & 255)) return cdna4_set_error_msg("resident_image: bad pointers, row stride or image alignment (256 bytes)");
     hipStream_t st = (hipStream_t)stream;
-    int rc = cdna4_launch_convert_weights(type, (const uint8_t *)W, w_row_bytes, M, K, (uint8_t *)image, st);
+    int rc = cdna4_resident_build(type, (const uint8_t *)W, w_row_bytes, M, K, (uint8_t *)image, st);
     if (rc) return rc;
     if (verify) {
         // the re-encoding a second time, into library scratch, compared byte for byte: a conversion that is not bit-stable on this device (round 3 saw ~1 % of an IQ4_XS
         // product differ between identical calls; its cause was traced to the re-encoding kernel) is refused HERE, at load time
-        const size_t bytes = cdna4_convert_weights_bytes(type, M, K), n16 = bytes / 16;
+        const size_t bytes = (size_t)M * cdna4_resident_image_row_bytes(type, K), n16 = bytes / 16;
         uint8_t *again = (uint8_t *)cdna4_gemm_scratch(bytes + 512, 3);
         if (!again) return cdna4_set_error_msg("resident_image: cannot allocate the verification scratch");
         unsigned *cnt = (unsigned *)(again + ((bytes + 255) & ~(size_t)255));
         hipError_t e = hipMemsetAsync(cnt, 0, 4, st);
         if (e != hipSuccess) return cdna4_set_error(e, __FILE__, __LINE__);
-        rc = cdna4_launch_convert_weights(type, (const uint8_t *)W, w_row_bytes, M, K, again, st);
+        rc = cdna4_resident_build(type, (const uint8_t *)W, w_row_bytes, M, K, again, st);
         if (rc) return rc;
         if (n16) hipLaunchKernelGGL(k_count_diff16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const u32x4 *)image, (const u32x4 *)again, (int64_t)n16, cnt);
         CDNA4_CHECK_LAUNCH();
@@ -349,7 +350,16 @@ int ggml_cdna4_mul_mat_fused_residual_may_alias(int type, int64_t M, int64_t K, 
 // the route ggml_cdna4_mul_mat(path = AUTO) takes for a contiguous, 256-byte-aligned call of this shape on the current device — host logic only, no launch, no scratch:
 //   1 one launch (activation quantizer inside the GEMV)     2 quantize + GEMV (columns staged in LDS)     3 quantize + int8 matrix-core kernel
 //   10 quantize + k_gemm_kq_t64     11 ONE launch: the quantizer inside k_gemm_kq_t64 (resident grids on an owned device)     12 + k_gemm_r8     13 + a 128 x 128-tile kernel     14 + an older per-lane-load GEMM;   + 100: behind an exact re-encoding of the weights
+static int route_of(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, int64_t B);
 int ggml_cdna4_mul_mat_route(int type, int64_t M, int64_t K, int64_t B) {
+    return route_of(type, (const void *)(uintptr_t)256, (int64_t)ggml_cdna4_row_size(type, K), M, K, B);
+}
+// the same for a concrete weight matrix: sees its alignment, its row stride and a RESIDENT image registered for it (Q4_0 with an image: 10 / 12 instead of 13)
+int ggml_cdna4_mul_mat_route_of(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, int64_t B) {
+    if (!W || w_row_bytes < (int64_t)ggml_cdna4_row_size(type, K)) return 0;
+    return route_of(type, W, w_row_bytes, M, K, B);
+}
+static int route_of(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, int64_t B) {
     if (!is_q(type) || M <= 0 || B <= 0 || K <= 0 || ggml_cdna4_row_size(type, K) == 0) return 0;
     if (cdna4_convert_weights_kmul(type) == 1) {
         const int tgt = cdna4_convert_weights_target(type);
@@ -361,7 +371,7 @@ int ggml_cdna4_mul_mat_route(int type, int64_t M, int64_t K, int64_t B) {
         const int64_t nbt = B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8));
         return (cdna4_gemv_fused_supported(type, K, B) && (B == 1 || nbt * K <= 32768)) ? 1 : 2;
     }
-    cdna4_gemm_args ra = gemm_args_of(type, (const void *)(uintptr_t)256, (int64_t)ggml_cdna4_row_size(type, K), (const void *)(uintptr_t)256, (float *)(uintptr_t)256, M, M, K, B, 0, 0, cdna4_epilogue{});
+    cdna4_gemm_args ra = gemm_args_of(type, W, w_row_bytes, (const void *)(uintptr_t)256, (float *)(uintptr_t)256, M, M, K, B, 0, 0, cdna4_epilogue{});
     ra.xf = (const float *)(uintptr_t)256; ra.xf_row_elems = K;       // (the call hands its fp32 rows over: the one-launch step is a candidate)
     return cdna4_gemm_q_route(ra);
 }

@@ -656,11 +656,9 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
     if (fa_takes_wide(N, H, B3)) {                                 // prefill that fills the chip: 128 query rows per work-group, K / V staged through LDS
         NEED(kvt == CDNA4_F16, "flash_attn_ext: the 128-row kernels take an F16 K / V");
         const dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B3);
-        static const bool chunks32 = getenv("CDNA4_FA_WIDE32") != nullptr;      // A/B knob: the 32-key-chunk kernel for every head size
-        if (D == 64 && !chunks32) hipLaunchKernelGGL(k_flash_attn_wide64<64>, grid, dim3(256), 0, st, p);
-        else if (D == 128 && !chunks32) hipLaunchKernelGGL(k_flash_attn_wide64<128>, grid, dim3(256), 0, st, p);
-        else if (D == 64) hipLaunchKernelGGL(k_flash_attn_wide<64>, grid, dim3(256), 0, st, p);
-        else if (D == 128) hipLaunchKernelGGL(k_flash_attn_wide<128>, grid, dim3(256), 0, st, p);
+        // (head sizes 64 / 128: 64-key chunks; 256: the 32-key-chunk kernel — its forms for the smaller heads were an A/B knob of round 3 and went in round 5)
+        if (D == 64) hipLaunchKernelGGL(k_flash_attn_wide64<64>, grid, dim3(256), 0, st, p);
+        else if (D == 128) hipLaunchKernelGGL(k_flash_attn_wide64<128>, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(k_flash_attn_wide<256>, grid, dim3(256), 0, st, p);
         CDNA4_CHECK_LAUNCH();
         return 0;

@@ -8,7 +8,7 @@
 
 // (form 2, k_gemm_r8, also takes Q5_K)
 static bool lds_supported_t(const cdna4_gemm_args &a, bool five_ok) {
-    if (a.type != CDNA4_Q4_K && !(five_ok && a.type == CDNA4_Q5_K)) return false;
+    if (a.type != CDNA4_Q4_K && !(five_ok && (a.type == CDNA4_Q5_K || a.type == CDNA4_Q4_0R))) return false;
     if (a.M <= 0 || a.B <= 0 || a.K % 256 || a.K < 256) return false;
     if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) || ((uintptr_t)a.xh & 15)) return false;
     return true;
@@ -73,7 +73,8 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
 #endif
     if (form == 2) {
         const bool tail = a.epi.bias || a.epi.act || a.epi.resid;
-        if (a.type == CDNA4_Q5_K) { if (tail) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q5_K, 0, true>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q5_K>), grid, dim3(512), 0, st, p); }
+        if (a.type == CDNA4_Q4_0R) { if (tail) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_0R, 0, true>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_0R>), grid, dim3(512), 0, st, p); }
+        else if (a.type == CDNA4_Q5_K) { if (tail) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q5_K, 0, true>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q5_K>), grid, dim3(512), 0, st, p); }
         else if (tail) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K, 0, true>), grid, dim3(512), 0, st, p);
         else hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K>), grid, dim3(512), 0, st, p);
         CDNA4_CHECK_LAUNCH();

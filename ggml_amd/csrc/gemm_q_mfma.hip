@@ -310,8 +310,25 @@ std::map<uintptr_t, resident_entry> g_resident;
 std::shared_mutex g_resident_mu;
 std::atomic<int> g_resident_n{0};
 }
+// bytes of one image row: the exact re-encodings of convert_w.hip, and — Q4_0 — the 16-byte-aligned re-layout Q4_0R (eight fp16 scales + 128 bytes of nibbles in Q4_K's order per
+// 256 weights: the SAME 144 bytes the source blocks take), which k_gemm_kq_t64 / k_gemm_r8 consume through LDS-DMA like Q4_K (0: no image for this type / K)
+size_t cdna4_resident_image_row_bytes(int type, int64_t K) {
+    if (type == CDNA4_Q4_0) return (K > 0 && K % 256 == 0) ? (size_t)(K / 256) * 144 : 0;
+    return K > 0 ? cdna4_convert_weights_bytes(type, 1, K) : 0;
+}
+// builds the image rows of M rows of W (re-encoding or re-layout) on `st`
+int cdna4_resident_build(int type, const uint8_t *W, int64_t w_row_bytes, int64_t M, int64_t K, uint8_t *out, hipStream_t st) {
+    if (type == CDNA4_Q4_0) {
+        if (K % 256 || M <= 0) return cdna4_set_error_msg("resident_image: Q4_0 rows must be whole 256-weight groups");
+        const int nsb = (int)(K / 256);
+        hipLaunchKernelGGL(k_repack_q4_0, dim3((unsigned)((M * nsb * 9 + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, nsb, out);
+        CDNA4_CHECK_LAUNCH();
+        return 0;
+    }
+    return cdna4_launch_convert_weights(type, W, w_row_bytes, M, K, out, st);
+}
 int cdna4_resident_register(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, const void *image) {
-    const size_t ib = cdna4_convert_weights_bytes(type, 1, K);
+    const size_t ib = cdna4_resident_image_row_bytes(type, K);
     if (!W || !image || M <= 0 || ib == 0 || w_row_bytes <= 0) return cdna4_set_error_msg("resident_image: bad arguments");
     std::unique_lock<std::shared_mutex> lock(g_resident_mu);
     g_resident[(uintptr_t)W] = resident_entry{(size_t)(M * w_row_bytes), (const uint8_t *)image, type, M, K, w_row_bytes, (int64_t)ib};
@@ -501,6 +518,19 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
         if (wlds && a.variant <= 0 && a.splitk <= 0 && cdna4_gemm_r8_preferred(a)) { ROUTE_END_K(true, 12); return cdna4_launch_gemm_lds(a, 256, 1, st, 2); }
     }
     if (splitk < 1 || (kunits % splitk && !uneven)) return cdna4_set_error_msg("gemm_q: splitk must divide the number of K units");
+    if constexpr (TYPE == CDNA4_Q4_0) {
+        // round 5: a RESIDENT Q4_0R image of this matrix (cdna4_resident_*: built once by the host / the CDNA4_Resident buffer type) puts Q4_0 on Q4_K's own kernels —
+        // k_gemm_r8 where its tiles fill the chip, k_gemm_kq_t64 otherwise (256-row tiles, ticketed / deep splits, the tail in the store) — instead of the staging kernel
+        if (a.variant <= 0 && a.splitk <= 2 && a.K % 256 == 0) {
+            const uint8_t *img = cdna4_resident_lookup(CDNA4_Q4_0, a.W, a.w_row_bytes, a.M, a.K);
+            if (img && !((uintptr_t)img & 15)) {
+                cdna4_gemm_args r = a; r.type = CDNA4_Q4_0R; r.W = img; r.w_row_bytes = (int64_t)(a.K / 256) * 144; r.xf = nullptr;
+                if (a.splitk <= 0 && cdna4_gemm_r8_preferred(r)) { ROUTE_END_K(true, 12); return cdna4_launch_gemm_lds(r, 256, 1, st, 2); }
+                ROUTE_END_K(true, 10);
+                return cdna4_launch_gemm_t64(r, 0, a.splitk, st);
+            }
+        }
+    }
     if constexpr (TYPE == CDNA4_Q4_0 || TYPE == CDNA4_Q8_0 || TYPE == CDNA4_Q6_K) {
         // 2-byte-aligned formats at prefill batch sizes: re-lay the weights into 16-byte-aligned superblocks (scratch, per
         // call: one extra read+write of W, ~5 us at 4096x4096) and run the LDS-DMA pipeline on that — 2.5-3x faster

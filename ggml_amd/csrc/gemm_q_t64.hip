@@ -13,7 +13,7 @@
 //  * 32-bit byte offsets reach the whole image.    CDNA4_NO_FUSEQ=1 turns it off (A/B, and the two-launch reference of the parity tests).
 static bool t64_fuses_quantizer(const cdna4_gemm_args &a, int nblk) {
     static const bool off = getenv("CDNA4_NO_FUSEQ") && atoi(getenv("CDNA4_NO_FUSEQ")) != 0;
-    if (off || !a.xf || cdna4_gemm_shared_device()) return false;
+    if (off || !a.xf || cdna4_gemm_shared_device() || a.type != CDNA4_Q4_K) return false;      // (Q4_0R meets Q8_0 activations: another quantizer)
     if ((((uintptr_t)a.xf) | (uintptr_t)(a.xf_row_elems * 4)) & 15) return false;
     if ((int64_t)a.B * a.K * 2 + 32768 >= ((int64_t)1 << 31) || (int64_t)a.B * (a.K / 256) >= ((int64_t)1 << 30)) return false;
     const int cus = cdna4_gemm_cu_count();
@@ -85,6 +85,15 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     if (abl) return cdna4_set_error_msg("gemm_t64: ablation not instantiated");
 #endif
     const bool tail = p.epi.bias != nullptr || p.epi.act != 0 || p.epi.resid != nullptr;
+    if (a.type == CDNA4_Q4_0R) {                                         // (a resident Q4_0R image: the same kernels, the {d, 0} sub-block constants)
+        if (tail) {
+            if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_0R, 128, false, 0, true>), grid, dim3(512), 0, st, p);
+            else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_0R, 256, false, 0, true>), grid, dim3(512), 0, st, p);
+        } else if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_0R, 128>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_0R, 256>), grid, dim3(512), 0, st, p);
+        CDNA4_CHECK_LAUNCH();
+        return 0;
+    }
     if (fq) {                                                            // (128-row tiles only: t64_make_plan)
         if (tail) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, false, 0, true, true>), grid, dim3(512), 0, st, p);
         else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, false, 0, false, true>), grid, dim3(512), 0, st, p);
@@ -98,7 +107,7 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
 }
 
 static int t64_make_plan(const cdna4_gemm_args &a, int tm, int splitk, t64_plan &pl) {
-    if (a.type != CDNA4_Q4_K) return cdna4_set_error_msg("gemm_t64: Q4_K only");
+    if (a.type != CDNA4_Q4_K && a.type != CDNA4_Q4_0R) return cdna4_set_error_msg("gemm_t64: Q4_K (or Q4_0 as its resident Q4_0R image) only");
     if (a.K % 256 || a.K < 256) return cdna4_set_error_msg("gemm_t64: K must be a whole number of superblocks");
     if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) || ((uintptr_t)a.xh & 15)) return cdna4_set_error_msg("gemm_t64: weight rows and the activation image must be 16-byte aligned");
     const int cus = cdna4_gemm_cu_count(), nsb = a.K / 256;

@@ -15,6 +15,7 @@ SYMBOLS = [
     ("ggml_cdna4_device_count", _int, []),
     ("ggml_cdna4_set_shared_device", _int, [_int]),
     ("ggml_cdna4_mul_mat_route", _int, [_int, _i64, _i64, _i64]),
+    ("ggml_cdna4_mul_mat_route_of", _int, [_int, _vp, _i64, _i64, _i64, _i64]),
     ("ggml_cdna4_set_device", _int, [_int]),
     ("ggml_cdna4_debug_trace", None, [_vp]),
     ("ggml_cdna4_scratch_generation", C.c_uint64, []),

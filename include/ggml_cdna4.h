@@ -70,6 +70,8 @@ int          ggml_cdna4_set_shared_device(int shared);
  *   + 100: behind an exact re-encoding of the weights (ggml_cdna4_convert_weights);  0: not a supported call.
  * For hosts that want to know what a shape costs before they choose a batch size, and for the tests that pin the route table (profiles/r04/batch_sweep.txt). */
 int          ggml_cdna4_mul_mat_route(int type, int64_t M, int64_t K, int64_t B);
+/* the same for a concrete weight matrix: sees its alignment, row stride and a resident image registered for it (Q4_0 with an image: 10 / 12 instead of 13) */
+int          ggml_cdna4_mul_mat_route_of(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, int64_t B);
 int          ggml_cdna4_set_device(int device);
 /* profiling hook (tools/microbench/gemm_bench only): a 64 KiB device buffer makes the 8-wave GEMM record per-phase
  * s_memtime stamps of its first work-group; NULL (default) selects the uninstrumented kernel */

@@ -9,7 +9,7 @@
 //            the plug-in replays the unchanged graph from a HIP graph (stderr under GGML_CDNA4_STATS: captures / replays); every result
 //            against the CPU backend, and input A eager == input A replayed, bit for bit
 //   split_harness <plugin.so> <type: q4_K|q4_0|q8_0|q5_K|q6_K|f16> <M> <K> <B> [resident]     -> one JSON line
-//   resident weights in the extra buffer type CDNA4_Resident (kernel-native images of the re-encoded formats, built once): types q5_0 q3_K q2_K q4_1 q5_1 iq4_nl iq4_xs
+//   resident weights in the extra buffer type CDNA4_Resident (kernel-native images of the re-encoded formats, built once): types q5_0 q3_K q2_K q4_1 q5_1 iq4_nl iq4_xs, and q4_0 (a 16-byte-aligned re-layout for Q4_K's kernels)
 #include "ggml.h"
 #include "ggml-alloc.h"
 #include "ggml-backend.h"
@@ -140,9 +140,9 @@ int main(int argc, char ** argv) {
         const std::vector<float> y_res2 = run_mul_mat(gpu, rbuft, type, M, K, B, wq2, x, NULL);
         const std::vector<float> y_def2 = run_mul_mat(gpu, ggml_backend_dev_buffer_type(dev), type, M, K, B, wq2, x, NULL);
         printf("{\"type\":\"%s\",\"M\":%lld,\"K\":%lld,\"B\":%lld,\"buft\":\"%s\",\"resident_vs_cpu_rel_l2\":%.3e,\"resident_bit_identical_to_default\":%s,\"decode_bit_identical_to_default\":%s,"
-               "\"rewritten_bit_identical_to_default\":%s,\"set_get_roundtrip\":%s}\n", ggml_type_name(type), (long long)M, (long long)K, (long long)B, ggml_backend_buft_name(rbuft), rel_l2(y_res, y_ref),
+               "\"rewritten_bit_identical_to_default\":%s,\"set_get_roundtrip\":%s,\"resident_vs_default_rel_l2\":%.3e,\"rewritten_vs_default_rel_l2\":%.3e}\n", ggml_type_name(type), (long long)M, (long long)K, (long long)B, ggml_backend_buft_name(rbuft), rel_l2(y_res, y_ref),
                memcmp(y_res.data(), y_def.data(), y_def.size() * 4) == 0 ? "true" : "false", memcmp(y_res1.data(), y_def1.data(), y_def1.size() * 4) == 0 ? "true" : "false",
-               memcmp(y_res2.data(), y_def2.data(), y_def2.size() * 4) == 0 ? "true" : "false", rw_back == wq ? "true" : "false");
+               memcmp(y_res2.data(), y_def2.data(), y_def2.size() * 4) == 0 ? "true" : "false", rw_back == wq ? "true" : "false", rel_l2(y_res, y_def), rel_l2(y_res2, y_def2));
         ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
         return 0;
     }

@@ -87,8 +87,9 @@ def test_64x128_wave_tile_kernel_resources(tmp_path):
     # the plain product (TAIL = false; the tail-carrying twin shares the main loop) and — round 5 — the one-launch step that carries the activation quantizer and the
     # grid barrier in its prologue (FQ = true): the loop must be the same loop, in particular without a scratch access in it (a spill there would also break the
     # kernel's counted vmcnt waits, which assume that LDS-DMA is the only vector-memory traffic of the loop)
-    for tm, fq, max_scratch in ((128, 0, 0), (256, 0, 128), (128, 1, 0)):
-        k = "_Z13k_gemm_kq_t64ILi12ELi%dELb0ELi0ELb0ELb%dEEv11gemm_params" % (tm, fq)
+    # (type 102 = Q4_0R, round 5: Q4_0 through its resident 16-byte-aligned image — the same loop with a two-instruction constant step)
+    for ty, tm, fq, max_scratch in ((12, 128, 0, 0), (12, 256, 0, 128), (12, 128, 1, 0), (102, 128, 0, 0), (102, 256, 0, 128)):
+        k = "_Z13k_gemm_kq_t64ILi%dELi%dELb0ELi0ELb0ELb%dEEv11gemm_params" % (ty, tm, fq)
         assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= 256
         assert _prop(asm, k, "private_seg_size") <= max_scratch
         assert _lds(asm, k) <= 160 * 1024

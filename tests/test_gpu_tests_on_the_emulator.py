@@ -48,16 +48,20 @@ SELECTION_R3 = [("test_gpu_parity.py", "test_small_batches_on_the_int8_matrix_co
 # round 5: resident kernel-native images — the registry, the verified build, the lookup of row slices and the bit-identity of the routes that use an image are host logic
 # as much as kernels
 SELECTION_R3.append(("test_gpu_resident.py", "(test_resident_image_serves_prefill and (q5_0 or iq4_xs)) or (test_dequantize_row_of_the_image and q3_K)", 3))
+# Q4_0 on Q4_K's kernels through a resident Q4_0R image: k_gemm_kq_t64 128-row tiles (and the tail in its store); with EMU_CUS=4 the routes a 256-CU part takes at full size —
+# k_gemm_r8 (whole rounds of 256 x 256 tiles) and k_gemm_kq_t64's 256-row tiles
+SELECTION_R3.append(("test_gpu_resident.py", "(test_q4_0_resident_image_puts and (512-1024-96 or 300-768)) or (test_q4_0_resident_image_carries and 768-512)", 4))
+SELECTION_R3.append(("test_gpu_resident.py", "test_q4_0_resident_image_puts and (1024-512-256 or 1280-512-200)", 2, {"EMU_CUS": "4"}))
 
 
-@pytest.mark.parametrize("fname,sel,at_least", SELECTION_R3)
-def test_round3_routes_pass_on_the_emulator(fname, sel, at_least):
+@pytest.mark.parametrize("fname,sel,at_least,extra_env", [s if len(s) == 4 else s + ({},) for s in SELECTION_R3])
+def test_round3_routes_pass_on_the_emulator(fname, sel, at_least, extra_env):
     if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
         pytest.skip("ROCm clang not available")
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: the -m gpu tests run on it, the emulation is refused (tests/emul_torch.py)")
-    env = dict(os.environ, CDNA4_TESTS_ON_EMULATOR="1")
+    env = dict(os.environ, CDNA4_TESTS_ON_EMULATOR="1", **extra_env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", fname), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", sel],
                        capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     tail = (r.stdout + r.stderr)[-3000:]
