@@ -11,6 +11,7 @@
 #include "ggml_cdna4_internal.h"
 #include "ggml_cdna4_ops.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -211,6 +212,30 @@ static bool supports_mul_mat_id(const ggml_tensor * op) {
     return true;
 }
 
+// ---- hand-off of quantized activations between MUL_MATs of the same src1 (wq / wk / wv, w_gate / w_up).  The kernel library leaves the image of a
+// call's activations in the workspace and says which (ggml_cdna4_act_image_key); the graph walk knows whether src1 and the workspace are untouched since.  The second
+// product is then ggml_cdna4_mul_mat_prepared[_fused]: the same kernel on the same image (bit-identical), one launch fewer.  GGML_CDNA4_NO_ACT_SHARE=1: off.
+static std::atomic<int> g_act_shared{0};
+extern "C" int ggml_backend_cdna4_act_shared_count(void) { return g_act_shared.load(); }
+static bool act_share_on() { static const bool off = getenv("GGML_CDNA4_NO_ACT_SHARE") != nullptr; return !off && !cdna4_exact_mode(); }
+// does the workspace hold the image a MUL_MAT of (type, M, K, B) over X would build?
+static bool act_image_ready(const cdna4_backend_ctx * ctx, ggml_type type, int64_t M, int64_t K, int64_t B, const void * X, int64_t x_stride, size_t need) {
+    const auto & im = ctx->act_image;
+    if (!act_share_on() || !im.key || im.uses != ctx->ws_uses || im.x != X || im.x_stride != x_stride || im.K != K || im.B != B || need > ctx->ws_size) return false;
+    return ggml_cdna4_act_image_key((int)type, M, K, B) == im.key;
+}
+// a ggml_cdna4_mul_mat[_fused] call of (type, M, K, B) over X has just been issued on the workspace
+static void act_image_note(cdna4_backend_ctx * ctx, ggml_type type, int64_t M, int64_t K, int64_t B, const void * X, int64_t x_stride) {
+    auto & im = ctx->act_image;
+    im.key = act_share_on() ? ggml_cdna4_act_image_key((int)type, M, K, B) : 0;
+    im.x = X; im.x_stride = x_stride; im.K = K; im.B = B; im.x_bytes = (size_t)((B - 1) * x_stride + K) * sizeof(float); im.uses = ctx->ws_uses;
+}
+// a node has written [p, p + n): activations that overlap it are no longer the ones the image was made of
+static void act_image_written(cdna4_backend_ctx * ctx, const void * p, size_t n) {
+    auto & im = ctx->act_image;
+    if (im.key && (const char *)p < (const char *)im.x + im.x_bytes && (const char *)im.x < (const char *)p + n) im.key = 0;
+}
+
 static enum ggml_status compute_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst) {
     const ggml_tensor * a = dst->src[0], * b = dst->src[1];
     if (a->buffer && cdna4_buft_is_split(a->buffer->buft)) return cdna4_split_mul_mat(ctx, dst);
@@ -223,6 +248,13 @@ static enum ggml_status compute_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * d
     const int64_t nbatch = collapse ? 1 : b->ne[2] * b->ne[3];
     const int64_t Bc = collapse ? N * b->ne[2] * b->ne[3] : N;
     const size_t need = exact ? ggml_cdna4_mul_mat_exact_workspace_size((int)a->type, K, Bc) : ggml_cdna4_mul_mat_workspace_size((int)a->type, K, Bc);
+    if (nbatch == 1 && !exact && act_image_ready(ctx, a->type, M, K, Bc, b->data, (int64_t)(b->nb[1] / sizeof(float)), need)) {
+        // the previous MUL_MAT quantized these very activations into the workspace: multiply them (the image stays valid for the next reader)
+        if (ggml_cdna4_mul_mat_prepared((int)a->type, a->data, (int64_t)a->nb[1], (float *)dst->data, (int64_t)(dst->nb[1] / sizeof(float)), M, K, Bc, ctx->ws, ctx->ws_size,
+                                        GGML_CDNA4_PATH_AUTO, 0, 0, ctx->stream)) { fprintf(stderr, "ggml-cdna4: MUL_MAT failed: %s\n", ggml_cdna4_last_error()); return GGML_STATUS_FAILED; }
+        ctx->n_act_shared++; g_act_shared++;
+        return GGML_STATUS_SUCCESS;
+    }
     void * ws = ctx->need_ws(need);
     if (!ws) return GGML_STATUS_ALLOC_FAILED;
     for (int64_t ib = 0; ib < nbatch; ib++) {
@@ -236,6 +268,7 @@ static enum ggml_status compute_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * d
                                                   M, K, Bc, ws, ctx->ws_size, GGML_CDNA4_PATH_AUTO, 0, 0, ctx->stream);
         if (rc) { fprintf(stderr, "ggml-cdna4: MUL_MAT failed: %s\n", ggml_cdna4_last_error()); return GGML_STATUS_FAILED; }
     }
+    if (nbatch == 1 && !exact) act_image_note(ctx, a->type, M, K, Bc, b->data, (int64_t)(b->nb[1] / sizeof(float)));
     return GGML_STATUS_SUCCESS;
 }
 
@@ -264,6 +297,7 @@ static void cdna4_backend_free(ggml_backend_t backend) {
     (void)hipStreamSynchronize(ctx->stream);
     cdna4_split_free_lanes(ctx);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "ggml-cdna4: %s: %d HIP-graph captures, %d replays\n", ctx->name.c_str(), ctx->n_graph_captures, ctx->n_graph_launches);
+    if (getenv("GGML_CDNA4_STATS") && ctx->n_act_shared) fprintf(stderr, "ggml-cdna4: %s: %d MUL_MATs multiplied the previous one's quantized activations\n", ctx->name.c_str(), ctx->n_act_shared);
     if (getenv("GGML_CDNA4_STATS") && (ctx->n_ksplit_rccl || ctx->n_ksplit_sum)) fprintf(stderr, "ggml-cdna4: %s: K-split MUL_MAT: %d RCCL all-reduces, %d in-order sums\n", ctx->name.c_str(), ctx->n_ksplit_rccl, ctx->n_ksplit_sum);
     for (auto & gs : ctx->graph_slots) if (gs.exec) (void)hipGraphExecDestroy(gs.exec);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
@@ -345,8 +379,18 @@ static int try_fused_mul_mat(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, co
     // an aliased residual must be the SAME view (same row stride): the kernel library refuses any other overlap, and a refusal here would fail a graph
     // whose nodes run fine one by one
     if (resid && resid->data == last->data && resid->nb[1] != last->nb[1]) return 0;
-    void * ws = ctx->need_ws(ggml_cdna4_mul_mat_workspace_size((int)a->type, K, B));
+    const size_t need = ggml_cdna4_mul_mat_workspace_size((int)a->type, K, B);
+    if (act_image_ready(ctx, a->type, M, K, B, b->data, (int64_t)(b->nb[1] / sizeof(float)), need)) {         // (compute_mul_mat: the hand-off of quantized activations)
+        if (ggml_cdna4_mul_mat_prepared_fused((int)a->type, a->data, (int64_t)a->nb[1], (float *)last->data, (int64_t)(last->nb[1] / sizeof(float)), M, K, B, (const float *)bias->data, act,
+                                              resid ? (const float *)resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / sizeof(float)) : 0, ctx->ws, ctx->ws_size, ctx->stream)) {
+            fprintf(stderr, "ggml-cdna4: fused MUL_MAT failed: %s\n", ggml_cdna4_last_error()); st = GGML_STATUS_FAILED;
+        }
+        ctx->n_act_shared++; g_act_shared++;
+        return used;
+    }
+    void * ws = ctx->need_ws(need);
     if (!ws) { st = GGML_STATUS_ALLOC_FAILED; return used; }
+    act_image_note(ctx, a->type, M, K, B, b->data, (int64_t)(b->nb[1] / sizeof(float)));
     const int rc = ggml_cdna4_mul_mat_fused((int)a->type, a->data, (int64_t)a->nb[1], (const float *)b->data, (int64_t)(b->nb[1] / sizeof(float)),
                                             (float *)last->data, (int64_t)(last->nb[1] / sizeof(float)), M, K, B, (const float *)bias->data, act,
                                             resid ? (const float *)resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / sizeof(float)) : 0, ws, ctx->ws_size, ctx->stream);
@@ -428,6 +472,7 @@ static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph)
     static const bool no_fuse = getenv("GGML_CDNA4_NO_FUSE") != nullptr || cdna4_exact_mode();      // (exact mode runs node by node: its kernels have no fused forms)
     const bool fuse = !no_fuse && n_nodes > 1;
     const use_counts uses = fuse ? use_counts(cgraph) : use_counts(nullptr, 0);
+    ctx->act_image.key = 0;                                              // (activations of an earlier graph: the host may have rewritten them since)
     for (int i = 0; i < n_nodes; i++) {
         ggml_tensor * node = ggml_graph_node(cgraph, i);
         if (ggml_is_empty(node)) continue;
@@ -438,7 +483,11 @@ static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph)
             else if (node->op == GGML_OP_NORM || node->op == GGML_OP_RMS_NORM) used = try_fused_norm(ctx, cgraph, i, uses, st);
             else if (node->op == GGML_OP_SCALE) used = try_fused_soft_max(ctx, cgraph, i, uses, st);
             if (st != GGML_STATUS_SUCCESS) return st;
-            if (used) { i += used - 1; continue; }
+            if (used) {
+                ggml_tensor * last = ggml_graph_node(cgraph, i + used - 1);     // (a chain writes its last node only)
+                act_image_written(ctx, last->data, ggml_nbytes(last));
+                i += used - 1; continue;
+            }
         }
         switch (node->op) {
             case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE: break;
@@ -450,6 +499,8 @@ static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph)
             fprintf(stderr, "ggml-cdna4: op %s (%s) failed\n", ggml_op_name(node->op), node->name);
             return st;
         }
+        if (node->op != GGML_OP_NONE && node->op != GGML_OP_RESHAPE && node->op != GGML_OP_VIEW && node->op != GGML_OP_PERMUTE && node->op != GGML_OP_TRANSPOSE)
+            act_image_written(ctx, node->data, ggml_nbytes(node));
     }
     return GGML_STATUS_SUCCESS;
 }
@@ -739,6 +790,7 @@ static void * cdna4_reg_get_proc_address(ggml_backend_reg_t, const char * name) 
     if (strcmp(name, "ggml_backend_dev_get_extra_bufts") == 0) return (void *)cdna4_dev_get_extra_bufts;
     if (strcmp(name, "ggml_backend_cdna4_resident_buffer_type") == 0) return (void *)cdna4_resident_buffer_type;     // (int device) -> the buffer type directly
     if (strcmp(name, "ggml_backend_get_features") == 0) return (void *)cdna4_get_features;
+    if (strcmp(name, "ggml_backend_cdna4_act_shared_count") == 0) return (void *)ggml_backend_cdna4_act_shared_count;   // MUL_MATs that reused the previous one's quantized activations (statistics)
     if (strcmp(name, "ggml_backend_cdna4_ksplit_buffer_type") == 0) return (void *)cdna4_ksplit_buffer_type;   // the K-split counterpart (no reference equivalent; ggml_cdna4_split.cpp)
     if (strcmp(name, "ggml_backend_split_buffer_type") == 0) return (void *)cdna4_split_buffer_type;      // ggml_backend_split_buffer_type_t, include/ggml-backend.h:188
     if (strcmp(name, "ggml_backend_cdna4_split_ranges") == 0) return (void *)ggml_backend_cdna4_split_ranges;   // the partition of either split, as pure arithmetic (ggml_cdna4_split.cpp)

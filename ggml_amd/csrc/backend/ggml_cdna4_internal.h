@@ -45,7 +45,13 @@ struct cdna4_backend_ctx {
     bool graphs_off = false;                                  // a capture failed once: stay on plain launches
     int n_graph_launches = 0, n_graph_captures = 0;           // (statistics, printed at free under GGML_CDNA4_STATS)
     int n_ksplit_rccl = 0, n_ksplit_sum = 0;                  // K-split MUL_MATs reduced by an RCCL all-reduce / by the in-order sum
+    // the quantized activations the workspace holds (ggml_cdna4_act_image_key; ggml_cdna4_backend.cpp: act_image_*): the next MUL_MAT of the same src1 multiplies them
+    // without quantizing again.  `uses` = ws_uses when they were written: any later hand-out of the workspace (another op's scratch, a growth) ends their life
+    uint64_t ws_uses = 0;
+    struct { const void * x = nullptr; int64_t x_stride = 0, K = 0, B = 0; size_t x_bytes = 0; uint32_t key = 0; uint64_t uses = 0; } act_image;
+    int n_act_shared = 0;                                     // MUL_MATs that took the hand-off (statistics; "ggml_backend_cdna4_act_shared_count")
     void * need_ws(size_t n) {
+        ws_uses++;
         if (n <= ws_size) return ws;
         HIP_OK(hipStreamSynchronize(stream));
         ws_gen++;                                             // a captured graph holds the old workspace address

@@ -375,9 +375,9 @@ static int route_of(int type, const void *W, int64_t w_row_bytes, int64_t M, int
     ra.xf = (const float *)(uintptr_t)256; ra.xf_row_elems = K;       // (the call hands its fp32 rows over: the one-launch step is a candidate)
     return cdna4_gemm_q_route(ra);
 }
-int ggml_cdna4_mul_mat_fused(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
-                             int64_t M, int64_t K, int64_t B, const float *bias, int act, const float *residual, int64_t residual_row_stride,
-                             void *workspace, size_t workspace_bytes, void *stream) {
+// the checks ggml_cdna4_mul_mat_fused and its pre-quantized twin share: 0, or the error status
+static int fused_tail_ok(int type, const void *W, int64_t w_row_bytes, float *Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B, int act,
+                         const float *residual, int64_t residual_row_stride, const void *workspace) {
     if (act != 0 && act != 1) return cdna4_set_error_msg("mul_mat_fused: act is 0 (none) or 1 (GELU)");
     if (residual && M > 0 && B > 0) {
         const char *r0 = (const char *)residual, *r1 = (const char *)(residual + (B - 1) * residual_row_stride + M);
@@ -389,8 +389,42 @@ int ggml_cdna4_mul_mat_fused(int type, const void *W, int64_t w_row_bytes, const
         if (overlap && !ok)
             return cdna4_set_error_msg("mul_mat_fused: residual overlaps Y (only an exact alias is allowed, and only where ggml_cdna4_mul_mat_fused_residual_may_alias says so)");
     }
+    return 0;
+}
+int ggml_cdna4_mul_mat_fused(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
+                             int64_t M, int64_t K, int64_t B, const float *bias, int act, const float *residual, int64_t residual_row_stride,
+                             void *workspace, size_t workspace_bytes, void *stream) {
+    if (const int rc = fused_tail_ok(type, W, w_row_bytes, Y, y_row_stride, M, K, B, act, residual, residual_row_stride, workspace)) return rc;
     cdna4_epilogue e{}; e.bias = bias; e.resid = residual; e.resid_row_stride = residual_row_stride; e.act = act;
     return mul_mat_impl(type, W, w_row_bytes, X, x_row_stride, Y, y_row_stride, M, K, B, workspace, workspace_bytes, GGML_CDNA4_PATH_AUTO, 0, 0, e, stream);
+}
+// ---- the graph-level hand-off of quantized activations (round 5).  A transformer layer multiplies the SAME activations by several weight matrices
+// (wq / wk / wv; w_gate / w_up): the CPU backend quantizes src1 once per MUL_MAT node (ggml-cpu.c:7490-7509) and so did every ggml_cdna4_mul_mat call.  A host that knows
+// the activations have not changed since the previous call on this workspace asks for the key of the image each call leaves there; equal non-zero keys (and equal X, row
+// stride, K, B) mean the second call can be ggml_cdna4_mul_mat_prepared[_fused] with path AUTO — the same kernels on the same image, bit-identical, one launch fewer.
+//   0: the call leaves no reusable image (one-launch decode / few-row forms quantize inside the kernel; re-encoded formats on the int8 matrix cores use their target's image)
+uint32_t ggml_cdna4_act_image_key(int type, int64_t M, int64_t K, int64_t B) {
+    if (!is_q(type) || M <= 0 || B <= 0 || K <= 0 || ggml_cdna4_row_size(type, K) == 0) return 0;
+    if (cdna4_convert_weights_kmul(type) == 1) {
+        const int tgt = cdna4_convert_weights_target(type);
+        if (tgt >= 0 && tgt != type && B >= 9 && use_mmq(tgt, M, K, B)) return 0;
+    }
+    const bool mmq = use_mmq(type, M, K, B);
+    const int path = resolve_path(type, GGML_CDNA4_PATH_AUTO, M, K, B);
+    if (path != GGML_CDNA4_PATH_GEMM && !mmq) return 0;                 // (the GEMV forms below the matrix-core kernels: one launch, or their own staged variant)
+    return 1u | (is_kq(type) ? 2u : 0u) | (cdna4_is_q81(type) ? 4u : 0u) | (cdna4_convert_weights_kmul(type) == 2 ? 8u : 0u) | (path == GGML_CDNA4_PATH_GEMM ? 16u : 0u);
+}
+// ggml_cdna4_mul_mat_fused on the image the previous call left in `workspace` (ggml_cdna4_act_image_key)
+int ggml_cdna4_mul_mat_prepared_fused(int type, const void *W, int64_t w_row_bytes, float *Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,
+                                      const float *bias, int act, const float *residual, int64_t residual_row_stride,
+                                      const void *workspace, size_t workspace_bytes, void *stream) {
+    if (const int rc = fused_tail_ok(type, W, w_row_bytes, Y, y_row_stride, M, K, B, act, residual, residual_row_stride, workspace)) return rc;
+    if (!ggml_cdna4_act_image_key(type, M, K, B)) return cdna4_set_error_msg("mul_mat_prepared_fused: a call of this shape has no prepared form (ggml_cdna4_act_image_key == 0)");
+    cdna4_epilogue e{}; e.bias = bias; e.resid = residual; e.resid_row_stride = residual_row_stride; e.act = act;
+    bool tail_done = false;
+    const int rc = mul_mat_prepared_impl(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, GGML_CDNA4_PATH_AUTO, 0, 0, e, &tail_done, stream);
+    if (rc || tail_done) return rc;
+    return cdna4_launch_epilogue(Y, y_row_stride, M, B, e, (hipStream_t)stream);
 }
 
 int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t w_expert_bytes, const float *b, int64_t b_row_stride, int64_t b_tok_stride,

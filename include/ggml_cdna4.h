@@ -153,6 +153,16 @@ int ggml_cdna4_mul_mat_fused(int type, const void * W, int64_t w_row_bytes, cons
  * for an overlap it cannot honour; partial overlaps are always an error. */
 int ggml_cdna4_mul_mat_fused_residual_may_alias(int type, int64_t M, int64_t K, int64_t B);
 
+/* Hand-off of quantized activations between MUL_MATs that read the SAME src1 (wq / wk / wv, w_gate / w_up): the CPU backend quantizes src1 once per node
+ * (src/ggml-cpu/ggml-cpu.c:7490-7509), and so does every ggml_cdna4_mul_mat call.  ggml_cdna4_act_image_key says which image a call of this shape leaves in its
+ * workspace (0: none that can be reused).  If the previous call on the SAME workspace had the same non-zero key, X, x_row_stride, K and B, and neither X nor the
+ * workspace has been written since, the next product may be ggml_cdna4_mul_mat_prepared(path = GGML_CDNA4_PATH_AUTO) or its fused twin below: the same kernel on
+ * the same image — bit-identical to ggml_cdna4_mul_mat[_fused], one launch fewer.  The plug-in's graph walk does exactly this (GGML_CDNA4_NO_ACT_SHARE=1: off). */
+uint32_t ggml_cdna4_act_image_key(int type, int64_t M, int64_t K, int64_t B);
+int ggml_cdna4_mul_mat_prepared_fused(int type, const void * W, int64_t w_row_bytes, float * Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,
+                                      const float * bias, int act, const float * residual, int64_t residual_row_stride,
+                                      const void * workspace, size_t workspace_bytes, void * stream);
+
 /* Activation quantizers (bit-exact with the reference); outputs may be NULL to skip them.
  *   qs  int8  [B][K]      d  f32 [B][K/256 | K/32]      bsums int16 [B][K/16] (Q8_K only)
  *   xh  fp16  B*K halves = fp16(d*q) in the MFMA path's private layout: element (b,k) at ((k/128)*B + b)*128 + k%128

@@ -8,7 +8,8 @@
 //   replay   a transformer MLP block (NORM, MUL, ADD, MUL_MAT, ADD, GELU, MUL_MAT, ADD, ADD) computed again and again with changing inputs:
 //            the plug-in replays the unchanged graph from a HIP graph (stderr under GGML_CDNA4_STATS: captures / replays); every result
 //            against the CPU backend, and input A eager == input A replayed, bit for bit
-//   split_harness <plugin.so> <type: q4_K|q4_0|q8_0|q5_K|q6_K|f16> <M> <K> <B> [resident]     -> one JSON line
+//   split_harness <plugin.so> <type: q4_K|q4_0|q8_0|q5_K|q6_K|f16> <M> <K> <B> [resident | hostptr | shared]     -> one JSON line
+//   shared   MUL_MATs that read the same src1 (wq / wk / wv; w_gate / w_up) take ONE activation quantization: hand-off count, output bytes' hash, time per graph
 //   resident weights in the extra buffer type CDNA4_Resident (kernel-native images of the re-encoded formats, built once): types q5_0 q3_K q2_K q4_1 q5_1 iq4_nl iq4_xs, and q4_0 (a 16-byte-aligned re-layout for Q4_K's kernels)
 #include "ggml.h"
 #include "ggml-alloc.h"
@@ -143,6 +144,82 @@ int main(int argc, char ** argv) {
                "\"rewritten_bit_identical_to_default\":%s,\"set_get_roundtrip\":%s,\"resident_vs_default_rel_l2\":%.3e,\"rewritten_vs_default_rel_l2\":%.3e}\n", ggml_type_name(type), (long long)M, (long long)K, (long long)B, ggml_backend_buft_name(rbuft), rel_l2(y_res, y_ref),
                memcmp(y_res.data(), y_def.data(), y_def.size() * 4) == 0 ? "true" : "false", memcmp(y_res1.data(), y_def1.data(), y_def1.size() * 4) == 0 ? "true" : "false",
                memcmp(y_res2.data(), y_def2.data(), y_def2.size() * 4) == 0 ? "true" : "false", rw_back == wq ? "true" : "false", rel_l2(y_res, y_def), rel_l2(y_res2, y_def2));
+        ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
+        return 0;
+    }
+
+    // ---- shared (argv[6] == "shared": only this section; M = model width D, K = FFN width H): an attention + FFN front like every llama layer's —
+    //      cur = rms_norm(X) * g;  Q = Wq cur, Kk = Wk cur (D / 4 rows: grouped-query), V = Wv cur + bv;  f = rms_norm(Q + X) * g;  out = Wd (silu(Wg f) * (Wu f)) —
+    //      three MUL_MATs read `cur` and two read `f`: the plug-in quantizes each of them ONCE (the CPU backend: once per node, ggml-cpu.c:7490-7509).  Reports the hand-offs
+    //      the first graph_compute took (proc address ggml_backend_cdna4_act_shared_count), FNV-1a of every output's bytes (the test runs it again under
+    //      GGML_CDNA4_NO_ACT_SHARE=1: same bytes), each output against the CPU backend, and the time per graph (HIP-graph replay).
+    if (argc > 6 && std::string(argv[6]) == "shared") {
+        const int64_t D = M, H = K;
+        auto build = [&](ggml_backend_t be, std::vector<std::vector<float>> & outs, double * us_per_graph, int * shared) {
+            ggml_init_params ip = { ggml_tensor_overhead() * 64 + ggml_graph_overhead(), NULL, true };
+            ggml_context * wctx = ggml_init(ip), * cctx = ggml_init(ip);
+            ggml_tensor * Wq = ggml_new_tensor_2d(wctx, type, D, D), * Wk = ggml_new_tensor_2d(wctx, type, D, D / 4), * Wv = ggml_new_tensor_2d(wctx, type, D, D / 4);
+            ggml_tensor * Wg = ggml_new_tensor_2d(wctx, type, D, H), * Wu = ggml_new_tensor_2d(wctx, type, D, H), * Wd = ggml_new_tensor_2d(wctx, type, H, D);
+            ggml_tensor * g = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, D), * bv = ggml_new_tensor_1d(wctx, GGML_TYPE_F32, D / 4);
+            ggml_backend_buffer_t wbuf = ggml_backend_alloc_ctx_tensors(wctx, be);
+            std::mt19937 r2(99);
+            std::uniform_real_distribution<float> uu(-1.f, 1.f);
+            for (ggml_tensor * W : { Wq, Wk, Wv, Wg, Wu, Wd }) {
+                std::vector<float> f((size_t)ggml_nelements(W));
+                const float sc = 2.0f / std::sqrt((float)W->ne[0]);
+                for (auto & v : f) v = uu(r2) * sc;
+                std::vector<uint8_t> q(ggml_nbytes(W));
+                ggml_quantize_chunk(type, f.data(), q.data(), 0, W->ne[1], W->ne[0], NULL);
+                ggml_backend_tensor_set(W, q.data(), 0, q.size());
+            }
+            std::vector<float> gv(D), bvv(D / 4);
+            for (auto & v : gv) v = 1.f + 0.1f * uu(r2);
+            for (auto & v : bvv) v = uu(r2);
+            ggml_backend_tensor_set(g, gv.data(), 0, D * 4); ggml_backend_tensor_set(bv, bvv.data(), 0, D);
+            ggml_tensor * X = ggml_new_tensor_2d(cctx, GGML_TYPE_F32, D, B);
+            ggml_set_input(X);
+            ggml_tensor * cur = ggml_mul(cctx, ggml_rms_norm(cctx, X, 1e-5f), g);
+            ggml_tensor * Q = ggml_mul_mat(cctx, Wq, cur), * Kk = ggml_mul_mat(cctx, Wk, cur), * V = ggml_add(cctx, ggml_mul_mat(cctx, Wv, cur), bv);
+            ggml_tensor * f = ggml_mul(cctx, ggml_rms_norm(cctx, ggml_add(cctx, Q, X), 1e-5f), g);
+            ggml_tensor * gate = ggml_mul_mat(cctx, Wg, f), * up = ggml_mul_mat(cctx, Wu, f);
+            ggml_tensor * out = ggml_mul_mat(cctx, Wd, ggml_mul(cctx, ggml_silu(cctx, gate), up));
+            ggml_set_output(Kk); ggml_set_output(V); ggml_set_output(out);
+            ggml_cgraph * gf = ggml_new_graph(cctx);
+            ggml_build_forward_expand(gf, Kk); ggml_build_forward_expand(gf, V); ggml_build_forward_expand(gf, out);
+            ggml_gallocr_t ga = ggml_gallocr_new(ggml_backend_get_default_buffer_type(be));
+            if (!ggml_gallocr_alloc_graph(ga, gf)) { fprintf(stderr, "graph allocation failed\n"); exit(1); }
+            std::vector<float> xin(x.begin(), x.begin() + (size_t)D * B);
+            typedef int (*count_fn)(void);
+            count_fn cnt = be == gpu ? (count_fn)ggml_backend_reg_get_proc_address(reg, "ggml_backend_cdna4_act_shared_count") : nullptr;
+            const int c0 = cnt ? cnt() : 0;
+            ggml_backend_tensor_set(X, xin.data(), 0, xin.size() * 4);
+            if (ggml_backend_graph_compute(be, gf) != GGML_STATUS_SUCCESS) { fprintf(stderr, "graph_compute failed\n"); exit(1); }
+            ggml_backend_synchronize(be);
+            if (shared) *shared = cnt ? cnt() - c0 : -1;
+            // (the outputs of the FIRST compute: the graph allocator may hand X's memory to a later node once X's last reader has run, so a second compute of the same
+            //  graph without a new tensor_set starts from other activations — the timing loop below does exactly that, on purpose)
+            outs.clear();
+            for (ggml_tensor * t : { Kk, V, out }) { std::vector<float> y((size_t)ggml_nelements(t)); ggml_backend_tensor_get(t, y.data(), 0, y.size() * 4); outs.push_back(y); }
+            if (us_per_graph) {
+                for (int i = 0; i < 5; i++) ggml_backend_graph_compute(be, gf);          // (second appearance: captured; then replays)
+                ggml_backend_synchronize(be);
+                const int64_t t0 = ggml_time_us();
+                const int n = 50;
+                for (int i = 0; i < n; i++) ggml_backend_graph_compute(be, gf);
+                ggml_backend_synchronize(be);
+                *us_per_graph = (double)(ggml_time_us() - t0) / n;
+            }
+            ggml_gallocr_free(ga); ggml_backend_buffer_free(wbuf); ggml_free(wctx); ggml_free(cctx);
+        };
+        ggml_time_init();
+        std::vector<std::vector<float>> y_gpu, y_cpu;
+        double us = 0; int shared = 0;
+        build(gpu, y_gpu, &us, &shared);
+        if (getenv("HARNESS_NO_CPU")) y_cpu = y_gpu; else build(cpu, y_cpu, nullptr, nullptr);      // (timing runs at full size skip the CPU backend's pass)
+        uint64_t h = 1469598103934665603ull;
+        for (const auto & y : y_gpu) for (size_t i = 0; i < y.size() * 4; i++) { h ^= ((const uint8_t *)y.data())[i]; h *= 1099511628211ull; }
+        printf("{\"type\":\"%s\",\"D\":%lld,\"H\":%lld,\"B\":%lld,\"act_hand_offs_first_compute\":%d,\"fnv1a\":\"%016llx\",\"us_per_graph\":%.2f,\"k_vs_cpu\":%.3e,\"v_vs_cpu\":%.3e,\"out_vs_cpu\":%.3e}\n",
+               ggml_type_name(type), (long long)D, (long long)H, (long long)B, shared, (unsigned long long)h, us, rel_l2(y_gpu[0], y_cpu[0]), rel_l2(y_gpu[1], y_cpu[1]), rel_l2(y_gpu[2], y_cpu[2]));
         ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
         return 0;
     }

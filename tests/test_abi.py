@@ -124,6 +124,32 @@ print(json.dumps(out))
     assert got[10][:9] == [1, 2, 2, 2, 113, 113, 113, 113, 113] and got[23][9] == 113
 
 
+def test_act_image_keys_for_a_256_cu_part(built):
+    """ggml_cdna4_act_image_key (round 5: the hand-off of quantized activations between MUL_MATs of one src1): which image a call leaves in its workspace.  Host logic.  Equal
+    non-zero keys = the same image: K-quants share the Q8_K fp16 image on the GEMM routes whatever M is (wq / wk / wv of a grouped-query layer), Q4_0 / Q8_0 the Q8_0 one;
+    the int8 image of the matrix-core kernel (5..48 rows) is another key; one-launch decode forms leave none (0); a shape where two formats take different routes
+    (64 rows: Q8_0 on the int8 matrix cores, Q4_0 on the fp16 GEMM) has different keys; two-part re-encodings (Q2_K) double the image: their own key."""
+    import subprocess, sys, json
+    code = r"""
+import ctypes as C, json, sys
+L = C.CDLL(sys.argv[1])
+f = L.ggml_cdna4_act_image_key; f.restype = C.c_uint32; f.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64]
+print(json.dumps({"kq_gemm": [f(12, 4096, 4096, 512), f(12, 1024, 4096, 512), f(14, 1024, 4096, 512), f(13, 14336, 4096, 512)],
+                  "q80_gemm": [f(2, 4096, 4096, 512), f(8, 1024, 4096, 512)], "decode": [f(12, 4096, 4096, 1), f(12, 4096, 4096, 4), f(2, 4096, 4096, 2)],
+                  "mmq": [f(12, 4096, 4096, 16), f(14, 1024, 4096, 16), f(8, 4096, 4096, 16)], "b64": [f(8, 4096, 14336, 64), f(2, 4096, 14336, 64)],
+                  "q2_K": f(10, 4096, 4096, 512), "q5_0_mmq": f(6, 4096, 4096, 16), "q5_0_gemm": f(6, 4096, 4096, 512), "bad": f(12, 4096, 100, 512)}))
+"""
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "ggml_amd", "lib", "libcdna4_kernels.so")], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, CDNA4_ASSUME_CUS="256", HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1"))
+    assert r.returncode == 0, r.stderr[-800:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["kq_gemm"] == [19, 19, 19, 19] and got["q80_gemm"] == [17, 17]
+    assert got["decode"] == [0, 0, 0]
+    assert got["mmq"] == [3, 3, 1]
+    assert got["b64"] == [1, 17]
+    assert got["q2_K"] == 27 and got["q5_0_mmq"] == 0 and got["q5_0_gemm"] == 17 and got["bad"] == 0
+
+
 def test_no_cpu_fallback(built):
     """without a GPU the product must raise, not compute on the host"""
     import torch
