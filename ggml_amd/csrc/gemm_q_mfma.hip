@@ -314,14 +314,16 @@ std::atomic<int> g_resident_n{0};
 // 256 weights: the SAME 144 bytes the source blocks take), which k_gemm_kq_t64 / k_gemm_r8 consume through LDS-DMA like Q4_K (0: no image for this type / K)
 size_t cdna4_resident_image_row_bytes(int type, int64_t K) {
     if (type == CDNA4_Q4_0) return (K > 0 && K % 256 == 0) ? (size_t)(K / 256) * 144 : 0;
+    if (type == CDNA4_Q8_0) return (K > 0 && K % 256 == 0) ? (size_t)(K / 256) * 272 : 0;          // Q8_0R: eight fp16 scales + the eight blocks' int8 (k_repack_q8_0)
     return K > 0 ? cdna4_convert_weights_bytes(type, 1, K) : 0;
 }
 // builds the image rows of M rows of W (re-encoding or re-layout) on `st`
 int cdna4_resident_build(int type, const uint8_t *W, int64_t w_row_bytes, int64_t M, int64_t K, uint8_t *out, hipStream_t st) {
-    if (type == CDNA4_Q4_0) {
-        if (K % 256 || M <= 0) return cdna4_set_error_msg("resident_image: Q4_0 rows must be whole 256-weight groups");
+    if (type == CDNA4_Q4_0 || type == CDNA4_Q8_0) {
+        if (K % 256 || M <= 0) return cdna4_set_error_msg("resident_image: Q4_0 / Q8_0 rows must be whole 256-weight groups");
         const int nsb = (int)(K / 256);
-        hipLaunchKernelGGL(k_repack_q4_0, dim3((unsigned)((M * nsb * 9 + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, nsb, out);
+        if (type == CDNA4_Q4_0) hipLaunchKernelGGL(k_repack_q4_0, dim3((unsigned)((M * nsb * 9 + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, nsb, out);
+        else hipLaunchKernelGGL(k_repack_q8_0, dim3((unsigned)((M * nsb * 17 + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, nsb, out);
         CDNA4_CHECK_LAUNCH();
         return 0;
     }
@@ -528,6 +530,24 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
                 if (a.splitk <= 0 && cdna4_gemm_r8_preferred(r)) { ROUTE_END_K(true, 12); return cdna4_launch_gemm_lds(r, 256, 1, st, 2); }
                 ROUTE_END_K(true, 10);
                 return cdna4_launch_gemm_t64(r, 0, a.splitk, st);
+            }
+        }
+    }
+    if constexpr (TYPE == CDNA4_Q8_0) {
+        // round 5: a resident Q8_0R image puts Q8_0 on k_gemm_r8 where its 256 x 256 tiles fill the chip (k_gemm_r8<Q8_0R>: 64 raw bytes per row and K tile)
+        if (a.variant <= 0 && a.splitk <= 0 && a.K % 256 == 0) {
+            const uint8_t *img = cdna4_resident_lookup(CDNA4_Q8_0, a.W, a.w_row_bytes, a.M, a.K);
+            if (img && !((uintptr_t)img & 15)) {
+                cdna4_gemm_args r = a; r.type = CDNA4_Q8_0R; r.W = img; r.w_row_bytes = (int64_t)(a.K / 256) * 272; r.xf = nullptr;
+                if (cdna4_gemm_r8_preferred(r)) { ROUTE_END_K(true, 12); return cdna4_launch_gemm_lds(r, 256, 1, st, 2); }
+                // smaller grids.  For Q4_K k_gemm_r8's co-resident split-K (2 / 4 / 8 work-groups per tile reduce-scatter their partial tiles) is level with or behind
+                // k_gemm_kq_t64; Q8_0's alternative is the staging kernel, 35 % behind r8 per tile.  MI355X, one box, alternating, us per call, staging kernel -> r8
+                // (profiles/r05/q80_r8_small.txt):   split in 2 (65 .. 128 tiles): 16384 x 8192 x 512 178 -> 139, 14336 x 4096 x 512 91 -> 71, 4096 x 4096 x 2048 103 -> 79;
+                // split in 4 / 8 (<= 64 tiles): only long rows pay — 8192 x 8192 x 512 90.6 -> 83.7, 4096 x 14336 x 512 83.3 -> 77.3, but 8192 x 4096 x 512 48.7 -> 53.2,
+                // 4096 x 4096 x 1024 49.2 -> 52.7, 4096 x 4096 x 512 31.0 -> 40.2.  One ragged round of at least 65 % of the CUs runs unsplit.
+                const int nt256 = ((a.M + 255) / 256) * ((a.B + 255) / 256), cus = cu_count(), co = cdna4_gemm_coresident_cus();
+                if (nt256 < cus && nt256 * 20 >= cus * 13) { ROUTE_END_K(true, 12); return cdna4_launch_gemm_lds(r, 256, 1, st, 2); }
+                if (nt256 * 2 <= co && a.K >= 1024 && (nt256 * 4 > co || a.K >= 8192)) { ROUTE_END_K(true, 12); return cdna4_launch_gemm_lds(r, 256, 0, st, 2); }
             }
         }
     }

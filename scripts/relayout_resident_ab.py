@@ -1,5 +1,5 @@
-"""Q4_0 prefill with and without a resident Q4_0R image, on ONE box, alternating: the per-call route (k_gemm_kq_w12 with loader waves that re-lay the 18-byte blocks) against
-k_gemm_kq_t64 / k_gemm_r8 on the image.  One JSON line per shape: GEMM-only time per call (HIP-graph replay, activations pre-quantized: ggml_cdna4_mul_mat_prepared), the
+"""Q4_0 / Q8_0 prefill (AB_TYPE=2 | 8) with and without a resident Q4_0R / Q8_0R image, on ONE box, alternating: the per-call route (k_gemm_kq_w12 with loader waves that
+re-lay the 18- / 34-byte blocks) against k_gemm_kq_t64 / k_gemm_r8 on the image.  One JSON line per shape: GEMM-only time per call (HIP-graph replay, activations pre-quantized: ggml_cdna4_mul_mat_prepared), the
 routes, the relative difference of the two results, and the oracle-independent check that the image route equals the per-call route within 1e-5."""
 import json
 import os
@@ -10,7 +10,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import bench  # noqa: E402
 
-Q4_0 = 2
+Q4_0 = int(os.environ.get("AB_TYPE", "2"))        # (the name stays: 2 = Q4_0, 8 = Q8_0)
 SHAPES = [(4096, 4096, 512), (4096, 14336, 512), (14336, 4096, 512), (4096, 4096, 128), (8192, 8192, 2048), (4096, 4096, 2048), (16384, 4096, 1024)]
 
 
@@ -30,7 +30,7 @@ def main():
         def call():
             h.stream = torch.cuda.current_stream(dev).cuda_stream
             h.gemm_only()
-        out = {"shape": "%dx%dx%d" % (m, k, b)}
+        out = {"type": Q4_0, "shape": "%dx%dx%d" % (m, k, b)}
         h.step(); torch.cuda.synchronize()
         y_percall = h.y.clone()
         res = {"percall": [], "resident": []}

@@ -383,6 +383,17 @@ def _emul_module(name):
     return mod
 
 
+@pytest.mark.parametrize("wtype", [2, 8])         # ggml type ids: Q4_0, Q8_0
+def test_r8_on_the_resident_relayouts_counted_waits_are_sufficient_and_tight(wtype):
+    """k_gemm_r8<Q4_0R | Q8_0R> (round 5) on the CPU with every LDS-DMA copy performed as LATE as its counted vmcnt wait allows: correct (Q8_0R issues TWO raw pieces per K
+    tile, so the loop's wait tolerates two outstanding operations instead of one); with every wait weakened by one the result is wrong — the waits are not slack.  Also the
+    reduce-scatter split in two and a ragged tile."""
+    mod = _emul_module("emul_check")
+    assert mod.run_relayout(300, 1280, 200, wtype, defer_dma=True) < 1e-6
+    assert mod.run_relayout(256, 1024, 256, wtype, splitk=2, defer_dma=True) < 1e-6
+    assert mod.run_relayout(256, 768, 256, wtype, defer_dma=True, weaken=1) > 1e-2
+
+
 @pytest.mark.parametrize("t,m,k", [(6, 8, 1024), (6, 33, 64), (11, 8, 1024), (11, 33, 512), (10, 8, 1024), (10, 33, 512), (10, 5, 256),
                                    (20, 8, 1024), (20, 33, 64), (3, 8, 1024), (3, 33, 128), (7, 8, 1024), (7, 33, 128), (23, 8, 1024), (23, 33, 256)])
 def test_weight_reencoding_sources_on_the_cpu_are_exact(t, m, k):

@@ -109,6 +109,41 @@ def test_q4_0_resident_image_puts_q4_0_on_q4_ks_kernels(env, m, k, b, cus, route
     assert torch.equal(y_after.view(torch.int32), y_percall.view(torch.int32))        # unregistered: the per-call route again, bit for bit
 
 
+@pytest.mark.parametrize("m,k,b,cus,route", [(1024, 512, 256, 4, 12), (1024, 768, 300, 4, 12), (900, 1280, 512, 4, 12), (512, 1024, 256, 4, 12), (768, 512, 200, 4, 12), (512, 1024, 96, 0, 13)])
+def test_q8_0_resident_image_puts_large_grids_on_k_gemm_r8(env, m, k, b, cus, route):
+    """round 5: Q8_0's 34-byte blocks leave its rows 2-byte aligned (prefill on the staging kernel k_gemm_kq_w12).  A resident Q8_0R image (eight fp16 scales + the eight
+    blocks' int8 per 256 weights, 272 bytes, 16-byte aligned) puts it on k_gemm_r8 where 256 x 256 tiles fill the chip: 64 raw bytes per row and K tile, lane half hh owns
+    32-block hh and its scale; also one ragged round of >= 65 % of the CUs (768 rows on 4 pretend CUs) and grids of 1/4 .. 1/2 tile per CU through the kernel's co-resident
+    split in two (512 x 1024 x 256 on 4 CUs).  Smaller grids keep the per-call route (bit-identical with or without the image).  `cus`: see the Q4_0 test."""
+    L, native, ops = env
+    t = R.Q8_0
+    on_emulator = os.environ.get("CDNA4_TESTS_ON_EMULATOR") == "1"
+    if cus and on_emulator and int(os.environ.get("EMU_CUS", "256")) != cus:
+        pytest.skip("needs EMU_CUS=%d (tests/test_gpu_tests_on_the_emulator.py sets it)" % cus)
+    w = R.random_weights(t, m, k, seed=m + k)
+    a = ops.QTensor.from_host_bytes(t, k, m, w, device="cuda:0")
+    x = torch.from_numpy(np.random.default_rng(b).uniform(-1, 1, (b, k)).astype(np.float32)).cuda()
+    y_percall = ops.mul_mat(a, x).clone()
+    n = L.ggml_cdna4_resident_image_size(int(t), m, k)
+    assert n == m * (k // 256) * 272 + 256
+    img = torch.empty(n, dtype=torch.uint8, device="cuda")
+    native.check(L.ggml_cdna4_resident_image_register(int(t), a.data.data_ptr(), a.row_bytes, m, k, img.data_ptr(), 1, None))
+    try:
+        if cus == 0 or on_emulator:
+            assert L.ggml_cdna4_mul_mat_route_of(int(t), a.data.data_ptr(), a.row_bytes, m, k, b) == route
+        y_res = ops.mul_mat(a, x)
+        torch.cuda.synchronize()
+        if route == 13:
+            assert torch.equal(y_res.view(torch.int32), y_percall.view(torch.int32))
+        assert R.rel_l2(y_res.cpu().numpy(), y_percall.cpu().numpy()) < 1e-5
+        e = R.rel_l2(y_res.cpu().numpy(), R.o_mul_mat(t, w, x.cpu().numpy(), m, k))
+        assert e < 1e-3, e
+        y1 = ops.mul_mat(a, x[:1].contiguous()).cpu().numpy()
+        assert R.rel_l2(y1, R.o_mul_mat(t, w, x[:1].cpu().numpy(), m, k)) < 1e-5
+    finally:
+        assert L.ggml_cdna4_resident_image_unregister(a.data.data_ptr()) == 0
+
+
 @pytest.mark.parametrize("tail", ["bias_gelu", "bias_residual"])
 @pytest.mark.parametrize("m,k,b", [(768, 512, 96), (3072, 768, 200)])
 def test_q4_0_resident_image_carries_the_fused_tail_in_the_store(env, m, k, b, tail):

@@ -32,6 +32,48 @@ def build(name="w12"):
     return exe
 
 
+def relayout_image(wtype, w, M, K):
+    """numpy restatement of k_repack_q4_0 / k_repack_q8_0 (gemm_q_mfma.hip): the resident 16-byte-aligned images Q4_0R / Q8_0R of M rows of Q4_0 / Q8_0 blocks"""
+    nsb = K // 256
+    if wtype == R.Q4_0:
+        blk = w.reshape(M, nsb, 8, 18)
+        out = np.zeros((M, nsb, 144), np.uint8)
+        out[:, :, :16] = blk[:, :, :, :2].reshape(M, nsb, 16)
+        qs = blk[:, :, :, 2:]                                        # weight j (< 16) = qs[j] & 15, weight 16 + j = qs[j] >> 4
+        q = np.concatenate([qs & 15, qs >> 4], axis=3)               # [M][nsb][8][32]
+        for g in range(4):
+            out[:, :, 16 + 32 * g:48 + 32 * g] = q[:, :, 2 * g] | (q[:, :, 2 * g + 1] << 4)
+        return out
+    blk = w.reshape(M, nsb, 8, 34)
+    out = np.zeros((M, nsb, 272), np.uint8)
+    out[:, :, :16] = blk[:, :, :, :2].reshape(M, nsb, 16)
+    out[:, :, 16:] = blk[:, :, :, 2:].reshape(M, nsb, 256)
+    return out
+
+
+def run_relayout(M, K, B, wtype, seed=1, timeout=900, splitk=1, defer_dma=False, weaken=0):
+    """k_gemm_r8<Q4_0R | Q8_0R> on the CPU (lds_emul): Q4_0 / Q8_0 weights through their resident re-layout, against the fp16 weights d * q the kernel builds"""
+    rng = np.random.default_rng(seed)
+    w = R.random_weights(wtype, M, K, seed)
+    xh = rng.uniform(-1, 1, (B, K)).astype(np.float16)
+    img = np.zeros((K // 128, B, 128), np.float16)
+    for p in range(128):
+        img[:, :, p] = xh[:, [pan * 128 + (p & ~3) + LC.PERM[p & 3] for pan in range(K // 128)]].T
+    wd = R.o_dequantize(wtype, w, K).reshape(M, K).astype(np.float16).astype(np.float64)       # d * q: exact in fp32, one rounding to fp16 — as the kernel's packed multiply
+    want = xh.astype(np.float64) @ wd.T
+    with tempfile.TemporaryDirectory() as d:
+        relayout_image(wtype, w, M, K).tofile(os.path.join(d, "w.bin")); img.tofile(os.path.join(d, "xh.bin"))
+        r = subprocess.run([build("lds"), str(M), str(K), str(B), os.path.join(d, "w.bin"), os.path.join(d, "xh.bin"), os.path.join(d, "y.bin"), str(splitk), "256", "3",
+                            "102" if wtype == R.Q4_0 else "108"], capture_output=True, text=True, timeout=timeout,
+                           env=dict(os.environ, EMU_DEFER_DMA="1" if defer_dma else "0", EMU_WEAKEN_WAITS=str(weaken)))
+        if r.returncode == 77:
+            import pytest
+            pytest.skip("the environment cannot host the emulation (process / thread limits)")
+        assert r.returncode == 0, r.stderr[-500:]
+        y = np.fromfile(os.path.join(d, "y.bin"), np.float32).reshape(B, M).astype(np.float64)
+    return np.linalg.norm(y - want) / np.linalg.norm(want)
+
+
 def run(M, K, B, seed=1, timeout=600, splitk=1, kernel="w12", exp=0, xchg_l2=1, return_y=False, defer_dma=False, wtype=None):
     rng = np.random.default_rng(seed)
     nsb = K // 256
