@@ -48,6 +48,9 @@ template <> struct QT<CDNA4_IQ4_XS> { static constexpr int BYTES = 136, QK = 256
 //   Q8_0R 272 B: fp16 d[8] | 256 int8 in k order
 //   Q6_KR 224 B: fp16 d, 14 B pad | int8 scales[16] | ql[128] | qh[64]
 enum : int { CDNA4_Q4_0R = 102, CDNA4_Q8_0R = 108, CDNA4_Q6_KR = 114 };
+// RESIDENT-only re-layout of Q6_K for k_gemm_r8 (round 5; cdna4_resident_*): the sixteen sub-block scales already multiplied by d, the 6-bit quants widened to int8 —
+//   Q6_K8 288 B: fp16 s[16] (s_i = fp16(d * scales[i])) | 256 int8 (q - 32) in k order          (the product s_i * (q - 32) is the one every Q6_K GEMM kernel here takes)
+enum : int { CDNA4_Q6_K8 = 115 };
 // "staged" forms: never in HBM — the loader waves of k_gemm_kq_w12 read the ORIGINAL 2-byte-aligned blocks and write these
 // 128-k stage rows straight into the LDS ring (re-layout while staging; no repack kernel, no scratch copy):
 //   Q4_0S 80 B: fp16 d[4], 8 B pad | 2 x 32 B nibbles in Q4_K order       Q8_0S 144 B: fp16 d[4], pad | 2 x 64 int8
@@ -59,6 +62,7 @@ template <> struct QT<CDNA4_Q6_KS> { static constexpr int BYTES = 210, QK = 256;
 template <> struct QT<CDNA4_Q4_0R> { static constexpr int BYTES = 144, QK = 256; static constexpr bool KQ = true; };
 template <> struct QT<CDNA4_Q8_0R> { static constexpr int BYTES = 272, QK = 256; static constexpr bool KQ = false; };
 template <> struct QT<CDNA4_Q6_KR> { static constexpr int BYTES = 224, QK = 256; static constexpr bool KQ = true; };
+template <> struct QT<CDNA4_Q6_K8> { static constexpr int BYTES = 288, QK = 256; static constexpr bool KQ = true; };
 
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));

@@ -8,7 +8,7 @@
 
 // (form 2, k_gemm_r8, also takes Q5_K)
 static bool lds_supported_t(const cdna4_gemm_args &a, bool five_ok) {
-    if (a.type != CDNA4_Q4_K && !(five_ok && (a.type == CDNA4_Q5_K || a.type == CDNA4_Q4_0R || a.type == CDNA4_Q8_0R))) return false;
+    if (a.type != CDNA4_Q4_K && !(five_ok && (a.type == CDNA4_Q5_K || a.type == CDNA4_Q4_0R || a.type == CDNA4_Q8_0R || a.type == CDNA4_Q6_K8))) return false;
     if (a.M <= 0 || a.B <= 0 || a.K % 256 || a.K < 256) return false;
     if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes) & 15) || ((uintptr_t)a.xh & 15)) return false;
     return true;
@@ -34,7 +34,7 @@ bool cdna4_gemm_r8_preferred(const cdna4_gemm_args &a) {
 // form: 2 = k_gemm_r8 (the only one left; 256-row tiles only)
 int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st, int form) {
     if (form != 2) return cdna4_set_error_msg("gemm_lds: k_gemm_lds / k_gemm_w4 were measured behind k_gemm_r8 and removed in round 5 (gemm_variant bit 26 selects k_gemm_r8)");
-    if (!lds_supported_t(a, form == 2)) return cdna4_set_error_msg("gemm_r8: Q4_K, Q5_K or the resident re-layouts Q4_0R / Q8_0R on 16-byte-aligned rows, whole superblocks");
+    if (!lds_supported_t(a, form == 2)) return cdna4_set_error_msg("gemm_r8: Q4_K, Q5_K or the resident re-layouts Q4_0R / Q8_0R / Q6_K8 on 16-byte-aligned rows, whole superblocks");
     const int cus = cdna4_gemm_cu_count(), nsb = a.K / 256;
     const int tiles_b = (a.B + 255) / 256;
     if (form == 2) tm = 256;
@@ -75,6 +75,7 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
         const bool tail = a.epi.bias || a.epi.act || a.epi.resid;
         if (a.type == CDNA4_Q4_0R) { if (tail) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_0R, 0, true>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_0R>), grid, dim3(512), 0, st, p); }
         else if (a.type == CDNA4_Q8_0R) { if (tail) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q8_0R, 0, true>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q8_0R>), grid, dim3(512), 0, st, p); }
+        else if (a.type == CDNA4_Q6_K8) { if (tail) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q6_K8, 0, true>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q6_K8>), grid, dim3(512), 0, st, p); }
         else if (a.type == CDNA4_Q5_K) { if (tail) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q5_K, 0, true>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q5_K>), grid, dim3(512), 0, st, p); }
         else if (tail) hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K, 0, true>), grid, dim3(512), 0, st, p);
         else hipLaunchKernelGGL((k_gemm_r8<CDNA4_Q4_K>), grid, dim3(512), 0, st, p);

@@ -70,6 +70,41 @@ __global__ __launch_bounds__(256) void k_repack_q6_K(const uint8_t *__restrict__
     reinterpret_cast<u32x4 *>(out)[t] = pc == 0 ? u32x4{(uint32_t)ld_u16(src + 208), 0u, 0u, 0u} : (pc == 1 ? ld16_a2(src + 192) : ld16_a2(src + 16 * (pc - 2)));
 }
 
+// Q6_K -> Q6_K8 (cdna4_common.h; resident images only): piece 0 / 1 = the sixteen fp16 scales fp16(d * scales[i]), pieces 2 .. 17 = sixteen weights each, q - 32 as int8,
+// in k order (weight 128 n + 32 quad + l: ql[64 n + 32 (quad & 1) + l] low / high nibble for quad < 2 / >= 2, bits 2 quad .. 2 quad + 1 of qh[32 n + l] — dequantize_row_q6_K,
+// /root/reference/src/ggml-quants.c:1610-1640)
+__global__ __launch_bounds__(256) void k_repack_q6_K8(const uint8_t *__restrict__ W, int64_t w_row_bytes, int M, int nsb, uint8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)M * nsb * 18) return;
+    const int pc = (int)(t % 18); const int64_t u = t / 18;
+    const int row = (int)(u / nsb), sb = (int)(u % nsb);
+    const uint8_t *src = W + (int64_t)row * w_row_bytes + (int64_t)sb * 210;       // ql[128] qh[64] scales[16] d
+    uint32_t o[4];
+    if (pc < 2) {
+        const float d = h2f(ld_u16(src + 208));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const half_t a = (half_t)(d * (float)(int8_t)src[192 + 8 * pc + 2 * i]), b = (half_t)(d * (float)(int8_t)src[192 + 8 * pc + 2 * i + 1]);
+            o[i] = (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+        }
+    } else {
+        const int w0 = 16 * (pc - 2), n = w0 >> 7, quad = (w0 >> 5) & 3, l0 = w0 & 31;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int l = l0 + 4 * i + b;
+                const uint32_t ql = src[64 * n + 32 * (quad & 1) + l], qh = src[128 + 32 * n + l];
+                const int q = (int)(((quad < 2 ? ql : ql >> 4) & 0xFu) | (((qh >> (2 * quad)) & 3u) << 4)) - 32;
+                v |= ((uint32_t)q & 0xFFu) << (8 * b);
+            }
+            o[i] = v;
+        }
+    }
+    reinterpret_cast<u32x4 *>(out)[t] = u32x4{o[0], o[1], o[2], o[3]};
+}
+
 // ------------------------------------------------------------------------------------------------------------
 void *cdna4_debug_trace = nullptr;   // profiling hook (ggml_cdna4_debug_trace): device buffer for k_gemm_kq_w8<.., true>
 
@@ -315,14 +350,16 @@ std::atomic<int> g_resident_n{0};
 size_t cdna4_resident_image_row_bytes(int type, int64_t K) {
     if (type == CDNA4_Q4_0) return (K > 0 && K % 256 == 0) ? (size_t)(K / 256) * 144 : 0;
     if (type == CDNA4_Q8_0) return (K > 0 && K % 256 == 0) ? (size_t)(K / 256) * 272 : 0;          // Q8_0R: eight fp16 scales + the eight blocks' int8 (k_repack_q8_0)
+    if (type == CDNA4_Q6_K) return (K > 0 && K % 256 == 0) ? (size_t)(K / 256) * 288 : 0;          // Q6_K8: sixteen fp16 scales (d multiplied in) + 256 int8 (k_repack_q6_K8)
     return K > 0 ? cdna4_convert_weights_bytes(type, 1, K) : 0;
 }
 // builds the image rows of M rows of W (re-encoding or re-layout) on `st`
 int cdna4_resident_build(int type, const uint8_t *W, int64_t w_row_bytes, int64_t M, int64_t K, uint8_t *out, hipStream_t st) {
-    if (type == CDNA4_Q4_0 || type == CDNA4_Q8_0) {
+    if (type == CDNA4_Q4_0 || type == CDNA4_Q8_0 || type == CDNA4_Q6_K) {
         if (K % 256 || M <= 0) return cdna4_set_error_msg("resident_image: Q4_0 / Q8_0 rows must be whole 256-weight groups");
         const int nsb = (int)(K / 256);
-        if (type == CDNA4_Q4_0) hipLaunchKernelGGL(k_repack_q4_0, dim3((unsigned)((M * nsb * 9 + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, nsb, out);
+        if (type == CDNA4_Q6_K) hipLaunchKernelGGL(k_repack_q6_K8, dim3((unsigned)((M * nsb * 18 + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, nsb, out);
+        else if (type == CDNA4_Q4_0) hipLaunchKernelGGL(k_repack_q4_0, dim3((unsigned)((M * nsb * 9 + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, nsb, out);
         else hipLaunchKernelGGL(k_repack_q8_0, dim3((unsigned)((M * nsb * 17 + 255) / 256)), dim3(256), 0, st, W, w_row_bytes, (int)M, nsb, out);
         CDNA4_CHECK_LAUNCH();
         return 0;
@@ -533,12 +570,12 @@ static int launch_type(const cdna4_gemm_args &a, hipStream_t st) {
             }
         }
     }
-    if constexpr (TYPE == CDNA4_Q8_0) {
-        // round 5: a resident Q8_0R image puts Q8_0 on k_gemm_r8 where its 256 x 256 tiles fill the chip (k_gemm_r8<Q8_0R>: 64 raw bytes per row and K tile)
+    if constexpr (TYPE == CDNA4_Q8_0 || TYPE == CDNA4_Q6_K) {
+        // round 5: a resident Q8_0R / Q6_K8 image puts Q8_0 / Q6_K on k_gemm_r8 where its 256 x 256 tiles fill the chip (k_gemm_r8<Q8_0R | Q6_K8>: 64 raw bytes per row and K tile)
         if (a.variant <= 0 && a.splitk <= 0 && a.K % 256 == 0) {
-            const uint8_t *img = cdna4_resident_lookup(CDNA4_Q8_0, a.W, a.w_row_bytes, a.M, a.K);
+            const uint8_t *img = cdna4_resident_lookup(TYPE, a.W, a.w_row_bytes, a.M, a.K);
             if (img && !((uintptr_t)img & 15)) {
-                cdna4_gemm_args r = a; r.type = CDNA4_Q8_0R; r.W = img; r.w_row_bytes = (int64_t)(a.K / 256) * 272; r.xf = nullptr;
+                cdna4_gemm_args r = a; r.type = TYPE == CDNA4_Q8_0 ? CDNA4_Q8_0R : CDNA4_Q6_K8; r.W = img; r.w_row_bytes = (int64_t)(a.K / 256) * (TYPE == CDNA4_Q8_0 ? 272 : 288); r.xf = nullptr;
                 if (cdna4_gemm_r8_preferred(r)) { ROUTE_END_K(true, 12); return cdna4_launch_gemm_lds(r, 256, 1, st, 2); }
                 // smaller grids.  For Q4_K k_gemm_r8's co-resident split-K (2 / 4 / 8 work-groups per tile reduce-scatter their partial tiles) is level with or behind
                 // k_gemm_kq_t64; Q8_0's alternative is the staging kernel, 35 % behind r8 per tile.  MI355X, one box, alternating, us per call, staging kernel -> r8

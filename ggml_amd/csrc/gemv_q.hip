@@ -528,10 +528,11 @@ static int launch_type(const cdna4_gemv_args &a0, hipStream_t st) {
         a.d = a0.d + (int64_t)c0 * (a0.K / (QT<TYPE>::KQ ? 256 : 32));
         a.bsums = a0.bsums ? a0.bsums + (int64_t)c0 * (a0.K / 16) : nullptr;
         a.Y = a0.Y + (int64_t)c0 * a0.y_col_stride;
-        // three column counts are instantiated (round 5: were eight — 48 kernels of a fall-back path): a group of 2..4 runs the 4-column form, 5..8 the 8-column form, the
-        // padding columns repeat the group's last one and are not stored (the same columns meet the same sums: results unchanged)
+        // two column counts are instantiated (round 4 had eight, round 5 first three — 24 .. 60 kernels of a fall-back path that AUTO reaches only where neither the
+        // one-launch nor the staged form exists): a group of 2..8 runs the 8-column form, the padding columns repeat the group's last one and are not stored (the
+        // same columns meet the same sums: results unchanged)
         a.ncol = nb;
-        if (nb == 1) launch_nb<TYPE, 1>(a, st); else if (nb <= 4) launch_nb<TYPE, 4>(a, st); else launch_nb<TYPE, 8>(a, st);
+        if (nb == 1) launch_nb<TYPE, 1>(a, st); else launch_nb<TYPE, 8>(a, st);
         CDNA4_CHECK_LAUNCH();
     }
     return 0;

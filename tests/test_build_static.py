@@ -383,9 +383,9 @@ def _emul_module(name):
     return mod
 
 
-@pytest.mark.parametrize("wtype", [2, 8])         # ggml type ids: Q4_0, Q8_0
+@pytest.mark.parametrize("wtype", [2, 8, 14])         # ggml type ids: Q4_0, Q8_0, Q6_K
 def test_r8_on_the_resident_relayouts_counted_waits_are_sufficient_and_tight(wtype):
-    """k_gemm_r8<Q4_0R | Q8_0R> (round 5) on the CPU with every LDS-DMA copy performed as LATE as its counted vmcnt wait allows: correct (Q8_0R issues TWO raw pieces per K
+    """k_gemm_r8<Q4_0R | Q8_0R | Q6_K8> (round 5) on the CPU with every LDS-DMA copy performed as LATE as its counted vmcnt wait allows: correct (Q8_0R issues TWO raw pieces per K
     tile, so the loop's wait tolerates two outstanding operations instead of one); with every wait weakened by one the result is wrong — the waits are not slack.  Also the
     reduce-scatter split in two and a ragged tile."""
     mod = _emul_module("emul_check")

@@ -110,13 +110,14 @@ def test_q4_0_resident_image_puts_q4_0_on_q4_ks_kernels(env, m, k, b, cus, route
 
 
 @pytest.mark.parametrize("m,k,b,cus,route", [(1024, 512, 256, 4, 12), (1024, 768, 300, 4, 12), (900, 1280, 512, 4, 12), (512, 1024, 256, 4, 12), (768, 512, 200, 4, 12), (512, 1024, 96, 0, 13)])
-def test_q8_0_resident_image_puts_large_grids_on_k_gemm_r8(env, m, k, b, cus, route):
-    """round 5: Q8_0's 34-byte blocks leave its rows 2-byte aligned (prefill on the staging kernel k_gemm_kq_w12).  A resident Q8_0R image (eight fp16 scales + the eight
-    blocks' int8 per 256 weights, 272 bytes, 16-byte aligned) puts it on k_gemm_r8 where 256 x 256 tiles fill the chip: 64 raw bytes per row and K tile, lane half hh owns
+@pytest.mark.parametrize("t", [R.Q8_0, R.Q6_K])
+def test_q8_0_and_q6_K_resident_images_put_large_grids_on_k_gemm_r8(env, t, m, k, b, cus, route):
+    """round 5: Q8_0's 34-byte and Q6_K's 210-byte blocks leave their rows 2-byte aligned (prefill on the staging kernel k_gemm_kq_w12).  A resident Q8_0R image (eight fp16
+    scales + the eight blocks' int8 per 256 weights, 272 bytes, 16-byte aligned) — for Q6_K: Q6_K8, sixteen fp16 scales with d multiplied in + the quants widened to int8,
+    288 bytes — puts them on k_gemm_r8 where 256 x 256 tiles fill the chip: 64 raw bytes per row and K tile, lane half hh owns
     32-block hh and its scale; also one ragged round of >= 65 % of the CUs (768 rows on 4 pretend CUs) and grids of 1/4 .. 1/2 tile per CU through the kernel's co-resident
     split in two (512 x 1024 x 256 on 4 CUs).  Smaller grids keep the per-call route (bit-identical with or without the image).  `cus`: see the Q4_0 test."""
     L, native, ops = env
-    t = R.Q8_0
     on_emulator = os.environ.get("CDNA4_TESTS_ON_EMULATOR") == "1"
     if cus and on_emulator and int(os.environ.get("EMU_CUS", "256")) != cus:
         pytest.skip("needs EMU_CUS=%d (tests/test_gpu_tests_on_the_emulator.py sets it)" % cus)
@@ -125,9 +126,15 @@ def test_q8_0_resident_image_puts_large_grids_on_k_gemm_r8(env, m, k, b, cus, ro
     x = torch.from_numpy(np.random.default_rng(b).uniform(-1, 1, (b, k)).astype(np.float32)).cuda()
     y_percall = ops.mul_mat(a, x).clone()
     n = L.ggml_cdna4_resident_image_size(int(t), m, k)
-    assert n == m * (k // 256) * 272 + 256
+    assert n == m * (k // 256) * (272 if t == R.Q8_0 else 288) + 256
     img = torch.empty(n, dtype=torch.uint8, device="cuda")
     native.check(L.ggml_cdna4_resident_image_register(int(t), a.data.data_ptr(), a.row_bytes, m, k, img.data_ptr(), 1, None))
+    # the image, byte for byte, against the numpy restatement of the re-layout (tools/emul/emul_check.py: relayout_image; Q6_K8's fp16 scales = fp16(d * scales[i]))
+    import sys
+    sys.path.insert(0, os.path.join(R.ROOT, "tools", "emul"))
+    import emul_check
+    torch.cuda.synchronize()
+    assert np.array_equal(img[:n - 256].cpu().numpy(), emul_check.relayout_image(t, w, m, k).reshape(-1))
     try:
         if cus == 0 or on_emulator:
             assert L.ggml_cdna4_mul_mat_route_of(int(t), a.data.data_ptr(), a.row_bytes, m, k, b) == route

@@ -44,6 +44,20 @@ def relayout_image(wtype, w, M, K):
         for g in range(4):
             out[:, :, 16 + 32 * g:48 + 32 * g] = q[:, :, 2 * g] | (q[:, :, 2 * g + 1] << 4)
         return out
+    if wtype == R.Q6_K:
+        blk = w.reshape(M, nsb, 210)
+        out = np.zeros((M, nsb, 288), np.uint8)
+        d = blk[:, :, 208:210].copy().view(np.float16).astype(np.float32)                     # [M][nsb][1]
+        sc = blk[:, :, 192:208].view(np.int8).astype(np.float32)
+        out[:, :, :32] = (d * sc).astype(np.float16).view(np.uint8).reshape(M, nsb, 32)
+        ql, qh = blk[:, :, :128], blk[:, :, 128:192]
+        for n in range(2):
+            for quad in range(4):
+                lo = ql[:, :, 64 * n + 32 * (quad & 1):][:, :, :32]
+                nib = (lo & 15) if quad < 2 else (lo >> 4)
+                q = (nib | (((qh[:, :, 32 * n:32 * n + 32] >> (2 * quad)) & 3) << 4)).astype(np.int16) - 32
+                out[:, :, 32 + 128 * n + 32 * quad:][:, :, :32] = q.astype(np.int8).view(np.uint8)
+        return out
     blk = w.reshape(M, nsb, 8, 34)
     out = np.zeros((M, nsb, 272), np.uint8)
     out[:, :, :16] = blk[:, :, :, :2].reshape(M, nsb, 16)
@@ -59,12 +73,18 @@ def run_relayout(M, K, B, wtype, seed=1, timeout=900, splitk=1, defer_dma=False,
     img = np.zeros((K // 128, B, 128), np.float16)
     for p in range(128):
         img[:, :, p] = xh[:, [pan * 128 + (p & ~3) + LC.PERM[p & 3] for pan in range(K // 128)]].T
-    wd = R.o_dequantize(wtype, w, K).reshape(M, K).astype(np.float16).astype(np.float64)       # d * q: exact in fp32, one rounding to fp16 — as the kernel's packed multiply
+    image = relayout_image(wtype, w, M, K)
+    if wtype == R.Q6_K:                                             # the kernel multiplies the image's fp16 scale by (q - 32): exact in fp32, one rounding to fp16
+        s16 = image[:, :, :32].copy().view(np.float16).astype(np.float32)                      # [M][nsb][16]
+        q8 = image[:, :, 32:].view(np.int8).astype(np.float32).reshape(M, K // 256, 16, 16)
+        wd = (s16[:, :, :, None] * q8).astype(np.float16).astype(np.float64).reshape(M, K)
+    else:
+        wd = R.o_dequantize(wtype, w, K).reshape(M, K).astype(np.float16).astype(np.float64)   # d * q: exact in fp32, one rounding to fp16 — as the kernel's packed multiply
     want = xh.astype(np.float64) @ wd.T
     with tempfile.TemporaryDirectory() as d:
-        relayout_image(wtype, w, M, K).tofile(os.path.join(d, "w.bin")); img.tofile(os.path.join(d, "xh.bin"))
+        image.tofile(os.path.join(d, "w.bin")); img.tofile(os.path.join(d, "xh.bin"))
         r = subprocess.run([build("lds"), str(M), str(K), str(B), os.path.join(d, "w.bin"), os.path.join(d, "xh.bin"), os.path.join(d, "y.bin"), str(splitk), "256", "3",
-                            "102" if wtype == R.Q4_0 else "108"], capture_output=True, text=True, timeout=timeout,
+                            "102" if wtype == R.Q4_0 else ("108" if wtype == R.Q8_0 else "115")], capture_output=True, text=True, timeout=timeout,
                            env=dict(os.environ, EMU_DEFER_DMA="1" if defer_dma else "0", EMU_WEAKEN_WAITS=str(weaken)))
         if r.returncode == 77:
             import pytest

@@ -96,8 +96,8 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < (size_t)B * M; i++) y[i] = -12345.f;
     // the parameter block exactly as cdna4_launch_gemm_lds() (gemm_q_lds.hip) fills it
     gemm_params p{};
-    const int wtype = argc > 10 ? atoi(argv[10]) : CDNA4_Q4_K;          // 12 Q4_K, 13 Q5_K, 102 Q4_0R, 108 Q8_0R (the resident re-layouts: w.bin holds the IMAGE)
-    p.W = w; p.w_row_bytes = (int64_t)(K / 256) * (wtype == CDNA4_Q5_K ? 176 : (wtype == CDNA4_Q8_0R ? 272 : 144));
+    const int wtype = argc > 10 ? atoi(argv[10]) : CDNA4_Q4_K;          // 12 Q4_K, 13 Q5_K, 102 Q4_0R, 108 Q8_0R, 115 Q6_K8 (the resident re-layouts: w.bin holds the IMAGE)
+    p.W = w; p.w_row_bytes = (int64_t)(K / 256) * (wtype == CDNA4_Q5_K ? 176 : (wtype == CDNA4_Q8_0R ? 272 : (wtype == CDNA4_Q6_K8 ? 288 : 144)));
     p.xh = (const half_t *)xh; p.xh_row = K; p.Y = y; p.y_row = M; p.M = M; p.K = K; p.B = B; p.splitk = splitk;
     if (tm != 128 && tm != 256) { fprintf(stderr, "tm 128 or 256\n"); return 2; }
     p.tiles_m = (M + tm - 1) / tm; p.tiles_b = (B + 255) / 256;
@@ -116,6 +116,7 @@ int main(int argc, char **argv) {
     if (wtype == CDNA4_Q5_K) emu_launch([&] { k_gemm_r8<CDNA4_Q5_K>(p); }, nblk, 512);
     else if (wtype == CDNA4_Q4_0R) emu_launch([&] { k_gemm_r8<CDNA4_Q4_0R>(p); }, nblk, 512);
     else if (wtype == CDNA4_Q8_0R) emu_launch([&] { k_gemm_r8<CDNA4_Q8_0R>(p); }, nblk, 512);
+    else if (wtype == CDNA4_Q6_K8) emu_launch([&] { k_gemm_r8<CDNA4_Q6_K8>(p); }, nblk, 512);
     else emu_launch([&] { k_gemm_r8<CDNA4_Q4_K>(p); }, nblk, 512);
     if (flags) for (int i = 0; i < 16384; i++) if (flags[i] != 0) { fprintf(stderr, "split-K counter word %d was not reset by the last work-group to leave (%u)\n", i, flags[i]); return 4; }
     FILE *f = fopen(argv[6], "wb"); fwrite(y, 4, (size_t)B * M, f); fclose(f);
