@@ -358,6 +358,36 @@ def format_rows(dev, steps):
     return rows
 
 
+def resident_image_rows(dev, steps):
+    """round 5: Q4_0 / Q8_0 / Q6_K prefill with a RESIDENT kernel-native image of the weights (ggml_cdna4_resident_image_*: Q4_0R / Q8_0R re-layouts, Q6_K8 widening — what the
+    plug-in's CDNA4_Resident buffer type builds at load) against the per-call route (the staging kernel k_gemm_kq_w12), GEMM only, on one large grid (random valid blocks:
+    the reference quantizer would take minutes on 64 M weights); Q4_K / Q5_K read their own 16-byte-aligned blocks and need no image"""
+    from ggml_amd import native
+    L = native.lib()
+    m, k, b = 16384, 4096, 1024
+    xs = np.random.default_rng(4321).uniform(-1, 1, (b, k)).astype(np.float32)
+    rows = {"shape": [m, k, b], "data": "random-valid-blocks"}
+    for t in (12, 2, 8, 14):
+        h = Hot(dev, t, synth_blocks(t, m, k, 1234), m, k, xs)
+        h.prepare()
+        row = {"route": L.ggml_cdna4_mul_mat_route_of(t, h.a.data.data_ptr(), h.a.row_bytes, m, k, b), "gemm_us": round(events_us(h.gemm_only, max(20, steps // 4), 5), 3)}
+        n = L.ggml_cdna4_resident_image_size(t, m, k)
+        if n:
+            img = torch.empty(n, dtype=torch.uint8, device=dev)
+            native.check(L.ggml_cdna4_resident_image_register(t, h.a.data.data_ptr(), h.a.row_bytes, m, k, img.data_ptr(), 1, None))
+            try:
+                row["resident_route"] = L.ggml_cdna4_mul_mat_route_of(t, h.a.data.data_ptr(), h.a.row_bytes, m, k, b)
+                row["resident_gemm_us"] = round(events_us(h.gemm_only, max(20, steps // 4), 5), 3)
+                row["resident_gemm_tflops"] = round(h.flops / row["resident_gemm_us"] / 1e6, 1)
+                row["image_bytes_over_weight_bytes"] = round((n - 256) / float(m * h.a.row_bytes), 3)
+            finally:
+                L.ggml_cdna4_resident_image_unregister(h.a.data.data_ptr())
+        row["gemm_tflops"] = round(h.flops / row["gemm_us"] / 1e6, 1)
+        rows[TYPE_NAME[t]] = row
+        del h
+    return rows
+
+
 def batch_sweep(dev, steps):
     """µs per MUL_MAT call (activation quantize included, HIP events) from decode to prefill batch sizes — one-launch GEMV (1..8 rows,
     columns from LDS; 3..8 rows over large matrices: the int8 matrix-core kernel), k_mmq_q4_K for 9..32 rows (mmq_i8.hip: v_mfma_i32_16x16x32_i8),
@@ -643,6 +673,9 @@ def main():
     native.lib()
 
     if args.leg is not None:
+        if args.leg == "resident_images":                                # (sessions short of GPU time measure this leg alone)
+            print(json.dumps({"resident_images": resident_image_rows(dev, max(50, min(args.steps, 200)))}), flush=True)
+            return
         fn = {"widening": lambda: widening_rows(dev, max(50, min(args.steps, 200)))}[args.leg]
         fn()                                                             # prints its rows itself (leg_row)
         return
@@ -748,6 +781,7 @@ def main():
             legs = (("decode", lambda: decode_rows(dev, steps), 150),
                     ("shapes", lambda: {"c3_4096x11008x512": shape_row(dev, Q4_K, 4096, 11008, 512, steps), "c5_32768x8192x512_one_gpu": shape_row(dev, Q4_K, 32768, 8192, 512, max(20, steps // 4))}, 200),
                     ("formats", lambda: format_rows(dev, steps), 230),
+                    ("resident_images", lambda: resident_image_rows(dev, steps), 238),
                     ("mul_mat_id", lambda: moe_row(dev, steps), 245),
                     ("batch_sweep", lambda: batch_sweep(dev, steps), 250),
                     ("widening", lambda: leg_in_child("widening", steps, int(max(30, min(120, time_left(330))))), 255),

@@ -297,7 +297,7 @@ static void cdna4_backend_free(ggml_backend_t backend) {
     (void)hipStreamSynchronize(ctx->stream);
     cdna4_split_free_lanes(ctx);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "ggml-cdna4: %s: %d HIP-graph captures, %d replays\n", ctx->name.c_str(), ctx->n_graph_captures, ctx->n_graph_launches);
-    if (getenv("GGML_CDNA4_STATS") && ctx->n_act_shared) fprintf(stderr, "ggml-cdna4: %s: %d MUL_MATs multiplied the previous one's quantized activations\n", ctx->name.c_str(), ctx->n_act_shared);
+    if (getenv("GGML_CDNA4_STATS") && ctx->n_act_shared) fprintf(stderr, "ggml-cdna4: %s: %d MUL_MATs multiplied quantized activations that were already in the workspace (%d images left by NORM chains)\n", ctx->name.c_str(), ctx->n_act_shared, ctx->n_act_produced);
     if (getenv("GGML_CDNA4_STATS") && (ctx->n_ksplit_rccl || ctx->n_ksplit_sum)) fprintf(stderr, "ggml-cdna4: %s: K-split MUL_MAT: %d RCCL all-reduces, %d in-order sums\n", ctx->name.c_str(), ctx->n_ksplit_rccl, ctx->n_ksplit_sum);
     for (auto & gs : ctx->graph_slots) if (gs.exec) (void)hipGraphExecDestroy(gs.exec);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
@@ -422,6 +422,25 @@ static int try_fused_norm(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, const
     float eps; memcpy(&eps, nm->op_params, sizeof(float));
     const ggml_cdna4_tensor dx = tdesc(nm->src[0]), dg = tdesc(gain), dd = tdesc(last);
     ggml_cdna4_tensor ds{}; if (shift) ds = tdesc(shift);
+    // the node behind the chain is a MUL_MAT that reads its rows and would quantize them to the K-quants' fp16 GEMM image (llama: rms_norm -> mul -> wq | w_gate): the
+    // chain's own launch leaves that image in the workspace (ggml_cdna4_op_norm_affine_q8_K: same fp32 rows, same image, bit for bit), so that no MUL_MAT of these rows
+    // pays a quantizer launch — the first one takes the hand-off like the others (compute_mul_mat / try_fused_mul_mat)
+    if (act_share_on() && i + used < ggml_graph_n_nodes(g)) {
+        const ggml_tensor * mmn = ggml_graph_node(g, i + used);
+        const ggml_tensor * a = mmn->op == GGML_OP_MUL_MAT ? mmn->src[0] : nullptr;
+        if (a && mmn->src[1] == last && is_qweight(a->type) && !(a->buffer && cdna4_buft_is_split(a->buffer->buft)) && a->ne[2] == 1 && a->ne[3] == 1 &&
+            last->ne[2] == 1 && last->ne[3] == 1 && last->nb[1] == (size_t)last->ne[0] * sizeof(float) && last->ne[0] % 256 == 0 && last->ne[0] <= 8192 &&
+            ggml_cdna4_act_image_key((int)a->type, a->ne[1], last->ne[0], last->ne[1]) == 19u) {
+            const size_t need = ggml_cdna4_mul_mat_workspace_size((int)a->type, last->ne[0], last->ne[1]);
+            void * ws = ctx->need_ws(need);
+            if (ws && ggml_cdna4_op_norm_affine_q8_K(&dx, &dg, shift ? &ds : nullptr, &dd, eps, nm->op == GGML_OP_RMS_NORM, (int)a->type, ws, ctx->ws_size, ctx->stream) == 0) {
+                act_image_note(ctx, a->type, a->ne[1], last->ne[0], last->ne[1], last->data, last->ne[0]);
+                ctx->act_image.producer = last->data;
+                ctx->n_act_produced++;
+                return used;
+            }
+        }
+    }
     // the fused entry point validates shapes and strides BEFORE its launch: a rejection has written nothing, and the nodes run one by one instead
     // (a layout each separate kernel accepts must not abort a graph that ran before the peephole existed)
     if (ggml_cdna4_op_norm_affine(&dx, &dg, shift ? &ds : nullptr, &dd, eps, nm->op == GGML_OP_RMS_NORM, ctx->stream)) { (void)st; return 0; }
@@ -485,7 +504,8 @@ static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph)
             if (st != GGML_STATUS_SUCCESS) return st;
             if (used) {
                 ggml_tensor * last = ggml_graph_node(cgraph, i + used - 1);     // (a chain writes its last node only)
-                act_image_written(ctx, last->data, ggml_nbytes(last));
+                if (ctx->act_image.producer == last->data) ctx->act_image.producer = nullptr;      // (the chain itself made the image of what it wrote)
+                else act_image_written(ctx, last->data, ggml_nbytes(last));
                 i += used - 1; continue;
             }
         }

@@ -48,7 +48,9 @@ struct cdna4_backend_ctx {
     // the quantized activations the workspace holds (ggml_cdna4_act_image_key; ggml_cdna4_backend.cpp: act_image_*): the next MUL_MAT of the same src1 multiplies them
     // without quantizing again.  `uses` = ws_uses when they were written: any later hand-out of the workspace (another op's scratch, a growth) ends their life
     uint64_t ws_uses = 0;
-    struct { const void * x = nullptr; int64_t x_stride = 0, K = 0, B = 0; size_t x_bytes = 0; uint32_t key = 0; uint64_t uses = 0; } act_image;
+    struct { const void * x = nullptr; int64_t x_stride = 0, K = 0, B = 0; size_t x_bytes = 0; uint32_t key = 0; uint64_t uses = 0;
+             const void * producer = nullptr; } act_image;     // producer: the node whose own launch wrote x AND the image (NORM chain: its write of x does not end the image's life)
+    int n_act_produced = 0;                                   // NORM chains that left the image of their rows for the next MUL_MAT
     int n_act_shared = 0;                                     // MUL_MATs that took the hand-off (statistics; "ggml_backend_cdna4_act_shared_count")
     void * need_ws(size_t n) {
         ws_uses++;

@@ -6,6 +6,7 @@
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
 #include "epilogue.h"
+#include "quantize_dev.h"
 #include <math.h>
 
 typedef ggml_cdna4_tensor T4;
@@ -94,15 +95,20 @@ __global__ __launch_bounds__(256) void k_unary(const float *__restrict__ x, floa
 // one 256-thread block per row; the row is re-read from L1/L2 (3 passes) — rows are K floats, a few KB
 // gain / shift (nullptr = none): the MUL and ADD that follow a NORM in every transformer graph (gpt-2: main-backend.cpp:476-488),
 // as the same two separate fp32 operations per element — bit-identical to NORM -> MUL -> ADD
-template <bool RMS>
-__global__ __launch_bounds__(256) void k_norm(const T4 a, const T4 d, float eps, const float *__restrict__ gain, const float *__restrict__ shift) {
+// Q8K (round 5): the row that was just normalised is ALSO quantized to the fp16 GEMM image of its Q8_K rounding — the activations the next MUL_MAT multiplies — so that
+// the graph's first reader of a normalised tensor pays no quantizer launch either.  The fp32 row is written as before (same code, same bits) and kept in LDS;
+// sixteen lanes per 256-value block run q8_K_group16_image (quantize_dev.h: the arithmetic of k_quantize_q8_K, bit for bit) on it.  xh = the image [n / 128][B][128],
+// pair-interleaved; n % 256 == 0, n <= 8192.
+template <bool RMS, bool Q8K = false>
+__global__ __launch_bounds__(256) void k_norm(const T4 a, const T4 d, float eps, const float *__restrict__ gain, const float *__restrict__ shift, uint8_t *__restrict__ xh, int64_t nrows_img) {
     __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) float yrow[Q8K ? 8192 : 4];
     const int64_t row = blockIdx.x;
     const idx4 x = {0, row % a.ne[1], (row / a.ne[1]) % a.ne[2], row / (a.ne[1] * a.ne[2])};
     const float *src = (const float *)at(a, x);
     float *dst = (float *)at(d, x);
     const int n = (int)a.ne[0];
-    auto put = [&](int i, float v) { if (gain) v = v * gain[i]; if (shift) v = v + shift[i]; dst[i] = v; };
+    auto put = [&](int i, float v) { if (gain) v = v * gain[i]; if (shift) v = v + shift[i]; dst[i] = v; if constexpr (Q8K) yrow[i] = v; };
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) { const float v = src[i]; s += RMS ? v * v : v; }
     s = block_sum(s, red);
@@ -116,6 +122,20 @@ __global__ __launch_bounds__(256) void k_norm(const T4 a, const T4 d, float eps,
         s2 = block_sum(s2, red);
         const float scale = 1.0f / sqrtf(s2 / n + eps);
         for (int i = threadIdx.x; i < n; i += 256) put(i, (src[i] - mean) * scale);
+    }
+    if constexpr (Q8K) {
+        __syncthreads();
+        const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;          // sixteen 16-lane groups: block grp, grp + 16, ..
+        for (int sb = grp; sb < n / 256; sb += 16) {
+            float e[16];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { e[i] = yrow[256 * sb + 8 * l16 + i]; e[8 + i] = yrow[256 * sb + 128 + 8 * l16 + i]; }
+            u32x4 o0, o1;
+            q8_K_group16_image(e, l16, o0, o1);
+            uint8_t *p0 = xh + (((int64_t)(2 * sb) * nrows_img + row) * 128 + 8 * l16) * 2;
+            *reinterpret_cast<u32x4 *>(p0) = o0;
+            *reinterpret_cast<u32x4 *>(p0 + nrows_img * 256) = o1;
+        }
     }
 }
 
@@ -544,8 +564,23 @@ int ggml_cdna4_op_norm_affine(const T4 *a, const T4 *gain, const T4 *shift, cons
     const int64_t nr = nrows(a);
     if (nr == 0 || a->ne[0] == 0) return 0;
     const float *gp = gain ? (const float *)gain->data : nullptr, *sp = shift ? (const float *)shift->data : nullptr;
-    if (rms) hipLaunchKernelGGL(k_norm<true>, dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp);
-    else hipLaunchKernelGGL(k_norm<false>, dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp);
+    if (rms) hipLaunchKernelGGL(k_norm<true>, dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)nullptr, (int64_t)0);
+    else hipLaunchKernelGGL(k_norm<false>, dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)nullptr, (int64_t)0);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+// the same + the Q8_K-rounded fp16 GEMM image of dst's rows into xh (capi.hip: ggml_cdna4_op_norm_affine_q8_K carves it out of a MUL_MAT workspace)
+int cdna4_launch_norm_affine_q8_K(const T4 *a, const T4 *gain, const T4 *shift, const T4 *d, float eps, int rms, void *xh, void *stream) {
+    NEED(a->type == CDNA4_F32 && d->type == CDNA4_F32 && same_shape(a, d) && a->nb[0] == 4 && d->nb[0] == 4, "norm: F32 rows only");
+    for (const T4 *g : {gain, shift})
+        NEED(!g || (g->type == CDNA4_F32 && g->nb[0] == 4 && g->ne[0] == a->ne[0] && g->ne[1] == 1 && g->ne[2] == 1 && g->ne[3] == 1), "norm: gain / shift are F32 vectors of ne[0] elements");
+    NEED(a->ne[0] % 256 == 0 && a->ne[0] <= 8192 && a->ne[0] > 0, "norm_q8_K: rows of 256 .. 8192 values, whole superblocks");
+    NEED(xh && !((uintptr_t)xh & 15), "norm_q8_K: the image must be 16-byte aligned");
+    const int64_t nr = nrows(a);
+    if (nr == 0) return 0;
+    const float *gp = gain ? (const float *)gain->data : nullptr, *sp = shift ? (const float *)shift->data : nullptr;
+    if (rms) hipLaunchKernelGGL((k_norm<true, true>), dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)xh, nr);
+    else hipLaunchKernelGGL((k_norm<false, true>), dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)xh, nr);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

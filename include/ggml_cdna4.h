@@ -210,6 +210,11 @@ int ggml_cdna4_op_norm(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor *
  * bit-identical to op_norm -> op_binary(MUL) -> op_binary(ADD) (gpt-2: main-backend.cpp:476-488) */
 int ggml_cdna4_op_norm_affine(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * gain, const ggml_cdna4_tensor * shift, const ggml_cdna4_tensor * dst,
                               float eps, int rms, void * stream);
+/* NORM / RMS_NORM [* gain] [+ shift] (ggml_cdna4_op_norm_affine, same bits in dst) that ALSO leaves in `workspace` the activation image a following
+ * ggml_cdna4_mul_mat(type, .., X = dst) would build, where that call's ggml_cdna4_act_image_key is the K-quants' fp16 GEMM image (== 19): the MUL_MATs that read dst
+ * then run ggml_cdna4_mul_mat_prepared[_fused] and no quantizer launch is paid for them.  dst: contiguous F32 rows of 256 .. 8192 values (whole superblocks). */
+int ggml_cdna4_op_norm_affine_q8_K(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * gain, const ggml_cdna4_tensor * shift, const ggml_cdna4_tensor * dst,
+                                   float eps, int rms, int type, void * workspace, size_t workspace_bytes, void * stream);
 /* softmax(src0*scale + slope*mask) over ne[0]; mask (F32 or F16, [ne0, ne1]) may be NULL; ALiBi slopes from
  * max_bias as ggml-cpu.c:8848-8944 */
 int ggml_cdna4_op_soft_max(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * mask, const ggml_cdna4_tensor * dst, float scale, float max_bias, void * stream);
