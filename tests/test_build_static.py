@@ -36,15 +36,19 @@ def _emulators_built_in_parallel():
                 pass
 
 
+def _isa_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_manifest", os.path.join(ROOT, "tools", "isa_manifest.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 @pytest.fixture(scope="module")
 def gemm_asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("asm") / "gemm.s"
-    src = os.path.join(ROOT, "ggml_amd", "csrc", "gemm_q_mfma.hip")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out), src],
-                   check=True, capture_output=True, timeout=900)
-    return out.read_text()
+    return _isa_tool().asm_of("gemm_q_mfma.hip")          # (cached compile shared with the manifest check: tools/isa_manifest.py)
 
 
 def _prop(asm, kernel, name):
@@ -79,11 +83,7 @@ def test_64x128_wave_tile_kernel_resources(tmp_path):
     parks one float4 in scratch in its EPILOGUE, which costs nothing); ring + reduction area within 160 KB of LDS"""
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    out = tmp_path / "t64.s"
-    src = os.path.join(ROOT, "ggml_amd", "csrc", "gemm_q_t64.hip")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm", "-S", "--cuda-device-only", "-o", str(out), src],
-                   check=True, capture_output=True, timeout=900)
-    asm = out.read_text()
+    asm = _isa_tool().asm_of("gemm_q_t64.hip")
     # the plain product (TAIL = false; the tail-carrying twin shares the main loop) and — round 5 — the one-launch step that carries the activation quantizer and the
     # grid barrier in its prologue (FQ = true): the loop must be the same loop, in particular without a scratch access in it (a spill there would also break the
     # kernel's counted vmcnt waits, which assume that LDS-DMA is the only vector-memory traffic of the loop)

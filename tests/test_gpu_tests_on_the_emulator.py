@@ -53,7 +53,7 @@ SELECTION_R3.append(("test_gpu_resident.py", "(test_resident_image_serves_prefil
 SELECTION_R3.append(("test_gpu_resident.py", "(test_q4_0_resident_image_puts and (512-1024-96 or 300-768)) or (test_q4_0_resident_image_carries and 768-512)", 4))
 SELECTION_R3.append(("test_gpu_resident.py", "test_q4_0_resident_image_puts and (1024-512-256 or 1280-512-200)", 2, {"EMU_CUS": "4"}))
 # Q8_0 on k_gemm_r8 through a resident Q8_0R image: whole rounds, one ragged round, the co-resident split in two (EMU_CUS=4), and the unchanged small-grid route
-SELECTION_R3.append(("test_gpu_resident.py", "test_q8_0_and_q6_K_resident_images_put and (1024-768-300 or 512-1024-256 or 768-512-200)", 6, {"EMU_CUS": "4"}))
+SELECTION_R3.append(("test_gpu_resident.py", "test_q8_0_and_q6_K_resident_images_put and (512-1024-256 or 768-512-200)", 4, {"EMU_CUS": "4"}))
 # the hand-off of quantized activations: the second product on the first one's image (C-ABI: act_image_key, mul_mat_prepared[_fused]) is bit-identical to quantizing again
 SELECTION_R3.append(("test_gpu_act_share.py", "(test_second_product and 16) or test_prepared_fused_refuses or (test_norm_that_also and 256-512)", 8))
 

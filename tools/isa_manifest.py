@@ -33,12 +33,30 @@ def compiler_version():
     return subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.strip().splitlines()[0:2]
 
 
+def asm_of(f):
+    """the gfx950 assembly of one kernel source under FLAGS.  Cached under build/isa_asm/ keyed by the contents of every file of csrc/ (one compile of gemm_q_t64.hip takes
+    ~110 s: the manifest check and the resource tests of tests/test_build_static.py read the same text)"""
+    h = hashlib.sha256(" ".join(FLAGS + compiler_version()).encode())
+    for name in sorted(os.listdir(CSRC)):
+        q = os.path.join(CSRC, name)
+        if os.path.isfile(q):
+            h.update(name.encode()); h.update(open(q, "rb").read())
+    cache = os.path.join(ROOT, "build", "isa_asm")
+    os.makedirs(cache, exist_ok=True)
+    out = os.path.join(cache, "%s.%s.s" % (f, h.hexdigest()[:16]))
+    if not os.path.exists(out):
+        for old in os.listdir(cache):
+            if old.startswith(f + "."):
+                os.remove(os.path.join(cache, old))
+        tmp = out + ".tmp%d" % os.getpid()
+        subprocess.run([HIPCC] + FLAGS + ["-o", tmp, os.path.join(CSRC, f)], check=True, capture_output=True, timeout=1500)
+        os.replace(tmp, out)
+    return open(out).read()
+
+
 def fingerprints(files=FILES, jobs=4):
     def one(f):
-        with tempfile.TemporaryDirectory() as d:
-            out = os.path.join(d, "k.s")
-            subprocess.run([HIPCC] + FLAGS + ["-o", out, os.path.join(CSRC, f)], check=True, capture_output=True, timeout=1500)
-            txt = open(out).read()
+        txt = asm_of(f)
         res = {}
         for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", txt, re.S | re.M):
             body = re.sub(r";.*", "", m.group(2))
