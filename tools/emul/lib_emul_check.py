@@ -80,14 +80,15 @@ def _run(args, env, timeout):
     return True
 
 
-def mul_mat(t, m, k, b, path=0, seed=1, cus=256, timeout=1800, w=None):
+def mul_mat(t, m, k, b, path=0, seed=1, cus=256, timeout=1800, w=None, resident=False, defer_dma=False):
     """-> (rel-L2 of the library's result vs the oracle's MUL_MAT of type t, the result) or None where the environment cannot host the emulation"""
     w = R.random_weights(t, m, k, seed) if w is None else w
     x = np.random.default_rng(seed + 1).uniform(-1, 1, (b, k)).astype(np.float32)
     with tempfile.TemporaryDirectory() as d:
         f = lambda n: os.path.join(d, n)
         w.tofile(f("w")); x.tofile(f("x"))
-        if not _run([build(), "mul_mat", str(int(t)), str(m), str(k), str(b), str(path), f("w"), f("x"), f("y")], {"EMU_CUS": cus}, timeout):
+        if not _run([build(), "mul_mat", str(int(t)), str(m), str(k), str(b), str(path), f("w"), f("x"), f("y")],
+                    {"EMU_CUS": cus, "EMU_RESIDENT": int(resident), "EMU_DEFER_DMA": int(defer_dma)}, timeout):
             return None
         y = np.fromfile(f("y"), np.float32).reshape(b, m)
     assert np.isfinite(y).all() and not (y == -12345.0).any(), "unwritten or non-finite outputs"

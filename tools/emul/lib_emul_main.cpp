@@ -38,6 +38,21 @@ int main(int argc, char **argv) {
         for (int64_t i = 0; i < M * B; i++) y[i] = -12345.f;
         const size_t wsn = ggml_cdna4_mul_mat_workspace_size(type, K, B);
         void *ws = emu_shared_alloc(wsn ? wsn : 256);
+        // EMU_RESIDENT=1: with a resident kernel-native image of the weights registered first (built twice and compared, like a host does at load) where the type has one
+        if (getenv("EMU_RESIDENT") && atoi(getenv("EMU_RESIDENT")) != 0) {
+            const size_t in = ggml_cdna4_resident_image_size(type, M, K);
+            if (in) {
+                void *img = emu_shared_alloc(in);
+                if (ggml_cdna4_resident_image_register(type, w, (int64_t)(wn / (size_t)M), M, K, img, 1, nullptr)) { fprintf(stderr, "resident_image_register: %s\n", ggml_cdna4_last_error()); return 1; }
+                const int route = ggml_cdna4_mul_mat_route_of(type, w, (int64_t)(wn / (size_t)M), M, K, B);
+                fprintf(stderr, "resident image registered: route %d\n", route);
+                // EMU_DEFER_DMA=2: defer only on the kernels whose every wait is a counted vmcnt in the source (k_gemm_kq_t64 = 10, k_gemm_r8 = 12).  The staged forms of
+                // k_gemm_kq_w12 rely on the compiler's own wait for their loader waves' register loads (everything older — the activation pieces — has landed with them):
+                // the emulation completes plain loads at once and has no such wait to retire the deferred copies
+                if (getenv("EMU_DEFER_DMA") && atoi(getenv("EMU_DEFER_DMA")) == 2 && route != 10 && route != 12) emu::g_defer_dma = false;
+            }
+        }
+        else if (getenv("EMU_DEFER_DMA") && atoi(getenv("EMU_DEFER_DMA")) == 2) emu::g_defer_dma = false;
         const int rc = ggml_cdna4_mul_mat(type, w, (int64_t)(wn / (size_t)M), x, K, y, M, M, K, B, ws, wsn, path, 0, 0, nullptr);
         if (rc) { fprintf(stderr, "mul_mat: %s\n", ggml_cdna4_last_error()); return 1; }
         store(argv[9], y, (size_t)(M * B) * 4);
