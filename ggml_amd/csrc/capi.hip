@@ -489,6 +489,15 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
             cdna4_gemm_args a{};
             a.type = type; a.W = (const uint8_t *)as; a.w_row_bytes = w_row_bytes; a.xh = mv.xh; a.xh_row_elems = K;
             a.Y = dst; a.y_row_elems = dst_row_stride; a.M = (int)M; a.K = (int)K; a.B = (int)mv.img_rows;
+            // Q4_0 experts with a RESIDENT Q4_0R image of the whole stack (the experts' rows back to back: ggml's 3-D expert tensor): Q4_K's grouped kernel instead of the
+            // per-lane-load one (round 5; the image is found by the stack's pointer, like ggml_cdna4_mul_mat finds a matrix's)
+            if (type == CDNA4_Q4_0 && K % 256 == 0 && w_expert_bytes == M * w_row_bytes) {
+                const uint8_t *img = cdna4_resident_lookup(CDNA4_Q4_0, as, w_row_bytes, M * n_expert, K);
+                if (img && !((uintptr_t)img & 15)) {
+                    a.type = CDNA4_Q4_0R; a.W = img; a.w_row_bytes = (K / 256) * 144;
+                    return cdna4_launch_gemm_t64_ids(a, mv.tile_expert, mv.img_dst, M * a.w_row_bytes, (hipStream_t)stream);
+                }
+            }
             return cdna4_launch_gemm_ids(a, mv.tile_expert, mv.img_dst, w_expert_bytes, (hipStream_t)stream);   // Q4_K: k_gemm_kq_t64<.., IDS>; Q5_K / Q6_K / Q4_0 / Q8_0: k_gemm_q<.., IDS>
         }
     }

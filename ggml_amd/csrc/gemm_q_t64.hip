@@ -159,7 +159,9 @@ static int t64_make_plan(const cdna4_gemm_args &a, int tm, int splitk, t64_plan 
 
 // grouped MUL_MAT_ID: one launch over (m tile) x (activation tile of the expert-sorted image); tiles past the last expert's run exit
 int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st) {
-    if (a.type != CDNA4_Q4_K || a.K % 256 || a.K < 256 || a.B % 128) return cdna4_set_error_msg("gemm_t64_ids: Q4_K, whole superblocks, image rows a multiple of 128");
+    // (Q4_0R: the expert stack's resident re-layout of Q4_0 — capi.hip finds it by the stack's pointer; the same loop with {d_j, 0} constants)
+    if ((a.type != CDNA4_Q4_K && a.type != CDNA4_Q4_0R) || a.K % 256 || a.K < 256 || a.B % 128) return cdna4_set_error_msg("gemm_t64_ids: Q4_K (or Q4_0R), whole superblocks, image rows a multiple of 128");
+    const bool z40 = a.type == CDNA4_Q4_0R;
     if ((((uintptr_t)a.W | (uintptr_t)a.w_row_bytes | (uintptr_t)w_expert_bytes) & 15) || ((uintptr_t)a.xh & 15)) return cdna4_set_error_msg("gemm_t64_ids: 16-byte alignment of the expert matrices and the image");
     gemm_params p{};
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.xh = (const half_t *)a.xh; p.xh_row = a.xh_row_elems;
@@ -180,7 +182,8 @@ int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expe
     p.tile_expert = tile_expert; p.row_dst = row_dst; p.w_expert_bytes = w_expert_bytes;
     if (!plan_off && tm == 128) { p.tile_order = tile_expert + p.tiles_b; p.tile_nfrag = tile_expert + 2 * p.tiles_b; }      // (k_moe_plan wrote them behind tile_expert: capi.hip moe_carve)
     if (tm == 256) {
-        hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256, true>), dim3(p.tiles_m * p.tiles_b), dim3(512), 0, st, p);
+        if (z40) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_0R, 256, true>), dim3(p.tiles_m * p.tiles_b), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256, true>), dim3(p.tiles_m * p.tiles_b), dim3(512), 0, st, p);
         CDNA4_CHECK_LAUNCH();
         return 0;
     }
@@ -196,7 +199,8 @@ int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expe
         char *sc = (char *)cdna4_gemm_scratch(fbytes + pbytes, 2);
         if (sc) { p.splitk = 2; p.tune = 2; p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes); }
     }
-    hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, true>), dim3(p.tiles_m * p.tiles_b * p.splitk), dim3(512), 0, st, p);
+    if (z40) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_0R, 128, true>), dim3(p.tiles_m * p.tiles_b * p.splitk), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, true>), dim3(p.tiles_m * p.tiles_b * p.splitk), dim3(512), 0, st, p);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

@@ -101,6 +101,15 @@ def test_64x128_wave_tile_kernel_resources(tmp_path):
         main = [lp for lp in loops if lp.count("v_mfma_f32_32x32x16_f16") == (32 if tm == 128 else 64)]
         assert len(main) == 2 and all("scratch_" not in lp for lp in main)
         assert sorted(lp.count("global_load_lds_dwordx4") for lp in main)[0] == 0        # the non-loader copy issues no LDS-DMA at all
+    # the grouped MUL_MAT_ID instantiations (IDS; Q4_K and — round 5 — Q4_0R on a resident image of the expert stack): no scratch access in any loop that issues MFMAs
+    for ty in (12, 102):
+        for tm in (128, 256):
+            k = "_Z13k_gemm_kq_t64ILi%dELi%dELb1ELi0ELb0ELb0EEv11gemm_params" % (ty, tm)
+            assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= 256 and _lds(asm, k) <= 160 * 1024
+            body = re.search(r"^%s:.*?^\.Lfunc_end" % re.escape(k), asm, re.S | re.M).group(0)
+            loops = [m.group(0) for chunk in body.split("Loop Header: Depth=1")[1:] for m in [re.search(r".*?s_cbranch_scc1", chunk, re.S)] if m]
+            mf = [lp for lp in loops if "v_mfma_f32_32x32x16_f16" in lp]
+            assert len(mf) >= 2 and all("scratch_" not in lp for lp in mf), k
     # nothing in this file loads into registers asynchronously: round 2's first version did (superblock headers, inline-asm
     # global_load_dwordx4 waited for a stage later) and hipcc copied the in-flight registers before the wait — one wave in a few
     # thousand got garbage constants on the GPU, invisibly to the CPU emulator.  Headers go through LDS (DMA) now.

@@ -151,6 +151,38 @@ def test_q8_0_and_q6_K_resident_images_put_large_grids_on_k_gemm_r8(env, t, m, k
         assert L.ggml_cdna4_resident_image_unregister(a.data.data_ptr()) == 0
 
 
+@pytest.mark.parametrize("m,k,n_expert,n_used,n_tok,cus", [(128, 512, 2, 2, 70, 0), (300, 1024, 4, 2, 100, 0), (512, 768, 2, 1, 130, 2), (1024, 1024, 8, 2, 256, 0)])
+def test_q4_0_expert_stack_with_a_resident_image_runs_q4_ks_grouped_kernel(env, m, k, n_expert, n_used, n_tok, cus):
+    """MUL_MAT_ID at prefill sizes on Q4_0 experts: without an image the grouped per-lane-load GEMM k_gemm_q<Q4_0, IDS>; with a resident Q4_0R image of the whole expert
+    stack (found by the stack's pointer) Q4_K's grouped k_gemm_kq_t64<Q4_0R, 128 | 256, IDS> — within 1e-5 of the other route, within the GEMM bar of the oracle's
+    MUL_MAT_ID; single-token calls read the source bytes (one launch), bit-identical with or without the image.  `cus` (emulator): a grid that takes 256-row tiles."""
+    L, native, ops = env
+    t = R.Q4_0
+    on_emulator = os.environ.get("CDNA4_TESTS_ON_EMULATOR") == "1"
+    if cus and on_emulator and int(os.environ.get("EMU_CUS", "256")) != cus:
+        pytest.skip("needs EMU_CUS=%d" % cus)
+    rng = np.random.default_rng(n_expert + n_tok)
+    w = R.random_weights(t, n_expert * m, k, seed=4)
+    xb = rng.uniform(-1, 1, (n_tok, n_used, k)).astype(np.float32)
+    ids = np.stack([rng.permutation(n_expert)[:n_used] for _ in range(n_tok)]).astype(np.int32)
+    a = ops.QTensor.from_host_bytes(t, k, n_expert * m, w, device="cuda:0")
+    xd, idd = torch.from_numpy(xb).cuda(), torch.from_numpy(ids).cuda()
+    y_plain = ops.mul_mat_id(a, xd, idd, n_expert=n_expert).clone()
+    y1_plain = ops.mul_mat_id(a, xd[:1].contiguous(), idd[:1].contiguous(), n_expert=n_expert).clone()
+    img = torch.empty(L.ggml_cdna4_resident_image_size(int(t), n_expert * m, k), dtype=torch.uint8, device="cuda")
+    native.check(L.ggml_cdna4_resident_image_register(int(t), a.data.data_ptr(), a.row_bytes, n_expert * m, k, img.data_ptr(), 1, None))
+    try:
+        y_res = ops.mul_mat_id(a, xd, idd, n_expert=n_expert)
+        y1_res = ops.mul_mat_id(a, xd[:1].contiguous(), idd[:1].contiguous(), n_expert=n_expert)
+        torch.cuda.synchronize()
+        yo = R.o_mul_mat_id(t, w, xb, ids, m, k, n_expert)
+        assert R.rel_l2(y_res.cpu().numpy(), yo) < 1e-3 and R.rel_l2(y_plain.cpu().numpy(), yo) < 1e-3
+        assert R.rel_l2(y_res.cpu().numpy(), y_plain.cpu().numpy()) < 1e-5
+        assert torch.equal(y1_res.view(torch.int32), y1_plain.view(torch.int32))
+    finally:
+        assert L.ggml_cdna4_resident_image_unregister(a.data.data_ptr()) == 0
+
+
 @pytest.mark.parametrize("tail", ["bias_gelu", "bias_residual"])
 @pytest.mark.parametrize("m,k,b", [(768, 512, 96), (3072, 768, 200)])
 def test_q4_0_resident_image_carries_the_fused_tail_in_the_store(env, m, k, b, tail):

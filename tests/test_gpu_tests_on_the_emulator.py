@@ -54,6 +54,8 @@ SELECTION_R3.append(("test_gpu_resident.py", "(test_q4_0_resident_image_puts and
 SELECTION_R3.append(("test_gpu_resident.py", "test_q4_0_resident_image_puts and (1024-512-256 or 1280-512-200)", 2, {"EMU_CUS": "4"}))
 # Q8_0 on k_gemm_r8 through a resident Q8_0R image: whole rounds, one ragged round, the co-resident split in two (EMU_CUS=4), and the unchanged small-grid route
 SELECTION_R3.append(("test_gpu_resident.py", "test_q8_0_and_q6_K_resident_images_put and (512-1024-256 or 768-512-200)", 4, {"EMU_CUS": "4"}))
+# grouped MUL_MAT_ID on Q4_0 experts through a resident image of the expert stack: k_gemm_kq_t64<Q4_0R, 128, IDS> with the plan's tile order
+SELECTION_R3.append(("test_gpu_resident.py", "test_q4_0_expert_stack and 128-512", 1))
 # the hand-off of quantized activations: the second product on the first one's image (C-ABI: act_image_key, mul_mat_prepared[_fused]) is bit-identical to quantizing again
 SELECTION_R3.append(("test_gpu_act_share.py", "(test_second_product and 16) or test_prepared_fused_refuses or (test_norm_that_also and 256-512)", 8))
 

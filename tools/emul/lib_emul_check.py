@@ -95,7 +95,7 @@ def mul_mat(t, m, k, b, path=0, seed=1, cus=256, timeout=1800, w=None, resident=
     return R.rel_l2(y, R.o_mul_mat(t, w, x, m, k)), y
 
 
-def mul_mat_id(t, m, k, n_expert, n_used, n_b, n_tok, seed=1, cus=256, timeout=1800):
+def mul_mat_id(t, m, k, n_expert, n_used, n_b, n_tok, seed=1, cus=256, timeout=1800, resident=False, defer_dma=False):
     rng = np.random.default_rng(seed)
     w = R.random_weights(t, n_expert * m, k, seed)
     xb = rng.uniform(-1, 1, (n_tok, n_b, k)).astype(np.float32)
@@ -103,7 +103,8 @@ def mul_mat_id(t, m, k, n_expert, n_used, n_b, n_tok, seed=1, cus=256, timeout=1
     with tempfile.TemporaryDirectory() as d:
         f = lambda n: os.path.join(d, n)
         w.tofile(f("w")); xb.tofile(f("x")); ids.tofile(f("i"))
-        if not _run([build(), "mul_mat_id"] + [str(int(v)) for v in (t, m, k, n_expert, n_used, n_b, n_tok)] + [f("w"), f("x"), f("i"), f("y")], {"EMU_CUS": cus}, timeout):
+        if not _run([build(), "mul_mat_id"] + [str(int(v)) for v in (t, m, k, n_expert, n_used, n_b, n_tok)] + [f("w"), f("x"), f("i"), f("y")],
+                    {"EMU_CUS": cus, "EMU_RESIDENT": int(resident), "EMU_DEFER_DMA": int(defer_dma)}, timeout):
             return None
         y = np.fromfile(f("y"), np.float32).reshape(n_tok, n_used, m)
     assert np.isfinite(y).all() and not (y == -12345.0).any(), "unwritten or non-finite outputs"

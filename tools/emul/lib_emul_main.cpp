@@ -66,6 +66,13 @@ int main(int argc, char **argv) {
         const size_t wsn = ggml_cdna4_mul_mat_id_workspace_size(type, K, NE, NU, NB, NT);
         void *ws = emu_shared_alloc(wsn ? wsn : 256);
         const int64_t rb = (int64_t)(wn / (size_t)(M * NE));
+        if (getenv("EMU_RESIDENT") && atoi(getenv("EMU_RESIDENT")) != 0) {      // a resident image of the whole expert stack (M * NE rows)
+            const size_t in = ggml_cdna4_resident_image_size(type, M * NE, K);
+            if (in) {
+                void *img = emu_shared_alloc(in);
+                if (ggml_cdna4_resident_image_register(type, w, rb, M * NE, K, img, 1, nullptr)) { fprintf(stderr, "resident_image_register: %s\n", ggml_cdna4_last_error()); return 1; }
+            }
+        }
         const int rc = ggml_cdna4_mul_mat_id(type, w, rb, rb * M, x, K, NB * K, ids, NU, y, M, NU * M, M, K, NE, NU, NB, NT, ws, wsn, nullptr);
         if (rc) { fprintf(stderr, "mul_mat_id: %s\n", ggml_cdna4_last_error()); return 1; }
         store(argv[12], y, (size_t)(M * NU * NT) * 4);
