@@ -75,13 +75,15 @@ static void resident_written(cdna4_buffer_ctx * ctx, ggml_tensor * tensor, size_
     if (r->written < total) return;
     r->written = 0;
     const ggml_tensor * t = r->tensor;
-    if (ggml_cdna4_resident_image_register((int)t->type, t->data, (int64_t)t->nb[1], t->ne[1], t->ne[0], r->image, 1, nullptr) == 0) r->registered = true;
+    // (rows = ne[1] * ne[2]: a contiguous expert stack is one image, found by the stack's pointer in MUL_MAT_ID)
+    if (ggml_cdna4_resident_image_register((int)t->type, t->data, (int64_t)t->nb[1], t->ne[1] * t->ne[2], t->ne[0], r->image, 1, nullptr) == 0) r->registered = true;
     else fprintf(stderr, "ggml-cdna4: no resident image for %s: %s\n", t->name, ggml_cdna4_last_error());
 }
 static void cdna4_resident_init_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor) {
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
-    if (tensor->view_src || tensor->ne[2] != 1 || tensor->ne[3] != 1 || !ggml_is_contiguous(tensor)) return;
-    const size_t bytes = ggml_cdna4_resident_image_size((int)tensor->type, tensor->ne[1], tensor->ne[0]);
+    // 2-D weights; 3-D expert stacks only for Q4_0, the one format whose grouped MUL_MAT_ID reads an image (capi.hip: ggml_cdna4_mul_mat_id)
+    if (tensor->view_src || tensor->ne[3] != 1 || !ggml_is_contiguous(tensor) || (tensor->ne[2] != 1 && tensor->type != GGML_TYPE_Q4_0)) return;
+    const size_t bytes = ggml_cdna4_resident_image_size((int)tensor->type, tensor->ne[1] * tensor->ne[2], tensor->ne[0]);
     if (bytes == 0) return;                                                         // a type that needs no image (or no MUL_MAT weight at all)
     if (resident_find(ctx, tensor)) return;
     HIP_OK(hipSetDevice(ctx->device));
