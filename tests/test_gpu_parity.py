@@ -454,14 +454,16 @@ def test_full_size_c5_config(gu):
         assert R.rel_l2(ysh, yh[:, r * 4096:(r + 1) * 4096]) < 2e-6
 
 
-def test_headline_shape_against_the_oracle_full_matrix(gu):
+@pytest.mark.parametrize("m,k,b", [(4096, 4096, 512), (4096, 11008, 512)])
+def test_headline_shape_against_the_oracle_full_matrix(gu, m, k, b):
     """the headline product, Q4_K [4096 x 4096] . [4096 x 512], ALL 2,097,152 outputs against the oracle's MUL_MAT (its
     OpenMP build finishes in seconds), on the PRESCRIBED inputs bench.py times (reference-quantized mt19937(1234) weights through oracle/_ref/synth_data when
     present, random valid blocks otherwise): rel-L2 over the whole matrix and the worst single output column, through AUTO (k_gemm_kq_t64, hand-off split) and
-    through the shared-device route (ticketed split)."""
+    through the shared-device route (ticketed split).  Round 5: the same for BASELINE configs[2], [4096 x 11008] . [11008 x 512] — the one
+    BASELINE shape with an odd superblock count (43: the split in two is 22 + 21)."""
     import bench as B
     from ggml_amd import ops, native
-    t, m, k, b = R.Q4_K, 4096, 4096, 512
+    t = R.Q4_K
     w, x, how = B.prescribed(t, m, k, 0, m, b)
     a, xd = gu.qtensor(t, w, m, k), gu.to_dev(x)
     want = R.o_mul_mat(t, w, x, m, k)
@@ -474,7 +476,7 @@ def test_headline_shape_against_the_oracle_full_matrix(gu):
             L.ggml_cdna4_set_shared_device(old)
         e = R.rel_l2(y, want)
         col = float(np.max(np.linalg.norm(y - want, axis=0) / np.maximum(np.linalg.norm(want, axis=0), 1e-30)))
-        gu.report(test="headline_full_matrix", data=how, shared_device=shared, rel_l2=e, worst_column_rel_l2=col)
+        gu.report(test="headline_full_matrix", m=m, k=k, b=b, data=how, shared_device=shared, rel_l2=e, worst_column_rel_l2=col)
         assert np.isfinite(y).all() and e < TOL_GEMM and col < 2 * TOL_GEMM, (shared, e, col)
 
 
