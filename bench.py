@@ -388,6 +388,48 @@ def resident_image_rows(dev, steps):
     return rows
 
 
+def layer_front_rows(dev, steps):
+    """round 5, through the C-ABI only: the front of a llama-8B-sized attention block — cur = rms_norm(x) * g, then wq (4096 x 4096), wk and wv
+    (1024 x 4096: grouped-query) on cur, Q4_K, 512 rows — as a host without the hand-off issues it (op_norm_affine + three ggml_cdna4_mul_mat: three activation
+    quantizations) and as the plug-in's graph walk issues it (op_norm_affine_q8_K leaves the image, three ggml_cdna4_mul_mat_prepared: none).  HIP-graph replay, one box,
+    alternating; the outputs of the two sequences are compared bit for bit."""
+    import ctypes as C
+    from ggml_amd import native, ops
+    L = native.lib()
+    t, d, b, mkv = Q4_K, 4096, 512, 1024
+    rng = np.random.default_rng(99)
+    x = torch.from_numpy(rng.standard_normal((1, 1, b, d)).astype(np.float32)).to(dev)
+    g = torch.from_numpy((1 + 0.1 * rng.standard_normal((1, 1, 1, d))).astype(np.float32)).to(dev)
+    cur = torch.empty_like(x)
+    ws_ = [ops.QTensor.from_host_bytes(t, d, m, synth_blocks(t, m, d, 7 + i), device=dev) for i, m in enumerate((d, mkv, mkv))]
+    outs = [[torch.empty((b, w.M), dtype=torch.float32, device=dev) for w in ws_] for _ in range(2)]
+    ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(t, d, b), dtype=torch.uint8, device=dev)
+    dx, dg, dc = ops._tensor_desc(x, 0), ops._tensor_desc(g, 0), ops._tensor_desc(cur, 0)
+    assert L.ggml_cdna4_act_image_key(t, d, d, b) == 19 and L.ggml_cdna4_act_image_key(t, mkv, d, b) == 19
+
+    def st():
+        return torch.cuda.current_stream(dev).cuda_stream
+
+    def plain():
+        native.check(L.ggml_cdna4_op_norm_affine(C.byref(dx), C.byref(dg), None, C.byref(dc), 1e-5, 1, st()))
+        for w, y in zip(ws_, outs[0]):
+            native.check(L.ggml_cdna4_mul_mat(t, w.data.data_ptr(), w.row_bytes, cur.data_ptr(), d, y.data_ptr(), w.M, w.M, d, b, ws.data_ptr(), ws.numel(), 0, 0, 0, st()))
+
+    def handed_off():
+        native.check(L.ggml_cdna4_op_norm_affine_q8_K(C.byref(dx), C.byref(dg), None, C.byref(dc), 1e-5, 1, t, ws.data_ptr(), ws.numel(), st()))
+        for w, y in zip(ws_, outs[1]):
+            native.check(L.ggml_cdna4_mul_mat_prepared(t, w.data.data_ptr(), w.row_bytes, y.data_ptr(), w.M, w.M, d, b, ws.data_ptr(), ws.numel(), 0, 0, 0, st()))
+
+    plain(); handed_off(); torch.cuda.synchronize(dev)
+    same = all(torch.equal(a.view(torch.int32), c.view(torch.int32)) for a, c in zip(outs[0], outs[1]))
+    us = {"plain": [], "handed_off": []}
+    for _ in range(2):
+        us["plain"].append(graph_us(dev, plain, 20)); us["handed_off"].append(graph_us(dev, handed_off, 20))
+    return {"workload": "rms_norm * g -> wq (4096x4096), wk, wv (1024x4096), Q4_K, 512 rows; C-ABI, HIP-graph replay", "bit_identical": bool(same),
+            "launches": {"plain": 1 + 3 * 2 - (1 if one_launch(t, d, d, b) else 0), "handed_off": 4},
+            "us_plain": round(min(us["plain"]), 2), "us_handed_off": round(min(us["handed_off"]), 2), "all_us": {k_: [round(v, 2) for v in vs] for k_, vs in us.items()}}
+
+
 def batch_sweep(dev, steps):
     """µs per MUL_MAT call (activation quantize included, HIP events) from decode to prefill batch sizes — one-launch GEMV (1..8 rows,
     columns from LDS; 3..8 rows over large matrices: the int8 matrix-core kernel), k_mmq_q4_K for 9..32 rows (mmq_i8.hip: v_mfma_i32_16x16x32_i8),
@@ -673,6 +715,9 @@ def main():
     native.lib()
 
     if args.leg is not None:
+        if args.leg == "layer_front":
+            print(json.dumps({"layer_front": layer_front_rows(dev, max(50, min(args.steps, 200)))}), flush=True)
+            return
         if args.leg == "resident_images":                                # (sessions short of GPU time measure this leg alone)
             print(json.dumps({"resident_images": resident_image_rows(dev, max(50, min(args.steps, 200)))}), flush=True)
             return
@@ -782,6 +827,7 @@ def main():
                     ("shapes", lambda: {"c3_4096x11008x512": shape_row(dev, Q4_K, 4096, 11008, 512, steps), "c5_32768x8192x512_one_gpu": shape_row(dev, Q4_K, 32768, 8192, 512, max(20, steps // 4))}, 200),
                     ("formats", lambda: format_rows(dev, steps), 230),
                     ("resident_images", lambda: resident_image_rows(dev, steps), 238),
+                    ("layer_front", lambda: layer_front_rows(dev, steps), 242),
                     ("mul_mat_id", lambda: moe_row(dev, steps), 245),
                     ("batch_sweep", lambda: batch_sweep(dev, steps), 250),
                     ("widening", lambda: leg_in_child("widening", steps, int(max(30, min(120, time_left(330))))), 255),
