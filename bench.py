@@ -388,7 +388,7 @@ def resident_image_rows(dev, steps):
     return rows
 
 
-def layer_front_rows(dev, steps):
+def layer_front_rows(dev, steps, d=4096, b=512, mkv=1024):
     """round 5, through the C-ABI only: the front of a llama-8B-sized attention block — cur = rms_norm(x) * g, then wq (4096 x 4096), wk and wv
     (1024 x 4096: grouped-query) on cur, Q4_K, 512 rows — as a host without the hand-off issues it (op_norm_affine + three ggml_cdna4_mul_mat: three activation
     quantizations) and as the plug-in's graph walk issues it (op_norm_affine_q8_K leaves the image, three ggml_cdna4_mul_mat_prepared: none).  HIP-graph replay, one box,
@@ -396,7 +396,7 @@ def layer_front_rows(dev, steps):
     import ctypes as C
     from ggml_amd import native, ops
     L = native.lib()
-    t, d, b, mkv = Q4_K, 4096, 512, 1024
+    t = Q4_K
     rng = np.random.default_rng(99)
     x = torch.from_numpy(rng.standard_normal((1, 1, b, d)).astype(np.float32)).to(dev)
     g = torch.from_numpy((1 + 0.1 * rng.standard_normal((1, 1, 1, d))).astype(np.float32)).to(dev)
@@ -425,7 +425,7 @@ def layer_front_rows(dev, steps):
     us = {"plain": [], "handed_off": []}
     for _ in range(2):
         us["plain"].append(graph_us(dev, plain, 20)); us["handed_off"].append(graph_us(dev, handed_off, 20))
-    return {"workload": "rms_norm * g -> wq (4096x4096), wk, wv (1024x4096), Q4_K, 512 rows; C-ABI, HIP-graph replay", "bit_identical": bool(same),
+    return {"workload": "rms_norm * g -> wq (%dx%d), wk, wv (%dx%d), Q4_K, %d rows; C-ABI, HIP-graph replay" % (d, d, mkv, d, b), "bit_identical": bool(same),
             "launches": {"plain": 1 + 3 * 2 - (1 if one_launch(t, d, d, b) else 0), "handed_off": 4},
             "us_plain": round(min(us["plain"]), 2), "us_handed_off": round(min(us["handed_off"]), 2), "all_us": {k_: [round(v, 2) for v in vs] for k_, vs in us.items()}}
 

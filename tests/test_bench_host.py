@@ -47,3 +47,33 @@ def test_roofline_names_the_kernel_the_auto_route_launches():
     assert "k_gemm_kq_t64<Q4_K" in b.kernel_name(b.Q4_K, 16384, 8192, 512)      # 128 tiles: r8 would need its split-K exchange, level with t64 at best
     assert "k_gemm_kq_t64<Q4_K, 128>" in b.kernel_name(b.Q4_K, 4096, 11008, 512)      # C3: 32 tiles of 256 x 256 would need an 8-way exchange
     assert "k_gemm_kq_t64<Q4_K, 256>" in b.kernel_name(b.Q4_K, 24576, 8192, 1024)     # 96 x 4 = 384 tiles of 256 x 256: 1.5 rounds, not preferred
+
+
+def test_layer_front_leg_on_the_emulator():
+    """bench.py's layer_front leg (C-ABI only: rms_norm + three products with three activation quantizations vs the NORM-produced image + three prepared products) at a
+    small size against the whole-library CPU emulation: the two sequences run, their outputs are bit-identical, the row has the keys the JSON line carries"""
+    import json
+    import subprocess
+    import sys
+    import pytest
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm clang not available")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: bench.py runs on it")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import json, sys, os
+sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, %r)
+import emul_torch
+emul_torch.activate()
+import torch, bench
+bench.graph_us = lambda dev, fn, n=40: (fn(), 1.0)[1]
+print(json.dumps(bench.layer_front_rows("cuda:0", 50, d=512, b=96, mkv=256)))
+""" % (root, root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, cwd=root)
+    if "cannot host the emulation" in (r.stdout + r.stderr):
+        pytest.skip("the environment cannot host the emulation")
+    assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+    row = json.loads(r.stdout.strip().splitlines()[-1])
+    assert row["bit_identical"] is True and row["launches"]["handed_off"] == 4 and "us_plain" in row and "us_handed_off" in row
