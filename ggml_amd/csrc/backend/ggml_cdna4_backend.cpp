@@ -430,12 +430,13 @@ static int try_fused_norm(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, const
     if (act_share_on() && i + used < ggml_graph_n_nodes(g)) {
         const ggml_tensor * mmn = ggml_graph_node(g, i + used);
         const ggml_tensor * a = mmn->op == GGML_OP_MUL_MAT ? mmn->src[0] : nullptr;
-        if (a && mmn->src[1] == last && is_qweight(a->type) && !(a->buffer && cdna4_buft_is_split(a->buffer->buft)) && a->ne[2] == 1 && a->ne[3] == 1 &&
-            last->ne[2] == 1 && last->ne[3] == 1 && last->nb[1] == (size_t)last->ne[0] * sizeof(float) && last->ne[0] % 256 == 0 && last->ne[0] <= 8192 &&
-            ggml_cdna4_act_image_key((int)a->type, a->ne[1], last->ne[0], last->ne[1]) == 19u) {
+        // (key 19: the K-quants' Q8_K image, rows of whole 256-value superblocks; 17: the 32-block formats' Q8_0 image — gpt-2's Q4_0 layers at prompt sizes)
+        const uint32_t key = a && mmn->src[1] == last && is_qweight(a->type) && last->ne[2] == 1 && last->ne[3] == 1 ? ggml_cdna4_act_image_key((int)a->type, a->ne[1], last->ne[0], last->ne[1]) : 0u;
+        if ((key == 19u || key == 17u) && !(a->buffer && cdna4_buft_is_split(a->buffer->buft)) && a->ne[2] == 1 && a->ne[3] == 1 &&
+            last->nb[1] == (size_t)last->ne[0] * sizeof(float) && last->ne[0] % (key == 19u ? 256 : 32) == 0 && last->ne[0] <= 8192) {
             const size_t need = ggml_cdna4_mul_mat_workspace_size((int)a->type, last->ne[0], last->ne[1]);
             void * ws = ctx->need_ws(need);
-            if (ws && ggml_cdna4_op_norm_affine_q8_K(&dx, &dg, shift ? &ds : nullptr, &dd, eps, nm->op == GGML_OP_RMS_NORM, (int)a->type, ws, ctx->ws_size, ctx->stream) == 0) {
+            if (ws && (key == 19u ? ggml_cdna4_op_norm_affine_q8_K : ggml_cdna4_op_norm_affine_q8_0)(&dx, &dg, shift ? &ds : nullptr, &dd, eps, nm->op == GGML_OP_RMS_NORM, (int)a->type, ws, ctx->ws_size, ctx->stream) == 0) {
                 act_image_note(ctx, a->type, a->ne[1], last->ne[0], last->ne[1], last->data, last->ne[0]);
                 ctx->act_image.producer = last->data;
                 ctx->n_act_produced++;

@@ -418,16 +418,28 @@ uint32_t ggml_cdna4_act_image_key(int type, int64_t M, int64_t K, int64_t B) {
 // would build — for the calls whose ggml_cdna4_act_image_key is the K-quants' fp16 GEMM image (19): the MUL_MATs of dst then run ggml_cdna4_mul_mat_prepared[_fused] and
 // the graph pays no quantizer launch for them at all.  dst's fp32 rows are written exactly as ggml_cdna4_op_norm_affine writes them; the image is bit-identical to
 // ggml_cdna4_prepare_act's.  Rows of 256 .. 8192 values, dst rows contiguous ([B][K]).
+static int norm_affine_act(const ggml_cdna4_tensor *src0, const ggml_cdna4_tensor *gain, const ggml_cdna4_tensor *shift, const ggml_cdna4_tensor *dst, float eps, int rms,
+                           int type, void *workspace, size_t workspace_bytes, void *stream, bool kq);
 int ggml_cdna4_op_norm_affine_q8_K(const ggml_cdna4_tensor *src0, const ggml_cdna4_tensor *gain, const ggml_cdna4_tensor *shift, const ggml_cdna4_tensor *dst, float eps, int rms,
                                    int type, void *workspace, size_t workspace_bytes, void *stream) {
     if (!is_q(type) || !is_kq(type) || cdna4_convert_weights_kmul(type) != 1) return cdna4_set_error_msg("norm_q8_K: the image is the K-quants' (Q8_K activations, single image)");
+    return norm_affine_act(src0, gain, shift, dst, eps, rms, type, workspace, workspace_bytes, stream, true);
+}
+// the same for the 32-block formats whose activations are Q8_0 (Q4_0 / Q8_0 / Q5_0 / IQ4_NL; ggml_cdna4_act_image_key == 17): the image of k_quantize_q8_0, bit for bit
+int ggml_cdna4_op_norm_affine_q8_0(const ggml_cdna4_tensor *src0, const ggml_cdna4_tensor *gain, const ggml_cdna4_tensor *shift, const ggml_cdna4_tensor *dst, float eps, int rms,
+                                   int type, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!is_q(type) || is_kq(type) || cdna4_is_q81(type) || cdna4_convert_weights_kmul(type) != 1) return cdna4_set_error_msg("norm_q8_0: the image is the 32-block formats' (Q8_0 activations, single image)");
+    return norm_affine_act(src0, gain, shift, dst, eps, rms, type, workspace, workspace_bytes, stream, false);
+}
+static int norm_affine_act(const ggml_cdna4_tensor *src0, const ggml_cdna4_tensor *gain, const ggml_cdna4_tensor *shift, const ggml_cdna4_tensor *dst, float eps, int rms,
+                           int type, void *workspace, size_t workspace_bytes, void *stream, bool kq) {
     const int64_t K = dst->ne[0], B = dst->ne[1] * dst->ne[2] * dst->ne[3];
-    if (K <= 0 || B <= 0 || K % 256) return cdna4_set_error_msg("norm_q8_K: rows of whole superblocks");
+    if (K <= 0 || B <= 0 || K % (kq ? 256 : 32)) return cdna4_set_error_msg("norm + activation image: rows of whole blocks");
     if (dst->nb[1] != K * 4 || (dst->ne[2] > 1 && dst->nb[2] != dst->ne[1] * dst->nb[1]) || (dst->ne[3] > 1 && dst->nb[3] != dst->ne[2] * dst->nb[2])) return cdna4_set_error_msg("norm_q8_K: dst rows must be contiguous");
     if (!workspace || ((uintptr_t)workspace & 255)) return cdna4_set_error_msg("norm_q8_K: workspace must be 256-byte aligned");
     const ws_view v = carve(type, K, B, workspace);
     if (workspace_bytes < v.total) return cdna4_set_error_msg("norm_q8_K: workspace too small");
-    return cdna4_launch_norm_affine_q8_K(src0, gain, shift, dst, eps, rms, v.xh, stream);
+    return cdna4_launch_norm_affine_q8_K(src0, gain, shift, dst, eps, rms, v.xh, stream, kq ? 1 : 0);
 }
 // ggml_cdna4_mul_mat_fused on the image the previous call left in `workspace` (ggml_cdna4_act_image_key)
 int ggml_cdna4_mul_mat_prepared_fused(int type, const void *W, int64_t w_row_bytes, float *Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,

@@ -107,7 +107,7 @@ int cdna4_launch_convert_weights(int type, const uint8_t *W, int64_t w_row_bytes
 
 // resident kernel-native images of the re-encoded formats (gemm_q_mfma.hip): registry keyed by the weight pointer
 struct ggml_cdna4_tensor;
-extern "C" int cdna4_launch_norm_affine_q8_K(const ggml_cdna4_tensor *a, const ggml_cdna4_tensor *gain, const ggml_cdna4_tensor *shift, const ggml_cdna4_tensor *d, float eps, int rms, void *xh, void *stream);   // ops.hip
+extern "C" int cdna4_launch_norm_affine_q8_K(const ggml_cdna4_tensor *a, const ggml_cdna4_tensor *gain, const ggml_cdna4_tensor *shift, const ggml_cdna4_tensor *d, float eps, int rms, void *xh, void *stream, int kq);   // ops.hip (kq: the Q8_K image / 0: the Q8_0 image)
 size_t cdna4_resident_image_row_bytes(int type, int64_t K);                 // 0: no image for this type / K
 int cdna4_resident_build(int type, const uint8_t *W, int64_t w_row_bytes, int64_t M, int64_t K, uint8_t *out, hipStream_t st);
 int cdna4_resident_register(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, const void *image);

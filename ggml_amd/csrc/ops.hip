@@ -99,16 +99,19 @@ __global__ __launch_bounds__(256) void k_unary(const float *__restrict__ x, floa
 // the graph's first reader of a normalised tensor pays no quantizer launch either.  The fp32 row is written as before (same code, same bits) and kept in LDS;
 // sixteen lanes per 256-value block run q8_K_group16_image (quantize_dev.h: the arithmetic of k_quantize_q8_K, bit for bit) on it.  xh = the image [n / 128][B][128],
 // pair-interleaved; n % 256 == 0, n <= 8192.
-template <bool RMS, bool Q8K = false>
+// IMG: 0 none, 1 the K-quants' image (Q8_K rounding, 256-value blocks, q8_K_group16_image), 2 the 32-block formats' image (Q8_0 rounding: the body of k_quantize_q8_0 —
+// quantize_act.hip; q8_0_block<false>, eight lanes per block — n % 32 == 0)
+template <bool RMS, int IMG = 0>
 __global__ __launch_bounds__(256) void k_norm(const T4 a, const T4 d, float eps, const float *__restrict__ gain, const float *__restrict__ shift, uint8_t *__restrict__ xh, int64_t nrows_img) {
     __shared__ float red[4];
-    __shared__ __attribute__((aligned(16))) float yrow[Q8K ? 8192 : 4];
+    constexpr bool Q8K = IMG == 1;
+    __shared__ __attribute__((aligned(16))) float yrow[IMG ? 8192 : 4];
     const int64_t row = blockIdx.x;
     const idx4 x = {0, row % a.ne[1], (row / a.ne[1]) % a.ne[2], row / (a.ne[1] * a.ne[2])};
     const float *src = (const float *)at(a, x);
     float *dst = (float *)at(d, x);
     const int n = (int)a.ne[0];
-    auto put = [&](int i, float v) { if (gain) v = v * gain[i]; if (shift) v = v + shift[i]; dst[i] = v; if constexpr (Q8K) yrow[i] = v; };
+    auto put = [&](int i, float v) { if (gain) v = v * gain[i]; if (shift) v = v + shift[i]; dst[i] = v; if constexpr (IMG != 0) yrow[i] = v; };
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) { const float v = src[i]; s += RMS ? v * v : v; }
     s = block_sum(s, red);
@@ -135,6 +138,21 @@ __global__ __launch_bounds__(256) void k_norm(const T4 a, const T4 d, float eps,
             uint8_t *p0 = xh + (((int64_t)(2 * sb) * nrows_img + row) * 128 + 8 * l16) * 2;
             *reinterpret_cast<u32x4 *>(p0) = o0;
             *reinterpret_cast<u32x4 *>(p0 + nrows_img * 256) = o1;
+        }
+    }
+    if constexpr (IMG == 2) {
+        __syncthreads();
+        // one thread per four values, eight lanes per 32-block (whole groups drop out together: n % 32 == 0), exactly as k_quantize_q8_0<false> maps them
+        for (int g4 = threadIdx.x; g4 < n / 4; g4 += 256) {
+            const float e[4] = {yrow[4 * g4], yrow[4 * g4 + 1], yrow[4 * g4 + 2], yrow[4 * g4 + 3]};
+            int q[4]; float dh;
+            q8_0_block<false>(e, q, dh);
+            half_t h[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) h[i] = (half_t)(dh * (float)q[i]);
+            const int64_t k = 4 * (int64_t)g4;
+            const half2_t lo = {h[0], h[2]}, hi = {h[1], h[3]};                 // pair-interleaved: (k0, k2, k1, k3)
+            *reinterpret_cast<u32x2 *>(xh + (((k >> 7) * nrows_img + row) * 128 + (k & 127)) * 2) = u32x2{__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
         }
     }
 }
@@ -564,23 +582,29 @@ int ggml_cdna4_op_norm_affine(const T4 *a, const T4 *gain, const T4 *shift, cons
     const int64_t nr = nrows(a);
     if (nr == 0 || a->ne[0] == 0) return 0;
     const float *gp = gain ? (const float *)gain->data : nullptr, *sp = shift ? (const float *)shift->data : nullptr;
-    if (rms) hipLaunchKernelGGL(k_norm<true>, dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)nullptr, (int64_t)0);
-    else hipLaunchKernelGGL(k_norm<false>, dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)nullptr, (int64_t)0);
+    if (rms) hipLaunchKernelGGL((k_norm<true, 0>), dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)nullptr, (int64_t)0);
+    else hipLaunchKernelGGL((k_norm<false, 0>), dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)nullptr, (int64_t)0);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
 // the same + the Q8_K-rounded fp16 GEMM image of dst's rows into xh (capi.hip: ggml_cdna4_op_norm_affine_q8_K carves it out of a MUL_MAT workspace)
-int cdna4_launch_norm_affine_q8_K(const T4 *a, const T4 *gain, const T4 *shift, const T4 *d, float eps, int rms, void *xh, void *stream) {
+// kq != 0: the Q8_K image (rows of whole 256-value superblocks); 0: the Q8_0 image (rows of whole 32-value blocks)
+int cdna4_launch_norm_affine_q8_K(const T4 *a, const T4 *gain, const T4 *shift, const T4 *d, float eps, int rms, void *xh, void *stream, int kq) {
     NEED(a->type == CDNA4_F32 && d->type == CDNA4_F32 && same_shape(a, d) && a->nb[0] == 4 && d->nb[0] == 4, "norm: F32 rows only");
     for (const T4 *g : {gain, shift})
         NEED(!g || (g->type == CDNA4_F32 && g->nb[0] == 4 && g->ne[0] == a->ne[0] && g->ne[1] == 1 && g->ne[2] == 1 && g->ne[3] == 1), "norm: gain / shift are F32 vectors of ne[0] elements");
-    NEED(a->ne[0] % 256 == 0 && a->ne[0] <= 8192 && a->ne[0] > 0, "norm_q8_K: rows of 256 .. 8192 values, whole superblocks");
+    NEED(a->ne[0] % (kq ? 256 : 32) == 0 && a->ne[0] <= 8192 && a->ne[0] > 0, "norm + activation image: rows of up to 8192 values, whole blocks");
     NEED(xh && !((uintptr_t)xh & 15), "norm_q8_K: the image must be 16-byte aligned");
     const int64_t nr = nrows(a);
     if (nr == 0) return 0;
     const float *gp = gain ? (const float *)gain->data : nullptr, *sp = shift ? (const float *)shift->data : nullptr;
-    if (rms) hipLaunchKernelGGL((k_norm<true, true>), dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)xh, nr);
-    else hipLaunchKernelGGL((k_norm<false, true>), dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)xh, nr);
+    if (kq) {
+        if (rms) hipLaunchKernelGGL((k_norm<true, 1>), dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)xh, nr);
+        else hipLaunchKernelGGL((k_norm<false, 1>), dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)xh, nr);
+    } else {
+        if (rms) hipLaunchKernelGGL((k_norm<true, 2>), dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)xh, nr);
+        else hipLaunchKernelGGL((k_norm<false, 2>), dim3((unsigned)nr), dim3(256), 0, (hipStream_t)stream, *a, *d, eps, gp, sp, (uint8_t *)xh, nr);
+    }
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

@@ -41,6 +41,7 @@ SYMBOLS = [
     ("ggml_cdna4_op_norm", _int, [_vp, _vp, C.c_float, _int, _vp]),
     ("ggml_cdna4_op_norm_affine", _int, [_vp, _vp, _vp, _vp, C.c_float, _int, _vp]),
     ("ggml_cdna4_op_norm_affine_q8_K", _int, [_vp, _vp, _vp, _vp, C.c_float, _int, _int, _vp, _sz, _vp]),
+    ("ggml_cdna4_op_norm_affine_q8_0", _int, [_vp, _vp, _vp, _vp, C.c_float, _int, _int, _vp, _sz, _vp]),
     ("ggml_cdna4_op_soft_max", _int, [_vp, _vp, _vp, C.c_float, C.c_float, _vp]),
     ("ggml_cdna4_op_soft_max_ext", _int, [_vp, _vp, _vp, C.c_float, C.c_float, _int, C.c_float, _int, _vp]),
     ("ggml_cdna4_op_diag_mask_inf", _int, [_vp, _vp, _int, _vp]),

@@ -215,6 +215,9 @@ int ggml_cdna4_op_norm_affine(const ggml_cdna4_tensor * src0, const ggml_cdna4_t
  * then run ggml_cdna4_mul_mat_prepared[_fused] and no quantizer launch is paid for them.  dst: contiguous F32 rows of 256 .. 8192 values (whole superblocks). */
 int ggml_cdna4_op_norm_affine_q8_K(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * gain, const ggml_cdna4_tensor * shift, const ggml_cdna4_tensor * dst,
                                    float eps, int rms, int type, void * workspace, size_t workspace_bytes, void * stream);
+/* the same for the 32-block formats whose activations are Q8_0 (Q4_0 / Q8_0 / Q5_0 / IQ4_NL: ggml_cdna4_act_image_key == 17); rows of whole 32-value blocks, up to 8192 */
+int ggml_cdna4_op_norm_affine_q8_0(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * gain, const ggml_cdna4_tensor * shift, const ggml_cdna4_tensor * dst,
+                                   float eps, int rms, int type, void * workspace, size_t workspace_bytes, void * stream);
 /* softmax(src0*scale + slope*mask) over ne[0]; mask (F32 or F16, [ne0, ne1]) may be NULL; ALiBi slopes from
  * max_bias as ggml-cpu.c:8848-8944 */
 int ggml_cdna4_op_soft_max(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * mask, const ggml_cdna4_tensor * dst, float scale, float max_bias, void * stream);

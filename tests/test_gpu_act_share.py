@@ -71,14 +71,17 @@ def test_second_product_on_the_first_ones_image_is_bit_identical(env, t1, t2, b)
 
 
 @pytest.mark.parametrize("rms,affine", [(1, "gain"), (0, "gain_shift"), (1, "none")])
-@pytest.mark.parametrize("t,m,k,b", [(R.Q4_K, 768, 1024, 96), (R.Q6_K, 256, 512, 200), (R.Q5_K, 1024, 2048, 130), (R.Q4_K, 512, 8192, 72)])
+@pytest.mark.parametrize("t,m,k,b", [(R.Q4_K, 768, 1024, 96), (R.Q6_K, 256, 512, 200), (R.Q5_K, 1024, 2048, 130), (R.Q4_K, 512, 8192, 72),
+                                     (R.Q4_0, 2304, 768, 200), (R.Q8_0, 256, 1280, 96), (R.Q5_0, 512, 1024, 130)])
 def test_norm_that_also_leaves_the_activation_image(env, t, m, k, b, rms, affine):
     """ggml_cdna4_op_norm_affine_q8_K: the normalised rows (same bits as ggml_cdna4_op_norm_affine) AND, in the workspace, the image ggml_cdna4_mul_mat would build of them —
     ggml_cdna4_mul_mat_prepared on that workspace equals ggml_cdna4_mul_mat on the normalised rows, bit for bit (the graph's first reader of a normalised tensor pays no
     quantizer launch: plug-in try_fused_norm)"""
     from test_gpu_cabi_ops import _desc, _dev, _ok, _st
     L, native, ops = env
-    assert L.ggml_cdna4_act_image_key(int(t), m, k, b) == 19
+    kq = t in (R.Q4_K, R.Q5_K, R.Q6_K)
+    assert L.ggml_cdna4_act_image_key(int(t), m, k, b) == (19 if kq else 17)
+    norm_act = L.ggml_cdna4_op_norm_affine_q8_K if kq else L.ggml_cdna4_op_norm_affine_q8_0              # (Q8_0-class formats, round 5: gpt-2's Q4_0 layers at prompt sizes)
     rng = np.random.default_rng(k + b)
     x = (rng.standard_normal((b, k)) * 3 + 0.5).astype(np.float32)
     g = (1 + 0.1 * rng.standard_normal(k)).astype(np.float32); sh = (0.05 * rng.standard_normal(k)).astype(np.float32)
@@ -89,7 +92,7 @@ def test_norm_that_also_leaves_the_activation_image(env, t, m, k, b, rms, affine
     sp = C.byref(_desc(sd, R.F32)) if affine == "gain_shift" else None
     ws = torch.empty(max(L.ggml_cdna4_mul_mat_workspace_size(int(t), k, b), 256), dtype=torch.uint8, device="cuda")
     _ok(L, L.ggml_cdna4_op_norm_affine(C.byref(_desc(xd, R.F32)), gp, sp, C.byref(_desc(y_ref, R.F32)), 1e-5, rms, _st()))
-    _ok(L, L.ggml_cdna4_op_norm_affine_q8_K(C.byref(_desc(xd, R.F32)), gp, sp, C.byref(_desc(y_q, R.F32)), 1e-5, rms, int(t), ws.data_ptr(), ws.numel(), _st()))
+    _ok(L, norm_act(C.byref(_desc(xd, R.F32)), gp, sp, C.byref(_desc(y_q, R.F32)), 1e-5, rms, int(t), ws.data_ptr(), ws.numel(), _st()))
     rb = R.row_size(t, k)
     o_prep = torch.full((b, m), 2.0, dtype=torch.float32, device="cuda"); o_ref = torch.empty((b, m), dtype=torch.float32, device="cuda")
     _ok(L, L.ggml_cdna4_mul_mat_prepared(int(t), wd.data_ptr(), rb, o_prep.data_ptr(), m, m, k, b, ws.data_ptr(), ws.numel(), 0, 0, 0, _st()))
@@ -99,8 +102,9 @@ def test_norm_that_also_leaves_the_activation_image(env, t, m, k, b, rms, affine
     assert torch.equal(y_q.view(torch.int32), y_ref.view(torch.int32))
     assert torch.equal(o_prep.view(torch.int32), o_ref.view(torch.int32))
     assert R.rel_l2(o_ref.cpu().numpy(), R.o_mul_mat(t, w, y_ref.cpu().numpy(), m, k)) < 1e-3
-    # refusals: a Q8_0-class format, rows that are not whole superblocks
-    assert L.ggml_cdna4_op_norm_affine_q8_K(C.byref(_desc(xd, R.F32)), gp, sp, C.byref(_desc(y_q, R.F32)), 1e-5, rms, int(R.Q4_0), ws.data_ptr(), ws.numel(), _st()) != 0
+    # refusals: the other activation class
+    other = L.ggml_cdna4_op_norm_affine_q8_0 if kq else L.ggml_cdna4_op_norm_affine_q8_K
+    assert other(C.byref(_desc(xd, R.F32)), gp, sp, C.byref(_desc(y_q, R.F32)), 1e-5, rms, int(t), ws.data_ptr(), ws.numel(), _st()) != 0
 
 
 def test_prepared_fused_refuses_a_shape_without_an_image(env):
@@ -131,11 +135,11 @@ def _harness(type_, d, h, b, share):
     return j
 
 
-@pytest.mark.parametrize("type_,d,h,b,hand_offs", [("q4_K", 1024, 2816, 96, 5), ("q4_K", 1024, 2816, 16, 3), ("q4_0", 768, 3072, 128, 3), ("q6_K", 1024, 2048, 200, 5),
+@pytest.mark.parametrize("type_,d,h,b,hand_offs", [("q4_K", 1024, 2816, 96, 5), ("q4_K", 1024, 2816, 16, 3), ("q4_0", 768, 3072, 128, 5), ("q6_K", 1024, 2048, 200, 5),
                                                     ("q8_0", 512, 2048, 24, 3), ("q4_K", 1024, 2816, 1, 0), ("q4_K", 2048, 5632, 512, 5), ("q5_K", 4096, 4096, 64, 3)])       # (Q5_K at 64 rows: the int8 matrix cores — their image is not the one a NORM chain leaves)
 def test_a_layers_shared_activations_are_quantized_once_through_ggmls_public_api(type_, d, h, b, hand_offs):
-    """rms_norm -> {wq, wk, wv + bias} and rms_norm -> {w_gate, w_up} -> w_down on the plug-in: three of the six MUL_MATs multiply the previous one's image — FIVE for K-quants on
-    the fp16 GEMM routes, where the rms_norm chain's own launch leaves the image and wq / w_gate take the hand-off too (none at decode size, where the quantizer lives inside
+    """rms_norm -> {wq, wk, wv + bias} and rms_norm -> {w_gate, w_up} -> w_down on the plug-in: three of the six MUL_MATs multiply the previous one's image — FIVE on the fp16 GEMM routes
+    (K-quants: the Q8_K image; Q4_0 / Q8_0: the Q8_0 image), where the rms_norm chain's own launch leaves the image and wq / w_gate take the hand-off too (none at decode size, where the quantizer lives inside
     the GEMV launch); the outputs' bytes equal those of a run with the hand-off off.  Against the CPU backend: K and V (one product
     of exact inputs) within the 1e-3 bar.  `out` sits behind two RE-QUANTIZATIONS of computed activations: a 4e-4 difference in Q moves ~2 % of f's int8 values by one step
     (step = max|f| / 127), which is a 3e-3 difference after the next product and ~1e-2 after the one behind it — the CPU algorithm's own sensitivity to its inputs
