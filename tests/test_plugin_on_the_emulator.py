@@ -1,0 +1,69 @@
+"""The ggml plug-in's HOST logic without a GPU: ggml_amd/csrc/backend/*.cpp built a second time against a host stand-in for the HIP runtime (tools/emul/shim_plugin) and the
+whole-library CPU emulation of the kernel library, driven through ggml's PUBLIC API by oracle/_ref/split_harness (the unmodified reference's libggml-base / ggml-cpu beside it) —
+tools/emul/plugin_emul_check.py.  What a GPU session checks at full size, at sizes the emulation finishes in seconds: the graph walk and its peepholes, the hand-off of
+quantized activations between MUL_MATs of one src1, NORM chains that leave the activation image (Q8_K and Q8_0 classes), the resident buffer type and its re-layouts.
+(Test infrastructure: nothing here is a CPU path of the product — the emulated libraries live under build/ and ggml_amd/ cannot load them.)"""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def plug():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the -m gpu tests drive the real plug-in on it")
+    spec = importlib.util.spec_from_file_location("plugin_emul_check", os.path.join(ROOT, "tools", "emul", "plugin_emul_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not mod.available():
+        pytest.skip("needs the reference tree (ggml headers), oracle/_ref/split_harness and ROCm's clang")
+    return mod
+
+
+def _shared(plug, type_, d, h, b, share):
+    env = {"HARNESS_NO_TIMING": 1}
+    if not share:
+        env["GGML_CDNA4_NO_ACT_SHARE"] = 1
+    j = plug.harness([type_, d, h, b, "shared"], env=env)
+    if j is None:
+        pytest.skip("the environment cannot host the emulation")
+    return j
+
+
+@pytest.mark.parametrize("type_,d,h,b,hand_offs", [("q4_K", 256, 512, 96, 5), ("q4_0", 256, 512, 96, 5), ("q8_0", 256, 512, 16, 3), ("q4_K", 256, 512, 1, 0)])
+def test_layer_front_through_ggmls_public_api_on_the_emulated_plugin(plug, type_, d, h, b, hand_offs):
+    """rms_norm -> {wq, wk, wv + bias}, rms_norm -> {w_gate, w_up} -> w_down (oracle/split_harness.cpp `shared`): the NORM chains leave the activation image on the fp16 GEMM routes
+    (Q8_K image for K-quants, Q8_0 image for Q4_0 — the k_norm<.., 2> path that was written after the round's GPU time ran out), wk / wv / w_up multiply the previous product's
+    image, the int8 routes of 16 rows share without a producer, one row shares nothing; the outputs' bytes equal those of a run with the hand-off off; K and V within the
+    1e-3 bar of the reference CPU backend"""
+    on, off = _shared(plug, type_, d, h, b, True), _shared(plug, type_, d, h, b, False)
+    assert on["act_hand_offs_first_compute"] == hand_offs and off["act_hand_offs_first_compute"] == 0, (on, off)
+    assert on["fnv1a"] == off["fnv1a"], (on, off)
+    assert on["k_vs_cpu"] < 1e-3 and on["v_vs_cpu"] < 1e-3 and on["out_vs_cpu"] < 3e-2, on
+
+
+@pytest.mark.parametrize("type_,m,k,b", [("q4_0", 256, 512, 96), ("q8_0", 256, 512, 40), ("q6_K", 128, 512, 96), ("q5_0", 128, 256, 40), ("q4_K", 128, 256, 40)])
+def test_resident_buffer_type_on_the_emulated_plugin(plug, type_, m, k, b):
+    """the CDNA4_Resident extra buffer type (ggml_backend_dev_get_extra_bufts): weights through ggml_backend_tensor_set, MUL_MAT at prefill and decode sizes, a rewrite — against the
+    default buffer type and the CPU backend (tests/test_gpu_resident.py's plug-in test, at emulation sizes; on a 256-CU part these small grids keep their per-call kernels, so the
+    image must simply not disturb anything: bit-identical)"""
+    j = plug.harness([type_, m, k, b, "resident"], env={"HARNESS_NO_TIMING": 1})
+    if j is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert j["buft"].startswith("CDNA4_Resident") and j["set_get_roundtrip"] is True
+    assert j["decode_bit_identical_to_default"] is True
+    assert j["resident_vs_default_rel_l2"] < 1e-5 and j["rewritten_vs_default_rel_l2"] < 1e-5 and j["resident_vs_cpu_rel_l2"] < 1e-3, j
+
+
+def test_resident_q8_0_takes_k_gemm_r8_on_a_small_pretend_chip(plug):
+    """EMU_CUS=4: a 512 x 1024 x 130 Q8_0 product is a quarter .. half tile per CU — with the image the plug-in's MUL_MAT runs k_gemm_r8<Q8_0R> (co-resident split in two), without it the
+    staging kernel: same result to 1e-5, within the bar of the CPU backend"""
+    j = plug.harness(["q8_0", 512, 1024, 130, "resident"], env={"HARNESS_NO_TIMING": 1, "EMU_CUS": 4})
+    if j is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert j["resident_bit_identical_to_default"] is False              # (another kernel, another summation order)
+    assert j["resident_vs_default_rel_l2"] < 1e-5 and j["resident_vs_cpu_rel_l2"] < 1e-3 and j["decode_bit_identical_to_default"] is True, j
