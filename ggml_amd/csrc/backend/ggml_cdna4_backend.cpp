@@ -439,7 +439,7 @@ static int try_fused_norm(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, const
             if (ws && (key == 19u ? ggml_cdna4_op_norm_affine_q8_K : ggml_cdna4_op_norm_affine_q8_0)(&dx, &dg, shift ? &ds : nullptr, &dd, eps, nm->op == GGML_OP_RMS_NORM, (int)a->type, ws, ctx->ws_size, ctx->stream) == 0) {
                 act_image_note(ctx, a->type, a->ne[1], last->ne[0], last->ne[1], last->data, last->ne[0]);
                 ctx->act_image.producer = last->data;
-                ctx->n_act_produced++;
+                if (ctx->n_act_produced++ == 0 && getenv("GGML_CDNA4_STATS")) fprintf(stderr, "ggml-cdna4: %s: a NORM chain left the activation image of its %lld x %lld rows for %s (key %u)\n", ctx->name.c_str(), (long long)last->ne[1], (long long)last->ne[0], mmn->name, key);
                 return used;
             }
         }
