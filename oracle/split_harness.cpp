@@ -8,7 +8,7 @@
 //   replay   a transformer MLP block (NORM, MUL, ADD, MUL_MAT, ADD, GELU, MUL_MAT, ADD, ADD) computed again and again with changing inputs:
 //            the plug-in replays the unchanged graph from a HIP graph (stderr under GGML_CDNA4_STATS: captures / replays); every result
 //            against the CPU backend, and input A eager == input A replayed, bit for bit
-//   split_harness <plugin.so> <type: q4_K|q4_0|q8_0|q5_K|q6_K|f16> <M> <K> <B> [resident | hostptr | shared]     -> one JSON line
+//   split_harness <plugin.so> <type: q4_K|q4_0|q8_0|q5_K|q6_K|f16> <M> <K> <B> [resident | hostptr | shared | moe]     -> one JSON line
 //   shared   MUL_MATs that read the same src1 (wq / wk / wv; w_gate / w_up) take ONE activation quantization: hand-off count, output bytes' hash, time per graph
 //   resident weights in the extra buffer type CDNA4_Resident (kernel-native images of the re-encoded formats, built once): types q5_0 q3_K q2_K q4_1 q5_1 iq4_nl iq4_xs, and q4_0 (a 16-byte-aligned re-layout for Q4_K's kernels)
 #include "ggml.h"
@@ -220,6 +220,58 @@ int main(int argc, char ** argv) {
         for (const auto & y : y_gpu) for (size_t i = 0; i < y.size() * 4; i++) { h ^= ((const uint8_t *)y.data())[i]; h *= 1099511628211ull; }
         printf("{\"type\":\"%s\",\"D\":%lld,\"H\":%lld,\"B\":%lld,\"act_hand_offs_first_compute\":%d,\"fnv1a\":\"%016llx\",\"us_per_graph\":%.2f,\"k_vs_cpu\":%.3e,\"v_vs_cpu\":%.3e,\"out_vs_cpu\":%.3e}\n",
                ggml_type_name(type), (long long)D, (long long)H, (long long)B, shared, (unsigned long long)h, us, rel_l2(y_gpu[0], y_cpu[0]), rel_l2(y_gpu[1], y_cpu[1]), rel_l2(y_gpu[2], y_cpu[2]));
+        ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
+        return 0;
+    }
+
+    // ---- moe (argv[6] == "moe": only this section; B = tokens): MUL_MAT_ID over an expert stack [K, M, 4 experts], two used per token, the stack living in the device's
+    //      default buffer type and in its first EXTRA buffer type (CDNA4_Resident: a Q4_0 stack gets ONE resident image, found by the stack's pointer) — each against the
+    //      CPU backend, and against each other; prefill size (B tokens) and a single token
+    if (argc > 6 && std::string(argv[6]) == "moe") {
+        typedef ggml_backend_buffer_type_t * (*extra_fn)(ggml_backend_dev_t);
+        extra_fn get_extra = (extra_fn)ggml_backend_reg_get_proc_address(reg, "ggml_backend_dev_get_extra_bufts");
+        if (!get_extra || !get_extra(dev) || !get_extra(dev)[0]) { fprintf(stderr, "no extra buffer types\n"); return 1; }
+        const int64_t NE = 4, NU = 2;
+        std::vector<float> wf3((size_t)M * K * NE);
+        for (auto & v : wf3) v = u(rng);
+        std::vector<uint8_t> wq3(ggml_row_size(type, K) * M * NE);
+        ggml_quantize_chunk(type, wf3.data(), wq3.data(), 0, M * NE, K, NULL);
+        auto run = [&](ggml_backend_t be, ggml_backend_buffer_type_t wbuft, int64_t NT) {
+            ggml_init_params ip = { ggml_tensor_overhead() * 16 + ggml_graph_overhead(), NULL, true };
+            ggml_context * wctx = ggml_init(ip), * cctx = ggml_init(ip);
+            ggml_tensor * AS = ggml_new_tensor_3d(wctx, type, K, M, NE);
+            ggml_backend_buffer_t wbuf = ggml_backend_alloc_ctx_tensors_from_buft(wctx, wbuft);
+            if (!wbuf) { fprintf(stderr, "weight buffer allocation failed\n"); exit(1); }
+            ggml_backend_buffer_set_usage(wbuf, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
+            ggml_backend_tensor_set(AS, wq3.data(), 0, wq3.size());
+            ggml_tensor * Bt = ggml_new_tensor_3d(cctx, GGML_TYPE_F32, K, NU, NT);
+            ggml_tensor * IDS = ggml_new_tensor_2d(cctx, GGML_TYPE_I32, NU, NT);
+            ggml_set_input(Bt); ggml_set_input(IDS);
+            ggml_tensor * Y = ggml_mul_mat_id(cctx, AS, Bt, IDS);
+            ggml_set_output(Y);
+            ggml_cgraph * gf = ggml_new_graph(cctx);
+            ggml_build_forward_expand(gf, Y);
+            ggml_gallocr_t ga = ggml_gallocr_new(ggml_backend_get_default_buffer_type(be));
+            if (!ggml_gallocr_alloc_graph(ga, gf)) { fprintf(stderr, "graph allocation failed\n"); exit(1); }
+            std::vector<float> xb((size_t)K * NU * NT);
+            std::mt19937 r3(7);
+            for (auto & v : xb) v = u(r3);
+            std::vector<int32_t> ids((size_t)NU * NT);
+            for (int64_t t = 0; t < NT; t++) { const int e0 = (int)(r3() % NE); ids[t * NU] = e0; ids[t * NU + 1] = (e0 + 1 + (int)(r3() % (NE - 1))) % (int)NE; }
+            ggml_backend_tensor_set(Bt, xb.data(), 0, xb.size() * 4); ggml_backend_tensor_set(IDS, ids.data(), 0, ids.size() * 4);
+            if (ggml_backend_graph_compute(be, gf) != GGML_STATUS_SUCCESS) { fprintf(stderr, "graph_compute failed\n"); exit(1); }
+            std::vector<float> y((size_t)M * NU * NT);
+            ggml_backend_tensor_get(Y, y.data(), 0, y.size() * 4);
+            ggml_gallocr_free(ga); ggml_backend_buffer_free(wbuf); ggml_free(wctx); ggml_free(cctx);
+            return y;
+        };
+        ggml_backend_buffer_type_t rbuft = get_extra(dev)[0], dbuft = ggml_backend_dev_buffer_type(dev), cbuft = ggml_backend_get_default_buffer_type(cpu);
+        const std::vector<float> y_res = run(gpu, rbuft, B), y_def = run(gpu, dbuft, B), y_cpu = run(cpu, cbuft, B);
+        const std::vector<float> y_res1 = run(gpu, rbuft, 1), y_def1 = run(gpu, dbuft, 1), y_cpu1 = run(cpu, cbuft, 1);
+        printf("{\"type\":\"%s\",\"M\":%lld,\"K\":%lld,\"tokens\":%lld,\"n_expert\":4,\"n_used\":2,\"buft\":\"%s\",\"resident_vs_cpu_rel_l2\":%.3e,\"default_vs_cpu_rel_l2\":%.3e,\"resident_vs_default_rel_l2\":%.3e,"
+               "\"resident_bit_identical_to_default\":%s,\"one_token_vs_cpu_rel_l2\":%.3e,\"one_token_bit_identical_to_default\":%s}\n", ggml_type_name(type), (long long)M, (long long)K, (long long)B,
+               ggml_backend_buft_name(rbuft), rel_l2(y_res, y_cpu), rel_l2(y_def, y_cpu), rel_l2(y_res, y_def), memcmp(y_res.data(), y_def.data(), y_def.size() * 4) == 0 ? "true" : "false",
+               rel_l2(y_res1, y_cpu1), memcmp(y_res1.data(), y_def1.data(), y_def1.size() * 4) == 0 ? "true" : "false");
         ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
         return 0;
     }

@@ -265,6 +265,24 @@ def test_resident_buffer_type_through_ggmls_public_api(type_, m, k, b):
     assert j["resident_vs_cpu_rel_l2"] < 1e-3, j
 
 
+@pytest.mark.parametrize("type_,m,k,tokens,other_kernel", [("q4_0", 512, 1024, 256, True), ("q4_0", 4096, 4096, 512, True), ("q4_K", 512, 1024, 256, False)])
+def test_expert_stack_in_the_resident_buffer_type_through_ggmls_public_api(type_, m, k, tokens, other_kernel):
+    """MUL_MAT_ID on a 3-D expert tensor (4 experts, 2 used per token) living in the plug-in's resident buffer type, against the default buffer type and the CPU backend
+    (oracle/split_harness.cpp `moe`): a Q4_0 stack gets ONE resident image and prefill-sized calls run Q4_K's grouped kernel on it; a single token reads the source bytes.
+    (Written after round 5's GPU time ran out: emulator-verified through the emulated plug-in, tests/test_plugin_on_the_emulator.py.)"""
+    if not os.path.exists(EXE):
+        pytest.fail("prebuilt oracle/_ref/split_harness missing from the snapshot")
+    r = subprocess.run([EXE, PLUGIN, type_, str(m), str(k), str(tokens), "moe"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    os.makedirs(os.path.join(R.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(R.ROOT, "gpurun_out", "split_report.jsonl"), "a") as f:
+        f.write(json.dumps(j) + "\n")
+    assert j["resident_vs_cpu_rel_l2"] < 1e-3 and j["default_vs_cpu_rel_l2"] < 1e-3 and j["resident_vs_default_rel_l2"] < 1e-5, j
+    assert j["resident_bit_identical_to_default"] is (not other_kernel), j
+    assert j["one_token_bit_identical_to_default"] is True and j["one_token_vs_cpu_rel_l2"] < 1e-5, j
+
+
 @pytest.mark.parametrize("name,t", TYPES)
 def test_reencoding_soak_every_build_equals_the_first(env, name, t):
     """the IQ4_XS prefill route is on by default on the strength of one root-cause fix; the defence asked for is a soak over several shapes with a

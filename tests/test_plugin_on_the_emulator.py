@@ -67,3 +67,16 @@ def test_resident_q8_0_takes_k_gemm_r8_on_a_small_pretend_chip(plug):
         pytest.skip("the environment cannot host the emulation")
     assert j["resident_bit_identical_to_default"] is False              # (another kernel, another summation order)
     assert j["resident_vs_default_rel_l2"] < 1e-5 and j["resident_vs_cpu_rel_l2"] < 1e-3 and j["decode_bit_identical_to_default"] is True, j
+
+
+@pytest.mark.parametrize("type_,m,k,tokens,other_kernel", [("q4_0", 128, 512, 100, True), ("q4_K", 128, 256, 70, False)])
+def test_expert_stack_in_the_resident_buffer_type_on_the_emulated_plugin(plug, type_, m, k, tokens, other_kernel):
+    """MUL_MAT_ID through ggml's public API (oracle/split_harness.cpp `moe`: a 3-D expert tensor, 4 experts, 2 used): a Q4_0 stack in the resident buffer type gets ONE image and
+    prefill-sized calls run Q4_K's grouped kernel on it (another kernel than the default buffer type's: not bit-identical, 1e-5 apart); a Q4_K stack needs no image (bit-identical);
+    a single token reads the source bytes either way"""
+    j = plug.harness([type_, m, k, tokens, "moe"], env={"HARNESS_NO_TIMING": 1})
+    if j is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert j["resident_vs_cpu_rel_l2"] < 1e-3 and j["default_vs_cpu_rel_l2"] < 1e-3 and j["resident_vs_default_rel_l2"] < 1e-5, j
+    assert j["resident_bit_identical_to_default"] is (not other_kernel), j
+    assert j["one_token_bit_identical_to_default"] is True and j["one_token_vs_cpu_rel_l2"] < 1e-5, j
