@@ -107,6 +107,31 @@ def test_norm_that_also_leaves_the_activation_image(env, t, m, k, b, rms, affine
     assert other(C.byref(_desc(xd, R.F32)), gp, sp, C.byref(_desc(y_q, R.F32)), 1e-5, rms, int(t), ws.data_ptr(), ws.numel(), _st()) != 0
 
 
+@pytest.mark.parametrize("t,k,b", [(R.Q4_0, 800, 5), (R.Q4_0, 96, 3), (R.Q8_0, 1056, 4), (R.Q4_0, 768, 200), (R.Q4_K, 768, 9), (R.Q6_K, 2048, 33), (R.Q5_K, 8192, 3)])
+def test_the_image_a_norm_leaves_is_prepare_acts_image_byte_for_byte(env, t, k, b):
+    """ggml_cdna4_op_norm_affine_q8_K / _q8_0 against ggml_cdna4_op_norm_affine + ggml_cdna4_prepare_act(PATH_GEMM): the fp32 rows and every byte of the fp16 image in the
+    workspace (capi.hip: carve — [qs][d][bsums][xh]); rows whose groups of four do not fill the last wave (800 = 200 groups, 96 = 24), a ragged last 128-panel (1056)"""
+    from test_gpu_cabi_ops import _desc, _dev, _ok, _st
+    L, native, ops = env
+    kq = t in (R.Q4_K, R.Q5_K, R.Q6_K)
+    rng = np.random.default_rng(k + b)
+    x = _dev((rng.standard_normal((b, k)) * 2).astype(np.float32)); g = _dev((1 + 0.1 * rng.standard_normal(k)).astype(np.float32))
+    y1 = torch.empty((b, k), dtype=torch.float32, device="cuda"); y2 = torch.empty((b, k), dtype=torch.float32, device="cuda")
+    n = max(L.ggml_cdna4_mul_mat_workspace_size(int(t), k, b), 256)
+    ws1 = torch.zeros(n, dtype=torch.uint8, device="cuda"); ws2 = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    _ok(L, L.ggml_cdna4_op_norm_affine(C.byref(_desc(x, R.F32)), C.byref(_desc(g, R.F32)), None, C.byref(_desc(y1, R.F32)), 1e-5, 1, _st()))
+    _ok(L, L.ggml_cdna4_prepare_act(int(t), y1.data_ptr(), k, k, b, ws1.data_ptr(), ws1.numel(), 2, _st()))
+    fn = L.ggml_cdna4_op_norm_affine_q8_K if kq else L.ggml_cdna4_op_norm_affine_q8_0
+    _ok(L, fn(C.byref(_desc(x, R.F32)), C.byref(_desc(g, R.F32)), None, C.byref(_desc(y2, R.F32)), 1e-5, 1, int(t), ws2.data_ptr(), ws2.numel(), _st()))
+    torch.cuda.synchronize()
+    a256 = lambda v: (v + 255) // 256 * 256
+    off = a256(b * k) + a256(b * (k // (256 if kq else 32)) * 4) + a256(b * (k // 16) * 2)
+    nimg = b * ((k + 127) // 128 * 128) * 2
+    assert torch.equal(y1.view(torch.int32), y2.view(torch.int32))
+    img1, img2 = ws1[off:off + nimg].cpu().numpy(), ws2[off:off + nimg].cpu().numpy()
+    assert (img1 != 0).sum() > nimg // 4 and np.array_equal(img1, img2)
+
+
 def test_prepared_fused_refuses_a_shape_without_an_image(env):
     from test_gpu_cabi_ops import _dev, _st
     L, native, ops = env

@@ -57,7 +57,7 @@ SELECTION_R3.append(("test_gpu_resident.py", "test_q8_0_and_q6_K_resident_images
 # grouped MUL_MAT_ID on Q4_0 experts through a resident image of the expert stack: k_gemm_kq_t64<Q4_0R, 128, IDS> with the plan's tile order
 SELECTION_R3.append(("test_gpu_resident.py", "test_q4_0_expert_stack and 128-512", 1))
 # the hand-off of quantized activations: the second product on the first one's image (C-ABI: act_image_key, mul_mat_prepared[_fused]) is bit-identical to quantizing again
-SELECTION_R3.append(("test_gpu_act_share.py", "(test_second_product and 16) or test_prepared_fused_refuses or (test_norm_that_also and (256-512 or 2304-768) and 1-gain)", 7))
+SELECTION_R3.append(("test_gpu_act_share.py", "(test_second_product and 16) or test_prepared_fused_refuses or (test_norm_that_also and (256-512 or 2304-768) and 1-gain) or (test_the_image_a_norm_leaves and not 8192 and not 768-200)", 12))
 
 
 @pytest.mark.parametrize("fname,sel,at_least,extra_env", [s if len(s) == 4 else s + ({},) for s in SELECTION_R3])
