@@ -51,16 +51,29 @@ def gemm_asm(tmp_path_factory):
     return _isa_tool().asm_of("gemm_q_mfma.hip")          # (cached compile shared with the manifest check: tools/isa_manifest.py)
 
 
-def _prop(asm, kernel, name):
-    m = re.search(r"\.set %s\.%s, (\d+)" % (re.escape(kernel), name), asm)
-    assert m, "kernel %s not found in the assembly" % kernel
-    return int(m.group(1))
+def _prop(asm, kernel, name):                                        # (plain finds: the assembly of one source is tens of MB)
+    key = ".set %s.%s, " % (kernel, name)
+    i = asm.find(key)
+    assert i >= 0, "kernel %s not found in the assembly" % kernel
+    return int(re.match(r"\d+", asm[i + len(key):i + len(key) + 16]).group(0))
+
+
+def _loops(body):
+    """the depth-1 loops of a kernel body: from each loop header to the first s_cbranch_scc1 behind it (plain finds: a lazy DOTALL regex is quadratic on a chunk without one)"""
+    out = []
+    for chunk in body.split("Loop Header: Depth=1")[1:]:
+        j = chunk.find("s_cbranch_scc1")
+        if j >= 0:
+            out.append(chunk[:j + len("s_cbranch_scc1")])
+    return out
 
 
 def _lds(asm, kernel):
-    m = re.search(r"\.amdhsa_kernel %s\n(?:.*\n)*?\s+\.amdhsa_group_segment_fixed_size (\d+)" % re.escape(kernel), asm)
-    assert m, kernel
-    return int(m.group(1))
+    i = asm.find(".amdhsa_kernel %s\n" % kernel)
+    assert i >= 0, kernel
+    key = ".amdhsa_group_segment_fixed_size "
+    j = asm.index(key, i)
+    return int(re.match(r"\d+", asm[j + len(key):j + len(key) + 16]).group(0))
 
 
 # mangled names: k_gemm_kq_w12<Q4_K, true, 0>, k_gemm_kq_w8p<Q5_K, false>, k_gemm_kq_w8<Q4_K, false, 20>
@@ -84,6 +97,10 @@ def test_64x128_wave_tile_kernel_resources(tmp_path):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
     asm = _isa_tool().asm_of("gemm_q_t64.hip")
+
+    def body_of(k):                                                     # (a 24-MB text: plain finds, not a DOTALL regex per kernel)
+        i = asm.index("\n" + k + ":")
+        return asm[i + 1:asm.index("\n.Lfunc_end", i)]
     # the plain product (TAIL = false; the tail-carrying twin shares the main loop) and — round 5 — the one-launch step that carries the activation quantizer and the
     # grid barrier in its prologue (FQ = true): the loop must be the same loop, in particular without a scratch access in it (a spill there would also break the
     # kernel's counted vmcnt waits, which assume that LDS-DMA is the only vector-memory traffic of the loop)
@@ -93,11 +110,11 @@ def test_64x128_wave_tile_kernel_resources(tmp_path):
         assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= 256
         assert _prop(asm, k, "private_seg_size") <= max_scratch
         assert _lds(asm, k) <= 160 * 1024
-        body = re.search(r"^%s:.*?^\.Lfunc_end" % re.escape(k), asm, re.S | re.M).group(0)
+        body = body_of(k)
         # the steady-state stage pairs — one copy of the loop for the four loader waves, one for the others: no scratch access inside
         # (the 256-row form parks a few loader-only address registers in scratch AROUND the loops), 32 / 64 MFMAs each
         # (a loop = from its header to the first backward branch BEFORE the next loop's header: the quantizer's rolled loop in the FQ prologue ends in another branch form)
-        loops = [m.group(0) for chunk in body.split("Loop Header: Depth=1")[1:] for m in [re.search(r".*?s_cbranch_scc1", chunk, re.S)] if m]
+        loops = _loops(body)
         main = [lp for lp in loops if lp.count("v_mfma_f32_32x32x16_f16") == (32 if tm == 128 else 64)]
         assert len(main) == 2 and all("scratch_" not in lp for lp in main)
         assert sorted(lp.count("global_load_lds_dwordx4") for lp in main)[0] == 0        # the non-loader copy issues no LDS-DMA at all
@@ -106,8 +123,8 @@ def test_64x128_wave_tile_kernel_resources(tmp_path):
         for tm in (128, 256):
             k = "_Z13k_gemm_kq_t64ILi%dELi%dELb1ELi0ELb0ELb0EEv11gemm_params" % (ty, tm)
             assert _prop(asm, k, "num_vgpr") + _prop(asm, k, "num_agpr") <= 256 and _lds(asm, k) <= 160 * 1024
-            body = re.search(r"^%s:.*?^\.Lfunc_end" % re.escape(k), asm, re.S | re.M).group(0)
-            loops = [m.group(0) for chunk in body.split("Loop Header: Depth=1")[1:] for m in [re.search(r".*?s_cbranch_scc1", chunk, re.S)] if m]
+            body = body_of(k)
+            loops = _loops(body)
             mf = [lp for lp in loops if "v_mfma_f32_32x32x16_f16" in lp]
             assert len(mf) >= 2 and all("scratch_" not in lp for lp in mf), k
     # nothing in this file loads into registers asynchronously: round 2's first version did (superblock headers, inline-asm
@@ -115,7 +132,8 @@ def test_64x128_wave_tile_kernel_resources(tmp_path):
     # thousand got garbage constants on the GPU, invisibly to the CPU emulator.  Headers go through LDS (DMA) now.
     # (round 5: the one-launch step's prologue loads the fp32 activations into registers — compiler-issued, compiler-counted loads in front of the grid barrier, never
     #  beside the loop's hand-counted LDS-DMA: every one of them precedes the kernel's first MFMA; the kernels without the quantizer still have none)
-    for name, kbody in re.findall(r"^(_Z13k_gemm_kq_t64\w+):(.*?)^\.Lfunc_end", asm, re.S | re.M):
+    for name in sorted(set(re.findall(r"^(_Z13k_gemm_kq_t64\w+):", asm, re.M))):
+        kbody = body_of(name)
         regloads = [m.start() for m in re.finditer(r"global_load_dwordx[24] v", kbody)]
         if name.endswith("ELb1EEv11gemm_params"):
             assert regloads and max(regloads) < kbody.index("v_mfma_f32_32x32x16_f16"), name

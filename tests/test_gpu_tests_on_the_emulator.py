@@ -47,20 +47,31 @@ SELECTION_R3 = [("test_gpu_parity.py", "test_small_batches_on_the_int8_matrix_co
 
 # round 5: resident kernel-native images — the registry, the verified build, the lookup of row slices and the bit-identity of the routes that use an image are host logic
 # as much as kernels
-SELECTION_R3.append(("test_gpu_resident.py", "(test_resident_image_serves_prefill and (q5_0 or iq4_xs)) or (test_dequantize_row_of_the_image and q3_K)", 3))
+SELECTION_R3.append(("test_gpu_resident.py", "(test_resident_image_serves_prefill and q5_0) or (test_dequantize_row_of_the_image and q3_K)", 2))
 # Q4_0 on Q4_K's kernels through a resident Q4_0R image: k_gemm_kq_t64 128-row tiles (and the tail in its store); with EMU_CUS=4 the routes a 256-CU part takes at full size —
 # k_gemm_r8 (whole rounds of 256 x 256 tiles) and k_gemm_kq_t64's 256-row tiles
 SELECTION_R3.append(("test_gpu_resident.py", "(test_q4_0_resident_image_puts and (512-1024-96 or 300-768)) or (test_q4_0_resident_image_carries and 768-512)", 4))
 SELECTION_R3.append(("test_gpu_resident.py", "test_q4_0_resident_image_puts and (1024-512-256 or 1280-512-200)", 2, {"EMU_CUS": "4"}))
 # Q8_0 on k_gemm_r8 through a resident Q8_0R image: whole rounds, one ragged round, the co-resident split in two (EMU_CUS=4), and the unchanged small-grid route
-SELECTION_R3.append(("test_gpu_resident.py", "test_q8_0_and_q6_K_resident_images_put and (512-1024-256 or 768-512-200)", 4, {"EMU_CUS": "4"}))
+SELECTION_R3.append(("test_gpu_resident.py", "test_q8_0_and_q6_K_resident_images_put and (512-1024-256 or (14 and 768-512-200))", 3, {"EMU_CUS": "4"}))
 # grouped MUL_MAT_ID on Q4_0 experts through a resident image of the expert stack: k_gemm_kq_t64<Q4_0R, 128, IDS> with the plan's tile order
 SELECTION_R3.append(("test_gpu_resident.py", "test_q4_0_expert_stack and 128-512", 1))
 # the hand-off of quantized activations: the second product on the first one's image (C-ABI: act_image_key, mul_mat_prepared[_fused]) is bit-identical to quantizing again
-SELECTION_R3.append(("test_gpu_act_share.py", "(test_second_product and 16) or test_prepared_fused_refuses or (test_norm_that_also and (256-512 or 2304-768) and 1-gain) or (test_the_image_a_norm_leaves and not 8192 and not 768-200)", 12))
+SELECTION_R3.append(("test_gpu_act_share.py", "(test_second_product and 16) or test_prepared_fused_refuses or (test_norm_that_also and (256-512 or 2304-768) and 1-gain) or (test_the_image_a_norm_leaves and (800-5 or 96-3 or 768-9))", 10))
 
 
-@pytest.mark.parametrize("fname,sel,at_least,extra_env", [s if len(s) == 4 else s + ({},) for s in SELECTION_R3])
+def _merged(selections):
+    """one pytest process per (test file, environment): the selections of a group joined with `or`, their minimum counts added (a process start costs ~10 s)"""
+    groups = {}
+    for s_ in selections:
+        fname, sel, at_least, env = s_ if len(s_) == 4 else s_ + ({},)
+        key = (fname, tuple(sorted(env.items())))
+        g = groups.setdefault(key, [fname, [], 0, env])
+        g[1].append("(" + sel + ")"); g[2] += at_least
+    return [(g[0], " or ".join(g[1]), g[2], g[3]) for g in groups.values()]
+
+
+@pytest.mark.parametrize("fname,sel,at_least,extra_env", _merged(SELECTION_R3), ids=lambda v: v if isinstance(v, str) and v.endswith(".py") else None)
 def test_round3_routes_pass_on_the_emulator(fname, sel, at_least, extra_env):
     if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
         pytest.skip("ROCm clang not available")

@@ -59,6 +59,7 @@ def test_resident_buffer_type_on_the_emulated_plugin(plug, type_, m, k, b):
     assert j["resident_vs_default_rel_l2"] < 1e-5 and j["rewritten_vs_default_rel_l2"] < 1e-5 and j["resident_vs_cpu_rel_l2"] < 1e-3, j
 
 
+@pytest.mark.skipif(not os.environ.get("CDNA4_FULL_CPU_SUITE"), reason="35 s: the C-ABI selection of tests/test_gpu_tests_on_the_emulator.py covers k_gemm_r8<Q8_0R>; CDNA4_FULL_CPU_SUITE=1 runs it through the plug-in too")
 def test_resident_q8_0_takes_k_gemm_r8_on_a_small_pretend_chip(plug):
     """EMU_CUS=4: a 512 x 1024 x 130 Q8_0 product is a quarter .. half tile per CU — with the image the plug-in's MUL_MAT runs k_gemm_r8<Q8_0R> (co-resident split in two), without it the
     staging kernel: same result to 1e-5, within the bar of the CPU backend"""
