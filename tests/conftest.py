@@ -6,6 +6,25 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (no GPU in the box) spreads over three pytest-xdist workers when the plug-in is installed and nobody asked for a worker count: its long tests are CPU
+    emulations of kernels in child processes (12 min serially, 7 on three workers).  Never with a GPU: the -m gpu tests share ONE device and some kernels wait for
+    co-resident work-groups of their own launch.  CDNA4_TESTS_SERIAL=1 keeps one process."""
+    if os.environ.get("CDNA4_TESTS_SERIAL") or os.environ.get("PYTEST_XDIST_WORKER") or os.environ.get("CDNA4_TESTS_ON_EMULATOR") == "1":
+        return None
+    if getattr(config.option, "numprocesses", "absent") is not None:      # no xdist, or -n given
+        return None
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return None
+    except Exception:  # noqa: BLE001
+        return None
+    config.option.numprocesses = 3
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     if os.environ.get("CDNA4_TESTS_ON_EMULATOR") == "1":
