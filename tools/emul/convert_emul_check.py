@@ -20,6 +20,16 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 Q5_0, Q8_0, Q2_K, Q3_K, Q6_K, Q4_1, Q5_1, IQ4_NL, IQ4_XS = 6, 8, 10, 11, 14, 3, 7, 20, 23
 
 
+import importlib.util as _ilu
+import sys as _sys
+_blm = _sys.modules.get("cdna4_emul_buildlock")                        # (one instance per process: its lock is re-entrant by a process-wide depth count)
+if _blm is None:
+    _bl = _ilu.spec_from_file_location("cdna4_emul_buildlock", __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "buildlock.py"))
+    _blm = _ilu.module_from_spec(_bl); _sys.modules["cdna4_emul_buildlock"] = _blm; _bl.loader.exec_module(_blm)
+_locked = _blm.locked          # (xdist workers share build/: one build at a time)
+
+
+@_locked
 def build():
     exe = os.path.join(HERE, "convert_emul")
     srcs = [os.path.join(HERE, "convert_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(ROOT, "ggml_amd", "csrc", f)

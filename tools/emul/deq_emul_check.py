@@ -20,6 +20,16 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 F16_FIELDS = {R.Q4_0: [0], R.Q4_1: [0, 2], R.Q5_0: [0], R.Q5_1: [0, 2], R.Q8_0: [0], R.Q2_K: [80, 82], R.Q3_K: [108], R.Q4_K: [0, 2], R.Q5_K: [0, 2], R.Q6_K: [208], R.IQ4_NL: [0], R.IQ4_XS: [0]}
 
 
+import importlib.util as _ilu
+import sys as _sys
+_blm = _sys.modules.get("cdna4_emul_buildlock")                        # (one instance per process: its lock is re-entrant by a process-wide depth count)
+if _blm is None:
+    _bl = _ilu.spec_from_file_location("cdna4_emul_buildlock", __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "buildlock.py"))
+    _blm = _ilu.module_from_spec(_bl); _sys.modules["cdna4_emul_buildlock"] = _blm; _bl.loader.exec_module(_blm)
+_locked = _blm.locked          # (xdist workers share build/: one build at a time)
+
+
+@_locked
 def build():
     exe = os.path.join(HERE, "deq_emul")
     csrc = os.path.join(ROOT, "ggml_amd", "csrc")

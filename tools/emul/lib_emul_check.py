@@ -25,6 +25,16 @@ TUS = ["capi.hip", "quantize_act.hip", "convert_w.hip", "gemv_q.hip", "mmq_i8.hi
 FLAGS = ["-std=c++17", "-O1", "-pthread", "-ffp-contract=off", "-I" + os.path.join(HERE, "shim"), "-I" + HERE, "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), "-Wno-unused-value"]
 
 
+import importlib.util as _ilu
+import sys as _sys
+_blm = _sys.modules.get("cdna4_emul_buildlock")                        # (one instance per process: its lock is re-entrant by a process-wide depth count)
+if _blm is None:
+    _bl = _ilu.spec_from_file_location("cdna4_emul_buildlock", __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "buildlock.py"))
+    _blm = _ilu.module_from_spec(_bl); _sys.modules["cdna4_emul_buildlock"] = _blm; _bl.loader.exec_module(_blm)
+_locked = _blm.locked          # (xdist workers share build/: one build at a time)
+
+
+@_locked
 def build():
     os.makedirs(OBJ, exist_ok=True)
     exe = os.path.join(OBJ, "lib_emul")
@@ -47,6 +57,7 @@ def build():
     return exe
 
 
+@_locked
 def build_so():
     """the same build as a shared library with the library's C-ABI (+ fattn.hip, + cdna4_emul_alloc): tests/emul_torch.py"""
     pic = os.path.join(OBJ, "pic")

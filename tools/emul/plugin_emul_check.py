@@ -23,6 +23,16 @@ def available():
     return os.path.exists(os.path.join(REF, "src", "ggml-backend-impl.h")) and os.path.exists(HARNESS) and os.path.exists(L.CLANG)
 
 
+import importlib.util as _ilu
+import sys as _sys
+_blm = _sys.modules.get("cdna4_emul_buildlock")                        # (one instance per process: its lock is re-entrant by a process-wide depth count)
+if _blm is None:
+    _bl = _ilu.spec_from_file_location("cdna4_emul_buildlock", __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "buildlock.py"))
+    _blm = _ilu.module_from_spec(_bl); _sys.modules["cdna4_emul_buildlock"] = _blm; _bl.loader.exec_module(_blm)
+_locked = _blm.locked          # (xdist workers share build/: one build at a time)
+
+
+@_locked
 def build():
     so = L.build_so()
     out = os.path.join(os.path.dirname(so), "libggml-cdna4-emul.so")
