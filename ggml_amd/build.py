@@ -24,7 +24,7 @@ ARCH = "gfx950"
 # -ffp-contract=off: the activation quantizers must round iscale*x before the int conversion, like the CPU
 HIPFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
-KERNEL_SRCS = ["quantize_act.hip", "gemv_q.hip", "mmq_i8.hip", "gemm_q_mfma.hip", "gemm_q_t64.hip", "gemm_q_lds.hip", "convert_w.hip", "ops.hip", "exact.hip", "fattn.hip", "capi.hip", "gguf_reader.cpp", "gguf_upload.hip"]
+KERNEL_SRCS = ["quantize_act.hip", "gemv_q.hip", "mmq_i8.hip", "gemm_q_mfma.hip", "gemm_q_t64.hip", "gemm_q_sk.hip", "gemm_q_lds.hip", "convert_w.hip", "ops.hip", "exact.hip", "fattn.hip", "capi.hip", "gguf_reader.cpp", "gguf_upload.hip"]
 BACKEND_SRCS = ["backend/ggml_cdna4_backend.cpp", "backend/ggml_cdna4_ops.cpp", "backend/ggml_cdna4_split.cpp"]
 
 

@@ -22,7 +22,14 @@
 struct cdna4_device_ctx { int device; std::string name, description; };
 struct cdna4_buft_ctx   { int device; std::string name; bool resident = false; };
 // resident: the buffer keeps, beside every eligible weight matrix, its kernel-native image (ggml_cdna4_resident_image_*): see the CDNA4_Resident buffer type below
-struct cdna4_resident_tensor { ggml_tensor * tensor; void * image; size_t written; bool registered; };
+// Everything the image needs is kept BY VALUE: the ggml contract lets the ggml_context (and with it every ggml_tensor) be freed before the buffer — the reference's own gpt-2
+// program does (examples/gpt-2/main-backend.cpp:936-939: ggml_free(ctx_w), then ggml_backend_buffer_free(buffer_w)) — so nothing here may touch the tensor after init_tensor
+// (the first version kept the ggml_tensor pointer and read ->data / ->ne in free_buffer).
+struct cdna4_resident_tensor {
+    void * data; int type; int64_t ne0, rows, nb1; size_t nbytes; std::string name;      // the weight: address, ggml type, K, ne[1] * ne[2], row stride, byte size
+    void * image; size_t written; bool registered;
+    bool overlaps(const void * p, size_t n) const { return (const char *)p < (const char *)data + nbytes && (const char *)data < (const char *)p + n; }
+};
 struct cdna4_buffer_ctx { int device; void * base; size_t size; bool resident = false; std::vector<cdna4_resident_tensor> res; bool host_registered = false; };
 
 static ggml_backend_reg_t ggml_backend_cdna4_reg(void);
@@ -36,7 +43,7 @@ static void cdna4_buffer_free(ggml_backend_buffer_t buffer) {
     HIP_OK(hipSetDevice(ctx->device));
     HIP_OK(hipDeviceSynchronize());
     for (cdna4_resident_tensor & r : ctx->res) {
-        if (r.registered) (void)ggml_cdna4_resident_image_unregister(r.tensor->data);
+        if (r.registered) (void)ggml_cdna4_resident_image_unregister(r.data);
         if (r.image) HIP_OK(hipFree(r.image));
     }
     if (ctx->host_registered) { HIP_OK(hipHostUnregister(ctx->base)); delete ctx; return; }      // (buffer_from_host_ptr: the memory is the host's)
@@ -58,26 +65,39 @@ static void cdna4_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor
 // ---- CDNA4_Resident: a weight written into such a buffer gets its kernel-native image built ONCE, when its last byte has arrived (set_tensor / cpy_tensor: the
 // reference repacks at the same moment, src/ggml-cpu/ggml-cpu-aarch64.cpp:4144-4172) — built twice and compared (a re-encoding that is not bit-stable is refused: the tensor
 // then simply has no image and every call re-encodes as before).  The original bytes stay in the buffer: get_tensor is the plain copy, decode reads them, views work.
-static cdna4_resident_tensor * resident_find(cdna4_buffer_ctx * ctx, const ggml_tensor * tensor) {
-    for (cdna4_resident_tensor & r : ctx->res) if (r.tensor == tensor || r.tensor->data == tensor->data) return &r;
+// the weight whose bytes [p, p + n) touches: matched by ADDRESS RANGE — a set_tensor / memset / cpy on a view at a non-zero offset (a row range of a
+// weight) or a graph node writing into a weight must find the image too, or prefill (the image) and decode (the source bytes) silently disagree
+static cdna4_resident_tensor * resident_find(cdna4_buffer_ctx * ctx, const void * p, size_t n) {
+    for (cdna4_resident_tensor & r : ctx->res) if (r.overlaps(p, n ? n : 1)) return &r;
     return nullptr;
 }
 static void resident_invalidate(cdna4_resident_tensor * r) {
-    if (r->registered) { (void)ggml_cdna4_resident_image_unregister(r->tensor->data); r->registered = false; }
+    if (r->registered) { (void)ggml_cdna4_resident_image_unregister(r->data); r->registered = false; }
 }
-static void resident_written(cdna4_buffer_ctx * ctx, ggml_tensor * tensor, size_t offset, size_t size) {
+// bytes [p, p + n) of the buffer have been rewritten
+static void resident_written_range(cdna4_buffer_ctx * ctx, const void * p, size_t n) {
+    if (!ctx->resident || n == 0) return;
+    for (cdna4_resident_tensor & r : ctx->res) {
+        if (!r.overlaps(p, n)) continue;
+        resident_invalidate(&r);
+        const char * lo = (const char *)p > (const char *)r.data ? (const char *)p : (const char *)r.data;
+        const char * hi = (const char *)p + n < (const char *)r.data + r.nbytes ? (const char *)p + n : (const char *)r.data + r.nbytes;
+        const size_t got = (size_t)(hi - lo);
+        r.written = (lo == (const char *)r.data && got >= r.nbytes) ? r.nbytes : r.written + got;       // (loaders write whole tensors; pieces are counted until they add up)
+        if (r.written < r.nbytes) continue;
+        r.written = 0;
+        // (rows = ne[1] * ne[2]: a contiguous expert stack is one image, found by the stack's pointer in MUL_MAT_ID)
+        if (ggml_cdna4_resident_image_register(r.type, r.data, r.nb1, r.rows, r.ne0, r.image, 1, nullptr) == 0) r.registered = true;
+        else fprintf(stderr, "ggml-cdna4: no resident image for %s: %s\n", r.name.c_str(), ggml_cdna4_last_error());
+    }
+}
+static void resident_written(cdna4_buffer_ctx * ctx, ggml_tensor * tensor, size_t offset, size_t size) { resident_written_range(ctx, (const char *)tensor->data + offset, size); }
+// a graph node wrote [p, p + n) (run_nodes): a weight underneath loses its image until it is written whole again (CPY / SET_ROWS into a weight, a quantized KV tensor
+// that was placed in this buffer type) — the per-call routes then read the source bytes, as the decode kernels always do
+static void cdna4_resident_node_wrote(ggml_backend_buffer_t buffer, const void * p, size_t n) {
+    cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
     if (!ctx->resident) return;
-    cdna4_resident_tensor * r = resident_find(ctx, tensor);
-    if (!r) return;
-    resident_invalidate(r);
-    const size_t total = ggml_nbytes(r->tensor);
-    r->written = (offset == 0 && size >= total) ? total : r->written + size;       // (loaders write whole tensors; pieces are counted until they add up)
-    if (r->written < total) return;
-    r->written = 0;
-    const ggml_tensor * t = r->tensor;
-    // (rows = ne[1] * ne[2]: a contiguous expert stack is one image, found by the stack's pointer in MUL_MAT_ID)
-    if (ggml_cdna4_resident_image_register((int)t->type, t->data, (int64_t)t->nb[1], t->ne[1] * t->ne[2], t->ne[0], r->image, 1, nullptr) == 0) r->registered = true;
-    else fprintf(stderr, "ggml-cdna4: no resident image for %s: %s\n", t->name, ggml_cdna4_last_error());
+    for (cdna4_resident_tensor & r : ctx->res) if (r.registered && r.overlaps(p, n)) { resident_invalidate(&r); r.written = 0; }
 }
 static void cdna4_resident_init_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor) {
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
@@ -85,11 +105,11 @@ static void cdna4_resident_init_tensor(ggml_backend_buffer_t buffer, ggml_tensor
     if (tensor->view_src || tensor->ne[3] != 1 || !ggml_is_contiguous(tensor) || (tensor->ne[2] != 1 && tensor->type != GGML_TYPE_Q4_0)) return;
     const size_t bytes = ggml_cdna4_resident_image_size((int)tensor->type, tensor->ne[1] * tensor->ne[2], tensor->ne[0]);
     if (bytes == 0) return;                                                         // a type that needs no image (or no MUL_MAT weight at all)
-    if (resident_find(ctx, tensor)) return;
+    if (resident_find(ctx, tensor->data, ggml_nbytes(tensor))) return;
     HIP_OK(hipSetDevice(ctx->device));
     void * img = nullptr;
     if (hipMalloc(&img, bytes) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "ggml-cdna4: no memory for the resident image of %s (per-call re-encoding stays)\n", tensor->name); return; }
-    ctx->res.push_back(cdna4_resident_tensor{tensor, img, 0, false});
+    ctx->res.push_back(cdna4_resident_tensor{tensor->data, (int)tensor->type, tensor->ne[0], tensor->ne[1] * tensor->ne[2], (int64_t)tensor->nb[1], ggml_nbytes(tensor), tensor->name, img, 0, false});
 }
 static void cdna4_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
     cdna4_buffer_ctx * ctx = (cdna4_buffer_ctx *)buffer->context;
@@ -221,21 +241,28 @@ static std::atomic<int> g_act_shared{0};
 extern "C" int ggml_backend_cdna4_act_shared_count(void) { return g_act_shared.load(); }
 static bool act_share_on() { static const bool off = getenv("GGML_CDNA4_NO_ACT_SHARE") != nullptr; return !off && !cdna4_exact_mode(); }
 // does the workspace hold the image a MUL_MAT of (type, M, K, B) over X would build?
-static bool act_image_ready(const cdna4_backend_ctx * ctx, ggml_type type, int64_t M, int64_t K, int64_t B, const void * X, int64_t x_stride, size_t need) {
+static bool act_image_ready(const cdna4_backend_ctx * ctx, const ggml_tensor * a, int64_t M, int64_t K, int64_t B, const void * X, int64_t x_stride, size_t need) {
     const auto & im = ctx->act_image;
     if (!act_share_on() || !im.key || im.uses != ctx->ws_uses || im.x != X || im.x_stride != x_stride || im.K != K || im.B != B || need > ctx->ws_size) return false;
-    return ggml_cdna4_act_image_key((int)type, M, K, B) == im.key;
+    return ggml_cdna4_act_image_key_of((int)a->type, a->data, (int64_t)a->nb[1], M, K, B) == im.key;
 }
-// a ggml_cdna4_mul_mat[_fused] call of (type, M, K, B) over X has just been issued on the workspace
-static void act_image_note(cdna4_backend_ctx * ctx, ggml_type type, int64_t M, int64_t K, int64_t B, const void * X, int64_t x_stride) {
+// a ggml_cdna4_mul_mat[_fused] call of weight a (M x K) with B rows of X has just been issued on the workspace.  The key is the CONCRETE matrix's (its alignment decides
+// whether the few-row call wrote the int8 image or quantized inside a one-launch GEMV and left the workspace alone: ADVICE r5)
+static void act_image_note(cdna4_backend_ctx * ctx, const ggml_tensor * a, int64_t M, int64_t K, int64_t B, const void * X, int64_t x_stride) {
     auto & im = ctx->act_image;
-    im.key = act_share_on() ? ggml_cdna4_act_image_key((int)type, M, K, B) : 0;
+    im.key = act_share_on() ? ggml_cdna4_act_image_key_of((int)a->type, a->data, (int64_t)a->nb[1], M, K, B) : 0;
     im.x = X; im.x_stride = x_stride; im.K = K; im.B = B; im.x_bytes = (size_t)((B - 1) * x_stride + K) * sizeof(float); im.uses = ctx->ws_uses;
 }
 // a node has written [p, p + n): activations that overlap it are no longer the ones the image was made of
 static void act_image_written(cdna4_backend_ctx * ctx, const void * p, size_t n) {
     auto & im = ctx->act_image;
     if (im.key && (const char *)p < (const char *)im.x + im.x_bytes && (const char *)im.x < (const char *)p + n) im.key = 0;
+}
+// ... and a weight of a CDNA4_Resident buffer underneath it loses its kernel-native image (CPY / SET_ROWS into a weight, a quantized KV tensor placed there)
+static void node_wrote(cdna4_backend_ctx * ctx, const ggml_tensor * t) {
+    act_image_written(ctx, t->data, ggml_nbytes(t));
+    ggml_backend_buffer_t buf = t->view_src ? t->view_src->buffer : t->buffer;
+    if (buffer_is_cdna4(buf) && ((cdna4_buffer_ctx *)buf->context)->resident) cdna4_resident_node_wrote(buf, t->data, ggml_nbytes(t));
 }
 
 static enum ggml_status compute_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * dst) {
@@ -250,12 +277,11 @@ static enum ggml_status compute_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * d
     const int64_t nbatch = collapse ? 1 : b->ne[2] * b->ne[3];
     const int64_t Bc = collapse ? N * b->ne[2] * b->ne[3] : N;
     const size_t need = exact ? ggml_cdna4_mul_mat_exact_workspace_size((int)a->type, K, Bc) : ggml_cdna4_mul_mat_workspace_size((int)a->type, K, Bc);
-    if (nbatch == 1 && !exact && act_image_ready(ctx, a->type, M, K, Bc, b->data, (int64_t)(b->nb[1] / sizeof(float)), need)) {
+    if (nbatch == 1 && !exact && act_image_ready(ctx, a, M, K, Bc, b->data, (int64_t)(b->nb[1] / sizeof(float)), need)) {
         // the previous MUL_MAT quantized these very activations into the workspace: multiply them (the image stays valid for the next reader)
         if (ggml_cdna4_mul_mat_prepared((int)a->type, a->data, (int64_t)a->nb[1], (float *)dst->data, (int64_t)(dst->nb[1] / sizeof(float)), M, K, Bc, ctx->ws, ctx->ws_size,
-                                        GGML_CDNA4_PATH_AUTO, 0, 0, ctx->stream)) { fprintf(stderr, "ggml-cdna4: MUL_MAT failed: %s\n", ggml_cdna4_last_error()); return GGML_STATUS_FAILED; }
-        ctx->n_act_shared++; g_act_shared++;
-        return GGML_STATUS_SUCCESS;
+                                        GGML_CDNA4_PATH_AUTO, 0, 0, ctx->stream) == 0) { ctx->n_act_shared++; g_act_shared++; return GGML_STATUS_SUCCESS; }
+        ctx->act_image.key = 0;                                         // (refused before any launch: the plain call below quantizes again — ADVICE r5)
     }
     void * ws = ctx->need_ws(need);
     if (!ws) return GGML_STATUS_ALLOC_FAILED;
@@ -270,7 +296,7 @@ static enum ggml_status compute_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * d
                                                   M, K, Bc, ws, ctx->ws_size, GGML_CDNA4_PATH_AUTO, 0, 0, ctx->stream);
         if (rc) { fprintf(stderr, "ggml-cdna4: MUL_MAT failed: %s\n", ggml_cdna4_last_error()); return GGML_STATUS_FAILED; }
     }
-    if (nbatch == 1 && !exact) act_image_note(ctx, a->type, M, K, Bc, b->data, (int64_t)(b->nb[1] / sizeof(float)));
+    if (nbatch == 1 && !exact) act_image_note(ctx, a, M, K, Bc, b->data, (int64_t)(b->nb[1] / sizeof(float)));
     return GGML_STATUS_SUCCESS;
 }
 
@@ -382,17 +408,17 @@ static int try_fused_mul_mat(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, co
     // whose nodes run fine one by one
     if (resid && resid->data == last->data && resid->nb[1] != last->nb[1]) return 0;
     const size_t need = ggml_cdna4_mul_mat_workspace_size((int)a->type, K, B);
-    if (act_image_ready(ctx, a->type, M, K, B, b->data, (int64_t)(b->nb[1] / sizeof(float)), need)) {         // (compute_mul_mat: the hand-off of quantized activations)
+    if (act_image_ready(ctx, a, M, K, B, b->data, (int64_t)(b->nb[1] / sizeof(float)), need)) {         // (compute_mul_mat: the hand-off of quantized activations)
         if (ggml_cdna4_mul_mat_prepared_fused((int)a->type, a->data, (int64_t)a->nb[1], (float *)last->data, (int64_t)(last->nb[1] / sizeof(float)), M, K, B, (const float *)bias->data, act,
-                                              resid ? (const float *)resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / sizeof(float)) : 0, ctx->ws, ctx->ws_size, ctx->stream)) {
-            fprintf(stderr, "ggml-cdna4: fused MUL_MAT failed: %s\n", ggml_cdna4_last_error()); st = GGML_STATUS_FAILED;
+                                              resid ? (const float *)resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / sizeof(float)) : 0, ctx->ws, ctx->ws_size, ctx->stream) == 0) {
+            ctx->n_act_shared++; g_act_shared++;
+            return used;
         }
-        ctx->n_act_shared++; g_act_shared++;
-        return used;
+        ctx->act_image.key = 0;                                         // (refused before any launch: the plain fused call below quantizes again — ADVICE r5)
     }
     void * ws = ctx->need_ws(need);
     if (!ws) { st = GGML_STATUS_ALLOC_FAILED; return used; }
-    act_image_note(ctx, a->type, M, K, B, b->data, (int64_t)(b->nb[1] / sizeof(float)));
+    act_image_note(ctx, a, M, K, B, b->data, (int64_t)(b->nb[1] / sizeof(float)));
     const int rc = ggml_cdna4_mul_mat_fused((int)a->type, a->data, (int64_t)a->nb[1], (const float *)b->data, (int64_t)(b->nb[1] / sizeof(float)),
                                             (float *)last->data, (int64_t)(last->nb[1] / sizeof(float)), M, K, B, (const float *)bias->data, act,
                                             resid ? (const float *)resid->data : nullptr, resid ? (int64_t)(resid->nb[1] / sizeof(float)) : 0, ws, ctx->ws_size, ctx->stream);
@@ -437,7 +463,7 @@ static int try_fused_norm(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, const
             const size_t need = ggml_cdna4_mul_mat_workspace_size((int)a->type, last->ne[0], last->ne[1]);
             void * ws = ctx->need_ws(need);
             if (ws && (key == 19u ? ggml_cdna4_op_norm_affine_q8_K : ggml_cdna4_op_norm_affine_q8_0)(&dx, &dg, shift ? &ds : nullptr, &dd, eps, nm->op == GGML_OP_RMS_NORM, (int)a->type, ws, ctx->ws_size, ctx->stream) == 0) {
-                act_image_note(ctx, a->type, a->ne[1], last->ne[0], last->ne[1], last->data, last->ne[0]);
+                act_image_note(ctx, a, a->ne[1], last->ne[0], last->ne[1], last->data, last->ne[0]);
                 ctx->act_image.producer = last->data;
                 if (ctx->n_act_produced++ == 0 && getenv("GGML_CDNA4_STATS")) fprintf(stderr, "ggml-cdna4: %s: a NORM chain left the activation image of its %lld x %lld rows for %s (key %u)\n", ctx->name.c_str(), (long long)last->ne[1], (long long)last->ne[0], mmn->name, key);
                 return used;
@@ -508,7 +534,7 @@ static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph)
             if (used) {
                 ggml_tensor * last = ggml_graph_node(cgraph, i + used - 1);     // (a chain writes its last node only)
                 if (ctx->act_image.producer == last->data) ctx->act_image.producer = nullptr;      // (the chain itself made the image of what it wrote)
-                else act_image_written(ctx, last->data, ggml_nbytes(last));
+                else node_wrote(ctx, last);
                 i += used - 1; continue;
             }
         }
@@ -523,7 +549,7 @@ static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph)
             return st;
         }
         if (node->op != GGML_OP_NONE && node->op != GGML_OP_RESHAPE && node->op != GGML_OP_VIEW && node->op != GGML_OP_PERMUTE && node->op != GGML_OP_TRANSPOSE)
-            act_image_written(ctx, node->data, ggml_nbytes(node));
+            node_wrote(ctx, node);
     }
     return GGML_STATUS_SUCCESS;
 }
@@ -544,7 +570,9 @@ static enum ggml_status cdna4_backend_graph_compute(ggml_backend_t backend, ggml
     if (no_graphs || ctx->graphs_off || ggml_graph_n_nodes(cgraph) < 2) return run_nodes(ctx, cgraph);
     uint64_t sig = graph_signature(cgraph);
     if (sig == 0) sig = 1;                                                     // (0 marks an unused slot)
-    // addresses the captured launches hold beyond the tensors': this context's workspace and the kernel library's scratch
+    // addresses and decisions the captured launches hold beyond the tensors': this context's workspace, the kernel library's scratch, and whether a weight's resident
+    // image was found and where (ggml_cdna4_scratch_generation also moves with every image registered or unregistered: ADVICE r5 — a partial set_tensor that drops an
+    // image, or a freed Resident buffer whose successor lands at the same address, must not replay launches that read the old image)
     const uint64_t gen = ggml_cdna4_scratch_generation() * 0x9E3779B97F4A7C15ull + ctx->ws_gen;
     cdna4_backend_ctx::graph_slot * slot = nullptr, * lru = &ctx->graph_slots[0];
     for (auto & gs : ctx->graph_slots) {
@@ -595,9 +623,11 @@ static void cdna4_backend_set_tensor_async(ggml_backend_t backend, ggml_tensor *
     ggml_backend_buffer_t buf = tensor->view_src ? tensor->view_src->buffer : tensor->buffer;
     GGML_ASSERT(buffer_is_cdna4(buf) && "set_tensor_async: the tensor must live in a buffer of this backend");
     HIP_OK(hipSetDevice(ctx->device));
-    HIP_OK(hipMemcpyAsync((char *)tensor->data + offset, data, size, hipMemcpyHostToDevice, ctx->stream));
     cdna4_buffer_ctx * bctx = (cdna4_buffer_ctx *)buf->context;
-    if (bctx->resident && resident_find(bctx, tensor)) { HIP_OK(hipStreamSynchronize(ctx->stream)); resident_written(bctx, tensor, offset, size); }   // (a weight with an image: the image follows its bytes)
+    // (buffer_from_host_ptr: the destination is the HOST's own memory — a plain copy behind whatever the stream still reads from it)
+    if (bctx->host_registered) { HIP_OK(hipStreamSynchronize(ctx->stream)); memcpy((char *)tensor->data + offset, data, size); return; }
+    HIP_OK(hipMemcpyAsync((char *)tensor->data + offset, data, size, hipMemcpyHostToDevice, ctx->stream));
+    if (bctx->resident && resident_find(bctx, (const char *)tensor->data + offset, size)) { HIP_OK(hipStreamSynchronize(ctx->stream)); resident_written(bctx, tensor, offset, size); }   // (a weight with an image: the image follows its bytes)
 }
 static void cdna4_backend_get_tensor_async(ggml_backend_t backend, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
@@ -667,6 +697,7 @@ extern "C" void * cdna4_backend_scratch(void * ctx, size_t n) { return ((cdna4_b
 // ============================================================================================================
 // device
 static const char * cdna4_dev_get_name(ggml_backend_dev_t dev) { return ((cdna4_device_ctx *)dev->context)->name.c_str(); }
+static bool cdna4_host_ptr_buffers_on() { static const bool on = getenv("GGML_CDNA4_HOST_PTR_BUFFERS") && atoi(getenv("GGML_CDNA4_HOST_PTR_BUFFERS")) != 0; return on; }
 static const char * cdna4_dev_get_description(ggml_backend_dev_t dev) { return ((cdna4_device_ctx *)dev->context)->description.c_str(); }
 static void cdna4_dev_get_memory(ggml_backend_dev_t dev, size_t * free, size_t * total) {
     HIP_OK(hipSetDevice(((cdna4_device_ctx *)dev->context)->device));
@@ -678,7 +709,10 @@ static void cdna4_dev_get_props(ggml_backend_dev_t dev, ggml_backend_dev_props *
     props->description = cdna4_dev_get_description(dev);
     props->type = GGML_BACKEND_DEVICE_TYPE_GPU;
     cdna4_dev_get_memory(dev, &props->memory_free, &props->memory_total);
-    props->caps = { /* async */ true, /* host_buffer */ true, /* buffer_from_host_ptr */ true, /* events */ true };
+    // buffer_from_host_ptr stays FALSE unless asked for (GGML_CDNA4_HOST_PTR_BUFFERS=1), like the reference's GPU backends (ggml-cuda.cu:2919 leaves the cap false and the
+    // slot NULL): llama.cpp checks the cap when use_mmap is on (its default) and would wrap the whole weight file — every offloaded weight then read over PCIe (63 GB/s against
+    // 8 TB/s), or, where hipHostRegister refuses the PROT_READ file mapping, "unable to allocate buffer" instead of a device buffer + copies
+    props->caps = { /* async */ true, /* host_buffer */ true, /* buffer_from_host_ptr */ cdna4_host_ptr_buffers_on(), /* events */ true };
 }
 static ggml_backend_t cdna4_dev_init_backend(ggml_backend_dev_t dev, const char *) {
     cdna4_device_ctx * dctx = (cdna4_device_ctx *)dev->context;
@@ -740,6 +774,7 @@ static ggml_backend_buffer_type_t cdna4_dev_get_host_buffer_type(ggml_backend_de
 // Meant for weights that are read rarely or must not be duplicated; prefill over the host link is bound by it (PCIe Gen5 x16: 63 GB/s).
 static ggml_backend_buffer_t cdna4_dev_buffer_from_host_ptr(ggml_backend_dev_t dev, void * ptr, size_t size, size_t /* max_tensor_size */) {
     const int device = ((cdna4_device_ctx *)dev->context)->device;
+    if (!cdna4_host_ptr_buffers_on()) return NULL;                      // (opt-in: see get_props)
     if (!ptr || size == 0 || hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return NULL; }
     if (hipHostRegister(ptr, size, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return NULL; }
     void * dptr = nullptr;

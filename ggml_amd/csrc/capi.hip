@@ -51,6 +51,28 @@ static moe_view moe_carve(int64_t K, int64_t n_expert, int64_t n_used, int64_t n
     return v;
 }
 
+// the stream-k form of the grouped MUL_MAT_ID (round 6; quantize_act.hip: cdna4_launch_moe_sk_front, gemm_q_sk.hip): tile records, the spans, and the fp16 image of the
+// n_tok * n_b activation rows in TOKEN order (the GEMM gathers a tile's rows itself: no per-pair copies, no padding rows)
+struct moe_sk_view { int32_t *tile_rec, *wg_begin; void *xh; int64_t n_rows, ntile_cap; size_t total; };
+static moe_sk_view moe_sk_carve(int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok, void *base) {
+    moe_sk_view v; uint8_t *p = (uint8_t *)base; size_t off = 0;
+    const int64_t n_pairs = n_tok * n_used;
+    v.n_rows = n_tok * n_b;
+    v.ntile_cap = (n_expert < n_pairs ? n_expert : n_pairs) + n_pairs / 128 + 1;          // >= sum_e ceil(cnt_e / 128)
+    v.tile_rec = (int32_t *)(p + off); off += align256((size_t)v.ntile_cap * CDNA4_SK_REC * 4);
+    v.wg_begin = (int32_t *)(p + off); off += align256((size_t)(1024 + 2) * 4);
+    v.xh = (void *)(p + off); off += align256((size_t)v.n_rows * K * 2) + 32768;
+    v.total = off;
+    return v;
+}
+// does ggml_cdna4_mul_mat_id take the stream-k form for this call?  Q4_K experts (Q4_0 with a resident image asks with CDNA4_Q4_0R); CDNA4_MOE_SK=0: the per-tile launches
+static bool moe_sk_on(int type, int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok) {
+    static const bool off = getenv("CDNA4_MOE_SK") && atoi(getenv("CDNA4_MOE_SK")) == 0;
+    if (off || n_expert > 1024) return false;
+    const moe_sk_view v = moe_sk_carve(K, n_expert, n_used, n_b, n_tok, nullptr);
+    return cdna4_gemm_sk_supported(type, M, K, v.n_rows, v.ntile_cap);
+}
+
 extern "C" {
 
 int ggml_cdna4_api_version(void) { return GGML_CDNA4_API_VERSION; }
@@ -84,7 +106,9 @@ size_t ggml_cdna4_mul_mat_id_workspace_size(int type, int64_t K, int64_t n_exper
     if (!is_q(type) || K <= 0 || n_tok <= 0 || n_used <= 0 || n_b <= 0 || n_expert <= 0) return 0;
     const size_t plain = carve(type, K, n_tok * n_b, nullptr).total;
     if (!cdna4_gemm_ids_supported(type, K) || n_tok * n_used <= 32) return plain;
-    const size_t grouped = moe_carve(K, n_expert, n_used, n_tok, nullptr).total;
+    size_t grouped = moe_carve(K, n_expert, n_used, n_tok, nullptr).total;
+    // (the stream-k form's carve — Q4_K, and Q4_0 in case its stack has a resident image; M is not known here: its tables do not depend on it)
+    if ((type == CDNA4_Q4_K || type == CDNA4_Q4_0) && K % 256 == 0 && n_expert <= 1024) { const size_t sk = moe_sk_carve(K, n_expert, n_used, n_b, n_tok, nullptr).total; if (sk > grouped) grouped = sk; }
     return grouped > plain ? grouped : plain;
 }
 
@@ -414,6 +438,13 @@ uint32_t ggml_cdna4_act_image_key(int type, int64_t M, int64_t K, int64_t B) {
     if (path != GGML_CDNA4_PATH_GEMM && !mmq) return 0;                 // (the GEMV forms below the matrix-core kernels: one launch, or their own staged variant)
     return 1u | (is_kq(type) ? 2u : 0u) | (cdna4_is_q81(type) ? 4u : 0u) | (cdna4_convert_weights_kmul(type) == 2 ? 8u : 0u) | (path == GGML_CDNA4_PATH_GEMM ? 16u : 0u);
 }
+// the key of the call on a CONCRETE weight matrix: a few-row call (int8 class) on rows that are not 16-byte aligned does not take the int8 matrix-core kernel — it may
+// quantize inside a one-launch GEMV and leave the workspace untouched (mul_mat_impl) — so such a call names no image
+uint32_t ggml_cdna4_act_image_key_of(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, int64_t B) {
+    const uint32_t key = ggml_cdna4_act_image_key(type, M, K, B);
+    if (key && !(key & 16u) && (((uintptr_t)W | (uintptr_t)w_row_bytes) & (type == CDNA4_Q6_K ? 1 : 15))) return 0;
+    return key;
+}
 // NORM / RMS_NORM [* gain] [+ shift] that ALSO leaves, in `workspace`, the activation image a following ggml_cdna4_mul_mat(type, .., X = dst, K = dst->ne[0], B = its rows)
 // would build — for the calls whose ggml_cdna4_act_image_key is the K-quants' fp16 GEMM image (19): the MUL_MATs of dst then run ggml_cdna4_mul_mat_prepared[_fused] and
 // the graph pays no quantizer launch for them at all.  dst's fp32 rows are written exactly as ggml_cdna4_op_norm_affine writes them; the image is bit-identical to
@@ -470,6 +501,36 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
     // (ggml_compute_forward_mul_mat_id groups the same way on the host: ggml-cpu.c:7648-7781)
     if (cdna4_gemm_ids_supported(type, K) && n_tok * n_used > 32 && n_expert <= 1024 && workspace && !((uintptr_t)workspace & 255) &&
         !(((uintptr_t)as | (uintptr_t)w_row_bytes | (uintptr_t)w_expert_bytes) & 1) && !(((uintptr_t)b | (uintptr_t)(b_row_stride * 4)) & 15)) {
+        // Q4_K experts, and Q4_0 experts whose stack has a RESIDENT Q4_0R image (ggml's 3-D expert tensor, rows back to back; found by the stack's pointer): the stream-k form —
+        // TWO launches (planner + token-order quantizer; one persistent grouped GEMM that gathers its rows), round 6
+        {
+            int sk_type = -1; const uint8_t *skW = (const uint8_t *)as; int64_t sk_row = w_row_bytes, sk_exp = w_expert_bytes;
+            if (type == CDNA4_Q4_K && !(((uintptr_t)as | (uintptr_t)w_row_bytes | (uintptr_t)w_expert_bytes) & 15)) sk_type = CDNA4_Q4_K;
+            else if (type == CDNA4_Q4_0 && K % 256 == 0 && w_expert_bytes == M * w_row_bytes) {
+                const uint8_t *img = cdna4_resident_lookup(CDNA4_Q4_0, as, w_row_bytes, M * n_expert, K);
+                if (img && !((uintptr_t)img & 15)) { sk_type = CDNA4_Q4_0R; skW = img; sk_row = (K / 256) * 144; sk_exp = M * sk_row; }
+            }
+            if (sk_type >= 0 && moe_sk_on(sk_type, M, K, n_expert, n_used, n_b, n_tok)) {
+                const moe_sk_view sv = moe_sk_carve(K, n_expert, n_used, n_b, n_tok, workspace);
+                if (workspace_bytes >= sv.total) {
+                    // cost of one (tile, m-tile, superblock) unit by the tile's fragments in use (1 .. 4), relative: the weight traffic and unpack work of a unit do not
+                    // depend on the fragments, its MFMAs and activation reads do (CDNA4_SK_CW=a,b,c,d: measurement knob)
+                    struct sk_costs { int c[4]; sk_costs() : c{11, 14, 17, 20} { int t4[4]; const char *ev = getenv("CDNA4_SK_CW");
+                        if (ev && sscanf(ev, "%d,%d,%d,%d", &t4[0], &t4[1], &t4[2], &t4[3]) == 4 && t4[0] > 0 && t4[1] > 0 && t4[2] > 0 && t4[3] > 0 && t4[3] < 256) for (int i = 0; i < 4; i++) c[i] = t4[i]; } };
+                    static const sk_costs costs;
+                    const int *cw = costs.c;
+                    const int G = cdna4_gemm_sk_spans();
+                    const int64_t upt = ((M + 127) / 128) * (K / 256);
+                    int rc = cdna4_launch_moe_sk_front(ids, ids_tok_stride, (int)n_tok, (int)n_used, (int)n_b, (int)n_expert, (int)sv.ntile_cap, (int)upt, G, cw, sv.tile_rec, sv.wg_begin,
+                                                       b, b_row_stride, K, sk_type == CDNA4_Q4_K, sv.xh, (hipStream_t)stream);
+                    if (rc) return rc;
+                    cdna4_gemm_args a{};
+                    a.type = sk_type; a.W = skW; a.w_row_bytes = sk_row; a.xh = sv.xh; a.xh_row_elems = K;
+                    a.Y = dst; a.y_row_elems = dst_row_stride; a.M = (int)M; a.K = (int)K; a.B = (int)sv.n_rows;
+                    return cdna4_launch_gemm_sk(a, sv.tile_rec, sv.wg_begin, G, sk_exp, (hipStream_t)stream);
+                }
+            }
+        }
         const moe_view mv = moe_carve(K, n_expert, n_used, n_tok, workspace);
         if (workspace_bytes >= mv.total && mv.img_rows * K * 2 < ((int64_t)1 << 31)) {
             int rc = cdna4_launch_moe_plan(ids, ids_tok_stride, (int)n_tok, (int)n_used, (int)n_b, (int)n_expert, (int)mv.img_rows, mv.img_src, mv.img_dst, mv.tile_expert, (hipStream_t)stream);

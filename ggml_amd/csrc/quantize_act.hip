@@ -28,12 +28,12 @@ __device__ __forceinline__ u32x2 pack4h(half_t a, half_t b, half_t c, half_t d) 
 // CONSECUTIVE elements per lane, i.e. four 16-byte loads at a 64-byte lane stride: each instruction touched 64 lines for a quarter of their bytes —
 // 6.8 us for the 512 x 4096 headline batch, 0.23 of HBM; VERDICT r3 "weak 5".)  The selection of the largest |x| (first index wins, signed value kept)
 // does not care which elements a lane holds as long as it scans them in rising index order; 4 butterfly rounds over the 16 lanes.
-__global__ __launch_bounds__(256) void k_quantize_q8_K(const float *__restrict__ x, int64_t x_row_stride, int K, int B,
-                                                       int8_t *__restrict__ qs, float *__restrict__ dd,
-                                                       int16_t *__restrict__ bsums, half_t *__restrict__ xh, const int32_t *__restrict__ src_rows) {
+// (the body as a device function of the launch-wide thread index t: k_quantize_q8_K below, and the work-groups behind the planner in k_moe_sk_front)
+__device__ __forceinline__ void quantize_q8_K_thread(const int64_t t, const float *__restrict__ x, int64_t x_row_stride, int K, int B,
+                                                     int8_t *__restrict__ qs, float *__restrict__ dd,
+                                                     int16_t *__restrict__ bsums, half_t *__restrict__ xh, const int32_t *__restrict__ src_rows) {
     const int nsb = K / QK_K;                                                // superblocks per row
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;              // (superblock over [B][nsb], lane l of 16)
-    const int64_t sbi = t >> 4;
+    const int64_t sbi = t >> 4;                                              // (superblock over [B][nsb], lane l = t & 15 of 16)
     if (sbi >= (int64_t)B * nsb) return;                                     // whole 16-lane groups drop out together
     const int l = (int)(t & 15), b = (int)(sbi / nsb), sb = (int)(sbi % nsb);
     // src_rows (grouped MUL_MAT_ID): output row b is the quantized input row src_rows[b]; < 0 = padding row, left untouched
@@ -90,14 +90,18 @@ __global__ __launch_bounds__(256) void k_quantize_q8_K(const float *__restrict__
         }
     }
 }
+__global__ __launch_bounds__(256) void k_quantize_q8_K(const float *__restrict__ x, int64_t x_row_stride, int K, int B,
+                                                       int8_t *__restrict__ qs, float *__restrict__ dd,
+                                                       int16_t *__restrict__ bsums, half_t *__restrict__ xh, const int32_t *__restrict__ src_rows) {
+    quantize_q8_K_thread((int64_t)blockIdx.x * 256 + threadIdx.x, x, x_row_stride, K, B, qs, dd, bsums, xh, src_rows);
+}
 
 // 8 lanes per 32-element block, 4 consecutive elements per lane.  REF=false: AVX2 semantics
 // (d = amax/127 -> fp16, id = 127/amax, RNE); REF=true: _ref semantics (id = 1/d, roundf ties away).
 template <bool REF>
-__global__ __launch_bounds__(256) void k_quantize_q8_0(const float *__restrict__ x, int64_t x_row_stride, int K, int B,
-                                                       int8_t *__restrict__ qs, float *__restrict__ dd, half_t *__restrict__ xh, const int32_t *__restrict__ src_rows) {
-    const int nb = K / 32;
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;             // one thread per 4 elements
+__device__ __forceinline__ void quantize_q8_0_thread(const int64_t t, const float *__restrict__ x, int64_t x_row_stride, int K, int B,
+                                                     int8_t *__restrict__ qs, float *__restrict__ dd, half_t *__restrict__ xh, const int32_t *__restrict__ src_rows) {
+    const int nb = K / 32;                                                  // (t: one thread per 4 elements)
     const int64_t blk = t >> 3;
     if (blk >= (int64_t)B * nb) return;                                     // whole 8-lane groups drop out together
     const int b = (int)(blk / nb), ib = (int)(blk % nb), sub = (int)(t & 7);
@@ -120,6 +124,11 @@ __global__ __launch_bounds__(256) void k_quantize_q8_0(const float *__restrict__
         const int64_t k = (int64_t)ib * 32 + sub * 4;
         *reinterpret_cast<u32x2 *>(xh + ((k >> 7) * B + b) * 128 + (k & 127)) = pack4h(h[0], h[2], h[1], h[3]);
     }
+}
+template <bool REF>
+__global__ __launch_bounds__(256) void k_quantize_q8_0(const float *__restrict__ x, int64_t x_row_stride, int K, int B,
+                                                       int8_t *__restrict__ qs, float *__restrict__ dd, half_t *__restrict__ xh, const int32_t *__restrict__ src_rows) {
+    quantize_q8_0_thread<REF>((int64_t)blockIdx.x * 256 + threadIdx.x, x, x_row_stride, K, B, qs, dd, xh, src_rows);
 }
 
 // Q8_1 — what the CPU backend quantizes the activations of Q4_1 / Q5_1 weights to (AVX2 body of quantize_row_q8_1,
@@ -225,6 +234,131 @@ int cdna4_launch_moe_plan(const int32_t *ids, int64_t ids_tok_stride, int n_tok,
                           int32_t *img_src, int32_t *img_dst, int32_t *tile_expert, hipStream_t st) {
     if (n_expert > 1024) return cdna4_set_error_msg("moe_plan: more than 1024 experts");
     hipLaunchKernelGGL(k_moe_plan, dim3(1), dim3(1024), 0, st, ids, ids_tok_stride, n_tok, n_used, n_b, n_expert, img_rows, img_src, img_dst, tile_expert);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+// ---- grouped MUL_MAT_ID, round 6: the front of the stream-k form — ONE launch whose work-group 0 plans and whose other work-groups quantize.
+// The activations are quantized in TOKEN order (row = token * n_b + slot % n_b: n_tok * n_b rows, not one per (token, slot) pair and no padding rows) — the grouped GEMM
+// (k_gemm_kq_sk, gemm_kq_sk.inc) gathers a tile's rows by index in its LDS-DMA, so the quantizer does not depend on the plan and the two share a launch.
+// The plan (what the CPU does on one thread before its per-expert mul_mats, ggml-cpu.c:7679-7694, and what ggml-cuda.cu:1975-1978 copies the ids to the HOST for):
+//   * counts per expert, tiles of up to 128 (token, slot) rows per expert — a tile RECORD per tile: [expert, rows, index within the expert, 32-row fragments with rows,
+//     src row of each of the 128 tile rows (padding rows: 0, a valid row), dst (token, slot) pair of each (padding: -1)];
+//   * the partition of the launch's work — (tile, m-tile, superblock) units, linear index u = (tile * tiles_m + m-tile) * nsb + superblock, weighted by the tile's fragment
+//     count — into G contiguous spans of equal cost: wg_begin[0 .. G] (the reference's stream-k decomposition, src/ggml-cuda/mmq.cuh:2588-2655, with weights).
+// Everything is a function of the ids alone except the ORDER of an expert's rows within its tiles (LDS atomics) — and no output element depends on its row's position.
+struct moe_sk_args {
+    const int32_t *ids; int64_t ids_tok_stride; int n_tok, n_used, n_b, n_expert;
+    int ntile_cap;                     // tile records the table can hold (>= min(n_expert, pairs) + pairs / 128)
+    int upt;                           // units per activation tile: tiles_m * nsb
+    int G;                             // work-groups of the GEMM launch
+    int cw[4];                         // cost of one unit of a tile with 1 .. 4 fragments (relative)
+    int32_t *tile_rec;                 // [ntile_cap][CDNA4_SK_REC]
+    int32_t *wg_begin;                 // [G + 2]: unit index where work-group w starts; [G] = end; [G + 1] = tiles in use
+};
+// in-place exclusive prefix sum of a[0 .. n) in LDS by the whole work-group (NT threads); a[n] = the total
+template <int NT> __device__ __forceinline__ void block_excl_scan(int *a, int n, int *tmp) {
+    const int tid = threadIdx.x, per = (n + NT - 1) / NT, lo = min(n, tid * per), hi = min(n, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; i++) s += a[i];
+    tmp[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < NT; d <<= 1) {
+        const int v = tid >= d ? tmp[tid - d] : 0;
+        __syncthreads();
+        tmp[tid] += v;
+        __syncthreads();
+    }
+    int run = tmp[tid] - s;
+    for (int i = lo; i < hi; i++) { const int v = a[i]; a[i] = run; run += v; }
+    if (tid == NT - 1) a[n] = tmp[NT - 1];
+    __syncthreads();
+}
+// first index i in [0, n) with a[i] > v (a non-decreasing), n if none
+__device__ __forceinline__ int upper_bound_i(const int *a, int n, long long v) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)a[mid] > v) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+__device__ void moe_sk_plan(const moe_sk_args &a) {
+    constexpr int NT = 256, REC = CDNA4_SK_REC;
+    __shared__ int cnt[1024], pos[1024], tpre[1025], cpre[CDNA4_SK_MAX_TILES + 1], tmp[NT];
+    __shared__ uint8_t trows[CDNA4_SK_MAX_TILES + 1];                   // rows of tile t, minus one
+    const int tid = threadIdx.x, n_pairs = a.n_tok * a.n_used, ne = a.n_expert;
+    for (int e = tid; e < ne; e += NT) { cnt[e] = 0; pos[e] = 0; }
+    __syncthreads();
+    for (int pr = tid; pr < n_pairs; pr += NT) {
+        const int e = a.ids[(int64_t)(pr / a.n_used) * a.ids_tok_stride + pr % a.n_used];
+        if (e >= 0 && e < ne) atomicAdd(&cnt[e], 1);
+    }
+    __syncthreads();
+    for (int e = tid; e < ne; e += NT) tpre[e] = (cnt[e] + 127) >> 7;
+    __syncthreads();
+    block_excl_scan<NT>(tpre, ne, tmp);
+    const int ntl = min(tpre[ne], a.ntile_cap);                          // (never more than the capacity by construction: the launcher sized it)
+    // tile headers, and the tiles' unit costs
+    for (int t = tid; t < ntl; t += NT) {
+        const int e = upper_bound_i(tpre, ne + 1, t) - 1, local = t - tpre[e];
+        const int rows = min(128, cnt[e] - 128 * local), nfrag = (rows + 31) >> 5;
+        int32_t *rec = a.tile_rec + (int64_t)t * REC;
+        rec[0] = e; rec[1] = rows; rec[2] = local; rec[3] = nfrag;
+        cpre[t] = a.cw[nfrag - 1]; trows[t] = (uint8_t)(rows - 1);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < ntl * 128; idx += NT) {                    // padding rows read activation row 0 and store nothing (the pairs below never write these entries)
+        const int t = idx >> 7, i = idx & 127;
+        if (i > (int)trows[t]) { int32_t *rec = a.tile_rec + (int64_t)t * REC; rec[4 + i] = 0; rec[132 + i] = -1; }
+    }
+    block_excl_scan<NT>(cpre, ntl, tmp);
+    // the spans: cost position of unit (t, l) = cpre[t] * upt + l * cw_t; work-group w starts at the first unit at or behind w / G of the total.  Fewer work-groups take
+    // part when the whole job is small (each gets at least about two superblocks of a full tile)
+    const long long CT = (long long)cpre[ntl] * a.upt;
+    long long geff = CT / (2 * (long long)a.cw[3]);
+    geff = geff < 1 ? 1 : (geff > a.G ? a.G : geff);
+    const long long u_end = (long long)ntl * a.upt;
+    for (int w = tid; w <= a.G; w += NT) {
+        long long u = u_end;
+        if (w < geff && ntl > 0) {
+            const long long x = CT * w / geff;
+            const int t = upper_bound_i(cpre, ntl + 1, x / a.upt) - 1;      // cpre[t] * upt <= x < cpre[t + 1] * upt
+            const long long c = cpre[t + 1] - cpre[t], rem = x - (long long)cpre[t] * a.upt;
+            u = (long long)t * a.upt + (rem + c - 1) / c;
+        }
+        a.wg_begin[w] = (int32_t)u;
+    }
+    if (tid == 0) a.wg_begin[a.G + 1] = ntl;
+    // the rows of every tile: pair pr = (token, slot) is row `rank` of its expert's run, in arrival order
+    for (int pr = tid; pr < n_pairs; pr += NT) {
+        const int tok = pr / a.n_used, slot = pr % a.n_used;
+        const int e = a.ids[(int64_t)tok * a.ids_tok_stride + slot];
+        if (e < 0 || e >= ne) continue;                                  // out-of-range id: the slot stays unwritten (as documented)
+        const int rank = atomicAdd(&pos[e], 1), t = tpre[e] + (rank >> 7);
+        if (t >= ntl) continue;
+        int32_t *rec = a.tile_rec + (int64_t)t * REC;
+        rec[4 + (rank & 127)] = tok * a.n_b + slot % a.n_b;              // slot u reads activation row u % n_b (ggml-cpu.c:7752)
+        rec[132 + (rank & 127)] = pr;
+    }
+}
+template <bool KQ>
+__global__ __launch_bounds__(256) void k_moe_sk_front(const moe_sk_args a, const float *__restrict__ x, int64_t x_row_stride, int K, int B, half_t *__restrict__ xh) {
+    if (blockIdx.x == 0) { moe_sk_plan(a); return; }
+    const int64_t t = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x;
+    if constexpr (KQ) quantize_q8_K_thread(t, x, x_row_stride, K, B, nullptr, nullptr, nullptr, xh, nullptr);
+    else quantize_q8_0_thread<false>(t, x, x_row_stride, K, B, nullptr, nullptr, xh, nullptr);
+}
+// x: the n_tok * n_b activation rows (x_row_stride apart); kq: Q8_K (K-quants) or Q8_0 rounding of the image; tile_rec / wg_begin: see moe_sk_args
+int cdna4_launch_moe_sk_front(const int32_t *ids, int64_t ids_tok_stride, int n_tok, int n_used, int n_b, int n_expert, int ntile_cap, int upt, int G, const int *cw,
+                              int32_t *tile_rec, int32_t *wg_begin, const float *x, int64_t x_row_stride, int64_t K, bool kq, void *xh, hipStream_t st) {
+    if (n_expert > 1024) return cdna4_set_error_msg("moe_sk_front: more than 1024 experts");
+    if (ntile_cap > CDNA4_SK_MAX_TILES) return cdna4_set_error_msg("moe_sk_front: too many tiles for the planner");
+    if (K % (kq ? QK_K : 32)) return cdna4_set_error_msg("moe_sk_front: K must be a whole number of activation blocks");
+    moe_sk_args a{};
+    a.ids = ids; a.ids_tok_stride = ids_tok_stride; a.n_tok = n_tok; a.n_used = n_used; a.n_b = n_b; a.n_expert = n_expert;
+    a.ntile_cap = ntile_cap; a.upt = upt; a.G = G; for (int i = 0; i < 4; i++) a.cw[i] = cw[i];
+    a.tile_rec = tile_rec; a.wg_begin = wg_begin;
+    const int64_t B = (int64_t)n_tok * n_b, nthr = kq ? B * (K / 16) : B * (K / 4);
+    const dim3 grid((unsigned)(1 + (nthr + 255) / 256));
+    if (kq) hipLaunchKernelGGL(k_moe_sk_front<true>, grid, dim3(256), 0, st, a, x, x_row_stride, (int)K, (int)B, (half_t *)xh);
+    else hipLaunchKernelGGL(k_moe_sk_front<false>, grid, dim3(256), 0, st, a, x, x_row_stride, (int)K, (int)B, (half_t *)xh);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

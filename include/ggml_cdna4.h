@@ -77,8 +77,9 @@ int          ggml_cdna4_set_device(int device);
  * s_memtime stamps of its first work-group; NULL (default) selects the uninstrumented kernel */
 void         ggml_cdna4_debug_trace(void * device_buffer);
 /* Library scratch (split-K exchange areas, re-laid weights) is allocated lazily per device and grown on demand; a launch captured into
- * a HIP graph holds the address it was given.  This counter changes whenever any such allocation is made or moved: a host that replays
- * captured launches compares it with the value at capture time and re-captures on a mismatch (the plug-in does). */
+ * a HIP graph holds the address it was given.  This counter changes whenever any such allocation is made or moved — and whenever a resident image is registered or
+ * unregistered (a captured launch holds "image found / not found" and the image's address): a host that replays captured launches compares it with the value at
+ * capture time and re-captures on a mismatch (the plug-in does). */
 uint64_t     ggml_cdna4_scratch_generation(void);
 
 size_t ggml_cdna4_row_size(int type, int64_t k);          /* bytes of one row of k weights; 0 if unsupported */
@@ -159,6 +160,9 @@ int ggml_cdna4_mul_mat_fused_residual_may_alias(int type, int64_t M, int64_t K, 
  * workspace has been written since, the next product may be ggml_cdna4_mul_mat_prepared(path = GGML_CDNA4_PATH_AUTO) or its fused twin below: the same kernel on
  * the same image — bit-identical to ggml_cdna4_mul_mat[_fused], one launch fewer.  The plug-in's graph walk does exactly this (GGML_CDNA4_NO_ACT_SHARE=1: off). */
 uint32_t ggml_cdna4_act_image_key(int type, int64_t M, int64_t K, int64_t B);
+/* the same for a concrete weight matrix (like ggml_cdna4_mul_mat_route_of): a few-row call on rows that are not 16-byte aligned leaves no int8 image (it may quantize
+ * inside a one-launch GEMV and never touch the workspace) — hosts that record the key after a call must ask with the pointers of THAT call */
+uint32_t ggml_cdna4_act_image_key_of(int type, const void * W, int64_t w_row_bytes, int64_t M, int64_t K, int64_t B);
 int ggml_cdna4_mul_mat_prepared_fused(int type, const void * W, int64_t w_row_bytes, float * Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,
                                       const float * bias, int act, const float * residual, int64_t residual_row_stride,
                                       const void * workspace, size_t workspace_bytes, void * stream);

@@ -55,7 +55,16 @@ static std::vector<float> run_mul_mat(ggml_backend_t backend, ggml_backend_buffe
     if (ggml_backend_graph_compute(backend, gf) != GGML_STATUS_SUCCESS) { fprintf(stderr, "graph_compute failed\n"); exit(1); }
     std::vector<float> y((size_t)M * B);
     ggml_backend_tensor_get(Y, y.data(), 0, y.size() * sizeof(float));
-    ggml_gallocr_free(ga); ggml_backend_buffer_free(wbuf); ggml_free(wctx); ggml_free(cctx);
+    // the reference's own teardown order (examples/gpt-2/main-backend.cpp:936-939): the ggml_context — and with it every ggml_tensor — goes BEFORE the weight buffer; its
+    // memory is scribbled over before the buffer is freed, so a buffer that still dereferences its tensors reads garbage (the CDNA4_Resident registry entry would
+    // survive, and the next weights at the same address would multiply the freed image — the `rewritten` runs of the resident section see exactly that)
+    ggml_gallocr_free(ga);
+    const size_t ctx_bytes = ggml_tensor_overhead() * 8 + ggml_graph_overhead();
+    ggml_free(wctx); ggml_free(cctx);
+    void * scribble[4];
+    for (void *& p : scribble) { p = malloc(ctx_bytes); if (p) memset(p, 0xAB, ctx_bytes); }
+    ggml_backend_buffer_free(wbuf);
+    for (void * p : scribble) free(p);
     return y;
 }
 

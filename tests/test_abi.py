@@ -137,7 +137,9 @@ f = L.ggml_cdna4_act_image_key; f.restype = C.c_uint32; f.argtypes = [C.c_int, C
 print(json.dumps({"kq_gemm": [f(12, 4096, 4096, 512), f(12, 1024, 4096, 512), f(14, 1024, 4096, 512), f(13, 14336, 4096, 512)],
                   "q80_gemm": [f(2, 4096, 4096, 512), f(8, 1024, 4096, 512)], "decode": [f(12, 4096, 4096, 1), f(12, 4096, 4096, 4), f(2, 4096, 4096, 2)],
                   "mmq": [f(12, 4096, 4096, 16), f(14, 1024, 4096, 16), f(8, 4096, 4096, 16)], "b64": [f(8, 4096, 14336, 64), f(2, 4096, 14336, 64)],
-                  "q2_K": f(10, 4096, 4096, 512), "q5_0_mmq": f(6, 4096, 4096, 16), "q5_0_gemm": f(6, 4096, 4096, 512), "bad": f(12, 4096, 100, 512)}))
+                  "q2_K": f(10, 4096, 4096, 512), "q5_0_mmq": f(6, 4096, 4096, 16), "q5_0_gemm": f(6, 4096, 4096, 512), "bad": f(12, 4096, 100, 512),
+                  "of": (lambda g: [g(12, 256, 2304, 4096, 4096, 16), g(12, 258, 2304, 4096, 4096, 16), g(12, 256, 2306, 4096, 4096, 16), g(12, 258, 2304, 4096, 4096, 512), g(14, 258, 3360, 4096, 4096, 16), g(14, 257, 3360, 4096, 4096, 16)])(
+                      (lambda h: (setattr(h, "restype", C.c_uint32), setattr(h, "argtypes", [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]), h)[2])(L.ggml_cdna4_act_image_key_of))}))
 """
     r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "ggml_amd", "lib", "libcdna4_kernels.so")], capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, CDNA4_ASSUME_CUS="256", HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1"))
@@ -148,6 +150,8 @@ print(json.dumps({"kq_gemm": [f(12, 4096, 4096, 512), f(12, 1024, 4096, 512), f(
     assert got["mmq"] == [3, 3, 1]
     assert got["b64"] == [1, 17]
     assert got["q2_K"] == 27 and got["q5_0_mmq"] == 0 and got["q5_0_gemm"] == 17 and got["bad"] == 0
+    # the key of a CONCRETE matrix: a few-row call on rows that are not 16-byte aligned (Q6_K: not 2-byte aligned) leaves no int8 image; the GEMM image does not care
+    assert got["of"] == [3, 0, 0, 19, 3, 0]
 
 
 def test_no_cpu_fallback(built):

@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import refutil as R  # noqa: E402
 
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-TUS = ["capi.hip", "quantize_act.hip", "convert_w.hip", "gemv_q.hip", "mmq_i8.hip", "gemm_q_mfma.hip", "gemm_q_t64.hip", "gemm_q_lds.hip", "ops.hip", "exact.hip"]
+TUS = ["capi.hip", "quantize_act.hip", "convert_w.hip", "gemv_q.hip", "mmq_i8.hip", "gemm_q_mfma.hip", "gemm_q_t64.hip", "gemm_q_sk.hip", "gemm_q_lds.hip", "ops.hip", "exact.hip"]
 FLAGS = ["-std=c++17", "-O1", "-pthread", "-ffp-contract=off", "-I" + os.path.join(HERE, "shim"), "-I" + HERE, "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), "-Wno-unused-value"]
 
 

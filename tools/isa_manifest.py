@@ -20,7 +20,7 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ggml_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-FILES = ["quantize_act.hip", "gemv_q.hip", "mmq_i8.hip", "gemm_q_mfma.hip", "gemm_q_t64.hip", "gemm_q_lds.hip", "exact.hip", "convert_w.hip", "ops.hip", "fattn.hip"]
+FILES = ["quantize_act.hip", "gemv_q.hip", "mmq_i8.hip", "gemm_q_mfma.hip", "gemm_q_t64.hip", "gemm_q_sk.hip", "gemm_q_lds.hip", "exact.hip", "convert_w.hip", "ops.hip", "fattn.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm", "-S", "--cuda-device-only"]
 # kernels written after the LAST full hardware session of the round being recorded (emulator-verified only).  Round 2 ended with such a list (Q4_1 /
 # Q5_1 / IQ4_* units, k_quantize_q8_1, the two-part re-encodings, k_q_to_f16_dense, k_cpy_f32_to_q45: see profiles/r02/isa_manifest.json); round 3's
