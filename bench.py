@@ -2,7 +2,8 @@
 """bench.py — BASELINE.json's metric on MI355X: effective TFLOPS (2*M*N*K) + tokens/s of the Q4_K MUL_MAT hot path.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config headline|c5] [--variant V --splitk S (kernel knobs, 0 = auto)]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; one rank per GPU, RCCL)
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; one rank per GPU, RCCL.
+   Started WITHOUT a launcher — `python bench.py --gpus N`, WORLD_SIZE unset — it re-executes itself under torch.distributed.run with N ranks: round 6.)
 
 config headline (default; the shape the metric is quoted on, BASELINE configs[1] / north-star target):
     per GPU Q4_K [4096x4096]·[4096x512]; one step = one pass of the hot path over one batch with W and the fp32 activations
@@ -698,15 +699,41 @@ def main():
     if args.lean:
         args.no_cpu_baseline = True
 
+    # `python bench.py --gpus N` without a launcher (a driver that only adds --gpus 8 to the 1-GPU command used to get a world of ONE): N ranks are
+    # started here, under the launcher the driver itself would use; rank 0's JSON line is this process's stdout
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("BENCH_NO_SPAWN") != "1":
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
+    # bench.py OWNS its device (one process per GPU, nothing else on it): it opts in to the routes that wait for co-resident work-groups (round 6: the library's DEFAULT is
+    # the shared mode, in which no launch ever waits for another work-group) and says so in `config`; the default mode's step time is reported beside it
+    os.environ.setdefault("GGML_CDNA4_OWNED_DEVICE", "1")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    selftest = os.environ.get("BENCH_DIST_SELFTEST") == "1"                  # tests/test_bench_host.py: the launch / rendezvous / reduce / rank-0 plumbing without a GPU (gloo)
     if args.gpus > 1 or world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        dist.init_process_group("gloo" if selftest and not torch.cuda.is_available() else "nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    if selftest:
+        # no GPU work: K "steps" of host time, the barrier + max-over-ranks reduction of the real path, ONE line from rank 0 with the world's size
+        if dist is not None: dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps): time.sleep(0.0005 * (rank + 1))
+        if dist is not None: dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if dist is not None: dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "selftest (no GPU work)", "value": None, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(float(el.item()) / max(1, args.steps) * 1e3, 5), "selftest": True, "gpus_requested": args.gpus}), flush=True)
+        if dist is not None: dist.barrier(); dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -789,7 +816,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic (%s)" % how,
             "config": {"workload": "Q4_K MUL_MAT [4096x4096]·[4096x512] per GPU; step = Q8_K activation quantize + fp16-MFMA GEMM, W and fp32 X resident in HBM",
-                       "M_per_gpu": M, "K": K, "B": B, "parallelism": "row-split x%d, output left sharded" % world, "gemm_variant": args.variant, "splitk": args.splitk},
+                       "M_per_gpu": M, "K": K, "B": B, "parallelism": "row-split x%d, output left sharded" % world, "gemm_variant": args.variant, "splitk": args.splitk,
+                       "device_mode": "owned (GGML_CDNA4_OWNED_DEVICE=1: bench.py has the GPU to itself); the library's default is the shared mode — see roofline.step_us_default_shared_mode"},
             "tokens_per_s": round(B * world / (ms_per_step * 1e-3), 1),
             "roofline": {"bound": "mfma", "kernel": kernel_name(Q4_K, M, K, B, fused) if args.variant == 0 else "gemm variant %d" % args.variant,
                          "achieved": round(gemm_tf, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tf / MFMA_F16_PEAK_TFLOPS, 4),
@@ -802,6 +830,13 @@ def main():
                          # the two launches the one-launch step replaces, each alone: the activation quantizer and the GEMM on prepared activations (AUTO's ticketed split)
                          "two_launch_components_us": {"k_quantize_q8_K": round(quant_us, 3), "k_gemm_kq_t64<Q4_K, 128>": round(gemm2_us, 3)}},
         }
+        # the same step in the library's DEFAULT mode (shared device: quantizer launch + GEMM with the ticketed split — nothing waits for a co-resident work-group)
+        try:
+            L_ = native.lib(); old_mode = L_.ggml_cdna4_set_shared_device(1)
+            out["roofline"]["step_us_default_shared_mode"] = round(events_us(h.step, args.steps, 10), 3)
+            L_.ggml_cdna4_set_shared_device(old_mode)
+        except Exception as e:  # noqa: BLE001
+            out["roofline"]["step_us_default_shared_mode"] = repr(e)[:120]
         # the step's other kernel, HBM-bound: reads the fp32 activations once, writes the pair-interleaved fp16 image + per-256 scale and per-16 sums
         qbytes = B * K * 4 + B * K * 2 + B * (K // 256) * 4 + B * (K // 16) * 2
         out["quantizer"] = {"kernel": "k_quantize_q8_K (fp32 rows -> fp16 GEMM image of the Q8_K-rounded activations, d, bsums)", "bound": "hbm", "us_per_launch": round(quant_us, 3),
@@ -813,9 +848,28 @@ def main():
             if "tflops" in lc:
                 lc["ours_over_library"] = round(gemm_tf / lc["tflops"], 3)
 
-    if dist is not None:                                              # a default multi-GPU run also carries BASELINE configs[4]
-        c5 = c5_leg(dist, dev, rank, world, max(10, args.steps // 4), max(3, args.warmup // 4))
+    if dist is not None:
+        # the headline's own collective legs (`value` is the compute-only weak-scaling number — the output of a row-split layer stays sharded, its
+        # consumer reads its own shard — and a >= 6x there says nothing about xGMI): the same step followed by the RCCL all-gather of the output, fp32 and fp16
+        legs = {"compute_only": {"ms_per_step": round(ms_per_step, 5), "tflops": round(value, 3)}}
+        yfull = torch.empty((world, B, M), dtype=torch.float32, device=dev)
+        y16 = torch.empty((B, M), dtype=torch.float16, device=dev)
+        yfull16 = torch.empty((world, B, M), dtype=torch.float16, device=dev)
+        for name, fn, nbytes in (("with_allgather_fp32", lambda: (h.step(), dist.all_gather_into_tensor(yfull, h.y)), B * M * 4),
+                                 ("with_allgather_fp16", lambda: (h.step(), y16.copy_(h.y), dist.all_gather_into_tensor(yfull16, y16)), B * M * 2)):
+            for _ in range(args.warmup): fn()
+            barrier(); t1 = time.perf_counter()
+            for _ in range(args.steps): fn()
+            barrier(); el = time.perf_counter() - t1
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms_c = float(tt.item()) / args.steps * 1e3
+            legs[name] = {"ms_per_step": round(ms_c, 5), "tflops": round(flops_step / (ms_c * 1e-3) / 1e12, 3), "collective": "RCCL all_gather_into_tensor, %d B/rank" % nbytes}
+        c5 = c5_leg(dist, dev, rank, world, max(10, args.steps // 4), max(3, args.warmup // 4))      # a default multi-GPU run also carries BASELINE configs[4]
         if rank == 0:
+            out["collective_legs"] = legs
+            out["accounting"] = ("`value` = compute_only: weak scaling of the headline with the output left sharded (no collective in the timed region); collective_legs has the same step "
+                                 "with the RCCL all-gather of the output behind it; c5 (BASELINE configs[4], strong scaling) carries compute_only / with_allgather_* / ksplit_allreduce")
             out["c5"] = c5
 
     if rank == 0 and world == 1:

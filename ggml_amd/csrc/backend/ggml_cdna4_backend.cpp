@@ -338,6 +338,8 @@ static void cdna4_backend_synchronize(ggml_backend_t backend) {
     cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
     HIP_OK(hipSetDevice(ctx->device));
     HIP_OK(hipStreamSynchronize(ctx->stream));
+    // (synchronize has no status to return: the fault stays pending for the next graph_compute, which fails; here it is only announced)
+    if (const int fault = ggml_cdna4_device_fault(0)) fprintf(stderr, "ggml-cdna4: %s: a launch gave up waiting for a co-resident work-group (code %d): the results behind this synchronize hold NaN tiles\n", ctx->name.c_str(), fault);
 }
 // ---- graph peepholes: chains every transformer graph contains, run as one launch each (bit-identical to the node-by-node sequence:
 // the fused kernels perform the same separate fp32 operations — include/ggml_cdna4.h).  A chain is taken only if every intermediate
@@ -566,6 +568,14 @@ static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph)
 static enum ggml_status cdna4_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
     cdna4_backend_ctx * ctx = (cdna4_backend_ctx *)backend->context;
     HIP_OK(hipSetDevice(ctx->device));
+    // an earlier launch on a route that waits for co-resident work-groups (GGML_CDNA4_OWNED_DEVICE=1 only) gave up waiting: what it wrote holds NaN tiles.  Said HERE, as a
+    // status — never a silently wrong tensor — and the kernel library has switched itself to the non-waiting routes (captured graphs hold the old routes: dropped)
+    if (const int fault = ggml_cdna4_device_fault(1)) {
+        fprintf(stderr, "ggml-cdna4: %s: an earlier graph waited for a co-resident work-group that never arrived (code %d) — the device is shared; its results are invalid. "
+                        "Continuing on the non-waiting routes.\n", ctx->name.c_str(), fault);
+        for (auto & gs : ctx->graph_slots) { if (gs.exec) (void)hipGraphExecDestroy(gs.exec); gs.exec = nullptr; gs.sig = 0; }
+        return GGML_STATUS_FAILED;
+    }
     static const bool no_graphs = getenv("GGML_CDNA4_NO_GRAPHS") != nullptr || cdna4_exact_mode();      // (the parity mode runs node by node, as ggml_cdna4_ops.h and exact.hip say: ADVICE r4)
     if (no_graphs || ctx->graphs_off || ggml_graph_n_nodes(cgraph) < 2) return run_nodes(ctx, cgraph);
     uint64_t sig = graph_signature(cgraph);

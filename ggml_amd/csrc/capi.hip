@@ -80,6 +80,37 @@ void ggml_cdna4_debug_trace(void *device_buffer) { cdna4_debug_trace = device_bu
 uint64_t ggml_cdna4_scratch_generation(void) { return cdna4_scratch_generation(); }
 const char *ggml_cdna4_last_error(void) { return g_err; }
 int ggml_cdna4_set_shared_device(int shared) { return cdna4_gemm_set_shared_device(shared); }
+// a launch on a route that WAITS for co-resident work-groups (only chosen on an owned device) ran into its bound: its output tile(s) are NaN.  Never silent: the code the
+// kernels stored (1 grid barrier, 2 / 4 hand-off, 3 reduce-scatter) comes back here, and the library has switched itself to the shared mode.
+int ggml_cdna4_device_fault(int clear) { return cdna4_gemm_take_fault(clear != 0); }
+// test hook: "another tenant" — work-groups that hold LDS (so that none of our 130-KB work-groups fits beside them) until the host releases them or the time is up
+#ifndef CDNA4_HW_OVERRIDE
+__global__ __launch_bounds__(64) void k_debug_occupy(const int *release, unsigned long long max_ticks, int lds_bytes) {
+    extern __shared__ uint8_t occ_lds[];
+    if (threadIdx.x == 0) occ_lds[lds_bytes - 1] = 1;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < max_ticks) {
+        if (release && __hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+#endif
+int ggml_cdna4_debug_occupy(int n_workgroups, int lds_kb, const int *release, int max_ms, void *stream) {
+    if (n_workgroups <= 0 || lds_kb < 1 || lds_kb > 160 || max_ms < 0 || max_ms > 20000) return cdna4_set_error_msg("debug_occupy: 1 .. 160 KB of LDS, at most 20 s");
+#ifndef CDNA4_HW_OVERRIDE
+    if (lds_kb > 64 && hipFuncSetAttribute(reinterpret_cast<const void *>(k_debug_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024) != hipSuccess) { (void)hipGetLastError(); return cdna4_set_error_msg("debug_occupy: cannot raise the LDS limit"); }
+    hipLaunchKernelGGL(k_debug_occupy, dim3(n_workgroups), dim3(64), lds_kb * 1024, (hipStream_t)stream, release, (unsigned long long)max_ms * 100000ull, lds_kb * 1024);
+    CDNA4_CHECK_LAUNCH();
+#endif
+    return 0;
+}
+static int fault_status() {
+    const int f = cdna4_gemm_take_fault(true);
+    if (!f) return 0;
+    snprintf(g_err, sizeof g_err, "an EARLIER launch waited for a co-resident work-group that never arrived (code %d): the device is not exclusively ours, that launch's output holds NaN tiles; "
+                                  "the library now uses the non-waiting routes (ggml_cdna4_set_shared_device(1))", f);
+    return -3;
+}
 int ggml_cdna4_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 int ggml_cdna4_set_device(int device) { hipError_t e = hipSetDevice(device); return e == hipSuccess ? 0 : cdna4_set_error(e, __FILE__, __LINE__); }
 
@@ -263,6 +294,7 @@ static int mul_mat_prepared_impl(int type, const void *W, int64_t w_row_bytes, f
                                  const void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, const cdna4_epilogue &epi, bool *tail_done, void *stream);
 int ggml_cdna4_mul_mat_prepared(int type, const void *W, int64_t w_row_bytes, float *Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,
                                 const void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, void *stream) {
+    if (const int frc = fault_status()) return frc;
     bool done = false;
     return mul_mat_prepared_impl(type, W, w_row_bytes, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, cdna4_epilogue{}, &done, stream);
 }
@@ -360,6 +392,7 @@ static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const floa
 }
 int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
                        int64_t M, int64_t K, int64_t B, void *workspace, size_t workspace_bytes, int path, int gemm_variant, int splitk, void *stream) {
+    if (const int frc = fault_status()) return frc;
     return mul_mat_impl(type, W, w_row_bytes, X, x_row_stride, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, cdna4_epilogue{}, stream);
 }
 // the GEMV routes (B <= 8) apply the tail where the element is reduced, and so does the Q4_K GEMM (k_gemm_kq_t64, on 16-byte-aligned rows: what every
@@ -418,6 +451,7 @@ static int fused_tail_ok(int type, const void *W, int64_t w_row_bytes, float *Y,
 int ggml_cdna4_mul_mat_fused(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
                              int64_t M, int64_t K, int64_t B, const float *bias, int act, const float *residual, int64_t residual_row_stride,
                              void *workspace, size_t workspace_bytes, void *stream) {
+    if (const int frc = fault_status()) return frc;
     if (const int rc = fused_tail_ok(type, W, w_row_bytes, Y, y_row_stride, M, K, B, act, residual, residual_row_stride, workspace)) return rc;
     cdna4_epilogue e{}; e.bias = bias; e.resid = residual; e.resid_row_stride = residual_row_stride; e.act = act;
     return mul_mat_impl(type, W, w_row_bytes, X, x_row_stride, Y, y_row_stride, M, K, B, workspace, workspace_bytes, GGML_CDNA4_PATH_AUTO, 0, 0, e, stream);
@@ -476,6 +510,7 @@ static int norm_affine_act(const ggml_cdna4_tensor *src0, const ggml_cdna4_tenso
 int ggml_cdna4_mul_mat_prepared_fused(int type, const void *W, int64_t w_row_bytes, float *Y, int64_t y_row_stride, int64_t M, int64_t K, int64_t B,
                                       const float *bias, int act, const float *residual, int64_t residual_row_stride,
                                       const void *workspace, size_t workspace_bytes, void *stream) {
+    if (const int frc = fault_status()) return frc;
     if (const int rc = fused_tail_ok(type, W, w_row_bytes, Y, y_row_stride, M, K, B, act, residual, residual_row_stride, workspace)) return rc;
     if (!ggml_cdna4_act_image_key(type, M, K, B)) return cdna4_set_error_msg("mul_mat_prepared_fused: a call of this shape has no prepared form (ggml_cdna4_act_image_key == 0)");
     cdna4_epilogue e{}; e.bias = bias; e.resid = residual; e.resid_row_stride = residual_row_stride; e.act = act;
@@ -489,6 +524,7 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
                           const int32_t *ids, int64_t ids_tok_stride, float *dst, int64_t dst_row_stride, int64_t dst_tok_stride,
                           int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok,
                           void *workspace, size_t workspace_bytes, void *stream) {
+    if (const int frc = fault_status()) return frc;
     if (!is_q(type)) return cdna4_set_error_msg("mul_mat_id: unsupported weight type");
     if (M <= 0 || n_tok <= 0 || n_used <= 0) return 0;
     if (K <= 0 || ggml_cdna4_row_size(type, K) == 0) return cdna4_set_error_msg("mul_mat_id: K is not a whole number of blocks");

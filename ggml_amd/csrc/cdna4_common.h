@@ -153,6 +153,17 @@ __device__ __forceinline__ bool wave_any(bool pred) {
     return v != 0;
 #endif
 }
+// bit l set iff the predicate holds in lane l (all 64 lanes of the wave execute this)
+__device__ __forceinline__ uint64_t wave_ballot(bool pred) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(pred);
+#else
+    const int l = (int)(threadIdx.x & 63);                 // (tools/emul: OR-reduction over the emulated shuffle)
+    int lo = (pred && l < 32) ? (int)(1u << l) : 0, hi = (pred && l >= 32) ? (int)(1u << (l - 32)) : 0;
+    for (int o = 32; o > 0; o >>= 1) { lo |= __shfl_xor(lo, o, 64); hi |= __shfl_xor(hi, o, 64); }
+    return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
+#endif
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

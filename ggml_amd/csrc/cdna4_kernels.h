@@ -91,6 +91,7 @@ bool cdna4_gemm_q_fuses_tail(const cdna4_gemm_args &a);
 bool cdna4_gemm_q_fuses_quantizer(const cdna4_gemm_args &a);
 bool cdna4_gemm_t64_fuses_quantizer(const cdna4_gemm_args &a, int tm, int splitk);      // gemm_q_t64.hip: the launcher's own plan
 int cdna4_gemm_q_route(const cdna4_gemm_args &a);              // the prefill kernel AUTO (or the given variant) would launch: ids in gemm_q_mfma.hip; no side effects
+int cdna4_gemm_take_fault(bool clear);                 // gemm_q_mfma.hip: the fault code a waiting exchange reported (0: none); a fault also demotes the library to the shared mode
 int cdna4_gemm_set_shared_device(int shared);          // gemm_q_mfma.hip: 1 = never choose a split-K exchange that spins on a co-resident partner; returns the old value
 // gemm_q_t64.hip — grouped MUL_MAT_ID: a.B = rows of the expert-sorted activation image, a.Y rows indexed through row_dst
 int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);

@@ -9,6 +9,9 @@
 
 #include "gemm_q_hw.h"            // the GPU-only statements as macros (tools/emul supplies host versions)
 
+// polls (s_sleep between them) a work-group spends waiting for a co-resident partner before it gives up: a few seconds — on a device the caller really owns the partner is
+// microseconds away (rounds 2-5 waited 2^26 polls, about a minute, for a word that then never came)
+#define CDNA4_SPIN_BOUND (1u << 22)
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 __device__ __forceinline__ void glds16(const void *g, void *l_wave_base) {
@@ -468,7 +471,14 @@ struct gemm_params {
     // k_gemm_kq_t64<.., 128, IDS> only (appended last; either may be null): tile_order[j] = the image tile the j-th group of tiles_m work-groups takes (fullest first),
     // tile_nfrag[t] = how many of tile t's four 32-row fragments hold rows (k_moe_plan, quantize_act.hip)
     const int32_t *tile_order; const int32_t *tile_nfrag;
+    // every kernel with an exchange that WAITS for a co-resident work-group (appended last): a word of pinned host memory (or null) that a wait which ran into its bound
+    // sets — the host turns it into an error status and demotes the library to the non-waiting routes (cdna4_gemm_fault_word, ggml_cdna4_device_fault)
+    unsigned *fault;
 };
+// a spin on a partner work-group gave up: the tile is poisoned (NaN) AND the host is told (system-scope store to the pinned fault word) — never NaN with status 0
+__device__ __forceinline__ void cdna4_report_fault(unsigned *fault, unsigned code) {
+    if (fault) __hip_atomic_store(fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Grid-wide barrier of a launch whose work-groups are ALL resident (the launcher's condition; one thread per work-group calls it, behind a __syncthreads()
 // that follows every wave's `s_waitcnt vmcnt(0)` on its write-through stores).  Two levels so that no word takes more than 32 + 8 arrivals: work-group b arrives
@@ -493,8 +503,8 @@ __device__ __forceinline__ bool cdna4_grid_barrier(unsigned *gb, unsigned nblk) 
         }
     }
     unsigned spins = 0;
-    while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0 && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
-    return spins < (1u << 22);
+    while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0 && ++spins < CDNA4_SPIN_BOUND) __builtin_amdgcn_s_sleep(1);
+    return spins < CDNA4_SPIN_BOUND;
 }
 // (A one-word form — every work-group adds a weight, the weights sum to 2^32, everybody polls the word until it is zero again — was built and measured in round 5: 256
 // arrivals and 255 pollers on ONE address cost +4 us at the headline shape and +10 us at 4096 x 11008 x 512 against this two-level form; profiles/r05/onelaunch_ab.txt.)
@@ -531,6 +541,8 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
 int cdna4_gemm_shared_device();                         // 1: the AUTO routes must not choose an exchange that spins on a co-resident partner (gemm_q_mfma.hip)
 int cdna4_gemm_set_shared_device(int shared);
 int cdna4_gemm_coresident_cus();                        // CUs that may be assumed to hold a grid all at once: the device's, or 0 in shared mode
+unsigned *cdna4_gemm_fault_word();                      // the device-visible fault word of the current device (pinned host memory), or nullptr
+int cdna4_gemm_take_fault(bool clear);                  // the fault code kernels reported since the last clear (0: none); a non-zero answer also switches the library to shared-device mode
 bool cdna4_gemm_lds_supported(const cdna4_gemm_args &a);                                     // gemm_q_lds.hip: weights dequantized into fp16 LDS tiles, 256-wide activation tile
 int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStream_t st, int form = 0);     //   tm 0 / 128 / 256, splitk 0 = choose; form 1 = k_gemm_w4 (one wave per SIMD); form 2 = k_gemm_r8 (32 x 256 wave tiles)
 bool cdna4_gemm_r8_preferred(const cdna4_gemm_args &a);                                      //   AUTO takes k_gemm_r8 for this call (large grids of 256 x 256 tiles)

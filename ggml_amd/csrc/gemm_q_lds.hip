@@ -62,6 +62,7 @@ int cdna4_launch_gemm_lds(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
         char *sc = (char *)cdna4_gemm_scratch(fbytes + pbytes, 9);
         if (!sc) return cdna4_set_error_msg("gemm_lds: cannot allocate split-K scratch");
         p.flags = (unsigned *)sc; p.partial = (float *)(sc + fbytes);
+        p.fault = cdna4_gemm_fault_word();
     }
     const dim3 grid(ntiles * splitk);
 #ifdef CDNA4_ABLATIONS

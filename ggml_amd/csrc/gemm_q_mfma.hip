@@ -397,19 +397,58 @@ const uint8_t *cdna4_resident_lookup(int type, const void *W, int64_t w_row_byte
     return e.image + row0 * e.image_row_bytes;
 }
 int cdna4_gemm_cu_count() { return cu_count(); }
-// The split-K exchanges that SPIN on a partner work-group (the hand-off of k_gemm_kq_t64 / the 128 x 128-tile kernels, k_gemm_r8's reduce-scatter) are only
-// chosen while every work-group of the grid is resident at once — true when the caller owns the device, not when another process or stream holds CUs
-// (a starved partner would run into the bounded spin and poison the tile with NaN).  ggml_cdna4_set_shared_device(1) (or GGML_CDNA4_SHARED_DEVICE=1) makes
-// the AUTO routes assume NO co-residency: no spinning exchange is ever chosen; small grids take the ticketed split (the last work-group to arrive sums,
-// nobody waits) or no split.  VERDICT r3 item 7(d).
+// The exchanges that WAIT for a partner work-group (the one-launch step's grid barrier, the hand-off of k_gemm_kq_t64 / the 128 x 128-tile kernels, k_gemm_r8's
+// reduce-scatter) are only correct while every work-group of the grid is resident at once — true when the caller owns the device, not when another process or stream holds
+// CUs.  Round 6: the DEFAULT is "shared" — AUTO never chooses a waiting exchange: small grids take the ticketed split (the last work-group to arrive sums,
+// nobody waits) or no split, the headline step is two launches; the reference's split work never waits on a co-resident block either (its stream-k partials are summed by a
+// second launch, src/ggml-cuda/mmq.cuh:2796-2822).  A host that owns the device opts in: ggml_cdna4_set_shared_device(0) / GGML_CDNA4_OWNED_DEVICE=1 (bench.py does, and says
+// so) — measured worth 1-2 % at the headline shape.  And a wait that runs into its bound is no longer silent: the work-group poisons its tile (NaN) AND sets the fault
+// word below; the next ggml_cdna4_mul_mat* call / the plug-in's next graph_compute returns an error status, and the library switches itself to the shared mode.
 static std::atomic<int> g_shared_device{-1};
 int cdna4_gemm_shared_device() {
     int v = g_shared_device.load(std::memory_order_relaxed);
-    if (v < 0) { v = (getenv("GGML_CDNA4_SHARED_DEVICE") && atoi(getenv("GGML_CDNA4_SHARED_DEVICE")) != 0) ? 1 : 0; g_shared_device.store(v, std::memory_order_relaxed); }
+    if (v < 0) {
+        v = 1;
+        if (getenv("GGML_CDNA4_OWNED_DEVICE") && atoi(getenv("GGML_CDNA4_OWNED_DEVICE")) != 0) v = 0;
+        if (getenv("GGML_CDNA4_SHARED_DEVICE")) v = atoi(getenv("GGML_CDNA4_SHARED_DEVICE")) != 0 ? 1 : 0;     // (the older knob, either way)
+        g_shared_device.store(v, std::memory_order_relaxed);
+    }
     return v;
 }
-int cdna4_gemm_set_shared_device(int shared) { const int old = cdna4_gemm_shared_device(); g_shared_device.store(shared ? 1 : 0, std::memory_order_relaxed); return old; }
+int cdna4_gemm_set_shared_device(int shared) {
+    const int old = cdna4_gemm_shared_device();
+    g_shared_device.store(shared ? 1 : 0, std::memory_order_relaxed);
+    if (old != (shared ? 1 : 0)) g_scratch_generation++;              // (the routes change: a host replaying captured launches re-captures)
+    return old;
+}
 int cdna4_gemm_coresident_cus() { return cdna4_gemm_shared_device() ? 0 : cu_count(); }
+// the fault word: four bytes of pinned, device-mapped host memory (portable: every device writes the same word); the kernels store to it at system scope, the host reads it
+// like any variable.  nullptr where the allocation fails (the kernels then only poison their tile, as before).
+static std::atomic<unsigned *> g_fault_host{nullptr};
+static std::mutex g_fault_mu;
+unsigned *cdna4_gemm_fault_word() {
+    unsigned *h = g_fault_host.load(std::memory_order_acquire);
+    if (!h) {
+        std::lock_guard<std::mutex> lock(g_fault_mu);
+        h = g_fault_host.load(std::memory_order_relaxed);
+        if (!h) {
+            void *ptr = nullptr;
+            if (hipHostMalloc(&ptr, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            for (int i = 0; i < 16; i++) ((volatile unsigned *)ptr)[i] = 0u;
+            h = (unsigned *)ptr; g_fault_host.store(h, std::memory_order_release);
+        }
+    }
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return (unsigned *)d;
+}
+int cdna4_gemm_take_fault(bool clear) {
+    unsigned *h = g_fault_host.load(std::memory_order_acquire);
+    if (!h) return 0;
+    const unsigned v = clear ? __atomic_exchange_n(h, 0u, __ATOMIC_ACQ_REL) : __atomic_load_n(h, __ATOMIC_ACQUIRE);
+    if (v && g_shared_device.exchange(1, std::memory_order_relaxed) != 1) g_scratch_generation++;      // never again on this process: the device is evidently not ours alone (captured launches hold the old routes: ggml_cdna4_scratch_generation moves)
+    return (int)v;
+}
 static int co_cus() { return cdna4_gemm_coresident_cus(); }
 
 // Route probe (the tail predictor must not be a hand-kept copy of the routing): cdna4_gemm_q_fuses_tail() runs the SAME routing code with the
@@ -460,6 +499,7 @@ static int launch_w8(const cdna4_gemm_args &a, int splitk, int opt, hipStream_t 
         const int nb = p.tiles_m * p.tiles_b * splitk;
         p.xchg_l2 = (p.partial && (nb & 7) == 0 && ((nb >> 3) % (p.tiles_b * 2)) == 0) ? 1 : 0;
     }
+    if (exchange && !ticketed) p.fault = cdna4_gemm_fault_word();         // (the waiting hand-off)
     p.tune = ticketed ? 2 : 0;      // bit1 = the ticketed split (gemm_w8_epilogue.inc); (bit0 = s_setprio 1 for the later-dispatched khalf-1 waves of k_gemm_kq_w8p: measured 26.31 vs 26.33 us, never enabled)
     const dim3 grid(p.tiles_m * p.tiles_b * splitk);
     // (the s_memtime trace instantiations <.., TRACE = true> exist in the -DCDNA4_ABLATIONS library of tools/microbench only)

@@ -31,6 +31,10 @@ int cdna4_launch_gemm_sk(const cdna4_gemm_args &a, const int32_t *tile_rec, cons
     p.W = a.W; p.w_row_bytes = a.w_row_bytes; p.w_expert_bytes = w_expert_bytes; p.xh = (const half_t *)a.xh;
     p.Y = a.Y; p.y_row = a.y_row_elems; p.M = a.M; p.K = a.K; p.B = a.B; p.tiles_m = (a.M + 127) / 128;
     p.tile_rec = tile_rec; p.wg_begin = wg_begin; p.tickets = (unsigned *)sc; p.partial = (float *)(sc + tbytes);
+#ifdef CDNA4_ABLATIONS
+    // measurement build (tools/microbench: libcdna4_kernels_abl.so): with a trace buffer set (ggml_cdna4_debug_trace: G * 512 bytes) the instrumented twin runs
+    if (cdna4_debug_trace && a.type == CDNA4_Q4_K) { p.trace = (unsigned long long *)cdna4_debug_trace; hipLaunchKernelGGL((k_gemm_kq_sk<CDNA4_Q4_K, true>), dim3(G), dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
+#endif
     if (a.type == CDNA4_Q4_0R) hipLaunchKernelGGL((k_gemm_kq_sk<CDNA4_Q4_0R>), dim3(G), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((k_gemm_kq_sk<CDNA4_Q4_K>), dim3(G), dim3(512), 0, st, p);
     CDNA4_CHECK_LAUNCH();

@@ -62,6 +62,7 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
         char *sc = (char *)cdna4_gemm_scratch(fbytes + pbytes, 2);
         if (!sc) return cdna4_set_error_msg("gemm_t64: cannot allocate split-K scratch");
         p.flags = (unsigned *)sc; p.gbar = (unsigned *)(sc + 49152);
+        if (fq || (splitk == 2 && !ticketed2)) p.fault = cdna4_gemm_fault_word();       // (the launches that wait: the grid barrier, the hand-off)
         if (splitk >= 2) {
             p.partial = (float *)(sc + fbytes);
             p.sb_split = (nsb + 1) / 2;

@@ -255,22 +255,21 @@ struct moe_sk_args {
     int32_t *tile_rec;                 // [ntile_cap][CDNA4_SK_REC]
     int32_t *wg_begin;                 // [G + 2]: unit index where work-group w starts; [G] = end; [G + 1] = tiles in use
 };
-// in-place exclusive prefix sum of a[0 .. n) in LDS by the whole work-group (NT threads); a[n] = the total
+// in-place exclusive prefix sum of a[0 .. n) in LDS by the whole work-group (NT threads); a[n] = the total.  Every thread sums a run of ceil(n / NT) entries, the runs' sums
+// are scanned inside each wave by shuffles and across the NT / 64 waves through `tmp` (two barriers, whatever n is)
 template <int NT> __device__ __forceinline__ void block_excl_scan(int *a, int n, int *tmp) {
-    const int tid = threadIdx.x, per = (n + NT - 1) / NT, lo = min(n, tid * per), hi = min(n, lo + per);
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6, per = (n + NT - 1) / NT, lo = min(n, tid * per), hi = min(n, lo + per);
     int s = 0;
     for (int i = lo; i < hi; i++) s += a[i];
-    tmp[tid] = s;
+    int inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d, 64); if (ln >= d) inc += v; }
+    if (ln == 63) tmp[wv] = inc;
     __syncthreads();
-    for (int d = 1; d < NT; d <<= 1) {
-        const int v = tid >= d ? tmp[tid - d] : 0;
-        __syncthreads();
-        tmp[tid] += v;
-        __syncthreads();
-    }
-    int run = tmp[tid] - s;
+    int run = inc - s;
+    for (int w = 0; w < wv; w++) run += tmp[w];
     for (int i = lo; i < hi; i++) { const int v = a[i]; a[i] = run; run += v; }
-    if (tid == NT - 1) a[n] = tmp[NT - 1];
+    if (tid == NT - 1) a[n] = run;                                     // (the last thread's run ends the array, or is empty behind it)
     __syncthreads();
 }
 // first index i in [0, n) with a[i] > v (a non-decreasing), n if none
@@ -280,16 +279,28 @@ __device__ __forceinline__ int upper_bound_i(const int *a, int n, long long v) {
     return lo;
 }
 __device__ void moe_sk_plan(const moe_sk_args &a) {
-    constexpr int NT = 256, REC = CDNA4_SK_REC;
-    __shared__ int cnt[1024], pos[1024], tpre[1025], cpre[CDNA4_SK_MAX_TILES + 1], tmp[NT];
+    constexpr int NT = 256, NW = NT / 64, REC = CDNA4_SK_REC, WTAB = 4096, CMAX = 16;
+    __shared__ int cnt[1024], tpre[1025], cpre[CDNA4_SK_MAX_TILES + 1], tmp[NW];
     __shared__ uint8_t trows[CDNA4_SK_MAX_TILES + 1];                   // rows of tile t, minus one
-    const int tid = threadIdx.x, n_pairs = a.n_tok * a.n_used, ne = a.n_expert;
-    for (int e = tid; e < ne; e += NT) { cnt[e] = 0; pos[e] = 0; }
+    __shared__ uint16_t wtab[WTAB];                                     // the stable ranking below: [chunk of the round][expert]
+    int *const pos = cnt;                                               // (the counts are dead once the tile headers are written: the same words count the rows placed so far)
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, n_pairs = a.n_tok * a.n_used, ne = a.n_expert;
+    auto id_of = [&](int pr) __attribute__((always_inline)) -> int {     // the expert of pair pr; -1: none (past the end, or an id out of range: the slot stays unwritten, as documented)
+        if (pr >= n_pairs) return -1;
+        const int tok = pr / a.n_used, e = a.ids[(int64_t)tok * a.ids_tok_stride + (pr - tok * a.n_used)];
+        return (e >= 0 && e < ne) ? e : -1;
+    };
+    // pairs are handled in CHUNKS of 64 (one wave each), a ROUND = CH chunks with CH * ne <= WTAB and at most CMAX / NW chunks per wave (their ids stay in registers);
+    // chunk c of a round goes to wave c % NW.  The ids of the FIRST round are loaded once, for the count and for the ranking
+    int CH = WTAB / (ne > 0 ? ne : 1); CH = CH > CMAX ? CMAX : (CH < NW ? NW : CH & ~(NW - 1));
+    int e_c[CMAX / NW];
+#pragma unroll
+    for (int i = 0; i < CMAX / NW; i++) e_c[i] = i * NW < CH ? id_of((i * NW + wv) * 64 + ln) : -1;
+    for (int e = tid; e < ne; e += NT) cnt[e] = 0;
     __syncthreads();
-    for (int pr = tid; pr < n_pairs; pr += NT) {
-        const int e = a.ids[(int64_t)(pr / a.n_used) * a.ids_tok_stride + pr % a.n_used];
-        if (e >= 0 && e < ne) atomicAdd(&cnt[e], 1);
-    }
+#pragma unroll
+    for (int i = 0; i < CMAX / NW; i++) if (e_c[i] >= 0) atomicAdd(&cnt[e_c[i]], 1);
+    for (int pr = CH * 64 + tid; pr < n_pairs; pr += NT) { const int e = id_of(pr); if (e >= 0) atomicAdd(&cnt[e], 1); }
     __syncthreads();
     for (int e = tid; e < ne; e += NT) tpre[e] = (cnt[e] + 127) >> 7;
     __syncthreads();
@@ -326,16 +337,55 @@ __device__ void moe_sk_plan(const moe_sk_args &a) {
         a.wg_begin[w] = (int32_t)u;
     }
     if (tid == 0) a.wg_begin[a.G + 1] = ntl;
-    // the rows of every tile: pair pr = (token, slot) is row `rank` of its expert's run, in arrival order
-    for (int pr = tid; pr < n_pairs; pr += NT) {
-        const int tok = pr / a.n_used, slot = pr % a.n_used;
-        const int e = a.ids[(int64_t)tok * a.ids_tok_stride + slot];
-        if (e < 0 || e >= ne) continue;                                  // out-of-range id: the slot stays unwritten (as documented)
-        const int rank = atomicAdd(&pos[e], 1), t = tpre[e] + (rank >> 7);
-        if (t >= ntl) continue;
-        int32_t *rec = a.tile_rec + (int64_t)t * REC;
-        rec[4 + (rank & 127)] = tok * a.n_b + slot % a.n_b;              // slot u reads activation row u % n_b (ggml-cpu.c:7752)
-        rec[132 + (rank & 127)] = pr;
+    // the rows of every tile: pair pr = (token, slot) is row `rank` of its expert's run, rank = the number of EARLIER pairs of the same expert — a STABLE counting sort, so
+    // that which tile a row lands in (and with it where its K range is cut and summed) is a function of the ids alone: the launch is bit-reproducible.  Per round: inside a
+    // chunk the rank among equal keys by ballots over the distinct keys present (at most 64, in practice the handful of experts); across chunks an exclusive prefix per expert
+    // over the round's table; across rounds the running pos[].
+    __syncthreads();
+    for (int e = tid; e < ne; e += NT) pos[e] = 0;
+    const uint64_t lt = ln ? (~0ull >> (64 - ln)) : 0ull;                 // lanes below this one
+    for (int base = 0; base < n_pairs; base += CH * 64) {
+        if (base) {
+#pragma unroll
+            for (int i = 0; i < CMAX / NW; i++) e_c[i] = i * NW < CH ? id_of(base + (i * NW + wv) * 64 + ln) : -1;
+        }
+        for (int i = tid; i < CH * ne; i += NT) wtab[i] = 0;
+        __syncthreads();                                                 // (also orders pos[] = 0 / the previous round's update in front of this round)
+        int r_c[CMAX / NW];
+#pragma unroll
+        for (int i = 0; i < CMAX / NW; i++) {
+            r_c[i] = 0;
+            if (i * NW >= CH) continue;                                  // (wave-uniform)
+            const int e = e_c[i];
+            int tot_w = 0;
+            bool todo = e >= 0;
+            for (uint64_t left = wave_ballot(todo); left != 0; left = wave_ballot(todo)) {
+                const int key = __builtin_amdgcn_readlane(e, __builtin_ctzll(left));
+                const uint64_t m = wave_ballot(e == key);
+                if (e == key) { r_c[i] = __builtin_popcountll(m & lt); tot_w = __builtin_popcountll(m); todo = false; }
+            }
+            if (e >= 0 && r_c[i] == 0) wtab[(i * NW + wv) * ne + e] = (uint16_t)tot_w;
+        }
+        __syncthreads();
+        for (int e = tid; e < ne; e += NT) {                             // exclusive prefix over the round's chunks, started at the rows placed by earlier rounds
+            int run = pos[e];
+            for (int c = 0; c < CH; c++) { const int v = wtab[c * ne + e]; wtab[c * ne + e] = (uint16_t)run; run += v; }
+            pos[e] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < CMAX / NW; i++) {
+            const int e = e_c[i];
+            if (i * NW >= CH || e < 0) continue;
+            const int pr = base + (i * NW + wv) * 64 + ln, tok = pr / a.n_used, slot = pr - tok * a.n_used;
+            const int rank = (int)wtab[(i * NW + wv) * ne + e] + r_c[i], t = tpre[e] + (rank >> 7);
+            if (t < ntl) {
+                int32_t *rec = a.tile_rec + (int64_t)t * REC;
+                rec[4 + (rank & 127)] = tok * a.n_b + slot % a.n_b;      // slot u reads activation row u % n_b (ggml-cpu.c:7752)
+                rec[132 + (rank & 127)] = pr;
+            }
+        }
+        __syncthreads();
     }
 }
 template <bool KQ>

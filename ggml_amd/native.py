@@ -5,6 +5,8 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libcdna4_kernels.so")
+if os.environ.get("CDNA4_KERNELS_LIB"):                # measurement only: the -DCDNA4_ABLATIONS twin of tools/microbench (timing-only / instrumented instantiations)
+    LIB_PATH = os.environ["CDNA4_KERNELS_LIB"]
 BACKEND_PATH = os.path.join(_PKG, "lib", "libggml-cdna4.so")
 
 # every symbol include/ggml_cdna4.h declares: (name, restype, argtypes)
@@ -14,6 +16,8 @@ SYMBOLS = [
     ("ggml_cdna4_last_error", C.c_char_p, []),
     ("ggml_cdna4_device_count", _int, []),
     ("ggml_cdna4_set_shared_device", _int, [_int]),
+    ("ggml_cdna4_device_fault", _int, [_int]),
+    ("ggml_cdna4_debug_occupy", _int, [_int, _int, _vp, _int, _vp]),
     ("ggml_cdna4_mul_mat_route", _int, [_int, _i64, _i64, _i64]),
     ("ggml_cdna4_mul_mat_route_of", _int, [_int, _vp, _i64, _i64, _i64, _i64]),
     ("ggml_cdna4_set_device", _int, [_int]),

@@ -59,11 +59,21 @@ enum ggml_cdna4_path {
 int          ggml_cdna4_api_version(void);
 const char * ggml_cdna4_last_error(void);                 /* thread-local, never NULL */
 int          ggml_cdna4_device_count(void);               /* number of visible HIP devices (0 if none) */
-/* 1: other work may hold CUs of this device while our kernels run (another process, another stream): the AUTO routes then never choose a split-K
- * exchange that SPINS on a co-resident partner work-group (k_gemm_kq_t64's hand-off, k_gemm_r8's reduce-scatter, the 128x128-tile kernels' hand-off) —
- * small grids take the ticketed split (the last work-group to arrive sums; nobody waits) or no split: slower at M = 4096, never a timed-out exchange.
- * 0 (default, or GGML_CDNA4_SHARED_DEVICE unset): the caller owns the device, as ggml_backend_sched does for its streams.  Returns the previous value. */
+/* 1 (the DEFAULT since round 6): other work may hold CUs of this device while our kernels run (another process, another stream — ordinary for a ggml plug-in): the AUTO
+ * routes never choose an exchange that WAITS for a co-resident partner work-group (the one-launch step's grid barrier, k_gemm_kq_t64's hand-off, k_gemm_r8's
+ * reduce-scatter, the 128x128-tile kernels' hand-off) — small grids take the ticketed split (the last work-group to arrive sums; nobody waits) or no split, the
+ * headline step is quantizer + GEMM: correct under any sharing, like the reference (whose stream-k partials are summed by a second launch, src/ggml-cuda/mmq.cuh:2796-2822).
+ * 0 (or GGML_CDNA4_OWNED_DEVICE=1 in the environment): the caller OWNS the device — the waiting routes become eligible (measured worth 1-2 % at
+ * [4096x4096]x[4096x512]; bench.py sets it and says so).  Returns the previous value. */
 int          ggml_cdna4_set_shared_device(int shared);
+/* Non-zero if, since the last clearing call, a launch on one of those waiting routes gave up waiting (1 grid barrier, 2 / 4 hand-off, 3 reduce-scatter): the device was not
+ * exclusively ours after all, that launch's output holds NaN tiles.  Seeing a fault also switches the library to the shared mode for the rest of the process.  Every
+ * ggml_cdna4_mul_mat* / _mul_mat_id call checks it first and returns -3 (ggml_cdna4_last_error says why) instead of launching — a wrong result is never handed back with
+ * status 0; the plug-in's graph_compute returns GGML_STATUS_FAILED.  clear = 0 only looks. */
+int          ggml_cdna4_device_fault(int clear);
+/* test hook (tests/test_gpu_shared_device.py): n_workgroups work-groups that each hold lds_kb KB of LDS (64 threads) and spin until *release (host-visible memory, may be
+ * null) becomes non-zero or max_ms milliseconds have passed — "another tenant" on the device.  Asynchronous on `stream`. */
+int          ggml_cdna4_debug_occupy(int n_workgroups, int lds_kb, const int * release, int max_ms, void * stream);
 /* Which route does ggml_cdna4_mul_mat(path = AUTO) take for a contiguous, 256-byte-aligned call of this shape on the current device?  Host logic only (no launch):
  *   1 one launch, activation quantizer inside the GEMV      2 quantize + GEMV      3 quantize + int8 matrix-core kernel (3..64 rows)
  *   10 quantize + k_gemm_kq_t64      12 quantize + k_gemm_r8      13 quantize + a 128x128-tile kernel      14 quantize + an older per-lane-load GEMM

@@ -27,6 +27,10 @@ def pytest_cmdline_main(config):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The suite OWNS its device (one process at a time on a box of its own), and most of its route pins, hand-off and one-launch tests were written for the routes an
+    # owned device takes: it says so, like bench.py does.  The DEFAULT mode (round 6: shared — nothing ever waits for a co-resident work-group) is what
+    # tests/test_gpu_shared_device.py and test_abi.py::test_route_table_for_a_256_cu_part run, in child processes without this variable.
+    os.environ.setdefault("GGML_CDNA4_OWNED_DEVICE", "1")
     if os.environ.get("CDNA4_TESTS_ON_EMULATOR") == "1":
         # tests/test_gpu_tests_on_the_emulator.py: selected -m gpu tests, unchanged, against the whole-library CPU emulation (tests/emul_torch.py)
         import emul_torch

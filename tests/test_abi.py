@@ -108,14 +108,18 @@ for t in (12, 13, 14, 2, 8, 6, 10, 23):
     out[t] = [f(t, 4096, 4096, b) for b in (1, 2, 4, 6, 16, 48, 64, 96, 512)] + [f(t, 32768, 8192, 512), f(t, 4096, 14336, 64), f(t, 4096, 4032, 96), f(t, 16384, 8192, 512), f(t, 4096, 14336, 4)]
 print(json.dumps(out))
 """
-    r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "ggml_amd", "lib", "libcdna4_kernels.so")], capture_output=True, text=True, timeout=120,
-                       env=dict(os.environ, CDNA4_ASSUME_CUS="256", HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1"))
-    assert r.returncode == 0, r.stderr[-800:]
-    got = {int(k): v for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items()}
+    def routes(**env):
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "ggml_amd", "lib", "libcdna4_kernels.so")], capture_output=True, text=True, timeout=120,
+                           env=dict({k: v for k, v in os.environ.items() if k not in ("GGML_CDNA4_OWNED_DEVICE", "GGML_CDNA4_SHARED_DEVICE")}, CDNA4_ASSUME_CUS="256", HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1", **env))
+        assert r.returncode == 0, r.stderr[-800:]
+        return {int(k): v for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items()}
+    got = routes()
     #            rows at 4096^2:  1  2  4  6  16  48  64  96  512 |  C5  4096x14336x64  K=4032x96  16384x8192x512  4096x14336x4
-    # (round 5: 11 = ONE launch — the activation quantizer and a grid barrier inside k_gemm_kq_t64<.., FQ> — where the grid is resident and the quantizer's share is one
-    #  pass of the work-groups: the headline shape; gemm_q_t64.hip: t64_fuses_quantizer)
-    assert got[12] == [1, 1, 1, 3, 3, 3, 3, 10, 11, 12, 10, 0, 10, 3]
+    # (round 6: the DEFAULT never takes a route that waits for a co-resident work-group — the headline shape is quantizer + k_gemm_kq_t64 (10); a host that owns the device
+    #  opts in, GGML_CDNA4_OWNED_DEVICE=1 / ggml_cdna4_set_shared_device(0), and gets round 5's ONE launch (11: the quantizer and a grid barrier inside k_gemm_kq_t64<.., FQ>))
+    assert got[12] == [1, 1, 1, 3, 3, 3, 3, 10, 10, 12, 10, 0, 10, 3]
+    assert routes(GGML_CDNA4_OWNED_DEVICE="1")[12] == [1, 1, 1, 3, 3, 3, 3, 10, 11, 12, 10, 0, 10, 3]
+    assert routes(GGML_CDNA4_SHARED_DEVICE="0")[12][8] == 11 and routes(GGML_CDNA4_OWNED_DEVICE="1", GGML_CDNA4_SHARED_DEVICE="1")[12][8] == 10      # (the older knob wins, either way)
     assert got[13] == [1, 1, 1, 3, 3, 3, 3, 13, 13, 12, 3, 0, 13, 3]
     assert got[14] == [1, 1, 1, 3, 3, 13, 13, 13, 13, 13, 13, 0, 13, 3]
     assert got[2] == [1, 1, 1, 3, 3, 3, 3, 13, 13, 13, 13, 14, 13, 3]

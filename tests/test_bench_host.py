@@ -77,3 +77,21 @@ print(json.dumps(bench.layer_front_rows("cuda:0", 50, d=512, b=96, mkv=256)))
     assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
     row = json.loads(r.stdout.strip().splitlines()[-1])
     assert row["bit_identical"] is True and row["launches"]["handed_off"] == 4 and "us_plain" in row and "us_handed_off" in row
+
+
+def test_gpus_n_without_a_launcher_spawns_n_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (what a driver that only adds --gpus N to the 1-GPU command runs) re-executes itself under torch.distributed.run:
+    two ranks rendezvous on 127.0.0.1, the max-over-ranks reduction runs, and rank 0 alone prints ONE line that says n_gpus = 2.  BENCH_DIST_SELFTEST=1 replaces the GPU
+    work by host sleeps (gloo instead of RCCL): the plumbing is what is under test."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_NO_SPAWN")}
+    env["BENCH_DIST_SELFTEST"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["gpus_requested"] == 2 and lines[0]["steps"] == 5, lines
+    assert lines[0]["ms_per_step"] >= 0.9                              # the MAX over the ranks: rank 1 sleeps 1 ms per step, rank 0 half of that
+    # ... and under a launcher (WORLD_SIZE set) it does not spawn again: a world of one stays one process
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    l1 = [json.loads(l) for l in r1.stdout.splitlines() if l.startswith("{")]
+    assert r1.returncode == 0 and len(l1) == 1 and l1[0]["n_gpus"] == 1, (r1.stdout + r1.stderr)[-1000:]

@@ -584,9 +584,9 @@ def test_mul_mat_id_few_rows_per_expert_takes_the_integer_path(gu, name, t, n_ex
 @pytest.mark.parametrize("n_expert,n_used,n_b_is_one,n_tok,m,k", [(8, 2, False, 512, 4096, 4096), (8, 2, False, 96, 512, 512), (4, 4, True, 33, 300, 768),
                                                                   (16, 2, False, 40, 256, 256), (8, 1, False, 700, 640, 1024), (3, 2, False, 200, 128, 2048)])
 def test_mul_mat_id_grouped_prefill(gu, name, t, n_expert, n_used, n_b_is_one, n_tok, m, k):
-    """prefill-sized MUL_MAT_ID (n_tok * n_used > 32) on all five formats: the (token, slot) rows are counting-sorted by expert on the device,
-    quantized through the sort (gather: Q8_K / Q8_0) and multiplied in ONE launch — k_gemm_kq_t64<.., IDS> for Q4_K, k_gemm_q<.., IDS> (per-lane loads
-    of the original blocks) for Q5_K / Q6_K / Q4_0 / Q8_0; ragged per-expert counts, experts that receive no row, an expert id out of range (its
+    """prefill-sized MUL_MAT_ID (n_tok * n_used > 32) on all five formats.  Q4_K (round 6): the stream-k form — planner + token-order quantizer in one launch, then ONE
+    persistent k_gemm_kq_sk launch over (tile, m-tile, superblock) units that gathers its activation rows; Q5_K / Q6_K / Q4_0 / Q8_0: the (token, slot) rows counting-sorted
+    by expert, quantized through the sort (gather) and multiplied by k_gemm_q<.., IDS> (per-lane loads of the original blocks); ragged per-expert counts, experts that receive no row, an expert id out of range (its
     slot must stay untouched), b broadcast over the slots (n_b = 1), repeated calls on one workspace.  Against the oracle's MUL_MAT_ID (per-expert
     mul_mat, ggml-cpu.c:7648-7781) with the GEMM tolerance."""
     from ggml_amd import ops
@@ -624,7 +624,8 @@ def test_mul_mat_id_grouped_prefill(gu, name, t, n_expert, n_used, n_b_is_one, n
     assert rc == 0, L.ggml_cdna4_last_error().decode()
     torch.cuda.synchronize()
     ob = out.cpu().numpy()
-    assert (ob[3, 0] == -77.0).all() and np.array_equal(ob[3, 1:], y[3, 1:]) and np.array_equal(ob[4], y[4])
+    # (the other rows: equal to the clean run up to fp32 summation order — one row fewer moves the spans of the stream-k partition, i.e. where a tile's K range is cut and summed)
+    assert (ob[3, 0] == -77.0).all() and R.rel_l2(ob[3, 1:], y[3, 1:]) < 2e-6 and R.rel_l2(ob[4], y[4]) < 2e-6 and R.rel_l2(ob[5:], y[5:]) < 2e-6
 
 def test_shared_device_mode_never_spins_and_agrees(gu):
     """GGML_CDNA4_SHARED_DEVICE=1 (ggml_cdna4_set_shared_device): the AUTO routes choose no split-K exchange that waits for a co-resident partner —

@@ -121,6 +121,7 @@ static inline void emu_sleep() { static thread_local unsigned n = 0; usleep(200)
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_s_memrealtime() 0ull
 #define __HIP_MEMORY_SCOPE_AGENT 0
+#define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
 #define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, order)
@@ -135,6 +136,12 @@ template <typename T> static inline T __shfl_xor(T v, int o, int = 64) {
     T r; memcpy(&r, &w.xch[l ^ o], 4);
     pthread_barrier_wait(&w.bar);
     return r;
+}
+// __shfl_up: lane l receives the value of lane l - d (its own below d); wave-collective like __shfl_xor
+template <typename T> static inline T emu_shfl_idx(T v, int src);
+template <typename T> static inline T __shfl_up(T v, unsigned d, int = 64) {
+    const int l = emu::t_threadIdx.x & 63;
+    return emu_shfl_idx(v, l >= (int)d ? l - (int)d : l);
 }
 // value of lane `src` (any lane of the wave): the fallback of cdna4_common.h's DPP helpers and of v_readlane
 template <typename T> static inline T emu_shfl_idx(T v, int src) {

@@ -44,7 +44,11 @@ struct hipDeviceProp_t { int multiProcessorCount; };
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 void *emu_shared_alloc(size_t n);
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = emu_shared_alloc(n); return 0; }
-static inline hipError_t hipFree(void *) { return 0; }                                  // (guard-paged mappings are left in place)
+static inline hipError_t hipFree(void *) { return 0; }
+#define hipHostMallocPortable 1
+#define hipHostMallocMapped 2
+static inline hipError_t hipHostMalloc(void **p, size_t n, int) { *p = emu_shared_alloc(n); return 0; }      // (the fault word: shared with the work-group processes)
+static inline hipError_t hipHostGetDevicePointer(void **d, void *h, int) { *d = h; return 0; }                                  // (guard-paged mappings are left in place)
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memmove(d, s, n); return 0; }

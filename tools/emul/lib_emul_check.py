@@ -106,20 +106,26 @@ def mul_mat(t, m, k, b, path=0, seed=1, cus=256, timeout=1800, w=None, resident=
     return R.rel_l2(y, R.o_mul_mat(t, w, x, m, k)), y
 
 
-def mul_mat_id(t, m, k, n_expert, n_used, n_b, n_tok, seed=1, cus=256, timeout=1800, resident=False, defer_dma=False):
+def mul_mat_id(t, m, k, n_expert, n_used, n_b, n_tok, seed=1, cus=256, timeout=1800, resident=False, defer_dma=False, ids=None, env=None, want_y=False):
+    """ids: the expert ids [n_tok][n_used] (default: random distinct experts per token); env: extra environment of the run (routing knobs); want_y: -> (rel-L2, y)"""
     rng = np.random.default_rng(seed)
     w = R.random_weights(t, n_expert * m, k, seed)
     xb = rng.uniform(-1, 1, (n_tok, n_b, k)).astype(np.float32)
-    ids = np.stack([rng.permutation(n_expert)[:n_used] for _ in range(n_tok)]).astype(np.int32)
+    if ids is None:
+        ids = np.stack([rng.permutation(n_expert)[:n_used] for _ in range(n_tok)]).astype(np.int32)
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
     with tempfile.TemporaryDirectory() as d:
         f = lambda n: os.path.join(d, n)
         w.tofile(f("w")); xb.tofile(f("x")); ids.tofile(f("i"))
         if not _run([build(), "mul_mat_id"] + [str(int(v)) for v in (t, m, k, n_expert, n_used, n_b, n_tok)] + [f("w"), f("x"), f("i"), f("y")],
-                    {"EMU_CUS": cus, "EMU_RESIDENT": int(resident), "EMU_DEFER_DMA": int(defer_dma)}, timeout):
+                    dict({"EMU_CUS": cus, "EMU_RESIDENT": int(resident), "EMU_DEFER_DMA": int(defer_dma)}, **(env or {})), timeout):
             return None
         y = np.fromfile(f("y"), np.float32).reshape(n_tok, n_used, m)
-    assert np.isfinite(y).all() and not (y == -12345.0).any(), "unwritten or non-finite outputs"
-    return R.rel_l2(y, R.o_mul_mat_id(t, w, xb, ids, m, k, n_expert))
+    valid = (ids >= 0) & (ids < n_expert)                                # (a slot with an out-of-range id stays unwritten: the driver's fill value)
+    assert np.isfinite(y).all() and not (y[valid] == -12345.0).any() and (y[~valid] == -12345.0).all(), "unwritten, overwritten or non-finite outputs"
+    yo = R.o_mul_mat_id(t, w, xb, np.where(valid, ids, 0), m, k, n_expert)
+    e = R.rel_l2(y[valid], yo[valid])
+    return (e, y) if want_y else e
 
 
 if __name__ == "__main__":
