@@ -241,8 +241,8 @@ int cdna4_launch_moe_plan(const int32_t *ids, int64_t ids_tok_stride, int n_tok,
 // The activations are quantized in TOKEN order (row = token * n_b + slot % n_b: n_tok * n_b rows, not one per (token, slot) pair and no padding rows) — the grouped GEMM
 // (k_gemm_kq_sk, gemm_kq_sk.inc) gathers a tile's rows by index in its LDS-DMA, so the quantizer does not depend on the plan and the two share a launch.
 // The plan (what the CPU does on one thread before its per-expert mul_mats, ggml-cpu.c:7679-7694, and what ggml-cuda.cu:1975-1978 copies the ids to the HOST for):
-//   * counts per expert, tiles of up to 128 (token, slot) rows per expert — a tile RECORD per tile: [expert, rows, index within the expert, 32-row fragments with rows,
-//     src row of each of the 128 tile rows (padding rows: 0, a valid row), dst (token, slot) pair of each (padding: -1)];
+//   * counts per expert, tiles of up to 128 (or 256) (token, slot) rows per expert — a tile RECORD per tile: [expert, rows, index within the expert, 32-row fragments with
+//     rows, src row of each tile row, dst (token, slot) pair of each]; the entries behind a tile's rows are not written (the GEMM clamps them);
 //   * the partition of the launch's work — (tile, m-tile, superblock) units, linear index u = (tile * tiles_m + m-tile) * nsb + superblock, weighted by the tile's fragment
 //     count — into G contiguous spans of equal cost: wg_begin[0 .. G] (the reference's stream-k decomposition, src/ggml-cuda/mmq.cuh:2588-2655, with weights).
 // Everything is a function of the ids alone except the ORDER of an expert's rows within its tiles (LDS atomics) — and no output element depends on its row's position.
@@ -251,8 +251,9 @@ struct moe_sk_args {
     int ntile_cap;                     // tile records the table can hold (>= min(n_expert, pairs) + pairs / 128)
     int upt;                           // units per activation tile: tiles_m * nsb
     int G;                             // work-groups of the GEMM launch
-    int cw[4];                         // cost of one unit of a tile with 1 .. 4 fragments (relative)
-    int32_t *tile_rec;                 // [ntile_cap][CDNA4_SK_REC]
+    int tile_rows;                     // rows per tile: 128 (k_gemm_kq_sk) or 256 (k_gemm_r8_sk); a tile record is 4 + 2 * tile_rows int32
+    int cw[8];                         // cost of one unit of a tile with 1 .. tile_rows / 32 fragments in use (relative)
+    int32_t *tile_rec;                 // [ntile_cap][4 + 2 * tile_rows]
     int32_t *wg_begin;                 // [G + 2]: unit index where work-group w starts; [G] = end; [G + 1] = tiles in use
 };
 // in-place exclusive prefix sum of a[0 .. n) in LDS by the whole work-group (NT threads); a[n] = the total.  Every thread sums a run of ceil(n / NT) entries, the runs' sums
@@ -278,135 +279,165 @@ __device__ __forceinline__ int upper_bound_i(const int *a, int n, long long v) {
     while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)a[mid] > v) hi = mid; else lo = mid + 1; }
     return lo;
 }
+// (written for SIZE: one work-group executes this code once per step, on the step's critical path, with a cold instruction cache — round 6 measured 11.8 us for a first
+//  version of 2,500 instructions (chunk loops unrolled four times, three 64-bit divisions per span); loops stay rolled, per-pair state lives in LDS, divisions are 32-bit)
+// (written for SIZE: one work-group executes this code ONCE per step, on the step's critical path, with a cold instruction cache — about 10 ns per instruction executed:
+//  round 6 measured 11.8 us for a first version of 2,500 instructions (chunk loops unrolled four times, 64-bit divisions, padding rows written out) and a timeline in which
+//  every phase, however little it computes, costs 1-4 us.  Loops stay rolled, per-pair state lives in LDS, a job of one ROUND takes no separate counting pass, the GEMM clamps
+//  a tile's padding rows itself.)
 __device__ void moe_sk_plan(const moe_sk_args &a) {
-    constexpr int NT = 256, NW = NT / 64, REC = CDNA4_SK_REC, WTAB = 4096, CMAX = 16;
+    constexpr int NT = 256, NW = NT / 64, WTAB = 4096, CMAX = 16;
+    const int trs = a.tile_rows == 256 ? 8 : 7, TR = 1 << trs, REC = 4 + 2 * TR;      // rows per tile (128: k_gemm_kq_sk, 256: k_gemm_r8_sk); int32 per tile record
     __shared__ int cnt[1024], tpre[1025], cpre[CDNA4_SK_MAX_TILES + 1], tmp[NW];
     __shared__ uint8_t trows[CDNA4_SK_MAX_TILES + 1];                   // rows of tile t, minus one
-    __shared__ uint16_t wtab[WTAB];                                     // the stable ranking below: [chunk of the round][expert]
-    int *const pos = cnt;                                               // (the counts are dead once the tile headers are written: the same words count the rows placed so far)
+    __shared__ uint16_t wtab[WTAB];                                     // the stable ranking: [chunk of the round][expert]
+    __shared__ int16_t ekey[CMAX * 64]; __shared__ uint8_t erank[CMAX * 64]; __shared__ int esrc[CMAX * 64];      // per pair of the round: expert (-1: none), rank inside its chunk, activation row
+    int *const pos = cnt;                                               // (the counts are dead once the tiles' rows are known: the same words count the rows placed so far)
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, n_pairs = a.n_tok * a.n_used, ne = a.n_expert;
-    auto id_of = [&](int pr) __attribute__((always_inline)) -> int {     // the expert of pair pr; -1: none (past the end, or an id out of range: the slot stays unwritten, as documented)
-        if (pr >= n_pairs) return -1;
-        const int tok = pr / a.n_used, e = a.ids[(int64_t)tok * a.ids_tok_stride + (pr - tok * a.n_used)];
-        return (e >= 0 && e < ne) ? e : -1;
-    };
-    // pairs are handled in CHUNKS of 64 (one wave each), a ROUND = CH chunks with CH * ne <= WTAB and at most CMAX / NW chunks per wave (their ids stay in registers);
-    // chunk c of a round goes to wave c % NW.  The ids of the FIRST round are loaded once, for the count and for the ranking
+    // The rows of every tile: pair pr = (token, slot) is row `rank` of its expert's run, rank = the number of EARLIER pairs of the same expert — a STABLE counting sort, so
+    // that which tile a row lands in (and with it where its K range is cut and summed) is a function of the ids alone: the launch is bit-reproducible.  Pairs are ranked in
+    // CHUNKS of 64 (one wave each), a ROUND = CH chunks (CH * ne <= WTAB entries of the table, at most CMAX), chunk c of a round by wave c % NW: inside a chunk the rank among
+    // equal keys by ballots over the distinct keys present (at most 64, in practice the handful of experts); across the round's chunks an exclusive prefix per expert over
+    // the table; across rounds the running pos[].
     int CH = WTAB / (ne > 0 ? ne : 1); CH = CH > CMAX ? CMAX : (CH < NW ? NW : CH & ~(NW - 1));
-    int e_c[CMAX / NW];
-#pragma unroll
-    for (int i = 0; i < CMAX / NW; i++) e_c[i] = i * NW < CH ? id_of((i * NW + wv) * 64 + ln) : -1;
-    for (int e = tid; e < ne; e += NT) cnt[e] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < CMAX / NW; i++) if (e_c[i] >= 0) atomicAdd(&cnt[e_c[i]], 1);
-    for (int pr = CH * 64 + tid; pr < n_pairs; pr += NT) { const int e = id_of(pr); if (e >= 0) atomicAdd(&cnt[e], 1); }
-    __syncthreads();
-    for (int e = tid; e < ne; e += NT) tpre[e] = (cnt[e] + 127) >> 7;
-    __syncthreads();
-    block_excl_scan<NT>(tpre, ne, tmp);
-    const int ntl = min(tpre[ne], a.ntile_cap);                          // (never more than the capacity by construction: the launcher sized it)
-    // tile headers, and the tiles' unit costs
-    for (int t = tid; t < ntl; t += NT) {
-        const int e = upper_bound_i(tpre, ne + 1, t) - 1, local = t - tpre[e];
-        const int rows = min(128, cnt[e] - 128 * local), nfrag = (rows + 31) >> 5;
-        int32_t *rec = a.tile_rec + (int64_t)t * REC;
-        rec[0] = e; rec[1] = rows; rec[2] = local; rec[3] = nfrag;
-        cpre[t] = a.cw[nfrag - 1]; trows[t] = (uint8_t)(rows - 1);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < ntl * 128; idx += NT) {                    // padding rows read activation row 0 and store nothing (the pairs below never write these entries)
-        const int t = idx >> 7, i = idx & 127;
-        if (i > (int)trows[t]) { int32_t *rec = a.tile_rec + (int64_t)t * REC; rec[4 + i] = 0; rec[132 + i] = -1; }
-    }
-    block_excl_scan<NT>(cpre, ntl, tmp);
-    // the spans: cost position of unit (t, l) = cpre[t] * upt + l * cw_t; work-group w starts at the first unit at or behind w / G of the total.  Fewer work-groups take
-    // part when the whole job is small (each gets at least about two superblocks of a full tile)
-    const long long CT = (long long)cpre[ntl] * a.upt;
-    long long geff = CT / (2 * (long long)a.cw[3]);
-    geff = geff < 1 ? 1 : (geff > a.G ? a.G : geff);
-    const long long u_end = (long long)ntl * a.upt;
-    for (int w = tid; w <= a.G; w += NT) {
-        long long u = u_end;
-        if (w < geff && ntl > 0) {
-            const long long x = CT * w / geff;
-            const int t = upper_bound_i(cpre, ntl + 1, x / a.upt) - 1;      // cpre[t] * upt <= x < cpre[t + 1] * upt
-            const long long c = cpre[t + 1] - cpre[t], rem = x - (long long)cpre[t] * a.upt;
-            u = (long long)t * a.upt + (rem + c - 1) / c;
-        }
-        a.wg_begin[w] = (int32_t)u;
-    }
-    if (tid == 0) a.wg_begin[a.G + 1] = ntl;
-    // the rows of every tile: pair pr = (token, slot) is row `rank` of its expert's run, rank = the number of EARLIER pairs of the same expert — a STABLE counting sort, so
-    // that which tile a row lands in (and with it where its K range is cut and summed) is a function of the ids alone: the launch is bit-reproducible.  Per round: inside a
-    // chunk the rank among equal keys by ballots over the distinct keys present (at most 64, in practice the handful of experts); across chunks an exclusive prefix per expert
-    // over the round's table; across rounds the running pos[].
-    __syncthreads();
-    for (int e = tid; e < ne; e += NT) pos[e] = 0;
+    const bool one_round = n_pairs <= CH * 64;
     const uint64_t lt = ln ? (~0ull >> (64 - ln)) : 0ull;                 // lanes below this one
-    for (int base = 0; base < n_pairs; base += CH * 64) {
-        if (base) {
-#pragma unroll
-            for (int i = 0; i < CMAX / NW; i++) e_c[i] = i * NW < CH ? id_of(base + (i * NW + wv) * 64 + ln) : -1;
-        }
+    // ranks the round's pairs inside their chunks (-> ekey / erank / esrc, per-chunk totals -> wtab), then turns the table into exclusive prefixes per expert started at start[e]
+    // (null: zero) and leaves the running totals in total[e]
+    auto rank_round = [&](int base, const int *start, int *total) __attribute__((always_inline)) {
         for (int i = tid; i < CH * ne; i += NT) wtab[i] = 0;
-        __syncthreads();                                                 // (also orders pos[] = 0 / the previous round's update in front of this round)
-        int r_c[CMAX / NW];
+        // the round's ids: all of a thread's loads in flight together (this loop IS unrolled: rolled, every chunk paid a memory round trip of its own — 4 of the
+        // planner's first 12 us); chunk c = NW i + wave is pairs base + NT i + tid
 #pragma unroll
         for (int i = 0; i < CMAX / NW; i++) {
-            r_c[i] = 0;
-            if (i * NW >= CH) continue;                                  // (wave-uniform)
-            const int e = e_c[i];
-            int tot_w = 0;
+            const int pr = base + i * NT + tid;
+            int e = -1, src = 0;
+            if (i * NW < CH && pr < n_pairs) {
+                const int tok = pr / a.n_used, slot = pr - tok * a.n_used;
+                e = a.ids[(int64_t)tok * a.ids_tok_stride + slot];
+                if (e < 0 || e >= ne) e = -1;                            // (an id out of range: the slot stays unwritten, as documented)
+                src = tok * a.n_b + slot % a.n_b;                        // slot u reads activation row u % n_b (ggml-cpu.c:7752)
+            }
+            ekey[i * NT + tid] = (int16_t)e; esrc[i * NT + tid] = src;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int c = wv; c < CH; c += NW) {                              // (wave-uniform trip count)
+            const int e = ekey[c * 64 + ln];
+            int rank_w = 0, tot_w = 0;
             bool todo = e >= 0;
             for (uint64_t left = wave_ballot(todo); left != 0; left = wave_ballot(todo)) {
                 const int key = __builtin_amdgcn_readlane(e, __builtin_ctzll(left));
                 const uint64_t m = wave_ballot(e == key);
-                if (e == key) { r_c[i] = __builtin_popcountll(m & lt); tot_w = __builtin_popcountll(m); todo = false; }
+                if (e == key) { rank_w = __builtin_popcountll(m & lt); tot_w = __builtin_popcountll(m); todo = false; }
             }
-            if (e >= 0 && r_c[i] == 0) wtab[(i * NW + wv) * ne + e] = (uint16_t)tot_w;
+            if (e >= 0 && rank_w == 0) wtab[c * ne + e] = (uint16_t)tot_w;
+            erank[c * 64 + ln] = (uint8_t)rank_w;
         }
         __syncthreads();
-        for (int e = tid; e < ne; e += NT) {                             // exclusive prefix over the round's chunks, started at the rows placed by earlier rounds
-            int run = pos[e];
+#pragma unroll 1
+        for (int e = tid; e < ne; e += NT) {
+            int run = start ? start[e] : 0;
             for (int c = 0; c < CH; c++) { const int v = wtab[c * ne + e]; wtab[c * ne + e] = (uint16_t)run; run += v; }
-            pos[e] = run;
+            total[e] = run;
         }
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < CMAX / NW; i++) {
-            const int e = e_c[i];
-            if (i * NW >= CH || e < 0) continue;
-            const int pr = base + (i * NW + wv) * 64 + ln, tok = pr / a.n_used, slot = pr - tok * a.n_used;
-            const int rank = (int)wtab[(i * NW + wv) * ne + e] + r_c[i], t = tpre[e] + (rank >> 7);
-            if (t < ntl) {
-                int32_t *rec = a.tile_rec + (int64_t)t * REC;
-                rec[4 + (rank & 127)] = tok * a.n_b + slot % a.n_b;      // slot u reads activation row u % n_b (ggml-cpu.c:7752)
-                rec[132 + (rank & 127)] = pr;
-            }
+    };
+    if (one_round) rank_round(0, nullptr, cnt);                          // (the totals ARE the counts: no separate counting pass)
+    else {
+        for (int e = tid; e < ne; e += NT) cnt[e] = 0;
+        __syncthreads();
+#pragma unroll 1
+        for (int pr = tid; pr < n_pairs; pr += NT) {
+            const int tok = pr / a.n_used, e = a.ids[(int64_t)tok * a.ids_tok_stride + (pr - tok * a.n_used)];
+            if (e >= 0 && e < ne) atomicAdd(&cnt[e], 1);
         }
         __syncthreads();
     }
+    for (int e = tid; e < ne; e += NT) tpre[e] = (cnt[e] + TR - 1) >> trs;
+    __syncthreads();
+    block_excl_scan<NT>(tpre, ne, tmp);
+    const int ntl = min(tpre[ne], a.ntile_cap);                          // (never more than the capacity by construction: the launcher sized it)
+    // rows and unit cost of every tile, in LDS (every GLOBAL store of the plan comes behind its last barrier: a barrier waits for the stores in front of it)
+#pragma unroll 1
+    for (int t = tid; t < ntl; t += NT) {
+        const int e = upper_bound_i(tpre, ne + 1, t) - 1;
+        const int rows = min(TR, cnt[e] - ((t - tpre[e]) << trs));
+        cpre[t] = a.cw[((rows + 31) >> 5) - 1]; trows[t] = (uint8_t)(rows - 1);
+    }
+    __syncthreads();
+    block_excl_scan<NT>(cpre, ntl, tmp);
+    auto place_round = [&](int base) __attribute__((always_inline)) {
+#pragma unroll 1
+        for (int i = tid; i < CH * 64; i += NT) {
+            const int e = ekey[i];
+            if (e < 0) continue;
+            const int rank = (int)wtab[(i >> 6) * ne + e] + (int)erank[i], t = tpre[e] + (rank >> trs), row = rank & (TR - 1);
+            if (t < ntl) { int32_t *rec = a.tile_rec + (int64_t)t * REC; rec[4 + row] = esrc[i]; rec[4 + TR + row] = base + i; }
+        }
+    };
+    if (one_round) place_round(0);
+    else {
+        for (int e = tid; e < ne; e += NT) pos[e] = 0;
+#pragma unroll 1
+        for (int base = 0; base < n_pairs; base += CH * 64) {
+            rank_round(base, pos, pos);                                  // (its first barrier also orders pos[] = 0 / the previous round's placement in front of this round)
+            place_round(base);
+            __syncthreads();
+        }
+    }
+    // tile headers (the GEMM treats the entries behind a tile's rows as padding itself: they are never written)
+    for (int t = tid; t < ntl; t += NT) {
+        const int e = upper_bound_i(tpre, ne + 1, t) - 1, rows = (int)trows[t] + 1;
+        int32_t *rec = a.tile_rec + (int64_t)t * REC;
+        rec[0] = e; rec[1] = rows; rec[2] = t - tpre[e]; rec[3] = (rows + 31) >> 5;
+    }
+    // the spans: cost position of unit (t, l) = cpre[t] * upt + l * cw_t (64-bit products, no 64-bit integer division); work-group w starts at the
+    // first unit at or behind w / geff of the total.  Fewer work-groups take part when the whole job is small (each gets at least about two superblocks of a full tile)
+    const unsigned long long CT = (unsigned long long)cpre[ntl] * (unsigned)a.upt;
+    const double CTd = (double)CT;
+    const double gq = CTd / (double)(2 * a.cw[TR / 32 - 1]);
+    const unsigned geff = gq < 1.0 ? 1u : (gq > (double)a.G ? (unsigned)a.G : (unsigned)gq);
+    const int u_end = ntl * a.upt;
+#pragma unroll 1
+    for (int w = tid; w <= a.G; w += NT) {
+        int u = u_end;
+        if ((unsigned)w < geff && ntl > 0) {
+            // (any non-decreasing sequence of positions below CT serves: CT w is exact in a double — CT < 2^40, w < 2^10 — and dividing by one positive constant keeps the order)
+            const unsigned long long x = (unsigned long long)(CTd * (double)w / (double)geff);
+            int lo = 0, hi = ntl + 1;                                    // first t with cpre[t] * upt > x, minus one
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((unsigned long long)cpre[mid] * (unsigned)a.upt > x) hi = mid; else lo = mid + 1; }
+            const int t = lo - 1;
+            const unsigned c = (unsigned)(cpre[t + 1] - cpre[t]), rem = (unsigned)(x - (unsigned long long)cpre[t] * (unsigned)a.upt);      // rem < c * upt
+            u = t * a.upt + (int)((rem + c - 1) / c);
+        }
+        a.wg_begin[w] = u;
+    }
+    if (tid == 0) a.wg_begin[a.G + 1] = ntl;
 }
 template <bool KQ>
 __global__ __launch_bounds__(256) void k_moe_sk_front(const moe_sk_args a, const float *__restrict__ x, int64_t x_row_stride, int K, int B, half_t *__restrict__ xh) {
-    if (blockIdx.x == 0) { moe_sk_plan(a); return; }
+    if (blockIdx.x == 0) { if (a.n_tok > 0) moe_sk_plan(a); return; }
     const int64_t t = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x;
     if constexpr (KQ) quantize_q8_K_thread(t, x, x_row_stride, K, B, nullptr, nullptr, nullptr, xh, nullptr);
     else quantize_q8_0_thread<false>(t, x, x_row_stride, K, B, nullptr, nullptr, xh, nullptr);
 }
 // x: the n_tok * n_b activation rows (x_row_stride apart); kq: Q8_K (K-quants) or Q8_0 rounding of the image; tile_rec / wg_begin: see moe_sk_args
-int cdna4_launch_moe_sk_front(const int32_t *ids, int64_t ids_tok_stride, int n_tok, int n_used, int n_b, int n_expert, int ntile_cap, int upt, int G, const int *cw,
+int cdna4_launch_moe_sk_front(const int32_t *ids, int64_t ids_tok_stride, int n_tok, int n_used, int n_b, int n_expert, int ntile_cap, int tile_rows, int upt, int G, const int *cw,
                               int32_t *tile_rec, int32_t *wg_begin, const float *x, int64_t x_row_stride, int64_t K, bool kq, void *xh, hipStream_t st) {
     if (n_expert > 1024) return cdna4_set_error_msg("moe_sk_front: more than 1024 experts");
+    if (tile_rows != 128 && tile_rows != 256) return cdna4_set_error_msg("moe_sk_front: tiles of 128 or 256 rows");
     if (ntile_cap > CDNA4_SK_MAX_TILES) return cdna4_set_error_msg("moe_sk_front: too many tiles for the planner");
     if (K % (kq ? QK_K : 32)) return cdna4_set_error_msg("moe_sk_front: K must be a whole number of activation blocks");
     moe_sk_args a{};
     a.ids = ids; a.ids_tok_stride = ids_tok_stride; a.n_tok = n_tok; a.n_used = n_used; a.n_b = n_b; a.n_expert = n_expert;
-    a.ntile_cap = ntile_cap; a.upt = upt; a.G = G; for (int i = 0; i < 4; i++) a.cw[i] = cw[i];
+    a.ntile_cap = ntile_cap; a.tile_rows = tile_rows; a.upt = upt; a.G = G; for (int i = 0; i < tile_rows / 32; i++) a.cw[i] = cw[i];
     a.tile_rec = tile_rec; a.wg_begin = wg_begin;
     const int64_t B = (int64_t)n_tok * n_b, nthr = kq ? B * (K / 16) : B * (K / 4);
-    const dim3 grid((unsigned)(1 + (nthr + 255) / 256));
+    // (CDNA4_SK_FRONT_ABL, timing only: 1 = the planner alone, 2 = the quantizer alone — the plan of an earlier call is used)
+    static const int abl = getenv("CDNA4_SK_FRONT_ABL") ? atoi(getenv("CDNA4_SK_FRONT_ABL")) : 0;
+    if (abl == 2) a.n_tok = 0;
+    const dim3 grid(abl == 1 ? 1u : (unsigned)(1 + (nthr + 255) / 256));
     if (kq) hipLaunchKernelGGL(k_moe_sk_front<true>, grid, dim3(256), 0, st, a, x, x_row_stride, (int)K, (int)B, (half_t *)xh);
     else hipLaunchKernelGGL(k_moe_sk_front<false>, grid, dim3(256), 0, st, a, x, x_row_stride, (int)K, (int)B, (half_t *)xh);
     CDNA4_CHECK_LAUNCH();

@@ -11,7 +11,7 @@ pthread_barrier_t g_wg_barrier;
 WaveState *g_waves;
 thread_local std::vector<Pending> t_vmq;
 bool g_defer_dma = getenv("EMU_DEFER_DMA") && atoi(getenv("EMU_DEFER_DMA")) != 0;
-size_t g_weaken = 0;
+size_t g_weaken = getenv("EMU_WEAKEN_WAITS") ? (size_t)atoi(getenv("EMU_WEAKEN_WAITS")) : 0;      // self-test of the counted waits: every wait tolerates this many more outstanding operations
 }
 __attribute__((aligned(16))) uint8_t smem[160 * 1024];             // the dynamic LDS of gemv_q.hip's kernels (a work-group is a process)
 void *emu_shared_alloc(size_t n) {                                   // between two inaccessible pages, shared with the work-group processes
