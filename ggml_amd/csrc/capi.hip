@@ -59,7 +59,7 @@ static moe_sk_view moe_sk_carve(int64_t K, int64_t n_expert, int64_t n_used, int
     const int64_t n_pairs = n_tok * n_used;
     v.n_rows = n_tok * n_b;
     v.ntile_cap = (n_expert < n_pairs ? n_expert : n_pairs) + n_pairs / 128 + 1;          // >= sum_e ceil(cnt_e / 128)
-    v.tile_rec = (int32_t *)(p + off); off += align256((size_t)v.ntile_cap * (4 + 2 * 256) * 4);       // (records of the 256-row tiling; the 128-row one has more, smaller ones: fits)
+    v.tile_rec = (int32_t *)(p + off); off += align256((size_t)v.ntile_cap * CDNA4_SK_REC * 4);
     v.wg_begin = (int32_t *)(p + off); off += align256((size_t)(1024 + 2) * 4);
     v.xh = (void *)(p + off); off += align256((size_t)v.n_rows * K * 2) + 32768;
     v.total = off;
@@ -553,25 +553,19 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
                     // issue work, which does not depend on the fragments — a tile with one fragment in use takes 1.78-1.91 us per superblock, a full one 1.86-1.92
                     // (profiles/r06/moe_sk_trace_*.txt), with or without the activation DMA of the empty fragments; weights that call light tiles cheaper lost: 8 x 2 x 512 x 4096^2,
                     // us per call, one box: 10,10,10,10 72.2 | 8,9,10,10 79.8 | 7,8,9,10 85.0 | 6,8,9,10 90.7 | 5,7,9,10 98.1 | 4,6,8,10 107.6 (CDNA4_SK_CW=a,b,c,d: measurement knob)
-                    struct sk_costs { int c[4], c8[8], tile; sk_costs() : c{10, 10, 10, 10}, c8{10, 10, 10, 10, 10, 10, 10, 10}, tile(0) {
-                        int t[8]; const char *ev = getenv("CDNA4_SK_CW");
-                        if (ev && sscanf(ev, "%d,%d,%d,%d", &t[0], &t[1], &t[2], &t[3]) == 4 && t[0] > 0 && t[1] > 0 && t[2] > 0 && t[3] > 0 && t[3] < 256) for (int i = 0; i < 4; i++) c[i] = t[i];
-                        ev = getenv("CDNA4_SK_CW8");
-                        if (ev && sscanf(ev, "%d,%d,%d,%d,%d,%d,%d,%d", &t[0], &t[1], &t[2], &t[3], &t[4], &t[5], &t[6], &t[7]) == 8) { bool ok = true; for (int i = 0; i < 8; i++) ok = ok && t[i] > 0 && t[i] < 256; if (ok) for (int i = 0; i < 8; i++) c8[i] = t[i]; }
-                        if (getenv("CDNA4_SK_TILE")) tile = atoi(getenv("CDNA4_SK_TILE")); } };
+                    struct sk_costs { int c[4]; sk_costs() : c{10, 10, 10, 10} { int t4[4]; const char *ev = getenv("CDNA4_SK_CW");
+                        if (ev && sscanf(ev, "%d,%d,%d,%d", &t4[0], &t4[1], &t4[2], &t4[3]) == 4 && t4[0] > 0 && t4[1] > 0 && t4[2] > 0 && t4[3] > 0 && t4[3] < 256) for (int i = 0; i < 4; i++) c[i] = t4[i]; } };
                     static const sk_costs costs;
-                    // tile rows: 256 (k_gemm_r8_sk: an expert's rows up to 256 are ONE visit of every m-tile) or 128 (k_gemm_kq_sk); CDNA4_SK_TILE forces one
-                    const int tile_rows = costs.tile == 128 || costs.tile == 256 ? costs.tile : 256;
-                    const int *cw = tile_rows == 256 ? costs.c8 : costs.c;
+                    const int *cw = costs.c;
                     const int G = cdna4_gemm_sk_spans();
-                    const int64_t upt = ((M + tile_rows - 1) / tile_rows) * (K / 256);
-                    int rc = cdna4_launch_moe_sk_front(ids, ids_tok_stride, (int)n_tok, (int)n_used, (int)n_b, (int)n_expert, (int)sv.ntile_cap, tile_rows, (int)upt, G, cw, sv.tile_rec, sv.wg_begin,
+                    const int64_t upt = ((M + 127) / 128) * (K / 256);
+                    int rc = cdna4_launch_moe_sk_front(ids, ids_tok_stride, (int)n_tok, (int)n_used, (int)n_b, (int)n_expert, (int)sv.ntile_cap, (int)upt, G, cw, sv.tile_rec, sv.wg_begin,
                                                        b, b_row_stride, K, sk_type == CDNA4_Q4_K, sv.xh, (hipStream_t)stream);
                     if (rc) return rc;
                     cdna4_gemm_args a{};
                     a.type = sk_type; a.W = skW; a.w_row_bytes = sk_row; a.xh = sv.xh; a.xh_row_elems = K;
                     a.Y = dst; a.y_row_elems = dst_row_stride; a.M = (int)M; a.K = (int)K; a.B = (int)sv.n_rows;
-                    return cdna4_launch_gemm_sk(a, sv.tile_rec, sv.wg_begin, G, sk_exp, tile_rows, (hipStream_t)stream);
+                    return cdna4_launch_gemm_sk(a, sv.tile_rec, sv.wg_begin, G, sk_exp, (hipStream_t)stream);
                 }
             }
         }

@@ -14,9 +14,9 @@ int cdna4_launch_quantize_q8_0(const float *x, int64_t x_row_stride, int64_t K, 
 int cdna4_launch_moe_plan(const int32_t *ids, int64_t ids_tok_stride, int n_tok, int n_used, int n_b, int n_expert, int img_rows,
                           int32_t *img_src, int32_t *img_dst, int32_t *tile_expert, hipStream_t st);
 // grouped MUL_MAT_ID, stream-k form (round 6): ONE launch = the planner (work-group 0) + the activation quantizer in token order; then k_gemm_kq_sk (gemm_q_sk.hip)
-#define CDNA4_SK_REC 260               // int32 per record of a 128-row tile: expert, rows, index within the expert, fragments, src row [128], dst pair [128]  (256-row tiles: 516)
+#define CDNA4_SK_REC 260               // int32 per tile record: expert, rows, index within the expert, fragments, src row [128], dst pair [128]
 #define CDNA4_SK_MAX_TILES 2047        // tiles the planner's LDS tables hold
-int cdna4_launch_moe_sk_front(const int32_t *ids, int64_t ids_tok_stride, int n_tok, int n_used, int n_b, int n_expert, int ntile_cap, int tile_rows, int upt, int G, const int *cw,
+int cdna4_launch_moe_sk_front(const int32_t *ids, int64_t ids_tok_stride, int n_tok, int n_used, int n_b, int n_expert, int ntile_cap, int upt, int G, const int *cw,
                               int32_t *tile_rec, int32_t *wg_begin, const float *x, int64_t x_row_stride, int64_t K, bool kq, void *xh, hipStream_t st);
 // Q8_1 (activations of Q4_1 / Q5_1 weights): as q8_0 without ref_rounding, plus s[B][K/32] = fp16(d * sum of the block's quants) as fp32
 // two_part: xh has 2 K columns, the second K holding s in the first column of every 32-block and zeros elsewhere (the GEMM image of Q4_1 / Q5_1)
@@ -98,7 +98,7 @@ int cdna4_launch_gemm_t64_ids(const cdna4_gemm_args &a, const int32_t *tile_expe
 // gemm_q_sk.hip — the same as ONE stream-k launch of persistent work-groups over the plan of cdna4_launch_moe_sk_front (a.B = rows of the token-order image)
 int cdna4_gemm_sk_spans();                                                                    // work-groups of the launch (= spans the planner cuts)
 bool cdna4_gemm_sk_supported(int type, int64_t M, int64_t K, int64_t n_rows, int64_t ntile_cap);
-int cdna4_launch_gemm_sk(const cdna4_gemm_args &a, const int32_t *tile_rec, const int32_t *wg_begin, int G, int64_t w_expert_bytes, int tile_rows, hipStream_t st);
+int cdna4_launch_gemm_sk(const cdna4_gemm_args &a, const int32_t *tile_rec, const int32_t *wg_begin, int G, int64_t w_expert_bytes, hipStream_t st);
 // the same for any of the five headline formats (gemm_q_mfma.hip): Q4_K on aligned rows -> k_gemm_kq_t64<.., IDS>, the others -> k_gemm_q<.., IDS>
 bool cdna4_gemm_ids_supported(int type, int64_t K);
 int cdna4_launch_gemm_ids(const cdna4_gemm_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);

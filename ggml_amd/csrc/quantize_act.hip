@@ -241,7 +241,7 @@ int cdna4_launch_moe_plan(const int32_t *ids, int64_t ids_tok_stride, int n_tok,
 // The activations are quantized in TOKEN order (row = token * n_b + slot % n_b: n_tok * n_b rows, not one per (token, slot) pair and no padding rows) — the grouped GEMM
 // (k_gemm_kq_sk, gemm_kq_sk.inc) gathers a tile's rows by index in its LDS-DMA, so the quantizer does not depend on the plan and the two share a launch.
 // The plan (what the CPU does on one thread before its per-expert mul_mats, ggml-cpu.c:7679-7694, and what ggml-cuda.cu:1975-1978 copies the ids to the HOST for):
-//   * counts per expert, tiles of up to 128 (or 256) (token, slot) rows per expert — a tile RECORD per tile: [expert, rows, index within the expert, 32-row fragments with
+//   * counts per expert, tiles of up to 128 (token, slot) rows per expert — a tile RECORD per tile: [expert, rows, index within the expert, 32-row fragments with
 //     rows, src row of each tile row, dst (token, slot) pair of each]; the entries behind a tile's rows are not written (the GEMM clamps them);
 //   * the partition of the launch's work — (tile, m-tile, superblock) units, linear index u = (tile * tiles_m + m-tile) * nsb + superblock, weighted by the tile's fragment
 //     count — into G contiguous spans of equal cost: wg_begin[0 .. G] (the reference's stream-k decomposition, src/ggml-cuda/mmq.cuh:2588-2655, with weights).
@@ -251,9 +251,8 @@ struct moe_sk_args {
     int ntile_cap;                     // tile records the table can hold (>= min(n_expert, pairs) + pairs / 128)
     int upt;                           // units per activation tile: tiles_m * nsb
     int G;                             // work-groups of the GEMM launch
-    int tile_rows;                     // rows per tile: 128 (k_gemm_kq_sk) or 256 (k_gemm_r8_sk); a tile record is 4 + 2 * tile_rows int32
-    int cw[8];                         // cost of one unit of a tile with 1 .. tile_rows / 32 fragments in use (relative)
-    int32_t *tile_rec;                 // [ntile_cap][4 + 2 * tile_rows]
+    int cw[4];                         // cost of one unit of a tile with 1 .. 4 fragments in use (relative)
+    int32_t *tile_rec;                 // [ntile_cap][CDNA4_SK_REC]
     int32_t *wg_begin;                 // [G + 2]: unit index where work-group w starts; [G] = end; [G + 1] = tiles in use
 };
 // in-place exclusive prefix sum of a[0 .. n) in LDS by the whole work-group (NT threads); a[n] = the total.  Every thread sums a run of ceil(n / NT) entries, the runs' sums
@@ -287,7 +286,7 @@ __device__ __forceinline__ int upper_bound_i(const int *a, int n, long long v) {
 //  a tile's padding rows itself.)
 __device__ void moe_sk_plan(const moe_sk_args &a) {
     constexpr int NT = 256, NW = NT / 64, WTAB = 4096, CMAX = 16;
-    const int trs = a.tile_rows == 256 ? 8 : 7, TR = 1 << trs, REC = 4 + 2 * TR;      // rows per tile (128: k_gemm_kq_sk, 256: k_gemm_r8_sk); int32 per tile record
+    constexpr int trs = 7, TR = 1 << trs, REC = CDNA4_SK_REC;           // rows per tile; int32 per tile record
     __shared__ int cnt[1024], tpre[1025], cpre[CDNA4_SK_MAX_TILES + 1], tmp[NW];
     __shared__ uint8_t trows[CDNA4_SK_MAX_TILES + 1];                   // rows of tile t, minus one
     __shared__ uint16_t wtab[WTAB];                                     // the stable ranking: [chunk of the round][expert]
@@ -396,7 +395,7 @@ __device__ void moe_sk_plan(const moe_sk_args &a) {
     // first unit at or behind w / geff of the total.  Fewer work-groups take part when the whole job is small (each gets at least about two superblocks of a full tile)
     const unsigned long long CT = (unsigned long long)cpre[ntl] * (unsigned)a.upt;
     const double CTd = (double)CT;
-    const double gq = CTd / (double)(2 * a.cw[TR / 32 - 1]);
+    const double gq = CTd / (double)(2 * a.cw[3]);
     const unsigned geff = gq < 1.0 ? 1u : (gq > (double)a.G ? (unsigned)a.G : (unsigned)gq);
     const int u_end = ntl * a.upt;
 #pragma unroll 1
@@ -417,21 +416,21 @@ __device__ void moe_sk_plan(const moe_sk_args &a) {
 }
 template <bool KQ>
 __global__ __launch_bounds__(256) void k_moe_sk_front(const moe_sk_args a, const float *__restrict__ x, int64_t x_row_stride, int K, int B, half_t *__restrict__ xh) {
-    if (blockIdx.x == 0) { if (a.n_tok > 0) moe_sk_plan(a); return; }
+    // (the planner is the step's critical path and shares its CU with quantizer work-groups: its waves go first)
+    if (blockIdx.x == 0) { if (a.n_tok > 0) { __builtin_amdgcn_s_setprio(3); moe_sk_plan(a); } return; }
     const int64_t t = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x;
     if constexpr (KQ) quantize_q8_K_thread(t, x, x_row_stride, K, B, nullptr, nullptr, nullptr, xh, nullptr);
     else quantize_q8_0_thread<false>(t, x, x_row_stride, K, B, nullptr, nullptr, xh, nullptr);
 }
 // x: the n_tok * n_b activation rows (x_row_stride apart); kq: Q8_K (K-quants) or Q8_0 rounding of the image; tile_rec / wg_begin: see moe_sk_args
-int cdna4_launch_moe_sk_front(const int32_t *ids, int64_t ids_tok_stride, int n_tok, int n_used, int n_b, int n_expert, int ntile_cap, int tile_rows, int upt, int G, const int *cw,
+int cdna4_launch_moe_sk_front(const int32_t *ids, int64_t ids_tok_stride, int n_tok, int n_used, int n_b, int n_expert, int ntile_cap, int upt, int G, const int *cw,
                               int32_t *tile_rec, int32_t *wg_begin, const float *x, int64_t x_row_stride, int64_t K, bool kq, void *xh, hipStream_t st) {
     if (n_expert > 1024) return cdna4_set_error_msg("moe_sk_front: more than 1024 experts");
-    if (tile_rows != 128 && tile_rows != 256) return cdna4_set_error_msg("moe_sk_front: tiles of 128 or 256 rows");
     if (ntile_cap > CDNA4_SK_MAX_TILES) return cdna4_set_error_msg("moe_sk_front: too many tiles for the planner");
     if (K % (kq ? QK_K : 32)) return cdna4_set_error_msg("moe_sk_front: K must be a whole number of activation blocks");
     moe_sk_args a{};
     a.ids = ids; a.ids_tok_stride = ids_tok_stride; a.n_tok = n_tok; a.n_used = n_used; a.n_b = n_b; a.n_expert = n_expert;
-    a.ntile_cap = ntile_cap; a.tile_rows = tile_rows; a.upt = upt; a.G = G; for (int i = 0; i < tile_rows / 32; i++) a.cw[i] = cw[i];
+    a.ntile_cap = ntile_cap; a.upt = upt; a.G = G; for (int i = 0; i < 4; i++) a.cw[i] = cw[i];
     a.tile_rec = tile_rec; a.wg_begin = wg_begin;
     const int64_t B = (int64_t)n_tok * n_b, nthr = kq ? B * (K / 16) : B * (K / 4);
     // (CDNA4_SK_FRONT_ABL, timing only: 1 = the planner alone, 2 = the quantizer alone — the plan of an earlier call is used)
