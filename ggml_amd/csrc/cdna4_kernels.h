@@ -66,6 +66,9 @@ int cdna4_launch_gemv_q_fused_ids(const cdna4_gemv_args &a, const float *x, int6
 // a.qs / a.d / a.bsums as for cdna4_launch_gemv_q (Q8_K workspace), a.epi applied in the store
 bool cdna4_mmq_supported(int type, int64_t M, int64_t K, int64_t B);
 int cdna4_launch_mmq(const cdna4_gemv_args &a, hipStream_t st);
+// the K-sliced ONE-launch form (Q4_K, 2 .. 32 rows): quantizer inside, x = the fp32 rows; g.qs / g.d / g.bsums unused
+bool cdna4_mmq_ks_supported(int type, int64_t M, int64_t K, int64_t B);
+int cdna4_launch_mmq_ks(const cdna4_gemv_args &g, const float *x, int64_t x_row_stride, hipStream_t st);
 bool cdna4_mmq_ids_supported(int type, int64_t K);                  // grouped MUL_MAT_ID on the int8 matrix cores: a.qs / a.d / a.bsums = the expert-sorted image (a.ncol rows)
 int cdna4_launch_mmq_ids(const cdna4_gemv_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);
 

@@ -801,7 +801,23 @@ static int launch_fused_nb(const cdna4_gemv_args &a, const float *x, int64_t x_r
     static bool raised_[16] = {};                                       // (a function attribute is per device)
     int dev_ = 0; if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 16) { (void)hipGetLastError(); dev_ = 0; }
     bool &raised = raised_[dev_];
-    if (!raised) { if (hipFuncSetAttribute((const void *)k_gemv_q_fused<TYPE, 8, 2, false, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { (void)hipGetLastError(); return cdna4_set_error_msg("gemv_q_fused: cannot raise the dynamic LDS limit"); } raised = true; }
+    if (!raised) {
+        if (hipFuncSetAttribute((const void *)k_gemv_q_fused<TYPE, 8, 2, false, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { (void)hipGetLastError(); return cdna4_set_error_msg("gemv_q_fused: cannot raise the dynamic LDS limit"); }
+        if constexpr (NB <= 4 && (QT<TYPE>::KQ || TYPE == CDNA4_Q4_0) && !(TYPE == CDNA4_Q5_K && NB == 2)) {      // (Q5_K x 2 columns needs more than the 128 registers of a 16-wave work-group)
+            if (hipFuncSetAttribute((const void *)k_gemv_q_fused<TYPE, 16, 1, false, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { (void)hipGetLastError(); return cdna4_set_error_msg("gemv_q_fused: cannot raise the dynamic LDS limit"); }
+        }
+        raised = true;
+    }
+    // Round 6: 2 and 4 rows take the 16-wave x 1-row work-groups of the one-row decode (round 5: the quantizer is still paid once per 16 weight rows, by twice as many
+    // lanes, and every wave multiplies ONE row) wherever that is one work-group per CU at most — CDNA4_FUSED_NB_CFG=0 keeps 8 x 2
+    static const int cfg_env = getenv("CDNA4_FUSED_NB_CFG") ? atoi(getenv("CDNA4_FUSED_NB_CFG")) : -1;
+    if constexpr (NB <= 4 && (QT<TYPE>::KQ || TYPE == CDNA4_Q4_0) && !(TYPE == CDNA4_Q5_K && NB == 2)) {      // (Q5_K x 2 columns needs more than the 128 registers of a 16-wave work-group)
+        if (cfg_env != 0 && (a.M + 15) / 16 <= cdna4_gemm_cu_count() && a.M >= 2048) {
+            hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 16, 1, false, NB>), dim3((a.M + 15) / 16), dim3(1024), lds, st, a, x, x_row_stride);
+            CDNA4_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((k_gemv_q_fused<TYPE, 8, 2, false, NB>), dim3((a.M + 15) / 16), dim3(512), lds, st, a, x, x_row_stride);
     CDNA4_CHECK_LAUNCH();
     return 0;
