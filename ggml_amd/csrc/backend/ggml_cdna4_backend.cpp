@@ -325,6 +325,7 @@ static void cdna4_backend_free(ggml_backend_t backend) {
     (void)hipStreamSynchronize(ctx->stream);
     cdna4_split_free_lanes(ctx);
     if (getenv("GGML_CDNA4_STATS")) fprintf(stderr, "ggml-cdna4: %s: %d HIP-graph captures, %d replays\n", ctx->name.c_str(), ctx->n_graph_captures, ctx->n_graph_launches);
+    if (getenv("GGML_CDNA4_STATS") && ctx->n_grouped) fprintf(stderr, "ggml-cdna4: %s: %d one-row MUL_MATs rode in the launch of another product of the same activations\n", ctx->name.c_str(), ctx->n_grouped);
     if (getenv("GGML_CDNA4_STATS") && ctx->n_act_shared) fprintf(stderr, "ggml-cdna4: %s: %d MUL_MATs multiplied quantized activations that were already in the workspace (%d images left by NORM chains)\n", ctx->name.c_str(), ctx->n_act_shared, ctx->n_act_produced);
     if (getenv("GGML_CDNA4_STATS") && (ctx->n_ksplit_rccl || ctx->n_ksplit_sum)) fprintf(stderr, "ggml-cdna4: %s: K-split MUL_MAT: %d RCCL all-reduces, %d in-order sums\n", ctx->name.c_str(), ctx->n_ksplit_rccl, ctx->n_ksplit_sum);
     for (auto & gs : ctx->graph_slots) if (gs.exec) (void)hipGraphExecDestroy(gs.exec);
@@ -427,6 +428,73 @@ static int try_fused_mul_mat(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, co
     if (rc) { fprintf(stderr, "ggml-cdna4: fused MUL_MAT failed: %s\n", ggml_cdna4_last_error()); st = GGML_STATUS_FAILED; }
     return used;
 }
+// ---- one-row MUL_MATs that read the SAME src1 (wq / wk / wv, w_gate / w_up of a decoded token) as ONE launch (round 6).  From the MUL_MAT at node i the
+// walk looks a few nodes ahead for plain one-row products of the same activation tensor, weight type and K; a later one may run early (with node i) when nothing between
+// the two touches its output's memory — the graph allocator placed that output assuming node order, so it may still hold a tensor that is live until then.  The products that
+// rode along are marked done and skipped when the walk reaches them.  Bit-identical to the node-by-node run (ggml_cdna4_mul_mat_group).  GGML_CDNA4_NO_GROUP=1: off.
+static std::atomic<int> g_grouped{0};
+extern "C" int ggml_backend_cdna4_grouped_count(void) { return g_grouped.load(); }
+static bool group_on() { static const bool off = getenv("GGML_CDNA4_NO_GROUP") != nullptr; return !off && !cdna4_exact_mode(); }
+static bool plain_one_row_mul_mat(const ggml_tensor * t) {
+    if (t->op != GGML_OP_MUL_MAT || ggml_is_empty(t)) return false;
+    const ggml_tensor * a = t->src[0], * b = t->src[1];
+    if (!is_qweight(a->type) || (a->buffer && cdna4_buft_is_split(a->buffer->buft))) return false;
+    if (a->ne[2] != 1 || a->ne[3] != 1 || b->ne[1] != 1 || b->ne[2] != 1 || b->ne[3] != 1 || b->type != GGML_TYPE_F32 || !ggml_is_contiguous(t) || t->type != GGML_TYPE_F32) return false;
+    return a->nb[0] == ggml_type_size(a->type) && b->nb[0] == sizeof(float) && !((uintptr_t)b->data & 15);
+}
+// tries to run node i together with later one-row products of its src1; returns true if node i has been computed (done[] marks every node the launch covered)
+static bool try_group_mul_mat(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, const use_counts & uses, std::vector<char> & done, enum ggml_status & st) {
+    ggml_tensor * mm = ggml_graph_node(g, i);
+    if (!group_on() || !plain_one_row_mul_mat(mm)) return false;
+    const int n_nodes = ggml_graph_n_nodes(g);
+    // a member: the product at node k, or the product + the ADD of a row vector behind it (a bias — at one row a residual looks the same and IS the same sum): the launch
+    // then writes the ADD's tensor and the product's own tensor is never written (as in try_fused_mul_mat)
+    struct member { int k; ggml_tensor * out; const ggml_tensor * bias; };
+    auto member_of = [&](int k, member & m) {
+        ggml_tensor * t = ggml_graph_node(g, k);
+        m.k = k; m.out = t; m.bias = nullptr;
+        if (k + 1 < n_nodes && !done[k + 1]) {
+            ggml_tensor * n1 = ggml_graph_node(g, k + 1);
+            const ggml_tensor * b = n1->op == GGML_OP_ADD && uses.only_reader(t, n1) && ggml_are_same_shape(n1, t) && ggml_is_contiguous(n1) ? other_src(n1, t) : nullptr;
+            if (b && is_row_vector_f32(b, t->src[0]->ne[1]) && !mem_overlap(n1, b) && !mem_overlap(n1, t->src[0]) && !mem_overlap(n1, t->src[1])) { m.out = n1; m.bias = b; }
+        }
+    };
+    member ms[4]; int n = 1;
+    member_of(i, ms[0]);
+    for (int k = i + 1; k < n_nodes && k <= i + 12 && n < 4; k++) {
+        ggml_tensor * t = ggml_graph_node(g, k);
+        if (done[k] || !plain_one_row_mul_mat(t) || t->src[1] != mm->src[1] || t->src[0]->type != mm->src[0]->type || t->src[0]->ne[0] != mm->src[0]->ne[0]) continue;
+        member c; member_of(k, c);
+        // the member runs EARLY: what it writes must not overlap anything the nodes in front of it (from i on, outside the group) read or write, the activation row, or
+        // another member's output
+        bool ok = !mem_overlap(c.out, mm->src[1]);
+        for (int q = 0; q < n && ok; q++) if (mem_overlap(c.out, ms[q].out) || (ms[q].bias && mem_overlap(c.out, ms[q].bias))) ok = false;
+        for (int q = i; q < k && ok; q++) {
+            const ggml_tensor * nq = ggml_graph_node(g, q);
+            if (mem_overlap(c.out, nq)) ok = false;
+            for (int j = 0; j < GGML_MAX_SRC && ok; j++) if (nq->src[j] && nq->src[j]->data && mem_overlap(c.out, nq->src[j])) ok = false;
+        }
+        if (getenv("GGML_CDNA4_GROUP_DEBUG")) fprintf(stderr, "ggml-cdna4: group candidate %s behind %s: %s\n", t->name, mm->name, ok ? "taken" : "its output's memory is in use in between");
+        if (ok) ms[n++] = c;
+    }
+    if (n < 2) return false;
+    const void * W[4]; int64_t rb[4], M[4]; float * Y[4]; const float * bias[4];
+    for (int q = 0; q < n; q++) {
+        const ggml_tensor * t = ggml_graph_node(g, ms[q].k);
+        W[q] = t->src[0]->data; rb[q] = (int64_t)t->src[0]->nb[1]; M[q] = t->src[0]->ne[1]; Y[q] = (float *)ms[q].out->data; bias[q] = ms[q].bias ? (const float *)ms[q].bias->data : nullptr;
+    }
+    const int rc = ggml_cdna4_mul_mat_group((int)mm->src[0]->type, n, W, rb, M, Y, bias, (const float *)mm->src[1]->data, mm->src[0]->ne[0], ctx->stream);
+    if (rc == -2) return false;                                         // no grouped form for these: node by node
+    if (rc) { fprintf(stderr, "ggml-cdna4: grouped MUL_MAT failed: %s\n", ggml_cdna4_last_error()); st = GGML_STATUS_FAILED; return true; }
+    for (int q = 0; q < n; q++) {
+        done[ms[q].k] = 1;
+        if (ms[q].bias) done[ms[q].k + 1] = 1;
+        node_wrote(ctx, ms[q].out);
+    }
+    ctx->n_grouped += n - 1; g_grouped += n - 1;
+    if (ctx->n_grouped == n - 1 && getenv("GGML_CDNA4_STATS")) fprintf(stderr, "ggml-cdna4: %s: %d one-row MUL_MATs of %s run as one launch (first: %s)\n", ctx->name.c_str(), n, mm->src[1]->name, mm->name);
+    return true;
+}
 static ggml_cdna4_tensor tdesc(const ggml_tensor * t) {
     ggml_cdna4_tensor d; d.data = t->data; d.type = (int32_t)t->type; d.reserved = 0;
     for (int k = 0; k < 4; k++) { d.ne[k] = t->ne[k]; d.nb[k] = (int64_t)t->nb[k]; }
@@ -523,11 +591,17 @@ static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph)
     const bool fuse = !no_fuse && n_nodes > 1;
     const use_counts uses = fuse ? use_counts(cgraph) : use_counts(nullptr, 0);
     ctx->act_image.key = 0;                                              // (activations of an earlier graph: the host may have rewritten them since)
+    std::vector<char> done(fuse ? n_nodes : 0, 0);                      // one-row MUL_MATs that already ran in an earlier node's launch (try_group_mul_mat)
     for (int i = 0; i < n_nodes; i++) {
         ggml_tensor * node = ggml_graph_node(cgraph, i);
         if (ggml_is_empty(node)) continue;
+        if (fuse && done[i]) continue;
         enum ggml_status st = GGML_STATUS_SUCCESS;
         if (fuse) {
+            if (node->op == GGML_OP_MUL_MAT && try_group_mul_mat(ctx, cgraph, i, uses, done, st)) {
+                if (st != GGML_STATUS_SUCCESS) return st;
+                continue;                                               // (done[] covers the group's nodes, this one's bias ADD included)
+            }
             int used = 0;
             if (node->op == GGML_OP_MUL_MAT) used = try_fused_mul_mat(ctx, cgraph, i, uses, st);
             else if (node->op == GGML_OP_NORM || node->op == GGML_OP_RMS_NORM) used = try_fused_norm(ctx, cgraph, i, uses, st);
@@ -858,6 +932,7 @@ static void * cdna4_reg_get_proc_address(ggml_backend_reg_t, const char * name) 
     if (strcmp(name, "ggml_backend_dev_get_extra_bufts") == 0) return (void *)cdna4_dev_get_extra_bufts;
     if (strcmp(name, "ggml_backend_cdna4_resident_buffer_type") == 0) return (void *)cdna4_resident_buffer_type;     // (int device) -> the buffer type directly
     if (strcmp(name, "ggml_backend_get_features") == 0) return (void *)cdna4_get_features;
+    if (strcmp(name, "ggml_backend_cdna4_grouped_count") == 0) return (void *)ggml_backend_cdna4_grouped_count;       // one-row MUL_MATs that rode in another product's launch (statistics)
     if (strcmp(name, "ggml_backend_cdna4_act_shared_count") == 0) return (void *)ggml_backend_cdna4_act_shared_count;   // MUL_MATs that reused the previous one's quantized activations (statistics)
     if (strcmp(name, "ggml_backend_cdna4_ksplit_buffer_type") == 0) return (void *)cdna4_ksplit_buffer_type;   // the K-split counterpart (no reference equivalent; ggml_cdna4_split.cpp)
     if (strcmp(name, "ggml_backend_split_buffer_type") == 0) return (void *)cdna4_split_buffer_type;      // ggml_backend_split_buffer_type_t, include/ggml-backend.h:188

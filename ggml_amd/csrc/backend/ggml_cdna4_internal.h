@@ -52,6 +52,7 @@ struct cdna4_backend_ctx {
              const void * producer = nullptr; } act_image;     // producer: the node whose own launch wrote x AND the image (NORM chain: its write of x does not end the image's life)
     int n_act_produced = 0;                                   // NORM chains that left the image of their rows for the next MUL_MAT
     int n_act_shared = 0;                                     // MUL_MATs that took the hand-off (statistics; "ggml_backend_cdna4_act_shared_count")
+    int n_grouped = 0;                                        // one-row MUL_MATs that rode in another one's launch (statistics; "ggml_backend_cdna4_grouped_count")
     void * need_ws(size_t n) {
         ws_uses++;
         if (n <= ws_size) return ws;

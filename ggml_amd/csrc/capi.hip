@@ -250,14 +250,6 @@ static bool use_mmq(int type, int64_t M, int64_t K, int64_t B) {
     if (B >= 49) return M * K <= ((int64_t)1 << 24) || type == CDNA4_Q8_0 || type == CDNA4_Q5_K;
     return false;
 }
-// the K-sliced ONE-launch int8 matrix-core kernel (mmq_i8.hip: k_mmq_ks_q4_K — quantizer inside, 128-row work-groups, K slices summed by the last arrival): Q4_K, 2 .. 32 rows.
-// CDNA4_MMQ_KS_MODE: 0 never, 1 (default) by the rule below, 2 wherever it exists (measurement).
-static bool use_mmq_ks(int type, int64_t M, int64_t K, int64_t B) {
-    static const int mode = getenv("CDNA4_MMQ_KS_MODE") ? atoi(getenv("CDNA4_MMQ_KS_MODE")) : 1;
-    if (mode == 0 || !cdna4_mmq_ks_supported(type, M, K, B)) return false;
-    if (mode == 2) return true;
-    return use_mmq(type, M, K, B);                                      // (where the two-launch int8 matrix-core route was taken)
-}
 static int resolve_path(int type, int path, int64_t M, int64_t K, int64_t B) {
     if (path == GGML_CDNA4_PATH_AUTO) {
         if (use_mmq(type, M, K, B)) return GGML_CDNA4_PATH_GEMV;
@@ -353,13 +345,6 @@ static int mul_mat_impl(int type, const void *W, int64_t w_row_bytes, const floa
             return mul_mat_impl(tgt, cw, (int64_t)ggml_cdna4_row_size(tgt, K), X, x_row_stride, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, epi, stream);
         }
     }
-    // ONE launch for 2 .. 32 rows of Q4_K (round 6): the activation quantizer inside the K-sliced int8 matrix-core kernel; the workspace is not touched
-    if (path == GGML_CDNA4_PATH_AUTO && use_mmq_ks(type, M, K, B) && !(((uintptr_t)W | (uintptr_t)w_row_bytes) & 15) && !(((uintptr_t)X | (uintptr_t)(x_row_stride * 4)) & 15)) {
-        cdna4_gemv_args g{};
-        g.type = type; g.W = (const uint8_t *)W; g.w_row_bytes = w_row_bytes; g.Y = Y; g.y_col_stride = y_row_stride;
-        g.M = (int)M; g.K = (int)K; g.ncol = (int)B; g.ids = nullptr; g.epi = epi;
-        return cdna4_launch_mmq_ks(g, X, x_row_stride, (hipStream_t)stream);
-    }
     // the int8 matrix-core kernel: AUTO only (an explicit PATH_GEMV keeps the v_dot4 units — tests compare the two), aligned Q4_K rows
     const bool mmq = path == GGML_CDNA4_PATH_AUTO && use_mmq(type, M, K, B) && !(((uintptr_t)W | (uintptr_t)w_row_bytes) & (type == CDNA4_Q6_K ? 1 : 15));
     path = resolve_path(type, path, M, K, B);
@@ -410,6 +395,23 @@ int ggml_cdna4_mul_mat(int type, const void *W, int64_t w_row_bytes, const float
     if (const int frc = fault_status()) return frc;
     return mul_mat_impl(type, W, w_row_bytes, X, x_row_stride, Y, y_row_stride, M, K, B, workspace, workspace_bytes, path, gemm_variant, splitk, cdna4_epilogue{}, stream);
 }
+// n MUL_MATs of ONE activation row (B = 1) in ONE launch: wq / wk / wv, w_gate / w_up of a decoded token (round 6).  Matrices of one type and K; bias[i] may be null.
+// Bit-identical to n ggml_cdna4_mul_mat[_fused] calls with B = 1 (the same kernel body per matrix).  Returns -2 where the call has no grouped form (the caller issues the
+// separate calls): types outside the five headline formats, a K the one-launch decode does not take, misaligned rows.
+int ggml_cdna4_mul_mat_group(int type, int n, const void *const *W, const int64_t *w_row_bytes, const int64_t *M, float *const *Y, const float *const *bias, const float *X, int64_t K, void *stream) {
+    if (const int frc = fault_status()) return frc;
+    if (n < 1 || n > CDNA4_GEMV_GROUP_MAX || !W || !w_row_bytes || !M || !Y || !X) { cdna4_set_error_msg("mul_mat_group: 1 .. 4 matrices"); return -2; }
+    if (!(type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K || type == CDNA4_Q4_0 || type == CDNA4_Q8_0) || K <= 0 || ggml_cdna4_row_size(type, K) == 0 ||
+        !cdna4_gemv_fused_supported(type, K, 1) || ((uintptr_t)X & 15)) { cdna4_set_error_msg("mul_mat_group: no grouped form for this type / K / alignment"); return -2; }
+    cdna4_gemv_group g{};
+    g.K = (int)K;
+    for (int i = 0; i < n; i++) {
+        if (M[i] <= 0 || M[i] > 0x7fffffff || !W[i] || !Y[i] || (((uintptr_t)W[i] | (uintptr_t)w_row_bytes[i]) & ((type == CDNA4_Q4_K || type == CDNA4_Q5_K) ? 15 : 1))) { cdna4_set_error_msg("mul_mat_group: bad or misaligned matrix"); return -2; }
+        if (use_mmq(type, M[i], K, 1) || resolve_path(type, GGML_CDNA4_PATH_AUTO, M[i], K, 1) != GGML_CDNA4_PATH_GEMV) { cdna4_set_error_msg("mul_mat_group: a matrix whose single call is not the one-launch GEMV"); return -2; }
+        g.W[i] = (const uint8_t *)W[i]; g.w_row_bytes[i] = w_row_bytes[i]; g.Y[i] = Y[i]; g.M[i] = (int)M[i]; g.bias[i] = bias ? bias[i] : nullptr;
+    }
+    return cdna4_launch_gemv_q_fused_grp(type, g, n, X, (hipStream_t)stream);
+}
 // the GEMV routes (B <= 8) apply the tail where the element is reduced, and so does the Q4_K GEMM (k_gemm_kq_t64, on 16-byte-aligned rows: what every
 // ggml buffer of the plug-in and every torch allocation gives); the older MFMA GEMM kernels write the product first (k_epilogue behind them)
 int ggml_cdna4_mul_mat_fused_residual_may_alias(int type, int64_t M, int64_t K, int64_t B) {
@@ -420,7 +422,7 @@ int ggml_cdna4_mul_mat_fused_residual_may_alias(int type, int64_t M, int64_t K, 
     return cdna4_gemm_q_fuses_tail(gemm_args_of(type, (const void *)(uintptr_t)256, (int64_t)ggml_cdna4_row_size(type, K), (const void *)(uintptr_t)256, (float *)(uintptr_t)256, M, M, K, B, 0, 0, e)) ? 1 : 0;
 }
 // the route ggml_cdna4_mul_mat(path = AUTO) takes for a contiguous, 256-byte-aligned call of this shape on the current device — host logic only, no launch, no scratch:
-//   1 one launch (activation quantizer inside the GEMV)     2 quantize + GEMV (columns staged in LDS)     3 quantize + int8 matrix-core kernel     4 ONE launch: the quantizer inside the K-sliced int8 matrix-core kernel (Q4_K, 2 .. 32 rows)
+//   1 one launch (activation quantizer inside the GEMV)     2 quantize + GEMV (columns staged in LDS)     3 quantize + int8 matrix-core kernel
 //   10 quantize + k_gemm_kq_t64     11 ONE launch: the quantizer inside k_gemm_kq_t64 (resident grids on an owned device)     12 + k_gemm_r8     13 + a 128 x 128-tile kernel     14 + an older per-lane-load GEMM;   + 100: behind an exact re-encoding of the weights
 static int route_of(int type, const void *W, int64_t w_row_bytes, int64_t M, int64_t K, int64_t B);
 int ggml_cdna4_mul_mat_route(int type, int64_t M, int64_t K, int64_t B) {
@@ -437,7 +439,6 @@ static int route_of(int type, const void *W, int64_t w_row_bytes, int64_t M, int
         const int tgt = cdna4_convert_weights_target(type);
         if (tgt >= 0 && tgt != type && B >= 9 && use_mmq(tgt, M, K, B)) return 103;
     }
-    if (use_mmq_ks(type, M, K, B) && !(((uintptr_t)W | (uintptr_t)w_row_bytes) & 15)) return 4;
     if (use_mmq(type, M, K, B)) return 3;
     const int path = resolve_path(type, GGML_CDNA4_PATH_AUTO, M, K, B);
     if (path == GGML_CDNA4_PATH_GEMV) {
@@ -483,7 +484,6 @@ uint32_t ggml_cdna4_act_image_key(int type, int64_t M, int64_t K, int64_t B) {
         const int tgt = cdna4_convert_weights_target(type);
         if (tgt >= 0 && tgt != type && B >= 9 && use_mmq(tgt, M, K, B)) return 0;
     }
-    if (use_mmq_ks(type, M, K, B)) return 0;                             // (ONE launch, the quantizer inside: the workspace is not touched)
     const bool mmq = use_mmq(type, M, K, B);
     const int path = resolve_path(type, GGML_CDNA4_PATH_AUTO, M, K, B);
     if (path != GGML_CDNA4_PATH_GEMM && !mmq) return 0;                 // (the GEMV forms below the matrix-core kernels: one launch, or their own staged variant)

@@ -59,6 +59,10 @@ int cdna4_launch_gemv_q_fused_n(const cdna4_gemv_args &a, const float *x, int64_
 // 2..8 pre-quantized activation rows (a.qs / a.d / a.bsums) copied into LDS once per work-group
 bool cdna4_gemv_staged_supported(int type, int64_t K, int64_t B);
 int cdna4_launch_gemv_q_staged(const cdna4_gemv_args &a, hipStream_t st);
+// several matrices (one type, one K) against ONE activation row in one launch: bit-identical to the separate one-row calls
+#define CDNA4_GEMV_GROUP_MAX 4
+struct cdna4_gemv_group { const uint8_t *W[CDNA4_GEMV_GROUP_MAX]; int64_t w_row_bytes[CDNA4_GEMV_GROUP_MAX]; float *Y[CDNA4_GEMV_GROUP_MAX]; const float *bias[CDNA4_GEMV_GROUP_MAX]; int M[CDNA4_GEMV_GROUP_MAX]; int K; };
+int cdna4_launch_gemv_q_fused_grp(int type, const cdna4_gemv_group &g, int n, const float *x, hipStream_t st);
 // single-token MUL_MAT_ID in one launch (a.ids set, a.ncol = n_used slots; x rows x_row_stride apart, slot u reads row u % a.n_b)
 int cdna4_launch_gemv_q_fused_ids(const cdna4_gemv_args &a, const float *x, int64_t x_row_stride, hipStream_t st);
 
@@ -66,9 +70,6 @@ int cdna4_launch_gemv_q_fused_ids(const cdna4_gemv_args &a, const float *x, int6
 // a.qs / a.d / a.bsums as for cdna4_launch_gemv_q (Q8_K workspace), a.epi applied in the store
 bool cdna4_mmq_supported(int type, int64_t M, int64_t K, int64_t B);
 int cdna4_launch_mmq(const cdna4_gemv_args &a, hipStream_t st);
-// the K-sliced ONE-launch form (Q4_K, 2 .. 32 rows): quantizer inside, x = the fp32 rows; g.qs / g.d / g.bsums unused
-bool cdna4_mmq_ks_supported(int type, int64_t M, int64_t K, int64_t B);
-int cdna4_launch_mmq_ks(const cdna4_gemv_args &g, const float *x, int64_t x_row_stride, hipStream_t st);
 bool cdna4_mmq_ids_supported(int type, int64_t K);                  // grouped MUL_MAT_ID on the int8 matrix cores: a.qs / a.d / a.bsums = the expert-sorted image (a.ncol rows)
 int cdna4_launch_mmq_ids(const cdna4_gemv_args &a, const int32_t *tile_expert, const int32_t *row_dst, int64_t w_expert_bytes, hipStream_t st);
 

@@ -559,9 +559,10 @@ static int launch_type(const cdna4_gemv_args &a0, hipStream_t st) {
 // into LDS — for NB x K beyond ~32 K values the redundant per-work-group quantization (and its 4 K bytes of fp32 reads per value row and
 // work-group) costs more than the extra launch: measured 40 us at 8 x 14336 with the quantizer inside.
 // (Round 4's DMA form — whole weight rows requested by LDS-DMA up front — was a measured loss and went in round 5: profiles/r04/decode_ab.txt.)
+// (the body as a device function: k_gemv_q_fused below, and k_gemv_q_fused_grp — several weight matrices against ONE activation row in one launch)
+extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 template <int TYPE, int NW, int ROWS, bool IDS = false, int NB = 1, bool PREQ = false>
-__global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, const float *__restrict__ x, int64_t x_row_stride) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+__device__ __forceinline__ void gemv_q_fused_body(cdna4_gemv_args a, const float *__restrict__ x, int64_t x_row_stride) {
     constexpr bool KQ = QT<TYPE>::KQ;
     if (IDS) {
         const int u = blockIdx.y, e = a.ids[u];
@@ -744,6 +745,23 @@ __global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, con
             const float s = wave_sum_dpp(acc[r][c]);
             if (lane == 0 && row0 + r < a.M && c < (NB == 1 ? 1 : a.ncol)) a.Y[(int64_t)c * a.y_col_stride + row0 + r] = epilogue_apply(a.epi, s, row0 + r, c);
         }
+}
+
+template <int TYPE, int NW, int ROWS, bool IDS = false, int NB = 1, bool PREQ = false>
+__global__ __launch_bounds__(NW * 64) void k_gemv_q_fused(cdna4_gemv_args a, const float *__restrict__ x, int64_t x_row_stride) {
+    gemv_q_fused_body<TYPE, NW, ROWS, IDS, NB, PREQ>(a, x, x_row_stride);
+}
+// Several MUL_MATs of ONE activation row in one launch (round 6, VERDICT r5 item 5: wq / wk / wv and w_gate / w_up of a decoded token share src1 — three launch ramps and
+// three kernel boundaries where one does): blockIdx.y = the matrix, blockIdx.x = its block of NW * ROWS rows (blocks past a matrix's rows leave at once).  Every work-group
+// runs the body of k_gemv_q_fused on its matrix: the same quantizer, the same dots in the same order — bit-identical to the separate calls.
+template <int TYPE, int NW, int ROWS>
+__global__ __launch_bounds__(NW * 64) void k_gemv_q_fused_grp(const cdna4_gemv_group g, const float *__restrict__ x) {
+    const int i = blockIdx.y;
+    if ((int)(blockIdx.x * NW * ROWS) >= g.M[i]) return;                  // (the whole work-group, before any barrier)
+    cdna4_gemv_args a{};
+    a.type = TYPE; a.W = g.W[i]; a.w_row_bytes = g.w_row_bytes[i]; a.Y = g.Y[i]; a.y_col_stride = g.M[i]; a.M = g.M[i]; a.K = g.K; a.ncol = 1; a.ids = nullptr;
+    a.epi.bias = g.bias[i];
+    gemv_q_fused_body<TYPE, NW, ROWS>(a, x, 0);
 }
 
 size_t cdna4_gemv_fused_lds_bytes(int type, int64_t K) {
@@ -962,4 +980,34 @@ int cdna4_launch_gemv_q_fused_ids(const cdna4_gemv_args &a, const float *x, int6
         case CDNA4_IQ4_XS: if (a.K % 256) return cdna4_set_error_msg("gemv_q: K must be a multiple of 256"); return launch_fused_ids<CDNA4_IQ4_XS>(a, x, x_row_stride, st);
     }
     return cdna4_set_error_msg("gemv_q: unsupported weight type");
+}
+
+// n (2 .. CDNA4_GEMV_GROUP_MAX) matrices of one type and K against the SAME fp32 activation row x: one launch (k_gemv_q_fused_grp)
+template <int TYPE>
+static int launch_fused_grp(const cdna4_gemv_group &g, int n, const float *x, hipStream_t st) {
+    const size_t lds = cdna4_gemv_fused_lds_bytes(TYPE, g.K);
+    int mmax = 0; for (int i = 0; i < n; i++) mmax = g.M[i] > mmax ? g.M[i] : mmax;
+    constexpr bool HAS16 = QT<TYPE>::KQ || TYPE == CDNA4_Q4_0;          // (the formats whose one-row launcher takes 16 waves x 1 row: launch_fused)
+    if constexpr (HAS16) {
+        if (mmax >= 2048) { hipLaunchKernelGGL((k_gemv_q_fused_grp<TYPE, 16, 1>), dim3((mmax + 15) / 16, n), dim3(1024), lds, st, g, x); CDNA4_CHECK_LAUNCH(); return 0; }
+    }
+    hipLaunchKernelGGL((k_gemv_q_fused_grp<TYPE, 8, 1>), dim3((mmax + 7) / 8, n), dim3(512), lds, st, g, x);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+int cdna4_launch_gemv_q_fused_grp(int type, const cdna4_gemv_group &g, int n, const float *x, hipStream_t st) {
+    if (n < 1 || n > CDNA4_GEMV_GROUP_MAX) return cdna4_set_error_msg("gemv_q_fused_grp: 1 .. 4 matrices");
+    if (!cdna4_gemv_fused_supported(type, g.K, 1) || ((uintptr_t)x & 15)) return cdna4_set_error_msg("gemv_q_fused_grp: unsupported shape or misaligned activation row");
+    for (int i = 0; i < n; i++) {
+        if (g.M[i] <= 0 || !g.W[i] || !g.Y[i]) return cdna4_set_error_msg("gemv_q_fused_grp: bad matrix");
+        if (((uintptr_t)g.W[i] | (uintptr_t)g.w_row_bytes[i]) & ((type == CDNA4_Q4_K || type == CDNA4_Q5_K) ? 15 : 1)) return cdna4_set_error_msg("gemv_q_fused_grp: misaligned weight rows");
+    }
+    switch (type) {
+        case CDNA4_Q4_K: return launch_fused_grp<CDNA4_Q4_K>(g, n, x, st);
+        case CDNA4_Q5_K: return launch_fused_grp<CDNA4_Q5_K>(g, n, x, st);
+        case CDNA4_Q6_K: return launch_fused_grp<CDNA4_Q6_K>(g, n, x, st);
+        case CDNA4_Q4_0: return launch_fused_grp<CDNA4_Q4_0>(g, n, x, st);
+        case CDNA4_Q8_0: return launch_fused_grp<CDNA4_Q8_0>(g, n, x, st);
+    }
+    return cdna4_set_error_msg("gemv_q_fused_grp: the five headline formats");
 }

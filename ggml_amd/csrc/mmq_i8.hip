@@ -24,11 +24,6 @@
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
 #include "epilogue.h"
-#include "quantize_dev.h"
-#include "gemm_q_hw.h"
-#include <stdlib.h>
-int cdna4_gemm_cu_count();
-void *cdna4_gemm_scratch(size_t bytes, int kind);
 
 typedef int intx4 __attribute__((ext_vector_type(4)));
 
@@ -480,231 +475,10 @@ __global__ __launch_bounds__(NW * 64) void k_mmq_q6_K(mmq_args a) {
     }
 }
 
-// ---- the K-SLICED one-launch form for Q4_K, 2 .. 32 activation rows (round 6) ----------------------------------------------------------------------
-// What it replaces at these sizes: k_quantize_q8_K + k_mmq_q4_K (two launches; 16-row-thin work-groups that re-fetch the sixteen columns' quants for every superblock: 58 MB
-// of L2 reads beside 33 MB of weights at 4096 x 14336 x 16 — 14.1 us where one row takes 7.5), and the 8-column GEMV forms.  Here a work-group owns 128 weight rows x ONE
-// K SLICE of KS superblocks: it quantizes its slice of the fp32 activation rows ITSELF (the arithmetic of k_quantize_q8_K, bit for bit: q8_K_group16_i8) into LDS — 16 K
-// values at most, two passes of the work-group, against the weight loads already in flight — and every wave multiplies its sixteen rows' slice by it on the int8 matrix
-// cores (the body of k_mmq_q4_K: ggml_vec_dot_q4_K_q8_K's integer block dots and fp32 scale products, src/ggml-cpu/ggml-cpu-quants.c:5549-6194).  The S slices of a row block
-// meet like the deep K split of k_gemm_kq_t64: every work-group parks its 128 x B partial (write-through), takes a ticket, the LAST one adds the slices in slice order and
-// stores with the MUL_MAT's tail — nobody waits, the sum does not depend on who is last.  ONE launch; activation reads 1 x the weight bytes instead of 1.7 x.
-// (reference dispatcher: ggml-cuda serves 1 .. 8 columns from one GEMV kernel, src/ggml-cuda/mmvq.cu:132-203, and MMQ above)
-struct mmq_ks_args {
-    const uint8_t *W; int64_t w_row_bytes;
-    const float *X; int64_t x_row;                                     // the fp32 activation rows
-    float *Y; int64_t y_row;                                           // Y[b * y_row + m]
-    int M, K, B, KS, S;                                                // KS superblocks per K slice, S slices
-    float *partial; unsigned *tickets;                                 // [row block][slice][wave][NCG][64] float4; one ticket word per row block (zero when idle)
-    cdna4_epilogue epi;
-};
-template <int NCG>
-__global__ __launch_bounds__(512) void k_mmq_ks_q4_K(const mmq_ks_args a) {
-    constexpr int WB = 144, WP = WB / 16, NWI = (16 * WP + 63) / 64, QO = 16, MAXKS = 4;
-    constexpr int XROW = 272, XS = 16 * XROW, MS = 16 * 32, XG = XS + MS;           // per (superblock, column group): 16 columns' quants | their pair sums + d
-    constexpr int ACT = MAXKS * NCG * XG, WSZ = 16 * WB;
-    __shared__ __attribute__((aligned(16))) uint8_t smem[ACT + 8 * WSZ];
-    __shared__ int last_flag;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int col = lane & 15, grp = lane >> 4;                        // MFMA lane roles: row / column l % 16, k-group l / 16
-    const int rb = blockIdx.x, sl = blockIdx.y;
-    const int nsb = a.K / 256, sb0 = sl * a.KS, nks = min(a.KS, nsb - sb0);
-    const int m0 = rb * 128 + wave * 16;
-    uint8_t *wl = smem + ACT + wave * WSZ;
-
-    // ---- the wave's first superblock of weights: requested BEFORE the activations are quantized (HBM latency under the quantizer)
-    struct Wreg { u32x4 w[NWI]; };
-    auto fetch_w = [&](int sb) __attribute__((always_inline)) {
-        Wreg r;
-#pragma unroll
-        for (int i = 0; i < NWI; i++) {                                  // piece i * 64 + lane of 16 WP: row piece / WP, chunk piece % WP
-            const int pc = min(i * 64 + lane, 16 * WP - 1), row = pc / WP, c = pc - row * WP;
-            r.w[i] = ld_u32x4(a.W + (int64_t)min(m0 + row, a.M - 1) * a.w_row_bytes + (int64_t)sb * WB + c * 16);
-        }
-        return r;
-    };
-    // ALL of the slice's superblocks at once (at most four: 12 registers each): a wave that fetched one superblock ahead waited a memory round trip per superblock — 4 x 1.5 us
-    // of a work-group's 10 (first version, profiles/r06/batch_ks_first.txt)
-    Wreg wr[MAXKS];
-#pragma unroll
-    for (int i = 0; i < MAXKS; i++) if (i < nks) wr[i] = fetch_w(sb0 + i);
-    asm volatile("" ::: "memory");
-    // ---- this slice of the activation rows -> Q8_K in LDS: 32 sixteen-lane groups, unit u = column * nks + superblock (consecutive groups read consecutive kilobytes)
-    {
-        const int g16 = tid >> 4, l = tid & 15, units = a.B * nks;
-        // (two units' loads in flight together: one L2 round trip per pair of passes)
-        float e2[2][16];
-        auto load_unit = [&](int u, float (&e)[16]) __attribute__((always_inline)) {
-            const int b = u / nks, sbl = u - b * nks;
-            const float *px = a.X + (int64_t)b * a.x_row + (int64_t)(sb0 + sbl) * 256 + 4 * l;
-#pragma unroll
-            for (int i = 0; i < 4; i++) { const float4 v = *reinterpret_cast<const float4 *>(px + 64 * i); e[4 * i] = v.x; e[4 * i + 1] = v.y; e[4 * i + 2] = v.z; e[4 * i + 3] = v.w; }
-        };
-        for (int u0 = g16; u0 < units; u0 += 64) {                       // (a 16-lane group enters and leaves together)
-            load_unit(u0, e2[0]);
-            if (u0 + 32 < units) load_unit(u0 + 32, e2[1]);
-#pragma unroll
-          for (int half = 0; half < 2; half++) {
-            const int u = u0 + 32 * half;
-            if (u >= units) break;
-            const float (&e)[16] = e2[half];
-            const int b = u / nks, sbl = u - b * nks;
-            int q[16]; float d;
-            q8_K_group16_i8(e, l, q, d);
-            uint8_t *xg = smem + (sbl * NCG + (b >> 4)) * XG;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int qq[4] = {q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]};
-                *reinterpret_cast<uint32_t *>(xg + (b & 15) * XROW + 64 * i + 4 * l) = pack4i8(qq);
-                // the pair sum bsums[2 j] + bsums[2 j + 1] of sub-block j = 2 i + (l >> 3): the sum over the eight lanes of this half row (integer: order-free)
-                int s8 = qq[0] + qq[1] + qq[2] + qq[3];
-                s8 += dpp_i32<0xB1>(s8); s8 += dpp_i32<0x4E>(s8); s8 += dpp_i32<0x141>(s8);
-                if ((l & 7) == 0) *reinterpret_cast<int16_t *>(xg + XS + (b & 15) * 32 + 2 * (2 * i + (l >> 3))) = (int16_t)s8;
-            }
-            if (l == 0) *reinterpret_cast<float *>(xg + XS + (b & 15) * 32 + 16) = d;
-          }
-        }
-    }
-    __syncthreads();
-
-    float acc[NCG][4];
-#pragma unroll
-    for (int g = 0; g < NCG; g++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) acc[g][i] = 0.f;
-#pragma unroll
-    for (int sbl = 0; sbl < MAXKS; sbl++) {
-        if (sbl >= nks) break;
-        CDNA4_WAVE_LDS_SYNC();                                           // the previous superblock's fragment reads are over
-#pragma unroll
-        for (int i = 0; i < NWI; i++) if (i * 64 + lane < 16 * WP) *reinterpret_cast<u32x4 *>(wl + (i * 64 + lane) * 16) = wr[sbl].w[i];
-        CDNA4_WAVE_LDS_SYNC();
-        // ---- this lane's weight row (column col of the MFMA's B operand): header, scales and minima (get_scale_min_k4, ggml-quants.c:631-638)
-        const u32x4 hdr = *reinterpret_cast<const u32x4 *>(wl + col * WB);
-        u32x2 wq[4];
-#pragma unroll
-        for (int gq = 0; gq < 4; gq++) wq[gq] = *reinterpret_cast<const u32x2 *>(wl + col * WB + QO + 32 * gq + 8 * grp);
-        const float dw = h2f(hdr.x & 0xFFFF), dmin = h2f(hdr.x >> 16);
-        int sc[8], mn[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) k4_scale_min_rt(hdr.y, hdr.z, hdr.w, j, sc[j], mn[j]);
-#pragma unroll
-        for (int g = 0; g < NCG; g++) {
-            const uint8_t *xg = smem + (sbl * NCG + g) * XG;
-            const uint8_t *xs = xg + col * XROW + 8 * grp;
-            intx4 sumi = {0, 0, 0, 0};
-#pragma unroll
-            for (int gq = 0; gq < 4; gq++) {                             // 64-weight group gq: sub-blocks 2 gq (low nibbles) and 2 gq + 1 (high)
-                const u32x2 xl = *reinterpret_cast<const u32x2 *>(xs + 64 * gq), xh = *reinterpret_cast<const u32x2 *>(xs + 64 * gq + 32);
-                const intx4 z = {0, 0, 0, 0};
-                const uint32_t l0 = wq[gq].x & 0x0F0F0F0Fu, l1 = wq[gq].y & 0x0F0F0F0Fu, h0 = (wq[gq].x >> 4) & 0x0F0F0F0Fu, h1 = (wq[gq].y >> 4) & 0x0F0F0F0Fu;
-                const intx4 sL = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xl.x, xl.y), as_i64(l0, l1), z, 0, 0, 0);
-                const intx4 sH = __builtin_amdgcn_mfma_i32_16x16x32_i8(as_i64(xh.x, xh.y), as_i64(h0, h1), z, 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; i++) sumi[i] += mul24(sc[2 * gq], sL[i]) + mul24(sc[2 * gq + 1], sH[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {                                // minimum term and the fp32 scale products: rows b = 4 grp + i of this column group
-                const uint8_t *mb = xg + XS + (4 * grp + i) * 32;
-                const u32x4 ps = *reinterpret_cast<const u32x4 *>(mb);
-                const float dy = *reinterpret_cast<const float *>(mb + 16);
-                const uint32_t pw[4] = {ps.x, ps.y, ps.z, ps.w};
-                int summs = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) summs += mul24(mn[2 * j], (int)(int16_t)(pw[j] & 0xFFFF)) + mul24(mn[2 * j + 1], (int)(int16_t)(pw[j] >> 16));
-                acc[g][i] += (dw * dy) * (float)sumi[i] - (dmin * dy) * (float)summs;
-            }
-        }
-    }
-    // ---- the S slices of the row block meet: park, ticket, the last arrival adds them in slice order (its own from registers at its place) and stores
-    bool keeper = true;
-    if (a.S > 1) {
-        float4 *const slots = reinterpret_cast<float4 *>(a.partial) + (size_t)rb * a.S * 8 * NCG * 64;
-        {
-            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slots + ((size_t)sl * 8 + wave) * NCG * 64, 0, NCG * 64 * 16, 0x00020000);
-#pragma unroll
-            for (int g = 0; g < NCG; g++) {
-                const float4 v = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (g * 64 + lane) * 16, 0, 16);      // aux 16 = sc1: write-through
-            }
-            CDNA4_WAIT_VM(0);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned *ticket = a.tickets + rb;
-            const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last_flag = old == (unsigned)(a.S - 1);
-            if (last_flag) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (replayable from a HIP graph)
-        }
-        __syncthreads();
-        keeper = last_flag != 0;
-        if (keeper) {
-            // (eight slices' loads in flight together: one at a time, every slice cost the last work-group a memory round trip — S = 14 of them at 4096 x 14336)
-            float4 sum[NCG];
-            for (int k0 = 0; k0 < a.S; k0 += 8) {
-                float4 v[8][NCG];
-#pragma unroll
-                for (int jj = 0; jj < 8; jj++) {
-                    const int k2 = k0 + jj;
-                    if (k2 < a.S && k2 != sl) {
-                        __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(slots + ((size_t)k2 * 8 + wave) * NCG * 64, 0, NCG * 64 * 16, 0x00020000);
-#pragma unroll
-                        for (int g = 0; g < NCG; g++) v[jj][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, (g * 64 + lane) * 16, 0, 17));   // sc0 sc1
-                    }
-                }
-#pragma unroll
-                for (int jj = 0; jj < 8; jj++) {
-                    const int k2 = k0 + jj;
-                    if (k2 >= a.S) break;
-#pragma unroll
-                    for (int g = 0; g < NCG; g++) {
-                        const float4 t = k2 == sl ? make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]) : v[jj][g];
-                        if (k2 == 0) sum[g] = t;
-                        else { sum[g].x += t.x; sum[g].y += t.y; sum[g].z += t.z; sum[g].w += t.w; }
-                    }
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < NCG; g++) { acc[g][0] = sum[g].x; acc[g][1] = sum[g].y; acc[g][2] = sum[g].z; acc[g][3] = sum[g].w; }
-        }
-    }
-    if (keeper) {
-#pragma unroll
-        for (int g = 0; g < NCG; g++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int b = g * 16 + 4 * grp + i, m = m0 + col;
-                if (b < a.B && m < a.M) a.Y[(int64_t)b * a.y_row + m] = epilogue_apply(a.epi, acc[g][i], m, b);
-            }
-    }
-}
-// Q4_K, 2 .. 32 activation rows, whole superblocks, 16-byte-aligned weight rows and activation rows (float4 loads)
-bool cdna4_mmq_ks_supported(int type, int64_t M, int64_t K, int64_t B) { return type == CDNA4_Q4_K && M > 0 && K >= 256 && K % 256 == 0 && B >= 2 && B <= 32; }
-int cdna4_launch_mmq_ks(const cdna4_gemv_args &g, const float *x, int64_t x_row_stride, hipStream_t st) {
-    if (!cdna4_mmq_ks_supported(g.type, g.M, g.K, g.ncol) || g.ids) return cdna4_set_error_msg("mmq_ks: unsupported type / shape");
-    if ((((uintptr_t)g.W | (uintptr_t)g.w_row_bytes) & 15) || (((uintptr_t)x | (uintptr_t)(x_row_stride * 4)) & 15)) return cdna4_set_error_msg("mmq_ks: weight rows and activation rows must be 16-byte aligned");
-    const int nsb = g.K / 256, rbs = (g.M + 127) / 128, cus = cdna4_gemm_cu_count();
-    // slices: about two work-groups per CU over the whole launch (57 KB of LDS each: two fit), at most four superblocks per slice (the quantizer's share: 16 K values)
-    static const int ks_env = getenv("CDNA4_MMQ_KS") ? atoi(getenv("CDNA4_MMQ_KS")) : 0;          // (measurement knob: superblocks per slice)
-    int KS = ks_env > 0 ? ks_env : (nsb * rbs + 2 * cus - 1) / (2 * cus);
-    KS = KS < 1 ? 1 : (KS > 4 ? 4 : KS);
-    const int S = (nsb + KS - 1) / KS, ncg = (g.ncol + 15) / 16;
-    mmq_ks_args a{};
-    a.W = g.W; a.w_row_bytes = g.w_row_bytes; a.X = x; a.x_row = x_row_stride; a.Y = g.Y; a.y_row = g.y_col_stride;
-    a.M = g.M; a.K = g.K; a.B = g.ncol; a.KS = KS; a.S = S; a.epi = g.epi;
-    if (S > 1) {
-        // parked partials behind 16 KB of ticket words (zero when idle: reset by their last user — graph-capturable)
-        if (rbs > 4096) return cdna4_set_error_msg("mmq_ks: too many row blocks for the ticket area");
-        const size_t tbytes = 16384, pbytes = (size_t)rbs * S * 8 * ncg * 1024;
-        char *sc = (char *)cdna4_gemm_scratch(tbytes + pbytes, 11);
-        if (!sc) return cdna4_set_error_msg("mmq_ks: cannot allocate the exchange scratch");
-        a.tickets = (unsigned *)sc; a.partial = (float *)(sc + tbytes);
-    }
-    const dim3 grid(rbs, S);
-    if (ncg == 1) hipLaunchKernelGGL((k_mmq_ks_q4_K<1>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_mmq_ks_q4_K<2>), grid, dim3(512), 0, st, a);
-    CDNA4_CHECK_LAUNCH();
-    return 0;
-}
+// (Round 6 built a K-SLICED one-launch form for 2 .. 32 rows of Q4_K — 128-row work-groups that quantize their K slice of the activations themselves and meet through parked
+//  partials + tickets, k_mmq_ks_q4_K, commit "small batches: ..." — 2e-7 from the oracle and BEHIND the two launches below at every size: 4096 x 14336 14.5-18.8 us against
+//  13.8-14.3, 4096^2 8.3-10.0 against 7.9 (profiles/r06/batch_ks_final.txt): a work-group's life there is a chain fetch -> quantize -> barrier -> multiply -> park -> ticket ->
+//  the last one's sum, with nothing to overlap it.  Removed.)
 bool cdna4_mmq_supported(int type, int64_t M, int64_t K, int64_t B) {
     if (type == CDNA4_Q6_K && B > 32) return false;                   // (its three- and four-group forms spill: two accumulator sets per block pair)
     return (type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K || type == CDNA4_Q4_0 || type == CDNA4_Q8_0) && M > 0 && K >= 256 && K % 256 == 0 && B >= 2 && B <= 64;

@@ -100,26 +100,3 @@ __device__ __forceinline__ void q8_K_group16_image(const float (&e)[16], int l16
     o1.x = pk(hv[8], hv[10]); o1.y = pk(hv[9], hv[11]); o1.z = pk(hv[12], hv[14]); o1.w = pk(hv[13], hv[15]);
 }
 
-// One Q8_K superblock by the 16 adjacent lanes of a DPP row -> its int8 quants and its scale: lane l holds the elements 64 i + 4 l + c (e[4 i + c], i, c = 0 .. 3 — four runs
-// of four, the load pattern of k_quantize_q8_K) and gets their quants q[4 i + c]; d is the block scale in every lane.  The arithmetic of k_quantize_q8_K
-// (quantize_act.hip; quantize_row_q8_K_ref, src/ggml-quants.c:2479-2516), bit for bit.  Used by the K-sliced small-batch kernel (mmq_i8.hip: k_mmq_ks_q4_K).
-__device__ __forceinline__ void q8_K_group16_i8(const float (&e)[16], int l, int (&q)[16], float &d) {
-    float amax = 0.f, mx = 0.f; int idx = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) { const float ax = fabsf(e[i]); if (ax > amax) { amax = ax; mx = e[i]; idx = 64 * (i >> 2) + 4 * l + (i & 3); } }
-    auto take = [&](float oa, float om, int oi) __attribute__((always_inline)) { if (oa > amax || (oa == amax && oi < idx)) { amax = oa; mx = om; idx = oi; } };
-    take(dpp_f32<0xB1>(amax), dpp_f32<0xB1>(mx), dpp_i32<0xB1>(idx));
-    take(dpp_f32<0x4E>(amax), dpp_f32<0x4E>(mx), dpp_i32<0x4E>(idx));
-    take(dpp_f32<0x141>(amax), dpp_f32<0x141>(mx), dpp_i32<0x141>(idx));
-    take(dpp_f32<0x140>(amax), dpp_f32<0x140>(mx), dpp_i32<0x140>(idx));
-    d = 0.f;
-    if (amax != 0.f) {
-        const float iscale = -127.f / mx;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { const int v = (int)__builtin_rintf(iscale * e[i]); q[i] = v < 127 ? v : 127; }   // nearest_int == RNE
-        d = 1.0f / iscale;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; i++) q[i] = 0;
-    }
-}

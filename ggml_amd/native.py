@@ -28,6 +28,7 @@ SYMBOLS = [
     ("ggml_cdna4_mul_mat", _int, [_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _int, _int, _int, _vp]),
     ("ggml_cdna4_mul_mat_fused", _int, [_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp, _i64, _vp, _sz, _vp]),
     ("ggml_cdna4_mul_mat_fused_residual_may_alias", _int, [_int, _i64, _i64, _i64]),
+    ("ggml_cdna4_mul_mat_group", _int, [_int, _int, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_vp), _vp, _i64, _vp]),
     ("ggml_cdna4_act_image_key", C.c_uint32, [_int, _i64, _i64, _i64]),
     ("ggml_cdna4_act_image_key_of", C.c_uint32, [_int, _vp, _i64, _i64, _i64, _i64]),
     ("ggml_cdna4_mul_mat_prepared_fused", _int, [_int, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp, _i64, _vp, _sz, _vp]),

@@ -158,6 +158,12 @@ int ggml_cdna4_mul_mat_id(int type, const void * as, int64_t w_row_bytes, int64_
 int ggml_cdna4_mul_mat_fused(int type, const void * W, int64_t w_row_bytes, const float * X, int64_t x_row_stride, float * Y, int64_t y_row_stride,
                              int64_t M, int64_t K, int64_t B, const float * bias, int act, const float * residual, int64_t residual_row_stride,
                              void * workspace, size_t workspace_bytes, void * stream);
+/* n (1 .. 4) MUL_MATs of ONE activation row in ONE launch — Y[i][m] = sum_k W[i][m][k] X[k] (+ bias[i][m]) for matrices of one type and K: wq / wk / wv and
+ * w_gate / w_up of a decoded token read the same src1 (examples/gpt-2/main-backend.cpp:476-521 has the fused c_attn; llama-style graphs have them apart).  Bit-identical
+ * to n ggml_cdna4_mul_mat / _mul_mat_fused calls with B = 1.  Returns -2 (nothing launched) where the call has no grouped form: the caller then issues the separate calls. */
+int ggml_cdna4_mul_mat_group(int type, int n, const void * const * W, const int64_t * w_row_bytes, const int64_t * M, float * const * Y, const float * const * bias,
+                             const float * X, int64_t K, void * stream);
+
 /* `residual` may alias Y EXACTLY (same pointer and row stride: an in-place ADD) only when the tail is applied by the store that produces the
  * element; this says whether that holds for a call of this shape (1) or whether residual and Y must not overlap at all (0: the product is
  * written first and the tail is a pass over Y — an aliased residual would already be overwritten).  ggml_cdna4_mul_mat_fused returns an error

@@ -164,6 +164,7 @@ int main(int argc, char ** argv) {
     //      GGML_CDNA4_NO_ACT_SHARE=1: same bytes), each output against the CPU backend, and the time per graph (HIP-graph replay).
     if (argc > 6 && std::string(argv[6]) == "shared") {
         const int64_t D = M, H = K;
+        int grouped = 0;
         auto build = [&](ggml_backend_t be, std::vector<std::vector<float>> & outs, double * us_per_graph, int * shared) {
             ggml_init_params ip = { ggml_tensor_overhead() * 64 + ggml_graph_overhead(), NULL, true };
             ggml_context * wctx = ggml_init(ip), * cctx = ggml_init(ip);
@@ -200,11 +201,13 @@ int main(int argc, char ** argv) {
             std::vector<float> xin(x.begin(), x.begin() + (size_t)D * B);
             typedef int (*count_fn)(void);
             count_fn cnt = be == gpu ? (count_fn)ggml_backend_reg_get_proc_address(reg, "ggml_backend_cdna4_act_shared_count") : nullptr;
-            const int c0 = cnt ? cnt() : 0;
+            count_fn gcnt = be == gpu ? (count_fn)ggml_backend_reg_get_proc_address(reg, "ggml_backend_cdna4_grouped_count") : nullptr;      // one-row MUL_MATs that rode in another's launch
+            const int c0 = cnt ? cnt() : 0, g0 = gcnt ? gcnt() : 0;
             ggml_backend_tensor_set(X, xin.data(), 0, xin.size() * 4);
             if (ggml_backend_graph_compute(be, gf) != GGML_STATUS_SUCCESS) { fprintf(stderr, "graph_compute failed\n"); exit(1); }
             ggml_backend_synchronize(be);
             if (shared) *shared = cnt ? cnt() - c0 : -1;
+            if (be == gpu) grouped = gcnt ? gcnt() - g0 : -1;
             // (the outputs of the FIRST compute: the graph allocator may hand X's memory to a later node once X's last reader has run, so a second compute of the same
             //  graph without a new tensor_set starts from other activations — the timing loop below does exactly that, on purpose)
             outs.clear();
@@ -227,8 +230,8 @@ int main(int argc, char ** argv) {
         if (getenv("HARNESS_NO_CPU")) y_cpu = y_gpu; else build(cpu, y_cpu, nullptr, nullptr);      // (timing runs at full size skip the CPU backend's pass)
         uint64_t h = 1469598103934665603ull;
         for (const auto & y : y_gpu) for (size_t i = 0; i < y.size() * 4; i++) { h ^= ((const uint8_t *)y.data())[i]; h *= 1099511628211ull; }
-        printf("{\"type\":\"%s\",\"D\":%lld,\"H\":%lld,\"B\":%lld,\"act_hand_offs_first_compute\":%d,\"fnv1a\":\"%016llx\",\"us_per_graph\":%.2f,\"k_vs_cpu\":%.3e,\"v_vs_cpu\":%.3e,\"out_vs_cpu\":%.3e}\n",
-               ggml_type_name(type), (long long)D, (long long)H, (long long)B, shared, (unsigned long long)h, us, rel_l2(y_gpu[0], y_cpu[0]), rel_l2(y_gpu[1], y_cpu[1]), rel_l2(y_gpu[2], y_cpu[2]));
+        printf("{\"type\":\"%s\",\"D\":%lld,\"H\":%lld,\"B\":%lld,\"act_hand_offs_first_compute\":%d,\"grouped_first_compute\":%d,\"fnv1a\":\"%016llx\",\"us_per_graph\":%.2f,\"k_vs_cpu\":%.3e,\"v_vs_cpu\":%.3e,\"out_vs_cpu\":%.3e}\n",
+               ggml_type_name(type), (long long)D, (long long)H, (long long)B, shared, grouped, (unsigned long long)h, us, rel_l2(y_gpu[0], y_cpu[0]), rel_l2(y_gpu[1], y_cpu[1]), rel_l2(y_gpu[2], y_cpu[2]));
         ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
         return 0;
     }

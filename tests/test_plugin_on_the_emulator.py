@@ -46,6 +46,20 @@ def test_layer_front_through_ggmls_public_api_on_the_emulated_plugin(plug, type_
     assert on["k_vs_cpu"] < 1e-3 and on["v_vs_cpu"] < 1e-3 and on["out_vs_cpu"] < 3e-2, on
 
 
+@pytest.mark.parametrize("type_", ["q4_K", "q4_0"])
+def test_one_row_products_of_one_src1_run_as_one_launch_on_the_emulated_plugin(plug, type_):
+    """round 6: at ONE activation row the layer front's products of `cur` (Wk, Wv + its bias, Wq + the residual row, which at one row is a bias) and of `f`
+    (w_gate, w_up) are two grouped launches instead of five (ggml_cdna4_mul_mat_group / k_gemv_q_fused_grp; the plug-in runs Wq and w_up EARLY, with the first product of their src1, after checking that
+    nothing in between touches their outputs' memory): three products rode along, and every output byte equals the node-by-node run (GGML_CDNA4_NO_GROUP=1)"""
+    on = plug.harness([type_, 256, 512, 1, "shared"], env={"HARNESS_NO_TIMING": 1})
+    off = plug.harness([type_, 256, 512, 1, "shared"], env={"HARNESS_NO_TIMING": 1, "GGML_CDNA4_NO_GROUP": 1})
+    if on is None or off is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert on["grouped_first_compute"] == 3 and off["grouped_first_compute"] == 0, (on, off)
+    assert on["fnv1a"] == off["fnv1a"], (on, off)
+    assert on["k_vs_cpu"] < 1e-3 and on["v_vs_cpu"] < 1e-3, on
+
+
 @pytest.mark.parametrize("type_,m,k,b", [("q4_0", 256, 512, 96), ("q8_0", 256, 512, 40), ("q6_K", 128, 512, 96), ("q5_0", 128, 256, 40), ("q4_K", 128, 256, 40)])
 def test_resident_buffer_type_on_the_emulated_plugin(plug, type_, m, k, b):
     """the CDNA4_Resident extra buffer type (ggml_backend_dev_get_extra_bufts): weights through ggml_backend_tensor_set, MUL_MAT at prefill and decode sizes, a rewrite — against the
