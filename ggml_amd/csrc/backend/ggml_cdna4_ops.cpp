@@ -98,10 +98,14 @@ enum ggml_status cdna4_ops_compute(void * ctx, ggml_tensor * node) {
         case GGML_OP_MUL: rc = ggml_cdna4_op_binary(GGML_CDNA4_MUL, &da, &db, &dd, stream); break;
         case GGML_OP_DIV: rc = ggml_cdna4_op_binary(GGML_CDNA4_DIV, &da, &db, &dd, stream); break;
         case GGML_OP_SCALE: { float s; memcpy(&s, node->op_params, sizeof(float)); rc = ggml_cdna4_op_scale(&da, &dd, s, stream); break; }
-        case GGML_OP_UNARY: rc = ggml_cdna4_op_unary(unary_id(node), &da, &dd, stream); break;
+        case GGML_OP_UNARY:
+            if (cdna4_exact_mode() && ggml_get_unary_op(node) == GGML_UNARY_OP_SILU && a->type == GGML_TYPE_F32 && ggml_is_contiguous(a) && ggml_is_contiguous(node)) rc = ggml_cdna4_op_silu_exact(&da, &dd, stream);
+            else rc = ggml_cdna4_op_unary(unary_id(node), &da, &dd, stream);
+            break;
         case GGML_OP_NORM: case GGML_OP_RMS_NORM: {
             float eps; memcpy(&eps, node->op_params, sizeof(float));
             if (cdna4_exact_mode() && node->op == GGML_OP_NORM) rc = ggml_cdna4_op_norm_exact(&da, &dd, eps, stream);
+            else if (cdna4_exact_mode() && a->type == GGML_TYPE_F32) rc = ggml_cdna4_op_rms_norm_exact(&da, &dd, eps, stream);
             else rc = ggml_cdna4_op_norm(&da, &dd, eps, node->op == GGML_OP_RMS_NORM, stream);
             break;
         }

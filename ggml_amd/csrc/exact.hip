@@ -62,6 +62,98 @@ __global__ __launch_bounds__(256) void k_mul_mat_exact_q(const uint8_t *__restri
     if (L == 0 && b < B) Y[(int64_t)b * y_row + m] = acc;
 }
 
+// ------------------------------------------------------------------------------------------------ MUL_MAT, Q4_K / Q5_K / Q6_K weights x Q8_K activations
+// The AVX2 bodies of ggml_vec_dot_q4_K_q8_K / _q5_K_q8_K / _q6_K_q8_K (src/ggml-cpu/ggml-cpu-quants.c:5712-5775, 6283-6364, 6941-7018).  Same wave shape as above:
+// lane L is 32-bit lane L of the __m256i `sumi` — bytes 4L .. 4L+3 of every 32-byte chunk, scaled by that chunk's 6-bit (Q4_K / Q5_K) or int8 (Q6_K: one scale per
+// 16 elements, so lanes 0-3 and 4-7 differ) scale; the integer sums are exact in any order (maddubs cannot saturate: <= 2*63*127), then per superblock
+// acc = fma(y.d * fp16(x.d), (float)sumi, acc) and hsum_float_8 at the end.  The mins: Q4_K keeps FOUR fp32 accumulators acc_m[k] = fma(dmin, (float)(mins[2k] * s[2k] +
+// mins[2k+1] * s[2k+1]), acc_m[k]) with s[j] = bsums[2j] + bsums[2j+1] (hadd_epi16 / madd_epi16), folded [0]+[2], [1]+[3], [0]+[1] and added LAST; Q5_K keeps ONE
+// scalar, summs = fma(dmin, (float)(sum of the four), summs) — gcc contracts `summs += dmin * x` (vfmadd231ss in oracle/_ref/libggml-cpu.so).
+template <int TYPE>
+__global__ __launch_bounds__(256) void k_mul_mat_exact_kq(const uint8_t *__restrict__ W, int64_t w_row_bytes, const int8_t *__restrict__ qs, const float *__restrict__ dd,
+                                                         const int16_t *__restrict__ bsums, float *__restrict__ Y, int64_t y_row, int M, int K, int B) {
+    const int lane = threadIdx.x & 63, L = lane & 7, c = lane >> 3;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ngrp = (B + 7) / 8;
+    if (unit >= (int64_t)M * ngrp) return;
+    const int m = (int)(unit / ngrp), b = (int)(unit % ngrp) * 8 + c;
+    const int nsb = K / QK_K;
+    const int bb = b < B ? b : B - 1;
+    const uint8_t *wrow = W + (int64_t)m * w_row_bytes;
+    const int8_t *xq = qs + (int64_t)bb * K;
+    const float *xd = dd + (int64_t)bb * nsb;
+    const int16_t *xs = bsums + (int64_t)bb * (K / 16);
+    constexpr uint32_t M4 = 0x0F0F0F0Fu;
+    float acc = 0.f, am = 0.f;
+    for (int i = 0; i < nsb; i++) {
+        const uint8_t *blk = wrow + (int64_t)i * QT<TYPE>::BYTES;
+        const int8_t *q8 = xq + i * QK_K + 4 * L;
+        const float yd = xd[i];
+        int sumi = 0;
+        float d;
+        if constexpr (TYPE == CDNA4_Q6_K) {                             // block_q6_K: ql[128] qh[64] scales[16] d
+            d = yd * h2f(ld_u16(blk + 208));
+            const int8_t *sc = reinterpret_cast<const int8_t *>(blk + 192) + (L >> 2);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint32_t l1 = ld_u32_a2(blk + 64 * j + 4 * L), l2 = ld_u32_a2(blk + 64 * j + 32 + 4 * L), h = ld_u32_a2(blk + 128 + 32 * j + 4 * L);
+                const uint32_t q[4] = {(l1 & M4) | ((h & 0x03030303u) << 4), (l2 & M4) | (((h >> 2) & 0x03030303u) << 4),
+                                       ((l1 >> 4) & M4) | (((h >> 4) & 0x03030303u) << 4), ((l2 >> 4) & M4) | (((h >> 6) & 0x03030303u) << 4)};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int y = *reinterpret_cast<const int *>(q8 + 128 * j + 32 * k);
+                    const int p = __builtin_amdgcn_sdot4((int)q[k], y, 0, false) - __builtin_amdgcn_sdot4(0x20202020, y, 0, false);
+                    sumi += (int)sc[8 * j + 2 * k] * p;
+                }
+            }
+        } else {                                                        // block_q4_K: d dmin scales[12] qs[128]; block_q5_K: d dmin scales[12] qh[32] qs[128]
+            d = yd * h2f(ld_u16(blk));
+            const float dmin = -yd * h2f(ld_u16(blk + 2));
+            uint32_t u0 = ld_u32_a2(blk + 4), u1 = ld_u32_a2(blk + 8), u2 = ld_u32_a2(blk + 12);
+            const uint32_t m1 = ((u2 >> 4) & M4) | (((u1 >> 6) & 0x03030303u) << 4);          // utmp[3]: mins 4 .. 7
+            const uint32_t m0 = u1 & 0x3F3F3F3Fu;                                              // utmp[2]: mins 0 .. 3
+            const uint32_t s1 = (u2 & M4) | (((u0 >> 6) & 0x03030303u) << 4);                 // utmp[1]: scales 4 .. 7
+            const uint32_t s0 = u0 & 0x3F3F3F3Fu;                                              // utmp[0]: scales 0 .. 3
+            const uint64_t sc = ((uint64_t)s1 << 32) | s0, mn = ((uint64_t)m1 << 32) | m0;
+            const uint8_t *qp = blk + (TYPE == CDNA4_Q5_K ? 48 : 16) + 4 * L;
+            uint32_t hb = 0;
+            if constexpr (TYPE == CDNA4_Q5_K) hb = ld_u32_a2(blk + 16 + 4 * L);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t q = ld_u32_a2(qp + 32 * j);
+                uint32_t lo = q & M4, hi = (q >> 4) & M4;
+                if constexpr (TYPE == CDNA4_Q5_K) { lo |= ((hb >> (2 * j)) & 0x01010101u) << 4; hi |= ((hb >> (2 * j + 1)) & 0x01010101u) << 4; }
+                const int yl = *reinterpret_cast<const int *>(q8 + 64 * j), yh = *reinterpret_cast<const int *>(q8 + 64 * j + 32);
+                sumi += (int)((sc >> (16 * j)) & 0xFF) * __builtin_amdgcn_sdot4((int)lo, yl, 0, false) + (int)((sc >> (16 * j + 8)) & 0xFF) * __builtin_amdgcn_sdot4((int)hi, yh, 0, false);
+            }
+            // prod[k] = mins[2k] * (bsums[4k] + bsums[4k+1]) + mins[2k+1] * (bsums[4k+2] + bsums[4k+3])
+            int prod[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int16_t *s = xs + i * 16 + 4 * k;
+                prod[k] = (int)((mn >> (16 * k)) & 0xFF) * ((int)s[0] + (int)s[1]) + (int)((mn >> (16 * k + 8)) & 0xFF) * ((int)s[2] + (int)s[3]);
+            }
+            if constexpr (TYPE == CDNA4_Q4_K) {
+                const int k = L & 3;
+                const int pk = k == 0 ? prod[0] : k == 1 ? prod[1] : k == 2 ? prod[2] : prod[3];
+                am = __builtin_fmaf(dmin, (float)pk, am);               // _mm_fmadd_ps(set1(dmin), cvtepi32_ps(prod), acc_m): lane k of acc_m lives in lanes L = k, k + 4
+            } else {
+                am = __builtin_fmaf(dmin, (float)(prod[0] + prod[1] + prod[2] + prod[3]), am);       // summs += dmin * hsum
+            }
+        }
+        acc = __builtin_fmaf(d, (float)sumi, acc);
+    }
+    acc = acc + __shfl_xor(acc, 4, 64);                                 // hsum_float_8
+    acc = acc + __shfl_xor(acc, 2, 64);
+    acc = acc + __shfl_xor(acc, 1, 64);
+    if constexpr (TYPE == CDNA4_Q4_K) {
+        am = am + __shfl_xor(am, 2, 64);                                // _mm_add_ps(acc_m, _mm_movehl_ps(acc_m, acc_m))
+        am = am + __shfl_xor(am, 1, 64);                                // _mm_add_ss(acc_m, _mm_movehdup_ps(acc_m))
+    }
+    if constexpr (TYPE != CDNA4_Q6_K) acc = acc + am;
+    if (L == 0 && b < B) Y[(int64_t)b * y_row + m] = acc;
+}
+
 // ------------------------------------------------------------------------------------------------ MUL_MAT, F32 x F32
 // half a wave (32 lanes = the four 8-lane accumulators) per output element
 __global__ __launch_bounds__(256) void k_mul_mat_exact_f32(const T4 a, const T4 b, const T4 d, int64_t nout) {
@@ -120,6 +212,32 @@ __global__ __launch_bounds__(64) void k_norm_exact(const T4 a, const T4 d, float
     for (int64_t i = 0; i < n; i++) y[i] = y[i] * scale;               // ggml_vec_scale_f32
 }
 
+// ------------------------------------------------------------------------------------------------ RMS_NORM: one lane per row (ggml_compute_forward_rms_norm_f32, ggml-cpu.c:7000-7046)
+__global__ __launch_bounds__(64) void k_rms_norm_exact(const T4 a, const T4 d, float eps, int64_t nrow) {
+    const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (row >= nrow) return;
+    const int64_t i1 = row % a.ne[1], i2 = (row / a.ne[1]) % a.ne[2], i3 = row / (a.ne[1] * a.ne[2]);
+    const float *x = (const float *)((const char *)a.data + i1 * a.nb[1] + i2 * a.nb[2] + i3 * a.nb[3]);
+    float *y = (float *)((char *)d.data + i1 * d.nb[1] + i2 * d.nb[2] + i3 * d.nb[3]);
+    const int64_t n = a.ne[0];
+    double sum = 0.0;
+    for (int64_t i = 0; i < n; i++) { const float sq = x[i] * x[i]; sum += (double)sq; }       // sum += (ggml_float)(x * x): an fp32 product, a double sum
+    const float mean = (float)(sum / (double)n);
+    const float scale = 1.0f / sqrtf(mean + eps);
+    for (int64_t i = 0; i < n; i++) y[i] = x[i] * scale;               // memcpy + ggml_vec_scale_f32
+}
+
+// ------------------------------------------------------------------------------------------------ SILU: ggml_vec_silu_f32 (ggml-cpu.c:2017-2039) — per ROW, chunks of eight through
+// ggml_v_silu (:1952-1959: x / (1 + ggml_v_expf(0 - x))), the row's last n % 8 elements through x / (1.0f + expf(-x)) with glibc's expf
+__global__ __launch_bounds__(256) void k_silu_exact(const float *__restrict__ x, float *__restrict__ y, int nc, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int col = (int)(i % nc);
+    const float v = x[i];
+    const float e = col < (nc & ~7) ? exact_v_expf(0.0f - v) : exact_expf_glibc(-v);
+    y[i] = v / (1.0f + e);
+}
+
 // ------------------------------------------------------------------------------------------------ SOFT_MAX (no mask, no ALiBi): one lane per row
 __global__ __launch_bounds__(64) void k_soft_max_exact(const float *__restrict__ x, float *__restrict__ y, int nc, int64_t nrow, float scale) {
     const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -145,26 +263,42 @@ __global__ __launch_bounds__(64) void k_soft_max_exact(const float *__restrict__
 
 extern "C" {
 
+static bool exact_kq(int type) { return type == CDNA4_Q4_K || type == CDNA4_Q5_K || type == CDNA4_Q6_K; }
+static bool exact_q0(int type) { return type == CDNA4_Q4_0 || type == CDNA4_Q8_0; }
+// workspace: int8 qs [B][K] | float d [B][K / block] | (K-quants) int16 bsums [B][K / 16]
+static size_t exact_ws_d(int64_t K, int64_t B) { return (size_t)((B * K + 255) & ~(int64_t)255); }
+static size_t exact_ws_bsums(int type, int64_t K, int64_t B) { return exact_ws_d(K, B) + (size_t)((B * (K / (exact_kq(type) ? QK_K : 32)) * 4 + 255) & ~(int64_t)255); }
+int ggml_cdna4_mul_mat_exact_supported(int type, int64_t K) { return K > 0 && ((exact_q0(type) && K % 32 == 0) || (exact_kq(type) && K % QK_K == 0)); }
 size_t ggml_cdna4_mul_mat_exact_workspace_size(int type, int64_t K, int64_t B) {
-    if ((type != CDNA4_Q4_0 && type != CDNA4_Q8_0) || K <= 0 || K % 32 || B <= 0) return 0;
-    return (size_t)((B * K + 255) & ~(int64_t)255) + (size_t)B * (K / 32) * 4 + 256;
+    if (!ggml_cdna4_mul_mat_exact_supported(type, K) || B <= 0) return 0;
+    return exact_ws_bsums(type, K, B) + (exact_kq(type) ? (size_t)B * (K / 16) * 2 : 0) + 256;
 }
-int ggml_cdna4_mul_mat_exact_supported(int type, int64_t K) { return (type == CDNA4_Q4_0 || type == CDNA4_Q8_0) && K > 0 && K % 32 == 0; }
-// ggml_compute_forward_mul_mat (src/ggml-cpu/ggml-cpu.c:7428-7605) for Q4_0 / Q8_0 weights, in the CPU's arithmetic AND order
+// ggml_compute_forward_mul_mat (src/ggml-cpu/ggml-cpu.c:7428-7605) for Q4_0 / Q8_0 / Q4_K / Q5_K / Q6_K weights, in the CPU's arithmetic AND order
 int ggml_cdna4_mul_mat_exact(int type, const void *W, int64_t w_row_bytes, const float *X, int64_t x_row_stride, float *Y, int64_t y_row_stride,
                              int64_t M, int64_t K, int64_t B, void *workspace, size_t workspace_bytes, void *stream) {
-    NEEDX(ggml_cdna4_mul_mat_exact_supported(type, K), "mul_mat_exact: Q4_0 / Q8_0 weights, K a multiple of 32");
+    NEEDX(ggml_cdna4_mul_mat_exact_supported(type, K), "mul_mat_exact: Q4_0 / Q8_0 weights with K a multiple of 32, or Q4_K / Q5_K / Q6_K with K a multiple of 256");
     if (M <= 0 || B <= 0) return 0;
     NEEDX(workspace && !((uintptr_t)workspace & 255) && workspace_bytes >= ggml_cdna4_mul_mat_exact_workspace_size(type, K, B), "mul_mat_exact: workspace too small or misaligned");
     NEEDX(!(((uintptr_t)X | (uintptr_t)(x_row_stride * 4)) & 15) && !(((uintptr_t)W | (uintptr_t)w_row_bytes) & 1), "mul_mat_exact: misaligned operands");
     int8_t *qs = (int8_t *)workspace;
-    float *dd = (float *)((char *)workspace + ((B * K + 255) & ~(int64_t)255));
-    int rc = cdna4_launch_quantize_q8_0(X, x_row_stride, K, B, qs, dd, nullptr, false, (hipStream_t)stream);       // the AVX2 body of quantize_row_q8_0: what the CPU backend runs
-    if (rc) return rc;
+    float *dd = (float *)((char *)workspace + exact_ws_d(K, B));
     const int64_t units = M * ((B + 7) / 8);
     const dim3 grid((unsigned)((units + 3) / 4));
-    if (type == CDNA4_Q4_0) hipLaunchKernelGGL(k_mul_mat_exact_q<CDNA4_Q4_0>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)W, w_row_bytes, qs, dd, Y, y_row_stride, (int)M, (int)K, (int)B);
-    else hipLaunchKernelGGL(k_mul_mat_exact_q<CDNA4_Q8_0>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t *)W, w_row_bytes, qs, dd, Y, y_row_stride, (int)M, (int)K, (int)B);
+    const hipStream_t st = (hipStream_t)stream;
+    if (exact_kq(type)) {
+        int16_t *bs = (int16_t *)((char *)workspace + exact_ws_bsums(type, K, B));
+        int rc = cdna4_launch_quantize_q8_K(X, x_row_stride, K, B, qs, dd, bs, nullptr, st);                // quantize_row_q8_K_ref: what the CPU backend runs (ggml-cpu-quants.c quantize_row_q8_K)
+        if (rc) return rc;
+        if (type == CDNA4_Q4_K) hipLaunchKernelGGL(k_mul_mat_exact_kq<CDNA4_Q4_K>, grid, dim3(256), 0, st, (const uint8_t *)W, w_row_bytes, qs, dd, bs, Y, y_row_stride, (int)M, (int)K, (int)B);
+        else if (type == CDNA4_Q5_K) hipLaunchKernelGGL(k_mul_mat_exact_kq<CDNA4_Q5_K>, grid, dim3(256), 0, st, (const uint8_t *)W, w_row_bytes, qs, dd, bs, Y, y_row_stride, (int)M, (int)K, (int)B);
+        else hipLaunchKernelGGL(k_mul_mat_exact_kq<CDNA4_Q6_K>, grid, dim3(256), 0, st, (const uint8_t *)W, w_row_bytes, qs, dd, bs, Y, y_row_stride, (int)M, (int)K, (int)B);
+        CDNA4_CHECK_LAUNCH();
+        return 0;
+    }
+    int rc = cdna4_launch_quantize_q8_0(X, x_row_stride, K, B, qs, dd, nullptr, false, st);       // the AVX2 body of quantize_row_q8_0: what the CPU backend runs
+    if (rc) return rc;
+    if (type == CDNA4_Q4_0) hipLaunchKernelGGL(k_mul_mat_exact_q<CDNA4_Q4_0>, grid, dim3(256), 0, st, (const uint8_t *)W, w_row_bytes, qs, dd, Y, y_row_stride, (int)M, (int)K, (int)B);
+    else hipLaunchKernelGGL(k_mul_mat_exact_q<CDNA4_Q8_0>, grid, dim3(256), 0, st, (const uint8_t *)W, w_row_bytes, qs, dd, Y, y_row_stride, (int)M, (int)K, (int)B);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }
@@ -185,6 +319,27 @@ int ggml_cdna4_op_norm_exact(const T4 *a, const T4 *d, float eps, void *stream) 
     const int64_t nr = a->ne[1] * a->ne[2] * a->ne[3];
     if (nr <= 0 || a->ne[0] <= 0) return 0;
     hipLaunchKernelGGL(k_norm_exact, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, (hipStream_t)stream, *a, *d, eps, nr);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+int ggml_cdna4_op_rms_norm_exact(const T4 *a, const T4 *d, float eps, void *stream) {
+    NEEDX(a->type == CDNA4_F32 && d->type == CDNA4_F32 && a->nb[0] == 4 && d->nb[0] == 4, "rms_norm_exact: F32 rows");
+    NEEDX(a->ne[0] == d->ne[0] && a->ne[1] == d->ne[1] && a->ne[2] == d->ne[2] && a->ne[3] == d->ne[3], "rms_norm_exact: shape mismatch");
+    const int64_t nr = a->ne[1] * a->ne[2] * a->ne[3];
+    if (nr <= 0 || a->ne[0] <= 0) return 0;
+    hipLaunchKernelGGL(k_rms_norm_exact, dim3((unsigned)((nr + 63) / 64)), dim3(64), 0, (hipStream_t)stream, *a, *d, eps, nr);
+    CDNA4_CHECK_LAUNCH();
+    return 0;
+}
+// contiguous F32 (what ggml_compute_forward_silu_f32 asserts: ggml-cpu.c:6369-6373)
+int ggml_cdna4_op_silu_exact(const T4 *a, const T4 *d, void *stream) {
+    NEEDX(a->type == CDNA4_F32 && d->type == CDNA4_F32, "silu_exact: F32");
+    NEEDX(a->nb[0] == 4 && a->nb[1] == a->ne[0] * 4 && a->nb[2] == a->nb[1] * a->ne[1] && a->nb[3] == a->nb[2] * a->ne[2], "silu_exact: contiguous source");
+    NEEDX(d->nb[0] == 4 && d->nb[1] == d->ne[0] * 4 && d->nb[2] == d->nb[1] * d->ne[1] && d->nb[3] == d->nb[2] * d->ne[2], "silu_exact: contiguous destination");
+    NEEDX(a->ne[0] == d->ne[0] && a->ne[1] == d->ne[1] && a->ne[2] == d->ne[2] && a->ne[3] == d->ne[3], "silu_exact: shape mismatch");
+    const int64_t n = a->ne[0] * a->ne[1] * a->ne[2] * a->ne[3];
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_silu_exact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float *)a->data, (float *)d->data, (int)a->ne[0], n);
     CDNA4_CHECK_LAUNCH();
     return 0;
 }

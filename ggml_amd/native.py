@@ -60,6 +60,8 @@ SYMBOLS = [
     ("ggml_cdna4_mul_mat_exact", _int, [_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
     ("ggml_cdna4_op_mul_mat_f_exact", _int, [_vp, _vp, _vp, _vp]),
     ("ggml_cdna4_op_norm_exact", _int, [_vp, _vp, C.c_float, _vp]),
+    ("ggml_cdna4_op_rms_norm_exact", _int, [_vp, _vp, C.c_float, _vp]),
+    ("ggml_cdna4_op_silu_exact", _int, [_vp, _vp, _vp]),
     ("ggml_cdna4_op_soft_max_exact", _int, [_vp, _vp, C.c_float, _vp]),
     ("ggml_cdna4_op_rope", _int, [_vp, _vp, _vp, _vp, _int, _int, _int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     ("ggml_cdna4_op_flash_attn_ext_supported", _int, [_i64, _int]),

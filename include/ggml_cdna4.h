@@ -264,7 +264,9 @@ int ggml_cdna4_op_mul_mat_f(const ggml_cdna4_tensor * src0, const ggml_cdna4_ten
  * differs from the CPU backend's by default, computed in the order of the x86-64-v3 (AVX2 + FMA) build of the reference, so that a whole graph reproduces the
  * CPU backend's logits bit for bit (BASELINE.json configs[3]).  Verification mode: order costs speed.
  * MUL_MAT, Q4_0 / Q8_0 weights: quantize_row_q8_0 (AVX2 body) + ggml_vec_dot_q4_0_q8_0 / _q8_0_q8_0 with eight lane accumulators and hsum_float_8
- * (src/ggml-cpu/ggml-cpu-quants.c:778-815, 2005-2028, 3520-3536, 49-55); workspace >= ggml_cdna4_mul_mat_exact_workspace_size, 256-byte aligned */
+ * (src/ggml-cpu/ggml-cpu-quants.c:778-815, 2005-2028, 3520-3536, 49-55); Q4_K / Q5_K / Q6_K weights (K a multiple of 256): quantize_row_q8_K +
+ * the AVX2 bodies of ggml_vec_dot_q4_K_q8_K / _q5_K_q8_K / _q6_K_q8_K (:5712-5775, 6283-6364, 6941-7018: eight lane accumulators, the mins in Q4_K's four-lane
+ * acc_m / Q5_K's scalar summs); workspace >= ggml_cdna4_mul_mat_exact_workspace_size, 256-byte aligned */
 int    ggml_cdna4_mul_mat_exact_supported(int type, int64_t K);
 size_t ggml_cdna4_mul_mat_exact_workspace_size(int type, int64_t K, int64_t B);
 int    ggml_cdna4_mul_mat_exact(int type, const void * W, int64_t w_row_bytes, const float * X, int64_t x_row_stride, float * Y, int64_t y_row_stride,
@@ -273,6 +275,10 @@ int    ggml_cdna4_mul_mat_exact(int type, const void * W, int64_t w_row_bytes, c
 int    ggml_cdna4_op_mul_mat_f_exact(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * src1, const ggml_cdna4_tensor * dst, void * stream);
 /* NORM with sequential double sums (ggml_compute_forward_norm_f32, ggml-cpu.c:6929-6978) */
 int    ggml_cdna4_op_norm_exact(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, float eps, void * stream);
+/* RMS_NORM with the sequential double sum of fp32 squares (ggml_compute_forward_rms_norm_f32, ggml-cpu.c:7000-7046) */
+int    ggml_cdna4_op_rms_norm_exact(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, float eps, void * stream);
+/* SILU on contiguous F32 rows: ggml_v_silu per chunk of 8 of a row, x / (1 + expf(-x)) with glibc's expf on the row's tail (ggml_vec_silu_f32, ggml-cpu.c:2017-2039, 1952-1959) */
+int    ggml_cdna4_op_silu_exact(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, void * stream);
 /* SOFT_MAX without mask / ALiBi on contiguous rows: ggml_v_expf per chunk of 8, the chunk sums in the AVX2 shuffle order accumulated in double, glibc's expf
  * on the tail (ggml_compute_forward_soft_max_f32, ggml-cpu.c:8848-8944, 2041-2092, 1912-1949) */
 int    ggml_cdna4_op_soft_max_exact(const ggml_cdna4_tensor * src0, const ggml_cdna4_tensor * dst, float scale, void * stream);

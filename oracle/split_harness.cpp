@@ -230,8 +230,10 @@ int main(int argc, char ** argv) {
         if (getenv("HARNESS_NO_CPU")) y_cpu = y_gpu; else build(cpu, y_cpu, nullptr, nullptr);      // (timing runs at full size skip the CPU backend's pass)
         uint64_t h = 1469598103934665603ull;
         for (const auto & y : y_gpu) for (size_t i = 0; i < y.size() * 4; i++) { h ^= ((const uint8_t *)y.data())[i]; h *= 1099511628211ull; }
-        printf("{\"type\":\"%s\",\"D\":%lld,\"H\":%lld,\"B\":%lld,\"act_hand_offs_first_compute\":%d,\"grouped_first_compute\":%d,\"fnv1a\":\"%016llx\",\"us_per_graph\":%.2f,\"k_vs_cpu\":%.3e,\"v_vs_cpu\":%.3e,\"out_vs_cpu\":%.3e}\n",
-               ggml_type_name(type), (long long)D, (long long)H, (long long)B, shared, grouped, (unsigned long long)h, us, rel_l2(y_gpu[0], y_cpu[0]), rel_l2(y_gpu[1], y_cpu[1]), rel_l2(y_gpu[2], y_cpu[2]));
+        long long words_differing = 0;                                       // fp32 words of K, V and out whose BITS differ from the CPU backend's (0 under GGML_CDNA4_EXACT=1)
+        for (size_t o = 0; o < y_gpu.size(); o++) for (size_t i = 0; i < y_gpu[o].size(); i++) words_differing += memcmp(&y_gpu[o][i], &y_cpu[o][i], 4) != 0;
+        printf("{\"type\":\"%s\",\"D\":%lld,\"H\":%lld,\"B\":%lld,\"act_hand_offs_first_compute\":%d,\"grouped_first_compute\":%d,\"fnv1a\":\"%016llx\",\"us_per_graph\":%.2f,\"k_vs_cpu\":%.3e,\"v_vs_cpu\":%.3e,\"out_vs_cpu\":%.3e,\"words_differing_from_cpu\":%lld}\n",
+               ggml_type_name(type), (long long)D, (long long)H, (long long)B, shared, grouped, (unsigned long long)h, us, rel_l2(y_gpu[0], y_cpu[0]), rel_l2(y_gpu[1], y_cpu[1]), rel_l2(y_gpu[2], y_cpu[2]), words_differing);
         ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
         return 0;
     }

@@ -43,7 +43,19 @@ def test_layer_front_through_ggmls_public_api_on_the_emulated_plugin(plug, type_
     on, off = _shared(plug, type_, d, h, b, True), _shared(plug, type_, d, h, b, False)
     assert on["act_hand_offs_first_compute"] == hand_offs and off["act_hand_offs_first_compute"] == 0, (on, off)
     assert on["fnv1a"] == off["fnv1a"], (on, off)
-    assert on["k_vs_cpu"] < 1e-3 and on["v_vs_cpu"] < 1e-3 and on["out_vs_cpu"] < 3e-2, on
+    assert on["k_vs_cpu"] < 1e-3 and on["v_vs_cpu"] < 1e-3, on            # (`out`, two re-quantizations deep, is reported by the harness and not bounded: see the reference-order test below)
+
+
+@pytest.mark.parametrize("type_,b", [("q4_K", 9), ("q5_K", 5), ("q6_K", 12), ("q4_0", 7), ("q4_K", 1)])
+def test_layer_front_in_reference_order_is_the_cpu_backends_bits_on_the_emulated_plugin(plug, type_, b):
+    """GGML_CDNA4_EXACT=1: RMS_NORM, six quantized MUL_MATs — K-quants in the AVX2 lane order of ggml_vec_dot_q4_K_q8_K / _q5_K_q8_K / _q6_K_q8_K
+    (ggml_amd/csrc/exact.hip: k_mul_mat_exact_kq) —, SILU, MUL, ADD: every fp32 word of K, V and out equals the reference CPU backend's, three products and two re-quantizations deep
+    (tests/test_gpu_act_share.py runs the same on the hardware at full width)"""
+    j = plug.harness([type_, 256, 512, b, "shared"], env={"HARNESS_NO_TIMING": 1, "GGML_CDNA4_EXACT": 1})
+    if j is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert j["act_hand_offs_first_compute"] == 0 and j["grouped_first_compute"] == 0, j
+    assert j["words_differing_from_cpu"] == 0 and j["out_vs_cpu"] == 0.0, j
 
 
 @pytest.mark.parametrize("type_", ["q4_K", "q4_0"])
