@@ -431,6 +431,29 @@ def layer_front_rows(dev, steps, d=4096, b=512, mkv=1024):
             "us_plain": round(min(us["plain"]), 2), "us_handed_off": round(min(us["handed_off"]), 2), "all_us": {k_: [round(v, 2) for v in vs] for k_, vs in us.items()}}
 
 
+def layer_front_one_row(timeout=100):
+    """round 6, through ggml's PUBLIC API on the plug-in (oracle/_ref/split_harness `shared`, HIP-graph replay): a llama-8B-sized attention + FFN front at ONE
+    activation row — rms_norm -> {wq, wk, wv + bias}, rms_norm -> {w_gate, w_up} -> w_down; D = 4096, H = 14336 — with the one-row MUL_MATs of one src1 grouped into one launch
+    (default) and node by node (GGML_CDNA4_NO_GROUP=1); the FNV-1a of the outputs' bytes must be equal"""
+    exe, plugin = os.path.join(REFDIR, "split_harness"), os.path.join(ROOT, "ggml_amd", "lib", "libggml-cdna4.so")
+    if not (os.path.exists(exe) and os.path.exists(plugin)):
+        return {"error": "oracle/_ref/split_harness or the plug-in is not in the snapshot"}
+    out = {"workload": "plug-in, ggml public API: attention + FFN front, D 4096, H 14336, ONE activation row; us per graph (HIP-graph replay of the plug-in)"}
+    for t in ("q4_K", "q4_0"):
+        row = {}
+        for name, env in (("grouped", {}), ("node_by_node", {"GGML_CDNA4_NO_GROUP": "1"})):
+            try:
+                r = subprocess.run([exe, plugin, t, "4096", "14336", "1", "shared"], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HARNESS_NO_CPU="1", **env))
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                row[name] = {"us_per_graph": j["us_per_graph"], "mul_mats_that_rode_along": j["grouped_first_compute"], "fnv1a": j["fnv1a"]}
+            except Exception as e:  # noqa: BLE001
+                row[name] = {"error": repr(e)[:200]}
+        if all("fnv1a" in v for v in row.values()):
+            row["bytes_equal"] = row["grouped"]["fnv1a"] == row["node_by_node"]["fnv1a"]
+        out[t] = row
+    return out
+
+
 def batch_sweep(dev, steps):
     """µs per MUL_MAT call (activation quantize included, HIP events) from decode to prefill batch sizes — one-launch GEMV (1..8 rows,
     columns from LDS; 3..8 rows over large matrices: the int8 matrix-core kernel), k_mmq_q4_K for 9..32 rows (mmq_i8.hip: v_mfma_i32_16x16x32_i8),
@@ -442,7 +465,7 @@ def batch_sweep(dev, steps):
         w, _, how = prescribed(Q4_K, m, k, 0, m, 1)
         a = ops.QTensor.from_host_bytes(Q4_K, k, m, w, device=dev)
         row = {}
-        for b in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+        for b in (1, 2, 3, 4, 8, 16, 32, 64, 128, 256):
             x = torch.from_numpy(np.random.default_rng(b).uniform(-1, 1, (b, k)).astype(np.float32)).to(dev)
             y = torch.empty((b, m), dtype=torch.float32, device=dev)
             row[str(b)] = round(graph_us(dev, lambda: ops.mul_mat(a, x, out=y), 40), 2)
@@ -475,7 +498,9 @@ def moe_row(dev, steps):
         fl = 2.0 * m * k * nt * n_used
         if nt > 1:
             out["prefill_512_tokens"] = {"us_per_call": round(us, 2), "effective_tflops": round(fl / us / 1e6, 1), "frac_of_mfma_roof": round(fl / us / 1e6 / MFMA_F16_PEAK_TFLOPS, 4),
-                                         "launches": "plan + gather-quantize + one grouped k_gemm_kq_t64<Q4_K, 256, IDS>", "padded_rows": "each expert's run rounded up to 128 image rows"}
+                                         "launches": "two: k_moe_sk_front (block 0: stable counting sort of the ids + tile records + work-queue spans; the other blocks: the activation quantizer, token order) "
+                                                     "and k_gemm_kq_sk (one persistent work-group per span of (tile, m-tile, superblock) units; partial tiles parked, the last arriver of a tile sums in span order — nobody waits)",
+                                         "tiles": "per expert ceil(rows / 128) image tiles; rows are gathered by per-lane source rows, nothing is padded in memory"}
         else:
             wbytes = n_used * m * (k // 256) * 144
             out["decode_1_token"] = {"us_per_call": round(us, 2), "GBps": round(wbytes / us / 1e3, 1), "frac_of_hbm_roof": round(wbytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches": "one (k_gemv_q_fused<.., IDS>)"}
@@ -828,7 +853,10 @@ def main():
                          "step_frac": round(value / world / MFMA_F16_PEAK_TFLOPS, 4),
                          "launches_per_step": 1 if fused else 2,
                          # the two launches the one-launch step replaces, each alone: the activation quantizer and the GEMM on prepared activations (AUTO's ticketed split)
-                         "two_launch_components_us": {"k_quantize_q8_K": round(quant_us, 3), "k_gemm_kq_t64<Q4_K, 128>": round(gemm2_us, 3)}},
+                         "two_launch_components_us": {"k_quantize_q8_K": round(quant_us, 3), "k_gemm_kq_t64<Q4_K, 128>": round(gemm2_us, 3)},
+                         # the in-graph case: the producer of src1 — the NORM chain's launch — already left the activation image, so the MUL_MAT node is the GEMM
+                         # alone on prepared activations (ggml_cdna4_mul_mat_prepared: what the plug-in issues for wq / wk / wv / w_gate / w_up behind a norm)
+                         "step_us_image_from_producer": round(gemm2_us, 3), "step_frac_image_from_producer": round(h.flops / gemm2_us / 1e6 / MFMA_F16_PEAK_TFLOPS, 4)},
         }
         # the same step in the library's DEFAULT mode (shared device: quantizer launch + GEMM with the ticketed split — nothing waits for a co-resident work-group)
         try:
@@ -882,6 +910,7 @@ def main():
                     ("formats", lambda: format_rows(dev, steps), 230),
                     ("resident_images", lambda: resident_image_rows(dev, steps), 238),
                     ("layer_front", lambda: layer_front_rows(dev, steps), 242),
+                    ("layer_front_one_row", lambda: layer_front_one_row(), 244),
                     ("mul_mat_id", lambda: moe_row(dev, steps), 245),
                     ("batch_sweep", lambda: batch_sweep(dev, steps), 250),
                     ("widening", lambda: leg_in_child("widening", steps, int(max(30, min(120, time_left(330))))), 255),

@@ -83,6 +83,8 @@ int cdna4_launch_gemm_t64(const cdna4_gemm_args &a, int tm, int splitk, hipStrea
     const int abl = a.variant >> 16;
 #define T64_ABL(A) if (abl == (A)) { if (tm == 128) hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, false, (A)>), grid, dim3(512), 0, st, p); else hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 256, false, (A)>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
     T64_ABL(1) T64_ABL(3) T64_ABL(4) T64_ABL(8) T64_ABL(15) T64_ABL(32) T64_ABL(256)
+    // the one-launch step with block 0's milestones (ggml_cdna4_debug_trace set, no variant): the instrumented twin of the FQ form
+    if (fq && p.trace && !abl && p.epi.bias == nullptr && p.epi.act == 0 && p.epi.resid == nullptr) { hipLaunchKernelGGL((k_gemm_kq_t64<CDNA4_Q4_K, 128, false, 256, false, true>), grid, dim3(512), 0, st, p); CDNA4_CHECK_LAUNCH(); return 0; }
     if (abl) return cdna4_set_error_msg("gemm_t64: ablation not instantiated");
 #endif
     const bool tail = p.epi.bias != nullptr || p.epi.act != 0 || p.epi.resid != nullptr;

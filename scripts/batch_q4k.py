@@ -8,10 +8,12 @@ import bench as B
 from ggml_amd import native, ops
 native.lib(); dev = torch.device("cuda", 0)
 out = {"tag": os.environ.get("AB_TAG", "")}
-for (m, k) in ((4096, 4096), (4096, 14336)):
+shapes = [tuple(int(v) for v in sh.split("x")) for sh in os.environ.get("BATCH_SHAPES", "4096x4096,4096x14336").split(",")]
+rows = [int(v) for v in os.environ.get("BATCH_ROWS", "1,2,3,4,6,8,12,16,24,32,48,64").split(",")]
+for (m, k) in shapes:
     a = ops.QTensor.from_host_bytes(12, k, m, B.synth_blocks(12, m, k, 7), device=dev)
     row = {}
-    for b in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64):
+    for b in rows:
         x = torch.from_numpy(np.random.default_rng(b).uniform(-1, 1, (b, k)).astype(np.float32)).to(dev)
         y = torch.empty((b, m), dtype=torch.float32, device=dev)
         row[b] = round(B.graph_us(dev, lambda: ops.mul_mat(a, x, out=y), 40), 2)

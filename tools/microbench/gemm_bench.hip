@@ -10,6 +10,15 @@
 #include <vector>
 #include <random>
 
+// block 0's milestones (gemm_kq_t64.inc: mile()), us since the kernel's entry stamp
+static void t64_milestones(const std::vector<unsigned long long> &tr) {
+    const unsigned long long e0 = tr[1];
+    auto us = [&](int i) { return tr[i] > e0 ? (double)(tr[i] - e0) / 100.0 : -1.0; };
+    printf("  block 0 milestones, us since entry (s_memrealtime):");
+    if (tr[4] > e0) printf("  own share quantized %.2f  grid barrier passed %.2f", us(4), us(5));
+    printf("  stage 0 in LDS %.2f  loop done %.2f  tiles exchanged %.2f  stores issued %.2f  stores drained %.2f\n", us(6), us(3), us(7), us(265), us(264));
+}
+
 int main(int argc, char **argv) {
     setvbuf(stdout, nullptr, _IOLBF, 0);          // a GPU fault aborts the process: keep what was printed so far
     const int64_t M = argc > 1 ? atoll(argv[1]) : 4096, K = argc > 2 ? atoll(argv[2]) : 4096, B = argc > 3 ? atoll(argv[3]) : 512;
@@ -105,6 +114,7 @@ int main(int argc, char **argv) {
                 if (n) printf("    wave %d (%2d stages): %7.0f | %6.0f | %6.0f | %6.0f ;  %7.0f\n", w, n, a[0] / n, a[1] / n, a[2] / n, a[3] / n, len / n);
             }
             for (int w : {0, 4}) { printf("    wave %d stage starts:", w); for (int sgi = 0; sgi < 16; sgi++) printf(" %u", st32[(w * 16 + sgi) * 4] - st32[0]); printf("\n"); }
+            t64_milestones(tr);
             continue;
         }
         if (v >= 65536) continue;                    // k_gemm_kq_w12 experiments record the clock only
@@ -124,6 +134,27 @@ int main(int argc, char **argv) {
             printf("wave %d stage %2d:", w, st + 4);
             for (int ph : {0, 1, 2, 3, 4, 5, 6}) printf(" %7lld", (long long)(tr[(w * 16 + st) * 8 + ph] - t0));
             printf("\n");
+        }
+    }
+    // GB_TRACE_FQ=1 (the -DCDNA4_ABLATIONS library, owned-device mode): the one-launch step (k_gemm_kq_t64<.., FQ>: quantizer share, grid barrier, multiply) with block 0's
+    // milestones, and the same launch timed by HIP events WITHOUT the instrumentation's drain (trace buffer off) — the difference between the event time and the last
+    // milestone is what the launch itself takes (dispatch to first instruction, last store to completion signal)
+    if (getenv("GB_TRACE_FQ")) {
+        auto step = [&]() { return ggml_cdna4_mul_mat(GGML_CDNA4_TYPE_Q4_K, dw, ggml_cdna4_row_size(GGML_CDNA4_TYPE_Q4_K, K), (const float *)dx, K, (float *)dy, M, M, K, B, ws, wsz, GGML_CDNA4_PATH_GEMM, 0, 0, 0); };
+        for (int i = 0; i < 20; i++) if (step()) { printf("one-launch step failed: %s\n", ggml_cdna4_last_error()); return 1; }
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        float best = 1e9f;
+        for (int r = 0; r < 4; r++) { hipEventRecord(e0, 0); for (int i = 0; i < 100; i++) step(); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; }
+        printf("one-launch step (route %d): %.2f us per launch by HIP events (100 back to back, min of 4)\n", ggml_cdna4_mul_mat_route(GGML_CDNA4_TYPE_Q4_K, M, K, B), best * 10.0f);
+        for (int rep = 0; rep < 3; rep++) {
+            hipMemset(dtr, 0, 65536);
+            for (int i = 0; i < 30; i++) step();                          // (the clock the chip settles at under load)
+            ggml_cdna4_debug_trace(dtr);
+            step();
+            hipDeviceSynchronize();
+            ggml_cdna4_debug_trace(nullptr);
+            std::vector<unsigned long long> tr(8 * 16 * 8 + 1104); hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost);
+            t64_milestones(tr);
         }
     }
     return 0;
