@@ -16,7 +16,7 @@ static void t64_milestones(const std::vector<unsigned long long> &tr) {
     auto us = [&](int i) { return tr[i] > e0 ? (double)(tr[i] - e0) / 100.0 : -1.0; };
     printf("  block 0 milestones, us since entry (s_memrealtime):");
     if (tr[4] > e0) printf("  own share quantized %.2f  grid barrier passed %.2f", us(4), us(5));
-    printf("  stage 0 in LDS %.2f  loop done %.2f  tiles exchanged %.2f  stores issued %.2f  stores drained %.2f\n", us(6), us(3), us(7), us(265), us(264));
+    printf("  stage 0 in LDS %.2f  loop done %.2f  K ways met in LDS %.2f  halves parked %.2f  partner's flag seen %.2f  tiles exchanged %.2f  stores issued %.2f  stores drained %.2f\n", us(6), us(3), us(266), us(267), us(268), us(7), us(265), us(264));
 }
 
 int main(int argc, char **argv) {
