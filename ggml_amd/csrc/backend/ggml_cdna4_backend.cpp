@@ -474,7 +474,6 @@ static bool try_group_mul_mat(cdna4_backend_ctx * ctx, ggml_cgraph * g, int i, c
             if (mem_overlap(c.out, nq)) ok = false;
             for (int j = 0; j < GGML_MAX_SRC && ok; j++) if (nq->src[j] && nq->src[j]->data && mem_overlap(c.out, nq->src[j])) ok = false;
         }
-        if (getenv("GGML_CDNA4_GROUP_DEBUG")) fprintf(stderr, "ggml-cdna4: group candidate %s behind %s: %s\n", t->name, mm->name, ok ? "taken" : "its output's memory is in use in between");
         if (ok) ms[n++] = c;
     }
     if (n < 2) return false;

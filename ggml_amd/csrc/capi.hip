@@ -563,6 +563,9 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
                 const uint8_t *img = cdna4_resident_lookup(CDNA4_Q4_0, as, w_row_bytes, M * n_expert, K);
                 if (img && !((uintptr_t)img & 15)) { sk_type = CDNA4_Q4_0R; skW = img; sk_row = (K / 256) * 144; sk_exp = M * sk_row; }
             }
+            // (CDNA4_MMQ_IDS=2 — a coverage / measurement knob — asks for the int8 matrix-core kernels below where there are few rows per expert)
+            static const bool mmq_ids_forced = getenv("CDNA4_MMQ_IDS") && atoi(getenv("CDNA4_MMQ_IDS")) == 2;
+            if (mmq_ids_forced && n_tok * n_used <= 32 * n_expert) sk_type = -1;
             if (sk_type >= 0 && moe_sk_on(sk_type, M, K, n_expert, n_used, n_b, n_tok)) {
                 const moe_sk_view sv = moe_sk_carve(K, n_expert, n_used, n_b, n_tok, workspace);
                 if (workspace_bytes >= sv.total) {
