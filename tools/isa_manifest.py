@@ -50,8 +50,9 @@ def asm_of(f):
     out = os.path.join(cache, "%s.%s.s" % (f, h.hexdigest()[:16]))
     if not os.path.exists(out):
         for old in os.listdir(cache):
-            if old.startswith(f + "."):
-                os.remove(os.path.join(cache, old))
+            if old.startswith(f + ".") and old.endswith(".s"):           # (never another process's output in flight, "<out>.tmp<pid>": xdist workers compile side by side)
+                try: os.remove(os.path.join(cache, old))
+                except FileNotFoundError: pass
         tmp = out + ".tmp%d" % os.getpid()
         subprocess.run([HIPCC] + FLAGS + ["-o", tmp, os.path.join(CSRC, f)], check=True, capture_output=True, timeout=1500)
         os.replace(tmp, out)
