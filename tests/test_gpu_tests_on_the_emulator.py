@@ -58,6 +58,9 @@ SELECTION_R3.append(("test_gpu_resident.py", "test_q8_0_and_q6_K_resident_images
 SELECTION_R3.append(("test_gpu_resident.py", "test_q4_0_expert_stack and 128-512", 1))
 # the hand-off of quantized activations: the second product on the first one's image (C-ABI: act_image_key, mul_mat_prepared[_fused]) is bit-identical to quantizing again
 SELECTION_R3.append(("test_gpu_act_share.py", "(test_second_product and 16) or test_prepared_fused_refuses or (test_norm_that_also and (256-512 or 2304-768) and 1-gain) or (test_the_image_a_norm_leaves and (800-5 or 96-3 or 768-9))", 10))
+# round 6: several one-row products of one activation row in ONE launch (ggml_cdna4_mul_mat_group / k_gemv_q_fused_grp) equal the single calls bit for bit, four ragged matrices
+# with and without bias, Q4_K / Q4_0 / Q6_K; what has no grouped form is refused with -2
+SELECTION_R3.append(("test_gpu_group.py", "(ms2 and (12 or 2 or 14)) or refuses", 6))
 
 
 def _merged(selections):
