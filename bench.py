@@ -496,11 +496,19 @@ def moe_row(dev, steps):
                                                  y.data_ptr(), m, n_used * m, m, k, n_expert, n_used, n_used, nt, ws.data_ptr(), ws.numel(), st))
         us = events_us(call, max(20, steps // 2), 5)
         fl = 2.0 * m * k * nt * n_used
+        us_prepared = None
+        if nt > 1 and L.ggml_cdna4_mul_mat_id_front_key(Q4_K, a.data.data_ptr(), a.row_bytes, m * a.row_bytes, m, k, n_expert, n_used, n_used, nt, ws.numel()):
+            # a second expert stack on the SAME (b, ids) — w_gate behind w_up of a mixture-of-experts layer — multiplies the front the call above left in the workspace: one launch
+            def prepared():
+                native.check(L.ggml_cdna4_mul_mat_id_prepared(Q4_K, a.data.data_ptr(), a.row_bytes, m * a.row_bytes, xb.data_ptr(), k, n_used * k, ids.data_ptr(), n_used,
+                                                              y.data_ptr(), m, n_used * m, m, k, n_expert, n_used, n_used, nt, ws.data_ptr(), ws.numel(), st))
+            call(); us_prepared = round(events_us(prepared, max(20, steps // 2), 5), 2)
         if nt > 1:
             out["prefill_512_tokens"] = {"us_per_call": round(us, 2), "effective_tflops": round(fl / us / 1e6, 1), "frac_of_mfma_roof": round(fl / us / 1e6 / MFMA_F16_PEAK_TFLOPS, 4),
                                          "launches": "two: k_moe_sk_front (block 0: stable counting sort of the ids + tile records + work-queue spans; the other blocks: the activation quantizer, token order) "
                                                      "and k_gemm_kq_sk (one persistent work-group per span of (tile, m-tile, superblock) units; partial tiles parked, the last arriver of a tile sums in span order — nobody waits)",
-                                         "tiles": "per expert ceil(rows / 128) image tiles; rows are gathered by per-lane source rows, nothing is padded in memory"}
+                                         "tiles": "per expert ceil(rows / 128) image tiles; rows are gathered by per-lane source rows, nothing is padded in memory",
+                                         "us_per_call_second_stack_on_the_same_front": us_prepared}
         else:
             wbytes = n_used * m * (k // 256) * 144
             out["decode_1_token"] = {"us_per_call": round(us, 2), "GBps": round(wbytes / us / 1e3, 1), "frac_of_hbm_roof": round(wbytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches": "one (k_gemv_q_fused<.., IDS>)"}

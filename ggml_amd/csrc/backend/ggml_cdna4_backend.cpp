@@ -261,6 +261,11 @@ static void act_image_written(cdna4_backend_ctx * ctx, const void * p, size_t n)
 // ... and a weight of a CDNA4_Resident buffer underneath it loses its kernel-native image (CPY / SET_ROWS into a weight, a quantized KV tensor placed there)
 static void node_wrote(cdna4_backend_ctx * ctx, const ggml_tensor * t) {
     act_image_written(ctx, t->data, ggml_nbytes(t));
+    {   // ... and a MUL_MAT_ID front made of activations / ids that overlap it
+        auto & mf = ctx->moe_front;
+        const char * p = (const char *)t->data; const size_t n = ggml_nbytes(t);
+        if (mf.key && ((p < (const char *)mf.b + mf.b_bytes && (const char *)mf.b < p + n) || (p < (const char *)mf.ids + mf.ids_bytes && (const char *)mf.ids < p + n))) mf.key = 0;
+    }
     ggml_backend_buffer_t buf = t->view_src ? t->view_src->buffer : t->buffer;
     if (buffer_is_cdna4(buf) && ((cdna4_buffer_ctx *)buf->context)->resident) cdna4_resident_node_wrote(buf, t->data, ggml_nbytes(t));
 }
@@ -300,19 +305,36 @@ static enum ggml_status compute_mul_mat(cdna4_backend_ctx * ctx, ggml_tensor * d
     return GGML_STATUS_SUCCESS;
 }
 
+static std::atomic<int> g_moe_front_shared{0};
+extern "C" int ggml_backend_cdna4_moe_front_shared_count(void) { return g_moe_front_shared.load(); }
 static enum ggml_status compute_mul_mat_id(cdna4_backend_ctx * ctx, ggml_tensor * dst) {
     const ggml_tensor * as = dst->src[0], * b = dst->src[1], * ids = dst->src[2];
     const int64_t K = as->ne[0], M = as->ne[1], n_expert = as->ne[2];
     const int64_t n_b = b->ne[1], n_tok = b->ne[2], n_used = ids->ne[0];
+    const int64_t b_row = (int64_t)(b->nb[1] / 4), b_tok = (int64_t)(b->nb[2] / 4), ids_tok = (int64_t)(ids->nb[1] / 4);
     const size_t need = ggml_cdna4_mul_mat_id_workspace_size((int)as->type, K, n_expert, n_used, n_b, n_tok);
+    auto & mf = ctx->moe_front;
+    // the previous MUL_MAT_ID sorted these very ids and quantized these very activations into the workspace (w_up, then w_gate, of a mixture-of-experts layer): multiply its front
+    if (act_share_on() && mf.key && mf.uses == ctx->ws_uses && need <= ctx->ws_size && mf.b == b->data && mf.ids == ids->data && mf.type == (int)as->type && mf.b_row == b_row &&
+        mf.b_tok == b_tok && mf.ids_tok == ids_tok && mf.M == M && mf.K == K && mf.n_expert == n_expert && mf.n_used == n_used && mf.n_b == n_b && mf.n_tok == n_tok &&
+        ggml_cdna4_mul_mat_id_front_key((int)as->type, as->data, (int64_t)as->nb[1], (int64_t)as->nb[2], M, K, n_expert, n_used, n_b, n_tok, ctx->ws_size) == mf.key) {
+        const int rc = ggml_cdna4_mul_mat_id_prepared((int)as->type, as->data, (int64_t)as->nb[1], (int64_t)as->nb[2], (const float *)b->data, b_row, b_tok, (const int32_t *)ids->data, ids_tok,
+                                                      (float *)dst->data, (int64_t)(dst->nb[1] / 4), (int64_t)(dst->nb[2] / 4), M, K, n_expert, n_used, n_b, n_tok, ctx->ws, ctx->ws_size, ctx->stream);
+        if (rc == 0) { ctx->n_moe_front_shared++; g_moe_front_shared++; return GGML_STATUS_SUCCESS; }
+        mf.key = 0;                                                     // (refused before any launch: the full call below)
+    }
     void * ws = ctx->need_ws(need);
     if (!ws) return GGML_STATUS_ALLOC_FAILED;
     const int rc = ggml_cdna4_mul_mat_id((int)as->type, as->data, (int64_t)as->nb[1], (int64_t)as->nb[2],
-                                         (const float *)b->data, (int64_t)(b->nb[1] / 4), (int64_t)(b->nb[2] / 4),
-                                         (const int32_t *)ids->data, (int64_t)(ids->nb[1] / 4),
+                                         (const float *)b->data, b_row, b_tok,
+                                         (const int32_t *)ids->data, ids_tok,
                                          (float *)dst->data, (int64_t)(dst->nb[1] / 4), (int64_t)(dst->nb[2] / 4),
                                          M, K, n_expert, n_used, n_b, n_tok, ws, ctx->ws_size, ctx->stream);
     if (rc) { fprintf(stderr, "ggml-cdna4: MUL_MAT_ID failed: %s\n", ggml_cdna4_last_error()); return GGML_STATUS_FAILED; }
+    mf.key = act_share_on() ? ggml_cdna4_mul_mat_id_front_key((int)as->type, as->data, (int64_t)as->nb[1], (int64_t)as->nb[2], M, K, n_expert, n_used, n_b, n_tok, ctx->ws_size) : 0;
+    mf.uses = ctx->ws_uses; mf.b = b->data; mf.ids = ids->data; mf.type = (int)as->type; mf.b_row = b_row; mf.b_tok = b_tok; mf.ids_tok = ids_tok;
+    mf.b_bytes = (size_t)((n_tok - 1) * b_tok + (n_b - 1) * b_row + K) * 4; mf.ids_bytes = (size_t)((n_tok - 1) * ids_tok + n_used) * 4;
+    mf.M = M; mf.K = K; mf.n_expert = n_expert; mf.n_used = n_used; mf.n_b = n_b; mf.n_tok = n_tok;
     return GGML_STATUS_SUCCESS;
 }
 
@@ -590,6 +612,7 @@ static enum ggml_status run_nodes(cdna4_backend_ctx * ctx, ggml_cgraph * cgraph)
     const bool fuse = !no_fuse && n_nodes > 1;
     const use_counts uses = fuse ? use_counts(cgraph) : use_counts(nullptr, 0);
     ctx->act_image.key = 0;                                              // (activations of an earlier graph: the host may have rewritten them since)
+    ctx->moe_front.key = 0;
     std::vector<char> done(fuse ? n_nodes : 0, 0);                      // one-row MUL_MATs that already ran in an earlier node's launch (try_group_mul_mat)
     for (int i = 0; i < n_nodes; i++) {
         ggml_tensor * node = ggml_graph_node(cgraph, i);
@@ -931,6 +954,7 @@ static void * cdna4_reg_get_proc_address(ggml_backend_reg_t, const char * name) 
     if (strcmp(name, "ggml_backend_dev_get_extra_bufts") == 0) return (void *)cdna4_dev_get_extra_bufts;
     if (strcmp(name, "ggml_backend_cdna4_resident_buffer_type") == 0) return (void *)cdna4_resident_buffer_type;     // (int device) -> the buffer type directly
     if (strcmp(name, "ggml_backend_get_features") == 0) return (void *)cdna4_get_features;
+    if (strcmp(name, "ggml_backend_cdna4_moe_front_shared_count") == 0) return (void *)ggml_backend_cdna4_moe_front_shared_count;   // MUL_MAT_IDs that multiplied the previous one's front (statistics)
     if (strcmp(name, "ggml_backend_cdna4_grouped_count") == 0) return (void *)ggml_backend_cdna4_grouped_count;       // one-row MUL_MATs that rode in another product's launch (statistics)
     if (strcmp(name, "ggml_backend_cdna4_act_shared_count") == 0) return (void *)ggml_backend_cdna4_act_shared_count;   // MUL_MATs that reused the previous one's quantized activations (statistics)
     if (strcmp(name, "ggml_backend_cdna4_ksplit_buffer_type") == 0) return (void *)cdna4_ksplit_buffer_type;   // the K-split counterpart (no reference equivalent; ggml_cdna4_split.cpp)

@@ -52,6 +52,11 @@ struct cdna4_backend_ctx {
              const void * producer = nullptr; } act_image;     // producer: the node whose own launch wrote x AND the image (NORM chain: its write of x does not end the image's life)
     int n_act_produced = 0;                                   // NORM chains that left the image of their rows for the next MUL_MAT
     int n_act_shared = 0;                                     // MUL_MATs that took the hand-off (statistics; "ggml_backend_cdna4_act_shared_count")
+    // the FRONT a prefill-sized MUL_MAT_ID left in the workspace (ggml_cdna4_mul_mat_id_front_key: sorted ids, tile records, spans, quantized activations): the next MUL_MAT_ID of
+    // the same (b, ids) and shape — the gate stack behind the up stack of a mixture-of-experts layer — multiplies it again.  Same life as act_image.
+    struct { uint32_t key = 0; uint64_t uses = 0; const void * b = nullptr, * ids = nullptr; size_t b_bytes = 0, ids_bytes = 0; int type = 0;
+             int64_t b_row = 0, b_tok = 0, ids_tok = 0, M = 0, K = 0, n_expert = 0, n_used = 0, n_b = 0, n_tok = 0; } moe_front;
+    int n_moe_front_shared = 0;                               // MUL_MAT_IDs that multiplied the previous one's front (statistics; "ggml_backend_cdna4_moe_front_shared_count")
     int n_grouped = 0;                                        // one-row MUL_MATs that rode in another one's launch (statistics; "ggml_backend_cdna4_grouped_count")
     void * need_ws(size_t n) {
         ws_uses++;

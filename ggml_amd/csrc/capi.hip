@@ -537,10 +537,59 @@ int ggml_cdna4_mul_mat_prepared_fused(int type, const void *W, int64_t w_row_byt
     return cdna4_launch_epilogue(Y, y_row_stride, M, B, e, (hipStream_t)stream);
 }
 
+// the work-queue form's choice for a call (shared by the call, its `prepared` twin and the key): Q4_K experts, or Q4_0 experts whose stack has a resident Q4_0R image
+struct moe_sk_pick { int type = -1; const uint8_t *W = nullptr; int64_t row = 0, exp = 0; };
+static moe_sk_pick moe_sk_pick_of(int type, const void *as, int64_t w_row_bytes, int64_t w_expert_bytes, int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok) {
+    moe_sk_pick r; r.W = (const uint8_t *)as; r.row = w_row_bytes; r.exp = w_expert_bytes;
+    if (type == CDNA4_Q4_K && !(((uintptr_t)as | (uintptr_t)w_row_bytes | (uintptr_t)w_expert_bytes) & 15)) r.type = CDNA4_Q4_K;
+    else if (type == CDNA4_Q4_0 && K % 256 == 0 && w_expert_bytes == M * w_row_bytes) {
+        const uint8_t *img = cdna4_resident_lookup(CDNA4_Q4_0, as, w_row_bytes, M * n_expert, K);
+        if (img && !((uintptr_t)img & 15)) { r.type = CDNA4_Q4_0R; r.W = img; r.row = (K / 256) * 144; r.exp = M * r.row; }
+    }
+    // (CDNA4_MMQ_IDS=2 — a coverage / measurement knob — asks for the int8 matrix-core kernels where there are few rows per expert)
+    static const bool mmq_ids_forced = getenv("CDNA4_MMQ_IDS") && atoi(getenv("CDNA4_MMQ_IDS")) == 2;
+    if (mmq_ids_forced && n_tok * n_used <= 32 * n_expert) r.type = -1;
+    if (r.type >= 0 && !moe_sk_on(r.type, M, K, n_expert, n_used, n_b, n_tok)) r.type = -1;
+    return r;
+}
+static bool moe_grouped_call(int type, const void *as, int64_t w_row_bytes, int64_t w_expert_bytes, const float *b, int64_t b_row_stride, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_tok, const void *workspace) {
+    return cdna4_gemm_ids_supported(type, K) && n_tok * n_used > 32 && n_expert <= 1024 && workspace && !((uintptr_t)workspace & 255) &&
+           !(((uintptr_t)as | (uintptr_t)w_row_bytes | (uintptr_t)w_expert_bytes) & 1) && !(((uintptr_t)b | (uintptr_t)(b_row_stride * 4)) & 15);
+}
+static int mul_mat_id_impl(bool front_in_place, int type, const void *as, int64_t w_row_bytes, int64_t w_expert_bytes, const float *b, int64_t b_row_stride, int64_t b_tok_stride,
+                           const int32_t *ids, int64_t ids_tok_stride, float *dst, int64_t dst_row_stride, int64_t dst_tok_stride,
+                           int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok,
+                           void *workspace, size_t workspace_bytes, void *stream);
 int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t w_expert_bytes, const float *b, int64_t b_row_stride, int64_t b_tok_stride,
                           const int32_t *ids, int64_t ids_tok_stride, float *dst, int64_t dst_row_stride, int64_t dst_tok_stride,
                           int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok,
                           void *workspace, size_t workspace_bytes, void *stream) {
+    return mul_mat_id_impl(false, type, as, w_row_bytes, w_expert_bytes, b, b_row_stride, b_tok_stride, ids, ids_tok_stride, dst, dst_row_stride, dst_tok_stride, M, K, n_expert, n_used, n_b, n_tok,
+                           workspace, workspace_bytes, stream);
+}
+// MUL_MAT_IDs of ONE (b, ids) — a mixture-of-experts layer's w_up and w_gate stacks (llama.cpp build_moe_ffn) — share everything the first launch of the work-queue form makes:
+// the sorted ids, the tile records, the spans, the quantized activations.  Non-zero: a ggml_cdna4_mul_mat_id of this call leaves that FRONT in its workspace, and
+// ggml_cdna4_mul_mat_id_prepared with other expert weights of the same type / M / K, the same b, ids, strides and counts, on the untouched workspace multiplies it again
+// (ONE launch instead of two, bit-identical to the full call).
+uint32_t ggml_cdna4_mul_mat_id_front_key(int type, const void *as, int64_t w_row_bytes, int64_t w_expert_bytes, int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok, size_t workspace_bytes) {
+    if (!is_q(type) || M <= 0 || K <= 0 || n_tok <= 0 || n_used <= 0 || n_b <= 0 || n_used % n_b || ggml_cdna4_row_size(type, K) == 0) return 0;
+    if (!(cdna4_gemm_ids_supported(type, K) && n_tok * n_used > 32 && n_expert <= 1024) || (((uintptr_t)as | (uintptr_t)w_row_bytes | (uintptr_t)w_expert_bytes) & 1)) return 0;
+    const moe_sk_pick pk = moe_sk_pick_of(type, as, w_row_bytes, w_expert_bytes, M, K, n_expert, n_used, n_b, n_tok);
+    if (pk.type < 0 || workspace_bytes < moe_sk_carve(K, n_expert, n_used, n_b, n_tok, nullptr).total) return 0;
+    return 0x4D510000u | (pk.type == CDNA4_Q4_K ? 1u : 2u);            // (the image's activation class; the rest of what the front depends on is what the caller compares)
+}
+int ggml_cdna4_mul_mat_id_prepared(int type, const void *as, int64_t w_row_bytes, int64_t w_expert_bytes, const float *b, int64_t b_row_stride, int64_t b_tok_stride,
+                                   const int32_t *ids, int64_t ids_tok_stride, float *dst, int64_t dst_row_stride, int64_t dst_tok_stride,
+                                   int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    if (!ggml_cdna4_mul_mat_id_front_key(type, as, w_row_bytes, w_expert_bytes, M, K, n_expert, n_used, n_b, n_tok, workspace_bytes)) { cdna4_set_error_msg("mul_mat_id_prepared: a call of this shape leaves no front (ggml_cdna4_mul_mat_id_front_key == 0)"); return -2; }
+    return mul_mat_id_impl(true, type, as, w_row_bytes, w_expert_bytes, b, b_row_stride, b_tok_stride, ids, ids_tok_stride, dst, dst_row_stride, dst_tok_stride, M, K, n_expert, n_used, n_b, n_tok,
+                           workspace, workspace_bytes, stream);
+}
+static int mul_mat_id_impl(bool front_in_place, int type, const void *as, int64_t w_row_bytes, int64_t w_expert_bytes, const float *b, int64_t b_row_stride, int64_t b_tok_stride,
+                           const int32_t *ids, int64_t ids_tok_stride, float *dst, int64_t dst_row_stride, int64_t dst_tok_stride,
+                           int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok,
+                           void *workspace, size_t workspace_bytes, void *stream) {
     if (const int frc = fault_status()) return frc;
     if (!is_q(type)) return cdna4_set_error_msg("mul_mat_id: unsupported weight type");
     if (M <= 0 || n_tok <= 0 || n_used <= 0) return 0;
@@ -552,21 +601,14 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
     // prefill-sized mixture-of-experts batches: group the (token, slot) rows by expert on the device and run ONE MFMA GEMM launch over
     // the (expert, activation tile) table — every expert's weights are read once per m-tile instead of once per column
     // (ggml_compute_forward_mul_mat_id groups the same way on the host: ggml-cpu.c:7648-7781)
-    if (cdna4_gemm_ids_supported(type, K) && n_tok * n_used > 32 && n_expert <= 1024 && workspace && !((uintptr_t)workspace & 255) &&
-        !(((uintptr_t)as | (uintptr_t)w_row_bytes | (uintptr_t)w_expert_bytes) & 1) && !(((uintptr_t)b | (uintptr_t)(b_row_stride * 4)) & 15)) {
+    if (front_in_place && !moe_grouped_call(type, as, w_row_bytes, w_expert_bytes, b, b_row_stride, K, n_expert, n_used, n_tok, workspace)) { cdna4_set_error_msg("mul_mat_id_prepared: misaligned operands"); return -2; }
+    if (moe_grouped_call(type, as, w_row_bytes, w_expert_bytes, b, b_row_stride, K, n_expert, n_used, n_tok, workspace)) {
         // Q4_K experts, and Q4_0 experts whose stack has a RESIDENT Q4_0R image (ggml's 3-D expert tensor, rows back to back; found by the stack's pointer): the stream-k form —
         // TWO launches (planner + token-order quantizer; one persistent grouped GEMM that gathers its rows), round 6
         {
-            int sk_type = -1; const uint8_t *skW = (const uint8_t *)as; int64_t sk_row = w_row_bytes, sk_exp = w_expert_bytes;
-            if (type == CDNA4_Q4_K && !(((uintptr_t)as | (uintptr_t)w_row_bytes | (uintptr_t)w_expert_bytes) & 15)) sk_type = CDNA4_Q4_K;
-            else if (type == CDNA4_Q4_0 && K % 256 == 0 && w_expert_bytes == M * w_row_bytes) {
-                const uint8_t *img = cdna4_resident_lookup(CDNA4_Q4_0, as, w_row_bytes, M * n_expert, K);
-                if (img && !((uintptr_t)img & 15)) { sk_type = CDNA4_Q4_0R; skW = img; sk_row = (K / 256) * 144; sk_exp = M * sk_row; }
-            }
-            // (CDNA4_MMQ_IDS=2 — a coverage / measurement knob — asks for the int8 matrix-core kernels below where there are few rows per expert)
-            static const bool mmq_ids_forced = getenv("CDNA4_MMQ_IDS") && atoi(getenv("CDNA4_MMQ_IDS")) == 2;
-            if (mmq_ids_forced && n_tok * n_used <= 32 * n_expert) sk_type = -1;
-            if (sk_type >= 0 && moe_sk_on(sk_type, M, K, n_expert, n_used, n_b, n_tok)) {
+            const moe_sk_pick pk = moe_sk_pick_of(type, as, w_row_bytes, w_expert_bytes, M, K, n_expert, n_used, n_b, n_tok);
+            const int sk_type = pk.type; const uint8_t *skW = pk.W; const int64_t sk_row = pk.row, sk_exp = pk.exp;
+            if (sk_type >= 0) {
                 const moe_sk_view sv = moe_sk_carve(K, n_expert, n_used, n_b, n_tok, workspace);
                 if (workspace_bytes >= sv.total) {
                     // cost of one (tile, m-tile, superblock) unit by the tile's fragments in use (1 .. 4), relative.  FLAT, by measurement: the k loop is bound by its unpack /
@@ -579,8 +621,9 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
                     const int *cw = costs.c;
                     const int G = cdna4_gemm_sk_spans();
                     const int64_t upt = ((M + 127) / 128) * (K / 256);
-                    int rc = cdna4_launch_moe_sk_front(ids, ids_tok_stride, (int)n_tok, (int)n_used, (int)n_b, (int)n_expert, (int)sv.ntile_cap, (int)upt, G, cw, sv.tile_rec, sv.wg_begin,
-                                                       b, b_row_stride, K, sk_type == CDNA4_Q4_K, sv.xh, (hipStream_t)stream);
+                    // (prepared: the front of an earlier call with the same b, ids and shape is in place)
+                    int rc = front_in_place ? 0 : cdna4_launch_moe_sk_front(ids, ids_tok_stride, (int)n_tok, (int)n_used, (int)n_b, (int)n_expert, (int)sv.ntile_cap, (int)upt, G, cw, sv.tile_rec, sv.wg_begin,
+                                                                            b, b_row_stride, K, sk_type == CDNA4_Q4_K, sv.xh, (hipStream_t)stream);
                     if (rc) return rc;
                     cdna4_gemm_args a{};
                     a.type = sk_type; a.W = skW; a.w_row_bytes = sk_row; a.xh = sv.xh; a.xh_row_elems = K;
@@ -589,6 +632,7 @@ int ggml_cdna4_mul_mat_id(int type, const void *as, int64_t w_row_bytes, int64_t
                 }
             }
         }
+        if (front_in_place) { cdna4_set_error_msg("mul_mat_id_prepared: this call does not take the work-queue form"); return -2; }
         const moe_view mv = moe_carve(K, n_expert, n_used, n_tok, workspace);
         if (workspace_bytes >= mv.total && mv.img_rows * K * 2 < ((int64_t)1 << 31)) {
             int rc = cdna4_launch_moe_plan(ids, ids_tok_stride, (int)n_tok, (int)n_used, (int)n_b, (int)n_expert, (int)mv.img_rows, mv.img_src, mv.img_dst, mv.tile_expert, (hipStream_t)stream);

@@ -37,6 +37,9 @@ SYMBOLS = [
     ("ggml_cdna4_mul_mat_id_workspace_size", _sz, [_int, _i64, _i64, _i64, _i64, _i64]),
     ("ggml_cdna4_mul_mat_id", _int, [_int, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64,
                                      _i64, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
+    ("ggml_cdna4_mul_mat_id_front_key", C.c_uint32, [_int, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _sz]),
+    ("ggml_cdna4_mul_mat_id_prepared", _int, [_int, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64,
+                                              _i64, _i64, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
     ("ggml_cdna4_quantize_q8_K", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     ("ggml_cdna4_quantize_q8_0", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp]),
     ("ggml_cdna4_quantize_q8_1", _int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

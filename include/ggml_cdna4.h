@@ -149,6 +149,20 @@ int ggml_cdna4_mul_mat_id(int type, const void * as, int64_t w_row_bytes, int64_
                           int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok,
                           void * workspace, size_t workspace_bytes, void * stream);
 
+/* MUL_MAT_IDs of ONE (b, ids): the up- and gate-projection expert stacks of a mixture-of-experts layer multiply the same activations routed by the same ids (the reference
+ * evaluates them as two independent nodes, each sorting and quantizing again: ggml-cpu.c:7609-7784).  ggml_cdna4_mul_mat_id_front_key != 0: a ggml_cdna4_mul_mat_id of this call
+ * takes the work-queue form and leaves its FRONT — sorted ids, tile records, spans, quantized activations — in the workspace; ggml_cdna4_mul_mat_id_prepared (same arguments,
+ * other expert weights of the same type / M / K; same b, ids, strides and counts; nothing written to b, ids or the workspace in between) multiplies that front again: ONE launch
+ * instead of two, bit-identical to the full call.  Returns -2 (nothing launched) where the call has no such form. */
+uint32_t ggml_cdna4_mul_mat_id_front_key(int type, const void * as, int64_t w_row_bytes, int64_t w_expert_bytes, int64_t M, int64_t K,
+                                         int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok, size_t workspace_bytes);
+int ggml_cdna4_mul_mat_id_prepared(int type, const void * as, int64_t w_row_bytes, int64_t w_expert_bytes,
+                                   const float * b, int64_t b_row_stride, int64_t b_tok_stride,
+                                   const int32_t * ids, int64_t ids_tok_stride,
+                                   float * dst, int64_t dst_row_stride, int64_t dst_tok_stride,
+                                   int64_t M, int64_t K, int64_t n_expert, int64_t n_used, int64_t n_b, int64_t n_tok,
+                                   void * workspace, size_t workspace_bytes, void * stream);
+
 /* MUL_MAT with its element-wise tail: Y[b][m] = (((W.X)[b][m] + bias[m]) -> GELU if act == 1) + residual[b][m]; bias / residual may be NULL.
  * What the gpt-2 graphs do in three nodes after every projection — MUL_MAT, ADD(bias), then GELU or ADD(residual)
  * (/root/reference/examples/gpt-2/main-backend.cpp:515-521, 595-600, 656-666, 690-698).  Each step is the same separate fp32 operation the

@@ -8,7 +8,7 @@
 //   replay   a transformer MLP block (NORM, MUL, ADD, MUL_MAT, ADD, GELU, MUL_MAT, ADD, ADD) computed again and again with changing inputs:
 //            the plug-in replays the unchanged graph from a HIP graph (stderr under GGML_CDNA4_STATS: captures / replays); every result
 //            against the CPU backend, and input A eager == input A replayed, bit for bit
-//   split_harness <plugin.so> <type: q4_K|q4_0|q8_0|q5_K|q6_K|f16> <M> <K> <B> [resident | hostptr | shared | moe]     -> one JSON line
+//   split_harness <plugin.so> <type: q4_K|q4_0|q8_0|q5_K|q6_K|f16> <M> <K> <B> [resident | hostptr | shared | moe | moeffn]     -> one JSON line
 //   shared   MUL_MATs that read the same src1 (wq / wk / wv; w_gate / w_up) take ONE activation quantization: hand-off count, output bytes' hash, time per graph
 //   resident weights in the extra buffer type CDNA4_Resident (kernel-native images of the re-encoded formats, built once): types q5_0 q3_K q2_K q4_1 q5_1 iq4_nl iq4_xs, and q4_0 (a 16-byte-aligned re-layout for Q4_K's kernels)
 #include "ggml.h"
@@ -286,6 +286,77 @@ int main(int argc, char ** argv) {
                "\"resident_bit_identical_to_default\":%s,\"one_token_vs_cpu_rel_l2\":%.3e,\"one_token_bit_identical_to_default\":%s}\n", ggml_type_name(type), (long long)M, (long long)K, (long long)B,
                ggml_backend_buft_name(rbuft), rel_l2(y_res, y_cpu), rel_l2(y_def, y_cpu), rel_l2(y_res, y_def), memcmp(y_res.data(), y_def.data(), y_def.size() * 4) == 0 ? "true" : "false",
                rel_l2(y_res1, y_cpu1), memcmp(y_res1.data(), y_def1.data(), y_def1.size() * 4) == 0 ? "true" : "false");
+        ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
+        return 0;
+    }
+
+    // ---- moeffn (argv[6] == "moeffn": only this section; M = model width D, K = expert FFN width H, B = tokens): a mixture-of-experts FFN as llama.cpp's build_moe_ffn issues it —
+    //      up = mul_mat_id(UP, cur, ids), gate = mul_mat_id(GATE, cur, ids), down = mul_mat_id(DOWN, up * silu(gate), ids); 8 experts, 2 used.  The up and gate stacks read the
+    //      same (cur, ids): the second multiplies the first one's front (proc address ggml_backend_cdna4_moe_front_shared_count); GGML_CDNA4_NO_ACT_SHARE=1 for the A/B twin.
+    if (argc > 6 && std::string(argv[6]) == "moeffn") {
+        const int64_t D = M, H = K, NE = 8, NU = 2, NT = B;
+        std::vector<std::vector<uint8_t>> stacks;
+        for (int i = 0; i < 3; i++) {
+            const int64_t rows = (i < 2 ? H : D) * NE, cols = i < 2 ? D : H;
+            std::vector<float> wf3((size_t)rows * cols);
+            for (auto & v : wf3) v = u(rng);
+            std::vector<uint8_t> q(ggml_row_size(type, cols) * rows);
+            ggml_quantize_chunk(type, wf3.data(), q.data(), 0, rows, cols, NULL);
+            stacks.push_back(q);
+        }
+        int shared = -1;
+        auto run = [&](ggml_backend_t be, double * us_per_graph) {
+            ggml_init_params ip = { ggml_tensor_overhead() * 32 + ggml_graph_overhead(), NULL, true };
+            ggml_context * wctx = ggml_init(ip), * cctx = ggml_init(ip);
+            ggml_tensor * UP = ggml_new_tensor_3d(wctx, type, D, H, NE), * GATE = ggml_new_tensor_3d(wctx, type, D, H, NE), * DOWN = ggml_new_tensor_3d(wctx, type, H, D, NE);
+            ggml_backend_buffer_t wbuf = ggml_backend_alloc_ctx_tensors(wctx, be);
+            if (!wbuf) { fprintf(stderr, "weight buffer allocation failed\n"); exit(1); }
+            ggml_backend_buffer_set_usage(wbuf, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
+            ggml_backend_tensor_set(UP, stacks[0].data(), 0, stacks[0].size()); ggml_backend_tensor_set(GATE, stacks[1].data(), 0, stacks[1].size()); ggml_backend_tensor_set(DOWN, stacks[2].data(), 0, stacks[2].size());
+            ggml_tensor * CUR = ggml_new_tensor_3d(cctx, GGML_TYPE_F32, D, 1, NT);
+            ggml_tensor * IDS = ggml_new_tensor_2d(cctx, GGML_TYPE_I32, NU, NT);
+            ggml_set_input(CUR); ggml_set_input(IDS);
+            ggml_tensor * up = ggml_mul_mat_id(cctx, UP, CUR, IDS), * gate = ggml_mul_mat_id(cctx, GATE, CUR, IDS);
+            ggml_tensor * out = ggml_mul_mat_id(cctx, DOWN, ggml_mul(cctx, up, ggml_silu(cctx, gate)), IDS);
+            ggml_set_output(out);
+            ggml_cgraph * gf = ggml_new_graph(cctx);
+            ggml_build_forward_expand(gf, out);
+            ggml_gallocr_t ga = ggml_gallocr_new(ggml_backend_get_default_buffer_type(be));
+            if (!ggml_gallocr_alloc_graph(ga, gf)) { fprintf(stderr, "graph allocation failed\n"); exit(1); }
+            std::vector<float> xb((size_t)D * NT);
+            std::mt19937 r3(7);
+            for (auto & v : xb) v = u(r3);
+            std::vector<int32_t> ids((size_t)NU * NT);
+            for (int64_t t = 0; t < NT; t++) { const int e0 = (int)(r3() % NE); ids[t * NU] = e0; ids[t * NU + 1] = (e0 + 1 + (int)(r3() % (NE - 1))) % (int)NE; }
+            typedef int (*count_fn)(void);
+            count_fn cnt = be == gpu ? (count_fn)ggml_backend_reg_get_proc_address(reg, "ggml_backend_cdna4_moe_front_shared_count") : nullptr;
+            const int c0 = cnt ? cnt() : 0;
+            ggml_backend_tensor_set(CUR, xb.data(), 0, xb.size() * 4); ggml_backend_tensor_set(IDS, ids.data(), 0, ids.size() * 4);
+            if (ggml_backend_graph_compute(be, gf) != GGML_STATUS_SUCCESS) { fprintf(stderr, "graph_compute failed\n"); exit(1); }
+            ggml_backend_synchronize(be);
+            if (be == gpu) shared = cnt ? cnt() - c0 : -1;
+            std::vector<float> y((size_t)ggml_nelements(out));
+            ggml_backend_tensor_get(out, y.data(), 0, y.size() * 4);
+            if (us_per_graph && !getenv("HARNESS_NO_TIMING")) {
+                for (int i = 0; i < 5; i++) { ggml_backend_tensor_set(CUR, xb.data(), 0, xb.size() * 4); ggml_backend_graph_compute(be, gf); }
+                ggml_backend_synchronize(be);
+                const int n = 50;
+                const int64_t t0 = ggml_time_us();
+                for (int i = 0; i < n; i++) ggml_backend_graph_compute(be, gf);
+                ggml_backend_synchronize(be);
+                *us_per_graph = (double)(ggml_time_us() - t0) / n;
+            }
+            ggml_gallocr_free(ga); ggml_backend_buffer_free(wbuf); ggml_free(wctx); ggml_free(cctx);
+            return y;
+        };
+        ggml_time_init();
+        double us = 0;
+        const std::vector<float> y_gpu = run(gpu, &us);
+        const std::vector<float> y_cpu = getenv("HARNESS_NO_CPU") ? y_gpu : run(cpu, nullptr);
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < y_gpu.size() * 4; i++) { h ^= ((const uint8_t *)y_gpu.data())[i]; h *= 1099511628211ull; }
+        printf("{\"type\":\"%s\",\"D\":%lld,\"H\":%lld,\"tokens\":%lld,\"n_expert\":8,\"n_used\":2,\"moe_fronts_shared_first_compute\":%d,\"fnv1a\":\"%016llx\",\"us_per_graph\":%.2f,\"out_vs_cpu\":%.3e}\n",
+               ggml_type_name(type), (long long)D, (long long)H, (long long)NT, shared, (unsigned long long)h, us, rel_l2(y_gpu, y_cpu));
         ggml_backend_free(gpu); ggml_backend_free(gpu2); ggml_backend_free(cpu);
         return 0;
     }

@@ -186,3 +186,30 @@ def test_the_layer_front_in_reference_order_is_the_cpu_backends_bits(type_, d, h
     j = _harness(type_, d, h, b, True, exact=True)
     assert j["act_hand_offs_first_compute"] == 0 and j["grouped_first_compute"] == 0, j          # (the mode runs node by node)
     assert j["words_differing_from_cpu"] == 0 and j["out_vs_cpu"] == 0.0, j
+
+
+def _moeffn(type_, d, h, tokens, share):
+    if not os.path.exists(EXE):
+        pytest.fail("prebuilt oracle/_ref/split_harness missing from the snapshot")
+    e = dict(os.environ)
+    e.pop("GGML_CDNA4_NO_ACT_SHARE", None)
+    if not share:
+        e["GGML_CDNA4_NO_ACT_SHARE"] = "1"
+    r = subprocess.run([EXE, PLUGIN, type_, str(d), str(h), str(tokens), "moeffn"], capture_output=True, text=True, timeout=900, env=e)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    j["share"] = share
+    os.makedirs(os.path.join(R.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(R.ROOT, "gpurun_out", "split_report.jsonl"), "a") as f:
+        f.write(json.dumps(j) + "\n")
+    return j
+
+
+@pytest.mark.parametrize("type_,d,h,tokens", [("q4_K", 2048, 1536, 512), ("q4_K", 1024, 2048, 100)])
+def test_moe_ffn_gate_stack_multiplies_the_up_stacks_front(type_, d, h, tokens):
+    """a mixture-of-experts FFN through ggml's public API (8 experts, 2 used; up, gate = MUL_MAT_ID of the same (cur, ids); down behind silu(gate) * up): the second stack takes the
+    first one's front — one launch instead of two —, THE GATE being byte equality with the sharing off; the distance to the CPU backend (two grouped fp16 products and a
+    re-quantization deep) is reported"""
+    on, off = _moeffn(type_, d, h, tokens, True), _moeffn(type_, d, h, tokens, False)
+    assert on["moe_fronts_shared_first_compute"] == 1 and off["moe_fronts_shared_first_compute"] == 0, (on, off)
+    assert on["fnv1a"] == off["fnv1a"], (on, off)

@@ -310,12 +310,17 @@ def test_buffer_from_host_ptr_through_ggmls_public_api(type_, m, k, b):
     host's address declines (NULL) and the harness reports it: then only the report is checked."""
     if not os.path.exists(EXE):
         pytest.fail("prebuilt oracle/_ref/split_harness missing from the snapshot")
-    r = subprocess.run([EXE, PLUGIN, type_, str(m), str(k), str(b), "hostptr"], capture_output=True, text=True, timeout=600)
+    # (round 6: the capability is opt-in — weights read over PCIe on every launch are not something a loader should pick by default — GGML_CDNA4_HOST_PTR_BUFFERS=1)
+    r = subprocess.run([EXE, PLUGIN, type_, str(m), str(k), str(b), "hostptr"], capture_output=True, text=True, timeout=600, env=dict(os.environ, GGML_CDNA4_HOST_PTR_BUFFERS="1"))
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     j = json.loads(r.stdout.strip().splitlines()[-1])
     with open(os.path.join(R.ROOT, "gpurun_out", "split_report.jsonl"), "a") as f:
         f.write(json.dumps(j) + "\n")
     assert j["caps_buffer_from_host_ptr"] is True
+    if type_ == "q8_0":                                                 # without the opt-in the device does not advertise it
+        r0 = subprocess.run([EXE, PLUGIN, type_, str(m), str(k), str(b), "hostptr"], capture_output=True, text=True, timeout=600, env={k_: v for k_, v in os.environ.items() if k_ != "GGML_CDNA4_HOST_PTR_BUFFERS"})
+        j0 = json.loads(r0.stdout.strip().splitlines()[-1]) if r0.returncode == 0 and r0.stdout.strip() else {}
+        assert j0.get("caps_buffer_from_host_ptr", False) is False, (r0.returncode, r0.stdout[-500:], r0.stderr[-500:])
     if j["declined"]:
         pytest.skip("the device does not map registered host memory at the host's address: buffer_from_host_ptr declines (the caller keeps device buffers)")
     assert j["tensor_in_host_range"] is True and j["get_roundtrip"] is True and j["bit_identical_to_default"] is True, j

@@ -61,6 +61,8 @@ SELECTION_R3.append(("test_gpu_act_share.py", "(test_second_product and 16) or t
 # round 6: several one-row products of one activation row in ONE launch (ggml_cdna4_mul_mat_group / k_gemv_q_fused_grp) equal the single calls bit for bit, four ragged matrices
 # with and without bias, Q4_K / Q4_0 / Q6_K; what has no grouped form is refused with -2
 SELECTION_R3.append(("test_gpu_group.py", "(ms2 and (12 or 2 or 14)) or refuses", 6))
+# ... and the second MUL_MAT_ID of one (b, ids) on the first one's front (ggml_cdna4_mul_mat_id_prepared): bit-identical to the full call; other routes leave no front
+SELECTION_R3.append(("test_gpu_moe_front.py", "4-2-True-96 or 8-2-False-40 or other_routes", 3))
 
 
 def _merged(selections):

@@ -58,6 +58,19 @@ def test_layer_front_in_reference_order_is_the_cpu_backends_bits_on_the_emulated
     assert j["words_differing_from_cpu"] == 0 and j["out_vs_cpu"] == 0.0, j
 
 
+def test_moe_ffn_second_stack_multiplies_the_first_ones_front_on_the_emulated_plugin(plug):
+    """round 6: a mixture-of-experts FFN as llama.cpp's build_moe_ffn issues it (oracle/split_harness.cpp `moeffn`: up and gate = MUL_MAT_ID of the same (cur, ids), down behind
+    silu(gate) * up): the gate stack multiplies the front the up stack's call left in the workspace — sorted ids, tile records, spans, quantized activations; one launch instead of
+    two — and every output byte equals the run with the sharing off; the down stack (other activations) makes its own front"""
+    on = plug.harness(["q4_K", 256, 512, 96, "moeffn"], env={"HARNESS_NO_TIMING": 1})
+    off = plug.harness(["q4_K", 256, 512, 96, "moeffn"], env={"HARNESS_NO_TIMING": 1, "GGML_CDNA4_NO_ACT_SHARE": 1})
+    if on is None or off is None:
+        pytest.skip("the environment cannot host the emulation")
+    assert on["moe_fronts_shared_first_compute"] == 1 and off["moe_fronts_shared_first_compute"] == 0, (on, off)
+    assert on["fnv1a"] == off["fnv1a"], (on, off)
+    assert on["out_vs_cpu"] < 2e-2, on                                    # (sanity only: two grouped fp16 GEMMs and a re-quantization deep)
+
+
 @pytest.mark.parametrize("type_", ["q4_K", "q4_0"])
 def test_one_row_products_of_one_src1_run_as_one_launch_on_the_emulated_plugin(plug, type_):
     """round 6: at ONE activation row the layer front's products of `cur` (Wk, Wv + its bias, Wq + the residual row, which at one row is a bias) and of `f`
