@@ -781,6 +781,9 @@ def main():
         if args.leg == "resident_images":                                # (sessions short of GPU time measure this leg alone)
             print(json.dumps({"resident_images": resident_image_rows(dev, max(50, min(args.steps, 200)))}), flush=True)
             return
+        if args.leg == "mul_mat_id":
+            print(json.dumps({"mul_mat_id": moe_row(dev, max(50, min(args.steps, 200)))}), flush=True)
+            return
         fn = {"widening": lambda: widening_rows(dev, max(50, min(args.steps, 200)))}[args.leg]
         fn()                                                             # prints its rows itself (leg_row)
         return
