@@ -114,6 +114,69 @@ def test_owned_mode_beside_a_tenant_is_correct_or_an_error_status_never_silent_n
         assert rec["rc_third_call"] == 0 and rec["third_call_rel_l2_vs_alone"] is not None and rec["third_call_rel_l2_vs_alone"] < 2e-6, rec
 
 
+CODE_MORE = r"""
+import ctypes as C, json, sys, time, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import refutil as R
+from ggml_amd import native, ops
+L = native.lib()
+st = torch.cuda.current_stream().cuda_stream
+rng = np.random.default_rng(5)
+def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+cases = {}
+# (a) prefill-sized MUL_MAT_ID on the work queue: persistent work-groups, partial tiles summed by the last arriver
+ne, nu, nt, m, k = 8, 2, 512, 1024, 1024
+rb = R.row_size(R.Q4_K, k)
+we = dev(R.random_weights(R.Q4_K, ne * m, k, seed=3)); xe = dev(rng.standard_normal((nt, nu, k)).astype(np.float32))
+ids = dev(np.stack([rng.permutation(ne)[:nu] for _ in range(nt)]).astype(np.int32))
+wse = torch.empty(L.ggml_cdna4_mul_mat_id_workspace_size(int(R.Q4_K), k, ne, nu, nu, nt), dtype=torch.uint8, device="cuda")
+def moe(y):
+    return L.ggml_cdna4_mul_mat_id(int(R.Q4_K), we.data_ptr(), rb, m * rb, xe.data_ptr(), k, nu * k, ids.data_ptr(), nu, y.data_ptr(), m, nu * m, m, k, ne, nu, nu, nt, wse.data_ptr(), wse.numel(), st)
+cases["mul_mat_id_work_queue"] = (moe, (nt, nu, m))
+# (b) a grid far below the chip: 32 tiles, K split four / eight ways, summed by the last arriver
+def mk(t, m_, k_, b_, seed):
+    a = ops.QTensor.from_host_bytes(t, k_, m_, R.random_weights(t, m_, k_, seed=seed), device="cuda:0")
+    x = dev(rng.uniform(-1, 1, (b_, k_)).astype(np.float32))
+    ws = torch.empty(L.ggml_cdna4_mul_mat_workspace_size(int(t), k_, b_), dtype=torch.uint8, device="cuda")
+    def f(y): return L.ggml_cdna4_mul_mat(int(t), a.data.data_ptr(), a.row_bytes, x.data_ptr(), k_, y.data_ptr(), m_, m_, k_, b_, ws.data_ptr(), ws.numel(), 0, 0, 0, st)
+    return f, (b_, m_), (a, x, ws)
+keep = []
+for name, t, m_, k_, b_ in (("deep_split_q4_K_4096x8192x96", R.Q4_K, 4096, 8192, 96), ("split_in_two_q4_K_4096x11008x512", R.Q4_K, 4096, 11008, 512), ("q8_0_8192x4096x512", R.Q8_0, 8192, 4096, 512)):
+    f, shp, k3 = mk(t, m_, k_, b_, 7); keep.append(k3); cases[name] = (f, shp)
+alone = {}
+for name, (f, shp) in cases.items():
+    y = torch.full(shp, 7.0, dtype=torch.float32, device="cuda"); assert f(y) == 0, L.ggml_cdna4_last_error(); torch.cuda.synchronize(); alone[name] = y.cpu().numpy()
+release = torch.zeros(16, dtype=torch.int32).pin_memory(); side = torch.cuda.Stream()
+ncu = torch.cuda.get_device_properties(0).multi_processor_count
+native.check(L.ggml_cdna4_debug_occupy(ncu // 2, 100, release.data_ptr(), 20000, side.cuda_stream))
+time.sleep(0.05)
+out = {}
+for name, (f, shp) in cases.items():
+    y = torch.full(shp, 7.0, dtype=torch.float32, device="cuda")
+    t0 = time.time(); rc = f(y); ev = torch.cuda.Event(); ev.record()
+    while not ev.query() and time.time() - t0 < 5.0: time.sleep(0.005)
+    done = bool(ev.query())
+    out[name] = {"rc": rc, "finished_while_tenant_held_cus": done, "bit_identical_to_alone": bool(done and np.array_equal(y.cpu().numpy().view(np.uint32), alone[name].view(np.uint32)))}
+release[0] = 1
+torch.cuda.synchronize()
+out["fault"] = L.ggml_cdna4_device_fault(0)
+print(json.dumps(out))
+""" % (R.ROOT, os.path.join(R.ROOT, "tests"))
+
+
+def test_default_mode_every_split_and_the_work_queue_finish_beside_a_tenant(gu):
+    """nothing the default mode launches waits for a co-resident work-group: with a tenant on half the CUs the work-queue MUL_MAT_ID (persistent work-groups, parked partial tiles),
+    a four- / eight-way K split, the split in two of C3 and a Q8_0 prefill all finish WHILE the tenant is there, bit-identical to the run alone on the device, no fault"""
+    env = {k: v for k, v in os.environ.items() if k not in ("GGML_CDNA4_OWNED_DEVICE", "GGML_CDNA4_SHARED_DEVICE")}
+    r = subprocess.run([sys.executable, "-c", CODE_MORE], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    gu.report(test="shared_device_default_with_tenant_more_routes", **rec)
+    assert rec.pop("fault") == 0
+    for name, v in rec.items():
+        assert v["rc"] == 0 and v["finished_while_tenant_held_cus"] and v["bit_identical_to_alone"], (name, v)
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(R.REF_DIR, "test-backend-ops")), reason="oracle/_ref not built")
 def test_stock_mul_mat_sweep_in_the_default_mode(gu):
     """the unmodified reference harness on the plug-in WITHOUT GGML_CDNA4_OWNED_DEVICE: what an ordinary ggml application gets"""
