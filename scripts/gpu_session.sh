@@ -1,7 +1,10 @@
 #!/bin/bash
-# a short session (rewritten per use; the numbers it produced are under profiles/rNN/): here — the default mode beside a tenant, more routes
+# a short session (rewritten per use): here — per-stage stamps of k_gemm_kq_t64's 128-row tile at C3 and at 8192 x 4096 x 512 (measurement build)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-export TMPDIR=/tmp PYTHONUNBUFFERED=1 GGML_CDNA4_OWNED_DEVICE=1
+export TMPDIR=/tmp GGML_CDNA4_OWNED_DEVICE=1
 O=$PWD/gpurun_out/session; mkdir -p $O; rm -rf $O/*
-timeout 900 python -m pytest tests/test_gpu_shared_device.py -q -m gpu -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$? $(tail -1 $O/pytest.log)" >> $O/summary.txt
-cat $O/summary.txt; grep -i "failed\|error\|assert" $O/pytest.log | head; grep "more_routes" gpurun_out/parity_report.jsonl | tail -1 | cut -c1-900
+cd tools/microbench
+for shape in "4096 11008 512" "8192 8192 512"; do
+  GB_VARIANTS="24583" GB_SPLITKS="2" GB_ROUNDS=3 GB_TRACE_REPS=30 GB_TRACE_SPLITK=2 timeout 200 ./gemm_bench_abl $shape 16801799 >> $O/t64_128_stage_trace.txt 2>&1
+done
+cut -c1-200 $O/t64_128_stage_trace.txt
