@@ -71,6 +71,10 @@ __device__ __forceinline__ long as_i64(uint32_t lo, uint32_t hi) { return (long)
 // strides 272 / 144 bytes: conflict-free).
 // FIVE: Q5_K — the same superblock with 32 bytes of fifth bits behind the header (bit 2 gq of qh[l]: sub-block 2 gq's weight l, bit 2 gq + 1: sub-block
 // 2 gq + 1's; src/ggml-quants.c:1482-1507): 176-byte rows, weights 0 .. 31 instead of 0 .. 15, everything else as Q4_K (ggml_vec_dot_q5_K_q8_K)
+// What bounds it (round 6, profiles/r06/NOTES.md §3): the ACTIVATION traffic from the L2 — every 16-row work-group reads all B x K quantized activations, 59 MB at 16 rows of
+// 4096 x 14336 beside 33 MB of weights, and a second column group costs as much again (11 -> 18 us).  Measured without effect on one box (mmq_prefetch_minmfma_ab.txt): the
+// minimum term on the matrix core + byte-wise scale decode (loop VALU 201 -> 142) together with the weight slabs prefetched three superblocks ahead: 14.1-14.7 vs 14.0-14.4 us
+// at 3-16 rows, 8.2 vs 7.9 at 4096^2 — not in the tree.  Fatter work-groups need a K split across work-groups, whose exchange cost what they saved (k_mmq_ks_q4_K, removed).
 template <int NCG, int NW, bool FIVE = false>
 __global__ __launch_bounds__(NW * 64) void k_mmq_q4_K(mmq_args a) {
     if (!mmq_ids_rebase<NCG>(a, a.K / 256)) return;

@@ -1,10 +1,12 @@
 #!/bin/bash
-# a short session (rewritten per use): here — per-stage stamps of k_gemm_kq_t64's 128-row tile at C3 and at 8192 x 4096 x 512 (measurement build)
+# a short session (rewritten per use): here — k_mmq_q4_K with the weights prefetched three superblocks ahead and the minimum term on the matrix core, against the previous
+# kernel (a twin library built from the previous source), alternating, device time
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-export TMPDIR=/tmp GGML_CDNA4_OWNED_DEVICE=1
-O=$PWD/gpurun_out/session; mkdir -p $O; rm -rf $O/*
-cd tools/microbench
-for shape in "4096 11008 512" "8192 8192 512"; do
-  GB_VARIANTS="24583" GB_SPLITKS="2" GB_ROUNDS=3 GB_TRACE_REPS=30 GB_TRACE_SPLITK=2 timeout 200 ./gemm_bench_abl $shape 16801799 >> $O/t64_128_stage_trace.txt 2>&1
+export TMPDIR=/tmp PYTHONUNBUFFERED=1 GGML_CDNA4_OWNED_DEVICE=1
+R=$PWD; O=$R/gpurun_out/session; mkdir -p $O; rm -rf $O/*
+timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider -k "small_batches or mul_mat_id" > $O/pytest.log 2>&1; echo "pytest rc=$? $(tail -1 $O/pytest.log)" >> $O/summary.txt
+for rep in 1 2; do
+  AB_TAG=new BATCH_ROWS=1,3,4,8,16,24,32,48,64 timeout 200 python scripts/batch_q4k.py 2>/dev/null | tail -1 >> $O/mmq_ab.txt
+  AB_TAG=prev CDNA4_KERNELS_LIB=$R/tools/microbench/ab/libcdna4_kernels_prev_mmq.so BATCH_ROWS=1,3,4,8,16,24,32,48,64 timeout 200 python scripts/batch_q4k.py 2>/dev/null | tail -1 >> $O/mmq_ab.txt
 done
-cut -c1-200 $O/t64_128_stage_trace.txt
+cat $O/summary.txt; cat $O/mmq_ab.txt
