@@ -539,6 +539,249 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn_wide64(const fattn_params
     if (q0 + n < p.n_q) fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + (q0 + n)) * p.n_head + head) * HS, o, 1.0f / S, h);
 }
 
+// ------------------------------------------------------------------------------------------------ pipelined kernel (prefill, head sizes 64 / 128)
+// NW waves x 32 query rows per work-group over 64-key chunks, the same accumulator-layout arithmetic as above, restructured around what the counters of the wide
+// kernel said (round 6): it spent its LDS cycles on bank conflicts of the padded K rows, eight extra MFMAs per chunk on the V x identity transposition with an LDS
+// round trip and a second barrier behind it, and its staging writes sat between the barriers.  Here
+//   * K / V chunks are DOUBLE-buffered in LDS, fetched into registers right behind the barrier that ends a chunk (two chunks ahead of their use) and written to the
+//     other buffer in the middle of the next chunk (between the softmax and the P.V products), when the loads have long landed: ONE barrier per chunk
+//   * K rows are stored with their 16-byte slots XOR-swizzled by the row, so the four 16-lane groups of a ds_read_b128 fragment read (32 rows, one slot column) hit
+//     16 distinct slots of the 256-byte bank row
+//   * V is stored row-major (64-byte segments XOR-swizzled by the row) and read with gfx950's LDS transpose read, ds_read_b64_tr_b16: a 16-lane group hands in the
+//     addresses of a [4 keys][16 d] block, 8 bytes per lane, and lane i receives column i — four keys of ITS head-dimension row, which is half an A fragment of the
+//     third product (keys 16 kt + 4 h + 0..3 and 16 kt + 8 + 4 h + 0..3: the k-slot order P's accumulator registers already have).  No transposing MFMA, no Vt buffer.
+//     (semantics pinned on the hardware by tools/microbench/tr16_probe.hip)
+//   * the grid is one-dimensional and XCD-aware: work item (batch, head, query tile) w runs on XCD w / (items / 8), so the query tiles of a head share one L2
+#if defined(__HIPCC__)
+typedef __fp16 fa_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ half4_t fa_lds_tr16(const uint8_t *p) {
+    return __builtin_bit_cast(half4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fa_fp16x4 *)(p)));
+}
+#else       // tools/emul: wave-collective — every lane posts its address; lane i of a 16-lane group takes element i % 4 of the lane 4 j + i / 4 for j = 0..3
+static inline half4_t fa_lds_tr16(const uint8_t *p) {
+    emu::WaveState &w = emu::my_wave();
+    const int l = (int)(emu::t_threadIdx.x & 63), i = l & 15, g = l >> 4;
+    memcpy(&w.A[l][0], &p, sizeof p);
+    pthread_barrier_wait(&w.bar);
+    half4_t r;
+    for (int j = 0; j < 4; j++) { const uint8_t *a; memcpy(&a, &w.A[16 * g + 4 * j + (i >> 2)][0], sizeof a); r[j] = *reinterpret_cast<const half_t *>(a + 2 * (i & 3)); }
+    pthread_barrier_wait(&w.bar);
+    return r;
+}
+#endif
+
+// value of the partner lane (lane ^ 32) combined with this lane's by a symmetric operation: v_permlane32_swap hands every lane BOTH halves' values
+#if defined(__HIPCC__)
+// (both results are pinned by an empty asm: hipcc 7.2 otherwise folds arithmetic on the PAIR of results as if they were one value — max(r0, r1) became r0, r0 + r1 became
+// r0 + r0 in the ISA: 1e-2 errors on MI355X, invisible to the CPU emulation; tools/microbench/tr16_probe.hip checks the pinned form on the hardware)
+__device__ __forceinline__ void fa_swap32(float v, float &lo, float &hi) {
+    const uint32_t a = __builtin_bit_cast(uint32_t, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    uint32_t r0 = r[0], r1 = r[1];
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    lo = __builtin_bit_cast(float, r0); hi = __builtin_bit_cast(float, r1);           // lo: the value of lane l % 32, hi: of lane 32 + l % 32
+}
+__device__ __forceinline__ float fa_max_xor32(float v) { float lo, hi; fa_swap32(v, lo, hi); return fmaxf(lo, hi); }
+__device__ __forceinline__ float fa_sum_xor32(float v) { float lo, hi; fa_swap32(v, lo, hi); return lo + hi; }
+extern __shared__ __attribute__((aligned(16))) uint8_t fa_dyn_lds[];
+#else
+static inline float fa_max_xor32(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+static inline float fa_sum_xor32(float v) { const float o = __shfl_xor(v, 32); return (emu::t_threadIdx.x & 32) ? o + v : v + o; }      // (lanes 0-31's value first, like the swap)
+extern uint8_t fa_dyn_lds[];                                     // tools/emul: the harness defines it (a work-group is a process)
+#endif
+
+// online-softmax update of a WHOLE 64-key chunk without softcap, the scale folded into the exponent: with y = raw score (+ mask * slope / scale), c2 = scale * log2(e) > 0,
+//     x2 = c2 y (the log2-domain score of fa_softmax_blocks),  max x2 = c2 max y,  2^(x2 - M) = v_exp_f32(fma(y, c2, -M))
+// — per score one fma (mask, read as fp16: v_fma_mix), one max, one fma, one exp, one add, one conversion.  (M, S) stay in the log2 domain: a ragged last chunk goes
+// through fa_softmax_blocks with the same running values.
+template <int NKB, bool MASK>
+__device__ __forceinline__ float fa_softmax_fast(floatx16 (&s)[NKB], const half4_t (&mreg)[NKB * 4], float c2, float mslope, float &M, float &S, half8_t (&pf)[NKB * 2]) {
+    if constexpr (MASK) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) s[kb][4 * g + j] = __builtin_fmaf((float)mreg[kb * 4 + g][j], mslope, s[kb][4 * g + j]);
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+    mx = fa_max_xor32(mx);
+    const float Mn = fmaxf(M, mx * c2);
+    const float Ms = (Mn == -INFINITY) ? 0.0f : Mn;                             // (see fa_softmax_step)
+    const float ms = __builtin_amdgcn_exp2f(M - Ms);
+    float sum = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c2, -Ms));
+            sum += e; pf[kb * 2 + (r >> 3)][r & 7] = (half_t)e;
+        }
+    sum = fa_sum_xor32(sum);
+    S = S * ms + sum; M = Mn;
+    return ms;
+}
+
+struct fa_true { static constexpr bool value = true; };
+struct fa_false { static constexpr bool value = false; };
+// MODE 0: no mask, no softcap, scale > 0; 1: the same with a 16-byte-aligned mask, staged through LDS (below); 2: everything else (fa_softmax_blocks on every chunk)
+template <int HS, int NW, int MODE>
+__global__ __launch_bounds__(64 * NW, HS == 128 && NW == 2 ? 1 : 2) void k_flash_attn_pipe(const fattn_params p, int qtiles) {
+    constexpr int NS = HS / 16, NB = HS / 32, NKB = 2, CK = 64, T = 64 * NW;
+    constexpr int RB = HS * 2, SPR = HS / 8;                      // bytes / 16-byte slots of a K / V row
+    constexpr int PL = CK * SPR / T;                              // 16-byte pieces of one chunk per thread and matrix
+    static_assert(HS == 64 || HS == 128, "head sizes 64 / 128"); static_assert(PL >= 1 && CK * SPR % T == 0, "staging");
+    uint8_t *const Ks = fa_dyn_lds, *const Vs = fa_dyn_lds + 2 * CK * RB;      // [2][CK * RB] each; MODE 1: + NW x 4 KB of mask (k_flash_attn_pipe_lds)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+    // work item of this work-group: consecutive items on one XCD (work-groups go to the XCDs round-robin)
+    int w = blockIdx.x;
+    if ((gridDim.x & 7) == 0) w = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    const int qt = w % qtiles, head = (w / qtiles) % p.n_head, b3 = w / (qtiles * p.n_head);
+    const int q0 = qt * (32 * NW) + 32 * wave;
+    const bool active = q0 < p.n_q;                               // a wave whose 32 rows are all past the end only helps with the staging
+    const int qi = min(q0 + n, p.n_q - 1);
+
+    half8_t qf[NS];
+    fa_load_q<NS>(p, qi, head, b3, h, qf);
+    const float slope2 = fa_slope(p, head) * 1.4426950408889634f;
+    const float c2 = p.scale * 1.4426950408889634f, mslope = slope2 / c2;       // (MODE 0 / 1: p.scale > 0, no softcap)
+    const char *kbase = p.k + (int64_t)(head / p.rk2) * p.k_nb2 + (int64_t)(b3 / p.rk3) * p.k_nb3;
+    const char *vbase = p.v + (int64_t)(head / p.rv2) * p.v_nb2 + (int64_t)(b3 / p.rv3) * p.v_nb3;
+    const half_t *mrow = p.mask ? (const half_t *)(p.mask + (int64_t)qi * p.mask_nb1) : nullptr;
+
+    float M = -INFINITY, S = 0.0f;
+    floatx16 o[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[b][r] = 0.0f;
+
+    // row swizzles: K slot ^= ksw(row) (16 distinct slots over any 16 consecutive rows); V 64-byte segment ^= vsw(row) (the 4 rows of a transpose read land in 4 bank quarters)
+    auto ksw = [](int row) { return HS == 128 ? (row & 15) : ((row >> 1) & 7); };
+    auto vsw = [](int row) { return HS == 128 ? (row & 3) : ((row >> 1) & 1); };
+    u32x4 kreg[PL], vreg[PL];
+    auto fetch_kv = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PL; i++) {
+            const int pc = tid + T * i, row = pc / SPR, col = pc % SPR;
+            const int64_t kr = min(CK * c + row, p.n_kv - 1);     // past the end: repeated, masked in the softmax
+            kreg[i] = *reinterpret_cast<const u32x4 *>(kbase + kr * p.k_nb1 + 16 * col);
+            vreg[i] = *reinterpret_cast<const u32x4 *>(vbase + kr * p.v_nb1 + 16 * col);
+        }
+    };
+    auto stage_kv = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PL; i++) {
+            const int pc = tid + T * i, row = pc / SPR, col = pc % SPR;
+            *reinterpret_cast<u32x4 *>(Ks + buf * (CK * RB) + row * RB + 16 * (col ^ ksw(row))) = kreg[i];
+            *reinterpret_cast<u32x4 *>(Vs + buf * (CK * RB) + row * RB + 64 * ((col >> 2) ^ vsw(row)) + 16 * (col & 3)) = vreg[i];
+        }
+    };
+    // MODE 1 — the mask of this WAVE's 32 query rows x 64 keys goes through 4 KB of LDS of its own: coalesced 16-byte loads (8 lanes = one 128-byte row) a chunk ahead
+    // into registers, written behind the softmax that read the previous chunk (a wave's LDS operations execute in order: no barrier), read back as the 8-byte groups
+    // the accumulator layout wants.  Row r's 8-byte units are XOR-swizzled by (r / 2) % 16: the 32 lanes of a read (32 rows, one unit column) hit 32 distinct bank pairs.
+    // (Per-lane 8-byte loads of the mask rows straight from memory touched 32 lines per instruction and cost the 4096^2 case 40 % of its time.)
+    uint8_t *const Mw = fa_dyn_lds + 4 * CK * RB + wave * 4096;
+    u32x4 mst[4];
+    auto fetch_mask = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int pc = lane + 64 * i, row = pc >> 3, col = pc & 7;
+            mst[i] = *reinterpret_cast<const u32x4 *>(p.mask + (int64_t)min(q0 + row, p.n_q - 1) * p.mask_nb1 + 2 * (CK * c) + 16 * col);
+        }
+    };
+    auto stage_mask = [&]() __attribute__((always_inline)) {
+        CDNA4_WAVE_LDS_SYNC();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int pc = lane + 64 * i, row = pc >> 3, col = pc & 7, f = (row >> 1) & 15;
+            const u32x4 v = (f & 1) ? u32x4{mst[i].z, mst[i].w, mst[i].x, mst[i].y} : mst[i];
+            *reinterpret_cast<u32x4 *>(Mw + row * 128 + 16 * (col ^ (f >> 1))) = v;
+        }
+        CDNA4_WAVE_LDS_SYNC();
+    };
+    // this lane's share of the operand addresses: K fragment (kb, st) = row 32 kb + n, slot 2 st + h; V transpose read (b, kt, u) = row 16 kt + 8 u + 4 h + i / 4,
+    // bytes 64 b + 32 g1 + 8 (i % 4) .. + 7 of the row (i = lane % 16, g1 = (lane / 16) % 2)
+    const int ti = lane & 15, g1 = (lane >> 4) & 1;
+    const int krow = n * RB, kx = ksw(n);
+    const int vrow = (4 * h + (ti >> 2)) * RB + 32 * g1 + 8 * (ti & 3), vx = vsw(4 * h + (ti >> 2));
+
+    const int nchunk = (p.n_kv + CK - 1) / CK, nwhole = p.n_kv / CK;
+    // one chunk: scores, softmax (FAST: fa_softmax_fast; else fa_softmax_blocks, which reads the mask itself), staging of the next chunk, P.V, barrier, request of chunk c + 2
+    auto chunk = [&](int c, auto fast_tag) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const uint8_t *Kc = Ks + (c & 1) * (CK * RB), *Vc = Vs + (c & 1) * (CK * RB);
+        half8_t pf[NKB * 2];
+        float ms = 1.0f;
+        if (active) {
+            floatx16 s[NKB];
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) s[kb][r] = 0.0f;
+#pragma unroll
+                for (int st = 0; st < NS; st++)
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Kc + 32 * kb * RB + krow + 16 * ((2 * st + h) ^ kx)), qf[st], s[kb], 0, 0, 0);
+            }
+            half4_t mreg[NKB * 4] = {};
+            if constexpr (FAST) {
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++) mreg[kb * 4 + g] = *reinterpret_cast<const half4_t *>(Mw + n * 128 + 8 * ((8 * kb + 2 * g + h) ^ ((n >> 1) & 15)));
+                }
+                ms = fa_softmax_fast<NKB, MODE == 1>(s, mreg, c2, mslope, M, S, pf);
+                if constexpr (MODE == 1) {
+                    if (c + 1 < nwhole) { stage_mask(); if (c + 2 < nwhole) fetch_mask(c + 2); }
+                }
+            } else {
+                fattn_params pg = p; pg.mask_vec = 0;                 // (element-wise path: mreg is not filled here)
+                ms = fa_softmax_blocks<NKB>(pg, s, CK * c, h, mrow, slope2, mreg, M, S, pf);
+            }
+        }
+        if (c + 1 < nchunk) stage_kv((c + 1) & 1);                  // chunk c + 1's registers (requested a chunk ago) -> the other buffer (free since the last barrier)
+        if (active) {
+            if (wave_any(ms != 1.0f)) {                             // (one branch in front of the block loop: see k_flash_attn_split)
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) o[b][r] *= ms;
+            }
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int kt = 0; kt < NKB * 2; kt++) {
+                    const uint8_t *va = Vc + 16 * kt * RB + vrow + 64 * (b ^ vx);
+                    const half4_t lo = fa_lds_tr16(va), hi = fa_lds_tr16(va + 8 * RB);
+                    const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kt], o[b], 0, 0, 0);
+                }
+        }
+        __syncthreads();                                          // everyone is done with buffer c & 1, buffer (c + 1) & 1 is complete
+        if (c + 2 < nchunk) fetch_kv(c + 2);                      // lands while chunk c + 1's scores and softmax run
+    };
+
+    fetch_kv(0);
+    if constexpr (MODE == 1) { if (active && nwhole > 0) fetch_mask(0); }
+    stage_kv(0);
+    if constexpr (MODE == 1) { if (active && nwhole > 0) { stage_mask(); if (nwhole > 1) fetch_mask(1); } }
+    __syncthreads();
+    if (nchunk > 1) fetch_kv(1);
+    if constexpr (MODE == 2) {
+        for (int c = 0; c < nchunk; c++) chunk(c, fa_false{});
+    } else {
+        for (int c = 0; c < nwhole; c++) chunk(c, fa_true{});
+        if (nwhole < nchunk) chunk(nwhole, fa_false{});
+    }
+    if (q0 + n < p.n_q) fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + (q0 + n)) * p.n_head + head) * HS, o, 1.0f / S, h);
+}
+template <int HS, int NW, int MODE> constexpr int k_flash_attn_pipe_lds() { return 4 * 64 * HS * 2 + (MODE == 1 ? NW * 4096 : 0); }
+
 #define NEED(cond, msg) do { if (!(cond)) return cdna4_set_error_msg(msg); } while (0)
 typedef ggml_cdna4_tensor T4;
 
@@ -653,6 +896,33 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
 
     p.mask_vec = mask && !(((uintptr_t)mask->data | (uintptr_t)mask->nb[1]) & 15);
     const int64_t cus = cdna4_gemm_cu_count();
+    // head sizes 64 / 128 with an F16 K / V: the pipelined kernel on the largest query tile (256 / 128 / 64 rows) that still gives every CU a work-group
+    // (CDNA4_FA_PIPE: measurement / test knob — 0 keeps the older kernels, 2 / 4 / 8 forces that many waves per work-group whatever the grid)
+    if (kvt == CDNA4_F16 && (D == 64 || D == 128) && N > 32) {
+        const char *e = getenv("CDNA4_FA_PIPE");
+        int nw = e ? atoi(e) : -1;
+        if (nw < 0) {
+            nw = 0;
+            for (int c = 8; c >= 2 && !nw; c >>= 1)
+                if (((N + 32 * c - 1) / (32 * c)) * H * B3 >= cus) nw = c;
+        }
+        if (nw == 2 || nw == 4 || nw == 8) {
+            const int64_t qtiles = (N + 32 * nw - 1) / (32 * nw), items = qtiles * H * B3;
+            NEED(items < (1ll << 31), "flash_attn_ext: too many query tiles for one grid");
+            const int mode = (logit_softcap != 0.0f || !(p.scale > 0.0f) || (mask && !p.mask_vec)) ? 2 : (mask ? 1 : 0);
+#define FA_PIPE3(HS_, NW_, MODE_) do { constexpr int lds_ = k_flash_attn_pipe_lds<HS_, NW_, MODE_>(); static bool raised_ = false;                                \
+                if (lds_ > 64 * 1024 && !raised_) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_flash_attn_pipe<HS_, NW_, MODE_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) { \
+                    (void)hipGetLastError(); return cdna4_set_error_msg("flash_attn_ext: cannot raise the dynamic LDS limit"); } raised_ = true; }                \
+                hipLaunchKernelGGL((k_flash_attn_pipe<HS_, NW_, MODE_>), dim3((unsigned)items), dim3(64 * NW_), lds_, st, p, (int)qtiles); } while (0)
+#define FA_PIPE(HS_, NW_) do { if (mode == 0) FA_PIPE3(HS_, NW_, 0); else if (mode == 1) FA_PIPE3(HS_, NW_, 1); else FA_PIPE3(HS_, NW_, 2); } while (0)
+            if (D == 64) { if (nw == 8) FA_PIPE(64, 8); else if (nw == 4) FA_PIPE(64, 4); else FA_PIPE(64, 2); }
+            else { if (nw == 8) FA_PIPE(128, 8); else if (nw == 4) FA_PIPE(128, 4); else FA_PIPE(128, 2); }
+#undef FA_PIPE3
+#undef FA_PIPE
+            CDNA4_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (fa_takes_wide(N, H, B3)) {                                 // prefill that fills the chip: 128 query rows per work-group, K / V staged through LDS
         NEED(kvt == CDNA4_F16, "flash_attn_ext: the 128-row kernels take an F16 K / V");
         const dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B3);

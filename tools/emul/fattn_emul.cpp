@@ -22,6 +22,7 @@ thread_local std::vector<Pending> t_vmq;
 bool g_defer_dma = false;
 size_t g_weaken = 0;
 }
+__attribute__((aligned(16))) uint8_t fa_dyn_lds[160 * 1024];           // the dynamic LDS of k_flash_attn_pipe (a work-group is a process: one array)
 int cdna4_set_error_msg(const char *m) { fprintf(stderr, "error: %s\n", m); return -1; }
 int cdna4_set_error(hipError_t, const char *, int) { return -1; }
 static void *shared_alloc(size_t n) {                                  // between two inaccessible pages: an out-of-bounds access kills the work-group

@@ -14,6 +14,7 @@ bool g_defer_dma = false;
 size_t g_weaken = 0;
 }
 __attribute__((aligned(16))) uint8_t smem[160 * 1024];
+__attribute__((aligned(16))) uint8_t fa_dyn_lds[160 * 1024];           // fattn.hip: k_flash_attn_pipe
 void *emu_shared_alloc(size_t n) {
     const size_t pg = 4096, body = (n + pg - 1) / pg * pg;
     char *p = (char *)mmap(nullptr, body + 2 * pg, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
