@@ -28,6 +28,7 @@
 #include "../../include/ggml_cdna4.h"
 #include "cdna4_common.h"
 #include "cdna4_kernels.h"
+#include "gemm_q_hw.h"
 #include <math.h>
 
 void *cdna4_gemm_scratch(size_t bytes, int kind);      // gemm_q_mfma.hip: per-device scratch (kind 4 = partial results of the key split)
@@ -629,28 +630,38 @@ __device__ __forceinline__ float fa_softmax_fast(floatx16 (&s)[NKB], const half4
 struct fa_true { static constexpr bool value = true; };
 struct fa_false { static constexpr bool value = false; };
 // MODE 0: no mask, no softcap, scale > 0; 1: the same with a 16-byte-aligned mask, staged through LDS (below); 2: everything else (fa_softmax_blocks on every chunk)
+//
+// Pipeline (round 6, second form — the counters of the first, register-staged form said: LDS conflict-free, but the matrix pipe 33 % busy in the steady state because a
+// wave's scores -> softmax -> P.V chain ran strictly in sequence and the two waves of a SIMD, held in step by the barrier, were in the SAME phase most of the time):
+//   * K / V / mask chunks travel by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass): requested at the top of a chunk into the buffer the last
+//     barrier freed, waited for (vmcnt(0)) in front of the barrier that ends the chunk — a whole chunk of flight time.  The LDS image of a DMA piece is lane-linear, so the
+//     swizzles are applied to the SOURCE address: the lane that fills LDS cell (row, s') fetches slot s' ^ swizzle(row) of that row.
+//   * the scores run ONE chunk ahead of the softmax: chunk c's step issues the 16 MFMAs of S(c + 1) = K(c + 1) Q^T next to the VALU work of softmax(S(c)) — independent
+//     instruction streams of one wave, which the matrix pipe and the VALU execute side by side — then P(c) V(c).  Two score accumulators alternate (the loop is unrolled
+//     by two so that no register copies are needed); K is therefore staged a chunk ahead of V.
 template <int HS, int NW, int MODE>
-__global__ __launch_bounds__(64 * NW, HS == 128 && NW == 2 ? 1 : 2) void k_flash_attn_pipe(const fattn_params p, int qtiles) {
-    constexpr int NS = HS / 16, NB = HS / 32, NKB = 2, CK = 64, T = 64 * NW;
+__global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_params p, int qtiles) {
+    constexpr int NS = HS / 16, NB = HS / 32, NKB = 2, CK = 64;
     constexpr int RB = HS * 2, SPR = HS / 8;                      // bytes / 16-byte slots of a K / V row
-    constexpr int PL = CK * SPR / T;                              // 16-byte pieces of one chunk per thread and matrix
-    static_assert(HS == 64 || HS == 128, "head sizes 64 / 128"); static_assert(PL >= 1 && CK * SPR % T == 0, "staging");
-    uint8_t *const Ks = fa_dyn_lds, *const Vs = fa_dyn_lds + 2 * CK * RB;      // [2][CK * RB] each; MODE 1: + NW x 4 KB of mask (k_flash_attn_pipe_lds)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+    constexpr int CB = CK * RB, NP = CB / 1024, PW = NP / NW;     // bytes of a chunk, 1 KB DMA pieces per chunk and matrix, pieces per wave
+    static_assert(HS == 64 || HS == 128, "head sizes 64 / 128"); static_assert(PW >= 1 && NP % NW == 0, "DMA pieces");
+    uint8_t *const smem = fa_dyn_lds;                             // K [2][CB] | V [2][CB] | MODE 1: mask [NW][32 rows x 128 B]
+    constexpr int K_OFF = 0, V_OFF = 2 * CB, M_OFF = 4 * CB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 31, h = lane >> 5;
+    const uint32_t lds0 = CDNA4_LDS_BASE(smem);
     // work item of this work-group: consecutive items on one XCD (work-groups go to the XCDs round-robin)
     int w = blockIdx.x;
     if ((gridDim.x & 7) == 0) w = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     const int qt = w % qtiles, head = (w / qtiles) % p.n_head, b3 = w / (qtiles * p.n_head);
-    const int q0 = qt * (32 * NW) + 32 * wave;
-    const bool active = q0 < p.n_q;                               // a wave whose 32 rows are all past the end only helps with the staging
+    const int q0 = qt * (32 * NW) + 32 * wave;                    // (rows past the end repeat the last row and are not stored)
     const int qi = min(q0 + n, p.n_q - 1);
 
     half8_t qf[NS];
     fa_load_q<NS>(p, qi, head, b3, h, qf);
     const float slope2 = fa_slope(p, head) * 1.4426950408889634f;
     const float c2 = p.scale * 1.4426950408889634f, mslope = slope2 / c2;       // (MODE 0 / 1: p.scale > 0, no softcap)
-    const char *kbase = p.k + (int64_t)(head / p.rk2) * p.k_nb2 + (int64_t)(b3 / p.rk3) * p.k_nb3;
-    const char *vbase = p.v + (int64_t)(head / p.rv2) * p.v_nb2 + (int64_t)(b3 / p.rv3) * p.v_nb3;
+    const uint8_t *kbase = (const uint8_t *)p.k + (int64_t)(head / p.rk2) * p.k_nb2 + (int64_t)(b3 / p.rk3) * p.k_nb3;
+    const uint8_t *vbase = (const uint8_t *)p.v + (int64_t)(head / p.rv2) * p.v_nb2 + (int64_t)(b3 / p.rv3) * p.v_nb3;
     const half_t *mrow = p.mask ? (const half_t *)(p.mask + (int64_t)qi * p.mask_nb1) : nullptr;
 
     float M = -INFINITY, S = 0.0f;
@@ -660,124 +671,180 @@ __global__ __launch_bounds__(64 * NW, HS == 128 && NW == 2 ? 1 : 2) void k_flash
 #pragma unroll
         for (int r = 0; r < 16; r++) o[b][r] = 0.0f;
 
-    // row swizzles: K slot ^= ksw(row) (16 distinct slots over any 16 consecutive rows); V 64-byte segment ^= vsw(row) (the 4 rows of a transpose read land in 4 bank quarters)
+    // row swizzles: K slot ^= ksw(row) (16 distinct slots over any 16 consecutive rows); V 64-byte segment ^= vsw(row) (the 4 rows of a transpose read land in 4 bank quarters);
+    // mask slot ^= (row / 2) % 8 (8-byte reads of one slot column over 32 rows: 2-way, eight reads per chunk)
     auto ksw = [](int row) { return HS == 128 ? (row & 15) : ((row >> 1) & 7); };
     auto vsw = [](int row) { return HS == 128 ? (row & 3) : ((row >> 1) & 1); };
-    u32x4 kreg[PL], vreg[PL];
-    auto fetch_kv = [&](int c) __attribute__((always_inline)) {
+    // DMA piece j of a chunk = LDS cells 64 j .. 64 j + 63 (16 bytes each): lane l fills cell (row (64 j + l) / SPR, slot (64 j + l) % SPR); wave w moves pieces w, w + NW, ..
+    // The source offsets of a whole chunk do not depend on the chunk: computed once.  A ragged last chunk clamps its rows (repeated rows, masked in the softmax).
+    auto kv_voff = [&](int i, bool is_v, int lim) __attribute__((always_inline)) {
+        const int j = wave + NW * i, cell = 64 * j + lane, row = cell / SPR, sp = cell % SPR;
+        const int slot = is_v ? ((((sp >> 2) ^ vsw(row)) << 2) | (sp & 3)) : (sp ^ ksw(row));
+        return (uint32_t)(min(row, lim) * (is_v ? p.v_nb1 : p.k_nb1) + 16 * slot);
+    };
+    uint32_t kvoff[PW], vvoff[PW], moff[4];
 #pragma unroll
-        for (int i = 0; i < PL; i++) {
-            const int pc = tid + T * i, row = pc / SPR, col = pc % SPR;
-            const int64_t kr = min(CK * c + row, p.n_kv - 1);     // past the end: repeated, masked in the softmax
-            kreg[i] = *reinterpret_cast<const u32x4 *>(kbase + kr * p.k_nb1 + 16 * col);
-            vreg[i] = *reinterpret_cast<const u32x4 *>(vbase + kr * p.v_nb1 + 16 * col);
+    for (int i = 0; i < PW; i++) { kvoff[i] = kv_voff(i, false, CK - 1); vvoff[i] = kv_voff(i, true, CK - 1); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int cell = 64 * i + lane, row = cell >> 3, sp = cell & 7;
+        moff[i] = (uint32_t)((int64_t)min(q0 + row, p.n_q - 1) * p.mask_nb1 + 16 * (sp ^ ((row >> 1) & 7)));
+    }
+    auto dma_kv = [&](int c, int buf, bool is_v) __attribute__((always_inline)) {
+        const int lim = p.n_kv - 1 - CK * c;                      // last valid row of the chunk
+        const uint8_t *src = is_v ? vbase + (int64_t)(CK * c) * p.v_nb1 : kbase + (int64_t)(CK * c) * p.k_nb1;
+        const uint32_t dst = lds0 + (is_v ? V_OFF : K_OFF) + buf * CB + 1024 * wave;
+        if (lim >= CK - 1) {
+#pragma unroll
+            for (int i = 0; i < PW; i++) CDNA4_DMA16(is_v ? vvoff[i] : kvoff[i], src, dst + 1024 * NW * i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PW; i++) { const uint32_t vo = kv_voff(i, is_v, lim); CDNA4_DMA16(vo, src, dst + 1024 * NW * i); }
         }
     };
-    auto stage_kv = [&](int buf) __attribute__((always_inline)) {
+    auto dma_mask = [&](int c) __attribute__((always_inline)) {
+        const uint8_t *src = (const uint8_t *)p.mask + 2 * (int64_t)(CK * c);
 #pragma unroll
-        for (int i = 0; i < PL; i++) {
-            const int pc = tid + T * i, row = pc / SPR, col = pc % SPR;
-            *reinterpret_cast<u32x4 *>(Ks + buf * (CK * RB) + row * RB + 16 * (col ^ ksw(row))) = kreg[i];
-            *reinterpret_cast<u32x4 *>(Vs + buf * (CK * RB) + row * RB + 64 * ((col >> 2) ^ vsw(row)) + 16 * (col & 3)) = vreg[i];
-        }
-    };
-    // MODE 1 — the mask of this WAVE's 32 query rows x 64 keys goes through 4 KB of LDS of its own: coalesced 16-byte loads (8 lanes = one 128-byte row) a chunk ahead
-    // into registers, written behind the softmax that read the previous chunk (a wave's LDS operations execute in order: no barrier), read back as the 8-byte groups
-    // the accumulator layout wants.  Row r's 8-byte units are XOR-swizzled by (r / 2) % 16: the 32 lanes of a read (32 rows, one unit column) hit 32 distinct bank pairs.
-    // (Per-lane 8-byte loads of the mask rows straight from memory touched 32 lines per instruction and cost the 4096^2 case 40 % of its time.)
-    uint8_t *const Mw = fa_dyn_lds + 4 * CK * RB + wave * 4096;
-    u32x4 mst[4];
-    auto fetch_mask = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int pc = lane + 64 * i, row = pc >> 3, col = pc & 7;
-            mst[i] = *reinterpret_cast<const u32x4 *>(p.mask + (int64_t)min(q0 + row, p.n_q - 1) * p.mask_nb1 + 2 * (CK * c) + 16 * col);
-        }
-    };
-    auto stage_mask = [&]() __attribute__((always_inline)) {
-        CDNA4_WAVE_LDS_SYNC();
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int pc = lane + 64 * i, row = pc >> 3, col = pc & 7, f = (row >> 1) & 15;
-            const u32x4 v = (f & 1) ? u32x4{mst[i].z, mst[i].w, mst[i].x, mst[i].y} : mst[i];
-            *reinterpret_cast<u32x4 *>(Mw + row * 128 + 16 * (col ^ (f >> 1))) = v;
-        }
-        CDNA4_WAVE_LDS_SYNC();
+        for (int i = 0; i < 4; i++) CDNA4_DMA16(moff[i], src, lds0 + M_OFF + wave * 4096 + 1024 * i);
     };
     // this lane's share of the operand addresses: K fragment (kb, st) = row 32 kb + n, slot 2 st + h; V transpose read (b, kt, u) = row 16 kt + 8 u + 4 h + i / 4,
     // bytes 64 b + 32 g1 + 8 (i % 4) .. + 7 of the row (i = lane % 16, g1 = (lane / 16) % 2)
     const int ti = lane & 15, g1 = (lane >> 4) & 1;
     const int krow = n * RB, kx = ksw(n);
     const int vrow = (4 * h + (ti >> 2)) * RB + 32 * g1 + 8 * (ti & 3), vx = vsw(4 * h + (ti >> 2));
+    const uint8_t *const Mw = smem + M_OFF + wave * 4096 + n * 128;
+    const int mx8 = (n >> 1) & 7;
 
-    const int nchunk = (p.n_kv + CK - 1) / CK, nwhole = p.n_kv / CK;
-    // one chunk: scores, softmax (FAST: fa_softmax_fast; else fa_softmax_blocks, which reads the mask itself), staging of the next chunk, P.V, barrier, request of chunk c + 2
-    auto chunk = [&](int c, auto fast_tag) __attribute__((always_inline)) {
-        constexpr bool FAST = decltype(fast_tag)::value;
-        const uint8_t *Kc = Ks + (c & 1) * (CK * RB), *Vc = Vs + (c & 1) * (CK * RB);
+    const int nchunk = (p.n_kv + CK - 1) / CK, nfast = MODE == 2 ? 0 : p.n_kv / CK;
+    auto scores = [&](int c, floatx16 (&s)[NKB]) __attribute__((always_inline)) {
+        const uint8_t *Kc = smem + K_OFF + (c & 1) * CB;
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) s[kb][r] = 0.0f;
+#pragma unroll
+            for (int st = 0; st < NS; st++)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Kc + 32 * kb * RB + krow + 16 * ((2 * st + h) ^ kx)), qf[st], s[kb], 0, 0, 0);
+        }
+    };
+    // chunk c: [top] request K(c + 2), V(c + 1) into the buffers the last barrier freed; scores of chunk c + 1 next to the softmax of chunk c (sc -> P); request mask(c + 1);
+    // O = O ms + V(c)^T P; all requests landed, barrier.  HOT: chunks c + 1, c + 2 exist and chunk c is a whole chunk on the fast path — no branches around the MFMA / VALU mix.
+    auto step = [&](int c, floatx16 (&sc)[NKB], floatx16 (&sn)[NKB], auto hot_tag) __attribute__((always_inline)) {
+        constexpr bool HOT = decltype(hot_tag)::value;
+        const bool fast = HOT || c < nfast;
+        if (HOT || c + 2 < nchunk) dma_kv(c + 2, c & 1, false);
+        if (HOT || c + 1 < nchunk) dma_kv(c + 1, (c + 1) & 1, true);
         half8_t pf[NKB * 2];
-        float ms = 1.0f;
-        if (active) {
-            floatx16 s[NKB];
-#pragma unroll
-            for (int kb = 0; kb < NKB; kb++) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) s[kb][r] = 0.0f;
-#pragma unroll
-                for (int st = 0; st < NS; st++)
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t *>(Kc + 32 * kb * RB + krow + 16 * ((2 * st + h) ^ kx)), qf[st], s[kb], 0, 0, 0);
-            }
+        float ms;
+        if constexpr (HOT) {
+            // The issue order is written out: a wave issues in order, so what is to run beside an MFMA has to stand behind it in the instruction stream, and hipcc's
+            // scheduler left to itself puts the 16 score MFMAs of chunk c + 1 in front of the whole softmax of chunk c.  Sixteen sections, fenced by sched_barrier(0):
+            // section m = the K fragment read of MFMA m + 2, MFMA m, one slice of the softmax — slices 0..7 the mask term and the running maximum of four scores each,
+            // then the row maximum and the factors, slices 8..15 exponent, sum and fp16 conversion of four scores each.
+            const uint8_t *Kn = smem + K_OFF + ((c + 1) & 1) * CB + krow;
+            auto kfrag = [&](int m) __attribute__((always_inline)) { return *reinterpret_cast<const half8_t *>(Kn + 32 * (m / NS) * RB + 16 * ((2 * (m % NS) + h) ^ kx)); };
+            constexpr int NM = NKB * NS, SL = 32 / NM;              // MFMAs of a chunk's scores; scores per softmax slice of a half (HS 128: 16 MFMAs, 4 scores; HS 64: 8 MFMAs, 8 scores)
+            constexpr int GS = 2 * SL / 4;                          // mask groups (four scores: one 8-byte read) per slice; requested one slice ahead
             half4_t mreg[NKB * 4] = {};
-            if constexpr (FAST) {
+            auto mask_groups = [&](int sl) __attribute__((always_inline)) {
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int g = GS * sl; g < GS * (sl + 1); g++) mreg[g] = *reinterpret_cast<const half4_t *>(Mw + 16 * (g ^ mx8) + 8 * h);
+                }
+            };
+            mask_groups(0);
+            half8_t kf[NM];
+            kf[0] = kfrag(0); kf[1] = kfrag(1);
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) sn[kb][r] = 0.0f;
+            float mx = -INFINITY, Ms = 0.0f, sum = 0.0f;
+            ms = 1.0f;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NM; m++) {
+                if (m + 2 < NM) kf[m + 2] = kfrag(m + 2);
+                sn[m / NS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[m], qf[m % NS], sn[m / NS], 0, 0, 0);
+                if (m < NM / 2) {                                   // slice m of the first half: 2 SL scores
+                    if (m + 1 < NM / 2) mask_groups(m + 1);
+#pragma unroll
+                    for (int e = 2 * SL * m; e < 2 * SL * (m + 1); e++) {
+                        const int kb = e >> 4, r = e & 15;
+                        if constexpr (MODE == 1) sc[kb][r] = __builtin_fmaf((float)mreg[kb * 4 + (r >> 2)][r & 3], mslope, sc[kb][r]);
+                        mx = fmaxf(mx, sc[kb][r]);
+                    }
+                    if (m == NM / 2 - 1) {
+                        mx = fa_max_xor32(mx);
+                        const float Mn = fmaxf(M, mx * c2);
+                        Ms = (Mn == -INFINITY) ? 0.0f : Mn;             // (see fa_softmax_step)
+                        ms = __builtin_amdgcn_exp2f(M - Ms);
+                        M = Mn;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 2 * SL * (m - NM / 2); e < 2 * SL * (m - NM / 2 + 1); e++) {
+                        const int kb = e >> 4, r = e & 15;
+                        const float ex = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r], c2, -Ms));
+                        sum += ex; pf[kb * 2 + (r >> 3)][r & 7] = (half_t)ex;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sum = fa_sum_xor32(sum);
+            S = S * ms + sum;
+            if constexpr (MODE == 1) { CDNA4_WAIT_LGKM0(); CDNA4_WAVE_LDS_SYNC(); dma_mask(c + 1); }     // (this wave's reads of mask(c) have returned)
+        } else {
+            if (c + 1 < nchunk) scores(c + 1, sn);
+            half4_t mreg[NKB * 4] = {};
+            if (fast) {
                 if constexpr (MODE == 1) {
 #pragma unroll
                     for (int kb = 0; kb < NKB; kb++)
 #pragma unroll
-                        for (int g = 0; g < 4; g++) mreg[kb * 4 + g] = *reinterpret_cast<const half4_t *>(Mw + n * 128 + 8 * ((8 * kb + 2 * g + h) ^ ((n >> 1) & 15)));
+                        for (int g = 0; g < 4; g++) mreg[kb * 4 + g] = *reinterpret_cast<const half4_t *>(Mw + 16 * ((4 * kb + g) ^ mx8) + 8 * h);
                 }
-                ms = fa_softmax_fast<NKB, MODE == 1>(s, mreg, c2, mslope, M, S, pf);
+                ms = fa_softmax_fast<NKB, MODE == 1>(sc, mreg, c2, mslope, M, S, pf);
                 if constexpr (MODE == 1) {
-                    if (c + 1 < nwhole) { stage_mask(); if (c + 2 < nwhole) fetch_mask(c + 2); }
+                    if (c + 1 < nfast) { CDNA4_WAIT_LGKM0(); CDNA4_WAVE_LDS_SYNC(); dma_mask(c + 1); }     // (this wave's reads of mask(c) have returned)
                 }
             } else {
-                fattn_params pg = p; pg.mask_vec = 0;                 // (element-wise path: mreg is not filled here)
-                ms = fa_softmax_blocks<NKB>(pg, s, CK * c, h, mrow, slope2, mreg, M, S, pf);
+                fattn_params pg = p; pg.mask_vec = 0;               // (element-wise path: mreg is not filled here)
+                ms = fa_softmax_blocks<NKB>(pg, sc, CK * c, h, mrow, slope2, mreg, M, S, pf);
             }
         }
-        if (c + 1 < nchunk) stage_kv((c + 1) & 1);                  // chunk c + 1's registers (requested a chunk ago) -> the other buffer (free since the last barrier)
-        if (active) {
-            if (wave_any(ms != 1.0f)) {                             // (one branch in front of the block loop: see k_flash_attn_split)
-#pragma unroll
-                for (int b = 0; b < NB; b++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) o[b][r] *= ms;
-            }
+        const uint8_t *Vc = smem + V_OFF + (c & 1) * CB;
+        if (wave_any(ms != 1.0f)) {                                 // (one branch in front of the block loop: see k_flash_attn_split)
 #pragma unroll
             for (int b = 0; b < NB; b++)
 #pragma unroll
-                for (int kt = 0; kt < NKB * 2; kt++) {
-                    const uint8_t *va = Vc + 16 * kt * RB + vrow + 64 * (b ^ vx);
-                    const half4_t lo = fa_lds_tr16(va), hi = fa_lds_tr16(va + 8 * RB);
-                    const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kt], o[b], 0, 0, 0);
-                }
+                for (int r = 0; r < 16; r++) o[b][r] *= ms;
         }
-        __syncthreads();                                          // everyone is done with buffer c & 1, buffer (c + 1) & 1 is complete
-        if (c + 2 < nchunk) fetch_kv(c + 2);                      // lands while chunk c + 1's scores and softmax run
+#pragma unroll
+        for (int kt = 0; kt < NKB * 2; kt++)                        // (consecutive MFMAs on different accumulators)
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const uint8_t *va = Vc + 16 * kt * RB + vrow + 64 * (b ^ vx);
+                const half4_t lo = fa_lds_tr16(va), hi = fa_lds_tr16(va + 8 * RB);
+                const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kt], o[b], 0, 0, 0);
+            }
+        CDNA4_WAIT_VM(0);
+        __syncthreads();                                          // everyone is done with K(c + 1)'s and V(c)'s reads; K(c + 2), V(c + 1), mask(c + 1) are in LDS
     };
 
-    fetch_kv(0);
-    if constexpr (MODE == 1) { if (active && nwhole > 0) fetch_mask(0); }
-    stage_kv(0);
-    if constexpr (MODE == 1) { if (active && nwhole > 0) { stage_mask(); if (nwhole > 1) fetch_mask(1); } }
+    dma_kv(0, 0, false); dma_kv(0, 0, true);
+    if (nchunk > 1) dma_kv(1, 1, false);
+    if constexpr (MODE == 1) { if (nfast > 0) dma_mask(0); }
+    CDNA4_WAIT_VM(0);
     __syncthreads();
-    if (nchunk > 1) fetch_kv(1);
-    if constexpr (MODE == 2) {
-        for (int c = 0; c < nchunk; c++) chunk(c, fa_false{});
-    } else {
-        for (int c = 0; c < nwhole; c++) chunk(c, fa_true{});
-        if (nwhole < nchunk) chunk(nwhole, fa_false{});
-    }
+    floatx16 sa[NKB], sb[NKB];
+    scores(0, sa);
+    __syncthreads();                                              // K(0) has been read by every wave: chunk 0's step may overwrite it with K(2)
+    int c = 0;
+    for (; c + 3 < nchunk && c + 1 < nfast; c += 2) { step(c, sa, sb, fa_true{}); step(c + 1, sb, sa, fa_true{}); }
+    for (; c + 1 < nchunk; c += 2) { step(c, sa, sb, fa_false{}); step(c + 1, sb, sa, fa_false{}); }
+    if (c < nchunk) step(c, sa, sb, fa_false{});
     if (q0 + n < p.n_q) fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + (q0 + n)) * p.n_head + head) * HS, o, 1.0f / S, h);
 }
 template <int HS, int NW, int MODE> constexpr int k_flash_attn_pipe_lds() { return 4 * 64 * HS * 2 + (MODE == 1 ? NW * 4096 : 0); }

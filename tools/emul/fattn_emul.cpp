@@ -71,6 +71,12 @@ int cdna4_gemm_cu_count() { const char *e = getenv("EMU_CUS"); return e ? atoi(e
 #define hipMemcpyDeviceToDevice 0
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+// the GPU-only statements of k_flash_attn_pipe (gemm_q_hw.h): LDS-DMA as a copy (at once, or at the wave's vmcnt wait with EMU_DEFER_DMA=1)
+#define CDNA4_HW_OVERRIDE
+#define CDNA4_LDS_BASE(smem_) 0u
+#define CDNA4_DMA16(voff, sbase, lds_addr) emu::vm_issue(smem + (lds_addr) + 16 * lane, (sbase) + (voff))
+#define CDNA4_WAIT_VM(n) emu::vm_wait(n)
+#define CDNA4_WAIT_LGKM0() ((void)0)
 #include "../../ggml_amd/csrc/ops.hip"
 #undef NEED
 #include "../../ggml_amd/csrc/fattn.hip"
@@ -79,6 +85,7 @@ static void slurp(const char *p, void *dst, size_t n) {
     FILE *f = fopen(p, "rb"); if (!f || fread(dst, 1, n, f) != n) { perror(p); exit(2); } fclose(f);
 }
 int main(int argc, char **argv) {
+    emu::g_defer_dma = getenv("EMU_DEFER_DMA") && atoi(getenv("EMU_DEFER_DMA")) != 0;
     if (argc < 19) { fprintf(stderr, "usage: fattn_emul D n_q n_head n_batch n_kv n_head_kv n_batch_kv has_mask mask_rows scale max_bias softcap permuted q k v mask out\n"); return 2; }
     const int64_t D = atoll(argv[1]), NQ = atoll(argv[2]), H = atoll(argv[3]), B3 = atoll(argv[4]), KV = atoll(argv[5]), HK = atoll(argv[6]), BK = atoll(argv[7]);
     const int has_mask = atoi(argv[8]); const int64_t MR = atoll(argv[9]);

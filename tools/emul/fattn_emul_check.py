@@ -31,7 +31,7 @@ _locked = _blm.locked          # (xdist workers share build/: one build at a tim
 def build():
     exe = os.path.join(HERE, "fattn_emul")
     csrc = os.path.join(ROOT, "ggml_amd", "csrc")
-    srcs = [os.path.join(HERE, "fattn_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(csrc, f) for f in ("fattn.hip", "ops.hip", "cdna4_common.h", "cdna4_kernels.h", "epilogue.h")]
+    srcs = [os.path.join(HERE, "fattn_emul.cpp"), os.path.join(HERE, "hip_emul.h")] + [os.path.join(csrc, f) for f in ("fattn.hip", "ops.hip", "cdna4_common.h", "cdna4_kernels.h", "epilogue.h", "gemm_q_hw.h")]
     if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
         subprocess.run([CLANG, "-std=c++17", "-O1", "-pthread", "-ffp-contract=off", "-I" + os.path.join(HERE, "shim"), "-I" + csrc, "-I" + os.path.join(ROOT, "include"),
                         "-Wno-unused-value", "-o", exe, srcs[0]], check=True, capture_output=True, timeout=600)
