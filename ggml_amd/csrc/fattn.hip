@@ -640,21 +640,36 @@ struct fa_false { static constexpr bool value = false; };
 //     instruction streams of one wave, which the matrix pipe and the VALU execute side by side — then P(c) V(c).  Two score accumulators alternate (the loop is unrolled
 //     by two so that no register copies are needed); K is therefore staged a chunk ahead of V.
 template <int HS, int NW, int MODE>
-__global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_params p, int qtiles) {
+__global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_params p, int qtiles, int xcd_map) {
     constexpr int NS = HS / 16, NB = HS / 32, NKB = 2, CK = 64;
     constexpr int RB = HS * 2, SPR = HS / 8;                      // bytes / 16-byte slots of a K / V row
     constexpr int CB = CK * RB, NP = CB / 1024, PW = NP / NW;     // bytes of a chunk, 1 KB DMA pieces per chunk and matrix, pieces per wave
     static_assert(HS == 64 || HS == 128, "head sizes 64 / 128"); static_assert(PW >= 1 && NP % NW == 0, "DMA pieces");
-    uint8_t *const smem = fa_dyn_lds;                             // K [2][CB] | V [2][CB] | MODE 1: mask [NW][32 rows x 128 B]
+    uint8_t *const smem = fa_dyn_lds;                             // K [2][CB] | V [2][CB] | MODE 1: mask [NW][2][32 rows x 128 B]
     constexpr int K_OFF = 0, V_OFF = 2 * CB, M_OFF = 4 * CB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 31, h = lane >> 5;
     const uint32_t lds0 = CDNA4_LDS_BASE(smem);
     // work item of this work-group: consecutive items on one XCD (work-groups go to the XCDs round-robin)
-    int w = blockIdx.x;
-    if ((gridDim.x & 7) == 0) w = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    const int qt = w % qtiles, head = (w / qtiles) % p.n_head, b3 = w / (qtiles * p.n_head);
-    const int q0 = qt * (32 * NW) + 32 * wave;                    // (rows past the end repeat the last row and are not stored)
-    const int qi = min(q0 + n, p.n_q - 1);
+    // (work-groups go to the XCDs round-robin: XCD x = blockIdx % 8 runs its slot-th item, slot = blockIdx / 8).  Without a mask an XCD takes whole heads (their K / V
+    // are read from memory once); with one — the same mask tile for every head — it takes a quarter of the (batch, head) pairs x half of the query tiles, eight query
+    // tiles of four heads at a time, so that K / V chunks AND mask chunks are each shared by several work-groups of the XCD's L2 while they stream
+    // (first form: whole heads per XCD with a mask — 842 MB fetched beyond the L2 for 160 MB of operands, every mask request an L2 miss)
+    int qt, hb;
+    {
+        const int nwg = (int)gridDim.x, hbs = nwg / qtiles, x = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+        if (xcd_map == 1 && (qtiles & 1) == 0 && (hbs & 3) == 0) {
+            const int qh = qtiles >> 1, hq = hbs >> 2;             // query tiles / (batch, head) pairs of one XCD
+            hb = (x >> 1) * hq + slot / qh; qt = (x & 1) * qh + slot % qh;
+        } else {
+            const int w = (nwg & 7) == 0 ? x * (nwg >> 3) + slot : (int)blockIdx.x;
+            qt = w % qtiles; hb = w / qtiles;
+        }
+    }
+    const int head = hb % p.n_head, b3 = hb / p.n_head;
+    // a wave whose 32 rows would reach past the end takes the LAST 32 rows instead (n_q >= 32 here): it recomputes rows another wave also computes — a row's result does
+    // not depend on who computes it, both store the same bits — and nothing below has to clamp a query row
+    const int q0 = min(qt * (32 * NW) + 32 * wave, p.n_q - 32);
+    const int qi = q0 + n;
 
     half8_t qf[NS];
     fa_load_q<NS>(p, qi, head, b3, h, qf);
@@ -677,42 +692,60 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
     auto vsw = [](int row) { return HS == 128 ? (row & 3) : ((row >> 1) & 1); };
     // DMA piece j of a chunk = LDS cells 64 j .. 64 j + 63 (16 bytes each): lane l fills cell (row (64 j + l) / SPR, slot (64 j + l) % SPR); wave w moves pieces w, w + NW, ..
     // The source offsets of a whole chunk do not depend on the chunk: computed once.  A ragged last chunk clamps its rows (repeated rows, masked in the softmax).
-    auto kv_voff = [&](int i, bool is_v, int lim) __attribute__((always_inline)) {
+    // One source offset per matrix: piece i of a wave lies DR = 64 NW / SPR rows behind piece i - 1, a multiple of 16, which every swizzle above ignores — the row
+    // distance goes into the (scalar) base address.  The mask's four pieces: rows 8 i + l / 8, swizzle (row / 2) % 8 — pieces 0 / 2 and 1 / 3 share their offsets.
+    constexpr int DR = 64 * NW / SPR;
+    static_assert(PW == 1 || DR % 16 == 0, "piece stride vs swizzle period");
+    auto kv_voff = [&](int i, bool is_v, int lim) __attribute__((always_inline)) {      // (32-bit arithmetic: the launcher checked 64 rows' worth of stride)
         const int j = wave + NW * i, cell = 64 * j + lane, row = cell / SPR, sp = cell % SPR;
         const int slot = is_v ? ((((sp >> 2) ^ vsw(row)) << 2) | (sp & 3)) : (sp ^ ksw(row));
-        return (uint32_t)(min(row, lim) * (is_v ? p.v_nb1 : p.k_nb1) + 16 * slot);
+        return (uint32_t)min(row, lim) * (uint32_t)(is_v ? p.v_nb1 : p.k_nb1) + (uint32_t)(16 * slot);
     };
-    uint32_t kvoff[PW], vvoff[PW], moff[4];
+    const uint32_t kvoff = kv_voff(0, false, CK - 1), vvoff = kv_voff(0, true, CK - 1);
+    uint32_t moff[2];
 #pragma unroll
-    for (int i = 0; i < PW; i++) { kvoff[i] = kv_voff(i, false, CK - 1); vvoff[i] = kv_voff(i, true, CK - 1); }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 2; i++) {
         const int cell = 64 * i + lane, row = cell >> 3, sp = cell & 7;
-        moff[i] = (uint32_t)((int64_t)min(q0 + row, p.n_q - 1) * p.mask_nb1 + 16 * (sp ^ ((row >> 1) & 7)));
+        moff[i] = (uint32_t)(q0 + row) * (uint32_t)p.mask_nb1 + (uint32_t)(16 * (sp ^ ((row >> 1) & 7)));     // (the launcher checked n_q rows' worth of stride)
     }
-    auto dma_kv = [&](int c, int buf, bool is_v) __attribute__((always_inline)) {
+    auto dma_kv = [&](int c, int buf, bool is_v, bool whole) __attribute__((always_inline)) {      // whole: the caller knows that chunk c is not the last one
         const int lim = p.n_kv - 1 - CK * c;                      // last valid row of the chunk
-        const uint8_t *src = is_v ? vbase + (int64_t)(CK * c) * p.v_nb1 : kbase + (int64_t)(CK * c) * p.k_nb1;
+        const int64_t nb1 = is_v ? p.v_nb1 : p.k_nb1;
+        const uint8_t *src = (is_v ? vbase : kbase) + (int64_t)(CK * c) * nb1;
         const uint32_t dst = lds0 + (is_v ? V_OFF : K_OFF) + buf * CB + 1024 * wave;
-        if (lim >= CK - 1) {
+        if (whole || lim >= CK - 1) {
 #pragma unroll
-            for (int i = 0; i < PW; i++) CDNA4_DMA16(is_v ? vvoff[i] : kvoff[i], src, dst + 1024 * NW * i);
-        } else {
+            for (int i = 0; i < PW; i++) CDNA4_DMA16(is_v ? vvoff : kvoff, src + (int64_t)(DR * i) * nb1, dst + 1024 * NW * i);
+        } else {                                                  // ragged last chunk: rows past the end repeat the last one (masked in the softmax)
 #pragma unroll
             for (int i = 0; i < PW; i++) { const uint32_t vo = kv_voff(i, is_v, lim); CDNA4_DMA16(vo, src, dst + 1024 * NW * i); }
         }
     };
-    auto dma_mask = [&](int c) __attribute__((always_inline)) {
+    auto dma_mask = [&](int c) __attribute__((always_inline)) {      // chunk c's mask rows of this wave -> its buffer c % 2
         const uint8_t *src = (const uint8_t *)p.mask + 2 * (int64_t)(CK * c);
 #pragma unroll
-        for (int i = 0; i < 4; i++) CDNA4_DMA16(moff[i], src, lds0 + M_OFF + wave * 4096 + 1024 * i);
+        for (int i = 0; i < 4; i++) CDNA4_DMA16(moff[i & 1], src + (int64_t)(16 * (i >> 1)) * p.mask_nb1, lds0 + M_OFF + wave * 8192 + (c & 1) * 4096 + 1024 * i);
+    };
+    // the same requests one piece at a time, for the hot step (whole chunks): op 0 .. NOPS - 1 = [MODE 1: the four mask pieces of chunk c + 1,] the PW K pieces of chunk
+    // c + 2, the PW V pieces of chunk c + 1 — issued one per section of the score / softmax stretch instead of as a burst behind the barrier (eight pieces per wave
+    // back to back, from all eight waves at once, cost the 4096^2 case 170 us: an LDS-DMA piece occupies the wave's issue for 60 - 185 cycles)
+    constexpr int NOPS = (MODE == 1 ? 4 : 0) + 2 * PW;
+    auto dma_op = [&](int op, int c) __attribute__((always_inline)) {
+        if (MODE == 1 && op < 4) {
+            CDNA4_DMA16(moff[op & 1], (const uint8_t *)p.mask + 2 * (int64_t)(CK * (c + 1)) + (int64_t)(16 * (op >> 1)) * p.mask_nb1, lds0 + M_OFF + wave * 8192 + ((c + 1) & 1) * 4096 + 1024 * op);
+        } else {
+            const int i = (op - (MODE == 1 ? 4 : 0)) % PW; const bool is_v = (op - (MODE == 1 ? 4 : 0)) >= PW;
+            const int cc = is_v ? c + 1 : c + 2, buf = is_v ? (c + 1) & 1 : c & 1;
+            const int64_t nb1 = is_v ? p.v_nb1 : p.k_nb1;
+            CDNA4_DMA16(is_v ? vvoff : kvoff, (is_v ? vbase : kbase) + (int64_t)(CK * cc + DR * i) * nb1, lds0 + (is_v ? V_OFF : K_OFF) + buf * CB + 1024 * wave + 1024 * NW * i);
+        }
     };
     // this lane's share of the operand addresses: K fragment (kb, st) = row 32 kb + n, slot 2 st + h; V transpose read (b, kt, u) = row 16 kt + 8 u + 4 h + i / 4,
     // bytes 64 b + 32 g1 + 8 (i % 4) .. + 7 of the row (i = lane % 16, g1 = (lane / 16) % 2)
     const int ti = lane & 15, g1 = (lane >> 4) & 1;
     const int krow = n * RB, kx = ksw(n);
     const int vrow = (4 * h + (ti >> 2)) * RB + 32 * g1 + 8 * (ti & 3), vx = vsw(4 * h + (ti >> 2));
-    const uint8_t *const Mw = smem + M_OFF + wave * 4096 + n * 128;
+    const uint8_t *const Mw = smem + M_OFF + wave * 8192 + n * 128;        // (+ 4096 for odd chunks)
     const int mx8 = (n >> 1) & 7;
 
     const int nchunk = (p.n_kv + CK - 1) / CK, nfast = MODE == 2 ? 0 : p.n_kv / CK;
@@ -728,12 +761,15 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
         }
     };
     // chunk c: [top] request K(c + 2), V(c + 1) into the buffers the last barrier freed; scores of chunk c + 1 next to the softmax of chunk c (sc -> P); request mask(c + 1);
-    // O = O ms + V(c)^T P; all requests landed, barrier.  HOT: chunks c + 1, c + 2 exist and chunk c is a whole chunk on the fast path — no branches around the MFMA / VALU mix.
+    // O = O ms + V(c)^T P; all requests landed, barrier.  HOT: chunks c + 1, c + 2 exist and are not the last, chunk c is a whole chunk on the fast path — no branches around the MFMA / VALU mix.
     auto step = [&](int c, floatx16 (&sc)[NKB], floatx16 (&sn)[NKB], auto hot_tag) __attribute__((always_inline)) {
         constexpr bool HOT = decltype(hot_tag)::value;
         const bool fast = HOT || c < nfast;
-        if (HOT || c + 2 < nchunk) dma_kv(c + 2, c & 1, false);
-        if (HOT || c + 1 < nchunk) dma_kv(c + 1, (c + 1) & 1, true);
+        if constexpr (!HOT) {
+            if (c + 2 < nchunk) dma_kv(c + 2, c & 1, false, false);
+            if (c + 1 < nchunk) dma_kv(c + 1, (c + 1) & 1, true, false);
+            if constexpr (MODE == 1) { if (c + 1 < nfast) dma_mask(c + 1); }       // (its buffer was last read by the softmax of chunk c - 1, in front of the last barrier)
+        }
         half8_t pf[NKB * 2];
         float ms;
         if constexpr (HOT) {
@@ -749,7 +785,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
             auto mask_groups = [&](int sl) __attribute__((always_inline)) {
                 if constexpr (MODE == 1) {
 #pragma unroll
-                    for (int g = GS * sl; g < GS * (sl + 1); g++) mreg[g] = *reinterpret_cast<const half4_t *>(Mw + 16 * (g ^ mx8) + 8 * h);
+                    for (int g = GS * sl; g < GS * (sl + 1); g++) mreg[g] = *reinterpret_cast<const half4_t *>(Mw + (c & 1) * 4096 + 16 * (g ^ mx8) + 8 * h);
                 }
             };
             mask_groups(0);
@@ -766,6 +802,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
             for (int m = 0; m < NM; m++) {
                 if (m + 2 < NM) kf[m + 2] = kfrag(m + 2);
                 sn[m / NS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[m], qf[m % NS], sn[m / NS], 0, 0, 0);
+#pragma unroll
+                for (int op = m * NOPS / NM; op < (m + 1) * NOPS / NM; op++) dma_op(op, c);      // (NOPS requests spread evenly over the NM sections)
                 if (m < NM / 2) {                                   // slice m of the first half: 2 SL scores
                     if (m + 1 < NM / 2) mask_groups(m + 1);
 #pragma unroll
@@ -793,7 +831,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
             }
             sum = fa_sum_xor32(sum);
             S = S * ms + sum;
-            if constexpr (MODE == 1) { CDNA4_WAIT_LGKM0(); CDNA4_WAVE_LDS_SYNC(); dma_mask(c + 1); }     // (this wave's reads of mask(c) have returned)
         } else {
             if (c + 1 < nchunk) scores(c + 1, sn);
             half4_t mreg[NKB * 4] = {};
@@ -802,12 +839,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
 #pragma unroll
                     for (int kb = 0; kb < NKB; kb++)
 #pragma unroll
-                        for (int g = 0; g < 4; g++) mreg[kb * 4 + g] = *reinterpret_cast<const half4_t *>(Mw + 16 * ((4 * kb + g) ^ mx8) + 8 * h);
+                        for (int g = 0; g < 4; g++) mreg[kb * 4 + g] = *reinterpret_cast<const half4_t *>(Mw + (c & 1) * 4096 + 16 * ((4 * kb + g) ^ mx8) + 8 * h);
                 }
                 ms = fa_softmax_fast<NKB, MODE == 1>(sc, mreg, c2, mslope, M, S, pf);
-                if constexpr (MODE == 1) {
-                    if (c + 1 < nfast) { CDNA4_WAIT_LGKM0(); CDNA4_WAVE_LDS_SYNC(); dma_mask(c + 1); }     // (this wave's reads of mask(c) have returned)
-                }
             } else {
                 fattn_params pg = p; pg.mask_vec = 0;               // (element-wise path: mreg is not filled here)
                 ms = fa_softmax_blocks<NKB>(pg, sc, CK * c, h, mrow, slope2, mreg, M, S, pf);
@@ -833,8 +867,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
         __syncthreads();                                          // everyone is done with K(c + 1)'s and V(c)'s reads; K(c + 2), V(c + 1), mask(c + 1) are in LDS
     };
 
-    dma_kv(0, 0, false); dma_kv(0, 0, true);
-    if (nchunk > 1) dma_kv(1, 1, false);
+    dma_kv(0, 0, false, false); dma_kv(0, 0, true, false);
+    if (nchunk > 1) dma_kv(1, 1, false, false);
     if constexpr (MODE == 1) { if (nfast > 0) dma_mask(0); }
     CDNA4_WAIT_VM(0);
     __syncthreads();
@@ -842,12 +876,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
     scores(0, sa);
     __syncthreads();                                              // K(0) has been read by every wave: chunk 0's step may overwrite it with K(2)
     int c = 0;
-    for (; c + 3 < nchunk && c + 1 < nfast; c += 2) { step(c, sa, sb, fa_true{}); step(c + 1, sb, sa, fa_true{}); }
+    for (; c + 4 < nchunk && c + 1 < nfast; c += 2) { step(c, sa, sb, fa_true{}); step(c + 1, sb, sa, fa_true{}); }       // (chunks c .. c + 3 are whole chunks, not the last)
     for (; c + 1 < nchunk; c += 2) { step(c, sa, sb, fa_false{}); step(c + 1, sb, sa, fa_false{}); }
     if (c < nchunk) step(c, sa, sb, fa_false{});
-    if (q0 + n < p.n_q) fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + (q0 + n)) * p.n_head + head) * HS, o, 1.0f / S, h);
+    fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + qi) * p.n_head + head) * HS, o, 1.0f / S, h);
 }
-template <int HS, int NW, int MODE> constexpr int k_flash_attn_pipe_lds() { return 4 * 64 * HS * 2 + (MODE == 1 ? NW * 4096 : 0); }
+template <int HS, int NW, int MODE> constexpr int k_flash_attn_pipe_lds() { return 4 * 64 * HS * 2 + (MODE == 1 ? NW * 8192 : 0); }
 
 #define NEED(cond, msg) do { if (!(cond)) return cdna4_set_error_msg(msg); } while (0)
 typedef ggml_cdna4_tensor T4;
@@ -970,20 +1004,22 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
         int nw = e ? atoi(e) : -1;
         if (nw < 0) {
             nw = 0;
-            for (int c = 8; c >= 2 && !nw; c >>= 1)
+            for (int c = 8; c >= (D == 128 ? 4 : 2) && !nw; c >>= 1)          // (head size 128 has no 2-wave form: its DMA pieces would straddle the K swizzle's period)
                 if (((N + 32 * c - 1) / (32 * c)) * H * B3 >= cus) nw = c;
         }
-        if (nw == 2 || nw == 4 || nw == 8) {
+        if ((nw == 2 && D == 64) || nw == 4 || nw == 8) {
             const int64_t qtiles = (N + 32 * nw - 1) / (32 * nw), items = qtiles * H * B3;
             NEED(items < (1ll << 31), "flash_attn_ext: too many query tiles for one grid");
+            NEED(k->nb[1] < (1ll << 25) && v->nb[1] < (1ll << 25) && (!mask || (N + 16) * mask->nb[1] < (1ll << 32)), "flash_attn_ext: row strides beyond the pipelined kernel's 32-bit offsets");
+            const int xcd_map = getenv("CDNA4_FA_MAP") ? atoi(getenv("CDNA4_FA_MAP")) : (mask ? 1 : 0);     // (A/B knob; see the kernel)
             const int mode = (logit_softcap != 0.0f || !(p.scale > 0.0f) || (mask && !p.mask_vec)) ? 2 : (mask ? 1 : 0);
 #define FA_PIPE3(HS_, NW_, MODE_) do { constexpr int lds_ = k_flash_attn_pipe_lds<HS_, NW_, MODE_>(); static bool raised_ = false;                                \
                 if (lds_ > 64 * 1024 && !raised_) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_flash_attn_pipe<HS_, NW_, MODE_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) { \
                     (void)hipGetLastError(); return cdna4_set_error_msg("flash_attn_ext: cannot raise the dynamic LDS limit"); } raised_ = true; }                \
-                hipLaunchKernelGGL((k_flash_attn_pipe<HS_, NW_, MODE_>), dim3((unsigned)items), dim3(64 * NW_), lds_, st, p, (int)qtiles); } while (0)
+                hipLaunchKernelGGL((k_flash_attn_pipe<HS_, NW_, MODE_>), dim3((unsigned)items), dim3(64 * NW_), lds_, st, p, (int)qtiles, xcd_map); } while (0)
 #define FA_PIPE(HS_, NW_) do { if (mode == 0) FA_PIPE3(HS_, NW_, 0); else if (mode == 1) FA_PIPE3(HS_, NW_, 1); else FA_PIPE3(HS_, NW_, 2); } while (0)
             if (D == 64) { if (nw == 8) FA_PIPE(64, 8); else if (nw == 4) FA_PIPE(64, 4); else FA_PIPE(64, 2); }
-            else { if (nw == 8) FA_PIPE(128, 8); else if (nw == 4) FA_PIPE(128, 4); else FA_PIPE(128, 2); }
+            else { if (nw == 8) FA_PIPE(128, 8); else FA_PIPE(128, 4); }
 #undef FA_PIPE3
 #undef FA_PIPE
             CDNA4_CHECK_LAUNCH();

@@ -22,6 +22,7 @@ H = 32
 shapes = [(4096, 4096), (2048, 2048), (1024, 1024), (512, 512), (512, 4096), (256, 2048)]
 if os.environ.get("FA_AB_SHAPES"): shapes = [tuple(int(x) for x in s_.split("x")) for s_ in os.environ["FA_AB_SHAPES"].split(",")]
 settings = [("0", "older"), (None, "auto"), ("8", "pipe8"), ("4", "pipe4"), ("2", "pipe2")]
+if os.environ.get("FA_AB_SETTINGS"): settings = [s_ for s_ in settings if s_[1] in os.environ["FA_AB_SETTINGS"].split(",")]
 for D in ([int(a) for a in sys.argv[1:]] or [128, 64]):
     for n_q, n_kv in shapes:
         g = torch.Generator().manual_seed(1)
