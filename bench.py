@@ -539,8 +539,15 @@ def widening_rows(dev, steps):
     for t in (6, 11, 10):
         fmt(t)
     rng = np.random.default_rng(11)
-    hs, nh = 128, 32
-    for n_q, n_kv in ((4096, 4096), (512, 512), (1, 4096), (1, 32768)):
+    nh = 32
+    def pipe_name(hs, n_q, n_kv, masked):               # the launcher's rule (fattn.hip: fa_f16): the tallest query tile that gives every CU a work-group
+        for nw in ((8, 4) if hs == 128 else (8, 4, 2)):
+            if (n_q + 32 * nw - 1) // (32 * nw) * nh >= 256:
+                return "k_flash_attn_pipe<%d, %d, %d>" % (hs, nw, 1 if masked else 0)
+        if hs == 128 and n_kv <= 1024 and (n_q + 127) // 128 * nh >= 128:
+            return "k_flash_attn_pipe<128, 4, %d>" % (1 if masked else 0)
+        return "k_flash_attn_split<%d>" % hs
+    for hs, n_q, n_kv, masked in ((128, 4096, 4096, True), (128, 4096, 4096, False), (64, 4096, 4096, True), (128, 1024, 1024, True), (128, 512, 512, True), (128, 1, 4096, True), (128, 1, 32768, True)):
         q = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_q, hs)).astype(np.float32)).to(dev)
         kk = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_kv, hs)).astype(np.float16)).to(dev)
         vv = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_kv, hs)).astype(np.float16)).to(dev)
@@ -549,16 +556,18 @@ def widening_rows(dev, steps):
         dq, dk, dv, dd = (ops._tensor_desc(t_, ty) for t_, ty in ((q, 0), (kk, 1), (vv, 1), (o, 0)))      # straight to the C-ABI (python's part
         dm = ops._tensor_desc(mk.view(1, 1, *mk.shape), 1)                                          # of a call would exceed the decode kernel)
         st, L, sc = torch.cuda.current_stream(dev).cuda_stream, native.lib(), float(1.0 / np.sqrt(hs))
-        us = events_us(lambda: native.check(L.ggml_cdna4_op_flash_attn_ext(C.byref(dq), C.byref(dk), C.byref(dv), C.byref(dm), C.byref(dd), sc, 0.0, 0.0, st)), max(20, steps // 4), 5)
+        pm = C.byref(dm) if masked else None
+        us = events_us(lambda: native.check(L.ggml_cdna4_op_flash_attn_ext(C.byref(dq), C.byref(dk), C.byref(dv), pm, C.byref(dd), sc, 0.0, 0.0, st)), max(20, steps // 4), 5)
         row = {"us_per_call": round(us, 2)}
         if n_q > 32:
             tf = 4.0 * nh * n_q * n_kv * hs / us / 1e6
-            row.update(tflops=round(tf, 1), frac_of_mfma_roof=round(tf / MFMA_F16_PEAK_TFLOPS, 4), kernel="k_flash_attn_wide64<128>" if (n_q + 127) // 128 * nh >= 256 else "k_flash_attn_split<128>")
+            row.update(tflops=round(tf, 1), frac_of_mfma_roof=round(tf / MFMA_F16_PEAK_TFLOPS, 4), kernel=pipe_name(hs, n_q, n_kv, masked))
         else:
             gb = 4.0 * nh * n_kv * hs / us / 1e3
             row.update(kv_GBps=round(gb, 1), frac_of_hbm_roof=round(gb / HBM_PEAK_GBS, 4), kernel="k_flash_attn_split<128> + k_flash_attn_merge<128>")
-        out["flash_attn_ext"]["hs128_h32_q%d_kv%d" % (n_q, n_kv)] = row
-        leg_row("flash_attn_ext", "hs128_h32_q%d_kv%d" % (n_q, n_kv), row)
+        name = "hs%d_h32_q%d_kv%d%s" % (hs, n_q, n_kv, "" if masked else "_no_mask")
+        out["flash_attn_ext"][name] = row
+        leg_row("flash_attn_ext", name, row)
     # decode over a QUANTIZED KV cache (Q8_0 / Q4_0 rows read by the key-split kernel's dequantizing operand loads): against the HBM roof on the
     # cache bytes actually read (34 / 18 bytes per 32 elements, K + V once)
     def block_rows(bb, nrows):                                        # random block rows: fp16 d = 1/64 in front of bb - 2 random quant bytes per 32 elements
@@ -566,7 +575,7 @@ def widening_rows(dev, steps):
         a[:, :, 0:2] = np.frombuffer(np.float16(1.0 / 64).tobytes(), dtype=np.uint8)
         return a.reshape(nrows, hs // 32 * bb)
     for tname, t, bb in (("q8_0", 8, 34), ("q4_0", 2, 18)):
-        n_q, n_kv = 1, 32768
+        hs, n_q, n_kv = 128, 1, 32768
         rb = hs // 32 * bb
         q = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_q, hs)).astype(np.float32)).to(dev)
         kk = torch.from_numpy(block_rows(bb, nh * n_kv).reshape(1, nh, n_kv, rb)).to(dev)

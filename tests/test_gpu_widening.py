@@ -179,6 +179,27 @@ def test_flash_attn_ext_variants(gu, kw):
     _fa_case(gu, **kw)
 
 
+_PIPE_CASES = [dict(D=128, n_q=300, n_head=4, n_kv=576), dict(D=64, n_q=130, n_head=4, n_kv=400, mask=False), dict(D=128, n_q=133, n_head=4, n_kv=328, n_head_kv=2, max_bias=8.0),
+               dict(D=64, n_q=100, n_head=3, n_kv=606, n_head_kv=1, inf_every=5), dict(D=64, n_q=290, n_head=2, n_kv=191, softcap=10.0), dict(D=128, n_q=70, n_head=2, n_kv=201),
+               dict(D=128, n_q=260, n_head=2, n_kv=257, n_batch=2, permuted=True), dict(D=64, n_q=33, n_head=2, n_kv=40), dict(D=128, n_q=64, n_head=1, n_kv=64), dict(D=64, n_q=512, n_head=2, n_kv=1024, n_head_kv=1)]
+
+
+@pytest.mark.parametrize("kw", _PIPE_CASES)
+def test_flash_attn_ext_pipelined_kernel(gu, monkeypatch, kw):
+    """k_flash_attn_pipe (round 6: K / V / mask by LDS-DMA, V through the LDS transpose read, scores a chunk ahead of the softmax) forced onto test-sized shapes with 8 / 4 / 2 waves
+    per work-group (CDNA4_FA_PIPE; head size 128 has no 2-wave form): the bars of every FLASH_ATTN_EXT case here, one result whatever the tile height, and 2e-5 from the older
+    kernels' result where both use 64-key chunks.  Cases: many chunks (the unrolled hot loop), ragged key counts (the element-wise last chunk), no mask, ALiBi, -inf stretches,
+    softcap (the general mode), grouped heads, batches, permuted tensors, fewer than 64 keys, one chunk, query counts that are no multiple of any tile."""
+    ys = {}
+    for nw in ((8, 4) if kw["D"] == 128 else (8, 4, 2)):
+        monkeypatch.setenv("CDNA4_FA_PIPE", str(nw))
+        ys[nw] = _fa_case(gu, **kw)
+    assert all(np.array_equal(ys[8], y) for y in ys.values())
+    monkeypatch.setenv("CDNA4_FA_PIPE", "0")
+    y0 = _fa_case(gu, **kw)
+    assert R.rel_l2(ys[8], y0) < 5e-4                                   # (the key-split kernel walks 32-key chunks: another rounding order)
+
+
 def test_flash_attn_ext_is_deterministic_and_row_independent(gu):
     """a query row's result does not depend on its neighbours in the tile or on the launch (no atomics, fixed merge order)"""
     from ggml_amd import ops
