@@ -766,6 +766,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
     const int mx8 = (n >> 1) & 7;
 
     const int nchunk = (p.n_kv + CK - 1) / CK, nfast = MODE == 2 ? 0 : p.n_kv / CK;
+#ifdef FA_STAMP
+    uint32_t stamp[6] = {};
+#endif
     auto scores = [&](int c, floatx16 (&s)[NKB]) __attribute__((always_inline)) {
         const uint8_t *Kc = smem + K_OFF + (c & 1) * CB;
 #pragma unroll
@@ -789,6 +792,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
         }
         half8_t pf[NKB * 2];
         float ms;
+#ifdef FA_STAMP
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        uint64_t t1 = t0, t2 = t0, t3 = t0, t4 = t0;
+#endif
         if constexpr (HOT) {
             // The issue order is written out: a wave issues in order, so what is to run beside an MFMA has to stand behind it in the instruction stream, and hipcc's
             // scheduler left to itself puts the 16 score MFMAs of chunk c + 1 in front of the whole softmax of chunk c.  Sixteen sections, fenced by sched_barrier(0):
@@ -805,7 +812,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
                     for (int g = GS * sl; g < GS * (sl + 1); g++) mreg[g] = *reinterpret_cast<const half4_t *>(Mw + (c & 1) * 4096 + 16 * (g ^ mx8) + 8 * h);
                 }
             };
-            mask_groups(0);
+            constexpr int MPF = NM / 2;                             // mask groups requested this many slices ahead (all of them at the top: one slice ahead left every slice of
+#pragma unroll                                                      // the first half waiting a full LDS round trip — 2,190 - 2,870 cycles for the half against 600 - 1,100 without a mask)
+            for (int sl = 0; sl < MPF && sl < NM / 2; sl++) mask_groups(sl);
             half8_t kf[NM];
             kf[0] = kfrag(0); kf[1] = kfrag(1);
 #pragma unroll
@@ -822,7 +831,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
 #pragma unroll
                 for (int op = m * NOPS / NM; op < (m + 1) * NOPS / NM; op++) dma_op(op, c);      // (NOPS requests spread evenly over the NM sections)
                 if (m < NM / 2) {                                   // slice m of the first half: 2 SL scores
-                    if (m + 1 < NM / 2) mask_groups(m + 1);
+                    if (m + MPF < NM / 2) mask_groups(m + MPF);
 #pragma unroll
                     for (int e = 2 * SL * m; e < 2 * SL * (m + 1); e++) {
                         const int kb = e >> 4, r = e & 15;
@@ -845,7 +854,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef FA_STAMP
+                if (m == NM / 2 - 1) t1 = __builtin_amdgcn_s_memtime();
+#endif
             }
+#ifdef FA_STAMP
+            t2 = __builtin_amdgcn_s_memtime();
+#endif
             sum = fa_sum_xor32(sum);
             S = S * ms + sum;
         } else {
@@ -880,8 +895,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
                 const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kt], o[b], 0, 0, 0);
             }
+#ifdef FA_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        t3 = __builtin_amdgcn_s_memtime();
+#endif
         CDNA4_WAIT_VM(0);
+#ifdef FA_STAMP
+        t4 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();                                          // everyone is done with K(c + 1)'s and V(c)'s reads; K(c + 2), V(c + 1), mask(c + 1) are in LDS
+#ifdef FA_STAMP
+        if (HOT) { const uint64_t t5 = __builtin_amdgcn_s_memtime(); stamp[0] += (uint32_t)(t1 - t0); stamp[1] += (uint32_t)(t2 - t1); stamp[2] += (uint32_t)(t3 - t2); stamp[3] += (uint32_t)(t4 - t3); stamp[4] += (uint32_t)(t5 - t4); stamp[5]++; }
+#endif
     };
 
     dma_kv(0, 0, false, false); dma_kv(0, 0, true, false);
@@ -896,6 +921,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
     for (; c + 4 < nchunk && c + 1 < nfast; c += 2) { step(c, sa, sb, fa_true{}); step(c + 1, sb, sa, fa_true{}); }       // (chunks c .. c + 3 are whole chunks, not the last)
     for (; c + 1 < nchunk; c += 2) { step(c, sa, sb, fa_false{}); step(c + 1, sb, sa, fa_false{}); }
     if (c < nchunk) step(c, sa, sb, fa_false{});
+#ifdef FA_STAMP
+    if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0 && (wave == 0 || wave == 5))
+        printf("FA_STAMP block %d wave %d hot steps %u: first half %u | second half %u | rescale + PV %u | vmcnt %u | barrier %u cycles per step\n", (int)blockIdx.x, wave, stamp[5],
+               stamp[0] / stamp[5], stamp[1] / stamp[5], stamp[2] / stamp[5], stamp[3] / stamp[5], stamp[4] / stamp[5]);
+#endif
     fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + qi) * p.n_head + head) * HS, o, 1.0f / S, h);
 }
 template <int HS, int NW, int MODE> constexpr int k_flash_attn_pipe_lds() { return 4 * 64 * HS * 2 + (MODE == 1 ? NW * 8192 : 0); }

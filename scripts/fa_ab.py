@@ -29,11 +29,12 @@ for D in ([int(a) for a in sys.argv[1:]] or [128, 64]):
         q = (torch.rand((1, H, n_q, D), generator=g) * 2 - 1).cuda()
         k = (torch.rand((1, H, n_kv, D), generator=g) * 2 - 1).half().cuda()
         v = (torch.rand((1, H, n_kv, D), generator=g) * 2 - 1).half().cuda()
-        m = (torch.rand(((n_q + 63) // 64 * 64, n_kv), generator=g) * 2 - 1).half().cuda()
+        mpad = int(os.environ.get("FA_AB_MASK_PAD", "0"))              # extra elements per mask row (a row stride that is no power of two)
+        m = (torch.rand(((n_q + 63) // 64 * 64, n_kv + mpad), generator=g) * 2 - 1).half().cuda()[:, :n_kv]
         sc = float(1.0 / np.sqrt(D))
-        o = ops.flash_attn_ext(q, k, v, m, sc)
+        o = ops.flash_attn_ext(q, k, v, m.contiguous(), sc)            # (the output buffer; the timed calls hand the strided mask to the C-ABI themselves)
         dq, dk, dv, dd = (ops._tensor_desc(t_, ty) for t_, ty in ((q, 0), (k, 1), (v, 1), (o, 0)))
-        dm = ops._tensor_desc(m.view(1, 1, *m.shape), 1)
+        dm = ops._tensor_desc(m[None, None], 1)
         st, L = torch.cuda.current_stream().cuda_stream, native.lib()
         pm = None if os.environ.get("FA_AB_NOMASK") else C.byref(dm)
         call = lambda: native.check(L.ggml_cdna4_op_flash_attn_ext(C.byref(dq), C.byref(dk), C.byref(dv), pm, C.byref(dd), sc, 0.0, 0.0, st))
