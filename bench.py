@@ -547,11 +547,13 @@ def widening_rows(dev, steps):
         if hs == 128 and n_kv <= 1024 and (n_q + 127) // 128 * nh >= 128:
             return "k_flash_attn_pipe<128, 4, %d>" % (1 if masked else 0)
         return "k_flash_attn_split<%d>" % hs
-    for hs, n_q, n_kv, masked in ((128, 4096, 4096, True), (128, 4096, 4096, False), (64, 4096, 4096, True), (128, 1024, 1024, True), (128, 512, 512, True), (128, 1, 4096, True), (128, 1, 32768, True)):
+    for hs, n_q, n_kv, masked in ((128, 4096, 4096, True), (128, 4096, 4096, "causal"), (128, 4096, 4096, False), (64, 4096, 4096, True), (128, 1024, 1024, True), (128, 512, 512, True), (128, 1, 4096, True), (128, 1, 32768, True)):
         q = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_q, hs)).astype(np.float32)).to(dev)
         kk = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_kv, hs)).astype(np.float16)).to(dev)
         vv = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_kv, hs)).astype(np.float16)).to(dev)
         mk = torch.from_numpy(rng.uniform(-1, 1, ((n_q + 63) // 64 * 64, n_kv)).astype(np.float16)).to(dev)
+        if masked == "causal":                                          # what a prefill graph passes: 0 on and below the diagonal, -inf above (half of the key chunks are skipped)
+            mk = torch.triu(torch.full((n_q, n_kv), float("-inf"), dtype=torch.float16, device=dev), diagonal=1)
         o = ops.flash_attn_ext(q, kk, vv, mk, 1.0 / np.sqrt(hs))                                   # checks the arguments once; the timed calls go
         dq, dk, dv, dd = (ops._tensor_desc(t_, ty) for t_, ty in ((q, 0), (kk, 1), (vv, 1), (o, 0)))      # straight to the C-ABI (python's part
         dm = ops._tensor_desc(mk.view(1, 1, *mk.shape), 1)                                          # of a call would exceed the decode kernel)
@@ -561,11 +563,14 @@ def widening_rows(dev, steps):
         row = {"us_per_call": round(us, 2)}
         if n_q > 32:
             tf = 4.0 * nh * n_q * n_kv * hs / us / 1e6
-            row.update(tflops=round(tf, 1), frac_of_mfma_roof=round(tf / MFMA_F16_PEAK_TFLOPS, 4), kernel=pipe_name(hs, n_q, n_kv, masked))
+            row.update(tflops=round(tf, 1), frac_of_mfma_roof=round(tf / MFMA_F16_PEAK_TFLOPS, 4), kernel=pipe_name(hs, n_q, n_kv, bool(masked)))
         else:
             gb = 4.0 * nh * n_kv * hs / us / 1e3
             row.update(kv_GBps=round(gb, 1), frac_of_hbm_roof=round(gb / HBM_PEAK_GBS, 4), kernel="k_flash_attn_split<128> + k_flash_attn_merge<128>")
-        name = "hs%d_h32_q%d_kv%d%s" % (hs, n_q, n_kv, "" if masked else "_no_mask")
+        if masked == "causal":
+            row.update(note="tflops / frac count the FULL 4 n_head n_q n_kv hs; about half of the key chunks are -inf for their whole query tile and are not walked "
+                            "(k_fa_mask_flags + chunk list, bit-identical to walking them)")
+        name = "hs%d_h32_q%d_kv%d%s" % (hs, n_q, n_kv, "_causal_mask" if masked == "causal" else ("" if masked else "_no_mask"))
         out["flash_attn_ext"][name] = row
         leg_row("flash_attn_ext", name, row)
     # decode over a QUANTIZED KV cache (Q8_0 / Q4_0 rows read by the key-split kernel's dequantizing operand loads): against the HBM roof on the

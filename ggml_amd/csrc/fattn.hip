@@ -644,6 +644,37 @@ __device__ __forceinline__ float fa_softmax_fast(floatx16 (&s)[NKB], const half4
     return ms;
 }
 
+// Which 64-key chunks does a query tile need at all?  A chunk whose mask entries are -inf for every row the tile's waves compute contributes P = 0, leaves (M, S) as they
+// are and multiplies O by 2^0: skipping it is bit-neutral — and it is what the reference does entry by entry (`if (mv == -INFINITY) continue`, ggml-cpu.c:10935-10938).  Under
+// a causal mask that is half of all chunks.  flags[tile][chunk] = 1 iff some entry of (the tile's rows) x (the chunk's keys) is not -inf; one work-group per (chunk, tile), which
+// stops at the first such entry (a mask without -inf stretches costs one 16-byte load per lane).  Rows: the tile's own and — ragged last tile — the rows its waves take instead
+// (k_flash_attn_pipe: the last 32).
+__global__ __launch_bounds__(256) void k_fa_mask_flags(const fattn_params p, int tile_rows, int nchunk, uint8_t *flags) {
+    __shared__ int any;
+    const int tid = threadIdx.x, c = blockIdx.x, t = blockIdx.y;
+    const int r_lo = min(t * tile_rows, max(p.n_q - 32, 0)), r_hi = min((t + 1) * tile_rows, p.n_q);
+    if (tid == 0) any = 0;
+    __syncthreads();
+    const int col = 64 * c + 8 * (tid & 7);
+    for (int r0 = r_lo; r0 < r_hi; r0 += 32) {
+        const int r = r0 + (tid >> 3);
+        bool mine = false;
+        if (r < r_hi && col < p.n_kv) {
+            const uint16_t *row = (const uint16_t *)(p.mask + (int64_t)r * p.mask_nb1) + col;
+            if (col + 8 <= p.n_kv) {
+                const u32x4 w = *reinterpret_cast<const u32x4 *>(row);
+                mine = w.x != 0xFC00FC00u || w.y != 0xFC00FC00u || w.z != 0xFC00FC00u || w.w != 0xFC00FC00u;
+            } else {
+                for (int e = 0; col + e < p.n_kv; e++) mine = mine || row[e] != 0xFC00u;
+            }
+        }
+        if (mine) any = 1;
+        __syncthreads();
+        if (any) break;                                             // (uniform: read behind the barrier)
+    }
+    if (tid == 0) flags[(int64_t)t * nchunk + c] = (uint8_t)(any != 0);
+}
+
 struct fa_true { static constexpr bool value = true; };
 struct fa_false { static constexpr bool value = false; };
 // MODE 0: no mask, no softcap, scale > 0; 1: the same with a 16-byte-aligned mask, staged through LDS (below); 2: everything else (fa_softmax_blocks on every chunk)
@@ -657,18 +688,18 @@ struct fa_false { static constexpr bool value = false; };
 //     instruction streams of one wave, which the matrix pipe and the VALU execute side by side — then P(c) V(c).  Two score accumulators alternate (the loop is unrolled
 //     by two so that no register copies are needed); K is therefore staged a chunk ahead of V.
 template <int HS, int NW, int MODE>
-__global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_params p, int qtiles, int xcd_map) {
+__global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_params p, int qtiles, int xcd_map, const uint8_t *flags) {
     constexpr int NS = HS / 16, NB = HS / 32, NKB = 2, CK = 64;
     constexpr int RB = HS * 2, SPR = HS / 8;                      // bytes / 16-byte slots of a K / V row
     constexpr int CB = CK * RB, NP = CB / 1024, PW = NP / NW;     // bytes of a chunk, 1 KB DMA pieces per chunk and matrix, pieces per wave
     static_assert(HS == 64 || HS == 128, "head sizes 64 / 128"); static_assert(PW >= 1 && NP % NW == 0, "DMA pieces");
-    uint8_t *const smem = fa_dyn_lds;                             // K [2][CB] | V [2][CB] | MODE 1: mask [NW][2][32 rows x 128 B]
-    constexpr int K_OFF = 0, V_OFF = 2 * CB, M_OFF = 4 * CB;
+    uint8_t *const smem = fa_dyn_lds;                             // K [2][CB] | V [2][CB] | MODE 1: mask [NW][2][32 rows x 128 B] | chunk list: count, ids (uint16 x 4096)
+    constexpr int K_OFF = 0, V_OFF = 2 * CB, M_OFF = 4 * CB, L_OFF = 4 * CB + (MODE == 1 ? NW * 8192 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 31, h = lane >> 5;
     const uint32_t lds0 = CDNA4_LDS_BASE(smem);
     // work item of this work-group: consecutive items on one XCD (work-groups go to the XCDs round-robin)
     // (work-groups go to the XCDs round-robin: XCD x = blockIdx % 8 runs its slot-th item, slot = blockIdx / 8).  Without a mask an XCD takes whole heads (their K / V
-    // are read from memory once); with one — the same mask tile for every head — it takes a quarter of the (batch, head) pairs x half of the query tiles, eight query
+    // are read from memory once); with one — the same mask tile for every head — it takes a quarter of the (batch, head) pairs x every second query tile, eight query
     // tiles of four heads at a time, so that K / V chunks AND mask chunks are each shared by several work-groups of the XCD's L2 while they stream
     // (first form: whole heads per XCD with a mask — 842 MB fetched beyond the L2 for 160 MB of operands, every mask request an L2 miss)
     int qt, hb;
@@ -676,7 +707,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
         const int nwg = (int)gridDim.x, hbs = nwg / qtiles, x = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
         if (xcd_map == 1 && (qtiles & 1) == 0 && (hbs & 3) == 0) {
             const int qh = qtiles >> 1, hq = hbs >> 2;             // query tiles / (batch, head) pairs of one XCD
-            hb = (x >> 1) * hq + slot / qh; qt = (x & 1) * qh + slot % qh;
+            // query tiles of one parity per XCD, the LAST tile first: under a causal mask tile t walks t + 1 times as many chunks as tile 0 — halves of the tile range
+            // per XCD left the upper half's XCDs with 2.8 times the work (255 us at 4096^2); late work-groups should be the short ones
+            // (the dispatcher seems to stripe work-groups over a few queues per XCD before they find a free CU: tile heights that descend with the slot gave 256 us like the
+            // unbalanced halves did.  The order below — 7 5 3 1 0 2 4 6 for eight tiles, rotated by the head — gives every residue class of the slot mod 2 / 4 the same work.)
+            const int j = (slot % qh + slot / qh) % qh, rank = (qh & 1) ? j : (j < qh / 2 ? qh - 1 - 2 * j : 2 * (j - qh / 2));
+            hb = (x >> 1) * hq + slot / qh; qt = 2 * rank + (x & 1);
         } else {
             const int w = (nwg & 7) == 0 ? x * (nwg >> 3) + slot : (int)blockIdx.x;
             qt = w % qtiles; hb = w / qtiles;
@@ -738,21 +774,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
             for (int i = 0; i < PW; i++) { const uint32_t vo = kv_voff(i, is_v, lim); CDNA4_DMA16(vo, src, dst + 1024 * NW * i); }
         }
     };
-    auto dma_mask = [&](int c) __attribute__((always_inline)) {      // chunk c's mask rows of this wave -> its buffer c % 2
+    auto dma_mask = [&](int c, int buf) __attribute__((always_inline)) {      // chunk c's mask rows of this wave -> its buffer buf
         const uint8_t *src = (const uint8_t *)p.mask + 2 * (int64_t)(CK * c);
 #pragma unroll
-        for (int i = 0; i < 4; i++) CDNA4_DMA16(moff[i & 1], src + (int64_t)(16 * (i >> 1)) * p.mask_nb1, lds0 + M_OFF + wave * 8192 + (c & 1) * 4096 + 1024 * i);
+        for (int i = 0; i < 4; i++) CDNA4_DMA16(moff[i & 1], src + (int64_t)(16 * (i >> 1)) * p.mask_nb1, lds0 + M_OFF + wave * 8192 + buf * 4096 + 1024 * i);
     };
     // the same requests one piece at a time, for the hot step (whole chunks): op 0 .. NOPS - 1 = [MODE 1: the four mask pieces of chunk c + 1,] the PW K pieces of chunk
     // c + 2, the PW V pieces of chunk c + 1 — issued one per section of the score / softmax stretch instead of as a burst behind the barrier (eight pieces per wave
     // back to back, from all eight waves at once, cost the 4096^2 case 170 us: an LDS-DMA piece occupies the wave's issue for 60 - 185 cycles)
     constexpr int NOPS = (MODE == 1 ? 4 : 0) + 2 * PW;
-    auto dma_op = [&](int op, int c) __attribute__((always_inline)) {
+    auto dma_op = [&](int op, int st, int ch1, int ch2) __attribute__((always_inline)) {      // step st; ch1 / ch2: the chunks of steps st + 1 / st + 2
         if (MODE == 1 && op < 4) {
-            CDNA4_DMA16(moff[op & 1], (const uint8_t *)p.mask + 2 * (int64_t)(CK * (c + 1)) + (int64_t)(16 * (op >> 1)) * p.mask_nb1, lds0 + M_OFF + wave * 8192 + ((c + 1) & 1) * 4096 + 1024 * op);
+            CDNA4_DMA16(moff[op & 1], (const uint8_t *)p.mask + 2 * (int64_t)(CK * ch1) + (int64_t)(16 * (op >> 1)) * p.mask_nb1, lds0 + M_OFF + wave * 8192 + ((st + 1) & 1) * 4096 + 1024 * op);
         } else {
             const int i = (op - (MODE == 1 ? 4 : 0)) % PW; const bool is_v = (op - (MODE == 1 ? 4 : 0)) >= PW;
-            const int cc = is_v ? c + 1 : c + 2, buf = is_v ? (c + 1) & 1 : c & 1;
+            const int cc = is_v ? ch1 : ch2, buf = is_v ? (st + 1) & 1 : st & 1;
             const int64_t nb1 = is_v ? p.v_nb1 : p.k_nb1;
             CDNA4_DMA16(is_v ? vvoff : kvoff, (is_v ? vbase : kbase) + (int64_t)(CK * cc + DR * i) * nb1, lds0 + (is_v ? V_OFF : K_OFF) + buf * CB + 1024 * wave + 1024 * NW * i);
         }
@@ -766,6 +802,23 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
     const int mx8 = (n >> 1) & 7;
 
     const int nchunk = (p.n_kv + CK - 1) / CK, nfast = MODE == 2 ? 0 : p.n_kv / CK;
+    // the chunks this tile walks, in ascending order: all of them, or — with flags from k_fa_mask_flags — those that are not -inf throughout for every row of the tile.
+    // The pipeline below counts STEPS i = 0 .. nlist - 1 (buffer parities follow i); the chunk of step i is cid(i).  Only the last entry can be the ragged chunk.
+    uint16_t *const lst = reinterpret_cast<uint16_t *>(smem + L_OFF);
+    if (wave == 0) {
+        int count = 0;
+        for (int base = 0; base < nchunk; base += 64) {
+            const int c = base + lane;
+            const bool keep = c < nchunk && (!flags || flags[(int64_t)qt * nchunk + c] != 0);
+            const uint64_t bal = wave_ballot(keep);
+            if (keep) lst[1 + count + __builtin_popcountll(bal & ((1ull << lane) - 1))] = (uint16_t)c;
+            count += __builtin_popcountll(bal);
+        }
+        if (lane == 0) { if (count == 0) { lst[1] = 0; count = 1; } lst[0] = (uint16_t)count; }      // (everything masked: chunk 0 alone gives what all of them would)
+    }
+    __syncthreads();
+    const int nlist = __builtin_amdgcn_readfirstlane((int)lst[0]);
+    auto cid = [&](int i) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane((int)lst[1 + i]); };
 #ifdef FA_STAMP
     uint32_t stamp[6] = {};
 #endif
@@ -782,13 +835,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
     };
     // chunk c: [top] request K(c + 2), V(c + 1) into the buffers the last barrier freed; scores of chunk c + 1 next to the softmax of chunk c (sc -> P); request mask(c + 1);
     // O = O ms + V(c)^T P; all requests landed, barrier.  HOT: chunks c + 1, c + 2 exist and are not the last, chunk c is a whole chunk on the fast path — no branches around the MFMA / VALU mix.
-    auto step = [&](int c, floatx16 (&sc)[NKB], floatx16 (&sn)[NKB], auto hot_tag) __attribute__((always_inline)) {
+    auto step = [&](int c, floatx16 (&sc)[NKB], floatx16 (&sn)[NKB], auto hot_tag) __attribute__((always_inline)) {      // c: the STEP; its chunk is ch0
         constexpr bool HOT = decltype(hot_tag)::value;
-        const bool fast = HOT || c < nfast;
+        const int ch0 = cid(c), ch1 = (HOT || c + 1 < nlist) ? cid(c + 1) : 0, ch2 = (HOT || c + 2 < nlist) ? cid(c + 2) : 0;      // the chunks of steps c, c + 1, c + 2
+        const bool fast = HOT || ch0 < nfast;
         if constexpr (!HOT) {
-            if (c + 2 < nchunk) dma_kv(c + 2, c & 1, false, false);
-            if (c + 1 < nchunk) dma_kv(c + 1, (c + 1) & 1, true, false);
-            if constexpr (MODE == 1) { if (c + 1 < nfast) dma_mask(c + 1); }       // (its buffer was last read by the softmax of chunk c - 1, in front of the last barrier)
+            if (c + 2 < nlist) dma_kv(ch2, c & 1, false, false);
+            if (c + 1 < nlist) dma_kv(ch1, (c + 1) & 1, true, false);
+            if constexpr (MODE == 1) { if (c + 1 < nlist && ch1 < nfast) dma_mask(ch1, (c + 1) & 1); }       // (its buffer was last read by the softmax of step c - 1, in front of the last barrier)
         }
         half8_t pf[NKB * 2];
         float ms;
@@ -829,7 +883,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
                 if (m + 2 < NM) kf[m + 2] = kfrag(m + 2);
                 sn[m / NS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[m], qf[m % NS], sn[m / NS], 0, 0, 0);
 #pragma unroll
-                for (int op = m * NOPS / NM; op < (m + 1) * NOPS / NM; op++) dma_op(op, c);      // (NOPS requests spread evenly over the NM sections)
+                for (int op = m * NOPS / NM; op < (m + 1) * NOPS / NM; op++) dma_op(op, c, ch1, ch2);      // (NOPS requests spread evenly over the NM sections)
                 if (m < NM / 2) {                                   // slice m of the first half: 2 SL scores
                     if (m + MPF < NM / 2) mask_groups(m + MPF);
 #pragma unroll
@@ -864,7 +918,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
             sum = fa_sum_xor32(sum);
             S = S * ms + sum;
         } else {
-            if (c + 1 < nchunk) scores(c + 1, sn);
+            if (c + 1 < nlist) scores(c + 1, sn);
             half4_t mreg[NKB * 4] = {};
             if (fast) {
                 if constexpr (MODE == 1) {
@@ -876,7 +930,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
                 ms = fa_softmax_fast<NKB, MODE == 1>(sc, mreg, c2, mslope, M, S, pf);
             } else {
                 fattn_params pg = p; pg.mask_vec = 0;               // (element-wise path: mreg is not filled here)
-                ms = fa_softmax_blocks<NKB>(pg, sc, CK * c, h, mrow, slope2, mreg, M, S, pf);
+                ms = fa_softmax_blocks<NKB>(pg, sc, CK * ch0, h, mrow, slope2, mreg, M, S, pf);
             }
         }
         const uint8_t *Vc = smem + V_OFF + (c & 1) * CB;
@@ -909,18 +963,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
 #endif
     };
 
-    dma_kv(0, 0, false, false); dma_kv(0, 0, true, false);
-    if (nchunk > 1) dma_kv(1, 1, false, false);
-    if constexpr (MODE == 1) { if (nfast > 0) dma_mask(0); }
+    dma_kv(cid(0), 0, false, false); dma_kv(cid(0), 0, true, false);
+    if (nlist > 1) dma_kv(cid(1), 1, false, false);
+    if constexpr (MODE == 1) { if (cid(0) < nfast) dma_mask(cid(0), 0); }
     CDNA4_WAIT_VM(0);
     __syncthreads();
     floatx16 sa[NKB], sb[NKB];
     scores(0, sa);
     __syncthreads();                                              // K(0) has been read by every wave: chunk 0's step may overwrite it with K(2)
     int c = 0;
-    for (; c + 4 < nchunk && c + 1 < nfast; c += 2) { step(c, sa, sb, fa_true{}); step(c + 1, sb, sa, fa_true{}); }       // (chunks c .. c + 3 are whole chunks, not the last)
-    for (; c + 1 < nchunk; c += 2) { step(c, sa, sb, fa_false{}); step(c + 1, sb, sa, fa_false{}); }
-    if (c < nchunk) step(c, sa, sb, fa_false{});
+    for (; c + 4 < nlist && nfast > 0; c += 2) { step(c, sa, sb, fa_true{}); step(c + 1, sb, sa, fa_true{}); }       // (steps c .. c + 3 are not the last: whole chunks)
+    for (; c + 1 < nlist; c += 2) { step(c, sa, sb, fa_false{}); step(c + 1, sb, sa, fa_false{}); }
+    if (c < nlist) step(c, sa, sb, fa_false{});
 #ifdef FA_STAMP
     if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0 && (wave == 0 || wave == 5))
         printf("FA_STAMP block %d wave %d hot steps %u: first half %u | second half %u | rescale + PV %u | vmcnt %u | barrier %u cycles per step\n", (int)blockIdx.x, wave, stamp[5],
@@ -928,7 +982,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
 #endif
     fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + qi) * p.n_head + head) * HS, o, 1.0f / S, h);
 }
-template <int HS, int NW, int MODE> constexpr int k_flash_attn_pipe_lds() { return 4 * 64 * HS * 2 + (MODE == 1 ? NW * 8192 : 0); }
+template <int HS, int NW, int MODE> constexpr int k_flash_attn_pipe_lds() { return 4 * 64 * HS * 2 + (MODE == 1 ? NW * 8192 : 0) + 8192 + 16; }
 
 #define NEED(cond, msg) do { if (!(cond)) return cdna4_set_error_msg(msg); } while (0)
 typedef ggml_cdna4_tensor T4;
@@ -1046,7 +1100,7 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
     const int64_t cus = cdna4_gemm_cu_count();
     // head sizes 64 / 128 with an F16 K / V: the pipelined kernel on the largest query tile (256 / 128 / 64 rows) that still gives every CU a work-group
     // (CDNA4_FA_PIPE: measurement / test knob — 0 keeps the older kernels, 2 / 4 / 8 forces that many waves per work-group whatever the grid)
-    if (kvt == CDNA4_F16 && (D == 64 || D == 128) && N > 32) {
+    if (kvt == CDNA4_F16 && (D == 64 || D == 128) && N > 32 && KV <= 4095 * 64) {
         const char *e = getenv("CDNA4_FA_PIPE");
         int nw = e ? atoi(e) : -1;
         if (nw < 0) {
@@ -1060,12 +1114,25 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
             const int64_t qtiles = (N + 32 * nw - 1) / (32 * nw), items = qtiles * H * B3;
             NEED(items < (1ll << 31), "flash_attn_ext: too many query tiles for one grid");
             NEED(k->nb[1] < (1ll << 25) && v->nb[1] < (1ll << 25) && (!mask || (N + 16) * mask->nb[1] < (1ll << 32)), "flash_attn_ext: row strides beyond the pipelined kernel's 32-bit offsets");
+            // chunks that are -inf throughout for a whole query tile are not walked (k_fa_mask_flags; bit-neutral): worth a pass over the mask from 2^20 entries on
+            // (CDNA4_FA_NO_SKIP / CDNA4_FA_SKIP_MIN: A/B and test knobs)
+            const int64_t nchunk64 = (KV + 63) / 64;
+            NEED(nchunk64 <= 4095, "flash_attn_ext: more than 4095 key chunks");
+            const uint8_t *flags = nullptr;
+            const int64_t skip_min = getenv("CDNA4_FA_SKIP_MIN") ? atoll(getenv("CDNA4_FA_SKIP_MIN")) : (1ll << 20);      // (tests: 0 takes the pass at any size)
+            if (mask && p.mask_vec && N * KV >= skip_min && !getenv("CDNA4_FA_NO_SKIP")) {
+                uint8_t *fl = (uint8_t *)cdna4_gemm_scratch((size_t)(qtiles * nchunk64) + 256, 11);
+                NEED(fl, "flash_attn_ext: cannot allocate the chunk flags");
+                hipLaunchKernelGGL(k_fa_mask_flags, dim3((unsigned)nchunk64, (unsigned)qtiles), dim3(256), 0, st, p, 32 * nw, (int)nchunk64, fl);
+                CDNA4_CHECK_LAUNCH();
+                flags = fl;
+            }
             const int xcd_map = getenv("CDNA4_FA_MAP") ? atoi(getenv("CDNA4_FA_MAP")) : (mask ? 1 : 0);     // (A/B knob; see the kernel)
             const int mode = (logit_softcap != 0.0f || !(p.scale > 0.0f) || (mask && !p.mask_vec)) ? 2 : (mask ? 1 : 0);
 #define FA_PIPE3(HS_, NW_, MODE_) do { constexpr int lds_ = k_flash_attn_pipe_lds<HS_, NW_, MODE_>(); static bool raised_ = false;                                \
                 if (lds_ > 64 * 1024 && !raised_) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_flash_attn_pipe<HS_, NW_, MODE_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) { \
                     (void)hipGetLastError(); return cdna4_set_error_msg("flash_attn_ext: cannot raise the dynamic LDS limit"); } raised_ = true; }                \
-                hipLaunchKernelGGL((k_flash_attn_pipe<HS_, NW_, MODE_>), dim3((unsigned)items), dim3(64 * NW_), lds_, st, p, (int)qtiles, xcd_map); } while (0)
+                hipLaunchKernelGGL((k_flash_attn_pipe<HS_, NW_, MODE_>), dim3((unsigned)items), dim3(64 * NW_), lds_, st, p, (int)qtiles, xcd_map, flags); } while (0)
 #define FA_PIPE(HS_, NW_) do { if (mode == 0) FA_PIPE3(HS_, NW_, 0); else if (mode == 1) FA_PIPE3(HS_, NW_, 1); else FA_PIPE3(HS_, NW_, 2); } while (0)
             if (D == 64) { if (nw == 8) FA_PIPE(64, 8); else if (nw == 4) FA_PIPE(64, 4); else FA_PIPE(64, 2); }
             else { if (nw == 8) FA_PIPE(128, 8); else FA_PIPE(128, 4); }

@@ -294,7 +294,7 @@ static void *g_scratch[192] = {nullptr}; static size_t g_scratch_bytes[192] = {0
 static std::mutex g_scratch_mu;                                     // the bookkeeping below, against host threads driving different devices; USE of an area stays stream-ordered per device
 static std::atomic<uint64_t> g_scratch_generation{0};
 uint64_t cdna4_scratch_generation() { return g_scratch_generation.load(); }
-static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: split-K exchange buffers, 1: repacked weights, 2: exchange buffers of gemm_q_t64.hip (reader-reset flags), 3: re-encoded weights (convert_w.hip), 4: partial results of the key-split FLASH_ATTN_EXT (fattn.hip), 5 / 6: fp16 copies of a quantized (or head-size-padded) K / V in front of FLASH_ATTN_EXT, 7 / 8: its padded q / dst, 9: split-K exchange of gemm_q_lds.hip, 10: parked partial tiles + tickets of gemm_q_sk.hip
+static void *get_scratch(size_t bytes, int kind = 0) {             // kind 0: split-K exchange buffers, 1: repacked weights, 2: exchange buffers of gemm_q_t64.hip (reader-reset flags), 3: re-encoded weights (convert_w.hip), 4: partial results of the key-split FLASH_ATTN_EXT (fattn.hip), 5 / 6: fp16 copies of a quantized (or head-size-padded) K / V in front of FLASH_ATTN_EXT, 7 / 8: its padded q / dst, 9: split-K exchange of gemm_q_lds.hip, 10: parked partial tiles + tickets of gemm_q_sk.hip, 11: chunk flags of FLASH_ATTN_EXT (fattn.hip: k_fa_mask_flags)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
     dev += 16 * kind;

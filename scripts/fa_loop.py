@@ -14,6 +14,8 @@ q = (torch.rand((1, H, n_q, D), generator=g) * 2 - 1).cuda()
 k = (torch.rand((1, H, n_kv, D), generator=g) * 2 - 1).half().cuda()
 v = (torch.rand((1, H, n_kv, D), generator=g) * 2 - 1).half().cuda()
 m = (torch.rand(((n_q + 63) // 64 * 64, n_kv), generator=g) * 2 - 1).half().cuda()
+if os.environ.get("FA_LOOP_CAUSAL"):
+    m = torch.triu(torch.full((n_q, n_kv), float("-inf"), dtype=torch.float16, device="cuda"), diagonal=1)
 scale = float(1.0 / np.sqrt(D))
 for _ in range(3):
     ops.flash_attn_ext(q, k, v, m, scale)

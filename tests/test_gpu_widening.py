@@ -133,7 +133,7 @@ def test_more_formats_to_float_is_bit_exact(gu, name, t):
 TOL_FA_EXACT = 1e-3
 
 
-def _fa_case(gu, D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max_bias=0.0, softcap=0.0, permuted=False, inf_every=0, seed=1):
+def _fa_case(gu, D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max_bias=0.0, softcap=0.0, permuted=False, inf_every=0, seed=1, causal=False):
     from ggml_amd import ops
     n_head_kv = n_head_kv or n_head
     rng = np.random.default_rng(seed)
@@ -144,6 +144,9 @@ def _fa_case(gu, D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max
     if mask and inf_every:
         m[:, ::inf_every] = -np.inf
         m[0, : n_kv // 2] = -np.inf
+    if mask and causal:                                                 # key j is visible to query i iff j <= i + (n_kv - n_q): whole chunks are -inf for whole query tiles
+        jj, ii = np.meshgrid(np.arange(n_kv), np.arange(m.shape[0]))
+        m[jj > ii + (n_kv - n_q)] = -np.inf
     scale = float(1.0 / np.sqrt(D))
     if permuted:        # memory order (batch, n_q / n_kv, n_head, D), handed over as a permuted view: the stock test's permute {0, 2, 1, 3}
         dev = lambda a: gu.to_dev(np.ascontiguousarray(a.transpose(0, 2, 1, 3))).permute(0, 2, 1, 3)
@@ -198,6 +201,21 @@ def test_flash_attn_ext_pipelined_kernel(gu, monkeypatch, kw):
     monkeypatch.setenv("CDNA4_FA_PIPE", "0")
     y0 = _fa_case(gu, **kw)
     assert R.rel_l2(ys[8], y0) < 5e-4                                   # (the key-split kernel walks 32-key chunks: another rounding order)
+
+
+@pytest.mark.parametrize("kw", [dict(D=64, n_q=300, n_head=2, n_kv=640), dict(D=128, n_q=200, n_head=2, n_kv=460, max_bias=8.0), dict(D=64, n_q=70, n_head=2, n_kv=700, softcap=5.0),
+                                dict(D=128, n_q=512, n_head=4, n_kv=512, n_head_kv=2), dict(D=64, n_q=100, n_head=1, n_kv=320, causal=False, inf_every=5)])
+def test_flash_attn_ext_skips_masked_chunks(gu, monkeypatch, kw):
+    """key chunks whose mask entries are -inf for every row of a query tile are not walked (k_fa_mask_flags + the chunk list of k_flash_attn_pipe; the reference skips -inf entries one
+    by one, ggml-cpu.c:10935-10938): causal masks — half of all chunks — with ALiBi, softcap, grouped heads, ragged key counts, and a mask with scattered -inf (nothing to skip).
+    The result is the one without the skipping, BIT FOR BIT, at every tile height; bars of the other FLASH_ATTN_EXT cases."""
+    kw = dict(dict(causal=True), **kw)
+    for nw in ((8, 4) if kw["D"] == 128 else (8, 2)):
+        monkeypatch.setenv("CDNA4_FA_PIPE", str(nw))
+        monkeypatch.setenv("CDNA4_FA_SKIP_MIN", "0"); monkeypatch.delenv("CDNA4_FA_NO_SKIP", raising=False)
+        y = _fa_case(gu, **kw)
+        monkeypatch.setenv("CDNA4_FA_NO_SKIP", "1")
+        assert np.array_equal(y, _fa_case(gu, **kw))
 
 
 def test_flash_attn_ext_is_deterministic_and_row_independent(gu):

@@ -38,7 +38,7 @@ def build():
     return exe
 
 
-def run(D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max_bias=0.0, softcap=0.0, permuted=False, inf_every=0, seed=1, timeout=1200, cus=256, mask_unaligned=False):
+def run(D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max_bias=0.0, softcap=0.0, permuted=False, inf_every=0, seed=1, timeout=1200, cus=256, mask_unaligned=False, causal=False, ret_y=False):
     """returns (rel-L2 vs the float64 operator, rel-L2 vs the oracle).  cus: the CU count the launcher sizes its grids for (the 128-row
     prefill kernel is chosen when its grid fills the chip: small values select it at test sizes)"""
     n_head_kv = n_head_kv or n_head
@@ -51,6 +51,9 @@ def run(D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max_bias=0.0
     if mask and inf_every:
         m[:, ::inf_every] = -np.inf
         m[0, : n_kv // 2] = -np.inf                    # a query row whose first chunks are masked entirely
+    if mask and causal:                                # key j visible to query i iff j <= i + (n_kv - n_q): whole chunks are -inf for whole tiles
+        jj, ii = np.meshgrid(np.arange(n_kv), np.arange(mrows))
+        m[jj > ii + (n_kv - n_q)] = -np.inf
     scale = 1.0 / np.sqrt(D)
     lay = (lambda a: np.ascontiguousarray(a.transpose(0, 2, 1, 3))) if permuted else (lambda a: a)
     with tempfile.TemporaryDirectory() as d:
@@ -67,6 +70,8 @@ def run(D, n_q, n_head, n_kv, n_head_kv=None, n_batch=1, mask=True, max_bias=0.0
     assert np.isfinite(y).all()
     ye = R.exact_flash_attn_ext(q, k, v, m, scale, max_bias, softcap)
     yo = R.o_flash_attn_ext(q, k, v, m, scale, max_bias, softcap)
+    if ret_y:
+        return R.rel_l2(y, ye), R.rel_l2(y, yo), y
     return R.rel_l2(y, ye), R.rel_l2(y, yo)
 
 
