@@ -1100,7 +1100,9 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
     const int64_t cus = cdna4_gemm_cu_count();
     // head sizes 64 / 128 with an F16 K / V: the pipelined kernel on the largest query tile (256 / 128 / 64 rows) that still gives every CU a work-group
     // (CDNA4_FA_PIPE: measurement / test knob — 0 keeps the older kernels, 2 / 4 / 8 forces that many waves per work-group whatever the grid)
-    if (kvt == CDNA4_F16 && (D == 64 || D == 128) && N > 32 && KV <= 4095 * 64) {
+    // (beyond its 32-bit source offsets, its chunk list or one grid the call takes the older kernels below)
+    const bool pipe_fits = KV <= 4095 * 64 && k->nb[1] < (1ll << 25) && v->nb[1] < (1ll << 25) && (!mask || (N + 16) * (int64_t)mask->nb[1] < (1ll << 32)) && ((N + 63) / 64) * H * B3 < (1ll << 31);
+    if (kvt == CDNA4_F16 && (D == 64 || D == 128) && N > 32 && pipe_fits) {
         const char *e = getenv("CDNA4_FA_PIPE");
         int nw = e ? atoi(e) : -1;
         if (nw < 0) {
