@@ -185,7 +185,7 @@ def test_flash_attn_ext_variants(gu, kw):
 _PIPE_CASES = [dict(D=128, n_q=300, n_head=4, n_kv=576), dict(D=64, n_q=130, n_head=4, n_kv=400, mask=False), dict(D=128, n_q=133, n_head=4, n_kv=328, n_head_kv=2, max_bias=8.0),
                dict(D=64, n_q=100, n_head=3, n_kv=606, n_head_kv=1, inf_every=5), dict(D=64, n_q=290, n_head=2, n_kv=191, softcap=10.0), dict(D=128, n_q=70, n_head=2, n_kv=201),
                dict(D=128, n_q=260, n_head=2, n_kv=257, n_batch=2, permuted=True), dict(D=64, n_q=33, n_head=2, n_kv=40), dict(D=128, n_q=64, n_head=1, n_kv=64), dict(D=64, n_q=512, n_head=2, n_kv=1024, n_head_kv=1),
-               dict(D=128, n_q=150, n_head=2, n_kv=330, softcap=7.0), dict(D=128, n_q=100, n_head=2, n_kv=325)]     # (head size 128 in the general mode: softcap; a mask whose rows are not 16-byte aligned)
+               dict(D=128, n_q=150, n_head=2, n_kv=330, softcap=7.0), dict(D=128, n_q=100, n_head=2, n_kv=325), dict(D=128, n_q=200, n_head=2, n_kv=448, mask=False)]     # (head size 128 in the general mode: softcap; a mask whose rows are not 16-byte aligned)
 
 
 @pytest.mark.parametrize("kw", _PIPE_CASES)
