@@ -130,16 +130,25 @@ template <int NB> __device__ __forceinline__ void fa_store(float *out, const flo
 // bytes per 32 elements instead of a read of that, a write and a read of 64): fp16(to_float(element)), the rounding an F16 cache holding the
 // dequantized values has (dequantize_row_q8_0 / _q4_0, src/ggml-quants.c:255-273, 367-377) — bit-identical to the converting path.  The eight quants sit 2 bytes
 // behind their block's d: two aligned dwords, or three and a 16-bit funnel shift (rows are 4-byte aligned: 34 n / 18 n bytes with n even).
-__device__ __forceinline__ u32x2 fa_ld8_a2(const char *p) {
-    if (((uintptr_t)p & 3) == 0) return u32x2{*reinterpret_cast<const uint32_t *>(p), *reinterpret_cast<const uint32_t *>(p + 4)};
-    const uint32_t w0 = *reinterpret_cast<const uint32_t *>(p - 2), w1 = *reinterpret_cast<const uint32_t *>(p + 2), w2 = *reinterpret_cast<const uint32_t *>(p + 6);
-    return u32x2{(w0 >> 16) | (w1 << 16), (w1 >> 16) | (w2 << 16)};
+// Load and conversion are separate steps (fa_kv_load / fa_kv_cvt): the decode kernel requests a chunk's fragments one chunk ahead and keeps the RAW 16 bytes in the registers
+// meanwhile — a conversion right behind the load would wait for it.  Raw form of a quantized fragment: x, y, z = the two or three aligned dwords that hold its 8 quant bytes,
+// w = the block's d in the low half, bit 16 = the bytes start 2 behind x (the funnel shift is part of the conversion), bit 17 = Q4_0's high nibbles.
+template <int KVT> __device__ __forceinline__ u32x4 fa_kv_load(const char *row, int e0) {
+    if constexpr (KVT == CDNA4_F16 || KVT == CDNA4_BF16) return *reinterpret_cast<const u32x4 *>(row + 2 * e0);
+    else {
+        constexpr int BB = KVT == CDNA4_Q8_0 ? 34 : 18;
+        const char *blk = row + (e0 >> 5) * BB, *q = blk + 2 + (KVT == CDNA4_Q8_0 ? (e0 & 31) : (e0 & 15));      // Q4_0: element i < 16: low nibble of byte i, i >= 16: high nibble of byte i - 16
+        u32x4 r;
+        r.w = (uint32_t)*reinterpret_cast<const uint16_t *>(blk) | ((KVT == CDNA4_Q4_0 && (e0 & 16)) ? 0x20000u : 0u);
+        if (((uintptr_t)q & 3) == 0) { r.x = *reinterpret_cast<const uint32_t *>(q); r.y = *reinterpret_cast<const uint32_t *>(q + 4); r.z = 0; }
+        else { r.x = *reinterpret_cast<const uint32_t *>(q - 2); r.y = *reinterpret_cast<const uint32_t *>(q + 2); r.z = *reinterpret_cast<const uint32_t *>(q + 6); r.w |= 0x10000u; }
+        return r;
+    }
 }
-template <int KVT> __device__ __forceinline__ half8_t fa_kv_frag(const char *row, int e0) {
-    if constexpr (KVT == CDNA4_F16) return *reinterpret_cast<const half8_t *>(row + 2 * e0);
+template <int KVT> __device__ __forceinline__ half8_t fa_kv_cvt(u32x4 raw) {
+    if constexpr (KVT == CDNA4_F16) return __builtin_bit_cast(half8_t, raw);
     else if constexpr (KVT == CDNA4_BF16) {                                 // bf16 -> fp32 (the 16 bits are the upper half) -> fp16: what k_q_to_f16_dense<BF16> writes
-        const u32x4 w = *reinterpret_cast<const u32x4 *>(row + 2 * e0);
-        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+        const uint32_t ww[4] = {raw.x, raw.y, raw.z, raw.w};
         half8_t out;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -151,21 +160,14 @@ template <int KVT> __device__ __forceinline__ half8_t fa_kv_frag(const char *row
         // Round 6: the conversion in packed fp16 arithmetic.  A byte b in 0..255 under the exponent byte 0x64 is the fp16 number 1024 + b, EXACTLY; subtracting 1152 (Q8_0: b =
         // q + 128) or 1032 (Q4_0: b = the nibble) leaves the integer quant, exactly; times d (an fp16 number) is one exact product rounded once to fp16 — the value
         // fp16(fp32(d) * q) of the element-wise form it replaces (the fp32 product of an 11-bit and an 8-bit significand is exact), bit for bit, subnormals included.
-        // 14 - 16 VALU per fragment instead of ~40: the decode over a quantized cache was bound by this conversion (BENCH r5: Q4_0 0.18, Q8_0 0.27 of the HBM roof).
-        constexpr int BB = KVT == CDNA4_Q8_0 ? 34 : 18;
-        const char *blk = row + (e0 >> 5) * BB;
-        const half_t d = *reinterpret_cast<const half_t *>(blk);
+        // 14 - 16 VALU per fragment instead of ~40.
+        const bool shifted = raw.w & 0x10000u;
+        u32x2 w = {shifted ? (raw.x >> 16) | (raw.y << 16) : raw.x, shifted ? (raw.y >> 16) | (raw.z << 16) : raw.y};
+        const half_t d = __builtin_bit_cast(half_t, (uint16_t)(raw.w & 0xFFFFu));
         const half2_t d2 = {d, d};
-        u32x2 w;
         half_t bias;
-        if constexpr (KVT == CDNA4_Q8_0) {
-            w = fa_ld8_a2(blk + 2 + (e0 & 31));
-            w.x ^= 0x80808080u; w.y ^= 0x80808080u; bias = (half_t)1152.0f;
-        } else {
-            w = fa_ld8_a2(blk + 2 + (e0 & 15));                         // element i < 16: low nibble of byte i, i >= 16: high nibble of byte i - 16
-            const int sh = (e0 & 16) ? 4 : 0;
-            w.x = (w.x >> sh) & 0x0F0F0F0Fu; w.y = (w.y >> sh) & 0x0F0F0F0Fu; bias = (half_t)1032.0f;
-        }
+        if constexpr (KVT == CDNA4_Q8_0) { w.x ^= 0x80808080u; w.y ^= 0x80808080u; bias = (half_t)1152.0f; }
+        else { const int sh = (raw.w & 0x20000u) ? 4 : 0; w.x = (w.x >> sh) & 0x0F0F0F0Fu; w.y = (w.y >> sh) & 0x0F0F0F0Fu; bias = (half_t)1032.0f; }
         const half2_t b2 = {bias, bias};
         half8_t out;
 #pragma unroll
@@ -211,15 +213,30 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_split(con
 
     const int nchunk = (p.n_kv + 31) / 32;
     const int c_lo = split * p.chunks_per_split, c_hi = min(nchunk, c_lo + p.chunks_per_split);
+    // The fragments of a chunk are requested ONE CHUNK AHEAD, into the registers the previous chunk's fragments have just left: K right behind the score products, V behind the
+    // last P.V product — a chunk's loads have the rest of the step (K) or the next step's scores and softmax (V) to arrive, at no extra registers.  (First the loop issued each
+    // fragment in front of its product: two exposed memory round trips per chunk; the F16 / Q8_0 / Q4_0 caches took 120 / 127 / 92 us at 32 K keys, within 30 % of each other in
+    // TIME — bound by the dependent load -> use chain, not by bytes.)
+    u32x4 kc[NS], vc[2 * NB];                                     // raw (fa_kv_load): converted where they are used
+    auto load_k = [&](int c) __attribute__((always_inline)) {
+        const char *kp = kbase + (int64_t)min(32 * c + n, p.n_kv - 1) * p.k_nb1;          // A row n of this lane = key 32 c + n (past the end: repeated, masked in the softmax)
+#pragma unroll
+        for (int st = 0; st < NS; st++) kc[st] = fa_kv_load<KVT>(kp, 16 * st + 8 * h);
+    };
+    auto load_v = [&](int c) __attribute__((always_inline)) {
+        const char *vp = vbase + (int64_t)min(32 * c + n, p.n_kv - 1) * p.v_nb1;
+#pragma unroll
+        for (int u = 0; u < 2 * NB; u++) vc[u] = fa_kv_load<KVT>(vp, 16 * u + 8 * h);
+    };
+    if (c_lo + wave < c_hi) { load_k(c_lo + wave); load_v(c_lo + wave); }
     for (int c = c_lo + wave; c < c_hi; c += 4) {
         const int kv0 = 32 * c;
-        const int64_t row = min(kv0 + n, p.n_kv - 1);             // A row n of this lane = key kv0 + n (past the end: repeated, masked below)
-        const char *kp = kbase + row * p.k_nb1, *vp = vbase + row * p.v_nb1;
         floatx16 s;
 #pragma unroll
         for (int r = 0; r < 16; r++) s[r] = 0.0f;
 #pragma unroll
-        for (int st = 0; st < NS; st++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_kv_frag<KVT>(kp, 16 * st + 8 * h), qf[st], s, 0, 0, 0);
+        for (int st = 0; st < NS; st++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_kv_cvt<KVT>(kc[st]), qf[st], s, 0, 0, 0);
+        if (c + 4 < c_hi) load_k(c + 4);
         half8_t pf[2];
         const float ms = fa_softmax_step(p, s, kv0, h, mrow, slope2, M, S, pf);
         // O^T *= ms, skipped while no row of the wave moved its maximum (x 1.0 is exact).  ONE branch in front of the block loop: with the test
@@ -236,14 +253,15 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_split(con
             floatx16 vt;
 #pragma unroll
             for (int r = 0; r < 16; r++) vt[r] = 0.0f;
-            vt = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_kv_frag<KVT>(vp, 32 * b + 8 * h), sel[0], vt, 0, 0, 0);
-            vt = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_kv_frag<KVT>(vp, 32 * b + 16 + 8 * h), sel[1], vt, 0, 0, 0);
+            vt = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_kv_cvt<KVT>(vc[2 * b]), sel[0], vt, 0, 0, 0);
+            vt = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_kv_cvt<KVT>(vc[2 * b + 1]), sel[1], vt, 0, 0, 0);
             half8_t vf[2];
 #pragma unroll
             for (int r = 0; r < 16; r++) vf[r >> 3][r & 7] = (half_t)vt[r];
             o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], pf[0], o[b], 0, 0, 0);
             o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1], pf[1], o[b], 0, 0, 0);
         }
+        if (c + 4 < c_hi) load_v(c + 4);
     }
 
     // the four partial results meet: waves 1..3 hand theirs to wave 0 one after the other through LDS (same lane <-> element mapping on
@@ -1018,7 +1036,7 @@ extern "C" int ggml_cdna4_op_flash_attn_ext(const T4 *q, const T4 *k, const T4 *
     NEED(D > 0 && D <= 256, "flash_attn_ext: head size must be 1..256");
     const bool pad = !fa_kernel_head_size(D);
     if (!pad && k->type == CDNA4_F16 && v->type == CDNA4_F16) return fa_f16(q, k, v, mask, d, scale, max_bias, logit_softcap, stream);
-    // a Q8_0 / Q4_0 / BF16 cache under the key-split kernel (decode, small batches): converted in the operand loads, no fp16 copy (fa_kv_frag)
+    // a Q8_0 / Q4_0 / BF16 cache under the key-split kernel (decode, small batches): converted from the raw fragment bytes, no fp16 copy (fa_kv_load / fa_kv_cvt)
     if (!pad && k->type == v->type && (k->type == CDNA4_Q8_0 || k->type == CDNA4_Q4_0 || k->type == CDNA4_BF16) && q->ne[1] > 0 && q->ne[2] > 0 && q->ne[3] > 0 &&
         !fa_takes_wide(q->ne[1], q->ne[2], q->ne[3]) && !getenv("CDNA4_FA_KV_COPY") &&
         !(((uintptr_t)k->data | (uintptr_t)v->data | (uintptr_t)k->nb[1] | (uintptr_t)k->nb[2] | (uintptr_t)k->nb[3] | (uintptr_t)v->nb[1] | (uintptr_t)v->nb[2] | (uintptr_t)v->nb[3]) & (k->type == CDNA4_BF16 ? 15 : 3)))
