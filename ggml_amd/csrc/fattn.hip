@@ -131,8 +131,8 @@ template <int NB> __device__ __forceinline__ void fa_store(float *out, const flo
 // dequantized values has (dequantize_row_q8_0 / _q4_0, src/ggml-quants.c:255-273, 367-377) — bit-identical to the converting path.  The eight quants sit 2 bytes
 // behind their block's d: two aligned dwords, or three and a 16-bit funnel shift (rows are 4-byte aligned: 34 n / 18 n bytes with n even).
 // Load and conversion are separate steps (fa_kv_load / fa_kv_cvt): the decode kernel requests a chunk's fragments one chunk ahead and keeps the RAW 16 bytes in the registers
-// meanwhile — a conversion right behind the load would wait for it.  Raw form of a quantized fragment: x, y, z = the two or three aligned dwords that hold its 8 quant bytes,
-// w = the block's d in the low half, bit 16 = the bytes start 2 behind x (the funnel shift is part of the conversion), bit 17 = Q4_0's high nibbles.
+// meanwhile — a conversion right behind the load would wait for it.  Raw form of a quantized fragment: x, y = its 8 quant bytes, w = the block's d in the low half,
+// bit 17 = Q4_0's high nibbles.
 template <int KVT> __device__ __forceinline__ u32x4 fa_kv_load(const char *row, int e0) {
     if constexpr (KVT == CDNA4_F16 || KVT == CDNA4_BF16) return *reinterpret_cast<const u32x4 *>(row + 2 * e0);
     else {
@@ -140,8 +140,11 @@ template <int KVT> __device__ __forceinline__ u32x4 fa_kv_load(const char *row, 
         const char *blk = row + (e0 >> 5) * BB, *q = blk + 2 + (KVT == CDNA4_Q8_0 ? (e0 & 31) : (e0 & 15));      // Q4_0: element i < 16: low nibble of byte i, i >= 16: high nibble of byte i - 16
         u32x4 r;
         r.w = (uint32_t)*reinterpret_cast<const uint16_t *>(blk) | ((KVT == CDNA4_Q4_0 && (e0 & 16)) ? 0x20000u : 0u);
-        if (((uintptr_t)q & 3) == 0) { r.x = *reinterpret_cast<const uint32_t *>(q); r.y = *reinterpret_cast<const uint32_t *>(q + 4); r.z = 0; }
-        else { r.x = *reinterpret_cast<const uint32_t *>(q - 2); r.y = *reinterpret_cast<const uint32_t *>(q + 2); r.z = *reinterpret_cast<const uint32_t *>(q + 6); r.w |= 0x10000u; }
+        // ONE 8-byte load at 2-byte alignment (global memory takes unaligned dword accesses on this target: hipcc emits global_load_dwordx2 for it) — the first form read two
+        // or three aligned dwords behind a per-lane alignment branch and funnel-shifted them
+        struct __attribute__((packed, aligned(2))) u64_a2 { uint64_t v; };
+        const uint64_t b8 = reinterpret_cast<const u64_a2 *>(q)->v;
+        r.x = (uint32_t)b8; r.y = (uint32_t)(b8 >> 32); r.z = 0;
         return r;
     }
 }
@@ -161,8 +164,7 @@ template <int KVT> __device__ __forceinline__ half8_t fa_kv_cvt(u32x4 raw) {
         // q + 128) or 1032 (Q4_0: b = the nibble) leaves the integer quant, exactly; times d (an fp16 number) is one exact product rounded once to fp16 — the value
         // fp16(fp32(d) * q) of the element-wise form it replaces (the fp32 product of an 11-bit and an 8-bit significand is exact), bit for bit, subnormals included.
         // 14 - 16 VALU per fragment instead of ~40.
-        const bool shifted = raw.w & 0x10000u;
-        u32x2 w = {shifted ? (raw.x >> 16) | (raw.y << 16) : raw.x, shifted ? (raw.y >> 16) | (raw.z << 16) : raw.y};
+        u32x2 w = {raw.x, raw.y};
         const half_t d = __builtin_bit_cast(half_t, (uint16_t)(raw.w & 0xFFFFu));
         const half2_t d2 = {d, d};
         half_t bias;
