@@ -1175,10 +1175,10 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
         return 0;
     }
     // decode / small batches: 32-row query tiles, the keys split over work-groups until the chip is full (two work-groups per CU), each split
-    // >= 8 chunks
+    // >= 16 chunks
     const int64_t nchunk = (KV + 31) / 32, qtiles = (N + 31) / 32, tiles = qtiles * H * B3;
     int64_t want = (2 * cus + tiles - 1) / tiles;
-    if (want > nchunk / 8) want = nchunk / 8;
+    { static const int64_t min_chunks = getenv("CDNA4_FA_SPLIT_MIN") ? atoll(getenv("CDNA4_FA_SPLIT_MIN")) : 16; if (want > nchunk / min_chunks) want = nchunk / min_chunks; }      // (each split at least 16 chunks — four per wave, which the one-chunk-ahead requests need to pay: 4 K keys x 32 heads 26.4 us at 8, 21.3 at 16, 25.4 at 32; CDNA4_FA_SPLIT_MIN: A/B knob)
     if (want < 1) want = 1;
     p.chunks_per_split = (int)((nchunk + want - 1) / want);
     p.nsplit = (int)((nchunk + p.chunks_per_split - 1) / p.chunks_per_split);
