@@ -573,6 +573,25 @@ def widening_rows(dev, steps):
         name = "hs%d_h32_q%d_kv%d%s" % (hs, n_q, n_kv, "_causal_mask" if masked == "causal" else ("" if masked else "_no_mask"))
         out["flash_attn_ext"][name] = row
         leg_row("flash_attn_ext", name, row)
+    # grouped-query decode (32 query heads on 8 K / V heads, 32 K keys, F16 cache): the heads of a group share a tile — the cache is read once per group (against the HBM roof on the
+    # cache bytes) — beside the one-head-per-tile form (CDNA4_FA_NO_PACK=1)
+    hs, nkvh, n_kv = 128, 8, 32768
+    q = torch.from_numpy(rng.uniform(-1, 1, (1, nh, 1, hs)).astype(np.float32)).to(dev)
+    kk = torch.from_numpy(rng.uniform(-1, 1, (1, nkvh, n_kv, hs)).astype(np.float16)).to(dev)
+    vv = torch.from_numpy(rng.uniform(-1, 1, (1, nkvh, n_kv, hs)).astype(np.float16)).to(dev)
+    mk = torch.from_numpy(rng.uniform(-1, 1, (64, n_kv)).astype(np.float16)).to(dev)
+    sc = float(1.0 / np.sqrt(hs))
+    row = {}
+    for tag, env in (("us_per_call", None), ("us_per_call_one_head_per_tile", "1")):
+        if env: os.environ["CDNA4_FA_NO_PACK"] = env
+        else: os.environ.pop("CDNA4_FA_NO_PACK", None)
+        ops.flash_attn_ext(q, kk, vv, mk, sc)
+        row[tag] = round(events_us(lambda: ops.flash_attn_ext(q, kk, vv, mk, sc), max(20, steps // 4), 5), 2)
+    os.environ.pop("CDNA4_FA_NO_PACK", None)
+    gb = 4.0 * nkvh * n_kv * hs / row["us_per_call"] / 1e3
+    row.update(cache_GBps=round(gb, 1), frac_of_hbm_roof=round(gb / HBM_PEAK_GBS, 4), kernel="k_flash_attn_split<128> (four heads per tile) + k_flash_attn_merge<128>", note="includes python's share of a call (a few us)")
+    out["flash_attn_ext"]["hs128_h32_kvh8_q1_kv32768_grouped_query"] = row
+    leg_row("flash_attn_ext", "hs128_h32_kvh8_q1_kv32768_grouped_query", row)
     # decode over a QUANTIZED KV cache (Q8_0 / Q4_0 rows read by the key-split kernel's dequantizing operand loads): against the HBM roof on the
     # cache bytes actually read (34 / 18 bytes per 32 elements, K + V once)
     def block_rows(bb, nrows):                                        # random block rows: fp16 d = 1/64 in front of bb - 2 random quant bytes per 32 elements

@@ -41,6 +41,7 @@ struct fattn_params {
     float scale, max_bias, logit_softcap, m0, m1; uint32_t n_head_log2;
     int mask_vec;                                  // mask rows are 16-byte aligned: whole chunks take the vector path of fa_softmax_step
     int nsplit, chunks_per_split;                  // key split over work-groups (k_flash_attn_split)
+    int pack;                                      // k_flash_attn_split: query heads of one K / V head that share a 32-row tile (grouped-query decode), 1 = none
     float *part;                                   // nsplit > 1: [batch][head][q tile][split][(2 + HS) x 32] floats
 };
 
@@ -195,8 +196,13 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_split(con
     __shared__ float Ms[32], Ss[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     const int qt = blockIdx.x / p.nsplit, split = blockIdx.x % p.nsplit;
-    const int q0 = qt * 32, head = blockIdx.y, b3 = blockIdx.z;
-    const int qi = min(q0 + n, p.n_q - 1);                        // rows past the end repeat the last one and are not stored
+    const int q0 = qt * 32, b3 = blockIdx.z;
+    // Grouped-query decode (p.pack = n_head / n_head_kv > 1, n_q * pack <= 32): the tile's rows are (query row, head of the group) pairs, row n = query n / pack of head
+    // blockIdx.y * pack + n % pack — the group's K / V rows are read ONCE for all of its heads (each head by itself read them again: pack times the cache traffic, and one
+    // useful column of the 32 x 32 MFMA tile per head).  Otherwise row n is query q0 + n of head blockIdx.y.
+    const int head = p.pack > 1 ? (int)blockIdx.y * p.pack + n % p.pack : (int)blockIdx.y;
+    const int qrow = p.pack > 1 ? n / p.pack : q0 + n;
+    const int qi = min(qrow, p.n_q - 1);                          // rows past the end repeat the last one and are not stored
 
     half8_t qf[NS], sel[2];
     fa_load_q<NS>(p, qi, head, b3, h, qf);
@@ -288,12 +294,12 @@ __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_split(con
             S = S * a0 + Sw * aw; M = Mn;
         }
     }
-    if (wave != 0 || q0 + n >= p.n_q) return;
+    if (wave != 0 || qrow >= p.n_q) return;
     if (p.nsplit == 1) {
-        fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + (q0 + n)) * p.n_head + head) * HS, o, 1.0f / S, h);
+        fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + qrow) * p.n_head + head) * HS, o, 1.0f / S, h);
     } else {
-        // this split's unnormalized (M, S, O) for k_flash_attn_merge: [.. tile][split][q][2 + HS] — the rows that exist, contiguous
-        float *pt = p.part + ((((int64_t)b3 * p.n_head + head) * gridDim.x + blockIdx.x) * 32 + n) * (HS + 4);
+        // this split's unnormalized (M, S, O) for k_flash_attn_merge: [.. head][tile][split][q][2 + HS] — the rows that exist, contiguous (grouped: one tile per head, row = query)
+        float *pt = p.part + ((((int64_t)b3 * p.n_head + head) * gridDim.x + blockIdx.x) * 32 + (p.pack > 1 ? qrow : n)) * (HS + 4);
         if (h == 0) { pt[0] = M; pt[1] = S; }
         fa_store<NB>(pt + 4, o, 1.0f, h);
     }
@@ -1174,19 +1180,26 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
         CDNA4_CHECK_LAUNCH();
         return 0;
     }
-    // decode / small batches: 32-row query tiles, the keys split over work-groups until the chip is full (two work-groups per CU), each split
+    // decode / small batches: 32-row query tiles, the keys split over work-groups until the chip is full (one or two work-groups per CU, below), each split
     // >= 16 chunks
-    const int64_t nchunk = (KV + 31) / 32, qtiles = (N + 31) / 32, tiles = qtiles * H * B3;
-    int64_t want = (2 * cus + tiles - 1) / tiles;
+    // grouped-query decode: the heads of a K / V head in one tile (k_flash_attn_split; CDNA4_FA_NO_PACK: A/B knob)
+    p.pack = (p.rk2 > 1 && p.rk2 == p.rv2 && N * p.rk2 <= 32 && !getenv("CDNA4_FA_NO_PACK")) ? p.rk2 : 1;
+    const int64_t HT = p.pack > 1 ? H / p.pack : H;                 // tiles along the head axis
+    const int64_t nchunk = (KV + 31) / 32, qtiles = (N + 31) / 32, tiles = qtiles * HT * B3;
+    // work-groups per CU the split aims at: ONE for F16 / BF16 rows (32 K keys x 32 heads 105.6 -> 99.2 us, grouped-query 8 K / V heads 60.6 -> 43.1: fewer partial results to
+    // write, merge and wait for), TWO for quantized rows, whose conversion is VALU work a second resident work-group hides (Q8_0 88.6 against 108.8, Q4_0 66.7 against 81.4)
+    static const int64_t wgs_knob = getenv("CDNA4_FA_SPLIT_WGS") ? atoll(getenv("CDNA4_FA_SPLIT_WGS")) : 0;      // (A/B knob)
+    const int64_t wgs_per_cu = wgs_knob > 0 ? wgs_knob : (kvq ? 2 : 1);
+    int64_t want = (wgs_per_cu * cus + tiles - 1) / tiles;
     { static const int64_t min_chunks = getenv("CDNA4_FA_SPLIT_MIN") ? atoll(getenv("CDNA4_FA_SPLIT_MIN")) : 16; if (want > nchunk / min_chunks) want = nchunk / min_chunks; }      // (each split at least 16 chunks — four per wave, which the one-chunk-ahead requests need to pay: 4 K keys x 32 heads 26.4 us at 8, 21.3 at 16, 25.4 at 32; CDNA4_FA_SPLIT_MIN: A/B knob)
     if (want < 1) want = 1;
     p.chunks_per_split = (int)((nchunk + want - 1) / want);
     p.nsplit = (int)((nchunk + p.chunks_per_split - 1) / p.chunks_per_split);
     if (p.nsplit > 1) {
-        p.part = (float *)cdna4_gemm_scratch((size_t)tiles * p.nsplit * 32 * (D + 4) * 4 + 256, 4);
+        p.part = (float *)cdna4_gemm_scratch((size_t)(qtiles * H * B3) * p.nsplit * 32 * (D + 4) * 4 + 256, 4);      // (per HEAD, also when the heads of a group share a tile)
         NEED(p.part, "flash_attn_ext: cannot allocate the key-split scratch");
     }
-    const dim3 grid((unsigned)(qtiles * p.nsplit), (unsigned)H, (unsigned)B3);
+    const dim3 grid((unsigned)(qtiles * p.nsplit), (unsigned)HT, (unsigned)B3);
 #define FA_SPLIT(T) do { if (D == 64) hipLaunchKernelGGL((k_flash_attn_split<64, T>), grid, dim3(256), 0, st, p); \
                          else if (D == 128) hipLaunchKernelGGL((k_flash_attn_split<128, T>), grid, dim3(256), 0, st, p); \
                          else hipLaunchKernelGGL((k_flash_attn_split<256, T>), grid, dim3(256), 0, st, p); } while (0)

@@ -219,6 +219,19 @@ def test_flash_attn_ext_skips_masked_chunks(gu, monkeypatch, kw):
         assert np.array_equal(y, _fa_case(gu, **kw))
 
 
+@pytest.mark.parametrize("kw", [dict(D=128, n_q=1, n_head=32, n_kv=4096, n_head_kv=8), dict(D=64, n_q=3, n_head=8, n_kv=1200, n_head_kv=1, max_bias=8.0, inf_every=7),
+                                dict(D=128, n_q=2, n_head=16, n_kv=300, n_head_kv=4, n_batch=2, permuted=True), dict(D=256, n_q=1, n_head=8, n_kv=2000, n_head_kv=2),
+                                dict(D=128, n_q=4, n_head=32, n_kv=700, n_head_kv=4)])
+def test_flash_attn_ext_grouped_query_decode_shares_the_tile(gu, monkeypatch, kw):
+    """grouped-query decode (n_q * n_head / n_head_kv <= 32): the heads of a K / V head are the rows of ONE 32-row tile of k_flash_attn_split, so the group's cache rows are read once
+    (p.pack).  Same bars as every FLASH_ATTN_EXT case, and the result of the one-head-per-tile form (CDNA4_FA_NO_PACK=1) to 2e-5 (the key split may differ between the two grids);
+    ALiBi slopes per row, -inf stretches, batches, permuted tensors, head size 256; the last case (4 x 8 = 32 rows) fills the tile, 4 x 8 > 32 would not pack."""
+    monkeypatch.delenv("CDNA4_FA_NO_PACK", raising=False)
+    y = _fa_case(gu, **kw)
+    monkeypatch.setenv("CDNA4_FA_NO_PACK", "1")
+    assert R.rel_l2(y, _fa_case(gu, **kw)) < 2e-5
+
+
 def test_flash_attn_ext_is_deterministic_and_row_independent(gu):
     """a query row's result does not depend on its neighbours in the tile or on the launch (no atomics, fixed merge order)"""
     from ggml_amd import ops
