@@ -30,6 +30,7 @@
 #include "cdna4_kernels.h"
 #include "gemm_q_hw.h"
 #include <math.h>
+#include <algorithm>
 
 void *cdna4_gemm_scratch(size_t bytes, int kind);      // gemm_q_mfma.hip: per-device scratch (kind 4 = partial results of the key split)
 int cdna4_gemm_cu_count();
@@ -744,6 +745,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
             qt = w % qtiles; hb = w / qtiles;
         }
     }
+    // key split (p.nsplit > 1: grids below one work-group per CU — a prefill chunk of a few hundred rows against a long context): the (batch, head) axis of the map above carries the
+    // split as its fastest part; split s walks chunks [s, s + 1) * chunks_per_split and leaves (M, S, O) unnormalized for k_flash_attn_pipe_merge
+    const int split = p.nsplit > 1 ? hb % p.nsplit : 0;
+    if (p.nsplit > 1) hb /= p.nsplit;
     const int head = hb % p.n_head, b3 = hb / p.n_head;
     // a wave whose 32 rows would reach past the end takes the LAST 32 rows instead (n_q >= 32 here): it recomputes rows another wave also computes — a row's result does
     // not depend on who computes it, both store the same bits — and nothing below has to clamp a query row
@@ -833,14 +838,15 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
     uint16_t *const lst = reinterpret_cast<uint16_t *>(smem + L_OFF);
     if (wave == 0) {
         int count = 0;
-        for (int base = 0; base < nchunk; base += 64) {
+        const int c_lo = split * p.chunks_per_split, c_hi = p.nsplit > 1 ? min(nchunk, c_lo + p.chunks_per_split) : nchunk;
+        for (int base = c_lo; base < c_hi; base += 64) {
             const int c = base + lane;
-            const bool keep = c < nchunk && (!flags || flags[(int64_t)qt * nchunk + c] != 0);
+            const bool keep = c < c_hi && (!flags || flags[(int64_t)qt * nchunk + c] != 0);
             const uint64_t bal = wave_ballot(keep);
             if (keep) lst[1 + count + __builtin_popcountll(bal & ((1ull << lane) - 1))] = (uint16_t)c;
             count += __builtin_popcountll(bal);
         }
-        if (lane == 0) { if (count == 0) { lst[1] = 0; count = 1; } lst[0] = (uint16_t)count; }      // (everything masked: chunk 0 alone gives what all of them would)
+        if (lane == 0) { if (count == 0) { lst[1] = (uint16_t)min(c_lo, nchunk - 1); count = 1; } lst[0] = (uint16_t)count; }      // (everything masked: one chunk alone gives what all of them would)
     }
     __syncthreads();
     const int nlist = __builtin_amdgcn_readfirstlane((int)lst[0]);
@@ -1006,7 +1012,32 @@ __global__ __launch_bounds__(64 * NW, 2) void k_flash_attn_pipe(const fattn_para
         printf("FA_STAMP block %d wave %d hot steps %u: first half %u | second half %u | rescale + PV %u | vmcnt %u | barrier %u cycles per step\n", (int)blockIdx.x, wave, stamp[5],
                stamp[0] / stamp[5], stamp[1] / stamp[5], stamp[2] / stamp[5], stamp[3] / stamp[5], stamp[4] / stamp[5]);
 #endif
-    fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + qi) * p.n_head + head) * HS, o, 1.0f / S, h);
+    if (p.nsplit == 1) {
+        fa_store<NB>(p.dst + (((int64_t)b3 * p.n_q + qi) * p.n_head + head) * HS, o, 1.0f / S, h);
+    } else {                                                      // [batch][head][query row][split][M, S, -, -, O]
+        float *pt = p.part + ((((int64_t)b3 * p.n_head + head) * p.n_q + qi) * p.nsplit + split) * (HS + 4);
+        if (h == 0) { pt[0] = M; pt[1] = S; }
+        fa_store<NB>(pt + 4, o, 1.0f, h);
+    }
+}
+// out[q][d] = sum_s O_s[q][d] 2^(M_s - M*) / sum_s S_s 2^(M_s - M*), splits in index order (deterministic).  One work-group per (32 query rows, head, batch).
+template <int HS>
+__global__ __launch_bounds__(256) void k_flash_attn_pipe_merge(const fattn_params p) {
+    const int q0 = 32 * blockIdx.x, head = blockIdx.y, b3 = blockIdx.z;
+    for (int i = threadIdx.x; i < 32 * HS; i += 256) {
+        const int q = q0 + i / HS, d = i % HS;
+        if (q >= p.n_q) break;
+        const float *base = p.part + (((int64_t)b3 * p.n_head + head) * p.n_q + q) * p.nsplit * (HS + 4);
+        float Mx = -INFINITY;
+        for (int s = 0; s < p.nsplit; s++) Mx = fmaxf(Mx, base[s * (HS + 4)]);
+        float num = 0.0f, den = 0.0f;
+        for (int s = 0; s < p.nsplit; s++) {
+            const float *pt = base + s * (HS + 4);
+            const float a = (pt[0] == -INFINITY) ? 0.0f : exp2f(pt[0] - Mx);      // (M in the log2 domain)
+            num += pt[4 + d] * a; den += pt[1] * a;
+        }
+        p.dst[(((int64_t)b3 * p.n_q + q) * p.n_head + head) * HS + d] = num * (1.0f / den);
+    }
 }
 template <int HS, int NW, int MODE> constexpr int k_flash_attn_pipe_lds() { return 4 * 64 * HS * 2 + (MODE == 1 ? NW * 8192 : 0) + 8192 + 16; }
 
@@ -1046,7 +1077,7 @@ extern "C" int ggml_cdna4_op_flash_attn_ext(const T4 *q, const T4 *k, const T4 *
     if (!pad && k->type == CDNA4_F16 && v->type == CDNA4_F16) return fa_f16(q, k, v, mask, d, scale, max_bias, logit_softcap, stream);
     // a Q8_0 / Q4_0 / BF16 cache under the key-split kernel (decode, small batches): converted from the raw fragment bytes, no fp16 copy (fa_kv_load / fa_kv_cvt)
     if (!pad && k->type == v->type && (k->type == CDNA4_Q8_0 || k->type == CDNA4_Q4_0 || k->type == CDNA4_BF16) && q->ne[1] > 0 && q->ne[2] > 0 && q->ne[3] > 0 &&
-        !fa_takes_wide(q->ne[1], q->ne[2], q->ne[3]) && !getenv("CDNA4_FA_KV_COPY") &&
+        !fa_takes_wide(q->ne[1], q->ne[2], q->ne[3]) && q->ne[1] < 128 && !getenv("CDNA4_FA_KV_COPY") &&      // (from 128 query rows on the F16 kernels' tiles and key split pay for the copy)
         !(((uintptr_t)k->data | (uintptr_t)v->data | (uintptr_t)k->nb[1] | (uintptr_t)k->nb[2] | (uintptr_t)k->nb[3] | (uintptr_t)v->nb[1] | (uintptr_t)v->nb[2] | (uintptr_t)v->nb[3]) & (k->type == CDNA4_BF16 ? 15 : 3)))
         return fa_f16(q, k, v, mask, d, scale, max_bias, logit_softcap, stream);
     hipStream_t st = (hipStream_t)stream;
@@ -1135,11 +1166,29 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
             nw = 0;
             for (int c = 8; c >= (D == 128 ? 4 : 2) && !nw; c >>= 1)          // (head size 128 has no 2-wave form: its DMA pieces would straddle the K swizzle's period)
                 if (((N + 32 * c - 1) / (32 * c)) * H * B3 >= cus) nw = c;
-            // half a chip of 128-row tiles over a short key range still beats the key-split kernel (512 x 512 x 32 heads: 25.8 against 28.8 us; at 4096 keys the split wins)
+            // below one work-group per CU: the smallest tile (128 rows at head size 128, 64 at 64) with the keys split over as many work-groups as fill the chip, each split at
+            // least four chunks (CDNA4_FA_PIPE_SPLIT=0: off — then half a chip of 128-row tiles over a short key range, which still beat the key-split kernel: 25.8 against 28.8 us
+            // at 512 x 512 x 32 heads)
+            if (!nw && N >= 128 && !(getenv("CDNA4_FA_PIPE_SPLIT") && atoi(getenv("CDNA4_FA_PIPE_SPLIT")) == 0)) {
+                const int c = D == 128 ? 4 : 2;
+                const int64_t it = ((N + 32 * c - 1) / (32 * c)) * H * B3, nc = (KV + 63) / 64;
+                int64_t want = (cus + it / 2) / it;
+                static const int64_t split_min = getenv("CDNA4_FA_PIPE_SPLIT_MIN") ? atoll(getenv("CDNA4_FA_PIPE_SPLIT_MIN")) : 32;      // (A/B and test knob)
+                if (want > nc / split_min) want = nc / split_min;              // (a split pays from about 32 chunks on: its partial results are written and merged — 512 x 4096 x 32 heads 150 -> 89 us with two splits of 32 chunks, 256 x 2048 46 -> 69 us with four of 8)
+                if (want >= 2) { nw = c; p.chunks_per_split = (int)((nc + want - 1) / want); p.nsplit = (int)((nc + p.chunks_per_split - 1) / p.chunks_per_split); }
+            }
             if (!nw && D == 128 && KV <= 1024 && ((N + 127) / 128) * H * B3 >= cus / 2) nw = 4;
         }
+        if (e && getenv("CDNA4_FA_PIPE_SPLIT") && atoi(getenv("CDNA4_FA_PIPE_SPLIT")) > 1) {      // (tests: a forced tile height with a forced key split)
+            const int64_t nc = (KV + 63) / 64, want = std::min<int64_t>(atoi(getenv("CDNA4_FA_PIPE_SPLIT")), nc);
+            p.chunks_per_split = (int)((nc + want - 1) / want); p.nsplit = (int)((nc + p.chunks_per_split - 1) / p.chunks_per_split);
+        }
         if ((nw == 2 && D == 64) || nw == 4 || nw == 8) {
-            const int64_t qtiles = (N + 32 * nw - 1) / (32 * nw), items = qtiles * H * B3;
+            const int64_t qtiles = (N + 32 * nw - 1) / (32 * nw), items = qtiles * H * B3 * p.nsplit;
+            if (p.nsplit > 1) {
+                p.part = (float *)cdna4_gemm_scratch((size_t)(B3 * H * N) * p.nsplit * (D + 4) * 4 + 256, 4);
+                NEED(p.part, "flash_attn_ext: cannot allocate the key-split scratch");
+            }
             NEED(items < (1ll << 31), "flash_attn_ext: too many query tiles for one grid");
             NEED(k->nb[1] < (1ll << 25) && v->nb[1] < (1ll << 25) && (!mask || (N + 16) * mask->nb[1] < (1ll << 32)), "flash_attn_ext: row strides beyond the pipelined kernel's 32-bit offsets");
             // chunks that are -inf throughout for a whole query tile are not walked (k_fa_mask_flags; bit-neutral): worth a pass over the mask from 2^20 entries on
@@ -1167,6 +1216,12 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
 #undef FA_PIPE3
 #undef FA_PIPE
             CDNA4_CHECK_LAUNCH();
+            if (p.nsplit > 1) {
+                const dim3 mgrid((unsigned)((N + 31) / 32), (unsigned)H, (unsigned)B3);
+                if (D == 64) hipLaunchKernelGGL(k_flash_attn_pipe_merge<64>, mgrid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL(k_flash_attn_pipe_merge<128>, mgrid, dim3(256), 0, st, p);
+                CDNA4_CHECK_LAUNCH();
+            }
             return 0;
         }
     }

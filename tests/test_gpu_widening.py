@@ -219,6 +219,20 @@ def test_flash_attn_ext_skips_masked_chunks(gu, monkeypatch, kw):
         assert np.array_equal(y, _fa_case(gu, **kw))
 
 
+@pytest.mark.parametrize("kw", [dict(D=128, n_q=300, n_head=2, n_kv=704), dict(D=64, n_q=100, n_head=3, n_kv=650, n_head_kv=1, inf_every=5), dict(D=128, n_q=200, n_head=2, n_kv=460, causal=True, max_bias=8.0),
+                                dict(D=64, n_q=130, n_head=2, n_kv=400, mask=False, n_batch=2, permuted=True), dict(D=64, n_q=70, n_head=2, n_kv=700, softcap=5.0, causal=True)])
+def test_flash_attn_ext_pipelined_kernel_with_a_key_split(gu, monkeypatch, kw):
+    """grids below one work-group per CU (a prefill chunk against a long context): k_flash_attn_pipe splits the KEYS over work-groups (each walks its share of the chunk list and
+    leaves (M, S, O)), k_flash_attn_pipe_merge combines them in split order.  Forced here onto test sizes (three splits, every tile height); bars of the other cases, and 5e-4 from
+    the unsplit result (fp16 P under another running maximum); a ragged last chunk, -inf chunks skipped inside a split, a split with nothing but -inf chunks (causal), no mask."""
+    for nw in ((8, 4) if kw["D"] == 128 else (8, 2)):
+        monkeypatch.setenv("CDNA4_FA_PIPE", str(nw)); monkeypatch.setenv("CDNA4_FA_SKIP_MIN", "0")
+        monkeypatch.setenv("CDNA4_FA_PIPE_SPLIT", "3")
+        y = _fa_case(gu, **kw)
+        monkeypatch.setenv("CDNA4_FA_PIPE_SPLIT", "1")
+        assert R.rel_l2(y, _fa_case(gu, **kw)) < 5e-4
+
+
 @pytest.mark.parametrize("kw", [dict(D=128, n_q=1, n_head=32, n_kv=4096, n_head_kv=8), dict(D=64, n_q=3, n_head=8, n_kv=1200, n_head_kv=1, max_bias=8.0, inf_every=7),
                                 dict(D=128, n_q=2, n_head=16, n_kv=300, n_head_kv=4, n_batch=2, permuted=True), dict(D=256, n_q=1, n_head=8, n_kv=2000, n_head_kv=2),
                                 dict(D=128, n_q=4, n_head=32, n_kv=700, n_head_kv=4)])
