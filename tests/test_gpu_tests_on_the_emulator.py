@@ -50,6 +50,8 @@ SELECTION_R3 = [("test_gpu_parity.py", "test_small_batches_on_the_int8_matrix_co
 SELECTION_R3.append(("test_gpu_widening.py", "test_flash_attn_ext_pipelined_kernel and (kw1 or kw5 or kw7 or kw8)", 4))
 # ... and its chunk list: causal masks with the -inf chunks skipped (k_fa_mask_flags) against walking them, bit for bit (plain, and the general mode with softcap)
 SELECTION_R3.append(("test_gpu_widening.py", "test_flash_attn_ext_skips_masked_chunks and (kw0 or kw2)", 2))
+# ... its key split (three forced splits + the merge kernel; -inf chunks inside a split) and the grouped-query decode tile of k_flash_attn_split (heads of a K / V head as tile rows)
+SELECTION_R3.append(("test_gpu_widening.py", "(test_flash_attn_ext_pipelined_kernel_with_a_key_split and kw1) or (test_flash_attn_ext_grouped_query_decode_shares_the_tile and (kw1 or kw2))", 3))
 # round 5: resident kernel-native images — the registry, the verified build, the lookup of row slices and the bit-identity of the routes that use an image are host logic
 # as much as kernels
 SELECTION_R3.append(("test_gpu_resident.py", "(test_resident_image_serves_prefill and q5_0) or (test_dequantize_row_of_the_image and q3_K)", 2))
