@@ -544,10 +544,15 @@ def widening_rows(dev, steps):
         for nw in ((8, 4) if hs == 128 else (8, 4, 2)):
             if (n_q + 32 * nw - 1) // (32 * nw) * nh >= 256:
                 return "k_flash_attn_pipe<%d, %d, %d>" % (hs, nw, 1 if masked else 0)
+        c = 4 if hs == 128 else 2                       # below one work-group per CU: the smallest tile with the keys split from 32 chunks per split on
+        it, nc = (n_q + 32 * c - 1) // (32 * c) * nh, (n_kv + 63) // 64
+        want = min((256 + it // 2) // it, nc // 32)
+        if n_q >= 128 and want >= 2:
+            return "k_flash_attn_pipe<%d, %d, %d> in %d key splits + k_flash_attn_pipe_merge" % (hs, c, 1 if masked else 0, -(-nc // -(-nc // want)))
         if hs == 128 and n_kv <= 1024 and (n_q + 127) // 128 * nh >= 128:
             return "k_flash_attn_pipe<128, 4, %d>" % (1 if masked else 0)
         return "k_flash_attn_split<%d>" % hs
-    for hs, n_q, n_kv, masked in ((128, 4096, 4096, True), (128, 4096, 4096, "causal"), (128, 4096, 4096, False), (64, 4096, 4096, True), (128, 1024, 1024, True), (128, 512, 512, True), (128, 1, 4096, True), (128, 1, 32768, True)):
+    for hs, n_q, n_kv, masked in ((128, 4096, 4096, True), (128, 4096, 4096, "causal"), (128, 4096, 4096, False), (64, 4096, 4096, True), (128, 1024, 1024, True), (128, 512, 512, True), (128, 512, 4096, True), (128, 512, 16384, True), (128, 1, 4096, True), (128, 1, 32768, True)):
         q = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_q, hs)).astype(np.float32)).to(dev)
         kk = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_kv, hs)).astype(np.float16)).to(dev)
         vv = torch.from_numpy(rng.uniform(-1, 1, (1, nh, n_kv, hs)).astype(np.float16)).to(dev)
