@@ -326,6 +326,43 @@ __global__ __launch_bounds__(256) void k_flash_attn_merge(const fattn_params p) 
     }
 }
 
+// The same for a handful of query rows (decode), one work-group per (query row, head, batch): k_flash_attn_merge gives a row's HS outputs to HS threads, each of which walks the
+// splits twice with a dependent wait per load — 7 - 20 us of a 66 - 97 us decode call over 16 - 64 splits (rocprofv3, round 6).  Here the splits' (M, S) are fetched side by side
+// into LDS, every thread derives the factors from there, and the 256 threads split the sum over the splits 256 / HS ways with four loads in flight each; the parts meet in LDS in
+// part order, the splits inside a part in index order (deterministic).
+template <int HS>
+__global__ __launch_bounds__(256) void k_flash_attn_merge_rows(const fattn_params p) {
+    constexpr int NP = 256 / HS;                                   // parts of the split range (HS 64: 4, 128: 2, 256: 1)
+    __shared__ float sA[512], sS[512], sN[NP][HS];
+    const int q = blockIdx.x, head = blockIdx.y, b3 = blockIdx.z, tid = threadIdx.x, d = tid % HS, part = tid / HS;
+    const int qt = q >> 5, qr = q & 31, qtiles = (p.n_q + 31) >> 5;
+    const float *base = p.part + ((((int64_t)b3 * p.n_head + head) * (qtiles * p.nsplit) + (int64_t)qt * p.nsplit) * 32 + qr) * (HS + 4);      // split s: + s * 32 * (HS + 4)
+    const int64_t sstride = 32 * (HS + 4);
+    for (int s = tid; s < p.nsplit; s += 256) { sA[s] = base[s * sstride]; sS[s] = base[s * sstride + 1]; }
+    __syncthreads();
+    float Mx = -INFINITY;
+    for (int s = 0; s < p.nsplit; s++) Mx = fmaxf(Mx, sA[s]);
+    float den = 0.0f;
+    for (int s = 0; s < p.nsplit; s++) { const float a = (sA[s] == -INFINITY) ? 0.0f : exp2f(sA[s] - Mx); den += sS[s] * a; }      // (M in the log2 domain; every thread the same order)
+    __syncthreads();
+    for (int s = tid; s < p.nsplit; s += 256) sA[s] = (sA[s] == -INFINITY) ? 0.0f : exp2f(sA[s] - Mx);
+    __syncthreads();
+    const int per = (p.nsplit + NP - 1) / NP, s0 = part * per, s1 = min(p.nsplit, s0 + per);
+    float num = 0.0f;
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+        const float o0 = base[(s + 0) * sstride + 4 + d], o1 = base[(s + 1) * sstride + 4 + d], o2 = base[(s + 2) * sstride + 4 + d], o3 = base[(s + 3) * sstride + 4 + d];
+        num += o0 * sA[s]; num += o1 * sA[s + 1]; num += o2 * sA[s + 2]; num += o3 * sA[s + 3];
+    }
+    for (; s < s1; s++) num += base[s * sstride + 4 + d] * sA[s];
+    sN[part][d] = num;
+    __syncthreads();
+    if (part != 0) return;
+#pragma unroll
+    for (int pp = 1; pp < NP; pp++) num += sN[pp][d];
+    p.dst[(((int64_t)b3 * p.n_q + q) * p.n_head + head) * HS + d] = num * (1.0f / den);
+}
+
 // ------------------------------------------------------------------------------------------------ wide kernel (prefill, 128 query rows per work-group)
 template <int HS>
 __global__ __launch_bounds__(256, HS <= 128 ? 2 : 1) void k_flash_attn_wide(const fattn_params p) {
@@ -1261,7 +1298,13 @@ static int fa_f16(const T4 *q, const T4 *k, const T4 *v, const T4 *mask, const T
     if (kvt == CDNA4_Q8_0) FA_SPLIT(CDNA4_Q8_0); else if (kvt == CDNA4_Q4_0) FA_SPLIT(CDNA4_Q4_0); else if (kvt == CDNA4_BF16) FA_SPLIT(CDNA4_BF16); else FA_SPLIT(CDNA4_F16);
 #undef FA_SPLIT
     CDNA4_CHECK_LAUNCH();
-    if (p.nsplit > 1) {
+    if (p.nsplit > 1 && N <= 4 && p.nsplit <= 512 && !getenv("CDNA4_FA_MERGE_OLD")) {      // a handful of rows: one work-group per row (CDNA4_FA_MERGE_OLD: A/B knob)
+        const dim3 mgrid((unsigned)N, (unsigned)H, (unsigned)B3);
+        if (D == 64) hipLaunchKernelGGL(k_flash_attn_merge_rows<64>, mgrid, dim3(256), 0, st, p);
+        else if (D == 128) hipLaunchKernelGGL(k_flash_attn_merge_rows<128>, mgrid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(k_flash_attn_merge_rows<256>, mgrid, dim3(256), 0, st, p);
+        CDNA4_CHECK_LAUNCH();
+    } else if (p.nsplit > 1) {
         const dim3 mgrid((unsigned)qtiles, (unsigned)H, (unsigned)B3);
         if (D == 64) hipLaunchKernelGGL(k_flash_attn_merge<64>, mgrid, dim3(256), 0, st, p);
         else if (D == 128) hipLaunchKernelGGL(k_flash_attn_merge<128>, mgrid, dim3(256), 0, st, p);
